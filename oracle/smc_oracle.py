@@ -1,0 +1,679 @@
+"""NumPy restatement of the nchopin/particles SMC hot path (CPU oracle).
+
+TEST INFRASTRUCTURE ONLY -- see ``oracle/__init__.py``.  Nothing under
+``particles_amd/`` imports this module.
+
+Every function cites the reference lines it follows (paths relative to
+/root/reference).  Third-party arithmetic the reference calls (numpy.random
+legacy generator, numpy/scipy linear algebra) is *called*, not restated, since
+the same numpy/scipy are present wherever the oracle runs.
+
+Pinned by ``tests/golden/*.npz`` (outputs of the imported reference produced by
+``tests/golden/make_golden.py``); ``tests/test_oracle_golden.py`` checks the
+oracle against them bit-for-bit.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+import scipy.linalg as sla
+
+C_NORM = 0.9189385332046727  # scipy.stats._continuous_distns._norm_pdf_logC
+HALFLOG2PI = 0.5 * np.log(2.0 * np.pi)  # particles/distributions.py:212
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CLIB = None
+
+
+def clib():
+    """The C half of the oracle (oracle/oracle.c), or None if not built."""
+    global _CLIB
+    if _CLIB is None:
+        path = os.path.join(_HERE, "_build", "liboracle.so")
+        if not os.path.exists(path):
+            return None
+        lib = ctypes.CDLL(path)
+        i64, dp, ip, up = (ctypes.c_int64, ctypes.POINTER(ctypes.c_double),
+                           ctypes.POINTER(ctypes.c_int64),
+                           ctypes.POINTER(ctypes.c_uint64))
+        lib.orc_inverse_cdf_seq.argtypes = [dp, dp, i64, i64, ip]
+        lib.orc_inverse_cdf_seq.restype = i64
+        lib.orc_inverse_cdf_q62.argtypes = [dp, dp, i64, i64, ip]
+        lib.orc_inverse_cdf_q62.restype = None
+        lib.orc_philox4x32_10.argtypes = [ctypes.POINTER(ctypes.c_uint32)] * 3
+        lib.orc_philox4x32_10.restype = None
+        lib.orc_toy_filter_philox.argtypes = [
+            dp, i64, i64, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+            ctypes.c_double, ctypes.c_double, ctypes.c_uint64, dp]
+        lib.orc_toy_filter_philox.restype = ctypes.c_double
+        _CLIB = lib
+    return _CLIB
+
+
+def _dp(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+# --------------------------------------------------------------------------
+# Weights / log-sum-exp          (particles/resampling.py)
+# --------------------------------------------------------------------------
+
+class Weights:
+    """resampling.py:191-244 (``Weights.__init__`` / ``add`` / ``N``)."""
+
+    def __init__(self, lw=None):
+        self.lw = lw
+        if lw is not None:
+            self.lw[np.isnan(self.lw)] = -np.inf          # :220 (in place!)
+            m = self.lw.max()                               # :221
+            w = np.exp(self.lw - m)                         # :222
+            s = w.sum()                                     # :223
+            self.log_mean = m + np.log(s / self.N)          # :224
+            self.W = w / s                                  # :225
+            self.ESS = 1.0 / np.sum(self.W ** 2)            # :226
+
+    @property
+    def N(self):
+        return 0 if self.lw is None else self.lw.shape[0]   # :228-230
+
+    def add(self, delta):
+        if self.lw is None:                                 # :241-244
+            return self.__class__(lw=delta)
+        return self.__class__(lw=self.lw + delta)
+
+
+def exp_and_normalise(lw):
+    """resampling.py:138-163."""
+    w = np.exp(lw - lw.max())
+    return w / w.sum()
+
+
+def essl(lw):
+    """resampling.py:166-188."""
+    w = np.exp(lw - lw.max())
+    return (w.sum()) ** 2 / np.sum(w ** 2)
+
+
+def log_sum_exp(v):
+    """resampling.py:247-270."""
+    m = v.max()
+    return m + np.log(np.sum(np.exp(v - m)))
+
+
+def log_mean_exp(v, W=None):
+    """resampling.py:291-317."""
+    m = v.max()
+    V = np.exp(v - m)
+    if W is None:
+        return m + np.log(np.mean(V))
+    return m + np.log(np.average(V, weights=W))
+
+
+def wmean_and_var(W, x):
+    """resampling.py:320-338."""
+    m = np.average(x, weights=W, axis=0)
+    m2 = np.average(x ** 2, weights=W, axis=0)
+    return {"mean": m, "var": m2 - m ** 2}
+
+
+# --------------------------------------------------------------------------
+# Resampling                      (particles/resampling.py)
+# --------------------------------------------------------------------------
+
+def inverse_cdf(su, W):
+    """resampling.py:484-509 -- sequential fp64 CDF, strict ``>`` compare.
+
+    Uses the C restatement (oracle.c: orc_inverse_cdf_seq) when built, else the
+    same loop in Python.  Raises IndexError where the pure-Python reference
+    would (su[n] > sum(W) through round-off).
+    """
+    su = np.ascontiguousarray(su, dtype=np.float64)
+    W = np.ascontiguousarray(W, dtype=np.float64)
+    M, N = su.shape[0], W.shape[0]
+    A = np.empty(M, dtype=np.int64)
+    lib = clib()
+    if lib is not None:
+        rc = lib.orc_inverse_cdf_seq(
+            _dp(su), _dp(W), M, N,
+            A.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)))
+        if rc != 0:
+            raise IndexError("inverse_cdf: su exceeds the total weight")
+        return A
+    j = 0
+    s = W[0]
+    for n in range(M):
+        while su[n] > s:
+            j += 1
+            s += W[j]
+        A[n] = j
+    return A
+
+
+def uniform_spacings_from(u):
+    """resampling.py:536-537 with the ``rand(N+1)`` draws passed in as ``u``."""
+    z = np.cumsum(-np.log(u))
+    return z[:-1] / z[-1]
+
+
+def su_systematic(M, u):
+    """resampling.py:609.  ``u`` = the ``rand(1)`` draw (shape (1,))."""
+    return (u + np.arange(M)) / M
+
+
+def su_stratified(M, u):
+    """resampling.py:602.  ``u`` = the ``rand(M)`` draws."""
+    return (u + np.arange(M)) / M
+
+
+N_UNIFORMS = {"systematic": lambda M: 1, "stratified": lambda M: M,
+              "multinomial": lambda M: M + 1}
+
+
+def sorted_uniforms(scheme, M, u):
+    if scheme == "systematic":
+        return su_systematic(M, u)
+    if scheme == "stratified":
+        return su_stratified(M, u)
+    if scheme == "multinomial":
+        return uniform_spacings_from(u)
+    raise ValueError("%s is not a valid resampling scheme" % scheme)  # :477-481
+
+
+def resampling(scheme, W, M=None, u=None, rng=None, cdf="seq"):
+    """resampling.py:477-481 + :540-558, :599-610.
+
+    ``u`` are the uniforms the scheme consumes (1, M, or M+1 of them); if None
+    they are drawn from ``rng`` (default: the numpy legacy global generator,
+    like the reference).  ``cdf='q62'`` swaps the sequential fp64 CDF for the
+    fixed-point contract of ``inverse_cdf_q62`` (what the HIP kernels use).
+    """
+    M = W.shape[0] if M is None else M
+    if scheme not in N_UNIFORMS:
+        raise ValueError("%s is not a valid resampling scheme" % scheme)
+    if u is None:
+        rng = LegacyRNG() if rng is None else rng
+        u = rng.rand(N_UNIFORMS[scheme](M))
+    su = sorted_uniforms(scheme, M, u)
+    return inverse_cdf(su, W) if cdf == "seq" else inverse_cdf_q62(su, W)
+
+
+# ---- the fixed-point ("Q62") CDF contract used by the HIP kernels ---------
+#
+# The reference accumulates the CDF strictly left to right in fp64
+# (resampling.py:500-508); no parallel scan can reproduce that rounding
+# sequence.  The HIP path therefore defines the CDF in exact integer
+# arithmetic, which is independent of summation order:
+#     q_i = rint(W_i * 2^62)            (0 when not W_i > 0)
+#     C_j = sum_{i<=j} q_i              (uint64, exact)
+#     T_n = ceil(su_n * 2^62)           (exact: power-of-two scaling)
+#     A_n = min(#{j : C_j < T_n}, N-1)  <=> smallest j with su_n <= C_j / 2^62
+# The boundary rule (strict '>' advances, ties go to the lower index) and the
+# final clamp are the reference's (resampling.py:505-508).
+# Any difference from the sequential-fp64 answer can only occur where su_n is
+# within the fp64 round-off of the sequential CDF (``audit_near_ties``).
+
+Q62 = float(2 ** 62)
+
+
+def q62_weights(W):
+    W = np.asarray(W, dtype=np.float64)
+    q = np.rint(np.where(W > 0, W, 0.0) * Q62)
+    return q.astype(np.uint64)
+
+
+def q62_threshold(su):
+    su = np.asarray(su, dtype=np.float64)
+    return np.ceil(np.maximum(su, 0.0) * Q62).astype(np.uint64)
+
+
+def inverse_cdf_q62(su, W):
+    C = np.cumsum(q62_weights(W), dtype=np.uint64)
+    T = q62_threshold(su)
+    A = np.searchsorted(C, T, side="left").astype(np.int64)
+    return np.minimum(A, W.shape[0] - 1)
+
+
+def audit_near_ties(su, W, A_a, A_b):
+    """Certify that every place two ancestor vectors differ is a near-tie.
+
+    A mismatch at n is accepted only if su[n] lies within N*2^-52 (the worst
+    case fp64 accumulation error of either CDF) of the extended-precision
+    CDF at every boundary between the two answers.  Returns (n_mismatch, ok).
+    """
+    bad = np.nonzero(A_a != A_b)[0]
+    if bad.size == 0:
+        return 0, True
+    cdf = np.cumsum(W.astype(np.longdouble))
+    tol = np.longdouble(W.shape[0]) * np.longdouble(2.0) ** -52
+    ok = True
+    for n in bad:
+        lo, hi = sorted((int(A_a[n]), int(A_b[n])))
+        gap = np.abs(cdf[lo:hi] - np.longdouble(su[n])).max()
+        ok &= bool(gap <= tol)
+    return int(bad.size), ok
+
+
+# --------------------------------------------------------------------------
+# Distributions                   (particles/distributions.py)
+# --------------------------------------------------------------------------
+
+def normal_rvs(loc, scale, z):
+    """distributions.py:270-271: ``random.normal(loc, scale, size)`` is
+    ``loc + scale * standard_normal(size)`` bit for bit (numpy legacy)."""
+    return loc + scale * z
+
+
+def normal_logpdf(x, loc=0.0, scale=1.0):
+    """distributions.py:273-274 -> scipy.stats.norm.logpdf:
+    ``y=(x-loc)/scale ; -y**2/2.0 - _norm_pdf_logC - log(scale)``."""
+    y = (np.asarray(x) - loc) / scale
+    return -y ** 2 / 2.0 - C_NORM - np.log(scale)
+
+
+def mvnormal_rvs(loc, scale, L, z):
+    """distributions.py:946-947, 961-969: ``loc + scale * dot(z, L.T)``."""
+    return loc + scale * np.dot(z, L.T)
+
+
+def mvnormal_logpdf(x, loc, scale, L):
+    """distributions.py:949-959."""
+    dim = L.shape[0]
+    halflogdetcor = np.sum(np.log(np.diag(L)))
+    xc = (x - loc) / scale
+    z = sla.solve_triangular(L, np.transpose(xc), lower=True)
+    if np.asarray(scale).ndim == 0:
+        logdet = dim * np.log(scale)
+    else:
+        logdet = np.sum(np.log(scale), axis=-1)
+    logdet += halflogdetcor
+    return -0.5 * np.sum(z * z, axis=0) - logdet - dim * HALFLOG2PI
+
+
+# --------------------------------------------------------------------------
+# RNG plumbing (the reference uses the numpy legacy global state)
+# --------------------------------------------------------------------------
+
+class LegacyRNG:
+    """numpy.random global generator, as used by resampling.py:135 and
+    distributions.py:209 (``stats.norm.rvs(size=(N,d))`` draws the same stream
+    as ``standard_normal((N,d))``)."""
+
+    def rand(self, k):
+        return np.random.rand(k)
+
+    def standard_normal(self, shape):
+        return np.random.standard_normal(shape)
+
+
+class RecordingRNG:
+    """Wraps an RNG and keeps the tape of draws, in consumption order."""
+
+    def __init__(self, inner=None):
+        self.inner = LegacyRNG() if inner is None else inner
+        self.tape = []
+
+    def rand(self, k):
+        u = self.inner.rand(k)
+        self.tape.append(("u", u))
+        return u
+
+    def standard_normal(self, shape):
+        z = self.inner.standard_normal(shape)
+        self.tape.append(("z", z))
+        return z
+
+
+class ReplayRNG:
+    def __init__(self, tape):
+        self.tape = list(tape)
+        self.pos = 0
+
+    def _next(self, kind, size):
+        k, a = self.tape[self.pos]
+        self.pos += 1
+        assert k == kind and a.size == size, "replay tape out of sync"
+        return a
+
+    def rand(self, k):
+        return self._next("u", k)
+
+    def standard_normal(self, shape):
+        return self._next("z", int(np.prod(shape))).reshape(shape)
+
+
+# --------------------------------------------------------------------------
+# State-space models on the hot path
+# --------------------------------------------------------------------------
+
+class LinGauss:
+    """kalman.py:397-452 (``LinearGauss``); README.md:66-72 ``ToySSM`` is the
+    case rho=1, sigmaX=1, sigma0=1."""
+    dim = 1
+
+    def __init__(self, rho=0.9, sigmaX=1.0, sigmaY=0.2, sigma0=None):
+        self.rho, self.sigmaX, self.sigmaY = rho, sigmaX, sigmaY
+        self.sigma0 = sigmaX / np.sqrt(1.0 - rho ** 2) if sigma0 is None else sigma0
+
+    def px0(self):                       # kalman.py:427-428
+        return 0.0, self.sigma0
+
+    def px(self, xp):                    # kalman.py:430-431
+        return self.rho * xp, self.sigmaX
+
+    def py_logpdf(self, y, xp, x):       # kalman.py:433-434
+        return normal_logpdf(y, loc=x, scale=self.sigmaY)
+
+    # optimal proposal, kalman.py:436-446
+    def proposal0(self, y0):
+        sig2post = 1.0 / (1.0 / self.sigma0 ** 2 + 1.0 / self.sigmaY ** 2)
+        mupost = sig2post * (y0 / self.sigmaY ** 2)
+        return mupost, np.sqrt(sig2post)
+
+    def proposal(self, xp, yt):
+        sig2post = 1.0 / (1.0 / self.sigmaX ** 2 + 1.0 / self.sigmaY ** 2)
+        mupost = sig2post * (self.rho * xp / self.sigmaX ** 2 + yt / self.sigmaY ** 2)
+        return mupost, np.sqrt(sig2post)
+
+    def kalman_matrices(self):
+        return (np.atleast_2d(self.rho), np.atleast_2d(1.0),
+                np.atleast_2d(self.sigmaX ** 2), np.atleast_2d(self.sigmaY ** 2),
+                np.zeros(1), np.atleast_2d(self.sigma0 ** 2))
+
+
+def ToySSM(sigma=0.2):
+    return LinGauss(rho=1.0, sigmaX=1.0, sigmaY=sigma, sigma0=1.0)
+
+
+class StochVol:
+    """state_space_models.py:446-473."""
+    dim = 1
+
+    def __init__(self, mu=-1.02, rho=0.9702, sigma=0.178):
+        self.mu, self.rho, self.sigma = mu, rho, sigma
+
+    def sig0(self):                      # :458-460
+        return self.sigma / np.sqrt(1.0 - self.rho ** 2)
+
+    def px0(self):                       # :462-463
+        return self.mu, self.sig0()
+
+    def px(self, xp):                    # :465-470
+        return (1.0 - self.rho) * self.mu + self.rho * xp, self.sigma
+
+    def py_logpdf(self, y, xp, x):       # :472-473
+        return normal_logpdf(y, loc=0.0, scale=np.exp(0.5 * x))
+
+
+class MVLinGauss:
+    """kalman.py:296-361 (``MVLinearGauss``)."""
+
+    def __init__(self, F=None, G=None, covX=None, covY=None, mu0=None, cov0=None):
+        self.covX, self.covY = np.atleast_2d(covX), np.atleast_2d(covY)
+        self.dx, self.dy = self.covX.shape[0], self.covY.shape[0]
+        self.mu0 = np.zeros(self.dx) if mu0 is None else mu0
+        self.cov0 = self.covX if cov0 is None else np.atleast_2d(cov0)
+        self.F = np.eye(self.dx) if F is None else np.atleast_2d(F)
+        self.G = np.eye(self.dy, self.dx) if G is None else np.atleast_2d(G)
+        self.dim = self.dx
+
+    def kalman_matrices(self):
+        return self.F, self.G, self.covX, self.covY, self.mu0, self.cov0
+
+
+def Guarniero(alpha=0.4, dx=2):
+    """kalman.py:364-394."""
+    F = np.empty((dx, dx))
+    for i in range(dx):
+        for j in range(dx):
+            F[i, j] = alpha ** (1 + abs(i - j))
+    return MVLinGauss(F=F, G=np.eye(dx), covX=np.eye(dx), covY=np.eye(dx))
+
+
+def _dotdot(a, b, c):
+    return np.dot(np.dot(a, b), c)                       # kalman.py:157-158
+
+
+def _dotdotinv(a, b, c):
+    return sla.solve(c, np.dot(a, b).T, assume_a="pos", overwrite_b=True).T  # :161-163
+
+
+def kalman_filter_step(G, covY, pred_mean, pred_cov, yt):
+    """kalman.py:196-229 (``filter_step``): returns filt_mean, filt_cov, logpyt."""
+    data_pred_mean = np.matmul(pred_mean, G.T)
+    data_pred_cov = _dotdot(G, pred_cov, G.T) + covY
+    if covY.shape[0] == 1:
+        logpyt = normal_logpdf(yt, loc=data_pred_mean, scale=np.sqrt(data_pred_cov))
+    else:
+        logpyt = mvnormal_logpdf(yt, data_pred_mean, 1.0,
+                                 np.linalg.cholesky(data_pred_cov))
+    residual = yt - data_pred_mean
+    gain = _dotdotinv(pred_cov, G.T, data_pred_cov)
+    filt_mean = pred_mean + np.matmul(residual, gain.T)
+    filt_cov = pred_cov - _dotdot(gain, G, pred_cov)
+    return filt_mean, filt_cov, logpyt
+
+
+def kalman_loglik(model, data):
+    """kalman.py:483-505 (``Kalman.filter``): exact log-likelihood and
+    filtering means of a linear Gaussian model -- the analytic KAT."""
+    F, G, covX, covY, mu0, cov0 = model.kalman_matrices()
+    ll, means = 0.0, []
+    for t, yt in enumerate(data):
+        if t == 0:
+            pm, pc = mu0, cov0
+        else:
+            pm = np.matmul(fm, F.T)                       # kalman.py:169-193
+            pc = _dotdot(F, fc, F.T) + covX
+        fm, fc, lp = kalman_filter_step(G, covY, pm, pc, np.asarray(yt))
+        ll += float(np.squeeze(lp))
+        means.append(np.squeeze(fm))
+    return ll, np.array(means)
+
+
+# --------------------------------------------------------------------------
+# The SMC step loop               (particles/core.py:299-383)
+# --------------------------------------------------------------------------
+
+def run_filter(model, data, N, scheme="systematic", ESSrmin=0.5, fk="bootstrap",
+               rng=None, keep=False, cdf="seq", T=None):
+    """core.py:369-383 ``SMC.__next__`` iterated to T, for the model families
+    on the hot path.  RNG consumption order per SURVEY appendix A:
+    t=0: standard_normal(N[,d]);  t>=1: [if ESS < N*ESSrmin: scheme uniforms]
+    then standard_normal(N[,d]).
+
+    Returns a dict of per-step lists (ESS, log_mean, loglt, logLt, rs_flag) and
+    the final X, Xp, A, lw, W; with keep=True also every step's X/A/lw/W.
+    """
+    rng = LegacyRNG() if rng is None else rng
+    T = len(data) if T is None else T
+    out = {k: [] for k in ("ESS", "log_mean", "loglt", "logLt", "rs_flag")}
+    hist = {k: [] for k in ("X", "A", "lw", "W")}
+    wgts = Weights()
+    X = Xp = A = None
+    logLt = 0.0
+    log_mean_w = None
+    mv = getattr(model, "dim", 1) > 1
+    if mv:
+        d = model.dim
+        LX = np.linalg.cholesky(model.covX)               # distributions.py:937
+        LY = np.linalg.cholesky(model.covY)
+        L0 = np.linalg.cholesky(model.cov0)
+        if fk == "guided":
+            # kalman.py:353-356 proposal0 ; filter_step with scalar-shaped mean
+            f0m, f0c, _ = kalman_filter_step(model.G, model.covY, model.mu0,
+                                             model.cov0, np.asarray(data[0]))
+            Lp0 = np.linalg.cholesky(f0c)
+    for t in range(T):
+        yt = np.asarray(data[t])
+        rs_flag = False
+        # ---- generate_particles / resample_move      core.py:315-337
+        if t == 0:
+            if mv:
+                z = rng.standard_normal((N, d))
+                if fk == "guided":
+                    X = mvnormal_rvs(f0m, 1.0, Lp0, z)    # state_space_models.py:374-375
+                else:
+                    X = mvnormal_rvs(model.mu0, 1.0, L0, z)  # kalman.py:339-340
+            elif fk == "guided":
+                loc, scale = model.proposal0(yt)
+                X = normal_rvs(loc, scale, rng.standard_normal(N))
+            else:
+                loc, scale = model.px0()
+                X = normal_rvs(loc, scale, rng.standard_normal(N))
+        else:
+            rs_flag = bool(wgts.ESS < N * ESSrmin)        # core.py:181-183, 327
+            if rs_flag:
+                u = rng.rand(N_UNIFORMS[scheme](N))
+                su = sorted_uniforms(scheme, N, u)
+                A = inverse_cdf(su, wgts.W) if cdf == "seq" else inverse_cdf_q62(su, wgts.W)
+                Xp = X[A]                                 # core.py:332
+                wgts = Weights()                          # core.py:299-305
+            else:
+                A = np.arange(N)                          # core.py:335-336
+                Xp = X
+            if mv:
+                z = rng.standard_normal((N, d))
+                m = np.dot(Xp, model.F.T)                 # kalman.py:342-343
+                if fk == "guided":                        # kalman.py:348-351
+                    pm, pc, _ = kalman_filter_step(model.G, model.covY, m,
+                                                   model.covX, yt)
+                    Lp = np.linalg.cholesky(pc)
+                    X = mvnormal_rvs(pm, 1.0, Lp, z)
+                else:
+                    X = mvnormal_rvs(m, 1.0, LX, z)
+            elif fk == "guided":
+                loc, scale = model.proposal(Xp, yt)
+                X = normal_rvs(loc, scale, rng.standard_normal(N))
+            else:
+                loc, scale = model.px(Xp)
+                X = normal_rvs(loc, scale, rng.standard_normal(N))
+        # ---- reweight_particles                      core.py:323-324
+        if mv:
+            lpy = mvnormal_logpdf(yt, np.dot(X, model.G.T), 1.0, LY)  # kalman.py:345-346
+            if fk == "guided":                            # state_space_models.py:380-392
+                if t == 0:
+                    inc = (mvnormal_logpdf(X, model.mu0, 1.0, L0) + lpy
+                           - mvnormal_logpdf(X, f0m, 1.0, Lp0))
+                else:
+                    inc = (mvnormal_logpdf(X, m, 1.0, LX) + lpy
+                           - mvnormal_logpdf(X, pm, 1.0, Lp))
+            else:
+                inc = lpy
+        elif fk == "guided":
+            if t == 0:
+                l0, s0 = model.px0()
+                q0, qs0 = model.proposal0(yt)
+                inc = (normal_logpdf(X, l0, s0) + model.py_logpdf(yt, None, X)
+                       - normal_logpdf(X, q0, qs0))
+            else:
+                l1, s1 = model.px(Xp)
+                q1, qs1 = model.proposal(Xp, yt)
+                inc = (normal_logpdf(X, l1, s1) + model.py_logpdf(yt, Xp, X)
+                       - normal_logpdf(X, q1, qs1))
+        else:
+            inc = model.py_logpdf(yt, Xp, X)              # state_space_models.py:332-333
+        wgts = wgts.add(inc)
+        # ---- compute_summaries                       core.py:351-359
+        prec = log_mean_w
+        log_mean_w = wgts.log_mean
+        loglt = log_mean_w if (t == 0 or rs_flag) else log_mean_w - prec
+        logLt += loglt
+        out["ESS"].append(float(wgts.ESS))
+        out["log_mean"].append(float(log_mean_w))
+        out["loglt"].append(float(loglt))
+        out["logLt"].append(float(logLt))
+        out["rs_flag"].append(rs_flag)
+        if keep:
+            hist["X"].append(X.copy())
+            hist["A"].append(None if A is None else A.copy())
+            hist["lw"].append(wgts.lw.copy())
+            hist["W"].append(wgts.W.copy())
+    out.update(X=X, Xp=Xp, A=A, lw=wgts.lw, W=wgts.W, final_logLt=logLt)
+    if keep:
+        out["hist"] = hist
+    return out
+
+
+# --------------------------------------------------------------------------
+# Philox4x32-10 + Box-Muller: the counter-based generator the HIP path uses in
+# production mode (there is no reference counterpart: the reference draws from
+# MT19937).  Restated here so tests can check the device stream bit-for-bit
+# for the integer part and to ~1 ulp for the Gaussian transform.
+# --------------------------------------------------------------------------
+
+PHILOX_M0, PHILOX_M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+PHILOX_W0, PHILOX_W1 = np.uint64(0x9E3779B9), np.uint64(0xBB67AE85)
+_M32 = np.uint64(0xFFFFFFFF)
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Salmon et al. 2011 (Random123 philox4x32, 10 rounds).  Inputs are
+    broadcastable integer arrays holding 32-bit words; returns 4 uint64 arrays
+    holding 32-bit words."""
+    c0, c1, c2, c3, k0, k1 = [np.asarray(v).astype(np.uint64) & _M32
+                              for v in np.broadcast_arrays(c0, c1, c2, c3, k0, k1)]
+    for r in range(10):
+        if r > 0:
+            k0 = (k0 + PHILOX_W0) & _M32
+            k1 = (k1 + PHILOX_W1) & _M32
+        p0 = PHILOX_M0 * c0
+        p1 = PHILOX_M1 * c2
+        hi0, lo0 = p0 >> np.uint64(32), p0 & _M32
+        hi1, lo1 = p1 >> np.uint64(32), p1 & _M32
+        c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
+    return c0, c1, c2, c3
+
+
+STREAM_NORMAL, STREAM_RESAMPLE, STREAM_SPACINGS = 0, 1, 2
+
+
+def philox_u64_pair(seed, idx, t, island, stream):
+    """The HIP path's counter layout: ctr=(idx, t, island, stream),
+    key=(seed lo32, seed hi32) -> two 64-bit words (x01, x23)."""
+    seed = int(seed)
+    r = philox4x32_10(idx, t, island, stream, seed & 0xFFFFFFFF, seed >> 32)
+    return (r[1] << np.uint64(32)) | r[0], (r[3] << np.uint64(32)) | r[2]
+
+
+def u01_open(x):
+    """(0,1): ((x >> 11) + 0.5) * 2^-53."""
+    return ((x >> np.uint64(11)).astype(np.float64) + 0.5) * 2.0 ** -53
+
+
+def u01_halfopen(x):
+    """[0,1): (x >> 11) * 2^-53 (numpy's ``rand`` convention)."""
+    return (x >> np.uint64(11)).astype(np.float64) * 2.0 ** -53
+
+
+def philox_normal_pair(seed, pair_idx, t, island=0, stream=STREAM_NORMAL):
+    """Box-Muller on the two open-interval uniforms of one Philox call:
+    (z_even, z_odd) = r*(cos, sin)(2*pi*u2), r = sqrt(-2 log u1)."""
+    x01, x23 = philox_u64_pair(seed, pair_idx, t, island, stream)
+    u1, u2 = u01_open(x01), u01_open(x23)
+    r = np.sqrt(-2.0 * np.log(u1))
+    return r * np.cos(2.0 * np.pi * u2), r * np.sin(2.0 * np.pi * u2)
+
+
+def philox_normals(seed, n, t, island=0):
+    """z_0..z_{n-1} of step t: particle i takes the (i&1) branch of pair i>>1."""
+    p = np.arange((n + 1) // 2)
+    z0, z1 = philox_normal_pair(seed, p, t, island)
+    return np.stack([z0, z1], axis=1).reshape(-1)[:n]
+
+
+def philox_resample_uniforms(seed, scheme, M, t, island=0):
+    """The uniforms the HIP path feeds to a scheme in production mode."""
+    if scheme == "systematic":
+        x01, _ = philox_u64_pair(seed, 0, t, island, STREAM_RESAMPLE)
+        return u01_halfopen(np.atleast_1d(x01))
+    if scheme == "stratified":
+        p = np.arange((M + 1) // 2)
+        x01, x23 = philox_u64_pair(seed, p, t, island, STREAM_RESAMPLE)
+        return np.stack([u01_halfopen(x01), u01_halfopen(x23)], axis=1).reshape(-1)[:M]
+    if scheme == "multinomial":
+        p = np.arange((M + 2) // 2)
+        x01, x23 = philox_u64_pair(seed, p, t, island, STREAM_SPACINGS)
+        return np.stack([u01_open(x01), u01_open(x23)], axis=1).reshape(-1)[:M + 1]
+    raise ValueError("%s is not a valid resampling scheme" % scheme)

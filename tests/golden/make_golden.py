@@ -1,0 +1,145 @@
+"""Generate golden vectors by RUNNING THE REFERENCE (nchopin/particles).
+
+Run in the build container only (needs /root/reference):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The reference is imported read-only from /root/reference with the numba stub
+in oracle/numba_shim (numba is not installed; the jitted functions then run
+as plain Python and compute the same values).  Outputs are the reference's own
+results on seeded inputs; they pin the CPU oracle (tests/test_oracle_golden.py)
+which in turn checks the HIP path.  /root/reference does not exist on the GPU
+box, so nothing else may import it.
+"""
+import os
+import sys
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path[:0] = [os.path.join(ROOT, "oracle", "numba_shim"), "/root/reference"]
+
+import numpy as np  # noqa: E402
+import particles  # noqa: E402
+from particles import distributions as dists  # noqa: E402
+from particles import kalman  # noqa: E402
+from particles import resampling as rs  # noqa: E402
+from particles import state_space_models as ssm  # noqa: E402
+
+
+class ToySSM(ssm.StateSpaceModel):          # README.md:66-72
+    def PX0(self):
+        return dists.Normal()
+
+    def PX(self, t, xp):
+        return dists.Normal(loc=xp)
+
+    def PY(self, t, xp, x):
+        return dists.Normal(loc=x, scale=self.sigma)
+
+
+def run_case(model, fk_cls, T, N, scheme, ESSrmin, data_seed=42, run_seed=123):
+    np.random.seed(data_seed)
+    x, y = model.simulate(T)
+    np.random.seed(run_seed)
+    pf = particles.SMC(fk=fk_cls(ssm=model, data=y), N=N, resampling=scheme,
+                       ESSrmin=ESSrmin)
+    pf.run()
+    return dict(
+        y=np.array(y), T=T, N=N, scheme=scheme, ESSrmin=ESSrmin,
+        data_seed=data_seed, run_seed=run_seed,
+        ESSs=np.array(pf.summaries.ESSs), logLts=np.array(pf.summaries.logLts),
+        rs_flags=np.array(pf.summaries.rs_flags), logLt=pf.logLt,
+        X=pf.X, A=pf.A, lw=pf.wgts.lw, W=pf.W)
+
+
+def main():
+    out = {}
+
+    # --- SMC runs (C1 and reduced-size C3/C4 of BASELINE.json) -------------
+    for scheme in ("systematic", "stratified", "multinomial"):
+        out["toy_%s" % scheme] = run_case(ToySSM(sigma=0.2), ssm.Bootstrap,
+                                          200, 1000, scheme, 0.5)
+        out["sv_%s" % scheme] = run_case(ssm.StochVol(), ssm.Bootstrap,
+                                         50, 2048, scheme, 1.0)
+    # adaptive resampling (some steps do not resample), odd N
+    out["lg_adaptive"] = run_case(kalman.LinearGauss(rho=0.9, sigmaX=1.0, sigmaY=1.5),
+                                  ssm.Bootstrap, 100, 777, "systematic", 0.5)
+    out["lg_guided"] = run_case(kalman.LinearGauss(rho=0.9, sigmaX=1.0, sigmaY=0.2),
+                                ssm.GuidedPF, 60, 500, "systematic", 0.5)
+    for dx in (4, 32):
+        mv = kalman.MVLinearGauss_Guarniero_etal(alpha=0.4, dx=dx)
+        out["mv%d_guided" % dx] = run_case(mv, ssm.GuidedPF, 12, 256, "systematic", 0.5)
+        out["mv%d_boot" % dx] = run_case(mv, ssm.Bootstrap, 12, 256, "stratified", 0.5)
+
+    # --- Kalman exact log-likelihoods (analytic KAT) ------------------------
+    for name, model in (("toy", kalman.LinearGauss(rho=1.0, sigmaX=1.0, sigmaY=0.2, sigma0=1.0)),
+                        ("mv32", kalman.MVLinearGauss_Guarniero_etal(alpha=0.4, dx=32))):
+        np.random.seed(42)
+        T = 200 if name == "toy" else 12
+        x, y = (ToySSM(sigma=0.2) if name == "toy" else model).simulate(T)
+        kf = kalman.Kalman(ssm=model, data=y)
+        kf.filter()
+        out["kalman_%s" % name] = dict(
+            y=np.array(y), loglik=float(np.sum(kf.logpyt)),
+            filt_means=np.array([np.squeeze(f.mean) for f in kf.filt]))
+
+    # --- resampling schemes on fixed weights --------------------------------
+    np.random.seed(7)
+    lw = 3.0 * np.random.randn(1500)
+    lw[[3, 500]] = -np.inf
+    W = rs.exp_and_normalise(lw)
+    res = dict(W=W, lw=lw)
+    for scheme in ("systematic", "stratified", "multinomial"):
+        for M in (1500, 400, 4000):
+            np.random.seed(11)
+            res["A_%s_%d" % (scheme, M)] = rs.resampling(scheme, W, M=M)
+    np.random.seed(5)
+    res["spacings_100"] = rs.uniform_spacings(100)
+    out["resampling"] = res
+
+    # --- Weights / log-sum-exp helpers --------------------------------------
+    np.random.seed(3)
+    lw = 10.0 * np.random.randn(1000)
+    lw[10] = np.nan
+    lw[20] = -np.inf
+    lwc = lw.copy()
+    w = rs.Weights(lw=lwc)
+    w2 = w.add(np.random.randn(1000))
+    out["weights"] = dict(
+        lw_in=lw, lw_after=w.lw, W=w.W, ESS=w.ESS, log_mean=w.log_mean,
+        W2=w2.W, ESS2=w2.ESS, log_mean2=w2.log_mean, lw2=w2.lw,
+        lse=rs.log_sum_exp(w.lw), lme=rs.log_mean_exp(w.lw),
+        lme_w=rs.log_mean_exp(w2.lw, W=w.W), essl=rs.essl(w.lw),
+        ean=rs.exp_and_normalise(w.lw),
+        wmean=rs.wmean_and_var(w.W, np.sin(np.arange(1000.0)))["mean"],
+        wvar=rs.wmean_and_var(w.W, np.sin(np.arange(1000.0)))["var"])
+
+    # --- distributions -------------------------------------------------------
+    np.random.seed(9)
+    xs = np.random.randn(64)
+    loc = np.random.randn(64)
+    dd = dict(x=xs, loc=loc,
+              normal_logpdf=dists.Normal(loc=loc, scale=0.7).logpdf(xs),
+              normal_logpdf_sv=dists.Normal(loc=0.0, scale=np.exp(0.5 * xs)).logpdf(np.array([0.3])))
+    np.random.seed(10)
+    dd["normal_rvs"] = dists.Normal(loc=loc, scale=0.7).rvs(size=64)
+    d = 5
+    Amat = np.random.randn(d, d)
+    cov = Amat @ Amat.T + d * np.eye(d)
+    mloc = np.random.randn(40, d)
+    mv = dists.MvNormal(loc=mloc, scale=1.3, cov=cov)
+    xs5 = np.random.randn(40, d)
+    dd.update(cov=cov, mloc=mloc, x5=xs5, mv_logpdf=mv.logpdf(xs5))
+    np.random.seed(12)
+    dd["mv_rvs"] = mv.rvs(size=40)
+    out["dists"] = dd
+
+    for name, case in out.items():
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **case)
+        print(name, {k: (v.shape if hasattr(v, "shape") and v.shape else v)
+                     for k, v in case.items() if k in ("logLt", "loglik", "X")})
+
+
+if __name__ == "__main__":
+    main()
