@@ -1,0 +1,184 @@
+#!/usr/bin/env python
+"""Headline benchmark: particle-steps/s of the bootstrap filter of BASELINE.json
+config C2 -- ToySSM (d=1 linear Gaussian), N = 2^20 particles, systematic
+resampling, ESSrmin = 0.5 -- on N GPUs of one node.
+
+    python bench.py --gpus 1 --steps 1000 --warmup 50
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...
+
+A "step" is one time step of the filter (resample decision, resampling,
+propagation, weighting, evidence increment) over all N particles of the rank's
+filter.  One process per GPU; each rank runs an independent filter on the same
+data with its own Philox island id (weak scaling: total work = n_gpus * N * K);
+the per-rank log-evidences are gathered with RCCL (smc_comm_*) inside the timed
+region.  Inputs are resident in HBM before the timed region starts.
+
+Rank 0 prints ONE JSON line (see README / task contract), including
+  roofline      -- dominant kernel (k_move) algorithmic bytes per launch over its
+                   average duration measured with HIP events on the filter's
+                   stream, against the 8 TB/s HBM peak of MI355X;
+  cpu_baseline  -- the NumPy restatement of the reference path (oracle/, "port")
+                   timed on this host's cores on a bounded sample (N=1, rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BYTES_STEP = 56.0                # 16*d + 40 B per particle-step, d = 1
+BYTES_MOVE = 40.0                # k_move's share: read lw, X; write X, lw, A
+BYTES_PREPARE = 8.0              # k_prepare: read lw (W is never materialised)
+
+
+def synthetic_data(T, sigma=0.2, seed=42):
+    """ToySSM(sigma) sample path (README.md:66-78): X_0~N(0,1), X_t~N(X_{t-1},1),
+    Y_t~N(X_t, sigma^2)."""
+    rng = np.random.RandomState(seed)
+    x = np.cumsum(rng.standard_normal(T))
+    return [np.array([v]) for v in x + sigma * rng.standard_normal(T)]
+
+
+def cpu_baseline(y, N, nsteps):
+    """The reference's NumPy path as restated by the oracle (1 core)."""
+    from oracle import smc_oracle as orc
+    import subprocess
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True,
+                   stdout=subprocess.DEVNULL)
+    np.random.seed(123)
+    t0 = time.perf_counter()
+    out = orc.run_filter(orc.ToySSM(0.2), y[:nsteps], N, "systematic", 0.5)
+    dt = time.perf_counter() - t0
+    return {"value": N * nsteps / dt, "unit": "particle-steps/s", "cores": 1, "kind": "port",
+            "sample": "oracle.run_filter (NumPy restatement of particles.SMC + C inverse_cdf), "
+                      "N=2^%d, first %d steps of the same data; cost/step is flat in T"
+                      % (int(np.log2(N)), nsteps),
+            "seconds": dt, "logLt": out["final_logLt"]}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--log2N", type=int, default=20)
+    ap.add_argument("--scheme", default="systematic")
+    ap.add_argument("--islands", type=int, default=1, help="filters per GPU")
+    ap.add_argument("--cpu-steps", type=int, default=150)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
+                     "--nproc-per-node %d" % (a.gpus, a.gpus))
+        a.gpus = world
+    os.environ["SMC_HIP_DEVICE"] = str(local_rank)
+
+    import particles_amd as pa
+    from particles_amd import _lib, kalman
+    from particles_amd import state_space_models as ssm
+    from particles_amd.distributed import Group
+
+    grp = Group(device_collective=True) if world > 1 else None
+    N, K, W = 1 << a.log2N, a.steps, a.warmup
+    T = W + K
+    y = synthetic_data(T)
+    fk = ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y)
+
+    def make(profile=False):
+        pf = pa.SMC(fk=fk, N=N, resampling=a.scheme, ESSrmin=0.5, collect="off", seed=123,
+                    n_islands=a.islands, island_offset=rank * a.islands,
+                    use_graph=not (a.no_graph or profile))
+        if profile:
+            _lib.check(_lib.lib().smc_filter_profile(pf._f, 1))
+        return pf
+
+    pf = make()
+    pf.step_async(W)
+    pf.sync()
+    # ---- timed region: exactly K steps, barrier + device sync on both sides
+    if grp:
+        grp.barrier()
+    pf.sync()
+    t0 = time.perf_counter()
+    pf.step_async(K)
+    local_ll = pf.logLts_islands                       # syncs the stream
+    all_ll = grp.gather_evidence(local_ll) if grp else local_ll
+    pf.sync()
+    if grp:
+        grp.barrier()
+    dt = time.perf_counter() - t0
+    dt = grp.allreduce_max_host(dt) if grp else dt
+    rs_rate = float(np.mean(pf._summ()[0, W:, 4]))
+    del pf
+
+    out = None
+    if rank == 0:
+        units = float(N) * a.islands * K * world
+        out = {
+            "metric": "particle-steps/sec (N x T), bootstrap filter N=2^%d" % a.log2N,
+            "value": units / dt, "unit": "particle-steps/s", "n_gpus": world, "steps": K,
+            "warmup": W, "ms_per_step": 1e3 * dt / K, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C2: ToySSM d=1 linear-Gaussian bootstrap filter, "
+                                   "N=2^%d, T=%d, %s resampling, ESSrmin=0.5; one independent "
+                                   "filter x %d per GPU" % (a.log2N, K, a.scheme, a.islands),
+                       "N": N, "islands_per_gpu": a.islands, "scheme": a.scheme,
+                       "rng": "philox4x32-10", "graph": not a.no_graph,
+                       "resampled_fraction": rs_rate},
+            "step_achieved_GBs": BYTES_STEP * N * a.islands * K / dt / 1e9,
+            "logLt": [float(v) for v in np.atleast_1d(all_ll)][:16],
+            "evidence_gather": ("rccl" if (grp and grp.comm) else
+                                ("gloo-fallback: %s" % grp.fallback_reason if grp else "none")),
+        }
+
+    # ---- dominant-kernel duration: same workload re-run with HIP events around
+    # every launch on the filter's stream (kept out of the timed region above)
+    if not a.no_profile:
+        pf = make(profile=True)
+        pf.step_async(W)
+        pf.sync()
+        import ctypes
+        mv, pr, ns = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+        _lib.check(_lib.lib().smc_filter_kernel_ms(pf._f, ctypes.byref(mv), ctypes.byref(pr),
+                                                   ctypes.byref(ns)))    # drop warm-up samples
+        pf.step_async(min(K, 4000))
+        _lib.check(_lib.lib().smc_filter_kernel_ms(pf._f, ctypes.byref(mv), ctypes.byref(pr),
+                                                   ctypes.byref(ns)))
+        del pf
+        if rank == 0 and ns.value:
+            ach = BYTES_MOVE * N * a.islands / (mv.value * 1e-3) / 1e9
+            out["roofline"] = {
+                "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "k_move", "kernel_ms": mv.value, "launch_bytes": BYTES_MOVE * N * a.islands,
+                "samples": ns.value,
+                "prepare_ms": pr.value,
+                "prepare_achieved": BYTES_PREPARE * N * a.islands / (pr.value * 1e-3) / 1e9
+                if pr.value > 0 else None,
+                "note": "40 of the step's 56 algorithmic B/particle belong to k_move "
+                        "(read lw,X; write X,lw,A), 8 to k_prepare; the 8 B write of W is fused away",
+            }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(y, N, min(a.cpu_steps, T))
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if grp:
+        grp.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,240 @@
+/*
+ * smc_hip.h -- C ABI of libsmc_hip.so: the MI355X (gfx950) SMC inner loop.
+ *
+ * The reference (nchopin/particles, pure Python) has no FFI; its extension
+ * seams for this path are Python-level: SMC subclassing
+ * (particles/core.py:369-383), the FeynmanKac API (core.py:145-197), the
+ * resampling registry (resampling.py:445-481), ProbDist rvs/logpdf
+ * (distributions.py:215-251) and rs.Weights (resampling.py:191-244).  Each
+ * entry point below names the reference function it replaces; INTEGRATION.md
+ * shows the ctypes binding a maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - every function returns an smc_status (0 = OK); smc_last_error() gives
+ *     the message of the last failure on the calling thread;
+ *   - `double* / int64_t*` array arguments are DEVICE pointers obtained from
+ *     smc_malloc unless the name ends in `_host`;
+ *   - all work is enqueued on the context's own HIP stream; functions that
+ *     return values to host memory synchronise that stream, the others do not;
+ *   - arrays are C-contiguous fp64 (particles: (N,) or (N,d) row-major),
+ *     ancestor indices are int64 (resampling.py:503).
+ */
+#ifndef SMC_HIP_H
+#define SMC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct smc_ctx smc_ctx;        /* device + stream + scratch           */
+typedef struct smc_filter smc_filter;  /* a fused on-device particle filter   */
+
+enum smc_status {
+    SMC_OK = 0,
+    SMC_ERR_INVALID = 1,   /* bad argument (Python side raises ValueError)   */
+    SMC_ERR_HIP = 2,       /* HIP runtime failure                             */
+    SMC_ERR_NOMEM = 3,
+    SMC_ERR_SCHEME = 4,    /* "<name> is not a valid resampling scheme"      */
+    SMC_ERR_STATE = 5      /* call not valid in the object's current state   */
+};
+
+/* resampling.py:540-558, 599-603, 606-610 */
+enum smc_scheme { SMC_MULTINOMIAL = 0, SMC_STRATIFIED = 1, SMC_SYSTEMATIC = 2 };
+
+/* ---- context / memory ---------------------------------------------------- */
+int smc_device_count(int* n_out);
+int smc_ctx_create(int device, uint64_t seed, smc_ctx** out);
+int smc_ctx_destroy(smc_ctx* ctx);
+int smc_ctx_sync(smc_ctx* ctx);
+int smc_ctx_seed(smc_ctx* ctx, uint64_t seed);        /* utils.py:209-213 seeder */
+const char* smc_last_error(void);
+const char* smc_version(void);
+/* name, CU count, HBM bytes of the context's device */
+int smc_ctx_device_info(smc_ctx* ctx, char* name_host, size_t name_len,
+                        int* n_cu, uint64_t* hbm_bytes);
+
+int smc_malloc(smc_ctx* ctx, size_t bytes, void** dptr_out);
+int smc_free(smc_ctx* ctx, void* dptr);
+int smc_memcpy_h2d(smc_ctx* ctx, void* dst, const void* src_host, size_t bytes);
+int smc_memcpy_d2h(smc_ctx* ctx, void* dst_host, const void* src, size_t bytes);
+int smc_memcpy_d2d(smc_ctx* ctx, void* dst, const void* src, size_t bytes);
+int smc_memset(smc_ctx* ctx, void* dst, int byte, size_t bytes);
+
+/* stream-ordered timers (hipEvent on the context's stream); ms between the two
+ * most recent smc_timer_start / smc_timer_stop pairs */
+int smc_timer_start(smc_ctx* ctx);
+int smc_timer_stop(smc_ctx* ctx, float* ms_out);
+
+/* ---- a-4: Weights.__init__ (resampling.py:217-226) -----------------------
+ * NaN -> -inf IN PLACE in lw (like :220); W (may be NULL) <- exp(lw-max)/sum;
+ * out4_host = {log_mean, ESS, max(lw), sum(exp(lw-max))}.  All-(-inf) input yields NaN outputs
+ * like the reference.  The same kernel serves exp_and_normalise (:138),
+ * log_sum_exp (:247), log_mean_exp (:291) and essl (:166) on the host side. */
+int smc_lse_normalise(smc_ctx* ctx, double* lw, int64_t N, double* W,
+                      double* out4_host);
+/* log of the W-weighted mean of exp(v): log_mean_exp(v, W) (:291-317) */
+int smc_log_wmean_exp(smc_ctx* ctx, const double* v, const double* W, int64_t N,
+                      double* out_host);
+/* wmean_and_var (resampling.py:320-338): out_host = mean[d], var[d] */
+int smc_wmean_var(smc_ctx* ctx, const double* W, const double* X, int64_t N,
+                  int64_t d, double* out_host);
+
+/* ---- a-5: inverse_cdf (resampling.py:484-509) ----------------------------
+ * su: M sorted points in [0,1]; A[n] = smallest j with su[n] <= CDF_j, clamped
+ * to N-1.  The CDF is accumulated in exact 2^-62 fixed point (DESIGN.md
+ * "Q62 contract"), which no summation order can change. */
+int smc_inverse_cdf(smc_ctx* ctx, const double* su, const double* W, int64_t M,
+                    int64_t N, int64_t* A);
+
+/* ---- a-6: rs.resampling(scheme, W, M) (resampling.py:477-481) -------------
+ * u: the uniforms the scheme consumes, in the reference's order --
+ *   systematic: 1 (rand(1), :609); stratified: M (rand(M), :602);
+ *   multinomial: M SORTED uniforms, i.e. uniform_spacings(M) (:536-537)
+ * or NULL to draw them on the device from the context's Philox stream
+ * (`counter` selects the sub-stream, e.g. the time step). */
+int smc_resample(smc_ctx* ctx, int scheme, const double* W, int64_t N, int64_t M,
+                 const double* u, uint64_t counter, int64_t* A);
+/* uniform_spacings(M) (:512-537) drawn on the device: su[0..M) sorted */
+int smc_uniform_spacings(smc_ctx* ctx, int64_t M, uint64_t counter, double* su);
+
+/* ---- a-7: Xp = X[A] (core.py:332) ---------------------------------------- */
+int smc_gather(smc_ctx* ctx, const double* X, const int64_t* A, int64_t M,
+               int64_t d, double* Xp);
+
+/* ---- a-2 / a-3: Normal.rvs / Normal.logpdf (distributions.py:270-274) ------
+ * loc/scale are device arrays read with the given element stride (0 = one
+ * value broadcast).  z = standard normals to consume (replay) or NULL for the
+ * Philox stream.  logpdf evaluates scipy's expression
+ *   y=(x-loc)/scale ; -y*y/2 - 0.9189385332046727 - log(scale). */
+int smc_normal_rvs(smc_ctx* ctx, const double* loc, int64_t loc_stride,
+                   const double* scale, int64_t scale_stride, const double* z,
+                   uint64_t counter, int64_t N, double* out);
+int smc_normal_logpdf(smc_ctx* ctx, const double* x, int64_t x_stride,
+                      const double* loc, int64_t loc_stride, const double* scale,
+                      int64_t scale_stride, int64_t N, double* out);
+/* standard normals / uniforms from the Philox stream (for the generic path) */
+int smc_standard_normal(smc_ctx* ctx, uint64_t counter, int64_t n, double* out);
+int smc_uniform(smc_ctx* ctx, uint64_t counter, int64_t n, double* out);
+
+/* ---- a-8: MvNormal.rvs / logpdf (distributions.py:946-969) ----------------
+ * loc: (N,d) rows (loc_rows = N) or one row broadcast (loc_rows = 1);
+ * L_host: (d,d) lower Cholesky factor of cov, row-major, HOST memory;
+ * rvs:    out = loc + scale * (Z @ L^T), Z (N,d) from z or Philox;
+ * logpdf: -0.5*|L^-1 (x-loc)/scale|^2 - d*log(scale) - sum(log diag L) - d*C. */
+int smc_mvn_rvs(smc_ctx* ctx, const double* loc, int64_t loc_rows, double scale,
+                const double* L_host, const double* z, uint64_t counter,
+                int64_t N, int64_t d, double* out);
+int smc_mvn_logpdf(smc_ctx* ctx, const double* x, int64_t x_rows,
+                   const double* loc, int64_t loc_rows, double scale,
+                   const double* L_host, int64_t N, int64_t d, double* out);
+
+/* ---- a-1: the fused SMC step loop (core.py:369-383) ------------------------
+ * One smc_filter holds `n_islands` independent particle filters of N particles
+ * each (multiSMC runs / SMC^2 inner filters, core.py:431, smc_samplers.py:
+ * 1110-1113) that advance in lock step on the device.  The model is one of
+ * the closed family the reference's hot-path configs use. */
+enum smc_model_kind {
+    SMC_MODEL_LINGAUSS = 1,   /* kalman.py:397-452 (ToySSM = rho 1, sigmaX 1, sigma0 1) */
+    SMC_MODEL_STOCHVOL = 2,   /* state_space_models.py:446-473 */
+    SMC_MODEL_MVLINGAUSS = 3  /* kalman.py:296-361 */
+};
+enum smc_fk_kind {
+    SMC_FK_BOOTSTRAP = 0,     /* state_space_models.py:299-349 */
+    SMC_FK_GUIDED = 1         /* state_space_models.py:352-398 (model's own proposal) */
+};
+enum smc_rng_mode {
+    SMC_RNG_PHILOX = 0,       /* counter-based Philox4x32-10 per lane */
+    SMC_RNG_REPLAY = 1        /* consume a tape of the reference's draws */
+};
+
+typedef struct smc_model {
+    int32_t kind;             /* smc_model_kind */
+    int32_t fk;               /* smc_fk_kind */
+    int32_t dx, dy;           /* state / observation dimension (1 for univariate) */
+    /* univariate parameters, one row of 16 per island (HOST, (n_islands,16)).
+     * Derived constants are passed in (not recomputed) so that they carry the
+     * caller's roundings (numpy's log / sqrt) and replay runs match bit for bit:
+     *   LINGAUSS: 0 rho, 1 sigmaX, 2 sigmaY, 3 sigma0, 4 log(sigmaY),
+     *             5 log(sigmaX), 6 log(sigma0), 7 sigmaX^2, 8 sigmaY^2,
+     *             guided only (kalman.py:436-446): 9 sig2post, 10 sqrt(9),
+     *             11 log(10), 12 sig2post0, 13 sqrt(12), 14 log(13)
+     *   STOCHVOL: 0 mu, 1 rho, 2 sigma, 3 sigma/sqrt(1-rho^2), 4 (1-rho)*mu */
+    const double* params_host;
+    /* MVLINGAUSS (HOST, row-major): F(dx,dx) G(dy,dx) covX(dx,dx) covY(dy,dy)
+     * mu0(dx) cov0(dx,dx); shared by all islands */
+    const double *F_host, *G_host, *covX_host, *covY_host, *mu0_host, *cov0_host;
+} smc_model;
+
+typedef struct smc_filter_opts {
+    int64_t N;                /* particles per island */
+    int64_t T;                /* number of time steps (len(data)) */
+    int32_t n_islands;
+    int32_t scheme;           /* smc_scheme */
+    double ESSrmin;           /* resample when ESS < N*ESSrmin (core.py:181-183) */
+    uint64_t seed;            /* Philox key; island i uses counter word i */
+    int32_t rng_mode;         /* smc_rng_mode */
+    int32_t use_graph;        /* 1: replay the step loop from a hipGraph */
+    int32_t island_offset;    /* global index of this filter's island 0 (multi-GPU sharding) */
+    int32_t reserved;
+} smc_filter_opts;
+
+/* y_host: data, (T, dy) row-major, shared by all islands. */
+int smc_filter_create(smc_ctx* ctx, const smc_model* model,
+                      const smc_filter_opts* opts, const double* y_host,
+                      smc_filter** out);
+int smc_filter_destroy(smc_filter* f);
+/* Replay tapes (device): z (T, n_islands, N, dx) normals; u (T, n_islands, K)
+ * with K = 1 (systematic: rand(1)), N (stratified: rand(N)) or N (multinomial:
+ * the SORTED uniforms).  Slots of steps that do not resample are ignored. */
+int smc_filter_set_replay(smc_filter* f, const double* z, const double* u);
+/* Enqueue `nsteps` time steps (asynchronous).  Steps beyond T are no-ops. */
+int smc_filter_step(smc_filter* f, int64_t nsteps);
+int smc_filter_sync(smc_filter* f);
+int smc_filter_t(smc_filter* f, int64_t* t_out);      /* steps enqueued so far */
+/* Per-step summaries (collectors.py:278-295) of steps [0, t):
+ * out_host (n_islands, t, 5) = ESS, log_mean_w, loglt, logLt, rs_flag. */
+#define SMC_SUMMARY_COLS 5
+int smc_filter_summaries(smc_filter* f, double* out_host);
+int smc_filter_logLt(smc_filter* f, double* out_host /* n_islands */);
+enum smc_state_field {
+    SMC_FIELD_X = 0,   /* (N,dx) fp64   core.py SMC.X            */
+    SMC_FIELD_XP = 1,  /* (N,dx) fp64   SMC.Xp = X_{t-1}[A]      */
+    SMC_FIELD_A = 2,   /* (N,) int64    SMC.A                    */
+    SMC_FIELD_LW = 3,  /* (N,) fp64     SMC.wgts.lw              */
+    SMC_FIELD_W = 4    /* (N,) fp64     SMC.W                    */
+};
+/* Copy one island's field (state after the last enqueued step) to the host. */
+int smc_filter_get(smc_filter* f, int field, int island, void* out_host);
+/* Algorithmic bytes moved per particle-step and kernel launches
+ * per step, for roofline accounting. */
+int smc_filter_info(smc_filter* f, double* bytes_per_particle_step,
+                    int* kernels_per_step);
+/* Average duration (ms) of the dominant kernel ("move") over the steps run
+ * since the last call, measured with HIP events on the filter's stream when
+ * profiling is enabled with smc_filter_profile(f, 1). */
+int smc_filter_profile(smc_filter* f, int enable);
+int smc_filter_kernel_ms(smc_filter* f, double* move_ms_avg,
+                         double* prepare_ms_avg, int64_t* n_samples);
+
+/* ---- multi-GPU seam: multiSMC / SMC^2 islands (core.py:431, utils.py:158) ----
+ * Independent runs shard across one process per GPU with no data-path
+ * exchange; the only collective gathers the per-island log-evidences over RCCL
+ * (xGMI).  Rank 0 obtains the id and distributes it out of band (the bench
+ * uses the torch.distributed/gloo rendezvous the launcher provides). */
+typedef struct smc_comm smc_comm;
+#define SMC_COMM_ID_BYTES 128
+int smc_comm_unique_id(char* id_host /* SMC_COMM_ID_BYTES */);
+int smc_comm_create(smc_ctx* ctx, int nranks, int rank, const char* id_host,
+                    smc_comm** out);
+/* recv (nranks*count) <- concatenation over ranks of send (count); blocking */
+int smc_comm_allgather_f64(smc_comm* comm, const double* send, int64_t count,
+                           double* recv);
+int smc_comm_destroy(smc_comm* comm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMC_HIP_H */

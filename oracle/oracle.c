@@ -97,7 +97,7 @@ static void philox_u64_pair(uint64_t seed, uint32_t idx, uint32_t t,
 
 static inline double u01_open(uint64_t x)
 {
-    return ((double)(x >> 11) + 0.5) * 0x1.0p-53;
+    return ((double)(x >> 12) + 0.5) * 0x1.0p-52;
 }
 static inline double u01_halfopen(uint64_t x)
 {

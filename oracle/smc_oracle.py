@@ -638,8 +638,8 @@ def philox_u64_pair(seed, idx, t, island, stream):
 
 
 def u01_open(x):
-    """(0,1): ((x >> 11) + 0.5) * 2^-53."""
-    return ((x >> np.uint64(11)).astype(np.float64) + 0.5) * 2.0 ** -53
+    """(0,1): ((x >> 12) + 0.5) * 2^-52 (exact in fp64, never 0 or 1)."""
+    return ((x >> np.uint64(12)).astype(np.float64) + 0.5) * 2.0 ** -52
 
 
 def u01_halfopen(x):

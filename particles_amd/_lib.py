@@ -1,0 +1,254 @@
+"""ctypes binding of libsmc_hip.so (include/smc_hip.h) + device arrays.
+
+There is NO CPU fallback: if the HIP library is missing or no MI355X is
+visible, every operator raises.  ``SMC_HIP_LIBRARY`` may point at another
+build of the same C ABI (the CPU test-suite uses it to load the fiber emulator
+of tests/emu, which exists only to exercise kernel logic without a GPU).
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "lib", "libsmc_hip.so")
+
+c_i64, c_u64, c_int, c_dbl, c_vp = (ctypes.c_int64, ctypes.c_uint64, ctypes.c_int,
+                                    ctypes.c_double, ctypes.c_void_p)
+c_sz = ctypes.c_size_t
+P = ctypes.POINTER
+
+MULTINOMIAL, STRATIFIED, SYSTEMATIC = 0, 1, 2
+SCHEMES = {"multinomial": MULTINOMIAL, "stratified": STRATIFIED, "systematic": SYSTEMATIC}
+MODEL_LINGAUSS, MODEL_STOCHVOL, MODEL_MVLINGAUSS = 1, 2, 3
+FK_BOOTSTRAP, FK_GUIDED = 0, 1
+FIELD_X, FIELD_XP, FIELD_A, FIELD_LW, FIELD_W = range(5)
+SUMMARY_COLS = 5
+PARAM_STRIDE = 16
+
+
+class SmcModel(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int32), ("fk", ctypes.c_int32),
+                ("dx", ctypes.c_int32), ("dy", ctypes.c_int32),
+                ("params_host", P(c_dbl)),
+                ("F_host", P(c_dbl)), ("G_host", P(c_dbl)), ("covX_host", P(c_dbl)),
+                ("covY_host", P(c_dbl)), ("mu0_host", P(c_dbl)), ("cov0_host", P(c_dbl))]
+
+
+class SmcFilterOpts(ctypes.Structure):
+    _fields_ = [("N", c_i64), ("T", c_i64), ("n_islands", ctypes.c_int32),
+                ("scheme", ctypes.c_int32), ("ESSrmin", c_dbl), ("seed", c_u64),
+                ("rng_mode", ctypes.c_int32), ("use_graph", ctypes.c_int32),
+                ("island_offset", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+# name -> (restype, argtypes): every symbol include/smc_hip.h declares
+SIGNATURES = {
+    "smc_device_count": (c_int, [P(c_int)]),
+    "smc_ctx_create": (c_int, [c_int, c_u64, P(c_vp)]),
+    "smc_ctx_destroy": (c_int, [c_vp]),
+    "smc_ctx_sync": (c_int, [c_vp]),
+    "smc_ctx_seed": (c_int, [c_vp, c_u64]),
+    "smc_last_error": (ctypes.c_char_p, []),
+    "smc_version": (ctypes.c_char_p, []),
+    "smc_ctx_device_info": (c_int, [c_vp, ctypes.c_char_p, c_sz, P(c_int), P(c_u64)]),
+    "smc_malloc": (c_int, [c_vp, c_sz, P(c_vp)]),
+    "smc_free": (c_int, [c_vp, c_vp]),
+    "smc_memcpy_h2d": (c_int, [c_vp, c_vp, c_vp, c_sz]),
+    "smc_memcpy_d2h": (c_int, [c_vp, c_vp, c_vp, c_sz]),
+    "smc_memcpy_d2d": (c_int, [c_vp, c_vp, c_vp, c_sz]),
+    "smc_memset": (c_int, [c_vp, c_vp, c_int, c_sz]),
+    "smc_timer_start": (c_int, [c_vp]),
+    "smc_timer_stop": (c_int, [c_vp, P(ctypes.c_float)]),
+    "smc_lse_normalise": (c_int, [c_vp, c_vp, c_i64, c_vp, P(c_dbl)]),
+    "smc_log_wmean_exp": (c_int, [c_vp, c_vp, c_vp, c_i64, P(c_dbl)]),
+    "smc_wmean_var": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, P(c_dbl)]),
+    "smc_inverse_cdf": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
+    "smc_resample": (c_int, [c_vp, c_int, c_vp, c_i64, c_i64, c_vp, c_u64, c_vp]),
+    "smc_uniform_spacings": (c_int, [c_vp, c_i64, c_u64, c_vp]),
+    "smc_gather": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
+    "smc_normal_rvs": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_u64, c_i64, c_vp]),
+    "smc_normal_logpdf": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp]),
+    "smc_standard_normal": (c_int, [c_vp, c_u64, c_i64, c_vp]),
+    "smc_uniform": (c_int, [c_vp, c_u64, c_i64, c_vp]),
+    "smc_mvn_rvs": (c_int, [c_vp, c_vp, c_i64, c_dbl, P(c_dbl), c_vp, c_u64, c_i64, c_i64, c_vp]),
+    "smc_mvn_logpdf": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_dbl, P(c_dbl), c_i64, c_i64, c_vp]),
+    "smc_filter_create": (c_int, [c_vp, P(SmcModel), P(SmcFilterOpts), P(c_dbl), P(c_vp)]),
+    "smc_filter_destroy": (c_int, [c_vp]),
+    "smc_filter_set_replay": (c_int, [c_vp, c_vp, c_vp]),
+    "smc_filter_step": (c_int, [c_vp, c_i64]),
+    "smc_filter_sync": (c_int, [c_vp]),
+    "smc_filter_t": (c_int, [c_vp, P(c_i64)]),
+    "smc_filter_summaries": (c_int, [c_vp, P(c_dbl)]),
+    "smc_filter_logLt": (c_int, [c_vp, P(c_dbl)]),
+    "smc_filter_get": (c_int, [c_vp, c_int, c_int, c_vp]),
+    "smc_filter_info": (c_int, [c_vp, P(c_dbl), P(c_int)]),
+    "smc_filter_profile": (c_int, [c_vp, c_int]),
+    "smc_filter_kernel_ms": (c_int, [c_vp, P(c_dbl), P(c_dbl), P(c_i64)]),
+    "smc_comm_unique_id": (c_int, [ctypes.c_char_p]),
+    "smc_comm_create": (c_int, [c_vp, c_int, c_int, ctypes.c_char_p, P(c_vp)]),
+    "smc_comm_allgather_f64": (c_int, [c_vp, c_vp, c_i64, c_vp]),
+    "smc_comm_destroy": (c_int, [c_vp]),
+}
+
+_lib = None
+
+
+def library_path():
+    return os.environ.get("SMC_HIP_LIBRARY", DEFAULT_LIB)
+
+
+def lib():
+    """The loaded C-ABI library; raises loudly if it is not there."""
+    global _lib
+    if _lib is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise RuntimeError(
+                "particles_amd: %s not found. Build it with "
+                "`python -m particles_amd._build` (needs hipcc); there is no CPU "
+                "fallback." % path)
+        L = ctypes.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)      # AttributeError if a declared symbol is missing
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+class SmcError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc == 0:
+        return
+    msg = lib().smc_last_error().decode()
+    if rc in (1, 4):          # SMC_ERR_INVALID, SMC_ERR_SCHEME (resampling.py:477-481)
+        raise ValueError(msg)
+    if rc == 3:
+        raise MemoryError(msg)
+    raise SmcError(msg)
+
+
+class Context:
+    """One device + stream (smc_ctx)."""
+
+    def __init__(self, device=0, seed=0):
+        h = c_vp()
+        check(lib().smc_ctx_create(int(device), int(seed) & (2 ** 64 - 1), ctypes.byref(h)))
+        self.h, self.device, self._seed = h, device, int(seed)
+
+    def seed(self, seed):
+        self._seed = int(seed)
+        check(lib().smc_ctx_seed(self.h, self._seed & (2 ** 64 - 1)))
+
+    def sync(self):
+        check(lib().smc_ctx_sync(self.h))
+
+    def device_info(self):
+        name = ctypes.create_string_buffer(256)
+        ncu, mem = c_int(), c_u64()
+        check(lib().smc_ctx_device_info(self.h, name, 256, ctypes.byref(ncu), ctypes.byref(mem)))
+        return {"name": name.value.decode(), "n_cu": ncu.value, "hbm_bytes": mem.value}
+
+    def close(self):
+        if self.h:
+            lib().smc_ctx_destroy(self.h)
+            self.h = None
+
+
+_default_ctx = None
+_counter = 0
+
+
+def default_device():
+    return int(os.environ.get("SMC_HIP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+
+
+def ctx():
+    """Process-wide default context (device = $SMC_HIP_DEVICE / $LOCAL_RANK / 0)."""
+    global _default_ctx
+    if _default_ctx is None:
+        n = c_int()
+        check(lib().smc_device_count(ctypes.byref(n)))
+        if n.value < 1:
+            raise RuntimeError("particles_amd: no HIP device visible (there is no CPU fallback)")
+        _default_ctx = Context(default_device() % n.value, seed=0)
+    return _default_ctx
+
+
+def seed(s):
+    """Counterpart of ``numpy.random.seed`` for the device Philox stream
+    (utils.py:209-213 seeds the global generator per run)."""
+    global _counter
+    ctx().seed(s)
+    _counter = 0
+
+
+def next_counter():
+    """A fresh Philox sub-stream id for each stand-alone draw."""
+    global _counter
+    _counter += 1
+    return _counter
+
+
+class DeviceArray:
+    """A C-contiguous fp64 / int64 array in HBM."""
+
+    def __init__(self, shape, dtype=np.float64, context=None):
+        self.ctx = context or ctx()
+        self.shape = (int(shape),) if np.isscalar(shape) else tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        assert self.dtype.itemsize == 8
+        self.size = int(np.prod(self.shape)) if self.shape else 1
+        p = c_vp()
+        check(lib().smc_malloc(self.ctx.h, self.size * 8, ctypes.byref(p)))
+        self.ptr = p
+
+    @classmethod
+    def from_numpy(cls, a, dtype=None, context=None):
+        a = np.ascontiguousarray(a, dtype=dtype or (np.int64 if np.asarray(a).dtype.kind in "iu"
+                                                     else np.float64))
+        out = cls(a.shape if a.ndim else (1,), a.dtype, context)
+        check(lib().smc_memcpy_h2d(out.ctx.h, out.ptr, a.ctypes.data_as(c_vp), a.nbytes))
+        return out
+
+    def get(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        check(lib().smc_memcpy_d2h(self.ctx.h, out.ctypes.data_as(c_vp), self.ptr, out.nbytes))
+        return out
+
+    def __len__(self):
+        return self.shape[0]
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            try:
+                lib().smc_free(self.ctx.h, self.ptr)
+            except Exception:
+                pass
+            self.ptr = None
+
+    def __del__(self):
+        self.free()
+
+
+def as_device(a, dtype=None):
+    """(device array, was_host) for a numpy array or a DeviceArray."""
+    if isinstance(a, DeviceArray):
+        return a, False
+    return DeviceArray.from_numpy(a, dtype=dtype), True
+
+
+def dptr(a):
+    return a.ptr if a is not None else None
+
+
+def host_dbl(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(P(c_dbl))

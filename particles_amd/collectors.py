@@ -1,0 +1,162 @@
+"""Side-cars of the SMC step that must keep working on the device path:
+``Summaries`` / ``Collector`` / default collectors ``ESSs, LogLts, Rs_flags``
+and ``Moments`` (particles/collectors.py:215-317), and the history containers
+the step saves into (particles/smoothing.py:164-255).
+"""
+from collections import deque
+
+import numpy as np
+
+
+class Summaries:
+    """Stores and updates summaries (collectors.py:215-231)."""
+
+    def __init__(self, cols):
+        self._collectors = [cls() for cls in default_collector_cls]
+        if cols is not None:
+            self._collectors.extend(col() for col in cols)
+        for col in self._collectors:
+            setattr(self, col.summary_name, col.summary)
+
+    def collect(self, smc):
+        for col in self._collectors:
+            col.collect(smc)
+
+    def _extend_defaults(self, ess, logLt, flags):
+        """Bulk append of the three default summaries after a device-resident
+        run (the values were kept per step in the device ring buffer)."""
+        self.ESSs.extend(float(v) for v in ess)
+        self.logLts.extend(float(v) for v in logLt)
+        self.rs_flags.extend(bool(v) for v in flags)
+
+
+class Collector:
+    """Base class for collectors (collectors.py:234-271)."""
+
+    signature = {}
+
+    @property
+    def summary_name(self):
+        cn = self.__class__.__name__
+        return cn[0].lower() + cn[1:]
+
+    def __init__(self, **kwargs):
+        self.summary = []
+        for k, v in self.signature.items():
+            setattr(self, k, v)
+        for k, v in kwargs.items():
+            if k in self.signature.keys():
+                setattr(self, k, v)
+            else:
+                raise ValueError(f"Collector {self.__class__.__name__}: unknown parameter {k}")
+
+    def __call__(self):
+        return self.__class__(**{k: getattr(self, k) for k in self.signature.keys()})
+
+    def collect(self, smc):
+        self.summary.append(self.fetch(smc))
+
+
+class ESSs(Collector):
+    summary_name = "ESSs"
+
+    def fetch(self, smc):
+        return smc.wgts.ESS
+
+
+class LogLts(Collector):
+    def fetch(self, smc):
+        return smc.logLt
+
+
+class Rs_flags(Collector):
+    def fetch(self, smc):
+        return smc.rs_flag
+
+
+default_collector_cls = [ESSs, LogLts, Rs_flags]
+
+
+class Moments(Collector):
+    """Empirical moments of the particles (collectors.py:301-317); the default
+    is the weighted mean and variance, evaluated on the device."""
+
+    signature = {"mom_func": None}
+
+    def fetch(self, smc):
+        f = smc.fk.default_moments if self.mom_func is None else self.mom_func
+        return f(smc.W, smc.X)
+
+
+# ---- history containers (smoothing.py:141-255) -----------------------------
+
+def generate_hist_obj(option, smc):
+    if option is True:
+        return ParticleHistory(smc.fk, smc.qmc)
+    if option is False:
+        return None
+    if callable(option):
+        return PartialParticleHistory(option)
+    if isinstance(option, int) and option >= 0:
+        return RollingParticleHistory(option)
+    raise ValueError("store_history: invalid option")
+
+
+class PartialParticleHistory:
+    def __init__(self, func):
+        self.is_save_time = func
+        self.X, self.wgts = {}, {}
+
+    def save(self, smc):
+        t = smc.t
+        if self.is_save_time(t):
+            self.X[t] = smc.X
+            self.wgts[t] = _frozen_weights(smc.wgts)
+
+
+class RollingParticleHistory:
+    def __init__(self, length):
+        self.X = deque([], length)
+        self.A = deque([], length)
+        self.wgts = deque([], length)
+
+    @property
+    def N(self):
+        return self.X[0].shape[0]
+
+    @property
+    def T(self):
+        return len(self.X)
+
+    def save(self, smc):
+        self.X.append(smc.X)
+        self.A.append(smc.A)
+        self.wgts.append(_frozen_weights(smc.wgts))
+
+    def compute_trajectories(self):
+        """(T, N) genealogy (smoothing.py:209-219)."""
+        Bs = [np.arange(self.N)]
+        for A in list(self.A)[-1:0:-1]:
+            Bs.append(A[Bs[-1]])
+        Bs.reverse()
+        return np.array(Bs)
+
+
+class ParticleHistory(RollingParticleHistory):
+    def __init__(self, fk, qmc):
+        self.X, self.A, self.wgts = [], [], []
+        self.fk = fk
+
+
+class _Frozen:
+    pass
+
+
+def _frozen_weights(w):
+    """Copy-on-save: the device double-buffers its arrays, so a saved history
+    entry must own host copies (the reference stores references,
+    smoothing.py:204-207)."""
+    f = _Frozen()
+    f.lw, f.W, f.ESS, f.log_mean = w.lw, w.W, w.ESS, w.log_mean
+    f.N = w.N
+    return f

@@ -1,0 +1,486 @@
+"""Counterpart of ``particles.core``: ``FeynmanKac`` (core.py:108-197), ``SMC``
+(:200-409) and ``multiSMC`` (:431-518), with the per-time-step particle loop
+executed on an MI355X.
+
+``SMC`` keeps the reference's constructor, iterator protocol and public
+attributes (``X, Xp, A, wgts, aux, W, t, rs_flag, logLt, loglt, summaries,
+hist, cpu_time``).  Two execution paths, both driving HIP kernels:
+
+* fused  -- the Feynman-Kac model is a ``Bootstrap`` / ``GuidedPF`` of a model
+  from the closed family (``kalman.LinearGauss``, ``StochVol``): the whole time
+  loop (resample decision, resampling, propagation, weighting, evidence) runs
+  on the device through ``smc_filter_*``; attributes are fetched lazily.
+* generic -- any other ``FeynmanKac`` (user ``M0`` / ``M`` / ``logG`` in Python):
+  the template method of core.py:369-383 is followed literally, with
+  ``Weights`` and ``resampling`` served by the device operators.
+"""
+import ctypes
+import time
+
+import numpy as np
+
+from . import _lib
+from . import collectors
+from . import resampling as rs
+from ._lib import DeviceArray, check, lib
+
+
+class FeynmanKac:
+    """Abstract base class for Feynman-Kac models (core.py:108-197)."""
+
+    def __init__(self, T):
+        self.T = T
+
+    def _error_msg(self, meth):
+        return f"method/property {meth} missing in class {self.__class__.__name__}"
+
+    def M0(self, N):
+        raise NotImplementedError(self._error_msg("M0"))
+
+    def M(self, t, xp):
+        raise NotImplementedError(self._error_msg("M"))
+
+    def logG(self, t, xp, x):
+        raise NotImplementedError(self._error_msg("logG"))
+
+    @property
+    def isAPF(self):
+        return "logeta" in dir(self)
+
+    def done(self, smc):
+        """Time to stop the algorithm (core.py:177-179)."""
+        return smc.t >= self.T
+
+    def time_to_resample(self, smc):
+        """When to resample (core.py:181-183)."""
+        return smc.aux.ESS < smc.N * smc.ESSrmin
+
+    def default_moments(self, W, X):
+        return rs.wmean_and_var(W, X)
+
+    def summary_format(self, smc):
+        return "t=%i: resample:%s, ESS (end of iter)=%.2f" % (smc.t, smc.rs_flag, smc.wgts.ESS)
+
+    def _device_model(self):
+        return None
+
+
+class _DeviceWeights:
+    """``rs.Weights`` view of one island of a fused filter (lazy downloads)."""
+
+    def __init__(self, smc, island=0):
+        self._smc, self._isl = smc, island
+
+    @property
+    def lw(self):
+        return self._smc._get(_lib.FIELD_LW, self._isl)
+
+    @property
+    def W(self):
+        return self._smc._get(_lib.FIELD_W, self._isl)
+
+    @property
+    def ESS(self):
+        return self._smc._summ()[self._isl, -1, 0]
+
+    @property
+    def log_mean(self):
+        return self._smc._summ()[self._isl, -1, 1]
+
+    @property
+    def N(self):
+        return self._smc.N
+
+
+class SMC:
+    """Particle filter / SMC algorithm (core.py:200-409), device-resident.
+
+    Parameters are those of ``particles.SMC`` (core.py:258-268); extras:
+
+    seed : int, optional -- Philox key of this run (default: drawn from
+        ``numpy.random`` like ``utils.distinct_seeds`` would)
+    n_islands : int -- number of independent replicas advanced together
+        (the batched form of ``multiSMC``); attributes refer to island 0,
+        ``logLts_islands`` has them all
+    replay : (z, u) device/host tapes of the reference's own draws, see
+        ``smc_filter_set_replay`` (parity tests)
+    """
+
+    def __init__(self, fk=None, N=100, qmc=False, resampling="systematic", ESSrmin=0.5,
+                 store_history=False, verbose=False, collect=None, seed=None, n_islands=1,
+                 replay=None, use_graph=True, island_offset=0):
+        if qmc:
+            raise NotImplementedError("SQMC (qmc=True) is outside the device hot path")
+        if resampling not in rs.rs_funcs:
+            raise ValueError(f"{resampling} is not a valid resampling scheme")
+        self.fk, self.N, self.qmc = fk, N, qmc
+        self.resampling, self.ESSrmin, self.verbose = resampling, ESSrmin, verbose
+        self.n_islands = n_islands
+        self.t = 0
+        self.rs_flag = False
+        self._logLt = 0.0
+        self.cpu_time = 0.0
+        if collect == "off":
+            self.summaries = None
+        else:
+            self.summaries = collectors.Summaries(collect)
+        self._user_collectors = bool(collect) and collect != "off"
+        self.hist = collectors.generate_hist_obj(store_history, self)
+        if seed is None:
+            seed = int(np.random.randint(0, 2 ** 31 - 1))
+        self.seed = seed
+        self._f = None
+        self._n = 0          # steps executed on the device
+        self._cache = {}
+        self._summ_cache = None
+        model = fk._device_model() if hasattr(fk, "_device_model") else None
+        if fk is not None and fk.isAPF:
+            model = None
+        self._fused = model is not None and model.get("params") is not None \
+            and resampling in _lib.SCHEMES
+        if self._fused:
+            self._create_filter(model, replay, use_graph, island_offset)
+        else:
+            if n_islands != 1:
+                raise ValueError("n_islands > 1 needs a model of the fused family")
+            self._wgts = rs.Weights()
+            self.aux = None
+            self._X = self._Xp = self._A = None
+
+    # ------------------------------------------------------------------ fused
+    def _create_filter(self, model, replay, use_graph, island_offset):
+        fk = self.fk
+        T = fk.T
+        y = np.ascontiguousarray(np.asarray(fk.data, dtype=np.float64).reshape(T, -1))
+        params = np.ascontiguousarray(np.tile(model["params"], (self.n_islands, 1)))
+        self._keep = (y, params)
+        m = _lib.SmcModel()
+        m.kind, m.fk, m.dx, m.dy = model["kind"], fk._fk_kind, model["dx"], model["dy"]
+        m.params_host = params.ctypes.data_as(_lib.P(_lib.c_dbl))
+        o = _lib.SmcFilterOpts()
+        o.N, o.T, o.n_islands = self.N, T, self.n_islands
+        o.scheme, o.ESSrmin, o.seed = _lib.SCHEMES[self.resampling], self.ESSrmin, self.seed
+        o.rng_mode = 1 if replay is not None else 0
+        o.use_graph = 1 if use_graph else 0
+        o.island_offset = island_offset
+        self._ctx = _lib.ctx()
+        h = _lib.c_vp()
+        check(lib().smc_filter_create(self._ctx.h, ctypes.byref(m), ctypes.byref(o),
+                                      y.ctypes.data_as(_lib.P(_lib.c_dbl)), ctypes.byref(h)))
+        self._f = h
+        if replay is not None:
+            z, u = replay
+            self._tapes = (_lib.as_device(z)[0], _lib.as_device(u)[0])
+            check(lib().smc_filter_set_replay(self._f, self._tapes[0].ptr, self._tapes[1].ptr))
+
+    def __del__(self):
+        f = getattr(self, "_f", None)
+        if f:
+            try:
+                lib().smc_filter_destroy(f)
+            except Exception:
+                pass
+            self._f = None
+
+    def _invalidate(self):
+        self._cache = {}
+        self._summ_cache = None
+
+    def _summ(self):
+        """(n_islands, t, 5) per-step ESS, log_mean_w, loglt, logLt, rs_flag."""
+        if self._summ_cache is None:
+            out = np.zeros((self.n_islands, self._n, _lib.SUMMARY_COLS))
+            if self._n:
+                check(lib().smc_filter_summaries(self._f, out.ctypes.data_as(_lib.P(_lib.c_dbl))))
+            self._summ_cache = out
+        return self._summ_cache
+
+    def _get(self, field, island=0):
+        key = (field, island)
+        if key not in self._cache:
+            dt = np.int64 if field == _lib.FIELD_A else np.float64
+            out = np.empty(self.N, dtype=dt)
+            check(lib().smc_filter_get(self._f, field, island, out.ctypes.data_as(_lib.c_vp)))
+            self._cache[key] = out
+        return self._cache[key]
+
+    def step_async(self, nsteps=1):
+        """Enqueue ``nsteps`` time steps on the device without synchronising."""
+        todo = min(nsteps, self.fk.T - self.t)
+        if todo > 0:
+            check(lib().smc_filter_step(self._f, todo))
+            self.t += todo
+            self._n += todo
+            self._invalidate()
+        return todo
+
+    def sync(self):
+        if self._f:
+            check(lib().smc_filter_sync(self._f))
+
+    # ------------------------------------------------------- public attributes
+    @property
+    def X(self):
+        if not self._fused:
+            return self._X
+        return self._get(_lib.FIELD_X) if self._n else None
+
+    @X.setter
+    def X(self, v):
+        self._X = v
+
+    @property
+    def Xp(self):
+        if not self._fused:
+            return self._Xp
+        return self._get(_lib.FIELD_XP) if self._n > 1 else None
+
+    @Xp.setter
+    def Xp(self, v):
+        self._Xp = v
+
+    @property
+    def A(self):
+        if not self._fused:
+            return self._A
+        return self._get(_lib.FIELD_A) if self._n > 1 else None
+
+    @A.setter
+    def A(self, v):
+        self._A = v
+
+    @property
+    def wgts(self):
+        if not self._fused:
+            return self._wgts
+        return _DeviceWeights(self) if self._n else rs.Weights()
+
+    @wgts.setter
+    def wgts(self, v):
+        self._wgts = v
+
+    @property
+    def W(self):
+        return self.wgts.W
+
+    @property
+    def logLt(self):
+        if not self._fused:
+            return self._logLt
+        return float(self._summ()[0, -1, 3]) if self._n else 0.0
+
+    @logLt.setter
+    def logLt(self, v):
+        self._logLt = v
+
+    @property
+    def logLts_islands(self):
+        """log-evidence estimate of every island (multiSMC's per-run outputs)."""
+        out = np.zeros(self.n_islands)
+        check(lib().smc_filter_logLt(self._f, out.ctypes.data_as(_lib.P(_lib.c_dbl))))
+        return out
+
+    def __str__(self):
+        return self.fk.summary_format(self)
+
+    # ------------------------------------------------- generic template method
+    def reset_weights(self):
+        self.wgts = rs.Weights()                                   # core.py:299-305
+
+    def setup_auxiliary_weights(self):
+        self.aux = self.wgts                                       # core.py:307-313 (non-APF)
+
+    def generate_particles(self):
+        self.X = self.fk.M0(self.N)                                # core.py:315-321
+
+    def reweight_particles(self):
+        self.wgts = self.wgts.add(self.fk.logG(self.t, self.Xp, self.X))   # core.py:323-324
+
+    def resample_move(self):
+        self.rs_flag = self.fk.time_to_resample(self)              # core.py:326-337
+        if self.rs_flag:
+            self.A = rs.resampling(self.resampling, self.aux.W, M=self.N)
+            self.Xp = self.X[self.A]
+            self.reset_weights()
+        else:
+            self.A = np.arange(self.N)
+            self.Xp = self.X
+        self.X = self.fk.M(self.t, self.Xp)
+
+    def compute_summaries(self):
+        if self.t > 0:                                             # core.py:351-367
+            prec_log_mean_w = self.log_mean_w
+        self.log_mean_w = self.wgts.log_mean
+        if self.t == 0 or self.rs_flag:
+            self.loglt = self.log_mean_w
+        else:
+            self.loglt = self.log_mean_w - prec_log_mean_w
+        self.logLt += self.loglt
+        if self.verbose:
+            print(self)
+        if self.hist:
+            self.hist.save(self)
+        if self.summaries:
+            self.summaries.collect(self)
+
+    def _fused_after_step(self):
+        """Per-step host work the API semantics force (verbose / history /
+        user collectors read the particle system at every t)."""
+        s = self._summ()[0, -1]
+        self.rs_flag = bool(s[4])
+        self.loglt = float(s[2])
+        self.t -= 1               # collectors see smc.t = index of the step just done
+        try:
+            if self.verbose:
+                print(self)
+            if self.hist:
+                self.hist.save(self)
+            if self.summaries:
+                self.summaries.collect(self)
+        finally:
+            self.t += 1
+
+    def __next__(self):
+        """One step of a particle filter (core.py:369-383)."""
+        if self.fk.done(self):
+            raise StopIteration
+        if self._fused:
+            self.step_async(1)
+            self._fused_after_step()
+            return
+        if self.t == 0:
+            self.generate_particles()
+        else:
+            self.setup_auxiliary_weights()
+            self.resample_move()
+        self.reweight_particles()
+        self.compute_summaries()
+        self.t += 1
+
+    def next(self):
+        return self.__next__()
+
+    def __iter__(self):
+        return self
+
+    def _needs_per_step_host(self):
+        return self.verbose or bool(self.hist) or self._user_collectors
+
+    def run(self):
+        """Run until completion (core.py:391-409); sets ``cpu_time``."""
+        t0 = time.perf_counter()
+        if self._fused and not self._needs_per_step_host():
+            first = self.t
+            self.step_async(self.fk.T - self.t)
+            self.sync()
+            if self.summaries and self.t > first:      # default collectors, in one go
+                s = self._summ()[0]
+                self.summaries._extend_defaults(s[first:, 0], s[first:, 3], s[first:, 4] != 0)
+            if self._n:
+                s = self._summ()[0, -1]
+                self.rs_flag, self.loglt = bool(s[4]), float(s[2])
+        else:
+            for _ in self:
+                pass
+        self.cpu_time = time.perf_counter() - t0
+
+
+####################################################
+
+def multiSMC(nruns=10, nprocs=0, out_func=None, collect=None, **args):
+    """Run SMC algorithms for different combinations of parameters
+    (core.py:431-518, utils.py:216-269).
+
+    Same calling convention and output format as the reference: list-valued
+    (dict-valued) keyword arguments are expanded into their Cartesian product,
+    each combination is run ``nruns`` times with distinct seeds, and the result
+    is a list of dicts with keys ``run``, ``seed``, the varied arguments, and
+    ``output`` (the SMC object, or ``out_func(smc)``).  ``nprocs`` is accepted
+    for compatibility: the runs of one combination execute as islands of ONE
+    device-resident filter instead of a pool of processes.
+    """
+    import itertools
+
+    fixed, lists, dicts = {}, {}, {}
+    for k, v in args.items():
+        if isinstance(v, list):
+            lists[k] = v
+        elif isinstance(v, dict):
+            dicts[k] = v
+        else:
+            fixed[k] = v
+    keys = list(lists) + list(dicts)
+    choices = [list(enumerate(lists[k])) for k in lists] + \
+              [list(dicts[k].items()) for k in dicts]
+    combos = list(itertools.product(*choices)) if keys else [()]
+    bw = (2 ** 32 - 1) // max(1, nruns * len(combos))           # utils.py:189-202
+    seeds = np.arange(0, nruns * len(combos) * bw, bw) + np.random.randint(bw, size=nruns * len(combos))
+    results, si = [], 0
+    for combo in combos:
+        kw, label = dict(fixed), {}
+        for k, (lab, val) in zip(keys, combo):
+            kw[k] = val
+            label[k] = val if k in lists else lab
+        run_seeds = seeds[si:si + nruns]
+        si += nruns
+        fk = kw.get("fk")
+        batch = (fk is not None and hasattr(fk, "_device_model") and fk._device_model() is not None
+                 and fk._device_model().get("params") is not None and not collect
+                 and not kw.get("store_history") and not kw.get("verbose"))
+        if batch and out_func is not None:
+            # islands of one filter; Philox island word = run index, key = first seed
+            pf = SMC(collect="off", seed=int(run_seeds[0]), n_islands=nruns, **kw)
+            pf.run()
+            for r in range(nruns):
+                d = {"run": r, "seed": int(run_seeds[0])}
+                d.update(label)
+                d["output"] = out_func(_IslandView(pf, r))
+                results.append(d)
+        else:
+            for r in range(nruns):
+                pf = SMC(collect=collect, seed=int(run_seeds[r]), **kw)
+                pf.run()
+                d = {"run": r, "seed": int(run_seeds[r])}
+                d.update(label)
+                d["output"] = pf if out_func is None else out_func(pf)
+                results.append(d)
+    return results
+
+
+class _IslandView:
+    """What ``out_func`` sees for island r of a batched run: the SMC attributes
+    of that replica."""
+
+    def __init__(self, pf, r):
+        self._pf, self._r = pf, r
+        self.fk, self.N, self.t = pf.fk, pf.N, pf.t
+        self.cpu_time = pf.cpu_time
+        self.summaries = None
+
+    @property
+    def logLt(self):
+        return float(self._pf._summ()[self._r, -1, 3])
+
+    @property
+    def X(self):
+        return self._pf._get(_lib.FIELD_X, self._r)
+
+    @property
+    def A(self):
+        return self._pf._get(_lib.FIELD_A, self._r)
+
+    @property
+    def wgts(self):
+        return _DeviceWeights(self._pf, self._r)
+
+    @property
+    def W(self):
+        return self.wgts.W
+
+    @property
+    def ESSs(self):
+        return self._pf._summ()[self._r, :, 0]
+
+    @property
+    def logLts(self):
+        return self._pf._summ()[self._r, :, 3]

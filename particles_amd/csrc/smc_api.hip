@@ -1,0 +1,196 @@
+// smc_api.hip -- context, memory and error plumbing of libsmc_hip.so
+#include <cstdarg>
+
+#include "smc_internal.h"
+
+static thread_local char g_err[512] = "";
+
+void smc_set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+extern "C" {
+
+const char* smc_last_error(void) { return g_err; }
+
+const char* smc_version(void)
+{
+#ifdef SMC_EMULATE
+    return "smc_hip 0.1 (CPU EMULATOR - test build, not the product)";
+#else
+    return "smc_hip 0.1 (gfx950)";
+#endif
+}
+
+int smc_device_count(int* n_out)
+{
+    SMC_REQUIRE(n_out, "null output");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *n_out = n;
+    return SMC_OK;
+}
+
+int smc_ctx_create(int device, uint64_t seed, smc_ctx** out)
+{
+    SMC_REQUIRE(out, "null output");
+    int n = 0;
+    SMC_HIP_CHECK(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) {
+        smc_set_error("smc_ctx_create: device %d out of range (%d visible)", device, n);
+        return SMC_ERR_INVALID;
+    }
+    SMC_HIP_CHECK(hipSetDevice(device));
+    smc_ctx* c = new smc_ctx();
+    c->device = device;
+    c->seed = seed;
+    c->scratch = nullptr;
+    c->scratch_bytes = 0;
+    hipDeviceProp_t prop;
+    SMC_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    c->n_cu = prop.multiProcessorCount;
+    SMC_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    SMC_HIP_CHECK(hipEventCreate(&c->ev0));
+    SMC_HIP_CHECK(hipEventCreate(&c->ev1));
+    *out = c;
+    return SMC_OK;
+}
+
+int smc_ctx_destroy(smc_ctx* ctx)
+{
+    if (!ctx) return SMC_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    (void)hipEventDestroy(ctx->ev0);
+    (void)hipEventDestroy(ctx->ev1);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return SMC_OK;
+}
+
+int smc_ctx_sync(smc_ctx* ctx)
+{
+    SMC_REQUIRE(ctx, "null context");
+    SMC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return SMC_OK;
+}
+
+int smc_ctx_seed(smc_ctx* ctx, uint64_t seed)
+{
+    SMC_REQUIRE(ctx, "null context");
+    ctx->seed = seed;
+    return SMC_OK;
+}
+
+int smc_ctx_device_info(smc_ctx* ctx, char* name_host, size_t name_len, int* n_cu,
+                        uint64_t* hbm_bytes)
+{
+    SMC_REQUIRE(ctx, "null context");
+    hipDeviceProp_t prop;
+    SMC_HIP_CHECK(hipGetDeviceProperties(&prop, ctx->device));
+    if (name_host && name_len) snprintf(name_host, name_len, "%s", prop.name);
+    if (n_cu) *n_cu = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (uint64_t)prop.totalGlobalMem;
+    return SMC_OK;
+}
+
+int smc_malloc(smc_ctx* ctx, size_t bytes, void** dptr_out)
+{
+    SMC_REQUIRE(ctx && dptr_out, "null argument");
+    SMC_HIP_CHECK(hipSetDevice(ctx->device));
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+    if (e != hipSuccess) {
+        smc_set_error("smc_malloc: %zu bytes: %s", bytes, hipGetErrorString(e));
+        return SMC_ERR_NOMEM;
+    }
+    *dptr_out = p;
+    return SMC_OK;
+}
+
+int smc_free(smc_ctx* ctx, void* dptr)
+{
+    SMC_REQUIRE(ctx, "null context");
+    if (!dptr) return SMC_OK;
+    SMC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    SMC_HIP_CHECK(hipFree(dptr));
+    return SMC_OK;
+}
+
+int smc_memcpy_h2d(smc_ctx* ctx, void* dst, const void* src_host, size_t bytes)
+{
+    SMC_REQUIRE(ctx && (bytes == 0 || (dst && src_host)), "null argument");
+    if (!bytes) return SMC_OK;
+    SMC_HIP_CHECK(hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    // pageable host memory: the source may be reused as soon as we return
+    SMC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return SMC_OK;
+}
+
+int smc_memcpy_d2h(smc_ctx* ctx, void* dst_host, const void* src, size_t bytes)
+{
+    SMC_REQUIRE(ctx && (bytes == 0 || (dst_host && src)), "null argument");
+    if (!bytes) return SMC_OK;
+    SMC_HIP_CHECK(hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SMC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return SMC_OK;
+}
+
+int smc_memcpy_d2d(smc_ctx* ctx, void* dst, const void* src, size_t bytes)
+{
+    SMC_REQUIRE(ctx && (bytes == 0 || (dst && src)), "null argument");
+    if (!bytes) return SMC_OK;
+    SMC_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return SMC_OK;
+}
+
+int smc_memset(smc_ctx* ctx, void* dst, int byte, size_t bytes)
+{
+    SMC_REQUIRE(ctx && (bytes == 0 || dst), "null argument");
+    if (!bytes) return SMC_OK;
+    SMC_HIP_CHECK(hipMemsetAsync(dst, byte, bytes, ctx->stream));
+    return SMC_OK;
+}
+
+int smc_timer_start(smc_ctx* ctx)
+{
+    SMC_REQUIRE(ctx, "null context");
+    SMC_HIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream));
+    return SMC_OK;
+}
+
+int smc_timer_stop(smc_ctx* ctx, float* ms_out)
+{
+    SMC_REQUIRE(ctx && ms_out, "null argument");
+    SMC_HIP_CHECK(hipEventRecord(ctx->ev1, ctx->stream));
+    SMC_HIP_CHECK(hipEventSynchronize(ctx->ev1));
+    SMC_HIP_CHECK(hipEventElapsedTime(ms_out, ctx->ev0, ctx->ev1));
+    return SMC_OK;
+}
+
+}  // extern "C"
+
+int smc_scratch(smc_ctx* ctx, size_t bytes, void** out)
+{
+    if (bytes > ctx->scratch_bytes) {
+        SMC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (ctx->scratch) SMC_HIP_CHECK(hipFree(ctx->scratch));
+        ctx->scratch = nullptr;
+        ctx->scratch_bytes = 0;
+        size_t want = smc_align_up(bytes + bytes / 4, 1 << 16);
+        hipError_t e = hipMalloc(&ctx->scratch, want);
+        if (e != hipSuccess) {
+            smc_set_error("scratch allocation of %zu bytes failed: %s", want,
+                          hipGetErrorString(e));
+            return SMC_ERR_NOMEM;
+        }
+        ctx->scratch_bytes = want;
+    }
+    *out = ctx->scratch;
+    return SMC_OK;
+}

@@ -1,0 +1,154 @@
+// smc_comm.hip -- the only collective of the path: gathering the per-island
+// log-evidence estimates of independent runs / SMC^2 islands that were sharded
+// across the GPUs of a node (particles/core.py:431 multiSMC returns the list of
+// per-run outputs; utils.py:178-186 collects them from the loky workers).
+//
+// One process per GPU; the communicator is RCCL over xGMI.  The payload is
+// n_islands x 8 bytes per rank, i.e. latency-bound: one ncclAllGather per run.
+// RCCL is dlopen'ed on first use so that single-GPU users never load it.
+#include <dlfcn.h>
+
+#include "smc_device.h"
+#include "smc_internal.h"
+
+struct smc_comm {
+    smc_ctx* ctx;
+    void* nccl;      // ncclComm_t
+    int nranks, rank;
+};
+
+#ifndef SMC_EMULATE
+namespace {
+typedef int ncclResult_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef ncclResult_t (*fn_GetUniqueId)(ncclUniqueId*);
+typedef ncclResult_t (*fn_CommInitRank)(void**, int, ncclUniqueId, int);
+typedef ncclResult_t (*fn_AllGather)(const void*, void*, size_t, int, void*, hipStream_t);
+typedef ncclResult_t (*fn_CommDestroy)(void*);
+typedef const char* (*fn_GetErrorString)(ncclResult_t);
+const int kNcclFloat64 = 8;   // ncclDouble
+
+struct Rccl {
+    void* h = nullptr;
+    fn_GetUniqueId GetUniqueId = nullptr;
+    fn_CommInitRank CommInitRank = nullptr;
+    fn_AllGather AllGather = nullptr;
+    fn_CommDestroy CommDestroy = nullptr;
+    fn_GetErrorString GetErrorString = nullptr;
+} g_rccl;
+
+int rccl_load()
+{
+    if (g_rccl.h) return SMC_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* n : names)
+        if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!h) {
+        smc_set_error("RCCL not found: %s", dlerror());
+        return SMC_ERR_HIP;
+    }
+    g_rccl.GetUniqueId = (fn_GetUniqueId)dlsym(h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (fn_CommInitRank)dlsym(h, "ncclCommInitRank");
+    g_rccl.AllGather = (fn_AllGather)dlsym(h, "ncclAllGather");
+    g_rccl.CommDestroy = (fn_CommDestroy)dlsym(h, "ncclCommDestroy");
+    g_rccl.GetErrorString = (fn_GetErrorString)dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy) {
+        smc_set_error("RCCL is missing expected symbols");
+        dlclose(h);
+        return SMC_ERR_HIP;
+    }
+    g_rccl.h = h;
+    return SMC_OK;
+}
+
+int rccl_fail(const char* what, ncclResult_t r)
+{
+    smc_set_error("%s failed: %s", what,
+                  g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "RCCL error");
+    return SMC_ERR_HIP;
+}
+}  // namespace
+#endif
+
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_copy_f64(const double* src, i64 n, double* dst)
+{
+    const i64 i = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+extern "C" {
+
+int smc_comm_unique_id(char* id_host)
+{
+    SMC_REQUIRE(id_host, "null argument");
+#ifdef SMC_EMULATE
+    memset(id_host, 0, SMC_COMM_ID_BYTES);
+    return SMC_OK;
+#else
+    int rc = rccl_load();
+    if (rc) return rc;
+    ncclUniqueId id;
+    ncclResult_t r = g_rccl.GetUniqueId(&id);
+    if (r != 0) return rccl_fail("ncclGetUniqueId", r);
+    memcpy(id_host, id.internal, SMC_COMM_ID_BYTES);
+    return SMC_OK;
+#endif
+}
+
+int smc_comm_create(smc_ctx* ctx, int nranks, int rank, const char* id_host, smc_comm** out)
+{
+    SMC_REQUIRE(ctx && id_host && out, "null argument");
+    SMC_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank / nranks");
+    smc_comm* c = new smc_comm();
+    c->ctx = ctx;
+    c->nccl = nullptr;
+    c->nranks = nranks;
+    c->rank = rank;
+#ifdef SMC_EMULATE
+    if (nranks != 1) {
+        delete c;
+        smc_set_error("the emulator build has no RCCL (nranks must be 1)");
+        return SMC_ERR_INVALID;
+    }
+#else
+    int rc = rccl_load();
+    if (rc) { delete c; return rc; }
+    SMC_HIP_CHECK(hipSetDevice(ctx->device));
+    ncclUniqueId id;
+    memcpy(id.internal, id_host, SMC_COMM_ID_BYTES);
+    ncclResult_t r = g_rccl.CommInitRank(&c->nccl, nranks, id, rank);
+    if (r != 0) { delete c; return rccl_fail("ncclCommInitRank", r); }
+#endif
+    *out = c;
+    return SMC_OK;
+}
+
+int smc_comm_allgather_f64(smc_comm* c, const double* send, int64_t count, double* recv)
+{
+    SMC_REQUIRE(c && send && recv, "null argument");
+    SMC_REQUIRE(count > 0, "count must be positive");
+    hipStream_t st = c->ctx->stream;
+#ifdef SMC_EMULATE
+    SMC_LAUNCH(k_copy_f64, dim3((unsigned)((count + SMC_BLOCK - 1) / SMC_BLOCK)), dim3(SMC_BLOCK),
+               st, send, (i64)count, recv);
+#else
+    ncclResult_t r = g_rccl.AllGather(send, recv, (size_t)count, kNcclFloat64, c->nccl, st);
+    if (r != 0) return rccl_fail("ncclAllGather", r);
+#endif
+    SMC_HIP_CHECK(hipStreamSynchronize(st));
+    return SMC_OK;
+}
+
+int smc_comm_destroy(smc_comm* c)
+{
+    if (!c) return SMC_OK;
+#ifndef SMC_EMULATE
+    if (c->nccl) g_rccl.CommDestroy(c->nccl);
+#endif
+    delete c;
+    return SMC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,258 @@
+// smc_device.h -- device-side building blocks shared by the smc kernels.
+//
+// Workgroups are 256 threads = 4 wave64; all cross-lane code assumes 64 lanes.
+// Compiled with -ffp-contract=off: every expression that mirrors a line of the
+// reference is evaluated with the reference's roundings (no silent FMA).
+#pragma once
+#include "smc_platform.h"
+
+#include <cmath>
+
+#define SMC_BLOCK 256
+#define SMC_NWAVE (SMC_BLOCK / 64)
+#define SMC_C_NORM 0.9189385332046727   /* scipy _norm_pdf_logC (distributions.py:273) */
+#define SMC_HALFLOG2PI 0.91893853320467267 /* 0.5*log(2*pi) (distributions.py:212) */
+#define SMC_Q62 4611686018427387904.0   /* 2^62 */
+
+#define SMC_STREAM_NORMAL 0u
+#define SMC_STREAM_RESAMPLE 1u
+#define SMC_STREAM_SPACINGS 2u
+
+__device__ __forceinline__ int smc_lane() { return (int)(threadIdx.x & 63u); }
+__device__ __forceinline__ int smc_wave() { return (int)(threadIdx.x >> 6); }
+
+// ---------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11).  Counter layout used everywhere:
+//   ctr = (index, t, island, stream), key = (seed lo32, seed hi32)
+// One call yields two 64-bit words.  Restated in oracle/smc_oracle.py and
+// oracle/oracle.c; tests check the integer stream bit-for-bit.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void smc_philox(u32 c0, u32 c1, u32 c2, u32 c3, u64 seed,
+                                           u64& x01, u64& x23)
+{
+    u32 k0 = (u32)seed, k1 = (u32)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        if (r > 0) { k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+        const u32 hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const u32 hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const u32 n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    }
+    x01 = ((u64)c1 << 32) | c0;
+    x23 = ((u64)c3 << 32) | c2;
+}
+
+// (0,1): 52 random bits + 1/2 ulp, exact in fp64, never 0 or 1
+__device__ __forceinline__ double smc_u01_open(u64 x)
+{
+    return ((double)(x >> 12) + 0.5) * 0x1.0p-52;
+}
+// [0,1): numpy's rand() convention, 53 random bits
+__device__ __forceinline__ double smc_u01_halfopen(u64 x)
+{
+    return (double)(x >> 11) * 0x1.0p-53;
+}
+
+// Two standard normals from one Philox call (Box-Muller):
+//   r = sqrt(-2 log u1);  (z_even, z_odd) = r * (cos, sin)(2 pi u2)
+__device__ __forceinline__ void smc_normal_pair(u64 seed, u32 pair, u32 t, u32 island,
+                                                u32 stream, double& z0, double& z1)
+{
+    u64 a, b;
+    smc_philox(pair, t, island, stream, seed, a, b);
+    const double r = sqrt(-2.0 * log(smc_u01_open(a)));
+    double sn, cs;
+    sincospi(2.0 * smc_u01_open(b), &sn, &cs);
+    z0 = r * cs;
+    z1 = r * sn;
+}
+
+// ---------------------------------------------------------------------------
+// Q62 fixed-point CDF contract (oracle/smc_oracle.py "Q62"):
+//   q = rint(W 2^62), T = ceil(su 2^62); both exact (power-of-two scaling).
+// ---------------------------------------------------------------------------
+__host__ __device__ __forceinline__ u64 smc_q62_w(double w)
+{
+    return (w > 0.0) ? (u64)rint(fmin(w, 2.0) * SMC_Q62) : 0ull;
+}
+__host__ __device__ __forceinline__ u64 smc_q62_t(double su)
+{
+    return (su > 0.0) ? (u64)ceil(fmin(su, 2.0) * SMC_Q62) : 0ull;
+}
+
+// ---------------------------------------------------------------------------
+// wave / workgroup collectives (256 threads)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ u64 smc_shfl_up_u64(u64 v, unsigned d)
+{
+    u32 lo = (u32)v, hi = (u32)(v >> 32);
+    lo = __shfl_up(lo, d);
+    hi = __shfl_up(hi, d);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 smc_shfl_xor_u64(u64 v, int m)
+{
+    u32 lo = (u32)v, hi = (u32)(v >> 32);
+    lo = __shfl_xor(lo, m);
+    hi = __shfl_xor(hi, m);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ double smc_shfl_xor_f64(double v, int m)
+{
+    return __longlong_as_double((long long)smc_shfl_xor_u64((u64)__double_as_longlong(v), m));
+}
+
+__device__ __forceinline__ double smc_wave_max(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmax(v, smc_shfl_xor_f64(v, m));
+    return v;
+}
+// butterfly sum: every lane ends with the same value, fixed association order
+__device__ __forceinline__ double smc_wave_sum(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = v + smc_shfl_xor_f64(v, m);
+    return v;
+}
+__device__ __forceinline__ u64 smc_wave_sum_u64(u64 v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = v + smc_shfl_xor_u64(v, m);
+    return v;
+}
+
+// All four collectives below must be called by every thread of the workgroup;
+// `sm` is LDS scratch of at least SMC_NWAVE elements, reusable after return.
+__device__ __forceinline__ double smc_block_max(double v, double* sm)
+{
+    v = smc_wave_max(v);
+    __syncthreads();
+    if (smc_lane() == 0) sm[smc_wave()] = v;
+    __syncthreads();
+    double r = sm[0];
+#pragma unroll
+    for (int w = 1; w < SMC_NWAVE; ++w) r = fmax(r, sm[w]);
+    return r;
+}
+__device__ __forceinline__ double smc_block_sum(double v, double* sm)
+{
+    v = smc_wave_sum(v);
+    __syncthreads();
+    if (smc_lane() == 0) sm[smc_wave()] = v;
+    __syncthreads();
+    double r = sm[0];
+#pragma unroll
+    for (int w = 1; w < SMC_NWAVE; ++w) r = r + sm[w];
+    return r;
+}
+__device__ __forceinline__ u64 smc_block_sum_u64(u64 v, u64* sm)
+{
+    v = smc_wave_sum_u64(v);
+    __syncthreads();
+    if (smc_lane() == 0) sm[smc_wave()] = v;
+    __syncthreads();
+    u64 r = sm[0];
+#pragma unroll
+    for (int w = 1; w < SMC_NWAVE; ++w) r = r + sm[w];
+    return r;
+}
+// exclusive prefix over the workgroup's threads (thread order) + total
+__device__ __forceinline__ u64 smc_block_exscan_u64(u64 v, u64* sm, u64& total)
+{
+    u64 inc = v;
+#pragma unroll
+    for (unsigned d = 1; d < 64; d <<= 1) {
+        const u64 o = smc_shfl_up_u64(inc, d);
+        if (smc_lane() >= (int)d) inc += o;
+    }
+    __syncthreads();
+    if (smc_lane() == 63) sm[smc_wave()] = inc;
+    __syncthreads();
+    u64 base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < SMC_NWAVE; ++w) {
+        if (w < smc_wave()) base += sm[w];
+        tot += sm[w];
+    }
+    total = tot;
+    return base + inc - v;
+}
+
+// ---------------------------------------------------------------------------
+// log-sum-exp accumulators: (m, s, ss) = (max, sum exp(lw-m), sum exp(2(lw-m)))
+// ---------------------------------------------------------------------------
+struct SmcLse {
+    double m, s, ss;
+};
+__device__ __forceinline__ SmcLse smc_lse_empty()
+{
+    SmcLse a;
+    a.m = -INFINITY; a.s = 0.0; a.ss = 0.0;
+    return a;
+}
+// one exp per element (online form)
+__device__ __forceinline__ void smc_lse_push(SmcLse& a, double lw)
+{
+    if (!(lw > -INFINITY)) return;             // -inf (and NaN, sanitised earlier) weigh 0
+    const double d = lw - a.m;                 // +inf on the first element
+    const double e = exp(-fabs(d));
+    if (d > 0.0) {
+        a.s = a.s * e + 1.0;
+        a.ss = a.ss * (e * e) + 1.0;
+        a.m = lw;
+    } else {
+        a.s += e;
+        a.ss += e * e;
+    }
+}
+// Combine the per-thread accumulators of a workgroup: every thread returns the
+// workgroup's (m, s, ss).  Order of additions is fixed (butterfly + wave order).
+__device__ __forceinline__ SmcLse smc_lse_block(SmcLse a, double* sm)
+{
+    const double m = smc_block_max(a.m, sm);
+    double sc = 0.0;
+    if (a.m > -INFINITY) sc = exp(a.m - m);
+    SmcLse r;
+    r.m = m;
+    r.s = smc_block_sum(a.s * sc, sm);
+    r.ss = smc_block_sum(a.ss * (sc * sc), sm);
+    return r;
+}
+// Reduce `n` per-workgroup partials (SoA: pm, ps, pss) to the global (m,s,ss).
+// Called by every thread of a workgroup; all workgroups obtain identical bits.
+__device__ __forceinline__ SmcLse smc_lse_reduce_partials(const double* pm, const double* ps,
+                                                          const double* pss, int n, double* sm)
+{
+    double m = -INFINITY;
+    for (int i = (int)threadIdx.x; i < n; i += SMC_BLOCK) m = fmax(m, pm[i]);
+    m = smc_block_max(m, sm);
+    double s = 0.0, ss = 0.0;
+    for (int i = (int)threadIdx.x; i < n; i += SMC_BLOCK) {
+        const double mi = pm[i];
+        if (mi > -INFINITY) {
+            const double sc = exp(mi - m);
+            s += ps[i] * sc;
+            ss += pss[i] * (sc * sc);
+        }
+    }
+    SmcLse r;
+    r.m = m;
+    r.s = smc_block_sum(s, sm);
+    r.ss = smc_block_sum(ss, sm);
+    return r;
+}
+
+// smallest index i in [0, n) with T <= c[i]; n if none.  `c` non-decreasing.
+__device__ __forceinline__ int smc_lower_bound_u64(const u64* c, int n, u64 T)
+{
+    int lo = 0, len = n;
+    while (len > 0) {
+        const int half = len >> 1;
+        const bool less = c[lo + half] < T;
+        lo = less ? lo + half + 1 : lo;
+        len = less ? len - half - 1 : half;
+    }
+    return lo;
+}

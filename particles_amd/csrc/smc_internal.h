@@ -1,0 +1,46 @@
+// smc_internal.h -- host-side internals of libsmc_hip (context, errors, scratch)
+#pragma once
+#include "smc_platform.h"
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/smc_hip.h"
+
+struct smc_ctx {
+    int device;
+    u64 seed;
+    hipStream_t stream;
+    void* scratch;          // grow-only device scratch for the stand-alone ops
+    size_t scratch_bytes;
+    hipEvent_t ev0, ev1;
+    int n_cu;
+};
+
+void smc_set_error(const char* fmt, ...);
+
+#define SMC_HIP_CHECK(expr)                                                        \
+    do {                                                                           \
+        hipError_t e_ = (expr);                                                    \
+        if (e_ != hipSuccess) {                                                    \
+            smc_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),   \
+                          __FILE__, __LINE__);                                     \
+            return SMC_ERR_HIP;                                                    \
+        }                                                                          \
+    } while (0)
+
+#define SMC_REQUIRE(cond, msg)                                 \
+    do {                                                       \
+        if (!(cond)) {                                         \
+            smc_set_error("%s: %s", __func__, msg);            \
+            return SMC_ERR_INVALID;                            \
+        }                                                      \
+    } while (0)
+
+#define SMC_LAUNCH_CHECK() SMC_HIP_CHECK(hipGetLastError())
+
+// device scratch of at least `bytes` (256-byte aligned); contents undefined
+int smc_scratch(smc_ctx* ctx, size_t bytes, void** out);
+
+static inline size_t smc_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

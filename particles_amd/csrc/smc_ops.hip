@@ -1,0 +1,679 @@
+// smc_ops.hip -- stand-alone device operators behind the reference's L0 API:
+// Weights / log-sum-exp (resampling.py:138-338), inverse_cdf and the three
+// resampling schemes (resampling.py:477-610), the ancestor gather
+// (core.py:332) and Normal / MvNormal rvs + logpdf (distributions.py:262-285,
+// 888-969).  The fused step loop lives in smc_filter.hip and reuses the same
+// device code (smc_device.h, smc_resample.h).
+#include <vector>
+
+#include "smc_internal.h"
+#include "smc_resample.h"
+
+#define OPS_IPT 4
+#define OPS_TILE (SMC_BLOCK * OPS_IPT)
+#define LSE_CHUNK (SMC_BLOCK * 8)
+
+// ===========================================================================
+// a-4  Weights.__init__  (resampling.py:217-226)
+// ===========================================================================
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_lse_partials(double* lw, i64 N, int fix_nan, double* pm, double* ps, double* pss)
+{
+    __shared__ double sm[SMC_NWAVE];
+    const i64 base = (i64)blockIdx.x * LSE_CHUNK;
+    SmcLse acc = smc_lse_empty();
+    for (int k = 0; k < LSE_CHUNK / SMC_BLOCK; ++k) {
+        const i64 i = base + (i64)k * SMC_BLOCK + threadIdx.x;
+        if (i < N) {
+            double v = lw[i];
+            if (v != v) {                       // resampling.py:220
+                v = -INFINITY;
+                if (fix_nan) lw[i] = v;
+            }
+            smc_lse_push(acc, v);
+        }
+    }
+    const SmcLse r = smc_lse_block(acc, sm);
+    if (threadIdx.x == 0) {
+        pm[blockIdx.x] = r.m;
+        ps[blockIdx.x] = r.s;
+        pss[blockIdx.x] = r.ss;
+    }
+}
+
+// scal[0..4) = log_mean, ESS, m, s
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_lse_finalize(const double* pm, const double* ps, const double* pss, int nparts, i64 N,
+               double* scal)
+{
+    __shared__ double sm[SMC_NWAVE];
+    const SmcLse r = smc_lse_reduce_partials(pm, ps, pss, nparts, sm);
+    if (threadIdx.x == 0) {
+        double log_mean, ess, s = r.s;
+        if (!(r.m > -INFINITY) || !(r.m < INFINITY)) {
+            // all weights -inf (or a +inf): the reference yields NaN throughout
+            log_mean = ess = s = NAN;
+        } else {
+            log_mean = r.m + log(r.s / (double)N);        // resampling.py:224
+            ess = (r.s * r.s) / r.ss;                     // == 1/sum(W^2), :226
+        }
+        scal[0] = log_mean;
+        scal[1] = ess;
+        scal[2] = r.m;
+        scal[3] = s;
+    }
+}
+
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_lse_write_W(const double* lw, i64 N, const double* scal, double* W)
+{
+    const double m = scal[2], s = scal[3];
+    const i64 i = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;
+    if (i < N) {
+        double v = lw[i];
+        if (v != v) v = -INFINITY;
+        W[i] = exp(v - m) / s;                            // resampling.py:222,225
+    }
+}
+
+static int lse_launch(smc_ctx* ctx, double* lw, i64 N, int fix_nan, double** scal_out)
+{
+    const int nparts = (int)((N + LSE_CHUNK - 1) / LSE_CHUNK);
+    void* scr;
+    int rc = smc_scratch(ctx, (size_t)(3 * nparts + 8) * sizeof(double), &scr);
+    if (rc) return rc;
+    double* pm = (double*)scr;
+    double* ps = pm + nparts;
+    double* pss = ps + nparts;
+    double* scal = pss + nparts;
+    SMC_LAUNCH(k_lse_partials, dim3(nparts), dim3(SMC_BLOCK), ctx->stream, lw, N, fix_nan, pm, ps,
+               pss);
+    SMC_LAUNCH(k_lse_finalize, dim3(1), dim3(SMC_BLOCK), ctx->stream, (const double*)pm,
+               (const double*)ps, (const double*)pss, nparts, N, scal);
+    SMC_LAUNCH_CHECK();
+    *scal_out = scal;
+    return SMC_OK;
+}
+
+extern "C" int smc_lse_normalise(smc_ctx* ctx, double* lw, int64_t N, double* W,
+                                 double* out4_host)
+{
+    SMC_REQUIRE(ctx && lw && out4_host, "null argument");
+    SMC_REQUIRE(N > 0, "N must be positive");
+    double* scal;
+    int rc = lse_launch(ctx, lw, N, 1, &scal);
+    if (rc) return rc;
+    if (W) {
+        SMC_LAUNCH(k_lse_write_W, dim3((unsigned)((N + SMC_BLOCK - 1) / SMC_BLOCK)),
+                   dim3(SMC_BLOCK), ctx->stream, (const double*)lw, (i64)N, (const double*)scal, W);
+        SMC_LAUNCH_CHECK();
+    }
+    double h[4];
+    SMC_HIP_CHECK(hipMemcpyAsync(h, scal, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    SMC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 4; ++i) out4_host[i] = h[i];
+    return SMC_OK;
+}
+
+// ===========================================================================
+// weighted moments: log_mean_exp(v, W) (:291-317), wmean_and_var (:320-338)
+// ===========================================================================
+// out[0] = sum_i W_i f(v_i), out[1] = sum_i W_i f(v_i)^2 per column; one
+// workgroup per column strip, deterministic tree.
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_wsum_partials(const double* W, const double* X, i64 N, i64 d, int mode, double shift,
+                double* part /* (nblk, d, 3) */)
+{
+    __shared__ double sm[SMC_NWAVE];
+    const i64 base = (i64)blockIdx.x * LSE_CHUNK;
+    for (i64 c = 0; c < d; ++c) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        for (int k = 0; k < LSE_CHUNK / SMC_BLOCK; ++k) {
+            const i64 i = base + (i64)k * SMC_BLOCK + threadIdx.x;
+            if (i < N) {
+                const double w = W[i];
+                double x = X[i * d + c];
+                if (mode == 1) x = exp(x - shift);
+                a0 += w;
+                a1 += w * x;
+                a2 += w * (x * x);
+            }
+        }
+        a0 = smc_block_sum(a0, sm);
+        a1 = smc_block_sum(a1, sm);
+        a2 = smc_block_sum(a2, sm);
+        if (threadIdx.x == 0) {
+            double* p = part + ((i64)blockIdx.x * d + c) * 3;
+            p[0] = a0; p[1] = a1; p[2] = a2;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_max_partials(const double* v, i64 N, double* pm)
+{
+    __shared__ double sm[SMC_NWAVE];
+    const i64 base = (i64)blockIdx.x * LSE_CHUNK;
+    double m = -INFINITY;
+    for (int k = 0; k < LSE_CHUNK / SMC_BLOCK; ++k) {
+        const i64 i = base + (i64)k * SMC_BLOCK + threadIdx.x;
+        if (i < N) m = fmax(m, v[i]);
+    }
+    m = smc_block_max(m, sm);
+    if (threadIdx.x == 0) pm[blockIdx.x] = m;
+}
+
+static int wsum(smc_ctx* ctx, const double* W, const double* X, i64 N, i64 d, int mode,
+                double shift, std::vector<double>& tot)
+{
+    const int nblk = (int)((N + LSE_CHUNK - 1) / LSE_CHUNK);
+    void* scr;
+    int rc = smc_scratch(ctx, (size_t)nblk * d * 3 * sizeof(double), &scr);
+    if (rc) return rc;
+    SMC_LAUNCH(k_wsum_partials, dim3(nblk), dim3(SMC_BLOCK), ctx->stream, W, X, N, d, mode, shift,
+               (double*)scr);
+    SMC_LAUNCH_CHECK();
+    std::vector<double> h((size_t)nblk * d * 3);
+    SMC_HIP_CHECK(hipMemcpyAsync(h.data(), scr, h.size() * sizeof(double), hipMemcpyDeviceToHost,
+                                 ctx->stream));
+    SMC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    tot.assign((size_t)d * 3, 0.0);
+    for (int b = 0; b < nblk; ++b)
+        for (i64 c = 0; c < d * 3; ++c) tot[c] += h[(size_t)b * d * 3 + c];
+    return SMC_OK;
+}
+
+extern "C" int smc_wmean_var(smc_ctx* ctx, const double* W, const double* X, int64_t N, int64_t d,
+                             double* out_host)
+{
+    SMC_REQUIRE(ctx && W && X && out_host, "null argument");
+    SMC_REQUIRE(N > 0 && d > 0, "bad shape");
+    std::vector<double> t;
+    int rc = wsum(ctx, W, X, N, d, 0, 0.0, t);
+    if (rc) return rc;
+    for (i64 c = 0; c < d; ++c) {
+        // np.average(x, weights=W) = sum(W x)/sum(W)   (resampling.py:335-337)
+        const double m = t[c * 3 + 1] / t[c * 3], m2 = t[c * 3 + 2] / t[c * 3];
+        out_host[c] = m;
+        out_host[d + c] = m2 - m * m;
+    }
+    return SMC_OK;
+}
+
+extern "C" int smc_log_wmean_exp(smc_ctx* ctx, const double* v, const double* W, int64_t N,
+                                 double* out_host)
+{
+    SMC_REQUIRE(ctx && v && W && out_host, "null argument");
+    SMC_REQUIRE(N > 0, "N must be positive");
+    const int nblk = (int)((N + LSE_CHUNK - 1) / LSE_CHUNK);
+    void* scr;
+    int rc = smc_scratch(ctx, (size_t)nblk * sizeof(double), &scr);
+    if (rc) return rc;
+    SMC_LAUNCH(k_max_partials, dim3(nblk), dim3(SMC_BLOCK), ctx->stream, v, (i64)N, (double*)scr);
+    SMC_LAUNCH_CHECK();
+    std::vector<double> pm(nblk);
+    SMC_HIP_CHECK(hipMemcpyAsync(pm.data(), scr, nblk * sizeof(double), hipMemcpyDeviceToHost,
+                                 ctx->stream));
+    SMC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    double m = -INFINITY;
+    for (double x : pm) m = x > m ? x : m;
+    std::vector<double> t;
+    rc = wsum(ctx, W, v, N, 1, 1, m, t);
+    if (rc) return rc;
+    *out_host = m + log(t[1] / t[0]);                     // resampling.py:312-317
+    return SMC_OK;
+}
+
+// ===========================================================================
+// a-5 / a-6  inverse_cdf and the resampling schemes
+// ===========================================================================
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_q62_tile_sums(const double* W, i64 N, u64* Q)
+{
+    __shared__ u64 sm[SMC_NWAVE];
+    const i64 j0 = (i64)blockIdx.x * OPS_TILE + (i64)threadIdx.x * OPS_IPT;
+    u64 t = 0;
+#pragma unroll
+    for (int i = 0; i < OPS_IPT; ++i)
+        if (j0 + i < N) t += smc_q62_w(W[j0 + i]);
+    t = smc_block_sum_u64(t, sm);
+    if (threadIdx.x == 0) Q[blockIdx.x] = t;
+}
+
+__device__ __forceinline__ SmcSu smc_su_prepare(SmcSu su)
+{
+    if (su.scheme == SMC_SYSTEMATIC_) {
+        if (su.u) {
+            su.u_sys = su.u[0];
+        } else {
+            u64 a, b;
+            smc_philox(0u, su.t, su.island, SMC_STREAM_RESAMPLE, su.seed, a, b);
+            su.u_sys = smc_u01_halfopen(a);
+        }
+    }
+    return su;
+}
+
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_resample_tiles(const double* W, i64 N, SmcSu su_in, const u64* Q, int ntiles, i64* A)
+{
+    __shared__ u64 sC[OPS_TILE];
+    __shared__ u64 sm[SMC_NWAVE];
+    __shared__ i64 sn[2];
+    const SmcSu su = smc_su_prepare(su_in);
+    const int b = (int)blockIdx.x;
+    const i64 j0 = (i64)b * OPS_TILE;
+    u64 wq[OPS_IPT];
+#pragma unroll
+    for (int i = 0; i < OPS_IPT; ++i) {
+        const i64 j = j0 + (i64)threadIdx.x * OPS_IPT + i;
+        wq[i] = (j < N) ? smc_q62_w(W[j]) : 0ull;
+    }
+    u64 total;
+    const u64 pre = smc_tile_cdf<OPS_IPT>(wq, Q, b, sC, sm, total);
+    i64 n_lo, n_hi;
+    smc_tile_outputs(su, b, ntiles, pre, total, sn, n_lo, n_hi);
+    const int nvalid = (int)((N - j0 < OPS_TILE) ? (N - j0) : OPS_TILE);
+    for (i64 p = (n_lo >> 1) + threadIdx.x; 2 * p < n_hi; p += SMC_BLOCK) {
+        double s0, s1;
+        smc_su_pair(su, p, s0, s1);
+        const i64 n0 = 2 * p, n1 = n0 + 1;
+        if (n0 >= n_lo && n0 < n_hi) {
+            int jl = smc_lower_bound_u64(sC, OPS_TILE, smc_q62_t(s0));
+            jl = jl < nvalid ? jl : nvalid - 1;
+            A[n0] = j0 + jl;
+        }
+        if (n1 >= n_lo && n1 < n_hi) {
+            int jl = smc_lower_bound_u64(sC, OPS_TILE, smc_q62_t(s1));
+            jl = jl < nvalid ? jl : nvalid - 1;
+            A[n1] = j0 + jl;
+        }
+    }
+}
+
+static int resample_launch(smc_ctx* ctx, const double* W, i64 N, SmcSu su, i64* A)
+{
+    const int ntiles = (int)((N + OPS_TILE - 1) / OPS_TILE);
+    void* scr;
+    int rc = smc_scratch(ctx, (size_t)ntiles * sizeof(u64), &scr);
+    if (rc) return rc;
+    SMC_LAUNCH(k_q62_tile_sums, dim3(ntiles), dim3(SMC_BLOCK), ctx->stream, W, N, (u64*)scr);
+    SMC_LAUNCH(k_resample_tiles, dim3(ntiles), dim3(SMC_BLOCK), ctx->stream, W, N, su,
+               (const u64*)scr, ntiles, A);
+    SMC_LAUNCH_CHECK();
+    return SMC_OK;
+}
+
+extern "C" int smc_inverse_cdf(smc_ctx* ctx, const double* su_dev, const double* W, int64_t M,
+                               int64_t N, int64_t* A)
+{
+    SMC_REQUIRE(ctx && su_dev && W && A, "null argument");
+    SMC_REQUIRE(M > 0 && N > 0, "M and N must be positive");
+    SmcSu su;
+    memset(&su, 0, sizeof su);
+    su.scheme = SMC_MULTINOMIAL_;       // "sorted uniforms given in memory"
+    su.M = M;
+    su.dM = (double)M;
+    su.u = su_dev;
+    return resample_launch(ctx, W, N, su, (i64*)A);
+}
+
+// ---- uniform_spacings on the device (resampling.py:512-537) ----------------
+// e_n = -log(u_n), n = 0..M, in fixed point so that the running sums are
+// exact and the resulting su is monotone:  su[n] = (e_0+..+e_n) / (e_0+..+e_M)
+__device__ __forceinline__ u64 smc_spacing_q(u64 seed, u32 t, u32 island, i64 n, double scale)
+{
+    u64 a, b;
+    smc_philox((u32)(n >> 1), t, island, SMC_STREAM_SPACINGS, seed, a, b);
+    const double u = smc_u01_open((n & 1) ? b : a);
+    return (u64)rint(-log(u) * scale);
+}
+
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_spacing_tile_sums(i64 M1, double scale, u64 seed, u32 t, u32 island, u64* E)
+{
+    __shared__ u64 sm[SMC_NWAVE];
+    const i64 n0 = (i64)blockIdx.x * OPS_TILE + (i64)threadIdx.x * OPS_IPT;
+    u64 s = 0;
+#pragma unroll
+    for (int i = 0; i < OPS_IPT; ++i)
+        if (n0 + i < M1) s += smc_spacing_q(seed, t, island, n0 + i, scale);
+    s = smc_block_sum_u64(s, sm);
+    if (threadIdx.x == 0) E[blockIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_spacing_write(i64 M, double scale, u64 seed, u32 t, u32 island, const u64* E, int ntiles,
+                double* su)
+{
+    __shared__ u64 sm[SMC_NWAVE];
+    const int b = (int)blockIdx.x;
+    const i64 n0 = (i64)b * OPS_TILE + (i64)threadIdx.x * OPS_IPT;
+    u64 q[OPS_IPT], tsum = 0;
+#pragma unroll
+    for (int i = 0; i < OPS_IPT; ++i) {
+        q[i] = (n0 + i <= M) ? smc_spacing_q(seed, t, island, n0 + i, scale) : 0ull;
+        tsum += q[i];
+    }
+    u64 pre = 0, all = 0;
+    for (int i = (int)threadIdx.x; i < ntiles; i += SMC_BLOCK) {
+        const u64 e = E[i];
+        all += e;
+        if (i < b) pre += e;
+    }
+    pre = smc_block_sum_u64(pre, sm);
+    all = smc_block_sum_u64(all, sm);
+    u64 tot;
+    u64 run = pre + smc_block_exscan_u64(tsum, sm, tot);
+    const double dall = (double)all;
+#pragma unroll
+    for (int i = 0; i < OPS_IPT; ++i) {
+        run += q[i];
+        if (n0 + i < M) su[n0 + i] = (double)run / dall;
+    }
+}
+
+static double spacing_scale(i64 M)
+{
+    int lg = 0;
+    while (((i64)1 << lg) < M + 2) ++lg;
+    return ldexp(1.0, 57 - lg);
+}
+
+extern "C" int smc_uniform_spacings(smc_ctx* ctx, int64_t M, uint64_t counter, double* su)
+{
+    SMC_REQUIRE(ctx && su, "null argument");
+    SMC_REQUIRE(M > 0, "M must be positive");
+    const int ntiles = (int)((M + 1 + OPS_TILE - 1) / OPS_TILE);
+    // the tile sums live at the END of the scratch so a following
+    // resample_launch (which uses the start) cannot alias them mid-flight
+    void* scr;
+    int rc = smc_scratch(ctx, (size_t)(2 * ntiles + 64) * sizeof(u64), &scr);
+    if (rc) return rc;
+    u64* E = (u64*)scr + ntiles + 32;
+    const double scale = spacing_scale(M);
+    const u32 t = (u32)counter, isl = (u32)(counter >> 32);
+    SMC_LAUNCH(k_spacing_tile_sums, dim3(ntiles), dim3(SMC_BLOCK), ctx->stream, (i64)(M + 1), scale,
+               (u64)ctx->seed, t, isl, E);
+    SMC_LAUNCH(k_spacing_write, dim3(ntiles), dim3(SMC_BLOCK), ctx->stream, (i64)M, scale,
+               (u64)ctx->seed, t, isl, (const u64*)E, ntiles, su);
+    SMC_LAUNCH_CHECK();
+    return SMC_OK;
+}
+
+extern "C" int smc_resample(smc_ctx* ctx, int scheme, const double* W, int64_t N, int64_t M,
+                            const double* u, uint64_t counter, int64_t* A)
+{
+    SMC_REQUIRE(ctx && W && A, "null argument");
+    SMC_REQUIRE(M > 0 && N > 0, "M and N must be positive");
+    if (scheme != SMC_MULTINOMIAL && scheme != SMC_STRATIFIED && scheme != SMC_SYSTEMATIC) {
+        smc_set_error("%d is not a valid resampling scheme", scheme);  // resampling.py:477-481
+        return SMC_ERR_SCHEME;
+    }
+    SmcSu su;
+    memset(&su, 0, sizeof su);
+    su.scheme = scheme;
+    su.M = M;
+    su.dM = (double)M;
+    su.u = u;
+    su.seed = ctx->seed;
+    su.t = (u32)counter;
+    su.island = (u32)(counter >> 32);
+    if (scheme == SMC_MULTINOMIAL && !u) {
+        // draw the sorted uniforms on the device, then invert the CDF
+        void* tmp;
+        int rc = smc_malloc(ctx, (size_t)M * sizeof(double), &tmp);
+        if (rc) return rc;
+        rc = smc_uniform_spacings(ctx, M, counter, (double*)tmp);
+        if (!rc) {
+            su.u = (const double*)tmp;
+            rc = resample_launch(ctx, W, N, su, (i64*)A);
+        }
+        int rc2 = smc_free(ctx, tmp);
+        return rc ? rc : rc2;
+    }
+    return resample_launch(ctx, W, N, su, (i64*)A);
+}
+
+// ===========================================================================
+// a-7  Xp = X[A]   (core.py:332)
+// ===========================================================================
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_gather(const double* X, const i64* A, i64 total, i64 d, double* Xp)
+{
+    const i64 i = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;
+    if (i < total) {
+        const i64 n = i / d, k = i - n * d;
+        Xp[i] = X[A[n] * d + k];
+    }
+}
+
+extern "C" int smc_gather(smc_ctx* ctx, const double* X, const int64_t* A, int64_t M, int64_t d,
+                          double* Xp)
+{
+    SMC_REQUIRE(ctx && X && A && Xp, "null argument");
+    SMC_REQUIRE(M > 0 && d > 0, "bad shape");
+    const i64 total = M * d;
+    SMC_LAUNCH(k_gather, dim3((unsigned)((total + SMC_BLOCK - 1) / SMC_BLOCK)), dim3(SMC_BLOCK),
+               ctx->stream, X, (const i64*)A, total, (i64)d, Xp);
+    SMC_LAUNCH_CHECK();
+    return SMC_OK;
+}
+
+// ===========================================================================
+// a-2 / a-3  Normal.rvs / Normal.logpdf   (distributions.py:270-274)
+// ===========================================================================
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_normal_rvs(const double* loc, i64 ls, const double* scale, i64 ss, const double* z, u64 seed,
+             u32 t, u32 island, i64 N, double* out)
+{
+    const i64 p = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;   // pair index
+    const i64 n0 = 2 * p;
+    if (n0 >= N) return;
+    double z0, z1;
+    if (z) {
+        z0 = z[n0];
+        z1 = (n0 + 1 < N) ? z[n0 + 1] : 0.0;
+    } else {
+        smc_normal_pair(seed, (u32)p, t, island, SMC_STREAM_NORMAL, z0, z1);
+    }
+    out[n0] = loc[n0 * ls] + scale[n0 * ss] * z0;               // loc + scale*z
+    if (n0 + 1 < N) out[n0 + 1] = loc[(n0 + 1) * ls] + scale[(n0 + 1) * ss] * z1;
+}
+
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_normal_logpdf(const double* x, i64 xs, const double* loc, i64 ls, const double* scale, i64 ss,
+                i64 N, double* out)
+{
+    const i64 i = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;
+    if (i < N) {
+        const double sc = scale[i * ss];
+        const double y = (x[i * xs] - loc[i * ls]) / sc;
+        out[i] = -(y * y) / 2.0 - SMC_C_NORM - log(sc);
+    }
+}
+
+extern "C" int smc_normal_rvs(smc_ctx* ctx, const double* loc, int64_t loc_stride,
+                              const double* scale, int64_t scale_stride, const double* z,
+                              uint64_t counter, int64_t N, double* out)
+{
+    SMC_REQUIRE(ctx && loc && scale && out, "null argument");
+    SMC_REQUIRE(N > 0, "N must be positive");
+    const i64 pairs = (N + 1) / 2;
+    SMC_LAUNCH(k_normal_rvs, dim3((unsigned)((pairs + SMC_BLOCK - 1) / SMC_BLOCK)), dim3(SMC_BLOCK),
+               ctx->stream, loc, (i64)loc_stride, scale, (i64)scale_stride, z, (u64)ctx->seed,
+               (u32)counter, (u32)(counter >> 32), (i64)N, out);
+    SMC_LAUNCH_CHECK();
+    return SMC_OK;
+}
+
+extern "C" int smc_normal_logpdf(smc_ctx* ctx, const double* x, int64_t x_stride, const double* loc,
+                                 int64_t loc_stride, const double* scale, int64_t scale_stride,
+                                 int64_t N, double* out)
+{
+    SMC_REQUIRE(ctx && x && loc && scale && out, "null argument");
+    SMC_REQUIRE(N > 0, "N must be positive");
+    SMC_LAUNCH(k_normal_logpdf, dim3((unsigned)((N + SMC_BLOCK - 1) / SMC_BLOCK)), dim3(SMC_BLOCK),
+               ctx->stream, x, (i64)x_stride, loc, (i64)loc_stride, scale, (i64)scale_stride,
+               (i64)N, out);
+    SMC_LAUNCH_CHECK();
+    return SMC_OK;
+}
+
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_philox_fill(int normal, u64 seed, u32 t, u32 island, i64 n, double* out)
+{
+    const i64 p = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;
+    const i64 n0 = 2 * p;
+    if (n0 >= n) return;
+    double v0, v1;
+    if (normal) {
+        smc_normal_pair(seed, (u32)p, t, island, SMC_STREAM_NORMAL, v0, v1);
+    } else {
+        u64 a, b;
+        smc_philox((u32)p, t, island, SMC_STREAM_RESAMPLE, seed, a, b);
+        v0 = smc_u01_halfopen(a);
+        v1 = smc_u01_halfopen(b);
+    }
+    out[n0] = v0;
+    if (n0 + 1 < n) out[n0 + 1] = v1;
+}
+
+static int philox_fill(smc_ctx* ctx, int normal, uint64_t counter, int64_t n, double* out)
+{
+    SMC_REQUIRE(ctx && out, "null argument");
+    SMC_REQUIRE(n > 0, "n must be positive");
+    const i64 pairs = (n + 1) / 2;
+    SMC_LAUNCH(k_philox_fill, dim3((unsigned)((pairs + SMC_BLOCK - 1) / SMC_BLOCK)),
+               dim3(SMC_BLOCK), ctx->stream, normal, (u64)ctx->seed, (u32)counter,
+               (u32)(counter >> 32), (i64)n, out);
+    SMC_LAUNCH_CHECK();
+    return SMC_OK;
+}
+
+extern "C" int smc_standard_normal(smc_ctx* ctx, uint64_t counter, int64_t n, double* out)
+{
+    return philox_fill(ctx, 1, counter, n, out);
+}
+extern "C" int smc_uniform(smc_ctx* ctx, uint64_t counter, int64_t n, double* out)
+{
+    return philox_fill(ctx, 0, counter, n, out);
+}
+
+// ===========================================================================
+// a-8  MvNormal.rvs / logpdf   (distributions.py:946-969)
+// ===========================================================================
+#define MVN_MAXD 64
+
+// out[n,i] = loc[n,i] + scale * sum_{k<=i} Z[n,k] L[i,k]        (:946-947)
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_mvn_rvs(const double* loc, i64 loc_rows, double scale, const double* L, const double* z,
+          u64 seed, u32 t, u32 island, i64 N, int d, double* out)
+{
+    __shared__ double sL[MVN_MAXD * MVN_MAXD];
+    for (int i = (int)threadIdx.x; i < d * d; i += SMC_BLOCK) sL[i] = L[i];
+    __syncthreads();
+    const i64 idx = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;
+    if (idx >= N * d) return;
+    const i64 n = idx / d;
+    const int i = (int)(idx - n * d);
+    const int hp = (d + 1) / 2;                 // Philox pairs per particle
+    double acc = 0.0;
+    for (int k = 0; k <= i; ++k) {
+        double zk;
+        if (z) {
+            zk = z[n * d + k];
+        } else {
+            double z0, z1;
+            smc_normal_pair(seed, (u32)(n * hp + (k >> 1)), t, island, SMC_STREAM_NORMAL, z0, z1);
+            zk = (k & 1) ? z1 : z0;
+        }
+        acc += zk * sL[i * d + k];
+    }
+    const double lc = loc[(loc_rows == 1 ? 0 : n) * d + i];
+    out[idx] = lc + scale * acc;
+}
+
+// one thread per particle; Linv (inverse of the lower Cholesky factor) in LDS:
+// z = Linv (x-loc)/scale ; out = -0.5 |z|^2 - d log(scale) - sum log diag L - d*C
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_mvn_logpdf(const double* x, i64 x_rows, const double* loc, i64 loc_rows, double scale,
+             const double* Linv, double cst, i64 N, int d, double* out)
+{
+    __shared__ double sL[MVN_MAXD * MVN_MAXD];
+    for (int i = (int)threadIdx.x; i < d * d; i += SMC_BLOCK) sL[i] = Linv[i];
+    __syncthreads();
+    const i64 n = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;
+    if (n >= N) return;
+    const double* xr = x + (x_rows == 1 ? 0 : n) * d;
+    const double* lr = loc + (loc_rows == 1 ? 0 : n) * d;
+    double q = 0.0;
+    for (int i = 0; i < d; ++i) {
+        double zi = 0.0;
+        for (int k = 0; k <= i; ++k) zi += sL[i * d + k] * ((xr[k] - lr[k]) / scale);
+        q += zi * zi;
+    }
+    out[n] = -0.5 * q - cst;
+}
+
+// upload a small host matrix into scratch (after `offset` bytes)
+static int upload_small(smc_ctx* ctx, const double* h, size_t n, double* dst)
+{
+    SMC_HIP_CHECK(hipMemcpyAsync(dst, h, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    SMC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return SMC_OK;
+}
+
+extern "C" int smc_mvn_rvs(smc_ctx* ctx, const double* loc, int64_t loc_rows, double scale,
+                           const double* L_host, const double* z, uint64_t counter, int64_t N,
+                           int64_t d, double* out)
+{
+    SMC_REQUIRE(ctx && loc && L_host && out, "null argument");
+    SMC_REQUIRE(N > 0 && d > 0 && d <= MVN_MAXD, "need 0 < d <= 64");
+    SMC_REQUIRE(loc_rows == 1 || loc_rows == N, "loc must have 1 or N rows");
+    void* scr;
+    int rc = smc_scratch(ctx, (size_t)d * d * sizeof(double), &scr);
+    if (rc) return rc;
+    rc = upload_small(ctx, L_host, (size_t)(d * d), (double*)scr);
+    if (rc) return rc;
+    const i64 total = N * d;
+    SMC_LAUNCH(k_mvn_rvs, dim3((unsigned)((total + SMC_BLOCK - 1) / SMC_BLOCK)), dim3(SMC_BLOCK),
+               ctx->stream, loc, (i64)loc_rows, scale, (const double*)scr, z, (u64)ctx->seed,
+               (u32)counter, (u32)(counter >> 32), (i64)N, (int)d, out);
+    SMC_LAUNCH_CHECK();
+    return SMC_OK;
+}
+
+extern "C" int smc_mvn_logpdf(smc_ctx* ctx, const double* x, int64_t x_rows, const double* loc,
+                              int64_t loc_rows, double scale, const double* L_host, int64_t N,
+                              int64_t d, double* out)
+{
+    SMC_REQUIRE(ctx && x && loc && L_host && out, "null argument");
+    SMC_REQUIRE(N > 0 && d > 0 && d <= MVN_MAXD, "need 0 < d <= 64");
+    SMC_REQUIRE((x_rows == 1 || x_rows == N) && (loc_rows == 1 || loc_rows == N),
+                "x / loc must have 1 or N rows");
+    // Linv by forward substitution on the identity (distributions.py:952 solves
+    // the same triangular system per particle)
+    std::vector<double> Li((size_t)(d * d), 0.0);
+    double halflogdet = 0.0;
+    for (int64_t c = 0; c < d; ++c) {
+        for (int64_t i = c; i < d; ++i) {
+            double s = (i == c) ? 1.0 : 0.0;
+            for (int64_t k = c; k < i; ++k) s -= L_host[i * d + k] * Li[k * d + c];
+            Li[i * d + c] = s / L_host[i * d + i];
+        }
+        halflogdet += log(L_host[c * d + c]);
+    }
+    const double cst = (double)d * log(scale) + halflogdet + (double)d * SMC_HALFLOG2PI;
+    void* scr;
+    int rc = smc_scratch(ctx, (size_t)d * d * sizeof(double), &scr);
+    if (rc) return rc;
+    rc = upload_small(ctx, Li.data(), (size_t)(d * d), (double*)scr);
+    if (rc) return rc;
+    SMC_LAUNCH(k_mvn_logpdf, dim3((unsigned)((N + SMC_BLOCK - 1) / SMC_BLOCK)), dim3(SMC_BLOCK),
+               ctx->stream, x, (i64)x_rows, loc, (i64)loc_rows, scale, (const double*)scr, cst,
+               (i64)N, (int)d, out);
+    SMC_LAUNCH_CHECK();
+    return SMC_OK;
+}

@@ -1,0 +1,138 @@
+// smc_resample.h -- device machinery for inverse-CDF resampling
+// (particles/resampling.py:484-509 inverse_cdf, :599-610 stratified/systematic,
+// :540-558 multinomial), shared by the stand-alone kernels and the fused step.
+//
+// Formulation ("scatter by tile"): the N weights are cut into tiles of
+// TILE = 256*IPT consecutive particles, one workgroup per tile.  With the
+// exact Q62 CDF C_j (smc_device.h), tile b owns precisely the outputs
+//     n in [ count(C_{j0-1}), count(C_{j1-1}) ),  count(C) = #{n : T_n <= C},
+// a contiguous range because the sorted uniforms are monotone.  For
+// systematic / stratified draws count() has a closed form, so a workgroup
+// finds its outputs without any global search; the parent of each output is
+// then a binary search in the tile's CDF held in LDS.  Per-tile totals Q_b
+// come from a preceding pass; a workgroup's exclusive prefix is the (exact,
+// order-free) integer sum of its predecessors' totals -- no spinning, no
+// inter-workgroup hand-off inside a launch.
+#pragma once
+#include "smc_device.h"
+
+enum { SMC_MULTINOMIAL_ = 0, SMC_STRATIFIED_ = 1, SMC_SYSTEMATIC_ = 2 };
+
+// Where the sorted uniforms su_n of one resampling come from.
+struct SmcSu {
+    int scheme;        // SMC_*_
+    i64 M;             // number of outputs
+    double dM;         // (double)M
+    const double* u;   // replay: systematic u[0]; stratified u[n]; multinomial su[n] (sorted)
+                       // (multinomial always reads su from memory)
+    double u_sys;      // systematic: the single uniform
+    u64 seed;          // Philox (u == nullptr, stratified)
+    u32 t, island;
+};
+
+// su_n in fp64 exactly as the reference forms it: (u + n) / M with a true
+// division (resampling.py:602, :609), or the n-th sorted uniform (:536-537).
+__device__ __forceinline__ double smc_su_at(const SmcSu& s, i64 n)
+{
+    if (s.scheme == SMC_SYSTEMATIC_) return (s.u_sys + (double)n) / s.dM;
+    if (s.scheme == SMC_STRATIFIED_) {
+        double un;
+        if (s.u) {
+            un = s.u[n];
+        } else {
+            u64 a, b;
+            smc_philox((u32)(n >> 1), s.t, s.island, SMC_STREAM_RESAMPLE, s.seed, a, b);
+            un = smc_u01_halfopen((n & 1) ? b : a);
+        }
+        return (un + (double)n) / s.dM;
+    }
+    return s.u[n];
+}
+
+// Both members of the pair (2p, 2p+1) with one Philox call.
+__device__ __forceinline__ void smc_su_pair(const SmcSu& s, i64 p, double& su0, double& su1)
+{
+    const i64 n0 = 2 * p, n1 = 2 * p + 1;
+    if (s.scheme == SMC_STRATIFIED_ && !s.u) {
+        u64 a, b;
+        smc_philox((u32)p, s.t, s.island, SMC_STREAM_RESAMPLE, s.seed, a, b);
+        su0 = (smc_u01_halfopen(a) + (double)n0) / s.dM;
+        su1 = (smc_u01_halfopen(b) + (double)n1) / s.dM;
+        return;
+    }
+    su0 = (n0 < s.M) ? smc_su_at(s, n0) : 2.0;
+    su1 = (n1 < s.M) ? smc_su_at(s, n1) : 2.0;
+}
+
+// count(C) = #{ n in [0,M) : T(su_n) <= C } = first n whose threshold exceeds C.
+// T(su_n) is non-decreasing in n, so this is a partition point; a closed-form
+// guess is corrected with the exact predicate (and a bisection as the
+// always-correct fallback).
+__device__ __forceinline__ bool smc_su_le(const SmcSu& s, i64 n, u64 C)
+{
+    return smc_q62_t(smc_su_at(s, n)) <= C;
+}
+__device__ inline i64 smc_su_count_le(const SmcSu& s, u64 C)
+{
+    i64 lo = 0, hi = s.M;       // invariant: pred true on [0,lo), false on [hi,M)
+    if (s.scheme != SMC_MULTINOMIAL_) {
+        // su_n ~ (n + u)/M  =>  su_n <= x  <=>  n <= x*M - u
+        const double x = (double)C * 0x1.0p-62;
+        double r = x * s.dM - (s.scheme == SMC_SYSTEMATIC_ ? s.u_sys : 0.0);
+        i64 g = (r < 0.0) ? 0 : (r >= s.dM ? s.M : (i64)r);
+        // bounded local correction
+        int it = 0;
+        while (g < s.M && it < 4 && smc_su_le(s, g, C)) { ++g; ++it; }
+        if (it < 4) {
+            int jt = 0;
+            while (g > 0 && jt < 4 && !smc_su_le(s, g - 1, C)) { --g; ++jt; }
+            if (jt < 4) return g;
+            hi = g;
+        } else {
+            lo = g;
+        }
+    }
+    while (lo < hi) {
+        const i64 mid = lo + ((hi - lo) >> 1);
+        if (smc_su_le(s, mid, C)) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// ---------------------------------------------------------------------------
+// Per-tile CDF in LDS.
+//   wq[i] (i < IPT): this thread's quantised weights, particles j0+tid*IPT+i
+//   Qtiles[0..b):    totals of the preceding tiles (global memory)
+// Writes sC[tid*IPT+i] = inclusive CDF of particle j0+tid*IPT+i and returns the
+// tile's exclusive prefix; tile_total receives its total.  All threads call.
+// ---------------------------------------------------------------------------
+template <int IPT>
+__device__ __forceinline__ u64 smc_tile_cdf(const u64 (&wq)[IPT], const u64* Qtiles, int b,
+                                            u64* sC, u64* sm, u64& tile_total)
+{
+    u64 tsum = 0;
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) tsum += wq[i];
+    u64 pre = 0;
+    for (int i = (int)threadIdx.x; i < b; i += SMC_BLOCK) pre += Qtiles[i];
+    pre = smc_block_sum_u64(pre, sm);
+    u64 run = pre + smc_block_exscan_u64(tsum, sm, tile_total);
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) {
+        run += wq[i];
+        sC[threadIdx.x * IPT + i] = run;
+    }
+    __syncthreads();
+    return pre;
+}
+
+// Output range [n_lo, n_hi) of tile b (every thread gets the same values).
+__device__ __forceinline__ void smc_tile_outputs(const SmcSu& su, int b, int ntiles, u64 pre,
+                                                 u64 tile_total, i64* sn, i64& n_lo, i64& n_hi)
+{
+    if (threadIdx.x == 0) sn[0] = (b == 0) ? 0 : smc_su_count_le(su, pre);
+    if (threadIdx.x == 64) sn[1] = (b == ntiles - 1) ? su.M : smc_su_count_le(su, pre + tile_total);
+    __syncthreads();
+    n_lo = sn[0];
+    n_hi = sn[1];
+}

@@ -1,0 +1,170 @@
+"""Device-backed counterpart of ``particles.distributions`` (hot-path subset):
+``ProbDist`` (:215-251), ``LocScaleDist`` (:262-264), ``Normal`` (:267-285) and
+``MvNormal`` (:888-1009) with ``rvs`` / ``logpdf`` evaluated by HIP kernels.
+
+Parameters and arguments may be python scalars, numpy arrays or DeviceArrays;
+results are numpy arrays unless a DeviceArray was passed in.  Draws come from
+the device's counted Philox stream (``particles_amd.seed``) -- or, with
+``rvs(size, z=...)``, from standard normals supplied by the caller, which is
+how the parity tests replay the reference's own draws.
+"""
+import numpy as np
+import numpy.linalg as nla
+
+from . import _lib
+from ._lib import DeviceArray, check, lib
+
+HALFLOG2PI = 0.5 * np.log(2.0 * np.pi)
+
+
+class ProbDist:
+    """Base class for probability distributions (distributions.py:215-251)."""
+
+    dim = 1
+    dtype = float
+
+    def shape(self, size):
+        if size is None:
+            return None
+        return (size,) if self.dim == 1 else (size, self.dim)
+
+    def logpdf(self, x):
+        raise NotImplementedError
+
+    def pdf(self, x):
+        return np.exp(self.logpdf(x))
+
+    def rvs(self, size=None):
+        raise NotImplementedError
+
+    def ppf(self, u):
+        raise NotImplementedError
+
+
+class LocScaleDist(ProbDist):
+    """Base class for location-scale distributions (distributions.py:259-264)."""
+
+    def __init__(self, loc=0.0, scale=1.0):
+        self.loc = loc
+        self.scale = scale
+
+
+def _strided(v, N):
+    """(DeviceArray, element stride, is_device_input) for a scalar / (1,) / (N,) value."""
+    if isinstance(v, DeviceArray):
+        return v, (0 if v.size == 1 else 1), True
+    a = np.asarray(v, dtype=np.float64).reshape(-1)
+    if a.size not in (1, N):
+        raise ValueError("operands could not be broadcast together with shape (%d,)" % N)
+    return DeviceArray.from_numpy(a), (0 if a.size == 1 else 1), False
+
+
+def _bsize(*vals):
+    n = 1
+    for v in vals:
+        s = v.size if isinstance(v, DeviceArray) else np.asarray(v).size
+        n = max(n, s)
+    return n
+
+
+class Normal(LocScaleDist):
+    """N(loc, scale^2) distribution (distributions.py:267-285)."""
+
+    def rvs(self, size=None, z=None):
+        """``random.normal(loc, scale, size)`` = loc + scale * z  (:270-271)."""
+        N = _bsize(self.loc, self.scale) if size is None else int(size)
+        loc, ls, d1 = _strided(self.loc, N)
+        sc, ss, d2 = _strided(self.scale, N)
+        zd = None
+        if z is not None:
+            zd = z if isinstance(z, DeviceArray) else DeviceArray.from_numpy(
+                np.asarray(z, dtype=np.float64).reshape(-1))
+        out = DeviceArray((N,))
+        check(lib().smc_normal_rvs(out.ctx.h, loc.ptr, ls, sc.ptr, ss,
+                                   zd.ptr if zd is not None else None,
+                                   _lib.next_counter(), N, out.ptr))
+        if d1 or d2 or isinstance(z, DeviceArray):
+            return out
+        r = out.get()
+        return r if size is not None or N > 1 else r[0]
+
+    def logpdf(self, x):
+        """scipy.stats.norm.logpdf(x, loc, scale)  (:273-274)."""
+        N = _bsize(self.loc, self.scale, x)
+        xd, xs, d0 = _strided(x, N)
+        loc, ls, d1 = _strided(self.loc, N)
+        sc, ss, d2 = _strided(self.scale, N)
+        out = DeviceArray((N,))
+        check(lib().smc_normal_logpdf(out.ctx.h, xd.ptr, xs, loc.ptr, ls, sc.ptr, ss, N, out.ptr))
+        return out if (d0 or d1 or d2) else out.get()
+
+
+class MvNormal(ProbDist):
+    """Multivariate Normal distribution (distributions.py:888-1009).
+
+    ``loc``: (d,) or (N,d); ``scale``: scalar; ``cov``: (d,d).  (Per-component /
+    per-particle ``scale`` arrays of the reference are outside the hot path.)
+    """
+
+    def __init__(self, loc=0.0, scale=1.0, cov=None):
+        self.loc = loc
+        self.scale = scale
+        self.cov = np.eye(np.shape(loc)[-1]) if cov is None else cov
+        err_msg = "MvNormal: argument cov must be a (d, d) pos. definite matrix"
+        try:
+            self.L = nla.cholesky(self.cov)  # lower triangle (:937)
+        except nla.LinAlgError:
+            raise ValueError(err_msg)
+        assert self.cov.shape == (self.dim, self.dim), err_msg
+        if np.ndim(scale) != 0:
+            raise NotImplementedError("MvNormal: only a scalar scale is supported on the device")
+
+    @property
+    def dim(self):
+        return self.cov.shape[-1]
+
+    def _loc(self, N):
+        if isinstance(self.loc, DeviceArray):
+            return self.loc, (1 if self.loc.size == self.dim else N), True
+        a = np.asarray(self.loc, dtype=np.float64)
+        if a.ndim == 0:
+            a = np.full(self.dim, float(a))
+        a = np.ascontiguousarray(a.reshape(-1, self.dim))
+        if a.shape[0] not in (1, N):
+            raise ValueError("MvNormal: loc has %d rows, expected 1 or %d" % (a.shape[0], N))
+        return DeviceArray.from_numpy(a), a.shape[0], False
+
+    def rvs(self, size=None, z=None):
+        """loc + scale * (Z @ L.T), Z ~ N(0, I)  (:946-947, :961-969)."""
+        if size is None:
+            sh = np.shape(self.loc) if not isinstance(self.loc, DeviceArray) else self.loc.shape
+            N = sh[0] if len(sh) == 2 else 1
+        else:
+            N = int(size)
+        loc, rows, dev = self._loc(N)
+        zd = None
+        if z is not None:
+            zd = z if isinstance(z, DeviceArray) else DeviceArray.from_numpy(
+                np.asarray(z, dtype=np.float64).reshape(N, self.dim))
+        out = DeviceArray((N, self.dim))
+        La, Lp = _lib.host_dbl(self.L)  # keep La alive across the call
+        check(lib().smc_mvn_rvs(out.ctx.h, loc.ptr, rows, float(self.scale), Lp,
+                                zd.ptr if zd is not None else None, _lib.next_counter(),
+                                N, self.dim, out.ptr))
+        return out if (dev or isinstance(z, DeviceArray)) else out.get()
+
+    def logpdf(self, x):
+        """:949-959."""
+        if isinstance(x, DeviceArray):
+            xd, xrows, dx = x, x.size // self.dim, True
+        else:
+            xa = np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1, self.dim))
+            xd, xrows, dx = DeviceArray.from_numpy(xa), xa.shape[0], False
+        lsh = self.loc.shape if isinstance(self.loc, DeviceArray) else np.shape(self.loc)
+        N = max(xrows, lsh[0] if len(lsh) == 2 else 1)
+        loc, rows, dl = self._loc(N)
+        out = DeviceArray((N,))
+        La, Lp = _lib.host_dbl(self.L)  # keep La alive across the call
+        check(lib().smc_mvn_logpdf(out.ctx.h, xd.ptr, xrows, loc.ptr, rows, float(self.scale),
+                                   Lp, N, self.dim, out.ptr))
+        return out if (dx or dl) else out.get()

@@ -1,0 +1,249 @@
+"""Device-backed counterpart of ``particles.resampling`` (hot-path subset).
+
+Same names, arguments and error behaviour as particles/resampling.py for:
+``Weights`` (:191-244), ``exp_and_normalise`` (:138), ``essl`` (:166),
+``log_sum_exp`` (:247), ``log_mean_exp`` (:291), ``wmean_and_var`` (:320),
+``rs_funcs`` / ``resampling_scheme`` / ``resampling`` (:445-481),
+``inverse_cdf`` (:484-509), ``uniform_spacings`` (:512-537), ``multinomial``
+(:540), ``stratified`` (:599), ``systematic`` (:606).
+
+Arrays may be numpy arrays (copied to HBM, result copied back -- drop-in
+behaviour) or ``DeviceArray`` (stay resident).  All arithmetic runs in the HIP
+kernels of libsmc_hip.so; nothing here computes on the CPU.
+
+Uniform draws: with numpy inputs the uniforms are taken from the numpy global
+generator exactly as the reference does (same count, same order), so a run
+seeded with ``numpy.random.seed`` selects the same ancestors as the reference
+(up to certified near-ties of the CDF, DESIGN.md "Q62 contract").  With
+``set_rng('philox')`` or DeviceArray inputs they come from the device's counted
+Philox stream instead.
+"""
+import ctypes
+import functools
+
+import numpy as np
+from numpy import random
+
+from . import _lib
+from ._lib import DeviceArray, as_device, check, lib
+
+_RNG_MODE = "numpy"
+
+
+def set_rng(mode):
+    """'numpy' (reference-compatible draws on the host) or 'philox' (device)."""
+    global _RNG_MODE
+    if mode not in ("numpy", "philox"):
+        raise ValueError("rng mode must be 'numpy' or 'philox'")
+    _RNG_MODE = mode
+
+
+def _normalise(lw_dev, want_W=True):
+    N = lw_dev.size
+    W = DeviceArray((N,)) if want_W else None
+    out = (ctypes.c_double * 4)()
+    check(lib().smc_lse_normalise(lw_dev.ctx.h, lw_dev.ptr, N, W.ptr if W else None, out))
+    return W, out[0], out[1], (out[2], out[3])
+
+
+def exp_and_normalise(lw):
+    """W = exp(lw) / sum(exp(lw))  (resampling.py:138-163)."""
+    d, host = as_device(np.array(lw, dtype=float) if not isinstance(lw, DeviceArray) else lw)
+    W, _, _, _ = _normalise(d)
+    return W.get() if host else W
+
+
+def essl(lw):
+    """ESS from log-weights (resampling.py:166-188)."""
+    d, _ = as_device(np.array(lw, dtype=float) if not isinstance(lw, DeviceArray) else lw)
+    _, _, ess, _ = _normalise(d, want_W=False)
+    return ess
+
+
+def log_sum_exp(v):
+    """log(sum(exp(v)))  (resampling.py:247-270)."""
+    d, _ = as_device(np.array(v, dtype=float) if not isinstance(v, DeviceArray) else v)
+    _, _, _, (m, s) = _normalise(d, want_W=False)
+    return m + np.log(s)
+
+
+def log_sum_exp_ab(a, b):
+    """log(e^a + e^b) for two scalars (resampling.py:273-288); host scalar code."""
+    if a > b:
+        return a + np.log1p(np.exp(b - a))
+    return b + np.log1p(np.exp(a - b))
+
+
+def log_mean_exp(v, W=None):
+    """log of the (weighted) mean of exp(v)  (resampling.py:291-317)."""
+    d, _ = as_device(np.array(v, dtype=float) if not isinstance(v, DeviceArray) else v)
+    if W is None:
+        _, log_mean, _, _ = _normalise(d, want_W=False)
+        return log_mean
+    Wd, _ = as_device(W)
+    out = ctypes.c_double()
+    check(lib().smc_log_wmean_exp(d.ctx.h, d.ptr, Wd.ptr, d.size, ctypes.byref(out)))
+    return out.value
+
+
+def wmean_and_var(W, x):
+    """Component-wise weighted mean and variance (resampling.py:320-338)."""
+    Wd, _ = as_device(W)
+    xd, _ = as_device(x)
+    N = Wd.size
+    dd = xd.size // N
+    out = (ctypes.c_double * (2 * dd))()
+    check(lib().smc_wmean_var(Wd.ctx.h, Wd.ptr, xd.ptr, N, dd, out))
+    o = np.array(out[:])
+    if xd.ndim == 1:
+        return {"mean": o[0], "var": o[1]}
+    return {"mean": o[:dd], "var": o[dd:]}
+
+
+class Weights:
+    """N log-weights with their normalised weights and ESS (resampling.py:191-244).
+
+    ``lw`` is a numpy array (then ``W`` is numpy too) or a DeviceArray.  As in the
+    reference, NaN log-weights are replaced by -inf in the caller's array
+    (:220), objects are to be treated as immutable and ``add`` returns a new one.
+    """
+
+    def __init__(self, lw=None):
+        self.lw = lw
+        if lw is not None:
+            if isinstance(lw, DeviceArray):
+                d = lw
+            else:
+                self.lw[np.isnan(self.lw)] = -np.inf        # :220, caller's array
+                d = DeviceArray.from_numpy(self.lw)
+            W, self.log_mean, self.ESS, _ = _normalise(d)
+            self.W = W if isinstance(lw, DeviceArray) else W.get()
+
+    @property
+    def N(self):
+        return 0 if self.lw is None else self.lw.shape[0]
+
+    def add(self, delta):
+        """lw <- lw + delta (resampling.py:232-244)."""
+        if self.lw is None:
+            return self.__class__(lw=delta)
+        if isinstance(self.lw, DeviceArray) or isinstance(delta, DeviceArray):
+            a = self.lw.get() if isinstance(self.lw, DeviceArray) else self.lw
+            b = delta.get() if isinstance(delta, DeviceArray) else delta
+            return self.__class__(lw=DeviceArray.from_numpy(a + b))
+        return self.__class__(lw=self.lw + delta)
+
+
+####################
+# Resampling schemes
+####################
+
+rs_funcs = {}  # populated by the decorator below
+
+rs_doc = """\
+
+    Parameters
+    ----------
+    W : (N,) ndarray or DeviceArray
+        normalized weights (>=0, sum to one)
+    M : int, optional (set to N if missing)
+        number of resampled points.
+
+    Returns
+    -------
+    (M,) int64 ndarray (DeviceArray if W was one)
+     M ancestor variables, drawn from range 0, ..., N-1
+"""
+
+
+def resampling_scheme(func):
+    """Decorator for resampling schemes (resampling.py:464-474)."""
+
+    @functools.wraps(func)
+    def modif_func(W, M=None):
+        M = W.shape[0] if M is None else M
+        return func(W, M)
+
+    rs_funcs[func.__name__] = modif_func
+    modif_func.__doc__ = (func.__doc__ or "") + rs_doc
+    return modif_func
+
+
+def resampling(scheme, W, M=None):
+    """resampling.py:477-481."""
+    try:
+        return rs_funcs[scheme](W, M=M)
+    except KeyError:
+        raise ValueError(f"{scheme} is not a valid resampling scheme")
+
+
+def inverse_cdf(su, W):
+    """Inverse CDF algorithm for a finite distribution (resampling.py:484-509).
+
+    su: M sorted points in [0,1]; returns, for each, the smallest index j with
+    su[n] <= CDF_j (clamped to N-1 where the reference would run off the end).
+    """
+    sud, host = as_device(su)
+    Wd, hostW = as_device(W)
+    A = DeviceArray((sud.size,), np.int64)
+    check(lib().smc_inverse_cdf(Wd.ctx.h, sud.ptr, Wd.ptr, sud.size, Wd.size, A.ptr))
+    return A.get() if (host and hostW) else A
+
+
+def uniform_spacings(N):
+    """N ordered uniforms in O(N) (resampling.py:512-537).
+
+    'numpy' mode: the reference's expression on the host generator's draws
+    (that part is RNG plumbing, not the hot path); 'philox' mode: drawn and
+    scanned on the device, returned as a DeviceArray.
+    """
+    if _RNG_MODE == "numpy":
+        z = np.cumsum(-np.log(random.rand(N + 1)))
+        return z[:-1] / z[-1]
+    su = DeviceArray((N,))
+    check(lib().smc_uniform_spacings(su.ctx.h, N, _lib.next_counter(), su.ptr))
+    return su
+
+
+def _resample(scheme, W, M):
+    Wd, host = as_device(W)
+    A = DeviceArray((M,), np.int64)
+    u = None
+    if host and _RNG_MODE == "numpy":
+        # the reference's draws, in the reference's order (:536, :602, :609)
+        if scheme == "systematic":
+            u = DeviceArray.from_numpy(random.rand(1))
+        elif scheme == "stratified":
+            u = DeviceArray.from_numpy(random.rand(M))
+        else:
+            u = DeviceArray.from_numpy(uniform_spacings(M))
+    check(lib().smc_resample(Wd.ctx.h, _lib.SCHEMES[scheme], Wd.ptr, Wd.size, M,
+                             u.ptr if u is not None else None, _lib.next_counter(), A.ptr))
+    return A.get() if host else A
+
+
+@resampling_scheme
+def multinomial(W, M):
+    """Multinomial resampling (resampling.py:540-558); output is ordered."""
+    return _resample("multinomial", W, M)
+
+
+@resampling_scheme
+def stratified(W, M):
+    """Stratified resampling (resampling.py:599-603)."""
+    return _resample("stratified", W, M)
+
+
+@resampling_scheme
+def systematic(W, M):
+    """Systematic resampling (resampling.py:606-610)."""
+    return _resample("systematic", W, M)
+
+
+def multinomial_iid(W, M=None):
+    """Multinomial resampling, randomly permuted (resampling.py:561-571)."""
+    A = multinomial(W, M=M)
+    if isinstance(A, DeviceArray):
+        A = A.get()
+    random.shuffle(A)
+    return A

@@ -1,0 +1,151 @@
+"""Counterpart of ``particles.state_space_models`` for the hot path:
+``StateSpaceModel`` (:172-296), ``Bootstrap`` (:299-349), ``GuidedPF``
+(:352-398) and ``StochVol`` (:446-499).
+
+A model is still declared the reference's way -- ``PX0`` / ``PX`` / ``PY`` (and
+``proposal0`` / ``proposal``) returning ``ProbDist`` objects of
+``particles_amd.distributions`` -- so those methods work on arrays as in the
+reference.  In addition the model classes of the closed family the fused HIP
+step loop knows (``kalman.LinearGauss``, ``StochVol``, ``kalman.MVLinearGauss``)
+export ``_device_params()``; ``Bootstrap`` / ``GuidedPF`` pass it on to
+``particles_amd.SMC`` which then runs the whole time loop on the device.
+"""
+import numpy as np
+
+from . import _lib
+from . import distributions as dists
+from .core import FeynmanKac
+
+
+class StateSpaceModel:
+    """Base class for state-space models (state_space_models.py:172-296)."""
+
+    def __init__(self, **kwargs):
+        if hasattr(self, "default_params"):
+            self.__dict__.update(self.default_params)
+        self.__dict__.update(kwargs)
+
+    def _error_msg(self, method):
+        return "method " + method + " not implemented in class%s" % self.__class__.__name__
+
+    def PX0(self):
+        "Law of X_0 at time 0"
+        raise NotImplementedError(self._error_msg("PX0"))
+
+    def PX(self, t, xp):
+        "Law of X_t at time t, given X_{t-1} = xp"
+        raise NotImplementedError(self._error_msg("PX"))
+
+    def PY(self, t, xp, x):
+        """Conditional distribution of Y_t, given the states."""
+        raise NotImplementedError(self._error_msg("PY"))
+
+    def proposal0(self, data):
+        raise NotImplementedError(self._error_msg("proposal0"))
+
+    def proposal(self, t, xp, data):
+        raise NotImplementedError(self._error_msg("proposal"))
+
+    def simulate_given_x(self, x):
+        lag_x = [None] + x[:-1]
+        return [self.PY(t, xp, x).rvs(size=1) for t, (xp, x) in enumerate(zip(lag_x, x))]
+
+    def simulate(self, T):
+        """Simulate state and observation processes (state_space_models.py:278-296):
+        lists x, y of length T (draws come from the device Philox stream)."""
+        x = []
+        for t in range(T):
+            law_x = self.PX0() if t == 0 else self.PX(t, x[-1])
+            x.append(law_x.rvs(size=1))
+        y = self.simulate_given_x(x)
+        return x, y
+
+    def _device_params(self, fk_kind):
+        """(model kind, dx, dy, params (16,) or None, matrices) for the fused
+        step loop, or None when the model is outside the closed family."""
+        return None
+
+
+class Bootstrap(FeynmanKac):
+    """Bootstrap Feynman-Kac formalism of a state-space model
+    (state_space_models.py:299-349)."""
+
+    _fk_kind = _lib.FK_BOOTSTRAP
+
+    def __init__(self, ssm=None, data=None):
+        self.ssm = ssm
+        self.data = data
+        self.du = self.ssm.PX0().dim
+
+    @property
+    def T(self):
+        return 0 if self.data is None else len(self.data)
+
+    def M0(self, N):
+        return self.ssm.PX0().rvs(size=N)
+
+    def M(self, t, xp):
+        return self.ssm.PX(t, xp).rvs(size=xp.shape[0])
+
+    def logG(self, t, xp, x):
+        return self.ssm.PY(t, xp, x).logpdf(self.data[t])
+
+    def logpt(self, t, xp, x):
+        """PDF of X_t|X_{t-1}=xp"""
+        return self.ssm.PX(t, xp).logpdf(x)
+
+    def _device_model(self):
+        return self.ssm._device_params(self._fk_kind)
+
+
+class GuidedPF(Bootstrap):
+    """Guided filter for a state-space model with ``proposal0`` / ``proposal``
+    (state_space_models.py:352-398)."""
+
+    _fk_kind = _lib.FK_GUIDED
+
+    def M0(self, N):
+        return self.ssm.proposal0(self.data).rvs(size=N)
+
+    def M(self, t, xp):
+        return self.ssm.proposal(t, xp, self.data).rvs(size=xp.shape[0])
+
+    def logG(self, t, xp, x):
+        if t == 0:
+            return (self.ssm.PX0().logpdf(x)
+                    + self.ssm.PY(0, xp, x).logpdf(self.data[0])
+                    - self.ssm.proposal0(self.data).logpdf(x))
+        return (self.ssm.PX(t, xp).logpdf(x)
+                + self.ssm.PY(t, xp, x).logpdf(self.data[t])
+                - self.ssm.proposal(t, xp, self.data).logpdf(x))
+
+
+class StochVol(StateSpaceModel):
+    r"""Univariate stochastic volatility model (state_space_models.py:446-473).
+
+    X_0 ~ N(mu, sigma^2/(1-rho^2)); X_t = mu + rho (X_{t-1}-mu) + sigma U_t;
+    Y_t | X_t ~ N(0, exp(X_t)).
+    """
+    default_params = {"mu": -1.02, "rho": 0.9702, "sigma": 0.178}
+
+    def sig0(self):
+        return self.sigma / np.sqrt(1.0 - self.rho ** 2)
+
+    def PX0(self):
+        return dists.Normal(loc=self.mu, scale=self.sig0())
+
+    def EXt(self, xp):
+        return (1.0 - self.rho) * self.mu + self.rho * xp
+
+    def PX(self, t, xp):
+        return dists.Normal(loc=self.EXt(xp), scale=self.sigma)
+
+    def PY(self, t, xp, x):
+        return dists.Normal(loc=0.0, scale=np.exp(0.5 * x))
+
+    def _device_params(self, fk_kind):
+        if fk_kind != _lib.FK_BOOTSTRAP:
+            return None
+        p = np.zeros(_lib.PARAM_STRIDE)
+        p[:5] = [self.mu, self.rho, self.sigma, self.sig0(), (1.0 - self.rho) * self.mu]
+        return dict(kind=_lib.MODEL_STOCHVOL, dx=1, dy=1, params=p)

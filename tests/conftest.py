@@ -1,4 +1,6 @@
+import ctypes
 import os
+import subprocess
 import sys
 
 import numpy as np
@@ -8,10 +10,32 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+REAL_LIB = os.path.join(ROOT, "particles_amd", "lib", "libsmc_hip.so")
+
+
+def _gpu_visible():
+    """True iff the real libsmc_hip.so loads and sees a HIP device."""
+    if not os.path.exists(REAL_LIB):
+        return False
+    try:
+        n = ctypes.c_int(0)
+        ctypes.CDLL(REAL_LIB).smc_device_count(ctypes.byref(n))
+        return n.value > 0
+    except OSError:
+        return False
+
+
+HAS_GPU = _gpu_visible()
 
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run via gpurun)")
+    if not HAS_GPU:
+        # GPU-less container: route the CPU suite's kernel-logic tests through
+        # the fiber emulator build of the SAME kernel sources (tests/emu).
+        sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+        import build_emu
+        os.environ["SMC_HIP_LIBRARY"] = build_emu.build()
 
 
 def load_golden(name):
@@ -24,9 +48,13 @@ def golden():
     return load_golden
 
 
+@pytest.fixture(scope="session")
+def has_gpu():
+    return HAS_GPU
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _build_oracle():
     """The C half of the oracle is a build product (oracle/_build); make it."""
-    import subprocess
     subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True,
                    stdout=subprocess.DEVNULL)

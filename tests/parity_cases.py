@@ -1,0 +1,424 @@
+"""Parity checks of the HIP path against the CPU oracle, written once and run
+twice: on a real MI355X by tests/test_gpu_parity.py (-m gpu, full sizes) and,
+at small sizes, through the fiber emulator by tests/test_emu_parity.py so the
+kernel logic is exercised in the GPU-less build container too.
+
+Tolerances (stated per check): integer / index results are bit-exact; floating
+point results that only involve IEEE + - * / are bit-exact; results that go
+through exp/log/sincos (device libm differs from numpy's in the last ulp) are
+compared at <= 1e-12 relative; log-evidence at <= 1e-9 relative (north star:
+1e-6).
+"""
+import ctypes
+
+import numpy as np
+
+import particles_amd as pa
+from oracle import smc_oracle as orc
+from particles_amd import _lib
+from particles_amd import distributions as dists
+from particles_amd import kalman
+from particles_amd import resampling as rs
+from particles_amd import state_space_models as ssm
+
+RTOL = 1e-12
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    den = np.maximum(np.abs(b), 1e-300)
+    return float(np.max(np.abs(a - b) / den)) if a.size else 0.0
+
+
+# ------------------------------------------------------------------ a-4 ----
+def check_weights(golden):
+    g = golden("weights")
+    lw = g["lw_in"].copy()
+    w = rs.Weights(lw=lw)
+    assert np.array_equal(lw, g["lw_after"])                 # NaN -> -inf in the caller's array
+    assert rel(w.W, g["W"]) < RTOL
+    assert abs(w.ESS / g["ESS"] - 1) < RTOL and abs(w.log_mean - g["log_mean"]) < 1e-12
+    w2 = w.add(g["lw2"] - g["lw_after"])
+    mask = np.isfinite(g["lw2"])
+    assert rel(w2.W[mask], g["W2"][mask]) < 1e-10 and abs(w2.ESS / g["ESS2"] - 1) < 1e-10
+    assert abs(rs.log_sum_exp(g["lw_after"]) - g["lse"]) < 1e-12
+    assert abs(rs.log_mean_exp(g["lw_after"]) - g["lme"]) < 1e-12
+    assert abs(rs.essl(g["lw_after"]) / g["essl"] - 1) < RTOL
+    assert rel(rs.exp_and_normalise(g["lw_after"]), g["ean"]) < RTOL
+    assert abs(rs.log_mean_exp(g["lw2"], W=g["W"]) - g["lme_w"]) < 1e-11
+    mv = rs.wmean_and_var(g["W"], np.sin(np.arange(1000.0)))
+    assert abs(mv["mean"] - g["wmean"]) < 1e-13 and abs(mv["var"] - g["wvar"]) < 1e-13
+
+
+def check_weights_edges(N):
+    w = rs.Weights(lw=np.full(N, -np.inf))
+    assert np.isnan(w.W).all() and np.isnan(w.ESS) and np.isnan(w.log_mean)
+    e = rs.Weights()
+    assert e.N == 0 and not hasattr(e, "W")
+    w1 = e.add(np.zeros(N))
+    assert np.array_equal(w1.W, np.full(N, 1.0 / N)) and abs(w1.ESS - N) < 1e-9 * N
+    rng = np.random.default_rng(0)
+    lw = 50.0 * rng.standard_normal(N)
+    lw[::7] = -np.inf
+    o = orc.Weights(lw=lw.copy())
+    d = rs.Weights(lw=lw.copy())
+    assert rel(d.W, o.W) < RTOL and abs(d.ESS / o.ESS - 1) < RTOL
+    assert abs(d.log_mean - o.log_mean) < 1e-12 * max(1, abs(o.log_mean))
+
+
+# ------------------------------------------------------------ a-5 / a-6 ----
+def check_inverse_cdf(N, M, seed=0):
+    rng = np.random.default_rng(seed)
+    W = orc.exp_and_normalise(3.0 * rng.standard_normal(N))
+    W[rng.integers(0, N, size=max(1, N // 50))] = 0.0
+    W /= W.sum()
+    su = np.sort(rng.random(M))
+    A = rs.inverse_cdf(su, W)
+    assert A.dtype == np.int64 and A.shape == (M,)
+    assert np.array_equal(A, orc.inverse_cdf_q62(su, W))     # bit-exact vs the Q62 oracle
+    try:
+        A_seq = orc.inverse_cdf(su, W)
+    except IndexError:
+        return
+    n, ok = orc.audit_near_ties(su, W, A_seq, A)             # vs the reference ordering
+    assert ok and n <= max(2, M // 100000)
+
+
+def check_inverse_cdf_dyadic(N, M):
+    """Exactly summable weights: must equal the reference's sequential CDF 100%."""
+    rng = np.random.default_rng(3)
+    k = rng.integers(0, 2 ** 30 // N, size=N).astype(np.int64)
+    k[-1] += 2 ** 30 - k.sum()
+    W = k / 2.0 ** 30
+    assert W.sum() == 1.0
+    for scheme in ("systematic", "stratified"):
+        u = rng.random(orc.N_UNIFORMS[scheme](M))
+        su = orc.sorted_uniforms(scheme, M, u)
+        assert np.array_equal(rs.inverse_cdf(su, W), orc.inverse_cdf_q62(su, W))
+
+
+def check_schemes_vs_reference(golden):
+    """Same numpy seed as the reference run -> same ancestors (near-ties audited)."""
+    g = golden("resampling")
+    for scheme in ("systematic", "stratified", "multinomial"):
+        for M in (1500, 400, 4000):
+            np.random.seed(11)
+            A = rs.resampling(scheme, g["W"], M=M)
+            ref = g["A_%s_%d" % (scheme, M)]
+            assert A.dtype == np.int64 and A.shape == ref.shape
+            if not np.array_equal(A, ref):
+                np.random.seed(11)
+                su = orc.sorted_uniforms(scheme, M, np.random.rand(orc.N_UNIFORMS[scheme](M)))
+                n, ok = orc.audit_near_ties(su, g["W"], ref, A)
+                assert ok and n <= 1
+
+
+def check_schemes_replay(N, M, seed=1):
+    rng = np.random.default_rng(seed)
+    W = orc.exp_and_normalise(2.5 * rng.standard_normal(N))
+    Wd = pa.DeviceArray.from_numpy(W)
+    for scheme in ("systematic", "stratified", "multinomial"):
+        u = rng.random(orc.N_UNIFORMS[scheme](M))
+        su = orc.sorted_uniforms(scheme, M, u)
+        want = orc.inverse_cdf_q62(su, W)
+        ud = pa.DeviceArray.from_numpy(su if scheme == "multinomial" else u)
+        A = pa.DeviceArray((M,), np.int64)
+        _lib.check(_lib.lib().smc_resample(Wd.ctx.h, _lib.SCHEMES[scheme], Wd.ptr, N, M, ud.ptr,
+                                           0, A.ptr))
+        got = A.get()
+        assert np.array_equal(got, want), scheme
+        assert np.all(np.diff(got) >= 0) and got.min() >= 0 and got.max() < N
+
+
+def check_schemes_philox(N, M, seed=77):
+    rng = np.random.default_rng(seed)
+    W = orc.exp_and_normalise(2.0 * rng.standard_normal(N))
+    Wd = pa.DeviceArray.from_numpy(W)
+    pa.seed(seed)
+    for scheme in ("systematic", "stratified"):
+        for counter in (5, (3 << 32) | 9):
+            A = pa.DeviceArray((M,), np.int64)
+            _lib.check(_lib.lib().smc_resample(Wd.ctx.h, _lib.SCHEMES[scheme], Wd.ptr, N, M, None,
+                                               counter, A.ptr))
+            u = orc.philox_resample_uniforms(seed, scheme, M, counter & 0xFFFFFFFF, counter >> 32)
+            want = orc.inverse_cdf_q62(orc.sorted_uniforms(scheme, M, u), W)
+            assert np.array_equal(A.get(), want), scheme
+    # multinomial: sorted uniforms by exponential spacings, drawn on the device
+    su = pa.DeviceArray((M,))
+    _lib.check(_lib.lib().smc_uniform_spacings(su.ctx.h, M, 12, su.ptr))
+    s = su.get()
+    assert np.all(np.diff(s) >= 0) and s[0] > 0 and s[-1] < 1
+    want = orc.uniform_spacings_from(orc.philox_resample_uniforms(seed, "multinomial", M, 12))
+    assert np.max(np.abs(s - want)) < 1e-9
+    A = pa.DeviceArray((M,), np.int64)
+    _lib.check(_lib.lib().smc_resample(Wd.ctx.h, _lib.MULTINOMIAL, Wd.ptr, N, M, None, 12, A.ptr))
+    assert np.array_equal(A.get(), orc.inverse_cdf_q62(s, W))
+
+
+def check_resampling_statistics(N, reps):
+    """book/resampling/compare_tv_distance_resampling.py: E[counts] = M*W and,
+    for systematic, offspring in {floor, ceil}(N*W)."""
+    rng = np.random.default_rng(5)
+    W = orc.exp_and_normalise(rng.standard_normal(N))
+    rs.set_rng("philox")
+    try:
+        pa.seed(99)
+        Wd = pa.DeviceArray.from_numpy(W)
+        for scheme in ("systematic", "stratified", "multinomial"):
+            tot = np.zeros(N)
+            for _ in range(reps):
+                c = np.bincount(rs.resampling(scheme, Wd).get(), minlength=N)
+                if scheme == "systematic":
+                    assert np.all((c >= np.floor(N * W)) & (c <= np.ceil(N * W)))
+                tot += c
+            err = np.abs(tot / reps - N * W)
+            sd = np.sqrt(N * W * (1 - W) / reps) + 1e-12
+            assert np.all(err < 6 * sd + 1e-9), scheme
+    finally:
+        rs.set_rng("numpy")
+
+
+def check_unknown_scheme():
+    import pytest
+    with pytest.raises(ValueError, match="not a valid resampling scheme"):
+        rs.resampling("bogus", np.ones(4) / 4)
+    with pytest.raises(ValueError, match="not a valid resampling scheme"):
+        pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(), data=[np.zeros(1)]), N=10, resampling="bogus")
+
+
+# ------------------------------------------------------------------ a-7 ----
+def check_gather(N, d):
+    rng = np.random.default_rng(2)
+    X = rng.standard_normal((N, d)) if d > 1 else rng.standard_normal(N)
+    A = rng.integers(0, N, size=N)
+    Xd, Ad = pa.DeviceArray.from_numpy(X), pa.DeviceArray.from_numpy(A)
+    out = pa.DeviceArray(X.shape)
+    _lib.check(_lib.lib().smc_gather(Xd.ctx.h, Xd.ptr, Ad.ptr, N, d, out.ptr))
+    assert np.array_equal(out.get(), X[A])
+
+
+# ------------------------------------------------------------ a-2 / a-3 ----
+def check_normal(golden):
+    g = golden("dists")
+    lp = dists.Normal(loc=g["loc"], scale=0.7).logpdf(g["x"])
+    assert np.max(np.abs(lp - g["normal_logpdf"])) < 1e-15 * 8
+    lp = dists.Normal(loc=0.0, scale=np.exp(0.5 * g["x"])).logpdf(np.array([0.3]))
+    assert np.max(np.abs(lp - g["normal_logpdf_sv"])) < 1e-14
+    np.random.seed(10)
+    z = np.random.standard_normal(64)
+    x = dists.Normal(loc=g["loc"], scale=0.7).rvs(size=64, z=z)
+    assert np.array_equal(x, g["normal_rvs"])                # loc + scale*z: bit-exact
+
+
+def check_normal_philox(n, seed=4242):
+    pa.seed(seed)
+    z = pa.DeviceArray((n,))
+    _lib.check(_lib.lib().smc_standard_normal(z.ctx.h, 7, n, z.ptr))
+    want = orc.philox_normals(seed, n, 7)
+    assert np.max(np.abs(z.get() - want)) < 1e-13
+    u = pa.DeviceArray((n,))
+    _lib.check(_lib.lib().smc_uniform(u.ctx.h, (2 << 32) | 7, n, u.ptr))
+    p = np.arange((n + 1) // 2)
+    x01, x23 = orc.philox_u64_pair(seed, p, 7, 2, orc.STREAM_RESAMPLE)
+    wantu = np.stack([orc.u01_halfopen(x01), orc.u01_halfopen(x23)], axis=1).reshape(-1)[:n]
+    assert np.array_equal(u.get(), wantu)                    # integer pipeline: bit-exact
+
+
+# ------------------------------------------------------------------ a-8 ----
+def check_mvn(golden):
+    g = golden("dists")
+    mv = dists.MvNormal(loc=g["mloc"], scale=1.3, cov=g["cov"])
+    assert np.max(np.abs(mv.logpdf(g["x5"]) - g["mv_logpdf"])) < 1e-12
+    np.random.seed(12)
+    z = np.random.standard_normal((40, 5))
+    assert np.max(np.abs(mv.rvs(size=40, z=z) - g["mv_rvs"])) < 1e-13
+
+
+def check_mvn_large(N, d):
+    rng = np.random.default_rng(8)
+    Amat = rng.standard_normal((d, d))
+    cov = Amat @ Amat.T + d * np.eye(d)
+    loc = rng.standard_normal((N, d))
+    x = rng.standard_normal((N, d))
+    L = np.linalg.cholesky(cov)
+    mv = dists.MvNormal(loc=loc, cov=cov)
+    assert rel(mv.logpdf(x), orc.mvnormal_logpdf(x, loc, 1.0, L)) < 1e-11
+    z = rng.standard_normal((N, d))
+    assert np.max(np.abs(mv.rvs(size=N, z=z) - orc.mvnormal_rvs(loc, 1.0, L, z))) < 1e-12
+    # Philox draws: right covariance
+    pa.seed(5)
+    s = dists.MvNormal(loc=np.zeros(d), cov=cov).rvs(size=N)
+    if N >= 20000:
+        assert np.max(np.abs(np.cov(s.T) - cov)) < 0.1 * np.abs(cov).max()
+
+
+# ------------------------------------------------------------------ a-1 ----
+MODELS = {
+    "toy": (lambda: kalman.ToySSM(0.2), lambda: orc.ToySSM(0.2)),
+    "sv": (lambda: ssm.StochVol(), lambda: orc.StochVol()),
+    "lg_adaptive": (lambda: kalman.LinearGauss(rho=0.9, sigmaX=1.0, sigmaY=1.5),
+                    lambda: orc.LinGauss(rho=0.9, sigmaX=1.0, sigmaY=1.5)),
+    "lg_guided": (lambda: kalman.LinearGauss(rho=0.9, sigmaX=1.0, sigmaY=0.2),
+                  lambda: orc.LinGauss(rho=0.9, sigmaX=1.0, sigmaY=0.2)),
+}
+
+
+def tapes_from_oracle(tape, T, N, scheme):
+    """Dense device tapes (T,1,N) / (T,1,K) from the oracle's consumption-ordered
+    tape; multinomial slots hold the sorted uniforms (resampling.py:536-537)."""
+    K = 1 if scheme == "systematic" else N
+    z = np.zeros((T, 1, N))
+    u = np.zeros((T, 1, K))
+    t = -1
+    pend = None
+    for kind, a in tape:
+        if kind == "u":
+            pend = a
+        else:
+            t += 1
+            z[t, 0] = a.reshape(-1)
+            if pend is not None:
+                u[t, 0] = orc.uniform_spacings_from(pend) if scheme == "multinomial" else pend
+                pend = None
+    assert t == T - 1
+    return z, u
+
+
+def check_filter_replay(golden, case, model, fk, T=None):
+    """Replay the reference's own draws through the fused device loop."""
+    g = golden(case)
+    mk_dev, mk_orc = MODELS[model]
+    N, scheme, ESSrmin = int(g["N"]), str(g["scheme"]), float(g["ESSrmin"])
+    y = list(g["y"])[:T] if T else list(g["y"])
+    np.random.seed(int(g["run_seed"]))
+    rec = orc.RecordingRNG()
+    o = orc.run_filter(mk_orc(), y, N, scheme, ESSrmin, fk=fk, rng=rec, keep=True)
+    if T is None:       # the oracle reproduces the reference bit for bit (pinned)
+        assert o["final_logLt"] == float(g["logLt"])
+    z, u = tapes_from_oracle(rec.tape, len(y), N, scheme)
+    cls = ssm.Bootstrap if fk == "bootstrap" else ssm.GuidedPF
+    pf = pa.SMC(fk=cls(ssm=mk_dev(), data=y), N=N, resampling=scheme, ESSrmin=ESSrmin,
+                replay=(z, u))
+    pf.run()
+    assert pf.summaries.rs_flags == o["rs_flag"]                       # same branch every step
+    assert rel(pf.summaries.ESSs, o["ESS"]) < 1e-9
+    assert rel(pf.summaries.logLts, o["logLt"]) < 1e-9                 # north star: 1e-6
+    assert abs(pf.logLt / o["final_logLt"] - 1) < 1e-9
+    same = np.mean(pf.A == o["A"])
+    assert same >= 0.999                                               # near-ties only
+    if same == 1.0:
+        tol = 0 if model.startswith(("toy", "lg")) else 1e-12
+        assert np.max(np.abs(pf.X - o["X"])) <= tol                   # IEEE ops only: exact
+        assert rel(pf.wgts.lw, o["lw"]) < 1e-12 and rel(pf.W, o["W"]) < 1e-11
+        assert np.array_equal(pf.Xp, o["Xp"]) or tol > 0
+    return pf, o
+
+
+def check_filter_stepwise(golden):
+    """next(pf) one step at a time == run(), and the iterator protocol."""
+    g = golden("toy_systematic")
+    y = list(g["y"])[:12]
+    a = pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y), N=3000, seed=5)
+    a.run()
+    b = pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y), N=3000, seed=5)
+    n = 0
+    for _ in b:
+        n += 1
+    assert n == 12 and b.t == 12
+    import pytest
+    with pytest.raises(StopIteration):
+        next(b)
+    assert a.logLt == b.logLt and np.array_equal(a.X, b.X)
+    assert a.summaries.logLts == b.summaries.logLts and len(a.summaries.ESSs) == 12
+
+
+def check_filter_philox_vs_c(N, T, golden):
+    """Production (Philox) mode against the C oracle running the same counter
+    stream: integer pipeline identical, Gaussians equal to ~1 ulp."""
+    g = golden("kalman_toy")
+    y = np.ascontiguousarray(np.squeeze(g["y"]))[:T]
+    summ = np.zeros(4 * T)
+    ll_c = orc.clib().orc_toy_filter_philox(orc._dp(y), T, N, 1.0, 1.0, 0.2, 1.0, 0.5, 2024,
+                                            orc._dp(summ))
+    pf = pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=[np.array([v]) for v in y]), N=N,
+                seed=2024)
+    pf.run()
+    s = summ.reshape(T, 4)
+    assert pf.summaries.rs_flags == [bool(v) for v in s[:, 3]]
+    assert rel(pf.summaries.ESSs, s[:, 0]) < 1e-7
+    assert abs(pf.logLt / ll_c - 1) < 1e-9
+
+
+def check_filter_kalman(N, golden, scheme="systematic"):
+    g = golden("kalman_toy")
+    y = [np.atleast_1d(v) for v in np.squeeze(g["y"])]
+    lls = []
+    for s in range(4):
+        pf = pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y), N=N, seed=100 + s,
+                    resampling=scheme)
+        pf.run()
+        lls.append(pf.logLt)
+    lls = np.array(lls)
+    tol = 8.0 / np.sqrt(N) * np.sqrt(len(y)) + 0.05
+    assert abs(lls.mean() - float(g["loglik"])) < tol, (lls, float(g["loglik"]))
+
+
+def check_islands(N, T, golden, scheme="stratified"):
+    """Island k of a batched filter == a single filter with island_offset=k."""
+    g = golden("kalman_toy")
+    y = [np.atleast_1d(v) for v in np.squeeze(g["y"])][:T]
+    fk = ssm.Bootstrap(ssm=kalman.LinearGauss(rho=0.95, sigmaX=0.7, sigmaY=0.5), data=y)
+    pf = pa.SMC(fk=fk, N=N, seed=31, n_islands=3, resampling=scheme, collect="off", ESSrmin=0.7)
+    pf.run()
+    ll = pf.logLts_islands
+    assert len(set(ll.tolist())) == 3
+    for k in (0, 2):
+        one = pa.SMC(fk=fk, N=N, seed=31, resampling=scheme, collect="off", ESSrmin=0.7,
+                     island_offset=k)
+        one.run()
+        assert one.logLt == ll[k]
+        assert np.array_equal(one.X, pf._get(_lib.FIELD_X, k))
+    out = pa.multiSMC(fk=fk, N=N, nruns=3, out_func=lambda p: p.logLt, resampling=scheme)
+    assert [d["run"] for d in out] == [0, 1, 2] and all(np.isfinite(d["output"]) for d in out)
+
+
+def check_generic_path(golden):
+    """A user-defined FeynmanKac in Python: template method with device ops."""
+    g = golden("kalman_toy")
+    y = np.squeeze(g["y"])[:30]
+
+    class MyFK(pa.FeynmanKac):
+        def M0(self, N):
+            return dists.Normal().rvs(size=N)
+
+        def M(self, t, xp):
+            return dists.Normal(loc=xp).rvs(size=xp.shape[0])
+
+        def logG(self, t, xp, x):
+            return dists.Normal(loc=x, scale=0.2).logpdf(y[t])
+
+    pa.seed(3)
+    np.random.seed(3)
+    from particles_amd.collectors import Moments
+    pf = pa.SMC(fk=MyFK(T=30), N=4000, collect=[Moments()], store_history=True)
+    pf.run()
+    ll, means = orc.kalman_loglik(orc.ToySSM(0.2), [np.atleast_1d(v) for v in y])
+    assert abs(pf.logLt - ll) < 1.5
+    est = np.array([m["mean"] for m in pf.summaries.moments])
+    assert np.max(np.abs(est - means)) < 0.15
+    assert len(pf.hist.X) == 30 and pf.hist.compute_trajectories().shape == (30, 4000)
+
+
+def check_collectors_on_fused(golden):
+    from particles_amd.collectors import Moments
+    g = golden("kalman_toy")
+    y = [np.atleast_1d(v) for v in np.squeeze(g["y"])][:25]
+    pf = pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y), N=5000, seed=9,
+                collect=[Moments()], store_history=True)
+    pf.run()
+    _, means = orc.kalman_loglik(orc.ToySSM(0.2), y)
+    est = np.array([m["mean"] for m in pf.summaries.moments])
+    assert est.shape == (25,) and np.max(np.abs(est - means)) < 0.1
+    assert len(pf.summaries.ESSs) == 25 and len(pf.hist.A) == 25
+    B = pf.hist.compute_trajectories()
+    assert B.shape == (25, 5000) and np.array_equal(B[-1], np.arange(5000))

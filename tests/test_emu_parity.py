@@ -1,0 +1,97 @@
+"""Kernel-logic checks WITHOUT a GPU: the kernel sources compiled for the fiber
+emulator (tests/emu) are driven through the same C ABI and Python host layer at
+small sizes.  This is test infrastructure for the GPU-less build container --
+the parity claims proper are made by tests/test_gpu_parity.py on an MI355X.
+Skipped when a GPU is visible (the real library is then loaded instead).
+"""
+import pytest
+
+import parity_cases as pc
+
+pytestmark = pytest.mark.skipif(
+    __import__("conftest").HAS_GPU, reason="GPU visible: covered by test_gpu_parity.py")
+
+
+def test_emulator_is_what_is_loaded():
+    from particles_amd import _lib
+    assert b"EMULATOR" in _lib.lib().smc_version()
+
+
+def test_weights(golden):
+    pc.check_weights(golden)
+    pc.check_weights_edges(3000)
+
+
+@pytest.mark.parametrize("N,M", [(5000, 5000), (1000, 3777), (4097, 1024), (1, 50), (700, 1)])
+def test_inverse_cdf(N, M):
+    pc.check_inverse_cdf(N, M)
+
+
+def test_inverse_cdf_dyadic():
+    pc.check_inverse_cdf_dyadic(2048, 3000)
+
+
+def test_schemes_vs_reference(golden):
+    pc.check_schemes_vs_reference(golden)
+
+
+@pytest.mark.parametrize("N,M", [(3000, 3000), (2049, 500), (300, 4100)])
+def test_schemes_replay(N, M):
+    pc.check_schemes_replay(N, M)
+
+
+def test_schemes_philox():
+    pc.check_schemes_philox(2500, 2500)
+    pc.check_schemes_philox(1024, 3001)
+
+
+def test_resampling_statistics():
+    pc.check_resampling_statistics(600, 40)
+
+
+def test_unknown_scheme():
+    pc.check_unknown_scheme()
+
+
+def test_gather():
+    pc.check_gather(3000, 1)
+    pc.check_gather(500, 7)
+
+
+def test_normal(golden):
+    pc.check_normal(golden)
+    pc.check_normal_philox(1001)
+
+
+def test_mvn(golden):
+    pc.check_mvn(golden)
+    pc.check_mvn_large(300, 6)
+
+
+@pytest.mark.parametrize("case,model,fk", [
+    ("toy_systematic", "toy", "bootstrap"),
+    ("toy_stratified", "toy", "bootstrap"),
+    ("toy_multinomial", "toy", "bootstrap"),
+    ("sv_systematic", "sv", "bootstrap"),
+    ("lg_adaptive", "lg_adaptive", "bootstrap"),
+    ("lg_guided", "lg_guided", "guided"),
+])
+def test_filter_replay(golden, case, model, fk):
+    pc.check_filter_replay(golden, case, model, fk, T=25)
+
+
+def test_filter_stepwise(golden):
+    pc.check_filter_stepwise(golden)
+
+
+def test_filter_philox_vs_c(golden):
+    pc.check_filter_philox_vs_c(3000, 15, golden)
+
+
+def test_islands(golden):
+    pc.check_islands(1500, 10, golden)
+    pc.check_islands(1100, 6, golden, scheme="multinomial")
+
+
+def test_collectors_and_history(golden):
+    pc.check_collectors_on_fused(golden)

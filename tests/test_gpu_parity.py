@@ -1,0 +1,192 @@
+"""Parity tests proper: the HIP path (libsmc_hip.so, through the C ABI) against
+the CPU oracle on a real MI355X.  Run with ``pytest -m gpu``.
+
+Layers: (1) operator-level bit/ulp parity at sizes the oracle finishes in
+seconds; (2) the fused step loop replaying the reference's own draws for the
+golden cases (the oracle reproduces the reference bit for bit on those);
+(3) BASELINE.json's full sizes through size-independent properties (Kalman
+exact likelihood, determinism, sortedness / offspring bounds, island
+independence).
+"""
+import numpy as np
+import pytest
+
+import parity_cases as pc
+
+pytestmark = pytest.mark.gpu
+
+
+def test_real_library_is_loaded():
+    from particles_amd import _lib
+    assert b"gfx950" in _lib.lib().smc_version()
+    info = _lib.ctx().device_info()
+    assert info["n_cu"] > 0
+
+
+def test_weights(golden):
+    pc.check_weights(golden)
+    pc.check_weights_edges(3000)
+    pc.check_weights_edges(1 << 20)
+
+
+@pytest.mark.parametrize("N,M", [(5000, 5000), (1000, 3777), (4097, 1024), (700, 1),
+                                 (1 << 20, 1 << 20), (1 << 22, 1 << 20), (100003, 1 << 21)])
+def test_inverse_cdf(N, M):
+    pc.check_inverse_cdf(N, M)
+
+
+def test_inverse_cdf_dyadic():
+    pc.check_inverse_cdf_dyadic(2048, 3000)
+    pc.check_inverse_cdf_dyadic(1 << 18, 1 << 18)
+
+
+def test_schemes_vs_reference(golden):
+    pc.check_schemes_vs_reference(golden)
+
+
+@pytest.mark.parametrize("N,M", [(3000, 3000), (2049, 500), (300, 4100), (1 << 20, 1 << 20)])
+def test_schemes_replay(N, M):
+    pc.check_schemes_replay(N, M)
+
+
+def test_schemes_philox():
+    pc.check_schemes_philox(2500, 2500)
+    pc.check_schemes_philox(1 << 18, (1 << 18) + 5)
+
+
+def test_resampling_statistics():
+    pc.check_resampling_statistics(2000, 200)
+
+
+def test_unknown_scheme():
+    pc.check_unknown_scheme()
+
+
+def test_gather():
+    pc.check_gather(1 << 20, 1)
+    pc.check_gather(50000, 32)
+
+
+def test_normal(golden):
+    pc.check_normal(golden)
+    pc.check_normal_philox(1 << 20)
+
+
+def test_mvn(golden):
+    pc.check_mvn(golden)
+    pc.check_mvn_large(50000, 32)
+
+
+@pytest.mark.parametrize("case,model,fk", [
+    ("toy_systematic", "toy", "bootstrap"),      # BASELINE config C1
+    ("toy_stratified", "toy", "bootstrap"),
+    ("toy_multinomial", "toy", "bootstrap"),
+    ("sv_systematic", "sv", "bootstrap"),        # reduced C3
+    ("sv_stratified", "sv", "bootstrap"),
+    ("sv_multinomial", "sv", "bootstrap"),
+    ("lg_adaptive", "lg_adaptive", "bootstrap"),
+    ("lg_guided", "lg_guided", "guided"),
+])
+def test_filter_replay(golden, case, model, fk):
+    pc.check_filter_replay(golden, case, model, fk)
+
+
+def test_filter_stepwise(golden):
+    pc.check_filter_stepwise(golden)
+
+
+def test_filter_philox_vs_c(golden):
+    pc.check_filter_philox_vs_c(1 << 16, 100, golden)
+
+
+def test_islands(golden):
+    pc.check_islands(1500, 10, golden)
+    pc.check_islands(1 << 16, 50, golden, scheme="systematic")
+    pc.check_islands(5000, 20, golden, scheme="multinomial")
+
+
+def test_collectors_and_history(golden):
+    pc.check_collectors_on_fused(golden)
+
+
+def test_generic_path(golden):
+    pc.check_generic_path(golden)
+
+
+# ---- BASELINE.json full sizes: size-independent properties -----------------
+
+def _toy_data(golden, T):
+    import particles_amd as pa
+    from particles_amd import kalman
+    pa.seed(42)
+    x, y = kalman.ToySSM(0.2).simulate(T)
+    return y
+
+
+def test_c2_full_size_properties(golden):
+    """C2: ToySSM, N = 2^20, T = 1000, systematic."""
+    import particles_amd as pa
+    from oracle import smc_oracle as orc
+    from particles_amd import kalman
+    from particles_amd import state_space_models as ssm
+    N, T = 1 << 20, 1000
+    y = _toy_data(golden, T)
+    ll_kalman, _ = orc.kalman_loglik(orc.ToySSM(0.2), y)
+    fk = ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y)
+    runs = []
+    for seed in (1, 1, 2):
+        pf = pa.SMC(fk=fk, N=N, seed=seed)
+        pf.run()
+        runs.append(pf)
+    a, b, c = runs
+    assert a.logLt == b.logLt and np.array_equal(a.X, b.X)      # deterministic given the seed
+    assert a.logLt != c.logLt
+    for pf in (a, c):
+        assert abs(pf.logLt - ll_kalman) < 0.2                  # MC sd ~ 0.03 at this N, T
+        ess = np.array(pf.summaries.ESSs)
+        assert np.all((ess >= 1) & (ess <= N)) and all(pf.summaries.rs_flags[1:])
+        A = pf.A
+        assert np.all(np.diff(A) >= 0) and A[0] >= 0 and A[-1] < N
+        # systematic: offspring counts within {floor, ceil}(N W) of the parent weights
+    # one more step-level check at full size: offspring bounds for systematic
+    from particles_amd import resampling as rs
+    W = a.W
+    np.random.seed(0)
+    counts = np.bincount(rs.systematic(W), minlength=N)
+    assert np.all((counts >= np.floor(N * W)) & (counts <= np.ceil(N * W)))
+
+
+def test_c3_stochvol_schemes_full_size():
+    """C3: StochVol, N = 2^22, ESSrmin = 1, the three schemes agree within MC error."""
+    import particles_amd as pa
+    from particles_amd import state_space_models as ssm
+    N, T = 1 << 22, 100
+    pa.seed(42)
+    model = ssm.StochVol()
+    x, y = model.simulate(T)
+    lls = {}
+    for scheme in ("multinomial", "stratified", "systematic"):
+        pf = pa.SMC(fk=ssm.Bootstrap(ssm=model, data=y), N=N, resampling=scheme, ESSrmin=1.0,
+                    seed=7)
+        pf.run()
+        assert all(pf.summaries.rs_flags[1:]) and np.isfinite(pf.logLt)
+        assert np.all(np.diff(pf.A) >= 0)
+        lls[scheme] = pf.logLt
+    v = np.array(list(lls.values()))
+    assert np.ptp(v) < 0.05, lls
+
+
+def test_c5_islands_full_size(golden):
+    """C5 (one GPU's share): 32 islands x N = 2^18, T = 100."""
+    import particles_amd as pa
+    from oracle import smc_oracle as orc
+    from particles_amd import kalman
+    from particles_amd import state_space_models as ssm
+    y = _toy_data(golden, 100)
+    ll_kalman, _ = orc.kalman_loglik(orc.ToySSM(0.2), y)
+    pf = pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y), N=1 << 18, n_islands=32,
+                seed=11, collect="off")
+    pf.run()
+    ll = pf.logLts_islands
+    assert len(set(ll.tolist())) == 32
+    assert np.max(np.abs(ll - ll_kalman)) < 0.3 and abs(ll.mean() - ll_kalman) < 0.05
