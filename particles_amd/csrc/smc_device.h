@@ -1,15 +1,19 @@
 // smc_device.h -- device-side building blocks shared by the smc kernels.
 //
-// Workgroups are 256 threads = 4 wave64; all cross-lane code assumes 64 lanes.
-// Compiled with -ffp-contract=off: every expression that mirrors a line of the
-// reference is evaluated with the reference's roundings (no silent FMA).
+// Workgroups are 256 threads = 4 wave64; all cross-lane code assumes 64 lanes
+// and runs on the DPP path (smc_dpp.h).  Compiled with -ffp-contract=off: every
+// expression that mirrors a line of the reference is evaluated with the
+// reference's roundings (no silent FMA).
 #pragma once
 #include "smc_platform.h"
 
 #include <cmath>
 
+#include "smc_dpp.h"
+
 #define SMC_BLOCK 256
 #define SMC_NWAVE (SMC_BLOCK / 64)
+#define SMC_SM (2 * SMC_NWAVE)          /* LDS scratch slots the collectives may use */
 #define SMC_C_NORM 0.9189385332046727   /* scipy _norm_pdf_logC (distributions.py:273) */
 #define SMC_HALFLOG2PI 0.91893853320467267 /* 0.5*log(2*pi) (distributions.py:212) */
 #define SMC_Q62 4611686018427387904.0   /* 2^62 */
@@ -82,49 +86,12 @@ __host__ __device__ __forceinline__ u64 smc_q62_t(double su)
 }
 
 // ---------------------------------------------------------------------------
-// wave / workgroup collectives (256 threads)
+// workgroup collectives (256 threads).  Every thread of the workgroup must
+// call; `sm` is LDS scratch (SMC_NWAVE slots per value) that must not be in use
+// when the call starts (each routine ends with all threads past its reads only
+// after the next barrier, so callers alternate scratch areas or pass `fence`).
+// All results have a fixed association order.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ u64 smc_shfl_up_u64(u64 v, unsigned d)
-{
-    u32 lo = (u32)v, hi = (u32)(v >> 32);
-    lo = __shfl_up(lo, d);
-    hi = __shfl_up(hi, d);
-    return ((u64)hi << 32) | lo;
-}
-__device__ __forceinline__ u64 smc_shfl_xor_u64(u64 v, int m)
-{
-    u32 lo = (u32)v, hi = (u32)(v >> 32);
-    lo = __shfl_xor(lo, m);
-    hi = __shfl_xor(hi, m);
-    return ((u64)hi << 32) | lo;
-}
-__device__ __forceinline__ double smc_shfl_xor_f64(double v, int m)
-{
-    return __longlong_as_double((long long)smc_shfl_xor_u64((u64)__double_as_longlong(v), m));
-}
-
-__device__ __forceinline__ double smc_wave_max(double v)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fmax(v, smc_shfl_xor_f64(v, m));
-    return v;
-}
-// butterfly sum: every lane ends with the same value, fixed association order
-__device__ __forceinline__ double smc_wave_sum(double v)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = v + smc_shfl_xor_f64(v, m);
-    return v;
-}
-__device__ __forceinline__ u64 smc_wave_sum_u64(u64 v)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = v + smc_shfl_xor_u64(v, m);
-    return v;
-}
-
-// All four collectives below must be called by every thread of the workgroup;
-// `sm` is LDS scratch of at least SMC_NWAVE elements, reusable after return.
 __device__ __forceinline__ double smc_block_max(double v, double* sm)
 {
     v = smc_wave_max(v);
@@ -147,6 +114,20 @@ __device__ __forceinline__ double smc_block_sum(double v, double* sm)
     for (int w = 1; w < SMC_NWAVE; ++w) r = r + sm[w];
     return r;
 }
+// two sums with one LDS exchange; sm needs 2*SMC_NWAVE slots
+__device__ __forceinline__ void smc_block_sum2(double& a, double& b, double* sm)
+{
+    a = smc_wave_sum(a);
+    b = smc_wave_sum(b);
+    __syncthreads();
+    if (smc_lane() == 0) { sm[smc_wave()] = a; sm[SMC_NWAVE + smc_wave()] = b; }
+    __syncthreads();
+    double ra = sm[0], rb = sm[SMC_NWAVE];
+#pragma unroll
+    for (int w = 1; w < SMC_NWAVE; ++w) { ra = ra + sm[w]; rb = rb + sm[SMC_NWAVE + w]; }
+    a = ra;
+    b = rb;
+}
 __device__ __forceinline__ u64 smc_block_sum_u64(u64 v, u64* sm)
 {
     v = smc_wave_sum_u64(v);
@@ -161,12 +142,7 @@ __device__ __forceinline__ u64 smc_block_sum_u64(u64 v, u64* sm)
 // exclusive prefix over the workgroup's threads (thread order) + total
 __device__ __forceinline__ u64 smc_block_exscan_u64(u64 v, u64* sm, u64& total)
 {
-    u64 inc = v;
-#pragma unroll
-    for (unsigned d = 1; d < 64; d <<= 1) {
-        const u64 o = smc_shfl_up_u64(inc, d);
-        if (smc_lane() >= (int)d) inc += o;
-    }
+    const u64 inc = smc_wave_scan_u64(v, SmcOpAddU64());
     __syncthreads();
     if (smc_lane() == 63) sm[smc_wave()] = inc;
     __syncthreads();
@@ -177,6 +153,27 @@ __device__ __forceinline__ u64 smc_block_exscan_u64(u64 v, u64* sm, u64& total)
         tot += sm[w];
     }
     total = tot;
+    return base + inc - v;
+}
+// exclusive prefix of `v` over threads AND the workgroup sum of `extra`, with a
+// single LDS exchange; sm needs 2*SMC_NWAVE slots
+__device__ __forceinline__ u64 smc_block_exscan_plus_sum_u64(u64 v, u64 extra, u64* sm,
+                                                             u64& total, u64& extra_sum)
+{
+    const u64 inc = smc_wave_scan_u64(v, SmcOpAddU64());
+    const u64 es = smc_wave_sum_u64(extra);
+    __syncthreads();
+    if (smc_lane() == 63) { sm[smc_wave()] = inc; sm[SMC_NWAVE + smc_wave()] = es; }
+    __syncthreads();
+    u64 base = 0, tot = 0, et = 0;
+#pragma unroll
+    for (int w = 0; w < SMC_NWAVE; ++w) {
+        if (w < smc_wave()) base += sm[w];
+        tot += sm[w];
+        et += sm[SMC_NWAVE + w];
+    }
+    total = tot;
+    extra_sum = et;
     return base + inc - v;
 }
 
@@ -208,7 +205,7 @@ __device__ __forceinline__ void smc_lse_push(SmcLse& a, double lw)
     }
 }
 // Combine the per-thread accumulators of a workgroup: every thread returns the
-// workgroup's (m, s, ss).  Order of additions is fixed (butterfly + wave order).
+// workgroup's (m, s, ss).  sm: 2*SMC_NWAVE doubles.
 __device__ __forceinline__ SmcLse smc_lse_block(SmcLse a, double* sm)
 {
     const double m = smc_block_max(a.m, sm);
@@ -216,8 +213,9 @@ __device__ __forceinline__ SmcLse smc_lse_block(SmcLse a, double* sm)
     if (a.m > -INFINITY) sc = exp(a.m - m);
     SmcLse r;
     r.m = m;
-    r.s = smc_block_sum(a.s * sc, sm);
-    r.ss = smc_block_sum(a.ss * (sc * sc), sm);
+    r.s = a.s * sc;
+    r.ss = a.ss * (sc * sc);
+    smc_block_sum2(r.s, r.ss, sm);
     return r;
 }
 // Reduce `n` per-workgroup partials (SoA: pm, ps, pss) to the global (m,s,ss).
@@ -239,8 +237,9 @@ __device__ __forceinline__ SmcLse smc_lse_reduce_partials(const double* pm, cons
     }
     SmcLse r;
     r.m = m;
-    r.s = smc_block_sum(s, sm);
-    r.ss = smc_block_sum(ss, sm);
+    r.s = s;
+    r.ss = ss;
+    smc_block_sum2(r.s, r.ss, sm);
     return r;
 }
 

@@ -19,7 +19,7 @@
 __global__ void __launch_bounds__(SMC_BLOCK)
 k_lse_partials(double* lw, i64 N, int fix_nan, double* pm, double* ps, double* pss)
 {
-    __shared__ double sm[SMC_NWAVE];
+    __shared__ double sm[SMC_SM];
     const i64 base = (i64)blockIdx.x * LSE_CHUNK;
     SmcLse acc = smc_lse_empty();
     for (int k = 0; k < LSE_CHUNK / SMC_BLOCK; ++k) {
@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(SMC_BLOCK)
 k_lse_finalize(const double* pm, const double* ps, const double* pss, int nparts, i64 N,
                double* scal)
 {
-    __shared__ double sm[SMC_NWAVE];
+    __shared__ double sm[SMC_SM];
     const SmcLse r = smc_lse_reduce_partials(pm, ps, pss, nparts, sm);
     if (threadIdx.x == 0) {
         double log_mean, ess, s = r.s;
@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(SMC_BLOCK)
 k_wsum_partials(const double* W, const double* X, i64 N, i64 d, int mode, double shift,
                 double* part /* (nblk, d, 3) */)
 {
-    __shared__ double sm[SMC_NWAVE];
+    __shared__ double sm[SMC_SM];
     const i64 base = (i64)blockIdx.x * LSE_CHUNK;
     for (i64 c = 0; c < d; ++c) {
         double a0 = 0.0, a1 = 0.0, a2 = 0.0;
@@ -153,7 +153,7 @@ k_wsum_partials(const double* W, const double* X, i64 N, i64 d, int mode, double
 __global__ void __launch_bounds__(SMC_BLOCK)
 k_max_partials(const double* v, i64 N, double* pm)
 {
-    __shared__ double sm[SMC_NWAVE];
+    __shared__ double sm[SMC_SM];
     const i64 base = (i64)blockIdx.x * LSE_CHUNK;
     double m = -INFINITY;
     for (int k = 0; k < LSE_CHUNK / SMC_BLOCK; ++k) {
@@ -231,7 +231,7 @@ extern "C" int smc_log_wmean_exp(smc_ctx* ctx, const double* v, const double* W,
 __global__ void __launch_bounds__(SMC_BLOCK)
 k_q62_tile_sums(const double* W, i64 N, u64* Q)
 {
-    __shared__ u64 sm[SMC_NWAVE];
+    __shared__ u64 sm[SMC_SM];
     const i64 j0 = (i64)blockIdx.x * OPS_TILE + (i64)threadIdx.x * OPS_IPT;
     u64 t = 0;
 #pragma unroll
@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(SMC_BLOCK)
 k_resample_tiles(const double* W, i64 N, SmcSu su_in, const u64* Q, int ntiles, i64* A)
 {
     __shared__ u64 sC[OPS_TILE];
-    __shared__ u64 sm[SMC_NWAVE];
+    __shared__ u64 sm[SMC_SM];
     __shared__ i64 sn[2];
     const SmcSu su = smc_su_prepare(su_in);
     const int b = (int)blockIdx.x;
@@ -333,7 +333,7 @@ __device__ __forceinline__ u64 smc_spacing_q(u64 seed, u32 t, u32 island, i64 n,
 __global__ void __launch_bounds__(SMC_BLOCK)
 k_spacing_tile_sums(i64 M1, double scale, u64 seed, u32 t, u32 island, u64* E)
 {
-    __shared__ u64 sm[SMC_NWAVE];
+    __shared__ u64 sm[SMC_SM];
     const i64 n0 = (i64)blockIdx.x * OPS_TILE + (i64)threadIdx.x * OPS_IPT;
     u64 s = 0;
 #pragma unroll
@@ -347,7 +347,7 @@ __global__ void __launch_bounds__(SMC_BLOCK)
 k_spacing_write(i64 M, double scale, u64 seed, u32 t, u32 island, const u64* E, int ntiles,
                 double* su)
 {
-    __shared__ u64 sm[SMC_NWAVE];
+    __shared__ u64 sm[SMC_SM];
     const int b = (int)blockIdx.x;
     const i64 n0 = (i64)b * OPS_TILE + (i64)threadIdx.x * OPS_IPT;
     u64 q[OPS_IPT], tsum = 0;

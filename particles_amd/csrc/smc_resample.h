@@ -99,6 +99,20 @@ __device__ inline i64 smc_su_count_le(const SmcSu& s, u64 C)
     return lo;
 }
 
+// Systematic draws with M = 2^k outputs: su_n = fl(u+n) / 2^k is an exact
+// scaling, so T_n = ceil(fl(u+n) * 2^(62-k)) and, because n <= fl(u+n) <= n+1,
+//     count(C) = nc + [T_nc <= C],   nc = floor(C / 2^(62-k))
+// exactly: one shift, one add, one compare -- no division, no search.
+__device__ __forceinline__ i64 smc_sys_count_pow2(u64 C, double u, int k, i64 M)
+{
+    const int sh = 62 - k;
+    const u64 nc = C >> sh;
+    if (nc >= (u64)M) return M;
+    const double scale = __longlong_as_double((long long)(1023 + sh) << 52);   // 2^sh
+    const u64 T = (u64)ceil((u + (double)(i64)nc) * scale);
+    return (i64)nc + (T <= C ? 1 : 0);
+}
+
 // ---------------------------------------------------------------------------
 // Per-tile CDF in LDS.
 //   wq[i] (i < IPT): this thread's quantised weights, particles j0+tid*IPT+i

@@ -249,6 +249,9 @@ inline T __shfl_down(T v, unsigned d, int width = 64) {
     return hipemu::exchange(v, emu_wbase() + src);
 }
 
+struct alignas(16) uint4 { unsigned x, y, z, w; };
+inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
+
 inline unsigned __umulhi(unsigned a, unsigned b) {
     return (unsigned)(((unsigned long long)a * b) >> 32);
 }

@@ -307,10 +307,14 @@ def check_filter_replay(golden, case, model, fk, T=None):
     same = np.mean(pf.A == o["A"])
     assert same >= 0.999                                               # near-ties only
     if same == 1.0:
-        tol = 0 if model.startswith(("toy", "lg")) else 1e-12
-        assert np.max(np.abs(pf.X - o["X"])) <= tol                   # IEEE ops only: exact
-        assert rel(pf.wgts.lw, o["lw"]) < 1e-12 and rel(pf.W, o["W"]) < 1e-11
-        assert np.array_equal(pf.Xp, o["Xp"]) or tol > 0
+        exact = model.startswith(("toy", "lg"))       # IEEE + - * / only -> bit-exact
+        assert np.max(np.abs(pf.X - o["X"])) <= (0 if exact else 1e-12)
+        assert np.array_equal(pf.Xp, o["Xp"])
+        if exact and fk == "bootstrap":
+            assert np.array_equal(pf.wgts.lw, o["lw"])
+        else:     # exp/log of the device libm differ from numpy's in the last ulp
+            assert np.allclose(pf.wgts.lw, o["lw"], rtol=1e-12, atol=1e-12)
+        assert rel(pf.W, o["W"]) < 1e-10
     return pf, o
 
 
@@ -332,16 +336,17 @@ def check_filter_stepwise(golden):
     assert a.summaries.logLts == b.summaries.logLts and len(a.summaries.ESSs) == 12
 
 
-def check_filter_philox_vs_c(N, T, golden):
+def check_filter_philox_vs_c(N, T, golden, sigmaY=0.2):
     """Production (Philox) mode against the C oracle running the same counter
-    stream: integer pipeline identical, Gaussians equal to ~1 ulp."""
+    stream: integer pipeline identical, Gaussians equal to ~1 ulp.  A small
+    sigmaY makes the weights degenerate (few parents, many offspring each)."""
     g = golden("kalman_toy")
     y = np.ascontiguousarray(np.squeeze(g["y"]))[:T]
     summ = np.zeros(4 * T)
-    ll_c = orc.clib().orc_toy_filter_philox(orc._dp(y), T, N, 1.0, 1.0, 0.2, 1.0, 0.5, 2024,
+    ll_c = orc.clib().orc_toy_filter_philox(orc._dp(y), T, N, 1.0, 1.0, sigmaY, 1.0, 0.5, 2024,
                                             orc._dp(summ))
-    pf = pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=[np.array([v]) for v in y]), N=N,
-                seed=2024)
+    pf = pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(sigmaY), data=[np.array([v]) for v in y]),
+                N=N, seed=2024)
     pf.run()
     s = summ.reshape(T, 4)
     assert pf.summaries.rs_flags == [bool(v) for v in s[:, 3]]

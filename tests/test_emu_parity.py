@@ -84,8 +84,10 @@ def test_filter_stepwise(golden):
     pc.check_filter_stepwise(golden)
 
 
-def test_filter_philox_vs_c(golden):
-    pc.check_filter_philox_vs_c(3000, 15, golden)
+@pytest.mark.parametrize("N,sigmaY", [(3000, 0.2), (4096, 0.2), (1024, 0.2), (8192, 0.002),
+                                      (2048, 1e-4)])
+def test_filter_philox_vs_c(golden, N, sigmaY):
+    pc.check_filter_philox_vs_c(N, 12, golden, sigmaY)
 
 
 def test_islands(golden):

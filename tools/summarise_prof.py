@@ -1,33 +1,46 @@
-"""Summarise rocprofv3 outputs (kernel stats + PMC csv) into a small text table."""
-import csv
+"""Summarise rocprofv3 (rocpd sqlite) outputs into a small text table:
+per-kernel call count / average duration from the kernel trace, and per-kernel
+per-dispatch averages of every PMC counter collected.
+
+    python tools/summarise_prof.py gpurun_out/prof_<tag>
+"""
 import glob
 import os
+import sqlite3
 import sys
 from collections import defaultdict
 
 out = sys.argv[1]
 
-
-def find(pattern):
-    return sorted(glob.glob(os.path.join(out, "**", pattern), recursive=True))
-
-
-for f in find("*kernel_stats.csv"):
-    print("== kernel stats:", os.path.relpath(f, out))
-    for row in csv.DictReader(open(f)):
-        print("  %-60s calls %6s  avg %10.2f us  total %10.2f ms  %5s%%" % (
-            row["Name"][:60], row["Calls"], float(row["AverageNs"]) / 1e3,
-            float(row["TotalDurationNs"]) / 1e6, row["Percentage"]))
-
-for f in find("*counter_collection.csv"):
-    acc = defaultdict(lambda: defaultdict(float))
-    cnt = defaultdict(int)
-    for row in csv.DictReader(open(f)):
-        k = row["Kernel_Name"][:48]
-        acc[k][row["Counter_Name"]] += float(row["Counter_Value"])
-        cnt[(k, row["Counter_Name"])] += 1
-    print("== counters:", os.path.relpath(f, out))
-    for k, d in acc.items():
-        for c, v in sorted(d.items()):
-            n = cnt[(k, c)]
-            print("  %-48s %-24s per-dispatch avg %16.1f  (n=%d)" % (k, c, v / n, n))
+for f in sorted(glob.glob(os.path.join(out, "**", "*_results.db"), recursive=True)):
+    c = sqlite3.connect(f)
+    rel = os.path.relpath(f, out)
+    try:
+        rows = list(c.execute("select name, total_calls, total_duration, average, percentage "
+                              "from top_kernels"))
+    except sqlite3.Error:
+        rows = []
+    if rows and "trace" in rel:
+        print("== kernel trace stats:", rel)
+        for name, calls, tot, avg, pct in rows:
+            print("  %-44s calls %6d  avg %9.3f us  total %10.3f us  %5.1f%%"
+                  % (name[:44], calls, avg, tot, pct))
+    try:
+        acc = defaultdict(float)
+        cnt = defaultdict(int)
+        dur = defaultdict(float)
+        for k, cn, v, d in c.execute("select kernel_name, counter_name, value, duration "
+                                     "from counters_collection"):
+            acc[(k[:44], cn)] += v
+            cnt[(k[:44], cn)] += 1
+            dur[(k[:44], cn)] += d
+    except sqlite3.Error:
+        acc = {}
+    if acc:
+        print("== counters (per-dispatch average):", rel)
+        for (k, cn), v in sorted(acc.items()):
+            if k.startswith("__amd"):
+                continue
+            n = cnt[(k, cn)]
+            print("  %-44s %-22s %18.1f   (n=%d, avg kernel %8.2f us under PMC)"
+                  % (k, cn, v / n, n, dur[(k, cn)] / n / 1e3))
