@@ -449,9 +449,19 @@ k_move(FArgs a)
         if (zt) {
             f_load4<double, F2d>(zt, n0, N, vec, 0.0, z4);
         } else {
+#if defined(ABL_NO_RNG)
+            z4[0] = 0.1 * (double)(n0 & 15); z4[1] = -z4[0]; z4[2] = 0.3; z4[3] = -0.7;
+#elif defined(ABL_NO_BM)
+            { u64 x0, x1, x2, x3;
+              smc_philox((u32)(n0 >> 1), (u32)t, gisl, 0u, a.seed, x0, x1);
+              smc_philox((u32)(n0 >> 1) + 1u, (u32)t, gisl, 0u, a.seed, x2, x3);
+              z4[0] = smc_u01_open(x0) - 0.5; z4[1] = smc_u01_open(x1) - 0.5;
+              z4[2] = smc_u01_open(x2) - 0.5; z4[3] = smc_u01_open(x3) - 0.5; }
+#else
             smc_normal_pair(a.seed, (u32)(n0 >> 1), (u32)t, gisl, SMC_STREAM_NORMAL, z4[0], z4[1]);
             smc_normal_pair(a.seed, (u32)(n0 >> 1) + 1u, (u32)t, gisl, SMC_STREAM_NORMAL, z4[2],
                             z4[3]);
+#endif
         }
         double xo4[4] = {0.0, 0.0, 0.0, 0.0}, lo4[4] = {0.0, 0.0, 0.0, 0.0};
         if (!resample && !first) {
@@ -469,9 +479,17 @@ k_move(FArgs a)
             if (lw != lw) lw = -INFINITY;                            // resampling.py:220
             lw4[i] = lw;
             a4[i] = resample ? j0 + par[i] : n0 + i;                 // core.py:329 / :335
+#if defined(ABL_NO_LSE)
+            if (ok[i]) { acc.m = fmax(acc.m, lw); acc.s += 1.0; acc.ss += 1.0; }
+#else
             if (ok[i]) smc_lse_push(acc, lw);
+#endif
         }
         const bool full = vec && ok[0] && ok[3];
+#if defined(ABL_NO_STORE)
+        if (lw4[0] == 1.2345) f_store4<double, F2d>(Xn, n0, full, ok, xn4);
+        continue;
+#endif
         f_store4<double, F2d>(Xn, n0, full, ok, xn4);
         f_store4<double, F2d>(lwn, n0, full, ok, lw4);
         if (!first) f_store4<i64, F2u>(A, n0, full, ok, a4);

@@ -1,0 +1,89 @@
+"""The N>1 path on CPU: world_size-2 processes, gloo rendezvous, island sharding
+and the evidence gather.  (The device-side gather is RCCL inside libsmc_hip; on
+the GPU-less container the Group is created with device_collective=False, which
+exercises the same sharding / ordering logic over gloo.)"""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+WORKER = r"""
+import os, sys, json
+sys.path.insert(0, {root!r})
+sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np
+import conftest                      # selects the emulator library when there is no GPU
+conftest.pytest_configure(type("C", (), {{"addinivalue_line": lambda *a: None}})())
+import particles_amd as pa
+from particles_amd import kalman, state_space_models as ssm
+from particles_amd.distributed import Group, shard_islands, log_mean_exp_host
+
+grp = Group(device_collective=False)
+TOTAL = 6
+first, count = shard_islands(TOTAL, grp.rank, grp.world)
+rng = np.random.RandomState(42)
+x = np.cumsum(rng.standard_normal(12))
+y = [np.array([v]) for v in x + 0.2 * rng.standard_normal(12)]
+fk = ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y)
+pf = pa.SMC(fk=fk, N=1500, seed=77, n_islands=count, island_offset=first, collect="off")
+pf.run()
+grp.barrier()
+allv = grp.gather_evidence(pf.logLts_islands)
+tmax = grp.allreduce_max_host(float(grp.rank))
+if grp.rank == 0:
+    print("RESULT " + json.dumps({{"ll": allv.tolist(), "tmax": tmax, "world": grp.world,
+                                   "lme": log_mean_exp_host(allv)}}))
+grp.close()
+"""
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_world(world, tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT))
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SMC_HIP_DEVICE="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    import json
+    line = [l for l in outs[0].splitlines() if l.startswith("RESULT ")][0]
+    return json.loads(line[7:])
+
+
+def test_shard_islands_partition():
+    from particles_amd.distributed import shard_islands
+    for total in (1, 5, 8, 256):
+        for world in (1, 2, 3, 8):
+            parts = [shard_islands(total, r, world) for r in range(world)]
+            assert sum(c for _, c in parts) == total
+            assert parts[0][0] == 0
+            for (f0, c0), (f1, _) in zip(parts, parts[1:]):
+                assert f0 + c0 == f1
+
+
+def test_world2_matches_world1(tmp_path, has_gpu):
+    """Sharding 6 islands over 2 ranks gives exactly the single-process answer,
+    in global island order (results do not depend on the number of GPUs)."""
+    one = _run_world(1, tmp_path)
+    two = _run_world(2, tmp_path)
+    assert two["world"] == 2 and two["tmax"] == 1.0
+    assert len(one["ll"]) == 6 and one["ll"] == two["ll"]
+    assert one["lme"] == two["lme"]
+    assert len(set(one["ll"])) == 6

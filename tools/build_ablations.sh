@@ -1,0 +1,12 @@
+#!/bin/bash
+# builds ablation variants of libsmc_hip.so (perf experiments only; never loaded by the product)
+set -e
+cd "$(dirname "$0")/.."
+mkdir -p particles_amd/lib/abl
+for v in NO_RNG NO_BM NO_LSE NO_STORE; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math \
+    -DABL_$v particles_amd/csrc/smc_api.hip particles_amd/csrc/smc_ops.hip particles_amd/csrc/smc_filter.hip \
+    particles_amd/csrc/smc_comm.hip -o particles_amd/lib/abl/libsmc_$v.so -ldl 2>/dev/null &
+done
+wait
+ls -la particles_amd/lib/abl
