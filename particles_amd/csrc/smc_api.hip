@@ -194,3 +194,16 @@ int smc_scratch(smc_ctx* ctx, size_t bytes, void** out)
     *out = ctx->scratch;
     return SMC_OK;
 }
+
+#ifdef SMC_EMULATE
+// test hooks (emulator build only): evaluate the lean math routines on the host
+#include "smc_math.h"
+extern "C" void smc_test_exp_nonpos(const double* x, int64_t n, double* out)
+{
+    for (int64_t i = 0; i < n; ++i) out[i] = smc_exp_nonpos(x[i]);
+}
+extern "C" void smc_test_sincospi_02(const double* a, int64_t n, double* s, double* c)
+{
+    for (int64_t i = 0; i < n; ++i) smc_sincospi_02(a[i], &s[i], &c[i]);
+}
+#endif

@@ -10,6 +10,7 @@
 #include <cmath>
 
 #include "smc_dpp.h"
+#include "smc_math.h"
 
 #define SMC_BLOCK 256
 #define SMC_NWAVE (SMC_BLOCK / 64)
@@ -38,10 +39,9 @@ __device__ __forceinline__ void smc_philox(u32 c0, u32 c1, u32 c2, u32 c3, u64 s
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         if (r > 0) { k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
-        const u32 hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const u32 hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        const u32 n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
-        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        const u64 p0 = (u64)0xD2511F53u * c0, p1 = (u64)0xCD9E8D57u * c2;   // v_mad_u64_u32
+        const u32 n0 = (u32)(p1 >> 32) ^ c1 ^ k0, n2 = (u32)(p0 >> 32) ^ c3 ^ k1;
+        c0 = n0; c1 = (u32)p1; c2 = n2; c3 = (u32)p0;
     }
     x01 = ((u64)c1 << 32) | c0;
     x23 = ((u64)c3 << 32) | c2;
@@ -67,7 +67,7 @@ __device__ __forceinline__ void smc_normal_pair(u64 seed, u32 pair, u32 t, u32 i
     smc_philox(pair, t, island, stream, seed, a, b);
     const double r = sqrt(-2.0 * log(smc_u01_open(a)));
     double sn, cs;
-    sincospi(2.0 * smc_u01_open(b), &sn, &cs);
+    smc_sincospi_02(2.0 * smc_u01_open(b), &sn, &cs);
     z0 = r * cs;
     z1 = r * sn;
 }
@@ -194,7 +194,7 @@ __device__ __forceinline__ void smc_lse_push(SmcLse& a, double lw)
 {
     if (!(lw > -INFINITY)) return;             // -inf (and NaN, sanitised earlier) weigh 0
     const double d = lw - a.m;                 // +inf on the first element
-    const double e = exp(-fabs(d));
+    const double e = smc_exp_nonpos(-fabs(d));
     if (d > 0.0) {
         a.s = a.s * e + 1.0;
         a.ss = a.ss * (e * e) + 1.0;
@@ -210,7 +210,7 @@ __device__ __forceinline__ SmcLse smc_lse_block(SmcLse a, double* sm)
 {
     const double m = smc_block_max(a.m, sm);
     double sc = 0.0;
-    if (a.m > -INFINITY) sc = exp(a.m - m);
+    if (a.m > -INFINITY) sc = smc_exp_nonpos(a.m - m);
     SmcLse r;
     r.m = m;
     r.s = a.s * sc;
@@ -230,7 +230,7 @@ __device__ __forceinline__ SmcLse smc_lse_reduce_partials(const double* pm, cons
     for (int i = (int)threadIdx.x; i < n; i += SMC_BLOCK) {
         const double mi = pm[i];
         if (mi > -INFINITY) {
-            const double sc = exp(mi - m);
+            const double sc = smc_exp_nonpos(mi - m);
             s += ps[i] * sc;
             ss += pss[i] * (sc * sc);
         }

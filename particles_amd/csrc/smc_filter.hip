@@ -121,6 +121,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     const size_t oPar = carve(M * PARAM_STRIDE * 8);
     const size_t oY = carve(T * 8);
     const size_t oCtl = carve(64);
+    const size_t oInfo = carve(M * INFO_STRIDE * 8);
     const size_t oSu = carve(need_su ? M * N * 8 : 8);
     const size_t oE = carve(need_su ? M * a.ntiles1 * 8 : 8);
     const size_t oTmp = carve(N * 8);
@@ -145,12 +146,14 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     a.params = dpar;
     a.y = dy;
     a.ctl = (i64*)(base + oCtl);
+    a.info = (double*)(base + oInfo);
     a.su = (double*)(base + oSu);
     a.E = (u64*)(base + oE);
     f->tmp = (double*)(base + oTmp);
     hipStream_t st = ctx->stream;
     SMC_HIP_CHECK(hipMemsetAsync(a.summ, 0, M * (T + 1) * SUMM_STRIDE * 8, st));
     SMC_HIP_CHECK(hipMemsetAsync(a.ctl, 0, 64, st));
+    SMC_HIP_CHECK(hipMemsetAsync(a.info, 0, M * INFO_STRIDE * 8, st));
     SMC_HIP_CHECK(hipMemsetAsync(a.A, 0, M * N * 8, st));
     SMC_HIP_CHECK(hipMemcpyAsync(dpar, model->params_host, M * PARAM_STRIDE * 8,
                                  hipMemcpyHostToDevice, st));

@@ -42,6 +42,7 @@
 #define F_PASS (SMC_BLOCK * 4)      /* offspring per pass: 4 per thread */
 #define SUMM_STRIDE 8   /* ESS, log_mean, loglt, logLt, rs_flag, m, s, - */
 #define PARAM_STRIDE 16
+#define INFO_STRIDE 8     /* per-island step record written by k_prepare: t, flag, y_t, m, 1/s */
 
 struct FArgs {
     i64 N, T;
@@ -57,7 +58,8 @@ struct FArgs {
     double* summ;          // (n_islands, T+1, SUMM_STRIDE)
     const double* params;  // (n_islands, PARAM_STRIDE)
     const double* y;       // (T,)
-    i64* ctl;              // [0] = t seen by k_prepare, [1] = t seen by k_move
+    i64* ctl;              // [0] = time index of the next step (advanced by k_move)
+    double* info;          // (n_islands, INFO_STRIDE) record of the step being run
     const double* zt;      // replay normals (T, n_islands, N) or null
     const double* ut;      // replay uniforms (T, n_islands, K) or null
     i64 ut_stride;         // K
@@ -134,7 +136,7 @@ __device__ __forceinline__ double m_step(const double* p, bool first, double y, 
 // W_i as the device defines it: exp(lw_i - m) * (1/s)   (resampling.py:222,225)
 __device__ __forceinline__ double f_weight(double lw, double m, double rs)
 {
-    return exp(lw - m) * rs;
+    return smc_exp_nonpos(lw - m) * rs;
 }
 
 // ---------------------------------------------------------------------------
@@ -181,9 +183,21 @@ k_prepare(FArgs a, int finalize_only)
     __shared__ u64 smu[SMC_SM];
     const int b = (int)blockIdx.x, isl = (int)blockIdx.y;
     const i64 t = a.ctl[0];
-    if (b == 0 && isl == 0 && threadIdx.x == 0) a.ctl[1] = t;
-    if (t == 0) return;               // nothing to finalise; step 0 never resamples
+    double* info = a.info + (i64)isl * INFO_STRIDE;
+    if (t == 0) {                     // nothing to finalise; step 0 never resamples
+        if (b == 0 && threadIdx.x == 0) {
+            info[0] = 0.0; info[1] = 0.0; info[2] = a.y[0]; info[3] = 0.0; info[4] = 0.0;
+        }
+        return;
+    }
     const i64 tp = t - 1;
+    // issue this tile's log-weight loads first: their latency hides behind the
+    // reduction of the partials below (they are only used when resampling)
+    const double* lw = ((tp & 1) ? a.lw1 : a.lw0) + (i64)isl * a.N;
+    const bool vec = (a.N & 3) == 0;
+    const i64 j0 = (i64)b * F_TILE + (i64)threadIdx.x * F_IPT;
+    double l4[4];
+    if (t < a.T && !finalize_only) f_load4<double, F2d>(lw, j0, a.N, vec, -INFINITY, l4);
     const double* pm = a.pm + (i64)isl * a.ntiles;
     const double* ps = a.ps + (i64)isl * a.ntiles;
     const double* pss = a.pss + (i64)isl * a.ntiles;
@@ -205,16 +219,18 @@ k_prepare(FArgs a, int finalize_only)
         row[3] = logLt;
         row[5] = r.m;
         row[6] = bad ? NAN : rs;
-        if (t < a.T) row[SUMM_STRIDE + 4] = flag ? 1.0 : 0.0;
+        if (t < a.T) {
+            row[SUMM_STRIDE + 4] = flag ? 1.0 : 0.0;
+            // everything k_move(t) needs, in one 64-byte record
+            info[0] = (double)t; info[1] = flag ? 1.0 : 0.0; info[2] = a.y[t];
+            info[3] = r.m; info[4] = rs;
+        } else {
+            info[0] = (double)t;
+        }
     }
     if (t >= a.T || finalize_only || !flag) return;
     // Q62 weights of step t-1's particles (the parents of step t) + tile total
-    const double* lw = ((tp & 1) ? a.lw1 : a.lw0) + (i64)isl * a.N;
     u64* q = a.q + (i64)isl * a.N;
-    const bool vec = (a.N & 3) == 0;
-    const i64 j0 = (i64)b * F_TILE + (i64)threadIdx.x * F_IPT;
-    double l4[4];
-    f_load4<double, F2d>(lw, j0, a.N, vec, -INFINITY, l4);
     u64 q4[4], s = 0;
     bool ok[4];
 #pragma unroll
@@ -244,9 +260,9 @@ k_f_spacing_sums(FArgs a)
 {
     __shared__ u64 smu[SMC_SM];
     const int b = (int)blockIdx.x, isl = (int)blockIdx.y;
-    const i64 t = a.ctl[1];
-    if (t >= a.T || t == 0) return;
-    if (a.summ[((i64)isl * (a.T + 1) + t) * SUMM_STRIDE + 4] == 0.0) return;
+    const double* info = a.info + (i64)isl * INFO_STRIDE;
+    const i64 t = (i64)info[0];
+    if (t >= a.T || t == 0 || info[1] == 0.0) return;
     const i64 n0 = (i64)b * F_TILE + (i64)threadIdx.x * F_IPT;
     u64 s = 0;
 #pragma unroll
@@ -261,9 +277,9 @@ k_f_spacing_write(FArgs a)
 {
     __shared__ u64 smu[SMC_SM];
     const int b = (int)blockIdx.x, isl = (int)blockIdx.y;
-    const i64 t = a.ctl[1];
-    if (t >= a.T || t == 0) return;
-    if (a.summ[((i64)isl * (a.T + 1) + t) * SUMM_STRIDE + 4] == 0.0) return;
+    const double* info = a.info + (i64)isl * INFO_STRIDE;
+    const i64 t = (i64)info[0];
+    if (t >= a.T || t == 0 || info[1] == 0.0) return;
     const u64* E = a.E + (i64)isl * a.ntiles1;
     const i64 n0 = (i64)b * F_TILE + (i64)threadIdx.x * F_IPT;
     u64 q[F_IPT], tsum = 0;
@@ -308,13 +324,14 @@ k_move(FArgs a)
     __shared__ u32 smx[SMC_NWAVE];
     const int b = (int)blockIdx.x, isl = (int)blockIdx.y;
     const int tid = (int)threadIdx.x;
-    const i64 t = a.ctl[1];
+    const double* info = a.info + (i64)isl * INFO_STRIDE;
+    const i64 t = (i64)info[0];
     if (t >= a.T) return;
     if (b == 0 && isl == 0 && tid == 0) a.ctl[0] = t + 1;
 
     const i64 N = a.N;
     const double* p = a.params + (i64)isl * PARAM_STRIDE;
-    const double yt = a.y[t];
+    const double yt = info[2];
     const u32 gisl = (u32)(a.island_offset + isl);
     const int cur = (int)(t & 1);
     double* Xn = (cur ? a.X1 : a.X0) + (i64)isl * N;
@@ -323,9 +340,8 @@ k_move(FArgs a)
     const double* lwo = (cur ? a.lw0 : a.lw1) + (i64)isl * N;
     i64* A = a.A + (i64)isl * N;
     const double* zt = a.zt ? a.zt + ((i64)t * a.n_islands + isl) * N : nullptr;
-    const double* row = a.summ + ((i64)isl * (a.T + 1) + t) * SUMM_STRIDE;
     const bool first = (t == 0);
-    const bool resample = !first && row[4] != 0.0;
+    const bool resample = !first && info[1] != 0.0;
     const bool vec = (N & 3) == 0;
     const i64 j0 = (i64)b * F_TILE;
 
@@ -373,10 +389,14 @@ k_move(FArgs a)
         if (scatter) {
             // first offspring of each parent, closed form (smc_resample.h)
             u64 c = cex;
+            const u64 Us = (u64)(su.u_sys *
+                                 __longlong_as_double((long long)(1023 + 62 - a.log2N) << 52));
 #pragma unroll
             for (int i = 0; i <= F_IPT; ++i) {
                 const i64 j = jt + i;
-                ns[i] = (j == 0) ? 0 : (j >= N ? N : smc_sys_count_pow2(c, su.u_sys, a.log2N, N));
+                ns[i] = (j == 0) ? 0
+                                 : (j >= N ? N
+                                           : smc_sys_count_pow2_fast(c, su.u_sys, Us, a.log2N, N));
                 if (i < F_IPT) c += q4[i];
             }
             if (tid == 0) sn[0] = ns[0];

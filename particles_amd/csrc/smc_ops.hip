@@ -72,7 +72,7 @@ k_lse_write_W(const double* lw, i64 N, const double* scal, double* W)
     if (i < N) {
         double v = lw[i];
         if (v != v) v = -INFINITY;
-        W[i] = exp(v - m) / s;                            // resampling.py:222,225
+        W[i] = smc_exp_nonpos(v - m) / s;                 // resampling.py:222,225
     }
 }
 

@@ -112,6 +112,21 @@ __device__ __forceinline__ i64 smc_sys_count_pow2(u64 C, double u, int k, i64 M)
     const u64 T = (u64)ceil((u + (double)(i64)nc) * scale);
     return (i64)nc + (T <= C ? 1 : 0);
 }
+// Integer-only shortcut of the same function.  fl(u+n) differs from u+n by at
+// most half an ulp of a number below 2^k, i.e. T_n = n 2^sh + u 2^sh +- 2^(sh+k-53)
+// = n 2^sh + Us +- 512 with Us = floor(u 2^sh).  So unless the fractional part
+// of C (below 2^sh) is within 1024 of Us, the comparison T_nc <= C is decided by
+// integers alone; the rare near-boundary case takes the exact path above.
+__device__ __forceinline__ i64 smc_sys_count_pow2_fast(u64 C, double u, u64 Us, int k, i64 M)
+{
+    const int sh = 62 - k;
+    const u64 nc = C >> sh;
+    if (nc >= (u64)M) return M;
+    const u64 frac = C & ((1ull << sh) - 1ull);
+    if (frac >= Us + 1024ull) return (i64)nc + 1;
+    if (frac + 1024ull <= Us) return (i64)nc;
+    return smc_sys_count_pow2(C, u, k, M);
+}
 
 // ---------------------------------------------------------------------------
 // Per-tile CDF in LDS.

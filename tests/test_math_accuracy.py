@@ -1,0 +1,69 @@
+"""Accuracy of the lean fp64 elementary functions (csrc/smc_math.h) against
+numpy's libm, evaluated on the host through the emulator build."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+
+
+@pytest.fixture(scope="module")
+def emu():
+    import build_emu
+    L = ctypes.CDLL(build_emu.build())
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def ulps(got, want):
+    return np.abs(got - want) / np.spacing(np.abs(want))
+
+
+def test_exp_nonpos(emu):
+    rng = np.random.default_rng(0)
+    x = np.concatenate([-rng.exponential(1.0, 200000), -rng.uniform(0, 745, 200000),
+                        -10.0 ** rng.uniform(-300, -1, 50000),
+                        np.array([0.0, -0.0, -1e-320, -708.0, -745.0, -745.13, -746.0, -1e4,
+                                  -np.inf])])
+    out = np.empty_like(x)
+    emu.smc_test_exp_nonpos(_p(x), x.size, _p(out))
+    want = np.exp(x)
+    norm = want > 1e-300
+    assert ulps(out[norm], want[norm]).max() <= 1.0
+    assert np.all(out[~norm] >= 0) and np.allclose(out[~norm], want[~norm], atol=1e-300)
+    assert out[-1] == 0.0 and out[0 - 9] == 1.0
+    nan = np.array([np.nan])
+    o = np.empty(1)
+    emu.smc_test_exp_nonpos(_p(nan), 1, _p(o))
+    assert np.isnan(o[0])
+
+
+def test_sincospi_02(emu):
+    rng = np.random.default_rng(1)
+    a = np.concatenate([rng.uniform(0, 2, 400000), ((rng.integers(0, 2 ** 52, 100000) + 0.5) * 2.0 ** -52) * 2,
+                        np.array([0.0, 0.25, 0.5, 0.75, 1.0, 1.25, 1.5, 1.75, 2.0, 2.0 ** -52, 1e-300])])
+    s = np.empty_like(a)
+    c = np.empty_like(a)
+    emu.smc_test_sincospi_02(_p(a), a.size, _p(s), _p(c))
+    al = a.astype(np.longdouble)
+    ws = np.sin(np.pi * al.astype(np.longdouble) * (np.longdouble(np.pi) / np.longdouble(float(np.pi)))) if False else None
+    # reference in extended precision: sin(pi a) with pi in long double
+    pi_l = np.longdouble("3.14159265358979323846264338327950288")
+    ws = np.sin(pi_l * al).astype(np.float64)
+    wc = np.cos(pi_l * al).astype(np.float64)
+    # absolute error relative to the unit circle (what Box-Muller needs) ...
+    assert np.max(np.abs(s - ws)) < 2.3e-16 and np.max(np.abs(c - wc)) < 2.3e-16
+    # ... and relative error away from the zeros
+    big = np.abs(ws) > 1e-3
+    assert ulps(s[big], ws[big]).max() <= 2.0
+    big = np.abs(wc) > 1e-3
+    assert ulps(c[big], wc[big]).max() <= 2.0
+    assert s[-11] == 0.0 and c[-11] == 1.0 and s[-9] == 1.0 and c[-7] == -1.0
