@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--log2N", type=int, default=20)
     ap.add_argument("--scheme", default="systematic")
     ap.add_argument("--islands", type=int, default=1, help="filters per GPU")
+    ap.add_argument("--essrmin", type=float, default=0.5)
     ap.add_argument("--cpu-steps", type=int, default=150)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
@@ -99,7 +100,7 @@ def main():
     fk = ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y)
 
     def make(profile=False):
-        pf = pa.SMC(fk=fk, N=N, resampling=a.scheme, ESSrmin=0.5, collect="off", seed=123,
+        pf = pa.SMC(fk=fk, N=N, resampling=a.scheme, ESSrmin=a.essrmin, collect="off", seed=123,
                     n_islands=a.islands, island_offset=rank * a.islands,
                     use_graph=not (a.no_graph or profile))
         if profile:

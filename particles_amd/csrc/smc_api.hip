@@ -202,6 +202,10 @@ extern "C" void smc_test_exp_nonpos(const double* x, int64_t n, double* out)
 {
     for (int64_t i = 0; i < n; ++i) out[i] = smc_exp_nonpos(x[i]);
 }
+extern "C" void smc_test_log_pos(const double* x, int64_t n, double* out)
+{
+    for (int64_t i = 0; i < n; ++i) out[i] = smc_log_pos(x[i]);
+}
 extern "C" void smc_test_sincospi_02(const double* a, int64_t n, double* s, double* c)
 {
     for (int64_t i = 0; i < n; ++i) smc_sincospi_02(a[i], &s[i], &c[i]);

@@ -65,7 +65,7 @@ __device__ __forceinline__ void smc_normal_pair(u64 seed, u32 pair, u32 t, u32 i
 {
     u64 a, b;
     smc_philox(pair, t, island, stream, seed, a, b);
-    const double r = sqrt(-2.0 * log(smc_u01_open(a)));
+    const double r = sqrt(-2.0 * smc_log_pos(smc_u01_open(a)));
     double sn, cs;
     smc_sincospi_02(2.0 * smc_u01_open(b), &sn, &cs);
     z0 = r * cs;

@@ -43,7 +43,7 @@ static void enqueue_step(smc_filter* f, int k_prof)
     hipStream_t st = f->ctx->stream;
     const dim3 grid(f->a.ntiles, f->a.n_islands);
     if (k_prof >= 0) (void)hipEventRecord(f->ev[3 * k_prof], st);
-    SMC_LAUNCH(k_prepare, grid, dim3(SMC_BLOCK), st, f->a, 0);
+    SMC_LAUNCH(k_prepare, grid, dim3(SMC_BLOCK), st, f->a);
     if (f->a.scheme == SMC_MULTINOMIAL && !f->a.ut) {
         const dim3 g1(f->a.ntiles1, f->a.n_islands);
         SMC_LAUNCH(k_f_spacing_sums, g1, dim3(SMC_BLOCK), st, f->a);
@@ -115,12 +115,13 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     const size_t oA = carve(M * N * 8);
     const size_t oq = carve(M * N * 8);
     const size_t oQ = carve(M * a.ntiles * 8);
+    const size_t oQpre = carve(M * a.ntiles * 8);
     const size_t oPm = carve(M * a.ntiles * 8), oPs = carve(M * a.ntiles * 8),
                  oPss = carve(M * a.ntiles * 8);
     const size_t oSum = carve(M * (T + 1) * SUMM_STRIDE * 8);
     const size_t oPar = carve(M * PARAM_STRIDE * 8);
     const size_t oY = carve(T * 8);
-    const size_t oCtl = carve(64);
+    const size_t oCtl = carve(M * 2 * sizeof(unsigned) + 64);
     const size_t oInfo = carve(M * INFO_STRIDE * 8);
     const size_t oSu = carve(need_su ? M * N * 8 : 8);
     const size_t oE = carve(need_su ? M * a.ntiles1 * 8 : 8);
@@ -139,21 +140,27 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     a.A = (i64*)(base + oA);
     a.q = (u64*)(base + oq);
     a.Q = (u64*)(base + oQ);
+    a.Qpre = (u64*)(base + oQpre);
     a.pm = (double*)(base + oPm); a.ps = (double*)(base + oPs); a.pss = (double*)(base + oPss);
     a.summ = (double*)(base + oSum);
     double* dpar = (double*)(base + oPar);
     double* dy = (double*)(base + oY);
     a.params = dpar;
     a.y = dy;
-    a.ctl = (i64*)(base + oCtl);
+    a.cnt = (unsigned*)(base + oCtl);
     a.info = (double*)(base + oInfo);
     a.su = (double*)(base + oSu);
     a.E = (u64*)(base + oE);
     f->tmp = (double*)(base + oTmp);
     hipStream_t st = ctx->stream;
     SMC_HIP_CHECK(hipMemsetAsync(a.summ, 0, M * (T + 1) * SUMM_STRIDE * 8, st));
-    SMC_HIP_CHECK(hipMemsetAsync(a.ctl, 0, 64, st));
-    SMC_HIP_CHECK(hipMemsetAsync(a.info, 0, M * INFO_STRIDE * 8, st));
+    SMC_HIP_CHECK(hipMemsetAsync(a.cnt, 0, M * 2 * sizeof(unsigned), st));
+    {   // step record of t = 0: {t, rs_flag, y_0, m, 1/s}
+        std::vector<double> h(M * INFO_STRIDE, 0.0);
+        for (size_t i = 0; i < M; ++i) h[i * INFO_STRIDE + 2] = y_host[0];
+        SMC_HIP_CHECK(hipMemcpyAsync(a.info, h.data(), h.size() * 8, hipMemcpyHostToDevice, st));
+        SMC_HIP_CHECK(hipStreamSynchronize(st));
+    }
     SMC_HIP_CHECK(hipMemsetAsync(a.A, 0, M * N * 8, st));
     SMC_HIP_CHECK(hipMemcpyAsync(dpar, model->params_host, M * PARAM_STRIDE * 8,
                                  hipMemcpyHostToDevice, st));
@@ -228,8 +235,6 @@ int smc_filter_step(smc_filter* f, int64_t nsteps)
         if (f->prof && f->prof_n < PROF_MAX) kp = f->prof_n++;
         enqueue_step(f, kp);
     }
-    // finalise the summaries of the last step run (idempotent)
-    SMC_LAUNCH(k_prepare, dim3(f->a.ntiles, f->a.n_islands), dim3(SMC_BLOCK), st, f->a, 1);
     SMC_LAUNCH_CHECK();
     f->t_host += todo;
     return SMC_OK;

@@ -9,26 +9,28 @@
 //
 // Two kernels per time step, no host round trip, no in-kernel spinning:
 //
-//   k_prepare(t): every workgroup reduces the per-workgroup log-sum-exp
-//       partials of step t-1 to (max, sum, sum of squares) -> ESS, log-mean
-//       weight and the resample decision of step t (core.py:181-183); if
-//       resampling, it converts its tile of log-weights to Q62 fixed point,
-//       q_i = rint(exp(lw_i-m)/s * 2^62), stores them and the tile total.
+//   k_prepare(t): only when step t resamples.  Converts its tile of
+//       log-weights to Q62 fixed point, q_i = rint(exp(lw_i-m)/s * 2^62), stores
+//       them and the tile total; the LAST workgroup to finish (atomic ticket)
+//       turns the tile totals into exclusive prefixes (exact integer scan).
 //   k_move(t): one workgroup per tile of 1024 consecutive parents.  From the q
-//       of its tile and the totals of the preceding tiles it knows the exact CDF
-//       of its parents, hence the contiguous range of offspring it owns
+//       of its tile and its exclusive prefix it knows the exact CDF of its
+//       parents, hence the contiguous range of offspring it owns
 //       (smc_resample.h).  Offspring are produced 4 per thread per pass:
 //         systematic, N a power of two: closed-form first-offspring index per
 //           parent, scattered into LDS and expanded by a max-scan (no search);
 //         otherwise: per-offspring binary search in the tile's CDF in LDS;
-//       then gather of the parent state from LDS, propagation
-//       x = loc(xp)+scale*z with a counted Philox normal (or a replayed draw),
-//       the weight increment log G, coalesced 32-byte stores of (A, X, lw) and
-//       the online log-sum-exp partial of the new weights.
+//       then, pair by pair so that stores overlap the next pair's arithmetic:
+//       gather of the parent state from LDS, propagation x = loc(xp)+scale*z
+//       with a counted Philox normal (or a replayed draw), the weight increment
+//       log G, 16-byte stores of (A, X, lw) and the online log-sum-exp partial.
+//       The LAST workgroup of each island to finish reduces the partials to
+//       (max, sum, sum of squares) -> ESS, log-mean weight, loglt/logLt of step
+//       t (core.py:355-359), the resample decision of step t+1 (core.py:181-183)
+//       and writes the 64-byte step record the next launches read.
 //
-// The time index lives in device memory (ctl[0]/ctl[1], ping-ponged between the
-// two kernels) so the same launches -- or one hipGraph holding many of them --
-// serve every step.
+// The time index lives in that device-resident record, so the same two launches
+// -- or one hipGraph holding many of them -- serve every step.
 //
 // HBM traffic per particle-step on a resampling step (d = 1):
 //   k_prepare: read lw (8), write q (8);  k_move: read q, X (16), write A, X, lw (24)
@@ -40,9 +42,9 @@
 #define F_IPT 4
 #define F_TILE (SMC_BLOCK * F_IPT)
 #define F_PASS (SMC_BLOCK * 4)      /* offspring per pass: 4 per thread */
-#define SUMM_STRIDE 8   /* ESS, log_mean, loglt, logLt, rs_flag, m, s, - */
+#define SUMM_STRIDE 8   /* ESS, log_mean, loglt, logLt, rs_flag, m, 1/s, - */
 #define PARAM_STRIDE 16
-#define INFO_STRIDE 8     /* per-island step record written by k_prepare: t, flag, y_t, m, 1/s */
+#define INFO_STRIDE 8   /* per-island step record: t, rs_flag, y_t, m, 1/s of step t-1 */
 
 struct FArgs {
     i64 N, T;
@@ -54,11 +56,12 @@ struct FArgs {
     i64* A;
     u64* q;                // (n_islands, N) Q62 weights of the parents
     u64* Q;                // (n_islands, ntiles) tile totals of q
-    double *pm, *ps, *pss;
+    u64* Qpre;             // (n_islands, ntiles) exclusive prefixes of Q
+    double *pm, *ps, *pss; // (n_islands, ntiles) log-sum-exp partials
+    unsigned* cnt;         // (n_islands, 2) completion tickets: k_move, k_prepare
     double* summ;          // (n_islands, T+1, SUMM_STRIDE)
     const double* params;  // (n_islands, PARAM_STRIDE)
     const double* y;       // (T,)
-    i64* ctl;              // [0] = time index of the next step (advanced by k_move)
     double* info;          // (n_islands, INFO_STRIDE) record of the step being run
     const double* zt;      // replay normals (T, n_islands, N) or null
     const double* ut;      // replay uniforms (T, n_islands, K) or null
@@ -140,10 +143,11 @@ __device__ __forceinline__ double f_weight(double lw, double m, double rs)
 }
 
 // ---------------------------------------------------------------------------
-// 4 consecutive elements per thread, as two 16-byte accesses when possible
+// 2 / 4 consecutive elements per thread as 16-byte accesses when possible
 // ---------------------------------------------------------------------------
 struct alignas(16) F2u { u64 a, b; };
 struct alignas(16) F2d { double a, b; };
+struct alignas(16) F2i { i64 a, b; };
 
 template <class T, class T2>
 __device__ __forceinline__ void f_load4(const T* p, i64 j, i64 N, bool vec, T fill, T (&o)[4])
@@ -172,76 +176,84 @@ __device__ __forceinline__ void f_store4(T* p, i64 n, bool full_vec, const bool 
             if (ok[i]) p[n + i] = v[i];
     }
 }
+template <class T, class T2>
+__device__ __forceinline__ void f_store2(T* p, i64 n, bool vec2, bool ok0, bool ok1, T v0, T v1)
+{
+    if (vec2 && ok0 && ok1) {
+        T2 v;
+        v.a = v0; v.b = v1;
+        *reinterpret_cast<T2*>(p + n) = v;
+    } else {
+        if (ok0) p[n] = v0;
+        if (ok1) p[n + 1] = v1;
+    }
+}
+
+// Ticket of the "last workgroup done" pattern: every workgroup publishes its
+// result, fences, and takes a ticket; the one that draws the last ticket sees
+// (after its own fence) everything the others published.  hipMalloc'ed memory
+// is coherent across the XCD L2s at agent scope, so plain loads after the fence
+// are enough; nobody spins.  Returns true in every thread of the last workgroup.
+__device__ __forceinline__ bool f_last_block(unsigned* ticket, unsigned nblocks, int* s_flag)
+{
+    __syncthreads();                         // this workgroup's global stores are issued
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned prev = atomicAdd(ticket, 1u);
+        *s_flag = (prev == nblocks - 1u);
+    }
+    __syncthreads();
+    const bool last = *s_flag != 0;
+    if (last) __threadfence();
+    return last;
+}
 
 // ---------------------------------------------------------------------------
 // k_prepare
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(SMC_BLOCK)
-k_prepare(FArgs a, int finalize_only)
+k_prepare(FArgs a)
 {
-    __shared__ double smd[SMC_SM];
     __shared__ u64 smu[SMC_SM];
+    __shared__ int s_last;
     const int b = (int)blockIdx.x, isl = (int)blockIdx.y;
-    const i64 t = a.ctl[0];
-    double* info = a.info + (i64)isl * INFO_STRIDE;
-    if (t == 0) {                     // nothing to finalise; step 0 never resamples
-        if (b == 0 && threadIdx.x == 0) {
-            info[0] = 0.0; info[1] = 0.0; info[2] = a.y[0]; info[3] = 0.0; info[4] = 0.0;
-        }
-        return;
-    }
-    const i64 tp = t - 1;
-    // issue this tile's log-weight loads first: their latency hides behind the
-    // reduction of the partials below (they are only used when resampling)
-    const double* lw = ((tp & 1) ? a.lw1 : a.lw0) + (i64)isl * a.N;
+    const double* info = a.info + (i64)isl * INFO_STRIDE;
+    const i64 t = (i64)info[0];
+    if (t >= a.T || info[1] == 0.0) return;          // step t does not resample
+    const double m = info[3], rs = info[4];
+    // Q62 weights of step t-1's particles (the parents of step t) + tile total
+    const double* lw = (((t - 1) & 1) ? a.lw1 : a.lw0) + (i64)isl * a.N;
+    u64* q = a.q + (i64)isl * a.N;
     const bool vec = (a.N & 3) == 0;
     const i64 j0 = (i64)b * F_TILE + (i64)threadIdx.x * F_IPT;
     double l4[4];
-    if (t < a.T && !finalize_only) f_load4<double, F2d>(lw, j0, a.N, vec, -INFINITY, l4);
-    const double* pm = a.pm + (i64)isl * a.ntiles;
-    const double* ps = a.ps + (i64)isl * a.ntiles;
-    const double* pss = a.pss + (i64)isl * a.ntiles;
-    const SmcLse r = smc_lse_reduce_partials(pm, ps, pss, a.ntiles, smd);
-    const bool bad = !(r.m > -INFINITY) || !(r.m < INFINITY);
-    const double ess = bad ? NAN : (r.s * r.s) / r.ss;                  // resampling.py:226
-    const double log_mean = bad ? NAN : r.m + log(r.s / (double)a.N);   // resampling.py:224
-    const bool flag = (t < a.T) && (ess < a.ess_thresh);                // core.py:181-183
-    const double rs = 1.0 / r.s;
-    if (b == 0 && threadIdx.x == 0) {
-        double* row = a.summ + ((i64)isl * (a.T + 1) + tp) * SUMM_STRIDE;
-        double loglt, logLt;                                            // core.py:355-359
-        if (tp == 0 || row[4] != 0.0) loglt = log_mean;
-        else loglt = log_mean - row[1 - SUMM_STRIDE];
-        logLt = (tp == 0 ? 0.0 : row[3 - SUMM_STRIDE]) + loglt;
-        row[0] = ess;
-        row[1] = log_mean;
-        row[2] = loglt;
-        row[3] = logLt;
-        row[5] = r.m;
-        row[6] = bad ? NAN : rs;
-        if (t < a.T) {
-            row[SUMM_STRIDE + 4] = flag ? 1.0 : 0.0;
-            // everything k_move(t) needs, in one 64-byte record
-            info[0] = (double)t; info[1] = flag ? 1.0 : 0.0; info[2] = a.y[t];
-            info[3] = r.m; info[4] = rs;
-        } else {
-            info[0] = (double)t;
-        }
-    }
-    if (t >= a.T || finalize_only || !flag) return;
-    // Q62 weights of step t-1's particles (the parents of step t) + tile total
-    u64* q = a.q + (i64)isl * a.N;
+    f_load4<double, F2d>(lw, j0, a.N, vec, -INFINITY, l4);
     u64 q4[4], s = 0;
     bool ok[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         ok[i] = j0 + i < a.N;
-        q4[i] = ok[i] ? smc_q62_w(f_weight(l4[i], r.m, rs)) : 0ull;
+        q4[i] = ok[i] ? smc_q62_w(f_weight(l4[i], m, rs)) : 0ull;
         s += q4[i];
     }
     f_store4<u64, F2u>(q, j0, vec && ok[3], ok, q4);
     s = smc_block_sum_u64(s, smu);
-    if (threadIdx.x == 0) a.Q[(i64)isl * a.ntiles + b] = s;
+    u64* Q = a.Q + (i64)isl * a.ntiles;
+    if (threadIdx.x == 0) Q[b] = s;
+    if (!f_last_block(a.cnt + isl * 2 + 1, (unsigned)a.ntiles, &s_last)) return;
+    // last workgroup: exclusive prefixes of the tile totals (exact integers)
+    u64* Qpre = a.Qpre + (i64)isl * a.ntiles;
+    const int per = (a.ntiles + SMC_BLOCK - 1) / SMC_BLOCK;
+    const int i0 = (int)threadIdx.x * per;
+    u64 loc = 0;
+    for (int i = i0; i < i0 + per && i < a.ntiles; ++i) loc += Q[i];
+    u64 tot;
+    u64 run = smc_block_exscan_u64(loc, smu, tot);
+    for (int i = i0; i < i0 + per && i < a.ntiles; ++i) {
+        Qpre[i] = run;
+        run += Q[i];
+    }
+    if (threadIdx.x == 0) a.cnt[isl * 2 + 1] = 0u;
 }
 
 // ---------------------------------------------------------------------------
@@ -322,12 +334,12 @@ k_move(FArgs a)
     __shared__ double smd[SMC_SM];
     __shared__ i64 sn[2];
     __shared__ u32 smx[SMC_NWAVE];
+    __shared__ int s_last;
     const int b = (int)blockIdx.x, isl = (int)blockIdx.y;
     const int tid = (int)threadIdx.x;
-    const double* info = a.info + (i64)isl * INFO_STRIDE;
+    double* info = a.info + (i64)isl * INFO_STRIDE;
     const i64 t = (i64)info[0];
     if (t >= a.T) return;
-    if (b == 0 && isl == 0 && tid == 0) a.ctl[0] = t + 1;
 
     const i64 N = a.N;
     const double* p = a.params + (i64)isl * PARAM_STRIDE;
@@ -342,7 +354,7 @@ k_move(FArgs a)
     const double* zt = a.zt ? a.zt + ((i64)t * a.n_islands + isl) * N : nullptr;
     const bool first = (t == 0);
     const bool resample = !first && info[1] != 0.0;
-    const bool vec = (N & 3) == 0;
+    const bool vec = (N & 3) == 0, vec2 = (N & 1) == 0;
     const i64 j0 = (i64)b * F_TILE;
 
     SmcLse acc = smc_lse_empty();
@@ -358,15 +370,12 @@ k_move(FArgs a)
         const i64 jt = j0 + (i64)tid * F_IPT;
         f_load4<u64, F2u>(a.q + (i64)isl * N, jt, N, vec, 0ull, q4);
         f_load4<double, F2d>(Xo, jt, N, vec, 0.0, x4);
+        const u64 pre = a.Qpre[(i64)isl * a.ntiles + b];
 #pragma unroll
         for (int i = 0; i < 4; ++i) sX[tid * F_IPT + i] = x4[i];
-        const u64* Qt = a.Q + (i64)isl * a.ntiles;
-        u64 pre_part = 0;
-        for (int i = tid; i < b; i += SMC_BLOCK) pre_part += Qt[i];
         const u64 tsum = q4[0] + q4[1] + q4[2] + q4[3];
-        u64 total, pre;
-        u64 cex = smc_block_exscan_plus_sum_u64(tsum, pre_part, smu, total, pre);
-        cex += pre;                                   // exclusive CDF of this thread's 1st parent
+        u64 total;
+        u64 cex = pre + smc_block_exscan_u64(tsum, smu, total);   // exclusive CDF, 1st parent
         su.scheme = a.scheme;
         su.M = N;
         su.dM = (double)N;
@@ -427,6 +436,13 @@ k_move(FArgs a)
             ok[i] = (n0 + i >= n_lo) && (n0 + i < n_hi);
             par[i] = tid * 4 + i;                      // element-wise: the particle itself
         }
+        // element-wise steps: the particle's own state / log-weight, requested now
+        // so that the loads fly while the normals are being generated
+        double xo4[4] = {0.0, 0.0, 0.0, 0.0}, lo4[4] = {0.0, 0.0, 0.0, 0.0};
+        if (!resample && !first && (ok[0] || ok[3])) {
+            f_load4<double, F2d>(Xo, n0, N, vec, 0.0, xo4);
+            f_load4<double, F2d>(lwo, n0, N, vec, 0.0, lo4);
+        }
         if (resample && scatter) {
             __syncthreads();                           // previous pass has read sP
             *reinterpret_cast<uint4*>(&sP[tid * 4]) = make_uint4(0u, 0u, 0u, 0u);
@@ -463,63 +479,74 @@ k_move(FArgs a)
                 par[i] = jl < nvalid ? jl : nvalid - 1;
             }
         }
-        if (!(ok[0] || ok[1] || ok[2] || ok[3])) continue;
-
-        double z4[4];
-        if (zt) {
-            f_load4<double, F2d>(zt, n0, N, vec, 0.0, z4);
-        } else {
-#if defined(ABL_NO_RNG)
-            z4[0] = 0.1 * (double)(n0 & 15); z4[1] = -z4[0]; z4[2] = 0.3; z4[3] = -0.7;
-#elif defined(ABL_NO_BM)
-            { u64 x0, x1, x2, x3;
-              smc_philox((u32)(n0 >> 1), (u32)t, gisl, 0u, a.seed, x0, x1);
-              smc_philox((u32)(n0 >> 1) + 1u, (u32)t, gisl, 0u, a.seed, x2, x3);
-              z4[0] = smc_u01_open(x0) - 0.5; z4[1] = smc_u01_open(x1) - 0.5;
-              z4[2] = smc_u01_open(x2) - 0.5; z4[3] = smc_u01_open(x3) - 0.5; }
-#else
-            smc_normal_pair(a.seed, (u32)(n0 >> 1), (u32)t, gisl, SMC_STREAM_NORMAL, z4[0], z4[1]);
-            smc_normal_pair(a.seed, (u32)(n0 >> 1) + 1u, (u32)t, gisl, SMC_STREAM_NORMAL, z4[2],
-                            z4[3]);
-#endif
-        }
-        double xo4[4] = {0.0, 0.0, 0.0, 0.0}, lo4[4] = {0.0, 0.0, 0.0, 0.0};
-        if (!resample && !first) {
-            f_load4<double, F2d>(Xo, n0, N, vec, 0.0, xo4);
-            f_load4<double, F2d>(lwo, n0, N, vec, 0.0, lo4);
-        }
-        double xn4[4], lw4[4];
-        i64 a4[4];
+        // ---- two pairs (n, n+1): one Philox call each; the stores of the first
+        // pair are in flight while the second pair is computed
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const double xp = resample ? sX[par[i]] : (first ? 0.0 : xo4[i]);
-            double inc;
-            xn4[i] = m_step<KIND, FK>(p, first, yt, xp, z4[i], inc);
-            double lw = (resample || first) ? inc : lo4[i] + inc;   // resampling.py:241-244
-            if (lw != lw) lw = -INFINITY;                            // resampling.py:220
-            lw4[i] = lw;
-            a4[i] = resample ? j0 + par[i] : n0 + i;                 // core.py:329 / :335
-#if defined(ABL_NO_LSE)
-            if (ok[i]) { acc.m = fmax(acc.m, lw); acc.s += 1.0; acc.ss += 1.0; }
-#else
-            if (ok[i]) smc_lse_push(acc, lw);
-#endif
+        for (int h = 0; h < 2; ++h) {
+            const bool ok0 = ok[2 * h], ok1 = ok[2 * h + 1];
+            if (!(ok0 || ok1)) continue;
+            const i64 n = n0 + 2 * h;
+            double z0, z1;
+            if (zt) {
+                z0 = ok0 ? zt[n] : 0.0;
+                z1 = ok1 ? zt[n + 1] : 0.0;
+            } else {
+                smc_normal_pair(a.seed, (u32)(n >> 1), (u32)t, gisl, SMC_STREAM_NORMAL, z0, z1);
+            }
+            double xv[2], lv[2];
+            i64 av[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int i = 2 * h + e;
+                const double xp = resample ? sX[par[i]] : xo4[i];
+                double inc;
+                xv[e] = m_step<KIND, FK>(p, first, yt, xp, e ? z1 : z0, inc);
+                double lw = (resample || first) ? inc : lo4[i] + inc;   // resampling.py:241-244
+                if (lw != lw) lw = -INFINITY;                            // resampling.py:220
+                lv[e] = lw;
+                av[e] = resample ? j0 + par[i] : n + e;                  // core.py:329 / :335
+                if (e ? ok1 : ok0) smc_lse_push(acc, lw);
+            }
+            f_store2<double, F2d>(Xn, n, vec2, ok0, ok1, xv[0], xv[1]);
+            f_store2<double, F2d>(lwn, n, vec2, ok0, ok1, lv[0], lv[1]);
+            if (!first) f_store2<i64, F2i>(A, n, vec2, ok0, ok1, av[0], av[1]);
         }
-        const bool full = vec && ok[0] && ok[3];
-#if defined(ABL_NO_STORE)
-        if (lw4[0] == 1.2345) f_store4<double, F2d>(Xn, n0, full, ok, xn4);
-        continue;
-#endif
-        f_store4<double, F2d>(Xn, n0, full, ok, xn4);
-        f_store4<double, F2d>(lwn, n0, full, ok, lw4);
-        if (!first) f_store4<i64, F2u>(A, n0, full, ok, a4);
     }
     const SmcLse r = smc_lse_block(acc, smd);
+    const i64 o = (i64)isl * a.ntiles;
     if (tid == 0) {
-        const i64 o = (i64)isl * a.ntiles + b;
-        a.pm[o] = r.m;
-        a.ps[o] = r.s;
-        a.pss[o] = r.ss;
+        a.pm[o + b] = r.m;
+        a.ps[o + b] = r.s;
+        a.pss[o + b] = r.ss;
+    }
+    if (!f_last_block(a.cnt + isl * 2, (unsigned)a.ntiles, &s_last)) return;
+
+    // ---- last workgroup of this island: finalise step t, decide step t+1
+    const SmcLse g = smc_lse_reduce_partials(a.pm + o, a.ps + o, a.pss + o, a.ntiles, smd);
+    if (tid == 0) {
+        const bool bad = !(g.m > -INFINITY) || !(g.m < INFINITY);
+        const double ess = bad ? NAN : (g.s * g.s) / g.ss;                  // resampling.py:226
+        const double log_mean = bad ? NAN : g.m + log(g.s / (double)N);     // resampling.py:224
+        const double rs = bad ? NAN : 1.0 / g.s;
+        double* row = a.summ + ((i64)isl * (a.T + 1) + t) * SUMM_STRIDE;
+        double loglt, logLt;                                                // core.py:355-359
+        if (first || resample) loglt = log_mean;
+        else loglt = log_mean - row[1 - SUMM_STRIDE];
+        logLt = (first ? 0.0 : row[3 - SUMM_STRIDE]) + loglt;
+        row[0] = ess;
+        row[1] = log_mean;
+        row[2] = loglt;
+        row[3] = logLt;
+        row[4] = resample ? 1.0 : 0.0;
+        row[5] = g.m;
+        row[6] = rs;
+        const bool flag = (t + 1 < a.T) && (ess < a.ess_thresh);            // core.py:181-183
+        info[1] = flag ? 1.0 : 0.0;
+        info[2] = (t + 1 < a.T) ? a.y[t + 1] : 0.0;
+        info[3] = g.m;
+        info[4] = rs;
+        info[0] = (double)(t + 1);
+        a.cnt[isl * 2] = 0u;
     }
 }
 

@@ -42,6 +42,34 @@ __host__ __device__ __forceinline__ double smc_exp_nonpos(double x)
     return (x < -745.2) ? 0.0 : y;
 }
 
+// log(x) for a positive, finite, normal x (the Box-Muller uniform lies in
+// [2^-53, 1)).  Classic argument reduction x = 2^k m, m in [sqrt(1/2), sqrt 2),
+// f = m-1, s = f/(2+f), log(1+f) = f - hfsq + s (hfsq + R(s^2)) with the
+// degree-14 Remez polynomial R of fdlibm's e_log.c (Sun Microsystems, public
+// algorithm); error < 1 ulp.  ~40 instructions against ~100 for the general
+// libm entry point (which also handles 0, inf, NaN, subnormals).
+__host__ __device__ __forceinline__ double smc_log_pos(double x)
+{
+    int e;
+    double m = frexp(x, &e);                       // m in [0.5, 1)
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? m + m : m;                            // [sqrt(1/2), sqrt 2)
+    e = lo ? e - 1 : e;
+    const double k = (double)e;
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double z = s * s, w = z * z;
+    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01),
+                              3.999999999940941908e-01);
+    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01),
+                                     2.857142874366239149e-01), 6.666666666666735130e-01);
+    const double R = t1 + t2;
+    const double hfsq = 0.5 * f * f;
+    // k ln2_hi - ((hfsq - (s (hfsq+R) + k ln2_lo)) - f)
+    return fma(k, 6.93147180369123816490e-01,
+               -((hfsq - fma(s, hfsq + R, k * 1.90821492927058770002e-10)) - f));
+}
+
 __host__ __device__ __forceinline__ void smc_sincospi_02(double a, double* sn, double* cs)
 {
     // a = q/2 + r, q in {0..4}, |r| <= 1/4 ; x = pi r in [-pi/4, pi/4]

@@ -46,6 +46,19 @@ def test_exp_nonpos(emu):
     assert np.isnan(o[0])
 
 
+def test_log_pos(emu):
+    rng = np.random.default_rng(2)
+    x = np.concatenate([(rng.integers(0, 2 ** 52, 400000) + 0.5) * 2.0 ** -52,
+                        10.0 ** rng.uniform(-300, 300, 100000), rng.uniform(0.5, 2.0, 200000),
+                        np.array([2.0 ** -53, 1.0 - 2.0 ** -53, 1.0, 0.5, 2.0, 0.70710678118654752])])
+    out = np.empty_like(x)
+    emu.smc_test_log_pos(_p(x), x.size, _p(out))
+    want = np.log(x.astype(np.longdouble)).astype(np.float64)
+    nz = want != 0
+    assert ulps(out[nz], want[nz]).max() <= 1.0
+    assert np.all(out[~nz] == 0.0)
+
+
 def test_sincospi_02(emu):
     rng = np.random.default_rng(1)
     a = np.concatenate([rng.uniform(0, 2, 400000), ((rng.integers(0, 2 ** 52, 100000) + 0.5) * 2.0 ** -52) * 2,
