@@ -34,8 +34,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_STEP = 56.0                # 16*d + 40 B per particle-step, d = 1
-BYTES_MOVE = 40.0                # k_move's share: read lw, X; write X, lw, A
-BYTES_PREPARE = 8.0              # k_prepare: read lw (W is never materialised)
+BYTES_MOVE = 32.0                # k_propagate: read A, gather X; write X, lw
+BYTES_PREPARE = 32.0             # k_prepare (read lw, write q) + k_ancestors (read q, write A)
 
 
 def synthetic_data(T, sigma=0.2, seed=42):
@@ -165,13 +165,15 @@ def main():
             out["roofline"] = {
                 "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "k_move", "kernel_ms": mv.value, "launch_bytes": BYTES_MOVE * N * a.islands,
+                "kernel": "k_propagate", "kernel_ms": mv.value,
+                "launch_bytes": BYTES_MOVE * N * a.islands,
                 "samples": ns.value,
                 "prepare_ms": pr.value,
                 "prepare_achieved": BYTES_PREPARE * N * a.islands / (pr.value * 1e-3) / 1e9
                 if pr.value > 0 else None,
-                "note": "40 of the step's 56 algorithmic B/particle belong to k_move "
-                        "(read lw,X; write X,lw,A), 8 to k_prepare; the 8 B write of W is fused away",
+                "note": "per particle-step: k_propagate 32 B (read A, gather X; write X, lw), "
+                        "k_prepare 16 B (read lw, write q), k_ancestors 16 B (read q, write A); "
+                        "prepare_ms covers k_prepare + k_ancestors",
             }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(y, N, min(a.cpu_steps, T))

@@ -73,6 +73,48 @@ __device__ __forceinline__ void smc_normal_pair(u64 seed, u32 pair, u32 t, u32 i
 }
 
 // ---------------------------------------------------------------------------
+// Publishing a few 8-byte values to another workgroup of the same launch
+// without fences (MI355X: per-XCD L2s, per-CU L1s): the producer stores them
+// with relaxed AGENT-scope atomics (write-through, `sc1`), drains its stores
+// (s_waitcnt vmcnt(0)) and then takes a ticket with an agent-scope atomicAdd;
+// the consumer that draws the last ticket reads them with relaxed agent-scope
+// atomic loads (served from L2, never from a stale L1).  A __threadfence()
+// here would write back the whole dirty L2 of the XCD per workgroup.
+// ---------------------------------------------------------------------------
+#ifdef SMC_EMULATE
+__device__ __forceinline__ void smc_st_agent(u64* p, u64 v) { *p = v; }
+__device__ __forceinline__ u64 smc_ld_agent(const u64* p) { return *p; }
+__device__ __forceinline__ void smc_drain_stores() {}
+__device__ __forceinline__ void smc_drain_stores_but4() {}
+#else
+__device__ __forceinline__ void smc_st_agent(u64* p, u64 v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 smc_ld_agent(const u64* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void smc_drain_stores()
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+// all but the 4 most recent vector-memory instructions of this wave have retired
+__device__ __forceinline__ void smc_drain_stores_but4()
+{
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+}
+#endif
+__device__ __forceinline__ void smc_st_agent_f64(double* p, double v)
+{
+    smc_st_agent(reinterpret_cast<u64*>(p), (u64)__double_as_longlong(v));
+}
+__device__ __forceinline__ double smc_ld_agent_f64(const double* p)
+{
+    return __longlong_as_double((long long)smc_ld_agent(reinterpret_cast<const u64*>(p)));
+}
+
+// ---------------------------------------------------------------------------
 // Q62 fixed-point CDF contract (oracle/smc_oracle.py "Q62"):
 //   q = rint(W 2^62), T = ceil(su 2^62); both exact (power-of-two scaling).
 // ---------------------------------------------------------------------------
@@ -220,27 +262,43 @@ __device__ __forceinline__ SmcLse smc_lse_block(SmcLse a, double* sm)
 }
 // Reduce `n` per-workgroup partials (SoA: pm, ps, pss) to the global (m,s,ss).
 // Called by every thread of a workgroup; all workgroups obtain identical bits.
+// merge another accumulator (m2, s2, ss2) into a
+__device__ __forceinline__ void smc_lse_merge(SmcLse& a, double m2, double s2, double ss2)
+{
+    if (!(m2 > -INFINITY)) return;
+    const double m = fmax(a.m, m2);
+    const double e1 = (a.m > -INFINITY) ? smc_exp_nonpos(a.m - m) : 0.0;
+    const double e2 = smc_exp_nonpos(m2 - m);
+    a.s = a.s * e1 + s2 * e2;
+    a.ss = a.ss * (e1 * e1) + ss2 * (e2 * e2);
+    a.m = m;
+}
+// Reduce `n` per-workgroup partials (SoA: pm, ps, pss) to the global (m,s,ss).
+// Called by every thread of ONE workgroup.  AGENT: the partials were published
+// by other workgroups of the same launch (smc_st_agent) and are read with
+// agent-scope loads; four entries of each array are requested back to back so
+// the whole read costs one memory round trip, not one per entry.
+template <bool AGENT = false>
 __device__ __forceinline__ SmcLse smc_lse_reduce_partials(const double* pm, const double* ps,
                                                           const double* pss, int n, double* sm)
 {
-    double m = -INFINITY;
-    for (int i = (int)threadIdx.x; i < n; i += SMC_BLOCK) m = fmax(m, pm[i]);
-    m = smc_block_max(m, sm);
-    double s = 0.0, ss = 0.0;
-    for (int i = (int)threadIdx.x; i < n; i += SMC_BLOCK) {
-        const double mi = pm[i];
-        if (mi > -INFINITY) {
-            const double sc = smc_exp_nonpos(mi - m);
-            s += ps[i] * sc;
-            ss += pss[i] * (sc * sc);
+    SmcLse acc = smc_lse_empty();
+    for (int base = 0; base < n; base += 4 * SMC_BLOCK) {
+        double vm[4], vs[4], vq[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = base + k * SMC_BLOCK + (int)threadIdx.x;
+            const bool in = i < n;
+            const int ii = in ? i : 0;
+            vm[k] = AGENT ? smc_ld_agent_f64(pm + ii) : pm[ii];
+            vs[k] = AGENT ? smc_ld_agent_f64(ps + ii) : ps[ii];
+            vq[k] = AGENT ? smc_ld_agent_f64(pss + ii) : pss[ii];
+            if (!in) vm[k] = -INFINITY;
         }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) smc_lse_merge(acc, vm[k], vs[k], vq[k]);
     }
-    SmcLse r;
-    r.m = m;
-    r.s = s;
-    r.ss = ss;
-    smc_block_sum2(r.s, r.ss, sm);
-    return r;
+    return smc_lse_block(acc, sm);
 }
 
 // smallest index i in [0, n) with T <= c[i]; n if none.  `c` non-decreasing.

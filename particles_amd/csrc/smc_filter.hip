@@ -12,7 +12,8 @@
 
 struct smc_filter {
     smc_ctx* ctx;
-    FArgs a;
+    FArgs a;               // host copy of the argument block
+    const FArgs* da;       // its device copy (kernels take the pointer: 8 B of kernarg)
     int kind, fk;
     i64 t_host;
     void* slab;            // one allocation holding every device array
@@ -27,30 +28,39 @@ struct smc_filter {
 
 typedef void (*move_fn)(FArgs);
 
-static void launch_move(smc_filter* f, dim3 grid)
+#define F_OPT 2     /* new particles per thread of k_propagate */
+
+static void launch_propagate(smc_filter* f)
 {
     hipStream_t st = f->ctx->stream;
+    const dim3 grid(f->a.nparts, f->a.n_islands);
     if (f->kind == SMC_MODEL_LINGAUSS && f->fk == SMC_FK_BOOTSTRAP)
-        SMC_LAUNCH((k_move<SMC_MODEL_LINGAUSS, SMC_FK_BOOTSTRAP>), grid, dim3(SMC_BLOCK), st, f->a);
+        SMC_LAUNCH((k_propagate<SMC_MODEL_LINGAUSS, SMC_FK_BOOTSTRAP, F_OPT>), grid,
+                   dim3(SMC_BLOCK), st, f->da);
     else if (f->kind == SMC_MODEL_LINGAUSS)
-        SMC_LAUNCH((k_move<SMC_MODEL_LINGAUSS, SMC_FK_GUIDED>), grid, dim3(SMC_BLOCK), st, f->a);
+        SMC_LAUNCH((k_propagate<SMC_MODEL_LINGAUSS, SMC_FK_GUIDED, F_OPT>), grid, dim3(SMC_BLOCK),
+                   st, f->da);
     else
-        SMC_LAUNCH((k_move<SMC_MODEL_STOCHVOL, SMC_FK_BOOTSTRAP>), grid, dim3(SMC_BLOCK), st, f->a);
+        SMC_LAUNCH((k_propagate<SMC_MODEL_STOCHVOL, SMC_FK_BOOTSTRAP, F_OPT>), grid,
+                   dim3(SMC_BLOCK), st, f->da);
 }
 
+// one time step: [k_prepare, (spacings), k_ancestors] do nothing unless the step
+// resamples (decided on the device by the previous k_propagate), then k_propagate
 static void enqueue_step(smc_filter* f, int k_prof)
 {
     hipStream_t st = f->ctx->stream;
     const dim3 grid(f->a.ntiles, f->a.n_islands);
     if (k_prof >= 0) (void)hipEventRecord(f->ev[3 * k_prof], st);
-    SMC_LAUNCH(k_prepare, grid, dim3(SMC_BLOCK), st, f->a);
+    SMC_LAUNCH(k_prepare, grid, dim3(SMC_BLOCK), st, f->da);
     if (f->a.scheme == SMC_MULTINOMIAL && !f->a.ut) {
         const dim3 g1(f->a.ntiles1, f->a.n_islands);
-        SMC_LAUNCH(k_f_spacing_sums, g1, dim3(SMC_BLOCK), st, f->a);
-        SMC_LAUNCH(k_f_spacing_write, g1, dim3(SMC_BLOCK), st, f->a);
+        SMC_LAUNCH(k_f_spacing_sums, g1, dim3(SMC_BLOCK), st, f->da);
+        SMC_LAUNCH(k_f_spacing_write, g1, dim3(SMC_BLOCK), st, f->da);
     }
+    SMC_LAUNCH(k_ancestors, grid, dim3(SMC_BLOCK), st, f->da);
     if (k_prof >= 0) (void)hipEventRecord(f->ev[3 * k_prof + 1], st);
-    launch_move(f, grid);
+    launch_propagate(f);
     if (k_prof >= 0) (void)hipEventRecord(f->ev[3 * k_prof + 2], st);
 }
 
@@ -116,16 +126,19 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     const size_t oq = carve(M * N * 8);
     const size_t oQ = carve(M * a.ntiles * 8);
     const size_t oQpre = carve(M * a.ntiles * 8);
-    const size_t oPm = carve(M * a.ntiles * 8), oPs = carve(M * a.ntiles * 8),
-                 oPss = carve(M * a.ntiles * 8);
+    a.nparts = (int)((o->N + (i64)SMC_BLOCK * F_OPT - 1) / ((i64)SMC_BLOCK * F_OPT));
+    const size_t oPm = carve(M * a.nparts * 8), oPs = carve(M * a.nparts * 8),
+                 oPss = carve(M * a.nparts * 8);
     const size_t oSum = carve(M * (T + 1) * SUMM_STRIDE * 8);
     const size_t oPar = carve(M * PARAM_STRIDE * 8);
     const size_t oY = carve(T * 8);
-    const size_t oCtl = carve(M * 2 * sizeof(unsigned) + 64);
+    const size_t oCtl = carve(M * 2 * F_CNT_WORDS * sizeof(unsigned));
     const size_t oInfo = carve(M * INFO_STRIDE * 8);
     const size_t oSu = carve(need_su ? M * N * 8 : 8);
     const size_t oE = carve(need_su ? M * a.ntiles1 * 8 : 8);
     const size_t oTmp = carve(N * 8);
+    const size_t oArgs = carve(sizeof(FArgs));
+    const size_t oTrace = carve(M * a.ntiles * 8 * 8);
     void* slab = nullptr;
     hipError_t e = hipMalloc(&slab, off);
     if (e != hipSuccess) {
@@ -152,9 +165,10 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     a.su = (double*)(base + oSu);
     a.E = (u64*)(base + oE);
     f->tmp = (double*)(base + oTmp);
+    a.trace = (u64*)(base + oTrace);
     hipStream_t st = ctx->stream;
     SMC_HIP_CHECK(hipMemsetAsync(a.summ, 0, M * (T + 1) * SUMM_STRIDE * 8, st));
-    SMC_HIP_CHECK(hipMemsetAsync(a.cnt, 0, M * 2 * sizeof(unsigned), st));
+    SMC_HIP_CHECK(hipMemsetAsync(a.cnt, 0, M * 2 * F_CNT_WORDS * sizeof(unsigned), st));
     {   // step record of t = 0: {t, rs_flag, y_0, m, 1/s}
         std::vector<double> h(M * INFO_STRIDE, 0.0);
         for (size_t i = 0; i < M; ++i) h[i * INFO_STRIDE + 2] = y_host[0];
@@ -166,9 +180,23 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
                                  hipMemcpyHostToDevice, st));
     SMC_HIP_CHECK(hipMemcpyAsync(dy, y_host, T * 8, hipMemcpyHostToDevice, st));
     SMC_HIP_CHECK(hipStreamSynchronize(st));
+    f->da = (const FArgs*)(base + oArgs);
+    SMC_HIP_CHECK(hipMemcpyAsync((void*)f->da, &f->a, sizeof(FArgs), hipMemcpyHostToDevice, st));
+    SMC_HIP_CHECK(hipStreamSynchronize(st));
     *out = f;
     return SMC_OK;
 }
+
+#ifdef SMC_TRACE
+// debug builds only (tools/trace_kmove.py): per-workgroup phase stamps of the last k_move
+int smc_debug_trace(smc_filter* f, uint64_t* out_host)
+{
+    SMC_HIP_CHECK(hipMemcpyAsync(out_host, f->a.trace, (size_t)f->a.n_islands * f->a.ntiles * 64,
+                                 hipMemcpyDeviceToHost, f->ctx->stream));
+    SMC_HIP_CHECK(hipStreamSynchronize(f->ctx->stream));
+    return SMC_OK;
+}
+#endif
 
 int smc_filter_destroy(smc_filter* f)
 {
@@ -191,6 +219,9 @@ int smc_filter_set_replay(smc_filter* f, const double* z, const double* u)
     f->a.ut = u;
     f->a.ut_stride = (f->a.scheme == SMC_SYSTEMATIC) ? 1 : f->a.N;
     f->a.rng_mode = SMC_RNG_REPLAY;
+    SMC_HIP_CHECK(hipMemcpyAsync((void*)f->da, &f->a, sizeof(FArgs), hipMemcpyHostToDevice,
+                                 f->ctx->stream));
+    SMC_HIP_CHECK(hipStreamSynchronize(f->ctx->stream));
     return SMC_OK;
 }
 
@@ -306,14 +337,28 @@ int smc_filter_get(smc_filter* f, int field, int island, void* out_host)
     case SMC_FIELD_X: src = X; break;
     case SMC_FIELD_LW: src = lw; break;
     case SMC_FIELD_A:
-        if (t < 2) { smc_set_error("smc_filter_get: A is undefined before step 1"); return SMC_ERR_STATE; }
-        src = A;
+    case SMC_FIELD_XP: {
+        if (t < 2) { smc_set_error("smc_filter_get: A / Xp are undefined before step 1"); return SMC_ERR_STATE; }
+        // did the last step resample?  (core.py:329-336: else A = arange(N), Xp = X)
+        double flag = 0.0;
+        SMC_HIP_CHECK(hipMemcpyAsync(&flag, f->a.summ + ((size_t)island * (f->a.T + 1) + (t - 1)) * SUMM_STRIDE + 4,
+                                     8, hipMemcpyDeviceToHost, st));
+        SMC_HIP_CHECK(hipStreamSynchronize(st));
+        if (flag == 0.0) {
+            if (field == SMC_FIELD_A) {
+                int64_t* o = (int64_t*)out_host;
+                for (i64 i = 0; i < N; ++i) o[i] = i;
+                return SMC_OK;
+            }
+            src = Xo;
+        } else if (field == SMC_FIELD_A) {
+            src = A;
+        } else {
+            SMC_LAUNCH(k_f_gather1, dim3(nb), dim3(SMC_BLOCK), st, Xo, A, N, f->tmp);
+            src = f->tmp;
+        }
         break;
-    case SMC_FIELD_XP:
-        if (t < 2) { smc_set_error("smc_filter_get: Xp is undefined before step 1"); return SMC_ERR_STATE; }
-        SMC_LAUNCH(k_f_gather1, dim3(nb), dim3(SMC_BLOCK), st, Xo, A, N, f->tmp);
-        src = f->tmp;
-        break;
+    }
     case SMC_FIELD_W: {
         const double* row = f->a.summ + ((size_t)island * (f->a.T + 1) + (t - 1)) * SUMM_STRIDE;
         SMC_LAUNCH(k_f_write_W, dim3(nb), dim3(SMC_BLOCK), st, lw, N, row, f->tmp);
@@ -334,7 +379,7 @@ int smc_filter_info(smc_filter* f, double* bytes_per_particle_step, int* kernels
 {
     SMC_REQUIRE(f, "null filter");
     if (bytes_per_particle_step) *bytes_per_particle_step = 16.0 * 1 + 40.0;   // SURVEY 8d, d = 1
-    if (kernels_per_step) *kernels_per_step = (f->a.scheme == SMC_MULTINOMIAL && !f->a.ut) ? 4 : 2;
+    if (kernels_per_step) *kernels_per_step = (f->a.scheme == SMC_MULTINOMIAL && !f->a.ut) ? 5 : 3;
     return SMC_OK;
 }
 

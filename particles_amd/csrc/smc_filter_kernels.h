@@ -49,6 +49,7 @@
 struct FArgs {
     i64 N, T;
     int ntiles, n_islands, scheme, rng_mode, island_offset;
+    int nparts;            // workgroups of k_propagate per island (= LSE partials)
     int log2N;             // k if N == 2^k, else -1
     double ess_thresh;
     u64 seed;
@@ -58,7 +59,7 @@ struct FArgs {
     u64* Q;                // (n_islands, ntiles) tile totals of q
     u64* Qpre;             // (n_islands, ntiles) exclusive prefixes of Q
     double *pm, *ps, *pss; // (n_islands, ntiles) log-sum-exp partials
-    unsigned* cnt;         // (n_islands, 2) completion tickets: k_move, k_prepare
+    unsigned* cnt;         // (n_islands, 2, F_CNT_WORDS) completion tickets: k_move, k_prepare
     double* summ;          // (n_islands, T+1, SUMM_STRIDE)
     const double* params;  // (n_islands, PARAM_STRIDE)
     const double* y;       // (T,)
@@ -70,7 +71,14 @@ struct FArgs {
     u64* E;                // multinomial, Philox mode: spacing tile sums (n_islands, ntiles1)
     int ntiles1;
     double spacing_scale;
+    u64* trace;            // SMC_TRACE builds: (n_islands, ntiles, 8) shader-clock stamps of k_move
 };
+
+#ifdef SMC_TRACE
+#define F_STAMP(k) do { if (threadIdx.x == 0) a.trace[((i64)blockIdx.y * a.ntiles + blockIdx.x) * 8 + (k)] = (u64)wall_clock64(); } while (0)
+#else
+#define F_STAMP(k) do { } while (0)
+#endif
 
 // ---------------------------------------------------------------------------
 // model family
@@ -189,31 +197,44 @@ __device__ __forceinline__ void f_store2(T* p, i64 n, bool vec2, bool ok0, bool 
     }
 }
 
-// Ticket of the "last workgroup done" pattern: every workgroup publishes its
-// result, fences, and takes a ticket; the one that draws the last ticket sees
-// (after its own fence) everything the others published.  hipMalloc'ed memory
-// is coherent across the XCD L2s at agent scope, so plain loads after the fence
-// are enough; nobody spins.  Returns true in every thread of the last workgroup.
-__device__ __forceinline__ bool f_last_block(unsigned* ticket, unsigned nblocks, int* s_flag)
+// Ticket of the "last workgroup done" pattern (smc_device.h, "Publishing ..."):
+// thread 0 has published this workgroup's values with smc_st_agent*, drains its
+// stores and takes a ticket; the workgroup that draws the last ticket reads
+// everybody's values with smc_ld_agent*.  Nobody spins, nobody fences.
+// One atomic word sustains only ~90 returning atomics per microsecond on
+// MI355X, so the ticket is two-level: 32 shard counters (64 B apart), whose
+// last arrivers take a ticket on the top counter.
+// Returns true in every thread of the last workgroup; it also re-arms the
+// counters for the next launch.
+#define F_CNT_STRIDE 16                       /* unsigned per counter: one 64-byte line */
+#define F_CNT_WORDS (34 * F_CNT_STRIDE)       /* top + 32 shards (+ pad) */
+__device__ __forceinline__ bool f_last_block(unsigned* cnt, int b, int nblocks, int* s_flag,
+                                             int later = 0)
 {
-    __syncthreads();                         // this workgroup's global stores are issued
     if (threadIdx.x == 0) {
-        __threadfence();
-        const unsigned prev = atomicAdd(ticket, 1u);
-        *s_flag = (prev == nblocks - 1u);
+        // wait for the published values only: `later` = a lower bound on the number
+        // of store instructions this thread issued AFTER them (stores retire in order)
+        if (later >= 4) smc_drain_stores_but4(); else smc_drain_stores();
+        const int shards = nblocks >= 64 ? 32 : 1;
+        const int s = b & (shards - 1);
+        const int size_s = nblocks / shards + (s < nblocks % shards ? 1 : 0);
+        bool last = atomicAdd(cnt + (1 + s) * F_CNT_STRIDE, 1u) == (unsigned)(size_s - 1);
+        if (last) last = atomicAdd(cnt, 1u) == (unsigned)(shards - 1);
+        if (last)
+            for (int i = 0; i <= shards; ++i) cnt[i * F_CNT_STRIDE] = 0u;
+        *s_flag = last;
     }
     __syncthreads();
-    const bool last = *s_flag != 0;
-    if (last) __threadfence();
-    return last;
+    return *s_flag != 0;
 }
 
 // ---------------------------------------------------------------------------
 // k_prepare
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(SMC_BLOCK)
-k_prepare(FArgs a)
+k_prepare(const FArgs* __restrict__ ap)
 {
+    const FArgs& a = *ap;
     __shared__ u64 smu[SMC_SM];
     __shared__ int s_last;
     const int b = (int)blockIdx.x, isl = (int)blockIdx.y;
@@ -236,24 +257,35 @@ k_prepare(FArgs a)
         q4[i] = ok[i] ? smc_q62_w(f_weight(l4[i], m, rs)) : 0ull;
         s += q4[i];
     }
-    f_store4<u64, F2u>(q, j0, vec && ok[3], ok, q4);
     s = smc_block_sum_u64(s, smu);
     u64* Q = a.Q + (i64)isl * a.ntiles;
-    if (threadIdx.x == 0) Q[b] = s;
-    if (!f_last_block(a.cnt + isl * 2 + 1, (unsigned)a.ntiles, &s_last)) return;
+    if (threadIdx.x == 0) smc_st_agent(Q + b, s);
+    f_store4<u64, F2u>(q, j0, vec && ok[3], ok, q4);     // after the publish: see f_last_block
+    if (!f_last_block(a.cnt + (isl * 2 + 1) * F_CNT_WORDS, b, a.ntiles, &s_last, 0)) return;
     // last workgroup: exclusive prefixes of the tile totals (exact integers)
     u64* Qpre = a.Qpre + (i64)isl * a.ntiles;
     const int per = (a.ntiles + SMC_BLOCK - 1) / SMC_BLOCK;
     const int i0 = (int)threadIdx.x * per;
     u64 loc = 0;
-    for (int i = i0; i < i0 + per && i < a.ntiles; ++i) loc += Q[i];
+    if (per <= 4) {               // up to 1024 tiles: all loads of a thread in flight at once
+        u64 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (k < per && i0 + k < a.ntiles) ? smc_ld_agent(Q + i0 + k) : 0ull;
+        loc = v[0] + v[1] + v[2] + v[3];
+        u64 tot;
+        u64 run = smc_block_exscan_u64(loc, smu, tot);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < per && i0 + k < a.ntiles) { Qpre[i0 + k] = run; run += v[k]; }
+        return;
+    }
+    for (int i = i0; i < i0 + per && i < a.ntiles; ++i) loc += smc_ld_agent(Q + i);
     u64 tot;
     u64 run = smc_block_exscan_u64(loc, smu, tot);
     for (int i = i0; i < i0 + per && i < a.ntiles; ++i) {
         Qpre[i] = run;
-        run += Q[i];
+        run += smc_ld_agent(Q + i);
     }
-    if (threadIdx.x == 0) a.cnt[isl * 2 + 1] = 0u;
 }
 
 // ---------------------------------------------------------------------------
@@ -268,8 +300,9 @@ __device__ __forceinline__ u64 f_spacing_q(const FArgs& a, u32 t, u32 gisl, i64 
 }
 
 __global__ void __launch_bounds__(SMC_BLOCK)
-k_f_spacing_sums(FArgs a)
+k_f_spacing_sums(const FArgs* __restrict__ ap)
 {
+    const FArgs& a = *ap;
     __shared__ u64 smu[SMC_SM];
     const int b = (int)blockIdx.x, isl = (int)blockIdx.y;
     const double* info = a.info + (i64)isl * INFO_STRIDE;
@@ -285,8 +318,9 @@ k_f_spacing_sums(FArgs a)
 }
 
 __global__ void __launch_bounds__(SMC_BLOCK)
-k_f_spacing_write(FArgs a)
+k_f_spacing_write(const FArgs* __restrict__ ap)
 {
+    const FArgs& a = *ap;
     __shared__ u64 smu[SMC_SM];
     const int b = (int)blockIdx.x, isl = (int)blockIdx.y;
     const double* info = a.info + (i64)isl * INFO_STRIDE;
@@ -320,109 +354,87 @@ k_f_spacing_write(FArgs a)
 }
 
 // ---------------------------------------------------------------------------
-// k_move
+// k_ancestors(t): integer-only.  One workgroup per tile of 1024 parents: exact
+// CDF of the tile from q and its exclusive prefix, the contiguous range of
+// offspring it owns, and the parent index of each of them -> A.
 // ---------------------------------------------------------------------------
-template <int KIND, int FK>
 __global__ void __launch_bounds__(SMC_BLOCK)
-k_move(FArgs a)
+k_ancestors(const FArgs* __restrict__ ap)
 {
-    __shared__ double sX[F_TILE];      // states of the tile's parents
+    const FArgs& a = *ap;
     __shared__ u64 sC[F_TILE];         // inclusive CDF of the tile (search path)
     __shared__ __attribute__((aligned(16))) u32 sP[F_PASS];   // parent of each offspring of a
                                                                // pass (scatter path)
     __shared__ u64 smu[SMC_SM];
-    __shared__ double smd[SMC_SM];
     __shared__ i64 sn[2];
     __shared__ u32 smx[SMC_NWAVE];
-    __shared__ int s_last;
     const int b = (int)blockIdx.x, isl = (int)blockIdx.y;
     const int tid = (int)threadIdx.x;
-    double* info = a.info + (i64)isl * INFO_STRIDE;
+    const double* info = a.info + (i64)isl * INFO_STRIDE;
     const i64 t = (i64)info[0];
-    if (t >= a.T) return;
-
+    if (t >= a.T || t == 0 || info[1] == 0.0) return;          // step t does not resample
     const i64 N = a.N;
-    const double* p = a.params + (i64)isl * PARAM_STRIDE;
-    const double yt = info[2];
     const u32 gisl = (u32)(a.island_offset + isl);
-    const int cur = (int)(t & 1);
-    double* Xn = (cur ? a.X1 : a.X0) + (i64)isl * N;
-    const double* Xo = (cur ? a.X0 : a.X1) + (i64)isl * N;
-    double* lwn = (cur ? a.lw1 : a.lw0) + (i64)isl * N;
-    const double* lwo = (cur ? a.lw0 : a.lw1) + (i64)isl * N;
     i64* A = a.A + (i64)isl * N;
-    const double* zt = a.zt ? a.zt + ((i64)t * a.n_islands + isl) * N : nullptr;
-    const bool first = (t == 0);
-    const bool resample = !first && info[1] != 0.0;
-    const bool vec = (N & 3) == 0, vec2 = (N & 1) == 0;
+    const bool vec = (N & 3) == 0;
     const i64 j0 = (i64)b * F_TILE;
 
-    SmcLse acc = smc_lse_empty();
-    i64 n_lo = j0, n_hi = (j0 + F_TILE < N) ? j0 + F_TILE : N;   // element-wise: own tile
-    i64 ns[F_IPT + 1];                                           // scatter path
-    bool scatter = false;
+    // ---- the tile's parents: q and their exact CDF
+    u64 q4[4];
+    const i64 jt = j0 + (i64)tid * F_IPT;
+    f_load4<u64, F2u>(a.q + (i64)isl * N, jt, N, vec, 0ull, q4);
+    const u64 pre = a.Qpre[(i64)isl * a.ntiles + b];
+    const u64 tsum = q4[0] + q4[1] + q4[2] + q4[3];
+    u64 total;
+    const u64 cex = pre + smc_block_exscan_u64(tsum, smu, total);   // exclusive CDF, 1st parent
     SmcSu su;
-
-    if (resample) {
-        // ---- the tile's parents: q, states, exact CDF
-        u64 q4[4];
-        double x4[4];
-        const i64 jt = j0 + (i64)tid * F_IPT;
-        f_load4<u64, F2u>(a.q + (i64)isl * N, jt, N, vec, 0ull, q4);
-        f_load4<double, F2d>(Xo, jt, N, vec, 0.0, x4);
-        const u64 pre = a.Qpre[(i64)isl * a.ntiles + b];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) sX[tid * F_IPT + i] = x4[i];
-        const u64 tsum = q4[0] + q4[1] + q4[2] + q4[3];
-        u64 total;
-        u64 cex = pre + smc_block_exscan_u64(tsum, smu, total);   // exclusive CDF, 1st parent
-        su.scheme = a.scheme;
-        su.M = N;
-        su.dM = (double)N;
-        su.u = a.ut ? a.ut + ((i64)t * a.n_islands + isl) * a.ut_stride
-                    : (a.scheme == SMC_MULTINOMIAL_ ? a.su + (i64)isl * N : nullptr);
-        su.u_sys = 0.0;
-        su.seed = a.seed;
-        su.t = (u32)t;
-        su.island = gisl;
-        if (a.scheme == SMC_SYSTEMATIC_) {
-            if (su.u) {
-                su.u_sys = su.u[0];
-            } else {
-                u64 x0, x1;
-                smc_philox(0u, su.t, su.island, SMC_STREAM_RESAMPLE, su.seed, x0, x1);
-                su.u_sys = smc_u01_halfopen(x0);
-            }
-        }
-        scatter = (a.scheme == SMC_SYSTEMATIC_) && a.log2N >= 0;
-        if (scatter) {
-            // first offspring of each parent, closed form (smc_resample.h)
-            u64 c = cex;
-            const u64 Us = (u64)(su.u_sys *
-                                 __longlong_as_double((long long)(1023 + 62 - a.log2N) << 52));
-#pragma unroll
-            for (int i = 0; i <= F_IPT; ++i) {
-                const i64 j = jt + i;
-                ns[i] = (j == 0) ? 0
-                                 : (j >= N ? N
-                                           : smc_sys_count_pow2_fast(c, su.u_sys, Us, a.log2N, N));
-                if (i < F_IPT) c += q4[i];
-            }
-            if (tid == 0) sn[0] = ns[0];
-            if (tid == SMC_BLOCK - 1) sn[1] = ns[F_IPT];
-            __syncthreads();
-            n_lo = sn[0];
-            n_hi = sn[1];
+    su.scheme = a.scheme;
+    su.M = N;
+    su.dM = (double)N;
+    su.u = a.ut ? a.ut + ((i64)t * a.n_islands + isl) * a.ut_stride
+                : (a.scheme == SMC_MULTINOMIAL_ ? a.su + (i64)isl * N : nullptr);
+    su.u_sys = 0.0;
+    su.seed = a.seed;
+    su.t = (u32)t;
+    su.island = gisl;
+    if (a.scheme == SMC_SYSTEMATIC_) {
+        if (su.u) {
+            su.u_sys = su.u[0];
         } else {
-            u64 c = cex;
-#pragma unroll
-            for (int i = 0; i < F_IPT; ++i) {
-                c += q4[i];
-                sC[tid * F_IPT + i] = c;
-            }
-            __syncthreads();
-            smc_tile_outputs(su, b, a.ntiles, pre, total, sn, n_lo, n_hi);
+            u64 x0, x1;
+            smc_philox(0u, su.t, su.island, SMC_STREAM_RESAMPLE, su.seed, x0, x1);
+            su.u_sys = smc_u01_halfopen(x0);
         }
+    }
+    const bool scatter = (a.scheme == SMC_SYSTEMATIC_) && a.log2N >= 0;
+    i64 n_lo, n_hi;
+    i64 ns[F_IPT + 1];
+    if (scatter) {
+        // first offspring of each parent, closed form (smc_resample.h)
+        u64 c = cex;
+        const u64 Us = (u64)(su.u_sys *
+                             __longlong_as_double((long long)(1023 + 62 - a.log2N) << 52));
+#pragma unroll
+        for (int i = 0; i <= F_IPT; ++i) {
+            const i64 j = jt + i;
+            ns[i] = (j == 0) ? 0
+                             : (j >= N ? N : smc_sys_count_pow2_fast(c, su.u_sys, Us, a.log2N, N));
+            if (i < F_IPT) c += q4[i];
+        }
+        if (tid == 0) sn[0] = ns[0];
+        if (tid == SMC_BLOCK - 1) sn[1] = ns[F_IPT];
+        __syncthreads();
+        n_lo = sn[0];
+        n_hi = sn[1];
+    } else {
+        u64 c = cex;
+#pragma unroll
+        for (int i = 0; i < F_IPT; ++i) {
+            c += q4[i];
+            sC[tid * F_IPT + i] = c;
+        }
+        __syncthreads();
+        smc_tile_outputs(su, b, a.ntiles, pre, total, sn, n_lo, n_hi);
     }
     const int nvalid = (int)((N - j0 < F_TILE) ? (N - j0) : F_TILE);
 
@@ -430,20 +442,10 @@ k_move(FArgs a)
     for (i64 pb = n_lo & ~(i64)3; pb < n_hi; pb += F_PASS) {
         const i64 n0 = pb + (i64)tid * 4;
         bool ok[4];
-        int par[4];
+        i64 a4[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ok[i] = (n0 + i >= n_lo) && (n0 + i < n_hi);
-            par[i] = tid * 4 + i;                      // element-wise: the particle itself
-        }
-        // element-wise steps: the particle's own state / log-weight, requested now
-        // so that the loads fly while the normals are being generated
-        double xo4[4] = {0.0, 0.0, 0.0, 0.0}, lo4[4] = {0.0, 0.0, 0.0, 0.0};
-        if (!resample && !first && (ok[0] || ok[3])) {
-            f_load4<double, F2d>(Xo, n0, N, vec, 0.0, xo4);
-            f_load4<double, F2d>(lwo, n0, N, vec, 0.0, lo4);
-        }
-        if (resample && scatter) {
+        for (int i = 0; i < 4; ++i) ok[i] = (n0 + i >= n_lo) && (n0 + i < n_hi);
+        if (scatter) {
             __syncthreads();                           // previous pass has read sP
             *reinterpret_cast<uint4*>(&sP[tid * 4]) = make_uint4(0u, 0u, 0u, 0u);
             __syncthreads();
@@ -465,64 +467,140 @@ k_move(FArgs a)
 #pragma unroll
             for (int w = 0; w < SMC_NWAVE - 1; ++w)
                 if (w < smc_wave()) ex = ex > smx[w] ? ex : smx[w];
-            par[0] = (int)(m0 > ex ? m0 : ex);
-            par[1] = (int)(m1 > ex ? m1 : ex);
-            par[2] = (int)(m2 > ex ? m2 : ex);
-            par[3] = (int)(m3 > ex ? m3 : ex);
-        } else if (resample) {
+            a4[0] = j0 + (i64)(m0 > ex ? m0 : ex);
+            a4[1] = j0 + (i64)(m1 > ex ? m1 : ex);
+            a4[2] = j0 + (i64)(m2 > ex ? m2 : ex);
+            a4[3] = j0 + (i64)(m3 > ex ? m3 : ex);
+        } else {
             double s4[4];
             smc_su_pair(su, n0 >> 1, s4[0], s4[1]);
             smc_su_pair(su, (n0 >> 1) + 1, s4[2], s4[3]);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                int jl = ok[i] ? smc_lower_bound_u64(sC, F_TILE, smc_q62_t(s4[i])) : 0;
-                par[i] = jl < nvalid ? jl : nvalid - 1;
+                const int jl = ok[i] ? smc_lower_bound_u64(sC, F_TILE, smc_q62_t(s4[i])) : 0;
+                a4[i] = j0 + (jl < nvalid ? jl : nvalid - 1);
             }
         }
-        // ---- two pairs (n, n+1): one Philox call each; the stores of the first
-        // pair are in flight while the second pair is computed
+        f_store4<i64, F2i>(A, n0, vec && ok[0] && ok[3], ok, a4);            // core.py:329
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_propagate(t): element-wise over the new particles, OPT consecutive ones per
+// thread.  x = loc(X_{t-1}[A]) + scale z, weight increment, log-weights, online
+// log-sum-exp partial; the last workgroup of the island finalises the step.
+// ---------------------------------------------------------------------------
+template <int KIND, int FK, int OPT>
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_propagate(const FArgs* __restrict__ ap)
+{
+    const FArgs& a = *ap;
+    __shared__ double smd[SMC_SM];
+    __shared__ int s_last;
+    const int b = (int)blockIdx.x, isl = (int)blockIdx.y;
+    const int tid = (int)threadIdx.x;
+    double* info = a.info + (i64)isl * INFO_STRIDE;
+    const i64 t = (i64)info[0];
+    if (t >= a.T) return;
+    const i64 N = a.N;
+    const double* p = a.params + (i64)isl * PARAM_STRIDE;
+    const double yt = info[2];
+    const u32 gisl = (u32)(a.island_offset + isl);
+    const int cur = (int)(t & 1);
+    double* Xn = (cur ? a.X1 : a.X0) + (i64)isl * N;
+    const double* Xo = (cur ? a.X0 : a.X1) + (i64)isl * N;
+    double* lwn = (cur ? a.lw1 : a.lw0) + (i64)isl * N;
+    const double* lwo = (cur ? a.lw0 : a.lw1) + (i64)isl * N;
+    const i64* A = a.A + (i64)isl * N;
+    const double* zt = a.zt ? a.zt + ((i64)t * a.n_islands + isl) * N : nullptr;
+    const bool first = (t == 0);
+    const bool resample = !first && info[1] != 0.0;
+    const bool vec = (N % OPT) == 0;          // every island base then is 8*OPT-byte aligned
+    const i64 n0 = ((i64)b * SMC_BLOCK + tid) * OPT;
+
+    SmcLse acc = smc_lse_empty();
+    if (n0 < N) {
+        const bool full = vec && n0 + OPT <= N;
+        double xp[OPT], lwp[OPT], z[OPT];
+        // ---- parents' states (gather through A when resampled) and old log-weights
+        if (resample) {
+            i64 an[OPT];
+            if (full) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const bool ok0 = ok[2 * h], ok1 = ok[2 * h + 1];
-            if (!(ok0 || ok1)) continue;
-            const i64 n = n0 + 2 * h;
-            double z0, z1;
-            if (zt) {
-                z0 = ok0 ? zt[n] : 0.0;
-                z1 = ok1 ? zt[n + 1] : 0.0;
+                for (int k = 0; k < OPT; k += 2) {
+                    const F2i v = *reinterpret_cast<const F2i*>(A + n0 + k);
+                    an[k] = v.a; an[k + 1] = v.b;
+                }
             } else {
-                smc_normal_pair(a.seed, (u32)(n >> 1), (u32)t, gisl, SMC_STREAM_NORMAL, z0, z1);
-            }
-            double xv[2], lv[2];
-            i64 av[2];
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int i = 2 * h + e;
-                const double xp = resample ? sX[par[i]] : xo4[i];
-                double inc;
-                xv[e] = m_step<KIND, FK>(p, first, yt, xp, e ? z1 : z0, inc);
-                double lw = (resample || first) ? inc : lo4[i] + inc;   // resampling.py:241-244
-                if (lw != lw) lw = -INFINITY;                            // resampling.py:220
-                lv[e] = lw;
-                av[e] = resample ? j0 + par[i] : n + e;                  // core.py:329 / :335
-                if (e ? ok1 : ok0) smc_lse_push(acc, lw);
+                for (int k = 0; k < OPT; ++k) an[k] = (n0 + k < N) ? A[n0 + k] : 0;
             }
-            f_store2<double, F2d>(Xn, n, vec2, ok0, ok1, xv[0], xv[1]);
-            f_store2<double, F2d>(lwn, n, vec2, ok0, ok1, lv[0], lv[1]);
-            if (!first) f_store2<i64, F2i>(A, n, vec2, ok0, ok1, av[0], av[1]);
+#pragma unroll
+            for (int k = 0; k < OPT; ++k) { xp[k] = Xo[an[k]]; lwp[k] = 0.0; }    // core.py:332
+        } else if (!first) {
+            if (full) {
+#pragma unroll
+                for (int k = 0; k < OPT; k += 2) {
+                    const F2d v = *reinterpret_cast<const F2d*>(Xo + n0 + k);
+                    const F2d w = *reinterpret_cast<const F2d*>(lwo + n0 + k);
+                    xp[k] = v.a; xp[k + 1] = v.b; lwp[k] = w.a; lwp[k + 1] = w.b;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < OPT; ++k) {
+                    xp[k] = (n0 + k < N) ? Xo[n0 + k] : 0.0;
+                    lwp[k] = (n0 + k < N) ? lwo[n0 + k] : 0.0;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < OPT; ++k) { xp[k] = 0.0; lwp[k] = 0.0; }
+        }
+        // ---- standard normals: one Philox call per (even, odd) pair, or the tape
+        if (zt) {
+#pragma unroll
+            for (int k = 0; k < OPT; ++k) z[k] = (n0 + k < N) ? zt[n0 + k] : 0.0;
+        } else {
+#pragma unroll
+            for (int k = 0; k < OPT; k += 2)
+                smc_normal_pair(a.seed, (u32)((n0 + k) >> 1), (u32)t, gisl, SMC_STREAM_NORMAL,
+                                z[k], z[k + 1]);
+        }
+        double xn[OPT], lw[OPT];
+#pragma unroll
+        for (int k = 0; k < OPT; ++k) {
+            double inc;
+            xn[k] = m_step<KIND, FK>(p, first, yt, xp[k], z[k], inc);
+            double l = (resample || first) ? inc : lwp[k] + inc;          // resampling.py:241-244
+            if (l != l) l = -INFINITY;                                     // resampling.py:220
+            lw[k] = l;
+            if (n0 + k < N) smc_lse_push(acc, l);
+        }
+        if (full) {
+#pragma unroll
+            for (int k = 0; k < OPT; k += 2) {
+                F2d v, w;
+                v.a = xn[k]; v.b = xn[k + 1]; w.a = lw[k]; w.b = lw[k + 1];
+                *reinterpret_cast<F2d*>(Xn + n0 + k) = v;
+                *reinterpret_cast<F2d*>(lwn + n0 + k) = w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < OPT; ++k)
+                if (n0 + k < N) { Xn[n0 + k] = xn[k]; lwn[n0 + k] = lw[k]; }
         }
     }
     const SmcLse r = smc_lse_block(acc, smd);
-    const i64 o = (i64)isl * a.ntiles;
+    const i64 o = (i64)isl * a.nparts;
     if (tid == 0) {
-        a.pm[o + b] = r.m;
-        a.ps[o + b] = r.s;
-        a.pss[o + b] = r.ss;
+        smc_st_agent_f64(a.pm + o + b, r.m);
+        smc_st_agent_f64(a.ps + o + b, r.s);
+        smc_st_agent_f64(a.pss + o + b, r.ss);
     }
-    if (!f_last_block(a.cnt + isl * 2, (unsigned)a.ntiles, &s_last)) return;
+    if (!f_last_block(a.cnt + (isl * 2) * F_CNT_WORDS, b, a.nparts, &s_last)) return;
 
     // ---- last workgroup of this island: finalise step t, decide step t+1
-    const SmcLse g = smc_lse_reduce_partials(a.pm + o, a.ps + o, a.pss + o, a.ntiles, smd);
+    const SmcLse g = smc_lse_reduce_partials<true>(a.pm + o, a.ps + o, a.pss + o, a.nparts, smd);
     if (tid == 0) {
         const bool bad = !(g.m > -INFINITY) || !(g.m < INFINITY);
         const double ess = bad ? NAN : (g.s * g.s) / g.ss;                  // resampling.py:226
@@ -546,7 +624,6 @@ k_move(FArgs a)
         info[3] = g.m;
         info[4] = rs;
         info[0] = (double)(t + 1);
-        a.cnt[isl * 2] = 0u;
     }
 }
 
