@@ -142,7 +142,7 @@ __device__ __forceinline__ double smc_block_max(double v, double* sm)
     __syncthreads();
     double r = sm[0];
 #pragma unroll
-    for (int w = 1; w < SMC_NWAVE; ++w) r = fmax(r, sm[w]);
+    for (int w = 1; w < SMC_NWAVE; ++w) r = smc_max2(r, sm[w]);
     return r;
 }
 __device__ __forceinline__ double smc_block_sum(double v, double* sm)
@@ -184,7 +184,7 @@ __device__ __forceinline__ u64 smc_block_sum_u64(u64 v, u64* sm)
 // exclusive prefix over the workgroup's threads (thread order) + total
 __device__ __forceinline__ u64 smc_block_exscan_u64(u64 v, u64* sm, u64& total)
 {
-    const u64 inc = smc_wave_scan_u64(v, SmcOpAddU64());
+    const u64 inc = smc_wave_scan_add_u64(v);
     __syncthreads();
     if (smc_lane() == 63) sm[smc_wave()] = inc;
     __syncthreads();
@@ -202,7 +202,7 @@ __device__ __forceinline__ u64 smc_block_exscan_u64(u64 v, u64* sm, u64& total)
 __device__ __forceinline__ u64 smc_block_exscan_plus_sum_u64(u64 v, u64 extra, u64* sm,
                                                              u64& total, u64& extra_sum)
 {
-    const u64 inc = smc_wave_scan_u64(v, SmcOpAddU64());
+    const u64 inc = smc_wave_scan_add_u64(v);
     const u64 es = smc_wave_sum_u64(extra);
     __syncthreads();
     if (smc_lane() == 63) { sm[smc_wave()] = inc; sm[SMC_NWAVE + smc_wave()] = es; }
@@ -266,30 +266,32 @@ __device__ __forceinline__ SmcLse smc_lse_block(SmcLse a, double* sm)
 __device__ __forceinline__ void smc_lse_merge(SmcLse& a, double m2, double s2, double ss2)
 {
     if (!(m2 > -INFINITY)) return;
-    const double m = fmax(a.m, m2);
+    const double m = smc_max2(a.m, m2);
     const double e1 = (a.m > -INFINITY) ? smc_exp_nonpos(a.m - m) : 0.0;
     const double e2 = smc_exp_nonpos(m2 - m);
     a.s = a.s * e1 + s2 * e2;
     a.ss = a.ss * (e1 * e1) + ss2 * (e2 * e2);
     a.m = m;
 }
-// Reduce `n` per-workgroup partials (SoA: pm, ps, pss) to the global (m,s,ss).
-// Called by every thread of ONE workgroup.  AGENT: the partials were published
-// by other workgroups of the same launch (smc_st_agent) and are read with
-// agent-scope loads; four entries of each array are requested back to back so
-// the whole read costs one memory round trip, not one per entry.
+// Reduce `count` per-workgroup partials (SoA: pm, ps, pss; entries first,
+// first+stride, ...) to one (m,s,ss).  Called by every thread of ONE workgroup.
+// AGENT: the partials were published by other workgroups of the same launch
+// (smc_st_agent) and are read with agent-scope loads; four entries of each
+// array are requested back to back so a batch costs one memory round trip.
 template <bool AGENT = false>
 __device__ __forceinline__ SmcLse smc_lse_reduce_partials(const double* pm, const double* ps,
-                                                          const double* pss, int n, double* sm)
+                                                          const double* pss, int count,
+                                                          double* sm, int first = 0,
+                                                          int stride = 1)
 {
     SmcLse acc = smc_lse_empty();
-    for (int base = 0; base < n; base += 4 * SMC_BLOCK) {
+    for (int base = 0; base < count; base += 4 * SMC_BLOCK) {
         double vm[4], vs[4], vq[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int i = base + k * SMC_BLOCK + (int)threadIdx.x;
-            const bool in = i < n;
-            const int ii = in ? i : 0;
+            const bool in = i < count;
+            const int ii = first + (in ? i : 0) * stride;
             vm[k] = AGENT ? smc_ld_agent_f64(pm + ii) : pm[ii];
             vs[k] = AGENT ? smc_ld_agent_f64(ps + ii) : ps[ii];
             vq[k] = AGENT ? smc_ld_agent_f64(pss + ii) : pss[ii];

@@ -1,11 +1,15 @@
 // smc_dpp.h -- wave64 scans / reductions on the DPP data path (v_mov_b32_dpp
 // row_shr / row_bcast), instead of ds_bpermute round trips through the LDS
-// hardware: a 6-step inclusive scan costs ~6 x (2 DPP moves + 1 op) VALU
-// instructions and no LDS latency.
+// hardware.
 //
 // Sequence (Kogge-Stone inside each row of 16 lanes, then row broadcasts):
-//   row_shr:1, row_shr:2, row_shr:4, row_shr:8, row_bcast:15, row_bcast:31
-// after which lane l holds op(x_0..x_l) and lane 63 the wave total.
+//   row_shr:1, row_shr:2, row_shr:4, row_shr:8, row_bcast:15 (rows 1,3),
+//   row_bcast:31 (rows 2,3)
+// after which lane l holds op(x_0..x_l) and lane 63 the wave total.  Lanes
+// without a source read the operation's identity straight from the DPP
+// controls (bound_ctrl zero-fill for sums, their own value for max; row_mask
+// for the broadcasts), so a step is two DPP moves and one op per 64-bit value
+// -- no compare/select.
 #pragma once
 #include "smc_platform.h"
 
@@ -14,32 +18,36 @@
 #define SMC_DPP_ROW_BCAST31 0x143
 #define SMC_DPP_WAVE_SHR1 0x138     /* lane l <- lane l-1 across the whole wave */
 
+// smc_dpp<CTRL, ROW_MASK, ZERO>(old, v): the value of v in the source lane that
+// CTRL designates; lanes whose row is not in ROW_MASK keep `old`; lanes whose
+// source does not exist get 0 if ZERO (bound_ctrl) else `old`.
 #ifdef SMC_EMULATE
-// emulator: source lane of each control code (guards in the callers make the
-// value delivered to lanes without a valid source irrelevant)
-template <int CTRL>
-inline unsigned smc_mov_dpp(unsigned v)
+template <int CTRL, int ROW_MASK, bool ZERO>
+inline unsigned smc_dpp(unsigned old, unsigned v)
 {
     const int l = emu_lane();
-    int src = l;
+    int src = -1;
     if (CTRL >= 0x111 && CTRL <= 0x11F) {
         const int n = CTRL - 0x110;
-        src = ((l & 15) >= n) ? l - n : l;
+        src = ((l & 15) >= n) ? l - n : -1;
     } else if (CTRL == SMC_DPP_ROW_BCAST15) {
-        src = (l >= 16) ? (l & ~15) - 1 : l;
+        src = (l >= 16) ? (l & ~15) - 1 : -1;
     } else if (CTRL == SMC_DPP_ROW_BCAST31) {
-        src = (l >= 32) ? 31 : l;
+        src = (l >= 32) ? 31 : -1;
     } else if (CTRL == SMC_DPP_WAVE_SHR1) {
-        src = (l >= 1) ? l - 1 : l;
+        src = (l >= 1) ? l - 1 : -1;
     }
-    return hipemu::exchange(v, emu_wbase() + src);
+    const unsigned got = hipemu::exchange(v, emu_wbase() + (src < 0 ? l : src));
+    if (!((ROW_MASK >> (l >> 4)) & 1)) return old;
+    if (src < 0) return ZERO ? 0u : old;
+    return got;
 }
 inline unsigned smc_readlane(unsigned v, int lane) { return hipemu::exchange(v, emu_wbase() + lane); }
 #else
-template <int CTRL>
-__device__ __forceinline__ unsigned smc_mov_dpp(unsigned v)
+template <int CTRL, int ROW_MASK, bool ZERO>
+__device__ __forceinline__ unsigned smc_dpp(unsigned old, unsigned v)
 {
-    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+    return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xf, ZERO);
 }
 __device__ __forceinline__ unsigned smc_readlane(unsigned v, int lane)
 {
@@ -48,15 +56,9 @@ __device__ __forceinline__ unsigned smc_readlane(unsigned v, int lane)
 #endif
 
 template <int CTRL>
-__device__ __forceinline__ u64 smc_mov_dpp64(u64 v)
+__device__ __forceinline__ unsigned smc_mov_dpp(unsigned v)      // lanes without source keep v
 {
-    const unsigned lo = smc_mov_dpp<CTRL>((unsigned)v), hi = smc_mov_dpp<CTRL>((unsigned)(v >> 32));
-    return ((u64)hi << 32) | lo;
-}
-template <int CTRL>
-__device__ __forceinline__ double smc_mov_dpp_f64(double v)
-{
-    return __longlong_as_double((long long)smc_mov_dpp64<CTRL>((u64)__double_as_longlong(v)));
+    return smc_dpp<CTRL, 0xf, false>(v, v);
 }
 __device__ __forceinline__ u64 smc_readlane64(u64 v, int lane)
 {
@@ -68,39 +70,88 @@ __device__ __forceinline__ double smc_readlane_f64(double v, int lane)
     return __longlong_as_double((long long)smc_readlane64((u64)__double_as_longlong(v), lane));
 }
 
-struct SmcOpAddU64 { __device__ __forceinline__ u64 operator()(u64 a, u64 b) const { return a + b; } };
-struct SmcOpMaxU32 { __device__ __forceinline__ unsigned operator()(unsigned a, unsigned b) const { return a > b ? a : b; } };
-struct SmcOpAddF64 { __device__ __forceinline__ double operator()(double a, double b) const { return a + b; } };
-struct SmcOpMaxF64 { __device__ __forceinline__ double operator()(double a, double b) const { return fmax(a, b); } };
-
-#define SMC_DPP_SCAN_BODY(MOV)                                                        \
-    const int l = (int)(threadIdx.x & 63u);                                            \
-    { auto t = op(MOV<SMC_DPP_ROW_SHR(1)>(v), v); if ((l & 15) >= 1) v = t; }          \
-    { auto t = op(MOV<SMC_DPP_ROW_SHR(2)>(v), v); if ((l & 15) >= 2) v = t; }          \
-    { auto t = op(MOV<SMC_DPP_ROW_SHR(4)>(v), v); if ((l & 15) >= 4) v = t; }          \
-    { auto t = op(MOV<SMC_DPP_ROW_SHR(8)>(v), v); if ((l & 15) >= 8) v = t; }          \
-    { auto t = op(MOV<SMC_DPP_ROW_BCAST15>(v), v); if ((l & 31) >= 16) v = t; }        \
-    { auto t = op(MOV<SMC_DPP_ROW_BCAST31>(v), v); if (l >= 32) v = t; }               \
-    return v;
+// 64-bit DPP move; OWN: lanes without a source see their own value (identity
+// of max), otherwise 0 (identity of +)
+template <int CTRL, int ROW_MASK, bool OWN>
+__device__ __forceinline__ u64 smc_dpp64(u64 v)
+{
+    const unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    const unsigned l2 = OWN ? smc_dpp<CTRL, ROW_MASK, false>(lo, lo) : smc_dpp<CTRL, ROW_MASK, true>(0u, lo);
+    const unsigned h2 = OWN ? smc_dpp<CTRL, ROW_MASK, false>(hi, hi) : smc_dpp<CTRL, ROW_MASK, true>(0u, hi);
+    return ((u64)h2 << 32) | l2;
+}
+template <int CTRL, int ROW_MASK, bool OWN>
+__device__ __forceinline__ double smc_dpp_f64(double v)
+{
+    return __longlong_as_double(
+        (long long)smc_dpp64<CTRL, ROW_MASK, OWN>((u64)__double_as_longlong(v)));
+}
 
 // inclusive scans over the 64 lanes of a wave (all lanes must be active)
-template <class Op>
-__device__ __forceinline__ u64 smc_wave_scan_u64(u64 v, Op op) { SMC_DPP_SCAN_BODY(smc_mov_dpp64) }
-template <class Op>
-__device__ __forceinline__ unsigned smc_wave_scan_u32(unsigned v, Op op) { SMC_DPP_SCAN_BODY(smc_mov_dpp) }
-template <class Op>
-__device__ __forceinline__ double smc_wave_scan_f64(double v, Op op) { SMC_DPP_SCAN_BODY(smc_mov_dpp_f64) }
+__device__ __forceinline__ u64 smc_wave_scan_add_u64(u64 v)
+{
+    v += smc_dpp64<SMC_DPP_ROW_SHR(1), 0xf, false>(v);
+    v += smc_dpp64<SMC_DPP_ROW_SHR(2), 0xf, false>(v);
+    v += smc_dpp64<SMC_DPP_ROW_SHR(4), 0xf, false>(v);
+    v += smc_dpp64<SMC_DPP_ROW_SHR(8), 0xf, false>(v);
+    v += smc_dpp64<SMC_DPP_ROW_BCAST15, 0xa, false>(v);
+    v += smc_dpp64<SMC_DPP_ROW_BCAST31, 0xc, false>(v);
+    return v;
+}
+__device__ __forceinline__ double smc_wave_scan_add_f64(double v)
+{
+    v = v + smc_dpp_f64<SMC_DPP_ROW_SHR(1), 0xf, false>(v);
+    v = v + smc_dpp_f64<SMC_DPP_ROW_SHR(2), 0xf, false>(v);
+    v = v + smc_dpp_f64<SMC_DPP_ROW_SHR(4), 0xf, false>(v);
+    v = v + smc_dpp_f64<SMC_DPP_ROW_SHR(8), 0xf, false>(v);
+    v = v + smc_dpp_f64<SMC_DPP_ROW_BCAST15, 0xa, false>(v);
+    v = v + smc_dpp_f64<SMC_DPP_ROW_BCAST31, 0xc, false>(v);
+    return v;
+}
+// max of two doubles in one instruction (fmax() canonicalises both operands
+// first: three v_max_f64); NaNs never reach the reductions (sanitised to -inf)
+__device__ __forceinline__ double smc_max2(double a, double b)
+{
+#ifdef SMC_EMULATE
+    return a > b ? a : b;
+#else
+    double o;
+    asm("v_max_f64 %0, %1, %2" : "=v"(o) : "v"(a), "v"(b));
+    return o;
+#endif
+}
+__device__ __forceinline__ double smc_wave_scan_max_f64(double v)
+{
+    v = smc_max2(v, smc_dpp_f64<SMC_DPP_ROW_SHR(1), 0xf, true>(v));
+    v = smc_max2(v, smc_dpp_f64<SMC_DPP_ROW_SHR(2), 0xf, true>(v));
+    v = smc_max2(v, smc_dpp_f64<SMC_DPP_ROW_SHR(4), 0xf, true>(v));
+    v = smc_max2(v, smc_dpp_f64<SMC_DPP_ROW_SHR(8), 0xf, true>(v));
+    v = smc_max2(v, smc_dpp_f64<SMC_DPP_ROW_BCAST15, 0xa, true>(v));
+    v = smc_max2(v, smc_dpp_f64<SMC_DPP_ROW_BCAST31, 0xc, true>(v));
+    return v;
+}
+__device__ __forceinline__ unsigned smc_wave_scan_max_u32(unsigned v)
+{
+    unsigned t;
+    t = smc_dpp<SMC_DPP_ROW_SHR(1), 0xf, true>(0u, v); v = v > t ? v : t;
+    t = smc_dpp<SMC_DPP_ROW_SHR(2), 0xf, true>(0u, v); v = v > t ? v : t;
+    t = smc_dpp<SMC_DPP_ROW_SHR(4), 0xf, true>(0u, v); v = v > t ? v : t;
+    t = smc_dpp<SMC_DPP_ROW_SHR(8), 0xf, true>(0u, v); v = v > t ? v : t;
+    t = smc_dpp<SMC_DPP_ROW_BCAST15, 0xa, true>(0u, v); v = v > t ? v : t;
+    t = smc_dpp<SMC_DPP_ROW_BCAST31, 0xc, true>(0u, v); v = v > t ? v : t;
+    return v;
+}
 
 // reductions: every lane receives the wave's result (order of operations fixed)
 __device__ __forceinline__ u64 smc_wave_sum_u64(u64 v)
 {
-    return smc_readlane64(smc_wave_scan_u64(v, SmcOpAddU64()), 63);
+    return smc_readlane64(smc_wave_scan_add_u64(v), 63);
 }
 __device__ __forceinline__ double smc_wave_sum(double v)
 {
-    return smc_readlane_f64(smc_wave_scan_f64(v, SmcOpAddF64()), 63);
+    return smc_readlane_f64(smc_wave_scan_add_f64(v), 63);
 }
 __device__ __forceinline__ double smc_wave_max(double v)
 {
-    return smc_readlane_f64(smc_wave_scan_f64(v, SmcOpMaxF64()), 63);
+    return smc_readlane_f64(smc_wave_scan_max_f64(v), 63);
 }

@@ -133,12 +133,13 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     const size_t oPar = carve(M * PARAM_STRIDE * 8);
     const size_t oY = carve(T * 8);
     const size_t oCtl = carve(M * 2 * F_CNT_WORDS * sizeof(unsigned));
+    const size_t oSpart = carve(M * 96 * 8);
     const size_t oInfo = carve(M * INFO_STRIDE * 8);
     const size_t oSu = carve(need_su ? M * N * 8 : 8);
     const size_t oE = carve(need_su ? M * a.ntiles1 * 8 : 8);
     const size_t oTmp = carve(N * 8);
     const size_t oArgs = carve(sizeof(FArgs));
-    const size_t oTrace = carve(M * a.ntiles * 8 * 8);
+    const size_t oTrace = carve(M * (size_t)(2 * a.ntiles + 8) * 8 * 8);
     void* slab = nullptr;
     hipError_t e = hipMalloc(&slab, off);
     if (e != hipSuccess) {
@@ -161,6 +162,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     a.params = dpar;
     a.y = dy;
     a.cnt = (unsigned*)(base + oCtl);
+    a.spart = (double*)(base + oSpart);
     a.info = (double*)(base + oInfo);
     a.su = (double*)(base + oSu);
     a.E = (u64*)(base + oE);
@@ -191,7 +193,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
 // debug builds only (tools/trace_kmove.py): per-workgroup phase stamps of the last k_move
 int smc_debug_trace(smc_filter* f, uint64_t* out_host)
 {
-    SMC_HIP_CHECK(hipMemcpyAsync(out_host, f->a.trace, (size_t)f->a.n_islands * f->a.ntiles * 64,
+    SMC_HIP_CHECK(hipMemcpyAsync(out_host, f->a.trace, (size_t)f->a.n_islands * f->a.nparts * 64,
                                  hipMemcpyDeviceToHost, f->ctx->stream));
     SMC_HIP_CHECK(hipStreamSynchronize(f->ctx->stream));
     return SMC_OK;

@@ -59,7 +59,8 @@ struct FArgs {
     u64* Q;                // (n_islands, ntiles) tile totals of q
     u64* Qpre;             // (n_islands, ntiles) exclusive prefixes of Q
     double *pm, *ps, *pss; // (n_islands, ntiles) log-sum-exp partials
-    unsigned* cnt;         // (n_islands, 2, F_CNT_WORDS) completion tickets: k_move, k_prepare
+    unsigned* cnt;         // (n_islands, 2, F_CNT_WORDS) completion tickets: k_propagate, k_prepare
+    double* spart;         // (n_islands, 3, 32) shard-level log-sum-exp partials
     double* summ;          // (n_islands, T+1, SUMM_STRIDE)
     const double* params;  // (n_islands, PARAM_STRIDE)
     const double* y;       // (T,)
@@ -75,7 +76,7 @@ struct FArgs {
 };
 
 #ifdef SMC_TRACE
-#define F_STAMP(k) do { if (threadIdx.x == 0) a.trace[((i64)blockIdx.y * a.ntiles + blockIdx.x) * 8 + (k)] = (u64)wall_clock64(); } while (0)
+#define F_STAMP(k) do { if (threadIdx.x == 0) a.trace[((i64)blockIdx.y * a.nparts + blockIdx.x) * 8 + (k)] = (u64)wall_clock64(); } while (0)
 #else
 #define F_STAMP(k) do { } while (0)
 #endif
@@ -459,7 +460,7 @@ k_ancestors(const FArgs* __restrict__ ap)
             const uint4 v = *reinterpret_cast<const uint4*>(&sP[tid * 4]);
             const u32 m0 = v.x, m1 = m0 > v.y ? m0 : v.y, m2 = m1 > v.z ? m1 : v.z,
                       m3 = m2 > v.w ? m2 : v.w;
-            const u32 inc = smc_wave_scan_u32(m3, SmcOpMaxU32());
+            const u32 inc = smc_wave_scan_max_u32(m3);
             u32 ex = smc_mov_dpp<SMC_DPP_WAVE_SHR1>(inc);
             if (smc_lane() == 0) ex = 0u;
             if (smc_lane() == 63) smx[smc_wave()] = inc;
@@ -499,9 +500,11 @@ k_propagate(const FArgs* __restrict__ ap)
     __shared__ int s_last;
     const int b = (int)blockIdx.x, isl = (int)blockIdx.y;
     const int tid = (int)threadIdx.x;
+    F_STAMP(0);
     double* info = a.info + (i64)isl * INFO_STRIDE;
     const i64 t = (i64)info[0];
     if (t >= a.T) return;
+    F_STAMP(1);
     const i64 N = a.N;
     const double* p = a.params + (i64)isl * PARAM_STRIDE;
     const double yt = info[2];
@@ -522,9 +525,10 @@ k_propagate(const FArgs* __restrict__ ap)
     if (n0 < N) {
         const bool full = vec && n0 + OPT <= N;
         double xp[OPT], lwp[OPT], z[OPT];
-        // ---- parents' states (gather through A when resampled) and old log-weights
+        // ---- ancestor indices (when resampled) or the particle's own state and
+        // log-weight: requested first, consumed after the normals are generated
+        i64 an[OPT];
         if (resample) {
-            i64 an[OPT];
             if (full) {
 #pragma unroll
                 for (int k = 0; k < OPT; k += 2) {
@@ -535,8 +539,6 @@ k_propagate(const FArgs* __restrict__ ap)
 #pragma unroll
                 for (int k = 0; k < OPT; ++k) an[k] = (n0 + k < N) ? A[n0 + k] : 0;
             }
-#pragma unroll
-            for (int k = 0; k < OPT; ++k) { xp[k] = Xo[an[k]]; lwp[k] = 0.0; }    // core.py:332
         } else if (!first) {
             if (full) {
 #pragma unroll
@@ -566,6 +568,11 @@ k_propagate(const FArgs* __restrict__ ap)
                 smc_normal_pair(a.seed, (u32)((n0 + k) >> 1), (u32)t, gisl, SMC_STREAM_NORMAL,
                                 z[k], z[k + 1]);
         }
+        if (resample) {
+#pragma unroll
+            for (int k = 0; k < OPT; ++k) { xp[k] = Xo[an[k]]; lwp[k] = 0.0; }    // core.py:332
+        }
+        F_STAMP(2);
         double xn[OPT], lw[OPT];
 #pragma unroll
         for (int k = 0; k < OPT; ++k) {
@@ -590,17 +597,46 @@ k_propagate(const FArgs* __restrict__ ap)
                 if (n0 + k < N) { Xn[n0 + k] = xn[k]; lwn[n0 + k] = lw[k]; }
         }
     }
+    F_STAMP(3);
     const SmcLse r = smc_lse_block(acc, smd);
+    F_STAMP(4);
     const i64 o = (i64)isl * a.nparts;
+    // ---- publish the partial; two-level "last one reduces" (no spinning):
+    // the last workgroup of each of the 32 shards reduces its shard's partials,
+    // the last of those reduces the 32 shard results and finalises the step
+    const int shards = a.nparts >= 64 ? 32 : 1;
+    const int sh = b & (shards - 1);
+    const int size_s = a.nparts / shards + (sh < a.nparts % shards ? 1 : 0);
+    unsigned* cnt = a.cnt + (isl * 2) * F_CNT_WORDS;
+    double* spart = a.spart + (i64)isl * 96;
     if (tid == 0) {
         smc_st_agent_f64(a.pm + o + b, r.m);
         smc_st_agent_f64(a.ps + o + b, r.s);
         smc_st_agent_f64(a.pss + o + b, r.ss);
+        smc_drain_stores();
+        s_last = atomicAdd(cnt + (1 + sh) * F_CNT_STRIDE, 1u) == (unsigned)(size_s - 1);
     }
-    if (!f_last_block(a.cnt + (isl * 2) * F_CNT_WORDS, b, a.nparts, &s_last)) return;
+    __syncthreads();
+    F_STAMP(5);
+    if (!s_last) return;
+    const SmcLse gs = smc_lse_reduce_partials<true>(a.pm + o, a.ps + o, a.pss + o, size_s, smd, sh,
+                                                    shards);
+    __syncthreads();
+    if (tid == 0) {
+        cnt[(1 + sh) * F_CNT_STRIDE] = 0u;                 // re-arm for the next launch
+        smc_st_agent_f64(spart + sh, gs.m);
+        smc_st_agent_f64(spart + 32 + sh, gs.s);
+        smc_st_agent_f64(spart + 64 + sh, gs.ss);
+        smc_drain_stores();
+        s_last = atomicAdd(cnt, 1u) == (unsigned)(shards - 1);
+        if (s_last) cnt[0] = 0u;
+    }
+    __syncthreads();
+    F_STAMP(6);
+    if (!s_last) return;
 
     // ---- last workgroup of this island: finalise step t, decide step t+1
-    const SmcLse g = smc_lse_reduce_partials<true>(a.pm + o, a.ps + o, a.pss + o, a.nparts, smd);
+    const SmcLse g = smc_lse_reduce_partials<true>(spart, spart + 32, spart + 64, shards, smd);
     if (tid == 0) {
         const bool bad = !(g.m > -INFINITY) || !(g.m < INFINITY);
         const double ess = bad ? NAN : (g.s * g.s) / g.ss;                  // resampling.py:226
@@ -625,6 +661,7 @@ k_propagate(const FArgs* __restrict__ ap)
         info[4] = rs;
         info[0] = (double)(t + 1);
     }
+    F_STAMP(7);
 }
 
 // W = exp(lw - m)/s for one island (SMC.W)

@@ -16,30 +16,66 @@
 
 #include <cmath>
 
+// Polynomial coefficients live in constant memory: the compiler fetches them
+// with scalar loads and feeds them to v_fma_f64 as SGPR operands.  Written as
+// literals they would each cost a v_mov_b64 (fp64 VOP3 encodings cannot carry a
+// 64-bit literal), i.e. double the instruction count of every polynomial.
+#ifdef SMC_EMULATE
+#define SMC_CONST static const
+#else
+#define SMC_CONST static __constant__ const
+#endif
+// p*r + K with K taken straight from an SGPR pair (VOP3 v_fma_f64).  Left to
+// itself the compiler picks the two-address v_fmac_f64, whose addend must sit in
+// the destination VGPR, and spends two v_mov_b32 per coefficient copying K there.
+#ifdef SMC_EMULATE
+#define SMC_FMA_K(p, r, K) fma((p), (r), (K))
+#else
+__device__ __forceinline__ double smc_fma_k(double p, double r, double K)
+{
+    double o;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(o) : "v"(p), "v"(r), "s"(K));
+    return o;
+}
+#define SMC_FMA_K(p, r, K) smc_fma_k((p), (r), (K))
+#endif
+
+SMC_CONST double smc_k_exp[16] = {
+    1.6059043836821613e-10, 2.0876756987868100e-09, 2.5052108385441720e-08,
+    2.7557319223985888e-07, 2.7557319223985893e-06, 2.4801587301587302e-05,
+    1.9841269841269841e-04, 1.3888888888888889e-03, 8.3333333333333332e-03,
+    4.1666666666666664e-02, 1.6666666666666666e-01, 0.5,
+    1.4426950408889634074, 6.93147180369123816490e-01, 1.90821492927058770002e-10, -745.2};
+SMC_CONST double smc_k_log[10] = {
+    1.531383769920937332e-01, 2.222219843214978396e-01, 3.999999999940941908e-01,
+    1.479819860511658591e-01, 1.818357216161805012e-01, 2.857142874366239149e-01,
+    6.666666666666735130e-01, 0.70710678118654752440, 6.93147180369123816490e-01,
+    1.90821492927058770002e-10};
+SMC_CONST double smc_k_sc[18] = {
+    2.8114572543455206e-15, -7.6471637318198164e-13, 1.6059043836821613e-10,
+    -2.5052108385441720e-08, 2.7557319223985893e-06, -1.9841269841269841e-04,
+    8.3333333333333332e-03, -1.6666666666666666e-01,
+    -1.5619206968586225e-16, 4.7794773323873853e-14, -1.1470745597729725e-11,
+    2.0876756987868100e-09, -2.7557319223985888e-07, 2.4801587301587302e-05,
+    -1.3888888888888889e-03, 4.1666666666666664e-02,
+    3.14159265358979311600e+00, 1.22464679914735317723e-16};
+
 __host__ __device__ __forceinline__ double smc_exp_nonpos(double x)
 {
+    const double* K = smc_k_exp;
     // k = round(x / ln2), r = x - k ln2 (Cody-Waite, two-part ln2), |r| <= ln2/2
-    const double k = rint(x * 1.4426950408889634074);
-    double r = fma(-k, 6.93147180369123816490e-01, x);     // ln2 high part
-    r = fma(-k, 1.90821492927058770002e-10, r);            // ln2 low part
-    // exp(r) by its Taylor polynomial of degree 13 (|r|^14/14! < 5e-18)
-    double p = 1.6059043836821613e-10;                     // 1/13!
-    p = fma(p, r, 2.0876756987868100e-09);                 // 1/12!
-    p = fma(p, r, 2.5052108385441720e-08);                 // 1/11!
-    p = fma(p, r, 2.7557319223985888e-07);                 // 1/10!
-    p = fma(p, r, 2.7557319223985893e-06);                 // 1/9!
-    p = fma(p, r, 2.4801587301587302e-05);                 // 1/8!
-    p = fma(p, r, 1.9841269841269841e-04);                 // 1/7!
-    p = fma(p, r, 1.3888888888888889e-03);                 // 1/6!
-    p = fma(p, r, 8.3333333333333332e-03);                 // 1/5!
-    p = fma(p, r, 4.1666666666666664e-02);                 // 1/4!
-    p = fma(p, r, 1.6666666666666666e-01);                 // 1/3!
-    p = fma(p, r, 0.5);
+    const double k = rint(x * K[12]);
+    double r = fma(-k, K[13], x);                          // ln2 high part
+    r = fma(-k, K[14], r);                                 // ln2 low part
+    // exp(r) by its Taylor polynomial of degree 13 (|r|^14/14! < 5e-18): 1/13! ... 1/2!
+    double p = K[0];
+#pragma unroll
+    for (int i = 1; i < 12; ++i) p = SMC_FMA_K(p, r, K[i]);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
     // x < -745.2 underflows to 0 (also covers -inf, where r would be NaN)
     const double y = ldexp(p, (int)k);
-    return (x < -745.2) ? 0.0 : y;
+    return (x < K[15]) ? 0.0 : y;
 }
 
 // log(x) for a positive, finite, normal x (the Box-Muller uniform lies in
@@ -50,51 +86,40 @@ __host__ __device__ __forceinline__ double smc_exp_nonpos(double x)
 // libm entry point (which also handles 0, inf, NaN, subnormals).
 __host__ __device__ __forceinline__ double smc_log_pos(double x)
 {
+    const double* K = smc_k_log;
     int e;
     double m = frexp(x, &e);                       // m in [0.5, 1)
-    const bool lo = m < 0.70710678118654752440;
+    const bool lo = m < K[7];
     m = lo ? m + m : m;                            // [sqrt(1/2), sqrt 2)
     e = lo ? e - 1 : e;
     const double k = (double)e;
     const double f = m - 1.0;
     const double s = f / (2.0 + f);
     const double z = s * s, w = z * z;
-    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01),
-                              3.999999999940941908e-01);
-    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01),
-                                     2.857142874366239149e-01), 6.666666666666735130e-01);
+    const double t1 = w * SMC_FMA_K(SMC_FMA_K(w * K[0], 1.0, K[1]) , w, K[2]);   // Lg6, Lg4, Lg2
+    const double t2 = z * SMC_FMA_K(SMC_FMA_K(SMC_FMA_K(w * K[3], 1.0, K[4]), w, K[5]), w, K[6]);
     const double R = t1 + t2;
     const double hfsq = 0.5 * f * f;
     // k ln2_hi - ((hfsq - (s (hfsq+R) + k ln2_lo)) - f)
-    return fma(k, 6.93147180369123816490e-01,
-               -((hfsq - fma(s, hfsq + R, k * 1.90821492927058770002e-10)) - f));
+    return fma(k, K[8], -((hfsq - fma(s, hfsq + R, k * K[9])) - f));
 }
 
 __host__ __device__ __forceinline__ void smc_sincospi_02(double a, double* sn, double* cs)
 {
+    const double* K = smc_k_sc;
     // a = q/2 + r, q in {0..4}, |r| <= 1/4 ; x = pi r in [-pi/4, pi/4]
     const double qd = rint(a + a);
     const double r = fma(-0.5, qd, a);
-    const double x = fma(r, 3.14159265358979311600e+00, r * 1.22464679914735317723e-16);
+    const double x = fma(r, K[16], r * K[17]);             // pi = hi + lo
     const double z = x * x;
     // sin x = x + x z S(z), S = Taylor up to x^17 ; cos x = 1 - z/2 + z^2 C(z) up to x^18
-    double s = 2.8114572543455206e-15;                     //  1/17!
-    s = fma(s, z, -7.6471637318198164e-13);                // -1/15!
-    s = fma(s, z, 1.6059043836821613e-10);                 //  1/13!
-    s = fma(s, z, -2.5052108385441720e-08);                // -1/11!
-    s = fma(s, z, 2.7557319223985893e-06);                 //  1/9!
-    s = fma(s, z, -1.9841269841269841e-04);                // -1/7!
-    s = fma(s, z, 8.3333333333333332e-03);                 //  1/5!
-    s = fma(s, z, -1.6666666666666666e-01);                // -1/3!
+    double s = K[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) s = SMC_FMA_K(s, z, K[i]);
     const double sx = fma(x * z, s, x);
-    double c = -1.5619206968586225e-16;                    // -1/18!
-    c = fma(c, z, 4.7794773323873853e-14);                 //  1/16!
-    c = fma(c, z, -1.1470745597729725e-11);                // -1/14!
-    c = fma(c, z, 2.0876756987868100e-09);                 //  1/12!
-    c = fma(c, z, -2.7557319223985888e-07);                // -1/10!
-    c = fma(c, z, 2.4801587301587302e-05);                 //  1/8!
-    c = fma(c, z, -1.3888888888888889e-03);                // -1/6!
-    c = fma(c, z, 4.1666666666666664e-02);                 //  1/4!
+    double c = K[8];
+#pragma unroll
+    for (int i = 9; i < 16; ++i) c = SMC_FMA_K(c, z, K[i]);
     const double cx = fma(z * z, c, fma(-0.5, z, 1.0));
     const int q = (int)qd;
     // rotate by q quarter turns: (sin, cos)(x + q pi/2)

@@ -13,13 +13,13 @@ x = np.cumsum(rng.standard_normal(80)); y = [np.array([v]) for v in x + 0.2 * rn
 pf = pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y), N=N, collect="off", seed=1, ESSrmin=ess, use_graph=False)
 pf.step_async(60); pf.sync()
 L = _lib.lib()
-nt = N // 1024
+nt = N // 512
 buf = np.zeros((nt, 8), dtype=np.uint64)
 L.smc_debug_trace.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 L.smc_debug_trace(pf._f, buf.ctypes.data_as(ctypes.c_void_p))
 t = buf.astype(np.float64)
 t0 = t[:, 0].min()
-names = ["entry", "info", "cdf/loads", "compute done", "lse_block", "pending stores", "ticket", "finalize(last)"]
+names = ["entry", "info", "loads+RNG", "compute+stores", "lse_block", "publish", "ticket", "finalize(last)"]
 print("ESSrmin", ess, " wall_clock64 ticks (100 MHz => 10 ns each)")
 for k in range(8):
     col = t[:, k]; col = col[col > 0] - t0
