@@ -28,7 +28,7 @@ struct smc_filter {
 
 typedef void (*move_fn)(FArgs);
 
-#define F_OPT 2     /* new particles per thread of k_propagate */
+#define F_OPT 4     /* new particles per thread of k_propagate */
 
 static void launch_propagate(smc_filter* f)
 {
