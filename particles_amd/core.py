@@ -136,8 +136,8 @@ class SMC:
         model = fk._device_model() if hasattr(fk, "_device_model") else None
         if fk is not None and fk.isAPF:
             model = None
-        self._fused = model is not None and model.get("params") is not None \
-            and resampling in _lib.SCHEMES
+        self._fused = model is not None and resampling in _lib.SCHEMES \
+            and (model.get("params") is not None or model["kind"] == _lib.MODEL_MVLINGAUSS)
         if self._fused:
             self._create_filter(model, replay, use_graph, island_offset)
         else:
@@ -152,11 +152,19 @@ class SMC:
         fk = self.fk
         T = fk.T
         y = np.ascontiguousarray(np.asarray(fk.data, dtype=np.float64).reshape(T, -1))
-        params = np.ascontiguousarray(np.tile(model["params"], (self.n_islands, 1)))
-        self._keep = (y, params)
         m = _lib.SmcModel()
         m.kind, m.fk, m.dx, m.dy = model["kind"], fk._fk_kind, model["dx"], model["dy"]
-        m.params_host = params.ctypes.data_as(_lib.P(_lib.c_dbl))
+        self._d = model["dx"]
+        if model.get("params") is not None:
+            params = np.ascontiguousarray(np.tile(model["params"], (self.n_islands, 1)))
+            m.params_host = params.ctypes.data_as(_lib.P(_lib.c_dbl))
+            self._keep = (y, params)
+        else:       # MVLinearGauss: the matrices, row-major fp64 (kalman.py:296-361)
+            mats = {k: np.ascontiguousarray(model[k], dtype=np.float64)
+                    for k in ("F", "G", "covX", "covY", "mu0", "cov0")}
+            for k, v in mats.items():
+                setattr(m, k + "_host", v.ctypes.data_as(_lib.P(_lib.c_dbl)))
+            self._keep = (y, mats)
         o = _lib.SmcFilterOpts()
         o.N, o.T, o.n_islands = self.N, T, self.n_islands
         o.scheme, o.ESSrmin, o.seed = _lib.SCHEMES[self.resampling], self.ESSrmin, self.seed
@@ -199,7 +207,9 @@ class SMC:
         key = (field, island)
         if key not in self._cache:
             dt = np.int64 if field == _lib.FIELD_A else np.float64
-            out = np.empty(self.N, dtype=dt)
+            d = getattr(self, "_d", 1)
+            shape = (self.N, d) if (d > 1 and field in (_lib.FIELD_X, _lib.FIELD_XP)) else self.N
+            out = np.empty(shape, dtype=dt)
             check(lib().smc_filter_get(self._f, field, island, out.ctypes.data_as(_lib.c_vp)))
             self._cache[key] = out
         return self._cache[key]
@@ -425,7 +435,7 @@ def multiSMC(nruns=10, nprocs=0, out_func=None, collect=None, **args):
         si += nruns
         fk = kw.get("fk")
         batch = (fk is not None and hasattr(fk, "_device_model") and fk._device_model() is not None
-                 and fk._device_model().get("params") is not None and not collect
+                 and not collect
                  and not kw.get("store_history") and not kw.get("verbose"))
         if batch and out_func is not None:
             # islands of one filter; Philox island word = run index, key = first seed

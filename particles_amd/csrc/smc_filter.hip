@@ -3,7 +3,7 @@
 // two-kernel step are in smc_filter_kernels.h.
 #include <vector>
 
-#include "smc_filter_kernels.h"
+#include "smc_filter_mv.h"
 
 // ---------------------------------------------------------------------------
 // host side
@@ -34,6 +34,18 @@ static void launch_propagate(smc_filter* f)
 {
     hipStream_t st = f->ctx->stream;
     const dim3 grid(f->a.nparts, f->a.n_islands);
+    if (f->kind == SMC_MODEL_MVLINGAUSS) {
+#define MV_CASE(FKV, DPV)                                                                   \
+    if (f->fk == FKV && f->a.dp == DPV) {                                                   \
+        SMC_LAUNCH((k_propagate_mv<FKV, DPV>), grid, dim3(SMC_BLOCK), st, f->da);           \
+        return;                                                                             \
+    }
+        MV_CASE(SMC_FK_BOOTSTRAP, 4) MV_CASE(SMC_FK_BOOTSTRAP, 8) MV_CASE(SMC_FK_BOOTSTRAP, 16)
+        MV_CASE(SMC_FK_BOOTSTRAP, 32) MV_CASE(SMC_FK_GUIDED, 4) MV_CASE(SMC_FK_GUIDED, 8)
+        MV_CASE(SMC_FK_GUIDED, 16) MV_CASE(SMC_FK_GUIDED, 32)
+#undef MV_CASE
+        return;
+    }
     if (f->kind == SMC_MODEL_LINGAUSS && f->fk == SMC_FK_BOOTSTRAP)
         SMC_LAUNCH((k_propagate<SMC_MODEL_LINGAUSS, SMC_FK_BOOTSTRAP, F_OPT>), grid,
                    dim3(SMC_BLOCK), st, f->da);
@@ -76,12 +88,28 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
         smc_set_error("%d is not a valid resampling scheme", o->scheme);
         return SMC_ERR_SCHEME;
     }
-    SMC_REQUIRE(model->kind == SMC_MODEL_LINGAUSS || model->kind == SMC_MODEL_STOCHVOL,
-                "fused filter: model kind must be LINGAUSS or STOCHVOL");
+    const bool mv = model->kind == SMC_MODEL_MVLINGAUSS;
+    SMC_REQUIRE(model->kind == SMC_MODEL_LINGAUSS || model->kind == SMC_MODEL_STOCHVOL || mv,
+                "fused filter: unknown model kind");
     SMC_REQUIRE(model->fk == SMC_FK_BOOTSTRAP ||
-                    (model->fk == SMC_FK_GUIDED && model->kind == SMC_MODEL_LINGAUSS),
-                "guided filter is available for LINGAUSS only");
-    SMC_REQUIRE(model->params_host, "params_host is required");
+                    (model->fk == SMC_FK_GUIDED && model->kind != SMC_MODEL_STOCHVOL),
+                "guided filter is available for LINGAUSS and MVLINGAUSS only");
+    SMC_REQUIRE(mv || model->params_host, "params_host is required");
+    int dxm = 1, dym = 1, dpm = 1;
+    std::vector<double> mvc_host;
+    if (mv) {
+        dxm = model->dx; dym = model->dy;
+        SMC_REQUIRE(dxm >= 1 && dxm <= 32 && dym >= 1 && dym <= dxm,
+                    "MVLINGAUSS needs 1 <= dy <= dx <= 32");
+        SMC_REQUIRE(model->F_host && model->G_host && model->covX_host && model->covY_host &&
+                        model->mu0_host && model->cov0_host, "MVLINGAUSS matrices are required");
+        dpm = dxm <= 4 ? 4 : dxm <= 8 ? 8 : dxm <= 16 ? 16 : 32;
+        if (!mv_build_constants(model, model->fk, dpm, o->T, y_host, mvc_host)) {
+            // same failure as MvNormal.__init__ (distributions.py:935-940)
+            smc_set_error("MvNormal: argument cov must be a (d, d) pos. definite matrix");
+            return SMC_ERR_INVALID;
+        }
+    }
     SMC_REQUIRE(o->N < ((i64)1 << 32), "N must be below 2^32");
     SMC_HIP_CHECK(hipSetDevice(ctx->device));
 
@@ -120,24 +148,27 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     // carve one slab
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o0 = off; off = smc_align_up(off + bytes, 256); return o0; };
-    const size_t oX0 = carve(M * N * 8), oX1 = carve(M * N * 8);
+    a.dx = dxm; a.dy = dym; a.dp = dpm;
+    const size_t oX0 = carve(M * N * dxm * 8), oX1 = carve(M * N * dxm * 8);
     const size_t oL0 = carve(M * N * 8), oL1 = carve(M * N * 8);
     const size_t oA = carve(M * N * 8);
     const size_t oq = carve(M * N * 8);
     const size_t oQ = carve(M * a.ntiles * 8);
     const size_t oQpre = carve(M * a.ntiles * 8);
-    a.nparts = (int)((o->N + (i64)SMC_BLOCK * F_OPT - 1) / ((i64)SMC_BLOCK * F_OPT));
+    const i64 per_wg = mv ? (i64)SMC_BLOCK : (i64)SMC_BLOCK * F_OPT;
+    a.nparts = (int)((o->N + per_wg - 1) / per_wg);
     const size_t oPm = carve(M * a.nparts * 8), oPs = carve(M * a.nparts * 8),
                  oPss = carve(M * a.nparts * 8);
     const size_t oSum = carve(M * (T + 1) * SUMM_STRIDE * 8);
     const size_t oPar = carve(M * PARAM_STRIDE * 8);
-    const size_t oY = carve(T * 8);
+    const size_t oY = carve(T * dym * 8);
+    const size_t oMvc = carve(mvc_host.size() * 8 + 8);
     const size_t oCtl = carve(M * 2 * F_CNT_WORDS * sizeof(unsigned));
     const size_t oSpart = carve(M * 96 * 8);
     const size_t oInfo = carve(M * INFO_STRIDE * 8);
     const size_t oSu = carve(need_su ? M * N * 8 : 8);
     const size_t oE = carve(need_su ? M * a.ntiles1 * 8 : 8);
-    const size_t oTmp = carve(N * 8);
+    const size_t oTmp = carve(N * dxm * 8);
     const size_t oArgs = carve(sizeof(FArgs));
     const size_t oTrace = carve(M * (size_t)(2 * a.ntiles + 8) * 8 * 8);
     void* slab = nullptr;
@@ -178,9 +209,14 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
         SMC_HIP_CHECK(hipStreamSynchronize(st));
     }
     SMC_HIP_CHECK(hipMemsetAsync(a.A, 0, M * N * 8, st));
-    SMC_HIP_CHECK(hipMemcpyAsync(dpar, model->params_host, M * PARAM_STRIDE * 8,
-                                 hipMemcpyHostToDevice, st));
-    SMC_HIP_CHECK(hipMemcpyAsync(dy, y_host, T * 8, hipMemcpyHostToDevice, st));
+    if (!mv)
+        SMC_HIP_CHECK(hipMemcpyAsync(dpar, model->params_host, M * PARAM_STRIDE * 8,
+                                     hipMemcpyHostToDevice, st));
+    a.mvc = (const double*)(base + oMvc);
+    if (mv)
+        SMC_HIP_CHECK(hipMemcpyAsync((void*)a.mvc, mvc_host.data(), mvc_host.size() * 8,
+                                     hipMemcpyHostToDevice, st));
+    SMC_HIP_CHECK(hipMemcpyAsync(dy, y_host, T * dym * 8, hipMemcpyHostToDevice, st));
     SMC_HIP_CHECK(hipStreamSynchronize(st));
     f->da = (const FArgs*)(base + oArgs);
     SMC_HIP_CHECK(hipMemcpyAsync((void*)f->da, &f->a, sizeof(FArgs), hipMemcpyHostToDevice, st));
@@ -329,14 +365,16 @@ int smc_filter_get(smc_filter* f, int field, int island, void* out_host)
     }
     hipStream_t st = f->ctx->stream;
     const int cur = (int)((t - 1) & 1);
-    const double* X = (cur ? f->a.X1 : f->a.X0) + (size_t)island * N;
-    const double* Xo = (cur ? f->a.X0 : f->a.X1) + (size_t)island * N;
+    const int dx = f->a.dx;
+    const double* X = (cur ? f->a.X1 : f->a.X0) + (size_t)island * N * dx;
+    const double* Xo = (cur ? f->a.X0 : f->a.X1) + (size_t)island * N * dx;
+    size_t nbytes = (size_t)N * 8;
     const double* lw = (cur ? f->a.lw1 : f->a.lw0) + (size_t)island * N;
     const i64* A = f->a.A + (size_t)island * N;
     const void* src = nullptr;
     const unsigned nb = (unsigned)((N + SMC_BLOCK - 1) / SMC_BLOCK);
     switch (field) {
-    case SMC_FIELD_X: src = X; break;
+    case SMC_FIELD_X: src = X; nbytes *= dx; break;
     case SMC_FIELD_LW: src = lw; break;
     case SMC_FIELD_A:
     case SMC_FIELD_XP: {
@@ -353,11 +391,14 @@ int smc_filter_get(smc_filter* f, int field, int island, void* out_host)
                 return SMC_OK;
             }
             src = Xo;
+            nbytes *= dx;
         } else if (field == SMC_FIELD_A) {
             src = A;
         } else {
-            SMC_LAUNCH(k_f_gather1, dim3(nb), dim3(SMC_BLOCK), st, Xo, A, N, f->tmp);
+            SMC_LAUNCH(k_f_gather_rows, dim3((unsigned)((N * dx + SMC_BLOCK - 1) / SMC_BLOCK)),
+                       dim3(SMC_BLOCK), st, Xo, A, N, dx, f->tmp);
             src = f->tmp;
+            nbytes *= dx;
         }
         break;
     }
@@ -372,7 +413,7 @@ int smc_filter_get(smc_filter* f, int field, int island, void* out_host)
         return SMC_ERR_INVALID;
     }
     SMC_LAUNCH_CHECK();
-    SMC_HIP_CHECK(hipMemcpyAsync(out_host, src, (size_t)N * 8, hipMemcpyDeviceToHost, st));
+    SMC_HIP_CHECK(hipMemcpyAsync(out_host, src, nbytes, hipMemcpyDeviceToHost, st));
     SMC_HIP_CHECK(hipStreamSynchronize(st));
     return SMC_OK;
 }
@@ -380,7 +421,7 @@ int smc_filter_get(smc_filter* f, int field, int island, void* out_host)
 int smc_filter_info(smc_filter* f, double* bytes_per_particle_step, int* kernels_per_step)
 {
     SMC_REQUIRE(f, "null filter");
-    if (bytes_per_particle_step) *bytes_per_particle_step = 16.0 * 1 + 40.0;   // SURVEY 8d, d = 1
+    if (bytes_per_particle_step) *bytes_per_particle_step = 16.0 * f->a.dx + 40.0;
     if (kernels_per_step) *kernels_per_step = (f->a.scheme == SMC_MULTINOMIAL && !f->a.ut) ? 5 : 3;
     return SMC_OK;
 }

@@ -72,6 +72,8 @@ struct FArgs {
     u64* E;                // multinomial, Philox mode: spacing tile sums (n_islands, ntiles1)
     int ntiles1;
     double spacing_scale;
+    int dx, dy, dp;        // state / observation dimension, dx padded to 4, 8, 16 or 32
+    const double* mvc;     // MVLINGAUSS: derived constants (see smc_filter_mv.h)
     u64* trace;            // SMC_TRACE builds: (n_islands, ntiles, 8) shader-clock stamps of k_move
 };
 
@@ -487,6 +489,85 @@ k_ancestors(const FArgs* __restrict__ ap)
 }
 
 // ---------------------------------------------------------------------------
+// End of a propagate kernel: combine the per-thread log-sum-exp accumulators of
+// the workgroup, publish the partial, and let the last workgroup of the island
+// finalise step t and decide step t+1.  Called by every thread.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void f_step_tail(const FArgs& a, const int isl, const int b,
+                                            const i64 t, const bool first, const bool resample,
+                                            const SmcLse acc, double* smd, int& s_last,
+                                            double* info)
+{
+    const int tid = (int)threadIdx.x;
+    const i64 N = a.N;
+    F_STAMP(3);
+    const SmcLse r = smc_lse_block(acc, smd);
+    F_STAMP(4);
+    const i64 o = (i64)isl * a.nparts;
+    // ---- publish the partial; two-level "last one reduces" (no spinning):
+    // the last workgroup of each of the 32 shards reduces its shard's partials,
+    // the last of those reduces the 32 shard results and finalises the step
+    const int shards = a.nparts >= 64 ? 32 : 1;
+    const int sh = b & (shards - 1);
+    const int size_s = a.nparts / shards + (sh < a.nparts % shards ? 1 : 0);
+    unsigned* cnt = a.cnt + (isl * 2) * F_CNT_WORDS;
+    double* spart = a.spart + (i64)isl * 96;
+    if (tid == 0) {
+        smc_st_agent_f64(a.pm + o + b, r.m);
+        smc_st_agent_f64(a.ps + o + b, r.s);
+        smc_st_agent_f64(a.pss + o + b, r.ss);
+        smc_drain_stores();
+        s_last = atomicAdd(cnt + (1 + sh) * F_CNT_STRIDE, 1u) == (unsigned)(size_s - 1);
+    }
+    __syncthreads();
+    F_STAMP(5);
+    if (!s_last) return;
+    const SmcLse gs = smc_lse_reduce_partials<true>(a.pm + o, a.ps + o, a.pss + o, size_s, smd, sh,
+                                                    shards);
+    __syncthreads();
+    if (tid == 0) {
+        cnt[(1 + sh) * F_CNT_STRIDE] = 0u;                 // re-arm for the next launch
+        smc_st_agent_f64(spart + sh, gs.m);
+        smc_st_agent_f64(spart + 32 + sh, gs.s);
+        smc_st_agent_f64(spart + 64 + sh, gs.ss);
+        smc_drain_stores();
+        s_last = atomicAdd(cnt, 1u) == (unsigned)(shards - 1);
+        if (s_last) cnt[0] = 0u;
+    }
+    __syncthreads();
+    F_STAMP(6);
+    if (!s_last) return;
+
+    // ---- last workgroup of this island: finalise step t, decide step t+1
+    const SmcLse g = smc_lse_reduce_partials<true>(spart, spart + 32, spart + 64, shards, smd);
+    if (tid == 0) {
+        const bool bad = !(g.m > -INFINITY) || !(g.m < INFINITY);
+        const double ess = bad ? NAN : (g.s * g.s) / g.ss;                  // resampling.py:226
+        const double log_mean = bad ? NAN : g.m + log(g.s / (double)N);     // resampling.py:224
+        const double rs = bad ? NAN : 1.0 / g.s;
+        double* row = a.summ + ((i64)isl * (a.T + 1) + t) * SUMM_STRIDE;
+        double loglt, logLt;                                                // core.py:355-359
+        if (first || resample) loglt = log_mean;
+        else loglt = log_mean - row[1 - SUMM_STRIDE];
+        logLt = (first ? 0.0 : row[3 - SUMM_STRIDE]) + loglt;
+        row[0] = ess;
+        row[1] = log_mean;
+        row[2] = loglt;
+        row[3] = logLt;
+        row[4] = resample ? 1.0 : 0.0;
+        row[5] = g.m;
+        row[6] = rs;
+        const bool flag = (t + 1 < a.T) && (ess < a.ess_thresh);            // core.py:181-183
+        info[1] = flag ? 1.0 : 0.0;
+        info[2] = (t + 1 < a.T) ? a.y[(t + 1) * a.dy] : 0.0;
+        info[3] = g.m;
+        info[4] = rs;
+        info[0] = (double)(t + 1);
+    }
+    F_STAMP(7);
+}
+
+// ---------------------------------------------------------------------------
 // k_propagate(t): element-wise over the new particles, OPT consecutive ones per
 // thread.  x = loc(X_{t-1}[A]) + scale z, weight increment, log-weights, online
 // log-sum-exp partial; the last workgroup of the island finalises the step.
@@ -597,71 +678,7 @@ k_propagate(const FArgs* __restrict__ ap)
                 if (n0 + k < N) { Xn[n0 + k] = xn[k]; lwn[n0 + k] = lw[k]; }
         }
     }
-    F_STAMP(3);
-    const SmcLse r = smc_lse_block(acc, smd);
-    F_STAMP(4);
-    const i64 o = (i64)isl * a.nparts;
-    // ---- publish the partial; two-level "last one reduces" (no spinning):
-    // the last workgroup of each of the 32 shards reduces its shard's partials,
-    // the last of those reduces the 32 shard results and finalises the step
-    const int shards = a.nparts >= 64 ? 32 : 1;
-    const int sh = b & (shards - 1);
-    const int size_s = a.nparts / shards + (sh < a.nparts % shards ? 1 : 0);
-    unsigned* cnt = a.cnt + (isl * 2) * F_CNT_WORDS;
-    double* spart = a.spart + (i64)isl * 96;
-    if (tid == 0) {
-        smc_st_agent_f64(a.pm + o + b, r.m);
-        smc_st_agent_f64(a.ps + o + b, r.s);
-        smc_st_agent_f64(a.pss + o + b, r.ss);
-        smc_drain_stores();
-        s_last = atomicAdd(cnt + (1 + sh) * F_CNT_STRIDE, 1u) == (unsigned)(size_s - 1);
-    }
-    __syncthreads();
-    F_STAMP(5);
-    if (!s_last) return;
-    const SmcLse gs = smc_lse_reduce_partials<true>(a.pm + o, a.ps + o, a.pss + o, size_s, smd, sh,
-                                                    shards);
-    __syncthreads();
-    if (tid == 0) {
-        cnt[(1 + sh) * F_CNT_STRIDE] = 0u;                 // re-arm for the next launch
-        smc_st_agent_f64(spart + sh, gs.m);
-        smc_st_agent_f64(spart + 32 + sh, gs.s);
-        smc_st_agent_f64(spart + 64 + sh, gs.ss);
-        smc_drain_stores();
-        s_last = atomicAdd(cnt, 1u) == (unsigned)(shards - 1);
-        if (s_last) cnt[0] = 0u;
-    }
-    __syncthreads();
-    F_STAMP(6);
-    if (!s_last) return;
-
-    // ---- last workgroup of this island: finalise step t, decide step t+1
-    const SmcLse g = smc_lse_reduce_partials<true>(spart, spart + 32, spart + 64, shards, smd);
-    if (tid == 0) {
-        const bool bad = !(g.m > -INFINITY) || !(g.m < INFINITY);
-        const double ess = bad ? NAN : (g.s * g.s) / g.ss;                  // resampling.py:226
-        const double log_mean = bad ? NAN : g.m + log(g.s / (double)N);     // resampling.py:224
-        const double rs = bad ? NAN : 1.0 / g.s;
-        double* row = a.summ + ((i64)isl * (a.T + 1) + t) * SUMM_STRIDE;
-        double loglt, logLt;                                                // core.py:355-359
-        if (first || resample) loglt = log_mean;
-        else loglt = log_mean - row[1 - SUMM_STRIDE];
-        logLt = (first ? 0.0 : row[3 - SUMM_STRIDE]) + loglt;
-        row[0] = ess;
-        row[1] = log_mean;
-        row[2] = loglt;
-        row[3] = logLt;
-        row[4] = resample ? 1.0 : 0.0;
-        row[5] = g.m;
-        row[6] = rs;
-        const bool flag = (t + 1 < a.T) && (ess < a.ess_thresh);            // core.py:181-183
-        info[1] = flag ? 1.0 : 0.0;
-        info[2] = (t + 1 < a.T) ? a.y[t + 1] : 0.0;
-        info[3] = g.m;
-        info[4] = rs;
-        info[0] = (double)(t + 1);
-    }
-    F_STAMP(7);
+    f_step_tail(a, isl, b, t, first, resample, acc, smd, s_last, info);
 }
 
 // W = exp(lw - m)/s for one island (SMC.W)

@@ -260,6 +260,10 @@ MODELS = {
                     lambda: orc.LinGauss(rho=0.9, sigmaX=1.0, sigmaY=1.5)),
     "lg_guided": (lambda: kalman.LinearGauss(rho=0.9, sigmaX=1.0, sigmaY=0.2),
                   lambda: orc.LinGauss(rho=0.9, sigmaX=1.0, sigmaY=0.2)),
+    "mv4": (lambda: kalman.MVLinearGauss_Guarniero_etal(alpha=0.4, dx=4),
+            lambda: orc.Guarniero(alpha=0.4, dx=4)),
+    "mv32": (lambda: kalman.MVLinearGauss_Guarniero_etal(alpha=0.4, dx=32),
+             lambda: orc.Guarniero(alpha=0.4, dx=32)),
 }
 
 
@@ -267,7 +271,8 @@ def tapes_from_oracle(tape, T, N, scheme):
     """Dense device tapes (T,1,N) / (T,1,K) from the oracle's consumption-ordered
     tape; multinomial slots hold the sorted uniforms (resampling.py:536-537)."""
     K = 1 if scheme == "systematic" else N
-    z = np.zeros((T, 1, N))
+    d = tape[0][1].size // N
+    z = np.zeros((T, 1, N) if d == 1 else (T, 1, N, d))
     u = np.zeros((T, 1, K))
     t = -1
     pend = None
@@ -276,7 +281,7 @@ def tapes_from_oracle(tape, T, N, scheme):
             pend = a
         else:
             t += 1
-            z[t, 0] = a.reshape(-1)
+            z[t, 0] = a.reshape(z.shape[2:])
             if pend is not None:
                 u[t, 0] = orc.uniform_spacings_from(pend) if scheme == "multinomial" else pend
                 pend = None
@@ -306,6 +311,12 @@ def check_filter_replay(golden, case, model, fk, T=None):
     assert abs(pf.logLt / o["final_logLt"] - 1) < 1e-9
     same = np.mean(pf.A == o["A"])
     assert same >= 0.999                                               # near-ties only
+    if model.startswith("mv"):        # matrix products: BLAS vs our FMA order, ~1e-13
+        if same == 1.0:
+            assert np.max(np.abs(pf.X - o["X"])) < 1e-11 and np.max(np.abs(pf.Xp - o["Xp"])) < 1e-11
+            assert np.allclose(pf.wgts.lw, o["lw"], rtol=1e-10, atol=1e-10)
+            assert rel(pf.W, o["W"]) < 1e-8
+        return pf, o
     if same == 1.0:
         exact = model.startswith(("toy", "lg"))       # IEEE + - * / only -> bit-exact
         assert np.max(np.abs(pf.X - o["X"])) <= (0 if exact else 1e-12)
@@ -385,6 +396,30 @@ def check_islands(N, T, golden, scheme="stratified"):
         assert np.array_equal(one.X, pf._get(_lib.FIELD_X, k))
     out = pa.multiSMC(fk=fk, N=N, nruns=3, out_func=lambda p: p.logLt, resampling=scheme)
     assert [d["run"] for d in out] == [0, 1, 2] and all(np.isfinite(d["output"]) for d in out)
+
+
+def check_mv_kalman(N, d, fk, scheme="systematic"):
+    """Production (Philox) mode of the multivariate filter against the exact
+    Kalman likelihood (kalman.py:483-505 restated in the oracle)."""
+    rng = np.random.RandomState(5)
+    T = 10
+    om = orc.Guarniero(alpha=0.4, dx=d)
+    x = np.zeros(d)
+    y = []
+    for t in range(T):
+        x = (om.F @ x if t else np.zeros(d)) + rng.standard_normal(d)
+        y.append((x + rng.standard_normal(d)).reshape(1, d))
+    ll, _ = orc.kalman_loglik(om, y)
+    cls = ssm.Bootstrap if fk == "bootstrap" else ssm.GuidedPF
+    lls = []
+    for s in range(3):
+        pf = pa.SMC(fk=cls(ssm=kalman.MVLinearGauss_Guarniero_etal(alpha=0.4, dx=d), data=y), N=N,
+                    seed=10 + s, resampling=scheme)
+        pf.run()
+        assert pf.X.shape == (N, d) and np.isfinite(pf.logLt)
+        lls.append(pf.logLt)
+    tol = (0.05 if fk == "guided" else 4.0 * d / np.sqrt(N) * 8) + 0.02
+    assert abs(np.mean(lls) - ll) < tol, (lls, ll)
 
 
 def check_generic_path(golden):

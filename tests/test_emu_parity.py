@@ -75,9 +75,18 @@ def test_mvn(golden):
     ("sv_systematic", "sv", "bootstrap"),
     ("lg_adaptive", "lg_adaptive", "bootstrap"),
     ("lg_guided", "lg_guided", "guided"),
+    ("mv4_guided", "mv4", "guided"),
+    ("mv4_boot", "mv4", "bootstrap"),
+    ("mv32_guided", "mv32", "guided"),
+    ("mv32_boot", "mv32", "bootstrap"),
 ])
 def test_filter_replay(golden, case, model, fk):
-    pc.check_filter_replay(golden, case, model, fk, T=25)
+    pc.check_filter_replay(golden, case, model, fk, T=12 if model.startswith("mv") else 25)
+
+
+def test_mv_philox_kalman():
+    pc.check_mv_kalman(2048, 4, "guided")
+    pc.check_mv_kalman(1000, 6, "guided", scheme="stratified")
 
 
 def test_filter_stepwise(golden):

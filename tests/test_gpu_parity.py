@@ -86,6 +86,10 @@ def test_mvn(golden):
     ("sv_multinomial", "sv", "bootstrap"),
     ("lg_adaptive", "lg_adaptive", "bootstrap"),
     ("lg_guided", "lg_guided", "guided"),
+    ("mv4_guided", "mv4", "guided"),             # reduced C4
+    ("mv4_boot", "mv4", "bootstrap"),
+    ("mv32_guided", "mv32", "guided"),
+    ("mv32_boot", "mv32", "bootstrap"),
 ])
 def test_filter_replay(golden, case, model, fk):
     pc.check_filter_replay(golden, case, model, fk)
@@ -113,6 +117,38 @@ def test_collectors_and_history(golden):
 
 def test_generic_path(golden):
     pc.check_generic_path(golden)
+
+
+def test_mv_philox_kalman():
+    pc.check_mv_kalman(1 << 16, 4, "guided")
+    pc.check_mv_kalman(20000, 6, "guided", scheme="stratified")
+    pc.check_mv_kalman(1 << 17, 32, "guided")
+    pc.check_mv_kalman(1 << 18, 8, "bootstrap")
+
+
+def test_c4_mv32_guided_full_size():
+    """C4: MVLinearGauss_Guarniero d=32, GuidedPF, N = 2^20: determinism and the
+    exact Kalman likelihood (guided + optimal proposal => tiny MC error)."""
+    import particles_amd as pa
+    from oracle import smc_oracle as orc
+    from particles_amd import kalman
+    from particles_amd import state_space_models as ssm
+    d, T, N = 32, 20, 1 << 20
+    rng = np.random.RandomState(3)
+    om = orc.Guarniero(alpha=0.4, dx=d)
+    x = np.zeros(d)
+    y = []
+    for t in range(T):
+        x = (om.F @ x if t else np.zeros(d)) + rng.standard_normal(d)
+        y.append((x + rng.standard_normal(d)).reshape(1, d))
+    ll, _ = orc.kalman_loglik(om, y)
+    fk = ssm.GuidedPF(ssm=kalman.MVLinearGauss_Guarniero_etal(alpha=0.4, dx=d), data=y)
+    a = pa.SMC(fk=fk, N=N, seed=4)
+    a.run()
+    b = pa.SMC(fk=fk, N=N, seed=4)
+    b.run()
+    assert a.logLt == b.logLt and np.array_equal(a.X, b.X) and a.X.shape == (N, d)
+    assert abs(a.logLt - ll) < 0.05, (a.logLt, ll)
 
 
 # ---- BASELINE.json full sizes: size-independent properties -----------------
