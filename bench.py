@@ -71,7 +71,10 @@ def main():
     ap.add_argument("--log2N", type=int, default=20)
     ap.add_argument("--scheme", default="systematic")
     ap.add_argument("--islands", type=int, default=1, help="filters per GPU")
-    ap.add_argument("--essrmin", type=float, default=0.5)
+    ap.add_argument("--essrmin", type=float, default=None)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"],
+                    help="BASELINE.json config: c2 = headline (default); the others are "
+                         "measurement aids, not bench lines")
     ap.add_argument("--cpu-steps", type=int, default=150)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
@@ -94,10 +97,43 @@ def main():
     from particles_amd.distributed import Group
 
     grp = Group(device_collective=True) if world > 1 else None
-    N, K, W = 1 << a.log2N, a.steps, a.warmup
+    K, W = a.steps, a.warmup
     T = W + K
-    y = synthetic_data(T)
-    fk = ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y)
+    d = 1
+    if a.workload == "c3":        # StochVol, N = 2^22, ESSrmin = 1
+        a.log2N = 22 if a.log2N == 20 else a.log2N
+        a.essrmin = 1.0 if a.essrmin is None else a.essrmin
+        rng = np.random.RandomState(42)
+        model = ssm.StochVol()
+        x = np.empty(T)
+        x[0] = model.mu + model.sig0() * rng.standard_normal()
+        for t in range(1, T):
+            x[t] = model.EXt(x[t - 1]) + model.sigma * rng.standard_normal()
+        y = [np.array([v]) for v in np.exp(0.5 * x) * rng.standard_normal(T)]
+        fk = ssm.Bootstrap(ssm=model, data=y)
+        wl = "C3: StochVol d=1 bootstrap filter"
+    elif a.workload == "c4":      # MVLinearGauss_Guarniero d = 32, guided, N = 2^20
+        d = 32
+        rng = np.random.RandomState(42)
+        model = kalman.MVLinearGauss_Guarniero_etal(alpha=0.4, dx=d)
+        x = np.zeros(d)
+        y = []
+        for t in range(T):
+            x = (model.F @ x if t else np.zeros(d)) + rng.standard_normal(d)
+            y.append((x + rng.standard_normal(d)).reshape(1, d))
+        fk = ssm.GuidedPF(ssm=model, data=y)
+        wl = "C4: MVLinearGauss_Guarniero d=32 guided filter"
+    else:
+        if a.workload == "c5":    # one GPU's share of 256 islands x 2^18
+            a.log2N, a.islands = 18, 32
+        y = synthetic_data(T)
+        fk = ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y)
+        wl = "C2: ToySSM d=1 linear-Gaussian bootstrap filter" if a.workload == "c2" else \
+             "C5: ToySSM d=1 bootstrap filter islands"
+    a.essrmin = 0.5 if a.essrmin is None else a.essrmin
+    N = 1 << a.log2N
+    bytes_step = 16.0 * d + 40.0
+    bytes_move = 16.0 * d + 16.0                    # k_propagate: read A, gather X; write X, lw
 
     def make(profile=False):
         pf = pa.SMC(fk=fk, N=N, resampling=a.scheme, ESSrmin=a.essrmin, collect="off", seed=123,
@@ -134,13 +170,13 @@ def main():
             "value": units / dt, "unit": "particle-steps/s", "n_gpus": world, "steps": K,
             "warmup": W, "ms_per_step": 1e3 * dt / K, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C2: ToySSM d=1 linear-Gaussian bootstrap filter, "
-                                   "N=2^%d, T=%d, %s resampling, ESSrmin=0.5; one independent "
-                                   "filter x %d per GPU" % (a.log2N, K, a.scheme, a.islands),
+            "config": {"workload": "%s, N=2^%d, T=%d, %s resampling, ESSrmin=%g; %d independent "
+                                   "filter(s) per GPU" % (wl, a.log2N, K, a.scheme, a.essrmin,
+                                                          a.islands),
                        "N": N, "islands_per_gpu": a.islands, "scheme": a.scheme,
                        "rng": "philox4x32-10", "graph": not a.no_graph,
                        "resampled_fraction": rs_rate},
-            "step_achieved_GBs": BYTES_STEP * N * a.islands * K / dt / 1e9,
+            "step_achieved_GBs": bytes_step * N * a.islands * K / dt / 1e9,
             "logLt": [float(v) for v in np.atleast_1d(all_ll)][:16],
             "evidence_gather": ("rccl" if (grp and grp.comm) else
                                 ("gloo-fallback: %s" % grp.fallback_reason if grp else "none")),
@@ -161,12 +197,12 @@ def main():
                                                    ctypes.byref(ns)))
         del pf
         if rank == 0 and ns.value:
-            ach = BYTES_MOVE * N * a.islands / (mv.value * 1e-3) / 1e9
+            ach = bytes_move * N * a.islands / (mv.value * 1e-3) / 1e9
             out["roofline"] = {
                 "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": None,
                 "kernel": "k_propagate", "kernel_ms": mv.value,
-                "launch_bytes": BYTES_MOVE * N * a.islands,
+                "launch_bytes": bytes_move * N * a.islands,
                 "samples": ns.value,
                 "prepare_ms": pr.value,
                 "prepare_achieved": BYTES_PREPARE * N * a.islands / (pr.value * 1e-3) / 1e9
@@ -175,7 +211,7 @@ def main():
                         "k_prepare 16 B (read lw, write q), k_ancestors 16 B (read q, write A); "
                         "prepare_ms covers k_prepare + k_ancestors",
             }
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.workload == "c2":
         out["cpu_baseline"] = cpu_baseline(y, N, min(a.cpu_steps, T))
     if rank == 0:
         print(json.dumps(out), flush=True)
