@@ -37,7 +37,7 @@ static void launch_propagate(smc_filter* f)
     if (f->kind == SMC_MODEL_MVLINGAUSS) {
 #define MV_CASE(FKV, DPV)                                                                   \
     if (f->fk == FKV && f->a.dp == DPV) {                                                   \
-        SMC_LAUNCH((k_propagate_mv<FKV, DPV>), grid, dim3(SMC_BLOCK), st, f->da);           \
+        SMC_LAUNCH((k_propagate_mv<FKV, DPV>), grid, dim3(SMC_BLOCK), st, f->da, f->a.mvc);           \
         return;                                                                             \
     }
         MV_CASE(SMC_FK_BOOTSTRAP, 4) MV_CASE(SMC_FK_BOOTSTRAP, 8) MV_CASE(SMC_FK_BOOTSTRAP, 16)

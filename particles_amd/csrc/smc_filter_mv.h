@@ -16,8 +16,10 @@
 // particle's current vector lives in LDS as a COLUMN (element k of thread p at
 // V[k*256+p]: conflict-free 8-byte accesses), the matrix is walked column by
 // column through SCALAR loads (it is the same for every lane) and each column
-// feeds DP independent v_fma_f64 accumulators held in registers -- full-rate
-// FMAs, no LDS operand traffic for the matrix.  Rows of X are gathered /
+// feeds DP independent v_fma_f64 accumulators held in registers.  The matrix in
+// use sits in LDS (8 KB, staged by the workgroup while the previous product
+// runs) and is read with broadcast ds_read_b128 -- per-lane global or scalar
+// loads inside the product loop left it waiting on memory every column.  Rows of X are gathered /
 // scattered cooperatively (16 lanes per 256-byte row) so global accesses stay
 // coalesced whole lines.  No MFMA: fp64 matrix and vector peaks are equal on
 // this part and the operands here are already register/SGPR resident.
@@ -39,16 +41,42 @@
 #define MV_STEP(dp) (MV_SCAL(dp) + 8)              /* per t: yw_t[dp] = L_Y^-1 y_t, ky_t[dp] = K y_t */
 #define MV_SIZE(dp, T) (MV_STEP(dp) + 2 * (size_t)(dp) * (T))
 
+// Stage one DP x DP matrix of the constants block into LDS (all threads call).
+// `pf` holds the thread's share: mv_fetch issues the global loads (early, so
+// their latency hides behind the previous product), mv_commit parks them in LDS.
 template <int DP>
-__device__ __forceinline__ void mv_matvec(const double* __restrict__ Mt, const double* vcol,
-                                          double (&acc)[DP])
+struct MvShare { double v[(DP * DP + SMC_BLOCK - 1) / SMC_BLOCK]; };
+template <int DP>
+__device__ __forceinline__ void mv_fetch(const double* __restrict__ gM, MvShare<DP>& pf)
 {
-    // acc += M v ; column k of M (contiguous in Mt) scaled by v_k
+#pragma unroll
+    for (int j = 0; j < (DP * DP + SMC_BLOCK - 1) / SMC_BLOCK; ++j) {
+        const int i = j * SMC_BLOCK + (int)threadIdx.x;
+        pf.v[j] = (i < DP * DP) ? gM[i] : 0.0;
+    }
+}
+template <int DP>
+__device__ __forceinline__ void mv_commit(const MvShare<DP>& pf, double* sM)
+{
+    __syncthreads();                      // the previous product has finished reading sM
+#pragma unroll
+    for (int j = 0; j < (DP * DP + SMC_BLOCK - 1) / SMC_BLOCK; ++j) {
+        const int i = j * SMC_BLOCK + (int)threadIdx.x;
+        if (i < DP * DP) sM[i] = pf.v[j];
+    }
+    __syncthreads();
+}
+
+template <int DP>
+__device__ __forceinline__ void mv_matvec(const double* sM, const double* vcol, double (&acc)[DP])
+{
+    // acc += M v ; column k of M (contiguous in sM, same address for every lane:
+    // LDS broadcast reads) scaled by v_k
 #pragma unroll 2
     for (int k = 0; k < DP; ++k) {
         const double vk = vcol[k * SMC_BLOCK];
 #pragma unroll
-        for (int i = 0; i < DP; ++i) acc[i] = fma(Mt[k * DP + i], vk, acc[i]);
+        for (int i = 0; i < DP; ++i) acc[i] = fma(sM[k * DP + i], vk, acc[i]);
     }
 }
 
@@ -103,16 +131,21 @@ __device__ __forceinline__ void mv_store_rows(double* base, int d, const i64* sR
 
 template <int FK, int DP>
 __global__ void __launch_bounds__(SMC_BLOCK)
-k_propagate_mv(const FArgs* __restrict__ ap)
+k_propagate_mv(const FArgs* __restrict__ ap, const double* __restrict__ C)
 {
+    // C (= ap->mvc) comes in as its own const __restrict__ kernel argument: only then
+    // does the compiler know the block is never written and fetch the matrix columns
+    // with SCALAR loads (s_load_dwordx16) instead of 64 identical vector loads
     const FArgs& a = *ap;
     __shared__ double sV0[DP * SMC_BLOCK];
     __shared__ double sV1[FK == SMC_FK_GUIDED ? DP * SMC_BLOCK : 1];
+    __shared__ __attribute__((aligned(16))) double sM[DP * DP];     // the matrix in use
     __shared__ i64 sRow[SMC_BLOCK];
     __shared__ double smd[SMC_SM];
     __shared__ int s_last;
     const int b = (int)blockIdx.x, isl = (int)blockIdx.y;
     const int tid = (int)threadIdx.x;
+    MvShare<DP> pf;
     double* info = a.info + (i64)isl * INFO_STRIDE;
     const i64 t = (i64)info[0];
     if (t >= a.T) return;
@@ -130,7 +163,6 @@ k_propagate_mv(const FArgs* __restrict__ ap)
     const bool resample = !first && info[1] != 0.0;
     const i64 n = (i64)b * SMC_BLOCK + tid;
     const bool valid = n < N;
-    const double* C = a.mvc;
     const double* scal = C + MV_SCAL(DP);
     const double* yw = C + MV_STEP(DP) + (size_t)t * 2 * DP;
     const double* ky = yw + DP;
@@ -138,6 +170,7 @@ k_propagate_mv(const FArgs* __restrict__ ap)
     double* V1 = sV1 + tid;
     double acc[DP];
 
+    mv_fetch<DP>(C + (first ? MV_LZ0 : MV_F) * DP * DP, pf);
     // ---- the parents' rows -> V0
     if (!first) {
         sRow[tid] = valid ? (resample ? A[n] : n) : -1;                    // core.py:332 / :336
@@ -151,19 +184,24 @@ k_propagate_mv(const FArgs* __restrict__ ap)
 #pragma unroll
         for (int i = 0; i < DP; ++i) acc[i] = mu[i];
     } else {
+        mv_commit<DP>(pf, sM);                                             // F
         if (FK == SMC_FK_GUIDED) {
+            mv_fetch<DP>(C + MV_B * DP * DP, pf);
 #pragma unroll
             for (int i = 0; i < DP; ++i) acc[i] = 0.0;
-            mv_matvec<DP>(C + MV_F * DP * DP, V0, acc);                    // m = F xp
+            mv_matvec<DP>(sM, V0, acc);                                    // m = F xp
 #pragma unroll
             for (int i = 0; i < DP; ++i) V1[i * SMC_BLOCK] = acc[i];
 #pragma unroll
             for (int i = 0; i < DP; ++i) acc[i] = ky[i];
-            mv_matvec<DP>(C + MV_B * DP * DP, V0, acc);                    // mu = B xp + K y
+            mv_commit<DP>(pf, sM);                                         // B
+            mv_fetch<DP>(C + MV_LZ * DP * DP, pf);
+            mv_matvec<DP>(sM, V0, acc);                                    // mu = B xp + K y
         } else {
+            mv_fetch<DP>(C + MV_LZ * DP * DP, pf);
 #pragma unroll
             for (int i = 0; i < DP; ++i) acc[i] = 0.0;
-            mv_matvec<DP>(C + MV_F * DP * DP, V0, acc);                    // mu = F xp
+            mv_matvec<DP>(sM, V0, acc);                                    // mu = F xp
         }
     }
     // ---- z -> V0 (the parent row is no longer needed), zz = |z|^2
@@ -189,7 +227,9 @@ k_propagate_mv(const FArgs* __restrict__ ap)
         }
     }
     // ---- x = mu + L z
-    mv_matvec<DP>(C + (first ? MV_LZ0 : MV_LZ) * DP * DP, V0, acc);
+    mv_commit<DP>(pf, sM);                                                 // L_z
+    mv_fetch<DP>(C + (FK == SMC_FK_GUIDED ? (first ? MV_X0INV : MV_XINV) : MV_NGY) * DP * DP, pf);
+    mv_matvec<DP>(sM, V0, acc);
     double uu = 0.0;
     if (FK == SMC_FK_GUIDED) {
         const double* mu0 = C + MV_VEC(DP);
@@ -204,14 +244,17 @@ k_propagate_mv(const FArgs* __restrict__ ap)
     if (FK == SMC_FK_GUIDED) {
 #pragma unroll
         for (int i = 0; i < DP; ++i) acc[i] = 0.0;
-        mv_matvec<DP>(C + (first ? MV_X0INV : MV_XINV) * DP * DP, V1, acc);
+        mv_commit<DP>(pf, sM);                                             // L_X^-1
+        mv_fetch<DP>(C + MV_NGY * DP * DP, pf);
+        mv_matvec<DP>(sM, V1, acc);
 #pragma unroll
         for (int i = 0; i < DP; ++i) uu = fma(acc[i], acc[i], uu);        // |L^-1 (x - m)|^2
     }
     // ---- w = L_Y^-1 (y - G x)
 #pragma unroll
     for (int i = 0; i < DP; ++i) acc[i] = yw[i];
-    mv_matvec<DP>(C + MV_NGY * DP * DP, V0, acc);
+    mv_commit<DP>(pf, sM);                                                 // -(L_Y^-1 G)
+    mv_matvec<DP>(sM, V0, acc);
     double ww = 0.0;
 #pragma unroll
     for (int i = 0; i < DP; ++i) ww = fma(acc[i], acc[i], ww);
