@@ -209,6 +209,11 @@ __device__ __forceinline__ void f_store2(T* p, i64 n, bool vec2, bool ok0, bool 
 // last arrivers take a ticket on the top counter.
 // Returns true in every thread of the last workgroup; it also re-arms the
 // counters for the next launch.
+// Up to this many tiles every k_ancestors workgroup adds up the totals of the
+// tiles before it by itself (<= 8 loads per thread, in parallel with its other
+// loads); beyond, the O(tiles^2) traffic would show and the last workgroup of
+// k_prepare scans the totals once instead (a serial tail of a few microseconds).
+#define F_DIRECT_PREFIX_MAX 2048
 #define F_CNT_STRIDE 16                       /* unsigned per counter: one 64-byte line */
 #define F_CNT_WORDS (34 * F_CNT_STRIDE)       /* top + 32 shards (+ pad) */
 __device__ __forceinline__ bool f_last_block(unsigned* cnt, int b, int nblocks, int* s_flag,
@@ -262,8 +267,12 @@ k_prepare(const FArgs* __restrict__ ap)
     }
     s = smc_block_sum_u64(s, smu);
     u64* Q = a.Q + (i64)isl * a.ntiles;
+    f_store4<u64, F2u>(q, j0, vec && ok[3], ok, q4);
+    if (a.ntiles <= F_DIRECT_PREFIX_MAX) {      // k_ancestors sums its predecessors itself
+        if (threadIdx.x == 0) Q[b] = s;
+        return;
+    }
     if (threadIdx.x == 0) smc_st_agent(Q + b, s);
-    f_store4<u64, F2u>(q, j0, vec && ok[3], ok, q4);     // after the publish: see f_last_block
     if (!f_last_block(a.cnt + (isl * 2 + 1) * F_CNT_WORDS, b, a.ntiles, &s_last, 0)) return;
     // last workgroup: exclusive prefixes of the tile totals (exact integers)
     u64* Qpre = a.Qpre + (i64)isl * a.ntiles;
@@ -386,10 +395,19 @@ k_ancestors(const FArgs* __restrict__ ap)
     u64 q4[4];
     const i64 jt = j0 + (i64)tid * F_IPT;
     f_load4<u64, F2u>(a.q + (i64)isl * N, jt, N, vec, 0ull, q4);
-    const u64 pre = a.Qpre[(i64)isl * a.ntiles + b];
     const u64 tsum = q4[0] + q4[1] + q4[2] + q4[3];
-    u64 total;
-    const u64 cex = pre + smc_block_exscan_u64(tsum, smu, total);   // exclusive CDF, 1st parent
+    u64 total, pre;
+    u64 cex;
+    if (a.ntiles <= F_DIRECT_PREFIX_MAX) {
+        const u64* Qt = a.Q + (i64)isl * a.ntiles;
+        u64 part = 0;
+        for (int i = tid; i < b; i += SMC_BLOCK) part += Qt[i];
+        cex = smc_block_exscan_plus_sum_u64(tsum, part, smu, total, pre);
+    } else {
+        pre = a.Qpre[(i64)isl * a.ntiles + b];
+        cex = smc_block_exscan_u64(tsum, smu, total);
+    }
+    cex += pre;                                                      // exclusive CDF, 1st parent
     SmcSu su;
     su.scheme = a.scheme;
     su.M = N;
