@@ -15,7 +15,7 @@ the per-rank log-evidences are gathered with RCCL (smc_comm_*) inside the timed
 region.  Inputs are resident in HBM before the timed region starts.
 
 Rank 0 prints ONE JSON line (see README / task contract), including
-  roofline      -- dominant kernel (k_move) algorithmic bytes per launch over its
+  roofline      -- dominant kernel (k_propagate) algorithmic bytes per launch over its
                    average duration measured with HIP events on the filter's
                    stream, against the 8 TB/s HBM peak of MI355X;
   cpu_baseline  -- the NumPy restatement of the reference path (oracle/, "port")
@@ -44,6 +44,27 @@ def synthetic_data(T, sigma=0.2, seed=42):
     rng = np.random.RandomState(seed)
     x = np.cumsum(rng.standard_normal(T))
     return [np.array([v]) for v in x + sigma * rng.standard_normal(T)]
+
+
+def measured_traffic(a, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of
+    this very command line (tools/gpu_profile.sh -> tools/summarise_prof.py:
+    FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as the
+    MI355X guide prescribes for gfx950).  PMC counters cannot be collected from
+    inside the process, so the figure is only reported for the configuration the
+    committed profile was taken on; otherwise traffic stays null."""
+    path = os.path.join(ROOT, "profiles", "traffic_%s.json" % a.workload)
+    if not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        rec = json.load(fh)
+    cfg = rec.get("config", {})
+    if (cfg.get("log2N"), cfg.get("islands"), cfg.get("scheme")) != (a.log2N, a.islands, a.scheme):
+        return None
+    for name, d in rec["kernels"].items():
+        if kernel in name:
+            return d["hbm_bytes_per_launch"], "rocprofv3 PMC, profiles/%s" % rec.get("summary", "")
+    return None
 
 
 def cpu_baseline(y, N, nsteps):
@@ -201,6 +222,7 @@ def main():
             out["roofline"] = {
                 "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "traffic_source": None,
                 "kernel": "k_propagate", "kernel_ms": mv.value,
                 "launch_bytes": bytes_move * N * a.islands,
                 "samples": ns.value,
@@ -211,6 +233,9 @@ def main():
                         "k_prepare 16 B (read lw, write q), k_ancestors 16 B (read q, write A); "
                         "prepare_ms covers k_prepare + k_ancestors",
             }
+            tr = measured_traffic(a, "k_propagate")
+            if tr:
+                out["roofline"]["traffic"], out["roofline"]["traffic_source"] = tr
     if rank == 0 and world == 1 and not a.no_cpu_baseline and a.workload == "c2":
         out["cpu_baseline"] = cpu_baseline(y, N, min(a.cpu_steps, T))
     if rank == 0:

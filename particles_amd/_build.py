@@ -9,9 +9,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libsmc_hip.so")
 SOURCES = ["smc_api.hip", "smc_ops.hip", "smc_filter.hip", "smc_comm.hip"]
-HEADERS = ["smc_platform.h", "smc_device.h", "smc_dpp.h", "smc_resample.h", "smc_internal.h",
-           "smc_filter_kernels.h",
-           os.path.join("..", "..", "include", "smc_hip.h")]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [
+    os.path.join("..", "..", "include", "smc_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
          "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 

@@ -44,3 +44,24 @@ for f in sorted(glob.glob(os.path.join(out, "**", "*_results.db"), recursive=Tru
             n = cnt[(k, cn)]
             print("  %-44s %-22s %18.1f   (n=%d, avg kernel %8.2f us under PMC)"
                   % (k, cn, v / n, n, dur[(k, cn)] / n / 1e3))
+
+# ---- machine-readable HBM traffic per launch (for bench.py's roofline.traffic)
+import json
+traffic = {}
+for f in sorted(glob.glob(os.path.join(out, "**", "*_results.db"), recursive=True)):
+    c = sqlite3.connect(f)
+    try:
+        for k, cn, v in c.execute("select kernel_name, counter_name, avg(value) from counters_collection "
+                                  "where counter_name in ('FETCH_SIZE','WRITE_SIZE') group by 1,2"):
+            traffic.setdefault(k, {})[cn] = v
+    except sqlite3.Error:
+        pass
+if traffic:
+    # FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B
+    # (MI355X_MICROARCH.md, HBM): double it for wide coalesced reads
+    res = {k: {"FETCH_SIZE_KiB": d.get("FETCH_SIZE"), "WRITE_SIZE_KiB": d.get("WRITE_SIZE"),
+               "hbm_bytes_per_launch": (2.0 * d.get("FETCH_SIZE", 0.0) + d.get("WRITE_SIZE", 0.0)) * 1024.0}
+           for k, d in traffic.items() if not k.startswith("__amd")}
+    with open(os.path.join(out, "traffic.json"), "w") as fh:
+        json.dump({"kernels": res}, fh, indent=1)
+    print("== traffic.json:", json.dumps(res))
