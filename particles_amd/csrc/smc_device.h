@@ -86,6 +86,7 @@ __device__ __forceinline__ void smc_st_agent(u64* p, u64 v) { *p = v; }
 __device__ __forceinline__ u64 smc_ld_agent(const u64* p) { return *p; }
 __device__ __forceinline__ void smc_drain_stores() {}
 __device__ __forceinline__ void smc_drain_stores_but4() {}
+__device__ __forceinline__ void smc_spin_pause() {}
 #else
 __device__ __forceinline__ void smc_st_agent(u64* p, u64 v)
 {
@@ -99,6 +100,7 @@ __device__ __forceinline__ void smc_drain_stores()
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
+__device__ __forceinline__ void smc_spin_pause() { __builtin_amdgcn_s_sleep(2); }
 // all but the 4 most recent vector-memory instructions of this wave have retired
 __device__ __forceinline__ void smc_drain_stores_but4()
 {

@@ -18,6 +18,7 @@ struct smc_filter {
     i64 t_host;
     void* slab;            // one allocation holding every device array
     bool use_graph;
+    bool fused;            // k_ancestors<true> (no k_prepare launch)
     hipGraphExec_t gexec;
     int graph_steps;
     bool prof;
@@ -64,13 +65,15 @@ static void enqueue_step(smc_filter* f, int k_prof)
     hipStream_t st = f->ctx->stream;
     const dim3 grid(f->a.ntiles, f->a.n_islands);
     if (k_prof >= 0) (void)hipEventRecord(f->ev[3 * k_prof], st);
-    SMC_LAUNCH(k_prepare, grid, dim3(SMC_BLOCK), st, f->da);
+    const bool fused = f->fused;
+    if (!fused) SMC_LAUNCH(k_prepare, grid, dim3(SMC_BLOCK), st, f->da);
     if (f->a.scheme == SMC_MULTINOMIAL && !f->a.ut) {
         const dim3 g1(f->a.ntiles1, f->a.n_islands);
         SMC_LAUNCH(k_f_spacing_sums, g1, dim3(SMC_BLOCK), st, f->da);
         SMC_LAUNCH(k_f_spacing_write, g1, dim3(SMC_BLOCK), st, f->da);
     }
-    SMC_LAUNCH(k_ancestors, grid, dim3(SMC_BLOCK), st, f->da);
+    if (fused) SMC_LAUNCH(k_ancestors<true>, grid, dim3(SMC_BLOCK), st, f->da);
+    else SMC_LAUNCH(k_ancestors<false>, grid, dim3(SMC_BLOCK), st, f->da);
     if (k_prof >= 0) (void)hipEventRecord(f->ev[3 * k_prof + 1], st);
     launch_propagate(f);
     if (k_prof >= 0) (void)hipEventRecord(f->ev[3 * k_prof + 2], st);
@@ -152,7 +155,10 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     const size_t oX0 = carve(M * N * dxm * 8), oX1 = carve(M * N * dxm * 8);
     const size_t oL0 = carve(M * N * 8), oL1 = carve(M * N * 8);
     const size_t oA = carve(M * N * 8);
-    const size_t oq = carve(M * N * 8);
+    // q is only materialised when k_prepare runs (more tiles than k_ancestors<true> handles)
+    // (published tile totals pay off only while every workgroup of the launch is resident)
+    f->fused = (i64)a.ntiles * (i64)M <= F_DIRECT_PREFIX_MAX;
+    const size_t oq = carve(f->fused ? 8 : M * N * 8);
     const size_t oQ = carve(M * a.ntiles * 8);
     const size_t oQpre = carve(M * a.ntiles * 8);
     const i64 per_wg = mv ? (i64)SMC_BLOCK : (i64)SMC_BLOCK * F_OPT;
@@ -202,6 +208,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     hipStream_t st = ctx->stream;
     SMC_HIP_CHECK(hipMemsetAsync(a.summ, 0, M * (T + 1) * SUMM_STRIDE * 8, st));
     SMC_HIP_CHECK(hipMemsetAsync(a.cnt, 0, M * 2 * F_CNT_WORDS * sizeof(unsigned), st));
+    SMC_HIP_CHECK(hipMemsetAsync(a.Q, 0, M * a.ntiles * 8, st));
     {   // step record of t = 0: {t, rs_flag, y_0, m, 1/s}
         std::vector<double> h(M * INFO_STRIDE, 0.0);
         for (size_t i = 0; i < M; ++i) h[i * INFO_STRIDE + 2] = y_host[0];

@@ -268,10 +268,6 @@ k_prepare(const FArgs* __restrict__ ap)
     s = smc_block_sum_u64(s, smu);
     u64* Q = a.Q + (i64)isl * a.ntiles;
     f_store4<u64, F2u>(q, j0, vec && ok[3], ok, q4);
-    if (a.ntiles <= F_DIRECT_PREFIX_MAX) {      // k_ancestors sums its predecessors itself
-        if (threadIdx.x == 0) Q[b] = s;
-        return;
-    }
     if (threadIdx.x == 0) smc_st_agent(Q + b, s);
     if (!f_last_block(a.cnt + (isl * 2 + 1) * F_CNT_WORDS, b, a.ntiles, &s_last, 0)) return;
     // last workgroup: exclusive prefixes of the tile totals (exact integers)
@@ -370,6 +366,7 @@ k_f_spacing_write(const FArgs* __restrict__ ap)
 // CDF of the tile from q and its exclusive prefix, the contiguous range of
 // offspring it owns, and the parent index of each of them -> A.
 // ---------------------------------------------------------------------------
+template <bool FUSED>
 __global__ void __launch_bounds__(SMC_BLOCK)
 k_ancestors(const FArgs* __restrict__ ap)
 {
@@ -394,16 +391,46 @@ k_ancestors(const FArgs* __restrict__ ap)
     // ---- the tile's parents: q and their exact CDF
     u64 q4[4];
     const i64 jt = j0 + (i64)tid * F_IPT;
-    f_load4<u64, F2u>(a.q + (i64)isl * N, jt, N, vec, 0ull, q4);
-    const u64 tsum = q4[0] + q4[1] + q4[2] + q4[3];
     u64 total, pre;
     u64 cex;
-    if (a.ntiles <= F_DIRECT_PREFIX_MAX) {
-        const u64* Qt = a.Q + (i64)isl * a.ntiles;
+    if (FUSED) {
+        // Q62 weights straight from the log-weights of step t-1 (f_weight); the
+        // tile total is published as total+1 (0 = "not there yet") and the totals
+        // of the tiles before this one are picked up the same way: all tiles of
+        // an island publish a few microseconds into the launch, lower-numbered
+        // workgroups are dispatched first, so the wait is short and cannot cycle.
+        // k_propagate(t) zeroes Q again.
+        const double m = info[3], rs = info[4];
+        const double* lw = (((t - 1) & 1) ? a.lw1 : a.lw0) + (i64)isl * N;
+        double l4[4];
+        f_load4<double, F2d>(lw, jt, N, vec, -INFINITY, l4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            q4[i] = (jt + i < N) ? smc_q62_w(f_weight(l4[i], m, rs)) : 0ull;
+        const u64 tsum = q4[0] + q4[1] + q4[2] + q4[3];
+        u64* Qt = a.Q + (i64)isl * a.ntiles;
+        const u64 mine = smc_block_sum_u64(tsum, smu);
+        if (tid == 0) smc_st_agent(Qt + b, mine + 1ull);
+        constexpr int NPRE = F_DIRECT_PREFIX_MAX / SMC_BLOCK;
+        u64 v[NPRE];
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k) {
+            const int i = tid + k * SMC_BLOCK;
+            v[k] = (i < b) ? smc_ld_agent(Qt + i) : 1ull;
+        }
         u64 part = 0;
-        for (int i = tid; i < b; i += SMC_BLOCK) part += Qt[i];
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k) {
+            while (v[k] == 0ull) {
+                smc_spin_pause();
+                v[k] = smc_ld_agent(Qt + tid + k * SMC_BLOCK);
+            }
+            part += v[k] - 1ull;
+        }
         cex = smc_block_exscan_plus_sum_u64(tsum, part, smu, total, pre);
     } else {
+        f_load4<u64, F2u>(a.q + (i64)isl * N, jt, N, vec, 0ull, q4);
+        const u64 tsum = q4[0] + q4[1] + q4[2] + q4[3];
         pre = a.Qpre[(i64)isl * a.ntiles + b];
         cex = smc_block_exscan_u64(tsum, smu, total);
     }
@@ -518,6 +545,10 @@ __device__ __forceinline__ void f_step_tail(const FArgs& a, const int isl, const
 {
     const int tid = (int)threadIdx.x;
     const i64 N = a.N;
+    {   // re-arm the tile totals k_ancestors<true> publishes (0 = "not there yet")
+        const i64 g = (i64)b * SMC_BLOCK + tid;
+        if (g < a.ntiles) a.Q[(i64)isl * a.ntiles + g] = 0ull;
+    }
     F_STAMP(3);
     const SmcLse r = smc_lse_block(acc, smd);
     F_STAMP(4);
