@@ -107,6 +107,20 @@ __device__ __forceinline__ void smc_drain_stores_but4()
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
 }
 #endif
+// A value every lane of the wavefront holds identically (loaded through a per-lane
+// address the compiler cannot prove uniform) -> an SGPR copy: conditions on it become
+// scalar branches instead of exec-mask regions.
+#ifdef SMC_EMULATE
+__device__ __forceinline__ double smc_uniform(double v) { return v; }
+#else
+__device__ __forceinline__ double smc_uniform(double v)
+{
+    const u64 x = (u64)__double_as_longlong(v);
+    const u32 lo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)x);
+    const u32 hi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(x >> 32));
+    return __longlong_as_double((long long)(((u64)hi << 32) | lo));
+}
+#endif
 __device__ __forceinline__ void smc_st_agent_f64(double* p, double v)
 {
     smc_st_agent(reinterpret_cast<u64*>(p), (u64)__double_as_longlong(v));

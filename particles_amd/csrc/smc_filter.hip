@@ -38,11 +38,15 @@ static void launch_propagate(smc_filter* f)
     if (f->kind == SMC_MODEL_MVLINGAUSS) {
 #define MV_CASE(FKV, DPV)                                                                   \
     if (f->fk == FKV && f->a.dp == DPV) {                                                   \
-        SMC_LAUNCH((k_propagate_mv<FKV, DPV>), grid, dim3(SMC_BLOCK), st, f->da, f->a.mvc);           \
+        if (f->a.dx == DPV)                                                                 \
+            SMC_LAUNCH((k_propagate_mv<FKV, DPV, true>), grid, dim3(SMC_BLOCK), st, f->da,  \
+                       f->a.mvc);                                                           \
+        else                                                                                \
+            SMC_LAUNCH((k_propagate_mv<FKV, DPV, false>), grid, dim3(SMC_BLOCK), st, f->da, \
+                       f->a.mvc);                                                           \
         return;                                                                             \
     }
-        MV_CASE(SMC_FK_BOOTSTRAP, 4) MV_CASE(SMC_FK_BOOTSTRAP, 8) MV_CASE(SMC_FK_BOOTSTRAP, 16)
-        MV_CASE(SMC_FK_BOOTSTRAP, 32) MV_CASE(SMC_FK_GUIDED, 4) MV_CASE(SMC_FK_GUIDED, 8)
+        MV_CASE(SMC_FK_BOOTSTRAP, 16) MV_CASE(SMC_FK_BOOTSTRAP, 32)
         MV_CASE(SMC_FK_GUIDED, 16) MV_CASE(SMC_FK_GUIDED, 32)
 #undef MV_CASE
         return;
@@ -106,7 +110,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
                     "MVLINGAUSS needs 1 <= dy <= dx <= 32");
         SMC_REQUIRE(model->F_host && model->G_host && model->covX_host && model->covY_host &&
                         model->mu0_host && model->cov0_host, "MVLINGAUSS matrices are required");
-        dpm = dxm <= 4 ? 4 : dxm <= 8 ? 8 : dxm <= 16 ? 16 : 32;
+        dpm = dxm <= 16 ? 16 : 32;              // padded to whole 16x16 MFMA blocks
         if (!mv_build_constants(model, model->fk, dpm, o->T, y_host, mvc_host)) {
             // same failure as MvNormal.__init__ (distributions.py:935-940)
             smc_set_error("MvNormal: argument cov must be a (d, d) pos. definite matrix");
@@ -161,7 +165,15 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     const size_t oq = carve(f->fused ? 8 : M * N * 8);
     const size_t oQ = carve(M * a.ntiles * 8);
     const size_t oQpre = carve(M * a.ntiles * 8);
-    const i64 per_wg = mv ? (i64)SMC_BLOCK : (i64)SMC_BLOCK * F_OPT;
+    // MV: a workgroup stages the step's matrices in LDS once and then walks
+    // mv_chunks chunks of 256 particles (2 workgroups per CU when N allows)
+    a.mv_chunks = 1;
+    if (mv) {
+        const char* e = getenv("SMC_MV_CHUNKS");
+        a.mv_chunks = e ? atoi(e) : 8;
+        while (a.mv_chunks > 1 && (i64)N / (SMC_BLOCK * a.mv_chunks) < 512) a.mv_chunks >>= 1;
+    }
+    const i64 per_wg = mv ? (i64)SMC_BLOCK * a.mv_chunks : (i64)SMC_BLOCK * F_OPT;
     a.nparts = (int)((o->N + per_wg - 1) / per_wg);
     const size_t oPm = carve(M * a.nparts * 8), oPs = carve(M * a.nparts * 8),
                  oPss = carve(M * a.nparts * 8);

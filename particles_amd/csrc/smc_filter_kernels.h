@@ -73,6 +73,7 @@ struct FArgs {
     int ntiles1;
     double spacing_scale;
     int dx, dy, dp;        // state / observation dimension, dx padded to 4, 8, 16 or 32
+    int mv_chunks;         // 256-particle chunks per workgroup of k_propagate_mv
     const double* mvc;     // MVLINGAUSS: derived constants (see smc_filter_mv.h)
     u64* trace;            // SMC_TRACE builds: (n_islands, ntiles, 8) shader-clock stamps of k_move
 };
@@ -247,9 +248,9 @@ k_prepare(const FArgs* __restrict__ ap)
     __shared__ int s_last;
     const int b = (int)blockIdx.x, isl = (int)blockIdx.y;
     const double* info = a.info + (i64)isl * INFO_STRIDE;
-    const i64 t = (i64)info[0];
-    if (t >= a.T || info[1] == 0.0) return;          // step t does not resample
-    const double m = info[3], rs = info[4];
+    const i64 t = (i64)smc_uniform(info[0]);
+    if (t >= a.T || smc_uniform(info[1]) == 0.0) return;          // step t does not resample
+    const double m = smc_uniform(info[3]), rs = smc_uniform(info[4]);
     // Q62 weights of step t-1's particles (the parents of step t) + tile total
     const double* lw = (((t - 1) & 1) ? a.lw1 : a.lw0) + (i64)isl * a.N;
     u64* q = a.q + (i64)isl * a.N;
@@ -314,8 +315,8 @@ k_f_spacing_sums(const FArgs* __restrict__ ap)
     __shared__ u64 smu[SMC_SM];
     const int b = (int)blockIdx.x, isl = (int)blockIdx.y;
     const double* info = a.info + (i64)isl * INFO_STRIDE;
-    const i64 t = (i64)info[0];
-    if (t >= a.T || t == 0 || info[1] == 0.0) return;
+    const i64 t = (i64)smc_uniform(info[0]);
+    if (t >= a.T || t == 0 || smc_uniform(info[1]) == 0.0) return;
     const i64 n0 = (i64)b * F_TILE + (i64)threadIdx.x * F_IPT;
     u64 s = 0;
 #pragma unroll
@@ -332,8 +333,8 @@ k_f_spacing_write(const FArgs* __restrict__ ap)
     __shared__ u64 smu[SMC_SM];
     const int b = (int)blockIdx.x, isl = (int)blockIdx.y;
     const double* info = a.info + (i64)isl * INFO_STRIDE;
-    const i64 t = (i64)info[0];
-    if (t >= a.T || t == 0 || info[1] == 0.0) return;
+    const i64 t = (i64)smc_uniform(info[0]);
+    if (t >= a.T || t == 0 || smc_uniform(info[1]) == 0.0) return;
     const u64* E = a.E + (i64)isl * a.ntiles1;
     const i64 n0 = (i64)b * F_TILE + (i64)threadIdx.x * F_IPT;
     u64 q[F_IPT], tsum = 0;
@@ -380,8 +381,8 @@ k_ancestors(const FArgs* __restrict__ ap)
     const int b = (int)blockIdx.x, isl = (int)blockIdx.y;
     const int tid = (int)threadIdx.x;
     const double* info = a.info + (i64)isl * INFO_STRIDE;
-    const i64 t = (i64)info[0];
-    if (t >= a.T || t == 0 || info[1] == 0.0) return;          // step t does not resample
+    const i64 t = (i64)smc_uniform(info[0]);
+    if (t >= a.T || t == 0 || smc_uniform(info[1]) == 0.0) return;          // step t does not resample
     const i64 N = a.N;
     const u32 gisl = (u32)(a.island_offset + isl);
     i64* A = a.A + (i64)isl * N;
@@ -400,7 +401,7 @@ k_ancestors(const FArgs* __restrict__ ap)
         // an island publish a few microseconds into the launch, lower-numbered
         // workgroups are dispatched first, so the wait is short and cannot cycle.
         // k_propagate(t) zeroes Q again.
-        const double m = info[3], rs = info[4];
+        const double m = smc_uniform(info[3]), rs = smc_uniform(info[4]);
         const double* lw = (((t - 1) & 1) ? a.lw1 : a.lw0) + (i64)isl * N;
         double l4[4];
         f_load4<double, F2d>(lw, jt, N, vec, -INFINITY, l4);
@@ -632,12 +633,12 @@ k_propagate(const FArgs* __restrict__ ap)
     const int tid = (int)threadIdx.x;
     F_STAMP(0);
     double* info = a.info + (i64)isl * INFO_STRIDE;
-    const i64 t = (i64)info[0];
+    const i64 t = (i64)smc_uniform(info[0]);
     if (t >= a.T) return;
     F_STAMP(1);
     const i64 N = a.N;
     const double* p = a.params + (i64)isl * PARAM_STRIDE;
-    const double yt = info[2];
+    const double yt = smc_uniform(info[2]);
     const u32 gisl = (u32)(a.island_offset + isl);
     const int cur = (int)(t & 1);
     double* Xn = (cur ? a.X1 : a.X0) + (i64)isl * N;
@@ -647,7 +648,7 @@ k_propagate(const FArgs* __restrict__ ap)
     const i64* A = a.A + (i64)isl * N;
     const double* zt = a.zt ? a.zt + ((i64)t * a.n_islands + isl) * N : nullptr;
     const bool first = (t == 0);
-    const bool resample = !first && info[1] != 0.0;
+    const bool resample = !first && smc_uniform(info[1]) != 0.0;
     const bool vec = (N % OPT) == 0;          // every island base then is 8*OPT-byte aligned
     const i64 n0 = ((i64)b * SMC_BLOCK + tid) * OPT;
 

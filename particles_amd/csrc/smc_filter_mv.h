@@ -12,22 +12,31 @@
 // The last term needs no solve: x - mu = L_P z, so it is -|z|^2/2 - c_P.
 // Triangular solves become products with the precomputed inverse factors.
 //
-// Mapping (MI355X): one thread per particle, 256 particles per workgroup.  The
-// particle's current vector lives in LDS as a COLUMN (element k of thread p at
-// V[k*256+p]: conflict-free 8-byte accesses), the matrix is walked column by
-// column through SCALAR loads (it is the same for every lane) and each column
-// feeds DP independent v_fma_f64 accumulators held in registers.  The matrix in
-// use sits in LDS (8 KB, staged by the workgroup while the previous product
-// runs) and is read with broadcast ds_read_b128 -- per-lane global or scalar
-// loads inside the product loop left it waiting on memory every column.  Rows of X are gathered /
-// scattered cooperatively (16 lanes per 256-byte row) so global accesses stay
-// coalesced whole lines.  No MFMA: fp64 matrix and vector peaks are equal on
-// this part and the operands here are already register/SGPR resident.
+// Mapping (MI355X).  This is the one GEMM-shaped piece of the path -- (N, d)
+// particle rows times (d, d) matrices, fp64 -- and it runs on the matrix cores:
+// v_mfma_f64_16x16x4_f64 computes D(16x16) += A(16x4) B(4x16) per wavefront.
+// A wave works on 16 particles at a time in the TRANSPOSED product
+//      out^T (d x 16 particles) = M (d x d) . v^T (d x 16 particles)
+// with A = a 16x4 block of the constant matrix (one double per lane, kept in
+// LDS in exactly the lane order the instruction wants) and B = 4 consecutive
+// dimensions of the 16 particles.  Lane l = 16 g + n holds, of particle n,
+// the dimensions congruent to g modulo 4 -- and that is also where the
+// instruction leaves its results (row = (lane>>4) + 4 reg, col = lane&15), so
+// the output of one product is the B operand of the next without moving a
+// single register: five chained products per particle (guided), each 16 (12
+// for the triangular factors, whose upper blocks are skipped) MFMAs per 16
+// particles, nothing staged through LDS but the matrices themselves.
+// A wave keeps two 16-particle groups in flight so that every matrix fragment
+// read feeds two independent accumulator chains.
+// Philox normals follow the usual contract (pair kp of particle n -> dimensions
+// 2kp, 2kp+1; counter n*ceil(d/2)+kp): the two lanes that own the halves of a
+// pair each generate half of the pairs and swap the other element.
 #pragma once
 #include "smc_filter_kernels.h"
 
-// ---- layout of the constants block `mvc` (doubles); every matrix is stored
-// transposed and zero-padded to DP x DP:  Mt[k*DP + i] = M[i][k]
+// ---- layout of the constants block `mvc` (doubles).  Every matrix is padded
+// with zeros to DP x DP (DP = 16 or 32) and stored as MFMA A-fragments:
+//   frag[(jb * DP/4 + kb) * 64 + lane] = M[16 jb + (lane & 15)][4 kb + (lane >> 4)]
 #define MV_F 0        /* F                                   */
 #define MV_B 1        /* (I - K G) F            (guided)     */
 #define MV_LZ 2       /* factor applied to z, t >= 1: L_X (bootstrap) / L_P (guided) */
@@ -41,237 +50,287 @@
 #define MV_STEP(dp) (MV_SCAL(dp) + 8)              /* per t: yw_t[dp] = L_Y^-1 y_t, ky_t[dp] = K y_t */
 #define MV_SIZE(dp, T) (MV_STEP(dp) + 2 * (size_t)(dp) * (T))
 
-// Stage one DP x DP matrix of the constants block into LDS (all threads call).
-// `pf` holds the thread's share: mv_fetch issues the global loads (early, so
-// their latency hides behind the previous product), mv_commit parks them in LDS.
-template <int DP>
-struct MvShare { double v[(DP * DP + SMC_BLOCK - 1) / SMC_BLOCK]; };
-template <int DP>
-__device__ __forceinline__ void mv_fetch(const double* __restrict__ gM, MvShare<DP>& pf)
-{
-#pragma unroll
-    for (int j = 0; j < (DP * DP + SMC_BLOCK - 1) / SMC_BLOCK; ++j) {
-        const int i = j * SMC_BLOCK + (int)threadIdx.x;
-        pf.v[j] = (i < DP * DP) ? gM[i] : 0.0;
-    }
-}
-template <int DP>
-__device__ __forceinline__ void mv_commit(const MvShare<DP>& pf, double* sM)
-{
-    __syncthreads();                      // the previous product has finished reading sM
-#pragma unroll
-    for (int j = 0; j < (DP * DP + SMC_BLOCK - 1) / SMC_BLOCK; ++j) {
-        const int i = j * SMC_BLOCK + (int)threadIdx.x;
-        if (i < DP * DP) sM[i] = pf.v[j];
-    }
-    __syncthreads();
-}
+#define MV_G 1        /* 16-particle groups a wave keeps in flight */
 
-template <int DP>
-__device__ __forceinline__ void mv_matvec(const double* sM, const double* vcol, double (&acc)[DP])
+// acc[gi][jb] += M . v[gi]   for the MV_G groups; `frag` = the matrix's fragments in LDS.
+// v[gi][kb] = dimension 4 kb + g of the lane's particle; acc[gi][jb][r] = dimension
+// 16 jb + 4 r + g.  LOWER: M is lower triangular, blocks above the diagonal are skipped.
+template <int DP, bool LOWER>
+__device__ __forceinline__ void mv_product(const double* frag, const double (&v)[MV_G][DP / 4],
+                                           smc_v4d (&acc)[MV_G][DP / 16], const int lane)
 {
-    // acc += M v ; column k of M (contiguous in sM, same address for every lane:
-    // LDS broadcast reads) scaled by v_k
-#pragma unroll 2
-    for (int k = 0; k < DP; ++k) {
-        const double vk = vcol[k * SMC_BLOCK];
+    // kb outer: consecutive MFMAs go to different accumulators (no dependent stalls)
 #pragma unroll
-        for (int i = 0; i < DP; ++i) acc[i] = fma(sM[k * DP + i], vk, acc[i]);
-    }
-}
-
-// rows[p] (>= 0) of a (.., d) row-major array -> columns of V; 16-byte chunks,
-// consecutive lanes on consecutive chunks of the same row
-template <int DP>
-__device__ __forceinline__ void mv_load_rows(const double* base, int d, const i64* sRow, double* V)
-{
-    const int tid = (int)threadIdx.x;
-    if (d == DP) {
-        constexpr int CPR = DP / 2;                 // 16-byte chunks per row
-        constexpr int RPI = SMC_BLOCK / CPR;        // rows per pass over the workgroup
-#pragma unroll 4
-        for (int j = 0; j < CPR; ++j) {
-            const int p = tid / CPR + RPI * j, c = tid % CPR;
-            const i64 r = sRow[p];
-            F2d v;
-            v.a = 0.0; v.b = 0.0;
-            if (r >= 0) v = *reinterpret_cast<const F2d*>(base + r * d + 2 * c);
-            V[(2 * c) * SMC_BLOCK + p] = v.a;
-            V[(2 * c + 1) * SMC_BLOCK + p] = v.b;
+    for (int kb = 0; kb < DP / 4; ++kb) {
+#pragma unroll
+        for (int jb = 0; jb < DP / 16; ++jb) {
+            if (LOWER && 4 * kb >= 16 * (jb + 1)) continue;
+            const double m = frag[(jb * (DP / 4) + kb) * 64 + lane];
+#pragma unroll
+            for (int gi = 0; gi < MV_G; ++gi)
+                acc[gi][jb] = smc_mfma_f64_16x16x4(m, v[gi][kb], acc[gi][jb]);
         }
-    } else {
-        const i64 r = sRow[tid];
-        for (int k = 0; k < DP; ++k) V[k * SMC_BLOCK + tid] = (k < d && r >= 0) ? base[r * d + k] : 0.0;
-    }
-}
-template <int DP>
-__device__ __forceinline__ void mv_store_rows(double* base, int d, const i64* sRow, const double* V)
-{
-    const int tid = (int)threadIdx.x;
-    if (d == DP) {
-        constexpr int CPR = DP / 2;
-        constexpr int RPI = SMC_BLOCK / CPR;
-#pragma unroll 4
-        for (int j = 0; j < CPR; ++j) {
-            const int p = tid / CPR + RPI * j, c = tid % CPR;
-            const i64 r = sRow[p];
-            if (r >= 0) {
-                F2d v;
-                v.a = V[(2 * c) * SMC_BLOCK + p];
-                v.b = V[(2 * c + 1) * SMC_BLOCK + p];
-                *reinterpret_cast<F2d*>(base + r * d + 2 * c) = v;
-            }
-        }
-    } else {
-        const i64 r = sRow[tid];
-        if (r >= 0)
-            for (int k = 0; k < d; ++k) base[r * d + k] = V[k * SMC_BLOCK + tid];
     }
 }
 
-template <int FK, int DP>
+// sum over the 4 lanes (g = 0..3) that share a particle; every one of them gets it
+__device__ __forceinline__ double mv_sum_g(double v)
+{
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+template <int FK, int DP, bool DFULL>
 __global__ void __launch_bounds__(SMC_BLOCK)
 k_propagate_mv(const FArgs* __restrict__ ap, const double* __restrict__ C)
 {
-    // C (= ap->mvc) comes in as its own const __restrict__ kernel argument: only then
-    // does the compiler know the block is never written and fetch the matrix columns
-    // with SCALAR loads (s_load_dwordx16) instead of 64 identical vector loads
+    constexpr int NV = DP / 4;                    // dimensions per lane
+    constexpr int NJ = DP / 16;                   // 16-row blocks of a product
+    constexpr int MM = DP * DP;
+    constexpr int NSLOT = (FK == SMC_FK_GUIDED) ? 5 : 3;
+    constexpr int S_F = 0, S_B = 1;
+    constexpr int S_LZ = (FK == SMC_FK_GUIDED) ? 2 : 1;
+    constexpr int S_XINV = 3;
+    constexpr int S_NGY = (FK == SMC_FK_GUIDED) ? 4 : 2;
     const FArgs& a = *ap;
-    __shared__ double sV0[DP * SMC_BLOCK];
-    __shared__ double sV1[FK == SMC_FK_GUIDED ? DP * SMC_BLOCK : 1];
-    __shared__ __attribute__((aligned(16))) double sM[DP * DP];     // the matrix in use
-    __shared__ i64 sRow[SMC_BLOCK];
+    __shared__ double sM[NSLOT * MM];
+    __shared__ double sVec[4 * DP];               // mu (t = 0) or K y_t | mu0 | L_Y^-1 y_t | -
     __shared__ double smd[SMC_SM];
     __shared__ int s_last;
     const int b = (int)blockIdx.x, isl = (int)blockIdx.y;
     const int tid = (int)threadIdx.x;
-    MvShare<DP> pf;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int g = lane >> 4, pn = lane & 15;
     double* info = a.info + (i64)isl * INFO_STRIDE;
-    const i64 t = (i64)info[0];
+    const i64 t = (i64)smc_uniform(info[0]);
     if (t >= a.T) return;
     const i64 N = a.N;
     const int d = a.dx;
     const u32 gisl = (u32)(a.island_offset + isl);
     const int cur = (int)(t & 1);
-    double* Xn = (cur ? a.X1 : a.X0) + (i64)isl * N * d;
-    const double* Xo = (cur ? a.X0 : a.X1) + (i64)isl * N * d;
-    double* lwn = (cur ? a.lw1 : a.lw0) + (i64)isl * N;
-    const double* lwo = (cur ? a.lw0 : a.lw1) + (i64)isl * N;
-    const i64* A = a.A + (i64)isl * N;
-    const double* zt = a.zt ? a.zt + ((i64)t * a.n_islands + isl) * N * d : nullptr;
+    SMC_GLOBAL(double) Xn = SMC_AS_GLOBAL(double, (cur ? a.X1 : a.X0) + (i64)isl * N * d);
+    SMC_GLOBAL(const double) Xo = SMC_AS_GLOBAL(const double, (cur ? a.X0 : a.X1) + (i64)isl * N * d);
+    SMC_GLOBAL(double) lwn = SMC_AS_GLOBAL(double, (cur ? a.lw1 : a.lw0) + (i64)isl * N);
+    SMC_GLOBAL(const double) lwo = SMC_AS_GLOBAL(const double, (cur ? a.lw0 : a.lw1) + (i64)isl * N);
+    SMC_GLOBAL(const i64) A = SMC_AS_GLOBAL(const i64, a.A + (i64)isl * N);
+    SMC_GLOBAL(const double) zt =
+        SMC_AS_GLOBAL(const double, a.zt ? a.zt + ((i64)t * a.n_islands + isl) * N * d : nullptr);
     const bool first = (t == 0);
-    const bool resample = !first && info[1] != 0.0;
-    const i64 n = (i64)b * SMC_BLOCK + tid;
-    const bool valid = n < N;
+    const bool resample = !first && smc_uniform(info[1]) != 0.0;
     const double* scal = C + MV_SCAL(DP);
     const double* yw = C + MV_STEP(DP) + (size_t)t * 2 * DP;
     const double* ky = yw + DP;
-    double* V0 = sV0 + tid;          // this thread's column
-    double* V1 = sV1 + tid;
-    double acc[DP];
 
-    mv_fetch<DP>(C + (first ? MV_LZ0 : MV_F) * DP * DP, pf);
-    // ---- the parents' rows -> V0
-    if (!first) {
-        sRow[tid] = valid ? (resample ? A[n] : n) : -1;                    // core.py:332 / :336
-        __syncthreads();
-        mv_load_rows<DP>(Xo, d, sRow, sV0);
-        __syncthreads();
-    }
-    // ---- mean of the proposal: acc = mu
-    if (first) {
-        const double* mu = C + MV_VEC(DP) + (FK == SMC_FK_GUIDED ? DP : 0);
-#pragma unroll
-        for (int i = 0; i < DP; ++i) acc[i] = mu[i];
-    } else {
-        mv_commit<DP>(pf, sM);                                             // F
-        if (FK == SMC_FK_GUIDED) {
-            mv_fetch<DP>(C + MV_B * DP * DP, pf);
-#pragma unroll
-            for (int i = 0; i < DP; ++i) acc[i] = 0.0;
-            mv_matvec<DP>(sM, V0, acc);                                    // m = F xp
-#pragma unroll
-            for (int i = 0; i < DP; ++i) V1[i * SMC_BLOCK] = acc[i];
-#pragma unroll
-            for (int i = 0; i < DP; ++i) acc[i] = ky[i];
-            mv_commit<DP>(pf, sM);                                         // B
-            mv_fetch<DP>(C + MV_LZ * DP * DP, pf);
-            mv_matvec<DP>(sM, V0, acc);                                    // mu = B xp + K y
-        } else {
-            mv_fetch<DP>(C + MV_LZ * DP * DP, pf);
-#pragma unroll
-            for (int i = 0; i < DP; ++i) acc[i] = 0.0;
-            mv_matvec<DP>(sM, V0, acc);                                    // mu = F xp
-        }
-    }
-    // ---- z -> V0 (the parent row is no longer needed), zz = |z|^2
-    double zz = 0.0;
-    __syncthreads();                        // everyone is done with the rows in sV0
-    if (zt) {
-        sRow[tid] = valid ? n : -1;
-        __syncthreads();
-        mv_load_rows<DP>(zt, d, sRow, sV0);
-        __syncthreads();
-        for (int k = 0; k < DP; ++k) { const double z = V0[k * SMC_BLOCK]; zz = fma(z, z, zz); }
-    } else {
-        const int hp = (d + 1) / 2;
-        for (int kp = 0; kp < DP / 2; ++kp) {
-            double z0 = 0.0, z1 = 0.0;
-            if (valid && 2 * kp < d) {
-                smc_normal_pair(a.seed, (u32)(n * hp + kp), (u32)t, gisl, SMC_STREAM_NORMAL, z0, z1);
-                if (2 * kp + 1 >= d) z1 = 0.0;
+    // ---- the matrices of this step -> LDS (fragment order, as stored)
+    {
+        const int m_lz = first ? MV_LZ0 : MV_LZ, m_xinv = first ? MV_X0INV : MV_XINV;
+        for (int i = tid; i < MM; i += SMC_BLOCK) {
+            if (!first) {
+                sM[S_F * MM + i] = C[MV_F * MM + i];
+                if (FK == SMC_FK_GUIDED) sM[S_B * MM + i] = C[MV_B * MM + i];
             }
-            V0[(2 * kp) * SMC_BLOCK] = z0;
-            V0[(2 * kp + 1) * SMC_BLOCK] = z1;
-            zz = fma(z0, z0, fma(z1, z1, zz));
+            sM[S_LZ * MM + i] = C[m_lz * MM + i];
+            if (FK == SMC_FK_GUIDED) sM[S_XINV * MM + i] = C[m_xinv * MM + i];
+            sM[S_NGY * MM + i] = C[MV_NGY * MM + i];
+        }
+        // per-lane reads of these vectors come from LDS: indexed by g from the constant
+        // block they turn into scalar loads plus a select chain per element
+        if (tid < DP) {
+            const double* mu = C + MV_VEC(DP) + (FK == SMC_FK_GUIDED ? DP : 0);
+            sVec[tid] = first ? mu[tid] : ((FK == SMC_FK_GUIDED) ? ky[tid] : 0.0);
+            sVec[DP + tid] = C[MV_VEC(DP) + tid];
+            sVec[2 * DP + tid] = yw[tid];
         }
     }
-    // ---- x = mu + L z
-    mv_commit<DP>(pf, sM);                                                 // L_z
-    mv_fetch<DP>(C + (FK == SMC_FK_GUIDED ? (first ? MV_X0INV : MV_XINV) : MV_NGY) * DP * DP, pf);
-    mv_matvec<DP>(sM, V0, acc);
-    double uu = 0.0;
-    if (FK == SMC_FK_GUIDED) {
-        const double* mu0 = C + MV_VEC(DP);
-#pragma unroll
-        for (int i = 0; i < DP; ++i) {
-            const double mi = first ? mu0[i] : V1[i * SMC_BLOCK];
-            V1[i * SMC_BLOCK] = acc[i] - mi;                               // x - m
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < DP; ++i) V0[i * SMC_BLOCK] = acc[i];               // x
-    if (FK == SMC_FK_GUIDED) {
-#pragma unroll
-        for (int i = 0; i < DP; ++i) acc[i] = 0.0;
-        mv_commit<DP>(pf, sM);                                             // L_X^-1
-        mv_fetch<DP>(C + MV_NGY * DP * DP, pf);
-        mv_matvec<DP>(sM, V1, acc);
-#pragma unroll
-        for (int i = 0; i < DP; ++i) uu = fma(acc[i], acc[i], uu);        // |L^-1 (x - m)|^2
-    }
-    // ---- w = L_Y^-1 (y - G x)
-#pragma unroll
-    for (int i = 0; i < DP; ++i) acc[i] = yw[i];
-    mv_commit<DP>(pf, sM);                                                 // -(L_Y^-1 G)
-    mv_matvec<DP>(sM, V0, acc);
-    double ww = 0.0;
-#pragma unroll
-    for (int i = 0; i < DP; ++i) ww = fma(acc[i], acc[i], ww);
-    double inc = -0.5 * ww - scal[1];                                      // kalman.py:345-346
-    if (FK == SMC_FK_GUIDED)                                               // ssm.py:380-392
-        inc = ((-0.5 * uu - scal[first ? 3 : 0]) + inc) - (-0.5 * zz - scal[first ? 4 : 2]);
-    SmcLse lacc = smc_lse_empty();
-    if (valid) {
-        double lw = (resample || first) ? inc : lwo[n] + inc;              // resampling.py:241-244
-        if (lw != lw) lw = -INFINITY;                                      // resampling.py:220
-        lwn[n] = lw;
-        smc_lse_push(lacc, lw);
-    }
-    // ---- rows of X out, whole lines
-    sRow[tid] = valid ? n : -1;
     __syncthreads();
-    mv_store_rows<DP>(Xn, d, sRow, sV0);
+    const double* vMu = sVec + g;                 // element 16 jb + 4 r of the lane's view
+    const double* vMu0 = sVec + DP + g;
+    const double* vYw = sVec + 2 * DP + g;
+
+    SmcLse lacc = smc_lse_empty();
+    const int hp = (d + 1) / 2;
+    // rows are requested one iteration ahead (and their ancestor index two ahead):
+    // at 2 waves per SIMD nothing else hides the two dependent round trips
+    const int nit = a.mv_chunks * (4 / MV_G);
+    auto particle = [&](int it, int gi) -> i64 {
+        return ((i64)b * a.mv_chunks + it / (4 / MV_G)) * SMC_BLOCK + (i64)wv * 64 +
+               (i64)((it % (4 / MV_G)) * MV_G + gi) * 16 + pn;
+    };
+    // loads are unconditional on clamped addresses and masked afterwards (selects, not
+    // exec-mask regions: those cost an SGPR pair each and spill)
+    constexpr bool dfull = DFULL;               // d == DP: no padded dimensions to mask
+    auto parent = [&](int it, int gi) -> i64 {                              // core.py:332 / :336
+        const i64 nn = particle(it, gi);
+        const bool ok = !first && it < nit && nn < N;
+        const i64 nc = nn < N ? nn : N - 1;
+        const i64 r = resample ? A[nc] : nc;
+        return ok ? r : -1;
+    };
+    auto load_row = [&](SMC_GLOBAL(const double) base, i64 row, double (&dst)[NV]) {
+        const bool rv = row >= 0;
+        SMC_GLOBAL(const double) pr = base + (rv ? row : 0) * d;
+#pragma unroll
+        for (int kb = 0; kb < NV; ++kb) {
+            const int k = 4 * kb + g;
+            const bool kin = dfull || k < d;
+            const double x = pr[kin ? k : 0];
+            dst[kb] = (rv && kin) ? x : 0.0;
+        }
+    };
+    i64 rnext[MV_G];
+    double nx[MV_G][NV];
+#pragma unroll
+    for (int gi = 0; gi < MV_G; ++gi) {
+        load_row(Xo, parent(0, gi), nx[gi]);
+        rnext[gi] = parent(1, gi);
+    }
+#pragma unroll 1
+    for (int it = 0; it < nit; ++it) {
+        i64 n[MV_G];
+        bool valid[MV_G];
+        double v[MV_G][NV];                 // current B operand: xp, then z, x, x - m
+        double lwprev[MV_G];
+        smc_v4d am[MV_G][NJ], ax[MV_G][NJ];
+        // ---- the parents' rows (requested during the previous iteration)
+#pragma unroll
+        for (int gi = 0; gi < MV_G; ++gi) {
+            n[gi] = particle(it, gi);
+            valid[gi] = n[gi] < N;
+#pragma unroll
+            for (int kb = 0; kb < NV; ++kb) v[gi][kb] = nx[gi][kb];
+            load_row(Xo, rnext[gi], nx[gi]);
+            rnext[gi] = parent(it + 2, gi);
+            lwprev[gi] = (resample || first) ? 0.0 : lwo[valid[gi] ? n[gi] : N - 1];
+        }
+        // ---- mean of the proposal -> ax ; guided keeps m = F xp in am
+#pragma unroll
+        for (int gi = 0; gi < MV_G; ++gi)
+#pragma unroll
+            for (int jb = 0; jb < NJ; ++jb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    ax[gi][jb][r] = vMu[16 * jb + 4 * r];                  // mu (t = 0) / K y_t / 0
+                    am[gi][jb][r] = first ? vMu0[16 * jb + 4 * r] : 0.0;
+                }
+        if (!first) {
+            if (FK == SMC_FK_GUIDED) {
+                mv_product<DP, false>(sM + S_F * MM, v, am, lane);          // m = F xp
+                mv_product<DP, false>(sM + S_B * MM, v, ax, lane);          // mu = B xp + K y
+            } else {
+                mv_product<DP, false>(sM + S_F * MM, v, ax, lane);          // mu = F xp
+            }
+        }
+        // ---- z -> v, zz = |z|^2
+        double zz[MV_G];
+#pragma unroll
+        for (int gi = 0; gi < MV_G; ++gi) {
+            if (zt) {
+                load_row(zt, valid[gi] ? n[gi] : -1, v[gi]);
+            } else {
+                // lane (g = 2h + e) needs element e of the pairs kp = 2 j + h, j < NV; the
+                // e = 0 lane generates j < NV/2, its e = 1 neighbour (lane + 16) the rest
+                const int h = g >> 1, e = g & 1;
+                double own[NV / 2], oth[NV / 2];
+#pragma unroll
+                for (int jj = 0; jj < NV / 2; ++jj) {
+                    const int j = jj + e * (NV / 2);
+                    const int kp = 2 * j + h;
+                    double z0, z1;
+                    smc_normal_pair(a.seed, (u32)(n[gi] * hp + kp), (u32)t, gisl,
+                                    SMC_STREAM_NORMAL, z0, z1);
+                    if (!dfull) {
+                        if (2 * kp >= d) z0 = 0.0;
+                        if (2 * kp + 1 >= d) z1 = 0.0;
+                    }
+                    own[jj] = e ? z1 : z0;
+                    oth[jj] = e ? z0 : z1;
+                }
+#pragma unroll
+                for (int jj = 0; jj < NV / 2; ++jj) oth[jj] = __shfl_xor(oth[jj], 16);
+#pragma unroll
+                for (int jj = 0; jj < NV / 2; ++jj) {
+                    v[gi][jj + e * (NV / 2)] = own[jj];
+                    v[gi][jj + (1 - e) * (NV / 2)] = oth[jj];
+                }
+            }
+            double q = 0.0;
+#pragma unroll
+            for (int kb = 0; kb < NV; ++kb) q = fma(v[gi][kb], v[gi][kb], q);
+            zz[gi] = q;
+        }
+        // ---- x = mu + L z
+        mv_product<DP, true>(sM + S_LZ * MM, v, ax, lane);
+        double uu[MV_G];
+        if (FK == SMC_FK_GUIDED) {
+            // u = L_X^-1 (x - m)
+            smc_v4d au[MV_G][NJ];
+#pragma unroll
+            for (int gi = 0; gi < MV_G; ++gi)
+#pragma unroll
+                for (int jb = 0; jb < NJ; ++jb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[gi][4 * jb + r] = ax[gi][jb][r] - am[gi][jb][r];
+                        au[gi][jb][r] = 0.0;
+                    }
+            mv_product<DP, true>(sM + S_XINV * MM, v, au, lane);
+#pragma unroll
+            for (int gi = 0; gi < MV_G; ++gi) {
+                double q = 0.0;
+#pragma unroll
+                for (int jb = 0; jb < NJ; ++jb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) q = fma(au[gi][jb][r], au[gi][jb][r], q);
+                uu[gi] = q;
+            }
+        }
+        // ---- w = L_Y^-1 (y - G x) ; rows of x out
+#pragma unroll
+        for (int gi = 0; gi < MV_G; ++gi)
+#pragma unroll
+            for (int jb = 0; jb < NJ; ++jb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[gi][4 * jb + r] = ax[gi][jb][r];
+                    am[gi][jb][r] = vYw[16 * jb + 4 * r];
+                }
+#pragma unroll
+        for (int gi = 0; gi < MV_G; ++gi)
+            if (valid[gi]) {
+                SMC_GLOBAL(double) px = Xn + n[gi] * d + g;
+                if (dfull) {
+#pragma unroll
+                    for (int kb = 0; kb < NV; ++kb) px[4 * kb] = v[gi][kb];
+                } else {
+#pragma unroll
+                    for (int kb = 0; kb < NV; ++kb)
+                        if (4 * kb + g < d) px[4 * kb] = v[gi][kb];
+                }
+            }
+        mv_product<DP, false>(sM + S_NGY * MM, v, am, lane);
+#pragma unroll
+        for (int gi = 0; gi < MV_G; ++gi) {
+            double ww = 0.0;
+#pragma unroll
+            for (int jb = 0; jb < NJ; ++jb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ww = fma(am[gi][jb][r], am[gi][jb][r], ww);
+            ww = mv_sum_g(ww);
+            const double zs = mv_sum_g(zz[gi]);
+            double inc = -0.5 * ww - scal[1];                                  // kalman.py:345-346
+            if (FK == SMC_FK_GUIDED) {                                         // ssm.py:380-392
+                const double us = mv_sum_g(uu[gi]);
+                inc = ((-0.5 * us - scal[first ? 3 : 0]) + inc) - (-0.5 * zs - scal[first ? 4 : 2]);
+            }
+            if (valid[gi] && g == 0) {
+                double lw = (resample || first) ? inc : lwprev[gi] + inc;      // resampling.py:241-244
+                if (lw != lw) lw = -INFINITY;                                  // resampling.py:220
+                lwn[n[gi]] = lw;
+                smc_lse_push(lacc, lw);
+            }
+        }
+    }
     f_step_tail(a, isl, b, t, first, resample, lacc, smd, s_last, info);
 }
 
@@ -363,11 +422,16 @@ inline bool gain(const Mat& P, const Mat& G, const Mat& R, int dx, int dy, Mat& 
         for (int j = 0; j < i; ++j) Pf[i * dx + j] = Pf[j * dx + i] = 0.5 * (Pf[i * dx + j] + Pf[j * dx + i]);
     return true;
 }
-// store M (r x c) transposed + padded into dst (dp x dp): dst[k*dp+i] = M[i][k]
-inline void put_t(double* dst, int dp, const Mat& M, int r, int c, double sign = 1.0)
+// store M (r x c), zero-padded to dp x dp, as MFMA A-fragments (layout at the top)
+inline void put_frag(double* dst, int dp, const Mat& M, int r, int c, double sign = 1.0)
 {
-    for (int i = 0; i < r; ++i)
-        for (int k = 0; k < c; ++k) dst[k * dp + i] = sign * M[i * c + k];
+    for (int jb = 0; jb < dp / 16; ++jb)
+        for (int kb = 0; kb < dp / 4; ++kb)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int row = 16 * jb + (lane & 15), col = 4 * kb + (lane >> 4);
+                dst[(jb * (dp / 4) + kb) * 64 + lane] =
+                    (row < r && col < c) ? sign * M[row * c + col] : 0.0;
+            }
 }
 }  // namespace mvh
 
@@ -387,8 +451,8 @@ inline bool mv_build_constants(const smc_model* m, int fk, int dp, i64 T, const 
     if (!chol(QX, dx, LX) || !chol(R, dy, LY) || !chol(Q0, dx, L0)) return false;
     Mat LYi = tri_inv(LY, dy);
     Mat GY = mul(LYi, dy, dy, G, dx);                                     // (dy,dx)
-    put_t(C + MV_F * dp * dp, dp, F, dx, dx);
-    put_t(C + MV_NGY * dp * dp, dp, GY, dy, dx, -1.0);
+    put_frag(C + MV_F * dp * dp, dp, F, dx, dx);
+    put_frag(C + MV_NGY * dp * dp, dp, GY, dy, dx, -1.0);
     double* scal = C + MV_SCAL(dp);
     scal[0] = logdiag(LX, dx) + dx * SMC_HALFLOG2PI;
     scal[1] = logdiag(LY, dy) + dy * SMC_HALFLOG2PI;
@@ -403,11 +467,11 @@ inline bool mv_build_constants(const smc_model* m, int fk, int dp, i64 T, const 
         Mat KG = mul(K, dx, dy, G, dx), IKG((size_t)dx * dx, 0.0);
         for (int i = 0; i < dx; ++i)
             for (int j = 0; j < dx; ++j) IKG[i * dx + j] = (i == j ? 1.0 : 0.0) - KG[i * dx + j];
-        put_t(C + MV_B * dp * dp, dp, mul(IKG, dx, dx, F, dx), dx, dx);
-        put_t(C + MV_LZ * dp * dp, dp, LP, dx, dx);
-        put_t(C + MV_LZ0 * dp * dp, dp, LP0, dx, dx);
-        put_t(C + MV_XINV * dp * dp, dp, tri_inv(LX, dx), dx, dx);
-        put_t(C + MV_X0INV * dp * dp, dp, tri_inv(L0, dx), dx, dx);
+        put_frag(C + MV_B * dp * dp, dp, mul(IKG, dx, dx, F, dx), dx, dx);
+        put_frag(C + MV_LZ * dp * dp, dp, LP, dx, dx);
+        put_frag(C + MV_LZ0 * dp * dp, dp, LP0, dx, dx);
+        put_frag(C + MV_XINV * dp * dp, dp, tri_inv(LX, dx), dx, dx);
+        put_frag(C + MV_X0INV * dp * dp, dp, tri_inv(L0, dx), dx, dx);
         scal[2] = logdiag(LP, dx) + dx * SMC_HALFLOG2PI;
         scal[4] = logdiag(LP0, dx) + dx * SMC_HALFLOG2PI;
         // proposal0 mean: mu0 + K0 (y0 - G mu0)           (kalman.py:353-356)
@@ -421,8 +485,8 @@ inline bool mv_build_constants(const smc_model* m, int fk, int dp, i64 T, const 
             C[MV_VEC(dp) + dp + i] = v;
         }
     } else {
-        put_t(C + MV_LZ * dp * dp, dp, LX, dx, dx);
-        put_t(C + MV_LZ0 * dp * dp, dp, L0, dx, dx);
+        put_frag(C + MV_LZ * dp * dp, dp, LX, dx, dx);
+        put_frag(C + MV_LZ0 * dp * dp, dp, L0, dx, dx);
     }
     for (i64 t = 0; t < T; ++t) {
         double* yw = C + MV_STEP(dp) + (size_t)t * 2 * dp;

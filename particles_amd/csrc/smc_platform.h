@@ -20,3 +20,28 @@
 typedef unsigned long long u64;
 typedef long long i64;
 typedef unsigned int u32;
+
+// 4 doubles per lane: the C/D operand of v_mfma_f64_16x16x4_f64
+#ifdef SMC_EMULATE
+struct smc_v4d {
+    double v[4];
+    double& operator[](int i) { return v[i]; }
+    const double& operator[](int i) const { return v[i]; }
+};
+#define smc_mfma_f64_16x16x4(a, b, c) hipemu_mfma_f64_16x16x4((a), (b), (c))
+#else
+typedef double smc_v4d __attribute__((ext_vector_type(4)));
+#define smc_mfma_f64_16x16x4(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+#endif
+
+// Pointers read out of the argument block are generic to the compiler and turn
+// into flat_* accesses, which count on lgkmcnt as well: every wait for an LDS
+// read then also waits for the global loads in flight.  SMC_GLOBAL marks them
+// as global memory (address space 1) so they become global_* (vmcnt only).
+#ifdef SMC_EMULATE
+#define SMC_GLOBAL(T) T*
+#define SMC_AS_GLOBAL(T, p) (p)
+#else
+#define SMC_GLOBAL(T) T __attribute__((address_space(1)))*
+#define SMC_AS_GLOBAL(T, p) ((T __attribute__((address_space(1)))*)(p))
+#endif

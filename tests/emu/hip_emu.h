@@ -64,6 +64,7 @@ struct State {
     long wbar_gen[MAXT / WAVE] = {0};
     int wave_live[MAXT / WAVE] = {0};
     uint64_t xch[MAXT];
+    double xa[MAXT], xb[MAXT];      // MFMA operands
     std::function<void()> body;
     bool error = false;
     alignas(16) char dyn_smem[160 * 1024];
@@ -179,6 +180,27 @@ inline T exchange(T v, int src_lane_abs) {
     return out;
 }
 
+// v_mfma_f64_16x16x4_f64: D(16x16) = C + A(16x4) B(4x16) over the wavefront.
+// Lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15]; it owns
+// D[(l >> 4) + 4 r][l & 15], r = 0..3 (cdna_hip_programming.md, f64 MFMA layout).
+template <typename V4>
+inline V4 mfma_f64_16x16x4(double a, double b, V4 c) {
+    State& s = S();
+    const int base = s.cur - s.cur % WAVE, l = s.cur % WAVE;
+    s.xa[s.cur] = a;
+    s.xb[s.cur] = b;
+    wave_barrier();
+    V4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int row = (l >> 4) + 4 * r, col = l & 15;
+        double acc = c[r];
+        for (int k = 0; k < 4; ++k) acc = std::fma(s.xa[base + row + 16 * k], s.xb[base + col + 16 * k], acc);
+        d[r] = acc;
+    }
+    wave_barrier();
+    return d;
+}
+
 template <typename F>
 inline void launch(dim3 grid, dim3 block, F&& f) {
     State& s = S();
@@ -216,6 +238,7 @@ static EmuBlockIdx blockIdx;
 static EmuBlockDim blockDim;
 static EmuGridDim gridDim;
 
+#define hipemu_mfma_f64_16x16x4(a, b, c) hipemu::mfma_f64_16x16x4((a), (b), (c))
 inline void __syncthreads() { hipemu::block_barrier(); }
 inline void __threadfence() {}
 
