@@ -12,7 +12,10 @@ SOURCES = ["smc_api.hip", "smc_ops.hip", "smc_filter.hip", "smc_comm.hip"]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [
     os.path.join("..", "..", "include", "smc_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-         "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+         "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
+         # MFMA results straight into VGPRs (they are the next product's B operand):
+         # no v_accvgpr_read/write copies
+         "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 
 
 def _hipcc():

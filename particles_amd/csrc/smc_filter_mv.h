@@ -65,6 +65,9 @@ __device__ __forceinline__ void mv_product(const double* frag, const double (&v)
 #pragma unroll
         for (int jb = 0; jb < DP / 16; ++jb) {
             if (LOWER && 4 * kb >= 16 * (jb + 1)) continue;
+#ifdef ABL_NO_MFMA            /* perf experiments only (tools/build_ablations.sh) */
+            continue;
+#endif
             const double m = frag[(jb * (DP / 4) + kb) * 64 + lane];
 #pragma unroll
             for (int gi = 0; gi < MV_G; ++gi)
@@ -174,10 +177,16 @@ k_propagate_mv(const FArgs* __restrict__ ap, const double* __restrict__ C)
         for (int kb = 0; kb < NV; ++kb) {
             const int k = 4 * kb + g;
             const bool kin = dfull || k < d;
+#ifdef ABL_NO_LOAD
+            const double x = (double)(k + (int)(row & 3)) * 0.03125;
+#else
             const double x = pr[kin ? k : 0];
+#endif
             dst[kb] = (rv && kin) ? x : 0.0;
         }
     };
+    static_assert(MV_G == 1, "the per-particle tail below assumes one group per iteration");
+    double kw = 0.0, kz = 0.0, ku = 0.0;
     i64 rnext[MV_G];
     double nx[MV_G][NV];
 #pragma unroll
@@ -190,7 +199,6 @@ k_propagate_mv(const FArgs* __restrict__ ap, const double* __restrict__ C)
         i64 n[MV_G];
         bool valid[MV_G];
         double v[MV_G][NV];                 // current B operand: xp, then z, x, x - m
-        double lwprev[MV_G];
         smc_v4d am[MV_G][NJ], ax[MV_G][NJ];
         // ---- the parents' rows (requested during the previous iteration)
 #pragma unroll
@@ -201,7 +209,6 @@ k_propagate_mv(const FArgs* __restrict__ ap, const double* __restrict__ C)
             for (int kb = 0; kb < NV; ++kb) v[gi][kb] = nx[gi][kb];
             load_row(Xo, rnext[gi], nx[gi]);
             rnext[gi] = parent(it + 2, gi);
-            lwprev[gi] = (resample || first) ? 0.0 : lwo[valid[gi] ? n[gi] : N - 1];
         }
         // ---- mean of the proposal -> ax ; guided keeps m = F xp in am
 #pragma unroll
@@ -237,8 +244,12 @@ k_propagate_mv(const FArgs* __restrict__ ap, const double* __restrict__ C)
                     const int j = jj + e * (NV / 2);
                     const int kp = 2 * j + h;
                     double z0, z1;
+#ifdef ABL_NO_RNG
+                    z0 = (double)(n[gi] & 7) * 0.25 - 1.0; z1 = (double)kp * 0.125 - 0.5;
+#else
                     smc_normal_pair(a.seed, (u32)(n[gi] * hp + kp), (u32)t, gisl,
                                     SMC_STREAM_NORMAL, z0, z1);
+#endif
                     if (!dfull) {
                         if (2 * kp >= d) z0 = 0.0;
                         if (2 * kp + 1 >= d) z1 = 0.0;
@@ -249,9 +260,9 @@ k_propagate_mv(const FArgs* __restrict__ ap, const double* __restrict__ C)
 #pragma unroll
                 for (int jj = 0; jj < NV / 2; ++jj) oth[jj] = __shfl_xor(oth[jj], 16);
 #pragma unroll
-                for (int jj = 0; jj < NV / 2; ++jj) {
-                    v[gi][jj + e * (NV / 2)] = own[jj];
-                    v[gi][jj + (1 - e) * (NV / 2)] = oth[jj];
+                for (int jj = 0; jj < NV / 2; ++jj) {       // selects, not v[.. + e * ..]
+                    v[gi][jj] = e ? oth[jj] : own[jj];
+                    v[gi][jj + NV / 2] = e ? own[jj] : oth[jj];
                 }
             }
             double q = 0.0;
@@ -297,7 +308,11 @@ k_propagate_mv(const FArgs* __restrict__ ap, const double* __restrict__ C)
                 }
 #pragma unroll
         for (int gi = 0; gi < MV_G; ++gi)
+#ifdef ABL_NO_STORE
+            if (valid[gi] && v[gi][0] == 123.456) {
+#else
             if (valid[gi]) {
+#endif
                 SMC_GLOBAL(double) px = Xn + n[gi] * d + g;
                 if (dfull) {
 #pragma unroll
@@ -316,18 +331,25 @@ k_propagate_mv(const FArgs* __restrict__ ap, const double* __restrict__ C)
             for (int jb = 0; jb < NJ; ++jb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) ww = fma(am[gi][jb][r], am[gi][jb][r], ww);
+            // the sums over the 4 lanes of a particle reach all of them; lane (n, g) keeps
+            // those of the chunk's group q == g, so that after 4 groups lane l owns particle
+            // l of the wave's 64 and the per-particle tail runs once, on full wavefronts
+            const int q = it & 3;
             ww = mv_sum_g(ww);
             const double zs = mv_sum_g(zz[gi]);
-            double inc = -0.5 * ww - scal[1];                                  // kalman.py:345-346
-            if (FK == SMC_FK_GUIDED) {                                         // ssm.py:380-392
-                const double us = mv_sum_g(uu[gi]);
-                inc = ((-0.5 * us - scal[first ? 3 : 0]) + inc) - (-0.5 * zs - scal[first ? 4 : 2]);
-            }
-            if (valid[gi] && g == 0) {
-                double lw = (resample || first) ? inc : lwprev[gi] + inc;      // resampling.py:241-244
-                if (lw != lw) lw = -INFINITY;                                  // resampling.py:220
-                lwn[n[gi]] = lw;
-                smc_lse_push(lacc, lw);
+            const double us = (FK == SMC_FK_GUIDED) ? mv_sum_g(uu[gi]) : 0.0;
+            if (q == g) { kw = ww; kz = zs; ku = us; }
+            if (q == 3) {
+                const i64 np = particle(it - 3, 0) - pn + lane;
+                double inc = -0.5 * kw - scal[1];                              // kalman.py:345-346
+                if (FK == SMC_FK_GUIDED)                                       // ssm.py:380-392
+                    inc = ((-0.5 * ku - scal[first ? 3 : 0]) + inc) - (-0.5 * kz - scal[first ? 4 : 2]);
+                if (np < N) {
+                    double lw = (resample || first) ? inc : lwo[np] + inc;     // resampling.py:241-244
+                    if (lw != lw) lw = -INFINITY;                              // resampling.py:220
+                    lwn[np] = lw;
+                    smc_lse_push(lacc, lw);
+                }
             }
         }
     }

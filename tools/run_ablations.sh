@@ -1,7 +1,7 @@
 #!/bin/bash
 # on the GPU box: time the bench under each ablation library
 R=$GRAFT_REPO_ROOT
-for v in "" NO_RNG NO_BM NO_LSE NO_STORE; do
+for v in "" ${ABLS:-NO_RNG NO_MFMA NO_LOAD NO_STORE}; do
   if [ -z "$v" ]; then lib=$R/particles_amd/lib/libsmc_hip.so; else lib=$R/particles_amd/lib/abl/libsmc_$v.so; fi
   SMC_HIP_LIBRARY=$lib timeout 120 python $R/bench.py --steps 300 --warmup 50 --no-cpu-baseline $EXTRA 2>&1 | python -c "
 import sys, json
