@@ -90,11 +90,11 @@ __device__ __forceinline__ void smc_spin_pause() {}
 #else
 __device__ __forceinline__ void smc_st_agent(u64* p, u64 v)
 {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(SMC_AS_GLOBAL(u64, p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ u64 smc_ld_agent(const u64* p)
 {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __hip_atomic_load(SMC_AS_GLOBAL(const u64, p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void smc_drain_stores()
 {

@@ -165,12 +165,11 @@ template <class T, class T2>
 __device__ __forceinline__ void f_load4(const T* p, i64 j, i64 N, bool vec, T fill, T (&o)[4])
 {
     if (vec && j + 3 < N) {
-        const T2 v0 = *reinterpret_cast<const T2*>(p + j);
-        const T2 v1 = *reinterpret_cast<const T2*>(p + j + 2);
-        o[0] = v0.a; o[1] = v0.b; o[2] = v1.a; o[3] = v1.b;
+        smc_ld2g(p + j, o[0], o[1]);
+        smc_ld2g(p + j + 2, o[2], o[3]);
     } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = (j + i < N) ? p[j + i] : fill;
+        for (int i = 0; i < 4; ++i) o[i] = (j + i < N) ? smc_ldg(p + j + i) : fill;
     }
 }
 template <class T, class T2>
@@ -178,26 +177,22 @@ __device__ __forceinline__ void f_store4(T* p, i64 n, bool full_vec, const bool 
                                          const T (&v)[4])
 {
     if (full_vec) {
-        T2 v0, v1;
-        v0.a = v[0]; v0.b = v[1]; v1.a = v[2]; v1.b = v[3];
-        *reinterpret_cast<T2*>(p + n) = v0;
-        *reinterpret_cast<T2*>(p + n + 2) = v1;
+        smc_st2g(p + n, v[0], v[1]);
+        smc_st2g(p + n + 2, v[2], v[3]);
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (ok[i]) p[n + i] = v[i];
+            if (ok[i]) smc_stg(p + n + i, v[i]);
     }
 }
 template <class T, class T2>
 __device__ __forceinline__ void f_store2(T* p, i64 n, bool vec2, bool ok0, bool ok1, T v0, T v1)
 {
     if (vec2 && ok0 && ok1) {
-        T2 v;
-        v.a = v0; v.b = v1;
-        *reinterpret_cast<T2*>(p + n) = v;
+        smc_st2g(p + n, v0, v1);
     } else {
-        if (ok0) p[n] = v0;
-        if (ok1) p[n + 1] = v1;
+        if (ok0) smc_stg(p + n, v0);
+        if (ok1) smc_stg(p + n + 1, v1);
     }
 }
 
@@ -663,26 +658,24 @@ k_propagate(const FArgs* __restrict__ ap)
             if (full) {
 #pragma unroll
                 for (int k = 0; k < OPT; k += 2) {
-                    const F2i v = *reinterpret_cast<const F2i*>(A + n0 + k);
-                    an[k] = v.a; an[k + 1] = v.b;
+                    smc_ld2g(A + n0 + k, an[k], an[k + 1]);
                 }
             } else {
 #pragma unroll
-                for (int k = 0; k < OPT; ++k) an[k] = (n0 + k < N) ? A[n0 + k] : 0;
+                for (int k = 0; k < OPT; ++k) an[k] = (n0 + k < N) ? smc_ldg(A + n0 + k) : 0;
             }
         } else if (!first) {
             if (full) {
 #pragma unroll
                 for (int k = 0; k < OPT; k += 2) {
-                    const F2d v = *reinterpret_cast<const F2d*>(Xo + n0 + k);
-                    const F2d w = *reinterpret_cast<const F2d*>(lwo + n0 + k);
-                    xp[k] = v.a; xp[k + 1] = v.b; lwp[k] = w.a; lwp[k + 1] = w.b;
+                    smc_ld2g(Xo + n0 + k, xp[k], xp[k + 1]);
+                    smc_ld2g(lwo + n0 + k, lwp[k], lwp[k + 1]);
                 }
             } else {
 #pragma unroll
                 for (int k = 0; k < OPT; ++k) {
-                    xp[k] = (n0 + k < N) ? Xo[n0 + k] : 0.0;
-                    lwp[k] = (n0 + k < N) ? lwo[n0 + k] : 0.0;
+                    xp[k] = (n0 + k < N) ? smc_ldg(Xo + n0 + k) : 0.0;
+                    lwp[k] = (n0 + k < N) ? smc_ldg(lwo + n0 + k) : 0.0;
                 }
             }
         } else {
@@ -692,7 +685,7 @@ k_propagate(const FArgs* __restrict__ ap)
         // ---- standard normals: one Philox call per (even, odd) pair, or the tape
         if (zt) {
 #pragma unroll
-            for (int k = 0; k < OPT; ++k) z[k] = (n0 + k < N) ? zt[n0 + k] : 0.0;
+            for (int k = 0; k < OPT; ++k) z[k] = (n0 + k < N) ? smc_ldg(zt + n0 + k) : 0.0;
         } else {
 #pragma unroll
             for (int k = 0; k < OPT; k += 2)
@@ -701,7 +694,7 @@ k_propagate(const FArgs* __restrict__ ap)
         }
         if (resample) {
 #pragma unroll
-            for (int k = 0; k < OPT; ++k) { xp[k] = Xo[an[k]]; lwp[k] = 0.0; }    // core.py:332
+            for (int k = 0; k < OPT; ++k) { xp[k] = smc_ldg(Xo + an[k]); lwp[k] = 0.0; }    // core.py:332
         }
         F_STAMP(2);
         double xn[OPT], lw[OPT];
@@ -717,15 +710,13 @@ k_propagate(const FArgs* __restrict__ ap)
         if (full) {
 #pragma unroll
             for (int k = 0; k < OPT; k += 2) {
-                F2d v, w;
-                v.a = xn[k]; v.b = xn[k + 1]; w.a = lw[k]; w.b = lw[k + 1];
-                *reinterpret_cast<F2d*>(Xn + n0 + k) = v;
-                *reinterpret_cast<F2d*>(lwn + n0 + k) = w;
+                smc_st2g(Xn + n0 + k, xn[k], xn[k + 1]);
+                smc_st2g(lwn + n0 + k, lw[k], lw[k + 1]);
             }
         } else {
 #pragma unroll
             for (int k = 0; k < OPT; ++k)
-                if (n0 + k < N) { Xn[n0 + k] = xn[k]; lwn[n0 + k] = lw[k]; }
+                if (n0 + k < N) { smc_stg(Xn + n0 + k, xn[k]); smc_stg(lwn + n0 + k, lw[k]); }
         }
     }
     f_step_tail(a, isl, b, t, first, resample, acc, smd, s_last, info);

@@ -45,3 +45,27 @@ typedef double smc_v4d __attribute__((ext_vector_type(4)));
 #define SMC_GLOBAL(T) T __attribute__((address_space(1)))*
 #define SMC_AS_GLOBAL(T, p) ((T __attribute__((address_space(1)))*)(p))
 #endif
+
+// Loads / stores through a generic pointer known to address global memory
+// (see SMC_GLOBAL): one or two consecutive elements (8 / 16 bytes).
+#ifdef SMC_EMULATE
+template <class T> inline T smc_ldg(const T* p) { return *p; }
+template <class T> inline void smc_stg(T* p, T v) { *p = v; }
+template <class T> inline void smc_ld2g(const T* p, T& a, T& b) { a = p[0]; b = p[1]; }
+template <class T> inline void smc_st2g(T* p, T a, T b) { p[0] = a; p[1] = b; }
+#else
+template <class T> __device__ __forceinline__ T smc_ldg(const T* p) { return *SMC_AS_GLOBAL(const T, p); }
+template <class T> __device__ __forceinline__ void smc_stg(T* p, T v) { *SMC_AS_GLOBAL(T, p) = v; }
+template <class T> __device__ __forceinline__ void smc_ld2g(const T* p, T& a, T& b)
+{
+    typedef T v2 __attribute__((ext_vector_type(2)));
+    const v2 v = *SMC_AS_GLOBAL(const v2, p);
+    a = v.x; b = v.y;
+}
+template <class T> __device__ __forceinline__ void smc_st2g(T* p, T a, T b)
+{
+    typedef T v2 __attribute__((ext_vector_type(2)));
+    v2 v; v.x = a; v.y = b;
+    *SMC_AS_GLOBAL(v2, p) = v;
+}
+#endif
