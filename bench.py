@@ -35,7 +35,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_STEP = 56.0                # 16*d + 40 B per particle-step, d = 1
 BYTES_MOVE = 32.0                # k_propagate: read A, gather X; write X, lw
-BYTES_PREPARE = 32.0             # k_prepare (read lw, write q) + k_ancestors (read q, write A)
+BYTES_PREPARE = 16.0             # k_ancestors<true>: read lw, write A  (C2; beyond 2048 workgroups
+                                 # k_prepare adds read lw / write q = 16 B more)
 
 
 def synthetic_data(T, sigma=0.2, seed=42):
@@ -227,11 +228,12 @@ def main():
                 "launch_bytes": bytes_move * N * a.islands,
                 "samples": ns.value,
                 "prepare_ms": pr.value,
-                "prepare_achieved": BYTES_PREPARE * N * a.islands / (pr.value * 1e-3) / 1e9
+                "prepare_achieved": (BYTES_PREPARE if ((N + 1023) // 1024) * a.islands <= 2048
+                                     else 2 * BYTES_PREPARE) * N * a.islands / (pr.value * 1e-3) / 1e9
                 if pr.value > 0 else None,
                 "note": "per particle-step: k_propagate 32 B (read A, gather X; write X, lw), "
-                        "k_prepare 16 B (read lw, write q), k_ancestors 16 B (read q, write A); "
-                        "prepare_ms covers k_prepare + k_ancestors",
+                        "k_ancestors 16 B (read lw, write A; +16 B for k_prepare's q beyond 2048 "
+                        "workgroups per launch); prepare_ms covers the resampling kernels",
             }
             tr = measured_traffic(a, "k_propagate")
             if tr:
