@@ -178,7 +178,10 @@ typedef struct smc_filter_opts {
     int32_t rng_mode;         /* smc_rng_mode */
     int32_t use_graph;        /* 1: replay the step loop from a hipGraph */
     int32_t island_offset;    /* global index of this filter's island 0 (multi-GPU sharding) */
-    int32_t reserved;
+    int32_t keep_history;     /* 1: X, A, lw of EVERY step stay resident -- the step loop writes step t
+                               * into slot t of (T, n_islands, N[, dx]) arrays instead of alternating
+                               * between two (ParticleHistory.save, smoothing.py:181-207, at no extra
+                               * traffic); needs T*n_islands*N*(8 dx + 16) bytes of HBM */
 } smc_filter_opts;
 
 /* y_host: data, (T, dy) row-major, shared by all islands. */
@@ -210,6 +213,12 @@ enum smc_state_field {
 int smc_filter_get(smc_filter* f, int field, int island, void* out_host);
 /* Algorithmic bytes moved per particle-step and kernel launches
  * per step, for roofline accounting. */
+/* keep_history filters: the state of an earlier step, fields as smc_filter_get
+ * (hist.X[step], hist.A[step], hist.wgts[step].lw / .W; smoothing.py:204-207). */
+int smc_filter_history(smc_filter* f, int field, int64_t step, int island, void* out_host);
+/* keep_history filters: genealogy of the current particles (compute_trajectories,
+ * smoothing.py:209-219): out_host (t, N) int64, row t-1 = arange(N), row s-1 = A_s[row s]. */
+int smc_filter_trajectories(smc_filter* f, int island, int64_t* out_host);
 int smc_filter_info(smc_filter* f, double* bytes_per_particle_step,
                     int* kernels_per_step);
 /* Average duration (ms) of the dominant kernel ("move") over the steps run

@@ -596,6 +596,17 @@ def run_filter(model, data, N, scheme="systematic", ESSrmin=0.5, fk="bootstrap",
     return out
 
 
+def compute_trajectories(A_list, N):
+    """Genealogy of the final particles (smoothing.py:209-219
+    ParticleHistory.compute_trajectories): B_{T-1} = arange(N), B_{t-1} = A_t[B_t];
+    ``A_list[t]`` is the ancestor vector of step t (entry 0 unused)."""
+    Bs = [np.arange(N)]
+    for A in A_list[-1:0:-1]:
+        Bs.append(A[Bs[-1]])
+    Bs.reverse()
+    return np.array(Bs)
+
+
 # --------------------------------------------------------------------------
 # Philox4x32-10 + Box-Muller: the counter-based generator the HIP path uses in
 # production mode (there is no reference counterpart: the reference draws from

@@ -39,7 +39,7 @@ class SmcFilterOpts(ctypes.Structure):
     _fields_ = [("N", c_i64), ("T", c_i64), ("n_islands", ctypes.c_int32),
                 ("scheme", ctypes.c_int32), ("ESSrmin", c_dbl), ("seed", c_u64),
                 ("rng_mode", ctypes.c_int32), ("use_graph", ctypes.c_int32),
-                ("island_offset", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("island_offset", ctypes.c_int32), ("keep_history", ctypes.c_int32)]
 
 
 # name -> (restype, argtypes): every symbol include/smc_hip.h declares
@@ -82,6 +82,8 @@ SIGNATURES = {
     "smc_filter_summaries": (c_int, [c_vp, P(c_dbl)]),
     "smc_filter_logLt": (c_int, [c_vp, P(c_dbl)]),
     "smc_filter_get": (c_int, [c_vp, c_int, c_int, c_vp]),
+    "smc_filter_history": (c_int, [c_vp, c_int, c_i64, c_int, c_vp]),
+    "smc_filter_trajectories": (c_int, [c_vp, c_int, P(c_i64)]),
     "smc_filter_info": (c_int, [c_vp, P(c_dbl), P(c_int)]),
     "smc_filter_profile": (c_int, [c_vp, c_int]),
     "smc_filter_kernel_ms": (c_int, [c_vp, P(c_dbl), P(c_dbl), P(c_i64)]),

@@ -7,6 +7,8 @@ from collections import deque
 
 import numpy as np
 
+from . import _lib
+
 
 class Summaries:
     """Stores and updates summaries (collectors.py:215-231)."""
@@ -146,6 +148,71 @@ class ParticleHistory(RollingParticleHistory):
     def __init__(self, fk, qmc):
         self.X, self.A, self.wgts = [], [], []
         self.fk = fk
+
+
+class _LazySteps:
+    """Sequence over the steps run so far whose items are fetched from the device
+    history on access."""
+
+    def __init__(self, smc, fetch):
+        self._smc, self._fetch = smc, fetch
+
+    def __len__(self):
+        return self._smc._n
+
+    def __getitem__(self, t):
+        n = len(self)
+        if isinstance(t, slice):
+            return [self[i] for i in range(*t.indices(n))]
+        if t < 0:
+            t += n
+        if not 0 <= t < n:
+            raise IndexError("history index out of range")
+        return self._fetch(t)
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
+class DeviceParticleHistory:
+    """``ParticleHistory`` (smoothing.py:222-255: ``X``, ``A``, ``wgts`` of every
+    step, ``compute_trajectories``) of a fused run: the history never leaves HBM
+    until an item is read -- the device step loop writes step t into slot t of
+    (T, N[, d]) arrays (``keep_history``), so ``save`` has nothing to do and
+    ``SMC.run`` keeps its single asynchronous launch sequence."""
+
+    def __init__(self, smc):
+        self._smc = smc
+        self.fk = smc.fk
+        self.X = _LazySteps(smc, lambda t: smc._history(_lib.FIELD_X, t))
+        # hist.A[0] is the A of a filter that has not resampled yet: None (core.py:229)
+        self.A = _LazySteps(smc, lambda t: smc._history(_lib.FIELD_A, t) if t else None)
+        self.wgts = _LazySteps(smc, self._wgts_at)
+
+    def _wgts_at(self, t):
+        smc = self._smc
+        f = _Frozen()
+        f.lw = smc._history(_lib.FIELD_LW, t)
+        f.W = smc._history(_lib.FIELD_W, t)
+        s = smc._summ()[0, t]
+        f.ESS, f.log_mean = float(s[0]), float(s[1])
+        f.N = smc.N
+        return f
+
+    @property
+    def N(self):
+        return self._smc.N
+
+    @property
+    def T(self):
+        return self._smc._n
+
+    def save(self, smc):            # the device already did
+        pass
+
+    def compute_trajectories(self):
+        """(T, N) genealogy (smoothing.py:209-219), computed on the device."""
+        return self._smc._trajectories()
 
 
 class _Frozen:

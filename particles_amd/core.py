@@ -126,6 +126,7 @@ class SMC:
             self.summaries = collectors.Summaries(collect)
         self._user_collectors = bool(collect) and collect != "off"
         self.hist = collectors.generate_hist_obj(store_history, self)
+        self._store_history = store_history
         if seed is None:
             seed = int(np.random.randint(0, 2 ** 31 - 1))
         self.seed = seed
@@ -139,7 +140,12 @@ class SMC:
         self._fused = model is not None and resampling in _lib.SCHEMES \
             and (model.get("params") is not None or model["kind"] == _lib.MODEL_MVLINGAUSS)
         if self._fused:
+            # full history on the fused path stays on the device: the step loop
+            # writes step t into slot t (no per-step host copies, no per-step sync)
+            self._device_hist = store_history is True
             self._create_filter(model, replay, use_graph, island_offset)
+            if self._device_hist:
+                self.hist = collectors.DeviceParticleHistory(self)
         else:
             if n_islands != 1:
                 raise ValueError("n_islands > 1 needs a model of the fused family")
@@ -171,6 +177,7 @@ class SMC:
         o.rng_mode = 1 if replay is not None else 0
         o.use_graph = 1 if use_graph else 0
         o.island_offset = island_offset
+        o.keep_history = 1 if self._device_hist else 0
         self._ctx = _lib.ctx()
         h = _lib.c_vp()
         check(lib().smc_filter_create(self._ctx.h, ctypes.byref(m), ctypes.byref(o),
@@ -213,6 +220,22 @@ class SMC:
             check(lib().smc_filter_get(self._f, field, island, out.ctypes.data_as(_lib.c_vp)))
             self._cache[key] = out
         return self._cache[key]
+
+    def _history(self, field, step, island=0):
+        """State of an earlier step of a store_history=True run (device-resident
+        history, smc_filter_history)."""
+        dt = np.int64 if field == _lib.FIELD_A else np.float64
+        d = getattr(self, "_d", 1)
+        shape = (self.N, d) if (d > 1 and field in (_lib.FIELD_X, _lib.FIELD_XP)) else self.N
+        out = np.empty(shape, dtype=dt)
+        check(lib().smc_filter_history(self._f, field, step, island, out.ctypes.data_as(_lib.c_vp)))
+        return out
+
+    def _trajectories(self, island=0):
+        out = np.empty((self._n, self.N), dtype=np.int64)
+        check(lib().smc_filter_trajectories(self._f, island,
+                                            out.ctypes.data_as(_lib.P(_lib.c_i64))))
+        return out
 
     def step_async(self, nsteps=1):
         """Enqueue ``nsteps`` time steps on the device without synchronising."""
@@ -374,7 +397,8 @@ class SMC:
         return self
 
     def _needs_per_step_host(self):
-        return self.verbose or bool(self.hist) or self._user_collectors
+        host_hist = bool(self.hist) and not getattr(self, "_device_hist", False)
+        return self.verbose or host_hist or self._user_collectors
 
     def run(self):
         """Run until completion (core.py:391-409); sets ``cpu_time``."""

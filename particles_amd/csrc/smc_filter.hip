@@ -85,6 +85,8 @@ static void enqueue_step(smc_filter* f, int k_prof)
 
 extern "C" {
 
+static int filter_fetch(smc_filter* f, int field, i64 s, int island, void* out_host);
+
 int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opts* o,
                       const double* y_host, smc_filter** out)
 {
@@ -156,9 +158,13 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o0 = off; off = smc_align_up(off + bytes, 256); return o0; };
     a.dx = dxm; a.dy = dym; a.dp = dpm;
-    const size_t oX0 = carve(M * N * dxm * 8), oX1 = carve(M * N * dxm * 8);
-    const size_t oL0 = carve(M * N * 8), oL1 = carve(M * N * 8);
-    const size_t oA = carve(M * N * 8);
+    a.hist = o->keep_history != 0;
+    const size_t nslots = a.hist ? T : 2;
+    a.xslot = (i64)(M * N * dxm);
+    a.lslot = (i64)(M * N);
+    const size_t oX0 = carve(nslots * M * N * dxm * 8);
+    const size_t oL0 = carve(nslots * M * N * 8);
+    const size_t oA = carve((a.hist ? T : 1) * M * N * 8);
     // q is only materialised when k_prepare runs (more tiles than k_ancestors<true> handles)
     // (published tile totals pay off only while every workgroup of the launch is resident)
     f->fused = (i64)a.ntiles * (i64)M <= F_DIRECT_PREFIX_MAX;
@@ -198,8 +204,8 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     }
     f->slab = slab;
     char* base = (char*)slab;
-    a.X0 = (double*)(base + oX0); a.X1 = (double*)(base + oX1);
-    a.lw0 = (double*)(base + oL0); a.lw1 = (double*)(base + oL1);
+    a.X = (double*)(base + oX0);
+    a.lw = (double*)(base + oL0);
     a.A = (i64*)(base + oA);
     a.q = (u64*)(base + oq);
     a.Q = (u64*)(base + oQ);
@@ -377,19 +383,26 @@ int smc_filter_get(smc_filter* f, int field, int island, void* out_host)
 {
     SMC_REQUIRE(f && out_host, "null argument");
     SMC_REQUIRE(island >= 0 && island < f->a.n_islands, "island out of range");
-    const i64 t = f->t_host, N = f->a.N;
+    const i64 t = f->t_host;
     if (t == 0) {
         smc_set_error("smc_filter_get: no step has run yet");
         return SMC_ERR_STATE;
     }
+    return filter_fetch(f, field, t - 1, island, out_host);
+}
+
+/* state of step s (the filter's current one, or -- keep_history -- any earlier one) */
+static int filter_fetch(smc_filter* f, int field, i64 s, int island, void* out_host)
+{
+    const i64 N = f->a.N;
+    const i64 t = s + 1;
     hipStream_t st = f->ctx->stream;
-    const int cur = (int)((t - 1) & 1);
     const int dx = f->a.dx;
-    const double* X = (cur ? f->a.X1 : f->a.X0) + (size_t)island * N * dx;
-    const double* Xo = (cur ? f->a.X0 : f->a.X1) + (size_t)island * N * dx;
+    const double* X = f_X(f->a, s) + (size_t)island * N * dx;
+    const double* Xo = f_X(f->a, s - 1) + (size_t)island * N * dx;
     size_t nbytes = (size_t)N * 8;
-    const double* lw = (cur ? f->a.lw1 : f->a.lw0) + (size_t)island * N;
-    const i64* A = f->a.A + (size_t)island * N;
+    const double* lw = f_lw(f->a, s) + (size_t)island * N;
+    const i64* A = f_A(f->a, s) + (size_t)island * N;
     const void* src = nullptr;
     const unsigned nb = (unsigned)((N + SMC_BLOCK - 1) / SMC_BLOCK);
     switch (field) {
@@ -434,6 +447,61 @@ int smc_filter_get(smc_filter* f, int field, int island, void* out_host)
     SMC_LAUNCH_CHECK();
     SMC_HIP_CHECK(hipMemcpyAsync(out_host, src, nbytes, hipMemcpyDeviceToHost, st));
     SMC_HIP_CHECK(hipStreamSynchronize(st));
+    return SMC_OK;
+}
+
+int smc_filter_history(smc_filter* f, int field, int64_t step, int island, void* out_host)
+{
+    SMC_REQUIRE(f && out_host, "null argument");
+    SMC_REQUIRE(island >= 0 && island < f->a.n_islands, "island out of range");
+    if (!f->a.hist) {
+        smc_set_error("smc_filter_history: the filter was created without keep_history");
+        return SMC_ERR_STATE;
+    }
+    if (step < 0 || step >= f->t_host) {
+        smc_set_error("smc_filter_history: step %lld has not run (t = %lld)", (long long)step,
+                      (long long)f->t_host);
+        return SMC_ERR_STATE;
+    }
+    return filter_fetch(f, field, step, island, out_host);
+}
+
+int smc_filter_trajectories(smc_filter* f, int island, int64_t* out_host)
+{
+    SMC_REQUIRE(f && out_host, "null argument");
+    SMC_REQUIRE(island >= 0 && island < f->a.n_islands, "island out of range");
+    if (!f->a.hist) {
+        smc_set_error("smc_filter_trajectories: the filter was created without keep_history");
+        return SMC_ERR_STATE;
+    }
+    const i64 t = f->t_host, N = f->a.N, T = f->a.T;
+    if (t == 0) {
+        smc_set_error("smc_filter_trajectories: no step has run yet");
+        return SMC_ERR_STATE;
+    }
+    hipStream_t st = f->ctx->stream;
+    // which steps resampled (A_s = arange otherwise, core.py:336)
+    std::vector<double> rows((size_t)t * SUMM_STRIDE);
+    SMC_HIP_CHECK(hipMemcpyAsync(rows.data(), f->a.summ + (size_t)island * (T + 1) * SUMM_STRIDE,
+                                 rows.size() * 8, hipMemcpyDeviceToHost, st));
+    SMC_HIP_CHECK(hipStreamSynchronize(st));
+    i64* B = nullptr;
+    hipError_t e = hipMalloc((void**)&B, (size_t)t * N * 8);
+    if (e != hipSuccess) {
+        smc_set_error("smc_filter_trajectories: %zu bytes: %s", (size_t)t * N * 8, hipGetErrorString(e));
+        return SMC_ERR_NOMEM;
+    }
+    const dim3 grid((unsigned)((N + SMC_BLOCK - 1) / SMC_BLOCK));
+    SMC_LAUNCH(k_f_iota, grid, dim3(SMC_BLOCK), st, N, B + (size_t)(t - 1) * N);
+    for (i64 s = t - 1; s >= 1; --s) {                  // smoothing.py:213-216
+        const i64* A = rows[(size_t)s * SUMM_STRIDE + 4] != 0.0 ? f_A(f->a, s) + (size_t)island * N : nullptr;
+        SMC_LAUNCH(k_f_genealogy, grid, dim3(SMC_BLOCK), st, A, (const i64*)(B + (size_t)s * N), N,
+                   B + (size_t)(s - 1) * N);
+    }
+    hipError_t e2 = hipMemcpyAsync(out_host, B, (size_t)t * N * 8, hipMemcpyDeviceToHost, st);
+    if (e2 == hipSuccess) e2 = hipStreamSynchronize(st);
+    (void)hipFree(B);
+    SMC_HIP_CHECK(e2);
     return SMC_OK;
 }
 

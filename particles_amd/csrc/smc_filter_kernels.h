@@ -53,8 +53,12 @@ struct FArgs {
     int log2N;             // k if N == 2^k, else -1
     double ess_thresh;
     u64 seed;
-    double *X0, *X1, *lw0, *lw1;
-    i64* A;
+    // states / log-weights / ancestors of step t live in slot f_slot(t): two alternating
+    // slots, or -- keep_history -- one slot per time step (the history IS the buffer)
+    double *X, *lw;        // (nslots, n_islands, N[, dx])
+    i64* A;                // (1 or T, n_islands, N)
+    i64 xslot, lslot;      // elements per slot: n_islands*N*dx, n_islands*N
+    int hist;
     u64* q;                // (n_islands, N) Q62 weights of the parents
     u64* Q;                // (n_islands, ntiles) tile totals of q
     u64* Qpre;             // (n_islands, ntiles) exclusive prefixes of Q
@@ -77,6 +81,14 @@ struct FArgs {
     const double* mvc;     // MVLINGAUSS: derived constants (see smc_filter_mv.h)
     u64* trace;            // SMC_TRACE builds: (n_islands, ntiles, 8) shader-clock stamps of k_move
 };
+
+__host__ __device__ __forceinline__ i64 f_slot(const FArgs& a, i64 t)
+{
+    return a.hist ? (t > 0 ? t : 0) : (t & 1);
+}
+__host__ __device__ __forceinline__ double* f_X(const FArgs& a, i64 t) { return a.X + f_slot(a, t) * a.xslot; }
+__host__ __device__ __forceinline__ double* f_lw(const FArgs& a, i64 t) { return a.lw + f_slot(a, t) * a.lslot; }
+__host__ __device__ __forceinline__ i64* f_A(const FArgs& a, i64 t) { return a.A + (a.hist ? t : 0) * a.lslot; }
 
 #ifdef SMC_TRACE
 #define F_STAMP(k) do { if (threadIdx.x == 0) a.trace[((i64)blockIdx.y * a.nparts + blockIdx.x) * 8 + (k)] = (u64)wall_clock64(); } while (0)
@@ -247,7 +259,7 @@ k_prepare(const FArgs* __restrict__ ap)
     if (t >= a.T || smc_uniform(info[1]) == 0.0) return;          // step t does not resample
     const double m = smc_uniform(info[3]), rs = smc_uniform(info[4]);
     // Q62 weights of step t-1's particles (the parents of step t) + tile total
-    const double* lw = (((t - 1) & 1) ? a.lw1 : a.lw0) + (i64)isl * a.N;
+    const double* lw = f_lw(a, t - 1) + (i64)isl * a.N;
     u64* q = a.q + (i64)isl * a.N;
     const bool vec = (a.N & 3) == 0;
     const i64 j0 = (i64)b * F_TILE + (i64)threadIdx.x * F_IPT;
@@ -380,7 +392,7 @@ k_ancestors(const FArgs* __restrict__ ap)
     if (t >= a.T || t == 0 || smc_uniform(info[1]) == 0.0) return;          // step t does not resample
     const i64 N = a.N;
     const u32 gisl = (u32)(a.island_offset + isl);
-    i64* A = a.A + (i64)isl * N;
+    i64* A = f_A(a, t) + (i64)isl * N;
     const bool vec = (N & 3) == 0;
     const i64 j0 = (i64)b * F_TILE;
 
@@ -397,7 +409,7 @@ k_ancestors(const FArgs* __restrict__ ap)
         // workgroups are dispatched first, so the wait is short and cannot cycle.
         // k_propagate(t) zeroes Q again.
         const double m = smc_uniform(info[3]), rs = smc_uniform(info[4]);
-        const double* lw = (((t - 1) & 1) ? a.lw1 : a.lw0) + (i64)isl * N;
+        const double* lw = f_lw(a, t - 1) + (i64)isl * N;
         double l4[4];
         f_load4<double, F2d>(lw, jt, N, vec, -INFINITY, l4);
 #pragma unroll
@@ -635,12 +647,11 @@ k_propagate(const FArgs* __restrict__ ap)
     const double* p = a.params + (i64)isl * PARAM_STRIDE;
     const double yt = smc_uniform(info[2]);
     const u32 gisl = (u32)(a.island_offset + isl);
-    const int cur = (int)(t & 1);
-    double* Xn = (cur ? a.X1 : a.X0) + (i64)isl * N;
-    const double* Xo = (cur ? a.X0 : a.X1) + (i64)isl * N;
-    double* lwn = (cur ? a.lw1 : a.lw0) + (i64)isl * N;
-    const double* lwo = (cur ? a.lw0 : a.lw1) + (i64)isl * N;
-    const i64* A = a.A + (i64)isl * N;
+    double* Xn = f_X(a, t) + (i64)isl * N;
+    const double* Xo = f_X(a, t - 1) + (i64)isl * N;
+    double* lwn = f_lw(a, t) + (i64)isl * N;
+    const double* lwo = f_lw(a, t - 1) + (i64)isl * N;
+    const i64* A = f_A(a, t) + (i64)isl * N;
     const double* zt = a.zt ? a.zt + ((i64)t * a.n_islands + isl) * N : nullptr;
     const bool first = (t == 0);
     const bool resample = !first && smc_uniform(info[1]) != 0.0;
@@ -736,4 +747,19 @@ k_f_gather1(const double* X, const i64* A, i64 N, double* Xp)
 {
     const i64 i = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;
     if (i < N) Xp[i] = X[A[i]];
+}
+
+// one backward step of the genealogy (smoothing.py:209-219): B_{s-1} = A_s[B_s]
+// (A == nullptr: step s did not resample, A_s = arange)
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_f_genealogy(const i64* A, const i64* Bs, i64 N, i64* Bprev)
+{
+    const i64 i = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;
+    if (i < N) Bprev[i] = A ? A[Bs[i]] : Bs[i];
+}
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_f_iota(i64 N, i64* B)
+{
+    const i64 i = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;
+    if (i < N) B[i] = i;
 }

@@ -111,12 +111,11 @@ k_propagate_mv(const FArgs* __restrict__ ap, const double* __restrict__ C)
     const i64 N = a.N;
     const int d = a.dx;
     const u32 gisl = (u32)(a.island_offset + isl);
-    const int cur = (int)(t & 1);
-    SMC_GLOBAL(double) Xn = SMC_AS_GLOBAL(double, (cur ? a.X1 : a.X0) + (i64)isl * N * d);
-    SMC_GLOBAL(const double) Xo = SMC_AS_GLOBAL(const double, (cur ? a.X0 : a.X1) + (i64)isl * N * d);
-    SMC_GLOBAL(double) lwn = SMC_AS_GLOBAL(double, (cur ? a.lw1 : a.lw0) + (i64)isl * N);
-    SMC_GLOBAL(const double) lwo = SMC_AS_GLOBAL(const double, (cur ? a.lw0 : a.lw1) + (i64)isl * N);
-    SMC_GLOBAL(const i64) A = SMC_AS_GLOBAL(const i64, a.A + (i64)isl * N);
+    SMC_GLOBAL(double) Xn = SMC_AS_GLOBAL(double, f_X(a, t) + (i64)isl * N * d);
+    SMC_GLOBAL(const double) Xo = SMC_AS_GLOBAL(const double, f_X(a, t - 1) + (i64)isl * N * d);
+    SMC_GLOBAL(double) lwn = SMC_AS_GLOBAL(double, f_lw(a, t) + (i64)isl * N);
+    SMC_GLOBAL(const double) lwo = SMC_AS_GLOBAL(const double, f_lw(a, t - 1) + (i64)isl * N);
+    SMC_GLOBAL(const i64) A = SMC_AS_GLOBAL(const i64, f_A(a, t) + (i64)isl * N);
     SMC_GLOBAL(const double) zt =
         SMC_AS_GLOBAL(const double, a.zt ? a.zt + ((i64)t * a.n_islands + isl) * N * d : nullptr);
     const bool first = (t == 0);

@@ -72,6 +72,23 @@ def main():
         out["mv%d_guided" % dx] = run_case(mv, ssm.GuidedPF, 12, 256, "systematic", 0.5)
         out["mv%d_boot" % dx] = run_case(mv, ssm.Bootstrap, 12, 256, "stratified", 0.5)
 
+    # --- full particle history + genealogy (smoothing.py:181-255), adaptive
+    # resampling so that some A_t are arange ---------------------------------
+    np.random.seed(42)
+    model = kalman.LinearGauss(rho=0.9, sigmaX=1.0, sigmaY=1.5)
+    x, y = model.simulate(30)
+    np.random.seed(123)
+    pf = particles.SMC(fk=ssm.Bootstrap(ssm=model, data=y), N=300, resampling="systematic",
+                       ESSrmin=0.5, store_history=True)
+    pf.run()
+    out["history"] = dict(
+        y=np.array(y), T=30, N=300, scheme="systematic", ESSrmin=0.5, data_seed=42, run_seed=123,
+        logLt=pf.logLt, rs_flags=np.array(pf.summaries.rs_flags),
+        hist_X=np.array(pf.hist.X), hist_A=np.array(pf.hist.A[1:]),
+        hist_lw=np.array([w.lw for w in pf.hist.wgts]), hist_W=np.array([w.W for w in pf.hist.wgts]),
+        A0_is_none=pf.hist.A[0] is None,
+        trajectories=np.array(pf.hist.compute_trajectories()))
+
     # --- Kalman exact log-likelihoods (analytic KAT) ------------------------
     for name, model in (("toy", kalman.LinearGauss(rho=1.0, sigmaX=1.0, sigmaY=0.2, sigma0=1.0)),
                         ("mv32", kalman.MVLinearGauss_Guarniero_etal(alpha=0.4, dx=32))):
@@ -135,7 +152,10 @@ def main():
     dd["mv_rvs"] = mv.rvs(size=40)
     out["dists"] = dd
 
+    only = sys.argv[1:]              # optional: names of the fixtures to (re)write
     for name, case in out.items():
+        if only and name not in only:
+            continue
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **case)
         print(name, {k: (v.shape if hasattr(v, "shape") and v.shape else v)
                      for k, v in case.items() if k in ("logLt", "loglik", "X")})

@@ -329,6 +329,73 @@ def check_filter_replay(golden, case, model, fk, T=None):
     return pf, o
 
 
+def check_device_history(golden):
+    """store_history=True on the fused path: the history stays in HBM
+    (keep_history) and hist.X / hist.A / hist.wgts / compute_trajectories are
+    served from it -- against the reference's own history (tests/golden/history.npz,
+    smoothing.py:181-219), replaying its draws."""
+    g = golden("history")
+    mk_dev, mk_orc = MODELS["lg_adaptive"]
+    N, T = int(g["N"]), int(g["T"])
+    y = list(g["y"])
+    np.random.seed(int(g["run_seed"]))
+    rec = orc.RecordingRNG()
+    o = orc.run_filter(mk_orc(), y, N, "systematic", 0.5, rng=rec)
+    assert o["final_logLt"] == float(g["logLt"])
+    z, u = tapes_from_oracle(rec.tape, T, N, "systematic")
+    pf = pa.SMC(fk=ssm.Bootstrap(ssm=mk_dev(), data=y), N=N, resampling="systematic",
+                ESSrmin=0.5, replay=(z, u), store_history=True)
+    assert not pf._needs_per_step_host()             # one asynchronous launch sequence
+    pf.run()
+    h = pf.hist
+    assert h.T == T and h.N == N and len(h.X) == T and h.A[0] is None
+    assert pf.summaries.rs_flags == [bool(v) for v in g["rs_flags"]]
+    for t in range(T):
+        assert np.array_equal(h.X[t], g["hist_X"][t])                 # IEEE + - * / only
+        assert np.array_equal(h.wgts[t].lw, g["hist_lw"][t])
+        assert rel(h.wgts[t].W, g["hist_W"][t]) < 1e-10
+        if t:
+            assert np.array_equal(h.A[t], g["hist_A"][t - 1])
+    assert np.array_equal(h.X[-1], pf.X) and np.array_equal(h.A[-1], pf.A)
+    assert np.array_equal(h.compute_trajectories(), g["trajectories"])
+    import pytest
+    with pytest.raises(IndexError):
+        h.X[T]
+    # a filter created without history refuses
+    pf2 = pa.SMC(fk=ssm.Bootstrap(ssm=mk_dev(), data=y), N=N, seed=3)
+    pf2.run()
+    with pytest.raises(Exception):
+        pf2._history(_lib_field_x(), 0)
+
+
+def _lib_field_x():
+    from particles_amd import _lib
+    return _lib.FIELD_X
+
+
+def check_device_history_philox(N, T, golden):
+    """Production mode: history on/off give the same run; the genealogy obeys
+    B_{t-1} = A_t[B_t] (smoothing.py:213-216), islands > 1 included."""
+    g = golden("kalman_toy")
+    y = [np.atleast_1d(v) for v in np.squeeze(g["y"])][:T]
+    mk = lambda **kw: pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y), N=N, seed=77, **kw)
+    a, b = mk(), mk(store_history=True, n_islands=1)
+    a.run(); b.run()
+    assert a.logLt == b.logLt and np.array_equal(a.X, b.X) and np.array_equal(a.A, b.A)
+    B = b.hist.compute_trajectories()
+    assert B.shape == (T, N) and np.array_equal(B[-1], np.arange(N))
+    for t in (T - 1, T // 2, 1):
+        assert np.array_equal(B[t - 1], b.hist.A[t][B[t]])
+    assert np.all(np.diff(B[0]) >= 0)                  # ancestors stay sorted (systematic)
+    assert np.array_equal(b.hist.X[3], mk_step_X(mk, 4))
+
+
+def mk_step_X(mk, nsteps):
+    p = mk()
+    p.step_async(nsteps)
+    return p.X
+
+
 def check_filter_stepwise(golden):
     """next(pf) one step at a time == run(), and the iterator protocol."""
     g = golden("toy_systematic")

@@ -93,6 +93,11 @@ def test_filter_stepwise(golden):
     pc.check_filter_stepwise(golden)
 
 
+def test_device_history(golden):
+    pc.check_device_history(golden)
+    pc.check_device_history_philox(1500, 9, golden)
+
+
 @pytest.mark.parametrize("N,sigmaY", [(3000, 0.2), (4096, 0.2), (1024, 0.2), (8192, 0.002),
                                       (2048, 1e-4)])
 def test_filter_philox_vs_c(golden, N, sigmaY):

@@ -99,6 +99,11 @@ def test_filter_stepwise(golden):
     pc.check_filter_stepwise(golden)
 
 
+def test_device_history(golden):
+    pc.check_device_history(golden)
+    pc.check_device_history_philox(100000, 9, golden)
+
+
 @pytest.mark.parametrize("N,sigmaY", [(1 << 16, 0.2), (3000, 0.2), (1024, 0.2), (1 << 18, 0.002),
                                       (1 << 14, 1e-4), (100000, 0.2)])
 def test_filter_philox_vs_c(golden, N, sigmaY):

@@ -40,6 +40,25 @@ def test_filter_bit_exact_vs_reference(golden, case, model, fk):
     assert np.array_equal(out["W"], g["W"])
 
 
+def test_history_and_genealogy_vs_reference(golden):
+    """Every step's X, A, lw, W and compute_trajectories (smoothing.py:181-219)."""
+    g = golden("history")
+    np.random.seed(int(g["run_seed"]))
+    N = int(g["N"])
+    out = orc.run_filter(MODELS["lg_adaptive"](), list(g["y"]), N, scheme=str(g["scheme"]),
+                         ESSrmin=float(g["ESSrmin"]), keep=True)
+    h = out["hist"]
+    assert out["final_logLt"] == float(g["logLt"]) and bool(g["A0_is_none"]) and h["A"][0] is None
+    assert np.array_equal(np.array(h["X"]), g["hist_X"])
+    assert np.array_equal(np.array(h["lw"]), g["hist_lw"])
+    assert np.array_equal(np.array(h["W"]), g["hist_W"])
+    # steps that did not resample: the reference stores arange (core.py:336)
+    A = [None] + [a if a is not None else np.arange(N) for a in h["A"][1:]]
+    assert np.array_equal(np.array(A[1:]), g["hist_A"])
+    assert 0 < int(g["rs_flags"].sum()) < len(A) - 1          # both branches are exercised
+    assert np.array_equal(orc.compute_trajectories(A, N), g["trajectories"])
+
+
 def test_replay_tape_reproduces_run(golden):
     g = golden("toy_stratified")
     np.random.seed(int(g["run_seed"]))
