@@ -227,14 +227,27 @@ def main():
                 "kernel": "k_propagate", "kernel_ms": mv.value,
                 "launch_bytes": bytes_move * N * a.islands,
                 "samples": ns.value,
-                "prepare_ms": pr.value,
+                "prepare_ms": max(out["ms_per_step"] - mv.value, 0.0),
                 "prepare_achieved": (BYTES_PREPARE if ((N + 1023) // 1024) * a.islands <= 2048
-                                     else 2 * BYTES_PREPARE) * N * a.islands / (pr.value * 1e-3) / 1e9
-                if pr.value > 0 else None,
+                                     else 2 * BYTES_PREPARE) * N * a.islands
+                / ((out["ms_per_step"] - mv.value) * 1e-3) / 1e9
+                if out["ms_per_step"] > mv.value else None,
                 "note": "per particle-step: k_propagate 32 B (read A, gather X; write X, lw), "
                         "k_ancestors 16 B (read lw, write A; +16 B for k_prepare's q beyond 2048 "
-                        "workgroups per launch); prepare_ms covers the resampling kernels",
+                        "workgroups per launch). kernel_ms = (HIP-event interval around whole steps) - "
+                        "(interval around the resampling kernels only), alternating steps, so the "
+                        "fixed ~4 us of an event interval cancels; prepare_ms = ms_per_step - kernel_ms",
             }
+            if a.workload == "c4":
+                # GEMM-shaped kernel: priced against the dense fp64 matrix peak (MI355X spec
+                # 78.6 TFLOP/s, = its fp64 vector peak).  72 MFMAs
+                # (v_mfma_f64_16x16x4: 2048 flop) per 16 particles for the guided d=32 step.
+                flop = 72 * 2048.0 / 16.0 * N * a.islands
+                tf = flop / (mv.value * 1e-3) / 1e12
+                out["roofline"].update({
+                    "bound": "mfma", "achieved": tf, "peak": 78.6, "unit": "TFLOP/s",
+                    "frac": tf / 78.6, "kernel": "k_propagate_mv", "launch_flop": flop,
+                    "hbm_achieved_GBs": ach})
             tr = measured_traffic(a, "k_propagate")
             if tr:
                 out["roofline"]["traffic"], out["roofline"]["traffic_source"] = tr

@@ -221,9 +221,13 @@ int smc_filter_history(smc_filter* f, int field, int64_t step, int island, void*
 int smc_filter_trajectories(smc_filter* f, int island, int64_t* out_host);
 int smc_filter_info(smc_filter* f, double* bytes_per_particle_step,
                     int* kernels_per_step);
-/* Average duration (ms) of the dominant kernel ("move") over the steps run
- * since the last call, measured with HIP events on the filter's stream when
- * profiling is enabled with smc_filter_profile(f, 1). */
+/* Average duration (ms) of the dominant kernel (the propagate kernel, "move")
+ * over the steps run since the last call, measured with HIP events on the
+ * filter's stream when profiling is enabled with smc_filter_profile(f, 1):
+ * even steps are bracketed as a whole, odd steps only up to the launch of the
+ * propagate kernel; move_ms_avg is the difference of the two averages (the
+ * fixed cost of an event interval cancels), prepare_ms_avg the raw interval of
+ * the resampling kernels (it still contains that fixed cost, ~4 us). */
 int smc_filter_profile(smc_filter* f, int enable);
 int smc_filter_kernel_ms(smc_filter* f, double* move_ms_avg,
                          double* prepare_ms_avg, int64_t* n_samples);
