@@ -188,7 +188,7 @@ def main():
     if rank == 0:
         units = float(N) * a.islands * K * world
         out = {
-            "metric": "particle-steps/sec (N x T), bootstrap filter N=2^%d" % a.log2N,
+            "metric": "particle-steps/sec (N x T), %s filter N=2^%d" % ("guided" if a.workload == "c4" else "bootstrap", a.log2N),
             "value": units / dt, "unit": "particle-steps/s", "n_gpus": world, "steps": K,
             "warmup": W, "ms_per_step": 1e3 * dt / K, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",

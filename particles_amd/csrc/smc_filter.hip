@@ -12,8 +12,8 @@
 
 struct smc_filter {
     smc_ctx* ctx;
-    FArgs a;               // host copy of the argument block
-    const FArgs* da;       // its device copy (kernels take the pointer: 8 B of kernarg)
+    FArgs a;               // the argument block: passed BY VALUE (kernarg segment: one scalar-load hop,
+                           // and the compiler knows its pointers address global memory)
     int kind, fk;
     i64 t_host;
     void* slab;            // one allocation holding every device array
@@ -39,10 +39,10 @@ static void launch_propagate(smc_filter* f)
 #define MV_CASE(FKV, DPV)                                                                   \
     if (f->fk == FKV && f->a.dp == DPV) {                                                   \
         if (f->a.dx == DPV)                                                                 \
-            SMC_LAUNCH((k_propagate_mv<FKV, DPV, true>), grid, dim3(SMC_BLOCK), st, f->da,  \
+            SMC_LAUNCH((k_propagate_mv<FKV, DPV, true>), grid, dim3(SMC_BLOCK), st, f->a,  \
                        f->a.mvc);                                                           \
         else                                                                                \
-            SMC_LAUNCH((k_propagate_mv<FKV, DPV, false>), grid, dim3(SMC_BLOCK), st, f->da, \
+            SMC_LAUNCH((k_propagate_mv<FKV, DPV, false>), grid, dim3(SMC_BLOCK), st, f->a, \
                        f->a.mvc);                                                           \
         return;                                                                             \
     }
@@ -53,13 +53,13 @@ static void launch_propagate(smc_filter* f)
     }
     if (f->kind == SMC_MODEL_LINGAUSS && f->fk == SMC_FK_BOOTSTRAP)
         SMC_LAUNCH((k_propagate<SMC_MODEL_LINGAUSS, SMC_FK_BOOTSTRAP, F_OPT>), grid,
-                   dim3(SMC_BLOCK), st, f->da);
+                   dim3(SMC_BLOCK), st, f->a);
     else if (f->kind == SMC_MODEL_LINGAUSS)
         SMC_LAUNCH((k_propagate<SMC_MODEL_LINGAUSS, SMC_FK_GUIDED, F_OPT>), grid, dim3(SMC_BLOCK),
-                   st, f->da);
+                   st, f->a);
     else
         SMC_LAUNCH((k_propagate<SMC_MODEL_STOCHVOL, SMC_FK_BOOTSTRAP, F_OPT>), grid,
-                   dim3(SMC_BLOCK), st, f->da);
+                   dim3(SMC_BLOCK), st, f->a);
 }
 
 // one time step: [k_prepare, (spacings), k_ancestors] do nothing unless the step
@@ -70,14 +70,14 @@ static void enqueue_step(smc_filter* f, int k_prof)
     const dim3 grid(f->a.ntiles, f->a.n_islands);
     if (k_prof >= 0) (void)hipEventRecord(f->ev[3 * k_prof], st);
     const bool fused = f->fused;
-    if (!fused) SMC_LAUNCH(k_prepare, grid, dim3(SMC_BLOCK), st, f->da);
+    if (!fused) SMC_LAUNCH(k_prepare, grid, dim3(SMC_BLOCK), st, f->a);
     if (f->a.scheme == SMC_MULTINOMIAL && !f->a.ut) {
         const dim3 g1(f->a.ntiles1, f->a.n_islands);
-        SMC_LAUNCH(k_f_spacing_sums, g1, dim3(SMC_BLOCK), st, f->da);
-        SMC_LAUNCH(k_f_spacing_write, g1, dim3(SMC_BLOCK), st, f->da);
+        SMC_LAUNCH(k_f_spacing_sums, g1, dim3(SMC_BLOCK), st, f->a);
+        SMC_LAUNCH(k_f_spacing_write, g1, dim3(SMC_BLOCK), st, f->a);
     }
-    if (fused) SMC_LAUNCH(k_ancestors<true>, grid, dim3(SMC_BLOCK), st, f->da);
-    else SMC_LAUNCH(k_ancestors<false>, grid, dim3(SMC_BLOCK), st, f->da);
+    if (fused) SMC_LAUNCH(k_ancestors<true>, grid, dim3(SMC_BLOCK), st, f->a);
+    else SMC_LAUNCH(k_ancestors<false>, grid, dim3(SMC_BLOCK), st, f->a);
     // odd samples split the step: [resampling kernels | propagate]; even ones time the whole
     // step.  Every event interval carries the same ~4 us of marker processing on MI355X
     // (tools/micro/events.hip), which cancels in (whole step) - (resampling part).
@@ -196,7 +196,6 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     const size_t oSu = carve(need_su ? M * N * 8 : 8);
     const size_t oE = carve(need_su ? M * a.ntiles1 * 8 : 8);
     const size_t oTmp = carve(N * dxm * 8);
-    const size_t oArgs = carve(sizeof(FArgs));
     const size_t oTrace = carve(M * (size_t)(2 * a.ntiles + 8) * 8 * 8);
     void* slab = nullptr;
     hipError_t e = hipMalloc(&slab, off);
@@ -246,8 +245,6 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
                                      hipMemcpyHostToDevice, st));
     SMC_HIP_CHECK(hipMemcpyAsync(dy, y_host, T * dym * 8, hipMemcpyHostToDevice, st));
     SMC_HIP_CHECK(hipStreamSynchronize(st));
-    f->da = (const FArgs*)(base + oArgs);
-    SMC_HIP_CHECK(hipMemcpyAsync((void*)f->da, &f->a, sizeof(FArgs), hipMemcpyHostToDevice, st));
     SMC_HIP_CHECK(hipStreamSynchronize(st));
     *out = f;
     return SMC_OK;
@@ -285,10 +282,7 @@ int smc_filter_set_replay(smc_filter* f, const double* z, const double* u)
     f->a.ut = u;
     f->a.ut_stride = (f->a.scheme == SMC_SYSTEMATIC) ? 1 : f->a.N;
     f->a.rng_mode = SMC_RNG_REPLAY;
-    SMC_HIP_CHECK(hipMemcpyAsync((void*)f->da, &f->a, sizeof(FArgs), hipMemcpyHostToDevice,
-                                 f->ctx->stream));
-    SMC_HIP_CHECK(hipStreamSynchronize(f->ctx->stream));
-    return SMC_OK;
+    return SMC_OK;      // (the argument block travels by value with every launch)
 }
 
 int smc_filter_step(smc_filter* f, int64_t nsteps)

@@ -7,34 +7,37 @@
 //     compute_summaries                         (core.py:351-359)
 // for `n_islands` independent filters advancing in lock step.
 //
-// Two kernels per time step, no host round trip, no in-kernel spinning:
+// Kernels of a time step (no host round trip; the argument block FArgs travels
+// by value in the kernarg segment):
 //
-//   k_prepare(t): only when step t resamples.  Converts its tile of
-//       log-weights to Q62 fixed point, q_i = rint(exp(lw_i-m)/s * 2^62), stores
-//       them and the tile total; the LAST workgroup to finish (atomic ticket)
-//       turns the tile totals into exclusive prefixes (exact integer scan).
-//   k_move(t): one workgroup per tile of 1024 consecutive parents.  From the q
-//       of its tile and its exclusive prefix it knows the exact CDF of its
-//       parents, hence the contiguous range of offspring it owns
-//       (smc_resample.h).  Offspring are produced 4 per thread per pass:
+//   k_ancestors<FUSED>(t): integer-only resampling, only when step t resamples.
+//       One workgroup per tile of 1024 consecutive parents: Q62 weights
+//       q_i = rint(exp(lw_i-m)/s * 2^62), the tile's exact CDF (tile totals are
+//       exchanged between workgroups, see the kernel), the contiguous range of
+//       offspring the tile owns (smc_resample.h) and the parent of each, 4 per
+//       thread per pass:
 //         systematic, N a power of two: closed-form first-offspring index per
 //           parent, scattered into LDS and expanded by a max-scan (no search);
-//         otherwise: per-offspring binary search in the tile's CDF in LDS;
-//       then, pair by pair so that stores overlap the next pair's arithmetic:
-//       gather of the parent state from LDS, propagation x = loc(xp)+scale*z
-//       with a counted Philox normal (or a replayed draw), the weight increment
-//       log G, 16-byte stores of (A, X, lw) and the online log-sum-exp partial.
-//       The LAST workgroup of each island to finish reduces the partials to
+//         otherwise: per-offspring binary search in the tile's CDF in LDS.
+//   [k_prepare(t): beyond 2048 workgroups per launch q and the scanned tile
+//       totals are produced by a launch of their own, k_ancestors<false> reads them]
+//   k_propagate<KIND,FK,OPT>(t): element-wise over the new particles: gather of
+//       the parent state X_{t-1}[A], x = loc(xp)+scale*z with a counted Philox
+//       normal (or a replayed draw), the weight increment log G, 32-byte stores
+//       of (X, lw) and the online log-sum-exp partial.  The LAST workgroup of
+//       each island to finish (two-level tickets) reduces the partials to
 //       (max, sum, sum of squares) -> ESS, log-mean weight, loglt/logLt of step
 //       t (core.py:355-359), the resample decision of step t+1 (core.py:181-183)
 //       and writes the 64-byte step record the next launches read.
+//   (k_propagate_mv in smc_filter_mv.h is the multivariate counterpart.)
 //
-// The time index lives in that device-resident record, so the same two launches
+// The time index lives in that device-resident record, so the same launches
 // -- or one hipGraph holding many of them -- serve every step.
 //
 // HBM traffic per particle-step on a resampling step (d = 1):
-//   k_prepare: read lw (8), write q (8);  k_move: read q, X (16), write A, X, lw (24)
-// = 56 B, the algorithmic figure of SURVEY 8d (W itself is never materialised).
+//   k_ancestors: read lw (8), write A (8);  k_propagate: read A, X (16), write X, lw (16)
+// = 48 B (+16 B for q when k_prepare runs) against SURVEY 8d's 56 B: W is never
+// materialised.
 #pragma once
 #include "smc_internal.h"
 #include "smc_resample.h"
@@ -248,9 +251,9 @@ __device__ __forceinline__ bool f_last_block(unsigned* cnt, int b, int nblocks, 
 // k_prepare
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(SMC_BLOCK)
-k_prepare(const FArgs* __restrict__ ap)
+k_prepare(const FArgs av)
 {
-    const FArgs& a = *ap;
+    const FArgs& a = av;
     __shared__ u64 smu[SMC_SM];
     __shared__ int s_last;
     const int b = (int)blockIdx.x, isl = (int)blockIdx.y;
@@ -316,9 +319,9 @@ __device__ __forceinline__ u64 f_spacing_q(const FArgs& a, u32 t, u32 gisl, i64 
 }
 
 __global__ void __launch_bounds__(SMC_BLOCK)
-k_f_spacing_sums(const FArgs* __restrict__ ap)
+k_f_spacing_sums(const FArgs av)
 {
-    const FArgs& a = *ap;
+    const FArgs& a = av;
     __shared__ u64 smu[SMC_SM];
     const int b = (int)blockIdx.x, isl = (int)blockIdx.y;
     const double* info = a.info + (i64)isl * INFO_STRIDE;
@@ -334,9 +337,9 @@ k_f_spacing_sums(const FArgs* __restrict__ ap)
 }
 
 __global__ void __launch_bounds__(SMC_BLOCK)
-k_f_spacing_write(const FArgs* __restrict__ ap)
+k_f_spacing_write(const FArgs av)
 {
-    const FArgs& a = *ap;
+    const FArgs& a = av;
     __shared__ u64 smu[SMC_SM];
     const int b = (int)blockIdx.x, isl = (int)blockIdx.y;
     const double* info = a.info + (i64)isl * INFO_STRIDE;
@@ -376,9 +379,9 @@ k_f_spacing_write(const FArgs* __restrict__ ap)
 // ---------------------------------------------------------------------------
 template <bool FUSED>
 __global__ void __launch_bounds__(SMC_BLOCK)
-k_ancestors(const FArgs* __restrict__ ap)
+k_ancestors(const FArgs av)
 {
-    const FArgs& a = *ap;
+    const FArgs& a = av;
     __shared__ u64 sC[F_TILE];         // inclusive CDF of the tile (search path)
     __shared__ __attribute__((aligned(16))) u32 sP[F_PASS];   // parent of each offspring of a
                                                                // pass (scatter path)
@@ -631,9 +634,9 @@ __device__ __forceinline__ void f_step_tail(const FArgs& a, const int isl, const
 // ---------------------------------------------------------------------------
 template <int KIND, int FK, int OPT>
 __global__ void __launch_bounds__(SMC_BLOCK)
-k_propagate(const FArgs* __restrict__ ap)
+k_propagate(const FArgs av)
 {
-    const FArgs& a = *ap;
+    const FArgs& a = av;
     __shared__ double smd[SMC_SM];
     __shared__ int s_last;
     const int b = (int)blockIdx.x, isl = (int)blockIdx.y;

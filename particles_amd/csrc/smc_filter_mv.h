@@ -86,7 +86,7 @@ __device__ __forceinline__ double mv_sum_g(double v)
 
 template <int FK, int DP, bool DFULL>
 __global__ void __launch_bounds__(SMC_BLOCK)
-k_propagate_mv(const FArgs* __restrict__ ap, const double* __restrict__ C)
+k_propagate_mv(const FArgs av, const double* __restrict__ C)
 {
     constexpr int NV = DP / 4;                    // dimensions per lane
     constexpr int NJ = DP / 16;                   // 16-row blocks of a product
@@ -96,7 +96,7 @@ k_propagate_mv(const FArgs* __restrict__ ap, const double* __restrict__ C)
     constexpr int S_LZ = (FK == SMC_FK_GUIDED) ? 2 : 1;
     constexpr int S_XINV = 3;
     constexpr int S_NGY = (FK == SMC_FK_GUIDED) ? 4 : 2;
-    const FArgs& a = *ap;
+    const FArgs& a = av;
     __shared__ double sM[NSLOT * MM];
     __shared__ double sVec[4 * DP];               // mu (t = 0) or K y_t | mu0 | L_Y^-1 y_t | -
     __shared__ double smd[SMC_SM];
