@@ -51,21 +51,27 @@ static void launch_propagate(smc_filter* f)
 #undef MV_CASE
         return;
     }
-    if (f->kind == SMC_MODEL_LINGAUSS && f->fk == SMC_FK_BOOTSTRAP)
-        SMC_LAUNCH((k_propagate<SMC_MODEL_LINGAUSS, SMC_FK_BOOTSTRAP, F_OPT>), grid,
-                   dim3(SMC_BLOCK), st, f->a);
-    else if (f->kind == SMC_MODEL_LINGAUSS)
-        SMC_LAUNCH((k_propagate<SMC_MODEL_LINGAUSS, SMC_FK_GUIDED, F_OPT>), grid, dim3(SMC_BLOCK),
-                   st, f->a);
-    else
-        SMC_LAUNCH((k_propagate<SMC_MODEL_STOCHVOL, SMC_FK_BOOTSTRAP, F_OPT>), grid,
-                   dim3(SMC_BLOCK), st, f->a);
+#define P_CASE(KINDV, FKV)                                                                    \
+    if (f->kind == KINDV && f->fk == FKV) {                                                   \
+        if (f->a.par >= 0)                                                                    \
+            SMC_LAUNCH((k_propagate<KINDV, FKV, F_OPT, true>), grid, dim3(SMC_BLOCK), st, f->a);  \
+        else                                                                                  \
+            SMC_LAUNCH((k_propagate<KINDV, FKV, F_OPT, false>), grid, dim3(SMC_BLOCK), st, f->a); \
+        return;                                                                               \
+    }
+    P_CASE(SMC_MODEL_LINGAUSS, SMC_FK_BOOTSTRAP)
+    P_CASE(SMC_MODEL_LINGAUSS, SMC_FK_GUIDED)
+    P_CASE(SMC_MODEL_STOCHVOL, SMC_FK_BOOTSTRAP)
+#undef P_CASE
 }
 
 // one time step: [k_prepare, (spacings), k_ancestors] do nothing unless the step
 // resamples (decided on the device by the previous k_propagate), then k_propagate
-static void enqueue_step(smc_filter* f, int k_prof)
+static void enqueue_step(smc_filter* f, int k_prof, i64 t)
 {
+    // the host knows the time index of every step it enqueues; inside a replayed graph
+    // only its parity is static (graphs hold an even number of steps and start at even t)
+    f->a.par = f->a.hist ? -1 : (int)(t & 1);
     hipStream_t st = f->ctx->stream;
     const dim3 grid(f->a.ntiles, f->a.n_islands);
     if (k_prof >= 0) (void)hipEventRecord(f->ev[3 * k_prof], st);
@@ -76,8 +82,9 @@ static void enqueue_step(smc_filter* f, int k_prof)
         SMC_LAUNCH(k_f_spacing_sums, g1, dim3(SMC_BLOCK), st, f->a);
         SMC_LAUNCH(k_f_spacing_write, g1, dim3(SMC_BLOCK), st, f->a);
     }
-    if (fused) SMC_LAUNCH(k_ancestors<true>, grid, dim3(SMC_BLOCK), st, f->a);
-    else SMC_LAUNCH(k_ancestors<false>, grid, dim3(SMC_BLOCK), st, f->a);
+    if (fused && f->a.par >= 0) SMC_LAUNCH((k_ancestors<true, true>), grid, dim3(SMC_BLOCK), st, f->a);
+    else if (fused) SMC_LAUNCH((k_ancestors<true, false>), grid, dim3(SMC_BLOCK), st, f->a);
+    else SMC_LAUNCH((k_ancestors<false, false>), grid, dim3(SMC_BLOCK), st, f->a);
     // odd samples split the step: [resampling kernels | propagate]; even ones time the whole
     // step.  Every event interval carries the same ~4 us of marker processing on MI355X
     // (tools/micro/events.hip), which cancels in (whole step) - (resampling part).
@@ -251,10 +258,12 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
 }
 
 #ifdef SMC_TRACE
-// debug builds only (tools/trace_kmove.py): per-workgroup phase stamps of the last k_move
+// debug builds only (tools/trace_step.py): per-workgroup phase stamps of the last step
 int smc_debug_trace(smc_filter* f, uint64_t* out_host)
 {
-    SMC_HIP_CHECK(hipMemcpyAsync(out_host, f->a.trace, (size_t)f->a.n_islands * f->a.nparts * 64,
+    // (n_islands, nparts, 8) stamps of k_propagate, then (n_islands, ntiles, 8) of k_ancestors
+    SMC_HIP_CHECK(hipMemcpyAsync(out_host, f->a.trace,
+                                 (size_t)f->a.n_islands * (f->a.nparts + f->a.ntiles) * 64,
                                  hipMemcpyDeviceToHost, f->ctx->stream));
     SMC_HIP_CHECK(hipStreamSynchronize(f->ctx->stream));
     return SMC_OK;
@@ -296,12 +305,12 @@ int smc_filter_step(smc_filter* f, int64_t nsteps)
     if (todo < 0) todo = 0;
     i64 done = 0;
 #ifndef SMC_EMULATE
-    const int GS = 25;
-    if (f->use_graph && !f->prof && todo > 0) {
+    const int GS = 24;                    // even: see enqueue_step
+    if (f->use_graph && !f->prof && todo >= GS + 1) {
         if (!f->gexec) {   // captured once, on the first call (kernel arguments are final by then)
             hipGraph_t g = nullptr;
             if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                for (int k = 0; k < GS; ++k) enqueue_step(f, -1);
+                for (int k = 0; k < GS; ++k) enqueue_step(f, -1, k);
                 if (hipStreamEndCapture(st, &g) == hipSuccess && g &&
                     hipGraphInstantiate(&f->gexec, g, nullptr, nullptr, 0) == hipSuccess) {
                     f->graph_steps = GS;
@@ -315,6 +324,10 @@ int smc_filter_step(smc_filter* f, int64_t nsteps)
             }
             (void)hipGetLastError();
         }
+        if (f->gexec && ((f->t_host + done) & 1)) {      // graphs start at even t
+            enqueue_step(f, -1, f->t_host + done);
+            ++done;
+        }
         while (f->gexec && todo - done >= f->graph_steps) {
             SMC_HIP_CHECK(hipGraphLaunch(f->gexec, st));
             done += f->graph_steps;
@@ -324,7 +337,7 @@ int smc_filter_step(smc_filter* f, int64_t nsteps)
     for (; done < todo; ++done) {
         int kp = -1;
         if (f->prof && f->prof_n < PROF_MAX) kp = f->prof_n++;
-        enqueue_step(f, kp);
+        enqueue_step(f, kp, f->t_host + done);
     }
     SMC_LAUNCH_CHECK();
     f->t_host += todo;

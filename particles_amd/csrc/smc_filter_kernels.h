@@ -62,6 +62,8 @@ struct FArgs {
     i64* A;                // (1 or T, n_islands, N)
     i64 xslot, lslot;      // elements per slot: n_islands*N*dx, n_islands*N
     int hist;
+    int par;               // t & 1 of the step this launch runs, or -1 (history slots): lets the
+                           // kernels form their addresses before the step record has arrived
     u64* q;                // (n_islands, N) Q62 weights of the parents
     u64* Q;                // (n_islands, ntiles) tile totals of q
     u64* Qpre;             // (n_islands, ntiles) exclusive prefixes of Q
@@ -95,8 +97,10 @@ __host__ __device__ __forceinline__ i64* f_A(const FArgs& a, i64 t) { return a.A
 
 #ifdef SMC_TRACE
 #define F_STAMP(k) do { if (threadIdx.x == 0) a.trace[((i64)blockIdx.y * a.nparts + blockIdx.x) * 8 + (k)] = (u64)wall_clock64(); } while (0)
+#define F_STAMP_A(k) do { if (threadIdx.x == 0) a.trace[((i64)a.n_islands * a.nparts + (i64)blockIdx.y * a.ntiles + blockIdx.x) * 8 + (k)] = (u64)wall_clock64(); } while (0)
 #else
 #define F_STAMP(k) do { } while (0)
+#define F_STAMP_A(k) do { } while (0)
 #endif
 
 // ---------------------------------------------------------------------------
@@ -377,7 +381,9 @@ k_f_spacing_write(const FArgs av)
 // CDF of the tile from q and its exclusive prefix, the contiguous range of
 // offspring it owns, and the parent index of each of them -> A.
 // ---------------------------------------------------------------------------
-template <bool FUSED>
+// SPEC: the buffer slots follow from a.par (kernarg), so the tile's log-weights are
+// requested right behind the step record instead of one memory round trip after it.
+template <bool FUSED, bool SPEC>
 __global__ void __launch_bounds__(SMC_BLOCK)
 k_ancestors(const FArgs av)
 {
@@ -391,17 +397,24 @@ k_ancestors(const FArgs av)
     const int b = (int)blockIdx.x, isl = (int)blockIdx.y;
     const int tid = (int)threadIdx.x;
     const double* info = a.info + (i64)isl * INFO_STRIDE;
-    const i64 t = (i64)smc_uniform(info[0]);
-    if (t >= a.T || t == 0 || smc_uniform(info[1]) == 0.0) return;          // step t does not resample
     const i64 N = a.N;
-    const u32 gisl = (u32)(a.island_offset + isl);
-    i64* A = f_A(a, t) + (i64)isl * N;
     const bool vec = (N & 3) == 0;
     const i64 j0 = (i64)b * F_TILE;
+    const i64 jt = j0 + (i64)tid * F_IPT;
+    F_STAMP_A(0);
+    const double r0 = smc_ldg(info), r1 = smc_ldg(info + 1), r3 = smc_ldg(info + 3),
+                 r4 = smc_ldg(info + 4);                      // requested first ...
+    double l4[4];
+    if (FUSED && SPEC)                                         // ... the data right behind
+        f_load4<double, F2d>(a.lw + (i64)(a.par ^ 1) * a.lslot + (i64)isl * N, jt, N, vec, -INFINITY, l4);
+    const i64 t = (i64)smc_uniform(r0);
+    if (t >= a.T || t == 0 || smc_uniform(r1) == 0.0) return;          // step t does not resample
+    F_STAMP_A(1);
+    const u32 gisl = (u32)(a.island_offset + isl);
+    i64* A = f_A(a, t) + (i64)isl * N;
 
     // ---- the tile's parents: q and their exact CDF
     u64 q4[4];
-    const i64 jt = j0 + (i64)tid * F_IPT;
     u64 total, pre;
     u64 cex;
     if (FUSED) {
@@ -411,17 +424,17 @@ k_ancestors(const FArgs av)
         // an island publish a few microseconds into the launch, lower-numbered
         // workgroups are dispatched first, so the wait is short and cannot cycle.
         // k_propagate(t) zeroes Q again.
-        const double m = smc_uniform(info[3]), rs = smc_uniform(info[4]);
-        const double* lw = f_lw(a, t - 1) + (i64)isl * N;
-        double l4[4];
-        f_load4<double, F2d>(lw, jt, N, vec, -INFINITY, l4);
+        const double m = smc_uniform(r3), rs = smc_uniform(r4);
+        if (!SPEC) f_load4<double, F2d>(f_lw(a, t - 1) + (i64)isl * N, jt, N, vec, -INFINITY, l4);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             q4[i] = (jt + i < N) ? smc_q62_w(f_weight(l4[i], m, rs)) : 0ull;
         const u64 tsum = q4[0] + q4[1] + q4[2] + q4[3];
         u64* Qt = a.Q + (i64)isl * a.ntiles;
+        F_STAMP_A(2);
         const u64 mine = smc_block_sum_u64(tsum, smu);
         if (tid == 0) smc_st_agent(Qt + b, mine + 1ull);
+        F_STAMP_A(3);
         constexpr int NPRE = F_DIRECT_PREFIX_MAX / SMC_BLOCK;
         u64 v[NPRE];
 #pragma unroll
@@ -438,6 +451,7 @@ k_ancestors(const FArgs av)
             }
             part += v[k] - 1ull;
         }
+        F_STAMP_A(4);
         cex = smc_block_exscan_plus_sum_u64(tsum, part, smu, total, pre);
     } else {
         f_load4<u64, F2u>(a.q + (i64)isl * N, jt, N, vec, 0ull, q4);
@@ -496,6 +510,7 @@ k_ancestors(const FArgs av)
         smc_tile_outputs(su, b, a.ntiles, pre, total, sn, n_lo, n_hi);
     }
     const int nvalid = (int)((N - j0 < F_TILE) ? (N - j0) : F_TILE);
+    F_STAMP_A(5);
 
     // ---- offspring, 4 consecutive ones per thread per pass
     for (i64 pb = n_lo & ~(i64)3; pb < n_hi; pb += F_PASS) {
@@ -542,6 +557,7 @@ k_ancestors(const FArgs av)
         }
         f_store4<i64, F2i>(A, n0, vec && ok[0] && ok[3], ok, a4);            // core.py:329
     }
+    F_STAMP_A(6);
 }
 
 // ---------------------------------------------------------------------------
@@ -582,15 +598,22 @@ __device__ __forceinline__ void f_step_tail(const FArgs& a, const int isl, const
     __syncthreads();
     F_STAMP(5);
     if (!s_last) return;
-    const SmcLse gs = smc_lse_reduce_partials<true>(a.pm + o, a.ps + o, a.pss + o, size_s, smd, sh,
-                                                    shards);
-    __syncthreads();
+    // Up to 2048 partials the last workgroup of the island reduces them all itself (<= 8
+    // loads per thread and array, one round trip): the shard level then only counts.
+    const bool direct = a.nparts <= 2048;
+    SmcLse gs = smc_lse_empty();
+    if (!direct) {
+        gs = smc_lse_reduce_partials<true>(a.pm + o, a.ps + o, a.pss + o, size_s, smd, sh, shards);
+        __syncthreads();
+    }
     if (tid == 0) {
         cnt[(1 + sh) * F_CNT_STRIDE] = 0u;                 // re-arm for the next launch
-        smc_st_agent_f64(spart + sh, gs.m);
-        smc_st_agent_f64(spart + 32 + sh, gs.s);
-        smc_st_agent_f64(spart + 64 + sh, gs.ss);
-        smc_drain_stores();
+        if (!direct) {
+            smc_st_agent_f64(spart + sh, gs.m);
+            smc_st_agent_f64(spart + 32 + sh, gs.s);
+            smc_st_agent_f64(spart + 64 + sh, gs.ss);
+            smc_drain_stores();
+        }
         s_last = atomicAdd(cnt, 1u) == (unsigned)(shards - 1);
         if (s_last) cnt[0] = 0u;
     }
@@ -599,7 +622,9 @@ __device__ __forceinline__ void f_step_tail(const FArgs& a, const int isl, const
     if (!s_last) return;
 
     // ---- last workgroup of this island: finalise step t, decide step t+1
-    const SmcLse g = smc_lse_reduce_partials<true>(spart, spart + 32, spart + 64, shards, smd);
+    const SmcLse g = direct
+        ? smc_lse_reduce_partials<true>(a.pm + o, a.ps + o, a.pss + o, a.nparts, smd)
+        : smc_lse_reduce_partials<true>(spart, spart + 32, spart + 64, shards, smd);
     if (tid == 0) {
         const bool bad = !(g.m > -INFINITY) || !(g.m < INFINITY);
         const double ess = bad ? NAN : (g.s * g.s) / g.ss;                  // resampling.py:226
@@ -632,7 +657,7 @@ __device__ __forceinline__ void f_step_tail(const FArgs& a, const int isl, const
 // thread.  x = loc(X_{t-1}[A]) + scale z, weight increment, log-weights, online
 // log-sum-exp partial; the last workgroup of the island finalises the step.
 // ---------------------------------------------------------------------------
-template <int KIND, int FK, int OPT>
+template <int KIND, int FK, int OPT, bool SPEC>
 __global__ void __launch_bounds__(SMC_BLOCK)
 k_propagate(const FArgs av)
 {
@@ -643,32 +668,52 @@ k_propagate(const FArgs av)
     const int tid = (int)threadIdx.x;
     F_STAMP(0);
     double* info = a.info + (i64)isl * INFO_STRIDE;
-    const i64 t = (i64)smc_uniform(info[0]);
+    const i64 N = a.N;
+    const bool vec = (N % OPT) == 0;          // every island base then is 8*OPT-byte aligned
+    const i64 n0 = ((i64)b * SMC_BLOCK + tid) * OPT;
+    const bool full = vec && n0 + OPT <= N;
+    const double r0 = smc_ldg(info), r1 = smc_ldg(info + 1), r2 = smc_ldg(info + 2);
+    // SPEC: slots from a.par (kernarg): the ancestor indices are requested right behind the
+    // step record, and the gather X_{t-1}[A] can leave as soon as they are back -- without
+    // waiting for the record (read in vain on the steps that do not resample)
+    i64 an[OPT];
+    if (SPEC && n0 < N) {
+        const i64* As = a.A + (i64)isl * N;
+        if (full) {
+#pragma unroll
+            for (int k = 0; k < OPT; k += 2) smc_ld2g(As + n0 + k, an[k], an[k + 1]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < OPT; ++k) an[k] = (n0 + k < N) ? smc_ldg(As + n0 + k) : 0;
+        }
+    }
+    double xg[OPT];
+    if (SPEC && n0 < N) {          // A always holds valid indices (zeros before the first resampling)
+        const double* Xs = a.X + (i64)(a.par ^ 1) * a.xslot + (i64)isl * N;
+#pragma unroll
+        for (int k = 0; k < OPT; ++k) xg[k] = smc_ldg(Xs + an[k]);
+    }
+    const i64 t = (i64)smc_uniform(r0);
     if (t >= a.T) return;
     F_STAMP(1);
-    const i64 N = a.N;
     const double* p = a.params + (i64)isl * PARAM_STRIDE;
-    const double yt = smc_uniform(info[2]);
+    const double yt = smc_uniform(r2);
     const u32 gisl = (u32)(a.island_offset + isl);
-    double* Xn = f_X(a, t) + (i64)isl * N;
-    const double* Xo = f_X(a, t - 1) + (i64)isl * N;
-    double* lwn = f_lw(a, t) + (i64)isl * N;
-    const double* lwo = f_lw(a, t - 1) + (i64)isl * N;
+    double* Xn = (SPEC ? a.X + (i64)a.par * a.xslot : f_X(a, t)) + (i64)isl * N;
+    const double* Xo = (SPEC ? a.X + (i64)(a.par ^ 1) * a.xslot : f_X(a, t - 1)) + (i64)isl * N;
+    double* lwn = (SPEC ? a.lw + (i64)a.par * a.lslot : f_lw(a, t)) + (i64)isl * N;
+    const double* lwo = (SPEC ? a.lw + (i64)(a.par ^ 1) * a.lslot : f_lw(a, t - 1)) + (i64)isl * N;
     const i64* A = f_A(a, t) + (i64)isl * N;
     const double* zt = a.zt ? a.zt + ((i64)t * a.n_islands + isl) * N : nullptr;
     const bool first = (t == 0);
-    const bool resample = !first && smc_uniform(info[1]) != 0.0;
-    const bool vec = (N % OPT) == 0;          // every island base then is 8*OPT-byte aligned
-    const i64 n0 = ((i64)b * SMC_BLOCK + tid) * OPT;
+    const bool resample = !first && smc_uniform(r1) != 0.0;
 
     SmcLse acc = smc_lse_empty();
     if (n0 < N) {
-        const bool full = vec && n0 + OPT <= N;
         double xp[OPT], lwp[OPT], z[OPT];
         // ---- ancestor indices (when resampled) or the particle's own state and
         // log-weight: requested first, consumed after the normals are generated
-        i64 an[OPT];
-        if (resample) {
+        if (resample && !SPEC) {
             if (full) {
 #pragma unroll
                 for (int k = 0; k < OPT; k += 2) {
@@ -678,7 +723,7 @@ k_propagate(const FArgs av)
 #pragma unroll
                 for (int k = 0; k < OPT; ++k) an[k] = (n0 + k < N) ? smc_ldg(A + n0 + k) : 0;
             }
-        } else if (!first) {
+        } else if (!first && !resample) {
             if (full) {
 #pragma unroll
                 for (int k = 0; k < OPT; k += 2) {
@@ -708,7 +753,7 @@ k_propagate(const FArgs av)
         }
         if (resample) {
 #pragma unroll
-            for (int k = 0; k < OPT; ++k) { xp[k] = smc_ldg(Xo + an[k]); lwp[k] = 0.0; }    // core.py:332
+            for (int k = 0; k < OPT; ++k) { xp[k] = SPEC ? xg[k] : smc_ldg(Xo + an[k]); lwp[k] = 0.0; }    // core.py:332
         }
         F_STAMP(2);
         double xn[OPT], lw[OPT];

@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 mkdir -p particles_amd/lib/abl
 for v in ${ABLS:-NO_RNG NO_MFMA NO_LOAD NO_STORE}; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -mllvm -amdgpu-mfma-vgpr-form=1 \
-    -DABL_$v particles_amd/csrc/smc_api.hip particles_amd/csrc/smc_ops.hip particles_amd/csrc/smc_filter.hip \
+    -DABL_$v -DSMC_$v particles_amd/csrc/smc_api.hip particles_amd/csrc/smc_ops.hip particles_amd/csrc/smc_filter.hip \
     particles_amd/csrc/smc_comm.hip -o particles_amd/lib/abl/libsmc_$v.so -ldl 2>/dev/null &
 done
 wait

@@ -1,0 +1,45 @@
+"""Phase timeline of the last step's kernels from a -DSMC_TRACE build
+(perf diagnostics; build: ABLS=TRACE bash tools/build_ablations.sh, run on the GPU box).
+
+Stamps are wall_clock64() ticks (100 MHz) taken by thread 0 of every workgroup;
+printed relative to the kernel's first stamp, in microseconds: min / median / max
+over workgroups."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["SMC_HIP_LIBRARY"] = os.path.join(ROOT, "particles_amd", "lib", "abl", "libsmc_TRACE.so")
+sys.path.insert(0, ROOT)
+import particles_amd as pa                                      # noqa: E402
+from particles_amd import _lib, kalman, state_space_models as ssm   # noqa: E402
+from bench import synthetic_data                                # noqa: E402
+
+log2N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+N = 1 << log2N
+y = synthetic_data(200)
+pf = pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y), N=N, seed=123, use_graph=False)
+pf.step_async(100)
+pf.sync()
+nparts, ntiles = N // 1024, N // 1024
+buf = np.zeros((nparts + ntiles) * 8, dtype=np.uint64)
+lib = _lib.lib()
+lib.smc_debug_trace.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+_lib.check(lib.smc_debug_trace(pf._f, buf.ctypes.data_as(ctypes.c_void_p)))
+for name, st, labels in (
+        ("k_ancestors<true>", buf[nparts * 8:].reshape(ntiles, 8),
+         ["start", "record", "q ready", "published", "prefix known", "counts", "end"]),
+        ("k_propagate", buf[:nparts * 8].reshape(nparts, 8),
+         ["start", "record", "loads+normals", "stores issued", "wg reduced", "shard ticket",
+          "top ticket", "finalised"])):
+    t0 = st[:, 0].min()
+    print("%s: %d workgroups, last start +%.2f us" % (name, st.shape[0], (st[:, 0].max() - t0) / 100.0))
+    for k, lab in enumerate(labels):
+        col = st[:, k].astype(np.int64) - int(t0)
+        col = col[st[:, k] >= t0]
+        if col.size == 0:
+            continue
+        print("  %-16s n=%5d  min %6.2f  median %6.2f  max %6.2f us"
+              % (lab, col.size, col.min() / 100.0, np.median(col) / 100.0, col.max() / 100.0))
