@@ -41,5 +41,12 @@ for name, st, labels in (
         col = col[st[:, k] >= t0]
         if col.size == 0:
             continue
-        print("  %-16s n=%5d  min %6.2f  median %6.2f  max %6.2f us"
-              % (lab, col.size, col.min() / 100.0, np.median(col) / 100.0, col.max() / 100.0))
+        print("  %-16s n=%5d  min %6.2f  median %6.2f  p90 %6.2f  p99 %6.2f  max %6.2f us (wg %d)"
+              % (lab, col.size, col.min() / 100.0, np.median(col) / 100.0, np.percentile(col, 90) / 100.0,
+                 np.percentile(col, 99) / 100.0, col.max() / 100.0, int(np.argmax(st[:, k]))))
+    if name.startswith("k_anc"):
+        d = (st[:, 3].astype(np.int64) - st[:, 2].astype(np.int64)) / 100.0
+        order = np.argsort(-d)[:8]
+        print("  slowest q-ready -> published:", [(int(i), float(d[i]), float((st[i, 0] - t0) / 100.0)) for i in order])
+        w = (st[:, 4].astype(np.int64) - st[:, 3].astype(np.int64)) / 100.0
+        print("  published -> prefix known by tile index quartile:", [round(float(np.median(w[q * 256:(q + 1) * 256])), 2) for q in range(ntiles // 256)])
