@@ -139,7 +139,9 @@ int smc_mvn_logpdf(smc_ctx* ctx, const double* x, int64_t x_rows,
 enum smc_model_kind {
     SMC_MODEL_LINGAUSS = 1,   /* kalman.py:397-452 (ToySSM = rho 1, sigmaX 1, sigma0 1) */
     SMC_MODEL_STOCHVOL = 2,   /* state_space_models.py:446-473 */
-    SMC_MODEL_MVLINGAUSS = 3  /* kalman.py:296-361 */
+    SMC_MODEL_MVLINGAUSS = 3, /* kalman.py:296-361 */
+    SMC_MODEL_GORDON = 4,     /* state_space_models.py:546-577 (bootstrap) */
+    SMC_MODEL_THETALOGISTIC = 5 /* state_space_models.py:657-683 (bootstrap) */
 };
 enum smc_fk_kind {
     SMC_FK_BOOTSTRAP = 0,     /* state_space_models.py:299-349 */
@@ -161,11 +163,17 @@ typedef struct smc_model {
      *             5 log(sigmaX), 6 log(sigma0), 7 sigmaX^2, 8 sigmaY^2,
      *             guided only (kalman.py:436-446): 9 sig2post, 10 sqrt(9),
      *             11 log(10), 12 sig2post0, 13 sqrt(12), 14 log(13)
-     *   STOCHVOL: 0 mu, 1 rho, 2 sigma, 3 sigma/sqrt(1-rho^2), 4 (1-rho)*mu */
+     *   STOCHVOL: 0 mu, 1 rho, 2 sigma, 3 sigma/sqrt(1-rho^2), 4 (1-rho)*mu
+     *   GORDON:   0 b, 1 sigmaX, 2 c, 3 sigma0 (2.0), 5 a;  aux_host[t] = d*cos(e*(t-1))
+     *   THETALOGISTIC: 0 tau0, 1 sigmaX, 2 sigmaY, 3 sigma0 (1.0), 4 log(sigmaY),
+     *             5 tau1, 6 tau2 */
     const double* params_host;
     /* MVLINGAUSS (HOST, row-major): F(dx,dx) G(dy,dx) covX(dx,dx) covY(dy,dy)
      * mu0(dx) cov0(dx,dx); shared by all islands */
     const double *F_host, *G_host, *covX_host, *covY_host, *mu0_host, *cov0_host;
+    /* per-step additive term of the transition mean, (T,) HOST, or NULL (GORDON:
+     * the caller's d*cos(e*(t-1)), entry 0 unused) */
+    const double* aux_host;
 } smc_model;
 
 typedef struct smc_filter_opts {

@@ -406,6 +406,42 @@ class StochVol:
         return normal_logpdf(y, loc=0.0, scale=np.exp(0.5 * x))
 
 
+class Gordon:
+    """state_space_models.py:546-577 (``Gordon_etal``); the transition depends on t."""
+    dim = 1
+    time_dependent = True
+
+    def __init__(self, a=0.05, b=0.5, c=25.0, d=8.0, e=1.2, sigmaX=3.162278):
+        self.a, self.b, self.c, self.d, self.e, self.sigmaX = a, b, c, d, e, sigmaX
+
+    def px0(self):                       # :565-566
+        return 0.0, 2.0
+
+    def px(self, xp, t):                 # :568-574
+        return (self.b * xp + self.c * xp / (1.0 + xp ** 2)
+                + self.d * np.cos(self.e * (t - 1)), self.sigmaX)
+
+    def py_logpdf(self, y, xp, x):       # :576-577
+        return normal_logpdf(y, loc=self.a * x ** 2, scale=1.0)
+
+
+class ThetaLogistic:
+    """state_space_models.py:657-683."""
+    dim = 1
+
+    def __init__(self, tau0=0.15, tau1=0.12, tau2=0.1, sigmaX=0.47, sigmaY=0.39):
+        self.tau0, self.tau1, self.tau2, self.sigmaX, self.sigmaY = tau0, tau1, tau2, sigmaX, sigmaY
+
+    def px0(self):                       # :674-675
+        return 0.0, 1.0
+
+    def px(self, xp):                    # :677-680
+        return xp + self.tau0 - self.tau1 * np.exp(self.tau2 * xp), self.sigmaX
+
+    def py_logpdf(self, y, xp, x):       # :682-683
+        return normal_logpdf(y, loc=x, scale=self.sigmaY)
+
+
 class MVLinGauss:
     """kalman.py:296-361 (``MVLinearGauss``)."""
 
@@ -547,7 +583,7 @@ def run_filter(model, data, N, scheme="systematic", ESSrmin=0.5, fk="bootstrap",
                 loc, scale = model.proposal(Xp, yt)
                 X = normal_rvs(loc, scale, rng.standard_normal(N))
             else:
-                loc, scale = model.px(Xp)
+                loc, scale = model.px(Xp, t) if getattr(model, "time_dependent", False) else model.px(Xp)
                 X = normal_rvs(loc, scale, rng.standard_normal(N))
         # ---- reweight_particles                      core.py:323-324
         if mv:

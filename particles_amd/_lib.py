@@ -20,7 +20,7 @@ P = ctypes.POINTER
 
 MULTINOMIAL, STRATIFIED, SYSTEMATIC = 0, 1, 2
 SCHEMES = {"multinomial": MULTINOMIAL, "stratified": STRATIFIED, "systematic": SYSTEMATIC}
-MODEL_LINGAUSS, MODEL_STOCHVOL, MODEL_MVLINGAUSS = 1, 2, 3
+MODEL_LINGAUSS, MODEL_STOCHVOL, MODEL_MVLINGAUSS, MODEL_GORDON, MODEL_THETALOGISTIC = 1, 2, 3, 4, 5
 FK_BOOTSTRAP, FK_GUIDED = 0, 1
 FIELD_X, FIELD_XP, FIELD_A, FIELD_LW, FIELD_W = range(5)
 SUMMARY_COLS = 5
@@ -32,7 +32,8 @@ class SmcModel(ctypes.Structure):
                 ("dx", ctypes.c_int32), ("dy", ctypes.c_int32),
                 ("params_host", P(c_dbl)),
                 ("F_host", P(c_dbl)), ("G_host", P(c_dbl)), ("covX_host", P(c_dbl)),
-                ("covY_host", P(c_dbl)), ("mu0_host", P(c_dbl)), ("cov0_host", P(c_dbl))]
+                ("covY_host", P(c_dbl)), ("mu0_host", P(c_dbl)), ("cov0_host", P(c_dbl)),
+                ("aux_host", P(c_dbl))]
 
 
 class SmcFilterOpts(ctypes.Structure):

@@ -164,7 +164,11 @@ class SMC:
         if model.get("params") is not None:
             params = np.ascontiguousarray(np.tile(model["params"], (self.n_islands, 1)))
             m.params_host = params.ctypes.data_as(_lib.P(_lib.c_dbl))
-            self._keep = (y, params)
+            aux = None
+            if model.get("aux") is not None:        # per-step term of the transition mean
+                aux = np.ascontiguousarray(model["aux"](T), dtype=np.float64)
+                m.aux_host = aux.ctypes.data_as(_lib.P(_lib.c_dbl))
+            self._keep = (y, params, aux)
         else:       # MVLinearGauss: the matrices, row-major fp64 (kalman.py:296-361)
             mats = {k: np.ascontiguousarray(model[k], dtype=np.float64)
                     for k in ("F", "G", "covX", "covY", "mu0", "cov0")}

@@ -62,6 +62,8 @@ static void launch_propagate(smc_filter* f)
     P_CASE(SMC_MODEL_LINGAUSS, SMC_FK_BOOTSTRAP)
     P_CASE(SMC_MODEL_LINGAUSS, SMC_FK_GUIDED)
     P_CASE(SMC_MODEL_STOCHVOL, SMC_FK_BOOTSTRAP)
+    P_CASE(SMC_MODEL_GORDON, SMC_FK_BOOTSTRAP)
+    P_CASE(SMC_MODEL_THETALOGISTIC, SMC_FK_BOOTSTRAP)
 #undef P_CASE
 }
 
@@ -108,11 +110,14 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
         return SMC_ERR_SCHEME;
     }
     const bool mv = model->kind == SMC_MODEL_MVLINGAUSS;
-    SMC_REQUIRE(model->kind == SMC_MODEL_LINGAUSS || model->kind == SMC_MODEL_STOCHVOL || mv,
+    SMC_REQUIRE(model->kind == SMC_MODEL_LINGAUSS || model->kind == SMC_MODEL_STOCHVOL || mv ||
+                    model->kind == SMC_MODEL_GORDON || model->kind == SMC_MODEL_THETALOGISTIC,
                 "fused filter: unknown model kind");
     SMC_REQUIRE(model->fk == SMC_FK_BOOTSTRAP ||
-                    (model->fk == SMC_FK_GUIDED && model->kind != SMC_MODEL_STOCHVOL),
+                    (model->fk == SMC_FK_GUIDED && (model->kind == SMC_MODEL_LINGAUSS || mv)),
                 "guided filter is available for LINGAUSS and MVLINGAUSS only");
+    SMC_REQUIRE(model->kind != SMC_MODEL_GORDON || model->aux_host,
+                "GORDON needs aux_host (d*cos(e*(t-1)) per step)");
     SMC_REQUIRE(mv || model->params_host, "params_host is required");
     int dxm = 1, dym = 1, dpm = 1;
     std::vector<double> mvc_host;
@@ -196,6 +201,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     const size_t oSum = carve(M * (T + 1) * SUMM_STRIDE * 8);
     const size_t oPar = carve(M * PARAM_STRIDE * 8);
     const size_t oY = carve(T * dym * 8);
+    const size_t oAux = carve(T * 8);
     const size_t oMvc = carve(mvc_host.size() * 8 + 8);
     const size_t oCtl = carve(M * 2 * F_CNT_WORDS * sizeof(unsigned));
     const size_t oSpart = carve(M * 96 * 8);
@@ -238,7 +244,10 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     SMC_HIP_CHECK(hipMemsetAsync(a.Q, 0, M * a.ntiles * 8, st));
     {   // step record of t = 0: {t, rs_flag, y_0, m, 1/s}
         std::vector<double> h(M * INFO_STRIDE, 0.0);
-        for (size_t i = 0; i < M; ++i) h[i * INFO_STRIDE + 2] = y_host[0];
+        for (size_t i = 0; i < M; ++i) {
+            h[i * INFO_STRIDE + 2] = y_host[0];
+            h[i * INFO_STRIDE + 5] = model->aux_host ? model->aux_host[0] : 0.0;
+        }
         SMC_HIP_CHECK(hipMemcpyAsync(a.info, h.data(), h.size() * 8, hipMemcpyHostToDevice, st));
         SMC_HIP_CHECK(hipStreamSynchronize(st));
     }
@@ -251,6 +260,10 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
         SMC_HIP_CHECK(hipMemcpyAsync((void*)a.mvc, mvc_host.data(), mvc_host.size() * 8,
                                      hipMemcpyHostToDevice, st));
     SMC_HIP_CHECK(hipMemcpyAsync(dy, y_host, T * dym * 8, hipMemcpyHostToDevice, st));
+    if (model->aux_host) {
+        a.aux = (const double*)(base + oAux);
+        SMC_HIP_CHECK(hipMemcpyAsync((void*)a.aux, model->aux_host, T * 8, hipMemcpyHostToDevice, st));
+    }
     SMC_HIP_CHECK(hipStreamSynchronize(st));
     SMC_HIP_CHECK(hipStreamSynchronize(st));
     *out = f;

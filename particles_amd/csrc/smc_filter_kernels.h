@@ -47,7 +47,7 @@
 #define F_PASS (SMC_BLOCK * 4)      /* offspring per pass: 4 per thread */
 #define SUMM_STRIDE 8   /* ESS, log_mean, loglt, logLt, rs_flag, m, 1/s, - */
 #define PARAM_STRIDE 16
-#define INFO_STRIDE 8   /* per-island step record: t, rs_flag, y_t, m, 1/s of step t-1 */
+#define INFO_STRIDE 8   /* per-island step record: t, rs_flag, y_t, m, 1/s of step t-1, aux_t */
 
 struct FArgs {
     i64 N, T;
@@ -73,6 +73,7 @@ struct FArgs {
     double* summ;          // (n_islands, T+1, SUMM_STRIDE)
     const double* params;  // (n_islands, PARAM_STRIDE)
     const double* y;       // (T,)
+    const double* aux;     // (T,) per-step scalar of the transition (GORDON: d cos(e (t-1))) or null
     double* info;          // (n_islands, INFO_STRIDE) record of the step being run
     const double* zt;      // replay normals (T, n_islands, N) or null
     const double* ut;      // replay uniforms (T, n_islands, K) or null
@@ -106,29 +107,42 @@ __host__ __device__ __forceinline__ i64* f_A(const FArgs& a, i64 t) { return a.A
 // ---------------------------------------------------------------------------
 // model family
 // ---------------------------------------------------------------------------
+// params row p[16] (host: particles_amd/*._device_params):
+//   LINGAUSS  rho, sigmaX, sigmaY, sigma0, log sigmaY, ... guided constants
+//   STOCHVOL  mu, rho, sigma, sig0, (1-rho) mu
+//   GORDON    b, sigmaX, c, sigma0 (= 2), -, a          aux_t = d cos(e (t-1))
+//   THETALOG  tau0, sigmaX, sigmaY, sigma0 (= 1), log sigmaY, tau1, tau2
 template <int KIND>
-__device__ __forceinline__ double m_trans_loc(const double* p, double xp)
+__device__ __forceinline__ double m_trans_loc(const double* p, double xp, double aux)
 {
     if (KIND == SMC_MODEL_LINGAUSS) return p[0] * xp;           // kalman.py:430-431
+    if (KIND == SMC_MODEL_GORDON)                               // state_space_models.py:568-574
+        return (p[0] * xp + (p[2] * xp) / (1.0 + xp * xp)) + aux;
+    if (KIND == SMC_MODEL_THETALOGISTIC)                        // state_space_models.py:677-680
+        return (xp + p[0]) - p[5] * exp(p[6] * xp);
     return p[4] + p[1] * xp;                                    // state_space_models.py:465-470
 }
 template <int KIND>
 __device__ __forceinline__ double m_trans_scale(const double* p)
 {
-    return (KIND == SMC_MODEL_LINGAUSS) ? p[1] : p[2];
+    return (KIND == SMC_MODEL_STOCHVOL) ? p[2] : p[1];
 }
 template <int KIND>
 __device__ __forceinline__ double m_init_loc(const double* p)
 {
-    return (KIND == SMC_MODEL_LINGAUSS) ? 0.0 : p[0];           // kalman.py:427 ; ssm.py:462
+    return (KIND == SMC_MODEL_STOCHVOL) ? p[0] : 0.0;           // ssm.py:462 ; kalman.py:427, ssm.py:565, :675
 }
 // log p(y_t | x_t) as scipy.stats.norm.logpdf evaluates it
 template <int KIND>
 __device__ __forceinline__ double m_obs_logpdf(const double* p, double y, double x)
 {
-    if (KIND == SMC_MODEL_LINGAUSS) {                           // kalman.py:433-434
+    if (KIND == SMC_MODEL_LINGAUSS || KIND == SMC_MODEL_THETALOGISTIC) {   // kalman.py:433-434, ssm.py:682-683
         const double v = (y - x) / p[2];
         return -(v * v) / 2.0 - SMC_C_NORM - p[4];
+    }
+    if (KIND == SMC_MODEL_GORDON) {                             // ssm.py:576-577: Normal(loc=a x^2), scale 1
+        const double v = (y - p[5] * (x * x)) / 1.0;
+        return -(v * v) / 2.0 - SMC_C_NORM - 0.0;
     }
     const double sc = exp(0.5 * x);                             // ssm.py:472-473
     const double v = (y - 0.0) / sc;
@@ -142,12 +156,12 @@ __device__ __forceinline__ double m_norm_logpdf(double x, double loc, double sca
 
 // one particle of one step: returns the new state, writes the weight increment
 template <int KIND, int FK>
-__device__ __forceinline__ double m_step(const double* p, bool first, double y, double xp,
-                                         double z, double& inc)
+__device__ __forceinline__ double m_step(const double* p, bool first, double y, double aux,
+                                         double xp, double z, double& inc)
 {
     if (FK == SMC_FK_BOOTSTRAP) {
         const double x = first ? m_init_loc<KIND>(p) + p[3] * z
-                               : m_trans_loc<KIND>(p, xp) + m_trans_scale<KIND>(p) * z;
+                               : m_trans_loc<KIND>(p, xp, aux) + m_trans_scale<KIND>(p) * z;
         inc = m_obs_logpdf<KIND>(p, y, x);
         return x;
     }
@@ -645,6 +659,7 @@ __device__ __forceinline__ void f_step_tail(const FArgs& a, const int isl, const
         const bool flag = (t + 1 < a.T) && (ess < a.ess_thresh);            // core.py:181-183
         info[1] = flag ? 1.0 : 0.0;
         info[2] = (t + 1 < a.T) ? a.y[(t + 1) * a.dy] : 0.0;
+        info[5] = (a.aux && t + 1 < a.T) ? a.aux[t + 1] : 0.0;
         info[3] = g.m;
         info[4] = rs;
         info[0] = (double)(t + 1);
@@ -672,7 +687,8 @@ k_propagate(const FArgs av)
     const bool vec = (N % OPT) == 0;          // every island base then is 8*OPT-byte aligned
     const i64 n0 = ((i64)b * SMC_BLOCK + tid) * OPT;
     const bool full = vec && n0 + OPT <= N;
-    const double r0 = smc_ldg(info), r1 = smc_ldg(info + 1), r2 = smc_ldg(info + 2);
+    const double r0 = smc_ldg(info), r1 = smc_ldg(info + 1), r2 = smc_ldg(info + 2),
+                 r5 = smc_ldg(info + 5);
     // SPEC: slots from a.par (kernarg): the ancestor indices are requested right behind the
     // step record, and the gather X_{t-1}[A] can leave as soon as they are back -- without
     // waiting for the record (read in vain on the steps that do not resample)
@@ -698,6 +714,7 @@ k_propagate(const FArgs av)
     F_STAMP(1);
     const double* p = a.params + (i64)isl * PARAM_STRIDE;
     const double yt = smc_uniform(r2);
+    const double aux = (KIND == SMC_MODEL_GORDON) ? smc_uniform(r5) : 0.0;
     const u32 gisl = (u32)(a.island_offset + isl);
     double* Xn = (SPEC ? a.X + (i64)a.par * a.xslot : f_X(a, t)) + (i64)isl * N;
     const double* Xo = (SPEC ? a.X + (i64)(a.par ^ 1) * a.xslot : f_X(a, t - 1)) + (i64)isl * N;
@@ -760,7 +777,7 @@ k_propagate(const FArgs av)
 #pragma unroll
         for (int k = 0; k < OPT; ++k) {
             double inc;
-            xn[k] = m_step<KIND, FK>(p, first, yt, xp[k], z[k], inc);
+            xn[k] = m_step<KIND, FK>(p, first, yt, aux, xp[k], z[k], inc);
             double l = (resample || first) ? inc : lwp[k] + inc;          // resampling.py:241-244
             if (l != l) l = -INFINITY;                                     // resampling.py:220
             lw[k] = l;

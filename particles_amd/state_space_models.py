@@ -149,3 +149,58 @@ class StochVol(StateSpaceModel):
         p = np.zeros(_lib.PARAM_STRIDE)
         p[:5] = [self.mu, self.rho, self.sigma, self.sig0(), (1.0 - self.rho) * self.mu]
         return dict(kind=_lib.MODEL_STOCHVOL, dx=1, dy=1, params=p)
+
+
+class Gordon_etal(StateSpaceModel):
+    r"""Toy example of Gordon et al (1993) (state_space_models.py:546-577).
+
+    X_0 ~ N(0, 2^2); X_t = b X_{t-1} + c X_{t-1}/(1+X_{t-1}^2) + d cos(e (t-1)) + sigmaX V_t;
+    Y_t | X_t ~ N(a X_t^2, 1).
+    """
+    default_params = {"a": 0.05, "b": 0.5, "c": 25.0, "d": 8.0, "e": 1.2, "sigmaX": 3.162278}
+
+    def PX0(self):
+        return dists.Normal(scale=2.0)
+
+    def PX(self, t, xp):
+        return dists.Normal(loc=self.b * xp + self.c * xp / (1.0 + xp ** 2)
+                            + self.d * np.cos(self.e * (t - 1)), scale=self.sigmaX)
+
+    def PY(self, t, xp, x):
+        return dists.Normal(loc=self.a * x ** 2)
+
+    def _device_params(self, fk_kind):
+        if fk_kind != _lib.FK_BOOTSTRAP:
+            return None
+        p = np.zeros(_lib.PARAM_STRIDE)
+        p[[0, 1, 2, 3, 5]] = [self.b, self.sigmaX, self.c, 2.0, self.a]
+        # the time-dependent term, with the host's cos (as PX evaluates it)
+        aux = lambda T: self.d * np.cos(self.e * (np.arange(T) - 1))
+        return dict(kind=_lib.MODEL_GORDON, dx=1, dy=1, params=p, aux=aux)
+
+
+class ThetaLogistic(StateSpaceModel):
+    r"""Theta-logistic model (state_space_models.py:657-683).
+
+    X_0 ~ N(0,1); X_t = X_{t-1} + tau0 - tau1 exp(tau2 X_{t-1}) + U_t, U_t ~ N(0, sigmaX^2);
+    Y_t = X_t + V_t, V_t ~ N(0, sigmaY^2).
+    """
+    default_params = {"tau0": 0.15, "tau1": 0.12, "tau2": 0.1, "sigmaX": 0.47, "sigmaY": 0.39}
+
+    def PX0(self):
+        return dists.Normal(loc=0.0, scale=1.0)
+
+    def PX(self, t, xp):
+        return dists.Normal(loc=xp + self.tau0 - self.tau1 * np.exp(self.tau2 * xp),
+                            scale=self.sigmaX)
+
+    def PY(self, t, xp, x):
+        return dists.Normal(loc=x, scale=self.sigmaY)
+
+    def _device_params(self, fk_kind):
+        if fk_kind != _lib.FK_BOOTSTRAP:
+            return None
+        p = np.zeros(_lib.PARAM_STRIDE)
+        p[:7] = [self.tau0, self.sigmaX, self.sigmaY, 1.0, np.log(self.sigmaY), self.tau1,
+                 self.tau2]
+        return dict(kind=_lib.MODEL_THETALOGISTIC, dx=1, dy=1, params=p)

@@ -72,6 +72,10 @@ def main():
         out["mv%d_guided" % dx] = run_case(mv, ssm.GuidedPF, 12, 256, "systematic", 0.5)
         out["mv%d_boot" % dx] = run_case(mv, ssm.Bootstrap, 12, 256, "stratified", 0.5)
 
+    # --- further univariate models of the fused family (state_space_models.py:546-577, 657-683)
+    out["gordon_boot"] = run_case(ssm.Gordon_etal(), ssm.Bootstrap, 40, 600, "systematic", 0.5)
+    out["theta_boot"] = run_case(ssm.ThetaLogistic(), ssm.Bootstrap, 40, 600, "stratified", 0.5)
+
     # --- full particle history + genealogy (smoothing.py:181-255), adaptive
     # resampling so that some A_t are arange ---------------------------------
     np.random.seed(42)

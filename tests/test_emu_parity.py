@@ -79,6 +79,8 @@ def test_mvn(golden):
     ("mv4_boot", "mv4", "bootstrap"),
     ("mv32_guided", "mv32", "guided"),
     ("mv32_boot", "mv32", "bootstrap"),
+    ("gordon_boot", "gordon", "bootstrap"),
+    ("theta_boot", "theta", "bootstrap"),
 ])
 def test_filter_replay(golden, case, model, fk):
     pc.check_filter_replay(golden, case, model, fk, T=12 if model.startswith("mv") else 25)
@@ -87,6 +89,11 @@ def test_filter_replay(golden, case, model, fk):
 def test_mv_philox_kalman():
     pc.check_mv_kalman(2048, 4, "guided")
     pc.check_mv_kalman(1000, 6, "guided", scheme="stratified")
+
+
+@pytest.mark.parametrize("case,model", [("gordon_boot", "gordon"), ("theta_boot", "theta")])
+def test_nonlinear_models_philox(golden, case, model):
+    pc.check_model_philox_vs_oracle(golden, case, model, N=4000)
 
 
 def test_filter_stepwise(golden):

@@ -15,13 +15,16 @@ MODELS = {
     "lg_guided": lambda: orc.LinGauss(rho=0.9, sigmaX=1.0, sigmaY=0.2),
     "mv4": lambda: orc.Guarniero(alpha=0.4, dx=4),
     "mv32": lambda: orc.Guarniero(alpha=0.4, dx=32),
+    "gordon": lambda: orc.Gordon(),
+    "theta": lambda: orc.ThetaLogistic(),
 }
 
 CASES = ([("toy_%s" % s, "toy", "bootstrap") for s in ("systematic", "stratified", "multinomial")]
          + [("sv_%s" % s, "sv", "bootstrap") for s in ("systematic", "stratified", "multinomial")]
          + [("lg_adaptive", "lg_adaptive", "bootstrap"), ("lg_guided", "lg_guided", "guided"),
             ("mv4_guided", "mv4", "guided"), ("mv4_boot", "mv4", "bootstrap"),
-            ("mv32_guided", "mv32", "guided"), ("mv32_boot", "mv32", "bootstrap")])
+            ("mv32_guided", "mv32", "guided"), ("mv32_boot", "mv32", "bootstrap"),
+            ("gordon_boot", "gordon", "bootstrap"), ("theta_boot", "theta", "bootstrap")])
 
 
 @pytest.mark.parametrize("case,model,fk", CASES)
