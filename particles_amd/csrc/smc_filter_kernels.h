@@ -575,13 +575,13 @@ k_ancestors(const FArgs av)
 }
 
 // ---------------------------------------------------------------------------
-// End of a propagate kernel: combine the per-thread log-sum-exp accumulators of
-// the workgroup, publish the partial, and let the last workgroup of the island
-// finalise step t and decide step t+1.  Called by every thread.
+// End of a propagate kernel: publish the workgroup's log-sum-exp partial `r` and
+// let the last workgroup of the island finalise step t and decide step t+1.
+// Called by every thread.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void f_step_tail(const FArgs& a, const int isl, const int b,
                                             const i64 t, const bool first, const bool resample,
-                                            const SmcLse acc, double* smd, int& s_last,
+                                            const SmcLse r, double* smd, int& s_last,
                                             double* info)
 {
     const int tid = (int)threadIdx.x;
@@ -590,8 +590,6 @@ __device__ __forceinline__ void f_step_tail(const FArgs& a, const int isl, const
         const i64 g = (i64)b * SMC_BLOCK + tid;
         if (g < a.ntiles) a.Q[(i64)isl * a.ntiles + g] = 0ull;
     }
-    F_STAMP(3);
-    const SmcLse r = smc_lse_block(acc, smd);
     F_STAMP(4);
     const i64 o = (i64)isl * a.nparts;
     // ---- publish the partial; two-level "last one reduces" (no spinning):
@@ -725,7 +723,9 @@ k_propagate(const FArgs av)
     const bool first = (t == 0);
     const bool resample = !first && smc_uniform(r1) != 0.0;
 
-    SmcLse acc = smc_lse_empty();
+    double lw[OPT];
+#pragma unroll
+    for (int k = 0; k < OPT; ++k) lw[k] = -INFINITY;
     if (n0 < N) {
         double xp[OPT], lwp[OPT], z[OPT];
         // ---- ancestor indices (when resampled) or the particle's own state and
@@ -773,15 +773,14 @@ k_propagate(const FArgs av)
             for (int k = 0; k < OPT; ++k) { xp[k] = SPEC ? xg[k] : smc_ldg(Xo + an[k]); lwp[k] = 0.0; }    // core.py:332
         }
         F_STAMP(2);
-        double xn[OPT], lw[OPT];
+        double xn[OPT];
 #pragma unroll
         for (int k = 0; k < OPT; ++k) {
             double inc;
             xn[k] = m_step<KIND, FK>(p, first, yt, aux, xp[k], z[k], inc);
             double l = (resample || first) ? inc : lwp[k] + inc;          // resampling.py:241-244
             if (l != l) l = -INFINITY;                                     // resampling.py:220
-            lw[k] = l;
-            if (n0 + k < N) smc_lse_push(acc, l);
+            lw[k] = (n0 + k < N) ? l : -INFINITY;
         }
         if (full) {
 #pragma unroll
@@ -795,7 +794,27 @@ k_propagate(const FArgs av)
                 if (n0 + k < N) { smc_stg(Xn + n0 + k, xn[k]); smc_stg(lwn + n0 + k, lw[k]); }
         }
     }
-    f_step_tail(a, isl, b, t, first, resample, acc, smd, s_last, info);
+    // ---- the workgroup's (max, sum e, sum e^2): max first, then ONE exp per particle
+    // against the workgroup's max (no per-thread rescaling, no branches)
+    F_STAMP(3);
+    SmcLse r;
+    {
+        double tm = lw[0];
+#pragma unroll
+        for (int k = 1; k < OPT; ++k) tm = smc_max2(tm, lw[k]);
+        r.m = smc_block_max(tm, smd);
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < OPT; ++k) {
+            const double e = (lw[k] > -INFINITY) ? smc_exp_nonpos(lw[k] - r.m) : 0.0;
+            s1 += e;
+            s2 = fma(e, e, s2);
+        }
+        smc_block_sum2(s1, s2, smd);
+        r.s = s1;
+        r.ss = s2;
+    }
+    f_step_tail(a, isl, b, t, first, resample, r, smd, s_last, info);
 }
 
 // W = exp(lw - m)/s for one island (SMC.W)

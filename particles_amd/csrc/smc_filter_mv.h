@@ -352,7 +352,7 @@ k_propagate_mv(const FArgs av, const double* __restrict__ C)
             }
         }
     }
-    f_step_tail(a, isl, b, t, first, resample, lacc, smd, s_last, info);
+    f_step_tail(a, isl, b, t, first, resample, smc_lse_block(lacc, smd), smd, s_last, info);
 }
 
 // X_{t-1}[A] for SMC.Xp, (N,d)
