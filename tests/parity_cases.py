@@ -352,6 +352,25 @@ def check_model_philox_vs_oracle(golden, case, model, N=20000):
     assert abs(np.mean(dev) - np.mean(ref)) < 0.25, (dev, ref)
 
 
+def check_edge_sizes():
+    """Ragged and tiny populations, single-step runs, every scheme (partial
+    wavefronts, partial tiles, tiles with no offspring)."""
+    rng = np.random.RandomState(0)
+    y = [np.array([v]) for v in rng.standard_normal(6)]
+    for N in (1, 2, 3, 63, 64, 65, 255, 257, 1023, 1025, 2049):
+        for scheme in ("systematic", "stratified", "multinomial"):
+            for T in (1, 6):
+                pf = pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.5), data=y[:T]), N=N,
+                            resampling=scheme, seed=3, ESSrmin=1.0)
+                pf.run()
+                assert np.isfinite(pf.logLt), (N, scheme, T)
+                assert pf.X.shape == (N,) and np.all(np.isfinite(pf.X))
+                assert abs(pf.W.sum() - 1.0) < 1e-12
+                if T > 1:
+                    A = pf.A
+                    assert A.min() >= 0 and A.max() < N and np.all(np.diff(A) >= 0)
+
+
 def check_device_history(golden):
     """store_history=True on the fused path: the history stays in HBM
     (keep_history) and hist.X / hist.A / hist.wgts / compute_trajectories are

@@ -96,6 +96,10 @@ def test_nonlinear_models_philox(golden, case, model):
     pc.check_model_philox_vs_oracle(golden, case, model, N=4000)
 
 
+def test_edge_sizes():
+    pc.check_edge_sizes()
+
+
 def test_filter_stepwise(golden):
     pc.check_filter_stepwise(golden)
 
