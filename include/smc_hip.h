@@ -131,6 +131,25 @@ int smc_mvn_logpdf(smc_ctx* ctx, const double* x, int64_t x_rows,
                    const double* loc, int64_t loc_rows, double scale,
                    const double* L_host, int64_t N, int64_t d, double* out);
 
+/* ---- (f) remaining schemes of rs_funcs ------------------------------------
+ * residual (resampling.py:611-626), two calls because the reference draws
+ * uniform_spacings(M - sip) AFTER it knows sip = sum floor(M W):
+ *   split:      r_dev (N) <- (M W - floor(M W)) / (M - sip), *sip_host <- sip
+ *   ancestors:  A[:sip] = arange(N).repeat(floor(M W));  A[sip:] = inverse_cdf(su_dev, r_dev)
+ *               (su_dev: M - sip sorted uniforms; may be NULL when sip == M) */
+int smc_residual_split(smc_ctx* ctx, const double* W, int64_t N, int64_t M,
+                       double* r_dev, int64_t* sip_host);
+int smc_residual_ancestors(smc_ctx* ctx, const double* W, const double* r_dev,
+                           int64_t N, int64_t M, int64_t sip, const double* su_dev,
+                           int64_t* A);
+/* killing (resampling.py:680-697; M == N):
+ *   split:      killed_dev[i] <- u_dev[i] * max(W) >= W[i], *nkilled_host <- their number
+ *   ancestors:  A = arange(N); A[killed] = Am (the caller's multinomial(W, nkilled), device) */
+int smc_killing_split(smc_ctx* ctx, const double* W, const double* u_dev, int64_t N,
+                      unsigned char* killed_dev, int64_t* nkilled_host);
+int smc_killing_ancestors(smc_ctx* ctx, const unsigned char* killed_dev, const int64_t* Am,
+                          int64_t N, int64_t* A);
+
 /* ---- a-1: the fused SMC step loop (core.py:369-383) ------------------------
  * One smc_filter holds `n_islands` independent particle filters of N particles
  * each (multiSMC runs / SMC^2 inner filters, core.py:431, smc_samplers.py:

@@ -199,6 +199,37 @@ def resampling(scheme, W, M=None, u=None, rng=None, cdf="seq"):
     return inverse_cdf(su, W) if cdf == "seq" else inverse_cdf_q62(su, W)
 
 
+def residual(W, M=None, rng=None, cdf="seq"):
+    """resampling.py:611-626: floor(M W) copies, then multinomial on the residuals."""
+    N = W.shape[0]
+    M = N if M is None else M
+    rng = LegacyRNG() if rng is None else rng
+    A = np.empty(M, dtype=np.int64)
+    MW = M * W
+    intpart = np.floor(MW).astype(np.int64)
+    sip = np.sum(intpart)
+    res = MW - intpart
+    sres = M - sip
+    A[:sip] = np.arange(N).repeat(intpart)
+    if sres > 0:
+        A[sip:] = resampling("multinomial", res / sres, M=sres, rng=rng, cdf=cdf)
+    return A
+
+
+def killing(W, M=None, rng=None, cdf="seq"):
+    """resampling.py:680-697."""
+    N = W.shape[0]
+    M = N if M is None else M
+    if M != N:
+        raise ValueError("killing resampling defined only for M=N")
+    rng = LegacyRNG() if rng is None else rng
+    killed = rng.rand(N) * W.max() >= W
+    nkilled = killed.sum()
+    A = np.arange(N)
+    A[killed] = resampling("multinomial", W, M=nkilled, rng=rng, cdf=cdf)
+    return A
+
+
 # ---- the fixed-point ("Q62") CDF contract used by the HIP kernels ---------
 #
 # The reference accumulates the CDF strictly left to right in fp64

@@ -82,6 +82,10 @@ SIGNATURES = {
     "smc_filter_t": (c_int, [c_vp, P(c_i64)]),
     "smc_filter_summaries": (c_int, [c_vp, P(c_dbl)]),
     "smc_filter_logLt": (c_int, [c_vp, P(c_dbl)]),
+    "smc_residual_split": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, P(c_i64)]),
+    "smc_residual_ancestors": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp]),
+    "smc_killing_split": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, P(c_i64)]),
+    "smc_killing_ancestors": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "smc_filter_get": (c_int, [c_vp, c_int, c_int, c_vp]),
     "smc_filter_history": (c_int, [c_vp, c_int, c_i64, c_int, c_vp]),
     "smc_filter_trajectories": (c_int, [c_vp, c_int, P(c_i64)]),

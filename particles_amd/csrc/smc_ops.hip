@@ -319,6 +319,204 @@ extern "C" int smc_inverse_cdf(smc_ctx* ctx, const double* su_dev, const double*
     return resample_launch(ctx, W, N, su, (i64*)A);
 }
 
+// ---- residual resampling (resampling.py:611-626) ----------------------------
+// A[:sip] = arange(N).repeat(floor(M W)) is an inverse CDF on INTEGER weights with the
+// thresholds n+1; the remaining M - sip draws are a multinomial on (M W - floor(M W)) /
+// (M - sip), i.e. smc_inverse_cdf on that vector.
+__device__ __forceinline__ u64 res_count(double w, double dM)
+{
+    const double c = floor(dM * w);                       // np.floor(M * W)
+    return c > 0.0 ? (u64)c : 0ull;
+}
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_residual_counts(const double* W, i64 N, double dM, u64* Q)
+{
+    __shared__ u64 sm[SMC_SM];
+    const i64 j0 = (i64)blockIdx.x * OPS_TILE + (i64)threadIdx.x * OPS_IPT;
+    u64 t = 0;
+#pragma unroll
+    for (int i = 0; i < OPS_IPT; ++i)
+        if (j0 + i < N) t += res_count(W[j0 + i], dM);
+    t = smc_block_sum_u64(t, sm);
+    if (threadIdx.x == 0) Q[blockIdx.x] = t;
+}
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_residual_split(const double* W, i64 N, double dM, double dsres, double* r)
+{
+    const i64 j = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;
+    if (j < N) {
+        const double mw = dM * W[j];
+        r[j] = (mw - floor(mw)) / dsres;                  // res / sres
+    }
+}
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_repeat_tiles(const double* W, i64 N, double dM, const u64* Q, i64* A)
+{
+    __shared__ u64 sC[OPS_TILE];
+    __shared__ u64 sm[SMC_SM];
+    const int b = (int)blockIdx.x;
+    const i64 j0 = (i64)b * OPS_TILE;
+    u64 c[OPS_IPT];
+#pragma unroll
+    for (int i = 0; i < OPS_IPT; ++i) {
+        const i64 j = j0 + (i64)threadIdx.x * OPS_IPT + i;
+        c[i] = (j < N) ? res_count(W[j], dM) : 0ull;
+    }
+    u64 total;
+    const u64 pre = smc_tile_cdf<OPS_IPT>(c, Q, b, sC, sm, total);
+    for (u64 n = pre + threadIdx.x; n < pre + total; n += SMC_BLOCK)       // its copies
+        A[n] = j0 + smc_lower_bound_u64(sC, OPS_TILE, n + 1ull);
+}
+
+extern "C" int smc_residual_split(smc_ctx* ctx, const double* W, int64_t N, int64_t M,
+                                  double* r_dev, int64_t* sip_host)
+{
+    SMC_REQUIRE(ctx && W && r_dev && sip_host, "null argument");
+    SMC_REQUIRE(M > 0 && N > 0, "M and N must be positive");
+    const int ntiles = (int)((N + OPS_TILE - 1) / OPS_TILE);
+    void* scr;
+    int rc = smc_scratch(ctx, (size_t)ntiles * sizeof(u64), &scr);
+    if (rc) return rc;
+    SMC_LAUNCH(k_residual_counts, dim3(ntiles), dim3(SMC_BLOCK), ctx->stream, W, (i64)N, (double)M,
+               (u64*)scr);
+    std::vector<u64> h(ntiles);
+    SMC_HIP_CHECK(hipMemcpyAsync(h.data(), scr, (size_t)ntiles * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SMC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    u64 sip = 0;
+    for (u64 v : h) sip += v;
+    *sip_host = (int64_t)sip;
+    const int64_t sres = M - (int64_t)sip;
+    if (sres > 0)
+        SMC_LAUNCH(k_residual_split, dim3((unsigned)((N + SMC_BLOCK - 1) / SMC_BLOCK)), dim3(SMC_BLOCK),
+                   ctx->stream, W, (i64)N, (double)M, (double)sres, r_dev);
+    SMC_LAUNCH_CHECK();
+    return SMC_OK;
+}
+
+extern "C" int smc_residual_ancestors(smc_ctx* ctx, const double* W, const double* r_dev, int64_t N,
+                                      int64_t M, int64_t sip, const double* su_dev, int64_t* A)
+{
+    SMC_REQUIRE(ctx && W && A, "null argument");
+    SMC_REQUIRE(M > 0 && N > 0 && sip >= 0 && sip <= M, "sizes out of range");
+    const int ntiles = (int)((N + OPS_TILE - 1) / OPS_TILE);
+    void* scr;
+    int rc = smc_scratch(ctx, (size_t)ntiles * sizeof(u64), &scr);
+    if (rc) return rc;
+    SMC_LAUNCH(k_residual_counts, dim3(ntiles), dim3(SMC_BLOCK), ctx->stream, W, (i64)N, (double)M,
+               (u64*)scr);
+    SMC_LAUNCH(k_repeat_tiles, dim3(ntiles), dim3(SMC_BLOCK), ctx->stream, W, (i64)N, (double)M,
+               (const u64*)scr, (i64*)A);
+    SMC_LAUNCH_CHECK();
+    if (M - sip > 0) {
+        SMC_REQUIRE(r_dev && su_dev, "residual weights and sorted uniforms are required");
+        return smc_inverse_cdf(ctx, su_dev, r_dev, M - sip, N, A + sip);
+    }
+    return SMC_OK;
+}
+
+// ---- killing resampling (resampling.py:680-697) -----------------------------
+// killed_i = u_i * max(W) >= W_i ; A = arange(N) ; A[killed] = multinomial(W, #killed)
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_wmax_partials(const double* W, i64 N, double* part)
+{
+    __shared__ double sm[SMC_SM];
+    double m = -INFINITY;
+    for (i64 j = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x; j < N; j += (i64)gridDim.x * SMC_BLOCK)
+        m = smc_max2(m, W[j]);
+    m = smc_block_max(m, sm);
+    if (threadIdx.x == 0) part[blockIdx.x] = m;
+}
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_killing_flags(const double* W, const double* u, i64 N, const double* part, int nparts,
+                unsigned char* killed, u64* Q)
+{
+    __shared__ u64 sm[SMC_SM];
+    double wmax = part[0];
+    for (int i = 1; i < nparts; ++i) wmax = smc_max2(wmax, part[i]);
+    const i64 j0 = (i64)blockIdx.x * OPS_TILE + (i64)threadIdx.x * OPS_IPT;
+    u64 t = 0;
+#pragma unroll
+    for (int i = 0; i < OPS_IPT; ++i)
+        if (j0 + i < N) {
+            const bool k = u[j0 + i] * wmax >= W[j0 + i];
+            killed[j0 + i] = k ? 1 : 0;
+            t += k ? 1ull : 0ull;
+        }
+    t = smc_block_sum_u64(t, sm);
+    if (threadIdx.x == 0) Q[blockIdx.x] = t;
+}
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_flag_tile_sums(const unsigned char* killed, i64 N, u64* Q)
+{
+    __shared__ u64 sm[SMC_SM];
+    const i64 j0 = (i64)blockIdx.x * OPS_TILE + (i64)threadIdx.x * OPS_IPT;
+    u64 t = 0;
+#pragma unroll
+    for (int i = 0; i < OPS_IPT; ++i)
+        if (j0 + i < N && killed[j0 + i]) t += 1ull;
+    t = smc_block_sum_u64(t, sm);
+    if (threadIdx.x == 0) Q[blockIdx.x] = t;
+}
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_killing_assign(const unsigned char* killed, const i64* Am, i64 N, const u64* Q, i64* A)
+{
+    __shared__ u64 sC[OPS_TILE];
+    __shared__ u64 sm[SMC_SM];
+    const int b = (int)blockIdx.x;
+    const i64 j0 = (i64)b * OPS_TILE + (i64)threadIdx.x * OPS_IPT;
+    u64 c[OPS_IPT];
+#pragma unroll
+    for (int i = 0; i < OPS_IPT; ++i) c[i] = (j0 + i < N && killed[j0 + i]) ? 1ull : 0ull;
+    u64 total;
+    smc_tile_cdf<OPS_IPT>(c, Q, b, sC, sm, total);         // inclusive ranks of the killed ones
+#pragma unroll
+    for (int i = 0; i < OPS_IPT; ++i)
+        if (j0 + i < N)
+            A[j0 + i] = c[i] ? Am[sC[threadIdx.x * OPS_IPT + i] - 1ull] : j0 + i;
+}
+
+extern "C" int smc_killing_split(smc_ctx* ctx, const double* W, const double* u_dev, int64_t N,
+                                 unsigned char* killed_dev, int64_t* nkilled_host)
+{
+    SMC_REQUIRE(ctx && W && u_dev && killed_dev && nkilled_host, "null argument");
+    SMC_REQUIRE(N > 0, "N must be positive");
+    const int ntiles = (int)((N + OPS_TILE - 1) / OPS_TILE);
+    const int nparts = ntiles < 64 ? ntiles : 64;
+    void* scr;
+    int rc = smc_scratch(ctx, (size_t)(ntiles + 64) * sizeof(u64), &scr);
+    if (rc) return rc;
+    double* part = (double*)scr;
+    u64* Q = (u64*)scr + 64;
+    SMC_LAUNCH(k_wmax_partials, dim3(nparts), dim3(SMC_BLOCK), ctx->stream, W, (i64)N, part);
+    SMC_LAUNCH(k_killing_flags, dim3(ntiles), dim3(SMC_BLOCK), ctx->stream, W, u_dev, (i64)N,
+               (const double*)part, nparts, killed_dev, Q);
+    std::vector<u64> h(ntiles);
+    SMC_HIP_CHECK(hipMemcpyAsync(h.data(), Q, (size_t)ntiles * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SMC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    u64 nk = 0;
+    for (u64 v : h) nk += v;
+    *nkilled_host = (int64_t)nk;
+    SMC_LAUNCH_CHECK();
+    return SMC_OK;
+}
+
+extern "C" int smc_killing_ancestors(smc_ctx* ctx, const unsigned char* killed_dev, const int64_t* Am,
+                                     int64_t N, int64_t* A)
+{
+    SMC_REQUIRE(ctx && killed_dev && A, "null argument");
+    SMC_REQUIRE(N > 0, "N must be positive");
+    const int ntiles = (int)((N + OPS_TILE - 1) / OPS_TILE);
+    void* scr;
+    int rc = smc_scratch(ctx, (size_t)ntiles * sizeof(u64), &scr);
+    if (rc) return rc;
+    // tile totals of the flags (k_residual-style sum over bytes)
+    SMC_LAUNCH(k_flag_tile_sums, dim3(ntiles), dim3(SMC_BLOCK), ctx->stream, killed_dev, (i64)N, (u64*)scr);
+    SMC_LAUNCH(k_killing_assign, dim3(ntiles), dim3(SMC_BLOCK), ctx->stream, killed_dev, (const i64*)Am,
+               (i64)N, (const u64*)scr, (i64*)A);
+    SMC_LAUNCH_CHECK();
+    return SMC_OK;
+}
+
 // ---- uniform_spacings on the device (resampling.py:512-537) ----------------
 // e_n = -log(u_n), n = 0..M, in fixed point so that the running sums are
 // exact and the resulting su is monotone:  su[n] = (e_0+..+e_n) / (e_0+..+e_M)

@@ -240,6 +240,56 @@ def systematic(W, M):
     return _resample("systematic", W, M)
 
 
+@resampling_scheme
+def residual(W, M):
+    """Residual resampling (resampling.py:611-626): ``floor(M W)`` copies of every
+    particle, then a multinomial draw of the remaining ``M - sum floor(M W)`` on the
+    residuals -- both parts on the device."""
+    Wd, host = as_device(W)
+    N = Wd.size
+    r = DeviceArray((N,))
+    sip = _lib.c_i64()
+    check(lib().smc_residual_split(Wd.ctx.h, Wd.ptr, N, M, r.ptr, ctypes.byref(sip)))
+    sres = M - sip.value
+    A = DeviceArray((M,), np.int64)
+    su = None
+    if sres > 0:                      # multinomial(res / sres, M=sres): its draws (:536)
+        su = uniform_spacings(sres)
+        su = su if isinstance(su, DeviceArray) else DeviceArray.from_numpy(su)
+    check(lib().smc_residual_ancestors(Wd.ctx.h, Wd.ptr, r.ptr, N, M, sip.value,
+                                       su.ptr if su is not None else None, A.ptr))
+    return A.get() if host else A
+
+
+@resampling_scheme
+def killing(W, M):
+    """Killing resampling (resampling.py:680-697): keep particle i with probability
+    ``W[i] / W.max()``, otherwise replace it by a multinomial draw.  Requires M = N."""
+    Wd, host = as_device(W)
+    N = Wd.size
+    if M != N:
+        raise ValueError("killing resampling defined only for M=N")
+    if host and _RNG_MODE == "numpy":
+        u = DeviceArray.from_numpy(random.rand(N))                 # :692
+    else:
+        u = DeviceArray((N,))
+        check(lib().smc_uniform(u.ctx.h, _lib.next_counter(), N, u.ptr))
+    killed = DeviceArray(((N + 7) // 8,))           # N bytes of flags
+    nk = _lib.c_i64()
+    check(lib().smc_killing_split(Wd.ctx.h, Wd.ptr, u.ptr, N, killed.ptr, ctypes.byref(nk)))
+    Am = None
+    if host and _RNG_MODE == "numpy":     # multinomial(W, nkilled) on the reference's draws (:695);
+        su = uniform_spacings(nk.value)   # with nkilled = 0 it still consumes rand(1)
+        if nk.value > 0:
+            Am = inverse_cdf(DeviceArray.from_numpy(su), Wd)
+    elif nk.value > 0:
+        Am = multinomial(Wd, M=nk.value)
+    A = DeviceArray((N,), np.int64)
+    check(lib().smc_killing_ancestors(Wd.ctx.h, killed.ptr, Am.ptr if Am is not None else None,
+                                      N, A.ptr))
+    return A.get() if host else A
+
+
 def multinomial_iid(W, M=None):
     """Multinomial resampling, randomly permuted (resampling.py:561-571)."""
     A = multinomial(W, M=M)

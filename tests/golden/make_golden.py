@@ -119,6 +119,20 @@ def main():
     res["spacings_100"] = rs.uniform_spacings(100)
     out["resampling"] = res
 
+    # --- residual and killing (resampling.py:611-626, 680-697), same weights --------------
+    res2 = dict(W=W)
+    for M in (1500, 400, 4000):
+        np.random.seed(11)
+        res2["A_residual_%d" % M] = rs.resampling("residual", W, M=M)
+    np.random.seed(11)
+    res2["A_killing_1500"] = rs.resampling("killing", W, M=1500)
+    Wd = np.zeros(64)
+    Wd[[3, 17, 40]] = [0.5, 0.25, 0.25]         # M W integral: no residual draw at all
+    np.random.seed(11)
+    res2["W_integral"] = Wd
+    res2["A_residual_integral"] = rs.resampling("residual", Wd, M=64)
+    out["resampling2"] = res2
+
     # --- Weights / log-sum-exp helpers --------------------------------------
     np.random.seed(3)
     lw = 10.0 * np.random.randn(1000)

@@ -113,6 +113,54 @@ def check_schemes_vs_reference(golden):
                 assert ok and n <= 1
 
 
+def check_residual_killing(golden):
+    """residual / killing (resampling.py:611-626, 680-697) on the device: same numpy
+    seed as the reference run; bit-exact against the oracle on the Q62 CDF, and equal to
+    the reference's ancestors except at audited near-ties of the multinomial part."""
+    g = golden("resampling2")
+    W = g["W"]
+    for M in (1500, 400, 4000):
+        np.random.seed(11)
+        A = rs.resampling("residual", W, M=M)
+        np.random.seed(11)
+        want = orc.residual(W, M, cdf="q62")
+        ref = g["A_residual_%d" % M]
+        assert A.dtype == np.int64 and A.shape == (M,) and np.array_equal(A, want)
+        sip = int(np.floor(M * W).sum())
+        assert np.array_equal(A[:sip], ref[:sip])             # the deterministic copies
+        assert np.mean(A == ref) >= 0.999
+    np.random.seed(11)
+    A = rs.resampling("killing", W, M=1500)
+    np.random.seed(11)
+    assert np.array_equal(A, orc.killing(W, 1500, cdf="q62"))
+    assert np.mean(A == g["A_killing_1500"]) >= 0.999
+    import pytest
+    with pytest.raises(ValueError, match="killing resampling defined only for M=N"):
+        rs.resampling("killing", W, M=100)
+    # M W integral: no residual draw, and no uniform is consumed (the reference draws none)
+    np.random.seed(11)
+    A = rs.resampling("residual", g["W_integral"], M=64)
+    assert np.array_equal(A, g["A_residual_integral"])
+    assert np.random.rand() == np.random.RandomState(11).rand()
+    # registry and the generic SMC path
+    assert {"residual", "killing"} <= set(rs.rs_funcs)
+    # large, Philox draws on the device: offspring counts of residual are floor(M W) or more
+    rng = np.random.default_rng(5)
+    N = 50000
+    Wl = orc.exp_and_normalise(2.0 * rng.standard_normal(N))
+    rs.set_rng("philox")
+    try:
+        Ad = rs.resampling("residual", pa.DeviceArray.from_numpy(Wl), M=N).get()
+        Ak = rs.resampling("killing", pa.DeviceArray.from_numpy(Wl), M=N).get()
+    finally:
+        rs.set_rng("numpy")
+    cnt = np.bincount(Ad, minlength=N)
+    assert cnt.sum() == N and np.all(cnt >= np.floor(N * Wl))
+    kept = Ak == np.arange(N)
+    assert abs(kept.mean() - np.mean(Wl / Wl.max())) < 0.02          # P(keep i) = W_i / max W
+    assert Ak.min() >= 0 and Ak.max() < N
+
+
 def check_schemes_replay(N, M, seed=1):
     rng = np.random.default_rng(seed)
     W = orc.exp_and_normalise(2.5 * rng.standard_normal(N))

@@ -49,6 +49,10 @@ def test_resampling_statistics():
     pc.check_resampling_statistics(600, 40)
 
 
+def test_residual_killing(golden):
+    pc.check_residual_killing(golden)
+
+
 def test_unknown_scheme():
     pc.check_unknown_scheme()
 

@@ -58,6 +58,10 @@ def test_resampling_statistics():
     pc.check_resampling_statistics(2000, 200)
 
 
+def test_residual_killing(golden):
+    pc.check_residual_killing(golden)
+
+
 def test_unknown_scheme():
     pc.check_unknown_scheme()
 

@@ -90,6 +90,19 @@ def test_resampling_schemes(golden, scheme, M):
     assert A.dtype == np.int64 and np.array_equal(A, g["A_%s_%d" % (scheme, M)])
 
 
+def test_residual_killing(golden):
+    g = golden("resampling2")
+    for M in (1500, 400, 4000):
+        np.random.seed(11)
+        assert np.array_equal(orc.residual(g["W"], M), g["A_residual_%d" % M])
+    np.random.seed(11)
+    assert np.array_equal(orc.killing(g["W"], 1500), g["A_killing_1500"])
+    np.random.seed(11)
+    assert np.array_equal(orc.residual(g["W_integral"], 64), g["A_residual_integral"])
+    with pytest.raises(ValueError):
+        orc.killing(g["W"], 10)
+
+
 def test_uniform_spacings(golden):
     np.random.seed(5)
     su = orc.uniform_spacings_from(np.random.rand(101))
