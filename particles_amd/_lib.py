@@ -169,6 +169,13 @@ _default_ctx = None
 _counter = 0
 
 
+# Where host-facing operators take their random draws from: "numpy" = the host's legacy
+# generator, in the reference's order (a run seeded with numpy.random.seed reproduces the
+# reference's run); "philox" = the device's counter-based generator.  Device-resident inputs
+# always use the device generator.  Set with particles_amd.resampling.set_rng().
+RNG_MODE = ["numpy"]
+
+
 def default_device():
     return int(os.environ.get("SMC_HIP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
 

@@ -92,13 +92,27 @@ class _DeviceWeights:
         return self._smc.N
 
 
+_seed_counter = [0]
+
+
+def _default_seed():
+    """Philox key of a run created without ``seed``: a function of numpy's legacy generator
+    state (so ``numpy.random.seed`` makes runs repeatable) that does NOT advance it -- the
+    reference's ``SMC.__init__`` draws nothing, and a run replaying the reference's draws
+    must find the stream where the reference finds it."""
+    import zlib
+    st = np.random.get_state()
+    _seed_counter[0] += 1
+    return (zlib.crc32(st[1].tobytes()) ^ (int(st[2]) * 2654435761) ^ (_seed_counter[0] << 20)) & (2 ** 31 - 1)
+
+
 class SMC:
     """Particle filter / SMC algorithm (core.py:200-409), device-resident.
 
     Parameters are those of ``particles.SMC`` (core.py:258-268); extras:
 
-    seed : int, optional -- Philox key of this run (default: drawn from
-        ``numpy.random`` like ``utils.distinct_seeds`` would)
+    seed : int, optional -- Philox key of this run (default: derived from the state of
+        ``numpy.random`` without advancing it)
     n_islands : int -- number of independent replicas advanced together
         (the batched form of ``multiSMC``); attributes refer to island 0,
         ``logLts_islands`` has them all
@@ -128,7 +142,7 @@ class SMC:
         self.hist = collectors.generate_hist_obj(store_history, self)
         self._store_history = store_history
         if seed is None:
-            seed = int(np.random.randint(0, 2 ** 31 - 1))
+            seed = _default_seed()
         self.seed = seed
         self._f = None
         self._n = 0          # steps executed on the device
@@ -322,10 +336,20 @@ class SMC:
 
     # ------------------------------------------------- generic template method
     def reset_weights(self):
-        self.wgts = rs.Weights()                                   # core.py:299-305
+        """Reset weights after a resampling step (core.py:299-305)."""
+        if self.fk.isAPF:
+            lw = rs.log_mean_exp(self.logetat, W=self.W) - self.logetat[self.A]
+            self.wgts = rs.Weights(lw=lw)
+        else:
+            self.wgts = rs.Weights()
 
     def setup_auxiliary_weights(self):
-        self.aux = self.wgts                                       # core.py:307-313 (non-APF)
+        """Auxiliary weights of the APF (core.py:307-313)."""
+        if self.fk.isAPF:
+            self.logetat = self.fk.logeta(self.t - 1, self.X)
+            self.aux = self.wgts.add(self.logetat)
+        else:
+            self.aux = self.wgts
 
     def generate_particles(self):
         self.X = self.fk.M0(self.N)                                # core.py:315-321

@@ -9,6 +9,7 @@ the device's counted Philox stream (``particles_amd.seed``) -- or, with
 how the parity tests replay the reference's own draws.
 """
 import numpy as np
+from numpy import random
 import numpy.linalg as nla
 
 from . import _lib
@@ -75,6 +76,8 @@ class Normal(LocScaleDist):
         N = _bsize(self.loc, self.scale) if size is None else int(size)
         loc, ls, d1 = _strided(self.loc, N)
         sc, ss, d2 = _strided(self.scale, N)
+        if z is None and _lib.RNG_MODE[0] == "numpy" and not (d1 or d2):
+            z = random.standard_normal(N)      # random.normal(loc, scale, N) draws exactly these
         zd = None
         if z is not None:
             zd = z if isinstance(z, DeviceArray) else DeviceArray.from_numpy(
@@ -142,6 +145,8 @@ class MvNormal(ProbDist):
         else:
             N = int(size)
         loc, rows, dev = self._loc(N)
+        if z is None and _lib.RNG_MODE[0] == "numpy" and not dev:
+            z = random.standard_normal((N, self.dim))      # stats.norm.rvs(size=(N, d)) (:968)
         zd = None
         if z is not None:
             zd = z if isinstance(z, DeviceArray) else DeviceArray.from_numpy(

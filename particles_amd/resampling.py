@@ -27,15 +27,13 @@ from numpy import random
 from . import _lib
 from ._lib import DeviceArray, as_device, check, lib
 
-_RNG_MODE = "numpy"
 
 
 def set_rng(mode):
     """'numpy' (reference-compatible draws on the host) or 'philox' (device)."""
-    global _RNG_MODE
     if mode not in ("numpy", "philox"):
         raise ValueError("rng mode must be 'numpy' or 'philox'")
-    _RNG_MODE = mode
+    _lib.RNG_MODE[0] = mode
 
 
 def _normalise(lw_dev, want_W=True):
@@ -197,7 +195,7 @@ def uniform_spacings(N):
     (that part is RNG plumbing, not the hot path); 'philox' mode: drawn and
     scanned on the device, returned as a DeviceArray.
     """
-    if _RNG_MODE == "numpy":
+    if _lib.RNG_MODE[0] == "numpy":
         z = np.cumsum(-np.log(random.rand(N + 1)))
         return z[:-1] / z[-1]
     su = DeviceArray((N,))
@@ -209,7 +207,7 @@ def _resample(scheme, W, M):
     Wd, host = as_device(W)
     A = DeviceArray((M,), np.int64)
     u = None
-    if host and _RNG_MODE == "numpy":
+    if host and _lib.RNG_MODE[0] == "numpy":
         # the reference's draws, in the reference's order (:536, :602, :609)
         if scheme == "systematic":
             u = DeviceArray.from_numpy(random.rand(1))
@@ -269,7 +267,7 @@ def killing(W, M):
     N = Wd.size
     if M != N:
         raise ValueError("killing resampling defined only for M=N")
-    if host and _RNG_MODE == "numpy":
+    if host and _lib.RNG_MODE[0] == "numpy":
         u = DeviceArray.from_numpy(random.rand(N))                 # :692
     else:
         u = DeviceArray((N,))
@@ -278,7 +276,7 @@ def killing(W, M):
     nk = _lib.c_i64()
     check(lib().smc_killing_split(Wd.ctx.h, Wd.ptr, u.ptr, N, killed.ptr, ctypes.byref(nk)))
     Am = None
-    if host and _RNG_MODE == "numpy":     # multinomial(W, nkilled) on the reference's draws (:695);
+    if host and _lib.RNG_MODE[0] == "numpy":     # multinomial(W, nkilled) on the reference's draws (:695);
         su = uniform_spacings(nk.value)   # with nkilled = 0 it still consumes rand(1)
         if nk.value > 0:
             Am = inverse_cdf(DeviceArray.from_numpy(su), Wd)

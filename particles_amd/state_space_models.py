@@ -120,6 +120,27 @@ class GuidedPF(Bootstrap):
                 - self.ssm.proposal(t, xp, self.data).logpdf(x))
 
 
+class APFMixin:
+    def logeta(self, t, x):
+        return self.ssm.logeta(t, x, self.data)
+
+
+class AuxiliaryPF(GuidedPF, APFMixin):
+    """Auxiliary particle filter (state_space_models.py:406-428); ``ssm`` must implement
+    ``proposal0``, ``proposal`` and ``logeta``.  Runs the template-method step with device
+    operators (the auxiliary weights are one more ``Weights.add`` / weighted log-mean-exp)."""
+
+    def _device_model(self):
+        return None
+
+
+class AuxiliaryBootstrap(Bootstrap, APFMixin):
+    """APF whose proposal is the transition kernel (state_space_models.py:431-438)."""
+
+    def _device_model(self):
+        return None
+
+
 class StochVol(StateSpaceModel):
     r"""Univariate stochastic volatility model (state_space_models.py:446-473).
 
@@ -142,6 +163,24 @@ class StochVol(StateSpaceModel):
 
     def PY(self, t, xp, x):
         return dists.Normal(loc=0.0, scale=np.exp(0.5 * x))
+
+    # Pitt & Shephard's proposal and auxiliary function (state_space_models.py:475-498)
+    def _xhat(self, xst, sig, yt):
+        return xst + 0.5 * sig ** 2 * (yt ** 2 * np.exp(-xst) - 1.0)
+
+    def proposal0(self, data):
+        return dists.Normal(loc=self._xhat(0.0, self.sig0(), data[0]), scale=self.sig0())
+
+    def proposal(self, t, xp, data):
+        return dists.Normal(loc=self._xhat(self.EXt(xp), self.sigma, data[t]), scale=self.sigma)
+
+    def logeta(self, t, x, data):
+        xst = self.EXt(x)
+        xstmmu = xst - self.mu
+        xhat = self._xhat(xst, self.sigma, data[t + 1])
+        xhatmmu = xhat - self.mu
+        return 0.5 / self.sigma ** 2 * (xhatmmu ** 2 - xstmmu ** 2) - 0.5 * data[
+            t + 1] ** 2 * np.exp(-xst) * (1.0 + xstmmu)
 
     def _device_params(self, fk_kind):
         if fk_kind != _lib.FK_BOOTSTRAP:

@@ -76,6 +76,10 @@ def main():
     out["gordon_boot"] = run_case(ssm.Gordon_etal(), ssm.Bootstrap, 40, 600, "systematic", 0.5)
     out["theta_boot"] = run_case(ssm.ThetaLogistic(), ssm.Bootstrap, 40, 600, "stratified", 0.5)
 
+    # --- auxiliary particle filter (core.py:299-313), Pitt & Shephard's StochVol proposal
+    out["sv_apf"] = run_case(ssm.StochVol(), ssm.AuxiliaryPF, 30, 500, "systematic", 0.5)
+    out["sv_guided"] = run_case(ssm.StochVol(), ssm.GuidedPF, 30, 500, "systematic", 0.5)
+
     # --- full particle history + genealogy (smoothing.py:181-255), adaptive
     # resampling so that some A_t are arange ---------------------------------
     np.random.seed(42)

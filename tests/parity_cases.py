@@ -606,6 +606,31 @@ def check_generic_path(golden):
     assert len(pf.hist.X) == 30 and pf.hist.compute_trajectories().shape == (30, 4000)
 
 
+def check_apf_and_guided_generic(golden):
+    """The template-method step with device operators, on the reference's own draws
+    (same numpy seed): the auxiliary particle filter (core.py:299-313; Pitt & Shephard's
+    proposal for StochVol, state_space_models.py:475-498) and the guided filter of the same
+    model, against the reference's outputs."""
+    for case, cls in (("sv_apf", ssm.AuxiliaryPF), ("sv_guided", ssm.GuidedPF)):
+        g = golden(case)
+        y = list(g["y"])
+        np.random.seed(int(g["run_seed"]))
+        pf = pa.SMC(fk=cls(ssm=ssm.StochVol(), data=y), N=int(g["N"]),
+                    resampling=str(g["scheme"]), ESSrmin=float(g["ESSrmin"]))
+        assert not pf._fused and pf.fk.isAPF == (case == "sv_apf")
+        pf.run()
+        assert pf.summaries.rs_flags == [bool(v) for v in g["rs_flags"]]
+        assert rel(pf.summaries.ESSs, g["ESSs"]) < 1e-9
+        assert rel(pf.summaries.logLts, g["logLts"]) < 1e-9
+        assert abs(pf.logLt / float(g["logLt"]) - 1) < 1e-10
+        same = np.mean(pf.A == g["A"])
+        assert same >= 0.999
+        if same == 1.0:
+            assert np.max(np.abs(pf.X - g["X"])) < 1e-12
+            assert np.allclose(pf.wgts.lw, g["lw"], rtol=1e-10, atol=1e-10)
+            assert rel(pf.W, g["W"]) < 1e-9
+
+
 def check_collectors_on_fused(golden):
     from particles_amd.collectors import Moments
     g = golden("kalman_toy")

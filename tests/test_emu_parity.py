@@ -124,5 +124,9 @@ def test_islands(golden):
     pc.check_islands(1100, 6, golden, scheme="multinomial")
 
 
+def test_apf_and_guided_generic(golden):
+    pc.check_apf_and_guided_generic(golden)
+
+
 def test_collectors_and_history(golden):
     pc.check_collectors_on_fused(golden)

@@ -139,6 +139,10 @@ def test_generic_path(golden):
     pc.check_generic_path(golden)
 
 
+def test_apf_and_guided_generic(golden):
+    pc.check_apf_and_guided_generic(golden)
+
+
 def test_mv_philox_kalman():
     pc.check_mv_kalman(1 << 16, 4, "guided")
     pc.check_mv_kalman(20000, 6, "guided", scheme="stratified")
