@@ -168,6 +168,8 @@ def main():
     pf = make()
     pf.step_async(W)
     pf.sync()
+    if grp:       # warm-up of the path's one collective too (RCCL sets its channels up lazily)
+        grp.gather_evidence(pf.logLts_islands)
     # ---- timed region: exactly K steps, barrier + device sync on both sides
     if grp:
         grp.barrier()

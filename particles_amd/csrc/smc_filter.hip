@@ -183,6 +183,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     // q is only materialised when k_prepare runs (more tiles than k_ancestors<true> handles)
     // (published tile totals pay off only while every workgroup of the launch is resident)
     f->fused = (i64)a.ntiles * (i64)M <= F_DIRECT_PREFIX_MAX;
+    if (getenv("SMC_FORCE_FUSED")) f->fused = a.ntiles <= F_DIRECT_PREFIX_MAX;   // experiments
     const size_t oq = carve(f->fused ? 8 : M * N * 8);
     const size_t oQ = carve(M * a.ntiles * 8);
     const size_t oQpre = carve(M * a.ntiles * 8);
