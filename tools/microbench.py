@@ -48,3 +48,18 @@ timeit("d2d copy 8N", lambda: L.smc_memcpy_d2d(ctx.h, out.ptr, x.ptr, 8 * N), 16
 u = DeviceArray.from_numpy(np.array([0.3]))
 timeit("resample systematic", lambda: L.smc_resample(ctx.h, 2, W.ptr, N, N, u.ptr, 0, A.ptr), 24 * N)
 timeit("resample stratified philox", lambda: L.smc_resample(ctx.h, 1, W.ptr, N, N, None, 0, A.ptr), 24 * N)
+
+# ---- PCIe-inclusive rate of the host-facing (numpy in -> numpy out) operators
+import time
+from particles_amd import resampling as rs
+Wh = W.get()
+lwh = lw.get()
+for name, fn, nbytes in (
+        ("rs.systematic host->host", lambda: rs.systematic(Wh, N), 16 * N),
+        ("rs.Weights host->host", lambda: rs.Weights(lw=lwh.copy()).W, 16 * N)):
+    fn()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        fn()
+    dt = (time.perf_counter() - t0) / 20
+    print("%-28s %8.1f us   %8.2f GB/s over PCIe (H2D + D2H incl. numpy-side copies)" % (name, dt * 1e6, nbytes / dt / 1e9))
