@@ -131,6 +131,13 @@ int smc_mvn_logpdf(smc_ctx* ctx, const double* x, int64_t x_rows,
                    const double* loc, int64_t loc_rows, double scale,
                    const double* L_host, int64_t N, int64_t d, double* out);
 
+/* ---- (f) weighted quantiles (resampling.py:381-417 wquantiles) -------------
+ * W (N), x (N,d) device; alphas_host (k) levels; out_host (d,k): for every column the
+ * np.interp-olated alpha-quantiles of the weighted sample (argsort, cumsum of the weights
+ * in that order, searchsorted, 2-point interpolation). */
+int smc_wquantiles(smc_ctx* ctx, const double* W, const double* x, int64_t N, int64_t d,
+                   const double* alphas_host, int k, double* out_host);
+
 /* ---- (f) remaining schemes of rs_funcs ------------------------------------
  * residual (resampling.py:611-626), two calls because the reference draws
  * uniform_spacings(M - sip) AFTER it knows sip = sum floor(M W):

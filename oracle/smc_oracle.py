@@ -663,6 +663,23 @@ def run_filter(model, data, N, scheme="systematic", ESSrmin=0.5, fk="bootstrap",
     return out
 
 
+def wquantiles(W, x, alphas=(0.25, 0.50, 0.75)):
+    """resampling.py:381-417 (``_wquantiles`` per column)."""
+    def one(xc):
+        N = W.shape[0]
+        order = np.argsort(xc)
+        cw = np.cumsum(W[order])
+        indices = np.searchsorted(cw, alphas)
+        out = []
+        for a, n in zip(alphas, indices):
+            prev = np.clip(n - 1, 0, N - 2)
+            out.append(np.interp(a, cw[prev:prev + 2], xc[order[prev:prev + 2]]))
+        return out
+    if x.ndim == 1:
+        return one(x)
+    return np.array([one(x[:, i]) for i in range(x.shape[1])])
+
+
 def compute_trajectories(A_list, N):
     """Genealogy of the final particles (smoothing.py:209-219
     ParticleHistory.compute_trajectories): B_{T-1} = arange(N), B_{t-1} = A_t[B_t];

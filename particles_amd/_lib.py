@@ -82,6 +82,7 @@ SIGNATURES = {
     "smc_filter_t": (c_int, [c_vp, P(c_i64)]),
     "smc_filter_summaries": (c_int, [c_vp, P(c_dbl)]),
     "smc_filter_logLt": (c_int, [c_vp, P(c_dbl)]),
+    "smc_wquantiles": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, P(c_dbl), c_int, P(c_dbl)]),
     "smc_residual_split": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, P(c_i64)]),
     "smc_residual_ancestors": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp]),
     "smc_killing_split": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, P(c_i64)]),

@@ -98,6 +98,23 @@ def wmean_and_var(W, x):
     return {"mean": o[:dd], "var": o[dd:]}
 
 
+def wquantiles(W, x, alphas=(0.25, 0.50, 0.75)):
+    """Quantiles for weighted data (resampling.py:381-417): ``(k,)`` for ``x`` of shape
+    ``(N,)``, ``(d, k)`` for ``(N, d)``."""
+    Wd, _ = as_device(W)
+    xd, _ = as_device(x)
+    N = Wd.size
+    dd = xd.size // N
+    al = np.ascontiguousarray(alphas, dtype=np.float64)
+    out = np.empty((dd, al.size))
+    check(lib().smc_wquantiles(Wd.ctx.h, Wd.ptr, xd.ptr, N, dd,
+                               al.ctypes.data_as(_lib.P(_lib.c_dbl)), al.size,
+                               out.ctypes.data_as(_lib.P(_lib.c_dbl))))
+    if xd.ndim == 1:
+        return list(out[0])
+    return out
+
+
 class Weights:
     """N log-weights with their normalised weights and ESS (resampling.py:191-244).
 

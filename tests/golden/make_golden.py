@@ -151,6 +151,8 @@ def main():
         lse=rs.log_sum_exp(w.lw), lme=rs.log_mean_exp(w.lw),
         lme_w=rs.log_mean_exp(w2.lw, W=w.W), essl=rs.essl(w.lw),
         ean=rs.exp_and_normalise(w.lw),
+        wq=np.array(rs.wquantiles(w.W, np.sin(np.arange(1000.0)), alphas=(0.05, 0.25, 0.5, 0.75, 0.999)))
+        , wq2=rs.wquantiles(w.W, np.stack([np.sin(np.arange(1000.0)), np.cos(3.0 * np.arange(1000.0))], axis=1)),
         wmean=rs.wmean_and_var(w.W, np.sin(np.arange(1000.0)))["mean"],
         wvar=rs.wmean_and_var(w.W, np.sin(np.arange(1000.0)))["var"])
 

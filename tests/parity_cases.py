@@ -50,6 +50,25 @@ def check_weights(golden):
     assert abs(mv["mean"] - g["wmean"]) < 1e-13 and abs(mv["var"] - g["wvar"]) < 1e-13
 
 
+def check_wquantiles(golden):
+    """rs.wquantiles (resampling.py:381-417): device sort + running sums against the
+    reference's values, and against the oracle on a larger weighted sample."""
+    g = golden("weights")
+    x = np.sin(np.arange(1000.0))
+    q = rs.wquantiles(g["W"], x, alphas=(0.05, 0.25, 0.5, 0.75, 0.999))
+    assert np.allclose(q, g["wq"], rtol=1e-12, atol=1e-13)
+    x2 = np.stack([x, np.cos(3.0 * np.arange(1000.0))], axis=1)
+    q2 = rs.wquantiles(g["W"], x2)
+    assert q2.shape == (2, 3) and np.allclose(q2, g["wq2"], rtol=1e-12, atol=1e-13)
+    rng = np.random.default_rng(8)
+    N = 200001
+    W = orc.exp_and_normalise(1.5 * rng.standard_normal(N))
+    xs = rng.standard_normal(N)
+    al = (0.001, 0.1, 0.5, 0.9, 0.9999)
+    assert np.allclose(rs.wquantiles(W, xs, alphas=al), orc.wquantiles(W, xs, alphas=al),
+                       rtol=1e-9, atol=1e-9)
+
+
 def check_weights_edges(N):
     w = rs.Weights(lw=np.full(N, -np.inf))                   # SURVEY appendix B
     assert np.isnan(w.W).all() and np.isnan(w.ESS) and np.isnan(w.log_mean)

@@ -49,6 +49,10 @@ def test_resampling_statistics():
     pc.check_resampling_statistics(600, 40)
 
 
+def test_wquantiles(golden):
+    pc.check_wquantiles(golden)
+
+
 def test_residual_killing(golden):
     pc.check_residual_killing(golden)
 

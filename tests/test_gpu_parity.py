@@ -58,6 +58,10 @@ def test_resampling_statistics():
     pc.check_resampling_statistics(2000, 200)
 
 
+def test_wquantiles(golden):
+    pc.check_wquantiles(golden)
+
+
 def test_residual_killing(golden):
     pc.check_residual_killing(golden)
 

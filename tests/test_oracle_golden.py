@@ -128,6 +128,14 @@ def test_weights(golden):
     assert mv["mean"] == g["wmean"] and mv["var"] == g["wvar"]
 
 
+def test_wquantiles(golden):
+    g = golden("weights")
+    x = np.sin(np.arange(1000.0))
+    assert np.array_equal(np.array(orc.wquantiles(g["W"], x, alphas=(0.05, 0.25, 0.5, 0.75, 0.999))), g["wq"])
+    x2 = np.stack([x, np.cos(3.0 * np.arange(1000.0))], axis=1)
+    assert np.array_equal(orc.wquantiles(g["W"], x2), g["wq2"])
+
+
 def test_weights_edge_cases():
     with np.errstate(all="ignore"):
         w = orc.Weights(lw=np.full(5, -np.inf))
