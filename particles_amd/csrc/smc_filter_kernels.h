@@ -493,7 +493,7 @@ k_ancestors(const FArgs av)
             su.u_sys = smc_u01_halfopen(x0);
         }
     }
-    const bool scatter = (a.scheme == SMC_SYSTEMATIC_) && a.log2N >= 0;
+    const bool scatter = (a.scheme == SMC_SYSTEMATIC_ || a.scheme == SMC_STRATIFIED_) && a.log2N >= 0;
     i64 n_lo, n_hi;
     i64 ns[F_IPT + 1];
     if (scatter) {
@@ -505,7 +505,9 @@ k_ancestors(const FArgs av)
         for (int i = 0; i <= F_IPT; ++i) {
             const i64 j = jt + i;
             ns[i] = (j == 0) ? 0
-                             : (j >= N ? N : smc_sys_count_pow2_fast(c, su.u_sys, Us, a.log2N, N));
+                  : (j >= N ? N
+                     : (a.scheme == SMC_SYSTEMATIC_ ? smc_sys_count_pow2_fast(c, su.u_sys, Us, a.log2N, N)
+                                                    : smc_strat_count_pow2(c, su, a.log2N, N)));
             if (i < F_IPT) c += q4[i];
         }
         if (tid == 0) sn[0] = ns[0];

@@ -128,6 +128,28 @@ __device__ __forceinline__ i64 smc_sys_count_pow2_fast(u64 C, double u, u64 Us, 
     return smc_sys_count_pow2(C, u, k, M);
 }
 
+// Stratified draws with M = 2^k outputs: su_n = fl(u_n + n) / 2^k lies in [n, n+1] / 2^k just
+// like the systematic ones, so the same closed form holds with the n-th uniform:
+//     count(C) = nc + [T_nc <= C],   nc = floor(C / 2^(62-k)),  T_nc = ceil(fl(u_nc + nc) 2^(62-k))
+// (one Philox call, or one tape read, per evaluation).
+__device__ __forceinline__ i64 smc_strat_count_pow2(u64 C, const SmcSu& s, int k, i64 M)
+{
+    const int sh = 62 - k;
+    const u64 nc = C >> sh;
+    if (nc >= (u64)M) return M;
+    double un;
+    if (s.u) {
+        un = s.u[nc];
+    } else {
+        u64 a, b;
+        smc_philox((u32)(nc >> 1), s.t, s.island, SMC_STREAM_RESAMPLE, s.seed, a, b);
+        un = smc_u01_halfopen((nc & 1) ? b : a);
+    }
+    const double scale = __longlong_as_double((long long)(1023 + sh) << 52);   // 2^sh
+    const u64 T = (u64)ceil((un + (double)(i64)nc) * scale);
+    return (i64)nc + (T <= C ? 1 : 0);
+}
+
 // ---------------------------------------------------------------------------
 // Per-tile CDF in LDS.
 //   wq[i] (i < IPT): this thread's quantised weights, particles j0+tid*IPT+i

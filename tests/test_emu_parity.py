@@ -104,6 +104,13 @@ def test_nonlinear_models_philox(golden, case, model):
     pc.check_model_philox_vs_oracle(golden, case, model, N=4000)
 
 
+@pytest.mark.parametrize("case,N", [("toy_stratified", 1024), ("toy_stratified", 4096),
+                                    ("toy_systematic", 2048), ("toy_multinomial", 1024)])
+def test_filter_replay_power_of_two(golden, case, N):
+    """N = 2^k takes the closed-form offspring counts (systematic and stratified)."""
+    pc.check_filter_replay(golden, case, "toy", "bootstrap", T=20, N=N)
+
+
 def test_edge_sizes():
     pc.check_edge_sizes()
 
