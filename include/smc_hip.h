@@ -167,7 +167,8 @@ enum smc_model_kind {
     SMC_MODEL_STOCHVOL = 2,   /* state_space_models.py:446-473 */
     SMC_MODEL_MVLINGAUSS = 3, /* kalman.py:296-361 */
     SMC_MODEL_GORDON = 4,     /* state_space_models.py:546-577 (bootstrap) */
-    SMC_MODEL_THETALOGISTIC = 5 /* state_space_models.py:657-683 (bootstrap) */
+    SMC_MODEL_THETALOGISTIC = 5, /* state_space_models.py:657-683 (bootstrap) */
+    SMC_MODEL_SVLEVERAGE = 6  /* state_space_models.py:501-541 StochVolLeverage (bootstrap) */
 };
 enum smc_fk_kind {
     SMC_FK_BOOTSTRAP = 0,     /* state_space_models.py:299-349 */
@@ -192,7 +193,8 @@ typedef struct smc_model {
      *   STOCHVOL: 0 mu, 1 rho, 2 sigma, 3 sigma/sqrt(1-rho^2), 4 (1-rho)*mu
      *   GORDON:   0 b, 1 sigmaX, 2 c, 3 sigma0 (2.0), 5 a;  aux_host[t] = d*cos(e*(t-1))
      *   THETALOGISTIC: 0 tau0, 1 sigmaX, 2 sigmaY, 3 sigma0 (1.0), 4 log(sigmaY),
-     *             5 tau1, 6 tau2 */
+     *             5 tau1, 6 tau2
+     *   SVLEVERAGE: as STOCHVOL, plus 5 phi, 6 sqrt(1 - phi^2) */
     const double* params_host;
     /* MVLINGAUSS (HOST, row-major): F(dx,dx) G(dy,dx) covX(dx,dx) covY(dy,dy)
      * mu0(dx) cov0(dx,dx); shared by all islands */

@@ -437,6 +437,23 @@ class StochVol:
         return normal_logpdf(y, loc=0.0, scale=np.exp(0.5 * x))
 
 
+class StochVolLeverage(StochVol):
+    """state_space_models.py:501-541: PY depends on (x_{t-1}, x_t)."""
+
+    def __init__(self, mu=-1.02, rho=0.9702, sigma=0.178, phi=0.0):
+        StochVol.__init__(self, mu, rho, sigma)
+        self.phi = phi
+
+    def py_logpdf(self, y, xp, x):       # :531-541 (xp is None at t = 0)
+        if xp is None:
+            u = (x - self.mu) / self.sig0()
+        else:
+            u = (x - self.px(xp)[0]) / self.sigma
+        std_x = np.exp(0.5 * x)
+        return normal_logpdf(y, loc=std_x * self.phi * u,
+                             scale=std_x * np.sqrt(1.0 - self.phi ** 2))
+
+
 class Gordon:
     """state_space_models.py:546-577 (``Gordon_etal``); the transition depends on t."""
     dim = 1

@@ -21,6 +21,7 @@ P = ctypes.POINTER
 MULTINOMIAL, STRATIFIED, SYSTEMATIC = 0, 1, 2
 SCHEMES = {"multinomial": MULTINOMIAL, "stratified": STRATIFIED, "systematic": SYSTEMATIC}
 MODEL_LINGAUSS, MODEL_STOCHVOL, MODEL_MVLINGAUSS, MODEL_GORDON, MODEL_THETALOGISTIC = 1, 2, 3, 4, 5
+MODEL_SVLEVERAGE = 6
 FK_BOOTSTRAP, FK_GUIDED = 0, 1
 FIELD_X, FIELD_XP, FIELD_A, FIELD_LW, FIELD_W = range(5)
 SUMMARY_COLS = 5

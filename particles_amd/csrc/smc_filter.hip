@@ -64,6 +64,7 @@ static void launch_propagate(smc_filter* f)
     P_CASE(SMC_MODEL_STOCHVOL, SMC_FK_BOOTSTRAP)
     P_CASE(SMC_MODEL_GORDON, SMC_FK_BOOTSTRAP)
     P_CASE(SMC_MODEL_THETALOGISTIC, SMC_FK_BOOTSTRAP)
+    P_CASE(SMC_MODEL_SVLEVERAGE, SMC_FK_BOOTSTRAP)
 #undef P_CASE
 }
 
@@ -111,7 +112,8 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     }
     const bool mv = model->kind == SMC_MODEL_MVLINGAUSS;
     SMC_REQUIRE(model->kind == SMC_MODEL_LINGAUSS || model->kind == SMC_MODEL_STOCHVOL || mv ||
-                    model->kind == SMC_MODEL_GORDON || model->kind == SMC_MODEL_THETALOGISTIC,
+                    model->kind == SMC_MODEL_GORDON || model->kind == SMC_MODEL_THETALOGISTIC ||
+                    model->kind == SMC_MODEL_SVLEVERAGE,
                 "fused filter: unknown model kind");
     SMC_REQUIRE(model->fk == SMC_FK_BOOTSTRAP ||
                     (model->fk == SMC_FK_GUIDED && (model->kind == SMC_MODEL_LINGAUSS || mv)),

@@ -112,6 +112,7 @@ __host__ __device__ __forceinline__ i64* f_A(const FArgs& a, i64 t) { return a.A
 //   STOCHVOL  mu, rho, sigma, sig0, (1-rho) mu
 //   GORDON    b, sigmaX, c, sigma0 (= 2), -, a          aux_t = d cos(e (t-1))
 //   THETALOG  tau0, sigmaX, sigmaY, sigma0 (= 1), log sigmaY, tau1, tau2
+//   SVLEVERAGE as STOCHVOL + 5 phi, 6 sqrt(1 - phi^2)
 template <int KIND>
 __device__ __forceinline__ double m_trans_loc(const double* p, double xp, double aux)
 {
@@ -125,17 +126,25 @@ __device__ __forceinline__ double m_trans_loc(const double* p, double xp, double
 template <int KIND>
 __device__ __forceinline__ double m_trans_scale(const double* p)
 {
-    return (KIND == SMC_MODEL_STOCHVOL) ? p[2] : p[1];
+    return (KIND == SMC_MODEL_STOCHVOL || KIND == SMC_MODEL_SVLEVERAGE) ? p[2] : p[1];
 }
 template <int KIND>
 __device__ __forceinline__ double m_init_loc(const double* p)
 {
-    return (KIND == SMC_MODEL_STOCHVOL) ? p[0] : 0.0;           // ssm.py:462 ; kalman.py:427, ssm.py:565, :675
+    return (KIND == SMC_MODEL_STOCHVOL || KIND == SMC_MODEL_SVLEVERAGE) ? p[0] : 0.0;   // ssm.py:462 ; kalman.py:427, ssm.py:565, :675
 }
 // log p(y_t | x_t) as scipy.stats.norm.logpdf evaluates it
 template <int KIND>
-__device__ __forceinline__ double m_obs_logpdf(const double* p, double y, double x)
+__device__ __forceinline__ double m_obs_logpdf(const double* p, double y, double x, double xp,
+                                               bool first)
 {
+    if (KIND == SMC_MODEL_SVLEVERAGE) {                         // ssm.py:531-541
+        const double u = first ? (x - p[0]) / p[3] : (x - (p[4] + p[1] * xp)) / p[2];
+        const double sx = exp(0.5 * x);
+        const double loc = sx * p[5] * u, sc = sx * p[6];
+        const double v = (y - loc) / sc;
+        return -(v * v) / 2.0 - SMC_C_NORM - log(sc);
+    }
     if (KIND == SMC_MODEL_LINGAUSS || KIND == SMC_MODEL_THETALOGISTIC) {   // kalman.py:433-434, ssm.py:682-683
         const double v = (y - x) / p[2];
         return -(v * v) / 2.0 - SMC_C_NORM - p[4];
@@ -162,7 +171,7 @@ __device__ __forceinline__ double m_step(const double* p, bool first, double y, 
     if (FK == SMC_FK_BOOTSTRAP) {
         const double x = first ? m_init_loc<KIND>(p) + p[3] * z
                                : m_trans_loc<KIND>(p, xp, aux) + m_trans_scale<KIND>(p) * z;
-        inc = m_obs_logpdf<KIND>(p, y, x);
+        inc = m_obs_logpdf<KIND>(p, y, x, xp, first);
         return x;
     }
     // guided filter with LinearGauss' optimal proposal (kalman.py:436-446,
@@ -170,13 +179,13 @@ __device__ __forceinline__ double m_step(const double* p, bool first, double y, 
     if (first) {
         const double mu = p[12] * (y / p[8]);
         const double x = mu + p[13] * z;
-        inc = (m_norm_logpdf(x, 0.0, p[3], p[6]) + m_obs_logpdf<KIND>(p, y, x))
+        inc = (m_norm_logpdf(x, 0.0, p[3], p[6]) + m_obs_logpdf<KIND>(p, y, x, xp, first))
               - m_norm_logpdf(x, mu, p[13], p[14]);
         return x;
     }
     const double mu = p[9] * (p[0] * xp / p[7] + y / p[8]);
     const double x = mu + p[10] * z;
-    inc = (m_norm_logpdf(x, p[0] * xp, p[1], p[5]) + m_obs_logpdf<KIND>(p, y, x))
+    inc = (m_norm_logpdf(x, p[0] * xp, p[1], p[5]) + m_obs_logpdf<KIND>(p, y, x, xp, first))
           - m_norm_logpdf(x, mu, p[10], p[11]);
     return x;
 }

@@ -190,6 +190,29 @@ class StochVol(StateSpaceModel):
         return dict(kind=_lib.MODEL_STOCHVOL, dx=1, dy=1, params=p)
 
 
+class StochVolLeverage(StochVol):
+    r"""Stochastic volatility with leverage (state_space_models.py:501-541): the innovations
+    of X_t and Y_t have correlation phi, i.e. Y_t | X_{t-1:t} ~ N(s phi z, s^2 (1 - phi^2)),
+    s = exp(x_t / 2), z = [x_t - mu - rho (x_{t-1} - mu)] / sigma."""
+    default_params = {"mu": -1.02, "rho": 0.9702, "sigma": 0.178, "phi": 0.0}
+
+    def PY(self, t, xp, x):
+        if t == 0:
+            u = (x - self.mu) / self.sig0()
+        else:
+            u = (x - self.EXt(xp)) / self.sigma
+        std_x = np.exp(0.5 * x)
+        return dists.Normal(loc=std_x * self.phi * u, scale=std_x * np.sqrt(1.0 - self.phi ** 2))
+
+    def _device_params(self, fk_kind):
+        if fk_kind != _lib.FK_BOOTSTRAP:
+            return None
+        p = np.zeros(_lib.PARAM_STRIDE)
+        p[:7] = [self.mu, self.rho, self.sigma, self.sig0(), (1.0 - self.rho) * self.mu, self.phi,
+                 np.sqrt(1.0 - self.phi ** 2)]
+        return dict(kind=_lib.MODEL_SVLEVERAGE, dx=1, dy=1, params=p)
+
+
 class Gordon_etal(StateSpaceModel):
     r"""Toy example of Gordon et al (1993) (state_space_models.py:546-577).
 

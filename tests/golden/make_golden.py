@@ -75,6 +75,8 @@ def main():
     # --- further univariate models of the fused family (state_space_models.py:546-577, 657-683)
     out["gordon_boot"] = run_case(ssm.Gordon_etal(), ssm.Bootstrap, 40, 600, "systematic", 0.5)
     out["theta_boot"] = run_case(ssm.ThetaLogistic(), ssm.Bootstrap, 40, 600, "stratified", 0.5)
+    out["svlev_boot"] = run_case(ssm.StochVolLeverage(phi=-0.5), ssm.Bootstrap, 40, 600,
+                                 "systematic", 0.5)
 
     # --- auxiliary particle filter (core.py:299-313), Pitt & Shephard's StochVol proposal
     out["sv_apf"] = run_case(ssm.StochVol(), ssm.AuxiliaryPF, 30, 500, "systematic", 0.5)

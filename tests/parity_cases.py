@@ -333,6 +333,7 @@ MODELS = {
              lambda: orc.Guarniero(alpha=0.4, dx=32)),
     "gordon": (lambda: ssm.Gordon_etal(), lambda: orc.Gordon()),
     "theta": (lambda: ssm.ThetaLogistic(), lambda: orc.ThetaLogistic()),
+    "svlev": (lambda: ssm.StochVolLeverage(phi=-0.5), lambda: orc.StochVolLeverage(phi=-0.5)),
 }
 
 

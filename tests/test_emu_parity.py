@@ -89,6 +89,7 @@ def test_mvn(golden):
     ("mv32_boot", "mv32", "bootstrap"),
     ("gordon_boot", "gordon", "bootstrap"),
     ("theta_boot", "theta", "bootstrap"),
+    ("svlev_boot", "svlev", "bootstrap"),
 ])
 def test_filter_replay(golden, case, model, fk):
     pc.check_filter_replay(golden, case, model, fk, T=12 if model.startswith("mv") else 25)

@@ -17,6 +17,7 @@ MODELS = {
     "mv32": lambda: orc.Guarniero(alpha=0.4, dx=32),
     "gordon": lambda: orc.Gordon(),
     "theta": lambda: orc.ThetaLogistic(),
+    "svlev": lambda: orc.StochVolLeverage(phi=-0.5),
 }
 
 CASES = ([("toy_%s" % s, "toy", "bootstrap") for s in ("systematic", "stratified", "multinomial")]
@@ -24,7 +25,8 @@ CASES = ([("toy_%s" % s, "toy", "bootstrap") for s in ("systematic", "stratified
          + [("lg_adaptive", "lg_adaptive", "bootstrap"), ("lg_guided", "lg_guided", "guided"),
             ("mv4_guided", "mv4", "guided"), ("mv4_boot", "mv4", "bootstrap"),
             ("mv32_guided", "mv32", "guided"), ("mv32_boot", "mv32", "bootstrap"),
-            ("gordon_boot", "gordon", "bootstrap"), ("theta_boot", "theta", "bootstrap")])
+            ("gordon_boot", "gordon", "bootstrap"), ("theta_boot", "theta", "bootstrap"),
+            ("svlev_boot", "svlev", "bootstrap")])
 
 
 @pytest.mark.parametrize("case,model,fk", CASES)
