@@ -249,6 +249,10 @@ enum smc_state_field {
 int smc_filter_get(smc_filter* f, int field, int island, void* out_host);
 /* Algorithmic bytes moved per particle-step and kernel launches
  * per step, for roofline accounting. */
+/* theta-level resampling of whole filters (SMC^2, smc_samplers.py:319-361): island i
+ * continues from the state of island src_host[i] (particles, log-weights, summaries, step
+ * record, parameter row).  Random streams stay tied to the slot.  Not with keep_history. */
+int smc_filter_permute_islands(smc_filter* f, const int64_t* src_host);
 /* keep_history filters: the state of an earlier step, fields as smc_filter_get
  * (hist.X[step], hist.A[step], hist.wgts[step].lw / .W; smoothing.py:204-207). */
 int smc_filter_history(smc_filter* f, int field, int64_t step, int island, void* out_host);

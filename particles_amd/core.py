@@ -125,6 +125,11 @@ class SMC:
                  replay=None, use_graph=True, island_offset=0):
         if qmc:
             raise NotImplementedError("SQMC (qmc=True) is outside the device hot path")
+        self._fk_list = None
+        if isinstance(fk, (list, tuple)):        # one Feynman-Kac model per island (SMC^2: one theta each)
+            self._fk_list = list(fk)
+            fk = self._fk_list[0]
+            n_islands = len(self._fk_list)
         if resampling not in rs.rs_funcs:
             raise ValueError(f"{resampling} is not a valid resampling scheme")
         self.fk, self.N, self.qmc = fk, N, qmc
@@ -176,7 +181,16 @@ class SMC:
         m.kind, m.fk, m.dx, m.dy = model["kind"], fk._fk_kind, model["dx"], model["dy"]
         self._d = model["dx"]
         if model.get("params") is not None:
-            params = np.ascontiguousarray(np.tile(model["params"], (self.n_islands, 1)))
+            if self._fk_list is None:
+                params = np.ascontiguousarray(np.tile(model["params"], (self.n_islands, 1)))
+            else:
+                rows = []
+                for g in self._fk_list:
+                    mg = g._device_model()
+                    if mg is None or mg["kind"] != model["kind"] or g._fk_kind != fk._fk_kind or g.T != T:
+                        raise ValueError("per-island models must be of one fused kind, with the same data")
+                    rows.append(mg["params"])
+                params = np.ascontiguousarray(np.stack(rows))
             m.params_host = params.ctypes.data_as(_lib.P(_lib.c_dbl))
             aux = None
             if model.get("aux") is not None:        # per-step term of the transition mean
@@ -254,6 +268,17 @@ class SMC:
         check(lib().smc_filter_trajectories(self._f, island,
                                             out.ctypes.data_as(_lib.P(_lib.c_i64))))
         return out
+
+    def permute_islands(self, A):
+        """theta-level resampling of whole filters (SMC^2, smc_samplers.py:319-361): island i
+        continues from the state of island ``A[i]``."""
+        A = np.ascontiguousarray(A, dtype=np.int64)
+        if A.shape != (self.n_islands,):
+            raise ValueError("permute_islands: one source island per island")
+        check(lib().smc_filter_permute_islands(self._f, A.ctypes.data_as(_lib.P(_lib.c_i64))))
+        if self._fk_list is not None:
+            self._fk_list = [self._fk_list[int(i)] for i in A]
+        self._invalidate()
 
     def step_async(self, nsteps=1):
         """Enqueue ``nsteps`` time steps on the device without synchronising."""

@@ -19,6 +19,7 @@ struct smc_filter {
     void* slab;            // one allocation holding every device array
     bool use_graph;
     bool fused;            // k_ancestors<true> (no k_prepare launch)
+    i64 perm_t;            // t_host at the last smc_filter_permute_islands (A / Xp undefined there)
     hipGraphExec_t gexec;
     int graph_steps;
     bool prof;
@@ -149,6 +150,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     f->graph_steps = 0;
     f->prof = false;
     f->prof_n = 0;
+    f->perm_t = -1;
     FArgs& a = f->a;
     memset(&a, 0, sizeof a);
     a.N = o->N;
@@ -437,6 +439,10 @@ static int filter_fetch(smc_filter* f, int field, i64 s, int island, void* out_h
     case SMC_FIELD_A:
     case SMC_FIELD_XP: {
         if (t < 2) { smc_set_error("smc_filter_get: A / Xp are undefined before step 1"); return SMC_ERR_STATE; }
+        if (f->perm_t == f->t_host && s == f->t_host - 1) {
+            smc_set_error("smc_filter_get: A / Xp are undefined right after smc_filter_permute_islands");
+            return SMC_ERR_STATE;
+        }
         // did the last step resample?  (core.py:329-336: else A = arange(N), Xp = X)
         double flag = 0.0;
         SMC_HIP_CHECK(hipMemcpyAsync(&flag, f->a.summ + ((size_t)island * (f->a.T + 1) + (t - 1)) * SUMM_STRIDE + 4,
@@ -473,6 +479,67 @@ static int filter_fetch(smc_filter* f, int field, i64 s, int island, void* out_h
     SMC_LAUNCH_CHECK();
     SMC_HIP_CHECK(hipMemcpyAsync(out_host, src, nbytes, hipMemcpyDeviceToHost, st));
     SMC_HIP_CHECK(hipStreamSynchronize(st));
+    return SMC_OK;
+}
+
+// theta-level resampling of whole filters (SMC^2: smc_samplers.py:319-361 FancyList
+// deep copies): island i continues from the state of island src[i] -- particles,
+// log-weights, per-step summaries, step record and parameter row move together; the
+// Philox streams stay tied to the SLOT (two copies of one island evolve independently).
+int smc_filter_permute_islands(smc_filter* f, const int64_t* src_host)
+{
+    SMC_REQUIRE(f && src_host, "null argument");
+    if (f->a.hist) {
+        smc_set_error("smc_filter_permute_islands: not available with keep_history");
+        return SMC_ERR_STATE;
+    }
+    const int M = f->a.n_islands;
+    const i64 N = f->a.N, T = f->a.T, t = f->t_host;
+    for (int i = 0; i < M; ++i)
+        if (src_host[i] < 0 || src_host[i] >= M) {
+            smc_set_error("smc_filter_permute_islands: source %lld out of range", (long long)src_host[i]);
+            return SMC_ERR_INVALID;
+        }
+    if (t == 0 || M == 1) return SMC_OK;
+    hipStream_t st = f->ctx->stream;
+    const int dx = f->a.dx;
+    const size_t bx = (size_t)N * dx * 8, bl = (size_t)N * 8, bs = (size_t)(T + 1) * SUMM_STRIDE * 8,
+                 bi = INFO_STRIDE * 8, bp = PARAM_STRIDE * 8;
+    const size_t per = bx + bl + bs + bi + bp;
+    char* tmp = nullptr;
+    hipError_t e = hipMalloc((void**)&tmp, per * M);
+    if (e != hipSuccess) {
+        smc_set_error("smc_filter_permute_islands: %zu bytes: %s", per * M, hipGetErrorString(e));
+        return SMC_ERR_NOMEM;
+    }
+    double* X = f_X(f->a, t - 1);
+    double* lw = f_lw(f->a, t - 1);
+    const bool has_params = f->kind != SMC_MODEL_MVLINGAUSS;
+    hipError_t rc = hipSuccess;
+    auto cp = [&](void* d, const void* s_, size_t n) {
+        if (rc == hipSuccess) rc = hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToDevice, st);
+    };
+    for (int i = 0; i < M; ++i) {                                   // gather into the staging area
+        const size_t s_ = (size_t)src_host[i];
+        char* o = tmp + per * i;
+        cp(o, X + s_ * N * dx, bx);
+        cp(o + bx, lw + s_ * N, bl);
+        cp(o + bx + bl, f->a.summ + s_ * (T + 1) * SUMM_STRIDE, bs);
+        cp(o + bx + bl + bs, f->a.info + s_ * INFO_STRIDE, bi);
+        if (has_params) cp(o + bx + bl + bs + bi, f->a.params + s_ * PARAM_STRIDE, bp);
+    }
+    for (int i = 0; i < M; ++i) {                                   // and back, slot by slot
+        const char* o = tmp + per * i;
+        cp(X + (size_t)i * N * dx, o, bx);
+        cp(lw + (size_t)i * N, o + bx, bl);
+        cp(f->a.summ + (size_t)i * (T + 1) * SUMM_STRIDE, o + bx + bl, bs);
+        cp(f->a.info + (size_t)i * INFO_STRIDE, o + bx + bl + bs, bi);
+        if (has_params) cp((void*)(f->a.params + (size_t)i * PARAM_STRIDE), o + bx + bl + bs + bi, bp);
+    }
+    if (rc == hipSuccess) rc = hipStreamSynchronize(st);
+    (void)hipFree(tmp);
+    SMC_HIP_CHECK(rc);
+    f->perm_t = t;
     return SMC_OK;
 }
 

@@ -577,6 +577,54 @@ def check_islands(N, T, golden, scheme="stratified"):
     assert [d["run"] for d in out] == [0, 1, 2] and all(np.isfinite(d["output"]) for d in out)
 
 
+def check_permute_islands(N, golden):
+    """One model per island (SMC^2: one theta each) and theta-level resampling of whole
+    filters (smc_samplers.py:319-361): identity and round trips are exact, copies carry
+    particles, evidence and parameters, and every island goes on under its new theta."""
+    g = golden("kalman_toy")
+    T, t0 = 40, 15
+    y = [np.atleast_1d(v) for v in np.squeeze(g["y"])][:T]
+    sig = [0.2, 0.5, 1.5]
+    mk = lambda: pa.SMC(fk=[ssm.Bootstrap(ssm=kalman.ToySSM(s), data=y) for s in sig], N=N, seed=77,
+                        collect="off")
+    ref = mk()
+    ref.run()
+    assert ref.n_islands == 3 and len(set(ref.logLts_islands.tolist())) == 3
+    # the per-island parameters are really used: evidence against the exact Kalman one
+    for k, s_ in enumerate(sig):
+        ll, _ = orc.kalman_loglik(orc.ToySSM(s_), y)
+        assert abs(ref.logLts_islands[k] - ll) < 0.3, (k, ref.logLts_islands[k], ll)
+    # identity, and a permutation undone before the next step: bit-identical runs
+    a = mk()
+    a.step_async(t0)
+    a.permute_islands([0, 1, 2])
+    a.permute_islands([1, 2, 0])
+    a.permute_islands([2, 0, 1])
+    a.step_async(T - t0)
+    assert np.array_equal(a.logLts_islands, ref.logLts_islands)
+    assert np.array_equal(a._get(_lib.FIELD_X, 1), ref._get(_lib.FIELD_X, 1))
+    # copies: island 2's filter takes over slots 0 and 1, island 0's goes to slot 2
+    b = mk()
+    b.step_async(t0)
+    before = b.logLts_islands.copy()
+    x2 = b._get(_lib.FIELD_X, 2).copy()
+    b.permute_islands([2, 2, 0])
+    assert np.array_equal(b.logLts_islands, before[[2, 2, 0]])
+    assert np.array_equal(b._get(_lib.FIELD_X, 0), x2) and np.array_equal(b._get(_lib.FIELD_X, 1), x2)
+    import pytest
+    with pytest.raises(Exception):
+        b._get(_lib.FIELD_A, 0)                  # undefined right after the permutation
+    b.step_async(T - t0)
+    ll = b.logLts_islands
+    assert ll[0] != ll[1]                        # same state, different random streams from here on
+    for k, src in enumerate([2, 2, 0]):          # and each goes on under the theta it inherited
+        full, _ = orc.kalman_loglik(orc.ToySSM(sig[src]), y)
+        head, _ = orc.kalman_loglik(orc.ToySSM(sig[src]), y[:t0])
+        assert abs((ll[k] - before[src]) - (full - head)) < 0.3, (k, ll[k] - before[src], full - head)
+    with pytest.raises(ValueError):
+        b.permute_islands([0, 1])
+
+
 def check_mv_kalman(N, d, fk, scheme="systematic"):
     """Production (Philox) mode of the multivariate filter against the exact
     Kalman likelihood (kalman.py:483-505 restated in the oracle)."""

@@ -140,5 +140,9 @@ def test_apf_and_guided_generic(golden):
     pc.check_apf_and_guided_generic(golden)
 
 
+def test_permute_islands(golden):
+    pc.check_permute_islands(3000, golden)
+
+
 def test_collectors_and_history(golden):
     pc.check_collectors_on_fused(golden)

@@ -143,6 +143,10 @@ def test_islands(golden):
     pc.check_islands(5000, 20, golden, scheme="multinomial")
 
 
+def test_permute_islands(golden):
+    pc.check_permute_islands(100000, golden)
+
+
 def test_collectors_and_history(golden):
     pc.check_collectors_on_fused(golden)
 
