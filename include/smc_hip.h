@@ -149,6 +149,11 @@ int smc_residual_split(smc_ctx* ctx, const double* W, int64_t N, int64_t M,
 int smc_residual_ancestors(smc_ctx* ctx, const double* W, const double* r_dev,
                            int64_t N, int64_t M, int64_t sip, const double* su_dev,
                            int64_t* A);
+/* ssp (resampling.py:628-678): u_dev = the N - 1 uniforms the reference draws.  A
+ * sequential process: one lane walks it on the device.  SMC_ERR_INVALID ("ssp resampling:
+ * wrong size for output") where the reference raises ValueError. */
+int smc_resample_ssp(smc_ctx* ctx, const double* W, const double* u_dev, int64_t N, int64_t M,
+                     int64_t* A);
 /* killing (resampling.py:680-697; M == N):
  *   split:      killed_dev[i] <- u_dev[i] * max(W) >= W[i], *nkilled_host <- their number
  *   ancestors:  A = arange(N); A[killed] = Am (the caller's multinomial(W, nkilled), device) */

@@ -216,6 +216,41 @@ def residual(W, M=None, rng=None, cdf="seq"):
     return A
 
 
+def ssp(W, M=None, rng=None):
+    """resampling.py:628-678 (Srinivasan sampling process), statement by statement."""
+    N = W.shape[0]
+    M = N if M is None else M
+    rng = LegacyRNG() if rng is None else rng
+    MW = M * W
+    nr_children = np.floor(MW).astype(np.int64)
+    xi = MW - nr_children
+    u = rng.rand(N - 1)
+    i, j = 0, 1
+    k = -1
+    for k in range(N - 1):
+        delta_i = min(xi[j], 1.0 - xi[i])
+        delta_j = min(xi[i], 1.0 - xi[j])
+        sum_delta = delta_i + delta_j
+        pj = delta_i / sum_delta if sum_delta > 0.0 else 0.0
+        if u[k] < pj:
+            j, i = i, j
+            delta_i = delta_j
+        if xi[j] < 1.0 - xi[i]:
+            xi[i] += delta_i
+            j = k + 2
+        else:
+            xi[j] -= delta_i
+            nr_children[i] += 1
+            i = k + 2
+    if np.sum(nr_children) == M - 1:
+        last_ij = i if j == k + 2 else j
+        if xi[last_ij] > 0.99:
+            nr_children[last_ij] += 1
+    if np.sum(nr_children) != M:
+        raise ValueError("ssp resampling: wrong size for output")
+    return np.arange(N).repeat(nr_children)
+
+
 def killing(W, M=None, rng=None, cdf="seq"):
     """resampling.py:680-697."""
     N = W.shape[0]

@@ -86,6 +86,7 @@ SIGNATURES = {
     "smc_wquantiles": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, P(c_dbl), c_int, P(c_dbl)]),
     "smc_residual_split": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, P(c_i64)]),
     "smc_residual_ancestors": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp]),
+    "smc_resample_ssp": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
     "smc_killing_split": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, P(c_i64)]),
     "smc_killing_ancestors": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "smc_filter_get": (c_int, [c_vp, c_int, c_int, c_vp]),

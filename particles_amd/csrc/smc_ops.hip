@@ -414,6 +414,121 @@ extern "C" int smc_residual_ancestors(smc_ctx* ctx, const double* W, const doubl
     return SMC_OK;
 }
 
+// ---- SSP resampling (resampling.py:628-678, Gerber, Chopin & Whiteley 2019) ---
+// The Srinivasan sampling process is a chain of N-1 pairwise steps, each depending on the
+// previous one: there is nothing to run in parallel, so ONE lane walks it on the device
+// (the weights stay where they are; ~N dependent iterations).  IEEE operations only, in
+// the reference's order: same uniforms -> same offspring counts.
+__global__ void k_ssp_counts(const double* W, const double* u, i64 N, double dM, double* xi,
+                             i64* nr, i64* sum_out)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    i64 total = 0;
+    for (i64 n = 0; n < N; ++n) {
+        const double mw = dM * W[n];
+        const double fl = floor(mw);
+        nr[n] = (i64)fl;
+        xi[n] = mw - fl;
+        total += (i64)fl;
+    }
+    i64 i = 0, j = 1, k = 0;
+    for (k = 0; k < N - 1; ++k) {
+        double delta_i = fmin(xi[j], 1.0 - xi[i]);          // increase i, decrease j
+        const double delta_j = fmin(xi[i], 1.0 - xi[j]);    // the opposite
+        const double sum_delta = delta_i + delta_j;
+        const double pj = sum_delta > 0.0 ? delta_i / sum_delta : 0.0;
+        if (u[k] < pj) {                                    // swap so that we always increase i
+            const i64 tmp = i; i = j; j = tmp;
+            delta_i = delta_j;
+        }
+        if (xi[j] < 1.0 - xi[i]) {
+            xi[i] += delta_i;
+            j = k + 2;
+        } else {
+            xi[j] -= delta_i;
+            nr[i] += 1;
+            ++total;
+            i = k + 2;
+        }
+    }
+    // round-off may leave one particle missing (resampling.py:669-673)
+    if (N >= 2 && total == (i64)dM - 1) {
+        const i64 last_ij = (j == (N - 2) + 2) ? i : j;
+        if (xi[last_ij] > 0.99) { nr[last_ij] += 1; ++total; }
+    }
+    *sum_out = total;
+}
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_count_tile_sums(const i64* nr, i64 N, u64* Q)
+{
+    __shared__ u64 sm[SMC_SM];
+    const i64 j0 = (i64)blockIdx.x * OPS_TILE + (i64)threadIdx.x * OPS_IPT;
+    u64 t = 0;
+#pragma unroll
+    for (int i = 0; i < OPS_IPT; ++i)
+        if (j0 + i < N) t += (u64)nr[j0 + i];
+    t = smc_block_sum_u64(t, sm);
+    if (threadIdx.x == 0) Q[blockIdx.x] = t;
+}
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_repeat_counts(const i64* nr, i64 N, const u64* Q, i64* A)         // arange(N).repeat(nr)
+{
+    __shared__ u64 sC[OPS_TILE];
+    __shared__ u64 sm[SMC_SM];
+    const int b = (int)blockIdx.x;
+    const i64 j0 = (i64)b * OPS_TILE;
+    u64 c[OPS_IPT];
+#pragma unroll
+    for (int i = 0; i < OPS_IPT; ++i) {
+        const i64 j = j0 + (i64)threadIdx.x * OPS_IPT + i;
+        c[i] = (j < N) ? (u64)nr[j] : 0ull;
+    }
+    u64 total;
+    const u64 pre = smc_tile_cdf<OPS_IPT>(c, Q, b, sC, sm, total);
+    for (u64 n = pre + threadIdx.x; n < pre + total; n += SMC_BLOCK)
+        A[n] = j0 + smc_lower_bound_u64(sC, OPS_TILE, n + 1ull);
+}
+
+extern "C" int smc_resample_ssp(smc_ctx* ctx, const double* W, const double* u_dev, int64_t N,
+                                int64_t M, int64_t* A)
+{
+    SMC_REQUIRE(ctx && W && A, "null argument");
+    SMC_REQUIRE(N > 0 && M > 0, "M and N must be positive");
+    SMC_REQUIRE(N == 1 || u_dev, "ssp needs N - 1 uniforms");
+    const int ntiles = (int)((N + OPS_TILE - 1) / OPS_TILE);
+    char* buf = nullptr;
+    hipError_t e = hipMalloc((void**)&buf, (size_t)N * 16 + 8 + (size_t)ntiles * 8);
+    if (e != hipSuccess) {
+        smc_set_error("smc_resample_ssp: %zu bytes: %s", (size_t)N * 16, hipGetErrorString(e));
+        return SMC_ERR_NOMEM;
+    }
+    double* xi = (double*)buf;
+    i64* nr = (i64*)(buf + (size_t)N * 8);
+    i64* sum = (i64*)(buf + (size_t)N * 16);
+    u64* Q = (u64*)(buf + (size_t)N * 16 + 8);
+    SMC_LAUNCH(k_ssp_counts, dim3(1), dim3(64), ctx->stream, W, u_dev, (i64)N, (double)M, xi, nr, sum);
+    i64 total = 0;
+    hipError_t rc = hipMemcpyAsync(&total, sum, 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (rc == hipSuccess) rc = hipStreamSynchronize(ctx->stream);
+    int ret = SMC_OK;
+    if (rc != hipSuccess) {
+        smc_set_error("smc_resample_ssp: %s", hipGetErrorString(rc));
+        ret = SMC_ERR_HIP;
+    } else if (total != M) {
+        // the reference raises ValueError (resampling.py:674-676)
+        smc_set_error("ssp resampling: wrong size for output");
+        ret = SMC_ERR_INVALID;
+    } else {
+        SMC_LAUNCH(k_count_tile_sums, dim3(ntiles), dim3(SMC_BLOCK), ctx->stream, (const i64*)nr, (i64)N, Q);
+        SMC_LAUNCH(k_repeat_counts, dim3(ntiles), dim3(SMC_BLOCK), ctx->stream, (const i64*)nr, (i64)N,
+                   (const u64*)Q, (i64*)A);
+        rc = hipStreamSynchronize(ctx->stream);
+        if (rc != hipSuccess) { smc_set_error("smc_resample_ssp: %s", hipGetErrorString(rc)); ret = SMC_ERR_HIP; }
+    }
+    (void)hipFree(buf);
+    return ret;
+}
+
 // ---- killing resampling (resampling.py:680-697) -----------------------------
 // killed_i = u_i * max(W) >= W_i ; A = arange(N) ; A[killed] = multinomial(W, #killed)
 __global__ void __launch_bounds__(SMC_BLOCK)

@@ -277,6 +277,23 @@ def residual(W, M):
 
 
 @resampling_scheme
+def ssp(W, M):
+    """SSP resampling (resampling.py:628-678): offspring numbers floor(M W) or floor(M W)+1,
+    consistent (Gerber, Chopin & Whiteley 2019).  Inherently sequential: one lane of the
+    device walks the chain, the weights stay resident."""
+    Wd, host = as_device(W)
+    N = Wd.size
+    if host and _lib.RNG_MODE[0] == "numpy":
+        u = DeviceArray.from_numpy(random.rand(N - 1)) if N > 1 else None        # :649
+    else:
+        u = DeviceArray((max(N - 1, 1),))
+        check(lib().smc_uniform(u.ctx.h, _lib.next_counter(), max(N - 1, 1), u.ptr))
+    A = DeviceArray((M,), np.int64)
+    check(lib().smc_resample_ssp(Wd.ctx.h, Wd.ptr, u.ptr if u is not None else None, N, M, A.ptr))
+    return A.get() if host else A
+
+
+@resampling_scheme
 def killing(W, M):
     """Killing resampling (resampling.py:680-697): keep particle i with probability
     ``W[i] / W.max()``, otherwise replace it by a multinomial draw.  Requires M = N."""

@@ -132,6 +132,9 @@ def main():
         res2["A_residual_%d" % M] = rs.resampling("residual", W, M=M)
     np.random.seed(11)
     res2["A_killing_1500"] = rs.resampling("killing", W, M=1500)
+    for M in (1500, 400, 4000):
+        np.random.seed(11)
+        res2["A_ssp_%d" % M] = rs.resampling("ssp", W, M=M)
     Wd = np.zeros(64)
     Wd[[3, 17, 40]] = [0.5, 0.25, 0.25]         # M W integral: no residual draw at all
     np.random.seed(11)

@@ -161,8 +161,13 @@ def check_residual_killing(golden):
     A = rs.resampling("residual", g["W_integral"], M=64)
     assert np.array_equal(A, g["A_residual_integral"])
     assert np.random.rand() == np.random.RandomState(11).rand()
-    # registry and the generic SMC path
-    assert {"residual", "killing"} <= set(rs.rs_funcs)
+    # ssp (resampling.py:628-678): IEEE operations only, same uniforms -> the reference's ancestors
+    for M in (1500, 400, 4000):
+        np.random.seed(11)
+        A = rs.resampling("ssp", W, M=M)
+        assert A.dtype == np.int64 and np.array_equal(A, g["A_ssp_%d" % M])
+    # the whole registry of the reference
+    assert set(rs.rs_funcs) == {"multinomial", "stratified", "systematic", "residual", "ssp", "killing"}
     # large, Philox draws on the device: offspring counts of residual are floor(M W) or more
     rng = np.random.default_rng(5)
     N = 50000
@@ -171,10 +176,14 @@ def check_residual_killing(golden):
     try:
         Ad = rs.resampling("residual", pa.DeviceArray.from_numpy(Wl), M=N).get()
         Ak = rs.resampling("killing", pa.DeviceArray.from_numpy(Wl), M=N).get()
+        As = rs.resampling("ssp", pa.DeviceArray.from_numpy(Wl[:5000] / Wl[:5000].sum()), M=5000).get()
     finally:
         rs.set_rng("numpy")
     cnt = np.bincount(Ad, minlength=N)
     assert cnt.sum() == N and np.all(cnt >= np.floor(N * Wl))
+    cs = np.bincount(As, minlength=5000)
+    fl = np.floor(5000 * Wl[:5000] / Wl[:5000].sum())
+    assert cs.sum() == 5000 and np.all(cs >= fl) and np.all(cs <= fl + 1)     # k or k+1 offspring
     kept = Ak == np.arange(N)
     assert abs(kept.mean() - np.mean(Wl / Wl.max())) < 0.02          # P(keep i) = W_i / max W
     assert Ak.min() >= 0 and Ak.max() < N

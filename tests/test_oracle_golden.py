@@ -99,6 +99,9 @@ def test_residual_killing(golden):
         assert np.array_equal(orc.residual(g["W"], M), g["A_residual_%d" % M])
     np.random.seed(11)
     assert np.array_equal(orc.killing(g["W"], 1500), g["A_killing_1500"])
+    for M in (1500, 400, 4000):
+        np.random.seed(11)
+        assert np.array_equal(orc.ssp(g["W"], M), g["A_ssp_%d" % M])
     np.random.seed(11)
     assert np.array_equal(orc.residual(g["W_integral"], 64), g["A_residual_integral"])
     with pytest.raises(ValueError):
