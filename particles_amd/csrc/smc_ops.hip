@@ -417,46 +417,83 @@ extern "C" int smc_residual_ancestors(smc_ctx* ctx, const double* W, const doubl
 // ---- SSP resampling (resampling.py:628-678, Gerber, Chopin & Whiteley 2019) ---
 // The Srinivasan sampling process is a chain of N-1 pairwise steps, each depending on the
 // previous one: there is nothing to run in parallel, so ONE lane walks it on the device
-// (the weights stay where they are; ~N dependent iterations).  IEEE operations only, in
-// the reference's order: same uniforms -> same offspring counts.
-__global__ void k_ssp_counts(const double* W, const double* u, i64 N, double dM, double* xi,
-                             i64* nr, i64* sum_out)
+// (the weights stay where they are; N-1 dependent iterations, one fp64 division each).
+// IEEE operations only, in the reference's order: same uniforms -> same offspring counts.
+#define SSP_CHUNK 512
+__global__ void __launch_bounds__(64)
+k_ssp_counts(const double* W, const double* u, i64 N, double dM, i64* nr, i64* sum_out)
 {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    i64 total = 0;
-    for (i64 n = 0; n < N; ++n) {
-        const double mw = dM * W[n];
-        const double fl = floor(mw);
-        nr[n] = (i64)fl;
-        xi[n] = mw - fl;
-        total += (i64)fl;
+    // One wavefront: all lanes stage the next SSP_CHUNK uniforms and candidates (fractional
+    // part and floor of M W) in LDS, lane 0 walks the chain on them.  The two active
+    // particles live in registers; a particle's offspring number is final when it leaves
+    // the active pair, so nr[] is written once per particle, never read.
+    __shared__ double sU[SSP_CHUNK], sX[SSP_CHUNK];
+    __shared__ i64 sF[SSP_CHUNK];
+    const int lane = (int)threadIdx.x;
+    i64 ii = 0, jj = 1, total = 0, fi = 0, fj = 0;
+    double xi = 0.0, xj = 0.0;
+    if (lane == 0) {
+        const double m0 = dM * W[0], f0 = floor(m0);
+        fi = (i64)f0; xi = m0 - f0;
+        if (N > 1) { const double m1 = dM * W[1], f1 = floor(m1); fj = (i64)f1; xj = m1 - f1; }
     }
-    i64 i = 0, j = 1, k = 0;
-    for (k = 0; k < N - 1; ++k) {
-        double delta_i = fmin(xi[j], 1.0 - xi[i]);          // increase i, decrease j
-        const double delta_j = fmin(xi[i], 1.0 - xi[j]);    // the opposite
-        const double sum_delta = delta_i + delta_j;
-        const double pj = sum_delta > 0.0 ? delta_i / sum_delta : 0.0;
-        if (u[k] < pj) {                                    // swap so that we always increase i
-            const i64 tmp = i; i = j; j = tmp;
-            delta_i = delta_j;
+    for (i64 k0 = 0; k0 < N - 1; k0 += SSP_CHUNK) {
+        const int cnt = (int)((N - 1 - k0 < SSP_CHUNK) ? (N - 1 - k0) : SSP_CHUNK);
+        __syncthreads();
+        for (int m = lane; m < cnt; m += 64) {
+            sU[m] = u[k0 + m];
+            const i64 n = k0 + m + 2;                       // the particle that enters after step k
+            if (n < N) {
+                const double mw = dM * W[n], fl = floor(mw);
+                sX[m] = mw - fl;
+                sF[m] = (i64)fl;
+            } else {
+                sX[m] = 0.0;
+                sF[m] = 0;
+            }
         }
-        if (xi[j] < 1.0 - xi[i]) {
-            xi[i] += delta_i;
-            j = k + 2;
-        } else {
-            xi[j] -= delta_i;
-            nr[i] += 1;
-            ++total;
-            i = k + 2;
+        __syncthreads();
+        if (lane == 0) {
+#pragma unroll 4
+            for (int m = 0; m < cnt; ++m) {
+                const i64 k = k0 + m;
+                double delta_i = fmin(xj, 1.0 - xi);            // increase i, decrease j
+                const double delta_j = fmin(xi, 1.0 - xj);      // the opposite
+                const double sum_delta = delta_i + delta_j;
+                const double pj = sum_delta > 0.0 ? delta_i / sum_delta : 0.0;
+                if (sU[m] < pj) {                               // swap so that we always increase i
+                    const i64 ti = ii; ii = jj; jj = ti;
+                    const i64 tf = fi; fi = fj; fj = tf;
+                    const double tx = xi; xi = xj; xj = tx;
+                    delta_i = delta_j;
+                }
+                if (xj < 1.0 - xi) {
+                    xi += delta_i;
+                    nr[jj] = fj;                                // j leaves with floor(M W_j) offspring
+                    total += fj;
+                    jj = k + 2; xj = sX[m]; fj = sF[m];
+                } else {
+                    xj -= delta_i;
+                    nr[ii] = fi + 1;                            // i leaves with one more
+                    total += fi + 1;
+                    ii = k + 2; xi = sX[m]; fi = sF[m];
+                }
+            }
         }
     }
-    // round-off may leave one particle missing (resampling.py:669-673)
-    if (N >= 2 && total == (i64)dM - 1) {
-        const i64 last_ij = (j == (N - 2) + 2) ? i : j;
-        if (xi[last_ij] > 0.99) { nr[last_ij] += 1; ++total; }
+    if (lane == 0) {
+        // the pair still active (one of the two indices is N when N >= 2: it never existed)
+        const bool has_i = ii < N, has_j = N > 1 && jj < N;
+        i64 tot = total + (has_i ? fi : 0) + (has_j ? fj : 0);
+        if (N >= 2 && tot == (i64)dM - 1) {                     // round-off (resampling.py:669-673)
+            const bool last_is_i = (jj == N);                   // last_ij = i if j == k + 2 else j
+            const double xl = last_is_i ? xi : xj;
+            if (xl > 0.99) { if (last_is_i) ++fi; else ++fj; ++tot; }
+        }
+        if (has_i) nr[ii] = fi;
+        if (has_j) nr[jj] = fj;
+        *sum_out = tot;
     }
-    *sum_out = total;
 }
 __global__ void __launch_bounds__(SMC_BLOCK)
 k_count_tile_sums(const i64* nr, i64 N, u64* Q)
@@ -497,16 +534,15 @@ extern "C" int smc_resample_ssp(smc_ctx* ctx, const double* W, const double* u_d
     SMC_REQUIRE(N == 1 || u_dev, "ssp needs N - 1 uniforms");
     const int ntiles = (int)((N + OPS_TILE - 1) / OPS_TILE);
     char* buf = nullptr;
-    hipError_t e = hipMalloc((void**)&buf, (size_t)N * 16 + 8 + (size_t)ntiles * 8);
+    hipError_t e = hipMalloc((void**)&buf, (size_t)N * 8 + 8 + (size_t)ntiles * 8);
     if (e != hipSuccess) {
-        smc_set_error("smc_resample_ssp: %zu bytes: %s", (size_t)N * 16, hipGetErrorString(e));
+        smc_set_error("smc_resample_ssp: %zu bytes: %s", (size_t)N * 8, hipGetErrorString(e));
         return SMC_ERR_NOMEM;
     }
-    double* xi = (double*)buf;
-    i64* nr = (i64*)(buf + (size_t)N * 8);
-    i64* sum = (i64*)(buf + (size_t)N * 16);
-    u64* Q = (u64*)(buf + (size_t)N * 16 + 8);
-    SMC_LAUNCH(k_ssp_counts, dim3(1), dim3(64), ctx->stream, W, u_dev, (i64)N, (double)M, xi, nr, sum);
+    i64* nr = (i64*)buf;
+    i64* sum = (i64*)(buf + (size_t)N * 8);
+    u64* Q = (u64*)(buf + (size_t)N * 8 + 8);
+    SMC_LAUNCH(k_ssp_counts, dim3(1), dim3(64), ctx->stream, W, u_dev, (i64)N, (double)M, nr, sum);
     i64 total = 0;
     hipError_t rc = hipMemcpyAsync(&total, sum, 8, hipMemcpyDeviceToHost, ctx->stream);
     if (rc == hipSuccess) rc = hipStreamSynchronize(ctx->stream);

@@ -166,6 +166,16 @@ def check_residual_killing(golden):
         np.random.seed(11)
         A = rs.resampling("ssp", W, M=M)
         assert A.dtype == np.int64 and np.array_equal(A, g["A_ssp_%d" % M])
+    assert np.array_equal(rs.ssp(np.array([1.0]), 5), np.zeros(5, dtype=np.int64))
+    for N in (2, 3, 7, 513, 514, 1025):          # chunk borders of the device walk, M != N
+        r2 = np.random.default_rng(N)
+        Wn = r2.random(N)
+        Wn /= Wn.sum()
+        for M in (N, 2 * N + 1):
+            np.random.seed(4)
+            got = rs.ssp(Wn, M)
+            np.random.seed(4)
+            assert np.array_equal(got, orc.ssp(Wn, M)), (N, M)
     # the whole registry of the reference
     assert set(rs.rs_funcs) == {"multinomial", "stratified", "systematic", "residual", "ssp", "killing"}
     # large, Philox draws on the device: offspring counts of residual are floor(M W) or more
