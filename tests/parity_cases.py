@@ -441,6 +441,24 @@ def check_model_philox_vs_oracle(golden, case, model, N=20000):
     assert abs(np.mean(dev) - np.mean(ref)) < 0.25, (dev, ref)
 
 
+def check_graph_replay_matches_direct(golden, N=5000):
+    """The hipGraph path (24 steps per graph, slot parity baked into the nodes) against plain
+    launches, entered at odd and even time indices and with adaptive resampling."""
+    g = golden("kalman_toy")
+    y = [np.atleast_1d(v) for v in np.squeeze(g["y"])][:130]
+    mk = lambda graph: pa.SMC(fk=ssm.Bootstrap(ssm=kalman.LinearGauss(rho=0.9, sigmaX=1.0, sigmaY=1.2),
+                                               data=y), N=N, seed=11, use_graph=graph, collect="off")
+    a = mk(False)
+    a.run()
+    b = mk(True)
+    for chunk in (7, 53, 26, 1, 43):             # odd entry, even entry, short tails
+        b.step_async(chunk)
+    assert b.t == 130 and a.logLt == b.logLt and np.array_equal(a.X, b.X)
+    s = a._summ()[0]
+    assert 0 < s[:, 4].sum() < 129               # both branches of the resample decision
+    assert np.array_equal(s, b._summ()[0])
+
+
 def check_edge_sizes():
     """Ragged and tiny populations, single-step runs, every scheme (partial
     wavefronts, partial tiles, tiles with no offspring)."""
