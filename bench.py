@@ -35,8 +35,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_STEP = 56.0                # 16*d + 40 B per particle-step, d = 1
 BYTES_MOVE = 32.0                # k_propagate: read A, gather X; write X, lw
-BYTES_PREPARE = 16.0             # k_ancestors<true>: read lw, write A  (C2; beyond 2048 workgroups
-                                 # k_prepare adds read lw / write q = 16 B more)
+BYTES_PREPARE = 16.0             # k_ancestors: read lw, write A  (beyond 2048 workgroups per launch
+                                 # k_prepare reads lw once more for the tile totals: + 8 B)
 
 
 def synthetic_data(T, sigma=0.2, seed=42):
@@ -231,12 +231,12 @@ def main():
                 "samples": ns.value,
                 "prepare_ms": max(out["ms_per_step"] - mv.value, 0.0),
                 "prepare_achieved": (BYTES_PREPARE if ((N + 1023) // 1024) * a.islands <= 2048
-                                     else 2 * BYTES_PREPARE) * N * a.islands
+                                     else BYTES_PREPARE + 8.0) * N * a.islands
                 / ((out["ms_per_step"] - mv.value) * 1e-3) / 1e9
                 if out["ms_per_step"] > mv.value else None,
                 "note": "per particle-step: k_propagate 32 B (read A, gather X; write X, lw), "
-                        "k_ancestors 16 B (read lw, write A; +16 B for k_prepare's q beyond 2048 "
-                        "workgroups per launch). kernel_ms = (HIP-event interval around whole steps) - "
+                        "k_ancestors 16 B (read lw, write A; + 8 B for k_prepare's pass over lw beyond "
+                        "2048 workgroups per launch). kernel_ms = (HIP-event interval around whole steps) - "
                         "(interval around the resampling kernels only), alternating steps, so the "
                         "fixed ~4 us of an event interval cancels; prepare_ms = ms_per_step - kernel_ms",
             }

@@ -184,11 +184,10 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     const size_t oX0 = carve(nslots * M * N * dxm * 8);
     const size_t oL0 = carve(nslots * M * N * 8);
     const size_t oA = carve((a.hist ? T : 1) * M * N * 8);
-    // q is only materialised when k_prepare runs (more tiles than k_ancestors<true> handles)
     // (published tile totals pay off only while every workgroup of the launch is resident)
     f->fused = (i64)a.ntiles * (i64)M <= F_DIRECT_PREFIX_MAX;
     if (getenv("SMC_FORCE_FUSED")) f->fused = a.ntiles <= F_DIRECT_PREFIX_MAX;   // experiments
-    const size_t oq = carve(f->fused ? 8 : M * N * 8);
+    if (getenv("SMC_FORCE_UNFUSED")) f->fused = false;        // tests: the k_prepare path at any size
     const size_t oQ = carve(M * a.ntiles * 8);
     const size_t oQpre = carve(M * a.ntiles * 8);
     // MV: a workgroup stages the step's matrices in LDS once and then walks
@@ -227,7 +226,6 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     a.X = (double*)(base + oX0);
     a.lw = (double*)(base + oL0);
     a.A = (i64*)(base + oA);
-    a.q = (u64*)(base + oq);
     a.Q = (u64*)(base + oQ);
     a.Qpre = (u64*)(base + oQpre);
     a.pm = (double*)(base + oPm); a.ps = (double*)(base + oPs); a.pss = (double*)(base + oPss);

@@ -64,7 +64,6 @@ struct FArgs {
     int hist;
     int par;               // t & 1 of the step this launch runs, or -1 (history slots): lets the
                            // kernels form their addresses before the step record has arrived
-    u64* q;                // (n_islands, N) Q62 weights of the parents
     u64* Q;                // (n_islands, ntiles) tile totals of q
     u64* Qpre;             // (n_islands, ntiles) exclusive prefixes of Q
     double *pm, *ps, *pss; // (n_islands, ntiles) log-sum-exp partials
@@ -290,7 +289,6 @@ k_prepare(const FArgs av)
     const double m = smc_uniform(info[3]), rs = smc_uniform(info[4]);
     // Q62 weights of step t-1's particles (the parents of step t) + tile total
     const double* lw = f_lw(a, t - 1) + (i64)isl * a.N;
-    u64* q = a.q + (i64)isl * a.N;
     const bool vec = (a.N & 3) == 0;
     const i64 j0 = (i64)b * F_TILE + (i64)threadIdx.x * F_IPT;
     double l4[4];
@@ -305,7 +303,6 @@ k_prepare(const FArgs av)
     }
     s = smc_block_sum_u64(s, smu);
     u64* Q = a.Q + (i64)isl * a.ntiles;
-    f_store4<u64, F2u>(q, j0, vec && ok[3], ok, q4);
     if (threadIdx.x == 0) smc_st_agent(Q + b, s);
     if (!f_last_block(a.cnt + (isl * 2 + 1) * F_CNT_WORDS, b, a.ntiles, &s_last, 0)) return;
     // last workgroup: exclusive prefixes of the tile totals (exact integers)
@@ -477,7 +474,13 @@ k_ancestors(const FArgs av)
         F_STAMP_A(4);
         cex = smc_block_exscan_plus_sum_u64(tsum, part, smu, total, pre);
     } else {
-        f_load4<u64, F2u>(a.q + (i64)isl * N, jt, N, vec, 0ull, q4);
+        // k_prepare kept only the tile totals: the Q62 weights are formed again from the
+        // log-weights (same expression, same bits) -- 8 B/particle of q traffic less each way
+        const double m = smc_uniform(r3), rs = smc_uniform(r4);
+        f_load4<double, F2d>(f_lw(a, t - 1) + (i64)isl * N, jt, N, vec, -INFINITY, l4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            q4[i] = (jt + i < N) ? smc_q62_w(f_weight(l4[i], m, rs)) : 0ull;
         const u64 tsum = q4[0] + q4[1] + q4[2] + q4[3];
         pre = a.Qpre[(i64)isl * a.ntiles + b];
         cex = smc_block_exscan_u64(tsum, smu, total);

@@ -459,6 +459,25 @@ def check_graph_replay_matches_direct(golden, N=5000):
     assert np.array_equal(s, b._summ()[0])
 
 
+def check_unfused_path(golden, monkeypatch):
+    """The k_prepare + k_ancestors<false> path (normally taken beyond 2048 workgroups per
+    launch) at test sizes: replay parity, and the same Philox run as the fused path."""
+    monkeypatch.setenv("SMC_FORCE_UNFUSED", "1")
+    for case in ("toy_systematic", "toy_stratified", "toy_multinomial"):
+        check_filter_replay(golden, case, "toy", "bootstrap", T=20)
+    check_filter_replay(golden, "toy_systematic", "toy", "bootstrap", T=20, N=4096)
+    g = golden("kalman_toy")
+    y = [np.atleast_1d(v) for v in np.squeeze(g["y"])][:30]
+    mk = lambda: pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y), N=5000, seed=4, n_islands=2,
+                        collect="off")
+    a = mk()
+    a.run()
+    monkeypatch.delenv("SMC_FORCE_UNFUSED")
+    b = mk()
+    b.run()
+    assert np.array_equal(a.logLts_islands, b.logLts_islands) and np.array_equal(a.X, b.X)
+
+
 def check_edge_sizes():
     """Ragged and tiny populations, single-step runs, every scheme (partial
     wavefronts, partial tiles, tiles with no offspring)."""

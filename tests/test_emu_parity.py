@@ -116,6 +116,10 @@ def test_graph_replay_matches_direct(golden):
     pc.check_graph_replay_matches_direct(golden, N=1500)
 
 
+def test_unfused_path(golden, monkeypatch):
+    pc.check_unfused_path(golden, monkeypatch)
+
+
 def test_edge_sizes():
     pc.check_edge_sizes()
 
