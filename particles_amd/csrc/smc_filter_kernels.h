@@ -19,8 +19,8 @@
 //         systematic, N a power of two: closed-form first-offspring index per
 //           parent, scattered into LDS and expanded by a max-scan (no search);
 //         otherwise: per-offspring binary search in the tile's CDF in LDS.
-//   [k_prepare(t): beyond 2048 workgroups per launch q and the scanned tile
-//       totals are produced by a launch of their own, k_ancestors<false> reads them]
+//   [k_prepare(t): beyond 2048 workgroups per launch the tile totals are computed and
+//       scanned by a launch of their own; k_ancestors<false> reads the scanned prefixes]
 //   k_propagate<KIND,FK,OPT>(t): element-wise over the new particles: gather of
 //       the parent state X_{t-1}[A], x = loc(xp)+scale*z with a counted Philox
 //       normal (or a replayed draw), the weight increment log G, 32-byte stores
@@ -36,8 +36,8 @@
 //
 // HBM traffic per particle-step on a resampling step (d = 1):
 //   k_ancestors: read lw (8), write A (8);  k_propagate: read A, X (16), write X, lw (16)
-// = 48 B (+16 B for q when k_prepare runs) against SURVEY 8d's 56 B: W is never
-// materialised.
+// = 48 B (+8 B when k_prepare reads lw for the totals) against SURVEY 8d's 56 B: neither
+// W nor its fixed-point image is ever materialised.
 #pragma once
 #include "smc_internal.h"
 #include "smc_resample.h"
