@@ -183,7 +183,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     a.lslot = (i64)(M * N);
     const size_t oX0 = carve(nslots * M * N * dxm * 8);
     const size_t oL0 = carve(nslots * M * N * 8);
-    const size_t oA = carve((a.hist ? T : 1) * M * N * 8);
+    const size_t oA = carve((a.hist ? T : 1) * M * N * 4);
     // (published tile totals pay off only while every workgroup of the launch is resident)
     f->fused = (i64)a.ntiles * (i64)M <= F_DIRECT_PREFIX_MAX;
     if (getenv("SMC_FORCE_FUSED")) f->fused = a.ntiles <= F_DIRECT_PREFIX_MAX;   // experiments
@@ -225,7 +225,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     char* base = (char*)slab;
     a.X = (double*)(base + oX0);
     a.lw = (double*)(base + oL0);
-    a.A = (i64*)(base + oA);
+    a.A = (u32*)(base + oA);
     a.Q = (u64*)(base + oQ);
     a.Qpre = (u64*)(base + oQpre);
     a.pm = (double*)(base + oPm); a.ps = (double*)(base + oPs); a.pss = (double*)(base + oPss);
@@ -254,7 +254,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
         SMC_HIP_CHECK(hipMemcpyAsync(a.info, h.data(), h.size() * 8, hipMemcpyHostToDevice, st));
         SMC_HIP_CHECK(hipStreamSynchronize(st));
     }
-    SMC_HIP_CHECK(hipMemsetAsync(a.A, 0, M * N * 8, st));
+    SMC_HIP_CHECK(hipMemsetAsync(a.A, 0, M * N * 4, st));
     if (!mv)
         SMC_HIP_CHECK(hipMemcpyAsync(dpar, model->params_host, M * PARAM_STRIDE * 8,
                                      hipMemcpyHostToDevice, st));
@@ -428,7 +428,7 @@ static int filter_fetch(smc_filter* f, int field, i64 s, int island, void* out_h
     const double* Xo = f_X(f->a, s - 1) + (size_t)island * N * dx;
     size_t nbytes = (size_t)N * 8;
     const double* lw = f_lw(f->a, s) + (size_t)island * N;
-    const i64* A = f_A(f->a, s) + (size_t)island * N;
+    const u32* A = f_A(f->a, s) + (size_t)island * N;
     const void* src = nullptr;
     const unsigned nb = (unsigned)((N + SMC_BLOCK - 1) / SMC_BLOCK);
     switch (field) {
@@ -455,7 +455,8 @@ static int filter_fetch(smc_filter* f, int field, i64 s, int island, void* out_h
             src = Xo;
             nbytes *= dx;
         } else if (field == SMC_FIELD_A) {
-            src = A;
+            SMC_LAUNCH(k_f_widen, dim3(nb), dim3(SMC_BLOCK), st, A, N, (i64*)f->tmp);
+            src = f->tmp;
         } else {
             SMC_LAUNCH(k_f_gather_rows, dim3((unsigned)((N * dx + SMC_BLOCK - 1) / SMC_BLOCK)),
                        dim3(SMC_BLOCK), st, Xo, A, N, dx, f->tmp);
@@ -585,7 +586,7 @@ int smc_filter_trajectories(smc_filter* f, int island, int64_t* out_host)
     const dim3 grid((unsigned)((N + SMC_BLOCK - 1) / SMC_BLOCK));
     SMC_LAUNCH(k_f_iota, grid, dim3(SMC_BLOCK), st, N, B + (size_t)(t - 1) * N);
     for (i64 s = t - 1; s >= 1; --s) {                  // smoothing.py:213-216
-        const i64* A = rows[(size_t)s * SUMM_STRIDE + 4] != 0.0 ? f_A(f->a, s) + (size_t)island * N : nullptr;
+        const u32* A = rows[(size_t)s * SUMM_STRIDE + 4] != 0.0 ? f_A(f->a, s) + (size_t)island * N : nullptr;
         SMC_LAUNCH(k_f_genealogy, grid, dim3(SMC_BLOCK), st, A, (const i64*)(B + (size_t)s * N), N,
                    B + (size_t)(s - 1) * N);
     }

@@ -59,7 +59,8 @@ struct FArgs {
     // states / log-weights / ancestors of step t live in slot f_slot(t): two alternating
     // slots, or -- keep_history -- one slot per time step (the history IS the buffer)
     double *X, *lw;        // (nslots, n_islands, N[, dx])
-    i64* A;                // (1 or T, n_islands, N)
+    u32* A;                // (1 or T, n_islands, N) ancestors, 32-bit in HBM (N < 2^32; the
+                           // ABI hands out int64 like the reference, resampling.py:503)
     i64 xslot, lslot;      // elements per slot: n_islands*N*dx, n_islands*N
     int hist;
     int par;               // t & 1 of the step this launch runs, or -1 (history slots): lets the
@@ -93,7 +94,7 @@ __host__ __device__ __forceinline__ i64 f_slot(const FArgs& a, i64 t)
 }
 __host__ __device__ __forceinline__ double* f_X(const FArgs& a, i64 t) { return a.X + f_slot(a, t) * a.xslot; }
 __host__ __device__ __forceinline__ double* f_lw(const FArgs& a, i64 t) { return a.lw + f_slot(a, t) * a.lslot; }
-__host__ __device__ __forceinline__ i64* f_A(const FArgs& a, i64 t) { return a.A + (a.hist ? t : 0) * a.lslot; }
+__host__ __device__ __forceinline__ u32* f_A(const FArgs& a, i64 t) { return a.A + (a.hist ? t : 0) * a.lslot; }
 
 #ifdef SMC_TRACE
 #define F_STAMP(k) do { if (threadIdx.x == 0) a.trace[((i64)blockIdx.y * a.nparts + blockIdx.x) * 8 + (k)] = (u64)wall_clock64(); } while (0)
@@ -431,7 +432,7 @@ k_ancestors(const FArgs av)
     if (t >= a.T || t == 0 || smc_uniform(r1) == 0.0) return;          // step t does not resample
     F_STAMP_A(1);
     const u32 gisl = (u32)(a.island_offset + isl);
-    i64* A = f_A(a, t) + (i64)isl * N;
+    u32* A = f_A(a, t) + (i64)isl * N;
 
     // ---- the tile's parents: q and their exact CDF
     u64 q4[4];
@@ -583,7 +584,16 @@ k_ancestors(const FArgs av)
                 a4[i] = j0 + (jl < nvalid ? jl : nvalid - 1);
             }
         }
-        f_store4<i64, F2i>(A, n0, vec && ok[0] && ok[3], ok, a4);            // core.py:329
+        {                                                                    // core.py:329
+            const u32 a32[4] = {(u32)a4[0], (u32)a4[1], (u32)a4[2], (u32)a4[3]};
+            if (vec && ok[0] && ok[3]) {
+                smc_st4g(A + n0, a32);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (ok[i]) smc_stg(A + n0 + i, a32[i]);
+            }
+        }
     }
     F_STAMP_A(6);
 }
@@ -684,6 +694,24 @@ __device__ __forceinline__ void f_step_tail(const FArgs& a, const int isl, const
 // thread.  x = loc(X_{t-1}[A]) + scale z, weight increment, log-weights, online
 // log-sum-exp partial; the last workgroup of the island finalises the step.
 // ---------------------------------------------------------------------------
+// OPT consecutive ancestor indices (32-bit in memory), 16-byte loads when aligned
+template <int OPT>
+__device__ __forceinline__ void f_load_anc(const u32* A, i64 n0, i64 N, bool full, i64 (&an)[OPT])
+{
+    if (full && OPT % 4 == 0) {
+#pragma unroll
+        for (int k = 0; k < OPT; k += 4) {
+            u32 v[4];
+            smc_ld4g(A + n0 + k, v);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) an[k + i] = (i64)v[i];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < OPT; ++k) an[k] = (n0 + k < N) ? (i64)smc_ldg(A + n0 + k) : 0;
+    }
+}
+
 template <int KIND, int FK, int OPT, bool SPEC>
 __global__ void __launch_bounds__(SMC_BLOCK)
 k_propagate(const FArgs av)
@@ -706,14 +734,8 @@ k_propagate(const FArgs av)
     // waiting for the record (read in vain on the steps that do not resample)
     i64 an[OPT];
     if (SPEC && n0 < N) {
-        const i64* As = a.A + (i64)isl * N;
-        if (full) {
-#pragma unroll
-            for (int k = 0; k < OPT; k += 2) smc_ld2g(As + n0 + k, an[k], an[k + 1]);
-        } else {
-#pragma unroll
-            for (int k = 0; k < OPT; ++k) an[k] = (n0 + k < N) ? smc_ldg(As + n0 + k) : 0;
-        }
+        const u32* As = a.A + (i64)isl * N;
+        f_load_anc<OPT>(As, n0, N, full, an);
     }
     double xg[OPT];
     if (SPEC && n0 < N) {          // A always holds valid indices (zeros before the first resampling)
@@ -732,7 +754,7 @@ k_propagate(const FArgs av)
     const double* Xo = (SPEC ? a.X + (i64)(a.par ^ 1) * a.xslot : f_X(a, t - 1)) + (i64)isl * N;
     double* lwn = (SPEC ? a.lw + (i64)a.par * a.lslot : f_lw(a, t)) + (i64)isl * N;
     const double* lwo = (SPEC ? a.lw + (i64)(a.par ^ 1) * a.lslot : f_lw(a, t - 1)) + (i64)isl * N;
-    const i64* A = f_A(a, t) + (i64)isl * N;
+    const u32* A = f_A(a, t) + (i64)isl * N;
     const double* zt = a.zt ? a.zt + ((i64)t * a.n_islands + isl) * N : nullptr;
     const bool first = (t == 0);
     const bool resample = !first && smc_uniform(r1) != 0.0;
@@ -745,15 +767,7 @@ k_propagate(const FArgs av)
         // ---- ancestor indices (when resampled) or the particle's own state and
         // log-weight: requested first, consumed after the normals are generated
         if (resample && !SPEC) {
-            if (full) {
-#pragma unroll
-                for (int k = 0; k < OPT; k += 2) {
-                    smc_ld2g(A + n0 + k, an[k], an[k + 1]);
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < OPT; ++k) an[k] = (n0 + k < N) ? smc_ldg(A + n0 + k) : 0;
-            }
+            f_load_anc<OPT>(A, n0, N, full, an);
         } else if (!first && !resample) {
             if (full) {
 #pragma unroll
@@ -841,7 +855,7 @@ k_f_write_W(const double* lw, i64 N, const double* row, double* W)
 }
 
 __global__ void __launch_bounds__(SMC_BLOCK)
-k_f_gather1(const double* X, const i64* A, i64 N, double* Xp)
+k_f_gather1(const double* X, const u32* A, i64 N, double* Xp)
 {
     const i64 i = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;
     if (i < N) Xp[i] = X[A[i]];
@@ -850,14 +864,22 @@ k_f_gather1(const double* X, const i64* A, i64 N, double* Xp)
 // one backward step of the genealogy (smoothing.py:209-219): B_{s-1} = A_s[B_s]
 // (A == nullptr: step s did not resample, A_s = arange)
 __global__ void __launch_bounds__(SMC_BLOCK)
-k_f_genealogy(const i64* A, const i64* Bs, i64 N, i64* Bprev)
+k_f_genealogy(const u32* A, const i64* Bs, i64 N, i64* Bprev)
 {
     const i64 i = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;
-    if (i < N) Bprev[i] = A ? A[Bs[i]] : Bs[i];
+    if (i < N) Bprev[i] = A ? (i64)A[Bs[i]] : Bs[i];
 }
 __global__ void __launch_bounds__(SMC_BLOCK)
 k_f_iota(i64 N, i64* B)
 {
     const i64 i = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;
     if (i < N) B[i] = i;
+}
+
+// ancestors as the ABI hands them out: int64 (resampling.py:503)
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_f_widen(const u32* A, i64 N, i64* out)
+{
+    const i64 i = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;
+    if (i < N) out[i] = (i64)A[i];
 }

@@ -115,7 +115,7 @@ k_propagate_mv(const FArgs av, const double* __restrict__ C)
     SMC_GLOBAL(const double) Xo = SMC_AS_GLOBAL(const double, f_X(a, t - 1) + (i64)isl * N * d);
     SMC_GLOBAL(double) lwn = SMC_AS_GLOBAL(double, f_lw(a, t) + (i64)isl * N);
     SMC_GLOBAL(const double) lwo = SMC_AS_GLOBAL(const double, f_lw(a, t - 1) + (i64)isl * N);
-    SMC_GLOBAL(const i64) A = SMC_AS_GLOBAL(const i64, f_A(a, t) + (i64)isl * N);
+    SMC_GLOBAL(const u32) A = SMC_AS_GLOBAL(const u32, f_A(a, t) + (i64)isl * N);
     SMC_GLOBAL(const double) zt =
         SMC_AS_GLOBAL(const double, a.zt ? a.zt + ((i64)t * a.n_islands + isl) * N * d : nullptr);
     const bool first = (t == 0);
@@ -162,12 +162,17 @@ k_propagate_mv(const FArgs av, const double* __restrict__ C)
     // loads are unconditional on clamped addresses and masked afterwards (selects, not
     // exec-mask regions: those cost an SGPR pair each and spill)
     constexpr bool dfull = DFULL;               // d == DP: no padded dimensions to mask
-    auto parent = [&](int it, int gi) -> i64 {                              // core.py:332 / :336
+    // The ancestor word of iteration it is REQUESTED two iterations ahead and only looked at
+    // when its row is requested (one iteration ahead): touching it earlier -- even to widen it
+    // to 64 bits -- makes the compiler wait for it, and with it for the row loads in flight.
+    auto parent_raw = [&](int it, int gi) -> u32 {
+        const i64 nn = particle(it, gi);
+        return A[nn < N ? nn : N - 1];
+    };
+    auto parent_row = [&](int it, int gi, u32 raw) -> i64 {               // core.py:332 / :336
         const i64 nn = particle(it, gi);
         const bool ok = !first && it < nit && nn < N;
-        const i64 nc = nn < N ? nn : N - 1;
-        const i64 r = resample ? A[nc] : nc;
-        return ok ? r : -1;
+        return ok ? (resample ? (i64)raw : nn) : -1;
     };
     auto load_row = [&](SMC_GLOBAL(const double) base, i64 row, double (&dst)[NV]) {
         const bool rv = row >= 0;
@@ -186,12 +191,12 @@ k_propagate_mv(const FArgs av, const double* __restrict__ C)
     };
     static_assert(MV_G == 1, "the per-particle tail below assumes one group per iteration");
     double kw = 0.0, kz = 0.0, ku = 0.0;
-    i64 rnext[MV_G];
+    u32 anext[MV_G];
     double nx[MV_G][NV];
 #pragma unroll
     for (int gi = 0; gi < MV_G; ++gi) {
-        load_row(Xo, parent(0, gi), nx[gi]);
-        rnext[gi] = parent(1, gi);
+        load_row(Xo, parent_row(0, gi, parent_raw(0, gi)), nx[gi]);
+        anext[gi] = parent_raw(1, gi);
     }
 #pragma unroll 1
     for (int it = 0; it < nit; ++it) {
@@ -206,8 +211,8 @@ k_propagate_mv(const FArgs av, const double* __restrict__ C)
             valid[gi] = n[gi] < N;
 #pragma unroll
             for (int kb = 0; kb < NV; ++kb) v[gi][kb] = nx[gi][kb];
-            load_row(Xo, rnext[gi], nx[gi]);
-            rnext[gi] = parent(it + 2, gi);
+            load_row(Xo, parent_row(it + 1, gi, anext[gi]), nx[gi]);
+            anext[gi] = parent_raw(it + 2, gi);
         }
         // ---- mean of the proposal -> ax ; guided keeps m = F xp in am
 #pragma unroll
@@ -357,12 +362,12 @@ k_propagate_mv(const FArgs av, const double* __restrict__ C)
 
 // X_{t-1}[A] for SMC.Xp, (N,d)
 __global__ void __launch_bounds__(SMC_BLOCK)
-k_f_gather_rows(const double* X, const i64* A, i64 N, int d, double* Xp)
+k_f_gather_rows(const double* X, const u32* A, i64 N, int d, double* Xp)
 {
     const i64 i = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;
     if (i < N * d) {
         const i64 nn = i / d;
-        Xp[i] = X[A[nn] * d + (i - nn * d)];
+        Xp[i] = X[(i64)A[nn] * d + (i - nn * d)];
     }
 }
 

@@ -53,6 +53,8 @@ template <class T> inline T smc_ldg(const T* p) { return *p; }
 template <class T> inline void smc_stg(T* p, T v) { *p = v; }
 template <class T> inline void smc_ld2g(const T* p, T& a, T& b) { a = p[0]; b = p[1]; }
 template <class T> inline void smc_st2g(T* p, T a, T b) { p[0] = a; p[1] = b; }
+template <class T> inline void smc_ld4g(const T* p, T (&o)[4]) { for (int i = 0; i < 4; ++i) o[i] = p[i]; }
+template <class T> inline void smc_st4g(T* p, const T (&v)[4]) { for (int i = 0; i < 4; ++i) p[i] = v[i]; }
 #else
 template <class T> __device__ __forceinline__ T smc_ldg(const T* p) { return *SMC_AS_GLOBAL(const T, p); }
 template <class T> __device__ __forceinline__ void smc_stg(T* p, T v) { *SMC_AS_GLOBAL(T, p) = v; }
@@ -67,5 +69,17 @@ template <class T> __device__ __forceinline__ void smc_st2g(T* p, T a, T b)
     typedef T v2 __attribute__((ext_vector_type(2)));
     v2 v; v.x = a; v.y = b;
     *SMC_AS_GLOBAL(v2, p) = v;
+}
+template <class T> __device__ __forceinline__ void smc_ld4g(const T* p, T (&o)[4])
+{
+    typedef T v4 __attribute__((ext_vector_type(4)));
+    const v4 v = *SMC_AS_GLOBAL(const v4, p);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+template <class T> __device__ __forceinline__ void smc_st4g(T* p, const T (&v)[4])
+{
+    typedef T v4 __attribute__((ext_vector_type(4)));
+    v4 w; w.x = v[0]; w.y = v[1]; w.z = v[2]; w.w = v[3];
+    *SMC_AS_GLOBAL(v4, p) = w;
 }
 #endif
