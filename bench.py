@@ -234,7 +234,9 @@ def main():
                                      else BYTES_PREPARE + 8.0) * N * a.islands
                 / ((out["ms_per_step"] - mv.value) * 1e-3) / 1e9
                 if out["ms_per_step"] > mv.value else None,
-                "note": "per particle-step: k_propagate 32 B (read A, gather X; write X, lw), "
+                "note": "algorithmic bytes in SURVEY 8d's accounting (int64 ancestors; they are stored as "
+                        "32-bit words, so the kernels physically move 4 B less per particle each). "
+                        "Per particle-step: k_propagate 32 B (read A, gather X; write X, lw), "
                         "k_ancestors 16 B (read lw, write A; + 8 B for k_prepare's pass over lw beyond "
                         "2048 workgroups per launch). kernel_ms = (HIP-event interval around whole steps) - "
                         "(interval around the resampling kernels only), alternating steps, so the "
