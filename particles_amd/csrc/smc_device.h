@@ -85,7 +85,6 @@ __device__ __forceinline__ void smc_normal_pair(u64 seed, u32 pair, u32 t, u32 i
 __device__ __forceinline__ void smc_st_agent(u64* p, u64 v) { *p = v; }
 __device__ __forceinline__ u64 smc_ld_agent(const u64* p) { return *p; }
 __device__ __forceinline__ void smc_drain_stores() {}
-__device__ __forceinline__ void smc_drain_stores_but4() {}
 __device__ __forceinline__ void smc_spin_pause() {}
 #else
 __device__ __forceinline__ void smc_st_agent(u64* p, u64 v)
@@ -101,11 +100,6 @@ __device__ __forceinline__ void smc_drain_stores()
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 __device__ __forceinline__ void smc_spin_pause() { __builtin_amdgcn_s_sleep(2); }
-// all but the 4 most recent vector-memory instructions of this wave have retired
-__device__ __forceinline__ void smc_drain_stores_but4()
-{
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-}
 #endif
 // A value every lane of the wavefront holds identically (loaded through a per-lane
 // address the compiler cannot prove uniform) -> an SGPR copy: conditions on it become

@@ -85,7 +85,7 @@ struct FArgs {
     int dx, dy, dp;        // state / observation dimension, dx padded to 4, 8, 16 or 32
     int mv_chunks;         // 256-particle chunks per workgroup of k_propagate_mv
     const double* mvc;     // MVLINGAUSS: derived constants (see smc_filter_mv.h)
-    u64* trace;            // SMC_TRACE builds: (n_islands, ntiles, 8) shader-clock stamps of k_move
+    u64* trace;            // SMC_TRACE builds: shader-clock stamps of the last step's workgroups
 };
 
 __host__ __device__ __forceinline__ i64 f_slot(const FArgs& a, i64 t)
@@ -197,13 +197,9 @@ __device__ __forceinline__ double f_weight(double lw, double m, double rs)
 }
 
 // ---------------------------------------------------------------------------
-// 2 / 4 consecutive elements per thread as 16-byte accesses when possible
+// 4 consecutive elements per thread as 16-byte accesses when possible
 // ---------------------------------------------------------------------------
-struct alignas(16) F2u { u64 a, b; };
-struct alignas(16) F2d { double a, b; };
-struct alignas(16) F2i { i64 a, b; };
-
-template <class T, class T2>
+template <class T>
 __device__ __forceinline__ void f_load4(const T* p, i64 j, i64 N, bool vec, T fill, T (&o)[4])
 {
     if (vec && j + 3 < N) {
@@ -214,7 +210,7 @@ __device__ __forceinline__ void f_load4(const T* p, i64 j, i64 N, bool vec, T fi
         for (int i = 0; i < 4; ++i) o[i] = (j + i < N) ? smc_ldg(p + j + i) : fill;
     }
 }
-template <class T, class T2>
+template <class T>
 __device__ __forceinline__ void f_store4(T* p, i64 n, bool full_vec, const bool (&ok)[4],
                                          const T (&v)[4])
 {
@@ -227,17 +223,6 @@ __device__ __forceinline__ void f_store4(T* p, i64 n, bool full_vec, const bool 
             if (ok[i]) smc_stg(p + n + i, v[i]);
     }
 }
-template <class T, class T2>
-__device__ __forceinline__ void f_store2(T* p, i64 n, bool vec2, bool ok0, bool ok1, T v0, T v1)
-{
-    if (vec2 && ok0 && ok1) {
-        smc_st2g(p + n, v0, v1);
-    } else {
-        if (ok0) smc_stg(p + n, v0);
-        if (ok1) smc_stg(p + n + 1, v1);
-    }
-}
-
 // Ticket of the "last workgroup done" pattern (smc_device.h, "Publishing ..."):
 // thread 0 has published this workgroup's values with smc_st_agent*, drains its
 // stores and takes a ticket; the workgroup that draws the last ticket reads
@@ -254,13 +239,10 @@ __device__ __forceinline__ void f_store2(T* p, i64 n, bool vec2, bool ok0, bool 
 #define F_DIRECT_PREFIX_MAX 2048
 #define F_CNT_STRIDE 16                       /* unsigned per counter: one 64-byte line */
 #define F_CNT_WORDS (34 * F_CNT_STRIDE)       /* top + 32 shards (+ pad) */
-__device__ __forceinline__ bool f_last_block(unsigned* cnt, int b, int nblocks, int* s_flag,
-                                             int later = 0)
+__device__ __forceinline__ bool f_last_block(unsigned* cnt, int b, int nblocks, int* s_flag)
 {
     if (threadIdx.x == 0) {
-        // wait for the published values only: `later` = a lower bound on the number
-        // of store instructions this thread issued AFTER them (stores retire in order)
-        if (later >= 4) smc_drain_stores_but4(); else smc_drain_stores();
+        smc_drain_stores();
         const int shards = nblocks >= 64 ? 32 : 1;
         const int s = b & (shards - 1);
         const int size_s = nblocks / shards + (s < nblocks % shards ? 1 : 0);
@@ -293,7 +275,7 @@ k_prepare(const FArgs av)
     const bool vec = (a.N & 3) == 0;
     const i64 j0 = (i64)b * F_TILE + (i64)threadIdx.x * F_IPT;
     double l4[4];
-    f_load4<double, F2d>(lw, j0, a.N, vec, -INFINITY, l4);
+    f_load4<double>(lw, j0, a.N, vec, -INFINITY, l4);
     u64 q4[4], s = 0;
     bool ok[4];
 #pragma unroll
@@ -305,7 +287,7 @@ k_prepare(const FArgs av)
     s = smc_block_sum_u64(s, smu);
     u64* Q = a.Q + (i64)isl * a.ntiles;
     if (threadIdx.x == 0) smc_st_agent(Q + b, s);
-    if (!f_last_block(a.cnt + (isl * 2 + 1) * F_CNT_WORDS, b, a.ntiles, &s_last, 0)) return;
+    if (!f_last_block(a.cnt + (isl * 2 + 1) * F_CNT_WORDS, b, a.ntiles, &s_last)) return;
     // last workgroup: exclusive prefixes of the tile totals (exact integers)
     u64* Qpre = a.Qpre + (i64)isl * a.ntiles;
     const int per = (a.ntiles + SMC_BLOCK - 1) / SMC_BLOCK;
@@ -427,7 +409,7 @@ k_ancestors(const FArgs av)
                  r4 = smc_ldg(info + 4);                      // requested first ...
     double l4[4];
     if (FUSED && SPEC)                                         // ... the data right behind
-        f_load4<double, F2d>(a.lw + (i64)(a.par ^ 1) * a.lslot + (i64)isl * N, jt, N, vec, -INFINITY, l4);
+        f_load4<double>(a.lw + (i64)(a.par ^ 1) * a.lslot + (i64)isl * N, jt, N, vec, -INFINITY, l4);
     const i64 t = (i64)smc_uniform(r0);
     if (t >= a.T || t == 0 || smc_uniform(r1) == 0.0) return;          // step t does not resample
     F_STAMP_A(1);
@@ -446,7 +428,7 @@ k_ancestors(const FArgs av)
         // workgroups are dispatched first, so the wait is short and cannot cycle.
         // k_propagate(t) zeroes Q again.
         const double m = smc_uniform(r3), rs = smc_uniform(r4);
-        if (!SPEC) f_load4<double, F2d>(f_lw(a, t - 1) + (i64)isl * N, jt, N, vec, -INFINITY, l4);
+        if (!SPEC) f_load4<double>(f_lw(a, t - 1) + (i64)isl * N, jt, N, vec, -INFINITY, l4);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             q4[i] = (jt + i < N) ? smc_q62_w(f_weight(l4[i], m, rs)) : 0ull;
@@ -478,7 +460,7 @@ k_ancestors(const FArgs av)
         // k_prepare kept only the tile totals: the Q62 weights are formed again from the
         // log-weights (same expression, same bits) -- 8 B/particle of q traffic less each way
         const double m = smc_uniform(r3), rs = smc_uniform(r4);
-        f_load4<double, F2d>(f_lw(a, t - 1) + (i64)isl * N, jt, N, vec, -INFINITY, l4);
+        f_load4<double>(f_lw(a, t - 1) + (i64)isl * N, jt, N, vec, -INFINITY, l4);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             q4[i] = (jt + i < N) ? smc_q62_w(f_weight(l4[i], m, rs)) : 0ull;
@@ -852,13 +834,6 @@ k_f_write_W(const double* lw, i64 N, const double* row, double* W)
     const double m = row[5], rs = row[6];
     const i64 i = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;
     if (i < N) W[i] = f_weight(lw[i], m, rs);
-}
-
-__global__ void __launch_bounds__(SMC_BLOCK)
-k_f_gather1(const double* X, const u32* A, i64 N, double* Xp)
-{
-    const i64 i = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;
-    if (i < N) Xp[i] = X[A[i]];
 }
 
 // one backward step of the genealogy (smoothing.py:209-219): B_{s-1} = A_s[B_s]
