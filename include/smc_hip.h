@@ -131,6 +131,18 @@ int smc_mvn_logpdf(smc_ctx* ctx, const double* x, int64_t x_rows,
                    const double* loc, int64_t loc_rows, double scale,
                    const double* L_host, int64_t N, int64_t d, double* out);
 
+/* ---- (b) arithmetic for device-resident model code -------------------------
+ * out[i] = a[i*stride_a] (op) b[i*stride_b]  (b == NULL: the scalar alpha).  A user-defined
+ * Feynman-Kac model (core.py:108-197) written with numpy expressions runs on arrays in HBM
+ * through this entry (particles_amd.DeviceArray operators and ufuncs). */
+enum smc_ew_op {
+    SMC_EW_ADD = 0, SMC_EW_SUB, SMC_EW_MUL, SMC_EW_DIV, SMC_EW_RSUB, SMC_EW_RDIV, SMC_EW_NEG,
+    SMC_EW_EXP, SMC_EW_LOG, SMC_EW_SQRT, SMC_EW_COS, SMC_EW_SIN, SMC_EW_ABS, SMC_EW_SQUARE,
+    SMC_EW_POW, SMC_EW_MIN, SMC_EW_MAX, SMC_EW_ARCTAN
+};
+int smc_elementwise(smc_ctx* ctx, int op, const double* a, int64_t stride_a, const double* b,
+                    int64_t stride_b, double alpha, int64_t n, double* out);
+
 /* ---- (f) weighted quantiles (resampling.py:381-417 wquantiles) -------------
  * W (N), x (N,d) device; alphas_host (k) levels; out_host (d,k): for every column the
  * np.interp-olated alpha-quantiles of the weighted sample (argsort, cumsum of the weights

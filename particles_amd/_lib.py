@@ -83,6 +83,7 @@ SIGNATURES = {
     "smc_filter_t": (c_int, [c_vp, P(c_i64)]),
     "smc_filter_summaries": (c_int, [c_vp, P(c_dbl)]),
     "smc_filter_logLt": (c_int, [c_vp, P(c_dbl)]),
+    "smc_elementwise": (c_int, [c_vp, c_int, c_vp, c_i64, c_vp, c_i64, c_dbl, c_i64, c_vp]),
     "smc_wquantiles": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, P(c_dbl), c_int, P(c_dbl)]),
     "smc_residual_split": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, P(c_i64)]),
     "smc_residual_ancestors": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp]),
@@ -178,6 +179,10 @@ _counter = 0
 # reference's run); "philox" = the device's counter-based generator.  Device-resident inputs
 # always use the device generator.  Set with particles_amd.resampling.set_rng().
 RNG_MODE = ["numpy"]
+# Host-facing operators return numpy arrays for numpy inputs (drop-in mode).  With
+# RESIDENT[0] = True (particles_amd.set_resident) they return DeviceArrays instead: a
+# user-defined model then runs its whole step in HBM (DeviceArray supports the arithmetic).
+RESIDENT = [False]
 
 
 def default_device():
@@ -243,6 +248,100 @@ class DeviceArray:
     @property
     def ndim(self):
         return len(self.shape)
+
+    # ---- arithmetic, so that model code written for numpy arrays (xp, x in M / logG of a
+    # FeynmanKac or StateSpaceModel subclass) runs unchanged on arrays that stay in HBM
+    __array_priority__ = 1000.0
+    _EW = {"add": 0, "sub": 1, "mul": 2, "div": 3, "rsub": 4, "rdiv": 5, "neg": 6, "exp": 7,
+           "log": 8, "sqrt": 9, "cos": 10, "sin": 11, "abs": 12, "square": 13, "pow": 14,
+           "min": 15, "max": 16, "arctan": 17}
+
+    def _ew(self, op, other=None):
+        if self.dtype != np.float64:
+            raise TypeError("device arithmetic is defined for float64 arrays")
+        b, sb, alpha, shape = None, 0, 0.0, self.shape
+        a, sa = self, 1
+        if other is not None:
+            if isinstance(other, DeviceArray):
+                if other.size == self.size:
+                    b, sb = other, 1
+                elif other.size == 1:
+                    b, sb = other, 0
+                elif self.size == 1:
+                    sa, b, sb, shape = 0, other, 1, other.shape
+                else:
+                    raise ValueError("operands could not be broadcast together")
+            elif np.ndim(other) == 0 or np.size(other) == 1:
+                alpha = float(np.asarray(other).reshape(-1)[0])
+            else:
+                o = np.asarray(other, dtype=np.float64)
+                if o.size != self.size:
+                    raise ValueError("operands could not be broadcast together")
+                b, sb = DeviceArray.from_numpy(o.reshape(self.shape), context=self.ctx), 1
+        out = DeviceArray(shape, np.float64, self.ctx)
+        check(lib().smc_elementwise(self.ctx.h, self._EW[op], a.ptr, sa, b.ptr if b is not None else None,
+                                    sb, alpha, out.size, out.ptr))
+        return out
+
+    def __add__(self, o): return self._ew("add", o)
+    def __radd__(self, o): return self._ew("add", o)
+    def __sub__(self, o): return self._ew("sub", o)
+    def __rsub__(self, o): return self._ew("rsub", o)
+    def __mul__(self, o): return self._ew("mul", o)
+    def __rmul__(self, o): return self._ew("mul", o)
+    def __truediv__(self, o): return self._ew("div", o)
+    def __rtruediv__(self, o): return self._ew("rdiv", o)
+    def __neg__(self): return self._ew("neg")
+    def __abs__(self): return self._ew("abs")
+
+    def __pow__(self, e):
+        if np.ndim(e) == 0 and e == 2:
+            return self._ew("square")           # as numpy: x ** 2 is x * x
+        if np.ndim(e) == 0 and e == 0.5:
+            return self._ew("sqrt")
+        return self._ew("pow", e)
+
+    _UFUNCS = {"add": ("add", "add"), "subtract": ("sub", "rsub"), "multiply": ("mul", "mul"),
+               "true_divide": ("div", "rdiv"), "divide": ("div", "rdiv"),
+               "minimum": ("min", "min"), "maximum": ("max", "max")}
+    _UNARY = {"exp": "exp", "log": "log", "sqrt": "sqrt", "cos": "cos", "sin": "sin",
+              "absolute": "abs", "fabs": "abs", "negative": "neg", "square": "square",
+              "arctan": "arctan"}
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        """numpy ufuncs called on a DeviceArray (np.exp(x), np.cos(x), 2.0 * x with a numpy
+        scalar on the left, ...) stay on the device."""
+        if method != "__call__" or kwargs:
+            return NotImplemented
+        name = ufunc.__name__
+        if name in self._UNARY and len(inputs) == 1:
+            return inputs[0]._ew(self._UNARY[name])
+        if name == "power" and isinstance(inputs[0], DeviceArray):
+            return inputs[0].__pow__(inputs[1])
+        if name in self._UFUNCS and len(inputs) == 2:
+            fwd, rev = self._UFUNCS[name]
+            if isinstance(inputs[0], DeviceArray):
+                return inputs[0]._ew(fwd, inputs[1])
+            return inputs[1]._ew(rev, inputs[0])
+        return NotImplemented
+
+    def __getitem__(self, idx):
+        """``x[A]`` with a device or host int64 index array (core.py:332 Xp = X[A])."""
+        A = idx if isinstance(idx, DeviceArray) else DeviceArray.from_numpy(
+            np.ascontiguousarray(idx, dtype=np.int64), context=self.ctx)
+        if A.dtype != np.int64 or self.dtype != np.float64:
+            raise TypeError("DeviceArray indexing takes an int64 index array on a float64 array")
+        d = self.size // self.shape[0]
+        out = DeviceArray((A.size,) + tuple(self.shape[1:]), np.float64, self.ctx)
+        check(lib().smc_gather(self.ctx.h, self.ptr, A.ptr, A.size, d, out.ptr))
+        return out
+
+    def squeeze(self):
+        return self
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.get()
+        return a if dtype is None else a.astype(dtype)
 
     def free(self):
         if getattr(self, "ptr", None):

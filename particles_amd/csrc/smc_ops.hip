@@ -319,6 +319,60 @@ extern "C" int smc_inverse_cdf(smc_ctx* ctx, const double* su_dev, const double*
     return resample_launch(ctx, W, N, su, (i64*)A);
 }
 
+// ---- element-wise arithmetic for device-resident model code -------------------
+// A user-defined Feynman-Kac model (core.py:108-197: M0 / M / logG written with numpy
+// expressions on xp, x) keeps working when its arrays live in HBM: DeviceArray routes
+// + - * / ** and the numpy ufuncs it is used with through this one kernel.  + - * / sqrt
+// are IEEE-exact like numpy's; exp / log / sin / cos are the device libm's.
+enum { EW_ADD = 0, EW_SUB, EW_MUL, EW_DIV, EW_RSUB, EW_RDIV, EW_NEG, EW_EXP, EW_LOG, EW_SQRT,
+       EW_COS, EW_SIN, EW_ABS, EW_SQUARE, EW_POW, EW_MIN, EW_MAX, EW_ARCTAN, EW_COUNT };
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_elementwise(int op, const double* a, i64 sa, const double* b, i64 sb, double alpha, i64 n,
+              double* out)
+{
+    const i64 i = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const double x = a[i * sa];
+    const double y = b ? b[i * sb] : alpha;
+    double r;
+    switch (op) {
+    case EW_ADD: r = x + y; break;
+    case EW_SUB: r = x - y; break;
+    case EW_MUL: r = x * y; break;
+    case EW_DIV: r = x / y; break;
+    case EW_RSUB: r = y - x; break;
+    case EW_RDIV: r = y / x; break;
+    case EW_NEG: r = -x; break;
+    case EW_EXP: r = exp(x); break;
+    case EW_LOG: r = log(x); break;
+    case EW_SQRT: r = sqrt(x); break;
+    case EW_COS: r = cos(x); break;
+    case EW_SIN: r = sin(x); break;
+    case EW_ABS: r = fabs(x); break;
+    case EW_SQUARE: r = x * x; break;
+    case EW_POW: r = pow(x, y); break;
+    case EW_MIN: r = (x != x || y != y) ? NAN : fmin(x, y); break;      // np.minimum propagates NaN
+    case EW_MAX: r = (x != x || y != y) ? NAN : fmax(x, y); break;
+    default: r = atan(x); break;
+    }
+    out[i] = r;
+}
+
+extern "C" int smc_elementwise(smc_ctx* ctx, int op, const double* a, int64_t stride_a,
+                               const double* b, int64_t stride_b, double alpha, int64_t n,
+                               double* out)
+{
+    SMC_REQUIRE(ctx && a && out, "null argument");
+    SMC_REQUIRE(op >= 0 && op < EW_COUNT, "unknown element-wise operation");
+    SMC_REQUIRE((stride_a == 0 || stride_a == 1) && (stride_b == 0 || stride_b == 1),
+                "strides must be 0 (broadcast) or 1");
+    if (n <= 0) return SMC_OK;
+    SMC_LAUNCH(k_elementwise, dim3((unsigned)((n + SMC_BLOCK - 1) / SMC_BLOCK)), dim3(SMC_BLOCK),
+               ctx->stream, op, a, (i64)stride_a, b, (i64)stride_b, alpha, (i64)n, out);
+    SMC_LAUNCH_CHECK();
+    return SMC_OK;
+}
+
 // ---- residual resampling (resampling.py:611-626) ----------------------------
 // A[:sip] = arange(N).repeat(floor(M W)) is an inverse CDF on INTEGER weights with the
 // thresholds n+1; the remaining M - sip draws are a multinomial on (M W - floor(M W)) /

@@ -76,7 +76,7 @@ class Normal(LocScaleDist):
         N = _bsize(self.loc, self.scale) if size is None else int(size)
         loc, ls, d1 = _strided(self.loc, N)
         sc, ss, d2 = _strided(self.scale, N)
-        if z is None and _lib.RNG_MODE[0] == "numpy" and not (d1 or d2):
+        if z is None and _lib.RNG_MODE[0] == "numpy":
             z = random.standard_normal(N)      # random.normal(loc, scale, N) draws exactly these
         zd = None
         if z is not None:
@@ -86,7 +86,7 @@ class Normal(LocScaleDist):
         check(lib().smc_normal_rvs(out.ctx.h, loc.ptr, ls, sc.ptr, ss,
                                    zd.ptr if zd is not None else None,
                                    _lib.next_counter(), N, out.ptr))
-        if d1 or d2 or isinstance(z, DeviceArray):
+        if d1 or d2 or isinstance(z, DeviceArray) or _lib.RESIDENT[0]:
             return out
         r = out.get()
         return r if size is not None or N > 1 else r[0]
@@ -99,7 +99,7 @@ class Normal(LocScaleDist):
         sc, ss, d2 = _strided(self.scale, N)
         out = DeviceArray((N,))
         check(lib().smc_normal_logpdf(out.ctx.h, xd.ptr, xs, loc.ptr, ls, sc.ptr, ss, N, out.ptr))
-        return out if (d0 or d1 or d2) else out.get()
+        return out if (d0 or d1 or d2 or _lib.RESIDENT[0]) else out.get()
 
 
 class MvNormal(ProbDist):
@@ -145,7 +145,7 @@ class MvNormal(ProbDist):
         else:
             N = int(size)
         loc, rows, dev = self._loc(N)
-        if z is None and _lib.RNG_MODE[0] == "numpy" and not dev:
+        if z is None and _lib.RNG_MODE[0] == "numpy":
             z = random.standard_normal((N, self.dim))      # stats.norm.rvs(size=(N, d)) (:968)
         zd = None
         if z is not None:
@@ -156,7 +156,7 @@ class MvNormal(ProbDist):
         check(lib().smc_mvn_rvs(out.ctx.h, loc.ptr, rows, float(self.scale), Lp,
                                 zd.ptr if zd is not None else None, _lib.next_counter(),
                                 N, self.dim, out.ptr))
-        return out if (dev or isinstance(z, DeviceArray)) else out.get()
+        return out if (dev or isinstance(z, DeviceArray) or _lib.RESIDENT[0]) else out.get()
 
     def logpdf(self, x):
         """:949-959."""
@@ -172,4 +172,4 @@ class MvNormal(ProbDist):
         La, Lp = _lib.host_dbl(self.L)  # keep La alive across the call
         check(lib().smc_mvn_logpdf(out.ctx.h, xd.ptr, xrows, loc.ptr, rows, float(self.scale),
                                    Lp, N, self.dim, out.ptr))
-        return out if (dx or dl) else out.get()
+        return out if (dx or dl or _lib.RESIDENT[0]) else out.get()

@@ -48,7 +48,7 @@ def exp_and_normalise(lw):
     """W = exp(lw) / sum(exp(lw))  (resampling.py:138-163)."""
     d, host = as_device(np.array(lw, dtype=float) if not isinstance(lw, DeviceArray) else lw)
     W, _, _, _ = _normalise(d)
-    return W.get() if host else W
+    return W.get() if (host and not _lib.RESIDENT[0]) else W
 
 
 def essl(lw):
@@ -143,9 +143,8 @@ class Weights:
         if self.lw is None:
             return self.__class__(lw=delta)
         if isinstance(self.lw, DeviceArray) or isinstance(delta, DeviceArray):
-            a = self.lw.get() if isinstance(self.lw, DeviceArray) else self.lw
-            b = delta.get() if isinstance(delta, DeviceArray) else delta
-            return self.__class__(lw=DeviceArray.from_numpy(a + b))
+            a = self.lw if isinstance(self.lw, DeviceArray) else DeviceArray.from_numpy(self.lw)
+            return self.__class__(lw=a + delta)             # element-wise add on the device
         return self.__class__(lw=self.lw + delta)
 
 
@@ -202,7 +201,7 @@ def inverse_cdf(su, W):
     Wd, hostW = as_device(W)
     A = DeviceArray((sud.size,), np.int64)
     check(lib().smc_inverse_cdf(Wd.ctx.h, sud.ptr, Wd.ptr, sud.size, Wd.size, A.ptr))
-    return A.get() if (host and hostW) else A
+    return A.get() if (host and hostW and not _lib.RESIDENT[0]) else A
 
 
 def uniform_spacings(N):
@@ -224,7 +223,7 @@ def _resample(scheme, W, M):
     Wd, host = as_device(W)
     A = DeviceArray((M,), np.int64)
     u = None
-    if host and _lib.RNG_MODE[0] == "numpy":
+    if _lib.RNG_MODE[0] == "numpy":
         # the reference's draws, in the reference's order (:536, :602, :609)
         if scheme == "systematic":
             u = DeviceArray.from_numpy(random.rand(1))
@@ -234,7 +233,7 @@ def _resample(scheme, W, M):
             u = DeviceArray.from_numpy(uniform_spacings(M))
     check(lib().smc_resample(Wd.ctx.h, _lib.SCHEMES[scheme], Wd.ptr, Wd.size, M,
                              u.ptr if u is not None else None, _lib.next_counter(), A.ptr))
-    return A.get() if host else A
+    return A.get() if (host and not _lib.RESIDENT[0]) else A
 
 
 @resampling_scheme
@@ -273,7 +272,7 @@ def residual(W, M):
         su = su if isinstance(su, DeviceArray) else DeviceArray.from_numpy(su)
     check(lib().smc_residual_ancestors(Wd.ctx.h, Wd.ptr, r.ptr, N, M, sip.value,
                                        su.ptr if su is not None else None, A.ptr))
-    return A.get() if host else A
+    return A.get() if (host and not _lib.RESIDENT[0]) else A
 
 
 @resampling_scheme
@@ -283,14 +282,14 @@ def ssp(W, M):
     device walks the chain, the weights stay resident."""
     Wd, host = as_device(W)
     N = Wd.size
-    if host and _lib.RNG_MODE[0] == "numpy":
+    if _lib.RNG_MODE[0] == "numpy":
         u = DeviceArray.from_numpy(random.rand(N - 1)) if N > 1 else None        # :649
     else:
         u = DeviceArray((max(N - 1, 1),))
         check(lib().smc_uniform(u.ctx.h, _lib.next_counter(), max(N - 1, 1), u.ptr))
     A = DeviceArray((M,), np.int64)
     check(lib().smc_resample_ssp(Wd.ctx.h, Wd.ptr, u.ptr if u is not None else None, N, M, A.ptr))
-    return A.get() if host else A
+    return A.get() if (host and not _lib.RESIDENT[0]) else A
 
 
 @resampling_scheme
@@ -301,7 +300,7 @@ def killing(W, M):
     N = Wd.size
     if M != N:
         raise ValueError("killing resampling defined only for M=N")
-    if host and _lib.RNG_MODE[0] == "numpy":
+    if _lib.RNG_MODE[0] == "numpy":
         u = DeviceArray.from_numpy(random.rand(N))                 # :692
     else:
         u = DeviceArray((N,))
@@ -310,7 +309,7 @@ def killing(W, M):
     nk = _lib.c_i64()
     check(lib().smc_killing_split(Wd.ctx.h, Wd.ptr, u.ptr, N, killed.ptr, ctypes.byref(nk)))
     Am = None
-    if host and _lib.RNG_MODE[0] == "numpy":     # multinomial(W, nkilled) on the reference's draws (:695);
+    if _lib.RNG_MODE[0] == "numpy":              # multinomial(W, nkilled) on the reference's draws (:695);
         su = uniform_spacings(nk.value)   # with nkilled = 0 it still consumes rand(1)
         if nk.value > 0:
             Am = inverse_cdf(DeviceArray.from_numpy(su), Wd)
@@ -319,7 +318,7 @@ def killing(W, M):
     A = DeviceArray((N,), np.int64)
     check(lib().smc_killing_ancestors(Wd.ctx.h, killed.ptr, Am.ptr if Am is not None else None,
                                       N, A.ptr))
-    return A.get() if host else A
+    return A.get() if (host and not _lib.RESIDENT[0]) else A
 
 
 def multinomial_iid(W, M=None):

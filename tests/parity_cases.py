@@ -757,6 +757,68 @@ def check_apf_and_guided_generic(golden):
             assert rel(pf.W, g["W"]) < 1e-9
 
 
+def check_resident_user_model(golden):
+    """A user-defined model written with numpy expressions (here Gordon et al's, transcribed
+    from state_space_models.py:546-577, and StochVol's) run through the template-method step
+    with its arrays resident in HBM (pa.set_resident): DeviceArray arithmetic and ufuncs.
+    Same numpy seed as the reference's run -> the reference's results."""
+    class MyGordon(ssm.StateSpaceModel):
+        default_params = {"a": 0.05, "b": 0.5, "c": 25.0, "d": 8.0, "e": 1.2, "sigmaX": 3.162278}
+
+        def PX0(self):
+            return dists.Normal(scale=2.0)
+
+        def PX(self, t, xp):
+            return dists.Normal(loc=self.b * xp + self.c * xp / (1.0 + xp ** 2)
+                                + self.d * np.cos(self.e * (t - 1)), scale=self.sigmaX)
+
+        def PY(self, t, xp, x):
+            return dists.Normal(loc=self.a * x ** 2)
+
+    class MySV(ssm.StochVol):
+        def _device_params(self, fk_kind):
+            return None                              # not the fused loop: the generic step
+
+    pa.set_resident(True)
+    try:
+        for case, model in (("gordon_boot", MyGordon()), ("sv_systematic", MySV())):
+            g = golden(case)
+            y = list(g["y"])
+            np.random.seed(int(g["run_seed"]))
+            pf = pa.SMC(fk=ssm.Bootstrap(ssm=model, data=y), N=int(g["N"]),
+                        resampling=str(g["scheme"]), ESSrmin=float(g["ESSrmin"]))
+            assert not pf._fused
+            pf.run()
+            assert isinstance(pf.X, pa.DeviceArray) and isinstance(pf.wgts.lw, pa.DeviceArray)
+            assert pf.summaries.rs_flags == [bool(v) for v in g["rs_flags"]]
+            assert rel(pf.summaries.logLts, g["logLts"]) < 1e-9
+            A = np.asarray(pf.A)
+            assert np.mean(A == g["A"]) >= 0.999
+            if np.array_equal(A, g["A"]):
+                assert np.max(np.abs(pf.X.get() - g["X"])) < 1e-11
+                assert np.allclose(np.asarray(pf.wgts.lw), g["lw"], rtol=1e-10, atol=1e-10)
+        # the operators themselves against numpy
+        rng = np.random.default_rng(2)
+        xh, yh = rng.standard_normal(1000), rng.random(1000) + 0.5
+        x, yv = pa.DeviceArray.from_numpy(xh), pa.DeviceArray.from_numpy(yh)
+        for got, want in ((2.0 * x + yv / 3.0 - 1.0, 2.0 * xh + yh / 3.0 - 1.0),
+                          (1.0 / (1.0 + x ** 2), 1.0 / (1.0 + xh ** 2)),
+                          (-(x - yv) * (yv - 2.0), -(xh - yh) * (yh - 2.0)),
+                          (np.sqrt(yv) + yv ** 0.5, 2.0 * np.sqrt(yh)),
+                          (np.float64(3.0) - x, 3.0 - xh),
+                          (np.minimum(x, yv), np.minimum(xh, yh)),
+                          (abs(x), np.abs(xh))):
+            assert np.array_equal(got.get(), want)                  # IEEE-exact operations
+        for got, want in ((np.exp(0.5 * x), np.exp(0.5 * xh)), (np.log(yv), np.log(yh)),
+                          (np.cos(x) * np.sin(x), np.cos(xh) * np.sin(xh)),
+                          (yv ** 1.7, yh ** 1.7)):
+            assert np.allclose(got.get(), want, rtol=1e-14, atol=1e-15)
+        idx = rng.integers(0, 1000, size=500)
+        assert np.array_equal(x[idx].get(), xh[idx])
+    finally:
+        pa.set_resident(False)
+
+
 def check_collectors_on_fused(golden):
     from particles_amd.collectors import Moments
     g = golden("kalman_toy")

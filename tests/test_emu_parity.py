@@ -144,6 +144,10 @@ def test_islands(golden):
     pc.check_islands(1100, 6, golden, scheme="multinomial")
 
 
+def test_resident_user_model(golden):
+    pc.check_resident_user_model(golden)
+
+
 def test_apf_and_guided_generic(golden):
     pc.check_apf_and_guided_generic(golden)
 

@@ -163,6 +163,10 @@ def test_generic_path(golden):
     pc.check_generic_path(golden)
 
 
+def test_resident_user_model(golden):
+    pc.check_resident_user_model(golden)
+
+
 def test_apf_and_guided_generic(golden):
     pc.check_apf_and_guided_generic(golden)
 
