@@ -50,6 +50,7 @@ int smc_ctx_create(int device, uint64_t seed, smc_ctx** out)
     c->seed = seed;
     c->scratch = nullptr;
     c->scratch_bytes = 0;
+    c->pooled_bytes = 0;
     hipDeviceProp_t prop;
     SMC_HIP_CHECK(hipGetDeviceProperties(&prop, device));
     c->n_cu = prop.multiProcessorCount;
@@ -66,6 +67,8 @@ int smc_ctx_destroy(smc_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    for (auto& kv : ctx->pool)
+        for (void* p : kv.second) (void)hipFree(p);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
     (void)hipStreamDestroy(ctx->stream);
@@ -103,12 +106,30 @@ int smc_malloc(smc_ctx* ctx, size_t bytes, void** dptr_out)
 {
     SMC_REQUIRE(ctx && dptr_out, "null argument");
     SMC_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t sz = smc_align_up(bytes ? bytes : 1, 256);
     void* p = nullptr;
-    hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
-    if (e != hipSuccess) {
-        smc_set_error("smc_malloc: %zu bytes: %s", bytes, hipGetErrorString(e));
-        return SMC_ERR_NOMEM;
+    auto it = ctx->pool.find(sz);
+    if (it != ctx->pool.end() && !it->second.empty()) {
+        p = it->second.back();
+        it->second.pop_back();
+        ctx->pooled_bytes -= sz;
+    } else {
+        hipError_t e = hipMalloc(&p, sz);
+        if (e != hipSuccess && ctx->pooled_bytes) {          // give the cached blocks back and retry
+            (void)hipStreamSynchronize(ctx->stream);
+            for (auto& kv : ctx->pool) {
+                for (void* q : kv.second) (void)hipFree(q);
+                kv.second.clear();
+            }
+            ctx->pooled_bytes = 0;
+            e = hipMalloc(&p, sz);
+        }
+        if (e != hipSuccess) {
+            smc_set_error("smc_malloc: %zu bytes: %s", bytes, hipGetErrorString(e));
+            return SMC_ERR_NOMEM;
+        }
     }
+    ctx->live[p] = sz;
     *dptr_out = p;
     return SMC_OK;
 }
@@ -117,6 +138,18 @@ int smc_free(smc_ctx* ctx, void* dptr)
 {
     SMC_REQUIRE(ctx, "null context");
     if (!dptr) return SMC_OK;
+    auto it = ctx->live.find(dptr);
+    if (it == ctx->live.end()) {
+        smc_set_error("smc_free: %p was not allocated by smc_malloc on this context", dptr);
+        return SMC_ERR_INVALID;
+    }
+    const size_t sz = it->second;
+    ctx->live.erase(it);
+    if (ctx->pooled_bytes + sz <= SMC_POOL_MAX_BYTES) {
+        ctx->pool[sz].push_back(dptr);
+        ctx->pooled_bytes += sz;
+        return SMC_OK;
+    }
     SMC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     SMC_HIP_CHECK(hipFree(dptr));
     return SMC_OK;

@@ -5,6 +5,8 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <unordered_map>
+#include <vector>
 
 #include "../../include/smc_hip.h"
 
@@ -16,7 +18,14 @@ struct smc_ctx {
     size_t scratch_bytes;
     hipEvent_t ev0, ev1;
     int n_cu;
+    // smc_malloc / smc_free recycle blocks by exact size: every user of a context is ordered
+    // on its one stream, so a freed block can be handed out again without synchronising (the
+    // temporaries of device-resident model code come and go at kernel-launch rate)
+    std::unordered_map<size_t, std::vector<void*>> pool;
+    std::unordered_map<void*, size_t> live;
+    size_t pooled_bytes;
 };
+#define SMC_POOL_MAX_BYTES ((size_t)8 << 30)
 
 void smc_set_error(const char* fmt, ...);
 
