@@ -33,6 +33,16 @@ alg.run()
 print("user-defined model  : logLt = %.4f, filtering mean at T-1 = %.4f"
       % (alg.logLt, alg.summaries.moments[-1]["mean"]))
 
+# ... with its particles resident in HBM and the device generator, at N = 2^20
+from particles_amd import resampling as rs              # noqa: E402
+particles.set_resident(True)
+rs.set_rng("philox")
+res = particles.SMC(fk=ssm.Bootstrap(ssm=my_model, data=y), N=1 << 20, collect="off")
+res.run()
+print("same model, resident : logLt = %.4f in %.1f ms (N = 2^20)" % (res.logLt, 1e3 * res.cpu_time))
+particles.set_resident(False)
+rs.set_rng("numpy")
+
 # ... a model of the fused family (here the same one, spelled as LinearGauss) runs the whole
 # T-loop on the device, here with 2^20 particles and the complete history kept in HBM
 from particles_amd import kalman                        # noqa: E402
