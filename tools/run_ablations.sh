@@ -8,7 +8,7 @@ import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
         d = json.loads(l); r = d.get('roofline', {})
-        print('%-10s ms/step %.4f  k_move %.4f ms  k_prepare %.4f ms' % ('${v:-base}', d['ms_per_step'], r.get('kernel_ms', 0), r.get('prepare_ms', 0)))
+        print('%-10s ms/step %.4f  propagate %.4f ms  resampling kernels %.4f ms' % ('${v:-base}', d['ms_per_step'], r.get('kernel_ms', 0), r.get('prepare_ms', 0)))
     elif 'rror' in l: print(l.strip())
 "
 done
