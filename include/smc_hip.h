@@ -142,6 +142,11 @@ enum smc_ew_op {
 };
 int smc_elementwise(smc_ctx* ctx, int op, const double* a, int64_t stride_a, const double* b,
                     int64_t stride_b, double alpha, int64_t n, double* out);
+/* strides: 1 = element i, 0 = one value for all, -m = element i mod m (row vector against (N,m)).
+ * out (N,k) = X (N,d) @ M_host (d,k), d, k <= 64: np.dot(xp, F.T) in a model's PX / PY
+ * (kalman.py:339-346). */
+int smc_rows_matmul(smc_ctx* ctx, const double* X, int64_t N, int64_t d, const double* M_host,
+                    int64_t k, double* out);
 
 /* ---- (f) weighted quantiles (resampling.py:381-417 wquantiles) -------------
  * W (N), x (N,d) device; alphas_host (k) levels; out_host (d,k): for every column the

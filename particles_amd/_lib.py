@@ -84,6 +84,7 @@ SIGNATURES = {
     "smc_filter_summaries": (c_int, [c_vp, P(c_dbl)]),
     "smc_filter_logLt": (c_int, [c_vp, P(c_dbl)]),
     "smc_elementwise": (c_int, [c_vp, c_int, c_vp, c_i64, c_vp, c_i64, c_dbl, c_i64, c_vp]),
+    "smc_rows_matmul": (c_int, [c_vp, c_vp, c_i64, c_i64, P(c_dbl), c_i64, c_vp]),
     "smc_wquantiles": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, P(c_dbl), c_int, P(c_dbl)]),
     "smc_residual_split": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, P(c_i64)]),
     "smc_residual_ancestors": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp]),
@@ -262,6 +263,8 @@ class DeviceArray:
         b, sb, alpha, shape = None, 0, 0.0, self.shape
         a, sa = self, 1
         if other is not None:
+            if not isinstance(other, DeviceArray) and np.size(other) > 1:
+                other = DeviceArray.from_numpy(np.asarray(other, dtype=np.float64), context=self.ctx)
             if isinstance(other, DeviceArray):
                 if other.size == self.size:
                     b, sb = other, 1
@@ -269,15 +272,14 @@ class DeviceArray:
                     b, sb = other, 0
                 elif self.size == 1:
                     sa, b, sb, shape = 0, other, 1, other.shape
+                elif self.ndim == 2 and other.size == self.shape[1]:      # (N, d) with a (d,) row
+                    b, sb = other, -self.shape[1]
+                elif other.ndim == 2 and self.size == other.shape[1]:
+                    sa, b, sb, shape = -other.shape[1], other, 1, other.shape
                 else:
                     raise ValueError("operands could not be broadcast together")
-            elif np.ndim(other) == 0 or np.size(other) == 1:
-                alpha = float(np.asarray(other).reshape(-1)[0])
             else:
-                o = np.asarray(other, dtype=np.float64)
-                if o.size != self.size:
-                    raise ValueError("operands could not be broadcast together")
-                b, sb = DeviceArray.from_numpy(o.reshape(self.shape), context=self.ctx), 1
+                alpha = float(np.asarray(other).reshape(-1)[0])
         out = DeviceArray(shape, np.float64, self.ctx)
         check(lib().smc_elementwise(self.ctx.h, self._EW[op], a.ptr, sa, b.ptr if b is not None else None,
                                     sb, alpha, out.size, out.ptr))
@@ -338,6 +340,25 @@ class DeviceArray:
 
     def squeeze(self):
         return self
+
+    def __matmul__(self, M):
+        """``X @ M`` for device rows ``X`` (N, d) and a small host matrix ``M`` (d, k)."""
+        Mh = np.ascontiguousarray(M, dtype=np.float64)
+        d = self.shape[-1] if self.ndim == 2 else 1
+        if Mh.ndim != 2 or Mh.shape[0] != d:
+            raise ValueError("matmul: shapes (%s) and %s do not align" % (self.shape, Mh.shape))
+        N = self.size // d
+        out = DeviceArray((N, Mh.shape[1]), np.float64, self.ctx)
+        check(lib().smc_rows_matmul(self.ctx.h, self.ptr, N, d, Mh.ctypes.data_as(P(c_dbl)),
+                                    Mh.shape[1], out.ptr))
+        return out
+
+    def __array_function__(self, func, types, args, kwargs):
+        """``np.dot(xp, F.T)`` as the reference's models write it (kalman.py:339)."""
+        if func in (np.dot, np.matmul) and len(args) == 2 and isinstance(args[0], DeviceArray) \
+                and not isinstance(args[1], DeviceArray) and not kwargs:
+            return args[0].__matmul__(args[1])
+        return NotImplemented
 
     def __array__(self, dtype=None, copy=None):
         a = self.get()

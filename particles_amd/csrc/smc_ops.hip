@@ -332,8 +332,9 @@ k_elementwise(int op, const double* a, i64 sa, const double* b, i64 sb, double a
 {
     const i64 i = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;
     if (i >= n) return;
-    const double x = a[i * sa];
-    const double y = b ? b[i * sb] : alpha;
+    // stride 1: element i; 0: one value for all; -m: element i mod m (a row vector against (N, m))
+    const double x = a[sa >= 0 ? i * sa : i % (-sa)];
+    const double y = b ? b[sb >= 0 ? i * sb : i % (-sb)] : alpha;
     double r;
     switch (op) {
     case EW_ADD: r = x + y; break;
@@ -364,11 +365,43 @@ extern "C" int smc_elementwise(smc_ctx* ctx, int op, const double* a, int64_t st
 {
     SMC_REQUIRE(ctx && a && out, "null argument");
     SMC_REQUIRE(op >= 0 && op < EW_COUNT, "unknown element-wise operation");
-    SMC_REQUIRE((stride_a == 0 || stride_a == 1) && (stride_b == 0 || stride_b == 1),
-                "strides must be 0 (broadcast) or 1");
+    SMC_REQUIRE(stride_a <= 1 && stride_b <= 1, "strides must be 1, 0 (broadcast) or -m (row vector)");
     if (n <= 0) return SMC_OK;
     SMC_LAUNCH(k_elementwise, dim3((unsigned)((n + SMC_BLOCK - 1) / SMC_BLOCK)), dim3(SMC_BLOCK),
                ctx->stream, op, a, (i64)stride_a, b, (i64)stride_b, alpha, (i64)n, out);
+    SMC_LAUNCH_CHECK();
+    return SMC_OK;
+}
+
+// out (N,k) = X (N,d) @ M (d,k), M small and shared (np.dot(xp, F.T) of a model's PX / PY)
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_rows_matmul(const double* X, i64 N, int d, const double* M, int k, double* out)
+{
+    __shared__ double sM[64 * 64];
+    for (int i = (int)threadIdx.x; i < d * k; i += SMC_BLOCK) sM[i] = M[i];
+    __syncthreads();
+    const i64 idx = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;
+    if (idx >= N * k) return;
+    const i64 n = idx / k;
+    const int j = (int)(idx - n * k);
+    double acc = 0.0;
+    for (int i = 0; i < d; ++i) acc = fma(X[n * d + i], sM[i * k + j], acc);
+    out[idx] = acc;
+}
+
+extern "C" int smc_rows_matmul(smc_ctx* ctx, const double* X, int64_t N, int64_t d,
+                               const double* M_host, int64_t k, double* out)
+{
+    SMC_REQUIRE(ctx && X && M_host && out, "null argument");
+    SMC_REQUIRE(N > 0 && d > 0 && d <= 64 && k > 0 && k <= 64, "need 0 < d, k <= 64");
+    void* scr;
+    int rc = smc_scratch(ctx, (size_t)(d * k) * 8, &scr);
+    if (rc) return rc;
+    SMC_HIP_CHECK(hipMemcpyAsync(scr, M_host, (size_t)(d * k) * 8, hipMemcpyHostToDevice, ctx->stream));
+    SMC_HIP_CHECK(hipStreamSynchronize(ctx->stream));      // M_host may be a temporary
+    const i64 total = (i64)N * k;
+    SMC_LAUNCH(k_rows_matmul, dim3((unsigned)((total + SMC_BLOCK - 1) / SMC_BLOCK)), dim3(SMC_BLOCK),
+               ctx->stream, X, (i64)N, (int)d, (const double*)scr, (int)k, out);
     SMC_LAUNCH_CHECK();
     return SMC_OK;
 }

@@ -797,6 +797,22 @@ def check_resident_user_model(golden):
             if np.array_equal(A, g["A"]):
                 assert np.max(np.abs(pf.X.get() - g["X"])) < 1e-11
                 assert np.allclose(np.asarray(pf.wgts.lw), g["lw"], rtol=1e-10, atol=1e-10)
+        # a multivariate model as the reference writes it (np.dot(xp, F.T), kalman.py:339-346)
+        class MyMV(kalman.MVLinearGauss_Guarniero_etal):
+            def _device_params(self, fk_kind):
+                return None
+        g = golden("mv4_boot")
+        y = list(g["y"])
+        np.random.seed(int(g["run_seed"]))
+        pf = pa.SMC(fk=ssm.Bootstrap(ssm=MyMV(alpha=0.4, dx=4), data=y), N=int(g["N"]),
+                    resampling=str(g["scheme"]), ESSrmin=float(g["ESSrmin"]))
+        assert not pf._fused
+        pf.run()
+        assert isinstance(pf.X, pa.DeviceArray) and pf.X.shape == (int(g["N"]), 4)
+        assert pf.summaries.rs_flags == [bool(v) for v in g["rs_flags"]]
+        assert rel(pf.summaries.logLts, g["logLts"]) < 1e-9
+        if np.array_equal(np.asarray(pf.A), g["A"]):
+            assert np.max(np.abs(pf.X.get() - g["X"])) < 1e-11
         # the operators themselves against numpy
         rng = np.random.default_rng(2)
         xh, yh = rng.standard_normal(1000), rng.random(1000) + 0.5
@@ -815,6 +831,13 @@ def check_resident_user_model(golden):
             assert np.allclose(got.get(), want, rtol=1e-14, atol=1e-15)
         idx = rng.integers(0, 1000, size=500)
         assert np.array_equal(x[idx].get(), xh[idx])
+        Xh, row, Mh = rng.standard_normal((300, 5)), rng.standard_normal(5), rng.standard_normal((5, 3))
+        Xd = pa.DeviceArray.from_numpy(Xh)
+        assert np.array_equal((Xd * row + 1.0).get(), Xh * row + 1.0)          # (N, d) with a (d,) row
+        assert np.array_equal((row - Xd).get(), row - Xh)
+        assert np.allclose((Xd @ Mh).get(), Xh @ Mh, rtol=1e-13, atol=1e-13)
+        assert np.allclose(np.dot(Xd, Mh).get(), Xh @ Mh, rtol=1e-13, atol=1e-13)
+        assert np.array_equal(Xd[idx[:50] % 300].get(), Xh[idx[:50] % 300])
     finally:
         pa.set_resident(False)
 
