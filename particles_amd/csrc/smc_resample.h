@@ -177,12 +177,46 @@ __device__ __forceinline__ u64 smc_tile_cdf(const u64 (&wq)[IPT], const u64* Qti
     return pre;
 }
 
+// The same count for sorted uniforms that sit in memory (multinomial), by a whole wavefront:
+// a 64-ary search -- 64 probes per round, log64(M) dependent loads instead of log2(M) (a
+// bisection by one lane costs 22 round trips to memory at M = 2^22, per tile).
+// Every lane of the calling wave must take part; all of them get the result.
+__device__ __forceinline__ i64 smc_su_count_le_wave(const SmcSu& s, u64 C)
+{
+    i64 lo = 0, hi = s.M;                 // pred true on [0, lo), false on [hi, M)
+    const int lane = smc_lane();
+    while (lo < hi) {
+        const i64 width = hi - lo;
+        const i64 stride = (width + 63) >> 6;
+        const i64 p = lo + (i64)lane * stride;
+        const bool in = p < hi;
+        const bool le = in && (smc_q62_t(s.u[p]) <= C);
+        const int cnt = (int)smc_wave_sum_u64(le ? 1ull : 0ull);      // monotone: the first cnt probes
+        const int nprobe = (int)((width + stride - 1) / stride);
+        const i64 nlo = cnt > 0 ? lo + (i64)(cnt - 1) * stride + 1 : lo;
+        const i64 nhi = cnt < nprobe ? lo + (i64)cnt * stride : hi;
+        lo = nlo;
+        hi = nhi;
+    }
+    return lo;
+}
+
 // Output range [n_lo, n_hi) of tile b (every thread gets the same values).
 __device__ __forceinline__ void smc_tile_outputs(const SmcSu& su, int b, int ntiles, u64 pre,
                                                  u64 tile_total, i64* sn, i64& n_lo, i64& n_hi)
 {
-    if (threadIdx.x == 0) sn[0] = (b == 0) ? 0 : smc_su_count_le(su, pre);
-    if (threadIdx.x == 64) sn[1] = (b == ntiles - 1) ? su.M : smc_su_count_le(su, pre + tile_total);
+    if (su.scheme == SMC_MULTINOMIAL_) {          // waves 0 and 1, cooperatively
+        if (smc_wave() == 0) {
+            const i64 v = (b == 0) ? 0 : smc_su_count_le_wave(su, pre);
+            if (smc_lane() == 0) sn[0] = v;
+        } else if (smc_wave() == 1) {
+            const i64 v = (b == ntiles - 1) ? su.M : smc_su_count_le_wave(su, pre + tile_total);
+            if (smc_lane() == 0) sn[1] = v;
+        }
+    } else {
+        if (threadIdx.x == 0) sn[0] = (b == 0) ? 0 : smc_su_count_le(su, pre);
+        if (threadIdx.x == 64) sn[1] = (b == ntiles - 1) ? su.M : smc_su_count_le(su, pre + tile_total);
+    }
     __syncthreads();
     n_lo = sn[0];
     n_hi = sn[1];
