@@ -240,6 +240,10 @@ typedef struct smc_filter_opts {
                                * into slot t of (T, n_islands, N[, dx]) arrays instead of alternating
                                * between two (ParticleHistory.save, smoothing.py:181-207, at no extra
                                * traffic); needs T*n_islands*N*(8 dx + 16) bytes of HBM */
+    int32_t moments;          /* 1: the Moments collector on the device (collectors.py:301-317 with
+                               * rs.wmean_and_var): weighted mean and variance of every component of
+                               * X_t after every step, no host round trip (smc_filter_moments) */
+    int32_t reserved;
 } smc_filter_opts;
 
 /* y_host: data, (T, dy) row-major, shared by all islands. */
@@ -271,6 +275,9 @@ enum smc_state_field {
 int smc_filter_get(smc_filter* f, int field, int island, void* out_host);
 /* Algorithmic bytes moved per particle-step and kernel launches
  * per step, for roofline accounting. */
+/* opts.moments filters: out_host (n_islands, t, 2*dx) = per step the dx weighted means, then the
+ * dx weighted variances of the particles (resampling.py:320-338). */
+int smc_filter_moments(smc_filter* f, double* out_host);
 /* theta-level resampling of whole filters (SMC^2, smc_samplers.py:319-361): island i
  * continues from the state of island src_host[i] (particles, log-weights, summaries, step
  * record, parameter row).  Random streams stay tied to the slot.  Not with keep_history. */

@@ -41,7 +41,8 @@ class SmcFilterOpts(ctypes.Structure):
     _fields_ = [("N", c_i64), ("T", c_i64), ("n_islands", ctypes.c_int32),
                 ("scheme", ctypes.c_int32), ("ESSrmin", c_dbl), ("seed", c_u64),
                 ("rng_mode", ctypes.c_int32), ("use_graph", ctypes.c_int32),
-                ("island_offset", ctypes.c_int32), ("keep_history", ctypes.c_int32)]
+                ("island_offset", ctypes.c_int32), ("keep_history", ctypes.c_int32),
+                ("moments", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 # name -> (restype, argtypes): every symbol include/smc_hip.h declares
@@ -92,6 +93,7 @@ SIGNATURES = {
     "smc_killing_split": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, P(c_i64)]),
     "smc_killing_ancestors": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "smc_filter_get": (c_int, [c_vp, c_int, c_int, c_vp]),
+    "smc_filter_moments": (c_int, [c_vp, P(c_dbl)]),
     "smc_filter_permute_islands": (c_int, [c_vp, P(c_i64)]),
     "smc_filter_history": (c_int, [c_vp, c_int, c_i64, c_int, c_vp]),
     "smc_filter_trajectories": (c_int, [c_vp, c_int, P(c_i64)]),

@@ -32,6 +32,13 @@ class Summaries:
         self.rs_flags.extend(bool(v) for v in flags)
 
 
+    def _extend_moments(self, moms):
+        """Bulk append for ``Moments`` collectors evaluated on the device."""
+        for col in self._collectors:
+            if isinstance(col, Moments):
+                col.summary.extend(moms)
+
+
 class Collector:
     """Base class for collectors (collectors.py:234-271)."""
 

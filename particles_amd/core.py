@@ -144,6 +144,12 @@ class SMC:
         else:
             self.summaries = collectors.Summaries(collect)
         self._user_collectors = bool(collect) and collect != "off"
+        # collect=[Moments()] with the default moments: evaluated on the device after every
+        # step (opts.moments), no per-step host work
+        self._device_moments = (
+            self._user_collectors and all(isinstance(c, collectors.Moments) and c.mom_func is None
+                                          for c in collect)
+            and type(fk).default_moments is FeynmanKac.default_moments)
         self.hist = collectors.generate_hist_obj(store_history, self)
         self._store_history = store_history
         if seed is None:
@@ -210,6 +216,7 @@ class SMC:
         o.use_graph = 1 if use_graph else 0
         o.island_offset = island_offset
         o.keep_history = 1 if self._device_hist else 0
+        o.moments = 1 if self._device_moments else 0
         self._ctx = _lib.ctx()
         h = _lib.c_vp()
         check(lib().smc_filter_create(self._ctx.h, ctypes.byref(m), ctypes.byref(o),
@@ -262,6 +269,16 @@ class SMC:
         out = np.empty(shape, dtype=dt)
         check(lib().smc_filter_history(self._f, field, step, island, out.ctypes.data_as(_lib.c_vp)))
         return out
+
+    def _moments(self, island=0):
+        """Per-step {'mean', 'var'} of the particles, computed on the device (opts.moments)."""
+        d = getattr(self, "_d", 1)
+        out = np.empty((self.n_islands, self._n, 2 * d))
+        check(lib().smc_filter_moments(self._f, out.ctypes.data_as(_lib.P(_lib.c_dbl))))
+        rows = out[island]
+        if d == 1:
+            return [{"mean": r[0], "var": r[1]} for r in rows]
+        return [{"mean": r[:d].copy(), "var": r[d:].copy()} for r in rows]
 
     def _trajectories(self, island=0):
         out = np.empty((self._n, self.N), dtype=np.int64)
@@ -451,7 +468,8 @@ class SMC:
 
     def _needs_per_step_host(self):
         host_hist = bool(self.hist) and not getattr(self, "_device_hist", False)
-        return self.verbose or host_hist or self._user_collectors
+        host_coll = self._user_collectors and not (self._fused and self._device_moments)
+        return self.verbose or host_hist or host_coll
 
     def run(self):
         """Run until completion (core.py:391-409); sets ``cpu_time``."""
@@ -463,6 +481,8 @@ class SMC:
             if self.summaries and self.t > first:      # default collectors, in one go
                 s = self._summ()[0]
                 self.summaries._extend_defaults(s[first:, 0], s[first:, 3], s[first:, 4] != 0)
+                if self._device_moments:
+                    self.summaries._extend_moments(self._moments()[first:])
             if self._n:
                 s = self._summ()[0, -1]
                 self.rs_flag, self.loglt = bool(s[4]), float(s[2])

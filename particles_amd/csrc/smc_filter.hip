@@ -95,6 +95,10 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t)
     if (k_prof >= 0 && (k_prof & 1)) (void)hipEventRecord(f->ev[3 * k_prof + 1], st);
     launch_propagate(f);
     if (k_prof >= 0) (void)hipEventRecord(f->ev[3 * k_prof + 2], st);
+    if (f->a.mom) {
+        SMC_LAUNCH(k_f_moments_partials, dim3(f->a.nmb, f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
+        SMC_LAUNCH(k_f_moments_final, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
+    }
 }
 
 extern "C" {
@@ -213,6 +217,9 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     const size_t oSu = carve(need_su ? M * N * 8 : 8);
     const size_t oE = carve(need_su ? M * a.ntiles1 * 8 : 8);
     const size_t oTmp = carve(N * dxm * 8);
+    a.nmb = (int)((o->N + F_MOM_CHUNK - 1) / F_MOM_CHUNK);
+    const size_t oMom = carve(o->moments ? M * T * 2 * dxm * 8 : 8);
+    const size_t oMpart = carve(o->moments ? M * a.nmb * dxm * 3 * 8 : 8);
     const size_t oTrace = carve(M * (size_t)(2 * a.ntiles + 8) * 8 * 8);
     void* slab = nullptr;
     hipError_t e = hipMalloc(&slab, off);
@@ -240,6 +247,10 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     a.su = (double*)(base + oSu);
     a.E = (u64*)(base + oE);
     f->tmp = (double*)(base + oTmp);
+    if (o->moments) {
+        a.mom = (double*)(base + oMom);
+        a.mpart = (double*)(base + oMpart);
+    }
     a.trace = (u64*)(base + oTrace);
     hipStream_t st = ctx->stream;
     SMC_HIP_CHECK(hipMemsetAsync(a.summ, 0, M * (T + 1) * SUMM_STRIDE * 8, st));
@@ -539,6 +550,22 @@ int smc_filter_permute_islands(smc_filter* f, const int64_t* src_host)
     (void)hipFree(tmp);
     SMC_HIP_CHECK(rc);
     f->perm_t = t;
+    return SMC_OK;
+}
+
+int smc_filter_moments(smc_filter* f, double* out_host)
+{
+    SMC_REQUIRE(f && out_host, "null argument");
+    if (!f->a.mom) {
+        smc_set_error("smc_filter_moments: the filter was created without opts.moments");
+        return SMC_ERR_STATE;
+    }
+    const i64 t = f->t_host, T = f->a.T;
+    const size_t w = (size_t)2 * f->a.dx;
+    for (int i = 0; i < f->a.n_islands && t > 0; ++i)
+        SMC_HIP_CHECK(hipMemcpyAsync(out_host + (size_t)i * t * w, f->a.mom + (size_t)i * T * w,
+                                     (size_t)t * w * 8, hipMemcpyDeviceToHost, f->ctx->stream));
+    SMC_HIP_CHECK(hipStreamSynchronize(f->ctx->stream));
     return SMC_OK;
 }
 

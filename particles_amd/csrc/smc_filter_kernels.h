@@ -73,6 +73,9 @@ struct FArgs {
     double* summ;          // (n_islands, T+1, SUMM_STRIDE)
     const double* params;  // (n_islands, PARAM_STRIDE)
     const double* y;       // (T,)
+    double* mom;           // (n_islands, T, 2*dx) weighted mean | variance per step, or null
+    double* mpart;         // (n_islands, nmb, dx, 3) partial sums of k_f_moments_partials
+    int nmb;
     const double* aux;     // (T,) per-step scalar of the transition (GORDON: d cos(e (t-1))) or null
     double* info;          // (n_islands, INFO_STRIDE) record of the step being run
     const double* zt;      // replay normals (T, n_islands, N) or null
@@ -857,4 +860,77 @@ k_f_widen(const u32* A, i64 N, i64* out)
 {
     const i64 i = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;
     if (i < N) out[i] = (i64)A[i];
+}
+
+// ---------------------------------------------------------------------------
+// Moments collector on the device (collectors.py:301-317 with the default
+// FeynmanKac.default_moments = rs.wmean_and_var, resampling.py:320-338): weighted mean
+// and variance of every component of X_t, written per step so that a run with
+// collect=[Moments()] stays one asynchronous launch sequence.  Runs after k_propagate(t)
+// (the record already says t+1).
+// ---------------------------------------------------------------------------
+#define F_MOM_CHUNK 4096
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_f_moments_partials(const FArgs av)
+{
+    const FArgs& a = av;
+    __shared__ double sm[SMC_SM];
+    const int b = (int)blockIdx.x, isl = (int)blockIdx.y;
+    const i64 t = (i64)smc_uniform(smc_ldg(a.info + (i64)isl * INFO_STRIDE)) - 1;     // step just done
+    if (t < 0 || t >= a.T) return;
+    const double* row = a.summ + ((i64)isl * (a.T + 1) + t) * SUMM_STRIDE;
+    const double m = smc_uniform(smc_ldg(row + 5)), rs = smc_uniform(smc_ldg(row + 6));
+    const i64 N = a.N;
+    const int d = a.dx;
+    const double* X = f_X(a, t) + (i64)isl * N * d;
+    const double* lw = f_lw(a, t) + (i64)isl * N;
+    const i64 base = (i64)b * F_MOM_CHUNK;
+    for (int c = 0; c < d; ++c) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        for (int k = 0; k < F_MOM_CHUNK / SMC_BLOCK; ++k) {
+            const i64 i = base + (i64)k * SMC_BLOCK + threadIdx.x;
+            if (i < N) {
+                const double w = f_weight(smc_ldg(lw + i), m, rs);
+                const double x = smc_ldg(X + i * d + c);
+                a0 += w;
+                a1 += w * x;
+                a2 += w * (x * x);
+            }
+        }
+        a0 = smc_block_sum(a0, sm);
+        a1 = smc_block_sum(a1, sm);
+        a2 = smc_block_sum(a2, sm);
+        if (threadIdx.x == 0) {
+            double* p = a.mpart + (((i64)isl * a.nmb + b) * d + c) * 3;
+            p[0] = a0; p[1] = a1; p[2] = a2;
+        }
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_f_moments_final(const FArgs av)
+{
+    const FArgs& a = av;
+    const int isl = (int)blockIdx.x;
+    const i64 t = (i64)smc_uniform(smc_ldg(a.info + (i64)isl * INFO_STRIDE)) - 1;
+    if (t < 0 || t >= a.T) return;
+    const int d = a.dx;
+    __shared__ double sm[SMC_SM];
+    for (int c = 0; c < d; ++c) {
+        double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+        for (int b = (int)threadIdx.x; b < a.nmb; b += SMC_BLOCK) {
+            const double* p = a.mpart + (((i64)isl * a.nmb + b) * d + c) * 3;
+            t0 += p[0]; t1 += p[1]; t2 += p[2];
+        }
+        t0 = smc_block_sum(t0, sm);                            // fixed association order
+        t1 = smc_block_sum(t1, sm);
+        t2 = smc_block_sum(t2, sm);
+        __syncthreads();
+        if (threadIdx.x != 0) continue;
+        // np.average(x, weights=W) = sum(W x) / sum(W)   (resampling.py:335-337)
+        const double mean = t1 / t0, m2 = t2 / t0;
+        double* o = a.mom + ((i64)isl * a.T + t) * 2 * d;
+        o[c] = mean;
+        o[d + c] = m2 - mean * mean;
+    }
 }

@@ -848,7 +848,29 @@ def check_collectors_on_fused(golden):
     y = [np.atleast_1d(v) for v in np.squeeze(g["y"])][:25]
     pf = pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y), N=5000, seed=9,
                 collect=[Moments()], store_history=True)
+    assert pf._device_moments and not pf._needs_per_step_host()      # moments and history on the device
     pf.run()
+    # the device-side Moments against rs.wmean_and_var on the stored history, step by step
+    for t in (0, 7, 24):
+        mv = rs.wmean_and_var(pf.hist.wgts[t].W, pf.hist.X[t])
+        assert abs(pf.summaries.moments[t]["mean"] - mv["mean"]) < 1e-12
+        assert abs(pf.summaries.moments[t]["var"] - mv["var"]) < 1e-11
+    # multivariate: (d,) means and variances
+    rng = np.random.RandomState(5)
+    ymv = [rng.standard_normal((1, 4)) for _ in range(8)]
+    pm = pa.SMC(fk=ssm.GuidedPF(ssm=kalman.MVLinearGauss_Guarniero_etal(alpha=0.4, dx=4), data=ymv),
+                N=3000, seed=2, collect=[Moments()])
+    pm.run()
+    last = pm.summaries.moments[-1]
+    mv = rs.wmean_and_var(pm.W, pm.X)
+    assert last["mean"].shape == (4,) and np.allclose(last["mean"], mv["mean"], atol=1e-12)
+    assert np.allclose(last["var"], mv["var"], atol=1e-11) and len(pm.summaries.moments) == 8
+    # a custom moment function keeps the per-step host path
+    pc_ = pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y[:5]), N=500, seed=9,
+                 collect=[Moments(mom_func=lambda W, X: float(np.sum(W * X)))])
+    assert pc_._needs_per_step_host()
+    pc_.run()
+    assert len(pc_.summaries.moments) == 5 and np.isfinite(pc_.summaries.moments[-1])
     _, means = orc.kalman_loglik(orc.ToySSM(0.2), y)
     est = np.array([m["mean"] for m in pf.summaries.moments])
     assert est.shape == (25,) and np.max(np.abs(est - means)) < 0.1
