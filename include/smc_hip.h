@@ -275,6 +275,9 @@ enum smc_state_field {
 int smc_filter_get(smc_filter* f, int field, int island, void* out_host);
 /* Algorithmic bytes moved per particle-step and kernel launches
  * per step, for roofline accounting. */
+/* PMCMC move of SMC^2 (smc_samplers.py:1129-1143): where accept_host[i] != 0, island i of dst
+ * takes over island i of src (same shapes, model kind and time index; one context). */
+int smc_filter_copy_islands(smc_filter* dst, smc_filter* src, const unsigned char* accept_host);
 /* opts.moments filters: out_host (n_islands, t, 2*dx) = per step the dx weighted means, then the
  * dx weighted variances of the particles (resampling.py:320-338). */
 int smc_filter_moments(smc_filter* f, double* out_host);

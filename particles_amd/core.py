@@ -297,6 +297,17 @@ class SMC:
             self._fk_list = [self._fk_list[int(i)] for i in A]
         self._invalidate()
 
+    def accept_islands_from(self, other, accept):
+        """PMCMC move of SMC^2 (smc_samplers.py:1129-1143): where ``accept[i]`` is true, island i
+        takes over island i of ``other`` (a batch run on the proposed thetas up to the same t)."""
+        acc = np.ascontiguousarray(accept, dtype=np.uint8)
+        if acc.shape != (self.n_islands,):
+            raise ValueError("accept_islands_from: one flag per island")
+        check(lib().smc_filter_copy_islands(self._f, other._f, acc.ctypes.data_as(_lib.c_vp)))
+        if self._fk_list is not None and other._fk_list is not None:
+            self._fk_list = [o if a else s for s, o, a in zip(self._fk_list, other._fk_list, acc)]
+        self._invalidate()
+
     def step_async(self, nsteps=1):
         """Enqueue ``nsteps`` time steps on the device without synchronising."""
         todo = min(nsteps, self.fk.T - self.t)

@@ -553,6 +553,44 @@ int smc_filter_permute_islands(smc_filter* f, const int64_t* src_host)
     return SMC_OK;
 }
 
+// PMCMC move of SMC^2 (smc_samplers.py:1129-1143): a second batch of filters was run on the
+// proposed thetas; where the proposal is accepted, island i of `dst` takes over island i of `src`.
+int smc_filter_copy_islands(smc_filter* dst, smc_filter* src, const unsigned char* accept_host)
+{
+    SMC_REQUIRE(dst && src && accept_host, "null argument");
+    SMC_REQUIRE(dst->ctx == src->ctx, "both filters must live on one context");
+    const FArgs &a = dst->a, &b = src->a;
+    if (a.hist || b.hist) {
+        smc_set_error("smc_filter_copy_islands: not available with keep_history");
+        return SMC_ERR_STATE;
+    }
+    SMC_REQUIRE(a.N == b.N && a.T == b.T && a.n_islands == b.n_islands && a.dx == b.dx &&
+                    dst->kind == src->kind && dst->fk == src->fk && dst->t_host == src->t_host,
+                "the two filters must have the same shape, model kind and time index");
+    const i64 N = a.N, T = a.T, t = dst->t_host;
+    if (t == 0) return SMC_OK;
+    hipStream_t st = dst->ctx->stream;
+    const size_t bx = (size_t)N * a.dx * 8, bl = (size_t)N * 8, bs = (size_t)(T + 1) * SUMM_STRIDE * 8;
+    hipError_t rc = hipSuccess;
+    auto cp = [&](void* d, const void* s_, size_t n) {
+        if (rc == hipSuccess) rc = hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToDevice, st);
+    };
+    for (int i = 0; i < a.n_islands; ++i) {
+        if (!accept_host[i]) continue;
+        cp(f_X(a, t - 1) + (size_t)i * N * a.dx, f_X(b, t - 1) + (size_t)i * N * a.dx, bx);
+        cp(f_lw(a, t - 1) + (size_t)i * N, f_lw(b, t - 1) + (size_t)i * N, bl);
+        cp(a.summ + (size_t)i * (T + 1) * SUMM_STRIDE, b.summ + (size_t)i * (T + 1) * SUMM_STRIDE, bs);
+        cp(a.info + (size_t)i * INFO_STRIDE, b.info + (size_t)i * INFO_STRIDE, INFO_STRIDE * 8);
+        if (dst->kind != SMC_MODEL_MVLINGAUSS)
+            cp((void*)(a.params + (size_t)i * PARAM_STRIDE), b.params + (size_t)i * PARAM_STRIDE,
+               PARAM_STRIDE * 8);
+    }
+    if (rc == hipSuccess) rc = hipStreamSynchronize(st);
+    SMC_HIP_CHECK(rc);
+    dst->perm_t = t;
+    return SMC_OK;
+}
+
 int smc_filter_moments(smc_filter* f, double* out_host)
 {
     SMC_REQUIRE(f && out_host, "null argument");

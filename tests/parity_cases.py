@@ -679,6 +679,25 @@ def check_permute_islands(N, golden):
         assert abs((ll[k] - before[src]) - (full - head)) < 0.3, (k, ll[k] - before[src], full - head)
     with pytest.raises(ValueError):
         b.permute_islands([0, 1])
+    # PMCMC move: islands accepted from a second batch run on other thetas
+    sig2 = [0.3, 0.6, 1.0]
+    cur, prop = mk(), pa.SMC(fk=[ssm.Bootstrap(ssm=kalman.ToySSM(s), data=y) for s in sig2], N=N,
+                             seed=78, collect="off")
+    cur.step_async(t0)
+    prop.step_async(t0)
+    lc, lp = cur.logLts_islands.copy(), prop.logLts_islands.copy()
+    xp1 = prop._get(_lib.FIELD_X, 1).copy()
+    cur.accept_islands_from(prop, [False, True, False])
+    assert np.array_equal(cur.logLts_islands, [lc[0], lp[1], lc[2]])
+    assert np.array_equal(cur._get(_lib.FIELD_X, 1), xp1)
+    cur.step_async(T - t0)
+    full, _ = orc.kalman_loglik(orc.ToySSM(sig2[1]), y)
+    head, _ = orc.kalman_loglik(orc.ToySSM(sig2[1]), y[:t0])
+    assert abs((cur.logLts_islands[1] - lp[1]) - (full - head)) < 0.3      # goes on under the new theta
+    short = mk()
+    short.step_async(3)
+    with pytest.raises(Exception):
+        cur.accept_islands_from(short, [True, True, True])                  # different time index
 
 
 def check_mv_kalman(N, d, fk, scheme="systematic"):
