@@ -280,3 +280,10 @@ def test_c5_islands_full_size(golden):
     ll = pf.logLts_islands
     assert len(set(ll.tolist())) == 32
     assert np.max(np.abs(ll - ll_kalman)) < 0.3 and abs(ll.mean() - ll_kalman) < 0.05
+
+
+def test_property_resampling_on_the_gpu():
+    """The hypothesis properties of tests/test_property_resampling.py against the real library."""
+    import test_property_resampling as tp
+    tp.test_schemes_equal_q62_oracle()
+    tp.test_weights_equal_oracle()
