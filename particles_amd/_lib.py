@@ -128,6 +128,11 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)      # AttributeError if a declared symbol is missing
             fn.restype, fn.argtypes = res, args
+        # the product only ever runs gfx950 code: a build of the C ABI for anything else (the
+        # test-suite's fiber emulator) is accepted only when the test harness says so
+        if b"gfx950" not in L.smc_version() and os.environ.get("SMC_TEST_EMULATOR") != "1":
+            raise RuntimeError("particles_amd: %s is not a gfx950 build (%s); there is no CPU "
+                               "fallback." % (path, L.smc_version().decode()))
         _lib = L
     return _lib
 

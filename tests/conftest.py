@@ -36,6 +36,7 @@ def pytest_configure(config):
         sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
         import build_emu
         os.environ["SMC_HIP_LIBRARY"] = build_emu.build()
+        os.environ["SMC_TEST_EMULATOR"] = "1"        # particles_amd refuses non-gfx950 builds otherwise
 
 
 def load_golden(name):

@@ -64,6 +64,19 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     importlib.reload  # (no reload needed: monkeypatch restores the cached handle)
 
 
+def test_emulator_build_is_refused_outside_the_test_harness(monkeypatch):
+    """The fiber-emulator build of the C ABI loads only when the test harness vouches for it."""
+    from conftest import HAS_GPU
+    if HAS_GPU:
+        pytest.skip("GPU present: the suite runs on the real library")
+    from particles_amd import _lib
+    assert b"gfx950" not in _lib.lib().smc_version()          # this suite runs on the emulator
+    monkeypatch.delenv("SMC_TEST_EMULATOR")
+    monkeypatch.setattr(_lib, "_lib", None)
+    with pytest.raises(RuntimeError, match="not a gfx950 build"):
+        _lib.lib()
+
+
 def test_no_gpu_fails_loudly():
     """On a GPU-less host the REAL library must refuse to create a context."""
     from conftest import HAS_GPU, REAL_LIB
