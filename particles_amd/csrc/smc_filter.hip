@@ -4,6 +4,7 @@
 #include <vector>
 
 #include "smc_filter_mv.h"
+#include "smc_filter_small.h"
 
 // ---------------------------------------------------------------------------
 // host side
@@ -321,6 +322,33 @@ int smc_filter_set_replay(smc_filter* f, const double* z, const double* u)
     return SMC_OK;      // (the argument block travels by value with every launch)
 }
 
+// N <= 1024, univariate, no per-step side kernels: one persistent workgroup per island runs the
+// requested steps in a single launch (smc_filter_small.h)
+static bool small_filter_ok(const smc_filter* f)
+{
+    return f->a.N <= F_TILE && f->kind != SMC_MODEL_MVLINGAUSS && !f->a.mom && !f->prof &&
+           !(f->a.scheme == SMC_MULTINOMIAL && !f->a.ut) && !getenv("SMC_NO_SMALL");
+}
+
+static void launch_small(smc_filter* f, int nsteps)
+{
+    hipStream_t st = f->ctx->stream;
+    const dim3 grid(1, f->a.n_islands);
+    f->a.par = -1;
+#define S_CASE(KINDV, FKV)                                                                       \
+    if (f->kind == KINDV && f->fk == FKV) {                                                      \
+        SMC_LAUNCH((k_filter_small<KINDV, FKV>), grid, dim3(SMC_BLOCK), st, f->a, nsteps);       \
+        return;                                                                                  \
+    }
+    S_CASE(SMC_MODEL_LINGAUSS, SMC_FK_BOOTSTRAP)
+    S_CASE(SMC_MODEL_LINGAUSS, SMC_FK_GUIDED)
+    S_CASE(SMC_MODEL_STOCHVOL, SMC_FK_BOOTSTRAP)
+    S_CASE(SMC_MODEL_GORDON, SMC_FK_BOOTSTRAP)
+    S_CASE(SMC_MODEL_THETALOGISTIC, SMC_FK_BOOTSTRAP)
+    S_CASE(SMC_MODEL_SVLEVERAGE, SMC_FK_BOOTSTRAP)
+#undef S_CASE
+}
+
 int smc_filter_step(smc_filter* f, int64_t nsteps)
 {
     SMC_REQUIRE(f, "null filter");
@@ -330,6 +358,12 @@ int smc_filter_step(smc_filter* f, int64_t nsteps)
     i64 todo = nsteps;
     if (f->t_host + todo > f->a.T) todo = f->a.T - f->t_host;
     if (todo < 0) todo = 0;
+    if (todo > 0 && small_filter_ok(f)) {
+        launch_small(f, (int)(todo > 0x7fffffff ? 0x7fffffff : todo));
+        SMC_LAUNCH_CHECK();
+        f->t_host += todo;
+        return SMC_OK;
+    }
     i64 done = 0;
 #ifndef SMC_EMULATE
     const int GS = 24;                    // even: see enqueue_step

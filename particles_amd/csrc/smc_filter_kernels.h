@@ -383,6 +383,123 @@ k_f_spacing_write(const FArgs av)
 }
 
 // ---------------------------------------------------------------------------
+// The offspring of one tile of parents (shared by k_ancestors and the single-workgroup
+// filter of smc_filter_small.h).  q4: the Q62 weights of this thread's 4 parents jt..jt+3,
+// cex: their exclusive CDF (tile prefix included), pre/total: the tile's prefix and total.
+// Calls sink(n0, ok[4], a4[4]) once per pass of 1024 offspring with the parents a4 of the
+// offspring n0..n0+3 this thread owns in the pass (ok: inside the tile's range).
+// ---------------------------------------------------------------------------
+template <class Sink>
+__device__ __forceinline__ void f_tile_offspring(const FArgs& a, const int isl, const i64 t,
+                                                 const int b, const i64 jt, const i64 j0,
+                                                 const u64 (&q4)[4], const u64 cex, const u64 pre,
+                                                 const u64 total, u64* sC, u32* sP, i64* sn, u32* smx,
+                                                 Sink&& sink)
+{
+    const int tid = (int)threadIdx.x;
+    const i64 N = a.N;
+    const u32 gisl = (u32)(a.island_offset + isl);
+    SmcSu su;
+    su.scheme = a.scheme;
+    su.M = N;
+    su.dM = (double)N;
+    su.u = a.ut ? a.ut + ((i64)t * a.n_islands + isl) * a.ut_stride
+                : (a.scheme == SMC_MULTINOMIAL_ ? a.su + (i64)isl * N : nullptr);
+    su.u_sys = 0.0;
+    su.seed = a.seed;
+    su.t = (u32)t;
+    su.island = gisl;
+    if (a.scheme == SMC_SYSTEMATIC_) {
+        if (su.u) {
+            su.u_sys = su.u[0];
+        } else {
+            u64 x0, x1;
+            smc_philox(0u, su.t, su.island, SMC_STREAM_RESAMPLE, su.seed, x0, x1);
+            su.u_sys = smc_u01_halfopen(x0);
+        }
+    }
+    const bool scatter = (a.scheme == SMC_SYSTEMATIC_ || a.scheme == SMC_STRATIFIED_) && a.log2N >= 0;
+    i64 n_lo, n_hi;
+    i64 ns[F_IPT + 1];
+    if (scatter) {
+        // first offspring of each parent, closed form (smc_resample.h)
+        u64 c = cex;
+        const u64 Us = (u64)(su.u_sys *
+                             __longlong_as_double((long long)(1023 + 62 - a.log2N) << 52));
+#pragma unroll
+        for (int i = 0; i <= F_IPT; ++i) {
+            const i64 j = jt + i;
+            ns[i] = (j == 0) ? 0
+                  : (j >= N ? N
+                     : (a.scheme == SMC_SYSTEMATIC_ ? smc_sys_count_pow2_fast(c, su.u_sys, Us, a.log2N, N)
+                                                    : smc_strat_count_pow2(c, su, a.log2N, N)));
+            if (i < F_IPT) c += q4[i];
+        }
+        if (tid == 0) sn[0] = ns[0];
+        if (tid == SMC_BLOCK - 1) sn[1] = ns[F_IPT];
+        __syncthreads();
+        n_lo = sn[0];
+        n_hi = sn[1];
+    } else {
+        u64 c = cex;
+#pragma unroll
+        for (int i = 0; i < F_IPT; ++i) {
+            c += q4[i];
+            sC[tid * F_IPT + i] = c;
+        }
+        __syncthreads();
+        smc_tile_outputs(su, b, a.ntiles, pre, total, sn, n_lo, n_hi);
+    }
+    const int nvalid = (int)((N - j0 < F_TILE) ? (N - j0) : F_TILE);
+
+    // ---- offspring, 4 consecutive ones per thread per pass
+    for (i64 pb = n_lo & ~(i64)3; pb < n_hi; pb += F_PASS) {
+        const i64 n0 = pb + (i64)tid * 4;
+        bool ok[4];
+        i64 a4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ok[i] = (n0 + i >= n_lo) && (n0 + i < n_hi);
+        if (scatter) {
+            __syncthreads();                           // previous pass has read sP
+            *reinterpret_cast<uint4*>(&sP[tid * 4]) = make_uint4(0u, 0u, 0u, 0u);
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < F_IPT; ++i) {
+                const i64 lo = ns[i] > pb ? ns[i] : pb;
+                const i64 hi = ns[i + 1] < pb + F_PASS ? ns[i + 1] : pb + F_PASS;
+                if (lo < hi) sP[lo - pb] = (u32)(tid * F_IPT + i);
+            }
+            __syncthreads();
+            const uint4 v = *reinterpret_cast<const uint4*>(&sP[tid * 4]);
+            const u32 m0 = v.x, m1 = m0 > v.y ? m0 : v.y, m2 = m1 > v.z ? m1 : v.z,
+                      m3 = m2 > v.w ? m2 : v.w;
+            const u32 inc = smc_wave_scan_max_u32(m3);
+            u32 ex = smc_mov_dpp<SMC_DPP_WAVE_SHR1>(inc);
+            if (smc_lane() == 0) ex = 0u;
+            if (smc_lane() == 63) smx[smc_wave()] = inc;
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < SMC_NWAVE - 1; ++w)
+                if (w < smc_wave()) ex = ex > smx[w] ? ex : smx[w];
+            a4[0] = j0 + (i64)(m0 > ex ? m0 : ex);
+            a4[1] = j0 + (i64)(m1 > ex ? m1 : ex);
+            a4[2] = j0 + (i64)(m2 > ex ? m2 : ex);
+            a4[3] = j0 + (i64)(m3 > ex ? m3 : ex);
+        } else {
+            double s4[4];
+            smc_su_pair(su, n0 >> 1, s4[0], s4[1]);
+            smc_su_pair(su, (n0 >> 1) + 1, s4[2], s4[3]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int jl = ok[i] ? smc_lower_bound_u64(sC, F_TILE, smc_q62_t(s4[i])) : 0;
+                a4[i] = j0 + (jl < nvalid ? jl : nvalid - 1);
+            }
+        }
+        sink(n0, ok, a4);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // k_ancestors(t): integer-only.  One workgroup per tile of 1024 parents: exact
 // CDF of the tile from q and its exclusive prefix, the contiguous range of
 // offspring it owns, and the parent index of each of them -> A.
@@ -472,114 +589,18 @@ k_ancestors(const FArgs av)
         cex = smc_block_exscan_u64(tsum, smu, total);
     }
     cex += pre;                                                      // exclusive CDF, 1st parent
-    SmcSu su;
-    su.scheme = a.scheme;
-    su.M = N;
-    su.dM = (double)N;
-    su.u = a.ut ? a.ut + ((i64)t * a.n_islands + isl) * a.ut_stride
-                : (a.scheme == SMC_MULTINOMIAL_ ? a.su + (i64)isl * N : nullptr);
-    su.u_sys = 0.0;
-    su.seed = a.seed;
-    su.t = (u32)t;
-    su.island = gisl;
-    if (a.scheme == SMC_SYSTEMATIC_) {
-        if (su.u) {
-            su.u_sys = su.u[0];
-        } else {
-            u64 x0, x1;
-            smc_philox(0u, su.t, su.island, SMC_STREAM_RESAMPLE, su.seed, x0, x1);
-            su.u_sys = smc_u01_halfopen(x0);
-        }
-    }
-    const bool scatter = (a.scheme == SMC_SYSTEMATIC_ || a.scheme == SMC_STRATIFIED_) && a.log2N >= 0;
-    i64 n_lo, n_hi;
-    i64 ns[F_IPT + 1];
-    if (scatter) {
-        // first offspring of each parent, closed form (smc_resample.h)
-        u64 c = cex;
-        const u64 Us = (u64)(su.u_sys *
-                             __longlong_as_double((long long)(1023 + 62 - a.log2N) << 52));
-#pragma unroll
-        for (int i = 0; i <= F_IPT; ++i) {
-            const i64 j = jt + i;
-            ns[i] = (j == 0) ? 0
-                  : (j >= N ? N
-                     : (a.scheme == SMC_SYSTEMATIC_ ? smc_sys_count_pow2_fast(c, su.u_sys, Us, a.log2N, N)
-                                                    : smc_strat_count_pow2(c, su, a.log2N, N)));
-            if (i < F_IPT) c += q4[i];
-        }
-        if (tid == 0) sn[0] = ns[0];
-        if (tid == SMC_BLOCK - 1) sn[1] = ns[F_IPT];
-        __syncthreads();
-        n_lo = sn[0];
-        n_hi = sn[1];
-    } else {
-        u64 c = cex;
-#pragma unroll
-        for (int i = 0; i < F_IPT; ++i) {
-            c += q4[i];
-            sC[tid * F_IPT + i] = c;
-        }
-        __syncthreads();
-        smc_tile_outputs(su, b, a.ntiles, pre, total, sn, n_lo, n_hi);
-    }
-    const int nvalid = (int)((N - j0 < F_TILE) ? (N - j0) : F_TILE);
     F_STAMP_A(5);
-
-    // ---- offspring, 4 consecutive ones per thread per pass
-    for (i64 pb = n_lo & ~(i64)3; pb < n_hi; pb += F_PASS) {
-        const i64 n0 = pb + (i64)tid * 4;
-        bool ok[4];
-        i64 a4[4];
+    f_tile_offspring(a, isl, t, b, jt, j0, q4, cex, pre, total, sC, sP, sn, smx,
+                     [&](i64 n0, const bool (&ok)[4], const i64 (&a4)[4]) {                // core.py:329
+                         const u32 a32[4] = {(u32)a4[0], (u32)a4[1], (u32)a4[2], (u32)a4[3]};
+                         if (vec && ok[0] && ok[3]) {
+                             smc_st4g(A + n0, a32);
+                         } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ok[i] = (n0 + i >= n_lo) && (n0 + i < n_hi);
-        if (scatter) {
-            __syncthreads();                           // previous pass has read sP
-            *reinterpret_cast<uint4*>(&sP[tid * 4]) = make_uint4(0u, 0u, 0u, 0u);
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < F_IPT; ++i) {
-                const i64 lo = ns[i] > pb ? ns[i] : pb;
-                const i64 hi = ns[i + 1] < pb + F_PASS ? ns[i + 1] : pb + F_PASS;
-                if (lo < hi) sP[lo - pb] = (u32)(tid * F_IPT + i);
-            }
-            __syncthreads();
-            const uint4 v = *reinterpret_cast<const uint4*>(&sP[tid * 4]);
-            const u32 m0 = v.x, m1 = m0 > v.y ? m0 : v.y, m2 = m1 > v.z ? m1 : v.z,
-                      m3 = m2 > v.w ? m2 : v.w;
-            const u32 inc = smc_wave_scan_max_u32(m3);
-            u32 ex = smc_mov_dpp<SMC_DPP_WAVE_SHR1>(inc);
-            if (smc_lane() == 0) ex = 0u;
-            if (smc_lane() == 63) smx[smc_wave()] = inc;
-            __syncthreads();
-#pragma unroll
-            for (int w = 0; w < SMC_NWAVE - 1; ++w)
-                if (w < smc_wave()) ex = ex > smx[w] ? ex : smx[w];
-            a4[0] = j0 + (i64)(m0 > ex ? m0 : ex);
-            a4[1] = j0 + (i64)(m1 > ex ? m1 : ex);
-            a4[2] = j0 + (i64)(m2 > ex ? m2 : ex);
-            a4[3] = j0 + (i64)(m3 > ex ? m3 : ex);
-        } else {
-            double s4[4];
-            smc_su_pair(su, n0 >> 1, s4[0], s4[1]);
-            smc_su_pair(su, (n0 >> 1) + 1, s4[2], s4[3]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int jl = ok[i] ? smc_lower_bound_u64(sC, F_TILE, smc_q62_t(s4[i])) : 0;
-                a4[i] = j0 + (jl < nvalid ? jl : nvalid - 1);
-            }
-        }
-        {                                                                    // core.py:329
-            const u32 a32[4] = {(u32)a4[0], (u32)a4[1], (u32)a4[2], (u32)a4[3]};
-            if (vec && ok[0] && ok[3]) {
-                smc_st4g(A + n0, a32);
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (ok[i]) smc_stg(A + n0 + i, a32[i]);
-            }
-        }
-    }
+                             for (int i = 0; i < 4; ++i)
+                                 if (ok[i]) smc_stg(A + n0 + i, a32[i]);
+                         }
+                     });
     F_STAMP_A(6);
 }
 

@@ -1,0 +1,169 @@
+// smc_filter_small.h -- the whole T-loop of a small particle filter in ONE launch.
+//
+// With N <= 1024 particles a filter is a single tile: one workgroup holds its particles in
+// registers (4 per thread), resamples through LDS and needs no other workgroup -- so there
+// is nothing to wait for between steps and the loop over time stays inside the kernel.
+// grid = (1, n_islands): every island is one persistent workgroup (the regime of SMC^2 and
+// PMMH, smc_samplers.py:1038-1167: many filters of 10^2..10^3 particles), and a step costs a
+// few microseconds instead of two kernel launches.
+//
+// Same arithmetic, in the same order, as k_ancestors<true> + k_propagate (f_tile_offspring,
+// m_step, the workgroup log-sum-exp): results are bit-identical to the multi-kernel path
+// (tests: check_small_filter_equals_general).  State is written back every step (X, lw, A,
+// summary row) -- a few KB -- so every API call behaves as after the general path.
+#pragma once
+#include "smc_filter_kernels.h"
+
+template <int KIND, int FK>
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_filter_small(const FArgs av, const int nsteps)
+{
+    const FArgs& a = av;
+    __shared__ u64 sC[F_TILE];
+    __shared__ __attribute__((aligned(16))) u32 sP[F_PASS];
+    __shared__ double sX[F_TILE];
+    __shared__ u64 smu[SMC_SM];
+    __shared__ double smd[SMC_SM];
+    __shared__ i64 sn[2];
+    __shared__ u32 smx[SMC_NWAVE];
+    const int isl = (int)blockIdx.y;
+    const int tid = (int)threadIdx.x;
+    const i64 N = a.N;
+    double* info = a.info + (i64)isl * INFO_STRIDE;
+    const u32 gisl = (u32)(a.island_offset + isl);
+    const double* p = a.params + (i64)isl * PARAM_STRIDE;
+    const i64 jt = (i64)tid * F_IPT;                       // this thread's particles jt..jt+3
+    const bool vec = (N & 3) == 0;
+
+    i64 t = (i64)smc_uniform(smc_ldg(info));
+    bool resample = smc_uniform(smc_ldg(info + 1)) != 0.0;
+    double m = smc_uniform(smc_ldg(info + 3)), rs = smc_uniform(smc_ldg(info + 4));
+    double prev_log_mean = 0.0, prev_logLt = 0.0;          // of step t-1 (core.py:355-359)
+    if (t > 0) {
+        const double* prow = a.summ + ((i64)isl * (a.T + 1) + (t - 1)) * SUMM_STRIDE;
+        prev_log_mean = smc_uniform(smc_ldg(prow + 1));
+        prev_logLt = smc_uniform(smc_ldg(prow + 3));
+    }
+    double y_next = (t < a.T) ? a.y[t * a.dy] : 0.0;
+    double aux_next = (KIND == SMC_MODEL_GORDON && a.aux && t < a.T) ? a.aux[t] : 0.0;
+    double x[4], lw[4];
+    if (t > 0) {                                           // continue a run
+        f_load4<double>(f_X(a, t - 1) + (i64)isl * N, jt, N, vec, 0.0, x);
+        f_load4<double>(f_lw(a, t - 1) + (i64)isl * N, jt, N, vec, -INFINITY, lw);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { x[k] = 0.0; lw[k] = -INFINITY; }
+    }
+
+    for (int step = 0; step < nsteps && t < a.T; ++step, ++t) {
+        const bool first = (t == 0);
+        const bool rsp = !first && resample;
+        const double yt = y_next, aux = aux_next;
+        if (t + 1 < a.T) {                                 // requested a whole step ahead
+            y_next = a.y[(t + 1) * a.dy];
+            if (KIND == SMC_MODEL_GORDON && a.aux) aux_next = a.aux[t + 1];
+        }
+        double xp[4], lwp[4];
+        u32* A = f_A(a, t) + (i64)isl * N;
+        if (rsp) {
+            // ---- ancestors: exactly k_ancestors<true> for the single tile b = 0
+            u64 q4[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q4[i] = (jt + i < N) ? smc_q62_w(f_weight(lw[i], m, rs)) : 0ull;
+            const u64 tsum = q4[0] + q4[1] + q4[2] + q4[3];
+            u64 total, pre;
+            const u64 cex = smc_block_exscan_plus_sum_u64(tsum, 0ull, smu, total, pre);
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sX[jt + k] = x[k];                 // parents' states for the gather
+            i64 an[4] = {0, 0, 0, 0};
+            f_tile_offspring(a, isl, t, 0, jt, 0, q4, cex, 0ull, total, sC, sP, sn, smx,
+                             [&](i64 n0, const bool (&ok)[4], const i64 (&a4)[4]) {
+                                 // N <= 1024: one pass, n0 == jt
+#pragma unroll
+                                 for (int i = 0; i < 4; ++i) an[i] = ok[i] ? a4[i] : 0;
+                                 const u32 a32[4] = {(u32)an[0], (u32)an[1], (u32)an[2], (u32)an[3]};
+                                 if (vec && ok[0] && ok[3]) {
+                                     smc_st4g(A + n0, a32);
+                                 } else {
+#pragma unroll
+                                     for (int i = 0; i < 4; ++i)
+                                         if (ok[i]) smc_stg(A + n0 + i, a32[i]);
+                                 }
+                             });
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { xp[k] = sX[an[k]]; lwp[k] = 0.0; }        // core.py:332
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { xp[k] = first ? 0.0 : x[k]; lwp[k] = first ? 0.0 : lw[k]; }
+        }
+        // ---- standard normals (same counters as k_propagate), propagate, weigh
+        double z[4];
+        if (a.zt) {
+            const double* zt = a.zt + ((i64)t * a.n_islands + isl) * N;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) z[k] = (jt + k < N) ? smc_ldg(zt + jt + k) : 0.0;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k += 2)
+                smc_normal_pair(a.seed, (u32)((jt + k) >> 1), (u32)t, gisl, SMC_STREAM_NORMAL, z[k], z[k + 1]);
+        }
+        bool okp[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            okp[k] = jt + k < N;
+            double inc;
+            x[k] = m_step<KIND, FK>(p, first, yt, aux, xp[k], z[k], inc);
+            double l = (rsp || first) ? inc : lwp[k] + inc;                         // resampling.py:241-244
+            if (l != l) l = -INFINITY;                                              // resampling.py:220
+            lw[k] = okp[k] ? l : -INFINITY;
+        }
+        f_store4<double>(f_X(a, t) + (i64)isl * N, jt, vec && okp[3], okp, x);
+        f_store4<double>(f_lw(a, t) + (i64)isl * N, jt, vec && okp[3], okp, lw);
+        // ---- log-sum-exp of the workgroup = of the filter (as in k_propagate)
+        double tm = lw[0];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) tm = smc_max2(tm, lw[k]);
+        const double gm = smc_block_max(tm, smd);
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double e = (lw[k] > -INFINITY) ? smc_exp_nonpos(lw[k] - gm) : 0.0;
+            s1 += e;
+            s2 = fma(e, e, s2);
+        }
+        smc_block_sum2(s1, s2, smd);
+        // ---- finalise step t (every thread computes the same scalars), decide step t+1
+        const bool bad = !(gm > -INFINITY) || !(gm < INFINITY);
+        const double ess = bad ? NAN : (s1 * s1) / s2;                              // resampling.py:226
+        const double log_mean = bad ? NAN : gm + log(s1 / (double)N);               // resampling.py:224
+        double* row = a.summ + ((i64)isl * (a.T + 1) + t) * SUMM_STRIDE;
+        double loglt;                                                               // core.py:355-359
+        if (first || rsp) loglt = log_mean;
+        else loglt = log_mean - prev_log_mean;
+        const double logLt = (first ? 0.0 : prev_logLt) + loglt;
+        prev_log_mean = log_mean;
+        prev_logLt = logLt;
+        if (tid == 0) {
+            row[0] = ess;
+            row[1] = log_mean;
+            row[2] = loglt;
+            row[3] = logLt;
+            row[4] = rsp ? 1.0 : 0.0;
+            row[5] = gm;
+            row[6] = bad ? NAN : 1.0 / s1;
+        }
+        m = gm;
+        rs = bad ? NAN : 1.0 / s1;
+        resample = (t + 1 < a.T) && (ess < a.ess_thresh);                           // core.py:181-183
+    }
+    if (tid == 0) {                 // the step record the other kernels / the next launch read
+        info[0] = (double)t;
+        info[1] = resample ? 1.0 : 0.0;
+        info[2] = (t < a.T) ? a.y[t * a.dy] : 0.0;
+        info[3] = m;
+        info[4] = rs;
+        info[5] = (a.aux && t < a.T) ? a.aux[t] : 0.0;
+    }
+}

@@ -478,6 +478,53 @@ def check_unfused_path(golden, monkeypatch):
     assert np.array_equal(a.logLts_islands, b.logLts_islands) and np.array_equal(a.X, b.X)
 
 
+def check_small_filter_equals_general(golden, monkeypatch, full=True):
+    """N <= 1024: the single-launch, single-workgroup filter (smc_filter_small.h) gives the
+    bits of the multi-kernel path -- models, schemes, adaptive resampling, islands, stepping
+    one step at a time, history -- and replays the reference's run."""
+    g = golden("kalman_toy")
+    y = [np.atleast_1d(v) for v in np.squeeze(g["y"])][:60]
+    cases = [
+        (lambda: kalman.ToySSM(0.2), ssm.Bootstrap, "systematic", 1000, 0.5),
+        (lambda: kalman.ToySSM(0.2), ssm.Bootstrap, "systematic", 1024, 0.5),
+        (lambda: kalman.ToySSM(0.2), ssm.Bootstrap, "stratified", 512, 0.5),
+        (lambda: kalman.ToySSM(0.2), ssm.Bootstrap, "stratified", 777, 1.0),
+        (lambda: kalman.LinearGauss(rho=0.9, sigmaX=1.0, sigmaY=1.5), ssm.Bootstrap, "systematic", 300, 0.5),
+        (lambda: kalman.LinearGauss(rho=0.9, sigmaX=1.0, sigmaY=0.3), ssm.GuidedPF, "systematic", 640, 0.5),
+        (lambda: ssm.StochVol(), ssm.Bootstrap, "systematic", 1000, 0.7),
+        (lambda: ssm.Gordon_etal(), ssm.Bootstrap, "stratified", 256, 0.5),
+        (lambda: ssm.ThetaLogistic(), ssm.Bootstrap, "systematic", 100, 0.5),
+        (lambda: ssm.StochVolLeverage(phi=-0.4), ssm.Bootstrap, "systematic", 1, 0.5),
+    ]
+    if not full:                     # the fiber emulator is slow: a representative subset
+        cases = [cases[0], cases[3], cases[5], cases[7], cases[9]]
+    for mk, cls, scheme, N, essr in cases:
+        runs = []
+        for small in (True, False):
+            if small:
+                monkeypatch.delenv("SMC_NO_SMALL", raising=False)
+            else:
+                monkeypatch.setenv("SMC_NO_SMALL", "1")
+            pf = pa.SMC(fk=cls(ssm=mk(), data=y), N=N, resampling=scheme, ESSrmin=essr, seed=5,
+                        n_islands=3, store_history=(N == 300))
+            pf.step_async(7)
+            for _ in range(4):
+                next(pf)
+            pf.run()
+            runs.append((pf.logLts_islands.copy(), pf._get(_lib.FIELD_X, 2).copy(), pf._summ().copy(),
+                         pf._get(_lib.FIELD_A, 1).copy(), pf.wgts.lw.copy(),
+                         pf.hist.X[20].copy() if N == 300 else None))
+        for u, v in zip(*runs):
+            assert (u is None and v is None) or np.array_equal(u, v, equal_nan=True), (scheme, N)
+    monkeypatch.delenv("SMC_NO_SMALL", raising=False)
+    # and the reference's own run through it (replay of its draws)
+    if full:
+        check_filter_replay(golden, "toy_systematic", "toy", "bootstrap", T=40)
+        check_filter_replay(golden, "toy_stratified", "toy", "bootstrap", T=40)
+        check_filter_replay(golden, "toy_multinomial", "toy", "bootstrap", T=40)
+        check_filter_replay(golden, "lg_adaptive", "lg_adaptive", "bootstrap", T=60)
+
+
 def check_edge_sizes():
     """Ragged and tiny populations, single-step runs, every scheme (partial
     wavefronts, partial tiles, tiles with no offspring)."""

@@ -126,6 +126,10 @@ def test_unfused_path(golden, monkeypatch):
     pc.check_unfused_path(golden, monkeypatch)
 
 
+def test_small_filter_equals_general(golden, monkeypatch):
+    pc.check_small_filter_equals_general(golden, monkeypatch)
+
+
 def test_edge_sizes():
     pc.check_edge_sizes()
 
