@@ -4,6 +4,7 @@ small sizes.  This is test infrastructure for the GPU-less build container --
 the parity claims proper are made by tests/test_gpu_parity.py on an MI355X.
 Skipped when a GPU is visible (the real library is then loaded instead).
 """
+import numpy as np
 import pytest
 
 import parity_cases as pc
@@ -162,3 +163,16 @@ def test_permute_islands(golden):
 
 def test_collectors_and_history(golden):
     pc.check_collectors_on_fused(golden)
+
+
+def test_smc2_example():
+    """examples/smc2_toy.py: SMC^2 assembled from the island primitives recovers sigma."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "smc2_toy", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                 "examples", "smc2_toy.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mean, sd = mod.main(T=12, Ntheta=6, Nx=64)
+    assert np.isfinite(mean) and np.isfinite(sd) and 0.05 < mean < 2.0

@@ -291,3 +291,16 @@ def test_property_resampling_on_the_gpu():
     import test_property_resampling as tp
     tp.test_schemes_equal_q62_oracle()
     tp.test_weights_equal_oracle()
+
+
+def test_smc2_example():
+    """examples/smc2_toy.py: SMC^2 assembled from the island primitives recovers sigma."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "smc2_toy", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                 "examples", "smc2_toy.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mean, sd = mod.main(T=60, Ntheta=128, Nx=256)
+    assert np.isfinite(mean) and np.isfinite(sd) and abs(mean - 0.3) < 0.15
