@@ -337,7 +337,11 @@ static void launch_small(smc_filter* f, int nsteps)
     f->a.par = -1;
 #define S_CASE(KINDV, FKV)                                                                       \
     if (f->kind == KINDV && f->fk == FKV) {                                                      \
-        SMC_LAUNCH((k_filter_small<KINDV, FKV>), grid, dim3(SMC_BLOCK), st, f->a, nsteps);       \
+        if (f->a.N <= 256)                                                                       \
+            SMC_LAUNCH((k_filter_small<KINDV, FKV, 64>), grid, dim3(64), st, f->a, nsteps);      \
+        else                                                                                     \
+            SMC_LAUNCH((k_filter_small<KINDV, FKV, SMC_BLOCK>), grid, dim3(SMC_BLOCK), st, f->a, \
+                       nsteps);                                                                  \
         return;                                                                                  \
     }
     S_CASE(SMC_MODEL_LINGAUSS, SMC_FK_BOOTSTRAP)

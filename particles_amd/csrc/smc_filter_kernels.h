@@ -389,13 +389,14 @@ k_f_spacing_write(const FArgs av)
 // Calls sink(n0, ok[4], a4[4]) once per pass of 1024 offspring with the parents a4 of the
 // offspring n0..n0+3 this thread owns in the pass (ok: inside the tile's range).
 // ---------------------------------------------------------------------------
-template <class Sink>
+template <int BS = SMC_BLOCK, class Sink>
 __device__ __forceinline__ void f_tile_offspring(const FArgs& a, const int isl, const i64 t,
                                                  const int b, const i64 jt, const i64 j0,
                                                  const u64 (&q4)[4], const u64 cex, const u64 pre,
                                                  const u64 total, u64* sC, u32* sP, i64* sn, u32* smx,
                                                  Sink&& sink)
 {
+    constexpr int TILE = BS * F_IPT, PASS = BS * 4, NW = BS / 64;     // of THIS workgroup size
     const int tid = (int)threadIdx.x;
     const i64 N = a.N;
     const u32 gisl = (u32)(a.island_offset + isl);
@@ -436,7 +437,7 @@ __device__ __forceinline__ void f_tile_offspring(const FArgs& a, const int isl, 
             if (i < F_IPT) c += q4[i];
         }
         if (tid == 0) sn[0] = ns[0];
-        if (tid == SMC_BLOCK - 1) sn[1] = ns[F_IPT];
+        if (tid == BS - 1) sn[1] = ns[F_IPT];
         __syncthreads();
         n_lo = sn[0];
         n_hi = sn[1];
@@ -448,12 +449,12 @@ __device__ __forceinline__ void f_tile_offspring(const FArgs& a, const int isl, 
             sC[tid * F_IPT + i] = c;
         }
         __syncthreads();
-        smc_tile_outputs(su, b, a.ntiles, pre, total, sn, n_lo, n_hi);
+        smc_tile_outputs<BS>(su, b, a.ntiles, pre, total, sn, n_lo, n_hi);
     }
-    const int nvalid = (int)((N - j0 < F_TILE) ? (N - j0) : F_TILE);
+    const int nvalid = (int)((N - j0 < TILE) ? (N - j0) : TILE);
 
     // ---- offspring, 4 consecutive ones per thread per pass
-    for (i64 pb = n_lo & ~(i64)3; pb < n_hi; pb += F_PASS) {
+    for (i64 pb = n_lo & ~(i64)3; pb < n_hi; pb += PASS) {
         const i64 n0 = pb + (i64)tid * 4;
         bool ok[4];
         i64 a4[4];
@@ -466,7 +467,7 @@ __device__ __forceinline__ void f_tile_offspring(const FArgs& a, const int isl, 
 #pragma unroll
             for (int i = 0; i < F_IPT; ++i) {
                 const i64 lo = ns[i] > pb ? ns[i] : pb;
-                const i64 hi = ns[i + 1] < pb + F_PASS ? ns[i + 1] : pb + F_PASS;
+                const i64 hi = ns[i + 1] < pb + PASS ? ns[i + 1] : pb + PASS;
                 if (lo < hi) sP[lo - pb] = (u32)(tid * F_IPT + i);
             }
             __syncthreads();
@@ -479,7 +480,7 @@ __device__ __forceinline__ void f_tile_offspring(const FArgs& a, const int isl, 
             if (smc_lane() == 63) smx[smc_wave()] = inc;
             __syncthreads();
 #pragma unroll
-            for (int w = 0; w < SMC_NWAVE - 1; ++w)
+            for (int w = 0; w < NW - 1; ++w)
                 if (w < smc_wave()) ex = ex > smx[w] ? ex : smx[w];
             a4[0] = j0 + (i64)(m0 > ex ? m0 : ex);
             a4[1] = j0 + (i64)(m1 > ex ? m1 : ex);
@@ -491,7 +492,7 @@ __device__ __forceinline__ void f_tile_offspring(const FArgs& a, const int isl, 
             smc_su_pair(su, (n0 >> 1) + 1, s4[2], s4[3]);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int jl = ok[i] ? smc_lower_bound_u64(sC, F_TILE, smc_q62_t(s4[i])) : 0;
+                const int jl = ok[i] ? smc_lower_bound_u64(sC, TILE, smc_q62_t(s4[i])) : 0;
                 a4[i] = j0 + (jl < nvalid ? jl : nvalid - 1);
             }
         }

@@ -14,20 +14,28 @@
 #pragma once
 #include "smc_filter_kernels.h"
 
-template <int KIND, int FK>
-__global__ void __launch_bounds__(SMC_BLOCK)
+// BS = 256 threads for N <= 1024, one wavefront (BS = 64) for N <= 256: then the workgroup
+// barriers are free and 4x as many filters are resident.  The workgroup collectives of
+// smc_device.h combine SMC_NWAVE per-wave slots; with fewer waves the unused slots hold the
+// neutral element (set once here, never written again), so the same routines -- and the same
+// association order, hence the same bits -- serve both sizes.
+template <int KIND, int FK, int BS>
+__global__ void __launch_bounds__(BS)
 k_filter_small(const FArgs av, const int nsteps)
 {
     const FArgs& a = av;
-    __shared__ u64 sC[F_TILE];
-    __shared__ __attribute__((aligned(16))) u32 sP[F_PASS];
-    __shared__ double sX[F_TILE];
+    __shared__ u64 sC[BS * F_IPT];
+    __shared__ __attribute__((aligned(16))) u32 sP[BS * 4];
+    __shared__ double sX[BS * F_IPT];
     __shared__ u64 smu[SMC_SM];
-    __shared__ double smd[SMC_SM];
+    __shared__ double smd[SMC_SM];          // sums
+    __shared__ double smm[SMC_SM];          // maxima
     __shared__ i64 sn[2];
     __shared__ u32 smx[SMC_NWAVE];
     const int isl = (int)blockIdx.y;
     const int tid = (int)threadIdx.x;
+    if (tid < SMC_SM) { smu[tid] = 0ull; smd[tid] = 0.0; smm[tid] = -INFINITY; }
+    __syncthreads();
     const i64 N = a.N;
     double* info = a.info + (i64)isl * INFO_STRIDE;
     const u32 gisl = (u32)(a.island_offset + isl);
@@ -77,7 +85,7 @@ k_filter_small(const FArgs av, const int nsteps)
 #pragma unroll
             for (int k = 0; k < 4; ++k) sX[jt + k] = x[k];                 // parents' states for the gather
             i64 an[4] = {0, 0, 0, 0};
-            f_tile_offspring(a, isl, t, 0, jt, 0, q4, cex, 0ull, total, sC, sP, sn, smx,
+            f_tile_offspring<BS>(a, isl, t, 0, jt, 0, q4, cex, 0ull, total, sC, sP, sn, smx,
                              [&](i64 n0, const bool (&ok)[4], const i64 (&a4)[4]) {
                                  // N <= 1024: one pass, n0 == jt
 #pragma unroll
@@ -125,7 +133,7 @@ k_filter_small(const FArgs av, const int nsteps)
         double tm = lw[0];
 #pragma unroll
         for (int k = 1; k < 4; ++k) tm = smc_max2(tm, lw[k]);
-        const double gm = smc_block_max(tm, smd);
+        const double gm = smc_block_max(tm, smm);
         double s1 = 0.0, s2 = 0.0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {

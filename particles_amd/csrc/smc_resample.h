@@ -201,21 +201,25 @@ __device__ __forceinline__ i64 smc_su_count_le_wave(const SmcSu& s, u64 C)
     return lo;
 }
 
-// Output range [n_lo, n_hi) of tile b (every thread gets the same values).
+// Output range [n_lo, n_hi) of tile b (every thread gets the same values).  BS = threads of
+// the workgroup (a one-wave workgroup does both ends with its only wave).
+template <int BS = SMC_BLOCK>
 __device__ __forceinline__ void smc_tile_outputs(const SmcSu& su, int b, int ntiles, u64 pre,
                                                  u64 tile_total, i64* sn, i64& n_lo, i64& n_hi)
 {
-    if (su.scheme == SMC_MULTINOMIAL_) {          // waves 0 and 1, cooperatively
+    constexpr int W1 = BS > 64 ? 1 : 0;           // the wave / thread that takes the upper end
+    if (su.scheme == SMC_MULTINOMIAL_) {          // one wave per end, cooperatively
         if (smc_wave() == 0) {
             const i64 v = (b == 0) ? 0 : smc_su_count_le_wave(su, pre);
             if (smc_lane() == 0) sn[0] = v;
-        } else if (smc_wave() == 1) {
+        }
+        if (smc_wave() == W1) {
             const i64 v = (b == ntiles - 1) ? su.M : smc_su_count_le_wave(su, pre + tile_total);
             if (smc_lane() == 0) sn[1] = v;
         }
     } else {
         if (threadIdx.x == 0) sn[0] = (b == 0) ? 0 : smc_su_count_le(su, pre);
-        if (threadIdx.x == 64) sn[1] = (b == ntiles - 1) ? su.M : smc_su_count_le(su, pre + tile_total);
+        if (threadIdx.x == 64 * W1) sn[1] = (b == ntiles - 1) ? su.M : smc_su_count_le(su, pre + tile_total);
     }
     __syncthreads();
     n_lo = sn[0];

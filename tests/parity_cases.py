@@ -486,6 +486,8 @@ def check_small_filter_equals_general(golden, monkeypatch, full=True):
     y = [np.atleast_1d(v) for v in np.squeeze(g["y"])][:60]
     cases = [
         (lambda: kalman.ToySSM(0.2), ssm.Bootstrap, "systematic", 1000, 0.5),
+        (lambda: kalman.ToySSM(0.2), ssm.Bootstrap, "systematic", 256, 0.5),
+        (lambda: kalman.ToySSM(0.2), ssm.Bootstrap, "stratified", 200, 0.8),
         (lambda: kalman.ToySSM(0.2), ssm.Bootstrap, "systematic", 1024, 0.5),
         (lambda: kalman.ToySSM(0.2), ssm.Bootstrap, "stratified", 512, 0.5),
         (lambda: kalman.ToySSM(0.2), ssm.Bootstrap, "stratified", 777, 1.0),
@@ -497,7 +499,7 @@ def check_small_filter_equals_general(golden, monkeypatch, full=True):
         (lambda: ssm.StochVolLeverage(phi=-0.4), ssm.Bootstrap, "systematic", 1, 0.5),
     ]
     if not full:                     # the fiber emulator is slow: a representative subset
-        cases = [cases[0], cases[3], cases[5], cases[7], cases[9]]
+        cases = [cases[0], cases[1], cases[5], cases[7], cases[9], cases[11]]
     for mk, cls, scheme, N, essr in cases:
         runs = []
         for small in (True, False):
@@ -523,6 +525,9 @@ def check_small_filter_equals_general(golden, monkeypatch, full=True):
         check_filter_replay(golden, "toy_stratified", "toy", "bootstrap", T=40)
         check_filter_replay(golden, "toy_multinomial", "toy", "bootstrap", T=40)
         check_filter_replay(golden, "lg_adaptive", "lg_adaptive", "bootstrap", T=60)
+        for case in ("toy_systematic", "toy_stratified", "toy_multinomial"):      # one-wave variant
+            check_filter_replay(golden, case, "toy", "bootstrap", T=30, N=256)
+            check_filter_replay(golden, case, "toy", "bootstrap", T=30, N=100)
 
 
 def check_edge_sizes():
