@@ -291,6 +291,9 @@ int smc_filter_history(smc_filter* f, int field, int64_t step, int island, void*
 /* keep_history filters: genealogy of the current particles (compute_trajectories,
  * smoothing.py:209-219): out_host (t, N) int64, row t-1 = arange(N), row s-1 = A_s[row s]. */
 int smc_filter_trajectories(smc_filter* f, int island, int64_t* out_host);
+/* keep_history filters: one genealogical line (extract_one_trajectory, smoothing.py:256-269):
+ * out_host (t, dx) = X_s[n_s] with n_{t-1} = n_last and n_{s-1} = A_s[n_s]. */
+int smc_filter_one_trajectory(smc_filter* f, int island, int64_t n_last, double* out_host);
 int smc_filter_info(smc_filter* f, double* bytes_per_particle_step,
                     int* kernels_per_step);
 /* Average duration (ms) of the dominant kernel (the propagate kernel, "move")

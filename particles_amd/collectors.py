@@ -221,6 +221,18 @@ class DeviceParticleHistory:
         """(T, N) genealogy (smoothing.py:209-219), computed on the device."""
         return self._smc._trajectories()
 
+    def extract_one_trajectory(self):
+        """A single trajectory (smoothing.py:256-269): the final state is drawn from the final
+        weights, its line of ancestors is followed back on the device."""
+        from . import resampling as rs
+        smc = self._smc
+        n = rs.multinomial_once(smc._history(_lib.FIELD_W, smc._n - 1))
+        d = getattr(smc, "_d", 1)
+        out = np.empty((smc._n, d))
+        _lib.check(_lib.lib().smc_filter_one_trajectory(smc._f, 0, n, out.ctypes.data_as(
+            _lib.P(_lib.c_dbl))))
+        return [row[0] if d == 1 else row.copy() for row in out]
+
 
 class _Frozen:
     pass

@@ -700,6 +700,32 @@ int smc_filter_trajectories(smc_filter* f, int island, int64_t* out_host)
     return SMC_OK;
 }
 
+int smc_filter_one_trajectory(smc_filter* f, int island, int64_t n_last, double* out_host)
+{
+    SMC_REQUIRE(f && out_host, "null argument");
+    SMC_REQUIRE(island >= 0 && island < f->a.n_islands, "island out of range");
+    if (!f->a.hist) {
+        smc_set_error("smc_filter_one_trajectory: the filter was created without keep_history");
+        return SMC_ERR_STATE;
+    }
+    const i64 t = f->t_host;
+    SMC_REQUIRE(t > 0 && n_last >= 0 && n_last < f->a.N, "no step has run, or particle index out of range");
+    hipStream_t st = f->ctx->stream;
+    double* buf = nullptr;
+    hipError_t e = hipMalloc((void**)&buf, (size_t)t * f->a.dx * 8);
+    if (e != hipSuccess) {
+        smc_set_error("smc_filter_one_trajectory: %s", hipGetErrorString(e));
+        return SMC_ERR_NOMEM;
+    }
+    const double* rows = f->a.summ + (size_t)island * (f->a.T + 1) * SUMM_STRIDE;
+    SMC_LAUNCH(k_f_one_trajectory, dim3(1), dim3(64), st, f->a, island, (i64)n_last, t, rows, buf);
+    hipError_t rc = hipMemcpyAsync(out_host, buf, (size_t)t * f->a.dx * 8, hipMemcpyDeviceToHost, st);
+    if (rc == hipSuccess) rc = hipStreamSynchronize(st);
+    (void)hipFree(buf);
+    SMC_HIP_CHECK(rc);
+    return SMC_OK;
+}
+
 int smc_filter_info(smc_filter* f, double* bytes_per_particle_step, int* kernels_per_step)
 {
     SMC_REQUIRE(f, "null filter");

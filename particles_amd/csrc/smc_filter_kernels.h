@@ -956,3 +956,19 @@ k_f_moments_final(const FArgs av)
         o[d + c] = m2 - mean * mean;
     }
 }
+
+// one genealogical line through the kept history (smoothing.py:256-269
+// extract_one_trajectory): n_{t-1} = A_t[n_t]; out (t_end, d) = X_t[n_t].  One lane.
+__global__ void k_f_one_trajectory(const FArgs av, int isl, i64 n_last, i64 t_end,
+                                   const double* rsflag /* (t_end, SUMM_STRIDE) rows */, double* out)
+{
+    const FArgs& a = av;
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    i64 n = n_last;
+    for (i64 t = t_end - 1; t >= 0; --t) {
+        const double* X = f_X(a, t) + (i64)isl * a.N * a.dx;
+        for (int c = 0; c < a.dx; ++c) out[t * a.dx + c] = X[n * a.dx + c];
+        if (t > 0 && rsflag[t * SUMM_STRIDE + 4] != 0.0)          // else A_t = arange (core.py:336)
+            n = (i64)(f_A(a, t) + (i64)isl * a.N)[n];
+    }
+}

@@ -321,6 +321,13 @@ def killing(W, M):
     return A.get() if (host and not _lib.RESIDENT[0]) else A
 
 
+def multinomial_once(W):
+    """One draw from the discrete distribution W (resampling.py:574-596):
+    ``np.searchsorted(np.cumsum(W), rand())``."""
+    Wh = W.get() if isinstance(W, DeviceArray) else np.asarray(W)
+    return int(np.searchsorted(np.cumsum(Wh), random.rand()))
+
+
 def multinomial_iid(W, M=None):
     """Multinomial resampling, randomly permuted (resampling.py:561-571)."""
     A = multinomial(W, M=M)

@@ -578,6 +578,17 @@ def check_device_history(golden):
             assert np.array_equal(h.A[t], g["hist_A"][t - 1])
     assert np.array_equal(h.X[-1], pf.X) and np.array_equal(h.A[-1], pf.A)
     assert np.array_equal(h.compute_trajectories(), g["trajectories"])
+    # extract_one_trajectory (smoothing.py:256-269): same draw, same line as from the fixture
+    np.random.seed(99)
+    traj = h.extract_one_trajectory()
+    np.random.seed(99)
+    n = int(np.searchsorted(np.cumsum(g["hist_W"][-1]), np.random.rand()))
+    want = []
+    for t in reversed(range(T)):
+        if t < T - 1:
+            n = g["hist_A"][t][n]                # hist_A[t] = A of step t+1
+        want.append(g["hist_X"][t][n])
+    assert len(traj) == T and np.array_equal(np.array(traj), np.array(want[::-1]))
     import pytest
     with pytest.raises(IndexError):
         h.X[T]
