@@ -115,6 +115,11 @@ int smc_normal_rvs(smc_ctx* ctx, const double* loc, int64_t loc_stride,
 int smc_normal_logpdf(smc_ctx* ctx, const double* x, int64_t x_stride,
                       const double* loc, int64_t loc_stride, const double* scale,
                       int64_t scale_stride, int64_t N, double* out);
+/* Poisson.logpdf (distributions.py:528-529 -> scipy.stats.poisson.logpmf):
+ *   xlogy(k, rate) - gammaln(k + 1) - rate,   xlogy(0, .) = 0;
+ * k / rate are device arrays read with the given element stride (0 = broadcast). */
+int smc_poisson_logpmf(smc_ctx* ctx, const double* k, int64_t k_stride, const double* rate,
+                       int64_t rate_stride, int64_t N, double* out);
 /* standard normals / uniforms from the Philox stream (for the generic path) */
 int smc_standard_normal(smc_ctx* ctx, uint64_t counter, int64_t n, double* out);
 int smc_uniform(smc_ctx* ctx, uint64_t counter, int64_t n, double* out);
@@ -190,7 +195,8 @@ enum smc_model_kind {
     SMC_MODEL_MVLINGAUSS = 3, /* kalman.py:296-361 */
     SMC_MODEL_GORDON = 4,     /* state_space_models.py:546-577 (bootstrap) */
     SMC_MODEL_THETALOGISTIC = 5, /* state_space_models.py:657-683 (bootstrap) */
-    SMC_MODEL_SVLEVERAGE = 6  /* state_space_models.py:501-541 StochVolLeverage (bootstrap) */
+    SMC_MODEL_SVLEVERAGE = 6, /* state_space_models.py:501-541 StochVolLeverage (bootstrap) */
+    SMC_MODEL_DISCRETECOX = 7 /* state_space_models.py:611-630: Y_t | x ~ Poisson(exp(x)) (bootstrap) */
 };
 enum smc_fk_kind {
     SMC_FK_BOOTSTRAP = 0,     /* state_space_models.py:299-349 */
@@ -216,13 +222,15 @@ typedef struct smc_model {
      *   GORDON:   0 b, 1 sigmaX, 2 c, 3 sigma0 (2.0), 5 a;  aux_host[t] = d*cos(e*(t-1))
      *   THETALOGISTIC: 0 tau0, 1 sigmaX, 2 sigmaY, 3 sigma0 (1.0), 4 log(sigmaY),
      *             5 tau1, 6 tau2
-     *   SVLEVERAGE: as STOCHVOL, plus 5 phi, 6 sqrt(1 - phi^2) */
+     *   SVLEVERAGE: as STOCHVOL, plus 5 phi, 6 sqrt(1 - phi^2)
+     *   DISCRETECOX: 0 mu, 1 phi, 2 sigma, 3 sigma/sqrt(1-phi^2);
+     *             aux_host[t] = gammaln(y_t + 1) (the data-only term of the Poisson log-pmf) */
     const double* params_host;
     /* MVLINGAUSS (HOST, row-major): F(dx,dx) G(dy,dx) covX(dx,dx) covY(dy,dy)
      * mu0(dx) cov0(dx,dx); shared by all islands */
     const double *F_host, *G_host, *covX_host, *covY_host, *mu0_host, *cov0_host;
-    /* per-step additive term of the transition mean, (T,) HOST, or NULL (GORDON:
-     * the caller's d*cos(e*(t-1)), entry 0 unused) */
+    /* per-step scalar of the model, (T,) HOST, or NULL (GORDON: additive term of the
+     * transition mean, the caller's d*cos(e*(t-1)), entry 0 unused; DISCRETECOX: gammaln(y_t+1)) */
     const double* aux_host;
 } smc_model;
 

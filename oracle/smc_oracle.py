@@ -19,6 +19,7 @@ import os
 
 import numpy as np
 import scipy.linalg as sla
+import scipy.special as ssp_special
 
 C_NORM = 0.9189385332046727  # scipy.stats._continuous_distns._norm_pdf_logC
 HALFLOG2PI = 0.5 * np.log(2.0 * np.pi)  # particles/distributions.py:212
@@ -338,6 +339,17 @@ def normal_logpdf(x, loc=0.0, scale=1.0):
     return -y ** 2 / 2.0 - C_NORM - np.log(scale)
 
 
+def poisson_logpmf(k, mu):
+    """distributions.py:528-529 -> scipy.stats.poisson.logpmf, whose ``_logpmf`` is
+    ``xlogy(k, mu) - gammaln(k + 1) - mu`` behind rv_discrete's guards (mu < 0 or NaN -> NaN;
+    k < 0 or not an integer -> -inf)."""
+    k, mu = np.broadcast_arrays(np.asarray(k, dtype=np.float64), np.asarray(mu, dtype=np.float64))
+    with np.errstate(all="ignore"):
+        r = ssp_special.xlogy(k, mu) - ssp_special.gammaln(k + 1.0) - mu
+    r = np.where((k < 0) | (np.floor(k) != k), -np.inf, r)
+    return np.where(~(mu >= 0) | np.isnan(k), np.nan, r)
+
+
 def mvnormal_rvs(loc, scale, L, z):
     """distributions.py:946-947, 961-969: ``loc + scale * dot(z, L.T)``."""
     return loc + scale * np.dot(z, L.T)
@@ -523,6 +535,23 @@ class ThetaLogistic:
 
     def py_logpdf(self, y, xp, x):       # :682-683
         return normal_logpdf(y, loc=x, scale=self.sigmaY)
+
+
+class DiscreteCox:
+    """state_space_models.py:611-630: Y_t | x ~ Poisson(exp(x))."""
+    dim = 1
+
+    def __init__(self, mu=0.0, sigma=1.0, phi=0.95):
+        self.mu, self.sigma, self.phi = mu, sigma, phi
+
+    def px0(self):                       # :621-624
+        return self.mu, self.sigma / np.sqrt(1.0 - self.phi ** 2)
+
+    def px(self, xp):                    # :626-627
+        return self.mu + self.phi * (xp - self.mu), self.sigma
+
+    def py_logpdf(self, y, xp, x):       # :629-630 -> distributions.py:528-529
+        return poisson_logpmf(y, np.exp(x))
 
 
 class MVLinGauss:

@@ -22,6 +22,7 @@ MULTINOMIAL, STRATIFIED, SYSTEMATIC = 0, 1, 2
 SCHEMES = {"multinomial": MULTINOMIAL, "stratified": STRATIFIED, "systematic": SYSTEMATIC}
 MODEL_LINGAUSS, MODEL_STOCHVOL, MODEL_MVLINGAUSS, MODEL_GORDON, MODEL_THETALOGISTIC = 1, 2, 3, 4, 5
 MODEL_SVLEVERAGE = 6
+MODEL_DISCRETECOX = 7
 FK_BOOTSTRAP, FK_GUIDED = 0, 1
 FIELD_X, FIELD_XP, FIELD_A, FIELD_LW, FIELD_W = range(5)
 SUMMARY_COLS = 5
@@ -72,6 +73,7 @@ SIGNATURES = {
     "smc_gather": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
     "smc_normal_rvs": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_u64, c_i64, c_vp]),
     "smc_normal_logpdf": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp]),
+    "smc_poisson_logpmf": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp]),
     "smc_standard_normal": (c_int, [c_vp, c_u64, c_i64, c_vp]),
     "smc_uniform": (c_int, [c_vp, c_u64, c_i64, c_vp]),
     "smc_mvn_rvs": (c_int, [c_vp, c_vp, c_i64, c_dbl, P(c_dbl), c_vp, c_u64, c_i64, c_i64, c_vp]),

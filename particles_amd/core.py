@@ -201,6 +201,9 @@ class SMC:
             aux = None
             if model.get("aux") is not None:        # per-step term of the transition mean
                 aux = np.ascontiguousarray(model["aux"](T), dtype=np.float64)
+            elif model.get("aux_from_data") is not None:      # per-step term of log p(y_t | x_t)
+                aux = np.ascontiguousarray(model["aux_from_data"](y), dtype=np.float64)
+            if aux is not None:
                 m.aux_host = aux.ctypes.data_as(_lib.P(_lib.c_dbl))
             self._keep = (y, params, aux)
         else:       # MVLinearGauss: the matrices, row-major fp64 (kalman.py:296-361)

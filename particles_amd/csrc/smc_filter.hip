@@ -67,6 +67,7 @@ static void launch_propagate(smc_filter* f)
     P_CASE(SMC_MODEL_GORDON, SMC_FK_BOOTSTRAP)
     P_CASE(SMC_MODEL_THETALOGISTIC, SMC_FK_BOOTSTRAP)
     P_CASE(SMC_MODEL_SVLEVERAGE, SMC_FK_BOOTSTRAP)
+    P_CASE(SMC_MODEL_DISCRETECOX, SMC_FK_BOOTSTRAP)
 #undef P_CASE
 }
 
@@ -119,13 +120,15 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     const bool mv = model->kind == SMC_MODEL_MVLINGAUSS;
     SMC_REQUIRE(model->kind == SMC_MODEL_LINGAUSS || model->kind == SMC_MODEL_STOCHVOL || mv ||
                     model->kind == SMC_MODEL_GORDON || model->kind == SMC_MODEL_THETALOGISTIC ||
-                    model->kind == SMC_MODEL_SVLEVERAGE,
+                    model->kind == SMC_MODEL_SVLEVERAGE || model->kind == SMC_MODEL_DISCRETECOX,
                 "fused filter: unknown model kind");
     SMC_REQUIRE(model->fk == SMC_FK_BOOTSTRAP ||
                     (model->fk == SMC_FK_GUIDED && (model->kind == SMC_MODEL_LINGAUSS || mv)),
                 "guided filter is available for LINGAUSS and MVLINGAUSS only");
     SMC_REQUIRE(model->kind != SMC_MODEL_GORDON || model->aux_host,
                 "GORDON needs aux_host (d*cos(e*(t-1)) per step)");
+    SMC_REQUIRE(model->kind != SMC_MODEL_DISCRETECOX || model->aux_host,
+                "DISCRETECOX needs aux_host (gammaln(y_t + 1) per step)");
     SMC_REQUIRE(mv || model->params_host, "params_host is required");
     int dxm = 1, dym = 1, dpm = 1;
     std::vector<double> mvc_host;
@@ -350,6 +353,7 @@ static void launch_small(smc_filter* f, int nsteps)
     S_CASE(SMC_MODEL_GORDON, SMC_FK_BOOTSTRAP)
     S_CASE(SMC_MODEL_THETALOGISTIC, SMC_FK_BOOTSTRAP)
     S_CASE(SMC_MODEL_SVLEVERAGE, SMC_FK_BOOTSTRAP)
+    S_CASE(SMC_MODEL_DISCRETECOX, SMC_FK_BOOTSTRAP)
 #undef S_CASE
 }
 

@@ -116,6 +116,13 @@ __host__ __device__ __forceinline__ u32* f_A(const FArgs& a, i64 t) { return a.A
 //   GORDON    b, sigmaX, c, sigma0 (= 2), -, a          aux_t = d cos(e (t-1))
 //   THETALOG  tau0, sigmaX, sigmaY, sigma0 (= 1), log sigmaY, tau1, tau2
 //   SVLEVERAGE as STOCHVOL + 5 phi, 6 sqrt(1 - phi^2)
+//   DISCRETECOX mu, phi, sigma, sig0                   aux_t = gammaln(y_t + 1)
+// models with a per-step scalar aux_t (FArgs::aux, slot 5 of the step record)
+template <int KIND>
+__host__ __device__ constexpr bool m_has_aux()
+{
+    return KIND == SMC_MODEL_GORDON || KIND == SMC_MODEL_DISCRETECOX;
+}
 template <int KIND>
 __device__ __forceinline__ double m_trans_loc(const double* p, double xp, double aux)
 {
@@ -124,23 +131,33 @@ __device__ __forceinline__ double m_trans_loc(const double* p, double xp, double
         return (p[0] * xp + (p[2] * xp) / (1.0 + xp * xp)) + aux;
     if (KIND == SMC_MODEL_THETALOGISTIC)                        // state_space_models.py:677-680
         return (xp + p[0]) - p[5] * exp(p[6] * xp);
+    if (KIND == SMC_MODEL_DISCRETECOX)                          // state_space_models.py:626-627
+        return p[0] + p[1] * (xp - p[0]);
     return p[4] + p[1] * xp;                                    // state_space_models.py:465-470
 }
 template <int KIND>
 __device__ __forceinline__ double m_trans_scale(const double* p)
 {
-    return (KIND == SMC_MODEL_STOCHVOL || KIND == SMC_MODEL_SVLEVERAGE) ? p[2] : p[1];
+    return (KIND == SMC_MODEL_STOCHVOL || KIND == SMC_MODEL_SVLEVERAGE ||
+            KIND == SMC_MODEL_DISCRETECOX) ? p[2] : p[1];
 }
 template <int KIND>
 __device__ __forceinline__ double m_init_loc(const double* p)
 {
-    return (KIND == SMC_MODEL_STOCHVOL || KIND == SMC_MODEL_SVLEVERAGE) ? p[0] : 0.0;   // ssm.py:462 ; kalman.py:427, ssm.py:565, :675
+    return (KIND == SMC_MODEL_STOCHVOL || KIND == SMC_MODEL_SVLEVERAGE ||
+            KIND == SMC_MODEL_DISCRETECOX) ? p[0] : 0.0;       // ssm.py:462, :621 ; kalman.py:427, ssm.py:565, :675
 }
 // log p(y_t | x_t) as scipy.stats.norm.logpdf evaluates it
 template <int KIND>
 __device__ __forceinline__ double m_obs_logpdf(const double* p, double y, double x, double xp,
-                                               bool first)
+                                               bool first, double aux)
 {
+    if (KIND == SMC_MODEL_DISCRETECOX) {                        // ssm.py:629-630, distributions.py:528-529
+        // scipy.stats.poisson._logpmf: xlogy(k, mu) - gammaln(k + 1) - mu, mu = exp(x)
+        const double mu = exp(x);
+        const double xl = (y == 0.0 && mu == mu) ? 0.0 : y * log(mu);
+        return (xl - aux) - mu;
+    }
     if (KIND == SMC_MODEL_SVLEVERAGE) {                         // ssm.py:531-541
         const double u = first ? (x - p[0]) / p[3] : (x - (p[4] + p[1] * xp)) / p[2];
         const double sx = exp(0.5 * x);
@@ -174,7 +191,7 @@ __device__ __forceinline__ double m_step(const double* p, bool first, double y, 
     if (FK == SMC_FK_BOOTSTRAP) {
         const double x = first ? m_init_loc<KIND>(p) + p[3] * z
                                : m_trans_loc<KIND>(p, xp, aux) + m_trans_scale<KIND>(p) * z;
-        inc = m_obs_logpdf<KIND>(p, y, x, xp, first);
+        inc = m_obs_logpdf<KIND>(p, y, x, xp, first, aux);
         return x;
     }
     // guided filter with LinearGauss' optimal proposal (kalman.py:436-446,
@@ -182,13 +199,13 @@ __device__ __forceinline__ double m_step(const double* p, bool first, double y, 
     if (first) {
         const double mu = p[12] * (y / p[8]);
         const double x = mu + p[13] * z;
-        inc = (m_norm_logpdf(x, 0.0, p[3], p[6]) + m_obs_logpdf<KIND>(p, y, x, xp, first))
+        inc = (m_norm_logpdf(x, 0.0, p[3], p[6]) + m_obs_logpdf<KIND>(p, y, x, xp, first, aux))
               - m_norm_logpdf(x, mu, p[13], p[14]);
         return x;
     }
     const double mu = p[9] * (p[0] * xp / p[7] + y / p[8]);
     const double x = mu + p[10] * z;
-    inc = (m_norm_logpdf(x, p[0] * xp, p[1], p[5]) + m_obs_logpdf<KIND>(p, y, x, xp, first))
+    inc = (m_norm_logpdf(x, p[0] * xp, p[1], p[5]) + m_obs_logpdf<KIND>(p, y, x, xp, first, aux))
           - m_norm_logpdf(x, mu, p[10], p[11]);
     return x;
 }
@@ -534,7 +551,6 @@ k_ancestors(const FArgs av)
     const i64 t = (i64)smc_uniform(r0);
     if (t >= a.T || t == 0 || smc_uniform(r1) == 0.0) return;          // step t does not resample
     F_STAMP_A(1);
-    const u32 gisl = (u32)(a.island_offset + isl);
     u32* A = f_A(a, t) + (i64)isl * N;
 
     // ---- the tile's parents: q and their exact CDF
@@ -755,7 +771,7 @@ k_propagate(const FArgs av)
     F_STAMP(1);
     const double* p = a.params + (i64)isl * PARAM_STRIDE;
     const double yt = smc_uniform(r2);
-    const double aux = (KIND == SMC_MODEL_GORDON) ? smc_uniform(r5) : 0.0;
+    const double aux = m_has_aux<KIND>() ? smc_uniform(r5) : 0.0;
     const u32 gisl = (u32)(a.island_offset + isl);
     double* Xn = (SPEC ? a.X + (i64)a.par * a.xslot : f_X(a, t)) + (i64)isl * N;
     const double* Xo = (SPEC ? a.X + (i64)(a.par ^ 1) * a.xslot : f_X(a, t - 1)) + (i64)isl * N;

@@ -53,7 +53,7 @@ k_filter_small(const FArgs av, const int nsteps)
         prev_logLt = smc_uniform(smc_ldg(prow + 3));
     }
     double y_next = (t < a.T) ? a.y[t * a.dy] : 0.0;
-    double aux_next = (KIND == SMC_MODEL_GORDON && a.aux && t < a.T) ? a.aux[t] : 0.0;
+    double aux_next = (m_has_aux<KIND>() && a.aux && t < a.T) ? a.aux[t] : 0.0;
     double x[4], lw[4];
     if (t > 0) {                                           // continue a run
         f_load4<double>(f_X(a, t - 1) + (i64)isl * N, jt, N, vec, 0.0, x);
@@ -69,7 +69,7 @@ k_filter_small(const FArgs av, const int nsteps)
         const double yt = y_next, aux = aux_next;
         if (t + 1 < a.T) {                                 // requested a whole step ahead
             y_next = a.y[(t + 1) * a.dy];
-            if (KIND == SMC_MODEL_GORDON && a.aux) aux_next = a.aux[t + 1];
+            if (m_has_aux<KIND>() && a.aux) aux_next = a.aux[t + 1];
         }
         double xp[4], lwp[4];
         u32* A = f_A(a, t) + (i64)isl * N;

@@ -957,6 +957,35 @@ extern "C" int smc_normal_logpdf(smc_ctx* ctx, const double* x, int64_t x_stride
     return SMC_OK;
 }
 
+// Poisson.logpdf (distributions.py:528-529): scipy.stats.poisson.logpmf with the generic
+// rv_discrete guards (rate < 0 or NaN -> NaN; k < 0 or not an integer -> -inf)
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_poisson_logpmf(const double* k, i64 ks, const double* rate, i64 rs, i64 N, double* out)
+{
+    const i64 i = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;
+    if (i >= N) return;
+    const double kk = k[i * ks], mu = rate[i * rs];
+    double r;
+    if (!(mu >= 0.0) || kk != kk) r = NAN;
+    else if (kk < 0.0 || floor(kk) != kk) r = -INFINITY;
+    else {
+        const double xl = (kk == 0.0) ? 0.0 : kk * log(mu);            // special.xlogy
+        r = (xl - lgamma(kk + 1.0)) - mu;
+    }
+    out[i] = r;
+}
+
+extern "C" int smc_poisson_logpmf(smc_ctx* ctx, const double* k, int64_t k_stride, const double* rate,
+                                  int64_t rate_stride, int64_t N, double* out)
+{
+    SMC_REQUIRE(ctx && k && rate && out, "null argument");
+    SMC_REQUIRE(N > 0, "N must be positive");
+    SMC_LAUNCH(k_poisson_logpmf, dim3((unsigned)((N + SMC_BLOCK - 1) / SMC_BLOCK)), dim3(SMC_BLOCK),
+               ctx->stream, k, (i64)k_stride, rate, (i64)rate_stride, (i64)N, out);
+    SMC_LAUNCH_CHECK();
+    return SMC_OK;
+}
+
 __global__ void __launch_bounds__(SMC_BLOCK)
 k_philox_fill(int normal, u64 seed, u32 t, u32 island, i64 n, double* out)
 {

@@ -102,6 +102,29 @@ class Normal(LocScaleDist):
         return out if (d0 or d1 or d2 or _lib.RESIDENT[0]) else out.get()
 
 
+class Poisson(ProbDist):
+    """Poisson(rate) distribution (distributions.py:519-532).  ``logpdf`` is evaluated on the
+    device for per-particle rates; ``rvs`` (only used to simulate data) draws on the host with
+    numpy's generator, as the reference does."""
+    dtype = "int64"
+
+    def __init__(self, rate=1.0):
+        self.rate = rate
+
+    def rvs(self, size=None):
+        rate = self.rate.get() if isinstance(self.rate, DeviceArray) else self.rate
+        return random.poisson(rate, size=size)                                   # :525-526
+
+    def logpdf(self, x):
+        """scipy.stats.poisson.logpmf(x, rate)  (:528-529)."""
+        N = _bsize(self.rate, x)
+        xd, xs, d0 = _strided(np.asarray(x, dtype=np.float64) if not isinstance(x, DeviceArray) else x, N)
+        rt, rs, d1 = _strided(self.rate, N)
+        out = DeviceArray((N,))
+        check(lib().smc_poisson_logpmf(out.ctx.h, xd.ptr, xs, rt.ptr, rs, N, out.ptr))
+        return out if (d0 or d1 or _lib.RESIDENT[0]) else out.get()
+
+
 class MvNormal(ProbDist):
     """Multivariate Normal distribution (distributions.py:888-1009).
 

@@ -241,6 +241,39 @@ class Gordon_etal(StateSpaceModel):
         return dict(kind=_lib.MODEL_GORDON, dx=1, dy=1, params=p, aux=aux)
 
 
+class DiscreteCox(StateSpaceModel):
+    r"""A discrete Cox model (state_space_models.py:611-630).
+
+    Y_t | X_t = x ~ Poisson(e^x);  X_t = mu + phi (X_{t-1} - mu) + U_t, U_t ~ N(0, sigma^2);
+    X_0 ~ N(mu, sigma^2 / (1 - phi^2)).
+    """
+    default_params = {"mu": 0.0, "sigma": 1.0, "phi": 0.95}
+
+    def PX0(self):
+        return dists.Normal(loc=self.mu, scale=self.sigma / np.sqrt(1.0 - self.phi ** 2))
+
+    def PX(self, t, xp):
+        return dists.Normal(loc=self.mu + self.phi * (xp - self.mu), scale=self.sigma)
+
+    def PY(self, t, xp, x):
+        return dists.Poisson(rate=np.exp(x))
+
+    def _device_params(self, fk_kind):
+        if fk_kind != _lib.FK_BOOTSTRAP:
+            return None
+        p = np.zeros(_lib.PARAM_STRIDE)
+        p[:4] = [self.mu, self.phi, self.sigma, self.sigma / np.sqrt(1.0 - self.phi ** 2)]
+
+        def aux(y):
+            # the data-only term of scipy's poisson._logpmf; counts outside the support get
+            # +inf so that every particle's increment is -inf, as rv_discrete.logpmf returns
+            from scipy.special import gammaln
+            y = np.asarray(y, dtype=np.float64).reshape(-1)
+            ok = (y >= 0) & (np.floor(y) == y)
+            return np.where(ok, gammaln(np.where(ok, y, 0.0) + 1.0), np.inf)
+        return dict(kind=_lib.MODEL_DISCRETECOX, dx=1, dy=1, params=p, aux_from_data=aux)
+
+
 class ThetaLogistic(StateSpaceModel):
     r"""Theta-logistic model (state_space_models.py:657-683).
 

@@ -77,6 +77,9 @@ def main():
     out["theta_boot"] = run_case(ssm.ThetaLogistic(), ssm.Bootstrap, 40, 600, "stratified", 0.5)
     out["svlev_boot"] = run_case(ssm.StochVolLeverage(phi=-0.5), ssm.Bootstrap, 40, 600,
                                  "systematic", 0.5)
+    # Poisson observations (state_space_models.py:611-630, distributions.py:519-532)
+    out["cox_boot"] = run_case(ssm.DiscreteCox(mu=0.5, sigma=0.4, phi=0.9), ssm.Bootstrap, 40, 600,
+                               "systematic", 0.5)
 
     # --- auxiliary particle filter (core.py:299-313), Pitt & Shephard's StochVol proposal
     out["sv_apf"] = run_case(ssm.StochVol(), ssm.AuxiliaryPF, 30, 500, "systematic", 0.5)

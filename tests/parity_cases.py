@@ -296,6 +296,48 @@ def check_normal(golden):
     assert np.array_equal(x, g["normal_rvs"])                # loc + scale*z: bit-exact
 
 
+def check_poisson(golden):
+    """Poisson.logpdf (distributions.py:528-529) against the oracle's restatement of scipy's
+    expression, guards included; then the DiscreteCox model on the generic path (PY returning
+    dists.Poisson, device ops) against the same model on the fused path."""
+    rng = np.random.default_rng(5)
+    x = rng.normal(0.5, 1.0, 3001)
+    for k in (0.0, 1.0, 7.0, 40.0):
+        lp = dists.Poisson(rate=np.exp(x)).logpdf(k)
+        ref = orc.poisson_logpmf(k, np.exp(x))
+        assert np.max(np.abs(lp - ref) / (1.0 + np.abs(ref))) < 1e-14
+    k = np.array([0.0, 3.0, -1.0, 2.5, 0.0, 4.0, 2.0, np.nan])
+    rate = np.array([0.0, 0.0, 1.0, 1.0, np.inf, np.nan, -1.0, 1.0])
+    lp = dists.Poisson(rate=rate).logpdf(k)
+    ref = orc.poisson_logpmf(k, rate)
+    assert np.array_equal(np.isnan(lp), np.isnan(ref))
+    assert np.array_equal(lp[~np.isnan(ref)], ref[~np.isnan(ref)])
+    assert lp[0] == 0.0 and lp[1] == -np.inf and lp[2] == -np.inf and lp[3] == -np.inf
+
+    g = golden("cox_boot")
+    y = list(g["y"])
+    model = ssm.DiscreteCox(mu=0.5, sigma=0.4, phi=0.9)
+
+    class GenericBootstrap(ssm.Bootstrap):
+        def _device_model(self):
+            return None
+
+    pa.seed(11)
+    fused = pa.SMC(fk=ssm.Bootstrap(ssm=model, data=y), N=8000)
+    fused.run()
+    pa.seed(12)
+    gen = pa.SMC(fk=GenericBootstrap(ssm=model, data=y), N=8000)
+    gen.run()
+    assert np.isfinite(fused.logLt) and abs(fused.logLt - gen.logLt) < 0.6
+    # counts outside the support: every increment is -inf, as rv_discrete.logpmf returns
+    bad = list(y)
+    bad[3] = np.array([2.5])
+    pf = pa.SMC(fk=ssm.Bootstrap(ssm=model, data=bad), N=64)
+    for _ in range(4):
+        next(pf)
+    assert np.all(np.isneginf(pf.wgts.lw))
+
+
 def check_normal_philox(n, seed=4242):
     pa.seed(seed)
     z = pa.DeviceArray((n,))
@@ -353,6 +395,8 @@ MODELS = {
     "gordon": (lambda: ssm.Gordon_etal(), lambda: orc.Gordon()),
     "theta": (lambda: ssm.ThetaLogistic(), lambda: orc.ThetaLogistic()),
     "svlev": (lambda: ssm.StochVolLeverage(phi=-0.5), lambda: orc.StochVolLeverage(phi=-0.5)),
+    "cox": (lambda: ssm.DiscreteCox(mu=0.5, sigma=0.4, phi=0.9),
+            lambda: orc.DiscreteCox(mu=0.5, sigma=0.4, phi=0.9)),
 }
 
 
@@ -497,6 +541,7 @@ def check_small_filter_equals_general(golden, monkeypatch, full=True):
         (lambda: ssm.Gordon_etal(), ssm.Bootstrap, "stratified", 256, 0.5),
         (lambda: ssm.ThetaLogistic(), ssm.Bootstrap, "systematic", 100, 0.5),
         (lambda: ssm.StochVolLeverage(phi=-0.4), ssm.Bootstrap, "systematic", 1, 0.5),
+        (lambda: ssm.DiscreteCox(mu=0.5, sigma=0.4, phi=0.9), ssm.Bootstrap, "systematic", 400, 0.5),
     ]
     if not full:                     # the fiber emulator is slow: a representative subset
         cases = [cases[0], cases[1], cases[5], cases[7], cases[9], cases[11]]

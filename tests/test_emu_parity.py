@@ -67,6 +67,10 @@ def test_gather():
     pc.check_gather(500, 7)
 
 
+def test_poisson_and_cox(golden):
+    pc.check_poisson(golden)
+
+
 def test_normal(golden):
     pc.check_normal(golden)
     pc.check_normal_philox(1001)
@@ -91,6 +95,7 @@ def test_mvn(golden):
     ("gordon_boot", "gordon", "bootstrap"),
     ("theta_boot", "theta", "bootstrap"),
     ("svlev_boot", "svlev", "bootstrap"),
+    ("cox_boot", "cox", "bootstrap"),
 ])
 def test_filter_replay(golden, case, model, fk):
     pc.check_filter_replay(golden, case, model, fk, T=12 if model.startswith("mv") else 25)
@@ -101,7 +106,8 @@ def test_mv_philox_kalman():
     pc.check_mv_kalman(1000, 6, "guided", scheme="stratified")
 
 
-@pytest.mark.parametrize("case,model", [("gordon_boot", "gordon"), ("theta_boot", "theta")])
+@pytest.mark.parametrize("case,model", [("gordon_boot", "gordon"), ("theta_boot", "theta"),
+                                        ("cox_boot", "cox")])
 def test_nonlinear_models_philox(golden, case, model):
     pc.check_model_philox_vs_oracle(golden, case, model, N=4000)
 

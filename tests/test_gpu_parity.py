@@ -75,6 +75,10 @@ def test_gather():
     pc.check_gather(50000, 32)
 
 
+def test_poisson_and_cox(golden):
+    pc.check_poisson(golden)
+
+
 def test_normal(golden):
     pc.check_normal(golden)
     pc.check_normal_philox(1 << 20)
@@ -101,12 +105,14 @@ def test_mvn(golden):
     ("gordon_boot", "gordon", "bootstrap"),
     ("theta_boot", "theta", "bootstrap"),
     ("svlev_boot", "svlev", "bootstrap"),
+    ("cox_boot", "cox", "bootstrap"),
 ])
 def test_filter_replay(golden, case, model, fk):
     pc.check_filter_replay(golden, case, model, fk)
 
 
-@pytest.mark.parametrize("case,model", [("gordon_boot", "gordon"), ("theta_boot", "theta")])
+@pytest.mark.parametrize("case,model", [("gordon_boot", "gordon"), ("theta_boot", "theta"),
+                                        ("cox_boot", "cox")])
 def test_nonlinear_models_philox(golden, case, model):
     pc.check_model_philox_vs_oracle(golden, case, model, N=50000)
 

@@ -18,6 +18,7 @@ MODELS = {
     "gordon": lambda: orc.Gordon(),
     "theta": lambda: orc.ThetaLogistic(),
     "svlev": lambda: orc.StochVolLeverage(phi=-0.5),
+    "cox": lambda: orc.DiscreteCox(mu=0.5, sigma=0.4, phi=0.9),
 }
 
 CASES = ([("toy_%s" % s, "toy", "bootstrap") for s in ("systematic", "stratified", "multinomial")]
@@ -26,7 +27,7 @@ CASES = ([("toy_%s" % s, "toy", "bootstrap") for s in ("systematic", "stratified
             ("mv4_guided", "mv4", "guided"), ("mv4_boot", "mv4", "bootstrap"),
             ("mv32_guided", "mv32", "guided"), ("mv32_boot", "mv32", "bootstrap"),
             ("gordon_boot", "gordon", "bootstrap"), ("theta_boot", "theta", "bootstrap"),
-            ("svlev_boot", "svlev", "bootstrap")])
+            ("svlev_boot", "svlev", "bootstrap"), ("cox_boot", "cox", "bootstrap")])
 
 
 @pytest.mark.parametrize("case,model,fk", CASES)
