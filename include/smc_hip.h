@@ -152,6 +152,10 @@ int smc_elementwise(smc_ctx* ctx, int op, const double* a, int64_t stride_a, con
  * (kalman.py:339-346). */
 int smc_rows_matmul(smc_ctx* ctx, const double* X, int64_t N, int64_t d, const double* M_host,
                     int64_t k, double* out);
+/* dst[i*dst_stride] = src[i*src_stride], i < n (strides in elements, >= 1): a column of an (N,d)
+ * array out (x[..., i], distributions.py:1102) or in (np.stack(cols, axis=1), :1106). */
+int smc_copy_strided(smc_ctx* ctx, const double* src, int64_t src_stride, double* dst,
+                     int64_t dst_stride, int64_t n);
 
 /* ---- (f) weighted quantiles (resampling.py:381-417 wquantiles) -------------
  * W (N), x (N,d) device; alphas_host (k) levels; out_host (d,k): for every column the

@@ -73,6 +73,7 @@ SIGNATURES = {
     "smc_gather": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
     "smc_normal_rvs": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_u64, c_i64, c_vp]),
     "smc_normal_logpdf": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp]),
+    "smc_copy_strided": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64]),
     "smc_poisson_logpmf": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp]),
     "smc_standard_normal": (c_int, [c_vp, c_u64, c_i64, c_vp]),
     "smc_uniform": (c_int, [c_vp, c_u64, c_i64, c_vp]),
@@ -338,8 +339,36 @@ class DeviceArray:
             return inputs[1]._ew(rev, inputs[0])
         return NotImplemented
 
+    def column(self, i):
+        """``x[..., i]`` of an (N, d) array as a contiguous (N,) device array
+        (distributions.py:1102)."""
+        if self.ndim != 2 or self.dtype != np.float64:
+            raise TypeError("column() takes a float64 (N, d) array")
+        N, d = self.shape
+        i = int(i) + (d if int(i) < 0 else 0)
+        if not 0 <= i < d:
+            raise IndexError("index %d is out of bounds for axis 1 with size %d" % (i, d))
+        out = DeviceArray((N,), np.float64, self.ctx)
+        check(lib().smc_copy_strided(self.ctx.h, c_vp(self.ptr.value + 8 * i), d, out.ptr, 1, N))
+        return out
+
+    @classmethod
+    def stack_columns(cls, cols):
+        """``np.stack(cols, axis=1)`` of (N,) device arrays (distributions.py:1106)."""
+        N, d = cols[0].size, len(cols)
+        out = cls((N, d), np.float64, cols[0].ctx)
+        for i, c in enumerate(cols):
+            if not isinstance(c, DeviceArray) or c.size != N:
+                raise ValueError("all input arrays must have the same shape")
+            check(lib().smc_copy_strided(out.ctx.h, c.ptr, 1, c_vp(out.ptr.value + 8 * i), d, N))
+        return out
+
     def __getitem__(self, idx):
-        """``x[A]`` with a device or host int64 index array (core.py:332 Xp = X[A])."""
+        """``x[A]`` with a device or host int64 index array (core.py:332 Xp = X[A]);
+        ``x[..., i]`` / ``x[:, i]``: one column of an (N, d) array."""
+        if isinstance(idx, tuple) and len(idx) == 2 and isinstance(idx[1], (int, np.integer)) \
+                and (idx[0] is Ellipsis or idx[0] == slice(None)):
+            return self.column(idx[1])
         A = idx if isinstance(idx, DeviceArray) else DeviceArray.from_numpy(
             np.ascontiguousarray(idx, dtype=np.int64), context=self.ctx)
         if A.dtype != np.int64 or self.dtype != np.float64:
@@ -369,6 +398,9 @@ class DeviceArray:
         if func in (np.dot, np.matmul) and len(args) == 2 and isinstance(args[0], DeviceArray) \
                 and not isinstance(args[1], DeviceArray) and not kwargs:
             return args[0].__matmul__(args[1])
+        if func is np.stack and len(args) == 1 and kwargs.get("axis", 0) == 1 \
+                and all(isinstance(c, DeviceArray) and c.ndim == 1 for c in args[0]):
+            return DeviceArray.stack_columns(list(args[0]))
         return NotImplemented
 
     def __array__(self, dtype=None, copy=None):

@@ -406,6 +406,24 @@ extern "C" int smc_rows_matmul(smc_ctx* ctx, const double* X, int64_t N, int64_t
     return SMC_OK;
 }
 
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_copy_strided(const double* src, i64 ss, double* dst, i64 ds, i64 n)
+{
+    const i64 i = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;
+    if (i < n) dst[i * ds] = src[i * ss];
+}
+
+extern "C" int smc_copy_strided(smc_ctx* ctx, const double* src, int64_t src_stride, double* dst,
+                                int64_t dst_stride, int64_t n)
+{
+    SMC_REQUIRE(ctx && src && dst, "null argument");
+    SMC_REQUIRE(n > 0 && src_stride >= 1 && dst_stride >= 1, "n and the strides must be positive");
+    SMC_LAUNCH(k_copy_strided, dim3((unsigned)((n + SMC_BLOCK - 1) / SMC_BLOCK)), dim3(SMC_BLOCK),
+               ctx->stream, src, (i64)src_stride, dst, (i64)dst_stride, (i64)n);
+    SMC_LAUNCH_CHECK();
+    return SMC_OK;
+}
+
 // ---- residual resampling (resampling.py:611-626) ----------------------------
 // A[:sip] = arange(N).repeat(floor(M W)) is an inverse CDF on INTEGER weights with the
 // thresholds n+1; the remaining M - sip draws are a multinomial on (M W - floor(M W)) /

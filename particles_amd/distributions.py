@@ -125,6 +125,23 @@ class Poisson(ProbDist):
         return out if (d0 or d1 or _lib.RESIDENT[0]) else out.get()
 
 
+class IndepProd(ProbDist):
+    """Product of independent univariate distributions (distributions.py:1066-1106): inputs and
+    outputs of shape (N, d) -- numpy arrays, or device arrays (``set_resident``), whose columns
+    are split / joined on the device."""
+
+    def __init__(self, *dists):
+        self.dists = dists
+        self.dim = len(dists)
+        self.dtype = "int64" if all(d.dtype == "int64" for d in dists) else float
+
+    def logpdf(self, x):
+        return sum([d.logpdf(x[..., i]) for i, d in enumerate(self.dists)])       # :1101-1102
+
+    def rvs(self, size=None):
+        return np.stack([d.rvs(size=size) for d in self.dists], axis=1)          # :1105-1106
+
+
 class MvNormal(ProbDist):
     """Multivariate Normal distribution (distributions.py:888-1009).
 

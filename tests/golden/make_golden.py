@@ -38,6 +38,21 @@ class ToySSM(ssm.StateSpaceModel):          # README.md:66-72
         return dists.Normal(loc=x, scale=self.sigma)
 
 
+class Indep2(ssm.StateSpaceModel):
+    """A bivariate model assembled with IndepProd (distributions.py:1066-1106): Gaussian
+    states, one Gaussian and one Poisson observation."""
+    def PX0(self):
+        return dists.IndepProd(dists.Normal(scale=1.0), dists.Normal(scale=2.0))
+
+    def PX(self, t, xp):
+        return dists.IndepProd(dists.Normal(loc=0.9 * xp[:, 0]),
+                               dists.Normal(loc=0.5 * xp[:, 1] + 0.1 * xp[:, 0], scale=0.7))
+
+    def PY(self, t, xp, x):
+        return dists.IndepProd(dists.Normal(loc=x[:, 0], scale=0.5),
+                               dists.Poisson(rate=np.exp(0.3 * x[:, 1])))
+
+
 def run_case(model, fk_cls, T, N, scheme, ESSrmin, data_seed=42, run_seed=123):
     np.random.seed(data_seed)
     x, y = model.simulate(T)
@@ -80,6 +95,8 @@ def main():
     # Poisson observations (state_space_models.py:611-630, distributions.py:519-532)
     out["cox_boot"] = run_case(ssm.DiscreteCox(mu=0.5, sigma=0.4, phi=0.9), ssm.Bootstrap, 40, 600,
                                "systematic", 0.5)
+
+    out["indep_boot"] = run_case(Indep2(), ssm.Bootstrap, 30, 400, "systematic", 0.5)
 
     # --- auxiliary particle filter (core.py:299-313), Pitt & Shephard's StochVol proposal
     out["sv_apf"] = run_case(ssm.StochVol(), ssm.AuxiliaryPF, 30, 500, "systematic", 0.5)

@@ -969,6 +969,68 @@ def check_resident_user_model(golden):
         pa.set_resident(False)
 
 
+def check_indep_prod(golden):
+    """IndepProd (distributions.py:1066-1106): a bivariate model with a Gaussian and a Poisson
+    observation, transcribed from the reference-side definition in tests/golden/make_golden.py;
+    same numpy seed -> the reference's run, with host arrays and with arrays resident in HBM."""
+    class Indep2(ssm.StateSpaceModel):
+        def PX0(self):
+            return dists.IndepProd(dists.Normal(scale=1.0), dists.Normal(scale=2.0))
+
+        def PX(self, t, xp):
+            return dists.IndepProd(dists.Normal(loc=0.9 * xp[:, 0]),
+                                   dists.Normal(loc=0.5 * xp[:, 1] + 0.1 * xp[:, 0], scale=0.7))
+
+        def PY(self, t, xp, x):
+            return dists.IndepProd(dists.Normal(loc=x[:, 0], scale=0.5),
+                                   dists.Poisson(rate=np.exp(0.3 * x[:, 1])))
+
+    g = golden("indep_boot")
+    y = list(g["y"])
+    for resident in (False, True):
+        pa.set_resident(resident)
+        try:
+            np.random.seed(int(g["run_seed"]))
+            pf = pa.SMC(fk=ssm.Bootstrap(ssm=Indep2(), data=y), N=int(g["N"]),
+                        resampling=str(g["scheme"]), ESSrmin=float(g["ESSrmin"]))
+            assert not pf._fused
+            pf.run()
+            assert isinstance(pf.X, pa.DeviceArray) == resident
+            X = np.asarray(pf.X)
+            assert X.shape == (int(g["N"]), 2)
+            assert pf.summaries.rs_flags == [bool(v) for v in g["rs_flags"]]
+            assert rel(pf.summaries.logLts, g["logLts"]) < 1e-9
+            A = np.asarray(pf.A)
+            assert np.mean(A == g["A"]) >= 0.995
+            if np.array_equal(A, g["A"]):
+                assert np.max(np.abs(X - g["X"])) < 1e-11
+                assert np.allclose(np.asarray(pf.wgts.lw), g["lw"], rtol=1e-10, atol=1e-10)
+        finally:
+            pa.set_resident(False)
+    # columns in and out of an (N, d) device array
+    rng = np.random.default_rng(8)
+    Xh = rng.standard_normal((257, 3))
+    Xh[5, 1] = np.inf
+    Xh[6, 2] = -0.0
+    Xd = pa.DeviceArray.from_numpy(Xh)
+    for i in (0, 1, 2, -1):
+        assert np.array_equal(Xd[..., i].get(), Xh[..., i]) and np.array_equal(Xd[:, i].get(), Xh[:, i])
+    back = np.stack([Xd[:, i] for i in range(3)], axis=1)
+    assert isinstance(back, pa.DeviceArray) and np.array_equal(back.get(), Xh)
+    assert np.array_equal(np.signbit(back.get()), np.signbit(Xh))
+    try:
+        Xd[:, 3]
+        raise AssertionError("column 3 of an (N, 3) array")
+    except IndexError:
+        pass
+    d = dists.IndepProd(dists.Normal(loc=1.0, scale=2.0), dists.Normal(), dists.Normal(scale=0.5))
+    Xh[5, 1] = 0.25
+    want = (orc.normal_logpdf(Xh[:, 0], 1.0, 2.0) + orc.normal_logpdf(Xh[:, 1])
+            + orc.normal_logpdf(Xh[:, 2], 0.0, 0.5))
+    assert np.allclose(d.logpdf(Xh), want, rtol=1e-14, atol=1e-14)
+    assert d.rvs(size=10).shape == (10, 3) and d.dim == 3
+
+
 def check_collectors_on_fused(golden):
     from particles_amd.collectors import Moments
     g = golden("kalman_toy")

@@ -75,6 +75,10 @@ def test_gather():
     pc.check_gather(50000, 32)
 
 
+def test_indep_prod(golden):
+    pc.check_indep_prod(golden)
+
+
 def test_poisson_and_cox(golden):
     pc.check_poisson(golden)
 
