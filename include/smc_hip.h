@@ -120,6 +120,12 @@ int smc_normal_logpdf(smc_ctx* ctx, const double* x, int64_t x_stride,
  * k / rate are device arrays read with the given element stride (0 = broadcast). */
 int smc_poisson_logpmf(smc_ctx* ctx, const double* k, int64_t k_stride, const double* rate,
                        int64_t rate_stride, int64_t N, double* out);
+/* Normal.ppf (distributions.py:276-277 -> scipy.stats.norm.ppf): ndtri(u) * scale + loc with
+ * Cephes' ndtri (the routine scipy.special.ndtri wraps); u, loc, scale strided as above.
+ * SQMC's Gamma0 / Gamma (state_space_models.py:335-340). */
+int smc_normal_ppf(smc_ctx* ctx, const double* u, int64_t u_stride, const double* loc,
+                   int64_t loc_stride, const double* scale, int64_t scale_stride, int64_t N,
+                   double* out);
 /* standard normals / uniforms from the Philox stream (for the generic path) */
 int smc_standard_normal(smc_ctx* ctx, uint64_t counter, int64_t n, double* out);
 int smc_uniform(smc_ctx* ctx, uint64_t counter, int64_t n, double* out);
@@ -156,6 +162,18 @@ int smc_rows_matmul(smc_ctx* ctx, const double* X, int64_t N, int64_t d, const d
  * array out (x[..., i], distributions.py:1102) or in (np.stack(cols, axis=1), :1106). */
 int smc_copy_strided(smc_ctx* ctx, const double* src, int64_t src_stride, double* dst,
                      int64_t dst_stride, int64_t n);
+
+/* ---- (f) SQMC building blocks (core.py:339-349, rqmc.py, hilbert.py:33-58) ---
+ * smc_argsort: out[i] = index of the i-th smallest x (np.argsort(x); hilbert_sort for d = 1;
+ *   stable, -0.0 before +0.0, NaNs last).
+ * smc_sobol: the first N points of the d-dimensional Sobol' sequence (Joe-Kuo direction numbers,
+ *   30 bits, Gray-code order: scipy.stats.qmc.Sobol(d, scramble=False) bit for bit), each
+ *   coordinate XOR-ed with a 30-bit digital shift drawn from the Philox stream `counter`
+ *   (randomised QMC; shift = 0 when scramble == 0), then rqmc.safe_generate's map
+ *   0.5 + (1 - 1e-10) (u - 0.5) when safe != 0.  d <= 10.  out (N, d) row-major. */
+int smc_argsort(smc_ctx* ctx, const double* x, int64_t N, int64_t* out);
+int smc_sobol(smc_ctx* ctx, int64_t N, int32_t d, int32_t scramble, int32_t safe,
+              uint64_t counter, double* out);
 
 /* ---- (f) weighted quantiles (resampling.py:381-417 wquantiles) -------------
  * W (N), x (N,d) device; alphas_host (k) levels; out_host (d,k): for every column the

@@ -744,6 +744,72 @@ def run_filter(model, data, N, scheme="systematic", ESSrmin=0.5, fk="bootstrap",
     return out
 
 
+def normal_ppf(u, loc=0.0, scale=1.0):
+    """distributions.py:276-277 -> scipy.stats.norm.ppf = ndtri(u) * scale + loc
+    (rv_continuous.ppf: ``self._ppf(q) * scale + loc``; ``_ppf`` is special.ndtri)."""
+    return ssp_special.ndtri(np.asarray(u, dtype=np.float64)) * scale + loc
+
+
+def run_sqmc(model, data, N, u_tape, fk="bootstrap", cdf="seq", T=None):
+    """SQMC (core.py:315-349, ``SMC(qmc=True)``) for a univariate model.  ``u_tape[t]`` are
+    the points the run consumes at step t -- rqmc.sobol(N, 1) at t = 0, rqmc.sobol(N, 2)
+    after -- recorded from the reference (they come from scipy's self-seeded Sobol' engine).
+    Always resamples: argsort of the first coordinate, particles in sorted (= Hilbert, d = 1:
+    hilbert.py:52-54) order, inverse CDF, move by the inverse-CDF transform Gamma."""
+    T = len(data) if T is None else T
+    out = {k: [] for k in ("ESS", "log_mean", "loglt", "logLt", "rs_flag")}
+    wgts = Weights()
+    X = Xp = A = None
+    logLt = 0.0
+    log_mean_w = None
+    for t in range(T):
+        yt = np.asarray(data[t])
+        u = np.asarray(u_tape[t])
+        if t == 0:                                        # core.py:315-319
+            loc, scale = model.proposal0(yt) if fk == "guided" else model.px0()
+            X = normal_ppf(u.squeeze(), loc, scale)       # state_space_models.py:335-336 / :394-395
+            rs_flag = False
+        else:                                             # core.py:339-349
+            rs_flag = True
+            tau = np.argsort(u[:, 0])
+            h_order = np.argsort(X, axis=0)               # hilbert.py:52-54
+            su, Ws = u[tau, 0], wgts.W[h_order]
+            A = h_order[inverse_cdf(su, Ws) if cdf == "seq" else inverse_cdf_q62(su, Ws)]
+            Xp = X[A]
+            v = u[tau, 1:].squeeze()
+            wgts = Weights()
+            if fk == "guided":
+                loc, scale = model.proposal(Xp, yt)
+            else:
+                loc, scale = model.px(Xp, t) if getattr(model, "time_dependent", False) else model.px(Xp)
+            X = normal_ppf(v, loc, scale)                 # :338-340 / :397-398
+        if fk == "guided":                                # state_space_models.py:380-392
+            if t == 0:
+                l0, s0 = model.px0()
+                q0, qs0 = model.proposal0(yt)
+                inc = (normal_logpdf(X, l0, s0) + model.py_logpdf(yt, None, X)
+                       - normal_logpdf(X, q0, qs0))
+            else:
+                l1, s1 = model.px(Xp)
+                q1, qs1 = model.proposal(Xp, yt)
+                inc = (normal_logpdf(X, l1, s1) + model.py_logpdf(yt, Xp, X)
+                       - normal_logpdf(X, q1, qs1))
+        else:
+            inc = model.py_logpdf(yt, Xp, X)
+        wgts = wgts.add(inc)
+        prec = log_mean_w                                 # core.py:351-359
+        log_mean_w = wgts.log_mean
+        loglt = log_mean_w if (t == 0 or rs_flag) else log_mean_w - prec
+        logLt += loglt
+        out["ESS"].append(float(wgts.ESS))
+        out["log_mean"].append(float(log_mean_w))
+        out["loglt"].append(float(loglt))
+        out["logLt"].append(float(logLt))
+        out["rs_flag"].append(rs_flag)
+    out.update(X=X, Xp=Xp, A=A, lw=wgts.lw, W=wgts.W, final_logLt=logLt)
+    return out
+
+
 def wquantiles(W, x, alphas=(0.25, 0.50, 0.75)):
     """resampling.py:381-417 (``_wquantiles`` per column)."""
     def one(xc):

@@ -7,6 +7,7 @@ CPU fallback: without the built library and a visible GPU the operators raise.
 """
 from ._lib import DeviceArray, seed  # noqa: F401
 from .core import SMC, FeynmanKac, multiSMC  # noqa: F401
+from . import hilbert, rqmc  # noqa: F401
 
 
 def set_resident(flag=True):

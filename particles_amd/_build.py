@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libsmc_hip.so")
-SOURCES = ["smc_api.hip", "smc_ops.hip", "smc_filter.hip", "smc_comm.hip", "smc_sort.hip"]
+SOURCES = ["smc_api.hip", "smc_ops.hip", "smc_filter.hip", "smc_comm.hip", "smc_sort.hip", "smc_qmc.hip"]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [
     os.path.join("..", "..", "include", "smc_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",

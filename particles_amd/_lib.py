@@ -74,6 +74,9 @@ SIGNATURES = {
     "smc_normal_rvs": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_u64, c_i64, c_vp]),
     "smc_normal_logpdf": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp]),
     "smc_copy_strided": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64]),
+    "smc_normal_ppf": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp]),
+    "smc_argsort": (c_int, [c_vp, c_vp, c_i64, c_vp]),
+    "smc_sobol": (c_int, [c_vp, c_i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_u64, c_vp]),
     "smc_poisson_logpmf": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp]),
     "smc_standard_normal": (c_int, [c_vp, c_u64, c_i64, c_vp]),
     "smc_uniform": (c_int, [c_vp, c_u64, c_i64, c_vp]),
@@ -371,10 +374,12 @@ class DeviceArray:
             return self.column(idx[1])
         A = idx if isinstance(idx, DeviceArray) else DeviceArray.from_numpy(
             np.ascontiguousarray(idx, dtype=np.int64), context=self.ctx)
-        if A.dtype != np.int64 or self.dtype != np.float64:
-            raise TypeError("DeviceArray indexing takes an int64 index array on a float64 array")
+        if A.dtype != np.int64:
+            raise TypeError("DeviceArray indexing takes an int64 index array")
         d = self.size // self.shape[0]
-        out = DeviceArray((A.size,) + tuple(self.shape[1:]), np.float64, self.ctx)
+        # (8-byte elements either way: an int64 array -- h_order[idx], core.py:344 -- is gathered
+        # by the same kernel, which only copies words)
+        out = DeviceArray((A.size,) + tuple(self.shape[1:]), self.dtype, self.ctx)
         check(lib().smc_gather(self.ctx.h, self.ptr, A.ptr, A.size, d, out.ptr))
         return out
 

@@ -21,7 +21,9 @@ import numpy as np
 
 from . import _lib
 from . import collectors
+from . import hilbert
 from . import resampling as rs
+from . import rqmc
 from ._lib import DeviceArray, check, lib
 
 
@@ -42,6 +44,14 @@ class FeynmanKac:
 
     def logG(self, t, xp, x):
         raise NotImplementedError(self._error_msg("logG"))
+
+    def Gamma0(self, u):
+        """Deterministic map of u ~ U([0,1]^d) to X_0 (SQMC, core.py:157-160)."""
+        raise NotImplementedError(self._error_msg("Gamma0"))
+
+    def Gamma(self, t, xp, u):
+        """Deterministic map of (xp, u) to X_t ~ M_t(xp, dx) (SQMC, core.py:162-166)."""
+        raise NotImplementedError(self._error_msg("Gamma"))
 
     @property
     def isAPF(self):
@@ -123,8 +133,9 @@ class SMC:
     def __init__(self, fk=None, N=100, qmc=False, resampling="systematic", ESSrmin=0.5,
                  store_history=False, verbose=False, collect=None, seed=None, n_islands=1,
                  replay=None, use_graph=True, island_offset=0):
-        if qmc:
-            raise NotImplementedError("SQMC (qmc=True) is outside the device hot path")
+        if qmc and getattr(fk, "du", 1) != 1:
+            raise NotImplementedError("SQMC (qmc=True) is built for univariate states (du = 1): "
+                                      "the Hilbert sort of (N, d) particles is not part of this path")
         self._fk_list = None
         if isinstance(fk, (list, tuple)):        # one Feynman-Kac model per island (SMC^2: one theta each)
             self._fk_list = list(fk)
@@ -161,6 +172,8 @@ class SMC:
         self._summ_cache = None
         model = fk._device_model() if hasattr(fk, "_device_model") else None
         if fk is not None and fk.isAPF:
+            model = None
+        if qmc:                    # SQMC: the template-method step on device operators
             model = None
         self._fused = model is not None and resampling in _lib.SCHEMES \
             and (model.get("params") is not None or model["kind"] == _lib.MODEL_MVLINGAUSS)
@@ -408,7 +421,11 @@ class SMC:
             self.aux = self.wgts
 
     def generate_particles(self):
-        self.X = self.fk.M0(self.N)                                # core.py:315-321
+        if self.qmc:                                               # core.py:315-321
+            u = rqmc.sobol(self.N, self.fk.du)
+            self.X = self.fk.Gamma0(u[:, 0])                       # (N,) since du = 1
+        else:
+            self.X = self.fk.M0(self.N)
 
     def reweight_particles(self):
         self.wgts = self.wgts.add(self.fk.logG(self.t, self.Xp, self.X))   # core.py:323-324
@@ -423,6 +440,22 @@ class SMC:
             self.A = np.arange(self.N)
             self.Xp = self.X
         self.X = self.fk.M(self.t, self.Xp)
+
+    def resample_move_qmc(self):
+        """SQMC step (core.py:339-349): always resample; the particles are visited in Hilbert
+        order (= sorted order for du = 1), the first QMC coordinate -- sorted -- drives the
+        inverse-CDF choice of ancestors, the others the move Gamma.  Sorts, gathers, inverse CDF
+        and the inverse-normal-CDF move are device operators."""
+        self.rs_flag = True
+        u = rqmc.sobol(self.N, self.fk.du + 1)
+        u0 = u[:, 0]
+        tau = hilbert.argsort(u0)
+        self.h_order = hilbert.hilbert_sort(self.X)
+        self.A = self.h_order[rs.inverse_cdf(u0[tau], self.aux.W[self.h_order])]
+        self.Xp = self.X[self.A]
+        v = u[:, 1][tau]                                           # u[tau, 1:].squeeze(), du = 1
+        self.reset_weights()
+        self.X = self.fk.Gamma(self.t, self.Xp, v)
 
     def compute_summaries(self):
         if self.t > 0:                                             # core.py:351-367
@@ -469,7 +502,10 @@ class SMC:
             self.generate_particles()
         else:
             self.setup_auxiliary_weights()
-            self.resample_move()
+            if self.qmc:
+                self.resample_move_qmc()
+            else:
+                self.resample_move()
         self.reweight_particles()
         self.compute_summaries()
         self.t += 1

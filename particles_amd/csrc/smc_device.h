@@ -32,7 +32,7 @@ __device__ __forceinline__ int smc_wave() { return (int)(threadIdx.x >> 6); }
 // One call yields two 64-bit words.  Restated in oracle/smc_oracle.py and
 // oracle/oracle.c; tests check the integer stream bit-for-bit.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void smc_philox(u32 c0, u32 c1, u32 c2, u32 c3, u64 seed,
+__host__ __device__ __forceinline__ void smc_philox(u32 c0, u32 c1, u32 c2, u32 c3, u64 seed,
                                            u64& x01, u64& x23)
 {
     u32 k0 = (u32)seed, k1 = (u32)(seed >> 32);

@@ -45,6 +45,58 @@ __global__ void k_quantile_probe(const double* cw, const double* xs, i64 N, cons
     out[4 * j + 3] = xs[prev + 1];
 }
 
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_iota_i64(i64 N, i64* out)
+{
+    const i64 i = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;
+    if (i < N) out[i] = i;
+}
+
+// np.argsort(x) (hilbert.py:52-54 for d = 1; core.py:342 argsort of the first QMC coordinate):
+// device-wide radix sort of (x, index) pairs
+extern "C" int smc_argsort(smc_ctx* ctx, const double* x, int64_t N, int64_t* out)
+{
+    SMC_REQUIRE(ctx && x && out, "null argument");
+    SMC_REQUIRE(N > 0 && N < ((int64_t)1 << 31), "N must be in [1, 2^31)");
+    hipStream_t st = ctx->stream;
+    SMC_HIP_CHECK(hipSetDevice(ctx->device));
+#ifdef SMC_EMULATE
+    {   // test infrastructure: host sort
+        SMC_HIP_CHECK(hipStreamSynchronize(st));
+        std::vector<i64> o((size_t)N);
+        std::iota(o.begin(), o.end(), 0);
+        std::stable_sort(o.begin(), o.end(), [&](i64 a, i64 b) { return x[a] < x[b]; });
+        for (i64 i = 0; i < N; ++i) out[i] = o[(size_t)i];
+        return SMC_OK;
+    }
+#else
+    void* buf = nullptr;
+    size_t tb = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, x, (double*)nullptr, (const i64*)nullptr,
+                                             (i64*)nullptr, (int)N, 0, 64, st);
+    const size_t nb = (size_t)N * 8;
+    hipError_t e = hipMalloc(&buf, 2 * nb + (tb ? tb : 8));
+    if (e != hipSuccess) {
+        smc_set_error("smc_argsort: %zu bytes: %s", 2 * nb + tb, hipGetErrorString(e));
+        return SMC_ERR_NOMEM;
+    }
+    double* ks = (double*)buf;
+    i64* idx = (i64*)((char*)buf + nb);
+    void* tmp = (char*)buf + 2 * nb;
+    SMC_LAUNCH(k_iota_i64, dim3((unsigned)((N + SMC_BLOCK - 1) / SMC_BLOCK)), dim3(SMC_BLOCK), st,
+               (i64)N, idx);
+    int rc = SMC_OK;
+    if (hipcub::DeviceRadixSort::SortPairs(tmp, tb, x, ks, (const i64*)idx, (i64*)out, (int)N, 0, 64,
+                                           st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) {
+        smc_set_error("smc_argsort: HIP error: %s", hipGetErrorString(hipGetLastError()));
+        rc = SMC_ERR_HIP;
+    }
+    (void)hipFree(buf);
+    return rc;
+#endif
+}
+
 extern "C" int smc_wquantiles(smc_ctx* ctx, const double* W, const double* x, int64_t N, int64_t d,
                               const double* alphas_host, int k, double* out_host)
 {

@@ -102,6 +102,20 @@ class Normal(LocScaleDist):
         return out if (d0 or d1 or d2 or _lib.RESIDENT[0]) else out.get()
 
 
+def _normal_ppf(self, u):
+    """scipy.stats.norm.ppf(u, loc, scale) = ndtri(u) * scale + loc  (:276-277)."""
+    N = _bsize(self.loc, self.scale, u)
+    ud, us, d0 = _strided(u, N)
+    loc, ls, d1 = _strided(self.loc, N)
+    sc, ss, d2 = _strided(self.scale, N)
+    out = DeviceArray((N,))
+    check(lib().smc_normal_ppf(out.ctx.h, ud.ptr, us, loc.ptr, ls, sc.ptr, ss, N, out.ptr))
+    return out if (d0 or d1 or d2 or _lib.RESIDENT[0]) else out.get()
+
+
+Normal.ppf = _normal_ppf
+
+
 class Poisson(ProbDist):
     """Poisson(rate) distribution (distributions.py:519-532).  ``logpdf`` is evaluated on the
     device for per-particle rates; ``rvs`` (only used to simulate data) draws on the host with

@@ -90,6 +90,12 @@ class Bootstrap(FeynmanKac):
     def logG(self, t, xp, x):
         return self.ssm.PY(t, xp, x).logpdf(self.data[t])
 
+    def Gamma0(self, u):
+        return self.ssm.PX0().ppf(u)                       # state_space_models.py:335-336
+
+    def Gamma(self, t, xp, u):
+        return self.ssm.PX(t, xp).ppf(u)                   # :338-340
+
     def logpt(self, t, xp, x):
         """PDF of X_t|X_{t-1}=xp"""
         return self.ssm.PX(t, xp).logpdf(x)
@@ -109,6 +115,12 @@ class GuidedPF(Bootstrap):
 
     def M(self, t, xp):
         return self.ssm.proposal(t, xp, self.data).rvs(size=xp.shape[0])
+
+    def Gamma0(self, u):
+        return self.ssm.proposal0(self.data).ppf(u)        # :394-395
+
+    def Gamma(self, t, xp, u):
+        return self.ssm.proposal(t, xp, self.data).ppf(u)  # :397-398
 
     def logG(self, t, xp, x):
         if t == 0:

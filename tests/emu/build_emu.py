@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "particles_amd", "csrc")
 OUT = os.path.join(HERE, "_build", "libsmc_emu.so")
-SOURCES = ["smc_api.hip", "smc_ops.hip", "smc_filter.hip", "smc_comm.hip", "smc_sort.hip"]
+SOURCES = ["smc_api.hip", "smc_ops.hip", "smc_filter.hip", "smc_comm.hip", "smc_sort.hip", "smc_qmc.hip"]
 
 
 def build(force=False):

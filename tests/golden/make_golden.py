@@ -68,6 +68,38 @@ def run_case(model, fk_cls, T, N, scheme, ESSrmin, data_seed=42, run_seed=123):
         X=pf.X, A=pf.A, lw=pf.wgts.lw, W=pf.W)
 
 
+def run_sqmc_case(model, fk_cls, T, N, data_seed=42, qmc_seed=7):
+    """SMC(qmc=True) (core.py:315-349).  rqmc.sobol draws from scipy's self-seeded engine, so
+    the run is made repeatable -- and its points recorded -- by giving the engine a seed."""
+    from scipy.stats import qmc
+    from particles import rqmc
+    np.random.seed(data_seed)
+    x, y = model.simulate(T)
+    tape = []
+    ss = np.random.SeedSequence(qmc_seed)
+
+    def seeded_sobol(N_, d):
+        eng = qmc.Sobol(d, seed=np.random.default_rng(ss.spawn(1)[0]))
+        u = eng.random(N_)
+        v = 0.5 + (1.0 - rqmc.TOL) * (u - 0.5)            # rqmc.py:9-13 safe_generate
+        tape.append(v)
+        return v
+
+    orig = rqmc.sobol
+    rqmc.sobol = seeded_sobol
+    try:
+        pf = particles.SMC(fk=fk_cls(ssm=model, data=y), N=N, qmc=True)
+        pf.run()
+    finally:
+        rqmc.sobol = orig
+    d = dict(y=np.array(y), T=T, N=N, scheme="systematic", ESSrmin=0.5, data_seed=data_seed,
+             run_seed=qmc_seed, ESSs=np.array(pf.summaries.ESSs),
+             logLts=np.array(pf.summaries.logLts), rs_flags=np.array(pf.summaries.rs_flags),
+             logLt=pf.logLt, X=pf.X, A=pf.A, lw=pf.wgts.lw, W=pf.W, u0=tape[0],
+             u=np.array(tape[1:]))
+    return d
+
+
 def main():
     out = {}
 
@@ -97,6 +129,13 @@ def main():
                                "systematic", 0.5)
 
     out["indep_boot"] = run_case(Indep2(), ssm.Bootstrap, 30, 400, "systematic", 0.5)
+
+    # --- SQMC (core.py:315-349): quasi-random points, Hilbert (sorted) order, ppf moves
+    out["sqmc_toy"] = run_sqmc_case(kalman.LinearGauss(rho=0.9, sigmaX=1.0, sigmaY=0.5),
+                                    ssm.Bootstrap, 30, 512)
+    out["sqmc_sv"] = run_sqmc_case(ssm.StochVol(), ssm.Bootstrap, 25, 300)
+    out["sqmc_guided"] = run_sqmc_case(kalman.LinearGauss(rho=0.9, sigmaX=1.0, sigmaY=0.3),
+                                       ssm.GuidedPF, 25, 256)
 
     # --- auxiliary particle filter (core.py:299-313), Pitt & Shephard's StochVol proposal
     out["sv_apf"] = run_case(ssm.StochVol(), ssm.AuxiliaryPF, 30, 500, "systematic", 0.5)

@@ -1031,6 +1031,88 @@ def check_indep_prod(golden):
     assert d.rvs(size=10).shape == (10, 3) and d.dim == 3
 
 
+def check_sqmc(golden, monkeypatch):
+    """SQMC (SMC(qmc=True), core.py:315-349) on device operators: the reference's runs on its
+    recorded Sobol' points; then the operators themselves (Sobol' generator vs scipy's, ndtri
+    vs scipy's, argsort vs numpy's) and a run on device-generated points against Kalman."""
+    from particles_amd import rqmc, hilbert
+    cases = [("sqmc_toy", lambda: kalman.LinearGauss(rho=0.9, sigmaX=1.0, sigmaY=0.5), ssm.Bootstrap),
+             ("sqmc_sv", lambda: ssm.StochVol(), ssm.Bootstrap),
+             ("sqmc_guided", lambda: kalman.LinearGauss(rho=0.9, sigmaX=1.0, sigmaY=0.3), ssm.GuidedPF)]
+    for case, mk, cls in cases:
+        g = golden(case)
+        y = list(g["y"])
+        for resident in (False, True):
+            tape = [g["u0"]] + list(g["u"])
+            it = iter(tape)
+
+            def replay(N, d, it=it, resident=resident):
+                u = next(it)
+                assert u.shape == (N, d)
+                return pa.DeviceArray.from_numpy(u) if resident else u
+            monkeypatch.setattr(rqmc, "sobol", replay)
+            pa.set_resident(resident)
+            try:
+                pf = pa.SMC(fk=cls(ssm=mk(), data=y), N=int(g["N"]), qmc=True)
+                assert not pf._fused
+                pf.run()
+                assert pf.summaries.rs_flags == [bool(v) for v in g["rs_flags"]]
+                assert rel(pf.summaries.logLts, g["logLts"]) < 1e-9
+                assert rel(pf.summaries.ESSs, g["ESSs"]) < 1e-8
+                A = np.asarray(pf.A)
+                assert np.mean(A == g["A"]) >= 0.995
+                if np.array_equal(A, g["A"]):
+                    assert np.max(np.abs(np.asarray(pf.X) - g["X"])) < 1e-11
+                    assert np.allclose(np.asarray(pf.wgts.lw), g["lw"], rtol=1e-10, atol=1e-10)
+            finally:
+                pa.set_resident(False)
+                monkeypatch.undo()
+    # ---- the operators
+    from scipy.stats import qmc
+    from scipy import special
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for d in (1, 2, 3, 7, 10):
+            ref = qmc.Sobol(d, scramble=False).random(1000)
+            assert np.array_equal(rqmc.sobol_unscrambled(1000, d), ref)
+    rng = np.random.default_rng(3)
+    u = np.concatenate([rng.random(5000), 10.0 ** -rng.uniform(1, 300, 2000),
+                        1.0 - 10.0 ** -rng.uniform(1, 15, 1000), [0.0, 1.0, 0.5, -0.1, 1.5, np.nan]])
+    got = dists.Normal(loc=0.3, scale=1.7).ppf(u)
+    want = special.ndtri(u) * 1.7 + 0.3
+    fin = np.isfinite(want)
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(got[np.isinf(want)], want[np.isinf(want)])
+    assert np.max(np.abs(got[fin] - want[fin]) / (1.0 + np.abs(want[fin]))) < 5e-16
+    central = fin & (u > 0.14) & (u < 0.86)
+    assert np.array_equal(got[central], want[central])           # IEEE + - * / only
+    x = rng.standard_normal(5003)
+    assert np.array_equal(hilbert.argsort(x), np.argsort(x, kind="stable"))
+    assert np.array_equal(hilbert.hilbert_sort(x.reshape(-1, 1)), np.argsort(x, kind="stable"))
+    # ---- a run on device-generated, digitally shifted points (Philox mode)
+    g = golden("kalman_toy")
+    y = [np.atleast_1d(v) for v in np.squeeze(g["y"])][:40]
+    ll, _ = orc.kalman_loglik(orc.ToySSM(0.2), y)
+    rs.set_rng("philox")
+    try:
+        pa.seed(5)
+        pts = rqmc.sobol(1024, 2)
+        assert isinstance(pts, pa.DeviceArray)
+        ph = pts.get()
+        assert ph.min() > 0.0 and ph.max() < 1.0
+        for c in range(2):           # a (0, m, 1)-net in base 2 survives the digital shift
+            assert np.array_equal(np.sort(np.floor(ph[:, c] * 1024).astype(int)), np.arange(1024))
+        lls = []
+        for s in range(4):
+            pa.seed(100 + s)
+            pf = pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y), N=4096, qmc=True)
+            pf.run()
+            lls.append(pf.logLt)
+        assert np.max(np.abs(np.array(lls) - ll)) < 0.25
+    finally:
+        rs.set_rng("numpy")
+
+
 def check_collectors_on_fused(golden):
     from particles_amd.collectors import Moments
     g = golden("kalman_toy")

@@ -75,6 +75,10 @@ def test_gather():
     pc.check_gather(50000, 32)
 
 
+def test_sqmc(golden, monkeypatch):
+    pc.check_sqmc(golden, monkeypatch)
+
+
 def test_indep_prod(golden):
     pc.check_indep_prod(golden)
 

@@ -30,6 +30,25 @@ CASES = ([("toy_%s" % s, "toy", "bootstrap") for s in ("systematic", "stratified
             ("svlev_boot", "svlev", "bootstrap"), ("cox_boot", "cox", "bootstrap")])
 
 
+SQMC_CASES = [("sqmc_toy", lambda: orc.LinGauss(rho=0.9, sigmaX=1.0, sigmaY=0.5), "bootstrap"),
+              ("sqmc_sv", lambda: orc.StochVol(), "bootstrap"),
+              ("sqmc_guided", lambda: orc.LinGauss(rho=0.9, sigmaX=1.0, sigmaY=0.3), "guided")]
+
+
+@pytest.mark.parametrize("case,mk,fk", SQMC_CASES)
+def test_sqmc_bit_exact_vs_reference(golden, case, mk, fk):
+    """SMC(qmc=True) of the reference (core.py:315-349) on its recorded Sobol' points."""
+    g = golden(case)
+    out = orc.run_sqmc(mk(), list(g["y"]), int(g["N"]), [g["u0"]] + list(g["u"]), fk=fk)
+    assert np.array_equal(np.array(out["rs_flag"]), g["rs_flags"])
+    assert np.array_equal(np.array(out["ESS"]), g["ESSs"])
+    assert np.array_equal(np.array(out["logLt"]), g["logLts"])
+    assert np.array_equal(out["X"], g["X"])
+    assert np.array_equal(out["A"], g["A"])
+    assert np.array_equal(out["lw"], g["lw"])
+    assert np.array_equal(out["W"], g["W"])
+
+
 @pytest.mark.parametrize("case,model,fk", CASES)
 def test_filter_bit_exact_vs_reference(golden, case, model, fk):
     g = golden(case)
