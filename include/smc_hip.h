@@ -172,6 +172,18 @@ int smc_copy_strided(smc_ctx* ctx, const double* src, int64_t src_stride, double
  *   (randomised QMC; shift = 0 when scramble == 0), then rqmc.safe_generate's map
  *   0.5 + (1 - 1e-10) (u - 0.5) when safe != 0.  d <= 10.  out (N, d) row-major. */
 int smc_argsort(smc_ctx* ctx, const double* x, int64_t N, int64_t* out);
+/* hilbert_sort (hilbert.py:33-58) of N vectors x (N, d), 2 <= d <= 16: standardise each
+ * component (np.mean / np.std over the particles), logistic map to (0,1), scale to integers
+ * below floor(2^(62/d)), Hilbert index of each point (Witham's codec, hilbert.py:61-292,
+ * restated with integer operations only), argsort of the indices.  keys_out (N) receives the
+ * Hilbert indices when not NULL. */
+int smc_hilbert_sort(smc_ctx* ctx, const double* x, int64_t N, int32_t d, int64_t* out,
+                     int64_t* keys_out);
+/* hilbert_array (hilbert.py:13-30): Hilbert indices of N points with non-negative integer
+ * coordinates xint (N, d) device int64, 1 <= d <= 16.  The index is accumulated in int64
+ * that wraps, as the reference's does when d * bit_length(max coordinate) > 63 (d >= 4 on
+ * hilbert_sort's grid); hilbert_sort orders the signed values like np.argsort. */
+int smc_hilbert_array(smc_ctx* ctx, const int64_t* xint, int64_t N, int32_t d, int64_t* out);
 int smc_sobol(smc_ctx* ctx, int64_t N, int32_t d, int32_t scramble, int32_t safe,
               uint64_t counter, double* out);
 

@@ -750,6 +750,77 @@ def normal_ppf(u, loc=0.0, scale=1.0):
     return ssp_special.ndtri(np.asarray(u, dtype=np.float64)) * scale + loc
 
 
+def _i64(v):
+    """wrap a Python int to int64 like numba / numpy scalar arithmetic does"""
+    v &= (1 << 64) - 1
+    return v - (1 << 64) if v >> 63 else v
+
+
+def _hb_gray_decode(n):                                   # hilbert.py:206-215
+    sh = 1
+    while True:
+        div = n >> sh
+        n ^= div
+        if div <= 1:
+            return n
+        sh <<= 1
+
+
+def _hb_encode_travel(start, end, mask, i):               # hilbert.py:227-236
+    travel_bit = start ^ end
+    g = (i ^ (i // 2)) * (travel_bit * 2)
+    return ((g | (g // (mask + 1))) & mask) ^ start
+
+
+def _hb_decode_travel(start, end, mask, g):               # hilbert.py:239-244
+    travel_bit = start ^ end
+    modulus = mask + 1
+    rg = (g ^ start) * (modulus // (travel_bit * 2))
+    return _hb_gray_decode((rg | (rg // modulus)) & mask)
+
+
+def hilbert_to_int(coords):
+    """hilbert.py:79-91 ``Hilbert_to_int``: chunks of nD bits, one bit per coordinate (coordinate
+    0 highest), most significant first (``unpack_coords`` / ``transpose_bits``, :146-190), each
+    decoded through the travelling Gray code of the current sub-cube; ``pack_index`` (:134-140)
+    accumulates in int64, which wraps once nD * nChunks > 63."""
+    coords = [int(c) for c in coords]
+    nD = len(coords)
+    biggest = max(coords)
+    nChunks = max(1, biggest.bit_length())                # int(ceil(log2(biggest + 1))), :149-156
+    mask = 2 ** nD - 1
+    start, end = 0, 2 ** ((-nChunks - 1) % nD)            # :94-99
+    z = 0
+    for j in range(nChunks):
+        bit = nChunks - 1 - j
+        chunk = 0
+        for c in coords:
+            chunk = chunk * 2 + ((c >> bit) & 1)
+        i = _hb_decode_travel(start, end, mask, chunk)
+        z = _i64((2 ** nD) * z + i)
+        start_i = max(0, (i - 1) & ~1)                    # child_start_end, :287-292
+        end_i = min(mask, (i + 1) | 1)
+        start, end = (_hb_encode_travel(start, end, mask, start_i),
+                      _hb_encode_travel(start, end, mask, end_i))
+    return z
+
+
+def hilbert_array(xint):                                  # hilbert.py:13-30
+    return np.array([hilbert_to_int(row) for row in np.asarray(xint)], dtype=np.int64)
+
+
+def hilbert_sort(x):
+    """hilbert.py:33-58."""
+    x = np.asarray(x)
+    d = 1 if x.ndim == 1 else x.shape[1]
+    if d == 1:
+        return np.argsort(x, axis=0)
+    xs = 1.0 / (1.0 + np.exp(-((x - np.mean(x, axis=0)) / np.std(x, axis=0))))
+    maxint = np.floor(2 ** (62 / d))
+    xint = np.floor(xs * maxint).astype(np.int64)
+    return np.argsort(hilbert_array(xint))
+
+
 def run_sqmc(model, data, N, u_tape, fk="bootstrap", cdf="seq", T=None):
     """SQMC (core.py:315-349, ``SMC(qmc=True)``) for a univariate model.  ``u_tape[t]`` are
     the points the run consumes at step t -- rqmc.sobol(N, 1) at t = 0, rqmc.sobol(N, 2)
@@ -762,28 +833,61 @@ def run_sqmc(model, data, N, u_tape, fk="bootstrap", cdf="seq", T=None):
     X = Xp = A = None
     logLt = 0.0
     log_mean_w = None
+    mv = getattr(model, "dim", 1) > 1
+    if mv:                                                # as run_filter; MvNormal.ppf (:970-981) =
+        LX = np.linalg.cholesky(model.covX)               # linear_transform(norm.ppf(u))
+        LY = np.linalg.cholesky(model.covY)
+        L0 = np.linalg.cholesky(model.cov0)
+        if fk == "guided":
+            f0m, f0c, _ = kalman_filter_step(model.G, model.covY, model.mu0, model.cov0,
+                                             np.asarray(data[0]))
+            Lp0 = np.linalg.cholesky(f0c)
     for t in range(T):
         yt = np.asarray(data[t])
         u = np.asarray(u_tape[t])
-        if t == 0:                                        # core.py:315-319
+        if t == 0 and mv:
+            z = normal_ppf(u)
+            X = mvnormal_rvs(f0m, 1.0, Lp0, z) if fk == "guided" else mvnormal_rvs(model.mu0, 1.0, L0, z)
+            rs_flag = False
+        elif t == 0:                                      # core.py:315-319
             loc, scale = model.proposal0(yt) if fk == "guided" else model.px0()
             X = normal_ppf(u.squeeze(), loc, scale)       # state_space_models.py:335-336 / :394-395
             rs_flag = False
         else:                                             # core.py:339-349
             rs_flag = True
             tau = np.argsort(u[:, 0])
-            h_order = np.argsort(X, axis=0)               # hilbert.py:52-54
+            h_order = hilbert_sort(X)                     # hilbert.py:33-58
             su, Ws = u[tau, 0], wgts.W[h_order]
             A = h_order[inverse_cdf(su, Ws) if cdf == "seq" else inverse_cdf_q62(su, Ws)]
             Xp = X[A]
             v = u[tau, 1:].squeeze()
             wgts = Weights()
-            if fk == "guided":
-                loc, scale = model.proposal(Xp, yt)
+            if mv:
+                z = normal_ppf(v)
+                m = np.dot(Xp, model.F.T)                 # kalman.py:342-343
+                if fk == "guided":                        # kalman.py:348-351
+                    pm, pc, _ = kalman_filter_step(model.G, model.covY, m, model.covX, yt)
+                    Lp = np.linalg.cholesky(pc)
+                    X = mvnormal_rvs(pm, 1.0, Lp, z)
+                else:
+                    X = mvnormal_rvs(m, 1.0, LX, z)
             else:
-                loc, scale = model.px(Xp, t) if getattr(model, "time_dependent", False) else model.px(Xp)
-            X = normal_ppf(v, loc, scale)                 # :338-340 / :397-398
-        if fk == "guided":                                # state_space_models.py:380-392
+                if fk == "guided":
+                    loc, scale = model.proposal(Xp, yt)
+                else:
+                    loc, scale = model.px(Xp, t) if getattr(model, "time_dependent", False) else model.px(Xp)
+                X = normal_ppf(v, loc, scale)             # :338-340 / :397-398
+        if mv:
+            lpy = mvnormal_logpdf(yt, np.dot(X, model.G.T), 1.0, LY)  # kalman.py:345-346
+            if fk == "guided":                            # state_space_models.py:380-392
+                if t == 0:
+                    inc = (mvnormal_logpdf(X, model.mu0, 1.0, L0) + lpy
+                           - mvnormal_logpdf(X, f0m, 1.0, Lp0))
+                else:
+                    inc = (mvnormal_logpdf(X, m, 1.0, LX) + lpy - mvnormal_logpdf(X, pm, 1.0, Lp))
+            else:
+                inc = lpy
+        elif fk == "guided":                              # state_space_models.py:380-392
             if t == 0:
                 l0, s0 = model.px0()
                 q0, qs0 = model.proposal0(yt)

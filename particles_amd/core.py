@@ -133,9 +133,6 @@ class SMC:
     def __init__(self, fk=None, N=100, qmc=False, resampling="systematic", ESSrmin=0.5,
                  store_history=False, verbose=False, collect=None, seed=None, n_islands=1,
                  replay=None, use_graph=True, island_offset=0):
-        if qmc and getattr(fk, "du", 1) != 1:
-            raise NotImplementedError("SQMC (qmc=True) is built for univariate states (du = 1): "
-                                      "the Hilbert sort of (N, d) particles is not part of this path")
         self._fk_list = None
         if isinstance(fk, (list, tuple)):        # one Feynman-Kac model per island (SMC^2: one theta each)
             self._fk_list = list(fk)
@@ -423,7 +420,7 @@ class SMC:
     def generate_particles(self):
         if self.qmc:                                               # core.py:315-321
             u = rqmc.sobol(self.N, self.fk.du)
-            self.X = self.fk.Gamma0(u[:, 0])                       # (N,) since du = 1
+            self.X = self.fk.Gamma0(u[:, 0] if self.fk.du == 1 else u)   # u.squeeze(): (N,) if du = 1
         else:
             self.X = self.fk.M0(self.N)
 
@@ -443,7 +440,7 @@ class SMC:
 
     def resample_move_qmc(self):
         """SQMC step (core.py:339-349): always resample; the particles are visited in Hilbert
-        order (= sorted order for du = 1), the first QMC coordinate -- sorted -- drives the
+        order (= sorted order for univariate particles), the first QMC coordinate -- sorted -- drives the
         inverse-CDF choice of ancestors, the others the move Gamma.  Sorts, gathers, inverse CDF
         and the inverse-normal-CDF move are device operators."""
         self.rs_flag = True
@@ -453,7 +450,12 @@ class SMC:
         self.h_order = hilbert.hilbert_sort(self.X)
         self.A = self.h_order[rs.inverse_cdf(u0[tau], self.aux.W[self.h_order])]
         self.Xp = self.X[self.A]
-        v = u[:, 1][tau]                                           # u[tau, 1:].squeeze(), du = 1
+        if self.fk.du == 1:
+            v = u[:, 1][tau]                                       # u[tau, 1:].squeeze()
+        elif isinstance(u, DeviceArray):
+            v = DeviceArray.stack_columns([u[:, 1 + i] for i in range(self.fk.du)])[tau]
+        else:
+            v = u[tau, 1:]
         self.reset_weights()
         self.X = self.fk.Gamma(self.t, self.Xp, v)
 

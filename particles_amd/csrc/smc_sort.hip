@@ -97,6 +97,189 @@ extern "C" int smc_argsort(smc_ctx* ctx, const double* x, int64_t N, int64_t* ou
 #endif
 }
 
+// ---------------------------------------------------------------------------
+// Hilbert sort (hilbert.py:33-58).  Witham's coordinate codec restated per point with
+// integer operations: the coordinates' bits are cut into chunks of d bits (one bit of every
+// coordinate, coordinate 0 highest), most significant chunk first; each chunk is decoded
+// through a Gray code rotated / reflected by the (start, end) corners of the current sub-cube.
+// ---------------------------------------------------------------------------
+__host__ __device__ __forceinline__ i64 hb_gray_encode(i64 bn) { return bn ^ (bn / 2); }      // :198-203
+__host__ __device__ __forceinline__ i64 hb_gray_decode(i64 n)                                  // :206-215
+{
+    i64 sh = 1;
+    for (;;) {
+        const i64 div = n >> sh;
+        n ^= div;
+        if (div <= 1) return n;
+        sh <<= 1;
+    }
+}
+__host__ __device__ __forceinline__ i64 hb_encode_travel(i64 start, i64 end, i64 mask, i64 i)  // :227-236
+{
+    const i64 travel_bit = start ^ end, modulus = mask + 1;
+    const i64 g = hb_gray_encode(i) * (travel_bit * 2);
+    return ((g | (g / modulus)) & mask) ^ start;
+}
+__host__ __device__ __forceinline__ i64 hb_decode_travel(i64 start, i64 end, i64 mask, i64 g)  // :239-244
+{
+    const i64 travel_bit = start ^ end, modulus = mask + 1;
+    const i64 rg = (g ^ start) * (modulus / (travel_bit * 2));
+    return hb_gray_decode((rg | (rg / modulus)) & mask);
+}
+// Hilbert_to_int (hilbert.py:79-91) of one point with d coordinates c[0..d)
+__host__ __device__ inline i64 hb_hilbert_to_int(const i64* c, int d)
+{
+    i64 biggest = 0;
+    for (int k = 0; k < d; ++k) biggest = c[k] > biggest ? c[k] : biggest;
+    int nchunks = 0;                                    // ceil(log2(biggest + 1)), at least 1 (:149-156)
+    while ((biggest >> nchunks) != 0) ++nchunks;
+    if (nchunks < 1) nchunks = 1;
+    const i64 mask = ((i64)1 << d) - 1;
+    i64 start = 0;                                      // initial_start_end (:94-99)
+    int e = (-nchunks - 1) % d;
+    if (e < 0) e += d;                                  // Python's %: 0 <= e < d
+    i64 end = (i64)1 << e;
+    i64 z = 0;
+    for (int j = 0; j < nchunks; ++j) {
+        // coord chunk j: bit (nchunks-1-j) of every coordinate, coordinate 0 highest (transpose_bits)
+        i64 chunk = 0;
+        const int bit = nchunks - 1 - j;
+        for (int k = 0; k < d; ++k) chunk = chunk * 2 + ((c[k] >> bit) & 1);
+        const i64 i = hb_decode_travel(start, end, mask, chunk);
+        // pack_index (:134-140), in int64 that wraps like numba's: from d = 4 on, d * nchunks
+        // exceeds 63 bits for the largest coordinates and the reference's index goes negative
+        z = (i64)(((u64)z << d) + (u64)i);
+        // child_start_end (:287-292)
+        i64 start_i = (i - 1) & ~(i64)1;
+        if (start_i < 0) start_i = 0;
+        i64 end_i = (i + 1) | 1;
+        if (end_i > mask) end_i = mask;
+        const i64 cs = hb_encode_travel(start, end, mask, start_i);
+        const i64 ce = hb_encode_travel(start, end, mask, end_i);
+        start = cs;
+        end = ce;
+    }
+    return z;
+}
+
+#define HB_MAXD 16
+// per-column sums (pass 0: of x; pass 1: of |x - mean|^2), one workgroup per column chunk
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_hb_colsum(const double* x, i64 N, int d, const double* mean, double* part)
+{
+    __shared__ double sm[SMC_SM];
+    const int c = (int)blockIdx.y;
+    double acc = 0.0;
+    for (i64 i = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x; i < N; i += (i64)gridDim.x * SMC_BLOCK) {
+        const double v = x[i * d + c];
+        if (mean) { const double r = v - mean[c]; acc += r * r; }
+        else acc += v;
+    }
+    acc = smc_block_sum(acc, sm);
+    if (threadIdx.x == 0) part[(i64)c * gridDim.x + blockIdx.x] = acc;
+}
+__global__ void k_hb_colfinal(const double* part, int nb, i64 N, int d, int pass, double* stat)
+{
+    const int c = (int)threadIdx.x;
+    if (c >= d) return;
+    double s = 0.0;
+    for (int b = 0; b < nb; ++b) s += part[(i64)c * nb + b];
+    stat[pass * HB_MAXD + c] = pass ? sqrt(s / (double)N) : s / (double)N;     // np.std / np.mean
+}
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_hb_keys(const double* x, i64 N, int d, const double* stat, double maxint, i64* keys)
+{
+    const i64 n = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;
+    if (n >= N) return;
+    i64 c[HB_MAXD];
+    for (int k = 0; k < d; ++k) {
+        const double s = (x[n * d + k] - stat[k]) / stat[HB_MAXD + k];
+        const double xs = 1.0 / (1.0 + exp(-s));                                 // invlogit (:9-10)
+        c[k] = (i64)floor(xs * maxint);                                          // :56-57
+    }
+    keys[n] = hb_hilbert_to_int(c, d);
+}
+
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_hb_index(const i64* xint, i64 N, int d, i64* out)
+{
+    const i64 n = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;
+    if (n >= N) return;
+    i64 c[HB_MAXD];
+    for (int k = 0; k < d; ++k) c[k] = xint[n * d + k];
+    out[n] = hb_hilbert_to_int(c, d);
+}
+
+extern "C" int smc_hilbert_array(smc_ctx* ctx, const int64_t* xint, int64_t N, int32_t d, int64_t* out)
+{
+    SMC_REQUIRE(ctx && xint && out, "null argument");
+    SMC_REQUIRE(N > 0 && d >= 1 && d <= HB_MAXD, "smc_hilbert_array: N > 0, 1 <= d <= 16");
+    SMC_LAUNCH(k_hb_index, dim3((unsigned)((N + SMC_BLOCK - 1) / SMC_BLOCK)), dim3(SMC_BLOCK),
+               ctx->stream, (const i64*)xint, (i64)N, (int)d, (i64*)out);
+    SMC_LAUNCH_CHECK();
+    return SMC_OK;
+}
+
+extern "C" int smc_hilbert_sort(smc_ctx* ctx, const double* x, int64_t N, int32_t d, int64_t* out,
+                                int64_t* keys_out)
+{
+    SMC_REQUIRE(ctx && x && out, "null argument");
+    SMC_REQUIRE(N > 0 && N < ((int64_t)1 << 31), "N must be in [1, 2^31)");
+    SMC_REQUIRE(d >= 2 && d <= HB_MAXD, "smc_hilbert_sort: 2 <= d <= 16 (d = 1: smc_argsort)");
+    hipStream_t st = ctx->stream;
+    SMC_HIP_CHECK(hipSetDevice(ctx->device));
+    const int nb = (int)((N + 4 * SMC_BLOCK - 1) / (4 * SMC_BLOCK) > 256 ? 256
+                                                                          : (N + 4 * SMC_BLOCK - 1) / (4 * SMC_BLOCK));
+    const size_t nbytes = (size_t)N * 8;
+    size_t tb = 0;
+#ifndef SMC_EMULATE
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (const i64*)nullptr, (i64*)nullptr,
+                                             (const i64*)nullptr, (i64*)nullptr, (int)N, 0, 64, st);
+#endif
+    void* buf = nullptr;
+    const size_t small = (size_t)(HB_MAXD * nb + 2 * HB_MAXD) * 8;
+    hipError_t e = hipMalloc(&buf, 3 * nbytes + small + (tb ? tb : 8));
+    if (e != hipSuccess) {
+        smc_set_error("smc_hilbert_sort: %zu bytes: %s", 3 * nbytes + small + tb, hipGetErrorString(e));
+        return SMC_ERR_NOMEM;
+    }
+    i64* keys = (i64*)buf;
+    i64* ks = (i64*)((char*)buf + nbytes);
+    i64* idx = (i64*)((char*)buf + 2 * nbytes);
+    double* part = (double*)((char*)buf + 3 * nbytes);
+    double* stat = part + (size_t)HB_MAXD * nb;
+    void* tmp = (char*)buf + 3 * nbytes + small;
+    const double maxint = floor(pow(2.0, 62.0 / (double)d));                     // :55
+    SMC_LAUNCH(k_hb_colsum, dim3(nb, d), dim3(SMC_BLOCK), st, x, (i64)N, (int)d, (const double*)nullptr, part);
+    SMC_LAUNCH(k_hb_colfinal, dim3(1), dim3(64), st, (const double*)part, nb, (i64)N, (int)d, 0, stat);
+    SMC_LAUNCH(k_hb_colsum, dim3(nb, d), dim3(SMC_BLOCK), st, x, (i64)N, (int)d, (const double*)stat, part);
+    SMC_LAUNCH(k_hb_colfinal, dim3(1), dim3(64), st, (const double*)part, nb, (i64)N, (int)d, 1, stat);
+    SMC_LAUNCH(k_hb_keys, dim3((unsigned)((N + SMC_BLOCK - 1) / SMC_BLOCK)), dim3(SMC_BLOCK), st, x,
+               (i64)N, (int)d, (const double*)stat, maxint, keys);
+    int rc = SMC_OK;
+#ifdef SMC_EMULATE
+    {
+        (void)ks; (void)idx; (void)tmp;
+        std::vector<i64> o((size_t)N);
+        std::iota(o.begin(), o.end(), 0);
+        std::stable_sort(o.begin(), o.end(), [&](i64 a, i64 b) { return keys[a] < keys[b]; });
+        for (i64 i = 0; i < N; ++i) out[i] = o[(size_t)i];
+    }
+#else
+    SMC_LAUNCH(k_iota_i64, dim3((unsigned)((N + SMC_BLOCK - 1) / SMC_BLOCK)), dim3(SMC_BLOCK), st,
+               (i64)N, idx);
+    // signed keys: np.argsort of the (possibly wrapped) int64 indices
+    if (hipcub::DeviceRadixSort::SortPairs(tmp, tb, (const i64*)keys, (i64*)ks, (const i64*)idx,
+                                           (i64*)out, (int)N, 0, 64, st) != hipSuccess) rc = SMC_ERR_HIP;
+#endif
+    if (rc == SMC_OK && keys_out &&
+        hipMemcpyAsync(keys_out, keys, nbytes, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = SMC_ERR_HIP;
+    if (hipStreamSynchronize(st) != hipSuccess) rc = SMC_ERR_HIP;
+    if (rc == SMC_ERR_HIP) smc_set_error("smc_hilbert_sort: HIP error: %s", hipGetErrorString(hipGetLastError()));
+    (void)hipFree(buf);
+    return rc;
+}
+
 extern "C" int smc_wquantiles(smc_ctx* ctx, const double* W, const double* x, int64_t N, int64_t d,
                               const double* alphas_host, int k, double* out_host)
 {

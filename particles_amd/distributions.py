@@ -155,6 +155,9 @@ class IndepProd(ProbDist):
     def rvs(self, size=None):
         return np.stack([d.rvs(size=size) for d in self.dists], axis=1)          # :1105-1106
 
+    def ppf(self, u):
+        return np.stack([d.ppf(u[..., i]) for i, d in enumerate(self.dists)], axis=1)   # :1108-1109
+
 
 class MvNormal(ProbDist):
     """Multivariate Normal distribution (distributions.py:888-1009).
@@ -211,6 +214,20 @@ class MvNormal(ProbDist):
                                 zd.ptr if zd is not None else None, _lib.next_counter(),
                                 N, self.dim, out.ptr))
         return out if (dev or isinstance(z, DeviceArray) or _lib.RESIDENT[0]) else out.get()
+
+    def ppf(self, u):
+        """linear_transform(norm.ppf(u)) for u (N, du) (:970-981); du = dim only (the partly
+        degenerate case du < dim of the reference is not built)."""
+        ud, host = _lib.as_device(u)
+        N, du = ud.shape
+        if du != self.dim:
+            raise NotImplementedError("MvNormal.ppf: u must have dim = %d columns" % self.dim)
+        z = DeviceArray((N, du), np.float64, ud.ctx)
+        zero = DeviceArray.from_numpy(np.array([0.0, 1.0]), context=ud.ctx)
+        check(lib().smc_normal_ppf(ud.ctx.h, ud.ptr, 1, zero.ptr, 0, _lib.c_vp(zero.ptr.value + 8), 0,
+                                   N * du, z.ptr))
+        x = self.rvs(size=N, z=z)
+        return x if (not host or _lib.RESIDENT[0] or isinstance(self.loc, DeviceArray)) else x.get()
 
     def logpdf(self, x):
         """:949-959."""

@@ -137,6 +137,26 @@ def main():
     out["sqmc_guided"] = run_sqmc_case(kalman.LinearGauss(rho=0.9, sigmaX=1.0, sigmaY=0.3),
                                        ssm.GuidedPF, 25, 256)
 
+    out["sqmc_mv2"] = run_sqmc_case(kalman.MVLinearGauss_Guarniero_etal(alpha=0.4, dx=2),
+                                    ssm.Bootstrap, 12, 256)
+    out["sqmc_mv3_guided"] = run_sqmc_case(kalman.MVLinearGauss_Guarniero_etal(alpha=0.4, dx=3),
+                                           ssm.GuidedPF, 8, 128)
+    # --- the Hilbert codec and sort on their own (hilbert.py:13-58)
+    from particles import hilbert
+    rng = np.random.default_rng(17)
+    hb = {}
+    for d in (2, 3, 5, 8):
+        maxint = np.floor(2 ** (62 / d))
+        xint = np.floor(rng.random((200, d)) * maxint).astype(np.int64)
+        xint[:6] = [[0] * d, [1] + [0] * (d - 1), [0] * (d - 1) + [1], [int(maxint) - 1] * d,
+                    [3] * d, [2 ** 10] + [5] * (d - 1)]
+        x = rng.standard_normal((300, d)) * (1.0 + np.arange(d))
+        hb["xint%d" % d] = xint
+        hb["h%d" % d] = hilbert.hilbert_array(xint)
+        hb["x%d" % d] = x
+        hb["order%d" % d] = hilbert.hilbert_sort(x)
+    out["hilbert"] = hb
+
     # --- auxiliary particle filter (core.py:299-313), Pitt & Shephard's StochVol proposal
     out["sv_apf"] = run_case(ssm.StochVol(), ssm.AuxiliaryPF, 30, 500, "systematic", 0.5)
     out["sv_guided"] = run_case(ssm.StochVol(), ssm.GuidedPF, 30, 500, "systematic", 0.5)

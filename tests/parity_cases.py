@@ -1038,7 +1038,9 @@ def check_sqmc(golden, monkeypatch):
     from particles_amd import rqmc, hilbert
     cases = [("sqmc_toy", lambda: kalman.LinearGauss(rho=0.9, sigmaX=1.0, sigmaY=0.5), ssm.Bootstrap),
              ("sqmc_sv", lambda: ssm.StochVol(), ssm.Bootstrap),
-             ("sqmc_guided", lambda: kalman.LinearGauss(rho=0.9, sigmaX=1.0, sigmaY=0.3), ssm.GuidedPF)]
+             ("sqmc_guided", lambda: kalman.LinearGauss(rho=0.9, sigmaX=1.0, sigmaY=0.3), ssm.GuidedPF),
+             ("sqmc_mv2", lambda: kalman.MVLinearGauss_Guarniero_etal(alpha=0.4, dx=2), ssm.Bootstrap),
+             ("sqmc_mv3_guided", lambda: kalman.MVLinearGauss_Guarniero_etal(alpha=0.4, dx=3), ssm.GuidedPF)]
     for case, mk, cls in cases:
         g = golden(case)
         y = list(g["y"])
@@ -1067,6 +1069,17 @@ def check_sqmc(golden, monkeypatch):
             finally:
                 pa.set_resident(False)
                 monkeypatch.undo()
+    # ---- the Hilbert codec and sort against the reference's (hilbert.py:13-58)
+    g = golden("hilbert")
+    for d in (2, 3, 5, 8):
+        assert np.array_equal(hilbert.hilbert_array(g["xint%d" % d]), g["h%d" % d])     # integers: exact
+        order = hilbert.hilbert_sort(g["x%d" % d])
+        assert sorted(order) == list(range(len(order)))
+        assert np.mean(order == g["order%d" % d]) >= 0.97      # the grid cell of a point may move by
+        #                                                        one where exp / mean / std differ by an ulp
+    xd = pa.DeviceArray.from_numpy(g["x3"])
+    od = hilbert.hilbert_sort(xd)
+    assert isinstance(od, pa.DeviceArray) and np.array_equal(od.get(), hilbert.hilbert_sort(g["x3"]))
     # ---- the operators
     from scipy.stats import qmc
     from scipy import special

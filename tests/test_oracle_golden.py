@@ -32,7 +32,18 @@ CASES = ([("toy_%s" % s, "toy", "bootstrap") for s in ("systematic", "stratified
 
 SQMC_CASES = [("sqmc_toy", lambda: orc.LinGauss(rho=0.9, sigmaX=1.0, sigmaY=0.5), "bootstrap"),
               ("sqmc_sv", lambda: orc.StochVol(), "bootstrap"),
-              ("sqmc_guided", lambda: orc.LinGauss(rho=0.9, sigmaX=1.0, sigmaY=0.3), "guided")]
+              ("sqmc_guided", lambda: orc.LinGauss(rho=0.9, sigmaX=1.0, sigmaY=0.3), "guided"),
+              ("sqmc_mv2", lambda: orc.Guarniero(alpha=0.4, dx=2), "bootstrap"),
+              ("sqmc_mv3_guided", lambda: orc.Guarniero(alpha=0.4, dx=3), "guided")]
+
+
+def test_hilbert_vs_reference(golden):
+    """hilbert_array / hilbert_sort (hilbert.py:13-58), int64 wrap-around from d = 4 included."""
+    g = golden("hilbert")
+    for d in (2, 3, 5, 8):
+        assert np.array_equal(orc.hilbert_array(g["xint%d" % d]), g["h%d" % d])
+        assert np.array_equal(orc.hilbert_sort(g["x%d" % d]), g["order%d" % d])
+    assert (g["h5"] < 0).any() and (g["h8"] < 0).any()
 
 
 @pytest.mark.parametrize("case,mk,fk", SQMC_CASES)
