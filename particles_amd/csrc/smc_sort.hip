@@ -75,11 +75,8 @@ extern "C" int smc_argsort(smc_ctx* ctx, const double* x, int64_t N, int64_t* ou
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, x, (double*)nullptr, (const i64*)nullptr,
                                              (i64*)nullptr, (int)N, 0, 64, st);
     const size_t nb = (size_t)N * 8;
-    hipError_t e = hipMalloc(&buf, 2 * nb + (tb ? tb : 8));
-    if (e != hipSuccess) {
-        smc_set_error("smc_argsort: %zu bytes: %s", 2 * nb + tb, hipGetErrorString(e));
-        return SMC_ERR_NOMEM;
-    }
+    // scratch from the context's pool: recycled in stream order, no sync, no hipMalloc per call
+    if (smc_malloc(ctx, 2 * nb + (tb ? tb : 8), &buf) != SMC_OK) return SMC_ERR_NOMEM;
     double* ks = (double*)buf;
     i64* idx = (i64*)((char*)buf + nb);
     void* tmp = (char*)buf + 2 * nb;
@@ -87,12 +84,11 @@ extern "C" int smc_argsort(smc_ctx* ctx, const double* x, int64_t N, int64_t* ou
                (i64)N, idx);
     int rc = SMC_OK;
     if (hipcub::DeviceRadixSort::SortPairs(tmp, tb, x, ks, (const i64*)idx, (i64*)out, (int)N, 0, 64,
-                                           st) != hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess) {
+                                           st) != hipSuccess) {
         smc_set_error("smc_argsort: HIP error: %s", hipGetErrorString(hipGetLastError()));
         rc = SMC_ERR_HIP;
     }
-    (void)hipFree(buf);
+    (void)smc_free(ctx, buf);
     return rc;
 #endif
 }
@@ -238,11 +234,7 @@ extern "C" int smc_hilbert_sort(smc_ctx* ctx, const double* x, int64_t N, int32_
 #endif
     void* buf = nullptr;
     const size_t small = (size_t)(HB_MAXD * nb + 2 * HB_MAXD) * 8;
-    hipError_t e = hipMalloc(&buf, 3 * nbytes + small + (tb ? tb : 8));
-    if (e != hipSuccess) {
-        smc_set_error("smc_hilbert_sort: %zu bytes: %s", 3 * nbytes + small + tb, hipGetErrorString(e));
-        return SMC_ERR_NOMEM;
-    }
+    if (smc_malloc(ctx, 3 * nbytes + small + (tb ? tb : 8), &buf) != SMC_OK) return SMC_ERR_NOMEM;
     i64* keys = (i64*)buf;
     i64* ks = (i64*)((char*)buf + nbytes);
     i64* idx = (i64*)((char*)buf + 2 * nbytes);
@@ -274,9 +266,11 @@ extern "C" int smc_hilbert_sort(smc_ctx* ctx, const double* x, int64_t N, int32_
 #endif
     if (rc == SMC_OK && keys_out &&
         hipMemcpyAsync(keys_out, keys, nbytes, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = SMC_ERR_HIP;
+#ifdef SMC_EMULATE
     if (hipStreamSynchronize(st) != hipSuccess) rc = SMC_ERR_HIP;
+#endif
     if (rc == SMC_ERR_HIP) smc_set_error("smc_hilbert_sort: HIP error: %s", hipGetErrorString(hipGetLastError()));
-    (void)hipFree(buf);
+    (void)smc_free(ctx, buf);
     return rc;
 }
 
