@@ -15,9 +15,10 @@ the per-rank log-evidences are gathered with RCCL (smc_comm_*) inside the timed
 region.  Inputs are resident in HBM before the timed region starts.
 
 Rank 0 prints ONE JSON line (see README / task contract), including
-  roofline      -- dominant kernel (k_propagate) algorithmic bytes per launch over its
-                   average duration measured with HIP events on the filter's
-                   stream, against the 8 TB/s HBM peak of MI355X;
+  roofline      -- the longer of the step's two kernels (resampling: k_ancestors2 /
+                   k_ancestors; propagate: k_propagate): algorithmic bytes per launch over
+                   its average duration measured with HIP events on the filter's stream,
+                   against the 8 TB/s HBM peak of MI355X; both kernels under per_kernel;
   cpu_baseline  -- the NumPy restatement of the reference path (oracle/, "port")
                    timed on this host's cores on a bounded sample (N=1, rank 0).
 """
@@ -219,28 +220,42 @@ def main():
         pf.step_async(min(K, 4000))
         _lib.check(_lib.lib().smc_filter_kernel_ms(pf._f, ctypes.byref(mv), ctypes.byref(pr),
                                                    ctypes.byref(ns)))
+        desc = ctypes.create_string_buffer(256)
+        _lib.check(_lib.lib().smc_filter_describe(pf._f, desc, 256))
+        kernels = desc.value.decode()
         del pf
         if rank == 0 and ns.value:
-            ach = bytes_move * N * a.islands / (mv.value * 1e-3) / 1e9
+            # the step is [resampling kernel(s)] + [propagate kernel]; the roofline object describes
+            # whichever takes longer, the other one is listed beside it
+            rs_name = "+".join(k for k in kernels.split("+") if not k.startswith("k_propagate"))
+            mv_name = [k for k in kernels.split("+") if k.startswith("k_propagate")][0]
+            rs_bytes = (BYTES_PREPARE + (8.0 if "k_prepare" in kernels else 0.0)) * N * a.islands
+            mv_bytes = bytes_move * N * a.islands
+            rs_ms = max(out["ms_per_step"] - mv.value, 0.0)
+            per = {mv_name: {"ms": mv.value, "launch_bytes": mv_bytes,
+                             "achieved": mv_bytes / (mv.value * 1e-3) / 1e9},
+                   rs_name: {"ms": rs_ms, "launch_bytes": rs_bytes,
+                             "achieved": rs_bytes / (rs_ms * 1e-3) / 1e9 if rs_ms > 0 else None}}
+            dom = mv_name if mv.value >= rs_ms else rs_name
+            ach = per[dom]["achieved"]
             out["roofline"] = {
                 "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": None,
                 "traffic_source": None,
-                "kernel": "k_propagate", "kernel_ms": mv.value,
-                "launch_bytes": bytes_move * N * a.islands,
+                "kernel": dom, "kernel_ms": per[dom]["ms"],
+                "launch_bytes": per[dom]["launch_bytes"],
                 "samples": ns.value,
-                "prepare_ms": max(out["ms_per_step"] - mv.value, 0.0),
-                "prepare_achieved": (BYTES_PREPARE if ((N + 1023) // 1024) * a.islands <= 2048
-                                     else BYTES_PREPARE + 8.0) * N * a.islands
-                / ((out["ms_per_step"] - mv.value) * 1e-3) / 1e9
-                if out["ms_per_step"] > mv.value else None,
+                "step_kernels": kernels, "per_kernel": per,
+                "step_frac": out["step_achieved_GBs"] / HBM_PEAK_GBS,
                 "note": "algorithmic bytes in SURVEY 8d's accounting (int64 ancestors; they are stored as "
                         "32-bit words, so the kernels physically move 4 B less per particle each). "
                         "Per particle-step: k_propagate 32 B (read A, gather X; write X, lw), "
-                        "k_ancestors 16 B (read lw, write A; + 8 B for k_prepare's pass over lw beyond "
-                        "2048 workgroups per launch). kernel_ms = (HIP-event interval around whole steps) - "
-                        "(interval around the resampling kernels only), alternating steps, so the "
-                        "fixed ~4 us of an event interval cancels; prepare_ms = ms_per_step - kernel_ms",
+                        "k_ancestors / k_ancestors2 16 B (read lw, write A; + 8 B for k_prepare's pass over "
+                        "lw beyond 2048 workgroups per launch). The propagate kernel's ms = (HIP-event "
+                        "interval around whole steps) - (interval around the resampling kernels only), "
+                        "alternating steps, so the fixed ~4 us of an event interval cancels; the resampling "
+                        "kernels' ms = ms_per_step - that. `kernel` is the one that takes longer; "
+                        "step_frac = 56 B x N / ms_per_step over the HBM peak (the whole step)",
             }
             if a.workload == "c4":
                 # GEMM-shaped kernel: priced against the dense fp64 matrix peak (MI355X spec
@@ -250,9 +265,10 @@ def main():
                 tf = flop / (mv.value * 1e-3) / 1e12
                 out["roofline"].update({
                     "bound": "mfma", "achieved": tf, "peak": 78.6, "unit": "TFLOP/s",
-                    "frac": tf / 78.6, "kernel": "k_propagate_mv", "launch_flop": flop,
-                    "hbm_achieved_GBs": ach})
-            tr = measured_traffic(a, "k_propagate")
+                    "frac": tf / 78.6, "kernel": "k_propagate_mv", "kernel_ms": mv.value,
+                    "launch_bytes": mv_bytes, "launch_flop": flop,
+                    "hbm_achieved_GBs": per[mv_name]["achieved"]})
+            tr = measured_traffic(a, out["roofline"]["kernel"].split("+")[-1].split("<")[0])
             if tr:
                 out["roofline"]["traffic"], out["roofline"]["traffic_source"] = tr
     if rank == 0 and world == 1 and not a.no_cpu_baseline and a.workload == "c2":

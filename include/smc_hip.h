@@ -346,6 +346,10 @@ int smc_filter_info(smc_filter* f, double* bytes_per_particle_step,
  * fixed cost of an event interval cancels), prepare_ms_avg the raw interval of
  * the resampling kernels (it still contains that fixed cost, ~4 us). */
 int smc_filter_profile(smc_filter* f, int enable);
+/* the kernels one time step of this filter launches, e.g. "k_ancestors2+k_propagate"
+ * (two-level CDF), "k_ancestors<fused>+k_propagate", "k_prepare+k_ancestors+k_propagate",
+ * "k_filter_small" (whole T-loop in one launch), "...+k_propagate_mv"; NUL-terminated into out. */
+int smc_filter_describe(smc_filter* f, char* out, size_t n);
 int smc_filter_kernel_ms(smc_filter* f, double* move_ms_avg,
                          double* prepare_ms_avg, int64_t* n_samples);
 

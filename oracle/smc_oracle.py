@@ -302,6 +302,53 @@ def inverse_cdf_q62(su, W):
     return np.minimum(A, W.shape[0] - 1)
 
 
+def inverse_cdf_2level(su, lw, tile=1024, P=50):
+    """The two-level exact CDF of the fused step loop for N = 2^k >= 2 tiles
+    (particles_amd/csrc/smc_filter_kernels.h, k_ancestors2).  Per aligned tile b of `tile`
+    log-weights: m_b = max, S_b = sum exp(lw - m_b); globally m = max m_b, s = sum S_b exp(m_b - m).
+    Tile shares of the 2^62 scale Q_b = rint(S_b exp(m_b - m) / s 2^62), G_b their exclusive sums;
+    inside a tile the integer CDF C_j of q_i = rint(exp(lw_i - m_b) 2^P), total t_b.  Offspring n
+    with threshold T_n = ceil(su_n 2^62) in (G_b, G_b + Q_b] takes the first parent j of tile b with
+    (T_n - G_b) t_b <= C_j Q_b -- exact rational comparisons (Python integers here); thresholds
+    beyond the last share go to the last particle, as resampling.py:500-509 would clamp."""
+    lw = np.asarray(lw, dtype=np.float64)
+    N = lw.shape[0]
+    nt = N // tile
+    assert nt * tile == N and nt >= 1
+    L = lw.reshape(nt, tile)
+    mb = L.max(axis=1)
+    with np.errstate(invalid="ignore"):
+        E = np.where(np.isneginf(L), 0.0, np.exp(L - mb[:, None]))
+    Sb = E.sum(axis=1)
+    m = mb.max()
+    eb = np.where(np.isneginf(mb), 0.0, np.exp(mb - m))
+    s = float(np.sum(Sb * eb))
+    rs = 1.0 / s
+    Q = [int(np.rint((Sb[b] * eb[b]) * rs * Q62)) for b in range(nt)]
+    G = np.concatenate([[0], np.cumsum(np.array(Q, dtype=object))])
+    q = np.rint(E * float(2 ** P)).astype(np.int64)
+    C = np.cumsum(q, axis=1)                                  # inclusive, exact (< 2^63)
+    T = [int(v) for v in q62_threshold(su)]
+    A = np.empty(len(T), dtype=np.int64)
+    b = 0
+    for n, Tn in enumerate(T):                                # su sorted: one sweep over the tiles
+        while b < nt - 1 and Tn > G[b + 1]:
+            b += 1
+        if Tn > G[nt]:
+            A[n] = N - 1
+            continue
+        tau, tb, Qb = Tn - int(G[b]), int(C[b, -1]), Q[b]
+        lo, hi = 0, tile - 1                                  # first j with tau * t_b <= C_j * Q_b
+        while lo < hi:
+            mid = (lo + hi) // 2
+            if tau * tb <= int(C[b, mid]) * Qb:
+                hi = mid
+            else:
+                lo = mid + 1
+        A[n] = b * tile + lo
+    return A
+
+
 def audit_near_ties(su, W, A_a, A_b):
     """Certify that every place two ancestor vectors differ is a near-tie.
 
@@ -675,7 +722,12 @@ def run_filter(model, data, N, scheme="systematic", ESSrmin=0.5, fk="bootstrap",
             if rs_flag:
                 u = rng.rand(N_UNIFORMS[scheme](N))
                 su = sorted_uniforms(scheme, N, u)
-                A = inverse_cdf(su, wgts.W) if cdf == "seq" else inverse_cdf_q62(su, wgts.W)
+                if cdf == "seq":
+                    A = inverse_cdf(su, wgts.W)
+                elif cdf == "2level":
+                    A = inverse_cdf_2level(su, wgts.lw)
+                else:
+                    A = inverse_cdf_q62(su, wgts.W)
                 Xp = X[A]                                 # core.py:332
                 wgts = Weights()                          # core.py:299-305
             else:

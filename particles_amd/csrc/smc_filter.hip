@@ -20,6 +20,7 @@ struct smc_filter {
     void* slab;            // one allocation holding every device array
     bool use_graph;
     bool fused;            // k_ancestors<true> (no k_prepare launch)
+    bool two_level;        // k_ancestors2 + tail-free k_propagate (two-level CDF, no intra-launch exchange)
     i64 perm_t;            // t_host at the last smc_filter_permute_islands (A / Xp undefined there)
     hipGraphExec_t gexec;
     int graph_steps;
@@ -55,7 +56,11 @@ static void launch_propagate(smc_filter* f)
     }
 #define P_CASE(KINDV, FKV)                                                                    \
     if (f->kind == KINDV && f->fk == FKV) {                                                   \
-        if (f->a.par >= 0)                                                                    \
+        if (f->two_level && f->a.par >= 0)                                                    \
+            SMC_LAUNCH((k_propagate<KINDV, FKV, F_OPT, true, false>), grid, dim3(SMC_BLOCK), st, f->a);  \
+        else if (f->two_level)                                                                \
+            SMC_LAUNCH((k_propagate<KINDV, FKV, F_OPT, false, false>), grid, dim3(SMC_BLOCK), st, f->a); \
+        else if (f->a.par >= 0)                                                               \
             SMC_LAUNCH((k_propagate<KINDV, FKV, F_OPT, true>), grid, dim3(SMC_BLOCK), st, f->a);  \
         else                                                                                  \
             SMC_LAUNCH((k_propagate<KINDV, FKV, F_OPT, false>), grid, dim3(SMC_BLOCK), st, f->a); \
@@ -81,6 +86,14 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t)
     hipStream_t st = f->ctx->stream;
     const dim3 grid(f->a.ntiles, f->a.n_islands);
     if (k_prof >= 0) (void)hipEventRecord(f->ev[3 * k_prof], st);
+    if (f->two_level) {
+        if (f->a.par >= 0) SMC_LAUNCH((k_ancestors2<true>), grid, dim3(SMC_BLOCK), st, f->a);
+        else SMC_LAUNCH((k_ancestors2<false>), grid, dim3(SMC_BLOCK), st, f->a);
+        if (k_prof >= 0 && (k_prof & 1)) (void)hipEventRecord(f->ev[3 * k_prof + 1], st);
+        launch_propagate(f);
+        if (k_prof >= 0) (void)hipEventRecord(f->ev[3 * k_prof + 2], st);
+        return;
+    }
     const bool fused = f->fused;
     if (!fused) SMC_LAUNCH(k_prepare, grid, dim3(SMC_BLOCK), st, f->a);
     if (f->a.scheme == SMC_MULTINOMIAL && !f->a.ut) {
@@ -218,6 +231,13 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     const size_t oCtl = carve(M * 2 * F_CNT_WORDS * sizeof(unsigned));
     const size_t oSpart = carve(M * 96 * 8);
     const size_t oInfo = carve(M * INFO_STRIDE * 8);
+    const size_t oInfo2 = carve(M * INFO_STRIDE * 8);
+    // two-level CDF: closed-form offspring counts (N = 2^k, systematic / stratified), at most
+    // 1024 tiles per island (4 partials per thread), at least 2 (below, the one-workgroup filter)
+    f->two_level = !mv && !o->moments && a.log2N >= 0 && a.ntiles >= 2 && a.ntiles <= 1024 &&
+                   (f->fused || getenv("SMC_TWO_LEVEL")) &&        // larger grids: k_prepare is as fast
+                   (o->scheme == SMC_SYSTEMATIC || o->scheme == SMC_STRATIFIED) &&
+                   !getenv("SMC_FLAT_CDF") && !getenv("SMC_FORCE_FUSED") && !getenv("SMC_FORCE_UNFUSED");
     const size_t oSu = carve(need_su ? M * N * 8 : 8);
     const size_t oE = carve(need_su ? M * a.ntiles1 * 8 : 8);
     const size_t oTmp = carve(N * dxm * 8);
@@ -248,6 +268,8 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     a.cnt = (unsigned*)(base + oCtl);
     a.spart = (double*)(base + oSpart);
     a.info = (double*)(base + oInfo);
+    a.info2 = (double*)(base + oInfo2);
+    a.exact_counts = getenv("SMC_EXACT_COUNTS") ? 1 : 0;
     a.su = (double*)(base + oSu);
     a.E = (u64*)(base + oE);
     f->tmp = (double*)(base + oTmp);
@@ -267,6 +289,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
             h[i * INFO_STRIDE + 5] = model->aux_host ? model->aux_host[0] : 0.0;
         }
         SMC_HIP_CHECK(hipMemcpyAsync(a.info, h.data(), h.size() * 8, hipMemcpyHostToDevice, st));
+        SMC_HIP_CHECK(hipMemsetAsync(a.info2, 0, M * INFO_STRIDE * 8, st));
         SMC_HIP_CHECK(hipStreamSynchronize(st));
     }
     SMC_HIP_CHECK(hipMemsetAsync(a.A, 0, M * N * 4, st));
@@ -408,6 +431,8 @@ int smc_filter_step(smc_filter* f, int64_t nsteps)
         if (f->prof && f->prof_n < PROF_MAX) kp = f->prof_n++;
         enqueue_step(f, kp, f->t_host + done);
     }
+    if (f->two_level && todo > 0)            // summary row of the last step (see k_flush2)
+        SMC_LAUNCH(k_flush2, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
     SMC_LAUNCH_CHECK();
     f->t_host += todo;
     return SMC_OK;
@@ -557,7 +582,8 @@ int smc_filter_permute_islands(smc_filter* f, const int64_t* src_host)
     const int dx = f->a.dx;
     const size_t bx = (size_t)N * dx * 8, bl = (size_t)N * 8, bs = (size_t)(T + 1) * SUMM_STRIDE * 8,
                  bi = INFO_STRIDE * 8, bp = PARAM_STRIDE * 8;
-    const size_t per = bx + bl + bs + bi + bp;
+    const size_t bq = f->two_level ? (size_t)f->a.nparts * 8 : 0;      // three partial arrays + info2
+    const size_t per = bx + bl + bs + bi + bp + 3 * bq + bi;
     char* tmp = nullptr;
     hipError_t e = hipMalloc((void**)&tmp, per * M);
     if (e != hipSuccess) {
@@ -579,6 +605,13 @@ int smc_filter_permute_islands(smc_filter* f, const int64_t* src_host)
         cp(o + bx + bl, f->a.summ + s_ * (T + 1) * SUMM_STRIDE, bs);
         cp(o + bx + bl + bs, f->a.info + s_ * INFO_STRIDE, bi);
         if (has_params) cp(o + bx + bl + bs + bi, f->a.params + s_ * PARAM_STRIDE, bp);
+        if (bq) {
+            char* q = o + bx + bl + bs + bi + bp;
+            cp(q, f->a.pm + s_ * f->a.nparts, bq);
+            cp(q + bq, f->a.ps + s_ * f->a.nparts, bq);
+            cp(q + 2 * bq, f->a.pss + s_ * f->a.nparts, bq);
+            cp(q + 3 * bq, f->a.info2 + s_ * INFO_STRIDE, bi);
+        }
     }
     for (int i = 0; i < M; ++i) {                                   // and back, slot by slot
         const char* o = tmp + per * i;
@@ -587,6 +620,13 @@ int smc_filter_permute_islands(smc_filter* f, const int64_t* src_host)
         cp(f->a.summ + (size_t)i * (T + 1) * SUMM_STRIDE, o + bx + bl, bs);
         cp(f->a.info + (size_t)i * INFO_STRIDE, o + bx + bl + bs, bi);
         if (has_params) cp((void*)(f->a.params + (size_t)i * PARAM_STRIDE), o + bx + bl + bs + bi, bp);
+        if (bq) {
+            const char* q = o + bx + bl + bs + bi + bp;
+            cp(f->a.pm + (size_t)i * f->a.nparts, q, bq);
+            cp(f->a.ps + (size_t)i * f->a.nparts, q + bq, bq);
+            cp(f->a.pss + (size_t)i * f->a.nparts, q + 2 * bq, bq);
+            cp(f->a.info2 + (size_t)i * INFO_STRIDE, q + 3 * bq, bi);
+        }
     }
     if (rc == hipSuccess) rc = hipStreamSynchronize(st);
     (void)hipFree(tmp);
@@ -607,7 +647,8 @@ int smc_filter_copy_islands(smc_filter* dst, smc_filter* src, const unsigned cha
         return SMC_ERR_STATE;
     }
     SMC_REQUIRE(a.N == b.N && a.T == b.T && a.n_islands == b.n_islands && a.dx == b.dx &&
-                    dst->kind == src->kind && dst->fk == src->fk && dst->t_host == src->t_host,
+                    dst->kind == src->kind && dst->fk == src->fk && dst->t_host == src->t_host &&
+                    dst->two_level == src->two_level,
                 "the two filters must have the same shape, model kind and time index");
     const i64 N = a.N, T = a.T, t = dst->t_host;
     if (t == 0) return SMC_OK;
@@ -626,6 +667,13 @@ int smc_filter_copy_islands(smc_filter* dst, smc_filter* src, const unsigned cha
         if (dst->kind != SMC_MODEL_MVLINGAUSS)
             cp((void*)(a.params + (size_t)i * PARAM_STRIDE), b.params + (size_t)i * PARAM_STRIDE,
                PARAM_STRIDE * 8);
+        if (dst->two_level) {
+            const size_t bq = (size_t)a.nparts * 8, oq = (size_t)i * a.nparts;
+            cp(a.pm + oq, b.pm + oq, bq);
+            cp(a.ps + oq, b.ps + oq, bq);
+            cp(a.pss + oq, b.pss + oq, bq);
+            cp(a.info2 + (size_t)i * INFO_STRIDE, b.info2 + (size_t)i * INFO_STRIDE, INFO_STRIDE * 8);
+        }
     }
     if (rc == hipSuccess) rc = hipStreamSynchronize(st);
     SMC_HIP_CHECK(rc);
@@ -747,6 +795,24 @@ int smc_filter_profile(smc_filter* f, int enable)
         f->ev.resize(3 * PROF_MAX);
         for (auto& e : f->ev) SMC_HIP_CHECK(hipEventCreate(&e));
     }
+    return SMC_OK;
+}
+
+int smc_filter_describe(smc_filter* f, char* out, size_t n)
+{
+    SMC_REQUIRE(f && out && n > 0, "null argument");
+    const bool mv = f->kind == SMC_MODEL_MVLINGAUSS;
+    std::string s;
+    if (small_filter_ok(f)) s = "k_filter_small";
+    else {
+        if (f->two_level) s = "k_ancestors2";
+        else if (f->fused) s = "k_ancestors<fused>";
+        else s = "k_prepare+k_ancestors";
+        if (f->a.scheme == SMC_MULTINOMIAL && !f->a.ut) s = "k_f_spacing_sums+k_f_spacing_write+" + s;
+        s += mv ? "+k_propagate_mv" : "+k_propagate";
+        if (f->a.mom) s += "+k_f_moments_partials+k_f_moments_final";
+    }
+    snprintf(out, n, "%s", s.c_str());
     return SMC_OK;
 }
 

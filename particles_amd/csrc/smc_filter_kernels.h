@@ -78,6 +78,9 @@ struct FArgs {
     int nmb;
     const double* aux;     // (T,) per-step scalar of the transition (GORDON: d cos(e (t-1))) or null
     double* info;          // (n_islands, INFO_STRIDE) record of the step being run
+    int exact_counts;      // two-level path, tests: always form c Q_b / t_b exactly (no fp64 band shortcut)
+    double* info2;         // two-level path: (n_islands, INFO_STRIDE) [0] = t for k_ancestors2 (written by
+                           // k_propagate's workgroup 0; `info` then is written by k_ancestors2's)
     const double* zt;      // replay normals (T, n_islands, N) or null
     const double* ut;      // replay uniforms (T, n_islands, K) or null
     i64 ut_stride;         // K
@@ -406,6 +409,51 @@ k_f_spacing_write(const FArgs av)
 // Calls sink(n0, ok[4], a4[4]) once per pass of 1024 offspring with the parents a4 of the
 // offspring n0..n0+3 this thread owns in the pass (ok: inside the tile's range).
 // ---------------------------------------------------------------------------
+// The scatter passes: given the first offspring ns[i] of this thread's 4 parents (ns[4]: of the
+// next thread's first), every parent writes its index at its first offspring's slot of the
+// pass (LDS) and a running maximum over the slots gives each offspring its parent.
+template <int BS = SMC_BLOCK, class Sink>
+__device__ __forceinline__ void f_scatter_passes(const i64 j0, const i64 n_lo, const i64 n_hi,
+                                                 const i64 (&ns)[F_IPT + 1], u32* sP, u32* smx,
+                                                 Sink&& sink)
+{
+    constexpr int PASS = BS * 4, NW = BS / 64;
+    const int tid = (int)threadIdx.x;
+    for (i64 pb = n_lo & ~(i64)3; pb < n_hi; pb += PASS) {
+        const i64 n0 = pb + (i64)tid * 4;
+        bool ok[4];
+        i64 a4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ok[i] = (n0 + i >= n_lo) && (n0 + i < n_hi);
+        __syncthreads();                           // previous pass has read sP
+        *reinterpret_cast<uint4*>(&sP[tid * 4]) = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < F_IPT; ++i) {
+            const i64 lo = ns[i] > pb ? ns[i] : pb;
+            const i64 hi = ns[i + 1] < pb + PASS ? ns[i + 1] : pb + PASS;
+            if (lo < hi) sP[lo - pb] = (u32)(tid * F_IPT + i);
+        }
+        __syncthreads();
+        const uint4 v = *reinterpret_cast<const uint4*>(&sP[tid * 4]);
+        const u32 m0 = v.x, m1 = m0 > v.y ? m0 : v.y, m2 = m1 > v.z ? m1 : v.z,
+                  m3 = m2 > v.w ? m2 : v.w;
+        const u32 inc = smc_wave_scan_max_u32(m3);
+        u32 ex = smc_mov_dpp<SMC_DPP_WAVE_SHR1>(inc);
+        if (smc_lane() == 0) ex = 0u;
+        if (smc_lane() == 63) smx[smc_wave()] = inc;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < NW - 1; ++w)
+            if (w < smc_wave()) ex = ex > smx[w] ? ex : smx[w];
+        a4[0] = j0 + (i64)(m0 > ex ? m0 : ex);
+        a4[1] = j0 + (i64)(m1 > ex ? m1 : ex);
+        a4[2] = j0 + (i64)(m2 > ex ? m2 : ex);
+        a4[3] = j0 + (i64)(m3 > ex ? m3 : ex);
+        sink(n0, ok, a4);
+    }
+}
+
 template <int BS = SMC_BLOCK, class Sink>
 __device__ __forceinline__ void f_tile_offspring(const FArgs& a, const int isl, const i64 t,
                                                  const int b, const i64 jt, const i64 j0,
@@ -413,7 +461,7 @@ __device__ __forceinline__ void f_tile_offspring(const FArgs& a, const int isl, 
                                                  const u64 total, u64* sC, u32* sP, i64* sn, u32* smx,
                                                  Sink&& sink)
 {
-    constexpr int TILE = BS * F_IPT, PASS = BS * 4, NW = BS / 64;     // of THIS workgroup size
+    constexpr int TILE = BS * F_IPT, PASS = BS * 4;                   // of THIS workgroup size
     const int tid = (int)threadIdx.x;
     const i64 N = a.N;
     const u32 gisl = (u32)(a.island_offset + isl);
@@ -458,6 +506,8 @@ __device__ __forceinline__ void f_tile_offspring(const FArgs& a, const int isl, 
         __syncthreads();
         n_lo = sn[0];
         n_hi = sn[1];
+        f_scatter_passes<BS>(j0, n_lo, n_hi, ns, sP, smx, sink);
+        return;
     } else {
         u64 c = cex;
 #pragma unroll
@@ -477,33 +527,7 @@ __device__ __forceinline__ void f_tile_offspring(const FArgs& a, const int isl, 
         i64 a4[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) ok[i] = (n0 + i >= n_lo) && (n0 + i < n_hi);
-        if (scatter) {
-            __syncthreads();                           // previous pass has read sP
-            *reinterpret_cast<uint4*>(&sP[tid * 4]) = make_uint4(0u, 0u, 0u, 0u);
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < F_IPT; ++i) {
-                const i64 lo = ns[i] > pb ? ns[i] : pb;
-                const i64 hi = ns[i + 1] < pb + PASS ? ns[i + 1] : pb + PASS;
-                if (lo < hi) sP[lo - pb] = (u32)(tid * F_IPT + i);
-            }
-            __syncthreads();
-            const uint4 v = *reinterpret_cast<const uint4*>(&sP[tid * 4]);
-            const u32 m0 = v.x, m1 = m0 > v.y ? m0 : v.y, m2 = m1 > v.z ? m1 : v.z,
-                      m3 = m2 > v.w ? m2 : v.w;
-            const u32 inc = smc_wave_scan_max_u32(m3);
-            u32 ex = smc_mov_dpp<SMC_DPP_WAVE_SHR1>(inc);
-            if (smc_lane() == 0) ex = 0u;
-            if (smc_lane() == 63) smx[smc_wave()] = inc;
-            __syncthreads();
-#pragma unroll
-            for (int w = 0; w < NW - 1; ++w)
-                if (w < smc_wave()) ex = ex > smx[w] ? ex : smx[w];
-            a4[0] = j0 + (i64)(m0 > ex ? m0 : ex);
-            a4[1] = j0 + (i64)(m1 > ex ? m1 : ex);
-            a4[2] = j0 + (i64)(m2 > ex ? m2 : ex);
-            a4[3] = j0 + (i64)(m3 > ex ? m3 : ex);
-        } else {
+        {
             double s4[4];
             smc_su_pair(su, n0 >> 1, s4[0], s4[1]);
             smc_su_pair(su, (n0 >> 1) + 1, s4[2], s4[3]);
@@ -735,7 +759,7 @@ __device__ __forceinline__ void f_load_anc(const u32* A, i64 n0, i64 N, bool ful
     }
 }
 
-template <int KIND, int FK, int OPT, bool SPEC>
+template <int KIND, int FK, int OPT, bool SPEC, bool TAIL = true>
 __global__ void __launch_bounds__(SMC_BLOCK)
 k_propagate(const FArgs av)
 {
@@ -865,7 +889,256 @@ k_propagate(const FArgs av)
         r.s = s1;
         r.ss = s2;
     }
-    f_step_tail(a, isl, b, t, first, resample, r, smd, s_last, info);
+    if (TAIL) {
+        f_step_tail(a, isl, b, t, first, resample, r, smd, s_last, info);
+    } else {
+        // two-level path: the partial is all this launch owes; k_ancestors2(t+1) -- every
+        // workgroup of it -- reduces the partials, so nobody waits for a last workgroup here
+        if (tid == 0) {
+            const i64 o = (i64)isl * a.nparts;
+            a.pm[o + b] = r.m;
+            a.ps[o + b] = r.s;
+            a.pss[o + b] = r.ss;
+            if (b == 0) a.info2[(i64)isl * INFO_STRIDE] = (double)(t + 1);
+        }
+        F_STAMP(4);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Two-level CDF (systematic / stratified, N = 2^k, 2..1024 tiles per island): the step loop
+// without any intra-launch exchange.
+//
+// k_propagate<.., TAIL = false>(t-1) leaves one log-sum-exp partial (m_b, S_b, SS_b) per
+// aligned tile of 1024 particles.  EVERY workgroup of k_ancestors2(t) reduces those <= 1024
+// partials itself (same loads, same order, same bits everywhere): (m, s) -> ESS, the
+// resample decision, and each tile's share of the 2^62 scale
+//     Q_b = rint(S_b exp(m_b - m) / s * 2^62),      G_b = sum_{b' < b} Q_b'   (exact integers).
+// Inside its tile a workgroup builds the exact integer CDF c_j of q_i = rint(exp(lw_i - m_b) 2^50)
+// (total t_b) and places parent j's first offspring at
+//     ns_j = #{ n : T_n <= G_b + floor(c_j Q_b / t_b) },      T_n = ceil(su_n 2^62)
+// -- i.e. offspring n with G_b < T_n <= G_b + Q_b belongs to the parent j of tile b with
+// c_j Q_b < (T_n - G_b) t_b <= c_{j+1} Q_b: an exact rational comparison, deterministic for
+// any schedule.  Compared with the flat Q62 contract (smc_resample.h) the tile totals no longer
+// need the normalised weights of other tiles, so the look-back of k_ancestors<true> -- a
+// store -> visible -> poll round trip -- and the ticket / last-workgroup tail of k_propagate
+// both disappear; what remains between the kernels is the launch boundary.  Restated in
+// oracle/smc_oracle.py (inverse_cdf_2level); agrees with the sequential fp64 CDF of the
+// reference except within rounding distance of a CDF step, like the flat contract.
+// Workgroup 0 writes the summary row of step t-1 and the record k_propagate(t) reads.
+// ---------------------------------------------------------------------------
+struct F2Red {
+    double m, s, ss, ess, log_mean, rs;
+    bool bad;
+};
+// every thread: partials tid*4 .. tid*4+3 of the island (e4: their exp(m_b - m)); all threads
+// receive the same reduced values
+__device__ __forceinline__ F2Red f2_reduce(const FArgs& a, const double (&pm4)[4],
+                                           const double (&ps4)[4], const double (&pss4)[4],
+                                           double (&e4)[4], double* smd)
+{
+    F2Red r;
+    double tm = pm4[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) tm = smc_max2(tm, pm4[k]);
+    r.m = smc_block_max(tm, smd);
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        e4[k] = (pm4[k] > -INFINITY) ? smc_exp_nonpos(pm4[k] - r.m) : 0.0;
+        s1 = fma(ps4[k], e4[k], s1);
+        s2 = fma(pss4[k], e4[k] * e4[k], s2);
+    }
+    smc_block_sum2(s1, s2, smd);
+    r.s = s1;
+    r.ss = s2;
+    r.bad = !(r.m > -INFINITY) || !(r.m < INFINITY);
+    r.ess = r.bad ? NAN : (s1 * s1) / s2;                               // resampling.py:226
+    r.log_mean = r.bad ? NAN : r.m + log(s1 / (double)a.N);             // resampling.py:224
+    r.rs = r.bad ? NAN : 1.0 / s1;
+    return r;
+}
+// summary row of step ts (the step the partials belong to) -- core.py:355-359
+__device__ __forceinline__ void f2_write_row(const FArgs& a, const int isl, const i64 ts, const F2Red& r)
+{
+    double* row = a.summ + ((i64)isl * (a.T + 1) + ts) * SUMM_STRIDE;
+    const bool first = (ts == 0);
+    const bool resampled = row[4] != 0.0;              // written when step ts was decided
+    const double loglt = (first || resampled) ? r.log_mean : r.log_mean - row[1 - SUMM_STRIDE];
+    row[0] = r.ess;
+    row[1] = r.log_mean;
+    row[2] = loglt;
+    row[3] = (first ? 0.0 : row[3 - SUMM_STRIDE]) + loglt;
+    row[5] = r.m;
+    row[6] = r.rs;
+}
+
+template <bool SPEC>
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_ancestors2(const FArgs av)
+{
+    const FArgs& a = av;
+    __shared__ __attribute__((aligned(16))) u32 sP[F_PASS];
+    __shared__ u64 smu[SMC_SM];
+    __shared__ double smd[SMC_SM];
+    __shared__ i64 sn[2];
+    __shared__ u32 smx[SMC_NWAVE];
+    __shared__ u64 sgq[2];
+    const int b = (int)blockIdx.x, isl = (int)blockIdx.y;
+    const int tid = (int)threadIdx.x;
+    const i64 N = a.N;
+    const bool vec = (N & 3) == 0;
+    const i64 j0 = (i64)b * F_TILE;
+    const i64 jt = j0 + (i64)tid * F_IPT;
+    F_STAMP_A(0);
+    const double r0 = smc_ldg(a.info2 + (i64)isl * INFO_STRIDE);
+    const i64 o = (i64)isl * a.nparts;
+    double pm4[4], ps4[4], pss4[4], l4[4];
+    const double mb_raw = smc_ldg(a.pm + o + b);              // what the local CDF needs first
+    if (SPEC)
+        f_load4<double>(a.lw + (i64)(a.par ^ 1) * a.lslot + (i64)isl * N, jt, N, vec, -INFINITY, l4);
+    {
+        const bool pvec = (a.nparts & 3) == 0;
+        f_load4<double>(a.pm + o, (i64)tid * 4, a.nparts, pvec, -INFINITY, pm4);
+        f_load4<double>(a.ps + o, (i64)tid * 4, a.nparts, pvec, 0.0, ps4);
+        f_load4<double>(a.pss + o, (i64)tid * 4, a.nparts, pvec, 0.0, pss4);
+    }
+    const i64 t = (i64)smc_uniform(r0);
+    double* info = a.info + (i64)isl * INFO_STRIDE;
+    if (t >= a.T) {
+        if (b == 0 && tid == 0) info[0] = (double)t;           // k_propagate returns on it
+        return;
+    }
+    if (t == 0) return;                                        // the host wrote the record of step 0
+    if (!SPEC) f_load4<double>(f_lw(a, t - 1) + (i64)isl * N, jt, N, vec, -INFINITY, l4);
+    F_STAMP_A(1);
+    // ---- the tile's own integer CDF, relative to the tile's maximum (needs nothing from the
+    // other tiles: done while the partials are still on their way; wasted only on the steps
+    // that turn out not to resample)
+    const double mb = smc_uniform(mb_raw);
+    u64 q4[4], tsum = 0ull;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double e = (l4[i] > -INFINITY) ? smc_exp_nonpos(l4[i] - mb) : 0.0;
+        q4[i] = (jt + i < N) ? (u64)rint(e * 1125899906842624.0) : 0ull;          // 2^50
+        tsum += q4[i];
+    }
+    u64 tb;
+    const u64 cex = smc_block_exscan_u64(tsum, smu, tb);
+    F_STAMP_A(2);
+    // ---- all partials -> (m, s), ESS, the decision; workgroup 0 writes them down
+    double e4[4];
+    const F2Red r = f2_reduce(a, pm4, ps4, pss4, e4, smd);
+    const bool resample = r.ess < a.ess_thresh;                // core.py:181-183 (t < T here)
+    if (b == 0 && tid == 0) {
+        f2_write_row(a, isl, t - 1, r);
+        a.summ[((i64)isl * (a.T + 1) + t) * SUMM_STRIDE + 4] = resample ? 1.0 : 0.0;
+        info[0] = (double)t;
+        info[1] = resample ? 1.0 : 0.0;
+        info[2] = a.y[t * a.dy];
+        info[3] = r.m;
+        info[4] = r.rs;
+        info[5] = a.aux ? a.aux[t] : 0.0;
+    }
+    F_STAMP_A(3);
+    if (!resample) return;
+
+    // ---- this tile's share Q_b of the 2^62 scale and the shares before it, G_b
+    u64 qbefore = 0ull;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const i64 i = (i64)tid * 4 + k;
+        const u64 Qk = (i < a.nparts) ? smc_q62_w((ps4[k] * e4[k]) * r.rs) : 0ull;
+        if (i < b) qbefore += Qk;
+        if (i == b) sgq[1] = Qk;
+    }
+    const u64 Gb = smc_block_sum_u64(qbefore, smu);            // (its barriers publish sgq[1])
+    const u64 Qb = sgq[1];
+    F_STAMP_A(4);
+    // ---- first offspring of each parent
+    const u32 gisl = (u32)(a.island_offset + isl);
+    SmcSu su;
+    su.scheme = a.scheme;
+    su.M = N;
+    su.dM = (double)N;
+    su.u = a.ut ? a.ut + ((i64)t * a.n_islands + isl) * a.ut_stride : nullptr;
+    su.u_sys = 0.0;
+    su.seed = a.seed;
+    su.t = (u32)t;
+    su.island = gisl;
+    if (a.scheme == SMC_SYSTEMATIC_) {
+        if (su.u) {
+            su.u_sys = su.u[0];
+        } else {
+            u64 x0, x1;
+            smc_philox(0u, su.t, su.island, SMC_STREAM_RESAMPLE, su.seed, x0, x1);
+            su.u_sys = smc_u01_halfopen(x0);
+        }
+    }
+    const u64 Us = (u64)(su.u_sys * __longlong_as_double((long long)(1023 + 62 - a.log2N) << 52));
+    i64 ns[F_IPT + 1];
+    u64 c = cex;
+    // c Q_b / t_b in fp64 is within 2^12 of the exact quotient (< 2^63, three roundings): enough
+    // to decide the count unless the position falls within that band of a threshold
+    const double qscale = (double)Qb / (double)(tb ? tb : 1ull);
+#pragma unroll
+    for (int i = 0; i <= F_IPT; ++i) {
+        const i64 j = jt + i;
+        if (j == 0) ns[i] = 0;
+        else if (j >= N) ns[i] = N;
+        else {
+            u64 qh = (u64)((double)c * qscale);
+            qh = qh > Qb ? Qb : qh;
+            i64 cnt = a.exact_counts ? -1
+                                     : smc_count_pow2_band(Gb + qh, 1ull << 13, su, su.u_sys, Us, a.log2N, N);
+            if (cnt < 0) {
+                const u64 C = Gb + smc_muldiv_floor(c, Qb, tb);
+                cnt = a.scheme == SMC_SYSTEMATIC_ ? smc_sys_count_pow2_fast(C, su.u_sys, Us, a.log2N, N)
+                                                  : smc_strat_count_pow2(C, su, a.log2N, N);
+            }
+            ns[i] = cnt;
+        }
+        if (i < F_IPT) c += q4[i];
+    }
+    if (tid == 0) sn[0] = ns[0];
+    if (tid == SMC_BLOCK - 1) sn[1] = ns[F_IPT];
+    __syncthreads();
+    const i64 n_lo = sn[0], n_hi = sn[1];
+    F_STAMP_A(5);
+    u32* A = f_A(a, t) + (i64)isl * N;
+    f_scatter_passes(j0, n_lo, n_hi, ns, sP, smx,
+                     [&](i64 n0, const bool (&ok)[4], const i64 (&a4)[4]) {                // core.py:329
+                         const u32 a32[4] = {(u32)a4[0], (u32)a4[1], (u32)a4[2], (u32)a4[3]};
+                         if (vec && ok[0] && ok[3]) {
+                             smc_st4g(A + n0, a32);
+                         } else {
+#pragma unroll
+                             for (int i = 0; i < 4; ++i)
+                                 if (ok[i]) smc_stg(A + n0 + i, a32[i]);
+                         }
+                     });
+    F_STAMP_A(6);
+}
+
+// the summary row of the last step done and the (m, 1/s) W is formed with: enqueued at the end
+// of every smc_filter_step call of the two-level path (one workgroup per island; idempotent --
+// k_ancestors2 of the next step writes the same row again)
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_flush2(const FArgs av)
+{
+    const FArgs& a = av;
+    __shared__ double smd[SMC_SM];
+    const int isl = (int)blockIdx.x, tid = (int)threadIdx.x;
+    const i64 t = (i64)smc_uniform(smc_ldg(a.info2 + (i64)isl * INFO_STRIDE));       // steps done
+    if (t <= 0) return;
+    const i64 o = (i64)isl * a.nparts;
+    double pm4[4], ps4[4], pss4[4], e4[4];
+    const bool pvec = (a.nparts & 3) == 0;
+    f_load4<double>(a.pm + o, (i64)tid * 4, a.nparts, pvec, -INFINITY, pm4);
+    f_load4<double>(a.ps + o, (i64)tid * 4, a.nparts, pvec, 0.0, ps4);
+    f_load4<double>(a.pss + o, (i64)tid * 4, a.nparts, pvec, 0.0, pss4);
+    const F2Red r = f2_reduce(a, pm4, ps4, pss4, e4, smd);
+    if (tid == 0) f2_write_row(a, isl, t - 1, r);
 }
 
 // W = exp(lw - m)/s for one island (SMC.W)

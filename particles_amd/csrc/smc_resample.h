@@ -128,6 +128,29 @@ __device__ __forceinline__ i64 smc_sys_count_pow2_fast(u64 C, double u, u64 Us, 
     return smc_sys_count_pow2(C, u, k, M);
 }
 
+// floor(c * Q / t) for 0 <= c <= t <= 2^60, Q < 2^63 (the two-level CDF of the step loop: a
+// position c of a tile's local integer CDF, total t, mapped onto the tile's share Q of the
+// global 2^62 scale).  fp64 estimate, exact 128-bit remainder, one fp64 correction, +-1 fix-up.
+__device__ __forceinline__ u64 smc_muldiv_floor(u64 c, u64 Q, u64 t)
+{
+    if (c == 0ull) return 0ull;
+    if (c >= t) return Q;
+    const double td = (double)t;
+    u64 q = (u64)(((double)c / td) * (double)Q);               // within ~2^11 of the quotient
+    const u64 lo1 = c * Q, hi1 = __umul64hi(c, Q);
+    const u64 lo2 = q * t, hi2 = __umul64hi(q, t);
+    const u64 rlo = lo1 - lo2;
+    const i64 rhi = (i64)(hi1 - hi2 - (lo1 < lo2 ? 1ull : 0ull));    // R = c Q - q t, |R| < 2^72
+    const double Rd = (double)rhi * 18446744073709551616.0 + (double)rlo;
+    q += (u64)(i64)floor(Rd / td);
+    i64 r = (i64)(c * Q - q * t);                              // now |r| < 2 t <= 2^61: 64 bits do
+    if (r < 0) { q -= 1ull; r += (i64)t; }
+    if (r < 0) { q -= 1ull; r += (i64)t; }
+    if (r >= (i64)t) { q += 1ull; r -= (i64)t; }
+    if (r >= (i64)t) { q += 1ull; r -= (i64)t; }
+    return q;
+}
+
 // Stratified draws with M = 2^k outputs: su_n = fl(u_n + n) / 2^k lies in [n, n+1] / 2^k just
 // like the systematic ones, so the same closed form holds with the n-th uniform:
 //     count(C) = nc + [T_nc <= C],   nc = floor(C / 2^(62-k)),  T_nc = ceil(fl(u_nc + nc) 2^(62-k))
@@ -148,6 +171,38 @@ __device__ __forceinline__ i64 smc_strat_count_pow2(u64 C, const SmcSu& s, int k
     const double scale = __longlong_as_double((long long)(1023 + sh) << 52);   // 2^sh
     const u64 T = (u64)ceil((un + (double)(i64)nc) * scale);
     return (i64)nc + (T <= C ? 1 : 0);
+}
+
+// ---------------------------------------------------------------------------
+// count(C) for a C known only to within +-E (E a power of two, far below 2^(62-k)): decided
+// whenever neither nc = floor(C / 2^(62-k)) nor the comparison T_nc <= C can change inside the
+// error band; returns -1 otherwise (the caller then forms C exactly).
+__device__ __forceinline__ i64 smc_count_pow2_band(u64 Ch, u64 E, const SmcSu& s, double u_sys,
+                                                   u64 Us, int k, i64 M)
+{
+    const int sh = 62 - k;
+    const u64 nc = Ch >> sh;
+    const u64 frac = Ch & ((1ull << sh) - 1ull);
+    if (frac < E || frac + E >= (1ull << sh)) return -1;        // nc itself could move
+    if (nc >= (u64)M) return M;
+    if (s.scheme == SMC_SYSTEMATIC_) {
+        if (frac >= Us + 1024ull + E) return (i64)nc + 1;
+        if (frac + 1024ull + E <= Us) return (i64)nc;
+        return -1;
+    }
+    double un;                                                  // stratified: the nc-th uniform
+    if (s.u) {
+        un = s.u[nc];
+    } else {
+        u64 a, b;
+        smc_philox((u32)(nc >> 1), s.t, s.island, SMC_STREAM_RESAMPLE, s.seed, a, b);
+        un = smc_u01_halfopen((nc & 1) ? b : a);
+    }
+    const double scale = __longlong_as_double((long long)(1023 + sh) << 52);   // 2^sh
+    const u64 T = (u64)ceil((un + (double)(i64)nc) * scale);
+    if (T + E <= Ch) return (i64)nc + 1;
+    if (T > Ch + E) return (i64)nc;
+    return -1;
 }
 
 // ---------------------------------------------------------------------------

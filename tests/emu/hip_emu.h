@@ -282,6 +282,9 @@ inline void sincospi(double x, double* s, double* c) {
     *s = sin(M_PI * x);
     *c = cos(M_PI * x);
 }
+inline unsigned long long __umul64hi(unsigned long long a, unsigned long long b) {
+    return (unsigned long long)(((unsigned __int128)a * b) >> 64);
+}
 inline double __longlong_as_double(long long v) { double d; memcpy(&d, &v, 8); return d; }
 inline long long __double_as_longlong(double d) { long long v; memcpy(&v, &d, 8); return v; }
 inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p += v; return o; }

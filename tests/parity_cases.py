@@ -485,6 +485,54 @@ def check_model_philox_vs_oracle(golden, case, model, N=20000):
     assert abs(np.mean(dev) - np.mean(ref)) < 0.25, (dev, ref)
 
 
+def check_two_level_cdf(golden, monkeypatch, N=4096, T=20):
+    """N = 2^k with 2..1024 tiles, systematic / stratified: the step loop runs on the two-level
+    exact CDF (k_ancestors2).  Replay of the reference's draws: against the oracle's restatement
+    of that contract, against the flat-Q62 device path, and against itself with the fp64 band
+    shortcut of the offspring counts switched off (every position formed exactly)."""
+    for case, scheme in (("toy_systematic", "systematic"), ("toy_stratified", "stratified")):
+        g = golden(case)
+        mk_dev, mk_orc = MODELS["toy"]
+        y = list(g["y"])[:T]
+        np.random.seed(int(g["run_seed"]))
+        rec = orc.RecordingRNG()
+        o = orc.run_filter(mk_orc(), y, N, scheme, 0.5, rng=rec, keep=True)          # reference semantics
+        z, u = tapes_from_oracle(rec.tape, len(y), N, scheme)
+        o2 = orc.run_filter(mk_orc(), y, N, scheme, 0.5, rng=orc.ReplayRNG(rec.tape), cdf="2level")
+        runs = {}
+        for name, env in (("two_level", {}), ("exact_counts", {"SMC_EXACT_COUNTS": "1"}),
+                          ("flat", {"SMC_FLAT_CDF": "1"})):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            pf = pa.SMC(fk=ssm.Bootstrap(ssm=mk_dev(), data=y), N=N, resampling=scheme, ESSrmin=0.5,
+                        replay=(z, u))
+            pf.run()
+            runs[name] = (np.array(pf.A), np.array(pf.X), list(pf.summaries.logLts), list(pf.summaries.rs_flags))
+            monkeypatch.undo()
+        A2, X2, ll2, rf2 = runs["two_level"]
+        assert np.array_equal(A2, runs["exact_counts"][0]) and np.array_equal(X2, runs["exact_counts"][1])
+        assert ll2 == runs["exact_counts"][2]
+        assert rf2 == o["rs_flag"] and any(rf2)
+        assert rel(ll2, o["logLt"]) < 1e-9 and rel(runs["flat"][2], o["logLt"]) < 1e-9
+        for ref in (o["A"], o2["A"], runs["flat"][0]):
+            assert np.mean(A2 == ref) >= 0.999                      # near-ties only
+        if np.array_equal(A2, o2["A"]):
+            assert np.array_equal(X2, o2["X"])                      # IEEE + - * / only
+    # the contract itself against the sequential fp64 CDF of the reference, skewed weights,
+    # -inf entries and an empty tile included
+    rng = np.random.default_rng(12)
+    lw = rng.normal(0.0, 3.0, size=4096)
+    lw[rng.random(4096) < 0.05] = -np.inf
+    lw[1024:2048] = -np.inf
+    W = np.exp(lw - lw.max())
+    W /= W.sum()
+    for M in (4096,):
+        su = (rng.random() + np.arange(M)) / M
+        A = orc.inverse_cdf_2level(su, lw)
+        assert np.mean(A == orc.inverse_cdf(su, W)) >= 0.999 and np.all(np.diff(A) >= 0)
+        assert not np.any((A >= 1024) & (A < 2048)) and np.all(W[A] > 0)
+
+
 def check_graph_replay_matches_direct(golden, N=5000):
     """The hipGraph path (24 steps per graph, slot parity baked into the nodes) against plain
     launches, entered at odd and even time indices and with adaptive resampling."""

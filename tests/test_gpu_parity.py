@@ -132,6 +132,10 @@ def test_filter_replay_power_of_two(golden, case, N):
     pc.check_filter_replay(golden, case, "toy", "bootstrap", T=20, N=N)
 
 
+def test_two_level_cdf(golden, monkeypatch):
+    pc.check_two_level_cdf(golden, monkeypatch)
+
+
 def test_graph_replay_matches_direct(golden):
     pc.check_graph_replay_matches_direct(golden, N=200000)
 

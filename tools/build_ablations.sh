@@ -6,7 +6,7 @@ mkdir -p particles_amd/lib/abl
 for v in ${ABLS:-NO_RNG NO_MFMA NO_LOAD NO_STORE}; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -mllvm -amdgpu-mfma-vgpr-form=1 \
     -DABL_$v -DSMC_$v particles_amd/csrc/smc_api.hip particles_amd/csrc/smc_ops.hip particles_amd/csrc/smc_filter.hip \
-    particles_amd/csrc/smc_comm.hip -o particles_amd/lib/abl/libsmc_$v.so -ldl 2>/dev/null &
+    particles_amd/csrc/smc_comm.hip particles_amd/csrc/smc_sort.hip particles_amd/csrc/smc_qmc.hip -o particles_amd/lib/abl/libsmc_$v.so -ldl 2>/dev/null &
 done
 wait
 ls -la particles_amd/lib/abl

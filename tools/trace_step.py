@@ -28,12 +28,15 @@ buf = np.zeros((nparts + ntiles) * 8, dtype=np.uint64)
 lib = _lib.lib()
 lib.smc_debug_trace.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 _lib.check(lib.smc_debug_trace(pf._f, buf.ctypes.data_as(ctypes.c_void_p)))
+two_level = not (os.environ.get("SMC_FLAT_CDF") or os.environ.get("SMC_FORCE_FUSED"))
 for name, st, labels in (
-        ("k_ancestors<true>", buf[nparts * 8:].reshape(ntiles, 8),
-         ["start", "record", "q ready", "published", "prefix known", "counts", "end"]),
+        ("k_ancestors2" if two_level else "k_ancestors<true>", buf[nparts * 8:].reshape(ntiles, 8),
+         ["start", "t + loads", "local cdf", "partials reduced", "tile shares", "counts", "end"] if two_level
+         else ["start", "record", "q ready", "published", "prefix known", "counts", "end"]),
         ("k_propagate", buf[:nparts * 8].reshape(nparts, 8),
-         ["start", "record", "loads+normals", "stores issued", "wg reduced", "shard ticket",
-          "top ticket", "finalised"])):
+         ["start", "record", "loads+normals", "stores issued", "partial written"] if two_level
+         else ["start", "record", "loads+normals", "stores issued", "wg reduced", "shard ticket",
+               "top ticket", "finalised"])):
     t0 = st[:, 0].min()
     print("%s: %d workgroups, last start +%.2f us" % (name, st.shape[0], (st[:, 0].max() - t0) / 100.0))
     for k, lab in enumerate(labels):
@@ -44,7 +47,7 @@ for name, st, labels in (
         print("  %-16s n=%5d  min %6.2f  median %6.2f  p90 %6.2f  p99 %6.2f  max %6.2f us (wg %d)"
               % (lab, col.size, col.min() / 100.0, np.median(col) / 100.0, np.percentile(col, 90) / 100.0,
                  np.percentile(col, 99) / 100.0, col.max() / 100.0, int(np.argmax(st[:, k]))))
-    if name.startswith("k_anc"):
+    if name == "k_ancestors<true>":
         d = (st[:, 3].astype(np.int64) - st[:, 2].astype(np.int64)) / 100.0
         order = np.argsort(-d)[:8]
         print("  slowest q-ready -> published:", [(int(i), float(d[i]), float((st[i, 0] - t0) / 100.0)) for i in order])
