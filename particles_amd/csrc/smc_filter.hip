@@ -21,6 +21,7 @@ struct smc_filter {
     bool use_graph;
     bool fused;            // k_ancestors<true> (no k_prepare launch)
     bool two_level;        // k_ancestors2 + tail-free k_propagate (two-level CDF, no intra-launch exchange)
+    bool two_level_mid;    // ... with k_reduce2 in front (grids too large for every workgroup to reduce)
     i64 perm_t;            // t_host at the last smc_filter_permute_islands (A / Xp undefined there)
     hipGraphExec_t gexec;
     int graph_steps;
@@ -87,8 +88,12 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t)
     const dim3 grid(f->a.ntiles, f->a.n_islands);
     if (k_prof >= 0) (void)hipEventRecord(f->ev[3 * k_prof], st);
     if (f->two_level) {
-        if (f->a.par >= 0) SMC_LAUNCH((k_ancestors2<true>), grid, dim3(SMC_BLOCK), st, f->a);
-        else SMC_LAUNCH((k_ancestors2<false>), grid, dim3(SMC_BLOCK), st, f->a);
+        if (f->two_level_mid) {
+            SMC_LAUNCH(k_reduce2, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
+            if (f->a.par >= 0) SMC_LAUNCH((k_ancestors2<true, true>), grid, dim3(SMC_BLOCK), st, f->a);
+            else SMC_LAUNCH((k_ancestors2<false, true>), grid, dim3(SMC_BLOCK), st, f->a);
+        } else if (f->a.par >= 0) SMC_LAUNCH((k_ancestors2<true, false>), grid, dim3(SMC_BLOCK), st, f->a);
+        else SMC_LAUNCH((k_ancestors2<false, false>), grid, dim3(SMC_BLOCK), st, f->a);
         if (k_prof >= 0 && (k_prof & 1)) (void)hipEventRecord(f->ev[3 * k_prof + 1], st);
         launch_propagate(f);
         if (k_prof >= 0) (void)hipEventRecord(f->ev[3 * k_prof + 2], st);
@@ -234,10 +239,14 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     const size_t oInfo2 = carve(M * INFO_STRIDE * 8);
     // two-level CDF: closed-form offspring counts (N = 2^k, systematic / stratified), at most
     // 1024 tiles per island (4 partials per thread), at least 2 (below, the one-workgroup filter)
-    f->two_level = !mv && !o->moments && a.log2N >= 0 && a.ntiles >= 2 && a.ntiles <= 1024 &&
-                   (f->fused || getenv("SMC_TWO_LEVEL")) &&        // larger grids: k_prepare is as fast
+    f->two_level = !mv && !o->moments && a.log2N >= 0 && a.ntiles >= 2 &&
+                   (a.ntiles <= 1024 || getenv("SMC_TWO_LEVEL_MID")) &&   // one huge filter: a single
+                   // workgroup reducing > 1024 partials costs more than k_prepare's pass (C3: 93 vs 86 us)
                    (o->scheme == SMC_SYSTEMATIC || o->scheme == SMC_STRATIFIED) &&
                    !getenv("SMC_FLAT_CDF") && !getenv("SMC_FORCE_FUSED") && !getenv("SMC_FORCE_UNFUSED");
+    // every workgroup reduces the partials itself while the launch is resident and an island has
+    // at most 1024 tiles (4 per thread); otherwise one workgroup per island does it first
+    f->two_level_mid = f->two_level && (!f->fused || a.ntiles > 1024 || getenv("SMC_TWO_LEVEL_MID"));
     const size_t oSu = carve(need_su ? M * N * 8 : 8);
     const size_t oE = carve(need_su ? M * a.ntiles1 * 8 : 8);
     const size_t oTmp = carve(N * dxm * 8);
@@ -805,7 +814,8 @@ int smc_filter_describe(smc_filter* f, char* out, size_t n)
     std::string s;
     if (small_filter_ok(f)) s = "k_filter_small";
     else {
-        if (f->two_level) s = "k_ancestors2";
+        if (f->two_level_mid) s = "k_reduce2+k_ancestors2";
+        else if (f->two_level) s = "k_ancestors2";
         else if (f->fused) s = "k_ancestors<fused>";
         else s = "k_prepare+k_ancestors";
         if (f->a.scheme == SMC_MULTINOMIAL && !f->a.ut) s = "k_f_spacing_sums+k_f_spacing_write+" + s;

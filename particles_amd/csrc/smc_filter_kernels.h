@@ -973,7 +973,128 @@ __device__ __forceinline__ void f2_write_row(const FArgs& a, const int isl, cons
     row[6] = r.rs;
 }
 
-template <bool SPEC>
+// MID: k_reduce2 ran first (one workgroup per island did the reduction and left (G_b, Q_b) in
+// Qpre / Q and the record in `info`): grids too large for every workgroup to repeat it.
+// the decision of step t and what k_propagate(t) reads (one thread)
+__device__ __forceinline__ void f2_write_record(const FArgs& a, const int isl, const i64 t, const F2Red& r,
+                                                const bool resample)
+{
+    double* info = a.info + (i64)isl * INFO_STRIDE;
+    f2_write_row(a, isl, t - 1, r);
+    a.summ[((i64)isl * (a.T + 1) + t) * SUMM_STRIDE + 4] = resample ? 1.0 : 0.0;
+    info[0] = (double)t;
+    info[1] = resample ? 1.0 : 0.0;
+    info[2] = a.y[t * a.dy];
+    info[3] = r.m;
+    info[4] = r.rs;
+    info[5] = a.aux ? a.aux[t] : 0.0;
+}
+// The same reduction by ONE workgroup for an island of any number of tiles: thread tid owns the
+// `per` consecutive partials from tid*per on (per = 4 up to 1024 tiles: then operation for
+// operation what f2_reduce does in every workgroup of k_ancestors2, hence the same bits).
+__device__ __forceinline__ F2Red f2_reduce_island(const FArgs& a, const int isl, const int per, double* smd)
+{
+    const i64 o = (i64)isl * a.nparts;
+    const i64 i0 = (i64)threadIdx.x * per;
+    F2Red r;
+    double tm = -INFINITY;
+    for (int k = 0; k < per; ++k)
+        if (i0 + k < a.nparts) tm = k ? smc_max2(tm, a.pm[o + i0 + k]) : a.pm[o + i0 + k];
+    r.m = smc_block_max(tm, smd);
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < per; ++k) {
+        if (i0 + k >= a.nparts) break;
+        const double pm = a.pm[o + i0 + k];
+        const double e = (pm > -INFINITY) ? smc_exp_nonpos(pm - r.m) : 0.0;
+        s1 = fma(a.ps[o + i0 + k], e, s1);
+        s2 = fma(a.pss[o + i0 + k], e * e, s2);
+    }
+    smc_block_sum2(s1, s2, smd);
+    r.s = s1;
+    r.ss = s2;
+    r.bad = !(r.m > -INFINITY) || !(r.m < INFINITY);
+    r.ess = r.bad ? NAN : (s1 * s1) / s2;
+    r.log_mean = r.bad ? NAN : r.m + log(s1 / (double)a.N);
+    r.rs = r.bad ? NAN : 1.0 / s1;
+    return r;
+}
+__device__ __forceinline__ int f2_per(const FArgs& a)
+{
+    const int per = (a.nparts + SMC_BLOCK - 1) / SMC_BLOCK;
+    return per < 4 ? 4 : per;
+}
+
+// k_reduce2(t): one workgroup per island reduces the partials of step t-1, decides step t,
+// writes the record, the summary row and every tile's (G_b, Q_b)
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_reduce2(const FArgs av)
+{
+    const FArgs& a = av;
+    __shared__ double smd[SMC_SM];
+    __shared__ u64 smu[SMC_SM];
+    const int isl = (int)blockIdx.x, tid = (int)threadIdx.x;
+    double* info = a.info + (i64)isl * INFO_STRIDE;
+    const i64 t = (i64)smc_uniform(smc_ldg(a.info2 + (i64)isl * INFO_STRIDE));
+    if (t >= a.T) {
+        if (tid == 0) info[0] = (double)t;
+        return;
+    }
+    if (t == 0) return;
+    const int per = f2_per(a);
+    const i64 o = (i64)isl * a.nparts;
+    const i64 i0 = (i64)tid * per;
+    if (per == 4) {
+        // up to 1024 tiles: all twelve loads of a thread in flight at once, then exactly
+        // k_ancestors2's own reduction
+        double pm4[4], ps4[4], pss4[4], e4[4];
+        const bool pvec = (a.nparts & 3) == 0;
+        f_load4<double>(a.pm + o, i0, a.nparts, pvec, -INFINITY, pm4);
+        f_load4<double>(a.ps + o, i0, a.nparts, pvec, 0.0, ps4);
+        f_load4<double>(a.pss + o, i0, a.nparts, pvec, 0.0, pss4);
+        const F2Red r = f2_reduce(a, pm4, ps4, pss4, e4, smd);
+        const bool resample = r.ess < a.ess_thresh;
+        if (tid == 0) f2_write_record(a, isl, t, r, resample);
+        if (!resample) return;
+        u64 Q4[4], run = 0ull;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            Q4[k] = (i0 + k < a.nparts) ? smc_q62_w((ps4[k] * e4[k]) * r.rs) : 0ull;
+            run += Q4[k];
+        }
+        u64 tot;
+        u64 g = smc_block_exscan_u64(run, smu, tot);
+        u64* G = a.Qpre + (i64)isl * a.ntiles;
+        u64* Q = a.Q + (i64)isl * a.ntiles;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (i0 + k < a.nparts) { G[i0 + k] = g; Q[i0 + k] = Q4[k]; g += Q4[k]; }
+        return;
+    }
+    const F2Red r = f2_reduce_island(a, isl, per, smd);
+    const bool resample = r.ess < a.ess_thresh;
+    if (tid == 0) f2_write_record(a, isl, t, r, resample);
+    if (!resample) return;
+    u64 run = 0ull;
+    for (int k = 0; k < per && i0 + k < a.nparts; ++k) {
+        const double pm = a.pm[o + i0 + k];
+        const double e = (pm > -INFINITY) ? smc_exp_nonpos(pm - r.m) : 0.0;
+        run += smc_q62_w((a.ps[o + i0 + k] * e) * r.rs);
+    }
+    u64 tot;
+    u64 g = smc_block_exscan_u64(run, smu, tot);
+    u64* G = a.Qpre + (i64)isl * a.ntiles;
+    u64* Q = a.Q + (i64)isl * a.ntiles;
+    for (int k = 0; k < per && i0 + k < a.nparts; ++k) {
+        const double pm = a.pm[o + i0 + k];
+        const double e = (pm > -INFINITY) ? smc_exp_nonpos(pm - r.m) : 0.0;
+        const u64 Qk = smc_q62_w((a.ps[o + i0 + k] * e) * r.rs);
+        G[i0 + k] = g;
+        Q[i0 + k] = Qk;
+        g += Qk;
+    }
+}
+
+template <bool SPEC, bool MID>
 __global__ void __launch_bounds__(SMC_BLOCK)
 k_ancestors2(const FArgs av)
 {
@@ -991,25 +1112,32 @@ k_ancestors2(const FArgs av)
     const i64 j0 = (i64)b * F_TILE;
     const i64 jt = j0 + (i64)tid * F_IPT;
     F_STAMP_A(0);
-    const double r0 = smc_ldg(a.info2 + (i64)isl * INFO_STRIDE);
+    double* info = a.info + (i64)isl * INFO_STRIDE;
+    const double r0 = smc_ldg(MID ? info : a.info2 + (i64)isl * INFO_STRIDE);
+    const double r1 = MID ? smc_ldg(info + 1) : 0.0;
     const i64 o = (i64)isl * a.nparts;
     double pm4[4], ps4[4], pss4[4], l4[4];
     const double mb_raw = smc_ldg(a.pm + o + b);              // what the local CDF needs first
+    u64 Gmid = 0ull, Qmid = 0ull;
+    if (MID) {
+        Gmid = smc_ldg(a.Qpre + (i64)isl * a.ntiles + b);
+        Qmid = smc_ldg(a.Q + (i64)isl * a.ntiles + b);
+    }
     if (SPEC)
         f_load4<double>(a.lw + (i64)(a.par ^ 1) * a.lslot + (i64)isl * N, jt, N, vec, -INFINITY, l4);
-    {
+    if (!MID) {
         const bool pvec = (a.nparts & 3) == 0;
         f_load4<double>(a.pm + o, (i64)tid * 4, a.nparts, pvec, -INFINITY, pm4);
         f_load4<double>(a.ps + o, (i64)tid * 4, a.nparts, pvec, 0.0, ps4);
         f_load4<double>(a.pss + o, (i64)tid * 4, a.nparts, pvec, 0.0, pss4);
     }
     const i64 t = (i64)smc_uniform(r0);
-    double* info = a.info + (i64)isl * INFO_STRIDE;
     if (t >= a.T) {
-        if (b == 0 && tid == 0) info[0] = (double)t;           // k_propagate returns on it
+        if (!MID && b == 0 && tid == 0) info[0] = (double)t;   // k_propagate returns on it
         return;
     }
     if (t == 0) return;                                        // the host wrote the record of step 0
+    if (MID && smc_uniform(r1) == 0.0) return;                 // k_reduce2: step t does not resample
     if (!SPEC) f_load4<double>(f_lw(a, t - 1) + (i64)isl * N, jt, N, vec, -INFINITY, l4);
     F_STAMP_A(1);
     // ---- the tile's own integer CDF, relative to the tile's maximum (needs nothing from the
@@ -1026,34 +1154,30 @@ k_ancestors2(const FArgs av)
     u64 tb;
     const u64 cex = smc_block_exscan_u64(tsum, smu, tb);
     F_STAMP_A(2);
-    // ---- all partials -> (m, s), ESS, the decision; workgroup 0 writes them down
-    double e4[4];
-    const F2Red r = f2_reduce(a, pm4, ps4, pss4, e4, smd);
-    const bool resample = r.ess < a.ess_thresh;                // core.py:181-183 (t < T here)
-    if (b == 0 && tid == 0) {
-        f2_write_row(a, isl, t - 1, r);
-        a.summ[((i64)isl * (a.T + 1) + t) * SUMM_STRIDE + 4] = resample ? 1.0 : 0.0;
-        info[0] = (double)t;
-        info[1] = resample ? 1.0 : 0.0;
-        info[2] = a.y[t * a.dy];
-        info[3] = r.m;
-        info[4] = r.rs;
-        info[5] = a.aux ? a.aux[t] : 0.0;
-    }
-    F_STAMP_A(3);
-    if (!resample) return;
-
-    // ---- this tile's share Q_b of the 2^62 scale and the shares before it, G_b
-    u64 qbefore = 0ull;
+    u64 Gb, Qb;
+    if (MID) {
+        Gb = smc_uniform(Gmid);
+        Qb = smc_uniform(Qmid);
+    } else {
+        // ---- all partials -> (m, s), ESS, the decision; workgroup 0 writes them down
+        double e4[4];
+        const F2Red r = f2_reduce(a, pm4, ps4, pss4, e4, smd);
+        const bool resample = r.ess < a.ess_thresh;            // core.py:181-183 (t < T here)
+        if (b == 0 && tid == 0) f2_write_record(a, isl, t, r, resample);
+        F_STAMP_A(3);
+        if (!resample) return;
+        // ---- this tile's share Q_b of the 2^62 scale and the shares before it, G_b
+        u64 qbefore = 0ull;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const i64 i = (i64)tid * 4 + k;
-        const u64 Qk = (i < a.nparts) ? smc_q62_w((ps4[k] * e4[k]) * r.rs) : 0ull;
-        if (i < b) qbefore += Qk;
-        if (i == b) sgq[1] = Qk;
+        for (int k = 0; k < 4; ++k) {
+            const i64 i = (i64)tid * 4 + k;
+            const u64 Qk = (i < a.nparts) ? smc_q62_w((ps4[k] * e4[k]) * r.rs) : 0ull;
+            if (i < b) qbefore += Qk;
+            if (i == b) sgq[1] = Qk;
+        }
+        Gb = smc_block_sum_u64(qbefore, smu);                  // (its barriers publish sgq[1])
+        Qb = sgq[1];
     }
-    const u64 Gb = smc_block_sum_u64(qbefore, smu);            // (its barriers publish sgq[1])
-    const u64 Qb = sgq[1];
     F_STAMP_A(4);
     // ---- first offspring of each parent
     const u32 gisl = (u32)(a.island_offset + isl);
@@ -1128,17 +1252,11 @@ k_flush2(const FArgs av)
 {
     const FArgs& a = av;
     __shared__ double smd[SMC_SM];
-    const int isl = (int)blockIdx.x, tid = (int)threadIdx.x;
+    const int isl = (int)blockIdx.x;
     const i64 t = (i64)smc_uniform(smc_ldg(a.info2 + (i64)isl * INFO_STRIDE));       // steps done
     if (t <= 0) return;
-    const i64 o = (i64)isl * a.nparts;
-    double pm4[4], ps4[4], pss4[4], e4[4];
-    const bool pvec = (a.nparts & 3) == 0;
-    f_load4<double>(a.pm + o, (i64)tid * 4, a.nparts, pvec, -INFINITY, pm4);
-    f_load4<double>(a.ps + o, (i64)tid * 4, a.nparts, pvec, 0.0, ps4);
-    f_load4<double>(a.pss + o, (i64)tid * 4, a.nparts, pvec, 0.0, pss4);
-    const F2Red r = f2_reduce(a, pm4, ps4, pss4, e4, smd);
-    if (tid == 0) f2_write_row(a, isl, t - 1, r);
+    const F2Red r = f2_reduce_island(a, isl, f2_per(a), smd);
+    if (threadIdx.x == 0) f2_write_row(a, isl, t - 1, r);
 }
 
 // W = exp(lw - m)/s for one island (SMC.W)

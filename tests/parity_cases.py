@@ -501,7 +501,7 @@ def check_two_level_cdf(golden, monkeypatch, N=4096, T=20):
         o2 = orc.run_filter(mk_orc(), y, N, scheme, 0.5, rng=orc.ReplayRNG(rec.tape), cdf="2level")
         runs = {}
         for name, env in (("two_level", {}), ("exact_counts", {"SMC_EXACT_COUNTS": "1"}),
-                          ("flat", {"SMC_FLAT_CDF": "1"})):
+                          ("mid", {"SMC_TWO_LEVEL_MID": "1"}), ("flat", {"SMC_FLAT_CDF": "1"})):
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
             pf = pa.SMC(fk=ssm.Bootstrap(ssm=mk_dev(), data=y), N=N, resampling=scheme, ESSrmin=0.5,
@@ -512,6 +512,10 @@ def check_two_level_cdf(golden, monkeypatch, N=4096, T=20):
         A2, X2, ll2, rf2 = runs["two_level"]
         assert np.array_equal(A2, runs["exact_counts"][0]) and np.array_equal(X2, runs["exact_counts"][1])
         assert ll2 == runs["exact_counts"][2]
+        # k_reduce2 in front (one workgroup per island reduces the partials) instead of every
+        # workgroup of k_ancestors2: the same operations in the same order, the same bits
+        assert np.array_equal(A2, runs["mid"][0]) and np.array_equal(X2, runs["mid"][1])
+        assert ll2 == runs["mid"][2]
         assert rf2 == o["rs_flag"] and any(rf2)
         assert rel(ll2, o["logLt"]) < 1e-9 and rel(runs["flat"][2], o["logLt"]) < 1e-9
         for ref in (o["A"], o2["A"], runs["flat"][0]):
