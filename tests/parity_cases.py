@@ -793,7 +793,7 @@ def check_islands(N, T, golden, scheme="stratified"):
     assert [d["run"] for d in out] == [0, 1, 2] and all(np.isfinite(d["output"]) for d in out)
 
 
-def check_permute_islands(N, golden):
+def check_permute_islands(N, golden, tol=0.3):
     """One model per island (SMC^2: one theta each) and theta-level resampling of whole
     filters (smc_samplers.py:319-361): identity and round trips are exact, copies carry
     particles, evidence and parameters, and every island goes on under its new theta."""
@@ -809,7 +809,7 @@ def check_permute_islands(N, golden):
     # the per-island parameters are really used: evidence against the exact Kalman one
     for k, s_ in enumerate(sig):
         ll, _ = orc.kalman_loglik(orc.ToySSM(s_), y)
-        assert abs(ref.logLts_islands[k] - ll) < 0.3, (k, ref.logLts_islands[k], ll)
+        assert abs(ref.logLts_islands[k] - ll) < tol, (k, ref.logLts_islands[k], ll)   # MC error + log-bias
     # identity, and a permutation undone before the next step: bit-identical runs
     a = mk()
     a.step_async(t0)

@@ -154,6 +154,7 @@ def test_filter_stepwise(golden):
 def test_device_history(golden):
     pc.check_device_history(golden)
     pc.check_device_history_philox(1500, 9, golden)
+    pc.check_device_history_philox(2048, 6, golden)             # two-level CDF path, history slots
 
 
 @pytest.mark.parametrize("N,sigmaY", [(3000, 0.2), (4096, 0.2), (1024, 0.2), (8192, 0.002),
@@ -177,6 +178,7 @@ def test_apf_and_guided_generic(golden):
 
 def test_permute_islands(golden):
     pc.check_permute_islands(3000, golden)
+    pc.check_permute_islands(2048, golden, tol=0.6)             # two-level path: partials travel too
 
 
 def test_collectors_and_history(golden):

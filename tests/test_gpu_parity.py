@@ -159,6 +159,7 @@ def test_filter_stepwise(golden):
 def test_device_history(golden):
     pc.check_device_history(golden)
     pc.check_device_history_philox(100000, 9, golden)
+    pc.check_device_history_philox(1 << 17, 9, golden)          # two-level CDF path, history slots
 
 
 @pytest.mark.parametrize("N,sigmaY", [(1 << 16, 0.2), (3000, 0.2), (1024, 0.2), (1 << 18, 0.002),
@@ -175,6 +176,7 @@ def test_islands(golden):
 
 def test_permute_islands(golden):
     pc.check_permute_islands(100000, golden)
+    pc.check_permute_islands(1 << 14, golden, tol=0.4)          # two-level path: partials travel too
 
 
 def test_collectors_and_history(golden):
