@@ -30,6 +30,9 @@
 //       t (core.py:355-359), the resample decision of step t+1 (core.py:181-183)
 //       and writes the 64-byte step record the next launches read.
 //   (k_propagate_mv in smc_filter_mv.h is the multivariate counterpart.)
+//   [k_reduce2] -> k_ancestors2 -> k_propagate<.., TAIL = false>: the same step on the
+//       two-level exact CDF (systematic / stratified, N = 2^k, 2..1024 tiles per island):
+//       no exchange inside any launch -- see "Two-level CDF" below.
 //
 // The time index lives in that device-resident record, so the same launches
 // -- or one hipGraph holding many of them -- serve every step.
