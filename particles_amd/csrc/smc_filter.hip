@@ -240,8 +240,6 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     // two-level CDF: closed-form offspring counts (N = 2^k, systematic / stratified), at most
     // 1024 tiles per island (4 partials per thread), at least 2 (below, the one-workgroup filter)
     f->two_level = !mv && !o->moments && a.log2N >= 0 && a.ntiles >= 2 &&
-                   (a.ntiles <= 1024 || getenv("SMC_TWO_LEVEL_MID")) &&   // one huge filter: a single
-                   // workgroup reducing > 1024 partials costs more than k_prepare's pass (C3: 93 vs 86 us)
                    (o->scheme == SMC_SYSTEMATIC || o->scheme == SMC_STRATIFIED) &&
                    !getenv("SMC_FLAT_CDF") && !getenv("SMC_FORCE_FUSED") && !getenv("SMC_FORCE_UNFUSED");
     // every workgroup reduces the partials itself while the launch is resident and an island has

@@ -992,25 +992,39 @@ __device__ __forceinline__ void f2_write_record(const FArgs& a, const int isl, c
     info[4] = r.rs;
     info[5] = a.aux ? a.aux[t] : 0.0;
 }
-// The same reduction by ONE workgroup for an island of any number of tiles: thread tid owns the
-// `per` consecutive partials from tid*per on (per = 4 up to 1024 tiles: then operation for
-// operation what f2_reduce does in every workgroup of k_ancestors2, hence the same bits).
-__device__ __forceinline__ F2Red f2_reduce_island(const FArgs& a, const int isl, const int per, double* smd)
+// The same reduction by ONE workgroup for an island of any number of tiles, in chunks of 1024
+// partials (thread tid: the four from 4*tid on of every chunk, coalesced 16-byte loads).  Up
+// to 1024 tiles that is operation for operation what f2_reduce does in every workgroup of
+// k_ancestors2, hence the same bits.
+__device__ __forceinline__ F2Red f2_reduce_island(const FArgs& a, const int isl, double* smd)
 {
     const i64 o = (i64)isl * a.nparts;
-    const i64 i0 = (i64)threadIdx.x * per;
+    const bool pvec = (a.nparts & 3) == 0;
+    const int nchunks = (a.nparts + 4 * SMC_BLOCK - 1) / (4 * SMC_BLOCK);
     F2Red r;
     double tm = -INFINITY;
-    for (int k = 0; k < per; ++k)
-        if (i0 + k < a.nparts) tm = k ? smc_max2(tm, a.pm[o + i0 + k]) : a.pm[o + i0 + k];
+    for (int c = 0; c < nchunks; ++c) {
+        double pm4[4];
+        f_load4<double>(a.pm + o, (i64)c * 4 * SMC_BLOCK + (i64)threadIdx.x * 4, a.nparts, pvec, -INFINITY, pm4);
+        double cm = pm4[0];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) cm = smc_max2(cm, pm4[k]);
+        tm = c ? smc_max2(tm, cm) : cm;
+    }
     r.m = smc_block_max(tm, smd);
     double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < per; ++k) {
-        if (i0 + k >= a.nparts) break;
-        const double pm = a.pm[o + i0 + k];
-        const double e = (pm > -INFINITY) ? smc_exp_nonpos(pm - r.m) : 0.0;
-        s1 = fma(a.ps[o + i0 + k], e, s1);
-        s2 = fma(a.pss[o + i0 + k], e * e, s2);
+    for (int c = 0; c < nchunks; ++c) {
+        const i64 i0 = (i64)c * 4 * SMC_BLOCK + (i64)threadIdx.x * 4;
+        double pm4[4], ps4[4], pss4[4];
+        f_load4<double>(a.pm + o, i0, a.nparts, pvec, -INFINITY, pm4);
+        f_load4<double>(a.ps + o, i0, a.nparts, pvec, 0.0, ps4);
+        f_load4<double>(a.pss + o, i0, a.nparts, pvec, 0.0, pss4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double e = (pm4[k] > -INFINITY) ? smc_exp_nonpos(pm4[k] - r.m) : 0.0;
+            s1 = fma(ps4[k], e, s1);
+            s2 = fma(pss4[k], e * e, s2);
+        }
     }
     smc_block_sum2(s1, s2, smd);
     r.s = s1;
@@ -1020,11 +1034,6 @@ __device__ __forceinline__ F2Red f2_reduce_island(const FArgs& a, const int isl,
     r.log_mean = r.bad ? NAN : r.m + log(s1 / (double)a.N);
     r.rs = r.bad ? NAN : 1.0 / s1;
     return r;
-}
-__device__ __forceinline__ int f2_per(const FArgs& a)
-{
-    const int per = (a.nparts + SMC_BLOCK - 1) / SMC_BLOCK;
-    return per < 4 ? 4 : per;
 }
 
 // k_reduce2(t): one workgroup per island reduces the partials of step t-1, decides step t,
@@ -1043,57 +1052,35 @@ k_reduce2(const FArgs av)
         return;
     }
     if (t == 0) return;
-    const int per = f2_per(a);
-    const i64 o = (i64)isl * a.nparts;
-    const i64 i0 = (i64)tid * per;
-    if (per == 4) {
-        // up to 1024 tiles: all twelve loads of a thread in flight at once, then exactly
-        // k_ancestors2's own reduction
-        double pm4[4], ps4[4], pss4[4], e4[4];
-        const bool pvec = (a.nparts & 3) == 0;
-        f_load4<double>(a.pm + o, i0, a.nparts, pvec, -INFINITY, pm4);
-        f_load4<double>(a.ps + o, i0, a.nparts, pvec, 0.0, ps4);
-        f_load4<double>(a.pss + o, i0, a.nparts, pvec, 0.0, pss4);
-        const F2Red r = f2_reduce(a, pm4, ps4, pss4, e4, smd);
-        const bool resample = r.ess < a.ess_thresh;
-        if (tid == 0) f2_write_record(a, isl, t, r, resample);
-        if (!resample) return;
-        u64 Q4[4], run = 0ull;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            Q4[k] = (i0 + k < a.nparts) ? smc_q62_w((ps4[k] * e4[k]) * r.rs) : 0ull;
-            run += Q4[k];
-        }
-        u64 tot;
-        u64 g = smc_block_exscan_u64(run, smu, tot);
-        u64* G = a.Qpre + (i64)isl * a.ntiles;
-        u64* Q = a.Q + (i64)isl * a.ntiles;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (i0 + k < a.nparts) { G[i0 + k] = g; Q[i0 + k] = Q4[k]; g += Q4[k]; }
-        return;
-    }
-    const F2Red r = f2_reduce_island(a, isl, per, smd);
+    const F2Red r = f2_reduce_island(a, isl, smd);
     const bool resample = r.ess < a.ess_thresh;
     if (tid == 0) f2_write_record(a, isl, t, r, resample);
     if (!resample) return;
-    u64 run = 0ull;
-    for (int k = 0; k < per && i0 + k < a.nparts; ++k) {
-        const double pm = a.pm[o + i0 + k];
-        const double e = (pm > -INFINITY) ? smc_exp_nonpos(pm - r.m) : 0.0;
-        run += smc_q62_w((a.ps[o + i0 + k] * e) * r.rs);
-    }
-    u64 tot;
-    u64 g = smc_block_exscan_u64(run, smu, tot);
+    // every tile's share and the shares before it, chunk by chunk (a running carry across chunks)
+    const i64 o = (i64)isl * a.nparts;
+    const bool pvec = (a.nparts & 3) == 0;
+    const int nchunks = (a.nparts + 4 * SMC_BLOCK - 1) / (4 * SMC_BLOCK);
     u64* G = a.Qpre + (i64)isl * a.ntiles;
     u64* Q = a.Q + (i64)isl * a.ntiles;
-    for (int k = 0; k < per && i0 + k < a.nparts; ++k) {
-        const double pm = a.pm[o + i0 + k];
-        const double e = (pm > -INFINITY) ? smc_exp_nonpos(pm - r.m) : 0.0;
-        const u64 Qk = smc_q62_w((a.ps[o + i0 + k] * e) * r.rs);
-        G[i0 + k] = g;
-        Q[i0 + k] = Qk;
-        g += Qk;
+    u64 carry = 0ull;
+    for (int c = 0; c < nchunks; ++c) {
+        const i64 i0 = (i64)c * 4 * SMC_BLOCK + (i64)tid * 4;
+        double pm4[4], ps4[4];
+        f_load4<double>(a.pm + o, i0, a.nparts, pvec, -INFINITY, pm4);
+        f_load4<double>(a.ps + o, i0, a.nparts, pvec, 0.0, ps4);
+        u64 Q4[4], run = 0ull;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double e = (pm4[k] > -INFINITY) ? smc_exp_nonpos(pm4[k] - r.m) : 0.0;
+            Q4[k] = (i0 + k < a.nparts) ? smc_q62_w((ps4[k] * e) * r.rs) : 0ull;
+            run += Q4[k];
+        }
+        u64 tot;
+        u64 g = carry + smc_block_exscan_u64(run, smu, tot);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (i0 + k < a.nparts) { G[i0 + k] = g; Q[i0 + k] = Q4[k]; g += Q4[k]; }
+        carry += tot;
     }
 }
 
@@ -1258,7 +1245,7 @@ k_flush2(const FArgs av)
     const int isl = (int)blockIdx.x;
     const i64 t = (i64)smc_uniform(smc_ldg(a.info2 + (i64)isl * INFO_STRIDE));       // steps done
     if (t <= 0) return;
-    const F2Red r = f2_reduce_island(a, isl, f2_per(a), smd);
+    const F2Red r = f2_reduce_island(a, isl, smd);
     if (threadIdx.x == 0) f2_write_row(a, isl, t - 1, r);
 }
 

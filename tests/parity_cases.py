@@ -537,6 +537,30 @@ def check_two_level_cdf(golden, monkeypatch, N=4096, T=20):
         assert not np.any((A >= 1024) & (A < 2048)) and np.all(W[A] > 0)
 
 
+def check_two_level_large(golden, monkeypatch, log2N=21, T=6):
+    """More than 1024 tiles per island: k_reduce2 walks the partials in chunks.  Production
+    (Philox) mode against the flat-Q62 path on the same counters: the same particle system up to
+    near-ties, and the exact-count switch changes nothing."""
+    g = golden("kalman_toy")
+    y = [np.atleast_1d(v) for v in np.squeeze(g["y"])][:T]
+    N = 1 << log2N
+    runs = {}
+    for name, env in (("two", {}), ("exact", {"SMC_EXACT_COUNTS": "1"}), ("flat", {"SMC_FLAT_CDF": "1"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        pf = pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y), N=N, seed=99, ESSrmin=1.0,
+                    resampling="systematic")
+        pf.run()
+        runs[name] = (np.array(pf.A), np.array(pf.X), list(pf.summaries.logLts), list(pf.summaries.rs_flags))
+        monkeypatch.undo()
+    assert all(runs["two"][3][1:]) and runs["two"][3] == runs["flat"][3]
+    assert np.array_equal(runs["two"][0], runs["exact"][0]) and np.array_equal(runs["two"][1], runs["exact"][1])
+    assert np.mean(runs["two"][0] == runs["flat"][0]) >= 0.999
+    assert rel(runs["two"][2], runs["flat"][2]) < 1e-6
+    ll, _ = orc.kalman_loglik(orc.ToySSM(0.2), y)
+    assert abs(runs["two"][2][-1] - ll) < 0.05
+
+
 def check_graph_replay_matches_direct(golden, N=5000):
     """The hipGraph path (24 steps per graph, slot parity baked into the nodes) against plain
     launches, entered at odd and even time indices and with adaptive resampling."""

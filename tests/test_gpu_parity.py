@@ -134,6 +134,7 @@ def test_filter_replay_power_of_two(golden, case, N):
 
 def test_two_level_cdf(golden, monkeypatch):
     pc.check_two_level_cdf(golden, monkeypatch)
+    pc.check_two_level_large(golden, monkeypatch)
 
 
 def test_graph_replay_matches_direct(golden):
