@@ -976,8 +976,6 @@ __device__ __forceinline__ void f2_write_row(const FArgs& a, const int isl, cons
     row[6] = r.rs;
 }
 
-// MID: k_reduce2 ran first (one workgroup per island did the reduction and left (G_b, Q_b) in
-// Qpre / Q and the record in `info`): grids too large for every workgroup to repeat it.
 // the decision of step t and what k_propagate(t) reads (one thread)
 __device__ __forceinline__ void f2_write_record(const FArgs& a, const int isl, const i64 t, const F2Red& r,
                                                 const bool resample)
@@ -1052,16 +1050,76 @@ k_reduce2(const FArgs av)
         return;
     }
     if (t == 0) return;
-    const F2Red r = f2_reduce_island(a, isl, smd);
-    const bool resample = r.ess < a.ess_thresh;
-    if (tid == 0) f2_write_record(a, isl, t, r, resample);
-    if (!resample) return;
-    // every tile's share and the shares before it, chunk by chunk (a running carry across chunks)
     const i64 o = (i64)isl * a.nparts;
     const bool pvec = (a.nparts & 3) == 0;
     const int nchunks = (a.nparts + 4 * SMC_BLOCK - 1) / (4 * SMC_BLOCK);
     u64* G = a.Qpre + (i64)isl * a.ntiles;
     u64* Q = a.Q + (i64)isl * a.ntiles;
+    if (nchunks <= 4) {
+        // up to 4096 tiles: every load of the workgroup in flight at once, the partials stay in
+        // registers across the three phases (same operations and order as f2_reduce_island)
+        double pm[4][4], ps[4][4], pss[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const i64 i0 = (i64)c * 4 * SMC_BLOCK + (i64)tid * 4;
+            f_load4<double>(a.pm + o, i0, a.nparts, pvec, -INFINITY, pm[c]);
+            f_load4<double>(a.ps + o, i0, a.nparts, pvec, 0.0, ps[c]);
+            f_load4<double>(a.pss + o, i0, a.nparts, pvec, 0.0, pss[c]);
+        }
+        F2Red r;
+        double tm = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            double cm = pm[c][0];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) cm = smc_max2(cm, pm[c][k]);
+            tm = c ? smc_max2(tm, cm) : cm;
+        }
+        r.m = smc_block_max(tm, smd);
+        double s1 = 0.0, s2 = 0.0, e[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                e[c][k] = (pm[c][k] > -INFINITY) ? smc_exp_nonpos(pm[c][k] - r.m) : 0.0;
+                s1 = fma(ps[c][k], e[c][k], s1);
+                s2 = fma(pss[c][k], e[c][k] * e[c][k], s2);
+            }
+        smc_block_sum2(s1, s2, smd);
+        r.s = s1;
+        r.ss = s2;
+        r.bad = !(r.m > -INFINITY) || !(r.m < INFINITY);
+        r.ess = r.bad ? NAN : (s1 * s1) / s2;
+        r.log_mean = r.bad ? NAN : r.m + log(s1 / (double)a.N);
+        r.rs = r.bad ? NAN : 1.0 / s1;
+        const bool resample = r.ess < a.ess_thresh;
+        if (tid == 0) f2_write_record(a, isl, t, r, resample);
+        if (!resample) return;
+        u64 carry = 0ull;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c >= nchunks) break;
+            const i64 i0 = (i64)c * 4 * SMC_BLOCK + (i64)tid * 4;
+            u64 Q4[4], run = 0ull;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                Q4[k] = (i0 + k < a.nparts) ? smc_q62_w((ps[c][k] * e[c][k]) * r.rs) : 0ull;
+                run += Q4[k];
+            }
+            u64 tot;
+            u64 g = carry + smc_block_exscan_u64(run, smu, tot);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (i0 + k < a.nparts) { G[i0 + k] = g; Q[i0 + k] = Q4[k]; g += Q4[k]; }
+            carry += tot;
+        }
+        return;
+    }
+    const F2Red r = f2_reduce_island(a, isl, smd);
+    const bool resample = r.ess < a.ess_thresh;
+    if (tid == 0) f2_write_record(a, isl, t, r, resample);
+    if (!resample) return;
+    // every tile's share and the shares before it, chunk by chunk (a running carry across chunks)
     u64 carry = 0ull;
     for (int c = 0; c < nchunks; ++c) {
         const i64 i0 = (i64)c * 4 * SMC_BLOCK + (i64)tid * 4;
@@ -1084,6 +1142,8 @@ k_reduce2(const FArgs av)
     }
 }
 
+// MID: k_reduce2 ran first (one workgroup per island did the reduction and left (G_b, Q_b) in
+// Qpre / Q and the record in `info`): grids too large for every workgroup to repeat it.
 template <bool SPEC, bool MID>
 __global__ void __launch_bounds__(SMC_BLOCK)
 k_ancestors2(const FArgs av)
