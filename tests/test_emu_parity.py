@@ -127,6 +127,15 @@ def test_filter_replay_power_of_two(golden, case, N):
     pc.check_filter_replay(golden, case, "toy", "bootstrap", T=20, N=N)
 
 
+def test_two_level_adaptive(golden):
+    """Steps that do not resample on the two-level path (evidence increments across them,
+    core.py:355-359) and the guided filter, N = 2^k."""
+    pf, o = pc.check_filter_replay(golden, "lg_adaptive", "lg_adaptive", "bootstrap", T=40, N=2048)
+    assert 0 < sum(o["rs_flag"]) < 39
+    pc.check_filter_replay(golden, "lg_guided", "lg_guided", "guided", T=30, N=4096)
+    pc.check_filter_replay(golden, "sv_stratified", "sv", "bootstrap", T=20, N=2048)
+
+
 def test_two_level_cdf(golden, monkeypatch):
     pc.check_two_level_cdf(golden, monkeypatch)
 
