@@ -537,6 +537,30 @@ def check_two_level_cdf(golden, monkeypatch, N=4096, T=20):
         assert not np.any((A >= 1024) & (A < 2048)) and np.all(W[A] > 0)
 
 
+def check_two_level_stepwise(N=2048):
+    """Two-level path: the summary row of a step is written by the next launch (or by the flush
+    that ends every smc_filter_step call) -- stepping one at a time with reads in between must
+    equal one run, for T = 1 included; StopIteration past T."""
+    rng = np.random.RandomState(3)
+    for T in (1, 2, 7):
+        y = [np.array([v]) for v in rng.standard_normal(T)]
+        mk = lambda: pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y), N=N, seed=5, ESSrmin=1.0)
+        a = mk()
+        a.run()
+        b = mk()
+        for t in range(T):
+            next(b)
+            assert b.summaries.ESSs[-1] == a.summaries.ESSs[t] and b.logLt == a.summaries.logLts[t]
+            assert abs(np.sum(b.W) - 1.0) < 1e-12
+        assert a.logLt == b.logLt and np.array_equal(a.X, b.X)
+        assert a.summaries.rs_flags == b.summaries.rs_flags == [False] + [True] * (T - 1)
+        try:
+            next(a)
+            raise AssertionError("no StopIteration past T")
+        except StopIteration:
+            pass
+
+
 def check_two_level_large(golden, monkeypatch, log2N=21, T=6):
     """More than 1024 tiles per island: k_reduce2 walks the partials in chunks.  Production
     (Philox) mode against the flat-Q62 path on the same counters: the same particle system up to
