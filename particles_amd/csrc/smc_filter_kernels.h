@@ -976,6 +976,75 @@ __device__ __forceinline__ void f2_write_row(const FArgs& a, const int isl, cons
     row[6] = r.rs;
 }
 
+// the sorted uniforms of step t (systematic: the one draw; stratified: read per offspring)
+__device__ __forceinline__ void f2_su(const FArgs& a, const int isl, const i64 t, SmcSu& su, u64& Us)
+{
+    su.scheme = a.scheme;
+    su.M = a.N;
+    su.dM = (double)a.N;
+    su.u = a.ut ? a.ut + ((i64)t * a.n_islands + isl) * a.ut_stride : nullptr;
+    su.u_sys = 0.0;
+    su.seed = a.seed;
+    su.t = (u32)t;
+    su.island = (u32)(a.island_offset + isl);
+    if (a.scheme == SMC_SYSTEMATIC_) {
+        if (su.u) {
+            su.u_sys = su.u[0];
+        } else {
+            u64 x0, x1;
+            smc_philox(0u, su.t, su.island, SMC_STREAM_RESAMPLE, su.seed, x0, x1);
+            su.u_sys = smc_u01_halfopen(x0);
+        }
+    }
+    Us = (u64)(su.u_sys * __longlong_as_double((long long)(1023 + 62 - a.log2N) << 52));
+}
+__device__ __forceinline__ i64 f2_count(const FArgs& a, const SmcSu& su, const u64 Us, const u64 C)
+{
+    return a.scheme == SMC_SYSTEMATIC_ ? smc_sys_count_pow2_fast(C, su.u_sys, Us, a.log2N, a.N)
+                                       : smc_strat_count_pow2(C, su, a.log2N, a.N);
+}
+// a tile's own integer CDF relative to its maximum mb: q_i = rint(exp(lw_i - mb) 2^50), the
+// exclusive prefix of this thread's four, the tile's total
+__device__ __forceinline__ u64 f2_local_cdf(const double (&l4)[4], const double mb, const i64 jt,
+                                            const i64 N, u64* smu, u64 (&q4)[4], u64& tb)
+{
+    u64 tsum = 0ull;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double e = (l4[i] > -INFINITY) ? smc_exp_nonpos(l4[i] - mb) : 0.0;
+        q4[i] = (jt + i < N) ? (u64)rint(e * 1125899906842624.0) : 0ull;          // 2^50
+        tsum += q4[i];
+    }
+    return smc_block_exscan_u64(tsum, smu, tb);
+}
+// first offspring ns[i] of the parents jt+i (ns[4]: of the next thread's first parent)
+__device__ __forceinline__ void f2_first_offspring(const FArgs& a, const SmcSu& su, const u64 Us,
+                                                   const u64 (&q4)[4], const u64 cex, const u64 tb,
+                                                   const u64 Gb, const u64 Qb, const i64 jt,
+                                                   i64 (&ns)[F_IPT + 1])
+{
+    const i64 N = a.N;
+    u64 c = cex;
+    // c Q_b / t_b in fp64 is within 2^12 of the exact quotient (< 2^63, three roundings): enough
+    // to decide the count unless the position falls within that band of a threshold
+    const double qscale = (double)Qb / (double)(tb ? tb : 1ull);
+#pragma unroll
+    for (int i = 0; i <= F_IPT; ++i) {
+        const i64 j = jt + i;
+        if (j == 0) ns[i] = 0;
+        else if (j >= N) ns[i] = N;
+        else {
+            u64 qh = (u64)((double)c * qscale);
+            qh = qh > Qb ? Qb : qh;
+            i64 cnt = a.exact_counts ? -1
+                                     : smc_count_pow2_band(Gb + qh, 1ull << 13, su, su.u_sys, Us, a.log2N, N);
+            if (cnt < 0) cnt = f2_count(a, su, Us, Gb + smc_muldiv_floor(c, Qb, tb));
+            ns[i] = cnt;
+        }
+        if (i < F_IPT) c += q4[i];
+    }
+}
+
 // the decision of step t and what k_propagate(t) reads (one thread)
 __device__ __forceinline__ void f2_write_record(const FArgs& a, const int isl, const i64 t, const F2Red& r,
                                                 const bool resample)
@@ -1194,15 +1263,8 @@ k_ancestors2(const FArgs av)
     // other tiles: done while the partials are still on their way; wasted only on the steps
     // that turn out not to resample)
     const double mb = smc_uniform(mb_raw);
-    u64 q4[4], tsum = 0ull;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const double e = (l4[i] > -INFINITY) ? smc_exp_nonpos(l4[i] - mb) : 0.0;
-        q4[i] = (jt + i < N) ? (u64)rint(e * 1125899906842624.0) : 0ull;          // 2^50
-        tsum += q4[i];
-    }
-    u64 tb;
-    const u64 cex = smc_block_exscan_u64(tsum, smu, tb);
+    u64 q4[4], tb;
+    const u64 cex = f2_local_cdf(l4, mb, jt, N, smu, q4, tb);
     F_STAMP_A(2);
     u64 Gb, Qb;
     if (MID) {
@@ -1230,50 +1292,11 @@ k_ancestors2(const FArgs av)
     }
     F_STAMP_A(4);
     // ---- first offspring of each parent
-    const u32 gisl = (u32)(a.island_offset + isl);
     SmcSu su;
-    su.scheme = a.scheme;
-    su.M = N;
-    su.dM = (double)N;
-    su.u = a.ut ? a.ut + ((i64)t * a.n_islands + isl) * a.ut_stride : nullptr;
-    su.u_sys = 0.0;
-    su.seed = a.seed;
-    su.t = (u32)t;
-    su.island = gisl;
-    if (a.scheme == SMC_SYSTEMATIC_) {
-        if (su.u) {
-            su.u_sys = su.u[0];
-        } else {
-            u64 x0, x1;
-            smc_philox(0u, su.t, su.island, SMC_STREAM_RESAMPLE, su.seed, x0, x1);
-            su.u_sys = smc_u01_halfopen(x0);
-        }
-    }
-    const u64 Us = (u64)(su.u_sys * __longlong_as_double((long long)(1023 + 62 - a.log2N) << 52));
+    u64 Us;
+    f2_su(a, isl, t, su, Us);
     i64 ns[F_IPT + 1];
-    u64 c = cex;
-    // c Q_b / t_b in fp64 is within 2^12 of the exact quotient (< 2^63, three roundings): enough
-    // to decide the count unless the position falls within that band of a threshold
-    const double qscale = (double)Qb / (double)(tb ? tb : 1ull);
-#pragma unroll
-    for (int i = 0; i <= F_IPT; ++i) {
-        const i64 j = jt + i;
-        if (j == 0) ns[i] = 0;
-        else if (j >= N) ns[i] = N;
-        else {
-            u64 qh = (u64)((double)c * qscale);
-            qh = qh > Qb ? Qb : qh;
-            i64 cnt = a.exact_counts ? -1
-                                     : smc_count_pow2_band(Gb + qh, 1ull << 13, su, su.u_sys, Us, a.log2N, N);
-            if (cnt < 0) {
-                const u64 C = Gb + smc_muldiv_floor(c, Qb, tb);
-                cnt = a.scheme == SMC_SYSTEMATIC_ ? smc_sys_count_pow2_fast(C, su.u_sys, Us, a.log2N, N)
-                                                  : smc_strat_count_pow2(C, su, a.log2N, N);
-            }
-            ns[i] = cnt;
-        }
-        if (i < F_IPT) c += q4[i];
-    }
+    f2_first_offspring(a, su, Us, q4, cex, tb, Gb, Qb, jt, ns);
     if (tid == 0) sn[0] = ns[0];
     if (tid == SMC_BLOCK - 1) sn[1] = ns[F_IPT];
     __syncthreads();
