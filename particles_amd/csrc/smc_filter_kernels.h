@@ -1262,6 +1262,9 @@ k_ancestors2(const FArgs av)
     // ---- the tile's own integer CDF, relative to the tile's maximum (needs nothing from the
     // other tiles: done while the partials are still on their way; wasted only on the steps
     // that turn out not to resample)
+    SmcSu su;                                                  // (the step's uniform: a Philox call
+    u64 Us;                                                    //  in the shadow of the loads)
+    f2_su(a, isl, t, su, Us);
     const double mb = smc_uniform(mb_raw);
     u64 q4[4], tb;
     const u64 cex = f2_local_cdf(l4, mb, jt, N, smu, q4, tb);
@@ -1292,9 +1295,6 @@ k_ancestors2(const FArgs av)
     }
     F_STAMP_A(4);
     // ---- first offspring of each parent
-    SmcSu su;
-    u64 Us;
-    f2_su(a, isl, t, su, Us);
     i64 ns[F_IPT + 1];
     f2_first_offspring(a, su, Us, q4, cex, tb, Gb, Qb, jt, ns);
     if (tid == 0) sn[0] = ns[0];
