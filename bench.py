@@ -112,7 +112,10 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
                      "--nproc-per-node %d" % (a.gpus, a.gpus))
         a.gpus = world
-    os.environ["SMC_HIP_DEVICE"] = str(local_rank)
+    # (functional test of the multi-rank path on a box with fewer GPUs than ranks:
+    #  SMC_BENCH_NGPU=1 lets all ranks share device 0; RCCL then refuses and the gather uses gloo)
+    ngpu = int(os.environ.get("SMC_BENCH_NGPU", "0"))
+    os.environ["SMC_HIP_DEVICE"] = str(local_rank % ngpu if ngpu > 0 else local_rank)
 
     import particles_amd as pa
     from particles_amd import _lib, kalman
