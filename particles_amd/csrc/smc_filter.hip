@@ -277,6 +277,9 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     a.info = (double*)(base + oInfo);
     a.info2 = (double*)(base + oInfo2);
     a.exact_counts = getenv("SMC_EXACT_COUNTS") ? 1 : 0;
+    // streaming stores pay while a launch is short (its end-of-kernel write-back shows): C2 +8 %;
+    // on the large grids they cost 2 % (C5)
+    a.nt = ((i64)a.ntiles * (i64)M <= F_DIRECT_PREFIX_MAX && !mv && !getenv("SMC_NO_NT")) ? 1 : 0;
     a.su = (double*)(base + oSu);
     a.E = (u64*)(base + oE);
     f->tmp = (double*)(base + oTmp);

@@ -81,6 +81,7 @@ struct FArgs {
     int nmb;
     const double* aux;     // (T,) per-step scalar of the transition (GORDON: d cos(e (t-1))) or null
     double* info;          // (n_islands, INFO_STRIDE) record of the step being run
+    int nt;                // bulk stores of X, lw, A as streaming (`nt`) stores: resident launches
     int exact_counts;      // two-level path, tests: always form c Q_b / t_b exactly (no fp64 band shortcut)
     double* info2;         // two-level path: (n_islands, INFO_STRIDE) [0] = t for k_ancestors2 (written by
                            // k_propagate's workgroup 0; `info` then is written by k_ancestors2's)
@@ -638,7 +639,8 @@ k_ancestors(const FArgs av)
                      [&](i64 n0, const bool (&ok)[4], const i64 (&a4)[4]) {                // core.py:329
                          const u32 a32[4] = {(u32)a4[0], (u32)a4[1], (u32)a4[2], (u32)a4[3]};
                          if (vec && ok[0] && ok[3]) {
-                             smc_st4g(A + n0, a32);
+                             if (a.nt) smc_st4g_nt(A + n0, a32);
+                             else smc_st4g(A + n0, a32);
                          } else {
 #pragma unroll
                              for (int i = 0; i < 4; ++i)
@@ -863,8 +865,13 @@ k_propagate(const FArgs av)
         if (full) {
 #pragma unroll
             for (int k = 0; k < OPT; k += 2) {
-                smc_st2g(Xn + n0 + k, xn[k], xn[k + 1]);
-                smc_st2g(lwn + n0 + k, lw[k], lw[k + 1]);
+                if (a.nt) {
+                    smc_st2g_nt(Xn + n0 + k, xn[k], xn[k + 1]);
+                    smc_st2g_nt(lwn + n0 + k, lw[k], lw[k + 1]);
+                } else {
+                    smc_st2g(Xn + n0 + k, xn[k], xn[k + 1]);
+                    smc_st2g(lwn + n0 + k, lw[k], lw[k + 1]);
+                }
             }
         } else {
 #pragma unroll
@@ -1307,7 +1314,8 @@ k_ancestors2(const FArgs av)
                      [&](i64 n0, const bool (&ok)[4], const i64 (&a4)[4]) {                // core.py:329
                          const u32 a32[4] = {(u32)a4[0], (u32)a4[1], (u32)a4[2], (u32)a4[3]};
                          if (vec && ok[0] && ok[3]) {
-                             smc_st4g(A + n0, a32);
+                             if (a.nt) smc_st4g_nt(A + n0, a32);
+                             else smc_st4g(A + n0, a32);
                          } else {
 #pragma unroll
                              for (int i = 0; i < 4; ++i)
