@@ -537,6 +537,32 @@ def check_two_level_cdf(golden, monkeypatch, N=4096, T=20):
         assert not np.any((A >= 1024) & (A < 2048)) and np.all(W[A] > 0)
 
 
+def check_describe():
+    """smc_filter_describe: which kernels a filter launches (the path selection DESIGN.md states)."""
+    y = [np.array([0.1 * k]) for k in range(4)]
+
+    def kernels(N, scheme="systematic", n_islands=1, model=None, **kw):
+        fk = ssm.Bootstrap(ssm=model or kalman.ToySSM(0.2), data=y)
+        pf = pa.SMC(fk=fk, N=N, resampling=scheme, n_islands=n_islands, seed=1, **kw)
+        buf = ctypes.create_string_buffer(256)
+        _lib.check(_lib.lib().smc_filter_describe(pf._f, buf, 256))
+        return buf.value.decode()
+
+    assert kernels(1000) == "k_filter_small"
+    assert kernels(1 << 12) == "k_ancestors2+k_propagate"                      # two-level, resident
+    assert kernels(1 << 12, "stratified") == "k_ancestors2+k_propagate"
+    assert kernels(1 << 12, n_islands=600) == "k_reduce2+k_ancestors2+k_propagate"   # 2400 workgroups
+    assert kernels(3000) == "k_ancestors<fused>+k_propagate"                   # N not a power of two
+    assert kernels(1 << 12, "multinomial") == \
+        "k_f_spacing_sums+k_f_spacing_write+k_ancestors<fused>+k_propagate"
+    mv = kalman.MVLinearGauss_Guarniero_etal(alpha=0.4, dx=4)
+    ymv = [np.zeros((1, 4)) for _ in range(4)]
+    pf = pa.SMC(fk=ssm.Bootstrap(ssm=mv, data=ymv), N=1 << 12, seed=1)
+    buf = ctypes.create_string_buffer(256)
+    _lib.check(_lib.lib().smc_filter_describe(pf._f, buf, 256))
+    assert buf.value.decode() == "k_ancestors<fused>+k_propagate_mv"
+
+
 def check_two_level_stepwise(N=2048):
     """Two-level path: the summary row of a step is written by the next launch (or by the flush
     that ends every smc_filter_step call) -- stepping one at a time with reads in between must

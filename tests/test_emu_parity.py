@@ -137,6 +137,7 @@ def test_two_level_adaptive(golden):
 
 
 def test_two_level_cdf(golden, monkeypatch):
+    pc.check_describe()
     pc.check_two_level_stepwise()
     pc.check_two_level_cdf(golden, monkeypatch)
 

@@ -142,6 +142,7 @@ def test_two_level_adaptive(golden):
 
 
 def test_two_level_cdf(golden, monkeypatch):
+    pc.check_describe()
     pc.check_two_level_stepwise()
     pc.check_two_level_cdf(golden, monkeypatch)
     pc.check_two_level_large(golden, monkeypatch)
