@@ -28,7 +28,21 @@ struct SmcSu {
     double u_sys;      // systematic: the single uniform
     u64 seed;          // Philox (u == nullptr, stratified)
     u32 t, island;
+    // stratified, Philox: the last pair of uniforms drawn (consecutive offspring share a call)
+    mutable u64 c_pair = ~0ull, c_a = 0ull, c_b = 0ull;
 };
+
+// the nc-th uniform of the stratified draw
+__device__ __forceinline__ double smc_strat_u(const SmcSu& s, u64 nc)
+{
+    if (s.u) return s.u[nc];
+    const u64 pr = nc >> 1;
+    if (pr != s.c_pair) {
+        smc_philox((u32)pr, s.t, s.island, SMC_STREAM_RESAMPLE, s.seed, s.c_a, s.c_b);
+        s.c_pair = pr;
+    }
+    return smc_u01_halfopen((nc & 1) ? s.c_b : s.c_a);
+}
 
 // su_n in fp64 exactly as the reference forms it: (u + n) / M with a true
 // division (resampling.py:602, :609), or the n-th sorted uniform (:536-537).
@@ -160,14 +174,7 @@ __device__ __forceinline__ i64 smc_strat_count_pow2(u64 C, const SmcSu& s, int k
     const int sh = 62 - k;
     const u64 nc = C >> sh;
     if (nc >= (u64)M) return M;
-    double un;
-    if (s.u) {
-        un = s.u[nc];
-    } else {
-        u64 a, b;
-        smc_philox((u32)(nc >> 1), s.t, s.island, SMC_STREAM_RESAMPLE, s.seed, a, b);
-        un = smc_u01_halfopen((nc & 1) ? b : a);
-    }
+    const double un = smc_strat_u(s, nc);
     const double scale = __longlong_as_double((long long)(1023 + sh) << 52);   // 2^sh
     const u64 T = (u64)ceil((un + (double)(i64)nc) * scale);
     return (i64)nc + (T <= C ? 1 : 0);
@@ -190,14 +197,7 @@ __device__ __forceinline__ i64 smc_count_pow2_band(u64 Ch, u64 E, const SmcSu& s
         if (frac + 1024ull + E <= Us) return (i64)nc;
         return -1;
     }
-    double un;                                                  // stratified: the nc-th uniform
-    if (s.u) {
-        un = s.u[nc];
-    } else {
-        u64 a, b;
-        smc_philox((u32)(nc >> 1), s.t, s.island, SMC_STREAM_RESAMPLE, s.seed, a, b);
-        un = smc_u01_halfopen((nc & 1) ? b : a);
-    }
+    const double un = smc_strat_u(s, nc);                       // stratified: the nc-th uniform
     const double scale = __longlong_as_double((long long)(1023 + sh) << 52);   // 2^sh
     const u64 T = (u64)ceil((un + (double)(i64)nc) * scale);
     if (T + E <= Ch) return (i64)nc + 1;
