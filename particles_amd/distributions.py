@@ -101,19 +101,15 @@ class Normal(LocScaleDist):
         check(lib().smc_normal_logpdf(out.ctx.h, xd.ptr, xs, loc.ptr, ls, sc.ptr, ss, N, out.ptr))
         return out if (d0 or d1 or d2 or _lib.RESIDENT[0]) else out.get()
 
-
-def _normal_ppf(self, u):
-    """scipy.stats.norm.ppf(u, loc, scale) = ndtri(u) * scale + loc  (:276-277)."""
-    N = _bsize(self.loc, self.scale, u)
-    ud, us, d0 = _strided(u, N)
-    loc, ls, d1 = _strided(self.loc, N)
-    sc, ss, d2 = _strided(self.scale, N)
-    out = DeviceArray((N,))
-    check(lib().smc_normal_ppf(out.ctx.h, ud.ptr, us, loc.ptr, ls, sc.ptr, ss, N, out.ptr))
-    return out if (d0 or d1 or d2 or _lib.RESIDENT[0]) else out.get()
-
-
-Normal.ppf = _normal_ppf
+    def ppf(self, u):
+        """scipy.stats.norm.ppf(u, loc, scale) = ndtri(u) * scale + loc  (:276-277)."""
+        N = _bsize(self.loc, self.scale, u)
+        ud, us, d0 = _strided(u, N)
+        loc, ls, d1 = _strided(self.loc, N)
+        sc, ss, d2 = _strided(self.scale, N)
+        out = DeviceArray((N,))
+        check(lib().smc_normal_ppf(out.ctx.h, ud.ptr, us, loc.ptr, ls, sc.ptr, ss, N, out.ptr))
+        return out if (d0 or d1 or d2 or _lib.RESIDENT[0]) else out.get()
 
 
 class Poisson(ProbDist):
