@@ -310,8 +310,7 @@ extern "C" int smc_inverse_cdf(smc_ctx* ctx, const double* su_dev, const double*
 {
     SMC_REQUIRE(ctx && su_dev && W && A, "null argument");
     SMC_REQUIRE(M > 0 && N > 0, "M and N must be positive");
-    SmcSu su;
-    memset(&su, 0, sizeof su);
+    SmcSu su{};                  // zeros, and the "no cached pair" mark of its default initialiser
     su.scheme = SMC_MULTINOMIAL_;       // "sorted uniforms given in memory"
     su.M = M;
     su.dM = (double)M;
@@ -865,8 +864,7 @@ extern "C" int smc_resample(smc_ctx* ctx, int scheme, const double* W, int64_t N
         smc_set_error("%d is not a valid resampling scheme", scheme);  // resampling.py:477-481
         return SMC_ERR_SCHEME;
     }
-    SmcSu su;
-    memset(&su, 0, sizeof su);
+    SmcSu su{};                  // zeros, and the "no cached pair" mark of its default initialiser
     su.scheme = scheme;
     su.M = M;
     su.dM = (double)M;

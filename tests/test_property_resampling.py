@@ -63,3 +63,29 @@ def test_weights_equal_oracle(c):
     d, o = rs.Weights(lw=lw.copy()), orc.Weights(lw=lw.copy())
     assert np.allclose(d.W, o.W, rtol=1e-12, atol=0.0)
     assert abs(d.ESS / o.ESS - 1.0) < 1e-11 and abs(d.log_mean - o.log_mean) < 1e-11 * max(1.0, abs(o.log_mean))
+
+
+@st.composite
+def case2(draw):
+    n = draw(st.sampled_from([2048, 4096]))
+    return weights(draw, n), draw(st.integers(0, 2 ** 31 - 1))
+
+
+@settings(max_examples=25, deadline=None, suppress_health_check=list(HealthCheck))
+@given(case2())
+def test_two_level_contract_matches_sequential_cdf(c):
+    """The two-level exact CDF of the fused step loop (oracle restatement of k_ancestors2's
+    contract) against the reference's sequential fp64 CDF: same ancestors except within
+    rounding distance of a CDF step; never a zero-weight parent; monotone."""
+    W, seed = c
+    rng = np.random.default_rng(seed)
+    with np.errstate(divide="ignore"):
+        lw = np.log(W) + rng.normal() * 50.0              # the contract takes log-weights, any offset
+    for su in ((rng.random() + np.arange(W.size)) / W.size,
+               (rng.random(W.size) + np.arange(W.size)) / W.size):
+        A = orc.inverse_cdf_2level(su, lw)
+        ref = orc.inverse_cdf(su, W)
+        assert np.all(np.diff(A) >= 0) and A.min() >= 0 and A.max() < W.size
+        assert np.all(W[A] > 0.0)
+        assert np.mean(A == ref) >= 0.995, np.mean(A == ref)
+        assert np.max(np.abs(A - ref)) <= 2 or np.mean(A == ref) >= 0.999
