@@ -245,6 +245,9 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     // every workgroup reduces the partials itself while the launch is resident and an island has
     // at most 1024 tiles (4 per thread); otherwise one workgroup per island does it first
     f->two_level_mid = f->two_level && (!f->fused || a.ntiles > 1024 || getenv("SMC_TWO_LEVEL_MID"));
+    const bool heavy_list = !mv && !getenv("SMC_NO_HEAVY");
+    const size_t oHcnt = carve(heavy_list ? M * 2 * sizeof(unsigned) : 8);
+    const size_t oHlist = carve(heavy_list ? M * 2 * F_HMAX * 3 * 8 : 8);
     const size_t oSu = carve(need_su ? M * N * 8 : 8);
     const size_t oE = carve(need_su ? M * a.ntiles1 * 8 : 8);
     const size_t oTmp = carve(N * dxm * 8);
@@ -276,6 +279,11 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     a.spart = (double*)(base + oSpart);
     a.info = (double*)(base + oInfo);
     a.info2 = (double*)(base + oInfo2);
+    if (heavy_list) {
+        a.hcnt = (unsigned*)(base + oHcnt);
+        a.hlist = (i64*)(base + oHlist);
+        SMC_HIP_CHECK(hipMemsetAsync(a.hcnt, 0, M * 2 * sizeof(unsigned), ctx->stream));
+    }
     a.exact_counts = getenv("SMC_EXACT_COUNTS") ? 1 : 0;
     // streaming stores pay while a launch is short (its end-of-kernel write-back shows): C2 +8 %;
     // on the large grids they cost 2 % (C5)

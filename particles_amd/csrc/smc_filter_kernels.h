@@ -45,6 +45,8 @@
 #include "smc_internal.h"
 #include "smc_resample.h"
 
+#define F_HMAX 64      /* heavy parents registered per island and step */
+#define F_HLOC 8       /* ... per tile */
 #define F_IPT 4
 #define F_TILE (SMC_BLOCK * F_IPT)
 #define F_PASS (SMC_BLOCK * 4)      /* offspring per pass: 4 per thread */
@@ -81,6 +83,11 @@ struct FArgs {
     int nmb;
     const double* aux;     // (T,) per-step scalar of the transition (GORDON: d cos(e (t-1))) or null
     double* info;          // (n_islands, INFO_STRIDE) record of the step being run
+    // heavy parents (>= 2048 offspring: at least one whole 1024-block of offspring is theirs):
+    // registered by the ancestors kernel, which then skips those blocks; k_propagate fills them
+    unsigned* hcnt;        // (n_islands, 2) entries per parity of t, or null (feature off)
+    i64* hlist;            // (n_islands, 2, F_HMAX, 3): first offspring, one past the last (both
+                           // multiples of 1024), parent
     int nt;                // bulk stores of X, lw, A as streaming (`nt`) stores: resident launches
     int exact_counts;      // two-level path, tests: always form c Q_b / t_b exactly (no fp64 band shortcut)
     double* info2;         // two-level path: (n_islands, INFO_STRIDE) [0] = t for k_ancestors2 (written by
@@ -416,14 +423,53 @@ k_f_spacing_write(const FArgs av)
 // The scatter passes: given the first offspring ns[i] of this thread's 4 parents (ns[4]: of the
 // next thread's first), every parent writes its index at its first offspring's slot of the
 // pass (LDS) and a running maximum over the slots gives each offspring its parent.
+// A parent with >= 2048 offspring owns whole 1024-blocks of them: it is registered (hlist) and
+// the passes that lie inside those blocks are skipped -- k_propagate's workgroup of such a block
+// takes the parent from the list and writes the block's ancestors itself, so a collapsed weight
+// vector costs the tile's workgroup a few passes instead of N / 1024.
 template <int BS = SMC_BLOCK, class Sink>
-__device__ __forceinline__ void f_scatter_passes(const i64 j0, const i64 n_lo, const i64 n_hi,
+__device__ __forceinline__ void f_scatter_passes(const FArgs& a, const int isl, const i64 t, const i64 jt,
+                                                 const i64 j0, const i64 n_lo, const i64 n_hi,
                                                  const i64 (&ns)[F_IPT + 1], u32* sP, u32* smx,
                                                  Sink&& sink)
 {
     constexpr int PASS = BS * 4, NW = BS / 64;
     const int tid = (int)threadIdx.x;
+    __shared__ i64 sH[2 * F_HLOC];
+    __shared__ unsigned sHn;
+    const bool heavy = a.hcnt && (n_hi - n_lo >= 2 * (i64)F_TILE);        // (same in every thread)
+    if (heavy) {
+        if (tid == 0) sHn = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < F_IPT; ++i) {
+            const i64 bs = ((ns[i] + F_TILE - 1) / F_TILE) * F_TILE, be = (ns[i + 1] / F_TILE) * F_TILE;
+            if (ns[i + 1] - ns[i] >= 2 * (i64)F_TILE && be > bs) {
+                const int par = (int)(t & 1);
+                const unsigned g = atomicAdd(a.hcnt + (i64)isl * 2 + par, 1u);
+                if (g < F_HMAX) {
+                    const unsigned k = atomicAdd(&sHn, 1u);
+                    if (k < F_HLOC) {
+                        i64* e = a.hlist + (((i64)isl * 2 + par) * F_HMAX + g) * 3;
+                        e[0] = bs; e[1] = be; e[2] = jt + i;
+                        sH[2 * k] = bs; sH[2 * k + 1] = be;
+                    } else {                       // no room here: the entry stays harmless (empty)
+                        i64* e = a.hlist + (((i64)isl * 2 + par) * F_HMAX + g) * 3;
+                        e[0] = 0; e[1] = 0; e[2] = 0;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const int nH = heavy ? (int)(sHn < F_HLOC ? sHn : F_HLOC) : 0;
     for (i64 pb = n_lo & ~(i64)3; pb < n_hi; pb += PASS) {
+        if (nH) {                                  // the whole pass inside a registered parent's blocks?
+            const i64 w_lo = pb > n_lo ? pb : n_lo, w_hi = pb + PASS < n_hi ? pb + PASS : n_hi;
+            bool skip = false;
+            for (int k = 0; k < nH; ++k) skip = skip || (sH[2 * k] <= w_lo && w_hi <= sH[2 * k + 1]);
+            if (skip) continue;
+        }
         const i64 n0 = pb + (i64)tid * 4;
         bool ok[4];
         i64 a4[4];
@@ -510,7 +556,7 @@ __device__ __forceinline__ void f_tile_offspring(const FArgs& a, const int isl, 
         __syncthreads();
         n_lo = sn[0];
         n_hi = sn[1];
-        f_scatter_passes<BS>(j0, n_lo, n_hi, ns, sP, smx, sink);
+        f_scatter_passes<BS>(a, isl, t, jt, j0, n_lo, n_hi, ns, sP, smx, sink);
         return;
     } else {
         u64 c = cex;
@@ -781,6 +827,8 @@ k_propagate(const FArgs av)
     const bool full = vec && n0 + OPT <= N;
     const double r0 = smc_ldg(info), r1 = smc_ldg(info + 1), r2 = smc_ldg(info + 2),
                  r5 = smc_ldg(info + 5);
+    unsigned nh0 = 0u, nh1 = 0u;                   // registered heavy parents, either parity of t
+    if (a.hcnt) { nh0 = smc_ldg(a.hcnt + (i64)isl * 2); nh1 = smc_ldg(a.hcnt + (i64)isl * 2 + 1); }
     // SPEC: slots from a.par (kernarg): the ancestor indices are requested right behind the
     // step record, and the gather X_{t-1}[A] can leave as soon as they are back -- without
     // waiting for the record (read in vain on the steps that do not resample)
@@ -810,6 +858,19 @@ k_propagate(const FArgs av)
     const double* zt = a.zt ? a.zt + ((i64)t * a.n_islands + isl) * N : nullptr;
     const bool first = (t == 0);
     const bool resample = !first && smc_uniform(r1) != 0.0;
+    // ---- is this block of offspring wholly a registered heavy parent's?  Then that parent is
+    // everybody's ancestor here and the block's A entries are ours to write
+    i64 heavy_parent = -1;
+    {
+        const unsigned nh = smc_uniform((t & 1) ? nh1 : nh0);
+        if (resample && nh) {
+            const i64 w0 = (i64)b * SMC_BLOCK * OPT;
+            const i64* hl = a.hlist + ((i64)isl * 2 + (t & 1)) * F_HMAX * 3;
+            for (unsigned e = 0; e < nh && e < F_HMAX; ++e)
+                if (hl[3 * e] <= w0 && w0 + (i64)SMC_BLOCK * OPT <= hl[3 * e + 1]) heavy_parent = hl[3 * e + 2];
+        }
+        if (a.hcnt && b == 0 && tid == 0) a.hcnt[(i64)isl * 2 + ((t & 1) ^ 1)] = 0u;    // next step's list
+    }
 
     double lw[OPT];
 #pragma unroll
@@ -848,7 +909,16 @@ k_propagate(const FArgs av)
                 smc_normal_pair(a.seed, (u32)((n0 + k) >> 1), (u32)t, gisl, SMC_STREAM_NORMAL,
                                 z[k], z[k + 1]);
         }
-        if (resample) {
+        if (resample && heavy_parent >= 0) {
+            const double xh = smc_ldg(Xo + heavy_parent);
+            u32* Aw = f_A(a, t) + (i64)isl * N;
+#pragma unroll
+            for (int k = 0; k < OPT; ++k) {
+                xp[k] = xh;
+                lwp[k] = 0.0;
+                if (n0 + k < N) Aw[n0 + k] = (u32)heavy_parent;
+            }
+        } else if (resample) {
 #pragma unroll
             for (int k = 0; k < OPT; ++k) { xp[k] = SPEC ? xg[k] : smc_ldg(Xo + an[k]); lwp[k] = 0.0; }    // core.py:332
         }
@@ -1310,7 +1380,7 @@ k_ancestors2(const FArgs av)
     const i64 n_lo = sn[0], n_hi = sn[1];
     F_STAMP_A(5);
     u32* A = f_A(a, t) + (i64)isl * N;
-    f_scatter_passes(j0, n_lo, n_hi, ns, sP, smx,
+    f_scatter_passes(a, isl, t, jt, j0, n_lo, n_hi, ns, sP, smx,
                      [&](i64 n0, const bool (&ok)[4], const i64 (&a4)[4]) {                // core.py:329
                          const u32 a32[4] = {(u32)a4[0], (u32)a4[1], (u32)a4[2], (u32)a4[3]};
                          if (vec && ok[0] && ok[3]) {

@@ -537,6 +537,38 @@ def check_two_level_cdf(golden, monkeypatch, N=4096, T=20):
         assert not np.any((A >= 1024) & (A < 2048)) and np.all(W[A] > 0)
 
 
+def check_heavy_parents(monkeypatch, N=8192, T=12):
+    """Collapsed / peaky weights: parents with >= 2048 offspring are registered by the ancestors
+    kernel, which skips the blocks of offspring that are wholly theirs; k_propagate fills those.
+    Same particles, ancestors and evidence as with the feature off, on the two-level and the flat
+    path, N a power of two or not."""
+    rng = np.random.RandomState(11)
+    y = [np.array([v]) for v in np.cumsum(rng.standard_normal(T))]
+    for sig, n in ((1e-6, N), (2e-3, N), (1e-6, N + 904)):
+        mk = lambda: pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(sig), data=y), N=n, seed=4, ESSrmin=1.0)
+        for flat in (False, True):
+            runs = []
+            for off in (False, True):
+                if flat:
+                    monkeypatch.setenv("SMC_FLAT_CDF", "1")
+                if off:
+                    monkeypatch.setenv("SMC_NO_HEAVY", "1")
+                pf = mk()
+                hist = []
+                for _ in range(T):
+                    next(pf)
+                    hist.append(np.array(pf.A) if pf.rs_flag else None)
+                runs.append((hist, np.array(pf.X), list(pf.summaries.logLts), list(pf.summaries.ESSs)))
+                monkeypatch.undo()
+            for a_on, a_off in zip(runs[0][0], runs[1][0]):
+                assert (a_on is None) == (a_off is None)
+                assert a_on is None or np.array_equal(a_on, a_off)
+            assert np.array_equal(runs[0][1], runs[1][1]) and runs[0][2] == runs[1][2]
+            if sig == 1e-6:                      # really collapsed: some step has one dominant parent
+                cnt = max(np.bincount(a).max() for a in runs[0][0] if a is not None)
+                assert cnt >= n // 2
+
+
 def check_describe():
     """smc_filter_describe: which kernels a filter launches (the path selection DESIGN.md states)."""
     y = [np.array([0.1 * k]) for k in range(4)]

@@ -136,6 +136,10 @@ def test_two_level_adaptive(golden):
     pc.check_filter_replay(golden, "sv_stratified", "sv", "bootstrap", T=20, N=2048)
 
 
+def test_heavy_parents(monkeypatch):
+    pc.check_heavy_parents(monkeypatch)
+
+
 def test_two_level_cdf(golden, monkeypatch):
     pc.check_describe()
     pc.check_two_level_stepwise()
