@@ -466,9 +466,13 @@ __device__ __forceinline__ void f_scatter_passes(const FArgs& a, const int isl, 
     for (i64 pb = n_lo & ~(i64)3; pb < n_hi; pb += PASS) {
         if (nH) {                                  // the whole pass inside a registered parent's blocks?
             const i64 w_lo = pb > n_lo ? pb : n_lo, w_hi = pb + PASS < n_hi ? pb + PASS : n_hi;
-            bool skip = false;
-            for (int k = 0; k < nH; ++k) skip = skip || (sH[2 * k] <= w_lo && w_hi <= sH[2 * k + 1]);
-            if (skip) continue;
+            i64 jump = 0;                          // passes to leave out, this one included
+            for (int k = 0; k < nH; ++k)
+                if (sH[2 * k] <= w_lo && w_hi <= sH[2 * k + 1]) {
+                    const i64 whole = (sH[2 * k + 1] - pb) / PASS;      // passes that end inside the blocks
+                    jump = whole > 1 ? whole : 1;
+                }
+            if (jump) { pb += (jump - 1) * PASS; continue; }
         }
         const i64 n0 = pb + (i64)tid * 4;
         bool ok[4];
