@@ -423,6 +423,34 @@ k_f_spacing_write(const FArgs av)
 // The scatter passes: given the first offspring ns[i] of this thread's 4 parents (ns[4]: of the
 // next thread's first), every parent writes its index at its first offspring's slot of the
 // pass (LDS) and a running maximum over the slots gives each offspring its parent.
+// (out of line: the tiles that call it are rare, the ones that do not keep their registers)
+__device__ __attribute__((noinline)) int f_register_heavy(unsigned* hcnt, i64* hlist, const i64 jt,
+                                                           const i64 n0, const i64 n1, const i64 n2,
+                                                           const i64 n3, const i64 n4, i64* sH, unsigned* sHn)
+{
+    const i64 ns[F_IPT + 1] = {n0, n1, n2, n3, n4};
+    if (threadIdx.x == 0) *sHn = 0u;
+    __syncthreads();
+    for (int i = 0; i < F_IPT; ++i) {
+        const i64 bs = ((ns[i] + F_TILE - 1) / F_TILE) * F_TILE, be = (ns[i + 1] / F_TILE) * F_TILE;
+        if (ns[i + 1] - ns[i] >= 2 * (i64)F_TILE && be > bs) {
+            const unsigned g = atomicAdd(hcnt, 1u);
+            if (g < F_HMAX) {
+                const unsigned k = atomicAdd(sHn, 1u);
+                i64* e = hlist + (i64)g * 3;
+                if (k < F_HLOC) {
+                    e[0] = bs; e[1] = be; e[2] = jt + i;
+                    sH[2 * k] = bs; sH[2 * k + 1] = be;
+                } else {                           // no room here: the entry stays harmless (empty)
+                    e[0] = 0; e[1] = 0; e[2] = 0;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    return (int)(*sHn < F_HLOC ? *sHn : F_HLOC);
+}
+
 // A parent with >= 2048 offspring owns whole 1024-blocks of them: it is registered (hlist) and
 // the passes that lie inside those blocks are skipped -- k_propagate's workgroup of such a block
 // takes the parent from the list and writes the block's ancestors itself, so a collapsed weight
@@ -438,31 +466,10 @@ __device__ __forceinline__ void f_scatter_passes(const FArgs& a, const int isl, 
     __shared__ i64 sH[2 * F_HLOC];
     __shared__ unsigned sHn;
     const bool heavy = a.hcnt && (n_hi - n_lo >= 2 * (i64)F_TILE);        // (same in every thread)
-    if (heavy) {
-        if (tid == 0) sHn = 0u;
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < F_IPT; ++i) {
-            const i64 bs = ((ns[i] + F_TILE - 1) / F_TILE) * F_TILE, be = (ns[i + 1] / F_TILE) * F_TILE;
-            if (ns[i + 1] - ns[i] >= 2 * (i64)F_TILE && be > bs) {
-                const int par = (int)(t & 1);
-                const unsigned g = atomicAdd(a.hcnt + (i64)isl * 2 + par, 1u);
-                if (g < F_HMAX) {
-                    const unsigned k = atomicAdd(&sHn, 1u);
-                    if (k < F_HLOC) {
-                        i64* e = a.hlist + (((i64)isl * 2 + par) * F_HMAX + g) * 3;
-                        e[0] = bs; e[1] = be; e[2] = jt + i;
-                        sH[2 * k] = bs; sH[2 * k + 1] = be;
-                    } else {                       // no room here: the entry stays harmless (empty)
-                        i64* e = a.hlist + (((i64)isl * 2 + par) * F_HMAX + g) * 3;
-                        e[0] = 0; e[1] = 0; e[2] = 0;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
-    const int nH = heavy ? (int)(sHn < F_HLOC ? sHn : F_HLOC) : 0;
+    int nH = 0;
+    if (heavy) nH = f_register_heavy(a.hcnt + (i64)isl * 2 + (t & 1),
+                                     a.hlist + ((i64)isl * 2 + (t & 1)) * F_HMAX * 3, jt,
+                                     ns[0], ns[1], ns[2], ns[3], ns[4], sH, &sHn);
     for (i64 pb = n_lo & ~(i64)3; pb < n_hi; pb += PASS) {
         if (nH) {                                  // the whole pass inside a registered parent's blocks?
             const i64 w_lo = pb > n_lo ? pb : n_lo, w_hi = pb + PASS < n_hi ? pb + PASS : n_hi;
