@@ -567,6 +567,20 @@ def check_heavy_parents(monkeypatch, N=8192, T=12):
             if sig == 1e-6:                      # really collapsed: some step has one dominant parent
                 cnt = max(np.bincount(a).max() for a in runs[0][0] if a is not None)
                 assert cnt >= n // 2
+    # several islands, each with its own list
+    outs = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("SMC_NO_HEAVY", "1")
+        pf = pa.SMC(fk=[ssm.Bootstrap(ssm=kalman.ToySSM(s_), data=y) for s_ in (1e-6, 0.2, 1e-5)], N=N, seed=9,
+                    ESSrmin=1.0, collect="off")
+        pf.run()
+        outs.append((pf.logLts_islands.copy(), [pf._get(_lib.FIELD_X, k).copy() for k in range(3)],
+                     [pf._get(_lib.FIELD_A, k).copy() for k in range(3)]))
+        monkeypatch.undo()
+    assert np.array_equal(outs[0][0], outs[1][0])
+    for k in range(3):
+        assert np.array_equal(outs[0][1][k], outs[1][1][k]) and np.array_equal(outs[0][2][k], outs[1][2][k])
 
 
 def check_describe():
