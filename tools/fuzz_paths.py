@@ -1,7 +1,8 @@
 """Randomised cross-check of the step-loop paths on the GPU: for random sizes, island counts,
 schemes, models and ESS thresholds the two-level path must be bit-identical with its fp64
 band shortcut switched off (SMC_EXACT_COUNTS) and with k_reduce2 in front (SMC_TWO_LEVEL_MID),
-and agree with the flat-Q62 path up to near-ties.
+with the heavy-parent list off (SMC_NO_HEAVY), and agree with the flat-Q62 path up to near-ties
+(collapsing-weight models included).
 
     python tools/fuzz_paths.py [n_cases] [seed]
 """
@@ -20,7 +21,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 
 
 def run(env, mk, y, N, M, scheme, essr, seed):
-    for k in ("SMC_EXACT_COUNTS", "SMC_TWO_LEVEL_MID", "SMC_FLAT_CDF"):
+    for k in ("SMC_EXACT_COUNTS", "SMC_TWO_LEVEL_MID", "SMC_FLAT_CDF", "SMC_NO_HEAVY"):
         os.environ.pop(k, None)
     os.environ.update(env)
     pf = pa.SMC(fk=ssm.Bootstrap(ssm=mk(), data=y), N=N, n_islands=M, resampling=scheme, ESSrmin=essr,
@@ -39,13 +40,14 @@ for c in range(ncases):
     scheme = str(rng.choice(["systematic", "stratified"]))
     essr = float(rng.choice([0.3, 0.5, 0.9, 1.0]))
     T = int(rng.integers(5, 40))
-    which = int(rng.integers(0, 4))
+    which = int(rng.integers(0, 6))
     mk = [lambda: kalman.ToySSM(0.2), lambda: kalman.ToySSM(0.01), lambda: ssm.StochVol(),
-          lambda: kalman.LinearGauss(rho=0.9, sigmaX=1.0, sigmaY=1.5)][which]
+          lambda: kalman.LinearGauss(rho=0.9, sigmaX=1.0, sigmaY=1.5),
+          lambda: kalman.ToySSM(1e-5), lambda: kalman.ToySSM(1e-8)][which]       # 4, 5: collapsing weights
     y = [np.array([v]) for v in np.cumsum(rng.standard_normal(T)) * (0.3 if which == 2 else 1.0)]
     seed = int(rng.integers(1, 1 << 30))
     base = run({}, mk, y, N, M, scheme, essr, seed)
-    for env in ({"SMC_EXACT_COUNTS": "1"}, {"SMC_TWO_LEVEL_MID": "1"}):
+    for env in ({"SMC_EXACT_COUNTS": "1"}, {"SMC_TWO_LEVEL_MID": "1"}, {"SMC_NO_HEAVY": "1"}):
         oth = run(env, mk, y, N, M, scheme, essr, seed)
         assert np.array_equal(base[0], oth[0]) and np.array_equal(base[1], oth[1]), (c, env, N, M, scheme)
         assert np.array_equal(base[2], oth[2]) and base[3] == oth[3] and np.array_equal(base[4], oth[4]), (c, env)
@@ -54,7 +56,8 @@ for c in range(ncases):
     if not same:
         flips += 1
         assert base[3] == flat[3] or abs(base[2][-1] - flat[2][-1]) < 0.5, (c, "flags differ", N, scheme)
-    assert np.all(np.isfinite(base[2])) and abs(base[2][-1] - flat[2][-1]) < 0.05 * np.sqrt(T) + 1e-9, \
+    tol = 0.05 * np.sqrt(T) + 1e-9 if which < 4 else 1e-6 * abs(flat[2][-1]) + 1.0
+    assert np.all(np.isfinite(base[2])) and abs(base[2][-1] - flat[2][-1]) < tol, \
         (c, N, M, scheme, base[2][-1], flat[2][-1])
     print("case %3d: N=2^%-2d M=%d %-10s ESSr=%.1f T=%-2d model %d  resampled %2d/%-2d  %s"
           % (c, k, M, scheme, essr, T, which, sum(base[3]), T, "== flat" if same else "near-tie vs flat"),
