@@ -36,6 +36,8 @@ flips = 0
 for c in range(ncases):
     k = int(rng.integers(11, 21))
     N = 1 << k
+    if rng.random() < 0.25:                 # not a power of two: the flat path only (heavy list on / off)
+        N += int(rng.integers(1, N))
     M = int(rng.choice([1, 1, 2, 5])) if k <= 17 else 1
     scheme = str(rng.choice(["systematic", "stratified"]))
     essr = float(rng.choice([0.3, 0.5, 0.9, 1.0]))
@@ -59,7 +61,7 @@ for c in range(ncases):
     tol = 0.05 * np.sqrt(T) + 1e-9 if which < 4 else 1e-6 * abs(flat[2][-1]) + 1.0
     assert np.all(np.isfinite(base[2])) and abs(base[2][-1] - flat[2][-1]) < tol, \
         (c, N, M, scheme, base[2][-1], flat[2][-1])
-    print("case %3d: N=2^%-2d M=%d %-10s ESSr=%.1f T=%-2d model %d  resampled %2d/%-2d  %s"
+    print("case %3d: N~2^%-2d M=%d %-10s ESSr=%.1f T=%-2d model %d  resampled %2d/%-2d  %s"
           % (c, k, M, scheme, essr, T, which, sum(base[3]), T, "== flat" if same else "near-tie vs flat"),
           flush=True)
 print("ok: %d cases, %d with a near-tie difference to the flat path, %.1f s" % (ncases, flips, time.time() - t0))
