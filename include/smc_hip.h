@@ -315,6 +315,12 @@ enum smc_state_field {
 };
 /* Copy one island's field (state after the last enqueued step) to the host. */
 int smc_filter_get(smc_filter* f, int field, int island, void* out_host);
+/* Replace the particles (X_host, (N,dx) or NULL) and / or the log-weights (lw_host, (N,) or
+ * NULL; univariate filters) of the step just done, island `island`: the counterpart of
+ * assigning SMC.X / SMC.wgts between two steps (core.py:222-233 attributes; e.g. an MCMC
+ * rejuvenation of the particles, smc_samplers.py:1129-1143).  ESS, log-mean weight and evidence
+ * of that step, the resample decision and the CDF of the next are recomputed on the device. */
+int smc_filter_set_state(smc_filter* f, int island, const double* X_host, const double* lw_host);
 /* Algorithmic bytes moved per particle-step and kernel launches
  * per step, for roofline accounting. */
 /* PMCMC move of SMC^2 (smc_samplers.py:1129-1143): where accept_host[i] != 0, island i of dst

@@ -177,3 +177,200 @@ double orc_toy_filter_philox(const double *y, int64_t T, int64_t N, double rho,
     free(X); free(Xn); free(lw); free(W); free(z); free(su); free(A);
     return logLt;
 }
+
+/* ==========================================================================
+ * The two-level exact CDF contract of the fused step loop,
+ * restated operation for operation so that the HIP kernels can be checked
+ * BIT FOR BIT (tests: np.array_equal on ancestors at N = 2^12 .. 2^22).
+ *
+ * What the contract fixes (and this file therefore repeats):
+ *   exp        the 13-term polynomial with Cody-Waite reduction below (the
+ *              device evaluates the same IEEE operations; fma() is explicit,
+ *              the file is built with -ffp-contract=off)
+ *   tile       1024 consecutive particles; its partial (m_b, S_b, SS_b) =
+ *              (max lw, sum e, sum e^2), e = exp(lw - m_b); summation tree:
+ *              4 consecutive elements left to right, then a balanced binary
+ *              tree over 64 such groups, then 4 such blocks left to right
+ *   island     m = max m_b; s = sum S_b e_b, ss = sum SS_b e_b^2 with
+ *              e_b = exp(m_b - m): per slot i of 256 the tiles 4i..4i+3 (and
+ *              +1024 c for every further chunk c) by fma left to right, then
+ *              the same 64-tree / 4-blocks order
+ *   shares     Q_b = rint(min(S_b e_b / s, 2) 2^62), G_b = sum_{b'<b} Q_b'
+ *   in a tile  q_i = rint(e_i 2^50), c_j = sum_{i<j} q_i, t_b = sum q_i
+ *   offspring  parent j of tile b owns the offspring n with
+ *              count(G_b + floor(c_j Q_b / t_b)) <= n < count(.. c_{j+1} ..),
+ *              count(C) = #{n : ceil(fl(u_n + n) 2^(62-k)) <= C}, N = 2^k
+ * Reference semantics being implemented: resampling.py:484-509, :599-610.
+ * ========================================================================== */
+static const double K_EXP[16] = {
+    1.6059043836821613e-10, 2.0876756987868100e-09, 2.5052108385441720e-08,
+    2.7557319223985888e-07, 2.7557319223985893e-06, 2.4801587301587302e-05,
+    1.9841269841269841e-04, 1.3888888888888889e-03, 8.3333333333333332e-03,
+    4.1666666666666664e-02, 1.6666666666666666e-01, 0.5,
+    1.4426950408889634074, 6.93147180369123816490e-01, 1.90821492927058770002e-10, -745.2};
+
+double orc_exp_nonpos(double x)
+{
+    const double k = rint(x * K_EXP[12]);
+    double r = fma(-k, K_EXP[13], x);
+    r = fma(-k, K_EXP[14], r);
+    double p = K_EXP[0];
+    for (int i = 1; i < 12; ++i) p = fma(p, r, K_EXP[i]);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    const double y = ldexp(p, (int)k);
+    return (x < K_EXP[15]) ? 0.0 : y;
+}
+void orc_exp_nonpos_v(const double *x, int64_t n, double *out)
+{
+    for (int64_t i = 0; i < n; ++i) out[i] = orc_exp_nonpos(x[i]);
+}
+
+/* balanced binary tree over 64 values (in place), pairs (2k, 2k+1) first */
+static double tree64(double *v)
+{
+    for (int w = 64; w > 1; w >>= 1)
+        for (int i = 0; i < w / 2; ++i) v[i] = v[2 * i] + v[2 * i + 1];
+    return v[0];
+}
+/* 256 slot values -> ((t0 + t1) + t2) + t3, t_w = tree over slots 64w .. 64w+63 */
+static double block_sum256(const double *slot)
+{
+    double r = 0.0;
+    for (int w = 0; w < 4; ++w) {
+        double v[64];
+        memcpy(v, slot + 64 * w, sizeof v);
+        const double t = tree64(v);
+        r = w ? r + t : t;
+    }
+    return r;
+}
+
+/* partial (m_b, S_b, SS_b) of every aligned tile of 1024 log-weights */
+void orc_tile_partials(const double *lw, int64_t N, double *pm, double *ps, double *pss)
+{
+    const int64_t nt = (N + 1023) / 1024;
+    for (int64_t b = 0; b < nt; ++b) {
+        double m = -INFINITY;
+        for (int64_t i = b * 1024; i < (b + 1) * 1024 && i < N; ++i)
+            if (lw[i] > m) m = lw[i];
+        double s1[256], s2[256];
+        for (int th = 0; th < 256; ++th) {
+            double a = 0.0, q = 0.0;
+            for (int k = 0; k < 4; ++k) {
+                const int64_t i = b * 1024 + 4 * th + k;
+                const double l = i < N ? lw[i] : -INFINITY;
+                const double e = (l > -INFINITY) ? orc_exp_nonpos(l - m) : 0.0;
+                a += e;
+                q = fma(e, e, q);
+            }
+            s1[th] = a;
+            s2[th] = q;
+        }
+        pm[b] = m;
+        ps[b] = block_sum256(s1);
+        pss[b] = block_sum256(s2);
+    }
+}
+
+/* island level: out = {m, s, ss, ESS, rs = 1/s}; Q, G (nt each) may be NULL */
+void orc_two_level_reduce(const double *pm, const double *ps, const double *pss, int64_t nt,
+                          double *out, uint64_t *Q, uint64_t *G)
+{
+    double m = -INFINITY;
+    for (int64_t b = 0; b < nt; ++b)
+        if (pm[b] > m) m = pm[b];
+    const int64_t nchunks = (nt + 1023) / 1024;
+    double s1[256], s2[256];
+    for (int th = 0; th < 256; ++th) {
+        double a = 0.0, q = 0.0;
+        for (int64_t c = 0; c < nchunks; ++c)
+            for (int k = 0; k < 4; ++k) {
+                const int64_t b = c * 1024 + 4 * th + k;
+                if (b >= nt) continue;                 /* fma(0, 0, a) = a */
+                const double e = (pm[b] > -INFINITY) ? orc_exp_nonpos(pm[b] - m) : 0.0;
+                a = fma(ps[b], e, a);
+                q = fma(pss[b], e * e, q);
+            }
+        s1[th] = a;
+        s2[th] = q;
+    }
+    const double s = block_sum256(s1), ss = block_sum256(s2);
+    const int bad = !(m > -INFINITY) || !(m < INFINITY);
+    out[0] = m;
+    out[1] = s;
+    out[2] = ss;
+    out[3] = bad ? NAN : (s * s) / ss;                 /* resampling.py:226 */
+    out[4] = bad ? NAN : 1.0 / s;
+    if (!Q) return;
+    uint64_t g = 0;
+    for (int64_t b = 0; b < nt; ++b) {
+        const double e = (pm[b] > -INFINITY) ? orc_exp_nonpos(pm[b] - m) : 0.0;
+        const double w = (ps[b] * e) * out[4];
+        const uint64_t qb = (w > 0.0) ? (uint64_t)rint(fmin(w, 2.0) * 4611686018427387904.0) : 0;
+        Q[b] = qb;
+        G[b] = g;
+        g += qb;
+    }
+}
+
+/* count(C) = #{ n < N : ceil(fl(u_n + n) 2^sh) <= C }, N = 2^k, sh = 62 - k
+ * (systematic: u_n = u[0]; stratified: u_n = u[n]) */
+static int64_t count_pow2(uint64_t C, const double *u, int stratified, int k, int64_t N)
+{
+    const int sh = 62 - k;
+    const uint64_t nc = C >> sh;
+    if (nc >= (uint64_t)N) return N;
+    const double un = stratified ? u[nc] : u[0];
+    const uint64_t T = (uint64_t)ceil((un + (double)(int64_t)nc) * ldexp(1.0, sh));
+    return (int64_t)nc + (T <= C ? 1 : 0);
+}
+
+/* The whole contract: ancestors A (N) from the log-weights of the parents.  scheme: 1
+ * stratified (u: N uniforms), 2 systematic (u: 1 uniform).  red (5): m, s, ss, ESS, 1/s.
+ * Returns 0, or 1 if N is not a power of two >= 2048 (the path does not apply). */
+int orc_inverse_cdf_2level(const double *lw, int64_t N, int scheme, const double *u,
+                           int64_t *A, double *red)
+{
+    int k = -1;
+    for (int i = 0; i < 62; ++i)
+        if (((int64_t)1 << i) == N) k = i;
+    if (k < 11) return 1;
+    const int64_t nt = N / 1024;
+    double *pm = malloc(sizeof(double) * nt), *ps = malloc(sizeof(double) * nt),
+           *pss = malloc(sizeof(double) * nt);
+    uint64_t *Q = malloc(sizeof(uint64_t) * nt), *G = malloc(sizeof(uint64_t) * nt);
+    orc_tile_partials(lw, N, pm, ps, pss);
+    orc_two_level_reduce(pm, ps, pss, nt, red, Q, G);
+    const int strat = scheme == 1;
+    int64_t prev = 0;                                  /* first offspring of parent j - 1 */
+    for (int64_t b = 0; b < nt; ++b) {
+        uint64_t q[1024], tb = 0;
+        for (int i = 0; i < 1024; ++i) {
+            const double l = lw[b * 1024 + i];
+            const double e = (l > -INFINITY) ? orc_exp_nonpos(l - pm[b]) : 0.0;
+            q[i] = (uint64_t)rint(e * 1125899906842624.0);
+            tb += q[i];
+        }
+        uint64_t c = 0;
+        for (int i = 0; i < 1024; ++i) {
+            const int64_t j = b * 1024 + i;
+            int64_t ns;
+            if (j == 0) ns = 0;
+            else {
+                uint64_t pos;
+                if (c == 0) pos = 0;
+                else if (c >= tb) pos = Q[b];
+                else pos = (uint64_t)(((unsigned __int128)c * Q[b]) / tb);
+                ns = count_pow2(G[b] + pos, u, strat, k, N);
+            }
+            /* offspring prev .. ns-1 belong to parent j - 1 */
+            for (int64_t n = prev; n < ns; ++n) A[n] = j - 1;
+            if (ns > prev) prev = ns;
+            c += q[i];
+        }
+    }
+    for (int64_t n = prev; n < N; ++n) A[n] = N - 1;   /* resampling.py:505-508 clamp */
+    free(pm); free(ps); free(pss); free(Q); free(G);
+    return 0;
+}

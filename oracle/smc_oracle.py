@@ -49,6 +49,14 @@ def clib():
             dp, i64, i64, ctypes.c_double, ctypes.c_double, ctypes.c_double,
             ctypes.c_double, ctypes.c_double, ctypes.c_uint64, dp]
         lib.orc_toy_filter_philox.restype = ctypes.c_double
+        lib.orc_exp_nonpos_v.argtypes = [dp, i64, dp]
+        lib.orc_exp_nonpos_v.restype = None
+        lib.orc_tile_partials.argtypes = [dp, i64, dp, dp, dp]
+        lib.orc_tile_partials.restype = None
+        lib.orc_two_level_reduce.argtypes = [dp, dp, dp, i64, dp, up, up]
+        lib.orc_two_level_reduce.restype = None
+        lib.orc_inverse_cdf_2level.argtypes = [dp, i64, ctypes.c_int, dp, ip, dp]
+        lib.orc_inverse_cdf_2level.restype = ctypes.c_int
         _CLIB = lib
     return _CLIB
 
@@ -302,30 +310,72 @@ def inverse_cdf_q62(su, W):
     return np.minimum(A, W.shape[0] - 1)
 
 
+def exp_contract(x):
+    """exp(x), x <= 0, as the two-level contract fixes it (oracle.c orc_exp_nonpos: Cody-Waite
+    reduction + degree-13 polynomial, IEEE operations only -- the device evaluates the same)."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(x)
+    clib().orc_exp_nonpos_v(_dp(x), x.size, _dp(out))
+    return out
+
+
+def tile_partials(lw):
+    """(m_b, S_b, SS_b) of every aligned tile of 1024 log-weights, the contract's summation
+    tree (oracle.c orc_tile_partials)."""
+    lw = np.ascontiguousarray(lw, dtype=np.float64)
+    nt = (lw.size + 1023) // 1024
+    pm, ps, pss = np.empty(nt), np.empty(nt), np.empty(nt)
+    clib().orc_tile_partials(_dp(lw), lw.size, _dp(pm), _dp(ps), _dp(pss))
+    return pm, ps, pss
+
+
+def two_level_reduce(pm, ps, pss):
+    """Island level of the contract: dict(m, s, ss, ESS, rs) and the integer shares Q_b, G_b."""
+    nt = pm.size
+    out = np.empty(5)
+    Q, G = np.empty(nt, dtype=np.uint64), np.empty(nt, dtype=np.uint64)
+    up = ctypes.POINTER(ctypes.c_uint64)
+    clib().orc_two_level_reduce(_dp(pm), _dp(ps), _dp(pss), nt, _dp(out), Q.ctypes.data_as(up),
+                                G.ctypes.data_as(up))
+    return dict(m=out[0], s=out[1], ss=out[2], ESS=out[3], rs=out[4]), Q, G
+
+
+def inverse_cdf_2level_c(scheme, u, lw):
+    """The whole contract in C (orc_inverse_cdf_2level; counts per parent, 128-bit products):
+    ancestors for `scheme` ('systematic': u = the one uniform, 'stratified': u = N uniforms) and
+    the island reduction.  Fast enough for N = 2^22."""
+    lw = np.ascontiguousarray(lw, dtype=np.float64)
+    u = np.ascontiguousarray(np.atleast_1d(u), dtype=np.float64)
+    A = np.empty(lw.size, dtype=np.int64)
+    red = np.empty(5)
+    rc = clib().orc_inverse_cdf_2level(_dp(lw), lw.size, {"stratified": 1, "systematic": 2}[scheme],
+                                       _dp(u), A.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), _dp(red))
+    if rc:
+        raise ValueError("two-level contract: N must be a power of two >= 2048")
+    return A, dict(m=red[0], s=red[1], ss=red[2], ESS=red[3], rs=red[4])
+
+
 def inverse_cdf_2level(su, lw, tile=1024, P=50):
     """The two-level exact CDF of the fused step loop for N = 2^k >= 2 tiles
-    (particles_amd/csrc/smc_filter_kernels.h, k_ancestors2).  Per aligned tile b of `tile`
-    log-weights: m_b = max, S_b = sum exp(lw - m_b); globally m = max m_b, s = sum S_b exp(m_b - m).
-    Tile shares of the 2^62 scale Q_b = rint(S_b exp(m_b - m) / s 2^62), G_b their exclusive sums;
-    inside a tile the integer CDF C_j of q_i = rint(exp(lw_i - m_b) 2^P), total t_b.  Offspring n
-    with threshold T_n = ceil(su_n 2^62) in (G_b, G_b + Q_b] takes the first parent j of tile b with
-    (T_n - G_b) t_b <= C_j Q_b -- exact rational comparisons (Python integers here); thresholds
-    beyond the last share go to the last particle, as resampling.py:500-509 would clamp."""
+    (particles_amd/csrc/smc_filter_kernels.h, k_ancestors2), formulated per OFFSPRING (the C
+    restatement and the kernels count per parent): tile partials and island reduction as the
+    contract fixes them (tile_partials, two_level_reduce), tile shares Q_b of the 2^62 scale with
+    exclusive sums G_b; inside a tile the integer CDF C_j of q_i = rint(exp(lw_i - m_b) 2^P),
+    total t_b.  Offspring n with threshold T_n = ceil(su_n 2^62) in (G_b, G_b + Q_b] takes the
+    first parent j of tile b with T_n - G_b <= floor(C_j Q_b / t_b) -- exact rational comparisons
+    (Python integers here); thresholds beyond the last share go to the last particle, as
+    resampling.py:500-509 would clamp."""
     lw = np.asarray(lw, dtype=np.float64)
     N = lw.shape[0]
     nt = N // tile
-    assert nt * tile == N and nt >= 1
+    assert nt * tile == N and nt >= 1 and tile == 1024
+    pm, ps, pss = tile_partials(lw)
+    _, Qa, Ga = two_level_reduce(pm, ps, pss)
+    Q = [int(v) for v in Qa]
+    G = [int(v) for v in Ga] + [int(Ga[-1]) + int(Qa[-1])]
     L = lw.reshape(nt, tile)
-    mb = L.max(axis=1)
     with np.errstate(invalid="ignore"):
-        E = np.where(np.isneginf(L), 0.0, np.exp(L - mb[:, None]))
-    Sb = E.sum(axis=1)
-    m = mb.max()
-    eb = np.where(np.isneginf(mb), 0.0, np.exp(mb - m))
-    s = float(np.sum(Sb * eb))
-    rs = 1.0 / s
-    Q = [int(np.rint((Sb[b] * eb[b]) * rs * Q62)) for b in range(nt)]
-    G = np.concatenate([[0], np.cumsum(np.array(Q, dtype=object))])
+        E = np.where(np.isneginf(L), 0.0, exp_contract(L - pm[:, None]))
     q = np.rint(E * float(2 ** P)).astype(np.int64)
     C = np.cumsum(q, axis=1)                                  # inclusive, exact (< 2^63)
     T = [int(v) for v in q62_threshold(su)]
@@ -337,11 +387,11 @@ def inverse_cdf_2level(su, lw, tile=1024, P=50):
         if Tn > G[nt]:
             A[n] = N - 1
             continue
-        tau, tb, Qb = Tn - int(G[b]), int(C[b, -1]), Q[b]
-        lo, hi = 0, tile - 1                                  # first j with tau * t_b <= C_j * Q_b
+        tau, tb, Qb = Tn - G[b], int(C[b, -1]), Q[b]
+        lo, hi = 0, tile - 1                                  # first j with tau <= floor(C_j Q_b / t_b)
         while lo < hi:
             mid = (lo + hi) // 2
-            if tau * tb <= int(C[b, mid]) * Qb:
+            if tb and tau <= (int(C[b, mid]) * Qb) // tb:
                 hi = mid
             else:
                 lo = mid + 1
@@ -671,12 +721,85 @@ def kalman_loglik(model, data):
 # The SMC step loop               (particles/core.py:299-383)
 # --------------------------------------------------------------------------
 
+class StepCtx:
+    """Per-run constants of ``propagate`` (Cholesky factors of the multivariate models)."""
+
+    def __init__(self, model, fk, y0):
+        self.mv = getattr(model, "dim", 1) > 1
+        if self.mv:
+            self.d = model.dim
+            self.LX = np.linalg.cholesky(model.covX)           # distributions.py:937
+            self.LY = np.linalg.cholesky(model.covY)
+            self.L0 = np.linalg.cholesky(model.cov0)
+            if fk == "guided":
+                # kalman.py:353-356 proposal0 ; filter_step with scalar-shaped mean
+                self.f0m, f0c, _ = kalman_filter_step(model.G, model.covY, model.mu0,
+                                                      model.cov0, np.asarray(y0))
+                self.Lp0 = np.linalg.cholesky(f0c)
+
+
+def propagate(model, fk, t, yt, Xp, z, ctx):
+    """Move and weigh of ONE step given the (resampled) parents Xp and the standard normals z:
+    core.py:315-324 with Bootstrap / GuidedPF (state_space_models.py:326-333, :374-392).
+    Returns (X_t, weight increment).  ``run_filter`` iterates it; the parity tests also call it
+    step by step on the device's own X_{t-1}[A_t] (teacher forcing)."""
+    if ctx.mv:
+        if t == 0:
+            if fk == "guided":
+                X = mvnormal_rvs(ctx.f0m, 1.0, ctx.Lp0, z)     # state_space_models.py:374-375
+            else:
+                X = mvnormal_rvs(model.mu0, 1.0, ctx.L0, z)    # kalman.py:339-340
+        else:
+            m = np.dot(Xp, model.F.T)                          # kalman.py:342-343
+            if fk == "guided":                                 # kalman.py:348-351
+                pm, pc, _ = kalman_filter_step(model.G, model.covY, m, model.covX, yt)
+                Lp = np.linalg.cholesky(pc)
+                X = mvnormal_rvs(pm, 1.0, Lp, z)
+            else:
+                X = mvnormal_rvs(m, 1.0, ctx.LX, z)
+        lpy = mvnormal_logpdf(yt, np.dot(X, model.G.T), 1.0, ctx.LY)   # kalman.py:345-346
+        if fk == "guided":                                     # state_space_models.py:380-392
+            if t == 0:
+                inc = (mvnormal_logpdf(X, model.mu0, 1.0, ctx.L0) + lpy
+                       - mvnormal_logpdf(X, ctx.f0m, 1.0, ctx.Lp0))
+            else:
+                inc = (mvnormal_logpdf(X, m, 1.0, ctx.LX) + lpy
+                       - mvnormal_logpdf(X, pm, 1.0, Lp))
+        else:
+            inc = lpy
+        return X, inc
+    if fk == "guided":
+        if t == 0:
+            loc, scale = model.proposal0(yt)
+            X = normal_rvs(loc, scale, z)
+            l0, s0 = model.px0()
+            inc = (normal_logpdf(X, l0, s0) + model.py_logpdf(yt, None, X)
+                   - normal_logpdf(X, loc, scale))
+        else:
+            loc, scale = model.proposal(Xp, yt)
+            X = normal_rvs(loc, scale, z)
+            l1, s1 = model.px(Xp)
+            inc = (normal_logpdf(X, l1, s1) + model.py_logpdf(yt, Xp, X)
+                   - normal_logpdf(X, loc, scale))
+        return X, inc
+    if t == 0:
+        loc, scale = model.px0()
+    else:
+        loc, scale = model.px(Xp, t) if getattr(model, "time_dependent", False) else model.px(Xp)
+    X = normal_rvs(loc, scale, z)
+    return X, model.py_logpdf(yt, Xp if t > 0 else None, X)    # state_space_models.py:332-333
+
+
 def run_filter(model, data, N, scheme="systematic", ESSrmin=0.5, fk="bootstrap",
                rng=None, keep=False, cdf="seq", T=None):
     """core.py:369-383 ``SMC.__next__`` iterated to T, for the model families
     on the hot path.  RNG consumption order per SURVEY appendix A:
     t=0: standard_normal(N[,d]);  t>=1: [if ESS < N*ESSrmin: scheme uniforms]
     then standard_normal(N[,d]).
+
+    cdf: "seq" the reference's sequential fp64 CDF (resampling.py:500-509), "q62" / "2level"
+    the device's exact integer contracts (then the resample decision also uses the contract's
+    ESS, so that such a run is the device's run bit for bit).
 
     Returns a dict of per-step lists (ESS, log_mean, loglt, logLt, rs_flag) and
     the final X, Xp, A, lw, W; with keep=True also every step's X/A/lw/W.
@@ -689,43 +812,24 @@ def run_filter(model, data, N, scheme="systematic", ESSrmin=0.5, fk="bootstrap",
     X = Xp = A = None
     logLt = 0.0
     log_mean_w = None
-    mv = getattr(model, "dim", 1) > 1
-    if mv:
-        d = model.dim
-        LX = np.linalg.cholesky(model.covX)               # distributions.py:937
-        LY = np.linalg.cholesky(model.covY)
-        L0 = np.linalg.cholesky(model.cov0)
-        if fk == "guided":
-            # kalman.py:353-356 proposal0 ; filter_step with scalar-shaped mean
-            f0m, f0c, _ = kalman_filter_step(model.G, model.covY, model.mu0,
-                                             model.cov0, np.asarray(data[0]))
-            Lp0 = np.linalg.cholesky(f0c)
+    ctx = StepCtx(model, fk, data[0])
+    zshape = (N, ctx.d) if ctx.mv else N
     for t in range(T):
         yt = np.asarray(data[t])
         rs_flag = False
         # ---- generate_particles / resample_move      core.py:315-337
-        if t == 0:
-            if mv:
-                z = rng.standard_normal((N, d))
-                if fk == "guided":
-                    X = mvnormal_rvs(f0m, 1.0, Lp0, z)    # state_space_models.py:374-375
-                else:
-                    X = mvnormal_rvs(model.mu0, 1.0, L0, z)  # kalman.py:339-340
-            elif fk == "guided":
-                loc, scale = model.proposal0(yt)
-                X = normal_rvs(loc, scale, rng.standard_normal(N))
-            else:
-                loc, scale = model.px0()
-                X = normal_rvs(loc, scale, rng.standard_normal(N))
-        else:
-            rs_flag = bool(wgts.ESS < N * ESSrmin)        # core.py:181-183, 327
+        if t > 0:
+            ess = wgts.ESS
+            if cdf == "2level":
+                ess = two_level_reduce(*tile_partials(wgts.lw))[0]["ESS"]
+            rs_flag = bool(ess < N * ESSrmin)             # core.py:181-183, 327
             if rs_flag:
                 u = rng.rand(N_UNIFORMS[scheme](N))
                 su = sorted_uniforms(scheme, N, u)
                 if cdf == "seq":
                     A = inverse_cdf(su, wgts.W)
                 elif cdf == "2level":
-                    A = inverse_cdf_2level(su, wgts.lw)
+                    A = inverse_cdf_2level_c(scheme, u, wgts.lw)[0]
                 else:
                     A = inverse_cdf_q62(su, wgts.W)
                 Xp = X[A]                                 # core.py:332
@@ -733,47 +837,8 @@ def run_filter(model, data, N, scheme="systematic", ESSrmin=0.5, fk="bootstrap",
             else:
                 A = np.arange(N)                          # core.py:335-336
                 Xp = X
-            if mv:
-                z = rng.standard_normal((N, d))
-                m = np.dot(Xp, model.F.T)                 # kalman.py:342-343
-                if fk == "guided":                        # kalman.py:348-351
-                    pm, pc, _ = kalman_filter_step(model.G, model.covY, m,
-                                                   model.covX, yt)
-                    Lp = np.linalg.cholesky(pc)
-                    X = mvnormal_rvs(pm, 1.0, Lp, z)
-                else:
-                    X = mvnormal_rvs(m, 1.0, LX, z)
-            elif fk == "guided":
-                loc, scale = model.proposal(Xp, yt)
-                X = normal_rvs(loc, scale, rng.standard_normal(N))
-            else:
-                loc, scale = model.px(Xp, t) if getattr(model, "time_dependent", False) else model.px(Xp)
-                X = normal_rvs(loc, scale, rng.standard_normal(N))
+        X, inc = propagate(model, fk, t, yt, Xp, rng.standard_normal(zshape), ctx)
         # ---- reweight_particles                      core.py:323-324
-        if mv:
-            lpy = mvnormal_logpdf(yt, np.dot(X, model.G.T), 1.0, LY)  # kalman.py:345-346
-            if fk == "guided":                            # state_space_models.py:380-392
-                if t == 0:
-                    inc = (mvnormal_logpdf(X, model.mu0, 1.0, L0) + lpy
-                           - mvnormal_logpdf(X, f0m, 1.0, Lp0))
-                else:
-                    inc = (mvnormal_logpdf(X, m, 1.0, LX) + lpy
-                           - mvnormal_logpdf(X, pm, 1.0, Lp))
-            else:
-                inc = lpy
-        elif fk == "guided":
-            if t == 0:
-                l0, s0 = model.px0()
-                q0, qs0 = model.proposal0(yt)
-                inc = (normal_logpdf(X, l0, s0) + model.py_logpdf(yt, None, X)
-                       - normal_logpdf(X, q0, qs0))
-            else:
-                l1, s1 = model.px(Xp)
-                q1, qs1 = model.proposal(Xp, yt)
-                inc = (normal_logpdf(X, l1, s1) + model.py_logpdf(yt, Xp, X)
-                       - normal_logpdf(X, q1, qs1))
-        else:
-            inc = model.py_logpdf(yt, Xp, X)              # state_space_models.py:332-333
         wgts = wgts.add(inc)
         # ---- compute_summaries                       core.py:351-359
         prec = log_mean_w

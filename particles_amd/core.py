@@ -321,6 +321,26 @@ class SMC:
             self._fk_list = [o if a else s for s, o, a in zip(self._fk_list, other._fk_list, acc)]
         self._invalidate()
 
+    def set_state(self, X=None, lw=None, island=0):
+        """Replace the particles and / or log-weights of the step just done (the reference lets
+        a caller assign ``pf.X`` / ``pf.wgts`` between two steps): the summaries of that step
+        and everything the next step derives from the weights are recomputed on the device."""
+        if not self._fused:
+            if X is not None:
+                self.X = X
+            if lw is not None:
+                self.wgts = rs.Weights(lw=np.array(lw, dtype=np.float64))
+            return
+        Xc = None if X is None else np.ascontiguousarray(X, dtype=np.float64)
+        lc = None if lw is None else np.ascontiguousarray(lw, dtype=np.float64)
+        d = getattr(self, "_d", 1)
+        if Xc is not None and Xc.size != self.N * d or lc is not None and lc.shape != (self.N,):
+            raise ValueError("set_state: X must be (N[, d]) and lw (N,)")
+        check(lib().smc_filter_set_state(
+            self._f, island, None if Xc is None else Xc.ctypes.data_as(_lib.c_vp),
+            None if lc is None else lc.ctypes.data_as(_lib.c_vp)))
+        self._invalidate()
+
     def step_async(self, nsteps=1):
         """Enqueue ``nsteps`` time steps on the device without synchronising."""
         todo = min(nsteps, self.fk.T - self.t)

@@ -577,6 +577,42 @@ static int filter_fetch(smc_filter* f, int field, i64 s, int island, void* out_h
     return SMC_OK;
 }
 
+// Replace the particles and / or log-weights of the step just done (island `island`) by host
+// arrays: what a caller does that moves particles itself between two steps (an MCMC
+// rejuvenation of the x-particles, importing a particle system; the reference's counterpart is
+// assigning pf.X / pf.wgts, core.py:222-233).  Everything the next step derives from the
+// log-weights (ESS, log-mean weight and evidence of this step, the resample decision and the
+// CDF of the next) is recomputed on the device as if the step had produced these values.
+int smc_filter_set_state(smc_filter* f, int island, const double* X_host, const double* lw_host)
+{
+    SMC_REQUIRE(f, "null filter");
+    SMC_REQUIRE(island >= 0 && island < f->a.n_islands, "island out of range");
+    if (f->t_host == 0) {
+        smc_set_error("smc_filter_set_state: no step has run yet");
+        return SMC_ERR_STATE;
+    }
+    if (f->kind == SMC_MODEL_MVLINGAUSS && lw_host) {
+        smc_set_error("smc_filter_set_state: log-weights of a multivariate filter cannot be replaced");
+        return SMC_ERR_STATE;
+    }
+    SMC_HIP_CHECK(hipSetDevice(f->ctx->device));
+    hipStream_t st = f->ctx->stream;
+    const i64 N = f->a.N, ts = f->t_host - 1;
+    if (X_host)
+        SMC_HIP_CHECK(hipMemcpyAsync(f_X(f->a, ts) + (size_t)island * N * f->a.dx, X_host,
+                                     (size_t)N * f->a.dx * 8, hipMemcpyHostToDevice, st));
+    if (lw_host) {
+        SMC_HIP_CHECK(hipMemcpyAsync(f_lw(f->a, ts) + (size_t)island * N, lw_host, (size_t)N * 8,
+                                     hipMemcpyHostToDevice, st));
+        SMC_LAUNCH(k_f_partials, dim3(f->a.nparts, f->a.n_islands), dim3(SMC_BLOCK), st, f->a, ts);
+        if (f->two_level) SMC_LAUNCH(k_flush2, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
+        else SMC_LAUNCH(k_f_restate, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a, ts);
+    }
+    SMC_LAUNCH_CHECK();
+    SMC_HIP_CHECK(hipStreamSynchronize(st));
+    return SMC_OK;
+}
+
 // theta-level resampling of whole filters (SMC^2: smc_samplers.py:319-361 FancyList
 // deep copies): island i continues from the state of island src[i] -- particles,
 // log-weights, per-step summaries, step record and parameter row move together; the

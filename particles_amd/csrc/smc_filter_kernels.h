@@ -707,6 +707,38 @@ k_ancestors(const FArgs av)
     F_STAMP_A(6);
 }
 
+// Step t is complete and its log-weights reduce to g = (max, sum e, sum e^2): summary row of t
+// (resampling.py:224-226, core.py:355-359), the resample decision of t+1 (core.py:181-183) and
+// the step record the launches of t+1 read.  One thread.
+__device__ __forceinline__ void f_finalise_step(const FArgs& a, const int isl, const i64 t,
+                                                const bool first, const bool resample,
+                                                const SmcLse g, double* info)
+{
+    const bool bad = !(g.m > -INFINITY) || !(g.m < INFINITY);
+    const double ess = bad ? NAN : (g.s * g.s) / g.ss;                  // resampling.py:226
+    const double log_mean = bad ? NAN : g.m + log(g.s / (double)a.N);   // resampling.py:224
+    const double rs = bad ? NAN : 1.0 / g.s;
+    double* row = a.summ + ((i64)isl * (a.T + 1) + t) * SUMM_STRIDE;
+    double loglt, logLt;                                                // core.py:355-359
+    if (first || resample) loglt = log_mean;
+    else loglt = log_mean - row[1 - SUMM_STRIDE];
+    logLt = (first ? 0.0 : row[3 - SUMM_STRIDE]) + loglt;
+    row[0] = ess;
+    row[1] = log_mean;
+    row[2] = loglt;
+    row[3] = logLt;
+    row[4] = resample ? 1.0 : 0.0;
+    row[5] = g.m;
+    row[6] = rs;
+    const bool flag = (t + 1 < a.T) && (ess < a.ess_thresh);            // core.py:181-183
+    info[1] = flag ? 1.0 : 0.0;
+    info[2] = (t + 1 < a.T) ? a.y[(t + 1) * a.dy] : 0.0;
+    info[5] = (a.aux && t + 1 < a.T) ? a.aux[t + 1] : 0.0;
+    info[3] = g.m;
+    info[4] = rs;
+    info[0] = (double)(t + 1);
+}
+
 // ---------------------------------------------------------------------------
 // End of a propagate kernel: publish the workgroup's log-sum-exp partial `r` and
 // let the last workgroup of the island finalise step t and decide step t+1.
@@ -770,31 +802,7 @@ __device__ __forceinline__ void f_step_tail(const FArgs& a, const int isl, const
     const SmcLse g = direct
         ? smc_lse_reduce_partials<true>(a.pm + o, a.ps + o, a.pss + o, a.nparts, smd)
         : smc_lse_reduce_partials<true>(spart, spart + 32, spart + 64, shards, smd);
-    if (tid == 0) {
-        const bool bad = !(g.m > -INFINITY) || !(g.m < INFINITY);
-        const double ess = bad ? NAN : (g.s * g.s) / g.ss;                  // resampling.py:226
-        const double log_mean = bad ? NAN : g.m + log(g.s / (double)N);     // resampling.py:224
-        const double rs = bad ? NAN : 1.0 / g.s;
-        double* row = a.summ + ((i64)isl * (a.T + 1) + t) * SUMM_STRIDE;
-        double loglt, logLt;                                                // core.py:355-359
-        if (first || resample) loglt = log_mean;
-        else loglt = log_mean - row[1 - SUMM_STRIDE];
-        logLt = (first ? 0.0 : row[3 - SUMM_STRIDE]) + loglt;
-        row[0] = ess;
-        row[1] = log_mean;
-        row[2] = loglt;
-        row[3] = logLt;
-        row[4] = resample ? 1.0 : 0.0;
-        row[5] = g.m;
-        row[6] = rs;
-        const bool flag = (t + 1 < a.T) && (ess < a.ess_thresh);            // core.py:181-183
-        info[1] = flag ? 1.0 : 0.0;
-        info[2] = (t + 1 < a.T) ? a.y[(t + 1) * a.dy] : 0.0;
-        info[5] = (a.aux && t + 1 < a.T) ? a.aux[t + 1] : 0.0;
-        info[3] = g.m;
-        info[4] = rs;
-        info[0] = (double)(t + 1);
-    }
+    if (tid == 0) f_finalise_step(a, isl, t, first, resample, g, info);
     F_STAMP(7);
 }
 
@@ -819,6 +827,31 @@ __device__ __forceinline__ void f_load_anc(const u32* A, i64 n0, i64 N, bool ful
 #pragma unroll
         for (int k = 0; k < OPT; ++k) an[k] = (n0 + k < N) ? (i64)smc_ldg(A + n0 + k) : 0;
     }
+}
+
+// The workgroup's log-sum-exp partial (max, sum e, sum e^2) of the OPT log-weights each thread
+// holds (-inf beyond N): max first, then ONE exp per particle against the workgroup's max (no
+// per-thread rescaling, no branches).  Fixed association order: the thread's OPT values left to
+// right, a balanced tree over the 64 lanes, the 4 waves left to right (oracle.c orc_tile_partials).
+template <int OPT>
+__device__ __forceinline__ SmcLse f_tile_lse(const double (&lw)[OPT], double* smd)
+{
+    SmcLse r;
+    double tm = lw[0];
+#pragma unroll
+    for (int k = 1; k < OPT; ++k) tm = smc_max2(tm, lw[k]);
+    r.m = smc_block_max(tm, smd);
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < OPT; ++k) {
+        const double e = (lw[k] > -INFINITY) ? smc_exp_nonpos(lw[k] - r.m) : 0.0;
+        s1 += e;
+        s2 = fma(e, e, s2);
+    }
+    smc_block_sum2(s1, s2, smd);
+    r.s = s1;
+    r.ss = s2;
+    return r;
 }
 
 template <int KIND, int FK, int OPT, bool SPEC, bool TAIL = true>
@@ -963,23 +996,7 @@ k_propagate(const FArgs av)
     // ---- the workgroup's (max, sum e, sum e^2): max first, then ONE exp per particle
     // against the workgroup's max (no per-thread rescaling, no branches)
     F_STAMP(3);
-    SmcLse r;
-    {
-        double tm = lw[0];
-#pragma unroll
-        for (int k = 1; k < OPT; ++k) tm = smc_max2(tm, lw[k]);
-        r.m = smc_block_max(tm, smd);
-        double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-        for (int k = 0; k < OPT; ++k) {
-            const double e = (lw[k] > -INFINITY) ? smc_exp_nonpos(lw[k] - r.m) : 0.0;
-            s1 += e;
-            s2 = fma(e, e, s2);
-        }
-        smc_block_sum2(s1, s2, smd);
-        r.s = s1;
-        r.ss = s2;
-    }
+    const SmcLse r = f_tile_lse<OPT>(lw, smd);
     if (TAIL) {
         f_step_tail(a, isl, b, t, first, resample, r, smd, s_last, info);
     } else {
@@ -1419,6 +1436,42 @@ k_flush2(const FArgs av)
     if (t <= 0) return;
     const F2Red r = f2_reduce_island(a, isl, smd);
     if (threadIdx.x == 0) f2_write_row(a, isl, t - 1, r);
+}
+
+// smc_filter_set_state: the log-weights of the current step were replaced from the host; the
+// per-tile partials k_propagate would have left (same device function, same bits) ...
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_f_partials(const FArgs av, const i64 ts)
+{
+    const FArgs& a = av;
+    __shared__ double smd[SMC_SM];
+    const int b = (int)blockIdx.x, isl = (int)blockIdx.y;
+    const i64 N = a.N;
+    const double* lwp = f_lw(a, ts) + (i64)isl * N;
+    double lw[F_IPT];
+    f_load4<double>(lwp, ((i64)b * SMC_BLOCK + threadIdx.x) * F_IPT, N, (N & 3) == 0, -INFINITY, lw);
+    const SmcLse r = f_tile_lse<F_IPT>(lw, smd);
+    if (threadIdx.x == 0) {
+        const i64 o = (i64)isl * a.nparts;
+        a.pm[o + b] = r.m;
+        a.ps[o + b] = r.s;
+        a.pss[o + b] = r.ss;
+    }
+}
+// ... and, on the paths whose k_propagate finalises the step itself (flat CDF, one-launch small
+// filter), the summary row of step ts and the record of step ts + 1, from those partials
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_f_restate(const FArgs av, const i64 ts)
+{
+    const FArgs& a = av;
+    __shared__ double smd[SMC_SM];
+    const int isl = (int)blockIdx.x;
+    const i64 o = (i64)isl * a.nparts;
+    const SmcLse g = smc_lse_reduce_partials<false>(a.pm + o, a.ps + o, a.pss + o, a.nparts, smd);
+    if (threadIdx.x == 0) {
+        const double* row = a.summ + ((i64)isl * (a.T + 1) + ts) * SUMM_STRIDE;
+        f_finalise_step(a, isl, ts, ts == 0, row[4] != 0.0, g, a.info + (i64)isl * INFO_STRIDE);
+    }
 }
 
 // W = exp(lw - m)/s for one island (SMC.W)

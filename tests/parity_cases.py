@@ -422,9 +422,130 @@ def tapes_from_oracle(tape, T, N, scheme):
     return z, u
 
 
+def describe(pf):
+    buf = ctypes.create_string_buffer(256)
+    _lib.check(_lib.lib().smc_filter_describe(pf._f, buf, 256))
+    return buf.value.decode()
+
+
+def audit_history(pf, mk_orc, fk, y, scheme, ESSrmin, z=None, u=None, exact=True, island=0,
+                  tol=1e-12, steps=None):
+    """Teacher-forced audit of a store_history=True fused run: EVERY step, EVERY entry.
+
+    For each step t the oracle is handed the device's own state of step t-1 and must reproduce
+    step t: the resample decision, the ancestors -- bit for bit against the device's exact CDF
+    contract (two-level: oracle.c orc_inverse_cdf_2level from the log-weights; flat Q62:
+    inverse_cdf_q62 from the weights), and against the reference's sequential fp64 CDF
+    (resampling.py:500-509) with every mismatch certified a near-tie -- then X_t from
+    X_{t-1}[A_t] and the step's normals, the log-weights, ESS and the evidence.  One flipped
+    ancestor therefore fails the step it occurs in instead of silently ending the comparison.
+    z, u: the replay tapes; None = production mode (the oracle's Philox restatement).
+    Returns the number of audited near-ties against the reference CDF."""
+    N, T = pf.N, pf._n
+    model = mk_orc()
+    ctx = orc.StepCtx(model, fk, y[0])
+    two_level = "k_ancestors2" in describe(pf)
+    summ = pf._summ()[island]
+    near_ties = 0
+    logLt = 0.0
+    prev_log_mean = None
+    lw_prev = X_prev = None
+    for t in (range(T) if steps is None else steps):
+        X = pf._history(_lib.FIELD_X, t, island)
+        lw = pf._history(_lib.FIELD_LW, t, island)
+        if t > 0 and (lw_prev is None):
+            X_prev = pf._history(_lib.FIELD_X, t - 1, island)
+            lw_prev = pf._history(_lib.FIELD_LW, t - 1, island)
+        rs_flag = bool(summ[t, 4])
+        Xp = None
+        if t > 0:
+            # ---- the decision (core.py:181-183) on the contract's ESS
+            if two_level:
+                ess_prev = orc.two_level_reduce(*orc.tile_partials(lw_prev))[0]["ESS"]
+                assert ess_prev == summ[t - 1, 0], (t, ess_prev, summ[t - 1, 0])
+            else:
+                ess_prev = summ[t - 1, 0]
+                assert abs(ess_prev / orc.Weights(lw=lw_prev.copy()).ESS - 1) < 1e-11
+            assert rs_flag == bool(ess_prev < N * ESSrmin), t
+            if rs_flag:
+                A = pf._history(_lib.FIELD_A, t, island)
+                if u is not None:
+                    ut = np.asarray(u[t, island])
+                else:
+                    ut = orc.philox_resample_uniforms(pf.seed, scheme, N, t, island)
+                if scheme == "multinomial":
+                    su = ut if u is not None else None
+                else:
+                    su = orc.sorted_uniforms(scheme, N, ut)
+                W_dev = pf._history(_lib.FIELD_W, t - 1, island)
+                if su is not None:
+                    if two_level:
+                        A_c, _ = orc.inverse_cdf_2level_c(scheme, ut, lw_prev)
+                    else:
+                        A_c = orc.inverse_cdf_q62(su, W_dev)
+                    assert np.array_equal(A, A_c), (t, int(np.sum(A != A_c)))      # the contract: bit-exact
+                    W_ref = orc.exp_and_normalise(lw_prev)
+                    try:
+                        A_ref = orc.inverse_cdf(su, W_ref)
+                    except IndexError:
+                        A_ref = None
+                    if A_ref is not None and not np.array_equal(A, A_ref):
+                        n, ok = orc.audit_near_ties(su, W_ref, A_ref, A)
+                        assert ok, (t, n)
+                        near_ties += n
+                assert A.min() >= 0 and A.max() < N and np.all(np.diff(A) >= 0)
+                Xp = X_prev[A]
+            else:
+                Xp = X_prev
+        # ---- move and weigh (core.py:315-324) from the device's own parents
+        d = X.shape[1] if X.ndim == 2 else 1
+        if z is not None:
+            zt = np.asarray(z[t, island])
+        elif d == 1:
+            zt = orc.philox_normals(pf.seed, N, t, island)
+        else:
+            zt = None
+        if zt is not None:
+            Xo, inc = orc.propagate(model, fk, t, np.asarray(y[t]), Xp, zt, ctx)
+            lwo = inc if (t == 0 or rs_flag) else lw_prev + inc
+            lwo = np.where(np.isnan(lwo), -np.inf, lwo)
+            if exact and z is not None:
+                assert np.array_equal(X, Xo), (t, "X")
+                if fk == "bootstrap":
+                    assert np.array_equal(lw, lwo), (t, "lw")
+                else:
+                    assert np.allclose(lw, lwo, rtol=tol, atol=tol), (t, "lw")
+            else:
+                assert np.allclose(X, Xo, rtol=tol, atol=tol), (t, "X", float(np.max(np.abs(X - Xo))))
+                assert np.allclose(lw, lwo, rtol=100 * tol, atol=100 * tol), (t, "lw")
+        # ---- summaries (resampling.py:217-226, core.py:351-359) from the device's log-weights
+        w = orc.Weights(lw=lw.copy())
+        assert abs(summ[t, 0] / w.ESS - 1) < 1e-10, (t, "ESS")
+        assert abs(summ[t, 1] - w.log_mean) < 1e-11 * max(1.0, abs(w.log_mean)), (t, "log_mean")
+        loglt = w.log_mean if (t == 0 or rs_flag) else w.log_mean - prev_log_mean
+        assert abs(summ[t, 2] - loglt) < 1e-10 * max(1.0, abs(loglt)), (t, "loglt")
+        if steps is None:
+            logLt += summ[t, 2]
+            assert abs(summ[t, 3] - logLt) < 1e-10 * max(1.0, abs(logLt)), (t, "logLt")
+        prev_log_mean = w.log_mean
+        lw_prev, X_prev = lw, X
+    return near_ties
+
+
+EXACT_MODELS = ("toy", "lg", "gordon")          # IEEE + - * / only: X (and bootstrap lw) bit-exact
+
+
 def check_filter_replay(golden, case, model, fk, T=None, N=None):
     """Replay the reference's own draws through the fused device loop.  ``N`` overrides
-    the fixture's population size (the oracle then plays the reference's part)."""
+    the fixture's population size (the oracle then plays the reference's part).
+
+    Three layers: (1) the free-running reference-semantics oracle: same branch at every step,
+    ESS / log-evidence to 1e-9; (2) ``audit_history``: every step teacher-forced from the
+    device's own previous state -- ancestors bit-exact against the device's integer CDF
+    contract, every mismatch against the reference's sequential CDF certified a near-tie, X /
+    lw of EVERY particle compared (bit-exact for the IEEE-only models); (3) the production
+    kernels (no history: slot parity baked into the launches) give the same bits as the
+    history-keeping ones that were audited."""
     g = golden(case)
     mk_dev, mk_orc = MODELS[model]
     scheme, ESSrmin = str(g["scheme"]), float(g["ESSrmin"])
@@ -437,32 +558,28 @@ def check_filter_replay(golden, case, model, fk, T=None, N=None):
         assert o["final_logLt"] == float(g["logLt"])
     z, u = tapes_from_oracle(rec.tape, len(y), N, scheme)
     cls = ssm.Bootstrap if fk == "bootstrap" else ssm.GuidedPF
-    pf = pa.SMC(fk=cls(ssm=mk_dev(), data=y), N=N, resampling=scheme, ESSrmin=ESSrmin,
-                replay=(z, u))
+    mk = lambda hist: pa.SMC(fk=cls(ssm=mk_dev(), data=y), N=N, resampling=scheme, ESSrmin=ESSrmin,
+                             replay=(z, u), store_history=hist)
+    pf = mk(False)
     pf.run()
     assert pf.summaries.rs_flags == o["rs_flag"]                       # same branch every step
     assert rel(pf.summaries.ESSs, o["ESS"]) < 1e-9
     assert rel(pf.summaries.logLts, o["logLt"]) < 1e-9                 # north star: 1e-6
     assert abs(pf.logLt / o["final_logLt"] - 1) < 1e-9
-    same = np.mean(pf.A == o["A"])
-    assert same >= 0.999                                               # near-ties only
-    if model.startswith("mv"):        # matrix products: BLAS vs our FMA order, ~1e-13
-        if same == 1.0:
-            assert np.max(np.abs(pf.X - o["X"])) < 1e-11 and np.max(np.abs(pf.Xp - o["Xp"])) < 1e-11
-            assert np.allclose(pf.wgts.lw, o["lw"], rtol=1e-10, atol=1e-10)
-            assert rel(pf.W, o["W"]) < 1e-8
-        return pf, o
-    if same == 1.0:
-        exact = model.startswith(("toy", "lg", "gordon"))     # IEEE + - * / only -> bit-exact
+    ph = mk(True)
+    ph.run()
+    assert np.array_equal(ph.X, pf.X) and np.array_equal(ph.wgts.lw, pf.wgts.lw)
+    assert np.array_equal(ph._summ(), pf._summ())
+    if len(y) > 1:
+        assert np.array_equal(ph.A, pf.A)
+    mv = model.startswith("mv")
+    ties = audit_history(ph, mk_orc, fk, y, scheme, ESSrmin, z=z, u=u,
+                         exact=model in EXACT_MODELS, tol=1e-11 if mv else 1e-12)
+    assert ties <= max(1, len(y) * N // 100000)
+    if ties == 0 and not mv and len(y) > 1 and np.array_equal(pf.A, o["A"]):
+        # nothing flipped anywhere: the free-running oracle IS this run
+        exact = model.startswith(EXACT_MODELS)
         assert np.max(np.abs(pf.X - o["X"])) <= (0 if exact else 1e-12)
-        if model == "theta":          # exp() inside the transition: device exp within 1 ulp of numpy's
-            assert np.max(np.abs(pf.Xp - o["Xp"])) <= 1e-12
-        else:
-            assert np.array_equal(pf.Xp, o["Xp"])
-        if exact and fk == "bootstrap":
-            assert np.array_equal(pf.wgts.lw, o["lw"])
-        else:     # exp/log of the device libm differ from numpy's in the last ulp
-            assert np.allclose(pf.wgts.lw, o["lw"], rtol=1e-12, atol=1e-12)
         assert rel(pf.W, o["W"]) < 1e-10
     return pf, o
 
@@ -487,9 +604,11 @@ def check_model_philox_vs_oracle(golden, case, model, N=20000):
 
 def check_two_level_cdf(golden, monkeypatch, N=4096, T=20):
     """N = 2^k with 2..1024 tiles, systematic / stratified: the step loop runs on the two-level
-    exact CDF (k_ancestors2).  Replay of the reference's draws: against the oracle's restatement
-    of that contract, against the flat-Q62 device path, and against itself with the fp64 band
-    shortcut of the offspring counts switched off (every position formed exactly)."""
+    exact CDF (k_ancestors2).  Replay of the reference's draws: the oracle run on the same
+    contract (cdf="2level": orc_inverse_cdf_2level + the contract's ESS) must be THE SAME RUN,
+    bit for bit -- ancestors, particles, log-weights, decisions; so must the device variants
+    (fp64 band shortcut off; k_reduce2 in front); the reference-semantics oracle and the flat-Q62
+    device path agree up to audited near-ties (check_filter_replay does the audit per step)."""
     for case, scheme in (("toy_systematic", "systematic"), ("toy_stratified", "stratified")):
         g = golden(case)
         mk_dev, mk_orc = MODELS["toy"]
@@ -498,16 +617,27 @@ def check_two_level_cdf(golden, monkeypatch, N=4096, T=20):
         rec = orc.RecordingRNG()
         o = orc.run_filter(mk_orc(), y, N, scheme, 0.5, rng=rec, keep=True)          # reference semantics
         z, u = tapes_from_oracle(rec.tape, len(y), N, scheme)
-        o2 = orc.run_filter(mk_orc(), y, N, scheme, 0.5, rng=orc.ReplayRNG(rec.tape), cdf="2level")
+        o2 = orc.run_filter(mk_orc(), y, N, scheme, 0.5, rng=orc.ReplayRNG(rec.tape), cdf="2level",
+                            keep=True)
         runs = {}
         for name, env in (("two_level", {}), ("exact_counts", {"SMC_EXACT_COUNTS": "1"}),
                           ("mid", {"SMC_TWO_LEVEL_MID": "1"}), ("flat", {"SMC_FLAT_CDF": "1"})):
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
             pf = pa.SMC(fk=ssm.Bootstrap(ssm=mk_dev(), data=y), N=N, resampling=scheme, ESSrmin=0.5,
-                        replay=(z, u))
+                        replay=(z, u), store_history=(name == "two_level"))
             pf.run()
             runs[name] = (np.array(pf.A), np.array(pf.X), list(pf.summaries.logLts), list(pf.summaries.rs_flags))
+            if name == "two_level":
+                assert "k_ancestors2" in describe(pf)
+                # the oracle on the device's contract is the device's run, step by step
+                for t in range(len(y)):
+                    assert np.array_equal(pf.hist.X[t], o2["hist"]["X"][t]), t
+                    assert np.array_equal(pf.hist.wgts[t].lw, o2["hist"]["lw"][t]), t
+                    if o2["rs_flag"][t]:
+                        assert np.array_equal(pf.hist.A[t], o2["hist"]["A"][t]), t
+                assert list(pf.summaries.rs_flags) == o2["rs_flag"]
+                assert rel(pf.summaries.logLts, o2["logLt"]) < 1e-12
             monkeypatch.undo()
         A2, X2, ll2, rf2 = runs["two_level"]
         assert np.array_equal(A2, runs["exact_counts"][0]) and np.array_equal(X2, runs["exact_counts"][1])
@@ -518,23 +648,100 @@ def check_two_level_cdf(golden, monkeypatch, N=4096, T=20):
         assert ll2 == runs["mid"][2]
         assert rf2 == o["rs_flag"] and any(rf2)
         assert rel(ll2, o["logLt"]) < 1e-9 and rel(runs["flat"][2], o["logLt"]) < 1e-9
-        for ref in (o["A"], o2["A"], runs["flat"][0]):
-            assert np.mean(A2 == ref) >= 0.999                      # near-ties only
-        if np.array_equal(A2, o2["A"]):
-            assert np.array_equal(X2, o2["X"])                      # IEEE + - * / only
-    # the contract itself against the sequential fp64 CDF of the reference, skewed weights,
-    # -inf entries and an empty tile included
-    rng = np.random.default_rng(12)
-    lw = rng.normal(0.0, 3.0, size=4096)
-    lw[rng.random(4096) < 0.05] = -np.inf
-    lw[1024:2048] = -np.inf
-    W = np.exp(lw - lw.max())
-    W /= W.sum()
-    for M in (4096,):
-        su = (rng.random() + np.arange(M)) / M
-        A = orc.inverse_cdf_2level(su, lw)
-        assert np.mean(A == orc.inverse_cdf(su, W)) >= 0.999 and np.all(np.diff(A) >= 0)
-        assert not np.any((A >= 1024) & (A < 2048)) and np.all(W[A] > 0)
+    check_two_level_injected()
+
+
+def check_two_level_injected(sizes=(4096,)):
+    """The contract itself on weights no filter run would produce -- skewed, -inf entries, an
+    empty tile, a collapsed vector: uploaded with smc_filter_set_state, one resampling step on the
+    device, ancestors against orc_inverse_cdf_2level BIT FOR BIT and against the reference's
+    sequential fp64 CDF (resampling.py:500-509) with every mismatch certified a near-tie."""
+    y = [np.array([0.3]), np.array([0.1])]
+    for N in sizes:
+        rng = np.random.default_rng(12 + N)
+        cases = []
+        lw = rng.normal(0.0, 3.0, size=N)
+        cases.append(("skewed", lw.copy()))
+        lw[rng.random(N) < 0.05] = -np.inf
+        lw[1024:2048] = -np.inf                                  # an empty tile
+        cases.append(("minus_inf", lw.copy()))
+        cases.append(("very_skewed", rng.normal(0.0, 40.0, size=N)))
+        c = np.full(N, -800.0)
+        c[N // 3] = 0.0
+        cases.append(("collapsed", c))
+        cases.append(("flat", np.zeros(N)))
+        for scheme in ("systematic", "stratified"):
+            for name, lwi in cases:
+                pf = pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y), N=N, resampling=scheme,
+                            ESSrmin=2.0, seed=7, collect="off")         # ESSrmin 2: always resample
+                next(pf)
+                pf.set_state(lw=lwi)
+                assert np.array_equal(pf.wgts.lw, lwi)
+                red = orc.two_level_reduce(*orc.tile_partials(lwi))[0]
+                assert pf.wgts.ESS == red["ESS"], (name, pf.wgts.ESS, red["ESS"])
+                X0 = np.array(pf.X)
+                next(pf)
+                assert pf.rs_flag
+                ut = orc.philox_resample_uniforms(pf.seed, scheme, N, 1)
+                A_c, _ = orc.inverse_cdf_2level_c(scheme, ut, lwi)
+                A = np.array(pf.A)
+                assert np.array_equal(A, A_c), (N, scheme, name, int(np.sum(A != A_c)))
+                assert np.array_equal(pf.Xp, X0[A])
+                su = orc.sorted_uniforms(scheme, N, ut)
+                W = orc.exp_and_normalise(lwi)
+                assert np.all(W[A] > 0)
+                A_ref = orc.inverse_cdf(su, W)
+                n, ok = orc.audit_near_ties(su, W, A_ref, A)
+                assert ok and n <= max(1, N // 100000), (N, scheme, name, n)
+
+
+def check_oracle_at_size(model, mk_dev, mk_orc, N, T, scheme="systematic", ESSrmin=0.5, fk="bootstrap",
+                         replay=True, n_islands=1, islands=(0,), seed=5, d=1, data_seed=3,
+                         expect_resample=True):
+    """Oracle parity at BASELINE.json's sizes: a store_history run of T steps audited step by
+    step (audit_history: ancestors bit-exact against the contract, near-ties against the
+    reference's CDF certified, every particle's X / lw, ESS, evidence), and the production
+    kernels (no history) reproduce its final state bit for bit.  replay=True: the numpy draws
+    of a reference run of this shape are generated here and fed through the tapes (X and, for
+    the IEEE-only models, lw then are bit-exact); False: production Philox streams."""
+    rng = np.random.RandomState(data_seed)
+    if d == 1:
+        y = [np.array([v]) for v in 0.4 * np.cumsum(rng.standard_normal(T))]
+    else:
+        y = [rng.standard_normal((1, d)) for _ in range(T)]
+    cls = ssm.Bootstrap if fk == "bootstrap" else ssm.GuidedPF
+    z = u = None
+    if replay:
+        assert n_islands == 1
+        # numpy.random's legacy generator, drawn directly into the dense tapes (any tapes are
+        # valid inputs: the claim is "identical normals and uniforms in, identical particles out")
+        np.random.seed(seed)
+        z = np.random.standard_normal((T, 1, N) if d == 1 else (T, 1, N, d))
+        K = 1 if scheme == "systematic" else N
+        u = np.random.rand(T, 1, K)
+        if scheme == "multinomial":
+            for t in range(T):
+                u[t, 0] = orc.uniform_spacings_from(np.random.rand(N + 1))
+    mk = lambda hist: pa.SMC(fk=cls(ssm=mk_dev(), data=y), N=N, resampling=scheme, ESSrmin=ESSrmin,
+                             replay=None if z is None else (z, u), store_history=hist,
+                             n_islands=n_islands, seed=seed, collect="off")
+    ph = mk(True)
+    ph.run()
+    ties = 0
+    for isl in islands:
+        ties += audit_history(ph, mk_orc, fk, y, scheme, ESSrmin, z=z, u=u, exact=model.startswith(EXACT_MODELS),
+                              island=isl, tol=1e-11 if d > 1 else 1e-12)
+    assert ties <= max(1, len(islands) * T * N // 100000), ties
+    pf = mk(False)
+    pf.run()
+    for isl in islands:
+        assert np.array_equal(pf._get(_lib.FIELD_X, isl), ph._get(_lib.FIELD_X, isl))
+        assert np.array_equal(pf._get(_lib.FIELD_LW, isl), ph._get(_lib.FIELD_LW, isl))
+        if ph._summ()[isl, -1, 4]:
+            assert np.array_equal(pf._get(_lib.FIELD_A, isl), ph._get(_lib.FIELD_A, isl))
+    assert np.array_equal(pf._summ(), ph._summ())
+    assert not expect_resample or np.any(ph._summ()[:, 1:, 4] != 0)
+    return ties
 
 
 def check_heavy_parents(monkeypatch, N=8192, T=12):
@@ -651,8 +858,9 @@ def check_two_level_large(golden, monkeypatch, log2N=21, T=6):
         monkeypatch.undo()
     assert all(runs["two"][3][1:]) and runs["two"][3] == runs["flat"][3]
     assert np.array_equal(runs["two"][0], runs["exact"][0]) and np.array_equal(runs["two"][1], runs["exact"][1])
-    assert np.mean(runs["two"][0] == runs["flat"][0]) >= 0.999
-    assert rel(runs["two"][2], runs["flat"][2]) < 1e-6
+    assert rel(runs["two"][2], runs["flat"][2]) < 1e-6       # (two particle systems after the first near-tie)
+    # the k_reduce2 route against the oracle, every step, every ancestor
+    check_oracle_at_size("toy", *MODELS["toy"], N, 4, "systematic", 1.0, replay=False, seed=99)
     ll, _ = orc.kalman_loglik(orc.ToySSM(0.2), y)
     assert abs(runs["two"][2][-1] - ll) < 0.05
 

@@ -211,3 +211,17 @@ def test_smc2_example():
     spec.loader.exec_module(mod)
     mean, sd = mod.main(T=12, Ntheta=6, Nx=64)
     assert np.isfinite(mean) and np.isfinite(sd) and 0.05 < mean < 2.0
+
+
+def test_oracle_at_size_small():
+    """check_oracle_at_size (the BASELINE-size oracle tests of the GPU suite) at emulator sizes:
+    replay and Philox, the three schemes, d = 4 guided / bootstrap, islands."""
+    toy, sv, mv4 = pc.MODELS["toy"], pc.MODELS["sv"], pc.MODELS["mv4"]
+    pc.check_oracle_at_size("toy", *toy, 4096, 8, "systematic", 0.5)
+    pc.check_oracle_at_size("toy", *toy, 2048, 5, "stratified", 0.7, replay=False)
+    pc.check_oracle_at_size("sv", *sv, 3000, 4, "multinomial", 1.0)
+    pc.check_oracle_at_size("sv", *sv, 2048, 4, "systematic", 1.0)
+    pc.check_oracle_at_size("mv4", *mv4, 1024, 3, "systematic", 1.0, fk="guided", d=4)
+    pc.check_oracle_at_size("mv4", *mv4, 1024, 3, "systematic", 0.5, fk="guided", d=4, expect_resample=False)
+    pc.check_oracle_at_size("toy", *toy, 2048, 4, "systematic", 0.5, replay=False, n_islands=3,
+                            islands=(0, 2), seed=21)

@@ -243,6 +243,45 @@ def test_c4_mv32_guided_full_size():
     assert abs(a.logLt - ll) < 0.05, (a.logLt, ll)
 
 
+# ---- BASELINE.json full sizes against the ORACLE ---------------------------
+
+def test_two_level_contract_injected_full_sizes():
+    """k_ancestors2 / k_reduce2 on uploaded weights (skewed, -inf, empty tile, collapsed):
+    np.array_equal with the oracle's restatement at N = 2^12 .. 2^22."""
+    pc.check_two_level_injected(sizes=(1 << 12, 1 << 17, 1 << 20, 1 << 22))
+
+
+def test_c2_oracle_full_size():
+    """C2's N = 2^20, T = 20, replay of numpy draws: every step audited, X / lw bit-exact."""
+    mk_dev, mk_orc = pc.MODELS["toy"]
+    pc.check_oracle_at_size("toy", mk_dev, mk_orc, 1 << 20, 20, "systematic", 0.5)
+    pc.check_oracle_at_size("toy", mk_dev, mk_orc, 1 << 20, 6, "systematic", 0.5, replay=False)
+
+
+@pytest.mark.parametrize("scheme", ["multinomial", "stratified", "systematic"])
+def test_c3_oracle_full_size(scheme):
+    """C3's N = 2^22 StochVol, ESSrmin = 1, each scheme against the oracle (not each other)."""
+    mk_dev, mk_orc = pc.MODELS["sv"]
+    pc.check_oracle_at_size("sv", mk_dev, mk_orc, 1 << 22, 5, scheme, 1.0)
+
+
+def test_c4_oracle_d32():
+    """C4's d = 32 guided filter at N = 2^17 against the oracle (replayed draws)."""
+    mk_dev, mk_orc = pc.MODELS["mv32"]
+    pc.check_oracle_at_size("mv32", mk_dev, mk_orc, 1 << 17, 4, "systematic", 1.0, fk="guided", d=32)
+    pc.check_oracle_at_size("mv32", mk_dev, mk_orc, 1 << 17, 3, "systematic", 0.5, fk="guided", d=32,
+                            expect_resample=False)
+    pc.check_oracle_at_size("mv32", mk_dev, mk_orc, 1 << 17, 3, "systematic", 1.0, fk="bootstrap", d=32)
+
+
+def test_c5_oracle_islands():
+    """C5's share of one GPU, 32 islands x N = 2^18, production Philox streams: islands 0, 13
+    and 31 audited step by step against the oracle's Philox restatement."""
+    mk_dev, mk_orc = pc.MODELS["toy"]
+    pc.check_oracle_at_size("toy", mk_dev, mk_orc, 1 << 18, 8, "systematic", 0.5, replay=False,
+                            n_islands=32, islands=(0, 13, 31), seed=21)
+
+
 # ---- BASELINE.json full sizes: size-independent properties -----------------
 
 def _toy_data(golden, T):

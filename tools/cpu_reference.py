@@ -1,0 +1,141 @@
+"""CPU baseline of BASELINE.md section 3: the REFERENCE ITSELF (nchopin/particles imported
+read-only from /root/reference) timed on the build container's host cores.
+
+    PYTHONDONTWRITEBYTECODE=1 python tools/cpu_reference.py        # -> profiles/cpu_reference.json
+
+/root/reference does not exist on the GPU box, so bench.py cannot run this there; it times the
+oracle port live ("kind": "port") and prints this file's figures beside it, labelled as measured
+in the build container.  Legs:
+  * inputs: ToySSM(sigma=0.2) (README.md:66-78), np.random.seed(42); x, y = model.simulate(T);
+    SMC(fk=Bootstrap(ssm, y), N, resampling='systematic', ESSrmin=0.5); run seed 123
+  * timing: the reference's own pf.cpu_time (utils.py:81-89 around SMC.run, core.py:391),
+    median of 3 repetitions; N = 2^20 runs T_timed steps (cost per step is flat in T)
+  * 1 core, resampling.inverse_cdf (resampling.py:484-509) (a) as the pure-Python loop that
+    `numba.jit` degrades to without numba, (b) bound to a gcc -O2 C restatement of the same loop
+    (oracle/oracle.c orc_inverse_cdf_seq: element-identical output is asserted here) standing in
+    for the numba-compiled function
+  * all cores: particles.multiSMC(nruns=16, nprocs=<nproc>, collect='off', out_func=logLt) on
+    N = 2^18, T = 20, after one warm-up call (core.py:431-518, utils.py:158-186)
+"""
+import ctypes
+import json
+import os
+import platform
+import statistics
+import subprocess
+import sys
+import time
+
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "oracle", "numba_shim"), "/root/reference", ROOT]
+
+import numpy as np  # noqa: E402
+import particles  # noqa: E402
+from particles import distributions as dists  # noqa: E402
+from particles import resampling as rs  # noqa: E402
+from particles import state_space_models as ssm  # noqa: E402
+
+
+class ToySSM(ssm.StateSpaceModel):          # README.md:66-72
+    default_params = {"sigma": 0.2}
+
+    def PX0(self):
+        return dists.Normal()
+
+    def PX(self, t, xp):
+        return dists.Normal(loc=xp)
+
+    def PY(self, t, xp, x):
+        return dists.Normal(loc=x, scale=self.sigma)
+
+
+def c_inverse_cdf():
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, stdout=subprocess.DEVNULL)
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "_build", "liboracle.so"))
+    dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)
+    lib.orc_inverse_cdf_seq.argtypes = [dp, dp, ctypes.c_int64, ctypes.c_int64, ip]
+    lib.orc_inverse_cdf_seq.restype = ctypes.c_int64
+
+    def inverse_cdf(su, W):
+        su = np.ascontiguousarray(su, dtype=np.float64)
+        W = np.ascontiguousarray(W, dtype=np.float64)
+        A = np.empty(su.shape[0], dtype=np.int64)
+        if lib.orc_inverse_cdf_seq(su.ctypes.data_as(dp), W.ctypes.data_as(dp), su.shape[0],
+                                   W.shape[0], A.ctypes.data_as(ip)):
+            raise IndexError("index out of bounds")
+        return A
+    return inverse_cdf
+
+
+def time_run(model, y, N, reps=3):
+    out = []
+    for r in range(reps):
+        np.random.seed(123)
+        pf = particles.SMC(fk=ssm.Bootstrap(ssm=model, data=y), N=N, resampling="systematic",
+                           ESSrmin=0.5, collect="off")
+        pf.run()
+        out.append(pf.cpu_time)
+    return statistics.median(out), out, pf.logLt
+
+
+def logLt_of(pf):
+    return pf.logLt
+
+
+def main():
+    res = {"host": {"cpu": platform.processor() or open("/proc/cpuinfo").read().split("model name")[1].split("\n")[0].strip(": \t"),
+                    "nproc": os.cpu_count(), "python": platform.python_version(),
+                    "numpy": np.__version__, "where": "build container (no GPU)"},
+           "reference": "nchopin/particles v%s at /root/reference" % getattr(particles, "__version__", "?"),
+           "legs": {}}
+    model = ToySSM(sigma=0.2)
+    py_icdf = rs.inverse_cdf
+    c_icdf = c_inverse_cdf()
+    # the C stand-in computes what the reference's loop computes
+    rng = np.random.default_rng(0)
+    W = rng.random(5000); W /= W.sum()
+    su = (rng.random() + np.arange(5000)) / 5000
+    assert np.array_equal(py_icdf(su, W), c_icdf(su, W))
+
+    for name, N, T in (("C1 N=1000 T=200", 1000, 200), ("C2-shape N=2^20 (30 steps timed)", 1 << 20, 30)):
+        np.random.seed(42)
+        x, y = model.simulate(T)
+        for variant, fn in (("c_inverse_cdf", c_icdf), ("pure_python_inverse_cdf", py_icdf)):
+            rs.inverse_cdf = fn
+            med, allt, ll = time_run(model, y, N)
+            res["legs"]["%s, 1 core, %s" % (name, variant)] = {
+                "seconds_median": med, "seconds": allt, "N": N, "T": T, "cores": 1,
+                "particle_steps_per_s": N * T / med, "ms_per_step": 1e3 * med / T, "logLt": float(ll)}
+            print(name, variant, "%.3f s  %.2f M particle-steps/s" % (med, N * T / med / 1e6), flush=True)
+    rs.inverse_cdf = c_icdf
+    # all cores: multiSMC over a loky/multiprocessing pool (workers import the pure-Python
+    # inverse_cdf: the patch above does not travel, so this leg is the stock reference)
+    nproc = os.cpu_count()
+    N, T, nruns = 1 << 18, 20, 16
+    np.random.seed(42)
+    x, y = model.simulate(T)
+    fk = ssm.Bootstrap(ssm=model, data=y)
+    kw = dict(fk=fk, N=N, resampling="systematic", ESSrmin=0.5, nruns=nruns, nprocs=nproc,
+              collect="off", out_func=logLt_of)
+    particles.multiSMC(**dict(kw, nruns=nproc, N=1000))          # pool warm-up
+    ts = []
+    for r in range(3):
+        t0 = time.perf_counter()
+        out = particles.multiSMC(**kw)
+        ts.append(time.perf_counter() - t0)
+    med = statistics.median(ts)
+    res["legs"]["C5-shape multiSMC 16 x (N=2^18, T=20), %d processes" % nproc] = {
+        "seconds_median": med, "seconds": ts, "N": N, "T": T, "nruns": nruns, "cores": nproc,
+        "particle_steps_per_s": nruns * N * T / med,
+        "inverse_cdf": "stock (pure Python in the workers: numba absent)",
+        "logLt_sd": float(np.std([o["output"] for o in out]))}
+    print("multiSMC %d procs: %.2f s  %.1f M particle-steps/s" % (nproc, med, nruns * N * T / med / 1e6), flush=True)
+    path = os.path.join(ROOT, "profiles", "cpu_reference.json")
+    with open(path, "w") as fh:
+        json.dump(res, fh, indent=1)
+    print("wrote", path)
+
+
+if __name__ == "__main__":
+    main()
