@@ -14,13 +14,24 @@ data with its own Philox island id (weak scaling: total work = n_gpus * N * K);
 the per-rank log-evidences are gathered with RCCL (smc_comm_*) inside the timed
 region.  Inputs are resident in HBM before the timed region starts.
 
+The timed region of exactly K steps (barrier + device sync on both sides) is repeated R times
+on consecutive stretches of the same run (R such that about 10^4 steps are timed in all);
+`ms_per_step` / `value` are the MEDIAN repetition, the spread is reported beside them -- a
+K = 20 region lasts half a millisecond and a single shot of it is noise.
+
 Rank 0 prints ONE JSON line (see README / task contract), including
   roofline      -- the longer of the step's two kernels (resampling: k_ancestors2 /
                    k_ancestors; propagate: k_propagate): algorithmic bytes per launch over
-                   its average duration measured with HIP events on the filter's stream,
-                   against the 8 TB/s HBM peak of MI355X; both kernels under per_kernel;
-  cpu_baseline  -- the NumPy restatement of the reference path (oracle/, "port")
-                   timed on this host's cores on a bounded sample (N=1, rank 0).
+                   its average duration, BOTH measured with HIP events on the filter's stream
+                   (smc_filter_kernel_ms), against the 8 TB/s HBM peak of MI355X;
+  cpu_baseline  -- N=1, rank 0: the reference itself (nchopin/particles, pf.cpu_time) when it is
+                   importable (build container), else the NumPy restatement of its path
+                   (oracle/, "port") timed on this host's cores on a bounded sample, with the
+                   reference's own figures from profiles/cpu_reference.json printed beside it.
+
+Other BASELINE.json configs: --workload c3 (StochVol N=2^22; --scheme), c4 (d=32 guided),
+c5 (32 islands x 2^18 per GPU; `--workload c5 --gpus 8` is the 256-island SCALE run, evidence
+all-gather over RCCL inside the timed region).
 """
 import argparse
 import json
@@ -41,11 +52,13 @@ BYTES_PREPARE = 16.0             # k_ancestors: read lw, write A  (beyond 2048 w
 
 
 def synthetic_data(T, sigma=0.2, seed=42):
-    """ToySSM(sigma) sample path (README.md:66-78): X_0~N(0,1), X_t~N(X_{t-1},1),
-    Y_t~N(X_t, sigma^2)."""
-    rng = np.random.RandomState(seed)
-    x = np.cumsum(rng.standard_normal(T))
-    return [np.array([v]) for v in x + sigma * rng.standard_normal(T)]
+    """BASELINE.md section 3's inputs: ToySSM(sigma) (README.md:66-78), np.random.seed(42);
+    x, y = model.simulate(T) -- our simulate() consumes numpy's legacy stream exactly as the
+    reference's does (state_space_models.py:283-323), so these are the reference's data."""
+    from particles_amd import kalman
+    np.random.seed(seed)
+    x, y = kalman.ToySSM(sigma).simulate(T)
+    return y
 
 
 def measured_traffic(a, kernel):
@@ -70,20 +83,48 @@ def measured_traffic(a, kernel):
 
 
 def cpu_baseline(y, N, nsteps):
-    """The reference's NumPy path as restated by the oracle (1 core)."""
-    from oracle import smc_oracle as orc
+    """CPU leg beside the GPU number.  With /root/reference importable (build container) the
+    reference itself, timed by its own pf.cpu_time (utils.py:81-89, core.py:391); on the GPU box
+    the oracle's restatement of that path ("port": same NumPy calls, C inverse_cdf), plus the
+    reference's figures measured in the build container (profiles/cpu_reference.json)."""
     import subprocess
     subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True,
                    stdout=subprocess.DEVNULL)
+    ref_file = os.path.join(ROOT, "profiles", "cpu_reference.json")
+    committed = None
+    if os.path.exists(ref_file):
+        with open(ref_file) as fh:
+            rec = json.load(fh)
+        committed = {"host": rec["host"], "source": "profiles/cpu_reference.json (tools/cpu_reference.py)",
+                     "legs": {k: {"particle_steps_per_s": v["particle_steps_per_s"], "cores": v["cores"]}
+                              for k, v in rec["legs"].items()}}
+    sample = ("N=2^%d, first %d steps of the same data (np.random.seed(42); simulate), run seed 123; "
+              "cost per step is flat in T" % (int(np.log2(N)), nsteps))
+    if os.path.isdir("/root/reference/particles"):
+        code = ("import sys, json; sys.dont_write_bytecode = True\n"
+                "sys.path.insert(0, %r)\n"
+                "import numpy as np, tools.cpu_reference as cr\n"
+                "m = cr.ToySSM(sigma=0.2); np.random.seed(42); x, y = m.simulate(%d)\n"
+                "med, allt, ll = cr.time_run(m, y, %d, reps=1)\n"
+                "print(json.dumps({'s': med, 'll': float(ll)}))\n"
+                % (ROOT, nsteps, N))
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT)
+        if r.returncode == 0:
+            o = json.loads(r.stdout.strip().splitlines()[-1])
+            return {"value": N * nsteps / o["s"], "unit": "particle-steps/s", "cores": 1,
+                    "kind": "reference", "seconds": o["s"], "logLt": o["ll"],
+                    "sample": "particles.SMC(...).run(), pf.cpu_time; inverse_cdf bound to its gcc -O2 "
+                              "restatement (numba absent); " + sample,
+                    "reference_build_container": committed}
+    from oracle import smc_oracle as orc
     np.random.seed(123)
     t0 = time.perf_counter()
     out = orc.run_filter(orc.ToySSM(0.2), y[:nsteps], N, "systematic", 0.5)
     dt = time.perf_counter() - t0
     return {"value": N * nsteps / dt, "unit": "particle-steps/s", "cores": 1, "kind": "port",
-            "sample": "oracle.run_filter (NumPy restatement of particles.SMC + C inverse_cdf), "
-                      "N=2^%d, first %d steps of the same data; cost/step is flat in T"
-                      % (int(np.log2(N)), nsteps),
-            "seconds": dt, "logLt": out["final_logLt"]}
+            "sample": "oracle.run_filter (NumPy restatement of particles.SMC + C inverse_cdf); " + sample,
+            "seconds": dt, "logLt": out["final_logLt"],
+            "reference_build_container": committed}
 
 
 def main():
@@ -96,9 +137,10 @@ def main():
     ap.add_argument("--islands", type=int, default=1, help="filters per GPU")
     ap.add_argument("--essrmin", type=float, default=None)
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"],
-                    help="BASELINE.json config: c2 = headline (default); the others are "
-                         "measurement aids, not bench lines")
+                    help="BASELINE.json config: c2 = headline (default)")
     ap.add_argument("--cpu-steps", type=int, default=150)
+    ap.add_argument("--reps", type=int, default=0,
+                    help="repetitions of the K-step timed region (0: about 10^4 timed steps in all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
@@ -113,7 +155,8 @@ def main():
                      "--nproc-per-node %d" % (a.gpus, a.gpus))
         a.gpus = world
     # (functional test of the multi-rank path on a box with fewer GPUs than ranks:
-    #  SMC_BENCH_NGPU=1 lets all ranks share device 0; RCCL then refuses and the gather uses gloo)
+    #  SMC_BENCH_NGPU=1 lets all ranks share device 0; RCCL then refuses, which is an ERROR unless
+    #  SMC_ALLOW_HOST_GATHER=1 routes the evidences over the host rendezvous)
     ngpu = int(os.environ.get("SMC_BENCH_NGPU", "0"))
     os.environ["SMC_HIP_DEVICE"] = str(local_rank % ngpu if ngpu > 0 else local_rank)
 
@@ -124,7 +167,9 @@ def main():
 
     grp = Group(device_collective=True) if world > 1 else None
     K, W = a.steps, a.warmup
-    T = W + K
+    heavy = a.workload in ("c3", "c4", "c5")        # 0.07-0.3 ms per step: fewer timed steps do
+    R = a.reps if a.reps > 0 else max(3, min(500, -(-(2000 if heavy else 10000) // K)))
+    T = W + R * K
     d = 1
     if a.workload == "c3":        # StochVol, N = 2^22, ESSrmin = 1
         a.log2N = 22 if a.log2N == 20 else a.log2N
@@ -174,19 +219,23 @@ def main():
     pf.sync()
     if grp:       # warm-up of the path's one collective too (RCCL sets its channels up lazily)
         grp.gather_evidence(pf.logLts_islands)
-    # ---- timed region: exactly K steps, barrier + device sync on both sides
+    # ---- timed region: exactly K steps, barrier + device sync on both sides; R repetitions
+    dts = np.zeros(R)
+    for r in range(R):
+        if grp:
+            grp.barrier()
+        pf.sync()
+        t0 = time.perf_counter()
+        pf.step_async(K)
+        local_ll = pf.logLts_islands                       # syncs the stream
+        all_ll = grp.gather_evidence(local_ll) if grp else local_ll
+        pf.sync()
+        if grp:
+            grp.barrier()
+        dts[r] = time.perf_counter() - t0
     if grp:
-        grp.barrier()
-    pf.sync()
-    t0 = time.perf_counter()
-    pf.step_async(K)
-    local_ll = pf.logLts_islands                       # syncs the stream
-    all_ll = grp.gather_evidence(local_ll) if grp else local_ll
-    pf.sync()
-    if grp:
-        grp.barrier()
-    dt = time.perf_counter() - t0
-    dt = grp.allreduce_max_host(dt) if grp else dt
+        dts = grp.allreduce_max_host(dts)                  # per repetition: the slowest rank
+    dt = float(np.median(dts))
     rs_rate = float(np.mean(pf._summ()[0, W:, 4]))
     del pf
 
@@ -197,6 +246,11 @@ def main():
             "metric": "particle-steps/sec (N x T), %s filter N=2^%d" % ("guided" if a.workload == "c4" else "bootstrap", a.log2N),
             "value": units / dt, "unit": "particle-steps/s", "n_gpus": world, "steps": K,
             "warmup": W, "ms_per_step": 1e3 * dt / K, "higher_is_better": True,
+            "timing": {"reps": R, "statistic": "median of the repetitions of the K-step region",
+                       "ms_per_step_min": 1e3 * float(dts.min()) / K,
+                       "ms_per_step_max": 1e3 * float(dts.max()) / K,
+                       "ms_per_step_p10_p90": [1e3 * float(np.percentile(dts, 10)) / K,
+                                               1e3 * float(np.percentile(dts, 90)) / K]},
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s, N=2^%d, T=%d, %s resampling, ESSrmin=%g; %d independent "
                                    "filter(s) per GPU" % (wl, a.log2N, K, a.scheme, a.essrmin,
@@ -206,8 +260,7 @@ def main():
                        "resampled_fraction": rs_rate},
             "step_achieved_GBs": bytes_step * N * a.islands * K / dt / 1e9,
             "logLt": [float(v) for v in np.atleast_1d(all_ll)][:16],
-            "evidence_gather": ("rccl" if (grp and grp.comm) else
-                                ("gloo-fallback: %s" % grp.fallback_reason if grp else "none")),
+            "evidence_gather": grp.evidence_path if grp else "none",
         }
 
     # ---- dominant-kernel duration: same workload re-run with HIP events around
@@ -234,7 +287,7 @@ def main():
             mv_name = [k for k in kernels.split("+") if k.startswith("k_propagate")][0]
             rs_bytes = (BYTES_PREPARE + (8.0 if "k_prepare" in kernels else 0.0)) * N * a.islands
             mv_bytes = bytes_move * N * a.islands
-            rs_ms = max(out["ms_per_step"] - mv.value, 0.0)
+            rs_ms = pr.value
             per = {mv_name: {"ms": mv.value, "launch_bytes": mv_bytes,
                              "achieved": mv_bytes / (mv.value * 1e-3) / 1e9},
                    rs_name: {"ms": rs_ms, "launch_bytes": rs_bytes,
@@ -254,10 +307,11 @@ def main():
                         "32-bit words, so the kernels physically move 4 B less per particle each). "
                         "Per particle-step: k_propagate 32 B (read A, gather X; write X, lw), "
                         "k_ancestors / k_ancestors2 16 B (read lw, write A; + 8 B for k_prepare's pass over "
-                        "lw beyond 2048 workgroups per launch). The propagate kernel's ms = (HIP-event "
-                        "interval around whole steps) - (interval around the resampling kernels only), "
-                        "alternating steps, so the fixed ~4 us of an event interval cancels; the resampling "
-                        "kernels' ms = ms_per_step - that. `kernel` is the one that takes longer; "
+                        "lw beyond 2048 workgroups per launch). Both parts are measured with HIP events on "
+                        "the filter's stream in a separate pass over the same workload: steps are sampled "
+                        "in three kinds (whole step / up to the propagate launch / from there on), "
+                        "propagate = whole - first part, resampling = whole - second part, so the fixed "
+                        "~4 us of an event interval cancels. `kernel` is the one that takes longer; "
                         "step_frac = 56 B x N / ms_per_step over the HBM peak (the whole step)",
             }
             if a.workload == "c4":
@@ -275,7 +329,8 @@ def main():
             if tr:
                 out["roofline"]["traffic"], out["roofline"]["traffic_source"] = tr
     if rank == 0 and world == 1 and not a.no_cpu_baseline and a.workload == "c2":
-        out["cpu_baseline"] = cpu_baseline(y, N, min(a.cpu_steps, T))
+        nst = min(a.cpu_steps, T) if a.log2N >= 18 else min(T, 2000)
+        out["cpu_baseline"] = cpu_baseline(y, N, nst)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if grp:

@@ -344,13 +344,13 @@ int smc_filter_trajectories(smc_filter* f, int island, int64_t* out_host);
 int smc_filter_one_trajectory(smc_filter* f, int island, int64_t n_last, double* out_host);
 int smc_filter_info(smc_filter* f, double* bytes_per_particle_step,
                     int* kernels_per_step);
-/* Average duration (ms) of the dominant kernel (the propagate kernel, "move")
- * over the steps run since the last call, measured with HIP events on the
- * filter's stream when profiling is enabled with smc_filter_profile(f, 1):
- * even steps are bracketed as a whole, odd steps only up to the launch of the
- * propagate kernel; move_ms_avg is the difference of the two averages (the
- * fixed cost of an event interval cancels), prepare_ms_avg the raw interval of
- * the resampling kernels (it still contains that fixed cost, ~4 us). */
+/* Average duration (ms) of the step's two parts -- the propagate kernel ("move") and the
+ * resampling kernel(s) in front of it ("prepare") -- over the steps run since the last call,
+ * measured with HIP events on the filter's stream when profiling is enabled with
+ * smc_filter_profile(f, 1).  Steps are sampled in three kinds: the whole step, the interval up to
+ * the launch of the propagate kernel, the interval from there to the end; move = whole - first,
+ * prepare = whole - second, so the fixed cost of an event interval (~4 us) cancels and each
+ * part is measured, not derived from the other. */
 int smc_filter_profile(smc_filter* f, int enable);
 /* the kernels one time step of this filter launches, e.g. "k_ancestors2+k_propagate"
  * (two-level CDF), "k_ancestors<fused>+k_propagate", "k_prepare+k_ancestors+k_propagate",

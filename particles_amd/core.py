@@ -172,8 +172,7 @@ class SMC:
             model = None
         if qmc:                    # SQMC: the template-method step on device operators
             model = None
-        self._fused = model is not None and resampling in _lib.SCHEMES \
-            and (model.get("params") is not None or model["kind"] == _lib.MODEL_MVLINGAUSS)
+        self._fused = self._will_fuse(fk, qmc, resampling, model)
         if self._fused:
             # full history on the fused path stays on the device: the step loop
             # writes step t into slot t (no per-step host copies, no per-step sync)
@@ -187,6 +186,17 @@ class SMC:
             self._wgts = rs.Weights()
             self.aux = None
             self._X = self._Xp = self._A = None
+
+    @staticmethod
+    def _will_fuse(fk, qmc=False, resampling="systematic", model=False):
+        """Does SMC(fk, qmc, resampling) run the fused device loop?  (One predicate for ``SMC``
+        and for ``multiSMC``'s decision to batch runs as islands.)"""
+        if fk is None or qmc or fk.isAPF or resampling not in _lib.SCHEMES:
+            return False
+        if model is False:
+            model = fk._device_model() if hasattr(fk, "_device_model") else None
+        return model is not None and (model.get("params") is not None
+                                      or model["kind"] == _lib.MODEL_MVLINGAUSS)
 
     # ------------------------------------------------------------------ fused
     def _create_filter(self, model, replay, use_graph, island_offset):
@@ -203,8 +213,17 @@ class SMC:
                 rows = []
                 for g in self._fk_list:
                     mg = g._device_model()
-                    if mg is None or mg["kind"] != model["kind"] or g._fk_kind != fk._fk_kind or g.T != T:
+                    if mg is None or mg["kind"] != model["kind"] or g._fk_kind != fk._fk_kind or g.T != T \
+                            or not np.array_equal(np.asarray(g.data, dtype=np.float64).reshape(T, -1), y):
                         raise ValueError("per-island models must be of one fused kind, with the same data")
+                    # the per-step scalar of the transition / observation law rides in ONE (T,) array
+                    # shared by all islands: the parameters it depends on must not vary
+                    for key in ("aux", "aux_from_data"):
+                        if model.get(key) is not None and not np.array_equal(
+                                np.asarray(mg[key](T if key == "aux" else y)),
+                                np.asarray(model[key](T if key == "aux" else y))):
+                            raise ValueError("per-island models: the per-step term of this model depends on a "
+                                             "parameter that differs between islands (not supported)")
                     rows.append(mg["params"])
                 params = np.ascontiguousarray(np.stack(rows))
             m.params_host = params.ctypes.data_as(_lib.P(_lib.c_dbl))
@@ -217,6 +236,9 @@ class SMC:
                 m.aux_host = aux.ctypes.data_as(_lib.P(_lib.c_dbl))
             self._keep = (y, params, aux)
         else:       # MVLinearGauss: the matrices, row-major fp64 (kalman.py:296-361)
+            if self._fk_list is not None:
+                raise ValueError("per-island models are not supported for MVLinearGauss (one set of "
+                                 "matrices per filter)")
             mats = {k: np.ascontiguousarray(model[k], dtype=np.float64)
                     for k in ("F", "G", "covX", "covY", "mu0", "cov0")}
             for k, v in mats.items():
@@ -603,9 +625,9 @@ def multiSMC(nruns=10, nprocs=0, out_func=None, collect=None, **args):
         run_seeds = seeds[si:si + nruns]
         si += nruns
         fk = kw.get("fk")
-        batch = (fk is not None and hasattr(fk, "_device_model") and fk._device_model() is not None
-                 and not collect
-                 and not kw.get("store_history") and not kw.get("verbose"))
+        batch = (SMC._will_fuse(fk, kw.get("qmc", False), kw.get("resampling", "systematic"))
+                 and not collect and not kw.get("store_history") and not kw.get("verbose")
+                 and kw.get("n_islands", 1) == 1)
         if batch and out_func is not None:
             # islands of one filter; Philox island word = run index, key = first seed
             pf = SMC(collect="off", seed=int(run_seeds[0]), n_islands=nruns, **kw)
@@ -617,6 +639,7 @@ def multiSMC(nruns=10, nprocs=0, out_func=None, collect=None, **args):
                 results.append(d)
         else:
             for r in range(nruns):
+                np.random.seed(int(run_seeds[r]))       # utils.py:209-213: the seeder of each run
                 pf = SMC(collect=collect, seed=int(run_seeds[r]), **kw)
                 pf.run()
                 d = {"run": r, "seed": int(run_seeds[r])}

@@ -22,9 +22,10 @@ struct smc_filter {
     bool fused;            // k_ancestors<true> (no k_prepare launch)
     bool two_level;        // k_ancestors2 + tail-free k_propagate (two-level CDF, no intra-launch exchange)
     bool two_level_mid;    // ... with k_reduce2 in front (grids too large for every workgroup to reduce)
+    bool anc2_r1;          // experiments / tests: round 1's k_ancestors2 (SMC_ANC2_R1)
     i64 perm_t;            // t_host at the last smc_filter_permute_islands (A / Xp undefined there)
-    hipGraphExec_t gexec;
-    int graph_steps;
+    hipGraphExec_t gexec[3];   // captured step sequences of F_GRAPH_SIZES steps (even: see enqueue_step)
+    bool graph_failed;
     bool prof;
     std::vector<hipEvent_t> ev;
     int prof_n;
@@ -88,13 +89,19 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t)
     const dim3 grid(f->a.ntiles, f->a.n_islands);
     if (k_prof >= 0) (void)hipEventRecord(f->ev[3 * k_prof], st);
     if (f->two_level) {
-        if (f->two_level_mid) {
-            SMC_LAUNCH(k_reduce2, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
-            if (f->a.par >= 0) SMC_LAUNCH((k_ancestors2<true, true>), grid, dim3(SMC_BLOCK), st, f->a);
-            else SMC_LAUNCH((k_ancestors2<false, true>), grid, dim3(SMC_BLOCK), st, f->a);
-        } else if (f->a.par >= 0) SMC_LAUNCH((k_ancestors2<true, false>), grid, dim3(SMC_BLOCK), st, f->a);
-        else SMC_LAUNCH((k_ancestors2<false, false>), grid, dim3(SMC_BLOCK), st, f->a);
-        if (k_prof >= 0 && (k_prof & 1)) (void)hipEventRecord(f->ev[3 * k_prof + 1], st);
+        if (f->two_level_mid) SMC_LAUNCH(k_reduce2, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
+#define A2_CASE(K, SPECV, MIDV)                                                              \
+    if ((f->a.par >= 0) == SPECV && f->two_level_mid == MIDV)                                \
+        SMC_LAUNCH((K<SPECV, MIDV>), grid, dim3(SMC_BLOCK), st, f->a);
+        if (f->anc2_r1) {
+            A2_CASE(k_ancestors2_r1, true, true) A2_CASE(k_ancestors2_r1, false, true)
+            A2_CASE(k_ancestors2_r1, true, false) A2_CASE(k_ancestors2_r1, false, false)
+        } else {
+            A2_CASE(k_ancestors2, true, true) A2_CASE(k_ancestors2, false, true)
+            A2_CASE(k_ancestors2, true, false) A2_CASE(k_ancestors2, false, false)
+        }
+#undef A2_CASE
+        if (k_prof >= 0 && (k_prof % 3)) (void)hipEventRecord(f->ev[3 * k_prof + 1], st);
         launch_propagate(f);
         if (k_prof >= 0) (void)hipEventRecord(f->ev[3 * k_prof + 2], st);
         return;
@@ -109,10 +116,12 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t)
     if (fused && f->a.par >= 0) SMC_LAUNCH((k_ancestors<true, true>), grid, dim3(SMC_BLOCK), st, f->a);
     else if (fused) SMC_LAUNCH((k_ancestors<true, false>), grid, dim3(SMC_BLOCK), st, f->a);
     else SMC_LAUNCH((k_ancestors<false, false>), grid, dim3(SMC_BLOCK), st, f->a);
-    // odd samples split the step: [resampling kernels | propagate]; even ones time the whole
-    // step.  Every event interval carries the same ~4 us of marker processing on MI355X
-    // (tools/micro/events.hip), which cancels in (whole step) - (resampling part).
-    if (k_prof >= 0 && (k_prof & 1)) (void)hipEventRecord(f->ev[3 * k_prof + 1], st);
+    // samples come in three kinds (k mod 3): 0 times the whole step, 1 the interval [start,
+    // resampling kernels done], 2 the interval [resampling kernels done, end].  Every event
+    // interval carries the same ~4 us of marker processing on MI355X (tools/micro/events.hip),
+    // which cancels in propagate = whole - first part, resampling = whole - second part: both
+    // kernels are MEASURED (smc_filter_kernel_ms), neither is derived from the step time.
+    if (k_prof >= 0 && (k_prof % 3)) (void)hipEventRecord(f->ev[3 * k_prof + 1], st);
     launch_propagate(f);
     if (k_prof >= 0) (void)hipEventRecord(f->ev[3 * k_prof + 2], st);
     if (f->a.mom) {
@@ -172,8 +181,8 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     f->fk = model->fk;
     f->t_host = 0;
     f->use_graph = o->use_graph != 0;
-    f->gexec = nullptr;
-    f->graph_steps = 0;
+    f->gexec[0] = f->gexec[1] = f->gexec[2] = nullptr;
+    f->graph_failed = false;
     f->prof = false;
     f->prof_n = 0;
     f->perm_t = -1;
@@ -245,6 +254,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     // every workgroup reduces the partials itself while the launch is resident and an island has
     // at most 1024 tiles (4 per thread); otherwise one workgroup per island does it first
     f->two_level_mid = f->two_level && (!f->fused || a.ntiles > 1024 || getenv("SMC_TWO_LEVEL_MID"));
+    f->anc2_r1 = getenv("SMC_ANC2_R1") != nullptr;
     const bool heavy_list = !mv && !getenv("SMC_NO_HEAVY");
     const size_t oHcnt = carve(heavy_list ? M * 2 * sizeof(unsigned) : 8);
     const size_t oHlist = carve(heavy_list ? M * 2 * F_HMAX * 3 * 8 : 8);
@@ -263,6 +273,18 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
         return SMC_ERR_NOMEM;
     }
     f->slab = slab;
+    // (from here on a failing HIP call must not leak the slab and the struct)
+#define F_CREATE_CHECK(expr)                                                                   \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            smc_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__,     \
+                          __LINE__);                                                           \
+            (void)hipFree(slab);                                                               \
+            delete f;                                                                          \
+            return SMC_ERR_HIP;                                                                \
+        }                                                                                      \
+    } while (0)
     char* base = (char*)slab;
     a.X = (double*)(base + oX0);
     a.lw = (double*)(base + oL0);
@@ -282,7 +304,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     if (heavy_list) {
         a.hcnt = (unsigned*)(base + oHcnt);
         a.hlist = (i64*)(base + oHlist);
-        SMC_HIP_CHECK(hipMemsetAsync(a.hcnt, 0, M * 2 * sizeof(unsigned), ctx->stream));
+        F_CREATE_CHECK(hipMemsetAsync(a.hcnt, 0, M * 2 * sizeof(unsigned), ctx->stream));
     }
     a.exact_counts = getenv("SMC_EXACT_COUNTS") ? 1 : 0;
     // streaming stores pay while a launch is short (its end-of-kernel write-back shows): C2 +8 %;
@@ -297,34 +319,44 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     }
     a.trace = (u64*)(base + oTrace);
     hipStream_t st = ctx->stream;
-    SMC_HIP_CHECK(hipMemsetAsync(a.summ, 0, M * (T + 1) * SUMM_STRIDE * 8, st));
-    SMC_HIP_CHECK(hipMemsetAsync(a.cnt, 0, M * 2 * F_CNT_WORDS * sizeof(unsigned), st));
-    SMC_HIP_CHECK(hipMemsetAsync(a.Q, 0, M * a.ntiles * 8, st));
+    F_CREATE_CHECK(hipMemsetAsync(a.summ, 0, M * (T + 1) * SUMM_STRIDE * 8, st));
+    F_CREATE_CHECK(hipMemsetAsync(a.cnt, 0, M * 2 * F_CNT_WORDS * sizeof(unsigned), st));
+    F_CREATE_CHECK(hipMemsetAsync(a.Q, 0, M * a.ntiles * 8, st));
     {   // step record of t = 0: {t, rs_flag, y_0, m, 1/s}
         std::vector<double> h(M * INFO_STRIDE, 0.0);
         for (size_t i = 0; i < M; ++i) {
             h[i * INFO_STRIDE + 2] = y_host[0];
             h[i * INFO_STRIDE + 5] = model->aux_host ? model->aux_host[0] : 0.0;
         }
-        SMC_HIP_CHECK(hipMemcpyAsync(a.info, h.data(), h.size() * 8, hipMemcpyHostToDevice, st));
-        SMC_HIP_CHECK(hipMemsetAsync(a.info2, 0, M * INFO_STRIDE * 8, st));
-        SMC_HIP_CHECK(hipStreamSynchronize(st));
+        F_CREATE_CHECK(hipMemcpyAsync(a.info, h.data(), h.size() * 8, hipMemcpyHostToDevice, st));
+        F_CREATE_CHECK(hipMemsetAsync(a.info2, 0, M * INFO_STRIDE * 8, st));
+        F_CREATE_CHECK(hipStreamSynchronize(st));
     }
-    SMC_HIP_CHECK(hipMemsetAsync(a.A, 0, M * N * 4, st));
-    if (!mv)
-        SMC_HIP_CHECK(hipMemcpyAsync(dpar, model->params_host, M * PARAM_STRIDE * 8,
+    F_CREATE_CHECK(hipMemsetAsync(a.A, 0, M * N * 4, st));
+    std::vector<double> par_host(M * PARAM_STRIDE, 0.0);
+    if (!mv) {       // the host's rows + the correctly rounded reciprocals smc_div_c works with
+        for (size_t i = 0; i < M; ++i)
+            for (int k = 0; k < PARAM_HOST; ++k) {
+                const double v = model->params_host[i * PARAM_HOST + k];
+                par_host[i * PARAM_STRIDE + k] = v;
+                const double av = v < 0 ? -v : v;
+                par_host[i * PARAM_STRIDE + PARAM_HOST + k] = (av > 1e-20 && av < 1e20) ? 1.0 / v : 0.0;
+            }
+        F_CREATE_CHECK(hipMemcpyAsync(dpar, par_host.data(), M * PARAM_STRIDE * 8,
                                      hipMemcpyHostToDevice, st));
+    }
     a.mvc = (const double*)(base + oMvc);
     if (mv)
-        SMC_HIP_CHECK(hipMemcpyAsync((void*)a.mvc, mvc_host.data(), mvc_host.size() * 8,
+        F_CREATE_CHECK(hipMemcpyAsync((void*)a.mvc, mvc_host.data(), mvc_host.size() * 8,
                                      hipMemcpyHostToDevice, st));
-    SMC_HIP_CHECK(hipMemcpyAsync(dy, y_host, T * dym * 8, hipMemcpyHostToDevice, st));
+    F_CREATE_CHECK(hipMemcpyAsync(dy, y_host, T * dym * 8, hipMemcpyHostToDevice, st));
     if (model->aux_host) {
         a.aux = (const double*)(base + oAux);
-        SMC_HIP_CHECK(hipMemcpyAsync((void*)a.aux, model->aux_host, T * 8, hipMemcpyHostToDevice, st));
+        F_CREATE_CHECK(hipMemcpyAsync((void*)a.aux, model->aux_host, T * 8, hipMemcpyHostToDevice, st));
     }
-    SMC_HIP_CHECK(hipStreamSynchronize(st));
-    SMC_HIP_CHECK(hipStreamSynchronize(st));
+    F_CREATE_CHECK(hipStreamSynchronize(st));
+    F_CREATE_CHECK(hipStreamSynchronize(st));
+#undef F_CREATE_CHECK
     *out = f;
     return SMC_OK;
 }
@@ -347,7 +379,8 @@ int smc_filter_destroy(smc_filter* f)
     if (!f) return SMC_OK;
     (void)hipSetDevice(f->ctx->device);
     (void)hipStreamSynchronize(f->ctx->stream);
-    if (f->gexec) (void)hipGraphExecDestroy(f->gexec);
+    for (hipGraphExec_t g : f->gexec)
+        if (g) (void)hipGraphExecDestroy(g);
     for (hipEvent_t e : f->ev) (void)hipEventDestroy(e);
     (void)hipFree(f->slab);
     delete f;
@@ -415,32 +448,33 @@ int smc_filter_step(smc_filter* f, int64_t nsteps)
     }
     i64 done = 0;
 #ifndef SMC_EMULATE
-    const int GS = 24;                    // even: see enqueue_step
-    if (f->use_graph && !f->prof && todo >= GS + 1) {
-        if (!f->gexec) {   // captured once, on the first call (kernel arguments are final by then)
-            hipGraph_t g = nullptr;
-            if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                for (int k = 0; k < GS; ++k) enqueue_step(f, -1, k);
-                if (hipStreamEndCapture(st, &g) == hipSuccess && g &&
-                    hipGraphInstantiate(&f->gexec, g, nullptr, nullptr, 0) == hipSuccess) {
-                    f->graph_steps = GS;
-                } else {
-                    f->gexec = nullptr;
-                    f->use_graph = false;
-                }
-                if (g) (void)hipGraphDestroy(g);
-            } else {
-                f->use_graph = false;
-            }
-            (void)hipGetLastError();
-        }
-        if (f->gexec && ((f->t_host + done) & 1)) {      // graphs start at even t
+    // hipGraphs of 24, 8 and 2 steps (even sizes, entered at even t: the slot parity is baked into
+    // the nodes), captured on first use; any request of two or more steps replays them greedily
+    static const int F_GRAPH_SIZES[3] = {24, 8, 2};
+    if (f->use_graph && !f->prof && !f->graph_failed && todo >= 2) {
+        if ((f->t_host + done) & 1) {                    // graphs start at even t
             enqueue_step(f, -1, f->t_host + done);
             ++done;
         }
-        while (f->gexec && todo - done >= f->graph_steps) {
-            SMC_HIP_CHECK(hipGraphLaunch(f->gexec, st));
-            done += f->graph_steps;
+        for (int gi = 0; gi < 3 && !f->graph_failed; ++gi) {
+            const int GS = F_GRAPH_SIZES[gi];
+            if (todo - done < GS) continue;
+            if (!f->gexec[gi]) {   // (kernel arguments are final by the first step call)
+                hipGraph_t g = nullptr;
+                bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
+                if (ok) {
+                    for (int k = 0; k < GS; ++k) enqueue_step(f, -1, k);
+                    ok = hipStreamEndCapture(st, &g) == hipSuccess && g &&
+                         hipGraphInstantiate(&f->gexec[gi], g, nullptr, nullptr, 0) == hipSuccess;
+                }
+                if (g) (void)hipGraphDestroy(g);
+                (void)hipGetLastError();
+                if (!ok) { f->gexec[gi] = nullptr; f->graph_failed = true; break; }
+            }
+            while (todo - done >= GS) {
+                SMC_HIP_CHECK(hipGraphLaunch(f->gexec[gi], st));
+                done += GS;
+            }
         }
     }
 #endif
@@ -876,22 +910,25 @@ int smc_filter_kernel_ms(smc_filter* f, double* move_ms_avg, double* prepare_ms_
 {
     SMC_REQUIRE(f && move_ms_avg && prepare_ms_avg && n_samples, "null argument");
     SMC_HIP_CHECK(hipStreamSynchronize(f->ctx->stream));
-    double whole = 0.0, pre = 0.0;
-    int nw = 0, np = 0;
+    double whole = 0.0, pre = 0.0, post = 0.0;
+    int nw = 0, np = 0, nq = 0;
     for (int k = 0; k < f->prof_n; ++k) {
         float a = 0.f;
-        if (k & 1) {
+        if (k % 3 == 1) {
             SMC_HIP_CHECK(hipEventElapsedTime(&a, f->ev[3 * k], f->ev[3 * k + 1]));
             pre += a; ++np;
+        } else if (k % 3 == 2) {
+            SMC_HIP_CHECK(hipEventElapsedTime(&a, f->ev[3 * k + 1], f->ev[3 * k + 2]));
+            post += a; ++nq;
         } else {
             SMC_HIP_CHECK(hipEventElapsedTime(&a, f->ev[3 * k], f->ev[3 * k + 2]));
             whole += a; ++nw;
         }
     }
     *n_samples = f->prof_n;
-    const double w = nw ? whole / nw : 0.0, p = np ? pre / np : 0.0;
+    const double w = nw ? whole / nw : 0.0, p = np ? pre / np : 0.0, q = nq ? post / nq : 0.0;
     *move_ms_avg = (nw && np) ? w - p : 0.0;
-    *prepare_ms_avg = p;
+    *prepare_ms_avg = (nw && nq) ? w - q : 0.0;
     f->prof_n = 0;
     return SMC_OK;
 }

@@ -51,7 +51,8 @@
 #define F_TILE (SMC_BLOCK * F_IPT)
 #define F_PASS (SMC_BLOCK * 4)      /* offspring per pass: 4 per thread */
 #define SUMM_STRIDE 8   /* ESS, log_mean, loglt, logLt, rs_flag, m, 1/s, - */
-#define PARAM_STRIDE 16
+#define PARAM_STRIDE 32  /* 16 model constants (the host's params row), then RN(1 / constant) of each */
+#define PARAM_HOST 16
 #define INFO_STRIDE 8   /* per-island step record: t, rs_flag, y_t, m, 1/s of step t-1, aux_t */
 
 struct FArgs {
@@ -121,6 +122,23 @@ __host__ __device__ __forceinline__ u32* f_A(const FArgs& a, i64 t) { return a.A
 #define F_STAMP_A(k) do { } while (0)
 #endif
 
+// a / b for a model constant b whose correctly rounded reciprocal rb = RN(1/b) sits next to it in
+// the params row (computed on the host): q0 = RN(a rb) is within 1 ulp of a/b, r = a - b q0 is
+// exact in the fma, and RN(q0 + r rb) = RN(a / b) (Markstein's theorem; 4e8 random and
+// adversarial pairs checked against the division in tools/micro/markstein.c) -- the IEEE
+// quotient, i.e. the reference's bits, in 3 instructions instead of 11.  Outside the range
+// where nothing can overflow or go subnormal on the way (a = 0, inf, NaN included; rb = 0
+// marks a divisor the host would not vouch for) the division itself is executed.
+__device__ __forceinline__ double smc_div_c(const double a, const double b, const double rb)
+{
+    const double q0 = a * rb;
+    const double r = fma(-q0, b, a);
+    double q = fma(r, rb, q0);
+    const double m = fabs(q0);
+    if (!(m > 1e-280 && m < 1e280)) q = a / b;
+    return q;
+}
+
 // ---------------------------------------------------------------------------
 // model family
 // ---------------------------------------------------------------------------
@@ -173,14 +191,15 @@ __device__ __forceinline__ double m_obs_logpdf(const double* p, double y, double
         return (xl - aux) - mu;
     }
     if (KIND == SMC_MODEL_SVLEVERAGE) {                         // ssm.py:531-541
-        const double u = first ? (x - p[0]) / p[3] : (x - (p[4] + p[1] * xp)) / p[2];
+        const double u = first ? smc_div_c(x - p[0], p[3], p[16 + 3])
+                               : smc_div_c(x - (p[4] + p[1] * xp), p[2], p[16 + 2]);
         const double sx = exp(0.5 * x);
         const double loc = sx * p[5] * u, sc = sx * p[6];
         const double v = (y - loc) / sc;
         return -(v * v) / 2.0 - SMC_C_NORM - log(sc);
     }
     if (KIND == SMC_MODEL_LINGAUSS || KIND == SMC_MODEL_THETALOGISTIC) {   // kalman.py:433-434, ssm.py:682-683
-        const double v = (y - x) / p[2];
+        const double v = smc_div_c(y - x, p[2], p[16 + 2]);
         return -(v * v) / 2.0 - SMC_C_NORM - p[4];
     }
     if (KIND == SMC_MODEL_GORDON) {                             // ssm.py:576-577: Normal(loc=a x^2), scale 1
@@ -191,9 +210,10 @@ __device__ __forceinline__ double m_obs_logpdf(const double* p, double y, double
     const double v = (y - 0.0) / sc;
     return -(v * v) / 2.0 - SMC_C_NORM - log(sc);
 }
-__device__ __forceinline__ double m_norm_logpdf(double x, double loc, double scale, double lscale)
+__device__ __forceinline__ double m_norm_logpdf(double x, double loc, double scale, double rscale,
+                                                double lscale)
 {
-    const double v = (x - loc) / scale;
+    const double v = smc_div_c(x - loc, scale, rscale);
     return -(v * v) / 2.0 - SMC_C_NORM - lscale;
 }
 
@@ -211,16 +231,16 @@ __device__ __forceinline__ double m_step(const double* p, bool first, double y, 
     // guided filter with LinearGauss' optimal proposal (kalman.py:436-446,
     // state_space_models.py:374-392)
     if (first) {
-        const double mu = p[12] * (y / p[8]);
+        const double mu = p[12] * smc_div_c(y, p[8], p[16 + 8]);
         const double x = mu + p[13] * z;
-        inc = (m_norm_logpdf(x, 0.0, p[3], p[6]) + m_obs_logpdf<KIND>(p, y, x, xp, first, aux))
-              - m_norm_logpdf(x, mu, p[13], p[14]);
+        inc = (m_norm_logpdf(x, 0.0, p[3], p[16 + 3], p[6]) + m_obs_logpdf<KIND>(p, y, x, xp, first, aux))
+              - m_norm_logpdf(x, mu, p[13], p[16 + 13], p[14]);
         return x;
     }
-    const double mu = p[9] * (p[0] * xp / p[7] + y / p[8]);
+    const double mu = p[9] * (smc_div_c(p[0] * xp, p[7], p[16 + 7]) + smc_div_c(y, p[8], p[16 + 8]));
     const double x = mu + p[10] * z;
-    inc = (m_norm_logpdf(x, p[0] * xp, p[1], p[5]) + m_obs_logpdf<KIND>(p, y, x, xp, first, aux))
-          - m_norm_logpdf(x, mu, p[10], p[11]);
+    inc = (m_norm_logpdf(x, p[0] * xp, p[1], p[16 + 1], p[5]) + m_obs_logpdf<KIND>(p, y, x, xp, first, aux))
+          - m_norm_logpdf(x, mu, p[10], p[16 + 10], p[11]);
     return x;
 }
 
@@ -1320,7 +1340,7 @@ k_reduce2(const FArgs av)
 // Qpre / Q and the record in `info`): grids too large for every workgroup to repeat it.
 template <bool SPEC, bool MID>
 __global__ void __launch_bounds__(SMC_BLOCK)
-k_ancestors2(const FArgs av)
+k_ancestors2_r1(const FArgs av)
 {
     const FArgs& a = av;
     __shared__ __attribute__((aligned(16))) u32 sP[F_PASS];
@@ -1420,6 +1440,313 @@ k_ancestors2(const FArgs av)
                                  if (ok[i]) smc_stg(A + n0 + i, a32[i]);
                          }
                      });
+    F_STAMP_A(6);
+}
+
+// ---------------------------------------------------------------------------
+// k_ancestors2, lean form (round 2).  Same contract, same bits as k_ancestors2_r1 above (tests
+// run both: SMC_ANC2_R1=1 selects the old one), about two thirds of its vector instructions and
+// a third of its barriers:
+//   * every block-wide exchange has its own LDS slots, so each costs ONE barrier, and exchanges
+//     that do not depend on each other share it (tile scan totals + maximum of the partials);
+//   * systematic: the first offspring of a parent is floor(Y - u) + 1 with the parent's position
+//     Y = (G_b + c Q_b / t_b) 2^-(62-k) in offspring units evaluated in fp64; the exact integer
+//     route (128-bit product, smc_muldiv_floor, then count()) is taken only when Y - u lies
+//     within eps = 16 N 2^-53 of an integer, ten times the worst-case error of the fp64
+//     evaluation (derivation at f2_ns_sys) -- probability 2^-28 per parent at N = 2^20;
+//   * the tile's first and one-past-last offspring come from the same function evaluated by
+//     every thread (uniform values), not from an LDS exchange;
+//   * ONE scatter pass over a window of 2048 offspring (8 KB of LDS, zeroed while the loads are
+//     in flight): a tile owns 1024 +- a few dozen offspring, which the 1024-wide window of r1
+//     split into two passes (4 barriers each) for every other tile.
+// ---------------------------------------------------------------------------
+struct F2Fast {
+    double Gd, r, u, eps, one_m_eps, dN;
+    u64 Gb, Qb, tb;
+};
+// First offspring of the parent at position c (0 <= c <= t_b) of tile b's local CDF, systematic,
+// N = 2^k: ns = count(C), C = G_b + floor(c Q_b / t_b), count(C) = #{n : fl(u + n) 2^sh <= C}
+// (sh = 62 - k).  With Y = C 2^-sh: ns = floor(Y - u) + 1 whenever Y - u is not within the
+// rounding errors of an integer.  fp64 evaluation z = fma((double)c, r, Gd) - u with
+// r = fl(fl(Q_b) / fl(t_b)) 2^-sh, Gd = fl(G_b) 2^-sh: |z - (Y - u)| <= (4 ulp on the product,
+// 1 on Gd, 1 on the fma, 1 on the subtraction, 1 for fl(u + n), 2^-9 for the floor in C) x N 2^-53
+// < 10 N 2^-53; the band is 16 N 2^-53.  Outside it the floor and the comparison are decided.
+__device__ __forceinline__ i64 f2_ns_sys(const FArgs& a, const SmcSu& su, const u64 Us, const F2Fast& f,
+                                         const u64 c)
+{
+    const double z = fma((double)c, f.r, f.Gd) - f.u;
+    const double fl = floor(z);
+    const double d = z - fl;
+    if (d > f.eps && d < f.one_m_eps) {
+        double v = fl + 1.0;
+        v = v < 0.0 ? 0.0 : v;
+        v = v > f.dN ? f.dN : v;
+        return (i64)(u32)v;
+    }
+    return f2_count(a, su, Us, f.Gb + smc_muldiv_floor(c, f.Qb, f.tb));
+}
+
+template <bool SPEC, bool MID>
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_ancestors2(const FArgs av)
+{
+    const FArgs& a = av;
+    constexpr int WIN = 2 * F_PASS;                                        // offspring per pass
+    __shared__ __attribute__((aligned(16))) u32 sP[WIN];
+    __shared__ u64 s_scan[SMC_NWAVE];                                      // one area per exchange
+    __shared__ double s_max[SMC_NWAVE];
+    __shared__ double s_sum[2 * SMC_NWAVE];
+    __shared__ u64 s_g[SMC_NWAVE + 1];
+    __shared__ u32 s_mx[2 * SMC_NWAVE];
+    const int b = (int)blockIdx.x, isl = (int)blockIdx.y;
+    const int tid = (int)threadIdx.x;
+    const int lane = smc_lane(), wave = smc_wave();
+    const i64 N = a.N;
+    const bool vec = (N & 3) == 0;
+    const i64 j0 = (i64)b * F_TILE;
+    const i64 jt = j0 + (i64)tid * F_IPT;
+    F_STAMP_A(0);
+    double* info = a.info + (i64)isl * INFO_STRIDE;
+    const double r0 = smc_ldg(MID ? info : a.info2 + (i64)isl * INFO_STRIDE);
+    const double r1 = MID ? smc_ldg(info + 1) : 0.0;
+    const i64 o = (i64)isl * a.nparts;
+    double pm4[4], ps4[4], pss4[4], l4[4];
+    const double mb_raw = smc_ldg(a.pm + o + b);              // what the local CDF needs first
+    u64 Gmid = 0ull, Qmid = 0ull;
+    if (MID) {
+        Gmid = smc_ldg(a.Qpre + (i64)isl * a.ntiles + b);
+        Qmid = smc_ldg(a.Q + (i64)isl * a.ntiles + b);
+    }
+    if (SPEC)
+        f_load4<double>(a.lw + (i64)(a.par ^ 1) * a.lslot + (i64)isl * N, jt, N, vec, -INFINITY, l4);
+    if (!MID) {
+        const bool pvec = (a.nparts & 3) == 0;
+        f_load4<double>(a.pm + o, (i64)tid * 4, a.nparts, pvec, -INFINITY, pm4);
+        f_load4<double>(a.ps + o, (i64)tid * 4, a.nparts, pvec, 0.0, ps4);
+        f_load4<double>(a.pss + o, (i64)tid * 4, a.nparts, pvec, 0.0, pss4);
+    }
+    // the scatter window of the first pass, while the loads are on their way
+    *reinterpret_cast<uint4*>(&sP[tid * 4]) = make_uint4(0u, 0u, 0u, 0u);
+    *reinterpret_cast<uint4*>(&sP[F_PASS + tid * 4]) = make_uint4(0u, 0u, 0u, 0u);
+    const i64 t = (i64)smc_uniform(r0);
+    if (t >= a.T) {
+        if (!MID && b == 0 && tid == 0) info[0] = (double)t;   // k_propagate returns on it
+        return;
+    }
+    if (t == 0) return;                                        // the host wrote the record of step 0
+    if (MID && smc_uniform(r1) == 0.0) return;                 // k_reduce2: step t does not resample
+    if (!SPEC) f_load4<double>(f_lw(a, t - 1) + (i64)isl * N, jt, N, vec, -INFINITY, l4);
+    F_STAMP_A(1);
+    SmcSu su;                                                  // (the step's uniform: a Philox call
+    u64 Us;                                                    //  in the shadow of the loads)
+    f2_su(a, isl, t, su, Us);
+    // ---- the tile's own integer CDF, relative to the tile's maximum
+    const double mb = smc_uniform(mb_raw);
+    u64 q4[4], tsum = 0ull;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double e = (l4[i] > -INFINITY) ? smc_exp_nonpos(l4[i] - mb) : 0.0;
+        q4[i] = (jt + i < N) ? (u64)rint(e * 1125899906842624.0) : 0ull;          // 2^50
+        tsum += q4[i];
+    }
+    const u64 inc = smc_wave_scan_add_u64(tsum);
+    if (lane == 63) s_scan[wave] = inc;
+    double tm = -INFINITY;
+    if (!MID) {                                                // ... and the maximum of the partials
+        tm = smc_max2(smc_max2(pm4[0], pm4[1]), smc_max2(pm4[2], pm4[3]));
+        tm = smc_wave_max(tm);
+        if (lane == 0) s_max[wave] = tm;
+    }
+    __syncthreads();                                           // (1) also: sP zeroed
+    u64 cex = inc - tsum, tb = 0ull;
+#pragma unroll
+    for (int w = 0; w < SMC_NWAVE; ++w) {
+        if (w < wave) cex += s_scan[w];
+        tb += s_scan[w];
+    }
+    F_STAMP_A(2);
+    u64 Gb, Qb;
+    if (MID) {
+        Gb = smc_uniform(Gmid);
+        Qb = smc_uniform(Qmid);
+    } else {
+        // ---- all partials -> (m, s), ESS, the decision (same operations and order as f2_reduce)
+        F2Red r;
+        r.m = s_max[0];
+#pragma unroll
+        for (int w = 1; w < SMC_NWAVE; ++w) r.m = smc_max2(r.m, s_max[w]);
+        double e4[4], s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            e4[k] = (pm4[k] > -INFINITY) ? smc_exp_nonpos(pm4[k] - r.m) : 0.0;
+            s1 = fma(ps4[k], e4[k], s1);
+            s2 = fma(pss4[k], e4[k] * e4[k], s2);
+        }
+        s1 = smc_wave_sum(s1);
+        s2 = smc_wave_sum(s2);
+        if (lane == 0) { s_sum[wave] = s1; s_sum[SMC_NWAVE + wave] = s2; }
+        __syncthreads();                                       // (2)
+        s1 = s_sum[0];
+        s2 = s_sum[SMC_NWAVE];
+#pragma unroll
+        for (int w = 1; w < SMC_NWAVE; ++w) { s1 = s1 + s_sum[w]; s2 = s2 + s_sum[SMC_NWAVE + w]; }
+        r.s = s1;
+        r.ss = s2;
+        r.bad = !(r.m > -INFINITY) || !(r.m < INFINITY);
+        r.ess = r.bad ? NAN : (s1 * s1) / s2;                              // resampling.py:226
+        r.rs = r.bad ? NAN : 1.0 / s1;
+        const bool resample = r.ess < a.ess_thresh;            // core.py:181-183 (t < T here)
+        if (b == 0 && tid == 0) {
+            r.log_mean = r.bad ? NAN : r.m + log(s1 / (double)a.N);        // resampling.py:224
+            f2_write_record(a, isl, t, r, resample);
+        }
+        F_STAMP_A(3);
+        if (!resample) return;
+        // ---- this tile's share Q_b of the 2^62 scale and the shares before it, G_b
+        u64 qbefore = 0ull;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = tid * 4 + k;
+            const u64 Qk = (i < a.nparts) ? smc_q62_w((ps4[k] * e4[k]) * r.rs) : 0ull;
+            if (i < b) qbefore += Qk;
+            if (i == b) s_g[SMC_NWAVE] = Qk;
+        }
+        qbefore = smc_wave_sum_u64(qbefore);
+        if (lane == 0) s_g[wave] = qbefore;
+        __syncthreads();                                       // (3)
+        Gb = s_g[0];
+#pragma unroll
+        for (int w = 1; w < SMC_NWAVE; ++w) Gb = Gb + s_g[w];
+        Qb = s_g[SMC_NWAVE];
+    }
+    F_STAMP_A(4);
+    // ---- first offspring of each parent; the tile's range [n_lo, n_hi)
+    i64 ns[F_IPT + 1], n_lo, n_hi;
+    if (a.scheme == SMC_SYSTEMATIC_) {
+        F2Fast f;
+        const int sh = 62 - a.log2N;
+        const double down = __longlong_as_double((long long)(1023 - sh) << 52);   // 2^-sh
+        f.Gb = Gb; f.Qb = Qb; f.tb = tb;
+        f.Gd = (double)Gb * down;
+        f.r = tb ? ((double)Qb / (double)tb) * down : 0.0;
+        f.u = su.u_sys;
+        f.dN = (double)N;
+        f.eps = a.exact_counts ? 2.0 : f.dN * 0x1.0p-49;                 // (2.0: always the exact route)
+        f.one_m_eps = 1.0 - f.eps;
+        u64 c = cex;
+#pragma unroll
+        for (int i = 0; i <= F_IPT; ++i) {
+            const i64 j = jt + i;
+            ns[i] = (j == 0) ? 0 : (j >= N ? N : f2_ns_sys(a, su, Us, f, c));
+            if (i < F_IPT) c += q4[i];
+        }
+        n_lo = (b == 0) ? 0 : f2_ns_sys(a, su, Us, f, 0ull);
+        n_hi = (b == a.ntiles - 1) ? N : f2_ns_sys(a, su, Us, f, tb);
+    } else {
+        f2_first_offspring(a, su, Us, q4, cex, tb, Gb, Qb, jt, ns);
+        __shared__ i64 s_n[2];
+        if (tid == 0) s_n[0] = ns[0];
+        if (tid == SMC_BLOCK - 1) s_n[1] = ns[F_IPT];
+        __syncthreads();
+        n_lo = s_n[0];
+        n_hi = s_n[1];
+    }
+    F_STAMP_A(5);
+    u32* A = f_A(a, t) + (i64)isl * N;
+    // ---- heavy parents (>= 2048 offspring): registered, their whole blocks left to k_propagate
+    __shared__ i64 sH[2 * F_HLOC];
+    __shared__ unsigned sHn;
+    int nH = 0;
+    if (a.hcnt && (n_hi - n_lo >= 2 * (i64)F_TILE))               // (same in every thread)
+        nH = f_register_heavy(a.hcnt + (i64)isl * 2 + (t & 1),
+                              a.hlist + ((i64)isl * 2 + (t & 1)) * F_HMAX * 3, jt,
+                              ns[0], ns[1], ns[2], ns[3], ns[4], sH, &sHn);
+    bool first_pass = true;
+    for (i64 pb = n_lo & ~(i64)3; pb < n_hi; pb += WIN) {
+        if (nH) {                                  // the whole pass inside a registered parent's blocks?
+            const i64 w_lo = pb > n_lo ? pb : n_lo, w_hi = pb + WIN < n_hi ? pb + WIN : n_hi;
+            i64 jump = 0;                          // passes to leave out, this one included
+            for (int k = 0; k < nH; ++k)
+                if (sH[2 * k] <= w_lo && w_hi <= sH[2 * k + 1]) {
+                    const i64 whole = (sH[2 * k + 1] - pb) / WIN;           // passes that end inside the blocks
+                    jump = whole > 1 ? whole : 1;
+                }
+            if (jump) { pb += (jump - 1) * WIN; continue; }
+        }
+        if (!first_pass) {
+            __syncthreads();                       // previous pass has read sP
+            *reinterpret_cast<uint4*>(&sP[tid * 4]) = make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4*>(&sP[F_PASS + tid * 4]) = make_uint4(0u, 0u, 0u, 0u);
+            __syncthreads();
+        }
+        first_pass = false;
+        // every parent writes its index at its first offspring's slot of the window
+        u32 rel[F_IPT + 1];
+#pragma unroll
+        for (int i = 0; i <= F_IPT; ++i) {
+            const i64 d = ns[i] - pb;
+            rel[i] = d < 0 ? 0u : (d > (i64)WIN ? (u32)WIN : (u32)d);
+        }
+#pragma unroll
+        for (int i = 0; i < F_IPT; ++i)
+            if (rel[i] < rel[i + 1]) sP[rel[i]] = (u32)(tid * F_IPT + i);
+        const bool two = n_hi > pb + F_PASS;       // does the second half of the window hold offspring?
+        __syncthreads();
+        // a running maximum over the slots gives each offspring its parent: both halves at once
+        const uint4 v = *reinterpret_cast<const uint4*>(&sP[tid * 4]);
+        uint4 w = make_uint4(0u, 0u, 0u, 0u);
+        if (two) w = *reinterpret_cast<const uint4*>(&sP[F_PASS + tid * 4]);
+        const u32 m0 = v.x, m1 = m0 > v.y ? m0 : v.y, m2 = m1 > v.z ? m1 : v.z, m3 = m2 > v.w ? m2 : v.w;
+        const u32 k0 = w.x, k1 = k0 > w.y ? k0 : w.y, k2 = k1 > w.z ? k1 : w.z, k3 = k2 > w.w ? k2 : w.w;
+        const u32 inc1 = smc_wave_scan_max_u32(m3);
+        u32 ex1 = smc_mov_dpp<SMC_DPP_WAVE_SHR1>(inc1);
+        if (lane == 0) ex1 = 0u;
+        u32 inc2 = 0u, ex2 = 0u;
+        if (two) {
+            inc2 = smc_wave_scan_max_u32(k3);
+            ex2 = smc_mov_dpp<SMC_DPP_WAVE_SHR1>(inc2);
+            if (lane == 0) ex2 = 0u;
+        }
+        if (lane == 63) { s_mx[wave] = inc1; s_mx[SMC_NWAVE + wave] = inc2; }
+        __syncthreads();
+        u32 all1 = 0u;
+#pragma unroll
+        for (int ww = 0; ww < SMC_NWAVE; ++ww) {
+            const u32 x1 = s_mx[ww], x2 = s_mx[SMC_NWAVE + ww];
+            all1 = all1 > x1 ? all1 : x1;
+            if (ww < wave) {
+                ex1 = ex1 > x1 ? ex1 : x1;
+                ex2 = ex2 > x2 ? ex2 : x2;
+            }
+        }
+        ex2 = ex2 > all1 ? ex2 : all1;             // the second half continues the first
+        {
+            const i64 n0 = pb + (i64)tid * 4;
+            const u32 a32[4] = {(u32)j0 + (m0 > ex1 ? m0 : ex1), (u32)j0 + (m1 > ex1 ? m1 : ex1),
+                                (u32)j0 + (m2 > ex1 ? m2 : ex1), (u32)j0 + (m3 > ex1 ? m3 : ex1)};
+            if (vec && n0 >= n_lo && n0 + 3 < n_hi) {                                   // core.py:329
+                if (a.nt) smc_st4g_nt(A + n0, a32);
+                else smc_st4g(A + n0, a32);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (n0 + i >= n_lo && n0 + i < n_hi) smc_stg(A + n0 + i, a32[i]);
+            }
+        }
+        if (two) {
+            const i64 n0 = pb + F_PASS + (i64)tid * 4;
+            const u32 a32[4] = {(u32)j0 + (k0 > ex2 ? k0 : ex2), (u32)j0 + (k1 > ex2 ? k1 : ex2),
+                                (u32)j0 + (k2 > ex2 ? k2 : ex2), (u32)j0 + (k3 > ex2 ? k3 : ex2)};
+            if (vec && n0 + 3 < n_hi) {            // (n0 >= n_lo: the second half starts 1024 past it)
+                if (a.nt) smc_st4g_nt(A + n0, a32);
+                else smc_st4g(A + n0, a32);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (n0 + i < n_hi) smc_stg(A + n0 + i, a32[i]);
+            }
+        }
+    }
     F_STAMP_A(6);
 }
 

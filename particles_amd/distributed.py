@@ -4,13 +4,28 @@ out to loky worker processes, particles/core.py:431, utils.py:158-186).
 
 The data path has no exchange step: each rank owns ``islands_per_rank`` whole
 filters.  The only collective is the gather of the per-island log-evidences,
-done with RCCL over xGMI inside libsmc_hip (``smc_comm_*``).  Host-side
-rendezvous (rank discovery, barrier, distributing the RCCL unique id, timing
-reduction) uses ``torch.distributed`` with the gloo backend and CPU tensors only
--- torch never touches the GPU in these processes.
+done with RCCL over xGMI inside libsmc_hip (``smc_comm_*``).
+
+Host-side rendezvous needs no framework: the launcher's environment (``RANK``,
+``WORLD_SIZE``, ``MASTER_ADDR``, ``MASTER_PORT`` -- what ``torch.distributed.run``
+or any other one-process-per-GPU launcher exports) is all it reads.  Rank 0
+listens on a TCP port of its own and the other ranks of the node find it through
+a key file; over that star every host-side operation is one ``exchange`` (an
+all-gather of a few bytes through rank 0): barrier, the max-over-ranks of the
+timings, and handing the 128-byte RCCL unique id to everybody.  No torch, no
+gloo, no MPI in the product path.
+
+If RCCL cannot be initialised the Group RAISES: a scale run must not silently
+measure something that never touched xGMI.  ``SMC_ALLOW_HOST_GATHER=1`` (or
+``device_collective=False``, CPU tests) routes the 8 bytes per island through the
+TCP star instead and says so in ``fallback_reason``.
 """
 import ctypes
 import os
+import socket
+import struct
+import tempfile
+import time
 
 import numpy as np
 
@@ -33,69 +48,172 @@ def shard_islands(n_total, rank, world):
     return first, count
 
 
-class Group:
-    """Process group: gloo for the host side, RCCL (inside libsmc_hip) for the
-    device-side gather.  ``device_collective=False`` keeps everything on gloo
-    (CPU-only tests)."""
+def _send_msg(sock, payload):
+    sock.sendall(struct.pack("<I", len(payload)) + payload)
 
-    def __init__(self, device_collective=True, backend_init=True):
-        self.rank, self.local_rank, self.world = env_rank_world()
-        self.dist = None
-        self.comm = None
-        self.fallback_reason = None
-        if self.world > 1:
-            import torch.distributed as dist
-            if backend_init and not dist.is_initialized():
-                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
-            self.dist = dist
-        if device_collective:
+
+def _recv_exact(sock, n):
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = sock.recv(n - len(buf))
+        if not chunk:
+            raise ConnectionError("rendezvous peer closed the connection")
+        buf += chunk
+    return bytes(buf)
+
+
+def _recv_msg(sock):
+    (n,) = struct.unpack("<I", _recv_exact(sock, 4))
+    return _recv_exact(sock, n)
+
+
+class _Star:
+    """All ranks of one node connected to rank 0.  The one primitive: ``exchange(payload)``
+    -> list of every rank's payload in rank order (an all-gather through rank 0)."""
+
+    def __init__(self, rank, world, timeout=120.0):
+        self.rank, self.world = rank, world
+        addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+        # the launcher may itself be listening on MASTER_PORT (torchrun's store does): rank 0
+        # binds a port of its own and publishes it in a file keyed by what all ranks of THIS
+        # launch share -- MASTER_PORT and the launcher's pid
+        key = "smc_rdzv_%s_%s_%d" % (os.environ.get("MASTER_PORT", "0"),
+                                     os.environ.get("TORCHELASTIC_RUN_ID", "x"), os.getppid())
+        self._keyfile = os.path.join(tempfile.gettempdir(), key)
+        self.peers = []
+        self.sock = None
+        if rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr if addr not in ("localhost",) else "127.0.0.1", 0))
+            srv.listen(world)
+            srv.settimeout(timeout)
+            tmp = self._keyfile + ".tmp%d" % os.getpid()
+            with open(tmp, "w") as fh:
+                fh.write("%d %d" % (srv.getsockname()[1], os.getpid()))
+            os.replace(tmp, self._keyfile)
+            conns = {}
+            while len(conns) < world - 1:
+                c, _ = srv.accept()
+                c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                c.settimeout(timeout)
+                (r,) = struct.unpack("<I", _recv_exact(c, 4))
+                conns[r] = c
+            srv.close()
+            self.peers = [conns[r] for r in range(1, world)]
+        else:
+            t0 = time.time()
+            port = None
+            while port is None:
+                try:
+                    with open(self._keyfile) as fh:
+                        port = int(fh.read().split()[0])
+                except (OSError, ValueError, IndexError):
+                    if time.time() - t0 > timeout:
+                        raise TimeoutError("rendezvous: rank 0 never published %s" % self._keyfile)
+                    time.sleep(0.01)
+            s = socket.create_connection((addr, port), timeout=timeout)
+            s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            s.sendall(struct.pack("<I", rank))
+            self.sock = s
+
+    def exchange(self, payload=b""):
+        if self.rank == 0:
+            parts = [payload] + [_recv_msg(c) for c in self.peers]
+            blob = b"".join(struct.pack("<I", len(p)) + p for p in parts)
+            for c in self.peers:
+                _send_msg(c, blob)
+            return parts
+        _send_msg(self.sock, payload)
+        blob = _recv_msg(self.sock)
+        parts, off = [], 0
+        for _ in range(self.world):
+            (n,) = struct.unpack_from("<I", blob, off)
+            parts.append(blob[off + 4:off + 4 + n])
+            off += 4 + n
+        return parts
+
+    def close(self):
+        for c in self.peers:
+            c.close()
+        if self.sock is not None:
+            self.sock.close()
+        if self.rank == 0:
             try:
-                self._init_rccl()
-            except Exception as e:           # keep the job alive: 8 bytes/rank can go over gloo
-                self.comm = None
-                self.fallback_reason = "%s: %s" % (type(e).__name__, e)
-            if self.world > 1:
-                # all ranks agree on whether RCCL is usable
-                ok = self.allreduce_min_host(1.0 if self.comm else 0.0)
-                if ok < 1.0 and self.comm:
-                    lib().smc_comm_destroy(self.comm)
-                    self.comm = None
-                    self.fallback_reason = self.fallback_reason or "RCCL unavailable on another rank"
+                os.unlink(self._keyfile)
+            except OSError:
+                pass
+        self.peers, self.sock = [], None
+
+
+class Group:
+    """Process group of a one-node launch: a TCP star for the host side, RCCL (inside
+    libsmc_hip) for the device-side gather of the evidences.  ``device_collective=False``
+    keeps the gather on the star as well (CPU-only tests)."""
+
+    def __init__(self, device_collective=True):
+        self.rank, self.local_rank, self.world = env_rank_world()
+        self.star = _Star(self.rank, self.world) if self.world > 1 else None
+        self.comm = None
+        self.fallback_reason = None if device_collective else "device_collective=False"
+        if device_collective:
+            err = self._init_rccl()
+            if err:
+                if os.environ.get("SMC_ALLOW_HOST_GATHER") != "1":
+                    self.close()
+                    raise RuntimeError("RCCL evidence gather unavailable (%s); set SMC_ALLOW_HOST_GATHER=1 "
+                                       "to gather over the host rendezvous instead" % err)
+                self.fallback_reason = err
 
     def _init_rccl(self):
+        """Every rank learns the unique id (or that rank 0 could not make one) in ONE exchange, then
+        all attempt ncclCommInitRank together and agree on the outcome: no rank is left waiting in
+        a collective the others never enter.  Returns None, or the reason RCCL is not usable."""
         uid = ctypes.create_string_buffer(128)
+        msg = b""
         if self.rank == 0:
-            check(lib().smc_comm_unique_id(uid))
-        if self.world > 1:
-            import torch
-            t = torch.frombuffer(bytearray(uid.raw), dtype=torch.uint8).clone()
-            self.dist.broadcast(t, src=0)
-            uid = ctypes.create_string_buffer(bytes(t.numpy().tobytes()), 128)
+            try:
+                check(lib().smc_comm_unique_id(uid))
+                msg = b"\x01" + uid.raw
+            except Exception as e:
+                msg = b"\x00" + str(e).encode()
+        first = self.star.exchange(msg)[0] if self.star else msg
+        if first[:1] != b"\x01":
+            return "rank 0: " + first[1:].decode(errors="replace")
+        uid = ctypes.create_string_buffer(first[1:129], 128)
         h = _lib.c_vp()
-        check(lib().smc_comm_create(_lib.ctx().h, self.world, self.rank, uid, ctypes.byref(h)))
+        err = b""
+        try:
+            check(lib().smc_comm_create(_lib.ctx().h, self.world, self.rank, uid, ctypes.byref(h)))
+        except Exception as e:
+            err = ("rank %d: %s" % (self.rank, e)).encode()
+        errs = self.star.exchange(err) if self.star else [err]
+        bad = [e for e in errs if e]
+        if bad:
+            if not err:
+                lib().smc_comm_destroy(h)
+            return bad[0].decode(errors="replace")
         self.comm = h
+        return None
 
-    # ---- host-side helpers (gloo) -------------------------------------------
+    # ---- host-side helpers (TCP star) -----------------------------------------
     def barrier(self):
-        if self.dist is not None:
-            self.dist.barrier()
+        if self.star:
+            self.star.exchange(b"")
 
     def _allreduce_host(self, v, op):
-        if self.dist is None:
-            return float(v)
-        import torch
-        t = torch.tensor([float(v)], dtype=torch.float64)
-        self.dist.all_reduce(t, op=op)
-        return float(t[0])
+        a = np.atleast_1d(np.asarray(v, dtype=np.float64))
+        if self.star:
+            parts = self.star.exchange(a.tobytes())
+            a = op(np.stack([np.frombuffer(p, dtype=np.float64) for p in parts]), axis=0)
+        return float(a[0]) if np.ndim(v) == 0 else a
 
     def allreduce_max_host(self, v):
-        import torch.distributed as d
-        return self._allreduce_host(v, d.ReduceOp.MAX) if self.dist else float(v)
+        """Element-wise maximum over ranks of a scalar or vector (the timings)."""
+        return self._allreduce_host(v, np.max)
 
     def allreduce_min_host(self, v):
-        import torch.distributed as d
-        return self._allreduce_host(v, d.ReduceOp.MIN) if self.dist else float(v)
+        return self._allreduce_host(v, np.min)
 
     # ---- the collective of the path ------------------------------------------
     def gather_evidence(self, local_logLt):
@@ -107,19 +225,24 @@ class Group:
             recv = DeviceArray((self.world * local.size,))
             check(lib().smc_comm_allgather_f64(self.comm, send.ptr, local.size, recv.ptr))
             return recv.get()
-        if self.dist is None:
+        if self.star is None:
             return local.copy()
-        import torch
-        outs = [torch.zeros(local.size, dtype=torch.float64) for _ in range(self.world)]
-        self.dist.all_gather(outs, torch.from_numpy(local.copy()))
-        return np.concatenate([o.numpy() for o in outs])
+        parts = self.star.exchange(local.tobytes())
+        return np.concatenate([np.frombuffer(p, dtype=np.float64) for p in parts])
+
+    @property
+    def evidence_path(self):
+        if self.comm is not None:
+            return "rccl"
+        return "none" if self.world == 1 else "host-fallback: %s" % self.fallback_reason
 
     def close(self):
         if self.comm is not None:
             lib().smc_comm_destroy(self.comm)
             self.comm = None
-        if self.dist is not None and self.dist.is_initialized():
-            self.dist.destroy_process_group()
+        if self.star is not None:
+            self.star.close()
+            self.star = None
 
 
 def log_mean_exp_host(v):

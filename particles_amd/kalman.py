@@ -65,6 +65,8 @@ class MVLinearGauss(ssms.StateSpaceModel):
                               cov=fc)
 
     def _device_params(self, fk_kind):
+        if not (1 <= self.dy <= self.dx <= 32):      # k_propagate_mv's range; beyond: generic path
+            return None
         return dict(kind=_lib.MODEL_MVLINGAUSS, dx=self.dx, dy=self.dy, params=None,
                     F=self.F, G=self.G, covX=self.covX, covY=self.covY,
                     mu0=self.mu0, cov0=self.cov0)

@@ -101,6 +101,23 @@ class Bootstrap(FeynmanKac):
         return self.ssm.PX(t, xp).logpdf(x)
 
     def _device_model(self):
+        """Parameters of the fused device loop, or None.  The fused kernels implement the STOCK
+        model: it is chosen only when neither this Feynman-Kac class nor the state-space model
+        overrides one of the methods the kernels stand for -- a user subclass that redefines
+        ``PY`` (or ``logG``, ``time_to_resample``, ...) must run its own code, through the
+        template-method path (the reference's normal way to customise a model)."""
+        base = GuidedPF if isinstance(self, GuidedPF) else Bootstrap
+        cls = type(self)
+        for name in ("M0", "M", "logG", "time_to_resample", "done", "_device_model"):
+            if getattr(cls, name) is not getattr(base, name):
+                return None
+        scls = type(self.ssm)
+        owner = next((c for c in scls.__mro__ if "_device_params" in vars(c)), None)
+        if owner is None:
+            return None
+        for name in ("PX0", "PX", "PY", "proposal0", "proposal"):
+            if getattr(scls, name, None) is not getattr(owner, name, None):
+                return None
         return self.ssm._device_params(self._fk_kind)
 
 

@@ -1,7 +1,8 @@
-"""The N>1 path on CPU: world_size-2 processes, gloo rendezvous, island sharding
-and the evidence gather.  (The device-side gather is RCCL inside libsmc_hip; on
-the GPU-less container the Group is created with device_collective=False, which
-exercises the same sharding / ordering logic over gloo.)"""
+"""The N>1 path on CPU: world_size-2 processes, the product's own TCP rendezvous, island
+sharding and the evidence gather.  (The device-side gather is RCCL inside libsmc_hip; on the
+GPU-less container the Group is created with device_collective=False, which exercises the same
+sharding / ordering logic over the host star.)  torch.distributed/gloo appears here only as an
+independent cross-check of the gathered values -- the product does not import torch."""
 import os
 import socket
 import subprocess
@@ -35,8 +36,21 @@ pf.run()
 grp.barrier()
 allv = grp.gather_evidence(pf.logLts_islands)
 tmax = grp.allreduce_max_host(float(grp.rank))
+vmax = grp.allreduce_max_host(np.array([1.0 + grp.rank, 5.0 - grp.rank]))
+gloo = None
+if grp.world > 1 and os.environ.get("SMC_TEST_GLOO") == "1":
+    import torch, torch.distributed as dist          # test-only cross-check
+    os.environ["MASTER_PORT"] = os.environ["GLOO_PORT"]
+    dist.init_process_group("gloo", rank=grp.rank, world_size=grp.world)
+    outs = [torch.zeros(count, dtype=torch.float64) for _ in range(grp.world)]
+    dist.all_gather(outs, torch.from_numpy(pf.logLts_islands.copy()))
+    gloo = np.concatenate([o.numpy() for o in outs]).tolist()
+    dist.destroy_process_group()
+assert "torch" not in sys.modules or gloo is not None, "the product path imported torch"
 if grp.rank == 0:
     print("RESULT " + json.dumps({{"ll": allv.tolist(), "tmax": tmax, "world": grp.world,
+                                   "vmax": vmax.tolist(), "gloo": gloo,
+                                   "path": grp.evidence_path,
                                    "lme": log_mean_exp_host(allv)}}))
 grp.close()
 """
@@ -50,14 +64,15 @@ def _free_port():
     return p
 
 
-def _run_world(world, tmp_path):
+def _run_world(world, tmp_path, gloo=False):
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(root=ROOT))
-    port = _free_port()
+    port, gport = _free_port(), _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SMC_HIP_DEVICE="0")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SMC_HIP_DEVICE="0",
+                   GLOO_PORT=str(gport), SMC_TEST_GLOO="1" if gloo else "0")
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=600)[0] for p in procs]
@@ -82,8 +97,12 @@ def test_world2_matches_world1(tmp_path, has_gpu):
     """Sharding 6 islands over 2 ranks gives exactly the single-process answer,
     in global island order (results do not depend on the number of GPUs)."""
     one = _run_world(1, tmp_path)
-    two = _run_world(2, tmp_path)
-    assert two["world"] == 2 and two["tmax"] == 1.0
+    two = _run_world(2, tmp_path, gloo=True)
+    three = _run_world(3, tmp_path)
+    assert two["world"] == 2 and two["tmax"] == 1.0 and two["vmax"] == [2.0, 5.0]
+    assert two["gloo"] == two["ll"]                 # the star's gather == gloo's all_gather
+    assert two["path"].startswith("host-fallback") and one["path"] == "none"
+    assert three["world"] == 3 and three["ll"] == one["ll"] and three["vmax"] == [3.0, 5.0]
     assert len(one["ll"]) == 6 and one["ll"] == two["ll"]
     assert one["lme"] == two["lme"]
     assert len(set(one["ll"])) == 6

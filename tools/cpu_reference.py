@@ -15,7 +15,8 @@ in the build container.  Legs:
     (oracle/oracle.c orc_inverse_cdf_seq: element-identical output is asserted here) standing in
     for the numba-compiled function
   * all cores: particles.multiSMC(nruns=16, nprocs=<nproc>, collect='off', out_func=logLt) on
-    N = 2^18, T = 20, after one warm-up call (core.py:431-518, utils.py:158-186)
+    N = 2^18, T = 20, after one warm-up call (core.py:431-518, utils.py:158-186), compiled
+    inverse_cdf in the workers as well
 """
 import ctypes
 import json
@@ -28,7 +29,47 @@ import time
 
 sys.dont_write_bytecode = True
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [os.path.join(ROOT, "oracle", "numba_shim"), "/root/reference", ROOT]
+
+# numba is absent: a stand-in package whose jit() hands back the function unchanged, EXCEPT
+# resampling.inverse_cdf, which it binds to the gcc -O2 restatement of the same loop
+# (oracle.c orc_inverse_cdf_seq) -- what numba would have compiled.  It sits on PYTHONPATH so
+# that multiSMC's worker processes get the same compiled inverse_cdf as the parent.
+SHIM = os.path.join("/tmp", "smc_numba_c_shim")
+os.makedirs(os.path.join(SHIM, "numba"), exist_ok=True)
+with open(os.path.join(SHIM, "numba", "__init__.py"), "w") as _fh:
+    _fh.write('''import ctypes, os
+import numpy as np
+_LIB = None
+def _c_inverse_cdf(py):
+    def inverse_cdf(su, W):
+        global _LIB
+        if _LIB is None:
+            _LIB = ctypes.CDLL(%r)
+            dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)
+            _LIB.orc_inverse_cdf_seq.argtypes = [dp, dp, ctypes.c_int64, ctypes.c_int64, ip]
+            _LIB.orc_inverse_cdf_seq.restype = ctypes.c_int64
+        dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)
+        su = np.ascontiguousarray(su, dtype=np.float64)
+        W = np.ascontiguousarray(W, dtype=np.float64)
+        A = np.empty(su.shape[0], dtype=np.int64)
+        if _LIB.orc_inverse_cdf_seq(su.ctypes.data_as(dp), W.ctypes.data_as(dp), su.shape[0],
+                                    W.shape[0], A.ctypes.data_as(ip)):
+            raise IndexError("index out of bounds")
+        return A
+    inverse_cdf.py_func = py
+    return inverse_cdf
+def jit(*args, **kwargs):
+    def wrap(f):
+        return _c_inverse_cdf(f) if f.__name__ == "inverse_cdf" else f
+    if len(args) == 1 and callable(args[0]) and not kwargs:
+        return wrap(args[0])
+    return wrap
+njit = jit
+''' % os.path.join(ROOT, "oracle", "_build", "liboracle.so"))
+subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, stdout=subprocess.DEVNULL)
+os.environ["PYTHONPATH"] = os.pathsep.join([SHIM, "/root/reference", ROOT, os.environ.get("PYTHONPATH", "")])
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+sys.path[:0] = [SHIM, "/root/reference", ROOT]
 
 import numpy as np  # noqa: E402
 import particles  # noqa: E402
@@ -51,21 +92,9 @@ class ToySSM(ssm.StateSpaceModel):          # README.md:66-72
 
 
 def c_inverse_cdf():
-    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, stdout=subprocess.DEVNULL)
-    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "_build", "liboracle.so"))
-    dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)
-    lib.orc_inverse_cdf_seq.argtypes = [dp, dp, ctypes.c_int64, ctypes.c_int64, ip]
-    lib.orc_inverse_cdf_seq.restype = ctypes.c_int64
-
-    def inverse_cdf(su, W):
-        su = np.ascontiguousarray(su, dtype=np.float64)
-        W = np.ascontiguousarray(W, dtype=np.float64)
-        A = np.empty(su.shape[0], dtype=np.int64)
-        if lib.orc_inverse_cdf_seq(su.ctypes.data_as(dp), W.ctypes.data_as(dp), su.shape[0],
-                                   W.shape[0], A.ctypes.data_as(ip)):
-            raise IndexError("index out of bounds")
-        return A
-    return inverse_cdf
+    """resampling.inverse_cdf as imported here: the compiled stand-in (its .py_func is the
+    reference's own Python loop)."""
+    return rs.inverse_cdf
 
 
 def time_run(model, y, N, reps=3):
@@ -90,8 +119,8 @@ def main():
            "reference": "nchopin/particles v%s at /root/reference" % getattr(particles, "__version__", "?"),
            "legs": {}}
     model = ToySSM(sigma=0.2)
-    py_icdf = rs.inverse_cdf
     c_icdf = c_inverse_cdf()
+    py_icdf = c_icdf.py_func
     # the C stand-in computes what the reference's loop computes
     rng = np.random.default_rng(0)
     W = rng.random(5000); W /= W.sum()
@@ -109,8 +138,8 @@ def main():
                 "particle_steps_per_s": N * T / med, "ms_per_step": 1e3 * med / T, "logLt": float(ll)}
             print(name, variant, "%.3f s  %.2f M particle-steps/s" % (med, N * T / med / 1e6), flush=True)
     rs.inverse_cdf = c_icdf
-    # all cores: multiSMC over a loky/multiprocessing pool (workers import the pure-Python
-    # inverse_cdf: the patch above does not travel, so this leg is the stock reference)
+    # all cores: multiSMC over its pool of worker processes (they import the same compiled
+    # inverse_cdf through PYTHONPATH)
     nproc = os.cpu_count()
     N, T, nruns = 1 << 18, 20, 16
     np.random.seed(42)
@@ -128,7 +157,7 @@ def main():
     res["legs"]["C5-shape multiSMC 16 x (N=2^18, T=20), %d processes" % nproc] = {
         "seconds_median": med, "seconds": ts, "N": N, "T": T, "nruns": nruns, "cores": nproc,
         "particle_steps_per_s": nruns * N * T / med,
-        "inverse_cdf": "stock (pure Python in the workers: numba absent)",
+        "inverse_cdf": "compiled stand-in (C), parent and workers",
         "logLt_sd": float(np.std([o["output"] for o in out]))}
     print("multiSMC %d procs: %.2f s  %.1f M particle-steps/s" % (nproc, med, nruns * N * T / med / 1e6), flush=True)
     path = os.path.join(ROOT, "profiles", "cpu_reference.json")

@@ -1,0 +1,56 @@
+#!/bin/bash
+# Run ON THE GPU BOX (gpurun): round-2 measurement batch.  $1 = tag, $2 = what ("all" | list)
+TAG=${1:-r02a}
+WHAT=${2:-"pytest bench ab c345 prof balance"}
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd $R
+jl() { grep '^{' "$1" | tail -1; }
+for w in $WHAT; do case $w in
+pytest)
+  (timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "rc=$?" >> $O/pytest_gpu.log)
+  tail -5 $O/pytest_gpu.log ;;
+smoke)
+  (timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "rc=$?" >> $O/smoke.log); tail -3 $O/smoke.log ;;
+bench)
+  timeout 300 python bench.py --steps 1000 --warmup 50 > $O/bench_c2_k1000.json 2> $O/bench_c2_k1000.err
+  timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_c2_k20.json 2> $O/bench_c2_k20.err
+  timeout 300 python bench.py > $O/bench_c2_default.json 2> $O/bench_c2_default.err
+  for f in $O/bench_c2_*.json; do python - "$f" <<'PY'
+import json,sys
+d=json.loads([l for l in open(sys.argv[1]) if l.startswith('{')][-1]); r=d.get('roofline',{})
+print(sys.argv[1].split('/')[-1], 'ms/step %.5f'%d['ms_per_step'], 'G/s %.2f'%(d['value']/1e9), d.get('timing'), {k:round(v['ms'],5) for k,v in r.get('per_kernel',{}).items()}, 'cpu', d.get('cpu_baseline',{}).get('value'))
+PY
+  done ;;
+ab)
+  SMC_ANC2_R1=1 timeout 300 python bench.py --steps 1000 --warmup 50 --no-cpu-baseline > $O/bench_c2_anc2r1.json 2>&1
+  SMC_NO_NT=1 timeout 300 python bench.py --steps 1000 --warmup 50 --no-cpu-baseline > $O/bench_c2_nont.json 2>&1
+  timeout 300 python bench.py --steps 1000 --warmup 50 --no-cpu-baseline --no-graph > $O/bench_c2_nograph.json 2>&1
+  for f in $O/bench_c2_anc2r1.json $O/bench_c2_nont.json $O/bench_c2_nograph.json; do python - "$f" <<'PY'
+import json,sys
+d=json.loads([l for l in open(sys.argv[1]) if l.startswith('{')][-1]); r=d.get('roofline',{})
+print(sys.argv[1].split('/')[-1], 'ms/step %.5f'%d['ms_per_step'], 'G/s %.2f'%(d['value']/1e9), {k:round(v['ms'],5) for k,v in r.get('per_kernel',{}).items()})
+PY
+  done ;;
+c345)
+  timeout 300 python bench.py --workload c5 --steps 200 --warmup 20 > $O/bench_c5.json 2>&1
+  for sc in systematic stratified multinomial; do timeout 300 python bench.py --workload c3 --scheme $sc --steps 200 --warmup 20 > $O/bench_c3_$sc.json 2>&1; done
+  timeout 300 python bench.py --workload c4 --steps 100 --warmup 10 > $O/bench_c4.json 2>&1
+  for f in $O/bench_c5.json $O/bench_c3_*.json $O/bench_c4.json; do python - "$f" <<'PY'
+import json,sys
+try:
+    d=json.loads([l for l in open(sys.argv[1]) if l.startswith('{')][-1]); r=d.get('roofline',{})
+    print(sys.argv[1].split('/')[-1], 'ms/step %.5f'%d['ms_per_step'], 'G/s %.2f'%(d['value']/1e9), {k:round(v['ms'],5) for k,v in r.get('per_kernel',{}).items()})
+except Exception as e: print(sys.argv[1], 'FAILED', e, open(sys.argv[1]).read()[-400:])
+PY
+  done ;;
+prof)
+  EXTRA="" bash tools/gpu_profile.sh ${TAG}_c2 400 > $O/prof_c2.txt 2>&1; tail -40 $O/prof_c2.txt ;;
+prof_r1)
+  export SMC_ANC2_R1=1; PASSES="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" bash tools/gpu_profile.sh ${TAG}_c2_anc2r1 400 > $O/prof_c2_r1.txt 2>&1; unset SMC_ANC2_R1; tail -25 $O/prof_c2_r1.txt ;;
+prof_c5)
+  EXTRA="--workload c5" bash tools/gpu_profile.sh ${TAG}_c5 100 > $O/prof_c5.txt 2>&1; tail -30 $O/prof_c5.txt ;;
+balance)
+  timeout 120 python tools/tile_balance.py 20 > $O/tile_balance.txt 2>&1; cat $O/tile_balance.txt ;;
+esac; done
