@@ -143,7 +143,7 @@ def main():
                     help="repetitions of the K-step timed region (0: about 10^4 timed steps in all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the steps from hipGraphs (default: eager launches)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -209,7 +209,7 @@ def main():
     def make(profile=False):
         pf = pa.SMC(fk=fk, N=N, resampling=a.scheme, ESSrmin=a.essrmin, collect="off", seed=123,
                     n_islands=a.islands, island_offset=rank * a.islands,
-                    use_graph=not (a.no_graph or profile))
+                    use_graph=a.graph and not profile)
         if profile:
             _lib.check(_lib.lib().smc_filter_profile(pf._f, 1))
         return pf
@@ -256,7 +256,7 @@ def main():
                                    "filter(s) per GPU" % (wl, a.log2N, K, a.scheme, a.essrmin,
                                                           a.islands),
                        "N": N, "islands_per_gpu": a.islands, "scheme": a.scheme,
-                       "rng": "philox4x32-10", "graph": not a.no_graph,
+                       "rng": "philox4x32-10", "graph": bool(a.graph),
                        "resampled_fraction": rs_rate},
             "step_achieved_GBs": bytes_step * N * a.islands * K / dt / 1e9,
             "logLt": [float(v) for v in np.atleast_1d(all_ll)][:16],

@@ -128,11 +128,14 @@ class SMC:
         ``logLts_islands`` has them all
     replay : (z, u) device/host tapes of the reference's own draws, see
         ``smc_filter_set_replay`` (parity tests)
+    use_graph : replay the step sequence from hipGraphs instead of launching the kernels one by
+        one (off by default: on MI355X a dependent kernel boundary costs the same either way,
+        eager launches measured 2 % faster at C2 and start sooner after an idle stream)
     """
 
     def __init__(self, fk=None, N=100, qmc=False, resampling="systematic", ESSrmin=0.5,
                  store_history=False, verbose=False, collect=None, seed=None, n_islands=1,
-                 replay=None, use_graph=True, island_offset=0):
+                 replay=None, use_graph=False, island_offset=0):
         self._fk_list = None
         if isinstance(fk, (list, tuple)):        # one Feynman-Kac model per island (SMC^2: one theta each)
             self._fk_list = list(fk)

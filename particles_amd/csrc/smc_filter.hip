@@ -521,17 +521,31 @@ int smc_filter_summaries(smc_filter* f, double* out_host)
     return SMC_OK;
 }
 
+// gather logLt of step t-1 of every island into one staging array (one D2H copy, one sync)
+__global__ void k_f_collect_logLt(const double* summ, i64 T, i64 t, int n, double* out)
+{
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i < n) out[i] = summ[((i64)i * (T + 1) + (t - 1)) * SUMM_STRIDE + 3];
+}
+
 int smc_filter_logLt(smc_filter* f, double* out_host)
 {
     SMC_REQUIRE(f && out_host, "null argument");
     const i64 t = f->t_host, T = f->a.T;
-    for (int i = 0; i < f->a.n_islands; ++i) out_host[i] = 0.0;
+    const int M = f->a.n_islands;
+    for (int i = 0; i < M; ++i) out_host[i] = 0.0;
     if (t == 0) return SMC_OK;
-    for (int i = 0; i < f->a.n_islands; ++i) {
-        const double* src = f->a.summ + ((size_t)i * (T + 1) + (t - 1)) * SUMM_STRIDE + 3;
-        SMC_HIP_CHECK(hipMemcpyAsync(out_host + i, src, 8, hipMemcpyDeviceToHost, f->ctx->stream));
+    hipStream_t st = f->ctx->stream;
+    if (M == 1) {
+        SMC_HIP_CHECK(hipMemcpyAsync(out_host, f->a.summ + (size_t)(t - 1) * SUMM_STRIDE + 3, 8,
+                                     hipMemcpyDeviceToHost, st));
+    } else {
+        SMC_REQUIRE((size_t)M * 8 <= (size_t)f->a.N * f->a.dx * 8, "more islands than staging space");
+        SMC_LAUNCH(k_f_collect_logLt, dim3((M + 255) / 256), dim3(256), st, f->a.summ, T, t, M, f->tmp);
+        SMC_LAUNCH_CHECK();
+        SMC_HIP_CHECK(hipMemcpyAsync(out_host, f->tmp, (size_t)M * 8, hipMemcpyDeviceToHost, st));
     }
-    SMC_HIP_CHECK(hipStreamSynchronize(f->ctx->stream));
+    SMC_HIP_CHECK(hipStreamSynchronize(st));
     return SMC_OK;
 }
 

@@ -770,7 +770,6 @@ __device__ __forceinline__ void f_step_tail(const FArgs& a, const int isl, const
                                             double* info)
 {
     const int tid = (int)threadIdx.x;
-    const i64 N = a.N;
     {   // re-arm the tile totals k_ancestors<true> publishes (0 = "not there yet")
         const i64 g = (i64)b * SMC_BLOCK + tid;
         if (g < a.ntiles) a.Q[(i64)isl * a.ntiles + g] = 0ull;

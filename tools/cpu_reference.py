@@ -113,7 +113,7 @@ def logLt_of(pf):
 
 
 def main():
-    res = {"host": {"cpu": platform.processor() or open("/proc/cpuinfo").read().split("model name")[1].split("\n")[0].strip(": \t"),
+    res = {"host": {"cpu": open("/proc/cpuinfo").read().split("model name")[1].split("\n")[0].strip(": \t"),
                     "nproc": os.cpu_count(), "python": platform.python_version(),
                     "numpy": np.__version__, "where": "build container (no GPU)"},
            "reference": "nchopin/particles v%s at /root/reference" % getattr(particles, "__version__", "?"),

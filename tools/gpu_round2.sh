@@ -26,8 +26,8 @@ PY
 ab)
   SMC_ANC2_R1=1 timeout 300 python bench.py --steps 1000 --warmup 50 --no-cpu-baseline > $O/bench_c2_anc2r1.json 2>&1
   SMC_NO_NT=1 timeout 300 python bench.py --steps 1000 --warmup 50 --no-cpu-baseline > $O/bench_c2_nont.json 2>&1
-  timeout 300 python bench.py --steps 1000 --warmup 50 --no-cpu-baseline --no-graph > $O/bench_c2_nograph.json 2>&1
-  for f in $O/bench_c2_anc2r1.json $O/bench_c2_nont.json $O/bench_c2_nograph.json; do python - "$f" <<'PY'
+  timeout 300 python bench.py --steps 1000 --warmup 50 --no-cpu-baseline --graph > $O/bench_c2_graph.json 2>&1
+  for f in $O/bench_c2_anc2r1.json $O/bench_c2_nont.json $O/bench_c2_graph.json; do python - "$f" <<'PY'
 import json,sys
 d=json.loads([l for l in open(sys.argv[1]) if l.startswith('{')][-1]); r=d.get('roofline',{})
 print(sys.argv[1].split('/')[-1], 'ms/step %.5f'%d['ms_per_step'], 'G/s %.2f'%(d['value']/1e9), {k:round(v['ms'],5) for k,v in r.get('per_kernel',{}).items()})
@@ -51,6 +51,8 @@ prof_r1)
   export SMC_ANC2_R1=1; PASSES="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" bash tools/gpu_profile.sh ${TAG}_c2_anc2r1 400 > $O/prof_c2_r1.txt 2>&1; unset SMC_ANC2_R1; tail -25 $O/prof_c2_r1.txt ;;
 prof_c5)
   EXTRA="--workload c5" bash tools/gpu_profile.sh ${TAG}_c5 100 > $O/prof_c5.txt 2>&1; tail -30 $O/prof_c5.txt ;;
+trace)
+  timeout 200 python tools/trace_step.py 20 > $O/trace_step.txt 2>&1; cat $O/trace_step.txt ;;
 balance)
   timeout 120 python tools/tile_balance.py 20 > $O/tile_balance.txt 2>&1; cat $O/tile_balance.txt ;;
 esac; done
