@@ -184,22 +184,23 @@ double orc_toy_filter_philox(const double *y, int64_t T, int64_t N, double rho,
  * BIT FOR BIT (tests: np.array_equal on ancestors at N = 2^12 .. 2^22).
  *
  * What the contract fixes (and this file therefore repeats):
- *   exp        the 13-term polynomial with Cody-Waite reduction below (the
- *              device evaluates the same IEEE operations; fma() is explicit,
- *              the file is built with -ffp-contract=off)
- *   tile       1024 consecutive particles; its partial (m_b, S_b, SS_b) =
- *              (max lw, sum e, sum e^2), e = exp(lw - m_b); summation tree:
- *              4 consecutive elements left to right, then a balanced binary
- *              tree over 64 such groups, then 4 such blocks left to right
- *   island     m = max m_b; s = sum S_b e_b, ss = sum SS_b e_b^2 with
- *              e_b = exp(m_b - m): per slot i of 256 the tiles 4i..4i+3 (and
- *              +1024 c for every further chunk c) by fma left to right, then
- *              the same 64-tree / 4-blocks order
- *   shares     Q_b = rint(min(S_b e_b / s, 2) 2^62), G_b = sum_{b'<b} Q_b'
- *   in a tile  q_i = rint(e_i 2^50), c_j = sum_{i<j} q_i, t_b = sum q_i
+ *   exp        exp(x) = p 2^k with k = rint(x log2 e) and p = P(x - k ln 2), P the degree-13
+ *              polynomial below after a Cody-Waite reduction (the device evaluates the same
+ *              IEEE operations; fma() is explicit, the file is built with -ffp-contract=off).
+ *              Weights are carried as (p, k) pairs: no maximum is needed to form them.
+ *   tile       1024 consecutive particles; K_b = max k_i, e_i = p_i 2^(k_i - K_b) (in [0, 1.42));
+ *              partial (K_b, S_b, SS_b) = (K_b, sum e, sum e^2); summation tree: 4 consecutive
+ *              elements left to right (e^2 by fma), then a balanced binary tree over 64 such
+ *              groups, then 4 such blocks left to right
+ *   island     K = max K_b; s = sum S_b 2^(K_b - K), ss = sum SS_b 2^(2 (K_b - K)) (exact
+ *              scalings): per slot i of 256 the tiles 4i..4i+3 (and + 1024 c for every further
+ *              chunk c) left to right, then the same 64-tree / 4-blocks order
+ *   shares     Q_b = rint(min(S_b 2^(K_b-K) / s, 2) 2^52), G_b = sum_{b'<b} Q_b' (exact
+ *              integers below 2^53: fp64 carries them)
+ *   in a tile  q_i = rint(e_i 2^49), c_j = sum_{i<j} q_i, t_b = sum q_i  (< 2^60)
  *   offspring  parent j of tile b owns the offspring n with
  *              count(G_b + floor(c_j Q_b / t_b)) <= n < count(.. c_{j+1} ..),
- *              count(C) = #{n : ceil(fl(u_n + n) 2^(62-k)) <= C}, N = 2^k
+ *              count(C) = #{n : ceil(fl(u_n + n) 2^(52-k)) <= C}, N = 2^k
  * Reference semantics being implemented: resampling.py:484-509, :599-610.
  * ========================================================================== */
 static const double K_EXP[16] = {
@@ -209,8 +210,10 @@ static const double K_EXP[16] = {
     4.1666666666666664e-02, 1.6666666666666666e-01, 0.5,
     1.4426950408889634074, 6.93147180369123816490e-01, 1.90821492927058770002e-10, -745.2};
 
-double orc_exp_nonpos(double x)
+/* exp(x) = p 2^k: returns p, writes k (an integer-valued double; -inf and p = 0 for x = -inf) */
+double orc_expk(double x, double *kout)
 {
+    if (!(x > -INFINITY)) { *kout = -INFINITY; return 0.0; }
     const double k = rint(x * K_EXP[12]);
     double r = fma(-k, K_EXP[13], x);
     r = fma(-k, K_EXP[14], r);
@@ -218,12 +221,35 @@ double orc_exp_nonpos(double x)
     for (int i = 1; i < 12; ++i) p = fma(p, r, K_EXP[i]);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
-    const double y = ldexp(p, (int)k);
-    return (x < K_EXP[15]) ? 0.0 : y;
+    *kout = k;
+    return p;
+}
+/* p 2^(k - K): the weight relative to the reference exponent K */
+static double scale_pk(double p, double k, double K)
+{
+    if (!(p > 0.0)) return 0.0;
+    double d = k - K;
+    if (!(d > -2000.0)) d = -2000.0;
+    return ldexp(p, (int)d);
+}
+double orc_exp_nonpos(double x)          /* exp(x), x <= 0, as the other device paths form it */
+{
+    double k;
+    const double p = orc_expk(x, &k);
+    return (x < K_EXP[15]) ? 0.0 : ldexp(p, (int)k);
 }
 void orc_exp_nonpos_v(const double *x, int64_t n, double *out)
 {
     for (int64_t i = 0; i < n; ++i) out[i] = orc_exp_nonpos(x[i]);
+}
+/* W-relative weights of a tile-less vector: e_i = p_i 2^(k_i - K) for a given K */
+void orc_weights_pk(const double *lw, int64_t n, double K, double *out)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        double k;
+        const double p = orc_expk(lw[i], &k);
+        out[i] = scale_pk(p, k, K);
+    }
 }
 
 /* balanced binary tree over 64 values (in place), pairs (2k, 2k+1) first */
@@ -246,40 +272,44 @@ static double block_sum256(const double *slot)
     return r;
 }
 
-/* partial (m_b, S_b, SS_b) of every aligned tile of 1024 log-weights */
-void orc_tile_partials(const double *lw, int64_t N, double *pm, double *ps, double *pss)
+/* partial (K_b, S_b, SS_b) of every aligned tile of 1024 log-weights; q (N, may be NULL): the
+ * integer weights q_i = rint(e_i 2^49) */
+void orc_tile_partials(const double *lw, int64_t N, double *pK, double *ps, double *pss, uint64_t *q)
 {
     const int64_t nt = (N + 1023) / 1024;
     for (int64_t b = 0; b < nt; ++b) {
-        double m = -INFINITY;
-        for (int64_t i = b * 1024; i < (b + 1) * 1024 && i < N; ++i)
-            if (lw[i] > m) m = lw[i];
+        double p[1024], k[1024], K = -INFINITY;
+        for (int i = 0; i < 1024; ++i) {
+            const int64_t j = b * 1024 + i;
+            p[i] = orc_expk(j < N ? lw[j] : -INFINITY, &k[i]);
+            if (k[i] > K) K = k[i];
+        }
         double s1[256], s2[256];
         for (int th = 0; th < 256; ++th) {
-            double a = 0.0, q = 0.0;
-            for (int k = 0; k < 4; ++k) {
-                const int64_t i = b * 1024 + 4 * th + k;
-                const double l = i < N ? lw[i] : -INFINITY;
-                const double e = (l > -INFINITY) ? orc_exp_nonpos(l - m) : 0.0;
+            double a = 0.0, qq = 0.0;
+            for (int c = 0; c < 4; ++c) {
+                const double e = scale_pk(p[4 * th + c], k[4 * th + c], K);
                 a += e;
-                q = fma(e, e, q);
+                qq = fma(e, e, qq);
+                if (q && b * 1024 + 4 * th + c < N)
+                    q[b * 1024 + 4 * th + c] = (uint64_t)rint(e * 562949953421312.0);   /* 2^49 */
             }
             s1[th] = a;
-            s2[th] = q;
+            s2[th] = qq;
         }
-        pm[b] = m;
+        pK[b] = K;
         ps[b] = block_sum256(s1);
         pss[b] = block_sum256(s2);
     }
 }
 
-/* island level: out = {m, s, ss, ESS, rs = 1/s}; Q, G (nt each) may be NULL */
-void orc_two_level_reduce(const double *pm, const double *ps, const double *pss, int64_t nt,
-                          double *out, uint64_t *Q, uint64_t *G)
+/* island level: out = {K, s, ss, ESS, rs = 1/s}; Q, G (nt each; integer-valued doubles) may be NULL */
+void orc_two_level_reduce(const double *pK, const double *ps, const double *pss, int64_t nt,
+                          double *out, double *Q, double *G)
 {
-    double m = -INFINITY;
+    double K = -INFINITY;
     for (int64_t b = 0; b < nt; ++b)
-        if (pm[b] > m) m = pm[b];
+        if (pK[b] > K) K = pK[b];
     const int64_t nchunks = (nt + 1023) / 1024;
     double s1[256], s2[256];
     for (int th = 0; th < 256; ++th) {
@@ -287,38 +317,40 @@ void orc_two_level_reduce(const double *pm, const double *ps, const double *pss,
         for (int64_t c = 0; c < nchunks; ++c)
             for (int k = 0; k < 4; ++k) {
                 const int64_t b = c * 1024 + 4 * th + k;
-                if (b >= nt) continue;                 /* fma(0, 0, a) = a */
-                const double e = (pm[b] > -INFINITY) ? orc_exp_nonpos(pm[b] - m) : 0.0;
-                a = fma(ps[b], e, a);
-                q = fma(pss[b], e * e, q);
+                if (b >= nt) continue;
+                double d = pK[b] - K;
+                if (!(d > -2000.0)) d = -2000.0;
+                a = a + ldexp(ps[b], (int)d);
+                q = q + ldexp(pss[b], 2 * (int)d);
             }
         s1[th] = a;
         s2[th] = q;
     }
     const double s = block_sum256(s1), ss = block_sum256(s2);
-    const int bad = !(m > -INFINITY) || !(m < INFINITY);
-    out[0] = m;
+    const int bad = !(K > -INFINITY) || !(K < INFINITY);
+    out[0] = K;
     out[1] = s;
     out[2] = ss;
     out[3] = bad ? NAN : (s * s) / ss;                 /* resampling.py:226 */
     out[4] = bad ? NAN : 1.0 / s;
     if (!Q) return;
-    uint64_t g = 0;
+    double g = 0.0;
     for (int64_t b = 0; b < nt; ++b) {
-        const double e = (pm[b] > -INFINITY) ? orc_exp_nonpos(pm[b] - m) : 0.0;
-        const double w = (ps[b] * e) * out[4];
-        const uint64_t qb = (w > 0.0) ? (uint64_t)rint(fmin(w, 2.0) * 4611686018427387904.0) : 0;
+        double d = pK[b] - K;
+        if (!(d > -2000.0)) d = -2000.0;
+        const double w = ldexp(ps[b], (int)d) * out[4];
+        const double qb = (w > 0.0) ? rint(fmin(w, 2.0) * 4503599627370496.0) : 0.0;   /* 2^52 */
         Q[b] = qb;
         G[b] = g;
-        g += qb;
+        g += qb;                                       /* exact: integers below 2^53 */
     }
 }
 
-/* count(C) = #{ n < N : ceil(fl(u_n + n) 2^sh) <= C }, N = 2^k, sh = 62 - k
+/* count(C) = #{ n < N : ceil(fl(u_n + n) 2^sh) <= C }, N = 2^k, sh = 52 - k
  * (systematic: u_n = u[0]; stratified: u_n = u[n]) */
 static int64_t count_pow2(uint64_t C, const double *u, int stratified, int k, int64_t N)
 {
-    const int sh = 62 - k;
+    const int sh = 52 - k;
     const uint64_t nc = C >> sh;
     if (nc >= (uint64_t)N) return N;
     const double un = stratified ? u[nc] : u[0];
@@ -327,31 +359,28 @@ static int64_t count_pow2(uint64_t C, const double *u, int stratified, int k, in
 }
 
 /* The whole contract: ancestors A (N) from the log-weights of the parents.  scheme: 1
- * stratified (u: N uniforms), 2 systematic (u: 1 uniform).  red (5): m, s, ss, ESS, 1/s.
+ * stratified (u: N uniforms), 2 systematic (u: 1 uniform).  red (5): K, s, ss, ESS, 1/s.
  * Returns 0, or 1 if N is not a power of two >= 2048 (the path does not apply). */
 int orc_inverse_cdf_2level(const double *lw, int64_t N, int scheme, const double *u,
                            int64_t *A, double *red)
 {
     int k = -1;
-    for (int i = 0; i < 62; ++i)
+    for (int i = 0; i < 40; ++i)
         if (((int64_t)1 << i) == N) k = i;
     if (k < 11) return 1;
     const int64_t nt = N / 1024;
-    double *pm = malloc(sizeof(double) * nt), *ps = malloc(sizeof(double) * nt),
-           *pss = malloc(sizeof(double) * nt);
-    uint64_t *Q = malloc(sizeof(uint64_t) * nt), *G = malloc(sizeof(uint64_t) * nt);
-    orc_tile_partials(lw, N, pm, ps, pss);
-    orc_two_level_reduce(pm, ps, pss, nt, red, Q, G);
+    double *pK = malloc(sizeof(double) * nt), *ps = malloc(sizeof(double) * nt),
+           *pss = malloc(sizeof(double) * nt), *Q = malloc(sizeof(double) * nt),
+           *G = malloc(sizeof(double) * nt);
+    uint64_t *q = malloc(sizeof(uint64_t) * N);
+    orc_tile_partials(lw, N, pK, ps, pss, q);
+    orc_two_level_reduce(pK, ps, pss, nt, red, Q, G);
     const int strat = scheme == 1;
     int64_t prev = 0;                                  /* first offspring of parent j - 1 */
     for (int64_t b = 0; b < nt; ++b) {
-        uint64_t q[1024], tb = 0;
-        for (int i = 0; i < 1024; ++i) {
-            const double l = lw[b * 1024 + i];
-            const double e = (l > -INFINITY) ? orc_exp_nonpos(l - pm[b]) : 0.0;
-            q[i] = (uint64_t)rint(e * 1125899906842624.0);
-            tb += q[i];
-        }
+        uint64_t tb = 0;
+        for (int i = 0; i < 1024; ++i) tb += q[b * 1024 + i];
+        const uint64_t Qb = (uint64_t)Q[b], Gb = (uint64_t)G[b];
         uint64_t c = 0;
         for (int i = 0; i < 1024; ++i) {
             const int64_t j = b * 1024 + i;
@@ -360,17 +389,17 @@ int orc_inverse_cdf_2level(const double *lw, int64_t N, int scheme, const double
             else {
                 uint64_t pos;
                 if (c == 0) pos = 0;
-                else if (c >= tb) pos = Q[b];
-                else pos = (uint64_t)(((unsigned __int128)c * Q[b]) / tb);
-                ns = count_pow2(G[b] + pos, u, strat, k, N);
+                else if (c >= tb) pos = Qb;
+                else pos = (uint64_t)(((unsigned __int128)c * Qb) / tb);
+                ns = count_pow2(Gb + pos, u, strat, k, N);
             }
             /* offspring prev .. ns-1 belong to parent j - 1 */
             for (int64_t n = prev; n < ns; ++n) A[n] = j - 1;
             if (ns > prev) prev = ns;
-            c += q[i];
+            c += q[j];
         }
     }
     for (int64_t n = prev; n < N; ++n) A[n] = N - 1;   /* resampling.py:505-508 clamp */
-    free(pm); free(ps); free(pss); free(Q); free(G);
+    free(pK); free(ps); free(pss); free(Q); free(G); free(q);
     return 0;
 }

@@ -51,9 +51,11 @@ def clib():
         lib.orc_toy_filter_philox.restype = ctypes.c_double
         lib.orc_exp_nonpos_v.argtypes = [dp, i64, dp]
         lib.orc_exp_nonpos_v.restype = None
-        lib.orc_tile_partials.argtypes = [dp, i64, dp, dp, dp]
+        lib.orc_tile_partials.argtypes = [dp, i64, dp, dp, dp, up]
         lib.orc_tile_partials.restype = None
-        lib.orc_two_level_reduce.argtypes = [dp, dp, dp, i64, dp, up, up]
+        lib.orc_weights_pk.argtypes = [dp, i64, ctypes.c_double, dp]
+        lib.orc_weights_pk.restype = None
+        lib.orc_two_level_reduce.argtypes = [dp, dp, dp, i64, dp, dp, dp]
         lib.orc_two_level_reduce.restype = None
         lib.orc_inverse_cdf_2level.argtypes = [dp, i64, ctypes.c_int, dp, ip, dp]
         lib.orc_inverse_cdf_2level.restype = ctypes.c_int
@@ -311,33 +313,44 @@ def inverse_cdf_q62(su, W):
 
 
 def exp_contract(x):
-    """exp(x), x <= 0, as the two-level contract fixes it (oracle.c orc_exp_nonpos: Cody-Waite
-    reduction + degree-13 polynomial, IEEE operations only -- the device evaluates the same)."""
+    """exp(x), x <= 0, as the device forms it (oracle.c orc_exp_nonpos: Cody-Waite reduction +
+    degree-13 polynomial, IEEE operations only)."""
     x = np.ascontiguousarray(x, dtype=np.float64)
     out = np.empty_like(x)
     clib().orc_exp_nonpos_v(_dp(x), x.size, _dp(out))
     return out
 
 
-def tile_partials(lw):
-    """(m_b, S_b, SS_b) of every aligned tile of 1024 log-weights, the contract's summation
-    tree (oracle.c orc_tile_partials)."""
+def weights_pk(lw, K):
+    """e_i = p_i 2^(k_i - K): the contract's weights relative to the reference exponent K
+    (oracle.c orc_weights_pk); with K of the island and 1/s: W_i = e_i / s."""
+    lw = np.ascontiguousarray(lw, dtype=np.float64)
+    out = np.empty_like(lw)
+    clib().orc_weights_pk(_dp(lw), lw.size, float(K), _dp(out))
+    return out
+
+
+def tile_partials(lw, with_q=False):
+    """(K_b, S_b, SS_b) of every aligned tile of 1024 log-weights, the contract's summation
+    tree (oracle.c orc_tile_partials); with_q: also the integer weights q_i = rint(e_i 2^49)."""
     lw = np.ascontiguousarray(lw, dtype=np.float64)
     nt = (lw.size + 1023) // 1024
-    pm, ps, pss = np.empty(nt), np.empty(nt), np.empty(nt)
-    clib().orc_tile_partials(_dp(lw), lw.size, _dp(pm), _dp(ps), _dp(pss))
-    return pm, ps, pss
-
-
-def two_level_reduce(pm, ps, pss):
-    """Island level of the contract: dict(m, s, ss, ESS, rs) and the integer shares Q_b, G_b."""
-    nt = pm.size
-    out = np.empty(5)
-    Q, G = np.empty(nt, dtype=np.uint64), np.empty(nt, dtype=np.uint64)
+    pK, ps, pss = np.empty(nt), np.empty(nt), np.empty(nt)
+    q = np.zeros(lw.size, dtype=np.uint64) if with_q else None
     up = ctypes.POINTER(ctypes.c_uint64)
-    clib().orc_two_level_reduce(_dp(pm), _dp(ps), _dp(pss), nt, _dp(out), Q.ctypes.data_as(up),
-                                G.ctypes.data_as(up))
-    return dict(m=out[0], s=out[1], ss=out[2], ESS=out[3], rs=out[4]), Q, G
+    clib().orc_tile_partials(_dp(lw), lw.size, _dp(pK), _dp(ps), _dp(pss),
+                             q.ctypes.data_as(up) if with_q else None)
+    return (pK, ps, pss, q) if with_q else (pK, ps, pss)
+
+
+def two_level_reduce(pK, ps, pss):
+    """Island level of the contract: dict(K, s, ss, ESS, rs) and the integer shares Q_b, G_b
+    (integer-valued doubles below 2^53)."""
+    nt = pK.size
+    out = np.empty(5)
+    Q, G = np.empty(nt), np.empty(nt)
+    clib().orc_two_level_reduce(_dp(pK), _dp(ps), _dp(pss), nt, _dp(out), _dp(Q), _dp(G))
+    return dict(K=out[0], s=out[1], ss=out[2], ESS=out[3], rs=out[4]), Q, G
 
 
 def inverse_cdf_2level_c(scheme, u, lw):
@@ -352,33 +365,30 @@ def inverse_cdf_2level_c(scheme, u, lw):
                                        _dp(u), A.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), _dp(red))
     if rc:
         raise ValueError("two-level contract: N must be a power of two >= 2048")
-    return A, dict(m=red[0], s=red[1], ss=red[2], ESS=red[3], rs=red[4])
+    return A, dict(K=red[0], s=red[1], ss=red[2], ESS=red[3], rs=red[4])
 
 
-def inverse_cdf_2level(su, lw, tile=1024, P=50):
+def inverse_cdf_2level(su, lw, tile=1024):
     """The two-level exact CDF of the fused step loop for N = 2^k >= 2 tiles
     (particles_amd/csrc/smc_filter_kernels.h, k_ancestors2), formulated per OFFSPRING (the C
     restatement and the kernels count per parent): tile partials and island reduction as the
-    contract fixes them (tile_partials, two_level_reduce), tile shares Q_b of the 2^62 scale with
-    exclusive sums G_b; inside a tile the integer CDF C_j of q_i = rint(exp(lw_i - m_b) 2^P),
-    total t_b.  Offspring n with threshold T_n = ceil(su_n 2^62) in (G_b, G_b + Q_b] takes the
-    first parent j of tile b with T_n - G_b <= floor(C_j Q_b / t_b) -- exact rational comparisons
-    (Python integers here); thresholds beyond the last share go to the last particle, as
+    contract fixes them (tile_partials, two_level_reduce), tile shares Q_b of the 2^52 scale with
+    exclusive sums G_b; inside a tile the integer CDF C_j of q_i = rint(e_i 2^49), total t_b.
+    Offspring n with threshold T_n = ceil(su_n 2^52) in (G_b, G_b + Q_b] takes the first parent j
+    of tile b with T_n - G_b <= floor(C_j Q_b / t_b) -- exact rational comparisons (Python
+    integers here); thresholds beyond the last share go to the last particle, as
     resampling.py:500-509 would clamp."""
     lw = np.asarray(lw, dtype=np.float64)
     N = lw.shape[0]
     nt = N // tile
     assert nt * tile == N and nt >= 1 and tile == 1024
-    pm, ps, pss = tile_partials(lw)
-    _, Qa, Ga = two_level_reduce(pm, ps, pss)
+    pK, ps, pss, q = tile_partials(lw, with_q=True)
+    _, Qa, Ga = two_level_reduce(pK, ps, pss)
     Q = [int(v) for v in Qa]
     G = [int(v) for v in Ga] + [int(Ga[-1]) + int(Qa[-1])]
-    L = lw.reshape(nt, tile)
-    with np.errstate(invalid="ignore"):
-        E = np.where(np.isneginf(L), 0.0, exp_contract(L - pm[:, None]))
-    q = np.rint(E * float(2 ** P)).astype(np.int64)
-    C = np.cumsum(q, axis=1)                                  # inclusive, exact (< 2^63)
-    T = [int(v) for v in q62_threshold(su)]
+    C = np.cumsum(q.reshape(nt, tile).astype(np.int64), axis=1)  # inclusive, exact (< 2^63)
+    su = np.asarray(su, dtype=np.float64)
+    T = [int(v) for v in np.ceil(np.maximum(su, 0.0) * float(2 ** 52))]
     A = np.empty(len(T), dtype=np.int64)
     b = 0
     for n, Tn in enumerate(T):                                # su sorted: one sweep over the tiles

@@ -115,6 +115,16 @@ __device__ __forceinline__ double smc_uniform(double v)
     return __longlong_as_double((long long)(((u64)hi << 32) | lo));
 }
 #endif
+__device__ __forceinline__ u64 smc_uniform_u64(u64 v)
+{
+#ifdef SMC_EMULATE
+    return v;
+#else
+    const u32 lo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)v);
+    const u32 hi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(v >> 32));
+    return ((u64)hi << 32) | lo;
+#endif
+}
 __device__ __forceinline__ void smc_st_agent_f64(double* p, double v)
 {
     smc_st_agent(reinterpret_cast<u64*>(p), (u64)__double_as_longlong(v));
@@ -199,6 +209,22 @@ __device__ __forceinline__ u64 smc_block_exscan_u64(u64 v, u64* sm, u64& total)
     if (smc_lane() == 63) sm[smc_wave()] = inc;
     __syncthreads();
     u64 base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < SMC_NWAVE; ++w) {
+        if (w < smc_wave()) base += sm[w];
+        tot += sm[w];
+    }
+    total = tot;
+    return base + inc - v;
+}
+// the same for integer-valued doubles whose sums stay below 2^53 (exact, order-free)
+__device__ __forceinline__ double smc_block_exscan_f64(double v, double* sm, double& total)
+{
+    const double inc = smc_wave_scan_add_f64(v);
+    __syncthreads();
+    if (smc_lane() == 63) sm[smc_wave()] = inc;
+    __syncthreads();
+    double base = 0.0, tot = 0.0;
 #pragma unroll
     for (int w = 0; w < SMC_NWAVE; ++w) {
         if (w < smc_wave()) base += sm[w];

@@ -22,7 +22,6 @@ struct smc_filter {
     bool fused;            // k_ancestors<true> (no k_prepare launch)
     bool two_level;        // k_ancestors2 + tail-free k_propagate (two-level CDF, no intra-launch exchange)
     bool two_level_mid;    // ... with k_reduce2 in front (grids too large for every workgroup to reduce)
-    bool anc2_r1;          // experiments / tests: round 1's k_ancestors2 (SMC_ANC2_R1)
     i64 perm_t;            // t_host at the last smc_filter_permute_islands (A / Xp undefined there)
     hipGraphExec_t gexec[3];   // captured step sequences of F_GRAPH_SIZES steps (even: see enqueue_step)
     bool graph_failed;
@@ -30,6 +29,7 @@ struct smc_filter {
     std::vector<hipEvent_t> ev;
     int prof_n;
     double* tmp;           // (N,) staging for W / Xp downloads
+    double* ll_stage;      // (n_islands,) staging for smc_filter_logLt
 };
 
 typedef void (*move_fn)(FArgs);
@@ -89,18 +89,12 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t)
     const dim3 grid(f->a.ntiles, f->a.n_islands);
     if (k_prof >= 0) (void)hipEventRecord(f->ev[3 * k_prof], st);
     if (f->two_level) {
-        if (f->two_level_mid) SMC_LAUNCH(k_reduce2, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
-#define A2_CASE(K, SPECV, MIDV)                                                              \
-    if ((f->a.par >= 0) == SPECV && f->two_level_mid == MIDV)                                \
-        SMC_LAUNCH((K<SPECV, MIDV>), grid, dim3(SMC_BLOCK), st, f->a);
-        if (f->anc2_r1) {
-            A2_CASE(k_ancestors2_r1, true, true) A2_CASE(k_ancestors2_r1, false, true)
-            A2_CASE(k_ancestors2_r1, true, false) A2_CASE(k_ancestors2_r1, false, false)
+        if (f->two_level_mid) {
+            SMC_LAUNCH(k_reduce2, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
+            SMC_LAUNCH((k_ancestors2<true>), grid, dim3(SMC_BLOCK), st, f->a);
         } else {
-            A2_CASE(k_ancestors2, true, true) A2_CASE(k_ancestors2, false, true)
-            A2_CASE(k_ancestors2, true, false) A2_CASE(k_ancestors2, false, false)
+            SMC_LAUNCH((k_ancestors2<false>), grid, dim3(SMC_BLOCK), st, f->a);
         }
-#undef A2_CASE
         if (k_prof >= 0 && (k_prof % 3)) (void)hipEventRecord(f->ev[3 * k_prof + 1], st);
         launch_propagate(f);
         if (k_prof >= 0) (void)hipEventRecord(f->ev[3 * k_prof + 2], st);
@@ -254,13 +248,15 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     // every workgroup reduces the partials itself while the launch is resident and an island has
     // at most 1024 tiles (4 per thread); otherwise one workgroup per island does it first
     f->two_level_mid = f->two_level && (!f->fused || a.ntiles > 1024 || getenv("SMC_TWO_LEVEL_MID"));
-    f->anc2_r1 = getenv("SMC_ANC2_R1") != nullptr;
     const bool heavy_list = !mv && !getenv("SMC_NO_HEAVY");
+    const size_t oCq = carve(f->two_level ? M * N * 8 : 8);
+    const size_t oTq = carve(f->two_level ? M * a.ntiles * 8 : 8);
     const size_t oHcnt = carve(heavy_list ? M * 2 * sizeof(unsigned) : 8);
     const size_t oHlist = carve(heavy_list ? M * 2 * F_HMAX * 3 * 8 : 8);
     const size_t oSu = carve(need_su ? M * N * 8 : 8);
     const size_t oE = carve(need_su ? M * a.ntiles1 * 8 : 8);
     const size_t oTmp = carve(N * dxm * 8);
+    const size_t oLL = carve(M * 8);
     a.nmb = (int)((o->N + F_MOM_CHUNK - 1) / F_MOM_CHUNK);
     const size_t oMom = carve(o->moments ? M * T * 2 * dxm * 8 : 8);
     const size_t oMpart = carve(o->moments ? M * a.nmb * dxm * 3 * 8 : 8);
@@ -298,6 +294,8 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     a.params = dpar;
     a.y = dy;
     a.cnt = (unsigned*)(base + oCtl);
+    a.cq = (u64*)(base + oCq);
+    a.tq = (u64*)(base + oTq);
     a.spart = (double*)(base + oSpart);
     a.info = (double*)(base + oInfo);
     a.info2 = (double*)(base + oInfo2);
@@ -313,6 +311,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     a.su = (double*)(base + oSu);
     a.E = (u64*)(base + oE);
     f->tmp = (double*)(base + oTmp);
+    f->ll_stage = (double*)(base + oLL);
     if (o->moments) {
         a.mom = (double*)(base + oMom);
         a.mpart = (double*)(base + oMpart);
@@ -540,10 +539,9 @@ int smc_filter_logLt(smc_filter* f, double* out_host)
         SMC_HIP_CHECK(hipMemcpyAsync(out_host, f->a.summ + (size_t)(t - 1) * SUMM_STRIDE + 3, 8,
                                      hipMemcpyDeviceToHost, st));
     } else {
-        SMC_REQUIRE((size_t)M * 8 <= (size_t)f->a.N * f->a.dx * 8, "more islands than staging space");
-        SMC_LAUNCH(k_f_collect_logLt, dim3((M + 255) / 256), dim3(256), st, f->a.summ, T, t, M, f->tmp);
+        SMC_LAUNCH(k_f_collect_logLt, dim3((M + 255) / 256), dim3(256), st, f->a.summ, T, t, M, f->ll_stage);
         SMC_LAUNCH_CHECK();
-        SMC_HIP_CHECK(hipMemcpyAsync(out_host, f->tmp, (size_t)M * 8, hipMemcpyDeviceToHost, st));
+        SMC_HIP_CHECK(hipMemcpyAsync(out_host, f->ll_stage, (size_t)M * 8, hipMemcpyDeviceToHost, st));
     }
     SMC_HIP_CHECK(hipStreamSynchronize(st));
     return SMC_OK;
@@ -611,7 +609,7 @@ static int filter_fetch(smc_filter* f, int field, i64 s, int island, void* out_h
     }
     case SMC_FIELD_W: {
         const double* row = f->a.summ + ((size_t)island * (f->a.T + 1) + (t - 1)) * SUMM_STRIDE;
-        SMC_LAUNCH(k_f_write_W, dim3(nb), dim3(SMC_BLOCK), st, lw, N, row, f->tmp);
+        SMC_LAUNCH(k_f_write_W, dim3(nb), dim3(SMC_BLOCK), st, lw, N, row, f->tmp, f->two_level ? 1 : 0);
         src = f->tmp;
         break;
     }
@@ -652,7 +650,8 @@ int smc_filter_set_state(smc_filter* f, int island, const double* X_host, const 
     if (lw_host) {
         SMC_HIP_CHECK(hipMemcpyAsync(f_lw(f->a, ts) + (size_t)island * N, lw_host, (size_t)N * 8,
                                      hipMemcpyHostToDevice, st));
-        SMC_LAUNCH(k_f_partials, dim3(f->a.nparts, f->a.n_islands), dim3(SMC_BLOCK), st, f->a, ts);
+        SMC_LAUNCH(k_f_partials, dim3(f->a.nparts, f->a.n_islands), dim3(SMC_BLOCK), st, f->a, ts,
+                   f->two_level ? 1 : 0);
         if (f->two_level) SMC_LAUNCH(k_flush2, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
         else SMC_LAUNCH(k_f_restate, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a, ts);
     }
@@ -684,8 +683,9 @@ int smc_filter_permute_islands(smc_filter* f, const int64_t* src_host)
     const int dx = f->a.dx;
     const size_t bx = (size_t)N * dx * 8, bl = (size_t)N * 8, bs = (size_t)(T + 1) * SUMM_STRIDE * 8,
                  bi = INFO_STRIDE * 8, bp = PARAM_STRIDE * 8;
-    const size_t bq = f->two_level ? (size_t)f->a.nparts * 8 : 0;      // three partial arrays + info2
-    const size_t per = bx + bl + bs + bi + bp + 3 * bq + bi;
+    const size_t bq = f->two_level ? (size_t)f->a.nparts * 8 : 0;      // partial arrays, t_b, info2, c_j
+    const size_t bc = f->two_level ? (size_t)N * 8 : 0;
+    const size_t per = bx + bl + bs + bi + bp + 4 * bq + bi + bc;
     char* tmp = nullptr;
     hipError_t e = hipMalloc((void**)&tmp, per * M);
     if (e != hipSuccess) {
@@ -713,6 +713,8 @@ int smc_filter_permute_islands(smc_filter* f, const int64_t* src_host)
             cp(q + bq, f->a.ps + s_ * f->a.nparts, bq);
             cp(q + 2 * bq, f->a.pss + s_ * f->a.nparts, bq);
             cp(q + 3 * bq, f->a.info2 + s_ * INFO_STRIDE, bi);
+            cp(q + 3 * bq + bi, f->a.tq + s_ * f->a.nparts, bq);
+            cp(q + 4 * bq + bi, f->a.cq + s_ * N, bc);
         }
     }
     for (int i = 0; i < M; ++i) {                                   // and back, slot by slot
@@ -728,6 +730,8 @@ int smc_filter_permute_islands(smc_filter* f, const int64_t* src_host)
             cp(f->a.ps + (size_t)i * f->a.nparts, q + bq, bq);
             cp(f->a.pss + (size_t)i * f->a.nparts, q + 2 * bq, bq);
             cp(f->a.info2 + (size_t)i * INFO_STRIDE, q + 3 * bq, bi);
+            cp(f->a.tq + (size_t)i * f->a.nparts, q + 3 * bq + bi, bq);
+            cp(f->a.cq + (size_t)i * N, q + 4 * bq + bi, bc);
         }
     }
     if (rc == hipSuccess) rc = hipStreamSynchronize(st);
@@ -775,6 +779,8 @@ int smc_filter_copy_islands(smc_filter* dst, smc_filter* src, const unsigned cha
             cp(a.ps + oq, b.ps + oq, bq);
             cp(a.pss + oq, b.pss + oq, bq);
             cp(a.info2 + (size_t)i * INFO_STRIDE, b.info2 + (size_t)i * INFO_STRIDE, INFO_STRIDE * 8);
+            cp(a.tq + oq, b.tq + oq, bq);
+            cp(a.cq + (size_t)i * N, b.cq + (size_t)i * N, (size_t)N * 8);
         }
     }
     if (rc == hipSuccess) rc = hipStreamSynchronize(st);

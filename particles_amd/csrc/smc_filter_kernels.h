@@ -73,7 +73,9 @@ struct FArgs {
                            // kernels form their addresses before the step record has arrived
     u64* Q;                // (n_islands, ntiles) tile totals of q
     u64* Qpre;             // (n_islands, ntiles) exclusive prefixes of Q
-    double *pm, *ps, *pss; // (n_islands, ntiles) log-sum-exp partials
+    double *pm, *ps, *pss; // (n_islands, ntiles) log-sum-exp partials (two-level path: K_b, S_b, SS_b)
+    u64* cq;               // two-level path: (n_islands, N) exclusive integer CDF of every particle in its tile
+    u64* tq;               // two-level path: (n_islands, ntiles) the tiles' integer totals t_b
     unsigned* cnt;         // (n_islands, 2, F_CNT_WORDS) completion tickets: k_propagate, k_prepare
     double* spart;         // (n_islands, 3, 32) shard-level log-sum-exp partials
     double* summ;          // (n_islands, T+1, SUMM_STRIDE)
@@ -848,6 +850,75 @@ __device__ __forceinline__ void f_load_anc(const u32* A, i64 n0, i64 N, bool ful
     }
 }
 
+// ---- two-level CDF path (contract: see "Two-level CDF" below): what k_propagate leaves per tile
+#define F2_QBITS 49                     /* local CDF: q_i = rint(e_i 2^49), t_b < 2^60 */
+#define F2_SBITS 52                     /* shares: Q_b = rint(W_b 2^52) */
+struct F2Red {
+    double K, s, ss, ess, log_mean, rs;
+    bool bad;
+};
+struct F2Tile {
+    double K, S, SS;
+    u64 tb;
+};
+// The tile's partial and integer CDF from the 4 log-weights each thread holds; cx: the
+// exclusive CDF positions of this thread's particles.  Two barriers; all threads get the result.
+// Association order of S, SS: the thread's 4 values left to right, a balanced tree over the 64
+// lanes, the 4 waves left to right (oracle.c orc_tile_partials).
+__device__ __forceinline__ F2Tile f2_tile_weights(const double (&lw)[4], u64 (&cx)[4])
+{
+    __shared__ double s_k[SMC_NWAVE];
+    __shared__ double s_s[2 * SMC_NWAVE];
+    __shared__ u64 s_c[SMC_NWAVE];
+    const int lane = smc_lane(), wave = smc_wave();
+    double p[4], k[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        p[i] = smc_expk(lw[i], k[i]);
+        const bool ok = lw[i] > -INFINITY;
+        p[i] = ok ? p[i] : 0.0;
+        k[i] = ok ? k[i] : -INFINITY;
+    }
+    double km = smc_max2(smc_max2(k[0], k[1]), smc_max2(k[2], k[3]));
+    km = smc_wave_max(km);
+    if (lane == 0) s_k[wave] = km;
+    __syncthreads();
+    F2Tile r;
+    r.K = s_k[0];
+#pragma unroll
+    for (int w = 1; w < SMC_NWAVE; ++w) r.K = smc_max2(r.K, s_k[w]);
+    double s1 = 0.0, s2 = 0.0;
+    u64 q[4], ts = 0ull;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double e = smc_scale_pk(p[i], k[i], r.K);
+        s1 += e;
+        s2 = fma(e, e, s2);
+        q[i] = (u64)rint(e * 562949953421312.0);                       // 2^49
+        ts += q[i];
+    }
+    s1 = smc_wave_sum(s1);
+    s2 = smc_wave_sum(s2);
+    const u64 inc = smc_wave_scan_add_u64(ts);
+    if (lane == 0) { s_s[wave] = s1; s_s[SMC_NWAVE + wave] = s2; }
+    if (lane == 63) s_c[wave] = inc;
+    __syncthreads();
+    r.S = s_s[0];
+    r.SS = s_s[SMC_NWAVE];
+    u64 c = inc - ts;
+    r.tb = 0ull;
+#pragma unroll
+    for (int w = 0; w < SMC_NWAVE; ++w) {
+        if (w > 0) { r.S = r.S + s_s[w]; r.SS = r.SS + s_s[SMC_NWAVE + w]; }
+        if (w < wave) c += s_c[w];
+        r.tb += s_c[w];
+    }
+    cx[0] = c;
+    cx[1] = c + q[0];
+    cx[2] = cx[1] + q[1];
+    cx[3] = cx[2] + q[2];
+    return r;
+}
 // The workgroup's log-sum-exp partial (max, sum e, sum e^2) of the OPT log-weights each thread
 // holds (-inf beyond N): max first, then ONE exp per particle against the workgroup's max (no
 // per-thread rescaling, no branches).  Fixed association order: the thread's OPT values left to
@@ -1015,17 +1086,26 @@ k_propagate(const FArgs av)
     // ---- the workgroup's (max, sum e, sum e^2): max first, then ONE exp per particle
     // against the workgroup's max (no per-thread rescaling, no branches)
     F_STAMP(3);
-    const SmcLse r = f_tile_lse<OPT>(lw, smd);
     if (TAIL) {
+        const SmcLse r = f_tile_lse<OPT>(lw, smd);
         f_step_tail(a, isl, b, t, first, resample, r, smd, s_last, info);
     } else {
-        // two-level path: the partial is all this launch owes; k_ancestors2(t+1) -- every
-        // workgroup of it -- reduces the partials, so nobody waits for a last workgroup here
+        // two-level path: the tile's partial and its integer CDF are all this launch owes;
+        // k_ancestors2(t+1) -- every workgroup of it -- reduces the partials, so nobody waits for
+        // a last workgroup here
+        static_assert(TAIL || OPT == 4, "the two-level path works on tiles of 256 x 4 particles");
+        u64 cx[4];
+        const double (&lw4)[4] = reinterpret_cast<const double (&)[4]>(lw);
+        const F2Tile r = f2_tile_weights(lw4, cx);
+        u64* cq = a.cq + (i64)isl * N + n0;
+        if (a.nt) { smc_st2g_nt(cq, cx[0], cx[1]); smc_st2g_nt(cq + 2, cx[2], cx[3]); }
+        else { smc_st2g(cq, cx[0], cx[1]); smc_st2g(cq + 2, cx[2], cx[3]); }
         if (tid == 0) {
             const i64 o = (i64)isl * a.nparts;
-            a.pm[o + b] = r.m;
-            a.ps[o + b] = r.s;
-            a.pss[o + b] = r.ss;
+            a.pm[o + b] = r.K;
+            a.ps[o + b] = r.S;
+            a.pss[o + b] = r.SS;
+            a.tq[o + b] = r.tb;
             if (b == 0) a.info2[(i64)isl * INFO_STRIDE] = (double)(t + 1);
         }
         F_STAMP(4);
@@ -1033,57 +1113,56 @@ k_propagate(const FArgs av)
 }
 
 // ---------------------------------------------------------------------------
-// Two-level CDF (systematic / stratified, N = 2^k, 2..1024 tiles per island): the step loop
-// without any intra-launch exchange.
+// Two-level CDF (systematic / stratified, N = 2^k, at least 2 tiles per island): the step loop
+// without any intra-launch exchange.  Contract (restated in oracle/oracle.c, checked bit for bit):
 //
-// k_propagate<.., TAIL = false>(t-1) leaves one log-sum-exp partial (m_b, S_b, SS_b) per
-// aligned tile of 1024 particles.  EVERY workgroup of k_ancestors2(t) reduces those <= 1024
-// partials itself (same loads, same order, same bits everywhere): (m, s) -> ESS, the
-// resample decision, and each tile's share of the 2^62 scale
-//     Q_b = rint(S_b exp(m_b - m) / s * 2^62),      G_b = sum_{b' < b} Q_b'   (exact integers).
-// Inside its tile a workgroup builds the exact integer CDF c_j of q_i = rint(exp(lw_i - m_b) 2^50)
-// (total t_b) and places parent j's first offspring at
-//     ns_j = #{ n : T_n <= G_b + floor(c_j Q_b / t_b) },      T_n = ceil(su_n 2^62)
+// Weights travel as pairs (p, k), exp(lw) = p 2^k (smc_expk): no maximum is needed to form them
+// and every change of reference is an exact power-of-two scaling.
+// k_propagate<.., TAIL = false>(t-1) ends, per aligned tile b of 1024 new particles, with
+//   K_b = max k_i,  e_i = p_i 2^(k_i - K_b),  the partial (K_b, S_b = sum e, SS_b = sum e^2),
+//   the tile's integer CDF  q_i = rint(e_i 2^49), c_j = sum_{i<j} q_i (stored: 8 B per particle),
+//   t_b = sum q_i  -- no tickets, no last workgroup.
+// EVERY workgroup of k_ancestors2(t) reduces the <= 1024 partials itself (same loads, same
+// order, same bits everywhere; k_reduce2 does it once per island for larger grids):
+//   K = max K_b, s = sum S_b 2^(K_b-K), ss likewise -> ESS, the resample decision, and each tile's
+//   share of the 2^52 scale  Q_b = rint(S_b 2^(K_b-K) / s 2^52),  G_b = sum_{b' < b} Q_b'
+//   (integers below 2^53, summed exactly in fp64).
+// Parent j of tile b then owns the offspring n with
+//     count(G_b + floor(c_j Q_b / t_b)) <= n < count(G_b + floor(c_{j+1} Q_b / t_b)),
+//     count(C) = #{ n : T_n <= C },  T_n = ceil(su_n 2^52)
 // -- i.e. offspring n with G_b < T_n <= G_b + Q_b belongs to the parent j of tile b with
-// c_j Q_b < (T_n - G_b) t_b <= c_{j+1} Q_b: an exact rational comparison, deterministic for
-// any schedule.  Compared with the flat Q62 contract (smc_resample.h) the tile totals no longer
-// need the normalised weights of other tiles, so the look-back of k_ancestors<true> -- a
-// store -> visible -> poll round trip -- and the ticket / last-workgroup tail of k_propagate
-// both disappear; what remains between the kernels is the launch boundary.  Restated in
-// oracle/smc_oracle.py (inverse_cdf_2level); agrees with the sequential fp64 CDF of the
-// reference except within rounding distance of a CDF step, like the flat contract.
+// c_j Q_b < (T_n - G_b) t_b <= c_{j+1} Q_b: an exact rational comparison, deterministic for any
+// schedule.  It agrees with the sequential fp64 CDF of the reference (resampling.py:500-509)
+// except within rounding distance of a CDF step.  Neither kernel of the step evaluates an exp
+// more than once per particle, and k_ancestors2 none at all.
 // Workgroup 0 writes the summary row of step t-1 and the record k_propagate(t) reads.
 // ---------------------------------------------------------------------------
-struct F2Red {
-    double m, s, ss, ess, log_mean, rs;
-    bool bad;
-};
-// every thread: partials tid*4 .. tid*4+3 of the island (e4: their exp(m_b - m)); all threads
-// receive the same reduced values
-__device__ __forceinline__ F2Red f2_reduce(const FArgs& a, const double (&pm4)[4],
-                                           const double (&ps4)[4], const double (&pss4)[4],
-                                           double (&e4)[4], double* smd)
+// S_b 2^(K_b - K) and SS_b 2^(2 (K_b - K)): a tile's sums on the island's reference (exact)
+__device__ __forceinline__ void f2_rescale(const double Kb, const double K, const double S, const double SS,
+                                           double& v, double& w)
 {
-    F2Red r;
-    double tm = pm4[0];
-#pragma unroll
-    for (int k = 1; k < 4; ++k) tm = smc_max2(tm, pm4[k]);
-    r.m = smc_block_max(tm, smd);
-    double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        e4[k] = (pm4[k] > -INFINITY) ? smc_exp_nonpos(pm4[k] - r.m) : 0.0;
-        s1 = fma(ps4[k], e4[k], s1);
-        s2 = fma(pss4[k], e4[k] * e4[k], s2);
-    }
-    smc_block_sum2(s1, s2, smd);
-    r.s = s1;
-    r.ss = s2;
-    r.bad = !(r.m > -INFINITY) || !(r.m < INFINITY);
-    r.ess = r.bad ? NAN : (s1 * s1) / s2;                               // resampling.py:226
-    r.log_mean = r.bad ? NAN : r.m + log(s1 / (double)a.N);             // resampling.py:224
-    r.rs = r.bad ? NAN : 1.0 / s1;
-    return r;
+    double d = Kb - K;
+    d = (d > -2000.0) ? d : -2000.0;
+    const int di = (int)d;
+    v = ldexp(S, di);
+    w = ldexp(SS, 2 * di);
+}
+__device__ __forceinline__ double f2_share(const double v, const double rs)
+{
+    const double w = v * rs;
+    return (w > 0.0) ? rint(fmin(w, 2.0) * 4503599627370496.0) : 0.0;      // 2^52
+}
+__device__ __forceinline__ void f2_finish(const FArgs& a, F2Red& r)
+{
+    r.bad = !(r.K > -INFINITY) || !(r.K < INFINITY);
+    r.ess = r.bad ? NAN : (r.s * r.s) / r.ss;                              // resampling.py:226
+    r.rs = r.bad ? NAN : 1.0 / r.s;
+}
+// log of the mean weight, m + log(s / N) with m = K ln 2 (resampling.py:224); one thread
+__device__ __forceinline__ double f2_log_mean(const FArgs& a, const F2Red& r)
+{
+    if (r.bad) return NAN;
+    return r.K * 6.93147180369123816490e-01 + (r.K * 1.90821492927058770002e-10 + log(r.s / (double)a.N));
 }
 // summary row of step ts (the step the partials belong to) -- core.py:355-359
 __device__ __forceinline__ void f2_write_row(const FArgs& a, const int isl, const i64 ts, const F2Red& r)
@@ -1091,16 +1170,19 @@ __device__ __forceinline__ void f2_write_row(const FArgs& a, const int isl, cons
     double* row = a.summ + ((i64)isl * (a.T + 1) + ts) * SUMM_STRIDE;
     const bool first = (ts == 0);
     const bool resampled = row[4] != 0.0;              // written when step ts was decided
-    const double loglt = (first || resampled) ? r.log_mean : r.log_mean - row[1 - SUMM_STRIDE];
+    const double log_mean = f2_log_mean(a, r);
+    const double loglt = (first || resampled) ? log_mean : log_mean - row[1 - SUMM_STRIDE];
     row[0] = r.ess;
-    row[1] = r.log_mean;
+    row[1] = log_mean;
     row[2] = loglt;
     row[3] = (first ? 0.0 : row[3 - SUMM_STRIDE]) + loglt;
-    row[5] = r.m;
+    row[5] = r.K;                                      // W = p 2^(k - K) / s  (k_f_write_W)
     row[6] = r.rs;
 }
 
-// the sorted uniforms of step t (systematic: the one draw; stratified: read per offspring)
+// the sorted uniforms of step t (systematic: the one draw; stratified: read per offspring);
+// kq: the "k" the count functions of smc_resample.h are called with -- they use 2^(62-k) per
+// offspring, the shares here live on the 2^52 scale, hence kq = log2 N + 10
 __device__ __forceinline__ void f2_su(const FArgs& a, const int isl, const i64 t, SmcSu& su, u64& Us)
 {
     su.scheme = a.scheme;
@@ -1120,356 +1202,26 @@ __device__ __forceinline__ void f2_su(const FArgs& a, const int isl, const i64 t
             su.u_sys = smc_u01_halfopen(x0);
         }
     }
-    Us = (u64)(su.u_sys * __longlong_as_double((long long)(1023 + 62 - a.log2N) << 52));
+    Us = (u64)(su.u_sys * __longlong_as_double((long long)(1023 + F2_SBITS - a.log2N) << 52));
 }
 __device__ __forceinline__ i64 f2_count(const FArgs& a, const SmcSu& su, const u64 Us, const u64 C)
 {
-    return a.scheme == SMC_SYSTEMATIC_ ? smc_sys_count_pow2_fast(C, su.u_sys, Us, a.log2N, a.N)
-                                       : smc_strat_count_pow2(C, su, a.log2N, a.N);
+    const int kq = a.log2N + (62 - F2_SBITS);
+    return a.scheme == SMC_SYSTEMATIC_ ? smc_sys_count_pow2_fast(C, su.u_sys, Us, kq, a.N)
+                                       : smc_strat_count_pow2(C, su, kq, a.N);
 }
-// a tile's own integer CDF relative to its maximum mb: q_i = rint(exp(lw_i - mb) 2^50), the
-// exclusive prefix of this thread's four, the tile's total
-__device__ __forceinline__ u64 f2_local_cdf(const double (&l4)[4], const double mb, const i64 jt,
-                                            const i64 N, u64* smu, u64 (&q4)[4], u64& tb)
-{
-    u64 tsum = 0ull;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const double e = (l4[i] > -INFINITY) ? smc_exp_nonpos(l4[i] - mb) : 0.0;
-        q4[i] = (jt + i < N) ? (u64)rint(e * 1125899906842624.0) : 0ull;          // 2^50
-        tsum += q4[i];
-    }
-    return smc_block_exscan_u64(tsum, smu, tb);
-}
-// first offspring ns[i] of the parents jt+i (ns[4]: of the next thread's first parent)
-__device__ __forceinline__ void f2_first_offspring(const FArgs& a, const SmcSu& su, const u64 Us,
-                                                   const u64 (&q4)[4], const u64 cex, const u64 tb,
-                                                   const u64 Gb, const u64 Qb, const i64 jt,
-                                                   i64 (&ns)[F_IPT + 1])
-{
-    const i64 N = a.N;
-    u64 c = cex;
-    // c Q_b / t_b in fp64 is within 2^12 of the exact quotient (< 2^63, three roundings): enough
-    // to decide the count unless the position falls within that band of a threshold
-    const double qscale = (double)Qb / (double)(tb ? tb : 1ull);
-#pragma unroll
-    for (int i = 0; i <= F_IPT; ++i) {
-        const i64 j = jt + i;
-        if (j == 0) ns[i] = 0;
-        else if (j >= N) ns[i] = N;
-        else {
-            u64 qh = (u64)((double)c * qscale);
-            qh = qh > Qb ? Qb : qh;
-            i64 cnt = a.exact_counts ? -1
-                                     : smc_count_pow2_band(Gb + qh, 1ull << 13, su, su.u_sys, Us, a.log2N, N);
-            if (cnt < 0) cnt = f2_count(a, su, Us, Gb + smc_muldiv_floor(c, Qb, tb));
-            ns[i] = cnt;
-        }
-        if (i < F_IPT) c += q4[i];
-    }
-}
-
-// the decision of step t and what k_propagate(t) reads (one thread)
-__device__ __forceinline__ void f2_write_record(const FArgs& a, const int isl, const i64 t, const F2Red& r,
-                                                const bool resample)
-{
-    double* info = a.info + (i64)isl * INFO_STRIDE;
-    f2_write_row(a, isl, t - 1, r);
-    a.summ[((i64)isl * (a.T + 1) + t) * SUMM_STRIDE + 4] = resample ? 1.0 : 0.0;
-    info[0] = (double)t;
-    info[1] = resample ? 1.0 : 0.0;
-    info[2] = a.y[t * a.dy];
-    info[3] = r.m;
-    info[4] = r.rs;
-    info[5] = a.aux ? a.aux[t] : 0.0;
-}
-// The same reduction by ONE workgroup for an island of any number of tiles, in chunks of 1024
-// partials (thread tid: the four from 4*tid on of every chunk, coalesced 16-byte loads).  Up
-// to 1024 tiles that is operation for operation what f2_reduce does in every workgroup of
-// k_ancestors2, hence the same bits.
-__device__ __forceinline__ F2Red f2_reduce_island(const FArgs& a, const int isl, double* smd)
-{
-    const i64 o = (i64)isl * a.nparts;
-    const bool pvec = (a.nparts & 3) == 0;
-    const int nchunks = (a.nparts + 4 * SMC_BLOCK - 1) / (4 * SMC_BLOCK);
-    F2Red r;
-    double tm = -INFINITY;
-    for (int c = 0; c < nchunks; ++c) {
-        double pm4[4];
-        f_load4<double>(a.pm + o, (i64)c * 4 * SMC_BLOCK + (i64)threadIdx.x * 4, a.nparts, pvec, -INFINITY, pm4);
-        double cm = pm4[0];
-#pragma unroll
-        for (int k = 1; k < 4; ++k) cm = smc_max2(cm, pm4[k]);
-        tm = c ? smc_max2(tm, cm) : cm;
-    }
-    r.m = smc_block_max(tm, smd);
-    double s1 = 0.0, s2 = 0.0;
-    for (int c = 0; c < nchunks; ++c) {
-        const i64 i0 = (i64)c * 4 * SMC_BLOCK + (i64)threadIdx.x * 4;
-        double pm4[4], ps4[4], pss4[4];
-        f_load4<double>(a.pm + o, i0, a.nparts, pvec, -INFINITY, pm4);
-        f_load4<double>(a.ps + o, i0, a.nparts, pvec, 0.0, ps4);
-        f_load4<double>(a.pss + o, i0, a.nparts, pvec, 0.0, pss4);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const double e = (pm4[k] > -INFINITY) ? smc_exp_nonpos(pm4[k] - r.m) : 0.0;
-            s1 = fma(ps4[k], e, s1);
-            s2 = fma(pss4[k], e * e, s2);
-        }
-    }
-    smc_block_sum2(s1, s2, smd);
-    r.s = s1;
-    r.ss = s2;
-    r.bad = !(r.m > -INFINITY) || !(r.m < INFINITY);
-    r.ess = r.bad ? NAN : (s1 * s1) / s2;
-    r.log_mean = r.bad ? NAN : r.m + log(s1 / (double)a.N);
-    r.rs = r.bad ? NAN : 1.0 / s1;
-    return r;
-}
-
-// k_reduce2(t): one workgroup per island reduces the partials of step t-1, decides step t,
-// writes the record, the summary row and every tile's (G_b, Q_b)
-__global__ void __launch_bounds__(SMC_BLOCK)
-k_reduce2(const FArgs av)
-{
-    const FArgs& a = av;
-    __shared__ double smd[SMC_SM];
-    __shared__ u64 smu[SMC_SM];
-    const int isl = (int)blockIdx.x, tid = (int)threadIdx.x;
-    double* info = a.info + (i64)isl * INFO_STRIDE;
-    const i64 t = (i64)smc_uniform(smc_ldg(a.info2 + (i64)isl * INFO_STRIDE));
-    if (t >= a.T) {
-        if (tid == 0) info[0] = (double)t;
-        return;
-    }
-    if (t == 0) return;
-    const i64 o = (i64)isl * a.nparts;
-    const bool pvec = (a.nparts & 3) == 0;
-    const int nchunks = (a.nparts + 4 * SMC_BLOCK - 1) / (4 * SMC_BLOCK);
-    u64* G = a.Qpre + (i64)isl * a.ntiles;
-    u64* Q = a.Q + (i64)isl * a.ntiles;
-    if (nchunks <= 4) {
-        // up to 4096 tiles: every load of the workgroup in flight at once, the partials stay in
-        // registers across the three phases (same operations and order as f2_reduce_island)
-        double pm[4][4], ps[4][4], pss[4][4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const i64 i0 = (i64)c * 4 * SMC_BLOCK + (i64)tid * 4;
-            f_load4<double>(a.pm + o, i0, a.nparts, pvec, -INFINITY, pm[c]);
-            f_load4<double>(a.ps + o, i0, a.nparts, pvec, 0.0, ps[c]);
-            f_load4<double>(a.pss + o, i0, a.nparts, pvec, 0.0, pss[c]);
-        }
-        F2Red r;
-        double tm = -INFINITY;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            double cm = pm[c][0];
-#pragma unroll
-            for (int k = 1; k < 4; ++k) cm = smc_max2(cm, pm[c][k]);
-            tm = c ? smc_max2(tm, cm) : cm;
-        }
-        r.m = smc_block_max(tm, smd);
-        double s1 = 0.0, s2 = 0.0, e[4][4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                e[c][k] = (pm[c][k] > -INFINITY) ? smc_exp_nonpos(pm[c][k] - r.m) : 0.0;
-                s1 = fma(ps[c][k], e[c][k], s1);
-                s2 = fma(pss[c][k], e[c][k] * e[c][k], s2);
-            }
-        smc_block_sum2(s1, s2, smd);
-        r.s = s1;
-        r.ss = s2;
-        r.bad = !(r.m > -INFINITY) || !(r.m < INFINITY);
-        r.ess = r.bad ? NAN : (s1 * s1) / s2;
-        r.log_mean = r.bad ? NAN : r.m + log(s1 / (double)a.N);
-        r.rs = r.bad ? NAN : 1.0 / s1;
-        const bool resample = r.ess < a.ess_thresh;
-        if (tid == 0) f2_write_record(a, isl, t, r, resample);
-        if (!resample) return;
-        u64 carry = 0ull;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if (c >= nchunks) break;
-            const i64 i0 = (i64)c * 4 * SMC_BLOCK + (i64)tid * 4;
-            u64 Q4[4], run = 0ull;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                Q4[k] = (i0 + k < a.nparts) ? smc_q62_w((ps[c][k] * e[c][k]) * r.rs) : 0ull;
-                run += Q4[k];
-            }
-            u64 tot;
-            u64 g = carry + smc_block_exscan_u64(run, smu, tot);
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (i0 + k < a.nparts) { G[i0 + k] = g; Q[i0 + k] = Q4[k]; g += Q4[k]; }
-            carry += tot;
-        }
-        return;
-    }
-    const F2Red r = f2_reduce_island(a, isl, smd);
-    const bool resample = r.ess < a.ess_thresh;
-    if (tid == 0) f2_write_record(a, isl, t, r, resample);
-    if (!resample) return;
-    // every tile's share and the shares before it, chunk by chunk (a running carry across chunks)
-    u64 carry = 0ull;
-    for (int c = 0; c < nchunks; ++c) {
-        const i64 i0 = (i64)c * 4 * SMC_BLOCK + (i64)tid * 4;
-        double pm4[4], ps4[4];
-        f_load4<double>(a.pm + o, i0, a.nparts, pvec, -INFINITY, pm4);
-        f_load4<double>(a.ps + o, i0, a.nparts, pvec, 0.0, ps4);
-        u64 Q4[4], run = 0ull;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const double e = (pm4[k] > -INFINITY) ? smc_exp_nonpos(pm4[k] - r.m) : 0.0;
-            Q4[k] = (i0 + k < a.nparts) ? smc_q62_w((ps4[k] * e) * r.rs) : 0ull;
-            run += Q4[k];
-        }
-        u64 tot;
-        u64 g = carry + smc_block_exscan_u64(run, smu, tot);
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (i0 + k < a.nparts) { G[i0 + k] = g; Q[i0 + k] = Q4[k]; g += Q4[k]; }
-        carry += tot;
-    }
-}
-
-// MID: k_reduce2 ran first (one workgroup per island did the reduction and left (G_b, Q_b) in
-// Qpre / Q and the record in `info`): grids too large for every workgroup to repeat it.
-template <bool SPEC, bool MID>
-__global__ void __launch_bounds__(SMC_BLOCK)
-k_ancestors2_r1(const FArgs av)
-{
-    const FArgs& a = av;
-    __shared__ __attribute__((aligned(16))) u32 sP[F_PASS];
-    __shared__ u64 smu[SMC_SM];
-    __shared__ double smd[SMC_SM];
-    __shared__ i64 sn[2];
-    __shared__ u32 smx[SMC_NWAVE];
-    __shared__ u64 sgq[2];
-    const int b = (int)blockIdx.x, isl = (int)blockIdx.y;
-    const int tid = (int)threadIdx.x;
-    const i64 N = a.N;
-    const bool vec = (N & 3) == 0;
-    const i64 j0 = (i64)b * F_TILE;
-    const i64 jt = j0 + (i64)tid * F_IPT;
-    F_STAMP_A(0);
-    double* info = a.info + (i64)isl * INFO_STRIDE;
-    const double r0 = smc_ldg(MID ? info : a.info2 + (i64)isl * INFO_STRIDE);
-    const double r1 = MID ? smc_ldg(info + 1) : 0.0;
-    const i64 o = (i64)isl * a.nparts;
-    double pm4[4], ps4[4], pss4[4], l4[4];
-    const double mb_raw = smc_ldg(a.pm + o + b);              // what the local CDF needs first
-    u64 Gmid = 0ull, Qmid = 0ull;
-    if (MID) {
-        Gmid = smc_ldg(a.Qpre + (i64)isl * a.ntiles + b);
-        Qmid = smc_ldg(a.Q + (i64)isl * a.ntiles + b);
-    }
-    if (SPEC)
-        f_load4<double>(a.lw + (i64)(a.par ^ 1) * a.lslot + (i64)isl * N, jt, N, vec, -INFINITY, l4);
-    if (!MID) {
-        const bool pvec = (a.nparts & 3) == 0;
-        f_load4<double>(a.pm + o, (i64)tid * 4, a.nparts, pvec, -INFINITY, pm4);
-        f_load4<double>(a.ps + o, (i64)tid * 4, a.nparts, pvec, 0.0, ps4);
-        f_load4<double>(a.pss + o, (i64)tid * 4, a.nparts, pvec, 0.0, pss4);
-    }
-    const i64 t = (i64)smc_uniform(r0);
-    if (t >= a.T) {
-        if (!MID && b == 0 && tid == 0) info[0] = (double)t;   // k_propagate returns on it
-        return;
-    }
-    if (t == 0) return;                                        // the host wrote the record of step 0
-    if (MID && smc_uniform(r1) == 0.0) return;                 // k_reduce2: step t does not resample
-    if (!SPEC) f_load4<double>(f_lw(a, t - 1) + (i64)isl * N, jt, N, vec, -INFINITY, l4);
-    F_STAMP_A(1);
-    // ---- the tile's own integer CDF, relative to the tile's maximum (needs nothing from the
-    // other tiles: done while the partials are still on their way; wasted only on the steps
-    // that turn out not to resample)
-    SmcSu su;                                                  // (the step's uniform: a Philox call
-    u64 Us;                                                    //  in the shadow of the loads)
-    f2_su(a, isl, t, su, Us);
-    const double mb = smc_uniform(mb_raw);
-    u64 q4[4], tb;
-    const u64 cex = f2_local_cdf(l4, mb, jt, N, smu, q4, tb);
-    F_STAMP_A(2);
-    u64 Gb, Qb;
-    if (MID) {
-        Gb = smc_uniform(Gmid);
-        Qb = smc_uniform(Qmid);
-    } else {
-        // ---- all partials -> (m, s), ESS, the decision; workgroup 0 writes them down
-        double e4[4];
-        const F2Red r = f2_reduce(a, pm4, ps4, pss4, e4, smd);
-        const bool resample = r.ess < a.ess_thresh;            // core.py:181-183 (t < T here)
-        if (b == 0 && tid == 0) f2_write_record(a, isl, t, r, resample);
-        F_STAMP_A(3);
-        if (!resample) return;
-        // ---- this tile's share Q_b of the 2^62 scale and the shares before it, G_b
-        u64 qbefore = 0ull;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const i64 i = (i64)tid * 4 + k;
-            const u64 Qk = (i < a.nparts) ? smc_q62_w((ps4[k] * e4[k]) * r.rs) : 0ull;
-            if (i < b) qbefore += Qk;
-            if (i == b) sgq[1] = Qk;
-        }
-        Gb = smc_block_sum_u64(qbefore, smu);                  // (its barriers publish sgq[1])
-        Qb = sgq[1];
-    }
-    F_STAMP_A(4);
-    // ---- first offspring of each parent
-    i64 ns[F_IPT + 1];
-    f2_first_offspring(a, su, Us, q4, cex, tb, Gb, Qb, jt, ns);
-    if (tid == 0) sn[0] = ns[0];
-    if (tid == SMC_BLOCK - 1) sn[1] = ns[F_IPT];
-    __syncthreads();
-    const i64 n_lo = sn[0], n_hi = sn[1];
-    F_STAMP_A(5);
-    u32* A = f_A(a, t) + (i64)isl * N;
-    f_scatter_passes(a, isl, t, jt, j0, n_lo, n_hi, ns, sP, smx,
-                     [&](i64 n0, const bool (&ok)[4], const i64 (&a4)[4]) {                // core.py:329
-                         const u32 a32[4] = {(u32)a4[0], (u32)a4[1], (u32)a4[2], (u32)a4[3]};
-                         if (vec && ok[0] && ok[3]) {
-                             if (a.nt) smc_st4g_nt(A + n0, a32);
-                             else smc_st4g(A + n0, a32);
-                         } else {
-#pragma unroll
-                             for (int i = 0; i < 4; ++i)
-                                 if (ok[i]) smc_stg(A + n0 + i, a32[i]);
-                         }
-                     });
-    F_STAMP_A(6);
-}
-
-// ---------------------------------------------------------------------------
-// k_ancestors2, lean form (round 2).  Same contract, same bits as k_ancestors2_r1 above (tests
-// run both: SMC_ANC2_R1=1 selects the old one), about two thirds of its vector instructions and
-// a third of its barriers:
-//   * every block-wide exchange has its own LDS slots, so each costs ONE barrier, and exchanges
-//     that do not depend on each other share it (tile scan totals + maximum of the partials);
-//   * systematic: the first offspring of a parent is floor(Y - u) + 1 with the parent's position
-//     Y = (G_b + c Q_b / t_b) 2^-(62-k) in offspring units evaluated in fp64; the exact integer
-//     route (128-bit product, smc_muldiv_floor, then count()) is taken only when Y - u lies
-//     within eps = 16 N 2^-53 of an integer, ten times the worst-case error of the fp64
-//     evaluation (derivation at f2_ns_sys) -- probability 2^-28 per parent at N = 2^20;
-//   * the tile's first and one-past-last offspring come from the same function evaluated by
-//     every thread (uniform values), not from an LDS exchange;
-//   * ONE scatter pass over a window of 2048 offspring (8 KB of LDS, zeroed while the loads are
-//     in flight): a tile owns 1024 +- a few dozen offspring, which the 1024-wide window of r1
-//     split into two passes (4 barriers each) for every other tile.
-// ---------------------------------------------------------------------------
 struct F2Fast {
     double Gd, r, u, eps, one_m_eps, dN;
     u64 Gb, Qb, tb;
 };
 // First offspring of the parent at position c (0 <= c <= t_b) of tile b's local CDF, systematic,
 // N = 2^k: ns = count(C), C = G_b + floor(c Q_b / t_b), count(C) = #{n : fl(u + n) 2^sh <= C}
-// (sh = 62 - k).  With Y = C 2^-sh: ns = floor(Y - u) + 1 whenever Y - u is not within the
+// (sh = 52 - k).  With Y = C 2^-sh: ns = floor(Y - u) + 1 whenever Y - u is not within the
 // rounding errors of an integer.  fp64 evaluation z = fma((double)c, r, Gd) - u with
-// r = fl(fl(Q_b) / fl(t_b)) 2^-sh, Gd = fl(G_b) 2^-sh: |z - (Y - u)| <= (4 ulp on the product,
-// 1 on Gd, 1 on the fma, 1 on the subtraction, 1 for fl(u + n), 2^-9 for the floor in C) x N 2^-53
-// < 10 N 2^-53; the band is 16 N 2^-53.  Outside it the floor and the comparison are decided.
+// r = fl(Q_b / fl(t_b)) 2^-sh, Gd = G_b 2^-sh (exact): |z - (Y - u)| <= (3 ulp on the product,
+// 1 on the fma, 1 on the subtraction, 1 for fl(u + n), 2^-sh for the floor in C) x N 2^-53
+// < 8 N 2^-53; the band is 16 N 2^-53.  Outside it the floor and the comparison are decided;
+// inside (probability 2^-28 per parent at N = 2^20) the exact integer route is taken.
 __device__ __forceinline__ i64 f2_ns_sys(const FArgs& a, const SmcSu& su, const u64 Us, const F2Fast& f,
                                          const u64 c)
 {
@@ -1484,24 +1236,163 @@ __device__ __forceinline__ i64 f2_ns_sys(const FArgs& a, const SmcSu& su, const 
     }
     return f2_count(a, su, Us, f.Gb + smc_muldiv_floor(c, f.Qb, f.tb));
 }
+// first offspring ns[i] of the parents jt+i at positions cx[i] (cx[4]: the next thread's first
+// parent, t_b for the last thread), any scheme: fp64 quotient within 2^12 of the truth, count
+// decided unless the position lies within that band of a threshold, else formed exactly
+__device__ __forceinline__ void f2_first_offspring(const FArgs& a, const SmcSu& su, const u64 Us,
+                                                   const u64 (&cx)[F_IPT + 1], const u64 tb,
+                                                   const u64 Gb, const u64 Qb, const i64 jt,
+                                                   i64 (&ns)[F_IPT + 1])
+{
+    const i64 N = a.N;
+    const int kq = a.log2N + (62 - F2_SBITS);
+    const double qscale = (double)Qb / (double)(tb ? tb : 1ull);
+#pragma unroll
+    for (int i = 0; i <= F_IPT; ++i) {
+        const i64 j = jt + i;
+        const u64 c = cx[i];
+        if (j == 0) ns[i] = 0;
+        else if (j >= N) ns[i] = N;
+        else {
+            u64 qh = (u64)((double)c * qscale);
+            qh = qh > Qb ? Qb : qh;
+            i64 cnt = a.exact_counts ? -1
+                                     : smc_count_pow2_band(Gb + qh, 1ull << 13, su, su.u_sys, Us, kq, N);
+            if (cnt < 0) cnt = f2_count(a, su, Us, Gb + smc_muldiv_floor(c, Qb, tb));
+            ns[i] = cnt;
+        }
+    }
+}
 
-template <bool SPEC, bool MID>
+// the decision of step t and what k_propagate(t) reads (one thread)
+__device__ __forceinline__ void f2_write_record(const FArgs& a, const int isl, const i64 t, const F2Red& r,
+                                                const bool resample)
+{
+    double* info = a.info + (i64)isl * INFO_STRIDE;
+    f2_write_row(a, isl, t - 1, r);
+    a.summ[((i64)isl * (a.T + 1) + t) * SUMM_STRIDE + 4] = resample ? 1.0 : 0.0;
+    info[0] = (double)t;
+    info[1] = resample ? 1.0 : 0.0;
+    info[2] = a.y[t * a.dy];
+    info[3] = r.K;
+    info[4] = r.rs;
+    info[5] = a.aux ? a.aux[t] : 0.0;
+}
+// The island's reduction by ONE workgroup for any number of tiles, in chunks of 1024 partials
+// (thread tid: the four from 4*tid on of every chunk).  Up to 1024 tiles that is operation for
+// operation what every workgroup of k_ancestors2 does, hence the same bits.
+__device__ __forceinline__ F2Red f2_reduce_island(const FArgs& a, const int isl, double* smd)
+{
+    const i64 o = (i64)isl * a.nparts;
+    const bool pvec = (a.nparts & 3) == 0;
+    const int nchunks = (a.nparts + 4 * SMC_BLOCK - 1) / (4 * SMC_BLOCK);
+    F2Red r;
+    double tm = -INFINITY;
+    for (int c = 0; c < nchunks; ++c) {
+        double pm4[4];
+        f_load4<double>(a.pm + o, (i64)c * 4 * SMC_BLOCK + (i64)threadIdx.x * 4, a.nparts, pvec, -INFINITY, pm4);
+        tm = smc_max2(tm, smc_max2(smc_max2(pm4[0], pm4[1]), smc_max2(pm4[2], pm4[3])));
+    }
+    r.K = smc_block_max(tm, smd);
+    double s1 = 0.0, s2 = 0.0;
+    for (int c = 0; c < nchunks; ++c) {
+        const i64 i0 = (i64)c * 4 * SMC_BLOCK + (i64)threadIdx.x * 4;
+        double pm4[4], ps4[4], pss4[4];
+        f_load4<double>(a.pm + o, i0, a.nparts, pvec, -INFINITY, pm4);
+        f_load4<double>(a.ps + o, i0, a.nparts, pvec, 0.0, ps4);
+        f_load4<double>(a.pss + o, i0, a.nparts, pvec, 0.0, pss4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            double v, w;
+            f2_rescale(pm4[k], r.K, ps4[k], pss4[k], v, w);
+            s1 = s1 + v;
+            s2 = s2 + w;
+        }
+    }
+    smc_block_sum2(s1, s2, smd);
+    r.s = s1;
+    r.ss = s2;
+    f2_finish(a, r);
+    return r;
+}
+
+// k_reduce2(t): one workgroup per island reduces the partials of step t-1, decides step t,
+// writes the record, the summary row and every tile's (G_b, Q_b) (integer-valued doubles)
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_reduce2(const FArgs av)
+{
+    const FArgs& a = av;
+    __shared__ double smd[SMC_SM];
+    __shared__ double sme[SMC_SM];
+    const int isl = (int)blockIdx.x, tid = (int)threadIdx.x;
+    double* info = a.info + (i64)isl * INFO_STRIDE;
+    const i64 t = (i64)smc_uniform(smc_ldg(a.info2 + (i64)isl * INFO_STRIDE));
+    if (t >= a.T) {
+        if (tid == 0) info[0] = (double)t;
+        return;
+    }
+    if (t == 0) return;
+    const i64 o = (i64)isl * a.nparts;
+    const bool pvec = (a.nparts & 3) == 0;
+    const int nchunks = (a.nparts + 4 * SMC_BLOCK - 1) / (4 * SMC_BLOCK);
+    double* G = reinterpret_cast<double*>(a.Qpre) + (i64)isl * a.ntiles;
+    double* Q = reinterpret_cast<double*>(a.Q) + (i64)isl * a.ntiles;
+    const F2Red r = f2_reduce_island(a, isl, smd);
+    const bool resample = r.ess < a.ess_thresh;
+    if (tid == 0) f2_write_record(a, isl, t, r, resample);
+    if (!resample) return;
+    // every tile's share and the shares before it, chunk by chunk (a running carry across chunks)
+    double carry = 0.0;
+    for (int c = 0; c < nchunks; ++c) {
+        const i64 i0 = (i64)c * 4 * SMC_BLOCK + (i64)tid * 4;
+        double pm4[4], ps4[4];
+        f_load4<double>(a.pm + o, i0, a.nparts, pvec, -INFINITY, pm4);
+        f_load4<double>(a.ps + o, i0, a.nparts, pvec, 0.0, ps4);
+        double Q4[4], run = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            double v, w;
+            f2_rescale(pm4[k], r.K, ps4[k], 0.0, v, w);
+            Q4[k] = (i0 + k < a.nparts) ? f2_share(v, r.rs) : 0.0;
+            run += Q4[k];
+        }
+        double tot;
+        double g = carry + smc_block_exscan_f64(run, sme, tot);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (i0 + k < a.nparts) { G[i0 + k] = g; Q[i0 + k] = Q4[k]; g += Q4[k]; }
+        carry += tot;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_ancestors2(t): one workgroup per tile of 1024 parents.  No exp, no division per particle:
+//   * loads the tile's stored integer CDF c_j (k_propagate wrote it) and, unless k_reduce2 ran
+//     (MID), the island's partials: K, s, ss, ESS, decision, (G_b, Q_b) -- every exchange has
+//     its own LDS slots and costs ONE barrier;
+//   * systematic: the first offspring of a parent is floor(Y - u) + 1 with the parent's position
+//     Y = (G_b + c Q_b / t_b) 2^-(52-k) in offspring units evaluated in fp64, the exact integer
+//     route only inside the error band (f2_ns_sys); the tile's range [n_lo, n_hi) from the same
+//     function evaluated by every thread (uniform values) instead of an LDS exchange;
+//   * ONE scatter pass over a window of 2048 offspring (8 KB of LDS, zeroed while the loads are
+//     in flight): a tile owns 1024 +- a few dozen offspring.
+// MID: k_reduce2 ran first: grids too large for every workgroup to repeat the reduction.
+// ---------------------------------------------------------------------------
+template <bool MID>
 __global__ void __launch_bounds__(SMC_BLOCK)
 k_ancestors2(const FArgs av)
 {
     const FArgs& a = av;
     constexpr int WIN = 2 * F_PASS;                                        // offspring per pass
     __shared__ __attribute__((aligned(16))) u32 sP[WIN];
-    __shared__ u64 s_scan[SMC_NWAVE];                                      // one area per exchange
-    __shared__ double s_max[SMC_NWAVE];
+    __shared__ double s_max[SMC_NWAVE];                                    // one area per exchange
     __shared__ double s_sum[2 * SMC_NWAVE];
-    __shared__ u64 s_g[SMC_NWAVE + 1];
+    __shared__ double s_g[SMC_NWAVE + 1];
     __shared__ u32 s_mx[2 * SMC_NWAVE];
     const int b = (int)blockIdx.x, isl = (int)blockIdx.y;
     const int tid = (int)threadIdx.x;
     const int lane = smc_lane(), wave = smc_wave();
     const i64 N = a.N;
-    const bool vec = (N & 3) == 0;
     const i64 j0 = (i64)b * F_TILE;
     const i64 jt = j0 + (i64)tid * F_IPT;
     F_STAMP_A(0);
@@ -1509,15 +1400,19 @@ k_ancestors2(const FArgs av)
     const double r0 = smc_ldg(MID ? info : a.info2 + (i64)isl * INFO_STRIDE);
     const double r1 = MID ? smc_ldg(info + 1) : 0.0;
     const i64 o = (i64)isl * a.nparts;
-    double pm4[4], ps4[4], pss4[4], l4[4];
-    const double mb_raw = smc_ldg(a.pm + o + b);              // what the local CDF needs first
-    u64 Gmid = 0ull, Qmid = 0ull;
+    double pm4[4], ps4[4], pss4[4];
+    double Gmid = 0.0, Qmid = 0.0;
     if (MID) {
-        Gmid = smc_ldg(a.Qpre + (i64)isl * a.ntiles + b);
-        Qmid = smc_ldg(a.Q + (i64)isl * a.ntiles + b);
+        Gmid = smc_ldg(reinterpret_cast<const double*>(a.Qpre) + (i64)isl * a.ntiles + b);
+        Qmid = smc_ldg(reinterpret_cast<const double*>(a.Q) + (i64)isl * a.ntiles + b);
     }
-    if (SPEC)
-        f_load4<double>(a.lw + (i64)(a.par ^ 1) * a.lslot + (i64)isl * N, jt, N, vec, -INFINITY, l4);
+    // the tile's integer CDF: this thread's 4 positions and the next thread's first
+    const u64* cq = a.cq + (i64)isl * N;
+    u64 cx[F_IPT + 1];
+    smc_ld2g(cq + jt, cx[0], cx[1]);
+    smc_ld2g(cq + jt + 2, cx[2], cx[3]);
+    cx[4] = (tid < SMC_BLOCK - 1) ? smc_ldg(cq + jt + 4) : 0ull;
+    const u64 tb_raw = smc_ldg(a.tq + o + b);
     if (!MID) {
         const bool pvec = (a.nparts & 3) == 0;
         f_load4<double>(a.pm + o, (i64)tid * 4, a.nparts, pvec, -INFINITY, pm4);
@@ -1534,52 +1429,32 @@ k_ancestors2(const FArgs av)
     }
     if (t == 0) return;                                        // the host wrote the record of step 0
     if (MID && smc_uniform(r1) == 0.0) return;                 // k_reduce2: step t does not resample
-    if (!SPEC) f_load4<double>(f_lw(a, t - 1) + (i64)isl * N, jt, N, vec, -INFINITY, l4);
     F_STAMP_A(1);
     SmcSu su;                                                  // (the step's uniform: a Philox call
     u64 Us;                                                    //  in the shadow of the loads)
     f2_su(a, isl, t, su, Us);
-    // ---- the tile's own integer CDF, relative to the tile's maximum
-    const double mb = smc_uniform(mb_raw);
-    u64 q4[4], tsum = 0ull;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const double e = (l4[i] > -INFINITY) ? smc_exp_nonpos(l4[i] - mb) : 0.0;
-        q4[i] = (jt + i < N) ? (u64)rint(e * 1125899906842624.0) : 0ull;          // 2^50
-        tsum += q4[i];
-    }
-    const u64 inc = smc_wave_scan_add_u64(tsum);
-    if (lane == 63) s_scan[wave] = inc;
-    double tm = -INFINITY;
-    if (!MID) {                                                // ... and the maximum of the partials
-        tm = smc_max2(smc_max2(pm4[0], pm4[1]), smc_max2(pm4[2], pm4[3]));
+    double Gd, Qd;
+    if (MID) {
+        Gd = smc_uniform(Gmid);
+        Qd = smc_uniform(Qmid);
+        __syncthreads();                                       // sP zeroed
+    } else {
+        // ---- all partials -> K, (s, ss), ESS, the decision (f2_reduce_island's operations)
+        double tm = smc_max2(smc_max2(pm4[0], pm4[1]), smc_max2(pm4[2], pm4[3]));
         tm = smc_wave_max(tm);
         if (lane == 0) s_max[wave] = tm;
-    }
-    __syncthreads();                                           // (1) also: sP zeroed
-    u64 cex = inc - tsum, tb = 0ull;
-#pragma unroll
-    for (int w = 0; w < SMC_NWAVE; ++w) {
-        if (w < wave) cex += s_scan[w];
-        tb += s_scan[w];
-    }
-    F_STAMP_A(2);
-    u64 Gb, Qb;
-    if (MID) {
-        Gb = smc_uniform(Gmid);
-        Qb = smc_uniform(Qmid);
-    } else {
-        // ---- all partials -> (m, s), ESS, the decision (same operations and order as f2_reduce)
+        __syncthreads();                                       // (1) also: sP zeroed
         F2Red r;
-        r.m = s_max[0];
+        r.K = s_max[0];
 #pragma unroll
-        for (int w = 1; w < SMC_NWAVE; ++w) r.m = smc_max2(r.m, s_max[w]);
-        double e4[4], s1 = 0.0, s2 = 0.0;
+        for (int w = 1; w < SMC_NWAVE; ++w) r.K = smc_max2(r.K, s_max[w]);
+        double v4[4], s1 = 0.0, s2 = 0.0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            e4[k] = (pm4[k] > -INFINITY) ? smc_exp_nonpos(pm4[k] - r.m) : 0.0;
-            s1 = fma(ps4[k], e4[k], s1);
-            s2 = fma(pss4[k], e4[k] * e4[k], s2);
+            double w;
+            f2_rescale(pm4[k], r.K, ps4[k], pss4[k], v4[k], w);
+            s1 = s1 + v4[k];
+            s2 = s2 + w;
         }
         s1 = smc_wave_sum(s1);
         s2 = smc_wave_sum(s2);
@@ -1591,58 +1466,54 @@ k_ancestors2(const FArgs av)
         for (int w = 1; w < SMC_NWAVE; ++w) { s1 = s1 + s_sum[w]; s2 = s2 + s_sum[SMC_NWAVE + w]; }
         r.s = s1;
         r.ss = s2;
-        r.bad = !(r.m > -INFINITY) || !(r.m < INFINITY);
-        r.ess = r.bad ? NAN : (s1 * s1) / s2;                              // resampling.py:226
-        r.rs = r.bad ? NAN : 1.0 / s1;
+        f2_finish(a, r);
         const bool resample = r.ess < a.ess_thresh;            // core.py:181-183 (t < T here)
-        if (b == 0 && tid == 0) {
-            r.log_mean = r.bad ? NAN : r.m + log(s1 / (double)a.N);        // resampling.py:224
-            f2_write_record(a, isl, t, r, resample);
-        }
+        if (b == 0 && tid == 0) f2_write_record(a, isl, t, r, resample);
         F_STAMP_A(3);
         if (!resample) return;
-        // ---- this tile's share Q_b of the 2^62 scale and the shares before it, G_b
-        u64 qbefore = 0ull;
+        // ---- this tile's share Q_b of the 2^52 scale and the shares before it, G_b
+        double qbefore = 0.0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int i = tid * 4 + k;
-            const u64 Qk = (i < a.nparts) ? smc_q62_w((ps4[k] * e4[k]) * r.rs) : 0ull;
-            if (i < b) qbefore += Qk;
+            const double Qk = (i < a.nparts) ? f2_share(v4[k], r.rs) : 0.0;
+            qbefore += (i < b) ? Qk : 0.0;
             if (i == b) s_g[SMC_NWAVE] = Qk;
         }
-        qbefore = smc_wave_sum_u64(qbefore);
+        qbefore = smc_wave_sum(qbefore);                       // (integers below 2^53: exact)
         if (lane == 0) s_g[wave] = qbefore;
         __syncthreads();                                       // (3)
-        Gb = s_g[0];
+        Gd = s_g[0];
 #pragma unroll
-        for (int w = 1; w < SMC_NWAVE; ++w) Gb = Gb + s_g[w];
-        Qb = s_g[SMC_NWAVE];
+        for (int w = 1; w < SMC_NWAVE; ++w) Gd = Gd + s_g[w];
+        Qd = s_g[SMC_NWAVE];
     }
+    const u64 tb = smc_uniform_u64(tb_raw);
+    if (tid == SMC_BLOCK - 1) cx[4] = tb;
     F_STAMP_A(4);
     // ---- first offspring of each parent; the tile's range [n_lo, n_hi)
+    const u64 Gb = (u64)Gd, Qb = (u64)Qd;
     i64 ns[F_IPT + 1], n_lo, n_hi;
     if (a.scheme == SMC_SYSTEMATIC_) {
         F2Fast f;
-        const int sh = 62 - a.log2N;
+        const int sh = F2_SBITS - a.log2N;
         const double down = __longlong_as_double((long long)(1023 - sh) << 52);   // 2^-sh
         f.Gb = Gb; f.Qb = Qb; f.tb = tb;
-        f.Gd = (double)Gb * down;
-        f.r = tb ? ((double)Qb / (double)tb) * down : 0.0;
+        f.Gd = Gd * down;
+        f.r = tb ? (Qd / (double)tb) * down : 0.0;
         f.u = su.u_sys;
         f.dN = (double)N;
         f.eps = a.exact_counts ? 2.0 : f.dN * 0x1.0p-49;                 // (2.0: always the exact route)
         f.one_m_eps = 1.0 - f.eps;
-        u64 c = cex;
 #pragma unroll
         for (int i = 0; i <= F_IPT; ++i) {
             const i64 j = jt + i;
-            ns[i] = (j == 0) ? 0 : (j >= N ? N : f2_ns_sys(a, su, Us, f, c));
-            if (i < F_IPT) c += q4[i];
+            ns[i] = (j == 0) ? 0 : (j >= N ? N : f2_ns_sys(a, su, Us, f, cx[i]));
         }
         n_lo = (b == 0) ? 0 : f2_ns_sys(a, su, Us, f, 0ull);
         n_hi = (b == a.ntiles - 1) ? N : f2_ns_sys(a, su, Us, f, tb);
     } else {
-        f2_first_offspring(a, su, Us, q4, cex, tb, Gb, Qb, jt, ns);
+        f2_first_offspring(a, su, Us, cx, tb, Gb, Qb, jt, ns);
         __shared__ i64 s_n[2];
         if (tid == 0) s_n[0] = ns[0];
         if (tid == SMC_BLOCK - 1) s_n[1] = ns[F_IPT];
@@ -1723,7 +1594,7 @@ k_ancestors2(const FArgs av)
             const i64 n0 = pb + (i64)tid * 4;
             const u32 a32[4] = {(u32)j0 + (m0 > ex1 ? m0 : ex1), (u32)j0 + (m1 > ex1 ? m1 : ex1),
                                 (u32)j0 + (m2 > ex1 ? m2 : ex1), (u32)j0 + (m3 > ex1 ? m3 : ex1)};
-            if (vec && n0 >= n_lo && n0 + 3 < n_hi) {                                   // core.py:329
+            if (n0 >= n_lo && n0 + 3 < n_hi) {                                          // core.py:329
                 if (a.nt) smc_st4g_nt(A + n0, a32);
                 else smc_st4g(A + n0, a32);
             } else {
@@ -1736,7 +1607,7 @@ k_ancestors2(const FArgs av)
             const i64 n0 = pb + F_PASS + (i64)tid * 4;
             const u32 a32[4] = {(u32)j0 + (k0 > ex2 ? k0 : ex2), (u32)j0 + (k1 > ex2 ? k1 : ex2),
                                 (u32)j0 + (k2 > ex2 ? k2 : ex2), (u32)j0 + (k3 > ex2 ? k3 : ex2)};
-            if (vec && n0 + 3 < n_hi) {            // (n0 >= n_lo: the second half starts 1024 past it)
+            if (n0 + 3 < n_hi) {                   // (n0 >= n_lo: the second half starts 1024 past it)
                 if (a.nt) smc_st4g_nt(A + n0, a32);
                 else smc_st4g(A + n0, a32);
             } else {
@@ -1749,7 +1620,7 @@ k_ancestors2(const FArgs av)
     F_STAMP_A(6);
 }
 
-// the summary row of the last step done and the (m, 1/s) W is formed with: enqueued at the end
+// the summary row of the last step done and the (K, 1/s) W is formed with: enqueued at the end
 // of every smc_filter_step call of the two-level path (one workgroup per island; idempotent --
 // k_ancestors2 of the next step writes the same row again)
 __global__ void __launch_bounds__(SMC_BLOCK)
@@ -1767,7 +1638,7 @@ k_flush2(const FArgs av)
 // smc_filter_set_state: the log-weights of the current step were replaced from the host; the
 // per-tile partials k_propagate would have left (same device function, same bits) ...
 __global__ void __launch_bounds__(SMC_BLOCK)
-k_f_partials(const FArgs av, const i64 ts)
+k_f_partials(const FArgs av, const i64 ts, const int two_level)
 {
     const FArgs& a = av;
     __shared__ double smd[SMC_SM];
@@ -1775,10 +1646,20 @@ k_f_partials(const FArgs av, const i64 ts)
     const i64 N = a.N;
     const double* lwp = f_lw(a, ts) + (i64)isl * N;
     double lw[F_IPT];
-    f_load4<double>(lwp, ((i64)b * SMC_BLOCK + threadIdx.x) * F_IPT, N, (N & 3) == 0, -INFINITY, lw);
+    const i64 n0 = ((i64)b * SMC_BLOCK + threadIdx.x) * F_IPT;
+    f_load4<double>(lwp, n0, N, (N & 3) == 0, -INFINITY, lw);
+    const i64 o = (i64)isl * a.nparts;
+    if (two_level) {
+        u64 cx[4];
+        const F2Tile r = f2_tile_weights(lw, cx);
+        u64* cq = a.cq + (i64)isl * N + n0;
+        smc_st2g(cq, cx[0], cx[1]);
+        smc_st2g(cq + 2, cx[2], cx[3]);
+        if (threadIdx.x == 0) { a.pm[o + b] = r.K; a.ps[o + b] = r.S; a.pss[o + b] = r.SS; a.tq[o + b] = r.tb; }
+        return;
+    }
     const SmcLse r = f_tile_lse<F_IPT>(lw, smd);
     if (threadIdx.x == 0) {
-        const i64 o = (i64)isl * a.nparts;
         a.pm[o + b] = r.m;
         a.ps[o + b] = r.s;
         a.pss[o + b] = r.ss;
@@ -1802,11 +1683,21 @@ k_f_restate(const FArgs av, const i64 ts)
 
 // W = exp(lw - m)/s for one island (SMC.W)
 __global__ void __launch_bounds__(SMC_BLOCK)
-k_f_write_W(const double* lw, i64 N, const double* row, double* W)
+k_f_write_W(const double* lw, i64 N, const double* row, double* W, const int kform)
 {
-    const double m = row[5], rs = row[6];
+    const double m = row[5], rs = row[6];     // kform (two-level path): row[5] = K, W = p 2^(k - K) / s
     const i64 i = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;
-    if (i < N) W[i] = f_weight(lw[i], m, rs);
+    if (i >= N) return;
+    if (kform) {
+        double k;
+        double p = smc_expk(lw[i], k);
+        const bool ok = lw[i] > -INFINITY;
+        p = ok ? p : 0.0;
+        k = ok ? k : -INFINITY;
+        W[i] = smc_scale_pk(p, k, m) * rs;
+    } else {
+        W[i] = f_weight(lw[i], m, rs);
+    }
 }
 
 // one backward step of the genealogy (smoothing.py:209-219): B_{s-1} = A_s[B_s]

@@ -60,6 +60,33 @@ SMC_CONST double smc_k_sc[18] = {
     -1.3888888888888889e-03, 4.1666666666666664e-02,
     3.14159265358979311600e+00, 1.22464679914735317723e-16};
 
+// exp(x) = p 2^k without forming 2^k: k = round(x / ln 2) (returned as an integer-valued double),
+// p = P(x - k ln 2) in [0.7071, 1.4143].  The two-level CDF path carries weights as such pairs:
+// a tile's (or the island's) reference is then a power of two, and rescaling a sum of weights to
+// another reference is an exact ldexp instead of another exp (oracle.c orc_expk).
+// x = -inf gives k = -inf and p = NaN: callers select (p, k) = (0, -inf) for it.
+__host__ __device__ __forceinline__ double smc_expk(double x, double& k)
+{
+    const double* K = smc_k_exp;
+    k = rint(x * K[12]);
+    double r = fma(-k, K[13], x);                          // ln2 high part
+    r = fma(-k, K[14], r);                                 // ln2 low part
+    double p = K[0];
+#pragma unroll
+    for (int i = 1; i < 12; ++i) p = SMC_FMA_K(p, r, K[i]);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return p;
+}
+// p 2^(k - K), K >= k: the weight relative to the reference exponent K (0 for p = 0; the
+// exponent difference is clamped where the result is 0 anyway, and for -inf - -inf)
+__host__ __device__ __forceinline__ double smc_scale_pk(double p, double k, double K)
+{
+    double d = k - K;
+    d = (d > -2000.0) ? d : -2000.0;
+    return ldexp(p, (int)d);
+}
+
 __host__ __device__ __forceinline__ double smc_exp_nonpos(double x)
 {
     const double* K = smc_k_exp;
