@@ -189,9 +189,10 @@ double orc_toy_filter_philox(const double *y, int64_t T, int64_t N, double rho,
  *              IEEE operations; fma() is explicit, the file is built with -ffp-contract=off).
  *              Weights are carried as (p, k) pairs: no maximum is needed to form them.
  *   tile       1024 consecutive particles; K_b = max k_i, e_i = p_i 2^(k_i - K_b) (in [0, 1.42));
- *              partial (K_b, S_b, SS_b) = (K_b, sum e, sum e^2); summation tree: 4 consecutive
- *              elements left to right (e^2 by fma), then a balanced binary tree over 64 such
- *              groups, then 4 such blocks left to right
+ *              partial (K_b, S_b, SS_b) = (K_b, sum e, sum e^2); summation tree: within each
+ *              group of 256 consecutive particles slot l of 64 takes the elements 2l, 2l+1,
+ *              128+2l, 129+2l in this order (e^2 by fma); a balanced binary tree over the 64
+ *              slots; the 4 groups left to right
  *   island     K = max K_b; s = sum S_b 2^(K_b - K), ss = sum SS_b 2^(2 (K_b - K)) (exact
  *              scalings): per slot i of 256 the tiles 4i..4i+3 (and + 1024 c for every further
  *              chunk c) left to right, then the same 64-tree / 4-blocks order
@@ -287,12 +288,15 @@ void orc_tile_partials(const double *lw, int64_t N, double *pK, double *ps, doub
         double s1[256], s2[256];
         for (int th = 0; th < 256; ++th) {
             double a = 0.0, qq = 0.0;
+            /* slot th holds the pairs (2l, 2l+1) and (128+2l, 128+2l+1) of its group of 256 */
+            const int g0 = (th & ~63) * 4 + 2 * (th & 63);
+            const int idx[4] = {g0, g0 + 1, g0 + 128, g0 + 129};
             for (int c = 0; c < 4; ++c) {
-                const double e = scale_pk(p[4 * th + c], k[4 * th + c], K);
+                const double e = scale_pk(p[idx[c]], k[idx[c]], K);
                 a += e;
                 qq = fma(e, e, qq);
-                if (q && b * 1024 + 4 * th + c < N)
-                    q[b * 1024 + 4 * th + c] = (uint64_t)rint(e * 562949953421312.0);   /* 2^49 */
+                if (q && b * 1024 + idx[c] < N)
+                    q[b * 1024 + idx[c]] = (uint64_t)rint(e * 562949953421312.0);   /* 2^49 */
             }
             s1[th] = a;
             s2[th] = qq;

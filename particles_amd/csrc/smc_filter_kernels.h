@@ -832,24 +832,6 @@ __device__ __forceinline__ void f_step_tail(const FArgs& a, const int isl, const
 // thread.  x = loc(X_{t-1}[A]) + scale z, weight increment, log-weights, online
 // log-sum-exp partial; the last workgroup of the island finalises the step.
 // ---------------------------------------------------------------------------
-// OPT consecutive ancestor indices (32-bit in memory), 16-byte loads when aligned
-template <int OPT>
-__device__ __forceinline__ void f_load_anc(const u32* A, i64 n0, i64 N, bool full, i64 (&an)[OPT])
-{
-    if (full && OPT % 4 == 0) {
-#pragma unroll
-        for (int k = 0; k < OPT; k += 4) {
-            u32 v[4];
-            smc_ld4g(A + n0 + k, v);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) an[k + i] = (i64)v[i];
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < OPT; ++k) an[k] = (n0 + k < N) ? (i64)smc_ldg(A + n0 + k) : 0;
-    }
-}
-
 // ---- two-level CDF path (contract: see "Two-level CDF" below): what k_propagate leaves per tile
 #define F2_QBITS 49                     /* local CDF: q_i = rint(e_i 2^49), t_b < 2^60 */
 #define F2_SBITS 52                     /* shares: Q_b = rint(W_b 2^52) */
@@ -861,10 +843,10 @@ struct F2Tile {
     double K, S, SS;
     u64 tb;
 };
-// The tile's partial and integer CDF from the 4 log-weights each thread holds; cx: the
-// exclusive CDF positions of this thread's particles.  Two barriers; all threads get the result.
-// Association order of S, SS: the thread's 4 values left to right, a balanced tree over the 64
-// lanes, the 4 waves left to right (oracle.c orc_tile_partials).
+// The tile's partial and integer CDF from the 4 log-weights each thread holds (ownership: f_own);
+// cx: the exclusive CDF positions of this thread's particles.  Two barriers; all threads get the
+// result.  Association order of S, SS: the thread's 4 values in slot order, a balanced tree over
+// the 64 lanes, the 4 waves left to right (oracle.c orc_tile_partials).
 __device__ __forceinline__ F2Tile f2_tile_weights(const double (&lw)[4], u64 (&cx)[4])
 {
     __shared__ double s_k[SMC_NWAVE];
@@ -888,34 +870,35 @@ __device__ __forceinline__ F2Tile f2_tile_weights(const double (&lw)[4], u64 (&c
 #pragma unroll
     for (int w = 1; w < SMC_NWAVE; ++w) r.K = smc_max2(r.K, s_k[w]);
     double s1 = 0.0, s2 = 0.0;
-    u64 q[4], ts = 0ull;
+    u64 q[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const double e = smc_scale_pk(p[i], k[i], r.K);
         s1 += e;
         s2 = fma(e, e, s2);
         q[i] = (u64)rint(e * 562949953421312.0);                       // 2^49
-        ts += q[i];
     }
     s1 = smc_wave_sum(s1);
     s2 = smc_wave_sum(s2);
-    const u64 inc = smc_wave_scan_add_u64(ts);
-    if (lane == 0) { s_s[wave] = s1; s_s[SMC_NWAVE + wave] = s2; }
-    if (lane == 63) s_c[wave] = inc;
+    // the thread's pairs are 128 particles apart (f_own): the wave's first pairs come first
+    const u64 sa = q[0] + q[1], sb = q[2] + q[3];
+    const u64 incA = smc_wave_scan_add_u64(sa), incB = smc_wave_scan_add_u64(sb);
+    const u64 totA = smc_readlane64(incA, 63), totB = smc_readlane64(incB, 63);
+    if (lane == 0) { s_s[wave] = s1; s_s[SMC_NWAVE + wave] = s2; s_c[wave] = totA + totB; }
     __syncthreads();
     r.S = s_s[0];
     r.SS = s_s[SMC_NWAVE];
-    u64 c = inc - ts;
+    u64 base = 0ull;
     r.tb = 0ull;
 #pragma unroll
     for (int w = 0; w < SMC_NWAVE; ++w) {
         if (w > 0) { r.S = r.S + s_s[w]; r.SS = r.SS + s_s[SMC_NWAVE + w]; }
-        if (w < wave) c += s_c[w];
+        if (w < wave) base += s_c[w];
         r.tb += s_c[w];
     }
-    cx[0] = c;
-    cx[1] = c + q[0];
-    cx[2] = cx[1] + q[1];
+    cx[0] = base + incA - sa;
+    cx[1] = cx[0] + q[0];
+    cx[2] = base + totA + incB - sb;
     cx[3] = cx[2] + q[2];
     return r;
 }
@@ -944,10 +927,42 @@ __device__ __forceinline__ SmcLse f_tile_lse(const double (&lw)[OPT], double* sm
     return r;
 }
 
+// Which 4 new particles a thread of k_propagate owns: the pairs (na, na+1) and (nb, nb+1) with
+// na = first of the wave's span of 256 + 2 lane, nb = na + 128 -- so that each 16-byte access of
+// the wave (64 lanes x 16 B) covers 1 KB of CONTIGUOUS memory.  With 4 consecutive particles per
+// thread a store instruction wrote every other 16 bytes: harmless for plain stores (the halves
+// merge in the L2), but streaming (`nt`) stores left the L2 as half lines and WRITE_SIZE was
+// 1.7x the bytes stored (profiles/r01n, r02b).  Slot k of a thread: k = 0, 1 the first pair,
+// 2, 3 the second.
+struct FOwn {
+    i64 na, nb;
+    bool full;             // the wave's whole span lies inside N (wave-uniform)
+};
+// PAIRS = false: 4 consecutive particles per thread (the flat-CDF path keeps it: its one-launch
+// twin k_filter_small holds 4 consecutive particles per thread and promises the same bits)
+template <bool PAIRS>
+__device__ __forceinline__ FOwn f_own(const int b, const int tid, const i64 N)
+{
+    FOwn o;
+    if (PAIRS) {
+        const i64 wb = ((i64)b * SMC_BLOCK + (tid & ~63)) * 4;
+        o.na = wb + 2 * (tid & 63);
+        o.nb = o.na + 128;
+        o.full = (N & 1) == 0 && wb + 256 <= N;
+    } else {
+        o.na = ((i64)b * SMC_BLOCK + tid) * 4;
+        o.nb = o.na + 2;
+        o.full = (N & 3) == 0 && o.na + 4 <= N;
+    }
+    return o;
+}
+__device__ __forceinline__ i64 f_own_idx(const FOwn& o, const int k) { return (k < 2 ? o.na : o.nb) + (k & 1); }
+
 template <int KIND, int FK, int OPT, bool SPEC, bool TAIL = true>
 __global__ void __launch_bounds__(SMC_BLOCK)
 k_propagate(const FArgs av)
 {
+    static_assert(OPT == 4, "two pairs per thread");
     const FArgs& a = av;
     __shared__ double smd[SMC_SM];
     __shared__ int s_last;
@@ -956,9 +971,8 @@ k_propagate(const FArgs av)
     F_STAMP(0);
     double* info = a.info + (i64)isl * INFO_STRIDE;
     const i64 N = a.N;
-    const bool vec = (N % OPT) == 0;          // every island base then is 8*OPT-byte aligned
-    const i64 n0 = ((i64)b * SMC_BLOCK + tid) * OPT;
-    const bool full = vec && n0 + OPT <= N;
+    const FOwn own = f_own<!TAIL>(b, tid, N);
+    const bool full = own.full;
     const double r0 = smc_ldg(info), r1 = smc_ldg(info + 1), r2 = smc_ldg(info + 2),
                  r5 = smc_ldg(info + 5);
     unsigned nh0 = 0u, nh1 = 0u;                   // registered heavy parents, either parity of t
@@ -966,13 +980,22 @@ k_propagate(const FArgs av)
     // SPEC: slots from a.par (kernarg): the ancestor indices are requested right behind the
     // step record, and the gather X_{t-1}[A] can leave as soon as they are back -- without
     // waiting for the record (read in vain on the steps that do not resample)
-    i64 an[OPT];
-    if (SPEC && n0 < N) {
-        const u32* As = a.A + (i64)isl * N;
-        f_load_anc<OPT>(As, n0, N, full, an);
-    }
+    u32 an[OPT] = {0u, 0u, 0u, 0u};
+    auto load_anc = [&](const u32* Ap) {
+        if (full) {
+            smc_ld2g(Ap + own.na, an[0], an[1]);
+            smc_ld2g(Ap + own.nb, an[2], an[3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < OPT; ++k) {
+                const i64 n = f_own_idx(own, k);
+                an[k] = (n < N) ? smc_ldg(Ap + n) : 0u;
+            }
+        }
+    };
+    if (SPEC && own.na < N) load_anc(a.A + (i64)isl * N);
     double xg[OPT];
-    if (SPEC && n0 < N) {          // A always holds valid indices (zeros before the first resampling)
+    if (SPEC && own.na < N) {      // A always holds valid indices (zeros before the first resampling)
         const double* Xs = a.X + (i64)(a.par ^ 1) * a.xslot + (i64)isl * N;
 #pragma unroll
         for (int k = 0; k < OPT; ++k) xg[k] = smc_ldg(Xs + an[k]);
@@ -1009,24 +1032,24 @@ k_propagate(const FArgs av)
     double lw[OPT];
 #pragma unroll
     for (int k = 0; k < OPT; ++k) lw[k] = -INFINITY;
-    if (n0 < N) {
+    if (own.na < N) {
         double xp[OPT], lwp[OPT], z[OPT];
         // ---- ancestor indices (when resampled) or the particle's own state and
         // log-weight: requested first, consumed after the normals are generated
         if (resample && !SPEC) {
-            f_load_anc<OPT>(A, n0, N, full, an);
+            load_anc(A);
         } else if (!first && !resample) {
             if (full) {
-#pragma unroll
-                for (int k = 0; k < OPT; k += 2) {
-                    smc_ld2g(Xo + n0 + k, xp[k], xp[k + 1]);
-                    smc_ld2g(lwo + n0 + k, lwp[k], lwp[k + 1]);
-                }
+                smc_ld2g(Xo + own.na, xp[0], xp[1]);
+                smc_ld2g(lwo + own.na, lwp[0], lwp[1]);
+                smc_ld2g(Xo + own.nb, xp[2], xp[3]);
+                smc_ld2g(lwo + own.nb, lwp[2], lwp[3]);
             } else {
 #pragma unroll
                 for (int k = 0; k < OPT; ++k) {
-                    xp[k] = (n0 + k < N) ? smc_ldg(Xo + n0 + k) : 0.0;
-                    lwp[k] = (n0 + k < N) ? smc_ldg(lwo + n0 + k) : 0.0;
+                    const i64 n = f_own_idx(own, k);
+                    xp[k] = (n < N) ? smc_ldg(Xo + n) : 0.0;
+                    lwp[k] = (n < N) ? smc_ldg(lwo + n) : 0.0;
                 }
             }
         } else {
@@ -1036,21 +1059,23 @@ k_propagate(const FArgs av)
         // ---- standard normals: one Philox call per (even, odd) pair, or the tape
         if (zt) {
 #pragma unroll
-            for (int k = 0; k < OPT; ++k) z[k] = (n0 + k < N) ? smc_ldg(zt + n0 + k) : 0.0;
+            for (int k = 0; k < OPT; ++k) {
+                const i64 n = f_own_idx(own, k);
+                z[k] = (n < N) ? smc_ldg(zt + n) : 0.0;
+            }
         } else {
-#pragma unroll
-            for (int k = 0; k < OPT; k += 2)
-                smc_normal_pair(a.seed, (u32)((n0 + k) >> 1), (u32)t, gisl, SMC_STREAM_NORMAL,
-                                z[k], z[k + 1]);
+            smc_normal_pair(a.seed, (u32)(own.na >> 1), (u32)t, gisl, SMC_STREAM_NORMAL, z[0], z[1]);
+            smc_normal_pair(a.seed, (u32)(own.nb >> 1), (u32)t, gisl, SMC_STREAM_NORMAL, z[2], z[3]);
         }
         if (resample && heavy_parent >= 0) {
             const double xh = smc_ldg(Xo + heavy_parent);
             u32* Aw = f_A(a, t) + (i64)isl * N;
 #pragma unroll
             for (int k = 0; k < OPT; ++k) {
+                const i64 n = f_own_idx(own, k);
                 xp[k] = xh;
                 lwp[k] = 0.0;
-                if (n0 + k < N) Aw[n0 + k] = (u32)heavy_parent;
+                if (n < N) Aw[n] = (u32)heavy_parent;
             }
         } else if (resample) {
 #pragma unroll
@@ -1064,42 +1089,42 @@ k_propagate(const FArgs av)
             xn[k] = m_step<KIND, FK>(p, first, yt, aux, xp[k], z[k], inc);
             double l = (resample || first) ? inc : lwp[k] + inc;          // resampling.py:241-244
             if (l != l) l = -INFINITY;                                     // resampling.py:220
-            lw[k] = (n0 + k < N) ? l : -INFINITY;
+            lw[k] = (f_own_idx(own, k) < N) ? l : -INFINITY;
         }
         if (full) {
-#pragma unroll
-            for (int k = 0; k < OPT; k += 2) {
-                if (a.nt) {
-                    smc_st2g_nt(Xn + n0 + k, xn[k], xn[k + 1]);
-                    smc_st2g_nt(lwn + n0 + k, lw[k], lw[k + 1]);
-                } else {
-                    smc_st2g(Xn + n0 + k, xn[k], xn[k + 1]);
-                    smc_st2g(lwn + n0 + k, lw[k], lw[k + 1]);
-                }
+            if (a.nt) {
+                smc_st2g_nt(Xn + own.na, xn[0], xn[1]);
+                smc_st2g_nt(Xn + own.nb, xn[2], xn[3]);
+                smc_st2g_nt(lwn + own.na, lw[0], lw[1]);
+                smc_st2g_nt(lwn + own.nb, lw[2], lw[3]);
+            } else {
+                smc_st2g(Xn + own.na, xn[0], xn[1]);
+                smc_st2g(Xn + own.nb, xn[2], xn[3]);
+                smc_st2g(lwn + own.na, lw[0], lw[1]);
+                smc_st2g(lwn + own.nb, lw[2], lw[3]);
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < OPT; ++k)
-                if (n0 + k < N) { smc_stg(Xn + n0 + k, xn[k]); smc_stg(lwn + n0 + k, lw[k]); }
+            for (int k = 0; k < OPT; ++k) {
+                const i64 n = f_own_idx(own, k);
+                if (n < N) { smc_stg(Xn + n, xn[k]); smc_stg(lwn + n, lw[k]); }
+            }
         }
     }
-    // ---- the workgroup's (max, sum e, sum e^2): max first, then ONE exp per particle
-    // against the workgroup's max (no per-thread rescaling, no branches)
     F_STAMP(3);
     if (TAIL) {
+        // ---- the workgroup's (max, sum e, sum e^2); its last arriver finalises the step
         const SmcLse r = f_tile_lse<OPT>(lw, smd);
         f_step_tail(a, isl, b, t, first, resample, r, smd, s_last, info);
     } else {
         // two-level path: the tile's partial and its integer CDF are all this launch owes;
         // k_ancestors2(t+1) -- every workgroup of it -- reduces the partials, so nobody waits for
-        // a last workgroup here
-        static_assert(TAIL || OPT == 4, "the two-level path works on tiles of 256 x 4 particles");
+        // a last workgroup here (N = 2^k >= 2048: every tile is full)
         u64 cx[4];
-        const double (&lw4)[4] = reinterpret_cast<const double (&)[4]>(lw);
-        const F2Tile r = f2_tile_weights(lw4, cx);
-        u64* cq = a.cq + (i64)isl * N + n0;
-        if (a.nt) { smc_st2g_nt(cq, cx[0], cx[1]); smc_st2g_nt(cq + 2, cx[2], cx[3]); }
-        else { smc_st2g(cq, cx[0], cx[1]); smc_st2g(cq + 2, cx[2], cx[3]); }
+        const F2Tile r = f2_tile_weights(lw, cx);
+        u64* cq = a.cq + (i64)isl * N;
+        if (a.nt) { smc_st2g_nt(cq + own.na, cx[0], cx[1]); smc_st2g_nt(cq + own.nb, cx[2], cx[3]); }
+        else { smc_st2g(cq + own.na, cx[0], cx[1]); smc_st2g(cq + own.nb, cx[2], cx[3]); }
         if (tid == 0) {
             const i64 o = (i64)isl * a.nparts;
             a.pm[o + b] = r.K;
@@ -1646,15 +1671,19 @@ k_f_partials(const FArgs av, const i64 ts, const int two_level)
     const i64 N = a.N;
     const double* lwp = f_lw(a, ts) + (i64)isl * N;
     double lw[F_IPT];
-    const i64 n0 = ((i64)b * SMC_BLOCK + threadIdx.x) * F_IPT;
-    f_load4<double>(lwp, n0, N, (N & 3) == 0, -INFINITY, lw);
+    const FOwn own = two_level ? f_own<true>(b, (int)threadIdx.x, N) : f_own<false>(b, (int)threadIdx.x, N);
+#pragma unroll
+    for (int k = 0; k < F_IPT; ++k) {
+        const i64 n = f_own_idx(own, k);
+        lw[k] = (n < N) ? smc_ldg(lwp + n) : -INFINITY;
+    }
     const i64 o = (i64)isl * a.nparts;
     if (two_level) {
         u64 cx[4];
         const F2Tile r = f2_tile_weights(lw, cx);
-        u64* cq = a.cq + (i64)isl * N + n0;
-        smc_st2g(cq, cx[0], cx[1]);
-        smc_st2g(cq + 2, cx[2], cx[3]);
+        u64* cq = a.cq + (i64)isl * N;
+        smc_st2g(cq + own.na, cx[0], cx[1]);
+        smc_st2g(cq + own.nb, cx[2], cx[3]);
         if (threadIdx.x == 0) { a.pm[o + b] = r.K; a.ps[o + b] = r.S; a.pss[o + b] = r.SS; a.tq[o + b] = r.tb; }
         return;
     }
