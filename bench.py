@@ -285,8 +285,12 @@ def main():
             # whichever takes longer, the other one is listed beside it
             rs_name = "+".join(k for k in kernels.split("+") if not k.startswith("k_propagate"))
             mv_name = [k for k in kernels.split("+") if k.startswith("k_propagate")][0]
+            # two-level path: k_propagate also writes the tile CDF (8 B), k_ancestors2 reads it
+            # instead of the log-weights: 16 d + 24 and 16 B; flat path: 16 d + 16 and 16 (+ 8) B;
+            # either way SURVEY 8d's 16 d + 40 B per particle-step in all
+            two = "k_ancestors2" in kernels
             rs_bytes = (BYTES_PREPARE + (8.0 if "k_prepare" in kernels else 0.0)) * N * a.islands
-            mv_bytes = bytes_move * N * a.islands
+            mv_bytes = (bytes_move + (8.0 if two else 0.0)) * N * a.islands
             rs_ms = pr.value
             per = {mv_name: {"ms": mv.value, "launch_bytes": mv_bytes,
                              "achieved": mv_bytes / (mv.value * 1e-3) / 1e9},
@@ -305,9 +309,10 @@ def main():
                 "step_frac": out["step_achieved_GBs"] / HBM_PEAK_GBS,
                 "note": "algorithmic bytes in SURVEY 8d's accounting (int64 ancestors; they are stored as "
                         "32-bit words, so the kernels physically move 4 B less per particle each). "
-                        "Per particle-step: k_propagate 32 B (read A, gather X; write X, lw), "
-                        "k_ancestors / k_ancestors2 16 B (read lw, write A; + 8 B for k_prepare's pass over "
-                        "lw beyond 2048 workgroups per launch). Both parts are measured with HIP events on "
+                        "Per particle-step, two-level path: k_propagate 16 d + 24 B (read A, gather X; write X, "
+                        "lw and the tile's integer CDF), k_ancestors2 16 B (read that CDF, write A); flat path: "
+                        "k_propagate 16 d + 16 B, k_ancestors 16 B (read lw, write A; + 8 B for k_prepare's pass "
+                        "over lw beyond 2048 workgroups per launch): 16 d + 40 B in all. Both parts are measured with HIP events on "
                         "the filter's stream in a separate pass over the same workload: steps are sampled "
                         "in three kinds (whole step / up to the propagate launch / from there on), "
                         "propagate = whole - first part, resampling = whole - second part, so the fixed "

@@ -379,3 +379,57 @@ def test_smc2_example():
     spec.loader.exec_module(mod)
     mean, sd = mod.main(T=60, Ntheta=128, Nx=256)
     assert np.isfinite(mean) and np.isfinite(sd) and abs(mean - 0.3) < 0.15
+
+
+RCCL_WORKER = r"""
+import os, sys, json
+sys.path.insert(0, {root!r})
+import numpy as np
+from particles_amd.distributed import Group
+grp = Group(device_collective=True)
+v = grp.gather_evidence(np.array([1.5 + grp.rank, -2.0 * grp.rank]))
+if grp.rank == 0:
+    print("RESULT " + json.dumps({{"v": v.tolist(), "path": grp.evidence_path}}))
+grp.close()
+"""
+
+
+def _run_ranks(world, tmp_path, extra_env):
+    import json, os, socket, subprocess, sys
+    from conftest import ROOT
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER.format(root=ROOT))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SMC_HIP_DEVICE="0", **extra_env)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    return procs, outs, json
+
+
+def test_rccl_gather_one_rank(tmp_path):
+    """The RCCL branch executes for real: world size 1 -- ncclGetUniqueId, ncclCommInitRank with
+    the 128-byte id passed by value, ncclAllGather of ncclDouble on the filter's stream."""
+    procs, outs, json = _run_ranks(1, tmp_path, {})
+    assert procs[0].returncode == 0, outs[0]
+    res = json.loads([l for l in outs[0].splitlines() if l.startswith("RESULT ")][0][7:])
+    assert res["path"] == "rccl" and res["v"] == [1.5, -0.0]
+
+
+def test_rccl_two_ranks_one_gpu(tmp_path):
+    """Two ranks on the ONE GPU of this box: the unique id travels over the TCP rendezvous,
+    both ranks call ncclCommInitRank -- RCCL either accepts (then the all-gather must be right)
+    or refuses two ranks on one device; the refusal must surface as an error (no silent
+    fallback), and with SMC_ALLOW_HOST_GATHER=1 as a labelled host fallback with the right values."""
+    procs, outs, json = _run_ranks(2, tmp_path, {"SMC_ALLOW_HOST_GATHER": "1"})
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    res = json.loads([l for l in outs[0].splitlines() if l.startswith("RESULT ")][0][7:])
+    assert res["v"] == [1.5, -0.0, 2.5, -2.0]
+    assert res["path"] == "rccl" or res["path"].startswith("host-fallback: ")
+    if res["path"] != "rccl":
+        procs, outs, json = _run_ranks(2, tmp_path, {})
+        assert all(p.returncode != 0 for p in procs)               # no opt-in: loud failure
+        assert "RCCL evidence gather unavailable" in "".join(outs)
