@@ -143,6 +143,8 @@ def main():
                     help="repetitions of the K-step timed region (0: about 10^4 timed steps in all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--collapsed", action="store_true",
+                    help="c4: the collapsed form of the optimal proposal's weight (SMC_FLAG_COLLAPSED_PROPOSAL)")
     ap.add_argument("--graph", action="store_true", help="replay the steps from hipGraphs (default: eager launches)")
     a = ap.parse_args()
 
@@ -193,7 +195,7 @@ def main():
             x = (model.F @ x if t else np.zeros(d)) + rng.standard_normal(d)
             y.append((x + rng.standard_normal(d)).reshape(1, d))
         fk = ssm.GuidedPF(ssm=model, data=y)
-        wl = "C4: MVLinearGauss_Guarniero d=32 guided filter"
+        wl = "C4: MVLinearGauss_Guarniero d=32 guided filter" + (" (collapsed proposal weight)" if a.collapsed else "")
     else:
         if a.workload == "c5":    # one GPU's share of 256 islands x 2^18
             a.log2N, a.islands = 18, 32
@@ -209,7 +211,7 @@ def main():
     def make(profile=False):
         pf = pa.SMC(fk=fk, N=N, resampling=a.scheme, ESSrmin=a.essrmin, collect="off", seed=123,
                     n_islands=a.islands, island_offset=rank * a.islands,
-                    use_graph=a.graph and not profile)
+                    use_graph=a.graph and not profile, collapsed_proposal=a.collapsed)
         if profile:
             _lib.check(_lib.lib().smc_filter_profile(pf._f, 1))
         return pf
@@ -323,7 +325,7 @@ def main():
                 # GEMM-shaped kernel: priced against the dense fp64 matrix peak (MI355X spec
                 # 78.6 TFLOP/s, = its fp64 vector peak).  72 MFMAs
                 # (v_mfma_f64_16x16x4: 2048 flop) per 16 particles for the guided d=32 step.
-                flop = 72 * 2048.0 / 16.0 * N * a.islands
+                flop = (44 if a.collapsed else 72) * 2048.0 / 16.0 * N * a.islands
                 tf = flop / (mv.value * 1e-3) / 1e12
                 out["roofline"].update({
                     "bound": "mfma", "achieved": tf, "peak": 78.6, "unit": "TFLOP/s",

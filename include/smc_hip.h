@@ -285,8 +285,14 @@ typedef struct smc_filter_opts {
     int32_t moments;          /* 1: the Moments collector on the device (collectors.py:301-317 with
                                * rs.wmean_and_var): weighted mean and variance of every component of
                                * X_t after every step, no host round trip (smc_filter_moments) */
-    int32_t reserved;
+    int32_t flags;            /* SMC_FLAG_* */
 } smc_filter_opts;
+/* MVLINGAUSS guided filter: evaluate the weight of the model's optimal proposal in its collapsed
+ * form log G_t = log p(y_t | x_{t-1}) = log N(y_t; G F x_{t-1}, G covX G' + covY) (the three
+ * terms of state_space_models.py:380-392 cancel to it analytically; S is the innovation
+ * covariance of kalman.py:215-229) -- 44 instead of 72 matrix instructions per 16 particles.
+ * Same particles; log-weights equal up to rounding, hence opt-in. */
+#define SMC_FLAG_COLLAPSED_PROPOSAL 1
 
 /* y_host: data, (T, dy) row-major, shared by all islands. */
 int smc_filter_create(smc_ctx* ctx, const smc_model* model,

@@ -43,7 +43,10 @@ class SmcFilterOpts(ctypes.Structure):
                 ("scheme", ctypes.c_int32), ("ESSrmin", c_dbl), ("seed", c_u64),
                 ("rng_mode", ctypes.c_int32), ("use_graph", ctypes.c_int32),
                 ("island_offset", ctypes.c_int32), ("keep_history", ctypes.c_int32),
-                ("moments", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("moments", ctypes.c_int32), ("flags", ctypes.c_int32)]
+
+
+FLAG_COLLAPSED_PROPOSAL = 1
 
 
 # name -> (restype, argtypes): every symbol include/smc_hip.h declares

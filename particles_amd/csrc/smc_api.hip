@@ -45,6 +45,13 @@ int smc_ctx_create(int device, uint64_t seed, smc_ctx** out)
         return SMC_ERR_INVALID;
     }
     SMC_HIP_CHECK(hipSetDevice(device));
+#ifndef SMC_EMULATE
+    // host threads waiting on the stream spin instead of sleeping: a filter's step loop is read
+    // back in units of a few hundred microseconds and a sleeping waiter adds tens of them
+    // (SMC_SYNC_YIELD=1 restores the runtime's default)
+    if (!getenv("SMC_SYNC_YIELD")) (void)hipSetDeviceFlags(hipDeviceScheduleSpin);
+    (void)hipGetLastError();
+#endif
     smc_ctx* c = new smc_ctx();
     c->device = device;
     c->seed = seed;

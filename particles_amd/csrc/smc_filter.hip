@@ -22,6 +22,7 @@ struct smc_filter {
     bool fused;            // k_ancestors<true> (no k_prepare launch)
     bool two_level;        // k_ancestors2 + tail-free k_propagate (two-level CDF, no intra-launch exchange)
     bool two_level_mid;    // ... with k_reduce2 in front (grids too large for every workgroup to reduce)
+    bool mv_collapsed;     // MVLINGAUSS guided: log G = log p(y_t | x_{t-1}) in one product (opts.flags)
     i64 perm_t;            // t_host at the last smc_filter_permute_islands (A / Xp undefined there)
     hipGraphExec_t gexec[3];   // captured step sequences of F_GRAPH_SIZES steps (even: see enqueue_step)
     bool graph_failed;
@@ -41,18 +42,19 @@ static void launch_propagate(smc_filter* f)
     hipStream_t st = f->ctx->stream;
     const dim3 grid(f->a.nparts, f->a.n_islands);
     if (f->kind == SMC_MODEL_MVLINGAUSS) {
-#define MV_CASE(FKV, DPV)                                                                   \
-    if (f->fk == FKV && f->a.dp == DPV) {                                                   \
+#define MV_CASE(FKV, DPV, COLLV)                                                            \
+    if (f->fk == FKV && f->a.dp == DPV && f->mv_collapsed == COLLV) {                       \
         if (f->a.dx == DPV)                                                                 \
-            SMC_LAUNCH((k_propagate_mv<FKV, DPV, true>), grid, dim3(SMC_BLOCK), st, f->a,  \
-                       f->a.mvc);                                                           \
+            SMC_LAUNCH((k_propagate_mv<FKV, DPV, true, COLLV>), grid, dim3(SMC_BLOCK), st,  \
+                       f->a, f->a.mvc);                                                     \
         else                                                                                \
-            SMC_LAUNCH((k_propagate_mv<FKV, DPV, false>), grid, dim3(SMC_BLOCK), st, f->a, \
-                       f->a.mvc);                                                           \
+            SMC_LAUNCH((k_propagate_mv<FKV, DPV, false, COLLV>), grid, dim3(SMC_BLOCK), st, \
+                       f->a, f->a.mvc);                                                     \
         return;                                                                             \
     }
-        MV_CASE(SMC_FK_BOOTSTRAP, 16) MV_CASE(SMC_FK_BOOTSTRAP, 32)
-        MV_CASE(SMC_FK_GUIDED, 16) MV_CASE(SMC_FK_GUIDED, 32)
+        MV_CASE(SMC_FK_BOOTSTRAP, 16, false) MV_CASE(SMC_FK_BOOTSTRAP, 32, false)
+        MV_CASE(SMC_FK_GUIDED, 16, false) MV_CASE(SMC_FK_GUIDED, 32, false)
+        MV_CASE(SMC_FK_GUIDED, 16, true) MV_CASE(SMC_FK_GUIDED, 32, true)
 #undef MV_CASE
         return;
     }
@@ -180,6 +182,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     f->prof = false;
     f->prof_n = 0;
     f->perm_t = -1;
+    f->mv_collapsed = mv && model->fk == SMC_FK_GUIDED && (o->flags & SMC_FLAG_COLLAPSED_PROPOSAL);
     FArgs& a = f->a;
     memset(&a, 0, sizeof a);
     a.N = o->N;
@@ -918,7 +921,7 @@ int smc_filter_describe(smc_filter* f, char* out, size_t n)
         else if (f->fused) s = "k_ancestors<fused>";
         else s = "k_prepare+k_ancestors";
         if (f->a.scheme == SMC_MULTINOMIAL && !f->a.ut) s = "k_f_spacing_sums+k_f_spacing_write+" + s;
-        s += mv ? "+k_propagate_mv" : "+k_propagate";
+        s += mv ? (f->mv_collapsed ? "+k_propagate_mv<collapsed>" : "+k_propagate_mv") : "+k_propagate";
         if (f->a.mom) s += "+k_f_moments_partials+k_f_moments_final";
     }
     snprintf(out, n, "%s", s.c_str());

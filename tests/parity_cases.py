@@ -1212,6 +1212,43 @@ def check_mv_kalman(N, d, fk, scheme="systematic"):
     assert abs(np.mean(lls) - ll) < tol, (lls, ll)
 
 
+def check_mv_collapsed(N, d, T=6):
+    """MVLinearGauss guided filter with the collapsed form of the optimal proposal's weight
+    (SMC_FLAG_COLLAPSED_PROPOSAL: log G = log p(y_t | x_{t-1})): the particles are the default
+    path's bit for bit as long as the resampling decisions agree, the log-weights equal up to
+    the rounding of the three-term expression it replaces (state_space_models.py:380-392), the
+    evidence agrees with the exact Kalman likelihood (kalman.py:483-505)."""
+    rng = np.random.RandomState(5)
+    om = orc.Guarniero(alpha=0.4, dx=d)
+    x = np.zeros(d)
+    y = []
+    for t in range(T):
+        x = (om.F @ x if t else np.zeros(d)) + rng.standard_normal(d)
+        y.append((x + rng.standard_normal(d)).reshape(1, d))
+    ll, _ = orc.kalman_loglik(om, y)
+    mk = lambda c, ess: pa.SMC(fk=ssm.GuidedPF(ssm=kalman.MVLinearGauss_Guarniero_etal(alpha=0.4, dx=d), data=y),
+                               N=N, seed=31, ESSrmin=ess, collapsed_proposal=c)
+    # ESSrmin = 0: never resample -> identical particle systems, the weights can be compared
+    a, b = mk(False, 0.0), mk(True, 0.0)
+    a.run()
+    b.run()
+    assert "collapsed" in describe(b) and "collapsed" not in describe(a)
+    assert np.array_equal(a.X, b.X)
+    assert np.allclose(a.wgts.lw, b.wgts.lw, rtol=0, atol=2e-10 * T * d), np.max(np.abs(a.wgts.lw - b.wgts.lw))
+    assert abs(a.logLt - b.logLt) < 1e-9 * abs(a.logLt)
+    c, c0 = mk(True, 0.5), mk(False, 0.5)
+    c.run()
+    c0.run()
+    assert c.summaries.rs_flags == c0.summaries.rs_flags and abs(c.logLt - c0.logLt) < 1e-8 * abs(c0.logLt)
+    if N >= 1 << 14:
+        assert abs(c.logLt - ll) < 0.07 * max(1.0, np.sqrt((1 << 17) / N)), (c.logLt, ll)
+    with np.errstate(all="ignore"):        # the flag is the guided MV filter's: ignored elsewhere
+        e = pa.SMC(fk=ssm.Bootstrap(ssm=kalman.MVLinearGauss_Guarniero_etal(alpha=0.4, dx=d), data=y), N=N,
+                   seed=31, collapsed_proposal=True)
+        e.run()
+        assert "collapsed" not in describe(e) and np.isfinite(e.logLt)
+
+
 def check_generic_path(golden):
     """A user-defined FeynmanKac in Python: template method with device ops."""
     g = golden("kalman_toy")

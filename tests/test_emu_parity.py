@@ -225,3 +225,8 @@ def test_oracle_at_size_small():
     pc.check_oracle_at_size("mv4", *mv4, 1024, 3, "systematic", 0.5, fk="guided", d=4, expect_resample=False)
     pc.check_oracle_at_size("toy", *toy, 2048, 4, "systematic", 0.5, replay=False, n_islands=3,
                             islands=(0, 2), seed=21)
+
+
+def test_mv_collapsed_proposal():
+    pc.check_mv_collapsed(2048, 4)
+    pc.check_mv_collapsed(1024, 20, T=4)

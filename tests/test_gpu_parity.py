@@ -274,6 +274,12 @@ def test_c4_oracle_d32():
     pc.check_oracle_at_size("mv32", mk_dev, mk_orc, 1 << 17, 3, "systematic", 1.0, fk="bootstrap", d=32)
 
 
+def test_mv_collapsed_proposal():
+    pc.check_mv_collapsed(1 << 14, 4)
+    pc.check_mv_collapsed(1 << 17, 32)
+    pc.check_mv_collapsed(1 << 15, 20, T=4)
+
+
 def test_c5_oracle_islands():
     """C5's share of one GPU, 32 islands x N = 2^18, production Philox streams: islands 0, 13
     and 31 audited step by step against the oracle's Philox restatement."""
