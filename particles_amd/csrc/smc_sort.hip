@@ -1,20 +1,318 @@
-// smc_sort.hip -- weighted quantiles (particles/resampling.py:381-417 wquantiles,
-// _wquantiles): argsort of the particles, running sum of the weights in that
-// order, searchsorted + np.interp between the two neighbours of each level.
+// smc_sort.hip -- device sorts of the path's callers: np.argsort of the first QMC coordinate and
+// the Hilbert sort of SQMC (particles/core.py:339-349, hilbert.py:33-58), weighted quantiles
+// (particles/resampling.py:381-417 wquantiles: argsort, running sum of the weights in that order,
+// searchsorted + np.interp between the two neighbours of each level).
 //
-// Not on the per-step path (a collector): the sort and the
-// scan are rocPRIM's through hipCUB (device-wide radix sort of (x, W) pairs,
-// inclusive sum); the search runs in one small kernel and the 2-point
-// interpolation of np.interp on the host from 4 numbers per level.
+// The sort is a hand-written stable LSD radix sort for gfx950 (wave64), 8 bits per pass over
+// order-preserving 64-bit images of the keys (fp64: sign flip / complement; int64: sign flip),
+// (key, 64-bit payload) pairs, three kernels per pass:
+//   k_rs_hist     per tile of 2048 keys: digit counts through LDS atomics -> hist[256][tiles] and
+//                 the 256 digit totals of the whole input
+//   k_rs_scan     one workgroup per digit: (keys with a smaller digit) + prefix sum of its row
+//                 -> the first output slot of every (digit, tile)
+//   k_rs_scatter  per tile: a wave takes 512 consecutive keys in 8 chunks of 64; the rank of a key
+//                 among the EARLIER keys of its digit is (keys of that digit in the wave's
+//                 earlier chunks: an LDS counter) + (lanes below it with the same digit: 8
+//                 ballots build the mask of equal digits, one popcount ranks) -- no sorting
+//                 network, no atomics, stable by construction; the tile is laid out in sorted
+//                 order in LDS (32 KB) and written out slot by slot, so that consecutive lanes
+//                 write the consecutive 8-byte slots of a digit's run.
+// HBM traffic per pass: read keys twice, read payload once, write both: 40 B per element.
+// The running sum of wquantiles is a three-kernel scan (tile sums, scan of the sums, apply).
+// Everything also runs under the fiber emulator (tests/emu), so the CPU suite exercises it.
 #include "smc_internal.h"
 #include "smc_device.h"
 #include <vector>
+
+#define RS_TILE 2048
+#define RS_SEG (RS_TILE / SMC_NWAVE)       /* keys per wave */
+#define RS_CH (RS_SEG / 64)                /* chunks of 64 per wave */
+
 #ifdef SMC_EMULATE
-#include <algorithm>
-#include <numeric>
+__device__ inline u64 smc_ballot(bool p) { return __ballot(p ? 1 : 0); }
+__device__ inline void smc_wave_lockstep() { emu_wave_sync(); }
 #else
-#include <hipcub/hipcub.hpp>
+__device__ __forceinline__ u64 smc_ballot(bool p) { return __ballot(p ? 1 : 0); }
+__device__ __forceinline__ void smc_wave_lockstep() {}     // a wavefront executes in lock step
 #endif
+
+enum { RS_KEY_F64 = 0, RS_KEY_I64 = 1 };
+// order-preserving map onto unsigned 64-bit integers
+__host__ __device__ __forceinline__ u64 rs_encode(u64 bits, int kind)
+{
+    if (kind == RS_KEY_I64) return bits ^ 0x8000000000000000ull;
+    return (bits >> 63) ? ~bits : (bits | 0x8000000000000000ull);      // fp64: -x < +x, NaN (+) last
+}
+__host__ __device__ __forceinline__ u64 rs_decode(u64 e, int kind)
+{
+    if (kind == RS_KEY_I64) return e ^ 0x8000000000000000ull;
+    return (e >> 63) ? (e & 0x7fffffffffffffffull) : ~e;
+}
+
+// keys -> sortable images; payload = the element's index (argsort) unless `vals` is given
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_rs_encode(const u64* keys, const u64* vals, i64 N, int kind, u64* ek, u64* ev)
+{
+    const i64 i = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;
+    if (i >= N) return;
+    ek[i] = rs_encode(keys[i], kind);
+    ev[i] = vals ? vals[i] : (u64)i;
+}
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_rs_decode(const u64* ek, i64 N, int kind, u64* keys)
+{
+    const i64 i = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;
+    if (i < N) keys[i] = rs_decode(ek[i], kind);
+}
+
+// hist[digit][tile] (digit-major: the scan below is then a plain prefix sum of one flat array per
+// digit row) and the digit totals of the whole input (256 global counters, zeroed per pass)
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_rs_hist(const u64* keys, i64 N, int shift, unsigned* hist, unsigned* total, int ntiles)
+{
+    __shared__ unsigned h[256];
+    const int tid = (int)threadIdx.x;
+    h[tid] = 0u;
+    __syncthreads();
+    const i64 base = (i64)blockIdx.x * RS_TILE;
+    const int lane = smc_lane();
+    const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int c = 0; c < RS_TILE / SMC_BLOCK; ++c) {
+        const i64 i = base + (i64)c * SMC_BLOCK + tid;
+        const bool valid = i < N;
+        const unsigned dg = valid ? (unsigned)(keys[i] >> shift) & 255u : 0u;
+        // one LDS atomic per distinct digit of the wave (the exponent bytes of fp64 keys take a
+        // handful of values: per-key atomics would serialise on them)
+        u64 mask = smc_ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) {
+            const bool mine = (dg >> bit) & 1u;
+            const u64 bb = smc_ballot(mine);
+            mask &= mine ? bb : ~bb;
+        }
+        if (valid && (mask & lt) == 0ull) atomicAdd(&h[dg], (unsigned)__popcll(mask));
+    }
+    __syncthreads();
+    const unsigned c = h[tid];
+    hist[(i64)tid * ntiles + blockIdx.x] = c;
+    if (c) atomicAdd(&total[tid], c);
+}
+
+// one workgroup per digit: first output slot of every (digit, tile) = (keys with a smaller digit)
+// + (keys with this digit in earlier tiles); in place.  The totals are consumed here and the
+// LAST workgroup leaves them zeroed for the next pass (ticket).
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_rs_scan(unsigned* hist, unsigned* total, unsigned* ticket, int ntiles)
+{
+    __shared__ u64 smu[SMC_SM];
+    __shared__ int s_last;
+    const int d = (int)blockIdx.x, tid = (int)threadIdx.x;
+    const u64 lower = (tid < d) ? (u64)total[tid] : 0ull;
+    u64 carry = smc_block_sum_u64(lower, smu);                // keys with a smaller digit
+    unsigned* row = hist + (i64)d * ntiles;
+    for (int w0 = 0; w0 < ntiles; w0 += SMC_BLOCK) {
+        const int w = w0 + tid;
+        const u64 c = (w < ntiles) ? (u64)row[w] : 0ull;
+        __syncthreads();
+        u64 tot;
+        const u64 ex = smc_block_exscan_u64(c, smu, tot);
+        if (w < ntiles) row[w] = (unsigned)(carry + ex);
+        carry += tot;
+    }
+    // re-arm the totals once every digit has read them
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (s_last) {
+        total[tid] = 0u;
+        if (tid == 0) *ticket = 0u;
+    }
+}
+
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_rs_scatter(const u64* keys, const u64* vals, i64 N, int shift, const unsigned* offs, int ntiles,
+             u64* okeys, u64* ovals)
+{
+    __shared__ unsigned cnt[SMC_NWAVE][256];
+    __shared__ unsigned start[256];              // first slot of each digit in the tile's sorted order
+    __shared__ unsigned goff[256];               // first output slot of (digit, this tile)
+    __shared__ u64 sk[RS_TILE], sv[RS_TILE];     // the tile in sorted order
+    __shared__ u64 smu[SMC_SM];
+    const int tid = (int)threadIdx.x, lane = smc_lane(), wave = smc_wave();
+#pragma unroll
+    for (int w = 0; w < SMC_NWAVE; ++w) cnt[w][tid] = 0u;
+    goff[tid] = offs[(i64)tid * ntiles + blockIdx.x];
+    __syncthreads();
+    const i64 tile0 = (i64)blockIdx.x * RS_TILE;
+    const i64 base = tile0 + (i64)wave * RS_SEG;
+    const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));       // lanes below this one
+    u64 k[RS_CH], v[RS_CH];
+    unsigned lrank[RS_CH];
+#pragma unroll
+    for (int c = 0; c < RS_CH; ++c) {
+        const i64 i = base + (i64)c * 64 + lane;
+        const bool valid = i < N;
+        k[c] = valid ? keys[i] : ~0ull;
+        v[c] = valid ? vals[i] : 0ull;
+    }
+#pragma unroll
+    for (int c = 0; c < RS_CH; ++c) {
+        const bool valid = base + (i64)c * 64 + lane < N;
+        const unsigned dg = (unsigned)(k[c] >> shift) & 255u;
+        u64 mask = smc_ballot(valid);                // lanes holding a key with THIS lane's digit
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) {
+            const bool mine = (dg >> bit) & 1u;
+            const u64 bb = smc_ballot(mine);
+            mask &= mine ? bb : ~bb;
+        }
+        const unsigned before = cnt[wave][dg];       // keys of this digit in the wave's earlier chunks
+        smc_wave_lockstep();
+        lrank[c] = before + (unsigned)__popcll(mask & lt);
+        if (valid && (mask & lt) == 0ull) cnt[wave][dg] = before + (unsigned)__popcll(mask);
+        smc_wave_lockstep();
+    }
+    __syncthreads();
+    {   // digit tid: its slots in the tile's sorted order start after all smaller digits; per
+        // wave, after the earlier waves' keys of the same digit
+        unsigned c4[SMC_NWAVE], tot = 0u;
+#pragma unroll
+        for (int w = 0; w < SMC_NWAVE; ++w) { c4[w] = cnt[w][tid]; tot += c4[w]; }
+        u64 all;
+        unsigned run = (unsigned)smc_block_exscan_u64((u64)tot, smu, all);
+        start[tid] = run;
+#pragma unroll
+        for (int w = 0; w < SMC_NWAVE; ++w) { cnt[w][tid] = run; run += c4[w]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < RS_CH; ++c) {
+        if (base + (i64)c * 64 + lane < N) {
+            const unsigned dg = (unsigned)(k[c] >> shift) & 255u;
+            const unsigned p = cnt[wave][dg] + lrank[c];
+            sk[p] = k[c];
+            sv[p] = v[c];
+        }
+    }
+    __syncthreads();
+    // out in sorted order: consecutive threads write consecutive slots of a digit's run
+    const i64 nin = (N - tile0 < RS_TILE) ? (N - tile0) : RS_TILE;
+#pragma unroll
+    for (int c = 0; c < RS_TILE / SMC_BLOCK; ++c) {
+        const int j = c * SMC_BLOCK + tid;
+        if (j < nin) {
+            const u64 kk = sk[j];
+            const unsigned dg = (unsigned)(kk >> shift) & 255u;
+            const i64 pos = (i64)goff[dg] + (j - (int)start[dg]);
+            okeys[pos] = kk;
+            ovals[pos] = sv[j];
+        }
+    }
+}
+
+// Stable sort of (key, payload) pairs by key: keys (N) 64-bit patterns of `kind`, vals (N) 64-bit
+// payloads or null (payload = index: argsort).  out_keys / out_vals (N each, either may be null).
+// Scratch from the context's pool (recycled in stream order).  N < 2^32.
+static int rs_sort_pairs(smc_ctx* ctx, const void* keys, const void* vals, i64 N, int kind, void* out_keys,
+                         void* out_vals)
+{
+    hipStream_t st = ctx->stream;
+    const int ntiles = (int)((N + RS_TILE - 1) / RS_TILE);
+    const size_t nb = (size_t)N * 8;
+    void* buf = nullptr;
+    if (smc_malloc(ctx, 4 * nb + (size_t)ntiles * 256 * 4 + 257 * 4, &buf) != SMC_OK) return SMC_ERR_NOMEM;
+    u64* k0 = (u64*)buf;
+    u64* v0 = (u64*)((char*)buf + nb);
+    u64* k1 = (u64*)((char*)buf + 2 * nb);
+    u64* v1 = (u64*)((char*)buf + 3 * nb);
+    unsigned* hist = (unsigned*)((char*)buf + 4 * nb);
+    unsigned* total = hist + (size_t)ntiles * 256;            // 256 digit totals + the scan's ticket
+    const dim3 ge((unsigned)((N + SMC_BLOCK - 1) / SMC_BLOCK));
+    (void)hipMemsetAsync(total, 0, 257 * 4, st);
+    SMC_LAUNCH(k_rs_encode, ge, dim3(SMC_BLOCK), st, (const u64*)keys, (const u64*)vals, N, kind, k0, v0);
+    for (int pass = 0; pass < 8; ++pass) {
+        const int shift = 8 * pass;
+        SMC_LAUNCH(k_rs_hist, dim3(ntiles), dim3(SMC_BLOCK), st, (const u64*)k0, N, shift, hist, total, ntiles);
+        SMC_LAUNCH(k_rs_scan, dim3(256), dim3(SMC_BLOCK), st, hist, total, total + 256, ntiles);
+        SMC_LAUNCH(k_rs_scatter, dim3(ntiles), dim3(SMC_BLOCK), st, (const u64*)k0, (const u64*)v0, N, shift,
+                   (const unsigned*)hist, ntiles, k1, v1);
+        u64* t = k0; k0 = k1; k1 = t;
+        t = v0; v0 = v1; v1 = t;
+    }
+    int rc = SMC_OK;
+    if (out_keys) SMC_LAUNCH(k_rs_decode, ge, dim3(SMC_BLOCK), st, (const u64*)k0, N, kind, (u64*)out_keys);
+    if (out_vals && hipMemcpyAsync(out_vals, v0, nb, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = SMC_ERR_HIP;
+    if (hipGetLastError() != hipSuccess) rc = SMC_ERR_HIP;
+#ifdef SMC_EMULATE
+    if (hipStreamSynchronize(st) != hipSuccess) rc = SMC_ERR_HIP;
+#endif
+    (void)smc_free(ctx, buf);
+    return rc;
+}
+
+// ---- inclusive running sum of N doubles (np.cumsum's role in wquantiles): tile sums, scan of
+// the sums by one workgroup, apply.  Fixed association order (tile by tile, lanes as a DPP scan).
+#define SC_TILE (SMC_BLOCK * 4)
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_sc_tile(const double* x, i64 N, double* out, double* tsum, const double* tpre)
+{
+    __shared__ double sm[SMC_SM];
+    const i64 i0 = (i64)blockIdx.x * SC_TILE + (i64)threadIdx.x * 4;
+    double v[4], s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[k] = (i0 + k < N) ? x[i0 + k] : 0.0; s += v[k]; }
+    const double inc = smc_wave_scan_add_f64(s);
+    __syncthreads();
+    if (smc_lane() == 63) sm[smc_wave()] = inc;
+    __syncthreads();
+    double base = tpre ? tpre[blockIdx.x] : 0.0, tot = 0.0;
+#pragma unroll
+    for (int w = 0; w < SMC_NWAVE; ++w) {
+        if (w < smc_wave()) base += sm[w];
+        tot += sm[w];
+    }
+    if (!tpre) {
+        if (threadIdx.x == 0) tsum[blockIdx.x] = tot;
+        return;
+    }
+    double run = base + inc - s;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        run += v[k];
+        if (i0 + k < N) out[i0 + k] = run;
+    }
+}
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_sc_sums(double* tsum, int nt)                 // exclusive scan of the tile sums, in place, one workgroup
+{
+    __shared__ double sm[SMC_SM];
+    double carry = 0.0;
+    for (int b0 = 0; b0 < nt; b0 += SMC_BLOCK) {
+        const int i = b0 + (int)threadIdx.x;
+        const double v = i < nt ? tsum[i] : 0.0;
+        const double inc = smc_wave_scan_add_f64(v);
+        __syncthreads();
+        if (smc_lane() == 63) sm[smc_wave()] = inc;
+        __syncthreads();
+        double base = carry, tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < SMC_NWAVE; ++w) {
+            if (w < smc_wave()) base += sm[w];
+            tot += sm[w];
+        }
+        if (i < nt) tsum[i] = base + inc - v;
+        carry += tot;
+    }
+}
+static void sc_inclusive_sum(smc_ctx* ctx, const double* x, i64 N, double* out, double* tsum)
+{
+    const int nt = (int)((N + SC_TILE - 1) / SC_TILE);
+    hipStream_t st = ctx->stream;
+    SMC_LAUNCH(k_sc_tile, dim3(nt), dim3(SMC_BLOCK), st, x, N, out, tsum, (const double*)nullptr);
+    SMC_LAUNCH(k_sc_sums, dim3(1), dim3(SMC_BLOCK), st, tsum, nt);
+    SMC_LAUNCH(k_sc_tile, dim3(nt), dim3(SMC_BLOCK), st, x, N, out, tsum, (const double*)tsum);
+}
 
 __global__ void k_column(const double* x, i64 N, i64 d, i64 col, double* out)
 {
@@ -53,44 +351,15 @@ k_iota_i64(i64 N, i64* out)
 }
 
 // np.argsort(x) (hilbert.py:52-54 for d = 1; core.py:342 argsort of the first QMC coordinate):
-// device-wide radix sort of (x, index) pairs
+// radix sort of (x, index) pairs; stable, like np.argsort(kind="stable") on ties
 extern "C" int smc_argsort(smc_ctx* ctx, const double* x, int64_t N, int64_t* out)
 {
     SMC_REQUIRE(ctx && x && out, "null argument");
     SMC_REQUIRE(N > 0 && N < ((int64_t)1 << 31), "N must be in [1, 2^31)");
-    hipStream_t st = ctx->stream;
     SMC_HIP_CHECK(hipSetDevice(ctx->device));
-#ifdef SMC_EMULATE
-    {   // test infrastructure: host sort
-        SMC_HIP_CHECK(hipStreamSynchronize(st));
-        std::vector<i64> o((size_t)N);
-        std::iota(o.begin(), o.end(), 0);
-        std::stable_sort(o.begin(), o.end(), [&](i64 a, i64 b) { return x[a] < x[b]; });
-        for (i64 i = 0; i < N; ++i) out[i] = o[(size_t)i];
-        return SMC_OK;
-    }
-#else
-    void* buf = nullptr;
-    size_t tb = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, x, (double*)nullptr, (const i64*)nullptr,
-                                             (i64*)nullptr, (int)N, 0, 64, st);
-    const size_t nb = (size_t)N * 8;
-    // scratch from the context's pool: recycled in stream order, no sync, no hipMalloc per call
-    if (smc_malloc(ctx, 2 * nb + (tb ? tb : 8), &buf) != SMC_OK) return SMC_ERR_NOMEM;
-    double* ks = (double*)buf;
-    i64* idx = (i64*)((char*)buf + nb);
-    void* tmp = (char*)buf + 2 * nb;
-    SMC_LAUNCH(k_iota_i64, dim3((unsigned)((N + SMC_BLOCK - 1) / SMC_BLOCK)), dim3(SMC_BLOCK), st,
-               (i64)N, idx);
-    int rc = SMC_OK;
-    if (hipcub::DeviceRadixSort::SortPairs(tmp, tb, x, ks, (const i64*)idx, (i64*)out, (int)N, 0, 64,
-                                           st) != hipSuccess) {
-        smc_set_error("smc_argsort: HIP error: %s", hipGetErrorString(hipGetLastError()));
-        rc = SMC_ERR_HIP;
-    }
-    (void)smc_free(ctx, buf);
+    const int rc = rs_sort_pairs(ctx, x, nullptr, (i64)N, RS_KEY_F64, nullptr, out);
+    if (rc == SMC_ERR_HIP) smc_set_error("smc_argsort: HIP error: %s", hipGetErrorString(hipGetLastError()));
     return rc;
-#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -227,20 +496,12 @@ extern "C" int smc_hilbert_sort(smc_ctx* ctx, const double* x, int64_t N, int32_
     const int nb = (int)((N + 4 * SMC_BLOCK - 1) / (4 * SMC_BLOCK) > 256 ? 256
                                                                           : (N + 4 * SMC_BLOCK - 1) / (4 * SMC_BLOCK));
     const size_t nbytes = (size_t)N * 8;
-    size_t tb = 0;
-#ifndef SMC_EMULATE
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (const i64*)nullptr, (i64*)nullptr,
-                                             (const i64*)nullptr, (i64*)nullptr, (int)N, 0, 64, st);
-#endif
     void* buf = nullptr;
     const size_t small = (size_t)(HB_MAXD * nb + 2 * HB_MAXD) * 8;
-    if (smc_malloc(ctx, 3 * nbytes + small + (tb ? tb : 8), &buf) != SMC_OK) return SMC_ERR_NOMEM;
+    if (smc_malloc(ctx, nbytes + small, &buf) != SMC_OK) return SMC_ERR_NOMEM;
     i64* keys = (i64*)buf;
-    i64* ks = (i64*)((char*)buf + nbytes);
-    i64* idx = (i64*)((char*)buf + 2 * nbytes);
-    double* part = (double*)((char*)buf + 3 * nbytes);
+    double* part = (double*)((char*)buf + nbytes);
     double* stat = part + (size_t)HB_MAXD * nb;
-    void* tmp = (char*)buf + 3 * nbytes + small;
     const double maxint = floor(pow(2.0, 62.0 / (double)d));                     // :55
     SMC_LAUNCH(k_hb_colsum, dim3(nb, d), dim3(SMC_BLOCK), st, x, (i64)N, (int)d, (const double*)nullptr, part);
     SMC_LAUNCH(k_hb_colfinal, dim3(1), dim3(64), st, (const double*)part, nb, (i64)N, (int)d, 0, stat);
@@ -248,22 +509,8 @@ extern "C" int smc_hilbert_sort(smc_ctx* ctx, const double* x, int64_t N, int32_
     SMC_LAUNCH(k_hb_colfinal, dim3(1), dim3(64), st, (const double*)part, nb, (i64)N, (int)d, 1, stat);
     SMC_LAUNCH(k_hb_keys, dim3((unsigned)((N + SMC_BLOCK - 1) / SMC_BLOCK)), dim3(SMC_BLOCK), st, x,
                (i64)N, (int)d, (const double*)stat, maxint, keys);
-    int rc = SMC_OK;
-#ifdef SMC_EMULATE
-    {
-        (void)ks; (void)idx; (void)tmp;
-        std::vector<i64> o((size_t)N);
-        std::iota(o.begin(), o.end(), 0);
-        std::stable_sort(o.begin(), o.end(), [&](i64 a, i64 b) { return keys[a] < keys[b]; });
-        for (i64 i = 0; i < N; ++i) out[i] = o[(size_t)i];
-    }
-#else
-    SMC_LAUNCH(k_iota_i64, dim3((unsigned)((N + SMC_BLOCK - 1) / SMC_BLOCK)), dim3(SMC_BLOCK), st,
-               (i64)N, idx);
     // signed keys: np.argsort of the (possibly wrapped) int64 indices
-    if (hipcub::DeviceRadixSort::SortPairs(tmp, tb, (const i64*)keys, (i64*)ks, (const i64*)idx,
-                                           (i64*)out, (int)N, 0, 64, st) != hipSuccess) rc = SMC_ERR_HIP;
-#endif
+    int rc = rs_sort_pairs(ctx, keys, nullptr, (i64)N, RS_KEY_I64, nullptr, out);
     if (rc == SMC_OK && keys_out &&
         hipMemcpyAsync(keys_out, keys, nbytes, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = SMC_ERR_HIP;
 #ifdef SMC_EMULATE
@@ -296,13 +543,7 @@ extern "C" int smc_wquantiles(smc_ctx* ctx, const double* W, const double* x, in
     void* tmp = nullptr;
     do {
         if (hipMemcpyAsync(al, alphas_host, (size_t)k * 8, hipMemcpyHostToDevice, st) != hipSuccess) { rc = SMC_ERR_HIP; break; }
-#ifndef SMC_EMULATE
-        size_t tb_sort = 0, tb_scan = 0;
-        (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb_sort, col, xs, W, ws, (int)N, 0, 64, st);
-        (void)hipcub::DeviceScan::InclusiveSum(nullptr, tb_scan, ws, cw, (int)N, st);
-        const size_t tb = tb_sort > tb_scan ? tb_sort : tb_scan;
-        if (hipMalloc(&tmp, tb ? tb : 8) != hipSuccess) { rc = SMC_ERR_NOMEM; break; }
-#endif
+        if (hipMalloc(&tmp, (size_t)((N + SC_TILE - 1) / SC_TILE) * 8 + 8) != hipSuccess) { rc = SMC_ERR_NOMEM; break; }
         std::vector<double> probes((size_t)4 * k);
         for (i64 c = 0; c < d && rc == SMC_OK; ++c) {
             const double* keys = x;
@@ -311,22 +552,10 @@ extern "C" int smc_wquantiles(smc_ctx* ctx, const double* W, const double* x, in
                            x, (i64)N, (i64)d, c, col);
                 keys = col;
             }
-#ifdef SMC_EMULATE
-            {   // test infrastructure: host sort (np.argsort + np.cumsum)
-                std::vector<i64> o((size_t)N);
-                std::iota(o.begin(), o.end(), 0);
-                std::stable_sort(o.begin(), o.end(), [&](i64 a, i64 b) { return keys[a] < keys[b]; });
-                double run = 0.0;
-                for (i64 i = 0; i < N; ++i) { xs[i] = keys[o[i]]; ws[i] = W[o[i]]; run += ws[i]; cw[i] = run; }
-            }
-#else
-            size_t tb1 = tb_sort, tb2 = tb_scan;
-            if (hipcub::DeviceRadixSort::SortPairs(tmp, tb1, keys, xs, W, ws, (int)N, 0, 64, st) != hipSuccess ||
-                hipcub::DeviceScan::InclusiveSum(tmp, tb2, ws, cw, (int)N, st) != hipSuccess) {
-                rc = SMC_ERR_HIP;
-                break;
-            }
-#endif
+            // (x, W) pairs sorted by x, then the running sum of the weights in that order
+            rc = rs_sort_pairs(ctx, keys, W, (i64)N, RS_KEY_F64, xs, ws);
+            if (rc != SMC_OK) break;
+            sc_inclusive_sum(ctx, ws, (i64)N, cw, (double*)tmp);
             SMC_LAUNCH(k_quantile_probe, dim3((unsigned)((k + SMC_BLOCK - 1) / SMC_BLOCK)), dim3(SMC_BLOCK), st,
                        (const double*)cw, (const double*)xs, (i64)N, (const double*)al, k, pr);
             if (hipMemcpyAsync(probes.data(), pr, (size_t)4 * k * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||

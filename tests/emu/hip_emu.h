@@ -272,6 +272,21 @@ inline T __shfl_down(T v, unsigned d, int width = 64) {
     return hipemu::exchange(v, emu_wbase() + src);
 }
 
+// wave-wide ballot: bit l = predicate of lane l (lanes that do not exist contribute 0)
+inline unsigned long long __ballot(int pred) {
+    hipemu::State& s = hipemu::S();
+    s.xch[s.cur] = pred ? 1ull : 0ull;
+    hipemu::wave_barrier();
+    unsigned long long m = 0;
+    const int base = emu_wbase();
+    for (int l = 0; l < 64 && base + l < s.nthreads; ++l)
+        if (s.xch[base + l]) m |= 1ull << l;
+    hipemu::wave_barrier();
+    return m;
+}
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline void emu_wave_sync() { hipemu::wave_barrier(); }
+
 struct alignas(16) uint4 { unsigned x, y, z, w; };
 inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 

@@ -69,6 +69,30 @@ def check_wquantiles(golden):
                        rtol=1e-9, atol=1e-9)
 
 
+def check_device_sort(sizes=(1, 63, 64, 2047, 2048, 2049, 50001)):
+    """The hand-written LSD radix sort (csrc/smc_sort.hip): argsort of doubles against
+    np.argsort(kind="stable") -- ties, signed zeros, infinities, tiny / huge magnitudes -- and the
+    Hilbert sort's signed int64 keys; a permutation, stable, for sizes around the tile edges."""
+    from particles_amd import hilbert
+    rng = np.random.default_rng(5)
+    for N in sizes:
+        x = rng.standard_normal(N) * 10.0 ** rng.integers(-300, 300, size=N)
+        if N > 8:
+            x[rng.integers(0, N, size=N // 3)] = x[1]                     # many ties
+            x[2], x[3], x[4], x[5] = 0.0, -0.0, np.inf, -np.inf
+        o = np.asarray(hilbert.argsort(x))
+        assert o.dtype == np.int64 and np.array_equal(np.sort(o), np.arange(N))
+        assert np.all(np.diff(x[o]) >= 0)
+        ref = np.argsort(x, kind="stable")
+        same_value = x[o] == x[ref]                   # (+0 and -0 compare equal: either order is a valid sort)
+        assert np.all(same_value)
+        nz = x[o] != 0.0
+        assert np.array_equal(o[nz], ref[nz])                                 # stable: ties in index order
+    pts = rng.standard_normal((4097, 2))
+    order = np.asarray(hilbert.hilbert_sort(pts))
+    assert np.array_equal(np.sort(order), np.arange(4097))
+
+
 def check_weights_edges(N):
     w = rs.Weights(lw=np.full(N, -np.inf))                   # SURVEY appendix B
     assert np.isnan(w.W).all() and np.isnan(w.ESS) and np.isnan(w.log_mean)

@@ -230,3 +230,7 @@ def test_oracle_at_size_small():
 def test_mv_collapsed_proposal():
     pc.check_mv_collapsed(2048, 4)
     pc.check_mv_collapsed(1024, 20, T=4)
+
+
+def test_device_sort():
+    pc.check_device_sort()

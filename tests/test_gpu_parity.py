@@ -439,3 +439,7 @@ def test_rccl_two_ranks_one_gpu(tmp_path):
         procs, outs, json = _run_ranks(2, tmp_path, {})
         assert all(p.returncode != 0 for p in procs)               # no opt-in: loud failure
         assert "RCCL evidence gather unavailable" in "".join(outs)
+
+
+def test_device_sort():
+    pc.check_device_sort(sizes=(1, 64, 2049, 50001, (1 << 20) + 3, 1 << 22))
