@@ -332,6 +332,25 @@ int smc_filter_set_state(smc_filter* f, int island, const double* X_host, const 
 /* PMCMC move of SMC^2 (smc_samplers.py:1129-1143): where accept_host[i] != 0, island i of dst
  * takes over island i of src (same shapes, model kind and time index; one context). */
 int smc_filter_copy_islands(smc_filter* dst, smc_filter* src, const unsigned char* accept_host);
+/* ---- SMC^2 (smc_samplers.py:1038-1167): the theta level on the device.  Every island is the
+ * particle filter of one theta-particle.  Once enabled (before the first step), every time step
+ * is followed by a one-workgroup kernel that adds the islands' evidence increments to the
+ * theta log-weights (SMC2.logG, :1099-1120) and evaluates the theta-level ESS; when it drops
+ * below ess_rmin * n_islands (core.py:181-183 for the outer SMC) the kernel records the step and
+ * FREEZES the batch -- the steps already enqueued behind it do nothing -- so the caller can
+ * enqueue many steps per synchronisation and deal with resample-move events when they occur:
+ *   smc_filter_step(f, K); smc_filter_theta_state(f, lw, &stop, &done, ess);
+ *   if (stop) { [resample thetas: smc_filter_permute_islands; PMCMC move: a second batch +
+ *                smc_filter_copy_islands] ; smc_filter_theta_resume(f, NULL); }            */
+int smc_filter_theta_enable(smc_filter* f, double ess_rmin);
+/* lw_theta_host (n_islands) or NULL; *stop_t = step at which the batch froze (0: running);
+ * *steps_done = time steps accounted for in the theta weights; ess_host (steps_done) or NULL:
+ * the theta-level ESS after every step. */
+int smc_filter_theta_state(smc_filter* f, double* lw_theta_host, int64_t* stop_t, int64_t* steps_done,
+                           double* ess_host);
+/* New theta log-weights (NULL: zeros, i.e. after a theta-level resampling) and, if frozen, back
+ * to the stop step: stepping continues from there. */
+int smc_filter_theta_resume(smc_filter* f, const double* lw_theta_host);
 /* opts.moments filters: out_host (n_islands, t, 2*dx) = per step the dx weighted means, then the
  * dx weighted variances of the particles (resampling.py:320-338). */
 int smc_filter_moments(smc_filter* f, double* out_host);

@@ -31,6 +31,10 @@ struct smc_filter {
     int prof_n;
     double* tmp;           // (N,) staging for W / Xp downloads
     double* ll_stage;      // (n_islands,) staging for smc_filter_logLt
+    // SMC^2 theta level (smc_filter_theta_enable): theta log-weights, stop record, ESS log
+    double *lwth, *th, *th_ess;
+    double th_ess_min;
+    void* th_buf;
 };
 
 typedef void (*move_fn)(FArgs);
@@ -182,6 +186,9 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     f->prof = false;
     f->prof_n = 0;
     f->perm_t = -1;
+    f->lwth = f->th = f->th_ess = nullptr;
+    f->th_buf = nullptr;
+    f->th_ess_min = 0.0;
     f->mv_collapsed = mv && model->fk == SMC_FK_GUIDED && (o->flags & SMC_FLAG_COLLAPSED_PROPOSAL);
     FArgs& a = f->a;
     memset(&a, 0, sizeof a);
@@ -385,6 +392,7 @@ int smc_filter_destroy(smc_filter* f)
         if (g) (void)hipGraphExecDestroy(g);
     for (hipEvent_t e : f->ev) (void)hipEventDestroy(e);
     (void)hipFree(f->slab);
+    if (f->th_buf) (void)hipFree(f->th_buf);
     delete f;
     return SMC_OK;
 }
@@ -442,6 +450,22 @@ int smc_filter_step(smc_filter* f, int64_t nsteps)
     i64 todo = nsteps;
     if (f->t_host + todo > f->a.T) todo = f->a.T - f->t_host;
     if (todo < 0) todo = 0;
+    if (todo > 0 && f->lwth) {
+        // theta level on: the theta-weights are updated behind every step (and may freeze the batch)
+        const bool small = small_filter_ok(f);
+        for (i64 k = 0; k < todo; ++k) {
+            if (small) launch_small(f, 1);
+            else {
+                enqueue_step(f, -1, f->t_host + k);
+                if (f->two_level) SMC_LAUNCH(k_flush2, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
+            }
+            SMC_LAUNCH(k_theta_update, dim3(1), dim3(SMC_BLOCK), st, f->a, f->lwth, f->th, f->th_ess,
+                       f->th_ess_min, f->two_level ? 1 : 0);
+        }
+        SMC_LAUNCH_CHECK();
+        f->t_host += todo;
+        return SMC_OK;
+    }
     if (todo > 0 && small_filter_ok(f)) {
         launch_small(f, (int)(todo > 0x7fffffff ? 0x7fffffff : todo));
         SMC_LAUNCH_CHECK();
@@ -663,10 +687,35 @@ int smc_filter_set_state(smc_filter* f, int island, const double* X_host, const 
     return SMC_OK;
 }
 
+// The per-island arrays that make up the state of a filter at step t-1 (what theta-level
+// resampling and the PMCMC move transport): (pointer, 8-byte words per island)
+struct IslandArray { void* p; i64 words; };
+static int island_arrays(smc_filter* f, i64 t, IslandArray* out)
+{
+    const FArgs& a = f->a;
+    const i64 N = a.N, T = a.T;
+    int n = 0;
+    out[n++] = {f_X(a, t - 1), N * a.dx};
+    out[n++] = {f_lw(a, t - 1), N};
+    out[n++] = {a.summ, (T + 1) * SUMM_STRIDE};
+    out[n++] = {a.info, INFO_STRIDE};
+    if (f->kind != SMC_MODEL_MVLINGAUSS) out[n++] = {(void*)a.params, PARAM_STRIDE};
+    if (f->two_level) {
+        out[n++] = {a.pm, a.nparts};
+        out[n++] = {a.ps, a.nparts};
+        out[n++] = {a.pss, a.nparts};
+        out[n++] = {a.tq, a.nparts};
+        out[n++] = {a.info2, INFO_STRIDE};
+        out[n++] = {a.cq, N};
+    }
+    return n;
+}
+
 // theta-level resampling of whole filters (SMC^2: smc_samplers.py:319-361 FancyList
 // deep copies): island i continues from the state of island src[i] -- particles,
 // log-weights, per-step summaries, step record and parameter row move together; the
 // Philox streams stay tied to the SLOT (two copies of one island evolve independently).
+// One gather kernel + one contiguous copy per array (a dozen launches, whatever n_islands).
 int smc_filter_permute_islands(smc_filter* f, const int64_t* src_host)
 {
     SMC_REQUIRE(f && src_host, "null argument");
@@ -675,68 +724,36 @@ int smc_filter_permute_islands(smc_filter* f, const int64_t* src_host)
         return SMC_ERR_STATE;
     }
     const int M = f->a.n_islands;
-    const i64 N = f->a.N, T = f->a.T, t = f->t_host;
+    const i64 t = f->t_host;
     for (int i = 0; i < M; ++i)
         if (src_host[i] < 0 || src_host[i] >= M) {
             smc_set_error("smc_filter_permute_islands: source %lld out of range", (long long)src_host[i]);
             return SMC_ERR_INVALID;
         }
     if (t == 0 || M == 1) return SMC_OK;
+    SMC_HIP_CHECK(hipSetDevice(f->ctx->device));
     hipStream_t st = f->ctx->stream;
-    const int dx = f->a.dx;
-    const size_t bx = (size_t)N * dx * 8, bl = (size_t)N * 8, bs = (size_t)(T + 1) * SUMM_STRIDE * 8,
-                 bi = INFO_STRIDE * 8, bp = PARAM_STRIDE * 8;
-    const size_t bq = f->two_level ? (size_t)f->a.nparts * 8 : 0;      // partial arrays, t_b, info2, c_j
-    const size_t bc = f->two_level ? (size_t)N * 8 : 0;
-    const size_t per = bx + bl + bs + bi + bp + 4 * bq + bi + bc;
+    IslandArray arr[16];
+    const int na = island_arrays(f, t, arr);
+    i64 maxw = 0;
+    for (int k = 0; k < na; ++k) maxw = arr[k].words > maxw ? arr[k].words : maxw;
     char* tmp = nullptr;
-    hipError_t e = hipMalloc((void**)&tmp, per * M);
+    const size_t stage = (size_t)M * maxw * 8, idxb = (size_t)M * 8;
+    hipError_t e = hipMalloc((void**)&tmp, stage + idxb);
     if (e != hipSuccess) {
-        smc_set_error("smc_filter_permute_islands: %zu bytes: %s", per * M, hipGetErrorString(e));
+        smc_set_error("smc_filter_permute_islands: %zu bytes: %s", stage + idxb, hipGetErrorString(e));
         return SMC_ERR_NOMEM;
     }
-    double* X = f_X(f->a, t - 1);
-    double* lw = f_lw(f->a, t - 1);
-    const bool has_params = f->kind != SMC_MODEL_MVLINGAUSS;
-    hipError_t rc = hipSuccess;
-    auto cp = [&](void* d, const void* s_, size_t n) {
-        if (rc == hipSuccess) rc = hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToDevice, st);
-    };
-    for (int i = 0; i < M; ++i) {                                   // gather into the staging area
-        const size_t s_ = (size_t)src_host[i];
-        char* o = tmp + per * i;
-        cp(o, X + s_ * N * dx, bx);
-        cp(o + bx, lw + s_ * N, bl);
-        cp(o + bx + bl, f->a.summ + s_ * (T + 1) * SUMM_STRIDE, bs);
-        cp(o + bx + bl + bs, f->a.info + s_ * INFO_STRIDE, bi);
-        if (has_params) cp(o + bx + bl + bs + bi, f->a.params + s_ * PARAM_STRIDE, bp);
-        if (bq) {
-            char* q = o + bx + bl + bs + bi + bp;
-            cp(q, f->a.pm + s_ * f->a.nparts, bq);
-            cp(q + bq, f->a.ps + s_ * f->a.nparts, bq);
-            cp(q + 2 * bq, f->a.pss + s_ * f->a.nparts, bq);
-            cp(q + 3 * bq, f->a.info2 + s_ * INFO_STRIDE, bi);
-            cp(q + 3 * bq + bi, f->a.tq + s_ * f->a.nparts, bq);
-            cp(q + 4 * bq + bi, f->a.cq + s_ * N, bc);
-        }
+    i64* src = (i64*)(tmp + stage);
+    hipError_t rc = hipMemcpyAsync(src, src_host, idxb, hipMemcpyHostToDevice, st);
+    for (int k = 0; k < na && rc == hipSuccess; ++k) {
+        const i64 w = arr[k].words;
+        const unsigned chunks = (unsigned)((w + SMC_BLOCK - 1) / SMC_BLOCK > 64 ? 64 : (w + SMC_BLOCK - 1) / SMC_BLOCK);
+        SMC_LAUNCH(k_island_gather, dim3(chunks, M), dim3(SMC_BLOCK), st, (const u64*)arr[k].p, (u64*)tmp,
+                   (const i64*)src, (const unsigned char*)nullptr, w);
+        rc = hipMemcpyAsync(arr[k].p, tmp, (size_t)M * w * 8, hipMemcpyDeviceToDevice, st);
     }
-    for (int i = 0; i < M; ++i) {                                   // and back, slot by slot
-        const char* o = tmp + per * i;
-        cp(X + (size_t)i * N * dx, o, bx);
-        cp(lw + (size_t)i * N, o + bx, bl);
-        cp(f->a.summ + (size_t)i * (T + 1) * SUMM_STRIDE, o + bx + bl, bs);
-        cp(f->a.info + (size_t)i * INFO_STRIDE, o + bx + bl + bs, bi);
-        if (has_params) cp((void*)(f->a.params + (size_t)i * PARAM_STRIDE), o + bx + bl + bs + bi, bp);
-        if (bq) {
-            const char* q = o + bx + bl + bs + bi + bp;
-            cp(f->a.pm + (size_t)i * f->a.nparts, q, bq);
-            cp(f->a.ps + (size_t)i * f->a.nparts, q + bq, bq);
-            cp(f->a.pss + (size_t)i * f->a.nparts, q + 2 * bq, bq);
-            cp(f->a.info2 + (size_t)i * INFO_STRIDE, q + 3 * bq, bi);
-            cp(f->a.tq + (size_t)i * f->a.nparts, q + 3 * bq + bi, bq);
-            cp(f->a.cq + (size_t)i * N, q + 4 * bq + bi, bc);
-        }
-    }
+    if (rc == hipSuccess) rc = hipGetLastError();
     if (rc == hipSuccess) rc = hipStreamSynchronize(st);
     (void)hipFree(tmp);
     SMC_HIP_CHECK(rc);
@@ -759,36 +776,92 @@ int smc_filter_copy_islands(smc_filter* dst, smc_filter* src, const unsigned cha
                     dst->kind == src->kind && dst->fk == src->fk && dst->t_host == src->t_host &&
                     dst->two_level == src->two_level,
                 "the two filters must have the same shape, model kind and time index");
-    const i64 N = a.N, T = a.T, t = dst->t_host;
+    const i64 t = dst->t_host;
     if (t == 0) return SMC_OK;
+    SMC_HIP_CHECK(hipSetDevice(dst->ctx->device));
     hipStream_t st = dst->ctx->stream;
-    const size_t bx = (size_t)N * a.dx * 8, bl = (size_t)N * 8, bs = (size_t)(T + 1) * SUMM_STRIDE * 8;
-    hipError_t rc = hipSuccess;
-    auto cp = [&](void* d, const void* s_, size_t n) {
-        if (rc == hipSuccess) rc = hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToDevice, st);
-    };
-    for (int i = 0; i < a.n_islands; ++i) {
-        if (!accept_host[i]) continue;
-        cp(f_X(a, t - 1) + (size_t)i * N * a.dx, f_X(b, t - 1) + (size_t)i * N * a.dx, bx);
-        cp(f_lw(a, t - 1) + (size_t)i * N, f_lw(b, t - 1) + (size_t)i * N, bl);
-        cp(a.summ + (size_t)i * (T + 1) * SUMM_STRIDE, b.summ + (size_t)i * (T + 1) * SUMM_STRIDE, bs);
-        cp(a.info + (size_t)i * INFO_STRIDE, b.info + (size_t)i * INFO_STRIDE, INFO_STRIDE * 8);
-        if (dst->kind != SMC_MODEL_MVLINGAUSS)
-            cp((void*)(a.params + (size_t)i * PARAM_STRIDE), b.params + (size_t)i * PARAM_STRIDE,
-               PARAM_STRIDE * 8);
-        if (dst->two_level) {
-            const size_t bq = (size_t)a.nparts * 8, oq = (size_t)i * a.nparts;
-            cp(a.pm + oq, b.pm + oq, bq);
-            cp(a.ps + oq, b.ps + oq, bq);
-            cp(a.pss + oq, b.pss + oq, bq);
-            cp(a.info2 + (size_t)i * INFO_STRIDE, b.info2 + (size_t)i * INFO_STRIDE, INFO_STRIDE * 8);
-            cp(a.tq + oq, b.tq + oq, bq);
-            cp(a.cq + (size_t)i * N, b.cq + (size_t)i * N, (size_t)N * 8);
-        }
+    const int M = a.n_islands;
+    unsigned char* mask = nullptr;
+    SMC_HIP_CHECK(hipMalloc((void**)&mask, (size_t)M));
+    hipError_t rc = hipMemcpyAsync(mask, accept_host, (size_t)M, hipMemcpyHostToDevice, st);
+    IslandArray da[16], sa[16];
+    const int na = island_arrays(dst, t, da);
+    (void)island_arrays(src, t, sa);
+    for (int k = 0; k < na && rc == hipSuccess; ++k) {
+        const i64 w = da[k].words;
+        const unsigned chunks = (unsigned)((w + SMC_BLOCK - 1) / SMC_BLOCK > 64 ? 64 : (w + SMC_BLOCK - 1) / SMC_BLOCK);
+        SMC_LAUNCH(k_island_gather, dim3(chunks, M), dim3(SMC_BLOCK), st, (const u64*)sa[k].p, (u64*)da[k].p,
+                   (const i64*)nullptr, (const unsigned char*)mask, w);
     }
+    if (rc == hipSuccess) rc = hipGetLastError();
     if (rc == hipSuccess) rc = hipStreamSynchronize(st);
+    (void)hipFree(mask);
     SMC_HIP_CHECK(rc);
     dst->perm_t = t;
+    return SMC_OK;
+}
+
+// ---- SMC^2: the theta level (see k_theta_update) -------------------------------------------
+int smc_filter_theta_enable(smc_filter* f, double ess_rmin)
+{
+    SMC_REQUIRE(f, "null filter");
+    SMC_REQUIRE(!f->a.hist && !f->a.mom, "the theta level is not available with keep_history / moments");
+    SMC_HIP_CHECK(hipSetDevice(f->ctx->device));
+    const size_t M = (size_t)f->a.n_islands, T = (size_t)f->a.T;
+    if (!f->th_buf) SMC_HIP_CHECK(hipMalloc(&f->th_buf, (M + TH_STRIDE + T) * 8));
+    SMC_HIP_CHECK(hipMemsetAsync(f->th_buf, 0, (M + TH_STRIDE + T) * 8, f->ctx->stream));
+    f->lwth = (double*)f->th_buf;
+    f->th = f->lwth + M;
+    f->th_ess = f->th + TH_STRIDE;
+    f->th_ess_min = ess_rmin * (double)M;
+    // (enabled on a batch that has already run t steps -- the exchange step: the theta weights
+    //  start at zero, or at what smc_filter_theta_resume sets, and account for steps >= t)
+    const double done = (double)f->t_host;
+    SMC_HIP_CHECK(hipMemcpyAsync(f->th + 2, &done, 8, hipMemcpyHostToDevice, f->ctx->stream));
+    SMC_HIP_CHECK(hipStreamSynchronize(f->ctx->stream));
+    return SMC_OK;
+}
+
+int smc_filter_theta_state(smc_filter* f, double* lw_theta_host, int64_t* stop_t, int64_t* steps_done,
+                           double* ess_host)
+{
+    SMC_REQUIRE(f && f->lwth, "the theta level is not enabled");
+    hipStream_t st = f->ctx->stream;
+    double th[TH_STRIDE];
+    SMC_HIP_CHECK(hipMemcpyAsync(th, f->th, sizeof th, hipMemcpyDeviceToHost, st));
+    if (lw_theta_host)
+        SMC_HIP_CHECK(hipMemcpyAsync(lw_theta_host, f->lwth, (size_t)f->a.n_islands * 8, hipMemcpyDeviceToHost, st));
+    SMC_HIP_CHECK(hipStreamSynchronize(st));
+    if (stop_t) *stop_t = (int64_t)th[0];
+    if (steps_done) *steps_done = (int64_t)th[2];
+    if (ess_host && th[2] > 0) {
+        SMC_HIP_CHECK(hipMemcpyAsync(ess_host, f->th_ess, (size_t)th[2] * 8, hipMemcpyDeviceToHost, st));
+        SMC_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    return SMC_OK;
+}
+
+// After a stop: new theta log-weights (null: zeros -- the outer resampling, core.py:299-305),
+// the time records back to the stop step, the host's step count with them; the filter then
+// continues from there.  Also valid when nothing stopped (lw_theta replaced, time unchanged).
+int smc_filter_theta_resume(smc_filter* f, const double* lw_theta_host)
+{
+    SMC_REQUIRE(f && f->lwth, "the theta level is not enabled");
+    SMC_HIP_CHECK(hipSetDevice(f->ctx->device));
+    hipStream_t st = f->ctx->stream;
+    double th[TH_STRIDE];
+    SMC_HIP_CHECK(hipMemcpyAsync(th, f->th, sizeof th, hipMemcpyDeviceToHost, st));
+    SMC_HIP_CHECK(hipStreamSynchronize(st));
+    if (lw_theta_host)
+        SMC_HIP_CHECK(hipMemcpyAsync(f->lwth, lw_theta_host, (size_t)f->a.n_islands * 8, hipMemcpyHostToDevice, st));
+    else
+        SMC_HIP_CHECK(hipMemsetAsync(f->lwth, 0, (size_t)f->a.n_islands * 8, st));
+    if (th[0] != 0.0) {
+        SMC_LAUNCH(k_theta_thaw, dim3(1), dim3(SMC_BLOCK), st, f->a, f->th, th[0]);
+        SMC_LAUNCH_CHECK();
+        f->t_host = (i64)th[0];
+    }
+    SMC_HIP_CHECK(hipStreamSynchronize(st));
     return SMC_OK;
 }
 

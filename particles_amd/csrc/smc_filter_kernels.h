@@ -1655,7 +1655,7 @@ k_flush2(const FArgs av)
     __shared__ double smd[SMC_SM];
     const int isl = (int)blockIdx.x;
     const i64 t = (i64)smc_uniform(smc_ldg(a.info2 + (i64)isl * INFO_STRIDE));       // steps done
-    if (t <= 0) return;
+    if (t <= 0 || t > a.T) return;                      // (t > T: records frozen by k_theta_update)
     const F2Red r = f2_reduce_island(a, isl, smd);
     if (threadIdx.x == 0) f2_write_row(a, isl, t - 1, r);
 }
@@ -1708,6 +1708,77 @@ k_f_restate(const FArgs av, const i64 ts)
         const double* row = a.summ + ((i64)isl * (a.T + 1) + ts) * SUMM_STRIDE;
         f_finalise_step(a, isl, ts, ts == 0, row[4] != 0.0, g, a.info + (i64)isl * INFO_STRIDE);
     }
+}
+
+// ---------------------------------------------------------------------------
+// SMC^2 (smc_samplers.py:1038-1167), theta level on the device.  Every island is the particle
+// filter of one theta-particle; after each time step the theta-weights pick up the islands'
+// evidence increments, lw_theta[i] += log p(y_t | y_{0:t-1}, theta_i) (SMC2.logG, :1099-1120), and
+// the theta-level ESS decides whether a resample-move step is due (core.py:181-183 applied to the
+// outer SMC).  When it is, the kernel FREEZES the batch: it records the step at which to stop and
+// pushes the device-resident time index of every island past T, so that the steps the host has
+// already enqueued behind it return at once -- the host enqueues K steps at a time and looks at
+// the stop record once per K, instead of synchronising after every step.
+// One workgroup.  th: [0] stop step (0 = running), [1] theta-ESS, [2] steps accounted for,
+// [3] log-mean-exp of lw_theta before the last resampling (evidence bookkeeping: unused here).
+// ---------------------------------------------------------------------------
+#define TH_STRIDE 8
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_theta_update(const FArgs av, double* lwth, double* th, double* ess_log, const double ess_min, const int two_level)
+{
+    const FArgs& a = av;
+    __shared__ double smd[SMC_SM];
+    const int tid = (int)threadIdx.x, M = a.n_islands;
+    if (th[0] != 0.0) return;                                  // frozen: waiting for the host
+    const i64 t = (i64)th[2];                                  // the step just done
+    if (t >= a.T) return;
+    // did the step really run?  (the filter's own record says how many steps are done)
+    const double done = two_level ? a.info2[0] : a.info[0];
+    if ((i64)done < t + 1) return;
+    SmcLse acc = smc_lse_empty();
+    for (int i = tid; i < M; i += SMC_BLOCK) {
+        const double inc = a.summ[((i64)i * (a.T + 1) + t) * SUMM_STRIDE + 2];      // loglt of step t
+        double l = lwth[i] + inc;
+        if (l != l) l = -INFINITY;
+        lwth[i] = l;
+        smc_lse_push(acc, l);
+    }
+    const SmcLse g = smc_lse_block(acc, smd);
+    if (tid == 0) {
+        const double ess = (g.s * g.s) / g.ss;
+        th[1] = ess;
+        th[2] = (double)(t + 1);
+        ess_log[t] = ess;
+    }
+    const bool stop = !((g.s * g.s) / g.ss >= ess_min) && t + 1 < a.T;
+    if (!stop) return;
+    if (tid == 0) th[0] = (double)(t + 1);
+    for (int i = tid; i < M; i += SMC_BLOCK) {                 // freeze: every kernel returns on t >= T
+        a.info[(i64)i * INFO_STRIDE] = 1e18;
+        a.info2[(i64)i * INFO_STRIDE] = 1e18;
+    }
+}
+// thaw: the time records back to step t (after the host has dealt with the stop)
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_theta_thaw(const FArgs av, double* th, const double t)
+{
+    const FArgs& a = av;
+    for (int i = (int)threadIdx.x; i < a.n_islands; i += SMC_BLOCK) {
+        a.info[(i64)i * INFO_STRIDE] = t;
+        a.info2[(i64)i * INFO_STRIDE] = t;
+    }
+    if (threadIdx.x == 0) { th[0] = 0.0; th[2] = t; }
+}
+// out[i][:] = in[src[i]][:] (src == null: identity) where keep == null or keep[i] != 0, for a
+// per-island array of `words` 8-byte words per island; grid (chunks, islands)
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_island_gather(const u64* in, u64* out, const i64* src, const unsigned char* keep, i64 words)
+{
+    const i64 i = (i64)blockIdx.y;
+    if (keep && !keep[i]) return;
+    const i64 s_ = src ? src[i] : i;
+    for (i64 w = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x; w < words; w += (i64)gridDim.x * SMC_BLOCK)
+        out[i * words + w] = in[s_ * words + w];
 }
 
 // W = exp(lw - m)/s for one island (SMC.W)

@@ -44,6 +44,7 @@ k_filter_small(const FArgs av, const int nsteps)
     const bool vec = (N & 3) == 0;
 
     i64 t = (i64)smc_uniform(smc_ldg(info));
+    if (t >= a.T) return;                                  // done, or frozen by k_theta_update
     bool resample = smc_uniform(smc_ldg(info + 1)) != 0.0;
     double m = smc_uniform(smc_ldg(info + 3)), rs = smc_uniform(smc_ldg(info + 4));
     double prev_log_mean = 0.0, prev_logLt = 0.0;          // of step t-1 (core.py:355-359)

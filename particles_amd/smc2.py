@@ -1,0 +1,236 @@
+"""SMC^2 (Chopin, Jacob & Papaspiliopoulos 2013; particles/smc_samplers.py:1038-1167) with the
+theta level on the device.
+
+N_theta parameter particles, each carrying a particle filter of N_x state particles: here ALL of
+them are islands of ONE device-resident filter, and the outer loop over time costs no host
+round trip per step:
+
+* `SMC2.logG` (smc_samplers.py:1099-1120: ``next(pf)`` for every theta, ``lpyt[m] = pf.loglt``) is one
+  batched step launch plus `k_theta_update`, which adds the islands' evidence increments to the
+  theta log-weights and evaluates the theta-level ESS **on the device**;
+* when the ESS drops below ``ESSrmin * N_theta`` (core.py:181-183 for the outer SMC) the kernel
+  freezes the batch; the host enqueues ``sync_every`` steps per synchronisation and only deals
+  with the resample-move events;
+* theta-level resampling of whole filters (`FancyList` deep copies, smc_samplers.py:319-361) is
+  `smc_filter_permute_islands`; the PMCMC move (`current_target`, :1129-1143: re-run every
+  filter from 0 to t on the proposed theta) is a second batch stepped to t in one call and
+  `smc_filter_copy_islands` for the accepted ones;
+* the exchange step (:1159-1163, N_x doubled when the acceptance rate is low) is a new batch
+  with 2 N_x particles run to t, the theta-weights picking up the ratio of the two evidences.
+
+The MCMC kernel is a Gaussian random walk on theta with covariance (2.38^2 / d) x the weighted
+covariance of the theta-particles, ``nmcmc`` sweeps (the reference's default is its waste-free
+variant, smc_samplers.py:596-700; the standard resample-move form is what is implemented here).
+The prior is any object with ``rvs(size) -> {name: array}`` (or a structured array) and
+``logpdf(theta) -> array``; `IndepPrior` covers independent scalar laws.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from . import resampling as rs
+from . import state_space_models as ssm
+from ._lib import check, lib
+from .core import SMC
+
+
+class IndepPrior:
+    """Independent scalar priors, host side: ``IndepPrior(sigma=("lognormal", -0.7, 0.5),
+    rho=("uniform", 0.0, 1.0))``.  Laws: normal(mu, sd), lognormal(mu, sd), uniform(a, b),
+    gamma(shape, rate), beta(a, b)."""
+
+    def __init__(self, **laws):
+        self.laws = dict(laws)
+        self.names = list(self.laws)
+
+    def rvs(self, size, rng=None):
+        rng = np.random if rng is None else rng
+        out = {}
+        for k, (kind, a, b) in self.laws.items():
+            if kind == "normal":
+                out[k] = a + b * rng.standard_normal(size)
+            elif kind == "lognormal":
+                out[k] = np.exp(a + b * rng.standard_normal(size))
+            elif kind == "uniform":
+                out[k] = a + (b - a) * rng.random_sample(size)
+            elif kind == "gamma":
+                out[k] = rng.gamma(a, 1.0 / b, size)
+            elif kind == "beta":
+                out[k] = rng.beta(a, b, size)
+            else:
+                raise ValueError("unknown law %r" % kind)
+        return out
+
+    def logpdf(self, theta):
+        from scipy import stats
+        lp = 0.0
+        for k, (kind, a, b) in self.laws.items():
+            v = np.asarray(theta[k], dtype=float)
+            if kind == "normal":
+                lp = lp + stats.norm.logpdf(v, a, b)
+            elif kind == "lognormal":
+                with np.errstate(invalid="ignore", divide="ignore"):
+                    lp = lp + np.where(v > 0, stats.norm.logpdf(np.log(np.where(v > 0, v, 1.0)), a, b)
+                                       - np.log(np.where(v > 0, v, 1.0)), -np.inf)
+            elif kind == "uniform":
+                lp = lp + np.where((v >= a) & (v <= b), -np.log(b - a), -np.inf)
+            elif kind == "gamma":
+                lp = lp + stats.gamma.logpdf(v, a, scale=1.0 / b)
+            elif kind == "beta":
+                lp = lp + stats.beta.logpdf(v, a, b)
+        return lp
+
+
+def _as_dict(theta):
+    if isinstance(theta, dict):
+        return {k: np.asarray(v, dtype=float) for k, v in theta.items()}
+    return {k: np.asarray(theta[k], dtype=float) for k in theta.dtype.names}
+
+
+class SMC2:
+    """``SMC2(ssm_cls, prior, data, init_Nx, N)``: N theta-particles x init_Nx state particles.
+
+    ssm_cls : a model class of the fused family (``ssm_cls(**theta)``), e.g. ``kalman.LinearGauss``
+    prior   : rvs(size) / logpdf(theta), theta a dict (or structured array) of scalar parameters
+    fk_cls  : ``Bootstrap`` (default) or ``GuidedPF``
+    ESSrmin : theta-level resampling threshold; nmcmc: random-walk sweeps per move step
+    ar_to_increase_Nx : double N_x (exchange step) when the acceptance rate falls below it (< 0: never)
+    sync_every : time steps enqueued per host synchronisation
+    """
+
+    def __init__(self, ssm_cls=None, prior=None, data=None, init_Nx=100, N=100, fk_cls=None, ESSrmin=0.5,
+                 nmcmc=3, ar_to_increase_Nx=-1.0, smc_options=None, seed=None, sync_every=16, max_Nx=1 << 16):
+        self.ssm_cls, self.prior, self.data = ssm_cls, prior, list(data)
+        self.fk_cls = ssm.Bootstrap if fk_cls is None else fk_cls
+        self.N, self.Nx, self.ESSrmin, self.nmcmc = int(N), int(init_Nx), ESSrmin, int(nmcmc)
+        self.ar_to_increase_Nx, self.max_Nx = ar_to_increase_Nx, max_Nx
+        self.smc_options = dict(smc_options or {})
+        self.sync_every = int(sync_every)
+        self.rng = np.random.RandomState(seed)
+        self._seed = int(self.rng.randint(1, 2 ** 31 - 1))
+        self.T = len(self.data)
+        self.t = 0
+        self.theta = _as_dict(prior.rvs(self.N, rng=self.rng) if isinstance(prior, IndepPrior)
+                              else prior.rvs(size=self.N))
+        self.names = list(self.theta)
+        self.lw = np.zeros(self.N)
+        self.logLt = 0.0                 # log evidence of the whole model (outer SMC, core.py:351-359)
+        self.ESSs, self.Nxs, self.acc_rates, self.move_times = [], [self.Nx], [], []
+        self._nbatch = 0
+        self._lw_at_reset = np.zeros(self.N)
+        self.pf = self._batch(self.theta, self.Nx, theta_level=True)
+
+    # ------------------------------------------------------------------ batches of filters
+    def _batch(self, theta, Nx, theta_level=False):
+        fks = [self.fk_cls(ssm=self.ssm_cls(**{k: float(theta[k][i]) for k in self.names}), data=self.data)
+               for i in range(self.N)]
+        self._nbatch += 1
+        pf = SMC(fk=fks, N=Nx, seed=(self._seed + 7919 * self._nbatch) % (2 ** 31 - 1), collect="off",
+                 **self.smc_options)
+        if not pf._fused:
+            raise ValueError("SMC2 needs a state-space model of the fused family")
+        if theta_level:
+            check(lib().smc_filter_theta_enable(pf._f, float(self.ESSrmin)))
+        return pf
+
+    def _theta_state(self, pf):
+        lw = np.empty(self.N)
+        stop, done = ctypes.c_int64(0), ctypes.c_int64(0)
+        ess = np.zeros(self.T)
+        check(lib().smc_filter_theta_state(pf._f, lw.ctypes.data_as(_lib.c_vp), ctypes.byref(stop),
+                                           ctypes.byref(done), ess.ctypes.data_as(_lib.c_vp)))
+        return lw, int(stop.value), int(done.value), ess
+
+    @property
+    def W(self):
+        w = np.exp(self.lw - self.lw.max())
+        return w / w.sum()
+
+    def _log_mean(self, lw):
+        m = lw.max()
+        return m + np.log(np.mean(np.exp(lw - m)))
+
+    # ------------------------------------------------------------------ the outer loop
+    def run(self):
+        while self.t < self.T:
+            k = min(self.sync_every, self.T - self.t)
+            self.pf.step_async(k)
+            lw, stop, done, ess = self._theta_state(self.pf)
+            t_new = stop if stop else done
+            self.ESSs.extend(ess[self.t:t_new].tolist())
+            # evidence of the whole model: log-mean of the theta weights since the last reset
+            self.lw = lw
+            self.t = t_new
+            self.pf.t = self.pf._n = t_new
+            self.pf._invalidate()
+            if stop:
+                self._resample_move()
+        self.logLt += self._log_mean(self.lw) - self._log_mean(self._lw_at_reset)
+        return self
+
+    def _resample_move(self):
+        import time
+        t0 = time.perf_counter()
+        # ---- outer evidence up to here, then theta-level resampling (core.py:326-337)
+        self.logLt += self._log_mean(self.lw) - self._log_mean(self._lw_at_reset)
+        W = self.W
+        np_state = np.random.get_state()
+        np.random.seed(self.rng.randint(0, 2 ** 31 - 1))
+        A = np.asarray(rs.systematic(W, M=self.N))
+        np.random.set_state(np_state)
+        mean = {k: float(np.sum(W * v)) for k, v in self.theta.items()}
+        X = np.stack([self.theta[k] for k in self.names], axis=1)
+        mu = np.array([mean[k] for k in self.names])
+        cov = (X - mu).T @ ((X - mu) * W[:, None])
+        d = len(self.names)
+        L = np.linalg.cholesky((2.38 ** 2 / d) * cov + 1e-12 * np.eye(d))
+        # resume first (time records back to t), then move the islands
+        check(lib().smc_filter_theta_resume(self.pf._f, None))
+        self.pf.permute_islands(A)
+        self.theta = {k: v[A].copy() for k, v in self.theta.items()}
+        self.lw = np.zeros(self.N)
+        self._lw_at_reset = np.zeros(self.N)
+        # ---- PMCMC move (smc_samplers.py:1129-1143): candidates re-run from 0 to t
+        lp_cur = np.asarray(self.prior.logpdf(self.theta), dtype=float) + self.pf.logLts_islands
+        acc_rate = 0.0
+        for sweep in range(self.nmcmc):
+            Z = self.rng.standard_normal((self.N, d)) @ L.T
+            prop = {k: self.theta[k] + Z[:, j] for j, k in enumerate(self.names)}
+            with np.errstate(all="ignore"):
+                lprior = np.asarray(self.prior.logpdf(prop), dtype=float)
+            ok = np.isfinite(lprior)
+            safe = {k: np.where(ok, prop[k], self.theta[k]) for k in self.names}   # a valid model for every island
+            cand = self._batch(safe, self.Nx)
+            cand.step_async(self.t)
+            lp_prop = np.where(ok, lprior + cand.logLts_islands, -np.inf)
+            acc = np.log(self.rng.random_sample(self.N)) < lp_prop - lp_cur
+            acc &= ok
+            self.pf.accept_islands_from(cand, acc)
+            self.theta = {k: np.where(acc, prop[k], self.theta[k]) for k in self.names}
+            lp_cur = np.where(acc, lp_prop, lp_cur)
+            acc_rate = float(np.mean(acc))
+            self.acc_rates.append(acc_rate)
+            del cand
+        # ---- exchange step (smc_samplers.py:1159-1163): more state particles when moves get rejected
+        if 0.0 <= acc_rate < self.ar_to_increase_Nx and 2 * self.Nx <= self.max_Nx:
+            new = self._batch(self.theta, 2 * self.Nx)
+            new.step_async(self.t)
+            liw = np.ascontiguousarray(new.logLts_islands - self.pf.logLts_islands)
+            check(lib().smc_filter_theta_enable(new._f, float(self.ESSrmin)))       # from step t on
+            check(lib().smc_filter_theta_resume(new._f, liw.ctypes.data_as(_lib.c_vp)))
+            self.pf = new
+            self.Nx *= 2
+            self.lw = liw.copy()
+            self._lw_at_reset = np.zeros(self.N)       # E[exp(liw)] = 1 under the extended target
+        self.Nxs.append(self.Nx)
+        self.move_times.append(time.perf_counter() - t0)
+
+    # ------------------------------------------------------------------ summaries
+    def posterior_mean(self):
+        W = self.W
+        return {k: float(np.sum(W * v)) for k, v in self.theta.items()}
+
+    def posterior_sd(self):
+        W, m = self.W, self.posterior_mean()
+        return {k: float(np.sqrt(np.sum(W * (v - m[k]) ** 2))) for k, v in self.theta.items()}

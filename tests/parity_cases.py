@@ -1273,6 +1273,54 @@ def check_mv_collapsed(N, d, T=6):
         assert "collapsed" not in describe(e) and np.isfinite(e.logLt)
 
 
+def check_smc2(Ntheta=64, Nx=128, T=30, seed=3):
+    """SMC^2 with the theta level on the device (particles_amd.smc2, smc_samplers.py:1038-1167).
+    (1) With the theta-level ESS threshold at 0 nothing ever stops: the device's theta weights
+    must then BE the islands' log-evidences, whatever the number of steps enqueued per sync.
+    (2) A full run: resample-move events happen, are dealt with at the right step (a frozen batch
+    does no step beyond the stop), the filters of all thetas stay in lock step, the posterior of
+    the unknown parameter covers the value the data were simulated with, the evidence of the
+    whole model is finite; (3) the exchange step doubles N_x and keeps going."""
+    from particles_amd import smc2
+    rng = np.random.RandomState(seed)
+    sig = 0.3
+    x = np.cumsum(rng.standard_normal(T))
+    y = [np.array([v]) for v in x + sig * rng.standard_normal(T)]
+    prior = smc2.IndepPrior(sigmaY=("lognormal", np.log(0.5), 0.5))
+    mk = lambda **kw: smc2.SMC2(ssm_cls=lambda sigmaY: kalman.LinearGauss(rho=1.0, sigmaX=1.0, sigmaY=sigmaY,
+                                                                          sigma0=1.0),
+                                prior=prior, data=y, init_Nx=Nx, N=Ntheta, seed=seed, **kw)
+    # (1)
+    a = mk(ESSrmin=0.0, sync_every=7)
+    a.run()
+    assert a.t == T and not a.move_times
+    assert np.array_equal(a.lw, a.pf.logLts_islands)
+    b = mk(ESSrmin=0.0, sync_every=T)
+    b.run()
+    assert np.array_equal(a.lw, b.lw) and a.logLt == b.logLt
+    # the theta-level ESS the device logged is the ESS of those weights
+    s = a.pf._summ()                                               # (Ntheta, T, 5)
+    lwt = np.cumsum(s[:, :, 2], axis=1)
+    for t in (0, T // 2, T - 1):
+        w = np.exp(lwt[:, t] - lwt[:, t].max())
+        assert abs(a.ESSs[t] / (w.sum() ** 2 / np.sum(w ** 2)) - 1) < 1e-12
+    # (2)
+    c = mk(ESSrmin=0.5, sync_every=5, nmcmc=2)
+    c.run()
+    assert c.t == T and len(c.move_times) >= 1 and np.isfinite(c.logLt)
+    assert len(c.ESSs) == T and c.pf.t == T
+    m, sd = c.posterior_mean()["sigmaY"], c.posterior_sd()["sigmaY"]
+    assert 0.05 < m < 1.5 and abs(m - sig) < 4 * sd + 0.15, (m, sd)
+    assert all(0.0 <= r <= 1.0 for r in c.acc_rates) and len(c.acc_rates) == 2 * len(c.move_times)
+    # every island of the surviving batch is at step T with a finite evidence
+    assert np.all(np.isfinite(c.pf.logLts_islands))
+    # (3) exchange step: every move is "rejected too often" -> N_x doubles (once: max_Nx)
+    e = mk(ESSrmin=0.5, sync_every=4, nmcmc=1, ar_to_increase_Nx=1.01, max_Nx=2 * Nx)
+    e.run()
+    assert e.t == T and e.Nx == 2 * Nx and e.pf.N == 2 * Nx and np.isfinite(e.logLt)
+    assert abs(e.posterior_mean()["sigmaY"] - sig) < 0.3
+
+
 def check_generic_path(golden):
     """A user-defined FeynmanKac in Python: template method with device ops."""
     g = golden("kalman_toy")

@@ -234,3 +234,7 @@ def test_mv_collapsed_proposal():
 
 def test_device_sort():
     pc.check_device_sort()
+
+
+def test_smc2_device_theta_level():
+    pc.check_smc2()

@@ -443,3 +443,7 @@ def test_rccl_two_ranks_one_gpu(tmp_path):
 
 def test_device_sort():
     pc.check_device_sort(sizes=(1, 64, 2049, 50001, (1 << 20) + 3, 1 << 22))
+
+
+def test_smc2_device_theta_level():
+    pc.check_smc2(Ntheta=256, Nx=512, T=60)
