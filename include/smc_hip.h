@@ -278,7 +278,9 @@ typedef struct smc_filter_opts {
     int32_t rng_mode;         /* smc_rng_mode */
     int32_t use_graph;        /* 1: replay the step loop from a hipGraph */
     int32_t island_offset;    /* global index of this filter's island 0 (multi-GPU sharding) */
-    int32_t keep_history;     /* 1: X, A, lw of EVERY step stay resident -- the step loop writes step t
+    int32_t keep_history;     /* k >= 2: the k most recent steps stay resident in a ring of k slots
+                               * (RollingParticleHistory, smoothing.py:186-207: k (8 dx + 12) B per particle);
+                               * 1: X, A, lw of EVERY step stay resident -- the step loop writes step t
                                * into slot t of (T, n_islands, N[, dx]) arrays instead of alternating
                                * between two (ParticleHistory.save, smoothing.py:181-207, at no extra
                                * traffic); needs T*n_islands*N*(8 dx + 16) bytes of HBM */

@@ -234,6 +234,70 @@ class DeviceParticleHistory:
         return [row[0] if d == 1 else row.copy() for row in out]
 
 
+class DeviceRollingParticleHistory:
+    """``RollingParticleHistory`` (smoothing.py:186-219) of a fused run: the k most recent
+    particle systems stay in a ring of k slots in HBM (``keep_history = k``), the step loop writes
+    them there, ``save`` has nothing to do.  ``X``, ``A``, ``wgts`` behave like the reference's
+    deques: index 0 is the oldest resident step, -1 the newest."""
+
+    def __init__(self, smc, length):
+        self._smc, self.length = smc, int(length)
+        self.fk = smc.fk
+        self.X = _Window(self, lambda t: smc._history(_lib.FIELD_X, t))
+        self.A = _Window(self, self._A_at)
+        self.wgts = _Window(self, lambda t: DeviceParticleHistory._wgts_at(self, t))
+
+    def _A_at(self, t):
+        smc = self._smc
+        if t == 0:
+            return None                                    # core.py:229: no ancestors at t = 0
+        if t - 1 < smc._n - self.length:                   # its parents' step has left the window:
+            s = smc._summ()[0, t]                          # the indices themselves are still there
+            if not s[4]:
+                return np.arange(smc.N)
+        return smc._history(_lib.FIELD_A, t)
+
+    @property
+    def N(self):
+        return self._smc.N
+
+    @property
+    def T(self):
+        return min(self._smc._n, self.length)
+
+    def save(self, smc):
+        pass
+
+    def compute_trajectories(self):
+        """(T, N) genealogy of the resident steps (smoothing.py:209-219), on the device."""
+        out = np.empty((self.T, self.N), dtype=np.int64)
+        _lib.check(_lib.lib().smc_filter_trajectories(self._smc._f, 0, out.ctypes.data_as(_lib.P(_lib.c_i64))))
+        return out
+
+
+class _Window:
+    """deque-like view of the resident steps of a rolling device history."""
+
+    def __init__(self, hist, fetch):
+        self._h, self._fetch = hist, fetch
+
+    def __len__(self):
+        return self._h.T
+
+    def __getitem__(self, i):
+        n = len(self)
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(n))]
+        if i < 0:
+            i += n
+        if not 0 <= i < n:
+            raise IndexError("history index out of range")
+        return self._fetch(self._h._smc._n - n + i)
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
 class _Frozen:
     pass
 

@@ -183,10 +183,15 @@ class SMC:
         if self._fused:
             # full history on the fused path stays on the device: the step loop
             # writes step t into slot t (no per-step host copies, no per-step sync)
-            self._device_hist = store_history is True
+            rolling = (isinstance(store_history, int) and not isinstance(store_history, bool)
+                       and store_history >= 2)
+            self._device_hist = store_history is True or rolling
+            self._keep_history = int(store_history) if rolling else (1 if store_history is True else 0)
             self._create_filter(model, replay, use_graph, island_offset)
-            if self._device_hist:
+            if store_history is True:
                 self.hist = collectors.DeviceParticleHistory(self)
+            elif rolling:       # RollingParticleHistory on the device: a ring of k slots
+                self.hist = collectors.DeviceRollingParticleHistory(self, store_history)
         else:
             if n_islands != 1:
                 raise ValueError("n_islands > 1 needs a model of the fused family")
@@ -257,7 +262,7 @@ class SMC:
         o.rng_mode = 1 if replay is not None else 0
         o.use_graph = 1 if use_graph else 0
         o.island_offset = island_offset
-        o.keep_history = 1 if self._device_hist else 0
+        o.keep_history = self._keep_history
         o.moments = 1 if self._device_moments else 0
         o.flags = _lib.FLAG_COLLAPSED_PROPOSAL if self._collapsed else 0
         self._ctx = _lib.ctx()

@@ -30,7 +30,8 @@ struct smc_filter {
     std::vector<hipEvent_t> ev;
     int prof_n;
     double* tmp;           // (N,) staging for W / Xp downloads
-    double* ll_stage;      // (n_islands,) staging for smc_filter_logLt
+    double* ll_stage;      // (n_islands,) staging for smc_filter_logLt: PINNED host memory the
+                           // collect kernel writes straight into (no copy engine, no staging)
     // SMC^2 theta level (smc_filter_theta_enable): theta log-weights, stop record, ESS log
     double *lwth, *th, *th_ess;
     double th_ess_min;
@@ -216,13 +217,15 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o0 = off; off = smc_align_up(off + bytes, 256); return o0; };
     a.dx = dxm; a.dy = dym; a.dp = dpm;
-    a.hist = o->keep_history != 0;
-    const size_t nslots = a.hist ? T : 2;
+    SMC_REQUIRE(o->keep_history >= 0, "keep_history must be 0, 1 or a window length >= 2");
+    a.hist = o->keep_history;                      // 0 / 1 (whole history) / k >= 2 (rolling window)
+    if (a.hist >= 2 && (size_t)a.hist >= T) a.hist = 1;      // a window as long as the run: all of it
+    const size_t nslots = a.hist == 1 ? T : (a.hist >= 2 ? (size_t)a.hist : 2);
     a.xslot = (i64)(M * N * dxm);
     a.lslot = (i64)(M * N);
     const size_t oX0 = carve(nslots * M * N * dxm * 8);
     const size_t oL0 = carve(nslots * M * N * 8);
-    const size_t oA = carve((a.hist ? T : 1) * M * N * 4);
+    const size_t oA = carve((a.hist ? nslots : 1) * M * N * 4);
     // (published tile totals pay off only while every workgroup of the launch is resident)
     f->fused = (i64)a.ntiles * (i64)M <= F_DIRECT_PREFIX_MAX;
     if (getenv("SMC_FORCE_FUSED")) f->fused = a.ntiles <= F_DIRECT_PREFIX_MAX;   // experiments
@@ -252,7 +255,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     const size_t oInfo2 = carve(M * INFO_STRIDE * 8);
     // two-level CDF: closed-form offspring counts (N = 2^k, systematic / stratified), at most
     // 1024 tiles per island (4 partials per thread), at least 2 (below, the one-workgroup filter)
-    f->two_level = !mv && !o->moments && a.log2N >= 0 && a.ntiles >= 2 &&
+    f->two_level = !mv && !o->moments && a.log2N >= 0 && a.log2N <= 30 && a.ntiles >= 2 &&
                    (o->scheme == SMC_SYSTEMATIC || o->scheme == SMC_STRATIFIED) &&
                    !getenv("SMC_FLAT_CDF") && !getenv("SMC_FORCE_FUSED") && !getenv("SMC_FORCE_UNFUSED");
     // every workgroup reduces the partials itself while the launch is resident and an island has
@@ -266,7 +269,6 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     const size_t oSu = carve(need_su ? M * N * 8 : 8);
     const size_t oE = carve(need_su ? M * a.ntiles1 * 8 : 8);
     const size_t oTmp = carve(N * dxm * 8);
-    const size_t oLL = carve(M * 8);
     a.nmb = (int)((o->N + F_MOM_CHUNK - 1) / F_MOM_CHUNK);
     const size_t oMom = carve(o->moments ? M * T * 2 * dxm * 8 : 8);
     const size_t oMpart = carve(o->moments ? M * a.nmb * dxm * 3 * 8 : 8);
@@ -321,7 +323,9 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     a.su = (double*)(base + oSu);
     a.E = (u64*)(base + oE);
     f->tmp = (double*)(base + oTmp);
-    f->ll_stage = (double*)(base + oLL);
+    f->ll_stage = nullptr;
+    if (hipHostMalloc((void**)&f->ll_stage, M * 8, hipHostMallocMapped) != hipSuccess) f->ll_stage = nullptr;
+    (void)hipGetLastError();
     if (o->moments) {
         a.mom = (double*)(base + oMom);
         a.mpart = (double*)(base + oMpart);
@@ -392,6 +396,7 @@ int smc_filter_destroy(smc_filter* f)
         if (g) (void)hipGraphExecDestroy(g);
     for (hipEvent_t e : f->ev) (void)hipEventDestroy(e);
     (void)hipFree(f->slab);
+    if (f->ll_stage) (void)hipHostFree(f->ll_stage);
     if (f->th_buf) (void)hipFree(f->th_buf);
     delete f;
     return SMC_OK;
@@ -562,14 +567,17 @@ int smc_filter_logLt(smc_filter* f, double* out_host)
     for (int i = 0; i < M; ++i) out_host[i] = 0.0;
     if (t == 0) return SMC_OK;
     hipStream_t st = f->ctx->stream;
-    if (M == 1) {
-        SMC_HIP_CHECK(hipMemcpyAsync(out_host, f->a.summ + (size_t)(t - 1) * SUMM_STRIDE + 3, 8,
-                                     hipMemcpyDeviceToHost, st));
-    } else {
+    if (f->ll_stage) {
+        // the kernel writes into pinned host memory: one launch + one (spinning) stream sync
         SMC_LAUNCH(k_f_collect_logLt, dim3((M + 255) / 256), dim3(256), st, f->a.summ, T, t, M, f->ll_stage);
         SMC_LAUNCH_CHECK();
-        SMC_HIP_CHECK(hipMemcpyAsync(out_host, f->ll_stage, (size_t)M * 8, hipMemcpyDeviceToHost, st));
+        SMC_HIP_CHECK(hipStreamSynchronize(st));
+        memcpy(out_host, f->ll_stage, (size_t)M * 8);
+        return SMC_OK;
     }
+    for (int i = 0; i < M; ++i)
+        SMC_HIP_CHECK(hipMemcpyAsync(out_host + i, f->a.summ + ((size_t)i * (T + 1) + (t - 1)) * SUMM_STRIDE + 3, 8,
+                                     hipMemcpyDeviceToHost, st));
     SMC_HIP_CHECK(hipStreamSynchronize(st));
     return SMC_OK;
 }
@@ -894,6 +902,15 @@ int smc_filter_history(smc_filter* f, int field, int64_t step, int island, void*
                       (long long)f->t_host);
         return SMC_ERR_STATE;
     }
+    if (f->a.hist >= 2) {          // rolling window: the f->a.hist most recent steps are resident
+        const i64 oldest = f->t_host - f->a.hist;
+        const bool needs_prev = field == SMC_FIELD_XP;         // Xp gathers from step - 1
+        if (step < oldest || (needs_prev && step - 1 < oldest && step > 0)) {
+            smc_set_error("smc_filter_history: step %lld has left the rolling window of %d steps",
+                          (long long)step, f->a.hist);
+            return SMC_ERR_STATE;
+        }
+    }
     return filter_fetch(f, field, step, island, out_host);
 }
 
@@ -916,20 +933,24 @@ int smc_filter_trajectories(smc_filter* f, int island, int64_t* out_host)
     SMC_HIP_CHECK(hipMemcpyAsync(rows.data(), f->a.summ + (size_t)island * (T + 1) * SUMM_STRIDE,
                                  rows.size() * 8, hipMemcpyDeviceToHost, st));
     SMC_HIP_CHECK(hipStreamSynchronize(st));
+    // rolling window: the genealogy of the resident steps only (RollingParticleHistory,
+    // smoothing.py:209-219 over its deque); out_host then holds min(t, window) rows
+    const i64 first = (f->a.hist >= 2 && t > f->a.hist) ? t - f->a.hist : 0;
+    const i64 nrows = t - first;
     i64* B = nullptr;
-    hipError_t e = hipMalloc((void**)&B, (size_t)t * N * 8);
+    hipError_t e = hipMalloc((void**)&B, (size_t)nrows * N * 8);
     if (e != hipSuccess) {
-        smc_set_error("smc_filter_trajectories: %zu bytes: %s", (size_t)t * N * 8, hipGetErrorString(e));
+        smc_set_error("smc_filter_trajectories: %zu bytes: %s", (size_t)nrows * N * 8, hipGetErrorString(e));
         return SMC_ERR_NOMEM;
     }
     const dim3 grid((unsigned)((N + SMC_BLOCK - 1) / SMC_BLOCK));
-    SMC_LAUNCH(k_f_iota, grid, dim3(SMC_BLOCK), st, N, B + (size_t)(t - 1) * N);
-    for (i64 s = t - 1; s >= 1; --s) {                  // smoothing.py:213-216
+    SMC_LAUNCH(k_f_iota, grid, dim3(SMC_BLOCK), st, N, B + (size_t)(nrows - 1) * N);
+    for (i64 s = t - 1; s >= first + 1; --s) {          // smoothing.py:213-216
         const u32* A = rows[(size_t)s * SUMM_STRIDE + 4] != 0.0 ? f_A(f->a, s) + (size_t)island * N : nullptr;
-        SMC_LAUNCH(k_f_genealogy, grid, dim3(SMC_BLOCK), st, A, (const i64*)(B + (size_t)s * N), N,
-                   B + (size_t)(s - 1) * N);
+        SMC_LAUNCH(k_f_genealogy, grid, dim3(SMC_BLOCK), st, A, (const i64*)(B + (size_t)(s - first) * N), N,
+                   B + (size_t)(s - first - 1) * N);
     }
-    hipError_t e2 = hipMemcpyAsync(out_host, B, (size_t)t * N * 8, hipMemcpyDeviceToHost, st);
+    hipError_t e2 = hipMemcpyAsync(out_host, B, (size_t)nrows * N * 8, hipMemcpyDeviceToHost, st);
     if (e2 == hipSuccess) e2 = hipStreamSynchronize(st);
     (void)hipFree(B);
     SMC_HIP_CHECK(e2);
@@ -940,8 +961,8 @@ int smc_filter_one_trajectory(smc_filter* f, int island, int64_t n_last, double*
 {
     SMC_REQUIRE(f && out_host, "null argument");
     SMC_REQUIRE(island >= 0 && island < f->a.n_islands, "island out of range");
-    if (!f->a.hist) {
-        smc_set_error("smc_filter_one_trajectory: the filter was created without keep_history");
+    if (f->a.hist != 1) {
+        smc_set_error("smc_filter_one_trajectory: the filter was created without keep_history = 1");
         return SMC_ERR_STATE;
     }
     const i64 t = f->t_host;

@@ -68,7 +68,8 @@ struct FArgs {
     u32* A;                // (1 or T, n_islands, N) ancestors, 32-bit in HBM (N < 2^32; the
                            // ABI hands out int64 like the reference, resampling.py:503)
     i64 xslot, lslot;      // elements per slot: n_islands*N*dx, n_islands*N
-    int hist;
+    int hist;              // 0: two alternating slots; 1: one slot per time step (the whole history
+                           // stays resident); k >= 2: a ring of k slots (the k most recent steps)
     int par;               // t & 1 of the step this launch runs, or -1 (history slots): lets the
                            // kernels form their addresses before the step record has arrived
     u64* Q;                // (n_islands, ntiles) tile totals of q
@@ -110,11 +111,13 @@ struct FArgs {
 
 __host__ __device__ __forceinline__ i64 f_slot(const FArgs& a, i64 t)
 {
-    return a.hist ? (t > 0 ? t : 0) : (t & 1);
+    if (a.hist == 0) return t & 1;
+    if (t < 0) t = 0;
+    return a.hist == 1 ? t : (i64)((u32)t % (u32)a.hist);
 }
 __host__ __device__ __forceinline__ double* f_X(const FArgs& a, i64 t) { return a.X + f_slot(a, t) * a.xslot; }
 __host__ __device__ __forceinline__ double* f_lw(const FArgs& a, i64 t) { return a.lw + f_slot(a, t) * a.lslot; }
-__host__ __device__ __forceinline__ u32* f_A(const FArgs& a, i64 t) { return a.A + (a.hist ? t : 0) * a.lslot; }
+__host__ __device__ __forceinline__ u32* f_A(const FArgs& a, i64 t) { return a.A + (a.hist ? f_slot(a, t) : 0) * a.lslot; }
 
 #ifdef SMC_TRACE
 #define F_STAMP(k) do { if (threadIdx.x == 0) a.trace[((i64)blockIdx.y * a.nparts + blockIdx.x) * 8 + (k)] = (u64)wall_clock64(); } while (0)
@@ -1556,17 +1559,22 @@ k_ancestors2(const FArgs av)
         nH = f_register_heavy(a.hcnt + (i64)isl * 2 + (t & 1),
                               a.hlist + ((i64)isl * 2 + (t & 1)) * F_HMAX * 3, jt,
                               ns[0], ns[1], ns[2], ns[3], ns[4], sH, &sHn);
+    // (32-bit arithmetic from here on: N <= 2^30 on this path, offspring indices fit)
+    u32 nsu[F_IPT + 1];
+#pragma unroll
+    for (int i = 0; i <= F_IPT; ++i) nsu[i] = (u32)ns[i];
+    const u32 lo = (u32)n_lo, hi = (u32)n_hi;
     bool first_pass = true;
-    for (i64 pb = n_lo & ~(i64)3; pb < n_hi; pb += WIN) {
+    for (u32 pb = lo & ~3u; pb < hi; pb += WIN) {
         if (nH) {                                  // the whole pass inside a registered parent's blocks?
-            const i64 w_lo = pb > n_lo ? pb : n_lo, w_hi = pb + WIN < n_hi ? pb + WIN : n_hi;
+            const i64 w_lo = pb > lo ? pb : lo, w_hi = pb + WIN < hi ? pb + WIN : hi;
             i64 jump = 0;                          // passes to leave out, this one included
             for (int k = 0; k < nH; ++k)
                 if (sH[2 * k] <= w_lo && w_hi <= sH[2 * k + 1]) {
-                    const i64 whole = (sH[2 * k + 1] - pb) / WIN;           // passes that end inside the blocks
+                    const i64 whole = (sH[2 * k + 1] - (i64)pb) / WIN;      // passes that end inside the blocks
                     jump = whole > 1 ? whole : 1;
                 }
-            if (jump) { pb += (jump - 1) * WIN; continue; }
+            if (jump) { pb += (u32)(jump - 1) * WIN; continue; }
         }
         if (!first_pass) {
             __syncthreads();                       // previous pass has read sP
@@ -1576,16 +1584,16 @@ k_ancestors2(const FArgs av)
         }
         first_pass = false;
         // every parent writes its index at its first offspring's slot of the window
-        u32 rel[F_IPT + 1];
+        int rel[F_IPT + 1];
 #pragma unroll
         for (int i = 0; i <= F_IPT; ++i) {
-            const i64 d = ns[i] - pb;
-            rel[i] = d < 0 ? 0u : (d > (i64)WIN ? (u32)WIN : (u32)d);
+            const int d = (int)(nsu[i] - pb);
+            rel[i] = d < 0 ? 0 : (d > WIN ? WIN : d);
         }
 #pragma unroll
         for (int i = 0; i < F_IPT; ++i)
             if (rel[i] < rel[i + 1]) sP[rel[i]] = (u32)(tid * F_IPT + i);
-        const bool two = n_hi > pb + F_PASS;       // does the second half of the window hold offspring?
+        const bool two = hi > pb + F_PASS;         // does the second half of the window hold offspring?
         __syncthreads();
         // a running maximum over the slots gives each offspring its parent: both halves at once
         const uint4 v = *reinterpret_cast<const uint4*>(&sP[tid * 4]);
@@ -1615,30 +1623,31 @@ k_ancestors2(const FArgs av)
             }
         }
         ex2 = ex2 > all1 ? ex2 : all1;             // the second half continues the first
+        const u32 jb = (u32)j0;
         {
-            const i64 n0 = pb + (i64)tid * 4;
-            const u32 a32[4] = {(u32)j0 + (m0 > ex1 ? m0 : ex1), (u32)j0 + (m1 > ex1 ? m1 : ex1),
-                                (u32)j0 + (m2 > ex1 ? m2 : ex1), (u32)j0 + (m3 > ex1 ? m3 : ex1)};
-            if (n0 >= n_lo && n0 + 3 < n_hi) {                                          // core.py:329
+            const u32 n0 = pb + (u32)tid * 4u;
+            const u32 a32[4] = {jb + (m0 > ex1 ? m0 : ex1), jb + (m1 > ex1 ? m1 : ex1),
+                                jb + (m2 > ex1 ? m2 : ex1), jb + (m3 > ex1 ? m3 : ex1)};
+            if (n0 >= lo && n0 + 3u < hi) {                                             // core.py:329
                 if (a.nt) smc_st4g_nt(A + n0, a32);
                 else smc_st4g(A + n0, a32);
             } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (n0 + i >= n_lo && n0 + i < n_hi) smc_stg(A + n0 + i, a32[i]);
+                for (u32 i = 0; i < 4u; ++i)
+                    if (n0 + i >= lo && n0 + i < hi) smc_stg(A + n0 + i, a32[i]);
             }
         }
         if (two) {
-            const i64 n0 = pb + F_PASS + (i64)tid * 4;
-            const u32 a32[4] = {(u32)j0 + (k0 > ex2 ? k0 : ex2), (u32)j0 + (k1 > ex2 ? k1 : ex2),
-                                (u32)j0 + (k2 > ex2 ? k2 : ex2), (u32)j0 + (k3 > ex2 ? k3 : ex2)};
-            if (n0 + 3 < n_hi) {                   // (n0 >= n_lo: the second half starts 1024 past it)
+            const u32 n0 = pb + F_PASS + (u32)tid * 4u;
+            const u32 a32[4] = {jb + (k0 > ex2 ? k0 : ex2), jb + (k1 > ex2 ? k1 : ex2),
+                                jb + (k2 > ex2 ? k2 : ex2), jb + (k3 > ex2 ? k3 : ex2)};
+            if (n0 + 3u < hi) {                    // (n0 >= lo: the second half starts 1024 past it)
                 if (a.nt) smc_st4g_nt(A + n0, a32);
                 else smc_st4g(A + n0, a32);
             } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (n0 + i < n_hi) smc_stg(A + n0 + i, a32[i]);
+                for (u32 i = 0; i < 4u; ++i)
+                    if (n0 + i < hi) smc_stg(A + n0 + i, a32[i]);
             }
         }
     }

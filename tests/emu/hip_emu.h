@@ -340,6 +340,9 @@ inline hipError_t hipDeviceSynchronize() { return 0; }
 inline hipError_t hipGetLastError() { return 0; }
 inline hipError_t hipMalloc(void** p, size_t n) { *p = calloc(1, n ? n : 1); return *p ? 0 : 2; }
 inline hipError_t hipFree(void* p) { free(p); return 0; }
+#define hipHostMallocMapped 0x2
+inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = calloc(1, n ? n : 1); return *p ? 0 : 2; }
+inline hipError_t hipHostFree(void* p) { free(p); return 0; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) {
     memcpy(d, s, n); return 0;
 }

@@ -1053,6 +1053,48 @@ def _lib_field_x():
     return _lib.FIELD_X
 
 
+def check_rolling_history(N=3000, T=23, ks=(2, 5, 9)):
+    """store_history=k (RollingParticleHistory, smoothing.py:186-219) on the fused path: a ring of
+    k slots in HBM.  Same run as with the whole history resident -- final state, summaries -- and
+    the window holds exactly its k most recent steps (X, A, log-weights, W, genealogy); older
+    steps are refused.  Both CDF paths (N a power of two or not), stepping with reads in between."""
+    rng = np.random.RandomState(8)
+    y = [np.array([v]) for v in 0.5 * np.cumsum(rng.standard_normal(T))]
+    for n in (N, 4096):
+        mk = lambda h: pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.3), data=y), N=n, seed=12, ESSrmin=0.7,
+                              store_history=h)
+        full = mk(True)
+        full.run()
+        Bfull = full.hist.compute_trajectories()
+        for k in ks:
+            r = mk(k)
+            assert isinstance(r.hist, pa.collectors.DeviceRollingParticleHistory)
+            for t in range(T):
+                next(r)
+                assert r.hist.T == min(t + 1, k) and len(r.hist.X) == r.hist.T
+                if t in (0, 1, k, T // 2):
+                    assert np.array_equal(r.hist.X[-1], full.hist.X[t])
+                    assert np.array_equal(r.hist.X[0], full.hist.X[max(0, t + 1 - k)])
+            assert np.array_equal(r.X, full.X) and np.array_equal(r._summ(), full._summ())
+            for i in range(k):
+                t = T - k + i
+                assert np.array_equal(r.hist.X[i], full.hist.X[t])
+                assert np.array_equal(r.hist.wgts[i].lw, full.hist.wgts[t].lw)
+                assert np.array_equal(r.hist.wgts[i].W, full.hist.wgts[t].W)
+                a_r, a_f = r.hist.A[i], full.hist.A[t]
+                assert (a_r is None) == (a_f is None) and (a_r is None or np.array_equal(a_r, a_f))
+            assert np.array_equal(r.hist.compute_trajectories(), Bfull[T - k:])
+            try:
+                r._history(_lib.FIELD_X, T - k - 1)
+                raise AssertionError("a step outside the window was served")
+            except RuntimeError:
+                pass
+    # a window as long as the run is the whole history
+    w = pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.3), data=y), N=N, seed=12, store_history=T + 5)
+    w.run()
+    assert len(w.hist.X) == T
+
+
 def check_device_history_philox(N, T, golden):
     """Production mode: history on/off give the same run; the genealogy obeys
     B_{t-1} = A_t[B_t] (smoothing.py:213-216), islands > 1 included."""

@@ -238,3 +238,7 @@ def test_device_sort():
 
 def test_smc2_device_theta_level():
     pc.check_smc2()
+
+
+def test_rolling_history_on_device():
+    pc.check_rolling_history(N=1500, T=14, ks=(2, 5))

@@ -447,3 +447,8 @@ def test_device_sort():
 
 def test_smc2_device_theta_level():
     pc.check_smc2(Ntheta=256, Nx=512, T=60)
+
+
+def test_rolling_history_on_device():
+    pc.check_rolling_history()
+    pc.check_rolling_history(N=1 << 17, T=12, ks=(3,))
