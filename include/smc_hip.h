@@ -334,6 +334,12 @@ int smc_filter_set_state(smc_filter* f, int island, const double* X_host, const 
 /* PMCMC move of SMC^2 (smc_samplers.py:1129-1143): where accept_host[i] != 0, island i of dst
  * takes over island i of src (same shapes, model kind and time index; one context). */
 int smc_filter_copy_islands(smc_filter* dst, smc_filter* src, const unsigned char* accept_host);
+/* Island migration: the state of whole filters (particles, log-weights, evidence history, step
+ * record, parameters, CDF partials) packed into / restored from a contiguous device buffer of
+ * n x smc_filter_island_bytes() bytes, entry j = island islands_host[j]. */
+int smc_filter_island_bytes(smc_filter* f, int64_t* bytes);
+int smc_filter_pack_islands(smc_filter* f, const int64_t* islands_host, int n, void* pack_dev);
+int smc_filter_unpack_islands(smc_filter* f, const int64_t* islands_host, int n, const void* pack_dev);
 /* ---- SMC^2 (smc_samplers.py:1038-1167): the theta level on the device.  Every island is the
  * particle filter of one theta-particle.  Once enabled (before the first step), every time step
  * is followed by a one-workgroup kernel that adds the islands' evidence increments to the
@@ -399,6 +405,12 @@ int smc_comm_create(smc_ctx* ctx, int nranks, int rank, const char* id_host,
 /* recv (nranks*count) <- concatenation over ranks of send (count); blocking */
 int smc_comm_allgather_f64(smc_comm* comm, const double* send, int64_t count,
                            double* recv);
+/* All-to-all of byte blocks between the ranks (island migration of multi-GPU SMC^2: a global
+ * theta-resampling, smc_samplers.py:319-361, moves whole filters between GPUs): grouped
+ * ncclSend / ncclRecv, one pair per peer over xGMI.  send / recv: device buffers; counts and
+ * displacements (bytes, HOST, one per rank; the self block included). */
+int smc_comm_alltoallv(smc_comm* comm, const void* send, const int64_t* scount, const int64_t* sdisp,
+                       void* recv, const int64_t* rcount, const int64_t* rdisp);
 int smc_comm_destroy(smc_comm* comm);
 
 #ifdef __cplusplus

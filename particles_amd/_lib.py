@@ -106,6 +106,9 @@ SIGNATURES = {
     "smc_killing_ancestors": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "smc_filter_get": (c_int, [c_vp, c_int, c_int, c_vp]),
     "smc_filter_set_state": (c_int, [c_vp, c_int, c_vp, c_vp]),
+    "smc_filter_island_bytes": (c_int, [c_vp, P(c_i64)]),
+    "smc_filter_pack_islands": (c_int, [c_vp, P(c_i64), c_int, c_vp]),
+    "smc_filter_unpack_islands": (c_int, [c_vp, P(c_i64), c_int, c_vp]),
     "smc_filter_theta_enable": (c_int, [c_vp, c_dbl]),
     "smc_filter_theta_state": (c_int, [c_vp, c_vp, P(c_i64), P(c_i64), c_vp]),
     "smc_filter_theta_resume": (c_int, [c_vp, c_vp]),
@@ -121,6 +124,7 @@ SIGNATURES = {
     "smc_comm_unique_id": (c_int, [ctypes.c_char_p]),
     "smc_comm_create": (c_int, [c_vp, c_int, c_int, ctypes.c_char_p, P(c_vp)]),
     "smc_comm_allgather_f64": (c_int, [c_vp, c_vp, c_i64, c_vp]),
+    "smc_comm_alltoallv": (c_int, [c_vp, c_vp, P(c_i64), P(c_i64), c_vp, P(c_i64), P(c_i64)]),
     "smc_comm_destroy": (c_int, [c_vp]),
 }
 

@@ -25,6 +25,10 @@ typedef ncclResult_t (*fn_GetUniqueId)(ncclUniqueId*);
 typedef ncclResult_t (*fn_CommInitRank)(void**, int, ncclUniqueId, int);
 typedef ncclResult_t (*fn_AllGather)(const void*, void*, size_t, int, void*, hipStream_t);
 typedef ncclResult_t (*fn_CommDestroy)(void*);
+typedef ncclResult_t (*fn_Send)(const void*, size_t, int, int, void*, hipStream_t);
+typedef ncclResult_t (*fn_Recv)(void*, size_t, int, int, void*, hipStream_t);
+typedef ncclResult_t (*fn_Group)(void);
+const int kNcclInt8 = 0;      // ncclChar
 typedef const char* (*fn_GetErrorString)(ncclResult_t);
 const int kNcclFloat64 = 8;   // ncclDouble
 
@@ -35,6 +39,9 @@ struct Rccl {
     fn_AllGather AllGather = nullptr;
     fn_CommDestroy CommDestroy = nullptr;
     fn_GetErrorString GetErrorString = nullptr;
+    fn_Send Send = nullptr;
+    fn_Recv Recv = nullptr;
+    fn_Group GroupStart = nullptr, GroupEnd = nullptr;
 } g_rccl;
 
 int rccl_load()
@@ -53,6 +60,10 @@ int rccl_load()
     g_rccl.AllGather = (fn_AllGather)dlsym(h, "ncclAllGather");
     g_rccl.CommDestroy = (fn_CommDestroy)dlsym(h, "ncclCommDestroy");
     g_rccl.GetErrorString = (fn_GetErrorString)dlsym(h, "ncclGetErrorString");
+    g_rccl.Send = (fn_Send)dlsym(h, "ncclSend");
+    g_rccl.Recv = (fn_Recv)dlsym(h, "ncclRecv");
+    g_rccl.GroupStart = (fn_Group)dlsym(h, "ncclGroupStart");
+    g_rccl.GroupEnd = (fn_Group)dlsym(h, "ncclGroupEnd");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy) {
         smc_set_error("RCCL is missing expected symbols");
         dlclose(h);
@@ -136,6 +147,38 @@ int smc_comm_allgather_f64(smc_comm* c, const double* send, int64_t count, doubl
 #else
     ncclResult_t r = g_rccl.AllGather(send, recv, (size_t)count, kNcclFloat64, c->nccl, st);
     if (r != 0) return rccl_fail("ncclAllGather", r);
+#endif
+    SMC_HIP_CHECK(hipStreamSynchronize(st));
+    return SMC_OK;
+}
+
+// All-to-all of byte blocks (island migration): rank p receives send[sdisp[p] .. + scount[p]) of
+// every rank into recv[rdisp[.] ..]: grouped ncclSend / ncclRecv over xGMI (point-to-point links:
+// one pair per peer, no ring), the self block included.  Counts and displacements in bytes (HOST).
+int smc_comm_alltoallv(smc_comm* c, const void* send, const int64_t* scount, const int64_t* sdisp,
+                       void* recv, const int64_t* rcount, const int64_t* rdisp)
+{
+    SMC_REQUIRE(c && scount && sdisp && rcount && rdisp, "null argument");
+    hipStream_t st = c->ctx->stream;
+#ifdef SMC_EMULATE
+    if (scount[0] != rcount[0]) { smc_set_error("alltoallv: self block sizes differ"); return SMC_ERR_INVALID; }
+    if (scount[0])
+        SMC_HIP_CHECK(hipMemcpyAsync((char*)recv + rdisp[0], (const char*)send + sdisp[0], (size_t)scount[0],
+                                     hipMemcpyDeviceToDevice, st));
+#else
+    if (!g_rccl.Send || !g_rccl.Recv || !g_rccl.GroupStart || !g_rccl.GroupEnd) {
+        smc_set_error("RCCL lacks ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd");
+        return SMC_ERR_HIP;
+    }
+    ncclResult_t r = g_rccl.GroupStart();
+    if (r != 0) return rccl_fail("ncclGroupStart", r);
+    for (int p = 0; p < c->nranks && r == 0; ++p) {
+        if (scount[p]) r = g_rccl.Send((const char*)send + sdisp[p], (size_t)scount[p], kNcclInt8, p, c->nccl, st);
+        if (r == 0 && rcount[p]) r = g_rccl.Recv((char*)recv + rdisp[p], (size_t)rcount[p], kNcclInt8, p, c->nccl, st);
+    }
+    const ncclResult_t r2 = g_rccl.GroupEnd();
+    if (r != 0) return rccl_fail("ncclSend / ncclRecv", r);
+    if (r2 != 0) return rccl_fail("ncclGroupEnd", r2);
 #endif
     SMC_HIP_CHECK(hipStreamSynchronize(st));
     return SMC_OK;

@@ -809,6 +809,62 @@ int smc_filter_copy_islands(smc_filter* dst, smc_filter* src, const unsigned cha
     return SMC_OK;
 }
 
+// ---- island migration between GPUs (multi-GPU SMC^2: theta-particles sharded over ranks, a
+// global theta-resampling moves whole filters; smc_comm_alltoallv carries the packed states) ----
+int smc_filter_island_bytes(smc_filter* f, int64_t* bytes)
+{
+    SMC_REQUIRE(f && bytes, "null argument");
+    IslandArray arr[16];
+    const int na = island_arrays(f, f->t_host > 0 ? f->t_host : 1, arr);
+    i64 w = 0;
+    for (int k = 0; k < na; ++k) w += arr[k].words;
+    *bytes = w * 8;
+    return SMC_OK;
+}
+
+static int island_pack(smc_filter* f, const int64_t* islands_host, int n, void* pack_dev, int unpack)
+{
+    SMC_REQUIRE(f && (n == 0 || (islands_host && pack_dev)), "null argument");
+    if (f->a.hist) {
+        smc_set_error("island migration is not available with keep_history");
+        return SMC_ERR_STATE;
+    }
+    if (n == 0 || f->t_host == 0) return SMC_OK;
+    for (int j = 0; j < n; ++j)
+        SMC_REQUIRE(islands_host[j] >= 0 && islands_host[j] < f->a.n_islands, "island out of range");
+    SMC_HIP_CHECK(hipSetDevice(f->ctx->device));
+    hipStream_t st = f->ctx->stream;
+    IslandArray arr[16];
+    const int na = island_arrays(f, f->t_host, arr);
+    i64 stride = 0;
+    for (int k = 0; k < na; ++k) stride += arr[k].words;
+    i64* idx = nullptr;
+    SMC_HIP_CHECK(hipMalloc((void**)&idx, (size_t)n * 8));
+    hipError_t rc = hipMemcpyAsync(idx, islands_host, (size_t)n * 8, hipMemcpyHostToDevice, st);
+    i64 off = 0;
+    for (int k = 0; k < na && rc == hipSuccess; ++k) {
+        const i64 w = arr[k].words;
+        const unsigned chunks = (unsigned)((w + SMC_BLOCK - 1) / SMC_BLOCK > 64 ? 64 : (w + SMC_BLOCK - 1) / SMC_BLOCK);
+        SMC_LAUNCH(k_island_pack, dim3(chunks, n), dim3(SMC_BLOCK), st, (u64*)arr[k].p, w, (u64*)pack_dev, stride,
+                   off, (const i64*)idx, unpack);
+        off += w;
+    }
+    if (rc == hipSuccess) rc = hipGetLastError();
+    if (rc == hipSuccess) rc = hipStreamSynchronize(st);
+    (void)hipFree(idx);
+    SMC_HIP_CHECK(rc);
+    if (unpack) f->perm_t = f->t_host;
+    return SMC_OK;
+}
+int smc_filter_pack_islands(smc_filter* f, const int64_t* islands_host, int n, void* pack_dev)
+{
+    return island_pack(f, islands_host, n, pack_dev, 0);
+}
+int smc_filter_unpack_islands(smc_filter* f, const int64_t* islands_host, int n, const void* pack_dev)
+{
+    return island_pack(f, islands_host, n, (void*)pack_dev, 1);
+}
+
 // ---- SMC^2: the theta level (see k_theta_update) -------------------------------------------
 int smc_filter_theta_enable(smc_filter* f, double ess_rmin)
 {

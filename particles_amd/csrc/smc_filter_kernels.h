@@ -1790,6 +1790,20 @@ k_island_gather(const u64* in, u64* out, const i64* src, const unsigned char* ke
         out[i * words + w] = in[s_ * words + w];
 }
 
+// pack / unpack island states for migration between GPUs: entry j of the pack buffer (stride
+// `pstride` words, this array at word offset `off`) <-> island idx[j] of a per-island array
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_island_pack(u64* arr, i64 words, u64* pack, i64 pstride, i64 off, const i64* idx, int unpack)
+{
+    const i64 j = (i64)blockIdx.y;
+    u64* a = arr + idx[j] * words;
+    u64* p = pack + j * pstride + off;
+    for (i64 w = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x; w < words; w += (i64)gridDim.x * SMC_BLOCK) {
+        if (unpack) a[w] = p[w];
+        else p[w] = a[w];
+    }
+}
+
 // W = exp(lw - m)/s for one island (SMC.W)
 __global__ void __launch_bounds__(SMC_BLOCK)
 k_f_write_W(const double* lw, i64 N, const double* row, double* W, const int kform)

@@ -211,6 +211,86 @@ k_rs_scatter(const u64* keys, const u64* vals, i64 N, int shift, const unsigned*
     }
 }
 
+// N <= 2048: the whole sort in ONE launch by one workgroup -- the 8 passes of the same ranking
+// scheme with the tile ping-ponging between registers and LDS (25 launches of a few microseconds
+// each would otherwise be the cost of sorting a few thousand keys: SQMC at small N).
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_rs_small(const u64* keys, const u64* vals, i64 N, int kind, u64* okeys, u64* ovals)
+{
+    __shared__ unsigned cnt[SMC_NWAVE][256];
+    __shared__ u64 sk[RS_TILE], sv[RS_TILE];
+    __shared__ u64 smu[SMC_SM];
+    const int tid = (int)threadIdx.x, lane = smc_lane(), wave = smc_wave();
+    const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int base = wave * RS_SEG;
+    u64 k[RS_CH], v[RS_CH];
+#pragma unroll
+    for (int c = 0; c < RS_CH; ++c) {
+        const int i = base + c * 64 + lane;
+        const bool valid = i < N;
+        k[c] = valid ? rs_encode(keys[i], kind) : ~0ull;
+        v[c] = valid ? (vals ? vals[i] : (u64)i) : 0ull;
+    }
+    for (int shift = 0; shift < 64; shift += 8) {
+#pragma unroll
+        for (int w = 0; w < SMC_NWAVE; ++w) cnt[w][tid] = 0u;
+        __syncthreads();
+        unsigned lrank[RS_CH];
+#pragma unroll
+        for (int c = 0; c < RS_CH; ++c) {
+            const bool valid = base + c * 64 + lane < N;
+            const unsigned dg = (unsigned)(k[c] >> shift) & 255u;
+            u64 mask = smc_ballot(valid);
+#pragma unroll
+            for (int bit = 0; bit < 8; ++bit) {
+                const bool mine = (dg >> bit) & 1u;
+                const u64 bb = smc_ballot(mine);
+                mask &= mine ? bb : ~bb;
+            }
+            const unsigned before = cnt[wave][dg];
+            smc_wave_lockstep();
+            lrank[c] = before + (unsigned)__popcll(mask & lt);
+            if (valid && (mask & lt) == 0ull) cnt[wave][dg] = before + (unsigned)__popcll(mask);
+            smc_wave_lockstep();
+        }
+        __syncthreads();
+        {
+            unsigned c4[SMC_NWAVE], tot = 0u;
+#pragma unroll
+            for (int w = 0; w < SMC_NWAVE; ++w) { c4[w] = cnt[w][tid]; tot += c4[w]; }
+            u64 all;
+            unsigned run = (unsigned)smc_block_exscan_u64((u64)tot, smu, all);
+#pragma unroll
+            for (int w = 0; w < SMC_NWAVE; ++w) { cnt[w][tid] = run; run += c4[w]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < RS_CH; ++c)
+            if (base + c * 64 + lane < N) {
+                const unsigned dg = (unsigned)(k[c] >> shift) & 255u;
+                const unsigned p = cnt[wave][dg] + lrank[c];
+                sk[p] = k[c];
+                sv[p] = v[c];
+            }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < RS_CH; ++c) {                 // back into registers, in the new order
+            const int i = base + c * 64 + lane;
+            k[c] = i < N ? sk[i] : ~0ull;
+            v[c] = i < N ? sv[i] : 0ull;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int c = 0; c < RS_CH; ++c) {
+        const int i = base + c * 64 + lane;
+        if (i < N) {
+            if (okeys) okeys[i] = rs_decode(k[c], kind);
+            if (ovals) ovals[i] = v[c];
+        }
+    }
+}
+
 // Stable sort of (key, payload) pairs by key: keys (N) 64-bit patterns of `kind`, vals (N) 64-bit
 // payloads or null (payload = index: argsort).  out_keys / out_vals (N each, either may be null).
 // Scratch from the context's pool (recycled in stream order).  N < 2^32.
@@ -218,6 +298,15 @@ static int rs_sort_pairs(smc_ctx* ctx, const void* keys, const void* vals, i64 N
                          void* out_vals)
 {
     hipStream_t st = ctx->stream;
+    if (N <= RS_TILE) {
+        SMC_LAUNCH(k_rs_small, dim3(1), dim3(SMC_BLOCK), st, (const u64*)keys, (const u64*)vals, N, kind,
+                   (u64*)out_keys, (u64*)out_vals);
+        int rc1 = hipGetLastError() == hipSuccess ? SMC_OK : SMC_ERR_HIP;
+#ifdef SMC_EMULATE
+        if (hipStreamSynchronize(st) != hipSuccess) rc1 = SMC_ERR_HIP;
+#endif
+        return rc1;
+    }
     const int ntiles = (int)((N + RS_TILE - 1) / RS_TILE);
     const size_t nb = (size_t)N * 8;
     void* buf = nullptr;

@@ -230,6 +230,60 @@ class Group:
         parts = self.star.exchange(local.tobytes())
         return np.concatenate([np.frombuffer(p, dtype=np.float64) for p in parts])
 
+    def migrate_islands(self, pf, src_global):
+        """Global theta-level resampling across GPUs (smc_samplers.py:319-361 on a sharded
+        population): global island slot g continues from the state of global island
+        ``src_global[g]`` -- the array is the same on every rank, every rank holds
+        ``pf.n_islands`` consecutive slots (rank r: r M .. r M + M - 1).  Whole island states
+        travel packed (smc_filter_pack_islands) through ONE all-to-all of byte blocks over RCCL
+        (ncclSend / ncclRecv pairs, smc_comm_alltoallv), or over the host star when the group
+        has no device collective.  Philox streams stay tied to the slot, as with
+        ``SMC.permute_islands``: the result equals the single-process permutation."""
+        M, W, r = pf.n_islands, self.world, self.rank
+        src = np.ascontiguousarray(src_global, dtype=np.int64)
+        if src.shape != (M * W,) or src.min() < 0 or src.max() >= M * W:
+            raise ValueError("migrate_islands: one source per global island slot")
+        nb = _lib.c_i64()
+        check(lib().smc_filter_island_bytes(pf._f, ctypes.byref(nb)))
+        nb = int(nb.value)
+        # what I send to rank p: the sources (mine) of p's slots, in slot order; what I receive from
+        # p: my slots whose source lives on p, in slot order -- both sides enumerate the same pairs
+        send_idx, recv_idx = [], []
+        for p in range(W):
+            sp = src[p * M:(p + 1) * M]
+            send_idx.append((sp[sp // M == r] - r * M).astype(np.int64))
+            mine = src[r * M:(r + 1) * M]
+            recv_idx.append(np.nonzero(mine // M == p)[0].astype(np.int64))
+        sc = np.array([len(v) * nb for v in send_idx], dtype=np.int64)
+        rc = np.array([len(v) * nb for v in recv_idx], dtype=np.int64)
+        sd = np.concatenate([[0], np.cumsum(sc)[:-1]]).astype(np.int64)
+        rd = np.concatenate([[0], np.cumsum(rc)[:-1]]).astype(np.int64)
+        s_all = np.ascontiguousarray(np.concatenate(send_idx)) if sc.sum() else np.zeros(0, dtype=np.int64)
+        r_all = np.ascontiguousarray(np.concatenate(recv_idx)) if rc.sum() else np.zeros(0, dtype=np.int64)
+        assert len(r_all) == M
+        sbuf = DeviceArray((max(1, int(sc.sum()) // 8),), dtype=np.int64)
+        rbuf = DeviceArray((max(1, int(rc.sum()) // 8),), dtype=np.int64)
+        P64 = _lib.P(_lib.c_i64)
+        if len(s_all):
+            check(lib().smc_filter_pack_islands(pf._f, s_all.ctypes.data_as(P64), len(s_all), sbuf.ptr))
+        if self.comm is not None:
+            check(lib().smc_comm_alltoallv(self.comm, sbuf.ptr, sc.ctypes.data_as(P64), sd.ctypes.data_as(P64),
+                                           rbuf.ptr, rc.ctypes.data_as(P64), rd.ctypes.data_as(P64)))
+        else:       # host path: everybody's send buffer to everybody, each picks its blocks
+            mine = sbuf.get().tobytes()[:int(sc.sum())]
+            hdr = np.concatenate([sc, sd]).tobytes()
+            parts = self.star.exchange(hdr + mine) if self.star else [hdr + mine]
+            out = bytearray(int(rc.sum()))
+            for p, blob in enumerate(parts):
+                h = np.frombuffer(blob[:16 * W], dtype=np.int64)
+                cnt, dsp = int(h[r]), int(h[W + r])
+                assert cnt == rc[p]
+                out[int(rd[p]):int(rd[p]) + cnt] = blob[16 * W + dsp:16 * W + dsp + cnt]
+            host = np.frombuffer(bytes(out) + b"\0" * (-len(out) % 8), dtype=np.int64)
+            rbuf = DeviceArray.from_numpy(host if host.size else np.zeros(1, dtype=np.int64))
+        check(lib().smc_filter_unpack_islands(pf._f, r_all.ctypes.data_as(P64), M, rbuf.ptr))
+        pf._invalidate()
+
     @property
     def evidence_path(self):
         if self.comm is not None:

@@ -34,7 +34,12 @@ def test_binding_table_matches_header():
 def test_hip_library_builds_loads_and_exports_everything():
     from particles_amd import _build
     path = _build.build()                      # hipcc --offload-arch=gfx950 (cross-compiles)
-    L = ctypes.CDLL(path)
+    # (conftest may already have dlopen'ed an OLDER build of this path in this process: load a copy)
+    import shutil
+    import tempfile
+    fresh = os.path.join(tempfile.mkdtemp(), "libsmc_hip_fresh.so")
+    shutil.copy(path, fresh)
+    L = ctypes.CDLL(fresh)
     for s in declared_symbols():
         assert hasattr(L, s), s
     L.smc_version.restype = ctypes.c_char_p

@@ -452,3 +452,42 @@ def test_smc2_device_theta_level():
 def test_rolling_history_on_device():
     pc.check_rolling_history()
     pc.check_rolling_history(N=1 << 17, T=12, ks=(3,))
+
+
+MIGRATE_WORKER = r"""
+import os, sys, json
+sys.path.insert(0, {root!r})
+import numpy as np
+import particles_amd as pa
+from particles_amd import kalman, state_space_models as ssm
+from particles_amd.distributed import Group
+grp = Group(device_collective=True)
+rng = np.random.RandomState(42)
+y = [np.array([v]) for v in np.cumsum(rng.standard_normal(12))]
+fk = ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y)
+mk = lambda: pa.SMC(fk=fk, N=4096, seed=77, n_islands=6, collect="off")
+src = np.array([4, 4, 0, 5, 1, 2])
+a = mk(); a.step_async(5); grp.migrate_islands(a, src); a.step_async(7)
+b = mk(); b.step_async(5); b.permute_islands(src); b.step_async(7)
+print("RESULT " + json.dumps({{"same": bool(np.array_equal(a.logLts_islands, b.logLts_islands)
+                                               and np.array_equal(a._get(0, 3), b._get(0, 3))),
+                               "path": grp.evidence_path}}))
+grp.close()
+"""
+
+
+def test_island_migration_through_rccl(tmp_path):
+    """Group.migrate_islands with the device collective: packed island states through
+    smc_comm_alltoallv (grouped ncclSend / ncclRecv; world size 1: the self block) must equal
+    SMC.permute_islands bit for bit, and the run continues identically."""
+    import json, os, socket, subprocess, sys
+    from conftest import ROOT
+    script = tmp_path / "migrate_worker.py"
+    script.write_text(MIGRATE_WORKER.format(root=ROOT))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(port), SMC_HIP_DEVICE="0")
+    p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0, p.stdout + p.stderr
+    res = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][0][7:])
+    assert res["path"] == "rccl" and res["same"]
