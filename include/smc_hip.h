@@ -234,7 +234,11 @@ enum smc_model_kind {
 };
 enum smc_fk_kind {
     SMC_FK_BOOTSTRAP = 0,     /* state_space_models.py:299-349 */
-    SMC_FK_GUIDED = 1         /* state_space_models.py:352-398 (model's own proposal) */
+    SMC_FK_GUIDED = 1,        /* state_space_models.py:352-398 (model's own proposal) */
+    SMC_FK_APF = 2            /* state_space_models.py:406-428 auxiliary PF: the guided step + the
+                               * auxiliary weights of core.py:299-313 (resampling on lw + logeta,
+                               * weights reset to log_mean_exp(logeta, W) - logeta[A]); STOCHVOL
+                               * (Pitt & Shephard, :475-498), N <= 1024 (the one-launch filter) */
 };
 enum smc_rng_mode {
     SMC_RNG_PHILOX = 0,       /* counter-based Philox4x32-10 per lane */
@@ -252,7 +256,8 @@ typedef struct smc_model {
      *             5 log(sigmaX), 6 log(sigma0), 7 sigmaX^2, 8 sigmaY^2,
      *             guided only (kalman.py:436-446): 9 sig2post, 10 sqrt(9),
      *             11 log(10), 12 sig2post0, 13 sqrt(12), 14 log(13)
-     *   STOCHVOL: 0 mu, 1 rho, 2 sigma, 3 sigma/sqrt(1-rho^2), 4 (1-rho)*mu
+     *   STOCHVOL: 0 mu, 1 rho, 2 sigma, 3 sigma/sqrt(1-rho^2), 4 (1-rho)*mu; guided / APF
+     *             (:475-498): 5 log(sigma), 6 log(sig0), 7 0.5*sigma^2, 8 0.5*sig0^2, 9 0.5/sigma^2
      *   GORDON:   0 b, 1 sigmaX, 2 c, 3 sigma0 (2.0), 5 a;  aux_host[t] = d*cos(e*(t-1))
      *   THETALOGISTIC: 0 tau0, 1 sigmaX, 2 sigmaY, 3 sigma0 (1.0), 4 log(sigmaY),
      *             5 tau1, 6 tau2

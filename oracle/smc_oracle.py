@@ -590,6 +590,23 @@ class StochVol:
     def py_logpdf(self, y, xp, x):       # :472-473
         return normal_logpdf(y, loc=0.0, scale=np.exp(0.5 * x))
 
+    # Pitt & Shephard's proposal and auxiliary function (:475-498)
+    def _xhat(self, xst, sig, yt):
+        return xst + 0.5 * sig ** 2 * (yt ** 2 * np.exp(-xst) - 1.0)
+
+    def proposal0(self, y0):
+        return self._xhat(0.0, self.sig0(), y0), self.sig0()
+
+    def proposal(self, xp, yt):
+        return self._xhat(self.px(xp)[0], self.sigma, yt), self.sigma
+
+    def logeta(self, x, y_next):
+        xst = self.px(x)[0]
+        xstmmu = xst - self.mu
+        xhat = self._xhat(xst, self.sigma, y_next)
+        xhatmmu = xhat - self.mu
+        return 0.5 / self.sigma ** 2 * (xhatmmu ** 2 - xstmmu ** 2) - 0.5 * y_next ** 2 * np.exp(-xst) * (1.0 + xstmmu)
+
 
 class StochVolLeverage(StochVol):
     """state_space_models.py:501-541: PY depends on (x_{t-1}, x_t)."""
@@ -778,7 +795,7 @@ def propagate(model, fk, t, yt, Xp, z, ctx):
         else:
             inc = lpy
         return X, inc
-    if fk == "guided":
+    if fk in ("guided", "apf"):
         if t == 0:
             loc, scale = model.proposal0(yt)
             X = normal_rvs(loc, scale, z)
@@ -826,24 +843,33 @@ def run_filter(model, data, N, scheme="systematic", ESSrmin=0.5, fk="bootstrap",
     zshape = (N, ctx.d) if ctx.mv else N
     for t in range(T):
         yt = np.asarray(data[t])
+        if fk in ("guided", "apf") and not ctx.mv:
+            yt = yt.reshape(-1)[0]                        # (the laws of the proposal index data[t] as a scalar)
         rs_flag = False
         # ---- generate_particles / resample_move      core.py:315-337
         if t > 0:
-            ess = wgts.ESS
+            aux = wgts
+            if fk == "apf":                               # core.py:307-313 setup_auxiliary_weights
+                logetat = model.logeta(X, np.asarray(data[t]).reshape(-1)[0])
+                aux = wgts.add(logetat)
+            ess = aux.ESS
             if cdf == "2level":
-                ess = two_level_reduce(*tile_partials(wgts.lw))[0]["ESS"]
+                ess = two_level_reduce(*tile_partials(aux.lw))[0]["ESS"]
             rs_flag = bool(ess < N * ESSrmin)             # core.py:181-183, 327
             if rs_flag:
                 u = rng.rand(N_UNIFORMS[scheme](N))
                 su = sorted_uniforms(scheme, N, u)
                 if cdf == "seq":
-                    A = inverse_cdf(su, wgts.W)
+                    A = inverse_cdf(su, aux.W)
                 elif cdf == "2level":
-                    A = inverse_cdf_2level_c(scheme, u, wgts.lw)[0]
+                    A = inverse_cdf_2level_c(scheme, u, aux.lw)[0]
                 else:
-                    A = inverse_cdf_q62(su, wgts.W)
+                    A = inverse_cdf_q62(su, aux.W)
                 Xp = X[A]                                 # core.py:332
-                wgts = Weights()                          # core.py:299-305
+                if fk == "apf":                           # core.py:299-305 reset_weights
+                    wgts = Weights(lw=log_mean_exp(logetat, W=wgts.W) - logetat[A])
+                else:
+                    wgts = Weights()
             else:
                 A = np.arange(N)                          # core.py:335-336
                 Xp = X

@@ -175,8 +175,11 @@ class SMC:
         self._cache = {}
         self._summ_cache = None
         model = fk._device_model() if hasattr(fk, "_device_model") else None
-        if fk is not None and fk.isAPF:
-            model = None
+        if fk is not None and fk.isAPF and not (
+                getattr(fk, "_fk_kind", None) == _lib.FK_APF and N <= 1024 and n_islands >= 1
+                and not (collect and collect != "off" and self._device_moments)
+                and not (resampling == "multinomial" and replay is None)):
+            model = None                       # APF beyond the one-launch filter: operator path
         if qmc:                    # SQMC: the template-method step on device operators
             model = None
         self._fused = self._will_fuse(fk, qmc, resampling, model)
@@ -203,7 +206,9 @@ class SMC:
     def _will_fuse(fk, qmc=False, resampling="systematic", model=False):
         """Does SMC(fk, qmc, resampling) run the fused device loop?  (One predicate for ``SMC``
         and for ``multiSMC``'s decision to batch runs as islands.)"""
-        if fk is None or qmc or fk.isAPF or resampling not in _lib.SCHEMES:
+        if fk is None or qmc or resampling not in _lib.SCHEMES:
+            return False
+        if fk.isAPF and getattr(fk, "_fk_kind", None) != _lib.FK_APF:
             return False
         if model is False:
             model = fk._device_model() if hasattr(fk, "_device_model") else None

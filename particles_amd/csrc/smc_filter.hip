@@ -78,6 +78,7 @@ static void launch_propagate(smc_filter* f)
     P_CASE(SMC_MODEL_LINGAUSS, SMC_FK_BOOTSTRAP)
     P_CASE(SMC_MODEL_LINGAUSS, SMC_FK_GUIDED)
     P_CASE(SMC_MODEL_STOCHVOL, SMC_FK_BOOTSTRAP)
+    P_CASE(SMC_MODEL_STOCHVOL, SMC_FK_GUIDED)
     P_CASE(SMC_MODEL_GORDON, SMC_FK_BOOTSTRAP)
     P_CASE(SMC_MODEL_THETALOGISTIC, SMC_FK_BOOTSTRAP)
     P_CASE(SMC_MODEL_SVLEVERAGE, SMC_FK_BOOTSTRAP)
@@ -151,8 +152,14 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
                     model->kind == SMC_MODEL_SVLEVERAGE || model->kind == SMC_MODEL_DISCRETECOX,
                 "fused filter: unknown model kind");
     SMC_REQUIRE(model->fk == SMC_FK_BOOTSTRAP ||
-                    (model->fk == SMC_FK_GUIDED && (model->kind == SMC_MODEL_LINGAUSS || mv)),
-                "guided filter is available for LINGAUSS and MVLINGAUSS only");
+                    (model->fk == SMC_FK_GUIDED &&
+                     (model->kind == SMC_MODEL_LINGAUSS || model->kind == SMC_MODEL_STOCHVOL || mv)) ||
+                    (model->fk == SMC_FK_APF && model->kind == SMC_MODEL_STOCHVOL),
+                "guided filter: LINGAUSS, STOCHVOL, MVLINGAUSS; auxiliary filter: STOCHVOL");
+    if (model->fk == SMC_FK_APF && (o->N > F_TILE || o->moments)) {
+        smc_set_error("the auxiliary particle filter is fused for N <= 1024 (the one-launch filter) only");
+        return SMC_ERR_INVALID;
+    }
     SMC_REQUIRE(model->kind != SMC_MODEL_GORDON || model->aux_host,
                 "GORDON needs aux_host (d*cos(e*(t-1)) per step)");
     SMC_REQUIRE(model->kind != SMC_MODEL_DISCRETECOX || model->aux_host,
@@ -439,6 +446,8 @@ static void launch_small(smc_filter* f, int nsteps)
     S_CASE(SMC_MODEL_LINGAUSS, SMC_FK_BOOTSTRAP)
     S_CASE(SMC_MODEL_LINGAUSS, SMC_FK_GUIDED)
     S_CASE(SMC_MODEL_STOCHVOL, SMC_FK_BOOTSTRAP)
+    S_CASE(SMC_MODEL_STOCHVOL, SMC_FK_GUIDED)
+    S_CASE(SMC_MODEL_STOCHVOL, SMC_FK_APF)
     S_CASE(SMC_MODEL_GORDON, SMC_FK_BOOTSTRAP)
     S_CASE(SMC_MODEL_THETALOGISTIC, SMC_FK_BOOTSTRAP)
     S_CASE(SMC_MODEL_SVLEVERAGE, SMC_FK_BOOTSTRAP)
@@ -455,6 +464,11 @@ int smc_filter_step(smc_filter* f, int64_t nsteps)
     i64 todo = nsteps;
     if (f->t_host + todo > f->a.T) todo = f->a.T - f->t_host;
     if (todo < 0) todo = 0;
+    if (todo > 0 && f->fk == SMC_FK_APF && !small_filter_ok(f)) {
+        smc_set_error("the auxiliary particle filter runs on the one-launch filter only (no profiling, "
+                      "no Philox multinomial)");
+        return SMC_ERR_STATE;
+    }
     if (todo > 0 && f->lwth) {
         // theta level on: the theta-weights are updated behind every step (and may freeze the batch)
         const bool small = small_filter_ok(f);

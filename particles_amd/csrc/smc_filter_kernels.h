@@ -222,11 +222,38 @@ __device__ __forceinline__ double m_norm_logpdf(double x, double loc, double sca
     return -(v * v) / 2.0 - SMC_C_NORM - lscale;
 }
 
+// StochVol, Pitt & Shephard (state_space_models.py:475-498): the proposal's mean
+// _xhat(xst, sig, y) = xst + 0.5 sig^2 (y^2 exp(-xst) - 1), half_s2 = 0.5 * sig ** 2 from the host
+__device__ __forceinline__ double m_sv_xhat(double xst, double half_s2, double y)
+{
+    return xst + half_s2 * ((y * y) * exp(-xst) - 1.0);
+}
+// ... and the auxiliary function logeta(t, x) with y = data[t + 1] (:491-498)
+__device__ __forceinline__ double m_sv_logeta(const double* p, double x, double y)
+{
+    const double xst = p[4] + p[1] * x;
+    const double xstmmu = xst - p[0];
+    const double xhatmmu = m_sv_xhat(xst, p[7], y) - p[0];
+    return p[9] * (xhatmmu * xhatmmu - xstmmu * xstmmu) - ((0.5 * (y * y)) * exp(-xst)) * (1.0 + xstmmu);
+}
+
 // one particle of one step: returns the new state, writes the weight increment
 template <int KIND, int FK>
 __device__ __forceinline__ double m_step(const double* p, bool first, double y, double aux,
                                          double xp, double z, double& inc)
 {
+    if (KIND == SMC_MODEL_STOCHVOL && FK != SMC_FK_BOOTSTRAP) {
+        // GuidedPF / AuxiliaryPF of StochVol (state_space_models.py:374-392 with :481-489)
+        const double xst = first ? 0.0 : p[4] + p[1] * xp;             // proposal0 centres _xhat at 0 (:483)
+        const double sc = first ? p[3] : p[2], rsc = first ? p[16 + 3] : p[16 + 2];
+        const double lsc = first ? p[6] : p[5];
+        const double xhat = m_sv_xhat(xst, first ? p[8] : p[7], y);
+        const double x = xhat + sc * z;
+        const double prior_loc = first ? p[0] : xst;                   // PX0 = N(mu, sig0), PX = N(EXt(xp), sigma)
+        inc = (m_norm_logpdf(x, prior_loc, sc, rsc, lsc) + m_obs_logpdf<KIND>(p, y, x, xp, first, aux))
+              - m_norm_logpdf(x, xhat, sc, rsc, lsc);
+        return x;
+    }
     if (FK == SMC_FK_BOOTSTRAP) {
         const double x = first ? m_init_loc<KIND>(p) + p[3] * z
                                : m_trans_loc<KIND>(p, xp, aux) + m_trans_scale<KIND>(p) * z;

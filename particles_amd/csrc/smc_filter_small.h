@@ -47,6 +47,10 @@ k_filter_small(const FArgs av, const int nsteps)
     if (t >= a.T) return;                                  // done, or frozen by k_theta_update
     bool resample = smc_uniform(smc_ldg(info + 1)) != 0.0;
     double m = smc_uniform(smc_ldg(info + 3)), rs = smc_uniform(smc_ldg(info + 4));
+    // APF (core.py:299-313): resampling runs on the AUXILIARY weights lw + logeta; (m, rs) then
+    // normalise those, and cconst = log_mean_exp(logeta, W) is what the weights are reset to
+    constexpr bool APF = FK == SMC_FK_APF;
+    double cconst = APF ? smc_uniform(smc_ldg(info + 6)) : 0.0;
     double prev_log_mean = 0.0, prev_logLt = 0.0;          // of step t-1 (core.py:355-359)
     if (t > 0) {
         const double* prow = a.summ + ((i64)isl * (a.T + 1) + (t - 1)) * SUMM_STRIDE;
@@ -78,7 +82,11 @@ k_filter_small(const FArgs av, const int nsteps)
             // ---- ancestors: exactly k_ancestors<true> for the single tile b = 0
             u64 q4[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) q4[i] = (jt + i < N) ? smc_q62_w(f_weight(lw[i], m, rs)) : 0ull;
+            for (int i = 0; i < 4; ++i) {
+                // (APF: the auxiliary weight of the parent, logeta(t - 1, x) with data[t] -- core.py:307-313)
+                const double la = APF ? lw[i] + m_sv_logeta(p, x[i], yt) : lw[i];
+                q4[i] = (jt + i < N) ? smc_q62_w(f_weight(la, m, rs)) : 0ull;
+            }
             const u64 tsum = q4[0] + q4[1] + q4[2] + q4[3];
             u64 total, pre;
             const u64 cex = smc_block_exscan_plus_sum_u64(tsum, 0ull, smu, total, pre);
@@ -102,7 +110,11 @@ k_filter_small(const FArgs av, const int nsteps)
                              });
             __syncthreads();
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { xp[k] = sX[an[k]]; lwp[k] = 0.0; }        // core.py:332
+            for (int k = 0; k < 4; ++k) {                                           // core.py:332
+                xp[k] = sX[an[k]];
+                // core.py:299-305 reset_weights: log_mean_exp(logeta, W) - logeta[A] for the APF
+                lwp[k] = APF ? cconst - m_sv_logeta(p, xp[k], yt) : 0.0;
+            }
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k) { xp[k] = first ? 0.0 : x[k]; lwp[k] = first ? 0.0 : lw[k]; }
@@ -124,7 +136,8 @@ k_filter_small(const FArgs av, const int nsteps)
             okp[k] = jt + k < N;
             double inc;
             x[k] = m_step<KIND, FK>(p, first, yt, aux, xp[k], z[k], inc);
-            double l = (rsp || first) ? inc : lwp[k] + inc;                         // resampling.py:241-244
+            double l = first ? inc : lwp[k] + inc;                                  // resampling.py:241-244
+                                                                                    // (lwp = 0 after a reset)
             if (l != l) l = -INFINITY;                                              // resampling.py:220
             lw[k] = okp[k] ? l : -INFINITY;
         }
@@ -166,6 +179,34 @@ k_filter_small(const FArgs av, const int nsteps)
         m = gm;
         rs = bad ? NAN : 1.0 / s1;
         resample = (t + 1 < a.T) && (ess < a.ess_thresh);                           // core.py:181-183
+        if (APF && t + 1 < a.T) {
+            // auxiliary weights of the NEXT step: aux = wgts.add(logeta(t, X)) (core.py:307-313);
+            // the decision, the CDF's normalisation and the reset constant come from them
+            double la[4], tma = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                la[k] = okp[k] ? lw[k] + m_sv_logeta(p, x[k], y_next) : -INFINITY;
+                if (la[k] != la[k]) la[k] = -INFINITY;
+                tma = smc_max2(tma, la[k]);
+            }
+            __syncthreads();
+            const double gma = smc_block_max(tma, smm);
+            double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double e = (la[k] > -INFINITY) ? smc_exp_nonpos(la[k] - gma) : 0.0;
+                a1 += e;
+                a2 = fma(e, e, a2);
+            }
+            __syncthreads();
+            smc_block_sum2(a1, a2, smd);
+            const bool bada = !(gma > -INFINITY) || !(gma < INFINITY);
+            const double essa = bada ? NAN : (a1 * a1) / a2;
+            resample = essa < a.ess_thresh;
+            m = gma;
+            rs = bada ? NAN : 1.0 / a1;
+            cconst = (gma - gm) + log(a1 / s1);           // log sum_i W_i exp(logeta_i)
+        }
     }
     if (tid == 0) {                 // the step record the other kernels / the next launch read
         info[0] = (double)t;
@@ -174,5 +215,6 @@ k_filter_small(const FArgs av, const int nsteps)
         info[3] = m;
         info[4] = rs;
         info[5] = (a.aux && t < a.T) ? a.aux[t] : 0.0;
+        if (APF) info[6] = cconst;
     }
 }

@@ -108,7 +108,7 @@ class Bootstrap(FeynmanKac):
         template-method path (the reference's normal way to customise a model)."""
         base = GuidedPF if isinstance(self, GuidedPF) else Bootstrap
         cls = type(self)
-        for name in ("M0", "M", "logG", "time_to_resample", "done", "_device_model"):
+        for name in ("M0", "M", "logG", "time_to_resample", "done"):
             if getattr(cls, name) is not getattr(base, name):
                 return None
         scls = type(self.ssm)
@@ -156,11 +156,21 @@ class APFMixin:
 
 class AuxiliaryPF(GuidedPF, APFMixin):
     """Auxiliary particle filter (state_space_models.py:406-428); ``ssm`` must implement
-    ``proposal0``, ``proposal`` and ``logeta``.  Runs the template-method step with device
-    operators (the auxiliary weights are one more ``Weights.add`` / weighted log-mean-exp)."""
+    ``proposal0``, ``proposal`` and ``logeta``.  For the stock ``StochVol`` and N <= 1024 the
+    whole filter -- auxiliary weights included -- runs fused on the device (one launch for the
+    T-loop, ``k_filter_small``); otherwise the template-method step with device operators (the
+    auxiliary weights are one more ``Weights.add`` / weighted log-mean-exp)."""
+
+    _fk_kind = _lib.FK_APF
 
     def _device_model(self):
-        return None
+        base = GuidedPF._device_model(self)
+        if base is None or not base.get("apf") or type(self).logeta is not APFMixin.logeta:
+            return None
+        owner = next((c for c in type(self.ssm).__mro__ if "_device_params" in vars(c)), None)
+        if getattr(type(self.ssm), "logeta", None) is not getattr(owner, "logeta", None):
+            return None
+        return base
 
 
 class AuxiliaryBootstrap(Bootstrap, APFMixin):
@@ -212,11 +222,12 @@ class StochVol(StateSpaceModel):
             t + 1] ** 2 * np.exp(-xst) * (1.0 + xstmmu)
 
     def _device_params(self, fk_kind):
-        if fk_kind != _lib.FK_BOOTSTRAP:
-            return None
         p = np.zeros(_lib.PARAM_STRIDE)
         p[:5] = [self.mu, self.rho, self.sigma, self.sig0(), (1.0 - self.rho) * self.mu]
-        return dict(kind=_lib.MODEL_STOCHVOL, dx=1, dy=1, params=p)
+        if fk_kind != _lib.FK_BOOTSTRAP:          # Pitt & Shephard's proposal / logeta (:475-498)
+            p[5:10] = [np.log(self.sigma), np.log(self.sig0()), 0.5 * self.sigma ** 2,
+                       0.5 * self.sig0() ** 2, 0.5 / self.sigma ** 2]
+        return dict(kind=_lib.MODEL_STOCHVOL, dx=1, dy=1, params=p, apf=True)
 
 
 class StochVolLeverage(StochVol):

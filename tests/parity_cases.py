@@ -1395,11 +1395,15 @@ def check_apf_and_guided_generic(golden):
     (same numpy seed): the auxiliary particle filter (core.py:299-313; Pitt & Shephard's
     proposal for StochVol, state_space_models.py:475-498) and the guided filter of the same
     model, against the reference's outputs."""
+    class GenericSV(ssm.StochVol):                   # keeps the model off the fused loop
+        def _device_params(self, fk_kind):
+            return None
+
     for case, cls in (("sv_apf", ssm.AuxiliaryPF), ("sv_guided", ssm.GuidedPF)):
         g = golden(case)
         y = list(g["y"])
         np.random.seed(int(g["run_seed"]))
-        pf = pa.SMC(fk=cls(ssm=ssm.StochVol(), data=y), N=int(g["N"]),
+        pf = pa.SMC(fk=cls(ssm=GenericSV(), data=y), N=int(g["N"]),
                     resampling=str(g["scheme"]), ESSrmin=float(g["ESSrmin"]))
         assert not pf._fused and pf.fk.isAPF == (case == "sv_apf")
         pf.run()
@@ -1413,6 +1417,53 @@ def check_apf_and_guided_generic(golden):
             assert np.max(np.abs(pf.X - g["X"])) < 1e-12
             assert np.allclose(pf.wgts.lw, g["lw"], rtol=1e-10, atol=1e-10)
             assert rel(pf.W, g["W"]) < 1e-9
+
+
+def check_apf_fused(golden):
+    """AuxiliaryPF and GuidedPF of the stock StochVol (Pitt & Shephard's proposal and logeta,
+    state_space_models.py:475-498; core.py:299-313) in the FUSED loop: the reference's own runs
+    (fixtures sv_apf / sv_guided: same numpy seed -> replayed draws) -- every resample decision,
+    ESS and evidence to 1e-9, the final ancestors, particles and weights; Philox mode agrees with
+    the operator-at-a-time path's estimate; beyond N = 1024 the APF keeps the operator path."""
+    for case, cls, fk in (("sv_apf", ssm.AuxiliaryPF, "apf"), ("sv_guided", ssm.GuidedPF, "guided")):
+        g = golden(case)
+        y = list(g["y"])
+        N, scheme, ESSrmin = int(g["N"]), str(g["scheme"]), float(g["ESSrmin"])
+        np.random.seed(int(g["run_seed"]))
+        rec = orc.RecordingRNG()
+        o = orc.run_filter(orc.StochVol(), y, N, scheme, ESSrmin, fk=fk, rng=rec, keep=True)
+        assert o["final_logLt"] == float(g["logLt"])                    # the oracle IS the reference run
+        z, u = tapes_from_oracle(rec.tape, len(y), N, scheme)
+        pf = pa.SMC(fk=cls(ssm=ssm.StochVol(), data=y), N=N, resampling=scheme, ESSrmin=ESSrmin, replay=(z, u))
+        assert pf._fused and describe(pf) == "k_filter_small"
+        pf.run()
+        assert pf.summaries.rs_flags == [bool(v) for v in g["rs_flags"]] and any(pf.summaries.rs_flags)
+        assert rel(pf.summaries.ESSs, g["ESSs"]) < 1e-9
+        assert rel(pf.summaries.logLts, g["logLts"]) < 1e-9
+        assert np.array_equal(pf.A, g["A"])
+        assert np.max(np.abs(pf.X - g["X"])) < 1e-12
+        assert np.allclose(pf.wgts.lw, g["lw"], rtol=1e-11, atol=1e-11) and rel(pf.W, g["W"]) < 1e-9
+        # stepping one at a time (the reset constant and the auxiliary normalisation travel in the record)
+        ps = pa.SMC(fk=cls(ssm=ssm.StochVol(), data=y), N=N, resampling=scheme, ESSrmin=ESSrmin, replay=(z, u))
+        for _ in range(len(y)):
+            next(ps)
+        assert ps.logLt == pf.logLt and np.array_equal(ps.X, pf.X)
+    # production mode: the fused APF and the operator path estimate the same evidence
+    g = golden("sv_apf")
+    y = list(g["y"])
+    lls = []
+    for s in range(4):
+        pf = pa.SMC(fk=ssm.AuxiliaryPF(ssm=ssm.StochVol(), data=y), N=1000, seed=50 + s)
+        assert pf._fused
+        pf.run()
+        lls.append(pf.logLt)
+    assert abs(np.mean(lls) - float(g["logLt"])) < 0.15, lls
+    big = pa.SMC(fk=ssm.AuxiliaryPF(ssm=ssm.StochVol(), data=y), N=3000)
+    assert not big._fused                                               # operator path beyond 1024
+    gd = pa.SMC(fk=ssm.GuidedPF(ssm=ssm.StochVol(), data=y), N=4096, seed=3)
+    assert gd._fused and "k_propagate" in describe(gd)                  # guided StochVol: every path
+    gd.run()
+    assert abs(gd.logLt - float(golden("sv_guided")["logLt"])) < 0.15
 
 
 def check_resident_user_model(golden):

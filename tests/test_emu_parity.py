@@ -242,3 +242,7 @@ def test_smc2_device_theta_level():
 
 def test_rolling_history_on_device():
     pc.check_rolling_history(N=1500, T=14, ks=(2, 5))
+
+
+def test_apf_and_guided_stochvol_fused(golden):
+    pc.check_apf_fused(golden)

@@ -491,3 +491,7 @@ def test_island_migration_through_rccl(tmp_path):
     assert p.returncode == 0, p.stdout + p.stderr
     res = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][0][7:])
     assert res["path"] == "rccl" and res["same"]
+
+
+def test_apf_and_guided_stochvol_fused(golden):
+    pc.check_apf_fused(golden)
