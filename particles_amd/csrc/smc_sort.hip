@@ -130,6 +130,23 @@ k_rs_scan(unsigned* hist, unsigned* total, unsigned* ticket, int ntiles)
     }
 }
 
+// the same for few tiles (<= 64): ONE workgroup, thread d walks digit d's short row
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_rs_scan_few(unsigned* hist, unsigned* total, int ntiles)
+{
+    __shared__ u64 smu[SMC_SM];
+    const int d = (int)threadIdx.x;
+    u64 all;
+    u64 run = smc_block_exscan_u64((u64)total[d], smu, all);
+    total[d] = 0u;
+    unsigned* row = hist + (i64)d * ntiles;
+    for (int w = 0; w < ntiles; ++w) {
+        const unsigned c = row[w];
+        row[w] = (unsigned)run;
+        run += c;
+    }
+}
+
 __global__ void __launch_bounds__(SMC_BLOCK)
 k_rs_scatter(const u64* keys, const u64* vals, i64 N, int shift, const unsigned* offs, int ntiles,
              u64* okeys, u64* ovals)
@@ -323,7 +340,8 @@ static int rs_sort_pairs(smc_ctx* ctx, const void* keys, const void* vals, i64 N
     for (int pass = 0; pass < 8; ++pass) {
         const int shift = 8 * pass;
         SMC_LAUNCH(k_rs_hist, dim3(ntiles), dim3(SMC_BLOCK), st, (const u64*)k0, N, shift, hist, total, ntiles);
-        SMC_LAUNCH(k_rs_scan, dim3(256), dim3(SMC_BLOCK), st, hist, total, total + 256, ntiles);
+        if (ntiles <= 64) SMC_LAUNCH(k_rs_scan_few, dim3(1), dim3(SMC_BLOCK), st, hist, total, ntiles);
+        else SMC_LAUNCH(k_rs_scan, dim3(256), dim3(SMC_BLOCK), st, hist, total, total + 256, ntiles);
         SMC_LAUNCH(k_rs_scatter, dim3(ntiles), dim3(SMC_BLOCK), st, (const u64*)k0, (const u64*)v0, N, shift,
                    (const unsigned*)hist, ntiles, k1, v1);
         u64* t = k0; k0 = k1; k1 = t;

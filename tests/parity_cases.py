@@ -50,7 +50,7 @@ def check_weights(golden):
     assert abs(mv["mean"] - g["wmean"]) < 1e-13 and abs(mv["var"] - g["wvar"]) < 1e-13
 
 
-def check_wquantiles(golden):
+def check_wquantiles(golden, N=200001):
     """rs.wquantiles (resampling.py:381-417): device sort + running sums against the
     reference's values, and against the oracle on a larger weighted sample."""
     g = golden("weights")
@@ -61,7 +61,6 @@ def check_wquantiles(golden):
     q2 = rs.wquantiles(g["W"], x2)
     assert q2.shape == (2, 3) and np.allclose(q2, g["wq2"], rtol=1e-12, atol=1e-13)
     rng = np.random.default_rng(8)
-    N = 200001
     W = orc.exp_and_normalise(1.5 * rng.standard_normal(N))
     xs = rng.standard_normal(N)
     al = (0.001, 0.1, 0.5, 0.9, 0.9999)
@@ -1613,7 +1612,7 @@ def check_indep_prod(golden):
     assert d.rvs(size=10).shape == (10, 3) and d.dim == 3
 
 
-def check_sqmc(golden, monkeypatch):
+def check_sqmc(golden, monkeypatch, philox_N=4096, philox_runs=4, philox_T=40):
     """SQMC (SMC(qmc=True), core.py:315-349) on device operators: the reference's runs on its
     recorded Sobol' points; then the operators themselves (Sobol' generator vs scipy's, ndtri
     vs scipy's, argsort vs numpy's) and a run on device-generated points against Kalman."""
@@ -1686,7 +1685,7 @@ def check_sqmc(golden, monkeypatch):
     assert np.array_equal(hilbert.hilbert_sort(x.reshape(-1, 1)), np.argsort(x, kind="stable"))
     # ---- a run on device-generated, digitally shifted points (Philox mode)
     g = golden("kalman_toy")
-    y = [np.atleast_1d(v) for v in np.squeeze(g["y"])][:40]
+    y = [np.atleast_1d(v) for v in np.squeeze(g["y"])][:philox_T]
     ll, _ = orc.kalman_loglik(orc.ToySSM(0.2), y)
     rs.set_rng("philox")
     try:
@@ -1698,9 +1697,9 @@ def check_sqmc(golden, monkeypatch):
         for c in range(2):           # a (0, m, 1)-net in base 2 survives the digital shift
             assert np.array_equal(np.sort(np.floor(ph[:, c] * 1024).astype(int)), np.arange(1024))
         lls = []
-        for s in range(4):
+        for s in range(philox_runs):
             pa.seed(100 + s)
-            pf = pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y), N=4096, qmc=True)
+            pf = pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y), N=philox_N, qmc=True)
             pf.run()
             lls.append(pf.logLt)
         assert np.max(np.abs(np.array(lls) - ll)) < 0.25
