@@ -186,6 +186,12 @@ int smc_hilbert_sort(smc_ctx* ctx, const double* x, int64_t N, int32_t d, int64_
 int smc_hilbert_array(smc_ctx* ctx, const int64_t* xint, int64_t N, int32_t d, int64_t* out);
 int smc_sobol(smc_ctx* ctx, int64_t N, int32_t d, int32_t scramble, int32_t safe,
               uint64_t counter, double* out);
+/* The same N points (N a power of two), rows in ascending order of the FIRST coordinate:
+ * out = smc_sobol(...)[argsort(smc_sobol(...)[:, 0])], without the sort -- the order is known in
+ * closed form (dimension 1 is the bit-reversed Gray code XOR the shift).  SQMC consumes its
+ * points only through u[tau] with tau = argsort(u[:, 0]) (core.py:343-347). */
+int smc_sobol_sorted(smc_ctx* ctx, int64_t N, int32_t d, int32_t scramble, int32_t safe,
+                     uint64_t counter, double* out);
 
 /* ---- (f) weighted quantiles (resampling.py:381-417 wquantiles) -------------
  * W (N), x (N,d) device; alphas_host (k) levels; out_host (d,k): for every column the

@@ -82,6 +82,7 @@ SIGNATURES = {
     "smc_hilbert_array": (c_int, [c_vp, c_vp, c_i64, ctypes.c_int32, c_vp]),
     "smc_hilbert_sort": (c_int, [c_vp, c_vp, c_i64, ctypes.c_int32, c_vp, c_vp]),
     "smc_sobol": (c_int, [c_vp, c_i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_u64, c_vp]),
+    "smc_sobol_sorted": (c_int, [c_vp, c_i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_u64, c_vp]),
     "smc_filter_describe": (c_int, [c_vp, ctypes.c_char_p, c_sz]),
     "smc_poisson_logpmf": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp]),
     "smc_standard_normal": (c_int, [c_vp, c_u64, c_i64, c_vp]),

@@ -504,16 +504,21 @@ class SMC:
         inverse-CDF choice of ancestors, the others the move Gamma.  Sorts, gathers, inverse CDF
         and the inverse-normal-CDF move are device operators."""
         self.rs_flag = True
-        u = rqmc.sobol(self.N, self.fk.du + 1)
-        u0 = u[:, 0]
-        tau = hilbert.argsort(u0)
+        us = rqmc.sobol_sorted(self.N, self.fk.du + 1)             # = u[tau] without the sort, when
+        if us is not None:                                         # the order is known in closed form
+            u, tau, su0 = us, None, us[:, 0]
+        else:
+            u = rqmc.sobol(self.N, self.fk.du + 1)
+            tau = hilbert.argsort(u[:, 0])
+            su0 = u[:, 0][tau]
         self.h_order = hilbert.hilbert_sort(self.X)
-        self.A = self.h_order[rs.inverse_cdf(u0[tau], self.aux.W[self.h_order])]
+        self.A = self.h_order[rs.inverse_cdf(su0, self.aux.W[self.h_order])]
         self.Xp = self.X[self.A]
         if self.fk.du == 1:
-            v = u[:, 1][tau]                                       # u[tau, 1:].squeeze()
+            v = u[:, 1] if tau is None else u[:, 1][tau]           # u[tau, 1:].squeeze()
         elif isinstance(u, DeviceArray):
-            v = DeviceArray.stack_columns([u[:, 1 + i] for i in range(self.fk.du)])[tau]
+            v = DeviceArray.stack_columns([u[:, 1 + i] for i in range(self.fk.du)])
+            v = v if tau is None else v[tau]
         else:
             v = u[tau, 1:]
         self.reset_weights()

@@ -107,14 +107,26 @@ struct SobolTable {
     u32 shift[SOBOL_MAXD];
 };
 
+// order_k < 0: row j holds point j.  order_k = log2 N >= 0: row j holds the point with the j-th
+// smallest FIRST coordinate.  Dimension 1's direction numbers are v_b = 2^(29-b), so the top
+// log2 N bits of x_0 are bitrev(gray(n)) ^ (the shift's top bits): the sorted order is known in
+// closed form and SQMC's argsort(u[:, 0]) (core.py:343) needs no sort.
 __global__ void __launch_bounds__(SMC_BLOCK)
-k_sobol(const SobolTable tb, i64 N, int d, int safe, double* out)
+k_sobol(const SobolTable tb, i64 N, int d, int safe, int order_k, double* out)
 {
     const i64 i = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;
     if (i >= N * d) return;
-    const i64 n = i / d;
-    const int c = (int)(i - n * d);
-    u64 g = (u64)n ^ ((u64)n >> 1);
+    const i64 row = i / d;
+    const int c = (int)(i - row * d);
+    u64 g;
+    if (order_k < 0) {
+        g = (u64)row ^ ((u64)row >> 1);
+    } else if (order_k == 0) {
+        g = 0;
+    } else {
+        const u32 top = (u32)row ^ (tb.shift[0] >> (SOBOL_BITS - order_k));
+        g = (u64)(__brev(top) >> (32 - order_k));                         // gray(n) of that point
+    }
     u32 x = tb.shift[c];
     for (int k = 0; k < SOBOL_BITS && g; ++k, g >>= 1)
         if (g & 1) x ^= tb.v[c][k];
@@ -130,8 +142,8 @@ static const int SOBOL_M[SOBOL_MAXD + 1][5] = {{0}, {0}, {1}, {1, 3}, {1, 3, 1},
                                                {1, 1, 3, 3}, {1, 3, 5, 13}, {1, 1, 5, 5, 17},
                                                {1, 1, 5, 5, 5}, {1, 1, 7, 11, 19}};
 
-extern "C" int smc_sobol(smc_ctx* ctx, int64_t N, int32_t d, int32_t scramble, int32_t safe,
-                         uint64_t counter, double* out)
+static int sobol_launch(smc_ctx* ctx, int64_t N, int32_t d, int32_t scramble, int32_t safe,
+                        uint64_t counter, int order_k, double* out)
 {
     SMC_REQUIRE(ctx && out, "null argument");
     SMC_REQUIRE(N > 0 && N <= ((int64_t)1 << SOBOL_BITS), "N must be in [1, 2^30]");
@@ -167,7 +179,22 @@ extern "C" int smc_sobol(smc_ctx* ctx, int64_t N, int32_t d, int32_t scramble, i
     }
     const i64 tot = (i64)N * d;
     SMC_LAUNCH(k_sobol, dim3((unsigned)((tot + SMC_BLOCK - 1) / SMC_BLOCK)), dim3(SMC_BLOCK),
-               ctx->stream, tb, (i64)N, (int)d, (int)safe, out);
+               ctx->stream, tb, (i64)N, (int)d, (int)safe, order_k, out);
     SMC_LAUNCH_CHECK();
     return SMC_OK;
+}
+
+extern "C" int smc_sobol(smc_ctx* ctx, int64_t N, int32_t d, int32_t scramble, int32_t safe,
+                         uint64_t counter, double* out)
+{
+    return sobol_launch(ctx, N, d, scramble, safe, counter, -1, out);
+}
+
+extern "C" int smc_sobol_sorted(smc_ctx* ctx, int64_t N, int32_t d, int32_t scramble, int32_t safe,
+                                uint64_t counter, double* out)
+{
+    SMC_REQUIRE(N > 0 && (N & (N - 1)) == 0, "smc_sobol_sorted: N must be a power of two");
+    int k = 0;
+    while (((int64_t)1 << k) < N) ++k;
+    return sobol_launch(ctx, N, d, scramble, safe, counter, k, out);
 }

@@ -32,6 +32,18 @@ def sobol(N, d):
     return out
 
 
+def sobol_sorted(N, d):
+    """``u = sobol(N, d); u[np.argsort(u[:, 0])]`` -- the only way SQMC reads its points
+    (core.py:343-347) -- or None when only the generic route exists.  With device-generated points
+    and N a power of two the sorted order is known in closed form (`smc_sobol_sorted`): no sort, no
+    gather."""
+    if _lib.RNG_MODE[0] == "numpy" or N & (N - 1):
+        return None
+    out = DeviceArray((N, d))
+    check(lib().smc_sobol_sorted(out.ctx.h, N, d, 1, 1, _lib.next_counter(), out.ptr))
+    return out
+
+
 def sobol_unscrambled(N, d):
     """The first N points of the plain Sobol' sequence, from the device (tests: equals
     ``scipy.stats.qmc.Sobol(d, scramble=False).random(N)``)."""

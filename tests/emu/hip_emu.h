@@ -285,6 +285,13 @@ inline unsigned long long __ballot(int pred) {
     return m;
 }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline unsigned int __brev(unsigned int v)
+{
+    v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+    v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+    v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4);
+    return __builtin_bswap32(v);
+}
 inline void emu_wave_sync() { hipemu::wave_barrier(); }
 
 struct alignas(16) uint4 { unsigned x, y, z, w; };

@@ -1314,7 +1314,7 @@ def check_mv_collapsed(N, d, T=6):
         assert "collapsed" not in describe(e) and np.isfinite(e.logLt)
 
 
-def check_smc2(Ntheta=64, Nx=128, T=30, seed=3):
+def check_smc2(Ntheta=64, Nx=128, T=30, seed=3, big_Nx=()):
     """SMC^2 with the theta level on the device (particles_amd.smc2, smc_samplers.py:1038-1167).
     (1) With the theta-level ESS threshold at 0 nothing ever stops: the device's theta weights
     must then BE the islands' log-evidences, whatever the number of steps enqueued per sync.
@@ -1355,6 +1355,20 @@ def check_smc2(Ntheta=64, Nx=128, T=30, seed=3):
     assert all(0.0 <= r <= 1.0 for r in c.acc_rates) and len(c.acc_rates) == 2 * len(c.move_times)
     # every island of the surviving batch is at step T with a finite evidence
     assert np.all(np.isfinite(c.pf.logLts_islands))
+    # (2b) the same on the multi-kernel paths (N_x = 2048: two-level CDF; 3000: flat CDF)
+    if big_Nx:
+        for nx in big_Nx:
+            d = smc2.SMC2(ssm_cls=lambda sigmaY: kalman.LinearGauss(rho=1.0, sigmaX=1.0, sigmaY=sigmaY, sigma0=1.0),
+                          prior=prior, data=y[:12], init_Nx=nx, N=min(Ntheta, 16), seed=seed, ESSrmin=0.95,
+                          sync_every=5, nmcmc=1)
+            d.run()
+            assert d.t == 12 and len(d.ESSs) == 12 and np.isfinite(d.logLt), (d.t, d.ESSs, d.logLt)
+            assert len(d.move_times) >= 1, d.ESSs
+            d0 = smc2.SMC2(ssm_cls=lambda sigmaY: kalman.LinearGauss(rho=1.0, sigmaX=1.0, sigmaY=sigmaY, sigma0=1.0),
+                           prior=prior, data=y[:12], init_Nx=nx, N=min(Ntheta, 16), seed=seed, ESSrmin=0.0,
+                           sync_every=12)
+            d0.run()
+            assert np.array_equal(d0.lw, d0.pf.logLts_islands)
     # (3) exchange step: every move is "rejected too often" -> N_x doubles (once: max_Nx)
     e = mk(ESSrmin=0.5, sync_every=4, nmcmc=1, ar_to_increase_Nx=1.01, max_Nx=2 * Nx)
     e.run()
@@ -1696,6 +1710,25 @@ def check_sqmc(golden, monkeypatch, philox_N=4096, philox_runs=4, philox_T=40):
         assert ph.min() > 0.0 and ph.max() < 1.0
         for c in range(2):           # a (0, m, 1)-net in base 2 survives the digital shift
             assert np.array_equal(np.sort(np.floor(ph[:, c] * 1024).astype(int)), np.arange(1024))
+        # the closed-form sorted order: sobol_sorted == sobol[argsort(first coordinate)], same stream
+        for n, d in ((1, 2), (2, 3), (64, 2), (1024, 4), (1 << 14, 2)):
+            pa.seed(11 + n)
+            u = rqmc.sobol(n, d).get()
+            pa.seed(11 + n)
+            us = rqmc.sobol_sorted(n, d)
+            assert np.array_equal(us.get(), u[np.argsort(u[:, 0], kind="stable")])
+        assert rqmc.sobol_sorted(1000, 2) is None                 # not a power of two: the generic route
+        # ... and the SQMC run is the same run with or without it (X, A, logLt bit for bit)
+        runs = []
+        for closed_form in (True, False):
+            if not closed_form:
+                monkeypatch.setattr(rqmc, "sobol_sorted", lambda N, d: None)
+            pa.seed(77)
+            pf = pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y[:8]), N=2048, qmc=True)
+            pf.run()
+            runs.append((np.asarray(pf.X), np.asarray(pf.A), pf.logLt))
+        monkeypatch.undo()
+        assert all(np.array_equal(a, b) for a, b in zip(runs[0], runs[1]))
         lls = []
         for s in range(philox_runs):
             pa.seed(100 + s)

@@ -237,7 +237,7 @@ def test_device_sort():
 
 
 def test_smc2_device_theta_level():
-    pc.check_smc2()
+    pc.check_smc2(big_Nx=(2048,))
 
 
 def test_rolling_history_on_device():

@@ -446,7 +446,7 @@ def test_device_sort():
 
 
 def test_smc2_device_theta_level():
-    pc.check_smc2(Ntheta=256, Nx=512, T=60)
+    pc.check_smc2(Ntheta=256, Nx=512, T=60, big_Nx=(2048, 3000))
 
 
 def test_rolling_history_on_device():

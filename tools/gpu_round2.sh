@@ -53,6 +53,8 @@ prof_c5)
   EXTRA="--workload c5" bash tools/gpu_profile.sh ${TAG}_c5 100 > $O/prof_c5.txt 2>&1; tail -30 $O/prof_c5.txt ;;
 trace)
   timeout 200 python tools/trace_step.py 20 > $O/trace_step.txt 2>&1; cat $O/trace_step.txt ;;
+sqmc)
+  timeout 200 python tools/sort_perf.py > $O/sort_perf.txt 2>&1; cat $O/sort_perf.txt ;;
 balance)
   timeout 120 python tools/tile_balance.py 20 > $O/tile_balance.txt 2>&1; cat $O/tile_balance.txt ;;
 esac; done
