@@ -119,20 +119,45 @@ class SMC2:
         self.ESSs, self.Nxs, self.acc_rates, self.move_times = [], [self.Nx], [], []
         self._nbatch = 0
         self._lw_at_reset = np.zeros(self.N)
+        self._lo, self._hi = self._my_slice()
         self.pf = self._batch(self.theta, self.Nx, theta_level=True)
 
     # ------------------------------------------------------------------ batches of filters
+    def _my_slice(self):
+        """The theta-particles whose filters live in this process (all of them here)."""
+        return 0, self.N
+
     def _batch(self, theta, Nx, theta_level=False):
+        """One filter per theta-particle of my slice, islands of one device filter; the Philox
+        streams are keyed by the GLOBAL theta index (island_offset), so a sharded population
+        runs the same filters as a single-process one."""
         fks = [self.fk_cls(ssm=self.ssm_cls(**{k: float(theta[k][i]) for k in self.names}), data=self.data)
-               for i in range(self.N)]
+               for i in range(self._lo, self._hi)]
         self._nbatch += 1
         pf = SMC(fk=fks, N=Nx, seed=(self._seed + 7919 * self._nbatch) % (2 ** 31 - 1), collect="off",
-                 **self.smc_options)
+                 island_offset=self._lo, **self.smc_options)
         if not pf._fused:
             raise ValueError("SMC2 needs a state-space model of the fused family")
         if theta_level:
-            check(lib().smc_filter_theta_enable(pf._f, float(self.ESSrmin)))
+            self._enable_theta_level(pf)
         return pf
+
+    # ---- the four places where a sharded population differs (ShardedSMC2 overrides them)
+    def _enable_theta_level(self, pf):
+        check(lib().smc_filter_theta_enable(pf._f, float(self.ESSrmin)))
+
+    def _evidences(self, pf):
+        """log-evidence of the filter of EVERY theta-particle, (N,)."""
+        return pf.logLts_islands
+
+    def _resample_filters(self, A):
+        check(lib().smc_filter_theta_resume(self.pf._f, None))     # time records back to t first
+        self.pf.permute_islands(A)
+
+    def _adopt(self, new, liw):
+        """Exchange step: `new` (2 N_x particles, at step t) replaces the batch; theta-weights liw."""
+        self._enable_theta_level(new)                                              # from step t on
+        check(lib().smc_filter_theta_resume(new._f, liw[self._lo:self._hi].ctypes.data_as(_lib.c_vp)))
 
     def _theta_state(self, pf):
         lw = np.empty(self.N)
@@ -185,14 +210,12 @@ class SMC2:
         cov = (X - mu).T @ ((X - mu) * W[:, None])
         d = len(self.names)
         L = np.linalg.cholesky((2.38 ** 2 / d) * cov + 1e-12 * np.eye(d))
-        # resume first (time records back to t), then move the islands
-        check(lib().smc_filter_theta_resume(self.pf._f, None))
-        self.pf.permute_islands(A)
+        self._resample_filters(A)
         self.theta = {k: v[A].copy() for k, v in self.theta.items()}
         self.lw = np.zeros(self.N)
         self._lw_at_reset = np.zeros(self.N)
         # ---- PMCMC move (smc_samplers.py:1129-1143): candidates re-run from 0 to t
-        lp_cur = np.asarray(self.prior.logpdf(self.theta), dtype=float) + self.pf.logLts_islands
+        lp_cur = np.asarray(self.prior.logpdf(self.theta), dtype=float) + self._evidences(self.pf)
         acc_rate = 0.0
         for sweep in range(self.nmcmc):
             Z = self.rng.standard_normal((self.N, d)) @ L.T
@@ -203,10 +226,10 @@ class SMC2:
             safe = {k: np.where(ok, prop[k], self.theta[k]) for k in self.names}   # a valid model for every island
             cand = self._batch(safe, self.Nx)
             cand.step_async(self.t)
-            lp_prop = np.where(ok, lprior + cand.logLts_islands, -np.inf)
+            lp_prop = np.where(ok, lprior + self._evidences(cand), -np.inf)
             acc = np.log(self.rng.random_sample(self.N)) < lp_prop - lp_cur
             acc &= ok
-            self.pf.accept_islands_from(cand, acc)
+            self.pf.accept_islands_from(cand, acc[self._lo:self._hi])
             self.theta = {k: np.where(acc, prop[k], self.theta[k]) for k in self.names}
             lp_cur = np.where(acc, lp_prop, lp_cur)
             acc_rate = float(np.mean(acc))
@@ -216,9 +239,8 @@ class SMC2:
         if 0.0 <= acc_rate < self.ar_to_increase_Nx and 2 * self.Nx <= self.max_Nx:
             new = self._batch(self.theta, 2 * self.Nx)
             new.step_async(self.t)
-            liw = np.ascontiguousarray(new.logLts_islands - self.pf.logLts_islands)
-            check(lib().smc_filter_theta_enable(new._f, float(self.ESSrmin)))       # from step t on
-            check(lib().smc_filter_theta_resume(new._f, liw.ctypes.data_as(_lib.c_vp)))
+            liw = np.ascontiguousarray(self._evidences(new) - self._evidences(self.pf))
+            self._adopt(new, liw)
             self.pf = new
             self.Nx *= 2
             self.lw = liw.copy()
@@ -234,3 +256,77 @@ class SMC2:
     def posterior_sd(self):
         W, m = self.W, self.posterior_mean()
         return {k: float(np.sqrt(np.sum(W * (v - m[k]) ** 2))) for k, v in self.theta.items()}
+
+
+class ShardedSMC2(SMC2):
+    """SMC^2 with the theta-population sharded over the GPUs of a node (one process per GPU,
+    ``group`` = `particles_amd.distributed.Group`): rank r holds the filters of theta-particles
+    r M .. r M + M - 1 (M = N / world) as islands of its device filter.
+
+    The theta level itself (N values of theta, N log-weights) is replicated: every rank draws the
+    same prior sample, the same resampling uniforms and the same random-walk proposals from one
+    seeded host generator, so the only data that crosses GPUs is
+
+    * per time step, the all-gather of the filters' evidence increments (N x 8 bytes over RCCL:
+      `Group.gather_evidence`) -- the theta-level ESS needs all of them, this is the exchange step
+      of the path;
+    * at a theta-resampling, whole filters: `Group.migrate_islands` (packed island states through one
+      all-to-all of ncclSend / ncclRecv pairs over xGMI; N_x x (16 d + 40) bytes per island and more
+      with history).
+
+    Philox streams are keyed by the global theta index and migration keeps them tied to the slot,
+    so the run is the SAME run for any world size (tests: world 2 == world 1, bit for bit)."""
+
+    def __init__(self, group=None, **kw):
+        self.group = group
+        world = group.world if group is not None else 1
+        if kw.get("N", 100) % world:
+            raise ValueError("ShardedSMC2: N must be a multiple of the number of ranks")
+        if not isinstance(kw.get("prior"), IndepPrior):
+            raise ValueError("ShardedSMC2 draws the replicated prior sample from its own seeded generator: "
+                             "use an IndepPrior")
+        if kw.get("seed") is None:
+            raise ValueError("ShardedSMC2 needs a seed (the same on every rank)")
+        super().__init__(**kw)
+        self._cum0 = np.zeros(self.N)        # filters' evidences at the last reset of the theta-weights
+        self._lw0 = np.zeros(self.N)         # theta log-weights at that reset
+
+    def _my_slice(self):
+        if self.group is None:
+            return 0, self.N
+        M = self.N // self.group.world
+        return self.group.rank * M, (self.group.rank + 1) * M
+
+    def _enable_theta_level(self, pf):
+        pass                      # the theta-level ESS needs every rank's increments: done in run()
+
+    def _evidences(self, pf):
+        local = pf.logLts_islands
+        return local if self.group is None else self.group.gather_evidence(local)
+
+    def _resample_filters(self, A):
+        if self.group is None:
+            self.pf.permute_islands(A)
+        else:
+            self.group.migrate_islands(self.pf, A)
+
+    def _adopt(self, new, liw):
+        pass
+
+    def _resample_move(self):
+        super()._resample_move()
+        self._cum0 = self._evidences(self.pf)      # after the moves: accepted filters changed theirs
+        self._lw0 = self.lw.copy()                 # zeros, or the exchange step's evidence ratios
+
+    def run(self):
+        while self.t < self.T:
+            self.pf.step_async(1)
+            self.t += 1
+            self.lw = self._lw0 + (self._evidences(self.pf) - self._cum0)
+            w = np.exp(self.lw - self.lw.max())
+            ess = float(w.sum() ** 2 / np.sum(w * w))
+            self.ESSs.append(ess)
+            if ess < self.ESSrmin * self.N:
+                self._resample_move()
+        self.logLt += self._log_mean(self.lw) - self._log_mean(self._lw_at_reset)
+        return self

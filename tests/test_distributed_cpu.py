@@ -130,3 +130,80 @@ def test_island_migration_world2_and_3_match_world1(tmp_path):
     import numpy as np
     base = _run_world(1, tmp_path)
     assert not np.allclose(base["ll"], one["ll"])          # the permutation did change the run
+
+
+SMC2_WORKER = r"""
+import os, sys, json
+sys.path.insert(0, {root!r})
+sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np
+import conftest
+conftest.pytest_configure(type("C", (), {{"addinivalue_line": lambda *a: None}})())
+from particles_amd import kalman, smc2
+from particles_amd.distributed import Group
+
+grp = Group(device_collective=os.environ.get("SMC_TEST_RCCL") == "1")
+rng = np.random.RandomState(4)
+T = int(os.environ.get("SMC_TEST_T", "14"))
+x = np.cumsum(rng.standard_normal(T))
+y = [np.array([v]) for v in x + 0.3 * rng.standard_normal(T)]
+prior = smc2.IndepPrior(sigmaY=("lognormal", np.log(0.8), 1.2))
+kw = dict(ssm_cls=lambda sigmaY: kalman.LinearGauss(rho=1.0, sigmaX=1.0, sigmaY=sigmaY, sigma0=1.0),
+          prior=prior, data=y, init_Nx=int(os.environ.get("SMC_TEST_NX", "128")), N=12, seed=5,
+          ESSrmin=0.8, nmcmc=2, ar_to_increase_Nx=float(os.environ.get("SMC_TEST_AR", "-1")), max_Nx=256)
+alg = smc2.ShardedSMC2(group=grp, **kw)
+alg.run()
+single = None
+if grp.world == 1:                 # the one-GPU class (theta level on the device) on the same problem
+    ref = smc2.SMC2(**kw)
+    ref.run()
+    single = {{"lw": ref.lw.tolist(), "theta": ref.theta["sigmaY"].tolist(), "logLt": ref.logLt,
+               "moves": len(ref.move_times)}}
+if grp.rank == 0:
+    print("RESULT " + json.dumps({{"lw": alg.lw.tolist(), "theta": alg.theta["sigmaY"].tolist(),
+                                   "logLt": alg.logLt, "ESSs": alg.ESSs, "moves": len(alg.move_times),
+                                   "acc": alg.acc_rates, "Nx": alg.Nx, "path": grp.evidence_path,
+                                   "local": alg.pf.n_islands, "single": single}}))
+grp.close()
+"""
+
+
+def _run_smc2_world(world, tmp_path, **env_extra):
+    script = tmp_path / "smc2_worker.py"
+    script.write_text(SMC2_WORKER.format(root=ROOT))
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SMC_HIP_DEVICE="0", **env_extra)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    import json
+    line = [l for l in outs[0].splitlines() if l.startswith("RESULT ")][0]
+    return json.loads(line[7:])
+
+
+def test_sharded_smc2_is_world_invariant(tmp_path):
+    """SMC^2 with the theta-population sharded over ranks (per-step all-gather of the evidence
+    increments, theta-resampling = migration of whole filters, PMCMC moves local): the run is the
+    same run for 1, 2 and 3 ranks -- theta-particles, theta-weights, evidence, ESS trajectory bit for
+    bit -- and agrees with the one-GPU class whose theta level lives on the device."""
+    one = _run_smc2_world(1, tmp_path)
+    two = _run_smc2_world(2, tmp_path)
+    three = _run_smc2_world(3, tmp_path)
+    assert one["moves"] >= 1 and one["local"] == 12 and two["local"] == 6 and three["local"] == 4
+    for other in (two, three):
+        for k in ("lw", "theta", "logLt", "ESSs", "moves", "acc", "Nx"):
+            assert one[k] == other[k], k
+    assert np.isfinite(one["logLt"]) and len(one["ESSs"]) == 14
+    # the one-GPU class accumulates the theta-weights on the device (increment by increment), this one
+    # differences the cumulated evidences: ulps apart, same decisions
+    s = one["single"]
+    assert s["moves"] == one["moves"] and np.allclose(s["theta"], one["theta"], rtol=1e-12, atol=0)
+    assert np.allclose(s["lw"], one["lw"], rtol=0, atol=1e-9) and abs(s["logLt"] - one["logLt"]) < 1e-9
+    # with the exchange step (N_x doubles when moves are rejected too often)
+    e1 = _run_smc2_world(1, tmp_path, SMC_TEST_AR="1.01", SMC_TEST_T="8")
+    e2 = _run_smc2_world(2, tmp_path, SMC_TEST_AR="1.01", SMC_TEST_T="8")
+    assert e1["Nx"] == 256 and all(e1[k] == e2[k] for k in ("lw", "theta", "logLt", "ESSs", "Nx"))

@@ -493,5 +493,20 @@ def test_island_migration_through_rccl(tmp_path):
     assert res["path"] == "rccl" and res["same"]
 
 
+def test_sharded_smc2_over_rccl(tmp_path):
+    """ShardedSMC2 on the device: world 1 with the RCCL communicator (all-gather of the evidence
+    increments every step, migration through smc_comm_alltoallv), then two ranks on this box's one
+    GPU (RCCL if it accepts two ranks per device, the labelled host fallback otherwise): the same run
+    bit for bit; larger filters (N_x = 4096: the multi-kernel step) as well."""
+    from test_distributed_cpu import _run_smc2_world
+    for nx in ("128", "4096"):
+        one = _run_smc2_world(1, tmp_path, SMC_TEST_RCCL="1", SMC_TEST_NX=nx)
+        two = _run_smc2_world(2, tmp_path, SMC_TEST_RCCL="1", SMC_ALLOW_HOST_GATHER="1", SMC_TEST_NX=nx)
+        assert one["path"] == "rccl" and one["moves"] >= 1
+        assert two["path"] == "rccl" or two["path"].startswith("host-fallback: ")
+        for k in ("lw", "theta", "logLt", "ESSs", "moves", "acc"):
+            assert one[k] == two[k], k
+
+
 def test_apf_and_guided_stochvol_fused(golden):
     pc.check_apf_fused(golden)
