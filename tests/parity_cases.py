@@ -930,7 +930,7 @@ def check_small_filter_equals_general(golden, monkeypatch, full=True):
     bits of the multi-kernel path -- models, schemes, adaptive resampling, islands, stepping
     one step at a time, history -- and replays the reference's run."""
     g = golden("kalman_toy")
-    y = [np.atleast_1d(v) for v in np.squeeze(g["y"])][:60]
+    y = [np.atleast_1d(v) for v in np.squeeze(g["y"])][:60 if full else 30]
     cases = [
         (lambda: kalman.ToySSM(0.2), ssm.Bootstrap, "systematic", 1000, 0.5),
         (lambda: kalman.ToySSM(0.2), ssm.Bootstrap, "systematic", 256, 0.5),
@@ -1186,12 +1186,11 @@ def check_islands(N, T, golden, scheme="stratified"):
     assert [d["run"] for d in out] == [0, 1, 2] and all(np.isfinite(d["output"]) for d in out)
 
 
-def check_permute_islands(N, golden, tol=0.3):
+def check_permute_islands(N, golden, tol=0.3, T=40, t0=15):
     """One model per island (SMC^2: one theta each) and theta-level resampling of whole
     filters (smc_samplers.py:319-361): identity and round trips are exact, copies carry
     particles, evidence and parameters, and every island goes on under its new theta."""
     g = golden("kalman_toy")
-    T, t0 = 40, 15
     y = [np.atleast_1d(v) for v in np.squeeze(g["y"])][:T]
     sig = [0.2, 0.5, 1.5]
     mk = lambda: pa.SMC(fk=[ssm.Bootstrap(ssm=kalman.ToySSM(s), data=y) for s in sig], N=N, seed=77,
@@ -1314,7 +1313,7 @@ def check_mv_collapsed(N, d, T=6):
         assert "collapsed" not in describe(e) and np.isfinite(e.logLt)
 
 
-def check_smc2(Ntheta=64, Nx=128, T=30, seed=3, big_Nx=()):
+def check_smc2(Ntheta=64, Nx=128, T=30, seed=3, big_Nx=(), big_N=16, big_T=12):
     """SMC^2 with the theta level on the device (particles_amd.smc2, smc_samplers.py:1038-1167).
     (1) With the theta-level ESS threshold at 0 nothing ever stops: the device's theta weights
     must then BE the islands' log-evidences, whatever the number of steps enqueued per sync.
@@ -1357,16 +1356,15 @@ def check_smc2(Ntheta=64, Nx=128, T=30, seed=3, big_Nx=()):
     assert np.all(np.isfinite(c.pf.logLts_islands))
     # (2b) the same on the multi-kernel paths (N_x = 2048: two-level CDF; 3000: flat CDF)
     if big_Nx:
+        mkb = lambda nx, **kw: smc2.SMC2(
+            ssm_cls=lambda sigmaY: kalman.LinearGauss(rho=1.0, sigmaX=1.0, sigmaY=sigmaY, sigma0=1.0),
+            prior=prior, data=y[:big_T], init_Nx=nx, N=min(Ntheta, big_N), seed=seed, **kw)
         for nx in big_Nx:
-            d = smc2.SMC2(ssm_cls=lambda sigmaY: kalman.LinearGauss(rho=1.0, sigmaX=1.0, sigmaY=sigmaY, sigma0=1.0),
-                          prior=prior, data=y[:12], init_Nx=nx, N=min(Ntheta, 16), seed=seed, ESSrmin=0.95,
-                          sync_every=5, nmcmc=1)
+            d = mkb(nx, ESSrmin=0.99, sync_every=5, nmcmc=1)
             d.run()
-            assert d.t == 12 and len(d.ESSs) == 12 and np.isfinite(d.logLt), (d.t, d.ESSs, d.logLt)
+            assert d.t == big_T and len(d.ESSs) == big_T and np.isfinite(d.logLt), (d.t, d.ESSs, d.logLt)
             assert len(d.move_times) >= 1, d.ESSs
-            d0 = smc2.SMC2(ssm_cls=lambda sigmaY: kalman.LinearGauss(rho=1.0, sigmaX=1.0, sigmaY=sigmaY, sigma0=1.0),
-                           prior=prior, data=y[:12], init_Nx=nx, N=min(Ntheta, 16), seed=seed, ESSrmin=0.0,
-                           sync_every=12)
+            d0 = mkb(nx, ESSrmin=0.0, sync_every=big_T)
             d0.run()
             assert np.array_equal(d0.lw, d0.pf.logLts_islands)
     # (3) exchange step: every move is "rejected too often" -> N_x doubles (once: max_Nx)
@@ -1626,7 +1624,8 @@ def check_indep_prod(golden):
     assert d.rvs(size=10).shape == (10, 3) and d.dim == 3
 
 
-def check_sqmc(golden, monkeypatch, philox_N=4096, philox_runs=4, philox_T=40):
+def check_sqmc(golden, monkeypatch, philox_N=4096, philox_runs=4, philox_T=40, sorted_N=(1, 2, 64, 1024, 1 << 14),
+               ab_N=2048, both_modes_for_all=True):
     """SQMC (SMC(qmc=True), core.py:315-349) on device operators: the reference's runs on its
     recorded Sobol' points; then the operators themselves (Sobol' generator vs scipy's, ndtri
     vs scipy's, argsort vs numpy's) and a run on device-generated points against Kalman."""
@@ -1639,7 +1638,7 @@ def check_sqmc(golden, monkeypatch, philox_N=4096, philox_runs=4, philox_T=40):
     for case, mk, cls in cases:
         g = golden(case)
         y = list(g["y"])
-        for resident in (False, True):
+        for resident in ((False, True) if both_modes_for_all or case == "sqmc_mv2" else (True,)):
             tape = [g["u0"]] + list(g["u"])
             it = iter(tape)
 
@@ -1711,7 +1710,7 @@ def check_sqmc(golden, monkeypatch, philox_N=4096, philox_runs=4, philox_T=40):
         for c in range(2):           # a (0, m, 1)-net in base 2 survives the digital shift
             assert np.array_equal(np.sort(np.floor(ph[:, c] * 1024).astype(int)), np.arange(1024))
         # the closed-form sorted order: sobol_sorted == sobol[argsort(first coordinate)], same stream
-        for n, d in ((1, 2), (2, 3), (64, 2), (1024, 4), (1 << 14, 2)):
+        for n, d in zip(sorted_N, (2, 3, 2, 4, 2, 3, 2)):
             pa.seed(11 + n)
             u = rqmc.sobol(n, d).get()
             pa.seed(11 + n)
@@ -1724,7 +1723,7 @@ def check_sqmc(golden, monkeypatch, philox_N=4096, philox_runs=4, philox_T=40):
             if not closed_form:
                 monkeypatch.setattr(rqmc, "sobol_sorted", lambda N, d: None)
             pa.seed(77)
-            pf = pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y[:8]), N=2048, qmc=True)
+            pf = pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y[:8]), N=ab_N, qmc=True)
             pf.run()
             runs.append((np.asarray(pf.X), np.asarray(pf.A), pf.logLt))
         monkeypatch.undo()

@@ -68,7 +68,8 @@ def test_gather():
 
 
 def test_sqmc(golden, monkeypatch):
-    pc.check_sqmc(golden, monkeypatch, philox_N=2048, philox_runs=2, philox_T=15)   # (emulated sorts are slow)
+    pc.check_sqmc(golden, monkeypatch, philox_N=1024, philox_runs=2, philox_T=10,   # (emulated sorts are slow)
+                  sorted_N=(1, 2, 64, 1024), ab_N=512, both_modes_for_all=False)
 
 
 def test_indep_prod(golden):
@@ -137,7 +138,7 @@ def test_two_level_adaptive(golden):
 
 
 def test_heavy_parents(monkeypatch):
-    pc.check_heavy_parents(monkeypatch)
+    pc.check_heavy_parents(monkeypatch, T=6)
 
 
 def test_two_level_cdf(golden, monkeypatch):
@@ -192,8 +193,8 @@ def test_apf_and_guided_generic(golden):
 
 
 def test_permute_islands(golden):
-    pc.check_permute_islands(3000, golden)
-    pc.check_permute_islands(2048, golden, tol=0.6)             # two-level path: partials travel too
+    pc.check_permute_islands(3000, golden, T=20, t0=8)
+    pc.check_permute_islands(2048, golden, tol=0.6, T=20, t0=8)  # two-level path: partials travel too
 
 
 def test_collectors_and_history(golden):
@@ -237,7 +238,7 @@ def test_device_sort():
 
 
 def test_smc2_device_theta_level():
-    pc.check_smc2(big_Nx=(2048,))
+    pc.check_smc2(Ntheta=32, Nx=64, big_Nx=(2048,), big_N=4, big_T=6)
 
 
 def test_rolling_history_on_device():
