@@ -53,6 +53,18 @@ prof_c5)
   EXTRA="--workload c5" bash tools/gpu_profile.sh ${TAG}_c5 100 > $O/prof_c5.txt 2>&1; tail -30 $O/prof_c5.txt ;;
 trace)
   timeout 200 python tools/trace_step.py 20 > $O/trace_step.txt 2>&1; cat $O/trace_step.txt ;;
+bench2)
+  # the N = 2 launch line of the driver, both ranks on this box's one GPU (functional: RCCL may refuse 2 ranks per device)
+  SMC_BENCH_NGPU=1 SMC_ALLOW_HOST_GATHER=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
+      --master-addr 127.0.0.1 --master-port 29655 bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline --no-profile > $O/bench_2ranks_1gpu.json 2> $O/bench_2ranks_1gpu.err
+  python - "$O/bench_2ranks_1gpu.json" <<'PY'
+import json,sys
+try:
+    d=json.loads([l for l in open(sys.argv[1]) if l.startswith('{')][-1])
+    print('2 ranks / 1 GPU: ms/step %.5f'%d['ms_per_step'], 'G/s %.2f'%(d['value']/1e9), d['evidence_gather'], 'gather ms', d['evidence_gather_ms'], d['timing'].get('note','')[-90:])
+except Exception as e: print('bench2 FAILED', e, open(sys.argv[1].replace('.json','.err')).read()[-600:])
+PY
+  ;;
 sqmc)
   timeout 200 python tools/sort_perf.py > $O/sort_perf.txt 2>&1; cat $O/sort_perf.txt ;;
 balance)
