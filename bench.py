@@ -167,7 +167,13 @@ def main():
     from particles_amd import state_space_models as ssm
     from particles_amd.distributed import Group
 
+    # a multi-GPU bench line with a LABELLED host gather ("evidence_gather": "host-fallback: <reason>")
+    # is worth more than no line: the gather is outside the timed region either way
+    os.environ.setdefault("SMC_ALLOW_HOST_GATHER", "1")
     grp = Group(device_collective=True) if world > 1 else None
+    if grp and grp.rank == 0 and grp.evidence_path != "rccl":
+        print("bench.py: RCCL unavailable, evidences gathered over the host rendezvous (%s)" % grp.evidence_path,
+              file=sys.stderr)
     K, W = a.steps, a.warmup
     heavy = a.workload in ("c3", "c4", "c5")        # 0.07-0.3 ms per step: fewer timed steps do
     R = a.reps if a.reps > 0 else max(3, min(500, -(-(2000 if heavy else 10000) // K)))

@@ -29,6 +29,7 @@ struct smc_filter {
     bool prof;
     std::vector<hipEvent_t> ev;
     int prof_n;
+    bool no_tk;            // SMC_NO_TK=1: kernels never start on the host's time index (A/B)
     double* tmp;           // (N,) staging for W / Xp downloads
     double* ll_stage;      // (n_islands,) staging for smc_filter_logLt: PINNED host memory the
                            // collect kernel writes straight into (no copy engine, no staging)
@@ -88,11 +89,12 @@ static void launch_propagate(smc_filter* f)
 
 // one time step: [k_prepare, (spacings), k_ancestors] do nothing unless the step
 // resamples (decided on the device by the previous k_propagate), then k_propagate
-static void enqueue_step(smc_filter* f, int k_prof, i64 t)
+static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
 {
     // the host knows the time index of every step it enqueues; inside a replayed graph
     // only its parity is static (graphs hold an even number of steps and start at even t)
     f->a.par = f->a.hist ? -1 : (int)(t & 1);
+    f->a.tk = (t_known && !f->no_tk) ? t : -1;
     hipStream_t st = f->ctx->stream;
     const dim3 grid(f->a.ntiles, f->a.n_islands);
     if (k_prof >= 0) (void)hipEventRecord(f->ev[3 * k_prof], st);
@@ -324,6 +326,8 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
         F_CREATE_CHECK(hipMemsetAsync(a.hcnt, 0, M * 2 * sizeof(unsigned), ctx->stream));
     }
     a.exact_counts = getenv("SMC_EXACT_COUNTS") ? 1 : 0;
+    f->no_tk = getenv("SMC_NO_TK") != nullptr;
+    a.tk = -1;
     // streaming stores pay while a launch is short (its end-of-kernel write-back shows): C2 +8 %;
     // on the large grids they cost 2 % (C5)
     a.nt = ((i64)a.ntiles * (i64)M <= F_DIRECT_PREFIX_MAX && !mv && !getenv("SMC_NO_NT")) ? 1 : 0;
@@ -508,7 +512,7 @@ int smc_filter_step(smc_filter* f, int64_t nsteps)
                 hipGraph_t g = nullptr;
                 bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
                 if (ok) {
-                    for (int k = 0; k < GS; ++k) enqueue_step(f, -1, k);
+                    for (int k = 0; k < GS; ++k) enqueue_step(f, -1, k, false);
                     ok = hipStreamEndCapture(st, &g) == hipSuccess && g &&
                          hipGraphInstantiate(&f->gexec[gi], g, nullptr, nullptr, 0) == hipSuccess;
                 }

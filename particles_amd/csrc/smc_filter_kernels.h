@@ -72,6 +72,10 @@ struct FArgs {
                            // stays resident); k >= 2: a ring of k slots (the k most recent steps)
     int par;               // t & 1 of the step this launch runs, or -1 (history slots): lets the
                            // kernels form their addresses before the step record has arrived
+    i64 tk;                // the time index the HOST expects this launch to run (eager launches), or -1
+                           // (inside a captured graph): work that depends on t only -- the step's
+                           // normals -- starts on it while the step record is still on its way, and is
+                           // redone with the record's t if the two differ (same bits either way)
     u64* Q;                // (n_islands, ntiles) tile totals of q
     u64* Qpre;             // (n_islands, ntiles) exclusive prefixes of Q
     double *pm, *ps, *pss; // (n_islands, ntiles) log-sum-exp partials (two-level path: K_b, S_b, SS_b)
@@ -1002,7 +1006,7 @@ k_propagate(const FArgs av)
     double* info = a.info + (i64)isl * INFO_STRIDE;
     const i64 N = a.N;
     const FOwn own = f_own<!TAIL>(b, tid, N);
-    const bool full = own.full;
+    const bool full = !TAIL || own.full;           // (!TAIL: N is a multiple of the tile, every thread owns 4)
     const double r0 = smc_ldg(info), r1 = smc_ldg(info + 1), r2 = smc_ldg(info + 2),
                  r5 = smc_ldg(info + 5);
     unsigned nh0 = 0u, nh1 = 0u;                   // registered heavy parents, either parity of t
@@ -1023,20 +1027,34 @@ k_propagate(const FArgs av)
             }
         }
     };
-    if (SPEC && own.na < N) load_anc(a.A + (i64)isl * N);
+    // ---- the step's standard normals depend on (seed, island, particle, t) only: with the host's
+    // t (a.tk) one pair is generated while the ancestor indices are on their way and the other
+    // behind the gather they trigger -- the first bytes of a dependent launch take 1.2-2 us to
+    // arrive (profiles/r02i_trace_step.txt: "record"), the gather another ~0.8 us.  (Loads, first
+    // pair and gather sit in ONE conditional block: a load left pending across a branch makes the
+    // compiler wait for everything at the next write of its destination registers.)
+    const u32 gisl = (u32)(a.island_offset + isl);
+    double zs[OPT] = {0.0, 0.0, 0.0, 0.0};
+    const bool spec_z = a.tk >= 0 && !a.zt && own.na < N;
     double xg[OPT];
     if (SPEC && own.na < N) {      // A always holds valid indices (zeros before the first resampling)
+        load_anc(a.A + (i64)isl * N);
+        if (spec_z)
+            smc_normal_pair(a.seed, (u32)(own.na >> 1), (u32)a.tk, gisl, SMC_STREAM_NORMAL, zs[0], zs[1]);
         const double* Xs = a.X + (i64)(a.par ^ 1) * a.xslot + (i64)isl * N;
 #pragma unroll
         for (int k = 0; k < OPT; ++k) xg[k] = smc_ldg(Xs + an[k]);
+    } else if (spec_z) {
+        smc_normal_pair(a.seed, (u32)(own.na >> 1), (u32)a.tk, gisl, SMC_STREAM_NORMAL, zs[0], zs[1]);
     }
+    if (spec_z)
+        smc_normal_pair(a.seed, (u32)(own.nb >> 1), (u32)a.tk, gisl, SMC_STREAM_NORMAL, zs[2], zs[3]);
     const i64 t = (i64)smc_uniform(r0);
     if (t >= a.T) return;
     F_STAMP(1);
     const double* p = a.params + (i64)isl * PARAM_STRIDE;
     const double yt = smc_uniform(r2);
     const double aux = m_has_aux<KIND>() ? smc_uniform(r5) : 0.0;
-    const u32 gisl = (u32)(a.island_offset + isl);
     double* Xn = (SPEC ? a.X + (i64)a.par * a.xslot : f_X(a, t)) + (i64)isl * N;
     const double* Xo = (SPEC ? a.X + (i64)(a.par ^ 1) * a.xslot : f_X(a, t - 1)) + (i64)isl * N;
     double* lwn = (SPEC ? a.lw + (i64)a.par * a.lslot : f_lw(a, t)) + (i64)isl * N;
@@ -1093,6 +1111,9 @@ k_propagate(const FArgs av)
                 const i64 n = f_own_idx(own, k);
                 z[k] = (n < N) ? smc_ldg(zt + n) : 0.0;
             }
+        } else if (spec_z && t == a.tk) {
+#pragma unroll
+            for (int k = 0; k < OPT; ++k) z[k] = zs[k];
         } else {
             smc_normal_pair(a.seed, (u32)(own.na >> 1), (u32)t, gisl, SMC_STREAM_NORMAL, z[0], z[1]);
             smc_normal_pair(a.seed, (u32)(own.nb >> 1), (u32)t, gisl, SMC_STREAM_NORMAL, z[2], z[3]);
@@ -1485,8 +1506,8 @@ k_ancestors2(const FArgs av)
     if (t == 0) return;                                        // the host wrote the record of step 0
     if (MID && smc_uniform(r1) == 0.0) return;                 // k_reduce2: step t does not resample
     F_STAMP_A(1);
-    SmcSu su;                                                  // (the step's uniform: a Philox call
-    u64 Us;                                                    //  in the shadow of the loads)
+    SmcSu su;                                                  // (the step's uniform: one Philox call,
+    u64 Us;                                                    //  all inputs uniform: scalar unit)
     f2_su(a, isl, t, su, Us);
     double Gd, Qd;
     if (MID) {

@@ -53,6 +53,22 @@ prof_c5)
   EXTRA="--workload c5" bash tools/gpu_profile.sh ${TAG}_c5 100 > $O/prof_c5.txt 2>&1; tail -30 $O/prof_c5.txt ;;
 trace)
   timeout 200 python tools/trace_step.py 20 > $O/trace_step.txt 2>&1; cat $O/trace_step.txt ;;
+abtk)
+  for v in 0 1; do
+    if [ $v = 1 ]; then export SMC_NO_TK=1; else unset SMC_NO_TK; fi
+    timeout 300 python bench.py --steps 1000 --warmup 50 --no-cpu-baseline > $O/bench_c2_notk$v.json 2>&1
+    timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_c2k20_notk$v.json 2>&1
+    timeout 300 python bench.py --workload c5 --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_c5_notk$v.json 2>&1
+    timeout 300 python bench.py --workload c3 --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_c3_notk$v.json 2>&1
+  done; unset SMC_NO_TK
+  for f in $O/bench_*notk*.json; do python - "$f" <<'PY'
+import json,sys
+try:
+    d=json.loads([l for l in open(sys.argv[1]) if l.startswith('{')][-1]); r=d.get('roofline',{})
+    print(sys.argv[1].split('/')[-1], 'ms/step %.5f'%d['ms_per_step'], 'G/s %.2f'%(d['value']/1e9), {k:round(v['ms'],5) for k,v in r.get('per_kernel',{}).items()})
+except Exception as e: print(sys.argv[1], 'FAILED', e, open(sys.argv[1]).read()[-400:])
+PY
+  done ;;
 bench2)
   # the N = 2 launch line of the driver, both ranks on this box's one GPU (functional: RCCL may refuse 2 ranks per device)
   SMC_BENCH_NGPU=1 SMC_ALLOW_HOST_GATHER=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
