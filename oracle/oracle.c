@@ -362,8 +362,23 @@ static int64_t count_pow2(uint64_t C, const double *u, int stratified, int k, in
     return (int64_t)nc + (T <= C ? 1 : 0);
 }
 
-/* The whole contract: ancestors A (N) from the log-weights of the parents.  scheme: 1
- * stratified (u: N uniforms), 2 systematic (u: 1 uniform).  red (5): K, s, ss, ESS, 1/s.
+/* multinomial: the N sorted uniforms su themselves (resampling.py:512-537), thresholds
+ * T_n = ceil(su_n 2^52): count(C) = #{ n < N : T_n <= C } by bisection (T_n is non-decreasing) */
+static int64_t count_sorted(uint64_t C, const double *su, int64_t N)
+{
+    int64_t lo = 0, hi = N;                            /* T_n <= C on [0, lo), > C on [hi, N) */
+    while (lo < hi) {
+        const int64_t mid = lo + (hi - lo) / 2;
+        const double v = su[mid];
+        const uint64_t T = (v > 0.0) ? (uint64_t)ceil(fmin(v, 2.0) * 4503599627370496.0) : 0;
+        if (T <= C) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+/* The whole contract: ancestors A (N) from the log-weights of the parents.  scheme: 0
+ * multinomial (u: the N sorted uniforms), 1 stratified (u: N uniforms), 2 systematic (u: 1
+ * uniform).  red (5): K, s, ss, ESS, 1/s.
  * Returns 0, or 1 if N is not a power of two >= 2048 (the path does not apply). */
 int orc_inverse_cdf_2level(const double *lw, int64_t N, int scheme, const double *u,
                            int64_t *A, double *red)
@@ -395,7 +410,7 @@ int orc_inverse_cdf_2level(const double *lw, int64_t N, int scheme, const double
                 if (c == 0) pos = 0;
                 else if (c >= tb) pos = Qb;
                 else pos = (uint64_t)(((unsigned __int128)c * Qb) / tb);
-                ns = count_pow2(Gb + pos, u, strat, k, N);
+                ns = scheme == 0 ? count_sorted(Gb + pos, u, N) : count_pow2(Gb + pos, u, strat, k, N);
             }
             /* offspring prev .. ns-1 belong to parent j - 1 */
             for (int64_t n = prev; n < ns; ++n) A[n] = j - 1;

@@ -355,13 +355,13 @@ def two_level_reduce(pK, ps, pss):
 
 def inverse_cdf_2level_c(scheme, u, lw):
     """The whole contract in C (orc_inverse_cdf_2level; counts per parent, 128-bit products):
-    ancestors for `scheme` ('systematic': u = the one uniform, 'stratified': u = N uniforms) and
-    the island reduction.  Fast enough for N = 2^22."""
+    ancestors for `scheme` ('systematic': u = the one uniform, 'stratified': u = N uniforms,
+    'multinomial': u = the N sorted uniforms) and the island reduction.  Fast enough for N = 2^22."""
     lw = np.ascontiguousarray(lw, dtype=np.float64)
     u = np.ascontiguousarray(np.atleast_1d(u), dtype=np.float64)
     A = np.empty(lw.size, dtype=np.int64)
     red = np.empty(5)
-    rc = clib().orc_inverse_cdf_2level(_dp(lw), lw.size, {"stratified": 1, "systematic": 2}[scheme],
+    rc = clib().orc_inverse_cdf_2level(_dp(lw), lw.size, {"multinomial": 0, "stratified": 1, "systematic": 2}[scheme],
                                        _dp(u), A.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), _dp(red))
     if rc:
         raise ValueError("two-level contract: N must be a power of two >= 2048")
@@ -862,7 +862,7 @@ def run_filter(model, data, N, scheme="systematic", ESSrmin=0.5, fk="bootstrap",
                 if cdf == "seq":
                     A = inverse_cdf(su, aux.W)
                 elif cdf == "2level":
-                    A = inverse_cdf_2level_c(scheme, u, aux.lw)[0]
+                    A = inverse_cdf_2level_c(scheme, su if scheme == "multinomial" else u, aux.lw)[0]
                 else:
                     A = inverse_cdf_q62(su, aux.W)
                 Xp = X[A]                                 # core.py:332

@@ -99,7 +99,16 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
     const dim3 grid(f->a.ntiles, f->a.n_islands);
     if (k_prof >= 0) (void)hipEventRecord(f->ev[3 * k_prof], st);
     if (f->two_level) {
-        if (f->two_level_mid) {
+        if (f->two_level_mid && f->a.scheme == SMC_MULTINOMIAL) {
+            SMC_LAUNCH(k_reduce2, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
+            if (!f->a.ut) {
+                const dim3 g1(f->a.ntiles1, f->a.n_islands);
+                SMC_LAUNCH(k_f_spacing_sums, g1, dim3(SMC_BLOCK), st, f->a);
+                SMC_LAUNCH(k_f_spacing_scan, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
+                SMC_LAUNCH(k_f_spacing_write, g1, dim3(SMC_BLOCK), st, f->a);
+            }
+            SMC_LAUNCH((k_ancestors2<true, true>), grid, dim3(SMC_BLOCK), st, f->a);
+        } else if (f->two_level_mid) {
             SMC_LAUNCH(k_reduce2, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
             SMC_LAUNCH((k_ancestors2<true>), grid, dim3(SMC_BLOCK), st, f->a);
         } else {
@@ -115,6 +124,7 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
     if (f->a.scheme == SMC_MULTINOMIAL && !f->a.ut) {
         const dim3 g1(f->a.ntiles1, f->a.n_islands);
         SMC_LAUNCH(k_f_spacing_sums, g1, dim3(SMC_BLOCK), st, f->a);
+        SMC_LAUNCH(k_f_spacing_scan, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
         SMC_LAUNCH(k_f_spacing_write, g1, dim3(SMC_BLOCK), st, f->a);
     }
     if (fused && f->a.par >= 0) SMC_LAUNCH((k_ancestors<true, true>), grid, dim3(SMC_BLOCK), st, f->a);
@@ -264,19 +274,22 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     const size_t oInfo2 = carve(M * INFO_STRIDE * 8);
     // two-level CDF: closed-form offspring counts (N = 2^k, systematic / stratified), at most
     // 1024 tiles per island (4 partials per thread), at least 2 (below, the one-workgroup filter)
+    // (multinomial: the counts are searches over the sorted uniforms -- the tape's, or the exponential
+    //  spacings drawn between k_reduce2, which decides the step, and k_ancestors2)
     f->two_level = !mv && !o->moments && a.log2N >= 0 && a.log2N <= 30 && a.ntiles >= 2 &&
-                   (o->scheme == SMC_SYSTEMATIC || o->scheme == SMC_STRATIFIED) &&
-                   !getenv("SMC_FLAT_CDF") && !getenv("SMC_FORCE_FUSED") && !getenv("SMC_FORCE_UNFUSED");
+                   !getenv("SMC_FLAT_CDF") && !getenv("SMC_FORCE_FUSED") && !getenv("SMC_FORCE_UNFUSED") &&
+                   !(o->scheme == SMC_MULTINOMIAL && getenv("SMC_FLAT_MULTINOMIAL"));
     // every workgroup reduces the partials itself while the launch is resident and an island has
     // at most 1024 tiles (4 per thread); otherwise one workgroup per island does it first
-    f->two_level_mid = f->two_level && (!f->fused || a.ntiles > 1024 || getenv("SMC_TWO_LEVEL_MID"));
+    f->two_level_mid = f->two_level && (!f->fused || a.ntiles > 1024 || getenv("SMC_TWO_LEVEL_MID") ||
+                                        o->scheme == SMC_MULTINOMIAL);
     const bool heavy_list = !mv && !getenv("SMC_NO_HEAVY");
     const size_t oCq = carve(f->two_level ? M * N * 8 : 8);
     const size_t oTq = carve(f->two_level ? M * a.ntiles * 8 : 8);
     const size_t oHcnt = carve(heavy_list ? M * 2 * sizeof(unsigned) : 8);
     const size_t oHlist = carve(heavy_list ? M * 2 * F_HMAX * 3 * 8 : 8);
     const size_t oSu = carve(need_su ? M * N * 8 : 8);
-    const size_t oE = carve(need_su ? M * a.ntiles1 * 8 : 8);
+    const size_t oE = carve(need_su ? M * (a.ntiles1 + 1) * 8 : 8);
     const size_t oTmp = carve(N * dxm * 8);
     a.nmb = (int)((o->N + F_MOM_CHUNK - 1) / F_MOM_CHUNK);
     const size_t oMom = carve(o->moments ? M * T * 2 * dxm * 8 : 8);
@@ -1088,7 +1101,7 @@ int smc_filter_describe(smc_filter* f, char* out, size_t n)
         else if (f->two_level) s = "k_ancestors2";
         else if (f->fused) s = "k_ancestors<fused>";
         else s = "k_prepare+k_ancestors";
-        if (f->a.scheme == SMC_MULTINOMIAL && !f->a.ut) s = "k_f_spacing_sums+k_f_spacing_write+" + s;
+        if (f->a.scheme == SMC_MULTINOMIAL && !f->a.ut) s = "k_f_spacing_sums+k_f_spacing_scan+k_f_spacing_write+" + s;
         s += mv ? (f->mv_collapsed ? "+k_propagate_mv<collapsed>" : "+k_propagate_mv") : "+k_propagate";
         if (f->a.mom) s += "+k_f_moments_partials+k_f_moments_final";
     }

@@ -425,12 +425,57 @@ k_f_spacing_sums(const FArgs av)
     const i64 t = (i64)smc_uniform(info[0]);
     if (t >= a.T || t == 0 || smc_uniform(info[1]) == 0.0) return;
     const i64 n0 = (i64)b * F_TILE + (i64)threadIdx.x * F_IPT;
+    // the integer spacings are parked in the su buffer (same 8 bytes per draw) for the second pass,
+    // which turns them into the sorted uniforms in place -- a Philox call and a log per draw once,
+    // not twice (the (N+1)-th spacing has no slot: its owner makes it again)
+    u64* park = reinterpret_cast<u64*>(a.su + (i64)isl * a.N);
     u64 s = 0;
 #pragma unroll
     for (int i = 0; i < F_IPT; ++i)
-        if (n0 + i <= a.N) s += f_spacing_q(a, (u32)t, (u32)(a.island_offset + isl), n0 + i);
+        if (n0 + i <= a.N) {
+            const u64 q = f_spacing_q(a, (u32)t, (u32)(a.island_offset + isl), n0 + i);
+            if (n0 + i < a.N) park[n0 + i] = q;
+            s += q;
+        }
     s = smc_block_sum_u64(s, smu);
-    if (threadIdx.x == 0) a.E[(i64)isl * a.ntiles1 + b] = s;
+    if (threadIdx.x == 0) a.E[(i64)isl * (a.ntiles1 + 1) + b] = s;
+}
+
+// E (n_islands, ntiles1 + 1): the tile totals -> their exclusive prefixes, the grand total in the
+// extra slot; one workgroup per island between the two passes (a ticket in k_f_spacing_sums -- 4097
+// atomics on 33 addresses at N = 2^22 -- cost 8 us, this launch costs 4)
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_f_spacing_scan(const FArgs av)
+{
+    const FArgs& a = av;
+    __shared__ u64 smu[SMC_SM];
+    const int isl = (int)blockIdx.x;
+    const double* info = a.info + (i64)isl * INFO_STRIDE;
+    const i64 t = (i64)smc_uniform(info[0]);
+    if (t >= a.T || t == 0 || smc_uniform(info[1]) == 0.0) return;
+    u64* E = a.E + (i64)isl * (a.ntiles1 + 1);
+    const int per = (a.ntiles1 + SMC_BLOCK - 1) / SMC_BLOCK;
+    const int i0 = (int)threadIdx.x * per;
+    const int i1 = (i0 + per < a.ntiles1) ? i0 + per : a.ntiles1;
+    u64 loc = 0;
+    for (int i = i0; i < i1; i += 8) {          // 8 loads in flight at a time
+        u64 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (i + k < i1) ? smc_ldg(E + i + k) : 0ull;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) loc += v[k];
+    }
+    u64 tot;
+    u64 run = smc_block_exscan_u64(loc, smu, tot);
+    for (int i = i0; i < i1; i += 8) {
+        u64 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (i + k < i1) ? smc_ldg(E + i + k) : 0ull;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (i + k < i1) { E[i + k] = run; run += v[k]; }
+    }
+    if (threadIdx.x == 0) E[a.ntiles1] = tot;
 }
 
 __global__ void __launch_bounds__(SMC_BLOCK)
@@ -442,24 +487,19 @@ k_f_spacing_write(const FArgs av)
     const double* info = a.info + (i64)isl * INFO_STRIDE;
     const i64 t = (i64)smc_uniform(info[0]);
     if (t >= a.T || t == 0 || smc_uniform(info[1]) == 0.0) return;
-    const u64* E = a.E + (i64)isl * a.ntiles1;
+    const u64* E = a.E + (i64)isl * (a.ntiles1 + 1);
+    const u64 pre = smc_uniform_u64(smc_ldg(E + b)), all = smc_uniform_u64(smc_ldg(E + a.ntiles1));
     const i64 n0 = (i64)b * F_TILE + (i64)threadIdx.x * F_IPT;
+    const u64* park = reinterpret_cast<const u64*>(a.su + (i64)isl * a.N);
     u64 q[F_IPT], tsum = 0;
 #pragma unroll
     for (int i = 0; i < F_IPT; ++i) {
-        q[i] = (n0 + i <= a.N) ? f_spacing_q(a, (u32)t, (u32)(a.island_offset + isl), n0 + i) : 0ull;
+        q[i] = (n0 + i < a.N) ? park[n0 + i]
+             : (n0 + i == a.N ? f_spacing_q(a, (u32)t, (u32)(a.island_offset + isl), n0 + i) : 0ull);
         tsum += q[i];
     }
-    u64 pre = 0, all = 0;
-    for (int i = (int)threadIdx.x; i < a.ntiles1; i += SMC_BLOCK) {
-        const u64 e = E[i];
-        all += e;
-        if (i < b) pre += e;
-    }
-    all = smc_block_sum_u64(all, smu);
-    u64 tot, pre_sum;
-    u64 run = smc_block_exscan_plus_sum_u64(tsum, pre, smu, tot, pre_sum);
-    run += pre_sum;
+    u64 tot;
+    u64 run = smc_block_exscan_u64(tsum, smu, tot) + pre;
     const double dall = (double)all;
     double* su = a.su + (i64)isl * a.N;
 #pragma unroll
@@ -1189,8 +1229,9 @@ k_propagate(const FArgs av)
 }
 
 // ---------------------------------------------------------------------------
-// Two-level CDF (systematic / stratified, N = 2^k, at least 2 tiles per island): the step loop
-// without any intra-launch exchange.  Contract (restated in oracle/oracle.c, checked bit for bit):
+// Two-level CDF (N = 2^k, at least 2 tiles per island; systematic / stratified with closed-form
+// counts, multinomial with counts by search over the sorted uniforms): the step loop without
+// any intra-launch exchange.  Contract (restated in oracle/oracle.c, checked bit for bit):
 //
 // Weights travel as pairs (p, k), exp(lw) = p 2^k (smc_expk): no maximum is needed to form them
 // and every change of reference is an exact power-of-two scaling.
@@ -1264,7 +1305,8 @@ __device__ __forceinline__ void f2_su(const FArgs& a, const int isl, const i64 t
     su.scheme = a.scheme;
     su.M = a.N;
     su.dM = (double)a.N;
-    su.u = a.ut ? a.ut + ((i64)t * a.n_islands + isl) * a.ut_stride : nullptr;
+    su.u = a.ut ? a.ut + ((i64)t * a.n_islands + isl) * a.ut_stride
+                : (a.scheme == SMC_MULTINOMIAL_ ? a.su + (i64)isl * a.N : nullptr);
     su.u_sys = 0.0;
     su.seed = a.seed;
     su.t = (u32)t;
@@ -1312,6 +1354,56 @@ __device__ __forceinline__ i64 f2_ns_sys(const FArgs& a, const SmcSu& su, const 
     }
     return f2_count(a, su, Us, f.Gb + smc_muldiv_floor(c, f.Qb, f.tb));
 }
+// ---- multinomial on the two-level path: the sorted uniforms sit in memory (the tape, or the
+// exponential spacings k_f_spacing_* left in a.su), thresholds T_n = ceil(su_n 2^52) on the
+// scale of the shares; count(C) = #{ n : T_n <= C } is a search
+#define F2_MW 2048                      /* thresholds staged in LDS per tile (its offspring: 1024 +- a few dozen) */
+__device__ __forceinline__ u64 f2_t52(const double su)
+{
+    return (su > 0.0) ? (u64)ceil(fmin(su, 2.0) * 4503599627370496.0) : 0ull;
+}
+// by a whole wavefront: a 64-ary search (log64 M dependent loads); every lane takes part and
+// gets the result (cf. smc_su_count_le_wave, the flat path's twin on the 2^62 scale)
+__device__ __forceinline__ i64 f2_count_sorted_wave(const double* u, const i64 M, const u64 C)
+{
+    i64 lo = 0, hi = M;                   // T_n <= C on [0, lo), > C on [hi, M)
+    const int lane = smc_lane();
+    while (lo < hi) {
+        const i64 width = hi - lo;
+        const i64 stride = (width + 63) >> 6;
+        const i64 p = lo + (i64)lane * stride;
+        const bool in = p < hi;
+        const bool le = in && (f2_t52(smc_ldg(u + (in ? p : lo))) <= C);
+        const int cnt = (int)smc_wave_sum_u64(le ? 1ull : 0ull);      // monotone: the first cnt probes
+        const int nprobe = (int)((width + stride - 1) / stride);
+        const i64 nlo = cnt > 0 ? lo + (i64)(cnt - 1) * stride + 1 : lo;
+        const i64 nhi = cnt < nprobe ? lo + (i64)cnt * stride : hi;
+        lo = nlo;
+        hi = nhi;
+    }
+    return lo;
+}
+// #{ i < n : T[i] <= C } in a sorted LDS window
+__device__ __forceinline__ int f2_count_lds(const u64* T, const int n, const u64 C)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (T[mid] <= C) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+// the same over memory, one lane: first index in [lo, hi) whose threshold exceeds C (tiles with
+// more than F2_MW offspring: collapsed weights, where speed is not the concern)
+__device__ inline i64 f2_count_sorted_range(const double* u, i64 lo, i64 hi, const u64 C)
+{
+    while (lo < hi) {
+        const i64 mid = lo + ((hi - lo) >> 1);
+        if (f2_t52(smc_ldg(u + mid)) <= C) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
 // first offspring ns[i] of the parents jt+i at positions cx[i] (cx[4]: the next thread's first
 // parent, t_b for the last thread), any scheme: fp64 quotient within 2^12 of the truth, count
 // decided unless the position lies within that band of a threshold, else formed exactly
@@ -1454,7 +1546,7 @@ k_reduce2(const FArgs av)
 //     in flight): a tile owns 1024 +- a few dozen offspring.
 // MID: k_reduce2 ran first: grids too large for every workgroup to repeat the reduction.
 // ---------------------------------------------------------------------------
-template <bool MID>
+template <bool MID, bool MULTI = false>
 __global__ void __launch_bounds__(SMC_BLOCK)
 k_ancestors2(const FArgs av)
 {
@@ -1570,7 +1662,60 @@ k_ancestors2(const FArgs av)
     // ---- first offspring of each parent; the tile's range [n_lo, n_hi)
     const u64 Gb = (u64)Gd, Qb = (u64)Qd;
     i64 ns[F_IPT + 1], n_lo, n_hi;
-    if (a.scheme == SMC_SYSTEMATIC_) {
+    if (MULTI) {
+        // ---- multinomial: the tile's range by two cooperative searches (one wave per end), its
+        // thresholds staged in LDS, every parent's count a search there; the position of a parent
+        // on the tile's share is formed exactly (128-bit product)
+        __shared__ i64 s_nm[2];
+        __shared__ u64 sT[F2_MW];
+        if (wave == 0) {
+            const i64 v = (b == 0) ? 0 : f2_count_sorted_wave(su.u, N, Gb);
+            if (lane == 0) s_nm[0] = v;
+        }
+        if (wave == 1) {
+            const i64 v = (b == a.ntiles - 1) ? N : f2_count_sorted_wave(su.u, N, Gb + Qb);
+            if (lane == 0) s_nm[1] = v;
+        }
+        __syncthreads();
+        n_lo = s_nm[0];
+        n_hi = s_nm[1];
+        const i64 width = n_hi - n_lo;
+        const bool staged = width <= F2_MW;
+        if (staged) {
+            for (int i = tid; i < (int)width; i += SMC_BLOCK) sT[i] = f2_t52(smc_ldg(su.u + n_lo + i));
+            __syncthreads();
+        }
+        // position of a parent on the tile's share: fp64 quotient within 2^12 of floor(c Q_b / t_b)
+        // (f2_first_offspring); the count is decided unless a threshold lies within 2^13 of it --
+        // then, and in tiles too wide to stage, the exact 128-bit quotient is formed
+        const double qscale = (double)Qb / (double)(tb ? tb : 1ull);
+        const u64 E = 1ull << 13;
+#pragma unroll
+        for (int i = 0; i <= F_IPT; ++i) {
+            const i64 j = jt + i;
+            const u64 c = cx[i];
+            if (j == 0) ns[i] = 0;
+            else if (j >= N) ns[i] = N;
+            else {
+                i64 cnt = -1;
+                if (staged && !a.exact_counts) {
+                    u64 qh = (u64)((double)c * qscale);
+                    qh = qh > Qb ? Qb : qh;
+                    const u64 Ch = Gb + qh;
+                    const int k = f2_count_lds(sT, (int)width, Ch);
+                    const bool below = k == 0 || sT[k - 1] + E <= Ch;
+                    const bool above = k == (int)width || sT[k] > Ch + E;
+                    if (below && above) cnt = n_lo + k;
+                }
+                if (cnt < 0) {
+                    const u64 pos = (c == 0ull) ? 0ull : (c >= tb ? Qb : smc_muldiv_floor(c, Qb, tb));
+                    cnt = staged ? n_lo + f2_count_lds(sT, (int)width, Gb + pos)
+                                 : f2_count_sorted_range(su.u, n_lo, n_hi, Gb + pos);
+                }
+                ns[i] = cnt;
+            }
+        }
+    } else if (a.scheme == SMC_SYSTEMATIC_) {
         F2Fast f;
         const int sh = F2_SBITS - a.log2N;
         const double down = __longlong_as_double((long long)(1023 - sh) << 52);   // 2^-sh

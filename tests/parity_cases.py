@@ -632,7 +632,8 @@ def check_two_level_cdf(golden, monkeypatch, N=4096, T=20):
     bit for bit -- ancestors, particles, log-weights, decisions; so must the device variants
     (fp64 band shortcut off; k_reduce2 in front); the reference-semantics oracle and the flat-Q62
     device path agree up to audited near-ties (check_filter_replay does the audit per step)."""
-    for case, scheme in (("toy_systematic", "systematic"), ("toy_stratified", "stratified")):
+    for case, scheme in (("toy_systematic", "systematic"), ("toy_stratified", "stratified"),
+                         ("toy_multinomial", "multinomial")):
         g = golden(case)
         mk_dev, mk_orc = MODELS["toy"]
         y = list(g["y"])[:T]
@@ -716,6 +717,27 @@ def check_two_level_injected(sizes=(4096,)):
                 A_ref = orc.inverse_cdf(su, W)
                 n, ok = orc.audit_near_ties(su, W, A_ref, A)
                 assert ok and n <= max(1, N // 100000), (N, scheme, name, n)
+        # multinomial: the sorted uniforms come from a tape (counts are searches over them)
+        z = rng.standard_normal((2, 1, N))
+        su = orc.uniform_spacings_from(rng.random(N + 1))
+        u = np.stack([np.zeros(N), su]).reshape(2, 1, N)
+        for name, lwi in cases:
+            pf = pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y), N=N, resampling="multinomial",
+                        ESSrmin=2.0, seed=7, collect="off", replay=(z, u))
+            assert "k_ancestors2" in describe(pf)
+            next(pf)
+            pf.set_state(lw=lwi)
+            X0 = np.array(pf.X)
+            next(pf)
+            assert pf.rs_flag
+            A_c, _ = orc.inverse_cdf_2level_c("multinomial", su, lwi)
+            A = np.array(pf.A)
+            assert np.array_equal(A, A_c), (N, "multinomial", name, int(np.sum(A != A_c)))
+            assert np.array_equal(pf.Xp, X0[A])
+            W = orc.exp_and_normalise(lwi)
+            assert np.all(W[A] > 0)
+            n, ok = orc.audit_near_ties(su, W, orc.inverse_cdf(su, W), A)
+            assert ok and n <= max(1, N // 100000), (N, "multinomial", name, n)
 
 
 def check_oracle_at_size(model, mk_dev, mk_orc, N, T, scheme="systematic", ESSrmin=0.5, fk="bootstrap",
@@ -830,7 +852,8 @@ def check_describe():
     assert kernels(1 << 12, n_islands=600) == "k_reduce2+k_ancestors2+k_propagate"   # 2400 workgroups
     assert kernels(3000) == "k_ancestors<fused>+k_propagate"                   # N not a power of two
     assert kernels(1 << 12, "multinomial") == \
-        "k_f_spacing_sums+k_f_spacing_write+k_ancestors<fused>+k_propagate"
+        "k_f_spacing_sums+k_f_spacing_scan+k_f_spacing_write+k_reduce2+k_ancestors2+k_propagate"   # two-level: counts by search
+    assert kernels(3000, "multinomial") == "k_f_spacing_sums+k_f_spacing_scan+k_f_spacing_write+k_ancestors<fused>+k_propagate"
     mv = kalman.MVLinearGauss_Guarniero_etal(alpha=0.4, dx=4)
     ymv = [np.zeros((1, 4)) for _ in range(4)]
     pf = pa.SMC(fk=ssm.Bootstrap(ssm=mv, data=ymv), N=1 << 12, seed=1)
@@ -904,6 +927,27 @@ def check_graph_replay_matches_direct(golden, N=5000):
     s = a._summ()[0]
     assert 0 < s[:, 4].sum() < 129               # both branches of the resample decision
     assert np.array_equal(s, b._summ()[0])
+
+
+def check_normals_on_host_t(golden, monkeypatch, sizes=(5000, 4096)):
+    """k_propagate starts the step's normals on the time index the host passes with the launch
+    (FArgs::tk) and falls back to the device record's t: with the feature off (SMC_NO_TK=1) the run
+    is the same run -- flat path (N = 5000) and two-level path (N = 4096), adaptive resampling."""
+    g = golden("kalman_toy")
+    y = [np.atleast_1d(v) for v in np.squeeze(g["y"])][:40]
+    for N in sizes:
+        runs = []
+        for off in (False, True):
+            if off:
+                monkeypatch.setenv("SMC_NO_TK", "1")
+            pf = pa.SMC(fk=ssm.Bootstrap(ssm=kalman.LinearGauss(rho=0.9, sigmaX=1.0, sigmaY=1.2), data=y),
+                        N=N, seed=11, n_islands=2, collect="off")
+            pf.step_async(13)
+            pf.run()
+            runs.append((pf.logLts_islands.copy(), pf._get(_lib.FIELD_X, 1).copy(), pf._summ().copy()))
+            monkeypatch.delenv("SMC_NO_TK", raising=False)
+        assert all(np.array_equal(u, v) for u, v in zip(*runs)), N
+        assert 0 < runs[0][2][0, :, 4].sum() < 39
 
 
 def check_unfused_path(golden, monkeypatch):

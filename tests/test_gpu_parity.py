@@ -156,6 +156,10 @@ def test_graph_replay_matches_direct(golden):
     pc.check_graph_replay_matches_direct(golden, N=200000)
 
 
+def test_normals_on_host_time_index(golden, monkeypatch):
+    pc.check_normals_on_host_t(golden, monkeypatch, sizes=(5000, 4096, 1 << 20))
+
+
 def test_unfused_path(golden, monkeypatch):
     pc.check_unfused_path(golden, monkeypatch)
 
