@@ -457,6 +457,20 @@ k_f_spacing_scan(const FArgs av)
     const int per = (a.ntiles1 + SMC_BLOCK - 1) / SMC_BLOCK;
     const int i0 = (int)threadIdx.x * per;
     const int i1 = (i0 + per < a.ntiles1) ? i0 + per : a.ntiles1;
+    if (per <= 24) {                            // up to 6144 tiles: every load in flight at once
+        u64 v[24], loc = 0;
+#pragma unroll
+        for (int k = 0; k < 24; ++k) { v[k] = (i0 + k < i1) ? smc_ldg(E + i0 + k) : 0ull; }
+#pragma unroll
+        for (int k = 0; k < 24; ++k) loc += v[k];
+        u64 tot;
+        u64 run = smc_block_exscan_u64(loc, smu, tot);
+#pragma unroll
+        for (int k = 0; k < 24; ++k)
+            if (i0 + k < i1) { E[i0 + k] = run; run += v[k]; }
+        if (threadIdx.x == 0) E[a.ntiles1] = tot;
+        return;
+    }
     u64 loc = 0;
     for (int i = i0; i < i1; i += 8) {          // 8 loads in flight at a time
         u64 v[8];
@@ -1484,6 +1498,56 @@ __device__ __forceinline__ F2Red f2_reduce_island(const FArgs& a, const int isl,
     return r;
 }
 
+// The same reduction with the partials of up to NC chunks (4096 tiles at NC = 4) held in registers:
+// every load of the island is in flight at once and the three passes (max, sums, shares) read
+// registers -- the same operations in the same order, hence the same bits, at one memory latency
+// instead of one per chunk and pass (k_reduce2 is ONE workgroup on the critical path of the step).
+template <int NC>
+__device__ __forceinline__ F2Red f2_reduce_island_cached(const FArgs& a, const int isl, double* smd,
+                                                         double (&pm)[NC][4], double (&ps)[NC][4])
+{
+    const i64 o = (i64)isl * a.nparts;
+    const bool pvec = (a.nparts & 3) == 0;
+    const int nchunks = (a.nparts + 4 * SMC_BLOCK - 1) / (4 * SMC_BLOCK);
+    double pss[NC][4];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const i64 i0 = (i64)c * 4 * SMC_BLOCK + (i64)threadIdx.x * 4;
+        if (c < nchunks) {
+            f_load4<double>(a.pm + o, i0, a.nparts, pvec, -INFINITY, pm[c]);
+            f_load4<double>(a.ps + o, i0, a.nparts, pvec, 0.0, ps[c]);
+            f_load4<double>(a.pss + o, i0, a.nparts, pvec, 0.0, pss[c]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { pm[c][k] = -INFINITY; ps[c][k] = 0.0; pss[c][k] = 0.0; }
+        }
+    }
+    F2Red r;
+    double tm = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+        if (c < nchunks)
+            tm = smc_max2(tm, smc_max2(smc_max2(pm[c][0], pm[c][1]), smc_max2(pm[c][2], pm[c][3])));
+    r.K = smc_block_max(tm, smd);
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+        if (c < nchunks) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                double v, w;
+                f2_rescale(pm[c][k], r.K, ps[c][k], pss[c][k], v, w);
+                s1 = s1 + v;
+                s2 = s2 + w;
+            }
+        }
+    smc_block_sum2(s1, s2, smd);
+    r.s = s1;
+    r.ss = s2;
+    f2_finish(a, r);
+    return r;
+}
+
 // k_reduce2(t): one workgroup per island reduces the partials of step t-1, decides step t,
 // writes the record, the summary row and every tile's (G_b, Q_b) (integer-valued doubles)
 __global__ void __launch_bounds__(SMC_BLOCK)
@@ -1505,6 +1569,35 @@ k_reduce2(const FArgs av)
     const int nchunks = (a.nparts + 4 * SMC_BLOCK - 1) / (4 * SMC_BLOCK);
     double* G = reinterpret_cast<double*>(a.Qpre) + (i64)isl * a.ntiles;
     double* Q = reinterpret_cast<double*>(a.Q) + (i64)isl * a.ntiles;
+    constexpr int NC = 4;
+    if (nchunks <= NC) {
+        double pmc[NC][4], psc[NC][4];
+        const F2Red r = f2_reduce_island_cached<NC>(a, isl, smd, pmc, psc);
+        const bool resample = r.ess < a.ess_thresh;
+        if (tid == 0) f2_write_record(a, isl, t, r, resample);
+        if (!resample) return;
+        double carry = 0.0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            if (c >= nchunks) break;
+            const i64 i0 = (i64)c * 4 * SMC_BLOCK + (i64)tid * 4;
+            double Q4[4], run = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                double v, w;
+                f2_rescale(pmc[c][k], r.K, psc[c][k], 0.0, v, w);
+                Q4[k] = (i0 + k < a.nparts) ? f2_share(v, r.rs) : 0.0;
+                run += Q4[k];
+            }
+            double tot;
+            double g = carry + smc_block_exscan_f64(run, sme, tot);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (i0 + k < a.nparts) { G[i0 + k] = g; Q[i0 + k] = Q4[k]; g += Q4[k]; }
+            carry += tot;
+        }
+        return;
+    }
     const F2Red r = f2_reduce_island(a, isl, smd);
     const bool resample = r.ess < a.ess_thresh;
     if (tid == 0) f2_write_record(a, isl, t, r, resample);
@@ -1858,7 +1951,13 @@ k_flush2(const FArgs av)
     const int isl = (int)blockIdx.x;
     const i64 t = (i64)smc_uniform(smc_ldg(a.info2 + (i64)isl * INFO_STRIDE));       // steps done
     if (t <= 0 || t > a.T) return;                      // (t > T: records frozen by k_theta_update)
-    const F2Red r = f2_reduce_island(a, isl, smd);
+    F2Red r;
+    if (a.nparts <= 4 * 4 * SMC_BLOCK) {                // all partials in registers: one memory latency
+        double pmc[4][4], psc[4][4];
+        r = f2_reduce_island_cached<4>(a, isl, smd, pmc, psc);
+    } else {
+        r = f2_reduce_island(a, isl, smd);
+    }
     if (threadIdx.x == 0) f2_write_row(a, isl, t - 1, r);
 }
 

@@ -51,6 +51,20 @@ prof_r1)
   export SMC_ANC2_R1=1; PASSES="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" bash tools/gpu_profile.sh ${TAG}_c2_anc2r1 400 > $O/prof_c2_r1.txt 2>&1; unset SMC_ANC2_R1; tail -25 $O/prof_c2_r1.txt ;;
 prof_c5)
   EXTRA="--workload c5" bash tools/gpu_profile.sh ${TAG}_c5 100 > $O/prof_c5.txt 2>&1; tail -30 $O/prof_c5.txt ;;
+quick)
+  (timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "rc=$?" >> $O/pytest_gpu.log); tail -3 $O/pytest_gpu.log
+  timeout 300 python bench.py --steps 1000 --warmup 50 --no-cpu-baseline > $O/bench_c2_k1000.json 2>&1
+  timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_c2_k20.json 2>&1
+  timeout 300 python bench.py --workload c5 --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_c5.json 2>&1
+  for sc in systematic stratified multinomial; do timeout 300 python bench.py --workload c3 --scheme $sc --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_c3_$sc.json 2>&1; done
+  for f in $O/bench_c2_k1000.json $O/bench_c2_k20.json $O/bench_c5.json $O/bench_c3_*.json; do python - "$f" <<'PY'
+import json,sys
+try:
+    d=json.loads([l for l in open(sys.argv[1]) if l.startswith('{')][-1]); r=d.get('roofline',{})
+    print(sys.argv[1].split('/')[-1], 'ms/step %.5f'%d['ms_per_step'], 'G/s %.2f'%(d['value']/1e9), {k[-28:]:round(v['ms'],5) for k,v in r.get('per_kernel',{}).items()})
+except Exception as e: print(sys.argv[1], 'FAILED', e, open(sys.argv[1]).read()[-400:])
+PY
+  done ;;
 c3m)
   (timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "rc=$?" >> $O/pytest_gpu.log); tail -3 $O/pytest_gpu.log
   SMC_FLAT_MULTINOMIAL=1 timeout 300 python bench.py --workload c3 --scheme multinomial --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_c3_multinomial_flat.json 2>&1
@@ -63,7 +77,21 @@ d=json.loads([l for l in open(sys.argv[1].replace('.json','_flat.json')) if l.st
 print('   (flat path) ms/step %.5f'%d['ms_per_step'], 'G/s %.2f'%(d['value']/1e9), {k:round(v['ms'],5) for k,v in r.get('per_kernel',{}).items()})
 PY
   ;;
-prof_c3m)
+prof_quick)
+  (timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "rc=$?" >> $O/pytest_gpu.log); tail -3 $O/pytest_gpu.log
+  timeout 300 python bench.py --steps 1000 --warmup 50 --no-cpu-baseline > $O/bench_c2_k1000.json 2>&1
+  timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_c2_k20.json 2>&1
+  timeout 300 python bench.py --workload c5 --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_c5.json 2>&1
+  for sc in systematic stratified multinomial; do timeout 300 python bench.py --workload c3 --scheme $sc --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_c3_$sc.json 2>&1; done
+  for f in $O/bench_c2_k1000.json $O/bench_c2_k20.json $O/bench_c5.json $O/bench_c3_*.json; do python - "$f" <<'PY'
+import json,sys
+try:
+    d=json.loads([l for l in open(sys.argv[1]) if l.startswith('{')][-1]); r=d.get('roofline',{})
+    print(sys.argv[1].split('/')[-1], 'ms/step %.5f'%d['ms_per_step'], 'G/s %.2f'%(d['value']/1e9), {k[-28:]:round(v['ms'],5) for k,v in r.get('per_kernel',{}).items()})
+except Exception as e: print(sys.argv[1], 'FAILED', e, open(sys.argv[1]).read()[-400:])
+PY
+  done ;;
+c3m)
   EXTRA="--workload c3 --scheme multinomial" PASSES="FETCH_SIZE;WRITE_SIZE" bash tools/gpu_profile.sh ${TAG}_c3m 60 > $O/prof_c3m.txt 2>&1; tail -30 $O/prof_c3m.txt ;;
 trace)
   timeout 200 python tools/trace_step.py 20 > $O/trace_step.txt 2>&1; cat $O/trace_step.txt ;;
