@@ -63,22 +63,30 @@ class IndepPrior:
         return out
 
     def logpdf(self, theta):
-        from scipy import stats
+        """Sum of the scalar log-densities (closed forms in NumPy: importing scipy.stats here would
+        cost the first resample-move event a quarter of a second)."""
+        from math import lgamma, log, pi
         lp = 0.0
-        for k, (kind, a, b) in self.laws.items():
-            v = np.asarray(theta[k], dtype=float)
-            if kind == "normal":
-                lp = lp + stats.norm.logpdf(v, a, b)
-            elif kind == "lognormal":
-                with np.errstate(invalid="ignore", divide="ignore"):
-                    lp = lp + np.where(v > 0, stats.norm.logpdf(np.log(np.where(v > 0, v, 1.0)), a, b)
-                                       - np.log(np.where(v > 0, v, 1.0)), -np.inf)
-            elif kind == "uniform":
-                lp = lp + np.where((v >= a) & (v <= b), -np.log(b - a), -np.inf)
-            elif kind == "gamma":
-                lp = lp + stats.gamma.logpdf(v, a, scale=1.0 / b)
-            elif kind == "beta":
-                lp = lp + stats.beta.logpdf(v, a, b)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            for k, (kind, a, b) in self.laws.items():
+                v = np.asarray(theta[k], dtype=float)
+                if kind == "normal":
+                    lp = lp - 0.5 * ((v - a) / b) ** 2 - log(b) - 0.5 * log(2.0 * pi)
+                elif kind == "lognormal":
+                    lv = np.log(np.where(v > 0, v, 1.0))
+                    lp = lp + np.where(v > 0, -0.5 * ((lv - a) / b) ** 2 - log(b) - 0.5 * log(2.0 * pi) - lv, -np.inf)
+                elif kind == "uniform":
+                    lp = lp + np.where((v >= a) & (v <= b), -log(b - a), -np.inf)
+                elif kind == "gamma":             # shape a, rate b
+                    lv = np.log(np.where(v > 0, v, 1.0))
+                    lp = lp + np.where(v > 0, a * log(b) - lgamma(a) + (a - 1.0) * lv - b * v, -np.inf)
+                elif kind == "beta":
+                    ok = (v > 0) & (v < 1)
+                    vs = np.where(ok, v, 0.5)
+                    lp = lp + np.where(ok, lgamma(a + b) - lgamma(a) - lgamma(b) + (a - 1.0) * np.log(vs)
+                                       + (b - 1.0) * np.log1p(-vs), -np.inf)
+                else:
+                    raise ValueError("unknown law %r" % kind)
         return lp
 
 

@@ -80,3 +80,26 @@ def test_sincospi_02(emu):
     big = np.abs(wc) > 1e-3
     assert ulps(c[big], wc[big]).max() <= 2.0
     assert s[-11] == 0.0 and c[-11] == 1.0 and s[-9] == 1.0 and c[-7] == -1.0
+
+
+def test_indep_prior_logpdf_matches_scipy():
+    """smc2.IndepPrior.logpdf: closed forms in NumPy (no scipy import on the SMC^2 hot path) against
+    scipy.stats, support boundaries included."""
+    import numpy as np
+    from scipy import stats
+    from particles_amd import smc2
+    rng = np.random.RandomState(0)
+    p = smc2.IndepPrior(a=("normal", 0.3, 1.2), b=("lognormal", -0.5, 0.7), c=("uniform", -1.0, 2.0),
+                        d=("gamma", 2.5, 1.5), e=("beta", 2.0, 3.5))
+    th = p.rvs(1000, rng=rng)
+    th["b"][:3] = [-1.0, 0.0, 1e-300]
+    th["c"][:2] = [-2.0, 3.0]
+    th["d"][:2] = [-1.0, 0.0]
+    th["e"][:3] = [0.0, 1.0, 1.5]
+    want = (stats.norm.logpdf(th["a"], 0.3, 1.2) + stats.lognorm.logpdf(th["b"], 0.7, scale=np.exp(-0.5))
+            + stats.uniform.logpdf(th["c"], -1.0, 3.0) + stats.gamma.logpdf(th["d"], 2.5, scale=1 / 1.5)
+            + stats.beta.logpdf(th["e"], 2.0, 3.5))
+    got = p.logpdf(th)
+    fin = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), fin) and fin.sum() > 900
+    assert np.max(np.abs(got[fin] - want[fin])) < 1e-13
