@@ -76,6 +76,8 @@ int smc_ctx_destroy(smc_ctx* ctx)
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     for (auto& kv : ctx->pool)
         for (void* p : kv.second) (void)hipFree(p);
+    for (auto& kv : ctx->pinned)
+        for (void* p : kv.second) (void)hipHostFree(p);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
     (void)hipStreamDestroy(ctx->stream);

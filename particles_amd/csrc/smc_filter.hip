@@ -295,10 +295,11 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     const size_t oMom = carve(o->moments ? M * T * 2 * dxm * 8 : 8);
     const size_t oMpart = carve(o->moments ? M * a.nmb * dxm * 3 * 8 : 8);
     const size_t oTrace = carve(M * (size_t)(2 * a.ntiles + 8) * 8 * 8);
+    // the slab comes from the context's pool (smc_malloc: blocks recycled by exact size, ordered on
+    // the context's one stream): a PMMH chain or the PMCMC moves of SMC^2 create and destroy a filter
+    // of the same shape per proposal, and hipMalloc / hipFree of tens of MB cost milliseconds each
     void* slab = nullptr;
-    hipError_t e = hipMalloc(&slab, off);
-    if (e != hipSuccess) {
-        smc_set_error("smc_filter_create: %zu bytes: %s", off, hipGetErrorString(e));
+    if (smc_malloc(ctx, off, &slab) != SMC_OK) {
         delete f;
         return SMC_ERR_NOMEM;
     }
@@ -310,7 +311,8 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
         if (e_ != hipSuccess) {                                                                \
             smc_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__,     \
                           __LINE__);                                                           \
-            (void)hipFree(slab);                                                               \
+            (void)smc_free(ctx, slab);                                                         \
+            if (f->ll_stage) (void)hipHostFree(f->ll_stage);                                   \
             delete f;                                                                          \
             return SMC_ERR_HIP;                                                                \
         }                                                                                      \
@@ -348,7 +350,15 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     a.E = (u64*)(base + oE);
     f->tmp = (double*)(base + oTmp);
     f->ll_stage = nullptr;
-    if (hipHostMalloc((void**)&f->ll_stage, M * 8, hipHostMallocMapped) != hipSuccess) f->ll_stage = nullptr;
+    {
+        auto it = ctx->pinned.find(M * 8);
+        if (it != ctx->pinned.end() && !it->second.empty()) {
+            f->ll_stage = (double*)it->second.back();
+            it->second.pop_back();
+        } else if (hipHostMalloc((void**)&f->ll_stage, M * 8, hipHostMallocMapped) != hipSuccess) {
+            f->ll_stage = nullptr;
+        }
+    }
     (void)hipGetLastError();
     if (o->moments) {
         a.mom = (double*)(base + oMom);
@@ -419,8 +429,12 @@ int smc_filter_destroy(smc_filter* f)
     for (hipGraphExec_t g : f->gexec)
         if (g) (void)hipGraphExecDestroy(g);
     for (hipEvent_t e : f->ev) (void)hipEventDestroy(e);
-    (void)hipFree(f->slab);
-    if (f->ll_stage) (void)hipHostFree(f->ll_stage);
+    (void)smc_free(f->ctx, f->slab);
+    if (f->ll_stage) {
+        auto& v = f->ctx->pinned[(size_t)f->a.n_islands * 8];
+        if (v.size() < 4) v.push_back(f->ll_stage);
+        else (void)hipHostFree(f->ll_stage);
+    }
     if (f->th_buf) (void)hipFree(f->th_buf);
     delete f;
     return SMC_OK;

@@ -24,6 +24,9 @@ struct smc_ctx {
     std::unordered_map<size_t, std::vector<void*>> pool;
     std::unordered_map<void*, size_t> live;
     size_t pooled_bytes;
+    // pinned (mapped) host staging blocks of destroyed filters, by size: hipHostMalloc / hipHostFree
+    // cost about a millisecond each and a PMMH chain makes a filter per proposal
+    std::unordered_map<size_t, std::vector<void*>> pinned;
 };
 #define SMC_POOL_MAX_BYTES ((size_t)8 << 30)
 
