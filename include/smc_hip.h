@@ -244,7 +244,8 @@ enum smc_fk_kind {
     SMC_FK_APF = 2            /* state_space_models.py:406-428 auxiliary PF: the guided step + the
                                * auxiliary weights of core.py:299-313 (resampling on lw + logeta,
                                * weights reset to log_mean_exp(logeta, W) - logeta[A]); STOCHVOL
-                               * (Pitt & Shephard, :475-498), N <= 1024 (the one-launch filter) */
+                               * (Pitt & Shephard, :475-498); N <= 1024 (the one-launch filter) or
+                               * N = 2^k >= 2048 (the two-level step); no moments, no rolling window */
 };
 enum smc_rng_mode {
     SMC_RNG_PHILOX = 0,       /* counter-based Philox4x32-10 per lane */

@@ -80,6 +80,7 @@ static void launch_propagate(smc_filter* f)
     P_CASE(SMC_MODEL_LINGAUSS, SMC_FK_GUIDED)
     P_CASE(SMC_MODEL_STOCHVOL, SMC_FK_BOOTSTRAP)
     P_CASE(SMC_MODEL_STOCHVOL, SMC_FK_GUIDED)
+    P_CASE(SMC_MODEL_STOCHVOL, SMC_FK_APF)              // (tail-free two-level launches only: create checks)
     P_CASE(SMC_MODEL_GORDON, SMC_FK_BOOTSTRAP)
     P_CASE(SMC_MODEL_THETALOGISTIC, SMC_FK_BOOTSTRAP)
     P_CASE(SMC_MODEL_SVLEVERAGE, SMC_FK_BOOTSTRAP)
@@ -168,9 +169,13 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
                      (model->kind == SMC_MODEL_LINGAUSS || model->kind == SMC_MODEL_STOCHVOL || mv)) ||
                     (model->fk == SMC_FK_APF && model->kind == SMC_MODEL_STOCHVOL),
                 "guided filter: LINGAUSS, STOCHVOL, MVLINGAUSS; auxiliary filter: STOCHVOL");
-    if (model->fk == SMC_FK_APF && (o->N > F_TILE || o->moments)) {
-        smc_set_error("the auxiliary particle filter is fused for N <= 1024 (the one-launch filter) only");
-        return SMC_ERR_INVALID;
+    {
+        const bool pow2 = o->N >= 2 * F_TILE && (o->N & (o->N - 1)) == 0 && o->N <= ((int64_t)1 << 30);
+        if (model->fk == SMC_FK_APF && (o->moments || (o->N > F_TILE && !pow2) || o->keep_history >= 2)) {
+            smc_set_error("the auxiliary particle filter is fused for N <= 1024 (the one-launch filter) and for "
+                          "N = 2^k >= 2048 (the two-level step); no moments, no rolling window");
+            return SMC_ERR_INVALID;
+        }
     }
     SMC_REQUIRE(model->kind != SMC_MODEL_GORDON || model->aux_host,
                 "GORDON needs aux_host (d*cos(e*(t-1)) per step)");
@@ -281,11 +286,18 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
                    !(o->scheme == SMC_MULTINOMIAL && getenv("SMC_FLAT_MULTINOMIAL"));
     // every workgroup reduces the partials itself while the launch is resident and an island has
     // at most 1024 tiles (4 per thread); otherwise one workgroup per island does it first
+    const bool apf2 = model->fk == SMC_FK_APF && o->N > F_TILE;      // APF on the two-level step: k_reduce2
+    if (apf2 && !f->two_level) {                                      // forms its two reductions
+        smc_set_error("the auxiliary particle filter beyond N = 1024 runs on the two-level step only");
+        delete f;
+        return SMC_ERR_INVALID;
+    }
     f->two_level_mid = f->two_level && (!f->fused || a.ntiles > 1024 || getenv("SMC_TWO_LEVEL_MID") ||
-                                        o->scheme == SMC_MULTINOMIAL);
+                                        o->scheme == SMC_MULTINOMIAL || apf2);
     const bool heavy_list = !mv && !getenv("SMC_NO_HEAVY");
     const size_t oCq = carve(f->two_level ? M * N * 8 : 8);
     const size_t oTq = carve(f->two_level ? M * a.ntiles * 8 : 8);
+    const size_t oP2 = carve(apf2 ? 3 * M * a.nparts * 8 : 8);
     const size_t oHcnt = carve(heavy_list ? M * 2 * sizeof(unsigned) : 8);
     const size_t oHlist = carve(heavy_list ? M * 2 * F_HMAX * 3 * 8 : 8);
     const size_t oSu = carve(need_su ? M * N * 8 : 8);
@@ -346,6 +358,12 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     // streaming stores pay while a launch is short (its end-of-kernel write-back shows): C2 +8 %;
     // on the large grids they cost 2 % (C5)
     a.nt = ((i64)a.ntiles * (i64)M <= F_DIRECT_PREFIX_MAX && !mv && !getenv("SMC_NO_NT")) ? 1 : 0;
+    a.pm2 = a.ps2 = a.pss2 = nullptr;
+    if (apf2) {
+        a.pm2 = (double*)(base + oP2);
+        a.ps2 = a.pm2 + M * a.nparts;
+        a.pss2 = a.ps2 + M * a.nparts;
+    }
     a.su = (double*)(base + oSu);
     a.E = (u64*)(base + oE);
     f->tmp = (double*)(base + oTmp);
@@ -495,9 +513,9 @@ int smc_filter_step(smc_filter* f, int64_t nsteps)
     i64 todo = nsteps;
     if (f->t_host + todo > f->a.T) todo = f->a.T - f->t_host;
     if (todo < 0) todo = 0;
-    if (todo > 0 && f->fk == SMC_FK_APF && !small_filter_ok(f)) {
-        smc_set_error("the auxiliary particle filter runs on the one-launch filter only (no profiling, "
-                      "no Philox multinomial)");
+    if (todo > 0 && f->fk == SMC_FK_APF && !small_filter_ok(f) && !f->a.pm2) {
+        smc_set_error("the auxiliary particle filter with N <= 1024 runs on the one-launch filter only (no "
+                      "profiling, no Philox multinomial)");
         return SMC_ERR_STATE;
     }
     if (todo > 0 && f->lwth) {
@@ -721,6 +739,10 @@ int smc_filter_set_state(smc_filter* f, int island, const double* X_host, const 
         smc_set_error("smc_filter_set_state: log-weights of a multivariate filter cannot be replaced");
         return SMC_ERR_STATE;
     }
+    if (f->a.pm2) {
+        smc_set_error("smc_filter_set_state: not available for the auxiliary filter on the two-level step");
+        return SMC_ERR_STATE;
+    }
     SMC_HIP_CHECK(hipSetDevice(f->ctx->device));
     hipStream_t st = f->ctx->stream;
     const i64 N = f->a.N, ts = f->t_host - 1;
@@ -772,6 +794,10 @@ static int island_arrays(smc_filter* f, i64 t, IslandArray* out)
 int smc_filter_permute_islands(smc_filter* f, const int64_t* src_host)
 {
     SMC_REQUIRE(f && src_host, "null argument");
+    if (f->a.pm2) {
+        smc_set_error("whole-island moves are not available for the auxiliary filter on the two-level step");
+        return SMC_ERR_STATE;
+    }
     if (f->a.hist) {
         smc_set_error("smc_filter_permute_islands: not available with keep_history");
         return SMC_ERR_STATE;
@@ -821,6 +847,10 @@ int smc_filter_copy_islands(smc_filter* dst, smc_filter* src, const unsigned cha
     SMC_REQUIRE(dst && src && accept_host, "null argument");
     SMC_REQUIRE(dst->ctx == src->ctx, "both filters must live on one context");
     const FArgs &a = dst->a, &b = src->a;
+    if (a.pm2 || b.pm2) {
+        smc_set_error("whole-island moves are not available for the auxiliary filter on the two-level step");
+        return SMC_ERR_STATE;
+    }
     if (a.hist || b.hist) {
         smc_set_error("smc_filter_copy_islands: not available with keep_history");
         return SMC_ERR_STATE;
@@ -870,6 +900,10 @@ int smc_filter_island_bytes(smc_filter* f, int64_t* bytes)
 static int island_pack(smc_filter* f, const int64_t* islands_host, int n, void* pack_dev, int unpack)
 {
     SMC_REQUIRE(f && (n == 0 || (islands_host && pack_dev)), "null argument");
+    if (f->a.pm2) {
+        smc_set_error("whole-island moves are not available for the auxiliary filter on the two-level step");
+        return SMC_ERR_STATE;
+    }
     if (f->a.hist) {
         smc_set_error("island migration is not available with keep_history");
         return SMC_ERR_STATE;
@@ -915,6 +949,7 @@ int smc_filter_theta_enable(smc_filter* f, double ess_rmin)
 {
     SMC_REQUIRE(f, "null filter");
     SMC_REQUIRE(!f->a.hist && !f->a.mom, "the theta level is not available with keep_history / moments");
+    SMC_REQUIRE(!f->a.pm2, "the theta level is not available for the auxiliary filter on the two-level step");
     SMC_HIP_CHECK(hipSetDevice(f->ctx->device));
     const size_t M = (size_t)f->a.n_islands, T = (size_t)f->a.T;
     if (!f->th_buf) SMC_HIP_CHECK(hipMalloc(&f->th_buf, (M + TH_STRIDE + T) * 8));

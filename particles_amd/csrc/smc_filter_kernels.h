@@ -72,6 +72,9 @@ struct FArgs {
                            // stays resident); k >= 2: a ring of k slots (the k most recent steps)
     int par;               // t & 1 of the step this launch runs, or -1 (history slots): lets the
                            // kernels form their addresses before the step record has arrived
+    double *pm2, *ps2, *pss2;   // APF on the two-level path: the tile partials of the PLAIN weights
+                           // (pm/ps/pss, cq, tq then describe the AUXILIARY weights lw + logeta,
+                           // which decide and drive the resampling -- core.py:307-313); else null
     i64 tk;                // the time index the HOST expects this launch to run (eager launches), or -1
                            // (inside a captured graph): work that depends on t only -- the step's
                            // normals -- starts on it while the step record is still on its way, and is
@@ -1063,6 +1066,8 @@ k_propagate(const FArgs av)
     const bool full = !TAIL || own.full;           // (!TAIL: N is a multiple of the tile, every thread owns 4)
     const double r0 = smc_ldg(info), r1 = smc_ldg(info + 1), r2 = smc_ldg(info + 2),
                  r5 = smc_ldg(info + 5);
+    constexpr bool APF = FK == SMC_FK_APF;         // (tail-free two-level path only: see the tail)
+    const double r6 = APF ? smc_ldg(info + 6) : 0.0;
     unsigned nh0 = 0u, nh1 = 0u;                   // registered heavy parents, either parity of t
     if (a.hcnt) { nh0 = smc_ldg(a.hcnt + (i64)isl * 2); nh1 = smc_ldg(a.hcnt + (i64)isl * 2 + 1); }
     // SPEC: slots from a.par (kernarg): the ancestor indices are requested right behind the
@@ -1132,6 +1137,7 @@ k_propagate(const FArgs av)
     }
 
     double lw[OPT];
+    double xkeep[OPT] = {0.0, 0.0, 0.0, 0.0};      // APF: the new particles, for the auxiliary weights
 #pragma unroll
     for (int k = 0; k < OPT; ++k) lw[k] = -INFINITY;
     if (own.na < N) {
@@ -1186,15 +1192,23 @@ k_propagate(const FArgs av)
 #pragma unroll
             for (int k = 0; k < OPT; ++k) { xp[k] = SPEC ? xg[k] : smc_ldg(Xo + an[k]); lwp[k] = 0.0; }    // core.py:332
         }
+        if (APF && resample) {
+            // core.py:299-305 reset_weights: log_mean_exp(logeta, W) - logeta[A]; the constant comes
+            // with the record (k_reduce2), logeta of the gathered parent is formed again here
+            const double cconst = smc_uniform(r6);
+#pragma unroll
+            for (int k = 0; k < OPT; ++k) lwp[k] = cconst - m_sv_logeta(p, xp[k], yt);
+        }
         F_STAMP(2);
         double xn[OPT];
 #pragma unroll
         for (int k = 0; k < OPT; ++k) {
             double inc;
             xn[k] = m_step<KIND, FK>(p, first, yt, aux, xp[k], z[k], inc);
-            double l = (resample || first) ? inc : lwp[k] + inc;          // resampling.py:241-244
+            double l = (first || (resample && !APF)) ? inc : lwp[k] + inc;    // resampling.py:241-244
             if (l != l) l = -INFINITY;                                     // resampling.py:220
             lw[k] = (f_own_idx(own, k) < N) ? l : -INFINITY;
+            if (APF) xkeep[k] = xn[k];
         }
         if (full) {
             if (a.nt) {
@@ -1226,6 +1240,27 @@ k_propagate(const FArgs av)
         // k_ancestors2(t+1) -- every workgroup of it -- reduces the partials, so nobody waits for
         // a last workgroup here (N = 2^k >= 2048: every tile is full)
         u64 cx[4];
+        if (APF) {
+            // the partial of the PLAIN weights first (evidence, the logged ESS, W): pm2 / ps2 / pss2;
+            // then everything the resampling of step t+1 reads -- partial, integer CDF, tile total --
+            // from the auxiliary weights lw + logeta(t, X) with data[t+1] (core.py:307-313)
+            const F2Tile r2 = f2_tile_weights(lw, cx);
+            if (tid == 0) {
+                const i64 o2 = (i64)isl * a.nparts;
+                a.pm2[o2 + b] = r2.K;
+                a.ps2[o2 + b] = r2.S;
+                a.pss2[o2 + b] = r2.SS;
+            }
+            if (t + 1 < a.T) {
+                const double y_next = a.y[(t + 1) * a.dy];
+#pragma unroll
+                for (int k = 0; k < OPT; ++k) {
+                    double la = lw[k] + m_sv_logeta(p, xkeep[k], y_next);
+                    if (la != la) la = -INFINITY;
+                    lw[k] = (lw[k] > -INFINITY) ? la : -INFINITY;
+                }
+            }
+        }
         const F2Tile r = f2_tile_weights(lw, cx);
         u64* cq = a.cq + (i64)isl * N;
         if (a.nt) { smc_st2g_nt(cq + own.na, cx[0], cx[1]); smc_st2g_nt(cq + own.nb, cx[2], cx[3]); }
@@ -1460,11 +1495,34 @@ __device__ __forceinline__ void f2_write_record(const FArgs& a, const int isl, c
     info[4] = r.rs;
     info[5] = a.aux ? a.aux[t] : 0.0;
 }
+// APF: the row of step t-1 comes from the PLAIN weights (evidence, logged ESS, W), the decision
+// and the shares from the auxiliary ones; the constant the weights are reset to,
+// log_mean_exp(logeta, W) = log(sum exp(lw + logeta) / sum exp(lw)), travels in slot 6
+__device__ __forceinline__ void f2_write_record_apf(const FArgs& a, const int isl, const i64 t,
+                                                    const F2Red& r_aux, const F2Red& r_plain,
+                                                    const bool resample)
+{
+    double* info = a.info + (i64)isl * INFO_STRIDE;
+    f2_write_row(a, isl, t - 1, r_plain);
+    a.summ[((i64)isl * (a.T + 1) + t) * SUMM_STRIDE + 4] = resample ? 1.0 : 0.0;
+    info[0] = (double)t;
+    info[1] = resample ? 1.0 : 0.0;
+    info[2] = a.y[t * a.dy];
+    info[3] = r_aux.K;
+    info[4] = r_aux.rs;
+    info[5] = a.aux ? a.aux[t] : 0.0;
+    info[6] = (r_aux.K - r_plain.K) * 6.93147180559945286227e-01 + log(r_aux.s / r_plain.s);
+}
 // The island's reduction by ONE workgroup for any number of tiles, in chunks of 1024 partials
 // (thread tid: the four from 4*tid on of every chunk).  Up to 1024 tiles that is operation for
 // operation what every workgroup of k_ancestors2 does, hence the same bits.
-__device__ __forceinline__ F2Red f2_reduce_island(const FArgs& a, const int isl, double* smd)
+__device__ __forceinline__ F2Red f2_reduce_island(const FArgs& a, const int isl, double* smd,
+                                                  const bool plain = false)
 {
+    // plain: the APF's partials of the plain weights (pm2 / ps2 / pss2) instead of the auxiliary ones
+    const double* Pm = plain ? a.pm2 : a.pm;
+    const double* Ps = plain ? a.ps2 : a.ps;
+    const double* Pss = plain ? a.pss2 : a.pss;
     const i64 o = (i64)isl * a.nparts;
     const bool pvec = (a.nparts & 3) == 0;
     const int nchunks = (a.nparts + 4 * SMC_BLOCK - 1) / (4 * SMC_BLOCK);
@@ -1472,7 +1530,7 @@ __device__ __forceinline__ F2Red f2_reduce_island(const FArgs& a, const int isl,
     double tm = -INFINITY;
     for (int c = 0; c < nchunks; ++c) {
         double pm4[4];
-        f_load4<double>(a.pm + o, (i64)c * 4 * SMC_BLOCK + (i64)threadIdx.x * 4, a.nparts, pvec, -INFINITY, pm4);
+        f_load4<double>(Pm + o, (i64)c * 4 * SMC_BLOCK + (i64)threadIdx.x * 4, a.nparts, pvec, -INFINITY, pm4);
         tm = smc_max2(tm, smc_max2(smc_max2(pm4[0], pm4[1]), smc_max2(pm4[2], pm4[3])));
     }
     r.K = smc_block_max(tm, smd);
@@ -1480,9 +1538,9 @@ __device__ __forceinline__ F2Red f2_reduce_island(const FArgs& a, const int isl,
     for (int c = 0; c < nchunks; ++c) {
         const i64 i0 = (i64)c * 4 * SMC_BLOCK + (i64)threadIdx.x * 4;
         double pm4[4], ps4[4], pss4[4];
-        f_load4<double>(a.pm + o, i0, a.nparts, pvec, -INFINITY, pm4);
-        f_load4<double>(a.ps + o, i0, a.nparts, pvec, 0.0, ps4);
-        f_load4<double>(a.pss + o, i0, a.nparts, pvec, 0.0, pss4);
+        f_load4<double>(Pm + o, i0, a.nparts, pvec, -INFINITY, pm4);
+        f_load4<double>(Ps + o, i0, a.nparts, pvec, 0.0, ps4);
+        f_load4<double>(Pss + o, i0, a.nparts, pvec, 0.0, pss4);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             double v, w;
@@ -1504,8 +1562,12 @@ __device__ __forceinline__ F2Red f2_reduce_island(const FArgs& a, const int isl,
 // instead of one per chunk and pass (k_reduce2 is ONE workgroup on the critical path of the step).
 template <int NC>
 __device__ __forceinline__ F2Red f2_reduce_island_cached(const FArgs& a, const int isl, double* smd,
-                                                         double (&pm)[NC][4], double (&ps)[NC][4])
+                                                         double (&pm)[NC][4], double (&ps)[NC][4],
+                                                         const bool plain = false)
 {
+    const double* Pm = plain ? a.pm2 : a.pm;
+    const double* Ps = plain ? a.ps2 : a.ps;
+    const double* Pss = plain ? a.pss2 : a.pss;
     const i64 o = (i64)isl * a.nparts;
     const bool pvec = (a.nparts & 3) == 0;
     const int nchunks = (a.nparts + 4 * SMC_BLOCK - 1) / (4 * SMC_BLOCK);
@@ -1514,9 +1576,9 @@ __device__ __forceinline__ F2Red f2_reduce_island_cached(const FArgs& a, const i
     for (int c = 0; c < NC; ++c) {
         const i64 i0 = (i64)c * 4 * SMC_BLOCK + (i64)threadIdx.x * 4;
         if (c < nchunks) {
-            f_load4<double>(a.pm + o, i0, a.nparts, pvec, -INFINITY, pm[c]);
-            f_load4<double>(a.ps + o, i0, a.nparts, pvec, 0.0, ps[c]);
-            f_load4<double>(a.pss + o, i0, a.nparts, pvec, 0.0, pss[c]);
+            f_load4<double>(Pm + o, i0, a.nparts, pvec, -INFINITY, pm[c]);
+            f_load4<double>(Ps + o, i0, a.nparts, pvec, 0.0, ps[c]);
+            f_load4<double>(Pss + o, i0, a.nparts, pvec, 0.0, pss[c]);
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k) { pm[c][k] = -INFINITY; ps[c][k] = 0.0; pss[c][k] = 0.0; }
@@ -1574,7 +1636,12 @@ k_reduce2(const FArgs av)
         double pmc[NC][4], psc[NC][4];
         const F2Red r = f2_reduce_island_cached<NC>(a, isl, smd, pmc, psc);
         const bool resample = r.ess < a.ess_thresh;
-        if (tid == 0) f2_write_record(a, isl, t, r, resample);
+        if (a.pm2) {
+            const F2Red r2 = f2_reduce_island(a, isl, sme, true);
+            if (tid == 0) f2_write_record_apf(a, isl, t, r, r2, resample);
+        } else if (tid == 0) {
+            f2_write_record(a, isl, t, r, resample);
+        }
         if (!resample) return;
         double carry = 0.0;
 #pragma unroll
@@ -1600,7 +1667,12 @@ k_reduce2(const FArgs av)
     }
     const F2Red r = f2_reduce_island(a, isl, smd);
     const bool resample = r.ess < a.ess_thresh;
-    if (tid == 0) f2_write_record(a, isl, t, r, resample);
+    if (a.pm2) {
+        const F2Red r2 = f2_reduce_island(a, isl, sme, true);
+        if (tid == 0) f2_write_record_apf(a, isl, t, r, r2, resample);
+    } else if (tid == 0) {
+        f2_write_record(a, isl, t, r, resample);
+    }
     if (!resample) return;
     // every tile's share and the shares before it, chunk by chunk (a running carry across chunks)
     double carry = 0.0;
@@ -1952,11 +2024,12 @@ k_flush2(const FArgs av)
     const i64 t = (i64)smc_uniform(smc_ldg(a.info2 + (i64)isl * INFO_STRIDE));       // steps done
     if (t <= 0 || t > a.T) return;                      // (t > T: records frozen by k_theta_update)
     F2Red r;
+    const bool plain = a.pm2 != nullptr;                // APF: the row describes the plain weights
     if (a.nparts <= 4 * 4 * SMC_BLOCK) {                // all partials in registers: one memory latency
         double pmc[4][4], psc[4][4];
-        r = f2_reduce_island_cached<4>(a, isl, smd, pmc, psc);
+        r = f2_reduce_island_cached<4>(a, isl, smd, pmc, psc, plain);
     } else {
-        r = f2_reduce_island(a, isl, smd);
+        r = f2_reduce_island(a, isl, smd, plain);
     }
     if (threadIdx.x == 0) f2_write_row(a, isl, t - 1, r);
 }

@@ -12,6 +12,7 @@ compared at <= 1e-12 relative; log-evidence at <= 1e-9 relative (north star:
 import ctypes
 
 import numpy as np
+import pytest
 
 import particles_amd as pa
 from oracle import smc_oracle as orc
@@ -1474,7 +1475,8 @@ def check_apf_and_guided_generic(golden):
             assert rel(pf.W, g["W"]) < 1e-9
 
 
-def check_apf_fused(golden):
+def check_apf_fused(golden, apf2_cases=((2048, "systematic", 0.7), (4096, "stratified", 0.9),
+                                         (4096, "multinomial", 0.7))):
     """AuxiliaryPF and GuidedPF of the stock StochVol (Pitt & Shephard's proposal and logeta,
     state_space_models.py:475-498; core.py:299-313) in the FUSED loop: the reference's own runs
     (fixtures sv_apf / sv_guided: same numpy seed -> replayed draws) -- every resample decision,
@@ -1514,7 +1516,41 @@ def check_apf_fused(golden):
         lls.append(pf.logLt)
     assert abs(np.mean(lls) - float(g["logLt"])) < 0.15, lls
     big = pa.SMC(fk=ssm.AuxiliaryPF(ssm=ssm.StochVol(), data=y), N=3000)
-    assert not big._fused                                               # operator path beyond 1024
+    assert not big._fused                      # beyond 1024 and not a power of two: the operator path
+    # ---- N = 2^k >= 2048: the APF on the two-level step.  k_propagate leaves TWO tile partials (plain
+    # weights: evidence, logged ESS, W; auxiliary weights lw + logeta: decision, shares, integer CDF),
+    # k_reduce2 reduces both and sends the reset constant with the record.  Against the oracle run on
+    # the same contract (cdf="2level"), replaying its draws: every decision, the final ancestors.
+    for N2, scheme, essr in apf2_cases:
+        yy = y[:30]
+        np.random.seed(7 + N2)
+        rec = orc.RecordingRNG()
+        o = orc.run_filter(orc.StochVol(), yy, N2, scheme, essr, fk="apf", rng=rec, keep=True, cdf="2level")
+        z, u = tapes_from_oracle(rec.tape, len(yy), N2, scheme)
+        mk = lambda **kw: pa.SMC(fk=ssm.AuxiliaryPF(ssm=ssm.StochVol(), data=yy), N=N2, resampling=scheme,
+                                 ESSrmin=essr, replay=(z, u), **kw)
+        pf = mk()
+        assert pf._fused and describe(pf).endswith("k_reduce2+k_ancestors2+k_propagate"), describe(pf)
+        pf.run()
+        assert pf.summaries.rs_flags == o["rs_flag"] and 2 <= sum(o["rs_flag"]) < len(yy) - 1
+        assert rel(pf.summaries.ESSs, o["ESS"]) < 1e-9 and rel(pf.summaries.logLts, o["logLt"]) < 1e-9
+        assert np.array_equal(pf.A, o["A"])
+        assert np.max(np.abs(pf.X - o["X"])) < 1e-12
+        assert np.allclose(pf.wgts.lw, o["lw"], rtol=1e-11, atol=1e-11) and rel(pf.W, o["W"]) < 1e-9
+        ps = mk(store_history=True)                    # one step at a time, history slots
+        for _ in range(len(yy)):
+            next(ps)
+        assert ps.logLt == pf.logLt and np.array_equal(ps.X, pf.X)
+        for t in (3, len(yy) - 1):
+            assert np.max(np.abs(ps.hist.X[t] - o["hist"]["X"][t])) < 1e-12
+            assert np.allclose(ps.hist.wgts[t].lw, o["hist"]["lw"][t], rtol=1e-11, atol=1e-11)
+        with pytest.raises(Exception):
+            pf.set_state(lw=np.zeros(N2))
+    # Philox mode, several islands: the evidence estimate
+    pf = pa.SMC(fk=ssm.AuxiliaryPF(ssm=ssm.StochVol(), data=y), N=apf2_cases[0][0], seed=5, n_islands=3, collect="off")
+    assert pf._fused
+    pf.run()
+    assert np.max(np.abs(pf.logLts_islands - float(g["logLt"]))) < 0.3, pf.logLts_islands
     gd = pa.SMC(fk=ssm.GuidedPF(ssm=ssm.StochVol(), data=y), N=4096, seed=3)
     assert gd._fused and "k_propagate" in describe(gd)                  # guided StochVol: every path
     gd.run()

@@ -250,4 +250,4 @@ def test_rolling_history_on_device():
 
 
 def test_apf_and_guided_stochvol_fused(golden):
-    pc.check_apf_fused(golden)
+    pc.check_apf_fused(golden, apf2_cases=((2048, "systematic", 0.7), (2048, "multinomial", 0.7)))
