@@ -514,4 +514,4 @@ def test_sharded_smc2_over_rccl(tmp_path):
 
 def test_apf_and_guided_stochvol_fused(golden):
     pc.check_apf_fused(golden, apf2_cases=((2048, "systematic", 0.7), (4096, "stratified", 0.9),
-                                         (4096, "multinomial", 0.7), (1 << 17, "systematic", 0.7)))
+                                         (4096, "multinomial", 0.7), (1 << 15, "systematic", 0.7)))
