@@ -136,3 +136,30 @@ def test_install_swaps_particles_smc_and_registry(ref):
     assert abs(lls[0] - lls[1]) < 1e-9 * abs(lls[0]), lls
     for n in names:
         del rs.rs_funcs[n]
+
+
+def test_reference_apf_runs_fused_through_the_adapter(ref):
+    """particles.AuxiliaryPF of the stock StochVol handed to HipSMC: N <= 1024 lands on the one-launch
+    filter, N = 2^k >= 2048 on the two-level step (both fused), other sizes on the operator path;
+    the evidence agrees with the reference's own run (same model, same data, its NumPy generator)."""
+    import particles_amd as pa
+    from particles_amd import adapter
+    from parity_cases import describe
+    particles, rssm = ref["particles"], ref["ssm"]
+    rng = np.random.RandomState(3)
+    y = [np.array([v]) for v in 0.6 * rng.standard_normal(30)]
+    fk = rssm.AuxiliaryPF(ssm=rssm.StochVol(mu=-1.0, rho=0.95, sigma=0.2), data=y)
+    HipSMC = adapter.HipSMC()
+    np.random.seed(5)
+    want = particles.SMC(fk=fk, N=2000)
+    want.run()
+    got = {}
+    for N in (1000, 2048, 3000):
+        pf = HipSMC(fk=fk, N=N, seed=8)
+        assert isinstance(pf, pa.SMC)
+        got[N] = pf
+        pf.run()
+        assert abs(pf.logLt - want.logLt) < 0.5, (N, pf.logLt, want.logLt)
+    assert got[1000]._fused and describe(got[1000]) == "k_filter_small"
+    assert got[2048]._fused and describe(got[2048]) == "k_reduce2+k_ancestors2+k_propagate"
+    assert not got[3000]._fused

@@ -39,7 +39,7 @@ for c in range(ncases):
     if rng.random() < 0.25:                 # not a power of two: the flat path only (heavy list on / off)
         N += int(rng.integers(1, N))
     M = int(rng.choice([1, 1, 2, 5])) if k <= 17 else 1
-    scheme = str(rng.choice(["systematic", "stratified"]))
+    scheme = str(rng.choice(["systematic", "stratified", "multinomial"]))     # (multinomial: counts by search)
     essr = float(rng.choice([0.3, 0.5, 0.9, 1.0]))
     T = int(rng.integers(5, 40))
     which = int(rng.integers(0, 6))
