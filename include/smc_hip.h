@@ -245,7 +245,7 @@ enum smc_fk_kind {
                                * auxiliary weights of core.py:299-313 (resampling on lw + logeta,
                                * weights reset to log_mean_exp(logeta, W) - logeta[A]); STOCHVOL
                                * (Pitt & Shephard, :475-498); N <= 1024 (the one-launch filter) or
-                               * N = 2^k >= 2048 (the two-level step); no moments, no rolling window */
+                               * 1024 < N <= 2^30 (the two-level step); no moments, no rolling window */
 };
 enum smc_rng_mode {
     SMC_RNG_PHILOX = 0,       /* counter-based Philox4x32-10 per lane */

@@ -362,6 +362,22 @@ static int64_t count_pow2(uint64_t C, const double *u, int stratified, int k, in
     return (int64_t)nc + (T <= C ? 1 : 0);
 }
 
+/* any N (not a power of two): su_n = fl(fl(u_n + n) / N), T_n = ceil(su_n 2^52) -- non-decreasing in n
+ * (fl(u_n + n) lies in [n, n + 1], rounding and ceil are monotone): count(C) by bisection on the
+ * definition (systematic: u_n = u[0]; stratified: u_n = u[n]) */
+static int64_t count_general(uint64_t C, const double *u, int stratified, int64_t N)
+{
+    int64_t lo = 0, hi = N;                            /* T_n <= C on [0, lo), > C on [hi, N) */
+    while (lo < hi) {
+        const int64_t mid = lo + (hi - lo) / 2;
+        const double un = stratified ? u[mid] : u[0];
+        const double v = (un + (double)mid) / (double)N;
+        const uint64_t T = (v > 0.0) ? (uint64_t)ceil(fmin(v, 2.0) * 4503599627370496.0) : 0;
+        if (T <= C) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
 /* multinomial: the N sorted uniforms su themselves (resampling.py:512-537), thresholds
  * T_n = ceil(su_n 2^52): count(C) = #{ n < N : T_n <= C } by bisection (T_n is non-decreasing) */
 static int64_t count_sorted(uint64_t C, const double *su, int64_t N)
@@ -379,15 +395,15 @@ static int64_t count_sorted(uint64_t C, const double *su, int64_t N)
 /* The whole contract: ancestors A (N) from the log-weights of the parents.  scheme: 0
  * multinomial (u: the N sorted uniforms), 1 stratified (u: N uniforms), 2 systematic (u: 1
  * uniform).  red (5): K, s, ss, ESS, 1/s.
- * Returns 0, or 1 if N is not a power of two >= 2048 (the path does not apply). */
+ * Returns 0, or 1 if N <= 1024 or N > 2^30 (the path does not apply). */
 int orc_inverse_cdf_2level(const double *lw, int64_t N, int scheme, const double *u,
                            int64_t *A, double *red)
 {
-    int k = -1;
+    int k = -1;                                        /* log2 N, or -1: the general counts */
     for (int i = 0; i < 40; ++i)
         if (((int64_t)1 << i) == N) k = i;
-    if (k < 11) return 1;
-    const int64_t nt = N / 1024;
+    if (N <= 1024 || N > ((int64_t)1 << 30)) return 1;
+    const int64_t nt = (N + 1023) / 1024;              /* the last tile may be ragged: -inf beyond N */
     double *pK = malloc(sizeof(double) * nt), *ps = malloc(sizeof(double) * nt),
            *pss = malloc(sizeof(double) * nt), *Q = malloc(sizeof(double) * nt),
            *G = malloc(sizeof(double) * nt);
@@ -398,10 +414,10 @@ int orc_inverse_cdf_2level(const double *lw, int64_t N, int scheme, const double
     int64_t prev = 0;                                  /* first offspring of parent j - 1 */
     for (int64_t b = 0; b < nt; ++b) {
         uint64_t tb = 0;
-        for (int i = 0; i < 1024; ++i) tb += q[b * 1024 + i];
+        for (int i = 0; i < 1024 && b * 1024 + i < N; ++i) tb += q[b * 1024 + i];
         const uint64_t Qb = (uint64_t)Q[b], Gb = (uint64_t)G[b];
         uint64_t c = 0;
-        for (int i = 0; i < 1024; ++i) {
+        for (int i = 0; i < 1024 && b * 1024 + i < N; ++i) {
             const int64_t j = b * 1024 + i;
             int64_t ns;
             if (j == 0) ns = 0;
@@ -410,7 +426,8 @@ int orc_inverse_cdf_2level(const double *lw, int64_t N, int scheme, const double
                 if (c == 0) pos = 0;
                 else if (c >= tb) pos = Qb;
                 else pos = (uint64_t)(((unsigned __int128)c * Qb) / tb);
-                ns = scheme == 0 ? count_sorted(Gb + pos, u, N) : count_pow2(Gb + pos, u, strat, k, N);
+                ns = scheme == 0 ? count_sorted(Gb + pos, u, N)
+                   : (k >= 0 ? count_pow2(Gb + pos, u, strat, k, N) : count_general(Gb + pos, u, strat, N));
             }
             /* offspring prev .. ns-1 belong to parent j - 1 */
             for (int64_t n = prev; n < ns; ++n) A[n] = j - 1;

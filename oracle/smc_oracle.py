@@ -364,7 +364,7 @@ def inverse_cdf_2level_c(scheme, u, lw):
     rc = clib().orc_inverse_cdf_2level(_dp(lw), lw.size, {"multinomial": 0, "stratified": 1, "systematic": 2}[scheme],
                                        _dp(u), A.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), _dp(red))
     if rc:
-        raise ValueError("two-level contract: N must be a power of two >= 2048")
+        raise ValueError("two-level contract: 1024 < N <= 2^30")
     return A, dict(K=red[0], s=red[1], ss=red[2], ESS=red[3], rs=red[4])
 
 
@@ -380,9 +380,10 @@ def inverse_cdf_2level(su, lw, tile=1024):
     resampling.py:500-509 would clamp."""
     lw = np.asarray(lw, dtype=np.float64)
     N = lw.shape[0]
-    nt = N // tile
-    assert nt * tile == N and nt >= 1 and tile == 1024
+    nt = (N + tile - 1) // tile
+    assert nt >= 1 and tile == 1024
     pK, ps, pss, q = tile_partials(lw, with_q=True)
+    q = np.concatenate([q, np.zeros(nt * tile - N, dtype=q.dtype)])      # a ragged last tile: zero weights
     _, Qa, Ga = two_level_reduce(pK, ps, pss)
     Q = [int(v) for v in Qa]
     G = [int(v) for v in Ga] + [int(Ga[-1]) + int(Qa[-1])]

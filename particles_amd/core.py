@@ -176,12 +176,12 @@ class SMC:
         self._summ_cache = None
         model = fk._device_model() if hasattr(fk, "_device_model") else None
         if fk is not None and fk.isAPF:
-            # fused APF: the one-launch filter (N <= 1024) or the two-level step (N = 2^k >= 2048)
+            # fused APF: the one-launch filter (N <= 1024) or the two-level step (N > 1024)
             stock = getattr(fk, "_fk_kind", None) == _lib.FK_APF
             no_mom = not (collect and collect != "off" and self._device_moments)
             small = N <= 1024 and not (resampling == "multinomial" and replay is None)
             rolling = isinstance(store_history, int) and not isinstance(store_history, bool) and store_history >= 2
-            two_level = 2048 <= N <= (1 << 30) and N & (N - 1) == 0 and not rolling
+            two_level = 1024 < N <= (1 << 30) and not rolling
             if not (stock and no_mom and (small or two_level)):
                 model = None                   # anything else: the operator path
         if qmc:                    # SQMC: the template-method step on device operators

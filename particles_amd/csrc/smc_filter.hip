@@ -22,6 +22,7 @@ struct smc_filter {
     bool fused;            // k_ancestors<true> (no k_prepare launch)
     bool two_level;        // k_ancestors2 + tail-free k_propagate (two-level CDF, no intra-launch exchange)
     bool two_level_mid;    // ... with k_reduce2 in front (grids too large for every workgroup to reduce)
+    bool ragged;           // two-level step with N not a multiple of the tile (k_propagate<.., RAGGED>)
     bool mv_collapsed;     // MVLINGAUSS guided: log G = log p(y_t | x_{t-1}) in one product (opts.flags)
     i64 perm_t;            // t_host at the last smc_filter_permute_islands (A / Xp undefined there)
     hipGraphExec_t gexec[3];   // captured step sequences of F_GRAPH_SIZES steps (even: see enqueue_step)
@@ -66,7 +67,11 @@ static void launch_propagate(smc_filter* f)
     }
 #define P_CASE(KINDV, FKV)                                                                    \
     if (f->kind == KINDV && f->fk == FKV) {                                                   \
-        if (f->two_level && f->a.par >= 0)                                                    \
+        if (f->two_level && f->ragged && f->a.par >= 0)                                       \
+            SMC_LAUNCH((k_propagate<KINDV, FKV, F_OPT, true, false, true>), grid, dim3(SMC_BLOCK), st, f->a);  \
+        else if (f->two_level && f->ragged)                                                   \
+            SMC_LAUNCH((k_propagate<KINDV, FKV, F_OPT, false, false, true>), grid, dim3(SMC_BLOCK), st, f->a); \
+        else if (f->two_level && f->a.par >= 0)                                               \
             SMC_LAUNCH((k_propagate<KINDV, FKV, F_OPT, true, false>), grid, dim3(SMC_BLOCK), st, f->a);  \
         else if (f->two_level)                                                                \
             SMC_LAUNCH((k_propagate<KINDV, FKV, F_OPT, false, false>), grid, dim3(SMC_BLOCK), st, f->a); \
@@ -111,9 +116,11 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
             SMC_LAUNCH((k_ancestors2<true, true>), grid, dim3(SMC_BLOCK), st, f->a);
         } else if (f->two_level_mid) {
             SMC_LAUNCH(k_reduce2, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
-            SMC_LAUNCH((k_ancestors2<true>), grid, dim3(SMC_BLOCK), st, f->a);
+            if (f->a.log2N >= 0) SMC_LAUNCH((k_ancestors2<true>), grid, dim3(SMC_BLOCK), st, f->a);
+            else SMC_LAUNCH((k_ancestors2<true, false, false>), grid, dim3(SMC_BLOCK), st, f->a);
         } else {
-            SMC_LAUNCH((k_ancestors2<false>), grid, dim3(SMC_BLOCK), st, f->a);
+            if (f->a.log2N >= 0) SMC_LAUNCH((k_ancestors2<false>), grid, dim3(SMC_BLOCK), st, f->a);
+            else SMC_LAUNCH((k_ancestors2<false, false, false>), grid, dim3(SMC_BLOCK), st, f->a);
         }
         if (k_prof >= 0 && (k_prof % 3)) (void)hipEventRecord(f->ev[3 * k_prof + 1], st);
         launch_propagate(f);
@@ -170,10 +177,10 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
                     (model->fk == SMC_FK_APF && model->kind == SMC_MODEL_STOCHVOL),
                 "guided filter: LINGAUSS, STOCHVOL, MVLINGAUSS; auxiliary filter: STOCHVOL");
     {
-        const bool pow2 = o->N >= 2 * F_TILE && (o->N & (o->N - 1)) == 0 && o->N <= ((int64_t)1 << 30);
-        if (model->fk == SMC_FK_APF && (o->moments || (o->N > F_TILE && !pow2) || o->keep_history >= 2)) {
+        const bool big = o->N > F_TILE && o->N <= ((int64_t)1 << 30);
+        if (model->fk == SMC_FK_APF && (o->moments || (o->N > F_TILE && !big) || o->keep_history >= 2)) {
             smc_set_error("the auxiliary particle filter is fused for N <= 1024 (the one-launch filter) and for "
-                          "N = 2^k >= 2048 (the two-level step); no moments, no rolling window");
+                          "1024 < N <= 2^30 (the two-level step); no moments, no rolling window");
             return SMC_ERR_INVALID;
         }
     }
@@ -281,7 +288,9 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     // 1024 tiles per island (4 partials per thread), at least 2 (below, the one-workgroup filter)
     // (multinomial: the counts are searches over the sorted uniforms -- the tape's, or the exponential
     //  spacings drawn between k_reduce2, which decides the step, and k_ancestors2)
-    f->two_level = !mv && !o->moments && a.log2N >= 0 && a.log2N <= 30 && a.ntiles >= 2 &&
+    // (any N >= 2 tiles: N = 2^k counts in closed form with integers, other N with the general counts)
+    f->two_level = !mv && !o->moments && o->N <= ((int64_t)1 << 30) && a.ntiles >= 2 &&
+                   !(a.log2N < 0 && getenv("SMC_POW2_ONLY")) &&
                    !getenv("SMC_FLAT_CDF") && !getenv("SMC_FORCE_FUSED") && !getenv("SMC_FORCE_UNFUSED") &&
                    !(o->scheme == SMC_MULTINOMIAL && getenv("SMC_FLAT_MULTINOMIAL"));
     // every workgroup reduces the partials itself while the launch is resident and an island has
@@ -295,7 +304,9 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     f->two_level_mid = f->two_level && (!f->fused || a.ntiles > 1024 || getenv("SMC_TWO_LEVEL_MID") ||
                                         o->scheme == SMC_MULTINOMIAL || apf2);
     const bool heavy_list = !mv && !getenv("SMC_NO_HEAVY");
-    const size_t oCq = carve(f->two_level ? M * N * 8 : 8);
+    f->ragged = f->two_level && (o->N % F_TILE) != 0;
+    a.ncq = (i64)a.ntiles * F_TILE;
+    const size_t oCq = carve(f->two_level ? M * (size_t)a.ncq * 8 : 8);
     const size_t oTq = carve(f->two_level ? M * a.ntiles * 8 : 8);
     const size_t oP2 = carve(apf2 ? 3 * M * a.nparts * 8 : 8);
     const size_t oHcnt = carve(heavy_list ? M * 2 * sizeof(unsigned) : 8);
@@ -781,7 +792,7 @@ static int island_arrays(smc_filter* f, i64 t, IslandArray* out)
         out[n++] = {a.pss, a.nparts};
         out[n++] = {a.tq, a.nparts};
         out[n++] = {a.info2, INFO_STRIDE};
-        out[n++] = {a.cq, N};
+        out[n++] = {a.cq, a.ncq};
     }
     return n;
 }

@@ -72,6 +72,7 @@ struct FArgs {
                            // stays resident); k >= 2: a ring of k slots (the k most recent steps)
     int par;               // t & 1 of the step this launch runs, or -1 (history slots): lets the
                            // kernels form their addresses before the step record has arrived
+    i64 ncq;               // per-island stride of cq: ntiles x 1024 (the last tile may be ragged)
     double *pm2, *ps2, *pss2;   // APF on the two-level path: the tile partials of the PLAIN weights
                            // (pm/ps/pss, cq, tq then describe the AUXILIARY weights lw + logeta,
                            // which decide and drive the resampling -- core.py:307-313); else null
@@ -1049,7 +1050,9 @@ __device__ __forceinline__ FOwn f_own(const int b, const int tid, const i64 N)
 }
 __device__ __forceinline__ i64 f_own_idx(const FOwn& o, const int k) { return (k < 2 ? o.na : o.nb) + (k & 1); }
 
-template <int KIND, int FK, int OPT, bool SPEC, bool TAIL = true>
+// RAGGED (tail-free launches only): N is not a multiple of the tile -- the last workgroup's threads
+// test their indices (everywhere else `full` is a compile-time constant: see the loads below)
+template <int KIND, int FK, int OPT, bool SPEC, bool TAIL = true, bool RAGGED = false>
 __global__ void __launch_bounds__(SMC_BLOCK)
 k_propagate(const FArgs av)
 {
@@ -1063,7 +1066,7 @@ k_propagate(const FArgs av)
     double* info = a.info + (i64)isl * INFO_STRIDE;
     const i64 N = a.N;
     const FOwn own = f_own<!TAIL>(b, tid, N);
-    const bool full = !TAIL || own.full;           // (!TAIL: N is a multiple of the tile, every thread owns 4)
+    const bool full = (TAIL || RAGGED) ? own.full : true;   // (tail-free, N a multiple of the tile: every thread owns 4)
     const double r0 = smc_ldg(info), r1 = smc_ldg(info + 1), r2 = smc_ldg(info + 2),
                  r5 = smc_ldg(info + 5);
     constexpr bool APF = FK == SMC_FK_APF;         // (tail-free two-level path only: see the tail)
@@ -1262,7 +1265,7 @@ k_propagate(const FArgs av)
             }
         }
         const F2Tile r = f2_tile_weights(lw, cx);
-        u64* cq = a.cq + (i64)isl * N;
+        u64* cq = a.cq + (i64)isl * a.ncq;
         if (a.nt) { smc_st2g_nt(cq + own.na, cx[0], cx[1]); smc_st2g_nt(cq + own.nb, cx[2], cx[3]); }
         else { smc_st2g(cq + own.na, cx[0], cx[1]); smc_st2g(cq + own.nb, cx[2], cx[3]); }
         if (tid == 0) {
@@ -1369,10 +1372,56 @@ __device__ __forceinline__ void f2_su(const FArgs& a, const int isl, const i64 t
             su.u_sys = smc_u01_halfopen(x0);
         }
     }
-    Us = (u64)(su.u_sys * __longlong_as_double((long long)(1023 + F2_SBITS - a.log2N) << 52));
+    Us = a.log2N >= 0 ? (u64)(su.u_sys * __longlong_as_double((long long)(1023 + F2_SBITS - a.log2N) << 52))
+                      : 0ull;                      // (the integer shortcut of N = 2^k only)
 }
+// ---- any N (not a power of two).  su_n = fl(fl(u_n + n) / N) lies in [fl(n / N), fl((n + 1) / N)]
+// (fl(u_n + n) in [n, n + 1]; rounding is monotone), so with B_n = ceil(fl(n / N) 2^52) the thresholds
+// T_n = ceil(su_n 2^52) satisfy B_n <= T_n <= B_{n+1} and, exactly as for N = 2^k,
+//     count(C) = #{ n : T_n <= C } = nc + [T_nc <= C],   nc = max{ n <= N : B_n <= C }.
+// nc is floor(C N 2^-52) up to the roundings of the definition: an fp64 guess, fixed with the
+// definition itself (a step or two); the oracle counts by bisection on the same definition.
+__device__ __forceinline__ u64 f2_t52_div(const double x, const double dN)
+{
+    const double v = x / dN;
+    return (v > 0.0) ? (u64)ceil(fmin(v, 2.0) * 4503599627370496.0) : 0ull;
+}
+__device__ inline i64 f2_nc_general(const u64 C, const double dN, const i64 N)
+{
+    const double z = (double)C * (dN * 0x1.0p-52);
+    i64 g = (z >= dN) ? N : (i64)z;
+    while (g < N && f2_t52_div((double)(g + 1), dN) <= C) ++g;
+    while (g > 0 && f2_t52_div((double)g, dN) > C) --g;
+    return g;
+}
+__device__ __attribute__((noinline)) i64 f2_count_general(const u64 C, const SmcSu& su)
+{
+    const i64 nc = f2_nc_general(C, su.dM, su.M);
+    if (nc >= su.M) return su.M;
+    const double un = (su.scheme == SMC_SYSTEMATIC_) ? su.u_sys : smc_strat_u(su, (u64)nc);
+    return nc + (f2_t52_div(un + (double)nc, su.dM) <= C ? 1 : 0);
+}
+// the same for a C known only to within +-E (E far below 2^52 / N): decided whenever neither nc nor
+// the comparison can change inside the band; -1 otherwise (cf. smc_count_pow2_band)
+__device__ __attribute__((noinline)) i64 f2_count_band_general(const u64 Ch, const u64 E, const SmcSu& su)
+{
+    const i64 N = su.M;
+    const i64 nc = f2_nc_general(Ch, su.dM, N);
+    if (nc >= N) return (f2_t52_div((double)N, su.dM) + E <= Ch) ? N : -1;
+    // nc must be the same for every C in [Ch - E, Ch + E]: B_nc + E <= Ch and B_{nc+1} > Ch + E
+    if (nc > 0 && f2_t52_div((double)nc, su.dM) + E > Ch) return -1;
+    if (f2_t52_div((double)(nc + 1), su.dM) <= Ch + E) return -1;
+    const double un = (su.scheme == SMC_SYSTEMATIC_) ? su.u_sys : smc_strat_u(su, (u64)nc);
+    const u64 T = f2_t52_div(un + (double)nc, su.dM);
+    if (T + E <= Ch) return nc + 1;
+    if (T > Ch + E) return nc;
+    return -1;
+}
+// POW2: a compile-time copy of a.log2N >= 0 -- the kernels of N = 2^k carry none of the general code
+template <bool POW2>
 __device__ __forceinline__ i64 f2_count(const FArgs& a, const SmcSu& su, const u64 Us, const u64 C)
 {
+    if (!POW2) return f2_count_general(C, su);
     const int kq = a.log2N + (62 - F2_SBITS);
     return a.scheme == SMC_SYSTEMATIC_ ? smc_sys_count_pow2_fast(C, su.u_sys, Us, kq, a.N)
                                        : smc_strat_count_pow2(C, su, kq, a.N);
@@ -1389,6 +1438,7 @@ struct F2Fast {
 // 1 on the fma, 1 on the subtraction, 1 for fl(u + n), 2^-sh for the floor in C) x N 2^-53
 // < 8 N 2^-53; the band is 16 N 2^-53.  Outside it the floor and the comparison are decided;
 // inside (probability 2^-28 per parent at N = 2^20) the exact integer route is taken.
+template <bool POW2>
 __device__ __forceinline__ i64 f2_ns_sys(const FArgs& a, const SmcSu& su, const u64 Us, const F2Fast& f,
                                          const u64 c)
 {
@@ -1401,7 +1451,7 @@ __device__ __forceinline__ i64 f2_ns_sys(const FArgs& a, const SmcSu& su, const 
         v = v > f.dN ? f.dN : v;
         return (i64)(u32)v;
     }
-    return f2_count(a, su, Us, f.Gb + smc_muldiv_floor(c, f.Qb, f.tb));
+    return f2_count<POW2>(a, su, Us, f.Gb + smc_muldiv_floor(c, f.Qb, f.tb));
 }
 // ---- multinomial on the two-level path: the sorted uniforms sit in memory (the tape, or the
 // exponential spacings k_f_spacing_* left in a.su), thresholds T_n = ceil(su_n 2^52) on the
@@ -1456,6 +1506,7 @@ __device__ inline i64 f2_count_sorted_range(const double* u, i64 lo, i64 hi, con
 // first offspring ns[i] of the parents jt+i at positions cx[i] (cx[4]: the next thread's first
 // parent, t_b for the last thread), any scheme: fp64 quotient within 2^12 of the truth, count
 // decided unless the position lies within that band of a threshold, else formed exactly
+template <bool POW2>
 __device__ __forceinline__ void f2_first_offspring(const FArgs& a, const SmcSu& su, const u64 Us,
                                                    const u64 (&cx)[F_IPT + 1], const u64 tb,
                                                    const u64 Gb, const u64 Qb, const i64 jt,
@@ -1474,8 +1525,9 @@ __device__ __forceinline__ void f2_first_offspring(const FArgs& a, const SmcSu& 
             u64 qh = (u64)((double)c * qscale);
             qh = qh > Qb ? Qb : qh;
             i64 cnt = a.exact_counts ? -1
-                                     : smc_count_pow2_band(Gb + qh, 1ull << 13, su, su.u_sys, Us, kq, N);
-            if (cnt < 0) cnt = f2_count(a, su, Us, Gb + smc_muldiv_floor(c, Qb, tb));
+                    : (POW2 ? smc_count_pow2_band(Gb + qh, 1ull << 13, su, su.u_sys, Us, kq, N)
+                            : f2_count_band_general(Gb + qh, 1ull << 13, su));
+            if (cnt < 0) cnt = f2_count<POW2>(a, su, Us, Gb + smc_muldiv_floor(c, Qb, tb));
             ns[i] = cnt;
         }
     }
@@ -1711,7 +1763,7 @@ k_reduce2(const FArgs av)
 //     in flight): a tile owns 1024 +- a few dozen offspring.
 // MID: k_reduce2 ran first: grids too large for every workgroup to repeat the reduction.
 // ---------------------------------------------------------------------------
-template <bool MID, bool MULTI = false>
+template <bool MID, bool MULTI = false, bool POW2 = true>
 __global__ void __launch_bounds__(SMC_BLOCK)
 k_ancestors2(const FArgs av)
 {
@@ -1740,7 +1792,7 @@ k_ancestors2(const FArgs av)
         Qmid = smc_ldg(reinterpret_cast<const double*>(a.Q) + (i64)isl * a.ntiles + b);
     }
     // the tile's integer CDF: this thread's 4 positions and the next thread's first
-    const u64* cq = a.cq + (i64)isl * N;
+    const u64* cq = a.cq + (i64)isl * a.ncq;
     u64 cx[F_IPT + 1];
     smc_ld2g(cq + jt, cx[0], cx[1]);
     smc_ld2g(cq + jt + 2, cx[2], cx[3]);
@@ -1882,8 +1934,7 @@ k_ancestors2(const FArgs av)
         }
     } else if (a.scheme == SMC_SYSTEMATIC_) {
         F2Fast f;
-        const int sh = F2_SBITS - a.log2N;
-        const double down = __longlong_as_double((long long)(1023 - sh) << 52);   // 2^-sh
+        const double down = (double)N * 0x1.0p-52;        // offspring per unit of the 2^52 scale (2^-sh for N = 2^k)
         f.Gb = Gb; f.Qb = Qb; f.tb = tb;
         f.Gd = Gd * down;
         f.r = tb ? (Qd / (double)tb) * down : 0.0;
@@ -1894,12 +1945,12 @@ k_ancestors2(const FArgs av)
 #pragma unroll
         for (int i = 0; i <= F_IPT; ++i) {
             const i64 j = jt + i;
-            ns[i] = (j == 0) ? 0 : (j >= N ? N : f2_ns_sys(a, su, Us, f, cx[i]));
+            ns[i] = (j == 0) ? 0 : (j >= N ? N : f2_ns_sys<POW2>(a, su, Us, f, cx[i]));
         }
-        n_lo = (b == 0) ? 0 : f2_ns_sys(a, su, Us, f, 0ull);
-        n_hi = (b == a.ntiles - 1) ? N : f2_ns_sys(a, su, Us, f, tb);
+        n_lo = (b == 0) ? 0 : f2_ns_sys<POW2>(a, su, Us, f, 0ull);
+        n_hi = (b == a.ntiles - 1) ? N : f2_ns_sys<POW2>(a, su, Us, f, tb);
     } else {
-        f2_first_offspring(a, su, Us, cx, tb, Gb, Qb, jt, ns);
+        f2_first_offspring<POW2>(a, su, Us, cx, tb, Gb, Qb, jt, ns);
         __shared__ i64 s_n[2];
         if (tid == 0) s_n[0] = ns[0];
         if (tid == SMC_BLOCK - 1) s_n[1] = ns[F_IPT];
@@ -2055,7 +2106,7 @@ k_f_partials(const FArgs av, const i64 ts, const int two_level)
     if (two_level) {
         u64 cx[4];
         const F2Tile r = f2_tile_weights(lw, cx);
-        u64* cq = a.cq + (i64)isl * N;
+        u64* cq = a.cq + (i64)isl * a.ncq;
         smc_st2g(cq + own.na, cx[0], cx[1]);
         smc_st2g(cq + own.nb, cx[2], cx[3]);
         if (threadIdx.x == 0) { a.pm[o + b] = r.K; a.ps[o + b] = r.S; a.pss[o + b] = r.SS; a.tq[o + b] = r.tb; }

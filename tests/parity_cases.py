@@ -676,7 +676,7 @@ def check_two_level_cdf(golden, monkeypatch, N=4096, T=20):
     check_two_level_injected()
 
 
-def check_two_level_injected(sizes=(4096,)):
+def check_two_level_injected(sizes=(4096, 3000)):
     """The contract itself on weights no filter run would produce -- skewed, -inf entries, an
     empty tile, a collapsed vector: uploaded with smc_filter_set_state, one resampling step on the
     device, ancestors against orc_inverse_cdf_2level BIT FOR BIT and against the reference's
@@ -851,10 +851,11 @@ def check_describe():
     assert kernels(1 << 12) == "k_ancestors2+k_propagate"                      # two-level, resident
     assert kernels(1 << 12, "stratified") == "k_ancestors2+k_propagate"
     assert kernels(1 << 12, n_islands=600) == "k_reduce2+k_ancestors2+k_propagate"   # 2400 workgroups
-    assert kernels(3000) == "k_ancestors<fused>+k_propagate"                   # N not a power of two
+    assert kernels(3000) == "k_ancestors2+k_propagate"                         # any N of >= 2 tiles: general counts
+    assert kernels(1500) == "k_ancestors2+k_propagate"                         # (2 tiles, the second ragged)
     assert kernels(1 << 12, "multinomial") == \
         "k_f_spacing_sums+k_f_spacing_scan+k_f_spacing_write+k_reduce2+k_ancestors2+k_propagate"   # two-level: counts by search
-    assert kernels(3000, "multinomial") == "k_f_spacing_sums+k_f_spacing_scan+k_f_spacing_write+k_ancestors<fused>+k_propagate"
+    assert kernels(1500, "multinomial") == "k_f_spacing_sums+k_f_spacing_scan+k_f_spacing_write+k_reduce2+k_ancestors2+k_propagate"
     mv = kalman.MVLinearGauss_Guarniero_etal(alpha=0.4, dx=4)
     ymv = [np.zeros((1, 4)) for _ in range(4)]
     pf = pa.SMC(fk=ssm.Bootstrap(ssm=mv, data=ymv), N=1 << 12, seed=1)
@@ -1476,7 +1477,7 @@ def check_apf_and_guided_generic(golden):
 
 
 def check_apf_fused(golden, apf2_cases=((2048, "systematic", 0.7), (4096, "stratified", 0.9),
-                                         (4096, "multinomial", 0.7))):
+                                         (4096, "multinomial", 0.7), (3000, "systematic", 0.7))):
     """AuxiliaryPF and GuidedPF of the stock StochVol (Pitt & Shephard's proposal and logeta,
     state_space_models.py:475-498; core.py:299-313) in the FUSED loop: the reference's own runs
     (fixtures sv_apf / sv_guided: same numpy seed -> replayed draws) -- every resample decision,
@@ -1515,9 +1516,10 @@ def check_apf_fused(golden, apf2_cases=((2048, "systematic", 0.7), (4096, "strat
         pf.run()
         lls.append(pf.logLt)
     assert abs(np.mean(lls) - float(g["logLt"])) < 0.15, lls
-    big = pa.SMC(fk=ssm.AuxiliaryPF(ssm=ssm.StochVol(), data=y), N=3000)
-    assert not big._fused                      # beyond 1024 and not a power of two: the operator path
-    # ---- N = 2^k >= 2048: the APF on the two-level step.  k_propagate leaves TWO tile partials (plain
+    from particles_amd.collectors import Moments
+    big = pa.SMC(fk=ssm.AuxiliaryPF(ssm=ssm.StochVol(), data=y), N=3000, collect=[Moments()])
+    assert not big._fused                      # device-side moments with the APF: the operator path
+    # ---- N >= 2048: the APF on the two-level step.  k_propagate leaves TWO tile partials (plain
     # weights: evidence, logged ESS, W; auxiliary weights lw + logeta: decision, shares, integer CDF),
     # k_reduce2 reduces both and sends the reset constant with the record.  Against the oracle run on
     # the same contract (cdf="2level"), replaying its draws: every decision, the final ancestors.

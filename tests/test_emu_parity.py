@@ -226,6 +226,8 @@ def test_oracle_at_size_small():
     pc.check_oracle_at_size("toy", *toy, 2048, 5, "stratified", 0.7, replay=False)
     pc.check_oracle_at_size("sv", *sv, 3000, 4, "multinomial", 1.0)
     pc.check_oracle_at_size("sv", *sv, 2048, 4, "systematic", 1.0)
+    pc.check_oracle_at_size("toy", *toy, 3001, 5, "systematic", 0.5)           # general counts, ragged last tile
+    pc.check_oracle_at_size("toy", *toy, 2500, 4, "stratified", 0.7, replay=False)
     pc.check_oracle_at_size("mv4", *mv4, 1024, 3, "systematic", 1.0, fk="guided", d=4)
     pc.check_oracle_at_size("mv4", *mv4, 1024, 3, "systematic", 0.5, fk="guided", d=4, expect_resample=False)
     pc.check_oracle_at_size("toy", *toy, 2048, 4, "systematic", 0.5, replay=False, n_islands=3,
@@ -250,4 +252,4 @@ def test_rolling_history_on_device():
 
 
 def test_apf_and_guided_stochvol_fused(golden):
-    pc.check_apf_fused(golden, apf2_cases=((2048, "systematic", 0.7), (2048, "multinomial", 0.7)))
+    pc.check_apf_fused(golden, apf2_cases=((2048, "systematic", 0.7), (2500, "multinomial", 0.7)))

@@ -252,7 +252,7 @@ def test_c4_mv32_guided_full_size():
 def test_two_level_contract_injected_full_sizes():
     """k_ancestors2 / k_reduce2 on uploaded weights (skewed, -inf, empty tile, collapsed):
     np.array_equal with the oracle's restatement at N = 2^12 .. 2^22."""
-    pc.check_two_level_injected(sizes=(1 << 12, 1 << 17, 1 << 20, 1 << 22))
+    pc.check_two_level_injected(sizes=(1 << 12, 1 << 17, 1 << 20, 1 << 22, 3000, 100000, 10 ** 6 + 1))
 
 
 def test_c2_oracle_full_size():
@@ -260,6 +260,11 @@ def test_c2_oracle_full_size():
     mk_dev, mk_orc = pc.MODELS["toy"]
     pc.check_oracle_at_size("toy", mk_dev, mk_orc, 1 << 20, 20, "systematic", 0.5)
     pc.check_oracle_at_size("toy", mk_dev, mk_orc, 1 << 20, 6, "systematic", 0.5, replay=False)
+    # population sizes users type: not powers of two, the last tile ragged (general counts)
+    pc.check_oracle_at_size("toy", mk_dev, mk_orc, 10 ** 6, 8, "systematic", 0.5)
+    pc.check_oracle_at_size("toy", mk_dev, mk_orc, 10 ** 5, 8, "stratified", 0.7)
+    pc.check_oracle_at_size("toy", mk_dev, mk_orc, 10 ** 6 + 3, 5, "multinomial", 1.0)
+    pc.check_oracle_at_size("toy", mk_dev, mk_orc, 10 ** 5, 6, "systematic", 0.5, replay=False)
 
 
 @pytest.mark.parametrize("scheme", ["multinomial", "stratified", "systematic"])
@@ -514,4 +519,4 @@ def test_sharded_smc2_over_rccl(tmp_path):
 
 def test_apf_and_guided_stochvol_fused(golden):
     pc.check_apf_fused(golden, apf2_cases=((2048, "systematic", 0.7), (4096, "stratified", 0.9),
-                                         (4096, "multinomial", 0.7), (1 << 15, "systematic", 0.7)))
+                                         (4096, "multinomial", 0.7), (1 << 15, "systematic", 0.7), (30000, "stratified", 0.7)))

@@ -51,6 +51,8 @@ prof_r1)
   export SMC_ANC2_R1=1; PASSES="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" bash tools/gpu_profile.sh ${TAG}_c2_anc2r1 400 > $O/prof_c2_r1.txt 2>&1; unset SMC_ANC2_R1; tail -25 $O/prof_c2_r1.txt ;;
 prof_c5)
   EXTRA="--workload c5" bash tools/gpu_profile.sh ${TAG}_c5 100 > $O/prof_c5.txt 2>&1; tail -30 $O/prof_c5.txt ;;
+sweep)
+  timeout 300 python tools/size_sweep.py > $O/size_sweep.txt 2>&1; cat $O/size_sweep.txt ;;
 fuzz)
   timeout 900 python tools/fuzz_paths.py 150 11 > $O/fuzz.txt 2>&1; tail -4 $O/fuzz.txt ;;
 smc2prof)
@@ -81,7 +83,9 @@ d=json.loads([l for l in open(sys.argv[1].replace('.json','_flat.json')) if l.st
 print('   (flat path) ms/step %.5f'%d['ms_per_step'], 'G/s %.2f'%(d['value']/1e9), {k:round(v['ms'],5) for k,v in r.get('per_kernel',{}).items()})
 PY
   ;;
-prof_fuzz)
+prof_sweep)
+  timeout 300 python tools/size_sweep.py > $O/size_sweep.txt 2>&1; cat $O/size_sweep.txt ;;
+fuzz)
   timeout 900 python tools/fuzz_paths.py 150 11 > $O/fuzz.txt 2>&1; tail -4 $O/fuzz.txt ;;
 smc2prof)
   timeout 300 python tools/smc2_profile.py > $O/smc2_profile.txt 2>&1; cat $O/smc2_profile.txt ;;
