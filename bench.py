@@ -74,7 +74,7 @@ def measured_traffic(a, kernel):
     with open(path) as fh:
         rec = json.load(fh)
     cfg = rec.get("config", {})
-    if (cfg.get("log2N"), cfg.get("islands"), cfg.get("scheme")) != (a.log2N, a.islands, a.scheme):
+    if a.N > 0 or (cfg.get("log2N"), cfg.get("islands"), cfg.get("scheme")) != (a.log2N, a.islands, a.scheme):
         return None
     for name, d in rec["kernels"].items():
         if kernel in name:
@@ -133,6 +133,8 @@ def main():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--log2N", type=int, default=20)
+    ap.add_argument("--N", type=int, default=0,
+                    help="population size that is not a power of two (side measurements; the headline is --log2N 20)")
     ap.add_argument("--scheme", default="systematic")
     ap.add_argument("--islands", type=int, default=1, help="filters per GPU")
     ap.add_argument("--essrmin", type=float, default=None)
@@ -210,7 +212,7 @@ def main():
         wl = "C2: ToySSM d=1 linear-Gaussian bootstrap filter" if a.workload == "c2" else \
              "C5: ToySSM d=1 bootstrap filter islands"
     a.essrmin = 0.5 if a.essrmin is None else a.essrmin
-    N = 1 << a.log2N
+    N = a.N if a.N > 0 else 1 << a.log2N
     bytes_step = 16.0 * d + 40.0
     bytes_move = 16.0 * d + 16.0                    # k_propagate: read A, gather X; write X, lw
 
@@ -265,7 +267,8 @@ def main():
     if rank == 0:
         units = float(N) * a.islands * K * world
         out = {
-            "metric": "particle-steps/sec (N x T), %s filter N=2^%d" % ("guided" if a.workload == "c4" else "bootstrap", a.log2N),
+            "metric": "particle-steps/sec (N x T), %s filter N=%s" % ("guided" if a.workload == "c4" else "bootstrap",
+                                                                          str(a.N) if a.N > 0 else "2^%d" % a.log2N),
             "value": units / dt, "unit": "particle-steps/s", "n_gpus": world, "steps": K,
             "warmup": W, "ms_per_step": 1e3 * dt / K, "higher_is_better": True,
             "timing": {"reps": R, "statistic": "median of the repetitions of the K-step region",
@@ -274,9 +277,9 @@ def main():
                        "ms_per_step_p10_p90": [1e3 * float(np.percentile(dts, 10)) / K,
                                                1e3 * float(np.percentile(dts, 90)) / K]},
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s, N=2^%d, T=%d, %s resampling, ESSrmin=%g; %d independent "
-                                   "filter(s) per GPU" % (wl, a.log2N, K, a.scheme, a.essrmin,
-                                                          a.islands),
+            "config": {"workload": "%s, N=%s, T=%d, %s resampling, ESSrmin=%g; %d independent "
+                                   "filter(s) per GPU" % (wl, str(a.N) if a.N > 0 else "2^%d" % a.log2N, K,
+                                                          a.scheme, a.essrmin, a.islands),
                        "N": N, "islands_per_gpu": a.islands, "scheme": a.scheme,
                        "rng": "philox4x32-10", "graph": bool(a.graph),
                        "resampled_fraction": rs_rate},

@@ -22,7 +22,8 @@ struct smc_filter {
     bool fused;            // k_ancestors<true> (no k_prepare launch)
     bool two_level;        // k_ancestors2 + tail-free k_propagate (two-level CDF, no intra-launch exchange)
     bool two_level_mid;    // ... with k_reduce2 in front (grids too large for every workgroup to reduce)
-    bool ragged;           // two-level step with N not a multiple of the tile (k_propagate<.., RAGGED>)
+    int ragged;            // two-level step with N not a multiple of the tile: 1 (N even), 2 (N odd), else 0
+                           // (k_propagate<.., RAGGED>)
     bool mv_collapsed;     // MVLINGAUSS guided: log G = log p(y_t | x_{t-1}) in one product (opts.flags)
     i64 perm_t;            // t_host at the last smc_filter_permute_islands (A / Xp undefined there)
     hipGraphExec_t gexec[3];   // captured step sequences of F_GRAPH_SIZES steps (even: see enqueue_step)
@@ -67,10 +68,14 @@ static void launch_propagate(smc_filter* f)
     }
 #define P_CASE(KINDV, FKV)                                                                    \
     if (f->kind == KINDV && f->fk == FKV) {                                                   \
-        if (f->two_level && f->ragged && f->a.par >= 0)                                       \
-            SMC_LAUNCH((k_propagate<KINDV, FKV, F_OPT, true, false, true>), grid, dim3(SMC_BLOCK), st, f->a);  \
-        else if (f->two_level && f->ragged)                                                   \
-            SMC_LAUNCH((k_propagate<KINDV, FKV, F_OPT, false, false, true>), grid, dim3(SMC_BLOCK), st, f->a); \
+        if (f->two_level && f->ragged == 1 && f->a.par >= 0)                                  \
+            SMC_LAUNCH((k_propagate<KINDV, FKV, F_OPT, true, false, 1>), grid, dim3(SMC_BLOCK), st, f->a);  \
+        else if (f->two_level && f->ragged == 1)                                              \
+            SMC_LAUNCH((k_propagate<KINDV, FKV, F_OPT, false, false, 1>), grid, dim3(SMC_BLOCK), st, f->a); \
+        else if (f->two_level && f->ragged == 2 && f->a.par >= 0)                             \
+            SMC_LAUNCH((k_propagate<KINDV, FKV, F_OPT, true, false, 2>), grid, dim3(SMC_BLOCK), st, f->a);  \
+        else if (f->two_level && f->ragged == 2)                                              \
+            SMC_LAUNCH((k_propagate<KINDV, FKV, F_OPT, false, false, 2>), grid, dim3(SMC_BLOCK), st, f->a); \
         else if (f->two_level && f->a.par >= 0)                                               \
             SMC_LAUNCH((k_propagate<KINDV, FKV, F_OPT, true, false>), grid, dim3(SMC_BLOCK), st, f->a);  \
         else if (f->two_level)                                                                \
@@ -254,9 +259,11 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     const size_t nslots = a.hist == 1 ? T : (a.hist >= 2 ? (size_t)a.hist : 2);
     a.xslot = (i64)(M * N * dxm);
     a.lslot = (i64)(M * N);
-    const size_t oX0 = carve(nslots * M * N * dxm * 8);
-    const size_t oL0 = carve(nslots * M * N * 8);
-    const size_t oA = carve((a.hist ? nslots : 1) * M * N * 4);
+    // (+ one tile of padding each: the ragged last tile's loads are unconditional, k_propagate<RAGGED = 1>)
+    const size_t oX0 = carve(nslots * M * N * dxm * 8 + F_TILE * dxm * 8);
+    const size_t oL0 = carve(nslots * M * N * 8 + F_TILE * 8);
+    const size_t nA = (a.hist ? nslots : 1) * M * N + F_TILE;
+    const size_t oA = carve(nA * 4);
     // (published tile totals pay off only while every workgroup of the launch is resident)
     f->fused = (i64)a.ntiles * (i64)M <= F_DIRECT_PREFIX_MAX;
     if (getenv("SMC_FORCE_FUSED")) f->fused = a.ntiles <= F_DIRECT_PREFIX_MAX;   // experiments
@@ -304,7 +311,9 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     f->two_level_mid = f->two_level && (!f->fused || a.ntiles > 1024 || getenv("SMC_TWO_LEVEL_MID") ||
                                         o->scheme == SMC_MULTINOMIAL || apf2);
     const bool heavy_list = !mv && !getenv("SMC_NO_HEAVY");
-    f->ragged = f->two_level && (o->N % F_TILE) != 0;
+    // (history slots are written step by step: the lanes beyond N of a slot would read indices nobody
+    //  initialised -- every access tests its index there as well)
+    f->ragged = (f->two_level && (o->N % F_TILE) != 0) ? (((o->N & 1) || a.hist) ? 2 : 1) : 0;
     a.ncq = (i64)a.ntiles * F_TILE;
     const size_t oCq = carve(f->two_level ? M * (size_t)a.ncq * 8 : 8);
     const size_t oTq = carve(f->two_level ? M * a.ntiles * 8 : 8);
@@ -408,7 +417,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
         F_CREATE_CHECK(hipMemsetAsync(a.info2, 0, M * INFO_STRIDE * 8, st));
         F_CREATE_CHECK(hipStreamSynchronize(st));
     }
-    F_CREATE_CHECK(hipMemsetAsync(a.A, 0, M * N * 4, st));
+    F_CREATE_CHECK(hipMemsetAsync(a.A, 0, (M * N + F_TILE) * 4, st));     // (+ the padding tile: valid indices)
     std::vector<double> par_host(M * PARAM_STRIDE, 0.0);
     if (!mv) {       // the host's rows + the correctly rounded reciprocals smc_div_c works with
         for (size_t i = 0; i < M; ++i)

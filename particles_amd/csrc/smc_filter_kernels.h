@@ -1050,9 +1050,12 @@ __device__ __forceinline__ FOwn f_own(const int b, const int tid, const i64 N)
 }
 __device__ __forceinline__ i64 f_own_idx(const FOwn& o, const int k) { return (k < 2 ? o.na : o.nb) + (k & 1); }
 
-// RAGGED (tail-free launches only): N is not a multiple of the tile -- the last workgroup's threads
-// test their indices (everywhere else `full` is a compile-time constant: see the loads below)
-template <int KIND, int FK, int OPT, bool SPEC, bool TAIL = true, bool RAGGED = false>
+// RAGGED (tail-free launches only): N is not a multiple of the tile.  1: N even -- the LOADS stay
+// unconditional 16-byte accesses (X, lw and A are allocated with a tile of padding, the lanes beyond N
+// read a neighbour's valid entries and are masked afterwards), only the stores test their indices;
+// `full` remains a compile-time constant where it matters (see the loads below).  2: N odd -- pairs
+// would straddle the islands' boundaries: every access tests its index.
+template <int KIND, int FK, int OPT, bool SPEC, bool TAIL = true, int RAGGED = 0>
 __global__ void __launch_bounds__(SMC_BLOCK)
 k_propagate(const FArgs av)
 {
@@ -1066,7 +1069,8 @@ k_propagate(const FArgs av)
     double* info = a.info + (i64)isl * INFO_STRIDE;
     const i64 N = a.N;
     const FOwn own = f_own<!TAIL>(b, tid, N);
-    const bool full = (TAIL || RAGGED) ? own.full : true;   // (tail-free, N a multiple of the tile: every thread owns 4)
+    const bool full = (TAIL || RAGGED == 2) ? own.full : true;   // loads (tail-free: every thread reads 4)
+    const bool full_st = (TAIL || RAGGED) ? own.full : true;     // stores
     const double r0 = smc_ldg(info), r1 = smc_ldg(info + 1), r2 = smc_ldg(info + 2),
                  r5 = smc_ldg(info + 5);
     constexpr bool APF = FK == SMC_FK_APF;         // (tail-free two-level path only: see the tail)
@@ -1213,7 +1217,7 @@ k_propagate(const FArgs av)
             lw[k] = (f_own_idx(own, k) < N) ? l : -INFINITY;
             if (APF) xkeep[k] = xn[k];
         }
-        if (full) {
+        if (full_st) {
             if (a.nt) {
                 smc_st2g_nt(Xn + own.na, xn[0], xn[1]);
                 smc_st2g_nt(Xn + own.nb, xn[2], xn[3]);
@@ -1386,7 +1390,7 @@ __device__ __forceinline__ u64 f2_t52_div(const double x, const double dN)
     const double v = x / dN;
     return (v > 0.0) ? (u64)ceil(fmin(v, 2.0) * 4503599627370496.0) : 0ull;
 }
-__device__ inline i64 f2_nc_general(const u64 C, const double dN, const i64 N)
+__device__ __forceinline__ i64 f2_nc_general(const u64 C, const double dN, const i64 N)
 {
     const double z = (double)C * (dN * 0x1.0p-52);
     i64 g = (z >= dN) ? N : (i64)z;
@@ -1394,7 +1398,7 @@ __device__ inline i64 f2_nc_general(const u64 C, const double dN, const i64 N)
     while (g > 0 && f2_t52_div((double)g, dN) > C) --g;
     return g;
 }
-__device__ __attribute__((noinline)) i64 f2_count_general(const u64 C, const SmcSu& su)
+__device__ __forceinline__ i64 f2_count_general(const u64 C, const SmcSu& su)
 {
     const i64 nc = f2_nc_general(C, su.dM, su.M);
     if (nc >= su.M) return su.M;
@@ -1402,17 +1406,20 @@ __device__ __attribute__((noinline)) i64 f2_count_general(const u64 C, const Smc
     return nc + (f2_t52_div(un + (double)nc, su.dM) <= C ? 1 : 0);
 }
 // the same for a C known only to within +-E (E far below 2^52 / N): decided whenever neither nc nor
-// the comparison can change inside the band; -1 otherwise (cf. smc_count_pow2_band)
-__device__ __attribute__((noinline)) i64 f2_count_band_general(const u64 Ch, const u64 E, const SmcSu& su)
+// the comparison can change inside the band; -1 otherwise (cf. smc_count_pow2_band).
+// z = Ch N 2^-52 in fp64; B_n differs from n 2^52 / N by < 2 units of the
+// scale, z from its real value by < N 2^-52 -- so unless z lies within (E + 4) N 2^-52 of an integer,
+// nc = floor(z) for every C of the band and only T_nc (one division) is left to compare
+__device__ __forceinline__ i64 f2_count_band_general_fast(const u64 Ch, const u64 E, const SmcSu& su)
 {
-    const i64 N = su.M;
-    const i64 nc = f2_nc_general(Ch, su.dM, N);
-    if (nc >= N) return (f2_t52_div((double)N, su.dM) + E <= Ch) ? N : -1;
-    // nc must be the same for every C in [Ch - E, Ch + E]: B_nc + E <= Ch and B_{nc+1} > Ch + E
-    if (nc > 0 && f2_t52_div((double)nc, su.dM) + E > Ch) return -1;
-    if (f2_t52_div((double)(nc + 1), su.dM) <= Ch + E) return -1;
+    const double sN = su.dM * 0x1.0p-52;
+    const double z = (double)Ch * sN;
+    const double fz = floor(z);
+    const double d = z - fz, delta = (double)(E + 4ull) * sN;
+    if (!(d > delta && d < 1.0 - delta) || !(fz < su.dM)) return -1;
+    const i64 nc = (i64)fz;
     const double un = (su.scheme == SMC_SYSTEMATIC_) ? su.u_sys : smc_strat_u(su, (u64)nc);
-    const u64 T = f2_t52_div(un + (double)nc, su.dM);
+    const u64 T = f2_t52_div(un + fz, su.dM);
     if (T + E <= Ch) return nc + 1;
     if (T > Ch + E) return nc;
     return -1;
@@ -1451,7 +1458,26 @@ __device__ __forceinline__ i64 f2_ns_sys(const FArgs& a, const SmcSu& su, const 
         v = v > f.dN ? f.dN : v;
         return (i64)(u32)v;
     }
+    if (!POW2) return -1;                 // general N: resolved by f2_resolve_general (one copy of the code)
     return f2_count<POW2>(a, su, Us, f.Gb + smc_muldiv_floor(c, f.Qb, f.tb));
+}
+// general N: the counts the fast tests left open (bit i of `need`: position c_i), by the definition.
+// A loop that is NOT unrolled around the one inlined copy of the exact route: it runs for one parent
+// in 2^28 (systematic) and must cost the common path neither registers nor a call.
+__device__ __forceinline__ void f2_resolve_general(const SmcSu& su, unsigned need, const u64 Gb, const u64 Qb,
+                                                   const u64 tb, const u64 (&c)[7], i64 (&ns)[7])
+{
+#pragma unroll 1
+    for (int i = 0; i < 7; ++i) {
+        if (!((need >> i) & 1u)) continue;
+        u64 ci = c[0];
+#pragma unroll
+        for (int k = 1; k < 7; ++k) ci = (i == k) ? c[k] : ci;
+        const u64 pos = (ci == 0ull) ? 0ull : (ci >= tb ? Qb : smc_muldiv_floor(ci, Qb, tb));
+        const i64 v = f2_count_general(Gb + pos, su);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) ns[k] = (i == k) ? v : ns[k];
+    }
 }
 // ---- multinomial on the two-level path: the sorted uniforms sit in memory (the tape, or the
 // exponential spacings k_f_spacing_* left in a.su), thresholds T_n = ceil(su_n 2^52) on the
@@ -1526,9 +1552,21 @@ __device__ __forceinline__ void f2_first_offspring(const FArgs& a, const SmcSu& 
             qh = qh > Qb ? Qb : qh;
             i64 cnt = a.exact_counts ? -1
                     : (POW2 ? smc_count_pow2_band(Gb + qh, 1ull << 13, su, su.u_sys, Us, kq, N)
-                            : f2_count_band_general(Gb + qh, 1ull << 13, su));
-            if (cnt < 0) cnt = f2_count<POW2>(a, su, Us, Gb + smc_muldiv_floor(c, Qb, tb));
-            ns[i] = cnt;
+                            : f2_count_band_general_fast(Gb + qh, 1ull << 13, su));
+            if (cnt < 0 && POW2) cnt = f2_count<POW2>(a, su, Us, Gb + smc_muldiv_floor(c, Qb, tb));
+            ns[i] = cnt;                          // (general N: -1 = open, see f2_resolve_general)
+        }
+    }
+    if (!POW2) {
+        unsigned need = 0u;
+        u64 c7[7] = {cx[0], cx[1], cx[2], cx[3], cx[4], 0ull, 0ull};
+        i64 n7[7] = {ns[0], ns[1], ns[2], ns[3], ns[4], 0, 0};
+#pragma unroll
+        for (int i = 0; i <= F_IPT; ++i) need |= (ns[i] < 0) ? (1u << i) : 0u;
+        if (need) {
+            f2_resolve_general(su, need, Gb, Qb, tb, c7, n7);
+#pragma unroll
+            for (int i = 0; i <= F_IPT; ++i) ns[i] = n7[i];
         }
     }
 }
@@ -1949,6 +1987,20 @@ k_ancestors2(const FArgs av)
         }
         n_lo = (b == 0) ? 0 : f2_ns_sys<POW2>(a, su, Us, f, 0ull);
         n_hi = (b == a.ntiles - 1) ? N : f2_ns_sys<POW2>(a, su, Us, f, tb);
+        if (!POW2) {
+            unsigned need = (n_lo < 0 ? 32u : 0u) | (n_hi < 0 ? 64u : 0u);
+#pragma unroll
+            for (int i = 0; i <= F_IPT; ++i) need |= (ns[i] < 0) ? (1u << i) : 0u;
+            if (need) {
+                const u64 c7[7] = {cx[0], cx[1], cx[2], cx[3], cx[4], 0ull, tb};
+                i64 n7[7] = {ns[0], ns[1], ns[2], ns[3], ns[4], n_lo, n_hi};
+                f2_resolve_general(su, need, Gb, Qb, tb, c7, n7);
+#pragma unroll
+                for (int i = 0; i <= F_IPT; ++i) ns[i] = n7[i];
+                n_lo = n7[5];
+                n_hi = n7[6];
+            }
+        }
     } else {
         f2_first_offspring<POW2>(a, su, Us, cx, tb, Gb, Qb, jt, ns);
         __shared__ i64 s_n[2];

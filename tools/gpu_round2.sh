@@ -51,6 +51,17 @@ prof_r1)
   export SMC_ANC2_R1=1; PASSES="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" bash tools/gpu_profile.sh ${TAG}_c2_anc2r1 400 > $O/prof_c2_r1.txt 2>&1; unset SMC_ANC2_R1; tail -25 $O/prof_c2_r1.txt ;;
 prof_c5)
   EXTRA="--workload c5" bash tools/gpu_profile.sh ${TAG}_c5 100 > $O/prof_c5.txt 2>&1; tail -30 $O/prof_c5.txt ;;
+benchN)
+  for n in 100000 1000000 10000000; do timeout 300 python bench.py --N $n --steps 400 --warmup 50 --no-cpu-baseline > $O/bench_N$n.json 2>&1; done
+  for sc in stratified multinomial; do timeout 300 python bench.py --N 1000000 --scheme $sc --essrmin 1.0 --steps 400 --warmup 50 --no-cpu-baseline > $O/bench_N1000000_$sc.json 2>&1; done
+  for f in $O/bench_N*.json; do python - "$f" <<'PY'
+import json,sys
+try:
+    d=json.loads([l for l in open(sys.argv[1]) if l.startswith('{')][-1]); r=d.get('roofline',{})
+    print(sys.argv[1].split('/')[-1], 'ms/step %.5f'%d['ms_per_step'], 'G/s %.2f'%(d['value']/1e9), {k[-28:]:round(v['ms'],5) for k,v in r.get('per_kernel',{}).items()})
+except Exception as e: print(sys.argv[1], 'FAILED', e, open(sys.argv[1]).read()[-400:])
+PY
+  done ;;
 sweep)
   timeout 300 python tools/size_sweep.py > $O/size_sweep.txt 2>&1; cat $O/size_sweep.txt ;;
 fuzz)
@@ -83,7 +94,18 @@ d=json.loads([l for l in open(sys.argv[1].replace('.json','_flat.json')) if l.st
 print('   (flat path) ms/step %.5f'%d['ms_per_step'], 'G/s %.2f'%(d['value']/1e9), {k:round(v['ms'],5) for k,v in r.get('per_kernel',{}).items()})
 PY
   ;;
-prof_sweep)
+prof_benchN)
+  for n in 100000 1000000 10000000; do timeout 300 python bench.py --N $n --steps 400 --warmup 50 --no-cpu-baseline > $O/bench_N$n.json 2>&1; done
+  for sc in stratified multinomial; do timeout 300 python bench.py --N 1000000 --scheme $sc --essrmin 1.0 --steps 400 --warmup 50 --no-cpu-baseline > $O/bench_N1000000_$sc.json 2>&1; done
+  for f in $O/bench_N*.json; do python - "$f" <<'PY'
+import json,sys
+try:
+    d=json.loads([l for l in open(sys.argv[1]) if l.startswith('{')][-1]); r=d.get('roofline',{})
+    print(sys.argv[1].split('/')[-1], 'ms/step %.5f'%d['ms_per_step'], 'G/s %.2f'%(d['value']/1e9), {k[-28:]:round(v['ms'],5) for k,v in r.get('per_kernel',{}).items()})
+except Exception as e: print(sys.argv[1], 'FAILED', e, open(sys.argv[1]).read()[-400:])
+PY
+  done ;;
+sweep)
   timeout 300 python tools/size_sweep.py > $O/size_sweep.txt 2>&1; cat $O/size_sweep.txt ;;
 fuzz)
   timeout 900 python tools/fuzz_paths.py 150 11 > $O/fuzz.txt 2>&1; tail -4 $O/fuzz.txt ;;
