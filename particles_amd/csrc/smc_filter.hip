@@ -130,6 +130,11 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
         if (k_prof >= 0 && (k_prof % 3)) (void)hipEventRecord(f->ev[3 * k_prof + 1], st);
         launch_propagate(f);
         if (k_prof >= 0) (void)hipEventRecord(f->ev[3 * k_prof + 2], st);
+        if (f->a.mom) {      // device-side Moments: the row of the step just done (K, 1/s) first
+            SMC_LAUNCH(k_flush2, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
+            SMC_LAUNCH(k_f_moments_partials, dim3(f->a.nmb, f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
+            SMC_LAUNCH(k_f_moments_final, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
+        }
         return;
     }
     const bool fused = f->fused;
@@ -296,7 +301,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     // (multinomial: the counts are searches over the sorted uniforms -- the tape's, or the exponential
     //  spacings drawn between k_reduce2, which decides the step, and k_ancestors2)
     // (any N >= 2 tiles: N = 2^k counts in closed form with integers, other N with the general counts)
-    f->two_level = !mv && !o->moments && o->N <= ((int64_t)1 << 30) && a.ntiles >= 2 &&
+    f->two_level = !mv && !(o->moments && model->fk == SMC_FK_APF) && o->N <= ((int64_t)1 << 30) && a.ntiles >= 2 &&
                    !(a.log2N < 0 && getenv("SMC_POW2_ONLY")) &&
                    !getenv("SMC_FLAT_CDF") && !getenv("SMC_FORCE_FUSED") && !getenv("SMC_FORCE_UNFUSED") &&
                    !(o->scheme == SMC_MULTINOMIAL && getenv("SMC_FLAT_MULTINOMIAL"));
@@ -313,6 +318,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     const bool heavy_list = !mv && !getenv("SMC_NO_HEAVY");
     // (history slots are written step by step: the lanes beyond N of a slot would read indices nobody
     //  initialised -- every access tests its index there as well)
+    a.kform = f->two_level ? 1 : 0;
     f->ragged = (f->two_level && (o->N % F_TILE) != 0) ? (((o->N & 1) || a.hist) ? 2 : 1) : 0;
     a.ncq = (i64)a.ntiles * F_TILE;
     const size_t oCq = carve(f->two_level ? M * (size_t)a.ncq * 8 : 8);

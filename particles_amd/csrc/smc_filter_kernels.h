@@ -72,6 +72,8 @@ struct FArgs {
                            // stays resident); k >= 2: a ring of k slots (the k most recent steps)
     int par;               // t & 1 of the step this launch runs, or -1 (history slots): lets the
                            // kernels form their addresses before the step record has arrived
+    int kform;             // two-level step: the row's (K, 1/s) normalise weights kept as (p, k) pairs, and
+                           // the count of steps done lives in info2 (the side kernels: moments)
     i64 ncq;               // per-island stride of cq: ntiles x 1024 (the last tile may be ragged)
     double *pm2, *ps2, *pss2;   // APF on the two-level path: the tile partials of the PLAIN weights
                            // (pm/ps/pss, cq, tq then describe the AUXILIARY weights lw + logeta,
@@ -2328,9 +2330,9 @@ k_f_moments_partials(const FArgs av)
     const FArgs& a = av;
     __shared__ double sm[SMC_SM];
     const int b = (int)blockIdx.x, isl = (int)blockIdx.y;
-    const i64 t = (i64)smc_uniform(smc_ldg(a.info + (i64)isl * INFO_STRIDE)) - 1;     // step just done
+    const i64 t = (i64)smc_uniform(smc_ldg((a.kform ? a.info2 : a.info) + (i64)isl * INFO_STRIDE)) - 1;   // step just done
     if (t < 0 || t >= a.T) return;
-    const double* row = a.summ + ((i64)isl * (a.T + 1) + t) * SUMM_STRIDE;
+    const double* row = a.summ + ((i64)isl * (a.T + 1) + t) * SUMM_STRIDE;     // (two-level: k_flush2 ran first)
     const double m = smc_uniform(smc_ldg(row + 5)), rs = smc_uniform(smc_ldg(row + 6));
     const i64 N = a.N;
     const int d = a.dx;
@@ -2342,7 +2344,15 @@ k_f_moments_partials(const FArgs av)
         for (int k = 0; k < F_MOM_CHUNK / SMC_BLOCK; ++k) {
             const i64 i = base + (i64)k * SMC_BLOCK + threadIdx.x;
             if (i < N) {
-                const double w = f_weight(smc_ldg(lw + i), m, rs);
+                const double l = smc_ldg(lw + i);
+                double w;
+                if (a.kform) {                     // W = p 2^(k - K) / s, as k_f_write_W forms it
+                    double k;
+                    const double p = smc_expk(l, k);
+                    w = (l > -INFINITY) ? smc_scale_pk(p, k, m) * rs : 0.0;
+                } else {
+                    w = f_weight(l, m, rs);
+                }
                 const double x = smc_ldg(X + i * d + c);
                 a0 += w;
                 a1 += w * x;
@@ -2364,7 +2374,7 @@ k_f_moments_final(const FArgs av)
 {
     const FArgs& a = av;
     const int isl = (int)blockIdx.x;
-    const i64 t = (i64)smc_uniform(smc_ldg(a.info + (i64)isl * INFO_STRIDE)) - 1;
+    const i64 t = (i64)smc_uniform(smc_ldg((a.kform ? a.info2 : a.info) + (i64)isl * INFO_STRIDE)) - 1;
     if (t < 0 || t >= a.T) return;
     const int d = a.dx;
     __shared__ double sm[SMC_SM];
