@@ -62,6 +62,10 @@ try:
 except Exception as e: print(sys.argv[1], 'FAILED', e, open(sys.argv[1]).read()[-400:])
 PY
   done ;;
+robust)
+  (timeout 200 python tools/robustness.py > $O/robustness.txt 2>&1; echo "rc=$?" >> $O/robustness.txt); cat $O/robustness.txt
+  (timeout 200 python tools/soak.py > $O/soak.txt 2>&1; echo "rc=$?" >> $O/soak.txt); cat $O/soak.txt
+  (timeout 300 python tools/fuzz_paths.py 400 23 > $O/fuzz400.txt 2>&1; echo "rc=$?" >> $O/fuzz400.txt); tail -3 $O/fuzz400.txt ;;
 sweep)
   timeout 300 python tools/size_sweep.py > $O/size_sweep.txt 2>&1; cat $O/size_sweep.txt ;;
 fuzz)
@@ -105,6 +109,10 @@ try:
 except Exception as e: print(sys.argv[1], 'FAILED', e, open(sys.argv[1]).read()[-400:])
 PY
   done ;;
+robust)
+  (timeout 200 python tools/robustness.py > $O/robustness.txt 2>&1; echo "rc=$?" >> $O/robustness.txt); cat $O/robustness.txt
+  (timeout 200 python tools/soak.py > $O/soak.txt 2>&1; echo "rc=$?" >> $O/soak.txt); cat $O/soak.txt
+  (timeout 300 python tools/fuzz_paths.py 400 23 > $O/fuzz400.txt 2>&1; echo "rc=$?" >> $O/fuzz400.txt); tail -3 $O/fuzz400.txt ;;
 sweep)
   timeout 300 python tools/size_sweep.py > $O/size_sweep.txt 2>&1; cat $O/size_sweep.txt ;;
 fuzz)
