@@ -72,12 +72,6 @@ struct FArgs {
                            // stays resident); k >= 2: a ring of k slots (the k most recent steps)
     int par;               // t & 1 of the step this launch runs, or -1 (history slots): lets the
                            // kernels form their addresses before the step record has arrived
-    int kform;             // two-level step: the row's (K, 1/s) normalise weights kept as (p, k) pairs, and
-                           // the count of steps done lives in info2 (the side kernels: moments)
-    i64 ncq;               // per-island stride of cq: ntiles x 1024 (the last tile may be ragged)
-    double *pm2, *ps2, *pss2;   // APF on the two-level path: the tile partials of the PLAIN weights
-                           // (pm/ps/pss, cq, tq then describe the AUXILIARY weights lw + logeta,
-                           // which decide and drive the resampling -- core.py:307-313); else null
     i64 tk;                // the time index the HOST expects this launch to run (eager launches), or -1
                            // (inside a captured graph): work that depends on t only -- the step's
                            // normals -- starts on it while the step record is still on its way, and is
@@ -117,6 +111,15 @@ struct FArgs {
     int mv_chunks;         // 256-particle chunks per workgroup of k_propagate_mv
     const double* mvc;     // MVLINGAUSS: derived constants (see smc_filter_mv.h)
     u64* trace;            // SMC_TRACE builds: shader-clock stamps of the last step's workgroups
+    // (late additions live at the END of the block: k_propagate sits at the scalar-register limit, and
+    //  a field inserted among the ones it loads made the compiler spill SGPRs in its prologue -- an
+    //  early s_waitcnt on the kernarg loads, 0.3 us per launch; profiles/r03n A/B)
+    int kform;             // two-level step: the row's (K, 1/s) normalise weights kept as (p, k) pairs, and
+                           // the count of steps done lives in info2 (the side kernels: moments)
+    i64 ncq;               // per-island stride of cq: ntiles x 1024 (the last tile may be ragged)
+    double *pm2, *ps2, *pss2;   // APF on the two-level path: the tile partials of the PLAIN weights
+                           // (pm/ps/pss, cq, tq then describe the AUXILIARY weights lw + logeta,
+                           // which decide and drive the resampling -- core.py:307-313); else null
 };
 
 __host__ __device__ __forceinline__ i64 f_slot(const FArgs& a, i64 t)
@@ -1271,7 +1274,7 @@ k_propagate(const FArgs av)
             }
         }
         const F2Tile r = f2_tile_weights(lw, cx);
-        u64* cq = a.cq + (i64)isl * a.ncq;
+        u64* cq = a.cq + (i64)isl * (RAGGED ? a.ncq : N);          // (whole tiles: ncq == N, already in registers)
         if (a.nt) { smc_st2g_nt(cq + own.na, cx[0], cx[1]); smc_st2g_nt(cq + own.nb, cx[2], cx[3]); }
         else { smc_st2g(cq + own.na, cx[0], cx[1]); smc_st2g(cq + own.nb, cx[2], cx[3]); }
         if (tid == 0) {
@@ -1832,7 +1835,7 @@ k_ancestors2(const FArgs av)
         Qmid = smc_ldg(reinterpret_cast<const double*>(a.Q) + (i64)isl * a.ntiles + b);
     }
     // the tile's integer CDF: this thread's 4 positions and the next thread's first
-    const u64* cq = a.cq + (i64)isl * a.ncq;
+    const u64* cq = a.cq + (i64)isl * ((POW2 && !MULTI) ? N : a.ncq);     // (N = 2^k: whole tiles, ncq == N)
     u64 cx[F_IPT + 1];
     smc_ld2g(cq + jt, cx[0], cx[1]);
     smc_ld2g(cq + jt + 2, cx[2], cx[3]);

@@ -62,6 +62,22 @@ try:
 except Exception as e: print(sys.argv[1], 'FAILED', e, open(sys.argv[1]).read()[-400:])
 PY
   done ;;
+abold)
+  # same box, the r03b-state library against the current one (C2, K = 1000 and K = 20, twice each, interleaved)
+  for rep in 1 2; do for lib in R03B NEW; do
+    if [ $lib = R03B ]; then export SMC_HIP_LIBRARY=$R/particles_amd/lib/abl/libsmc_R03B.so; else unset SMC_HIP_LIBRARY; fi
+    timeout 300 python bench.py --steps 1000 --warmup 50 --no-cpu-baseline > $O/ab_${lib}_k1000_$rep.json 2>&1
+    timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/ab_${lib}_k20_$rep.json 2>&1
+    timeout 300 python bench.py --workload c5 --steps 200 --warmup 20 --no-cpu-baseline > $O/ab_${lib}_c5_$rep.json 2>&1
+  done; done; unset SMC_HIP_LIBRARY
+  for f in $O/ab_*.json; do python - "$f" <<'PY'
+import json,sys
+try:
+    d=json.loads([l for l in open(sys.argv[1]) if l.startswith('{')][-1]); r=d.get('roofline',{})
+    print(sys.argv[1].split('/')[-1], 'ms/step %.5f'%d['ms_per_step'], 'G/s %.2f'%(d['value']/1e9), {k[-20:]:round(v['ms'],5) for k,v in r.get('per_kernel',{}).items()})
+except Exception as e: print(sys.argv[1], 'FAILED', e, open(sys.argv[1]).read()[-300:])
+PY
+  done ;;
 robust)
   (timeout 200 python tools/robustness.py > $O/robustness.txt 2>&1; echo "rc=$?" >> $O/robustness.txt); cat $O/robustness.txt
   (timeout 200 python tools/soak.py > $O/soak.txt 2>&1; echo "rc=$?" >> $O/soak.txt); cat $O/soak.txt
@@ -107,6 +123,22 @@ try:
     d=json.loads([l for l in open(sys.argv[1]) if l.startswith('{')][-1]); r=d.get('roofline',{})
     print(sys.argv[1].split('/')[-1], 'ms/step %.5f'%d['ms_per_step'], 'G/s %.2f'%(d['value']/1e9), {k[-28:]:round(v['ms'],5) for k,v in r.get('per_kernel',{}).items()})
 except Exception as e: print(sys.argv[1], 'FAILED', e, open(sys.argv[1]).read()[-400:])
+PY
+  done ;;
+abold)
+  # same box, the r03b-state library against the current one (C2, K = 1000 and K = 20, twice each, interleaved)
+  for rep in 1 2; do for lib in R03B NEW; do
+    if [ $lib = R03B ]; then export SMC_HIP_LIBRARY=$R/particles_amd/lib/abl/libsmc_R03B.so; else unset SMC_HIP_LIBRARY; fi
+    timeout 300 python bench.py --steps 1000 --warmup 50 --no-cpu-baseline > $O/ab_${lib}_k1000_$rep.json 2>&1
+    timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/ab_${lib}_k20_$rep.json 2>&1
+    timeout 300 python bench.py --workload c5 --steps 200 --warmup 20 --no-cpu-baseline > $O/ab_${lib}_c5_$rep.json 2>&1
+  done; done; unset SMC_HIP_LIBRARY
+  for f in $O/ab_*.json; do python - "$f" <<'PY'
+import json,sys
+try:
+    d=json.loads([l for l in open(sys.argv[1]) if l.startswith('{')][-1]); r=d.get('roofline',{})
+    print(sys.argv[1].split('/')[-1], 'ms/step %.5f'%d['ms_per_step'], 'G/s %.2f'%(d['value']/1e9), {k[-20:]:round(v['ms'],5) for k,v in r.get('per_kernel',{}).items()})
+except Exception as e: print(sys.argv[1], 'FAILED', e, open(sys.argv[1]).read()[-300:])
 PY
   done ;;
 robust)
