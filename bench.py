@@ -287,6 +287,10 @@ def main():
             "logLt": [float(v) for v in np.atleast_1d(all_ll)][:16],
             "evidence_gather": grp.evidence_path if grp else "none",
             "evidence_gather_ms": gather_ms,
+            # the library's Group raises when RCCL cannot be initialised; bench.py opts into the host
+            # gather (SMC_ALLOW_HOST_GATHER, set above unless the caller exported 0) so that a scale
+            # line exists either way -- and says so here: rccl false = no collective touched xGMI
+            "rccl": bool(grp and grp.evidence_path == "rccl") if grp else None,
         }
         if grp:
             out["timing"]["note"] = (
