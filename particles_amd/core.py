@@ -175,15 +175,10 @@ class SMC:
         self._cache = {}
         self._summ_cache = None
         model = fk._device_model() if hasattr(fk, "_device_model") else None
-        if fk is not None and fk.isAPF:
-            # fused APF: the one-launch filter (N <= 1024) or the two-level step (N > 1024)
-            stock = getattr(fk, "_fk_kind", None) == _lib.FK_APF
-            no_mom = not (collect and collect != "off" and self._device_moments)
-            small = N <= 1024 and not (resampling == "multinomial" and replay is None)
-            rolling = isinstance(store_history, int) and not isinstance(store_history, bool) and store_history >= 2
-            two_level = 1024 < N <= (1 << 30) and not rolling
-            if not (stock and no_mom and (small or two_level)):
-                model = None                   # anything else: the operator path
+        if fk is not None and fk.isAPF and not self._apf_fusable(
+                fk, N, resampling, replay, store_history,
+                bool(collect and collect != "off" and self._device_moments)):
+            model = None                       # the operator path
         if qmc:                    # SQMC: the template-method step on device operators
             model = None
         self._fused = self._will_fuse(fk, qmc, resampling, model)
@@ -205,6 +200,16 @@ class SMC:
             self._wgts = rs.Weights()
             self.aux = None
             self._X = self._Xp = self._A = None
+
+    @staticmethod
+    def _apf_fusable(fk, N, resampling, replay, store_history, device_moments):
+        """Fused APF: the one-launch filter (N <= 1024; no Philox multinomial there) or the two-level
+        step (N > 1024; no rolling window); stock StochVol only, no device-side moments."""
+        stock = getattr(fk, "_fk_kind", None) == _lib.FK_APF
+        small = N <= 1024 and not (resampling == "multinomial" and replay is None)
+        rolling = isinstance(store_history, int) and not isinstance(store_history, bool) and store_history >= 2
+        two_level = 1024 < N <= (1 << 30) and not rolling
+        return stock and not device_moments and (small or two_level)
 
     @staticmethod
     def _will_fuse(fk, qmc=False, resampling="systematic", model=False):
@@ -654,7 +659,9 @@ def multiSMC(nruns=10, nprocs=0, out_func=None, collect=None, **args):
         fk = kw.get("fk")
         batch = (SMC._will_fuse(fk, kw.get("qmc", False), kw.get("resampling", "systematic"))
                  and not collect and not kw.get("store_history") and not kw.get("verbose")
-                 and kw.get("n_islands", 1) == 1)
+                 and kw.get("n_islands", 1) == 1
+                 and not (fk.isAPF and not SMC._apf_fusable(fk, kw.get("N", 100), kw.get("resampling", "systematic"),
+                                                            None, False, False)))
         if batch and out_func is not None:
             # islands of one filter; Philox island word = run index, key = first seed
             pf = SMC(collect="off", seed=int(run_seeds[0]), n_islands=nruns, **kw)

@@ -1548,6 +1548,13 @@ def check_apf_fused(golden, apf2_cases=((2048, "systematic", 0.7), (4096, "strat
             assert np.allclose(ps.hist.wgts[t].lw, o["hist"]["lw"][t], rtol=1e-11, atol=1e-11)
         with pytest.raises(Exception):
             pf.set_state(lw=np.zeros(N2))
+    # multiSMC: batched as islands where the APF is fused, run by run where it is not (Philox
+    # multinomial at N <= 1024 is not on the one-launch filter)
+    fk_apf = ssm.AuxiliaryPF(ssm=ssm.StochVol(), data=y[:15])
+    for kw in (dict(N=300), dict(N=300, resampling="multinomial"), dict(N=2048, resampling="multinomial")):
+        res = pa.multiSMC(fk=fk_apf, nruns=3, out_func=lambda pf: pf.logLt, **kw)
+        assert len(res) == 3 and all(np.isfinite(r["output"]) for r in res), kw
+        assert len({r["output"] for r in res}) == 3
     # Philox mode, several islands: the evidence estimate
     pf = pa.SMC(fk=ssm.AuxiliaryPF(ssm=ssm.StochVol(), data=y), N=apf2_cases[0][0], seed=5, n_islands=3, collect="off")
     assert pf._fused
