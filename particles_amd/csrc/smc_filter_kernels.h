@@ -440,12 +440,20 @@ k_f_spacing_sums(const FArgs av)
     u64* park = reinterpret_cast<u64*>(a.su + (i64)isl * a.N);
     u64 s = 0;
 #pragma unroll
-    for (int i = 0; i < F_IPT; ++i)
-        if (n0 + i <= a.N) {
-            const u64 q = f_spacing_q(a, (u32)t, (u32)(a.island_offset + isl), n0 + i);
-            if (n0 + i < a.N) park[n0 + i] = q;
-            s += q;
-        }
+    for (int i = 0; i < F_IPT; i += 2) {           // (n0 is a multiple of 4: draws 2p, 2p + 1 share a Philox call)
+        u64 x, y;
+        if (n0 + i <= a.N)
+            smc_philox((u32)((n0 + i) >> 1), (u32)t, (u32)(a.island_offset + isl), SMC_STREAM_SPACINGS, a.seed, x, y);
+        else
+            x = y = 0ull;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            if (n0 + i + h <= a.N) {
+                const u64 q = (u64)rint(-log(smc_u01_open(h ? y : x)) * a.spacing_scale);
+                if (n0 + i + h < a.N) park[n0 + i + h] = q;
+                s += q;
+            }
+    }
     s = smc_block_sum_u64(s, smu);
     if (threadIdx.x == 0) a.E[(i64)isl * (a.ntiles1 + 1) + b] = s;
 }

@@ -78,6 +78,11 @@ try:
 except Exception as e: print(sys.argv[1], 'FAILED', e, open(sys.argv[1]).read()[-300:])
 PY
   done ;;
+examples)
+  for e in examples/*.py; do echo "== $e"; (timeout 200 python $e 2>&1 | tail -6); done > $O/examples.txt 2>&1
+  echo "== sharded smc2, 2 ranks on this GPU (host gather opt-in)" >> $O/examples.txt
+  (SMC_ALLOW_HOST_GATHER=1 SMC_HIP_DEVICE=0 timeout 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29677 examples/smc2_toy.py 2>&1 | grep -v "^\*\|OMP_NUM" | tail -5) >> $O/examples.txt 2>&1
+  cat $O/examples.txt ;;
 robust)
   (timeout 200 python tools/robustness.py > $O/robustness.txt 2>&1; echo "rc=$?" >> $O/robustness.txt); cat $O/robustness.txt
   (timeout 200 python tools/soak.py > $O/soak.txt 2>&1; echo "rc=$?" >> $O/soak.txt); cat $O/soak.txt
@@ -141,6 +146,11 @@ try:
 except Exception as e: print(sys.argv[1], 'FAILED', e, open(sys.argv[1]).read()[-300:])
 PY
   done ;;
+examples)
+  for e in examples/*.py; do echo "== $e"; (timeout 200 python $e 2>&1 | tail -6); done > $O/examples.txt 2>&1
+  echo "== sharded smc2, 2 ranks on this GPU (host gather opt-in)" >> $O/examples.txt
+  (SMC_ALLOW_HOST_GATHER=1 SMC_HIP_DEVICE=0 timeout 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29677 examples/smc2_toy.py 2>&1 | grep -v "^\*\|OMP_NUM" | tail -5) >> $O/examples.txt 2>&1
+  cat $O/examples.txt ;;
 robust)
   (timeout 200 python tools/robustness.py > $O/robustness.txt 2>&1; echo "rc=$?" >> $O/robustness.txt); cat $O/robustness.txt
   (timeout 200 python tools/soak.py > $O/soak.txt 2>&1; echo "rc=$?" >> $O/soak.txt); cat $O/soak.txt
