@@ -1258,7 +1258,7 @@ k_propagate(const FArgs av)
     } else {
         // two-level path: the tile's partial and its integer CDF are all this launch owes;
         // k_ancestors2(t+1) -- every workgroup of it -- reduces the partials, so nobody waits for
-        // a last workgroup here (N = 2^k >= 2048: every tile is full)
+        // a last workgroup here (tiles are full, or RAGGED: -inf weights beyond N)
         u64 cx[4];
         if (APF) {
             // the partial of the PLAIN weights first (evidence, the logged ESS, W): pm2 / ps2 / pss2;
