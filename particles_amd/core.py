@@ -597,10 +597,35 @@ class SMC:
         host_coll = self._user_collectors and not (self._fused and self._device_moments)
         return self.verbose or host_hist or host_coll
 
+    def _run_to_save_times(self):
+        """``store_history=<callable>`` (PartialParticleHistory, smoothing.py:164-184) on the fused
+        path: the steps between two save times are enqueued in one call; the host synchronises --
+        and copies X and the weights, which the history has to own anyway -- only AT the save times."""
+        T, first = self.fk.T, self.t
+        while self.t < T:
+            nxt = next((u for u in range(self.t, T) if self.hist.is_save_time(u)), None)
+            self.step_async((T if nxt is None else nxt + 1) - self.t)
+            if nxt is not None:
+                self.hist.X[nxt] = self.X
+                self.hist.wgts[nxt] = collectors._frozen_weights(self.wgts)
+        self.sync()
+        if self.summaries and self.t > first:
+            s = self._summ()[0]
+            self.summaries._extend_defaults(s[first:, 0], s[first:, 3], s[first:, 4] != 0)
+            if self._device_moments:
+                self.summaries._extend_moments(self._moments()[first:])
+        if self._n:
+            s = self._summ()[0, -1]
+            self.rs_flag, self.loglt = bool(s[4]), float(s[2])
+
     def run(self):
         """Run until completion (core.py:391-409); sets ``cpu_time``."""
         t0 = time.perf_counter()
-        if self._fused and not self._needs_per_step_host():
+        partial = (self._fused and isinstance(self.hist, collectors.PartialParticleHistory)
+                   and not self.verbose and not (self._user_collectors and not self._device_moments))
+        if partial:
+            self._run_to_save_times()
+        elif self._fused and not self._needs_per_step_host():
             first = self.t
             self.step_async(self.fk.T - self.t)
             self.sync()

@@ -1098,6 +1098,34 @@ def _lib_field_x():
     return _lib.FIELD_X
 
 
+def check_partial_history(N=3000, T=23):
+    """``store_history=<callable>`` (PartialParticleHistory, smoothing.py:164-184) on the fused path:
+    the run synchronises at the save times only; what it saves is what a run with the whole history
+    holds at those times (same seed: same run), keys as in the reference (the saved t)."""
+    rng = np.random.RandomState(2)
+    y = [np.array([v]) for v in np.cumsum(rng.standard_normal(T))]
+    fk = lambda: ssm.Bootstrap(ssm=kalman.LinearGauss(rho=0.9, sigmaX=1.0, sigmaY=1.2), data=y)
+    save = lambda t: t % 7 == 3 or t == T - 1
+    full = pa.SMC(fk=fk(), N=N, seed=5, store_history=True)
+    full.run()
+    calls = []
+    part = pa.SMC(fk=fk(), N=N, seed=5, store_history=lambda t: (calls.append(t), save(t))[1])
+    part.run()
+    assert part._fused and sorted(part.hist.X) == [t for t in range(T) if save(t)] == sorted(part.hist.wgts)
+    for t in part.hist.X:
+        assert np.array_equal(part.hist.X[t], full.hist.X[t])
+        assert np.array_equal(part.hist.wgts[t].lw, full.hist.wgts[t].lw)
+        assert abs(part.hist.wgts[t].ESS - full.hist.wgts[t].ESS) < 1e-9 * N
+    assert part.logLt == full.logLt and part.summaries.logLts == full.summaries.logLts
+    assert part.summaries.rs_flags == full.summaries.rs_flags
+    # stepping by hand keeps the reference's per-step save
+    byhand = pa.SMC(fk=fk(), N=N, seed=5, store_history=save)
+    for _ in byhand:
+        pass
+    assert sorted(byhand.hist.X) == sorted(part.hist.X)
+    assert all(np.array_equal(byhand.hist.X[t], part.hist.X[t]) for t in part.hist.X)
+
+
 def check_rolling_history(N=3000, T=23, ks=(2, 5, 9)):
     """store_history=k (RollingParticleHistory, smoothing.py:186-219) on the fused path: a ring of
     k slots in HBM.  Same run as with the whole history resident -- final state, summaries -- and

@@ -247,6 +247,10 @@ def test_smc2_device_theta_level():
     pc.check_smc2(Ntheta=32, Nx=64, big_Nx=(2048,), big_N=4, big_T=6)
 
 
+def test_partial_history_syncs_at_save_times_only():
+    pc.check_partial_history(N=1500, T=16)
+
+
 def test_rolling_history_on_device():
     pc.check_rolling_history(N=1500, T=14, ks=(2, 5))
 

@@ -458,6 +458,10 @@ def test_smc2_device_theta_level():
     pc.check_smc2(Ntheta=256, Nx=512, T=60, big_Nx=(2048, 3000))
 
 
+def test_partial_history_syncs_at_save_times_only():
+    pc.check_partial_history(N=100000, T=40)
+
+
 def test_rolling_history_on_device():
     pc.check_rolling_history()
     pc.check_rolling_history(N=1 << 17, T=12, ks=(3,))
