@@ -931,12 +931,12 @@ def check_graph_replay_matches_direct(golden, N=5000):
     assert np.array_equal(s, b._summ()[0])
 
 
-def check_normals_on_host_t(golden, monkeypatch, sizes=(5000, 4096)):
+def check_normals_on_host_t(golden, monkeypatch, sizes=(5000, 4096), T=40):
     """k_propagate starts the step's normals on the time index the host passes with the launch
     (FArgs::tk) and falls back to the device record's t: with the feature off (SMC_NO_TK=1) the run
     is the same run -- flat path (N = 5000) and two-level path (N = 4096), adaptive resampling."""
     g = golden("kalman_toy")
-    y = [np.atleast_1d(v) for v in np.squeeze(g["y"])][:40]
+    y = [np.atleast_1d(v) for v in np.squeeze(g["y"])][:T]
     for N in sizes:
         runs = []
         for off in (False, True):
@@ -949,7 +949,7 @@ def check_normals_on_host_t(golden, monkeypatch, sizes=(5000, 4096)):
             runs.append((pf.logLts_islands.copy(), pf._get(_lib.FIELD_X, 1).copy(), pf._summ().copy()))
             monkeypatch.delenv("SMC_NO_TK", raising=False)
         assert all(np.array_equal(u, v) for u, v in zip(*runs)), N
-        assert 0 < runs[0][2][0, :, 4].sum() < 39
+        assert 0 < runs[0][2][0, :, 4].sum() < T - 1
 
 
 def check_unfused_path(golden, monkeypatch):
@@ -1302,7 +1302,7 @@ def check_permute_islands(N, golden, tol=0.3, T=40, t0=15):
     for k, src in enumerate([2, 2, 0]):          # and each goes on under the theta it inherited
         full, _ = orc.kalman_loglik(orc.ToySSM(sig[src]), y)
         head, _ = orc.kalman_loglik(orc.ToySSM(sig[src]), y[:t0])
-        assert abs((ll[k] - before[src]) - (full - head)) < 0.3, (k, ll[k] - before[src], full - head)
+        assert abs((ll[k] - before[src]) - (full - head)) < max(0.3, tol), (k, ll[k] - before[src], full - head)
     with pytest.raises(ValueError):
         b.permute_islands([0, 1])
     # PMCMC move: islands accepted from a second batch run on other thetas
@@ -1742,7 +1742,7 @@ def check_indep_prod(golden):
 
 
 def check_sqmc(golden, monkeypatch, philox_N=4096, philox_runs=4, philox_T=40, sorted_N=(1, 2, 64, 1024, 1 << 14),
-               ab_N=2048, both_modes_for_all=True):
+               ab_N=2048, both_modes_for_all=True, replay_cases=None):
     """SQMC (SMC(qmc=True), core.py:315-349) on device operators: the reference's runs on its
     recorded Sobol' points; then the operators themselves (Sobol' generator vs scipy's, ndtri
     vs scipy's, argsort vs numpy's) and a run on device-generated points against Kalman."""
@@ -1753,6 +1753,8 @@ def check_sqmc(golden, monkeypatch, philox_N=4096, philox_runs=4, philox_T=40, s
              ("sqmc_mv2", lambda: kalman.MVLinearGauss_Guarniero_etal(alpha=0.4, dx=2), ssm.Bootstrap),
              ("sqmc_mv3_guided", lambda: kalman.MVLinearGauss_Guarniero_etal(alpha=0.4, dx=3), ssm.GuidedPF)]
     for case, mk, cls in cases:
+        if replay_cases is not None and case not in replay_cases:
+            continue
         g = golden(case)
         y = list(g["y"])
         for resident in ((False, True) if both_modes_for_all or case == "sqmc_mv2" else (True,)):
