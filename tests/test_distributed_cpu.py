@@ -207,3 +207,32 @@ def test_sharded_smc2_is_world_invariant(tmp_path):
     e1 = _run_smc2_world(1, tmp_path, SMC_TEST_AR="1.01", SMC_TEST_T="8")
     e2 = _run_smc2_world(2, tmp_path, SMC_TEST_AR="1.01", SMC_TEST_T="8")
     assert e1["Nx"] == 256 and all(e1[k] == e2[k] for k in ("lw", "theta", "logLt", "ESSs", "Nx"))
+
+
+def test_bench_two_ranks_launch_line(tmp_path):
+    """The driver's N = 2 launch line of bench.py, through the emulator (both ranks on 'device' 0):
+    the N > 1 path -- rendezvous, island offsets per rank, max-over-ranks timing, the separately timed
+    evidence gather, the labelled host fallback -- must produce the one JSON line with its contract keys."""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    env = dict(os.environ, SMC_TEST_EMULATOR="1", SMC_HIP_LIBRARY=build_emu.build(), SMC_BENCH_NGPU="1",
+               MASTER_ADDR="127.0.0.1")
+    env.pop("SMC_ALLOW_HOST_GATHER", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "3", "--warmup", "1", "--log2N", "11", "--reps", "2",
+           "--no-cpu-baseline", "--no-profile"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+              "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["rccl"] is False and d["evidence_gather"].startswith("host-fallback")
+    assert len(d["logLt"]) == 2 and d["logLt"][0] != d["logLt"][1]      # one filter per rank, distinct streams
+    assert d["evidence_gather_ms"] is not None and "timing" in d and "note" in d["timing"]
+    assert "RCCL unavailable" in p.stderr
