@@ -1163,6 +1163,15 @@ def philox_normals(seed, n, t, island=0):
     return np.stack([z0, z1], axis=1).reshape(-1)[:n]
 
 
+def philox_normals_mv(seed, n, d, t, island=0):
+    """(n, d) normals of step t of a multivariate filter: pair kp of particle i is Philox index
+    i * ceil(d/2) + kp and yields the dimensions 2kp, 2kp + 1 (smc_filter_mv.h)."""
+    hp = (d + 1) // 2
+    idx = (np.arange(n, dtype=np.uint64)[:, None] * np.uint64(hp) + np.arange(hp, dtype=np.uint64)[None, :])
+    z0, z1 = philox_normal_pair(seed, idx & _M32, t, island)
+    return np.stack([z0, z1], axis=2).reshape(n, 2 * hp)[:, :d]
+
+
 def philox_resample_uniforms(seed, scheme, M, t, island=0):
     """The uniforms the HIP path feeds to a scheme in production mode."""
     if scheme == "systematic":

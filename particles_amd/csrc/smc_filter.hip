@@ -279,9 +279,15 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     // mv_chunks chunks of 256 particles (2 workgroups per CU when N allows)
     a.mv_chunks = 1;
     if (mv) {
+        // 8 by default, halved until the grid has at least 512 workgroups; SMC_MV_CHUNKS=1|2|4|8
+        // (tests) is taken as given, so that the multi-chunk prefetch loop is audited at small N too
         const char* e = getenv("SMC_MV_CHUNKS");
-        a.mv_chunks = e ? atoi(e) : 8;
-        while (a.mv_chunks > 1 && (i64)N / (SMC_BLOCK * a.mv_chunks) < 512) a.mv_chunks >>= 1;
+        const int forced = e ? atoi(e) : 0;
+        if (forced == 1 || forced == 2 || forced == 4 || forced == 8) a.mv_chunks = forced;
+        else {
+            a.mv_chunks = 8;
+            while (a.mv_chunks > 1 && (i64)N / (SMC_BLOCK * a.mv_chunks) < 512) a.mv_chunks >>= 1;
+        }
     }
     const i64 per_wg = mv ? (i64)SMC_BLOCK * a.mv_chunks : (i64)SMC_BLOCK * F_OPT;
     a.nparts = (int)((o->N + per_wg - 1) / per_wg);
@@ -1178,6 +1184,7 @@ int smc_filter_describe(smc_filter* f, char* out, size_t n)
         else s = "k_prepare+k_ancestors";
         if (f->a.scheme == SMC_MULTINOMIAL && !f->a.ut) s = "k_f_spacing_sums+k_f_spacing_scan+k_f_spacing_write+" + s;
         s += mv ? (f->mv_collapsed ? "+k_propagate_mv<collapsed>" : "+k_propagate_mv") : "+k_propagate";
+        if (mv) s += " [mv_chunks=" + std::to_string(f->a.mv_chunks) + "]";
         if (f->a.mom) s += "+k_f_moments_partials+k_f_moments_final";
     }
     snprintf(out, n, "%s", s.c_str());

@@ -528,7 +528,7 @@ def audit_history(pf, mk_orc, fk, y, scheme, ESSrmin, z=None, u=None, exact=True
         elif d == 1:
             zt = orc.philox_normals(pf.seed, N, t, island)
         else:
-            zt = None
+            zt = orc.philox_normals_mv(pf.seed, N, d, t, island)
         if zt is not None:
             Xo, inc = orc.propagate(model, fk, t, np.asarray(y[t]), Xp, zt, ctx)
             lwo = inc if (t == 0 or rs_flag) else lw_prev + inc

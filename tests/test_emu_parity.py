@@ -111,6 +111,23 @@ def test_filter_replay(golden, case, model, fk):
     pc.check_filter_replay(golden, case, model, fk, T=12 if model.startswith("mv") else 25)
 
 
+@pytest.mark.parametrize("chunks,N", [(2, 300), (4, 1100), (8, 1300)])
+def test_mv_multi_chunk_loop(golden, monkeypatch, chunks, N):
+    """k_propagate_mv walks `mv_chunks` chunks of 256 particles per workgroup, rows requested one
+    iteration ahead and ancestor words two ahead; production picks 2 / 4 / 8 chunks only from
+    N = 2^18 on (C4 runs 8), so the loop is forced here (SMC_MV_CHUNKS) and every particle of
+    every step is audited against the oracle: whole and partial chunks, chunks wholly beyond N,
+    more than one workgroup; guided, bootstrap and the collapsed weight."""
+    monkeypatch.setenv("SMC_MV_CHUNKS", str(chunks))
+    pf, _ = pc.check_filter_replay(golden, "mv32_guided", "mv32", "guided", T=4, N=N)
+    assert "[mv_chunks=%d]" % chunks in pc.describe(pf)
+    pf, _ = pc.check_filter_replay(golden, "mv4_boot", "mv4", "bootstrap", T=4, N=N + 1)
+    assert "[mv_chunks=%d]" % chunks in pc.describe(pf)
+    mk_dev, mk_orc = pc.MODELS["mv32"]
+    pc.check_oracle_at_size("mv32", mk_dev, mk_orc, N, 3, "systematic", 1.0, fk="guided", d=32, replay=False)
+    pc.check_mv_collapsed(N, 32, T=3)
+
+
 def test_mv_philox_kalman():
     pc.check_mv_kalman(2048, 4, "guided")
     pc.check_mv_kalman(1000, 6, "guided", scheme="stratified")

@@ -283,6 +283,26 @@ def test_c4_oracle_d32():
     pc.check_oracle_at_size("mv32", mk_dev, mk_orc, 1 << 17, 3, "systematic", 1.0, fk="bootstrap", d=32)
 
 
+@pytest.mark.parametrize("log2N,chunks", [(18, 2), (19, 4), (20, 8)])
+def test_c4_oracle_d32_every_chunk_count(log2N, chunks):
+    """C4 as it is benchmarked: N = 2^20 runs k_propagate_mv with 8 chunks of 256 particles per
+    workgroup (2^18: 2, 2^19: 4) -- a different prefetch loop from the single chunk of N <= 2^17.
+    Every particle of every step against the oracle (kalman.py:339-356, distributions.py:931-969):
+    guided and bootstrap on replayed numpy draws, guided on the production Philox streams (the
+    oracle restates the (particle, pair) -> counter layout), and the collapsed weight."""
+    mk_dev, mk_orc = pc.MODELS["mv32"]
+    N = 1 << log2N
+    import particles_amd as pa
+    from particles_amd import kalman, state_space_models as ssm
+    y = [np.zeros((1, 32))] * 2
+    probe = pa.SMC(fk=ssm.GuidedPF(ssm=kalman.MVLinearGauss_Guarniero_etal(alpha=0.4, dx=32), data=y), N=N)
+    assert "[mv_chunks=%d]" % chunks in pc.describe(probe)          # what production picks at this N
+    pc.check_oracle_at_size("mv32", mk_dev, mk_orc, N, 3, "systematic", 1.0, fk="guided", d=32)
+    pc.check_oracle_at_size("mv32", mk_dev, mk_orc, N, 3, "systematic", 1.0, fk="bootstrap", d=32)
+    pc.check_oracle_at_size("mv32", mk_dev, mk_orc, N, 3, "systematic", 1.0, fk="guided", d=32, replay=False)
+    pc.check_mv_collapsed(N, 32, T=3)
+
+
 def test_mv_collapsed_proposal():
     pc.check_mv_collapsed(1 << 14, 4)
     pc.check_mv_collapsed(1 << 17, 32)
