@@ -10,9 +10,11 @@ resampling, ESSrmin = 0.5 -- on N GPUs of one node.
 A "step" is one time step of the filter (resample decision, resampling,
 propagation, weighting, evidence increment) over all N particles of the rank's
 filter.  One process per GPU; each rank runs an independent filter on the same
-data with its own Philox island id (weak scaling: total work = n_gpus * N * K);
-the per-rank log-evidences are gathered with RCCL (smc_comm_*) inside the timed
-region.  Inputs are resident in HBM before the timed region starts.
+data with its own Philox island id (weak scaling: total work = n_gpus * N * K).
+The path has NO data-path collective, so the timed region contains none: the one
+collective of the path -- the all-gather of the per-island log-evidences over RCCL
+(smc_comm_*), once per RUN of T steps -- is timed on its own and reported beside the
+value (`evidence_gather_ms`).  Inputs are resident in HBM before the timed region starts.
 
 The timed region of exactly K steps (barrier + device sync on both sides) is repeated R times
 on consecutive stretches of the same run (R such that about 10^4 steps are timed in all);
@@ -20,22 +22,27 @@ on consecutive stretches of the same run (R such that about 10^4 steps are timed
 K = 20 region lasts half a millisecond and a single shot of it is noise.
 
 Rank 0 prints ONE JSON line (see README / task contract), including
-  roofline      -- the longer of the step's two kernels (resampling: k_ancestors2 /
-                   k_ancestors; propagate: k_propagate): algorithmic bytes per launch over
-                   its average duration, BOTH measured with HIP events on the filter's stream
-                   (smc_filter_kernel_ms), against the 8 TB/s HBM peak of MI355X;
-  cpu_baseline  -- N=1, rank 0: the reference itself (nchopin/particles, pf.cpu_time) when it is
-                   importable (build container), else the NumPy restatement of its path
-                   (oracle/, "port") timed on this host's cores on a bounded sample, with the
-                   reference's own figures from profiles/cpu_reference.json printed beside it.
+  roofline        -- the longer of the step's two kernels (resampling: k_ancestors2 /
+                     k_ancestors; propagate: k_propagate): algorithmic bytes per launch over
+                     its average duration, BOTH measured with HIP events on the filter's stream
+                     (smc_filter_kernel_ms), against the 8 TB/s HBM peak of MI355X;
+  cpu_baseline    -- N=1, rank 0: the CPU path on THIS host's cores (nproc stated): one core and
+                     all cores (independent runs over worker processes, the shape of
+                     multiSMC(nruns, nprocs=nproc), core.py:431 / utils.py:158-186).  kind =
+                     "reference" when nchopin/particles is importable from /root/reference (build
+                     container: its own pf.cpu_time), else "port": the NumPy restatement of its path
+                     (oracle/), with the reference's figures from profiles/cpu_reference.json beside it;
+  other_workloads -- N=1, default workload only: one bounded measurement of each of the other
+                     BASELINE.json configs (C3 x three schemes, C4, C4 collapsed weight, C5) with
+                     value, ms_per_step, step_frac and the dominant kernel's roofline fraction.
 
-Other BASELINE.json configs: --workload c3 (StochVol N=2^22; --scheme), c4 (d=32 guided),
-c5 (32 islands x 2^18 per GPU; `--workload c5 --gpus 8` is the 256-island SCALE run, evidence
-all-gather over RCCL inside the timed region).
+A single BASELINE.json config as the headline of the line: --workload c3 (StochVol N=2^22; --scheme),
+c4 (d=32 guided), c5 (32 islands x 2^18 per GPU; `--workload c5 --gpus 8` is the 256-island run).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -45,10 +52,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-BYTES_STEP = 56.0                # 16*d + 40 B per particle-step, d = 1
-BYTES_MOVE = 32.0                # k_propagate: read A, gather X; write X, lw
+FP64_PEAK_TF = 78.6              # dense fp64 matrix (= vector) peak
 BYTES_PREPARE = 16.0             # k_ancestors: read lw, write A  (beyond 2048 workgroups per launch
                                  # k_prepare reads lw once more for the tile totals: + 8 B)
+REFERENCE_DIR = "/root/reference"
 
 
 def synthetic_data(T, sigma=0.2, seed=42):
@@ -82,14 +89,84 @@ def measured_traffic(a, kernel):
     return None
 
 
-def cpu_baseline(y, N, nsteps):
-    """CPU leg beside the GPU number.  With /root/reference importable (build container) the
-    reference itself, timed by its own pf.cpu_time (utils.py:81-89, core.py:391); on the GPU box
-    the oracle's restatement of that path ("port": same NumPy calls, C inverse_cdf), plus the
-    reference's figures measured in the build container (profiles/cpu_reference.json)."""
-    import subprocess
-    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True,
-                   stdout=subprocess.DEVNULL)
+# ----------------------------------------------------------------------------------------------
+# CPU baseline
+# ----------------------------------------------------------------------------------------------
+def host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def reference_available():
+    return os.path.isdir(os.path.join(REFERENCE_DIR, "particles"))
+
+
+def _cpu_worker(kind, N, nsteps, nruns, start_at):
+    """One worker PROCESS of the CPU baseline (bench.py --cpu-worker ...): `nruns` independent
+    bootstrap filters of N particles over the first `nsteps` observations, one after the other,
+    on one core.  Prints {"t0", "t1", "seconds", "logLt"}; the parent aggregates."""
+    for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ[k] = "1"
+    if kind == "reference":
+        sys.dont_write_bytecode = True
+        import tools.cpu_reference as cr            # numba shim + compiled inverse_cdf + /root/reference
+        model = cr.ToySSM(sigma=0.2)
+        np.random.seed(42)
+        x, y = model.simulate(nsteps)
+
+        def one(seed):
+            np.random.seed(seed)
+            pf = cr.particles.SMC(fk=cr.ssm.Bootstrap(ssm=model, data=y), N=N, resampling="systematic",
+                                  ESSrmin=0.5, collect="off")
+            pf.run()
+            return pf.cpu_time, float(pf.logLt)       # the reference's own timer (utils.py:81-89)
+    else:
+        from oracle import smc_oracle as orc
+        y = synthetic_data(nsteps)
+
+        def one(seed):
+            np.random.seed(seed)
+            t0 = time.perf_counter()
+            out = orc.run_filter(orc.ToySSM(0.2), y[:nsteps], N, "systematic", 0.5)
+            return time.perf_counter() - t0, float(out["final_logLt"])
+    while time.time() < start_at:
+        time.sleep(0.005)
+    t0 = time.time()
+    secs, lls = 0.0, []
+    for r in range(nruns):
+        s, ll = one(123 + r)
+        secs += s
+        lls.append(ll)
+    print(json.dumps({"t0": t0, "t1": time.time(), "seconds": secs, "logLt": lls}), flush=True)
+
+
+def _spawn_workers(kind, N, nsteps, runs_per_worker, nworkers, lead_s):
+    start_at = time.time() + lead_s
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-worker", kind, str(N), str(nsteps),
+           str(runs_per_worker), repr(start_at)]
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env)
+             for _ in range(nworkers)]
+    outs = []
+    for p in procs:
+        so, se = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("cpu worker failed: " + se[-1500:])
+        outs.append(json.loads(so.strip().splitlines()[-1]))
+    return outs
+
+
+def cpu_baseline(N, nsteps, all_cores=True, kind=None):
+    """CPU legs beside the GPU number, on this host's cores.
+    kind "reference": nchopin/particles itself (importable only where /root/reference exists: the
+    build container), timed by its own pf.cpu_time, `inverse_cdf` bound to its gcc -O2 restatement
+    (numba is absent); kind "port": oracle.run_filter, the NumPy restatement of that path."""
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, stdout=subprocess.DEVNULL)
+    if kind is None:
+        kind = "reference" if reference_available() else "port"
+    nproc = host_cores()
     ref_file = os.path.join(ROOT, "profiles", "cpu_reference.json")
     committed = None
     if os.path.exists(ref_file):
@@ -98,41 +175,231 @@ def cpu_baseline(y, N, nsteps):
         committed = {"host": rec["host"], "source": "profiles/cpu_reference.json (tools/cpu_reference.py)",
                      "legs": {k: {"particle_steps_per_s": v["particle_steps_per_s"], "cores": v["cores"]}
                               for k, v in rec["legs"].items()}}
-    sample = ("N=2^%d, first %d steps of the same data (np.random.seed(42); simulate), run seed 123; "
-              "cost per step is flat in T" % (int(np.log2(N)), nsteps))
-    if os.path.isdir("/root/reference/particles"):
-        code = ("import sys, json; sys.dont_write_bytecode = True\n"
-                "sys.path.insert(0, %r)\n"
-                "import numpy as np, tools.cpu_reference as cr\n"
-                "m = cr.ToySSM(sigma=0.2); np.random.seed(42); x, y = m.simulate(%d)\n"
-                "med, allt, ll = cr.time_run(m, y, %d, reps=1)\n"
-                "print(json.dumps({'s': med, 'll': float(ll)}))\n"
-                % (ROOT, nsteps, N))
-        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT)
-        if r.returncode == 0:
-            o = json.loads(r.stdout.strip().splitlines()[-1])
-            return {"value": N * nsteps / o["s"], "unit": "particle-steps/s", "cores": 1,
-                    "kind": "reference", "seconds": o["s"], "logLt": o["ll"],
-                    "sample": "particles.SMC(...).run(), pf.cpu_time; inverse_cdf bound to its gcc -O2 "
-                              "restatement (numba absent); " + sample,
-                    "reference_build_container": committed}
-    from oracle import smc_oracle as orc
-    np.random.seed(123)
-    t0 = time.perf_counter()
-    out = orc.run_filter(orc.ToySSM(0.2), y[:nsteps], N, "systematic", 0.5)
-    dt = time.perf_counter() - t0
-    return {"value": N * nsteps / dt, "unit": "particle-steps/s", "cores": 1, "kind": "port",
-            "sample": "oracle.run_filter (NumPy restatement of particles.SMC + C inverse_cdf); " + sample,
-            "seconds": dt, "logLt": out["final_logLt"],
-            "reference_build_container": committed}
+    what = ("particles.SMC(...).run(), pf.cpu_time; inverse_cdf bound to its gcc -O2 restatement (numba absent)"
+            if kind == "reference" else
+            "oracle.run_filter (NumPy restatement of particles.SMC + C inverse_cdf)")
+    sample = ("%s; N=2^%d, first %d steps of the same data (np.random.seed(42); simulate), run seed 123; "
+              "cost per step is flat in T" % (what, int(np.log2(N)), nsteps))
+    one = _spawn_workers(kind, N, nsteps, 1, 1, 0.0)[0]
+    out = {"value": N * nsteps / one["seconds"], "unit": "particle-steps/s", "cores": 1, "kind": kind,
+           "sample": sample, "seconds": one["seconds"], "logLt": one["logLt"][0],
+           "host": {"nproc": nproc, "cpu": _cpu_name()},
+           "reference_build_container": committed}
+    if all_cores and nproc > 1:
+        # independent runs over worker processes: what multiSMC(nruns, nprocs=nproc) does (core.py:431,
+        # utils.py:158-186); one run of N = 2^18, 20 steps per core (BASELINE.md section 3's shape), at
+        # least 16 runs in all; workers start together after their imports
+        Na, Ta = min(N, 1 << 18), min(nsteps, 20)
+        per = max(1, -(-16 // nproc))
+        ws = _spawn_workers(kind, Na, Ta, per, nproc, 4.0 + 0.02 * nproc)
+        wall = max(w["t1"] for w in ws) - min(w["t0"] for w in ws)
+        out["all_cores"] = {
+            "value": nproc * per * Na * Ta / wall, "unit": "particle-steps/s", "cores": nproc, "kind": kind,
+            "seconds": wall, "runs": nproc * per,
+            "sample": "%d independent runs of (N=2^%d, %d steps) over %d worker processes, one per core "
+                      "(multiSMC(nruns=%d, nprocs=%d) shape); wall = last end - first start"
+                      % (nproc * per, int(np.log2(Na)), Ta, nproc, nproc * per, nproc),
+            "logLt_sd": float(np.std([l for w in ws for l in w["logLt"]]))}
+    return out
+
+
+def _cpu_name():
+    try:
+        return open("/proc/cpuinfo").read().split("model name")[1].split("\n")[0].strip(": \t")
+    except Exception:
+        return "unknown"
+
+
+# ----------------------------------------------------------------------------------------------
+# workloads (BASELINE.json configs)
+# ----------------------------------------------------------------------------------------------
+def make_workload(name, T, scheme="systematic", log2N=None, N=0, islands=1, essrmin=None, collapsed=False):
+    from particles_amd import kalman
+    from particles_amd import state_space_models as ssm
+    d = 1
+    if name == "c3":          # StochVol, N = 2^22, ESSrmin = 1: every step resamples
+        log2N = 22 if log2N is None else log2N
+        essrmin = 1.0 if essrmin is None else essrmin
+        rng = np.random.RandomState(42)
+        model = ssm.StochVol()
+        x = np.empty(T)
+        x[0] = model.mu + model.sig0() * rng.standard_normal()
+        for t in range(1, T):
+            x[t] = model.EXt(x[t - 1]) + model.sigma * rng.standard_normal()
+        y = [np.array([v]) for v in np.exp(0.5 * x) * rng.standard_normal(T)]
+        fk = ssm.Bootstrap(ssm=model, data=y)
+        label = "C3: StochVol d=1 bootstrap filter"
+    elif name == "c4":        # MVLinearGauss_Guarniero d = 32, guided, N = 2^20
+        d = 32
+        log2N = 20 if log2N is None else log2N
+        rng = np.random.RandomState(42)
+        model = kalman.MVLinearGauss_Guarniero_etal(alpha=0.4, dx=d)
+        x = np.zeros(d)
+        y = []
+        for t in range(T):
+            x = (model.F @ x if t else np.zeros(d)) + rng.standard_normal(d)
+            y.append((x + rng.standard_normal(d)).reshape(1, d))
+        fk = ssm.GuidedPF(ssm=model, data=y)
+        label = "C4: MVLinearGauss_Guarniero d=32 guided filter" + (" (collapsed proposal weight)" if collapsed else "")
+    else:
+        if name == "c5":      # one GPU's share of 256 islands x 2^18
+            log2N, islands = 18, 32
+        log2N = 20 if log2N is None else log2N
+        fk = ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=synthetic_data(T))
+        label = "C2: ToySSM d=1 linear-Gaussian bootstrap filter" if name == "c2" else \
+                "C5: ToySSM d=1 bootstrap filter islands"
+    return {"name": name, "fk": fk, "N": N if N > 0 else 1 << log2N, "log2N": log2N, "Nlabel": str(N) if N > 0 else "2^%d" % log2N,
+            "islands": islands, "scheme": scheme, "essrmin": 0.5 if essrmin is None else essrmin, "d": d,
+            "label": label, "collapsed": collapsed, "guided": name == "c4"}
+
+
+def make_filter(wl, rank=0, graph=False, profile=False):
+    import particles_amd as pa
+    from particles_amd import _lib
+    pf = pa.SMC(fk=wl["fk"], N=wl["N"], resampling=wl["scheme"], ESSrmin=wl["essrmin"], collect="off", seed=123,
+                n_islands=wl["islands"], island_offset=rank * wl["islands"],
+                use_graph=graph and not profile, collapsed_proposal=wl["collapsed"])
+    if profile:
+        _lib.check(_lib.lib().smc_filter_profile(pf._f, 1))
+    return pf
+
+
+def time_steps(pf, K, W, R, grp=None):
+    """W untimed steps, then R repetitions of: [barrier,] device sync, clock, K steps, device sync, clock
+    [, barrier].  Returns the R local times."""
+    pf.step_async(W)
+    pf.sync()
+    if grp:       # warm-up of the path's one collective too (RCCL sets its channels up lazily)
+        grp.gather_evidence(pf.logLts_islands)
+    dts = np.zeros(R)
+    for r in range(R):
+        if grp:
+            grp.barrier()
+        pf.sync()
+        t0 = time.perf_counter()
+        pf.step_async(K)
+        pf.sync()
+        dts[r] = time.perf_counter() - t0
+        if grp:
+            grp.barrier()
+    return dts
+
+
+def kernel_profile(wl, K, W, rank=0):
+    """The same workload re-run with HIP events around every launch on the filter's stream (kept out of
+    the timed region): average duration of the propagate kernel and of the resampling kernel(s)."""
+    import ctypes
+    from particles_amd import _lib
+    pf = make_filter(wl, rank, profile=True)
+    pf.step_async(W)
+    pf.sync()
+    mv, pr, ns = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+    _lib.check(_lib.lib().smc_filter_kernel_ms(pf._f, ctypes.byref(mv), ctypes.byref(pr),
+                                               ctypes.byref(ns)))    # drop warm-up samples
+    pf.step_async(min(K, 4000))
+    _lib.check(_lib.lib().smc_filter_kernel_ms(pf._f, ctypes.byref(mv), ctypes.byref(pr), ctypes.byref(ns)))
+    desc = ctypes.create_string_buffer(256)
+    _lib.check(_lib.lib().smc_filter_describe(pf._f, desc, 256))
+    del pf
+    return mv.value, pr.value, ns.value, desc.value.decode()
+
+
+def roofline(wl, step_GBs, mv_ms, rs_ms, nsamples, kernels):
+    """The roofline object of one workload from the measured durations of its step's two parts."""
+    N, isl, d = wl["N"], wl["islands"], wl["d"]
+    names = kernels.split(" [")[0].split("+")
+    rs_name = "+".join(k for k in names if not k.startswith("k_propagate"))
+    mv_name = [k for k in names if k.startswith("k_propagate")][0]
+    # two-level path: k_propagate also writes the tile CDF (8 B), k_ancestors2 reads it
+    # instead of the log-weights: 16 d + 24 and 16 B; flat path: 16 d + 16 and 16 (+ 8) B;
+    # either way SURVEY 8d's 16 d + 40 B per particle-step in all
+    two = "k_ancestors2" in kernels
+    rs_bytes = (BYTES_PREPARE + (8.0 if "k_prepare" in kernels else 0.0)) * N * isl
+    mv_bytes = (16.0 * d + 16.0 + (8.0 if two else 0.0)) * N * isl
+    mv_ms = mv_ms if mv_ms > 0 else 1e-9          # (the emulator's events read 0)
+    per = {mv_name: {"ms": mv_ms, "launch_bytes": mv_bytes, "achieved": mv_bytes / (mv_ms * 1e-3) / 1e9},
+           rs_name: {"ms": rs_ms, "launch_bytes": rs_bytes,
+                     "achieved": rs_bytes / (rs_ms * 1e-3) / 1e9 if rs_ms > 0 else None}}
+    dom = mv_name if mv_ms >= rs_ms else rs_name
+    ach = per[dom]["achieved"]
+    out = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+           "traffic": None, "traffic_source": None, "kernel": dom, "kernel_ms": per[dom]["ms"],
+           "launch_bytes": per[dom]["launch_bytes"], "samples": nsamples, "step_kernels": kernels,
+           "per_kernel": per, "step_frac": step_GBs / HBM_PEAK_GBS}
+    if wl["guided"] and d == 32:
+        # GEMM-shaped kernel: priced against the dense fp64 matrix peak (MI355X spec 78.6 TFLOP/s, = its
+        # fp64 vector peak; SURVEY App. D).  72 MFMAs (v_mfma_f64_16x16x4: 2048 flop) per 16 particles
+        # for the guided d=32 step, 44 with the collapsed weight.
+        flop = (44 if wl["collapsed"] else 72) * 2048.0 / 16.0 * N * isl
+        tf = flop / (mv_ms * 1e-3) / 1e12
+        out.update({"bound": "mfma", "achieved": tf, "peak": FP64_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TF,
+                    "kernel": "k_propagate_mv", "kernel_ms": mv_ms, "launch_bytes": mv_bytes, "launch_flop": flop,
+                    "hbm_achieved_GBs": per[mv_name]["achieved"]})
+    return out
+
+
+ROOFLINE_NOTE = (
+    "algorithmic bytes in SURVEY 8d's accounting (int64 ancestors; they are stored as 32-bit words, so the "
+    "kernels physically move 4 B less per particle each). Per particle-step, two-level path: k_propagate "
+    "16 d + 24 B (read A, gather X; write X, lw and the tile's integer CDF), k_ancestors2 16 B (read that CDF, "
+    "write A); flat path: k_propagate 16 d + 16 B, k_ancestors 16 B (read lw, write A; + 8 B for k_prepare's "
+    "pass over lw beyond 2048 workgroups per launch): 16 d + 40 B in all. Both parts are measured with HIP "
+    "events on the filter's stream in a separate pass over the same workload: steps are sampled in three "
+    "kinds (whole step / up to the propagate launch / from there on), propagate = whole - first part, "
+    "resampling = whole - second part, so the fixed ~4 us of an event interval cancels. `kernel` is the one "
+    "that takes longer; step_frac = (16 d + 40) B x N / ms_per_step over the HBM peak (the whole step)")
+
+
+def other_workloads(K=20, W=10, R=7, shrink=0):
+    """One bounded measurement of each BASELINE.json config that is not the headline (driver-visible
+    C3 / C4 / C5): same timed region as the headline (K steps between device syncs, median of R).
+    shrink > 0 (functional tests without a GPU): every N = 2^shrink, C5 with 2 islands."""
+    legs = [("c3_systematic", dict(name="c3", scheme="systematic")),
+            ("c3_stratified", dict(name="c3", scheme="stratified")),
+            ("c3_multinomial", dict(name="c3", scheme="multinomial")),
+            ("c4", dict(name="c4")),
+            ("c4_collapsed", dict(name="c4", collapsed=True)),
+            ("c5", dict(name="c5"))]
+    out = {}
+    for key, kw in legs:
+        t_leg = time.perf_counter()
+        try:
+            if shrink:
+                kw = dict(kw, log2N=shrink)
+            wl = make_workload(T=W + R * K, **kw)
+            if shrink and kw["name"] == "c5":
+                wl.update(N=1 << shrink, log2N=shrink, Nlabel="2^%d" % shrink, islands=2)
+            pf = make_filter(wl)
+            dts = time_steps(pf, K, W, R)
+            rs_rate = float(np.mean(pf._summ()[0, W:, 4]))
+            del pf
+            dt = float(np.median(dts))
+            units = float(wl["N"]) * wl["islands"] * K
+            step_GBs = (16.0 * wl["d"] + 40.0) * units / dt / 1e9
+            mv_ms, rs_ms, ns, kernels = kernel_profile(wl, 45 if not shrink else 6, W)
+            rf = roofline(wl, step_GBs, mv_ms, rs_ms, ns, kernels)
+            out[key] = {"workload": "%s, N=%s, %s resampling, ESSrmin=%g, %d filter(s) per GPU"
+                                    % (wl["label"], wl["Nlabel"], wl["scheme"], wl["essrmin"], wl["islands"]),
+                        "value": units / dt, "unit": "particle-steps/s", "ms_per_step": 1e3 * dt / K,
+                        "steps": K, "warmup": W, "reps": R, "resampled_fraction": rs_rate,
+                        "step_frac": rf["step_frac"], "kernel": rf["kernel"], "kernel_ms": rf["kernel_ms"],
+                        "bound": rf["bound"], "frac": rf["frac"], "step_kernels": kernels,
+                        "per_kernel_ms": {k: v["ms"] for k, v in rf["per_kernel"].items()},
+                        "leg_seconds": time.perf_counter() - t_leg}
+        except Exception as e:          # one failing leg must not cost the headline its line
+            out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return out
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
+        kind, N, nsteps, nruns, start_at = sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), float(sys.argv[6])
+        return _cpu_worker(kind, N, nsteps, nruns, start_at)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--log2N", type=int, default=20)
+    ap.add_argument("--log2N", type=int, default=None)
     ap.add_argument("--N", type=int, default=0,
                     help="population size that is not a power of two (side measurements; the headline is --log2N 20)")
     ap.add_argument("--scheme", default="systematic")
@@ -145,6 +412,9 @@ def main():
                     help="repetitions of the K-step timed region (0: about 10^4 timed steps in all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="skip the bounded C3 / C4 / C5 measurements added to the default line")
+    ap.add_argument("--other-shrink", type=int, default=0, help=argparse.SUPPRESS)     # tests: other_workloads at 2^k
     ap.add_argument("--collapsed", action="store_true",
                     help="c4: the collapsed form of the optimal proposal's weight (SMC_FLAG_COLLAPSED_PROPOSAL)")
     ap.add_argument("--graph", action="store_true", help="replay the steps from hipGraphs (default: eager launches)")
@@ -162,11 +432,10 @@ def main():
     #  SMC_BENCH_NGPU=1 lets all ranks share device 0; RCCL then refuses, which is an ERROR unless
     #  SMC_ALLOW_HOST_GATHER=1 routes the evidences over the host rendezvous)
     ngpu = int(os.environ.get("SMC_BENCH_NGPU", "0"))
-    os.environ["SMC_HIP_DEVICE"] = str(local_rank % ngpu if ngpu > 0 else local_rank)
+    device = local_rank % ngpu if ngpu > 0 else local_rank
+    os.environ["SMC_HIP_DEVICE"] = str(device)
 
-    import particles_amd as pa
-    from particles_amd import _lib, kalman
-    from particles_amd import state_space_models as ssm
+    from particles_amd import _lib
     from particles_amd.distributed import Group
 
     # a multi-GPU bench line with a LABELLED host gather ("evidence_gather": "host-fallback: <reason>")
@@ -176,75 +445,30 @@ def main():
     if grp and grp.rank == 0 and grp.evidence_path != "rccl":
         print("bench.py: RCCL unavailable, evidences gathered over the host rendezvous (%s)" % grp.evidence_path,
               file=sys.stderr)
+    devices = None
+    if grp:
+        # one GPU per rank: the ranks' PCI bus ids must be distinct unless the caller shares devices
+        # on purpose (SMC_BENCH_NGPU: functional tests on a box with fewer GPUs than ranks)
+        devices = grp.allgather_str("%d:%s" % (device, _lib.ctx().device_pci()))
+        if ngpu == 0 and len(set(s.split(":", 1)[1] for s in devices)) != len(devices):
+            sys.exit("bench.py: ranks share a GPU (%s): launch one rank per GPU" % devices)
     K, W = a.steps, a.warmup
     heavy = a.workload in ("c3", "c4", "c5")        # 0.07-0.3 ms per step: fewer timed steps do
     R = a.reps if a.reps > 0 else max(3, min(500, -(-(2000 if heavy else 10000) // K)))
     T = W + R * K
-    d = 1
-    if a.workload == "c3":        # StochVol, N = 2^22, ESSrmin = 1
-        a.log2N = 22 if a.log2N == 20 else a.log2N
-        a.essrmin = 1.0 if a.essrmin is None else a.essrmin
-        rng = np.random.RandomState(42)
-        model = ssm.StochVol()
-        x = np.empty(T)
-        x[0] = model.mu + model.sig0() * rng.standard_normal()
-        for t in range(1, T):
-            x[t] = model.EXt(x[t - 1]) + model.sigma * rng.standard_normal()
-        y = [np.array([v]) for v in np.exp(0.5 * x) * rng.standard_normal(T)]
-        fk = ssm.Bootstrap(ssm=model, data=y)
-        wl = "C3: StochVol d=1 bootstrap filter"
-    elif a.workload == "c4":      # MVLinearGauss_Guarniero d = 32, guided, N = 2^20
-        d = 32
-        rng = np.random.RandomState(42)
-        model = kalman.MVLinearGauss_Guarniero_etal(alpha=0.4, dx=d)
-        x = np.zeros(d)
-        y = []
-        for t in range(T):
-            x = (model.F @ x if t else np.zeros(d)) + rng.standard_normal(d)
-            y.append((x + rng.standard_normal(d)).reshape(1, d))
-        fk = ssm.GuidedPF(ssm=model, data=y)
-        wl = "C4: MVLinearGauss_Guarniero d=32 guided filter" + (" (collapsed proposal weight)" if a.collapsed else "")
-    else:
-        if a.workload == "c5":    # one GPU's share of 256 islands x 2^18
-            a.log2N, a.islands = 18, 32
-        y = synthetic_data(T)
-        fk = ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y)
-        wl = "C2: ToySSM d=1 linear-Gaussian bootstrap filter" if a.workload == "c2" else \
-             "C5: ToySSM d=1 bootstrap filter islands"
-    a.essrmin = 0.5 if a.essrmin is None else a.essrmin
-    N = a.N if a.N > 0 else 1 << a.log2N
+    wl = make_workload(a.workload, T, scheme=a.scheme, log2N=a.log2N, N=a.N, islands=a.islands,
+                       essrmin=a.essrmin, collapsed=a.collapsed)
+    a.log2N, a.islands = wl["log2N"], wl["islands"]
+    N, d = wl["N"], wl["d"]
     bytes_step = 16.0 * d + 40.0
-    bytes_move = 16.0 * d + 16.0                    # k_propagate: read A, gather X; write X, lw
 
-    def make(profile=False):
-        pf = pa.SMC(fk=fk, N=N, resampling=a.scheme, ESSrmin=a.essrmin, collect="off", seed=123,
-                    n_islands=a.islands, island_offset=rank * a.islands,
-                    use_graph=a.graph and not profile, collapsed_proposal=a.collapsed)
-        if profile:
-            _lib.check(_lib.lib().smc_filter_profile(pf._f, 1))
-        return pf
-
-    pf = make()
-    pf.step_async(W)
-    pf.sync()
-    if grp:       # warm-up of the path's one collective too (RCCL sets its channels up lazily)
-        grp.gather_evidence(pf.logLts_islands)
+    pf = make_filter(wl, rank, graph=a.graph)
     # ---- timed region: exactly K steps, barrier + device sync on both sides; R repetitions.
     # Every rank reads its clock right after ITS device sync; the closing barrier follows, and the
     # repetition's time is the MAX over ranks of those local times -- the instant the last rank
     # finished, without the latency of the host-side barrier itself (a TCP star: ~0.1 ms, which at
     # K = 20 steps of 20 us would be a quarter of the region).
-    dts = np.zeros(R)
-    for r in range(R):
-        if grp:
-            grp.barrier()
-        pf.sync()
-        t0 = time.perf_counter()
-        pf.step_async(K)
-        pf.sync()
-        dts[r] = time.perf_counter() - t0
-        if grp:
-            grp.barrier()
+    dts = time_steps(pf, K, W, R, grp)
     local_ll = pf.logLts_islands
     # the path's one collective: the all-gather of the per-island evidences, ONCE PER RUN (after the
     # T steps of a filter, not after every K-step repetition) -- timed on its own and reported
@@ -265,10 +489,9 @@ def main():
 
     out = None
     if rank == 0:
-        units = float(N) * a.islands * K * world
+        units = float(N) * wl["islands"] * K * world
         out = {
-            "metric": "particle-steps/sec (N x T), %s filter N=%s" % ("guided" if a.workload == "c4" else "bootstrap",
-                                                                          str(a.N) if a.N > 0 else "2^%d" % a.log2N),
+            "metric": "particle-steps/sec (N x T), %s filter N=%s" % ("guided" if wl["guided"] else "bootstrap", wl["Nlabel"]),
             "value": units / dt, "unit": "particle-steps/s", "n_gpus": world, "steps": K,
             "warmup": W, "ms_per_step": 1e3 * dt / K, "higher_is_better": True,
             "timing": {"reps": R, "statistic": "median of the repetitions of the K-step region",
@@ -278,12 +501,13 @@ def main():
                                                1e3 * float(np.percentile(dts, 90)) / K]},
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s, N=%s, T=%d, %s resampling, ESSrmin=%g; %d independent "
-                                   "filter(s) per GPU" % (wl, str(a.N) if a.N > 0 else "2^%d" % a.log2N, K,
-                                                          a.scheme, a.essrmin, a.islands),
-                       "N": N, "islands_per_gpu": a.islands, "scheme": a.scheme,
-                       "rng": "philox4x32-10", "graph": bool(a.graph),
-                       "resampled_fraction": rs_rate},
-            "step_achieved_GBs": bytes_step * N * a.islands * K / dt / 1e9,
+                                   "filter(s) per GPU" % (wl["label"], wl["Nlabel"], K, wl["scheme"], wl["essrmin"],
+                                                          wl["islands"]),
+                       "N": N, "islands_per_gpu": wl["islands"], "scheme": wl["scheme"],
+                       "rng": _lib.lib().smc_version().decode().split("rng=")[-1].split()[0]
+                       if b"rng=" in _lib.lib().smc_version() else "philox4x32-10",
+                       "graph": bool(a.graph), "resampled_fraction": rs_rate},
+            "step_achieved_GBs": bytes_step * N * wl["islands"] * K / dt / 1e9,
             "logLt": [float(v) for v in np.atleast_1d(all_ll)][:16],
             "evidence_gather": grp.evidence_path if grp else "none",
             "evidence_gather_ms": gather_ms,
@@ -292,6 +516,8 @@ def main():
             # line exists either way -- and says so here: rccl false = no collective touched xGMI
             "rccl": bool(grp and grp.evidence_path == "rccl") if grp else None,
         }
+        if devices is not None:
+            out["rank_devices"] = devices
         if grp:
             out["timing"]["note"] = (
                 "per repetition: max over ranks of each rank's own [barrier, device sync, clock] ... K steps ... "
@@ -299,79 +525,22 @@ def main():
                 "per run of T steps and is timed separately (evidence_gather_ms = %.3f ms = %.2f %% of a T = 1000 run)"
                 % (gather_ms, 100.0 * gather_ms / (1e3 * dt / K * 1000.0)))
 
-    # ---- dominant-kernel duration: same workload re-run with HIP events around
-    # every launch on the filter's stream (kept out of the timed region above)
+    # ---- dominant-kernel duration (HIP events on the filter's stream, outside the timed region)
     if not a.no_profile:
-        pf = make(profile=True)
-        pf.step_async(W)
-        pf.sync()
-        import ctypes
-        mv, pr, ns = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
-        _lib.check(_lib.lib().smc_filter_kernel_ms(pf._f, ctypes.byref(mv), ctypes.byref(pr),
-                                                   ctypes.byref(ns)))    # drop warm-up samples
-        pf.step_async(min(K, 4000))
-        _lib.check(_lib.lib().smc_filter_kernel_ms(pf._f, ctypes.byref(mv), ctypes.byref(pr),
-                                                   ctypes.byref(ns)))
-        desc = ctypes.create_string_buffer(256)
-        _lib.check(_lib.lib().smc_filter_describe(pf._f, desc, 256))
-        kernels = desc.value.decode()
-        del pf
-        if rank == 0 and ns.value:
-            # the step is [resampling kernel(s)] + [propagate kernel]; the roofline object describes
-            # whichever takes longer, the other one is listed beside it
-            rs_name = "+".join(k for k in kernels.split("+") if not k.startswith("k_propagate"))
-            mv_name = [k for k in kernels.split("+") if k.startswith("k_propagate")][0]
-            # two-level path: k_propagate also writes the tile CDF (8 B), k_ancestors2 reads it
-            # instead of the log-weights: 16 d + 24 and 16 B; flat path: 16 d + 16 and 16 (+ 8) B;
-            # either way SURVEY 8d's 16 d + 40 B per particle-step in all
-            two = "k_ancestors2" in kernels
-            rs_bytes = (BYTES_PREPARE + (8.0 if "k_prepare" in kernels else 0.0)) * N * a.islands
-            mv_bytes = (bytes_move + (8.0 if two else 0.0)) * N * a.islands
-            rs_ms = pr.value
-            per = {mv_name: {"ms": mv.value, "launch_bytes": mv_bytes,
-                             "achieved": mv_bytes / (mv.value * 1e-3) / 1e9},
-                   rs_name: {"ms": rs_ms, "launch_bytes": rs_bytes,
-                             "achieved": rs_bytes / (rs_ms * 1e-3) / 1e9 if rs_ms > 0 else None}}
-            dom = mv_name if mv.value >= rs_ms else rs_name
-            ach = per[dom]["achieved"]
-            out["roofline"] = {
-                "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                "traffic_source": None,
-                "kernel": dom, "kernel_ms": per[dom]["ms"],
-                "launch_bytes": per[dom]["launch_bytes"],
-                "samples": ns.value,
-                "step_kernels": kernels, "per_kernel": per,
-                "step_frac": out["step_achieved_GBs"] / HBM_PEAK_GBS,
-                "note": "algorithmic bytes in SURVEY 8d's accounting (int64 ancestors; they are stored as "
-                        "32-bit words, so the kernels physically move 4 B less per particle each). "
-                        "Per particle-step, two-level path: k_propagate 16 d + 24 B (read A, gather X; write X, "
-                        "lw and the tile's integer CDF), k_ancestors2 16 B (read that CDF, write A); flat path: "
-                        "k_propagate 16 d + 16 B, k_ancestors 16 B (read lw, write A; + 8 B for k_prepare's pass "
-                        "over lw beyond 2048 workgroups per launch): 16 d + 40 B in all. Both parts are measured with HIP events on "
-                        "the filter's stream in a separate pass over the same workload: steps are sampled "
-                        "in three kinds (whole step / up to the propagate launch / from there on), "
-                        "propagate = whole - first part, resampling = whole - second part, so the fixed "
-                        "~4 us of an event interval cancels. `kernel` is the one that takes longer; "
-                        "step_frac = 56 B x N / ms_per_step over the HBM peak (the whole step)",
-            }
-            if a.workload == "c4":
-                # GEMM-shaped kernel: priced against the dense fp64 matrix peak (MI355X spec
-                # 78.6 TFLOP/s, = its fp64 vector peak).  72 MFMAs
-                # (v_mfma_f64_16x16x4: 2048 flop) per 16 particles for the guided d=32 step.
-                flop = (44 if a.collapsed else 72) * 2048.0 / 16.0 * N * a.islands
-                tf = flop / (mv.value * 1e-3) / 1e12
-                out["roofline"].update({
-                    "bound": "mfma", "achieved": tf, "peak": 78.6, "unit": "TFLOP/s",
-                    "frac": tf / 78.6, "kernel": "k_propagate_mv", "kernel_ms": mv.value,
-                    "launch_bytes": mv_bytes, "launch_flop": flop,
-                    "hbm_achieved_GBs": per[mv_name]["achieved"]})
+        mv_ms, rs_ms, ns, kernels = kernel_profile(wl, K, W, rank)
+        if rank == 0 and ns:
+            out["roofline"] = roofline(wl, out["step_achieved_GBs"], mv_ms, rs_ms, ns, kernels)
+            out["roofline"]["note"] = ROOFLINE_NOTE
             tr = measured_traffic(a, out["roofline"]["kernel"].split("+")[-1].split("<")[0])
             if tr:
                 out["roofline"]["traffic"], out["roofline"]["traffic_source"] = tr
+    if rank == 0 and world == 1 and a.workload == "c2" and a.N == 0 and not a.no_other_workloads \
+            and (a.log2N == 20 or a.other_shrink):
+        out["other_workloads"] = (other_workloads(K=3, W=2, R=2, shrink=a.other_shrink) if a.other_shrink
+                                  else other_workloads())
     if rank == 0 and world == 1 and not a.no_cpu_baseline and a.workload == "c2":
         nst = min(a.cpu_steps, T) if a.log2N >= 18 else min(T, 2000)
-        out["cpu_baseline"] = cpu_baseline(y, N, nst)
+        out["cpu_baseline"] = cpu_baseline(N, nst)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if grp:

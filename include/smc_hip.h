@@ -56,6 +56,11 @@ const char* smc_version(void);
 int smc_ctx_device_info(smc_ctx* ctx, char* name_host, size_t name_len,
                         int* n_cu, uint64_t* hbm_bytes);
 
+/* PCI bus id ("0000:05:00.0") of the context's device: what distinguishes the GPUs of one node
+ * whatever ordinal a process sees them under (one-rank-per-GPU launches check that the ranks'
+ * ids differ before they build the RCCL communicator) */
+int smc_ctx_device_pci(smc_ctx* ctx, char* out_host, size_t len);
+
 int smc_malloc(smc_ctx* ctx, size_t bytes, void** dptr_out);
 int smc_free(smc_ctx* ctx, void* dptr);
 int smc_memcpy_h2d(smc_ctx* ctx, void* dst, const void* src_host, size_t bytes);

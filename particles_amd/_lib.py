@@ -59,6 +59,7 @@ SIGNATURES = {
     "smc_last_error": (ctypes.c_char_p, []),
     "smc_version": (ctypes.c_char_p, []),
     "smc_ctx_device_info": (c_int, [c_vp, ctypes.c_char_p, c_sz, P(c_int), P(c_u64)]),
+    "smc_ctx_device_pci": (c_int, [c_vp, ctypes.c_char_p, c_sz]),
     "smc_malloc": (c_int, [c_vp, c_sz, P(c_vp)]),
     "smc_free": (c_int, [c_vp, c_vp]),
     "smc_memcpy_h2d": (c_int, [c_vp, c_vp, c_vp, c_sz]),
@@ -194,6 +195,12 @@ class Context:
         ncu, mem = c_int(), c_u64()
         check(lib().smc_ctx_device_info(self.h, name, 256, ctypes.byref(ncu), ctypes.byref(mem)))
         return {"name": name.value.decode(), "n_cu": ncu.value, "hbm_bytes": mem.value}
+
+    def device_pci(self):
+        """PCI bus id of the device: the same GPU has the same id in every process of the node."""
+        buf = ctypes.create_string_buffer(64)
+        check(lib().smc_ctx_device_pci(self.h, buf, 64))
+        return buf.value.decode()
 
     def close(self):
         if self.h:

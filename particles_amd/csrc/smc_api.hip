@@ -111,6 +111,13 @@ int smc_ctx_device_info(smc_ctx* ctx, char* name_host, size_t name_len, int* n_c
     return SMC_OK;
 }
 
+int smc_ctx_device_pci(smc_ctx* ctx, char* out_host, size_t len)
+{
+    SMC_REQUIRE(ctx && out_host && len >= 16, "null argument or buffer below 16 bytes");
+    SMC_HIP_CHECK(hipDeviceGetPCIBusId(out_host, (int)len, ctx->device));
+    return SMC_OK;
+}
+
 int smc_malloc(smc_ctx* ctx, size_t bytes, void** dptr_out)
 {
     SMC_REQUIRE(ctx && dptr_out, "null argument");

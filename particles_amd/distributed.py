@@ -82,39 +82,65 @@ class _Star:
         self._keyfile = os.path.join(tempfile.gettempdir(), key)
         self.peers = []
         self.sock = None
+        # every rank of one launch shares this nonce: the key file of a crashed earlier launch (same
+        # MASTER_PORT and run id, e.g. torchrun's defaults) carries another one and is ignored
+        nonce = "%s_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "x"),
+                              os.getppid())
         if rank == 0:
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
             srv.bind((addr if addr not in ("localhost",) else "127.0.0.1", 0))
             srv.listen(world)
             srv.settimeout(timeout)
-            tmp = self._keyfile + ".tmp%d" % os.getpid()
-            with open(tmp, "w") as fh:
-                fh.write("%d %d" % (srv.getsockname()[1], os.getpid()))
-            os.replace(tmp, self._keyfile)
+            # a stale file from a crashed launch goes first; the new one is created exclusively
+            # (no following of a symlink somebody planted in the shared temp directory), mode 0600
+            try:
+                os.unlink(self._keyfile)
+            except OSError:
+                pass
+            fd = os.open(self._keyfile, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
+            with os.fdopen(fd, "w") as fh:
+                fh.write("%d %d %s\n" % (srv.getsockname()[1], os.getpid(), nonce))
             conns = {}
-            while len(conns) < world - 1:
-                c, _ = srv.accept()
-                c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                c.settimeout(timeout)
-                (r,) = struct.unpack("<I", _recv_exact(c, 4))
-                conns[r] = c
+            try:
+                while len(conns) < world - 1:
+                    c, _ = srv.accept()
+                    c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    c.settimeout(timeout)
+                    hello = _recv_msg(c).decode(errors="replace").split(" ", 1)
+                    if len(hello) != 2 or hello[1] != nonce or not hello[0].isdigit() \
+                            or not 0 < int(hello[0]) < world or int(hello[0]) in conns:
+                        c.close()                      # not a rank of this launch
+                        continue
+                    conns[int(hello[0])] = c
+            except Exception:
+                for c in conns.values():
+                    c.close()
+                srv.close()
+                self.close()
+                raise
             srv.close()
             self.peers = [conns[r] for r in range(1, world)]
         else:
             t0 = time.time()
-            port = None
-            while port is None:
+            s = None
+            while s is None:
+                # (re-)read the file until it names a live listener of THIS launch: a stale file is
+                # replaced by rank 0 a moment later, and a refused connection means exactly that
                 try:
                     with open(self._keyfile) as fh:
-                        port = int(fh.read().split()[0])
+                        f = fh.read().split()
+                    if len(f) != 3 or f[2] != nonce or not f[0].isdigit() or not f[1].isdigit():
+                        raise ValueError("not this launch's key file")
+                    os.kill(int(f[1]), 0)              # the rank 0 that wrote it is alive (else: OSError)
+                    s = socket.create_connection((addr, int(f[0])), timeout=timeout)
                 except (OSError, ValueError, IndexError):
+                    s = None
                     if time.time() - t0 > timeout:
-                        raise TimeoutError("rendezvous: rank 0 never published %s" % self._keyfile)
+                        raise TimeoutError("rendezvous: rank 0 never published a live %s" % self._keyfile)
                     time.sleep(0.01)
-            s = socket.create_connection((addr, port), timeout=timeout)
             s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-            s.sendall(struct.pack("<I", rank))
+            _send_msg(s, ("%d %s" % (rank, nonce)).encode())
             self.sock = s
 
     def exchange(self, payload=b""):
@@ -200,6 +226,12 @@ class Group:
     def barrier(self):
         if self.star:
             self.star.exchange(b"")
+
+    def allgather_str(self, text):
+        """Every rank's string, in rank order (host side)."""
+        if not self.star:
+            return [text]
+        return [p.decode(errors="replace") for p in self.star.exchange(text.encode())]
 
     def _allreduce_host(self, v, op):
         a = np.atleast_1d(np.asarray(v, dtype=np.float64))

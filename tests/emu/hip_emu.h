@@ -340,6 +340,9 @@ inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     p->totalGlobalMem = 0;
     return 0;
 }
+inline hipError_t hipDeviceGetPCIBusId(char* out, int len, int dev) {
+    snprintf(out, (size_t)len, "emu0:%02x:00.0", dev); return 0;
+}
 inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, int) { *s = nullptr; return 0; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }

@@ -1,0 +1,75 @@
+"""bench.py's contract on the CPU (fiber emulator standing in for the GPU): the one JSON line, the
+`other_workloads` block that makes C3 / C4 / C5 driver-visible, and the CPU-baseline legs."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+            "scaling", "vs_baseline", "dtype", "data", "config")
+
+
+def _emu_env():
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    return dict(os.environ, SMC_TEST_EMULATOR="1", SMC_HIP_LIBRARY=build_emu.build())
+
+
+def test_default_line_carries_other_workloads_and_cpu_legs(tmp_path):
+    """`python bench.py` (N = 1, default workload) shrunk to emulator sizes: top-level fields are C2's,
+    `other_workloads` holds one measurement per remaining BASELINE.json config, `cpu_baseline` states
+    the host's core count and has a one-core and an all-cores leg."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--log2N", "11",
+           "--reps", "2", "--other-shrink", "10", "--cpu-steps", "4"]
+    p = subprocess.run(cmd, env=_emu_env(), capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in CONTRACT:
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and "C2" in d["config"]["workload"]
+    assert "roofline" in d and d["roofline"]["bound"] == "hbm"
+    ow = d["other_workloads"]
+    assert sorted(ow) == ["c3_multinomial", "c3_stratified", "c3_systematic", "c4", "c4_collapsed", "c5"]
+    for key, leg in ow.items():
+        assert "error" not in leg, (key, leg)
+        for k in ("value", "ms_per_step", "step_frac", "kernel", "frac", "step_kernels"):
+            assert k in leg, (key, k)
+        assert leg["value"] > 0 and leg["resampled_fraction"] > 0
+    assert ow["c4"]["bound"] == "mfma" and "k_propagate_mv" in ow["c4"]["step_kernels"]
+    assert "collapsed" in ow["c4_collapsed"]["step_kernels"]
+    assert "k_f_spacing" in ow["c3_multinomial"]["step_kernels"] or "spacing" in ow["c3_multinomial"]["step_kernels"]
+    cb = d["cpu_baseline"]
+    assert cb["cores"] == 1 and cb["value"] > 0 and cb["host"]["nproc"] >= 1
+    assert cb["kind"] == ("reference" if os.path.isdir("/root/reference/particles") else "port")
+    if cb["host"]["nproc"] > 1:
+        ac = cb["all_cores"]
+        assert ac["cores"] == cb["host"]["nproc"] and ac["runs"] >= 16 and ac["value"] > 0 and ac["kind"] == cb["kind"]
+
+
+@pytest.mark.parametrize("kind", ["port", "reference"])
+def test_cpu_baseline_kinds(kind):
+    """Both CPU legs on demand: the oracle port (what the GPU box runs) and -- where
+    /root/reference exists -- the reference itself; the same data and seeds, so the two
+    log-evidences agree to the last bit (the oracle is pinned to the reference)."""
+    import bench
+    if kind == "reference" and not bench.reference_available():
+        pytest.skip("/root/reference is not present on this box")
+    cb = bench.cpu_baseline(1 << 12, 6, all_cores=False, kind=kind)
+    assert cb["kind"] == kind and cb["cores"] == 1 and cb["value"] > 0
+    if bench.reference_available():
+        other = bench.cpu_baseline(1 << 12, 6, all_cores=False, kind="port" if kind == "reference" else "reference")
+        assert other["logLt"] == cb["logLt"]
+
+
+def test_auto_kind_follows_the_reference_tree(monkeypatch):
+    import bench
+    monkeypatch.setattr(bench, "REFERENCE_DIR", "/nonexistent")
+    assert not bench.reference_available()
+    assert bench.cpu_baseline(1 << 10, 4, all_cores=False)["kind"] == "port"

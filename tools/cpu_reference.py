@@ -36,8 +36,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # that multiSMC's worker processes get the same compiled inverse_cdf as the parent.
 SHIM = os.path.join("/tmp", "smc_numba_c_shim")
 os.makedirs(os.path.join(SHIM, "numba"), exist_ok=True)
-with open(os.path.join(SHIM, "numba", "__init__.py"), "w") as _fh:
-    _fh.write('''import ctypes, os
+_SHIM_SRC = ('''import ctypes, os
 import numpy as np
 _LIB = None
 def _c_inverse_cdf(py):
@@ -66,6 +65,14 @@ def jit(*args, **kwargs):
     return wrap
 njit = jit
 ''' % os.path.join(ROOT, "oracle", "_build", "liboracle.so"))
+# (several worker processes of bench.py's all-cores leg import this module at once: the file is put in
+#  place atomically, and only when it is not already the one wanted)
+_shim_path = os.path.join(SHIM, "numba", "__init__.py")
+if not (os.path.exists(_shim_path) and open(_shim_path).read() == _SHIM_SRC):
+    _tmp = _shim_path + ".%d" % os.getpid()
+    with open(_tmp, "w") as _fh:
+        _fh.write(_SHIM_SRC)
+    os.replace(_tmp, _shim_path)
 subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, stdout=subprocess.DEVNULL)
 os.environ["PYTHONPATH"] = os.pathsep.join([SHIM, "/root/reference", ROOT, os.environ.get("PYTHONPATH", "")])
 os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
