@@ -255,6 +255,10 @@ extern "C" void smc_test_log_pos(const double* x, int64_t n, double* out)
 {
     for (int64_t i = 0; i < n; ++i) out[i] = smc_log_pos(x[i]);
 }
+extern "C" void smc_test_bm_pair(const uint64_t* a, const uint64_t* b, int64_t n, double* z0, double* z1)
+{
+    for (int64_t i = 0; i < n; ++i) smc_bm_pair(smc_ntab, a[i], b[i], z0[i], z1[i]);
+}
 extern "C" void smc_test_sincospi_02(const double* a, int64_t n, double* s, double* c)
 {
     for (int64_t i = 0; i < n; ++i) smc_sincospi_02(a[i], &s[i], &c[i]);

@@ -32,12 +32,15 @@ __device__ __forceinline__ int smc_wave() { return (int)(threadIdx.x >> 6); }
 // One call yields two 64-bit words.  Restated in oracle/smc_oracle.py and
 // oracle/oracle.c; tests check the integer stream bit-for-bit.
 // ---------------------------------------------------------------------------
+#ifndef SMC_PHILOX_ROUNDS
+#define SMC_PHILOX_ROUNDS 10
+#endif
 __host__ __device__ __forceinline__ void smc_philox(u32 c0, u32 c1, u32 c2, u32 c3, u64 seed,
                                            u64& x01, u64& x23)
 {
     u32 k0 = (u32)seed, k1 = (u32)(seed >> 32);
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < SMC_PHILOX_ROUNDS; ++r) {
         if (r > 0) { k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
         const u64 p0 = (u64)0xD2511F53u * c0, p1 = (u64)0xCD9E8D57u * c2;   // v_mad_u64_u32
         const u32 n0 = (u32)(p1 >> 32) ^ c1 ^ k0, n2 = (u32)(p0 >> 32) ^ c3 ^ k1;
@@ -59,17 +62,26 @@ __device__ __forceinline__ double smc_u01_halfopen(u64 x)
 }
 
 // Two standard normals from one Philox call (Box-Muller):
-//   r = sqrt(-2 log u1);  (z_even, z_odd) = r * (cos, sin)(2 pi u2)
-__device__ __forceinline__ void smc_normal_pair(u64 seed, u32 pair, u32 t, u32 island,
+//   r = sqrt(-2 log u1);  (z_even, z_odd) = r * (cos, sin)(2 pi u2),  u = ((x >> 12) + 1/2) 2^-52
+// ntab: the tables of smc_math.h's smc_bm_pair staged in LDS (SMC_NTAB_LDS + smc_ntab_stage + a
+// barrier at the top of the kernel).  -DSMC_BM_LEGACY (A/B builds only): the table-free
+// evaluation of rounds 1-2 (same uniforms, results equal to a few ulp).
+#define SMC_NTAB_LDS(name) __shared__ __attribute__((aligned(16))) double name[2 * SMC_NTAB_N]
+__device__ __forceinline__ void smc_normal_pair(const double* ntab, u64 seed, u32 pair, u32 t, u32 island,
                                                 u32 stream, double& z0, double& z1)
 {
     u64 a, b;
     smc_philox(pair, t, island, stream, seed, a, b);
+#ifdef SMC_BM_LEGACY
+    (void)ntab;
     const double r = sqrt(-2.0 * smc_log_pos(smc_u01_open(a)));
     double sn, cs;
     smc_sincospi_02(2.0 * smc_u01_open(b), &sn, &cs);
     z0 = r * cs;
     z1 = r * sn;
+#else
+    smc_bm_pair(ntab, a, b, z0, z1);
+#endif
 }
 
 // ---------------------------------------------------------------------------

@@ -1076,9 +1076,13 @@ k_propagate(const FArgs av)
     const FArgs& a = av;
     __shared__ double smd[SMC_SM];
     __shared__ int s_last;
+    SMC_NTAB_LDS(s_ntab);
     const int b = (int)blockIdx.x, isl = (int)blockIdx.y;
     const int tid = (int)threadIdx.x;
     F_STAMP(0);
+    // the Box-Muller tables (6 KB, L2-resident) are the first thing requested: they are back, and in
+    // LDS, before the step record of a dependent launch has arrived
+    smc_ntab_stage(s_ntab, tid, SMC_BLOCK);
     double* info = a.info + (i64)isl * INFO_STRIDE;
     const i64 N = a.N;
     const FOwn own = f_own<!TAIL>(b, tid, N);
@@ -1116,18 +1120,19 @@ k_propagate(const FArgs av)
     double zs[OPT] = {0.0, 0.0, 0.0, 0.0};
     const bool spec_z = a.tk >= 0 && !a.zt && own.na < N;
     double xg[OPT];
+    __syncthreads();               // s_ntab staged
     if (SPEC && own.na < N) {      // A always holds valid indices (zeros before the first resampling)
         load_anc(a.A + (i64)isl * N);
         if (spec_z)
-            smc_normal_pair(a.seed, (u32)(own.na >> 1), (u32)a.tk, gisl, SMC_STREAM_NORMAL, zs[0], zs[1]);
+            smc_normal_pair(s_ntab, a.seed, (u32)(own.na >> 1), (u32)a.tk, gisl, SMC_STREAM_NORMAL, zs[0], zs[1]);
         const double* Xs = a.X + (i64)(a.par ^ 1) * a.xslot + (i64)isl * N;
 #pragma unroll
         for (int k = 0; k < OPT; ++k) xg[k] = smc_ldg(Xs + an[k]);
     } else if (spec_z) {
-        smc_normal_pair(a.seed, (u32)(own.na >> 1), (u32)a.tk, gisl, SMC_STREAM_NORMAL, zs[0], zs[1]);
+        smc_normal_pair(s_ntab, a.seed, (u32)(own.na >> 1), (u32)a.tk, gisl, SMC_STREAM_NORMAL, zs[0], zs[1]);
     }
     if (spec_z)
-        smc_normal_pair(a.seed, (u32)(own.nb >> 1), (u32)a.tk, gisl, SMC_STREAM_NORMAL, zs[2], zs[3]);
+        smc_normal_pair(s_ntab, a.seed, (u32)(own.nb >> 1), (u32)a.tk, gisl, SMC_STREAM_NORMAL, zs[2], zs[3]);
     const i64 t = (i64)smc_uniform(r0);
     if (t >= a.T) return;
     F_STAMP(1);
@@ -1195,8 +1200,8 @@ k_propagate(const FArgs av)
 #pragma unroll
             for (int k = 0; k < OPT; ++k) z[k] = zs[k];
         } else {
-            smc_normal_pair(a.seed, (u32)(own.na >> 1), (u32)t, gisl, SMC_STREAM_NORMAL, z[0], z[1]);
-            smc_normal_pair(a.seed, (u32)(own.nb >> 1), (u32)t, gisl, SMC_STREAM_NORMAL, z[2], z[3]);
+            smc_normal_pair(s_ntab, a.seed, (u32)(own.na >> 1), (u32)t, gisl, SMC_STREAM_NORMAL, z[0], z[1]);
+            smc_normal_pair(s_ntab, a.seed, (u32)(own.nb >> 1), (u32)t, gisl, SMC_STREAM_NORMAL, z[2], z[3]);
         }
         if (resample && heavy_parent >= 0) {
             const double xh = smc_ldg(Xo + heavy_parent);

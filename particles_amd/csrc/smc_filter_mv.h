@@ -113,8 +113,10 @@ k_propagate_mv(const FArgs av, const double* __restrict__ C)
     __shared__ double sVec[4 * DP];               // mu (t = 0) or K y_t | mu0 | L_Y^-1 y_t | -
     __shared__ double smd[SMC_SM];
     __shared__ int s_last;
+    SMC_NTAB_LDS(s_ntab);
     const int b = (int)blockIdx.x, isl = (int)blockIdx.y;
     const int tid = (int)threadIdx.x;
+    smc_ntab_stage(s_ntab, tid, SMC_BLOCK);        // (the barrier behind the matrices covers it)
     const int lane = tid & 63, wv = tid >> 6;
     const int g = lane >> 4, pn = lane & 15;
     double* info = a.info + (i64)isl * INFO_STRIDE;
@@ -276,7 +278,7 @@ k_propagate_mv(const FArgs av, const double* __restrict__ C)
 #ifdef ABL_NO_RNG
                     z0 = (double)(n[gi] & 7) * 0.25 - 1.0; z1 = (double)kp * 0.125 - 0.5;
 #else
-                    smc_normal_pair(a.seed, (u32)(n[gi] * hp + kp), (u32)t, gisl,
+                    smc_normal_pair(s_ntab, a.seed, (u32)(n[gi] * hp + kp), (u32)t, gisl,
                                     SMC_STREAM_NORMAL, z0, z1);
 #endif
                     if (!dfull) {

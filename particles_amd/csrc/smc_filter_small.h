@@ -32,9 +32,11 @@ k_filter_small(const FArgs av, const int nsteps)
     __shared__ double smm[SMC_SM];          // maxima
     __shared__ i64 sn[2];
     __shared__ u32 smx[SMC_NWAVE];
+    SMC_NTAB_LDS(s_ntab);
     const int isl = (int)blockIdx.y;
     const int tid = (int)threadIdx.x;
     if (tid < SMC_SM) { smu[tid] = 0ull; smd[tid] = 0.0; smm[tid] = -INFINITY; }
+    smc_ntab_stage(s_ntab, tid, BS);
     __syncthreads();
     const i64 N = a.N;
     double* info = a.info + (i64)isl * INFO_STRIDE;
@@ -128,7 +130,7 @@ k_filter_small(const FArgs av, const int nsteps)
         } else {
 #pragma unroll
             for (int k = 0; k < 4; k += 2)
-                smc_normal_pair(a.seed, (u32)((jt + k) >> 1), (u32)t, gisl, SMC_STREAM_NORMAL, z[k], z[k + 1]);
+                smc_normal_pair(s_ntab, a.seed, (u32)((jt + k) >> 1), (u32)t, gisl, SMC_STREAM_NORMAL, z[k], z[k + 1]);
         }
         bool okp[4];
 #pragma unroll

@@ -131,6 +131,102 @@ __host__ __device__ __forceinline__ double smc_log_pos(double x)
     return fma(k, K[8], -((hfsq - fma(s, hfsq + R, k * K[9])) - f));
 }
 
+// ---------------------------------------------------------------------------
+// Box-Muller on two 52-bit uniforms, table-driven (round 3).  The two transcendental pieces of a
+// normal pair -- log of the radius uniform, sin/cos of the angle -- were 127 of the 185 VALU
+// instructions of a pair (polynomials of degree 14 and 2 x 8, a true division, range selects).
+// Both arguments are known bit patterns, so the top bits index a small table and the remaining
+// bits feed a short polynomial:
+//   log u,  u = (k + 1/2) 2^-52:  u = m 2^e, node j = round(128 (m - 1)), r = m RN(1/c_j) - 1 (one
+//       fma, |r| <= 2^-8), log u = e' ln2 + logc_j + log1p(r) with logc_j = -log RN(1/c_j) (an
+//       identity for ANY invc), nodes above sqrt 2 filed under the next exponent so that nothing
+//       cancels as u -> 1 (last node: invc = 1/2, logc = 0 exactly).  <= 3 ulp.
+//   sin, cos of 2 pi u, u = (k + 1/2) 2^-52: top 8 bits = one of 256 centre angles (table), the
+//       44 bits below = the offset x in (-pi/256, pi/256): sin x, cos x - 1 by 3 terms each, one
+//       angle addition.  Absolute error < 2e-16; no quadrant logic.
+//   sqrt(s), s = -2 log u > 0: v_rsq_f64 + one Goldschmidt step + one correction.  <= 1 ulp.
+// tools/gen_normal_tables.py makes the tables (smc_normal_tab.h, 6 KB); kernels stage them in LDS
+// (smc_ntab_stage) -- the two lookups of a pair are lane-random 16-byte reads.
+// ---------------------------------------------------------------------------
+#define SMC_NTAB_DECL SMC_CONST
+#include "smc_normal_tab.h"
+
+// stage the tables in LDS (2 * SMC_NTAB_N doubles): every thread of the workgroup calls, a
+// barrier must follow before the first smc_bm_pair
+__device__ __forceinline__ void smc_ntab_stage(double* lds, const int tid, const int nthreads)
+{
+    for (int i = tid; i < SMC_NTAB_N; i += nthreads) {
+        lds[2 * i] = smc_ntab[2 * i];
+        lds[2 * i + 1] = smc_ntab[2 * i + 1];
+    }
+}
+
+SMC_CONST double smc_k_bm[16] = {
+    1.0 / 7.0, -1.0 / 6.0, 0.2, -0.25, 1.0 / 3.0, -0.5,                  // log1p
+    6.93147180369123816490e-01, 1.90821492927058770002e-10,              // ln2 hi, lo
+    0.024543692606170259675,                                             // 2 pi / 256
+    1.0 / 120.0, -1.0 / 6.0,                                             // sin x - x
+    -1.0 / 720.0, 1.0 / 24.0, -0.5,                                      // cos x - 1
+    0x1.fffffffffffffp-1, 0x1.7ffffffffffcp+0};                          // 1 - 2^-53, 1.5 - 2^-45
+
+#ifdef SMC_EMULATE
+__host__ __device__ __forceinline__ double smc_frexp_m(double x, int& e) { return frexp(x, &e); }
+__host__ __device__ __forceinline__ double smc_rsq(double x) { return 1.0 / sqrt(x); }
+#else
+__device__ __forceinline__ double smc_frexp_m(double x, int& e)
+{
+    e = __builtin_amdgcn_frexp_exp(x);
+    return __builtin_amdgcn_frexp_mant(x);
+}
+__device__ __forceinline__ double smc_rsq(double x) { return __builtin_amdgcn_rsq(x); }
+#endif
+
+// (z0, z1) = sqrt(-2 log u1) (cos, sin)(2 pi u2), u1 = ((a >> 12) + 1/2) 2^-52, u2 likewise from b;
+// tab: the staged tables (LDS)
+__host__ __device__ __forceinline__ void smc_bm_pair(const double* tab, const u64 a, const u64 b,
+                                                     double& z0, double& z1)
+{
+    const double* K = smc_k_bm;
+    // ---- log u1
+    const double D = __longlong_as_double((long long)((a >> 12) | 0x3FF0000000000000ull));   // 1 + k 2^-52
+    const double u = D - K[14];                                 // (k + 1/2) 2^-52, exact
+    int e;
+    const double mm = smc_frexp_m(u, e);                        // u = mm 2^e, mm in [1/2, 1)
+    const u32 hi = (u32)((u64)__double_as_longlong(mm) >> 32);
+    const u32 j = (((hi >> 12) & 0xFFu) + 1u) >> 1;             // nearest of 129 nodes of 2 mm in [1, 2]
+    const double invc2 = tab[2 * j], logc = tab[2 * j + 1];
+    const double r = fma(mm, invc2, -1.0);
+    const double ed = (double)(e - 1 + (j >= (u32)SMC_NTAB_JUP ? 1 : 0));
+    double p = SMC_FMA_K(r, K[0], K[1]);
+    p = SMC_FMA_K(p, r, K[2]);
+    p = SMC_FMA_K(p, r, K[3]);
+    p = SMC_FMA_K(p, r, K[4]);
+    p = SMC_FMA_K(p, r, K[5]);
+    const double lp = fma(p, r * r, r);                         // log1p(r)
+    const double L = fma(ed, K[6], logc) + fma(ed, K[7], lp);   // log u1 < 0
+    // ---- radius sqrt(-2 L)
+    const double s = -2.0 * L;
+    const double y = smc_rsq(s);
+    double g = s * y, h = 0.5 * y;
+    const double e1 = fma(-h, g, 0.5);
+    g = fma(g, e1, g);
+    h = fma(h, e1, h);
+    g = fma(fma(-g, g, s), h, g);
+    // ---- angle 2 pi u2 = 2 pi (i + 1/2 + rho) / 256
+    const u64 kb = b >> 12;
+    const u32 i = (u32)(kb >> 44);
+    const double D2 = __longlong_as_double((long long)(((kb << 8) & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull));
+    const double x = (D2 - K[15]) * K[8];                       // offset from the centre angle, |x| < pi/256
+    const double z = x * x;
+    const double sx = fma(x * z, SMC_FMA_K(z, K[9], K[10]), x);                 // sin x
+    const double dc = z * SMC_FMA_K(SMC_FMA_K(z, K[11], K[12]), z, K[13]);      // cos x - 1
+    const double si = tab[2 * (SMC_NTAB_SC + i)], ci = tab[2 * (SMC_NTAB_SC + i) + 1];
+    const double sn = fma(ci, sx, fma(si, dc, si));
+    const double cs = fma(-si, sx, fma(ci, dc, ci));
+    z0 = g * cs;
+    z1 = g * sn;
+}
+
 __host__ __device__ __forceinline__ void smc_sincospi_02(double a, double* sn, double* cs)
 {
     const double* K = smc_k_sc;

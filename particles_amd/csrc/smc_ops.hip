@@ -920,6 +920,9 @@ __global__ void __launch_bounds__(SMC_BLOCK)
 k_normal_rvs(const double* loc, i64 ls, const double* scale, i64 ss, const double* z, u64 seed,
              u32 t, u32 island, i64 N, double* out)
 {
+    SMC_NTAB_LDS(s_ntab);
+    smc_ntab_stage(s_ntab, (int)threadIdx.x, SMC_BLOCK);
+    __syncthreads();
     const i64 p = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;   // pair index
     const i64 n0 = 2 * p;
     if (n0 >= N) return;
@@ -928,7 +931,7 @@ k_normal_rvs(const double* loc, i64 ls, const double* scale, i64 ss, const doubl
         z0 = z[n0];
         z1 = (n0 + 1 < N) ? z[n0 + 1] : 0.0;
     } else {
-        smc_normal_pair(seed, (u32)p, t, island, SMC_STREAM_NORMAL, z0, z1);
+        smc_normal_pair(s_ntab, seed, (u32)p, t, island, SMC_STREAM_NORMAL, z0, z1);
     }
     out[n0] = loc[n0 * ls] + scale[n0 * ss] * z0;               // loc + scale*z
     if (n0 + 1 < N) out[n0 + 1] = loc[(n0 + 1) * ls] + scale[(n0 + 1) * ss] * z1;
@@ -1005,12 +1008,15 @@ extern "C" int smc_poisson_logpmf(smc_ctx* ctx, const double* k, int64_t k_strid
 __global__ void __launch_bounds__(SMC_BLOCK)
 k_philox_fill(int normal, u64 seed, u32 t, u32 island, i64 n, double* out)
 {
+    SMC_NTAB_LDS(s_ntab);
+    smc_ntab_stage(s_ntab, (int)threadIdx.x, SMC_BLOCK);
+    __syncthreads();
     const i64 p = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;
     const i64 n0 = 2 * p;
     if (n0 >= n) return;
     double v0, v1;
     if (normal) {
-        smc_normal_pair(seed, (u32)p, t, island, SMC_STREAM_NORMAL, v0, v1);
+        smc_normal_pair(s_ntab, seed, (u32)p, t, island, SMC_STREAM_NORMAL, v0, v1);
     } else {
         u64 a, b;
         smc_philox((u32)p, t, island, SMC_STREAM_RESAMPLE, seed, a, b);
@@ -1053,7 +1059,9 @@ k_mvn_rvs(const double* loc, i64 loc_rows, double scale, const double* L, const 
           u64 seed, u32 t, u32 island, i64 N, int d, double* out)
 {
     __shared__ double sL[MVN_MAXD * MVN_MAXD];
+    SMC_NTAB_LDS(s_ntab);
     for (int i = (int)threadIdx.x; i < d * d; i += SMC_BLOCK) sL[i] = L[i];
+    smc_ntab_stage(s_ntab, (int)threadIdx.x, SMC_BLOCK);
     __syncthreads();
     const i64 idx = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;
     if (idx >= N * d) return;
@@ -1067,7 +1075,7 @@ k_mvn_rvs(const double* loc, i64 loc_rows, double scale, const double* L, const 
             zk = z[n * d + k];
         } else {
             double z0, z1;
-            smc_normal_pair(seed, (u32)(n * hp + (k >> 1)), t, island, SMC_STREAM_NORMAL, z0, z1);
+            smc_normal_pair(s_ntab, seed, (u32)(n * hp + (k >> 1)), t, island, SMC_STREAM_NORMAL, z0, z1);
             zk = (k & 1) ? z1 : z0;
         }
         acc += zk * sL[i * d + k];

@@ -39,6 +39,17 @@ def pytest_configure(config):
         os.environ["SMC_TEST_EMULATOR"] = "1"        # particles_amd refuses non-gfx950 builds otherwise
 
 
+def pytest_xdist_auto_num_workers(config):
+    """`-n auto` (pytest.ini): up to 8 worker processes for the emulator suite, none on a GPU box."""
+    if HAS_GPU or os.environ.get("SMC_TEST_SERIAL") == "1":
+        return 0
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(0, min(8, n)) if n > 1 else 0
+
+
 def load_golden(name):
     with np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False) as f:
         return {k: f[k] for k in f.files}

@@ -861,7 +861,7 @@ def check_describe():
     pf = pa.SMC(fk=ssm.Bootstrap(ssm=mv, data=ymv), N=1 << 12, seed=1)
     buf = ctypes.create_string_buffer(256)
     _lib.check(_lib.lib().smc_filter_describe(pf._f, buf, 256))
-    assert buf.value.decode() == "k_ancestors<fused>+k_propagate_mv"
+    assert buf.value.decode() == "k_ancestors<fused>+k_propagate_mv [mv_chunks=1]"
 
 
 def check_two_level_stepwise(N=2048):
@@ -968,7 +968,9 @@ def check_unfused_path(golden, monkeypatch):
     monkeypatch.delenv("SMC_FORCE_UNFUSED")
     b = mk()
     b.run()
-    assert np.array_equal(a.logLts_islands, b.logLts_islands) and np.array_equal(a.X, b.X)
+    # same particles; the evidence is summed in (p, k) pairs on the two-level step and against the
+    # maximum on the flat one: equal up to the rounding of a sum of N terms
+    assert np.array_equal(a.X, b.X) and np.allclose(a.logLts_islands, b.logLts_islands, rtol=1e-13, atol=0)
 
 
 def check_small_filter_equals_general(golden, monkeypatch, full=True):

@@ -1,0 +1,58 @@
+#!/bin/bash
+# Run ON THE GPU BOX (gpurun): round-3 measurement batches.  $1 = tag, $2 = stages
+TAG=${1:-r04a}
+WHAT=${2:-"rates pytest smoke bench abrng"}
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd $R
+line() { python - "$1" <<'PY'
+import json,sys
+try:
+    d=json.loads([l for l in open(sys.argv[1]) if l.startswith('{')][-1]); r=d.get('roofline',{})
+    print(sys.argv[1].split('/')[-1], 'ms/step %.5f'%d['ms_per_step'], 'G/s %.2f'%(d['value']/1e9),
+          {k[-24:]:round(v['ms'],5) for k,v in r.get('per_kernel',{}).items()}, 'step_frac %.3f'%r.get('step_frac',0))
+    for k,v in d.get('other_workloads',{}).items():
+        print('   ', k, v.get('error') or ('%.2f G/s  %.4f ms/step  step_frac %.3f  %s frac %.3f' % (v['value']/1e9, v['ms_per_step'], v['step_frac'], v['kernel'][-20:], v['frac'])))
+    c=d.get('cpu_baseline')
+    if c: print('    cpu', c['kind'], '1 core %.1f M/s'%(c['value']/1e6), 'nproc', c['host']['nproc'], 'all cores %.1f M/s'%(c.get('all_cores',{}).get('value',0)/1e6))
+except Exception as e: print(sys.argv[1], 'FAILED', e, open(sys.argv[1]).read()[-600:])
+PY
+}
+for w in $WHAT; do case $w in
+rates)
+  (timeout 300 tools/micro/_build/rates > $O/rates.txt 2>&1; echo "rc=$?" >> $O/rates.txt); cat $O/rates.txt ;;
+pytest)
+  (timeout 2400 python -m pytest tests -m gpu -x -q --durations=15 > $O/pytest_gpu.log 2>&1; echo "rc=$?" >> $O/pytest_gpu.log)
+  tail -25 $O/pytest_gpu.log ;;
+smoke)
+  (timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "rc=$?" >> $O/smoke.log); tail -3 $O/smoke.log ;;
+bench)
+  /usr/bin/time -v timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_line.json 2> $O/bench_driver_line.err
+  line $O/bench_driver_line.json; grep -E "Elapsed|Maximum resident" $O/bench_driver_line.err
+  timeout 300 python bench.py --steps 1000 --warmup 50 --no-cpu-baseline --no-other-workloads > $O/bench_c2_k1000.json 2> $O/bench_c2_k1000.err
+  line $O/bench_c2_k1000.json ;;
+abrng)
+  # one box: table-free Box-Muller (rounds 1-2) | table-driven (this tree) | table-driven + Philox4x32-7
+  for rep in 1 2; do for lib in BM_LEGACY NEW PHILOX_ROUNDS=7; do
+    if [ $lib = NEW ]; then unset SMC_HIP_LIBRARY; else export SMC_HIP_LIBRARY=$R/particles_amd/lib/abl/libsmc_$lib.so; fi
+    timeout 300 python bench.py --steps 1000 --warmup 50 --no-cpu-baseline --no-other-workloads > $O/ab_${lib}_c2k1000_$rep.json 2>&1
+    timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-workloads > $O/ab_${lib}_c2k20_$rep.json 2>&1
+    timeout 300 python bench.py --workload c5 --steps 100 --warmup 10 > $O/ab_${lib}_c5_$rep.json 2>&1
+    if [ $rep = 1 ]; then
+      timeout 300 python bench.py --workload c4 --steps 50 --warmup 10 > $O/ab_${lib}_c4_$rep.json 2>&1
+      timeout 300 python bench.py --workload c4 --collapsed --steps 50 --warmup 10 > $O/ab_${lib}_c4coll_$rep.json 2>&1
+      timeout 300 python bench.py --workload c3 --steps 100 --warmup 10 > $O/ab_${lib}_c3_$rep.json 2>&1
+    fi
+  done; done; unset SMC_HIP_LIBRARY
+  for f in $O/ab_*.json; do line $f; done ;;
+prof)
+  EXTRA="--no-cpu-baseline --no-other-workloads" bash tools/gpu_profile.sh ${TAG}_c2 400 > $O/prof_c2.txt 2>&1; tail -40 $O/prof_c2.txt ;;
+prof_c3m)
+  EXTRA="--workload c3 --scheme multinomial" bash tools/gpu_profile.sh ${TAG}_c3m 100 > $O/prof_c3m.txt 2>&1; tail -40 $O/prof_c3m.txt ;;
+c3m)
+  for sc in multinomial stratified systematic; do
+    timeout 300 python bench.py --workload c3 --scheme $sc --steps 100 --warmup 10 > $O/bench_c3_$sc.json 2>&1; line $O/bench_c3_$sc.json; done ;;
+*)
+  echo "unknown stage $w" ;;
+esac; done
