@@ -318,6 +318,12 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model,
                       const smc_filter_opts* opts, const double* y_host,
                       smc_filter** out);
 int smc_filter_destroy(smc_filter* f);
+/* An independent copy of a filter in its current state: copy.deepcopy(pf) of the reference
+ * (theta-level resampling of SMC^2 deep-copies every duplicated filter, smc_samplers.py:319-361).
+ * Replay tapes are shared (caller-owned, read-only).  The copy's Philox streams are the source's
+ * (same seed, island ids, time): smc_filter_reseed gives it draws of its own from the next step on. */
+int smc_filter_clone(smc_filter* src, smc_filter** out);
+int smc_filter_reseed(smc_filter* f, uint64_t seed);
 /* Replay tapes (device): z (T, n_islands, N, dx) normals; u (T, n_islands, K)
  * with K = 1 (systematic: rand(1)), N (stratified: rand(N)) or N (multinomial:
  * the SORTED uniforms).  Slots of steps that do not resample are ignored. */

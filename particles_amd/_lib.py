@@ -92,6 +92,8 @@ SIGNATURES = {
     "smc_mvn_logpdf": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_dbl, P(c_dbl), c_i64, c_i64, c_vp]),
     "smc_filter_create": (c_int, [c_vp, P(SmcModel), P(SmcFilterOpts), P(c_dbl), P(c_vp)]),
     "smc_filter_destroy": (c_int, [c_vp]),
+    "smc_filter_clone": (c_int, [c_vp, P(c_vp)]),
+    "smc_filter_reseed": (c_int, [c_vp, c_u64]),
     "smc_filter_set_replay": (c_int, [c_vp, c_vp, c_vp]),
     "smc_filter_step": (c_int, [c_vp, c_i64]),
     "smc_filter_sync": (c_int, [c_vp]),

@@ -298,6 +298,33 @@ class SMC:
                 pass
             self._f = None
 
+    def __deepcopy__(self, memo):
+        """``copy.deepcopy(pf)`` as the reference's SMC^2 does it for every duplicated theta-particle
+        (smc_samplers.py:319-361 ``all_distinct``): the device filter is CLONED in its current state
+        (smc_filter_clone: particles, weights, summaries, step record) -- the handle is never shared, so
+        neither copy can free the other's filter.  Copies of a reference filter diverge because numpy's
+        global generator moves on; here the streams are a function of (seed, island, particle, t), so
+        the copy is re-keyed (smc_filter_reseed) and draws noise of its own from its next step on."""
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        shared = ("_f", "_ctx", "_tapes", "_keep")          # handles / read-only host arrays behind them
+        for k, v in self.__dict__.items():
+            if k in shared:
+                new.__dict__[k] = v
+            elif k in ("_cache", "_summ_cache"):
+                new.__dict__[k] = {} if k == "_cache" else None
+            else:
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        if getattr(self, "_fused", False) and self._f:
+            h = _lib.c_vp()
+            new._f = None                                  # (a failing clone must not leave the source's handle here)
+            check(lib().smc_filter_clone(self._f, ctypes.byref(h)))
+            new._f = h
+            new.seed = _default_seed()
+            check(lib().smc_filter_reseed(new._f, new.seed))
+        return new
+
     def _invalidate(self):
         self._cache = {}
         self._summ_cache = None

@@ -257,7 +257,7 @@ extern "C" void smc_test_log_pos(const double* x, int64_t n, double* out)
 }
 extern "C" void smc_test_bm_pair(const uint64_t* a, const uint64_t* b, int64_t n, double* z0, double* z1)
 {
-    for (int64_t i = 0; i < n; ++i) smc_bm_pair(smc_ntab, a[i], b[i], z0[i], z1[i]);
+    for (int64_t i = 0; i < n; ++i) smc_bm_pair(reinterpret_cast<const SmcD2*>(smc_ntab), a[i], b[i], z0[i], z1[i]);
 }
 extern "C" void smc_test_sincospi_02(const double* a, int64_t n, double* s, double* c)
 {

@@ -66,8 +66,8 @@ __device__ __forceinline__ double smc_u01_halfopen(u64 x)
 // ntab: the tables of smc_math.h's smc_bm_pair staged in LDS (SMC_NTAB_LDS + smc_ntab_stage + a
 // barrier at the top of the kernel).  -DSMC_BM_LEGACY (A/B builds only): the table-free
 // evaluation of rounds 1-2 (same uniforms, results equal to a few ulp).
-#define SMC_NTAB_LDS(name) __shared__ __attribute__((aligned(16))) double name[2 * SMC_NTAB_N]
-__device__ __forceinline__ void smc_normal_pair(const double* ntab, u64 seed, u32 pair, u32 t, u32 island,
+#define SMC_NTAB_LDS(name) __shared__ SmcD2 name[SMC_NTAB_LDS_N]
+__device__ __forceinline__ void smc_normal_pair(const SmcD2* ntab, u64 seed, u32 pair, u32 t, u32 island,
                                                 u32 stream, double& z0, double& z1)
 {
     u64 a, b;

@@ -1,6 +1,7 @@
 // smc_filter.hip -- host side of the fused on-device SMC step loop
 // (smc_filter_* of include/smc_hip.h).  The kernels and the description of the
 // two-kernel step are in smc_filter_kernels.h.
+#include <type_traits>
 #include <vector>
 
 #include "smc_filter_mv.h"
@@ -18,6 +19,7 @@ struct smc_filter {
     int kind, fk;
     i64 t_host;
     void* slab;            // one allocation holding every device array
+    size_t slab_bytes;
     bool use_graph;
     bool fused;            // k_ancestors<true> (no k_prepare launch)
     bool two_level;        // k_ancestors2 + tail-free k_propagate (two-level CDF, no intra-launch exchange)
@@ -348,6 +350,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
         return SMC_ERR_NOMEM;
     }
     f->slab = slab;
+    f->slab_bytes = off;
     // (from here on a failing HIP call must not leak the slab and the struct)
 #define F_CREATE_CHECK(expr)                                                                   \
     do {                                                                                       \
@@ -487,6 +490,77 @@ int smc_filter_destroy(smc_filter* f)
     }
     if (f->th_buf) (void)hipFree(f->th_buf);
     delete f;
+    return SMC_OK;
+}
+
+// An independent copy of a filter in its current state: what copy.deepcopy(pf) is to the reference
+// (smc_samplers.py:319-361: theta-level resampling of SMC^2 deep-copies every duplicated filter).
+// One slab allocation, one device-to-device copy, every slab pointer of the argument block re-based;
+// replay tapes (caller-owned, read-only) are shared.  Philox streams are a function of
+// (seed, island id, particle, t): a clone continues with the SAME draws as its source -- exactly
+// what deepcopy of a filter plus numpy's global generator gives the reference NOT; callers that
+// need the copies to diverge re-seed them (smc_filter_reseed).
+int smc_filter_clone(smc_filter* src, smc_filter** out)
+{
+    SMC_REQUIRE(src && out, "null argument");
+    smc_ctx* ctx = src->ctx;
+    SMC_HIP_CHECK(hipSetDevice(ctx->device));
+    void* slab = nullptr;
+    if (smc_malloc(ctx, src->slab_bytes, &slab) != SMC_OK) return SMC_ERR_NOMEM;
+    smc_filter* f = new smc_filter(*src);
+    f->slab = slab;
+    f->gexec[0] = f->gexec[1] = f->gexec[2] = nullptr;      // graphs hold the source's addresses
+    f->graph_failed = false;
+    f->prof = false;
+    f->prof_n = 0;
+    f->ev.clear();
+    f->ll_stage = nullptr;
+    f->th_buf = nullptr;
+    f->lwth = f->th = f->th_ess = nullptr;
+    const char* s0 = (const char*)src->slab;
+    const ptrdiff_t delta = (char*)slab - s0;
+    auto rebase = [&](auto*& p) {
+        const char* c = (const char*)p;
+        if (c && c >= s0 && c < s0 + src->slab_bytes) p = (std::remove_reference_t<decltype(p)>)((char*)p + delta);
+    };
+    FArgs& a = f->a;
+    rebase(a.X); rebase(a.lw); rebase(a.A); rebase(a.Q); rebase(a.Qpre); rebase(a.pm); rebase(a.ps); rebase(a.pss);
+    rebase(a.cq); rebase(a.tq); rebase(a.cnt); rebase(a.spart); rebase(a.summ); rebase(a.params); rebase(a.y);
+    rebase(a.mom); rebase(a.mpart); rebase(a.aux); rebase(a.info); rebase(a.hcnt); rebase(a.hlist); rebase(a.info2);
+    rebase(a.su); rebase(a.E); rebase(a.mvc); rebase(a.trace); rebase(a.pm2); rebase(a.ps2); rebase(a.pss2);
+    rebase(f->tmp);
+    hipStream_t st = ctx->stream;
+    hipError_t e = hipMemcpyAsync(slab, src->slab, src->slab_bytes, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess && src->th_buf) {
+        const size_t M = (size_t)a.n_islands, T = (size_t)a.T, nb = (M + TH_STRIDE + T) * 8;
+        e = hipMalloc(&f->th_buf, nb);
+        if (e == hipSuccess) e = hipMemcpyAsync(f->th_buf, src->th_buf, nb, hipMemcpyDeviceToDevice, st);
+        f->lwth = (double*)f->th_buf;
+        f->th = f->lwth + M;
+        f->th_ess = f->th + TH_STRIDE;
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        smc_set_error("smc_filter_clone: %s", hipGetErrorString(e));
+        if (f->th_buf) (void)hipFree(f->th_buf);
+        (void)smc_free(ctx, slab);
+        delete f;
+        return SMC_ERR_HIP;
+    }
+    if (hipHostMalloc((void**)&f->ll_stage, (size_t)a.n_islands * 8, hipHostMallocMapped) != hipSuccess)
+        f->ll_stage = nullptr;
+    (void)hipGetLastError();
+    *out = f;
+    return SMC_OK;
+}
+
+// New Philox key for the steps still to run (a clone that must not repeat its source's draws).
+int smc_filter_reseed(smc_filter* f, uint64_t seed)
+{
+    SMC_REQUIRE(f, "null filter");
+    f->a.seed = seed;
+    for (hipGraphExec_t& g : f->gexec)          // captured launches carry the old key by value
+        if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
     return SMC_OK;
 }
 
@@ -771,8 +845,11 @@ int smc_filter_set_state(smc_filter* f, int island, const double* X_host, const 
         smc_set_error("smc_filter_set_state: log-weights of a multivariate filter cannot be replaced");
         return SMC_ERR_STATE;
     }
-    if (f->a.pm2) {
-        smc_set_error("smc_filter_set_state: not available for the auxiliary filter on the two-level step");
+    if (f->fk == SMC_FK_APF) {
+        // the next step of an auxiliary filter resamples on lw + logeta(X) and resets the weights to a
+        // constant formed from both (core.py:299-313): replacing X or lw alone would leave the record's
+        // auxiliary normalisation and reset constant stale (one-launch filter and two-level step alike)
+        smc_set_error("smc_filter_set_state: not available for the auxiliary particle filter");
         return SMC_ERR_STATE;
     }
     SMC_HIP_CHECK(hipSetDevice(f->ctx->device));

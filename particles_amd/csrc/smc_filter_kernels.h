@@ -981,7 +981,9 @@ __device__ __forceinline__ F2Tile f2_tile_weights(const double (&lw)[4], u64 (&c
         const double e = smc_scale_pk(p[i], k[i], r.K);
         s1 += e;
         s2 = fma(e, e, s2);
-        q[i] = (u64)rint(e * 562949953421312.0);                       // 2^49
+        // q = rint(e 2^49) < 2^50 read off the mantissa of e 2^49 + 2^52 (one rounding, to the nearest
+        // even integer: the same value as (u64)rint(e * 2^49), in 2 instructions instead of 10)
+        q[i] = (u64)__double_as_longlong(fma(e, 562949953421312.0, 4503599627370496.0)) & 0x000FFFFFFFFFFFFFull;
     }
     s1 = smc_wave_sum(s1);
     s2 = smc_wave_sum(s2);
@@ -1080,9 +1082,6 @@ k_propagate(const FArgs av)
     const int b = (int)blockIdx.x, isl = (int)blockIdx.y;
     const int tid = (int)threadIdx.x;
     F_STAMP(0);
-    // the Box-Muller tables (6 KB, L2-resident) are the first thing requested: they are back, and in
-    // LDS, before the step record of a dependent launch has arrived
-    smc_ntab_stage(s_ntab, tid, SMC_BLOCK);
     double* info = a.info + (i64)isl * INFO_STRIDE;
     const i64 N = a.N;
     const FOwn own = f_own<!TAIL>(b, tid, N);
@@ -1118,11 +1117,23 @@ k_propagate(const FArgs av)
     // compiler wait for everything at the next write of its destination registers.)
     const u32 gisl = (u32)(a.island_offset + isl);
     double zs[OPT] = {0.0, 0.0, 0.0, 0.0};
-    const bool spec_z = a.tk >= 0 && !a.zt && own.na < N;
+    // tail-free launches over whole tiles: every thread owns 4 particles (no exec-mask region around
+    // the speculative block: the loads below stay in flight across the staging barrier)
+    constexpr bool ALL_IN = !TAIL && RAGGED == 0;
+    const bool mine = ALL_IN || own.na < N;
+    const bool spec_z = a.tk >= 0 && !a.zt && mine;
     double xg[OPT];
-    __syncthreads();               // s_ntab staged
-    if (SPEC && own.na < N) {      // A always holds valid indices (zeros before the first resampling)
-        load_anc(a.A + (i64)isl * N);
+    // ---- request order: step record (above), Box-Muller tables (6 KB, L2-resident), ancestor
+    // indices; the tables go to LDS as soon as they are back -- the indices are still on their way
+    SmcNtabRegs<SMC_BLOCK> ntr;
+    smc_ntab_fetch<SMC_BLOCK>(ntr, tid);
+#ifndef SMC_EMULATE
+    asm volatile("" ::: "memory");                    // (the table loads are ISSUED first: vmcnt retires in order)
+#endif
+    if (SPEC && mine) load_anc(a.A + (i64)isl * N);   // A always holds valid indices (zeros before the first resampling)
+    smc_ntab_store<SMC_BLOCK>(ntr, s_ntab, tid);
+    __syncthreads();
+    if (SPEC && mine) {
         if (spec_z)
             smc_normal_pair(s_ntab, a.seed, (u32)(own.na >> 1), (u32)a.tk, gisl, SMC_STREAM_NORMAL, zs[0], zs[1]);
         const double* Xs = a.X + (i64)(a.par ^ 1) * a.xslot + (i64)isl * N;

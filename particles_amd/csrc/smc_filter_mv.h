@@ -116,7 +116,7 @@ k_propagate_mv(const FArgs av, const double* __restrict__ C)
     SMC_NTAB_LDS(s_ntab);
     const int b = (int)blockIdx.x, isl = (int)blockIdx.y;
     const int tid = (int)threadIdx.x;
-    smc_ntab_stage(s_ntab, tid, SMC_BLOCK);        // (the barrier behind the matrices covers it)
+    smc_ntab_stage<SMC_BLOCK>(s_ntab, tid);       // (the barrier behind the matrices covers it)
     const int lane = tid & 63, wv = tid >> 6;
     const int g = lane >> 4, pn = lane & 15;
     double* info = a.info + (i64)isl * INFO_STRIDE;

@@ -36,7 +36,7 @@ k_filter_small(const FArgs av, const int nsteps)
     const int isl = (int)blockIdx.y;
     const int tid = (int)threadIdx.x;
     if (tid < SMC_SM) { smu[tid] = 0ull; smd[tid] = 0.0; smm[tid] = -INFINITY; }
-    smc_ntab_stage(s_ntab, tid, BS);
+    smc_ntab_stage<BS>(s_ntab, tid);
     __syncthreads();
     const i64 N = a.N;
     double* info = a.info + (i64)isl * INFO_STRIDE;

@@ -148,17 +148,48 @@ __host__ __device__ __forceinline__ double smc_log_pos(double x)
 // tools/gen_normal_tables.py makes the tables (smc_normal_tab.h, 6 KB); kernels stage them in LDS
 // (smc_ntab_stage) -- the two lookups of a pair are lane-random 16-byte reads.
 // ---------------------------------------------------------------------------
-#define SMC_NTAB_DECL SMC_CONST
+#define SMC_NTAB_DECL SMC_CONST __attribute__((aligned(16)))
 #include "smc_normal_tab.h"
 
-// stage the tables in LDS (2 * SMC_NTAB_N doubles): every thread of the workgroup calls, a
-// barrier must follow before the first smc_bm_pair
-__device__ __forceinline__ void smc_ntab_stage(double* lds, const int tid, const int nthreads)
+// one table entry: 16 bytes, read with one ds_read_b128
+struct __attribute__((aligned(16))) SmcD2 {
+    double x, y;
+};
+// stage the tables in LDS (SMC_NTAB_N entries): every thread of the workgroup calls, a barrier
+// must follow before the first smc_bm_pair.  Two phases so that a kernel can have its own first
+// loads in flight between them: smc_ntab_fetch issues the (L2-resident) table loads into
+// registers, smc_ntab_store writes them to LDS.  NTH threads; 385 entries: at most NE per thread.
+template <int NTH>
+struct SmcNtabRegs {
+    static constexpr int NE = (SMC_NTAB_N + NTH - 1) / NTH;
+    SmcD2 e[NE];
+};
+template <int NTH>
+__device__ __forceinline__ void smc_ntab_fetch(SmcNtabRegs<NTH>& r, const int tid)
 {
-    for (int i = tid; i < SMC_NTAB_N; i += nthreads) {
-        lds[2 * i] = smc_ntab[2 * i];
-        lds[2 * i + 1] = smc_ntab[2 * i + 1];
+    const SmcD2* src = reinterpret_cast<const SmcD2*>(smc_ntab);
+#pragma unroll
+    for (int k = 0; k < SmcNtabRegs<NTH>::NE; ++k) {
+        const int i = tid + k * NTH;
+        r.e[k] = src[i < SMC_NTAB_N ? i : SMC_NTAB_N - 1];       // (unconditional: clamped address)
     }
+}
+// (the LDS array has SMC_NTAB_LDS_N >= NE * NTH entries: loads and stores are unconditional -- behind
+//  a condition the compiler sinks each load next to its store and waits for everything in between)
+#define SMC_NTAB_LDS_N 512
+template <int NTH>
+__device__ __forceinline__ void smc_ntab_store(const SmcNtabRegs<NTH>& r, SmcD2* lds, const int tid)
+{
+    static_assert(SmcNtabRegs<NTH>::NE * NTH <= SMC_NTAB_LDS_N, "LDS table too small for this workgroup size");
+#pragma unroll
+    for (int k = 0; k < SmcNtabRegs<NTH>::NE; ++k) lds[tid + k * NTH] = r.e[k];
+}
+template <int NTH>
+__device__ __forceinline__ void smc_ntab_stage(SmcD2* lds, const int tid)
+{
+    SmcNtabRegs<NTH> r;
+    smc_ntab_fetch<NTH>(r, tid);
+    smc_ntab_store<NTH>(r, lds, tid);
 }
 
 SMC_CONST double smc_k_bm[16] = {
@@ -183,7 +214,7 @@ __device__ __forceinline__ double smc_rsq(double x) { return __builtin_amdgcn_rs
 
 // (z0, z1) = sqrt(-2 log u1) (cos, sin)(2 pi u2), u1 = ((a >> 12) + 1/2) 2^-52, u2 likewise from b;
 // tab: the staged tables (LDS)
-__host__ __device__ __forceinline__ void smc_bm_pair(const double* tab, const u64 a, const u64 b,
+__host__ __device__ __forceinline__ void smc_bm_pair(const SmcD2* tab, const u64 a, const u64 b,
                                                      double& z0, double& z1)
 {
     const double* K = smc_k_bm;
@@ -194,7 +225,8 @@ __host__ __device__ __forceinline__ void smc_bm_pair(const double* tab, const u6
     const double mm = smc_frexp_m(u, e);                        // u = mm 2^e, mm in [1/2, 1)
     const u32 hi = (u32)((u64)__double_as_longlong(mm) >> 32);
     const u32 j = (((hi >> 12) & 0xFFu) + 1u) >> 1;             // nearest of 129 nodes of 2 mm in [1, 2]
-    const double invc2 = tab[2 * j], logc = tab[2 * j + 1];
+    const SmcD2 lt = tab[j];
+    const double invc2 = lt.x, logc = lt.y;
     const double r = fma(mm, invc2, -1.0);
     const double ed = (double)(e - 1 + (j >= (u32)SMC_NTAB_JUP ? 1 : 0));
     double p = SMC_FMA_K(r, K[0], K[1]);
@@ -220,7 +252,8 @@ __host__ __device__ __forceinline__ void smc_bm_pair(const double* tab, const u6
     const double z = x * x;
     const double sx = fma(x * z, SMC_FMA_K(z, K[9], K[10]), x);                 // sin x
     const double dc = z * SMC_FMA_K(SMC_FMA_K(z, K[11], K[12]), z, K[13]);      // cos x - 1
-    const double si = tab[2 * (SMC_NTAB_SC + i)], ci = tab[2 * (SMC_NTAB_SC + i) + 1];
+    const SmcD2 st = tab[SMC_NTAB_SC + i];
+    const double si = st.x, ci = st.y;
     const double sn = fma(ci, sx, fma(si, dc, si));
     const double cs = fma(-si, sx, fma(ci, dc, ci));
     z0 = g * cs;

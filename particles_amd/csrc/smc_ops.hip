@@ -921,7 +921,7 @@ k_normal_rvs(const double* loc, i64 ls, const double* scale, i64 ss, const doubl
              u32 t, u32 island, i64 N, double* out)
 {
     SMC_NTAB_LDS(s_ntab);
-    smc_ntab_stage(s_ntab, (int)threadIdx.x, SMC_BLOCK);
+    smc_ntab_stage<SMC_BLOCK>(s_ntab, (int)threadIdx.x);
     __syncthreads();
     const i64 p = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;   // pair index
     const i64 n0 = 2 * p;
@@ -1009,7 +1009,7 @@ __global__ void __launch_bounds__(SMC_BLOCK)
 k_philox_fill(int normal, u64 seed, u32 t, u32 island, i64 n, double* out)
 {
     SMC_NTAB_LDS(s_ntab);
-    smc_ntab_stage(s_ntab, (int)threadIdx.x, SMC_BLOCK);
+    smc_ntab_stage<SMC_BLOCK>(s_ntab, (int)threadIdx.x);
     __syncthreads();
     const i64 p = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;
     const i64 n0 = 2 * p;
@@ -1061,7 +1061,7 @@ k_mvn_rvs(const double* loc, i64 loc_rows, double scale, const double* L, const 
     __shared__ double sL[MVN_MAXD * MVN_MAXD];
     SMC_NTAB_LDS(s_ntab);
     for (int i = (int)threadIdx.x; i < d * d; i += SMC_BLOCK) sL[i] = L[i];
-    smc_ntab_stage(s_ntab, (int)threadIdx.x, SMC_BLOCK);
+    smc_ntab_stage<SMC_BLOCK>(s_ntab, (int)threadIdx.x);
     __syncthreads();
     const i64 idx = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;
     if (idx >= N * d) return;

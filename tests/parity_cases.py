@@ -1578,6 +1578,13 @@ def check_apf_fused(golden, apf2_cases=((2048, "systematic", 0.7), (4096, "strat
             assert np.allclose(ps.hist.wgts[t].lw, o["hist"]["lw"][t], rtol=1e-11, atol=1e-11)
         with pytest.raises(Exception):
             pf.set_state(lw=np.zeros(N2))
+    # ... and on the one-launch filter (N <= 1024) as well: the record's auxiliary normalisation and
+    # reset constant come from lw + logeta(X), replacing either alone must be refused, not half-done
+    small = pa.SMC(fk=ssm.AuxiliaryPF(ssm=ssm.StochVol(), data=y[:10]), N=500, seed=2)
+    small.step_async(4)
+    for kw in (dict(lw=np.zeros(500)), dict(X=np.zeros(500))):
+        with pytest.raises(Exception, match="auxiliary"):
+            small.set_state(**kw)
     # multiSMC: batched as islands where the APF is fused, run by run where it is not (Philox
     # multinomial at N <= 1024 is not on the one-launch filter)
     fk_apf = ssm.AuxiliaryPF(ssm=ssm.StochVol(), data=y[:15])

@@ -163,3 +163,80 @@ def test_reference_apf_runs_fused_through_the_adapter(ref):
     assert got[1000]._fused and describe(got[1000]) == "k_filter_small"
     assert got[2048]._fused and describe(got[2048]) == "k_reduce2+k_ancestors2+k_propagate"
     assert got[3000]._fused and describe(got[3000]) == "k_reduce2+k_ancestors2+k_propagate"
+
+
+def test_deepcopy_clones_the_device_filter(ref):
+    """copy.deepcopy of a device filter (what the reference's theta-level resampling does to every
+    duplicated particle filter, smc_samplers.py:319-361): an independent filter in the same state --
+    same particles, weights and evidence now, its own handle (destroying one leaves the other
+    usable), its own noise from the next step on."""
+    import copy
+    import particles_amd as pa
+    from particles_amd import kalman, state_space_models as ssm
+    y = [np.array([0.3 * np.sin(t)]) for t in range(20)]
+    for N in (300, 3000):                                   # one-launch filter / two-level step
+        pf = pa.SMC(fk=ssm.Bootstrap(ssm=kalman.LinearGauss(sigmaX=0.8, sigmaY=0.4, rho=0.9), data=y), N=N, seed=7)
+        for _ in range(8):
+            next(pf)
+        cp = copy.deepcopy(pf)
+        assert cp._f is not pf._f and cp._f.value != pf._f.value and cp.t == pf.t == 8
+        assert np.array_equal(cp.X, pf.X) and np.array_equal(cp.wgts.lw, pf.wgts.lw) and cp.logLt == pf.logLt
+        assert cp.summaries.ESSs == pf.summaries.ESSs and cp.summaries is not pf.summaries
+        ref_run = pa.SMC(fk=ssm.Bootstrap(ssm=kalman.LinearGauss(sigmaX=0.8, sigmaY=0.4, rho=0.9), data=y), N=N, seed=7)
+        ref_run.run()
+        for _ in range(12):
+            next(pf)
+            next(cp)
+        assert pf.logLt == ref_run.logLt and np.array_equal(pf.X, ref_run.X)       # the source is undisturbed
+        assert cp.logLt != pf.logLt and abs(cp.logLt - pf.logLt) < 3.0             # the copy drew its own noise
+        del pf                                                                      # frees the source's filter only
+        assert np.isfinite(cp.X).all() and len(cp.summaries.ESSs) == 20
+
+
+def test_reference_smc2_runs_on_device_filters_under_install(ref):
+    """The reference's own SMC2 (smc_samplers.py:1038-1167), unchanged, after adapter.install():
+    alg_instance's particles.SMC(...) yields device filters, logG steps them one by one, the
+    theta-level resampling deep-copies the duplicated ones (FancyList / all_distinct) and the PMCMC
+    move builds fresh ones.  The run must complete, resample-move at least once, and its posterior
+    and evidence must agree with the same algorithm on the reference's NumPy filters."""
+    import particles_amd as pa
+    from particles_amd import adapter
+    particles, rk, dists = ref["particles"], ref["kalman"], ref["dists"]
+    from particles import smc_samplers as ssp
+    np.random.seed(4)
+    model = rk.LinearGauss(sigmaX=1.0, sigmaY=0.4, rho=0.8)
+    x, y = model.simulate(25)
+    prior = dists.StructDist({"rho": dists.Uniform(a=0.3, b=0.99), "sigmaY": dists.Gamma(a=2.0, b=4.0)})
+
+    def run(seed):
+        np.random.seed(seed)
+        fk = ssp.SMC2(ssm_cls=rk.LinearGauss, prior=prior, data=y, init_Nx=64, len_chain=3, wastefree=False)
+        alg = particles.SMC(fk=fk, N=24, verbose=False)
+        alg.run()
+        return alg
+
+    base = run(11)                                   # NumPy filters
+    made = []
+    real_init = pa.SMC.__init__
+
+    def spy(self, *a, **kw):
+        real_init(self, *a, **kw)
+        made.append(self._fused)
+    adapter.install()
+    pa.SMC.__init__ = spy
+    try:
+        dev = run(11)
+        outer_is_reference = not isinstance(dev, pa.SMC)
+    finally:
+        pa.SMC.__init__ = real_init
+        adapter.uninstall()
+    assert outer_is_reference                        # SMC2 itself is a Feynman-Kac object we do not reinterpret
+    assert len(made) >= 24 and all(made)             # every inner filter is a fused device filter
+    assert all(isinstance(pf, pa.SMC) for pf in dev.X.pfs)
+    assert len({pf._f.value for pf in dev.X.pfs}) == 24          # all distinct handles after the deep copies
+    assert sum(dev.summaries.rs_flags) >= 1 and sum(base.summaries.rs_flags) >= 1
+    assert np.isfinite(dev.logLt) and abs(dev.logLt - base.logLt) < 3.0, (dev.logLt, base.logLt)
+    for k in ("rho", "sigmaY"):
+        mb = np.average(base.X.theta[k], weights=base.W)
+        md = np.average(dev.X.theta[k], weights=dev.W)
+        assert abs(mb - md) < 0.25, (k, mb, md)

@@ -82,6 +82,44 @@ def test_sincospi_02(emu):
     assert s[-11] == 0.0 and c[-11] == 1.0 and s[-9] == 1.0 and c[-7] == -1.0
 
 
+def test_box_muller_pair_table_driven(emu):
+    """smc_bm_pair (table-driven log / sin / cos, rsq-based sqrt) on 2 x 52 random bits against the
+    definition in extended precision: z = sqrt(-2 log u1) (cos, sin)(2 pi u2), u = (k + 1/2) 2^-52.
+    Error budget: |dz| <= 6e-16 x radius (unit-circle error 2e-16 + radius 4 ulp); moments of N(0, 1)."""
+    rng = np.random.default_rng(0)
+    n = 1500000
+    a = rng.integers(0, 2 ** 64, n, dtype=np.uint64)
+    b = rng.integers(0, 2 ** 64, n, dtype=np.uint64)
+    edge = np.array([0, (1 << 64) - 1, 1 << 12, 1 << 63, (1 << 63) - 1, (1 << 63) + (1 << 12)], dtype=np.uint64)
+    a[:6] = edge
+    b[6:12] = edge
+    ne = 12 + 2000
+    a[12:1012] = np.uint64((1 << 64) - 1) - (rng.integers(0, 2 ** 30, 1000, dtype=np.uint64) << np.uint64(12))   # u1 -> 1
+    a[1012:2012] = rng.integers(0, 2 ** 20, 1000, dtype=np.uint64) << np.uint64(12)                              # u1 -> 0
+    # every node boundary of the log table: mantissas at (2 j + 1) / 256 +- 1 ulp
+    z0 = np.empty(n)
+    z1 = np.empty(n)
+    pu = ctypes.POINTER(ctypes.c_uint64)
+    emu.smc_test_bm_pair(a.ctypes.data_as(pu), b.ctypes.data_as(pu), ctypes.c_int64(n), _p(z0), _p(z1))
+    ld = np.longdouble
+    u1 = ((a >> np.uint64(12)).astype(ld) + ld(0.5)) * ld(2.0) ** -52
+    u2 = ((b >> np.uint64(12)).astype(ld) + ld(0.5)) * ld(2.0) ** -52
+    pi_l = ld("3.14159265358979323846264338327950288")
+    r = np.sqrt(-2 * np.log(u1))
+    w0, w1 = r * np.cos(2 * pi_l * u2), r * np.sin(2 * pi_l * u2)
+    rr = r.astype(np.float64)
+    assert np.all(np.isfinite(z0)) and np.all(np.isfinite(z1))
+    assert np.max(np.abs(z0 - w0).astype(np.float64) / rr) < 6e-16
+    assert np.max(np.abs(z1 - w1).astype(np.float64) / rr) < 6e-16
+    rad = np.sqrt(z0.astype(ld) ** 2 + z1.astype(ld) ** 2)
+    assert float(np.max(np.abs(rad / r - 1))) < 5 * 2.0 ** -53
+    zz = np.concatenate([z0[ne:], z1[ne:]])
+    m = zz.size
+    assert abs(zz.mean()) < 4 / np.sqrt(m) and abs(zz.var() - 1) < 4 * np.sqrt(2 / m)
+    assert abs(np.mean(zz ** 3)) < 4 * np.sqrt(15 / m) and abs(np.mean(zz ** 4) - 3) < 4 * np.sqrt(96 / m)
+    assert abs(np.mean(z0[ne:] * z1[ne:])) < 4 / np.sqrt(n)
+
+
 def test_indep_prior_logpdf_matches_scipy():
     """smc2.IndepPrior.logpdf: closed forms in NumPy (no scipy import on the SMC^2 hot path) against
     scipy.stats, support boundaries included."""

@@ -28,8 +28,8 @@ pytest)
 smoke)
   (timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "rc=$?" >> $O/smoke.log); tail -3 $O/smoke.log ;;
 bench)
-  /usr/bin/time -v timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_line.json 2> $O/bench_driver_line.err
-  line $O/bench_driver_line.json; grep -E "Elapsed|Maximum resident" $O/bench_driver_line.err
+  SECONDS=0; timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_line.json 2> $O/bench_driver_line.err; echo "driver line wall ${SECONDS}s"
+  line $O/bench_driver_line.json; tail -3 $O/bench_driver_line.err
   timeout 300 python bench.py --steps 1000 --warmup 50 --no-cpu-baseline --no-other-workloads > $O/bench_c2_k1000.json 2> $O/bench_c2_k1000.err
   line $O/bench_c2_k1000.json ;;
 abrng)
