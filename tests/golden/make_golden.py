@@ -260,6 +260,40 @@ def main():
     dd["mv_rvs"] = mv.rvs(size=40)
     out["dists"] = dd
 
+    # --- SMC^2 (smc_samplers.py:1038-1167): R independent runs of the REFERENCE's algorithm on one data
+    # set -- standard (not waste-free) resample-move with len_chain - 1 random-walk steps, the form the
+    # device implements -- recorded run by run: the device's runs must be draws from the same
+    # distributions (tests compare means within 3 standard errors)
+    if "smc2_ref" in sys.argv[1:] or not sys.argv[1:]:
+        from particles import smc_samplers as ssp
+        R, T, N, Nx, len_chain = 24, 40, 64, 64, 4
+        np.random.seed(4)
+        x, y = kalman.LinearGauss(sigmaX=1.0, sigmaY=0.4, rho=0.8).simulate(T)
+        prior = dists.StructDist({"rho": dists.Uniform(a=0.3, b=0.99), "sigmaY": dists.Gamma(a=2.0, b=4.0)})
+        rec = dict(logLt=[], m_rho=[], m_sigmaY=[], s_rho=[], s_sigmaY=[], ESSs=[], rs_flags=[], Nx_final=[])
+        for r in range(R):
+            np.random.seed(1000 + r)
+            fk = ssp.SMC2(ssm_cls=kalman.LinearGauss, prior=prior, data=y, init_Nx=Nx, len_chain=len_chain,
+                          wastefree=False, ar_to_increase_Nx=-1.0)
+            alg = particles.SMC(fk=fk, N=N, ESSrmin=0.5)
+            alg.run()
+            W = alg.W
+            for k in ("rho", "sigmaY"):
+                m = np.sum(W * alg.X.theta[k])
+                rec["m_" + k].append(m)
+                rec["s_" + k].append(np.sqrt(np.sum(W * (alg.X.theta[k] - m) ** 2)))
+            rec["logLt"].append(alg.logLt)
+            rec["ESSs"].append(alg.summaries.ESSs)
+            rec["rs_flags"].append(alg.summaries.rs_flags)
+            rec["Nx_final"].append(alg.X.pfs[0].N)
+            print("smc2_ref run", r, alg.logLt, rec["m_rho"][-1], rec["m_sigmaY"][-1], sum(alg.summaries.rs_flags), flush=True)
+        kal = kalman.Kalman(ssm=kalman.LinearGauss(sigmaX=1.0, sigmaY=0.4, rho=0.8), data=y)
+        kal.filter()
+        out["smc2_ref"] = dict(y=np.array(y), R=R, T=T, N=N, Nx=Nx, len_chain=len_chain, ESSrmin=0.5,
+                               prior_rho=np.array([0.3, 0.99]), prior_sigmaY=np.array([2.0, 4.0]),
+                               sigmaX=1.0, true_rho=0.8, true_sigmaY=0.4, kalman_loglik_at_truth=np.sum(kal.logpyt),
+                               **{k: np.array(v, dtype=float) for k, v in rec.items()})
+
     only = sys.argv[1:]              # optional: names of the fixtures to (re)write
     for name, case in out.items():
         if only and name not in only:

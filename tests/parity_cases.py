@@ -1450,6 +1450,61 @@ def check_smc2(Ntheta=64, Nx=128, T=30, seed=3, big_Nx=(), big_N=16, big_T=12):
     assert abs(e.posterior_mean()["sigmaY"] - sig) < 0.3
 
 
+def check_smc2_vs_reference(golden, R=24, sharded=False, tol_se=3.0):
+    """SMC^2 pinned to the REFERENCE's SMC^2 (smc_samplers.py:1038-1167): tests/golden/smc2_ref.npz holds
+    24 independent runs of particles.SMC(fk=SMC2(kalman.LinearGauss, StructDist{rho ~ U(0.3, 0.99),
+    sigmaY ~ Gamma(2, 4)}, init_Nx=64, len_chain=4, wastefree=False), N=64) on one simulated data set,
+    run by run (tests/golden/make_golden.py smc2_ref).  The device class runs the same algorithm --
+    same prior, N_theta, N_x, ESS threshold, 3 random-walk Metropolis steps per move calibrated on the
+    weighted theta-particles -- R times with different seeds; every summary must be a draw from the same
+    distribution: means within `tol_se` standard errors (both sides' Monte Carlo error counted) for the
+    evidence of the whole model, the posterior mean and sd of each parameter, the ESS trajectory and the
+    number of resample-move events.  A wrong weight update, move or exchange shifts these by many SEs."""
+    from particles_amd import smc2
+    g = golden("smc2_ref")
+    y = [np.atleast_1d(v) for v in np.squeeze(g["y"])]
+    T, N, Nx = int(g["T"]), int(g["N"]), int(g["Nx"])
+    prior = smc2.IndepPrior(rho=("uniform", float(g["prior_rho"][0]), float(g["prior_rho"][1])),
+                            sigmaY=("gamma", float(g["prior_sigmaY"][0]), float(g["prior_sigmaY"][1])))
+    cls = smc2.ShardedSMC2 if sharded else smc2.SMC2
+    rec = {k: [] for k in ("logLt", "m_rho", "m_sigmaY", "s_rho", "s_sigmaY", "ESSs", "nmoves")}
+    for r in range(R):
+        alg = cls(ssm_cls=lambda rho, sigmaY: kalman.LinearGauss(sigmaX=float(g["sigmaX"]), sigmaY=sigmaY, rho=rho),
+                  prior=prior, data=y, init_Nx=Nx, N=N, ESSrmin=float(g["ESSrmin"]), nmcmc=int(g["len_chain"]) - 1,
+                  seed=500 + r, sync_every=8)
+        alg.run()
+        assert alg.t == T and len(alg.ESSs) == T
+        m, sd = alg.posterior_mean(), alg.posterior_sd()
+        rec["logLt"].append(alg.logLt)
+        for k in ("rho", "sigmaY"):
+            rec["m_" + k].append(m[k])
+            rec["s_" + k].append(sd[k])
+        rec["ESSs"].append(alg.ESSs)
+        rec["nmoves"].append(len(alg.move_times))
+    ref = {k: np.asarray(g[k], dtype=float) for k in ("logLt", "m_rho", "m_sigmaY", "s_rho", "s_sigmaY", "ESSs")}
+    ref["nmoves"] = np.asarray(g["rs_flags"], dtype=float).sum(axis=1)
+    report = {}
+
+    def same_mean(name, a, b):
+        a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+        se = np.sqrt(a.var(ddof=1) / a.size + b.var(ddof=1) / b.size)
+        z = (a.mean() - b.mean()) / max(se, 1e-300)
+        report[name] = (round(float(a.mean()), 4), round(float(b.mean()), 4), round(float(z), 2))
+        return abs(z) <= tol_se
+
+    ok = [same_mean(k, rec[k], ref[k]) for k in ("logLt", "m_rho", "m_sigmaY", "s_rho", "s_sigmaY", "nmoves")]
+    E, Er = np.asarray(rec["ESSs"]), ref["ESSs"]                        # (R, T) ESS after every step
+    ok.append(same_mean("ESS_mean", E.mean(axis=1), Er.mean(axis=1)))
+    for t in (1, T // 4, T // 2, T - 1):
+        ok.append(same_mean("ESS_t%d" % t, E[:, t], Er[:, t]))
+    print("smc2 vs reference (device mean, reference mean, z):", report)
+    # 11 comparisons at 3 SE: a correct implementation fails one of them with probability ~3 %
+    # -> allow ONE excursion up to 4 SE, none beyond
+    zs = np.array([abs(v[2]) for v in report.values()])
+    assert np.all(zs <= tol_se + 1.0) and np.sum(zs > tol_se) <= 1, report
+    return report
+
+
 def check_generic_path(golden):
     """A user-defined FeynmanKac in Python: template method with device ops."""
     g = golden("kalman_toy")

@@ -478,6 +478,13 @@ def test_smc2_device_theta_level():
     pc.check_smc2(Ntheta=256, Nx=512, T=60, big_Nx=(2048, 3000))
 
 
+@pytest.mark.parametrize("sharded", [False, True])
+def test_smc2_pinned_to_the_reference(golden, sharded):
+    """Device SMC^2 (one-GPU class and the sharded class at world 1) against 24 recorded runs of the
+    reference's own SMC2: evidence, posterior moments, ESS trajectory, number of moves within 3 SE."""
+    pc.check_smc2_vs_reference(golden, R=48, sharded=sharded)
+
+
 def test_partial_history_syncs_at_save_times_only():
     pc.check_partial_history(N=100000, T=40)
 
