@@ -103,10 +103,12 @@ def reference_available():
     return os.path.isdir(os.path.join(REFERENCE_DIR, "particles"))
 
 
-def _cpu_worker(kind, N, nsteps, nruns, start_at):
+def _cpu_worker(kind, N, nsteps, nruns, gate):
     """One worker PROCESS of the CPU baseline (bench.py --cpu-worker ...): `nruns` independent
     bootstrap filters of N particles over the first `nsteps` observations, one after the other,
-    on one core.  Prints {"t0", "t1", "seconds", "logLt"}; the parent aggregates."""
+    on one core.  gate: a directory -- the worker drops a `ready.<pid>` file when its imports are
+    done and starts when the parent creates `go` (so that all workers run at the same time).
+    Prints {"t0", "t1", "seconds", "logLt"}; the parent aggregates."""
     for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
         os.environ[k] = "1"
     if kind == "reference":
@@ -131,8 +133,11 @@ def _cpu_worker(kind, N, nsteps, nruns, start_at):
             t0 = time.perf_counter()
             out = orc.run_filter(orc.ToySSM(0.2), y[:nsteps], N, "systematic", 0.5)
             return time.perf_counter() - t0, float(out["final_logLt"])
-    while time.time() < start_at:
-        time.sleep(0.005)
+    if gate:
+        open(os.path.join(gate, "ready.%d" % os.getpid()), "w").close()
+        t_wait = time.time()
+        while not os.path.exists(os.path.join(gate, "go")) and time.time() - t_wait < 300:
+            time.sleep(0.002)
     t0 = time.time()
     secs, lls = 0.0, []
     for r in range(nruns):
@@ -142,19 +147,30 @@ def _cpu_worker(kind, N, nsteps, nruns, start_at):
     print(json.dumps({"t0": t0, "t1": time.time(), "seconds": secs, "logLt": lls}), flush=True)
 
 
-def _spawn_workers(kind, N, nsteps, runs_per_worker, nworkers, lead_s):
-    start_at = time.time() + lead_s
+def _spawn_workers(kind, N, nsteps, runs_per_worker, nworkers):
+    import tempfile
+    gate = tempfile.mkdtemp(prefix="smc_cpu_gate_") if nworkers > 1 else ""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-worker", kind, str(N), str(nsteps),
-           str(runs_per_worker), repr(start_at)]
+           str(runs_per_worker), gate]
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
     procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env)
              for _ in range(nworkers)]
+    if gate:
+        t_wait = time.time()        # all imports done (or a worker died / 120 s passed): go
+        while time.time() - t_wait < 120:
+            if sum(f.startswith("ready.") for f in os.listdir(gate)) >= nworkers or any(p.poll() is not None for p in procs):
+                break
+            time.sleep(0.01)
+        open(os.path.join(gate, "go"), "w").close()
     outs = []
     for p in procs:
         so, se = p.communicate()
         if p.returncode != 0:
             raise RuntimeError("cpu worker failed: " + se[-1500:])
         outs.append(json.loads(so.strip().splitlines()[-1]))
+    if gate:
+        import shutil
+        shutil.rmtree(gate, ignore_errors=True)
     return outs
 
 
@@ -180,24 +196,28 @@ def cpu_baseline(N, nsteps, all_cores=True, kind=None):
             "oracle.run_filter (NumPy restatement of particles.SMC + C inverse_cdf)")
     sample = ("%s; N=2^%d, first %d steps of the same data (np.random.seed(42); simulate), run seed 123; "
               "cost per step is flat in T" % (what, int(np.log2(N)), nsteps))
-    one = _spawn_workers(kind, N, nsteps, 1, 1, 0.0)[0]
+    one = _spawn_workers(kind, N, nsteps, 1, 1)[0]
     out = {"value": N * nsteps / one["seconds"], "unit": "particle-steps/s", "cores": 1, "kind": kind,
            "sample": sample, "seconds": one["seconds"], "logLt": one["logLt"][0],
            "host": {"nproc": nproc, "cpu": _cpu_name()},
            "reference_build_container": committed}
     if all_cores and nproc > 1:
         # independent runs over worker processes: what multiSMC(nruns, nprocs=nproc) does (core.py:431,
-        # utils.py:158-186); one run of N = 2^18, 20 steps per core (BASELINE.md section 3's shape), at
-        # least 16 runs in all; workers start together after their imports
-        Na, Ta = min(N, 1 << 18), min(nsteps, 20)
+        # utils.py:158-186): runs of N = 2^18 (BASELINE.md section 3's shape), at least 16 in all and at
+        # least one per core, long enough (about 10^8 particle-steps per worker) that process start-up
+        # and scheduling noise do not matter; the workers start together once all have imported
+        Na = min(N, 1 << 18)
+        Ta = max(1, min(nsteps, int(1e8 // Na) if kind == "port" else int(3e7 // Na)))
         per = max(1, -(-16 // nproc))
-        ws = _spawn_workers(kind, Na, Ta, per, nproc, 4.0 + 0.02 * nproc)
+        ws = _spawn_workers(kind, Na, Ta, per, nproc)
         wall = max(w["t1"] for w in ws) - min(w["t0"] for w in ws)
         out["all_cores"] = {
             "value": nproc * per * Na * Ta / wall, "unit": "particle-steps/s", "cores": nproc, "kind": kind,
             "seconds": wall, "runs": nproc * per,
+            "sum_of_worker_rates": float(sum(per * Na * Ta / (w["t1"] - w["t0"]) for w in ws)),
+            "start_skew_s": max(w["t0"] for w in ws) - min(w["t0"] for w in ws),
             "sample": "%d independent runs of (N=2^%d, %d steps) over %d worker processes, one per core "
-                      "(multiSMC(nruns=%d, nprocs=%d) shape); wall = last end - first start"
+                      "(multiSMC(nruns=%d, nprocs=%d) shape); value = all work / (last end - first start)"
                       % (nproc * per, int(np.log2(Na)), Ta, nproc, nproc * per, nproc),
             "logLt_sd": float(np.std([l for w in ws for l in w["logLt"]]))}
     return out
@@ -393,8 +413,8 @@ def other_workloads(K=20, W=10, R=7, shrink=0):
 
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
-        kind, N, nsteps, nruns, start_at = sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), float(sys.argv[6])
-        return _cpu_worker(kind, N, nsteps, nruns, start_at)
+        kind, N, nsteps, nruns = sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+        return _cpu_worker(kind, N, nsteps, nruns, sys.argv[6] if len(sys.argv) > 6 else "")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)

@@ -379,6 +379,9 @@ int smc_filter_theta_enable(smc_filter* f, double ess_rmin);
  * the theta-level ESS after every step. */
 int smc_filter_theta_state(smc_filter* f, double* lw_theta_host, int64_t* stop_t, int64_t* steps_done,
                            double* ess_host);
+/* out_host (steps_done): log of the mean theta weight after every step accounted for -- the outer
+ * SMC's log_mean_w (core.py:351-359), from which the model's evidence increments follow */
+int smc_filter_theta_logmeans(smc_filter* f, double* out_host, int64_t* steps_done);
 /* New theta log-weights (NULL: zeros, i.e. after a theta-level resampling) and, if frozen, back
  * to the stop step: stepping continues from there. */
 int smc_filter_theta_resume(smc_filter* f, const double* lw_theta_host);

@@ -116,6 +116,7 @@ SIGNATURES = {
     "smc_filter_theta_enable": (c_int, [c_vp, c_dbl]),
     "smc_filter_theta_state": (c_int, [c_vp, c_vp, P(c_i64), P(c_i64), c_vp]),
     "smc_filter_theta_resume": (c_int, [c_vp, c_vp]),
+    "smc_filter_theta_logmeans": (c_int, [c_vp, c_vp, P(c_i64)]),
     "smc_filter_copy_islands": (c_int, [c_vp, c_vp, c_vp]),
     "smc_filter_moments": (c_int, [c_vp, P(c_dbl)]),
     "smc_filter_permute_islands": (c_int, [c_vp, P(c_i64)]),

@@ -7,6 +7,7 @@ module plugs into exactly those:
 
     import particles, particles_amd.adapter as hip
     pmmh = particles.mcmc.PMMH(..., smc_cls=hip.HipSMC())          # fused device filter per theta
+    alg = hip.HipSMC()(fk=particles.smc_samplers.SMC2(..., wastefree=False), N=...)   # SMC^2 on the device class
     hip.register_into(particles.resampling)                         # 'systematic_hip', ...
     hip.install()      # particles.SMC -> HipSMC, for callers that name particles.SMC themselves
 
@@ -75,6 +76,157 @@ def adapt(fk):
     return _FK_TABLE[name](ssm=model, data=fk.data)
 
 
+class _Theta:
+    """What ``alg.X`` of an outer SMC over SMC2 exposes (smc_samplers.py ThetaParticles): ``theta`` as a
+    structured array, ``lpost``, ``N``, the inner filters' size."""
+
+    def __init__(self, run):
+        self._run = run
+
+    @property
+    def theta(self):
+        d = self._run._alg.theta
+        out = np.empty(self._run.N, dtype=[(k, float) for k in d])
+        for k, v in d.items():
+            out[k] = v
+        return out
+
+    @property
+    def N(self):
+        return self._run.N
+
+    @property
+    def Nx(self):
+        return self._run._alg.Nx
+
+    @property
+    def lpost(self):
+        a = self._run._alg
+        with np.errstate(all="ignore"):
+            return np.asarray(a.prior.logpdf(a.theta), dtype=float) + a._evidences(a.pf)
+
+
+class _ThetaWeights:
+    def __init__(self, run):
+        self._run = run
+
+    @property
+    def lw(self):
+        return self._run._alg.lw
+
+    @property
+    def W(self):
+        return self._run._alg.W
+
+    @property
+    def ESS(self):
+        W = self.W
+        return 1.0 / np.sum(W * W)
+
+
+class _Summ:
+    def __init__(self, alg):
+        self.ESSs, self.logLts, self.rs_flags = list(alg.ESSs), list(alg.logLts), list(alg.rs_flags)
+
+
+class DeviceSMC2Run:
+    """``particles.SMC(fk=SMC2(ssm_cls, prior, data, init_Nx, ar_to_increase_Nx, len_chain, wastefree=False), N=...)``
+    (smc_samplers.py:1038-1167 under core.py:200-409) on the device class ``particles_amd.smc2.SMC2``:
+    all N filters are islands of one device filter, the theta level lives on the device, a
+    resample-move re-runs candidate batches.  Same algorithm as the reference's standard (not
+    waste-free) resample-move: ``len_chain - 1`` random-walk Metropolis steps calibrated on the weighted
+    theta-particles (smc_samplers.py:617-632), systematic theta-resampling at ESS < ESSrmin N, exchange
+    step when the acceptance rate falls below ``ar_to_increase_Nx``.  Attributes of the outer SMC that
+    callers read: ``X.theta``, ``W``, ``wgts``, ``logLt``, ``t``, ``N``, ``fk``, ``summaries`` (ESSs,
+    logLts, rs_flags), ``cpu_time``; ``run()`` / ``next()`` / iteration."""
+
+    def __init__(self, fk, ssm_cls, fk_cls, N=100, ESSrmin=0.5, resampling="systematic", seed=None, **kw):
+        from . import smc2
+        if resampling != "systematic":
+            raise ValueError("SMC^2 on the device resamples the theta level with the systematic scheme")
+        self.fk, self.N, self.ESSrmin = fk, N, ESSrmin
+        opts = {k: v for k, v in (fk.smc_options or {}).items() if k in ("resampling", "ESSrmin")}
+        self._alg = smc2.SMC2(ssm_cls=ssm_cls, prior=fk.prior, data=fk.data, init_Nx=fk.init_Nx, N=N, fk_cls=fk_cls,
+                              ESSrmin=ESSrmin, nmcmc=fk.move.nsteps, ar_to_increase_Nx=fk.ar_to_increase_Nx,
+                              smc_options=opts, seed=seed, sync_every=kw.pop("sync_every", 16))
+        self.X, self.wgts = _Theta(self), _ThetaWeights(self)
+        self.cpu_time = 0.0
+        self.rs_flag = False
+
+    t = property(lambda self: self._alg.t)
+    logLt = property(lambda self: self._alg.logLts[-1] if self._alg.logLts and self._alg.t < self._alg.T
+                     else self._alg.logLt)
+    W = property(lambda self: self._alg.W)
+    summaries = property(lambda self: _Summ(self._alg))
+
+    def run(self):
+        import time
+        t0 = time.perf_counter()
+        self._alg.run()
+        self.cpu_time = time.perf_counter() - t0
+
+    def __next__(self):
+        a = self._alg
+        if a.t >= a.T:
+            raise StopIteration
+        keep, a.sync_every = a.sync_every, 1
+        T_keep, t0 = a.T, a.t
+        try:                                   # one time step: the loop of run() limited to t0 + 1
+            a.pf.step_async(1)
+            lw, stop, done, ess = a._theta_state(a.pf)
+            t_new = stop if stop else done
+            a.ESSs.extend(ess[a.t:t_new].tolist())
+            lm = a._theta_logmeans(a.pf)
+            a.logLts.extend((a.logLt + lm[a.t:t_new] - a._log_mean(a._lw_at_reset)).tolist())
+            a.lw, a.t = lw, t_new
+            a.pf.t = a.pf._n = t_new
+            a.pf._invalidate()
+            self.rs_flag = bool(stop)
+            if stop:
+                a._resample_move()
+            if a.t >= T_keep:
+                a.logLt += a._log_mean(a.lw) - a._log_mean(a._lw_at_reset)
+        finally:
+            a.sync_every = keep
+
+    next = __next__
+
+    def __iter__(self):
+        return self
+
+
+def adapt_smc2(fk):
+    """(our model class, our Feynman-Kac class) if `fk` is the reference's SMC2 in a form the device
+    class implements exactly -- stock model class, Bootstrap / GuidedPF inner filters, the standard
+    (wastefree=False) random-walk move -- else None (the reference's outer loop then runs it; with
+    ``install()`` its inner filters are still device filters)."""
+    try:
+        from particles import smc_samplers as ssp
+        from particles import state_space_models as rssm
+    except ImportError:
+        return None
+    if type(fk) is not ssp.SMC2 or fk.wastefree:
+        return None
+    if type(fk.move) is not ssp.AdaptiveMCMCSequence or fk.move.adaptive or type(fk.move.mcmc) is not ssp.ArrayRandomWalk:
+        return None
+    name = fk.ssm_cls.__name__
+    import importlib
+    stock = None
+    for m in ("particles.kalman", "particles.state_space_models"):
+        if getattr(importlib.import_module(m), name, None) is fk.ssm_cls:
+            stock = name
+    if stock is None or stock not in _SSM_TABLE:
+        return None
+    ours, keys = _SSM_TABLE[stock]
+    if fk.fk_cls is rssm.Bootstrap:
+        fkc = ssm.Bootstrap
+    elif fk.fk_cls is rssm.GuidedPF:
+        fkc = ssm.GuidedPF
+    else:
+        return None
+    return ours, fkc
+
+
 _HIP_SMC = None
 
 
@@ -91,6 +243,11 @@ def HipSMC():
 
         class HipSMC(base):
             def __new__(cls, fk=None, **kw):
+                two = adapt_smc2(fk) if fk is not None else None
+                if two is not None and not kw.get("qmc") and not kw.get("store_history") \
+                        and kw.get("collect") in (None, "off") and not kw.get("verbose"):
+                    kw2 = {k: v for k, v in kw.items() if k in ("N", "ESSrmin", "resampling", "seed")}
+                    return DeviceSMC2Run(fk, two[0], two[1], **kw2)
                 mine = adapt(fk) if fk is not None else None
                 if mine is None or kw.get("qmc"):
                     return super().__new__(cls)            # the reference's own path

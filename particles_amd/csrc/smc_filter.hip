@@ -532,7 +532,7 @@ int smc_filter_clone(smc_filter* src, smc_filter** out)
     hipStream_t st = ctx->stream;
     hipError_t e = hipMemcpyAsync(slab, src->slab, src->slab_bytes, hipMemcpyDeviceToDevice, st);
     if (e == hipSuccess && src->th_buf) {
-        const size_t M = (size_t)a.n_islands, T = (size_t)a.T, nb = (M + TH_STRIDE + T) * 8;
+        const size_t M = (size_t)a.n_islands, T = (size_t)a.T, nb = (M + TH_STRIDE + 2 * T) * 8;
         e = hipMalloc(&f->th_buf, nb);
         if (e == hipSuccess) e = hipMemcpyAsync(f->th_buf, src->th_buf, nb, hipMemcpyDeviceToDevice, st);
         f->lwth = (double*)f->th_buf;
@@ -1061,8 +1061,8 @@ int smc_filter_theta_enable(smc_filter* f, double ess_rmin)
     SMC_REQUIRE(!f->a.pm2, "the theta level is not available for the auxiliary filter on the two-level step");
     SMC_HIP_CHECK(hipSetDevice(f->ctx->device));
     const size_t M = (size_t)f->a.n_islands, T = (size_t)f->a.T;
-    if (!f->th_buf) SMC_HIP_CHECK(hipMalloc(&f->th_buf, (M + TH_STRIDE + T) * 8));
-    SMC_HIP_CHECK(hipMemsetAsync(f->th_buf, 0, (M + TH_STRIDE + T) * 8, f->ctx->stream));
+    if (!f->th_buf) SMC_HIP_CHECK(hipMalloc(&f->th_buf, (M + TH_STRIDE + 2 * T) * 8));
+    SMC_HIP_CHECK(hipMemsetAsync(f->th_buf, 0, (M + TH_STRIDE + 2 * T) * 8, f->ctx->stream));
     f->lwth = (double*)f->th_buf;
     f->th = f->lwth + M;
     f->th_ess = f->th + TH_STRIDE;
@@ -1089,6 +1089,23 @@ int smc_filter_theta_state(smc_filter* f, double* lw_theta_host, int64_t* stop_t
     if (steps_done) *steps_done = (int64_t)th[2];
     if (ess_host && th[2] > 0) {
         SMC_HIP_CHECK(hipMemcpyAsync(ess_host, f->th_ess, (size_t)th[2] * 8, hipMemcpyDeviceToHost, st));
+        SMC_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    return SMC_OK;
+}
+
+// log-mean of the theta weights after every step accounted for (the outer SMC's log_mean_w,
+// core.py:351-359: its differences between resamplings are the evidence increments of the model)
+int smc_filter_theta_logmeans(smc_filter* f, double* out_host, int64_t* steps_done)
+{
+    SMC_REQUIRE(f && f->lwth && out_host, "the theta level is not enabled, or null output");
+    hipStream_t st = f->ctx->stream;
+    double th[TH_STRIDE];
+    SMC_HIP_CHECK(hipMemcpyAsync(th, f->th, sizeof th, hipMemcpyDeviceToHost, st));
+    SMC_HIP_CHECK(hipStreamSynchronize(st));
+    if (steps_done) *steps_done = (int64_t)th[2];
+    if (th[2] > 0) {
+        SMC_HIP_CHECK(hipMemcpyAsync(out_host, f->th_ess + f->a.T, (size_t)th[2] * 8, hipMemcpyDeviceToHost, st));
         SMC_HIP_CHECK(hipStreamSynchronize(st));
     }
     return SMC_OK;

@@ -2255,6 +2255,8 @@ k_theta_update(const FArgs av, double* lwth, double* th, double* ess_log, const 
         th[1] = ess;
         th[2] = (double)(t + 1);
         ess_log[t] = ess;
+        ess_log[a.T + t] = g.m + log(g.s / (double)M);         // log-mean of the theta weights after step t
+                                                               // (the outer evidence, core.py:355-359)
     }
     const bool stop = !((g.s * g.s) / g.ss >= ess_min) && t + 1 < a.T;
     if (!stop) return;

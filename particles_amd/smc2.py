@@ -119,12 +119,24 @@ class SMC2:
         self._seed = int(self.rng.randint(1, 2 ** 31 - 1))
         self.T = len(self.data)
         self.t = 0
-        self.theta = _as_dict(prior.rvs(self.N, rng=self.rng) if isinstance(prior, IndepPrior)
-                              else prior.rvs(size=self.N))
+        if isinstance(prior, IndepPrior):
+            self.theta = _as_dict(prior.rvs(self.N, rng=self.rng))
+        else:
+            # a prior that draws from numpy's global generator (the reference's StructDist): seeded from
+            # this run's own generator for the duration of the call, so that `seed` fixes the run
+            np_state = np.random.get_state()
+            np.random.seed(self.rng.randint(0, 2 ** 31 - 1))
+            try:
+                self.theta = _as_dict(prior.rvs(size=self.N))
+            finally:
+                np.random.set_state(np_state)
         self.names = list(self.theta)
         self.lw = np.zeros(self.N)
         self.logLt = 0.0                 # log evidence of the whole model (outer SMC, core.py:351-359)
         self.ESSs, self.Nxs, self.acc_rates, self.move_times = [], [self.Nx], [], []
+        # per step, as the outer particles.SMC would collect them (collectors.py:278-295): the model's
+        # log-evidence after step t, and whether a resample-move preceded step t
+        self.logLts, self.move_steps = [], []
         self._nbatch = 0
         self._lw_at_reset = np.zeros(self.N)
         self._lo, self._hi = self._my_slice()
@@ -175,6 +187,18 @@ class SMC2:
                                            ctypes.byref(done), ess.ctypes.data_as(_lib.c_vp)))
         return lw, int(stop.value), int(done.value), ess
 
+    def _theta_logmeans(self, pf):
+        """log-mean theta weight after every step the device has accounted for, (T,) (zeros beyond)."""
+        out = np.zeros(self.T)
+        done = ctypes.c_int64(0)
+        check(lib().smc_filter_theta_logmeans(pf._f, out.ctypes.data_as(_lib.c_vp), ctypes.byref(done)))
+        return out
+
+    @property
+    def rs_flags(self):
+        """rs_flags[t]: did a resample-move precede step t (the outer SMC's rs_flag, core.py:326-337)"""
+        return [t in self.move_steps for t in range(len(self.ESSs))]
+
     @property
     def W(self):
         w = np.exp(self.lw - self.lw.max())
@@ -192,6 +216,8 @@ class SMC2:
             lw, stop, done, ess = self._theta_state(self.pf)
             t_new = stop if stop else done
             self.ESSs.extend(ess[self.t:t_new].tolist())
+            lm = self._theta_logmeans(self.pf)
+            self.logLts.extend((self.logLt + lm[self.t:t_new] - self._log_mean(self._lw_at_reset)).tolist())
             # evidence of the whole model: log-mean of the theta weights since the last reset
             self.lw = lw
             self.t = t_new
@@ -205,6 +231,7 @@ class SMC2:
     def _resample_move(self):
         import time
         t0 = time.perf_counter()
+        self.move_steps.append(self.t)
         # ---- outer evidence up to here, then theta-level resampling (core.py:326-337)
         self.logLt += self._log_mean(self.lw) - self._log_mean(self._lw_at_reset)
         W = self.W
@@ -334,7 +361,11 @@ class ShardedSMC2(SMC2):
             w = np.exp(self.lw - self.lw.max())
             ess = float(w.sum() ** 2 / np.sum(w * w))
             self.ESSs.append(ess)
-            if ess < self.ESSrmin * self.N:
+            self.logLts.append(self.logLt + self._log_mean(self.lw) - self._log_mean(self._lw_at_reset))
+            # (never after the last step: the device theta level -- k_theta_update: t + 1 < T -- and the
+            #  reference's outer SMC stop there; a move at t = T would re-run every filter for nothing
+            #  and make world-1 runs differ from the one-GPU class)
+            if ess < self.ESSrmin * self.N and self.t < self.T:
                 self._resample_move()
         self.logLt += self._log_mean(self.lw) - self._log_mean(self._lw_at_reset)
         return self

@@ -210,7 +210,9 @@ def test_reference_smc2_runs_on_device_filters_under_install(ref):
 
     def run(seed):
         np.random.seed(seed)
-        fk = ssp.SMC2(ssm_cls=rk.LinearGauss, prior=prior, data=y, init_Nx=64, len_chain=3, wastefree=False)
+        # (the reference's default, waste-free move: not a form the device class implements, so the outer
+        #  loop stays the reference's under install() -- only its inner filters change)
+        fk = ssp.SMC2(ssm_cls=rk.LinearGauss, prior=prior, data=y, init_Nx=64, len_chain=3, wastefree=True)
         alg = particles.SMC(fk=fk, N=24, verbose=False)
         alg.run()
         return alg
@@ -233,10 +235,47 @@ def test_reference_smc2_runs_on_device_filters_under_install(ref):
     assert outer_is_reference                        # SMC2 itself is a Feynman-Kac object we do not reinterpret
     assert len(made) >= 24 and all(made)             # every inner filter is a fused device filter
     assert all(isinstance(pf, pa.SMC) for pf in dev.X.pfs)
-    assert len({pf._f.value for pf in dev.X.pfs}) == 24          # all distinct handles after the deep copies
+    assert len({pf._f.value for pf in dev.X.pfs}) == len(dev.X.pfs) >= 24    # all distinct handles after the deep copies
     assert sum(dev.summaries.rs_flags) >= 1 and sum(base.summaries.rs_flags) >= 1
     assert np.isfinite(dev.logLt) and abs(dev.logLt - base.logLt) < 3.0, (dev.logLt, base.logLt)
     for k in ("rho", "sigmaY"):
         mb = np.average(base.X.theta[k], weights=base.W)
         md = np.average(dev.X.theta[k], weights=dev.W)
         assert abs(mb - md) < 0.25, (k, mb, md)
+
+
+def test_reference_smc2_object_maps_onto_the_device_class(ref):
+    """HipSMC(fk=<the reference's SMC2, wastefree=False>, N=...) is the device class behind the outer
+    SMC's attributes (X.theta, W, logLt, summaries, run / next); anything the device class does not
+    implement exactly (the waste-free move, a user's model class) stays with the reference's loop."""
+    from particles_amd import adapter, smc2
+    particles, rk, dists, rssm = ref["particles"], ref["kalman"], ref["dists"], ref["ssm"]
+    from particles import smc_samplers as ssp
+    np.random.seed(4)
+    x, y = rk.LinearGauss(sigmaX=1.0, sigmaY=0.4, rho=0.8).simulate(16)
+    prior = dists.StructDist({"rho": dists.Uniform(a=0.3, b=0.99), "sigmaY": dists.Gamma(a=2.0, b=4.0)})
+    HipSMC = adapter.HipSMC()
+    fk = ssp.SMC2(ssm_cls=rk.LinearGauss, prior=prior, data=y, init_Nx=32, len_chain=3, wastefree=False)
+    alg = HipSMC(fk=fk, N=16, seed=3)
+    assert isinstance(alg, adapter.DeviceSMC2Run) and isinstance(alg._alg, smc2.SMC2)
+    assert alg._alg.nmcmc == 2 and alg._alg.Nx == 32 and alg.N == 16
+    alg.run()
+    th = alg.X.theta
+    assert th.dtype.names == ("rho", "sigmaY") and th.shape == (16,) and alg.t == 16
+    assert np.all((th["rho"] > 0.3) & (th["rho"] < 0.99)) and np.all(th["sigmaY"] > 0)
+    assert abs(alg.W.sum() - 1) < 1e-12 and np.isfinite(alg.logLt) and alg.cpu_time > 0
+    s = alg.summaries
+    assert len(s.ESSs) == len(s.logLts) == len(s.rs_flags) == 16 and s.logLts[-1] == alg.logLt
+    assert not s.rs_flags[0] and all(0 < e <= 16 for e in s.ESSs)
+    # one step at a time gives the same run (same seed)
+    stp = HipSMC(fk=fk, N=16, seed=3)
+    for _ in stp:
+        pass
+    assert stp.logLt == alg.logLt and np.array_equal(stp.X.theta, th) and stp.summaries.ESSs == s.ESSs
+    # not ours: the waste-free move (the reference's default), a user's subclass of a stock model
+    wf = HipSMC(fk=ssp.SMC2(ssm_cls=rk.LinearGauss, prior=prior, data=y, init_Nx=32), N=16)
+    assert isinstance(wf, particles.SMC) and not isinstance(wf, adapter.DeviceSMC2Run)
+
+    class MyLG(rk.LinearGauss):
+        pass
+    assert adapter.adapt_smc2(ssp.SMC2(ssm_cls=MyLG, prior=prior, data=y, wastefree=False)) is None
