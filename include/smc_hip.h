@@ -395,6 +395,11 @@ int smc_filter_permute_islands(smc_filter* f, const int64_t* src_host);
 /* keep_history filters: the state of an earlier step, fields as smc_filter_get
  * (hist.X[step], hist.A[step], hist.wgts[step].lw / .W; smoothing.py:204-207). */
 int smc_filter_history(smc_filter* f, int field, int64_t step, int island, void* out_host);
+/* Multinomial filters in production (Philox) mode: out_host (N) = the sorted uniforms
+ * uniform_spacings(N) (resampling.py:512-537) the resampling of step t (1 <= t < T) draws for this
+ * island -- a function of (seed, island, t) only.  The step loop never writes them (the two-level
+ * step regenerates the few it compares with); this entry is for inspection and the parity tests. */
+int smc_filter_spacings(smc_filter* f, int64_t t, int island, double* out_host);
 /* keep_history filters: genealogy of the current particles (compute_trajectories,
  * smoothing.py:209-219): out_host (t, N) int64, row t-1 = arange(N), row s-1 = A_s[row s]. */
 int smc_filter_trajectories(smc_filter* f, int island, int64_t* out_host);

@@ -1172,6 +1172,20 @@ def philox_normals_mv(seed, n, d, t, island=0):
     return np.stack([z0, z1], axis=2).reshape(n, 2 * hp)[:, :d]
 
 
+def philox_spacings(seed, M, t, island=0):
+    """The device's uniform_spacings(M) in production mode (resampling.py:512-537 on the Philox
+    stream): M + 1 exponential draws in fixed point, q_n = rint(-log(u_n) 2^s), s = 57 - ceil(log2(M + 2)),
+    u_n the open-interval uniform of word n & 1 of Philox call n >> 1 (stream 2); su_n = Z_n / Z_M,
+    Z_n = q_0 + .. + q_n (exact integers: monotone whatever the summation order)."""
+    lg = 0
+    while (1 << lg) < M + 2:
+        lg += 1
+    u = philox_resample_uniforms(seed, "multinomial", M, t, island)        # M + 1 open-interval uniforms
+    q = np.rint(-np.log(u) * 2.0 ** (57 - lg)).astype(np.uint64)
+    z = np.cumsum(q)
+    return z[:-1].astype(np.float64) / np.float64(z[-1])
+
+
 def philox_resample_uniforms(seed, scheme, M, t, island=0):
     """The uniforms the HIP path feeds to a scheme in production mode."""
     if scheme == "systematic":

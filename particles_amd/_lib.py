@@ -123,6 +123,7 @@ SIGNATURES = {
     "smc_filter_history": (c_int, [c_vp, c_int, c_i64, c_int, c_vp]),
     "smc_filter_one_trajectory": (c_int, [c_vp, c_int, c_i64, P(c_dbl)]),
     "smc_filter_trajectories": (c_int, [c_vp, c_int, P(c_i64)]),
+    "smc_filter_spacings": (c_int, [c_vp, c_i64, c_int, P(c_dbl)]),
     "smc_filter_info": (c_int, [c_vp, P(c_dbl), P(c_int)]),
     "smc_filter_profile": (c_int, [c_vp, c_int]),
     "smc_filter_kernel_ms": (c_int, [c_vp, P(c_dbl), P(c_dbl), P(c_i64)]),

@@ -369,6 +369,13 @@ class SMC:
             return [{"mean": r[0], "var": r[1]} for r in rows]
         return [{"mean": r[:d].copy(), "var": r[d:].copy()} for r in rows]
 
+    def _spacings(self, t, island=0):
+        """The sorted uniforms the multinomial resampling of step t draws on the device (production
+        mode): smc_filter_spacings."""
+        out = np.empty(self.N)
+        check(lib().smc_filter_spacings(self._f, int(t), island, out.ctypes.data_as(_lib.P(_lib.c_dbl))))
+        return out
+
     def _trajectories(self, island=0):
         out = np.empty((self._n, self.N), dtype=np.int64)
         check(lib().smc_filter_trajectories(self._f, island,

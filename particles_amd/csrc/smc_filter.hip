@@ -115,12 +115,15 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
         if (f->two_level_mid && f->a.scheme == SMC_MULTINOMIAL) {
             SMC_LAUNCH(k_reduce2, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
             if (!f->a.ut) {
+                // production mode: the tile sums of the exponential spacings and their prefixes; the
+                // sorted uniforms themselves are never written -- k_ancestors2 regenerates what it needs
                 const dim3 g1(f->a.ntiles1, f->a.n_islands);
-                SMC_LAUNCH(k_f_spacing_sums, g1, dim3(SMC_BLOCK), st, f->a);
+                SMC_LAUNCH(k_f_spacing_sums<false>, g1, dim3(SMC_BLOCK), st, f->a);
                 SMC_LAUNCH(k_f_spacing_scan, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
-                SMC_LAUNCH(k_f_spacing_write, g1, dim3(SMC_BLOCK), st, f->a);
+                SMC_LAUNCH((k_ancestors2<true, true, true, true>), grid, dim3(SMC_BLOCK), st, f->a);
+            } else {
+                SMC_LAUNCH((k_ancestors2<true, true>), grid, dim3(SMC_BLOCK), st, f->a);
             }
-            SMC_LAUNCH((k_ancestors2<true, true>), grid, dim3(SMC_BLOCK), st, f->a);
         } else if (f->two_level_mid) {
             SMC_LAUNCH(k_reduce2, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
             if (f->a.log2N >= 0) SMC_LAUNCH((k_ancestors2<true>), grid, dim3(SMC_BLOCK), st, f->a);
@@ -143,7 +146,7 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
     if (!fused) SMC_LAUNCH(k_prepare, grid, dim3(SMC_BLOCK), st, f->a);
     if (f->a.scheme == SMC_MULTINOMIAL && !f->a.ut) {
         const dim3 g1(f->a.ntiles1, f->a.n_islands);
-        SMC_LAUNCH(k_f_spacing_sums, g1, dim3(SMC_BLOCK), st, f->a);
+        SMC_LAUNCH(k_f_spacing_sums<true>, g1, dim3(SMC_BLOCK), st, f->a);
         SMC_LAUNCH(k_f_spacing_scan, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
         SMC_LAUNCH(k_f_spacing_write, g1, dim3(SMC_BLOCK), st, f->a);
     }
@@ -334,7 +337,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     const size_t oP2 = carve(apf2 ? 3 * M * a.nparts * 8 : 8);
     const size_t oHcnt = carve(heavy_list ? M * 2 * sizeof(unsigned) : 8);
     const size_t oHlist = carve(heavy_list ? M * 2 * F_HMAX * 3 * 8 : 8);
-    const size_t oSu = carve(need_su ? M * N * 8 : 8);
+    const size_t oSu = carve((need_su && !f->two_level) ? M * N * 8 : 8);     // (two-level step: never materialised)
     const size_t oE = carve(need_su ? M * (a.ntiles1 + 1) * 8 : 8);
     const size_t oTmp = carve(N * dxm * 8);
     a.nmb = (int)((o->N + F_MOM_CHUNK - 1) / F_MOM_CHUNK);
@@ -1176,6 +1179,24 @@ int smc_filter_history(smc_filter* f, int field, int64_t step, int island, void*
     return filter_fetch(f, field, step, island, out_host);
 }
 
+int smc_filter_spacings(smc_filter* f, int64_t t, int island, double* out_host)
+{
+    SMC_REQUIRE(f && out_host, "null argument");
+    SMC_REQUIRE(island >= 0 && island < f->a.n_islands, "island out of range");
+    SMC_REQUIRE(t >= 1 && t < f->a.T, "resampling happens at steps 1 .. T - 1");
+    if (f->a.scheme != SMC_MULTINOMIAL || f->a.ut || f->kind == SMC_MODEL_MVLINGAUSS) {
+        smc_set_error("smc_filter_spacings: a univariate multinomial filter in production (Philox) mode only");
+        return SMC_ERR_STATE;
+    }
+    SMC_HIP_CHECK(hipSetDevice(f->ctx->device));
+    hipStream_t st = f->ctx->stream;
+    SMC_LAUNCH(k_f_spacings_out, dim3(1), dim3(SMC_BLOCK), st, f->a, (i64)t, island, f->tmp);
+    SMC_LAUNCH_CHECK();
+    SMC_HIP_CHECK(hipMemcpyAsync(out_host, f->tmp, (size_t)f->a.N * 8, hipMemcpyDeviceToHost, st));
+    SMC_HIP_CHECK(hipStreamSynchronize(st));
+    return SMC_OK;
+}
+
 int smc_filter_trajectories(smc_filter* f, int island, int64_t* out_host)
 {
     SMC_REQUIRE(f && out_host, "null argument");
@@ -1276,7 +1297,8 @@ int smc_filter_describe(smc_filter* f, char* out, size_t n)
         else if (f->two_level) s = "k_ancestors2";
         else if (f->fused) s = "k_ancestors<fused>";
         else s = "k_prepare+k_ancestors";
-        if (f->a.scheme == SMC_MULTINOMIAL && !f->a.ut) s = "k_f_spacing_sums+k_f_spacing_scan+k_f_spacing_write+" + s;
+        if (f->a.scheme == SMC_MULTINOMIAL && !f->a.ut)
+            s = (f->two_level ? "k_f_spacing_sums+k_f_spacing_scan+" : "k_f_spacing_sums+k_f_spacing_scan+k_f_spacing_write+") + s;
         s += mv ? (f->mv_collapsed ? "+k_propagate_mv<collapsed>" : "+k_propagate_mv") : "+k_propagate";
         if (mv) s += " [mv_chunks=" + std::to_string(f->a.mv_chunks) + "]";
         if (f->a.mom) s += "+k_f_moments_partials+k_f_moments_final";

@@ -417,44 +417,53 @@ k_prepare(const FArgs av)
 // multinomial, Philox mode: sorted uniforms by exponential spacings
 // (resampling.py:512-537), batched over islands, skipped when not resampling
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ u64 f_spacing_q(const FArgs& a, u32 t, u32 gisl, i64 n)
+// The integer spacing of draw n in [0, N] of step t: rint(-log(u_n) 2^s), u_n the open-interval
+// uniform of Philox word n & 1 of call n >> 1 (stream SPACINGS); log by the table-driven routine
+// of the normals (smc_log_u52: <= 3 ulp), the rounding read off the mantissa (q < 2^51).
+__device__ __forceinline__ u64 f_spacing_int(const SmcD2* ntab, const u64 x, const double scale)
 {
-    u64 x, y;
-    smc_philox((u32)(n >> 1), t, gisl, SMC_STREAM_SPACINGS, a.seed, x, y);
-    return (u64)rint(-log(smc_u01_open((n & 1) ? y : x)) * a.spacing_scale);
+    const double m = fma(-smc_log_u52(ntab, x), scale, 4503599627370496.0);      // 2^52 + rint(-log(u) 2^s)
+    return (u64)__double_as_longlong(m) & 0x000FFFFFFFFFFFFFull;
+}
+// the 4 draws n0 .. n0 + 3 of a thread (n0 a multiple of 4: two Philox calls); 0 beyond draw N
+__device__ __forceinline__ void f_spacing_q4(const FArgs& a, const SmcD2* ntab, const u32 t, const u32 gisl,
+                                             const i64 n0, u64 (&q)[4])
+{
+#pragma unroll
+    for (int i = 0; i < 4; i += 2) {
+        u64 x, y;
+        smc_philox((u32)((n0 + i) >> 1), t, gisl, SMC_STREAM_SPACINGS, a.seed, x, y);
+        q[i] = (n0 + i <= a.N) ? f_spacing_int(ntab, x, a.spacing_scale) : 0ull;
+        q[i + 1] = (n0 + i + 1 <= a.N) ? f_spacing_int(ntab, y, a.spacing_scale) : 0ull;
+    }
 }
 
+// PARK (flat-CDF step): the integers are parked in the su buffer for k_f_spacing_write, which turns
+// them into the sorted uniforms in place.  The two-level step never materialises the uniforms:
+// k_ancestors2<.., REGEN> regenerates the draws of the few tiles it needs from the tile prefixes.
+template <bool PARK>
 __global__ void __launch_bounds__(SMC_BLOCK)
 k_f_spacing_sums(const FArgs av)
 {
     const FArgs& a = av;
     __shared__ u64 smu[SMC_SM];
+    SMC_NTAB_LDS(s_ntab);
     const int b = (int)blockIdx.x, isl = (int)blockIdx.y;
+    smc_ntab_stage<SMC_BLOCK>(s_ntab, (int)threadIdx.x);
+    __syncthreads();
     const double* info = a.info + (i64)isl * INFO_STRIDE;
     const i64 t = (i64)smc_uniform(info[0]);
     if (t >= a.T || t == 0 || smc_uniform(info[1]) == 0.0) return;
     const i64 n0 = (i64)b * F_TILE + (i64)threadIdx.x * F_IPT;
-    // the integer spacings are parked in the su buffer (same 8 bytes per draw) for the second pass,
-    // which turns them into the sorted uniforms in place -- a Philox call and a log per draw once,
-    // not twice (the (N+1)-th spacing has no slot: its owner makes it again)
-    u64* park = reinterpret_cast<u64*>(a.su + (i64)isl * a.N);
-    u64 s = 0;
+    u64 q[4];
+    f_spacing_q4(a, s_ntab, (u32)t, (u32)(a.island_offset + isl), n0, q);
+    if (PARK) {
+        u64* park = reinterpret_cast<u64*>(a.su + (i64)isl * a.N);
 #pragma unroll
-    for (int i = 0; i < F_IPT; i += 2) {           // (n0 is a multiple of 4: draws 2p, 2p + 1 share a Philox call)
-        u64 x, y;
-        if (n0 + i <= a.N)
-            smc_philox((u32)((n0 + i) >> 1), (u32)t, (u32)(a.island_offset + isl), SMC_STREAM_SPACINGS, a.seed, x, y);
-        else
-            x = y = 0ull;
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-            if (n0 + i + h <= a.N) {
-                const u64 q = (u64)rint(-log(smc_u01_open(h ? y : x)) * a.spacing_scale);
-                if (n0 + i + h < a.N) park[n0 + i + h] = q;
-                s += q;
-            }
+        for (int i = 0; i < F_IPT; ++i)
+            if (n0 + i < a.N) park[n0 + i] = q[i];
     }
-    s = smc_block_sum_u64(s, smu);
+    const u64 s = smc_block_sum_u64(q[0] + q[1] + q[2] + q[3], smu);
     if (threadIdx.x == 0) a.E[(i64)isl * (a.ntiles1 + 1) + b] = s;
 }
 
@@ -514,7 +523,10 @@ k_f_spacing_write(const FArgs av)
 {
     const FArgs& a = av;
     __shared__ u64 smu[SMC_SM];
+    SMC_NTAB_LDS(s_ntab);
     const int b = (int)blockIdx.x, isl = (int)blockIdx.y;
+    smc_ntab_stage<SMC_BLOCK>(s_ntab, (int)threadIdx.x);
+    __syncthreads();
     const double* info = a.info + (i64)isl * INFO_STRIDE;
     const i64 t = (i64)smc_uniform(info[0]);
     if (t >= a.T || t == 0 || smc_uniform(info[1]) == 0.0) return;
@@ -523,10 +535,12 @@ k_f_spacing_write(const FArgs av)
     const i64 n0 = (i64)b * F_TILE + (i64)threadIdx.x * F_IPT;
     const u64* park = reinterpret_cast<const u64*>(a.su + (i64)isl * a.N);
     u64 q[F_IPT], tsum = 0;
+    const bool has_last = n0 <= a.N && a.N < n0 + F_IPT;       // the (N+1)-th spacing has no slot: made again
+    u64 qn[4] = {0ull, 0ull, 0ull, 0ull};
+    if (has_last) f_spacing_q4(a, s_ntab, (u32)t, (u32)(a.island_offset + isl), n0, qn);
 #pragma unroll
     for (int i = 0; i < F_IPT; ++i) {
-        q[i] = (n0 + i < a.N) ? park[n0 + i]
-             : (n0 + i == a.N ? f_spacing_q(a, (u32)t, (u32)(a.island_offset + isl), n0 + i) : 0ull);
+        q[i] = (n0 + i < a.N) ? park[n0 + i] : (n0 + i == a.N ? qn[i] : 0ull);
         tsum += q[i];
     }
     u64 tot;
@@ -1558,6 +1572,92 @@ __device__ inline i64 f2_count_sorted_range(const double* u, i64 lo, i64 hi, con
     return lo;
 }
 
+// ---- multinomial, production (Philox) mode: the sorted uniforms are NEVER materialised.  Draw n has
+// the integer spacing q_n (f_spacing_q4), Z_n = q_0 + .. + q_n, su_n = fl(Z_n) / fl(Z_N) (resampling.py:
+// 536-537: z[:-1] / z[-1]), T_n = ceil(su_n 2^52).  k_f_spacing_sums / _scan leave the exclusive prefix
+// of every tile of 1024 draws (E[k] = Z_{1024 k - 1}) and the total (E[ntiles1] = Z_N), so the last
+// threshold of every tile is known without generating it: B_k = T_{1024 k - 1} = t52(E[k] / all).  Hence
+//     count(C) = #{n : T_n <= C} = 1024 k* + #{n in tile k* : T_n <= C},  k* = max{k : B_k <= C}  (B_0 = 0)
+// -- a search over the tile prefixes, then ONE tile of draws regenerated (same Philox counters, same
+// bits) and scanned.  A tile of 1024 parents owns 1024 +- a few dozen offspring, i.e. boundaries in
+// 2 (sometimes 1 or 3) tiles of draws; tiles no boundary falls into are never generated, so a
+// collapsed weight vector costs a few tiles as well.
+struct F2Regen {
+    const u64* E;          // (ntiles1 + 1) tile prefixes, the total last
+    int ntiles1;
+    double dall, rdall;    // fl(Z_N) and its correctly rounded reciprocal (smc_div_c: the IEEE quotient)
+};
+__device__ __forceinline__ u64 f2_regen_B(const F2Regen& g, const i64 k)
+{
+    return f2_t52(smc_div_c((double)smc_ldg(g.E + k), g.dall, g.rdall));
+}
+// #{k in [0, ntiles1] : B_k <= C} >= 1 by a whole wavefront: first a window of 64 tiles centred on the
+// expected one (the uniforms deviate from n / N by O(1 / sqrt N): +- a tile or two), then 64-ary
+__device__ __forceinline__ i64 f2_regen_tiles_le_wave(const F2Regen& g, const u64 C, const i64 guess)
+{
+    const i64 M = (i64)g.ntiles1 + 1;
+    const int lane = smc_lane();
+    i64 lo = 0, hi = M;                                        // B_k <= C on [0, lo), > C on [hi, M)
+    {
+        i64 w0 = guess - 32;
+        w0 = w0 > M - 64 ? M - 64 : w0;
+        w0 = w0 < 0 ? 0 : w0;
+        const i64 k = w0 + lane;
+        const bool in = k < M;
+        const bool le = in && f2_regen_B(g, in ? k : 0) <= C;
+        const int cnt = (int)smc_wave_sum_u64(le ? 1ull : 0ull);
+        const int nprobe = (int)(M - w0 < 64 ? M - w0 : 64);
+        if (cnt > 0) lo = w0 + cnt;
+        if (cnt < nprobe) hi = w0 + cnt;
+        if (cnt == 0) hi = w0;
+        if (hi < lo) hi = lo;
+    }
+    while (lo < hi) {
+        const i64 width = hi - lo;
+        const i64 stride = (width + 63) >> 6;
+        const i64 p = lo + (i64)lane * stride;
+        const bool in = p < hi;
+        const bool le = in && f2_regen_B(g, in ? p : lo) <= C;
+        const int cnt = (int)smc_wave_sum_u64(le ? 1ull : 0ull);
+        const int nprobe = (int)((width + stride - 1) / stride);
+        const i64 nlo = cnt > 0 ? lo + (i64)(cnt - 1) * stride + 1 : lo;
+        const i64 nhi = cnt < nprobe ? lo + (i64)cnt * stride : hi;
+        lo = nlo;
+        hi = nhi;
+    }
+    return lo;
+}
+// the same by one lane over the tiles k_lo + 1 .. k_hi (tiles wider than the LDS stage of B values)
+__device__ inline i64 f2_regen_tiles_le_range(const F2Regen& g, i64 lo, i64 hi, const u64 C)
+{
+    while (lo < hi) {                                          // first k in [lo, hi) with B_k > C
+        const i64 mid = lo + ((hi - lo) >> 1);
+        if (f2_regen_B(g, mid) <= C) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+// The thresholds of the 1024 draws of tile k into sT (every thread of the workgroup calls; two
+// barriers inside, one more is the caller's before sT is read); draws beyond N - 1 hold no uniform:
+// their slots get 2^63 (never counted)
+__device__ __forceinline__ void f2_regen_tile(const FArgs& a, const SmcD2* ntab, const F2Regen& g, const u32 t,
+                                              const u32 gisl, const i64 k, u64* sT, u64* smu)
+{
+    const int tid = (int)threadIdx.x;
+    const i64 n0 = k * F_TILE + (i64)tid * F_IPT;
+    u64 q[4];
+    f_spacing_q4(a, ntab, t, gisl, n0, q);
+    u64 tot;
+    u64 run = smc_block_exscan_u64(q[0] + q[1] + q[2] + q[3], smu, tot) + smc_ldg(g.E + k);
+    u64 T[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        run += q[i];
+        T[i] = (n0 + i < a.N) ? f2_t52(smc_div_c((double)run, g.dall, g.rdall)) : (1ull << 63);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sT[tid * 4 + i] = T[i];
+}
+
 // first offspring ns[i] of the parents jt+i at positions cx[i] (cx[4]: the next thread's first
 // parent, t_b for the last thread), any scheme: fp64 quotient within 2^12 of the truth, count
 // decided unless the position lies within that band of a threshold, else formed exactly
@@ -1830,10 +1930,13 @@ k_reduce2(const FArgs av)
 //     in flight): a tile owns 1024 +- a few dozen offspring.
 // MID: k_reduce2 ran first: grids too large for every workgroup to repeat the reduction.
 // ---------------------------------------------------------------------------
-template <bool MID, bool MULTI = false, bool POW2 = true>
+// REGEN (MID, MULTI, Philox mode): the thresholds of the sorted uniforms come from regenerated tiles
+// of draws instead of memory (see F2Regen above).
+template <bool MID, bool MULTI = false, bool POW2 = true, bool REGEN = false>
 __global__ void __launch_bounds__(SMC_BLOCK)
 k_ancestors2(const FArgs av)
 {
+    static_assert(!REGEN || (MID && MULTI), "regenerated thresholds: multinomial behind k_reduce2");
     const FArgs& a = av;
     constexpr int WIN = 2 * F_PASS;                                        // offspring per pass
     __shared__ __attribute__((aligned(16))) u32 sP[WIN];
@@ -1946,7 +2049,135 @@ k_ancestors2(const FArgs av)
     // ---- first offspring of each parent; the tile's range [n_lo, n_hi)
     const u64 Gb = (u64)Gd, Qb = (u64)Qd;
     i64 ns[F_IPT + 1], n_lo, n_hi;
-    if (MULTI) {
+    if (REGEN) {
+        __shared__ __attribute__((aligned(16))) u64 sT[F_TILE];            // thresholds of one tile of draws
+        __shared__ u64 sB[SMC_BLOCK];                                      // B_k of the tiles k_lo + 1 .. k_hi
+        __shared__ u64 smu[SMC_SM];
+        __shared__ i64 s_k[2];
+        __shared__ u32 s_cur[SMC_NWAVE];
+        __shared__ i64 s_edge[SMC_BLOCK + 1];
+        SMC_NTAB_LDS(s_ntab);
+        smc_ntab_stage<SMC_BLOCK>(s_ntab, tid);
+        const u32 gisl = (u32)(a.island_offset + isl);
+        F2Regen g;
+        g.E = a.E + (i64)isl * (a.ntiles1 + 1);
+        g.ntiles1 = a.ntiles1;
+        g.dall = (double)smc_uniform_u64(smc_ldg(g.E + a.ntiles1));
+        g.rdall = 1.0 / g.dall;
+        // ---- the tiles of draws the tile's two ends fall into (one wave per end)
+        const double per52 = (double)(N + 1) * 0x1.0p-62;                  // tiles of draws per unit of the scale
+        if (wave == 0) {
+            const i64 v = f2_regen_tiles_le_wave(g, Gb, (i64)((double)Gb * per52)) - 1;
+            if (lane == 0) s_k[0] = v;
+        }
+        if (wave == 1) {
+            const i64 v = f2_regen_tiles_le_wave(g, Gb + Qb, (i64)((double)(Gb + Qb) * per52)) - 1;
+            if (lane == 0) s_k[1] = v;
+        }
+        __syncthreads();                                                   // (also: s_ntab staged)
+        const i64 k_lo = s_k[0], k_hi = s_k[1];
+        const i64 nb = k_hi - k_lo;                                        // B values strictly inside the range
+        const bool b_staged = nb <= SMC_BLOCK;
+        if (b_staged && tid < nb) sB[tid] = f2_regen_B(g, k_lo + 1 + tid);
+        __syncthreads();
+        // ---- every boundary's position on the scale and its tile of draws.  fp64 quotient within 2^12 of
+        // floor(c Q_b / t_b) (f2_first_offspring); a tile edge B_k within 2^13 of it: the exact quotient
+        const double qscale = (double)Qb / (double)(tb ? tb : 1ull);
+        const u64 BAND = 1ull << 13;
+        u64 Cj[F_IPT + 1];
+        u32 kj[F_IPT + 1];                                                 // (tile of draws: < 2^21 on this path)
+        bool exact[F_IPT + 1], open[F_IPT + 1];
+#pragma unroll
+        for (int i = 0; i <= F_IPT; ++i) {
+            const i64 j = jt + i;
+            const u64 c = cx[i];
+            // (the 5th boundary is the next thread's first -- taken from it below -- except the last
+            //  thread's: the tile's upper end, c = t_b)
+            open[i] = j > 0 && j < N && (i < F_IPT || tid == SMC_BLOCK - 1);
+            ns[i] = (j == 0) ? 0 : N;
+            exact[i] = a.exact_counts != 0;
+            u64 pos;
+            if (c == 0ull || c >= tb) {            // the tile's own ends: exact, and the same integers the
+                pos = c == 0ull ? 0ull : Qb;       // neighbouring tiles form for theirs
+                exact[i] = true;
+            } else if (exact[i]) {
+                pos = smc_muldiv_floor(c, Qb, tb);
+            } else {
+                pos = (u64)((double)c * qscale);
+                pos = pos > Qb ? Qb : pos;
+            }
+            Cj[i] = Gb + pos;
+            kj[i] = (u32)k_lo;
+            if (open[i]) {
+                for (int pass = 0; pass < 2; ++pass) {
+                    int kk;
+                    u64 below = 0ull, above = ~0ull;
+                    if (b_staged) {
+                        kk = f2_count_lds(sB, (int)nb, Cj[i]);
+                        if (kk > 0) below = sB[kk - 1];
+                        if (kk < (int)nb) above = sB[kk];
+                    } else {
+                        kk = (int)(f2_regen_tiles_le_range(g, k_lo + 1, k_hi + 1, Cj[i]) - (k_lo + 1));
+                        if (kk > 0) below = f2_regen_B(g, k_lo + kk);
+                        if (kk < (int)nb) above = f2_regen_B(g, k_lo + 1 + kk);
+                    }
+                    kj[i] = (u32)(k_lo + kk);
+                    const bool near = (kk > 0 && below + BAND > Cj[i]) || (kk < (int)nb && above <= Cj[i] + BAND);
+                    if (exact[i] || !near) break;
+                    Cj[i] = Gb + ((c == 0ull) ? 0ull : (c >= tb ? Qb : smc_muldiv_floor(c, Qb, tb)));
+                    exact[i] = true;
+                }
+            }
+        }
+        // ---- the tiles some boundary falls into, in increasing order: regenerate, count
+        u32 prev = 0u;
+        bool first_round = true;
+        for (;;) {
+            u32 mine = 0xFFFFFFFFu;
+#pragma unroll
+            for (int i = 0; i <= F_IPT; ++i)
+                if (open[i] && (first_round || kj[i] > prev) && kj[i] < mine) mine = kj[i];
+            // block minimum = complement of the maximum of the complements
+            const u32 wmx = smc_readlane(smc_wave_scan_max_u32(~mine), 63);
+            __syncthreads();                                               // the previous round has read s_cur / sT
+            if (lane == 0) s_cur[wave] = wmx;
+            __syncthreads();
+            u32 mx = s_cur[0];
+#pragma unroll
+            for (int w = 1; w < SMC_NWAVE; ++w) mx = s_cur[w] > mx ? s_cur[w] : mx;
+            const u32 cur = ~mx;
+            if (cur == 0xFFFFFFFFu) break;
+            prev = cur;
+            first_round = false;
+            if (cur >= (u32)a.ntiles1) continue;                           // every draw counted: ns stays N
+            f2_regen_tile(a, s_ntab, g, (u32)t, gisl, (i64)cur, sT, smu);
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i <= F_IPT; ++i) {
+                if (!(open[i] && kj[i] == cur)) continue;
+                int k = f2_count_lds(sT, F_TILE, Cj[i]);
+                if (!exact[i]) {
+                    const bool below = k == 0 || sT[k - 1] + BAND <= Cj[i];
+                    const bool above = k == F_TILE || sT[k] > Cj[i] + BAND;
+                    if (!(below && above)) {       // a threshold within the band: the exact position (same tile:
+                        const u64 c = cx[i];       //  its edges were not within the band)
+                        const u64 pos = (c == 0ull) ? 0ull : (c >= tb ? Qb : smc_muldiv_floor(c, Qb, tb));
+                        k = f2_count_lds(sT, F_TILE, Gb + pos);
+                    }
+                }
+                const i64 v = (i64)cur * F_TILE + k;
+                ns[i] = v < N ? v : N;
+            }
+        }
+        // ---- the next thread's first boundary; the tile's range
+        __syncthreads();
+        s_edge[tid] = ns[0];
+        if (tid == SMC_BLOCK - 1) s_edge[SMC_BLOCK] = ns[F_IPT];
+        __syncthreads();
+        if (tid < SMC_BLOCK - 1) ns[F_IPT] = s_edge[tid + 1];
+        n_lo = s_edge[0];
+        n_hi = s_edge[SMC_BLOCK];
+    } else if (MULTI) {
         // ---- multinomial: the tile's range by two cooperative searches (one wave per end), its
         // thresholds staged in LDS, every parent's count a search there; the position of a parent
         // on the tile's share is formed exactly (128-bit product)
@@ -2142,6 +2373,40 @@ k_ancestors2(const FArgs av)
         }
     }
     F_STAMP_A(6);
+}
+
+// smc_filter_spacings: the sorted uniforms the multinomial resampling of step t draws in production
+// mode, written out (inspection / tests: the step loop itself never materialises them).  ONE
+// workgroup walks the tiles of draws in order: same integers, same prefix sums, same quotients as
+// k_f_spacing_sums / _scan / k_ancestors2<REGEN> (and k_f_spacing_write on the flat step).
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_f_spacings_out(const FArgs av, const i64 t, const int isl, double* out)
+{
+    const FArgs& a = av;
+    __shared__ u64 smu[SMC_SM];
+    SMC_NTAB_LDS(s_ntab);
+    const int tid = (int)threadIdx.x;
+    smc_ntab_stage<SMC_BLOCK>(s_ntab, tid);
+    __syncthreads();
+    const u32 gisl = (u32)(a.island_offset + isl);
+    u64* Z = reinterpret_cast<u64*>(out);
+    u64 carry = 0ull;
+    for (int k = 0; k < a.ntiles1; ++k) {
+        const i64 n0 = (i64)k * F_TILE + (i64)tid * F_IPT;
+        u64 q[4];
+        f_spacing_q4(a, s_ntab, (u32)t, gisl, n0, q);
+        u64 tot;
+        u64 run = carry + smc_block_exscan_u64(q[0] + q[1] + q[2] + q[3], smu, tot);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            run += q[i];
+            if (n0 + i < a.N) Z[n0 + i] = run;
+        }
+        carry += tot;
+        __syncthreads();
+    }
+    const double dall = (double)carry;
+    for (i64 n = tid; n < a.N; n += SMC_BLOCK) out[n] = (double)Z[n] / dall;
 }
 
 // the summary row of the last step done and the (K, 1/s) W is formed with: enqueued at the end

@@ -212,13 +212,10 @@ __device__ __forceinline__ double smc_frexp_m(double x, int& e)
 __device__ __forceinline__ double smc_rsq(double x) { return __builtin_amdgcn_rsq(x); }
 #endif
 
-// (z0, z1) = sqrt(-2 log u1) (cos, sin)(2 pi u2), u1 = ((a >> 12) + 1/2) 2^-52, u2 likewise from b;
-// tab: the staged tables (LDS)
-__host__ __device__ __forceinline__ void smc_bm_pair(const SmcD2* tab, const u64 a, const u64 b,
-                                                     double& z0, double& z1)
+// log u for u = ((a >> 12) + 1/2) 2^-52 in (0, 1): < 0, <= 3 ulp; tab: the staged tables (LDS)
+__host__ __device__ __forceinline__ double smc_log_u52(const SmcD2* tab, const u64 a)
 {
     const double* K = smc_k_bm;
-    // ---- log u1
     const double D = __longlong_as_double((long long)((a >> 12) | 0x3FF0000000000000ull));   // 1 + k 2^-52
     const double u = D - K[14];                                 // (k + 1/2) 2^-52, exact
     int e;
@@ -235,7 +232,16 @@ __host__ __device__ __forceinline__ void smc_bm_pair(const SmcD2* tab, const u64
     p = SMC_FMA_K(p, r, K[4]);
     p = SMC_FMA_K(p, r, K[5]);
     const double lp = fma(p, r * r, r);                         // log1p(r)
-    const double L = fma(ed, K[6], logc) + fma(ed, K[7], lp);   // log u1 < 0
+    return fma(ed, K[6], logc) + fma(ed, K[7], lp);
+}
+
+// (z0, z1) = sqrt(-2 log u1) (cos, sin)(2 pi u2), u1 = ((a >> 12) + 1/2) 2^-52, u2 likewise from b;
+// tab: the staged tables (LDS)
+__host__ __device__ __forceinline__ void smc_bm_pair(const SmcD2* tab, const u64 a, const u64 b,
+                                                     double& z0, double& z1)
+{
+    const double* K = smc_k_bm;
+    const double L = smc_log_u52(tab, a);                       // log u1 < 0
     // ---- radius sqrt(-2 L)
     const double s = -2.0 * L;
     const double y = smc_rsq(s);

@@ -498,7 +498,11 @@ def audit_history(pf, mk_orc, fk, y, scheme, ESSrmin, z=None, u=None, exact=True
                 else:
                     ut = orc.philox_resample_uniforms(pf.seed, scheme, N, t, island)
                 if scheme == "multinomial":
-                    su = ut if u is not None else None
+                    # the tape's sorted uniforms, or -- production mode -- the device's own
+                    # (smc_filter_spacings: the step loop never writes them; statistics and the Philox
+                    # layout of the draws are checked in check_device_spacings)
+                    su = ut if u is not None else pf._spacings(t, island)
+                    ut = su
                 else:
                     su = orc.sorted_uniforms(scheme, N, ut)
                 W_dev = pf._history(_lib.FIELD_W, t - 1, island)
@@ -718,19 +722,22 @@ def check_two_level_injected(sizes=(4096, 3000)):
                 A_ref = orc.inverse_cdf(su, W)
                 n, ok = orc.audit_near_ties(su, W, A_ref, A)
                 assert ok and n <= max(1, N // 100000), (N, scheme, name, n)
-        # multinomial: the sorted uniforms come from a tape (counts are searches over them)
+        # multinomial: the sorted uniforms come from a tape (counts are searches over them), or --
+        # production mode -- are the device's own draws, regenerated tile by tile inside k_ancestors2
+        # (smc_filter_spacings writes them out for the oracle; with the fp64 shortcut and without)
         z = rng.standard_normal((2, 1, N))
-        su = orc.uniform_spacings_from(rng.random(N + 1))
-        u = np.stack([np.zeros(N), su]).reshape(2, 1, N)
-        for name, lwi in cases:
+        su_tape = orc.uniform_spacings_from(rng.random(N + 1))
+        u = np.stack([np.zeros(N), su_tape]).reshape(2, 1, N)
+        for (name, lwi), rep in [((n_, l_), r_) for n_, l_ in cases for r_ in (True, False)]:
             pf = pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y), N=N, resampling="multinomial",
-                        ESSrmin=2.0, seed=7, collect="off", replay=(z, u))
-            assert "k_ancestors2" in describe(pf)
+                        ESSrmin=2.0, seed=7, collect="off", replay=(z, u) if rep else None)
+            assert "k_ancestors2" in describe(pf) and ("k_f_spacing_sums" in describe(pf)) == (not rep)
             next(pf)
             pf.set_state(lw=lwi)
             X0 = np.array(pf.X)
             next(pf)
             assert pf.rs_flag
+            su = su_tape if rep else pf._spacings(1)
             A_c, _ = orc.inverse_cdf_2level_c("multinomial", su, lwi)
             A = np.array(pf.A)
             assert np.array_equal(A, A_c), (N, "multinomial", name, int(np.sum(A != A_c)))
@@ -788,6 +795,36 @@ def check_oracle_at_size(model, mk_dev, mk_orc, N, T, scheme="systematic", ESSrm
     assert np.array_equal(pf._summ(), ph._summ())
     assert not expect_resample or np.any(ph._summ()[:, 1:, 4] != 0)
     return ties
+
+
+def check_device_spacings(sizes=(2048, 3000, 1 << 14), seed=91):
+    """The sorted uniforms of the multinomial resampling in production mode (uniform_spacings,
+    resampling.py:512-537, by exponential spacings drawn from the Philox stream): smc_filter_spacings
+    against the oracle's restatement of the draw layout (draw n <- word n & 1 of call n >> 1, stream 2,
+    q_n = rint(-log(u_n) 2^s), su_n = Z_n / Z_N) -- equal up to the ulps by which the device's
+    table-driven log differs from libm's inside the rint -- sorted, in (0, 1), uniform order statistics;
+    and the ancestors of the step are the contract's for exactly these uniforms (audit_history)."""
+    rng = np.random.RandomState(4)
+    T = 6
+    y = [np.array([v]) for v in 0.5 * np.cumsum(rng.standard_normal(T))]
+    for N in sizes:
+        for n_islands, isl in ((1, 0), (3, 2)):
+            pf = pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y), N=N, resampling="multinomial", ESSrmin=1.0,
+                        seed=seed, store_history=True, n_islands=n_islands, collect="off")
+            pf.run()
+            assert "k_f_spacing_write" not in describe(pf)
+            for t in (1, T - 1):
+                su = pf._spacings(t, isl)
+                want = orc.philox_spacings(seed, N, t, isl)
+                assert su.shape == (N,) and np.all(np.diff(su) >= 0) and su[0] > 0 and su[-1] < 1
+                assert np.max(np.abs(su - want)) < 1e-13, (N, t, float(np.max(np.abs(su - want))))
+            ties = audit_history(pf, lambda: orc.ToySSM(0.2), "bootstrap", y, "multinomial", 1.0, island=isl)
+            assert ties <= max(1, T * N // 100000)
+    # order statistics of N uniforms: E su_n = (n + 1) / (N + 1), and a Kolmogorov distance of the size
+    # 1 / sqrt(N) from the uniform law
+    N = sizes[-1]
+    d = np.max(np.abs(su - (np.arange(N) + 1.0) / (N + 1)))
+    assert d < 2.5 / np.sqrt(N), d
 
 
 def check_heavy_parents(monkeypatch, N=8192, T=12):
@@ -854,8 +891,8 @@ def check_describe():
     assert kernels(3000) == "k_ancestors2+k_propagate"                         # any N of >= 2 tiles: general counts
     assert kernels(1500) == "k_ancestors2+k_propagate"                         # (2 tiles, the second ragged)
     assert kernels(1 << 12, "multinomial") == \
-        "k_f_spacing_sums+k_f_spacing_scan+k_f_spacing_write+k_reduce2+k_ancestors2+k_propagate"   # two-level: counts by search
-    assert kernels(1500, "multinomial") == "k_f_spacing_sums+k_f_spacing_scan+k_f_spacing_write+k_reduce2+k_ancestors2+k_propagate"
+        "k_f_spacing_sums+k_f_spacing_scan+k_reduce2+k_ancestors2+k_propagate"   # two-level: counts by search, draws regenerated
+    assert kernels(1500, "multinomial") == "k_f_spacing_sums+k_f_spacing_scan+k_reduce2+k_ancestors2+k_propagate"
     mv = kalman.MVLinearGauss_Guarniero_etal(alpha=0.4, dx=4)
     ymv = [np.zeros((1, 4)) for _ in range(4)]
     pf = pa.SMC(fk=ssm.Bootstrap(ssm=mv, data=ymv), N=1 << 12, seed=1)

@@ -257,6 +257,10 @@ def test_mv_collapsed_proposal():
     pc.check_mv_collapsed(1024, 20, T=4)
 
 
+def test_multinomial_spacings_regenerated():
+    pc.check_device_spacings(sizes=(2048, 3000))
+
+
 def test_device_sort():
     pc.check_device_sort(sizes=(1, 63, 64, 2047, 2048, 2049, 9001))
 

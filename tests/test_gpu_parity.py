@@ -470,6 +470,10 @@ def test_rccl_two_ranks_one_gpu(tmp_path):
         assert "RCCL evidence gather unavailable" in "".join(outs)
 
 
+def test_multinomial_spacings_regenerated():
+    pc.check_device_spacings(sizes=(2048, 3000, 1 << 14, 10 ** 6 + 1, 1 << 22))
+
+
 def test_device_sort():
     pc.check_device_sort(sizes=(1, 64, 2049, 50001, (1 << 20) + 3, 1 << 22))
 
