@@ -115,11 +115,12 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
         if (f->two_level_mid && f->a.scheme == SMC_MULTINOMIAL) {
             SMC_LAUNCH(k_reduce2, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
             if (!f->a.ut) {
-                // production mode: the tile sums of the exponential spacings and their prefixes; the
-                // sorted uniforms themselves are never written -- k_ancestors2 regenerates what it needs
+                // production mode: uniform_spacings in two passes over the same draws (tile sums, their
+                // prefixes, the uniforms written once); k_ancestors2 finds its window through the prefixes
                 const dim3 g1(f->a.ntiles1, f->a.n_islands);
-                SMC_LAUNCH(k_f_spacing_sums<false>, g1, dim3(SMC_BLOCK), st, f->a);
+                SMC_LAUNCH(k_f_spacing_sums, g1, dim3(SMC_BLOCK), st, f->a);
                 SMC_LAUNCH(k_f_spacing_scan, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
+                SMC_LAUNCH(k_f_spacing_write, g1, dim3(SMC_BLOCK), st, f->a);
                 SMC_LAUNCH((k_ancestors2<true, true, true, true>), grid, dim3(SMC_BLOCK), st, f->a);
             } else {
                 SMC_LAUNCH((k_ancestors2<true, true>), grid, dim3(SMC_BLOCK), st, f->a);
@@ -146,7 +147,7 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
     if (!fused) SMC_LAUNCH(k_prepare, grid, dim3(SMC_BLOCK), st, f->a);
     if (f->a.scheme == SMC_MULTINOMIAL && !f->a.ut) {
         const dim3 g1(f->a.ntiles1, f->a.n_islands);
-        SMC_LAUNCH(k_f_spacing_sums<true>, g1, dim3(SMC_BLOCK), st, f->a);
+        SMC_LAUNCH(k_f_spacing_sums, g1, dim3(SMC_BLOCK), st, f->a);
         SMC_LAUNCH(k_f_spacing_scan, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
         SMC_LAUNCH(k_f_spacing_write, g1, dim3(SMC_BLOCK), st, f->a);
     }
@@ -337,7 +338,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     const size_t oP2 = carve(apf2 ? 3 * M * a.nparts * 8 : 8);
     const size_t oHcnt = carve(heavy_list ? M * 2 * sizeof(unsigned) : 8);
     const size_t oHlist = carve(heavy_list ? M * 2 * F_HMAX * 3 * 8 : 8);
-    const size_t oSu = carve((need_su && !f->two_level) ? M * N * 8 : 8);     // (two-level step: never materialised)
+    const size_t oSu = carve(need_su ? M * N * 8 + 16 : 8);
     const size_t oE = carve(need_su ? M * (a.ntiles1 + 1) * 8 : 8);
     const size_t oTmp = carve(N * dxm * 8);
     a.nmb = (int)((o->N + F_MOM_CHUNK - 1) / F_MOM_CHUNK);
@@ -1297,8 +1298,7 @@ int smc_filter_describe(smc_filter* f, char* out, size_t n)
         else if (f->two_level) s = "k_ancestors2";
         else if (f->fused) s = "k_ancestors<fused>";
         else s = "k_prepare+k_ancestors";
-        if (f->a.scheme == SMC_MULTINOMIAL && !f->a.ut)
-            s = (f->two_level ? "k_f_spacing_sums+k_f_spacing_scan+" : "k_f_spacing_sums+k_f_spacing_scan+k_f_spacing_write+") + s;
+        if (f->a.scheme == SMC_MULTINOMIAL && !f->a.ut) s = "k_f_spacing_sums+k_f_spacing_scan+k_f_spacing_write+" + s;
         s += mv ? (f->mv_collapsed ? "+k_propagate_mv<collapsed>" : "+k_propagate_mv") : "+k_propagate";
         if (mv) s += " [mv_chunks=" + std::to_string(f->a.mv_chunks) + "]";
         if (f->a.mom) s += "+k_f_moments_partials+k_f_moments_final";

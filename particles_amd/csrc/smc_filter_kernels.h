@@ -438,10 +438,9 @@ __device__ __forceinline__ void f_spacing_q4(const FArgs& a, const SmcD2* ntab, 
     }
 }
 
-// PARK (flat-CDF step): the integers are parked in the su buffer for k_f_spacing_write, which turns
-// them into the sorted uniforms in place.  The two-level step never materialises the uniforms:
-// k_ancestors2<.., REGEN> regenerates the draws of the few tiles it needs from the tile prefixes.
-template <bool PARK>
+// Pass 1 of uniform_spacings: the tile sums of the integer spacings.  Nothing else is written: pass 2
+// (k_f_spacing_write) makes the same draws again -- 54 instructions per draw with the table-driven log,
+// against 16 bytes of traffic per draw for parking them (round 2 parked: its log was libm's).
 __global__ void __launch_bounds__(SMC_BLOCK)
 k_f_spacing_sums(const FArgs av)
 {
@@ -457,12 +456,6 @@ k_f_spacing_sums(const FArgs av)
     const i64 n0 = (i64)b * F_TILE + (i64)threadIdx.x * F_IPT;
     u64 q[4];
     f_spacing_q4(a, s_ntab, (u32)t, (u32)(a.island_offset + isl), n0, q);
-    if (PARK) {
-        u64* park = reinterpret_cast<u64*>(a.su + (i64)isl * a.N);
-#pragma unroll
-        for (int i = 0; i < F_IPT; ++i)
-            if (n0 + i < a.N) park[n0 + i] = q[i];
-    }
     const u64 s = smc_block_sum_u64(q[0] + q[1] + q[2] + q[3], smu);
     if (threadIdx.x == 0) a.E[(i64)isl * (a.ntiles1 + 1) + b] = s;
 }
@@ -533,16 +526,9 @@ k_f_spacing_write(const FArgs av)
     const u64* E = a.E + (i64)isl * (a.ntiles1 + 1);
     const u64 pre = smc_uniform_u64(smc_ldg(E + b)), all = smc_uniform_u64(smc_ldg(E + a.ntiles1));
     const i64 n0 = (i64)b * F_TILE + (i64)threadIdx.x * F_IPT;
-    const u64* park = reinterpret_cast<const u64*>(a.su + (i64)isl * a.N);
-    u64 q[F_IPT], tsum = 0;
-    const bool has_last = n0 <= a.N && a.N < n0 + F_IPT;       // the (N+1)-th spacing has no slot: made again
-    u64 qn[4] = {0ull, 0ull, 0ull, 0ull};
-    if (has_last) f_spacing_q4(a, s_ntab, (u32)t, (u32)(a.island_offset + isl), n0, qn);
-#pragma unroll
-    for (int i = 0; i < F_IPT; ++i) {
-        q[i] = (n0 + i < a.N) ? park[n0 + i] : (n0 + i == a.N ? qn[i] : 0ull);
-        tsum += q[i];
-    }
+    u64 q[F_IPT];
+    f_spacing_q4(a, s_ntab, (u32)t, (u32)(a.island_offset + isl), n0, q);      // the same draws as pass 1
+    const u64 tsum = q[0] + q[1] + q[2] + q[3];
     u64 tot;
     u64 run = smc_block_exscan_u64(tsum, smu, tot) + pre;
     const double dall = (double)all;
@@ -1572,16 +1558,20 @@ __device__ inline i64 f2_count_sorted_range(const double* u, i64 lo, i64 hi, con
     return lo;
 }
 
-// ---- multinomial, production (Philox) mode: the sorted uniforms are NEVER materialised.  Draw n has
-// the integer spacing q_n (f_spacing_q4), Z_n = q_0 + .. + q_n, su_n = fl(Z_n) / fl(Z_N) (resampling.py:
-// 536-537: z[:-1] / z[-1]), T_n = ceil(su_n 2^52).  k_f_spacing_sums / _scan leave the exclusive prefix
-// of every tile of 1024 draws (E[k] = Z_{1024 k - 1}) and the total (E[ntiles1] = Z_N), so the last
-// threshold of every tile is known without generating it: B_k = T_{1024 k - 1} = t52(E[k] / all).  Hence
+// ---- multinomial, production (Philox) mode.  Draw n has the integer spacing q_n (f_spacing_q4),
+// Z_n = q_0 + .. + q_n, su_n = fl(Z_n) / fl(Z_N) (resampling.py:536-537: z[:-1] / z[-1]), written ONCE by
+// k_f_spacing_write; T_n = ceil(su_n 2^52).  k_f_spacing_sums / _scan leave the exclusive prefix of every
+// tile of 1024 draws (E[k] = Z_{1024 k - 1}) and the total (E[ntiles1] = Z_N), so the LAST threshold of
+// every tile is known without touching the uniforms: B_k = T_{1024 k - 1} = t52(E[k] / all).  Hence
 //     count(C) = #{n : T_n <= C} = 1024 k* + #{n in tile k* : T_n <= C},  k* = max{k : B_k <= C}  (B_0 = 0)
-// -- a search over the tile prefixes, then ONE tile of draws regenerated (same Philox counters, same
-// bits) and scanned.  A tile of 1024 parents owns 1024 +- a few dozen offspring, i.e. boundaries in
-// 2 (sometimes 1 or 3) tiles of draws; tiles no boundary falls into are never generated, so a
-// collapsed weight vector costs a few tiles as well.
+// -- one probe of the 32 KB of prefixes (a window of 64 tiles centred on the expected one) instead of
+// four dependent rounds of a 64-ary search over the N uniforms; the tiles k*(G_b) .. k*(G_b + Q_b) (2,
+// sometimes 1 or 3: a tile of 1024 parents owns 1024 +- a few dozen offspring) are then staged in LDS
+// whole and every boundary of the tile is a bisection there.
+// (Measured alternative, r04d: never writing the uniforms and REGENERATING those tiles inside
+//  k_ancestors2 brings its traffic down to 1.05x the bytes it must move but costs 2 700 VALU
+//  instructions per wave -- 94 us against 42 at N = 2^22: on this part 8 bytes from HBM are four times
+//  cheaper than 54 instructions.)
 struct F2Regen {
     const u64* E;          // (ntiles1 + 1) tile prefixes, the total last
     int ntiles1;
@@ -1626,36 +1616,6 @@ __device__ __forceinline__ i64 f2_regen_tiles_le_wave(const F2Regen& g, const u6
         hi = nhi;
     }
     return lo;
-}
-// the same by one lane over the tiles k_lo + 1 .. k_hi (tiles wider than the LDS stage of B values)
-__device__ inline i64 f2_regen_tiles_le_range(const F2Regen& g, i64 lo, i64 hi, const u64 C)
-{
-    while (lo < hi) {                                          // first k in [lo, hi) with B_k > C
-        const i64 mid = lo + ((hi - lo) >> 1);
-        if (f2_regen_B(g, mid) <= C) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-}
-// The thresholds of the 1024 draws of tile k into sT (every thread of the workgroup calls; two
-// barriers inside, one more is the caller's before sT is read); draws beyond N - 1 hold no uniform:
-// their slots get 2^63 (never counted)
-__device__ __forceinline__ void f2_regen_tile(const FArgs& a, const SmcD2* ntab, const F2Regen& g, const u32 t,
-                                              const u32 gisl, const i64 k, u64* sT, u64* smu)
-{
-    const int tid = (int)threadIdx.x;
-    const i64 n0 = k * F_TILE + (i64)tid * F_IPT;
-    u64 q[4];
-    f_spacing_q4(a, ntab, t, gisl, n0, q);
-    u64 tot;
-    u64 run = smc_block_exscan_u64(q[0] + q[1] + q[2] + q[3], smu, tot) + smc_ldg(g.E + k);
-    u64 T[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        run += q[i];
-        T[i] = (n0 + i < a.N) ? f2_t52(smc_div_c((double)run, g.dall, g.rdall)) : (1ull << 63);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) sT[tid * 4 + i] = T[i];
 }
 
 // first offspring ns[i] of the parents jt+i at positions cx[i] (cx[4]: the next thread's first
@@ -1930,8 +1890,8 @@ k_reduce2(const FArgs av)
 //     in flight): a tile owns 1024 +- a few dozen offspring.
 // MID: k_reduce2 ran first: grids too large for every workgroup to repeat the reduction.
 // ---------------------------------------------------------------------------
-// REGEN (MID, MULTI, Philox mode): the thresholds of the sorted uniforms come from regenerated tiles
-// of draws instead of memory (see F2Regen above).
+// REGEN (MID, MULTI, Philox mode): the tile's window of the sorted uniforms is found through the tile
+// prefixes of the spacings (one probe, see F2Regen above) and staged whole; tapes keep the search.
 template <bool MID, bool MULTI = false, bool POW2 = true, bool REGEN = false>
 __global__ void __launch_bounds__(SMC_BLOCK)
 k_ancestors2(const FArgs av)
@@ -2050,21 +2010,16 @@ k_ancestors2(const FArgs av)
     const u64 Gb = (u64)Gd, Qb = (u64)Qd;
     i64 ns[F_IPT + 1], n_lo, n_hi;
     if (REGEN) {
-        __shared__ __attribute__((aligned(16))) u64 sT[F_TILE];            // thresholds of one tile of draws
-        __shared__ u64 sB[SMC_BLOCK];                                      // B_k of the tiles k_lo + 1 .. k_hi
-        __shared__ u64 smu[SMC_SM];
+        constexpr int MAXT = 3;                                            // tiles of draws staged at once
+        __shared__ __attribute__((aligned(16))) u64 sT[MAXT * F_TILE];     // their thresholds (24 KB)
         __shared__ i64 s_k[2];
-        __shared__ u32 s_cur[SMC_NWAVE];
         __shared__ i64 s_edge[SMC_BLOCK + 1];
-        SMC_NTAB_LDS(s_ntab);
-        smc_ntab_stage<SMC_BLOCK>(s_ntab, tid);
-        const u32 gisl = (u32)(a.island_offset + isl);
         F2Regen g;
         g.E = a.E + (i64)isl * (a.ntiles1 + 1);
         g.ntiles1 = a.ntiles1;
         g.dall = (double)smc_uniform_u64(smc_ldg(g.E + a.ntiles1));
         g.rdall = 1.0 / g.dall;
-        // ---- the tiles of draws the tile's two ends fall into (one wave per end)
+        // ---- the tiles of draws the tile's two ends fall into (one wave per end, one probe each)
         const double per52 = (double)(N + 1) * 0x1.0p-62;                  // tiles of draws per unit of the scale
         if (wave == 0) {
             const i64 v = f2_regen_tiles_le_wave(g, Gb, (i64)((double)Gb * per52)) - 1;
@@ -2074,100 +2029,63 @@ k_ancestors2(const FArgs av)
             const i64 v = f2_regen_tiles_le_wave(g, Gb + Qb, (i64)((double)(Gb + Qb) * per52)) - 1;
             if (lane == 0) s_k[1] = v;
         }
-        __syncthreads();                                                   // (also: s_ntab staged)
-        const i64 k_lo = s_k[0], k_hi = s_k[1];
-        const i64 nb = k_hi - k_lo;                                        // B values strictly inside the range
-        const bool b_staged = nb <= SMC_BLOCK;
-        if (b_staged && tid < nb) sB[tid] = f2_regen_B(g, k_lo + 1 + tid);
         __syncthreads();
-        // ---- every boundary's position on the scale and its tile of draws.  fp64 quotient within 2^12 of
-        // floor(c Q_b / t_b) (f2_first_offspring); a tile edge B_k within 2^13 of it: the exact quotient
+        const i64 k_lo = s_k[0];
+        i64 k_hi = s_k[1];
+        k_hi = k_hi > (i64)a.ntiles1 - 1 ? (i64)a.ntiles1 - 1 : k_hi;       // (C >= 2^52: every draw counted)
+        const i64 w_lo = k_lo * F_TILE;                                    // first draw of the window
+        i64 w_hi = (k_hi + 1) * F_TILE;
+        w_hi = w_hi > N ? N : w_hi;                                        // one past its last uniform
+        const int nw = (int)(w_hi - w_lo);
+        const bool staged = k_hi - k_lo < MAXT;
+        if (staged) {
+            // whole tiles, 16-byte loads where the tile is whole (su is 8-byte aligned per island; N even
+            // and the window start a multiple of 1024 make the pairs aligned)
+            for (int i = tid * 2; i < nw; i += 2 * SMC_BLOCK) {
+                if (i + 1 < nw && ((N & 1) == 0)) {
+                    double u0, u1;
+                    smc_ld2g(su.u + w_lo + i, u0, u1);
+                    sT[i] = f2_t52(u0);
+                    sT[i + 1] = f2_t52(u1);
+                } else {
+                    sT[i] = f2_t52(smc_ldg(su.u + w_lo + i));
+                    if (i + 1 < nw) sT[i + 1] = f2_t52(smc_ldg(su.u + w_lo + i + 1));
+                }
+            }
+            __syncthreads();
+        }
+        // ---- every boundary: fp64 quotient within 2^12 of floor(c Q_b / t_b) (f2_first_offspring), the
+        // count decided unless a threshold lies within 2^13 of it -- then the exact 128-bit quotient
         const double qscale = (double)Qb / (double)(tb ? tb : 1ull);
         const u64 BAND = 1ull << 13;
-        u64 Cj[F_IPT + 1];
-        u32 kj[F_IPT + 1];                                                 // (tile of draws: < 2^21 on this path)
-        bool exact[F_IPT + 1], open[F_IPT + 1];
 #pragma unroll
         for (int i = 0; i <= F_IPT; ++i) {
             const i64 j = jt + i;
             const u64 c = cx[i];
             // (the 5th boundary is the next thread's first -- taken from it below -- except the last
             //  thread's: the tile's upper end, c = t_b)
-            open[i] = j > 0 && j < N && (i < F_IPT || tid == SMC_BLOCK - 1);
+            const bool open = j > 0 && j < N && (i < F_IPT || tid == SMC_BLOCK - 1);
             ns[i] = (j == 0) ? 0 : N;
-            exact[i] = a.exact_counts != 0;
-            u64 pos;
-            if (c == 0ull || c >= tb) {            // the tile's own ends: exact, and the same integers the
-                pos = c == 0ull ? 0ull : Qb;       // neighbouring tiles form for theirs
-                exact[i] = true;
-            } else if (exact[i]) {
-                pos = smc_muldiv_floor(c, Qb, tb);
-            } else {
-                pos = (u64)((double)c * qscale);
-                pos = pos > Qb ? Qb : pos;
+            if (!open) continue;
+            const bool end = c == 0ull || c >= tb;                        // the tile's own ends: exact integers
+            i64 cnt = -1;
+            if (staged && !a.exact_counts && !end) {
+                u64 qh = (u64)((double)c * qscale);
+                qh = qh > Qb ? Qb : qh;
+                const u64 Ch = Gb + qh;
+                const int k = f2_count_lds(sT, nw, Ch);
+                // (a threshold of the tile before the window is <= B_{k_lo} <= G_b <= Ch: only its distance
+                //  matters, and B_{k_lo} itself is the window's lower guard)
+                const bool below = k == 0 ? (k_lo == 0 || f2_regen_B(g, k_lo) + BAND <= Ch) : sT[k - 1] + BAND <= Ch;
+                const bool above = k == nw ? (w_hi >= N || f2_regen_B(g, k_hi + 1) > Ch + BAND) : sT[k] > Ch + BAND;
+                if (below && above) cnt = w_lo + k;
             }
-            Cj[i] = Gb + pos;
-            kj[i] = (u32)k_lo;
-            if (open[i]) {
-                for (int pass = 0; pass < 2; ++pass) {
-                    int kk;
-                    u64 below = 0ull, above = ~0ull;
-                    if (b_staged) {
-                        kk = f2_count_lds(sB, (int)nb, Cj[i]);
-                        if (kk > 0) below = sB[kk - 1];
-                        if (kk < (int)nb) above = sB[kk];
-                    } else {
-                        kk = (int)(f2_regen_tiles_le_range(g, k_lo + 1, k_hi + 1, Cj[i]) - (k_lo + 1));
-                        if (kk > 0) below = f2_regen_B(g, k_lo + kk);
-                        if (kk < (int)nb) above = f2_regen_B(g, k_lo + 1 + kk);
-                    }
-                    kj[i] = (u32)(k_lo + kk);
-                    const bool near = (kk > 0 && below + BAND > Cj[i]) || (kk < (int)nb && above <= Cj[i] + BAND);
-                    if (exact[i] || !near) break;
-                    Cj[i] = Gb + ((c == 0ull) ? 0ull : (c >= tb ? Qb : smc_muldiv_floor(c, Qb, tb)));
-                    exact[i] = true;
-                }
+            if (cnt < 0) {
+                const u64 pos = (c == 0ull) ? 0ull : (c >= tb ? Qb : smc_muldiv_floor(c, Qb, tb));
+                cnt = staged ? w_lo + f2_count_lds(sT, nw, Gb + pos)
+                             : f2_count_sorted_range(su.u, w_lo, w_hi, Gb + pos);
             }
-        }
-        // ---- the tiles some boundary falls into, in increasing order: regenerate, count
-        u32 prev = 0u;
-        bool first_round = true;
-        for (;;) {
-            u32 mine = 0xFFFFFFFFu;
-#pragma unroll
-            for (int i = 0; i <= F_IPT; ++i)
-                if (open[i] && (first_round || kj[i] > prev) && kj[i] < mine) mine = kj[i];
-            // block minimum = complement of the maximum of the complements
-            const u32 wmx = smc_readlane(smc_wave_scan_max_u32(~mine), 63);
-            __syncthreads();                                               // the previous round has read s_cur / sT
-            if (lane == 0) s_cur[wave] = wmx;
-            __syncthreads();
-            u32 mx = s_cur[0];
-#pragma unroll
-            for (int w = 1; w < SMC_NWAVE; ++w) mx = s_cur[w] > mx ? s_cur[w] : mx;
-            const u32 cur = ~mx;
-            if (cur == 0xFFFFFFFFu) break;
-            prev = cur;
-            first_round = false;
-            if (cur >= (u32)a.ntiles1) continue;                           // every draw counted: ns stays N
-            f2_regen_tile(a, s_ntab, g, (u32)t, gisl, (i64)cur, sT, smu);
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i <= F_IPT; ++i) {
-                if (!(open[i] && kj[i] == cur)) continue;
-                int k = f2_count_lds(sT, F_TILE, Cj[i]);
-                if (!exact[i]) {
-                    const bool below = k == 0 || sT[k - 1] + BAND <= Cj[i];
-                    const bool above = k == F_TILE || sT[k] > Cj[i] + BAND;
-                    if (!(below && above)) {       // a threshold within the band: the exact position (same tile:
-                        const u64 c = cx[i];       //  its edges were not within the band)
-                        const u64 pos = (c == 0ull) ? 0ull : (c >= tb ? Qb : smc_muldiv_floor(c, Qb, tb));
-                        k = f2_count_lds(sT, F_TILE, Gb + pos);
-                    }
-                }
-                const i64 v = (i64)cur * F_TILE + k;
-                ns[i] = v < N ? v : N;
-            }
+            ns[i] = cnt < N ? cnt : N;
         }
         // ---- the next thread's first boundary; the tile's range
         __syncthreads();

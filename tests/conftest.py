@@ -70,3 +70,24 @@ def _build_oracle():
     """The C half of the oracle is a build product (oracle/_build); make it."""
     subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True,
                    stdout=subprocess.DEVNULL)
+
+
+def pytest_terminal_summary(terminalreporter):
+    """The near-tie counts every audit observed (tests/parity_cases.log_near_ties), totalled: the log
+    of a run records how often the exact integer CDF and the reference's sequential fp64 CDF chose a
+    different -- certified near-tie -- ancestor."""
+    try:
+        import parity_cases as pc
+    except Exception:
+        return
+    if not pc.NEAR_TIE_LOG:
+        return
+    tr = terminalreporter
+    tr.write_sep("=", "near-ties against the reference's sequential CDF")
+    tot_t = tot_d = 0
+    for where, ties, draws in pc.NEAR_TIE_LOG:
+        tot_t += ties
+        tot_d += draws
+        if ties or draws >= 1 << 20:
+            tr.write_line("  %-52s %6d of %13d" % (where, ties, draws))
+    tr.write_line("  TOTAL %d near-ties in %d audited ancestors (%.2e per ancestor)" % (tot_t, tot_d, tot_t / max(1, tot_d)))

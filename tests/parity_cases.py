@@ -562,6 +562,17 @@ def audit_history(pf, mk_orc, fk, y, scheme, ESSrmin, z=None, u=None, exact=True
 
 EXACT_MODELS = ("toy", "lg", "gordon")          # IEEE + - * / only: X (and bootstrap lw) bit-exact
 
+NEAR_TIE_LOG = []
+
+
+def log_near_ties(where, ties, draws):
+    """Every audit records how many ancestors differed from the reference's sequential fp64 CDF
+    (each one certified a near-tie) out of how many draws: the test log then holds the observed
+    rate (pytest -s / the captured output of the GPU log), not an expectation."""
+    NEAR_TIE_LOG.append((where, int(ties), int(draws)))
+    print("near-ties vs the reference CDF: %-46s %6d of %12d ancestors (%.2e)"
+          % (where, ties, draws, ties / max(1, draws)))
+
 
 def check_filter_replay(golden, case, model, fk, T=None, N=None):
     """Replay the reference's own draws through the fused device loop.  ``N`` overrides
@@ -603,6 +614,7 @@ def check_filter_replay(golden, case, model, fk, T=None, N=None):
     mv = model.startswith("mv")
     ties = audit_history(ph, mk_orc, fk, y, scheme, ESSrmin, z=z, u=u,
                          exact=model in EXACT_MODELS, tol=1e-11 if mv else 1e-12)
+    log_near_ties("replay %s/%s N=%d T=%d %s" % (case, fk, N, len(y), scheme), ties, sum(o["rs_flag"]) * N)
     assert ties <= max(1, len(y) * N // 100000)
     if ties == 0 and not mv and len(y) > 1 and np.array_equal(pf.A, o["A"]):
         # nothing flipped anywhere: the free-running oracle IS this run
@@ -721,6 +733,7 @@ def check_two_level_injected(sizes=(4096, 3000)):
                 assert np.all(W[A] > 0)
                 A_ref = orc.inverse_cdf(su, W)
                 n, ok = orc.audit_near_ties(su, W, A_ref, A)
+                log_near_ties("injected %s %s N=%d" % (name, scheme, N), n, N)
                 assert ok and n <= max(1, N // 100000), (N, scheme, name, n)
         # multinomial: the sorted uniforms come from a tape (counts are searches over them), or --
         # production mode -- are the device's own draws, regenerated tile by tile inside k_ancestors2
@@ -745,6 +758,7 @@ def check_two_level_injected(sizes=(4096, 3000)):
             W = orc.exp_and_normalise(lwi)
             assert np.all(W[A] > 0)
             n, ok = orc.audit_near_ties(su, W, orc.inverse_cdf(su, W), A)
+            log_near_ties("injected %s multinomial %s N=%d" % (name, "tape" if rep else "philox", N), n, N)
             assert ok and n <= max(1, N // 100000), (N, "multinomial", name, n)
 
 
@@ -784,6 +798,8 @@ def check_oracle_at_size(model, mk_dev, mk_orc, N, T, scheme="systematic", ESSrm
     for isl in islands:
         ties += audit_history(ph, mk_orc, fk, y, scheme, ESSrmin, z=z, u=u, exact=model.startswith(EXACT_MODELS),
                               island=isl, tol=1e-11 if d > 1 else 1e-12)
+    log_near_ties("%s/%s N=%d T=%d %s %s" % (model, fk, N, T, scheme, "replay" if replay else "philox"), ties,
+                  int(np.sum(ph._summ()[list(islands), :, 4])) * N)
     assert ties <= max(1, len(islands) * T * N // 100000), ties
     pf = mk(False)
     pf.run()
@@ -812,7 +828,6 @@ def check_device_spacings(sizes=(2048, 3000, 1 << 14), seed=91):
             pf = pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y), N=N, resampling="multinomial", ESSrmin=1.0,
                         seed=seed, store_history=True, n_islands=n_islands, collect="off")
             pf.run()
-            assert "k_f_spacing_write" not in describe(pf)
             for t in (1, T - 1):
                 su = pf._spacings(t, isl)
                 want = orc.philox_spacings(seed, N, t, isl)
@@ -891,8 +906,8 @@ def check_describe():
     assert kernels(3000) == "k_ancestors2+k_propagate"                         # any N of >= 2 tiles: general counts
     assert kernels(1500) == "k_ancestors2+k_propagate"                         # (2 tiles, the second ragged)
     assert kernels(1 << 12, "multinomial") == \
-        "k_f_spacing_sums+k_f_spacing_scan+k_reduce2+k_ancestors2+k_propagate"   # two-level: counts by search, draws regenerated
-    assert kernels(1500, "multinomial") == "k_f_spacing_sums+k_f_spacing_scan+k_reduce2+k_ancestors2+k_propagate"
+        "k_f_spacing_sums+k_f_spacing_scan+k_f_spacing_write+k_reduce2+k_ancestors2+k_propagate"   # two-level: counts by search
+    assert kernels(1500, "multinomial") == "k_f_spacing_sums+k_f_spacing_scan+k_f_spacing_write+k_reduce2+k_ancestors2+k_propagate"
     mv = kalman.MVLinearGauss_Guarniero_etal(alpha=0.4, dx=4)
     ymv = [np.zeros((1, 4)) for _ in range(4)]
     pf = pa.SMC(fk=ssm.Bootstrap(ssm=mv, data=ymv), N=1 << 12, seed=1)
