@@ -1582,25 +1582,35 @@ __device__ __forceinline__ u64 f2_regen_B(const F2Regen& g, const i64 k)
     return f2_t52(smc_div_c((double)smc_ldg(g.E + k), g.dall, g.rdall));
 }
 // #{k in [0, ntiles1] : B_k <= C} >= 1 by a whole wavefront: first a window of 64 tiles centred on the
-// expected one (the uniforms deviate from n / N by O(1 / sqrt N): +- a tile or two), then 64-ary
-__device__ __forceinline__ i64 f2_regen_tiles_le_wave(const F2Regen& g, const u64 C, const i64 guess)
+// expected one (the uniforms deviate from n / N by O(1 / sqrt N): +- a tile or two), then 64-ary.
+// Bl, Bh: the bracketing values B_{k*} <= C < B_{k* + 1} (the last threshold of tile k* - 1 and of
+// tile k*): they come out of the probe's own lanes when the window brackets the answer (one round
+// trip in all), else they are loaded.
+__device__ __forceinline__ i64 f2_regen_tiles_le_wave(const F2Regen& g, const u64 C, const i64 guess, u64& Bl, u64& Bh)
 {
     const i64 M = (i64)g.ntiles1 + 1;
     const int lane = smc_lane();
     i64 lo = 0, hi = M;                                        // B_k <= C on [0, lo), > C on [hi, M)
+    bool have = false;
     {
         i64 w0 = guess - 32;
         w0 = w0 > M - 64 ? M - 64 : w0;
         w0 = w0 < 0 ? 0 : w0;
         const i64 k = w0 + lane;
         const bool in = k < M;
-        const bool le = in && f2_regen_B(g, in ? k : 0) <= C;
+        const u64 Bk = in ? f2_regen_B(g, k) : ~0ull;
+        const bool le = in && Bk <= C;
         const int cnt = (int)smc_wave_sum_u64(le ? 1ull : 0ull);
         const int nprobe = (int)(M - w0 < 64 ? M - w0 : 64);
         if (cnt > 0) lo = w0 + cnt;
         if (cnt < nprobe) hi = w0 + cnt;
         if (cnt == 0) hi = w0;
         if (hi < lo) hi = lo;
+        if (cnt > 0 && cnt < nprobe) {                         // bracketed inside the window
+            Bl = smc_readlane64(Bk, cnt - 1);
+            Bh = smc_readlane64(Bk, cnt);
+            have = true;
+        }
     }
     while (lo < hi) {
         const i64 width = hi - lo;
@@ -1614,6 +1624,20 @@ __device__ __forceinline__ i64 f2_regen_tiles_le_wave(const F2Regen& g, const u6
         const i64 nhi = cnt < nprobe ? lo + (i64)cnt * stride : hi;
         lo = nlo;
         hi = nhi;
+    }
+    if (!have) {
+        Bl = f2_regen_B(g, lo - 1);
+        Bh = lo < M ? f2_regen_B(g, lo) : ~0ull;
+    }
+    return lo;
+}
+// #{ i < n : T[i] <= C } in a sorted LDS window of integer-valued doubles
+__device__ __forceinline__ int f2_count_lds_f64(const double* T, const int n, const double C)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (T[mid] <= C) lo = mid + 1; else hi = mid;
     }
     return lo;
 }
@@ -2010,54 +2034,69 @@ k_ancestors2(const FArgs av)
     const u64 Gb = (u64)Gd, Qb = (u64)Qd;
     i64 ns[F_IPT + 1], n_lo, n_hi;
     if (REGEN) {
-        constexpr int MAXT = 3;                                            // tiles of draws staged at once
-        __shared__ __attribute__((aligned(16))) u64 sT[MAXT * F_TILE];     // their thresholds (24 KB)
+        // thresholds as integer-valued doubles (<= 2^52: exact, compared in fp64; no 64-bit conversions)
+        constexpr int WMAX = 1536;                                         // staged thresholds (12 KB)
+        constexpr int MARGIN = 128;                                        // > 8 sigma of a position inside a tile
+        __shared__ __attribute__((aligned(16))) double sT[WMAX];
         __shared__ i64 s_k[2];
+        __shared__ double s_b[4];
         __shared__ i64 s_edge[SMC_BLOCK + 1];
         F2Regen g;
         g.E = a.E + (i64)isl * (a.ntiles1 + 1);
         g.ntiles1 = a.ntiles1;
         g.dall = (double)smc_uniform_u64(smc_ldg(g.E + a.ntiles1));
         g.rdall = 1.0 / g.dall;
-        // ---- the tiles of draws the tile's two ends fall into (one wave per end, one probe each)
+        // ---- the tiles of draws the tile's two ends fall into (one wave per end, one probe each) and,
+        // by interpolation between the tile's first and last threshold, where in them
         const double per52 = (double)(N + 1) * 0x1.0p-62;                  // tiles of draws per unit of the scale
-        if (wave == 0) {
-            const i64 v = f2_regen_tiles_le_wave(g, Gb, (i64)((double)Gb * per52)) - 1;
-            if (lane == 0) s_k[0] = v;
-        }
-        if (wave == 1) {
-            const i64 v = f2_regen_tiles_le_wave(g, Gb + Qb, (i64)((double)(Gb + Qb) * per52)) - 1;
-            if (lane == 0) s_k[1] = v;
+        if (wave < 2) {
+            const u64 C = wave == 0 ? Gb : Gb + Qb;
+            u64 Bl, Bh;
+            const i64 v = f2_regen_tiles_le_wave(g, C, (i64)((double)C * per52), Bl, Bh) - 1;
+            if (lane == 0) { s_k[wave] = v; s_b[2 * wave] = (double)Bl; s_b[2 * wave + 1] = (double)(Bh == ~0ull ? Bl + 1ull : Bh); }
         }
         __syncthreads();
         const i64 k_lo = s_k[0];
         i64 k_hi = s_k[1];
         k_hi = k_hi > (i64)a.ntiles1 - 1 ? (i64)a.ntiles1 - 1 : k_hi;       // (C >= 2^52: every draw counted)
-        const i64 w_lo = k_lo * F_TILE;                                    // first draw of the window
+        const i64 w_lo = k_lo * F_TILE;                                    // the tiles' draws: [w_lo, w_hi)
         i64 w_hi = (k_hi + 1) * F_TILE;
-        w_hi = w_hi > N ? N : w_hi;                                        // one past its last uniform
-        const int nw = (int)(w_hi - w_lo);
-        const bool staged = k_hi - k_lo < MAXT;
+        w_hi = w_hi > N ? N : w_hi;
+        const double Cl = (double)Gb, Ch_ = (double)(Gb + Qb);
+        const double f_lo = (Cl - s_b[0]) / (s_b[1] - s_b[0]), f_hi = (Ch_ - s_b[2]) / (s_b[3] - s_b[2]);
+        i64 s0 = w_lo + (i64)(f_lo * (double)F_TILE) - MARGIN;
+        i64 s1 = k_hi * F_TILE + (i64)(f_hi * (double)F_TILE) + MARGIN;
+        s0 = (s0 < w_lo ? w_lo : s0) & ~(i64)1;
+        s1 = s1 > w_hi ? w_hi : s1;
+        s1 = s1 < s0 ? s0 : s1;
+        const int nw = (int)(s1 - s0);
+        bool staged = nw <= WMAX;
         if (staged) {
-            // whole tiles, 16-byte loads where the tile is whole (su is 8-byte aligned per island; N even
-            // and the window start a multiple of 1024 make the pairs aligned)
             for (int i = tid * 2; i < nw; i += 2 * SMC_BLOCK) {
-                if (i + 1 < nw && ((N & 1) == 0)) {
-                    double u0, u1;
-                    smc_ld2g(su.u + w_lo + i, u0, u1);
-                    sT[i] = f2_t52(u0);
-                    sT[i + 1] = f2_t52(u1);
-                } else {
-                    sT[i] = f2_t52(smc_ldg(su.u + w_lo + i));
-                    if (i + 1 < nw) sT[i + 1] = f2_t52(smc_ldg(su.u + w_lo + i + 1));
+                double u0, u1 = 2.0;
+                if (i + 1 < nw && (N & 1) == 0) smc_ld2g(su.u + s0 + i, u0, u1);
+                else {
+                    u0 = smc_ldg(su.u + s0 + i);
+                    if (i + 1 < nw) u1 = smc_ldg(su.u + s0 + i + 1);
                 }
+                sT[i] = ceil(u0 * 4503599627370496.0);
+                if (i + 1 < nw) sT[i + 1] = ceil(u1 * 4503599627370496.0);
             }
             __syncthreads();
+            // the window must hold every threshold in (G_b, G_b + Q_b]: the one before it at or below
+            // G_b (or the window starts with its tile), the one after it above G_b + Q_b (or it ends
+            // with its tile) -- else (skewed spacings: never seen) the slow path
+            const bool ok_lo = s0 == w_lo || (nw > 0 && sT[0] <= Cl);
+            const bool ok_hi = s1 == w_hi || (nw > 0 && sT[nw - 1] > Ch_);
+            staged = ok_lo && ok_hi;
         }
         // ---- every boundary: fp64 quotient within 2^12 of floor(c Q_b / t_b) (f2_first_offspring), the
-        // count decided unless a threshold lies within 2^13 of it -- then the exact 128-bit quotient
+        // count decided unless a threshold lies within 2^13 of it -- then the exact 128-bit quotient.
+        // A thread's boundaries are consecutive and a parent owns about one offspring: after the first
+        // bisection the next counts are a few steps further on.
         const double qscale = (double)Qb / (double)(tb ? tb : 1ull);
-        const u64 BAND = 1ull << 13;
+        const double BAND = 8192.0;
+        int kprev = -1;
 #pragma unroll
         for (int i = 0; i <= F_IPT; ++i) {
             const i64 j = jt + i;
@@ -2069,21 +2108,32 @@ k_ancestors2(const FArgs av)
             if (!open) continue;
             const bool end = c == 0ull || c >= tb;                        // the tile's own ends: exact integers
             i64 cnt = -1;
-            if (staged && !a.exact_counts && !end) {
-                u64 qh = (u64)((double)c * qscale);
-                qh = qh > Qb ? Qb : qh;
-                const u64 Ch = Gb + qh;
-                const int k = f2_count_lds(sT, nw, Ch);
-                // (a threshold of the tile before the window is <= B_{k_lo} <= G_b <= Ch: only its distance
-                //  matters, and B_{k_lo} itself is the window's lower guard)
-                const bool below = k == 0 ? (k_lo == 0 || f2_regen_B(g, k_lo) + BAND <= Ch) : sT[k - 1] + BAND <= Ch;
-                const bool above = k == nw ? (w_hi >= N || f2_regen_B(g, k_hi + 1) > Ch + BAND) : sT[k] > Ch + BAND;
-                if (below && above) cnt = w_lo + k;
-            }
-            if (cnt < 0) {
+            if (staged) {
+                bool exact = end || a.exact_counts != 0;
+                u64 pos;
+                if (end) pos = c == 0ull ? 0ull : Qb;
+                else if (exact) pos = smc_muldiv_floor(c, Qb, tb);
+                else { pos = (u64)((double)c * qscale); pos = pos > Qb ? Qb : pos; }
+                for (int pass = 0; pass < 2; ++pass) {
+                    const double Cd = (double)(Gb + pos);
+                    int k;
+                    if (kprev >= 0 && pass == 0) {                        // gallop from the previous boundary's count
+                        k = kprev;
+                        int st = 0;
+                        while (st < 4 && k < nw && sT[k] <= Cd) { ++k; ++st; }
+                        if (st == 4 && k < nw && sT[k] <= Cd) k += f2_count_lds_f64(sT + k, nw - k, Cd);
+                    } else {
+                        k = f2_count_lds_f64(sT, nw, Cd);
+                    }
+                    const bool below = k == 0 || sT[k - 1] + BAND <= Cd;   // (k == 0: the threshold before the
+                    const bool above = k == nw || sT[k] > Cd + BAND;       //  window is <= G_b - ... : see ok_lo)
+                    if (exact || (below && above)) { cnt = s0 + k; kprev = k; break; }
+                    pos = smc_muldiv_floor(c, Qb, tb);
+                    exact = true;
+                }
+            } else {
                 const u64 pos = (c == 0ull) ? 0ull : (c >= tb ? Qb : smc_muldiv_floor(c, Qb, tb));
-                cnt = staged ? w_lo + f2_count_lds(sT, nw, Gb + pos)
-                             : f2_count_sorted_range(su.u, w_lo, w_hi, Gb + pos);
+                cnt = f2_count_sorted_range(su.u, w_lo, w_hi, Gb + pos);
             }
             ns[i] = cnt < N ? cnt : N;
         }
