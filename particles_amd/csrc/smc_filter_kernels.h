@@ -2037,7 +2037,7 @@ k_ancestors2(const FArgs av)
         // thresholds as integer-valued doubles (<= 2^52: exact, compared in fp64; no 64-bit conversions)
         constexpr int WMAX = 1536;                                         // staged thresholds (12 KB)
         constexpr int MARGIN = 128;                                        // > 8 sigma of a position inside a tile
-        __shared__ __attribute__((aligned(16))) double sT[WMAX];
+        __shared__ __attribute__((aligned(16))) double sT[WMAX + 4];       // (+ 4 guard slots)
         __shared__ i64 s_k[2];
         __shared__ double s_b[4];
         __shared__ i64 s_edge[SMC_BLOCK + 1];
@@ -2090,52 +2090,74 @@ k_ancestors2(const FArgs av)
             const bool ok_hi = s1 == w_hi || (nw > 0 && sT[nw - 1] > Ch_);
             staged = ok_lo && ok_hi;
         }
-        // ---- every boundary: fp64 quotient within 2^12 of floor(c Q_b / t_b) (f2_first_offspring), the
-        // count decided unless a threshold lies within 2^13 of it -- then the exact 128-bit quotient.
-        // A thread's boundaries are consecutive and a parent owns about one offspring: after the first
-        // bisection the next counts are a few steps further on.
+        // ---- every boundary: position on the scale as G_b + floor(c Q_b / t_b) with the quotient in fp64
+        // (within 2^12 of the exact one; all values integers below 2^53: exact doubles), the count decided
+        // unless a threshold lies within 2^13 of it -- then the exact 128-bit quotient.  A thread's boundaries
+        // are consecutive and a parent owns about one offspring: ONE bisection for the first, then each
+        // count is the previous one plus the number of the next 4 thresholds at or below the new position
+        // (all lanes do the same 4 comparisons; a parent with more than 3 offspring: 2 % of them: bisects).
         const double qscale = (double)Qb / (double)(tb ? tb : 1ull);
-        const double BAND = 8192.0;
-        int kprev = -1;
+        const double BAND = 8192.0, Gbd = (double)Gb, Qbd = (double)Qb;
+        if (staged) {
+            // guards: sT[-1] below everything this tile compares with (see ok_lo), 4 slots of +inf at the end
+            for (int i = tid; i < 4; i += SMC_BLOCK) sT[nw + i] = INFINITY;
+            __syncthreads();
+            int kprev = 0;
+            bool have_prev = false;
 #pragma unroll
-        for (int i = 0; i <= F_IPT; ++i) {
-            const i64 j = jt + i;
-            const u64 c = cx[i];
-            // (the 5th boundary is the next thread's first -- taken from it below -- except the last
-            //  thread's: the tile's upper end, c = t_b)
-            const bool open = j > 0 && j < N && (i < F_IPT || tid == SMC_BLOCK - 1);
-            ns[i] = (j == 0) ? 0 : N;
-            if (!open) continue;
-            const bool end = c == 0ull || c >= tb;                        // the tile's own ends: exact integers
-            i64 cnt = -1;
-            if (staged) {
+            for (int i = 0; i <= F_IPT; ++i) {
+                const i64 j = jt + i;
+                const u64 c = cx[i];
+                // (the 5th boundary is the next thread's first -- taken from it below -- except the last
+                //  thread's: the tile's upper end, c = t_b)
+                const bool open = j > 0 && j < N && (i < F_IPT || tid == SMC_BLOCK - 1);
+                ns[i] = (j == 0) ? 0 : N;
+                if (!open) continue;
+                const bool end = c == 0ull || c >= tb;                    // the tile's own ends: exact integers
                 bool exact = end || a.exact_counts != 0;
-                u64 pos;
-                if (end) pos = c == 0ull ? 0ull : Qb;
-                else if (exact) pos = smc_muldiv_floor(c, Qb, tb);
-                else { pos = (u64)((double)c * qscale); pos = pos > Qb ? Qb : pos; }
-                for (int pass = 0; pass < 2; ++pass) {
-                    const double Cd = (double)(Gb + pos);
-                    int k;
-                    if (kprev >= 0 && pass == 0) {                        // gallop from the previous boundary's count
-                        k = kprev;
-                        int st = 0;
-                        while (st < 4 && k < nw && sT[k] <= Cd) { ++k; ++st; }
-                        if (st == 4 && k < nw && sT[k] <= Cd) k += f2_count_lds_f64(sT + k, nw - k, Cd);
-                    } else {
+                double Cd;
+                if (end) Cd = c == 0ull ? Gbd : Gbd + Qbd;
+                else if (exact) Cd = (double)(Gb + smc_muldiv_floor(c, Qb, tb));
+                else Cd = Gbd + fmin(floor((double)c * qscale), Qbd);
+                int k;
+                if (have_prev) {
+                    const double t0 = sT[kprev], t1 = sT[kprev + 1], t2 = sT[kprev + 2], t3 = sT[kprev + 3];
+                    const int adv = (t0 <= Cd ? 1 : 0) + (t1 <= Cd ? 1 : 0) + (t2 <= Cd ? 1 : 0) + (t3 <= Cd ? 1 : 0);
+                    k = kprev + adv;
+                    if (adv == 4) k += f2_count_lds_f64(sT + k, nw - k, Cd);
+                } else {
+                    k = f2_count_lds_f64(sT, nw, Cd);
+                }
+                if (!exact) {
+                    const bool below = k == 0 || sT[k - 1] + BAND <= Cd;   // (k == 0: see ok_lo)
+                    const bool above = sT[k] > Cd + BAND;                  // (k == nw: the +inf guard)
+                    if (!(below && above)) {
+                        Cd = (double)(Gb + smc_muldiv_floor(c, Qb, tb));
                         k = f2_count_lds_f64(sT, nw, Cd);
                     }
-                    const bool below = k == 0 || sT[k - 1] + BAND <= Cd;   // (k == 0: the threshold before the
-                    const bool above = k == nw || sT[k] > Cd + BAND;       //  window is <= G_b - ... : see ok_lo)
-                    if (exact || (below && above)) { cnt = s0 + k; kprev = k; break; }
-                    pos = smc_muldiv_floor(c, Qb, tb);
-                    exact = true;
                 }
-            } else {
-                const u64 pos = (c == 0ull) ? 0ull : (c >= tb ? Qb : smc_muldiv_floor(c, Qb, tb));
-                cnt = f2_count_sorted_range(su.u, w_lo, w_hi, Gb + pos);
+                kprev = k;
+                have_prev = true;
+                const i64 cnt = s0 + k;
+                ns[i] = cnt < N ? cnt : N;
             }
-            ns[i] = cnt < N ? cnt : N;
+        } else {
+#pragma unroll 1
+            for (int i = 0; i <= F_IPT; ++i) {
+                const i64 j = jt + i;
+                u64 c = cx[0];
+#pragma unroll
+                for (int q = 1; q <= F_IPT; ++q) c = (i == q) ? cx[q] : c;
+                const bool open = j > 0 && j < N && (i < F_IPT || tid == SMC_BLOCK - 1);
+                i64 v = (j == 0) ? 0 : N;
+                if (open) {
+                    const u64 pos = (c == 0ull) ? 0ull : (c >= tb ? Qb : smc_muldiv_floor(c, Qb, tb));
+                    const i64 cnt = f2_count_sorted_range(su.u, w_lo, w_hi, Gb + pos);
+                    v = cnt < N ? cnt : N;
+                }
+#pragma unroll
+                for (int q = 0; q <= F_IPT; ++q) ns[q] = (i == q) ? v : ns[q];
+            }
         }
         // ---- the next thread's first boundary; the tile's range
         __syncthreads();
