@@ -118,9 +118,19 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
                 // production mode: uniform_spacings in two passes over the same draws (tile sums, their
                 // prefixes, the uniforms written once); k_ancestors2 finds its window through the prefixes
                 const dim3 g1(f->a.ntiles1, f->a.n_islands);
-                SMC_LAUNCH(k_f_spacing_sums, g1, dim3(SMC_BLOCK), st, f->a);
-                SMC_LAUNCH(k_f_spacing_scan, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
-                SMC_LAUNCH(k_f_spacing_write, g1, dim3(SMC_BLOCK), st, f->a);
+                if (f->a.sp_tpw) {                 // one pass (decoupled look-back): every workgroup resident
+                    const dim3 gw(f->a.sp_nwg, f->a.n_islands);
+                    switch (f->a.sp_tpw) {
+                    case 1: SMC_LAUNCH(k_f_spacing_onepass<1>, gw, dim3(SMC_BLOCK), st, f->a); break;
+                    case 2: SMC_LAUNCH(k_f_spacing_onepass<2>, gw, dim3(SMC_BLOCK), st, f->a); break;
+                    case 4: SMC_LAUNCH(k_f_spacing_onepass<4>, gw, dim3(SMC_BLOCK), st, f->a); break;
+                    default: SMC_LAUNCH(k_f_spacing_onepass<8>, gw, dim3(SMC_BLOCK), st, f->a); break;
+                    }
+                } else {
+                    SMC_LAUNCH(k_f_spacing_sums, g1, dim3(SMC_BLOCK), st, f->a);
+                    SMC_LAUNCH(k_f_spacing_scan, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
+                    SMC_LAUNCH(k_f_spacing_write, g1, dim3(SMC_BLOCK), st, f->a);
+                }
                 SMC_LAUNCH((k_ancestors2<true, true, true, true>), grid, dim3(SMC_BLOCK), st, f->a);
             } else {
                 SMC_LAUNCH((k_ancestors2<true, true>), grid, dim3(SMC_BLOCK), st, f->a);
@@ -340,6 +350,16 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     const size_t oHlist = carve(heavy_list ? M * 2 * F_HMAX * 3 * 8 : 8);
     const size_t oSu = carve(need_su ? M * N * 8 + 16 : 8);
     const size_t oE = carve(need_su ? M * (a.ntiles1 + 1) * 8 : 8);
+    // one-pass uniform_spacings (two-level step, Philox draws): 1, 2, 4 or 8 tiles of draws per workgroup,
+    // the fewest that keep the whole launch resident (<= 1024 workgroups: half of what the chip holds);
+    // more islands than that: the three-pass form
+    a.sp_tpw = a.sp_nwg = 0;
+    if (need_su && f->two_level && !getenv("SMC_SPACING_3PASS"))
+        for (int tpw = 1; tpw <= 8 && !a.sp_tpw; tpw *= 2) {
+            const i64 nwg = (a.ntiles1 + tpw - 1) / tpw;
+            if (nwg * (i64)M <= 1024) { a.sp_tpw = tpw; a.sp_nwg = (int)nwg; }
+        }
+    const size_t oSst = carve(a.sp_tpw ? M * a.sp_nwg * 8 : 8);
     const size_t oTmp = carve(N * dxm * 8);
     a.nmb = (int)((o->N + F_MOM_CHUNK - 1) / F_MOM_CHUNK);
     const size_t oMom = carve(o->moments ? M * T * 2 * dxm * 8 : 8);
@@ -405,6 +425,8 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     }
     a.su = (double*)(base + oSu);
     a.E = (u64*)(base + oE);
+    a.sst = (u64*)(base + oSst);
+    if (a.sp_tpw) F_CREATE_CHECK(hipMemsetAsync(a.sst, 0, M * a.sp_nwg * 8, ctx->stream));
     f->tmp = (double*)(base + oTmp);
     f->ll_stage = nullptr;
     {
@@ -531,7 +553,7 @@ int smc_filter_clone(smc_filter* src, smc_filter** out)
     rebase(a.X); rebase(a.lw); rebase(a.A); rebase(a.Q); rebase(a.Qpre); rebase(a.pm); rebase(a.ps); rebase(a.pss);
     rebase(a.cq); rebase(a.tq); rebase(a.cnt); rebase(a.spart); rebase(a.summ); rebase(a.params); rebase(a.y);
     rebase(a.mom); rebase(a.mpart); rebase(a.aux); rebase(a.info); rebase(a.hcnt); rebase(a.hlist); rebase(a.info2);
-    rebase(a.su); rebase(a.E); rebase(a.mvc); rebase(a.trace); rebase(a.pm2); rebase(a.ps2); rebase(a.pss2);
+    rebase(a.su); rebase(a.E); rebase(a.sst); rebase(a.mvc); rebase(a.trace); rebase(a.pm2); rebase(a.ps2); rebase(a.pss2);
     rebase(f->tmp);
     hipStream_t st = ctx->stream;
     hipError_t e = hipMemcpyAsync(slab, src->slab, src->slab_bytes, hipMemcpyDeviceToDevice, st);
@@ -1298,7 +1320,8 @@ int smc_filter_describe(smc_filter* f, char* out, size_t n)
         else if (f->two_level) s = "k_ancestors2";
         else if (f->fused) s = "k_ancestors<fused>";
         else s = "k_prepare+k_ancestors";
-        if (f->a.scheme == SMC_MULTINOMIAL && !f->a.ut) s = "k_f_spacing_sums+k_f_spacing_scan+k_f_spacing_write+" + s;
+        if (f->a.scheme == SMC_MULTINOMIAL && !f->a.ut)
+            s = (f->a.sp_tpw ? "k_f_spacing_onepass+" : "k_f_spacing_sums+k_f_spacing_scan+k_f_spacing_write+") + s;
         s += mv ? (f->mv_collapsed ? "+k_propagate_mv<collapsed>" : "+k_propagate_mv") : "+k_propagate";
         if (mv) s += " [mv_chunks=" + std::to_string(f->a.mv_chunks) + "]";
         if (f->a.mom) s += "+k_f_moments_partials+k_f_moments_final";

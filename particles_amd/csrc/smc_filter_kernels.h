@@ -117,6 +117,9 @@ struct FArgs {
     int kform;             // two-level step: the row's (K, 1/s) normalise weights kept as (p, k) pairs, and
                            // the count of steps done lives in info2 (the side kernels: moments)
     i64 ncq;               // per-island stride of cq: ntiles x 1024 (the last tile may be ragged)
+    u64* sst;              // one-pass uniform_spacings: (n_islands, sp_nwg) look-back status words, 0 between steps
+    int sp_tpw, sp_nwg;    // ... tiles of draws per workgroup (0: the three-pass form) and workgroups per island;
+                           // `su` then holds the integer prefix sums Z_n (u64), not the quotients
     double *pm2, *ps2, *pss2;   // APF on the two-level path: the tile partials of the PLAIN weights
                            // (pm/ps/pss, cq, tq then describe the AUXILIARY weights lw + logeta,
                            // which decide and drive the resampling -- core.py:307-313); else null
@@ -537,6 +540,113 @@ k_f_spacing_write(const FArgs av)
     for (int i = 0; i < F_IPT; ++i) {
         run += q[i];
         if (n0 + i < a.N) su[n0 + i] = (double)run / dall;
+    }
+}
+
+// uniform_spacings in ONE pass (two-level step, production mode): a workgroup makes the draws of TPW
+// consecutive tiles (32 per thread at TPW = 8, kept in registers), scans them, publishes its total,
+// obtains the total of everything before it by a decoupled look-back over the workgroups' status
+// words and writes the integer prefix sums Z_n -- the draws are made once, 8 bytes per draw are
+// written once (k_ancestors2 divides by Z_N when it stages its window), and the tile prefixes E[k] the
+// window search needs come out on the way.  Status word of workgroup w: (value << 2) | flag, flag 1 =
+// value is the workgroup's own total, 2 = the inclusive prefix up to and including it; 0 = not there
+// yet (k_ancestors2 zeroes the words again).  The grid is sized by the host so that EVERY workgroup is
+// resident at once (<= 1024 of them): a spinning workgroup can then never keep the one it waits for
+// off the chip, whatever the dispatch order; the spin is bounded all the same.
+#define SP_FLAG_AGG 1ull
+#define SP_FLAG_INC 2ull
+template <int TPW>
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_f_spacing_onepass(const FArgs av)
+{
+    const FArgs& a = av;
+    __shared__ u64 s_w[TPW][SMC_NWAVE];
+    __shared__ u64 s_pre;
+    SMC_NTAB_LDS(s_ntab);
+    const int w = (int)blockIdx.x, isl = (int)blockIdx.y;
+    const int tid = (int)threadIdx.x, lane = smc_lane(), wave = smc_wave();
+    smc_ntab_stage<SMC_BLOCK>(s_ntab, tid);
+    __syncthreads();
+    const double* info = a.info + (i64)isl * INFO_STRIDE;
+    const i64 t = (i64)smc_uniform(info[0]);
+    if (t >= a.T || t == 0 || smc_uniform(info[1]) == 0.0) return;
+    const u32 gisl = (u32)(a.island_offset + isl);
+    u64* st = a.sst + (i64)isl * a.sp_nwg;
+    u64* E = a.E + (i64)isl * (a.ntiles1 + 1);
+    u64* Z = reinterpret_cast<u64*>(a.su) + (i64)isl * a.N;
+    // ---- the draws of my tiles (tile r: draws 1024 (w TPW + r) + 4 tid ..), wave scans, tile totals
+    u64 q[TPW][4], inc[TPW];
+#pragma unroll
+    for (int r = 0; r < TPW; ++r) {
+        const i64 k = (i64)w * TPW + r;
+        if (k < a.ntiles1) f_spacing_q4(a, s_ntab, (u32)t, gisl, k * F_TILE + (i64)tid * F_IPT, q[r]);
+        else { q[r][0] = q[r][1] = q[r][2] = q[r][3] = 0ull; }
+        inc[r] = smc_wave_scan_add_u64(q[r][0] + q[r][1] + q[r][2] + q[r][3]);
+    }
+    if (lane == 63) {
+#pragma unroll
+        for (int r = 0; r < TPW; ++r) s_w[r][wave] = inc[r];
+    }
+    __syncthreads();
+    u64 base[TPW], total = 0ull;          // base[r]: everything of my workgroup before this thread's draws of tile r
+#pragma unroll
+    for (int r = 0; r < TPW; ++r) {
+        u64 b = total;
+#pragma unroll
+        for (int v = 0; v < SMC_NWAVE; ++v) {
+            if (v < wave) b += s_w[r][v];
+            total += s_w[r][v];
+        }
+        base[r] = b + inc[r] - (q[r][0] + q[r][1] + q[r][2] + q[r][3]);
+    }
+    // ---- publish my total, look back for the prefix (wave 0; lanes = the 64 nearest predecessors)
+    if (wave == 0) {
+        if (lane == 0) smc_st_agent(st + w, (total << 2) | (w == 0 ? SP_FLAG_INC : SP_FLAG_AGG));
+        u64 excl = 0ull;
+        int look = w - 1;
+        while (look >= 0) {
+            const int idx = look - lane;
+            u64 word = SP_FLAG_INC;                                        // before workgroup 0: prefix 0
+            if (idx >= 0) {
+                word = smc_ld_agent(st + idx);
+                for (int spin = 0; (word & 3ull) == 0ull && spin < (1 << 22); ++spin) {
+                    smc_spin_pause();
+                    word = smc_ld_agent(st + idx);
+                }
+            }
+            const u64 mask = __ballot((word & 3ull) == SP_FLAG_INC ? 1 : 0);   // nearest one holding a prefix
+            const int first = mask ? __builtin_ctzll(mask) : 64;
+            excl += smc_wave_sum_u64(lane <= first ? (word >> 2) : 0ull);
+            if (mask) break;
+            look -= 64;
+        }
+        if (lane == 0) {
+            if (w > 0) smc_st_agent(st + w, ((excl + total) << 2) | SP_FLAG_INC);
+            s_pre = excl;
+            if (w == a.sp_nwg - 1) E[a.ntiles1] = excl + total;           // Z_N
+        }
+    }
+    __syncthreads();
+    const u64 pre = s_pre;
+    // ---- the prefix sums of my draws; the tiles' exclusive prefixes for the window search
+#pragma unroll
+    for (int r = 0; r < TPW; ++r) {
+        const i64 k = (i64)w * TPW + r;
+        if (k >= a.ntiles1) break;
+        const i64 n0 = k * F_TILE + (i64)tid * F_IPT;
+        u64 run = pre + base[r];
+        if (tid == 0) E[k] = run;
+        u64 z4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { run += q[r][i]; z4[i] = run; }
+        if (n0 + 3 < a.N && (a.N & 1) == 0) {
+            smc_st2g(Z + n0, z4[0], z4[1]);
+            smc_st2g(Z + n0 + 2, z4[2], z4[3]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (n0 + i < a.N) smc_stg(Z + n0 + i, z4[i]);
+        }
     }
 }
 
@@ -2071,6 +2181,8 @@ k_ancestors2(const FArgs av)
         s1 = s1 < s0 ? s0 : s1;
         const int nw = (int)(s1 - s0);
         bool staged = nw <= WMAX;
+        const bool zform = a.sp_tpw > 0;           // su holds the integer prefix sums Z_n: su_n = fl(Z_n) / fl(Z_N)
+        if (zform && b < a.sp_nwg && tid == 0) a.sst[(i64)isl * a.sp_nwg + b] = 0ull;     // look-back words: re-armed
         if (staged) {
             for (int i = tid * 2; i < nw; i += 2 * SMC_BLOCK) {
                 double u0, u1 = 2.0;
@@ -2078,6 +2190,10 @@ k_ancestors2(const FArgs av)
                 else {
                     u0 = smc_ldg(su.u + s0 + i);
                     if (i + 1 < nw) u1 = smc_ldg(su.u + s0 + i + 1);
+                }
+                if (zform) {
+                    u0 = smc_div_c((double)(u64)__double_as_longlong(u0), g.dall, g.rdall);
+                    u1 = smc_div_c((double)(u64)__double_as_longlong(u1), g.dall, g.rdall);
                 }
                 sT[i] = ceil(u0 * 4503599627370496.0);
                 if (i + 1 < nw) sT[i + 1] = ceil(u1 * 4503599627370496.0);
@@ -2152,8 +2268,14 @@ k_ancestors2(const FArgs av)
                 i64 v = (j == 0) ? 0 : N;
                 if (open) {
                     const u64 pos = (c == 0ull) ? 0ull : (c >= tb ? Qb : smc_muldiv_floor(c, Qb, tb));
-                    const i64 cnt = f2_count_sorted_range(su.u, w_lo, w_hi, Gb + pos);
-                    v = cnt < N ? cnt : N;
+                    i64 lo_ = w_lo, hi_ = w_hi;                            // first threshold in the tiles above C
+                    while (lo_ < hi_) {
+                        const i64 mid = lo_ + ((hi_ - lo_) >> 1);
+                        double um = smc_ldg(su.u + mid);
+                        if (zform) um = smc_div_c((double)(u64)__double_as_longlong(um), g.dall, g.rdall);
+                        if (f2_t52(um) <= Gb + pos) lo_ = mid + 1; else hi_ = mid;
+                    }
+                    v = lo_ < N ? lo_ : N;
                 }
 #pragma unroll
                 for (int q = 0; q <= F_IPT; ++q) ns[q] = (i == q) ? v : ns[q];

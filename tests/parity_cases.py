@@ -744,7 +744,7 @@ def check_two_level_injected(sizes=(4096, 3000)):
         for (name, lwi), rep in [((n_, l_), r_) for n_, l_ in cases for r_ in (True, False)]:
             pf = pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y), N=N, resampling="multinomial",
                         ESSrmin=2.0, seed=7, collect="off", replay=(z, u) if rep else None)
-            assert "k_ancestors2" in describe(pf) and ("k_f_spacing_sums" in describe(pf)) == (not rep)
+            assert "k_ancestors2" in describe(pf) and ("k_f_spacing_onepass" in describe(pf)) == (not rep)
             next(pf)
             pf.set_state(lw=lwi)
             X0 = np.array(pf.X)
@@ -906,8 +906,8 @@ def check_describe():
     assert kernels(3000) == "k_ancestors2+k_propagate"                         # any N of >= 2 tiles: general counts
     assert kernels(1500) == "k_ancestors2+k_propagate"                         # (2 tiles, the second ragged)
     assert kernels(1 << 12, "multinomial") == \
-        "k_f_spacing_sums+k_f_spacing_scan+k_f_spacing_write+k_reduce2+k_ancestors2+k_propagate"   # two-level: counts by search
-    assert kernels(1500, "multinomial") == "k_f_spacing_sums+k_f_spacing_scan+k_f_spacing_write+k_reduce2+k_ancestors2+k_propagate"
+        "k_f_spacing_onepass+k_reduce2+k_ancestors2+k_propagate"   # two-level: one-pass spacings, counts by search
+    assert kernels(1500, "multinomial") == "k_f_spacing_onepass+k_reduce2+k_ancestors2+k_propagate"
     mv = kalman.MVLinearGauss_Guarniero_etal(alpha=0.4, dx=4)
     ymv = [np.zeros((1, 4)) for _ in range(4)]
     pf = pa.SMC(fk=ssm.Bootstrap(ssm=mv, data=ymv), N=1 << 12, seed=1)
