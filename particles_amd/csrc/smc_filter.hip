@@ -357,7 +357,22 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     if (need_su && f->two_level && !getenv("SMC_SPACING_3PASS"))
         for (int tpw = 1; tpw <= 8 && !a.sp_tpw; tpw *= 2) {
             const i64 nwg = (a.ntiles1 + tpw - 1) / tpw;
-            if (nwg * (i64)M <= 1024) { a.sp_tpw = tpw; a.sp_nwg = (int)nwg; }
+            int per_cu = 0;                        // workgroups of this instantiation a CU holds at once
+#ifdef SMC_EMULATE
+            per_cu = 4;
+#else
+            const void* fn = tpw == 1 ? (const void*)k_f_spacing_onepass<1> : tpw == 2 ? (const void*)k_f_spacing_onepass<2>
+                           : tpw == 4 ? (const void*)k_f_spacing_onepass<4> : (const void*)k_f_spacing_onepass<8>;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, SMC_BLOCK, 0) != hipSuccess) per_cu = 0;
+            (void)hipGetLastError();
+#endif
+            // (a margin of one workgroup per CU: the occupancy API is optimistic near register-file edges)
+#ifdef SMC_EMULATE
+            const i64 cap = 1024;                  // (workgroups run one after the other, in order)
+#else
+            const i64 cap = (i64)(per_cu > 1 ? per_cu - 1 : 0) * ctx->n_cu;
+#endif
+            if (nwg * (i64)M <= cap && nwg * (i64)M <= 1024) { a.sp_tpw = tpw; a.sp_nwg = (int)nwg; }
         }
     const size_t oSst = carve(a.sp_tpw ? M * a.sp_nwg * 8 : 8);
     const size_t oTmp = carve(N * dxm * 8);

@@ -548,15 +548,17 @@ k_f_spacing_write(const FArgs av)
 // obtains the total of everything before it by a decoupled look-back over the workgroups' status
 // words and writes the integer prefix sums Z_n -- the draws are made once, 8 bytes per draw are
 // written once (k_ancestors2 divides by Z_N when it stages its window), and the tile prefixes E[k] the
-// window search needs come out on the way.  Status word of workgroup w: (value << 2) | flag, flag 1 =
-// value is the workgroup's own total, 2 = the inclusive prefix up to and including it; 0 = not there
-// yet (k_ancestors2 zeroes the words again).  The grid is sized by the host so that EVERY workgroup is
-// resident at once (<= 1024 of them): a spinning workgroup can then never keep the one it waits for
-// off the chip, whatever the dispatch order; the spin is bounded all the same.
+// window search needs come out on the way.  Status word of workgroup w: (its total << 2) | 1, 0 = not
+// there yet (k_ancestors2 zeroes the words again).  The grid is sized by the host so that EVERY
+// workgroup is resident at once (smc_filter_create asks the runtime how many fit): a spinning
+// workgroup can then never keep the one it waits for off the chip, whatever the dispatch order; the
+// spin is bounded all the same.  (3 waves per SIMD at least: 170 VGPRs for the 32 draws of a thread.)
 #define SP_FLAG_AGG 1ull
-#define SP_FLAG_INC 2ull
 template <int TPW>
 __global__ void __launch_bounds__(SMC_BLOCK)
+#ifndef SMC_EMULATE
+__attribute__((amdgpu_waves_per_eu(3, 8)))
+#endif
 k_f_spacing_onepass(const FArgs av)
 {
     const FArgs& a = av;
@@ -599,32 +601,29 @@ k_f_spacing_onepass(const FArgs av)
         }
         base[r] = b + inc[r] - (q[r][0] + q[r][1] + q[r][2] + q[r][3]);
     }
-    // ---- publish my total, look back for the prefix (wave 0; lanes = the 64 nearest predecessors)
-    if (wave == 0) {
-        if (lane == 0) smc_st_agent(st + w, (total << 2) | (w == 0 ? SP_FLAG_INC : SP_FLAG_AGG));
+    // ---- publish my total; the prefix = the totals of ALL workgroups before me (<= 1024 of them: up to 4
+    // per thread, every load in flight at once -- the workgroups generate side by side and publish within
+    // a microsecond of each other, so a chained look-back would only add its w / 64 dependent rounds)
+    if (tid == 0) smc_st_agent(st + w, (total << 2) | SP_FLAG_AGG);
+    u64 part = 0ull;
+    for (int idx = tid; idx < w; idx += SMC_BLOCK) {
+        u64 word = smc_ld_agent(st + idx);
+        for (int spin = 0; (word & 3ull) == 0ull && spin < (1 << 22); ++spin) {
+            smc_spin_pause();
+            word = smc_ld_agent(st + idx);
+        }
+        part += word >> 2;
+    }
+    __syncthreads();                                                       // (s_w has been read)
+    part = smc_wave_sum_u64(part);
+    if (lane == 0) s_w[0][wave] = part;
+    __syncthreads();
+    if (tid == 0) {
         u64 excl = 0ull;
-        int look = w - 1;
-        while (look >= 0) {
-            const int idx = look - lane;
-            u64 word = SP_FLAG_INC;                                        // before workgroup 0: prefix 0
-            if (idx >= 0) {
-                word = smc_ld_agent(st + idx);
-                for (int spin = 0; (word & 3ull) == 0ull && spin < (1 << 22); ++spin) {
-                    smc_spin_pause();
-                    word = smc_ld_agent(st + idx);
-                }
-            }
-            const u64 mask = __ballot((word & 3ull) == SP_FLAG_INC ? 1 : 0);   // nearest one holding a prefix
-            const int first = mask ? __builtin_ctzll(mask) : 64;
-            excl += smc_wave_sum_u64(lane <= first ? (word >> 2) : 0ull);
-            if (mask) break;
-            look -= 64;
-        }
-        if (lane == 0) {
-            if (w > 0) smc_st_agent(st + w, ((excl + total) << 2) | SP_FLAG_INC);
-            s_pre = excl;
-            if (w == a.sp_nwg - 1) E[a.ntiles1] = excl + total;           // Z_N
-        }
+#pragma unroll
+        for (int v = 0; v < SMC_NWAVE; ++v) excl += s_w[0][v];
+        s_pre = excl;
+        if (w == a.sp_nwg - 1) E[a.ntiles1] = excl + total;               // Z_N
     }
     __syncthreads();
     const u64 pre = s_pre;
