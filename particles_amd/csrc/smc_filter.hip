@@ -356,7 +356,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     a.sp_tpw = a.sp_nwg = 0;
     if (need_su && f->two_level && !getenv("SMC_SPACING_3PASS"))
         for (int tpw = 1; tpw <= 8 && !a.sp_tpw; tpw *= 2) {
-            const i64 nwg = (a.ntiles1 + tpw - 1) / tpw;
+            const i64 nwg = (a.ntiles + tpw - 1) / tpw;
             int per_cu = 0;                        // workgroups of this instantiation a CU holds at once
 #ifdef SMC_EMULATE
             per_cu = 4;

@@ -578,12 +578,21 @@ k_f_spacing_onepass(const FArgs av)
     u64* Z = reinterpret_cast<u64*>(a.su) + (i64)isl * a.N;
     // ---- the draws of my tiles (tile r: draws 1024 (w TPW + r) + 4 tid ..), wave scans, tile totals
     u64 q[TPW][4], inc[TPW];
+    // (tiles of the N uniforms: k < ntiles.  The (N+1)-th draw, which only the total needs, sits in the last
+    //  of them unless N is a multiple of 1024 -- then the last workgroup makes it by itself, below: the
+    //  grid stays ceil(ntiles / TPW) workgroups, 512 at N = 2^22, which is what the chip holds for certain)
 #pragma unroll
     for (int r = 0; r < TPW; ++r) {
         const i64 k = (i64)w * TPW + r;
-        if (k < a.ntiles1) f_spacing_q4(a, s_ntab, (u32)t, gisl, k * F_TILE + (i64)tid * F_IPT, q[r]);
+        if (k < a.ntiles) f_spacing_q4(a, s_ntab, (u32)t, gisl, k * F_TILE + (i64)tid * F_IPT, q[r]);
         else { q[r][0] = q[r][1] = q[r][2] = q[r][3] = 0ull; }
         inc[r] = smc_wave_scan_add_u64(q[r][0] + q[r][1] + q[r][2] + q[r][3]);
+    }
+    u64 q_last = 0ull;                             // draw N when it has a tile of its own
+    if (w == a.sp_nwg - 1 && a.ntiles1 > a.ntiles && tid == 0) {
+        u64 ql[4];
+        f_spacing_q4(a, s_ntab, (u32)t, gisl, a.N, ql);       // (N a multiple of 1024 here: draw N is slot 0)
+        q_last = ql[0];
     }
     if (lane == 63) {
 #pragma unroll
@@ -623,7 +632,10 @@ k_f_spacing_onepass(const FArgs av)
 #pragma unroll
         for (int v = 0; v < SMC_NWAVE; ++v) excl += s_w[0][v];
         s_pre = excl;
-        if (w == a.sp_nwg - 1) E[a.ntiles1] = excl + total;               // Z_N
+        if (w == a.sp_nwg - 1) {
+            if (a.ntiles1 > a.ntiles) E[a.ntiles] = excl + total;         // the prefix of draw N's own tile
+            E[a.ntiles1] = excl + total + q_last;                         // Z_N
+        }
     }
     __syncthreads();
     const u64 pre = s_pre;
@@ -631,7 +643,7 @@ k_f_spacing_onepass(const FArgs av)
 #pragma unroll
     for (int r = 0; r < TPW; ++r) {
         const i64 k = (i64)w * TPW + r;
-        if (k >= a.ntiles1) break;
+        if (k >= a.ntiles) break;
         const i64 n0 = k * F_TILE + (i64)tid * F_IPT;
         u64 run = pre + base[r];
         if (tid == 0) E[k] = run;
