@@ -17,7 +17,10 @@ struct smc_comm {
     int nranks, rank;
 };
 
-#ifndef SMC_EMULATE
+// The binding below is compiled into the emulator build as well: with SMC_RCCL_LIBRARY naming a
+// library that exports the nccl* entry points (tests/emu/fake_rccl.c: a multi-process test double on
+// host memory) the CPU suite drives exactly the calls -- argument order, counts, datatypes, group
+// nesting -- that run over xGMI on a node; without it the emulator has its one-rank stub.
 namespace {
 typedef int ncclResult_t;
 typedef struct { char internal[128]; } ncclUniqueId;
@@ -47,10 +50,11 @@ struct Rccl {
 int rccl_load()
 {
     if (g_rccl.h) return SMC_OK;
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // SMC_RCCL_LIBRARY: another build of RCCL (or, in the CPU tests, the test double)
+    const char* names[] = {getenv("SMC_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void* h = nullptr;
     for (const char* n : names)
-        if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+        if (n && *n && (h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
     if (!h) {
         smc_set_error("RCCL not found: %s", dlerror());
         return SMC_ERR_HIP;
@@ -79,8 +83,12 @@ int rccl_fail(const char* what, ncclResult_t r)
                   g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "RCCL error");
     return SMC_ERR_HIP;
 }
-}  // namespace
+#ifdef SMC_EMULATE
+bool use_rccl() { const char* e = getenv("SMC_RCCL_LIBRARY"); return e && *e; }
+#else
+constexpr bool use_rccl() { return true; }
 #endif
+}  // namespace
 
 __global__ void __launch_bounds__(SMC_BLOCK)
 k_copy_f64(const double* src, i64 n, double* dst)
@@ -94,10 +102,10 @@ extern "C" {
 int smc_comm_unique_id(char* id_host)
 {
     SMC_REQUIRE(id_host, "null argument");
-#ifdef SMC_EMULATE
-    memset(id_host, 0, SMC_COMM_ID_BYTES);
-    return SMC_OK;
-#else
+    if (!use_rccl()) {
+        memset(id_host, 0, SMC_COMM_ID_BYTES);
+        return SMC_OK;
+    }
     int rc = rccl_load();
     if (rc) return rc;
     ncclUniqueId id;
@@ -105,7 +113,6 @@ int smc_comm_unique_id(char* id_host)
     if (r != 0) return rccl_fail("ncclGetUniqueId", r);
     memcpy(id_host, id.internal, SMC_COMM_ID_BYTES);
     return SMC_OK;
-#endif
 }
 
 int smc_comm_create(smc_ctx* ctx, int nranks, int rank, const char* id_host, smc_comm** out)
@@ -117,13 +124,15 @@ int smc_comm_create(smc_ctx* ctx, int nranks, int rank, const char* id_host, smc
     c->nccl = nullptr;
     c->nranks = nranks;
     c->rank = rank;
-#ifdef SMC_EMULATE
-    if (nranks != 1) {
-        delete c;
-        smc_set_error("the emulator build has no RCCL (nranks must be 1)");
-        return SMC_ERR_INVALID;
+    if (!use_rccl()) {
+        if (nranks != 1) {
+            delete c;
+            smc_set_error("the emulator build has no RCCL (nranks must be 1)");
+            return SMC_ERR_INVALID;
+        }
+        *out = c;
+        return SMC_OK;
     }
-#else
     int rc = rccl_load();
     if (rc) { delete c; return rc; }
     SMC_HIP_CHECK(hipSetDevice(ctx->device));
@@ -131,7 +140,6 @@ int smc_comm_create(smc_ctx* ctx, int nranks, int rank, const char* id_host, smc
     memcpy(id.internal, id_host, SMC_COMM_ID_BYTES);
     ncclResult_t r = g_rccl.CommInitRank(&c->nccl, nranks, id, rank);
     if (r != 0) { delete c; return rccl_fail("ncclCommInitRank", r); }
-#endif
     *out = c;
     return SMC_OK;
 }
@@ -141,13 +149,13 @@ int smc_comm_allgather_f64(smc_comm* c, const double* send, int64_t count, doubl
     SMC_REQUIRE(c && send && recv, "null argument");
     SMC_REQUIRE(count > 0, "count must be positive");
     hipStream_t st = c->ctx->stream;
-#ifdef SMC_EMULATE
-    SMC_LAUNCH(k_copy_f64, dim3((unsigned)((count + SMC_BLOCK - 1) / SMC_BLOCK)), dim3(SMC_BLOCK),
-               st, send, (i64)count, recv);
-#else
-    ncclResult_t r = g_rccl.AllGather(send, recv, (size_t)count, kNcclFloat64, c->nccl, st);
-    if (r != 0) return rccl_fail("ncclAllGather", r);
-#endif
+    if (!c->nccl) {              // (emulator's one-rank stub)
+        SMC_LAUNCH(k_copy_f64, dim3((unsigned)((count + SMC_BLOCK - 1) / SMC_BLOCK)), dim3(SMC_BLOCK),
+                   st, send, (i64)count, recv);
+    } else {
+        ncclResult_t r = g_rccl.AllGather(send, recv, (size_t)count, kNcclFloat64, c->nccl, st);
+        if (r != 0) return rccl_fail("ncclAllGather", r);
+    }
     SMC_HIP_CHECK(hipStreamSynchronize(st));
     return SMC_OK;
 }
@@ -160,12 +168,14 @@ int smc_comm_alltoallv(smc_comm* c, const void* send, const int64_t* scount, con
 {
     SMC_REQUIRE(c && scount && sdisp && rcount && rdisp, "null argument");
     hipStream_t st = c->ctx->stream;
-#ifdef SMC_EMULATE
-    if (scount[0] != rcount[0]) { smc_set_error("alltoallv: self block sizes differ"); return SMC_ERR_INVALID; }
-    if (scount[0])
-        SMC_HIP_CHECK(hipMemcpyAsync((char*)recv + rdisp[0], (const char*)send + sdisp[0], (size_t)scount[0],
-                                     hipMemcpyDeviceToDevice, st));
-#else
+    if (!c->nccl) {              // (emulator's one-rank stub)
+        if (scount[0] != rcount[0]) { smc_set_error("alltoallv: self block sizes differ"); return SMC_ERR_INVALID; }
+        if (scount[0])
+            SMC_HIP_CHECK(hipMemcpyAsync((char*)recv + rdisp[0], (const char*)send + sdisp[0], (size_t)scount[0],
+                                         hipMemcpyDeviceToDevice, st));
+        SMC_HIP_CHECK(hipStreamSynchronize(st));
+        return SMC_OK;
+    }
     if (!g_rccl.Send || !g_rccl.Recv || !g_rccl.GroupStart || !g_rccl.GroupEnd) {
         smc_set_error("RCCL lacks ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd");
         return SMC_ERR_HIP;
@@ -179,7 +189,6 @@ int smc_comm_alltoallv(smc_comm* c, const void* send, const int64_t* scount, con
     const ncclResult_t r2 = g_rccl.GroupEnd();
     if (r != 0) return rccl_fail("ncclSend / ncclRecv", r);
     if (r2 != 0) return rccl_fail("ncclGroupEnd", r2);
-#endif
     SMC_HIP_CHECK(hipStreamSynchronize(st));
     return SMC_OK;
 }
@@ -187,9 +196,7 @@ int smc_comm_alltoallv(smc_comm* c, const void* send, const int64_t* scount, con
 int smc_comm_destroy(smc_comm* c)
 {
     if (!c) return SMC_OK;
-#ifndef SMC_EMULATE
     if (c->nccl) g_rccl.CommDestroy(c->nccl);
-#endif
     delete c;
     return SMC_OK;
 }

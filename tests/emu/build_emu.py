@@ -26,5 +26,18 @@ def build(force=False):
     return OUT
 
 
+def build_fake_rccl(force=False):
+    """tests/emu/_build/libfake_rccl.so: the RCCL test double (fake_rccl.c) the emulator build binds when
+    SMC_RCCL_LIBRARY points at it."""
+    src = os.path.join(HERE, "fake_rccl.c")
+    out = os.path.join(HERE, "_build", "libfake_rccl.so")
+    if force or not os.path.exists(out) or os.path.getmtime(src) > os.path.getmtime(out):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        tmp = out + ".tmp%d" % os.getpid()
+        subprocess.run(["gcc", "-O1", "-g", "-std=gnu11", "-fPIC", "-shared", "-Wall", src, "-o", tmp], check=True)
+        os.replace(tmp, out)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force=True))

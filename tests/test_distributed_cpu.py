@@ -24,7 +24,7 @@ import particles_amd as pa
 from particles_amd import kalman, state_space_models as ssm
 from particles_amd.distributed import Group, shard_islands, log_mean_exp_host
 
-grp = Group(device_collective=False)
+grp = Group(device_collective=os.environ.get("SMC_TEST_RCCL") == "1")
 TOTAL = 6
 first, count = shard_islands(TOTAL, grp.rank, grp.world)
 rng = np.random.RandomState(42)
@@ -73,7 +73,14 @@ def _free_port():
     return p
 
 
-def _run_world(world, tmp_path, gloo=False, migrate=False):
+def _fake_rccl_env(tmp_path):
+    """Environment that makes the emulator build of smc_comm bind the RCCL test double."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    return {"SMC_RCCL_LIBRARY": build_emu.build_fake_rccl(), "SMC_TEST_RCCL": "1", "TMPDIR": str(tmp_path)}
+
+
+def _run_world(world, tmp_path, gloo=False, migrate=False, **env_extra):
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(root=ROOT))
     port, gport = _free_port(), _free_port()
@@ -82,7 +89,7 @@ def _run_world(world, tmp_path, gloo=False, migrate=False):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SMC_HIP_DEVICE="0",
                    GLOO_PORT=str(gport), SMC_TEST_GLOO="1" if gloo else "0",
-                   SMC_TEST_MIGRATE="1" if migrate else "0")
+                   SMC_TEST_MIGRATE="1" if migrate else "0", **env_extra)
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=600)[0] for p in procs]
@@ -207,6 +214,65 @@ def test_sharded_smc2_is_world_invariant(tmp_path):
     e1 = _run_smc2_world(1, tmp_path, SMC_TEST_AR="1.01", SMC_TEST_T="8")
     e2 = _run_smc2_world(2, tmp_path, SMC_TEST_AR="1.01", SMC_TEST_T="8")
     assert e1["Nx"] == 256 and all(e1[k] == e2[k] for k in ("lw", "theta", "logLt", "ESSs", "Nx"))
+
+
+def test_multi_rank_rccl_calls_through_the_test_double(tmp_path, has_gpu):
+    """The device-collective branch of the Group with 2 and 3 ranks -- ncclCommInitRank, ncclAllGather,
+    grouped ncclSend / ncclRecv -- against tests/emu/fake_rccl.c, which moves the bytes between the
+    emulator processes and refuses protocol violations (datatype codes, counts that differ between a
+    matched pair, point-to-point calls outside a group): evidences, island migration and the sharded
+    SMC^2 give what the host star and the single process give, and `evidence_path` says "rccl"."""
+    if has_gpu:
+        pytest.skip("the test double stands in for RCCL on GPU-less boxes")
+    env = _fake_rccl_env(tmp_path)
+    one = _run_world(1, tmp_path)
+    for world in (2, 3):
+        got = _run_world(world, tmp_path, **env)
+        assert got["path"] == "rccl" and got["world"] == world and got["ll"] == one["ll"]
+    m1 = _run_world(1, tmp_path, migrate=True)
+    m3 = _run_world(3, tmp_path, migrate=True, **env)
+    assert m3["path"] == "rccl" and m3["ll"] == m1["ll"]
+    s1 = _run_smc2_world(1, tmp_path)
+    s2 = _run_smc2_world(2, tmp_path, **env)
+    assert s2["path"] == "rccl"
+    for k in ("lw", "theta", "logLt", "ESSs", "moves", "acc", "Nx"):
+        assert s1[k] == s2[k], k
+
+
+def test_rccl_test_double_refuses_protocol_violations(tmp_path):
+    """The double itself: what it accepts is what RCCL accepts from smc_comm, what it refuses would
+    deadlock or corrupt on a node."""
+    import ctypes
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    L = ctypes.CDLL(build_emu.build_fake_rccl())
+    L.ncclGetErrorString.restype = ctypes.c_char_p
+
+    class Uid(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+    os.environ["TMPDIR"] = str(tmp_path)
+    uid = Uid()
+    assert L.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    comm = ctypes.c_void_p()
+    assert L.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    a = (ctypes.c_double * 4)(1, 2, 3, 4)
+    b = (ctypes.c_double * 4)()
+    assert L.ncclAllGather(a, b, ctypes.c_size_t(4), 8, comm, None) == 0 and list(b) == [1, 2, 3, 4]
+    assert L.ncclAllGather(a, b, ctypes.c_size_t(4), 7, comm, None) != 0                       # ncclFloat is not ours
+    assert b"datatype" in L.ncclGetErrorString(4)
+    assert L.ncclSend(a, ctypes.c_size_t(32), 0, 0, comm, None) != 0                            # outside a group
+    assert b"outside ncclGroupStart" in L.ncclGetErrorString(5)
+    assert L.ncclGroupStart() == 0
+    assert L.ncclSend(a, ctypes.c_size_t(32), 0, 0, comm, None) == 0
+    assert L.ncclRecv(b, ctypes.c_size_t(16), 0, 0, comm, None) == 0                            # 16 != 32 bytes
+    assert L.ncclGroupEnd() != 0 and b"byte count differs" in L.ncclGetErrorString(5)
+    assert L.ncclGroupStart() == 0
+    assert L.ncclSend(a, ctypes.c_size_t(32), 0, 3, comm, None) != 0                            # peer out of range
+    assert L.ncclGroupEnd() == 0
+    assert L.ncclGroupEnd() != 0                                                                # unbalanced
+    bad = Uid()
+    assert L.ncclCommInitRank(ctypes.byref(ctypes.c_void_p()), 2, bad, 0) != 0                  # an id nobody made
+    assert L.ncclCommDestroy(comm) == 0
 
 
 def test_bench_two_ranks_launch_line(tmp_path):
