@@ -94,6 +94,13 @@ int smc_wmean_var(smc_ctx* ctx, const double* W, const double* X, int64_t N,
 int smc_inverse_cdf(smc_ctx* ctx, const double* su, const double* W, int64_t M,
                     int64_t N, int64_t* A);
 
+/* The same with the reference's own CDF, literally: S_j accumulated left to right in fp64
+ * (resampling.py:500-509: s += W[j]), A[n] = first j with su[n] <= S_j.  Given identical (su, W)
+ * the ancestors ARE the reference's, bit for bit.  One wavefront walks the N weights (the order
+ * of the additions is the result): milliseconds at N = 2^20, hence a separate entry. */
+int smc_inverse_cdf_strict(smc_ctx* ctx, const double* su, const double* W, int64_t M,
+                           int64_t N, int64_t* A);
+
 /* ---- a-6: rs.resampling(scheme, W, M) (resampling.py:477-481) -------------
  * u: the uniforms the scheme consumes, in the reference's order --
  *   systematic: 1 (rand(1), :609); stratified: M (rand(M), :602);
@@ -312,6 +319,11 @@ typedef struct smc_filter_opts {
  * covariance of kalman.py:215-229) -- 44 instead of 72 matrix instructions per 16 particles.
  * Same particles; log-weights equal up to rounding, hence opt-in. */
 #define SMC_FLAG_COLLAPSED_PROPOSAL 1
+/* Univariate filters on the two-level step: ancestors by the reference's sequential fp64 CDF of the
+ * filter's own normalised weights (what smc_filter_get(SMC_FIELD_W) returns for the step before) --
+ * A_t == particles.resampling.inverse_cdf(su, W_{t-1}) bit for bit -- instead of the exact integer
+ * CDF.  Costs a one-wavefront pass over the weights per resampling step (ms at N = 2^20). */
+#define SMC_FLAG_STRICT_ANCESTORS 2
 
 /* y_host: data, (T, dy) row-major, shared by all islands. */
 int smc_filter_create(smc_ctx* ctx, const smc_model* model,

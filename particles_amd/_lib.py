@@ -47,6 +47,7 @@ class SmcFilterOpts(ctypes.Structure):
 
 
 FLAG_COLLAPSED_PROPOSAL = 1
+FLAG_STRICT_ANCESTORS = 2
 
 
 # name -> (restype, argtypes): every symbol include/smc_hip.h declares
@@ -72,6 +73,7 @@ SIGNATURES = {
     "smc_log_wmean_exp": (c_int, [c_vp, c_vp, c_vp, c_i64, P(c_dbl)]),
     "smc_wmean_var": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, P(c_dbl)]),
     "smc_inverse_cdf": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
+    "smc_inverse_cdf_strict": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
     "smc_resample": (c_int, [c_vp, c_int, c_vp, c_i64, c_i64, c_vp, c_u64, c_vp]),
     "smc_uniform_spacings": (c_int, [c_vp, c_i64, c_u64, c_vp]),
     "smc_gather": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),

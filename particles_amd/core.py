@@ -131,6 +131,9 @@ class SMC:
     collapsed_proposal : GuidedPF of an MVLinearGauss only -- weigh with the collapsed form of the
         optimal proposal's weight, log p(y_t | x_{t-1}) (SMC_FLAG_COLLAPSED_PROPOSAL): same
         particles, log-weights equal up to rounding, 40 % fewer matrix instructions
+    strict_ancestors : univariate Bootstrap / Guided filters -- resample with the reference's own
+        sequential fp64 CDF of the filter's weights (SMC_FLAG_STRICT_ANCESTORS): ``A`` equals
+        ``particles.resampling.inverse_cdf(su, W)`` bit for bit, at milliseconds per resampling step
     use_graph : replay the step sequence from hipGraphs instead of launching the kernels one by
         one (off by default: on MI355X a dependent kernel boundary costs the same either way,
         eager launches measured 2 % faster at C2 and start sooner after an idle stream)
@@ -138,7 +141,7 @@ class SMC:
 
     def __init__(self, fk=None, N=100, qmc=False, resampling="systematic", ESSrmin=0.5,
                  store_history=False, verbose=False, collect=None, seed=None, n_islands=1,
-                 replay=None, use_graph=False, island_offset=0, collapsed_proposal=False):
+                 replay=None, use_graph=False, island_offset=0, collapsed_proposal=False, strict_ancestors=False):
         self._fk_list = None
         if isinstance(fk, (list, tuple)):        # one Feynman-Kac model per island (SMC^2: one theta each)
             self._fk_list = list(fk)
@@ -154,6 +157,7 @@ class SMC:
         self._logLt = 0.0
         self.cpu_time = 0.0
         self._collapsed = bool(collapsed_proposal)
+        self._strict = bool(strict_ancestors)
         if collect == "off":
             self.summaries = None
         else:
@@ -278,7 +282,8 @@ class SMC:
         o.island_offset = island_offset
         o.keep_history = self._keep_history
         o.moments = 1 if self._device_moments else 0
-        o.flags = _lib.FLAG_COLLAPSED_PROPOSAL if self._collapsed else 0
+        o.flags = (_lib.FLAG_COLLAPSED_PROPOSAL if self._collapsed else 0) | \
+                  (_lib.FLAG_STRICT_ANCESTORS if self._strict else 0)
         self._ctx = _lib.ctx()
         h = _lib.c_vp()
         check(lib().smc_filter_create(self._ctx.h, ctypes.byref(m), ctypes.byref(o),

@@ -27,6 +27,8 @@ struct smc_filter {
     int ragged;            // two-level step with N not a multiple of the tile: 1 (N even), 2 (N odd), else 0
                            // (k_propagate<.., RAGGED>)
     bool mv_collapsed;     // MVLINGAUSS guided: log G = log p(y_t | x_{t-1}) in one product (opts.flags)
+    bool strict;           // SMC_FLAG_STRICT_ANCESTORS: sequential fp64 CDF of the filter's weights
+    double* strict_ws;     // (n_islands, N) W -> S
     i64 perm_t;            // t_host at the last smc_filter_permute_islands (A / Xp undefined there)
     hipGraphExec_t gexec[3];   // captured step sequences of F_GRAPH_SIZES steps (even: see enqueue_step)
     bool graph_failed;
@@ -111,6 +113,28 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
     hipStream_t st = f->ctx->stream;
     const dim3 grid(f->a.ntiles, f->a.n_islands);
     if (k_prof >= 0) (void)hipEventRecord(f->ev[3 * k_prof], st);
+    if (f->strict) {
+        // decision + normalisation of step t-1 (two-level: k_reduce2; flat: k_propagate's tail did it),
+        // W_{t-1}, its sequential CDF, the searches
+        if (f->two_level) SMC_LAUNCH(k_reduce2, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
+        if (f->a.scheme == SMC_MULTINOMIAL && !f->a.ut)
+            for (int i = 0; i < f->a.n_islands; ++i)
+                SMC_LAUNCH(k_f_spacings_step, dim3(1), dim3(SMC_BLOCK), st, f->a, i, f->a.su + (size_t)i * f->a.N);
+        const unsigned nb = (unsigned)((f->a.N + SMC_BLOCK - 1) / SMC_BLOCK);
+        SMC_LAUNCH(k_strict_W, dim3(nb, f->a.n_islands), dim3(SMC_BLOCK), st, f->a, f->strict_ws);
+        SMC_LAUNCH(k_strict_cdf, dim3(1, f->a.n_islands), dim3(64), st, f->a, f->strict_ws);
+        SMC_LAUNCH(k_strict_search, dim3((unsigned)((f->a.N / 2 + SMC_BLOCK) / SMC_BLOCK), f->a.n_islands), dim3(SMC_BLOCK), st,
+                   f->a, (const double*)f->strict_ws, (const double*)f->a.su);
+        if (k_prof >= 0 && (k_prof % 3)) (void)hipEventRecord(f->ev[3 * k_prof + 1], st);
+        launch_propagate(f);
+        if (k_prof >= 0) (void)hipEventRecord(f->ev[3 * k_prof + 2], st);
+        if (f->a.mom) {
+            if (f->two_level) SMC_LAUNCH(k_flush2, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
+            SMC_LAUNCH(k_f_moments_partials, dim3(f->a.nmb, f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
+            SMC_LAUNCH(k_f_moments_final, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
+        }
+        return;
+    }
     if (f->two_level) {
         if (f->two_level_mid && f->a.scheme == SMC_MULTINOMIAL) {
             SMC_LAUNCH(k_reduce2, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
@@ -248,6 +272,13 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     f->th_buf = nullptr;
     f->th_ess_min = 0.0;
     f->mv_collapsed = mv && model->fk == SMC_FK_GUIDED && (o->flags & SMC_FLAG_COLLAPSED_PROPOSAL);
+    f->strict = (o->flags & SMC_FLAG_STRICT_ANCESTORS) != 0;
+    f->strict_ws = nullptr;
+    if (f->strict && (mv || model->fk == SMC_FK_APF || o->N >= ((i64)1 << 32))) {
+        smc_set_error("SMC_FLAG_STRICT_ANCESTORS: univariate Bootstrap / Guided filters");
+        delete f;
+        return SMC_ERR_INVALID;
+    }
     FArgs& a = f->a;
     memset(&a, 0, sizeof a);
     a.N = o->N;
@@ -337,7 +368,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     }
     f->two_level_mid = f->two_level && (!f->fused || a.ntiles > 1024 || getenv("SMC_TWO_LEVEL_MID") ||
                                         o->scheme == SMC_MULTINOMIAL || apf2);
-    const bool heavy_list = !mv && !getenv("SMC_NO_HEAVY");
+    const bool heavy_list = !mv && !f->strict && !getenv("SMC_NO_HEAVY");
     // (history slots are written step by step: the lanes beyond N of a slot would read indices nobody
     //  initialised -- every access tests its index there as well)
     a.kform = f->two_level ? 1 : 0;
@@ -354,7 +385,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     // the fewest that keep the whole launch resident (<= 1024 workgroups: half of what the chip holds);
     // more islands than that: the three-pass form
     a.sp_tpw = a.sp_nwg = 0;
-    if (need_su && f->two_level && !getenv("SMC_SPACING_3PASS"))
+    if (need_su && f->two_level && !f->strict && !getenv("SMC_SPACING_3PASS"))
         for (int tpw = 1; tpw <= 8 && !a.sp_tpw; tpw *= 2) {
             const i64 nwg = (a.ntiles + tpw - 1) / tpw;
             int per_cu = 0;                        // workgroups of this instantiation a CU holds at once
@@ -376,6 +407,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
         }
     const size_t oSst = carve(a.sp_tpw ? M * a.sp_nwg * 8 : 8);
     const size_t oTmp = carve(N * dxm * 8);
+    const size_t oStrict = carve(f->strict ? M * N * 8 : 8);
     a.nmb = (int)((o->N + F_MOM_CHUNK - 1) / F_MOM_CHUNK);
     const size_t oMom = carve(o->moments ? M * T * 2 * dxm * 8 : 8);
     const size_t oMpart = carve(o->moments ? M * a.nmb * dxm * 3 * 8 : 8);
@@ -443,6 +475,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     a.sst = (u64*)(base + oSst);
     if (a.sp_tpw) F_CREATE_CHECK(hipMemsetAsync(a.sst, 0, M * a.sp_nwg * 8, ctx->stream));
     f->tmp = (double*)(base + oTmp);
+    f->strict_ws = (double*)(base + oStrict);
     f->ll_stage = nullptr;
     {
         auto it = ctx->pinned.find(M * 8);
@@ -569,7 +602,7 @@ int smc_filter_clone(smc_filter* src, smc_filter** out)
     rebase(a.cq); rebase(a.tq); rebase(a.cnt); rebase(a.spart); rebase(a.summ); rebase(a.params); rebase(a.y);
     rebase(a.mom); rebase(a.mpart); rebase(a.aux); rebase(a.info); rebase(a.hcnt); rebase(a.hlist); rebase(a.info2);
     rebase(a.su); rebase(a.E); rebase(a.sst); rebase(a.mvc); rebase(a.trace); rebase(a.pm2); rebase(a.ps2); rebase(a.pss2);
-    rebase(f->tmp);
+    rebase(f->tmp); rebase(f->strict_ws);
     hipStream_t st = ctx->stream;
     hipError_t e = hipMemcpyAsync(slab, src->slab, src->slab_bytes, hipMemcpyDeviceToDevice, st);
     if (e == hipSuccess && src->th_buf) {
@@ -621,7 +654,7 @@ int smc_filter_set_replay(smc_filter* f, const double* z, const double* u)
 // requested steps in a single launch (smc_filter_small.h)
 static bool small_filter_ok(const smc_filter* f)
 {
-    return f->a.N <= F_TILE && f->kind != SMC_MODEL_MVLINGAUSS && !f->a.mom && !f->prof &&
+    return f->a.N <= F_TILE && f->kind != SMC_MODEL_MVLINGAUSS && !f->a.mom && !f->prof && !f->strict &&
            !(f->a.scheme == SMC_MULTINOMIAL && !f->a.ut) && !getenv("SMC_NO_SMALL");
 }
 
@@ -1330,7 +1363,9 @@ int smc_filter_describe(smc_filter* f, char* out, size_t n)
     const bool mv = f->kind == SMC_MODEL_MVLINGAUSS;
     std::string s;
     if (small_filter_ok(f)) s = "k_filter_small";
-    else {
+    else if (f->strict) {
+        s = std::string(f->two_level ? "k_reduce2+" : "") + "k_strict_W+k_strict_cdf+k_strict_search+k_propagate";
+    } else {
         if (f->two_level_mid) s = "k_reduce2+k_ancestors2";
         else if (f->two_level) s = "k_ancestors2";
         else if (f->fused) s = "k_ancestors<fused>";

@@ -2498,6 +2498,100 @@ k_ancestors2(const FArgs av)
     F_STAMP_A(6);
 }
 
+// ---- SMC_FLAG_STRICT_ANCESTORS: the reference's sequential fp64 CDF (smc_resample.h "STRICT") on the
+// filter's own normalised weights, in place of the exact integer CDFs.  W_{t-1} is written out (the
+// same values smc_filter_get(SMC_FIELD_W) returns), k_seq_cdf turns it into S in place, every
+// offspring searches S with its own sorted uniform.
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_strict_W(const FArgs av, double* Wout)
+{
+    const FArgs& a = av;
+    const int isl = (int)blockIdx.y;
+    const double* info = a.info + (i64)isl * INFO_STRIDE;
+    const i64 t = (i64)smc_uniform(info[0]);
+    if (t >= a.T || t == 0 || smc_uniform(info[1]) == 0.0) return;
+    const i64 i = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;
+    if (i >= a.N) return;
+    const double* row = a.summ + ((i64)isl * (a.T + 1) + (t - 1)) * SUMM_STRIDE;
+    const double m = row[5], rs = row[6];
+    const double lw = (f_lw(a, t - 1) + (i64)isl * a.N)[i];
+    double W;
+    if (a.kform) {
+        double k;
+        double p = smc_expk(lw, k);
+        const bool ok = lw > -INFINITY;
+        p = ok ? p : 0.0;
+        k = ok ? k : -INFINITY;
+        W = smc_scale_pk(p, k, m) * rs;
+    } else {
+        W = f_weight(lw, m, rs);
+    }
+    Wout[(i64)isl * a.N + i] = W;
+}
+// (k_seq_cdf needs the decision too: a wrapper that returns early when the step does not resample)
+__global__ void __launch_bounds__(64)
+k_strict_cdf(const FArgs av, double* WS)
+{
+    const FArgs& a = av;
+    const int isl = (int)blockIdx.y, lane = (int)threadIdx.x;
+    const double* info = a.info + (i64)isl * INFO_STRIDE;
+    const i64 t = (i64)smc_uniform(info[0]);
+    if (t >= a.T || t == 0 || smc_uniform(info[1]) == 0.0) return;
+    double* o = WS + (i64)isl * a.N;
+    const i64 n = a.N;
+    double s = 0.0;
+    bool first = true;
+    for (i64 c = 0; c < n; c += 64) {
+        const i64 i = c + lane;
+        const double wi = i < n ? o[i] : 0.0;
+        double mine = 0.0;
+        const int m = (int)(n - c < 64 ? n - c : 64);
+        for (int k = 0; k < m; ++k) {
+            const double wk = smc_readlane_f64(wi, k);
+            s = first ? wk : s + wk;
+            first = false;
+            if (lane == k) mine = s;
+        }
+        if (i < n) o[i] = mine;
+    }
+}
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_strict_search(const FArgs av, const double* S, const double* su_mem)
+{
+    const FArgs& a = av;
+    const int isl = (int)blockIdx.y;
+    const double* info = a.info + (i64)isl * INFO_STRIDE;
+    const i64 t = (i64)smc_uniform(info[0]);
+    if (t >= a.T || t == 0 || smc_uniform(info[1]) == 0.0) return;
+    const i64 N = a.N;
+    SmcSu su;
+    su.scheme = a.scheme;
+    su.M = N;
+    su.dM = (double)N;
+    su.u = a.ut ? a.ut + ((i64)t * a.n_islands + isl) * a.ut_stride
+                : (a.scheme == SMC_MULTINOMIAL_ ? su_mem + (i64)isl * N : nullptr);
+    su.u_sys = 0.0;
+    su.seed = a.seed;
+    su.t = (u32)t;
+    su.island = (u32)(a.island_offset + isl);
+    if (a.scheme == SMC_SYSTEMATIC_) {
+        if (su.u) su.u_sys = su.u[0];
+        else {
+            u64 x0, x1;
+            smc_philox(0u, su.t, su.island, SMC_STREAM_RESAMPLE, su.seed, x0, x1);
+            su.u_sys = smc_u01_halfopen(x0);
+        }
+    }
+    const i64 p = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;       // offspring 2p, 2p + 1
+    if (2 * p >= N) return;
+    double s0, s1;
+    smc_su_pair(su, p, s0, s1);
+    u32* A = f_A(a, t) + (i64)isl * N;
+    const double* Si = S + (i64)isl * N;
+    A[2 * p] = (u32)smc_first_ge(Si, N, s0);
+    if (2 * p + 1 < N) A[2 * p + 1] = (u32)smc_first_ge(Si, N, s1);
+}
+
 // smc_filter_spacings: the sorted uniforms the multinomial resampling of step t draws in production
 // mode, written out (inspection / tests: the step loop itself never materialises them).  ONE
 // workgroup walks the tiles of draws in order: same integers, same prefix sums, same quotients as
@@ -2511,6 +2605,40 @@ k_f_spacings_out(const FArgs av, const i64 t, const int isl, double* out)
     const int tid = (int)threadIdx.x;
     smc_ntab_stage<SMC_BLOCK>(s_ntab, tid);
     __syncthreads();
+    const u32 gisl = (u32)(a.island_offset + isl);
+    u64* Z = reinterpret_cast<u64*>(out);
+    u64 carry = 0ull;
+    for (int k = 0; k < a.ntiles1; ++k) {
+        const i64 n0 = (i64)k * F_TILE + (i64)tid * F_IPT;
+        u64 q[4];
+        f_spacing_q4(a, s_ntab, (u32)t, gisl, n0, q);
+        u64 tot;
+        u64 run = carry + smc_block_exscan_u64(q[0] + q[1] + q[2] + q[3], smu, tot);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            run += q[i];
+            if (n0 + i < a.N) Z[n0 + i] = run;
+        }
+        carry += tot;
+        __syncthreads();
+    }
+    const double dall = (double)carry;
+    for (i64 n = tid; n < a.N; n += SMC_BLOCK) out[n] = (double)Z[n] / dall;
+}
+
+// the same inside the step loop (strict mode, Philox multinomial): step and decision from the record
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_f_spacings_step(const FArgs av, const int isl, double* out)
+{
+    const FArgs& a = av;
+    __shared__ u64 smu[SMC_SM];
+    SMC_NTAB_LDS(s_ntab);
+    const int tid = (int)threadIdx.x;
+    smc_ntab_stage<SMC_BLOCK>(s_ntab, tid);
+    __syncthreads();
+    const double* info = a.info + (i64)isl * INFO_STRIDE;
+    const i64 t = (i64)smc_uniform(info[0]);
+    if (t >= a.T || t == 0 || smc_uniform(info[1]) == 0.0) return;
     const u32 gisl = (u32)(a.island_offset + isl);
     u64* Z = reinterpret_cast<u64*>(out);
     u64 carry = 0ull;

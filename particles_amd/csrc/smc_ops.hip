@@ -318,6 +318,53 @@ extern "C" int smc_inverse_cdf(smc_ctx* ctx, const double* su_dev, const double*
     return resample_launch(ctx, W, N, su, (i64*)A);
 }
 
+// S (n) <- sequential fp64 prefix sums of W (n); grid (1, islands) x 64 threads, arrays island-major
+__global__ void __launch_bounds__(64)
+k_seq_cdf(const double* W, const i64 n, double* S)
+{
+    const int lane = (int)threadIdx.x;
+    const double* w = W + (i64)blockIdx.y * n;
+    double* o = S + (i64)blockIdx.y * n;
+    double s = 0.0;
+    bool first = true;
+    for (i64 c = 0; c < n; c += 64) {
+        const i64 i = c + lane;
+        const double wi = i < n ? w[i] : 0.0;
+        double mine = 0.0;
+        const int m = (int)(n - c < 64 ? n - c : 64);
+        for (int k = 0; k < m; ++k) {
+            const double wk = smc_readlane_f64(wi, k);
+            s = first ? wk : s + wk;                            // s = W[0], then s += W[j]
+            first = false;
+            if (lane == k) mine = s;
+        }
+        if (i < n) o[i] = mine;
+    }
+}
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_search_strict(const double* su, const double* S, i64 M, i64 N, i64* A)
+{
+    const i64 n = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;
+    if (n < M) A[n] = smc_first_ge(S, N, su[n]);
+}
+
+// inverse_cdf exactly as the reference computes it (sequential fp64 CDF): see smc_resample.h "STRICT"
+extern "C" int smc_inverse_cdf_strict(smc_ctx* ctx, const double* su_dev, const double* W, int64_t M,
+                                      int64_t N, int64_t* A)
+{
+    SMC_REQUIRE(ctx && su_dev && W && A, "null argument");
+    SMC_REQUIRE(M > 0 && N > 0, "M and N must be positive");
+    SMC_HIP_CHECK(hipSetDevice(ctx->device));
+    void* scr;
+    int rc = smc_scratch(ctx, (size_t)N * 8, &scr);
+    if (rc) return rc;
+    SMC_LAUNCH(k_seq_cdf, dim3(1, 1), dim3(64), ctx->stream, W, (i64)N, (double*)scr);
+    SMC_LAUNCH(k_search_strict, dim3((unsigned)((M + SMC_BLOCK - 1) / SMC_BLOCK)), dim3(SMC_BLOCK), ctx->stream,
+               su_dev, (const double*)scr, (i64)M, (i64)N, (i64*)A);
+    SMC_LAUNCH_CHECK();
+    return SMC_OK;
+}
+
 // ---- element-wise arithmetic for device-resident model code -------------------
 // A user-defined Feynman-Kac model (core.py:108-197: M0 / M / logG written with numpy
 // expressions on xp, x) keeps working when its arrays live in HBM: DeviceArray routes

@@ -280,3 +280,28 @@ __device__ __forceinline__ void smc_tile_outputs(const SmcSu& su, int b, int nti
     n_lo = sn[0];
     n_hi = sn[1];
 }
+
+
+// ---------------------------------------------------------------------------
+// STRICT mode: the reference's own inverse CDF, literally (resampling.py:500-509):
+//     s = W[0]; j = 0;  for n: while su[n] > s: j += 1; s += W[j];  A[n] = j
+// i.e. A[n] = the first j with su[n] <= S_j, S_j = ((W_0 + W_1) + W_2) + ... accumulated LEFT TO
+// RIGHT in fp64.  The order of the additions is the result, so the prefix cannot be formed in
+// parallel: one wavefront walks the weights -- its lanes fetch 64 consecutive weights at a time
+// (coalesced), the 64 additions of a chunk are a dependent chain on the scalar value of the running
+// sum (v_readlane feeds it) -- about 10 cycles per weight, 4-5 ms at N = 2^20.  The searches
+// against S are then independent.  Opt-in (SMC_FLAG_STRICT_ANCESTORS / smc_inverse_cdf_strict): the
+// default exact integer CDFs give the same ancestors except where su[n] lies within rounding
+// distance of a step of S, at 1/500 of the cost.
+// ---------------------------------------------------------------------------
+// first j in [0, n) with x <= S[j]; n - 1 if none (the reference would run off the end of W there:
+// IndexError in Python, an unchecked read under numba)
+__device__ __forceinline__ i64 smc_first_ge(const double* S, const i64 n, const double x)
+{
+    i64 lo = 0, hi = n;
+    while (lo < hi) {
+        const i64 mid = lo + ((hi - lo) >> 1);
+        if (S[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    return lo < n ? lo : n - 1;
+}

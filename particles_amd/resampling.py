@@ -191,16 +191,29 @@ def resampling(scheme, W, M=None):
         raise ValueError(f"{scheme} is not a valid resampling scheme")
 
 
-def inverse_cdf(su, W):
+STRICT = [False]
+
+
+def set_strict(flag=True):
+    """Resample with the reference's own CDF -- S_j accumulated left to right in fp64
+    (resampling.py:500-509) -- instead of the exact integer CDF: ``inverse_cdf`` and the schemes built on
+    it then return the reference's ancestors bit for bit for identical ``(su, W)``, at milliseconds per
+    call at N = 2^20 (one wavefront walks the weights: the order of the additions is the result)."""
+    STRICT[0] = bool(flag)
+
+
+def inverse_cdf(su, W, strict=None):
     """Inverse CDF algorithm for a finite distribution (resampling.py:484-509).
 
     su: M sorted points in [0,1]; returns, for each, the smallest index j with
     su[n] <= CDF_j (clamped to N-1 where the reference would run off the end).
+    strict (default: ``set_strict``'s value): the sequential fp64 CDF of the reference, literally.
     """
     sud, host = as_device(su)
     Wd, hostW = as_device(W)
     A = DeviceArray((sud.size,), np.int64)
-    check(lib().smc_inverse_cdf(Wd.ctx.h, sud.ptr, Wd.ptr, sud.size, Wd.size, A.ptr))
+    fn = lib().smc_inverse_cdf_strict if (STRICT[0] if strict is None else strict) else lib().smc_inverse_cdf
+    check(fn(Wd.ctx.h, sud.ptr, Wd.ptr, sud.size, Wd.size, A.ptr))
     return A.get() if (host and hostW and not _lib.RESIDENT[0]) else A
 
 
@@ -220,6 +233,23 @@ def uniform_spacings(N):
 
 
 def _resample(scheme, W, M):
+    if STRICT[0]:
+        # the reference's expressions for the sorted uniforms (:536-537, :602, :609) on its draws (or the
+        # device's), then the reference's CDF
+        if _lib.RNG_MODE[0] == "numpy":
+            draw = random.rand
+        else:
+            def draw(k):
+                u = DeviceArray((max(k, 1),))
+                check(lib().smc_uniform(u.ctx.h, _lib.next_counter(), max(k, 1), u.ptr))
+                return u.get()[:k]
+        if scheme == "systematic":
+            su = (draw(1) + np.arange(M)) / M
+        elif scheme == "stratified":
+            su = (draw(M) + np.arange(M)) / M
+        else:
+            su = uniform_spacings(M)
+        return inverse_cdf(su, W, strict=True)
     Wd, host = as_device(W)
     A = DeviceArray((M,), np.int64)
     u = None

@@ -842,6 +842,90 @@ def check_device_spacings(sizes=(2048, 3000, 1 << 14), seed=91):
     assert d < 2.5 / np.sqrt(N), d
 
 
+def check_strict_ancestors(sizes=(3000, 4096), op_N=1 << 14, op_cases=12):
+    """The literal guarantee of the north star: identical (su, W) in, the reference's ancestors out.
+    (1) operator: rs.inverse_cdf(su, W, strict=True) == the reference's sequential loop
+    (resampling.py:500-509, restated in the oracle and pinned by the golden fixtures) on random,
+    skewed, sparse and near-degenerate weight vectors, no tolerance, no near-tie audit;
+    (2) the fused loop with strict_ancestors=True: at every resampling step
+    A_t == inverse_cdf(su_t, W_{t-1}) with W_{t-1} the filter's own weights, for the three schemes,
+    replayed and Philox draws, N <= 1024 (flat step) and above (two-level step), islands."""
+    rng = np.random.default_rng(5)
+    for c in range(op_cases):
+        N = op_N if c % 3 else op_N + 37
+        kind = c % 4
+        lw = rng.normal(0.0, (0.5, 3.0, 12.0, 40.0)[kind], size=N)
+        if kind == 2:
+            lw[rng.random(N) < 0.3] = -np.inf
+        W = orc.exp_and_normalise(lw)
+        for su in ((rng.random() + np.arange(N)) / N, (rng.random(N) + np.arange(N)) / N,
+                   orc.uniform_spacings_from(rng.random(N + 1))):
+            try:
+                want = orc.inverse_cdf(su, W)
+            except IndexError:
+                continue                                   # su[-1] beyond the rounded total: no reference answer
+            got = rs.inverse_cdf(su, W, strict=True)
+            assert np.array_equal(got, want), (c, int(np.sum(got != want)))
+    # rs.set_strict: the schemes themselves
+    rs.set_strict(True)
+    try:
+        W = orc.exp_and_normalise(rng.normal(0.0, 2.0, size=5000))
+        for scheme in ("systematic", "stratified", "multinomial"):
+            np.random.seed(8)
+            got = rs.resampling(scheme, W, M=4000)
+            np.random.seed(8)
+            want = orc.resampling(scheme, W, M=4000)
+            assert np.array_equal(got, want), scheme
+    finally:
+        rs.set_strict(False)
+    # (2)
+    T = 7
+    yr = np.random.RandomState(2)
+    y = [np.array([v]) for v in 0.4 * np.cumsum(yr.standard_normal(T))]
+    for N in (700,) + tuple(sizes):
+        for scheme in ("systematic", "stratified", "multinomial"):
+            for replay in (True, False):
+                z = u = None
+                if replay:
+                    np.random.seed(3)
+                    z = np.random.standard_normal((T, 1, N))
+                    u = np.random.rand(T, 1, 1 if scheme == "systematic" else N)
+                    if scheme == "multinomial":
+                        for t in range(T):
+                            u[t, 0] = orc.uniform_spacings_from(np.random.rand(N + 1))
+                nisl = 1 if replay else 2
+                pf = pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y), N=N, resampling=scheme, ESSrmin=0.9,
+                            seed=11, store_history=True, strict_ancestors=True, collect="off",
+                            replay=None if z is None else (z, u), n_islands=nisl)
+                pf.run()
+                assert "k_strict_cdf" in describe(pf)
+                summ = pf._summ()
+                for isl in range(nisl):
+                    nres = 0
+                    for t in range(1, T):
+                        if not summ[isl, t, 4]:
+                            continue
+                        nres += 1
+                        W = pf._history(_lib.FIELD_W, t - 1, isl)
+                        if u is not None:
+                            ut = np.asarray(u[t, isl])
+                        elif scheme == "multinomial":
+                            ut = pf._spacings(t, isl)
+                        else:
+                            ut = orc.philox_resample_uniforms(pf.seed, scheme, N, t, isl)
+                        su = ut if scheme == "multinomial" else orc.sorted_uniforms(scheme, N, ut)
+                        try:
+                            want = orc.inverse_cdf(su, W)
+                        except IndexError:
+                            continue
+                        A = pf._history(_lib.FIELD_A, t, isl)
+                        assert np.array_equal(A, want), (N, scheme, replay, t, int(np.sum(A != want)))
+                        assert np.array_equal(pf._history(_lib.FIELD_XP, t, isl), pf._history(_lib.FIELD_X, t - 1, isl)[A])
+                    assert nres >= 2, (N, scheme, nres)
+    with pytest.raises(ValueError):
+        pa.SMC(fk=ssm.AuxiliaryPF(ssm=ssm.StochVol(), data=y), N=500, strict_ancestors=True)
+
+
 def check_heavy_parents(monkeypatch, N=8192, T=12):
     """Collapsed / peaky weights: parents with >= 2048 offspring are registered by the ancestors
     kernel, which skips the blocks of offspring that are wholly theirs; k_propagate fills those.
