@@ -256,7 +256,8 @@ enum smc_fk_kind {
     SMC_FK_APF = 2            /* state_space_models.py:406-428 auxiliary PF: the guided step + the
                                * auxiliary weights of core.py:299-313 (resampling on lw + logeta,
                                * weights reset to log_mean_exp(logeta, W) - logeta[A]); STOCHVOL
-                               * (Pitt & Shephard, :475-498); N <= 1024 (the one-launch filter) or
+                               * (Pitt & Shephard, :475-498) and LINGAUSS (kalman.py:448-452: the
+                               * predictive density of y_{t+1}); N <= 1024 (the one-launch filter) or
                                * 1024 < N <= 2^30 (the two-level step); no moments, no rolling window */
 };
 enum smc_rng_mode {
@@ -274,7 +275,8 @@ typedef struct smc_model {
      *   LINGAUSS: 0 rho, 1 sigmaX, 2 sigmaY, 3 sigma0, 4 log(sigmaY),
      *             5 log(sigmaX), 6 log(sigma0), 7 sigmaX^2, 8 sigmaY^2,
      *             guided only (kalman.py:436-446): 9 sig2post, 10 sqrt(9),
-     *             11 log(10), 12 sig2post0, 13 sqrt(12), 14 log(13)
+     *             11 log(10), 12 sig2post0, 13 sqrt(12), 14 log(13);
+     *             auxiliary filter (:448-452): 15 sqrt(sigmaX^2 + sigmaY^2)
      *   STOCHVOL: 0 mu, 1 rho, 2 sigma, 3 sigma/sqrt(1-rho^2), 4 (1-rho)*mu; guided / APF
      *             (:475-498): 5 log(sigma), 6 log(sig0), 7 0.5*sigma^2, 8 0.5*sig0^2, 9 0.5/sigma^2
      *   GORDON:   0 b, 1 sigmaX, 2 c, 3 sigma0 (2.0), 5 a;  aux_host[t] = d*cos(e*(t-1))

@@ -562,6 +562,9 @@ class LinGauss:
         mupost = sig2post * (self.rho * xp / self.sigmaX ** 2 + yt / self.sigmaY ** 2)
         return mupost, np.sqrt(sig2post)
 
+    def logeta(self, x, y_next):         # kalman.py:448-452
+        return normal_logpdf(y_next, self.rho * x, np.sqrt(self.sigmaX ** 2 + self.sigmaY ** 2))
+
     def kalman_matrices(self):
         return (np.atleast_2d(self.rho), np.atleast_2d(1.0),
                 np.atleast_2d(self.sigmaX ** 2), np.atleast_2d(self.sigmaY ** 2),

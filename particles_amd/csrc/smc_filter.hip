@@ -95,6 +95,7 @@ static void launch_propagate(smc_filter* f)
     P_CASE(SMC_MODEL_STOCHVOL, SMC_FK_BOOTSTRAP)
     P_CASE(SMC_MODEL_STOCHVOL, SMC_FK_GUIDED)
     P_CASE(SMC_MODEL_STOCHVOL, SMC_FK_APF)              // (tail-free two-level launches only: create checks)
+    P_CASE(SMC_MODEL_LINGAUSS, SMC_FK_APF)
     P_CASE(SMC_MODEL_GORDON, SMC_FK_BOOTSTRAP)
     P_CASE(SMC_MODEL_THETALOGISTIC, SMC_FK_BOOTSTRAP)
     P_CASE(SMC_MODEL_SVLEVERAGE, SMC_FK_BOOTSTRAP)
@@ -224,8 +225,8 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     SMC_REQUIRE(model->fk == SMC_FK_BOOTSTRAP ||
                     (model->fk == SMC_FK_GUIDED &&
                      (model->kind == SMC_MODEL_LINGAUSS || model->kind == SMC_MODEL_STOCHVOL || mv)) ||
-                    (model->fk == SMC_FK_APF && model->kind == SMC_MODEL_STOCHVOL),
-                "guided filter: LINGAUSS, STOCHVOL, MVLINGAUSS; auxiliary filter: STOCHVOL");
+                    (model->fk == SMC_FK_APF && (model->kind == SMC_MODEL_STOCHVOL || model->kind == SMC_MODEL_LINGAUSS)),
+                "guided filter: LINGAUSS, STOCHVOL, MVLINGAUSS; auxiliary filter: STOCHVOL, LINGAUSS");
     {
         const bool big = o->N > F_TILE && o->N <= ((int64_t)1 << 30);
         if (model->fk == SMC_FK_APF && (o->moments || (o->N > F_TILE && !big) || o->keep_history >= 2)) {
@@ -677,6 +678,7 @@ static void launch_small(smc_filter* f, int nsteps)
     S_CASE(SMC_MODEL_STOCHVOL, SMC_FK_BOOTSTRAP)
     S_CASE(SMC_MODEL_STOCHVOL, SMC_FK_GUIDED)
     S_CASE(SMC_MODEL_STOCHVOL, SMC_FK_APF)
+    S_CASE(SMC_MODEL_LINGAUSS, SMC_FK_APF)
     S_CASE(SMC_MODEL_GORDON, SMC_FK_BOOTSTRAP)
     S_CASE(SMC_MODEL_THETALOGISTIC, SMC_FK_BOOTSTRAP)
     S_CASE(SMC_MODEL_SVLEVERAGE, SMC_FK_BOOTSTRAP)

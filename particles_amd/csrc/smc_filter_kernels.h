@@ -253,6 +253,20 @@ __device__ __forceinline__ double m_sv_logeta(const double* p, double x, double 
     return p[9] * (xhatmmu * xhatmmu - xstmmu * xstmmu) - ((0.5 * (y * y)) * exp(-xst)) * (1.0 + xstmmu);
 }
 
+// the auxiliary function logeta(t, x) of the models whose APF is fused, y = data[t + 1]:
+//   STOCHVOL  Pitt & Shephard's (state_space_models.py:491-498)
+//   LINGAUSS  log N(y; rho x, sqrt(sigmaX^2 + sigmaY^2)) (kalman.py:448-452) as scipy evaluates it;
+//             p[15] = that scale (from the host, with its rounding), its log formed here
+template <int KIND>
+__device__ __forceinline__ double m_logeta(const double* p, double x, double y)
+{
+    if (KIND == SMC_MODEL_LINGAUSS) {
+        const double v = smc_div_c(y - p[0] * x, p[15], p[16 + 15]);
+        return -(v * v) / 2.0 - SMC_C_NORM - log(p[15]);
+    }
+    return m_sv_logeta(p, x, y);
+}
+
 // one particle of one step: returns the new state, writes the weight increment
 template <int KIND, int FK>
 __device__ __forceinline__ double m_step(const double* p, bool first, double y, double aux,
@@ -1354,7 +1368,7 @@ k_propagate(const FArgs av)
             // with the record (k_reduce2), logeta of the gathered parent is formed again here
             const double cconst = smc_uniform(r6);
 #pragma unroll
-            for (int k = 0; k < OPT; ++k) lwp[k] = cconst - m_sv_logeta(p, xp[k], yt);
+            for (int k = 0; k < OPT; ++k) lwp[k] = cconst - m_logeta<KIND>(p, xp[k], yt);
         }
         F_STAMP(2);
         double xn[OPT];
@@ -1412,7 +1426,7 @@ k_propagate(const FArgs av)
                 const double y_next = a.y[(t + 1) * a.dy];
 #pragma unroll
                 for (int k = 0; k < OPT; ++k) {
-                    double la = lw[k] + m_sv_logeta(p, xkeep[k], y_next);
+                    double la = lw[k] + m_logeta<KIND>(p, xkeep[k], y_next);
                     if (la != la) la = -INFINITY;
                     lw[k] = (lw[k] > -INFINITY) ? la : -INFINITY;
                 }

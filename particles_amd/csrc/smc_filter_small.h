@@ -86,7 +86,7 @@ k_filter_small(const FArgs av, const int nsteps)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 // (APF: the auxiliary weight of the parent, logeta(t - 1, x) with data[t] -- core.py:307-313)
-                const double la = APF ? lw[i] + m_sv_logeta(p, x[i], yt) : lw[i];
+                const double la = APF ? lw[i] + m_logeta<KIND>(p, x[i], yt) : lw[i];
                 q4[i] = (jt + i < N) ? smc_q62_w(f_weight(la, m, rs)) : 0ull;
             }
             const u64 tsum = q4[0] + q4[1] + q4[2] + q4[3];
@@ -115,7 +115,7 @@ k_filter_small(const FArgs av, const int nsteps)
             for (int k = 0; k < 4; ++k) {                                           // core.py:332
                 xp[k] = sX[an[k]];
                 // core.py:299-305 reset_weights: log_mean_exp(logeta, W) - logeta[A] for the APF
-                lwp[k] = APF ? cconst - m_sv_logeta(p, xp[k], yt) : 0.0;
+                lwp[k] = APF ? cconst - m_logeta<KIND>(p, xp[k], yt) : 0.0;
             }
         } else {
 #pragma unroll
@@ -187,7 +187,7 @@ k_filter_small(const FArgs av, const int nsteps)
             double la[4], tma = -INFINITY;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                la[k] = okp[k] ? lw[k] + m_sv_logeta(p, x[k], y_next) : -INFINITY;
+                la[k] = okp[k] ? lw[k] + m_logeta<KIND>(p, x[k], y_next) : -INFINITY;
                 if (la[k] != la[k]) la[k] = -INFINITY;
                 tma = smc_max2(tma, la[k]);
             }

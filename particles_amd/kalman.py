@@ -119,6 +119,11 @@ class LinearGauss(MVLinearGauss):
         mupost = sig2post * (self.rho * xp / self.sigmaX ** 2 + data[t] / self.sigmaY ** 2)
         return dists.Normal(loc=mupost, scale=np.sqrt(sig2post))
 
+    def logeta(self, t, x, data):
+        """Auxiliary function of the APF (kalman.py:448-452): the predictive density of y_{t+1}."""
+        law = dists.Normal(loc=self.rho * x, scale=np.sqrt(self.sigmaX ** 2 + self.sigmaY ** 2))
+        return law.logpdf(data[t + 1])
+
     def _device_params(self, fk_kind):
         p = np.zeros(_lib.PARAM_STRIDE)
         sx2, sy2 = self.sigmaX ** 2, self.sigmaY ** 2
@@ -128,7 +133,8 @@ class LinearGauss(MVLinearGauss):
                   np.log(self.sigmaY), np.log(self.sigmaX), np.log(self.sigma0), sx2, sy2,
                   s2p, np.sqrt(s2p), np.log(np.sqrt(s2p)),
                   s2p0, np.sqrt(s2p0), np.log(np.sqrt(s2p0))]
-        return dict(kind=_lib.MODEL_LINGAUSS, dx=1, dy=1, params=p)
+        p[15] = np.sqrt(sx2 + sy2)                 # scale of logeta (APF)
+        return dict(kind=_lib.MODEL_LINGAUSS, dx=1, dy=1, params=p, apf=True)
 
 
 def ToySSM(sigma=0.2):

@@ -159,6 +159,8 @@ def main():
 
     # --- auxiliary particle filter (core.py:299-313), Pitt & Shephard's StochVol proposal
     out["sv_apf"] = run_case(ssm.StochVol(), ssm.AuxiliaryPF, 30, 500, "systematic", 0.5)
+    out["lg_apf"] = run_case(kalman.LinearGauss(rho=0.9, sigmaX=1.0, sigmaY=0.6), ssm.AuxiliaryPF, 30, 500,
+                             "systematic", 0.5)
     out["sv_guided"] = run_case(ssm.StochVol(), ssm.GuidedPF, 30, 500, "systematic", 0.5)
 
     # --- full particle history + genealogy (smoothing.py:181-255), adaptive

@@ -1794,6 +1794,49 @@ def check_apf_fused(golden, apf2_cases=((2048, "systematic", 0.7), (4096, "strat
     assert abs(gd.logLt - float(golden("sv_guided")["logLt"])) < 0.15
 
 
+def check_apf_lingauss(golden, big=((2048, "systematic", 0.7), (3000, "stratified", 0.8))):
+    """AuxiliaryPF of the stock LinearGauss (kalman.py:436-452: optimal proposal, logeta = the predictive
+    density of y_{t+1}) in the fused loop: the reference's own run (fixture lg_apf, replayed draws) --
+    decisions, ESS and evidence to 1e-9, final ancestors, particles and weights -- on the one-launch
+    filter; on the two-level step against the oracle run on the same contract; the exact Kalman
+    likelihood in Philox mode."""
+    g = golden("lg_apf")
+    y = list(g["y"])
+    N, scheme, ESSrmin = int(g["N"]), str(g["scheme"]), float(g["ESSrmin"])
+    mk_o = lambda: orc.LinGauss(rho=0.9, sigmaX=1.0, sigmaY=0.6)
+    mk_d = lambda: kalman.LinearGauss(rho=0.9, sigmaX=1.0, sigmaY=0.6)
+    np.random.seed(int(g["run_seed"]))
+    rec = orc.RecordingRNG()
+    o = orc.run_filter(mk_o(), y, N, scheme, ESSrmin, fk="apf", rng=rec, keep=True)
+    assert o["final_logLt"] == float(g["logLt"])                        # the oracle IS the reference run
+    z, u = tapes_from_oracle(rec.tape, len(y), N, scheme)
+    pf = pa.SMC(fk=ssm.AuxiliaryPF(ssm=mk_d(), data=y), N=N, resampling=scheme, ESSrmin=ESSrmin, replay=(z, u))
+    assert pf._fused and describe(pf) == "k_filter_small"
+    pf.run()
+    assert pf.summaries.rs_flags == [bool(v) for v in g["rs_flags"]] and any(pf.summaries.rs_flags)
+    assert rel(pf.summaries.ESSs, g["ESSs"]) < 1e-9 and rel(pf.summaries.logLts, g["logLts"]) < 1e-9
+    assert np.array_equal(pf.A, g["A"]) and np.max(np.abs(pf.X - g["X"])) < 1e-12
+    assert np.allclose(pf.wgts.lw, g["lw"], rtol=1e-11, atol=1e-11) and rel(pf.W, g["W"]) < 1e-9
+    for N2, sch, essr in big:
+        np.random.seed(3 + N2)
+        rec = orc.RecordingRNG()
+        o = orc.run_filter(mk_o(), y, N2, sch, essr, fk="apf", rng=rec, keep=True, cdf="2level")
+        z, u = tapes_from_oracle(rec.tape, len(y), N2, sch)
+        pf = pa.SMC(fk=ssm.AuxiliaryPF(ssm=mk_d(), data=y), N=N2, resampling=sch, ESSrmin=essr, replay=(z, u))
+        assert pf._fused and describe(pf).endswith("k_reduce2+k_ancestors2+k_propagate"), describe(pf)
+        pf.run()
+        assert pf.summaries.rs_flags == o["rs_flag"] and sum(o["rs_flag"]) >= 2
+        assert rel(pf.summaries.ESSs, o["ESS"]) < 1e-9 and rel(pf.summaries.logLts, o["logLt"]) < 1e-9
+        assert np.array_equal(pf.A, o["A"]) and np.max(np.abs(pf.X - o["X"])) < 1e-12
+    ll, _ = orc.kalman_loglik(mk_o(), y)
+    lls = []
+    for s in range(4):
+        pf = pa.SMC(fk=ssm.AuxiliaryPF(ssm=mk_d(), data=y), N=4096, seed=60 + s)
+        pf.run()
+        lls.append(pf.logLt)
+    assert abs(np.mean(lls) - ll) < 0.1, (lls, ll)
+
+
 def check_resident_user_model(golden):
     """A user-defined model written with numpy expressions (here Gordon et al's, transcribed
     from state_space_models.py:546-577, and StochVol's) run through the template-method step

@@ -265,6 +265,10 @@ def test_strict_ancestors_equal_the_reference_cdf():
     pc.check_strict_ancestors(sizes=(3000,), op_N=5000, op_cases=8)
 
 
+def test_apf_lingauss_fused(golden):
+    pc.check_apf_lingauss(golden)
+
+
 def test_device_sort():
     pc.check_device_sort(sizes=(1, 63, 64, 2047, 2048, 2049, 9001))
 

@@ -478,6 +478,10 @@ def test_strict_ancestors_equal_the_reference_cdf():
     pc.check_strict_ancestors(sizes=(3000, 1 << 17), op_N=1 << 20, op_cases=100)
 
 
+def test_apf_lingauss_fused(golden):
+    pc.check_apf_lingauss(golden)
+
+
 def test_device_sort():
     pc.check_device_sort(sizes=(1, 64, 2049, 50001, (1 << 20) + 3, 1 << 22))
 

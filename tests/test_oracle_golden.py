@@ -13,6 +13,7 @@ MODELS = {
     "sv": lambda: orc.StochVol(),
     "lg_adaptive": lambda: orc.LinGauss(rho=0.9, sigmaX=1.0, sigmaY=1.5),
     "lg_guided": lambda: orc.LinGauss(rho=0.9, sigmaX=1.0, sigmaY=0.2),
+    "lg_apf": lambda: orc.LinGauss(rho=0.9, sigmaX=1.0, sigmaY=0.6),
     "mv4": lambda: orc.Guarniero(alpha=0.4, dx=4),
     "mv32": lambda: orc.Guarniero(alpha=0.4, dx=32),
     "gordon": lambda: orc.Gordon(),
@@ -28,7 +29,7 @@ CASES = ([("toy_%s" % s, "toy", "bootstrap") for s in ("systematic", "stratified
             ("mv32_guided", "mv32", "guided"), ("mv32_boot", "mv32", "bootstrap"),
             ("gordon_boot", "gordon", "bootstrap"), ("theta_boot", "theta", "bootstrap"),
             ("svlev_boot", "svlev", "bootstrap"), ("cox_boot", "cox", "bootstrap"),
-            ("sv_guided", "sv", "guided"), ("sv_apf", "sv", "apf")])
+            ("sv_guided", "sv", "guided"), ("sv_apf", "sv", "apf"), ("lg_apf", "lg_apf", "apf")])
 
 
 SQMC_CASES = [("sqmc_toy", lambda: orc.LinGauss(rho=0.9, sigmaX=1.0, sigmaY=0.5), "bootstrap"),
