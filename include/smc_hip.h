@@ -327,6 +327,25 @@ typedef struct smc_filter_opts {
  * CDF.  Costs a one-wavefront pass over the weights per resampling step (ms at N = 2^20). */
 #define SMC_FLAG_STRICT_ANCESTORS 2
 
+/* Verification switches (bits 8 and up of opts.flags): each selects an ALTERNATIVE CODE PATH that must
+ * give the same results (the same bits, or the documented near-tie differences between the two exact
+ * CDFs) as the one a filter of that shape takes by default -- the parity suite and tools/fuzz_paths.py
+ * run both and compare.  Nothing here changes what is computed; the library reads no environment
+ * variable to choose a path (the Python layer maps its SMC_* test variables onto these bits). */
+#define SMC_PATH_FLAT_CDF        (1 << 8)   /* flat Q62 CDF (k_ancestors [+ k_prepare]) where the two-level step applies */
+#define SMC_PATH_TWO_LEVEL_MID   (1 << 9)   /* k_reduce2 in front of k_ancestors2 even on resident grids */
+#define SMC_PATH_EXACT_COUNTS    (1 << 10)  /* form every c Q_b / t_b exactly (no fp64 band shortcut) */
+#define SMC_PATH_FORCE_FUSED     (1 << 11)  /* flat step: published tile totals regardless of the grid size */
+#define SMC_PATH_FORCE_UNFUSED   (1 << 12)  /* flat step: k_prepare regardless of the grid size */
+#define SMC_PATH_NO_SMALL        (1 << 13)  /* N <= 1024: the multi-kernel step instead of k_filter_small */
+#define SMC_PATH_NO_NT           (1 << 14)  /* plain instead of streaming stores */
+#define SMC_PATH_NO_HEAVY        (1 << 15)  /* no heavy-parent list */
+#define SMC_PATH_NO_TK           (1 << 16)  /* normals never start on the host's time index */
+#define SMC_PATH_FLAT_MULTINOMIAL (1 << 17) /* multinomial on the flat step */
+#define SMC_PATH_POW2_ONLY       (1 << 18)  /* N not a power of two on the flat step */
+#define SMC_PATH_SPACING_3PASS   (1 << 19)  /* uniform_spacings in three passes instead of one */
+#define SMC_PATH_MV_CHUNKS(n)    (((n) & 15) << 20)   /* k_propagate_mv: n = 1, 2, 4, 8 chunks per workgroup */
+
 /* y_host: data, (T, dy) row-major, shared by all islands. */
 int smc_filter_create(smc_ctx* ctx, const smc_model* model,
                       const smc_filter_opts* opts, const double* y_host,

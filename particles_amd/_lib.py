@@ -48,6 +48,23 @@ class SmcFilterOpts(ctypes.Structure):
 
 FLAG_COLLAPSED_PROPOSAL = 1
 FLAG_STRICT_ANCESTORS = 2
+# verification switches (include/smc_hip.h SMC_PATH_*): the environment variables the test-suite and
+# tools/ set to force an alternative, equivalent code path; read HERE, not in the library
+PATH_FLAGS = {"SMC_FLAT_CDF": 1 << 8, "SMC_TWO_LEVEL_MID": 1 << 9, "SMC_EXACT_COUNTS": 1 << 10,
+              "SMC_FORCE_FUSED": 1 << 11, "SMC_FORCE_UNFUSED": 1 << 12, "SMC_NO_SMALL": 1 << 13,
+              "SMC_NO_NT": 1 << 14, "SMC_NO_HEAVY": 1 << 15, "SMC_NO_TK": 1 << 16,
+              "SMC_FLAT_MULTINOMIAL": 1 << 17, "SMC_POW2_ONLY": 1 << 18, "SMC_SPACING_3PASS": 1 << 19}
+
+
+def path_flags():
+    f = 0
+    for name, bit in PATH_FLAGS.items():
+        if os.environ.get(name):
+            f |= bit
+    mv = os.environ.get("SMC_MV_CHUNKS")
+    if mv and int(mv) in (1, 2, 4, 8):
+        f |= int(mv) << 20
+    return f
 
 
 # name -> (restype, argtypes): every symbol include/smc_hip.h declares

@@ -283,7 +283,7 @@ class SMC:
         o.keep_history = self._keep_history
         o.moments = 1 if self._device_moments else 0
         o.flags = (_lib.FLAG_COLLAPSED_PROPOSAL if self._collapsed else 0) | \
-                  (_lib.FLAG_STRICT_ANCESTORS if self._strict else 0)
+                  (_lib.FLAG_STRICT_ANCESTORS if self._strict else 0) | _lib.path_flags()
         self._ctx = _lib.ctx()
         h = _lib.c_vp()
         check(lib().smc_filter_create(self._ctx.h, ctypes.byref(m), ctypes.byref(o),

@@ -35,7 +35,8 @@ struct smc_filter {
     bool prof;
     std::vector<hipEvent_t> ev;
     int prof_n;
-    bool no_tk;            // SMC_NO_TK=1: kernels never start on the host's time index (A/B)
+    bool no_tk;            // SMC_PATH_NO_TK: kernels never start on the host's time index (A/B)
+    bool no_small;         // SMC_PATH_NO_SMALL
     double* tmp;           // (N,) staging for W / Xp downloads
     double* ll_stage;      // (n_islands,) staging for smc_filter_logLt: PINNED host memory the
                            // collect kernel writes straight into (no copy engine, no staging)
@@ -274,6 +275,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     f->th_ess_min = 0.0;
     f->mv_collapsed = mv && model->fk == SMC_FK_GUIDED && (o->flags & SMC_FLAG_COLLAPSED_PROPOSAL);
     f->strict = (o->flags & SMC_FLAG_STRICT_ANCESTORS) != 0;
+    f->no_small = (o->flags & SMC_PATH_NO_SMALL) != 0;
     f->strict_ws = nullptr;
     if (f->strict && (mv || model->fk == SMC_FK_APF || o->N >= ((i64)1 << 32))) {
         smc_set_error("SMC_FLAG_STRICT_ANCESTORS: univariate Bootstrap / Guided filters");
@@ -319,18 +321,17 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     const size_t oA = carve(nA * 4);
     // (published tile totals pay off only while every workgroup of the launch is resident)
     f->fused = (i64)a.ntiles * (i64)M <= F_DIRECT_PREFIX_MAX;
-    if (getenv("SMC_FORCE_FUSED")) f->fused = a.ntiles <= F_DIRECT_PREFIX_MAX;   // experiments
-    if (getenv("SMC_FORCE_UNFUSED")) f->fused = false;        // tests: the k_prepare path at any size
+    if (o->flags & SMC_PATH_FORCE_FUSED) f->fused = a.ntiles <= F_DIRECT_PREFIX_MAX;
+    if (o->flags & SMC_PATH_FORCE_UNFUSED) f->fused = false;  // tests: the k_prepare path at any size
     const size_t oQ = carve(M * a.ntiles * 8);
     const size_t oQpre = carve(M * a.ntiles * 8);
     // MV: a workgroup stages the step's matrices in LDS once and then walks
     // mv_chunks chunks of 256 particles (2 workgroups per CU when N allows)
     a.mv_chunks = 1;
     if (mv) {
-        // 8 by default, halved until the grid has at least 512 workgroups; SMC_MV_CHUNKS=1|2|4|8
+        // 8 by default, halved until the grid has at least 512 workgroups; SMC_PATH_MV_CHUNKS(1|2|4|8)
         // (tests) is taken as given, so that the multi-chunk prefetch loop is audited at small N too
-        const char* e = getenv("SMC_MV_CHUNKS");
-        const int forced = e ? atoi(e) : 0;
+        const int forced = (o->flags >> 20) & 15;
         if (forced == 1 || forced == 2 || forced == 4 || forced == 8) a.mv_chunks = forced;
         else {
             a.mv_chunks = 8;
@@ -356,9 +357,9 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     //  spacings drawn between k_reduce2, which decides the step, and k_ancestors2)
     // (any N >= 2 tiles: N = 2^k counts in closed form with integers, other N with the general counts)
     f->two_level = !mv && !(o->moments && model->fk == SMC_FK_APF) && o->N <= ((int64_t)1 << 30) && a.ntiles >= 2 &&
-                   !(a.log2N < 0 && getenv("SMC_POW2_ONLY")) &&
-                   !getenv("SMC_FLAT_CDF") && !getenv("SMC_FORCE_FUSED") && !getenv("SMC_FORCE_UNFUSED") &&
-                   !(o->scheme == SMC_MULTINOMIAL && getenv("SMC_FLAT_MULTINOMIAL"));
+                   !(a.log2N < 0 && (o->flags & SMC_PATH_POW2_ONLY)) &&
+                   !(o->flags & (SMC_PATH_FLAT_CDF | SMC_PATH_FORCE_FUSED | SMC_PATH_FORCE_UNFUSED)) &&
+                   !(o->scheme == SMC_MULTINOMIAL && (o->flags & SMC_PATH_FLAT_MULTINOMIAL));
     // every workgroup reduces the partials itself while the launch is resident and an island has
     // at most 1024 tiles (4 per thread); otherwise one workgroup per island does it first
     const bool apf2 = model->fk == SMC_FK_APF && o->N > F_TILE;      // APF on the two-level step: k_reduce2
@@ -367,9 +368,9 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
         delete f;
         return SMC_ERR_INVALID;
     }
-    f->two_level_mid = f->two_level && (!f->fused || a.ntiles > 1024 || getenv("SMC_TWO_LEVEL_MID") ||
+    f->two_level_mid = f->two_level && (!f->fused || a.ntiles > 1024 || (o->flags & SMC_PATH_TWO_LEVEL_MID) ||
                                         o->scheme == SMC_MULTINOMIAL || apf2);
-    const bool heavy_list = !mv && !f->strict && !getenv("SMC_NO_HEAVY");
+    const bool heavy_list = !mv && !f->strict && !(o->flags & SMC_PATH_NO_HEAVY);
     // (history slots are written step by step: the lanes beyond N of a slot would read indices nobody
     //  initialised -- every access tests its index there as well)
     a.kform = f->two_level ? 1 : 0;
@@ -386,7 +387,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     // the fewest that keep the whole launch resident (<= 1024 workgroups: half of what the chip holds);
     // more islands than that: the three-pass form
     a.sp_tpw = a.sp_nwg = 0;
-    if (need_su && f->two_level && !f->strict && !getenv("SMC_SPACING_3PASS"))
+    if (need_su && f->two_level && !f->strict && !(o->flags & SMC_PATH_SPACING_3PASS))
         for (int tpw = 1; tpw <= 8 && !a.sp_tpw; tpw *= 2) {
             const i64 nwg = (a.ntiles + tpw - 1) / tpw;
             int per_cu = 0;                        // workgroups of this instantiation a CU holds at once
@@ -459,12 +460,12 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
         a.hlist = (i64*)(base + oHlist);
         F_CREATE_CHECK(hipMemsetAsync(a.hcnt, 0, M * 2 * sizeof(unsigned), ctx->stream));
     }
-    a.exact_counts = getenv("SMC_EXACT_COUNTS") ? 1 : 0;
-    f->no_tk = getenv("SMC_NO_TK") != nullptr;
+    a.exact_counts = (o->flags & SMC_PATH_EXACT_COUNTS) ? 1 : 0;
+    f->no_tk = (o->flags & SMC_PATH_NO_TK) != 0;
     a.tk = -1;
     // streaming stores pay while a launch is short (its end-of-kernel write-back shows): C2 +8 %;
     // on the large grids they cost 2 % (C5)
-    a.nt = ((i64)a.ntiles * (i64)M <= F_DIRECT_PREFIX_MAX && !mv && !getenv("SMC_NO_NT")) ? 1 : 0;
+    a.nt = ((i64)a.ntiles * (i64)M <= F_DIRECT_PREFIX_MAX && !mv && !(o->flags & SMC_PATH_NO_NT)) ? 1 : 0;
     a.pm2 = a.ps2 = a.pss2 = nullptr;
     if (apf2) {
         a.pm2 = (double*)(base + oP2);
@@ -656,7 +657,7 @@ int smc_filter_set_replay(smc_filter* f, const double* z, const double* u)
 static bool small_filter_ok(const smc_filter* f)
 {
     return f->a.N <= F_TILE && f->kind != SMC_MODEL_MVLINGAUSS && !f->a.mom && !f->prof && !f->strict &&
-           !(f->a.scheme == SMC_MULTINOMIAL && !f->a.ut) && !getenv("SMC_NO_SMALL");
+           !(f->a.scheme == SMC_MULTINOMIAL && !f->a.ut) && !f->no_small;
 }
 
 static void launch_small(smc_filter* f, int nsteps)

@@ -75,9 +75,6 @@ __device__ __forceinline__ void mv_product(const double* frag, const double (&v)
 #pragma unroll
         for (int jb = 0; jb < DP / 16; ++jb) {
             if (LOWER && 4 * kb >= 16 * (jb + 1)) continue;
-#ifdef ABL_NO_MFMA            /* perf experiments only (tools/build_ablations.sh) */
-            continue;
-#endif
             const double m = frag[(jb * (DP / 4) + kb) * 64 + lane];
 #pragma unroll
             for (int gi = 0; gi < MV_G; ++gi)
@@ -196,11 +193,7 @@ k_propagate_mv(const FArgs av, const double* __restrict__ C)
         for (int kb = 0; kb < NV; ++kb) {
             const int k = 4 * kb + g;
             const bool kin = dfull || k < d;
-#ifdef ABL_NO_LOAD
-            const double x = (double)(k + (int)(row & 3)) * 0.03125;
-#else
             const double x = pr[kin ? k : 0];
-#endif
             dst[kb] = (rv && kin) ? x : 0.0;
         }
     };
@@ -275,12 +268,8 @@ k_propagate_mv(const FArgs av, const double* __restrict__ C)
                     const int j = jj + e * (NV / 2);
                     const int kp = 2 * j + h;
                     double z0, z1;
-#ifdef ABL_NO_RNG
-                    z0 = (double)(n[gi] & 7) * 0.25 - 1.0; z1 = (double)kp * 0.125 - 0.5;
-#else
                     smc_normal_pair(s_ntab, a.seed, (u32)(n[gi] * hp + kp), (u32)t, gisl,
                                     SMC_STREAM_NORMAL, z0, z1);
-#endif
                     if (!dfull) {
                         if (2 * kp >= d) z0 = 0.0;
                         if (2 * kp + 1 >= d) z1 = 0.0;
@@ -341,11 +330,7 @@ k_propagate_mv(const FArgs av, const double* __restrict__ C)
                 }
 #pragma unroll
         for (int gi = 0; gi < MV_G; ++gi)
-#ifdef ABL_NO_STORE
-            if (valid[gi] && v[gi][0] == 123.456) {
-#else
             if (valid[gi]) {
-#endif
                 SMC_GLOBAL(double) px = Xn + n[gi] * d + g;
                 if (dfull) {
 #pragma unroll
