@@ -53,6 +53,25 @@ prof_c3m)
 c3m)
   for sc in multinomial stratified systematic; do
     timeout 300 python bench.py --workload c3 --scheme $sc --steps 100 --warmup 10 > $O/bench_c3_$sc.json 2>&1; line $O/bench_c3_$sc.json; done ;;
+robust)
+  (timeout 300 python tools/robustness.py > $O/robustness.txt 2>&1; echo "rc=$?" >> $O/robustness.txt); tail -25 $O/robustness.txt
+  (timeout 300 python tools/soak.py > $O/soak.txt 2>&1; echo "rc=$?" >> $O/soak.txt); tail -8 $O/soak.txt
+  (timeout 400 python tools/fuzz_paths.py 400 23 > $O/fuzz400.txt 2>&1; echo "rc=$?" >> $O/fuzz400.txt); tail -3 $O/fuzz400.txt ;;
+sweep)
+  (timeout 300 python tools/size_sweep.py > $O/size_sweep.txt 2>&1); cat $O/size_sweep.txt ;;
+trace)
+  (timeout 200 python tools/trace_step.py > $O/trace_step.txt 2>&1); cat $O/trace_step.txt ;;
+prof_c5)
+  EXTRA="--workload c5" bash tools/gpu_profile.sh ${TAG}_c5 100 > $O/prof_c5.txt 2>&1; tail -30 $O/prof_c5.txt ;;
+prof_c4)
+  EXTRA="--workload c4" bash tools/gpu_profile.sh ${TAG}_c4 50 > $O/prof_c4.txt 2>&1; tail -24 $O/prof_c4.txt ;;
+c45)
+  timeout 300 python bench.py --workload c5 --steps 200 --warmup 20 > $O/bench_c5.json 2>&1; line $O/bench_c5.json
+  timeout 300 python bench.py --workload c4 --steps 100 --warmup 10 > $O/bench_c4.json 2>&1; line $O/bench_c4.json
+  timeout 300 python bench.py --workload c4 --collapsed --steps 100 --warmup 10 > $O/bench_c4_collapsed.json 2>&1; line $O/bench_c4_collapsed.json ;;
+two_ranks)
+  # the driver's N = 2 launch line with both ranks on this box's one GPU (RCCL refuses: labelled host fallback)
+  SMC_BENCH_NGPU=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 20 --warmup 5 > $O/bench_2ranks_1gpu.json 2> $O/bench_2ranks_1gpu.err; line $O/bench_2ranks_1gpu.json; tail -2 $O/bench_2ranks_1gpu.err ;;
 *)
   echo "unknown stage $w" ;;
 esac; done
