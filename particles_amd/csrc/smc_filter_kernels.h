@@ -576,6 +576,11 @@ __attribute__((amdgpu_waves_per_eu(3, 8)))
 k_f_spacing_onepass(const FArgs av)
 {
     const FArgs& a = av;
+    // 32 draws per thread = 64 registers: with everything else the kernel spilled 100 B per lane at the
+    // 168 registers that keep 3 waves per SIMD (13 MB of scratch traffic per launch at N = 2^22); the
+    // draws of the tiles beyond TREG wait in LDS instead (conflict-free: slot i of a thread at i * 256 + tid)
+    constexpr int TREG = TPW > 4 ? 4 : TPW;
+    __shared__ u64 s_q[TPW > TREG ? TPW - TREG : 1][4 * SMC_BLOCK];
     __shared__ u64 s_w[TPW][SMC_NWAVE];
     __shared__ u64 s_pre;
     SMC_NTAB_LDS(s_ntab);
@@ -601,6 +606,10 @@ k_f_spacing_onepass(const FArgs av)
         if (k < a.ntiles) f_spacing_q4(a, s_ntab, (u32)t, gisl, k * F_TILE + (i64)tid * F_IPT, q[r]);
         else { q[r][0] = q[r][1] = q[r][2] = q[r][3] = 0ull; }
         inc[r] = smc_wave_scan_add_u64(q[r][0] + q[r][1] + q[r][2] + q[r][3]);
+        if (r >= TREG) {                           // the last two tiles' draws wait in LDS (see s_q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s_q[r - TREG][i * SMC_BLOCK + tid] = q[r][i];
+        }
     }
     u64 q_last = 0ull;                             // draw N when it has a tile of its own
     if (w == a.sp_nwg - 1 && a.ntiles1 > a.ntiles && tid == 0) {
@@ -663,7 +672,10 @@ k_f_spacing_onepass(const FArgs av)
         if (tid == 0) E[k] = run;
         u64 z4[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { run += q[r][i]; z4[i] = run; }
+        for (int i = 0; i < 4; ++i) {
+            run += (r >= TREG) ? s_q[r - TREG][i * SMC_BLOCK + tid] : q[r][i];
+            z4[i] = run;
+        }
         if (n0 + 3 < a.N && (a.N & 1) == 0) {
             smc_st2g(Z + n0, z4[0], z4[1]);
             smc_st2g(Z + n0 + 2, z4[2], z4[3]);
