@@ -326,6 +326,13 @@ typedef struct smc_filter_opts {
  * A_t == particles.resampling.inverse_cdf(su, W_{t-1}) bit for bit -- instead of the exact integer
  * CDF.  Costs a one-wavefront pass over the weights per resampling step (ms at N = 2^20). */
 #define SMC_FLAG_STRICT_ANCESTORS 2
+/* SQMC (particles.SMC(qmc=True), core.py:315-321, 339-349) as a fused loop: univariate Bootstrap / Guided
+ * filters, N = 2^k >= 2048.  Every step sorts the particles (hilbert_sort = argsort for d = 1: the radix sort),
+ * chooses ancestors by the inverse CDF of the weights in sorted order at the sorted first coordinates of a
+ * scrambled Sobol' point set (known in closed form for N = 2^k: no second sort), and moves with the
+ * inverse normal CDF of the second coordinates (Gamma = ProbDist.ppf).  Always resamples (core.py:340):
+ * `scheme` and `ESSrmin` are ignored.  The points are smc_sobol's (see smc_filter_sqmc_points). */
+#define SMC_FLAG_SQMC 4
 
 /* Verification switches (bits 8 and up of opts.flags): each selects an ALTERNATIVE CODE PATH that must
  * give the same results (the same bits, or the documented near-tie differences between the two exact
@@ -351,6 +358,11 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model,
                       const smc_filter_opts* opts, const double* y_host,
                       smc_filter** out);
 int smc_filter_destroy(smc_filter* f);
+/* SMC_FLAG_SQMC filters, before the first step: the run's points are those of smc_sobol /
+ * smc_sobol_sorted (scramble = safe = 1) under a context seeded with point_seed -- point set `counter0`
+ * (1 coordinate, rqmc.sobol(N, 1), core.py:317) for t = 0 and `counter0 + t` (2 coordinates,
+ * core.py:341) for step t; island i takes counter word i << 32 on top.  Default: (opts.seed, 1). */
+int smc_filter_sqmc_points(smc_filter* f, uint64_t point_seed, uint64_t counter0);
 /* An independent copy of a filter in its current state: copy.deepcopy(pf) of the reference
  * (theta-level resampling of SMC^2 deep-copies every duplicated filter, smc_samplers.py:319-361).
  * Replay tapes are shared (caller-owned, read-only).  The copy's Philox streams are the source's

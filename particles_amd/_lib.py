@@ -48,6 +48,7 @@ class SmcFilterOpts(ctypes.Structure):
 
 FLAG_COLLAPSED_PROPOSAL = 1
 FLAG_STRICT_ANCESTORS = 2
+FLAG_SQMC = 4
 # verification switches (include/smc_hip.h SMC_PATH_*): the environment variables the test-suite and
 # tools/ set to force an alternative, equivalent code path; read HERE, not in the library
 PATH_FLAGS = {"SMC_FLAT_CDF": 1 << 8, "SMC_TWO_LEVEL_MID": 1 << 9, "SMC_EXACT_COUNTS": 1 << 10,
@@ -113,6 +114,7 @@ SIGNATURES = {
     "smc_filter_destroy": (c_int, [c_vp]),
     "smc_filter_clone": (c_int, [c_vp, P(c_vp)]),
     "smc_filter_reseed": (c_int, [c_vp, c_u64]),
+    "smc_filter_sqmc_points": (c_int, [c_vp, c_u64, c_u64]),
     "smc_filter_set_replay": (c_int, [c_vp, c_vp, c_vp]),
     "smc_filter_step": (c_int, [c_vp, c_i64]),
     "smc_filter_sync": (c_int, [c_vp]),
@@ -244,6 +246,8 @@ RNG_MODE = ["numpy"]
 # RESIDENT[0] = True (particles_amd.set_resident) they return DeviceArrays instead: a
 # user-defined model then runs its whole step in HBM (DeviceArray supports the arithmetic).
 RESIDENT = [False]
+# SMC(qmc=True) on the fused SQMC step (SMC_FLAG_SQMC) where it applies; False: always the operator path
+FUSED_SQMC = [True]
 
 
 def default_device():

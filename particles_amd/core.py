@@ -183,9 +183,9 @@ class SMC:
                 fk, N, resampling, replay, store_history,
                 bool(collect and collect != "off" and self._device_moments)):
             model = None                       # the operator path
-        if qmc:                    # SQMC: the template-method step on device operators
-            model = None
-        self._fused = self._will_fuse(fk, qmc, resampling, model)
+        if qmc and not self._sqmc_fusable(fk, N, model, replay, use_graph, strict_ancestors):
+            model = None           # SQMC as the template-method step on device operators
+        self._fused = self._will_fuse(fk, qmc, resampling, model, N=N)
         if self._fused:
             # full history on the fused path stays on the device: the step loop
             # writes step t into slot t (no per-step host copies, no per-step sync)
@@ -216,15 +216,27 @@ class SMC:
         return stock and not device_moments and (small or two_level)
 
     @staticmethod
-    def _will_fuse(fk, qmc=False, resampling="systematic", model=False):
+    def _sqmc_fusable(fk, N, model, replay=None, use_graph=False, strict=False):
+        """SQMC as a fused loop (SMC_FLAG_SQMC): univariate Bootstrap / Guided filters of the fused family,
+        N = 2^k >= 2048 (the sorted Sobol' order in closed form), device-generated points."""
+        return (_lib.FUSED_SQMC[0] and _lib.RNG_MODE[0] == "philox" and model is not None
+                and model.get("params") is not None and model.get("dx", 1) == 1
+                and getattr(fk, "_fk_kind", None) in (_lib.FK_BOOTSTRAP, _lib.FK_GUIDED)
+                and 2048 <= N <= (1 << 30) and N & (N - 1) == 0
+                and replay is None and not use_graph and not strict)
+
+    @staticmethod
+    def _will_fuse(fk, qmc=False, resampling="systematic", model=False, N=None):
         """Does SMC(fk, qmc, resampling) run the fused device loop?  (One predicate for ``SMC``
         and for ``multiSMC``'s decision to batch runs as islands.)"""
-        if fk is None or qmc or resampling not in _lib.SCHEMES:
+        if fk is None or resampling not in _lib.SCHEMES:
             return False
         if fk.isAPF and getattr(fk, "_fk_kind", None) != _lib.FK_APF:
             return False
         if model is False:
             model = fk._device_model() if hasattr(fk, "_device_model") else None
+        if qmc and (N is None or not SMC._sqmc_fusable(fk, N, model)):
+            return False
         return model is not None and (model.get("params") is not None
                                       or model["kind"] == _lib.MODEL_MVLINGAUSS)
 
@@ -283,12 +295,18 @@ class SMC:
         o.keep_history = self._keep_history
         o.moments = 1 if self._device_moments else 0
         o.flags = (_lib.FLAG_COLLAPSED_PROPOSAL if self._collapsed else 0) | \
-                  (_lib.FLAG_STRICT_ANCESTORS if self._strict else 0) | _lib.path_flags()
+                  (_lib.FLAG_STRICT_ANCESTORS if self._strict else 0) | \
+                  (_lib.FLAG_SQMC if self.qmc else 0) | _lib.path_flags()
         self._ctx = _lib.ctx()
         h = _lib.c_vp()
         check(lib().smc_filter_create(self._ctx.h, ctypes.byref(m), ctypes.byref(o),
                                       y.ctypes.data_as(_lib.P(_lib.c_dbl)), ctypes.byref(h)))
         self._f = h
+        if self.qmc:
+            # the points of the operator path (rqmc.sobol / sobol_sorted): the context's key, one
+            # point-set counter per time step -- the same run whichever path executes it
+            check(lib().smc_filter_sqmc_points(self._f, self._ctx._seed & (2 ** 64 - 1), _lib._counter + 1))
+            _lib._counter += T
         if replay is not None:
             z, u = replay
             self._tapes = (_lib.as_device(z)[0], _lib.as_device(u)[0])
@@ -721,7 +739,7 @@ def multiSMC(nruns=10, nprocs=0, out_func=None, collect=None, **args):
         run_seeds = seeds[si:si + nruns]
         si += nruns
         fk = kw.get("fk")
-        batch = (SMC._will_fuse(fk, kw.get("qmc", False), kw.get("resampling", "systematic"))
+        batch = (SMC._will_fuse(fk, kw.get("qmc", False), kw.get("resampling", "systematic"), N=kw.get("N", 100))
                  and not collect and not kw.get("store_history") and not kw.get("verbose")
                  and kw.get("n_islands", 1) == 1
                  and not (fk.isAPF and not SMC._apf_fusable(fk, kw.get("N", 100), kw.get("resampling", "systematic"),

@@ -6,6 +6,7 @@
 
 #include "smc_filter_mv.h"
 #include "smc_filter_small.h"
+#include "smc_filter_sqmc.h"
 
 // ---------------------------------------------------------------------------
 // host side
@@ -29,6 +30,13 @@ struct smc_filter {
     bool mv_collapsed;     // MVLINGAUSS guided: log G = log p(y_t | x_{t-1}) in one product (opts.flags)
     bool strict;           // SMC_FLAG_STRICT_ANCESTORS: sequential fp64 CDF of the filter's weights
     double* strict_ws;     // (n_islands, N) W -> S
+    // SMC_FLAG_SQMC (smc_filter_sqmc.h): the point stream, the tape of ndtri(second coordinate), the
+    // sort's workspace and -- more than one island -- the islands' permutations
+    bool sqmc;
+    u64 sq_seed, sq_ctr0;
+    double* sq_z;
+    u64* sq_perm;
+    void* sq_ws;
     i64 perm_t;            // t_host at the last smc_filter_permute_islands (A / Xp undefined there)
     hipGraphExec_t gexec[3];   // captured step sequences of F_GRAPH_SIZES steps (even: see enqueue_step)
     bool graph_failed;
@@ -115,6 +123,41 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
     hipStream_t st = f->ctx->stream;
     const dim3 grid(f->a.ntiles, f->a.n_islands);
     if (k_prof >= 0) (void)hipEventRecord(f->ev[3 * k_prof], st);
+    if (f->sqmc) {
+        // smc_filter_sqmc.h.  The tapes of the step are per-step buffers: the kernels index tapes by
+        // (t, island), so the pointers are rebased to put row t on the buffer (the host knows t: eager launches)
+        FArgs& a = f->a;
+        const i64 MN = (i64)a.n_islands * a.N;
+        a.zt = f->sq_z - t * MN;
+        a.ut = a.su - t * MN;
+        a.ut_stride = a.N;
+        if (t == 0) {
+            SMC_LAUNCH(k_sq_init, dim3((unsigned)((a.N + SMC_BLOCK - 1) / SMC_BLOCK), a.n_islands), dim3(SMC_BLOCK), st,
+                       f->a, f->sq_z, f->sq_seed, f->sq_ctr0);
+        } else {
+            const u64* perm = f->sq_perm;
+            for (int i = 0; i < a.n_islands; ++i) {        // h_order = argsort(X_{t-1}) (hilbert.py:52-54, d = 1)
+                u64* v0 = nullptr;
+                (void)smc_rs_sort_ws(f->ctx, f_X(a, t - 1) + (i64)i * a.N, nullptr, a.N, 0, f->sq_ws, nullptr, &v0);
+                if (a.n_islands == 1) perm = v0;
+                else (void)hipMemcpyAsync(f->sq_perm + (i64)i * a.N, v0, (size_t)a.N * 8, hipMemcpyDeviceToDevice, st);
+            }
+            SMC_LAUNCH(k_sq_permute, grid, dim3(SMC_BLOCK), st, f->a, perm, a.su, f->sq_z, f->sq_seed, f->sq_ctr0);
+            SMC_LAUNCH(k_reduce2, dim3(a.n_islands), dim3(SMC_BLOCK), st, f->a);
+            SMC_LAUNCH((k_ancestors2<true, true>), grid, dim3(SMC_BLOCK), st, f->a);
+            SMC_LAUNCH(k_sq_compose, dim3((unsigned)((a.N / 4 + SMC_BLOCK - 1) / SMC_BLOCK), a.n_islands), dim3(SMC_BLOCK), st,
+                       f->a, perm);
+        }
+        if (k_prof >= 0 && (k_prof % 3)) (void)hipEventRecord(f->ev[3 * k_prof + 1], st);
+        launch_propagate(f);
+        if (k_prof >= 0) (void)hipEventRecord(f->ev[3 * k_prof + 2], st);
+        if (a.mom) {
+            SMC_LAUNCH(k_flush2, dim3(a.n_islands), dim3(SMC_BLOCK), st, f->a);
+            SMC_LAUNCH(k_f_moments_partials, dim3(a.nmb, a.n_islands), dim3(SMC_BLOCK), st, f->a);
+            SMC_LAUNCH(k_f_moments_final, dim3(a.n_islands), dim3(SMC_BLOCK), st, f->a);
+        }
+        return;
+    }
     if (f->strict) {
         // decision + normalisation of step t-1 (two-level: k_reduce2; flat: k_propagate's tail did it),
         // W_{t-1}, its sequential CDF, the searches
@@ -277,6 +320,27 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     f->strict = (o->flags & SMC_FLAG_STRICT_ANCESTORS) != 0;
     f->no_small = (o->flags & SMC_PATH_NO_SMALL) != 0;
     f->strict_ws = nullptr;
+    f->sqmc = (o->flags & SMC_FLAG_SQMC) != 0;
+    f->sq_seed = o->seed;
+    f->sq_ctr0 = 1;
+    f->sq_z = nullptr;
+    f->sq_perm = nullptr;
+    f->sq_ws = nullptr;
+    if (f->sqmc) {
+        // core.py:339-349 on the two-level step: univariate Normal kernels (Gamma = ppf), N = 2^k >= 2 tiles
+        // (the sorted Sobol' order in closed form), device-generated points
+        bool pow2 = false;
+        for (int k = 11; k <= 30; ++k) pow2 = pow2 || (((i64)1 << k) == o->N);
+        if (mv || !(model->fk == SMC_FK_BOOTSTRAP || model->fk == SMC_FK_GUIDED) || !pow2 || f->strict ||
+            o->rng_mode != SMC_RNG_PHILOX || o->use_graph ||
+            (o->flags & (SMC_PATH_FLAT_CDF | SMC_PATH_FORCE_FUSED | SMC_PATH_FORCE_UNFUSED | SMC_PATH_FLAT_MULTINOMIAL))) {
+            smc_set_error("SMC_FLAG_SQMC: univariate Bootstrap / Guided filters, N = 2^k with 11 <= k <= 30, "
+                          "Philox mode, eager launches, the two-level step");
+            delete f;
+            return SMC_ERR_INVALID;
+        }
+    }
+    const int scheme = f->sqmc ? (int)SMC_MULTINOMIAL : (int)o->scheme;     // (sorted uniforms from a tape)
     if (f->strict && (mv || model->fk == SMC_FK_APF || o->N >= ((i64)1 << 32))) {
         smc_set_error("SMC_FLAG_STRICT_ANCESTORS: univariate Bootstrap / Guided filters");
         delete f;
@@ -289,10 +353,10 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     a.n_islands = o->n_islands;
     a.ntiles = (int)((o->N + F_TILE - 1) / F_TILE);
     a.ntiles1 = (int)((o->N + 1 + F_TILE - 1) / F_TILE);
-    a.scheme = o->scheme;
+    a.scheme = scheme;
     a.rng_mode = o->rng_mode;
     a.island_offset = o->island_offset;
-    a.ess_thresh = (double)o->N * o->ESSrmin;
+    a.ess_thresh = f->sqmc ? INFINITY : (double)o->N * o->ESSrmin;     // (SQMC always resamples, core.py:340)
     a.seed = o->seed;
     a.log2N = -1;
     for (int k = 0; k < 62; ++k)
@@ -303,7 +367,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
         a.spacing_scale = ldexp(1.0, 57 - lg);
     }
     const size_t M = (size_t)o->n_islands, N = (size_t)o->N, T = (size_t)o->T;
-    const bool need_su = (o->scheme == SMC_MULTINOMIAL);
+    const bool need_su = (scheme == SMC_MULTINOMIAL);
     // carve one slab
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o0 = off; off = smc_align_up(off + bytes, 256); return o0; };
@@ -359,7 +423,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     f->two_level = !mv && !(o->moments && model->fk == SMC_FK_APF) && o->N <= ((int64_t)1 << 30) && a.ntiles >= 2 &&
                    !(a.log2N < 0 && (o->flags & SMC_PATH_POW2_ONLY)) &&
                    !(o->flags & (SMC_PATH_FLAT_CDF | SMC_PATH_FORCE_FUSED | SMC_PATH_FORCE_UNFUSED)) &&
-                   !(o->scheme == SMC_MULTINOMIAL && (o->flags & SMC_PATH_FLAT_MULTINOMIAL));
+                   !(scheme == SMC_MULTINOMIAL && (o->flags & SMC_PATH_FLAT_MULTINOMIAL));
     // every workgroup reduces the partials itself while the launch is resident and an island has
     // at most 1024 tiles (4 per thread); otherwise one workgroup per island does it first
     const bool apf2 = model->fk == SMC_FK_APF && o->N > F_TILE;      // APF on the two-level step: k_reduce2
@@ -369,8 +433,9 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
         return SMC_ERR_INVALID;
     }
     f->two_level_mid = f->two_level && (!f->fused || a.ntiles > 1024 || (o->flags & SMC_PATH_TWO_LEVEL_MID) ||
-                                        o->scheme == SMC_MULTINOMIAL || apf2);
-    const bool heavy_list = !mv && !f->strict && !(o->flags & SMC_PATH_NO_HEAVY);
+                                        scheme == SMC_MULTINOMIAL || apf2);
+    // (SQMC: k_ancestors2 counts in SORTED positions; a heavy parent's blocks would be filled with that index)
+    const bool heavy_list = !mv && !f->strict && !f->sqmc && !(o->flags & SMC_PATH_NO_HEAVY);
     // (history slots are written step by step: the lanes beyond N of a slot would read indices nobody
     //  initialised -- every access tests its index there as well)
     a.kform = f->two_level ? 1 : 0;
@@ -387,7 +452,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     // the fewest that keep the whole launch resident (<= 1024 workgroups: half of what the chip holds);
     // more islands than that: the three-pass form
     a.sp_tpw = a.sp_nwg = 0;
-    if (need_su && f->two_level && !f->strict && !(o->flags & SMC_PATH_SPACING_3PASS))
+    if (need_su && f->two_level && !f->strict && !f->sqmc && !(o->flags & SMC_PATH_SPACING_3PASS))
         for (int tpw = 1; tpw <= 8 && !a.sp_tpw; tpw *= 2) {
             const i64 nwg = (a.ntiles + tpw - 1) / tpw;
             int per_cu = 0;                        // workgroups of this instantiation a CU holds at once
@@ -410,6 +475,14 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     const size_t oSst = carve(a.sp_tpw ? M * a.sp_nwg * 8 : 8);
     const size_t oTmp = carve(N * dxm * 8);
     const size_t oStrict = carve(f->strict ? M * N * 8 : 8);
+    if (f->sqmc && !f->two_level) {
+        smc_set_error("SMC_FLAG_SQMC needs the two-level step");
+        delete f;
+        return SMC_ERR_INVALID;
+    }
+    const size_t oSqZ = carve(f->sqmc ? M * N * 8 : 8);
+    const size_t oSqPerm = carve(f->sqmc && M > 1 ? M * N * 8 : 8);
+    const size_t oSqWs = carve(f->sqmc ? smc_rs_ws_bytes((i64)N) : 8);
     a.nmb = (int)((o->N + F_MOM_CHUNK - 1) / F_MOM_CHUNK);
     const size_t oMom = carve(o->moments ? M * T * 2 * dxm * 8 : 8);
     const size_t oMpart = carve(o->moments ? M * a.nmb * dxm * 3 * 8 : 8);
@@ -478,6 +551,11 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     if (a.sp_tpw) F_CREATE_CHECK(hipMemsetAsync(a.sst, 0, M * a.sp_nwg * 8, ctx->stream));
     f->tmp = (double*)(base + oTmp);
     f->strict_ws = (double*)(base + oStrict);
+    if (f->sqmc) {
+        f->sq_z = (double*)(base + oSqZ);
+        f->sq_perm = (u64*)(base + oSqPerm);
+        f->sq_ws = base + oSqWs;
+    }
     f->ll_stage = nullptr;
     {
         auto it = ctx->pinned.find(M * 8);
@@ -604,7 +682,7 @@ int smc_filter_clone(smc_filter* src, smc_filter** out)
     rebase(a.cq); rebase(a.tq); rebase(a.cnt); rebase(a.spart); rebase(a.summ); rebase(a.params); rebase(a.y);
     rebase(a.mom); rebase(a.mpart); rebase(a.aux); rebase(a.info); rebase(a.hcnt); rebase(a.hlist); rebase(a.info2);
     rebase(a.su); rebase(a.E); rebase(a.sst); rebase(a.mvc); rebase(a.trace); rebase(a.pm2); rebase(a.ps2); rebase(a.pss2);
-    rebase(f->tmp); rebase(f->strict_ws);
+    rebase(f->tmp); rebase(f->strict_ws); rebase(f->sq_z); rebase(f->sq_perm); rebase(f->sq_ws);
     hipStream_t st = ctx->stream;
     hipError_t e = hipMemcpyAsync(slab, src->slab, src->slab_bytes, hipMemcpyDeviceToDevice, st);
     if (e == hipSuccess && src->th_buf) {
@@ -640,9 +718,24 @@ int smc_filter_reseed(smc_filter* f, uint64_t seed)
     return SMC_OK;
 }
 
+// SMC_FLAG_SQMC: which points the run uses -- the stand-alone operator's stream (smc_sobol with
+// scramble = safe = 1 under a context seeded with `point_seed`): point set counter0 at t = 0 (one
+// coordinate), counter0 + t at step t (two coordinates, sorted by the first).  Default: the filter's own
+// seed, counter0 = 1.
+int smc_filter_sqmc_points(smc_filter* f, uint64_t point_seed, uint64_t counter0)
+{
+    SMC_REQUIRE(f, "null filter");
+    SMC_REQUIRE(f->sqmc, "the filter was not created with SMC_FLAG_SQMC");
+    SMC_REQUIRE(f->t_host == 0, "the point stream must be chosen before the first step");
+    f->sq_seed = point_seed;
+    f->sq_ctr0 = counter0;
+    return SMC_OK;
+}
+
 int smc_filter_set_replay(smc_filter* f, const double* z, const double* u)
 {
     SMC_REQUIRE(f, "null filter");
+    SMC_REQUIRE(!f->sqmc, "SMC_FLAG_SQMC filters generate their points on the device");
     SMC_REQUIRE(f->t_host == 0, "replay tapes must be set before the first step");
     SMC_REQUIRE(z && u, "both tapes are required");
     f->a.zt = z;
@@ -1366,7 +1459,10 @@ int smc_filter_describe(smc_filter* f, char* out, size_t n)
     const bool mv = f->kind == SMC_MODEL_MVLINGAUSS;
     std::string s;
     if (small_filter_ok(f)) s = "k_filter_small";
-    else if (f->strict) {
+    else if (f->sqmc) {
+        s = "k_rs_sort+k_sq_permute+k_reduce2+k_ancestors2+k_sq_compose+k_propagate";
+        if (f->a.mom) s += "+k_f_moments_partials+k_f_moments_final";
+    } else if (f->strict) {
         s = std::string(f->two_level ? "k_reduce2+" : "") + "k_strict_W+k_strict_cdf+k_strict_search+k_propagate";
     } else {
         if (f->two_level_mid) s = "k_reduce2+k_ancestors2";

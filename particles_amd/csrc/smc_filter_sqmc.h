@@ -1,0 +1,107 @@
+// smc_filter_sqmc.h -- the SQMC step (particles/core.py:339-349, Gerber & Chopin's sequential quasi-Monte
+// Carlo) of a univariate fused filter, on the kernels of the two-level step:
+//
+//     u = sobol(N, 2);  tau = argsort(u[:, 0])                    -> closed form for N = 2^k (smc_qmc.h)
+//     h_order = hilbert_sort(X) = argsort(X)            (d = 1)   -> the radix sort (smc_sort.hip)
+//     A = h_order[inverse_cdf(u[tau, 0], W[h_order])]             -> k_sq_permute: the tile partials and integer
+//                                                                    CDFs of the weights IN SORTED ORDER and the
+//                                                                    sorted first coordinates as a tape of sorted
+//                                                                    uniforms; k_reduce2 + k_ancestors2<MID, MULTI>
+//                                                                    unchanged; k_sq_compose: A <- h_order[A]
+//     X = Gamma(t, X[A], u[tau, 1])  (ppf of the Normal kernel)   -> k_propagate unchanged, its standard normals
+//                                                                    z_n = ndtri(u[tau_n, 1]) read from a tape
+//                                                                    k_sq_permute wrote
+// SQMC always resamples (core.py:340): the filter's ESS threshold is +inf.  The points are the stand-alone
+// operator's (smc_sobol / smc_sobol_sorted with scramble = safe = 1): point set `ctr0 + t` of the stream keyed
+// by `pseed`, so that a run of SMC(qmc=True) on the operators and the fused run see the same points.
+#pragma once
+#include "smc_filter_kernels.h"
+#include "smc_qmc.h"
+
+// t = 0 (core.py:315-321 generate_particles: X_0 = Gamma0(sobol(N, 1))): the tape of step 0
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_sq_init(const FArgs av, double* zbuf, const u64 pseed, const u64 ctr0)
+{
+    const FArgs& a = av;
+    const int isl = (int)blockIdx.y;
+    const i64 n = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;
+    if (n >= a.N) return;
+    const u64 ctr = ctr0 + ((u64)(u32)(a.island_offset + isl) << 32);
+    const u32 sh0 = smc_sobol_shift(pseed, ctr, 0u);
+    u32 x0, x1;
+    smc_sobol2((u32)n ^ ((u32)n >> 1), sh0, 0u, x0, x1);
+    zbuf[(i64)isl * a.N + n] = smc_ndtri(smc_sobol_safe(x0));
+}
+
+// step t >= 1, one workgroup per tile of 1024 SORTED positions (ownership as in the tail-free k_propagate):
+// gathers the log-weights of step t-1 through the sort's permutation and leaves what k_propagate(t-1) left
+// for the unsorted order -- (K_b, S_b, SS_b), the tile's integer CDF, t_b -- for the sorted one; writes the
+// tapes of step t.
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_sq_permute(const FArgs av, const u64* perm, double* ubuf, double* zbuf, const u64 pseed, const u64 ctr0)
+{
+    const FArgs& a = av;
+    const int b = (int)blockIdx.x, isl = (int)blockIdx.y, tid = (int)threadIdx.x;
+    const i64 N = a.N;
+    const i64 t = (i64)smc_uniform(smc_ldg(a.info2 + (i64)isl * INFO_STRIDE));
+    if (t >= a.T || t == 0) return;
+    const FOwn own = f_own<true>(b, tid, N);
+    const u64* pi = perm + (i64)isl * N;
+    const double* lwo = f_lw(a, t - 1) + (i64)isl * N;
+    u64 p4[4];
+    smc_ld2g(pi + own.na, p4[0], p4[1]);
+    smc_ld2g(pi + own.nb, p4[2], p4[3]);
+    double lw[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) lw[k] = smc_ldg(lwo + p4[k]);
+    // the step's points, while the gather is on its way
+    const u64 ctr = ctr0 + (u64)t + ((u64)(u32)(a.island_offset + isl) << 32);
+    const u32 sh0 = smc_sobol_shift(pseed, ctr, 0u), sh1 = smc_sobol_shift(pseed, ctr, 1u);
+    double u0[4], z[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const u32 row = (u32)f_own_idx(own, k);
+        u32 x0, x1;
+        smc_sobol2(smc_sobol_sorted_gray(row, sh0, a.log2N), sh0, sh1, x0, x1);
+        u0[k] = smc_sobol_safe(x0);
+        z[k] = smc_ndtri(smc_sobol_safe(x1));
+    }
+    double* ub = ubuf + (i64)isl * N;
+    double* zb = zbuf + (i64)isl * N;
+    smc_st2g(ub + own.na, u0[0], u0[1]);
+    smc_st2g(ub + own.nb, u0[2], u0[3]);
+    smc_st2g(zb + own.na, z[0], z[1]);
+    smc_st2g(zb + own.nb, z[2], z[3]);
+    u64 cx[4];
+    const F2Tile r = f2_tile_weights(lw, cx);
+    u64* cq = a.cq + (i64)isl * a.ncq;
+    smc_st2g(cq + own.na, cx[0], cx[1]);
+    smc_st2g(cq + own.nb, cx[2], cx[3]);
+    if (tid == 0) {
+        const i64 o = (i64)isl * a.nparts;
+        a.pm[o + b] = r.K;
+        a.ps[o + b] = r.S;
+        a.pss[o + b] = r.SS;
+        a.tq[o + b] = r.tb;
+    }
+}
+
+// A_t <- h_order[A_t]: k_ancestors2 counted in sorted positions (core.py:344)
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_sq_compose(const FArgs av, const u64* perm)
+{
+    const FArgs& a = av;
+    const int isl = (int)blockIdx.y;
+    const double* info = a.info + (i64)isl * INFO_STRIDE;
+    const i64 t = (i64)smc_uniform(smc_ldg(info));
+    if (t >= a.T || t == 0 || smc_uniform(smc_ldg(info + 1)) == 0.0) return;
+    const i64 n = ((i64)blockIdx.x * SMC_BLOCK + threadIdx.x) * 4;
+    if (n >= a.N) return;
+    u32* A = f_A(a, t) + (i64)isl * a.N;
+    const u64* pi = perm + (i64)isl * a.N;
+    u32 a4[4];
+    smc_ld4g(A + n, a4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a4[k] = (u32)smc_ldg(pi + a4[k]);
+    smc_st4g(A + n, a4);
+}

@@ -55,4 +55,10 @@ void smc_set_error(const char* fmt, ...);
 // device scratch of at least `bytes` (256-byte aligned); contents undefined
 int smc_scratch(smc_ctx* ctx, size_t bytes, void** out);
 
+// radix sort of (64-bit key, 64-bit payload) pairs in a caller-owned workspace (smc_sort.hip); kind 0: the
+// keys are fp64 bit patterns, 1: int64.  vals null: payload = index (argsort).  The results stay in `ws`.
+size_t smc_rs_ws_bytes(long long N);
+int smc_rs_sort_ws(smc_ctx* ctx, const void* keys, const void* vals, long long N, int kind, void* ws,
+                   unsigned long long** sorted_keys, unsigned long long** sorted_vals);
+
 static inline size_t smc_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

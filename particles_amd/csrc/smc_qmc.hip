@@ -4,74 +4,7 @@
 // distributions.py:276-277).  The argsort of hilbert_sort (d = 1) lives in smc_sort.hip.
 #include "smc_internal.h"
 #include "smc_device.h"
-
-// ---------------------------------------------------------------------------
-// ndtri: Cephes' inverse of the standard normal CDF -- the routine behind
-// scipy.special.ndtri / scipy.stats.norm.ppf -- restated: central region by a
-// rational function of (y - 1/2)^2, tails by rational functions of
-// 1/sqrt(-2 log y).  Only IEEE + - * / in the central region (bit-identical to
-// scipy there); the tails add the device's log / sqrt (<= 1 ulp each).
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ double ndtri_polevl(double x, const double* c, int n)
-{
-    double a = c[0];
-    for (int i = 1; i <= n; ++i) a = a * x + c[i];
-    return a;
-}
-__device__ __forceinline__ double ndtri_p1evl(double x, const double* c, int n)
-{
-    double a = x + c[0];
-    for (int i = 1; i < n; ++i) a = a * x + c[i];
-    return a;
-}
-__device__ double smc_ndtri(double y0)
-{
-    const double P0[5] = {-5.99633501014107895267E1, 9.80010754185999661536E1,
-                          -5.66762857469070293439E1, 1.39312609387279679503E1,
-                          -1.23916583867381258016E0};
-    const double Q0[8] = {1.95448858338141759834E0, 4.67627912898881538453E0,
-                          8.63602421390890590575E1, -2.25462687854119370527E2,
-                          2.00260212380060660359E2, -8.20372256168333339912E1,
-                          1.59056225126211695515E1, -1.18331621121330003142E0};
-    const double P1[9] = {4.05544892305962419923E0, 3.15251094599893866154E1,
-                          5.71628192246421288162E1, 4.40805073893200834700E1,
-                          1.46849561928858024014E1, 2.18663306850790267539E0,
-                          -1.40256079171354495875E-1, -3.50424626827848203418E-2,
-                          -8.57456785154685413611E-4};
-    const double Q1[8] = {1.57799883256466749731E1, 4.53907635128879210584E1,
-                          4.13172038254672030440E1, 1.50425385692907503408E1,
-                          2.50464946208309415979E0, -1.42182922854787788574E-1,
-                          -3.80806407691578277194E-2, -9.33259480895457427372E-4};
-    const double P2[9] = {3.23774891776946035970E0, 6.91522889068984211695E0,
-                          3.93881025292474443415E0, 1.33303460815807542389E0,
-                          2.01485389549179081538E-1, 1.23716634817820021358E-2,
-                          3.01581553508235416007E-4, 2.65806974686737550832E-6,
-                          6.23974539184983293730E-9};
-    const double Q2[8] = {6.02427039364742014255E0, 3.67983563856160859403E0,
-                          1.37702099489081330271E0, 2.16236993594496635890E-1,
-                          1.34204006088543189037E-2, 3.28014464682127739104E-4,
-                          2.89247864745380683936E-6, 6.79019408009981274425E-9};
-    const double s2pi = 2.50662827463100050242E0, em2 = 0.13533528323661269189;   // sqrt(2 pi), exp(-2)
-    if (y0 == 0.0) return -INFINITY;
-    if (y0 == 1.0) return INFINITY;
-    if (!(y0 > 0.0 && y0 < 1.0)) return NAN;
-    bool neg = true;
-    double y = y0;
-    if (y > 1.0 - em2) { y = 1.0 - y; neg = false; }
-    if (y > em2) {
-        y = y - 0.5;
-        const double y2 = y * y;
-        const double x = y + y * (y2 * ndtri_polevl(y2, P0, 4) / ndtri_p1evl(y2, Q0, 8));
-        return x * s2pi;
-    }
-    double x = sqrt(-2.0 * log(y));
-    const double x0 = x - log(x) / x;
-    const double z = 1.0 / x;
-    const double x1 = (x < 8.0) ? z * ndtri_polevl(z, P1, 8) / ndtri_p1evl(z, Q1, 8)
-                                : z * ndtri_polevl(z, P2, 8) / ndtri_p1evl(z, Q2, 8);
-    x = x0 - x1;
-    return neg ? -x : x;
-}
+#include "smc_qmc.h"
 
 __global__ void __launch_bounds__(SMC_BLOCK)
 k_normal_ppf(const double* u, i64 us, const double* loc, i64 ls, const double* scale, i64 ss, i64 N,
@@ -99,7 +32,6 @@ extern "C" int smc_normal_ppf(smc_ctx* ctx, const double* u, int64_t u_stride, c
 // of the direction numbers v_k over the set bits k of gray(n) = n ^ (n >> 1): every point is
 // independent of the others, one thread per (point, coordinate).
 // ---------------------------------------------------------------------------
-#define SOBOL_BITS 30
 #define SOBOL_MAXD 10
 
 struct SobolTable {
@@ -166,10 +98,7 @@ static int sobol_launch(smc_ctx* ctx, int64_t N, int32_t d, int32_t scramble, in
         for (int k = 0; k < SOBOL_BITS; ++k) tb.v[dim - 1][k] = m[k] << (SOBOL_BITS - 1 - k);
         u32 sh = 0u;
         if (scramble) {                       // digital shift: one Philox word per coordinate
-            u64 x0, x1;
-            smc_philox((u32)(dim - 1), (u32)counter, (u32)(counter >> 32), SMC_STREAM_RESAMPLE,
-                       (u64)ctx->seed, x0, x1);
-            sh = (u32)(x0 >> (64 - SOBOL_BITS));
+            sh = smc_sobol_shift((u64)ctx->seed, counter, (u32)(dim - 1));
         }
         tb.shift[dim - 1] = sh;
     }

@@ -308,6 +308,58 @@ k_rs_small(const u64* keys, const u64* vals, i64 N, int kind, u64* okeys, u64* o
     }
 }
 
+// Workspace form (smc_internal.h): the caller owns `ws` (smc_rs_ws_bytes(N) bytes, reusable from call to
+// call in stream order); the sorted payloads (argsort: the permutation, as 64-bit words) and the sorted
+// key IMAGES (rs_encode) are left inside it -- no copy-out.  The fused SQMC step of the filter sorts
+// through this entry once per time step.
+size_t smc_rs_ws_bytes(i64 N)
+{
+    const size_t ntiles = (size_t)((N + RS_TILE - 1) / RS_TILE);
+    return 4 * (size_t)N * 8 + ntiles * 256 * 4 + 257 * 4 + 256;
+}
+int smc_rs_sort_ws(smc_ctx* ctx, const void* keys, const void* vals, i64 N, int kind, void* ws,
+                   u64** sorted_keys, u64** sorted_vals)
+{
+    hipStream_t st = ctx->stream;
+    const size_t nb = (size_t)N * 8;
+    u64* k0 = (u64*)ws;
+    u64* v0 = (u64*)((char*)ws + nb);
+    u64* k1 = (u64*)((char*)ws + 2 * nb);
+    u64* v1 = (u64*)((char*)ws + 3 * nb);
+    int rc = SMC_OK;
+    if (N <= RS_TILE) {
+        // (k_rs_small hands out DECODED keys: callers of this branch that want images re-encode)
+        SMC_LAUNCH(k_rs_small, dim3(1), dim3(SMC_BLOCK), st, (const u64*)keys, (const u64*)vals, N, kind, k0, v0);
+        if (hipGetLastError() != hipSuccess) rc = SMC_ERR_HIP;
+        if (sorted_keys) *sorted_keys = k0;
+        if (sorted_vals) *sorted_vals = v0;
+    } else {
+        const int ntiles = (int)((N + RS_TILE - 1) / RS_TILE);
+        unsigned* hist = (unsigned*)((char*)ws + 4 * nb);
+        unsigned* total = hist + (size_t)ntiles * 256;            // 256 digit totals + the scan's ticket
+        const dim3 ge((unsigned)((N + SMC_BLOCK - 1) / SMC_BLOCK));
+        (void)hipMemsetAsync(total, 0, 257 * 4, st);
+        SMC_LAUNCH(k_rs_encode, ge, dim3(SMC_BLOCK), st, (const u64*)keys, (const u64*)vals, N, kind, k0, v0);
+        for (int pass = 0; pass < 8; ++pass) {
+            const int shift = 8 * pass;
+            SMC_LAUNCH(k_rs_hist, dim3(ntiles), dim3(SMC_BLOCK), st, (const u64*)k0, N, shift, hist, total, ntiles);
+            if (ntiles <= 64) SMC_LAUNCH(k_rs_scan_few, dim3(1), dim3(SMC_BLOCK), st, hist, total, ntiles);
+            else SMC_LAUNCH(k_rs_scan, dim3(256), dim3(SMC_BLOCK), st, hist, total, total + 256, ntiles);
+            SMC_LAUNCH(k_rs_scatter, dim3(ntiles), dim3(SMC_BLOCK), st, (const u64*)k0, (const u64*)v0, N, shift,
+                       (const unsigned*)hist, ntiles, k1, v1);
+            u64* t = k0; k0 = k1; k1 = t;
+            t = v0; v0 = v1; v1 = t;
+        }
+        if (hipGetLastError() != hipSuccess) rc = SMC_ERR_HIP;
+        if (sorted_keys) *sorted_keys = k0;                       // (8 passes: back in the first pair)
+        if (sorted_vals) *sorted_vals = v0;
+    }
+#ifdef SMC_EMULATE
+    if (hipStreamSynchronize(st) != hipSuccess) rc = SMC_ERR_HIP;
+#endif
+    return rc;
+}
+
 // Stable sort of (key, payload) pairs by key: keys (N) 64-bit patterns of `kind`, vals (N) 64-bit
 // payloads or null (payload = index: argsort).  out_keys / out_vals (N each, either may be null).
 // Scratch from the context's pool (recycled in stream order).  N < 2^32.
@@ -324,32 +376,13 @@ static int rs_sort_pairs(smc_ctx* ctx, const void* keys, const void* vals, i64 N
 #endif
         return rc1;
     }
-    const int ntiles = (int)((N + RS_TILE - 1) / RS_TILE);
-    const size_t nb = (size_t)N * 8;
     void* buf = nullptr;
-    if (smc_malloc(ctx, 4 * nb + (size_t)ntiles * 256 * 4 + 257 * 4, &buf) != SMC_OK) return SMC_ERR_NOMEM;
-    u64* k0 = (u64*)buf;
-    u64* v0 = (u64*)((char*)buf + nb);
-    u64* k1 = (u64*)((char*)buf + 2 * nb);
-    u64* v1 = (u64*)((char*)buf + 3 * nb);
-    unsigned* hist = (unsigned*)((char*)buf + 4 * nb);
-    unsigned* total = hist + (size_t)ntiles * 256;            // 256 digit totals + the scan's ticket
+    if (smc_malloc(ctx, smc_rs_ws_bytes(N), &buf) != SMC_OK) return SMC_ERR_NOMEM;
+    u64 *k0 = nullptr, *v0 = nullptr;
+    int rc = smc_rs_sort_ws(ctx, keys, vals, N, kind, buf, &k0, &v0);
     const dim3 ge((unsigned)((N + SMC_BLOCK - 1) / SMC_BLOCK));
-    (void)hipMemsetAsync(total, 0, 257 * 4, st);
-    SMC_LAUNCH(k_rs_encode, ge, dim3(SMC_BLOCK), st, (const u64*)keys, (const u64*)vals, N, kind, k0, v0);
-    for (int pass = 0; pass < 8; ++pass) {
-        const int shift = 8 * pass;
-        SMC_LAUNCH(k_rs_hist, dim3(ntiles), dim3(SMC_BLOCK), st, (const u64*)k0, N, shift, hist, total, ntiles);
-        if (ntiles <= 64) SMC_LAUNCH(k_rs_scan_few, dim3(1), dim3(SMC_BLOCK), st, hist, total, ntiles);
-        else SMC_LAUNCH(k_rs_scan, dim3(256), dim3(SMC_BLOCK), st, hist, total, total + 256, ntiles);
-        SMC_LAUNCH(k_rs_scatter, dim3(ntiles), dim3(SMC_BLOCK), st, (const u64*)k0, (const u64*)v0, N, shift,
-                   (const unsigned*)hist, ntiles, k1, v1);
-        u64* t = k0; k0 = k1; k1 = t;
-        t = v0; v0 = v1; v1 = t;
-    }
-    int rc = SMC_OK;
     if (out_keys) SMC_LAUNCH(k_rs_decode, ge, dim3(SMC_BLOCK), st, (const u64*)k0, N, kind, (u64*)out_keys);
-    if (out_vals && hipMemcpyAsync(out_vals, v0, nb, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = SMC_ERR_HIP;
+    if (out_vals && hipMemcpyAsync(out_vals, v0, (size_t)N * 8, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = SMC_ERR_HIP;
     if (hipGetLastError() != hipSuccess) rc = SMC_ERR_HIP;
 #ifdef SMC_EMULATE
     if (hipStreamSynchronize(st) != hipSuccess) rc = SMC_ERR_HIP;

@@ -2081,13 +2081,18 @@ def check_sqmc(golden, monkeypatch, philox_N=4096, philox_runs=4, philox_T=40, s
         assert rqmc.sobol_sorted(1000, 2) is None                 # not a power of two: the generic route
         # ... and the SQMC run is the same run with or without it (X, A, logLt bit for bit)
         runs = []
-        for closed_form in (True, False):
-            if not closed_form:
-                monkeypatch.setattr(rqmc, "sobol_sorted", lambda N, d: None)
-            pa.seed(77)
-            pf = pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y[:8]), N=ab_N, qmc=True)
-            pf.run()
-            runs.append((np.asarray(pf.X), np.asarray(pf.A), pf.logLt))
+        _lib.FUSED_SQMC[0] = False                   # (the operator path: the fused step has its own check)
+        try:
+            for closed_form in (True, False):
+                if not closed_form:
+                    monkeypatch.setattr(rqmc, "sobol_sorted", lambda N, d: None)
+                pa.seed(77)
+                pf = pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y[:8]), N=ab_N, qmc=True)
+                assert not pf._fused
+                pf.run()
+                runs.append((np.asarray(pf.X), np.asarray(pf.A), pf.logLt))
+        finally:
+            _lib.FUSED_SQMC[0] = True
         monkeypatch.undo()
         assert all(np.array_equal(a, b) for a, b in zip(runs[0], runs[1]))
         lls = []
@@ -2098,6 +2103,152 @@ def check_sqmc(golden, monkeypatch, philox_N=4096, philox_runs=4, philox_T=40, s
             lls.append(pf.logLt)
         assert np.max(np.abs(np.array(lls) - ll)) < 0.25
     finally:
+        rs.set_rng("numpy")
+
+
+def sobol_sorted_points_np(seed, counter, N, d):
+    """The d-dimensional scrambled Sobol' point set `counter` of the device stream, sorted by its first
+    coordinate -- restated with scipy's engine for the sequence (Joe & Kuo's direction numbers, 30 bits,
+    Gray-code order), the digital shift from the Philox restatement (word 0 of call (coordinate, counter
+    lo, counter hi, stream 1), top 30 bits), rqmc.py:9-13's safe_generate, and a stable argsort: no
+    closed form.  Returns (points in Gray order, the same sorted by the first coordinate)."""
+    import warnings
+    from scipy.stats import qmc
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        base = qmc.Sobol(d, scramble=False).random(N)
+    xi = np.rint(base * 2.0 ** 30).astype(np.uint64)
+    assert np.array_equal(xi / 2.0 ** 30, base)
+    for c in range(d):
+        x01, _ = orc.philox_u64_pair(seed, np.array([c]), int(counter) & 0xFFFFFFFF, int(counter) >> 32, orc.STREAM_RESAMPLE)
+        xi[:, c] ^= np.uint64(int(x01[0]) >> 34)
+    u = 0.5 + (1.0 - 1e-10) * (xi.astype(np.float64) / 2.0 ** 30 - 0.5)
+    return u, u[np.argsort(u[:, 0], kind="stable")]
+
+
+def audit_sqmc_history(pf, mk_orc, fk, y, point_seed, ctr0, island=0, tol=1e-12):
+    """Teacher-forced audit of a fused SQMC run with store_history=True (core.py:315-321, 339-349): from
+    the device's own X_{t-1}, lw_{t-1} every step must be h_order = argsort(X_{t-1}); A_t =
+    h_order[inverse_cdf(u[tau, 0], W[h_order])] -- bit for bit on the two-level contract (oracle.c) applied
+    to the weights in sorted order, and against the reference's sequential fp64 CDF with every mismatch a
+    certified near-tie; X_t = Gamma(t, X_{t-1}[A_t], u[tau, 1]) with scipy's ndtri; weights, ESS,
+    evidence.  Returns the near-tie count."""
+    from scipy import special
+    N, T = pf.N, pf._n
+    model = mk_orc()
+    ctx = orc.StepCtx(model, fk, y[0])
+    summ = pf._summ()[island]
+    near_ties = 0
+    logLt = 0.0
+    X_prev = lw_prev = None
+    for t in range(T):
+        X = pf._history(_lib.FIELD_X, t, island)
+        lw = pf._history(_lib.FIELD_LW, t, island)
+        ctr = ctr0 + t + (island << 32)
+        if t == 0:
+            u, _ = sobol_sorted_points_np(point_seed, ctr, N, 1)
+            zt, Xp = special.ndtri(u[:, 0]), None
+        else:
+            assert bool(summ[t, 4])                                    # always resamples (core.py:340)
+            _, us = sobol_sorted_points_np(point_seed, ctr, N, 2)
+            h = np.argsort(X_prev, kind="stable")
+            lws = lw_prev[h]
+            A = pf._history(_lib.FIELD_A, t, island)
+            A_c, _ = orc.inverse_cdf_2level_c("multinomial", us[:, 0], lws)
+            assert np.array_equal(A, h[A_c]), (t, int(np.sum(A != h[A_c])))
+            W_ref = orc.exp_and_normalise(lws)
+            try:
+                A_ref = orc.inverse_cdf(us[:, 0], W_ref)
+            except IndexError:
+                A_ref = None
+            if A_ref is not None and not np.array_equal(A_c, A_ref):
+                n, ok = orc.audit_near_ties(us[:, 0], W_ref, A_ref, A_c)
+                assert ok, (t, n)
+                near_ties += n
+            ess_prev = orc.two_level_reduce(*orc.tile_partials(lws))[0]["ESS"]     # (partials of the sorted order)
+            assert ess_prev == summ[t - 1, 0], (t, ess_prev, summ[t - 1, 0])
+            Xp = X_prev[A]
+            zt = special.ndtri(us[:, 1])
+        Xo, inc = orc.propagate(model, fk, t, np.asarray(y[t]), Xp, zt, ctx)
+        lwo = np.where(np.isnan(inc), -np.inf, inc)
+        assert np.allclose(X, Xo, rtol=tol, atol=tol), (t, "X", float(np.max(np.abs(X - Xo))))
+        assert np.allclose(lw, lwo, rtol=100 * tol, atol=100 * tol), (t, "lw")
+        w = orc.Weights(lw=lw.copy())
+        assert abs(summ[t, 0] / w.ESS - 1) < 1e-10 and abs(summ[t, 2] - w.log_mean) < 1e-10 * max(1.0, abs(w.log_mean)), t
+        logLt += summ[t, 2]
+        assert abs(summ[t, 3] - logLt) < 1e-10 * max(1.0, abs(logLt)), (t, "logLt")
+        X_prev, lw_prev = X, lw
+    log_near_ties("sqmc N=%d T=%d" % (N, T), near_ties, N * max(T - 1, 0))
+    return near_ties
+
+
+def check_sqmc_fused(sizes=(2048, 4096), T=6, audit_sizes=(4096,), islands_N=2048):
+    """SMC(qmc=True) as a fused loop (SMC_FLAG_SQMC; smc_filter_sqmc.h): (1) the SAME run as the
+    operator path on the same points -- X, lw, A of every step bit for bit where the two exact CDFs
+    (two-level vs flat Q62) agree, i.e. everywhere but at certified near-ties; (2) the teacher-forced
+    audit against the oracle and the reference's formula; (3) islands = independent runs with their own
+    point sets; (4) what does not fuse runs on the operators."""
+    cases = [("toy", lambda: kalman.ToySSM(0.2), lambda: orc.ToySSM(0.2), ssm.Bootstrap, "bootstrap"),
+             ("sv", lambda: ssm.StochVol(), lambda: orc.StochVol(), ssm.Bootstrap, "bootstrap"),
+             ("lg_guided", lambda: kalman.LinearGauss(rho=0.9, sigmaX=1.0, sigmaY=0.3),
+              lambda: orc.LinGauss(rho=0.9, sigmaX=1.0, sigmaY=0.3), ssm.GuidedPF, "guided")]
+    rng = np.random.RandomState(12)
+    y = [np.array([v]) for v in 0.5 * np.cumsum(rng.standard_normal(T))]
+    rs.set_rng("philox")
+    try:
+        for name, mk, mk_o, cls, fkname in cases:
+            for N in sizes:
+                runs = []
+                for fused in (True, False):
+                    _lib.FUSED_SQMC[0] = fused
+                    pa.seed(31)
+                    pf = pa.SMC(fk=cls(ssm=mk(), data=y), N=N, qmc=True, collect="off")
+                    assert pf._fused == fused
+                    if fused:
+                        assert "k_sq_permute" in describe(pf) and "k_rs_sort" in describe(pf)
+                    steps = []
+                    for t in range(T):
+                        next(pf)
+                        steps.append((np.asarray(pf.X).copy(), None if t == 0 else np.asarray(pf.A).copy(),
+                                      np.asarray(pf.wgts.lw).copy(), float(pf.logLt)))
+                    runs.append(steps)
+                _lib.FUSED_SQMC[0] = True
+                for t in range(T):
+                    (Xa, Aa, la, La), (Xb, Ab, lb, Lb) = runs[0][t], runs[1][t]
+                    if Aa is not None and not np.array_equal(Aa, Ab):
+                        break                 # a near-tie between the two exact CDFs: the audit below decides
+                    assert np.array_equal(Xa, Xb) and np.array_equal(la, lb), (name, N, t)
+                    assert abs(La - Lb) < 1e-12 * max(1.0, abs(La)), (name, N, t)
+                else:
+                    t = T
+                assert t >= T - 1 or N > 1 << 16, (name, N, t)
+            for N in audit_sizes:
+                pa.seed(47)
+                c0 = _lib._counter + 1
+                pf = pa.SMC(fk=cls(ssm=mk(), data=y), N=N, qmc=True, collect="off", store_history=True)
+                assert pf._fused
+                pf.run()
+                audit_sqmc_history(pf, mk_o, fkname, y, 47, c0)
+                # the production run (no history) ends in the same state
+                pa.seed(47)
+                pq = pa.SMC(fk=cls(ssm=mk(), data=y), N=N, qmc=True, collect="off")
+                pq.run()
+                assert np.array_equal(np.asarray(pq.X), np.asarray(pf.X)) and pq.logLt == pf.logLt
+        # islands: each an SQMC run of its own (point sets keyed by the island id)
+        pa.seed(53)
+        c0 = _lib._counter + 1
+        pf = pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y), N=islands_N, qmc=True, collect="off",
+                    store_history=True, n_islands=3)
+        pf.run()
+        for isl in (0, 2):
+            audit_sqmc_history(pf, lambda: orc.ToySSM(0.2), "bootstrap", y, 53, c0, island=isl)
+        ll = pf.logLt_islands() if hasattr(pf, "logLt_islands") else None
+        # (4) outside the fused family: the operator path
+        pa.seed(3)
+        assert not pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y), N=1000, qmc=True)._fused       # N != 2^k
+        assert not pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y), N=1024, qmc=True)._fused       # one tile
+    finally:
+        _lib.FUSED_SQMC[0] = True
         rs.set_rng("numpy")
 
 

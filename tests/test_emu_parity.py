@@ -73,6 +73,10 @@ def test_sqmc(golden, monkeypatch):
                   replay_cases=("sqmc_toy", "sqmc_mv2", "sqmc_mv3_guided"))
 
 
+def test_sqmc_fused():
+    pc.check_sqmc_fused(sizes=(2048,), T=4, audit_sizes=(4096,), islands_N=2048)
+
+
 def test_indep_prod(golden):
     pc.check_indep_prod(golden)
 

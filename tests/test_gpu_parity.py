@@ -79,6 +79,29 @@ def test_sqmc(golden, monkeypatch):
     pc.check_sqmc(golden, monkeypatch)
 
 
+def test_sqmc_fused():
+    pc.check_sqmc_fused(sizes=(2048, 1 << 16), T=6, audit_sizes=(1 << 14, 1 << 20), islands_N=1 << 13)
+
+
+def test_sqmc_fused_large_grid():
+    """N = 2^22: 4096 tiles (k_reduce2's chunked reduction), 2048 sort tiles."""
+    import numpy as np
+    from particles_amd import _lib, kalman, resampling as rs, state_space_models as ssm
+    import particles_amd as pa
+    from oracle import smc_oracle as orc
+    y = [np.array([v]) for v in (0.3, -0.2, 0.5)]
+    rs.set_rng("philox")
+    try:
+        pa.seed(61)
+        c0 = _lib._counter + 1
+        pf = pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y), N=1 << 22, qmc=True, collect="off", store_history=True)
+        assert pf._fused
+        pf.run()
+        pc.audit_sqmc_history(pf, lambda: orc.ToySSM(0.2), "bootstrap", y, 61, c0)
+    finally:
+        rs.set_rng("numpy")
+
+
 def test_indep_prod(golden):
     pc.check_indep_prod(golden)
 

@@ -48,6 +48,12 @@ abrng)
   for f in $O/ab_*.json; do line $f; done ;;
 prof)
   EXTRA="--no-cpu-baseline --no-other-workloads" bash tools/gpu_profile.sh ${TAG}_c2 400 > $O/prof_c2.txt 2>&1; tail -40 $O/prof_c2.txt ;;
+prof_sqmc)
+  P=$O/prof_sqmc; mkdir -p $P
+  (cd /tmp && export TMPDIR=/tmp && timeout 200 rocprofv3 --kernel-trace --stats -d $P/trace -o trace -- python $R/tools/sqmc_perf.py 20 30 > $P/trace.log 2>&1)
+  python tools/summarise_prof.py $P > $O/sqmc_summary.txt 2>&1; rm -rf $P/trace; find $P -name "*.db" -delete 2>/dev/null
+  tail -5 $P/trace.log; head -40 $O/sqmc_summary.txt
+  timeout 300 python tools/sqmc_perf.py > $O/sqmc_perf.txt 2>&1; cat $O/sqmc_perf.txt ;;
 prof_c3m)
   EXTRA="--workload c3 --scheme multinomial" bash tools/gpu_profile.sh ${TAG}_c3m 100 > $O/prof_c3m.txt 2>&1; tail -40 $O/prof_c3m.txt ;;
 c3m)

@@ -40,6 +40,9 @@ def run(model, N, T, label):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:                       # python tools/sqmc_perf.py 20 [T]: one size, for profiling
+        run(kalman.ToySSM(0.2), 1 << int(sys.argv[1]), int(sys.argv[2]) if len(sys.argv) > 2 else 30, "ToySSM d=1")
+        sys.exit(0)
     for k in (12, 16, 20):
         run(kalman.ToySSM(0.2), 1 << k, 30, "ToySSM d=1")
     for k in (12, 16, 18):
