@@ -6,9 +6,9 @@
 // The sort is a hand-written stable LSD radix sort for gfx950 (wave64), 8 bits per pass over
 // order-preserving 64-bit images of the keys (fp64: sign flip / complement; int64: sign flip),
 // (key, 64-bit payload) pairs, three kernels per pass:
-//   k_rs_hist     per tile of 2048 keys: digit counts through LDS atomics -> hist[256][tiles] and
-//                 the 256 digit totals of the whole input
-//   k_rs_scan     one workgroup per digit: (keys with a smaller digit) + prefix sum of its row
+//   k_rs_hist     per tile of 2048 keys: digit counts through LDS atomics -> hist[256][tiles]
+//   k_rs_scan     one workgroup per digit: prefix sum of its row (keys of this digit in earlier tiles)
+//                 and the row's total; the scatter adds the totals of the smaller digits
 //                 -> the first output slot of every (digit, tile)
 //   k_rs_scatter  per tile: a wave takes 512 consecutive keys in 8 chunks of 64; the rank of a key
 //                 among the EARLIER keys of its digit is (keys of that digit in the wave's
@@ -17,7 +17,8 @@
 //                 network, no atomics, stable by construction; the tile is laid out in sorted
 //                 order in LDS (32 KB) and written out slot by slot, so that consecutive lanes
 //                 write the consecutive 8-byte slots of a digit's run.
-// HBM traffic per pass: read keys twice, read payload once, write both: 40 B per element.
+// HBM traffic per pass: read keys twice, read payload once, write both: 40 B per element (the first pass
+// reads the caller's keys and generates the index payload; an argsort's last pass writes no keys).
 // The running sum of wquantiles is a three-kernel scan (tile sums, scan of the sums, apply).
 // Everything also runs under the fiber emulator (tests/emu), so the CPU suite exercises it.
 #include "smc_internal.h"
@@ -49,15 +50,6 @@ __host__ __device__ __forceinline__ u64 rs_decode(u64 e, int kind)
     return (e >> 63) ? (e & 0x7fffffffffffffffull) : ~e;
 }
 
-// keys -> sortable images; payload = the element's index (argsort) unless `vals` is given
-__global__ void __launch_bounds__(SMC_BLOCK)
-k_rs_encode(const u64* keys, const u64* vals, i64 N, int kind, u64* ek, u64* ev)
-{
-    const i64 i = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;
-    if (i >= N) return;
-    ek[i] = rs_encode(keys[i], kind);
-    ev[i] = vals ? vals[i] : (u64)i;
-}
 __global__ void __launch_bounds__(SMC_BLOCK)
 k_rs_decode(const u64* ek, i64 N, int kind, u64* keys)
 {
@@ -66,9 +58,14 @@ k_rs_decode(const u64* ek, i64 N, int kind, u64* keys)
 }
 
 // hist[digit][tile] (digit-major: the scan below is then a plain prefix sum of one flat array per
-// digit row) and the digit totals of the whole input (256 global counters, zeroed per pass)
+// digit row).  RAW (the first pass): the caller's keys, mapped to their sortable images on the fly -- no
+// encode pass, no copy of the input.
+// (Rounds 1-2 also accumulated the 256 digit totals of the whole input here with global atomics: 512
+//  workgroups x 256 atomics on one kilobyte cost 9 of the kernel's 14 us at N = 2^20; the scan's
+//  workgroups now leave their row totals and the scatter adds up the smaller digits' itself.)
+template <bool RAW>
 __global__ void __launch_bounds__(SMC_BLOCK)
-k_rs_hist(const u64* keys, i64 N, int shift, unsigned* hist, unsigned* total, int ntiles)
+k_rs_hist(const u64* keys, i64 N, int shift, int kind, unsigned* hist, int ntiles)
 {
     __shared__ unsigned h[256];
     const int tid = (int)threadIdx.x;
@@ -77,11 +74,18 @@ k_rs_hist(const u64* keys, i64 N, int shift, unsigned* hist, unsigned* total, in
     const i64 base = (i64)blockIdx.x * RS_TILE;
     const int lane = smc_lane();
     const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    u64 kk[RS_TILE / SMC_BLOCK];
+#pragma unroll
+    for (int c = 0; c < RS_TILE / SMC_BLOCK; ++c) {
+        const i64 i = base + (i64)c * SMC_BLOCK + tid;
+        kk[c] = (i < N) ? keys[i] : 0ull;
+    }
 #pragma unroll
     for (int c = 0; c < RS_TILE / SMC_BLOCK; ++c) {
         const i64 i = base + (i64)c * SMC_BLOCK + tid;
         const bool valid = i < N;
-        const unsigned dg = valid ? (unsigned)(keys[i] >> shift) & 255u : 0u;
+        const u64 e = RAW ? rs_encode(kk[c], kind) : kk[c];
+        const unsigned dg = valid ? (unsigned)(e >> shift) & 255u : 0u;
         // one LDS atomic per distinct digit of the wave (the exponent bytes of fp64 keys take a
         // handful of values: per-key atomics would serialise on them)
         u64 mask = smc_ballot(valid);
@@ -94,22 +98,17 @@ k_rs_hist(const u64* keys, i64 N, int shift, unsigned* hist, unsigned* total, in
         if (valid && (mask & lt) == 0ull) atomicAdd(&h[dg], (unsigned)__popcll(mask));
     }
     __syncthreads();
-    const unsigned c = h[tid];
-    hist[(i64)tid * ntiles + blockIdx.x] = c;
-    if (c) atomicAdd(&total[tid], c);
+    hist[(i64)tid * ntiles + blockIdx.x] = h[tid];
 }
 
-// one workgroup per digit: first output slot of every (digit, tile) = (keys with a smaller digit)
-// + (keys with this digit in earlier tiles); in place.  The totals are consumed here and the
-// LAST workgroup leaves them zeroed for the next pass (ticket).
+// one workgroup per digit: the exclusive prefix sum of its row in place (keys with this digit in earlier
+// tiles) and the row's total; the scatter adds the totals of the smaller digits
 __global__ void __launch_bounds__(SMC_BLOCK)
-k_rs_scan(unsigned* hist, unsigned* total, unsigned* ticket, int ntiles)
+k_rs_scan(unsigned* hist, unsigned* rowtot, int ntiles)
 {
     __shared__ u64 smu[SMC_SM];
-    __shared__ int s_last;
     const int d = (int)blockIdx.x, tid = (int)threadIdx.x;
-    const u64 lower = (tid < d) ? (u64)total[tid] : 0ull;
-    u64 carry = smc_block_sum_u64(lower, smu);                // keys with a smaller digit
+    u64 carry = 0ull;
     unsigned* row = hist + (i64)d * ntiles;
     for (int w0 = 0; w0 < ntiles; w0 += SMC_BLOCK) {
         const int w = w0 + tid;
@@ -120,36 +119,30 @@ k_rs_scan(unsigned* hist, unsigned* total, unsigned* ticket, int ntiles)
         if (w < ntiles) row[w] = (unsigned)(carry + ex);
         carry += tot;
     }
-    // re-arm the totals once every digit has read them
-    __syncthreads();
-    if (tid == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
-    __syncthreads();
-    if (s_last) {
-        total[tid] = 0u;
-        if (tid == 0) *ticket = 0u;
-    }
+    if (tid == 0) rowtot[d] = (unsigned)carry;
 }
 
 // the same for few tiles (<= 64): ONE workgroup, thread d walks digit d's short row
 __global__ void __launch_bounds__(SMC_BLOCK)
-k_rs_scan_few(unsigned* hist, unsigned* total, int ntiles)
+k_rs_scan_few(unsigned* hist, unsigned* rowtot, int ntiles)
 {
-    __shared__ u64 smu[SMC_SM];
     const int d = (int)threadIdx.x;
-    u64 all;
-    u64 run = smc_block_exscan_u64((u64)total[d], smu, all);
-    total[d] = 0u;
+    unsigned run = 0u;
     unsigned* row = hist + (i64)d * ntiles;
     for (int w = 0; w < ntiles; ++w) {
         const unsigned c = row[w];
-        row[w] = (unsigned)run;
+        row[w] = run;
         run += c;
     }
+    rowtot[d] = run;
 }
 
+// RAW (the first pass): the caller's keys and -- vals null -- the index as payload.  okeys null (a last
+// pass whose caller wants the permutation only): the keys are not written.
+template <bool RAW>
 __global__ void __launch_bounds__(SMC_BLOCK)
-k_rs_scatter(const u64* keys, const u64* vals, i64 N, int shift, const unsigned* offs, int ntiles,
-             u64* okeys, u64* ovals)
+k_rs_scatter(const u64* keys, const u64* vals, i64 N, int shift, int kind, const unsigned* offs,
+             const unsigned* rowtot, int ntiles, u64* okeys, u64* ovals)
 {
     __shared__ unsigned cnt[SMC_NWAVE][256];
     __shared__ unsigned start[256];              // first slot of each digit in the tile's sorted order
@@ -159,8 +152,8 @@ k_rs_scatter(const u64* keys, const u64* vals, i64 N, int shift, const unsigned*
     const int tid = (int)threadIdx.x, lane = smc_lane(), wave = smc_wave();
 #pragma unroll
     for (int w = 0; w < SMC_NWAVE; ++w) cnt[w][tid] = 0u;
-    goff[tid] = offs[(i64)tid * ntiles + blockIdx.x];
-    __syncthreads();
+    const unsigned my_off = offs[(i64)tid * ntiles + blockIdx.x];
+    const unsigned my_tot = rowtot[tid];
     const i64 tile0 = (i64)blockIdx.x * RS_TILE;
     const i64 base = tile0 + (i64)wave * RS_SEG;
     const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));       // lanes below this one
@@ -171,11 +164,18 @@ k_rs_scatter(const u64* keys, const u64* vals, i64 N, int shift, const unsigned*
         const i64 i = base + (i64)c * 64 + lane;
         const bool valid = i < N;
         k[c] = valid ? keys[i] : ~0ull;
-        v[c] = valid ? vals[i] : 0ull;
+        v[c] = (RAW && !vals) ? (u64)i : (valid ? vals[i] : 0ull);
     }
+    {   // keys with a smaller digit anywhere in the input
+        u64 all;
+        const u64 lower = smc_block_exscan_u64((u64)my_tot, smu, all);
+        goff[tid] = (unsigned)lower + my_off;
+    }
+    __syncthreads();
 #pragma unroll
     for (int c = 0; c < RS_CH; ++c) {
         const bool valid = base + (i64)c * 64 + lane < N;
+        if (RAW) k[c] = valid ? rs_encode(k[c], kind) : ~0ull;
         const unsigned dg = (unsigned)(k[c] >> shift) & 255u;
         u64 mask = smc_ballot(valid);                // lanes holding a key with THIS lane's digit
 #pragma unroll
@@ -222,7 +222,7 @@ k_rs_scatter(const u64* keys, const u64* vals, i64 N, int shift, const unsigned*
             const u64 kk = sk[j];
             const unsigned dg = (unsigned)(kk >> shift) & 255u;
             const i64 pos = (i64)goff[dg] + (j - (int)start[dg]);
-            okeys[pos] = kk;
+            if (okeys) okeys[pos] = kk;
             ovals[pos] = sv[j];
         }
     }
@@ -315,7 +315,7 @@ k_rs_small(const u64* keys, const u64* vals, i64 N, int kind, u64* okeys, u64* o
 size_t smc_rs_ws_bytes(i64 N)
 {
     const size_t ntiles = (size_t)((N + RS_TILE - 1) / RS_TILE);
-    return 4 * (size_t)N * 8 + ntiles * 256 * 4 + 257 * 4 + 256;
+    return 4 * (size_t)N * 8 + ntiles * 256 * 4 + 256 * 4 + 256;
 }
 int smc_rs_sort_ws(smc_ctx* ctx, const void* keys, const void* vals, i64 N, int kind, void* ws,
                    u64** sorted_keys, u64** sorted_vals)
@@ -336,19 +336,27 @@ int smc_rs_sort_ws(smc_ctx* ctx, const void* keys, const void* vals, i64 N, int 
     } else {
         const int ntiles = (int)((N + RS_TILE - 1) / RS_TILE);
         unsigned* hist = (unsigned*)((char*)ws + 4 * nb);
-        unsigned* total = hist + (size_t)ntiles * 256;            // 256 digit totals + the scan's ticket
-        const dim3 ge((unsigned)((N + SMC_BLOCK - 1) / SMC_BLOCK));
-        (void)hipMemsetAsync(total, 0, 257 * 4, st);
-        SMC_LAUNCH(k_rs_encode, ge, dim3(SMC_BLOCK), st, (const u64*)keys, (const u64*)vals, N, kind, k0, v0);
+        unsigned* rowtot = hist + (size_t)ntiles * 256;           // 256 row totals
+        // pass 0 reads the caller's arrays (encoded on the fly, payload = index unless given) into the
+        // second pair; 8 passes: the result is back in the first pair.  The last pass writes no keys
+        // unless the caller asked for them.
+        const u64 *ks = (const u64*)keys, *vs = (const u64*)vals;
+        u64 *kd = k1, *vd = v1;
         for (int pass = 0; pass < 8; ++pass) {
             const int shift = 8 * pass;
-            SMC_LAUNCH(k_rs_hist, dim3(ntiles), dim3(SMC_BLOCK), st, (const u64*)k0, N, shift, hist, total, ntiles);
-            if (ntiles <= 64) SMC_LAUNCH(k_rs_scan_few, dim3(1), dim3(SMC_BLOCK), st, hist, total, ntiles);
-            else SMC_LAUNCH(k_rs_scan, dim3(256), dim3(SMC_BLOCK), st, hist, total, total + 256, ntiles);
-            SMC_LAUNCH(k_rs_scatter, dim3(ntiles), dim3(SMC_BLOCK), st, (const u64*)k0, (const u64*)v0, N, shift,
-                       (const unsigned*)hist, ntiles, k1, v1);
-            u64* t = k0; k0 = k1; k1 = t;
-            t = v0; v0 = v1; v1 = t;
+            if (pass == 0) SMC_LAUNCH(k_rs_hist<true>, dim3(ntiles), dim3(SMC_BLOCK), st, ks, N, shift, kind, hist, ntiles);
+            else SMC_LAUNCH(k_rs_hist<false>, dim3(ntiles), dim3(SMC_BLOCK), st, ks, N, shift, kind, hist, ntiles);
+            if (ntiles <= 64) SMC_LAUNCH(k_rs_scan_few, dim3(1), dim3(SMC_BLOCK), st, hist, rowtot, ntiles);
+            else SMC_LAUNCH(k_rs_scan, dim3(256), dim3(SMC_BLOCK), st, hist, rowtot, ntiles);
+            u64* ko = (pass == 7 && !sorted_keys) ? nullptr : kd;
+            if (pass == 0)
+                SMC_LAUNCH(k_rs_scatter<true>, dim3(ntiles), dim3(SMC_BLOCK), st, ks, vs, N, shift, kind,
+                           (const unsigned*)hist, (const unsigned*)rowtot, ntiles, ko, vd);
+            else
+                SMC_LAUNCH(k_rs_scatter<false>, dim3(ntiles), dim3(SMC_BLOCK), st, ks, vs, N, shift, kind,
+                           (const unsigned*)hist, (const unsigned*)rowtot, ntiles, ko, vd);
+            ks = kd; vs = vd;
+            if (kd == k1) { kd = k0; vd = v0; } else { kd = k1; vd = v1; }
         }
         if (hipGetLastError() != hipSuccess) rc = SMC_ERR_HIP;
         if (sorted_keys) *sorted_keys = k0;                       // (8 passes: back in the first pair)
@@ -379,7 +387,7 @@ static int rs_sort_pairs(smc_ctx* ctx, const void* keys, const void* vals, i64 N
     void* buf = nullptr;
     if (smc_malloc(ctx, smc_rs_ws_bytes(N), &buf) != SMC_OK) return SMC_ERR_NOMEM;
     u64 *k0 = nullptr, *v0 = nullptr;
-    int rc = smc_rs_sort_ws(ctx, keys, vals, N, kind, buf, &k0, &v0);
+    int rc = smc_rs_sort_ws(ctx, keys, vals, N, kind, buf, out_keys ? &k0 : nullptr, &v0);
     const dim3 ge((unsigned)((N + SMC_BLOCK - 1) / SMC_BLOCK));
     if (out_keys) SMC_LAUNCH(k_rs_decode, ge, dim3(SMC_BLOCK), st, (const u64*)k0, N, kind, (u64*)out_keys);
     if (out_vals && hipMemcpyAsync(out_vals, v0, (size_t)N * 8, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = SMC_ERR_HIP;

@@ -48,6 +48,9 @@ abrng)
   for f in $O/ab_*.json; do line $f; done ;;
 prof)
   EXTRA="--no-cpu-baseline --no-other-workloads" bash tools/gpu_profile.sh ${TAG}_c2 400 > $O/prof_c2.txt 2>&1; tail -40 $O/prof_c2.txt ;;
+sqmc)
+  (timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "sqmc" > $O/pytest_sqmc.log 2>&1; echo "rc=$?" >> $O/pytest_sqmc.log); tail -8 $O/pytest_sqmc.log
+  timeout 300 python tools/sqmc_perf.py > $O/sqmc_perf.txt 2>&1; cat $O/sqmc_perf.txt ;;
 prof_sqmc)
   P=$O/prof_sqmc; mkdir -p $P
   (cd /tmp && export TMPDIR=/tmp && timeout 200 rocprofv3 --kernel-trace --stats -d $P/trace -o trace -- python $R/tools/sqmc_perf.py 20 30 > $P/trace.log 2>&1)

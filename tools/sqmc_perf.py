@@ -16,13 +16,15 @@ from particles_amd import kalman, resampling as rs
 from particles_amd import state_space_models as ssm
 
 
-def run(model, N, T, label):
+def run(model, N, T, label, fused=True):
     np.random.seed(42)
     rs.set_rng("numpy")
     pa.set_resident(False)
     x, y = model.simulate(T)
     rs.set_rng("philox")
     pa.set_resident(True)
+    from particles_amd import _lib
+    _lib.FUSED_SQMC[0] = fused
     try:
         out = []
         for rep in range(3):
@@ -32,18 +34,20 @@ def run(model, N, T, label):
             pf.run()
             ll = float(pf.logLt)              # forces completion
             out.append((time.perf_counter() - t0) / T)
-        print("%-28s N=2^%-2d  %8.3f ms/step  %7.2f M particle-steps/s   logLt %.3f"
-              % (label, int(np.log2(N)), 1e3 * min(out), N / min(out) / 1e6, ll))
+        print("%-28s N=2^%-2d  %-9s %8.3f ms/step  %7.2f M particle-steps/s   logLt %.3f"
+              % (label, int(np.log2(N)), "fused" if pf._fused else "operators", 1e3 * min(out), N / min(out) / 1e6, ll))
     finally:
         pa.set_resident(False)
         rs.set_rng("numpy")
+        _lib.FUSED_SQMC[0] = True
 
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:                       # python tools/sqmc_perf.py 20 [T]: one size, for profiling
         run(kalman.ToySSM(0.2), 1 << int(sys.argv[1]), int(sys.argv[2]) if len(sys.argv) > 2 else 30, "ToySSM d=1")
         sys.exit(0)
-    for k in (12, 16, 20):
+    for k in (12, 16, 20, 22):
         run(kalman.ToySSM(0.2), 1 << k, 30, "ToySSM d=1")
+        run(kalman.ToySSM(0.2), 1 << k, 30, "ToySSM d=1", fused=False)
     for k in (12, 16, 18):
         run(kalman.MVLinearGauss_Guarniero_etal(alpha=0.4, dx=2), 1 << k, 20, "MVLinearGauss d=2 (Hilbert)")
