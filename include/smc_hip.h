@@ -419,6 +419,15 @@ int smc_filter_unpack_islands(smc_filter* f, const int64_t* islands_host, int n,
  *   if (stop) { [resample thetas: smc_filter_permute_islands; PMCMC move: a second batch +
  *                smc_filter_copy_islands] ; smc_filter_theta_resume(f, NULL); }            */
 int smc_filter_theta_enable(smc_filter* f, double ess_rmin);
+/* The same for a theta-population SHARDED over the ranks of `comm` (multi-GPU SMC^2; every rank holds
+ * n_islands consecutive theta-particles, rank r the global indices r M .. r M + M - 1).  The theta level
+ * is replicated: each step is followed by one ncclAllGather of the ranks' evidence increments ENQUEUED ON
+ * THE CONTEXT'S STREAM (N_theta x 8 bytes over xGMI, no host synchronisation) and the same one-workgroup
+ * update on every rank -- same values, same order, same bits, hence the same ESS, the same decision and
+ * the same freeze on every rank and for every world size.  smc_filter_theta_state / _resume / _logmeans
+ * then exchange nranks x n_islands values.  Every rank makes the same calls in the same order. */
+typedef struct smc_comm smc_comm;
+int smc_filter_theta_enable_sharded(smc_filter* f, smc_comm* comm, double ess_rmin);
 /* lw_theta_host (n_islands) or NULL; *stop_t = step at which the batch froze (0: running);
  * *steps_done = time steps accounted for in the theta weights; ess_host (steps_done) or NULL:
  * the theta-level ESS after every step. */
@@ -473,7 +482,6 @@ int smc_filter_kernel_ms(smc_filter* f, double* move_ms_avg,
  * exchange; the only collective gathers the per-island log-evidences over RCCL
  * (xGMI).  Rank 0 obtains the id and distributes it out of band (the bench
  * uses the torch.distributed/gloo rendezvous the launcher provides). */
-typedef struct smc_comm smc_comm;
 #define SMC_COMM_ID_BYTES 128
 int smc_comm_unique_id(char* id_host /* SMC_COMM_ID_BYTES */);
 int smc_comm_create(smc_ctx* ctx, int nranks, int rank, const char* id_host,
@@ -481,6 +489,10 @@ int smc_comm_create(smc_ctx* ctx, int nranks, int rank, const char* id_host,
 /* recv (nranks*count) <- concatenation over ranks of send (count); blocking */
 int smc_comm_allgather_f64(smc_comm* comm, const double* send, int64_t count,
                            double* recv);
+/* ... enqueued on the context's stream without waiting for it */
+int smc_comm_allgather_f64_async(smc_comm* comm, const double* send, int64_t count,
+                                 double* recv);
+int smc_comm_rank(smc_comm* comm, int32_t* rank, int32_t* nranks);
 /* All-to-all of byte blocks between the ranks (island migration of multi-GPU SMC^2: a global
  * theta-resampling, smc_samplers.py:319-361, moves whole filters between GPUs): grouped
  * ncclSend / ncclRecv, one pair per peer over xGMI.  send / recv: device buffers; counts and

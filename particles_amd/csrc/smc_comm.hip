@@ -11,12 +11,6 @@
 #include "smc_device.h"
 #include "smc_internal.h"
 
-struct smc_comm {
-    smc_ctx* ctx;
-    void* nccl;      // ncclComm_t
-    int nranks, rank;
-};
-
 // The binding below is compiled into the emulator build as well: with SMC_RCCL_LIBRARY naming a
 // library that exports the nccl* entry points (tests/emu/fake_rccl.c: a multi-process test double on
 // host memory) the CPU suite drives exactly the calls -- argument order, counts, datatypes, group
@@ -144,7 +138,9 @@ int smc_comm_create(smc_ctx* ctx, int nranks, int rank, const char* id_host, smc
     return SMC_OK;
 }
 
-int smc_comm_allgather_f64(smc_comm* c, const double* send, int64_t count, double* recv)
+// enqueued on the context's stream, no synchronisation: the theta level of a sharded SMC^2 gathers the
+// filters' evidence increments behind every time step without a host round trip (smc_filter_theta_enable_sharded)
+int smc_comm_allgather_f64_async(smc_comm* c, const double* send, int64_t count, double* recv)
 {
     SMC_REQUIRE(c && send && recv, "null argument");
     SMC_REQUIRE(count > 0, "count must be positive");
@@ -153,10 +149,28 @@ int smc_comm_allgather_f64(smc_comm* c, const double* send, int64_t count, doubl
         SMC_LAUNCH(k_copy_f64, dim3((unsigned)((count + SMC_BLOCK - 1) / SMC_BLOCK)), dim3(SMC_BLOCK),
                    st, send, (i64)count, recv);
     } else {
+#ifdef SMC_EMULATE
+        SMC_HIP_CHECK(hipStreamSynchronize(st));      // (the test double reads host memory: launches are done first)
+#endif
         ncclResult_t r = g_rccl.AllGather(send, recv, (size_t)count, kNcclFloat64, c->nccl, st);
         if (r != 0) return rccl_fail("ncclAllGather", r);
     }
-    SMC_HIP_CHECK(hipStreamSynchronize(st));
+    return SMC_OK;
+}
+
+int smc_comm_allgather_f64(smc_comm* c, const double* send, int64_t count, double* recv)
+{
+    const int rc = smc_comm_allgather_f64_async(c, send, count, recv);
+    if (rc) return rc;
+    SMC_HIP_CHECK(hipStreamSynchronize(c->ctx->stream));
+    return SMC_OK;
+}
+
+int smc_comm_rank(smc_comm* c, int32_t* rank, int32_t* nranks)
+{
+    SMC_REQUIRE(c && rank && nranks, "null argument");
+    *rank = c->rank;
+    *nranks = c->nranks;
     return SMC_OK;
 }
 

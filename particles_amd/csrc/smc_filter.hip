@@ -52,6 +52,12 @@ struct smc_filter {
     double *lwth, *th, *th_ess;
     double th_ess_min;
     void* th_buf;
+    // ... of a population sharded over ranks (smc_filter_theta_enable_sharded): the theta level is
+    // replicated -- th_n = nranks x n_islands log-weights on every rank -- and fed by an all-gather of the
+    // ranks' evidence increments enqueued behind every step
+    smc_comm* th_comm;
+    int th_n;
+    double *th_send, *th_recv;
 };
 
 typedef void (*move_fn)(FArgs);
@@ -316,6 +322,9 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     f->lwth = f->th = f->th_ess = nullptr;
     f->th_buf = nullptr;
     f->th_ess_min = 0.0;
+    f->th_comm = nullptr;
+    f->th_n = 0;
+    f->th_send = f->th_recv = nullptr;
     f->mv_collapsed = mv && model->fk == SMC_FK_GUIDED && (o->flags & SMC_FLAG_COLLAPSED_PROPOSAL);
     f->strict = (o->flags & SMC_FLAG_STRICT_ANCESTORS) != 0;
     f->no_small = (o->flags & SMC_PATH_NO_SMALL) != 0;
@@ -686,12 +695,15 @@ int smc_filter_clone(smc_filter* src, smc_filter** out)
     hipStream_t st = ctx->stream;
     hipError_t e = hipMemcpyAsync(slab, src->slab, src->slab_bytes, hipMemcpyDeviceToDevice, st);
     if (e == hipSuccess && src->th_buf) {
-        const size_t M = (size_t)a.n_islands, T = (size_t)a.T, nb = (M + TH_STRIDE + 2 * T) * 8;
+        const size_t M = (size_t)a.n_islands, T = (size_t)a.T, Ng = (size_t)src->th_n;
+        const size_t nb = (Ng + TH_STRIDE + 2 * T + (src->th_comm ? M + Ng : 0)) * 8;
         e = hipMalloc(&f->th_buf, nb);
         if (e == hipSuccess) e = hipMemcpyAsync(f->th_buf, src->th_buf, nb, hipMemcpyDeviceToDevice, st);
         f->lwth = (double*)f->th_buf;
-        f->th = f->lwth + M;
+        f->th = f->lwth + Ng;
         f->th_ess = f->th + TH_STRIDE;
+        f->th_send = src->th_comm ? f->th_ess + 2 * T : nullptr;
+        f->th_recv = src->th_comm ? f->th_send + M : nullptr;
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) {
@@ -803,8 +815,17 @@ int smc_filter_step(smc_filter* f, int64_t nsteps)
                 enqueue_step(f, -1, f->t_host + k);
                 if (f->two_level) SMC_LAUNCH(k_flush2, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
             }
+            if (f->th_comm) {
+                // sharded population: my filters' increments -> all ranks' (ncclAllGather on this stream, no
+                // host round trip) -> the replicated theta level, the same arithmetic on every rank
+                SMC_LAUNCH(k_theta_pack, dim3(1), dim3(SMC_BLOCK), st, f->a, (const double*)f->th, f->th_send,
+                           f->two_level ? 1 : 0);
+                const int rc = smc_comm_allgather_f64_async(f->th_comm, f->th_send, f->a.n_islands, f->th_recv);
+                if (rc) return rc;
+            }
             SMC_LAUNCH(k_theta_update, dim3(1), dim3(SMC_BLOCK), st, f->a, f->lwth, f->th, f->th_ess,
-                       f->th_ess_min, f->two_level ? 1 : 0);
+                       f->th_ess_min, f->two_level ? 1 : 0, (const double*)(f->th_comm ? f->th_recv : nullptr),
+                       f->th_comm ? f->th_n : f->a.n_islands);
         }
         SMC_LAUNCH_CHECK();
         f->t_host += todo;
@@ -1224,25 +1245,47 @@ int smc_filter_unpack_islands(smc_filter* f, const int64_t* islands_host, int n,
 }
 
 // ---- SMC^2: the theta level (see k_theta_update) -------------------------------------------
-int smc_filter_theta_enable(smc_filter* f, double ess_rmin)
+static int theta_enable(smc_filter* f, double ess_rmin, smc_comm* comm)
 {
     SMC_REQUIRE(f, "null filter");
     SMC_REQUIRE(!f->a.hist && !f->a.mom, "the theta level is not available with keep_history / moments");
     SMC_REQUIRE(!f->a.pm2, "the theta level is not available for the auxiliary filter on the two-level step");
+    SMC_REQUIRE(!comm || comm->ctx == f->ctx, "the communicator belongs to another context");
     SMC_HIP_CHECK(hipSetDevice(f->ctx->device));
     const size_t M = (size_t)f->a.n_islands, T = (size_t)f->a.T;
-    if (!f->th_buf) SMC_HIP_CHECK(hipMalloc(&f->th_buf, (M + TH_STRIDE + 2 * T) * 8));
-    SMC_HIP_CHECK(hipMemsetAsync(f->th_buf, 0, (M + TH_STRIDE + 2 * T) * 8, f->ctx->stream));
+    const size_t Ng = comm ? M * (size_t)comm->nranks : M;
+    const size_t nb = (Ng + TH_STRIDE + 2 * T + (comm ? M + Ng : 0)) * 8;
+    if (f->th_buf && (size_t)f->th_n != Ng) { (void)hipFree(f->th_buf); f->th_buf = nullptr; }
+    if (!f->th_buf) SMC_HIP_CHECK(hipMalloc(&f->th_buf, nb));
+    SMC_HIP_CHECK(hipMemsetAsync(f->th_buf, 0, nb, f->ctx->stream));
     f->lwth = (double*)f->th_buf;
-    f->th = f->lwth + M;
+    f->th = f->lwth + Ng;
     f->th_ess = f->th + TH_STRIDE;
-    f->th_ess_min = ess_rmin * (double)M;
+    f->th_comm = comm;
+    f->th_n = (int)Ng;
+    f->th_send = comm ? f->th_ess + 2 * T : nullptr;
+    f->th_recv = comm ? f->th_send + M : nullptr;
+    f->th_ess_min = ess_rmin * (double)Ng;
     // (enabled on a batch that has already run t steps -- the exchange step: the theta weights
     //  start at zero, or at what smc_filter_theta_resume sets, and account for steps >= t)
     const double done = (double)f->t_host;
     SMC_HIP_CHECK(hipMemcpyAsync(f->th + 2, &done, 8, hipMemcpyHostToDevice, f->ctx->stream));
     SMC_HIP_CHECK(hipStreamSynchronize(f->ctx->stream));
     return SMC_OK;
+}
+int smc_filter_theta_enable(smc_filter* f, double ess_rmin) { return theta_enable(f, ess_rmin, nullptr); }
+
+// The theta level of a population sharded over the ranks of `comm` (every rank: the same number of
+// islands, rank r holds the global theta indices r M .. r M + M - 1): replicated on every rank, fed behind
+// every step by ONE ncclAllGather of the ranks' evidence increments enqueued on the context's stream --
+// the same arithmetic on the same N_theta values in the same order everywhere, hence the same decisions
+// on every rank and for every world size, and no host synchronisation per step.  smc_filter_theta_state /
+// _resume / _logmeans then speak of all nranks x n_islands theta-particles.  Every rank must make the same
+// calls in the same order (smc_filter_step enqueues a collective per step).
+int smc_filter_theta_enable_sharded(smc_filter* f, smc_comm* comm, double ess_rmin)
+{
+    SMC_REQUIRE(comm, "null communicator");
+    return theta_enable(f, ess_rmin, comm);
 }
 
 int smc_filter_theta_state(smc_filter* f, double* lw_theta_host, int64_t* stop_t, int64_t* steps_done,
@@ -1253,7 +1296,7 @@ int smc_filter_theta_state(smc_filter* f, double* lw_theta_host, int64_t* stop_t
     double th[TH_STRIDE];
     SMC_HIP_CHECK(hipMemcpyAsync(th, f->th, sizeof th, hipMemcpyDeviceToHost, st));
     if (lw_theta_host)
-        SMC_HIP_CHECK(hipMemcpyAsync(lw_theta_host, f->lwth, (size_t)f->a.n_islands * 8, hipMemcpyDeviceToHost, st));
+        SMC_HIP_CHECK(hipMemcpyAsync(lw_theta_host, f->lwth, (size_t)f->th_n * 8, hipMemcpyDeviceToHost, st));
     SMC_HIP_CHECK(hipStreamSynchronize(st));
     if (stop_t) *stop_t = (int64_t)th[0];
     if (steps_done) *steps_done = (int64_t)th[2];
@@ -1293,9 +1336,9 @@ int smc_filter_theta_resume(smc_filter* f, const double* lw_theta_host)
     SMC_HIP_CHECK(hipMemcpyAsync(th, f->th, sizeof th, hipMemcpyDeviceToHost, st));
     SMC_HIP_CHECK(hipStreamSynchronize(st));
     if (lw_theta_host)
-        SMC_HIP_CHECK(hipMemcpyAsync(f->lwth, lw_theta_host, (size_t)f->a.n_islands * 8, hipMemcpyHostToDevice, st));
+        SMC_HIP_CHECK(hipMemcpyAsync(f->lwth, lw_theta_host, (size_t)f->th_n * 8, hipMemcpyHostToDevice, st));
     else
-        SMC_HIP_CHECK(hipMemsetAsync(f->lwth, 0, (size_t)f->a.n_islands * 8, st));
+        SMC_HIP_CHECK(hipMemsetAsync(f->lwth, 0, (size_t)f->th_n * 8, st));
     if (th[0] != 0.0) {
         SMC_LAUNCH(k_theta_thaw, dim3(1), dim3(SMC_BLOCK), st, f->a, f->th, th[0]);
         SMC_LAUNCH_CHECK();

@@ -2771,8 +2771,12 @@ k_f_restate(const FArgs av, const i64 ts)
 // [3] log-mean-exp of lw_theta before the last resampling (evidence bookkeeping: unused here).
 // ---------------------------------------------------------------------------
 #define TH_STRIDE 8
+// `gathered` (sharded population, smc_filter_theta_enable_sharded): the evidence increments of ALL Ng
+// theta-particles, gathered from the ranks by the launch before (k_theta_pack + ncclAllGather); lwth then
+// holds Ng replicated log-weights and the reductions run over them -- the same on every rank.
 __global__ void __launch_bounds__(SMC_BLOCK)
-k_theta_update(const FArgs av, double* lwth, double* th, double* ess_log, const double ess_min, const int two_level)
+k_theta_update(const FArgs av, double* lwth, double* th, double* ess_log, const double ess_min, const int two_level,
+               const double* gathered, const int Ng)
 {
     const FArgs& a = av;
     __shared__ double smd[SMC_SM];
@@ -2784,8 +2788,9 @@ k_theta_update(const FArgs av, double* lwth, double* th, double* ess_log, const 
     const double done = two_level ? a.info2[0] : a.info[0];
     if ((i64)done < t + 1) return;
     SmcLse acc = smc_lse_empty();
-    for (int i = tid; i < M; i += SMC_BLOCK) {
-        const double inc = a.summ[((i64)i * (a.T + 1) + t) * SUMM_STRIDE + 2];      // loglt of step t
+    for (int i = tid; i < Ng; i += SMC_BLOCK) {
+        const double inc = gathered ? gathered[i]
+                                    : a.summ[((i64)i * (a.T + 1) + t) * SUMM_STRIDE + 2];      // loglt of step t
         double l = lwth[i] + inc;
         if (l != l) l = -INFINITY;
         lwth[i] = l;
@@ -2797,7 +2802,7 @@ k_theta_update(const FArgs av, double* lwth, double* th, double* ess_log, const 
         th[1] = ess;
         th[2] = (double)(t + 1);
         ess_log[t] = ess;
-        ess_log[a.T + t] = g.m + log(g.s / (double)M);         // log-mean of the theta weights after step t
+        ess_log[a.T + t] = g.m + log(g.s / (double)Ng);        // log-mean of the theta weights after step t
                                                                // (the outer evidence, core.py:355-359)
     }
     const bool stop = !((g.s * g.s) / g.ss >= ess_min) && t + 1 < a.T;
@@ -2807,6 +2812,19 @@ k_theta_update(const FArgs av, double* lwth, double* th, double* ess_log, const 
         a.info[(i64)i * INFO_STRIDE] = 1e18;
         a.info2[(i64)i * INFO_STRIDE] = 1e18;
     }
+}
+// sharded population: my islands' evidence increments of the step just done, in the send buffer of the
+// all-gather (zeros when the batch is frozen or past T: k_theta_update then ignores what was gathered)
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_theta_pack(const FArgs av, const double* th, double* send, const int two_level)
+{
+    const FArgs& a = av;
+    const int tid = (int)threadIdx.x, M = a.n_islands;
+    const i64 t = (i64)th[2];
+    const double done = two_level ? a.info2[0] : a.info[0];
+    const bool live = th[0] == 0.0 && t < a.T && (i64)done >= t + 1;
+    for (int i = tid; i < M; i += SMC_BLOCK)
+        send[i] = live ? a.summ[((i64)i * (a.T + 1) + t) * SUMM_STRIDE + 2] : 0.0;
 }
 // thaw: the time records back to step t (after the host has dealt with the stop)
 __global__ void __launch_bounds__(SMC_BLOCK)

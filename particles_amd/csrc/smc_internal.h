@@ -32,6 +32,13 @@ struct smc_ctx {
 
 void smc_set_error(const char* fmt, ...);
 
+// communicator of the sharded runs (smc_comm.hip): one RCCL communicator per process
+struct smc_comm {
+    smc_ctx* ctx;
+    void* nccl;      // ncclComm_t; null: the emulator's one-rank stub
+    int nranks, rank;
+};
+
 #define SMC_HIP_CHECK(expr)                                                        \
     do {                                                                           \
         hipError_t e_ = (expr);                                                    \

@@ -312,9 +312,16 @@ class ShardedSMC2(SMC2):
     Philox streams are keyed by the global theta index and migration keeps them tied to the slot,
     so the run is the SAME run for any world size (tests: world 2 == world 1, bit for bit)."""
 
-    def __init__(self, group=None, **kw):
+    def __init__(self, group=None, device_theta=None, **kw):
         self.group = group
         world = group.world if group is not None else 1
+        # the theta level on the device (smc_filter_theta_enable_sharded: an all-gather of the increments
+        # enqueued behind every step, `sync_every` steps per host synchronisation) wherever the group
+        # has its device collective; over the host star (CPU tests without RCCL) the per-step form
+        has_comm = group is not None and group.comm is not None
+        self.device_theta = has_comm if device_theta is None else bool(device_theta)
+        if self.device_theta and not has_comm:
+            raise ValueError("ShardedSMC2(device_theta=True) needs a Group with its device collective (RCCL)")
         if kw.get("N", 100) % world:
             raise ValueError("ShardedSMC2: N must be a multiple of the number of ranks")
         if not isinstance(kw.get("prior"), IndepPrior):
@@ -333,27 +340,36 @@ class ShardedSMC2(SMC2):
         return self.group.rank * M, (self.group.rank + 1) * M
 
     def _enable_theta_level(self, pf):
-        pass                      # the theta-level ESS needs every rank's increments: done in run()
+        if self.device_theta:                # replicated theta level fed by ncclAllGather on the stream
+            check(lib().smc_filter_theta_enable_sharded(pf._f, self.group.comm, float(self.ESSrmin)))
+        # (else: the theta-level ESS needs every rank's increments: done on the host in run())
 
     def _evidences(self, pf):
         local = pf.logLts_islands
         return local if self.group is None else self.group.gather_evidence(local)
 
     def _resample_filters(self, A):
+        if self.device_theta:
+            check(lib().smc_filter_theta_resume(self.pf._f, None))     # time records back to t first
         if self.group is None:
             self.pf.permute_islands(A)
         else:
             self.group.migrate_islands(self.pf, A)
 
     def _adopt(self, new, liw):
-        pass
+        if self.device_theta:                # every rank holds all N theta-weights
+            self._enable_theta_level(new)
+            check(lib().smc_filter_theta_resume(new._f, np.ascontiguousarray(liw).ctypes.data_as(_lib.c_vp)))
 
     def _resample_move(self):
         super()._resample_move()
-        self._cum0 = self._evidences(self.pf)      # after the moves: accepted filters changed theirs
-        self._lw0 = self.lw.copy()                 # zeros, or the exchange step's evidence ratios
+        if not self.device_theta:
+            self._cum0 = self._evidences(self.pf)      # after the moves: accepted filters changed theirs
+            self._lw0 = self.lw.copy()                 # zeros, or the exchange step's evidence ratios
 
     def run(self):
+        if self.device_theta:
+            return super().run()
         while self.t < self.T:
             self.pf.step_async(1)
             self.t += 1

@@ -165,11 +165,12 @@ if grp.world == 1:                 # the one-GPU class (theta level on the devic
     ref = smc2.SMC2(**kw)
     ref.run()
     single = {{"lw": ref.lw.tolist(), "theta": ref.theta["sigmaY"].tolist(), "logLt": ref.logLt,
-               "moves": len(ref.move_times)}}
+               "moves": len(ref.move_times), "ESSs": ref.ESSs, "logLts": ref.logLts, "Nx": ref.Nx}}
 if grp.rank == 0:
     print("RESULT " + json.dumps({{"lw": alg.lw.tolist(), "theta": alg.theta["sigmaY"].tolist(),
                                    "logLt": alg.logLt, "ESSs": alg.ESSs, "moves": len(alg.move_times),
                                    "acc": alg.acc_rates, "Nx": alg.Nx, "path": grp.evidence_path,
+                                   "device_theta": alg.device_theta, "logLts": alg.logLts,
                                    "local": alg.pf.n_islands, "single": single}}))
 grp.close()
 """
@@ -232,11 +233,28 @@ def test_multi_rank_rccl_calls_through_the_test_double(tmp_path, has_gpu):
     m1 = _run_world(1, tmp_path, migrate=True)
     m3 = _run_world(3, tmp_path, migrate=True, **env)
     assert m3["path"] == "rccl" and m3["ll"] == m1["ll"]
-    s1 = _run_smc2_world(1, tmp_path)
+    # sharded SMC^2 with its theta level ON THE DEVICE (smc_filter_theta_enable_sharded: ncclAllGather of the
+    # increments enqueued behind every step, `sync_every` steps per host synchronisation): worlds 1, 2, 3
+    # are the same run, and so is the one-GPU class -- bit for bit, the same kernel on the same N values
+    s1 = _run_smc2_world(1, tmp_path, **env)
     s2 = _run_smc2_world(2, tmp_path, **env)
-    assert s2["path"] == "rccl"
-    for k in ("lw", "theta", "logLt", "ESSs", "moves", "acc", "Nx"):
-        assert s1[k] == s2[k], k
+    s3 = _run_smc2_world(3, tmp_path, **env)
+    assert s2["path"] == "rccl" and s1["device_theta"] and s2["device_theta"] and s3["device_theta"]
+    assert s1["moves"] >= 1 and s2["local"] == 6 and s3["local"] == 4
+    for k in ("lw", "theta", "logLt", "ESSs", "logLts", "moves", "acc", "Nx"):
+        assert s1[k] == s2[k] == s3[k], k
+    single = s1["single"]
+    for k in ("lw", "theta", "logLt", "ESSs", "logLts", "moves", "Nx"):
+        assert single[k] == s1[k], k
+    # ... with the exchange step (a new batch adopts the replicated theta-weights)
+    e1 = _run_smc2_world(1, tmp_path, SMC_TEST_AR="1.01", SMC_TEST_T="8", **env)
+    e2 = _run_smc2_world(2, tmp_path, SMC_TEST_AR="1.01", SMC_TEST_T="8", **env)
+    assert e1["Nx"] == 256 and all(e1[k] == e2[k] for k in ("lw", "theta", "logLt", "ESSs", "Nx"))
+    assert all(e1["single"][k] == e1[k] for k in ("lw", "theta", "logLt", "ESSs", "Nx"))
+    # the per-step host form (no device collective) decides the same and agrees to rounding
+    h2 = _run_smc2_world(2, tmp_path)
+    assert not h2["device_theta"] and h2["moves"] == s2["moves"] and h2["theta"] == s2["theta"]
+    assert np.allclose(h2["lw"], s2["lw"], rtol=0, atol=1e-9)
 
 
 def test_rccl_test_double_refuses_protocol_violations(tmp_path):

@@ -569,18 +569,29 @@ def test_island_migration_through_rccl(tmp_path):
 
 
 def test_sharded_smc2_over_rccl(tmp_path):
-    """ShardedSMC2 on the device: world 1 with the RCCL communicator (all-gather of the evidence
-    increments every step, migration through smc_comm_alltoallv), then two ranks on this box's one
-    GPU (RCCL if it accepts two ranks per device, the labelled host fallback otherwise): the same run
-    bit for bit; larger filters (N_x = 4096: the multi-kernel step) as well."""
+    """ShardedSMC2 on the device: world 1 with the RCCL communicator -- the theta level replicated on the
+    device, fed by ncclAllGather of the evidence increments enqueued behind every step
+    (smc_filter_theta_enable_sharded), migration through smc_comm_alltoallv: the same run as the one-GPU
+    class bit for bit.  Then two ranks on this box's one GPU (RCCL if it accepts two ranks per device, the
+    labelled host fallback with its per-step host theta level otherwise: same decisions, weights to
+    rounding); larger filters (N_x = 4096: the multi-kernel step) as well."""
+    import numpy as np
     from test_distributed_cpu import _run_smc2_world
     for nx in ("128", "4096"):
         one = _run_smc2_world(1, tmp_path, SMC_TEST_RCCL="1", SMC_TEST_NX=nx)
         two = _run_smc2_world(2, tmp_path, SMC_TEST_RCCL="1", SMC_ALLOW_HOST_GATHER="1", SMC_TEST_NX=nx)
-        assert one["path"] == "rccl" and one["moves"] >= 1
+        assert one["path"] == "rccl" and one["device_theta"] and one["moves"] >= 1
+        for k in ("lw", "theta", "logLt", "ESSs", "logLts", "moves", "Nx"):
+            assert one["single"][k] == one[k], k
         assert two["path"] == "rccl" or two["path"].startswith("host-fallback: ")
-        for k in ("lw", "theta", "logLt", "ESSs", "moves", "acc"):
-            assert one[k] == two[k], k
+        if two["device_theta"]:
+            for k in ("lw", "theta", "logLt", "ESSs", "moves", "acc"):
+                assert one[k] == two[k], k
+        else:
+            for k in ("theta", "moves", "acc"):
+                assert one[k] == two[k], k
+            assert np.allclose(one["lw"], two["lw"], rtol=0, atol=1e-9) and abs(one["logLt"] - two["logLt"]) < 1e-9
+            assert np.allclose(one["ESSs"], two["ESSs"], rtol=1e-9)
 
 
 def test_apf_and_guided_stochvol_fused(golden):
