@@ -697,6 +697,10 @@ class MVLinGauss:
     def kalman_matrices(self):
         return self.F, self.G, self.covX, self.covY, self.mu0, self.cov0
 
+    def logeta(self, x, y_next):
+        """kalman.py:358-361: ``logpyt`` of ``filter_step_asarray`` on the prediction (F x, covX)."""
+        return kalman_filter_step(self.G, self.covY, np.matmul(x, self.F.T), self.covX, y_next)[2]
+
 
 def Guarniero(alpha=0.4, dx=2):
     """kalman.py:364-394."""
@@ -762,7 +766,7 @@ class StepCtx:
             self.LX = np.linalg.cholesky(model.covX)           # distributions.py:937
             self.LY = np.linalg.cholesky(model.covY)
             self.L0 = np.linalg.cholesky(model.cov0)
-            if fk == "guided":
+            if fk in ("guided", "apf"):
                 # kalman.py:353-356 proposal0 ; filter_step with scalar-shaped mean
                 self.f0m, f0c, _ = kalman_filter_step(model.G, model.covY, model.mu0,
                                                       model.cov0, np.asarray(y0))
@@ -775,6 +779,8 @@ def propagate(model, fk, t, yt, Xp, z, ctx):
     Returns (X_t, weight increment).  ``run_filter`` iterates it; the parity tests also call it
     step by step on the device's own X_{t-1}[A_t] (teacher forcing)."""
     if ctx.mv:
+        if fk == "apf":
+            fk = "guided"                                      # AuxiliaryPF(GuidedPF): the same move and logG
         if t == 0:
             if fk == "guided":
                 X = mvnormal_rvs(ctx.f0m, 1.0, ctx.Lp0, z)     # state_space_models.py:374-375
@@ -854,7 +860,7 @@ def run_filter(model, data, N, scheme="systematic", ESSrmin=0.5, fk="bootstrap",
         if t > 0:
             aux = wgts
             if fk == "apf":                               # core.py:307-313 setup_auxiliary_weights
-                logetat = model.logeta(X, np.asarray(data[t]).reshape(-1)[0])
+                logetat = model.logeta(X, np.asarray(data[t]) if ctx.mv else np.asarray(data[t]).reshape(-1)[0])
                 aux = wgts.add(logetat)
             ess = aux.ESS
             if cdf == "2level":

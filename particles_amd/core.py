@@ -210,6 +210,10 @@ class SMC:
         """Fused APF: the one-launch filter (N <= 1024; no Philox multinomial there) or the two-level
         step (N > 1024; no rolling window); stock StochVol only, no device-side moments."""
         stock = getattr(fk, "_fk_kind", None) == _lib.FK_APF
+        model = fk._device_model() if hasattr(fk, "_device_model") else None
+        if stock and model is not None and model["kind"] == _lib.MODEL_MVLINGAUSS:
+            # MVLinearGauss: k_mv_aux in front of the flat step, any N; no history slots, no device moments
+            return not store_history and not device_moments
         small = N <= 1024 and not (resampling == "multinomial" and replay is None)
         rolling = isinstance(store_history, int) and not isinstance(store_history, bool) and store_history >= 2
         two_level = 1024 < N <= (1 << 30) and not rolling

@@ -82,6 +82,7 @@ static void launch_propagate(smc_filter* f)
         MV_CASE(SMC_FK_BOOTSTRAP, 16, false) MV_CASE(SMC_FK_BOOTSTRAP, 32, false)
         MV_CASE(SMC_FK_GUIDED, 16, false) MV_CASE(SMC_FK_GUIDED, 32, false)
         MV_CASE(SMC_FK_GUIDED, 16, true) MV_CASE(SMC_FK_GUIDED, 32, true)
+        MV_CASE(SMC_FK_APF, 16, false) MV_CASE(SMC_FK_APF, 32, false)
 #undef MV_CASE
         return;
     }
@@ -229,6 +230,15 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
         return;
     }
     const bool fused = f->fused;
+    if (f->kind == SMC_MODEL_MVLINGAUSS && f->fk == SMC_FK_APF) {
+        // auxiliary weights of step t (core.py:307-313) before its resampling: smc_filter_mv.h
+        const dim3 gp(f->a.nparts, f->a.n_islands);
+        if (f->a.dp == 16 && f->a.dx == 16) SMC_LAUNCH((k_mv_aux<16, true>), gp, dim3(SMC_BLOCK), st, f->a, f->a.mvc);
+        else if (f->a.dp == 16) SMC_LAUNCH((k_mv_aux<16, false>), gp, dim3(SMC_BLOCK), st, f->a, f->a.mvc);
+        else if (f->a.dx == 32) SMC_LAUNCH((k_mv_aux<32, true>), gp, dim3(SMC_BLOCK), st, f->a, f->a.mvc);
+        else SMC_LAUNCH((k_mv_aux<32, false>), gp, dim3(SMC_BLOCK), st, f->a, f->a.mvc);
+        SMC_LAUNCH(k_mv_aux_restate, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
+    }
     if (!fused) SMC_LAUNCH(k_prepare, grid, dim3(SMC_BLOCK), st, f->a);
     if (f->a.scheme == SMC_MULTINOMIAL && !f->a.ut) {
         const dim3 g1(f->a.ntiles1, f->a.n_islands);
@@ -275,11 +285,16 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     SMC_REQUIRE(model->fk == SMC_FK_BOOTSTRAP ||
                     (model->fk == SMC_FK_GUIDED &&
                      (model->kind == SMC_MODEL_LINGAUSS || model->kind == SMC_MODEL_STOCHVOL || mv)) ||
-                    (model->fk == SMC_FK_APF && (model->kind == SMC_MODEL_STOCHVOL || model->kind == SMC_MODEL_LINGAUSS)),
-                "guided filter: LINGAUSS, STOCHVOL, MVLINGAUSS; auxiliary filter: STOCHVOL, LINGAUSS");
+                    (model->fk == SMC_FK_APF && (model->kind == SMC_MODEL_STOCHVOL || model->kind == SMC_MODEL_LINGAUSS || mv)),
+                "guided filter: LINGAUSS, STOCHVOL, MVLINGAUSS; auxiliary filter: STOCHVOL, LINGAUSS, MVLINGAUSS");
     {
         const bool big = o->N > F_TILE && o->N <= ((int64_t)1 << 30);
-        if (model->fk == SMC_FK_APF && (o->moments || (o->N > F_TILE && !big) || o->keep_history >= 2)) {
+        if (mv && model->fk == SMC_FK_APF && (o->moments || o->keep_history)) {
+            smc_set_error("the auxiliary particle filter of MVLINGAUSS: no moments, no history slots (the auxiliary "
+                          "weights take the place of the previous step's while it resamples)");
+            return SMC_ERR_INVALID;
+        }
+        if (!mv && model->fk == SMC_FK_APF && (o->moments || (o->N > F_TILE && !big) || o->keep_history >= 2)) {
             smc_set_error("the auxiliary particle filter is fused for N <= 1024 (the one-launch filter) and for "
                           "1024 < N <= 2^30 (the two-level step); no moments, no rolling window");
             return SMC_ERR_INVALID;
@@ -435,7 +450,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
                    !(scheme == SMC_MULTINOMIAL && (o->flags & SMC_PATH_FLAT_MULTINOMIAL));
     // every workgroup reduces the partials itself while the launch is resident and an island has
     // at most 1024 tiles (4 per thread); otherwise one workgroup per island does it first
-    const bool apf2 = model->fk == SMC_FK_APF && o->N > F_TILE;      // APF on the two-level step: k_reduce2
+    const bool apf2 = !mv && model->fk == SMC_FK_APF && o->N > F_TILE;      // APF on the two-level step: k_reduce2
     if (apf2 && !f->two_level) {                                      // forms its two reductions
         smc_set_error("the auxiliary particle filter beyond N = 1024 runs on the two-level step only");
         delete f;
@@ -489,6 +504,8 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
         delete f;
         return SMC_ERR_INVALID;
     }
+    const bool apf_mv = mv && model->fk == SMC_FK_APF;
+    const size_t oEta = carve(apf_mv ? 2 * M * N * 8 : 8);
     const size_t oSqZ = carve(f->sqmc ? M * N * 8 : 8);
     const size_t oSqPerm = carve(f->sqmc && M > 1 ? M * N * 8 : 8);
     const size_t oSqWs = carve(f->sqmc ? smc_rs_ws_bytes((i64)N) : 8);
@@ -560,6 +577,10 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     if (a.sp_tpw) F_CREATE_CHECK(hipMemsetAsync(a.sst, 0, M * a.sp_nwg * 8, ctx->stream));
     f->tmp = (double*)(base + oTmp);
     f->strict_ws = (double*)(base + oStrict);
+    if (apf_mv) {
+        a.eta = (double*)(base + oEta);
+        a.lwsv = a.eta + M * N;
+    }
     if (f->sqmc) {
         f->sq_z = (double*)(base + oSqZ);
         f->sq_perm = (u64*)(base + oSqPerm);
@@ -691,6 +712,7 @@ int smc_filter_clone(smc_filter* src, smc_filter** out)
     rebase(a.cq); rebase(a.tq); rebase(a.cnt); rebase(a.spart); rebase(a.summ); rebase(a.params); rebase(a.y);
     rebase(a.mom); rebase(a.mpart); rebase(a.aux); rebase(a.info); rebase(a.hcnt); rebase(a.hlist); rebase(a.info2);
     rebase(a.su); rebase(a.E); rebase(a.sst); rebase(a.mvc); rebase(a.trace); rebase(a.pm2); rebase(a.ps2); rebase(a.pss2);
+    rebase(a.eta); rebase(a.lwsv);
     rebase(f->tmp); rebase(f->strict_ws); rebase(f->sq_z); rebase(f->sq_perm); rebase(f->sq_ws);
     hipStream_t st = ctx->stream;
     hipError_t e = hipMemcpyAsync(slab, src->slab, src->slab_bytes, hipMemcpyDeviceToDevice, st);
@@ -801,7 +823,7 @@ int smc_filter_step(smc_filter* f, int64_t nsteps)
     i64 todo = nsteps;
     if (f->t_host + todo > f->a.T) todo = f->a.T - f->t_host;
     if (todo < 0) todo = 0;
-    if (todo > 0 && f->fk == SMC_FK_APF && !small_filter_ok(f) && !f->a.pm2) {
+    if (todo > 0 && f->fk == SMC_FK_APF && f->kind != SMC_MODEL_MVLINGAUSS && !small_filter_ok(f) && !f->a.pm2) {
         smc_set_error("the auxiliary particle filter with N <= 1024 runs on the one-launch filter only (no "
                       "profiling, no Philox multinomial)");
         return SMC_ERR_STATE;
@@ -1514,6 +1536,7 @@ int smc_filter_describe(smc_filter* f, char* out, size_t n)
         else s = "k_prepare+k_ancestors";
         if (f->a.scheme == SMC_MULTINOMIAL && !f->a.ut)
             s = (f->a.sp_tpw ? "k_f_spacing_onepass+" : "k_f_spacing_sums+k_f_spacing_scan+k_f_spacing_write+") + s;
+        if (mv && f->fk == SMC_FK_APF) s = "k_mv_aux+k_mv_aux_restate+" + s;
         s += mv ? (f->mv_collapsed ? "+k_propagate_mv<collapsed>" : "+k_propagate_mv") : "+k_propagate";
         if (mv) s += " [mv_chunks=" + std::to_string(f->a.mv_chunks) + "]";
         if (f->a.mom) s += "+k_f_moments_partials+k_f_moments_final";

@@ -123,6 +123,8 @@ struct FArgs {
     double *pm2, *ps2, *pss2;   // APF on the two-level path: the tile partials of the PLAIN weights
                            // (pm/ps/pss, cq, tq then describe the AUXILIARY weights lw + logeta,
                            // which decide and drive the resampling -- core.py:307-313); else null
+    double *eta, *lwsv;    // APF of MVLINGAUSS (smc_filter_mv.h k_mv_aux): (n_islands, N) logeta of the step's
+                           // parents and their plain log-weights, set aside while lw + eta drives the resampling
 };
 
 __host__ __device__ __forceinline__ i64 f_slot(const FArgs& a, i64 t)

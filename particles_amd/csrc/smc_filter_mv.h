@@ -36,6 +36,13 @@
 // particles, nothing staged through LDS but the matrices themselves.
 // A wave keeps two 16-particle groups in flight so that every matrix fragment
 // read feeds two independent accumulator chains.
+// FK = SMC_FK_APF (AuxiliaryPF of the model, kalman.py:358-361): the guided filter above plus the auxiliary
+// weights of core.py:299-313.  logeta(t-1, x) = log p(y_t | x_{t-1} = x) = log N(y_t; G F x, S) is the collapsed
+// form's one product; k_mv_aux(t) evaluates it for the particles of step t-1 at the start of step t, leaves
+// eta and the plain log-weights aside and puts lw + eta in their place, k_mv_aux_restate redoes the island's
+// reduction, decision and normalisation on them (the resampling kernels then run unchanged), and the
+// propagate kernel resets a resampled particle's weight to log_mean_exp(eta, W) - eta[A] (the constant
+// travels in the step record) or restores the plain weight.
 // Philox normals follow the usual contract (pair kp of particle n -> dimensions
 // 2kp, 2kp+1; counter n*ceil(d/2)+kp): the two lanes that own the halves of a
 // pair each generate half of the pairs and swap the other element.
@@ -96,10 +103,12 @@ __global__ void __launch_bounds__(SMC_BLOCK)
 k_propagate_mv(const FArgs av, const double* __restrict__ C)
 {
     static_assert(!COLL || FK == SMC_FK_GUIDED, "the collapsed form is the guided filter's");
+    constexpr bool APF = FK == SMC_FK_APF;
+    constexpr bool GUIDED = FK == SMC_FK_GUIDED || APF;           // the optimal proposal
     constexpr int NV = DP / 4;                    // dimensions per lane
     constexpr int NJ = DP / 16;                   // 16-row blocks of a product
     constexpr int MM = DP * DP;
-    constexpr bool GUIDED3 = FK == SMC_FK_GUIDED && !COLL;        // the reference's three-term weight
+    constexpr bool GUIDED3 = GUIDED && !COLL;                     // the reference's three-term weight
     constexpr int NSLOT = GUIDED3 ? 5 : 3;
     constexpr int S_F = 0, S_B = COLL ? 0 : 1;
     constexpr int S_LZ = GUIDED3 ? 2 : 1;
@@ -142,7 +151,7 @@ k_propagate_mv(const FArgs av, const double* __restrict__ C)
         for (int i = tid; i < MM; i += SMC_BLOCK) {
             if (!first) {
                 if (!COLL) sM[S_F * MM + i] = C[MV_F * MM + i];
-                if (FK == SMC_FK_GUIDED) sM[S_B * MM + i] = C[MV_B * MM + i];
+                if (GUIDED) sM[S_B * MM + i] = C[MV_B * MM + i];
             }
             sM[S_LZ * MM + i] = C[m_lz * MM + i];
             if (GUIDED3) sM[S_XINV * MM + i] = C[m_xinv * MM + i];
@@ -151,8 +160,8 @@ k_propagate_mv(const FArgs av, const double* __restrict__ C)
         // per-lane reads of these vectors come from LDS: indexed by g from the constant
         // block they turn into scalar loads plus a select chain per element
         if (tid < DP) {
-            const double* mu = C + MV_VEC(DP) + (FK == SMC_FK_GUIDED ? DP : 0);
-            sVec[tid] = first ? mu[tid] : ((FK == SMC_FK_GUIDED) ? ky[tid] : 0.0);
+            const double* mu = C + MV_VEC(DP) + (GUIDED ? DP : 0);
+            sVec[tid] = first ? mu[tid] : (GUIDED ? ky[tid] : 0.0);
             sVec[DP + tid] = C[MV_VEC(DP) + tid];
             sVec[2 * DP + tid] = COLL ? ys[tid] : yw[tid];
         }
@@ -245,7 +254,7 @@ k_propagate_mv(const FArgs av, const double* __restrict__ C)
                 mv_product<DP, false>(sM + S_NGY * MM, v, am, lane);        // w
             }
         } else if (!first) {
-            if (FK == SMC_FK_GUIDED) {
+            if (GUIDED) {
                 mv_product<DP, false>(sM + S_F * MM, v, am, lane);          // m = F xp
                 mv_product<DP, false>(sM + S_B * MM, v, ax, lane);          // mu = B xp + K y
             } else {
@@ -364,7 +373,15 @@ k_propagate_mv(const FArgs av, const double* __restrict__ C)
                     inc = ((-0.5 * ku - scal[first ? 3 : 0]) + inc) - (-0.5 * kz - scal[first ? 4 : 2]);
                 if (COLL) inc = first ? scal[6] : -0.5 * kw - scal[5];         // log p(y_t | x_{t-1})
                 if (np < N) {
-                    double lw = (resample || first) ? inc : lwo[np] + inc;     // resampling.py:241-244
+                    double lw;
+                    if (APF && !first) {
+                        // core.py:299-305 reset_weights: log_mean_exp(logeta, W) - logeta[A] (the constant comes
+                        // with the record, k_mv_aux_restate); not resampled: the plain weight k_mv_aux set aside
+                        const double prev = resample ? smc_uniform(info[6]) - a.eta[(i64)isl * N + A[np]]
+                                                     : a.lwsv[(i64)isl * N + np];
+                        lw = prev + inc;
+                    } else
+                    lw = (resample || first) ? inc : lwo[np] + inc;            // resampling.py:241-244
                     if (lw != lw) lw = -INFINITY;                              // resampling.py:220
                     lwn[np] = lw;
                     smc_lse_push(lacc, lw);
@@ -373,6 +390,110 @@ k_propagate_mv(const FArgs av, const double* __restrict__ C)
         }
     }
     f_step_tail(a, isl, b, t, first, resample, smc_lse_block(lacc, smd), smd, s_last, info);
+}
+
+// ---- AuxiliaryPF (see the top): eta_i = logeta(t-1, X_{t-1,i}) with y_t, the auxiliary log-weights in place
+// of the plain ones (which wait in a.lwsv), the workgroup's log-sum-exp partial of them.  Same blocking as
+// the propagate kernel (nparts partials per island).
+template <int DP, bool DFULL>
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_mv_aux(const FArgs av, const double* __restrict__ C)
+{
+    constexpr int NV = DP / 4, NJ = DP / 16, MM = DP * DP;
+    const FArgs& a = av;
+    __shared__ double sM[MM];
+    __shared__ double sY[DP];
+    __shared__ double smd[SMC_SM];
+    const int b = (int)blockIdx.x, isl = (int)blockIdx.y, tid = (int)threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6, g = lane >> 4, pn = lane & 15;
+    const double* info = a.info + (i64)isl * INFO_STRIDE;
+    const i64 t = (i64)smc_uniform(info[0]);                  // the step about to run
+    if (t >= a.T || t == 0) return;
+    const i64 N = a.N;
+    const int d = a.dx;
+    const double* Xo = f_X(a, t - 1) + (i64)isl * N * d;
+    double* lw = f_lw(a, t - 1) + (i64)isl * N;
+    const double* ys = C + MV_STEP(DP) + (size_t)t * MV_NSTEPV * DP + 2 * DP;     // L_S^-1 y_t
+    const double cS = C[MV_SCAL(DP) + 5];
+    for (int i = tid; i < MM; i += SMC_BLOCK) sM[i] = C[MV_NGF * MM + i];
+    if (tid < DP) sY[tid] = ys[tid];
+    __syncthreads();
+    SmcLse lacc = smc_lse_empty();
+    double kw = 0.0;
+    const int nit = a.mv_chunks * 4;
+#pragma unroll 1
+    for (int it = 0; it < nit; ++it) {
+        const i64 n = ((i64)b * a.mv_chunks + it / 4) * SMC_BLOCK + (i64)wv * 64 + (i64)(it & 3) * 16 + pn;
+        const bool valid = n < N;
+        double v[1][NV];
+        smc_v4d acc[1][NJ];
+        const double* pr = Xo + (valid ? n : 0) * d;
+#pragma unroll
+        for (int kb = 0; kb < NV; ++kb) {
+            const int k = 4 * kb + g;
+            const bool kin = DFULL || k < d;
+            const double x = pr[kin ? k : 0];
+            v[0][kb] = (valid && kin) ? x : 0.0;
+        }
+#pragma unroll
+        for (int jb = 0; jb < NJ; ++jb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[0][jb][r] = sY[16 * jb + 4 * r + g];
+        mv_product<DP, false>(sM, v, acc, lane);                        // w = L_S^-1 (y_t - G F x)
+        double ww = 0.0;
+#pragma unroll
+        for (int jb = 0; jb < NJ; ++jb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ww = fma(acc[0][jb][r], acc[0][jb][r], ww);
+        ww = mv_sum_g(ww);
+        const int q = it & 3;
+        if (q == g) kw = ww;
+        if (q == 3) {                     // lane l now owns particle l of the wave's 64
+            const i64 np = ((i64)b * a.mv_chunks + it / 4) * SMC_BLOCK + (i64)wv * 64 + lane;
+            if (np < N) {
+                const double eta = -0.5 * kw - cS;                      // kalman.py:358-361
+                const double l = lw[np];
+                double la = l + eta;                                    // core.py:307-313 (Weights.add)
+                if (la != la) la = -INFINITY;
+                a.eta[(i64)isl * N + np] = eta;
+                a.lwsv[(i64)isl * N + np] = l;
+                lw[np] = la;
+                smc_lse_push(lacc, la);
+            }
+        }
+    }
+    const SmcLse r = smc_lse_block(lacc, smd);
+    if (tid == 0) {
+        const i64 o = (i64)isl * a.nparts;
+        a.pm[o + b] = r.m;
+        a.ps[o + b] = r.s;
+        a.pss[o + b] = r.ss;
+    }
+}
+// one workgroup per island: the auxiliary weights' (max, sum, sum of squares) -> ESS, the decision of step t
+// (fk.time_to_resample on aux.ESS, core.py:181-183), the normalisation the resampling kernels use and the
+// reset constant log_mean_exp(eta, W) = log-mean of the auxiliary weights - log-mean of the plain ones
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_mv_aux_restate(const FArgs av)
+{
+    const FArgs& a = av;
+    __shared__ double smd[SMC_SM];
+    const int isl = (int)blockIdx.x;
+    double* info = a.info + (i64)isl * INFO_STRIDE;
+    const i64 t = (i64)smc_uniform(info[0]);
+    if (t >= a.T || t == 0) return;
+    const i64 o = (i64)isl * a.nparts;
+    const SmcLse g = smc_lse_reduce_partials<true>(a.pm + o, a.ps + o, a.pss + o, a.nparts, smd);
+    if (threadIdx.x == 0) {
+        const bool bad = !(g.m > -INFINITY) || !(g.m < INFINITY);
+        const double ess = bad ? NAN : (g.s * g.s) / g.ss;
+        const double log_mean = bad ? NAN : g.m + log(g.s / (double)a.N);
+        const double* row = a.summ + ((i64)isl * (a.T + 1) + (t - 1)) * SUMM_STRIDE;
+        info[1] = (ess < a.ess_thresh) ? 1.0 : 0.0;
+        info[3] = g.m;
+        info[4] = bad ? NAN : 1.0 / g.s;
+        info[6] = log_mean - row[1];
+    }
 }
 
 // X_{t-1}[A] for SMC.Xp, (N,d)
@@ -500,7 +621,7 @@ inline bool mv_build_constants(const smc_model* m, int fk, int dp, i64 T, const 
     scal[3] = logdiag(L0, dx) + dx * SMC_HALFLOG2PI;
     for (int i = 0; i < dx; ++i) C[MV_VEC(dp) + i] = mu0[i];
     Mat K, K0, LSi;
-    if (fk == SMC_FK_GUIDED) {
+    if (fk == SMC_FK_GUIDED || fk == SMC_FK_APF) {
         Mat P, P0, LP, LP0;
         if (!gain(QX, G, R, dx, dy, K, P) || !gain(Q0, G, R, dx, dy, K0, P0)) return false;
         if (!chol(P, dx, LP) || !chol(P0, dx, LP0)) return false;
@@ -560,7 +681,7 @@ inline bool mv_build_constants(const smc_model* m, int fk, int dp, i64 T, const 
             for (int j = 0; j <= i; ++j) v += LYi[i * dy + j] * yt[j];
             yw[i] = v;
         }
-        if (fk == SMC_FK_GUIDED) {
+        if (fk == SMC_FK_GUIDED || fk == SMC_FK_APF) {
             for (int i = 0; i < dx; ++i) {
                 double v = 0.0;
                 for (int j = 0; j < dy; ++j) v += K[i * dy + j] * yt[j];

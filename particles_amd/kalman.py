@@ -64,12 +64,18 @@ class MVLinearGauss(ssms.StateSpaceModel):
         return dists.MvNormal(loc=self.mu0 + np.dot(data[0] - np.dot(self.mu0, self.G.T), K.T),
                               cov=fc)
 
+    def logeta(self, t, x, data):
+        """log p(y_{t+1} | x_t = x) = log N(y_{t+1}; G F x, G covX G' + covY)  (kalman.py:358-361: the
+        ``logpyt`` of ``filter_step`` on the one-step prediction from x)."""
+        S = self.G @ self.covX @ self.G.T + self.covY
+        return dists.MvNormal(loc=np.dot(np.dot(x, self.F.T), self.G.T), cov=S).logpdf(data[t + 1])
+
     def _device_params(self, fk_kind):
         if not (1 <= self.dy <= self.dx <= 32):      # k_propagate_mv's range; beyond: generic path
             return None
         return dict(kind=_lib.MODEL_MVLINGAUSS, dx=self.dx, dy=self.dy, params=None,
                     F=self.F, G=self.G, covX=self.covX, covY=self.covY,
-                    mu0=self.mu0, cov0=self.cov0)
+                    mu0=self.mu0, cov0=self.cov0, apf=True)
 
 
 class MVLinearGauss_Guarniero_etal(MVLinearGauss):

@@ -162,6 +162,9 @@ def main():
     out["lg_apf"] = run_case(kalman.LinearGauss(rho=0.9, sigmaX=1.0, sigmaY=0.6), ssm.AuxiliaryPF, 30, 500,
                              "systematic", 0.5)
     out["sv_guided"] = run_case(ssm.StochVol(), ssm.GuidedPF, 30, 500, "systematic", 0.5)
+    # AuxiliaryPF of the multivariate model (kalman.py:348-361: optimal proposal, logeta = log p(y_{t+1} | x_t))
+    out["mv_apf"] = run_case(kalman.MVLinearGauss_Guarniero_etal(alpha=0.4, dx=4), ssm.AuxiliaryPF, 16, 400,
+                             "systematic", 0.7)
 
     # --- full particle history + genealogy (smoothing.py:181-255), adaptive
     # resampling so that some A_t are arange ---------------------------------

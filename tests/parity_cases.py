@@ -1837,6 +1837,58 @@ def check_apf_lingauss(golden, big=((2048, "systematic", 0.7), (3000, "stratifie
     assert abs(np.mean(lls) - ll) < 0.1, (lls, ll)
 
 
+def check_apf_mv(golden, big=((3000, 8, "systematic", 0.7), (1 << 13, 32, "stratified", 0.8), (2048, 5, "multinomial", 0.9)),
+                 philox_N=4096):
+    """AuxiliaryPF of MVLinearGauss (kalman.py:348-361: optimal proposal, logeta = log p(y_{t+1} | x_t)) in the
+    fused loop (k_mv_aux + k_mv_aux_restate in front of the flat step, smc_filter_mv.h): the reference's own
+    run (fixture mv_apf, replayed draws) -- decisions, ESS and evidence to 1e-9, final ancestors, particles
+    and weights; larger N, d up to 32 and the three schemes against the oracle on the device's Q62
+    contract; the exact Kalman likelihood in Philox mode; what the fused loop refuses goes to the operators."""
+    g = golden("mv_apf")
+    y = list(g["y"])
+    N, scheme, ESSrmin = int(g["N"]), str(g["scheme"]), float(g["ESSrmin"])
+    np.random.seed(int(g["run_seed"]))
+    rec = orc.RecordingRNG()
+    o = orc.run_filter(orc.Guarniero(alpha=0.4, dx=4), y, N, scheme, ESSrmin, fk="apf", rng=rec, keep=True)
+    assert o["final_logLt"] == float(g["logLt"])                        # the oracle IS the reference run
+    z, u = tapes_from_oracle(rec.tape, len(y), N, scheme)
+    mk_d = lambda dx=4: kalman.MVLinearGauss_Guarniero_etal(alpha=0.4, dx=dx)
+    pf = pa.SMC(fk=ssm.AuxiliaryPF(ssm=mk_d(), data=y), N=N, resampling=scheme, ESSrmin=ESSrmin, replay=(z, u))
+    assert pf._fused and describe(pf).startswith("k_mv_aux+k_mv_aux_restate+"), describe(pf)
+    pf.run()
+    assert pf.summaries.rs_flags == [bool(v) for v in g["rs_flags"]] and any(pf.summaries.rs_flags)
+    assert not all(pf.summaries.rs_flags[1:])                           # both branches of the weight reset
+    assert rel(pf.summaries.ESSs, g["ESSs"]) < 1e-9 and rel(pf.summaries.logLts, g["logLts"]) < 1e-9
+    assert np.mean(pf.A == g["A"]) >= 0.999
+    if np.array_equal(pf.A, g["A"]):
+        assert np.max(np.abs(pf.X - g["X"])) < 1e-11
+        assert np.allclose(pf.wgts.lw, g["lw"], rtol=1e-10, atol=1e-10) and rel(pf.W, g["W"]) < 1e-9
+    for N2, d, sch, essr in big:
+        rng = np.random.RandomState(d)
+        y2 = [rng.standard_normal(d) for _ in range(7)]
+        np.random.seed(3 + N2)
+        rec = orc.RecordingRNG()
+        o = orc.run_filter(orc.Guarniero(alpha=0.4, dx=d), y2, N2, sch, essr, fk="apf", rng=rec, keep=True, cdf="q62")
+        z, u = tapes_from_oracle(rec.tape, len(y2), N2, sch)
+        pf = pa.SMC(fk=ssm.AuxiliaryPF(ssm=mk_d(d), data=y2), N=N2, resampling=sch, ESSrmin=essr, replay=(z, u),
+                    n_islands=1)
+        assert pf._fused and "k_mv_aux" in describe(pf)
+        pf.run()
+        assert pf.summaries.rs_flags == o["rs_flag"] and sum(o["rs_flag"]) >= 1
+        assert rel(pf.summaries.ESSs, o["ESS"]) < 1e-9 and rel(pf.summaries.logLts, o["logLt"]) < 1e-9
+        assert np.array_equal(pf.A, o["A"]), int(np.sum(pf.A != o["A"]))
+        assert np.max(np.abs(pf.X - o["X"])) < 1e-10 and np.allclose(pf.wgts.lw, o["lw"], rtol=1e-9, atol=1e-9)
+    # Philox mode, islands: unbiased likelihood against Kalman's
+    mo = orc.Guarniero(alpha=0.4, dx=4)
+    ll, _ = orc.kalman_loglik(mo, y)
+    pf = pa.SMC(fk=ssm.AuxiliaryPF(ssm=mk_d(), data=y), N=philox_N, seed=71, n_islands=4, collect="off")
+    pf.run()
+    lls = pf.logLts_islands
+    assert abs(np.mean(lls) - ll) < 0.15 and np.std(lls) < 0.3, (lls, ll)
+    # history slots and device moments: the operator path
+    assert not pa.SMC(fk=ssm.AuxiliaryPF(ssm=mk_d(), data=y), N=500, store_history=True)._fused
+
+
 def check_resident_user_model(golden):
     """A user-defined model written with numpy expressions (here Gordon et al's, transcribed
     from state_space_models.py:546-577, and StochVol's) run through the template-method step

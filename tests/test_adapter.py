@@ -163,6 +163,19 @@ def test_reference_apf_runs_fused_through_the_adapter(ref):
     assert got[1000]._fused and describe(got[1000]) == "k_filter_small"
     assert got[2048]._fused and describe(got[2048]) == "k_reduce2+k_ancestors2+k_propagate"
     assert got[3000]._fused and describe(got[3000]) == "k_reduce2+k_ancestors2+k_propagate"
+    # ... and of the stock MVLinearGauss (kalman.py:348-361): the auxiliary weights in front of the flat step
+    rk = ref["kalman"] if "kalman" in ref else __import__("particles.kalman", fromlist=["kalman"])
+    model = rk.MVLinearGauss_Guarniero_etal(alpha=0.4, dx=3)
+    np.random.seed(2)
+    x, ymv = model.simulate(12)
+    fk = rssm.AuxiliaryPF(ssm=model, data=ymv)
+    np.random.seed(6)
+    want = particles.SMC(fk=fk, N=2000)
+    want.run()
+    pf = HipSMC(fk=fk, N=2000, seed=9)
+    assert isinstance(pf, pa.SMC) and pf._fused and describe(pf).startswith("k_mv_aux+k_mv_aux_restate+")
+    pf.run()
+    assert abs(pf.logLt - want.logLt) < 0.5, (pf.logLt, want.logLt)
 
 
 def test_deepcopy_clones_the_device_filter(ref):

@@ -273,6 +273,10 @@ def test_apf_lingauss_fused(golden):
     pc.check_apf_lingauss(golden)
 
 
+def test_apf_mvlingauss_fused(golden):
+    pc.check_apf_mv(golden, big=((3000, 8, "systematic", 0.7), (2048, 5, "multinomial", 0.9)), philox_N=2048)
+
+
 def test_device_sort():
     pc.check_device_sort(sizes=(1, 63, 64, 2047, 2048, 2049, 9001))
 

@@ -505,6 +505,11 @@ def test_apf_lingauss_fused(golden):
     pc.check_apf_lingauss(golden)
 
 
+def test_apf_mvlingauss_fused(golden):
+    pc.check_apf_mv(golden, big=((3000, 8, "systematic", 0.7), (1 << 13, 32, "stratified", 0.8), (2048, 5, "multinomial", 0.9),
+                                 (1 << 17, 32, "systematic", 0.7), (1 << 19, 16, "systematic", 0.7)))
+
+
 def test_device_sort():
     pc.check_device_sort(sizes=(1, 64, 2049, 50001, (1 << 20) + 3, 1 << 22))
 
