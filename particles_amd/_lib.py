@@ -54,7 +54,8 @@ FLAG_SQMC = 4
 PATH_FLAGS = {"SMC_FLAT_CDF": 1 << 8, "SMC_TWO_LEVEL_MID": 1 << 9, "SMC_EXACT_COUNTS": 1 << 10,
               "SMC_FORCE_FUSED": 1 << 11, "SMC_FORCE_UNFUSED": 1 << 12, "SMC_NO_SMALL": 1 << 13,
               "SMC_NO_NT": 1 << 14, "SMC_NO_HEAVY": 1 << 15, "SMC_NO_TK": 1 << 16,
-              "SMC_FLAT_MULTINOMIAL": 1 << 17, "SMC_POW2_ONLY": 1 << 18, "SMC_SPACING_3PASS": 1 << 19}
+              "SMC_FLAT_MULTINOMIAL": 1 << 17, "SMC_POW2_ONLY": 1 << 18, "SMC_SPACING_3PASS": 1 << 19,
+              "SMC_SPLIT_REDUCE": 1 << 24}
 
 
 def path_flags():
@@ -62,6 +63,9 @@ def path_flags():
     for name, bit in PATH_FLAGS.items():
         if os.environ.get(name):
             f |= bit
+    tp = os.environ.get("SMC_SP_TPW")
+    if tp and int(tp) in (1, 2, 4, 8):
+        f |= int(tp) << 25
     mv = os.environ.get("SMC_MV_CHUNKS")
     if mv and int(mv) in (1, 2, 4, 8):
         f |= int(mv) << 20

@@ -32,6 +32,8 @@ struct smc_filter {
     double* strict_ws;     // (n_islands, N) W -> S
     // SMC_FLAG_SQMC (smc_filter_sqmc.h): the point stream, the tape of ndtri(second coordinate), the
     // sort's workspace and -- more than one island -- the islands' permutations
+    u64 sp_epoch;          // launches of the merged spacings + reduction kernel so far (see FArgs::sp_epoch)
+    bool sp_merge;
     bool sqmc;
     u64 sq_seed, sq_ctr0;
     double* sq_z;
@@ -189,13 +191,16 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
     }
     if (f->two_level) {
         if (f->two_level_mid && f->a.scheme == SMC_MULTINOMIAL) {
-            SMC_LAUNCH(k_reduce2, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
+            // (the island's reduction: a launch of its own, or workgroup 0 of the one-pass spacings kernel)
+            const bool merge = f->sp_merge && !f->a.ut && f->a.sp_tpw && t_known;
+            f->a.sp_epoch = merge ? ++f->sp_epoch : 0ull;
+            if (!merge) SMC_LAUNCH(k_reduce2, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
             if (!f->a.ut) {
                 // production mode: uniform_spacings in two passes over the same draws (tile sums, their
                 // prefixes, the uniforms written once); k_ancestors2 finds its window through the prefixes
                 const dim3 g1(f->a.ntiles1, f->a.n_islands);
                 if (f->a.sp_tpw) {                 // one pass (decoupled look-back): every workgroup resident
-                    const dim3 gw(f->a.sp_nwg, f->a.n_islands);
+                    const dim3 gw(f->a.sp_nwg + (merge ? 1 : 0), f->a.n_islands);
                     switch (f->a.sp_tpw) {
                     case 1: SMC_LAUNCH(k_f_spacing_onepass<1>, gw, dim3(SMC_BLOCK), st, f->a); break;
                     case 2: SMC_LAUNCH(k_f_spacing_onepass<2>, gw, dim3(SMC_BLOCK), st, f->a); break;
@@ -476,8 +481,11 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     // the fewest that keep the whole launch resident (<= 1024 workgroups: half of what the chip holds);
     // more islands than that: the three-pass form
     a.sp_tpw = a.sp_nwg = 0;
+    bool merge_fits = false;
     if (need_su && f->two_level && !f->strict && !f->sqmc && !(o->flags & SMC_PATH_SPACING_3PASS))
         for (int tpw = 1; tpw <= 8 && !a.sp_tpw; tpw *= 2) {
+            const int forced_tpw = (o->flags >> 25) & 15;          // SMC_PATH_SP_TPW (A/B: workgroups wait for
+            if (forced_tpw && tpw != forced_tpw) continue;         //  lower-numbered ones only, dispatch is in order)
             const i64 nwg = (a.ntiles + tpw - 1) / tpw;
             int per_cu = 0;                        // workgroups of this instantiation a CU holds at once
 #ifdef SMC_EMULATE
@@ -494,9 +502,24 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
 #else
             const i64 cap = (i64)(per_cu > 1 ? per_cu - 1 : 0) * ctx->n_cu;
 #endif
-            if (nwg * (i64)M <= cap && nwg * (i64)M <= 1024) { a.sp_tpw = tpw; a.sp_nwg = (int)nwg; }
+            if ((nwg * (i64)M <= cap && nwg * (i64)M <= 1024) || (forced_tpw && nwg <= 1024)) {
+                a.sp_tpw = tpw;
+                a.sp_nwg = (int)nwg;
+                // one workgroup more per island when the reduction rides along (see sp_merge): it is the first
+                // of the launch and waits for nobody, the others wait for lower-numbered ones only -- dispatch is
+                // in order, so the margin kept above is not needed for it, the chip's nominal capacity is
+#ifdef SMC_EMULATE
+                merge_fits = true;
+#else
+                merge_fits = (nwg + 1) * (i64)M <= (i64)per_cu * ctx->n_cu || forced_tpw;
+#endif
+            }
         }
     const size_t oSst = carve(a.sp_tpw ? M * a.sp_nwg * 8 : 8);
+    const size_t oSdec = carve(M * 8);
+    f->sp_epoch = 0;
+    // (inside a replayed graph the argument block -- the epoch with it -- is frozen: separate launches there)
+    f->sp_merge = a.sp_tpw && merge_fits && !o->use_graph && !(o->flags & SMC_PATH_SPLIT_REDUCE);
     const size_t oTmp = carve(N * dxm * 8);
     const size_t oStrict = carve(f->strict ? M * N * 8 : 8);
     if (f->sqmc && !f->two_level) {
@@ -575,6 +598,8 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     a.E = (u64*)(base + oE);
     a.sst = (u64*)(base + oSst);
     if (a.sp_tpw) F_CREATE_CHECK(hipMemsetAsync(a.sst, 0, M * a.sp_nwg * 8, ctx->stream));
+    a.sdec = (u64*)(base + oSdec);
+    F_CREATE_CHECK(hipMemsetAsync(a.sdec, 0, M * 8, ctx->stream));
     f->tmp = (double*)(base + oTmp);
     f->strict_ws = (double*)(base + oStrict);
     if (apf_mv) {
@@ -712,7 +737,7 @@ int smc_filter_clone(smc_filter* src, smc_filter** out)
     rebase(a.cq); rebase(a.tq); rebase(a.cnt); rebase(a.spart); rebase(a.summ); rebase(a.params); rebase(a.y);
     rebase(a.mom); rebase(a.mpart); rebase(a.aux); rebase(a.info); rebase(a.hcnt); rebase(a.hlist); rebase(a.info2);
     rebase(a.su); rebase(a.E); rebase(a.sst); rebase(a.mvc); rebase(a.trace); rebase(a.pm2); rebase(a.ps2); rebase(a.pss2);
-    rebase(a.eta); rebase(a.lwsv);
+    rebase(a.eta); rebase(a.lwsv); rebase(a.sdec);
     rebase(f->tmp); rebase(f->strict_ws); rebase(f->sq_z); rebase(f->sq_perm); rebase(f->sq_ws);
     hipStream_t st = ctx->stream;
     hipError_t e = hipMemcpyAsync(slab, src->slab, src->slab_bytes, hipMemcpyDeviceToDevice, st);
@@ -1536,6 +1561,10 @@ int smc_filter_describe(smc_filter* f, char* out, size_t n)
         else s = "k_prepare+k_ancestors";
         if (f->a.scheme == SMC_MULTINOMIAL && !f->a.ut)
             s = (f->a.sp_tpw ? "k_f_spacing_onepass+" : "k_f_spacing_sums+k_f_spacing_scan+k_f_spacing_write+") + s;
+        if (f->sp_merge && f->a.scheme == SMC_MULTINOMIAL && !f->a.ut && f->two_level_mid) {
+            const size_t p = s.find("+k_reduce2");
+            if (p != std::string::npos) s.replace(0, p + 10, "k_f_spacing_onepass<with k_reduce2>");
+        }
         if (mv && f->fk == SMC_FK_APF) s = "k_mv_aux+k_mv_aux_restate+" + s;
         s += mv ? (f->mv_collapsed ? "+k_propagate_mv<collapsed>" : "+k_propagate_mv") : "+k_propagate";
         if (mv) s += " [mv_chunks=" + std::to_string(f->a.mv_chunks) + "]";

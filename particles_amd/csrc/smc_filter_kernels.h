@@ -123,6 +123,8 @@ struct FArgs {
     double *pm2, *ps2, *pss2;   // APF on the two-level path: the tile partials of the PLAIN weights
                            // (pm/ps/pss, cq, tq then describe the AUXILIARY weights lw + logeta,
                            // which decide and drive the resampling -- core.py:307-313); else null
+    u64* sdec;             // one-pass uniform_spacings with the island's reduction as its workgroup 0 (sp_epoch != 0):
+    u64 sp_epoch;          // (n_islands) decision words, (epoch << 2) | 2 resample, | 1 not; epoch: unique per launch
     double *eta, *lwsv;    // APF of MVLINGAUSS (smc_filter_mv.h k_mv_aux): (n_islands, N) logeta of the step's
                            // parents and their plain log-weights, set aside while lw + eta drives the resampling
 };
@@ -229,9 +231,13 @@ __device__ __forceinline__ double m_obs_logpdf(const double* p, double y, double
         const double v = (y - p[5] * (x * x)) / 1.0;
         return -(v * v) / 2.0 - SMC_C_NORM - 0.0;
     }
-    const double sc = exp(0.5 * x);                             // ssm.py:472-473
-    const double v = (y - 0.0) / sc;
-    return -(v * v) / 2.0 - SMC_C_NORM - log(sc);
+    // StochVol, ssm.py:472-473: Normal(loc=0, scale=exp(x / 2)).logpdf(y) = -v^2 / 2 - log sqrt(2 pi) - log(scale),
+    // v = y / scale.  scipy forms scale, divides by it and takes its log; here log(exp(h)) is h itself and the
+    // quotient is y exp(-h): one exp instead of exp + division + log (a quarter of k_propagate's arithmetic for
+    // this model), the same value to within the 1-2 ulp of either route (tests: 1e-12 on the log-weights).
+    const double h = 0.5 * x;
+    const double v = y * exp(-h);
+    return -(v * v) / 2.0 - SMC_C_NORM - h;
 }
 __device__ __forceinline__ double m_norm_logpdf(double x, double loc, double scale, double rscale,
                                                 double lscale)
@@ -570,6 +576,11 @@ k_f_spacing_write(const FArgs av)
 // workgroup can then never keep the one it waits for off the chip, whatever the dispatch order; the
 // spin is bounded all the same.  (3 waves per SIMD at least: 170 VGPRs for the 32 draws of a thread.)
 #define SP_FLAG_AGG 1ull
+// a.sp_epoch != 0: the launch carries one workgroup more per island -- workgroup 0 is k_reduce2 (the island's
+// reduction, the decision of step t, the tiles' shares), the others draw while it works and look at its
+// decision before they publish anything: the 9 us of a one-workgroup launch on the critical path of
+// every multinomial step (4096 tiles) disappear behind the 4 M logarithms.
+__device__ __forceinline__ int f2_reduce2_island(const FArgs& a, const int isl, double* smd, double* sme);
 template <int TPW>
 __global__ void __launch_bounds__(SMC_BLOCK)
 #ifndef SMC_EMULATE
@@ -586,13 +597,27 @@ k_f_spacing_onepass(const FArgs av)
     __shared__ u64 s_w[TPW][SMC_NWAVE];
     __shared__ u64 s_pre;
     SMC_NTAB_LDS(s_ntab);
-    const int w = (int)blockIdx.x, isl = (int)blockIdx.y;
+    const bool merged = a.sp_epoch != 0ull;
+    const int isl = (int)blockIdx.y;
     const int tid = (int)threadIdx.x, lane = smc_lane(), wave = smc_wave();
+    if (merged && blockIdx.x == 0) {
+        __shared__ double smd[SMC_SM];
+        __shared__ double sme[SMC_SM];
+        const int dec = f2_reduce2_island(a, isl, smd, sme);
+        __syncthreads();
+        if (tid == 0) {
+            smc_drain_stores();
+            smc_st_agent(a.sdec + isl, (a.sp_epoch << 2) | (dec == 1 ? 2ull : 1ull));
+        }
+        return;
+    }
+    const int w = (int)blockIdx.x - (merged ? 1 : 0);
     smc_ntab_stage<SMC_BLOCK>(s_ntab, tid);
     __syncthreads();
-    const double* info = a.info + (i64)isl * INFO_STRIDE;
+    // (merged: the record is being written by workgroup 0 -- the count of steps done is k_propagate's)
+    const double* info = merged ? a.info2 + (i64)isl * INFO_STRIDE : a.info + (i64)isl * INFO_STRIDE;
     const i64 t = (i64)smc_uniform(info[0]);
-    if (t >= a.T || t == 0 || smc_uniform(info[1]) == 0.0) return;
+    if (t >= a.T || t == 0 || (!merged && smc_uniform(info[1]) == 0.0)) return;
     const u32 gisl = (u32)(a.island_offset + isl);
     u64* st = a.sst + (i64)isl * a.sp_nwg;
     u64* E = a.E + (i64)isl * (a.ntiles1 + 1);
@@ -634,6 +659,20 @@ k_f_spacing_onepass(const FArgs av)
             total += s_w[r][v];
         }
         base[r] = b + inc[r] - (q[r][0] + q[r][1] + q[r][2] + q[r][3]);
+    }
+    if (merged) {                                  // the decision of step t (workgroup 0, long done by now)
+        if (tid == 0) {
+            u64 word = smc_ld_agent(a.sdec + isl);
+            for (int spin = 0; (word >> 2) != a.sp_epoch && spin < (1 << 24); ++spin) {
+                smc_spin_pause();
+                word = smc_ld_agent(a.sdec + isl);
+            }
+            s_pre = word;
+        }
+        __syncthreads();
+        const u64 word = s_pre;
+        __syncthreads();
+        if ((word >> 2) != a.sp_epoch || (word & 3ull) != 2ull) return;
     }
     // ---- publish my total; the prefix = the totals of ALL workgroups before me (<= 1024 of them: up to 4
     // per thread, every load in flight at once -- the workgroups generate side by side and publish within
@@ -1780,6 +1819,28 @@ __device__ __forceinline__ i64 f2_regen_tiles_le_wave(const F2Regen& g, const u6
     }
     return lo;
 }
+// The same answer from a window of 64 tile prefixes that was requested BEFORE C was known (k_ancestors2 asks for
+// the prefixes around its own tile index with its first loads: the tile shares deviate from 1 / ntiles by a few
+// per cent, the window covers +- 32 tiles) -- when it brackets C the probe costs no round trip of its own.
+// Ek: prefix w0 + lane (any value beyond the table).  Returns the count, or -1: not bracketed, probe again.
+__device__ __forceinline__ i64 f2_regen_tiles_le_spec(const F2Regen& g, const u64 C, const i64 w0, const u64 Ek,
+                                                      u64& Bl, u64& Bh)
+{
+    const i64 M = (i64)g.ntiles1 + 1;
+    const int lane = smc_lane();
+    const i64 k = w0 + lane;
+    const bool in = k < M;
+    const u64 Bk = in ? f2_t52(smc_div_c((double)Ek, g.dall, g.rdall)) : ~0ull;
+    const bool le = in && Bk <= C;
+    const int cnt = (int)smc_wave_sum_u64(le ? 1ull : 0ull);
+    const int nprobe = (int)(M - w0 < 64 ? M - w0 : 64);
+    if (cnt > 0 && cnt < nprobe) {
+        Bl = smc_readlane64(Bk, cnt - 1);
+        Bh = smc_readlane64(Bk, cnt);
+        return w0 + cnt;
+    }
+    return -1;
+}
 // #{ i < n : T[i] <= C } in a sorted LDS window of integer-valued doubles
 __device__ __forceinline__ int f2_count_lds_f64(const double* T, const int n, const double C)
 {
@@ -1964,20 +2025,19 @@ __device__ __forceinline__ F2Red f2_reduce_island_cached(const FArgs& a, const i
 
 // k_reduce2(t): one workgroup per island reduces the partials of step t-1, decides step t,
 // writes the record, the summary row and every tile's (G_b, Q_b) (integer-valued doubles)
-__global__ void __launch_bounds__(SMC_BLOCK)
-k_reduce2(const FArgs av)
+// (a function of the island: k_reduce2 is one launch of it per step; the one-pass spacings kernel of the
+//  multinomial scheme runs it as ITS workgroup 0, side by side with the workgroups that draw.)
+// Returns -1: no step to run (t = 0, or the filter is past T / frozen), 0: step t does not resample, 1: it does.
+__device__ __forceinline__ int f2_reduce2_island(const FArgs& a, const int isl, double* smd, double* sme)
 {
-    const FArgs& a = av;
-    __shared__ double smd[SMC_SM];
-    __shared__ double sme[SMC_SM];
-    const int isl = (int)blockIdx.x, tid = (int)threadIdx.x;
+    const int tid = (int)threadIdx.x;
     double* info = a.info + (i64)isl * INFO_STRIDE;
     const i64 t = (i64)smc_uniform(smc_ldg(a.info2 + (i64)isl * INFO_STRIDE));
     if (t >= a.T) {
         if (tid == 0) info[0] = (double)t;
-        return;
+        return -1;
     }
-    if (t == 0) return;
+    if (t == 0) return -1;
     const i64 o = (i64)isl * a.nparts;
     const bool pvec = (a.nparts & 3) == 0;
     const int nchunks = (a.nparts + 4 * SMC_BLOCK - 1) / (4 * SMC_BLOCK);
@@ -1994,7 +2054,7 @@ k_reduce2(const FArgs av)
         } else if (tid == 0) {
             f2_write_record(a, isl, t, r, resample);
         }
-        if (!resample) return;
+        if (!resample) return 0;
         double carry = 0.0;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -2015,7 +2075,7 @@ k_reduce2(const FArgs av)
                 if (i0 + k < a.nparts) { G[i0 + k] = g; Q[i0 + k] = Q4[k]; g += Q4[k]; }
             carry += tot;
         }
-        return;
+        return 1;
     }
     const F2Red r = f2_reduce_island(a, isl, smd);
     const bool resample = r.ess < a.ess_thresh;
@@ -2025,7 +2085,7 @@ k_reduce2(const FArgs av)
     } else if (tid == 0) {
         f2_write_record(a, isl, t, r, resample);
     }
-    if (!resample) return;
+    if (!resample) return 0;
     // every tile's share and the shares before it, chunk by chunk (a running carry across chunks)
     double carry = 0.0;
     for (int c = 0; c < nchunks; ++c) {
@@ -2048,7 +2108,16 @@ k_reduce2(const FArgs av)
             if (i0 + k < a.nparts) { G[i0 + k] = g; Q[i0 + k] = Q4[k]; g += Q4[k]; }
         carry += tot;
     }
+    return 1;
 }
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_reduce2(const FArgs av)
+{
+    __shared__ double smd[SMC_SM];
+    __shared__ double sme[SMC_SM];
+    (void)f2_reduce2_island(av, (int)blockIdx.x, smd, sme);
+}
+
 
 // ---------------------------------------------------------------------------
 // k_ancestors2(t): one workgroup per tile of 1024 parents.  No exp, no division per particle:
@@ -2101,6 +2170,19 @@ k_ancestors2(const FArgs av)
     smc_ld2g(cq + jt + 2, cx[2], cx[3]);
     cx[4] = (tid < SMC_BLOCK - 1) ? smc_ldg(cq + jt + 4) : 0ull;
     const u64 tb_raw = smc_ldg(a.tq + o + b);
+    // (REGEN) the spacings' total and the tile prefixes around this tile, requested with the first loads
+    u64 spec_all = 0ull, spec_E = 0ull;
+    i64 spec_w0 = 0;
+    if (REGEN) {
+        const u64* Eb = a.E + (i64)isl * (a.ntiles1 + 1);
+        const i64 M1 = (i64)a.ntiles1 + 1;
+        spec_all = smc_ldg(Eb + a.ntiles1);
+        spec_w0 = (i64)b - 32;
+        spec_w0 = spec_w0 > M1 - 64 ? M1 - 64 : spec_w0;
+        spec_w0 = spec_w0 < 0 ? 0 : spec_w0;
+        const i64 ks = spec_w0 + lane;
+        spec_E = smc_ldg(Eb + (ks < M1 ? ks : M1 - 1));
+    }
     if (!MID) {
         const bool pvec = (a.nparts & 3) == 0;
         f_load4<double>(a.pm + o, (i64)tid * 4, a.nparts, pvec, -INFINITY, pm4);
@@ -2193,7 +2275,7 @@ k_ancestors2(const FArgs av)
         F2Regen g;
         g.E = a.E + (i64)isl * (a.ntiles1 + 1);
         g.ntiles1 = a.ntiles1;
-        g.dall = (double)smc_uniform_u64(smc_ldg(g.E + a.ntiles1));
+        g.dall = (double)smc_uniform_u64(spec_all);
         g.rdall = 1.0 / g.dall;
         // ---- the tiles of draws the tile's two ends fall into (one wave per end, one probe each) and,
         // by interpolation between the tile's first and last threshold, where in them
@@ -2201,7 +2283,9 @@ k_ancestors2(const FArgs av)
         if (wave < 2) {
             const u64 C = wave == 0 ? Gb : Gb + Qb;
             u64 Bl, Bh;
-            const i64 v = f2_regen_tiles_le_wave(g, C, (i64)((double)C * per52), Bl, Bh) - 1;
+            i64 v = f2_regen_tiles_le_spec(g, C, spec_w0, spec_E, Bl, Bh);
+            if (v < 0) v = f2_regen_tiles_le_wave(g, C, (i64)((double)C * per52), Bl, Bh);
+            v -= 1;
             if (lane == 0) { s_k[wave] = v; s_b[2 * wave] = (double)Bl; s_b[2 * wave + 1] = (double)(Bh == ~0ull ? Bl + 1ull : Bh); }
         }
         __syncthreads();

@@ -990,8 +990,9 @@ def check_describe():
     assert kernels(3000) == "k_ancestors2+k_propagate"                         # any N of >= 2 tiles: general counts
     assert kernels(1500) == "k_ancestors2+k_propagate"                         # (2 tiles, the second ragged)
     assert kernels(1 << 12, "multinomial") == \
-        "k_f_spacing_onepass+k_reduce2+k_ancestors2+k_propagate"   # two-level: one-pass spacings, counts by search
-    assert kernels(1500, "multinomial") == "k_f_spacing_onepass+k_reduce2+k_ancestors2+k_propagate"
+        "k_f_spacing_onepass<with k_reduce2>+k_ancestors2+k_propagate"   # two-level: one-pass spacings (the island's
+    #                                                                   reduction is their workgroup 0), counts by search
+    assert kernels(1500, "multinomial") == "k_f_spacing_onepass<with k_reduce2>+k_ancestors2+k_propagate"
     mv = kalman.MVLinearGauss_Guarniero_etal(alpha=0.4, dx=4)
     ymv = [np.zeros((1, 4)) for _ in range(4)]
     pf = pa.SMC(fk=ssm.Bootstrap(ssm=mv, data=ymv), N=1 << 12, seed=1)
@@ -1107,6 +1108,32 @@ def check_unfused_path(golden, monkeypatch):
     # same particles; the evidence is summed in (p, k) pairs on the two-level step and against the
     # maximum on the flat one: equal up to the rounding of a sum of N terms
     assert np.array_equal(a.X, b.X) and np.allclose(a.logLts_islands, b.logLts_islands, rtol=1e-13, atol=0)
+
+
+def check_merged_reduce_ab(golden, monkeypatch, sizes=(4096, 3000), T=25):
+    """Multinomial on the two-level step: the island's reduction as workgroup 0 of the one-pass spacings
+    kernel (default) and as a launch of its own (SMC_PATH_SPLIT_REDUCE) are the same run bit for bit --
+    adaptive resampling (steps that resample and steps that do not: the draws made side by side with the
+    reduction are then dropped), islands, SMC^2's frozen batches."""
+    g = golden("kalman_toy")
+    y = [np.atleast_1d(v) for v in np.squeeze(g["y"])][:T]
+    for N in sizes:
+        runs = []
+        for split in (False, True):
+            if split:
+                monkeypatch.setenv("SMC_SPLIT_REDUCE", "1")
+            pf = pa.SMC(fk=ssm.Bootstrap(ssm=kalman.LinearGauss(rho=0.9, sigmaX=1.0, sigmaY=1.5), data=y), N=N,
+                        resampling="multinomial", ESSrmin=0.5, seed=21, n_islands=3, collect="off")
+            assert ("<with k_reduce2>" in describe(pf)) == (not split), describe(pf)
+            pf.step_async(T // 2)
+            pf.run()
+            flags = pf._summ()[:, :, 4]
+            runs.append((np.array(pf.X), np.array(pf.A), pf.logLts_islands.copy(), flags.copy()))
+            if split:
+                monkeypatch.delenv("SMC_SPLIT_REDUCE")
+        assert 0 < runs[0][3][:, 1:].mean() < 1                     # both kinds of step occurred
+        for a, b in zip(runs[0], runs[1]):
+            assert np.array_equal(a, b)
 
 
 def check_small_filter_equals_general(golden, monkeypatch, full=True):
@@ -2269,7 +2296,9 @@ def check_sqmc_fused(sizes=(2048, 4096), T=6, audit_sizes=(4096,), islands_N=204
                     (Xa, Aa, la, La), (Xb, Ab, lb, Lb) = runs[0][t], runs[1][t]
                     if Aa is not None and not np.array_equal(Aa, Ab):
                         break                 # a near-tie between the two exact CDFs: the audit below decides
-                    assert np.array_equal(Xa, Xb) and np.array_equal(la, lb), (name, N, t)
+                    # (StochVol: the fused kernels form log N(y; 0, e^{x/2}) with one exp, the operators as scipy does)
+                    assert np.array_equal(Xa, Xb), (name, N, t)
+                    assert np.array_equal(la, lb) if name != "sv" else np.allclose(la, lb, rtol=1e-13, atol=1e-13), (name, N, t)
                     assert abs(La - Lb) < 1e-12 * max(1.0, abs(La)), (name, N, t)
                 else:
                     t = T

@@ -269,6 +269,10 @@ def test_strict_ancestors_equal_the_reference_cdf():
     pc.check_strict_ancestors(sizes=(3000,), op_N=5000, op_cases=8)
 
 
+def test_merged_reduce_equals_split(golden, monkeypatch):
+    pc.check_merged_reduce_ab(golden, monkeypatch, sizes=(4096, 3000))
+
+
 def test_apf_lingauss_fused(golden):
     pc.check_apf_lingauss(golden)
 

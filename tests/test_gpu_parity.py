@@ -501,6 +501,10 @@ def test_strict_ancestors_equal_the_reference_cdf():
     pc.check_strict_ancestors(sizes=(3000, 1 << 17), op_N=1 << 20, op_cases=100)
 
 
+def test_merged_reduce_equals_split(golden, monkeypatch):
+    pc.check_merged_reduce_ab(golden, monkeypatch, sizes=(4096, 3000, 1 << 20))
+
+
 def test_apf_lingauss_fused(golden):
     pc.check_apf_lingauss(golden)
 
