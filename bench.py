@@ -253,7 +253,7 @@ def _cpu_name():
 # ----------------------------------------------------------------------------------------------
 # workloads (BASELINE.json configs)
 # ----------------------------------------------------------------------------------------------
-def make_workload(name, T, scheme="systematic", log2N=None, N=0, islands=1, essrmin=None, collapsed=False):
+def make_workload(name, T, scheme="systematic", log2N=None, N=0, islands=1, essrmin=None, collapsed=False, qmc=False):
     from particles_amd import kalman
     from particles_amd import state_space_models as ssm
     d = 1
@@ -288,17 +288,28 @@ def make_workload(name, T, scheme="systematic", log2N=None, N=0, islands=1, essr
         fk = ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=synthetic_data(T))
         label = "C2: ToySSM d=1 linear-Gaussian bootstrap filter" if name == "c2" else \
                 "C5: ToySSM d=1 bootstrap filter islands"
+        if qmc:               # SMC(qmc=True) on C2's model and size (core.py:339-349), the fused SQMC step
+            label = "SQMC (Sobol' points, sort, inverse CDF, ppf moves) on C2's model"
     return {"name": name, "fk": fk, "N": N if N > 0 else 1 << log2N, "log2N": log2N, "Nlabel": str(N) if N > 0 else "2^%d" % log2N,
             "islands": islands, "scheme": scheme, "essrmin": 0.5 if essrmin is None else essrmin, "d": d,
-            "label": label, "collapsed": collapsed, "guided": name == "c4"}
+            "label": label, "collapsed": collapsed, "guided": name == "c4", "qmc": qmc}
 
 
 def make_filter(wl, rank=0, graph=False, profile=False):
     import particles_amd as pa
     from particles_amd import _lib
-    pf = pa.SMC(fk=wl["fk"], N=wl["N"], resampling=wl["scheme"], ESSrmin=wl["essrmin"], collect="off", seed=123,
-                n_islands=wl["islands"], island_offset=rank * wl["islands"],
-                use_graph=graph and not profile, collapsed_proposal=wl["collapsed"])
+    from particles_amd import resampling as rs
+    mode = _lib.RNG_MODE[0]
+    if wl.get("qmc"):
+        rs.set_rng("philox")              # (device-generated points: the fused SQMC step)
+    try:
+        pf = pa.SMC(fk=wl["fk"], N=wl["N"], resampling=wl["scheme"], ESSrmin=wl["essrmin"], collect="off", seed=123,
+                    n_islands=wl["islands"], island_offset=rank * wl["islands"], qmc=bool(wl.get("qmc")),
+                    use_graph=graph and not profile, collapsed_proposal=wl["collapsed"])
+    finally:
+        rs.set_rng(mode)
+    if wl.get("qmc") and not pf._fused:
+        raise RuntimeError("SQMC did not take the fused step (N = 2^k >= 2048 is required)")
     if profile:
         _lib.check(_lib.lib().smc_filter_profile(pf._f, 1))
     return pf
@@ -399,13 +410,14 @@ def other_workloads(K=20, W=10, R=7, shrink=0):
             ("c3_multinomial", dict(name="c3", scheme="multinomial")),
             ("c4", dict(name="c4")),
             ("c4_collapsed", dict(name="c4", collapsed=True)),
-            ("c5", dict(name="c5"))]
+            ("c5", dict(name="c5")),
+            ("sqmc", dict(name="c2", qmc=True))]
     out = {}
     for key, kw in legs:
         t_leg = time.perf_counter()
         try:
             if shrink:
-                kw = dict(kw, log2N=shrink)
+                kw = dict(kw, log2N=max(shrink, 11) if kw.get("qmc") else shrink)
             wl = make_workload(T=W + R * K, **kw)
             if shrink and kw["name"] == "c5":
                 wl.update(N=1 << shrink, log2N=shrink, Nlabel="2^%d" % shrink, islands=2)

@@ -84,6 +84,26 @@ __device__ __forceinline__ void smc_normal_pair(const SmcD2* ntab, u64 seed, u32
 #endif
 }
 
+// the two halves of smc_normal_pair: the counter-based bits need no table -- a kernel whose tables are still
+// on their way to LDS draws them first (k_propagate's prologue) -- the transform does
+__device__ __forceinline__ void smc_normal_bits(u64 seed, u32 pair, u32 t, u32 island, u32 stream, u64& a, u64& b)
+{
+    smc_philox(pair, t, island, stream, seed, a, b);
+}
+__device__ __forceinline__ void smc_normal_from_bits(const SmcD2* ntab, const u64 a, const u64 b, double& z0, double& z1)
+{
+#ifdef SMC_BM_LEGACY
+    (void)ntab;
+    const double r = sqrt(-2.0 * smc_log_pos(smc_u01_open(a)));
+    double sn, cs;
+    smc_sincospi_02(2.0 * smc_u01_open(b), &sn, &cs);
+    z0 = r * cs;
+    z1 = r * sn;
+#else
+    smc_bm_pair(ntab, a, b, z0, z1);
+#endif
+}
+
 // ---------------------------------------------------------------------------
 // Publishing a few 8-byte values to another workgroup of the same launch
 // without fences (MI355X: per-XCD L2s, per-CU L1s): the producer stores them

@@ -138,8 +138,10 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
         FArgs& a = f->a;
         const i64 MN = (i64)a.n_islands * a.N;
         a.zt = f->sq_z - t * MN;
-        a.ut = a.su - t * MN;
+        a.ut = a.su - t * MN;              // (never read: the thresholds are a function of n, f2_sq_T)
         a.ut_stride = a.N;
+        a.sq_seed = f->sq_seed;
+        a.sq_ctr = f->sq_ctr0;
         if (t == 0) {
             SMC_LAUNCH(k_sq_init, dim3((unsigned)((a.N + SMC_BLOCK - 1) / SMC_BLOCK), a.n_islands), dim3(SMC_BLOCK), st,
                        f->a, f->sq_z, f->sq_seed, f->sq_ctr0);
@@ -151,9 +153,9 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
                 if (a.n_islands == 1) perm = v0;
                 else (void)hipMemcpyAsync(f->sq_perm + (i64)i * a.N, v0, (size_t)a.N * 8, hipMemcpyDeviceToDevice, st);
             }
-            SMC_LAUNCH(k_sq_permute, grid, dim3(SMC_BLOCK), st, f->a, perm, a.su, f->sq_z, f->sq_seed, f->sq_ctr0);
+            SMC_LAUNCH(k_sq_permute, grid, dim3(SMC_BLOCK), st, f->a, perm, f->sq_z, f->sq_seed, f->sq_ctr0);
             SMC_LAUNCH(k_reduce2, dim3(a.n_islands), dim3(SMC_BLOCK), st, f->a);
-            SMC_LAUNCH((k_ancestors2<true, true>), grid, dim3(SMC_BLOCK), st, f->a);
+            SMC_LAUNCH((k_ancestors2<true, true, true, false, true>), grid, dim3(SMC_BLOCK), st, f->a);
             SMC_LAUNCH(k_sq_compose, dim3((unsigned)((a.N / 4 + SMC_BLOCK - 1) / SMC_BLOCK), a.n_islands), dim3(SMC_BLOCK), st,
                        f->a, perm);
         }

@@ -123,6 +123,7 @@ struct FArgs {
     double *pm2, *ps2, *pss2;   // APF on the two-level path: the tile partials of the PLAIN weights
                            // (pm/ps/pss, cq, tq then describe the AUXILIARY weights lw + logeta,
                            // which decide and drive the resampling -- core.py:307-313); else null
+    u64 sq_seed, sq_ctr;   // SMC_FLAG_SQMC (smc_filter_sqmc.h): the point stream's key and the point set of step t = sq_ctr + t
     u64* sdec;             // one-pass uniform_spacings with the island's reduction as its workgroup 0 (sp_epoch != 0):
     u64 sp_epoch;          // (n_islands) decision words, (epoch << 2) | 2 resample, | 1 not; epoch: unique per launch
     double *eta, *lwsv;    // APF of MVLINGAUSS (smc_filter_mv.h k_mv_aux): (n_islands, N) logeta of the step's
@@ -1319,19 +1320,31 @@ k_propagate(const FArgs av)
     asm volatile("" ::: "memory");                    // (the table loads are ISSUED first: vmcnt retires in order)
 #endif
     if (SPEC && mine) load_anc(a.A + (i64)isl * N);   // A always holds valid indices (zeros before the first resampling)
+    // the Philox calls of the step's normals need no table: they run while it is on its way
+    u64 pa0 = 0ull, pa1 = 0ull, pb0 = 0ull, pb1 = 0ull;
+#ifndef SMC_PHILOX_LATE
+    if (spec_z) {
+        smc_normal_bits(a.seed, (u32)(own.na >> 1), (u32)a.tk, gisl, SMC_STREAM_NORMAL, pa0, pa1);
+        smc_normal_bits(a.seed, (u32)(own.nb >> 1), (u32)a.tk, gisl, SMC_STREAM_NORMAL, pb0, pb1);
+    }
+#endif
     smc_ntab_store<SMC_BLOCK>(ntr, s_ntab, tid);
     __syncthreads();
+#ifdef SMC_PHILOX_LATE                             // (A/B builds: the calls behind the table barrier, as in r04)
+    if (spec_z) {
+        smc_normal_bits(a.seed, (u32)(own.na >> 1), (u32)a.tk, gisl, SMC_STREAM_NORMAL, pa0, pa1);
+        smc_normal_bits(a.seed, (u32)(own.nb >> 1), (u32)a.tk, gisl, SMC_STREAM_NORMAL, pb0, pb1);
+    }
+#endif
     if (SPEC && mine) {
-        if (spec_z)
-            smc_normal_pair(s_ntab, a.seed, (u32)(own.na >> 1), (u32)a.tk, gisl, SMC_STREAM_NORMAL, zs[0], zs[1]);
+        if (spec_z) smc_normal_from_bits(s_ntab, pa0, pa1, zs[0], zs[1]);
         const double* Xs = a.X + (i64)(a.par ^ 1) * a.xslot + (i64)isl * N;
 #pragma unroll
         for (int k = 0; k < OPT; ++k) xg[k] = smc_ldg(Xs + an[k]);
     } else if (spec_z) {
-        smc_normal_pair(s_ntab, a.seed, (u32)(own.na >> 1), (u32)a.tk, gisl, SMC_STREAM_NORMAL, zs[0], zs[1]);
+        smc_normal_from_bits(s_ntab, pa0, pa1, zs[0], zs[1]);
     }
-    if (spec_z)
-        smc_normal_pair(s_ntab, a.seed, (u32)(own.nb >> 1), (u32)a.tk, gisl, SMC_STREAM_NORMAL, zs[2], zs[3]);
+    if (spec_z) smc_normal_from_bits(s_ntab, pb0, pb1, zs[2], zs[3]);
     const i64 t = (i64)smc_uniform(r0);
     if (t >= a.T) return;
     F_STAMP(1);
@@ -1852,6 +1865,43 @@ __device__ __forceinline__ int f2_count_lds_f64(const double* T, const int n, co
     return lo;
 }
 
+// ---- SQMC (smc_filter_sqmc.h): the n-th smallest first coordinate of the N = 2^k points of step t is
+// x_0 = (n << (30 - k)) | (low bits of the digital shift), su_n = safe_generate(x_0 2^-30) (rqmc.py:9-13): the
+// thresholds T_n = ceil(su_n 2^52) are a function of n, and count(C) = #{n : T_n <= C} is a guess fixed with
+// that definition (T is monotone in n)
+struct F2Sq {
+    u32 low;               // the shift's low 30 - k bits
+    int sh;                // 30 - k
+    i64 N;
+};
+__device__ __forceinline__ void f2_sq_init(const FArgs& a, const int isl, const i64 t, F2Sq& q)
+{
+    const u64 ctr = a.sq_ctr + (u64)t + ((u64)(u32)(a.island_offset + isl) << 32);
+    u64 x0, x1;
+    smc_philox(0u, (u32)ctr, (u32)(ctr >> 32), SMC_STREAM_RESAMPLE, a.sq_seed, x0, x1);
+    const u32 sh0 = (u32)(x0 >> 34);                                      // (smc_sobol_shift: 30 bits)
+    q.sh = 30 - a.log2N;
+    q.low = sh0 & ((1u << q.sh) - 1u);
+    q.N = a.N;
+}
+__device__ __forceinline__ u64 f2_sq_T(const F2Sq& q, const i64 n)
+{
+    const u32 x = ((u32)n << q.sh) | q.low;
+    const double u = (double)x * (1.0 / 1073741824.0);
+    return f2_t52(0.5 + (1.0 - 1e-10) * (u - 0.5));                       // smc_sobol_safe
+}
+__device__ __forceinline__ i64 f2_sq_count(const F2Sq& q, const u64 C)
+{
+    const double y = ((double)C * 0x1.0p-52 - 0.5) / (1.0 - 1e-10) + 0.5;
+    double g = floor((y * 1073741824.0 - (double)q.low) * __longlong_as_double((long long)(1023 - q.sh) << 52));
+    g = g < -1.0 ? -1.0 : g;
+    g = g > (double)(q.N - 1) ? (double)(q.N - 1) : g;
+    i64 n = (i64)g;                                                        // last threshold at or below C (guess)
+    while (n + 1 < q.N && f2_sq_T(q, n + 1) <= C) ++n;
+    while (n >= 0 && f2_sq_T(q, n) > C) --n;
+    return n + 1;
+}
+
 // first offspring ns[i] of the parents jt+i at positions cx[i] (cx[4]: the next thread's first
 // parent, t_b for the last thread), any scheme: fp64 quotient within 2^12 of the truth, count
 // decided unless the position lies within that band of a threshold, else formed exactly
@@ -2134,11 +2184,15 @@ k_reduce2(const FArgs av)
 // ---------------------------------------------------------------------------
 // REGEN (MID, MULTI, Philox mode): the tile's window of the sorted uniforms is found through the tile
 // prefixes of the spacings (one probe, see F2Regen above) and staged whole; tapes keep the search.
-template <bool MID, bool MULTI = false, bool POW2 = true, bool REGEN = false>
+// SQ (SMC_FLAG_SQMC; MID, MULTI, N = 2^k): the sorted uniforms are the sorted first coordinates of the step's
+// Sobol' points -- a regular grid (the digital shift's low bits, rqmc's safe_generate map): threshold n is a
+// function of n, counts are a guess fixed with the definition, nothing is read.
+template <bool MID, bool MULTI = false, bool POW2 = true, bool REGEN = false, bool SQ = false>
 __global__ void __launch_bounds__(SMC_BLOCK)
 k_ancestors2(const FArgs av)
 {
     static_assert(!REGEN || (MID && MULTI), "regenerated thresholds: multinomial behind k_reduce2");
+    static_assert(!SQ || (MID && MULTI && POW2 && !REGEN), "SQMC: the tape form of the multinomial search");
     const FArgs& a = av;
     constexpr int WIN = 2 * F_PASS;                                        // offspring per pass
     __shared__ __attribute__((aligned(16))) u32 sP[WIN];
@@ -2418,12 +2472,14 @@ k_ancestors2(const FArgs av)
         // on the tile's share is formed exactly (128-bit product)
         __shared__ i64 s_nm[2];
         __shared__ u64 sT[F2_MW];
+        F2Sq sq;
+        if (SQ) f2_sq_init(a, isl, t, sq);
         if (wave == 0) {
-            const i64 v = (b == 0) ? 0 : f2_count_sorted_wave(su.u, N, Gb);
+            const i64 v = (b == 0) ? 0 : (SQ ? f2_sq_count(sq, Gb) : f2_count_sorted_wave(su.u, N, Gb));
             if (lane == 0) s_nm[0] = v;
         }
         if (wave == 1) {
-            const i64 v = (b == a.ntiles - 1) ? N : f2_count_sorted_wave(su.u, N, Gb + Qb);
+            const i64 v = (b == a.ntiles - 1) ? N : (SQ ? f2_sq_count(sq, Gb + Qb) : f2_count_sorted_wave(su.u, N, Gb + Qb));
             if (lane == 0) s_nm[1] = v;
         }
         __syncthreads();
@@ -2432,7 +2488,8 @@ k_ancestors2(const FArgs av)
         const i64 width = n_hi - n_lo;
         const bool staged = width <= F2_MW;
         if (staged) {
-            for (int i = tid; i < (int)width; i += SMC_BLOCK) sT[i] = f2_t52(smc_ldg(su.u + n_lo + i));
+            for (int i = tid; i < (int)width; i += SMC_BLOCK)
+                sT[i] = SQ ? f2_sq_T(sq, n_lo + i) : f2_t52(smc_ldg(su.u + n_lo + i));
             __syncthreads();
         }
         // position of a parent on the tile's share: fp64 quotient within 2^12 of floor(c Q_b / t_b)
@@ -2460,7 +2517,7 @@ k_ancestors2(const FArgs av)
                 if (cnt < 0) {
                     const u64 pos = (c == 0ull) ? 0ull : (c >= tb ? Qb : smc_muldiv_floor(c, Qb, tb));
                     cnt = staged ? n_lo + f2_count_lds(sT, (int)width, Gb + pos)
-                                 : f2_count_sorted_range(su.u, n_lo, n_hi, Gb + pos);
+                                 : (SQ ? f2_sq_count(sq, Gb + pos) : f2_count_sorted_range(su.u, n_lo, n_hi, Gb + pos));
                 }
                 ns[i] = cnt;
             }

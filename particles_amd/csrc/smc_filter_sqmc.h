@@ -4,10 +4,11 @@
 //     u = sobol(N, 2);  tau = argsort(u[:, 0])                    -> closed form for N = 2^k (smc_qmc.h)
 //     h_order = hilbert_sort(X) = argsort(X)            (d = 1)   -> the radix sort (smc_sort.hip)
 //     A = h_order[inverse_cdf(u[tau, 0], W[h_order])]             -> k_sq_permute: the tile partials and integer
-//                                                                    CDFs of the weights IN SORTED ORDER and the
-//                                                                    sorted first coordinates as a tape of sorted
-//                                                                    uniforms; k_reduce2 + k_ancestors2<MID, MULTI>
-//                                                                    unchanged; k_sq_compose: A <- h_order[A]
+//                                                                    CDFs of the weights IN SORTED ORDER; k_reduce2;
+//                                                                    k_ancestors2<MID, MULTI, .., SQ>: the multinomial
+//                                                                    counts with the thresholds a FUNCTION of n (the
+//                                                                    sorted first coordinates are a regular grid:
+//                                                                    f2_sq_T); k_sq_compose: A <- h_order[A]
 //     X = Gamma(t, X[A], u[tau, 1])  (ppf of the Normal kernel)   -> k_propagate unchanged, its standard normals
 //                                                                    z_n = ndtri(u[tau_n, 1]) read from a tape
 //                                                                    k_sq_permute wrote
@@ -38,7 +39,7 @@ k_sq_init(const FArgs av, double* zbuf, const u64 pseed, const u64 ctr0)
 // for the unsorted order -- (K_b, S_b, SS_b), the tile's integer CDF, t_b -- for the sorted one; writes the
 // tapes of step t.
 __global__ void __launch_bounds__(SMC_BLOCK)
-k_sq_permute(const FArgs av, const u64* perm, double* ubuf, double* zbuf, const u64 pseed, const u64 ctr0)
+k_sq_permute(const FArgs av, const u64* perm, double* zbuf, const u64 pseed, const u64 ctr0)
 {
     const FArgs& a = av;
     const int b = (int)blockIdx.x, isl = (int)blockIdx.y, tid = (int)threadIdx.x;
@@ -57,19 +58,16 @@ k_sq_permute(const FArgs av, const u64* perm, double* ubuf, double* zbuf, const 
     // the step's points, while the gather is on its way
     const u64 ctr = ctr0 + (u64)t + ((u64)(u32)(a.island_offset + isl) << 32);
     const u32 sh0 = smc_sobol_shift(pseed, ctr, 0u), sh1 = smc_sobol_shift(pseed, ctr, 1u);
-    double u0[4], z[4];
+    double z[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const u32 row = (u32)f_own_idx(own, k);
         u32 x0, x1;
         smc_sobol2(smc_sobol_sorted_gray(row, sh0, a.log2N), sh0, sh1, x0, x1);
-        u0[k] = smc_sobol_safe(x0);
         z[k] = smc_ndtri(smc_sobol_safe(x1));
     }
-    double* ub = ubuf + (i64)isl * N;
+    // (the sorted first coordinates are not written: k_ancestors2<SQ> forms the thresholds from n -- f2_sq_T)
     double* zb = zbuf + (i64)isl * N;
-    smc_st2g(ub + own.na, u0[0], u0[1]);
-    smc_st2g(ub + own.nb, u0[2], u0[3]);
     smc_st2g(zb + own.na, z[0], z[1]);
     smc_st2g(zb + own.nb, z[2], z[3]);
     u64 cx[4];

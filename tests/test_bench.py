@@ -36,7 +36,8 @@ def test_default_line_carries_other_workloads_and_cpu_legs(tmp_path):
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and "C2" in d["config"]["workload"]
     assert "roofline" in d and d["roofline"]["bound"] == "hbm"
     ow = d["other_workloads"]
-    assert sorted(ow) == ["c3_multinomial", "c3_stratified", "c3_systematic", "c4", "c4_collapsed", "c5"]
+    assert sorted(ow) == ["c3_multinomial", "c3_stratified", "c3_systematic", "c4", "c4_collapsed", "c5", "sqmc"]
+    assert "k_sq_permute" in ow["sqmc"]["step_kernels"] and "k_rs_sort" in ow["sqmc"]["step_kernels"]
     for key, leg in ow.items():
         assert "error" not in leg, (key, leg)
         for k in ("value", "ms_per_step", "step_frac", "kernel", "frac", "step_kernels"):
