@@ -507,7 +507,7 @@ def main():
     K, W = a.steps, a.warmup
     heavy = a.workload in ("c3", "c4", "c5")        # 0.07-0.3 ms per step: fewer timed steps do
     R = a.reps if a.reps > 0 else max(3, min(500, -(-(2000 if heavy else 10000) // K)))
-    T = W + R * K
+    T = W + R * K + (K if world > 1 else 0)      # (N > 1: one more K-step region, timed WITH the evidence gather)
     wl = make_workload(a.workload, T, scheme=a.scheme, log2N=a.log2N, N=a.N, islands=a.islands,
                        essrmin=a.essrmin, collapsed=a.collapsed)
     a.log2N, a.islands = wl["log2N"], wl["islands"]
@@ -525,6 +525,7 @@ def main():
     # the path's one collective: the all-gather of the per-island evidences, ONCE PER RUN (after the
     # T steps of a filter, not after every K-step repetition) -- timed on its own and reported
     gather_ms = None
+    with_gather = None
     all_ll = local_ll
     if grp:
         g = np.zeros(5)
@@ -535,6 +536,14 @@ def main():
             g[i] = time.perf_counter() - t0
         gather_ms = 1e3 * float(np.median(grp.allreduce_max_host(g)))
         dts = grp.allreduce_max_host(dts)                  # per repetition: the slowest rank
+        # one K-step region with the path's collective INSIDE it (the reference's multiSMC returns when the
+        # last worker's results have been collected, utils.py:178-186): reported beside the headline
+        grp.barrier()
+        pf.sync()
+        t0 = time.perf_counter()
+        pf.step_async(K)
+        all_ll = grp.gather_evidence(pf.logLts_islands)
+        with_gather = float(grp.allreduce_max_host(time.perf_counter() - t0))
     dt = float(np.median(dts))
     rs_rate = float(np.mean(pf._summ()[0, W:, 4]))
     del pf
@@ -571,6 +580,7 @@ def main():
         if devices is not None:
             out["rank_devices"] = devices
         if grp:
+            out["timing"]["ms_per_step_with_gather"] = 1e3 * with_gather / K
             out["timing"]["note"] = (
                 "per repetition: max over ranks of each rank's own [barrier, device sync, clock] ... K steps ... "
                 "[device sync, clock], closing barrier after the clock; the all-gather of the evidences happens once "

@@ -319,4 +319,5 @@ def test_bench_two_ranks_launch_line(tmp_path):
     assert d["rccl"] is False and d["evidence_gather"].startswith("host-fallback")
     assert len(d["logLt"]) == 2 and d["logLt"][0] != d["logLt"][1]      # one filter per rank, distinct streams
     assert d["evidence_gather_ms"] is not None and "timing" in d and "note" in d["timing"]
+    assert d["timing"]["ms_per_step_with_gather"] >= d["ms_per_step"] * 0.5      # the region that holds the collective
     assert "RCCL unavailable" in p.stderr
