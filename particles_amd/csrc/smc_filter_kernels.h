@@ -2264,6 +2264,9 @@ k_ancestors2(const FArgs av)
         __syncthreads();                                       // sP zeroed
     } else {
         // ---- all partials -> K, (s, ss), ESS, the decision (f2_reduce_island's operations)
+        // (measured, r05p: ONE exchange -- every wave summing on its own maximum, the four wave results put on K
+        //  afterwards, the same bits because power-of-two scalings commute with the roundings -- is 0.12 us
+        //  SLOWER per step: the extra ldexp pairs cost more than the barrier they save)
         double tm = smc_max2(smc_max2(pm4[0], pm4[1]), smc_max2(pm4[2], pm4[3]));
         tm = smc_wave_max(tm);
         if (lane == 0) s_max[wave] = tm;

@@ -78,6 +78,16 @@ c45)
   timeout 300 python bench.py --workload c5 --steps 200 --warmup 20 > $O/bench_c5.json 2>&1; line $O/bench_c5.json
   timeout 300 python bench.py --workload c4 --steps 100 --warmup 10 > $O/bench_c4.json 2>&1; line $O/bench_c4.json
   timeout 300 python bench.py --workload c4 --collapsed --steps 100 --warmup 10 > $O/bench_c4_collapsed.json 2>&1; line $O/bench_c4_collapsed.json ;;
+two_procs_c3m)
+  # two processes sharing the one GPU, each a C3 multinomial filter (the merged spacings + reduction launch waits
+  # on lower-numbered workgroups only: progress must not depend on every workgroup being resident)
+  (timeout 300 python bench.py --workload c3 --scheme multinomial --steps 100 --warmup 10 --no-profile > $O/c3m_proc_a.json 2>&1 &
+   timeout 300 python bench.py --workload c3 --scheme multinomial --steps 100 --warmup 10 --no-profile > $O/c3m_proc_b.json 2>&1; wait)
+  for f in $O/c3m_proc_a.json $O/c3m_proc_b.json; do python - $f <<'PY'
+import json,sys
+d=json.loads([l for l in open(sys.argv[1]) if l.startswith('{')][-1]); print(sys.argv[1].split('/')[-1], 'ms/step %.5f'%d['ms_per_step'], 'G/s %.2f'%(d['value']/1e9), 'logLt', d['logLt'][:1])
+PY
+  done ;;
 two_ranks)
   # the driver's N = 2 launch line with both ranks on this box's one GPU (RCCL refuses: labelled host fallback)
   SMC_BENCH_NGPU=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 20 --warmup 5 > $O/bench_2ranks_1gpu.json 2> $O/bench_2ranks_1gpu.err; line $O/bench_2ranks_1gpu.json; tail -2 $O/bench_2ranks_1gpu.err ;;
