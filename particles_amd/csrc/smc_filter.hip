@@ -133,13 +133,11 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
     const dim3 grid(f->a.ntiles, f->a.n_islands);
     if (k_prof >= 0) (void)hipEventRecord(f->ev[3 * k_prof], st);
     if (f->sqmc) {
-        // smc_filter_sqmc.h.  The tapes of the step are per-step buffers: the kernels index tapes by
-        // (t, island), so the pointers are rebased to put row t on the buffer (the host knows t: eager launches)
+        // smc_filter_sqmc.h.  The step's normals come from a tape that is ONE step's buffer (zt_ts = 0),
+        // written by k_sq_init / k_sq_permute just before; the thresholds are a function of n (f2_sq_T)
         FArgs& a = f->a;
-        const i64 MN = (i64)a.n_islands * a.N;
-        a.zt = f->sq_z - t * MN;
-        a.ut = a.su - t * MN;              // (never read: the thresholds are a function of n, f2_sq_T)
-        a.ut_stride = a.N;
+        a.zt = f->sq_z;
+        a.zt_ts = 0;
         a.sq_seed = f->sq_seed;
         a.sq_ctr = f->sq_ctr0;
         if (t == 0) {
@@ -800,6 +798,7 @@ int smc_filter_set_replay(smc_filter* f, const double* z, const double* u)
     SMC_REQUIRE(f->t_host == 0, "replay tapes must be set before the first step");
     SMC_REQUIRE(z && u, "both tapes are required");
     f->a.zt = z;
+    f->a.zt_ts = (i64)f->a.n_islands * f->a.N * f->a.dx;
     f->a.ut = u;
     f->a.ut_stride = (f->a.scheme == SMC_SYSTEMATIC) ? 1 : f->a.N;
     f->a.rng_mode = SMC_RNG_REPLAY;

@@ -123,6 +123,8 @@ struct FArgs {
     double *pm2, *ps2, *pss2;   // APF on the two-level path: the tile partials of the PLAIN weights
                            // (pm/ps/pss, cq, tq then describe the AUXILIARY weights lw + logeta,
                            // which decide and drive the resampling -- core.py:307-313); else null
+    i64 zt_ts;             // elements per time step of the tape zt: n_islands x N x dx (replay), 0: ONE step's buffer,
+                           // rewritten before every step (SMC_FLAG_SQMC: ndtri of the step's second Sobol' coordinates)
     u64 sq_seed, sq_ctr;   // SMC_FLAG_SQMC (smc_filter_sqmc.h): the point stream's key and the point set of step t = sq_ctr + t
     u64* sdec;             // one-pass uniform_spacings with the island's reduction as its workgroup 0 (sp_epoch != 0):
     u64 sp_epoch;          // (n_islands) decision words, (epoch << 2) | 2 resample, | 1 not; epoch: unique per launch
@@ -1356,7 +1358,7 @@ k_propagate(const FArgs av)
     double* lwn = (SPEC ? a.lw + (i64)a.par * a.lslot : f_lw(a, t)) + (i64)isl * N;
     const double* lwo = (SPEC ? a.lw + (i64)(a.par ^ 1) * a.lslot : f_lw(a, t - 1)) + (i64)isl * N;
     const u32* A = f_A(a, t) + (i64)isl * N;
-    const double* zt = a.zt ? a.zt + ((i64)t * a.n_islands + isl) * N : nullptr;
+    const double* zt = a.zt ? a.zt + ((i64)t * a.zt_ts + (i64)isl * N) : nullptr;
     const bool first = (t == 0);
     const bool resample = !first && smc_uniform(r1) != 0.0;
     // ---- is this block of offspring wholly a registered heavy parent's?  Then that parent is

@@ -137,7 +137,7 @@ k_propagate_mv(const FArgs av, const double* __restrict__ C)
     SMC_GLOBAL(const double) lwo = SMC_AS_GLOBAL(const double, f_lw(a, t - 1) + (i64)isl * N);
     SMC_GLOBAL(const u32) A = SMC_AS_GLOBAL(const u32, f_A(a, t) + (i64)isl * N);
     SMC_GLOBAL(const double) zt =
-        SMC_AS_GLOBAL(const double, a.zt ? a.zt + ((i64)t * a.n_islands + isl) * N * d : nullptr);
+        SMC_AS_GLOBAL(const double, a.zt ? a.zt + ((i64)t * a.zt_ts + (i64)isl * N * d) : nullptr);
     const bool first = (t == 0);
     const bool resample = !first && smc_uniform(info[1]) != 0.0;
     const double* scal = C + MV_SCAL(DP);

@@ -124,7 +124,7 @@ k_filter_small(const FArgs av, const int nsteps)
         // ---- standard normals (same counters as k_propagate), propagate, weigh
         double z[4];
         if (a.zt) {
-            const double* zt = a.zt + ((i64)t * a.n_islands + isl) * N;
+            const double* zt = a.zt + ((i64)t * a.zt_ts + (i64)isl * N);
 #pragma unroll
             for (int k = 0; k < 4; ++k) z[k] = (jt + k < N) ? smc_ldg(zt + jt + k) : 0.0;
         } else {
