@@ -408,6 +408,10 @@ int smc_filter_copy_islands(smc_filter* dst, smc_filter* src, const unsigned cha
  * record, parameters, CDF partials) packed into / restored from a contiguous device buffer of
  * n x smc_filter_island_bytes() bytes, entry j = island islands_host[j]. */
 int smc_filter_island_bytes(smc_filter* f, int64_t* bytes);
+/* A filter that has not stepped yet takes time index t; its state is then supplied by
+ * smc_filter_unpack_islands (every island, before the next step).  Waste-free SMC^2
+ * (smc_samplers.py:669-684) assembles its new population from the chains' batches this way. */
+int smc_filter_fast_forward(smc_filter* f, int64_t t);
 int smc_filter_pack_islands(smc_filter* f, const int64_t* islands_host, int n, void* pack_dev);
 int smc_filter_unpack_islands(smc_filter* f, const int64_t* islands_host, int n, const void* pack_dev);
 /* ---- SMC^2 (smc_samplers.py:1038-1167): the theta level on the device.  Every island is the

@@ -119,6 +119,7 @@ SIGNATURES = {
     "smc_filter_clone": (c_int, [c_vp, P(c_vp)]),
     "smc_filter_reseed": (c_int, [c_vp, c_u64]),
     "smc_filter_sqmc_points": (c_int, [c_vp, c_u64, c_u64]),
+    "smc_filter_fast_forward": (c_int, [c_vp, c_i64]),
     "smc_filter_theta_enable_sharded": (c_int, [c_vp, c_vp, c_dbl]),
     "smc_comm_allgather_f64_async": (c_int, [c_vp, c_vp, c_i64, c_vp]),
     "smc_comm_rank": (c_int, [c_vp, P(c_int), P(c_int)]),

@@ -86,14 +86,14 @@ class _Theta:
     @property
     def theta(self):
         d = self._run._alg.theta
-        out = np.empty(self._run.N, dtype=[(k, float) for k in d])
+        out = np.empty(self._run._alg.N, dtype=[(k, float) for k in d])     # (waste-free: N x len_chain of them)
         for k, v in d.items():
             out[k] = v
         return out
 
     @property
     def N(self):
-        return self._run.N
+        return self._run._alg.N
 
     @property
     def Nx(self):
@@ -130,7 +130,7 @@ class _Summ:
 
 
 class DeviceSMC2Run:
-    """``particles.SMC(fk=SMC2(ssm_cls, prior, data, init_Nx, ar_to_increase_Nx, len_chain, wastefree=False), N=...)``
+    """``particles.SMC(fk=SMC2(ssm_cls, prior, data, init_Nx, ar_to_increase_Nx, len_chain[, wastefree=False]), N=...)``
     (smc_samplers.py:1038-1167 under core.py:200-409) on the device class ``particles_amd.smc2.SMC2``:
     all N filters are islands of one device filter, the theta level lives on the device, a
     resample-move re-runs candidate batches.  Same algorithm as the reference's standard (not
@@ -148,7 +148,8 @@ class DeviceSMC2Run:
         opts = {k: v for k, v in (fk.smc_options or {}).items() if k in ("resampling", "ESSrmin")}
         self._alg = smc2.SMC2(ssm_cls=ssm_cls, prior=fk.prior, data=fk.data, init_Nx=fk.init_Nx, N=N, fk_cls=fk_cls,
                               ESSrmin=ESSrmin, nmcmc=fk.move.nsteps, ar_to_increase_Nx=fk.ar_to_increase_Nx,
-                              smc_options=opts, seed=seed, sync_every=kw.pop("sync_every", 16))
+                              smc_options=opts, seed=seed, sync_every=kw.pop("sync_every", 16),
+                              wastefree=bool(fk.wastefree), len_chain=fk.move.nsteps + 1)
         self.X, self.wgts = _Theta(self), _ThetaWeights(self)
         self.cpu_time = 0.0
         self.rs_flag = False
@@ -197,17 +198,21 @@ class DeviceSMC2Run:
 
 def adapt_smc2(fk):
     """(our model class, our Feynman-Kac class) if `fk` is the reference's SMC2 in a form the device
-    class implements exactly -- stock model class, Bootstrap / GuidedPF inner filters, the standard
-    (wastefree=False) random-walk move -- else None (the reference's outer loop then runs it; with
-    ``install()`` its inner filters are still device filters)."""
+    class implements exactly -- stock model class, Bootstrap / GuidedPF inner filters, random-walk
+    Metropolis steps in the waste-free sequence (the reference's default) or the standard one -- else
+    None (the reference's outer loop then runs it; with ``install()`` its inner filters are still device
+    filters)."""
     try:
         from particles import smc_samplers as ssp
         from particles import state_space_models as rssm
     except ImportError:
         return None
-    if type(fk) is not ssp.SMC2 or fk.wastefree:
+    if type(fk) is not ssp.SMC2:
         return None
-    if type(fk.move) is not ssp.AdaptiveMCMCSequence or fk.move.adaptive or type(fk.move.mcmc) is not ssp.ArrayRandomWalk:
+    if fk.wastefree:        # the reference's default: MCMCSequenceWF (smc_samplers.py:669-684) of random-walk steps
+        if type(fk.move) is not ssp.MCMCSequenceWF or type(fk.move.mcmc) is not ssp.ArrayRandomWalk:
+            return None
+    elif type(fk.move) is not ssp.AdaptiveMCMCSequence or fk.move.adaptive or type(fk.move.mcmc) is not ssp.ArrayRandomWalk:
         return None
     name = fk.ssm_cls.__name__
     import importlib

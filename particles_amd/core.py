@@ -431,6 +431,33 @@ class SMC:
             self._fk_list = [o if a else s for s, o, a in zip(self._fk_list, other._fk_list, acc)]
         self._invalidate()
 
+    def take_islands_from(self, other, src, dst=None):
+        """Islands ``dst`` (default: 0 .. len(src) - 1) of this filter continue from the state of islands
+        ``src`` of ``other`` (same model family, N and data; both at the same time index, or this one
+        fresh: it is then fast-forwarded to ``other``'s).  Whole filters move packed
+        (smc_filter_pack_islands / _unpack_islands), Philox streams stay with the slot."""
+        src = np.ascontiguousarray(src, dtype=np.int64)
+        dst = np.arange(len(src), dtype=np.int64) if dst is None else np.ascontiguousarray(dst, dtype=np.int64)
+        if len(src) != len(dst):
+            raise ValueError("take_islands_from: one destination per source")
+        if self._n == 0 and other._n > 0:
+            check(lib().smc_filter_fast_forward(self._f, other._n))
+            self.t = self._n = other._n
+        if self._n != other._n:
+            raise ValueError("take_islands_from: the two filters are at different time steps")
+        if other._n == 0 or len(src) == 0:
+            return
+        nb = _lib.c_i64()
+        check(lib().smc_filter_island_bytes(other._f, ctypes.byref(nb)))
+        buf = DeviceArray((max(1, len(src) * int(nb.value) // 8),), dtype=np.int64)
+        P64 = _lib.P(_lib.c_i64)
+        check(lib().smc_filter_pack_islands(other._f, src.ctypes.data_as(P64), len(src), buf.ptr))
+        check(lib().smc_filter_unpack_islands(self._f, dst.ctypes.data_as(P64), len(dst), buf.ptr))
+        if self._fk_list is not None and other._fk_list is not None:
+            for s_, d_ in zip(src, dst):
+                self._fk_list[int(d_)] = other._fk_list[int(s_)]
+        self._invalidate()
+
     def set_state(self, X=None, lw=None, island=0):
         """Replace the particles and / or log-weights of the step just done (the reference lets
         a caller assign ``pf.X`` / ``pf.wgts`` between two steps): the summaries of that step

@@ -1292,6 +1292,21 @@ int smc_filter_unpack_islands(smc_filter* f, const int64_t* islands_host, int n,
     return island_pack(f, islands_host, n, (void*)pack_dev, 1);
 }
 
+// A filter that has not stepped yet takes the time index t: its state at t - 1 is then whatever
+// smc_filter_unpack_islands puts there (waste-free SMC^2 assembles its new population from the chains'
+// batches this way: smc_samplers.py:669-684 keeps every intermediate state WITH its particle filter).
+// Islands that receive no state must not be stepped.
+int smc_filter_fast_forward(smc_filter* f, int64_t t)
+{
+    SMC_REQUIRE(f, "null filter");
+    SMC_REQUIRE(f->t_host == 0, "smc_filter_fast_forward: the filter has already stepped");
+    SMC_REQUIRE(t >= 0 && t <= f->a.T, "smc_filter_fast_forward: t must be in [0, T]");
+    SMC_REQUIRE(!f->a.hist && !f->sqmc && !f->lwth, "smc_filter_fast_forward: no history slots, SQMC or theta level");
+    f->t_host = t;
+    f->perm_t = t;
+    return SMC_OK;
+}
+
 // ---- SMC^2: the theta level (see k_theta_update) -------------------------------------------
 static int theta_enable(smc_filter* f, double ess_rmin, smc_comm* comm)
 {

@@ -105,12 +105,23 @@ class SMC2:
     ESSrmin : theta-level resampling threshold; nmcmc: random-walk sweeps per move step
     ar_to_increase_Nx : double N_x (exchange step) when the acceptance rate falls below it (< 0: never)
     sync_every : time steps enqueued per host synchronisation
+    wastefree, len_chain : the waste-free variant (Dau & Chopin 2022; the reference's default,
+        smc_samplers.py:669-684, 730-768): the population is N x len_chain theta-particles; a move
+        resamples N of them and runs from each a chain of len_chain - 1 PMMH steps of which EVERY state is
+        kept -- with its particle filter.  (``nmcmc`` is then len_chain - 1; ``self.N`` is the population.)
     """
 
     def __init__(self, ssm_cls=None, prior=None, data=None, init_Nx=100, N=100, fk_cls=None, ESSrmin=0.5,
-                 nmcmc=3, ar_to_increase_Nx=-1.0, smc_options=None, seed=None, sync_every=16, max_Nx=1 << 16):
+                 nmcmc=3, ar_to_increase_Nx=-1.0, smc_options=None, seed=None, sync_every=16, max_Nx=1 << 16,
+                 wastefree=False, len_chain=10):
         self.ssm_cls, self.prior, self.data = ssm_cls, prior, list(data)
         self.fk_cls = ssm.Bootstrap if fk_cls is None else fk_cls
+        self.wastefree = bool(wastefree)
+        self.M, self.P = int(N), (int(len_chain) if wastefree else 1)     # chains per move, states kept per chain
+        if self.wastefree:
+            if self.P < 2:
+                raise ValueError("waste-free SMC^2 needs len_chain >= 2")
+            N, nmcmc = self.M * self.P, self.P - 1
         self.N, self.Nx, self.ESSrmin, self.nmcmc = int(N), int(init_Nx), ESSrmin, int(nmcmc)
         self.ar_to_increase_Nx, self.max_Nx = ar_to_increase_Nx, max_Nx
         self.smc_options = dict(smc_options or {})
@@ -147,15 +158,16 @@ class SMC2:
         """The theta-particles whose filters live in this process (all of them here)."""
         return 0, self.N
 
-    def _batch(self, theta, Nx, theta_level=False):
-        """One filter per theta-particle of my slice, islands of one device filter; the Philox
-        streams are keyed by the GLOBAL theta index (island_offset), so a sharded population
-        runs the same filters as a single-process one."""
+    def _batch(self, theta, Nx, theta_level=False, whole=False):
+        """One filter per theta-particle of my slice (``whole``: of ALL the theta given -- the chains of a
+        waste-free move), islands of one device filter; the Philox streams are keyed by the GLOBAL theta
+        index (island_offset), so a sharded population runs the same filters as a single-process one."""
+        lo, hi = (0, len(theta[self.names[0]])) if whole else (self._lo, self._hi)
         fks = [self.fk_cls(ssm=self.ssm_cls(**{k: float(theta[k][i]) for k in self.names}), data=self.data)
-               for i in range(self._lo, self._hi)]
+               for i in range(lo, hi)]
         self._nbatch += 1
         pf = SMC(fk=fks, N=Nx, seed=(self._seed + 7919 * self._nbatch) % (2 ** 31 - 1), collect="off",
-                 island_offset=self._lo, **self.smc_options)
+                 island_offset=lo, **self.smc_options)
         if not pf._fused:
             raise ValueError("SMC2 needs a state-space model of the fused family")
         if theta_level:
@@ -237,7 +249,7 @@ class SMC2:
         W = self.W
         np_state = np.random.get_state()
         np.random.seed(self.rng.randint(0, 2 ** 31 - 1))
-        A = np.asarray(rs.systematic(W, M=self.N))
+        A = np.asarray(rs.systematic(W, M=self.M if self.wastefree else self.N))
         np.random.set_state(np_state)
         mean = {k: float(np.sum(W * v)) for k, v in self.theta.items()}
         X = np.stack([self.theta[k] for k in self.names], axis=1)
@@ -245,6 +257,12 @@ class SMC2:
         cov = (X - mu).T @ ((X - mu) * W[:, None])
         d = len(self.names)
         L = np.linalg.cholesky((2.38 ** 2 / d) * cov + 1e-12 * np.eye(d))
+        if self.wastefree:
+            acc_rate = self._wastefree_move(A, L, d)
+            self._maybe_exchange(acc_rate)
+            self.Nxs.append(self.Nx)
+            self.move_times.append(time.perf_counter() - t0)
+            return
         self._resample_filters(A)
         self.theta = {k: v[A].copy() for k, v in self.theta.items()}
         self.lw = np.zeros(self.N)
@@ -270,6 +288,56 @@ class SMC2:
             acc_rate = float(np.mean(acc))
             self.acc_rates.append(acc_rate)
             del cand
+        self._maybe_exchange(acc_rate)
+        self.Nxs.append(self.Nx)
+        self.move_times.append(time.perf_counter() - t0)
+
+    def _wastefree_move(self, A, L, d):
+        """MCMCSequenceWF (smc_samplers.py:669-684) on device filters: the M resampled theta-particles start M
+        chains of P - 1 PMMH steps (a candidate batch of M filters run from 0 to t per step, as in the standard
+        move); every state of every chain stays, together with its filter -- the new population is the
+        concatenation [x_0, x_1, .., x_{P-1}] of M theta-particles each, as the reference builds it."""
+        M, P, t = self.M, self.P, self.t
+        check(lib().smc_filter_theta_resume(self.pf._f, None))          # time records back to t
+        ev_all = self._evidences(self.pf)
+        cur = self._batch({k: v[A] for k, v in self.theta.items()}, self.Nx, whole=True)
+        cur.take_islands_from(self.pf, A)                               # the resampled filters themselves
+        th = {k: v[A].copy() for k, v in self.theta.items()}
+        lp = np.asarray(self.prior.logpdf(th), dtype=float) + ev_all[A]
+        states, thetas, ars = [cur], [th], []
+        for k in range(1, P):
+            Z = self.rng.standard_normal((M, d)) @ L.T
+            prop = {n_: th[n_] + Z[:, j] for j, n_ in enumerate(self.names)}
+            with np.errstate(all="ignore"):
+                lprior = np.asarray(self.prior.logpdf(prop), dtype=float)
+            ok = np.isfinite(lprior)
+            safe = {n_: np.where(ok, prop[n_], th[n_]) for n_ in self.names}
+            cand = self._batch(safe, self.Nx, whole=True)
+            cand.step_async(t)
+            lp_prop = np.where(ok, lprior + cand.logLts_islands, -np.inf)
+            acc = (np.log(self.rng.random_sample(M)) < lp_prop - lp) & ok
+            nxt = self._batch(th, self.Nx, whole=True)                  # x = x.copy(): the chain's next state
+            nxt.take_islands_from(states[-1], np.arange(M))
+            nxt.accept_islands_from(cand, acc)
+            th = {n_: np.where(acc, prop[n_], th[n_]) for n_ in self.names}
+            lp = np.where(acc, lp_prop, lp)
+            states.append(nxt)
+            thetas.append(th)
+            ars.append(float(np.mean(acc)))
+            del cand
+        self.acc_rates.extend(ars)
+        # ---- the new population: all states of all chains, one batch of M P filters at time t
+        self.theta = {n_: np.concatenate([th_[n_] for th_ in thetas]) for n_ in self.names}
+        new = self._batch(self.theta, self.Nx)
+        for k, st in enumerate(states):
+            new.take_islands_from(st, np.arange(M), np.arange(k * M, (k + 1) * M))
+        self._enable_theta_level(new)                                   # from step t on, weights zero
+        self.pf = new
+        self.lw = np.zeros(self.N)
+        self._lw_at_reset = np.zeros(self.N)
+        return float(np.mean(ars)) if ars else 1.0
+
+    def _maybe_exchange(self, acc_rate):
         # ---- exchange step (smc_samplers.py:1159-1163): more state particles when moves get rejected
         if 0.0 <= acc_rate < self.ar_to_increase_Nx and 2 * self.Nx <= self.max_Nx:
             new = self._batch(self.theta, 2 * self.Nx)
@@ -280,8 +348,6 @@ class SMC2:
             self.Nx *= 2
             self.lw = liw.copy()
             self._lw_at_reset = np.zeros(self.N)       # E[exp(liw)] = 1 under the extended target
-        self.Nxs.append(self.Nx)
-        self.move_times.append(time.perf_counter() - t0)
 
     # ------------------------------------------------------------------ summaries
     def posterior_mean(self):
@@ -329,6 +395,8 @@ class ShardedSMC2(SMC2):
                              "use an IndepPrior")
         if kw.get("seed") is None:
             raise ValueError("ShardedSMC2 needs a seed (the same on every rank)")
+        if kw.get("wastefree"):
+            raise ValueError("ShardedSMC2: the waste-free move is implemented for one process (SMC2)")
         super().__init__(**kw)
         self._cum0 = np.zeros(self.N)        # filters' evidences at the last reset of the theta-weights
         self._lw0 = np.zeros(self.N)         # theta log-weights at that reset

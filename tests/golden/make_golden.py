@@ -299,6 +299,36 @@ def main():
                                sigmaX=1.0, true_rho=0.8, true_sigmaY=0.4, kalman_loglik_at_truth=np.sum(kal.logpyt),
                                **{k: np.array(v, dtype=float) for k, v in rec.items()})
 
+    # --- the same with the reference's DEFAULT move, waste-free (smc_samplers.py:669-684, 730-768): N chains of
+    # len_chain states, all kept -- a population of N x len_chain theta-particles
+    if "smc2_wf_ref" in sys.argv[1:] or not sys.argv[1:]:
+        from particles import smc_samplers as ssp
+        R, T, N, Nx, len_chain = 32, 40, 32, 64, 4
+        np.random.seed(4)
+        x, y = kalman.LinearGauss(sigmaX=1.0, sigmaY=0.4, rho=0.8).simulate(T)
+        prior = dists.StructDist({"rho": dists.Uniform(a=0.3, b=0.99), "sigmaY": dists.Gamma(a=2.0, b=4.0)})
+        rec = dict(logLt=[], m_rho=[], m_sigmaY=[], s_rho=[], s_sigmaY=[], ESSs=[], rs_flags=[], Nx_final=[])
+        for r in range(R):
+            np.random.seed(2000 + r)
+            fk = ssp.SMC2(ssm_cls=kalman.LinearGauss, prior=prior, data=y, init_Nx=Nx, len_chain=len_chain,
+                          wastefree=True, ar_to_increase_Nx=-1.0)
+            alg = particles.SMC(fk=fk, N=N, ESSrmin=0.5)
+            alg.run()
+            W = alg.W
+            assert alg.X.N == N * len_chain
+            for k in ("rho", "sigmaY"):
+                m = np.sum(W * alg.X.theta[k])
+                rec["m_" + k].append(m)
+                rec["s_" + k].append(np.sqrt(np.sum(W * (alg.X.theta[k] - m) ** 2)))
+            rec["logLt"].append(alg.logLt)
+            rec["ESSs"].append(alg.summaries.ESSs)
+            rec["rs_flags"].append(alg.summaries.rs_flags)
+            rec["Nx_final"].append(alg.X.pfs[0].N)
+            print("smc2_wf_ref run", r, alg.logLt, rec["m_rho"][-1], rec["m_sigmaY"][-1], sum(alg.summaries.rs_flags), flush=True)
+        out["smc2_wf_ref"] = dict(y=np.array(y), R=R, T=T, N=N, Nx=Nx, len_chain=len_chain, ESSrmin=0.5,
+                                  prior_rho=np.array([0.3, 0.99]), prior_sigmaY=np.array([2.0, 4.0]), sigmaX=1.0,
+                                  **{k: np.array(v, dtype=float) for k, v in rec.items()})
+
     only = sys.argv[1:]              # optional: names of the fixtures to (re)write
     for name, case in out.items():
         if only and name not in only:

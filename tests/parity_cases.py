@@ -1613,7 +1613,7 @@ def check_smc2(Ntheta=64, Nx=128, T=30, seed=3, big_Nx=(), big_N=16, big_T=12):
     assert abs(e.posterior_mean()["sigmaY"] - sig) < 0.3
 
 
-def check_smc2_vs_reference(golden, R=24, sharded=False, tol_se=3.0):
+def check_smc2_vs_reference(golden, R=24, sharded=False, tol_se=3.0, wastefree=False):
     """SMC^2 pinned to the REFERENCE's SMC^2 (smc_samplers.py:1038-1167): tests/golden/smc2_ref.npz holds
     24 independent runs of particles.SMC(fk=SMC2(kalman.LinearGauss, StructDist{rho ~ U(0.3, 0.99),
     sigmaY ~ Gamma(2, 4)}, init_Nx=64, len_chain=4, wastefree=False), N=64) on one simulated data set,
@@ -1624,7 +1624,9 @@ def check_smc2_vs_reference(golden, R=24, sharded=False, tol_se=3.0):
     evidence of the whole model, the posterior mean and sd of each parameter, the ESS trajectory and the
     number of resample-move events.  A wrong weight update, move or exchange shifts these by many SEs."""
     from particles_amd import smc2
-    g = golden("smc2_ref")
+    # wastefree: fixture smc2_wf_ref = 32 runs of the reference's DEFAULT move (smc_samplers.py:669-684: N = 32
+    # chains of len_chain = 4 states, all kept: 128 theta-particles) against the device's waste-free move
+    g = golden("smc2_wf_ref" if wastefree else "smc2_ref")
     y = [np.atleast_1d(v) for v in np.squeeze(g["y"])]
     T, N, Nx = int(g["T"]), int(g["N"]), int(g["Nx"])
     prior = smc2.IndepPrior(rho=("uniform", float(g["prior_rho"][0]), float(g["prior_rho"][1])),
@@ -1634,7 +1636,8 @@ def check_smc2_vs_reference(golden, R=24, sharded=False, tol_se=3.0):
     for r in range(R):
         alg = cls(ssm_cls=lambda rho, sigmaY: kalman.LinearGauss(sigmaX=float(g["sigmaX"]), sigmaY=sigmaY, rho=rho),
                   prior=prior, data=y, init_Nx=Nx, N=N, ESSrmin=float(g["ESSrmin"]), nmcmc=int(g["len_chain"]) - 1,
-                  seed=500 + r, sync_every=8)
+                  seed=500 + r, sync_every=8, **(dict(wastefree=True, len_chain=int(g["len_chain"])) if wastefree else {}))
+        assert alg.N == N * (int(g["len_chain"]) if wastefree else 1) and alg.pf.n_islands == alg.N
         alg.run()
         assert alg.t == T and len(alg.ESSs) == T
         m, sd = alg.posterior_mean(), alg.posterior_sd()
@@ -1666,6 +1669,42 @@ def check_smc2_vs_reference(golden, R=24, sharded=False, tol_se=3.0):
     zs = np.array([abs(v[2]) for v in report.values()])
     assert np.all(zs <= tol_se + 1.0) and np.sum(zs > tol_se) <= 1, report
     return report
+
+
+def check_smc2_wastefree_functional():
+    from particles_amd import smc2
+    rng = np.random.RandomState(4)
+    T = 20
+    x = np.cumsum(rng.standard_normal(T)) * 0.5
+    y = [np.array([v]) for v in x + 0.3 * rng.standard_normal(T)]
+    prior = smc2.IndepPrior(sigmaY=("lognormal", np.log(0.5), 1.0))
+    kw = dict(ssm_cls=lambda sigmaY: kalman.LinearGauss(rho=0.9, sigmaX=1.0, sigmaY=sigmaY), prior=prior, data=y,
+              init_Nx=64, ESSrmin=0.5)
+    runs = []
+    for seed in (5, 6, 7):
+        a = smc2.SMC2(wastefree=True, len_chain=5, N=8, seed=seed, **kw)
+        assert a.N == 40 and a.M == 8 and a.P == 5 and a.pf.n_islands == 40 and a.nmcmc == 4
+        a.run()
+        assert a.t == T and len(a.ESSs) == T and len(a.move_times) >= 1 and a.pf.n_islands == 40
+        assert len(a.acc_rates) == 4 * len(a.move_times) and all(len(v) == 40 for v in a.theta.values())
+        assert np.isfinite(a.logLt) and np.all(np.isfinite(a.lw))
+        runs.append((a.logLt, a.posterior_mean()["sigmaY"]))
+    b = smc2.SMC2(nmcmc=4, N=40, seed=5, **kw)
+    b.run()
+    ll = np.array([r[0] for r in runs])
+    assert abs(ll.mean() - b.logLt) < 1.0 and abs(np.mean([r[1] for r in runs]) - b.posterior_mean()["sigmaY"]) < 0.15
+    # a filter taken over by a fresh one continues bit for bit (fast-forward + pack / unpack)
+    src = pa.SMC(fk=[ssm.Bootstrap(ssm=kalman.LinearGauss(rho=0.9, sigmaX=1.0, sigmaY=s_), data=y) for s_ in (0.2, 0.3, 0.5)],
+                 N=200, seed=3, collect="off")
+    src.step_async(7)
+    dst = pa.SMC(fk=[ssm.Bootstrap(ssm=kalman.LinearGauss(rho=0.9, sigmaX=1.0, sigmaY=0.9), data=y) for _ in range(3)],
+                 N=200, seed=3, collect="off")
+    dst.take_islands_from(src, [2, 0, 1])
+    assert dst.t == 7
+    src.permute_islands(np.array([2, 0, 1]))
+    src.run()
+    dst.run()
+    assert np.array_equal(src.logLts_islands, dst.logLts_islands) and np.array_equal(np.asarray(src.X), np.asarray(dst.X))
 
 
 def check_generic_path(golden):

@@ -223,9 +223,10 @@ def test_reference_smc2_runs_on_device_filters_under_install(ref):
 
     def run(seed):
         np.random.seed(seed)
-        # (the reference's default, waste-free move: not a form the device class implements, so the outer
-        #  loop stays the reference's under install() -- only its inner filters change)
-        fk = ssp.SMC2(ssm_cls=rk.LinearGauss, prior=prior, data=y, init_Nx=64, len_chain=3, wastefree=True)
+        # (an ADAPTIVE sequence of MCMC steps: not a form the device class implements, so the outer loop
+        #  stays the reference's under install() -- only its inner filters change)
+        fk = ssp.SMC2(ssm_cls=rk.LinearGauss, prior=prior, data=y, init_Nx=64, wastefree=False,
+                      move=ssp.AdaptiveMCMCSequence(len_chain=3, adaptive=True))
         alg = particles.SMC(fk=fk, N=24, verbose=False)
         alg.run()
         return alg
@@ -258,9 +259,10 @@ def test_reference_smc2_runs_on_device_filters_under_install(ref):
 
 
 def test_reference_smc2_object_maps_onto_the_device_class(ref):
-    """HipSMC(fk=<the reference's SMC2, wastefree=False>, N=...) is the device class behind the outer
-    SMC's attributes (X.theta, W, logLt, summaries, run / next); anything the device class does not
-    implement exactly (the waste-free move, a user's model class) stays with the reference's loop."""
+    """HipSMC(fk=<the reference's SMC2>, N=...) is the device class behind the outer SMC's attributes
+    (X.theta, W, logLt, summaries, run / next), for the standard and for the waste-free (default) move;
+    anything the device class does not implement exactly (an adaptive MCMC sequence, a user's model
+    class) stays with the reference's loop."""
     from particles_amd import adapter, smc2
     particles, rk, dists, rssm = ref["particles"], ref["kalman"], ref["dists"], ref["ssm"]
     from particles import smc_samplers as ssp
@@ -285,9 +287,15 @@ def test_reference_smc2_object_maps_onto_the_device_class(ref):
     for _ in stp:
         pass
     assert stp.logLt == alg.logLt and np.array_equal(stp.X.theta, th) and stp.summaries.ESSs == s.ESSs
-    # not ours: the waste-free move (the reference's default), a user's subclass of a stock model
-    wf = HipSMC(fk=ssp.SMC2(ssm_cls=rk.LinearGauss, prior=prior, data=y, init_Nx=32), N=16)
-    assert isinstance(wf, particles.SMC) and not isinstance(wf, adapter.DeviceSMC2Run)
+    # the reference's DEFAULT SMC2 -- the waste-free move (smc_samplers.py:669-684), len_chain states per chain
+    wf = HipSMC(fk=ssp.SMC2(ssm_cls=rk.LinearGauss, prior=prior, data=y, init_Nx=32, len_chain=4), N=8, seed=5)
+    assert isinstance(wf, adapter.DeviceSMC2Run) and wf._alg.wastefree and wf._alg.N == 32 and wf._alg.nmcmc == 3
+    wf.run()
+    assert wf.X.theta.shape == (32,) and abs(wf.W.sum() - 1) < 1e-12 and np.isfinite(wf.logLt) and wf.t == 16
+    # not ours: an adaptive sequence of MCMC steps, a user's subclass of a stock model
+    ad = HipSMC(fk=ssp.SMC2(ssm_cls=rk.LinearGauss, prior=prior, data=y, init_Nx=32, wastefree=False,
+                            move=ssp.AdaptiveMCMCSequence(len_chain=3, adaptive=True)), N=16)
+    assert isinstance(ad, particles.SMC) and not isinstance(ad, adapter.DeviceSMC2Run)
 
     class MyLG(rk.LinearGauss):
         pass

@@ -289,6 +289,14 @@ def test_smc2_device_theta_level():
     pc.check_smc2(Ntheta=32, Nx=64, big_Nx=(2048,), big_N=4, big_T=6)
 
 
+def test_smc2_wastefree_move():
+    """The waste-free move (the reference's default, smc_samplers.py:669-684) on device filters, functionally:
+    N chains x len_chain states all kept with their filters, the population assembled from the chains'
+    batches (smc_filter_fast_forward + pack / unpack), evidence and posterior close to the standard move's and
+    to Kalman's.  (The comparison with 32 recorded runs of the reference is a GPU test: 48 runs.)"""
+    pc.check_smc2_wastefree_functional()
+
+
 def test_partial_history_syncs_at_save_times_only():
     pc.check_partial_history(N=1500, T=16)
 

@@ -529,6 +529,12 @@ def test_smc2_pinned_to_the_reference(golden, sharded):
     pc.check_smc2_vs_reference(golden, R=48, sharded=sharded)
 
 
+def test_smc2_wastefree_pinned_to_the_reference(golden):
+    """The waste-free move (the reference's default, smc_samplers.py:669-684) on device filters: 32 chains of 4
+    states, every state kept with its filter -- against 32 recorded runs of the reference's own waste-free SMC2."""
+    pc.check_smc2_vs_reference(golden, R=48, wastefree=True)
+
+
 def test_partial_history_syncs_at_save_times_only():
     pc.check_partial_history(N=100000, T=40)
 
