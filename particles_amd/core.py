@@ -227,7 +227,7 @@ class SMC:
                 and model.get("params") is not None and model.get("dx", 1) == 1
                 and getattr(fk, "_fk_kind", None) in (_lib.FK_BOOTSTRAP, _lib.FK_GUIDED)
                 and 2048 <= N <= (1 << 30) and N & (N - 1) == 0
-                and replay is None and not use_graph and not strict)
+                and replay is None and not strict)
 
     @staticmethod
     def _will_fuse(fk, qmc=False, resampling="systematic", model=False, N=None):

@@ -140,7 +140,8 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
         a.zt_ts = 0;
         a.sq_seed = f->sq_seed;
         a.sq_ctr = f->sq_ctr0;
-        if (t == 0) {
+        // (inside a captured graph only the parity of t is static: replays start at t >= 2, see smc_filter_step)
+        if (t_known && t == 0) {
             SMC_LAUNCH(k_sq_init, dim3((unsigned)((a.N + SMC_BLOCK - 1) / SMC_BLOCK), a.n_islands), dim3(SMC_BLOCK), st,
                        f->a, f->sq_z, f->sq_seed, f->sq_ctr0);
         } else {
@@ -361,10 +362,10 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
         bool pow2 = false;
         for (int k = 11; k <= 30; ++k) pow2 = pow2 || (((i64)1 << k) == o->N);
         if (mv || !(model->fk == SMC_FK_BOOTSTRAP || model->fk == SMC_FK_GUIDED) || !pow2 || f->strict ||
-            o->rng_mode != SMC_RNG_PHILOX || o->use_graph ||
+            o->rng_mode != SMC_RNG_PHILOX ||
             (o->flags & (SMC_PATH_FLAT_CDF | SMC_PATH_FORCE_FUSED | SMC_PATH_FORCE_UNFUSED | SMC_PATH_FLAT_MULTINOMIAL))) {
             smc_set_error("SMC_FLAG_SQMC: univariate Bootstrap / Guided filters, N = 2^k with 11 <= k <= 30, "
-                          "Philox mode, eager launches, the two-level step");
+                          "Philox mode, the two-level step");
             delete f;
             return SMC_ERR_INVALID;
         }
@@ -891,7 +892,8 @@ int smc_filter_step(smc_filter* f, int64_t nsteps)
     // the nodes), captured on first use; any request of two or more steps replays them greedily
     static const int F_GRAPH_SIZES[3] = {24, 8, 2};
     if (f->use_graph && !f->prof && !f->graph_failed && todo >= 2) {
-        if ((f->t_host + done) & 1) {                    // graphs start at even t
+        // graphs start at even t (SQMC: at even t >= 2 -- step 0 has no sort, the captured sequence always does)
+        while (done < todo && (((f->t_host + done) & 1) || (f->sqmc && f->t_host + done < 2))) {
             enqueue_step(f, -1, f->t_host + done);
             ++done;
         }

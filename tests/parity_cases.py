@@ -2354,6 +2354,12 @@ def check_sqmc_fused(sizes=(2048, 4096), T=6, audit_sizes=(4096,), islands_N=204
                 pq = pa.SMC(fk=cls(ssm=mk(), data=y), N=N, qmc=True, collect="off")
                 pq.run()
                 assert np.array_equal(np.asarray(pq.X), np.asarray(pf.X)) and pq.logLt == pf.logLt
+                # ... and so does the loop replayed from hipGraphs (steps 0 and 1 eagerly, then captured pairs)
+                pa.seed(47)
+                pg = pa.SMC(fk=cls(ssm=mk(), data=y), N=N, qmc=True, collect="off", use_graph=True)
+                assert pg._fused
+                pg.run()
+                assert np.array_equal(np.asarray(pg.X), np.asarray(pf.X)) and pg.logLt == pf.logLt
         # islands: each an SQMC run of its own (point sets keyed by the island id)
         pa.seed(53)
         c0 = _lib._counter + 1

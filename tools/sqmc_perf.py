@@ -16,7 +16,7 @@ from particles_amd import kalman, resampling as rs
 from particles_amd import state_space_models as ssm
 
 
-def run(model, N, T, label, fused=True):
+def run(model, N, T, label, fused=True, graph=False):
     np.random.seed(42)
     rs.set_rng("numpy")
     pa.set_resident(False)
@@ -29,13 +29,13 @@ def run(model, N, T, label, fused=True):
         out = []
         for rep in range(3):
             pa.seed(7 + rep)
-            pf = pa.SMC(fk=ssm.Bootstrap(ssm=model, data=y), N=N, qmc=True, collect="off")
+            pf = pa.SMC(fk=ssm.Bootstrap(ssm=model, data=y), N=N, qmc=True, collect="off", use_graph=graph)
             t0 = time.perf_counter()
             pf.run()
             ll = float(pf.logLt)              # forces completion
             out.append((time.perf_counter() - t0) / T)
-        print("%-28s N=2^%-2d  %-9s %8.3f ms/step  %7.2f M particle-steps/s   logLt %.3f"
-              % (label, int(np.log2(N)), "fused" if pf._fused else "operators", 1e3 * min(out), N / min(out) / 1e6, ll))
+        print("%-28s N=2^%-2d  %-11s %8.3f ms/step  %7.2f M particle-steps/s   logLt %.3f"
+              % (label, int(np.log2(N)), ("fused+graph" if graph else "fused") if pf._fused else "operators", 1e3 * min(out), N / min(out) / 1e6, ll))
     finally:
         pa.set_resident(False)
         rs.set_rng("numpy")
@@ -48,6 +48,7 @@ if __name__ == "__main__":
         sys.exit(0)
     for k in (12, 16, 20, 22):
         run(kalman.ToySSM(0.2), 1 << k, 30, "ToySSM d=1")
+        run(kalman.ToySSM(0.2), 1 << k, 30, "ToySSM d=1", graph=True)
         run(kalman.ToySSM(0.2), 1 << k, 30, "ToySSM d=1", fused=False)
     for k in (12, 16, 18):
         run(kalman.MVLinearGauss_Guarniero_etal(alpha=0.4, dx=2), 1 << k, 20, "MVLinearGauss d=2 (Hilbert)")
