@@ -2348,6 +2348,7 @@ k_ancestors2(const FArgs av)
             if (lane == 0) { s_k[wave] = v; s_b[2 * wave] = (double)Bl; s_b[2 * wave + 1] = (double)(Bh == ~0ull ? Bl + 1ull : Bh); }
         }
         __syncthreads();
+        F_STAMP_A(2);                                                      // (REGEN: tile prefixes probed)
         const i64 k_lo = s_k[0];
         i64 k_hi = s_k[1];
         k_hi = k_hi > (i64)a.ntiles1 - 1 ? (i64)a.ntiles1 - 1 : k_hi;       // (C >= 2^52: every draw counted)
@@ -2366,18 +2367,31 @@ k_ancestors2(const FArgs av)
         const bool zform = a.sp_tpw > 0;           // su holds the integer prefix sums Z_n: su_n = fl(Z_n) / fl(Z_N)
         if (zform && b < a.sp_nwg && tid == 0) a.sst[(i64)isl * a.sp_nwg + b] = 0ull;     // look-back words: re-armed
         if (staged) {
-            for (int i = tid * 2; i < nw; i += 2 * SMC_BLOCK) {
-                double u0, u1 = 2.0;
-                if (i + 1 < nw && (N & 1) == 0) smc_ld2g(su.u + s0 + i, u0, u1);
-                else {
-                    u0 = smc_ldg(su.u + s0 + i);
-                    if (i + 1 < nw) u1 = smc_ldg(su.u + s0 + i + 1);
+            // (WMAX = 3 x 512: at most three pairs per thread -- all of them requested before the first is used;
+            //  the loop form waited for each pair in turn, 3.0 -> ... us per workgroup in r05t's timeline)
+            constexpr int NPAIR = WMAX / (2 * SMC_BLOCK);
+            double w0[NPAIR], w1[NPAIR];
+            const bool even = (N & 1) == 0;
+#pragma unroll
+            for (int r = 0; r < NPAIR; ++r) {
+                const int i = tid * 2 + r * 2 * SMC_BLOCK;
+                w0[r] = 2.0;
+                w1[r] = 2.0;
+                if (i + 1 < nw && even) smc_ld2g(su.u + s0 + i, w0[r], w1[r]);
+                else if (i < nw) {
+                    w0[r] = smc_ldg(su.u + s0 + i);
+                    if (i + 1 < nw) w1[r] = smc_ldg(su.u + s0 + i + 1);
                 }
+            }
+#pragma unroll
+            for (int r = 0; r < NPAIR; ++r) {
+                const int i = tid * 2 + r * 2 * SMC_BLOCK;
+                double u0 = w0[r], u1 = w1[r];
                 if (zform) {
                     u0 = smc_div_c((double)(u64)__double_as_longlong(u0), g.dall, g.rdall);
                     u1 = smc_div_c((double)(u64)__double_as_longlong(u1), g.dall, g.rdall);
                 }
-                sT[i] = ceil(u0 * 4503599627370496.0);
+                if (i < nw) sT[i] = ceil(u0 * 4503599627370496.0);
                 if (i + 1 < nw) sT[i + 1] = ceil(u1 * 4503599627370496.0);
             }
             __syncthreads();
@@ -2400,6 +2414,7 @@ k_ancestors2(const FArgs av)
             // guards: sT[-1] below everything this tile compares with (see ok_lo), 4 slots of +inf at the end
             for (int i = tid; i < 4; i += SMC_BLOCK) sT[nw + i] = INFINITY;
             __syncthreads();
+            F_STAMP_A(3);                                                  // (REGEN: window staged)
             int kprev = 0;
             bool have_prev = false;
 #pragma unroll
@@ -2419,9 +2434,19 @@ k_ancestors2(const FArgs av)
                 else Cd = Gbd + fmin(floor((double)c * qscale), Qbd);
                 int k;
                 if (have_prev) {
-                    const double t0 = sT[kprev], t1 = sT[kprev + 1], t2 = sT[kprev + 2], t3 = sT[kprev + 3];
-                    const int adv = (t0 <= Cd ? 1 : 0) + (t1 <= Cd ? 1 : 0) + (t2 <= Cd ? 1 : 0) + (t3 <= Cd ? 1 : 0);
-                    k = kprev + adv;
+                    // (a parent with more than 3 offspring -- 2 % of them, but 3 waves in 4 hold one -- takes a
+                    //  second and a third step of 4 probes before it bisects: a step is ONE LDS latency, the
+                    //  bisection eleven; r05t: the counts went from 4.9 to ... us per workgroup)
+                    k = kprev;
+                    int adv = 4;
+#pragma unroll
+                    for (int s_ = 0; s_ < 3; ++s_) {
+                        if (adv == 4) {
+                            const double t0 = sT[k], t1 = sT[k + 1], t2 = sT[k + 2], t3 = sT[k + 3];
+                            adv = (t0 <= Cd ? 1 : 0) + (t1 <= Cd ? 1 : 0) + (t2 <= Cd ? 1 : 0) + (t3 <= Cd ? 1 : 0);
+                            k += adv;
+                        }
+                    }
                     if (adv == 4) k += f2_count_lds_f64(sT + k, nw - k, Cd);
                 } else {
                     k = f2_count_lds_f64(sT, nw, Cd);

@@ -70,6 +70,9 @@ sweep)
   (timeout 300 python tools/size_sweep.py > $O/size_sweep.txt 2>&1); cat $O/size_sweep.txt ;;
 trace)
   (timeout 200 python tools/trace_step.py > $O/trace_step.txt 2>&1); cat $O/trace_step.txt ;;
+trace_c3m)
+  (timeout 200 python tools/trace_step.py 22 multinomial sv > $O/trace_c3m.txt 2>&1); cat $O/trace_c3m.txt
+  (timeout 200 python tools/trace_step.py 22 systematic sv > $O/trace_c3s.txt 2>&1); cat $O/trace_c3s.txt ;;
 prof_c5)
   EXTRA="--workload c5" bash tools/gpu_profile.sh ${TAG}_c5 100 > $O/prof_c5.txt 2>&1; tail -30 $O/prof_c5.txt ;;
 prof_c4)

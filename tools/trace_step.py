@@ -18,11 +18,15 @@ from particles_amd import _lib, kalman, state_space_models as ssm   # noqa: E402
 from bench import synthetic_data                                # noqa: E402
 
 log2N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+scheme = sys.argv[2] if len(sys.argv) > 2 else "systematic"
 N = 1 << log2N
 y = synthetic_data(200)
-pf = pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y), N=N, seed=123, use_graph=False)
+model = ssm.StochVol() if len(sys.argv) > 3 and sys.argv[3] == "sv" else kalman.ToySSM(0.2)
+pf = pa.SMC(fk=ssm.Bootstrap(ssm=model, data=y), N=N, seed=123, use_graph=False, resampling=scheme,
+            ESSrmin=1.0 if len(sys.argv) > 2 else 0.5)
 pf.step_async(100)
 pf.sync()
+
 nparts, ntiles = N // 1024, N // 1024
 buf = np.zeros((nparts + ntiles) * 8, dtype=np.uint64)
 lib = _lib.lib()
@@ -47,6 +51,17 @@ for name, st, labels in (
         print("  %-16s n=%5d  min %6.2f  median %6.2f  p90 %6.2f  p99 %6.2f  max %6.2f us (wg %d)"
               % (lab, col.size, col.min() / 100.0, np.median(col) / 100.0, np.percentile(col, 90) / 100.0,
                  np.percentile(col, 99) / 100.0, col.max() / 100.0, int(np.argmax(st[:, k]))))
+    if st.shape[0] > 1024:
+        # several rounds of workgroups: what a workgroup spends between two of its own stamps
+        print("  per workgroup, between consecutive stamps (median / p90 us):")
+        prev = 0
+        for k in range(1, len(labels)):
+            ok = (st[:, k] >= st[:, prev]) & (st[:, k] > 0)
+            if not ok.any():
+                continue
+            dlt = (st[ok, k].astype(np.int64) - st[ok, prev].astype(np.int64)) / 100.0
+            print("    %-18s -> %-18s %6.2f / %6.2f" % (labels[prev], labels[k], np.median(dlt), np.percentile(dlt, 90)))
+            prev = k
     if name == "k_ancestors<true>":
         d = (st[:, 3].astype(np.int64) - st[:, 2].astype(np.int64)) / 100.0
         order = np.argsort(-d)[:8]
