@@ -132,7 +132,7 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
     hipStream_t st = f->ctx->stream;
     const dim3 grid(f->a.ntiles, f->a.n_islands);
     if (k_prof >= 0) (void)hipEventRecord(f->ev[3 * k_prof], st);
-    if (f->sqmc) {
+    if (f->sqmc && f->kind != SMC_MODEL_MVLINGAUSS) {
         // smc_filter_sqmc.h.  The step's normals come from a tape that is ONE step's buffer (zt_ts = 0),
         // written by k_sq_init / k_sq_permute just before; the thresholds are a function of n (f2_sq_T)
         FArgs& a = f->a;
@@ -236,6 +236,33 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
         return;
     }
     const bool fused = f->fused;
+    if (f->sqmc) {
+        // SQMC of a multivariate filter (smc_filter_sqmc.h): Hilbert order, the step's points, the tapes; the flat
+        // step then runs as it is -- its multinomial search over the sorted uniforms in a.su, its propagate
+        // kernel fed from the tape of ndtri values
+        FArgs& a = f->a;
+        const int d = a.dx;
+        const unsigned nb = (unsigned)((a.N + SMC_BLOCK - 1) / SMC_BLOCK);
+        double* U = (double*)f->sq_ws;
+        double* lws = U + (size_t)a.N * (d + 1);
+        a.zt = f->sq_z;
+        a.zt_ts = 0;
+        for (int i = 0; i < a.n_islands; ++i) {
+            const u64 ctr = f->sq_ctr0 + (u64)t + ((u64)(u32)(a.island_offset + i) << 32);
+            if (t == 0) {
+                (void)smc_sobol_points(f->ctx, f->sq_seed, a.N, d, ctr, 0, U);
+                SMC_LAUNCH(k_sqmv_tapes, dim3(nb), dim3(SMC_BLOCK), st, f->a, i, (const i64*)nullptr, (const double*)U, d,
+                           lws, f->sq_z);
+            } else {
+                i64* perm = (i64*)f->sq_perm + (size_t)i * a.N;
+                (void)smc_hilbert_sort(f->ctx, f_X(a, t - 1) + (size_t)i * a.N * d, a.N, d, (int64_t*)perm, nullptr);
+                (void)smc_sobol_points(f->ctx, f->sq_seed, a.N, d + 1, ctr, 1, U);
+                SMC_LAUNCH(k_sqmv_tapes, dim3(nb), dim3(SMC_BLOCK), st, f->a, i, (const i64*)perm, (const double*)U, d + 1,
+                           lws, f->sq_z);
+                (void)hipMemcpyAsync(f_lw(a, t - 1) + (size_t)i * a.N, lws, (size_t)a.N * 8, hipMemcpyDeviceToDevice, st);
+            }
+        }
+    }
     if (f->kind == SMC_MODEL_MVLINGAUSS && f->fk == SMC_FK_APF) {
         // auxiliary weights of step t (core.py:307-313) before its resampling: smc_filter_mv.h
         const dim3 gp(f->a.nparts, f->a.n_islands);
@@ -246,7 +273,7 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
         SMC_LAUNCH(k_mv_aux_restate, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
     }
     if (!fused) SMC_LAUNCH(k_prepare, grid, dim3(SMC_BLOCK), st, f->a);
-    if (f->a.scheme == SMC_MULTINOMIAL && !f->a.ut) {
+    if (f->a.scheme == SMC_MULTINOMIAL && !f->a.ut && !f->sqmc) {
         const dim3 g1(f->a.ntiles1, f->a.n_islands);
         SMC_LAUNCH(k_f_spacing_sums, g1, dim3(SMC_BLOCK), st, f->a);
         SMC_LAUNCH(k_f_spacing_scan, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
@@ -255,6 +282,10 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
     if (fused && f->a.par >= 0) SMC_LAUNCH((k_ancestors<true, true>), grid, dim3(SMC_BLOCK), st, f->a);
     else if (fused) SMC_LAUNCH((k_ancestors<true, false>), grid, dim3(SMC_BLOCK), st, f->a);
     else SMC_LAUNCH((k_ancestors<false, false>), grid, dim3(SMC_BLOCK), st, f->a);
+    if (f->sqmc && t > 0)                          // A <- h_order[A] (core.py:344)
+        for (int i = 0; i < f->a.n_islands; ++i)
+            SMC_LAUNCH(k_sqmv_compose, dim3((unsigned)((f->a.N + SMC_BLOCK - 1) / SMC_BLOCK)), dim3(SMC_BLOCK), st, f->a, i,
+                       (const i64*)f->sq_perm + (size_t)i * f->a.N);
     // samples come in three kinds (k mod 3): 0 times the whole step, 1 the interval [start,
     // resampling kernels done], 2 the interval [resampling kernels done, end].  Every event
     // interval carries the same ~4 us of marker processing on MI355X (tools/micro/events.hip),
@@ -357,15 +388,18 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     f->sq_perm = nullptr;
     f->sq_ws = nullptr;
     if (f->sqmc) {
-        // core.py:339-349 on the two-level step: univariate Normal kernels (Gamma = ppf), N = 2^k >= 2 tiles
-        // (the sorted Sobol' order in closed form), device-generated points
+        // core.py:339-349 as a fused loop.  Univariate Normal kernels (Gamma = ppf): the two-level step, N = 2^k >=
+        // 2 tiles (the sorted Sobol' order in closed form).  MVLINGAUSS (2 <= d <= 9: d + 1 Sobol' coordinates): the
+        // flat step behind the Hilbert sort, N = 2^k >= 32, no history slots (the sorted weights take the slot).
         bool pow2 = false;
-        for (int k = 11; k <= 30; ++k) pow2 = pow2 || (((i64)1 << k) == o->N);
-        if (mv || !(model->fk == SMC_FK_BOOTSTRAP || model->fk == SMC_FK_GUIDED) || !pow2 || f->strict ||
-            o->rng_mode != SMC_RNG_PHILOX ||
+        for (int k = mv ? 5 : 11; k <= 30; ++k) pow2 = pow2 || (((i64)1 << k) == o->N);
+        const bool fk_ok = model->fk == SMC_FK_BOOTSTRAP || model->fk == SMC_FK_GUIDED;
+        const bool mv_ok = !mv || (model->dx >= 2 && model->dx <= 9 && !o->keep_history && !o->moments &&
+                                   !(o->flags & SMC_FLAG_COLLAPSED_PROPOSAL));
+        if (!fk_ok || !pow2 || !mv_ok || f->strict || o->rng_mode != SMC_RNG_PHILOX || (mv && o->use_graph) ||
             (o->flags & (SMC_PATH_FLAT_CDF | SMC_PATH_FORCE_FUSED | SMC_PATH_FORCE_UNFUSED | SMC_PATH_FLAT_MULTINOMIAL))) {
-            smc_set_error("SMC_FLAG_SQMC: univariate Bootstrap / Guided filters, N = 2^k with 11 <= k <= 30, "
-                          "Philox mode, the two-level step");
+            smc_set_error("SMC_FLAG_SQMC: Bootstrap / Guided filters; univariate models: N = 2^k with 11 <= k <= 30; "
+                          "MVLINGAUSS: 2 <= d <= 9, N = 2^k with 5 <= k <= 30, eager launches, no history slots; Philox mode");
             delete f;
             return SMC_ERR_INVALID;
         }
@@ -523,16 +557,17 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     f->sp_merge = a.sp_tpw && merge_fits && !o->use_graph && !(o->flags & SMC_PATH_SPLIT_REDUCE);
     const size_t oTmp = carve(N * dxm * 8);
     const size_t oStrict = carve(f->strict ? M * N * 8 : 8);
-    if (f->sqmc && !f->two_level) {
+    if (f->sqmc && !mv && !f->two_level) {
         smc_set_error("SMC_FLAG_SQMC needs the two-level step");
         delete f;
         return SMC_ERR_INVALID;
     }
     const bool apf_mv = mv && model->fk == SMC_FK_APF;
     const size_t oEta = carve(apf_mv ? 2 * M * N * 8 : 8);
-    const size_t oSqZ = carve(f->sqmc ? M * N * 8 : 8);
-    const size_t oSqPerm = carve(f->sqmc && M > 1 ? M * N * 8 : 8);
-    const size_t oSqWs = carve(f->sqmc ? smc_rs_ws_bytes((i64)N) : 8);
+    const size_t oSqZ = carve(f->sqmc ? M * N * dxm * 8 : 8);
+    const size_t oSqPerm = carve(f->sqmc && (M > 1 || mv) ? M * N * 8 : 8);
+    // (univariate: the sort's workspace; multivariate: the step's points (N, d + 1) and a row of sorted log-weights)
+    const size_t oSqWs = carve(!f->sqmc ? 8 : mv ? (N * (dxm + 1) + N) * 8 : smc_rs_ws_bytes((i64)N));
     a.nmb = (int)((o->N + F_MOM_CHUNK - 1) / F_MOM_CHUNK);
     const size_t oMom = carve(o->moments ? M * T * 2 * dxm * 8 : 8);
     const size_t oMpart = carve(o->moments ? M * a.nmb * dxm * 3 * 8 : 8);
@@ -1567,7 +1602,10 @@ int smc_filter_describe(smc_filter* f, char* out, size_t n)
     const bool mv = f->kind == SMC_MODEL_MVLINGAUSS;
     std::string s;
     if (small_filter_ok(f)) s = "k_filter_small";
-    else if (f->sqmc) {
+    else if (f->sqmc && mv) {
+        s = std::string("smc_hilbert_sort+k_sobol+k_sqmv_tapes+") + (f->fused ? "k_ancestors<fused>" : "k_prepare+k_ancestors") +
+            "+k_sqmv_compose+k_propagate_mv [mv_chunks=" + std::to_string(f->a.mv_chunks) + "]";
+    } else if (f->sqmc) {
         s = "k_rs_sort+k_sq_permute+k_reduce2+k_ancestors2+k_sq_compose+k_propagate";
         if (f->a.mom) s += "+k_f_moments_partials+k_f_moments_final";
     } else if (f->strict) {

@@ -84,6 +84,44 @@ k_sq_permute(const FArgs av, const u64* perm, double* zbuf, const u64 pseed, con
     }
 }
 
+// ---- multivariate filters (MVLinearGauss, 2 <= d <= 9; the flat step): h_order = hilbert_sort(X) (hilbert.py:33-58,
+// the stand-alone operator's kernels), the step's d + 1 Sobol' coordinates sorted by the first (smc_sobol_points).
+// k_sqmv_tapes: the tape of the moves z = ndtri(u[:, 1:]) and -- t >= 1 -- the log-weights of step t - 1 in
+// Hilbert order (to a scratch row, copied over the slot afterwards: the flat resampling kernels form their exact
+// Q62 CDF straight from that slot) and the sorted first coordinates in the buffer the flat multinomial search
+// reads its sorted uniforms from (a.su).
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_sqmv_tapes(const FArgs av, const int isl, const i64* perm, const double* U, const int du, double* lw_sorted, double* zbuf)
+{
+    const FArgs& a = av;
+    const i64 n = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;
+    if (n >= a.N) return;
+    const int d = a.dx;
+    const double* row = U + n * du;
+    double* z = zbuf + ((i64)isl * a.N + n) * d;
+    for (int j = 0; j < d; ++j) z[j] = smc_ndtri(row[du - d + j]);
+    if (perm) {
+        const i64 t = (i64)smc_uniform(smc_ldg(a.info + (i64)isl * INFO_STRIDE));
+        if (t >= a.T || t == 0) return;
+        lw_sorted[n] = smc_ldg(f_lw(a, t - 1) + (i64)isl * a.N + perm[n]);
+        a.su[(i64)isl * a.N + n] = row[0];
+    }
+}
+// A_t <- h_order[A_t] (int64 permutation of the Hilbert sort)
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_sqmv_compose(const FArgs av, const int isl, const i64* perm)
+{
+    const FArgs& a = av;
+    const double* info = a.info + (i64)isl * INFO_STRIDE;
+    // (the flat step's record: info[0] = the step being run, info[1] = its decision)
+    const i64 t = (i64)smc_uniform(smc_ldg(info));
+    if (t >= a.T || t == 0 || smc_uniform(smc_ldg(info + 1)) == 0.0) return;
+    const i64 n = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;
+    if (n >= a.N) return;
+    u32* A = f_A(a, t) + (i64)isl * a.N;
+    A[n] = (u32)perm[A[n]];
+}
+
 // A_t <- h_order[A_t]: k_ancestors2 counted in sorted positions (core.py:344)
 __global__ void __launch_bounds__(SMC_BLOCK)
 k_sq_compose(const FArgs av, const u64* perm)

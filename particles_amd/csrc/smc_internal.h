@@ -68,4 +68,10 @@ size_t smc_rs_ws_bytes(long long N);
 int smc_rs_sort_ws(smc_ctx* ctx, const void* keys, const void* vals, long long N, int kind, void* ws,
                    unsigned long long** sorted_keys, unsigned long long** sorted_vals);
 
+// the scrambled Sobol' point set `counter` of the stream keyed by `seed` (smc_qmc.hip), (N, d) row-major
+int smc_sobol_points(smc_ctx* ctx, unsigned long long seed, long long N, int d, unsigned long long counter, int sorted,
+                     double* out);
+// hilbert_sort (smc_sort.hip; the C-ABI entry, declared here for the fused SQMC step)
+extern "C" int smc_hilbert_sort(smc_ctx* ctx, const double* x, int64_t N, int32_t d, int64_t* out, int64_t* keys_out);
+
 static inline size_t smc_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

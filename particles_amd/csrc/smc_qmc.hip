@@ -75,7 +75,7 @@ static const int SOBOL_M[SOBOL_MAXD + 1][5] = {{0}, {0}, {1}, {1, 3}, {1, 3, 1},
                                                {1, 1, 5, 5, 5}, {1, 1, 7, 11, 19}};
 
 static int sobol_launch(smc_ctx* ctx, int64_t N, int32_t d, int32_t scramble, int32_t safe,
-                        uint64_t counter, int order_k, double* out)
+                        uint64_t counter, int order_k, double* out, const u64* seed_override = nullptr)
 {
     SMC_REQUIRE(ctx && out, "null argument");
     SMC_REQUIRE(N > 0 && N <= ((int64_t)1 << SOBOL_BITS), "N must be in [1, 2^30]");
@@ -98,7 +98,7 @@ static int sobol_launch(smc_ctx* ctx, int64_t N, int32_t d, int32_t scramble, in
         for (int k = 0; k < SOBOL_BITS; ++k) tb.v[dim - 1][k] = m[k] << (SOBOL_BITS - 1 - k);
         u32 sh = 0u;
         if (scramble) {                       // digital shift: one Philox word per coordinate
-            sh = smc_sobol_shift((u64)ctx->seed, counter, (u32)(dim - 1));
+            sh = smc_sobol_shift(seed_override ? *seed_override : (u64)ctx->seed, counter, (u32)(dim - 1));
         }
         tb.shift[dim - 1] = sh;
     }
@@ -111,6 +111,21 @@ static int sobol_launch(smc_ctx* ctx, int64_t N, int32_t d, int32_t scramble, in
                ctx->stream, tb, (i64)N, (int)d, (int)safe, order_k, out);
     SMC_LAUNCH_CHECK();
     return SMC_OK;
+}
+
+// smc_internal.h: the point set `counter` of the stream keyed by `seed` (scramble = safe = 1), rows in Gray-code
+// order (sorted = 0) or sorted by the first coordinate (N = 2^k) -- the fused SQMC step of the multivariate filters
+int smc_sobol_points(smc_ctx* ctx, unsigned long long seed, long long N, int d, unsigned long long counter, int sorted,
+                     double* out)
+{
+    int k = -1;
+    if (sorted) {
+        SMC_REQUIRE(N > 0 && (N & (N - 1)) == 0, "smc_sobol_points: N must be a power of two");
+        k = 0;
+        while (((long long)1 << k) < N) ++k;
+    }
+    const u64 s = (u64)seed;
+    return sobol_launch(ctx, N, d, 1, 1, counter, k, out, &s);
 }
 
 extern "C" int smc_sobol(smc_ctx* ctx, int64_t N, int32_t d, int32_t scramble, int32_t safe,

@@ -207,7 +207,8 @@ class MvNormal(ProbDist):
         out = DeviceArray((N, self.dim))
         La, Lp = _lib.host_dbl(self.L)  # keep La alive across the call
         check(lib().smc_mvn_rvs(out.ctx.h, loc.ptr, rows, float(self.scale), Lp,
-                                zd.ptr if zd is not None else None, _lib.next_counter(),
+                                zd.ptr if zd is not None else None,
+                                _lib.next_counter() if zd is None else 0,      # (a sub-stream only when it draws)
                                 N, self.dim, out.ptr))
         return out if (dev or isinstance(z, DeviceArray) or _lib.RESIDENT[0]) else out.get()
 

@@ -2378,6 +2378,71 @@ def check_sqmc_fused(sizes=(2048, 4096), T=6, audit_sizes=(4096,), islands_N=204
         rs.set_rng("numpy")
 
 
+def check_sqmc_fused_mv(cases=((1024, 2), (4096, 3), (2048, 5)), T=5, islands_N=512):
+    """SMC(qmc=True) of MVLinearGauss (2 <= d <= 9) as a fused loop: Hilbert sort + the step's d + 1 Sobol'
+    coordinates + the flat step (smc_filter_sqmc.h) -- the SAME run as the operator path on the same points:
+    ancestors identical (both form the flat Q62 CDF of the weights in Hilbert order), particles and weights to
+    1e-12 (MFMA summation order); Kalman's likelihood; islands; what does not fuse."""
+    rs.set_rng("philox")
+    try:
+        for N, d in cases:
+            model_o = orc.Guarniero(alpha=0.4, dx=d)
+            rng = np.random.RandomState(d)
+            y = [rng.standard_normal(d) for _ in range(T)]
+            for cls in (ssm.Bootstrap, ssm.GuidedPF):
+                runs = []
+                for fused in (True, False):
+                    _lib.FUSED_SQMC[0] = fused
+                    pa.seed(17)
+                    pf = pa.SMC(fk=cls(ssm=kalman.MVLinearGauss_Guarniero_etal(alpha=0.4, dx=d), data=y), N=N, qmc=True,
+                                collect="off")
+                    assert pf._fused == fused
+                    if fused:
+                        assert describe(pf).startswith("smc_hilbert_sort+k_sobol+k_sqmv_tapes+"), describe(pf)
+                    steps = []
+                    for t in range(T):
+                        next(pf)
+                        assert pf.rs_flag == (t > 0)
+                        steps.append((np.asarray(pf.X).copy(), None if t == 0 else np.asarray(pf.A).copy(),
+                                      np.asarray(pf.wgts.lw).copy(), float(pf.logLt)))
+                    runs.append(steps)
+                _lib.FUSED_SQMC[0] = True
+                for t in range(T):
+                    (Xa, Aa, la, La), (Xb, Ab, lb, Lb) = runs[0][t], runs[1][t]
+                    if Aa is not None and not np.array_equal(Aa, Ab):
+                        # (the weights agree to ~1e-15: a tie decided by their last bits; rare, and the end of a
+                        #  step-by-step comparison)
+                        assert np.mean(Aa != Ab) < 0.005, (N, d, t)
+                        break
+                    # (products summed in MFMA order here, in the operators' order there)
+                    assert np.allclose(Xa, Xb, rtol=1e-12, atol=1e-12) and np.allclose(la, lb, rtol=1e-11, atol=1e-11), (N, d, t)
+                    assert abs(La - Lb) < 1e-11 * max(1.0, abs(La))
+                else:
+                    t = T
+                assert t >= 2, (N, d, t)
+        # evidence against Kalman's, islands with their own point sets
+        d = 3
+        rng = np.random.RandomState(1)
+        y = [0.5 * rng.standard_normal(d) for _ in range(12)]
+        ll, _ = orc.kalman_loglik(orc.Guarniero(alpha=0.4, dx=d), y)
+        pa.seed(23)
+        pf = pa.SMC(fk=ssm.GuidedPF(ssm=kalman.MVLinearGauss_Guarniero_etal(alpha=0.4, dx=d), data=y), N=islands_N, qmc=True,
+                    collect="off", n_islands=4)
+        assert pf._fused
+        pf.run()
+        lls = pf.logLts_islands
+        assert len(set(lls.tolist())) == 4 and np.max(np.abs(lls - ll)) < 0.3, (lls, ll)
+        # not fused: d beyond the 10 Sobol' coordinates, history slots, N not a power of two
+        mk = lambda dx: kalman.MVLinearGauss_Guarniero_etal(alpha=0.4, dx=dx)
+        y10 = [rng.standard_normal(10) for _ in range(3)]
+        assert not pa.SMC(fk=ssm.Bootstrap(ssm=mk(10), data=y10), N=256, qmc=True)._fused
+        assert not pa.SMC(fk=ssm.Bootstrap(ssm=mk(3), data=y), N=256, qmc=True, store_history=True)._fused
+        assert not pa.SMC(fk=ssm.Bootstrap(ssm=mk(3), data=y), N=300, qmc=True)._fused
+    finally:
+        _lib.FUSED_SQMC[0] = True
+        rs.set_rng("numpy")
+
+
 def check_collectors_on_fused(golden):
     from particles_amd.collectors import Moments
     g = golden("kalman_toy")

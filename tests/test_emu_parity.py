@@ -77,6 +77,10 @@ def test_sqmc_fused():
     pc.check_sqmc_fused(sizes=(2048,), T=4, audit_sizes=(4096,), islands_N=2048)
 
 
+def test_sqmc_fused_multivariate():
+    pc.check_sqmc_fused_mv(cases=((1024, 2), (2048, 5)), T=4, islands_N=256)
+
+
 def test_indep_prod(golden):
     pc.check_indep_prod(golden)
 

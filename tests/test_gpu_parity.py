@@ -102,6 +102,10 @@ def test_sqmc_fused_large_grid():
         rs.set_rng("numpy")
 
 
+def test_sqmc_fused_multivariate():
+    pc.check_sqmc_fused_mv(cases=((1024, 2), (4096, 3), (1 << 16, 5), (1 << 18, 9)), T=5, islands_N=1 << 12)
+
+
 def test_indep_prod(golden):
     pc.check_indep_prod(golden)
 

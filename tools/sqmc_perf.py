@@ -50,5 +50,6 @@ if __name__ == "__main__":
         run(kalman.ToySSM(0.2), 1 << k, 30, "ToySSM d=1")
         run(kalman.ToySSM(0.2), 1 << k, 30, "ToySSM d=1", graph=True)
         run(kalman.ToySSM(0.2), 1 << k, 30, "ToySSM d=1", fused=False)
-    for k in (12, 16, 18):
+    for k in (12, 16, 18, 20):
         run(kalman.MVLinearGauss_Guarniero_etal(alpha=0.4, dx=2), 1 << k, 20, "MVLinearGauss d=2 (Hilbert)")
+        run(kalman.MVLinearGauss_Guarniero_etal(alpha=0.4, dx=2), 1 << k, 20, "MVLinearGauss d=2 (Hilbert)", fused=False)
