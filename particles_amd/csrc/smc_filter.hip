@@ -34,7 +34,7 @@ struct smc_filter {
     // sort's workspace and -- more than one island -- the islands' permutations
     u64 sp_epoch;          // launches of the merged spacings + reduction kernel so far (see FArgs::sp_epoch)
     bool sp_merge;
-    bool sqmc;
+    bool sqmc, sq_gather;
     u64 sq_seed, sq_ctr0;
     double* sq_z;
     u64* sq_perm;
@@ -145,14 +145,28 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
             SMC_LAUNCH(k_sq_init, dim3((unsigned)((a.N + SMC_BLOCK - 1) / SMC_BLOCK), a.n_islands), dim3(SMC_BLOCK), st,
                        f->a, f->sq_z, f->sq_seed, f->sq_ctr0);
         } else {
-            const u64* perm = f->sq_perm;
+            // bootstrap filters whose weight depends on the new particle only: the sorted weights are recomputed
+            // from the sorted keys (k_sq_permute<.., true>); SMC_PATH_SQ_GATHER (A/B) and the others gather them
+            // (one island, N beyond the one-workgroup sort: the workspace then holds the key images of that island)
+            const bool recompute = f->fk == SMC_FK_BOOTSTRAP && f->kind != SMC_MODEL_SVLEVERAGE && !f->sq_gather &&
+                                   a.n_islands == 1 && a.N > 2048;
+            const u64 *perm = f->sq_perm, *skeys = nullptr;
             for (int i = 0; i < a.n_islands; ++i) {        // h_order = argsort(X_{t-1}) (hilbert.py:52-54, d = 1)
-                u64* v0 = nullptr;
-                (void)smc_rs_sort_ws(f->ctx, f_X(a, t - 1) + (i64)i * a.N, nullptr, a.N, 0, f->sq_ws, nullptr, &v0);
-                if (a.n_islands == 1) perm = v0;
+                u64 *k0 = nullptr, *v0 = nullptr;
+                (void)smc_rs_sort_ws(f->ctx, f_X(a, t - 1) + (i64)i * a.N, nullptr, a.N, 0, f->sq_ws, recompute ? &k0 : nullptr, &v0);
+                if (a.n_islands == 1) { perm = v0; skeys = k0; }
                 else (void)hipMemcpyAsync(f->sq_perm + (i64)i * a.N, v0, (size_t)a.N * 8, hipMemcpyDeviceToDevice, st);
             }
-            SMC_LAUNCH(k_sq_permute, grid, dim3(SMC_BLOCK), st, f->a, perm, f->sq_z, f->sq_seed, f->sq_ctr0);
+#define SQ_CASE(KINDV)                                                                                           \
+    if (f->kind == KINDV) {                                                                                      \
+        if (recompute) SMC_LAUNCH((k_sq_permute<KINDV, true>), grid, dim3(SMC_BLOCK), st, f->a, perm, skeys, f->sq_z, \
+                                  f->sq_seed, f->sq_ctr0);                                                       \
+        else SMC_LAUNCH((k_sq_permute<KINDV, false>), grid, dim3(SMC_BLOCK), st, f->a, perm, skeys, f->sq_z,      \
+                        f->sq_seed, f->sq_ctr0);                                                                 \
+    }
+            SQ_CASE(SMC_MODEL_LINGAUSS) SQ_CASE(SMC_MODEL_STOCHVOL) SQ_CASE(SMC_MODEL_GORDON)
+            SQ_CASE(SMC_MODEL_THETALOGISTIC) SQ_CASE(SMC_MODEL_SVLEVERAGE) SQ_CASE(SMC_MODEL_DISCRETECOX)
+#undef SQ_CASE
             SMC_LAUNCH(k_reduce2, dim3(a.n_islands), dim3(SMC_BLOCK), st, f->a);
             SMC_LAUNCH((k_ancestors2<true, true, true, false, true>), grid, dim3(SMC_BLOCK), st, f->a);
             SMC_LAUNCH(k_sq_compose, dim3((unsigned)((a.N / 4 + SMC_BLOCK - 1) / SMC_BLOCK), a.n_islands), dim3(SMC_BLOCK), st,
@@ -382,6 +396,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     f->no_small = (o->flags & SMC_PATH_NO_SMALL) != 0;
     f->strict_ws = nullptr;
     f->sqmc = (o->flags & SMC_FLAG_SQMC) != 0;
+    f->sq_gather = (o->flags & SMC_PATH_SQ_GATHER) != 0;
     f->sq_seed = o->seed;
     f->sq_ctr0 = 1;
     f->sq_z = nullptr;

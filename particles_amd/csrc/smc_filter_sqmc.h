@@ -35,11 +35,16 @@ k_sq_init(const FArgs av, double* zbuf, const u64 pseed, const u64 ctr0)
 }
 
 // step t >= 1, one workgroup per tile of 1024 SORTED positions (ownership as in the tail-free k_propagate):
-// gathers the log-weights of step t-1 through the sort's permutation and leaves what k_propagate(t-1) left
-// for the unsorted order -- (K_b, S_b, SS_b), the tile's integer CDF, t_b -- for the sorted one; writes the
-// tapes of step t.
+// leaves what k_propagate(t-1) left for the unsorted order -- (K_b, S_b, SS_b), the tile's integer CDF, t_b --
+// for the sorted one; writes the tape of step t's moves.  The log-weights of step t - 1 in sorted order:
+//   RECOMPUTE (bootstrap filters whose log G depends on the new particle only): SQMC always resamples, so
+//     lw_{t-1} = log G_{t-1}(x) = m_obs_logpdf(y_{t-1}, x) -- evaluated again from the SORTED KEYS (the sort's
+//     key images decode to the particles: a sequential read) by the very function k_propagate stored it with,
+//     hence the same bits (check_sqmc_fused runs both forms and compares the ESS rows with ==);
+//   else gathered through the permutation (a random 8-byte gather of 8 MB at N = 2^20: 20 of the kernel's 30 us).
+template <int KIND, bool RECOMPUTE>
 __global__ void __launch_bounds__(SMC_BLOCK)
-k_sq_permute(const FArgs av, const u64* perm, double* zbuf, const u64 pseed, const u64 ctr0)
+k_sq_permute(const FArgs av, const u64* perm, const u64* skeys, double* zbuf, const u64 pseed, const u64 ctr0)
 {
     const FArgs& a = av;
     const int b = (int)blockIdx.x, isl = (int)blockIdx.y, tid = (int)threadIdx.x;
@@ -47,23 +52,54 @@ k_sq_permute(const FArgs av, const u64* perm, double* zbuf, const u64 pseed, con
     const i64 t = (i64)smc_uniform(smc_ldg(a.info2 + (i64)isl * INFO_STRIDE));
     if (t >= a.T || t == 0) return;
     const FOwn own = f_own<true>(b, tid, N);
-    const u64* pi = perm + (i64)isl * N;
-    const double* lwo = f_lw(a, t - 1) + (i64)isl * N;
-    u64 p4[4];
-    smc_ld2g(pi + own.na, p4[0], p4[1]);
-    smc_ld2g(pi + own.nb, p4[2], p4[3]);
     double lw[4];
+    if (RECOMPUTE) {
+        const u64* sk = skeys + (i64)isl * N;
+        u64 k4[4];
+        smc_ld2g(sk + own.na, k4[0], k4[1]);
+        smc_ld2g(sk + own.nb, k4[2], k4[3]);
+        const double* p = a.params + (i64)isl * PARAM_STRIDE;
+        const double y = a.y[(t - 1) * a.dy];
+        const double aux = (m_has_aux<KIND>() && a.aux) ? a.aux[t - 1] : 0.0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) lw[k] = smc_ldg(lwo + p4[k]);
-    // the step's points, while the gather is on its way
+        for (int k = 0; k < 4; ++k) {
+            const u64 e = k4[k];                                   // rs_decode (fp64 keys)
+            const double x = __longlong_as_double((long long)((e >> 63) ? (e & 0x7fffffffffffffffull) : ~e));
+            double l = m_obs_logpdf<KIND>(p, y, x, 0.0, t - 1 == 0, aux);
+            if (l != l) l = -INFINITY;                             // resampling.py:220
+            lw[k] = l;
+        }
+    } else {
+        const u64* pi = perm + (i64)isl * N;
+        const double* lwo = f_lw(a, t - 1) + (i64)isl * N;
+        u64 p4[4];
+        smc_ld2g(pi + own.na, p4[0], p4[1]);
+        smc_ld2g(pi + own.nb, p4[2], p4[3]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lw[k] = smc_ldg(lwo + p4[k]);
+    }
+    // the step's points, while the loads are on their way.  Second coordinate of the point with Gray code g:
+    // the XOR of the direction numbers v_k over the set bits of g -- looked up 7 bits at a time in tables the
+    // workgroup builds once (5 x 128 words of LDS) instead of walking the 20 bits of every g
+    __shared__ u32 s_v2[5 * 128];
+    for (int e = tid; e < 5 * 128; e += SMC_BLOCK) {
+        const int c = e >> 7, bits = e & 127;
+        u32 m = 1u, acc = 0u;
+        for (int k = 0; k < 7 * c + 7 && k < SOBOL_BITS; ++k) {
+            if (k >= 7 * c && ((bits >> (k - 7 * c)) & 1)) acc ^= m << (SOBOL_BITS - 1 - k);
+            m ^= m << 1;
+        }
+        s_v2[e] = acc;
+    }
+    __syncthreads();
     const u64 ctr = ctr0 + (u64)t + ((u64)(u32)(a.island_offset + isl) << 32);
     const u32 sh0 = smc_sobol_shift(pseed, ctr, 0u), sh1 = smc_sobol_shift(pseed, ctr, 1u);
     double z[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const u32 row = (u32)f_own_idx(own, k);
-        u32 x0, x1;
-        smc_sobol2(smc_sobol_sorted_gray(row, sh0, a.log2N), sh0, sh1, x0, x1);
+        const u32 g = smc_sobol_sorted_gray((u32)f_own_idx(own, k), sh0, a.log2N);
+        const u32 x1 = sh1 ^ s_v2[g & 127u] ^ s_v2[128 + ((g >> 7) & 127u)] ^ s_v2[256 + ((g >> 14) & 127u)] ^
+                       s_v2[384 + ((g >> 21) & 127u)] ^ s_v2[512 + ((g >> 28) & 127u)];
         z[k] = smc_ndtri(smc_sobol_safe(x1));
     }
     // (the sorted first coordinates are not written: k_ancestors2<SQ> forms the thresholds from n -- f2_sq_T)

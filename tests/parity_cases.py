@@ -10,6 +10,7 @@ compared at <= 1e-12 relative; log-evidence at <= 1e-9 relative (north star:
 1e-6).
 """
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -2354,6 +2355,17 @@ def check_sqmc_fused(sizes=(2048, 4096), T=6, audit_sizes=(4096,), islands_N=204
                 pq = pa.SMC(fk=cls(ssm=mk(), data=y), N=N, qmc=True, collect="off")
                 pq.run()
                 assert np.array_equal(np.asarray(pq.X), np.asarray(pf.X)) and pq.logLt == pf.logLt
+                # ... the sorted weights recomputed from the sorted keys (bootstrap filters) or gathered through the
+                # permutation (SMC_PATH_SQ_GATHER): the same bits -- ESS of every step, particles, ancestors
+                os.environ["SMC_SQ_GATHER"] = "1"
+                try:
+                    pa.seed(47)
+                    pg = pa.SMC(fk=cls(ssm=mk(), data=y), N=N, qmc=True, collect="off")
+                    pg.run()
+                finally:
+                    del os.environ["SMC_SQ_GATHER"]
+                assert np.array_equal(pg._summ(), pq._summ()) and np.array_equal(np.asarray(pg.X), np.asarray(pq.X))
+                assert np.array_equal(np.asarray(pg.A), np.asarray(pq.A))
                 # ... and so does the loop replayed from hipGraphs (steps 0 and 1 eagerly, then captured pairs)
                 pa.seed(47)
                 pg = pa.SMC(fk=cls(ssm=mk(), data=y), N=N, qmc=True, collect="off", use_graph=True)
