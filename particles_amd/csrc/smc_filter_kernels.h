@@ -213,9 +213,10 @@ __device__ __forceinline__ double m_obs_logpdf(const double* p, double y, double
                                                bool first, double aux)
 {
     if (KIND == SMC_MODEL_DISCRETECOX) {                        // ssm.py:629-630, distributions.py:528-529
-        // scipy.stats.poisson._logpmf: xlogy(k, mu) - gammaln(k + 1) - mu, mu = exp(x)
+        // scipy.stats.poisson._logpmf: xlogy(k, mu) - gammaln(k + 1) - mu, mu = exp(x); log(mu) is x itself
+        // (as for StochVol below: one exp, no log; equal to the 1-2 ulp of either route)
         const double mu = exp(x);
-        const double xl = (y == 0.0 && mu == mu) ? 0.0 : y * log(mu);
+        const double xl = (y == 0.0 && mu == mu) ? 0.0 : y * x;
         return (xl - aux) - mu;
     }
     if (KIND == SMC_MODEL_SVLEVERAGE) {                         // ssm.py:531-541
@@ -2107,24 +2108,45 @@ __device__ __forceinline__ int f2_reduce2_island(const FArgs& a, const int isl, 
             f2_write_record(a, isl, t, r, resample);
         }
         if (!resample) return 0;
+        // every tile's share and the shares before it.  The chunks' four scans share ONE exchange (wave scans of
+        // the four per-thread sums side by side, 16 wave totals through LDS, two barriers in all instead of eight):
+        // the shares are integers below 2^53, their sums exact in any order
+        __shared__ double s_x4[NC * SMC_NWAVE];
+        double Q4[NC][4], run[NC], inc[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const i64 i0 = (i64)c * 4 * SMC_BLOCK + (i64)tid * 4;
+            run[c] = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                double v, w;
+                f2_rescale(pmc[c][k], r.K, psc[c][k], 0.0, v, w);
+                Q4[c][k] = (c < nchunks && i0 + k < a.nparts) ? f2_share(v, r.rs) : 0.0;
+                run[c] += Q4[c][k];
+            }
+            inc[c] = smc_wave_scan_add_f64(run[c]);
+        }
+        __syncthreads();
+        if (smc_lane() == 63) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) s_x4[c * SMC_NWAVE + smc_wave()] = inc[c];
+        }
+        __syncthreads();
         double carry = 0.0;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             if (c >= nchunks) break;
             const i64 i0 = (i64)c * 4 * SMC_BLOCK + (i64)tid * 4;
-            double Q4[4], run = 0.0;
+            double base = 0.0, tot = 0.0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                double v, w;
-                f2_rescale(pmc[c][k], r.K, psc[c][k], 0.0, v, w);
-                Q4[k] = (i0 + k < a.nparts) ? f2_share(v, r.rs) : 0.0;
-                run += Q4[k];
+            for (int w = 0; w < SMC_NWAVE; ++w) {
+                if (w < smc_wave()) base += s_x4[c * SMC_NWAVE + w];
+                tot += s_x4[c * SMC_NWAVE + w];
             }
-            double tot;
-            double g = carry + smc_block_exscan_f64(run, sme, tot);
+            double g = carry + base + inc[c] - run[c];
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (i0 + k < a.nparts) { G[i0 + k] = g; Q[i0 + k] = Q4[k]; g += Q4[k]; }
+                if (i0 + k < a.nparts) { G[i0 + k] = g; Q[i0 + k] = Q4[c][k]; g += Q4[c][k]; }
             carry += tot;
         }
         return 1;
