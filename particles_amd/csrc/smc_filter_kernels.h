@@ -1310,8 +1310,10 @@ k_propagate(const FArgs av)
     const u32 gisl = (u32)(a.island_offset + isl);
     double zs[OPT] = {0.0, 0.0, 0.0, 0.0};
     // tail-free launches over whole tiles: every thread owns 4 particles (no exec-mask region around
-    // the speculative block: the loads below stay in flight across the staging barrier)
-    constexpr bool ALL_IN = !TAIL && RAGGED == 0;
+    // the speculative block: the loads below stay in flight across the staging barrier).  RAGGED == 1 (N even,
+    // a ragged last tile) too: its loads are unconditional on padded arrays -- the threads beyond N read the
+    // padding's valid entries (A is zero there) and never store
+    constexpr bool ALL_IN = !TAIL && RAGGED != 2;
     const bool mine = ALL_IN || own.na < N;
     const bool spec_z = a.tk >= 0 && !a.zt && mine;
     double xg[OPT];
