@@ -501,8 +501,13 @@ def main():
     if grp:
         # one GPU per rank: the ranks' PCI bus ids must be distinct unless the caller shares devices
         # on purpose (SMC_BENCH_NGPU: functional tests on a box with fewer GPUs than ranks)
-        devices = grp.allgather_str("%d:%s" % (device, _lib.ctx().device_pci()))
-        if ngpu == 0 and len(set(s.split(":", 1)[1] for s in devices)) != len(devices):
+        try:
+            pci = _lib.ctx().device_pci()
+        except Exception:                   # (a bus id the runtime cannot name must not cost the line)
+            pci = ""
+        devices = grp.allgather_str("%d:%s" % (device, pci))
+        pcis = [s.split(":", 1)[1] for s in devices]
+        if ngpu == 0 and all(pcis) and len(set(pcis)) != len(pcis):
             sys.exit("bench.py: ranks share a GPU (%s): launch one rank per GPU" % devices)
     K, W = a.steps, a.warmup
     heavy = a.workload in ("c3", "c4", "c5")        # 0.07-0.3 ms per step: fewer timed steps do
