@@ -327,7 +327,8 @@ typedef struct smc_filter_opts {
  * CDF.  Costs a one-wavefront pass over the weights per resampling step (ms at N = 2^20). */
 #define SMC_FLAG_STRICT_ANCESTORS 2
 /* SQMC (particles.SMC(qmc=True), core.py:315-321, 339-349) as a fused loop: univariate Bootstrap / Guided
- * filters, N = 2^k >= 2048.  Every step sorts the particles (hilbert_sort = argsort for d = 1: the radix sort),
+ * filters, N = 2^k >= 32 (N < 2048, and MVLINGAUSS with 2 <= d <= 9: the flat step -- eager launches, no history
+ * slots, no moments; N >= 2048: the two-level step).  Every step sorts the particles (hilbert_sort = argsort for d = 1: the radix sort),
  * chooses ancestors by the inverse CDF of the weights in sorted order at the sorted first coordinates of a
  * scrambled Sobol' point set (known in closed form for N = 2^k: no second sort), and moves with the
  * inverse normal CDF of the second coordinates (Gamma = ProbDist.ppf).  Always resamples (core.py:340):

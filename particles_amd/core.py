@@ -185,9 +185,9 @@ class SMC:
             model = None                       # the operator path
         if qmc and not self._sqmc_fusable(fk, N, model, replay, use_graph, strict_ancestors):
             model = None           # SQMC as the template-method step on device operators
-        if qmc and model is not None and model["kind"] == _lib.MODEL_MVLINGAUSS and (
+        if qmc and model is not None and (model["kind"] == _lib.MODEL_MVLINGAUSS or N < 2048) and (
                 store_history or collapsed_proposal or (collect and collect != "off" and self._device_moments)):
-            model = None           # (the fused multivariate SQMC step keeps no history slots / device moments)
+            model = None           # (the fused SQMC on the flat step keeps no history slots / device moments)
         self._fused = self._will_fuse(fk, qmc, resampling, model, N=N)
         if self._fused:
             # full history on the fused path stays on the device: the step loop
@@ -224,15 +224,16 @@ class SMC:
 
     @staticmethod
     def _sqmc_fusable(fk, N, model, replay=None, use_graph=False, strict=False):
-        """SQMC as a fused loop (SMC_FLAG_SQMC): univariate Bootstrap / Guided filters of the fused family,
-        N = 2^k >= 2048 (the sorted Sobol' order in closed form), device-generated points."""
+        """SQMC as a fused loop (SMC_FLAG_SQMC): Bootstrap / Guided filters of the fused family, N = 2^k >= 32,
+        device-generated points (N >= 2048, univariate: the two-level step; else the flat step, eager launches)."""
         if not (_lib.FUSED_SQMC[0] and _lib.RNG_MODE[0] == "philox" and model is not None
                 and getattr(fk, "_fk_kind", None) in (_lib.FK_BOOTSTRAP, _lib.FK_GUIDED)
                 and N <= (1 << 30) and N & (N - 1) == 0 and replay is None and not strict):
             return False
         if model["kind"] == _lib.MODEL_MVLINGAUSS:      # the flat step behind the Hilbert sort, d + 1 <= 10 Sobol' coordinates
             return 2 <= model["dx"] <= 9 and N >= 32 and not use_graph
-        return model.get("params") is not None and model.get("dx", 1) == 1 and N >= 2048
+        return (model.get("params") is not None and model.get("dx", 1) == 1 and N >= 32
+                and not (use_graph and N < 2048))
 
     @staticmethod
     def _will_fuse(fk, qmc=False, resampling="systematic", model=False, N=None):

@@ -35,6 +35,7 @@ struct smc_filter {
     u64 sp_epoch;          // launches of the merged spacings + reduction kernel so far (see FArgs::sp_epoch)
     bool sp_merge;
     bool sqmc, sq_gather;
+    bool sq_flat;          // SQMC on the flat step (multivariate filters; univariate ones below two tiles)
     u64 sq_seed, sq_ctr0;
     double* sq_z;
     u64* sq_perm;
@@ -132,7 +133,7 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
     hipStream_t st = f->ctx->stream;
     const dim3 grid(f->a.ntiles, f->a.n_islands);
     if (k_prof >= 0) (void)hipEventRecord(f->ev[3 * k_prof], st);
-    if (f->sqmc && f->kind != SMC_MODEL_MVLINGAUSS) {
+    if (f->sqmc && !f->sq_flat) {
         // smc_filter_sqmc.h.  The step's normals come from a tape that is ONE step's buffer (zt_ts = 0),
         // written by k_sq_init / k_sq_permute just before; the thresholds are a function of n (f2_sq_T)
         FArgs& a = f->a;
@@ -250,10 +251,11 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
         return;
     }
     const bool fused = f->fused;
-    if (f->sqmc) {
-        // SQMC of a multivariate filter (smc_filter_sqmc.h): Hilbert order, the step's points, the tapes; the flat
-        // step then runs as it is -- its multinomial search over the sorted uniforms in a.su, its propagate
-        // kernel fed from the tape of ndtri values
+    if (f->sq_flat) {
+        // SQMC of a multivariate filter, or of a univariate one of fewer than two tiles (smc_filter_sqmc.h):
+        // Hilbert order (d = 1: the radix argsort), the step's points, the tapes; the flat step then runs as it
+        // is -- its multinomial search over the sorted uniforms in a.su, its propagate kernel fed from the tape
+        // of ndtri values
         FArgs& a = f->a;
         const int d = a.dx;
         const unsigned nb = (unsigned)((a.N + SMC_BLOCK - 1) / SMC_BLOCK);
@@ -269,7 +271,13 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
                            lws, f->sq_z);
             } else {
                 i64* perm = (i64*)f->sq_perm + (size_t)i * a.N;
-                (void)smc_hilbert_sort(f->ctx, f_X(a, t - 1) + (size_t)i * a.N * d, a.N, d, (int64_t*)perm, nullptr);
+                if (d == 1) {                      // hilbert.py:52-54: argsort
+                    u64* v0 = nullptr;
+                    (void)smc_rs_sort_ws(f->ctx, f_X(a, t - 1) + (size_t)i * a.N, nullptr, a.N, 0, (void*)(lws + a.N), nullptr, &v0);
+                    (void)hipMemcpyAsync(perm, v0, (size_t)a.N * 8, hipMemcpyDeviceToDevice, st);
+                } else {
+                    (void)smc_hilbert_sort(f->ctx, f_X(a, t - 1) + (size_t)i * a.N * d, a.N, d, (int64_t*)perm, nullptr);
+                }
                 (void)smc_sobol_points(f->ctx, f->sq_seed, a.N, d + 1, ctr, 1, U);
                 SMC_LAUNCH(k_sqmv_tapes, dim3(nb), dim3(SMC_BLOCK), st, f->a, i, (const i64*)perm, (const double*)U, d + 1,
                            lws, f->sq_z);
@@ -296,7 +304,7 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
     if (fused && f->a.par >= 0) SMC_LAUNCH((k_ancestors<true, true>), grid, dim3(SMC_BLOCK), st, f->a);
     else if (fused) SMC_LAUNCH((k_ancestors<true, false>), grid, dim3(SMC_BLOCK), st, f->a);
     else SMC_LAUNCH((k_ancestors<false, false>), grid, dim3(SMC_BLOCK), st, f->a);
-    if (f->sqmc && t > 0)                          // A <- h_order[A] (core.py:344)
+    if (f->sq_flat && t > 0)                       // A <- h_order[A] (core.py:344)
         for (int i = 0; i < f->a.n_islands; ++i)
             SMC_LAUNCH(k_sqmv_compose, dim3((unsigned)((f->a.N + SMC_BLOCK - 1) / SMC_BLOCK)), dim3(SMC_BLOCK), st, f->a, i,
                        (const i64*)f->sq_perm + (size_t)i * f->a.N);
@@ -396,6 +404,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     f->no_small = (o->flags & SMC_PATH_NO_SMALL) != 0;
     f->strict_ws = nullptr;
     f->sqmc = (o->flags & SMC_FLAG_SQMC) != 0;
+    f->sq_flat = false;
     f->sq_gather = (o->flags & SMC_PATH_SQ_GATHER) != 0;
     f->sq_seed = o->seed;
     f->sq_ctr0 = 1;
@@ -403,18 +412,20 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     f->sq_perm = nullptr;
     f->sq_ws = nullptr;
     if (f->sqmc) {
-        // core.py:339-349 as a fused loop.  Univariate Normal kernels (Gamma = ppf): the two-level step, N = 2^k >=
-        // 2 tiles (the sorted Sobol' order in closed form).  MVLINGAUSS (2 <= d <= 9: d + 1 Sobol' coordinates): the
-        // flat step behind the Hilbert sort, N = 2^k >= 32, no history slots (the sorted weights take the slot).
+        // core.py:339-349 as a fused loop.  Univariate Normal kernels (Gamma = ppf), N = 2^k >= 2 tiles: the
+        // two-level step (the sorted Sobol' order in closed form).  MVLINGAUSS (2 <= d <= 9: d + 1 Sobol'
+        // coordinates) and univariate filters of N = 2^k < 2 tiles: the flat step behind the Hilbert sort / the
+        // argsort, N >= 32, no history slots (the sorted weights take the slot).
         bool pow2 = false;
-        for (int k = mv ? 5 : 11; k <= 30; ++k) pow2 = pow2 || (((i64)1 << k) == o->N);
+        for (int k = 5; k <= 30; ++k) pow2 = pow2 || (((i64)1 << k) == o->N);
+        f->sq_flat = mv || o->N < 2 * F_TILE;
         const bool fk_ok = model->fk == SMC_FK_BOOTSTRAP || model->fk == SMC_FK_GUIDED;
-        const bool mv_ok = !mv || (model->dx >= 2 && model->dx <= 9 && !o->keep_history && !o->moments &&
-                                   !(o->flags & SMC_FLAG_COLLAPSED_PROPOSAL));
-        if (!fk_ok || !pow2 || !mv_ok || f->strict || o->rng_mode != SMC_RNG_PHILOX || (mv && o->use_graph) ||
+        const bool mv_ok = !f->sq_flat || ((!mv || (model->dx >= 2 && model->dx <= 9)) && !o->keep_history && !o->moments &&
+                                           !(o->flags & SMC_FLAG_COLLAPSED_PROPOSAL));
+        if (!fk_ok || !pow2 || !mv_ok || f->strict || o->rng_mode != SMC_RNG_PHILOX || (f->sq_flat && o->use_graph) ||
             (o->flags & (SMC_PATH_FLAT_CDF | SMC_PATH_FORCE_FUSED | SMC_PATH_FORCE_UNFUSED | SMC_PATH_FLAT_MULTINOMIAL))) {
-            smc_set_error("SMC_FLAG_SQMC: Bootstrap / Guided filters; univariate models: N = 2^k with 11 <= k <= 30; "
-                          "MVLINGAUSS: 2 <= d <= 9, N = 2^k with 5 <= k <= 30, eager launches, no history slots; Philox mode");
+            smc_set_error("SMC_FLAG_SQMC: Bootstrap / Guided filters, N = 2^k with 5 <= k <= 30, Philox mode; MVLINGAUSS "
+                          "(2 <= d <= 9) and univariate models with k <= 10: eager launches, no history slots, no moments");
             delete f;
             return SMC_ERR_INVALID;
         }
@@ -572,7 +583,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     f->sp_merge = a.sp_tpw && merge_fits && !o->use_graph && !(o->flags & SMC_PATH_SPLIT_REDUCE);
     const size_t oTmp = carve(N * dxm * 8);
     const size_t oStrict = carve(f->strict ? M * N * 8 : 8);
-    if (f->sqmc && !mv && !f->two_level) {
+    if (f->sqmc && !f->sq_flat && !f->two_level) {
         smc_set_error("SMC_FLAG_SQMC needs the two-level step");
         delete f;
         return SMC_ERR_INVALID;
@@ -580,9 +591,11 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     const bool apf_mv = mv && model->fk == SMC_FK_APF;
     const size_t oEta = carve(apf_mv ? 2 * M * N * 8 : 8);
     const size_t oSqZ = carve(f->sqmc ? M * N * dxm * 8 : 8);
-    const size_t oSqPerm = carve(f->sqmc && (M > 1 || mv) ? M * N * 8 : 8);
-    // (univariate: the sort's workspace; multivariate: the step's points (N, d + 1) and a row of sorted log-weights)
-    const size_t oSqWs = carve(!f->sqmc ? 8 : mv ? (N * (dxm + 1) + N) * 8 : smc_rs_ws_bytes((i64)N));
+    const size_t oSqPerm = carve(f->sqmc && (M > 1 || f->sq_flat) ? M * N * 8 : 8);
+    // (two-level: the sort's workspace; flat: the step's points (N, d + 1), a row of sorted log-weights and -- d = 1
+    // -- the sort's workspace behind them)
+    const size_t oSqWs = carve(!f->sqmc ? 8 : f->sq_flat ? (N * (dxm + 1) + N) * 8 + (mv ? 0 : smc_rs_ws_bytes((i64)N))
+                                                          : smc_rs_ws_bytes((i64)N));
     a.nmb = (int)((o->N + F_MOM_CHUNK - 1) / F_MOM_CHUNK);
     const size_t oMom = carve(o->moments ? M * T * 2 * dxm * 8 : 8);
     const size_t oMpart = carve(o->moments ? M * a.nmb * dxm * 3 * 8 : 8);
@@ -861,7 +874,7 @@ int smc_filter_set_replay(smc_filter* f, const double* z, const double* u)
 static bool small_filter_ok(const smc_filter* f)
 {
     return f->a.N <= F_TILE && f->kind != SMC_MODEL_MVLINGAUSS && !f->a.mom && !f->prof && !f->strict &&
-           !(f->a.scheme == SMC_MULTINOMIAL && !f->a.ut) && !f->no_small;
+           !(f->a.scheme == SMC_MULTINOMIAL && !f->a.ut) && !f->no_small && !f->sqmc;
 }
 
 static void launch_small(smc_filter* f, int nsteps)
@@ -1617,9 +1630,9 @@ int smc_filter_describe(smc_filter* f, char* out, size_t n)
     const bool mv = f->kind == SMC_MODEL_MVLINGAUSS;
     std::string s;
     if (small_filter_ok(f)) s = "k_filter_small";
-    else if (f->sqmc && mv) {
-        s = std::string("smc_hilbert_sort+k_sobol+k_sqmv_tapes+") + (f->fused ? "k_ancestors<fused>" : "k_prepare+k_ancestors") +
-            "+k_sqmv_compose+k_propagate_mv [mv_chunks=" + std::to_string(f->a.mv_chunks) + "]";
+    else if (f->sq_flat) {
+        s = std::string(mv ? "smc_hilbert_sort" : "k_rs_sort") + "+k_sobol+k_sqmv_tapes+" + (f->fused ? "k_ancestors<fused>" : "k_prepare+k_ancestors") +
+            "+k_sqmv_compose+" + (mv ? "k_propagate_mv [mv_chunks=" + std::to_string(f->a.mv_chunks) + "]" : std::string("k_propagate"));
     } else if (f->sqmc) {
         s = "k_rs_sort+k_sq_permute+k_reduce2+k_ancestors2+k_sq_compose+k_propagate";
         if (f->a.mom) s += "+k_f_moments_partials+k_f_moments_final";

@@ -63,15 +63,12 @@ k_rs_decode(const u64* ek, i64 N, int kind, u64* keys)
 // (Rounds 1-2 also accumulated the 256 digit totals of the whole input here with global atomics: 512
 //  workgroups x 256 atomics on one kilobyte cost 9 of the kernel's 14 us at N = 2^20; the scan's
 //  workgroups now leave their row totals and the scatter adds up the smaller digits' itself.)
+// the digit counts of tile `tile` into h[256] (LDS, zeroed by the caller, a barrier behind it)
 template <bool RAW>
-__global__ void __launch_bounds__(SMC_BLOCK)
-k_rs_hist(const u64* keys, i64 N, int shift, int kind, unsigned* hist, int ntiles)
+__device__ __forceinline__ void rs_tile_hist(const u64* keys, i64 N, int shift, int kind, int tile, unsigned* h)
 {
-    __shared__ unsigned h[256];
     const int tid = (int)threadIdx.x;
-    h[tid] = 0u;
-    __syncthreads();
-    const i64 base = (i64)blockIdx.x * RS_TILE;
+    const i64 base = (i64)tile * RS_TILE;
     const int lane = smc_lane();
     const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     u64 kk[RS_TILE / SMC_BLOCK];
@@ -97,6 +94,17 @@ k_rs_hist(const u64* keys, i64 N, int shift, int kind, unsigned* hist, int ntile
         }
         if (valid && (mask & lt) == 0ull) atomicAdd(&h[dg], (unsigned)__popcll(mask));
     }
+}
+
+template <bool RAW>
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_rs_hist(const u64* keys, i64 N, int shift, int kind, unsigned* hist, int ntiles)
+{
+    __shared__ unsigned h[256];
+    const int tid = (int)threadIdx.x;
+    h[tid] = 0u;
+    __syncthreads();
+    rs_tile_hist<RAW>(keys, N, shift, kind, (int)blockIdx.x, h);
     __syncthreads();
     hist[(i64)tid * ntiles + blockIdx.x] = h[tid];
 }
@@ -122,24 +130,16 @@ k_rs_scan(unsigned* hist, unsigned* rowtot, int ntiles)
     if (tid == 0) rowtot[d] = (unsigned)carry;
 }
 
-// the same for few tiles (<= 64): ONE workgroup, thread d walks digit d's short row
-__global__ void __launch_bounds__(SMC_BLOCK)
-k_rs_scan_few(unsigned* hist, unsigned* rowtot, int ntiles)
-{
-    const int d = (int)threadIdx.x;
-    unsigned run = 0u;
-    unsigned* row = hist + (i64)d * ntiles;
-    for (int w = 0; w < ntiles; ++w) {
-        const unsigned c = row[w];
-        row[w] = run;
-        run += c;
-    }
-    rowtot[d] = run;
-}
-
 // RAW (the first pass): the caller's keys and -- vals null -- the index as payload.  okeys null (a last
 // pass whose caller wants the permutation only): the keys are not written.
-template <bool RAW>
+// MODE 0: offs = the scanned histogram, rowtot = the digit totals (k_rs_scan).  Below that the passes are bound by
+// the latency chains of their launches (24 kernels of 5 - 9 us for the sort of 2^13 .. 2^17 keys), so one kernel
+// fewer per pass: MODE 1 (<= RS_FEW tiles): offs = the RAW histogram, thread d adds up digit d's short row itself.
+// (Measured and dropped: no histogram kernel either, every workgroup counting the digits of ALL <= 8 tiles -- the
+//  eight dependent tile reads cost more than the launch they save: 0.207 ms per SQMC step at N = 2^14 against
+//  0.15.)
+#define RS_FEW 64
+template <bool RAW, int MODE>
 __global__ void __launch_bounds__(SMC_BLOCK)
 k_rs_scatter(const u64* keys, const u64* vals, i64 N, int shift, int kind, const unsigned* offs,
              const unsigned* rowtot, int ntiles, u64* okeys, u64* ovals)
@@ -152,8 +152,20 @@ k_rs_scatter(const u64* keys, const u64* vals, i64 N, int shift, int kind, const
     const int tid = (int)threadIdx.x, lane = smc_lane(), wave = smc_wave();
 #pragma unroll
     for (int w = 0; w < SMC_NWAVE; ++w) cnt[w][tid] = 0u;
-    const unsigned my_off = offs[(i64)tid * ntiles + blockIdx.x];
-    const unsigned my_tot = rowtot[tid];
+    unsigned my_off, my_tot;
+    if constexpr (MODE == 0) {
+        my_off = offs[(i64)tid * ntiles + blockIdx.x];
+        my_tot = rowtot[tid];
+    } else {
+        const unsigned* row = offs + (i64)tid * ntiles;
+        my_off = 0u;
+        my_tot = 0u;
+        for (int w = 0; w < ntiles; ++w) {
+            const unsigned c = row[w];
+            my_off += (w < (int)blockIdx.x) ? c : 0u;
+            my_tot += c;
+        }
+    }
     const i64 tile0 = (i64)blockIdx.x * RS_TILE;
     const i64 base = tile0 + (i64)wave * RS_SEG;
     const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));       // lanes below this one
@@ -228,33 +240,41 @@ k_rs_scatter(const u64* keys, const u64* vals, i64 N, int shift, int kind, const
     }
 }
 
-// N <= 2048: the whole sort in ONE launch by one workgroup -- the 8 passes of the same ranking
-// scheme with the tile ping-ponging between registers and LDS (25 launches of a few microseconds
-// each would otherwise be the cost of sorting a few thousand keys: SQMC at small N).
+// N <= TILE: the whole sort in ONE launch by one workgroup -- the 8 passes of the same ranking scheme with the
+// tile ping-ponging between registers and LDS (24 launches of ~9 us each, bound by their own latency chains,
+// would otherwise be the cost of sorting a few thousand keys: SQMC at small N).  TILE = 2048 (any payload; DECODED
+// keys out -- the operators' entry points write straight to the caller's arrays); TILE = 4096 / 8192 (PV = u32:
+// argsort only, the index as payload held in 32 bits so that the tile fits the CU's LDS; key IMAGES out, the
+// contract of smc_rs_sort_ws beyond 2048 keys).
+template <int TILE, typename PV>
 __global__ void __launch_bounds__(SMC_BLOCK)
 k_rs_small(const u64* keys, const u64* vals, i64 N, int kind, u64* okeys, u64* ovals)
 {
+    constexpr int SEG = TILE / SMC_NWAVE, CH = SEG / 64;
+    constexpr bool IMAGES = TILE > RS_TILE;
     __shared__ unsigned cnt[SMC_NWAVE][256];
-    __shared__ u64 sk[RS_TILE], sv[RS_TILE];
+    __shared__ u64 sk[TILE];
+    __shared__ PV sv[TILE];
     __shared__ u64 smu[SMC_SM];
     const int tid = (int)threadIdx.x, lane = smc_lane(), wave = smc_wave();
     const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const int base = wave * RS_SEG;
-    u64 k[RS_CH], v[RS_CH];
+    const int base = wave * SEG;
+    u64 k[CH];
+    PV v[CH];
 #pragma unroll
-    for (int c = 0; c < RS_CH; ++c) {
+    for (int c = 0; c < CH; ++c) {
         const int i = base + c * 64 + lane;
         const bool valid = i < N;
         k[c] = valid ? rs_encode(keys[i], kind) : ~0ull;
-        v[c] = valid ? (vals ? vals[i] : (u64)i) : 0ull;
+        v[c] = valid ? ((sizeof(PV) == 8 && vals) ? (PV)vals[i] : (PV)i) : (PV)0;
     }
     for (int shift = 0; shift < 64; shift += 8) {
 #pragma unroll
         for (int w = 0; w < SMC_NWAVE; ++w) cnt[w][tid] = 0u;
         __syncthreads();
-        unsigned lrank[RS_CH];
+        unsigned lrank[CH];
 #pragma unroll
-        for (int c = 0; c < RS_CH; ++c) {
+        for (int c = 0; c < CH; ++c) {
             const bool valid = base + c * 64 + lane < N;
             const unsigned dg = (unsigned)(k[c] >> shift) & 255u;
             u64 mask = smc_ballot(valid);
@@ -282,7 +302,7 @@ k_rs_small(const u64* keys, const u64* vals, i64 N, int kind, u64* okeys, u64* o
         }
         __syncthreads();
 #pragma unroll
-        for (int c = 0; c < RS_CH; ++c)
+        for (int c = 0; c < CH; ++c)
             if (base + c * 64 + lane < N) {
                 const unsigned dg = (unsigned)(k[c] >> shift) & 255u;
                 const unsigned p = cnt[wave][dg] + lrank[c];
@@ -291,22 +311,23 @@ k_rs_small(const u64* keys, const u64* vals, i64 N, int kind, u64* okeys, u64* o
             }
         __syncthreads();
 #pragma unroll
-        for (int c = 0; c < RS_CH; ++c) {                 // back into registers, in the new order
+        for (int c = 0; c < CH; ++c) {                 // back into registers, in the new order
             const int i = base + c * 64 + lane;
             k[c] = i < N ? sk[i] : ~0ull;
-            v[c] = i < N ? sv[i] : 0ull;
+            v[c] = i < N ? sv[i] : (PV)0;
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int c = 0; c < RS_CH; ++c) {
+    for (int c = 0; c < CH; ++c) {
         const int i = base + c * 64 + lane;
         if (i < N) {
-            if (okeys) okeys[i] = rs_decode(k[c], kind);
-            if (ovals) ovals[i] = v[c];
+            if (okeys) okeys[i] = IMAGES ? k[c] : rs_decode(k[c], kind);
+            if (ovals) ovals[i] = (u64)v[c];
         }
     }
 }
+#define RS_ONE_WG 8192      /* argsorts up to here: one workgroup (k_rs_small<4096 / 8192, u32>) */
 
 // Workspace form (smc_internal.h): the caller owns `ws` (smc_rs_ws_bytes(N) bytes, reusable from call to
 // call in stream order); the sorted payloads (argsort: the permutation, as 64-bit words) and the sorted
@@ -329,7 +350,13 @@ int smc_rs_sort_ws(smc_ctx* ctx, const void* keys, const void* vals, i64 N, int 
     int rc = SMC_OK;
     if (N <= RS_TILE) {
         // (k_rs_small hands out DECODED keys: callers of this branch that want images re-encode)
-        SMC_LAUNCH(k_rs_small, dim3(1), dim3(SMC_BLOCK), st, (const u64*)keys, (const u64*)vals, N, kind, k0, v0);
+        SMC_LAUNCH((k_rs_small<RS_TILE, u64>), dim3(1), dim3(SMC_BLOCK), st, (const u64*)keys, (const u64*)vals, N, kind, k0, v0);
+        if (hipGetLastError() != hipSuccess) rc = SMC_ERR_HIP;
+        if (sorted_keys) *sorted_keys = k0;
+        if (sorted_vals) *sorted_vals = v0;
+    } else if (N <= RS_ONE_WG && !vals) {
+        if (N <= 4096) SMC_LAUNCH((k_rs_small<4096, u32>), dim3(1), dim3(SMC_BLOCK), st, (const u64*)keys, (const u64*)nullptr, N, kind, k0, v0);
+        else SMC_LAUNCH((k_rs_small<8192, u32>), dim3(1), dim3(SMC_BLOCK), st, (const u64*)keys, (const u64*)nullptr, N, kind, k0, v0);
         if (hipGetLastError() != hipSuccess) rc = SMC_ERR_HIP;
         if (sorted_keys) *sorted_keys = k0;
         if (sorted_vals) *sorted_vals = v0;
@@ -342,19 +369,19 @@ int smc_rs_sort_ws(smc_ctx* ctx, const void* keys, const void* vals, i64 N, int 
         // unless the caller asked for them.
         const u64 *ks = (const u64*)keys, *vs = (const u64*)vals;
         u64 *kd = k1, *vd = v1;
+        const int mode = ntiles <= RS_FEW ? 1 : 0;
         for (int pass = 0; pass < 8; ++pass) {
             const int shift = 8 * pass;
             if (pass == 0) SMC_LAUNCH(k_rs_hist<true>, dim3(ntiles), dim3(SMC_BLOCK), st, ks, N, shift, kind, hist, ntiles);
             else SMC_LAUNCH(k_rs_hist<false>, dim3(ntiles), dim3(SMC_BLOCK), st, ks, N, shift, kind, hist, ntiles);
-            if (ntiles <= 64) SMC_LAUNCH(k_rs_scan_few, dim3(1), dim3(SMC_BLOCK), st, hist, rowtot, ntiles);
-            else SMC_LAUNCH(k_rs_scan, dim3(256), dim3(SMC_BLOCK), st, hist, rowtot, ntiles);
+            if (mode == 0) SMC_LAUNCH(k_rs_scan, dim3(256), dim3(SMC_BLOCK), st, hist, rowtot, ntiles);
             u64* ko = (pass == 7 && !sorted_keys) ? nullptr : kd;
-            if (pass == 0)
-                SMC_LAUNCH(k_rs_scatter<true>, dim3(ntiles), dim3(SMC_BLOCK), st, ks, vs, N, shift, kind,
-                           (const unsigned*)hist, (const unsigned*)rowtot, ntiles, ko, vd);
-            else
-                SMC_LAUNCH(k_rs_scatter<false>, dim3(ntiles), dim3(SMC_BLOCK), st, ks, vs, N, shift, kind,
-                           (const unsigned*)hist, (const unsigned*)rowtot, ntiles, ko, vd);
+#define RS_SCATTER(RAWV, MODEV)                                                                                     \
+    SMC_LAUNCH((k_rs_scatter<RAWV, MODEV>), dim3(ntiles), dim3(SMC_BLOCK), st, ks, vs, N, shift, kind,               \
+               (const unsigned*)hist, (const unsigned*)rowtot, ntiles, ko, vd)
+            if (pass == 0) { if (mode == 1) RS_SCATTER(true, 1); else RS_SCATTER(true, 0); }
+            else { if (mode == 1) RS_SCATTER(false, 1); else RS_SCATTER(false, 0); }
+#undef RS_SCATTER
             ks = kd; vs = vd;
             if (kd == k1) { kd = k0; vd = v0; } else { kd = k1; vd = v1; }
         }
@@ -376,7 +403,7 @@ static int rs_sort_pairs(smc_ctx* ctx, const void* keys, const void* vals, i64 N
 {
     hipStream_t st = ctx->stream;
     if (N <= RS_TILE) {
-        SMC_LAUNCH(k_rs_small, dim3(1), dim3(SMC_BLOCK), st, (const u64*)keys, (const u64*)vals, N, kind,
+        SMC_LAUNCH((k_rs_small<RS_TILE, u64>), dim3(1), dim3(SMC_BLOCK), st, (const u64*)keys, (const u64*)vals, N, kind,
                    (u64*)out_keys, (u64*)out_vals);
         int rc1 = hipGetLastError() == hipSuccess ? SMC_OK : SMC_ERR_HIP;
 #ifdef SMC_EMULATE

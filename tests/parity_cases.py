@@ -2384,7 +2384,67 @@ def check_sqmc_fused(sizes=(2048, 4096), T=6, audit_sizes=(4096,), islands_N=204
         # (4) outside the fused family: the operator path
         pa.seed(3)
         assert not pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y), N=1000, qmc=True)._fused       # N != 2^k
-        assert not pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y), N=1024, qmc=True)._fused       # one tile
+        # (below two tiles the flat step runs it -- check_sqmc_fused_small -- and keeps no history slots)
+        assert not pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y), N=1024, qmc=True, store_history=True)._fused
+    finally:
+        _lib.FUSED_SQMC[0] = True
+        rs.set_rng("numpy")
+
+
+def check_sqmc_fused_small(sizes=(32, 256, 1024), T=6):
+    """SMC(qmc=True) of a univariate filter below two tiles (N = 2^k, 32 <= N <= 1024) as a fused loop on the flat
+    step: argsort + the step's 2 Sobol' coordinates + k_sqmv_tapes + the flat multinomial search + k_propagate fed
+    from the tape -- the SAME run as the operator path on the same points (both form the flat Q62 CDF of the sorted
+    weights: ancestors identical); islands with their own point sets against Kalman's likelihood."""
+    cases = [("toy", lambda: kalman.ToySSM(0.2), ssm.Bootstrap),
+             ("sv", lambda: ssm.StochVol(), ssm.Bootstrap),
+             ("lg_guided", lambda: kalman.LinearGauss(rho=0.9, sigmaX=1.0, sigmaY=0.3), ssm.GuidedPF)]
+    rng = np.random.RandomState(12)
+    y = [np.array([v]) for v in 0.5 * np.cumsum(rng.standard_normal(T))]
+    rs.set_rng("philox")
+    try:
+        for name, mk, cls in cases:
+            for N in sizes:
+                runs = []
+                for fused in (True, False):
+                    _lib.FUSED_SQMC[0] = fused
+                    pa.seed(31)
+                    pf = pa.SMC(fk=cls(ssm=mk(), data=y), N=N, qmc=True, collect="off")
+                    assert pf._fused == fused
+                    if fused:
+                        assert describe(pf).startswith("k_rs_sort+k_sobol+k_sqmv_tapes+"), describe(pf)
+                    steps = []
+                    for t in range(T):
+                        next(pf)
+                        assert pf.rs_flag == (t > 0)
+                        steps.append((np.asarray(pf.X).copy(), None if t == 0 else np.asarray(pf.A).copy(),
+                                      np.asarray(pf.wgts.lw).copy(), float(pf.logLt)))
+                    runs.append(steps)
+                _lib.FUSED_SQMC[0] = True
+                for t in range(T):
+                    (Xa, Aa, la, La), (Xb, Ab, lb, Lb) = runs[0][t], runs[1][t]
+                    if name == "sv" and Aa is not None and not np.array_equal(Aa, Ab):
+                        break                  # (weights that differ in their last bits: see below)
+                    assert Aa is None or np.array_equal(Aa, Ab), (name, N, t)
+                    assert np.array_equal(Xa, Xb), (name, N, t)
+                    # (StochVol: the fused kernels form log N(y; 0, e^{x/2}) with one exp, the operators as scipy does)
+                    assert np.array_equal(la, lb) if name != "sv" else np.allclose(la, lb, rtol=1e-13, atol=1e-13), (name, N, t)
+                    assert abs(La - Lb) < 1e-12 * max(1.0, abs(La)), (name, N, t)
+                else:
+                    t = T
+                assert t >= 2, (name, N, t)
+        # islands: each an SQMC run of its own; the evidence of a linear Gaussian model
+        model = kalman.LinearGauss(rho=0.9, sigmaX=1.0, sigmaY=0.3)
+        ll = orc.kalman_loglik(orc.LinGauss(rho=0.9, sigmaX=1.0, sigmaY=0.3), y)
+        ll = float(ll[0]) if isinstance(ll, tuple) else float(ll)
+        pa.seed(53)
+        pf = pa.SMC(fk=ssm.GuidedPF(ssm=model, data=y), N=512, qmc=True, collect="off", n_islands=4)
+        assert pf._fused
+        pf.run()
+        lls = pf.logLts_islands
+        assert len(set(lls.tolist())) == 4 and np.max(np.abs(lls - ll)) < 0.1, (lls, ll)
+        assert not pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y), N=16, qmc=True)._fused
+        assert not pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y), N=512, qmc=True, use_graph=True)._fused
     finally:
         _lib.FUSED_SQMC[0] = True
         rs.set_rng("numpy")

@@ -77,6 +77,10 @@ def test_sqmc_fused():
     pc.check_sqmc_fused(sizes=(2048,), T=4, audit_sizes=(4096,), islands_N=2048)
 
 
+def test_sqmc_fused_small():
+    pc.check_sqmc_fused_small(sizes=(32, 1024), T=4)
+
+
 def test_sqmc_fused_multivariate():
     pc.check_sqmc_fused_mv(cases=((1024, 2), (2048, 5)), T=4, islands_N=256)
 
@@ -286,7 +290,7 @@ def test_apf_mvlingauss_fused(golden):
 
 
 def test_device_sort():
-    pc.check_device_sort(sizes=(1, 63, 64, 2047, 2048, 2049, 9001))
+    pc.check_device_sort(sizes=(1, 63, 64, 2047, 2048, 2049, 4096, 4097, 8192, 9001, 17000, 133001))   # (one / few / many sort tiles: the three forms of the scatter)
 
 
 def test_smc2_device_theta_level():

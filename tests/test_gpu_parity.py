@@ -102,6 +102,10 @@ def test_sqmc_fused_large_grid():
         rs.set_rng("numpy")
 
 
+def test_sqmc_fused_small():
+    pc.check_sqmc_fused_small()
+
+
 def test_sqmc_fused_multivariate():
     pc.check_sqmc_fused_mv(cases=((1024, 2), (4096, 3), (1 << 16, 5), (1 << 18, 9)), T=5, islands_N=1 << 12)
 
@@ -519,7 +523,7 @@ def test_apf_mvlingauss_fused(golden):
 
 
 def test_device_sort():
-    pc.check_device_sort(sizes=(1, 64, 2049, 50001, (1 << 20) + 3, 1 << 22))
+    pc.check_device_sort(sizes=(1, 64, 2049, 4096, 4097, 8192, 8193, 16384, 16385, 50001, 131072, 131073, (1 << 20) + 3, 1 << 22))
 
 
 def test_smc2_device_theta_level():

@@ -80,7 +80,7 @@ try:
     for c in range(nsq):
         which = int(rng.integers(0, 5))
         d = [1, 1, 1, 2, 3][which]
-        k = int(rng.integers(11, 19)) if d == 1 else int(rng.integers(6, 17))
+        k = int(rng.integers(5, 19)) if d == 1 else int(rng.integers(6, 17))      # (d = 1: flat step below 2^11)
         N, T = 1 << k, int(rng.integers(3, 9))
         mk, cls = [(lambda: kalman.ToySSM(0.2), ssm.Bootstrap), (lambda: ssm.StochVol(), ssm.Bootstrap),
                    (lambda: kalman.LinearGauss(rho=0.9, sigmaX=1.0, sigmaY=0.3), ssm.GuidedPF),

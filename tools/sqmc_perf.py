@@ -46,7 +46,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 1:                       # python tools/sqmc_perf.py 20 [T]: one size, for profiling
         run(kalman.ToySSM(0.2), 1 << int(sys.argv[1]), int(sys.argv[2]) if len(sys.argv) > 2 else 30, "ToySSM d=1")
         sys.exit(0)
-    for k in (12, 16, 20, 22):
+    for k in (7, 10):                           # below two tiles: the flat step (eager launches)
+        run(kalman.ToySSM(0.2), 1 << k, 100, "ToySSM d=1")
+        run(kalman.ToySSM(0.2), 1 << k, 100, "ToySSM d=1", fused=False)
+    for k in (12, 13, 14, 16, 20, 22):
         run(kalman.ToySSM(0.2), 1 << k, 30, "ToySSM d=1")
         run(kalman.ToySSM(0.2), 1 << k, 30, "ToySSM d=1", graph=True)
         run(kalman.ToySSM(0.2), 1 << k, 30, "ToySSM d=1", fused=False)
