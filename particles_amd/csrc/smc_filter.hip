@@ -232,13 +232,23 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
             } else {
                 SMC_LAUNCH((k_ancestors2<true, true>), grid, dim3(SMC_BLOCK), st, f->a);
             }
-        } else if (f->two_level_mid) {
-            SMC_LAUNCH(k_reduce2, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
-            if (f->a.log2N >= 0) SMC_LAUNCH((k_ancestors2<true>), grid, dim3(SMC_BLOCK), st, f->a);
-            else SMC_LAUNCH((k_ancestors2<true, false, false>), grid, dim3(SMC_BLOCK), st, f->a);
         } else {
-            if (f->a.log2N >= 0) SMC_LAUNCH((k_ancestors2<false>), grid, dim3(SMC_BLOCK), st, f->a);
-            else SMC_LAUNCH((k_ancestors2<false, false, false>), grid, dim3(SMC_BLOCK), st, f->a);
+            // closed-form counts: one instantiation per scheme (see k_ancestors2's SCH)
+            if (f->two_level_mid) SMC_LAUNCH(k_reduce2, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
+#ifdef SMC_NO_SCHEME_SPLIT                         /* (A/B builds: tools/build_ablations.sh) */
+#define A2_CASE(MIDV, POW2V, SCHV) SMC_LAUNCH((k_ancestors2<MIDV, false, POW2V>), grid, dim3(SMC_BLOCK), st, f->a)
+#else
+#define A2_CASE(MIDV, POW2V, SCHV) SMC_LAUNCH((k_ancestors2<MIDV, false, POW2V, false, false, SCHV>), grid, dim3(SMC_BLOCK), st, f->a)
+#endif
+            const bool sys = f->a.scheme == SMC_SYSTEMATIC, p2 = f->a.log2N >= 0;
+            if (f->two_level_mid) {
+                if (p2) { if (sys) A2_CASE(true, true, SMC_SYSTEMATIC_); else A2_CASE(true, true, SMC_STRATIFIED_); }
+                else { if (sys) A2_CASE(true, false, SMC_SYSTEMATIC_); else A2_CASE(true, false, SMC_STRATIFIED_); }
+            } else {
+                if (p2) { if (sys) A2_CASE(false, true, SMC_SYSTEMATIC_); else A2_CASE(false, true, SMC_STRATIFIED_); }
+                else { if (sys) A2_CASE(false, false, SMC_SYSTEMATIC_); else A2_CASE(false, false, SMC_STRATIFIED_); }
+            }
+#undef A2_CASE
         }
         if (k_prof >= 0 && (k_prof % 3)) (void)hipEventRecord(f->ev[3 * k_prof + 1], st);
         launch_propagate(f);

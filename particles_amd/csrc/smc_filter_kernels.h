@@ -1591,18 +1591,19 @@ __device__ __forceinline__ void f2_write_row(const FArgs& a, const int isl, cons
 // the sorted uniforms of step t (systematic: the one draw; stratified: read per offspring);
 // kq: the "k" the count functions of smc_resample.h are called with -- they use 2^(62-k) per
 // offspring, the shares here live on the 2^52 scale, hence kq = log2 N + 10
-__device__ __forceinline__ void f2_su(const FArgs& a, const int isl, const i64 t, SmcSu& su, u64& Us)
+__device__ __forceinline__ void f2_su(const FArgs& a, const int isl, const i64 t, SmcSu& su, u64& Us, const int scheme_k = 0)
 {
-    su.scheme = a.scheme;
+    const int scheme = scheme_k ? scheme_k : a.scheme;       // (scheme_k: the kernel's compile-time copy, see k_ancestors2)
+    su.scheme = scheme;
     su.M = a.N;
     su.dM = (double)a.N;
     su.u = a.ut ? a.ut + ((i64)t * a.n_islands + isl) * a.ut_stride
-                : (a.scheme == SMC_MULTINOMIAL_ ? a.su + (i64)isl * a.N : nullptr);
+                : (scheme == SMC_MULTINOMIAL_ ? a.su + (i64)isl * a.N : nullptr);
     su.u_sys = 0.0;
     su.seed = a.seed;
     su.t = (u32)t;
     su.island = (u32)(a.island_offset + isl);
-    if (a.scheme == SMC_SYSTEMATIC_) {
+    if (scheme == SMC_SYSTEMATIC_) {
         if (su.u) {
             su.u_sys = su.u[0];
         } else {
@@ -1665,7 +1666,7 @@ __device__ __forceinline__ i64 f2_count(const FArgs& a, const SmcSu& su, const u
 {
     if (!POW2) return f2_count_general(C, su);
     const int kq = a.log2N + (62 - F2_SBITS);
-    return a.scheme == SMC_SYSTEMATIC_ ? smc_sys_count_pow2_fast(C, su.u_sys, Us, kq, a.N)
+    return su.scheme == SMC_SYSTEMATIC_ ? smc_sys_count_pow2_fast(C, su.u_sys, Us, kq, a.N)
                                        : smc_strat_count_pow2(C, su, kq, a.N);
 }
 struct F2Fast {
@@ -2230,7 +2231,9 @@ k_reduce2(const FArgs av)
 // SQ (SMC_FLAG_SQMC; MID, MULTI, N = 2^k): the sorted uniforms are the sorted first coordinates of the step's
 // Sobol' points -- a regular grid (the digital shift's low bits, rqmc's safe_generate map): threshold n is a
 // function of n, counts are a guess fixed with the definition, nothing is read.
-template <bool MID, bool MULTI = false, bool POW2 = true, bool REGEN = false, bool SQ = false>
+// SCH (closed-form counts): SMC_STRATIFIED_ / SMC_SYSTEMATIC_ as a compile-time constant -- the kernel of one scheme
+// carries none of the other's code (the stratified draw inlines a dozen Philox calls); 0: a.scheme at run time.
+template <bool MID, bool MULTI = false, bool POW2 = true, bool REGEN = false, bool SQ = false, int SCH = 0>
 __global__ void __launch_bounds__(SMC_BLOCK)
 k_ancestors2(const FArgs av)
 {
@@ -2299,7 +2302,7 @@ k_ancestors2(const FArgs av)
     F_STAMP_A(1);
     SmcSu su;                                                  // (the step's uniform: one Philox call,
     u64 Us;                                                    //  all inputs uniform: scalar unit)
-    f2_su(a, isl, t, su, Us);
+    f2_su(a, isl, t, su, Us, SCH);
     double Gd, Qd;
     if (MID) {
         Gd = smc_uniform(Gmid);
@@ -2593,7 +2596,7 @@ k_ancestors2(const FArgs av)
                 ns[i] = cnt;
             }
         }
-    } else if (a.scheme == SMC_SYSTEMATIC_) {
+    } else if ((SCH ? SCH : a.scheme) == SMC_SYSTEMATIC_) {
         F2Fast f;
         const double down = (double)N * 0x1.0p-52;        // offspring per unit of the 2^52 scale (2^-sh for N = 2^k)
         f.Gb = Gb; f.Qb = Qb; f.tb = tb;
