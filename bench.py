@@ -68,25 +68,52 @@ def synthetic_data(T, sigma=0.2, seed=42):
     return y
 
 
-def measured_traffic(a, kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of
-    this very command line (tools/gpu_profile.sh -> tools/summarise_prof.py:
-    FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as the
-    MI355X guide prescribes for gfx950).  PMC counters cannot be collected from
-    inside the process, so the figure is only reported for the configuration the
-    committed profile was taken on; otherwise traffic stays null."""
-    path = os.path.join(ROOT, "profiles", "traffic_%s.json" % a.workload)
+def leg_key(wl):
+    """Name of a workload in `other_workloads` and in profiles/traffic_<key>.json."""
+    if wl.get("qmc"):
+        return "sqmc"
+    if wl["name"] == "c3":
+        return "c3_" + wl["scheme"]
+    if wl["name"] == "c4":
+        return "c4_collapsed" if wl["collapsed"] else "c4"
+    return wl["name"]
+
+
+def measured_traffic(wl, kernel, profiles=None):
+    """HBM bytes per launch of `kernel` (`a+b`: the sum over the launches named) from the committed
+    rocprofv3 PMC passes of this workload's own command line (tools/gpu_profile_all.sh ->
+    tools/summarise_prof.py: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as the
+    MI355X guide prescribes for gfx950).  PMC counters cannot be collected from inside the process, so
+    the figure is reported only when the committed record's `config` is the configuration being run;
+    otherwise traffic stays null.  Returns (bytes, source) or None."""
+    path = os.path.join(profiles or os.path.join(ROOT, "profiles"), "traffic_%s.json" % leg_key(wl))
     if not os.path.exists(path):
         return None
     with open(path) as fh:
         rec = json.load(fh)
     cfg = rec.get("config", {})
-    if a.N > 0 or (cfg.get("log2N"), cfg.get("islands"), cfg.get("scheme")) != (a.log2N, a.islands, a.scheme):
+    if wl["Nlabel"] != "2^%d" % wl["log2N"] or \
+            (cfg.get("log2N"), cfg.get("islands"), cfg.get("scheme")) != (wl["log2N"], wl["islands"], wl["scheme"]) or \
+            bool(cfg.get("collapsed")) != bool(wl["collapsed"]) or bool(cfg.get("qmc")) != bool(wl.get("qmc")):
         return None
-    for name, d in rec["kernels"].items():
-        if kernel in name:
-            return d["hbm_bytes_per_launch"], "rocprofv3 PMC, profiles/%s" % rec.get("summary", "")
-    return None
+    total, found = 0.0, 0
+    base = lambda name: name.replace("void ", "").split("<")[0].split("(")[0].strip()
+    steps = max([d.get("launches") or 0 for name, d in rec["kernels"].items() if base(name).startswith("k_propagate")] + [0])
+    for part in kernel.split("+"):
+        part = part.split("<")[0].split("(")[0].strip()
+        if part == "k_rs_sort":         # the radix sort is several launches per step (k_rs_hist / _scan / _scatter)
+            parts = [d for name, d in rec["kernels"].items() if base(name).startswith("k_rs_")]
+            if parts and steps and all(d.get("launches") for d in parts):
+                total += sum(d["hbm_bytes_per_launch"] * d["launches"] for d in parts) / steps
+                found += 1
+            continue
+        hits = [d["hbm_bytes_per_launch"] for name, d in rec["kernels"].items() if part == base(name)]
+        if hits:
+            total += max(hits)          # (instantiations of one template: the one that carries the step)
+            found += 1
+    if not found:
+        return None
+    return total, "rocprofv3 PMC, profiles/%s" % rec.get("summary", "")
 
 
 # ----------------------------------------------------------------------------------------------
@@ -437,7 +464,12 @@ def other_workloads(K=20, W=10, R=7, shrink=0):
                         "step_frac": rf["step_frac"], "kernel": rf["kernel"], "kernel_ms": rf["kernel_ms"],
                         "bound": rf["bound"], "frac": rf["frac"], "step_kernels": kernels,
                         "per_kernel_ms": {k: v["ms"] for k, v in rf["per_kernel"].items()},
+                        "launch_bytes": rf["launch_bytes"],
+                        "traffic": None, "traffic_source": None,
                         "leg_seconds": time.perf_counter() - t_leg}
+            tr = None if shrink else measured_traffic(wl, rf["kernel"])
+            if tr:
+                out[key]["traffic"], out[key]["traffic_source"] = tr
         except Exception as e:          # one failing leg must not cost the headline its line
             out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
     return out
@@ -469,6 +501,7 @@ def main():
     ap.add_argument("--other-shrink", type=int, default=0, help=argparse.SUPPRESS)     # tests: other_workloads at 2^k
     ap.add_argument("--collapsed", action="store_true",
                     help="c4: the collapsed form of the optimal proposal's weight (SMC_FLAG_COLLAPSED_PROPOSAL)")
+    ap.add_argument("--qmc", action="store_true", help="c2: SMC(qmc=True), the fused SQMC step (the `sqmc` leg)")
     ap.add_argument("--graph", action="store_true", help="replay the steps from hipGraphs (default: eager launches)")
     a = ap.parse_args()
 
@@ -514,7 +547,7 @@ def main():
     R = a.reps if a.reps > 0 else max(3, min(500, -(-(2000 if heavy else 10000) // K)))
     T = W + R * K + (K if world > 1 else 0)      # (N > 1: one more K-step region, timed WITH the evidence gather)
     wl = make_workload(a.workload, T, scheme=a.scheme, log2N=a.log2N, N=a.N, islands=a.islands,
-                       essrmin=a.essrmin, collapsed=a.collapsed)
+                       essrmin=a.essrmin, collapsed=a.collapsed, qmc=a.qmc)
     a.log2N, a.islands = wl["log2N"], wl["islands"]
     N, d = wl["N"], wl["d"]
     bytes_step = 16.0 * d + 40.0
@@ -598,7 +631,7 @@ def main():
         if rank == 0 and ns:
             out["roofline"] = roofline(wl, out["step_achieved_GBs"], mv_ms, rs_ms, ns, kernels)
             out["roofline"]["note"] = ROOFLINE_NOTE
-            tr = measured_traffic(a, out["roofline"]["kernel"].split("+")[-1].split("<")[0])
+            tr = measured_traffic(wl, out["roofline"]["kernel"])
             if tr:
                 out["roofline"]["traffic"], out["roofline"]["traffic_source"] = tr
     if rank == 0 and world == 1 and a.workload == "c2" and a.N == 0 and not a.no_other_workloads \

@@ -739,7 +739,7 @@ class SMC:
 
 ####################################################
 
-def multiSMC(nruns=10, nprocs=0, out_func=None, collect=None, **args):
+def multiSMC(nruns=10, nprocs=0, out_func=None, collect=None, group=None, **args):
     """Run SMC algorithms for different combinations of parameters
     (core.py:431-518, utils.py:216-269).
 
@@ -750,6 +750,18 @@ def multiSMC(nruns=10, nprocs=0, out_func=None, collect=None, **args):
     ``output`` (the SMC object, or ``out_func(smc)``).  ``nprocs`` is accepted
     for compatibility: the runs of one combination execute as islands of ONE
     device-resident filter instead of a pool of processes.
+
+    group : ``particles_amd.distributed.Group`` -- the multi-GPU form of the reference's
+        ``nprocs`` (utils.py:158-186 fans the runs out to worker processes; here one process per
+        GPU was launched and EVERY rank makes this same call).  The ``nruns`` runs of each
+        combination are block-partitioned over the ranks (``shard_islands``), each share runs as
+        islands ``first .. first + count - 1`` of the combination's filter -- the Philox island
+        word is the GLOBAL run index, so the results do not depend on the number of ranks -- and
+        the outputs are gathered in run order on every rank: numeric ``out_func`` results
+        (a float or equal-shaped float arrays: the log-evidences of BASELINE config C5) through
+        the group's RCCL all-gather, anything else pickled over the host rendezvous.  With
+        ``out_func=None`` a remote run's output is a host snapshot (``RunSnapshot``) of its SMC
+        object: device memory does not travel.
     """
     import itertools
 
@@ -767,6 +779,13 @@ def multiSMC(nruns=10, nprocs=0, out_func=None, collect=None, **args):
     combos = list(itertools.product(*choices)) if keys else [()]
     bw = (2 ** 32 - 1) // max(1, nruns * len(combos))           # utils.py:189-202
     seeds = np.arange(0, nruns * len(combos) * bw, bw) + np.random.randint(bw, size=nruns * len(combos))
+    rank, world = (group.rank, group.world) if group is not None else (0, 1)
+    if world > 1:
+        seeds = group.broadcast_host(seeds)          # rank 0's draw: one job, one set of seeds
+    first, count = 0, nruns
+    if world > 1:
+        from .distributed import shard_islands
+        first, count = shard_islands(nruns, rank, world)
     results, si = [], 0
     for combo in combos:
         kw, label = dict(fixed), {}
@@ -781,25 +800,45 @@ def multiSMC(nruns=10, nprocs=0, out_func=None, collect=None, **args):
                  and kw.get("n_islands", 1) == 1
                  and not (fk.isAPF and not SMC._apf_fusable(fk, kw.get("N", 100), kw.get("resampling", "systematic"),
                                                             None, False, False)))
+        mine = []                                    # this rank's outputs, runs first .. first + count - 1
         if batch and out_func is not None:
-            # islands of one filter; Philox island word = run index, key = first seed
-            pf = SMC(collect="off", seed=int(run_seeds[0]), n_islands=nruns, **kw)
-            pf.run()
-            for r in range(nruns):
-                d = {"run": r, "seed": int(run_seeds[0])}
-                d.update(label)
-                d["output"] = out_func(_IslandView(pf, r))
-                results.append(d)
+            # islands of one filter; Philox island word = (global) run index, key = first seed
+            if count > 0:
+                pf = SMC(collect="off", seed=int(run_seeds[0]), n_islands=count, island_offset=first, **kw)
+                pf.run()
+                mine = [out_func(_IslandView(pf, r)) for r in range(count)]
+            out_seeds = [int(run_seeds[0])] * nruns
         else:
-            for r in range(nruns):
+            for r in range(first, first + count):
                 np.random.seed(int(run_seeds[r]))       # utils.py:209-213: the seeder of each run
                 pf = SMC(collect=collect, seed=int(run_seeds[r]), **kw)
                 pf.run()
-                d = {"run": r, "seed": int(run_seeds[r])}
-                d.update(label)
-                d["output"] = pf if out_func is None else out_func(pf)
-                results.append(d)
+                mine.append(out_func(pf) if out_func is not None else (pf if world == 1 else RunSnapshot(pf)))
+            out_seeds = [int(v) for v in run_seeds]
+        outputs = mine if world == 1 else group.gather_outputs(mine, nruns)
+        for r in range(nruns):
+            d = {"run": r, "seed": out_seeds[r]}
+            d.update(label)
+            d["output"] = outputs[r]
+            results.append(d)
     return results
+
+
+class RunSnapshot:
+    """Host copy of what a finished SMC run leaves behind (multiSMC over several ranks with
+    ``out_func=None``: the reference pickles the SMC object back from its worker process,
+    utils.py:178-186; a device-resident filter cannot travel, its results can)."""
+
+    def __init__(self, pf):
+        self.N, self.t, self.cpu_time = pf.N, pf.t, pf.cpu_time
+        self.logLt = float(pf.logLt)
+        self.X = np.array(pf.X)
+        w = pf.wgts
+        self.lw, self.W, self.ESS = np.array(w.lw), np.array(w.W), float(w.ESS)
+        sm = pf.summaries
+        self.summaries = None if sm is None else {k: list(getattr(sm, k).copy() if hasattr(getattr(sm, k), "copy")
+                                                         else getattr(sm, k))
+                                                  for k in ("ESSs", "logLts", "rs_flags") if hasattr(sm, k)}
 
 
 class _IslandView:

@@ -247,6 +247,56 @@ class Group:
     def allreduce_min_host(self, v):
         return self._allreduce_host(v, np.min)
 
+    def broadcast_host(self, arr):
+        """Rank 0's array on every rank (host side; a few bytes: seeds, flags)."""
+        a = np.ascontiguousarray(arr)
+        if not self.star:
+            return a
+        blob = self.star.exchange(a.tobytes() if self.rank == 0 else b"")[0]
+        return np.frombuffer(blob, dtype=a.dtype).reshape(a.shape).copy()
+
+    def allgather_obj(self, obj):
+        """Every rank's picklable object, in rank order (host side)."""
+        import pickle
+        if not self.star:
+            return [obj]
+        return [pickle.loads(p) for p in self.star.exchange(pickle.dumps(obj, protocol=4))]
+
+    def gather_outputs(self, mine, total):
+        """multiSMC's collection step (utils.py:178-186): rank r holds the outputs of the runs
+        ``shard_islands(total, r, world)`` in run order; every rank gets all ``total`` of them in
+        run order.  Numeric outputs -- floats or float arrays of one shape, the same on every
+        rank -- cross the ranks through the evidence all-gather (RCCL; blocks padded to the
+        largest share, since ncclAllGather wants equal counts); anything else is pickled over the
+        host star.  Which of the two is one agreement round over the star, so that no rank enters
+        a collective the others do not."""
+        shares = [shard_islands(total, r, self.world)[1] for r in range(self.world)]
+        if len(mine) != shares[self.rank]:
+            raise ValueError("gather_outputs: rank %d holds %d outputs, its share is %d"
+                             % (self.rank, len(mine), shares[self.rank]))
+        shape, scalar = None, False
+        try:
+            arrs = [np.asarray(v) for v in mine]
+            if all(a.dtype.kind == "f" and a.dtype.itemsize == 8 for a in arrs) and len({a.shape for a in arrs}) <= 1:
+                shape = arrs[0].shape if arrs else "any"
+                scalar = all(np.ndim(v) == 0 and not isinstance(v, np.ndarray) for v in mine)
+        except Exception:
+            shape = None
+        votes = self.allgather_obj((shape, scalar))
+        shapes = {v[0] for v in votes if v[0] != "any"}
+        if None not in shapes and len(shapes) == 1:
+            shp = shapes.pop()
+            per = int(np.prod(shp)) if shp else 1
+            block = np.full(max(shares) * per, np.nan)
+            if mine:
+                block[:len(mine) * per] = np.stack([np.asarray(v, dtype=np.float64).reshape(per) for v in mine]).ravel()
+            allv = self.gather_evidence(block).reshape(self.world, max(shares), per)
+            rows = [allv[r, i] for r in range(self.world) for i in range(shares[r])]
+            if all(v[1] for v in votes):
+                return [float(v[0]) for v in rows]
+            return [v.reshape(shp).copy() for v in rows]
+        return [o for part in self.allgather_obj(list(mine)) for o in part]
+
     # ---- the collective of the path ------------------------------------------
     def gather_evidence(self, local_logLt):
         """All ranks' per-island log-evidences, concatenated in rank order.

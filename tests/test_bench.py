@@ -75,3 +75,38 @@ def test_auto_kind_follows_the_reference_tree(monkeypatch):
     monkeypatch.setattr(bench, "REFERENCE_DIR", "/nonexistent")
     assert not bench.reference_available()
     assert bench.cpu_baseline(1 << 10, 4, all_cores=False)["kind"] == "port"
+
+
+def test_committed_traffic_files_are_usable():
+    """Every committed profiles/traffic_<key>.json must be a record bench.py can use: written by
+    tools/summarise_prof.py WITH its config / summary / command, naming a summary that is committed
+    beside it, and `measured_traffic` must return a number for the workload the record describes
+    (round 3's driver line carried `roofline.traffic: null` because a refreshed file had lost its
+    `config`)."""
+    import glob
+    import bench
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_*.json")))
+    assert files
+    for f in files:
+        rec = json.load(open(f))
+        key = os.path.basename(f)[len("traffic_"):-len(".json")]
+        for k in ("kernels", "config", "summary", "command"):
+            assert k in rec, (f, k)
+        assert os.path.exists(os.path.join(ROOT, "profiles", rec["summary"])), (f, rec["summary"])
+        cfg = rec["config"]
+        wl = bench.make_workload(cfg["workload"], 4, scheme=cfg["scheme"], collapsed=bool(cfg.get("collapsed")),
+                                 qmc=bool(cfg.get("qmc")))
+        assert bench.leg_key(wl) == key, (f, bench.leg_key(wl))
+        assert (wl["log2N"], wl["islands"]) == (cfg["log2N"], cfg["islands"]), f
+        names = [n for n in rec["kernels"] if "k_propagate" in n]
+        assert names, f
+        tr = bench.measured_traffic(wl, "k_propagate_mv" if cfg["workload"] == "c4" else "k_propagate")
+        assert tr is not None and tr[0] > 1e6, (f, tr)
+        # algorithmic bytes of the propagate launch (SURVEY 8d) against what the counters saw: within 2x
+        alg = (16.0 * wl["d"] + 24.0) * wl["N"] * wl["islands"]
+        assert 0.4 < tr[0] / alg < 2.0, (f, tr[0] / alg)
+        # a different size is NOT this record's workload
+        wl2 = bench.make_workload(cfg["workload"], 4, scheme=cfg["scheme"], log2N=cfg["log2N"] - 1,
+                                  collapsed=bool(cfg.get("collapsed")), qmc=bool(cfg.get("qmc")))
+        if cfg["workload"] != "c5":
+            assert bench.measured_traffic(wl2, "k_propagate") is None

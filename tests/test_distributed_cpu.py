@@ -257,6 +257,85 @@ def test_multi_rank_rccl_calls_through_the_test_double(tmp_path, has_gpu):
     assert np.allclose(h2["lw"], s2["lw"], rtol=0, atol=1e-9)
 
 
+MULTI_WORKER = r"""
+import os, sys, json
+sys.path.insert(0, {root!r})
+sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np
+import conftest
+conftest.pytest_configure(type("C", (), {{"addinivalue_line": lambda *a: None}})())
+import particles_amd as pa
+from particles_amd import kalman, state_space_models as ssm
+from particles_amd.distributed import Group
+
+grp = Group(device_collective=os.environ.get("SMC_TEST_RCCL") == "1")
+rng = np.random.RandomState(42)
+x = np.cumsum(rng.standard_normal(10))
+y = [np.array([v]) for v in x + 0.2 * rng.standard_normal(10)]
+fk = ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y)
+np.random.seed(5 + grp.rank)          # the ranks' numpy streams differ: rank 0's seeds must win
+# (1) the C5 shape: nruns islands, a float per run -> the RCCL all-gather
+r1 = pa.multiSMC(nruns=7, fk=fk, N=[600, 1100], resampling="systematic", group=grp,
+                 out_func=lambda pf: pf.logLt)
+# (2) an array per run (the evidence trajectory)
+r2 = pa.multiSMC(nruns=5, fk=fk, N=600, group=grp, out_func=lambda pf: np.array(pf.logLts))
+# (3) objects: pickled over the star
+r3 = pa.multiSMC(nruns=4, fk=fk, N=600, group=grp, out_func=lambda pf: {{"ll": pf.logLt, "N": pf.N}})
+# (4) no out_func: the unbatched path, a host snapshot of every run; fewer runs than ranks at world 3
+r4 = pa.multiSMC(nruns=2, fk=fk, N=400, group=grp)
+if grp.rank == 0:
+    print("RESULT " + json.dumps({{
+        "r1": [[d["run"], d["seed"], d["N"], d["output"]] for d in r1],
+        "r2": [[d["run"], d["seed"], d["output"].tolist()] for d in r2],
+        "r3": [[d["run"], d["seed"], d["output"]] for d in r3],
+        "r4": [[d["run"], d["seed"], d["output"].logLt, float(d["output"].X.sum()), d["output"].t] for d in r4],
+        "types": [type(r1[0]["output"]).__name__, type(r2[0]["output"]).__name__, type(r4[0]["output"]).__name__],
+        "path": grp.evidence_path}}))
+grp.close()
+"""
+
+
+def _run_multi_world(world, tmp_path, **env_extra):
+    import json
+    script = tmp_path / "multi_worker.py"
+    script.write_text(MULTI_WORKER.format(root=ROOT))
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SMC_HIP_DEVICE="0", **env_extra)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    return json.loads([l for l in outs[0].splitlines() if l.startswith("RESULT ")][0][7:])
+
+
+def test_multiSMC_over_a_group_is_world_invariant(tmp_path, has_gpu):
+    """The reference's multi-run seam (core.py:431-518, utils.py:158-186) over one process per GPU:
+    `multiSMC(..., group=Group())` called by every rank shards the runs, gathers the outputs in run
+    order and returns the reference's list of dicts -- worlds 2 and 3 (host star, and the RCCL
+    branch through the protocol-checking double) equal the world-1 result bit for bit."""
+    one = _run_multi_world(1, tmp_path)
+    assert one["types"] == ["float", "ndarray", "SMC"]          # one process: the SMC objects themselves
+    assert [r[0] for r in one["r1"]] == list(range(7)) * 2 and [r[2] for r in one["r1"]] == [600] * 7 + [1100] * 7
+    assert len({r[3] for r in one["r1"]}) == 14                     # distinct streams per run and per N
+    assert len(one["r2"]) == 5 and len(one["r2"][0][2]) == 10 and len(one["r4"]) == 2 and one["r4"][0][4] == 10
+    for world in (2, 3):
+        got = _run_multi_world(world, tmp_path)
+        assert got["path"].startswith("host-fallback")
+        for k in ("r1", "r2", "r3", "r4"):
+            assert got[k] == one[k], (world, k)
+        assert got["types"][:2] == ["float", "ndarray"] and got["types"][2] == "RunSnapshot"
+    if not has_gpu:
+        env = _fake_rccl_env(tmp_path)
+        for world in (2, 3):
+            got = _run_multi_world(world, tmp_path, **env)
+            assert got["path"] == "rccl"
+            for k in ("r1", "r2", "r3", "r4"):
+                assert got[k] == one[k], (world, k)
+
+
 def test_rccl_test_double_refuses_protocol_violations(tmp_path):
     """The double itself: what it accepts is what RCCL accepts from smc_comm, what it refuses would
     deadlock or corrupt on a node."""

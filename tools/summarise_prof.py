@@ -2,7 +2,13 @@
 per-kernel call count / average duration from the kernel trace, and per-kernel
 per-dispatch averages of every PMC counter collected.
 
-    python tools/summarise_prof.py gpurun_out/prof_<tag>
+    python tools/summarise_prof.py gpurun_out/prof_<tag> [--config JSON] [--command STR] [--summary NAME]
+
+With PMC passes of FETCH_SIZE / WRITE_SIZE present it also writes <dir>/traffic.json =
+{"kernels": {name: {..., "hbm_bytes_per_launch"}}, "config": {...}, "summary": NAME, "command": STR}:
+the record bench.py's `measured_traffic` matches against the workload it is running (config:
+workload key, log2N, islands, scheme), so the three optional arguments are what makes the file usable
+as profiles/traffic_<key>.json (tests/test_bench.py::test_committed_traffic_files_are_usable).
 """
 import glob
 import os
@@ -10,7 +16,14 @@ import sqlite3
 import sys
 from collections import defaultdict
 
-out = sys.argv[1]
+import argparse
+_ap = argparse.ArgumentParser()
+_ap.add_argument("out")
+_ap.add_argument("--config", default="")
+_ap.add_argument("--command", default="")
+_ap.add_argument("--summary", default="")
+_a = _ap.parse_args()
+out = _a.out
 
 for f in sorted(glob.glob(os.path.join(out, "**", "*_results.db"), recursive=True)):
     c = sqlite3.connect(f)
@@ -51,17 +64,26 @@ traffic = {}
 for f in sorted(glob.glob(os.path.join(out, "**", "*_results.db"), recursive=True)):
     c = sqlite3.connect(f)
     try:
-        for k, cn, v in c.execute("select kernel_name, counter_name, avg(value) from counters_collection "
-                                  "where counter_name in ('FETCH_SIZE','WRITE_SIZE') group by 1,2"):
+        for k, cn, v, n in c.execute("select kernel_name, counter_name, avg(value), count(*) from counters_collection "
+                                     "where counter_name in ('FETCH_SIZE','WRITE_SIZE') group by 1,2"):
             traffic.setdefault(k, {})[cn] = v
+            traffic[k]["launches"] = n
     except sqlite3.Error:
         pass
 if traffic:
     # FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B
     # (MI355X_MICROARCH.md, HBM): double it for wide coalesced reads
     res = {k: {"FETCH_SIZE_KiB": d.get("FETCH_SIZE"), "WRITE_SIZE_KiB": d.get("WRITE_SIZE"),
-               "hbm_bytes_per_launch": (2.0 * d.get("FETCH_SIZE", 0.0) + d.get("WRITE_SIZE", 0.0)) * 1024.0}
+               "hbm_bytes_per_launch": (2.0 * d.get("FETCH_SIZE", 0.0) + d.get("WRITE_SIZE", 0.0)) * 1024.0,
+               "launches": d.get("launches")}
            for k, d in traffic.items() if not k.startswith("__amd")}
     with open(os.path.join(out, "traffic.json"), "w") as fh:
-        json.dump({"kernels": res}, fh, indent=1)
+        rec = {"kernels": res}
+        if _a.config:
+            rec["config"] = json.loads(_a.config)
+        if _a.summary:
+            rec["summary"] = _a.summary
+        if _a.command:
+            rec["command"] = _a.command
+        json.dump(rec, fh, indent=1)
     print("== traffic.json:", json.dumps(res))
