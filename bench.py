@@ -310,7 +310,8 @@ def make_workload(name, T, scheme="systematic", log2N=None, N=0, islands=1, essr
         label = "C4: MVLinearGauss_Guarniero d=32 guided filter" + (" (collapsed proposal weight)" if collapsed else "")
     else:
         if name == "c5":      # one GPU's share of 256 islands x 2^18
-            log2N, islands = 18, 32
+            log2N = 18 if log2N is None else log2N            # (smaller: functional tests on the emulator)
+            islands = 32 if islands == 1 else islands
         log2N = 20 if log2N is None else log2N
         fk = ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=synthetic_data(T))
         label = "C2: ToySSM d=1 linear-Gaussian bootstrap filter" if name == "c2" else \
@@ -501,6 +502,9 @@ def main():
     ap.add_argument("--other-shrink", type=int, default=0, help=argparse.SUPPRESS)     # tests: other_workloads at 2^k
     ap.add_argument("--collapsed", action="store_true",
                     help="c4: the collapsed form of the optimal proposal's weight (SMC_FLAG_COLLAPSED_PROPOSAL)")
+    ap.add_argument("--allow-host-gather", action="store_true",
+                    help="N > 1: if RCCL cannot be initialised, gather the evidences over the host rendezvous "
+                         "(labelled in the line) instead of failing")
     ap.add_argument("--qmc", action="store_true", help="c2: SMC(qmc=True), the fused SQMC step (the `sqmc` leg)")
     ap.add_argument("--graph", action="store_true", help="replay the steps from hipGraphs (default: eager launches)")
     a = ap.parse_args()
@@ -515,7 +519,7 @@ def main():
         a.gpus = world
     # (functional test of the multi-rank path on a box with fewer GPUs than ranks:
     #  SMC_BENCH_NGPU=1 lets all ranks share device 0; RCCL then refuses, which is an ERROR unless
-    #  SMC_ALLOW_HOST_GATHER=1 routes the evidences over the host rendezvous)
+    #  --allow-host-gather routes the evidences over the host rendezvous)
     ngpu = int(os.environ.get("SMC_BENCH_NGPU", "0"))
     device = local_rank % ngpu if ngpu > 0 else local_rank
     os.environ["SMC_HIP_DEVICE"] = str(device)
@@ -523,10 +527,24 @@ def main():
     from particles_amd import _lib
     from particles_amd.distributed import Group
 
-    # a multi-GPU bench line with a LABELLED host gather ("evidence_gather": "host-fallback: <reason>")
-    # is worth more than no line: the gather is outside the timed region either way
-    os.environ.setdefault("SMC_ALLOW_HOST_GATHER", "1")
-    grp = Group(device_collective=True) if world > 1 else None
+    # N > 1: the path's one collective is RCCL's.  If RCCL cannot be initialised the run FAILS (rank 0
+    # prints the reason as a JSON object with "error" and exits non-zero): a scale line must never be a
+    # host-star line mistaken for an xGMI one.  --allow-host-gather (functional tests on a box with fewer
+    # GPUs than ranks) opts into the labelled host gather: "rccl": false, "evidence_gather": "host-fallback: ..."
+    if a.allow_host_gather:
+        os.environ["SMC_ALLOW_HOST_GATHER"] = "1"
+    else:
+        os.environ.pop("SMC_ALLOW_HOST_GATHER", None)
+    grp = None
+    if world > 1:
+        try:
+            grp = Group(device_collective=True)
+        except RuntimeError as e:
+            if rank == 0:
+                print(json.dumps({"error": str(e), "rccl": False, "n_gpus": world,
+                                  "hint": "bench.py --allow-host-gather gathers the evidences over the host rendezvous"}),
+                      flush=True)
+            sys.exit(3)
     if grp and grp.rank == 0 and grp.evidence_path != "rccl":
         print("bench.py: RCCL unavailable, evidences gathered over the host rendezvous (%s)" % grp.evidence_path,
               file=sys.stderr)
@@ -586,6 +604,35 @@ def main():
     rs_rate = float(np.mean(pf._summ()[0, W:, 4]))
     del pf
 
+    # C5 at the reference's own seam: ONE call of multiSMC (core.py:431-518) by every rank -- the
+    # 32 x n_gpus runs sharded over the ranks as islands, the per-run log-evidences gathered by the
+    # group's RCCL all-gather -- over K steps of the same data, timed WITH everything the call does
+    # (filter construction, the T-loop, the gather): reported beside the headline, whose timed region
+    # holds the steps only
+    multi = None
+    if a.workload == "c5" and a.N == 0:
+        import particles_amd as pa
+        wl5 = make_workload("c5", K, scheme=a.scheme, essrmin=a.essrmin, log2N=a.log2N, islands=a.islands)
+        nruns = wl5["islands"] * world
+        kw5 = dict(nruns=nruns, fk=wl5["fk"], N=wl5["N"], resampling=wl5["scheme"], ESSrmin=wl5["essrmin"],
+                   group=grp, out_func=lambda pf_: pf_.logLt)
+        np.random.seed(4242)
+        pa.multiSMC(**kw5)                           # (first call: allocations, RCCL channels)
+        if grp:
+            grp.barrier()
+        t0 = time.perf_counter()
+        res = pa.multiSMC(**kw5)
+        sec = time.perf_counter() - t0
+        sec = float(grp.allreduce_max_host(sec)) if grp else sec
+        lls = np.array([r["output"] for r in res])
+        from particles_amd.distributed import log_mean_exp_host
+        multi = {"call": "particles_amd.multiSMC(nruns=%d, fk=Bootstrap(ToySSM, T=%d), N=2^%d, group=Group(), "
+                         "out_func=lambda pf: pf.logLt)" % (nruns, K, wl5["log2N"]),
+                 "nruns": nruns, "seconds": sec, "value": nruns * float(wl5["N"]) * K / sec,
+                 "unit": "particle-steps/s", "evidence_gather": grp.evidence_path if grp else "none",
+                 "log_mean_exp_evidence": log_mean_exp_host(lls), "logLt_sd_over_runs": float(lls.std()),
+                 "distinct_runs": int(len(set(lls.tolist())))}
+
     out = None
     if rank == 0:
         units = float(N) * wl["islands"] * K * world
@@ -610,13 +657,14 @@ def main():
             "logLt": [float(v) for v in np.atleast_1d(all_ll)][:16],
             "evidence_gather": grp.evidence_path if grp else "none",
             "evidence_gather_ms": gather_ms,
-            # the library's Group raises when RCCL cannot be initialised; bench.py opts into the host
-            # gather (SMC_ALLOW_HOST_GATHER, set above unless the caller exported 0) so that a scale
-            # line exists either way -- and says so here: rccl false = no collective touched xGMI
+            # the library's Group raises when RCCL cannot be initialised and bench.py then fails; only
+            # --allow-host-gather produces a line with rccl false (= no collective touched xGMI)
             "rccl": bool(grp and grp.evidence_path == "rccl") if grp else None,
         }
         if devices is not None:
             out["rank_devices"] = devices
+        if multi is not None:
+            out["multiSMC"] = multi
         if grp:
             out["timing"]["ms_per_step_with_gather"] = 1e3 * with_gather / K
             out["timing"]["note"] = (

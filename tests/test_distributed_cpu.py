@@ -386,7 +386,16 @@ def test_bench_two_ranks_launch_line(tmp_path):
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
            "--gpus", "2", "--steps", "3", "--warmup", "1", "--log2N", "11", "--reps", "2",
            "--no-cpu-baseline", "--no-profile"]
+    # without RCCL the launch line FAILS, and says why in a JSON object (a scale line is never a host-star line
+    # by accident) ...
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert p.returncode != 0
+    err = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(err) == 1 and "RCCL" in err[0]["error"] and err[0]["rccl"] is False and "value" not in err[0]
+    # ... unless the caller opts into the labelled host gather
+    cmd[cmd.index("--master-port") + 1] = str(_free_port())
+    p = subprocess.run(cmd + ["--allow-host-gather"], env=env, capture_output=True, text=True, timeout=600,
+                       cwd=str(tmp_path))
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                   # rank 0 prints ONE line
@@ -400,3 +409,14 @@ def test_bench_two_ranks_launch_line(tmp_path):
     assert d["evidence_gather_ms"] is not None and "timing" in d and "note" in d["timing"]
     assert d["timing"]["ms_per_step_with_gather"] >= d["ms_per_step"] * 0.5      # the region that holds the collective
     assert "RCCL unavailable" in p.stderr
+    # C5 under the same launch line is ONE call of the reference's multiSMC per rank (bench.py's `multiSMC` block)
+    cmd5 = list(cmd)
+    cmd5[cmd5.index("--master-port") + 1] = str(_free_port())
+    cmd5[cmd5.index("--log2N") + 1] = "10"
+    p = subprocess.run(cmd5 + ["--allow-host-gather", "--workload", "c5", "--islands", "3"], env=env,
+                       capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    d5 = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    m = d5["multiSMC"]
+    assert m["nruns"] == 6 and m["distinct_runs"] == 6 and m["value"] > 0 and "multiSMC(nruns=6" in m["call"]
+    assert m["evidence_gather"].startswith("host-fallback") and d5["config"]["islands_per_gpu"] == 3
