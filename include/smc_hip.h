@@ -353,6 +353,8 @@ typedef struct smc_filter_opts {
 #define SMC_PATH_POW2_ONLY       (1 << 18)  /* N not a power of two on the flat step */
 #define SMC_PATH_SPACING_3PASS   (1 << 19)  /* uniform_spacings in three passes instead of one */
 #define SMC_PATH_SPLIT_REDUCE     (1 << 24)  /* multinomial, one-pass spacings: k_reduce2 as a launch of its own */
+#define SMC_PATH_NO_WIDE          (1 << 30)  /* resident two-level step: k_ancestors2 (one tile per workgroup) instead of k_ancestors2w */
+#define SMC_PATH_WIDE4            (1 << 7)   /* k_ancestors2w with 4 tiles per workgroup instead of 2 */
 #define SMC_PATH_SQ_GATHER        (1 << 29)  /* SMC_FLAG_SQMC: gather the sorted log-weights where they could be recomputed */
 #define SMC_PATH_SP_TPW(n)        (((n) & 15) << 25)   /* one-pass spacings: n = 1, 2, 4, 8 tiles of draws per workgroup */
 #define SMC_PATH_MV_CHUNKS(n)    (((n) & 15) << 20)   /* k_propagate_mv: n = 1, 2, 4, 8 chunks per workgroup */

@@ -7,6 +7,7 @@
 #include "smc_filter_mv.h"
 #include "smc_filter_small.h"
 #include "smc_filter_sqmc.h"
+#include "smc_filter_wide.h"
 
 // ---------------------------------------------------------------------------
 // host side
@@ -48,6 +49,7 @@ struct smc_filter {
     int prof_n;
     bool no_tk;            // SMC_PATH_NO_TK: kernels never start on the host's time index (A/B)
     bool no_small;         // SMC_PATH_NO_SMALL
+    int wide_tpw;          // k_ancestors2w: tiles per workgroup (0: k_ancestors2, one tile per workgroup)
     double* tmp;           // (N,) staging for W / Xp downloads
     double* ll_stage;      // (n_islands,) staging for smc_filter_logLt: PINNED host memory the
                            // collect kernel writes straight into (no copy engine, no staging)
@@ -244,6 +246,16 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
             if (f->two_level_mid) {
                 if (p2) { if (sys) A2_CASE(true, true, SMC_SYSTEMATIC_); else A2_CASE(true, true, SMC_STRATIFIED_); }
                 else { if (sys) A2_CASE(true, false, SMC_SYSTEMATIC_); else A2_CASE(true, false, SMC_STRATIFIED_); }
+            } else if (p2 && f->wide_tpw) {
+                // resident grid, N = 2^k: TPW tiles per workgroup, the partials reduced by its first 4 waves only
+                const dim3 gridw(f->a.ntiles / f->wide_tpw, f->a.n_islands);
+                if (f->wide_tpw == 4) {
+                    if (sys) SMC_LAUNCH((k_ancestors2w<4, SMC_SYSTEMATIC_>), gridw, dim3(SMC_BLOCK * 4), st, f->a);
+                    else SMC_LAUNCH((k_ancestors2w<4, SMC_STRATIFIED_>), gridw, dim3(SMC_BLOCK * 4), st, f->a);
+                } else {
+                    if (sys) SMC_LAUNCH((k_ancestors2w<2, SMC_SYSTEMATIC_>), gridw, dim3(SMC_BLOCK * 2), st, f->a);
+                    else SMC_LAUNCH((k_ancestors2w<2, SMC_STRATIFIED_>), gridw, dim3(SMC_BLOCK * 2), st, f->a);
+                }
             } else {
                 if (p2) { if (sys) A2_CASE(false, true, SMC_SYSTEMATIC_); else A2_CASE(false, true, SMC_STRATIFIED_); }
                 else { if (sys) A2_CASE(false, false, SMC_SYSTEMATIC_); else A2_CASE(false, false, SMC_STRATIFIED_); }
@@ -534,6 +546,13 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     }
     f->two_level_mid = f->two_level && (!f->fused || a.ntiles > 1024 || (o->flags & SMC_PATH_TWO_LEVEL_MID) ||
                                         scheme == SMC_MULTINOMIAL || apf2);
+    // resident grids of N = 2^k: 2 tiles per workgroup (smc_filter_wide.h; C2, same box: 17.6 us per step, 4 tiles 18.3,
+    // one tile -- k_ancestors2 -- 18.1: profiles/r12d); SMC_PATH_NO_WIDE / _WIDE4 (A/B)
+    f->wide_tpw = 0;
+    if (f->two_level && !f->two_level_mid && a.log2N >= 0 && !(o->flags & SMC_PATH_NO_WIDE) && !f->strict && !f->sqmc) {
+        const int want = (o->flags & SMC_PATH_WIDE4) ? 4 : 2;
+        f->wide_tpw = (a.ntiles % want) == 0 ? want : ((a.ntiles % 2) == 0 ? 2 : 0);
+    }
     // (SQMC: k_ancestors2 counts in SORTED positions; a heavy parent's blocks would be filled with that index)
     const bool heavy_list = !mv && !f->strict && !f->sqmc && !(o->flags & SMC_PATH_NO_HEAVY);
     // (history slots are written step by step: the lanes beyond N of a slot would read indices nobody
@@ -661,7 +680,8 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     a.tk = -1;
     // streaming stores pay while a launch is short (its end-of-kernel write-back shows): C2 +8 %;
     // on the large grids they cost 2 % (C5)
-    a.nt = ((i64)a.ntiles * (i64)M <= F_DIRECT_PREFIX_MAX && !mv && !(o->flags & SMC_PATH_NO_NT)) ? 1 : 0;
+    a.nt = ((i64)a.ntiles * (i64)M <= F_DIRECT_PREFIX_MAX && !mv && !(o->flags & SMC_PATH_NO_NT)) ? 15 : 0;
+    if (a.nt && getenv("SMC_EXP_NT")) a.nt = atoi(getenv("SMC_EXP_NT"));          // (experiment: which arrays stream)
     a.pm2 = a.ps2 = a.pss2 = nullptr;
     if (apf2) {
         a.pm2 = (double*)(base + oP2);
@@ -1650,7 +1670,7 @@ int smc_filter_describe(smc_filter* f, char* out, size_t n)
         s = std::string(f->two_level ? "k_reduce2+" : "") + "k_strict_W+k_strict_cdf+k_strict_search+k_propagate";
     } else {
         if (f->two_level_mid) s = "k_reduce2+k_ancestors2";
-        else if (f->two_level) s = "k_ancestors2";
+        else if (f->two_level) s = f->wide_tpw ? "k_ancestors2w" : "k_ancestors2";
         else if (f->fused) s = "k_ancestors<fused>";
         else s = "k_prepare+k_ancestors";
         if (f->a.scheme == SMC_MULTINOMIAL && !f->a.ut)

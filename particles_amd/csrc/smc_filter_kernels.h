@@ -1015,7 +1015,7 @@ k_ancestors(const FArgs av)
                      [&](i64 n0, const bool (&ok)[4], const i64 (&a4)[4]) {                // core.py:329
                          const u32 a32[4] = {(u32)a4[0], (u32)a4[1], (u32)a4[2], (u32)a4[3]};
                          if (vec && ok[0] && ok[3]) {
-                             if (a.nt) smc_st4g_nt(A + n0, a32);
+                             if (a.nt & 8) smc_st4g_nt(A + n0, a32);
                              else smc_st4g(A + n0, a32);
                          } else {
 #pragma unroll
@@ -1453,14 +1453,17 @@ k_propagate(const FArgs av)
             if (APF) xkeep[k] = xn[k];
         }
         if (full_st) {
-            if (a.nt) {
+            if (a.nt & 1) {
                 smc_st2g_nt(Xn + own.na, xn[0], xn[1]);
                 smc_st2g_nt(Xn + own.nb, xn[2], xn[3]);
-                smc_st2g_nt(lwn + own.na, lw[0], lw[1]);
-                smc_st2g_nt(lwn + own.nb, lw[2], lw[3]);
             } else {
                 smc_st2g(Xn + own.na, xn[0], xn[1]);
                 smc_st2g(Xn + own.nb, xn[2], xn[3]);
+            }
+            if (a.nt & 2) {
+                smc_st2g_nt(lwn + own.na, lw[0], lw[1]);
+                smc_st2g_nt(lwn + own.nb, lw[2], lw[3]);
+            } else {
                 smc_st2g(lwn + own.na, lw[0], lw[1]);
                 smc_st2g(lwn + own.nb, lw[2], lw[3]);
             }
@@ -1505,7 +1508,7 @@ k_propagate(const FArgs av)
         }
         const F2Tile r = f2_tile_weights(lw, cx);
         u64* cq = a.cq + (i64)isl * (RAGGED ? a.ncq : N);          // (whole tiles: ncq == N, already in registers)
-        if (a.nt) { smc_st2g_nt(cq + own.na, cx[0], cx[1]); smc_st2g_nt(cq + own.nb, cx[2], cx[3]); }
+        if (a.nt & 4) { smc_st2g_nt(cq + own.na, cx[0], cx[1]); smc_st2g_nt(cq + own.nb, cx[2], cx[3]); }
         else { smc_st2g(cq + own.na, cx[0], cx[1]); smc_st2g(cq + own.nb, cx[2], cx[3]); }
         if (tid == 0) {
             const i64 o = (i64)isl * a.nparts;
@@ -1607,9 +1610,13 @@ __device__ __forceinline__ void f2_su(const FArgs& a, const int isl, const i64 t
         if (su.u) {
             su.u_sys = su.u[0];
         } else {
+#ifdef SMC_EXP_NOPHILOX                     /* (timing experiment: what the scalar Philox call costs the launch) */
+            su.u_sys = 0.37 + 1e-3 * (double)(su.t & 255u);
+#else
             u64 x0, x1;
             smc_philox(0u, su.t, su.island, SMC_STREAM_RESAMPLE, su.seed, x0, x1);
             su.u_sys = smc_u01_halfopen(x0);
+#endif
         }
     }
     Us = a.log2N >= 0 ? (u64)(su.u_sys * __longlong_as_double((long long)(1023 + F2_SBITS - a.log2N) << 52))
@@ -2733,7 +2740,7 @@ k_ancestors2(const FArgs av)
             const u32 a32[4] = {jb + (m0 > ex1 ? m0 : ex1), jb + (m1 > ex1 ? m1 : ex1),
                                 jb + (m2 > ex1 ? m2 : ex1), jb + (m3 > ex1 ? m3 : ex1)};
             if (n0 >= lo && n0 + 3u < hi) {                                             // core.py:329
-                if (a.nt) smc_st4g_nt(A + n0, a32);
+                if (a.nt & 8) smc_st4g_nt(A + n0, a32);
                 else smc_st4g(A + n0, a32);
             } else {
 #pragma unroll
@@ -2746,7 +2753,7 @@ k_ancestors2(const FArgs av)
             const u32 a32[4] = {jb + (k0 > ex2 ? k0 : ex2), jb + (k1 > ex2 ? k1 : ex2),
                                 jb + (k2 > ex2 ? k2 : ex2), jb + (k3 > ex2 ? k3 : ex2)};
             if (n0 + 3u < hi) {                    // (n0 >= lo: the second half starts 1024 past it)
-                if (a.nt) smc_st4g_nt(A + n0, a32);
+                if (a.nt & 8) smc_st4g_nt(A + n0, a32);
                 else smc_st4g(A + n0, a32);
             } else {
 #pragma unroll

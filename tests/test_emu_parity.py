@@ -148,7 +148,7 @@ def test_mv_philox_kalman():
 @pytest.mark.parametrize("case,model", [("gordon_boot", "gordon"), ("theta_boot", "theta"),
                                         ("cox_boot", "cox")])
 def test_nonlinear_models_philox(golden, case, model):
-    pc.check_model_philox_vs_oracle(golden, case, model, N=4000)
+    pc.check_model_philox_vs_oracle(golden, case, model, N=2000, runs=16)
 
 
 @pytest.mark.parametrize("case,N", [("toy_stratified", 1024), ("toy_stratified", 4096),
