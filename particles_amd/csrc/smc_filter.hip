@@ -553,6 +553,11 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
         const int want = (o->flags & SMC_PATH_WIDE4) ? 4 : 2;
         f->wide_tpw = (a.ntiles % want) == 0 ? want : ((a.ntiles % 2) == 0 ? 2 : 0);
     }
+    // (measured and kept out, round 4: the reduction MERGED into the resampling launch on grids beyond 2048 workgroups --
+    //  (a) every workgroup of k_ancestors2w reducing: C5 99.2 us per step (2 tiles per workgroup) / 117.2 (4) against 92.9
+    //  behind k_reduce2 (r12h); (b) workgroup 0 of k_ancestors2 reducing, the others waiting for its word with their
+    //  loads in flight and reading (G_b, Q_b) past their L2: C3 60.7 against 57.6 us, C5 159 against 99 -- a dependent
+    //  global round trip in every workgroup costs more than the launch it saves (r12j))
     // (SQMC: k_ancestors2 counts in SORTED positions; a heavy parent's blocks would be filled with that index)
     const bool heavy_list = !mv && !f->strict && !f->sqmc && !(o->flags & SMC_PATH_NO_HEAVY);
     // (history slots are written step by step: the lanes beyond N of a slot would read indices nobody
@@ -681,7 +686,8 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     // streaming stores pay while a launch is short (its end-of-kernel write-back shows): C2 +8 %;
     // on the large grids they cost 2 % (C5)
     a.nt = ((i64)a.ntiles * (i64)M <= F_DIRECT_PREFIX_MAX && !mv && !(o->flags & SMC_PATH_NO_NT)) ? 15 : 0;
-    if (a.nt && getenv("SMC_EXP_NT")) a.nt = atoi(getenv("SMC_EXP_NT"));          // (experiment: which arrays stream)
+    // (bits: 1 X, 2 lw, 4 the tile CDF, 8 A.  Measured at C2, r12f: any mask that streams lw -- written every step, read
+    //  only on the steps that do not resample -- is as fast as streaming everything, 17.63 us; none: 19.31)
     a.pm2 = a.ps2 = a.pss2 = nullptr;
     if (apf2) {
         a.pm2 = (double*)(base + oP2);

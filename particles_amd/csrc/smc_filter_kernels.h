@@ -1610,13 +1610,9 @@ __device__ __forceinline__ void f2_su(const FArgs& a, const int isl, const i64 t
         if (su.u) {
             su.u_sys = su.u[0];
         } else {
-#ifdef SMC_EXP_NOPHILOX                     /* (timing experiment: what the scalar Philox call costs the launch) */
-            su.u_sys = 0.37 + 1e-3 * (double)(su.t & 255u);
-#else
             u64 x0, x1;
             smc_philox(0u, su.t, su.island, SMC_STREAM_RESAMPLE, su.seed, x0, x1);
             su.u_sys = smc_u01_halfopen(x0);
-#endif
         }
     }
     Us = a.log2N >= 0 ? (u64)(su.u_sys * __longlong_as_double((long long)(1023 + F2_SBITS - a.log2N) << 52))
@@ -1716,6 +1712,24 @@ __device__ __forceinline__ i64 f2_ns_strat(const FArgs& a, const SmcSu& su, cons
     if (d > f.eps && d < f.one_m_eps) {
         if (!(fl < f.dN)) return (i64)f.dN;
         const double e = d - smc_strat_u(su, (u64)fl);
+        if (e > f.eps) return (i64)(u32)fl + 1;
+        if (e < -f.eps) return (i64)(u32)fl;
+    }
+    return f2_count<true>(a, su, Us, f.Gb + smc_muldiv_floor(c, f.Qb, f.tb));
+}
+// ... with the uniforms of the offspring nfirst, nfirst + 1, ... staged in LDS by the workgroup (k_ancestors2): every
+// floor(Y) of the tile lies inside the staged window (the caller checks the tile's share against its size)
+#define F2_SU_PAIRS 640                 /* staged pairs of stratified uniforms per tile: 1280 offspring, 1.25 x the average */
+__device__ __forceinline__ i64 f2_ns_strat_lds(const FArgs& a, const SmcSu& su, const u64 Us, const F2Fast& f, const u64 c,
+                                               const double* sU, const double nfirst)
+{
+    const double Y = fma((double)c, f.r, f.Gd);
+    const double fl = floor(Y);
+    const double d = Y - fl;
+    if (d > f.eps && d < f.one_m_eps) {
+        if (!(fl < f.dN)) return (i64)f.dN;
+        const int k = (int)(fl - nfirst);
+        const double e = d - sU[k];
         if (e > f.eps) return (i64)(u32)fl + 1;
         if (e < -f.eps) return (i64)(u32)fl;
     }
@@ -2645,10 +2659,47 @@ k_ancestors2(const FArgs av)
             f.dN = (double)N;
             f.eps = a.exact_counts ? 2.0 : f.dN * 0x1.0p-49;
             f.one_m_eps = 1.0 - f.eps;
+            // ---- the stratified uniforms of the tile's offspring, staged in LDS.  A parent at position Y of the
+            // offspring scale needs u_n for n = floor(Y): generated per parent that is one Philox call per boundary
+            // (5 per thread, each behind a divergent "same pair as before?" test -- 9.4 us of C3's 25.8 us launch
+            // against the systematic scheme's 16.4).  The tile's boundaries all lie in [floor(G_b down), that +
+            // Q_b down + 2]: the workgroup generates that window once -- F2_SU_PAIRS Philox calls for the tile,
+            // 2 or 3 per thread, each giving the pair (u_2p, u_2p+1) -- and a boundary READS its uniform.  The same
+            // counters, the same uniforms, the same counts.  Tiles whose window does not fit (a share beyond 1.24 x
+            // the average) and the tape mode keep the per-boundary calls.
+            __shared__ __attribute__((aligned(16))) double sU[2 * F2_SU_PAIRS];
+            const double nfirst = floor(f.Gd * 0.5) * 2.0;                 // first staged offspring (even)
+#ifdef SMC_NO_SU_STAGE                     /* (A/B builds: tools/build_ablations.sh) */
+            const bool stage = false;
+#else
+            const bool stage = !su.u && (Qd * down + 4.0 <= (double)(2 * F2_SU_PAIRS - 2)) && nfirst < f.dN;
+#endif
+            if (stage) {
+                const u32 p0 = (u32)(nfirst * 0.5);
 #pragma unroll
-            for (int i = 0; i <= F_IPT; ++i) {
-                const i64 j = jt + i;
-                ns[i] = (j == 0) ? 0 : (j >= N ? N : f2_ns_strat(a, su, Us, f, cx[i]));
+                for (int r = 0; r < (F2_SU_PAIRS + SMC_BLOCK - 1) / SMC_BLOCK; ++r) {
+                    const int q = tid + r * SMC_BLOCK;
+                    if (q < F2_SU_PAIRS) {                                 // (whole waves: F2_SU_PAIRS % 64 == 0)
+                        u64 xa, xb;
+                        smc_philox(p0 + (u32)q, su.t, su.island, SMC_STREAM_RESAMPLE, su.seed, xa, xb);
+                        double2 uu;
+                        uu.x = smc_u01_halfopen(xa);
+                        uu.y = smc_u01_halfopen(xb);
+                        *reinterpret_cast<double2*>(&sU[2 * q]) = uu;
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i <= F_IPT; ++i) {
+                    const i64 j = jt + i;
+                    ns[i] = (j == 0) ? 0 : (j >= N ? N : f2_ns_strat_lds(a, su, Us, f, cx[i], sU, nfirst));
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i <= F_IPT; ++i) {
+                    const i64 j = jt + i;
+                    ns[i] = (j == 0) ? 0 : (j >= N ? N : f2_ns_strat(a, su, Us, f, cx[i]));
+                }
             }
         } else {
             f2_first_offspring<POW2>(a, su, Us, cx, tb, Gb, Qb, jt, ns);

@@ -178,10 +178,40 @@ k_ancestors2w(const FArgs av)
         n_lo = (b == 0) ? 0 : f2_ns_sys<true>(a, su, Us, f, 0ull);
         n_hi = (b == a.ntiles - 1) ? N : f2_ns_sys<true>(a, su, Us, f, tb);
     } else {
+        // the stratified uniforms of each tile's offspring staged in LDS (k_ancestors2: F2_SU_PAIRS Philox calls per
+        // tile instead of one per boundary); every tile of the workgroup must fit its window -- the barrier is shared
+        __shared__ __attribute__((aligned(16))) double sU_all[TPW][2 * F2_SU_PAIRS];
+        double* sU = sU_all[st];
+        const double nfirst = floor(f.Gd * 0.5) * 2.0;                     // first staged offspring (even)
+        bool stage = !su.u;
 #pragma unroll
-        for (int i = 0; i <= F_IPT; ++i) {
-            const i64 j = jt + i;
-            ns[i] = (j == 0) ? 0 : (j >= N ? N : f2_ns_strat(a, su, Us, f, cx[i]));
+        for (int k = 0; k < TPW; ++k) stage = stage && (Qall[k] * down + 4.0 <= (double)(2 * F2_SU_PAIRS - 2));
+        if (stage) {
+            const u32 p0 = (u32)(nfirst * 0.5);
+#pragma unroll
+            for (int r = 0; r < (F2_SU_PAIRS + SMC_BLOCK - 1) / SMC_BLOCK; ++r) {
+                const int q = tid + r * SMC_BLOCK;
+                if (q < F2_SU_PAIRS && nfirst < f.dN) {
+                    u64 xa, xb;
+                    smc_philox(p0 + (u32)q, su.t, su.island, SMC_STREAM_RESAMPLE, su.seed, xa, xb);
+                    double2 uu;
+                    uu.x = smc_u01_halfopen(xa);
+                    uu.y = smc_u01_halfopen(xb);
+                    *reinterpret_cast<double2*>(&sU[2 * q]) = uu;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i <= F_IPT; ++i) {
+                const i64 j = jt + i;
+                ns[i] = (j == 0) ? 0 : (j >= N ? N : f2_ns_strat_lds(a, su, Us, f, cx[i], sU, nfirst));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i <= F_IPT; ++i) {
+                const i64 j = jt + i;
+                ns[i] = (j == 0) ? 0 : (j >= N ? N : f2_ns_strat(a, su, Us, f, cx[i]));
+            }
         }
         i64* s_n = s_n_all[st];
         if (tid == 0) s_n[0] = ns[0];

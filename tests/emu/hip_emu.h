@@ -295,6 +295,7 @@ inline unsigned int __brev(unsigned int v)
 inline void emu_wave_sync() { hipemu::wave_barrier(); }
 
 struct alignas(16) uint4 { unsigned x, y, z, w; };
+struct alignas(16) double2 { double x, y; };
 inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 
 inline unsigned __umulhi(unsigned a, unsigned b) {
