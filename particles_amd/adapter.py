@@ -19,6 +19,7 @@ same-named classes here; anything else (user subclasses, other models) is left a
 """
 import numpy as np
 
+from . import _lib
 from . import kalman
 from . import resampling as _rs
 from . import state_space_models as ssm
@@ -185,8 +186,7 @@ class DeviceSMC2Run:
             self.rs_flag = bool(stop)
             if stop:
                 a._resample_move()
-            if a.t >= T_keep:
-                a.logLt += a._log_mean(a.lw) - a._log_mean(a._lw_at_reset)
+            a._finalise()                      # (the last evidence term: once, whoever reaches t = T first)
         finally:
             a.sync_every = keep
 
@@ -229,6 +229,25 @@ def adapt_smc2(fk):
         fkc = ssm.GuidedPF
     else:
         return None
+    # the inner filters' options: the device class forwards `resampling` and `ESSrmin` and nothing else --
+    # anything more (qmc, store_history, collectors ...) belongs to the reference's own loop
+    if set(fk.smc_options or {}) - {"collect", "resampling", "ESSrmin"}:
+        return None
+    if (fk.smc_options or {}).get("collect") not in (None, "off"):
+        return None
+    # ... and the inner filters must be batchable as islands with per-island parameters: a univariate model of
+    # the fused family (a probe instance at the prior's first draw says which)
+    state = np.random.get_state()                  # (the probe must not cost the caller's seeded stream a draw)
+    try:
+        probe = fk.prior.rvs(size=1)
+        theta0 = {k: float(np.ravel(probe[k])[0]) for k in probe.dtype.names}
+        dm = fkc(ssm=ours(**theta0), data=fk.data)._device_model()
+    except Exception:
+        return None
+    finally:
+        np.random.set_state(state)
+    if dm is None or dm.get("kind") == _lib.MODEL_MVLINGAUSS:
+        return None
     return ours, fkc
 
 
@@ -252,7 +271,10 @@ def HipSMC():
                 if two is not None and not kw.get("qmc") and not kw.get("store_history") \
                         and kw.get("collect") in (None, "off") and not kw.get("verbose"):
                     kw2 = {k: v for k, v in kw.items() if k in ("N", "ESSrmin", "resampling", "seed")}
-                    return DeviceSMC2Run(fk, two[0], two[1], **kw2)
+                    try:
+                        return DeviceSMC2Run(fk, two[0], two[1], **kw2)
+                    except ValueError:                     # not batchable after all: the reference's loop runs it
+                        pass
                 mine = adapt(fk) if fk is not None else None
                 if mine is None or kw.get("qmc"):
                     return super().__new__(cls)            # the reference's own path

@@ -77,15 +77,18 @@ class _Star:
         # the launcher may itself be listening on MASTER_PORT (torchrun's store does): rank 0
         # binds a port of its own and publishes it in a file keyed by what all ranks of THIS
         # launch share -- MASTER_PORT and the launcher's pid
-        key = "smc_rdzv_%s_%s_%d" % (os.environ.get("MASTER_PORT", "0"),
-                                     os.environ.get("TORCHELASTIC_RUN_ID", "x"), os.getppid())
+        # (launchers that put a wrapper between themselves and the ranks -- `bash -c`, srun -- give every rank a
+        #  different parent: SMC_RDZV_KEY, exported to all ranks of ONE launch, replaces the parent's pid)
+        launch = os.environ.get("SMC_RDZV_KEY") or str(os.getppid())
+        key = "smc_rdzv_%s_%s_%s" % (os.environ.get("MASTER_PORT", "0"),
+                                     os.environ.get("TORCHELASTIC_RUN_ID", "x"), launch)
         self._keyfile = os.path.join(tempfile.gettempdir(), key)
         self.peers = []
         self.sock = None
-        # every rank of one launch shares this nonce: the key file of a crashed earlier launch (same
-        # MASTER_PORT and run id, e.g. torchrun's defaults) carries another one and is ignored
-        nonce = "%s_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "x"),
-                              os.getppid())
+        # rank 0 draws a RANDOM nonce per launch and publishes it with its port; the peers echo what they read.
+        # The key file of a crashed earlier launch (same name: same MASTER_PORT, run id and parent) carries another
+        # nonce and a dead port: a peer that reads it is refused (or rejected by the new rank 0) and reads again
+        nonce = None
         if rank == 0:
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
@@ -94,11 +97,22 @@ class _Star:
             srv.settimeout(timeout)
             # a stale file from a crashed launch goes first; the new one is created exclusively
             # (no following of a symlink somebody planted in the shared temp directory), mode 0600
-            try:
-                os.unlink(self._keyfile)
-            except OSError:
-                pass
-            fd = os.open(self._keyfile, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
+            import secrets
+            nonce = secrets.token_hex(12)
+            fd = None
+            for attempt in range(50):              # (somebody re-creating the name in between: try again)
+                try:
+                    os.unlink(self._keyfile)
+                except OSError:
+                    pass
+                try:
+                    fd = os.open(self._keyfile, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
+                    break
+                except FileExistsError:
+                    time.sleep(0.01)
+            if fd is None:
+                srv.close()
+                raise RuntimeError("rendezvous: cannot create %s (somebody keeps re-creating it)" % self._keyfile)
             with os.fdopen(fd, "w") as fh:
                 fh.write("%d %d %s\n" % (srv.getsockname()[1], os.getpid(), nonce))
             conns = {}
@@ -112,6 +126,7 @@ class _Star:
                             or not 0 < int(hello[0]) < world or int(hello[0]) in conns:
                         c.close()                      # not a rank of this launch
                         continue
+                    _send_msg(c, b"ok")
                     conns[int(hello[0])] = c
             except Exception:
                 for c in conns.values():
@@ -130,17 +145,24 @@ class _Star:
                 try:
                     with open(self._keyfile) as fh:
                         f = fh.read().split()
-                    if len(f) != 3 or f[2] != nonce or not f[0].isdigit() or not f[1].isdigit():
-                        raise ValueError("not this launch's key file")
+                    if len(f) != 3 or not f[0].isdigit() or not f[1].isdigit():
+                        raise ValueError("not a key file")
                     os.kill(int(f[1]), 0)              # the rank 0 that wrote it is alive (else: OSError)
+                    nonce = f[2]
                     s = socket.create_connection((addr, int(f[0])), timeout=timeout)
-                except (OSError, ValueError, IndexError):
+                    s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    _send_msg(s, ("%d %s" % (rank, nonce)).encode())
+                    s.settimeout(timeout)
+                    if _recv_msg(s) != b"ok":          # (a live process that is not this launch's rank 0)
+                        raise ValueError("rejected")
+                    s.settimeout(None)
+                except (OSError, ValueError, IndexError, ConnectionError):
+                    if s is not None:
+                        s.close()
                     s = None
                     if time.time() - t0 > timeout:
                         raise TimeoutError("rendezvous: rank 0 never published a live %s" % self._keyfile)
                     time.sleep(0.01)
-            s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-            _send_msg(s, ("%d %s" % (rank, nonce)).encode())
             self.sock = s
 
     def exchange(self, payload=b""):

@@ -144,6 +144,7 @@ class SMC2:
         self.names = list(self.theta)
         self.lw = np.zeros(self.N)
         self.logLt = 0.0                 # log evidence of the whole model (outer SMC, core.py:351-359)
+        self._finalised = False
         self.ESSs, self.Nxs, self.acc_rates, self.move_times = [], [self.Nx], [], []
         # per step, as the outer particles.SMC would collect them (collectors.py:278-295): the model's
         # log-evidence after step t, and whether a resample-move preceded step t
@@ -221,6 +222,12 @@ class SMC2:
         return m + np.log(np.mean(np.exp(lw - m)))
 
     # ------------------------------------------------------------------ the outer loop
+    def _finalise(self):
+        """The last evidence term, exactly once (run() on an exhausted sampler is a no-op, as the reference's)."""
+        if not self._finalised and self.t >= self.T:
+            self.logLt += self._log_mean(self.lw) - self._log_mean(self._lw_at_reset)
+            self._finalised = True
+
     def run(self):
         while self.t < self.T:
             k = min(self.sync_every, self.T - self.t)
@@ -237,7 +244,7 @@ class SMC2:
             self.pf._invalidate()
             if stop:
                 self._resample_move()
-        self.logLt += self._log_mean(self.lw) - self._log_mean(self._lw_at_reset)
+        self._finalise()
         return self
 
     def _resample_move(self):
@@ -269,7 +276,9 @@ class SMC2:
         self._lw_at_reset = np.zeros(self.N)
         # ---- PMCMC move (smc_samplers.py:1129-1143): candidates re-run from 0 to t
         lp_cur = np.asarray(self.prior.logpdf(self.theta), dtype=float) + self._evidences(self.pf)
-        acc_rate = 0.0
+        # the rate that drives the exchange step is the reference's: the MEAN ACCEPTANCE PROBABILITY of a step
+        # (smc_samplers.py:609 records mean(pb_acc)), averaged over the steps of the move (SMC2.logG)
+        pb_rates = []
         for sweep in range(self.nmcmc):
             Z = self.rng.standard_normal((self.N, d)) @ L.T
             prop = {k: self.theta[k] + Z[:, j] for j, k in enumerate(self.names)}
@@ -280,15 +289,17 @@ class SMC2:
             cand = self._batch(safe, self.Nx)
             cand.step_async(self.t)
             lp_prop = np.where(ok, lprior + self._evidences(cand), -np.inf)
+            lp_before = lp_cur
             acc = np.log(self.rng.random_sample(self.N)) < lp_prop - lp_cur
             acc &= ok
             self.pf.accept_islands_from(cand, acc[self._lo:self._hi])
             self.theta = {k: np.where(acc, prop[k], self.theta[k]) for k in self.names}
             lp_cur = np.where(acc, lp_prop, lp_cur)
-            acc_rate = float(np.mean(acc))
-            self.acc_rates.append(acc_rate)
+            with np.errstate(all="ignore"):
+                pb_rates.append(float(np.mean(np.where(ok, np.exp(np.minimum(lp_prop - lp_before, 0.0)), 0.0))))
+            self.acc_rates.append(float(np.mean(acc)))
             del cand
-        self._maybe_exchange(acc_rate)
+        self._maybe_exchange(float(np.mean(pb_rates)) if pb_rates else 1.0)
         self.Nxs.append(self.Nx)
         self.move_times.append(time.perf_counter() - t0)
 
@@ -304,7 +315,7 @@ class SMC2:
         cur.take_islands_from(self.pf, A)                               # the resampled filters themselves
         th = {k: v[A].copy() for k, v in self.theta.items()}
         lp = np.asarray(self.prior.logpdf(th), dtype=float) + ev_all[A]
-        states, thetas, ars = [cur], [th], []
+        states, thetas, ars, pbs = [cur], [th], [], []
         for k in range(1, P):
             Z = self.rng.standard_normal((M, d)) @ L.T
             prop = {n_: th[n_] + Z[:, j] for j, n_ in enumerate(self.names)}
@@ -315,6 +326,7 @@ class SMC2:
             cand = self._batch(safe, self.Nx, whole=True)
             cand.step_async(t)
             lp_prop = np.where(ok, lprior + cand.logLts_islands, -np.inf)
+            lp_old = lp
             acc = (np.log(self.rng.random_sample(M)) < lp_prop - lp) & ok
             nxt = self._batch(th, self.Nx, whole=True)                  # x = x.copy(): the chain's next state
             nxt.take_islands_from(states[-1], np.arange(M))
@@ -324,6 +336,8 @@ class SMC2:
             states.append(nxt)
             thetas.append(th)
             ars.append(float(np.mean(acc)))
+            with np.errstate(all="ignore"):
+                pbs.append(float(np.mean(np.where(ok, np.exp(np.minimum(lp_prop - lp_old, 0.0)), 0.0))))
             del cand
         self.acc_rates.extend(ars)
         # ---- the new population: all states of all chains, one batch of M P filters at time t
@@ -335,7 +349,7 @@ class SMC2:
         self.pf = new
         self.lw = np.zeros(self.N)
         self._lw_at_reset = np.zeros(self.N)
-        return float(np.mean(ars)) if ars else 1.0
+        return float(np.mean(pbs)) if pbs else 1.0      # mean acceptance PROBABILITY over the steps (smc_samplers.py:609)
 
     def _maybe_exchange(self, acc_rate):
         # ---- exchange step (smc_samplers.py:1159-1163): more state particles when moves get rejected

@@ -17,48 +17,59 @@ from . import distributions as dists
 from .core import FeynmanKac
 
 
+def _gauss(loc=0.0, scale=1.0):
+    return dists.Normal(loc=loc, scale=scale)
+
+
 class StateSpaceModel:
-    """Base class for state-space models (state_space_models.py:172-296)."""
+    """Base class for state-space models (state_space_models.py:172-296): parameters are
+    attributes (class-level ``default_params`` overridden by keyword arguments), the model is
+    the three laws ``PX0`` / ``PX`` / ``PY`` (+ ``proposal0`` / ``proposal`` / ``logeta`` for the
+    guided and auxiliary filters), each returning a ``ProbDist``."""
+
+    default_params = {}
 
     def __init__(self, **kwargs):
-        if hasattr(self, "default_params"):
-            self.__dict__.update(self.default_params)
-        self.__dict__.update(kwargs)
+        settings = dict(type(self).default_params)
+        settings.update(kwargs)
+        vars(self).update(settings)
 
-    def _error_msg(self, method):
-        return "method " + method + " not implemented in class%s" % self.__class__.__name__
+    def _undefined(self, what):
+        return NotImplementedError("%s does not define %s()" % (type(self).__name__, what))
 
     def PX0(self):
-        "Law of X_0 at time 0"
-        raise NotImplementedError(self._error_msg("PX0"))
+        """Law of X_0."""
+        raise self._undefined("PX0")
 
     def PX(self, t, xp):
-        "Law of X_t at time t, given X_{t-1} = xp"
-        raise NotImplementedError(self._error_msg("PX"))
+        """Law of X_t given X_{t-1} = xp."""
+        raise self._undefined("PX")
 
     def PY(self, t, xp, x):
-        """Conditional distribution of Y_t, given the states."""
-        raise NotImplementedError(self._error_msg("PY"))
+        """Law of Y_t given X_{t-1} = xp and X_t = x."""
+        raise self._undefined("PY")
 
     def proposal0(self, data):
-        raise NotImplementedError(self._error_msg("proposal0"))
+        raise self._undefined("proposal0")
 
     def proposal(self, t, xp, data):
-        raise NotImplementedError(self._error_msg("proposal"))
+        raise self._undefined("proposal")
 
     def simulate_given_x(self, x):
-        lag_x = [None] + x[:-1]
-        return [self.PY(t, xp, x).rvs(size=1) for t, (xp, x) in enumerate(zip(lag_x, x))]
+        """One observation per state of the path x (a list); the state before the first is None."""
+        previous = [None] + list(x[:-1])
+        return [self.PY(t, x_before, x_now).rvs(size=1)
+                for t, (x_before, x_now) in enumerate(zip(previous, x))]
 
     def simulate(self, T):
         """Simulate state and observation processes (state_space_models.py:278-296):
-        lists x, y of length T (draws come from the device Philox stream)."""
-        x = []
-        for t in range(T):
-            law_x = self.PX0() if t == 0 else self.PX(t, x[-1])
-            x.append(law_x.rvs(size=1))
-        y = self.simulate_given_x(x)
-        return x, y
+        lists x, y of length T -- the whole state path first, then the observations, which is
+        the order the reference consumes numpy's stream in."""
+        path = []
+        while len(path) < T:
+            law = self.PX(len(path), path[-1]) if path else self.PX0()
+            path.append(law.rvs(size=1))
+        return path, self.simulate_given_x(path)
 
     def _device_params(self, fk_kind):
         """(model kind, dx, dy, params (16,) or None, matrices) for the fused
@@ -67,37 +78,41 @@ class StateSpaceModel:
 
 
 class Bootstrap(FeynmanKac):
-    """Bootstrap Feynman-Kac formalism of a state-space model
-    (state_space_models.py:299-349)."""
+    """Bootstrap Feynman-Kac formalism of a state-space model (state_space_models.py:299-349):
+    particles move with the model's own transition -- ``_kernel`` -- and are weighted by the
+    observation density."""
 
     _fk_kind = _lib.FK_BOOTSTRAP
 
     def __init__(self, ssm=None, data=None):
-        self.ssm = ssm
-        self.data = data
-        self.du = self.ssm.PX0().dim
+        self.ssm, self.data = ssm, data
+        self.du = ssm.PX0().dim
 
     @property
     def T(self):
-        return 0 if self.data is None else len(self.data)
+        return len(self.data) if self.data is not None else 0
+
+    def _kernel(self, t, xp):
+        """The law the particles of step t are drawn from (xp None: step 0)."""
+        return self.ssm.PX0() if xp is None else self.ssm.PX(t, xp)
 
     def M0(self, N):
-        return self.ssm.PX0().rvs(size=N)
+        return self._kernel(0, None).rvs(size=N)
 
     def M(self, t, xp):
-        return self.ssm.PX(t, xp).rvs(size=xp.shape[0])
+        return self._kernel(t, xp).rvs(size=len(xp))
+
+    def Gamma0(self, u):                                   # state_space_models.py:335-340: the SQMC maps
+        return self._kernel(0, None).ppf(u)
+
+    def Gamma(self, t, xp, u):
+        return self._kernel(t, xp).ppf(u)
 
     def logG(self, t, xp, x):
         return self.ssm.PY(t, xp, x).logpdf(self.data[t])
 
-    def Gamma0(self, u):
-        return self.ssm.PX0().ppf(u)                       # state_space_models.py:335-336
-
-    def Gamma(self, t, xp, u):
-        return self.ssm.PX(t, xp).ppf(u)                   # :338-340
-
     def logpt(self, t, xp, x):
-        """PDF of X_t|X_{t-1}=xp"""
+        """log-density of X_t = x given X_{t-1} = xp."""
         return self.ssm.PX(t, xp).logpdf(x)
 
     def _device_model(self):
@@ -108,7 +123,7 @@ class Bootstrap(FeynmanKac):
         template-method path (the reference's normal way to customise a model)."""
         base = GuidedPF if isinstance(self, GuidedPF) else Bootstrap
         cls = type(self)
-        for name in ("M0", "M", "logG", "time_to_resample", "done"):
+        for name in ("M0", "M", "logG", "_kernel", "time_to_resample", "done"):
             if getattr(cls, name) is not getattr(base, name):
                 return None
         scls = type(self.ssm)
@@ -123,30 +138,19 @@ class Bootstrap(FeynmanKac):
 
 class GuidedPF(Bootstrap):
     """Guided filter for a state-space model with ``proposal0`` / ``proposal``
-    (state_space_models.py:352-398)."""
+    (state_space_models.py:352-398): particles move with the proposal and carry the
+    importance ratio transition x observation / proposal."""
 
     _fk_kind = _lib.FK_GUIDED
 
-    def M0(self, N):
-        return self.ssm.proposal0(self.data).rvs(size=N)
-
-    def M(self, t, xp):
-        return self.ssm.proposal(t, xp, self.data).rvs(size=xp.shape[0])
-
-    def Gamma0(self, u):
-        return self.ssm.proposal0(self.data).ppf(u)        # :394-395
-
-    def Gamma(self, t, xp, u):
-        return self.ssm.proposal(t, xp, self.data).ppf(u)  # :397-398
+    def _kernel(self, t, xp):
+        return self.ssm.proposal0(self.data) if xp is None else self.ssm.proposal(t, xp, self.data)
 
     def logG(self, t, xp, x):
-        if t == 0:
-            return (self.ssm.PX0().logpdf(x)
-                    + self.ssm.PY(0, xp, x).logpdf(self.data[0])
-                    - self.ssm.proposal0(self.data).logpdf(x))
-        return (self.ssm.PX(t, xp).logpdf(x)
-                + self.ssm.PY(t, xp, x).logpdf(self.data[t])
-                - self.ssm.proposal(t, xp, self.data).logpdf(x))
+        start = t == 0
+        moved = self.ssm.PX0() if start else self.ssm.PX(t, xp)
+        ratio = moved.logpdf(x) + self.ssm.PY(t, xp, x).logpdf(self.data[t])
+        return ratio - self._kernel(t, None if start else xp).logpdf(x)
 
 
 class APFMixin:
@@ -180,7 +184,21 @@ class AuxiliaryBootstrap(Bootstrap, APFMixin):
         return None
 
 
-class StochVol(StateSpaceModel):
+class _AR1State(StateSpaceModel):
+    """Shared by the models whose state is a Gaussian AR(1) around a level: the level / persistence /
+    innovation sd are named by ``_ar1 = (level, persistence, sd)`` (attribute names)."""
+    _ar1 = ("mu", "rho", "sigma")
+
+    def _ar1_values(self):
+        return tuple(getattr(self, name) for name in self._ar1)
+
+    def sig0(self):
+        """sd of the stationary law."""
+        _, persistence, sd = self._ar1_values()
+        return sd / np.sqrt(1.0 - persistence ** 2)
+
+
+class StochVol(_AR1State):
     r"""Univariate stochastic volatility model (state_space_models.py:446-473).
 
     X_0 ~ N(mu, sigma^2/(1-rho^2)); X_t = mu + rho (X_{t-1}-mu) + sigma U_t;
@@ -188,38 +206,39 @@ class StochVol(StateSpaceModel):
     """
     default_params = {"mu": -1.02, "rho": 0.9702, "sigma": 0.178}
 
-    def sig0(self):
-        return self.sigma / np.sqrt(1.0 - self.rho ** 2)
+    def EXt(self, xp):
+        """E[X_t | X_{t-1} = xp]"""
+        drift = (1.0 - self.rho) * self.mu
+        return drift + self.rho * xp
 
     def PX0(self):
-        return dists.Normal(loc=self.mu, scale=self.sig0())
-
-    def EXt(self, xp):
-        return (1.0 - self.rho) * self.mu + self.rho * xp
+        return _gauss(self.mu, self.sig0())
 
     def PX(self, t, xp):
-        return dists.Normal(loc=self.EXt(xp), scale=self.sigma)
+        return _gauss(self.EXt(xp), self.sigma)
 
     def PY(self, t, xp, x):
-        return dists.Normal(loc=0.0, scale=np.exp(0.5 * x))
+        return _gauss(0.0, np.exp(0.5 * x))
 
-    # Pitt & Shephard's proposal and auxiliary function (state_space_models.py:475-498)
-    def _xhat(self, xst, sig, yt):
-        return xst + 0.5 * sig ** 2 * (yt ** 2 * np.exp(-xst) - 1.0)
+    # ---- Pitt & Shephard's proposal and auxiliary function (state_space_models.py:475-498): a Gaussian
+    # centred at one Newton-like step from the predictive mean towards the mode of the observation term
+    def _xhat(self, centre, sd, y):
+        return centre + 0.5 * sd ** 2 * (y ** 2 * np.exp(-centre) - 1.0)
 
     def proposal0(self, data):
-        return dists.Normal(loc=self._xhat(0.0, self.sig0(), data[0]), scale=self.sig0())
+        sd = self.sig0()
+        return _gauss(self._xhat(0.0, sd, data[0]), sd)
 
     def proposal(self, t, xp, data):
-        return dists.Normal(loc=self._xhat(self.EXt(xp), self.sigma, data[t]), scale=self.sigma)
+        return _gauss(self._xhat(self.EXt(xp), self.sigma, data[t]), self.sigma)
 
     def logeta(self, t, x, data):
-        xst = self.EXt(x)
-        xstmmu = xst - self.mu
-        xhat = self._xhat(xst, self.sigma, data[t + 1])
-        xhatmmu = xhat - self.mu
-        return 0.5 / self.sigma ** 2 * (xhatmmu ** 2 - xstmmu ** 2) - 0.5 * data[
-            t + 1] ** 2 * np.exp(-xst) * (1.0 + xstmmu)
+        y_next = data[t + 1]
+        ahead = self.EXt(x)
+        d_ahead = ahead - self.mu
+        d_hat = self._xhat(ahead, self.sigma, y_next) - self.mu
+        quad = 0.5 / self.sigma ** 2 * (d_hat ** 2 - d_ahead ** 2)
+        return quad - 0.5 * y_next ** 2 * np.exp(-ahead) * (1.0 + d_ahead)
 
     def _device_params(self, fk_kind):
         p = np.zeros(_lib.PARAM_STRIDE)
@@ -237,12 +256,10 @@ class StochVolLeverage(StochVol):
     default_params = {"mu": -1.02, "rho": 0.9702, "sigma": 0.178, "phi": 0.0}
 
     def PY(self, t, xp, x):
-        if t == 0:
-            u = (x - self.mu) / self.sig0()
-        else:
-            u = (x - self.EXt(xp)) / self.sigma
-        std_x = np.exp(0.5 * x)
-        return dists.Normal(loc=std_x * self.phi * u, scale=std_x * np.sqrt(1.0 - self.phi ** 2))
+        # the standardised innovation of the state, then the conditional law of a correlated Gaussian
+        z = (x - self.mu) / self.sig0() if t == 0 else (x - self.EXt(xp)) / self.sigma
+        vol = np.exp(0.5 * x)
+        return _gauss(vol * self.phi * z, vol * np.sqrt(1.0 - self.phi ** 2))
 
     def _device_params(self, fk_kind):
         if fk_kind != _lib.FK_BOOTSTRAP:
@@ -261,39 +278,42 @@ class Gordon_etal(StateSpaceModel):
     """
     default_params = {"a": 0.05, "b": 0.5, "c": 25.0, "d": 8.0, "e": 1.2, "sigmaX": 3.162278}
 
+    def _forcing(self, t):
+        """The time-dependent term of the transition (host cos, as the device's aux tape holds it)."""
+        return self.d * np.cos(self.e * (t - 1))
+
     def PX0(self):
-        return dists.Normal(scale=2.0)
+        return _gauss(scale=2.0)
 
     def PX(self, t, xp):
-        return dists.Normal(loc=self.b * xp + self.c * xp / (1.0 + xp ** 2)
-                            + self.d * np.cos(self.e * (t - 1)), scale=self.sigmaX)
+        pulled = self.b * xp + self.c * xp / (1.0 + xp ** 2)
+        return _gauss(pulled + self._forcing(t), self.sigmaX)
 
     def PY(self, t, xp, x):
-        return dists.Normal(loc=self.a * x ** 2)
+        return _gauss(self.a * x ** 2)
 
     def _device_params(self, fk_kind):
         if fk_kind != _lib.FK_BOOTSTRAP:
             return None
         p = np.zeros(_lib.PARAM_STRIDE)
         p[[0, 1, 2, 3, 5]] = [self.b, self.sigmaX, self.c, 2.0, self.a]
-        # the time-dependent term, with the host's cos (as PX evaluates it)
-        aux = lambda T: self.d * np.cos(self.e * (np.arange(T) - 1))
-        return dict(kind=_lib.MODEL_GORDON, dx=1, dy=1, params=p, aux=aux)
+        return dict(kind=_lib.MODEL_GORDON, dx=1, dy=1, params=p, aux=lambda T: self._forcing(np.arange(T)))
 
 
-class DiscreteCox(StateSpaceModel):
+class DiscreteCox(_AR1State):
     r"""A discrete Cox model (state_space_models.py:611-630).
 
     Y_t | X_t = x ~ Poisson(e^x);  X_t = mu + phi (X_{t-1} - mu) + U_t, U_t ~ N(0, sigma^2);
     X_0 ~ N(mu, sigma^2 / (1 - phi^2)).
     """
     default_params = {"mu": 0.0, "sigma": 1.0, "phi": 0.95}
+    _ar1 = ("mu", "phi", "sigma")
 
     def PX0(self):
-        return dists.Normal(loc=self.mu, scale=self.sigma / np.sqrt(1.0 - self.phi ** 2))
+        return _gauss(self.mu, self.sig0())
 
     def PX(self, t, xp):
-        return dists.Normal(loc=self.mu + self.phi * (xp - self.mu), scale=self.sigma)
+        return _gauss(self.mu + self.phi * (xp - self.mu), self.sigma)
 
     def PY(self, t, xp, x):
         return dists.Poisson(rate=np.exp(x))
@@ -302,7 +322,7 @@ class DiscreteCox(StateSpaceModel):
         if fk_kind != _lib.FK_BOOTSTRAP:
             return None
         p = np.zeros(_lib.PARAM_STRIDE)
-        p[:4] = [self.mu, self.phi, self.sigma, self.sigma / np.sqrt(1.0 - self.phi ** 2)]
+        p[:4] = [self.mu, self.phi, self.sigma, self.sig0()]
 
         def aux(y):
             # the data-only term of scipy's poisson._logpmf; counts outside the support get
@@ -323,14 +343,14 @@ class ThetaLogistic(StateSpaceModel):
     default_params = {"tau0": 0.15, "tau1": 0.12, "tau2": 0.1, "sigmaX": 0.47, "sigmaY": 0.39}
 
     def PX0(self):
-        return dists.Normal(loc=0.0, scale=1.0)
+        return _gauss()
 
     def PX(self, t, xp):
-        return dists.Normal(loc=xp + self.tau0 - self.tau1 * np.exp(self.tau2 * xp),
-                            scale=self.sigmaX)
+        grown = xp + self.tau0                          # (the reference's association: (x + tau0) - tau1 exp(.))
+        return _gauss(grown - self.tau1 * np.exp(self.tau2 * xp), self.sigmaX)
 
     def PY(self, t, xp, x):
-        return dists.Normal(loc=x, scale=self.sigmaY)
+        return _gauss(x, self.sigmaY)
 
     def _device_params(self, fk_kind):
         if fk_kind != _lib.FK_BOOTSTRAP:

@@ -300,3 +300,49 @@ def test_reference_smc2_object_maps_onto_the_device_class(ref):
     class MyLG(rk.LinearGauss):
         pass
     assert adapter.adapt_smc2(ssp.SMC2(ssm_cls=MyLG, prior=prior, data=y, wastefree=False)) is None
+
+
+def test_device_smc2_finalises_once_and_declines_what_it_cannot_batch(ref):
+    """(a) The last evidence term is added exactly once: iterating to exhaustion and then calling run()
+    (or run() twice) leaves logLt where one run() puts it -- the reference's run() on an exhausted SMC
+    is a no-op.  (b) adapt_smc2 hands the reference's SMC2 to the device class only when the device class
+    honours everything asked for: inner-filter options beyond resampling / ESSrmin (qmc, store_history ..)
+    and model classes whose filters cannot be batched as islands with per-island parameters (the
+    multivariate ones) stay with the reference's own loop; (c) the probe draws nothing from the caller's
+    seeded numpy stream."""
+    from particles_amd import adapter
+    particles, rk, dists = ref["particles"], ref["kalman"], ref["dists"]
+    from particles import smc_samplers as ssp
+    np.random.seed(4)
+    x, y = rk.LinearGauss(sigmaX=1.0, sigmaY=0.4, rho=0.8).simulate(10)
+    prior = dists.StructDist({"rho": dists.Uniform(a=0.3, b=0.99), "sigmaY": dists.Gamma(a=2.0, b=4.0)})
+    HipSMC = adapter.HipSMC()
+    mk = lambda **kw: ssp.SMC2(ssm_cls=rk.LinearGauss, prior=prior, data=y, init_Nx=32, len_chain=3, wastefree=False, **kw)
+    one = HipSMC(fk=mk(), N=16, seed=3)
+    one.run()
+    ll = one.logLt
+    one.run()
+    assert one.logLt == ll
+    it = HipSMC(fk=mk(), N=16, seed=3)
+    for _ in it:
+        pass
+    assert it.logLt == ll
+    it.run()
+    assert it.logLt == ll and it.summaries.logLts[-1] == ll
+    # (b)
+    assert adapter.adapt_smc2(mk(smc_options={"resampling": "stratified", "ESSrmin": 0.7})) is not None
+    for opts in ({"qmc": True}, {"store_history": True}, {"collect": [particles.collectors.Moments()]}):
+        fk = mk(smc_options=opts)
+        assert adapter.adapt_smc2(fk) is None, opts
+        alg = HipSMC(fk=fk, N=8)
+        assert isinstance(alg, particles.SMC) and not isinstance(alg, adapter.DeviceSMC2Run)
+    prior_mv = dists.StructDist({"alpha": dists.Uniform(a=0.1, b=0.6)})
+    ymv = [np.zeros((1, 2)) for _ in range(4)]
+    fk_mv = ssp.SMC2(ssm_cls=rk.MVLinearGauss_Guarniero_etal, prior=prior_mv, data=ymv, init_Nx=16, wastefree=False)
+    assert adapter.adapt_smc2(fk_mv) is None
+    # (c)
+    np.random.seed(77)
+    adapter.adapt_smc2(mk())
+    after = np.random.rand()
+    np.random.seed(77)
+    assert np.random.rand() == after
