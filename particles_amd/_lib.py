@@ -55,7 +55,8 @@ PATH_FLAGS = {"SMC_FLAT_CDF": 1 << 8, "SMC_TWO_LEVEL_MID": 1 << 9, "SMC_EXACT_CO
               "SMC_FORCE_FUSED": 1 << 11, "SMC_FORCE_UNFUSED": 1 << 12, "SMC_NO_SMALL": 1 << 13,
               "SMC_NO_NT": 1 << 14, "SMC_NO_HEAVY": 1 << 15, "SMC_NO_TK": 1 << 16,
               "SMC_FLAT_MULTINOMIAL": 1 << 17, "SMC_POW2_ONLY": 1 << 18, "SMC_SPACING_3PASS": 1 << 19,
-              "SMC_SPLIT_REDUCE": 1 << 24, "SMC_SQ_GATHER": 1 << 29, "SMC_NO_WIDE": 1 << 30, "SMC_WIDE4": 1 << 7}
+              "SMC_SPLIT_REDUCE": 1 << 24, "SMC_SQ_GATHER": 1 << 29, "SMC_NO_WIDE": 1 << 30, "SMC_WIDE4": 1 << 7,
+              "SMC_STRICT_LITERAL": 1 << 6}
 
 
 def path_flags():
@@ -96,6 +97,7 @@ SIGNATURES = {
     "smc_wmean_var": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, P(c_dbl)]),
     "smc_inverse_cdf": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
     "smc_inverse_cdf_strict": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
+    "smc_seq_prefix_sums": (c_int, [c_vp, c_vp, c_i64, c_vp, c_int, P(c_i64)]),
     "smc_resample": (c_int, [c_vp, c_int, c_vp, c_i64, c_i64, c_vp, c_u64, c_vp]),
     "smc_uniform_spacings": (c_int, [c_vp, c_i64, c_u64, c_vp]),
     "smc_gather": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),

@@ -8,6 +8,7 @@
 #include "smc_filter_small.h"
 #include "smc_filter_sqmc.h"
 #include "smc_filter_wide.h"
+#include "smc_seqsum.h"
 
 // ---------------------------------------------------------------------------
 // host side
@@ -30,7 +31,8 @@ struct smc_filter {
                            // (k_propagate<.., RAGGED>)
     bool mv_collapsed;     // MVLINGAUSS guided: log G = log p(y_t | x_{t-1}) in one product (opts.flags)
     bool strict;           // SMC_FLAG_STRICT_ANCESTORS: sequential fp64 CDF of the filter's weights
-    double* strict_ws;     // (n_islands, N) W -> S
+    double* strict_ws;     // (n_islands, N) W | (n_islands, N) S | scratch of smc_seqsum.h
+    bool strict_literal;   // SMC_PATH_STRICT_LITERAL: S by the one-lane walk, in place
     // SMC_FLAG_SQMC (smc_filter_sqmc.h): the point stream, the tape of ndtri(second coordinate), the
     // sort's workspace and -- more than one island -- the islands' permutations
     u64 sp_epoch;          // launches of the merged spacings + reduction kernel so far (see FArgs::sp_epoch)
@@ -194,9 +196,18 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
                 SMC_LAUNCH(k_f_spacings_step, dim3(1), dim3(SMC_BLOCK), st, f->a, i, f->a.su + (size_t)i * f->a.N);
         const unsigned nb = (unsigned)((f->a.N + SMC_BLOCK - 1) / SMC_BLOCK);
         SMC_LAUNCH(k_strict_W, dim3(nb, f->a.n_islands), dim3(SMC_BLOCK), st, f->a, f->strict_ws);
-        SMC_LAUNCH(k_strict_cdf, dim3(1, f->a.n_islands), dim3(64), st, f->a, f->strict_ws);
+        // S = the reference's sequential fp64 prefix sums of W, every bit, computed in parallel (smc_seqsum.h); the
+        // literal one-lane walk (k_strict_cdf, 2.5 ms at N = 2^20) behind SMC_PATH_STRICT_LITERAL (A/B, tests)
+        double* S = f->strict_ws + (size_t)f->a.n_islands * f->a.N;
+        if (f->strict_literal) {
+            SMC_LAUNCH(k_strict_cdf, dim3(1, f->a.n_islands), dim3(64), st, f->a, f->strict_ws);
+            S = f->strict_ws;
+        } else {
+            seq_prefix_sums_launch(st, f->strict_ws, f->a.N, f->a.n_islands, S, (void*)(S + (size_t)f->a.n_islands * f->a.N),
+                                   SeqGate{f->a.info, INFO_STRIDE, f->a.T, nullptr}, false, false);
+        }
         SMC_LAUNCH(k_strict_search, dim3((unsigned)((f->a.N / 2 + SMC_BLOCK) / SMC_BLOCK), f->a.n_islands), dim3(SMC_BLOCK), st,
-                   f->a, (const double*)f->strict_ws, (const double*)f->a.su);
+                   f->a, (const double*)S, (const double*)f->a.su);
         if (k_prof >= 0 && (k_prof % 3)) (void)hipEventRecord(f->ev[3 * k_prof + 1], st);
         launch_propagate(f);
         if (k_prof >= 0) (void)hipEventRecord(f->ev[3 * k_prof + 2], st);
@@ -423,6 +434,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     f->th_send = f->th_recv = nullptr;
     f->mv_collapsed = mv && model->fk == SMC_FK_GUIDED && (o->flags & SMC_FLAG_COLLAPSED_PROPOSAL);
     f->strict = (o->flags & SMC_FLAG_STRICT_ANCESTORS) != 0;
+    f->strict_literal = (o->flags & SMC_PATH_STRICT_LITERAL) != 0;
     f->no_small = (o->flags & SMC_PATH_NO_SMALL) != 0;
     f->strict_ws = nullptr;
     f->sqmc = (o->flags & SMC_FLAG_SQMC) != 0;
@@ -616,7 +628,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     // (inside a replayed graph the argument block -- the epoch with it -- is frozen: separate launches there)
     f->sp_merge = a.sp_tpw && merge_fits && !o->use_graph && !(o->flags & SMC_PATH_SPLIT_REDUCE);
     const size_t oTmp = carve(N * dxm * 8);
-    const size_t oStrict = carve(f->strict ? M * N * 8 : 8);
+    const size_t oStrict = carve(f->strict ? 2 * M * N * 8 + seq_scratch_bytes((i64)N, (int)M) : 8);
     if (f->sqmc && !f->sq_flat && !f->two_level) {
         smc_set_error("SMC_FLAG_SQMC needs the two-level step");
         delete f;
@@ -702,6 +714,8 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     F_CREATE_CHECK(hipMemsetAsync(a.sdec, 0, M * 8, ctx->stream));
     f->tmp = (double*)(base + oTmp);
     f->strict_ws = (double*)(base + oStrict);
+    if (f->strict)         // (the exception counters of smc_seqsum.h: zero once, re-armed by its passes)
+        F_CREATE_CHECK(hipMemsetAsync(f->strict_ws + 2 * M * N, 0, seq_scratch_bytes((i64)N, (int)M), ctx->stream));
     if (apf_mv) {
         a.eta = (double*)(base + oEta);
         a.lwsv = a.eta + M * N;
@@ -1673,7 +1687,8 @@ int smc_filter_describe(smc_filter* f, char* out, size_t n)
         s = "k_rs_sort+k_sq_permute+k_reduce2+k_ancestors2+k_sq_compose+k_propagate";
         if (f->a.mom) s += "+k_f_moments_partials+k_f_moments_final";
     } else if (f->strict) {
-        s = std::string(f->two_level ? "k_reduce2+" : "") + "k_strict_W+k_strict_cdf+k_strict_search+k_propagate";
+        s = std::string(f->two_level ? "k_reduce2+" : "") + "k_strict_W+" + (f->strict_literal ? "k_strict_cdf" : "k_seq_elem") +
+            "+k_strict_search+k_propagate";
     } else {
         if (f->two_level_mid) s = "k_reduce2+k_ancestors2";
         else if (f->two_level) s = f->wide_tpw ? "k_ancestors2w" : "k_ancestors2";

@@ -10,6 +10,7 @@ compared at <= 1e-12 relative; log-evidence at <= 1e-9 relative (north star:
 1e-6).
 """
 import ctypes
+
 import os
 
 import numpy as np
@@ -18,6 +19,7 @@ import pytest
 import particles_amd as pa
 from oracle import smc_oracle as orc
 from particles_amd import _lib
+from particles_amd._lib import DeviceArray
 from particles_amd import distributions as dists
 from particles_amd import kalman
 from particles_amd import resampling as rs
@@ -930,7 +932,7 @@ def check_strict_ancestors(sizes=(3000, 4096), op_N=1 << 14, op_cases=12):
                             seed=11, store_history=True, strict_ancestors=True, collect="off",
                             replay=None if z is None else (z, u), n_islands=nisl)
                 pf.run()
-                assert "k_strict_cdf" in describe(pf)
+                assert "k_seq_elem" in describe(pf)         # (the sequential CDF by its parallel emulation, csrc/smc_seqsum.h)
                 summ = pf._summ()
                 for isl in range(nisl):
                     nres = 0
@@ -956,6 +958,73 @@ def check_strict_ancestors(sizes=(3000, 4096), op_N=1 << 14, op_cases=12):
                     assert nres >= 2, (N, scheme, nres)
     with pytest.raises(ValueError):
         pa.SMC(fk=ssm.AuxiliaryPF(ssm=ssm.StochVol(), data=y), N=500, strict_ancestors=True)
+
+
+def check_seq_prefix_sums(sizes=(5000, 1 << 14, 20001), monkeypatch=None):
+    """csrc/smc_seqsum.h: the reference's sequential fp64 prefix sums (resampling.py:506-508: s = W[0]; s += W[j])
+    computed in parallel must be THE SAME DOUBLES as the loop's, whatever the weights: the element-level pass (mode 0),
+    the tile walk it falls back to (mode 2) and the literal one-lane walk (mode 1) against a Python loop -- random,
+    uniform, skewed over 100 orders of magnitude, one particle holding all the mass (zeros around a power of two),
+    sparse, exactly summable, engineered rounding ties, subnormal-range and unnormalised weights.  And the filter's
+    strict mode gives the same run with the literal walk in place of the emulation."""
+    def seq(W, mode):
+        d = DeviceArray.from_numpy(np.ascontiguousarray(W))
+        S = DeviceArray((len(W),))
+        c = ctypes.c_int64(-9)
+        _lib.check(_lib.lib().smc_seq_prefix_sums(_lib.ctx().h, d.ptr, len(W), S.ptr, mode, ctypes.byref(c)))
+        return S.get(), c.value
+
+    def loop(W):
+        out = np.empty_like(W)
+        acc = W[0]
+        out[0] = acc
+        for j in range(1, len(W)):
+            acc = acc + W[j]
+            out[j] = acc
+        return out
+
+    rng = np.random.default_rng(1)
+    fast = 0
+    for N in sizes:
+        cases = {}
+        w = np.exp(3 * rng.standard_normal(N)); cases["lognormal"] = w / w.sum()
+        cases["uniform"] = np.full(N, 1.0 / N)
+        w = np.exp(40 * rng.standard_normal(N)); cases["very skewed"] = w / w.sum()
+        w = np.zeros(N); w[N // 3] = 1.0; cases["collapsed"] = w
+        w = rng.random(N); w[rng.random(N) < 0.3] = 0.0; cases["sparse"] = w / w.sum()
+        cases["dyadic"] = rng.integers(0, 2 ** 30 // N, size=N).astype(np.float64) / 2.0 ** 30
+        w = np.full(N, 2.0 ** -40); w[0] = 0.25; w[1::2] = 3 * 2.0 ** -55; cases["ties"] = w
+        cases["tiny"] = rng.random(N) * 1e-300
+        cases["unnormalised"] = rng.random(N) * 1e6
+        w = np.zeros(N); w[-1] = 0.5; cases["late mass"] = w
+        for name, W in cases.items():
+            want = loop(W).view(np.uint64)
+            a, fb = seq(W, 0)
+            assert np.array_equal(a.view(np.uint64), want), (N, name, "element pass", int((a.view(np.uint64) != want).sum()))
+            b, nx = seq(W, 2)
+            assert np.array_equal(b.view(np.uint64), want), (N, name, "tile walk", int((b.view(np.uint64) != want).sum()))
+            c, _ = seq(W, 1)
+            assert np.array_equal(c.view(np.uint64), want), (N, name, "literal")
+            assert fb in (0, -1) and 0 < nx <= (N + 1023) // 1024
+            fast += fb == 0
+            if name in ("lognormal", "uniform", "collapsed", "sparse", "dyadic", "late mass"):
+                assert fb == 0, (N, name)                        # these stay on the element-level pass
+            if name in ("very skewed", "ties") and N >= 16384:
+                assert fb == -1, (N, name)                       # more exceptions than the list holds: the tile walk
+    assert fast >= 6 * len(sizes)
+    if monkeypatch is not None:
+        y = [np.array([v]) for v in 0.4 * np.cumsum(np.random.RandomState(2).standard_normal(6))]
+        runs = {}
+        for name, env in (("emulated", {}), ("literal", {"SMC_STRICT_LITERAL": "1"})):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            pf = pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y), N=3000, ESSrmin=0.9, seed=11, strict_ancestors=True,
+                        collect="off", n_islands=2)
+            pf.run()
+            assert ("k_strict_cdf" in describe(pf)) == (name == "literal")
+            runs[name] = (np.array(pf.A), np.array(pf.X), pf.logLts_islands.copy())
+            monkeypatch.undo()
+        assert all(np.array_equal(p, q) for p, q in zip(runs["emulated"], runs["literal"]))
 
 
 def check_heavy_parents(monkeypatch, N=8192, T=12):

@@ -315,3 +315,7 @@ def test_rolling_history_on_device():
 
 def test_apf_and_guided_stochvol_fused(golden):
     pc.check_apf_fused(golden, apf2_cases=((2048, "systematic", 0.7), (2500, "multinomial", 0.7)))
+
+
+def test_sequential_prefix_sums_in_parallel(monkeypatch):
+    pc.check_seq_prefix_sums(sizes=(5000, 1 << 14), monkeypatch=monkeypatch)

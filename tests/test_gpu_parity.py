@@ -627,3 +627,9 @@ def test_sharded_smc2_over_rccl(tmp_path):
 def test_apf_and_guided_stochvol_fused(golden):
     pc.check_apf_fused(golden, apf2_cases=((2048, "systematic", 0.7), (4096, "stratified", 0.9),
                                          (4096, "multinomial", 0.7), (1 << 15, "systematic", 0.7), (30000, "stratified", 0.7)))
+
+
+@pytest.mark.gpu
+def test_sequential_prefix_sums_in_parallel(monkeypatch):
+    import parity_cases as pc
+    pc.check_seq_prefix_sums(sizes=(5000, 1 << 16, (1 << 18) + 77), monkeypatch=monkeypatch)
