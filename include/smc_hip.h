@@ -363,6 +363,7 @@ typedef struct smc_filter_opts {
 #define SMC_PATH_SPACING_3PASS   (1 << 19)  /* uniform_spacings in three passes instead of one */
 #define SMC_PATH_SPLIT_REDUCE     (1 << 24)  /* multinomial, one-pass spacings: k_reduce2 as a launch of its own */
 #define SMC_PATH_NO_WIDE          (1 << 30)  /* resident two-level step: k_ancestors2 (one tile per workgroup) instead of k_ancestors2w */
+#define SMC_PATH_NO_XCD_CHUNKS    (1 << 5)   /* two-level step: tile = workgroup index instead of contiguous runs of tiles per XCD */
 #define SMC_PATH_STRICT_LITERAL   (1 << 6)   /* SMC_FLAG_STRICT_ANCESTORS: the sequential CDF by the literal one-lane walk, not its parallel emulation */
 #define SMC_PATH_WIDE4            (1 << 7)   /* k_ancestors2w with 4 tiles per workgroup instead of 2 */
 #define SMC_PATH_SQ_GATHER        (1 << 29)  /* SMC_FLAG_SQMC: gather the sorted log-weights where they could be recomputed */

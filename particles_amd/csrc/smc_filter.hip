@@ -565,6 +565,9 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
         const int want = (o->flags & SMC_PATH_WIDE4) ? 4 : 2;
         f->wide_tpw = (a.ntiles % want) == 0 ? want : ((a.ntiles % 2) == 0 ? 2 : 0);
     }
+    // consecutive tiles on one XCD (f_tile_xcd): grids of whole multiples of 8 x (tiles per workgroup of the resampling launch)
+    a.xcd_chunks = (f->two_level && !mv && !f->strict && !f->sqmc && !(o->flags & SMC_PATH_NO_XCD_CHUNKS) &&
+                    a.ntiles % (8 * (f->wide_tpw ? f->wide_tpw : 1)) == 0) ? 1 : 0;
     // (measured and kept out, round 4: the reduction MERGED into the resampling launch on grids beyond 2048 workgroups --
     //  (a) every workgroup of k_ancestors2w reducing: C5 99.2 us per step (2 tiles per workgroup) / 117.2 (4) against 92.9
     //  behind k_reduce2 (r12h); (b) workgroup 0 of k_ancestors2 reducing, the others waiting for its word with their
@@ -698,6 +701,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     // streaming stores pay while a launch is short (its end-of-kernel write-back shows): C2 +8 %;
     // on the large grids they cost 2 % (C5)
     a.nt = ((i64)a.ntiles * (i64)M <= F_DIRECT_PREFIX_MAX && !mv && !(o->flags & SMC_PATH_NO_NT)) ? 15 : 0;
+    if (a.nt && getenv("SMC_EXP_NT")) a.nt = atoi(getenv("SMC_EXP_NT"));
     // (bits: 1 X, 2 lw, 4 the tile CDF, 8 A.  Measured at C2, r12f: any mask that streams lw -- written every step, read
     //  only on the steps that do not resample -- is as fast as streaming everything, 17.63 us; none: 19.31)
     a.pm2 = a.ps2 = a.pss2 = nullptr;

@@ -130,7 +130,17 @@ struct FArgs {
     u64 sp_epoch;          // (n_islands) decision words, (epoch << 2) | 2 resample, | 1 not; epoch: unique per launch
     double *eta, *lwsv;    // APF of MVLINGAUSS (smc_filter_mv.h k_mv_aux): (n_islands, N) logeta of the step's
                            // parents and their plain log-weights, set aside while lw + eta drives the resampling
+    int xcd_chunks;        // two-level step: workgroup -> tile map that keeps CONSECUTIVE tiles on one XCD (f_tile_xcd)
 };
+// Workgroups go round the 8 XCDs (each with its own L2): with tile = workgroup index, neighbouring tiles sit on
+// different XCDs -- but a tile's offspring start in the tile next door as soon as the weights drift, and their parents'
+// states were written there: k_propagate then reads A and gathers X through another XCD's L2.  With the map below
+// XCD x owns the tiles x ntiles/8 .. (x+1) ntiles/8 - 1: neighbours share an L2 (C2: r12v A/B).  Any bijection is
+// correct -- a workgroup just processes the tile the map gives it.
+__device__ __forceinline__ int f_tile_xcd(const FArgs& a, const int bx)
+{
+    return a.xcd_chunks ? (bx & 7) * (a.ntiles >> 3) + (bx >> 3) : bx;
+}
 
 __host__ __device__ __forceinline__ i64 f_slot(const FArgs& a, i64 t)
 {
@@ -1271,7 +1281,7 @@ k_propagate(const FArgs av)
     __shared__ double smd[SMC_SM];
     __shared__ int s_last;
     SMC_NTAB_LDS(s_ntab);
-    const int b = (int)blockIdx.x, isl = (int)blockIdx.y;
+    const int b = f_tile_xcd(av, (int)blockIdx.x), isl = (int)blockIdx.y;
     const int tid = (int)threadIdx.x;
     F_STAMP(0);
     double* info = a.info + (i64)isl * INFO_STRIDE;
@@ -2267,7 +2277,7 @@ k_ancestors2(const FArgs av)
     __shared__ double s_sum[2 * SMC_NWAVE];
     __shared__ double s_g[SMC_NWAVE + 1];
     __shared__ u32 s_mx[2 * SMC_NWAVE];
-    const int b = (int)blockIdx.x, isl = (int)blockIdx.y;
+    const int b = f_tile_xcd(av, (int)blockIdx.x), isl = (int)blockIdx.y;
     const int tid = (int)threadIdx.x;
     const int lane = smc_lane(), wave = smc_wave();
     const i64 N = a.N;

@@ -48,8 +48,10 @@ k_ancestors2w(const FArgs av)
     // one tile per workgroup, profiles/r12c)
     const bool xcd_map = (a.ntiles % (8 * TPW)) == 0;
     const int bx = (int)blockIdx.x;
-    const int b_first = xcd_map ? (bx / 8) * (8 * TPW) + (bx % 8) : bx * TPW;
-    const int b_step = xcd_map ? 8 : 1;
+    // (a.xcd_chunks -- f_tile_xcd: XCD x owns a contiguous run of tiles -- : TPW consecutive tiles of this XCD's run)
+    const int b_first = a.xcd_chunks ? (bx & 7) * (a.ntiles >> 3) + (bx >> 3) * TPW
+                                     : (xcd_map ? (bx / 8) * (8 * TPW) + (bx % 8) : bx * TPW);
+    const int b_step = a.xcd_chunks ? 1 : (xcd_map ? 8 : 1);
     const int b = b_first + st * b_step, isl = (int)blockIdx.y;
     const bool red = st == 0;                                              // the reducing waves
     u32* sP = sP_all[st];
