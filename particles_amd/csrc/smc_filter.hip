@@ -701,9 +701,9 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     // streaming stores pay while a launch is short (its end-of-kernel write-back shows): C2 +8 %;
     // on the large grids they cost 2 % (C5)
     a.nt = ((i64)a.ntiles * (i64)M <= F_DIRECT_PREFIX_MAX && !mv && !(o->flags & SMC_PATH_NO_NT)) ? 15 : 0;
-    if (a.nt && getenv("SMC_EXP_NT")) a.nt = atoi(getenv("SMC_EXP_NT"));
     // (bits: 1 X, 2 lw, 4 the tile CDF, 8 A.  Measured at C2, r12f: any mask that streams lw -- written every step, read
-    //  only on the steps that do not resample -- is as fast as streaming everything, 17.63 us; none: 19.31)
+    //  only on the steps that do not resample -- is as fast as streaming everything, 17.63 us; none: 19.31.  With
+    //  consecutive tiles per XCD, r12w: 15: 17.4, X plain 17.5, X and the tile CDF plain 18.0, lw only 18.3)
     a.pm2 = a.ps2 = a.pss2 = nullptr;
     if (apf2) {
         a.pm2 = (double*)(base + oP2);

@@ -417,7 +417,6 @@ k_seq_elem_chain(const double* W, const i64 n, const int ntiles, const u64* Rt, 
 {
     __shared__ u64 smu[SMC_SM];
     __shared__ SeqX sx[SEQ_XCAP];
-    __shared__ u64 s_carry;
     const int isl = (int)blockIdx.x, tid = (int)threadIdx.x;
     if (!seq_gate_open(gate, isl)) return;
     double* So = S + (i64)isl * n;
@@ -467,7 +466,6 @@ k_seq_elem_chain(const double* W, const i64 n, const int ntiles, const u64* Rt, 
     if (tid == 0) {
         double s = 0.0;
         u64 Pprev = 0ull;
-        i64 jprev = -1;
         bool ok = true;                                        // (s = 0 + W[0] = W[0] starts the chain, resampling.py:506)
         for (int i = 0; ok && i < (int)cnt; ++i) {
             const i64 j = sx[i].j;
@@ -483,7 +481,6 @@ k_seq_elem_chain(const double* W, const i64 n, const int ntiles, const u64* Rt, 
             sx[i].S = s;
             So[j] = s;
             Pprev = sx[i].P;
-            jprev = j;
         }
         if (!ok) need_fallback[isl] = 1u;
     }
