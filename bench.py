@@ -241,6 +241,12 @@ def cpu_baseline(N, nsteps, all_cores=True, kind=None):
            "sample": sample, "seconds": one["seconds"], "logLt": one["logLt"][0],
            "host": {"nproc": nproc, "cpu": _cpu_name()},
            "reference_build_container": committed}
+    if kind == "port":
+        # (so that nobody reads the port's figure as the reference's: the restatement has none of scipy.stats'
+        #  per-call overhead and is several times FASTER than nchopin/particles itself on the same core)
+        out["note"] = ("kind 'port' = the oracle's NumPy restatement of particles.SMC (the reference tree does not exist on "
+                       "this box); it is faster than the reference itself -- the reference's own figures, timed in the "
+                       "build container, are under reference_build_container")
     if all_cores and nproc > 1:
         # independent runs over worker processes: what multiSMC(nruns, nprocs=nproc) does (core.py:431,
         # utils.py:158-186): runs of N = 2^18 (BASELINE.md section 3's shape), at least 16 in all and at

@@ -262,6 +262,8 @@ enum smc_model_kind {
 enum smc_fk_kind {
     SMC_FK_BOOTSTRAP = 0,     /* state_space_models.py:299-349 */
     SMC_FK_GUIDED = 1,        /* state_space_models.py:352-398 (model's own proposal) */
+    SMC_FK_APF_BOOT = 3,      /* state_space_models.py:431-438 AuxiliaryBootstrap: the BOOTSTRAP step (proposal = the
+                               * transition) + the auxiliary weights of SMC_FK_APF; STOCHVOL, LINGAUSS; same limits */
     SMC_FK_APF = 2            /* state_space_models.py:406-428 auxiliary PF: the guided step + the
                                * auxiliary weights of core.py:299-313 (resampling on lw + logeta,
                                * weights reset to log_mean_exp(logeta, W) - logeta[A]); STOCHVOL

@@ -778,6 +778,8 @@ def propagate(model, fk, t, yt, Xp, z, ctx):
     core.py:315-324 with Bootstrap / GuidedPF (state_space_models.py:326-333, :374-392).
     Returns (X_t, weight increment).  ``run_filter`` iterates it; the parity tests also call it
     step by step on the device's own X_{t-1}[A_t] (teacher forcing)."""
+    if fk == "apfboot":
+        fk = "bootstrap"                                       # AuxiliaryBootstrap(Bootstrap): the bootstrap move and logG
     if ctx.mv:
         if fk == "apf":
             fk = "guided"                                      # AuxiliaryPF(GuidedPF): the same move and logG
@@ -859,7 +861,7 @@ def run_filter(model, data, N, scheme="systematic", ESSrmin=0.5, fk="bootstrap",
         # ---- generate_particles / resample_move      core.py:315-337
         if t > 0:
             aux = wgts
-            if fk == "apf":                               # core.py:307-313 setup_auxiliary_weights
+            if fk in ("apf", "apfboot"):                  # core.py:307-313 setup_auxiliary_weights
                 logetat = model.logeta(X, np.asarray(data[t]) if ctx.mv else np.asarray(data[t]).reshape(-1)[0])
                 aux = wgts.add(logetat)
             ess = aux.ESS
@@ -876,7 +878,7 @@ def run_filter(model, data, N, scheme="systematic", ESSrmin=0.5, fk="bootstrap",
                 else:
                     A = inverse_cdf_q62(su, aux.W)
                 Xp = X[A]                                 # core.py:332
-                if fk == "apf":                           # core.py:299-305 reset_weights
+                if fk in ("apf", "apfboot"):              # core.py:299-305 reset_weights
                     wgts = Weights(lw=log_mean_exp(logetat, W=wgts.W) - logetat[A])
                 else:
                     wgts = Weights()

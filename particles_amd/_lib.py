@@ -23,7 +23,7 @@ SCHEMES = {"multinomial": MULTINOMIAL, "stratified": STRATIFIED, "systematic": S
 MODEL_LINGAUSS, MODEL_STOCHVOL, MODEL_MVLINGAUSS, MODEL_GORDON, MODEL_THETALOGISTIC = 1, 2, 3, 4, 5
 MODEL_SVLEVERAGE = 6
 MODEL_DISCRETECOX = 7
-FK_BOOTSTRAP, FK_GUIDED, FK_APF = 0, 1, 2
+FK_BOOTSTRAP, FK_GUIDED, FK_APF, FK_APF_BOOT = 0, 1, 2, 3
 FIELD_X, FIELD_XP, FIELD_A, FIELD_LW, FIELD_W = range(5)
 SUMMARY_COLS = 5
 PARAM_STRIDE = 16

@@ -212,7 +212,7 @@ class SMC:
     def _apf_fusable(fk, N, resampling, replay, store_history, device_moments):
         """Fused APF: the one-launch filter (N <= 1024; no Philox multinomial there) or the two-level
         step (N > 1024; no rolling window); stock StochVol only, no device-side moments."""
-        stock = getattr(fk, "_fk_kind", None) == _lib.FK_APF
+        stock = getattr(fk, "_fk_kind", None) in (_lib.FK_APF, _lib.FK_APF_BOOT)
         model = fk._device_model() if hasattr(fk, "_device_model") else None
         if stock and model is not None and model["kind"] == _lib.MODEL_MVLINGAUSS:
             # MVLinearGauss: k_mv_aux in front of the flat step, any N; no history slots, no device moments
@@ -241,7 +241,7 @@ class SMC:
         and for ``multiSMC``'s decision to batch runs as islands.)"""
         if fk is None or resampling not in _lib.SCHEMES:
             return False
-        if fk.isAPF and getattr(fk, "_fk_kind", None) != _lib.FK_APF:
+        if fk.isAPF and getattr(fk, "_fk_kind", None) not in (_lib.FK_APF, _lib.FK_APF_BOOT):
             return False
         if model is False:
             model = fk._device_model() if hasattr(fk, "_device_model") else None

@@ -119,6 +119,8 @@ static void launch_propagate(smc_filter* f)
     P_CASE(SMC_MODEL_STOCHVOL, SMC_FK_GUIDED)
     P_CASE(SMC_MODEL_STOCHVOL, SMC_FK_APF)              // (tail-free two-level launches only: create checks)
     P_CASE(SMC_MODEL_LINGAUSS, SMC_FK_APF)
+    P_CASE(SMC_MODEL_STOCHVOL, SMC_FK_APF_BOOT)
+    P_CASE(SMC_MODEL_LINGAUSS, SMC_FK_APF_BOOT)
     P_CASE(SMC_MODEL_GORDON, SMC_FK_BOOTSTRAP)
     P_CASE(SMC_MODEL_THETALOGISTIC, SMC_FK_BOOTSTRAP)
     P_CASE(SMC_MODEL_SVLEVERAGE, SMC_FK_BOOTSTRAP)
@@ -377,8 +379,10 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     SMC_REQUIRE(model->fk == SMC_FK_BOOTSTRAP ||
                     (model->fk == SMC_FK_GUIDED &&
                      (model->kind == SMC_MODEL_LINGAUSS || model->kind == SMC_MODEL_STOCHVOL || mv)) ||
-                    (model->fk == SMC_FK_APF && (model->kind == SMC_MODEL_STOCHVOL || model->kind == SMC_MODEL_LINGAUSS || mv)),
-                "guided filter: LINGAUSS, STOCHVOL, MVLINGAUSS; auxiliary filter: STOCHVOL, LINGAUSS, MVLINGAUSS");
+                    (model->fk == SMC_FK_APF && (model->kind == SMC_MODEL_STOCHVOL || model->kind == SMC_MODEL_LINGAUSS || mv)) ||
+                    (model->fk == SMC_FK_APF_BOOT && (model->kind == SMC_MODEL_STOCHVOL || model->kind == SMC_MODEL_LINGAUSS)),
+                "guided filter: LINGAUSS, STOCHVOL, MVLINGAUSS; auxiliary filter: STOCHVOL, LINGAUSS, MVLINGAUSS; "
+                "auxiliary bootstrap filter: STOCHVOL, LINGAUSS");
     {
         const bool big = o->N > F_TILE && o->N <= ((int64_t)1 << 30);
         if (mv && model->fk == SMC_FK_APF && (o->moments || o->keep_history)) {
@@ -386,7 +390,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
                           "weights take the place of the previous step's while it resamples)");
             return SMC_ERR_INVALID;
         }
-        if (!mv && model->fk == SMC_FK_APF && (o->moments || (o->N > F_TILE && !big) || o->keep_history >= 2)) {
+        if (!mv && f_is_apf(model->fk) && (o->moments || (o->N > F_TILE && !big) || o->keep_history >= 2)) {
             smc_set_error("the auxiliary particle filter is fused for N <= 1024 (the one-launch filter) and for "
                           "1024 < N <= 2^30 (the two-level step); no moments, no rolling window");
             return SMC_ERR_INVALID;
@@ -465,7 +469,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
         }
     }
     const int scheme = f->sqmc ? (int)SMC_MULTINOMIAL : (int)o->scheme;     // (sorted uniforms from a tape)
-    if (f->strict && (mv || model->fk == SMC_FK_APF || o->N >= ((i64)1 << 32))) {
+    if (f->strict && (mv || f_is_apf(model->fk) || o->N >= ((i64)1 << 32))) {
         smc_set_error("SMC_FLAG_STRICT_ANCESTORS: univariate Bootstrap / Guided filters");
         delete f;
         return SMC_ERR_INVALID;
@@ -544,13 +548,13 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     // (multinomial: the counts are searches over the sorted uniforms -- the tape's, or the exponential
     //  spacings drawn between k_reduce2, which decides the step, and k_ancestors2)
     // (any N >= 2 tiles: N = 2^k counts in closed form with integers, other N with the general counts)
-    f->two_level = !mv && !(o->moments && model->fk == SMC_FK_APF) && o->N <= ((int64_t)1 << 30) && a.ntiles >= 2 &&
+    f->two_level = !mv && !(o->moments && f_is_apf(model->fk)) && o->N <= ((int64_t)1 << 30) && a.ntiles >= 2 &&
                    !(a.log2N < 0 && (o->flags & SMC_PATH_POW2_ONLY)) &&
                    !(o->flags & (SMC_PATH_FLAT_CDF | SMC_PATH_FORCE_FUSED | SMC_PATH_FORCE_UNFUSED)) &&
                    !(scheme == SMC_MULTINOMIAL && (o->flags & SMC_PATH_FLAT_MULTINOMIAL));
     // every workgroup reduces the partials itself while the launch is resident and an island has
     // at most 1024 tiles (4 per thread); otherwise one workgroup per island does it first
-    const bool apf2 = !mv && model->fk == SMC_FK_APF && o->N > F_TILE;      // APF on the two-level step: k_reduce2
+    const bool apf2 = !mv && f_is_apf(model->fk) && o->N > F_TILE;      // APF on the two-level step: k_reduce2
     if (apf2 && !f->two_level) {                                      // forms its two reductions
         smc_set_error("the auxiliary particle filter beyond N = 1024 runs on the two-level step only");
         delete f;
@@ -951,6 +955,8 @@ static void launch_small(smc_filter* f, int nsteps)
     S_CASE(SMC_MODEL_STOCHVOL, SMC_FK_GUIDED)
     S_CASE(SMC_MODEL_STOCHVOL, SMC_FK_APF)
     S_CASE(SMC_MODEL_LINGAUSS, SMC_FK_APF)
+    S_CASE(SMC_MODEL_STOCHVOL, SMC_FK_APF_BOOT)
+    S_CASE(SMC_MODEL_LINGAUSS, SMC_FK_APF_BOOT)
     S_CASE(SMC_MODEL_GORDON, SMC_FK_BOOTSTRAP)
     S_CASE(SMC_MODEL_THETALOGISTIC, SMC_FK_BOOTSTRAP)
     S_CASE(SMC_MODEL_SVLEVERAGE, SMC_FK_BOOTSTRAP)
@@ -967,7 +973,7 @@ int smc_filter_step(smc_filter* f, int64_t nsteps)
     i64 todo = nsteps;
     if (f->t_host + todo > f->a.T) todo = f->a.T - f->t_host;
     if (todo < 0) todo = 0;
-    if (todo > 0 && f->fk == SMC_FK_APF && f->kind != SMC_MODEL_MVLINGAUSS && !small_filter_ok(f) && !f->a.pm2) {
+    if (todo > 0 && f_is_apf(f->fk) && f->kind != SMC_MODEL_MVLINGAUSS && !small_filter_ok(f) && !f->a.pm2) {
         smc_set_error("the auxiliary particle filter with N <= 1024 runs on the one-launch filter only (no "
                       "profiling, no Philox multinomial)");
         return SMC_ERR_STATE;
@@ -1203,7 +1209,7 @@ int smc_filter_set_state(smc_filter* f, int island, const double* X_host, const 
         smc_set_error("smc_filter_set_state: log-weights of a multivariate filter cannot be replaced");
         return SMC_ERR_STATE;
     }
-    if (f->fk == SMC_FK_APF) {
+    if (f_is_apf(f->fk)) {
         // the next step of an auxiliary filter resamples on lw + logeta(X) and resets the weights to a
         // constant formed from both (core.py:299-313): replacing X or lw alone would leave the record's
         // auxiliary normalisation and reset constant stale (one-launch filter and two-level step alike)

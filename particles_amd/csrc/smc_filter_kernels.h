@@ -289,12 +289,15 @@ __device__ __forceinline__ double m_logeta(const double* p, double x, double y)
     return m_sv_logeta(p, x, y);
 }
 
+// auxiliary filters: AuxiliaryPF (guided move) and AuxiliaryBootstrap (bootstrap move) share the auxiliary weights
+__host__ __device__ constexpr bool f_is_apf(const int fk) { return fk == SMC_FK_APF || fk == SMC_FK_APF_BOOT; }
+__host__ __device__ constexpr bool f_boot_move(const int fk) { return fk == SMC_FK_BOOTSTRAP || fk == SMC_FK_APF_BOOT; }
 // one particle of one step: returns the new state, writes the weight increment
 template <int KIND, int FK>
 __device__ __forceinline__ double m_step(const double* p, bool first, double y, double aux,
                                          double xp, double z, double& inc)
 {
-    if (KIND == SMC_MODEL_STOCHVOL && FK != SMC_FK_BOOTSTRAP) {
+    if (KIND == SMC_MODEL_STOCHVOL && !f_boot_move(FK)) {
         // GuidedPF / AuxiliaryPF of StochVol (state_space_models.py:374-392 with :481-489)
         const double xst = first ? 0.0 : p[4] + p[1] * xp;             // proposal0 centres _xhat at 0 (:483)
         const double sc = first ? p[3] : p[2], rsc = first ? p[16 + 3] : p[16 + 2];
@@ -306,7 +309,7 @@ __device__ __forceinline__ double m_step(const double* p, bool first, double y, 
               - m_norm_logpdf(x, xhat, sc, rsc, lsc);
         return x;
     }
-    if (FK == SMC_FK_BOOTSTRAP) {
+    if (f_boot_move(FK)) {
         const double x = first ? m_init_loc<KIND>(p) + p[3] * z
                                : m_trans_loc<KIND>(p, xp, aux) + m_trans_scale<KIND>(p) * z;
         inc = m_obs_logpdf<KIND>(p, y, x, xp, first, aux);
@@ -1291,7 +1294,7 @@ k_propagate(const FArgs av)
     const bool full_st = (TAIL || RAGGED) ? own.full : true;     // stores
     const double r0 = smc_ldg(info), r1 = smc_ldg(info + 1), r2 = smc_ldg(info + 2),
                  r5 = smc_ldg(info + 5);
-    constexpr bool APF = FK == SMC_FK_APF;         // (tail-free two-level path only: see the tail)
+    constexpr bool APF = f_is_apf(FK);             // (tail-free two-level path only: see the tail)
     const double r6 = APF ? smc_ldg(info + 6) : 0.0;
     unsigned nh0 = 0u, nh1 = 0u;                   // registered heavy parents, either parity of t
     if (a.hcnt) { nh0 = smc_ldg(a.hcnt + (i64)isl * 2); nh1 = smc_ldg(a.hcnt + (i64)isl * 2 + 1); }

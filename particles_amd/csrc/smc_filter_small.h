@@ -51,7 +51,7 @@ k_filter_small(const FArgs av, const int nsteps)
     double m = smc_uniform(smc_ldg(info + 3)), rs = smc_uniform(smc_ldg(info + 4));
     // APF (core.py:299-313): resampling runs on the AUXILIARY weights lw + logeta; (m, rs) then
     // normalise those, and cconst = log_mean_exp(logeta, W) is what the weights are reset to
-    constexpr bool APF = FK == SMC_FK_APF;
+    constexpr bool APF = f_is_apf(FK);
     double cconst = APF ? smc_uniform(smc_ldg(info + 6)) : 0.0;
     double prev_log_mean = 0.0, prev_logLt = 0.0;          // of step t-1 (core.py:355-359)
     if (t > 0) {

@@ -178,10 +178,22 @@ class AuxiliaryPF(GuidedPF, APFMixin):
 
 
 class AuxiliaryBootstrap(Bootstrap, APFMixin):
-    """APF whose proposal is the transition kernel (state_space_models.py:431-438)."""
+    """APF whose proposal is the transition kernel (state_space_models.py:431-438): the bootstrap move and
+    weight, resampling on ``lw + logeta``.  Fused for the stock ``StochVol`` and ``LinearGauss``
+    (``SMC_FK_APF_BOOT``: the bootstrap step of the kernels with the auxiliary weights of ``AuxiliaryPF``)."""
+
+    _fk_kind = _lib.FK_APF_BOOT
 
     def _device_model(self):
-        return None
+        base = Bootstrap._device_model(self)
+        if base is None or not base.get("apf") or type(self).logeta is not APFMixin.logeta:
+            return None
+        if base["kind"] not in (_lib.MODEL_STOCHVOL, _lib.MODEL_LINGAUSS):
+            return None                                    # (the multivariate auxiliary filter is the guided one)
+        owner = next((c for c in type(self.ssm).__mro__ if "_device_params" in vars(c)), None)
+        if getattr(type(self.ssm), "logeta", None) is not getattr(owner, "logeta", None):
+            return None
+        return base
 
 
 class _AR1State(StateSpaceModel):

@@ -162,6 +162,10 @@ def main():
     out["lg_apf"] = run_case(kalman.LinearGauss(rho=0.9, sigmaX=1.0, sigmaY=0.6), ssm.AuxiliaryPF, 30, 500,
                              "systematic", 0.5)
     out["sv_guided"] = run_case(ssm.StochVol(), ssm.GuidedPF, 30, 500, "systematic", 0.5)
+    # AuxiliaryBootstrap (state_space_models.py:431-438): the bootstrap move with the auxiliary weights
+    out["sv_apfboot"] = run_case(ssm.StochVol(), ssm.AuxiliaryBootstrap, 30, 500, "systematic", 0.5)
+    out["lg_apfboot"] = run_case(kalman.LinearGauss(rho=0.9, sigmaX=1.0, sigmaY=0.6), ssm.AuxiliaryBootstrap, 30, 500,
+                                 "stratified", 0.6)
     # AuxiliaryPF of the multivariate model (kalman.py:348-361: optimal proposal, logeta = log p(y_{t+1} | x_t))
     out["mv_apf"] = run_case(kalman.MVLinearGauss_Guarniero_etal(alpha=0.4, dx=4), ssm.AuxiliaryPF, 16, 400,
                              "systematic", 0.7)

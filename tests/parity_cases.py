@@ -2004,6 +2004,59 @@ def check_apf_lingauss(golden, big=((2048, "systematic", 0.7), (3000, "stratifie
     assert abs(np.mean(lls) - ll) < 0.1, (lls, ll)
 
 
+def check_apf_bootstrap(golden, big=((2048, "systematic", 0.7), (3000, "stratified", 0.8), (4096, "multinomial", 0.7))):
+    """AuxiliaryBootstrap (state_space_models.py:431-438: the bootstrap move and weight, resampling on lw + logeta,
+    weights reset per core.py:299-313) of the stock StochVol and LinearGauss in the fused loop (SMC_FK_APF_BOOT): the
+    reference's own runs (fixtures sv_apfboot / lg_apfboot, replayed draws) -- decisions, ESS and evidence to 1e-9,
+    final ancestors, particles and weights -- on the one-launch filter; on the two-level step against the oracle run
+    on the same contract; a user's subclass with its own logeta keeps the template-method path."""
+    for case, mk_o, mk_d in (("sv_apfboot", orc.StochVol, ssm.StochVol),
+                             ("lg_apfboot", lambda: orc.LinGauss(rho=0.9, sigmaX=1.0, sigmaY=0.6),
+                              lambda: kalman.LinearGauss(rho=0.9, sigmaX=1.0, sigmaY=0.6))):
+        g = golden(case)
+        y = list(g["y"])
+        N, scheme, ESSrmin = int(g["N"]), str(g["scheme"]), float(g["ESSrmin"])
+        np.random.seed(int(g["run_seed"]))
+        rec = orc.RecordingRNG()
+        o = orc.run_filter(mk_o(), y, N, scheme, ESSrmin, fk="apfboot", rng=rec, keep=True)
+        assert o["final_logLt"] == float(g["logLt"])                    # the oracle IS the reference run
+        z, u = tapes_from_oracle(rec.tape, len(y), N, scheme)
+        pf = pa.SMC(fk=ssm.AuxiliaryBootstrap(ssm=mk_d(), data=y), N=N, resampling=scheme, ESSrmin=ESSrmin, replay=(z, u))
+        assert pf._fused and pf.fk.isAPF and describe(pf) == "k_filter_small"
+        pf.run()
+        assert pf.summaries.rs_flags == [bool(v) for v in g["rs_flags"]] and any(pf.summaries.rs_flags)
+        assert rel(pf.summaries.ESSs, g["ESSs"]) < 1e-9 and rel(pf.summaries.logLts, g["logLts"]) < 1e-9
+        assert np.array_equal(pf.A, g["A"]) and np.max(np.abs(pf.X - g["X"])) < 1e-12
+        assert np.allclose(pf.wgts.lw, g["lw"], rtol=1e-11, atol=1e-11) and rel(pf.W, g["W"]) < 1e-9
+        for N2, sch, essr in big:
+            np.random.seed(3 + N2)
+            rec = orc.RecordingRNG()
+            o = orc.run_filter(mk_o(), y, N2, sch, essr, fk="apfboot", rng=rec, keep=True, cdf="2level")
+            z, u = tapes_from_oracle(rec.tape, len(y), N2, sch)
+            pf = pa.SMC(fk=ssm.AuxiliaryBootstrap(ssm=mk_d(), data=y), N=N2, resampling=sch, ESSrmin=essr, replay=(z, u))
+            assert pf._fused and "k_reduce2" in describe(pf) and describe(pf).endswith("k_ancestors2+k_propagate"), describe(pf)
+            pf.run()
+            assert pf.summaries.rs_flags == o["rs_flag"] and sum(o["rs_flag"]) >= 2
+            assert rel(pf.summaries.ESSs, o["ESS"]) < 1e-9 and rel(pf.summaries.logLts, o["logLt"]) < 1e-9
+            assert np.array_equal(pf.A, o["A"]) and np.max(np.abs(pf.X - o["X"])) < 1e-12
+    # Philox mode against the exact likelihood (LinearGauss)
+    g = golden("lg_apfboot")
+    y = list(g["y"])
+    ll, _ = orc.kalman_loglik(orc.LinGauss(rho=0.9, sigmaX=1.0, sigmaY=0.6), y)
+    lls = []
+    for s_ in range(6):
+        pf = pa.SMC(fk=ssm.AuxiliaryBootstrap(ssm=kalman.LinearGauss(rho=0.9, sigmaX=1.0, sigmaY=0.6), data=y), N=4096, seed=80 + s_)
+        pf.run()
+        lls.append(pf.logLt)
+    assert abs(np.mean(lls) - ll) < 4.0 * max(np.std(lls, ddof=1), 0.02) / np.sqrt(6) + 0.02, (lls, ll)
+
+    class MyAux(ssm.AuxiliaryBootstrap):
+        def logeta(self, t, x):
+            return 0.0 * x
+    pf = pa.SMC(fk=MyAux(ssm=ssm.StochVol(), data=y), N=500)
+    assert not pf._fused
+
+
 def check_apf_mv(golden, big=((3000, 8, "systematic", 0.7), (1 << 13, 32, "stratified", 0.8), (2048, 5, "multinomial", 0.9)),
                  philox_N=4096):
     """AuxiliaryPF of MVLinearGauss (kalman.py:348-361: optimal proposal, logeta = log p(y_{t+1} | x_t)) in the

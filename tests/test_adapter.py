@@ -163,6 +163,16 @@ def test_reference_apf_runs_fused_through_the_adapter(ref):
     assert got[1000]._fused and describe(got[1000]) == "k_filter_small"
     assert got[2048]._fused and describe(got[2048]) == "k_reduce2+k_ancestors2+k_propagate"
     assert got[3000]._fused and describe(got[3000]) == "k_reduce2+k_ancestors2+k_propagate"
+    # ... the reference's AuxiliaryBootstrap (state_space_models.py:431-438) of a stock model: fused as well
+    fkb = rssm.AuxiliaryBootstrap(ssm=rssm.StochVol(mu=-1.0, rho=0.95, sigma=0.2), data=y)
+    np.random.seed(5)
+    wantb = particles.SMC(fk=fkb, N=2000)
+    wantb.run()
+    for N, kern in ((1000, "k_filter_small"), (2048, "k_reduce2+k_ancestors2+k_propagate")):
+        pf = HipSMC(fk=fkb, N=N, seed=8)
+        assert isinstance(pf, pa.SMC) and pf._fused and pf.fk.isAPF and describe(pf) == kern
+        pf.run()
+        assert abs(pf.logLt - wantb.logLt) < 0.5, (N, pf.logLt, wantb.logLt)
     # ... and of the stock MVLinearGauss (kalman.py:348-361): the auxiliary weights in front of the flat step
     rk = ref["kalman"] if "kalman" in ref else __import__("particles.kalman", fromlist=["kalman"])
     model = rk.MVLinearGauss_Guarniero_etal(alpha=0.4, dx=3)

@@ -319,3 +319,7 @@ def test_apf_and_guided_stochvol_fused(golden):
 
 def test_sequential_prefix_sums_in_parallel(monkeypatch):
     pc.check_seq_prefix_sums(sizes=(5000, 1 << 14), monkeypatch=monkeypatch)
+
+
+def test_auxiliary_bootstrap_fused(golden):
+    pc.check_apf_bootstrap(golden, big=((2048, "systematic", 0.7), (3000, "stratified", 0.8)))

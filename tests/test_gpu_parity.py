@@ -633,3 +633,9 @@ def test_apf_and_guided_stochvol_fused(golden):
 def test_sequential_prefix_sums_in_parallel(monkeypatch):
     import parity_cases as pc
     pc.check_seq_prefix_sums(sizes=(5000, 1 << 16, (1 << 18) + 77), monkeypatch=monkeypatch)
+
+
+@pytest.mark.gpu
+def test_auxiliary_bootstrap_fused(golden):
+    import parity_cases as pc
+    pc.check_apf_bootstrap(golden)

@@ -30,7 +30,7 @@ CASES = ([("toy_%s" % s, "toy", "bootstrap") for s in ("systematic", "stratified
             ("gordon_boot", "gordon", "bootstrap"), ("theta_boot", "theta", "bootstrap"),
             ("svlev_boot", "svlev", "bootstrap"), ("cox_boot", "cox", "bootstrap"),
             ("sv_guided", "sv", "guided"), ("sv_apf", "sv", "apf"), ("lg_apf", "lg_apf", "apf"),
-            ("mv_apf", "mv4", "apf")])
+            ("mv_apf", "mv4", "apf"), ("sv_apfboot", "sv", "apfboot"), ("lg_apfboot", "lg_apf", "apfboot")])
 
 
 SQMC_CASES = [("sqmc_toy", lambda: orc.LinGauss(rho=0.9, sigmaX=1.0, sigmaY=0.5), "bootstrap"),
