@@ -435,9 +435,12 @@ ROOFLINE_NOTE = (
     "that takes longer; step_frac = (16 d + 40) B x N / ms_per_step over the HBM peak (the whole step)")
 
 
-def other_workloads(K=20, W=10, R=7, shrink=0):
+def other_workloads(K=20, W=100, R=15, shrink=0):
     """One bounded measurement of each BASELINE.json config that is not the headline (driver-visible
-    C3 / C4 / C5): same timed region as the headline (K steps between device syncs, median of R).
+    C3 / C4 / C5): same timed region as the headline (K steps between device syncs, median of R; W = 100
+    untimed steps first -- a leg starts on a GPU that idled while the host built its filter, and with 10
+    warm-up steps the seven regions of round 3 were measured on the clock ramp: C3 read 71 G/s here
+    against 78 in a run of its own).
     shrink > 0 (functional tests without a GPU): every N = 2^shrink, C5 with 2 islands."""
     legs = [("c3_systematic", dict(name="c3", scheme="systematic")),
             ("c3_stratified", dict(name="c3", scheme="stratified")),
