@@ -37,6 +37,7 @@ struct smc_filter {
     // sort's workspace and -- more than one island -- the islands' permutations
     u64 sp_epoch;          // launches of the merged spacings + reduction kernel so far (see FArgs::sp_epoch)
     bool sp_merge;
+    bool flush_pending;    // two-level step: the summary row of the last step enqueued is still to be written (k_flush2 on demand)
     bool sqmc, sq_gather;
     bool sq_flat;          // SQMC on the flat step (multivariate filters; univariate ones below two tiles)
     u64 sq_seed, sq_ctr0;
@@ -360,6 +361,7 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
 extern "C" {
 
 static int filter_fetch(smc_filter* f, int field, i64 s, int island, void* out_host);
+static void flush_rows(smc_filter* f);
 
 int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opts* o,
                       const double* y_host, smc_filter** out)
@@ -632,6 +634,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     const size_t oSst = carve(a.sp_tpw ? M * a.sp_nwg * 8 : 8);
     const size_t oSdec = carve(M * 8);
     f->sp_epoch = 0;
+    f->flush_pending = false;
     // (inside a replayed graph the argument block -- the epoch with it -- is frozen: separate launches there)
     f->sp_merge = a.sp_tpw && merge_fits && !o->use_graph && !(o->flags & SMC_PATH_SPLIT_REDUCE);
     const size_t oTmp = carve(N * dxm * 8);
@@ -833,6 +836,7 @@ int smc_filter_destroy(smc_filter* f)
 // need the copies to diverge re-seed them (smc_filter_reseed).
 int smc_filter_clone(smc_filter* src, smc_filter** out)
 {
+    if (src) { (void)hipSetDevice(src->ctx->device); flush_rows(src); }
     SMC_REQUIRE(src && out, "null argument");
     smc_ctx* ctx = src->ctx;
     SMC_HIP_CHECK(hipSetDevice(ctx->device));
@@ -964,6 +968,19 @@ static void launch_small(smc_filter* f, int nsteps)
 #undef S_CASE
 }
 
+// The summary row of step t (ESS, evidence terms, the (K, 1/s) its weights are normalised with) is written by the
+// reduction that OPENS step t + 1; behind the last step enqueued nobody has done it yet.  k_flush2 does -- when
+// somebody asks for results (every accessor below calls this), not at the end of every smc_filter_step call: a
+// caller that steps in pieces (20 steps, sync, 20 steps ...) paid a launch per piece for a row the next piece's first
+// kernel writes anyway.
+static void flush_rows(smc_filter* f)
+{
+    if (f && f->flush_pending) {
+        f->flush_pending = false;
+        SMC_LAUNCH(k_flush2, dim3(f->a.n_islands), dim3(SMC_BLOCK), f->ctx->stream, f->a);
+    }
+}
+
 int smc_filter_step(smc_filter* f, int64_t nsteps)
 {
     SMC_REQUIRE(f, "null filter");
@@ -1047,8 +1064,7 @@ int smc_filter_step(smc_filter* f, int64_t nsteps)
         if (f->prof && f->prof_n < PROF_MAX) kp = f->prof_n++;
         enqueue_step(f, kp, f->t_host + done);
     }
-    if (f->two_level && todo > 0)            // summary row of the last step (see k_flush2)
-        SMC_LAUNCH(k_flush2, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
+    if (f->two_level && todo > 0) f->flush_pending = true;      // summary row of the last step: flush_rows, on demand
     SMC_LAUNCH_CHECK();
     f->t_host += todo;
     return SMC_OK;
@@ -1070,6 +1086,7 @@ int smc_filter_t(smc_filter* f, int64_t* t_out)
 
 int smc_filter_summaries(smc_filter* f, double* out_host)
 {
+    if (f) { (void)hipSetDevice(f->ctx->device); flush_rows(f); }
     SMC_REQUIRE(f && out_host, "null argument");
     const i64 t = f->t_host, T = f->a.T;
     if (t == 0) return SMC_OK;
@@ -1094,6 +1111,7 @@ __global__ void k_f_collect_logLt(const double* summ, i64 T, i64 t, int n, doubl
 
 int smc_filter_logLt(smc_filter* f, double* out_host)
 {
+    if (f) { (void)hipSetDevice(f->ctx->device); flush_rows(f); }
     SMC_REQUIRE(f && out_host, "null argument");
     const i64 t = f->t_host, T = f->a.T;
     const int M = f->a.n_islands;
@@ -1117,6 +1135,7 @@ int smc_filter_logLt(smc_filter* f, double* out_host)
 
 int smc_filter_get(smc_filter* f, int field, int island, void* out_host)
 {
+    if (f) { (void)hipSetDevice(f->ctx->device); flush_rows(f); }
     SMC_REQUIRE(f && out_host, "null argument");
     SMC_REQUIRE(island >= 0 && island < f->a.n_islands, "island out of range");
     const i64 t = f->t_host;
@@ -1199,6 +1218,7 @@ static int filter_fetch(smc_filter* f, int field, i64 s, int island, void* out_h
 // CDF of the next) is recomputed on the device as if the step had produced these values.
 int smc_filter_set_state(smc_filter* f, int island, const double* X_host, const double* lw_host)
 {
+    if (f) { (void)hipSetDevice(f->ctx->device); flush_rows(f); }
     SMC_REQUIRE(f, "null filter");
     SMC_REQUIRE(island >= 0 && island < f->a.n_islands, "island out of range");
     if (f->t_host == 0) {
@@ -1266,6 +1286,7 @@ static int island_arrays(smc_filter* f, i64 t, IslandArray* out)
 // One gather kernel + one contiguous copy per array (a dozen launches, whatever n_islands).
 int smc_filter_permute_islands(smc_filter* f, const int64_t* src_host)
 {
+    if (f) { (void)hipSetDevice(f->ctx->device); flush_rows(f); }
     SMC_REQUIRE(f && src_host, "null argument");
     if (f->a.pm2) {
         smc_set_error("whole-island moves are not available for the auxiliary filter on the two-level step");
@@ -1317,6 +1338,8 @@ int smc_filter_permute_islands(smc_filter* f, const int64_t* src_host)
 // proposed thetas; where the proposal is accepted, island i of `dst` takes over island i of `src`.
 int smc_filter_copy_islands(smc_filter* dst, smc_filter* src, const unsigned char* accept_host)
 {
+    if (dst) { (void)hipSetDevice(dst->ctx->device); flush_rows(dst); }
+    if (src) flush_rows(src);
     SMC_REQUIRE(dst && src && accept_host, "null argument");
     SMC_REQUIRE(dst->ctx == src->ctx, "both filters must live on one context");
     const FArgs &a = dst->a, &b = src->a;
@@ -1410,10 +1433,12 @@ static int island_pack(smc_filter* f, const int64_t* islands_host, int n, void* 
 }
 int smc_filter_pack_islands(smc_filter* f, const int64_t* islands_host, int n, void* pack_dev)
 {
+    if (f) { (void)hipSetDevice(f->ctx->device); flush_rows(f); }
     return island_pack(f, islands_host, n, pack_dev, 0);
 }
 int smc_filter_unpack_islands(smc_filter* f, const int64_t* islands_host, int n, const void* pack_dev)
 {
+    if (f) { (void)hipSetDevice(f->ctx->device); flush_rows(f); }
     return island_pack(f, islands_host, n, (void*)pack_dev, 1);
 }
 
@@ -1423,6 +1448,7 @@ int smc_filter_unpack_islands(smc_filter* f, const int64_t* islands_host, int n,
 // Islands that receive no state must not be stepped.
 int smc_filter_fast_forward(smc_filter* f, int64_t t)
 {
+    if (f) { (void)hipSetDevice(f->ctx->device); flush_rows(f); }
     SMC_REQUIRE(f, "null filter");
     SMC_REQUIRE(f->t_host == 0, "smc_filter_fast_forward: the filter has already stepped");
     SMC_REQUIRE(t >= 0 && t <= f->a.T, "smc_filter_fast_forward: t must be in [0, T]");
@@ -1435,6 +1461,7 @@ int smc_filter_fast_forward(smc_filter* f, int64_t t)
 // ---- SMC^2: the theta level (see k_theta_update) -------------------------------------------
 static int theta_enable(smc_filter* f, double ess_rmin, smc_comm* comm)
 {
+    if (f) { (void)hipSetDevice(f->ctx->device); flush_rows(f); }
     SMC_REQUIRE(f, "null filter");
     SMC_REQUIRE(!f->a.hist && !f->a.mom, "the theta level is not available with keep_history / moments");
     SMC_REQUIRE(!f->a.pm2, "the theta level is not available for the auxiliary filter on the two-level step");
@@ -1479,6 +1506,7 @@ int smc_filter_theta_enable_sharded(smc_filter* f, smc_comm* comm, double ess_rm
 int smc_filter_theta_state(smc_filter* f, double* lw_theta_host, int64_t* stop_t, int64_t* steps_done,
                            double* ess_host)
 {
+    if (f) { (void)hipSetDevice(f->ctx->device); flush_rows(f); }
     SMC_REQUIRE(f && f->lwth, "the theta level is not enabled");
     hipStream_t st = f->ctx->stream;
     double th[TH_STRIDE];
@@ -1499,6 +1527,7 @@ int smc_filter_theta_state(smc_filter* f, double* lw_theta_host, int64_t* stop_t
 // core.py:351-359: its differences between resamplings are the evidence increments of the model)
 int smc_filter_theta_logmeans(smc_filter* f, double* out_host, int64_t* steps_done)
 {
+    if (f) { (void)hipSetDevice(f->ctx->device); flush_rows(f); }
     SMC_REQUIRE(f && f->lwth && out_host, "the theta level is not enabled, or null output");
     hipStream_t st = f->ctx->stream;
     double th[TH_STRIDE];
@@ -1517,6 +1546,7 @@ int smc_filter_theta_logmeans(smc_filter* f, double* out_host, int64_t* steps_do
 // continues from there.  Also valid when nothing stopped (lw_theta replaced, time unchanged).
 int smc_filter_theta_resume(smc_filter* f, const double* lw_theta_host)
 {
+    if (f) { (void)hipSetDevice(f->ctx->device); flush_rows(f); }
     SMC_REQUIRE(f && f->lwth, "the theta level is not enabled");
     SMC_HIP_CHECK(hipSetDevice(f->ctx->device));
     hipStream_t st = f->ctx->stream;
@@ -1538,6 +1568,7 @@ int smc_filter_theta_resume(smc_filter* f, const double* lw_theta_host)
 
 int smc_filter_moments(smc_filter* f, double* out_host)
 {
+    if (f) { (void)hipSetDevice(f->ctx->device); flush_rows(f); }
     SMC_REQUIRE(f && out_host, "null argument");
     if (!f->a.mom) {
         smc_set_error("smc_filter_moments: the filter was created without opts.moments");
@@ -1554,6 +1585,7 @@ int smc_filter_moments(smc_filter* f, double* out_host)
 
 int smc_filter_history(smc_filter* f, int field, int64_t step, int island, void* out_host)
 {
+    if (f) { (void)hipSetDevice(f->ctx->device); flush_rows(f); }
     SMC_REQUIRE(f && out_host, "null argument");
     SMC_REQUIRE(island >= 0 && island < f->a.n_islands, "island out of range");
     if (!f->a.hist) {
@@ -1579,6 +1611,7 @@ int smc_filter_history(smc_filter* f, int field, int64_t step, int island, void*
 
 int smc_filter_spacings(smc_filter* f, int64_t t, int island, double* out_host)
 {
+    if (f) { (void)hipSetDevice(f->ctx->device); flush_rows(f); }
     SMC_REQUIRE(f && out_host, "null argument");
     SMC_REQUIRE(island >= 0 && island < f->a.n_islands, "island out of range");
     SMC_REQUIRE(t >= 1 && t < f->a.T, "resampling happens at steps 1 .. T - 1");
@@ -1597,6 +1630,7 @@ int smc_filter_spacings(smc_filter* f, int64_t t, int island, double* out_host)
 
 int smc_filter_trajectories(smc_filter* f, int island, int64_t* out_host)
 {
+    if (f) { (void)hipSetDevice(f->ctx->device); flush_rows(f); }
     SMC_REQUIRE(f && out_host, "null argument");
     SMC_REQUIRE(island >= 0 && island < f->a.n_islands, "island out of range");
     if (!f->a.hist) {
@@ -1640,6 +1674,7 @@ int smc_filter_trajectories(smc_filter* f, int island, int64_t* out_host)
 
 int smc_filter_one_trajectory(smc_filter* f, int island, int64_t n_last, double* out_host)
 {
+    if (f) { (void)hipSetDevice(f->ctx->device); flush_rows(f); }
     SMC_REQUIRE(f && out_host, "null argument");
     SMC_REQUIRE(island >= 0 && island < f->a.n_islands, "island out of range");
     if (f->a.hist != 1) {
