@@ -571,9 +571,10 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
         const int want = (o->flags & SMC_PATH_WIDE4) ? 4 : 2;
         f->wide_tpw = (a.ntiles % want) == 0 ? want : ((a.ntiles % 2) == 0 ? 2 : 0);
     }
-    // consecutive tiles on one XCD (f_tile_xcd): grids of whole multiples of 8 x (tiles per workgroup of the resampling launch)
-    a.xcd_chunks = (f->two_level && !mv && !f->strict && !f->sqmc && !(o->flags & SMC_PATH_NO_XCD_CHUNKS) &&
-                    a.ntiles % (8 * (f->wide_tpw ? f->wide_tpw : 1)) == 0) ? 1 : 0;
+    // consecutive tiles on one XCD (f_tile_xcd): any number of tiles with one tile per resampling workgroup; with
+    // k_ancestors2w whole multiples of 8 x (its tiles per workgroup) -- else the wide kernel keeps its own XCD-strided map
+    a.xcd_chunks = (f->two_level && !mv && !f->strict && !f->sqmc && !(o->flags & SMC_PATH_NO_XCD_CHUNKS) && a.ntiles >= 16 &&
+                    (!f->wide_tpw || a.ntiles % (8 * f->wide_tpw) == 0)) ? 1 : 0;
     // (measured and kept out, round 4: the reduction MERGED into the resampling launch on grids beyond 2048 workgroups --
     //  (a) every workgroup of k_ancestors2w reducing: C5 99.2 us per step (2 tiles per workgroup) / 117.2 (4) against 92.9
     //  behind k_reduce2 (r12h); (b) workgroup 0 of k_ancestors2 reducing, the others waiting for its word with their

@@ -135,11 +135,15 @@ struct FArgs {
 // Workgroups go round the 8 XCDs (each with its own L2): with tile = workgroup index, neighbouring tiles sit on
 // different XCDs -- but a tile's offspring start in the tile next door as soon as the weights drift, and their parents'
 // states were written there: k_propagate then reads A and gathers X through another XCD's L2.  With the map below
-// XCD x owns the tiles x ntiles/8 .. (x+1) ntiles/8 - 1: neighbours share an L2 (C2: r12v A/B).  Any bijection is
-// correct -- a workgroup just processes the tile the map gives it.
+// XCD x owns a contiguous run of tiles: neighbours share an L2 (C2: r12v A/B).  Any bijection is correct -- a workgroup
+// just processes the tile the map gives it.  Workgroup bx sits on XCD c = bx mod 8 and is that XCD's q-th (q = bx / 8);
+// XCD c receives ceil((ntiles - c) / 8) workgroups, so its run starts at c floor(ntiles / 8) + min(c, ntiles mod 8):
+// a bijection for ANY number of tiles (round sizes like N = 10^6 included).
 __device__ __forceinline__ int f_tile_xcd(const FArgs& a, const int bx)
 {
-    return a.xcd_chunks ? (bx & 7) * (a.ntiles >> 3) + (bx >> 3) : bx;
+    if (!a.xcd_chunks) return bx;
+    const int c = bx & 7, base = a.ntiles >> 3, rem = a.ntiles & 7;
+    return c * base + (c < rem ? c : rem) + (bx >> 3);
 }
 
 __host__ __device__ __forceinline__ i64 f_slot(const FArgs& a, i64 t)
