@@ -33,6 +33,27 @@ from . import _lib
 from ._lib import DeviceArray, check, lib
 
 
+class _StdoutToStderr:
+    """RCCL prints a version banner on STDOUT when it initialises; a launch line that promises ONE JSON line on
+    stdout (bench.py) must not carry it: file descriptor 1 points at stderr while the library initialises."""
+
+    def __enter__(self):
+        import sys
+        try:
+            sys.stdout.flush()
+            self._saved = os.dup(1)
+            os.dup2(2, 1)
+        except OSError:
+            self._saved = None
+        return self
+
+    def __exit__(self, *exc):
+        if self._saved is not None:
+            os.dup2(self._saved, 1)
+            os.close(self._saved)
+        return False
+
+
 def env_rank_world():
     return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
             int(os.environ.get("WORLD_SIZE", "1")))
@@ -221,7 +242,8 @@ class Group:
         msg = b""
         if self.rank == 0:
             try:
-                check(lib().smc_comm_unique_id(uid))
+                with _StdoutToStderr():
+                    check(lib().smc_comm_unique_id(uid))
                 msg = b"\x01" + uid.raw
             except Exception as e:
                 msg = b"\x00" + str(e).encode()
@@ -232,7 +254,8 @@ class Group:
         h = _lib.c_vp()
         err = b""
         try:
-            check(lib().smc_comm_create(_lib.ctx().h, self.world, self.rank, uid, ctypes.byref(h)))
+            with _StdoutToStderr():
+                check(lib().smc_comm_create(_lib.ctx().h, self.world, self.rank, uid, ctypes.byref(h)))
         except Exception as e:
             err = ("rank %d: %s" % (self.rank, e)).encode()
         errs = self.star.exchange(err) if self.star else [err]
