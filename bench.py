@@ -376,12 +376,17 @@ def kernel_profile(wl, K, W, rank=0):
     import ctypes
     from particles_amd import _lib
     pf = make_filter(wl, rank, profile=True)
+    # (at least 60 untimed steps and 240 sampled ones whatever K is -- the data permitting: at the driver's K = 20 the
+    #  20 sampled steps of round 3 gave seven samples per kind on a GPU that had just idled, and the dominant kernel
+    #  read 4 % slower than in rocprofv3's trace of the same command)
+    T = wl["fk"].T
+    W = max(W, min(60, T // 4))
     pf.step_async(W)
     pf.sync()
     mv, pr, ns = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
     _lib.check(_lib.lib().smc_filter_kernel_ms(pf._f, ctypes.byref(mv), ctypes.byref(pr),
                                                ctypes.byref(ns)))    # drop warm-up samples
-    pf.step_async(min(K, 4000))
+    pf.step_async(max(1, min(max(K, 240), 4000, T - W)))
     _lib.check(_lib.lib().smc_filter_kernel_ms(pf._f, ctypes.byref(mv), ctypes.byref(pr), ctypes.byref(ns)))
     desc = ctypes.create_string_buffer(256)
     _lib.check(_lib.lib().smc_filter_describe(pf._f, desc, 256))
