@@ -197,17 +197,20 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
         if (f->a.scheme == SMC_MULTINOMIAL && !f->a.ut)
             for (int i = 0; i < f->a.n_islands; ++i)
                 SMC_LAUNCH(k_f_spacings_step, dim3(1), dim3(SMC_BLOCK), st, f->a, i, f->a.su + (size_t)i * f->a.N);
-        const unsigned nb = (unsigned)((f->a.N + SMC_BLOCK - 1) / SMC_BLOCK);
-        SMC_LAUNCH(k_strict_W, dim3(nb, f->a.n_islands), dim3(SMC_BLOCK), st, f->a, f->strict_ws);
+        const unsigned nb = (unsigned)((f->a.N + 1023) / 1024);
         // S = the reference's sequential fp64 prefix sums of W, every bit, computed in parallel (smc_seqsum.h); the
-        // literal one-lane walk (k_strict_cdf, 2.5 ms at N = 2^20) behind SMC_PATH_STRICT_LITERAL (A/B, tests)
+        // literal one-lane walk (k_strict_cdf, 44 ms at N = 2^20) behind SMC_PATH_STRICT_LITERAL (A/B, tests)
         double* S = f->strict_ws + (size_t)f->a.n_islands * f->a.N;
+        void* seq_scr = (void*)(S + (size_t)f->a.n_islands * f->a.N);
         if (f->strict_literal) {
+            SMC_LAUNCH(k_strict_W, dim3(nb, f->a.n_islands), dim3(SMC_BLOCK), st, f->a, f->strict_ws, (double*)nullptr);
             SMC_LAUNCH(k_strict_cdf, dim3(1, f->a.n_islands), dim3(64), st, f->a, f->strict_ws);
             S = f->strict_ws;
         } else {
-            seq_prefix_sums_launch(st, f->strict_ws, f->a.N, f->a.n_islands, S, (void*)(S + (size_t)f->a.n_islands * f->a.N),
-                                   SeqGate{f->a.info, INFO_STRIDE, f->a.T, nullptr}, false, false);
+            SMC_LAUNCH(k_strict_W, dim3(nb, f->a.n_islands), dim3(SMC_BLOCK), st, f->a, f->strict_ws,
+                       seq_scratch_carve(seq_scr, f->a.N, f->a.n_islands).tsum);
+            seq_prefix_sums_launch(st, f->strict_ws, f->a.N, f->a.n_islands, S, seq_scr,
+                                   SeqGate{f->a.info, INFO_STRIDE, f->a.T, nullptr}, false, false, true);
         }
         SMC_LAUNCH(k_strict_search, dim3((unsigned)((f->a.N / 2 + SMC_BLOCK) / SMC_BLOCK), f->a.n_islands), dim3(SMC_BLOCK), st,
                    f->a, (const double*)S, (const double*)f->a.su);

@@ -2838,30 +2838,43 @@ k_ancestors2(const FArgs av)
 // same values smc_filter_get(SMC_FIELD_W) returns), k_seq_cdf turns it into S in place, every
 // offspring searches S with its own sorted uniform.
 __global__ void __launch_bounds__(SMC_BLOCK)
-k_strict_W(const FArgs av, double* Wout)
+k_strict_W(const FArgs av, double* Wout, double* tsum)
 {
+    // one tile of 1024 weights per workgroup, 4 per thread; tsum (may be null): the tile's fp64 sum -- the estimate
+    // smc_seqsum.h's passes start from (its k_seq_tile_sums, saved a launch)
     const FArgs& a = av;
-    const int isl = (int)blockIdx.y;
+    __shared__ double smd[SMC_SM];
+    const int isl = (int)blockIdx.y, b = (int)blockIdx.x;
     const double* info = a.info + (i64)isl * INFO_STRIDE;
     const i64 t = (i64)smc_uniform(info[0]);
     if (t >= a.T || t == 0 || smc_uniform(info[1]) == 0.0) return;
-    const i64 i = (i64)blockIdx.x * SMC_BLOCK + threadIdx.x;
-    if (i >= a.N) return;
     const double* row = a.summ + ((i64)isl * (a.T + 1) + (t - 1)) * SUMM_STRIDE;
     const double m = row[5], rs = row[6];
-    const double lw = (f_lw(a, t - 1) + (i64)isl * a.N)[i];
-    double W;
-    if (a.kform) {
-        double k;
-        double p = smc_expk(lw, k);
-        const bool ok = lw > -INFINITY;
-        p = ok ? p : 0.0;
-        k = ok ? k : -INFINITY;
-        W = smc_scale_pk(p, k, m) * rs;
-    } else {
-        W = f_weight(lw, m, rs);
+    const double* lwp = f_lw(a, t - 1) + (i64)isl * a.N;
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const i64 i = (i64)b * 1024 + (i64)threadIdx.x * 4 + k;
+        if (i >= a.N) continue;
+        const double lw = lwp[i];
+        double W;
+        if (a.kform) {
+            double kk;
+            double p = smc_expk(lw, kk);
+            const bool ok = lw > -INFINITY;
+            p = ok ? p : 0.0;
+            kk = ok ? kk : -INFINITY;
+            W = smc_scale_pk(p, kk, m) * rs;
+        } else {
+            W = f_weight(lw, m, rs);
+        }
+        Wout[(i64)isl * a.N + i] = W;
+        v += W;
     }
-    Wout[(i64)isl * a.N + i] = W;
+    if (tsum) {
+        v = smc_block_sum(v, smd);
+        if (threadIdx.x == 0) tsum[(i64)isl * gridDim.x + b] = v;
+    }
 }
 // (k_seq_cdf needs the decision too: a wrapper that returns early when the step does not resample)
 __global__ void __launch_bounds__(64)

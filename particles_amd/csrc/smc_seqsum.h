@@ -325,15 +325,15 @@ k_seq_fill(const double* W, const i64 n, const int* tk, const double* tstart, do
 // part shrinks to the exceptions themselves: one thread walks the sorted list, s <- (I(s) + P-difference) on the grid,
 // then s <- s + W_x with the hardware's own addition.  k_seq_elem_fill writes S_j = (I(S_x) + P[j+1] - P[x+1]) g for the
 // regular elements behind exception x and VERIFIES what the walk assumed (the base's binade is E_j, the integer stays
-// below 2^53): any violation, or more exceptions than the list holds, raises `need_fallback` and the tile walk redoes
-// the array.  Cost at N = 2^20: four short launches.
+// below 2^53): any violation, or more exceptions than the list holds, raises `need_fallback` and k_seq_fallback redoes
+// the array.  Cost at N = 2^20: four short launches (+ the fallback's, which returns at once).
 #define SEQ_E_ANY (-2)                 /* SeqElem::E of a zero element: regular on whatever grid the sum is on */
-#define SEQ_XCAP 1024                  /* exceptions the list holds per island (32 KB of LDS in the walk) */
-struct SeqX {                          // one exception: its index and value, P in front of it (tile-local, then global), S behind it
+#define SEQ_XCAP 2048                  /* exceptions the list holds per island (48 KB of LDS in the walk): more than a
+                                          sum can cross binades (2046) -- only engineered ties or NaN weights overflow it */
+struct SeqX {                          // one exception: its index and value, P in front of it (tile-local, then global)
     i64 j;
     u64 P;
     double w;
-    double S;
 };
 // what a thread knows about its 4 elements of tile b (the same code in the classify and the fill pass: same bits)
 struct SeqElem {
@@ -404,7 +404,6 @@ k_seq_elem_classify(const double* W, const i64 n, const double* tsum, u64* Rt, S
                 x.j = i0 + k;
                 x.P = e.Pex[k];
                 x.w = e.w[k];
-                x.S = 0.0;
                 xlist[(i64)isl * SEQ_XCAP + slot] = x;
             }
         }
@@ -445,7 +444,7 @@ k_seq_elem_chain(const double* W, const i64 n, const int ntiles, const u64* Rt, 
             x = xl[i];
             x.P += Pto[x.j / SEQ_TILE];
         } else {
-            x.j = (i64)0x7fffffffffffffffll; x.P = 0ull; x.w = 0.0; x.S = 0.0;
+            x.j = (i64)0x7fffffffffffffffll; x.P = 0ull; x.w = 0.0;
         }
         sx[i] = x;
     }
@@ -478,7 +477,6 @@ k_seq_elem_chain(const double* W, const i64 n, const int ntiles, const u64* Rt, 
                 s = __longlong_as_double((long long)(((u64)Es << 52) | (Iv & 0x000FFFFFFFFFFFFFull)));
             }
             s = s + sx[i].w;                                   // resampling.py:508, the hardware's own addition
-            sx[i].S = s;
             So[j] = s;
             Pprev = sx[i].P;
         }
@@ -540,7 +538,7 @@ k_seq_elem_fill(const double* W, const i64 n, const double* tsum, const u64* Pt,
             baseS = So[(i64)b * SEQ_TILE + (last - 1u)];
             baseP = Ptb + s_P[last - 1u];
         } else if (base0 >= 0) {
-            baseS = xl[base0].S;
+            baseS = So[xl[base0].j];                           // (the walk wrote the exception's own sum)
             baseP = xl[base0].P;
         }
         const u64 dP = Ptb + e.Pex[k] + e.r[k] - baseP;
@@ -556,6 +554,36 @@ k_seq_elem_fill(const double* W, const i64 n, const double* tsum, const u64* Pt,
         So[i0 + k] = __longlong_as_double((long long)(((u64)Es << 52) | (Iv & 0x000FFFFFFFFFFFFFull)));
     }
     if (bad) need_fallback[isl] = 1u;
+}
+
+// ---- the fallback as ONE launch (the filter's step loop pays a launch for it every step, needed or not): one
+// workgroup per island does every tile exactly with seq_tile_block_exact -- a clean tile is one scan, an exceptional
+// one a scan per exception.  ~3 us per tile: milliseconds at N = 2^20, but only engineered ties, NaN or negative
+// weights get here (SEQ_XCAP holds more exceptions than a sum can cross binades).  The tile walk above (three
+// launches, 0.2 - 0.8 ms) stays as smc_seq_prefix_sums' mode 2.
+static __global__ void __launch_bounds__(SMC_BLOCK)
+k_seq_fallback(const double* W, const i64 n, double* S, const SeqGate gate)
+{
+    __shared__ u64 smu[SMC_SM];
+    __shared__ int s_idx;
+    __shared__ double s_tmp;
+    const int isl = (int)blockIdx.x, tid = (int)threadIdx.x;
+    if (!seq_gate_open(gate, isl)) return;
+    const double* w = W + (i64)isl * n;
+    double* So = S + (i64)isl * n;
+    double s = 0.0;
+    bool first = true;
+    for (i64 lo = 0; lo < n; lo += SEQ_TILE) {
+        const int m_all = (int)(lo + SEQ_TILE < n ? SEQ_TILE : n - lo);
+        double w4[4], o4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w4[k] = tid * 4 + k < m_all ? w[lo + tid * 4 + k] : 0.0;
+        s = seq_tile_block_exact(w4, o4, m_all, s, first, smu, &s_idx, &s_tmp);
+        first = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (tid * 4 + k < m_all) So[lo + tid * 4 + k] = o4[k];
+    }
 }
 
 // scratch the passes need besides S, per island: per tile 4 x 8 + 2 x 8 bytes, the exception list, three words
@@ -603,12 +631,14 @@ static inline const unsigned* seq_need_ptr(const void* scratch, const i64 n, con
 // zero_counters = false: the caller zeroed it once (the exception counters are re-armed by the passes themselves).
 // tiles_only: the tile walk alone (tests: the fallback must give the same bits)
 static inline void seq_prefix_sums_launch(hipStream_t st, const double* W, const i64 n, const int islands, double* S, void* scratch,
-                                          const SeqGate gate, const bool tiles_only = false, const bool zero_counters = true)
+                                          const SeqGate gate, const bool tiles_only = false, const bool zero_counters = true,
+                                          const bool have_tile_sums = false)
 {
     const int ntiles = (int)((n + SEQ_TILE - 1) / SEQ_TILE);
     const SeqScratch q = seq_scratch_carve(scratch, n, islands);
     if (zero_counters) (void)hipMemsetAsync(q.xcount, 0, (size_t)islands * 8, st);       // (xcount and need: adjacent)
-    SMC_LAUNCH(k_seq_tile_sums, dim3(ntiles, islands), dim3(SMC_BLOCK), st, W, n, q.tsum, gate);
+    // (have_tile_sums: the caller's kernel that wrote W left the tiles' fp64 sums in the scratch's first array)
+    if (!have_tile_sums) SMC_LAUNCH(k_seq_tile_sums, dim3(ntiles, islands), dim3(SMC_BLOCK), st, W, n, q.tsum, gate);
     SeqGate fb = gate;
     if (!tiles_only) {
         SMC_LAUNCH(k_seq_elem_classify, dim3(ntiles, islands), dim3(SMC_BLOCK), st, W, n, (const double*)q.tsum, q.Rt, q.xlist,
@@ -617,7 +647,9 @@ static inline void seq_prefix_sums_launch(hipStream_t st, const double* W, const
                    q.need, q.tbase, S, gate);
         SMC_LAUNCH(k_seq_elem_fill, dim3(ntiles, islands), dim3(SMC_BLOCK), st, W, n, (const double*)q.tsum, (const u64*)q.Pt,
                    (const SeqX*)q.xlist, q.need, (const int*)q.tbase, S, gate);
-        fb.only_if = q.need;                                   // the tile walk: only where the fast path gave up
+        fb.only_if = q.need;                                   // only where the fast path gave up
+        SMC_LAUNCH(k_seq_fallback, dim3(islands), dim3(SMC_BLOCK), st, W, n, S, fb);
+        return;
     }
     SMC_LAUNCH(k_seq_tile_classify, dim3(ntiles, islands), dim3(SMC_BLOCK), st, W, n, (const double*)q.tsum, q.tk, q.tT, fb);
     SMC_LAUNCH(k_seq_chain, dim3(islands), dim3(SMC_BLOCK), st, W, n, ntiles, q.tk, (const u64*)q.tT, q.tstart, S, q.nseq, fb);

@@ -1009,8 +1009,8 @@ def check_seq_prefix_sums(sizes=(5000, 1 << 14, 20001), monkeypatch=None):
             fast += fb == 0
             if name in ("lognormal", "uniform", "collapsed", "sparse", "dyadic", "late mass"):
                 assert fb == 0, (N, name)                        # these stay on the element-level pass
-            if name in ("very skewed", "ties") and N >= 16384:
-                assert fb == -1, (N, name)                       # more exceptions than the list holds: the tile walk
+            if name == "ties" and N >= 16384:
+                assert fb == -1, (N, name)                       # more exceptions than the list holds: the exact fallback
     assert fast >= 6 * len(sizes)
     if monkeypatch is not None:
         y = [np.array([v]) for v in 0.4 * np.cumsum(np.random.RandomState(2).standard_normal(6))]

@@ -39,13 +39,14 @@ for log2N in (16, 20, 22):
         same = np.array_equal(a.view(np.uint64), b.view(np.uint64)) and np.array_equal(a2.view(np.uint64), b.view(np.uint64))
         t = {}
         for mode in (0, 2, 1):
-            ctx().sync()
-            t0 = time.perf_counter()
-            reps = 20 if mode != 1 else 3
-            for _ in range(reps):
+            ts = []
+            for _ in range(9 if mode != 1 else 3):             # (one call per device synchronisation; the median)
+                ctx().sync()
+                t0 = time.perf_counter()
                 seq(d, Sa, N, mode)
-            ctx().sync()
-            t[mode] = (time.perf_counter() - t0) / reps * 1e6
+                ctx().sync()
+                ts.append(time.perf_counter() - t0)
+            t[mode] = float(np.median(ts)) * 1e6
         print("N=2^%d %-10s %s  element pass %s %8.1f us | tile walk alone (%4d of %5d tiles exact) %8.1f us | literal walk %9.1f us"
               % (log2N, name, "EQUAL" if same else "DIFFERENT (%d)" % int((a != b).sum()), "fell back" if fb else "        ",
                  t[0], nseq, N // 1024, t[2], t[1]), flush=True)
