@@ -52,6 +52,11 @@
 #define F_PASS (SMC_BLOCK * 4)      /* offspring per pass: 4 per thread */
 #define SUMM_STRIDE 8   /* ESS, log_mean, loglt, logLt, rs_flag, m, 1/s, - */
 #define PARAM_STRIDE 32  /* 16 model constants (the host's params row), then RN(1 / constant) of each */
+#ifdef SMC_PARAMS_IN_GLOBAL              /* (A/B builds: k_propagate reading the constants through the argument's pointer) */
+#define SMC_PARAMS_GLOBAL 1
+#else
+#define SMC_PARAMS_GLOBAL 0
+#endif
 #define PARAM_HOST 16
 #define INFO_STRIDE 8   /* per-island step record: t, rs_flag, y_t, m, 1/s of step t-1, aux_t */
 
@@ -1338,6 +1343,14 @@ k_propagate(const FArgs av)
     // indices; the tables go to LDS as soon as they are back -- the indices are still on their way
     SmcNtabRegs<SMC_BLOCK> ntr;
     smc_ntab_fetch<SMC_BLOCK>(ntr, tid);
+    // the island's model constants: staged in LDS with the tables (same barrier).  Read through the kernel
+    // argument's pointer they are global loads the compiler has to repeat behind every store it cannot see through
+    // (the streaming stores are inline asm with a memory clobber, the plain ones may alias) -- and a repeated global
+    // load in the middle of the move / weigh phase waits, in order, for the stores just issued in front of it
+    // (s_waitcnt vmcnt(0): a round trip to HBM).  From LDS they are ds_reads that wait for nothing of the kind.
+    __shared__ double s_par[PARAM_STRIDE];
+    double par_reg = 0.0;
+    if (!SMC_PARAMS_GLOBAL && tid < PARAM_STRIDE) par_reg = smc_ldg(a.params + (i64)isl * PARAM_STRIDE + tid);
 #ifndef SMC_EMULATE
     asm volatile("" ::: "memory");                    // (the table loads are ISSUED first: vmcnt retires in order)
 #endif
@@ -1351,6 +1364,7 @@ k_propagate(const FArgs av)
     }
 #endif
     smc_ntab_store<SMC_BLOCK>(ntr, s_ntab, tid);
+    if (!SMC_PARAMS_GLOBAL && tid < PARAM_STRIDE) s_par[tid] = par_reg;
     __syncthreads();
 #ifdef SMC_PHILOX_LATE                             // (A/B builds: the calls behind the table barrier, as in r04)
     if (spec_z) {
@@ -1370,7 +1384,7 @@ k_propagate(const FArgs av)
     const i64 t = (i64)smc_uniform(r0);
     if (t >= a.T) return;
     F_STAMP(1);
-    const double* p = a.params + (i64)isl * PARAM_STRIDE;
+    const double* p = SMC_PARAMS_GLOBAL ? a.params + (i64)isl * PARAM_STRIDE : s_par;
     const double yt = smc_uniform(r2);
     const double aux = m_has_aux<KIND>() ? smc_uniform(r5) : 0.0;
     double* Xn = (SPEC ? a.X + (i64)a.par * a.xslot : f_X(a, t)) + (i64)isl * N;
