@@ -1341,8 +1341,7 @@ k_propagate(const FArgs av)
     double xg[OPT];
     // ---- request order: step record (above), Box-Muller tables (6 KB, L2-resident), ancestor
     // indices; the tables go to LDS as soon as they are back -- the indices are still on their way
-    SmcNtabRegs<SMC_BLOCK> ntr;
-    smc_ntab_fetch<SMC_BLOCK>(ntr, tid);
+    smc_ntab_stage_async<SMC_BLOCK>(s_ntab, tid);
     // the island's model constants: staged in LDS with the tables (same barrier).  Read through the kernel
     // argument's pointer they are global loads the compiler has to repeat behind every store it cannot see through
     // (the streaming stores are inline asm with a memory clobber, the plain ones may alias) -- and a repeated global
@@ -1363,7 +1362,6 @@ k_propagate(const FArgs av)
         smc_normal_bits(a.seed, (u32)(own.nb >> 1), (u32)a.tk, gisl, SMC_STREAM_NORMAL, pb0, pb1);
     }
 #endif
-    smc_ntab_store<SMC_BLOCK>(ntr, s_ntab, tid);
     if (!SMC_PARAMS_GLOBAL && tid < PARAM_STRIDE) s_par[tid] = par_reg;
     __syncthreads();
 #ifdef SMC_PHILOX_LATE                             // (A/B builds: the calls behind the table barrier, as in r04)
@@ -1413,7 +1411,9 @@ k_propagate(const FArgs av)
     double xkeep[OPT] = {0.0, 0.0, 0.0, 0.0};      // APF: the new particles, for the auxiliary weights
 #pragma unroll
     for (int k = 0; k < OPT; ++k) lw[k] = -INFINITY;
-    if (own.na < N) {
+    if (mine) {                                     // (whole tiles: every thread -- no path around the block on which
+        // the speculative loads would still be pending, which cost a vmcnt(0) -- the X / lw stores' acknowledgement
+        // -- at the join, in front of the tile's weights)
         double xp[OPT], lwp[OPT], z[OPT];
         // ---- ancestor indices (when resampled) or the particle's own state and
         // log-weight: requested first, consumed after the normals are generated
