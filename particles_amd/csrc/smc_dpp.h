@@ -108,6 +108,42 @@ __device__ __forceinline__ double smc_wave_scan_add_f64(double v)
     v = v + smc_dpp_f64<SMC_DPP_ROW_BCAST31, 0xc, false>(v);
     return v;
 }
+// two independent scans, step by step side by side: a DPP move must wait two cycles for the VALU result it reads,
+// and each chain alone is six such dependent steps -- written (and, with the scheduler kept out, issued) alternately
+// each chain's add covers the other's wait.  Same operations per chain, hence the same bits as two calls above.
+#define SMC_SCAN2_STEP(OP, CTRL, MASK)                     \
+    {                                                      \
+        const auto ta = OP<CTRL, MASK, false>(a);          \
+        const auto tb = OP<CTRL, MASK, false>(b);          \
+        a = a + ta;                                        \
+        b = b + tb;                                        \
+    }
+__device__ __forceinline__ void smc_wave_scan_add_f64x2(double& a, double& b)
+{
+    SMC_SCAN2_STEP(smc_dpp_f64, SMC_DPP_ROW_SHR(1), 0xf)
+    SMC_SCAN2_STEP(smc_dpp_f64, SMC_DPP_ROW_SHR(2), 0xf)
+    SMC_SCAN2_STEP(smc_dpp_f64, SMC_DPP_ROW_SHR(4), 0xf)
+    SMC_SCAN2_STEP(smc_dpp_f64, SMC_DPP_ROW_SHR(8), 0xf)
+    SMC_SCAN2_STEP(smc_dpp_f64, SMC_DPP_ROW_BCAST15, 0xa)
+    SMC_SCAN2_STEP(smc_dpp_f64, SMC_DPP_ROW_BCAST31, 0xc)
+}
+__device__ __forceinline__ void smc_wave_scan_add_u64x2(u64& a, u64& b)
+{
+    SMC_SCAN2_STEP(smc_dpp64, SMC_DPP_ROW_SHR(1), 0xf)
+    SMC_SCAN2_STEP(smc_dpp64, SMC_DPP_ROW_SHR(2), 0xf)
+    SMC_SCAN2_STEP(smc_dpp64, SMC_DPP_ROW_SHR(4), 0xf)
+    SMC_SCAN2_STEP(smc_dpp64, SMC_DPP_ROW_SHR(8), 0xf)
+    SMC_SCAN2_STEP(smc_dpp64, SMC_DPP_ROW_BCAST15, 0xa)
+    SMC_SCAN2_STEP(smc_dpp64, SMC_DPP_ROW_BCAST31, 0xc)
+}
+#undef SMC_SCAN2_STEP
+// the two sums of a wave (every lane receives them)
+__device__ __forceinline__ void smc_wave_sum2(double& a, double& b)
+{
+    smc_wave_scan_add_f64x2(a, b);
+    a = smc_readlane_f64(a, 63);
+    b = smc_readlane_f64(b, 63);
+}
 // max of two doubles in one instruction (fmax() canonicalises both operands
 // first: three v_max_f64); NaNs never reach the reductions (sanitised to -inf)
 __device__ __forceinline__ double smc_max2(double a, double b)

@@ -1199,11 +1199,11 @@ __device__ __forceinline__ F2Tile f2_tile_weights(const double (&lw)[4], u64 (&c
         // even integer: the same value as (u64)rint(e * 2^49), in 2 instructions instead of 10)
         q[i] = (u64)__double_as_longlong(fma(e, 562949953421312.0, 4503599627370496.0)) & 0x000FFFFFFFFFFFFFull;
     }
-    s1 = smc_wave_sum(s1);
-    s2 = smc_wave_sum(s2);
+    smc_wave_sum2(s1, s2);
     // the thread's pairs are 128 particles apart (f_own): the wave's first pairs come first
     const u64 sa = q[0] + q[1], sb = q[2] + q[3];
-    const u64 incA = smc_wave_scan_add_u64(sa), incB = smc_wave_scan_add_u64(sb);
+    u64 incA = sa, incB = sb;
+    smc_wave_scan_add_u64x2(incA, incB);
     const u64 totA = smc_readlane64(incA, 63), totB = smc_readlane64(incB, 63);
     if (lane == 0) { s_s[wave] = s1; s_s[SMC_NWAVE + wave] = s2; s_c[wave] = totA + totB; }
     __syncthreads();

@@ -31,7 +31,8 @@ k_ancestors2w(const FArgs av)
     __shared__ __attribute__((aligned(16))) u32 sP_all[TPW][WIN];
     __shared__ double s_max[SMC_NWAVE];                                    // one area per exchange
     __shared__ double s_sum[2 * SMC_NWAVE];
-    __shared__ double s_g[TPW * SMC_NWAVE + TPW];                          // per tile: shares before it, per wave; the TPW shares
+    __shared__ double s_wt[SMC_NWAVE];                                     // the shares held by each reducing wave
+    __shared__ double s_before[TPW], s_Qb[TPW];                            // per tile: shares before it within its wave; its own
     __shared__ int s_dec;
     __shared__ u32 s_mx_all[TPW][2 * SMC_NWAVE];
     __shared__ i64 s_n_all[TPW][2];
@@ -57,6 +58,7 @@ k_ancestors2w(const FArgs av)
     u32* sP = sP_all[st];
     u32* s_mx = s_mx_all[st];
     const i64 N = a.N;
+    F_STAMP_A(0);
     const i64 j0 = (i64)b * F_TILE;
     const i64 jt = j0 + (i64)tid * F_IPT;
     double* info = a.info + (i64)isl * INFO_STRIDE;
@@ -85,6 +87,7 @@ k_ancestors2w(const FArgs av)
         return;
     }
     if (t == 0) return;                                        // the host wrote the record of step 0
+    F_STAMP_A(1);
     SmcSu su;                                                  // (the step's uniform: one Philox call,
     u64 Us;                                                    //  all inputs uniform: scalar unit)
     f2_su(a, isl, t, su, Us, SCH);
@@ -95,6 +98,7 @@ k_ancestors2w(const FArgs av)
         if (lane == 0) s_max[wave] = tm;
     }
     __syncthreads();                                           // (1) also: sP zeroed
+    F_STAMP_A(2);
     double v4[4] = {0.0, 0.0, 0.0, 0.0};
     F2Red r;
     r.K = 0.0;
@@ -110,8 +114,7 @@ k_ancestors2w(const FArgs av)
             s1 = s1 + v4[k];
             s2 = s2 + w;
         }
-        s1 = smc_wave_sum(s1);
-        s2 = smc_wave_sum(s2);
+        smc_wave_sum2(s1, s2);
         if (lane == 0) { s_sum[wave] = s1; s_sum[SMC_NWAVE + wave] = s2; }
     }
     __syncthreads();                                           // (2)
@@ -125,35 +128,36 @@ k_ancestors2w(const FArgs av)
         const bool resample = r.ess < a.ess_thresh;            // core.py:181-183 (t < T here)
         if (blockIdx.x == 0 && tid == 0) f2_write_record(a, isl, t, r, resample);
         if (tid == 0) s_dec = resample ? 1 : 0;
-        // ---- the shares Q_b of this workgroup's tiles and the shares before each of them
-        double qbefore[TPW];
+        // ---- the shares Q_b of this workgroup's tiles and the shares before each of them: ONE scan of the
+        // threads' sums (integers below 2^53: every association gives the same doubles), from which the thread
+        // that holds tile b's partial (tid == b / 4) reads off what lies in front of b within its wave; the
+        // waves' totals complete it on the other side of the barrier
+        double Q4[4];
 #pragma unroll
-        for (int q = 0; q < TPW; ++q) qbefore[q] = 0.0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = tid * 4 + k;
-            const double Qk = (i < a.nparts) ? f2_share(v4[k], r.rs) : 0.0;
-#pragma unroll
-            for (int q = 0; q < TPW; ++q) {
-                const int bq = b_first + q * b_step;
-                qbefore[q] += (i < bq) ? Qk : 0.0;
-                if (i == bq) s_g[TPW * SMC_NWAVE + q] = Qk;
-            }
-        }
+        for (int k = 0; k < 4; ++k) Q4[k] = (tid * 4 + k < a.nparts) ? f2_share(v4[k], r.rs) : 0.0;
+        const double q01 = Q4[0] + Q4[1], q012 = q01 + Q4[2], qsum = q012 + Q4[3];
+        const double incl = smc_wave_scan_add_f64(qsum);
+        if (lane == 63) s_wt[wave] = incl;
 #pragma unroll
         for (int q = 0; q < TPW; ++q) {
-            const double qs = smc_wave_sum(qbefore[q]);        // (integers below 2^53: exact)
-            if (lane == 0) s_g[q * SMC_NWAVE + wave] = qs;
+            const int bq = b_first + q * b_step;
+            if (tid == (bq >> 2)) {
+                const int kk = bq & 3;
+                s_before[q] = (incl - qsum) + (kk == 0 ? 0.0 : (kk == 1 ? Q4[0] : (kk == 2 ? q01 : q012)));
+                s_Qb[q] = kk == 0 ? Q4[0] : (kk == 1 ? Q4[1] : (kk == 2 ? Q4[2] : Q4[3]));
+            }
         }
     }
     __syncthreads();                                           // (3)
+    F_STAMP_A(3);
     if (!s_dec) return;
-    double Gd = s_g[st * SMC_NWAVE];
+    double Gd = s_before[st];
+    const int wave_b = b >> 8;                                 // the wave of the thread that holds tile b's partial
 #pragma unroll
-    for (int w = 1; w < SMC_NWAVE; ++w) Gd = Gd + s_g[st * SMC_NWAVE + w];
+    for (int w = 0; w < SMC_NWAVE - 1; ++w) Gd = Gd + (w < wave_b ? s_wt[w] : 0.0);
     double Qall[TPW];
 #pragma unroll
-    for (int k = 0; k < TPW; ++k) Qall[k] = s_g[TPW * SMC_NWAVE + k];
+    for (int k = 0; k < TPW; ++k) Qall[k] = s_Qb[k];
     double Qd = Qall[0];
 #pragma unroll
     for (int k = 1; k < TPW; ++k) Qd = (k == st) ? Qall[k] : Qd;
@@ -222,6 +226,7 @@ k_ancestors2w(const FArgs av)
         n_lo = s_n[0];
         n_hi = s_n[1];
     }
+    F_STAMP_A(4);
     u32* A = f_A(a, t) + (i64)isl * N;
     // (32-bit arithmetic from here on: N <= 2^30 on this path, offspring indices fit)
     u32 nsu[F_IPT + 1];
@@ -309,6 +314,7 @@ k_ancestors2w(const FArgs av)
     if (!slow) {                                   // one window per tile (an empty tile goes through the barriers)
         const bool act = lo < hi;
         pass(act ? (lo & ~3u) : 0u, act);
+        F_STAMP_A(5);
         return;
     }
     // ---- the general case, all tiles together.  Heavy parents (>= 2048 offspring): registered, their

@@ -32,6 +32,7 @@ buf = np.zeros((nparts + ntiles) * 8, dtype=np.uint64)
 lib = _lib.lib()
 lib.smc_debug_trace.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 _lib.check(lib.smc_debug_trace(pf._f, buf.ctypes.data_as(ctypes.c_void_p)))
+wide = two_level_wide = log2N <= 20 and scheme != "multinomial" and not os.environ.get("SMC_NO_WIDE")
 two_level = not (os.environ.get("SMC_FLAT_CDF") or os.environ.get("SMC_FORCE_FUSED"))
 for name, st, labels in (
         ("k_ancestors2" if two_level else "k_ancestors<true>", buf[nparts * 8:].reshape(ntiles, 8),
@@ -41,6 +42,10 @@ for name, st, labels in (
          ["start", "record", "loads+normals", "stores issued", "partial written"] if two_level
          else ["start", "record", "loads+normals", "stores issued", "wg reduced", "shard ticket",
                "top ticket", "finalised"])):
+    raw = st
+    st = st[st[:, 0] > 0]                                       # (k_ancestors2w: one row per workgroup of TPW tiles)
+    if wide and name.startswith("k_ancestors2"):
+        name, labels = "k_ancestors2w", ["start", "t known", "max exchanged", "shares known", "counts", "end"]
     t0 = st[:, 0].min()
     print("%s: %d workgroups, last start +%.2f us" % (name, st.shape[0], (st[:, 0].max() - t0) / 100.0))
     for k, lab in enumerate(labels):
@@ -51,6 +56,19 @@ for name, st, labels in (
         print("  %-16s n=%5d  min %6.2f  median %6.2f  p90 %6.2f  p99 %6.2f  max %6.2f us (wg %d)"
               % (lab, col.size, col.min() / 100.0, np.median(col) / 100.0, np.percentile(col, 90) / 100.0,
                  np.percentile(col, 99) / 100.0, col.max() / 100.0, int(np.argmax(st[:, k]))))
+    if os.environ.get("TRACE_WHO"):
+        # who is late?  per stamp: workgroups later than median + 1 us, by XCD (index % 8) and by index range
+        idx = np.nonzero(raw[:, 0] > 0)[0]
+        for k, lab in enumerate(labels):
+            col = (st[:, k].astype(np.int64) - int(t0)) / 100.0
+            late = col > np.median(col) + 1.0
+            if late.sum() == 0:
+                continue
+            print("    late at %-16s %4d wgs; by xcd %s; by eighth of the grid %s; start of the late %.2f (all %.2f)"
+                  % (lab, late.sum(), np.bincount(idx[late] % 8, minlength=8).tolist(),
+                     np.bincount(idx[late] * 8 // raw.shape[0], minlength=8).tolist(),
+                     np.median((st[late, 0].astype(np.int64) - int(t0)) / 100.0),
+                     np.median((st[:, 0].astype(np.int64) - int(t0)) / 100.0)))
     if st.shape[0] > 1024:
         # several rounds of workgroups: what a workgroup spends between two of its own stamps
         print("  per workgroup, between consecutive stamps (median / p90 us):")
