@@ -40,25 +40,45 @@ __device__ __forceinline__ double smc_fma_k(double p, double r, double K)
 #define SMC_FMA_K(p, r, K) smc_fma_k((p), (r), (K))
 #endif
 
-SMC_CONST double smc_k_exp[16] = {
+// The coefficient tables are used by functions the host can call too (the debug entry points of smc_api.hip).  A
+// static device variable that a __host__ __device__ function names is externalised by the compiler, and an external
+// symbol of a -fPIC code object is addressed through the GOT: one more dependent scalar load in front of every
+// s_load of a coefficient (k_propagate: three such chains on its common path).  So each table exists twice -- a
+// device copy that only a __device__ accessor names, a host copy -- and SMC_K(name) picks by compilation pass.
+#ifdef SMC_EMULATE
+#define SMC_K_TABLE(name, n, ...) static const double name[n] = {__VA_ARGS__};
+#define SMC_K(name) name
+#else
+#define SMC_K_TABLE(name, n, ...)                                          \
+    static __constant__ const double name##_dev[n] = {__VA_ARGS__};        \
+    static const double name##_host[n] = {__VA_ARGS__};                    \
+    __device__ __forceinline__ const double* name##_ptr() { return name##_dev; }
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SMC_K(name) name##_ptr()
+#else
+#define SMC_K(name) name##_host
+#endif
+#endif
+
+SMC_K_TABLE(smc_k_exp, 16,
     1.6059043836821613e-10, 2.0876756987868100e-09, 2.5052108385441720e-08,
     2.7557319223985888e-07, 2.7557319223985893e-06, 2.4801587301587302e-05,
     1.9841269841269841e-04, 1.3888888888888889e-03, 8.3333333333333332e-03,
     4.1666666666666664e-02, 1.6666666666666666e-01, 0.5,
-    1.4426950408889634074, 6.93147180369123816490e-01, 1.90821492927058770002e-10, -745.2};
-SMC_CONST double smc_k_log[10] = {
+    1.4426950408889634074, 6.93147180369123816490e-01, 1.90821492927058770002e-10, -745.2)
+SMC_K_TABLE(smc_k_log, 10,
     1.531383769920937332e-01, 2.222219843214978396e-01, 3.999999999940941908e-01,
     1.479819860511658591e-01, 1.818357216161805012e-01, 2.857142874366239149e-01,
     6.666666666666735130e-01, 0.70710678118654752440, 6.93147180369123816490e-01,
-    1.90821492927058770002e-10};
-SMC_CONST double smc_k_sc[18] = {
+    1.90821492927058770002e-10)
+SMC_K_TABLE(smc_k_sc, 18,
     2.8114572543455206e-15, -7.6471637318198164e-13, 1.6059043836821613e-10,
     -2.5052108385441720e-08, 2.7557319223985893e-06, -1.9841269841269841e-04,
     8.3333333333333332e-03, -1.6666666666666666e-01,
     -1.5619206968586225e-16, 4.7794773323873853e-14, -1.1470745597729725e-11,
     2.0876756987868100e-09, -2.7557319223985888e-07, 2.4801587301587302e-05,
     -1.3888888888888889e-03, 4.1666666666666664e-02,
-    3.14159265358979311600e+00, 1.22464679914735317723e-16};
+    3.14159265358979311600e+00, 1.22464679914735317723e-16)
 
 // exp(x) = p 2^k without forming 2^k: k = round(x / ln 2) (returned as an integer-valued double),
 // p = P(x - k ln 2) in [0.7071, 1.4143].  The two-level CDF path carries weights as such pairs:
@@ -67,7 +87,7 @@ SMC_CONST double smc_k_sc[18] = {
 // x = -inf gives k = -inf and p = NaN: callers select (p, k) = (0, -inf) for it.
 __host__ __device__ __forceinline__ double smc_expk(double x, double& k)
 {
-    const double* K = smc_k_exp;
+    const double* K = SMC_K(smc_k_exp);
     k = rint(x * K[12]);
     double r = fma(-k, K[13], x);                          // ln2 high part
     r = fma(-k, K[14], r);                                 // ln2 low part
@@ -89,7 +109,7 @@ __host__ __device__ __forceinline__ double smc_scale_pk(double p, double k, doub
 
 __host__ __device__ __forceinline__ double smc_exp_nonpos(double x)
 {
-    const double* K = smc_k_exp;
+    const double* K = SMC_K(smc_k_exp);
     // k = round(x / ln2), r = x - k ln2 (Cody-Waite, two-part ln2), |r| <= ln2/2
     const double k = rint(x * K[12]);
     double r = fma(-k, K[13], x);                          // ln2 high part
@@ -113,7 +133,7 @@ __host__ __device__ __forceinline__ double smc_exp_nonpos(double x)
 // libm entry point (which also handles 0, inf, NaN, subnormals).
 __host__ __device__ __forceinline__ double smc_log_pos(double x)
 {
-    const double* K = smc_k_log;
+    const double* K = SMC_K(smc_k_log);
     int e;
     double m = frexp(x, &e);                       // m in [0.5, 1)
     const bool lo = m < K[7];
@@ -219,13 +239,13 @@ __device__ __forceinline__ void smc_ntab_stage(SmcD2* lds, const int tid)
     smc_ntab_store<NTH>(r, lds, tid);
 }
 
-SMC_CONST double smc_k_bm[16] = {
+SMC_K_TABLE(smc_k_bm, 16,
     1.0 / 7.0, -1.0 / 6.0, 0.2, -0.25, 1.0 / 3.0, -0.5,                  // log1p
     6.93147180369123816490e-01, 1.90821492927058770002e-10,              // ln2 hi, lo
     0.024543692606170259675,                                             // 2 pi / 256
     1.0 / 120.0, -1.0 / 6.0,                                             // sin x - x
     -1.0 / 720.0, 1.0 / 24.0, -0.5,                                      // cos x - 1
-    0x1.fffffffffffffp-1, 0x1.7ffffffffffcp+0};                          // 1 - 2^-53, 1.5 - 2^-45
+    0x1.fffffffffffffp-1, 0x1.7ffffffffffcp+0)                          // 1 - 2^-53, 1.5 - 2^-45
 
 #ifdef SMC_EMULATE
 __host__ __device__ __forceinline__ double smc_frexp_m(double x, int& e) { return frexp(x, &e); }
@@ -242,7 +262,7 @@ __device__ __forceinline__ double smc_rsq(double x) { return __builtin_amdgcn_rs
 // log u for u = ((a >> 12) + 1/2) 2^-52 in (0, 1): < 0, <= 3 ulp; tab: the staged tables (LDS)
 __host__ __device__ __forceinline__ double smc_log_u52(const SmcD2* tab, const u64 a)
 {
-    const double* K = smc_k_bm;
+    const double* K = SMC_K(smc_k_bm);
     const double D = __longlong_as_double((long long)((a >> 12) | 0x3FF0000000000000ull));   // 1 + k 2^-52
     const double u = D - K[14];                                 // (k + 1/2) 2^-52, exact
     int e;
@@ -267,7 +287,7 @@ __host__ __device__ __forceinline__ double smc_log_u52(const SmcD2* tab, const u
 __host__ __device__ __forceinline__ void smc_bm_pair(const SmcD2* tab, const u64 a, const u64 b,
                                                      double& z0, double& z1)
 {
-    const double* K = smc_k_bm;
+    const double* K = SMC_K(smc_k_bm);
     const double L = smc_log_u52(tab, a);                       // log u1 < 0
     // ---- radius sqrt(-2 L)
     const double s = -2.0 * L;
@@ -295,7 +315,7 @@ __host__ __device__ __forceinline__ void smc_bm_pair(const SmcD2* tab, const u64
 
 __host__ __device__ __forceinline__ void smc_sincospi_02(double a, double* sn, double* cs)
 {
-    const double* K = smc_k_sc;
+    const double* K = SMC_K(smc_k_sc);
     // a = q/2 + r, q in {0..4}, |r| <= 1/4 ; x = pi r in [-pi/4, pi/4]
     const double qd = rint(a + a);
     const double r = fma(-0.5, qd, a);
