@@ -137,6 +137,31 @@ __device__ __forceinline__ void smc_wave_scan_add_u64x2(u64& a, u64& b)
     SMC_SCAN2_STEP(smc_dpp64, SMC_DPP_ROW_BCAST31, 0xc)
 }
 #undef SMC_SCAN2_STEP
+// two inclusive scans of values below 2^51 as four scans of limbs (26 low bits, 25 high): 64 limbs sum to less than
+// 2^32, so no carry ever leaves a limb on the way, each step of each limb is ONE v_add_u32 with a DPP operand, and
+// (high << 26) + low puts the exact sums back together -- 12 instructions per scan instead of 24 and none of the
+// waits between a 64-bit add and the move that reads it.  Integer arithmetic: the same values as the 64-bit scans.
+__device__ __forceinline__ unsigned smc_wave_scan_add_u32(unsigned v)
+{
+    v += smc_dpp<SMC_DPP_ROW_SHR(1), 0xf, true>(0u, v);
+    v += smc_dpp<SMC_DPP_ROW_SHR(2), 0xf, true>(0u, v);
+    v += smc_dpp<SMC_DPP_ROW_SHR(4), 0xf, true>(0u, v);
+    v += smc_dpp<SMC_DPP_ROW_SHR(8), 0xf, true>(0u, v);
+    v += smc_dpp<SMC_DPP_ROW_BCAST15, 0xa, true>(0u, v);
+    v += smc_dpp<SMC_DPP_ROW_BCAST31, 0xc, true>(0u, v);
+    return v;
+}
+__device__ __forceinline__ void smc_wave_scan_add_u51x2(u64& a, u64& b)
+{
+    unsigned al = (unsigned)a & 0x3FFFFFFu, ah = (unsigned)(a >> 26);
+    unsigned bl = (unsigned)b & 0x3FFFFFFu, bh = (unsigned)(b >> 26);
+    al = smc_wave_scan_add_u32(al);
+    ah = smc_wave_scan_add_u32(ah);
+    bl = smc_wave_scan_add_u32(bl);
+    bh = smc_wave_scan_add_u32(bh);
+    a = ((u64)ah << 26) + al;
+    b = ((u64)bh << 26) + bl;
+}
 // the two sums of a wave (every lane receives them)
 __device__ __forceinline__ void smc_wave_sum2(double& a, double& b)
 {

@@ -1185,9 +1185,8 @@ __device__ __forceinline__ F2Tile f2_tile_weights(const double (&lw)[4], u64 (&c
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         p[i] = smc_expk(lw[i], k[i]);
-        const bool ok = lw[i] > -INFINITY;
-        p[i] = ok ? p[i] : 0.0;
-        k[i] = ok ? k[i] : -INFINITY;
+        p[i] = (lw[i] > -INFINITY) ? p[i] : 0.0;   // (k is -inf by itself there: rint(-inf log2 e); NaNs never arrive,
+                                                   //  the callers turn them into -inf)
     }
     double km = smc_max2(smc_max2(k[0], k[1]), smc_max2(k[2], k[3]));
     km = smc_wave_max(km);
@@ -1211,8 +1210,8 @@ __device__ __forceinline__ F2Tile f2_tile_weights(const double (&lw)[4], u64 (&c
     smc_wave_sum2(s1, s2);
     // the thread's pairs are 128 particles apart (f_own): the wave's first pairs come first
     const u64 sa = q[0] + q[1], sb = q[2] + q[3];
-    u64 incA = sa, incB = sb;
-    smc_wave_scan_add_u64x2(incA, incB);
+    u64 incA = sa, incB = sb;                      // (q < 2^50: the pairs' sums fit 51 bits)
+    smc_wave_scan_add_u51x2(incA, incB);
     const u64 totA = smc_readlane64(incA, 63), totB = smc_readlane64(incB, 63);
     if (lane == 0) { s_s[wave] = s1; s_s[SMC_NWAVE + wave] = s2; s_c[wave] = totA + totB; }
     __syncthreads();
@@ -1489,7 +1488,7 @@ k_propagate(const FArgs av)
             xn[k] = m_step<KIND, FK>(p, first, yt, aux, xp[k], z[k], inc);
             double l = (first || (resample && !APF)) ? inc : lwp[k] + inc;    // resampling.py:241-244
             if (l != l) l = -INFINITY;                                     // resampling.py:220
-            lw[k] = (f_own_idx(own, k) < N) ? l : -INFINITY;
+            lw[k] = (ALL_IN && RAGGED == 0) ? l : ((f_own_idx(own, k) < N) ? l : -INFINITY);   // (whole tiles: all in)
             if (APF) xkeep[k] = xn[k];
         }
         if (full_st) {

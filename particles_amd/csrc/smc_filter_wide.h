@@ -181,8 +181,6 @@ k_ancestors2w(const FArgs av)
             const i64 j = jt + i;
             ns[i] = (j == 0) ? 0 : (j >= N ? N : f2_ns_sys<true>(a, su, Us, f, cx[i]));
         }
-        n_lo = (b == 0) ? 0 : f2_ns_sys<true>(a, su, Us, f, 0ull);
-        n_hi = (b == a.ntiles - 1) ? N : f2_ns_sys<true>(a, su, Us, f, tb);
     } else {
         // the stratified uniforms of each tile's offspring staged in LDS (k_ancestors2: F2_SU_PAIRS Philox calls per
         // tile instead of one per boundary); every tile of the workgroup must fit its window -- the barrier is shared
@@ -219,6 +217,10 @@ k_ancestors2w(const FArgs av)
                 ns[i] = (j == 0) ? 0 : (j >= N ? N : f2_ns_strat(a, su, Us, f, cx[i]));
             }
         }
+    }
+    {
+        // the tile's range [n_lo, n_hi): its first thread's first count and its last thread's last (positions 0 and
+        // t_b of the tile's CDF) -- handed round through LDS; evaluating them in every thread was 2 of its 7 counts
         i64* s_n = s_n_all[st];
         if (tid == 0) s_n[0] = ns[0];
         if (tid == SMC_BLOCK - 1) s_n[1] = ns[F_IPT];
