@@ -2671,8 +2671,19 @@ k_ancestors2(const FArgs av)
             const i64 j = jt + i;
             ns[i] = (j == 0) ? 0 : (j >= N ? N : f2_ns_sys<POW2>(a, su, Us, f, cx[i]));
         }
-        n_lo = (b == 0) ? 0 : f2_ns_sys<POW2>(a, su, Us, f, 0ull);
-        n_hi = (b == a.ntiles - 1) ? N : f2_ns_sys<POW2>(a, su, Us, f, tb);
+        if (POW2) {
+            // the tile's range: its first thread's first count and its last thread's last (positions 0 and t_b),
+            // handed round through LDS instead of evaluated by every thread (2 of its 7 counts)
+            __shared__ i64 s_nsys[2];
+            if (tid == 0) s_nsys[0] = ns[0];
+            if (tid == SMC_BLOCK - 1) s_nsys[1] = ns[F_IPT];
+            __syncthreads();
+            n_lo = s_nsys[0];
+            n_hi = s_nsys[1];
+        } else {
+            n_lo = (b == 0) ? 0 : f2_ns_sys<POW2>(a, su, Us, f, 0ull);
+            n_hi = (b == a.ntiles - 1) ? N : f2_ns_sys<POW2>(a, su, Us, f, tb);
+        }
         if (!POW2) {
             unsigned need = (n_lo < 0 ? 32u : 0u) | (n_hi < 0 ? 64u : 0u);
 #pragma unroll
