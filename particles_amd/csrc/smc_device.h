@@ -35,19 +35,41 @@ __device__ __forceinline__ int smc_wave() { return (int)(threadIdx.x >> 6); }
 #ifndef SMC_PHILOX_ROUNDS
 #define SMC_PHILOX_ROUNDS 10
 #endif
-__host__ __device__ __forceinline__ void smc_philox(u32 c0, u32 c1, u32 c2, u32 c3, u64 seed,
-                                           u64& x01, u64& x23)
+// a ^ b ^ c in one instruction (gfx950's v_bitop3_b32, truth table 0x96); left to itself the compiler keeps the
+// two v_xor_b32 of each of a round's two words -- 40 of a pair of calls' 116 vector instructions
+__host__ __device__ __forceinline__ u32 smc_xor3(u32 a, u32 b, u32 c)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SMC_EMULATE) && !defined(SMC_NO_BITOP3)
+    return (u32)__builtin_amdgcn_bitop3_b32((int)a, (int)b, (int)c, 0x96);
+#else
+    return a ^ b ^ c;
+#endif
+}
+template <bool XOR3>
+__host__ __device__ __forceinline__ void smc_philox_t(u32 c0, u32 c1, u32 c2, u32 c3, u64 seed,
+                                             u64& x01, u64& x23)
 {
     u32 k0 = (u32)seed, k1 = (u32)(seed >> 32);
 #pragma unroll
     for (int r = 0; r < SMC_PHILOX_ROUNDS; ++r) {
         if (r > 0) { k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
         const u64 p0 = (u64)0xD2511F53u * c0, p1 = (u64)0xCD9E8D57u * c2;   // v_mad_u64_u32
-        const u32 n0 = (u32)(p1 >> 32) ^ c1 ^ k0, n2 = (u32)(p0 >> 32) ^ c3 ^ k1;
+        const u32 h1 = (u32)(p1 >> 32), h0 = (u32)(p0 >> 32);
+        const u32 n0 = XOR3 ? smc_xor3(h1, c1, k0) : (h1 ^ c1 ^ k0), n2 = XOR3 ? smc_xor3(h0, c3, k1) : (h0 ^ c3 ^ k1);
         c0 = n0; c1 = (u32)p1; c2 = n2; c3 = (u32)p0;
     }
     x01 = ((u64)c1 << 32) | c0;
     x23 = ((u64)c3 << 32) | c2;
+}
+__host__ __device__ __forceinline__ void smc_philox(u32 c0, u32 c1, u32 c2, u32 c3, u64 seed, u64& x01, u64& x23)
+{
+    smc_philox_t<true>(c0, c1, c2, c3, seed, x01, x23);
+}
+// the same function for a call whose inputs are all wave-uniform (the systematic scheme's one draw): plain xors, which
+// the compiler keeps on the scalar unit together with the multiplies
+__host__ __device__ __forceinline__ void smc_philox_uniform(u32 c0, u32 c1, u32 c2, u32 c3, u64 seed, u64& x01, u64& x23)
+{
+    smc_philox_t<false>(c0, c1, c2, c3, seed, x01, x23);
 }
 
 // (0,1): 52 random bits + 1/2 ulp, exact in fp64, never 0 or 1

@@ -891,7 +891,7 @@ __device__ __forceinline__ void f_tile_offspring(const FArgs& a, const int isl, 
             su.u_sys = su.u[0];
         } else {
             u64 x0, x1;
-            smc_philox(0u, su.t, su.island, SMC_STREAM_RESAMPLE, su.seed, x0, x1);
+            smc_philox_uniform(0u, su.t, su.island, SMC_STREAM_RESAMPLE, su.seed, x0, x1);
             su.u_sys = smc_u01_halfopen(x0);
         }
     }
@@ -1650,7 +1650,7 @@ __device__ __forceinline__ void f2_su(const FArgs& a, const int isl, const i64 t
             su.u_sys = su.u[0];
         } else {
             u64 x0, x1;
-            smc_philox(0u, su.t, su.island, SMC_STREAM_RESAMPLE, su.seed, x0, x1);
+            smc_philox_uniform(0u, su.t, su.island, SMC_STREAM_RESAMPLE, su.seed, x0, x1);
             su.u_sys = smc_u01_halfopen(x0);
         }
     }
@@ -1961,7 +1961,7 @@ __device__ __forceinline__ void f2_sq_init(const FArgs& a, const int isl, const 
 {
     const u64 ctr = a.sq_ctr + (u64)t + ((u64)(u32)(a.island_offset + isl) << 32);
     u64 x0, x1;
-    smc_philox(0u, (u32)ctr, (u32)(ctr >> 32), SMC_STREAM_RESAMPLE, a.sq_seed, x0, x1);
+    smc_philox_uniform(0u, (u32)ctr, (u32)(ctr >> 32), SMC_STREAM_RESAMPLE, a.sq_seed, x0, x1);
     const u32 sh0 = (u32)(x0 >> 34);                                      // (smc_sobol_shift: 30 bits)
     q.sh = 30 - a.log2N;
     q.low = sh0 & ((1u << q.sh) - 1u);
@@ -2959,7 +2959,7 @@ k_strict_search(const FArgs av, const double* S, const double* su_mem)
         if (su.u) su.u_sys = su.u[0];
         else {
             u64 x0, x1;
-            smc_philox(0u, su.t, su.island, SMC_STREAM_RESAMPLE, su.seed, x0, x1);
+            smc_philox_uniform(0u, su.t, su.island, SMC_STREAM_RESAMPLE, su.seed, x0, x1);
             su.u_sys = smc_u01_halfopen(x0);
         }
     }

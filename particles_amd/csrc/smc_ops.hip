@@ -249,7 +249,7 @@ __device__ __forceinline__ SmcSu smc_su_prepare(SmcSu su)
             su.u_sys = su.u[0];
         } else {
             u64 a, b;
-            smc_philox(0u, su.t, su.island, SMC_STREAM_RESAMPLE, su.seed, a, b);
+            smc_philox_uniform(0u, su.t, su.island, SMC_STREAM_RESAMPLE, su.seed, a, b);
             su.u_sys = smc_u01_halfopen(a);
         }
     }
