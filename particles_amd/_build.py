@@ -15,7 +15,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
          "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
          # MFMA results straight into VGPRs (they are the next product's B operand):
          # no v_accvgpr_read/write copies
-         "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+         "-mllvm", "-amdgpu-mfma-vgpr-form=1",
+         # leading scalar kernel arguments preloaded into SGPRs by the command processor (kernels that take
+         # only the argument block are unaffected)
+         "-mllvm", "-amdgpu-kernarg-preload-count=14"]
 
 
 def _hipcc():

@@ -94,24 +94,26 @@ static void launch_propagate(smc_filter* f)
 #undef MV_CASE
         return;
     }
+// (k_propagate's leading arguments: the fields its first loads are addressed with, preloaded into SGPRs)
+#define P_LEAD f->a.A, f->a.info, f->a.params, f->a.hcnt, f->a.N, f->a.ntiles | (f->a.xcd_chunks ? 1 << 30 : 0)
 #define P_CASE(KINDV, FKV)                                                                    \
     if (f->kind == KINDV && f->fk == FKV) {                                                   \
         if (f->two_level && f->ragged == 1 && f->a.par >= 0)                                  \
-            SMC_LAUNCH((k_propagate<KINDV, FKV, F_OPT, true, false, 1>), grid, dim3(SMC_BLOCK), st, f->a);  \
+            SMC_LAUNCH((k_propagate<KINDV, FKV, F_OPT, true, false, 1>), grid, dim3(SMC_BLOCK), st, P_LEAD, f->a);  \
         else if (f->two_level && f->ragged == 1)                                              \
-            SMC_LAUNCH((k_propagate<KINDV, FKV, F_OPT, false, false, 1>), grid, dim3(SMC_BLOCK), st, f->a); \
+            SMC_LAUNCH((k_propagate<KINDV, FKV, F_OPT, false, false, 1>), grid, dim3(SMC_BLOCK), st, P_LEAD, f->a); \
         else if (f->two_level && f->ragged == 2 && f->a.par >= 0)                             \
-            SMC_LAUNCH((k_propagate<KINDV, FKV, F_OPT, true, false, 2>), grid, dim3(SMC_BLOCK), st, f->a);  \
+            SMC_LAUNCH((k_propagate<KINDV, FKV, F_OPT, true, false, 2>), grid, dim3(SMC_BLOCK), st, P_LEAD, f->a);  \
         else if (f->two_level && f->ragged == 2)                                              \
-            SMC_LAUNCH((k_propagate<KINDV, FKV, F_OPT, false, false, 2>), grid, dim3(SMC_BLOCK), st, f->a); \
+            SMC_LAUNCH((k_propagate<KINDV, FKV, F_OPT, false, false, 2>), grid, dim3(SMC_BLOCK), st, P_LEAD, f->a); \
         else if (f->two_level && f->a.par >= 0)                                               \
-            SMC_LAUNCH((k_propagate<KINDV, FKV, F_OPT, true, false>), grid, dim3(SMC_BLOCK), st, f->a);  \
+            SMC_LAUNCH((k_propagate<KINDV, FKV, F_OPT, true, false>), grid, dim3(SMC_BLOCK), st, P_LEAD, f->a);  \
         else if (f->two_level)                                                                \
-            SMC_LAUNCH((k_propagate<KINDV, FKV, F_OPT, false, false>), grid, dim3(SMC_BLOCK), st, f->a); \
+            SMC_LAUNCH((k_propagate<KINDV, FKV, F_OPT, false, false>), grid, dim3(SMC_BLOCK), st, P_LEAD, f->a); \
         else if (f->a.par >= 0)                                                               \
-            SMC_LAUNCH((k_propagate<KINDV, FKV, F_OPT, true>), grid, dim3(SMC_BLOCK), st, f->a);  \
+            SMC_LAUNCH((k_propagate<KINDV, FKV, F_OPT, true>), grid, dim3(SMC_BLOCK), st, P_LEAD, f->a);  \
         else                                                                                  \
-            SMC_LAUNCH((k_propagate<KINDV, FKV, F_OPT, false>), grid, dim3(SMC_BLOCK), st, f->a); \
+            SMC_LAUNCH((k_propagate<KINDV, FKV, F_OPT, false>), grid, dim3(SMC_BLOCK), st, P_LEAD, f->a); \
         return;                                                                               \
     }
     P_CASE(SMC_MODEL_LINGAUSS, SMC_FK_BOOTSTRAP)
@@ -127,6 +129,7 @@ static void launch_propagate(smc_filter* f)
     P_CASE(SMC_MODEL_SVLEVERAGE, SMC_FK_BOOTSTRAP)
     P_CASE(SMC_MODEL_DISCRETECOX, SMC_FK_BOOTSTRAP)
 #undef P_CASE
+#undef P_LEAD
 }
 
 // one time step: [k_prepare, (spacings), k_ancestors] do nothing unless the step
@@ -266,12 +269,14 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
             } else if (p2 && f->wide_tpw) {
                 // resident grid, N = 2^k: TPW tiles per workgroup, the partials reduced by its first 4 waves only
                 const dim3 gridw(f->a.ntiles / f->wide_tpw, f->a.n_islands);
+                // (leading arguments: the fields the kernel's first loads are addressed with, preloaded into SGPRs)
+#define W_LEAD f->a.info2, f->a.pm, f->a.ps, f->a.pss, f->a.cq, f->a.N, f->a.ntiles | (f->a.xcd_chunks ? 1 << 30 : 0)
                 if (f->wide_tpw == 4) {
-                    if (sys) SMC_LAUNCH((k_ancestors2w<4, SMC_SYSTEMATIC_>), gridw, dim3(SMC_BLOCK * 4), st, f->a);
-                    else SMC_LAUNCH((k_ancestors2w<4, SMC_STRATIFIED_>), gridw, dim3(SMC_BLOCK * 4), st, f->a);
+                    if (sys) SMC_LAUNCH((k_ancestors2w<4, SMC_SYSTEMATIC_>), gridw, dim3(SMC_BLOCK * 4), st, W_LEAD, f->a);
+                    else SMC_LAUNCH((k_ancestors2w<4, SMC_STRATIFIED_>), gridw, dim3(SMC_BLOCK * 4), st, W_LEAD, f->a);
                 } else {
-                    if (sys) SMC_LAUNCH((k_ancestors2w<2, SMC_SYSTEMATIC_>), gridw, dim3(SMC_BLOCK * 2), st, f->a);
-                    else SMC_LAUNCH((k_ancestors2w<2, SMC_STRATIFIED_>), gridw, dim3(SMC_BLOCK * 2), st, f->a);
+                    if (sys) SMC_LAUNCH((k_ancestors2w<2, SMC_SYSTEMATIC_>), gridw, dim3(SMC_BLOCK * 2), st, W_LEAD, f->a);
+                    else SMC_LAUNCH((k_ancestors2w<2, SMC_STRATIFIED_>), gridw, dim3(SMC_BLOCK * 2), st, W_LEAD, f->a);
                 }
             } else {
                 if (p2) { if (sys) A2_CASE(false, true, SMC_SYSTEMATIC_); else A2_CASE(false, true, SMC_STRATIFIED_); }

@@ -144,6 +144,13 @@ struct FArgs {
 // just processes the tile the map gives it.  Workgroup bx sits on XCD c = bx mod 8 and is that XCD's q-th (q = bx / 8);
 // XCD c receives ceil((ntiles - c) / 8) workgroups, so its run starts at c floor(ntiles / 8) + min(c, ntiles mod 8):
 // a bijection for ANY number of tiles (round sizes like N = 10^6 included).
+__device__ __forceinline__ int f_tile_xcd_geom(const int geom, const int bx)      // geom: ntiles | xcd_chunks << 30
+{
+    if (!(geom >> 30)) return bx;
+    const int ntiles = geom & 0x3FFFFFFF;
+    const int c = bx & 7, base = ntiles >> 3, rem = ntiles & 7;
+    return c * base + (c < rem ? c : rem) + (bx >> 3);
+}
 __device__ __forceinline__ int f_tile_xcd(const FArgs& a, const int bx)
 {
     if (!a.xcd_chunks) return bx;
@@ -1294,18 +1301,22 @@ __device__ __forceinline__ i64 f_own_idx(const FOwn& o, const int k) { return (k
 // would straddle the islands' boundaries: every access tests its index.
 template <int KIND, int FK, int OPT, bool SPEC, bool TAIL = true, int RAGGED = 0>
 __global__ void __launch_bounds__(SMC_BLOCK)
-k_propagate(const FArgs av)
+k_propagate(const u32* __restrict__ pre_A, double* __restrict__ pre_info, const double* __restrict__ pre_params,
+            const unsigned* __restrict__ pre_hcnt, const i64 pre_N, const int pre_geom, const FArgs av)
 {
+    // (leading scalar arguments = fields of the block that the launch's first loads are addressed with: the command
+    //  processor preloads them into SGPRs -- -amdgpu-kernarg-preload-count -- and those loads leave without waiting for
+    //  a scalar load of the kernarg segment; pre_geom: ntiles | xcd_chunks << 30)
     static_assert(OPT == 4, "two pairs per thread");
     const FArgs& a = av;
     __shared__ double smd[SMC_SM];
     __shared__ int s_last;
     SMC_NTAB_LDS(s_ntab);
-    const int b = f_tile_xcd(av, (int)blockIdx.x), isl = (int)blockIdx.y;
+    const int b = f_tile_xcd_geom(pre_geom, (int)blockIdx.x), isl = (int)blockIdx.y;
     const int tid = (int)threadIdx.x;
     F_STAMP(0);
-    double* info = a.info + (i64)isl * INFO_STRIDE;
-    const i64 N = a.N;
+    double* info = pre_info + (i64)isl * INFO_STRIDE;
+    const i64 N = pre_N;
     const FOwn own = f_own<!TAIL>(b, tid, N);
     const bool full = (TAIL || RAGGED == 2) ? own.full : true;   // loads (tail-free: every thread reads 4)
     const bool full_st = (TAIL || RAGGED) ? own.full : true;     // stores
@@ -1314,7 +1325,7 @@ k_propagate(const FArgs av)
     constexpr bool APF = f_is_apf(FK);             // (tail-free two-level path only: see the tail)
     const double r6 = APF ? smc_ldg(info + 6) : 0.0;
     unsigned nh0 = 0u, nh1 = 0u;                   // registered heavy parents, either parity of t
-    if (a.hcnt) { nh0 = smc_ldg(a.hcnt + (i64)isl * 2); nh1 = smc_ldg(a.hcnt + (i64)isl * 2 + 1); }
+    if (pre_hcnt) { nh0 = smc_ldg(pre_hcnt + (i64)isl * 2); nh1 = smc_ldg(pre_hcnt + (i64)isl * 2 + 1); }
     // SPEC: slots from a.par (kernarg): the ancestor indices are requested right behind the
     // step record, and the gather X_{t-1}[A] can leave as soon as they are back -- without
     // waiting for the record (read in vain on the steps that do not resample)
@@ -1349,7 +1360,8 @@ k_propagate(const FArgs av)
     double xg[OPT];
     // ---- request order: step record (above), Box-Muller tables (6 KB, L2-resident), ancestor
     // indices; the tables go to LDS as soon as they are back -- the indices are still on their way
-    smc_ntab_stage_async<SMC_BLOCK>(s_ntab, tid);
+    SmcNtabRegs<SMC_BLOCK> ntr;
+    smc_ntab_fetch<SMC_BLOCK>(ntr, tid);
     // the island's model constants: staged in LDS with the tables (same barrier).  Read through the kernel
     // argument's pointer they are global loads the compiler has to repeat behind every store it cannot see through
     // (the streaming stores are inline asm with a memory clobber, the plain ones may alias) -- and a repeated global
@@ -1357,11 +1369,16 @@ k_propagate(const FArgs av)
     // (s_waitcnt vmcnt(0): a round trip to HBM).  From LDS they are ds_reads that wait for nothing of the kind.
     __shared__ double s_par[PARAM_STRIDE];
     double par_reg = 0.0;
-    if (!SMC_PARAMS_GLOBAL && tid < PARAM_STRIDE) par_reg = smc_ldg(a.params + (i64)isl * PARAM_STRIDE + tid);
+    if (!SMC_PARAMS_GLOBAL && tid < PARAM_STRIDE) par_reg = smc_ldg(pre_params + (i64)isl * PARAM_STRIDE + tid);
 #ifndef SMC_EMULATE
     asm volatile("" ::: "memory");                    // (the table loads are ISSUED first: vmcnt retires in order)
 #endif
-    if (SPEC && mine) load_anc(a.A + (i64)isl * N);   // A always holds valid indices (zeros before the first resampling)
+    if (SPEC && mine) load_anc(pre_A + (i64)isl * N);   // A always holds valid indices (zeros before the first resampling)
+    // the tables go to LDS here, behind the requests for the indices: the wait in front of the ds_writes is for the
+    // tables only (vmcnt retires in order), the indices stay in flight across the Philox calls below.  (Measured
+    // against: the tables staged before the indices are requested, through global_load_lds_dwordx4, and the
+    // indices requested first of all -- within 0.15 us of each other, this order ahead: profiles/r12_same_box_ab.txt r12ay)
+    smc_ntab_store<SMC_BLOCK>(ntr, s_ntab, tid);
     // the Philox calls of the step's normals need no table: they run while it is on its way
     u64 pa0 = 0ull, pa1 = 0ull, pb0 = 0ull, pb1 = 0ull;
 #ifndef SMC_PHILOX_LATE

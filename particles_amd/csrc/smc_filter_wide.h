@@ -22,8 +22,15 @@
 
 template <int TPW, int SCH>
 __global__ void __launch_bounds__(SMC_BLOCK * TPW)
-k_ancestors2w(const FArgs av)
+k_ancestors2w(const double* __restrict__ pre_info2, const double* __restrict__ pre_pm, const double* __restrict__ pre_ps,
+              const double* __restrict__ pre_pss, const u64* __restrict__ pre_cq, const i64 pre_N, const int pre_geom,
+              const FArgs av)
 {
+    // pre_geom: ntiles (== nparts on this path) | xcd_chunks << 30
+    // (the leading arguments repeat fields of the block: scalar kernel arguments in front can be PRELOADED into SGPRs
+    //  by the command processor -- -amdgpu-kernarg-preload-count -- so the launch's first loads need not wait for a
+    //  scalar load of their own addresses from the kernarg segment; a firmware that does not preload runs the
+    //  compiler's prologue, which fetches them the old way)
     static_assert(TPW == 2 || TPW == 4, "tiles per workgroup");
     static_assert(SCH == SMC_SYSTEMATIC_ || SCH == SMC_STRATIFIED_, "closed-form counts");
     const FArgs& a = av;
@@ -47,37 +54,39 @@ k_ancestors2w(const FArgs av)
     // of ITS XCD (b = x, x + 8, ... within a group of 8 TPW tiles) where the grid allows, so that the integer CDF it
     // reads and the ancestors it writes stay in that L2 (consecutive tiles: C2 19.7 us per step against 18.1 with
     // one tile per workgroup, profiles/r12c)
-    const bool xcd_map = (a.ntiles % (8 * TPW)) == 0;
+    const int ntiles = pre_geom & 0x3FFFFFFF;
+    const bool xcd_chunks = (pre_geom >> 30) != 0;
+    const bool xcd_map = (ntiles % (8 * TPW)) == 0;
     const int bx = (int)blockIdx.x;
-    // (a.xcd_chunks -- f_tile_xcd: XCD x owns a contiguous run of tiles -- : TPW consecutive tiles of this XCD's run)
-    const int b_first = a.xcd_chunks ? (bx & 7) * (a.ntiles >> 3) + (bx >> 3) * TPW
-                                     : (xcd_map ? (bx / 8) * (8 * TPW) + (bx % 8) : bx * TPW);
-    const int b_step = a.xcd_chunks ? 1 : (xcd_map ? 8 : 1);
+    // (xcd_chunks -- f_tile_xcd: XCD x owns a contiguous run of tiles -- : TPW consecutive tiles of this XCD's run)
+    const int b_first = xcd_chunks ? (bx & 7) * (ntiles >> 3) + (bx >> 3) * TPW
+                                   : (xcd_map ? (bx / 8) * (8 * TPW) + (bx % 8) : bx * TPW);
+    const int b_step = xcd_chunks ? 1 : (xcd_map ? 8 : 1);
     const int b = b_first + st * b_step, isl = (int)blockIdx.y;
     const bool red = st == 0;                                              // the reducing waves
     u32* sP = sP_all[st];
     u32* s_mx = s_mx_all[st];
-    const i64 N = a.N;
+    const i64 N = pre_N;
     F_STAMP_A(0);
     const i64 j0 = (i64)b * F_TILE;
     const i64 jt = j0 + (i64)tid * F_IPT;
     double* info = a.info + (i64)isl * INFO_STRIDE;
-    const double r0 = smc_ldg(a.info2 + (i64)isl * INFO_STRIDE);
-    const i64 o = (i64)isl * a.nparts;
+    const double r0 = smc_ldg(pre_info2 + (i64)isl * INFO_STRIDE);
+    const i64 o = (i64)isl * ntiles;                                       // (nparts == ntiles: one partial per tile)
     double pm4[4] = {0.0, 0.0, 0.0, 0.0}, ps4[4] = {0.0, 0.0, 0.0, 0.0}, pss4[4] = {0.0, 0.0, 0.0, 0.0};
     // the tile's integer CDF: this thread's 4 positions and the next thread's first
-    const u64* cq = a.cq + (i64)isl * N;                                   // (N = 2^k: whole tiles, ncq == N)
+    const u64* cq = pre_cq + (i64)isl * N;                                   // (N = 2^k: whole tiles, ncq == N)
     u64 cx[F_IPT + 1];
     smc_ld2g(cq + jt, cx[0], cx[1]);
     smc_ld2g(cq + jt + 2, cx[2], cx[3]);
     cx[4] = (tid < SMC_BLOCK - 1) ? smc_ldg(cq + jt + 4) : 0ull;
-    const u64 tb_raw = smc_ldg(a.tq + o + b);
     if (red) {
-        const bool pvec = (a.nparts & 3) == 0;
-        f_load4<double>(a.pm + o, (i64)tid * 4, a.nparts, pvec, -INFINITY, pm4);
-        f_load4<double>(a.ps + o, (i64)tid * 4, a.nparts, pvec, 0.0, ps4);
-        f_load4<double>(a.pss + o, (i64)tid * 4, a.nparts, pvec, 0.0, pss4);
+        const bool pvec = (ntiles & 3) == 0;
+        f_load4<double>(pre_pm + o, (i64)tid * 4, ntiles, pvec, -INFINITY, pm4);
+        f_load4<double>(pre_ps + o, (i64)tid * 4, ntiles, pvec, 0.0, ps4);
+        f_load4<double>(pre_pss + o, (i64)tid * 4, ntiles, pvec, 0.0, pss4);
     }
+    const u64 tb_raw = smc_ldg(a.tq + o + b);      // (the first use of the argument block: its scalar loads have had the time of the requests above)
     // the scatter window of the first pass, while the loads are on their way
     *reinterpret_cast<uint4*>(&sP[tid * 4]) = make_uint4(0u, 0u, 0u, 0u);
     *reinterpret_cast<uint4*>(&sP[F_PASS + tid * 4]) = make_uint4(0u, 0u, 0u, 0u);

@@ -204,33 +204,6 @@ __device__ __forceinline__ void smc_ntab_store(const SmcNtabRegs<NTH>& r, SmcD2*
 #pragma unroll
     for (int k = 0; k < SmcNtabRegs<NTH>::NE; ++k) lds[tid + k * NTH] = r.e[k];
 }
-// the same copy without the registers (-DSMC_NTAB_GLDS): global_load_lds_dwordx4 writes 16 bytes per lane straight
-// into LDS (one wave-uniform base + lane * 16, which is exactly the tables' own order).  Side-effecting, so the
-// compiler leaves the requests where they are written -- in front of whatever the kernel computes while they are
-// on their way -- instead of sinking an invariant load down to its ds_write; the barrier that follows carries the
-// vmcnt(0).  Measured on C2 (profiles/r12_same_box_ab.txt, r12am): 16.99 us per step against 16.91 through the
-// registers -- the tables arrive from L2 well inside the wait for the ancestor indices either way -- so the
-// register path stays the default.
-template <int NTH>
-__device__ __forceinline__ void smc_ntab_stage_async(SmcD2* lds, const int tid)
-{
-#if defined(SMC_EMULATE) || !defined(SMC_NTAB_GLDS)
-    SmcNtabRegs<NTH> r;
-    smc_ntab_fetch<NTH>(r, tid);
-    smc_ntab_store<NTH>(r, lds, tid);
-#else
-    static_assert(NTH % 64 == 0, "whole waves");
-    const SmcD2* src = reinterpret_cast<const SmcD2*>(smc_ntab);
-    const int wave0 = tid & ~63;
-#pragma unroll
-    for (int k = 0; k < SmcNtabRegs<NTH>::NE; ++k) {
-        const int i = tid + k * NTH;
-        const SmcD2* g = src + (i < SMC_NTAB_N ? i : SMC_NTAB_N - 1);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)(lds + wave0 + k * NTH), 16, 0, 0);
-    }
-#endif
-}
 template <int NTH>
 __device__ __forceinline__ void smc_ntab_stage(SmcD2* lds, const int tid)
 {
