@@ -127,15 +127,6 @@ __device__ __forceinline__ void smc_wave_scan_add_f64x2(double& a, double& b)
     SMC_SCAN2_STEP(smc_dpp_f64, SMC_DPP_ROW_BCAST15, 0xa)
     SMC_SCAN2_STEP(smc_dpp_f64, SMC_DPP_ROW_BCAST31, 0xc)
 }
-__device__ __forceinline__ void smc_wave_scan_add_u64x2(u64& a, u64& b)
-{
-    SMC_SCAN2_STEP(smc_dpp64, SMC_DPP_ROW_SHR(1), 0xf)
-    SMC_SCAN2_STEP(smc_dpp64, SMC_DPP_ROW_SHR(2), 0xf)
-    SMC_SCAN2_STEP(smc_dpp64, SMC_DPP_ROW_SHR(4), 0xf)
-    SMC_SCAN2_STEP(smc_dpp64, SMC_DPP_ROW_SHR(8), 0xf)
-    SMC_SCAN2_STEP(smc_dpp64, SMC_DPP_ROW_BCAST15, 0xa)
-    SMC_SCAN2_STEP(smc_dpp64, SMC_DPP_ROW_BCAST31, 0xc)
-}
 #undef SMC_SCAN2_STEP
 // two inclusive scans of values below 2^51 as four scans of limbs (26 low bits, 25 high): 64 limbs sum to less than
 // 2^32, so no carry ever leaves a limb on the way, each step of each limb is ONE v_add_u32 with a DPP operand, and

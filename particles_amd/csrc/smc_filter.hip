@@ -615,6 +615,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
             int per_cu = 0;                        // workgroups of this instantiation a CU holds at once
 #ifdef SMC_EMULATE
             per_cu = 4;
+            (void)per_cu;
 #else
             const void* fn = tpw == 1 ? (const void*)k_f_spacing_onepass<1> : tpw == 2 ? (const void*)k_f_spacing_onepass<2>
                            : tpw == 4 ? (const void*)k_f_spacing_onepass<4> : (const void*)k_f_spacing_onepass<8>;
