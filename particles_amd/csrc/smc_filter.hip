@@ -266,6 +266,12 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
             if (f->two_level_mid) {
                 if (p2) { if (sys) A2_CASE(true, true, SMC_SYSTEMATIC_); else A2_CASE(true, true, SMC_STRATIFIED_); }
                 else { if (sys) A2_CASE(true, false, SMC_SYSTEMATIC_); else A2_CASE(true, false, SMC_STRATIFIED_); }
+            } else if (!p2 && f->wide_tpw) {
+                // resident grid, any N, systematic: two tiles per workgroup over the runs of tiles f_tile_xcd gives the XCDs
+                const int per_run = (f->a.ntiles + 7) / 8;
+                const dim3 gridw(f->a.xcd_chunks ? 8 * ((per_run + 1) / 2) : (f->a.ntiles + 1) / 2, f->a.n_islands);
+                SMC_LAUNCH((k_ancestors2w<2, SMC_SYSTEMATIC_, false>), gridw, dim3(SMC_BLOCK * 2), st, f->a.info2, f->a.pm, f->a.ps,
+                           f->a.pss, f->a.cq, f->a.N, f->a.ntiles | (f->a.xcd_chunks ? 1 << 30 : 0), f->a);
             } else if (p2 && f->wide_tpw) {
                 // resident grid, N = 2^k: TPW tiles per workgroup, the partials reduced by its first 4 waves only
                 const dim3 gridw(f->a.ntiles / f->wide_tpw, f->a.n_islands);
@@ -579,10 +585,15 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
         const int want = (o->flags & SMC_PATH_WIDE4) ? 4 : 2;
         f->wide_tpw = (a.ntiles % want) == 0 ? want : ((a.ntiles % 2) == 0 ? 2 : 0);
     }
+    // ... and of any other N under the systematic scheme (k_ancestors2w<2, .., POW2 = false>: the general counts, any
+    // number of tiles -- the last workgroup of a run may hold one tile)
+    if (f->two_level && !f->two_level_mid && a.log2N < 0 && scheme == SMC_SYSTEMATIC && a.ntiles >= 2 &&
+        !(o->flags & (SMC_PATH_NO_WIDE | SMC_PATH_POW2_ONLY)) && !f->strict && !f->sqmc)
+        f->wide_tpw = 2;
     // consecutive tiles on one XCD (f_tile_xcd): any number of tiles with one tile per resampling workgroup; with
     // k_ancestors2w whole multiples of 8 x (its tiles per workgroup) -- else the wide kernel keeps its own XCD-strided map
     a.xcd_chunks = (f->two_level && !mv && !f->strict && !f->sqmc && !(o->flags & SMC_PATH_NO_XCD_CHUNKS) && a.ntiles >= 16 &&
-                    (!f->wide_tpw || a.ntiles % (8 * f->wide_tpw) == 0)) ? 1 : 0;
+                    (!f->wide_tpw || a.log2N < 0 || a.ntiles % (8 * f->wide_tpw) == 0)) ? 1 : 0;
     // (measured and kept out, round 4: the reduction MERGED into the resampling launch on grids beyond 2048 workgroups --
     //  (a) every workgroup of k_ancestors2w reducing: C5 99.2 us per step (2 tiles per workgroup) / 117.2 (4) against 92.9
     //  behind k_reduce2 (r12h); (b) workgroup 0 of k_ancestors2 reducing, the others waiting for its word with their

@@ -20,7 +20,7 @@
 // a.ntiles % TPW == 0).
 #pragma once
 
-template <int TPW, int SCH>
+template <int TPW, int SCH, bool POW2 = true>
 __global__ void __launch_bounds__(SMC_BLOCK * TPW)
 k_ancestors2w(const double* __restrict__ pre_info2, const double* __restrict__ pre_pm, const double* __restrict__ pre_ps,
               const double* __restrict__ pre_pss, const u64* __restrict__ pre_cq, const i64 pre_N, const int pre_geom,
@@ -33,6 +33,7 @@ k_ancestors2w(const double* __restrict__ pre_info2, const double* __restrict__ p
     //  compiler's prologue, which fetches them the old way)
     static_assert(TPW == 2 || TPW == 4, "tiles per workgroup");
     static_assert(SCH == SMC_SYSTEMATIC_ || SCH == SMC_STRATIFIED_, "closed-form counts");
+    static_assert(POW2 || SCH == SMC_SYSTEMATIC_, "general N: the systematic scheme");
     const FArgs& a = av;
     constexpr int WIN = 2 * F_PASS;                                        // offspring per pass
     __shared__ __attribute__((aligned(16))) u32 sP_all[TPW][WIN];
@@ -59,10 +60,29 @@ k_ancestors2w(const double* __restrict__ pre_info2, const double* __restrict__ p
     const bool xcd_map = (ntiles % (8 * TPW)) == 0;
     const int bx = (int)blockIdx.x;
     // (xcd_chunks -- f_tile_xcd: XCD x owns a contiguous run of tiles -- : TPW consecutive tiles of this XCD's run)
-    const int b_first = xcd_chunks ? (bx & 7) * (ntiles >> 3) + (bx >> 3) * TPW
-                                   : (xcd_map ? (bx / 8) * (8 * TPW) + (bx % 8) : bx * TPW);
-    const int b_step = xcd_chunks ? 1 : (xcd_map ? 8 : 1);
-    const int b = b_first + st * b_step, isl = (int)blockIdx.y;
+    int b_first = xcd_chunks ? (bx & 7) * (ntiles >> 3) + (bx >> 3) * TPW
+                             : (xcd_map ? (bx / 8) * (8 * TPW) + (bx % 8) : bx * TPW);
+    int b_step = xcd_chunks ? 1 : (xcd_map ? 8 : 1);
+    int n_here = TPW;                                                      // this workgroup's tiles
+    if (!POW2) {
+        // any number of tiles (POW2 = false: general N): consecutive tiles of the run f_tile_xcd gives this XCD (or of
+        // the whole range), the last workgroup of a run holding fewer than TPW -- its other waves go through the
+        // barriers with a copy of the first tile's data and write nothing
+        b_step = 1;
+        if (xcd_chunks) {
+            const int c = bx & 7, base = ntiles >> 3, rem = ntiles & 7;
+            const int len = base + (c < rem ? 1 : 0), q0 = (bx >> 3) * TPW;
+            b_first = c * base + (c < rem ? c : rem) + q0;
+            n_here = len - q0;
+        } else {
+            b_first = bx * TPW;
+            n_here = ntiles - b_first;
+        }
+        if (n_here <= 0) return;                                           // (uniform: before any barrier)
+        n_here = n_here > TPW ? TPW : n_here;
+    }
+    const bool tile_ok = POW2 || st < n_here;
+    const int b = tile_ok ? b_first + st * b_step : b_first, isl = (int)blockIdx.y;
     const bool red = st == 0;                                              // the reducing waves
     u32* sP = sP_all[st];
     u32* s_mx = s_mx_all[st];
@@ -75,7 +95,7 @@ k_ancestors2w(const double* __restrict__ pre_info2, const double* __restrict__ p
     const i64 o = (i64)isl * ntiles;                                       // (nparts == ntiles: one partial per tile)
     double pm4[4] = {0.0, 0.0, 0.0, 0.0}, ps4[4] = {0.0, 0.0, 0.0, 0.0}, pss4[4] = {0.0, 0.0, 0.0, 0.0};
     // the tile's integer CDF: this thread's 4 positions and the next thread's first
-    const u64* cq = pre_cq + (i64)isl * N;                                   // (N = 2^k: whole tiles, ncq == N)
+    const u64* cq = pre_cq + (i64)isl * ((i64)ntiles * F_TILE);            // (ncq = ntiles x 1024; N = 2^k: == N)
     u64 cx[F_IPT + 1];
     smc_ld2g(cq + jt, cx[0], cx[1]);
     smc_ld2g(cq + jt + 2, cx[2], cx[3]);
@@ -149,7 +169,7 @@ k_ancestors2w(const double* __restrict__ pre_info2, const double* __restrict__ p
         if (lane == 63) s_wt[wave] = incl;
 #pragma unroll
         for (int q = 0; q < TPW; ++q) {
-            const int bq = b_first + q * b_step;
+            const int bq = (POW2 || q < n_here) ? b_first + q * b_step : b_first;
             if (tid == (bq >> 2)) {
                 const int kk = bq & 3;
                 s_before[q] = (incl - qsum) + (kk == 0 ? 0.0 : (kk == 1 ? Q4[0] : (kk == 2 ? q01 : q012)));
@@ -188,7 +208,19 @@ k_ancestors2w(const double* __restrict__ pre_info2, const double* __restrict__ p
 #pragma unroll
         for (int i = 0; i <= F_IPT; ++i) {
             const i64 j = jt + i;
-            ns[i] = (j == 0) ? 0 : (j >= N ? N : f2_ns_sys<true>(a, su, Us, f, cx[i]));
+            ns[i] = (j == 0) ? 0 : (j >= N ? N : f2_ns_sys<POW2>(a, su, Us, f, cx[i]));
+        }
+        if (!POW2) {                               // (general N: the counts the fp64 shortcut left open, formed exactly)
+            unsigned need = 0u;
+#pragma unroll
+            for (int i = 0; i <= F_IPT; ++i) need |= (ns[i] < 0) ? (1u << i) : 0u;
+            if (need) {
+                const u64 c7[7] = {cx[0], cx[1], cx[2], cx[3], cx[4], 0ull, tb};
+                i64 n7[7] = {ns[0], ns[1], ns[2], ns[3], ns[4], 0, 0};
+                f2_resolve_general(su, need, Gb, Qb, tb, c7, n7);
+#pragma unroll
+                for (int i = 0; i <= F_IPT; ++i) ns[i] = n7[i];
+            }
         }
     } else {
         // the stratified uniforms of each tile's offspring staged in LDS (k_ancestors2: F2_SU_PAIRS Philox calls per
@@ -323,7 +355,7 @@ k_ancestors2w(const double* __restrict__ pre_info2, const double* __restrict__ p
 #pragma unroll
     for (int k = 0; k < TPW; ++k) slow = slow || !(Qall[k] * down + 2.0 <= (double)(WIN - 4));
     if (!slow) {                                   // one window per tile (an empty tile goes through the barriers)
-        const bool act = lo < hi;
+        const bool act = tile_ok && lo < hi;
         pass(act ? (lo & ~3u) : 0u, act);
         F_STAMP_A(5);
         return;
@@ -333,7 +365,7 @@ k_ancestors2w(const double* __restrict__ pre_info2, const double* __restrict__ p
     i64* sH = sH_all[st];
     int nH = 0;
     if (a.hcnt) {
-        const bool cand = n_hi - n_lo >= 2 * (i64)F_TILE;
+        const bool cand = tile_ok && n_hi - n_lo >= 2 * (i64)F_TILE;
         unsigned* hcnt = a.hcnt + (i64)isl * 2 + (t & 1);
         i64* hlist = a.hlist + ((i64)isl * 2 + (t & 1)) * F_HMAX * 3;
         if (tid == 0) sHn_all[st] = 0u;
@@ -363,7 +395,7 @@ k_ancestors2w(const double* __restrict__ pre_info2, const double* __restrict__ p
     bool first_pass = true;
     for (;;) {
         // this tile's next window: the passes that lie wholly inside a registered parent's blocks are left out
-        bool act = pb < hi;
+        bool act = tile_ok && pb < hi;
         while (act && nH) {
             const i64 w_lo = pb > lo ? pb : lo, w_hi = pb + WIN < hi ? pb + WIN : hi;
             i64 jump = 0;                          // passes to leave out, this one included

@@ -713,6 +713,33 @@ def check_two_level_cdf(golden, monkeypatch, N=4096, T=20):
     check_two_level_injected()
 
 
+def check_wide_general(monkeypatch, sizes=(1500, 3000, 17 * 1024 + 1, 19 * 1024 - 3), T=6):
+    """Any N under the systematic scheme on k_ancestors2w<.., POW2 = false> (two tiles per workgroup, the general
+    counts, odd numbers of tiles, a ragged last tile, runs of tiles per XCD) against k_ancestors2 (one tile per
+    workgroup): the same run bit for bit -- typical weights and a collapsing population (heavy parents), one island
+    and three, with the fp64 shortcut off and with the plain tile map."""
+    for N in sizes:
+        for sigY in (0.2, 1e-4):
+            rng = np.random.RandomState(N % 1000)
+            x = np.cumsum(rng.standard_normal(T))
+            y = [np.array([v]) for v in x + sigY * rng.standard_normal(T)]
+            model = kalman.LinearGauss(sigmaY=sigY, sigmaX=1.0, rho=0.9, sigma0=1.0)
+            runs = {}
+            for name, env in (("narrow", {"SMC_NO_WIDE": "1"}), ("wide", {}), ("exact", {"SMC_EXACT_COUNTS": "1"}),
+                              ("plain_map", {"SMC_NO_XCD_CHUNKS": "1"})):
+                for k, v in env.items():
+                    monkeypatch.setenv(k, v)
+                pf = pa.SMC(fk=ssm.Bootstrap(ssm=model, data=y), N=N, resampling="systematic", ESSrmin=1.0,
+                            collect="off", seed=5, store_history=True, n_islands=3 if N < 4000 else 1)
+                assert ("k_ancestors2w" in describe(pf)) == (name != "narrow"), (name, describe(pf))
+                pf.run()
+                runs[name] = ([np.array(a) for a in pf.hist.A[1:]], np.array(pf.X), np.array(pf.logLt))
+                monkeypatch.undo()
+            for name in ("wide", "exact", "plain_map"):
+                assert all(np.array_equal(a, b) for a, b in zip(runs["narrow"][0], runs[name][0])), (N, sigY, name)
+                assert np.array_equal(runs["narrow"][1], runs[name][1]) and np.array_equal(runs["narrow"][2], runs[name][2]), (N, sigY, name)
+
+
 def check_two_level_injected(sizes=(4096, 3000)):
     """The contract itself on weights no filter run would produce -- skewed, -inf entries, an
     empty tile, a collapsed vector: uploaded with smc_filter_set_state, one resampling step on the
@@ -1088,8 +1115,9 @@ def check_describe():
     assert kernels(1 << 12) == "k_ancestors2w+k_propagate"                     # two-level, resident, N = 2^k: 2 tiles per workgroup
     assert kernels(1 << 12, "stratified") == "k_ancestors2w+k_propagate"
     assert kernels(1 << 12, n_islands=600) == "k_reduce2+k_ancestors2+k_propagate"   # 2400 workgroups
-    assert kernels(3000) == "k_ancestors2+k_propagate"                         # any N of >= 2 tiles: general counts
-    assert kernels(1500) == "k_ancestors2+k_propagate"                         # (2 tiles, the second ragged)
+    assert kernels(3000) == "k_ancestors2w+k_propagate"                        # any N of >= 2 tiles, systematic: general counts,
+    assert kernels(1500) == "k_ancestors2w+k_propagate"                        #  two tiles per workgroup (2 tiles, the second ragged)
+    assert kernels(3000, "stratified") == "k_ancestors2+k_propagate"           # (the other closed-form scheme: one tile per workgroup)
     assert kernels(1 << 12, "multinomial") == \
         "k_f_spacing_onepass<with k_reduce2>+k_ancestors2+k_propagate"   # two-level: one-pass spacings (the island's
     #                                                                   reduction is their workgroup 0), counts by search

@@ -171,6 +171,10 @@ def test_heavy_parents(monkeypatch):
     pc.check_heavy_parents(monkeypatch, T=6)
 
 
+def test_wide_general(monkeypatch):
+    pc.check_wide_general(monkeypatch)
+
+
 def test_two_level_cdf(golden, monkeypatch):
     pc.check_describe()
     pc.check_two_level_stepwise()

@@ -176,6 +176,10 @@ def test_heavy_parents(monkeypatch):
     pc.check_heavy_parents(monkeypatch)
 
 
+def test_wide_general(monkeypatch):
+    pc.check_wide_general(monkeypatch, sizes=(1500, 3000, 17 * 1024 + 1, 10 ** 6 + 3))
+
+
 def test_two_level_cdf(golden, monkeypatch):
     pc.check_describe()
     pc.check_two_level_stepwise()
