@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run ON THE GPU BOX (gpurun): round-4 evidence on the last tree.  $1 = tag (files land in gpurun_out/<tag>/)
-TAG=${1:-r13b}
+TAG=${1:-r13c}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
