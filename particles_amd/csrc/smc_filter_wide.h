@@ -15,9 +15,10 @@
 // second scatter pass or owns a heavy parent takes ALL tiles of the workgroup through the pass loop
 // (`slow`, decided from the tiles' shares, which every thread holds).
 //
-// Contract, results and the heavy-parent protocol with k_propagate are k_ancestors2's;
-// N = 2^k, systematic / stratified with closed-form counts, no k_reduce2 in front (a.ntiles <= 1024,
-// a.ntiles % TPW == 0).
+// Contract, results and the heavy-parent protocol with k_propagate are k_ancestors2's; no k_reduce2 in
+// front (a.ntiles <= 1024).  POW2 = true: N = 2^k, systematic / stratified with closed-form integer counts,
+// a.ntiles % TPW == 0.  POW2 = false (systematic): any N -- the general counts, any number of tiles (the last
+// workgroup of a run of tiles may hold fewer than TPW), a ragged last tile.
 #pragma once
 
 template <int TPW, int SCH, bool POW2 = true>
