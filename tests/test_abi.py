@@ -59,6 +59,56 @@ def test_code_object_targets_gfx950_only():
         assert other not in blob
 
 
+def _amdgpu_kernel_descriptors(path):
+    """{kernel symbol: its 64-byte amdhsa kernel descriptor} over every AMDGPU code object embedded in the library"""
+    import struct
+    blob = open(path, "rb").read()
+    out, pos = {}, 0
+    while True:
+        pos = blob.find(b"\x7fELF\x02\x01\x01", pos)
+        if pos < 0:
+            return out
+        e = blob[pos:]
+        pos += 4
+        if len(e) < 64 or struct.unpack_from("<H", e, 18)[0] != 224:          # e_machine: EM_AMDGPU
+            continue
+        shoff, = struct.unpack_from("<Q", e, 40)
+        shentsize, shnum, _ = struct.unpack_from("<HHH", e, 58)
+        secs = [struct.unpack_from("<IIQQQQIIQQ", e, shoff + i * shentsize) for i in range(shnum)]
+        for (_n, typ, _f, _a, off, size, link, _i, _al, _es) in secs:
+            if typ != 2:                                                       # SHT_SYMTAB
+                continue
+            stroff = secs[link][4]
+            for k in range(size // 24):
+                st_name, _info, _other, shndx, value, st_size = struct.unpack_from("<IBBHQQ", e, off + k * 24)
+                sym = e[stroff + st_name:e.index(b"\0", stroff + st_name)].decode()
+                if sym.endswith(".kd") and st_size == 64 and 0 < shndx < shnum:
+                    sec = secs[shndx]
+                    at = sec[4] + value - sec[3]
+                    out[sym[:-3]] = e[at:at + 64]
+
+
+def test_step_kernels_preload_their_leading_arguments():
+    """The two kernels of the resident step take the fields their first loads are addressed with as leading scalar
+    arguments, and the build asks for them in SGPRs (-amdgpu-kernarg-preload-count): the kernel descriptors of the
+    built code object must say so (kernarg_preload_spec_length: 11 dwords for k_propagate -- A, info, params, hcnt, N,
+    geometry --, 13 for k_ancestors2w) -- a reordered signature or a lost flag would silently cost 0.4 us per step."""
+    import struct
+    from particles_amd import _build
+    assert "-amdgpu-kernarg-preload-count=14" in _build.FLAGS
+    kd = _amdgpu_kernel_descriptors(_build.build())
+    assert len(kd) > 100
+    prop = {k: v for k, v in kd.items() if k.startswith("_Z11k_propagateI")}
+    wide = {k: v for k, v in kd.items() if k.startswith("_Z13k_ancestors2wI")}
+    assert len(prop) >= 24 and len(wide) >= 5
+    for k, v in prop.items():
+        assert struct.unpack_from("<H", v, 58)[0] & 0x7f == 11, k
+    for k, v in wide.items():
+        assert struct.unpack_from("<H", v, 58)[0] & 0x7f == 13, k
+    # (kernels that take only the argument block preload nothing)
+    assert struct.unpack_from("<H", kd["_Z9k_reduce25FArgs"], 58)[0] & 0x7f == 0
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     import importlib
     from particles_amd import _lib
