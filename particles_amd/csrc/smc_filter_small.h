@@ -37,11 +37,16 @@ k_filter_small(const FArgs av, const int nsteps)
     const int tid = (int)threadIdx.x;
     if (tid < SMC_SM) { smu[tid] = 0ull; smd[tid] = 0.0; smm[tid] = -INFINITY; }
     smc_ntab_stage<BS>(s_ntab, tid);
+    // the island's model constants in LDS (as in k_propagate: read through the argument block's pointer they are global
+    // loads repeated behind every step's stores, each with a wait that also drains those stores)
+    __shared__ double s_par[PARAM_STRIDE];
+    static_assert(BS >= PARAM_STRIDE, "one constant per thread");
+    if (tid < PARAM_STRIDE) s_par[tid] = smc_ldg(a.params + (i64)isl * PARAM_STRIDE + tid);
     __syncthreads();
     const i64 N = a.N;
     double* info = a.info + (i64)isl * INFO_STRIDE;
     const u32 gisl = (u32)(a.island_offset + isl);
-    const double* p = a.params + (i64)isl * PARAM_STRIDE;
+    const double* p = s_par;
     const i64 jt = (i64)tid * F_IPT;                       // this thread's particles jt..jt+3
     const bool vec = (N & 3) == 0;
 
