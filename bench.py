@@ -72,11 +72,12 @@ def leg_key(wl):
     """Name of a workload in `other_workloads` and in profiles/traffic_<key>.json."""
     if wl.get("qmc"):
         return "sqmc"
+    sfx = "_strict" if wl.get("strict") else ""
     if wl["name"] == "c3":
-        return "c3_" + wl["scheme"]
+        return "c3_" + wl["scheme"] + sfx
     if wl["name"] == "c4":
         return "c4_collapsed" if wl["collapsed"] else "c4"
-    return wl["name"]
+    return wl["name"] + sfx
 
 
 def measured_traffic(wl, kernel, profiles=None):
@@ -94,7 +95,8 @@ def measured_traffic(wl, kernel, profiles=None):
     cfg = rec.get("config", {})
     if wl["Nlabel"] != "2^%d" % wl["log2N"] or \
             (cfg.get("log2N"), cfg.get("islands"), cfg.get("scheme")) != (wl["log2N"], wl["islands"], wl["scheme"]) or \
-            bool(cfg.get("collapsed")) != bool(wl["collapsed"]) or bool(cfg.get("qmc")) != bool(wl.get("qmc")):
+            bool(cfg.get("collapsed")) != bool(wl["collapsed"]) or bool(cfg.get("qmc")) != bool(wl.get("qmc")) or \
+            bool(cfg.get("strict")) != bool(wl.get("strict")):
         return None
     total, found = 0.0, 0
     base = lambda name: name.replace("void ", "").split("<")[0].split("(")[0].strip()
@@ -286,7 +288,8 @@ def _cpu_name():
 # ----------------------------------------------------------------------------------------------
 # workloads (BASELINE.json configs)
 # ----------------------------------------------------------------------------------------------
-def make_workload(name, T, scheme="systematic", log2N=None, N=0, islands=1, essrmin=None, collapsed=False, qmc=False):
+def make_workload(name, T, scheme="systematic", log2N=None, N=0, islands=1, essrmin=None, collapsed=False, qmc=False,
+                  strict=False):
     from particles_amd import kalman
     from particles_amd import state_space_models as ssm
     d = 1
@@ -326,7 +329,8 @@ def make_workload(name, T, scheme="systematic", log2N=None, N=0, islands=1, essr
             label = "SQMC (Sobol' points, sort, inverse CDF, ppf moves) on C2's model"
     return {"name": name, "fk": fk, "N": N if N > 0 else 1 << log2N, "log2N": log2N, "Nlabel": str(N) if N > 0 else "2^%d" % log2N,
             "islands": islands, "scheme": scheme, "essrmin": 0.5 if essrmin is None else essrmin, "d": d,
-            "label": label, "collapsed": collapsed, "guided": name == "c4", "qmc": qmc}
+            "label": label + (" [strict_ancestors: the reference's sequential fp64 inverse_cdf, bit for bit]" if strict else ""),
+            "collapsed": collapsed, "guided": name == "c4", "qmc": qmc, "strict": strict}
 
 
 def make_filter(wl, rank=0, graph=False, profile=False):
@@ -339,7 +343,8 @@ def make_filter(wl, rank=0, graph=False, profile=False):
     try:
         pf = pa.SMC(fk=wl["fk"], N=wl["N"], resampling=wl["scheme"], ESSrmin=wl["essrmin"], collect="off", seed=123,
                     n_islands=wl["islands"], island_offset=rank * wl["islands"], qmc=bool(wl.get("qmc")),
-                    use_graph=graph and not profile, collapsed_proposal=wl["collapsed"])
+                    use_graph=graph and not profile, collapsed_proposal=wl["collapsed"],
+                    strict_ancestors=bool(wl.get("strict")))
     finally:
         rs.set_rng(mode)
     if wl.get("qmc") and not pf._fused:
@@ -403,8 +408,11 @@ def roofline(wl, step_GBs, mv_ms, rs_ms, nsamples, kernels):
     # two-level path: k_propagate also writes the tile CDF (8 B), k_ancestors2 reads it
     # instead of the log-weights: 16 d + 24 and 16 B; flat path: 16 d + 16 and 16 (+ 8) B;
     # either way SURVEY 8d's 16 d + 40 B per particle-step in all
-    two = "k_ancestors2" in kernels
-    rs_bytes = (BYTES_PREPARE + (8.0 if "k_prepare" in kernels else 0.0)) * N * isl
+    strict2 = "k_strict_classify" in kernels
+    two = "k_ancestors2" in kernels or strict2
+    # strict two-level step: k_strict_classify reads lw and writes the 8-byte integer prefix of every weight's rounding,
+    # k_strict_search reads it and writes A: 32 B per particle (the sequential CDF itself is never written)
+    rs_bytes = (32.0 if strict2 else BYTES_PREPARE + (8.0 if "k_prepare" in kernels else 0.0)) * N * isl
     mv_bytes = (16.0 * d + 16.0 + (8.0 if two else 0.0)) * N * isl
     mv_ms = mv_ms if mv_ms > 0 else 1e-9          # (the emulator's events read 0)
     per = {mv_name: {"ms": mv_ms, "launch_bytes": mv_bytes, "achieved": mv_bytes / (mv_ms * 1e-3) / 1e9},
@@ -521,6 +529,9 @@ def main():
                          "(labelled in the line) instead of failing")
     ap.add_argument("--qmc", action="store_true", help="c2: SMC(qmc=True), the fused SQMC step (the `sqmc` leg)")
     ap.add_argument("--graph", action="store_true", help="replay the steps from hipGraphs (default: eager launches)")
+    ap.add_argument("--strict", action="store_true",
+                    help="c2 / c3 / c5: strict_ancestors=True -- the reference's sequential fp64 inverse_cdf (resampling.py:484-509), "
+                         "literally (the `*_strict` legs)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -579,7 +590,7 @@ def main():
     R = a.reps if a.reps > 0 else max(3, min(500, -(-(2000 if heavy else 10000) // K)))
     T = W + R * K + (K if world > 1 else 0)      # (N > 1: one more K-step region, timed WITH the evidence gather)
     wl = make_workload(a.workload, T, scheme=a.scheme, log2N=a.log2N, N=a.N, islands=a.islands,
-                       essrmin=a.essrmin, collapsed=a.collapsed, qmc=a.qmc)
+                       essrmin=a.essrmin, collapsed=a.collapsed, qmc=a.qmc, strict=a.strict)
     a.log2N, a.islands = wl["log2N"], wl["islands"]
     N, d = wl["N"], wl["d"]
     bytes_step = 16.0 * d + 40.0

@@ -8,7 +8,7 @@
 #include "smc_filter_small.h"
 #include "smc_filter_sqmc.h"
 #include "smc_filter_wide.h"
-#include "smc_seqsum.h"
+#include "smc_filter_strict.h"
 
 // ---------------------------------------------------------------------------
 // host side
@@ -194,29 +194,42 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
         return;
     }
     if (f->strict) {
-        // decision + normalisation of step t-1 (two-level: k_reduce2; flat: k_propagate's tail did it),
-        // W_{t-1}, its sequential CDF, the searches
-        if (f->two_level) SMC_LAUNCH(k_reduce2, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
+        // decision + normalisation of step t-1 (two-level: by k_strict_classify's workgroups themselves, or k_reduce2
+        // beyond 1024 tiles / for multinomial draws / the literal walk; flat: k_propagate's tail did it), the
+        // sequential CDF of W_{t-1}, the searches
+        if (f->two_level && (f->two_level_mid || f->strict_literal)) SMC_LAUNCH(k_reduce2, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
         if (f->a.scheme == SMC_MULTINOMIAL && !f->a.ut)
             for (int i = 0; i < f->a.n_islands; ++i)
                 SMC_LAUNCH(k_f_spacings_step, dim3(1), dim3(SMC_BLOCK), st, f->a, i, f->a.su + (size_t)i * f->a.N);
         const unsigned nb = (unsigned)((f->a.N + 1023) / 1024);
-        // S = the reference's sequential fp64 prefix sums of W, every bit, computed in parallel (smc_seqsum.h); the
-        // literal one-lane walk (k_strict_cdf, 44 ms at N = 2^20) behind SMC_PATH_STRICT_LITERAL (A/B, tests)
+        const dim3 gt(nb, f->a.n_islands);
+        // (strict_ws: (n_islands, N) W | (n_islands, N) S | the scratch of smc_seqx.h | (n_islands, ntiles) tile sums)
         double* S = f->strict_ws + (size_t)f->a.n_islands * f->a.N;
-        void* seq_scr = (void*)(S + (size_t)f->a.n_islands * f->a.N);
+        void* sqx_scr = (void*)(S + (size_t)f->a.n_islands * f->a.N);
+        const SqxArgs q = sqx_carve(sqx_scr, f->a.N, f->a.n_islands);
+        const SeqGate gate{f->a.info, INFO_STRIDE, f->a.T, nullptr};
         if (f->strict_literal) {
-            SMC_LAUNCH(k_strict_W, dim3(nb, f->a.n_islands), dim3(SMC_BLOCK), st, f->a, f->strict_ws, (double*)nullptr);
+            // the definition: W written out, ONE lane adding it up in place (44 ms at N = 2^20), a search per offspring
+            SMC_LAUNCH(k_strict_W, gt, dim3(SMC_BLOCK), st, f->a, f->strict_ws, (double*)nullptr);
             SMC_LAUNCH(k_strict_cdf, dim3(1, f->a.n_islands), dim3(64), st, f->a, f->strict_ws);
-            S = f->strict_ws;
+            SMC_LAUNCH(k_strict_search_S, dim3((unsigned)((f->a.N / 2 + SMC_BLOCK) / SMC_BLOCK), f->a.n_islands), dim3(SMC_BLOCK), st,
+                       f->a, (const double*)f->strict_ws, (const double*)f->a.su);
+        } else if (f->two_level) {
+            // the same doubles in two launches, S never written (smc_filter_strict.h)
+            if (f->two_level_mid) SMC_LAUNCH(k_strict_classify<true>, gt, dim3(SMC_BLOCK), st, f->a, q);
+            else SMC_LAUNCH(k_strict_classify<false>, gt, dim3(SMC_BLOCK), st, f->a, q);
+            SMC_LAUNCH(k_strict_search, gt, dim3(SMC_BLOCK), st, f->a, q);
         } else {
-            SMC_LAUNCH(k_strict_W, dim3(nb, f->a.n_islands), dim3(SMC_BLOCK), st, f->a, f->strict_ws,
-                       seq_scratch_carve(seq_scr, f->a.N, f->a.n_islands).tsum);
-            seq_prefix_sums_launch(st, f->strict_ws, f->a.N, f->a.n_islands, S, seq_scr,
-                                   SeqGate{f->a.info, INFO_STRIDE, f->a.T, nullptr}, false, false, true);
+            // one tile (or a flat test path): W materialised, the two launches of smc_seqx.h on the array, S written
+            size_t used = 0;
+            (void)sqx_carve(sqx_scr, f->a.N, f->a.n_islands, &used);
+            double* tsum = (double*)((char*)sqx_scr + used);
+            SMC_LAUNCH(k_strict_W, gt, dim3(SMC_BLOCK), st, f->a, f->strict_ws, tsum);
+            SMC_LAUNCH(k_sqx_classify, gt, dim3(SMC_BLOCK), st, (const double*)f->strict_ws, (const double*)tsum, q, gate);
+            SMC_LAUNCH(k_sqx_fill, gt, dim3(SMC_BLOCK), st, q, S, gate);
+            SMC_LAUNCH(k_strict_search_S, dim3((unsigned)((f->a.N / 2 + SMC_BLOCK) / SMC_BLOCK), f->a.n_islands), dim3(SMC_BLOCK), st,
+                       f->a, (const double*)S, (const double*)f->a.su);
         }
-        SMC_LAUNCH(k_strict_search, dim3((unsigned)((f->a.N / 2 + SMC_BLOCK) / SMC_BLOCK), f->a.n_islands), dim3(SMC_BLOCK), st,
-                   f->a, (const double*)S, (const double*)f->a.su);
         if (k_prof >= 0 && (k_prof % 3)) (void)hipEventRecord(f->ev[3 * k_prof + 1], st);
         launch_propagate(f);
         if (k_prof >= 0) (void)hipEventRecord(f->ev[3 * k_prof + 2], st);
@@ -659,7 +672,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     // (inside a replayed graph the argument block -- the epoch with it -- is frozen: separate launches there)
     f->sp_merge = a.sp_tpw && merge_fits && !o->use_graph && !(o->flags & SMC_PATH_SPLIT_REDUCE);
     const size_t oTmp = carve(N * dxm * 8);
-    const size_t oStrict = carve(f->strict ? 2 * M * N * 8 + seq_scratch_bytes((i64)N, (int)M) : 8);
+    const size_t oStrict = carve(f->strict ? 2 * M * N * 8 + sqx_scratch_bytes((i64)N, (int)M) + M * a.ntiles * 8 + 64 : 8);
     if (f->sqmc && !f->sq_flat && !f->two_level) {
         smc_set_error("SMC_FLAG_SQMC needs the two-level step");
         delete f;
@@ -746,8 +759,8 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     F_CREATE_CHECK(hipMemsetAsync(a.sdec, 0, M * 8, ctx->stream));
     f->tmp = (double*)(base + oTmp);
     f->strict_ws = (double*)(base + oStrict);
-    if (f->strict)         // (the exception counters of smc_seqsum.h: zero once, re-armed by its passes)
-        F_CREATE_CHECK(hipMemsetAsync(f->strict_ws + 2 * M * N, 0, seq_scratch_bytes((i64)N, (int)M), ctx->stream));
+    if (f->strict)         // (the counters of smc_seqx.h: zero once, re-armed by its passes)
+        sqx_zero_counters(ctx->stream, (void*)(f->strict_ws + 2 * M * N), (i64)N, (int)M);
     if (apf_mv) {
         a.eta = (double*)(base + oEta);
         a.lwsv = a.eta + M * N;
@@ -1753,8 +1766,9 @@ int smc_filter_describe(smc_filter* f, char* out, size_t n)
         s = "k_rs_sort+k_sq_permute+k_reduce2+k_ancestors2+k_sq_compose+k_propagate";
         if (f->a.mom) s += "+k_f_moments_partials+k_f_moments_final";
     } else if (f->strict) {
-        s = std::string(f->two_level ? "k_reduce2+" : "") + "k_strict_W+" + (f->strict_literal ? "k_strict_cdf" : "k_seq_elem") +
-            "+k_strict_search+k_propagate";
+        if (f->strict_literal) s = std::string(f->two_level ? "k_reduce2+" : "") + "k_strict_W+k_strict_cdf+k_strict_search_S+k_propagate";
+        else if (f->two_level) s = std::string(f->two_level_mid ? "k_reduce2+" : "") + "k_strict_classify+k_strict_search+k_propagate";
+        else s = "k_strict_W+k_sqx_classify+k_sqx_fill+k_strict_search_S+k_propagate";
     } else {
         if (f->two_level_mid) s = "k_reduce2+k_ancestors2";
         else if (f->two_level) s = f->wide_tpw ? "k_ancestors2w" : "k_ancestors2";

@@ -2891,7 +2891,7 @@ __global__ void __launch_bounds__(SMC_BLOCK)
 k_strict_W(const FArgs av, double* Wout, double* tsum)
 {
     // one tile of 1024 weights per workgroup, 4 per thread; tsum (may be null): the tile's fp64 sum -- the estimate
-    // smc_seqsum.h's passes start from (its k_seq_tile_sums, saved a launch)
+    // smc_seqx.h's classification starts from (k_seq_tile_sums, saved a launch)
     const FArgs& a = av;
     __shared__ double smd[SMC_SM];
     const int isl = (int)blockIdx.y, b = (int)blockIdx.x;
@@ -2953,8 +2953,10 @@ k_strict_cdf(const FArgs av, double* WS)
         if (i < n) o[i] = mine;
     }
 }
+// (the searches against a MATERIALISED S: filters of one tile, the flat test paths, the literal walk; the two-level step
+//  never writes S -- smc_filter_strict.h)
 __global__ void __launch_bounds__(SMC_BLOCK)
-k_strict_search(const FArgs av, const double* S, const double* su_mem)
+k_strict_search_S(const FArgs av, const double* S, const double* su_mem)
 {
     const FArgs& a = av;
     const int isl = (int)blockIdx.y;

@@ -1,0 +1,143 @@
+// smc_filter_strict.h -- SMC_FLAG_STRICT_ANCESTORS on the two-level step: the reference's own inverse_cdf
+// (resampling.py:484-509: the CDF accumulated sequentially in fp64, the strict `>` advance) on the filter's own
+// normalised weights, as TWO launches between two k_propagate launches (smc_seqx.h):
+//
+//   k_strict_classify<MID>(t)  one workgroup per tile of 1024 parents.  Unless k_reduce2 ran (MID: more than 1024
+//       tiles, multinomial), every workgroup reduces the island's log-sum-exp partials itself -- K, s, ESS, the
+//       decision, exactly k_ancestors2's operations -- and workgroup 0 writes the step record and the summary row.
+//       W_j = p_j 2^(k_j - K) / s (the values smc_filter_get(SMC_FIELD_W) returns) is formed in registers and never
+//       stored; the estimate of the running sum in front of the tile comes from the same partials (S_b 2^(K_b - K) / s:
+//       within a few ulps of the tile's true sum).  Classification, the exception lists, and -- in the last workgroup
+//       of the island to finish -- the walk, the verification and the tiles' headers: sqx_classify_tile / sqx_chain.
+//   k_strict_search(t)         one workgroup per tile of parents: the tile's sums staged in LDS, its range of
+//       offspring, a bisection per offspring: A_t (sqx_search_tile).
+//
+// The step is then k_propagate -> k_strict_classify -> k_strict_search -> k_propagate: three dependent launches
+// (round 4: eight).  Filters of fewer than two tiles, and the flat-CDF test paths, keep the materialised form
+// (k_strict_W -> smc_seqx.h on the array -> k_sqx_fill -> k_strict_search_S).
+#pragma once
+#include "smc_filter_kernels.h"
+#include "smc_seqx.h"
+
+// the filter's normalised weights of step t - 1, formed on the fly
+struct SqxSrcFilter {
+    const double* lw;
+    double K, rs;
+    int kform;
+    i64 n;
+    __device__ __forceinline__ double weight(const double l) const
+    {
+        if (kform) {
+            double kk;
+            double p = smc_expk(l, kk);
+            const bool ok = l > -INFINITY;
+            p = ok ? p : 0.0;
+            kk = ok ? kk : -INFINITY;
+            return smc_scale_pk(p, kk, K) * rs;
+        }
+        return f_weight(l, K, rs);
+    }
+    __device__ __forceinline__ void load4(const i64 i0, double (&w)[4]) const
+    {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w[k] = (i0 + k < n) ? weight(lw[i0 + k]) : 0.0;
+    }
+};
+
+template <bool MID>
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_strict_classify(const FArgs av, const SqxArgs q)
+{
+    const FArgs& a = av;
+    __shared__ double s_max[SMC_NWAVE];
+    __shared__ double s_sum[2 * SMC_NWAVE];
+    __shared__ double smd[SMC_SM];
+    __shared__ int s_flag;
+    const int b = (int)blockIdx.x, isl = (int)blockIdx.y, tid = (int)threadIdx.x;
+    const int lane = smc_lane(), wave = smc_wave();
+    double* info = a.info + (i64)isl * INFO_STRIDE;
+    const double r0 = smc_ldg(MID ? info : a.info2 + (i64)isl * INFO_STRIDE);
+    const i64 o = (i64)isl * a.nparts;
+    double pm4[4], ps4[4], pss4[4];
+    if (!MID) {
+        const bool pvec = (a.nparts & 3) == 0;
+        f_load4<double>(a.pm + o, (i64)tid * 4, a.nparts, pvec, -INFINITY, pm4);
+        f_load4<double>(a.ps + o, (i64)tid * 4, a.nparts, pvec, 0.0, ps4);
+        f_load4<double>(a.pss + o, (i64)tid * 4, a.nparts, pvec, 0.0, pss4);
+    }
+    const i64 t = (i64)smc_uniform(r0);
+    if (t >= a.T) {
+        if (!MID && b == 0 && tid == 0) info[0] = (double)t;   // k_propagate returns on it
+        return;
+    }
+    if (t == 0) return;                                        // the host wrote the record of step 0
+    double K, rs, before = 0.0;
+    if (MID) {
+        if (smc_uniform(smc_ldg(info + 1)) == 0.0) return;     // k_reduce2: step t does not resample
+        K = smc_uniform(smc_ldg(info + 3));
+        rs = smc_uniform(smc_ldg(info + 4));
+        for (int i = tid; i < b; i += SMC_BLOCK) {
+            double v, w;
+            f2_rescale(smc_ldg(a.pm + o + i), K, smc_ldg(a.ps + o + i), 0.0, v, w);
+            before += v * rs;
+        }
+        before = smc_block_sum(before, smd);
+        __syncthreads();
+    } else {
+        // ---- all partials -> K, (s, ss), ESS, the decision: k_ancestors2's operations, hence its bits
+        double tm = smc_max2(smc_max2(pm4[0], pm4[1]), smc_max2(pm4[2], pm4[3]));
+        tm = smc_wave_max(tm);
+        if (lane == 0) s_max[wave] = tm;
+        __syncthreads();
+        F2Red r;
+        r.K = s_max[0];
+#pragma unroll
+        for (int w = 1; w < SMC_NWAVE; ++w) r.K = smc_max2(r.K, s_max[w]);
+        double v4[4], s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            double w;
+            f2_rescale(pm4[k], r.K, ps4[k], pss4[k], v4[k], w);
+            s1 = s1 + v4[k];
+            s2 = s2 + w;
+        }
+        s1 = smc_wave_sum(s1);
+        s2 = smc_wave_sum(s2);
+        if (lane == 0) { s_sum[wave] = s1; s_sum[SMC_NWAVE + wave] = s2; }
+        __syncthreads();
+        s1 = s_sum[0];
+        s2 = s_sum[SMC_NWAVE];
+#pragma unroll
+        for (int w = 1; w < SMC_NWAVE; ++w) { s1 = s1 + s_sum[w]; s2 = s2 + s_sum[SMC_NWAVE + w]; }
+        r.s = s1;
+        r.ss = s2;
+        f2_finish(a, r);
+        const bool resample = r.ess < a.ess_thresh;            // core.py:181-183 (t < T here)
+        if (b == 0 && tid == 0) f2_write_record(a, isl, t, r, resample);
+        if (!resample) return;
+        K = r.K;
+        rs = r.rs;
+        // the estimate of the sum in front of this tile: the tiles' shares of the island's sum
+#pragma unroll
+        for (int k = 0; k < 4; ++k) before += (tid * 4 + k < b) ? v4[k] * rs : 0.0;
+        before = smc_block_sum(before, smd);
+        __syncthreads();
+    }
+    const SqxSrcFilter src{f_lw(a, t - 1) + (i64)isl * a.N, K, rs, a.kform, a.N};
+    sqx_classify_tile(src, isl, b, before, q);
+    if (sqx_last_block(q.tick + (i64)isl * SQX_CNT_WORDS, b, q.ntiles, &s_flag)) sqx_chain(src, isl, q);
+}
+
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_strict_search(const FArgs av, const SqxArgs q)
+{
+    const FArgs& a = av;
+    const int isl = (int)blockIdx.y;
+    const double* info = a.info + (i64)isl * INFO_STRIDE;
+    const i64 t = (i64)smc_uniform(smc_ldg(info));
+    if (t >= a.T || t == 0 || smc_uniform(smc_ldg(info + 1)) == 0.0) return;
+    SmcSu su;
+    u64 Us;
+    f2_su(a, isl, t, su, Us);
+    sqx_search_tile<u32>(q, isl, (int)blockIdx.x, su, f_A(a, t) + (i64)isl * a.N);
+}

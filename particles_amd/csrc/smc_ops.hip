@@ -8,7 +8,7 @@
 
 #include "smc_internal.h"
 #include "smc_resample.h"
-#include "smc_seqsum.h"
+#include "smc_seqx.h"
 
 #define OPS_IPT 4
 #define OPS_TILE (SMC_BLOCK * OPS_IPT)
@@ -349,50 +349,76 @@ k_search_strict(const double* su, const double* S, i64 M, i64 N, i64* A)
     if (n < M) A[n] = smc_first_ge(S, N, su[n]);
 }
 
-// S <- prefix sums of W as the reference's loop forms them (test hook: mode 0 the parallel emulation of
-// smc_seqsum.h, mode 1 the literal one-lane walk it must equal bit for bit)
+// the two launches of smc_seqx.h on an array of weights (+ the pass that estimates the tiles' sums)
+static void sqx_launch_array(hipStream_t st, const double* W, const i64 N, void* scr, SqxArgs& q, double** tsum_out = nullptr)
+{
+    q = sqx_carve(scr, N, 1);
+    size_t used = 0;
+    (void)sqx_carve(scr, N, 1, &used);
+    double* tsum = (double*)((char*)scr + used);
+    sqx_zero_counters(st, scr, N, 1);
+    const SeqGate gate{nullptr, 0, 0, nullptr};
+    SMC_LAUNCH(k_seq_tile_sums, dim3(q.ntiles, 1), dim3(SMC_BLOCK), st, W, N, tsum, gate);
+    SMC_LAUNCH(k_sqx_classify, dim3(q.ntiles, 1), dim3(SMC_BLOCK), st, W, (const double*)tsum, q, gate);
+    if (tsum_out) *tsum_out = tsum;
+}
+static size_t sqx_array_scratch(const i64 N) { return sqx_scratch_bytes(N, 1) + (size_t)((N + SEQ_TILE - 1) / SEQ_TILE) * 8 + 64; }
+
+// S <- prefix sums of W as the reference's loop forms them (test hook: mode 0 the two-launch emulation of smc_seqx.h,
+// mode 2 the tile walk of smc_seqsum.h, mode 1 the literal one-lane walk both must equal bit for bit).
+// n_sequential_tiles: mode 2: tiles the walk did exactly; mode 0: -1 if the island took the exact path, else the number of
+// exceptions the walk handled.
 extern "C" int smc_seq_prefix_sums(smc_ctx* ctx, const double* W, int64_t N, double* S, int mode, int64_t* n_sequential_tiles)
 {
     SMC_REQUIRE(ctx && W && S, "null argument");
     if (n_sequential_tiles) *n_sequential_tiles = (N + SEQ_TILE - 1) / SEQ_TILE;
-    SMC_REQUIRE(N > 0, "N must be positive");
+    SMC_REQUIRE(N > 0 && N < ((int64_t)1 << 32), "N must be positive (and below 2^32)");
     SMC_HIP_CHECK(hipSetDevice(ctx->device));
     if (mode == 1) {
         SMC_LAUNCH(k_seq_cdf, dim3(1, 1), dim3(64), ctx->stream, W, (i64)N, S);
-    } else {
+    } else if (mode == 2) {
         void* scr;
         int rc = smc_scratch(ctx, seq_scratch_bytes((i64)N, 1), &scr);
         if (rc) return rc;
-        seq_prefix_sums_launch(ctx->stream, W, (i64)N, 1, S, scr, SeqGate{nullptr, 0, 0, nullptr}, mode == 2);
+        seq_tile_walk_launch(ctx->stream, W, (i64)N, 1, S, scr);
         if (n_sequential_tiles) {
-            // mode 2: tiles the walk did exactly; mode 0: -1 if the element-level pass had to fall back, else 0
             unsigned long long c = 0ull;
-            unsigned need = 0u;
             SMC_HIP_CHECK(hipMemcpyAsync(&c, seq_nseq_ptr(scr, (i64)N, 1), 8, hipMemcpyDeviceToHost, ctx->stream));
-            SMC_HIP_CHECK(hipMemcpyAsync(&need, seq_need_ptr(scr, (i64)N, 1), 4, hipMemcpyDeviceToHost, ctx->stream));
             SMC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-            *n_sequential_tiles = mode == 2 ? (int64_t)c : (need ? -1 : 0);
+            *n_sequential_tiles = (int64_t)c;
+        }
+    } else {
+        void* scr;
+        int rc = smc_scratch(ctx, sqx_array_scratch((i64)N), &scr);
+        if (rc) return rc;
+        SqxArgs q;
+        sqx_launch_array(ctx->stream, W, (i64)N, scr, q);
+        SMC_LAUNCH(k_sqx_fill, dim3(q.ntiles, 1), dim3(SMC_BLOCK), ctx->stream, q, S, SeqGate{nullptr, 0, 0, nullptr});
+        if (n_sequential_tiles) {
+            unsigned long long c[2] = {0ull, 0ull};
+            SMC_HIP_CHECK(hipMemcpyAsync(c, q.ctr + 2, 16, hipMemcpyDeviceToHost, ctx->stream));
+            SMC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            *n_sequential_tiles = c[0] ? -1 : (int64_t)c[1];
         }
     }
     SMC_LAUNCH_CHECK();
     return SMC_OK;
 }
 
-// inverse_cdf exactly as the reference computes it (sequential fp64 CDF): see smc_resample.h "STRICT"
+// inverse_cdf exactly as the reference computes it (sequential fp64 CDF, resampling.py:500-509): the sums by the two
+// launches of smc_seqx.h, never written out -- every tile of parents finds its offspring among the sorted uniforms
 extern "C" int smc_inverse_cdf_strict(smc_ctx* ctx, const double* su_dev, const double* W, int64_t M,
                                       int64_t N, int64_t* A)
 {
     SMC_REQUIRE(ctx && su_dev && W && A, "null argument");
-    SMC_REQUIRE(M > 0 && N > 0, "M and N must be positive");
+    SMC_REQUIRE(M > 0 && N > 0 && N < ((int64_t)1 << 32), "M and N must be positive (N below 2^32)");
     SMC_HIP_CHECK(hipSetDevice(ctx->device));
-    // S = the reference's sequential prefix sums, bit for bit: in parallel (smc_seqsum.h) -- k_seq_cdf, the literal
-    // one-lane walk, stays as the definition the tests compare it with (smc_seq_cdf_literal)
     void* scr;
-    int rc = smc_scratch(ctx, (size_t)N * 8 + seq_scratch_bytes((i64)N, 1), &scr);
+    int rc = smc_scratch(ctx, sqx_array_scratch((i64)N), &scr);
     if (rc) return rc;
-    seq_prefix_sums_launch(ctx->stream, W, (i64)N, 1, (double*)scr, (char*)scr + (size_t)N * 8, SeqGate{nullptr, 0, 0, nullptr});
-    SMC_LAUNCH(k_search_strict, dim3((unsigned)((M + SMC_BLOCK - 1) / SMC_BLOCK)), dim3(SMC_BLOCK), ctx->stream,
-               su_dev, (const double*)scr, (i64)M, (i64)N, (i64*)A);
+    SqxArgs q;
+    sqx_launch_array(ctx->stream, W, (i64)N, scr, q);
+    SMC_LAUNCH(k_sqx_search_sorted, dim3(q.ntiles, 1), dim3(SMC_BLOCK), ctx->stream, q, su_dev, (i64)M, (i64*)A);
     SMC_LAUNCH_CHECK();
     return SMC_OK;
 }

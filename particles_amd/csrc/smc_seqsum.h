@@ -22,8 +22,10 @@
 // W >= 0 (ties, zeros, subnormals, one element holding all the mass); NaN or negative weights make every tile
 // fail its verification and the whole array goes element by element -- slow, still the reference's values.
 //
-// Cost at N = 2^20: ~50 us instead of 2.5 ms (profiles/r12*_strict*).  Used by smc_inverse_cdf_strict
-// (smc_ops.hip) and by the filter's SMC_FLAG_STRICT_ANCESTORS path (smc_filter.hip).
+// Cost at N = 2^20: 0.2 - 0.8 ms instead of 43 (profiles/r12*_strict*).  Since round 5 this tile walk is the
+// definition-level form the tests hold the production path against (smc_seq_prefix_sums mode 2); the production path --
+// smc_inverse_cdf_strict (smc_ops.hip) and the filter's SMC_FLAG_STRICT_ANCESTORS (smc_filter.hip) -- is smc_seqx.h: the
+// same idea at ELEMENT granularity in two launches, with seq_tile_block_exact below as its exact fallback.
 #pragma once
 
 #define SEQ_TILE 1024                  /* elements per tile: 4 per thread of a 256-thread workgroup */
@@ -315,290 +317,17 @@ k_seq_fill(const double* W, const i64 n, const int* tk, const double* tstart, do
     }
 }
 
-// =====================================================================================================================
-// The same at ELEMENT granularity -- the fast path; the tile walk above is its fallback.
-// An element j is REGULAR when the estimate puts the running sum before AND after it inside one binade E_j (margin as
-// above) and it is neither a tie nor above that binade; everything else -- the few elements at which the sum changes
-// binade, the first elements of the array, ties -- is an EXCEPTION, a few dozen per call.  Consecutive regular elements
-// share their grid (E_{j+1} = E_j: see DESIGN 5.4), so between two exceptions the chain is an integer sum
-// P[j] = sum_{i < j} r_i of the regular elements' roundings -- one parallel scan over the whole array -- and the SERIAL
-// part shrinks to the exceptions themselves: one thread walks the sorted list, s <- (I(s) + P-difference) on the grid,
-// then s <- s + W_x with the hardware's own addition.  k_seq_elem_fill writes S_j = (I(S_x) + P[j+1] - P[x+1]) g for the
-// regular elements behind exception x and VERIFIES what the walk assumed (the base's binade is E_j, the integer stays
-// below 2^53): any violation, or more exceptions than the list holds, raises `need_fallback` and k_seq_fallback redoes
-// the array.  Cost at N = 2^20: four short launches (+ the fallback's, which returns at once).
-#define SEQ_E_ANY (-2)                 /* SeqElem::E of a zero element: regular on whatever grid the sum is on */
-#define SEQ_XCAP 2048                  /* exceptions the list holds per island (48 KB of LDS in the walk): more than a
-                                          sum can cross binades (2046) -- only engineered ties or NaN weights overflow it */
-struct SeqX {                          // one exception: its index and value, P in front of it (tile-local, then global)
-    i64 j;
-    u64 P;
-    double w;
-};
-// what a thread knows about its 4 elements of tile b (the same code in the classify and the fill pass: same bits)
-struct SeqElem {
-    double w[4];
-    int E[4];                          // grid (biased exponent) of a regular element; -1: exception
-    u64 r[4];                          // its rounding (0 for exceptions)
-    u64 Pex[4];                        // tile-local exclusive prefix of r at each element
-    u64 rtot;                          // the tile's sum of r
-};
-__device__ __forceinline__ void seq_elem_eval(const double* w, const i64 n, const double* ts, const int b, SeqElem& e,
-                                              double* smd, u64* smu)
-{
-    const int tid = (int)threadIdx.x;
-    double before = 0.0;
-    for (int j = tid; j < b; j += SMC_BLOCK) before += ts[j];
-    before = smc_block_sum(before, smd);
-    const i64 i0 = (i64)b * SEQ_TILE + (i64)tid * 4;
-    double mysum = 0.0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        e.w[k] = (i0 + k < n) ? w[i0 + k] : 0.0;
-        mysum += e.w[k];
-    }
-    __syncthreads();                                           // (smd is reused)
-    double tot;
-    double run = before + smc_block_exscan_f64(mysum, smd, tot);   // estimate of the running sum in front of my elements
-    u64 rs = 0ull;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const double lo = run, hi = run + e.w[k];
-        run = hi;
-        const int E_lo = seq_bexp(lo * (1.0 - 0x1.0p-20)), E_hi = seq_bexp(hi * (1.0 + 0x1.0p-20));
-        bool tie, big;
-        const u64 r = seq_round_to_grid(e.w[k], E_lo >= 1 ? E_lo : 1, tie, big);
-        const bool regular = i0 + k < n && lo > 0.0 && E_lo == E_hi && E_lo >= 1 && E_lo < 0x7fe && !tie && !big;
-        // (a zero adds nothing on any grid: regular wherever the sum is -- SEQ_E_ANY; this keeps a collapsed weight
-        //  vector, zeros around one mass sitting exactly on a power of two, on the fast path)
-        const bool zero = i0 + k < n && e.w[k] == 0.0 && (u64)__double_as_longlong(e.w[k]) == 0ull;
-        e.E[k] = zero ? SEQ_E_ANY : (regular ? E_lo : -1);
-        e.r[k] = (regular && !zero) ? r : 0ull;
-        rs += e.r[k];
-    }
-    u64 pre = smc_block_exscan_u64(rs, smu, e.rtot);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        e.Pex[k] = pre;
-        pre += e.r[k];
-    }
-}
-static __global__ void __launch_bounds__(SMC_BLOCK)
-k_seq_elem_classify(const double* W, const i64 n, const double* tsum, u64* Rt, SeqX* xlist, unsigned* xcount, unsigned* need_fallback,
-                    const SeqGate gate)
-{
-    __shared__ double smd[SMC_SM];
-    __shared__ u64 smu[SMC_SM];
-    const int isl = (int)blockIdx.y, b = (int)blockIdx.x, tid = (int)threadIdx.x, ntiles = (int)gridDim.x;
-    if (!seq_gate_open(gate, isl)) return;
-    SeqElem e;
-    seq_elem_eval(W + (i64)isl * n, n, tsum + (i64)isl * ntiles, b, e, smd, smu);
-    if (tid == 0) Rt[(i64)isl * ntiles + b] = e.rtot;
-    const i64 i0 = (i64)b * SEQ_TILE + (i64)tid * 4;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (i0 + k < n && e.E[k] == -1) {
-            const unsigned slot = atomicAdd(xcount + isl, 1u);
-            if (slot < SEQ_XCAP) {
-                SeqX x;
-                x.j = i0 + k;
-                x.P = e.Pex[k];
-                x.w = e.w[k];
-                xlist[(i64)isl * SEQ_XCAP + slot] = x;
-            }
-        }
-    }
-}
-// one workgroup per island: the tiles' P offsets, the exceptions in order, the walk over them, every tile's base
-static __global__ void __launch_bounds__(SMC_BLOCK)
-k_seq_elem_chain(const double* W, const i64 n, const int ntiles, const u64* Rt, u64* Pt, SeqX* xlist, unsigned* xcount,
-                 unsigned* need_fallback, int* tbase, double* S, const SeqGate gate)
-{
-    __shared__ u64 smu[SMC_SM];
-    __shared__ SeqX sx[SEQ_XCAP];
-    const int isl = (int)blockIdx.x, tid = (int)threadIdx.x;
-    if (!seq_gate_open(gate, isl)) return;
-    double* So = S + (i64)isl * n;
-    u64* Pto = Pt + (i64)isl * ntiles;
-    SeqX* xl = xlist + (i64)isl * SEQ_XCAP;
-    const unsigned cnt = xcount[isl];
-    __syncthreads();
-    if (tid == 0) { xcount[isl] = 0u; need_fallback[isl] = cnt > SEQ_XCAP ? 1u : 0u; }     // (the counter: re-armed)
-    if (cnt > SEQ_XCAP) return;                                // too many: the tile walk does the array
-    // ---- P offsets of the tiles
-    u64 carry = 0ull;
-    for (int b0 = 0; b0 < ntiles; b0 += SMC_BLOCK) {
-        const int b = b0 + tid;
-        u64 tot;
-        const u64 pre = smc_block_exscan_u64(b < ntiles ? Rt[(i64)isl * ntiles + b] : 0ull, smu, tot);
-        if (b < ntiles) Pto[b] = carry + pre;
-        carry += tot;
-        __syncthreads();
-    }
-    // ---- the exceptions, sorted by index (bitonic, padded with +inf keys), P made global
-    int m = 1;
-    while (m < (int)cnt) m <<= 1;
-    for (int i = tid; i < m; i += SMC_BLOCK) {
-        SeqX x;
-        if (i < (int)cnt) {
-            x = xl[i];
-            x.P += Pto[x.j / SEQ_TILE];
-        } else {
-            x.j = (i64)0x7fffffffffffffffll; x.P = 0ull; x.w = 0.0;
-        }
-        sx[i] = x;
-    }
-    __syncthreads();
-    for (int k = 2; k <= m; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < m; i += SMC_BLOCK) {
-                const int l = i ^ j;
-                if (l > i) {
-                    const bool up = (i & k) == 0;
-                    const SeqX a = sx[i], c = sx[l];
-                    if ((a.j > c.j) == up) { sx[i] = c; sx[l] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    // ---- the walk (one thread): segment of regular elements as an integer sum, the exception with the hardware's addition
-    if (tid == 0) {
-        double s = 0.0;
-        u64 Pprev = 0ull;
-        bool ok = true;                                        // (s = 0 + W[0] = W[0] starts the chain, resampling.py:506)
-        for (int i = 0; ok && i < (int)cnt; ++i) {
-            const i64 j = sx[i].j;
-            const u64 dP = sx[i].P - Pprev;
-            if (dP != 0ull) {                                  // regular non-zero elements in between: on the grid of s
-                const int Es = seq_bexp(s);
-                const u64 I = ((u64)__double_as_longlong(s) & 0x000FFFFFFFFFFFFFull) | 0x0010000000000000ull;
-                const u64 Iv = I + dP;
-                ok = Es >= 1 && Es < 0x7ff && Iv < (1ull << 53);
-                s = __longlong_as_double((long long)(((u64)Es << 52) | (Iv & 0x000FFFFFFFFFFFFFull)));
-            }
-            s = s + sx[i].w;                                   // resampling.py:508, the hardware's own addition
-            So[j] = s;
-            Pprev = sx[i].P;
-        }
-        if (!ok) need_fallback[isl] = 1u;
-    }
-    __syncthreads();
-    // ---- every tile's base: the last exception in front of it (index into the sorted list, written back for the fill)
-    for (int i = tid; i < (int)cnt; i += SMC_BLOCK) xl[i] = sx[i];
-    for (int b = tid; b < ntiles; b += SMC_BLOCK) {
-        const i64 lo_j = (i64)b * SEQ_TILE;
-        int lo = 0, hi = (int)cnt;                             // first exception with j >= lo_j
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (sx[mid].j < lo_j) lo = mid + 1; else hi = mid;
-        }
-        tbase[(i64)isl * ntiles + b] = lo - 1;                 // (-1 for tile 0: it starts with exception 0)
-    }
-}
-static __global__ void __launch_bounds__(SMC_BLOCK)
-k_seq_elem_fill(const double* W, const i64 n, const double* tsum, const u64* Pt, const SeqX* xlist, unsigned* need_fallback,
-                const int* tbase, double* S, const SeqGate gate)
-{
-    __shared__ double smd[SMC_SM];
-    __shared__ u64 smu[SMC_SM];
-    __shared__ u32 s_mx[SMC_NWAVE];
-    __shared__ u64 s_P[SEQ_TILE];
-    const int isl = (int)blockIdx.y, b = (int)blockIdx.x, tid = (int)threadIdx.x, ntiles = (int)gridDim.x;
-    if (!seq_gate_open(gate, isl)) return;
-    if (smc_uniform_u64((u64)need_fallback[isl]) != 0ull) return;      // (the walk gave up: the tile passes write S)
-    SeqElem e;
-    seq_elem_eval(W + (i64)isl * n, n, tsum + (i64)isl * ntiles, b, e, smd, smu);
-    double* So = S + (i64)isl * n;
-    const SeqX* xl = xlist + (i64)isl * SEQ_XCAP;
-    const u64 Ptb = Pt[(i64)isl * ntiles + b];
-    const int base0 = tbase[(i64)isl * ntiles + b];
-    // last exception at or in front of each element, inside the tile: a running maximum over (local index + 1)
-    u32 mine = 0u;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        s_P[tid * 4 + k] = e.Pex[k];
-        if (e.E[k] == -1 && (i64)b * SEQ_TILE + tid * 4 + k < n) mine = (u32)(tid * 4 + k + 1);
-    }
-    const u32 inc = smc_wave_scan_max_u32(mine);
-    u32 ex = smc_mov_dpp<SMC_DPP_WAVE_SHR1>(inc);
-    if (smc_lane() == 0) ex = 0u;
-    if (smc_lane() == 63) s_mx[smc_wave()] = inc;
-    __syncthreads();                                           // (s_P is written too)
-    for (int ww = 0; ww < smc_wave(); ++ww) ex = ex > s_mx[ww] ? ex : s_mx[ww];
-    u32 last = ex;                                             // exceptions in front of this thread's elements
-    bool bad = false;
-    const i64 i0 = (i64)b * SEQ_TILE + (i64)tid * 4;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (i0 + k >= n) continue;
-        if (e.E[k] == -1) { last = (u32)(tid * 4 + k + 1); continue; }   // its S is the walk's
-        double baseS = 0.0;                                    // (nothing in front: the sum is still zero)
-        u64 baseP = 0ull;
-        if (last) {                                            // an exception inside the tile
-            baseS = So[(i64)b * SEQ_TILE + (last - 1u)];
-            baseP = Ptb + s_P[last - 1u];
-        } else if (base0 >= 0) {
-            baseS = So[xl[base0].j];                           // (the walk wrote the exception's own sum)
-            baseP = xl[base0].P;
-        }
-        const u64 dP = Ptb + e.Pex[k] + e.r[k] - baseP;
-        if (dP == 0ull) {                                      // only zeros since the base: its value, whatever it is
-            bad = bad || (e.E[k] != SEQ_E_ANY && e.E[k] != seq_bexp(baseS));
-            So[i0 + k] = baseS;
-            continue;
-        }
-        const int Es = seq_bexp(baseS);
-        const u64 I = ((u64)__double_as_longlong(baseS) & 0x000FFFFFFFFFFFFFull) | 0x0010000000000000ull;
-        const u64 Iv = I + dP;
-        bad = bad || Es < 1 || Es >= 0x7ff || (e.E[k] != SEQ_E_ANY && Es != e.E[k]) || Iv >= (1ull << 53);
-        So[i0 + k] = __longlong_as_double((long long)(((u64)Es << 52) | (Iv & 0x000FFFFFFFFFFFFFull)));
-    }
-    if (bad) need_fallback[isl] = 1u;
-}
-
-// ---- the fallback as ONE launch (the filter's step loop pays a launch for it every step, needed or not): one
-// workgroup per island does every tile exactly with seq_tile_block_exact -- a clean tile is one scan, an exceptional
-// one a scan per exception.  ~3 us per tile: milliseconds at N = 2^20, but only engineered ties, NaN or negative
-// weights get here (SEQ_XCAP holds more exceptions than a sum can cross binades).  The tile walk above (three
-// launches, 0.2 - 0.8 ms) stays as smc_seq_prefix_sums' mode 2.
-static __global__ void __launch_bounds__(SMC_BLOCK)
-k_seq_fallback(const double* W, const i64 n, double* S, const SeqGate gate)
-{
-    __shared__ u64 smu[SMC_SM];
-    __shared__ int s_idx;
-    __shared__ double s_tmp;
-    const int isl = (int)blockIdx.x, tid = (int)threadIdx.x;
-    if (!seq_gate_open(gate, isl)) return;
-    const double* w = W + (i64)isl * n;
-    double* So = S + (i64)isl * n;
-    double s = 0.0;
-    bool first = true;
-    for (i64 lo = 0; lo < n; lo += SEQ_TILE) {
-        const int m_all = (int)(lo + SEQ_TILE < n ? SEQ_TILE : n - lo);
-        double w4[4], o4[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) w4[k] = tid * 4 + k < m_all ? w[lo + tid * 4 + k] : 0.0;
-        s = seq_tile_block_exact(w4, o4, m_all, s, first, smu, &s_idx, &s_tmp);
-        first = false;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (tid * 4 + k < m_all) So[lo + tid * 4 + k] = o4[k];
-    }
-}
-
-// scratch the passes need besides S, per island: per tile 4 x 8 + 2 x 8 bytes, the exception list, three words
+// scratch the tile walk needs besides S, per island: per tile 3 x 8 + 4 bytes, a counter
 static inline size_t seq_scratch_bytes(const i64 n, const int islands)
 {
     const size_t ntiles = (size_t)((n + SEQ_TILE - 1) / SEQ_TILE);
-    return (size_t)islands * (ntiles * 48 + SEQ_XCAP * sizeof(SeqX) + 32);
+    return (size_t)islands * (ntiles * 32 + 16) + 64;
 }
 struct SeqScratch {
     double *tsum, *tstart;
-    u64 *tT, *Rt, *Pt;
-    int *tk, *tbase;
-    SeqX* xlist;
+    u64* tT;
+    int* tk;
     unsigned long long* nseq;
-    unsigned *xcount, *need;
 };
 static inline SeqScratch seq_scratch_carve(void* scratch, const i64 n, const int islands)
 {
@@ -608,50 +337,24 @@ static inline SeqScratch seq_scratch_carve(void* scratch, const i64 n, const int
     q.tsum = (double*)p; p += nt * 8;
     q.tstart = (double*)p; p += nt * 8;
     q.tT = (u64*)p; p += nt * 8;
-    q.Rt = (u64*)p; p += nt * 8;
-    q.Pt = (u64*)p; p += nt * 8;
-    q.tk = (int*)p; p += nt * 4;
-    q.tbase = (int*)p; p += nt * 4;
-    q.xlist = (SeqX*)p; p += (size_t)islands * SEQ_XCAP * sizeof(SeqX);
     q.nseq = (unsigned long long*)p; p += (size_t)islands * 8;
-    q.xcount = (unsigned*)p; p += (size_t)islands * 4;
-    q.need = (unsigned*)p;
+    q.tk = (int*)p;
     return q;
 }
-// (where the walk's count of tiles it did exactly sits in the scratch: one u64 per island; the fallback flag)
+// (where the walk's count of tiles it did exactly sits in the scratch: one u64 per island)
 static inline const unsigned long long* seq_nseq_ptr(const void* scratch, const i64 n, const int islands)
 {
     return seq_scratch_carve((void*)scratch, n, islands).nseq;
 }
-static inline const unsigned* seq_need_ptr(const void* scratch, const i64 n, const int islands)
-{
-    return seq_scratch_carve((void*)scratch, n, islands).need;
-}
-// S <- the reference's sequential fp64 prefix sums of W (both (islands, n), S may not alias W).  `scratch`: seq_scratch_bytes;
-// zero_counters = false: the caller zeroed it once (the exception counters are re-armed by the passes themselves).
-// tiles_only: the tile walk alone (tests: the fallback must give the same bits)
-static inline void seq_prefix_sums_launch(hipStream_t st, const double* W, const i64 n, const int islands, double* S, void* scratch,
-                                          const SeqGate gate, const bool tiles_only = false, const bool zero_counters = true,
-                                          const bool have_tile_sums = false)
+// S <- the reference's sequential fp64 prefix sums of W (both (islands, n), S may not alias W) by the TILE WALK: the
+// definition-level parallel form the two-launch path of smc_seqx.h is tested against (smc_seq_prefix_sums mode 2).
+static inline void seq_tile_walk_launch(hipStream_t st, const double* W, const i64 n, const int islands, double* S, void* scratch)
 {
     const int ntiles = (int)((n + SEQ_TILE - 1) / SEQ_TILE);
     const SeqScratch q = seq_scratch_carve(scratch, n, islands);
-    if (zero_counters) (void)hipMemsetAsync(q.xcount, 0, (size_t)islands * 8, st);       // (xcount and need: adjacent)
-    // (have_tile_sums: the caller's kernel that wrote W left the tiles' fp64 sums in the scratch's first array)
-    if (!have_tile_sums) SMC_LAUNCH(k_seq_tile_sums, dim3(ntiles, islands), dim3(SMC_BLOCK), st, W, n, q.tsum, gate);
-    SeqGate fb = gate;
-    if (!tiles_only) {
-        SMC_LAUNCH(k_seq_elem_classify, dim3(ntiles, islands), dim3(SMC_BLOCK), st, W, n, (const double*)q.tsum, q.Rt, q.xlist,
-                   q.xcount, q.need, gate);
-        SMC_LAUNCH(k_seq_elem_chain, dim3(islands), dim3(SMC_BLOCK), st, W, n, ntiles, (const u64*)q.Rt, q.Pt, q.xlist, q.xcount,
-                   q.need, q.tbase, S, gate);
-        SMC_LAUNCH(k_seq_elem_fill, dim3(ntiles, islands), dim3(SMC_BLOCK), st, W, n, (const double*)q.tsum, (const u64*)q.Pt,
-                   (const SeqX*)q.xlist, q.need, (const int*)q.tbase, S, gate);
-        fb.only_if = q.need;                                   // only where the fast path gave up
-        SMC_LAUNCH(k_seq_fallback, dim3(islands), dim3(SMC_BLOCK), st, W, n, S, fb);
-        return;
-    }
-    SMC_LAUNCH(k_seq_tile_classify, dim3(ntiles, islands), dim3(SMC_BLOCK), st, W, n, (const double*)q.tsum, q.tk, q.tT, fb);
-    SMC_LAUNCH(k_seq_chain, dim3(islands), dim3(SMC_BLOCK), st, W, n, ntiles, q.tk, (const u64*)q.tT, q.tstart, S, q.nseq, fb);
-    SMC_LAUNCH(k_seq_fill, dim3(ntiles, islands), dim3(SMC_BLOCK), st, W, n, (const int*)q.tk, (const double*)q.tstart, S, fb);
+    const SeqGate gate{nullptr, 0, 0, nullptr};
+    SMC_LAUNCH(k_seq_tile_sums, dim3(ntiles, islands), dim3(SMC_BLOCK), st, W, n, q.tsum, gate);
+    SMC_LAUNCH(k_seq_tile_classify, dim3(ntiles, islands), dim3(SMC_BLOCK), st, W, n, (const double*)q.tsum, q.tk, q.tT, gate);
+    SMC_LAUNCH(k_seq_chain, dim3(islands), dim3(SMC_BLOCK), st, W, n, ntiles, q.tk, (const u64*)q.tT, q.tstart, S, q.nseq, gate);
+    SMC_LAUNCH(k_seq_fill, dim3(ntiles, islands), dim3(SMC_BLOCK), st, W, n, (const int*)q.tk, (const double*)q.tstart, S, gate);
 }

@@ -312,6 +312,8 @@ inline double __longlong_as_double(long long v) { double d; memcpy(&d, &v, 8); r
 inline long long __double_as_longlong(double d) { long long v; memcpy(&v, &d, 8); return v; }
 inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p += v; return o; }
 inline int atomicMin(int* p, int v) { int o = *p; if (v < o) *p = v; return o; }
+inline unsigned atomicMin(unsigned* p, unsigned v) { unsigned o = *p; if (v < o) *p = v; return o; }
+inline unsigned atomicMax(unsigned* p, unsigned v) { unsigned o = *p; if (v > o) *p = v; return o; }
 inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) {
     unsigned long long o = *p; *p += v; return o;
 }

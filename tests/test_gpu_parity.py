@@ -517,7 +517,20 @@ def test_multinomial_spacings_regenerated():
 
 
 def test_strict_ancestors_equal_the_reference_cdf():
-    pc.check_strict_ancestors(sizes=(3000, 1 << 17), op_N=1 << 20, op_cases=100)
+    pc.check_strict_ancestors(sizes=(3000, 1 << 17, (1 << 18) + 333), op_N=1 << 20, op_cases=100)
+
+
+def test_strict_ancestors_c2_full_size():
+    """The north star's literal guarantee at the size it is benchmarked on: C2's N = 2^20, the fused strict loop --
+    at every resampling step A_t == inverse_cdf(su_t, W_{t-1}) of the reference (resampling.py:484-509), replayed and
+    Philox draws, np.array_equal (no near-tie allowance)."""
+    pc.check_strict_ancestors(sizes=(1 << 20,), op_cases=0, schemes=("systematic",), small=False, T=6, ESSrmin=0.5)
+
+
+@pytest.mark.parametrize("scheme", ["systematic", "stratified", "multinomial"])
+def test_strict_ancestors_c3_full_size(scheme):
+    """... and at C3's: StochVol, N = 2^22 (4096 tiles: k_reduce2 in front), ESSrmin = 1, each scheme."""
+    pc.check_strict_ancestors(sizes=(1 << 22,), op_cases=0, schemes=(scheme,), model="sv", small=False, T=4, ESSrmin=1.0)
 
 
 def test_merged_reduce_equals_split(golden, monkeypatch):

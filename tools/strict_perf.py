@@ -23,7 +23,9 @@ def seq(d, S, N, mode, count=False):
 rng = np.random.default_rng(1)
 for log2N in (16, 20, 22):
     N = 1 << log2N
+    deg = np.exp(-60.0 + rng.standard_normal(N)); deg[rng.choice(N, 8, replace=False)] = 1.0
     cases = {"lognormal": np.exp(3 * rng.standard_normal(N)), "uniform": np.ones(N), "skewed": np.exp(40 * rng.standard_normal(N)),
+             "degenerate": deg,
              "zeros": rng.random(N) * (rng.random(N) > 0.3), "collapsed": np.eye(1, N, N // 3)[0] + 0.0,
              "dyadic": rng.integers(0, 2 ** 30 // N + 2, size=N).astype(np.float64)}
     for name, w in cases.items():
@@ -47,32 +49,38 @@ for log2N in (16, 20, 22):
                 ctx().sync()
                 ts.append(time.perf_counter() - t0)
             t[mode] = float(np.median(ts)) * 1e6
-        print("N=2^%d %-10s %s  element pass %s %8.1f us | tile walk alone (%4d of %5d tiles exact) %8.1f us | literal walk %9.1f us"
-              % (log2N, name, "EQUAL" if same else "DIFFERENT (%d)" % int((a != b).sum()), "fell back" if fb else "        ",
-                 t[0], nseq, N // 1024, t[2], t[1]), flush=True)
+        print("N=2^%d %-10s %s  two launches (%s) %8.1f us | tile walk alone (%4d of %5d tiles exact) %8.1f us | literal walk %9.1f us"
+              % (log2N, name, "EQUAL" if same else "DIFFERENT (%d)" % int((a != b).sum()),
+                 "EXACT PATH     " if fb < 0 else "%3d exceptions" % fb, t[0], nseq, N // 1024, t[2], t[1]), flush=True)
         assert same
 
-# ---- the filter's strict mode on C2 (ToySSM, N = 2^20, systematic)
-T = 120
+# ---- the filter's strict mode on C2 (ToySSM, N = 2^20, systematic) and C3 (StochVol, N = 2^22)
+T = 220
 y = bench.synthetic_data(T)
-fk = ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y)
 res = {}
-for name, env in (("parallel", {}), ("literal", {"SMC_STRICT_LITERAL": "1"})):
-    os.environ.pop("SMC_STRICT_LITERAL", None)
-    os.environ.update(env)
-    pf = pa.SMC(fk=fk, N=1 << 20, seed=5, collect="off", strict_ancestors=True)
-    pf.step_async(20)
-    pf.sync()
-    t0 = time.perf_counter()
-    pf.step_async(100)
-    pf.sync()
-    dt = (time.perf_counter() - t0) / 100
-    res[name] = (dt, np.array(pf.A), pf.logLt)
-    print("strict C2 (%s CDF): %.1f us per step, %.2f G particle-steps/s" % (name, dt * 1e6, (1 << 20) / dt / 1e9), flush=True)
-assert np.array_equal(res["parallel"][1], res["literal"][1]) and res["parallel"][2] == res["literal"][2]
-os.environ.pop("SMC_STRICT_LITERAL", None)
-pf = pa.SMC(fk=fk, N=1 << 20, seed=5, collect="off")
-pf.step_async(20); pf.sync()
-t0 = time.perf_counter(); pf.step_async(100); pf.sync()
-print("default C2: %.1f us per step" % ((time.perf_counter() - t0) / 100 * 1e6))
-print("strict ancestors: the two CDFs give the same run, bit for bit")
+for wl, mk, N, essr in (("C2", lambda: kalman.ToySSM(0.2), 1 << 20, 0.5), ("C3", lambda: ssm.StochVol(), 1 << 22, 1.0)):
+    for scheme in (("systematic",) if wl == "C2" else ("systematic", "stratified", "multinomial")):
+        fk = ssm.Bootstrap(ssm=mk(), data=y)
+        for strict in (True, False):
+            pf = pa.SMC(fk=fk, N=N, seed=5, collect="off", strict_ancestors=strict, resampling=scheme, ESSrmin=essr)
+            pf.step_async(20)
+            pf.sync()
+            ts = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                pf.step_async(40)
+                pf.sync()
+                ts.append((time.perf_counter() - t0) / 40)
+            dt = float(np.median(ts))
+            print("%s %-11s %-7s: %7.1f us per step, %6.2f G particle-steps/s" % (wl, scheme, "strict" if strict else "default", dt * 1e6, N / dt / 1e9),
+                  flush=True)
+if os.environ.get("SMC_STRICT_PERF_LITERAL"):
+    fk = ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y[:30])
+    for name, env in (("parallel", {}), ("literal", {"SMC_STRICT_LITERAL": "1"})):
+        os.environ.pop("SMC_STRICT_LITERAL", None)
+        os.environ.update(env)
+        pf = pa.SMC(fk=fk, N=1 << 20, seed=5, collect="off", strict_ancestors=True)
+        pf.run()
+        res[name] = (np.array(pf.A), pf.logLt)
+    assert np.array_equal(res["parallel"][0], res["literal"][0]) and res["parallel"][1] == res["literal"][1]
+    print("strict ancestors: the two-launch CDF and the literal walk give the same run, bit for bit")
