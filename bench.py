@@ -68,6 +68,21 @@ def synthetic_data(T, sigma=0.2, seed=42):
     return y
 
 
+def kalman_loglik_toy(y, sigma=0.2):
+    """Exact log-likelihood of ToySSM(sigma) (README.md:66-72: X_0 ~ N(0,1), X_t = X_{t-1} + N(0,1), Y_t = X_t +
+    N(0, sigma^2)) by the scalar Kalman recursions (kalman.py:169-229 specialised to d = 1): what every particle
+    estimate of log p(y_{0:n}) in the line -- the GPU's, the CPU baseline's -- estimates."""
+    m, P, ll = 0.0, 1.0, 0.0
+    for t, yt in enumerate(np.asarray(y, dtype=np.float64).ravel()):
+        if t:
+            P = P + 1.0
+        S = P + sigma * sigma
+        ll += -0.5 * (np.log(2.0 * np.pi * S) + (yt - m) ** 2 / S)
+        Kg = P / S
+        m, P = m + Kg * (yt - m), (1.0 - Kg) * P
+    return float(ll)
+
+
 def leg_key(wl):
     """Name of a workload in `other_workloads` and in profiles/traffic_<key>.json."""
     if wl.get("qmc"):
@@ -80,13 +95,13 @@ def leg_key(wl):
     return wl["name"] + sfx
 
 
-def measured_traffic(wl, kernel, profiles=None):
-    """HBM bytes per launch of `kernel` (`a+b`: the sum over the launches named) from the committed
-    rocprofv3 PMC passes of this workload's own command line (tools/gpu_profile_all.sh ->
-    tools/summarise_prof.py: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as the
-    MI355X guide prescribes for gfx950).  PMC counters cannot be collected from inside the process, so
-    the figure is reported only when the committed record's `config` is the configuration being run;
-    otherwise traffic stays null.  Returns (bytes, source) or None."""
+def committed_profile(wl, kernel, profiles=None):
+    """What the committed rocprofv3 passes of this workload's own command line say about `kernel` (`a+b`: the sum over
+    the launches named): HBM bytes per launch from the PMC passes (tools/gpu_profile_all.sh -> tools/summarise_prof.py:
+    FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as the MI355X guide prescribes for gfx950) and the
+    average duration in the --kernel-trace --stats pass.  PMC counters cannot be collected from inside the process, so the
+    figures are reported only when the committed record's `config` is the configuration being run; otherwise None.
+    Returns {"bytes", "avg_us" (None in records older than round 5), "source"} or None."""
     path = os.path.join(profiles or os.path.join(ROOT, "profiles"), "traffic_%s.json" % leg_key(wl))
     if not os.path.exists(path):
         return None
@@ -98,24 +113,64 @@ def measured_traffic(wl, kernel, profiles=None):
             bool(cfg.get("collapsed")) != bool(wl["collapsed"]) or bool(cfg.get("qmc")) != bool(wl.get("qmc")) or \
             bool(cfg.get("strict")) != bool(wl.get("strict")):
         return None
-    total, found = 0.0, 0
+    total, found, us, us_ok = 0.0, 0, 0.0, True
     base = lambda name: name.replace("void ", "").split("<")[0].split("(")[0].strip()
     steps = max([d.get("launches") or 0 for name, d in rec["kernels"].items() if base(name).startswith("k_propagate")] + [0])
     for part in kernel.split("+"):
-        part = part.split("<")[0].split("(")[0].strip()
+        part = part.split("<")[0].split("(")[0].split(" [")[0].strip()
         if part == "k_rs_sort":         # the radix sort is several launches per step (k_rs_hist / _scan / _scatter)
             parts = [d for name, d in rec["kernels"].items() if base(name).startswith("k_rs_")]
             if parts and steps and all(d.get("launches") for d in parts):
                 total += sum(d["hbm_bytes_per_launch"] * d["launches"] for d in parts) / steps
+                if all(d.get("avg_us") for d in parts):
+                    us += sum(d["avg_us"] * d["launches"] for d in parts) / steps
+                else:
+                    us_ok = False
                 found += 1
             continue
-        hits = [d["hbm_bytes_per_launch"] for name, d in rec["kernels"].items() if part == base(name)]
+        hits = [d for name, d in rec["kernels"].items() if part == base(name)]
         if hits:
-            total += max(hits)          # (instantiations of one template: the one that carries the step)
+            d = max(hits, key=lambda h: h["hbm_bytes_per_launch"])   # (instantiations of one template: the one that carries the step)
+            total += d["hbm_bytes_per_launch"]
+            if d.get("avg_us"):
+                us += d["avg_us"]
+            else:
+                us_ok = False
             found += 1
     if not found:
         return None
-    return total, "rocprofv3 PMC, profiles/%s" % rec.get("summary", "")
+    return {"bytes": total, "avg_us": us if us_ok and us > 0 else None,
+            "source": "rocprofv3 PMC, profiles/%s" % rec.get("summary", "")}
+
+
+def measured_traffic(wl, kernel, profiles=None):
+    """(HBM bytes per launch, source) of `kernel` from the committed PMC passes, or None (see committed_profile)."""
+    cp = committed_profile(wl, kernel, profiles)
+    return (cp["bytes"], cp["source"]) if cp else None
+
+
+def add_profile_fractions(rf, wl, profiles=None):
+    """roofline.frac is measured live with HIP events; the two fractions a reader can RECOMPUTE from profiles/ go beside
+    it: frac_rocprof = the same algorithmic bytes (or flop) over the kernel's average duration in the committed
+    rocprofv3 --kernel-trace --stats pass, frac_physical = the HBM bytes the committed PMC passes counted over that
+    duration (hbm-bound legs).  Both null until a round-5 record (with avg_us) of this workload is committed."""
+    rf.update({"frac_rocprof": None, "frac_physical": None, "rocprof_kernel_us": None})
+    cp = committed_profile(wl, rf["kernel"], profiles)
+    if not cp:
+        return rf
+    rf["traffic"], rf["traffic_source"] = cp["bytes"], cp["source"]
+    if cp["avg_us"]:
+        sec = cp["avg_us"] * 1e-6
+        rf["rocprof_kernel_us"] = cp["avg_us"]
+        if rf["bound"] == "mfma":
+            rf["frac_rocprof"] = rf["launch_flop"] / sec / 1e12 / FP64_PEAK_TF
+        else:
+            rf["frac_rocprof"] = rf["launch_bytes"] / sec / 1e9 / HBM_PEAK_GBS
+            rf["frac_physical"] = cp["bytes"] / sec / 1e9 / HBM_PEAK_GBS
+        rf["fractions_note"] = ("frac: HIP events, this run; frac_rocprof: launch_bytes (launch_flop) / rocprof_kernel_us / peak; "
+                                "frac_physical: traffic / rocprof_kernel_us / peak -- rocprof_kernel_us and traffic are the "
+                                "committed record's (%s)" % cp["source"])
+    return rf
 
 
 # ----------------------------------------------------------------------------------------------
@@ -461,7 +516,11 @@ def other_workloads(K=20, W=100, R=15, shrink=0):
             ("c4", dict(name="c4")),
             ("c4_collapsed", dict(name="c4", collapsed=True)),
             ("c5", dict(name="c5")),
-            ("sqmc", dict(name="c2", qmc=True))]
+            ("sqmc", dict(name="c2", qmc=True)),
+            # the north star's LITERAL parity contract (strict_ancestors=True: the reference's sequential fp64
+            # inverse_cdf, resampling.py:484-509, bit for bit) on the headline configuration and on C3
+            ("c2_strict", dict(name="c2", strict=True)),
+            ("c3_systematic_strict", dict(name="c3", scheme="systematic", strict=True))]
     out = {}
     for key, kw in legs:
         t_leg = time.perf_counter()
@@ -490,12 +549,31 @@ def other_workloads(K=20, W=100, R=15, shrink=0):
                         "launch_bytes": rf["launch_bytes"],
                         "traffic": None, "traffic_source": None,
                         "leg_seconds": time.perf_counter() - t_leg}
-            tr = None if shrink else measured_traffic(wl, rf["kernel"])
-            if tr:
-                out[key]["traffic"], out[key]["traffic_source"] = tr
+            if not shrink:
+                add_profile_fractions(rf, wl)
+            for k in ("traffic", "traffic_source", "frac_rocprof", "frac_physical", "rocprof_kernel_us", "launch_flop"):
+                if k in rf:
+                    out[key][k] = rf[k]
         except Exception as e:          # one failing leg must not cost the headline its line
             out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
     return out
+
+
+def _spawn_ranks(n):
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=os.environ.get("MASTER_PORT", str(port)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    sys.exit(rc)
 
 
 def main():
@@ -538,9 +616,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
-                     "--nproc-per-node %d" % (a.gpus, a.gpus))
+        if world == 1 and a.gpus > 1 and "RANK" not in os.environ:
+            # not under a launcher: spawn the N ranks here (one process per GPU, RANK / LOCAL_RANK / WORLD_SIZE /
+            # MASTER_* as torch.distributed.run would set them -- the library's own TCP rendezvous needs nothing else;
+            # the torchrun form keeps working, the 8-GPU line just does not depend on torch being installed)
+            return _spawn_ranks(a.gpus)
         a.gpus = world
     # (functional test of the multi-rank path on a box with fewer GPUs than ranks:
     #  SMC_BENCH_NGPU=1 lets all ranks share device 0; RCCL then refuses, which is an ERROR unless
@@ -626,7 +706,21 @@ def main():
         all_ll = grp.gather_evidence(pf.logLts_islands)
         with_gather = float(grp.allreduce_max_host(time.perf_counter() - t0))
     dt = float(np.median(dts))
-    rs_rate = float(np.mean(pf._summ()[0, W:, 4]))
+    summ0 = pf._summ()[0]
+    rs_rate = float(np.mean(summ0[W:, 4]))
+    # the self-check a reader can hold the timed kernels to: the evidence estimate after the first n steps of THIS run
+    # (the filter the timed region ran on) beside the exact Kalman value of the same n observations; cpu_baseline.logLt
+    # (another random stream, the same n when --cpu-steps allows) lands in the same block below
+    n_chk = int(min(a.cpu_steps, T) if a.log2N >= 18 else min(T, 2000))        # (= the CPU baseline's sample)
+    self_check = None
+    if a.workload == "c2" and d == 1 and not a.qmc:
+        kal = kalman_loglik_toy(wl["fk"].data[:n_chk])
+        self_check = {"steps": n_chk, "gpu_logLt": float(summ0[n_chk - 1, 3]), "kalman_logLt": kal,
+                      "gpu_minus_kalman": float(summ0[n_chk - 1, 3]) - kal,
+                      "note": "log p(y_0..y_{n-1}) of the first n = steps observations: gpu_logLt from the run the timed region "
+                              "belongs to (Philox stream 123), kalman_logLt exact (scalar Kalman filter, bench.kalman_loglik_toy), "
+                              "cpu_logLt the CPU baseline's estimate on its own random stream; a particle estimate at N = 2^20 "
+                              "has a standard deviation of a few 10^-2 here (profiles/r12g_bias_check.txt)"}
     del pf
 
     # C5 at the reference's own seam: ONE call of multiSMC (core.py:431-518) by every rank -- the
@@ -686,6 +780,8 @@ def main():
             # --allow-host-gather produces a line with rccl false (= no collective touched xGMI)
             "rccl": bool(grp and grp.evidence_path == "rccl") if grp else None,
         }
+        if self_check is not None:
+            out["self_check"] = self_check
         if devices is not None:
             out["rank_devices"] = devices
         if multi is not None:
@@ -702,11 +798,27 @@ def main():
     if not a.no_profile:
         mv_ms, rs_ms, ns, kernels = kernel_profile(wl, K, W, rank)
         if rank == 0 and ns:
-            out["roofline"] = roofline(wl, out["step_achieved_GBs"], mv_ms, rs_ms, ns, kernels)
+            out["roofline"] = add_profile_fractions(roofline(wl, out["step_achieved_GBs"], mv_ms, rs_ms, ns, kernels), wl)
             out["roofline"]["note"] = ROOFLINE_NOTE
-            tr = measured_traffic(wl, out["roofline"]["kernel"])
-            if tr:
-                out["roofline"]["traffic"], out["roofline"]["traffic_source"] = tr
+            if a.workload == "c2" and d == 1 and not a.qmc and world == 1:
+                # what actually limits this leg (profiles/r13c_size_sweep.txt): the step's time is flat from
+                # N = 10^4 to 10^5 -- two dependent launches -- and k_propagate is VALU-bound in its active window; the
+                # floor is measured here, on the same filter at N = 2^14
+                try:
+                    wl_f = make_workload("c2", W + 400, scheme=a.scheme, log2N=14, essrmin=a.essrmin, strict=a.strict)
+                    pf_f = make_filter(wl_f)
+                    floor = float(np.median(time_steps(pf_f, 100, W, 4))) / 100
+                    del pf_f
+                    out["roofline"].update({
+                        "limiter": "valu+latency", "launch_floor_us": 1e6 * floor,
+                        "launch_floor_frac_of_step": floor / (dt / K),
+                        "limiter_note": "bound/frac price the dominant kernel against the HBM roofline as the contract asks, but "
+                                        "this leg is NOT bandwidth-bound: launch_floor_us is the same step at N = 2^14 (the "
+                                        "dependent launches with almost no data), and the kernel's active window is VALU-bound "
+                                        "(656 vector instructions per wave of 4 particles; its 46 MB working set lives in the "
+                                        "Infinity Cache)"})
+                except Exception as e:
+                    out["roofline"]["limiter_error"] = "%s: %s" % (type(e).__name__, e)
     if rank == 0 and world == 1 and a.workload == "c2" and a.N == 0 and not a.no_other_workloads \
             and (a.log2N == 20 or a.other_shrink):
         out["other_workloads"] = (other_workloads(K=3, W=2, R=2, shrink=a.other_shrink) if a.other_shrink
@@ -715,6 +827,9 @@ def main():
         nst = min(a.cpu_steps, T) if a.log2N >= 18 else min(T, 2000)
         try:
             out["cpu_baseline"] = cpu_baseline(N, nst)
+            if "self_check" in out and nst == out["self_check"]["steps"]:
+                out["self_check"]["cpu_logLt"] = out["cpu_baseline"]["logLt"]
+                out["self_check"]["cpu_minus_kalman"] = out["cpu_baseline"]["logLt"] - out["self_check"]["kalman_logLt"]
         except Exception as e:          # a reported baseline, not the measurement: never costs the line
             out["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:

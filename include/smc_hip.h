@@ -497,6 +497,20 @@ int smc_filter_profile(smc_filter* f, int enable);
  * (two-level CDF), "k_ancestors<fused>+k_propagate", "k_prepare+k_ancestors+k_propagate",
  * "k_filter_small" (whole T-loop in one launch), "...+k_propagate_mv"; NUL-terminated into out. */
 int smc_filter_describe(smc_filter* f, char* out, size_t n);
+/* Checkpoint / resume -- what pickling a particles.SMC object is to the reference (core.py:415-428 returns the SMC
+ * objects of worker processes, utils.py:178-186; SURVEY 5 "checkpoint / resume").  The state is every device array of
+ * the filter plus its host-side counters, as one host buffer of smc_filter_state_bytes bytes; smc_filter_load_state
+ * accepts it into a filter created from the same (model, options, data) -- shape mismatches are SMC_ERR_INVALID -- and
+ * the run then continues bit for bit.  (Replay tapes are the caller's arrays: set them again.) */
+int smc_filter_state_bytes(smc_filter* f, int64_t* nbytes);
+int smc_filter_save_state(smc_filter* f, void* out_host, int64_t nbytes);
+int smc_filter_load_state(smc_filter* f, const void* in_host, int64_t nbytes);
+/* SMC_FLAG_STRICT_ANCESTORS (the reference's sequential fp64 inverse_cdf, resampling.py:484-509): how the last
+ * resampling step of `island` formed that CDF -- *exact_path = 0: the two-launch emulation (csrc/smc_seqx.h), its
+ * assumptions verified; 1: the exact scan-until-exception path (milliseconds; engineered ties, NaN / negative
+ * weights); *exceptions: the elements the emulation's serial walk handled.  Diagnostics: the results are the
+ * reference's either way. */
+int smc_filter_strict_stats(smc_filter* f, int32_t island, int64_t* exact_path, int64_t* exceptions);
 int smc_filter_kernel_ms(smc_filter* f, double* move_ms_avg,
                          double* prepare_ms_avg, int64_t* n_samples);
 

@@ -111,6 +111,10 @@ SIGNATURES = {
     "smc_sobol": (c_int, [c_vp, c_i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_u64, c_vp]),
     "smc_sobol_sorted": (c_int, [c_vp, c_i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_u64, c_vp]),
     "smc_filter_describe": (c_int, [c_vp, ctypes.c_char_p, c_sz]),
+    "smc_filter_state_bytes": (c_int, [c_vp, ctypes.POINTER(ctypes.c_int64)]),
+    "smc_filter_save_state": (c_int, [c_vp, c_vp, ctypes.c_int64]),
+    "smc_filter_load_state": (c_int, [c_vp, c_vp, ctypes.c_int64]),
+    "smc_filter_strict_stats": (c_int, [c_vp, ctypes.c_int32, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
     "smc_poisson_logpmf": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp]),
     "smc_standard_normal": (c_int, [c_vp, c_u64, c_i64, c_vp]),
     "smc_uniform": (c_int, [c_vp, c_u64, c_i64, c_vp]),
@@ -291,6 +295,10 @@ def next_counter():
     return _counter
 
 
+def _device_array_from_host(a):
+    return DeviceArray.from_numpy(a, dtype=a.dtype)
+
+
 class DeviceArray:
     """A C-contiguous fp64 / int64 array in HBM."""
 
@@ -316,6 +324,11 @@ class DeviceArray:
         out = np.empty(self.shape, dtype=self.dtype)
         check(lib().smc_memcpy_d2h(self.ctx.h, out.ctypes.data_as(c_vp), self.ptr, out.nbytes))
         return out
+
+    def __reduce__(self):
+        """Pickling moves the values through the host (the reference's arrays are numpy arrays: utils.py:178-186
+        ships them between processes as such); the copy lives in the unpickling process's context."""
+        return (_device_array_from_host, (self.get(),))
 
     def __len__(self):
         return self.shape[0]

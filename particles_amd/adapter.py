@@ -269,12 +269,12 @@ def HipSMC():
             def __new__(cls, fk=None, **kw):
                 two = adapt_smc2(fk) if fk is not None else None
                 if two is not None and not kw.get("qmc") and not kw.get("store_history") \
-                        and kw.get("collect") in (None, "off") and not kw.get("verbose"):
+                        and kw.get("collect") in (None, "off") and not kw.get("verbose") \
+                        and kw.get("resampling", "systematic") == "systematic":     # (the device theta level's scheme)
                     kw2 = {k: v for k, v in kw.items() if k in ("N", "ESSrmin", "resampling", "seed")}
-                    try:
-                        return DeviceSMC2Run(fk, two[0], two[1], **kw2)
-                    except ValueError:                     # not batchable after all: the reference's loop runs it
-                        pass
+                    # (adapt_smc2 made every batchability check -- before any draw or device allocation -- so an
+                    #  error from here on is a real one: a bad prior / theta shape, an unknown scheme; it surfaces)
+                    return DeviceSMC2Run(fk, two[0], two[1], **kw2)
                 mine = adapt(fk) if fk is not None else None
                 if mine is None or kw.get("qmc"):
                     return super().__new__(cls)            # the reference's own path
@@ -283,6 +283,30 @@ def HipSMC():
 
         _HIP_SMC = HipSMC
     return _HIP_SMC
+
+
+class _HipRun:
+    """The worker functor of the reference's multiSMC (core.py:415-423 ``_picklable_f``) with HipSMC where it names
+    ``SMC``: picklable, so the reference's loky workers (utils.py:178-186) can receive it -- each worker process then
+    builds device filters of its own and sends the finished ``SMC`` objects back PICKLED (``SMC.__getstate__``: the
+    filter's device state as one host buffer), exactly as the reference returns its NumPy-backed ones."""
+
+    def __init__(self, fun=None):
+        self.fun = fun
+
+    def __call__(self, **kwargs):
+        pf = HipSMC()(**kwargs)
+        pf.run()
+        return pf if self.fun is None else self.fun(pf)
+
+
+def multiSMC(nruns=10, nprocs=0, out_func=None, collect=None, **args):
+    """``particles.multiSMC`` (core.py:431-518) with every run a HipSMC: the reference's own ``utils.multiplexer`` --
+    cartesian products of list / dict arguments, one seed per run, ``nprocs`` loky worker processes -- drives it, the
+    result is the reference's list of dicts (``'output'``: the finished filter, or ``out_func`` of it)."""
+    from particles import utils
+    return utils.multiplexer(f=_HipRun(out_func), nruns=nruns, nprocs=nprocs, seeding=True,
+                             protected_args={"collect": collect}, **args)
 
 
 def install():

@@ -191,10 +191,17 @@ class DeviceParticleHistory:
     def __init__(self, smc):
         self._smc = smc
         self.fk = smc.fk
-        self.X = _LazySteps(smc, lambda t: smc._history(_lib.FIELD_X, t))
+        # (bound methods, not lambdas: the history object pickles with its filter)
+        self.X = _LazySteps(smc, self._X_at)
         # hist.A[0] is the A of a filter that has not resampled yet: None (core.py:229)
-        self.A = _LazySteps(smc, lambda t: smc._history(_lib.FIELD_A, t) if t else None)
+        self.A = _LazySteps(smc, self._A_at)
         self.wgts = _LazySteps(smc, self._wgts_at)
+
+    def _X_at(self, t):
+        return self._smc._history(_lib.FIELD_X, t)
+
+    def _A_at(self, t):
+        return self._smc._history(_lib.FIELD_A, t) if t else None
 
     def _wgts_at(self, t):
         smc = self._smc
@@ -243,9 +250,15 @@ class DeviceRollingParticleHistory:
     def __init__(self, smc, length):
         self._smc, self.length = smc, int(length)
         self.fk = smc.fk
-        self.X = _Window(self, lambda t: smc._history(_lib.FIELD_X, t))
+        self.X = _Window(self, self._X_at)
         self.A = _Window(self, self._A_at)
-        self.wgts = _Window(self, lambda t: DeviceParticleHistory._wgts_at(self, t))
+        self.wgts = _Window(self, self._wgts_at)
+
+    def _X_at(self, t):
+        return self._smc._history(_lib.FIELD_X, t)
+
+    def _wgts_at(self, t):
+        return DeviceParticleHistory._wgts_at(self, t)
 
     def _A_at(self, t):
         smc = self._smc

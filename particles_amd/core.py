@@ -189,6 +189,7 @@ class SMC:
                 store_history or collapsed_proposal or (collect and collect != "off" and self._device_moments)):
             model = None           # (the fused SQMC on the flat step keeps no history slots / device moments)
         self._fused = self._will_fuse(fk, qmc, resampling, model, N=N)
+        self._ctor = (use_graph, island_offset, replay is not None)       # (what __setstate__ re-creates the filter with)
         if self._fused:
             # full history on the fused path stays on the device: the step loop
             # writes step t into slot t (no per-step host copies, no per-step sync)
@@ -357,6 +358,36 @@ class SMC:
             new.seed = _default_seed()
             check(lib().smc_filter_reseed(new._f, new.seed))
         return new
+
+    # ---- pickling: checkpoint / resume, and how multiSMC's worker processes hand their filters back
+    # (core.py:415-428, utils.py:178-186).  The device filter travels as ONE host buffer -- every device array of its
+    # slab plus the host-side counters (smc_filter_save_state) -- and is re-created from the same (model, options, data)
+    # on the other side (smc_filter_create + smc_filter_load_state): q = pickle.loads(pickle.dumps(pf)) continues bit for
+    # bit, history slots, summary ring, Philox counters and all.
+    def __getstate__(self):
+        d = {k: v for k, v in self.__dict__.items() if k not in ("_f", "_ctx", "_tapes", "_keep", "_cache", "_summ_cache")}
+        d["_state_blob"] = None
+        d["_tapes_host"] = None
+        if getattr(self, "_fused", False) and self._f:
+            nb = _lib.c_i64()
+            check(lib().smc_filter_state_bytes(self._f, ctypes.byref(nb)))
+            blob = np.empty(int(nb.value), dtype=np.uint8)
+            check(lib().smc_filter_save_state(self._f, blob.ctypes.data_as(_lib.c_vp), int(nb.value)))
+            d["_state_blob"] = blob
+            if getattr(self, "_tapes", None) is not None:
+                d["_tapes_host"] = tuple(t.get() for t in self._tapes)
+        return d
+
+    def __setstate__(self, d):
+        blob, tapes = d.pop("_state_blob", None), d.pop("_tapes_host", None)
+        self.__dict__.update(d)
+        self._f = None
+        self._cache, self._summ_cache = {}, None
+        if blob is not None:
+            use_graph, island_offset, _ = self._ctor
+            model = self.fk._device_model()
+            self._create_filter(model, tapes, use_graph, island_offset)
+            check(lib().smc_filter_load_state(self._f, blob.ctypes.data_as(_lib.c_vp), blob.nbytes))
 
     def _invalidate(self):
         self._cache = {}

@@ -197,16 +197,34 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
         // decision + normalisation of step t-1 (two-level: by k_strict_classify's workgroups themselves, or k_reduce2
         // beyond 1024 tiles / for multinomial draws / the literal walk; flat: k_propagate's tail did it), the
         // sequential CDF of W_{t-1}, the searches
-        if (f->two_level && (f->two_level_mid || f->strict_literal)) SMC_LAUNCH(k_reduce2, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
-        if (f->a.scheme == SMC_MULTINOMIAL && !f->a.ut)
+        // (multinomial, Philox draws: uniform_spacings in one pass, the island's reduction as its workgroup 0 where the
+        //  grid fits -- as on the default path; the literal walk and one-tile filters: one workgroup per island)
+        const bool sp1 = f->a.scheme == SMC_MULTINOMIAL && !f->a.ut && f->a.sp_tpw;
+        const bool merge = sp1 && f->sp_merge && t_known;
+        f->a.sp_epoch = merge ? ++f->sp_epoch : 0ull;
+        if (f->two_level && (f->two_level_mid || f->strict_literal) && !merge)
+            SMC_LAUNCH(k_reduce2, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
+        if (sp1) {
+            const dim3 gw(f->a.sp_nwg + (merge ? 1 : 0), f->a.n_islands);
+            switch (f->a.sp_tpw) {
+            case 1: SMC_LAUNCH(k_f_spacing_onepass<1>, gw, dim3(SMC_BLOCK), st, f->a); break;
+            case 2: SMC_LAUNCH(k_f_spacing_onepass<2>, gw, dim3(SMC_BLOCK), st, f->a); break;
+            case 4: SMC_LAUNCH(k_f_spacing_onepass<4>, gw, dim3(SMC_BLOCK), st, f->a); break;
+            default: SMC_LAUNCH(k_f_spacing_onepass<8>, gw, dim3(SMC_BLOCK), st, f->a); break;
+            }
+        } else if (f->a.scheme == SMC_MULTINOMIAL && !f->a.ut) {
             for (int i = 0; i < f->a.n_islands; ++i)
                 SMC_LAUNCH(k_f_spacings_step, dim3(1), dim3(SMC_BLOCK), st, f->a, i, f->a.su + (size_t)i * f->a.N);
+        }
         const unsigned nb = (unsigned)((f->a.N + 1023) / 1024);
         const dim3 gt(nb, f->a.n_islands);
         // (strict_ws: (n_islands, N) W | (n_islands, N) S | the scratch of smc_seqx.h | (n_islands, ntiles) tile sums)
         double* S = f->strict_ws + (size_t)f->a.n_islands * f->a.N;
         void* sqx_scr = (void*)(S + (size_t)f->a.n_islands * f->a.N);
-        const SqxArgs q = sqx_carve(sqx_scr, f->a.N, f->a.n_islands);
+        SqxArgs q = sqx_carve(sqx_scr, f->a.N, f->a.n_islands);
+#ifdef SMC_TRACE
+        q.trace = f->a.trace + (size_t)f->a.n_islands * (f->a.nparts + f->a.ntiles) * 8;
+#endif
         const SeqGate gate{f->a.info, INFO_STRIDE, f->a.T, nullptr};
         if (f->strict_literal) {
             // the definition: W written out, ONE lane adding it up in place (44 ms at N = 2^20), a search per offspring
@@ -631,7 +649,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     // more islands than that: the three-pass form
     a.sp_tpw = a.sp_nwg = 0;
     bool merge_fits = false;
-    if (need_su && f->two_level && !f->strict && !f->sqmc && !(o->flags & SMC_PATH_SPACING_3PASS))
+    if (need_su && f->two_level && !(f->strict && f->strict_literal) && !f->sqmc && !(o->flags & SMC_PATH_SPACING_3PASS))
         for (int tpw = 1; tpw <= 8 && !a.sp_tpw; tpw *= 2) {
             const int forced_tpw = (o->flags >> 25) & 15;          // SMC_PATH_SP_TPW (A/B: workgroups wait for
             if (forced_tpw && tpw != forced_tpw) continue;         //  lower-numbered ones only, dispatch is in order)
@@ -689,7 +707,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     a.nmb = (int)((o->N + F_MOM_CHUNK - 1) / F_MOM_CHUNK);
     const size_t oMom = carve(o->moments ? M * T * 2 * dxm * 8 : 8);
     const size_t oMpart = carve(o->moments ? M * a.nmb * dxm * 3 * 8 : 8);
-    const size_t oTrace = carve(M * (size_t)(2 * a.ntiles + 8) * 8 * 8);
+    const size_t oTrace = carve(M * (size_t)(2 * a.ntiles + 8) * 8 * 8 + (size_t)(2 * a.ntiles + 16) * 8 * 8);
     // the slab comes from the context's pool (smc_malloc: blocks recycled by exact size, ordered on
     // the context's one stream): a PMMH chain or the PMCMC moves of SMC^2 create and destroy a filter
     // of the same shape per proposal, and hipMalloc / hipFree of tens of MB cost milliseconds each
@@ -840,6 +858,14 @@ int smc_debug_trace(smc_filter* f, uint64_t* out_host)
     SMC_HIP_CHECK(hipStreamSynchronize(f->ctx->stream));
     return SMC_OK;
 }
+// ... of the strict step's two launches (island 0): (2 ntiles + 8, 8) stamps -- classify per tile, the chain, search per tile
+int smc_debug_trace_strict(smc_filter* f, uint64_t* out_host)
+{
+    SMC_HIP_CHECK(hipMemcpyAsync(out_host, f->a.trace + (size_t)f->a.n_islands * (f->a.nparts + f->a.ntiles) * 8,
+                                 (size_t)(2 * f->a.ntiles + 8) * 64, hipMemcpyDeviceToHost, f->ctx->stream));
+    SMC_HIP_CHECK(hipStreamSynchronize(f->ctx->stream));
+    return SMC_OK;
+}
 #endif
 
 int smc_filter_destroy(smc_filter* f)
@@ -924,6 +950,70 @@ int smc_filter_clone(smc_filter* src, smc_filter** out)
         f->ll_stage = nullptr;
     (void)hipGetLastError();
     *out = f;
+    return SMC_OK;
+}
+
+// ---- checkpoint / resume (pickling of a device filter: core.py:415-428 returns SMC objects from worker processes,
+// utils.py:178-186).  The state of a filter is its slab -- every device array, no pointers inside -- plus a handful of
+// host words; a filter created from the same (model, options, data) has the same layout, so the slab of one can be
+// loaded into the other and the run continues bit for bit.
+struct FStateHeader {
+    u64 magic, slab_bytes;
+    i64 N, T, t_host, perm_t;
+    int n_islands, scheme, kind, fk, hist, dx, flags_strict, flags_sqmc;
+    u64 seed, sp_epoch, sq_seed, sq_ctr0;
+    int flush_pending, island_offset;
+};
+#define F_STATE_MAGIC 0x534d435f53544131ull    /* "SMC_STA1" */
+int smc_filter_state_bytes(smc_filter* f, int64_t* nbytes)
+{
+    SMC_REQUIRE(f && nbytes, "null argument");
+    SMC_REQUIRE(!f->th_buf, "a filter with a theta level (SMC^2) is checkpointed by its owner, not as a filter");
+    *nbytes = (int64_t)(sizeof(FStateHeader) + f->slab_bytes);
+    return SMC_OK;
+}
+int smc_filter_save_state(smc_filter* f, void* out_host, int64_t nbytes)
+{
+    SMC_REQUIRE(f && out_host, "null argument");
+    SMC_REQUIRE(!f->th_buf, "a filter with a theta level (SMC^2) is checkpointed by its owner, not as a filter");
+    SMC_REQUIRE(nbytes == (int64_t)(sizeof(FStateHeader) + f->slab_bytes), "buffer size: smc_filter_state_bytes");
+    SMC_HIP_CHECK(hipSetDevice(f->ctx->device));
+    flush_rows(f);
+    FStateHeader h;
+    memset(&h, 0, sizeof h);
+    h.magic = F_STATE_MAGIC; h.slab_bytes = f->slab_bytes;
+    h.N = f->a.N; h.T = f->a.T; h.t_host = f->t_host; h.perm_t = f->perm_t;
+    h.n_islands = f->a.n_islands; h.scheme = f->a.scheme; h.kind = f->kind; h.fk = f->fk; h.hist = f->a.hist; h.dx = f->a.dx;
+    h.flags_strict = f->strict ? 1 : 0; h.flags_sqmc = f->sqmc ? 1 : 0;
+    h.seed = f->a.seed; h.sp_epoch = f->sp_epoch; h.sq_seed = f->sq_seed; h.sq_ctr0 = f->sq_ctr0;
+    h.flush_pending = f->flush_pending ? 1 : 0; h.island_offset = f->a.island_offset;
+    memcpy(out_host, &h, sizeof h);
+    SMC_HIP_CHECK(hipMemcpyAsync((char*)out_host + sizeof h, f->slab, f->slab_bytes, hipMemcpyDeviceToHost, f->ctx->stream));
+    SMC_HIP_CHECK(hipStreamSynchronize(f->ctx->stream));
+    return SMC_OK;
+}
+int smc_filter_load_state(smc_filter* f, const void* in_host, int64_t nbytes)
+{
+    SMC_REQUIRE(f && in_host, "null argument");
+    SMC_REQUIRE(!f->th_buf, "a filter with a theta level (SMC^2) is checkpointed by its owner, not as a filter");
+    SMC_REQUIRE(nbytes >= (int64_t)sizeof(FStateHeader), "truncated state");
+    FStateHeader h;
+    memcpy(&h, in_host, sizeof h);
+    SMC_REQUIRE(h.magic == F_STATE_MAGIC, "not a filter state (magic)");
+    SMC_REQUIRE(h.slab_bytes == f->slab_bytes && nbytes == (int64_t)(sizeof h + h.slab_bytes) && h.N == f->a.N && h.T == f->a.T &&
+                    h.n_islands == f->a.n_islands && h.scheme == f->a.scheme && h.kind == f->kind && h.fk == f->fk &&
+                    h.hist == f->a.hist && h.dx == f->a.dx && h.flags_strict == (f->strict ? 1 : 0) &&
+                    h.flags_sqmc == (f->sqmc ? 1 : 0),
+                "the state belongs to a filter of another shape (model, N, T, islands, scheme, history or flags differ)");
+    SMC_HIP_CHECK(hipSetDevice(f->ctx->device));
+    SMC_HIP_CHECK(hipMemcpyAsync(f->slab, (const char*)in_host + sizeof h, f->slab_bytes, hipMemcpyHostToDevice, f->ctx->stream));
+    SMC_HIP_CHECK(hipStreamSynchronize(f->ctx->stream));
+    f->t_host = h.t_host; f->perm_t = h.perm_t;
+    f->a.seed = h.seed; f->sp_epoch = h.sp_epoch; f->sq_seed = h.sq_seed; f->sq_ctr0 = h.sq_ctr0;
+    f->flush_pending = h.flush_pending != 0;
+    f->a.island_offset = h.island_offset;
+    for (hipGraphExec_t& g : f->gexec)          // captured launches carry the old key / counters by value
+        if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
     return SMC_OK;
 }
 
@@ -1750,6 +1840,20 @@ int smc_filter_profile(smc_filter* f, int enable)
         f->ev.resize(3 * PROF_MAX);
         for (auto& e : f->ev) SMC_HIP_CHECK(hipEventCreate(&e));
     }
+    return SMC_OK;
+}
+
+int smc_filter_strict_stats(smc_filter* f, int32_t island, int64_t* exact_path, int64_t* exceptions)
+{
+    SMC_REQUIRE(f && exact_path && exceptions, "null argument");
+    SMC_REQUIRE(f->strict && !f->strict_literal, "not a strict_ancestors filter");
+    SMC_REQUIRE(island >= 0 && island < f->a.n_islands, "island out of range");
+    const SqxArgs q = sqx_carve((void*)(f->strict_ws + 2 * (size_t)f->a.n_islands * f->a.N), f->a.N, f->a.n_islands);
+    unsigned long long c[2] = {0ull, 0ull};
+    SMC_HIP_CHECK(hipMemcpyAsync(c, q.ctr + (size_t)island * 4 + 2, 16, hipMemcpyDeviceToHost, f->ctx->stream));
+    SMC_HIP_CHECK(hipStreamSynchronize(f->ctx->stream));
+    *exact_path = (int64_t)c[0];
+    *exceptions = (int64_t)c[1];
     return SMC_OK;
 }
 

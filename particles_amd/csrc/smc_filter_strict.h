@@ -50,13 +50,15 @@ k_strict_classify(const FArgs av, const SqxArgs q)
 {
     const FArgs& a = av;
     __shared__ double s_max[SMC_NWAVE];
-    __shared__ double s_sum[2 * SMC_NWAVE];
+    __shared__ double s_esc[SMC_NWAVE];
+    __shared__ double s_sum[3 * SMC_NWAVE];
     __shared__ double smd[SMC_SM];
-    __shared__ int s_flag;
     const int b = (int)blockIdx.x, isl = (int)blockIdx.y, tid = (int)threadIdx.x;
     const int lane = smc_lane(), wave = smc_wave();
+    SQX_STAMP(q, b, 0);
     double* info = a.info + (i64)isl * INFO_STRIDE;
     const double r0 = smc_ldg(MID ? info : a.info2 + (i64)isl * INFO_STRIDE);
+    const double r1 = MID ? smc_ldg(info + 1) : 0.0, r3 = MID ? smc_ldg(info + 3) : 0.0, r4 = MID ? smc_ldg(info + 4) : 0.0;
     const i64 o = (i64)isl * a.nparts;
     double pm4[4], ps4[4], pss4[4];
     if (!MID) {
@@ -65,29 +67,60 @@ k_strict_classify(const FArgs av, const SqxArgs q)
         f_load4<double>(a.ps + o, (i64)tid * 4, a.nparts, pvec, 0.0, ps4);
         f_load4<double>(a.pss + o, (i64)tid * 4, a.nparts, pvec, 0.0, pss4);
     }
+    const double Kb_v = smc_ldg(a.pm + o + b);                 // this tile's own exponent: the scale of the in-tile estimate
+    // the tile's log-weights, requested with the first loads from the slot the host expects (a.tk; redone below if the
+    // record says otherwise -- inside a replayed graph)
+    const i64 i0 = (i64)b * SEQ_TILE + (i64)tid * 4;
+    double l4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    if (a.tk >= 1) {
+        const double* lwp = f_lw(a, a.tk - 1) + (i64)isl * a.N;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) l4[k] = (i0 + k < a.N) ? smc_ldg(lwp + i0 + k) : -INFINITY;
+    }
     const i64 t = (i64)smc_uniform(r0);
     if (t >= a.T) {
         if (!MID && b == 0 && tid == 0) info[0] = (double)t;   // k_propagate returns on it
         return;
     }
     if (t == 0) return;                                        // the host wrote the record of step 0
+    if (MID && smc_uniform(r1) == 0.0) return;                 // k_reduce2: step t does not resample
+    if (t != a.tk) {
+        const double* lwp = f_lw(a, t - 1) + (i64)isl * a.N;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) l4[k] = (i0 + k < a.N) ? smc_ldg(lwp + i0 + k) : -INFINITY;
+    }
+    // ---- (p, k) of the tile's weights and the in-tile prefix of their values on the TILE's scale 2^(k - K_b): nothing
+    // here needs the island's reduction, so its wave totals travel with the reduction's first exchange
+    const double Kb = smc_uniform(Kb_v);
+    double p4[4], k4[4], e4[4], esum = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        p4[k] = smc_expk(l4[k], k4[k]);
+        const bool ok = l4[k] > -INFINITY;
+        p4[k] = ok ? p4[k] : 0.0;
+        k4[k] = ok ? k4[k] : -INFINITY;
+        e4[k] = a.kform ? smc_scale_pk(p4[k], k4[k], Kb) : 0.0;
+        esum += e4[k];
+    }
+    const double einc = smc_wave_scan_add_f64(esum);
     double K, rs, before = 0.0;
     if (MID) {
-        if (smc_uniform(smc_ldg(info + 1)) == 0.0) return;     // k_reduce2: step t does not resample
-        K = smc_uniform(smc_ldg(info + 3));
-        rs = smc_uniform(smc_ldg(info + 4));
+        K = smc_uniform(r3);
+        rs = smc_uniform(r4);
+        if (lane == 63) s_esc[wave] = einc;
         for (int i = tid; i < b; i += SMC_BLOCK) {
             double v, w;
             f2_rescale(smc_ldg(a.pm + o + i), K, smc_ldg(a.ps + o + i), 0.0, v, w);
-            before += v * rs;
+            before += v;
         }
-        before = smc_block_sum(before, smd);
-        __syncthreads();
+        before = smc_block_sum(before, smd) * rs;              // (barriers inside: s_esc is complete)
     } else {
-        // ---- all partials -> K, (s, ss), ESS, the decision: k_ancestors2's operations, hence its bits
+        // ---- all partials -> K, (s, ss), ESS, the decision: k_ancestors2's operations, hence its bits; the estimate of
+        // the sum in front of this tile (the shares of the tiles before it) rides in the second exchange
         double tm = smc_max2(smc_max2(pm4[0], pm4[1]), smc_max2(pm4[2], pm4[3]));
         tm = smc_wave_max(tm);
         if (lane == 0) s_max[wave] = tm;
+        if (lane == 63) s_esc[wave] = einc;
         __syncthreads();
         F2Red r;
         r.K = s_max[0];
@@ -100,15 +133,22 @@ k_strict_classify(const FArgs av, const SqxArgs q)
             f2_rescale(pm4[k], r.K, ps4[k], pss4[k], v4[k], w);
             s1 = s1 + v4[k];
             s2 = s2 + w;
+            before += (tid * 4 + k < b) ? v4[k] : 0.0;
         }
         s1 = smc_wave_sum(s1);
         s2 = smc_wave_sum(s2);
-        if (lane == 0) { s_sum[wave] = s1; s_sum[SMC_NWAVE + wave] = s2; }
+        before = smc_wave_sum(before);
+        if (lane == 0) { s_sum[wave] = s1; s_sum[SMC_NWAVE + wave] = s2; s_sum[2 * SMC_NWAVE + wave] = before; }
         __syncthreads();
         s1 = s_sum[0];
         s2 = s_sum[SMC_NWAVE];
+        before = s_sum[2 * SMC_NWAVE];
 #pragma unroll
-        for (int w = 1; w < SMC_NWAVE; ++w) { s1 = s1 + s_sum[w]; s2 = s2 + s_sum[SMC_NWAVE + w]; }
+        for (int w = 1; w < SMC_NWAVE; ++w) {
+            s1 = s1 + s_sum[w];
+            s2 = s2 + s_sum[SMC_NWAVE + w];
+            before = before + s_sum[2 * SMC_NWAVE + w];
+        }
         r.s = s1;
         r.ss = s2;
         f2_finish(a, r);
@@ -117,27 +157,51 @@ k_strict_classify(const FArgs av, const SqxArgs q)
         if (!resample) return;
         K = r.K;
         rs = r.rs;
-        // the estimate of the sum in front of this tile: the tiles' shares of the island's sum
-#pragma unroll
-        for (int k = 0; k < 4; ++k) before += (tid * 4 + k < b) ? v4[k] * rs : 0.0;
-        before = smc_block_sum(before, smd);
-        __syncthreads();
+        before = before * rs;
     }
+    // the weights themselves (the values smc_filter_get(SMC_FIELD_W) returns), and the estimate in front of this
+    // thread's first one: the tiles before + the in-tile prefix put on the island's scale
     const SqxSrcFilter src{f_lw(a, t - 1) + (i64)isl * a.N, K, rs, a.kform, a.N};
-    sqx_classify_tile(src, isl, b, before, q);
-    if (sqx_last_block(q.tick + (i64)isl * SQX_CNT_WORDS, b, q.ntiles, &s_flag)) sqx_chain(src, isl, q);
+    double w4[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w4[k] = (i0 + k < a.N) ? (a.kform ? smc_scale_pk(p4[k], k4[k], K) * rs : src.weight(l4[k])) : 0.0;
+    double ebase = 0.0;
+#pragma unroll
+    for (int w = 0; w < SMC_NWAVE; ++w) ebase += (w < wave) ? s_esc[w] : 0.0;
+    double dsc = Kb - K;                                       // (<= 0: K is the maximum of the tiles' exponents)
+    dsc = (dsc > -2000.0) ? dsc : -2000.0;
+    const double run0 = before + ldexp(ebase + einc - esum, (int)dsc) * rs;
+    SQX_STAMP(q, b, 1);
+    if (sqx_classify_tile(w4, run0, isl, b, q)) sqx_chain(src, isl, q);
 }
 
 __global__ void __launch_bounds__(SMC_BLOCK)
 k_strict_search(const FArgs av, const SqxArgs q)
 {
     const FArgs& a = av;
-    const int isl = (int)blockIdx.y;
+    __shared__ double sS[SEQ_TILE];
+    const int isl = (int)blockIdx.y, b = (int)blockIdx.x;
+    SQX_STAMP(q, q.ntiles + 8 + b, 0);
     const double* info = a.info + (i64)isl * INFO_STRIDE;
-    const i64 t = (i64)smc_uniform(smc_ldg(info));
-    if (t >= a.T || t == 0 || smc_uniform(smc_ldg(info + 1)) == 0.0) return;
+    // every load of the common path in one go: the record, what the tile's sums are staged from, the spacings' total
+    const double r0 = smc_ldg(info), r1 = smc_ldg(info + 1);
+    const SqxStage ld = sqx_stage_load(q, isl, b);
+    const bool zform = a.scheme == SMC_MULTINOMIAL_ && !a.ut && a.sp_tpw;
+    const u64 zall = zform ? smc_ldg(a.E + (i64)isl * (a.ntiles1 + 1) + a.ntiles1) : 0ull;
+    const i64 t = (i64)smc_uniform(r0);
+    if (t >= a.T || t == 0 || smc_uniform(r1) == 0.0) return;
     SmcSu su;
     u64 Us;
     f2_su(a, isl, t, su, Us);
-    sqx_search_tile<u32>(q, isl, (int)blockIdx.x, su, f_A(a, t) + (i64)isl * a.N);
+    if (a.log2N >= 0) su.rM = 1.0 / su.dM;                     // (N = 2^k: the division by N is an exact scaling)
+    if (zform) {
+        // one-pass uniform_spacings (k_f_spacing_onepass): the integer prefix sums; the look-back words re-armed
+        su.z = reinterpret_cast<const u64*>(a.su) + (i64)isl * a.N;
+        su.dall = (double)smc_uniform_u64(zall);
+        if (b < a.sp_nwg && threadIdx.x == 0) a.sst[(i64)isl * a.sp_nwg + b] = 0ull;
+    }
+    SQX_STAMP(q, q.ntiles + 8 + b, 1);
+    const double S_start = sqx_stage_tile(q, isl, b, ld, sS);
+    SQX_STAMP(q, q.ntiles + 8 + b, 2);
+    sqx_search_tile<u32>(q, b, su, sS, S_start, f_A(a, t) + (i64)isl * a.N);
 }

@@ -30,7 +30,15 @@ struct SmcSu {
     u32 t, island;
     // stratified, Philox: the last pair of uniforms drawn (consecutive offspring share a call)
     mutable u64 c_pair = ~0ull, c_a = 0ull, c_b = 0ull;
+    // multinomial, one-pass uniform_spacings: the integer prefix sums Z_n of the draws and (double)Z_N -- su_n = Z_n / Z_N,
+    // the quotient resampling.py:537 forms (null: `u` holds the quotients)
+    const u64* z = nullptr;
+    double dall = 1.0;
+    // M a power of two: 1 / M -- the division by M is then an exact scaling and x * rM the same double as x / M
+    // (0: divide)
+    double rM = 0.0;
 };
+__device__ __forceinline__ double smc_su_div(const SmcSu& s, const double y) { return s.rM != 0.0 ? y * s.rM : y / s.dM; }
 
 // the nc-th uniform of the stratified draw
 __device__ __forceinline__ double smc_strat_u(const SmcSu& s, u64 nc)
@@ -48,7 +56,7 @@ __device__ __forceinline__ double smc_strat_u(const SmcSu& s, u64 nc)
 // division (resampling.py:602, :609), or the n-th sorted uniform (:536-537).
 __device__ __forceinline__ double smc_su_at(const SmcSu& s, i64 n)
 {
-    if (s.scheme == SMC_SYSTEMATIC_) return (s.u_sys + (double)n) / s.dM;
+    if (s.scheme == SMC_SYSTEMATIC_) return smc_su_div(s, s.u_sys + (double)n);
     if (s.scheme == SMC_STRATIFIED_) {
         double un;
         if (s.u) {
@@ -58,9 +66,9 @@ __device__ __forceinline__ double smc_su_at(const SmcSu& s, i64 n)
             smc_philox((u32)(n >> 1), s.t, s.island, SMC_STREAM_RESAMPLE, s.seed, a, b);
             un = smc_u01_halfopen((n & 1) ? b : a);
         }
-        return (un + (double)n) / s.dM;
+        return smc_su_div(s, un + (double)n);
     }
-    return s.u[n];
+    return s.z ? (double)s.z[n] / s.dall : s.u[n];
 }
 
 // Both members of the pair (2p, 2p+1) with one Philox call.
@@ -70,8 +78,8 @@ __device__ __forceinline__ void smc_su_pair(const SmcSu& s, i64 p, double& su0, 
     if (s.scheme == SMC_STRATIFIED_ && !s.u) {
         u64 a, b;
         smc_philox((u32)p, s.t, s.island, SMC_STREAM_RESAMPLE, s.seed, a, b);
-        su0 = (smc_u01_halfopen(a) + (double)n0) / s.dM;
-        su1 = (smc_u01_halfopen(b) + (double)n1) / s.dM;
+        su0 = smc_su_div(s, smc_u01_halfopen(a) + (double)n0);
+        su1 = smc_su_div(s, smc_u01_halfopen(b) + (double)n1);
         return;
     }
     su0 = (n0 < s.M) ? smc_su_at(s, n0) : 2.0;

@@ -39,7 +39,7 @@
 #pragma once
 #include "smc_seqsum.h"
 
-#define SQX_CAP 512                    /* exceptions per island the walk takes (16 KB of LDS) */
+#define SQX_CAP 256                    /* exceptions per island the walk takes (6 KB of LDS): a few dozen occur */
 #define SQX_TCAP 254                   /* ... per tile */
 #define SQX_CNT_STRIDE 16
 #define SQX_CNT_WORDS (34 * SQX_CNT_STRIDE)
@@ -60,7 +60,14 @@ struct SqxArgs {
     u64* ctr;                          // (islands, 4) exceptions appended | overflow | mode of the last run | its exceptions
     unsigned* tick;                    // (islands, SQX_CNT_WORDS) completion tickets
     double* Sfull;                     // (islands, n) the exact path's sums (mode 1)
+    u64* trace;                        // SMC_TRACE builds: (2 ntiles + 8, 8) shader-clock stamps (rows: classify per tile,
+                                       // 8 rows of the chain, search per tile), else null
 };
+#ifdef SMC_TRACE
+#define SQX_STAMP(q, row, k) do { if ((q).trace && threadIdx.x == 0 && blockIdx.y == 0) (q).trace[(i64)(row) * 8 + (k)] = (u64)wall_clock64(); } while (0)
+#else
+#define SQX_STAMP(q, row, k) do { } while (0)
+#endif
 static inline SqxArgs sqx_carve(void* scratch, const i64 n, const int islands, size_t* bytes = nullptr, size_t* counters_at = nullptr,
                                 size_t* counters_bytes = nullptr)
 {
@@ -69,6 +76,7 @@ static inline SqxArgs sqx_carve(void* scratch, const i64 n, const int islands, s
     q.n = n;
     q.ntiles = (int)nt;
     q.margin = ldexp((double)(8192 + 8 * (i64)nt), -53);
+    q.trace = nullptr;
     char* p = (char*)scratch;
     q.Pin = (u64*)p; p += M * nt * SEQ_TILE * 8;
     q.Sfull = (double*)p; p += M * ((size_t)n + 8) * 8;
@@ -113,6 +121,24 @@ struct SqxSrcArray {
     }
 };
 
+// seq_round_to_grid with fewer instructions: (M + half) >> sh instead of quotient, remainder and compare -- the same
+// integer except at an exact tie, which is flagged (and then an exception) either way
+__device__ __forceinline__ u64 sqx_round_to_grid(const double W, const int Es, bool& tie, bool& big)
+{
+    const u64 bits = (u64)__double_as_longlong(W);
+    const int e = (int)(bits >> 52);                           // (a sign bit makes e >= 0x800: `big` below)
+    const u64 M = (bits & 0x000FFFFFFFFFFFFFull) | (e ? 0x0010000000000000ull : 0ull);
+    int sh = Es - (e ? e : 1);
+    tie = false;
+    big = sh < 0 || e >= 0x7ff;                                // (inf / NaN / negative: never regular)
+    if (big) return 0ull;
+    if (sh == 0) return M;
+    sh = sh > 63 ? 63 : sh;
+    const u64 half = 1ull << (sh - 1);
+    const u64 t = M + half;
+    tie = (t & ((half << 1) - 1ull)) == 0ull;
+    return t >> sh;
+}
 __device__ __forceinline__ u64 sqx_mant(const double s)       // the integer of s on its own grid (implicit bit included)
 {
     const u64 b = (u64)__double_as_longlong(s);
@@ -140,45 +166,66 @@ __device__ __forceinline__ bool sqx_last_block(unsigned* cnt, const int b, const
 }
 
 // ---- launch 1, per tile ------------------------------------------------------------------------------------------
-// `before`: the estimate of the sum in front of tile b (the same value in every thread)
-template <class Src>
-__device__ __forceinline__ void sqx_classify_tile(const Src& src, const int isl, const int b, const double before, const SqxArgs& q)
+// w: this thread's weights 4 tid .. 4 tid + 3 of tile b (0 beyond n); run0: the estimate of the running sum in front of
+// the thread's first element.  Takes the workgroup's completion ticket (the Pin stores -- read by the next launch only --
+// are issued behind it, so that the ticket does not wait for them) and returns whether this workgroup is the island's last.
+__device__ __forceinline__ bool sqx_classify_tile(const double (&w)[4], const double run0, const int isl, const int b, const SqxArgs& q)
 {
-    __shared__ double smd[SMC_SM];
+    __shared__ int s_flag;
     __shared__ u64 smu[SMC_NWAVE];
     __shared__ u32 smx[SMC_NWAVE];
     __shared__ u32 s_lo[SQX_TCAP + 2], s_hi[SQX_TCAP + 2];
     __shared__ u32 s_base;
     const int tid = (int)threadIdx.x, lane = smc_lane(), wave = smc_wave();
     const i64 j0 = (i64)b * SEQ_TILE, i0 = j0 + (i64)tid * 4;
-    double w[4];
-    src.load4(i0, w);
-    for (int i = tid; i < SQX_TCAP + 2; i += SMC_BLOCK) { s_lo[i] = 0u; s_hi[i] = 2047u; }
-    double tot;
-    double run = before + smc_block_exscan_f64((w[0] + w[1]) + (w[2] + w[3]), smd, tot);   // (barrier inside: slots armed)
+    for (int i = tid; i < SQX_TCAP + 2; i += SMC_BLOCK) { s_lo[i] = 0u; s_hi[i] = 2047u; }      // (armed by the barrier below)
     const double dn = 1.0 - q.margin, up = 1.0 + q.margin;
     u64 r[4], rsum = 0ull;
     u32 aLo[4], aHi[4], nx = 0u;
     bool exc[4];
+    double hi4[4];
+    hi4[0] = run0 + w[0];
+    hi4[1] = hi4[0] + w[1];
+    hi4[2] = hi4[1] + w[2];
+    hi4[3] = hi4[2] + w[3];
+    // the common case decided once per thread: the estimate puts the sum in front of the thread's first element and
+    // behind its last inside ONE binade (margins included) -- then every element of the thread sees that grid (the
+    // estimate is monotone inside a thread), and what is left per element is the rounding itself
+    const int E_a = seq_bexp(run0 * dn), E_b = seq_bexp(hi4[3] * up);
+    if (run0 > 0.0 && E_a == E_b && E_a >= 1 && E_b < 0x7fe) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const double lo = run, hi = run + w[k];
-        run = hi;
-        const int E_lo = seq_bexp(lo * dn), E_hi = seq_bexp(hi * up);
-        bool tie, big;
-        const u64 rr = seq_round_to_grid(w[k], E_lo >= 1 ? E_lo : 1, tie, big);
-        const bool inside = i0 + k < q.n;
-        const bool zero = (u64)__double_as_longlong(w[k]) == 0ull;              // (+0.0: beyond n as well)
-        const bool grid_ok = lo > 0.0 && E_lo >= 1 && E_hi < 0x7fe && !tie && !big;
-        const bool regular = grid_ok && E_lo == E_hi;
-        const bool edge = grid_ok && E_hi == E_lo + 1 && rr == 0ull;            // below half a unit of the finer grid
-        exc[k] = inside && !zero && !regular && !edge;
-        r[k] = (regular && !zero) ? rr : 0ull;
-        aLo[k] = (zero || exc[k]) ? 0u : (u32)E_lo;
-        aHi[k] = (zero || exc[k]) ? 2047u : (u32)E_hi;
-        rsum += r[k];
-        nx += exc[k] ? 1u : 0u;
+        for (int k = 0; k < 4; ++k) {
+            bool tie, big;
+            const u64 rr = sqx_round_to_grid(w[k], E_a, tie, big);
+            const bool zero = (u64)__double_as_longlong(w[k]) == 0ull;          // (+0.0: beyond n as well)
+            exc[k] = i0 + k < q.n && !zero && (tie || big);
+            r[k] = (zero || exc[k]) ? 0ull : rr;
+            aLo[k] = (zero || exc[k]) ? 0u : (u32)E_a;
+            aHi[k] = (zero || exc[k]) ? 2047u : (u32)E_a;
+            rsum += r[k];
+            nx += exc[k] ? 1u : 0u;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double lo = k ? hi4[k - 1] : run0, hi = hi4[k];
+            const int E_lo = seq_bexp(lo * dn), E_hi = seq_bexp(hi * up);
+            bool tie, big;
+            const u64 rr = sqx_round_to_grid(w[k], E_lo >= 1 ? E_lo : 1, tie, big);
+            const bool inside = i0 + k < q.n;
+            const bool zero = (u64)__double_as_longlong(w[k]) == 0ull;
+            const bool grid_ok = lo > 0.0 && E_lo >= 1 && E_hi < 0x7fe && !tie && !big;
+            const bool regular = grid_ok && E_lo == E_hi;
+            const bool edge = grid_ok && E_hi == E_lo + 1 && rr == 0ull;        // below half a unit of the finer grid
+            exc[k] = inside && !zero && !regular && !edge;
+            r[k] = (regular && !zero) ? rr : 0ull;
+            aLo[k] = (zero || exc[k]) ? 0u : (u32)E_lo;
+            aHi[k] = (zero || exc[k]) ? 2047u : (u32)E_hi;
+            rsum += r[k];
+            nx += exc[k] ? 1u : 0u;
+        }
     }
+    SQX_STAMP(q, b, 2);
     // tile-local prefixes of the roundings and of the exception count: one exchange
     const u64 rinc = smc_wave_scan_add_u64(rsum);
     const u32 xinc = smc_wave_scan_add_u32(nx);
@@ -205,8 +252,7 @@ __device__ __forceinline__ void sqx_classify_tile(const Src& src, const int isl,
             s += exc[k] ? 1u : 0u;
         }
     }
-    smc_st2g(q.Pin + (i64)isl * q.ntiles * SEQ_TILE + i0, Pin[0], Pin[1]);
-    smc_st2g(q.Pin + (i64)isl * q.ntiles * SEQ_TILE + i0 + 2, Pin[2], Pin[3]);
+    SQX_STAMP(q, b, 3);
     const bool tile_over = xtot > (u32)SQX_TCAP;
     // the segments' intervals: slot = exceptions in front of the element (an exception's own slot is neutral)
     if (!tile_over) {
@@ -246,133 +292,179 @@ __device__ __forceinline__ void sqx_classify_tile(const Src& src, const int isl,
                 smc_st_agent(e + 3, (u64)s_lo[seg[k] + 1] | ((u64)s_hi[seg[k] + 1] << 16));
             }
     }
+    SQX_STAMP(q, b, 4);
+    const bool last = sqx_last_block(q.tick + (i64)isl * SQX_CNT_WORDS, b, q.ntiles, &s_flag);
+    smc_st2g(q.Pin + (i64)isl * q.ntiles * SEQ_TILE + i0, Pin[0], Pin[1]);
+    smc_st2g(q.Pin + (i64)isl * q.ntiles * SEQ_TILE + i0 + 2, Pin[2], Pin[3]);
+    SQX_STAMP(q, b, 5);
+    return last;
 }
 
 // ---- launch 1, the island's serial part: the last workgroup to arrive ----------------------------------------------
+// One workgroup, on the critical path of the step: every global load it needs that does not depend on another is issued
+// up front (the counters, the first 1024 tiles' totals and head intervals, every slot of the exception list), so that the
+// whole function pays about three memory latencies; the walk reads (dP, W) pairs from LDS, branch-free.
 template <class Src>
 __device__ __forceinline__ void sqx_chain(const Src& src, const int isl, const SqxArgs& q)
 {
     __shared__ u32 c_j[SQX_CAP];
     __shared__ u32 c_acc[SQX_CAP];
-    __shared__ u64 c_P[SQX_CAP];
+    __shared__ u64 c_P[SQX_CAP];                               // global P in front of each exception
     __shared__ double c_w[SQX_CAP];
     __shared__ double c_S[SQX_CAP];
     __shared__ u64 smu[SMC_SM];
     __shared__ int c_ok, s_idx;
     __shared__ double s_tmp;
+    static_assert(SQX_CAP == SMC_BLOCK, "one exception slot per thread");
     const int tid = (int)threadIdx.x, ntiles = q.ntiles;
     u64* ctr = q.ctr + (i64)isl * 4;
+    u64* Pt = q.Pt + (i64)isl * (ntiles + 1);
+    SQX_STAMP(q, ntiles, 0);
+    // ---- every independent load, at once
     const u64 cnt64 = smc_ld_agent(ctr), ovf = smc_ld_agent(ctr + 1);
-    __syncthreads();
+    const u64* ex = q.xraw + ((i64)isl * SQX_CAP + tid) * 4;
+    const u64 e0 = smc_ld_agent(ex), e1 = smc_ld_agent(ex + 1), e2 = smc_ld_agent(ex + 2), e3 = smc_ld_agent(ex + 3);
+    u64 rt0[4], hs0[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int b = tid * 4 + k;
+        rt0[k] = b < ntiles ? smc_ld_agent(q.Rt + (i64)isl * ntiles + b) : 0ull;
+        hs0[k] = b < ntiles ? smc_ld_agent(q.hseg + (i64)isl * ntiles + b) : (2047ull << 16);
+    }
+    __syncthreads();                                           // (every thread has read the counters)
+    SQX_STAMP(q, ntiles, 1);
     if (tid == 0) { smc_st_agent(ctr, 0ull); smc_st_agent(ctr + 1, 0ull); c_ok = 1; }   // (re-armed for the next launch)
     bool slow = ovf != 0ull || cnt64 > (u64)SQX_CAP;
     const int cnt = slow ? 0 : (int)cnt64;
-    u64* Pt = q.Pt + (i64)isl * (ntiles + 1);
     if (!slow) {
-        // ---- P offsets of the tiles
-        u64 carry = 0ull;
-        for (int b0 = 0; b0 < ntiles; b0 += SMC_BLOCK) {
-            const int b = b0 + tid;
+        // ---- P offsets of the tiles: thread tid owns tiles 4 tid .. 4 tid + 3 of every chunk of 1024
+        u64 carry = 0ull, pt0[4] = {0ull, 0ull, 0ull, 0ull};
+        for (int c0 = 0; c0 < ntiles; c0 += 4 * SMC_BLOCK) {
+            u64 rt[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int b = c0 + tid * 4 + k;
+                rt[k] = c0 == 0 ? rt0[k] : (b < ntiles ? smc_ld_agent(q.Rt + (i64)isl * ntiles + b) : 0ull);
+            }
             u64 tot;
-            const u64 pre = smc_block_exscan_u64(b < ntiles ? smc_ld_agent(q.Rt + (i64)isl * ntiles + b) : 0ull, smu, tot);
-            if (b < ntiles) Pt[b] = carry + pre;
+            u64 run = carry + smc_block_exscan_u64((rt[0] + rt[1]) + (rt[2] + rt[3]), smu, tot);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int b = c0 + tid * 4 + k;
+                if (b < ntiles) Pt[b] = run;
+                if (c0 == 0) pt0[k] = run;
+                run += rt[k];
+            }
             carry += tot;
             __syncthreads();
         }
         if (tid == 0) Pt[ntiles] = carry;
-        // ---- the exceptions in order of index (each thread: up to SQX_CAP / 256 of them; rank by counting)
-        constexpr int PER = SQX_CAP / SMC_BLOCK;
-        u64 e0[PER], e1[PER], e2[PER], e3[PER];
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int i = tid + k * SMC_BLOCK;
-            e0[k] = e1[k] = e2[k] = e3[k] = 0ull;
-            if (i < cnt) {
-                const u64* e = q.xraw + ((i64)isl * SQX_CAP + i) * 4;
-                e0[k] = smc_ld_agent(e);
-                e1[k] = smc_ld_agent(e + 1);
-                e2[k] = smc_ld_agent(e + 2);
-                e3[k] = smc_ld_agent(e + 3);
-                c_j[i] = (u32)e0[k];
-            }
-        }
+        SQX_STAMP(q, ntiles, 2);
+        // ---- the exceptions in order of index (rank by counting: a few dozen of them)
+        if (tid < cnt) c_j[tid] = (u32)e0;
         __syncthreads();                                       // (c_j complete; Pt visible to the workgroup)
-        int rank[PER];
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int i = tid + k * SMC_BLOCK;
-            rank[k] = 0;
-            if (i < cnt) {
-                const u32 mine = (u32)e0[k];
-                for (int m = 0; m < cnt; ++m) rank[k] += c_j[m] < mine ? 1 : 0;
-            }
+        int rank = 0;
+        u64 Pg = 0ull;
+        if (tid < cnt) {
+            Pg = e1 + Pt[(int)(e0 >> 10)];
+            const u32 mine = (u32)e0;
+            for (int m = 0; m < cnt; ++m) rank += c_j[m] < mine ? 1 : 0;
         }
         __syncthreads();
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int i = tid + k * SMC_BLOCK;
-            if (i < cnt) {
-                const int d = rank[k];
-                c_j[d] = (u32)e0[k];
-                c_P[d] = e1[k] + Pt[(int)(e0[k] >> 10)];
-                c_w[d] = __longlong_as_double((long long)e2[k]);
-                c_acc[d] = (u32)e3[k];
-            }
+        if (tid < cnt) {
+            c_j[rank] = (u32)e0;
+            c_P[rank] = Pg;
+            c_w[rank] = __longlong_as_double((long long)e2);
+            c_acc[rank] = (u32)e3;
+            q.xs[((i64)isl * SQX_CAP + rank) * 4 + 2] = e1;     // (Pin of the exception: launch 2 reads it)
         }
         __syncthreads();
+        SQX_STAMP(q, ntiles, 3);
         // ---- the walk (one thread): a run of regular elements is an integer added on the grid of s, an exception the
-        // hardware's own addition (resampling.py:506-508)
+        // hardware's own addition (resampling.py:506-508).  pack(bexp(s), mant(s) + 0) == s for every s >= 0: no branch
+        // on dP; the checks apply where dP != 0 and are collected off the chain of s.
         if (tid == 0) {
             double s = 0.0;
+#ifndef SMC_EMULATE
+            // (only lane 0 is here, and the compiler would keep the chain of s in scalar registers -- a
+            //  v_readfirstlane and a handful of SALU operations between two v_add_f64, 95 ns per exception;
+            //  as a vector value it is nine dependent VALU operations)
+            asm volatile("" : "+v"(s));
+#endif
             u64 Pprev = 0ull;
-            bool ok = true;
+            u32 viol = 0u;
+            const bool head = cnt > 0 && c_j[0] == 0u;         // (s = W[0] starts the chain: not 0 + W[0])
+            u64 Pn = cnt > 0 ? c_P[0] : 0ull;                  // (the next exception's P and W: read one step ahead,
+            double wn = cnt > 0 ? c_w[0] : 0.0;                //  so that no LDS latency sits on the chain of s)
             for (int i = 0; i < cnt; ++i) {
-                const u64 dP = c_P[i] - Pprev;
-                if (dP != 0ull) {
-                    const int Es = seq_bexp(s);
-                    const u64 Iv = sqx_mant(s) + dP;
-                    ok = ok && Es >= 1 && Es < 0x7ff && Iv < (1ull << 53);
-                    s = sqx_pack(Es, Iv);
-                }
-                s = c_j[i] == 0u ? c_w[i] : s + c_w[i];        // (s = W[0] starts the chain)
+                const u64 Pi = Pn;
+                const double w = wn;
+                const int i1 = i + 1 < cnt ? i + 1 : i;
+                Pn = c_P[i1];
+                wn = c_w[i1];
+                const u64 dP = Pi - Pprev;
+                Pprev = Pi;
+                const u64 sb = (u64)__double_as_longlong(s);
+                const u32 hi = (u32)(sb >> 32), Es = hi >> 20;  // (s >= 0: no sign bit)
+                const u32 mh = (hi & 0xfffffu) | ((Es < 1u ? Es : 1u) << 20);
+                const u64 Iv = (((u64)mh << 32) | (u32)sb) + dP;
+                const u32 ih = (u32)(Iv >> 32);
+                viol |= (dP != 0ull && (Es - 1u >= 0x7feu || (ih >> 21) != 0u)) ? 1u : 0u;
+                s = __longlong_as_double((long long)(((u64)((Es << 20) | (ih & 0xfffffu)) << 32) | (u32)Iv)) + w;
+                if (i == 0 && head) s = w;
                 c_S[i] = s;
-                Pprev = c_P[i];
             }
-            const u64 dP = Pt[ntiles] - Pprev;                 // the run behind the last exception
-            if (dP != 0ull) {
-                const int Es = seq_bexp(s);
-                ok = ok && Es >= 1 && Es < 0x7ff && sqx_mant(s) + dP < (1ull << 53);
-            }
+            const u64 dP = carry - Pprev;                      // the run behind the last exception
+            const int Es = seq_bexp(s);
+            const bool ok = viol == 0u && (dP == 0ull || (Es >= 1 && Es < 0x7ff && sqx_mant(s) + dP < (1ull << 53)));
             if (!ok) c_ok = 0;
         }
         __syncthreads();
+        SQX_STAMP(q, ntiles, 4);
         // ---- verification of every segment against the binade the walk found in front of it; the tiles' headers
         bool bad = false;
-        for (int i = tid; i < cnt; i += SMC_BLOCK) {
-            const u32 e = (u32)seq_bexp(c_S[i]);
-            bad = bad || e < (c_acc[i] & 0xffffu) || e > (c_acc[i] >> 16);
-            u64* o = q.xs + ((i64)isl * SQX_CAP + i) * 4;
-            o[0] = (u64)c_j[i];
-            o[1] = (u64)__double_as_longlong(c_S[i]);
-            o[2] = c_P[i] - Pt[(int)(c_j[i] >> 10)];
+        if (tid < cnt) {
+            const u32 e = (u32)seq_bexp(c_S[tid]);
+            bad = e < (c_acc[tid] & 0xffffu) || e > (c_acc[tid] >> 16);
+            u64* o = q.xs + ((i64)isl * SQX_CAP + tid) * 4;
+            o[0] = (u64)c_j[tid];
+            o[1] = (u64)__double_as_longlong(c_S[tid]);
         }
-        for (int b = tid; b <= ntiles; b += SMC_BLOCK) {
-            const u64 lo_j = (u64)b * SEQ_TILE;
-            int lo = 0, hi = cnt;                              // first exception with index >= the tile's start
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if ((u64)c_j[mid] < lo_j) lo = mid + 1; else hi = mid;
+        // (measured and dropped, r14: waves 1-3 looking their tiles' first exceptions up WHILE lane 0 walks -- their LDS
+        //  traffic sits in front of the walk's reads, and three waves do four waves' work afterwards: 20.8 against 18.5 us)
+        for (int c0 = 0; c0 < ntiles; c0 += 4 * SMC_BLOCK) {
+            u64 hs[4], pt[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int b = c0 + tid * 4 + k;
+                hs[k] = c0 == 0 ? hs0[k] : (b < ntiles ? smc_ld_agent(q.hseg + (i64)isl * ntiles + b) : (2047ull << 16));
+                pt[k] = c0 == 0 ? pt0[k] : (b < ntiles ? Pt[b] : 0ull);
             }
-            q.xfirst[(i64)isl * (ntiles + 1) + b] = lo;
-            if (b == ntiles) break;
-            const int qx = lo - 1;
-            const double sb = qx < 0 ? 0.0 : c_S[qx];
-            const u32 e = (u32)seq_bexp(sb);
-            const u64 hs = smc_ld_agent(q.hseg + (i64)isl * ntiles + b);
-            bad = bad || e < (u32)(hs & 0xffffull) || e > (u32)(hs >> 16);
-            q.hE[(i64)isl * ntiles + b] = (int)e;
-            q.hI[(i64)isl * ntiles + b] = sqx_mant(sb) + (Pt[b] - (qx < 0 ? 0ull : c_P[qx]));
+            // first exception with index >= each tile's start: four branch-free lower bounds side by side (the same
+            // number of rounds for all, the LDS reads of a round independent)
+            int lo[4] = {0, 0, 0, 0};
+            const u32 key0 = (u32)(c0 + tid * 4) << 10;         // (N < 2^32)
+            for (int n = cnt; n > 1;) {
+                const int half = n >> 1;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) lo[k] = c_j[lo[k] + half - 1] < key0 + ((u32)k << 10) ? lo[k] + half : lo[k];
+                n -= half;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int b = c0 + tid * 4 + k;
+                if (b >= ntiles) continue;
+                if (cnt > 0) lo[k] += c_j[lo[k]] < key0 + ((u32)k << 10) ? 1 : 0;
+                q.xfirst[(i64)isl * (ntiles + 1) + b] = lo[k];
+                const int qx = lo[k] - 1;
+                const double sb = qx < 0 ? 0.0 : c_S[qx];
+                const u32 e = (u32)seq_bexp(sb);
+                bad = bad || e < (u32)(hs[k] & 0xffffull) || e > (u32)(hs[k] >> 16);
+                q.hE[(i64)isl * ntiles + b] = (int)e;
+                q.hI[(i64)isl * ntiles + b] = sqx_mant(sb) + (pt[k] - (qx < 0 ? 0ull : c_P[qx]));
+            }
         }
+        if (tid == 0) q.xfirst[(i64)isl * (ntiles + 1) + ntiles] = cnt;
         if (bad) c_ok = 0;                                     // (benign race: every writer stores 0)
         __syncthreads();
         slow = c_ok == 0;
@@ -394,16 +486,37 @@ __device__ __forceinline__ void sqx_chain(const Src& src, const int isl, const S
         }
     }
     if (tid == 0) { ctr[2] = slow ? 1ull : 0ull; ctr[3] = cnt64; }
+    SQX_STAMP(q, ntiles, 5);
 }
 
 // ---- launch 2: a tile's sums in LDS ------------------------------------------------------------------------------
-// sS[0 .. 1023] <- S_j of tile b (beyond n: the last sum); returns the sum in front of the tile (-inf for tile 0).
-// Every thread must call; ends with a barrier.
-__device__ __forceinline__ double sqx_stage_tile(const SqxArgs& q, const int isl, const int b, double* sS)
+// What a workgroup needs of tile b, requested in one go (sqx_stage_load: nothing here depends on the step record, so
+// the filter's kernel issues these loads together with the record's) ...
+struct SqxStage {
+    u64 mode, hI, Pin[4];
+    int hE, xf0, xf1;
+};
+__device__ __forceinline__ SqxStage sqx_stage_load(const SqxArgs& q, const int isl, const int b)
 {
+    SqxStage st;
+    const i64 i0 = (i64)b * SEQ_TILE + (i64)threadIdx.x * 4;
+    st.mode = smc_ldg(q.ctr + (i64)isl * 4 + 2);
+    st.hE = q.hE[(i64)isl * q.ntiles + b];
+    st.hI = smc_ldg(q.hI + (i64)isl * q.ntiles + b);
+    st.xf0 = q.xfirst[(i64)isl * (q.ntiles + 1) + b];
+    st.xf1 = q.xfirst[(i64)isl * (q.ntiles + 1) + b + 1];
+    smc_ld2g(q.Pin + (i64)isl * q.ntiles * SEQ_TILE + i0, st.Pin[0], st.Pin[1]);
+    smc_ld2g(q.Pin + (i64)isl * q.ntiles * SEQ_TILE + i0 + 2, st.Pin[2], st.Pin[3]);
+    return st;
+}
+// ... and sS[0 .. 1023] <- S_j of tile b (beyond n: the last sum); returns the sum in front of the tile (-inf for
+// tile 0).  Every thread must call; ends with a barrier.
+__device__ __forceinline__ double sqx_stage_tile(const SqxArgs& q, const int isl, const int b, const SqxStage& ld, double* sS)
+{
+    __shared__ u64 s_x[3 * 64];                                // a batch of the tile's exceptions (index, S bits, Pin)
     const int tid = (int)threadIdx.x;
     const i64 j0 = (i64)b * SEQ_TILE, i0 = j0 + (i64)tid * 4;
-    const u64 mode = smc_uniform_u64(smc_ldg(q.ctr + (i64)isl * 4 + 2));
+    const u64 mode = smc_uniform_u64(ld.mode);
     double S_start;
     if (mode != 0ull) {
         const double* Sf = q.Sfull + (i64)isl * (q.n + 8);
@@ -411,32 +524,33 @@ __device__ __forceinline__ double sqx_stage_tile(const SqxArgs& q, const int isl
         for (int k = 0; k < 4; ++k) sS[tid * 4 + k] = Sf[i0 + k < q.n ? i0 + k : q.n - 1];
         S_start = b ? Sf[j0 - 1] : -INFINITY;
     } else {
-        const int hE = q.hE[(i64)isl * q.ntiles + b];
-        const u64 hI = smc_ldg(q.hI + (i64)isl * q.ntiles + b);
-        const int xf0 = (int)smc_uniform_u64((u64)q.xfirst[(i64)isl * (q.ntiles + 1) + b]);
-        const int xf1 = (int)smc_uniform_u64((u64)q.xfirst[(i64)isl * (q.ntiles + 1) + b + 1]);
-        u64 Pin[4];
-        smc_ld2g(q.Pin + (i64)isl * q.ntiles * SEQ_TILE + i0, Pin[0], Pin[1]);
-        smc_ld2g(q.Pin + (i64)isl * q.ntiles * SEQ_TILE + i0 + 2, Pin[2], Pin[3]);
+        const int hE = (int)smc_uniform_u64((u64)ld.hE);
+        const u64 hI = smc_uniform_u64(ld.hI);
+        const int xf0 = (int)smc_uniform_u64((u64)ld.xf0), xf1 = (int)smc_uniform_u64((u64)ld.xf1);
         int bE[4];
         u64 bI[4], bP[4];
         double fin[4];
         bool isfin[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) { bE[k] = hE; bI[k] = hI; bP[k] = 0ull; fin[k] = 0.0; isfin[k] = false; }
-        for (int e = xf0; e < xf1; ++e) {                      // (uniform trip count: the tile's exceptions, in order)
-            const u64* x = q.xs + ((i64)isl * SQX_CAP + e) * 4;
-            const i64 jx = (i64)smc_uniform_u64(smc_ldg(x));
-            const double Sx = __longlong_as_double((long long)smc_uniform_u64(smc_ldg(x + 1)));
-            const u64 Px = smc_uniform_u64(smc_ldg(x + 2));
+        for (int e0 = xf0; e0 < xf1; e0 += 64) {               // (uniform trip counts: the tile's exceptions, in order)
+            const int ne = xf1 - e0 < 64 ? xf1 - e0 : 64;
+            __syncthreads();
+            if (tid < 3 * ne) s_x[tid] = smc_ldg(q.xs + ((i64)isl * SQX_CAP + e0 + tid / 3) * 4 + tid % 3);
+            __syncthreads();
+            for (int e = 0; e < ne; ++e) {
+                const i64 jx = (i64)s_x[3 * e];
+                const double Sx = __longlong_as_double((long long)s_x[3 * e + 1]);
+                const u64 Px = s_x[3 * e + 2];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (i0 + k > jx) { bE[k] = seq_bexp(Sx); bI[k] = sqx_mant(Sx); bP[k] = Px; isfin[k] = false; }
-                if (i0 + k == jx) { fin[k] = Sx; isfin[k] = true; }
+                for (int k = 0; k < 4; ++k) {
+                    if (i0 + k > jx) { bE[k] = seq_bexp(Sx); bI[k] = sqx_mant(Sx); bP[k] = Px; }
+                    if (i0 + k == jx) { fin[k] = Sx; isfin[k] = true; }
+                }
             }
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) sS[tid * 4 + k] = isfin[k] ? fin[k] : sqx_pack(bE[k], bI[k] + (Pin[k] - bP[k]));
+        for (int k = 0; k < 4; ++k) sS[tid * 4 + k] = isfin[k] ? fin[k] : sqx_pack(bE[k], bI[k] + (ld.Pin[k] - bP[k]));
         S_start = b ? sqx_pack(hE, hI) : -INFINITY;
     }
     __syncthreads();
@@ -467,10 +581,28 @@ __device__ inline i64 sqx_count_le(const SmcSu& s, const double x)
     }
     return lo;
 }
+// the same by a whole wave (every lane calls, x uniform across the wave): lane l evaluates the definition at
+// guess - 32 + l -- one division per lane, side by side -- and a ballot counts; the sequential form above only if
+// the window does not bracket the answer (it does: the guess is off by a unit at most)
+__device__ __forceinline__ i64 sqx_count_le_wave(const SmcSu& s, const double x)
+{
+    if (!(x >= 0.0)) return 0;
+    const double r = x * s.dM - (s.scheme == SMC_SYSTEMATIC_ ? s.u_sys : 0.0);
+    i64 g = (r < 0.0) ? 0 : (r >= s.dM ? s.M : (i64)r + 1);
+    g = g > s.M ? s.M : g;
+    const i64 n = g - 32 + smc_lane();
+    const bool in = n >= 0 && n < s.M;
+    const bool le = in ? smc_su_at(s, in ? n : 0) <= x : n < 0;
+    const u64 mask = __ballot(le ? 1 : 0);
+    const bool bracketed = (mask & 1ull) != 0ull && (mask >> 63) == 0ull;      // true at the low end, false at the high end
+    if (bracketed && (mask & (mask + 1ull)) == 0ull) return g - 32 + (i64)__popcll(mask);
+    return sqx_count_le(s, x);
+}
 // the same for sorted uniforms in memory, two thresholds at once: a 256-ary search by the workgroup (three rounds at
 // M = 2^22 instead of 22 dependent loads).  Every thread must call; the results are the same in every thread.
-__device__ __forceinline__ void sqx_count_le_sorted2(const double* su, const i64 M, const double xa, const double xb, i64& na, i64& nb)
+__device__ __forceinline__ void sqx_count_le_sorted2(const SmcSu& su, const double xa, const double xb, i64& na, i64& nb)
 {
+    const i64 M = su.M;
     __shared__ u32 s_c[2 * SMC_NWAVE];
     const int tid = (int)threadIdx.x, lane = smc_lane(), wave = smc_wave();
     i64 lo[2] = {0, 0}, hi[2] = {M, M};
@@ -485,7 +617,7 @@ __device__ __forceinline__ void sqx_count_le_sorted2(const double* su, const i64
             const i64 span = hi[v] - lo[v];
             chunk[v] = span > 0 ? (span + SMC_BLOCK - 1) / SMC_BLOCK : 1;
             const i64 idx = lo[v] + (i64)tid * chunk[v];
-            const bool t = idx < hi[v] && su[idx] <= x[v];
+            const bool t = idx < hi[v] && smc_su_at(su, idx) <= x[v];
             c[v] = (u32)__popcll(__ballot(t ? 1 : 0));
         }
         __syncthreads();
@@ -507,47 +639,86 @@ __device__ __forceinline__ void sqx_count_le_sorted2(const double* su, const i64
     na = lo[0];
     nb = lo[1];
 }
-// first k in [0, m) with x <= S[k]; m - 1 if none
-__device__ __forceinline__ int sqx_first_ge_lds(const double* S, const int m, const double x)
+// first k in [0, m) with x <= S[k] (m - 1 if none), for eight thresholds side by side: branch-free lower bounds with
+// the same number of rounds, the eight LDS reads of a round independent of one another
+__device__ __forceinline__ void sqx_first_ge_lds8(const double* S, const int m, const double (&x)[8], int (&out)[8])
 {
-    int lo = 0, hi = m;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (S[mid] < x) lo = mid + 1; else hi = mid;
+    int lo[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // (measured, r14: the ten rounds of a whole tile unrolled with compile-time steps -- immediate offsets in the LDS
+    //  reads -- run 3.2 us against 2.1 for this loop: the unrolled form serialises on its waits)
+    for (int n = m; n > 1;) {
+        const int half = n >> 1;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) lo[k] = S[lo[k] + half - 1] < x[k] ? lo[k] + half : lo[k];
+        n -= half;
     }
-    return lo < m ? lo : m - 1;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        lo[k] += S[lo[k]] < x[k] ? 1 : 0;
+        out[k] = lo[k] < m ? lo[k] : m - 1;
+    }
 }
 // the offspring of tile b: n with S_start < su_n <= S_end (the last tile takes every offspring left: the reference
 // would run off the end of W there), each written with its ancestor.  AT: u32 (the filter) or i64 (the operator).
+// sS: the tile's sums, staged (sqx_stage_tile).
 template <class AT>
-__device__ __forceinline__ void sqx_search_tile(const SqxArgs& q, const int isl, const int b, const SmcSu& su, AT* A)
+__device__ __forceinline__ void sqx_search_tile(const SqxArgs& q, const int b, const SmcSu& su, const double* sS, const double S_start, AT* A)
 {
-    __shared__ double sS[SEQ_TILE];
+    __shared__ i64 s_n[2];
     const int tid = (int)threadIdx.x;
     const i64 j0 = (i64)b * SEQ_TILE;
     const int m_all = (int)(j0 + SEQ_TILE < q.n ? SEQ_TILE : q.n - j0);
-    const double S_start = sqx_stage_tile(q, isl, b, sS);
     const double S_end = sS[m_all - 1];
     const bool last = b == q.ntiles - 1;
     i64 n_lo, n_hi;
     if (su.scheme == SMC_MULTINOMIAL_) {
-        sqx_count_le_sorted2(su.u, su.M, S_start, S_end, n_lo, n_hi);
+        sqx_count_le_sorted2(su, S_start, S_end, n_lo, n_hi);
     } else {
-        n_lo = b ? sqx_count_le(su, S_start) : 0;
-        n_hi = last ? su.M : sqx_count_le(su, S_end);
+        // wave 0: the offspring in front of the tile; wave 1: those up to its end
+        if (smc_wave() < 2) {
+            const i64 c = sqx_count_le_wave(su, smc_wave() == 0 ? S_start : S_end);
+            if (smc_lane() == 0) s_n[smc_wave()] = c;
+        }
+        __syncthreads();
+        n_lo = s_n[0];
+        n_hi = s_n[1];
     }
     if (b == 0) n_lo = 0;
     if (last) n_hi = su.M;
-    if (su.scheme == SMC_MULTINOMIAL_) {
-        for (i64 n = n_lo + tid; n < n_hi; n += SMC_BLOCK) A[n] = (AT)(j0 + sqx_first_ge_lds(sS, m_all, su.u[n]));
-        return;
+    SQX_STAMP(q, q.ntiles + 8 + b, 3);
+    // passes of 2048 offspring, two groups of four consecutive ones per thread (pairs: a Philox call each under
+    // stratified draws), the eight bisections of a thread side by side
+    for (i64 n0 = (n_lo & ~(i64)3) + (i64)tid * 4; n0 < n_hi; n0 += 8 * SMC_BLOCK) {
+        double x[8];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const i64 ng = n0 + (i64)g * 4 * SMC_BLOCK;
+            if (su.scheme == SMC_MULTINOMIAL_) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) x[4 * g + k] = ng + k < su.M ? smc_su_at(su, ng + k) : 2.0;
+            } else if (su.scheme == SMC_SYSTEMATIC_ && su.M < ((i64)1 << 30)) {
+                // fl(fl(u + n) / M) with a 32-bit conversion of n (the same double as the 64-bit one)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    x[4 * g + k] = ng + k < su.M ? smc_su_div(su, su.u_sys + (double)(int)(ng + k)) : 2.0;
+            } else {
+                smc_su_pair(su, ng >> 1, x[4 * g], x[4 * g + 1]);
+                smc_su_pair(su, (ng >> 1) + 1, x[4 * g + 2], x[4 * g + 3]);
+            }
+        }
+        SQX_STAMP(q, q.ntiles + 8 + b, 5);
+        int a8[8];
+        sqx_first_ge_lds8(sS, m_all, x, a8);
+        SQX_STAMP(q, q.ntiles + 8 + b, 6);
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const i64 n = n0 + (i64)g * 4 * SMC_BLOCK + k;
+                if (n >= n_lo && n < n_hi) A[n] = (AT)(j0 + a8[4 * g + k]);
+            }
     }
-    for (i64 p = (n_lo >> 1) + tid; 2 * p < n_hi; p += SMC_BLOCK) {      // pairs (2p, 2p + 1): one Philox call
-        double s0, s1;
-        smc_su_pair(su, p, s0, s1);
-        if (2 * p >= n_lo) A[2 * p] = (AT)(j0 + sqx_first_ge_lds(sS, m_all, s0));
-        if (2 * p + 1 < n_hi) A[2 * p + 1] = (AT)(j0 + sqx_first_ge_lds(sS, m_all, s1));
-    }
+    SQX_STAMP(q, q.ntiles + 8 + b, 4);
 }
 
 // ---- the stand-alone operators' kernels (W an array; the tiles' sums by k_seq_tile_sums) ------------------------------
@@ -555,7 +726,6 @@ static __global__ void __launch_bounds__(SMC_BLOCK)
 k_sqx_classify(const double* W, const double* tsum, const SqxArgs q, const SeqGate gate)
 {
     __shared__ double smd[SMC_SM];
-    __shared__ int s_flag;
     const int b = (int)blockIdx.x, isl = (int)blockIdx.y, tid = (int)threadIdx.x;
     if (!seq_gate_open(gate, isl)) return;
     const double* ts = tsum + (i64)isl * q.ntiles;
@@ -564,8 +734,11 @@ k_sqx_classify(const double* W, const double* tsum, const SqxArgs q, const SeqGa
     before = smc_block_sum(before, smd);
     __syncthreads();
     const SqxSrcArray src{W + (i64)isl * q.n, q.n};
-    sqx_classify_tile(src, isl, b, before, q);
-    if (sqx_last_block(q.tick + (i64)isl * SQX_CNT_WORDS, b, q.ntiles, &s_flag)) sqx_chain(src, isl, q);
+    double w4[4], tot;
+    src.load4((i64)b * SEQ_TILE + (i64)tid * 4, w4);
+    const double run0 = before + smc_block_exscan_f64((w4[0] + w4[1]) + (w4[2] + w4[3]), smd, tot);
+    __syncthreads();
+    if (sqx_classify_tile(w4, run0, isl, b, q)) sqx_chain(src, isl, q);
 }
 static __global__ void __launch_bounds__(SMC_BLOCK)
 k_sqx_fill(const SqxArgs q, double* S, const SeqGate gate)
@@ -573,7 +746,8 @@ k_sqx_fill(const SqxArgs q, double* S, const SeqGate gate)
     __shared__ double sS[SEQ_TILE];
     const int b = (int)blockIdx.x, isl = (int)blockIdx.y, tid = (int)threadIdx.x;
     if (!seq_gate_open(gate, isl)) return;
-    (void)sqx_stage_tile(q, isl, b, sS);
+    const SqxStage ld = sqx_stage_load(q, isl, b);
+    (void)sqx_stage_tile(q, isl, b, ld, sS);
     const i64 i0 = (i64)b * SEQ_TILE + (i64)tid * 4;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -591,5 +765,8 @@ k_sqx_search_sorted(const SqxArgs q, const double* su_sorted, const i64 M, i64* 
     su.seed = 0ull;
     su.t = 0u;
     su.island = 0u;
-    sqx_search_tile<i64>(q, (int)blockIdx.y, (int)blockIdx.x, su, A);
+    __shared__ double sS[SEQ_TILE];
+    const SqxStage ld = sqx_stage_load(q, (int)blockIdx.y, (int)blockIdx.x);
+    const double S_start = sqx_stage_tile(q, (int)blockIdx.y, (int)blockIdx.x, ld, sS);
+    sqx_search_tile<i64>(q, (int)blockIdx.x, su, sS, S_start, A);
 }

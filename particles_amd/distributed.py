@@ -69,7 +69,12 @@ def shard_islands(n_total, rank, world):
     return first, count
 
 
-def _send_msg(sock, payload):
+def _send_msg(sock, payload, key=None):
+    """Length-prefixed message; with `key` (the launch's nonce) an HMAC-SHA256 tag follows the payload."""
+    if key is not None:
+        import hashlib
+        import hmac
+        payload = payload + hmac.new(key, payload, hashlib.sha256).digest()
     sock.sendall(struct.pack("<I", len(payload)) + payload)
 
 
@@ -83,9 +88,18 @@ def _recv_exact(sock, n):
     return bytes(buf)
 
 
-def _recv_msg(sock):
+def _recv_msg(sock, key=None):
     (n,) = struct.unpack("<I", _recv_exact(sock, 4))
-    return _recv_exact(sock, n)
+    data = _recv_exact(sock, n)
+    if key is None:
+        return data
+    # every message behind the handshake is authenticated with the launch's nonce (the 0600 key file): a process that
+    # merely reaches the port cannot feed the ranks a pickle (allgather_obj / gather_outputs unpickle what arrives)
+    import hashlib
+    import hmac
+    if n < 32 or not hmac.compare_digest(hmac.new(key, data[:-32], hashlib.sha256).digest(), data[-32:]):
+        raise ConnectionError("rendezvous: message authentication failed")
+    return data[:-32]
 
 
 class _Star:
@@ -140,14 +154,21 @@ class _Star:
             try:
                 while len(conns) < world - 1:
                     c, _ = srv.accept()
-                    c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                    c.settimeout(timeout)
-                    hello = _recv_msg(c).decode(errors="replace").split(" ", 1)
+                    try:
+                        c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                        c.settimeout(timeout)
+                        hello = _recv_msg(c).decode(errors="replace").split(" ", 1)
+                    except (OSError, ConnectionError, ValueError, struct.error):
+                        c.close()                      # a half-open or garbled hello: not our business
+                        continue
                     if len(hello) != 2 or hello[1] != nonce or not hello[0].isdigit() \
                             or not 0 < int(hello[0]) < world or int(hello[0]) in conns:
                         c.close()                      # not a rank of this launch
                         continue
                     _send_msg(c, b"ok")
+                    # (the rendezvous timeout ends here: the collectives that follow wait as long as the slowest
+                    #  rank's work takes -- uneven shares, a first-use build on one rank)
+                    c.settimeout(None)
                     conns[int(hello[0])] = c
             except Exception:
                 for c in conns.values():
@@ -157,6 +178,7 @@ class _Star:
                 raise
             srv.close()
             self.peers = [conns[r] for r in range(1, world)]
+            self._key = nonce.encode()
         else:
             t0 = time.time()
             s = None
@@ -185,16 +207,17 @@ class _Star:
                         raise TimeoutError("rendezvous: rank 0 never published a live %s" % self._keyfile)
                     time.sleep(0.01)
             self.sock = s
+            self._key = nonce.encode()
 
     def exchange(self, payload=b""):
         if self.rank == 0:
-            parts = [payload] + [_recv_msg(c) for c in self.peers]
+            parts = [payload] + [_recv_msg(c, self._key) for c in self.peers]
             blob = b"".join(struct.pack("<I", len(p)) + p for p in parts)
             for c in self.peers:
-                _send_msg(c, blob)
+                _send_msg(c, blob, self._key)
             return parts
-        _send_msg(self.sock, payload)
-        blob = _recv_msg(self.sock)
+        _send_msg(self.sock, payload, self._key)
+        blob = _recv_msg(self.sock, self._key)
         parts, off = [], 0
         for _ in range(self.world):
             (n,) = struct.unpack_from("<I", blob, off)
@@ -301,7 +324,9 @@ class Group:
         return np.frombuffer(blob, dtype=a.dtype).reshape(a.shape).copy()
 
     def allgather_obj(self, obj):
-        """Every rank's picklable object, in rank order (host side)."""
+        """Every rank's picklable object, in rank order (host side).  Trust boundary: the bytes unpickled here arrived
+        over the star, whose every message carries an HMAC keyed by the launch's nonce (a 0600 file in the temp
+        directory): only processes of the launching user can produce them."""
         import pickle
         if not self.star:
             return [obj]

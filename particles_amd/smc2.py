@@ -146,6 +146,7 @@ class SMC2:
         self.logLt = 0.0                 # log evidence of the whole model (outer SMC, core.py:351-359)
         self._finalised = False
         self.ESSs, self.Nxs, self.acc_rates, self.move_times = [], [self.Nx], [], []
+        self.acc_fractions = []                    # realised acceptance fractions of the PMCMC steps (acc_rates: probabilities)
         # per step, as the outer particles.SMC would collect them (collectors.py:278-295): the model's
         # log-evidence after step t, and whether a resample-move preceded step t
         self.logLts, self.move_steps = [], []
@@ -297,7 +298,10 @@ class SMC2:
             lp_cur = np.where(acc, lp_prop, lp_cur)
             with np.errstate(all="ignore"):
                 pb_rates.append(float(np.mean(np.where(ok, np.exp(np.minimum(lp_prop - lp_before, 0.0)), 0.0))))
-            self.acc_rates.append(float(np.mean(acc)))
+            # (the reference stores the mean acceptance PROBABILITY, smc_samplers.py:607-611; the realised
+            #  fraction -- a noisier estimate of the same quantity -- under a name of its own)
+            self.acc_rates.append(pb_rates[-1])
+            self.acc_fractions.append(float(np.mean(acc)))
             del cand
         self._maybe_exchange(float(np.mean(pb_rates)) if pb_rates else 1.0)
         self.Nxs.append(self.Nx)
@@ -339,7 +343,8 @@ class SMC2:
             with np.errstate(all="ignore"):
                 pbs.append(float(np.mean(np.where(ok, np.exp(np.minimum(lp_prop - lp_old, 0.0)), 0.0))))
             del cand
-        self.acc_rates.extend(ars)
+        self.acc_rates.extend(pbs)                 # (smc_samplers.py:681-682: mean acceptance probabilities)
+        self.acc_fractions.extend(ars)
         # ---- the new population: all states of all chains, one batch of M P filters at time t
         self.theta = {n_: np.concatenate([th_[n_] for th_ in thetas]) for n_ in self.names}
         new = self._batch(self.theta, self.Nx)

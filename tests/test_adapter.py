@@ -356,3 +356,45 @@ def test_device_smc2_finalises_once_and_declines_what_it_cannot_batch(ref):
     after = np.random.rand()
     np.random.seed(77)
     assert np.random.rand() == after
+
+
+def _pf_logLt(pf):
+    return pf.logLt
+
+
+def test_multismc_workers_return_pickled_device_filters(ref):
+    """The REAL particles machinery (utils.multiplexer, loky worker processes) with HipSMC in the workers
+    (adapter.multiSMC): nprocs = 2 worker processes build device filters, run them, and hand the finished SMC objects
+    back PICKLED (SMC.__getstate__: smc_filter_save_state) -- core.py:415-428, utils.py:178-186.  What arrives is a live
+    device filter again: its particles, weights and summaries are those of the run, equal to the same seeded runs done
+    in this process."""
+    import pickle
+    import particles_amd as pa
+    from particles_amd import adapter
+    rk, rssm = ref["kalman"], ref["ssm"]
+    np.random.seed(5)
+    model = rk.LinearGauss(sigmaX=1.0, sigmaY=0.4, rho=0.9)
+    x, y = model.simulate(12)
+    fk = rssm.Bootstrap(ssm=model, data=y)
+    np.random.seed(77)
+    par = adapter.multiSMC(fk=fk, N=3000, nruns=4, nprocs=2)
+    assert [r["run"] for r in par] == [0, 1, 2, 3]
+    for a in par:
+        pa_ = a["output"]
+        assert isinstance(pa_, pa.SMC) and pa_._fused and pa_.t == 12
+        pb = pa.SMC(fk=adapter.adapt(fk), N=3000, seed=pa_.seed)             # the same Philox key, run here
+        pb.run()
+        assert pa_.logLt == pb.logLt and np.array_equal(np.array(pa_.X), np.array(pb.X))
+        assert np.array_equal(np.array(pa_.wgts.W), np.array(pb.wgts.W))
+        assert list(pa_.summaries.logLts) == list(pb.summaries.logLts)
+    assert len({r["output"].logLt for r in par}) == 4                    # distinct seeds, distinct runs
+    # out_func runs in the worker: only its value travels
+    lls = adapter.multiSMC(fk=fk, N=3000, nruns=4, nprocs=2, out_func=_pf_logLt)
+    assert all(isinstance(r["output"], float) for r in lls) and len({r["output"] for r in lls}) == 4
+    # and a pickled filter is a checkpoint: it resumes where it stood
+    q = pa.SMC(fk=adapter.adapt(fk), N=3000, seed=9)
+    for _ in range(5):
+        next(q)
+    z = pickle.loads(pickle.dumps(q))
+    q.run(); z.run()
+    assert q.logLt == z.logLt and np.array_equal(np.array(q.X), np.array(z.X))

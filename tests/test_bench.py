@@ -36,7 +36,18 @@ def test_default_line_carries_other_workloads_and_cpu_legs(tmp_path):
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and "C2" in d["config"]["workload"]
     assert "roofline" in d and d["roofline"]["bound"] == "hbm"
     ow = d["other_workloads"]
-    assert sorted(ow) == ["c3_multinomial", "c3_stratified", "c3_systematic", "c4", "c4_collapsed", "c5", "sqmc"]
+    assert sorted(ow) == ["c2_strict", "c3_multinomial", "c3_stratified", "c3_systematic", "c3_systematic_strict", "c4",
+                          "c4_collapsed", "c5", "sqmc"]
+    # the literal-parity contract (strict_ancestors) is on the driver's line, with its own kernels
+    for key in ("c2_strict", "c3_systematic_strict"):
+        assert "k_strict_classify+k_strict_search" in ow[key]["step_kernels"] or "k_sqx_classify" in ow[key]["step_kernels"], ow[key]
+        assert "strict_ancestors" in ow[key]["workload"]
+    # what limits C2, and the self-check a reader can hold the timed kernels to
+    assert d["roofline"]["limiter"] == "valu+latency" and d["roofline"]["launch_floor_us"] >= 0
+    sc = d["self_check"]
+    assert sc["steps"] == 7 and abs(sc["gpu_logLt"] - sc["kalman_logLt"]) < 1.0 and abs(sc["cpu_logLt"] - sc["kalman_logLt"]) < 1.0
+    for k in ("frac", "frac_rocprof", "frac_physical"):
+        assert k in d["roofline"], k
     assert "k_sq_permute" in ow["sqmc"]["step_kernels"] and "k_rs_sort" in ow["sqmc"]["step_kernels"]
     for key, leg in ow.items():
         assert "error" not in leg, (key, leg)

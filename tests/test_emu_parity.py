@@ -281,6 +281,17 @@ def test_strict_ancestors_equal_the_reference_cdf():
     pc.check_strict_ancestors(sizes=(3000,), op_N=5000, op_cases=8)
 
 
+def test_strict_ancestors_more_tiles_and_models():
+    """The two-launch strict step beyond a few tiles, a ragged size, the nonlinear model, every resampling step
+    verified to have taken the fast path (smc_filter_strict_stats)."""
+    pc.check_strict_ancestors(sizes=(9000, 8192), op_cases=0, schemes=("systematic", "multinomial"), model="sv", small=False,
+                              T=4, ESSrmin=1.0)
+
+
+def test_pickle_resume_of_device_filters():
+    pc.check_pickle_resume()
+
+
 def test_merged_reduce_equals_split(golden, monkeypatch):
     pc.check_merged_reduce_ab(golden, monkeypatch, sizes=(4096, 3000))
 

@@ -520,6 +520,10 @@ def test_strict_ancestors_equal_the_reference_cdf():
     pc.check_strict_ancestors(sizes=(3000, 1 << 17, (1 << 18) + 333), op_N=1 << 20, op_cases=100)
 
 
+def test_pickle_resume_of_device_filters():
+    pc.check_pickle_resume(sizes=(700, 3000, 1 << 18))
+
+
 def test_strict_ancestors_c2_full_size():
     """The north star's literal guarantee at the size it is benchmarked on: C2's N = 2^20, the fused strict loop --
     at every resampling step A_t == inverse_cdf(su_t, W_{t-1}) of the reference (resampling.py:484-509), replayed and

@@ -15,4 +15,8 @@ a)  # strict v2: parity at full size, timings, a kernel trace of the strict C2 s
     tail -2 $O/r14a_c2_strict_trace.log
     rm -rf $O/trace_c2_strict
     ;;
+t)  # in-kernel timelines of the strict step (needs particles_amd/lib/abl/libsmc_TRACE.so)
+    python tools/trace_strict.py 20 systematic > $O/r14_trace_strict_c2.txt 2>&1; cat $O/r14_trace_strict_c2.txt
+    python tools/trace_strict.py 22 systematic sv > $O/r14_trace_strict_c3.txt 2>&1; cat $O/r14_trace_strict_c3.txt
+    ;;
 esac

@@ -58,9 +58,20 @@ for f in sorted(glob.glob(os.path.join(out, "**", "*_results.db"), recursive=Tru
             print("  %-44s %-22s %18.1f   (n=%d, avg kernel %8.2f us under PMC)"
                   % (k, cn, v / n, n, dur[(k, cn)] / n / 1e3))
 
-# ---- machine-readable HBM traffic per launch (for bench.py's roofline.traffic)
+# ---- machine-readable HBM traffic per launch (for bench.py's roofline.traffic) and the kernels' average duration
+# in the --kernel-trace --stats pass (for roofline.frac_rocprof / frac_physical: the fractions a reader can recompute)
 import json
 traffic = {}
+avg_us = {}
+for f in sorted(glob.glob(os.path.join(out, "**", "*_results.db"), recursive=True)):
+    if "trace" not in os.path.relpath(f, out):
+        continue
+    c = sqlite3.connect(f)
+    try:
+        for name, calls, avg in c.execute("select name, total_calls, average from top_kernels"):
+            avg_us[name] = (float(avg), int(calls))
+    except sqlite3.Error:
+        pass
 for f in sorted(glob.glob(os.path.join(out, "**", "*_results.db"), recursive=True)):
     c = sqlite3.connect(f)
     try:
@@ -70,12 +81,26 @@ for f in sorted(glob.glob(os.path.join(out, "**", "*_results.db"), recursive=Tru
             traffic[k]["launches"] = n
     except sqlite3.Error:
         pass
+def _base(name):
+    return name.replace("void ", "").split("(")[0].strip()
+
+
+def _avg(k):
+    """(average us, launches) of kernel k in the trace pass: by its full name, else by name + template arguments."""
+    if k in avg_us:
+        return avg_us[k]
+    hits = [v for n, v in avg_us.items() if _base(n) == _base(k)]
+    return hits[0] if len(hits) == 1 else (None, None)
+
+
 if traffic:
     # FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B
     # (MI355X_MICROARCH.md, HBM): double it for wide coalesced reads
     res = {k: {"FETCH_SIZE_KiB": d.get("FETCH_SIZE"), "WRITE_SIZE_KiB": d.get("WRITE_SIZE"),
                "hbm_bytes_per_launch": (2.0 * d.get("FETCH_SIZE", 0.0) + d.get("WRITE_SIZE", 0.0)) * 1024.0,
-               "launches": d.get("launches")}
+               "launches": d.get("launches"),
+               # average duration in the --kernel-trace --stats pass (no counters armed), and its launches
+               "avg_us": _avg(k)[0], "trace_launches": _avg(k)[1]}
            for k, d in traffic.items() if not k.startswith("__amd")}
     with open(os.path.join(out, "traffic.json"), "w") as fh:
         rec = {"kernels": res}
