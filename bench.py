@@ -187,7 +187,7 @@ def reference_available():
     return os.path.isdir(os.path.join(REFERENCE_DIR, "particles"))
 
 
-def _cpu_worker(kind, N, nsteps, nruns, gate):
+def _cpu_worker(kind, N, nsteps, nruns, gate, Tdata=0):
     """One worker PROCESS of the CPU baseline (bench.py --cpu-worker ...): `nruns` independent
     bootstrap filters of N particles over the first `nsteps` observations, one after the other,
     on one core.  gate: a directory -- the worker drops a `ready.<pid>` file when its imports are
@@ -200,7 +200,8 @@ def _cpu_worker(kind, N, nsteps, nruns, gate):
         import tools.cpu_reference as cr            # numba shim + compiled inverse_cdf + /root/reference
         model = cr.ToySSM(sigma=0.2)
         np.random.seed(42)
-        x, y = model.simulate(nsteps)
+        x, y = model.simulate(max(nsteps, Tdata))     # (the GPU run's series: simulate(T) draws depend on T)
+        y = y[:nsteps]
 
         def one(seed):
             np.random.seed(seed)
@@ -210,7 +211,7 @@ def _cpu_worker(kind, N, nsteps, nruns, gate):
             return pf.cpu_time, float(pf.logLt)       # the reference's own timer (utils.py:81-89)
     else:
         from oracle import smc_oracle as orc
-        y = synthetic_data(nsteps)
+        y = synthetic_data(max(nsteps, Tdata))        # (the GPU run's series, of which the first nsteps are filtered)
 
         def one(seed):
             np.random.seed(seed)
@@ -231,11 +232,11 @@ def _cpu_worker(kind, N, nsteps, nruns, gate):
     print(json.dumps({"t0": t0, "t1": time.time(), "seconds": secs, "logLt": lls}), flush=True)
 
 
-def _spawn_workers(kind, N, nsteps, runs_per_worker, nworkers):
+def _spawn_workers(kind, N, nsteps, runs_per_worker, nworkers, Tdata=0):
     import tempfile
     gate = tempfile.mkdtemp(prefix="smc_cpu_gate_") if nworkers > 1 else ""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-worker", kind, str(N), str(nsteps),
-           str(runs_per_worker), gate]
+           str(runs_per_worker), gate, str(int(Tdata))]
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
     procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env)
              for _ in range(nworkers)]
@@ -271,7 +272,7 @@ def _spawn_workers(kind, N, nsteps, runs_per_worker, nworkers):
     return outs
 
 
-def cpu_baseline(N, nsteps, all_cores=True, kind=None):
+def cpu_baseline(N, nsteps, all_cores=True, kind=None, Tdata=0):
     """CPU legs beside the GPU number, on this host's cores.
     kind "reference": nchopin/particles itself (importable only where /root/reference exists: the
     build container), timed by its own pf.cpu_time, `inverse_cdf` bound to its gcc -O2 restatement
@@ -293,7 +294,7 @@ def cpu_baseline(N, nsteps, all_cores=True, kind=None):
             "oracle.run_filter (NumPy restatement of particles.SMC + C inverse_cdf)")
     sample = ("%s; N=2^%d, first %d steps of the same data (np.random.seed(42); simulate), run seed 123; "
               "cost per step is flat in T" % (what, int(np.log2(N)), nsteps))
-    one = _spawn_workers(kind, N, nsteps, 1, 1)[0]
+    one = _spawn_workers(kind, N, nsteps, 1, 1, Tdata)[0]
     out = {"value": N * nsteps / one["seconds"], "unit": "particle-steps/s", "cores": 1, "kind": kind,
            "sample": sample, "seconds": one["seconds"], "logLt": one["logLt"][0],
            "host": {"nproc": nproc, "cpu": _cpu_name()},
@@ -579,7 +580,8 @@ def _spawn_ranks(n):
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
         kind, N, nsteps, nruns = sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
-        return _cpu_worker(kind, N, nsteps, nruns, sys.argv[6] if len(sys.argv) > 6 else "")
+        return _cpu_worker(kind, N, nsteps, nruns, sys.argv[6] if len(sys.argv) > 6 else "",
+                           int(sys.argv[7]) if len(sys.argv) > 7 else 0)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
@@ -826,7 +828,7 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline and a.workload == "c2":
         nst = min(a.cpu_steps, T) if a.log2N >= 18 else min(T, 2000)
         try:
-            out["cpu_baseline"] = cpu_baseline(N, nst)
+            out["cpu_baseline"] = cpu_baseline(N, nst, Tdata=T)
             if "self_check" in out and nst == out["self_check"]["steps"]:
                 out["self_check"]["cpu_logLt"] = out["cpu_baseline"]["logLt"]
                 out["self_check"]["cpu_minus_kalman"] = out["cpu_baseline"]["logLt"] - out["self_check"]["kalman_logLt"]

@@ -86,6 +86,9 @@ int smc_log_wmean_exp(smc_ctx* ctx, const double* v, const double* W, int64_t N,
 /* wmean_and_var (resampling.py:320-338): out_host = mean[d], var[d] */
 int smc_wmean_var(smc_ctx* ctx, const double* W, const double* X, int64_t N,
                   int64_t d, double* out_host);
+/* resampling.wmean_and_cov (resampling.py:341-358): out_host = mean (d) | covariance (d, d) row-major of the weighted
+ * data -- np.average(x, weights=W, axis=0), np.cov(x.T, aweights=W, ddof=0); X is (N, d) row-major, d <= 32. */
+int smc_wmean_cov(smc_ctx* ctx, const double* W, const double* X, int64_t N, int64_t d, double* out_host);
 
 /* ---- a-5: inverse_cdf (resampling.py:484-509) ----------------------------
  * su: M sorted points in [0,1]; A[n] = smallest j with su[n] <= CDF_j, clamped

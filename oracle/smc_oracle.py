@@ -129,6 +129,27 @@ def wmean_and_var(W, x):
     return {"mean": m, "var": m2 - m ** 2}
 
 
+def wmean_and_cov(W, x):
+    """resampling.py:341-358."""
+    m = np.average(x, weights=W, axis=0)
+    cov = np.cov(x.T, aweights=W, ddof=0)
+    return m, cov
+
+
+def wmean_and_var_str_array(W, x):
+    """resampling.py:361-380."""
+    m = np.empty(shape=x.shape[1:], dtype=x.dtype)
+    v = np.empty_like(m)
+    for p in x.dtype.names:
+        m[p], v[p] = wmean_and_var(W, x[p]).values()
+    return {"mean": m, "var": v}
+
+
+def wquantiles_str_array(W, x, alphas=(0.25, 0.50, 0.75)):
+    """resampling.py:420-442."""
+    return {p: wquantiles(W, x[p], alphas) for p in x.dtype.names}
+
+
 # --------------------------------------------------------------------------
 # Resampling                      (particles/resampling.py)
 # --------------------------------------------------------------------------

@@ -95,6 +95,7 @@ SIGNATURES = {
     "smc_lse_normalise": (c_int, [c_vp, c_vp, c_i64, c_vp, P(c_dbl)]),
     "smc_log_wmean_exp": (c_int, [c_vp, c_vp, c_vp, c_i64, P(c_dbl)]),
     "smc_wmean_var": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, P(c_dbl)]),
+    "smc_wmean_cov": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, P(c_dbl)]),
     "smc_inverse_cdf": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
     "smc_inverse_cdf_strict": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
     "smc_seq_prefix_sums": (c_int, [c_vp, c_vp, c_i64, c_vp, c_int, P(c_i64)]),

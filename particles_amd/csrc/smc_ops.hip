@@ -202,6 +202,82 @@ extern "C" int smc_wmean_var(smc_ctx* ctx, const double* W, const double* X, int
     return SMC_OK;
 }
 
+// partial sums of w (x_i - m_i)(x_j - m_j), i <= j, over a chunk of particles: one workgroup per chunk, thread k
+// of pair (i, j) accumulates its particles (d <= 32: at most 528 pairs, two or three per thread)
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_wcov_partials(const double* W, const double* X, i64 N, int d, const double* mean, double* part)
+{
+    __shared__ double sX[64 * 33];                             // 64 particles of the chunk at a time, centred
+    __shared__ double sW[64];
+    __shared__ double smean[32];
+    const int tid = (int)threadIdx.x;
+    if (tid < d) smean[tid] = mean[tid];
+    const int npair = d * (d + 1) / 2;
+    double acc[3] = {0.0, 0.0, 0.0};
+    int pi[3], pj[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {                              // pair index -> (i, j), i <= j, row-major upper triangle
+        int p = tid + r * SMC_BLOCK, i = 0;
+        if (p >= npair) p = 0;
+        while (p >= d - i) { p -= d - i; ++i; }
+        pi[r] = i;
+        pj[r] = i + p;
+    }
+    const i64 base = (i64)blockIdx.x * LSE_CHUNK;
+    for (int c0 = 0; c0 < LSE_CHUNK; c0 += 64) {
+        __syncthreads();
+        for (int e = tid; e < 64 * d; e += SMC_BLOCK) {
+            const int n = e / d, c = e - n * d;
+            const i64 g = base + c0 + n;
+            sX[n * 33 + c] = g < N ? X[g * d + c] - smean[c] : 0.0;
+        }
+        if (tid < 64) sW[tid] = base + c0 + tid < N ? W[base + c0 + tid] : 0.0;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            if (tid + r * SMC_BLOCK >= npair) continue;
+            double a = acc[r];
+            for (int n = 0; n < 64; ++n) a += sW[n] * (sX[n * 33 + pi[r]] * sX[n * 33 + pj[r]]);
+            acc[r] = a;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+        if (tid + r * SMC_BLOCK < npair) part[(i64)blockIdx.x * npair + tid + r * SMC_BLOCK] = acc[r];
+}
+
+// (mean, cov) of weighted data: np.average(x, weights=W, axis=0) and np.cov(x.T, aweights=W, ddof=0)
+// (resampling.py:341-358): out_host = mean (d) | cov (d, d) row-major.  d <= 32.
+extern "C" int smc_wmean_cov(smc_ctx* ctx, const double* W, const double* X, int64_t N, int64_t d, double* out_host)
+{
+    SMC_REQUIRE(ctx && W && X && out_host, "null argument");
+    SMC_REQUIRE(N > 0 && d > 0 && d <= 32, "bad shape (d <= 32)");
+    std::vector<double> t;
+    int rc = wsum(ctx, W, X, N, d, 0, 0.0, t);
+    if (rc) return rc;
+    const double wtot = t[0];
+    for (i64 c = 0; c < d; ++c) out_host[c] = t[c * 3 + 1] / t[c * 3];
+    const int nblk = (int)((N + LSE_CHUNK - 1) / LSE_CHUNK), npair = (int)(d * (d + 1) / 2);
+    void* scr;
+    rc = smc_scratch(ctx, (size_t)(nblk * npair + 32) * sizeof(double), &scr);
+    if (rc) return rc;
+    double* dmean = (double*)scr + (size_t)nblk * npair;
+    SMC_HIP_CHECK(hipMemcpyAsync(dmean, out_host, (size_t)d * 8, hipMemcpyHostToDevice, ctx->stream));
+    SMC_LAUNCH(k_wcov_partials, dim3(nblk), dim3(SMC_BLOCK), ctx->stream, W, X, (i64)N, (int)d, (const double*)dmean, (double*)scr);
+    SMC_LAUNCH_CHECK();
+    std::vector<double> h((size_t)nblk * npair);
+    SMC_HIP_CHECK(hipMemcpyAsync(h.data(), scr, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SMC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    int p = 0;
+    for (int i = 0; i < (int)d; ++i)
+        for (int j = i; j < (int)d; ++j, ++p) {
+            double a = 0.0;
+            for (int b = 0; b < nblk; ++b) a += h[(size_t)b * npair + p];
+            out_host[d + i * d + j] = out_host[d + j * d + i] = a / wtot;
+        }
+    return SMC_OK;
+}
+
 extern "C" int smc_log_wmean_exp(smc_ctx* ctx, const double* v, const double* W, int64_t N,
                                  double* out_host)
 {

@@ -98,6 +98,40 @@ def wmean_and_var(W, x):
     return {"mean": o[:dd], "var": o[dd:]}
 
 
+def wmean_and_cov(W, x):
+    """Weighted mean and covariance matrix (resampling.py:341-358): ``(mean, cov)``, cov = np.cov(x.T, aweights=W,
+    ddof=0); a 0-d array for one-dimensional data, as numpy returns it."""
+    Wd, _ = as_device(W)
+    xd, _ = as_device(x)
+    N = Wd.size
+    dd = xd.size // N
+    if dd > 32:                                   # (beyond the kernel's tile: numpy on the host, the reference's own lines)
+        xh = xd.get().reshape(N, dd)
+        Wh = Wd.get()
+        return np.average(xh, weights=Wh, axis=0), np.cov(xh.T, aweights=Wh, ddof=0)
+    out = (ctypes.c_double * (dd + dd * dd))()
+    check(lib().smc_wmean_cov(Wd.ctx.h, Wd.ptr, xd.ptr, N, dd, out))
+    o = np.array(out[:])
+    if xd.ndim == 1:
+        return o[0], np.array(o[1])
+    return o[:dd], o[dd:].reshape(dd, dd)
+
+
+def wmean_and_var_str_array(W, x):
+    """Weighted mean and variance of each component of a structured array (resampling.py:361-380)."""
+    m = np.empty(shape=x.shape[1:], dtype=x.dtype)
+    v = np.empty_like(m)
+    for p in x.dtype.names:
+        m[p], v[p] = wmean_and_var(W, np.ascontiguousarray(x[p])).values()
+    return {"mean": m, "var": v}
+
+
+def wquantiles_str_array(W, x, alphas=(0.25, 0.50, 0.75)):
+    """Quantiles of weighted data stored in a structured array, one entry per field (resampling.py:420-442; the
+    reference's default ``alphas=(0.25, 0.50, 0, 75)`` is a typo for these three)."""
+    return {p: wquantiles(W, np.ascontiguousarray(x[p]), alphas) for p in x.dtype.names}
+
+
 def wquantiles(W, x, alphas=(0.25, 0.50, 0.75)):
     """Quantiles for weighted data (resampling.py:381-417): ``(k,)`` for ``x`` of shape
     ``(N,)``, ``(d, k)`` for ``(N, d)``."""

@@ -333,6 +333,20 @@ def main():
                                   prior_rho=np.array([0.3, 0.99]), prior_sigmaY=np.array([2.0, 4.0]), sigmaX=1.0,
                                   **{k: np.array(v, dtype=float) for k, v in rec.items()})
 
+    # --- wmean_and_cov, the structured-array moments / quantiles (resampling.py:341-380, 420-442) ----------
+    rng = np.random.RandomState(21)
+    Wm = rs.exp_and_normalise(2.0 * rng.randn(1500))
+    Xm = rng.randn(1500, 5) @ rng.randn(5, 5) + np.arange(5.0)
+    m5, c5 = rs.wmean_and_cov(Wm, Xm)
+    m1, c1 = rs.wmean_and_cov(Wm, Xm[:, 0])
+    xs = np.zeros(1500, dtype=[("a", float), ("b", float)])
+    xs["a"], xs["b"] = Xm[:, 1], np.exp(0.3 * Xm[:, 2])
+    mv = rs.wmean_and_var_str_array(Wm, xs)
+    wq = rs.wquantiles_str_array(Wm, xs, alphas=(0.1, 0.5, 0.9))
+    out["moments_cov"] = dict(W=Wm, X=Xm, mean5=m5, cov5=c5, mean1=m1, cov1=np.array(c1), sa=xs["a"], sb=xs["b"],
+                              sm_a=mv["mean"]["a"], sm_b=mv["mean"]["b"], sv_a=mv["var"]["a"], sv_b=mv["var"]["b"],
+                              sq_a=np.array(wq["a"]), sq_b=np.array(wq["b"]))
+
     only = sys.argv[1:]              # optional: names of the fixtures to (re)write
     for name, case in out.items():
         if only and name not in only:

@@ -72,6 +72,31 @@ def check_wquantiles(golden, N=200001):
                        rtol=1e-9, atol=1e-9)
 
 
+def check_wmean_and_cov(golden, N=150001):
+    """rs.wmean_and_cov / wmean_and_var_str_array / wquantiles_str_array (resampling.py:341-380, 420-442) on the
+    device against the reference's own outputs (fixture moments_cov) and, on a larger sample and at d = 1 .. 32,
+    against the oracle's restatement."""
+    g = golden("moments_cov")
+    m, c = rs.wmean_and_cov(g["W"], g["X"])
+    assert np.allclose(m, g["mean5"], rtol=1e-13, atol=1e-14) and np.allclose(c, g["cov5"], rtol=1e-12, atol=1e-13)
+    assert c.shape == (5, 5) and np.array_equal(c, c.T)
+    m1, c1 = rs.wmean_and_cov(g["W"], g["X"][:, 0])
+    assert abs(m1 - g["mean1"]) < 1e-13 and np.ndim(c1) == 0 and abs(float(c1) - float(g["cov1"])) < 1e-12
+    xs = np.zeros(len(g["W"]), dtype=[("a", float), ("b", float)])
+    xs["a"], xs["b"] = g["sa"], g["sb"]
+    mv = rs.wmean_and_var_str_array(g["W"], xs)
+    assert abs(mv["mean"]["a"] - g["sm_a"]) < 1e-13 and abs(mv["var"]["b"] - g["sv_b"]) < 1e-12
+    wq = rs.wquantiles_str_array(g["W"], xs, alphas=(0.1, 0.5, 0.9))
+    assert np.allclose(wq["a"], g["sq_a"], rtol=1e-12, atol=1e-13) and np.allclose(wq["b"], g["sq_b"], rtol=1e-12, atol=1e-13)
+    rng = np.random.default_rng(4)
+    W = orc.exp_and_normalise(1.5 * rng.standard_normal(N))
+    for d in (1, 2, 7, 32, 40):                       # (40: beyond the kernel's tile -- the host route)
+        X = rng.standard_normal((N, d)) @ rng.standard_normal((d, d)) + 3.0
+        m, c = rs.wmean_and_cov(W, X)
+        mo, co = orc.wmean_and_cov(W, X)
+        assert np.allclose(m, mo, rtol=1e-11, atol=1e-12) and np.allclose(c, np.atleast_2d(co), rtol=1e-9, atol=1e-10), d
+
+
 def check_device_sort(sizes=(1, 63, 64, 2047, 2048, 2049, 50001)):
     """The hand-written LSD radix sort (csrc/smc_sort.hip): argsort of doubles against
     np.argsort(kind="stable") -- ties, signed zeros, infinities, tiny / huge magnitudes -- and the

@@ -106,7 +106,7 @@ def test_committed_traffic_files_are_usable():
         assert os.path.exists(os.path.join(ROOT, "profiles", rec["summary"])), (f, rec["summary"])
         cfg = rec["config"]
         wl = bench.make_workload(cfg["workload"], 4, scheme=cfg["scheme"], collapsed=bool(cfg.get("collapsed")),
-                                 qmc=bool(cfg.get("qmc")))
+                                 qmc=bool(cfg.get("qmc")), strict=bool(cfg.get("strict")))
         assert bench.leg_key(wl) == key, (f, bench.leg_key(wl))
         assert (wl["log2N"], wl["islands"]) == (cfg["log2N"], cfg["islands"]), f
         names = [n for n in rec["kernels"] if "k_propagate" in n]
@@ -118,6 +118,52 @@ def test_committed_traffic_files_are_usable():
         assert 0.4 < tr[0] / alg < 2.0, (f, tr[0] / alg)
         # a different size is NOT this record's workload
         wl2 = bench.make_workload(cfg["workload"], 4, scheme=cfg["scheme"], log2N=cfg["log2N"] - 1,
-                                  collapsed=bool(cfg.get("collapsed")), qmc=bool(cfg.get("qmc")))
+                                  collapsed=bool(cfg.get("collapsed")), qmc=bool(cfg.get("qmc")), strict=bool(cfg.get("strict")))
         if cfg["workload"] != "c5":
             assert bench.measured_traffic(wl2, "k_propagate") is None
+
+
+def test_fractions_are_reproducible_from_profiles():
+    """every leg's `frac_rocprof` and `frac_physical` must be what a reader computes by hand from the
+    committed record -- algorithmic (or counted) bytes / the kernel's average duration in the rocprofv3 trace pass / the
+    peak -- and that duration must be the one printed in the summary file the record names."""
+    import glob
+    import re
+    import bench
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_*.json")))
+    assert len(files) >= 10
+    for f in files:
+        rec = json.load(open(f))
+        cfg = rec["config"]
+        wl = bench.make_workload(cfg["workload"], 4, scheme=cfg["scheme"], collapsed=bool(cfg.get("collapsed")),
+                                 qmc=bool(cfg.get("qmc")), strict=bool(cfg.get("strict")))
+        mv = "k_propagate_mv" if cfg["workload"] == "c4" else "k_propagate"
+        name, d = [(n, v) for n, v in rec["kernels"].items() if bench_base(n) == mv][0]
+        assert d["avg_us"] and d["avg_us"] > 1.0, f
+        # the duration in the record is the one in the summary text (the trace pass's table)
+        txt = open(os.path.join(ROOT, "profiles", rec["summary"])).read()
+        rows = re.findall(r"^\s+(.*?)\s+calls\s+\d+\s+avg\s+([0-9.]+) us", txt, flags=re.M)
+        avgs = [float(a) for n_, a in rows if n_.replace("void ", "").startswith(mv + ("<" if "<" in name else "("))
+                or n_.replace("void ", "").split("<")[0].split("(")[0] == mv]
+        assert any(abs(a - d["avg_us"]) < 5e-4 for a in avgs), (f, avgs, d["avg_us"])
+        N, isl, dd = wl["N"], wl["islands"], wl["d"]
+        two = any(k in " ".join(rec["kernels"]) for k in ("k_ancestors2", "k_strict_classify"))
+        rf = {"kernel": mv, "bound": "hbm", "launch_bytes": (16.0 * dd + 16.0 + (8.0 if two else 0.0)) * N * isl}
+        if cfg["workload"] == "c4":
+            rf.update(bound="mfma", launch_flop=(44 if cfg.get("collapsed") else 72) * 2048.0 / 16.0 * N * isl)
+        bench.add_profile_fractions(rf, wl)
+        sec = d["avg_us"] * 1e-6
+        if rf["bound"] == "mfma":
+            assert abs(rf["frac_rocprof"] - rf["launch_flop"] / sec / 1e12 / bench.FP64_PEAK_TF) < 1e-12
+            assert 0.3 < rf["frac_rocprof"] < 0.8, (f, rf["frac_rocprof"])
+        else:
+            assert abs(rf["frac_rocprof"] - rf["launch_bytes"] / sec / 1e9 / bench.HBM_PEAK_GBS) < 1e-12
+            assert abs(rf["frac_physical"] - d["hbm_bytes_per_launch"] / sec / 1e9 / bench.HBM_PEAK_GBS) < 1e-12
+            # (the counters see fewer bytes than SURVEY's accounting -- 32-bit ancestors -- except under SQMC, whose
+            #  k_propagate also reads the tape of ndtri values)
+            assert 0.3 < rf["frac_physical"] < 1.0 and 0.3 < rf["frac_rocprof"] < 1.0, (f, rf)
+            assert cfg.get("qmc") or rf["frac_physical"] <= rf["frac_rocprof"] * 1.05, (f, rf)
+
+
+def bench_base(name):
+    return name.replace("void ", "").split("<")[0].split("(")[0].strip()

@@ -50,6 +50,10 @@ def test_resampling_statistics():
     pc.check_resampling_statistics(600, 40)
 
 
+def test_wmean_and_cov(golden):
+    pc.check_wmean_and_cov(golden, N=20001)
+
+
 def test_wquantiles(golden):
     pc.check_wquantiles(golden, N=9001)          # (the emulator runs the radix sort lane by lane)
 

@@ -58,6 +58,10 @@ def test_resampling_statistics():
     pc.check_resampling_statistics(2000, 200)
 
 
+def test_wmean_and_cov(golden):
+    pc.check_wmean_and_cov(golden)
+
+
 def test_wquantiles(golden):
     pc.check_wquantiles(golden)
 

@@ -167,6 +167,21 @@ def test_weights(golden):
     assert mv["mean"] == g["wmean"] and mv["var"] == g["wvar"]
 
 
+def test_wmean_and_cov_and_structured_arrays(golden):
+    """resampling.py:341-380, 420-442 restated: bit for bit against the reference's own outputs."""
+    g = golden("moments_cov")
+    m, c = orc.wmean_and_cov(g["W"], g["X"])
+    assert np.array_equal(m, g["mean5"]) and np.array_equal(c, g["cov5"])
+    m1, c1 = orc.wmean_and_cov(g["W"], g["X"][:, 0])
+    assert m1 == g["mean1"] and np.array_equal(np.array(c1), g["cov1"])
+    xs = np.zeros(len(g["W"]), dtype=[("a", float), ("b", float)])
+    xs["a"], xs["b"] = g["sa"], g["sb"]
+    mv = orc.wmean_and_var_str_array(g["W"], xs)
+    assert mv["mean"]["a"] == g["sm_a"] and mv["mean"]["b"] == g["sm_b"] and mv["var"]["a"] == g["sv_a"] and mv["var"]["b"] == g["sv_b"]
+    wq = orc.wquantiles_str_array(g["W"], xs, alphas=(0.1, 0.5, 0.9))
+    assert np.array_equal(np.array(wq["a"]), g["sq_a"]) and np.array_equal(np.array(wq["b"]), g["sq_b"])
+
+
 def test_wquantiles(golden):
     g = golden("weights")
     x = np.sin(np.arange(1000.0))

@@ -6,7 +6,7 @@
 #   profiles/traffic_<leg>.json        bench.py's roofline.traffic source (config + command inside)
 # are what to copy out of gpurun_out/<tag>/.
 TAG=${1:-r12p}
-LEGS=${2:-"c2 c3_systematic c3_stratified c3_multinomial c4 c4_collapsed c5 sqmc"}
+LEGS=${2:-"c2 c3_systematic c3_stratified c3_multinomial c4 c4_collapsed c5 sqmc c2_strict c3_systematic_strict"}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -25,6 +25,8 @@ for leg in $LEGS; do
                     PASSES="FETCH_SIZE;WRITE_SIZE;SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAIT_INST_ANY;SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY SQ_INSTS_SALU GRBM_GUI_ACTIVE" ;;
     c5)             ARGS="--workload c5"; CFG='{"workload":"c5","log2N":18,"islands":32,"scheme":"systematic"}' ;;
     sqmc)           ARGS="--workload c2 --qmc"; STEPS=40; CFG='{"workload":"c2","log2N":20,"islands":1,"scheme":"systematic","qmc":true}' ;;
+    c2_strict)      ARGS="--workload c2 --strict"; STEPS=200; CFG='{"workload":"c2","log2N":20,"islands":1,"scheme":"systematic","strict":true}' ;;
+    c3_systematic_strict) ARGS="--workload c3 --scheme systematic --strict"; CFG='{"workload":"c3","log2N":22,"islands":1,"scheme":"systematic","strict":true}' ;;
     *) echo "unknown leg $leg"; continue ;;
   esac
   P=$O/prof_$leg

@@ -15,6 +15,24 @@ a)  # strict v2: parity at full size, timings, a kernel trace of the strict C2 s
     tail -2 $O/r14a_c2_strict_trace.log
     rm -rf $O/trace_c2_strict
     ;;
+full)  # the whole GPU suite, the driver's bench line, K = 1000, the profiles of every leg
+    timeout 900 python -m pytest tests -m gpu -x -q > $O/${TAG:-r14}_pytest_gpu.log 2>&1; echo "pytest rc $?" >> $O/${TAG:-r14}_pytest_gpu.log
+    tail -6 $O/${TAG:-r14}_pytest_gpu.log
+    timeout 600 python bench.py --steps 20 --warmup 5 > $O/${TAG:-r14}_bench_driver_line.json 2> $O/${TAG:-r14}_bench_driver_line.err; echo "bench rc $?"
+    timeout 300 python bench.py --steps 1000 --warmup 50 --no-other-workloads --no-cpu-baseline > $O/${TAG:-r14}_bench_c2_k1000.json 2>/dev/null
+    python - <<PY
+import json
+d = json.load(open("$O/${TAG:-r14}_bench_driver_line.json"))
+print("C2", d["value"] / 1e9, d["ms_per_step"], d["roofline"]["frac"], d["roofline"].get("launch_floor_us"), d.get("self_check"))
+for k, v in d["other_workloads"].items():
+    print(k, v.get("value", 0) / 1e9, v.get("ms_per_step"), v.get("frac"), v.get("error"))
+d = json.load(open("$O/${TAG:-r14}_bench_c2_k1000.json"))
+print("C2 K=1000", d["value"] / 1e9, d["ms_per_step"])
+PY
+    ;;
+prof)
+    bash tools/gpu_profile_all.sh ${TAG:-r14} "$2"
+    ;;
 t)  # in-kernel timelines of the strict step (needs particles_amd/lib/abl/libsmc_TRACE.so)
     python tools/trace_strict.py 20 systematic > $O/r14_trace_strict_c2.txt 2>&1; cat $O/r14_trace_strict_c2.txt
     python tools/trace_strict.py 22 systematic sv > $O/r14_trace_strict_c3.txt 2>&1; cat $O/r14_trace_strict_c3.txt
