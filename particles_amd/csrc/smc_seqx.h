@@ -383,7 +383,47 @@ __device__ __forceinline__ void sqx_chain(const Src& src, const int isl, const S
         // ---- the walk (one thread): a run of regular elements is an integer added on the grid of s, an exception the
         // hardware's own addition (resampling.py:506-508).  pack(bexp(s), mant(s) + 0) == s for every s >= 0: no branch
         // on dP; the checks apply where dP != 0 and are collected off the chain of s.
-        if (tid == 0) {
+        if (cnt <= 64) {
+            // up to 64 exceptions (the rule: a few dozen): lane l of wave 0 holds exception l's (dP, W) in registers and
+            // the wave walks in lockstep -- v_readlane feeds the chain of s, nothing on it waits for LDS
+            if (tid < 64) {
+                const int lane = tid;
+                const u64 Pl = lane < cnt ? c_P[lane] : 0ull;
+                const u64 dPl = Pl - ((lane > 0 && lane < cnt) ? c_P[lane - 1] : 0ull);
+                const double wl = lane < cnt ? c_w[lane] : 0.0;
+                const bool head = cnt > 0 && c_j[0] == 0u;     // (s = W[0] starts the chain: not 0 + W[0])
+                double s = 0.0, Sl = 0.0;
+#ifndef SMC_EMULATE
+                asm volatile("" : "+v"(s));                    // (a vector value: see the scalar-register note below)
+#endif
+                // (a single wave issues every instruction of the loop back to back -- 28 of them cost 90 ns per exception;
+                //  the checks of the walk's assumptions are therefore NOT made here but afterwards, by every lane for
+                //  its own exception, from the sum its left neighbour recorded)
+                for (int i = 0; i < cnt; ++i) {
+                    const u64 dP = smc_readlane64(dPl, i);
+                    const double w = smc_readlane_f64(wl, i);
+                    const u64 sb = (u64)__double_as_longlong(s);
+                    const u32 hi = (u32)(sb >> 32), Es = hi >> 20;  // (s >= 0: no sign bit)
+                    const u32 mh = (hi & 0xfffffu) | ((Es < 1u ? Es : 1u) << 20);
+                    const u64 Iv = (((u64)mh << 32) | (u32)sb) + dP;
+                    s = __longlong_as_double((long long)(((u64)((Es << 20) | ((u32)(Iv >> 32) & 0xfffffu)) << 32) | (u32)Iv)) + w;
+                    if (i == 0 && head) s = w;
+                    Sl = lane == i ? s : Sl;
+                }
+                if (lane < cnt) c_S[lane] = Sl;
+                // lane i: was the integer step in front of exception i legitimate?  (the sum in front of it: lane i - 1's)
+                const double sprev = smc_dpp_f64<SMC_DPP_WAVE_SHR1, 0xf, false>(Sl);   // (lane 0: 0.0, nothing summed yet)
+                bool bad = false;
+                if (lane < cnt && dPl != 0ull) {
+                    const int Ep = seq_bexp(sprev);
+                    bad = Ep < 1 || Ep >= 0x7ff || sqx_mant(sprev) + dPl >= (1ull << 53);
+                }
+                const u64 dP = carry - (cnt ? smc_readlane64(Pl, cnt - 1) : 0ull);   // the run behind the last exception
+                const int Es = seq_bexp(s);
+                bad = bad || (dP != 0ull && !(Es >= 1 && Es < 0x7ff && sqx_mant(s) + dP < (1ull << 53)));
+                if (bad) c_ok = 0;                             // (benign race: every writer stores 0)
+            }
+        } else if (tid == 0) {
             double s = 0.0;
 #ifndef SMC_EMULATE
             // (only lane 0 is here, and the compiler would keep the chain of s in scalar registers -- a
@@ -393,7 +433,7 @@ __device__ __forceinline__ void sqx_chain(const Src& src, const int isl, const S
 #endif
             u64 Pprev = 0ull;
             u32 viol = 0u;
-            const bool head = cnt > 0 && c_j[0] == 0u;         // (s = W[0] starts the chain: not 0 + W[0])
+            const bool head = cnt > 0 && c_j[0] == 0u;
             u64 Pn = cnt > 0 ? c_P[0] : 0ull;                  // (the next exception's P and W: read one step ahead,
             double wn = cnt > 0 ? c_w[0] : 0.0;                //  so that no LDS latency sits on the chain of s)
             for (int i = 0; i < cnt; ++i) {
@@ -405,7 +445,7 @@ __device__ __forceinline__ void sqx_chain(const Src& src, const int isl, const S
                 const u64 dP = Pi - Pprev;
                 Pprev = Pi;
                 const u64 sb = (u64)__double_as_longlong(s);
-                const u32 hi = (u32)(sb >> 32), Es = hi >> 20;  // (s >= 0: no sign bit)
+                const u32 hi = (u32)(sb >> 32), Es = hi >> 20;
                 const u32 mh = (hi & 0xfffffu) | ((Es < 1u ? Es : 1u) << 20);
                 const u64 Iv = (((u64)mh << 32) | (u32)sb) + dP;
                 const u32 ih = (u32)(Iv >> 32);

@@ -1057,6 +1057,7 @@ def check_seq_prefix_sums(sizes=(5000, 1 << 14, 20001), monkeypatch=None):
         w = rng.random(N); w[rng.random(N) < 0.3] = 0.0; cases["sparse"] = w / w.sum()
         cases["dyadic"] = rng.integers(0, 2 ** 30 // N, size=N).astype(np.float64) / 2.0 ** 30
         w = np.full(N, 2.0 ** -40); w[0] = 0.25; w[1::2] = 3 * 2.0 ** -55; cases["ties"] = w
+        w = np.full(N, 2.0 ** -40); w[0] = 0.25; w[1:241:2] = 3 * 2.0 ** -55; cases["some ties"] = w    # 120 ties: the walk's LDS form
         cases["tiny"] = rng.random(N) * 1e-300
         cases["unnormalised"] = rng.random(N) * 1e6
         w = np.zeros(N); w[-1] = 0.5; cases["late mass"] = w
@@ -1075,8 +1076,10 @@ def check_seq_prefix_sums(sizes=(5000, 1 << 14, 20001), monkeypatch=None):
             assert fb >= -1 and 0 < nx <= (N + 1023) // 1024
             fast += fb >= 0
             log.append((N, name, fb))
-            if name not in ("ties", "tiny"):
+            if name not in ("ties", "tiny", "some ties"):
                 assert 0 <= fb <= 300, (N, name, fb)             # these stay on the fast path (fb: exceptions walked)
+            if name == "some ties":
+                assert 64 < fb <= 256, (N, name, fb)             # more exceptions than a wave holds, fewer than the list
             if name == "ties" and N >= 16384:
                 assert fb == -1, (N, name)                       # more exceptions than the lists hold: the exact path
     assert fast >= 8 * len(sizes)

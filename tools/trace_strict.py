@@ -46,6 +46,12 @@ def show(name, rows, labels, t0=None):
     return t0
 
 
+rows = st[:nt]
+late = np.argsort(-rows[:, 5].astype(np.int64))[:8]
+t00 = rows[rows[:, 0] > 0][:, 0].min()
+print("latest tickets (workgroup: start, reduced, ticket us):",
+      [(int(i), round((int(rows[i, 0]) - int(t00)) / 100.0, 2), round((int(rows[i, 1]) - int(t00)) / 100.0, 2),
+        round((int(rows[i, 5]) - int(t00)) / 100.0, 2)) for i in late])
 t0 = show("k_strict_classify", st[:nt], ["start", "reduced: K, s, before", "classified", "prefixes", "published", "ticket taken"])
 show("  the island's chain (last workgroup)", st[nt:nt + 1], ["start", "loads back", "tile prefixes", "sorted", "walked", "end"], t0)
 show("k_strict_search", st[nt + 8:], ["start", "record + su", "tile staged", "range known", "end", "last pass: thresholds", "last pass: bisected"])
