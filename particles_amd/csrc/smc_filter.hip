@@ -635,6 +635,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     // (history slots are written step by step: the lanes beyond N of a slot would read indices nobody
     //  initialised -- every access tests its index there as well)
     a.kform = f->two_level ? 1 : 0;
+    a.strict_e = (f->strict && f->two_level && !f->strict_literal) ? 1 : 0;
     f->ragged = (f->two_level && (o->N % F_TILE) != 0) ? (((o->N & 1) || a.hist) ? 2 : 1) : 0;
     a.ncq = (i64)a.ntiles * F_TILE;
     const size_t oCq = carve(f->two_level ? M * (size_t)a.ncq * 8 : 8);

@@ -136,6 +136,9 @@ struct FArgs {
     double *eta, *lwsv;    // APF of MVLINGAUSS (smc_filter_mv.h k_mv_aux): (n_islands, N) logeta of the step's
                            // parents and their plain log-weights, set aside while lw + eta drives the resampling
     int xcd_chunks;        // two-level step: workgroup -> tile map that keeps CONSECUTIVE tiles on one XCD (f_tile_xcd)
+    int strict_e;          // SMC_FLAG_STRICT_ANCESTORS on the two-level step: nobody reads the tile's integer CDF, so `cq` holds
+                           // every particle's weight on its TILE's scale instead, e_j = p_j 2^(k_j - K_b) (a double): what
+                           // k_strict_classify forms W_j from without evaluating an exponential again
 };
 // Workgroups go round the 8 XCDs (each with its own L2): with tile = workgroup index, neighbouring tiles sit on
 // different XCDs -- but a tile's offspring start in the tile next door as soon as the weights drift, and their parents'
@@ -1238,6 +1241,45 @@ __device__ __forceinline__ F2Tile f2_tile_weights(const double (&lw)[4], u64 (&c
     cx[3] = cx[2] + q[2];
     return r;
 }
+// The same partial WITHOUT the integer CDF (FArgs::strict_e): the tile-scale weights e_i themselves come back (their bit
+// patterns: they take the integer CDF's place in `cq`).  S, SS: the operations of f2_tile_weights in its order, hence its bits.
+__device__ __forceinline__ F2Tile f2_tile_weights_e(const double (&lw)[4], u64 (&cx)[4])
+{
+    __shared__ double s_k[SMC_NWAVE];
+    __shared__ double s_s[2 * SMC_NWAVE];
+    const int lane = smc_lane(), wave = smc_wave();
+    double p[4], k[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        p[i] = smc_expk(lw[i], k[i]);
+        p[i] = (lw[i] > -INFINITY) ? p[i] : 0.0;
+    }
+    double km = smc_max2(smc_max2(k[0], k[1]), smc_max2(k[2], k[3]));
+    km = smc_wave_max(km);
+    if (lane == 0) s_k[wave] = km;
+    __syncthreads();
+    F2Tile r;
+    r.K = s_k[0];
+#pragma unroll
+    for (int w = 1; w < SMC_NWAVE; ++w) r.K = smc_max2(r.K, s_k[w]);
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double e = smc_scale_pk(p[i], k[i], r.K);
+        s1 += e;
+        s2 = fma(e, e, s2);
+        cx[i] = (u64)__double_as_longlong(e);
+    }
+    smc_wave_sum2(s1, s2);
+    if (lane == 0) { s_s[wave] = s1; s_s[SMC_NWAVE + wave] = s2; }
+    __syncthreads();
+    r.S = s_s[0];
+    r.SS = s_s[SMC_NWAVE];
+#pragma unroll
+    for (int w = 1; w < SMC_NWAVE; ++w) { r.S = r.S + s_s[w]; r.SS = r.SS + s_s[SMC_NWAVE + w]; }
+    r.tb = 0ull;
+    return r;
+}
 // The workgroup's log-sum-exp partial (max, sum e, sum e^2) of the OPT log-weights each thread
 // holds (-inf beyond N): max first, then ONE exp per particle against the workgroup's max (no
 // per-thread rescaling, no branches).  Fixed association order: the thread's OPT values left to
@@ -1562,7 +1604,7 @@ k_propagate(const u32* __restrict__ pre_A, double* __restrict__ pre_info, const 
                 }
             }
         }
-        const F2Tile r = f2_tile_weights(lw, cx);
+        const F2Tile r = (!APF && a.strict_e) ? f2_tile_weights_e(lw, cx) : f2_tile_weights(lw, cx);
         u64* cq = a.cq + (i64)isl * (RAGGED ? a.ncq : N);          // (whole tiles: ncq == N, already in registers)
         if (a.nt & 4) { smc_st2g_nt(cq + own.na, cx[0], cx[1]); smc_st2g_nt(cq + own.nb, cx[2], cx[3]); }
         else { smc_st2g(cq + own.na, cx[0], cx[1]); smc_st2g(cq + own.nb, cx[2], cx[3]); }
@@ -3102,7 +3144,7 @@ k_f_partials(const FArgs av, const i64 ts, const int two_level)
     const i64 o = (i64)isl * a.nparts;
     if (two_level) {
         u64 cx[4];
-        const F2Tile r = f2_tile_weights(lw, cx);
+        const F2Tile r = a.strict_e ? f2_tile_weights_e(lw, cx) : f2_tile_weights(lw, cx);
         u64* cq = a.cq + (i64)isl * a.ncq;
         smc_st2g(cq + own.na, cx[0], cx[1]);
         smc_st2g(cq + own.nb, cx[2], cx[3]);

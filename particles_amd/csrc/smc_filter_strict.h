@@ -53,7 +53,12 @@ k_strict_classify(const FArgs av, const SqxArgs q)
     __shared__ double s_esc[SMC_NWAVE];
     __shared__ double s_sum[3 * SMC_NWAVE];
     __shared__ double smd[SMC_SM];
-    const int b = (int)blockIdx.x, isl = (int)blockIdx.y, tid = (int)threadIdx.x;
+    // (workgroups are dispatched in index order and the island's chain starts when the LAST of them has taken its ticket:
+    //  the two tiles that take longest -- the head of the array, a dozen exceptions, and its end, inside the margin of the
+    //  binade edge at 1.0 -- go first)
+    const int bx = (int)blockIdx.x;
+    const int b = bx == 0 ? 0 : (bx == 1 ? q.ntiles - 1 : bx - 1);
+    const int isl = (int)blockIdx.y, tid = (int)threadIdx.x;
     const int lane = smc_lane(), wave = smc_wave();
     SQX_STAMP(q, b, 0);
     double* info = a.info + (i64)isl * INFO_STRIDE;
@@ -68,14 +73,14 @@ k_strict_classify(const FArgs av, const SqxArgs q)
         f_load4<double>(a.pss + o, (i64)tid * 4, a.nparts, pvec, 0.0, pss4);
     }
     const double Kb_v = smc_ldg(a.pm + o + b);                 // this tile's own exponent: the scale of the in-tile estimate
-    // the tile's log-weights, requested with the first loads from the slot the host expects (a.tk; redone below if the
-    // record says otherwise -- inside a replayed graph)
+    // the tile's weights on the tile's own scale, e_j = p_j 2^(k_j - K_b): k_propagate left them where the default step keeps
+    // the integer CDF (FArgs::strict_e) -- no slot arithmetic (one array, rewritten every step), no exponential here
     const i64 i0 = (i64)b * SEQ_TILE + (i64)tid * 4;
-    double l4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    if (a.tk >= 1) {
-        const double* lwp = f_lw(a, a.tk - 1) + (i64)isl * a.N;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) l4[k] = (i0 + k < a.N) ? smc_ldg(lwp + i0 + k) : -INFINITY;
+    u64 eb[4];
+    {
+        const u64* ce = a.cq + (i64)isl * a.ncq + i0;          // (padded to whole tiles: in bounds; 0 beyond N)
+        smc_ld2g(ce, eb[0], eb[1]);
+        smc_ld2g(ce + 2, eb[2], eb[3]);
     }
     const i64 t = (i64)smc_uniform(r0);
     if (t >= a.T) {
@@ -84,22 +89,13 @@ k_strict_classify(const FArgs av, const SqxArgs q)
     }
     if (t == 0) return;                                        // the host wrote the record of step 0
     if (MID && smc_uniform(r1) == 0.0) return;                 // k_reduce2: step t does not resample
-    if (t != a.tk) {
-        const double* lwp = f_lw(a, t - 1) + (i64)isl * a.N;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) l4[k] = (i0 + k < a.N) ? smc_ldg(lwp + i0 + k) : -INFINITY;
-    }
-    // ---- (p, k) of the tile's weights and the in-tile prefix of their values on the TILE's scale 2^(k - K_b): nothing
-    // here needs the island's reduction, so its wave totals travel with the reduction's first exchange
     const double Kb = smc_uniform(Kb_v);
-    double p4[4], k4[4], e4[4], esum = 0.0;
+    double e4[4], esum = 0.0;
+    bool deep = false;                                         // a subnormal e: 2^-1022 and more below the tile's maximum
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        p4[k] = smc_expk(l4[k], k4[k]);
-        const bool ok = l4[k] > -INFINITY;
-        p4[k] = ok ? p4[k] : 0.0;
-        k4[k] = ok ? k4[k] : -INFINITY;
-        e4[k] = a.kform ? smc_scale_pk(p4[k], k4[k], Kb) : 0.0;
+        e4[k] = (i0 + k < a.N) ? __longlong_as_double((long long)eb[k]) : 0.0;
+        deep = deep || (e4[k] != 0.0 && e4[k] < 0x1.0p-1022);
         esum += e4[k];
     }
     const double einc = smc_wave_scan_add_f64(esum);
@@ -159,17 +155,23 @@ k_strict_classify(const FArgs av, const SqxArgs q)
         rs = r.rs;
         before = before * rs;
     }
-    // the weights themselves (the values smc_filter_get(SMC_FIELD_W) returns), and the estimate in front of this
-    // thread's first one: the tiles before + the in-tile prefix put on the island's scale
+    // the weights themselves (the values smc_filter_get(SMC_FIELD_W) returns): p 2^(k - K) / s = e 2^(K_b - K) / s -- the
+    // second scaling is exact (or rounds the same exact value once) as long as e is a normal number; a subnormal e has
+    // already lost bits, and such a particle goes back to its log-weight (never in practice: 700 nats below its tile's best)
     const SqxSrcFilter src{f_lw(a, t - 1) + (i64)isl * a.N, K, rs, a.kform, a.N};
+    double dsc = Kb - K;                                       // (<= 0: K is the maximum of the tiles' exponents)
+    dsc = (dsc > -2000.0) ? dsc : -2000.0;
     double w4[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) w4[k] = (i0 + k < a.N) ? (a.kform ? smc_scale_pk(p4[k], k4[k], K) * rs : src.weight(l4[k])) : 0.0;
+    for (int k = 0; k < 4; ++k) w4[k] = ldexp(e4[k], (int)dsc) * rs;
+    if (deep) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (e4[k] != 0.0 && e4[k] < 0x1.0p-1022) w4[k] = src.weight(src.lw[i0 + k]);
+    }
     double ebase = 0.0;
 #pragma unroll
     for (int w = 0; w < SMC_NWAVE; ++w) ebase += (w < wave) ? s_esc[w] : 0.0;
-    double dsc = Kb - K;                                       // (<= 0: K is the maximum of the tiles' exponents)
-    dsc = (dsc > -2000.0) ? dsc : -2000.0;
     const double run0 = before + ldexp(ebase + einc - esum, (int)dsc) * rs;
     SQX_STAMP(q, b, 1);
     if (sqx_classify_tile(w4, run0, isl, b, q)) sqx_chain(src, isl, q);

@@ -254,26 +254,43 @@ __device__ __forceinline__ bool sqx_classify_tile(const double (&w)[4], const do
     }
     SQX_STAMP(q, b, 3);
     const bool tile_over = xtot > (u32)SQX_TCAP;
-    // the segments' intervals: slot = exceptions in front of the element (an exception's own slot is neutral)
+    // (the tile's slots in the island's exception list: a global atomic with a return value -- issued here, consumed
+    //  after the segments' intervals are formed, so that its round trip overlaps them)
+    u32 base_t0 = 0u;
+    if (tid == 0 && xtot) base_t0 = (u32)atomicAdd(reinterpret_cast<unsigned long long*>(q.ctr + (i64)isl * 4), (unsigned long long)xtot);
+    // the segments' intervals: slot = exceptions in front of the element (an exception's own slot is neutral).
+    // A wave without an exception (nearly all of them) holds ONE segment: its 64 lanes' bounds are reduced on the DPP
+    // path and one lane updates the slot -- 256 same-address LDS atomics per tile cost 1 us of the tile's 8.
     if (!tile_over) {
-        u32 cl = aLo[0], ch = aHi[0], cs = seg[0] + (exc[0] ? 1u : 0u);
-        // (an exception closes its segment: what follows it accumulates in slot seg + 1)
+        const bool wave_plain = __ballot(nx != 0u ? 1 : 0) == 0ull;
+        if (wave_plain) {
+            u32 cl = aLo[0], ch = aHi[0];
 #pragma unroll
-        for (int k = 1; k < 4; ++k) {
-            const u32 sk = seg[k] + (exc[k] ? 1u : 0u);
-            if (sk != cs) {
-                if (cl != 0u || ch != 2047u) { atomicMax(&s_lo[cs], cl); atomicMin(&s_hi[cs], ch); }
-                cl = aLo[k]; ch = aHi[k]; cs = sk;
-            } else {
+            for (int k = 1; k < 4; ++k) {
                 cl = cl > aLo[k] ? cl : aLo[k];
                 ch = ch < aHi[k] ? ch : aHi[k];
             }
+            const u32 wl = smc_wave_scan_max_u32(cl), wh = smc_wave_scan_max_u32(2047u - ch);
+            if (lane == 63 && (wl != 0u || wh != 0u)) { atomicMax(&s_lo[seg[0]], wl); atomicMin(&s_hi[seg[0]], 2047u - wh); }
+        } else {
+            u32 cl = aLo[0], ch = aHi[0], cs = seg[0] + (exc[0] ? 1u : 0u);
+            // (an exception closes its segment: what follows it accumulates in slot seg + 1)
+#pragma unroll
+            for (int k = 1; k < 4; ++k) {
+                const u32 sk = seg[k] + (exc[k] ? 1u : 0u);
+                if (sk != cs) {
+                    if (cl != 0u || ch != 2047u) { atomicMax(&s_lo[cs], cl); atomicMin(&s_hi[cs], ch); }
+                    cl = aLo[k]; ch = aHi[k]; cs = sk;
+                } else {
+                    cl = cl > aLo[k] ? cl : aLo[k];
+                    ch = ch < aHi[k] ? ch : aHi[k];
+                }
+            }
+            if (cl != 0u || ch != 2047u) { atomicMax(&s_lo[cs], cl); atomicMin(&s_hi[cs], ch); }
         }
-        if (cl != 0u || ch != 2047u) { atomicMax(&s_lo[cs], cl); atomicMin(&s_hi[cs], ch); }
     }
     if (tid == 0) {
-        u32 base = 0u;
-        if (xtot) base = (u32)atomicAdd(reinterpret_cast<unsigned long long*>(q.ctr + (i64)isl * 4), (unsigned long long)xtot);
+        const u32 base = base_t0;
         s_base = base;
         if (tile_over || base + xtot > (u32)SQX_CAP) smc_st_agent(q.ctr + (i64)isl * 4 + 1, 1ull);
         smc_st_agent(q.Rt + (i64)isl * q.ntiles + b, rtot);
@@ -698,12 +715,104 @@ __device__ __forceinline__ void sqx_first_ge_lds8(const double* S, const int m, 
         out[k] = lo[k] < m ? lo[k] : m - 1;
     }
 }
+// ---- systematic draws, N < 2^30: the offspring of a tile WITHOUT a search.  su_n = fl(fl(u + n) / N) is monotone in
+// n, so parent j owns the offspring n_{j-1} <= n < n_j with n_j = #{ n : su_n <= S_j } -- a count with a closed-form
+// guess, fixed with the definition itself (two evaluations: four instructions each) -- and the tile's ancestors are
+// one scatter of the parents' indices at their first offspring plus a running maximum over a window of offspring
+// (k_ancestors2's shape): ~140 vector instructions per thread where eight bisections of ten rounds took ~480.
+// Branch-free: with r = S N - u the count is floor(r) + 1 up to ONE unit either way -- r and the definition's two
+// roundings are each within N 2^-51 <= 2^-21 of their exact values for N < 2^30 -- so two evaluations of the definition,
+// at g - 1 and at g, decide among g - 1, g and g + 1.
+__device__ __forceinline__ int sqx_sys_count(const SmcSu& su, const int N, const double S)
+{
+    const double r = S * su.dM - su.u_sys;
+    int g = r < 0.0 ? 0 : (r >= su.dM ? N : (int)r + 1);       // (S = -inf, NaN: 0)
+    g = g > N ? N : g;
+    const bool le0 = g < 1 || smc_su_div(su, su.u_sys + (double)(g - 1)) <= S;
+    const bool le1 = g < N && smc_su_div(su, su.u_sys + (double)g) <= S;
+    const int c = g - 1 + (le0 ? 1 : 0) + (le1 ? 1 : 0);
+    return S >= 0.0 ? c : 0;
+}
+template <class AT>
+__device__ __forceinline__ void sqx_scatter_tile(const SqxArgs& q, const int b, const SmcSu& su, const double* sS, const double S_start, AT* A)
+{
+    constexpr int WIN = 8 * SMC_BLOCK;
+    __shared__ __attribute__((aligned(16))) u32 sP[WIN];
+    __shared__ u32 s_wm[SMC_NWAVE];
+    __shared__ u32 s_carry;
+    const int tid = (int)threadIdx.x, lane = smc_lane(), wave = smc_wave();
+    const i64 j0 = (i64)b * SEQ_TILE;
+    const int m_all = (int)(j0 + SEQ_TILE < q.n ? SEQ_TILE : q.n - j0);
+    const int N = (int)su.M;
+    const bool last = b == q.ntiles - 1;
+    // n_j of this thread's four parents and of the one in front of them
+    int nj[5];
+    {
+        const int l0 = tid * 4;
+        const double Sp = l0 == 0 ? S_start : sS[l0 - 1];
+        nj[0] = (b == 0 && l0 == 0) ? 0 : sqx_sys_count(su, N, Sp);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int l = l0 + k;
+            nj[k + 1] = (last && l >= m_all - 1) ? N : sqx_sys_count(su, N, sS[l < m_all ? l : m_all - 1]);
+        }
+    }
+    // the tile's range: the first thread's nj[0], the last thread's nj[4]
+    if (tid == 0) sP[0] = (u32)nj[0];
+    if (tid == SMC_BLOCK - 1) sP[1] = (u32)nj[4];
+    __syncthreads();
+    const int n_lo = (int)sP[0], n_hi = (int)sP[1];
+    __syncthreads();
+    SQX_STAMP(q, q.ntiles + 8 + b, 3);
+    for (int base = n_lo; base < n_hi; base += WIN) {
+        *reinterpret_cast<uint4*>(&sP[tid * 8]) = make_uint4(0u, 0u, 0u, 0u);
+        *reinterpret_cast<uint4*>(&sP[tid * 8 + 4]) = make_uint4(0u, 0u, 0u, 0u);
+        if (tid == 0) s_carry = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (nj[k + 1] <= nj[k]) continue;                      // no offspring
+            const int first = nj[k] - base;
+            if (first >= 0 && first < WIN) sP[first] = (u32)(tid * 4 + k + 1);
+            else if (first < 0 && nj[k + 1] > base) s_carry = (u32)(tid * 4 + k + 1);   // the parent that straddles the window's start
+        }
+        __syncthreads();
+        u32 v[8];
+        {
+            const uint4 a4 = *reinterpret_cast<const uint4*>(&sP[tid * 8]), b4 = *reinterpret_cast<const uint4*>(&sP[tid * 8 + 4]);
+            v[0] = a4.x; v[1] = a4.y; v[2] = a4.z; v[3] = a4.w; v[4] = b4.x; v[5] = b4.y; v[6] = b4.z; v[7] = b4.w;
+        }
+#pragma unroll
+        for (int i = 1; i < 8; ++i) v[i] = v[i] > v[i - 1] ? v[i] : v[i - 1];
+        const u32 inc = smc_wave_scan_max_u32(v[7]);
+        u32 ex = smc_mov_dpp<SMC_DPP_WAVE_SHR1>(inc);
+        if (lane == 0) ex = 0u;
+        if (lane == 63) s_wm[wave] = inc;
+        __syncthreads();
+        u32 pre = s_carry;
+        for (int w = 0; w < wave; ++w) pre = pre > s_wm[w] ? pre : s_wm[w];
+        pre = pre > ex ? pre : ex;
+        const int lim = n_hi - base;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const u32 m = v[i] > pre ? v[i] : pre;
+            if (tid * 8 + i < lim) A[(i64)base + tid * 8 + i] = (AT)(j0 + (i64)m - 1);
+        }
+        __syncthreads();
+    }
+    SQX_STAMP(q, q.ntiles + 8 + b, 4);
+}
+
 // the offspring of tile b: n with S_start < su_n <= S_end (the last tile takes every offspring left: the reference
 // would run off the end of W there), each written with its ancestor.  AT: u32 (the filter) or i64 (the operator).
 // sS: the tile's sums, staged (sqx_stage_tile).
 template <class AT>
 __device__ __forceinline__ void sqx_search_tile(const SqxArgs& q, const int b, const SmcSu& su, const double* sS, const double S_start, AT* A)
 {
+    if (su.scheme == SMC_SYSTEMATIC_ && su.M < ((i64)1 << 30) && q.n < ((i64)1 << 30)) {
+        sqx_scatter_tile<AT>(q, b, su, sS, S_start, A);            // (uniform branch: no search at all)
+        return;
+    }
     __shared__ i64 s_n[2];
     const int tid = (int)threadIdx.x;
     const i64 j0 = (i64)b * SEQ_TILE;

@@ -969,7 +969,9 @@ def check_strict_ancestors(sizes=(3000, 4096), op_N=1 << 14, op_cases=12, scheme
     # (2)
     yr = np.random.RandomState(2)
     y = [np.array([v]) for v in 0.4 * np.cumsum(yr.standard_normal(T))]
-    mk_model = {"toy": lambda: kalman.ToySSM(0.2), "sv": lambda: ssm.StochVol()}[model]
+    # ("peaky" / "collapsed": a few parents -- one parent -- own most offspring: the scatter search's multi-window passes)
+    mk_model = {"toy": lambda: kalman.ToySSM(0.2), "sv": lambda: ssm.StochVol(), "peaky": lambda: kalman.ToySSM(2e-3),
+                "collapsed": lambda: kalman.ToySSM(1e-6)}[model]
     for N in ((700,) if small else ()) + tuple(sizes):
         for scheme in schemes:
             for replay in replays:

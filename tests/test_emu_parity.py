@@ -292,6 +292,14 @@ def test_strict_ancestors_more_tiles_and_models():
                               T=4, ESSrmin=1.0)
 
 
+def test_strict_ancestors_heavy_parents():
+    """Strict step when a few parents (one parent) own most of the offspring: the systematic scatter search runs several
+    windows per tile and carries the straddling parent across them."""
+    for model in ("peaky", "collapsed"):
+        pc.check_strict_ancestors(sizes=(9000, 8192), op_cases=0, schemes=("systematic", "stratified"), model=model, small=False,
+                                  T=5, ESSrmin=1.0, replays=(False,))
+
+
 def test_pickle_resume_of_device_filters():
     pc.check_pickle_resume()
 

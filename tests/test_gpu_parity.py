@@ -524,6 +524,12 @@ def test_strict_ancestors_equal_the_reference_cdf():
     pc.check_strict_ancestors(sizes=(3000, 1 << 17, (1 << 18) + 333), op_N=1 << 20, op_cases=100)
 
 
+def test_strict_ancestors_heavy_parents():
+    for model in ("peaky", "collapsed"):
+        pc.check_strict_ancestors(sizes=(9000, 1 << 18), op_cases=0, schemes=("systematic", "stratified", "multinomial"), model=model,
+                                  small=False, T=5, ESSrmin=1.0)
+
+
 def test_pickle_resume_of_device_filters():
     pc.check_pickle_resume(sizes=(700, 3000, 1 << 18))
 
