@@ -100,17 +100,18 @@ int smc_inverse_cdf(smc_ctx* ctx, const double* su, const double* W, int64_t M,
 /* The same with the reference's own CDF, literally: S_j accumulated left to right in fp64
  * (resampling.py:500-509: s += W[j]), A[n] = first j with su[n] <= S_j.  Given identical (su, W)
  * the ancestors ARE the reference's, bit for bit.  The N dependent roundings are reproduced in
- * parallel (csrc/smc_seqsum.h: inside a binade the chain is an integer sum; the dozen or two tiles
- * where it crosses a binade, or meets an exact tie, are added element by element): tens of
- * microseconds at N = 2^20 where the literal one-lane walk takes 2.5 ms. */
+ * parallel (csrc/smc_seqx.h: inside a binade the chain is an integer prefix sum; the few dozen elements
+ * where it crosses a binade, or meets an exact tie, are walked exactly; every assumption is verified
+ * before an ancestor is written, the CDF itself is never stored): tens of microseconds at N = 2^20
+ * where the literal one-lane walk takes 43 ms.  W >= 0, N < 2^32. */
 int smc_inverse_cdf_strict(smc_ctx* ctx, const double* su, const double* W, int64_t M,
                            int64_t N, int64_t* A);
 
 /* S[j] = W[0] + W[1] + ... + W[j] rounded after every addition, as the reference's loop forms them
- * (resampling.py:500-509).  mode 0: the parallel emulation smc_inverse_cdf_strict uses (element-level pass, the
- * tile walk behind it where it gives up); mode 2: the tile walk alone; mode 1: the literal one-lane walk.  All agree
- * bit for bit for any W >= 0 (tests compare them).  n_sequential_tiles (may be null): mode 2 -- tiles of 1024 the walk
- * did exactly; mode 0 -- 0, or -1 if the element-level pass fell back to the tile walk; mode 1 -- all tiles. */
+ * (resampling.py:500-509).  mode 0: the two-launch emulation smc_inverse_cdf_strict and the filter's strict mode use
+ * (csrc/smc_seqx.h), written out; mode 2: the tile walk (csrc/smc_seqsum.h); mode 1: the literal one-lane walk.  All
+ * agree bit for bit for any W >= 0 (tests compare them).  n_sequential_tiles (may be null): mode 0 -- the exceptions
+ * the emulation walked, or -1 if it took its exact path; mode 2 -- tiles of 1024 the walk did exactly; mode 1 -- all. */
 int smc_seq_prefix_sums(smc_ctx* ctx, const double* W, int64_t N, double* S, int mode, int64_t* n_sequential_tiles);
 
 /* ---- a-6: rs.resampling(scheme, W, M) (resampling.py:477-481) -------------
@@ -372,6 +373,8 @@ typedef struct smc_filter_opts {
 #define SMC_PATH_STRICT_LITERAL   (1 << 6)   /* SMC_FLAG_STRICT_ANCESTORS: the sequential CDF by the literal one-lane walk, not its parallel emulation */
 #define SMC_PATH_WIDE4            (1 << 7)   /* k_ancestors2w with 4 tiles per workgroup instead of 2 */
 #define SMC_PATH_SQ_GATHER        (1 << 29)  /* SMC_FLAG_SQMC: gather the sorted log-weights where they could be recomputed */
+#define SMC_PATH_SP_SIDE          (1 << 3)   /* multinomial: the NEXT step's spacings drawn on a side stream beside k_propagate (A/B: measured slower) */
+#define SMC_PATH_NO_SP_SIDE       (1 << 4)   /* ... never (the default) */
 #define SMC_PATH_SP_TPW(n)        (((n) & 15) << 25)   /* one-pass spacings: n = 1, 2, 4, 8 tiles of draws per workgroup */
 #define SMC_PATH_MV_CHUNKS(n)    (((n) & 15) << 20)   /* k_propagate_mv: n = 1, 2, 4, 8 chunks per workgroup */
 

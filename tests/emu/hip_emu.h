@@ -364,6 +364,7 @@ inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return 0; }
 inline hipError_t hipEventDestroy(hipEvent_t) { return 0; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return 0; }
 inline hipError_t hipStreamBeginCapture(hipStream_t, int) { return 1; }  // graphs: unsupported

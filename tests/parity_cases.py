@@ -2860,3 +2860,40 @@ def check_pickle_resume(sizes=(700, 3000)):
     blob = np.empty(nb.value, dtype=np.uint8)
     _lib.check(_lib.lib().smc_filter_save_state(a._f, blob.ctypes.data_as(ctypes.c_void_p), nb.value))
     assert _lib.lib().smc_filter_load_state(b._f, blob.ctypes.data_as(ctypes.c_void_p), nb.value) != 0
+
+
+def check_spacings_side_stream(monkeypatch, sizes=(3000, 8192), T=9):
+    """Multinomial resampling with the NEXT step's uniform_spacings drawn ahead on the filter's side stream
+    (smc_filter::sp_side, SMC_SP_SIDE=1: built as round 4's verdict proposed, measured slower at C3 and therefore off by
+    default) is the same run as with the spacings drawn inside the step, bit for bit: every step resampling or only some (spacings drawn
+    ahead and not used), islands, a deep copy and a pickle taken mid-run, a filter stepped in pieces."""
+    import copy
+    import pickle
+    yr = np.random.RandomState(2)
+    y = [np.array([v]) for v in 0.4 * np.cumsum(yr.standard_normal(T))]
+    for N in sizes:
+        for essr, nisl in ((1.0, 1), (0.5, 2)):
+            runs = {}
+            for name, env in (("side", "SMC_SP_SIDE"), ("inline", "SMC_NO_SP_SIDE")):
+                monkeypatch.setenv(env, "1")
+                pf = pa.SMC(fk=ssm.Bootstrap(ssm=ssm.StochVol(), data=y), N=N, resampling="multinomial", ESSrmin=essr, seed=4,
+                            n_islands=nisl, store_history=True)
+                pf.step_async(3)
+                c = copy.deepcopy(pf)
+                z = pickle.loads(pickle.dumps(pf))
+                outs = []
+                for r in (pf, z):
+                    r.step_async(2)
+                    r.run()
+                    outs.append((np.array(r.X), np.array(r.A), r.logLts_islands.copy(), r._summ().copy(),
+                                 [r._history(_lib.FIELD_A, t, nisl - 1) for t in range(1, T)]))
+                c.run()                                    # (re-keyed by deepcopy: a different run, but a run)
+                assert c.t == T and np.all(np.isfinite(c.logLts_islands))
+                runs[name] = outs
+                monkeypatch.undo()
+            a, b = runs["side"][0], runs["inline"][0]
+            for u, v in zip(a, b):
+                assert all(np.array_equal(p, q) for p, q in zip(u, v)) if isinstance(u, list) else np.array_equal(u, v), (N, essr)
+            for u, v in zip(runs["side"][0], runs["side"][1]):             # the pickled copy: the same run
+                assert all(np.array_equal(p, q) for p, q in zip(u, v)) if isinstance(u, list) else np.array_equal(u, v), (N, essr)
+            assert (a[3][0, :, 4].mean() == 1.0 - 1.0 / T) == (essr == 1.0)

@@ -300,6 +300,10 @@ def test_strict_ancestors_heavy_parents():
                                   T=5, ESSrmin=1.0, replays=(False,))
 
 
+def test_multinomial_spacings_on_the_side_stream(monkeypatch):
+    pc.check_spacings_side_stream(monkeypatch)
+
+
 def test_pickle_resume_of_device_filters():
     pc.check_pickle_resume()
 

@@ -530,6 +530,10 @@ def test_strict_ancestors_heavy_parents():
                                   small=False, T=5, ESSrmin=1.0)
 
 
+def test_multinomial_spacings_on_the_side_stream(monkeypatch):
+    pc.check_spacings_side_stream(monkeypatch, sizes=(3000, 1 << 18, 1 << 21))
+
+
 def test_pickle_resume_of_device_filters():
     pc.check_pickle_resume(sizes=(700, 3000, 1 << 18))
 
