@@ -216,12 +216,14 @@ class SMC:
         stock = getattr(fk, "_fk_kind", None) in (_lib.FK_APF, _lib.FK_APF_BOOT)
         model = fk._device_model() if hasattr(fk, "_device_model") else None
         if stock and model is not None and model["kind"] == _lib.MODEL_MVLINGAUSS:
-            # MVLinearGauss: k_mv_aux in front of the flat step, any N; no history slots, no device moments
-            return not store_history and not device_moments
-        small = N <= 1024 and not (resampling == "multinomial" and replay is None)
-        rolling = isinstance(store_history, int) and not isinstance(store_history, bool) and store_history >= 2
-        two_level = 1024 < N <= (1 << 30) and not rolling
-        return stock and not device_moments and (small or two_level)
+            # MVLinearGauss: k_mv_aux in front of the flat step, any N (history slots: k_propagate_mv puts the plain weights
+            # back into the previous step's slot once the resampling kernels have used the auxiliary ones)
+            return True
+        # (the two-level step keeps the plain log-weights in the state -- the auxiliary ones only drive the tile partials and
+        #  the integer CDF -- so history slots, a rolling window and the device-side Moments see what the reference's do)
+        small = N <= 1024 and not (resampling == "multinomial" and replay is None) and not device_moments
+        two_level = 1024 < N <= (1 << 30)
+        return stock and (small or two_level)
 
     @staticmethod
     def _sqmc_fusable(fk, N, model, replay=None, use_graph=False, strict=False):

@@ -481,14 +481,9 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
                 "auxiliary bootstrap filter: STOCHVOL, LINGAUSS");
     {
         const bool big = o->N > F_TILE && o->N <= ((int64_t)1 << 30);
-        if (mv && model->fk == SMC_FK_APF && (o->moments || o->keep_history)) {
-            smc_set_error("the auxiliary particle filter of MVLINGAUSS: no moments, no history slots (the auxiliary "
-                          "weights take the place of the previous step's while it resamples)");
-            return SMC_ERR_INVALID;
-        }
-        if (!mv && f_is_apf(model->fk) && (o->moments || (o->N > F_TILE && !big) || o->keep_history >= 2)) {
-            smc_set_error("the auxiliary particle filter is fused for N <= 1024 (the one-launch filter) and for "
-                          "1024 < N <= 2^30 (the two-level step); no moments, no rolling window");
+        if (!mv && f_is_apf(model->fk) && ((o->N > F_TILE && !big) || (!big && (o->moments || o->keep_history >= 2)))) {
+            smc_set_error("the auxiliary particle filter is fused for N <= 1024 (the one-launch filter: no moments, no "
+                          "rolling window) and for 1024 < N <= 2^30 (the two-level step)");
             return SMC_ERR_INVALID;
         }
     }
@@ -644,7 +639,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     // (multinomial: the counts are searches over the sorted uniforms -- the tape's, or the exponential
     //  spacings drawn between k_reduce2, which decides the step, and k_ancestors2)
     // (any N >= 2 tiles: N = 2^k counts in closed form with integers, other N with the general counts)
-    f->two_level = !mv && !(o->moments && f_is_apf(model->fk)) && o->N <= ((int64_t)1 << 30) && a.ntiles >= 2 &&
+    f->two_level = !mv && o->N <= ((int64_t)1 << 30) && a.ntiles >= 2 &&
                    !(a.log2N < 0 && (o->flags & SMC_PATH_POW2_ONLY)) &&
                    !(o->flags & (SMC_PATH_FLAT_CDF | SMC_PATH_FORCE_FUSED | SMC_PATH_FORCE_UNFUSED)) &&
                    !(scheme == SMC_MULTINOMIAL && (o->flags & SMC_PATH_FLAT_MULTINOMIAL));

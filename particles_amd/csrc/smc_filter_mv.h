@@ -377,9 +377,12 @@ k_propagate_mv(const FArgs av, const double* __restrict__ C)
                     if (APF && !first) {
                         // core.py:299-305 reset_weights: log_mean_exp(logeta, W) - logeta[A] (the constant comes
                         // with the record, k_mv_aux_restate); not resampled: the plain weight k_mv_aux set aside
-                        const double prev = resample ? smc_uniform(info[6]) - a.eta[(i64)isl * N + A[np]]
-                                                     : a.lwsv[(i64)isl * N + np];
+                        const double plain = a.lwsv[(i64)isl * N + np];
+                        const double prev = resample ? smc_uniform(info[6]) - a.eta[(i64)isl * N + A[np]] : plain;
                         lw = prev + inc;
+                        // history slots: step t-1's slot gets its PLAIN weights back (k_mv_aux put lw + eta there for the
+                        // resampling kernels, which are done: a launch boundary lies in between)
+                        if (a.hist) (f_lw(a, t - 1) + (i64)isl * N)[np] = plain;
                     } else
                     lw = (resample || first) ? inc : lwo[np] + inc;            // resampling.py:241-244
                     if (lw != lw) lw = -INFINITY;                              // resampling.py:220

@@ -1981,8 +1981,23 @@ def check_apf_fused(golden, apf2_cases=((2048, "systematic", 0.7), (4096, "strat
         lls.append(pf.logLt)
     assert abs(np.mean(lls) - float(g["logLt"])) < 0.15, lls
     from particles_amd.collectors import Moments
-    big = pa.SMC(fk=ssm.AuxiliaryPF(ssm=ssm.StochVol(), data=y), N=3000, collect=[Moments()])
-    assert not big._fused                      # device-side moments with the APF: the operator path
+    small = pa.SMC(fk=ssm.AuxiliaryPF(ssm=ssm.StochVol(), data=y), N=800, collect=[Moments()])
+    assert not small._fused                    # device-side moments with the one-launch APF: the operator path
+    # N > 1024: the fused APF with the device-side Moments collector, whole history and a rolling window (VERDICT r4
+    # missing 2: core.py:299-313 + smoothing.py:181-255) -- the moments are wmean_and_var of the stored (plain) weights
+    for scheme in ("systematic", "multinomial"):
+        big = pa.SMC(fk=ssm.AuxiliaryPF(ssm=ssm.StochVol(), data=y[:12]), N=3000, collect=[Moments()], store_history=True,
+                     resampling=scheme, seed=9)
+        assert big._fused and "k_f_moments" in describe(big), describe(big)
+        big.run()
+        for t in (0, 5, 11):
+            mv = rs.wmean_and_var(big.hist.wgts[t].W, big.hist.X[t])
+            assert abs(big.summaries.moments[t]["mean"] - mv["mean"]) < 1e-12 and abs(big.summaries.moments[t]["var"] - mv["var"]) < 1e-11
+        roll = pa.SMC(fk=ssm.AuxiliaryPF(ssm=ssm.StochVol(), data=y[:12]), N=3000, store_history=3, resampling=scheme, seed=9)
+        assert roll._fused
+        roll.run()
+        assert roll.logLt == big.logLt and np.array_equal(np.array(roll.hist.X[-1]), np.array(big.hist.X[11]))
+        assert np.array_equal(np.array(roll.hist.A[-2]), np.array(big.hist.A[10]))
     # ---- N >= 2048: the APF on the two-level step.  k_propagate leaves TWO tile partials (plain
     # weights: evidence, logged ESS, W; auxiliary weights lw + logeta: decision, shares, integer CDF),
     # k_reduce2 reduces both and sends the reset constant with the record.  Against the oracle run on
@@ -2149,9 +2164,11 @@ def check_apf_mv(golden, big=((3000, 8, "systematic", 0.7), (1 << 13, 32, "strat
     assert o["final_logLt"] == float(g["logLt"])                        # the oracle IS the reference run
     z, u = tapes_from_oracle(rec.tape, len(y), N, scheme)
     mk_d = lambda dx=4: kalman.MVLinearGauss_Guarniero_etal(alpha=0.4, dx=dx)
+    z0, u0 = z, u
     pf = pa.SMC(fk=ssm.AuxiliaryPF(ssm=mk_d(), data=y), N=N, resampling=scheme, ESSrmin=ESSrmin, replay=(z, u))
     assert pf._fused and describe(pf).startswith("k_mv_aux+k_mv_aux_restate+"), describe(pf)
     pf.run()
+    pf0_logLt, pf0_X = pf.logLt, np.array(pf.X)
     assert pf.summaries.rs_flags == [bool(v) for v in g["rs_flags"]] and any(pf.summaries.rs_flags)
     assert not all(pf.summaries.rs_flags[1:])                           # both branches of the weight reset
     assert rel(pf.summaries.ESSs, g["ESSs"]) < 1e-9 and rel(pf.summaries.logLts, g["logLts"]) < 1e-9
@@ -2181,8 +2198,32 @@ def check_apf_mv(golden, big=((3000, 8, "systematic", 0.7), (1 << 13, 32, "strat
     pf.run()
     lls = pf.logLts_islands
     assert abs(np.mean(lls) - ll) < 0.15 and np.std(lls) < 0.3, (lls, ll)
-    # history slots and device moments: the operator path
-    assert not pa.SMC(fk=ssm.AuxiliaryPF(ssm=mk_d(), data=y), N=500, store_history=True)._fused
+    # history slots, a rolling window and device moments in the fused loop (VERDICT r4 missing 2): the SAME run as without
+    # them (replayed draws: the fixture's own), the stored weights are the PLAIN ones (k_propagate_mv puts them back into
+    # the slot k_mv_aux wrote the auxiliary weights to), the moments are wmean_and_var of the stored history
+    from particles_amd.collectors import Moments
+    base = pa.SMC(fk=ssm.AuxiliaryPF(ssm=mk_d(), data=y), N=N, resampling=scheme, ESSrmin=ESSrmin, replay=(z0, u0), store_history=True)
+    assert base._fused and "k_mv_aux" in describe(base)
+    base.run()
+    assert base.logLt == pf0_logLt and np.array_equal(np.array(base.X), pf0_X)
+    hist = pa.SMC(fk=ssm.AuxiliaryPF(ssm=mk_d(), data=y), N=N, resampling=scheme, ESSrmin=ESSrmin, replay=(z0, u0),
+                  store_history=True, collect=[Moments()])
+    assert hist._fused and "k_f_moments" in describe(hist)
+    hist.run()
+    assert hist.logLt == pf0_logLt
+    for t in (0, 3, len(y) - 2, len(y) - 1):
+        Wt, Xt = hist.hist.wgts[t].W, hist.hist.X[t]
+        assert abs(Wt.sum() - 1.0) < 1e-12
+        mvt = rs.wmean_and_var(Wt, Xt)
+        assert np.allclose(hist.summaries.moments[t]["mean"], mvt["mean"], rtol=1e-11, atol=1e-12)
+        assert np.allclose(hist.summaries.moments[t]["var"], mvt["var"], rtol=1e-10, atol=1e-11)
+        # the stored log-weights are the plain ones: their ESS is the logged ESS of that step
+        assert abs(1.0 / np.sum(Wt ** 2) / hist.summaries.ESSs[t] - 1.0) < 1e-9
+    roll = pa.SMC(fk=ssm.AuxiliaryPF(ssm=mk_d(), data=y), N=N, resampling=scheme, ESSrmin=ESSrmin, replay=(z0, u0), store_history=2)
+    assert roll._fused
+    roll.run()
+    assert roll.logLt == pf0_logLt and np.array_equal(np.array(roll.hist.X[-1]), np.array(hist.hist.X[len(y) - 1]))
+    assert np.allclose(roll.hist.wgts[-2].lw, hist.hist.wgts[len(y) - 2].lw, rtol=0, atol=0)
 
 
 def check_resident_user_model(golden):
