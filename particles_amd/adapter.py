@@ -35,6 +35,9 @@ _SSM_TABLE = {
     "Gordon_etal": (ssm.Gordon_etal, ("a", "b", "c", "d", "e", "sigmaX")),
     "ThetaLogistic": (ssm.ThetaLogistic, ("tau0", "tau1", "tau2", "sigmaX", "sigmaY")),
     "DiscreteCox": (ssm.DiscreteCox, ("mu", "sigma", "phi")),
+    # (no fused descriptor: the template-method step on device operators)
+    "BearingsOnly": (ssm.BearingsOnly, ("sigmaX", "sigmaY", "x0")),
+    "MVStochVol": (ssm.MVStochVol, ("mu", "covX", "corY", "F")),
 }
 _FK_TABLE = {"Bootstrap": ssm.Bootstrap, "GuidedPF": ssm.GuidedPF,
              "AuxiliaryPF": ssm.AuxiliaryPF, "AuxiliaryBootstrap": ssm.AuxiliaryBootstrap}

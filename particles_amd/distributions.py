@@ -135,6 +135,29 @@ class Poisson(ProbDist):
         return out if (d0 or d1 or _lib.RESIDENT[0]) else out.get()
 
 
+class Dirac(ProbDist):
+    """Dirac mass (distributions.py:454-472): the deterministic components of a product law (BearingsOnly's
+    velocities).  Host arrays in, host arrays out -- there is nothing to compute."""
+
+    def __init__(self, loc=0.0):
+        self.loc = loc
+
+    def rvs(self, size=None):
+        if isinstance(self.loc, np.ndarray):
+            return self.loc.copy()
+        if isinstance(self.loc, DeviceArray):
+            return self.loc.get()
+        return np.full(1 if size is None else size, self.loc)
+
+    def logpdf(self, x):
+        loc = self.loc.get() if isinstance(self.loc, DeviceArray) else self.loc
+        xx = x.get() if isinstance(x, DeviceArray) else x
+        return np.where(xx == loc, 0.0, -np.inf)
+
+    def ppf(self, u):
+        return self.rvs(size=u.shape[0])
+
+
 class IndepProd(ProbDist):
     """Product of independent univariate distributions (distributions.py:1066-1106): inputs and
     outputs of shape (N, d) -- numpy arrays, or device arrays (``set_resident``), whose columns
@@ -172,8 +195,10 @@ class MvNormal(ProbDist):
         except nla.LinAlgError:
             raise ValueError(err_msg)
         assert self.cov.shape == (self.dim, self.dim), err_msg
-        if np.ndim(scale) != 0:
-            raise NotImplementedError("MvNormal: only a scalar scale is supported on the device")
+        # a per-particle / per-component scale (distributions.py:925-929; MVStochVol's observation law): the kernels take a
+        # scalar, so the array form standardises on the host side of the operator -- (x - loc) / scale through the unit-scale
+        # law, minus sum(log scale) -- the reference's own lines :949-959 regrouped
+        self._array_scale = np.ndim(scale) != 0
 
     @property
     def dim(self):
@@ -190,8 +215,18 @@ class MvNormal(ProbDist):
             raise ValueError("MvNormal: loc has %d rows, expected 1 or %d" % (a.shape[0], N))
         return DeviceArray.from_numpy(a), a.shape[0], False
 
+    def _unit(self):
+        return MvNormal(loc=np.zeros(self.dim), scale=1.0, cov=self.cov)
+
     def rvs(self, size=None, z=None):
         """loc + scale * (Z @ L.T), Z ~ N(0, I)  (:946-947, :961-969)."""
+        if self._array_scale:
+            sc = np.asarray(self.scale.get() if isinstance(self.scale, DeviceArray) else self.scale, dtype=np.float64)
+            lo = np.asarray(self.loc.get() if isinstance(self.loc, DeviceArray) else self.loc, dtype=np.float64)
+            N = int(size) if size is not None else np.broadcast(lo, sc).shape[0]
+            zl = self._unit().rvs(size=N, z=z)                  # Z @ L.T
+            zl = zl.get() if isinstance(zl, DeviceArray) else zl
+            return lo + sc * zl
         if size is None:
             sh = np.shape(self.loc) if not isinstance(self.loc, DeviceArray) else self.loc.shape
             N = sh[0] if len(sh) == 2 else 1
@@ -228,6 +263,13 @@ class MvNormal(ProbDist):
 
     def logpdf(self, x):
         """:949-959."""
+        if self._array_scale:
+            sc = np.asarray(self.scale.get() if isinstance(self.scale, DeviceArray) else self.scale, dtype=np.float64)
+            lo = np.asarray(self.loc.get() if isinstance(self.loc, DeviceArray) else self.loc, dtype=np.float64)
+            xx = np.asarray(x.get() if isinstance(x, DeviceArray) else x, dtype=np.float64)
+            base = self._unit().logpdf(np.ascontiguousarray((xx - lo) / sc))
+            base = base.get() if isinstance(base, DeviceArray) else base
+            return base - np.sum(np.log(sc), axis=-1)
         if isinstance(x, DeviceArray):
             xd, xrows, dx = x, x.size // self.dim, True
         else:

@@ -312,6 +312,47 @@ class Gordon_etal(StateSpaceModel):
         return dict(kind=_lib.MODEL_GORDON, dx=1, dy=1, params=p, aux=lambda T: self._forcing(np.arange(T)))
 
 
+class BearingsOnly(StateSpaceModel):
+    """Bearings-only tracking (state_space_models.py:580-606): positions with Gaussian increments, velocities carried by
+    Dirac laws, the bearing observed.  No fused descriptor: it runs on the template-method step (device operators for
+    the Normal components, the weights and the resampling)."""
+    default_params = {"sigmaX": 2.0e-4, "sigmaY": 1e-3, "x0": np.array([3e-3, -3e-3, 1.0, 1.0])}
+
+    def PX0(self):
+        return dists.IndepProd(dists.Normal(loc=self.x0[0], scale=self.sigmaX), dists.Normal(loc=self.x0[1], scale=self.sigmaX),
+                               dists.Dirac(loc=self.x0[2]), dists.Dirac(loc=self.x0[3]))
+
+    def PX(self, t, xp):
+        xp = np.asarray(xp)
+        return dists.IndepProd(dists.Normal(loc=xp[:, 0], scale=self.sigmaX), dists.Normal(loc=xp[:, 1], scale=self.sigmaX),
+                               dists.Dirac(loc=xp[:, 0] + xp[:, 2]), dists.Dirac(loc=xp[:, 1] + xp[:, 3]))
+
+    def PY(self, t, xp, x):
+        x = np.asarray(x)
+        angle = np.arctan(x[:, 3] / x[:, 2])
+        angle[x[:, 2] < 0.0] += np.pi
+        return dists.Normal(loc=angle, scale=self.sigmaY)
+
+
+class MVStochVol(StateSpaceModel):
+    """Multivariate stochastic volatility (state_space_models.py:630-655): X_t - mu = F (X_{t-1} - mu) + U_t, U_t ~ N(0, covX);
+    Y_t(k) = exp(X_t(k) / 2) V_t(k), V_t ~ N(0, corY).  No fused descriptor (the observation law's scale varies by particle
+    AND component): the template-method step, MvNormal on the device operators."""
+    default_params = {"mu": 0.0, "covX": None, "corY": None, "F": None}
+
+    def offset(self):
+        return self.mu - np.dot(self.F, self.mu)
+
+    def PX0(self):
+        return dists.MvNormal(loc=self.mu, cov=self.covX)
+
+    def PX(self, t, xp):
+        return dists.MvNormal(loc=np.dot(np.asarray(xp), self.F.T) + self.offset(), cov=self.covX)
+
+    def PY(self, t, xp, x):
+        return dists.MvNormal(loc=np.zeros(np.shape(x)[-1]), scale=np.exp(0.5 * np.asarray(x)), cov=self.corY)
+
+
 class DiscreteCox(_AR1State):
     r"""A discrete Cox model (state_space_models.py:611-630).
 

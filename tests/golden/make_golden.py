@@ -333,6 +333,17 @@ def main():
                                   prior_rho=np.array([0.3, 0.99]), prior_sigmaY=np.array([2.0, 4.0]), sigmaX=1.0,
                                   **{k: np.array(v, dtype=float) for k, v in rec.items()})
 
+    # --- the two models without a fused descriptor (state_space_models.py:580-606, 630-655): Bootstrap filters
+    out["bearings_boot"] = run_case(ssm.BearingsOnly(), ssm.Bootstrap, 25, 400, "systematic", 0.5)
+    rngm = np.random.RandomState(5)
+    Fm = 0.8 * np.eye(3) + 0.05 * rngm.randn(3, 3)
+    cx = 0.2 * (np.eye(3) + 0.3 * np.ones((3, 3)))
+    cy = np.eye(3) + 0.4 * (np.ones((3, 3)) - np.eye(3))
+    mvsv = ssm.MVStochVol(mu=np.array([-1.0, -0.5, 0.2]), covX=cx, corY=cy, F=Fm)
+    case = run_case(mvsv, ssm.Bootstrap, 25, 400, "stratified", 0.5)
+    case.update(F=Fm, covX=cx, corY=cy, mu=np.array([-1.0, -0.5, 0.2]))
+    out["mvsv_boot"] = case
+
     # --- wmean_and_cov, the structured-array moments / quantiles (resampling.py:341-380, 420-442) ----------
     rng = np.random.RandomState(21)
     Wm = rs.exp_and_normalise(2.0 * rng.randn(1500))

@@ -2938,3 +2938,40 @@ def check_spacings_side_stream(monkeypatch, sizes=(3000, 8192), T=9):
             for u, v in zip(runs["side"][0], runs["side"][1]):             # the pickled copy: the same run
                 assert all(np.array_equal(p, q) for p, q in zip(u, v)) if isinstance(u, list) else np.array_equal(u, v), (N, essr)
             assert (a[3][0, :, 4].mean() == 1.0 - 1.0 / T) == (essr == 1.0)
+
+
+def check_models_without_descriptor(golden):
+    """BearingsOnly and MVStochVol (state_space_models.py:580-606, 630-655): no fused descriptor -- the template-method step
+    on device operators (Normal / MvNormal rvs + logpdf, Weights, resampling, gather), numpy's generator consumed in the
+    reference's order -- against the reference's own Bootstrap runs (fixtures bearings_boot, mvsv_boot): decisions, ESS and
+    evidence to 1e-9, the final particles, ancestors and weights."""
+    g = golden("bearings_boot")
+    cases = [(g, ssm.BearingsOnly())]
+    g2 = golden("mvsv_boot")
+    cases.append((g2, ssm.MVStochVol(mu=g2["mu"], covX=g2["covX"], corY=g2["corY"], F=g2["F"])))
+    for g, model in cases:
+        y = list(g["y"])
+        np.random.seed(int(g["run_seed"]))
+        pf = pa.SMC(fk=ssm.Bootstrap(ssm=model, data=y), N=int(g["N"]), resampling=str(g["scheme"]), ESSrmin=float(g["ESSrmin"]))
+        assert not pf._fused
+        pf.run()
+        assert pf.summaries.rs_flags == [bool(v) for v in g["rs_flags"]] and any(pf.summaries.rs_flags)
+        assert rel(pf.summaries.ESSs, g["ESSs"]) < 1e-9 and rel(pf.summaries.logLts, g["logLts"]) < 1e-9
+        A = np.asarray(pf.A)
+        assert np.mean(A == g["A"]) >= 0.999                    # (the exact integer CDF: certified near-ties only)
+        if np.array_equal(A, g["A"]):
+            assert np.max(np.abs(np.asarray(pf.X) - g["X"])) < 1e-11
+            assert np.allclose(np.asarray(pf.wgts.lw), g["lw"], rtol=1e-10, atol=1e-10)
+    # the law MVStochVol observes through: MvNormal with a per-particle, per-component scale (distributions.py:925-959)
+    rng = np.random.default_rng(3)
+    sc = np.exp(0.3 * rng.standard_normal((50, 3)))
+    cov = g2["corY"]
+    x = rng.standard_normal((50, 3))
+    law = dists.MvNormal(loc=np.zeros(3), scale=sc, cov=cov)
+    L = np.linalg.cholesky(cov)
+    z = np.linalg.solve(L, (x / sc).T)
+    want = -0.5 * np.sum(z * z, axis=0) - (np.sum(np.log(sc), axis=-1) + np.sum(np.log(np.diag(L)))) - 3 * 0.9189385332046727
+    assert np.allclose(law.logpdf(x), want, rtol=1e-12, atol=1e-12)
+    assert law.rvs(size=50).shape == (50, 3)
+    d = dists.Dirac(loc=np.array([1.0, 2.0]))
+    assert np.array_equal(d.rvs(), [1.0, 2.0]) and np.array_equal(d.logpdf(np.array([1.0, 3.0])), [0.0, -np.inf])

@@ -534,6 +534,10 @@ def test_multinomial_spacings_on_the_side_stream(monkeypatch):
     pc.check_spacings_side_stream(monkeypatch, sizes=(3000, 1 << 18, 1 << 21))
 
 
+def test_models_without_a_fused_descriptor(golden):
+    pc.check_models_without_descriptor(golden)
+
+
 def test_pickle_resume_of_device_filters():
     pc.check_pickle_resume(sizes=(700, 3000, 1 << 18))
 
