@@ -807,9 +807,11 @@ def main():
                 # N = 10^4 to 10^5 -- two dependent launches -- and k_propagate is VALU-bound in its active window; the
                 # floor is measured here, on the same filter at N = 2^14
                 try:
-                    wl_f = make_workload("c2", W + 400, scheme=a.scheme, log2N=14, essrmin=a.essrmin, strict=a.strict)
+                    kf, rf_ = (100, 4) if not a.other_shrink else (2, 1)       # (functional tests on the emulator: a token run)
+                    wl_f = make_workload("c2", W + kf * rf_, scheme=a.scheme, log2N=14 if not a.other_shrink else 11,
+                                         essrmin=a.essrmin, strict=a.strict)
                     pf_f = make_filter(wl_f)
-                    floor = float(np.median(time_steps(pf_f, 100, W, 4))) / 100
+                    floor = float(np.median(time_steps(pf_f, kf, W, rf_))) / kf
                     del pf_f
                     out["roofline"].update({
                         "limiter": "valu+latency", "launch_floor_us": 1e6 * floor,

@@ -52,7 +52,6 @@ k_strict_classify(const FArgs av, const SqxArgs q)
     __shared__ double s_max[SMC_NWAVE];
     __shared__ double s_esc[SMC_NWAVE];
     __shared__ double s_sum[3 * SMC_NWAVE];
-    __shared__ double smd[SMC_SM];
     // (workgroups are dispatched in index order and the island's chain starts when the LAST of them has taken its ticket:
     //  the two tiles that take longest -- the head of the array, a dozen exceptions, and its end, inside the margin of the
     //  binade edge at 1.0 -- go first)
@@ -73,6 +72,7 @@ k_strict_classify(const FArgs av, const SqxArgs q)
         f_load4<double>(a.pss + o, (i64)tid * 4, a.nparts, pvec, 0.0, pss4);
     }
     const double Kb_v = smc_ldg(a.pm + o + b);                 // this tile's own exponent: the scale of the in-tile estimate
+    const double Gb_v = MID ? smc_ldg(reinterpret_cast<const double*>(a.Qpre) + (i64)isl * a.ntiles + b) : 0.0;
     // the tile's weights on the tile's own scale, e_j = p_j 2^(k_j - K_b): k_propagate left them where the default step keeps
     // the integer CDF (FArgs::strict_e) -- no slot arithmetic (one array, rewritten every step), no exponential here
     const i64 i0 = (i64)b * SEQ_TILE + (i64)tid * 4;
@@ -104,12 +104,10 @@ k_strict_classify(const FArgs av, const SqxArgs q)
         K = smc_uniform(r3);
         rs = smc_uniform(r4);
         if (lane == 63) s_esc[wave] = einc;
-        for (int i = tid; i < b; i += SMC_BLOCK) {
-            double v, w;
-            f2_rescale(smc_ldg(a.pm + o + i), K, smc_ldg(a.ps + o + i), 0.0, v, w);
-            before += v;
-        }
-        before = smc_block_sum(before, smd) * rs;              // (barriers inside: s_esc is complete)
+        // the estimate in front of this tile: k_reduce2 left every tile's share of the 2^52 scale and the shares before it
+        // (G_b: integers below 2^53, each share rounded once -- within ntiles 2^-53 of the normalised sum, inside the margin)
+        before = smc_uniform(Gb_v) * 0x1.0p-52;
+        __syncthreads();                                       // (s_esc is complete)
     } else {
         // ---- all partials -> K, (s, ss), ESS, the decision: k_ancestors2's operations, hence its bits; the estimate of
         // the sum in front of this tile (the shares of the tiles before it) rides in the second exchange
