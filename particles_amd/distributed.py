@@ -436,6 +436,66 @@ class Group:
         check(lib().smc_filter_unpack_islands(pf._f, r_all.ctypes.data_as(P64), M, rbuf.ptr))
         pf._invalidate()
 
+    def move_islands(self, src_pf, dst_pf, dst_slots, src_slots):
+        """Whole filters from one sharded batch into another: global slot ``dst_slots[i]`` of ``dst_pf`` (every rank
+        holds ``dst_pf.n_islands`` consecutive slots) continues from global slot ``src_slots[i]`` of ``src_pf`` (likewise
+        sharded, possibly with another count per rank).  The two arrays are the same on every rank.  Packed island
+        states, one all-to-all (RCCL send / recv pairs, or the host star), as ``migrate_islands`` -- of which this is the
+        two-batch form: the chains of a waste-free move start from resampled members of the population and their states
+        become the next population (smc_samplers.py:669-684).  A fresh ``dst_pf`` is fast-forwarded to ``src_pf``'s time."""
+        dst = np.ascontiguousarray(dst_slots, dtype=np.int64)
+        src = np.ascontiguousarray(src_slots, dtype=np.int64)
+        Ms, Md, W, r = src_pf.n_islands, dst_pf.n_islands, self.world, self.rank
+        if dst.shape != src.shape or (len(dst) and (dst.min() < 0 or dst.max() >= Md * W or src.min() < 0 or src.max() >= Ms * W)):
+            raise ValueError("move_islands: one source slot per destination slot, inside the two batches")
+        if dst_pf._n == 0 and src_pf._n > 0:
+            check(lib().smc_filter_fast_forward(dst_pf._f, src_pf._n))
+            dst_pf.t = dst_pf._n = src_pf._n
+        if dst_pf._n != src_pf._n:
+            raise ValueError("move_islands: the two batches are at different time steps")
+        nb = _lib.c_i64()
+        check(lib().smc_filter_island_bytes(src_pf._f, ctypes.byref(nb)))
+        nb2 = _lib.c_i64()
+        check(lib().smc_filter_island_bytes(dst_pf._f, ctypes.byref(nb2)))
+        if nb.value != nb2.value:
+            raise ValueError("move_islands: the two batches hold filters of different shapes")
+        nb = int(nb.value)
+        send_idx, recv_idx = [], []
+        for p in range(W):
+            sel = (dst // Md == p) & (src // Ms == r)          # what I send to p: my sources of p's slots, in pair order
+            send_idx.append((src[sel] - r * Ms).astype(np.int64))
+            sel = (dst // Md == r) & (src // Ms == p)          # what I receive from p: my slots whose source lives on p
+            recv_idx.append((dst[sel] - r * Md).astype(np.int64))
+        sc = np.array([len(v) * nb for v in send_idx], dtype=np.int64)
+        rc = np.array([len(v) * nb for v in recv_idx], dtype=np.int64)
+        sd = np.concatenate([[0], np.cumsum(sc)[:-1]]).astype(np.int64)
+        rd = np.concatenate([[0], np.cumsum(rc)[:-1]]).astype(np.int64)
+        s_all = np.ascontiguousarray(np.concatenate(send_idx)) if sc.sum() else np.zeros(0, dtype=np.int64)
+        r_all = np.ascontiguousarray(np.concatenate(recv_idx)) if rc.sum() else np.zeros(0, dtype=np.int64)
+        sbuf = DeviceArray((max(1, int(sc.sum()) // 8),), dtype=np.int64)
+        rbuf = DeviceArray((max(1, int(rc.sum()) // 8),), dtype=np.int64)
+        P64 = _lib.P(_lib.c_i64)
+        if len(s_all):
+            check(lib().smc_filter_pack_islands(src_pf._f, s_all.ctypes.data_as(P64), len(s_all), sbuf.ptr))
+        if self.comm is not None:
+            check(lib().smc_comm_alltoallv(self.comm, sbuf.ptr, sc.ctypes.data_as(P64), sd.ctypes.data_as(P64),
+                                           rbuf.ptr, rc.ctypes.data_as(P64), rd.ctypes.data_as(P64)))
+        else:
+            mine = sbuf.get().tobytes()[:int(sc.sum())]
+            hdr = np.concatenate([sc, sd]).tobytes()
+            parts = self.star.exchange(hdr + mine) if self.star else [hdr + mine]
+            out = bytearray(int(rc.sum()))
+            for p, blob in enumerate(parts):
+                h = np.frombuffer(blob[:16 * W], dtype=np.int64)
+                cnt, dsp = int(h[r]), int(h[W + r])
+                assert cnt == rc[p]
+                out[int(rd[p]):int(rd[p]) + cnt] = blob[16 * W + dsp:16 * W + dsp + cnt]
+            host = np.frombuffer(bytes(out) + b"\0" * (-len(out) % 8), dtype=np.int64)
+            rbuf = DeviceArray.from_numpy(host if host.size else np.zeros(1, dtype=np.int64))
+        if len(r_all):
+            check(lib().smc_filter_unpack_islands(dst_pf._f, r_all.ctypes.data_as(P64), len(r_all), rbuf.ptr))
+        dst_pf._invalidate()
+
     @property
     def evidence_path(self):
         if self.comm is not None:

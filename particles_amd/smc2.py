@@ -160,11 +160,14 @@ class SMC2:
         """The theta-particles whose filters live in this process (all of them here)."""
         return 0, self.N
 
-    def _batch(self, theta, Nx, theta_level=False, whole=False):
+    def _batch(self, theta, Nx, theta_level=False, whole=False, span=None):
         """One filter per theta-particle of my slice (``whole``: of ALL the theta given -- the chains of a
-        waste-free move), islands of one device filter; the Philox streams are keyed by the GLOBAL theta
-        index (island_offset), so a sharded population runs the same filters as a single-process one."""
+        waste-free move; ``span`` = (lo, hi): of that range of them -- a rank's share of the chains), islands of one
+        device filter; the Philox streams are keyed by the GLOBAL theta index (island_offset), so a sharded population
+        runs the same filters as a single-process one."""
         lo, hi = (0, len(theta[self.names[0]])) if whole else (self._lo, self._hi)
+        if span is not None:
+            lo, hi = span
         fks = [self.fk_cls(ssm=self.ssm_cls(**{k: float(theta[k][i]) for k in self.names}), data=self.data)
                for i in range(lo, hi)]
         self._nbatch += 1
@@ -414,8 +417,8 @@ class ShardedSMC2(SMC2):
                              "use an IndepPrior")
         if kw.get("seed") is None:
             raise ValueError("ShardedSMC2 needs a seed (the same on every rank)")
-        if kw.get("wastefree"):
-            raise ValueError("ShardedSMC2: the waste-free move is implemented for one process (SMC2)")
+        if kw.get("wastefree") and kw.get("N", 100) % world:
+            raise ValueError("ShardedSMC2(wastefree=True): the number of chains N must be a multiple of the number of ranks")
         super().__init__(**kw)
         self._cum0 = np.zeros(self.N)        # filters' evidences at the last reset of the theta-weights
         self._lw0 = np.zeros(self.N)         # theta log-weights at that reset
@@ -442,6 +445,62 @@ class ShardedSMC2(SMC2):
             self.pf.permute_islands(A)
         else:
             self.group.migrate_islands(self.pf, A)
+
+    def _wastefree_move(self, A, L, d):
+        """MCMCSequenceWF (smc_samplers.py:669-684) on a population sharded over ranks: rank r runs the chains
+        r M/R .. (r + 1) M/R - 1 -- their starting filters arrive from wherever the resampled theta-particles live
+        (Group.move_islands), the proposals, acceptance uniforms and theta values are replicated (one seeded host
+        generator, the candidates' evidences all-gathered), every state of every chain stays with its filter, and the
+        new population [x_0, .., x_{P-1}] is assembled across ranks by P more moves of whole filters.  Same Philox keys
+        (global chain / theta index), same batch seeds, same arithmetic: the same run as one process, bit for bit."""
+        if self.group is None:
+            return super()._wastefree_move(A, L, d)
+        M, P, t, grp = self.M, self.P, self.t, self.group
+        R, r = grp.world, grp.rank
+        Mr = M // R
+        clo, chi = r * Mr, (r + 1) * Mr
+        if self.device_theta:
+            check(lib().smc_filter_theta_resume(self.pf._f, None))      # time records back to t
+        ev_all = self._evidences(self.pf)
+        th = {k: v[A].copy() for k, v in self.theta.items()}            # (replicated: all M chains)
+        cur = self._batch(th, self.Nx, span=(clo, chi))
+        grp.move_islands(self.pf, cur, np.arange(M), A)                 # the resampled filters themselves
+        lp = np.asarray(self.prior.logpdf(th), dtype=float) + ev_all[A]
+        states, thetas, ars, pbs = [cur], [th], [], []
+        for k in range(1, P):
+            Z = self.rng.standard_normal((M, d)) @ L.T
+            prop = {n_: th[n_] + Z[:, j] for j, n_ in enumerate(self.names)}
+            with np.errstate(all="ignore"):
+                lprior = np.asarray(self.prior.logpdf(prop), dtype=float)
+            ok = np.isfinite(lprior)
+            safe = {n_: np.where(ok, prop[n_], th[n_]) for n_ in self.names}
+            cand = self._batch(safe, self.Nx, span=(clo, chi))
+            cand.step_async(t)
+            lp_prop = np.where(ok, lprior + grp.gather_evidence(cand.logLts_islands), -np.inf)
+            lp_old = lp
+            acc = (np.log(self.rng.random_sample(M)) < lp_prop - lp) & ok
+            nxt = self._batch(th, self.Nx, span=(clo, chi))             # x = x.copy(): the chain's next state
+            nxt.take_islands_from(states[-1], np.arange(Mr))
+            nxt.accept_islands_from(cand, acc[clo:chi])
+            th = {n_: np.where(acc, prop[n_], th[n_]) for n_ in self.names}
+            lp = np.where(acc, lp_prop, lp)
+            states.append(nxt)
+            thetas.append(th)
+            ars.append(float(np.mean(acc)))
+            with np.errstate(all="ignore"):
+                pbs.append(float(np.mean(np.where(ok, np.exp(np.minimum(lp_prop - lp_old, 0.0)), 0.0))))
+            del cand
+        self.acc_rates.extend(pbs)
+        self.acc_fractions.extend(ars)
+        self.theta = {n_: np.concatenate([th_[n_] for th_ in thetas]) for n_ in self.names}
+        new = self._batch(self.theta, self.Nx)
+        for k, st in enumerate(states):
+            grp.move_islands(st, new, k * M + np.arange(M), np.arange(M))
+        self._enable_theta_level(new)                                   # from step t on, weights zero
+        self.pf = new
+        self.lw = np.zeros(self.N)
+        self._lw_at_reset = np.zeros(self.N)
+        return float(np.mean(pbs)) if pbs else 1.0
 
     def _adopt(self, new, liw):
         if self.device_theta:                # every rank holds all N theta-weights

@@ -158,6 +158,8 @@ prior = smc2.IndepPrior(sigmaY=("lognormal", np.log(0.8), 1.2))
 kw = dict(ssm_cls=lambda sigmaY: kalman.LinearGauss(rho=1.0, sigmaX=1.0, sigmaY=sigmaY, sigma0=1.0),
           prior=prior, data=y, init_Nx=int(os.environ.get("SMC_TEST_NX", "128")), N=12, seed=5,
           ESSrmin=0.8, nmcmc=2, ar_to_increase_Nx=float(os.environ.get("SMC_TEST_AR", "-1")), max_Nx=256)
+if os.environ.get("SMC_TEST_WF") == "1":       # waste-free move: 6 chains x 2 states = the same 12 theta-particles
+    kw.update(N=6, wastefree=True, len_chain=2)
 alg = smc2.ShardedSMC2(group=grp, **kw)
 alg.run()
 single = None
@@ -215,6 +217,30 @@ def test_sharded_smc2_is_world_invariant(tmp_path):
     e1 = _run_smc2_world(1, tmp_path, SMC_TEST_AR="1.01", SMC_TEST_T="8")
     e2 = _run_smc2_world(2, tmp_path, SMC_TEST_AR="1.01", SMC_TEST_T="8")
     assert e1["Nx"] == 256 and all(e1[k] == e2[k] for k in ("lw", "theta", "logLt", "ESSs", "Nx"))
+
+
+def test_sharded_wastefree_smc2_is_world_invariant(tmp_path):
+    """The waste-free move (MCMCSequenceWF, smc_samplers.py:669-684: every state of every chain kept with its filter) on a
+    population sharded over ranks: the chains' starting filters cross ranks (Group.move_islands), each rank
+    runs its share of the chains, the new population is assembled across ranks -- worlds 2 and 3 are the same run as world 1
+    bit for bit, over the host star and through the RCCL double, and world 1 agrees with the one-process class."""
+    one = _run_smc2_world(1, tmp_path, SMC_TEST_WF="1")
+    assert one["moves"] >= 1 and one["local"] == 12
+    for world in (2, 3):
+        other = _run_smc2_world(world, tmp_path, SMC_TEST_WF="1")
+        assert other["local"] == 12 // world
+        for k in ("lw", "theta", "logLt", "ESSs", "moves", "acc", "Nx"):
+            assert one[k] == other[k], (world, k)
+    s = one["single"]
+    assert s["moves"] == one["moves"] and np.allclose(s["theta"], one["theta"], rtol=1e-12, atol=0)
+    assert np.allclose(s["lw"], one["lw"], rtol=0, atol=1e-9) and abs(s["logLt"] - one["logLt"]) < 1e-9
+    two_rccl = _run_smc2_world(2, tmp_path, SMC_TEST_WF="1", **_fake_rccl_env(tmp_path))
+    assert two_rccl["path"] == "rccl" and two_rccl["device_theta"]
+    # (the device theta level accumulates the weights increment by increment, the host form differences cumulated
+    #  evidences: the proposal covariance, hence theta, agrees to rounding; same decisions)
+    assert one["moves"] == two_rccl["moves"] and one["Nx"] == two_rccl["Nx"]
+    assert np.allclose(one["theta"], two_rccl["theta"], rtol=1e-12, atol=0)
+    assert np.allclose(one["lw"], two_rccl["lw"], rtol=0, atol=1e-9) and abs(one["logLt"] - two_rccl["logLt"]) < 1e-9
 
 
 def test_multi_rank_rccl_calls_through_the_test_double(tmp_path, has_gpu):
