@@ -111,7 +111,7 @@ int smc_inverse_cdf_strict(smc_ctx* ctx, const double* su, const double* W, int6
  * (resampling.py:500-509).  mode 0: the two-launch emulation smc_inverse_cdf_strict and the filter's strict mode use
  * (csrc/smc_seqx.h), written out; mode 2: the tile walk (csrc/smc_seqsum.h); mode 1: the literal one-lane walk.  All
  * agree bit for bit for any W >= 0 (tests compare them).  n_sequential_tiles (may be null): mode 0 -- the exceptions
- * the emulation walked, or -1 if it took its exact path; mode 2 -- tiles of 1024 the walk did exactly; mode 1 -- all. */
+ * the emulation walked, or -why (< 0) if it took its exact path (why: smc_filter_strict_stats); mode 2 -- tiles of 1024 the walk did exactly; mode 1 -- all. */
 int smc_seq_prefix_sums(smc_ctx* ctx, const double* W, int64_t N, double* S, int mode, int64_t* n_sequential_tiles);
 
 /* ---- a-6: rs.resampling(scheme, W, M) (resampling.py:477-481) -------------
@@ -513,8 +513,10 @@ int smc_filter_save_state(smc_filter* f, void* out_host, int64_t nbytes);
 int smc_filter_load_state(smc_filter* f, const void* in_host, int64_t nbytes);
 /* SMC_FLAG_STRICT_ANCESTORS (the reference's sequential fp64 inverse_cdf, resampling.py:484-509): how the last
  * resampling step of `island` formed that CDF -- *exact_path = 0: the two-launch emulation (csrc/smc_seqx.h), its
- * assumptions verified; 1: the exact scan-until-exception path (milliseconds; engineered ties, NaN / negative
- * weights); *exceptions: the elements the emulation's serial walk handled.  Diagnostics: the results are the
+ * assumptions verified; non-zero: the exact scan-until-exception path ran (milliseconds at N = 2^20), the value saying
+ * why (1: more exceptions than the lists hold -- engineered ties, NaN / negative weights; 2: an integer step of the walk
+ * left its binade; 4 / 8: a segment behind an exception / a tile's head expected another binade than the walk found);
+ * *exceptions: the elements the emulation's serial walk handled.  Diagnostics: the results are the
  * reference's either way. */
 int smc_filter_strict_stats(smc_filter* f, int32_t island, int64_t* exact_path, int64_t* exceptions);
 int smc_filter_kernel_ms(smc_filter* f, double* move_ms_avg,

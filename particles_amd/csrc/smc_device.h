@@ -287,6 +287,24 @@ __device__ __forceinline__ double smc_block_exscan_f64(double v, double* sm, dou
     total = tot;
     return base + inc - v;
 }
+// the same for positive terms whose exclusive prefix must keep its RELATIVE accuracy (inc - v cancels where a thread's
+// own term dominates everything before it): the left neighbour's inclusive sum, nothing subtracted
+__device__ __forceinline__ double smc_block_exscan_pos_f64(double v, double* sm, double& total)
+{
+    const double inc = smc_wave_scan_add_f64(v);
+    const double exc = smc_dpp_f64<SMC_DPP_WAVE_SHR1, 0xf, false>(inc);   // (lane 0: 0.0)
+    __syncthreads();
+    if (smc_lane() == 63) sm[smc_wave()] = inc;
+    __syncthreads();
+    double base = 0.0, tot = 0.0;
+#pragma unroll
+    for (int w = 0; w < SMC_NWAVE; ++w) {
+        if (w < smc_wave()) base += sm[w];
+        tot += sm[w];
+    }
+    total = tot;
+    return base + exc;
+}
 // exclusive prefix of `v` over threads AND the workgroup sum of `extra`, with a
 // single LDS exchange; sm needs 2*SMC_NWAVE slots
 __device__ __forceinline__ u64 smc_block_exscan_plus_sum_u64(u64 v, u64 extra, u64* sm,

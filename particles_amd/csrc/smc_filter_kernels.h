@@ -2219,7 +2219,8 @@ __device__ __forceinline__ F2Red f2_reduce_island_cached(const FArgs& a, const i
 }
 
 // k_reduce2(t): one workgroup per island reduces the partials of step t-1, decides step t,
-// writes the record, the summary row and every tile's (G_b, Q_b) (integer-valued doubles)
+// writes the record, the summary row and every tile's (G_b, Q_b) (integer-valued doubles: shares of 2^52; a strict
+// filter reads G_b only as its estimate of the sum in front of tile b and gets fractions of 1, relatively accurate)
 // (a function of the island: k_reduce2 is one launch of it per step; the one-pass spacings kernel of the
 //  multinomial scheme runs it as ITS workgroup 0, side by side with the workgroups that draw.)
 // Returns -1: no step to run (t = 0, or the filter is past T / frozen), 0: step t does not resample, 1: it does.
@@ -2263,11 +2264,18 @@ __device__ __forceinline__ int f2_reduce2_island(const FArgs& a, const int isl, 
             for (int k = 0; k < 4; ++k) {
                 double v, w;
                 f2_rescale(pmc[c][k], r.K, psc[c][k], 0.0, v, w);
-                Q4[c][k] = (c < nchunks && i0 + k < a.nparts) ? f2_share(v, r.rs) : 0.0;
+                Q4[c][k] = (c < nchunks && i0 + k < a.nparts) ? (a.strict_e ? v * r.rs : f2_share(v, r.rs)) : 0.0;
                 run[c] += Q4[c][k];
             }
             inc[c] = smc_wave_scan_add_f64(run[c]);
         }
+        // (the sums in front of a thread: its left neighbour's inclusive ones, nothing subtracted -- the same exact
+        //  integers for the shares; for a strict filter, whose G_b is the estimate of the normalised sum in front of
+        //  tile b as a fraction, inc - run would cancel in front of a heavy tile and lose the RELATIVE accuracy the
+        //  classification's margin assumes)
+        double exl[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) exl[c] = smc_dpp_f64<SMC_DPP_WAVE_SHR1, 0xf, false>(inc[c]);
         __syncthreads();
         if (smc_lane() == 63) {
 #pragma unroll
@@ -2285,7 +2293,7 @@ __device__ __forceinline__ int f2_reduce2_island(const FArgs& a, const int isl, 
                 if (w < smc_wave()) base += s_x4[c * SMC_NWAVE + w];
                 tot += s_x4[c * SMC_NWAVE + w];
             }
-            double g = carry + base + inc[c] - run[c];
+            double g = carry + (base + exl[c]);
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (i0 + k < a.nparts) { G[i0 + k] = g; Q[i0 + k] = Q4[c][k]; g += Q4[c][k]; }
@@ -2314,11 +2322,11 @@ __device__ __forceinline__ int f2_reduce2_island(const FArgs& a, const int isl, 
         for (int k = 0; k < 4; ++k) {
             double v, w;
             f2_rescale(pm4[k], r.K, ps4[k], 0.0, v, w);
-            Q4[k] = (i0 + k < a.nparts) ? f2_share(v, r.rs) : 0.0;
+            Q4[k] = (i0 + k < a.nparts) ? (a.strict_e ? v * r.rs : f2_share(v, r.rs)) : 0.0;
             run += Q4[k];
         }
         double tot;
-        double g = carry + smc_block_exscan_f64(run, sme, tot);
+        double g = carry + smc_block_exscan_pos_f64(run, sme, tot);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if (i0 + k < a.nparts) { G[i0 + k] = g; Q[i0 + k] = Q4[k]; g += Q4[k]; }

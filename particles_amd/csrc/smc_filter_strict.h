@@ -99,14 +99,19 @@ k_strict_classify(const FArgs av, const SqxArgs q)
         esum += e4[k];
     }
     const double einc = smc_wave_scan_add_f64(esum);
+    // (the sum in front of this thread: the left neighbour's inclusive one -- NOT einc - esum, which cancels wherever the
+    //  weights rise steeply, the head of every array, and then sends the step to the exact path)
+    const double eexc = smc_dpp_f64<SMC_DPP_WAVE_SHR1, 0xf, false>(einc);
     double K, rs, before = 0.0;
     if (MID) {
         K = smc_uniform(r3);
         rs = smc_uniform(r4);
         if (lane == 63) s_esc[wave] = einc;
-        // the estimate in front of this tile: k_reduce2 left every tile's share of the 2^52 scale and the shares before it
-        // (G_b: integers below 2^53, each share rounded once -- within ntiles 2^-53 of the normalised sum, inside the margin)
-        before = smc_uniform(Gb_v) * 0x1.0p-52;
+        // the estimate in front of this tile: k_reduce2 left the tiles' fractions of the normalised sum and their prefixes
+        // (FArgs::strict_e: plain doubles, positive terms added forwards -- relative error below ntiles 2^-53 however
+        //  little of the mass lies in front of the tile; the default step's integer shares of 2^52 are accurate to
+        //  2^-53 of the TOTAL, which is nothing in front of the first heavy particle of a collapsed population)
+        before = smc_uniform(Gb_v);
         __syncthreads();                                       // (s_esc is complete)
     } else {
         // ---- all partials -> K, (s, ss), ESS, the decision: k_ancestors2's operations, hence its bits; the estimate of
@@ -170,7 +175,7 @@ k_strict_classify(const FArgs av, const SqxArgs q)
     double ebase = 0.0;
 #pragma unroll
     for (int w = 0; w < SMC_NWAVE; ++w) ebase += (w < wave) ? s_esc[w] : 0.0;
-    const double run0 = before + ldexp(ebase + einc - esum, (int)dsc) * rs;
+    const double run0 = before + ldexp(ebase + eexc, (int)dsc) * rs;
     SQX_STAMP(q, b, 1);
     if (sqx_classify_tile(w4, run0, isl, b, q)) sqx_chain(src, isl, q);
 }

@@ -474,7 +474,7 @@ extern "C" int smc_seq_prefix_sums(smc_ctx* ctx, const double* W, int64_t N, dou
             unsigned long long c[2] = {0ull, 0ull};
             SMC_HIP_CHECK(hipMemcpyAsync(c, q.ctr + 2, 16, hipMemcpyDeviceToHost, ctx->stream));
             SMC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-            *n_sequential_tiles = c[0] ? -1 : (int64_t)c[1];
+            *n_sequential_tiles = c[0] ? -(int64_t)c[0] : (int64_t)c[1];   // (< 0: the exact path ran, -why)
         }
     }
     SMC_LAUNCH_CHECK();

@@ -330,7 +330,8 @@ __device__ __forceinline__ void sqx_chain(const Src& src, const int isl, const S
     __shared__ double c_w[SQX_CAP];
     __shared__ double c_S[SQX_CAP];
     __shared__ u64 smu[SMC_SM];
-    __shared__ int c_ok, s_idx;
+    __shared__ int c_ok, s_idx;                                // c_ok: 1, or 0 with c_why saying which assumption failed
+    __shared__ unsigned c_why;
     __shared__ double s_tmp;
     static_assert(SQX_CAP == SMC_BLOCK, "one exception slot per thread");
     const int tid = (int)threadIdx.x, ntiles = q.ntiles;
@@ -350,8 +351,9 @@ __device__ __forceinline__ void sqx_chain(const Src& src, const int isl, const S
     }
     __syncthreads();                                           // (every thread has read the counters)
     SQX_STAMP(q, ntiles, 1);
-    if (tid == 0) { smc_st_agent(ctr, 0ull); smc_st_agent(ctr + 1, 0ull); c_ok = 1; }   // (re-armed for the next launch)
+    if (tid == 0) { smc_st_agent(ctr, 0ull); smc_st_agent(ctr + 1, 0ull); c_ok = 1; c_why = 0u; }   // (re-armed for the next launch)
     bool slow = ovf != 0ull || cnt64 > (u64)SQX_CAP;
+    if (slow && tid == 0) c_why = 1u;                          // more exceptions than the lists hold
     const int cnt = slow ? 0 : (int)cnt64;
     if (!slow) {
         // ---- P offsets of the tiles: thread tid owns tiles 4 tid .. 4 tid + 3 of every chunk of 1024
@@ -438,7 +440,7 @@ __device__ __forceinline__ void sqx_chain(const Src& src, const int isl, const S
                 const u64 dP = carry - (cnt ? smc_readlane64(Pl, cnt - 1) : 0ull);   // the run behind the last exception
                 const int Es = seq_bexp(s);
                 bad = bad || (dP != 0ull && !(Es >= 1 && Es < 0x7ff && sqx_mant(s) + dP < (1ull << 53)));
-                if (bad) c_ok = 0;                             // (benign race: every writer stores 0)
+                if (bad) { c_ok = 0; atomicOr(&c_why, 2u); }   // the walk: an integer step left its binade
             }
         } else if (tid == 0) {
             double s = 0.0;
@@ -474,7 +476,7 @@ __device__ __forceinline__ void sqx_chain(const Src& src, const int isl, const S
             const u64 dP = carry - Pprev;                      // the run behind the last exception
             const int Es = seq_bexp(s);
             const bool ok = viol == 0u && (dP == 0ull || (Es >= 1 && Es < 0x7ff && sqx_mant(s) + dP < (1ull << 53)));
-            if (!ok) c_ok = 0;
+            if (!ok) { c_ok = 0; atomicOr(&c_why, 2u); }
         }
         __syncthreads();
         SQX_STAMP(q, ntiles, 4);
@@ -483,6 +485,13 @@ __device__ __forceinline__ void sqx_chain(const Src& src, const int isl, const S
         if (tid < cnt) {
             const u32 e = (u32)seq_bexp(c_S[tid]);
             bad = e < (c_acc[tid] & 0xffffu) || e > (c_acc[tid] >> 16);
+            if (bad) atomicOr(&c_why, 4u);                     // the segment behind an exception expected another binade
+#ifdef SQX_DEBUG_PRINT
+            if (bad) {
+                printf("WHY4 isl %d cnt %d x %d j %u S %a (E %u) acc [%u,%u] w %a P %llu\n", isl, cnt, tid, c_j[tid], c_S[tid], e, c_acc[tid] & 0xffffu, c_acc[tid] >> 16, c_w[tid], (unsigned long long)c_P[tid]);
+                for (int m = (tid > 2 ? tid - 2 : 0); m < cnt && m < tid + 3; ++m) printf("     x %d j %u S %a w %a acc [%u,%u] P %llu\n", m, c_j[m], c_S[m], c_w[m], c_acc[m] & 0xffffu, c_acc[m] >> 16, (unsigned long long)c_P[m]);
+            }
+#endif
             u64* o = q.xs + ((i64)isl * SQX_CAP + tid) * 4;
             o[0] = (u64)c_j[tid];
             o[1] = (u64)__double_as_longlong(c_S[tid]);
@@ -516,7 +525,9 @@ __device__ __forceinline__ void sqx_chain(const Src& src, const int isl, const S
                 const int qx = lo[k] - 1;
                 const double sb = qx < 0 ? 0.0 : c_S[qx];
                 const u32 e = (u32)seq_bexp(sb);
-                bad = bad || e < (u32)(hs[k] & 0xffffull) || e > (u32)(hs[k] >> 16);
+                const bool badh = e < (u32)(hs[k] & 0xffffull) || e > (u32)(hs[k] >> 16);
+                if (badh) atomicOr(&c_why, 8u);                // a tile's head segment expected another binade
+                bad = bad || badh;
                 q.hE[(i64)isl * ntiles + b] = (int)e;
                 q.hI[(i64)isl * ntiles + b] = sqx_mant(sb) + (pt[k] - (qx < 0 ? 0ull : c_P[qx]));
             }
@@ -542,7 +553,8 @@ __device__ __forceinline__ void sqx_chain(const Src& src, const int isl, const S
                 if (tid * 4 + k < m_all) So[lo + tid * 4 + k] = o4[k];
         }
     }
-    if (tid == 0) { ctr[2] = slow ? 1ull : 0ull; ctr[3] = cnt64; }
+    __syncthreads();
+    if (tid == 0) { ctr[2] = slow ? (u64)(c_why ? c_why : 16u) : 0ull; ctr[3] = cnt64; }   // (mode word: 0, or why the exact path ran)
     SQX_STAMP(q, ntiles, 5);
 }
 
@@ -885,7 +897,7 @@ k_sqx_classify(const double* W, const double* tsum, const SqxArgs q, const SeqGa
     const SqxSrcArray src{W + (i64)isl * q.n, q.n};
     double w4[4], tot;
     src.load4((i64)b * SEQ_TILE + (i64)tid * 4, w4);
-    const double run0 = before + smc_block_exscan_f64((w4[0] + w4[1]) + (w4[2] + w4[3]), smd, tot);
+    const double run0 = before + smc_block_exscan_pos_f64((w4[0] + w4[1]) + (w4[2] + w4[3]), smd, tot);
     __syncthreads();
     if (sqx_classify_tile(w4, run0, isl, b, q)) sqx_chain(src, isl, q);
 }

@@ -1024,6 +1024,30 @@ def check_strict_ancestors(sizes=(3000, 4096), op_N=1 << 14, op_cases=12, scheme
         pa.SMC(fk=ssm.AuxiliaryPF(ssm=ssm.StochVol(), data=y), N=500, strict_ancestors=True)
 
 
+def check_strict_never_leaves_the_fast_path(cases, T=300):
+    """The two-launch emulation must not merely be right (its exact path makes it right whatever happens): on a filter's
+    own weights it must verify EVERY step.  Round 5's soak found one step in five hundred taking the exact path
+    (milliseconds at N = 2^20): the estimate of the sum in front of a thread was formed as `inclusive - own`, which
+    cancels at the head of every array, where the weights rise over a hundred binades in a dozen elements.  Every
+    step's statistics are read here, not the last one's."""
+    yr = np.random.RandomState(4)
+    y = [np.array([v]) for v in 0.4 * np.cumsum(yr.standard_normal(T))]
+    mk = {"toy": lambda: kalman.ToySSM(0.2), "sv": lambda: ssm.StochVol(), "peaky": lambda: kalman.ToySSM(2e-3),
+          "collapsed": lambda: kalman.ToySSM(1e-6)}
+    for N, nisl, scheme, model, ESSrmin in cases:
+        pf = pa.SMC(fk=ssm.Bootstrap(ssm=mk[model](), data=y), N=N, resampling=scheme, ESSrmin=ESSrmin, seed=77,
+                    strict_ancestors=True, collect="off", n_islands=nisl)
+        worst = 0
+        for t in range(T):
+            pf.step_async(1)
+            for isl in range(nisl):
+                ex, nx = ctypes.c_int64(-1), ctypes.c_int64(-1)
+                _lib.check(_lib.lib().smc_filter_strict_stats(pf._f, isl, ctypes.byref(ex), ctypes.byref(nx)))
+                assert ex.value == 0, (N, nisl, scheme, model, t, isl, ex.value, nx.value)
+                worst = max(worst, nx.value)
+        assert np.all(np.isfinite(pf.logLts_islands)) and worst <= 256, (N, scheme, model, worst)
+
+
 def check_seq_prefix_sums(sizes=(5000, 1 << 14, 20001), monkeypatch=None):
     """csrc/smc_seqsum.h: the reference's sequential fp64 prefix sums (resampling.py:506-508: s = W[0]; s += W[j])
     computed in parallel must be THE SAME DOUBLES as the loop's, whatever the weights: the element-level pass (mode 0),

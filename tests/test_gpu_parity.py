@@ -530,6 +530,16 @@ def test_strict_ancestors_heavy_parents():
                                   small=False, T=5, ESSrmin=1.0)
 
 
+def test_strict_verifies_every_step():
+    pc.check_strict_never_leaves_the_fast_path(
+        [(5000, 4, "systematic", "toy", 0.5), (3000, 8, "multinomial", "toy", 0.5), (70000, 2, "stratified", "sv", 1.0),
+         (1 << 16, 2, "systematic", "peaky", 1.0)], T=1000)
+    # more than 1024 tiles (k_reduce2's prefixes are the estimate in front of a tile): even and collapsed mass
+    pc.check_strict_never_leaves_the_fast_path(
+        [((1 << 21) + 5, 1, "systematic", "toy", 0.5), (1 << 21, 1, "stratified", "collapsed", 1.0),
+         (1 << 21, 1, "multinomial", "peaky", 1.0)], T=40)
+
+
 def test_multinomial_spacings_on_the_side_stream(monkeypatch):
     pc.check_spacings_side_stream(monkeypatch, sizes=(3000, 1 << 18, 1 << 21))
 
