@@ -468,7 +468,9 @@ def roofline(wl, step_GBs, mv_ms, rs_ms, nsamples, kernels):
     two = "k_ancestors2" in kernels or strict2
     # strict two-level step: k_strict_classify reads lw and writes the 8-byte integer prefix of every weight's rounding,
     # k_strict_search reads it and writes A: 32 B per particle (the sequential CDF itself is never written)
-    rs_bytes = (32.0 if strict2 else BYTES_PREPARE + (8.0 if "k_prepare" in kernels else 0.0)) * N * isl
+    # (k_strict_step, both in one launch: that prefix stays in registers -- 16 B, the tile-scale weights in, A out)
+    rs_bytes = ((16.0 if "k_strict_step" in kernels else 32.0) if strict2
+                else BYTES_PREPARE + (8.0 if "k_prepare" in kernels else 0.0)) * N * isl
     mv_bytes = (16.0 * d + 16.0 + (8.0 if two else 0.0)) * N * isl
     mv_ms = mv_ms if mv_ms > 0 else 1e-9          # (the emulator's events read 0)
     per = {mv_name: {"ms": mv_ms, "launch_bytes": mv_bytes, "achieved": mv_bytes / (mv_ms * 1e-3) / 1e9},

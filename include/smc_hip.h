@@ -375,6 +375,8 @@ typedef struct smc_filter_opts {
 #define SMC_PATH_SQ_GATHER        (1 << 29)  /* SMC_FLAG_SQMC: gather the sorted log-weights where they could be recomputed */
 #define SMC_PATH_SP_SIDE          (1 << 3)   /* multinomial: the NEXT step's spacings drawn on a side stream beside k_propagate (A/B: measured slower) */
 #define SMC_PATH_NO_SP_SIDE       (1 << 4)   /* ... never (the default) */
+#define SMC_PATH_STRICT_ONE_LAUNCH (1u << 31)  /* SMC_FLAG_STRICT_ANCESTORS: k_strict_classify + k_strict_search as ONE launch (k_strict_step) where
+                                                * the whole grid is resident at once; the caller vouches that no other process shares the device */
 #define SMC_PATH_SP_TPW(n)        (((n) & 15) << 25)   /* one-pass spacings: n = 1, 2, 4, 8 tiles of draws per workgroup */
 #define SMC_PATH_MV_CHUNKS(n)    (((n) & 15) << 20)   /* k_propagate_mv: n = 1, 2, 4, 8 chunks per workgroup */
 

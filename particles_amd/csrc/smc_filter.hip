@@ -33,6 +33,8 @@ struct smc_filter {
     bool strict;           // SMC_FLAG_STRICT_ANCESTORS: sequential fp64 CDF of the filter's weights
     double* strict_ws;     // (n_islands, N) W | (n_islands, N) S | scratch of smc_seqsum.h
     bool strict_literal;   // SMC_PATH_STRICT_LITERAL: S by the one-lane walk, in place
+    bool strict_one_launch; // classify + search as ONE launch (k_strict_step): every workgroup of the grid resident at once
+    unsigned long long strict_epoch;   // ... its launches, numbered (SqxArgs::epoch)
     // SMC_FLAG_SQMC (smc_filter_sqmc.h): the point stream, the tape of ndtri(second coordinate), the
     // sort's workspace and -- more than one island -- the islands' permutations
     u64 sp_epoch;          // launches of the merged spacings + reduction kernel so far (see FArgs::sp_epoch)
@@ -258,9 +260,17 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
                        f->a, (const double*)f->strict_ws, (const double*)f->a.su);
         } else if (f->two_level) {
             // the same doubles in two launches, S never written (smc_filter_strict.h)
-            if (f->two_level_mid) SMC_LAUNCH(k_strict_classify<true>, gt, dim3(SMC_BLOCK), st, f->a, q);
-            else SMC_LAUNCH(k_strict_classify<false>, gt, dim3(SMC_BLOCK), st, f->a, q);
-            SMC_LAUNCH(k_strict_search, gt, dim3(SMC_BLOCK), st, f->a, q);
+            // ... or in one, where the whole grid is resident at once (k_strict_step)
+            if (f->strict_one_launch) {
+                do q.epoch = ++f->strict_epoch; while ((uint32_t)q.epoch == 0u);   // (0: the tag of never-written words)
+                if (const char* e = getenv("SMC_STRICT_POLL")) q.poll = atoi(e);   // (perf experiments)
+                if (f->two_level_mid) SMC_LAUNCH(k_strict_step<true>, gt, dim3(SMC_BLOCK), st, f->a, q);
+                else SMC_LAUNCH(k_strict_step<false>, gt, dim3(SMC_BLOCK), st, f->a, q);
+            } else {
+                if (f->two_level_mid) SMC_LAUNCH(k_strict_classify<true>, gt, dim3(SMC_BLOCK), st, f->a, q);
+                else SMC_LAUNCH(k_strict_classify<false>, gt, dim3(SMC_BLOCK), st, f->a, q);
+                SMC_LAUNCH(k_strict_search, gt, dim3(SMC_BLOCK), st, f->a, q);
+            }
         } else {
             // one tile (or a flat test path): W materialised, the two launches of smc_seqx.h on the array, S written
             size_t used = 0;
@@ -745,6 +755,28 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     f->flush_pending = false;
     // (inside a replayed graph the argument block -- the epoch with it -- is frozen: separate launches there)
     f->sp_merge = a.sp_tpw && merge_fits && !o->use_graph && !(o->flags & SMC_PATH_SPLIT_REDUCE);
+    // strict ancestors, two-level step: classify + search as ONE launch (k_strict_step) -- only when SMC_PATH_STRICT_ONE_LAUNCH
+    // asks for it, and then only where the runtime says the whole grid is resident at once and the island has at most 1024
+    // tiles: the kernel waits inside the launch, and a workgroup that could not start would be waited for for ever.  Built
+    // and measured in round 5 (profiles/r14h_strict_one_launch.txt): 36.8 against 37.1 us per C2 step -- the second launch's
+    // dispatch was already hidden behind the first one's tail, so what is saved is the 8-byte round trip of the roundings'
+    // prefixes.  One per cent does not pay for the condition it needs: two PROCESSES sharing the device (multiSMC with
+    // nprocs = 2 on one GPU) each get part of the CUs, and two such kernels would wait for each other's slots.  Off by default.
+    // (Not inside replayed graphs either: the epoch is a kernel argument.)
+    f->strict_one_launch = false;
+    f->strict_epoch = 0ull;
+#ifndef SMC_EMULATE
+    if (f->strict && f->two_level && !f->strict_literal && !o->use_graph && ((uint32_t)o->flags & SMC_PATH_STRICT_ONE_LAUNCH)) {
+        int per_cu = 0, cus = 0;
+        const hipError_t e1 = f->two_level_mid
+            ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_strict_step<true>, SMC_BLOCK, 0)
+            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_strict_step<false>, SMC_BLOCK, 0);
+        const hipError_t e2 = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+        const size_t wgs = (size_t)((N + 1023) / 1024) * M;
+        f->strict_one_launch = e1 == hipSuccess && e2 == hipSuccess && wgs <= (size_t)per_cu * (size_t)cus && a.ntiles <= 1024;
+        (void)hipGetLastError();
+    }
+#endif
     const size_t oTmp = carve(N * dxm * 8);
     const size_t oStrict = carve(f->strict ? 2 * M * N * 8 + sqx_scratch_bytes((i64)N, (int)M) + M * a.ntiles * 8 + 64 : 8);
     if (f->sqmc && !f->sq_flat && !f->two_level) {
@@ -1097,6 +1129,8 @@ int smc_filter_load_state(smc_filter* f, const void* in_host, int64_t nbytes)
     f->flush_pending = h.flush_pending != 0;
     f->a.island_offset = h.island_offset;
     f->sp_ahead_t = -1;                    // (spacings drawn ahead belonged to the filter this one was)
+    if (f->strict && !f->strict_literal)   // (k_strict_step's epoch word counted the OTHER filter's launches)
+        sqx_zero_done(f->ctx->stream, (void*)(f->strict_ws + 2 * (size_t)f->a.n_islands * f->a.N), f->a.N, f->a.n_islands);
     if (f->sp_side) SMC_HIP_CHECK(hipMemsetAsync(f->sst2[1], 0, (size_t)f->a.n_islands * f->a.sp_nwg * 8, f->ctx->stream));
     for (hipGraphExec_t& g : f->gexec)          // captured launches carry the old key / counters by value
         if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
@@ -1959,7 +1993,8 @@ int smc_filter_describe(smc_filter* f, char* out, size_t n)
         if (f->a.mom) s += "+k_f_moments_partials+k_f_moments_final";
     } else if (f->strict) {
         if (f->strict_literal) s = std::string(f->two_level ? "k_reduce2+" : "") + "k_strict_W+k_strict_cdf+k_strict_search_S+k_propagate";
-        else if (f->two_level) s = std::string(f->two_level_mid ? "k_reduce2+" : "") + "k_strict_classify+k_strict_search+k_propagate";
+        else if (f->two_level) s = std::string(f->two_level_mid ? "k_reduce2+" : "") +
+                                   (f->strict_one_launch ? "k_strict_step[k_strict_classify+k_strict_search]" : "k_strict_classify+k_strict_search") + "+k_propagate";
         else s = "k_strict_W+k_sqx_classify+k_sqx_fill+k_strict_search_S+k_propagate";
     } else {
         if (f->two_level_mid) s = "k_reduce2+k_ancestors2";

@@ -44,11 +44,11 @@ struct SqxSrcFilter {
     }
 };
 
-template <bool MID>
-__global__ void __launch_bounds__(SMC_BLOCK)
-k_strict_classify(const FArgs av, const SqxArgs q)
+// FUSED (k_strict_step): the roundings' prefixes stay in pin_keep, the chain's results go out for the other workgroups of
+// the same launch.  Returns whether step t resamples (the same answer in every workgroup of the island); t_out = t.
+template <bool MID, bool FUSED>
+__device__ __forceinline__ bool strict_classify_part(const FArgs& a, const SqxArgs& q, u64* pin_keep, int& b_out, i64& t_out, u64* lds8k)
 {
-    const FArgs& a = av;
     __shared__ double s_max[SMC_NWAVE];
     __shared__ double s_esc[SMC_NWAVE];
     __shared__ double s_sum[3 * SMC_NWAVE];
@@ -83,12 +83,14 @@ k_strict_classify(const FArgs av, const SqxArgs q)
         smc_ld2g(ce + 2, eb[2], eb[3]);
     }
     const i64 t = (i64)smc_uniform(r0);
+    b_out = b;
+    t_out = t;
     if (t >= a.T) {
         if (!MID && b == 0 && tid == 0) info[0] = (double)t;   // k_propagate returns on it
-        return;
+        return false;
     }
-    if (t == 0) return;                                        // the host wrote the record of step 0
-    if (MID && smc_uniform(r1) == 0.0) return;                 // k_reduce2: step t does not resample
+    if (t == 0) return false;                                  // the host wrote the record of step 0
+    if (MID && smc_uniform(r1) == 0.0) return false;           // k_reduce2: step t does not resample
     const double Kb = smc_uniform(Kb_v);
     double e4[4], esum = 0.0;
     bool deep = false;                                         // a subnormal e: 2^-1022 and more below the tile's maximum
@@ -153,7 +155,7 @@ k_strict_classify(const FArgs av, const SqxArgs q)
         f2_finish(a, r);
         const bool resample = r.ess < a.ess_thresh;            // core.py:181-183 (t < T here)
         if (b == 0 && tid == 0) f2_write_record(a, isl, t, r, resample);
-        if (!resample) return;
+        if (!resample) return false;
         K = r.K;
         rs = r.rs;
         before = before * rs;
@@ -177,24 +179,34 @@ k_strict_classify(const FArgs av, const SqxArgs q)
     for (int w = 0; w < SMC_NWAVE; ++w) ebase += (w < wave) ? s_esc[w] : 0.0;
     const double run0 = before + ldexp(ebase + eexc, (int)dsc) * rs;
     SQX_STAMP(q, b, 1);
-    if (sqx_classify_tile(w4, run0, isl, b, q)) sqx_chain(src, isl, q);
+    if (sqx_classify_tile(w4, run0, isl, b, q, FUSED ? pin_keep : nullptr)) sqx_chain<SqxSrcFilter, FUSED>(src, isl, q, lds8k);
+    return true;
+}
+template <bool MID>
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_strict_classify(const FArgs av, const SqxArgs q)
+{
+    __shared__ u64 c_Pt[SEQ_TILE];
+    int b;
+    i64 t;
+    (void)strict_classify_part<MID, false>(av, q, nullptr, b, t, c_Pt);
 }
 
-__global__ void __launch_bounds__(SMC_BLOCK)
-k_strict_search(const FArgs av, const SqxArgs q)
+// FUSED: the step resamples and t is known (t_in); the chain's results are another workgroup's stores of this launch.
+template <bool FUSED>
+__device__ __forceinline__ void strict_search_part(const FArgs& a, const SqxArgs& q, const int b, const i64 t_in, const u64* pin_keep, double* sS)
 {
-    const FArgs& a = av;
-    __shared__ double sS[SEQ_TILE];
-    const int isl = (int)blockIdx.y, b = (int)blockIdx.x;
+    const int isl = (int)blockIdx.y;
     SQX_STAMP(q, q.ntiles + 8 + b, 0);
     const double* info = a.info + (i64)isl * INFO_STRIDE;
     // every load of the common path in one go: the record, what the tile's sums are staged from, the spacings' total
-    const double r0 = smc_ldg(info), r1 = smc_ldg(info + 1);
-    const SqxStage ld = sqx_stage_load(q, isl, b);
+    const double r0 = FUSED ? 0.0 : smc_ldg(info), r1 = FUSED ? 1.0 : smc_ldg(info + 1);
+    SqxStage ld;
+    if (!FUSED) ld = sqx_stage_load(q, isl, b);
     const bool zform = a.scheme == SMC_MULTINOMIAL_ && !a.ut && a.sp_tpw;
     const u64 zall = zform ? smc_ldg(a.E + (i64)isl * (a.ntiles1 + 1) + a.ntiles1) : 0ull;
-    const i64 t = (i64)smc_uniform(r0);
-    if (t >= a.T || t == 0 || smc_uniform(r1) == 0.0) return;
+    const i64 t = FUSED ? t_in : (i64)smc_uniform(r0);
+    if (!FUSED && (t >= a.T || t == 0 || smc_uniform(r1) == 0.0)) return;
     SmcSu su;
     u64 Us;
     f2_su(a, isl, t, su, Us);
@@ -206,7 +218,36 @@ k_strict_search(const FArgs av, const SqxArgs q)
         if (b < a.sp_nwg && threadIdx.x == 0) a.sst[(i64)isl * a.sp_nwg + b] = 0ull;
     }
     SQX_STAMP(q, q.ntiles + 8 + b, 1);
-    const double S_start = sqx_stage_tile(q, isl, b, ld, sS);
+    if (FUSED) ld = sqx_stage_wait(q, isl, b, pin_keep);      // (everything that does not need the chain is done: now wait for it)
+    const double S_start = sqx_stage_tile<FUSED>(q, isl, b, ld, sS);
     SQX_STAMP(q, q.ntiles + 8 + b, 2);
     sqx_search_tile<u32>(q, b, su, sS, S_start, f_A(a, t) + (i64)isl * a.N);
+}
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_strict_search(const FArgs av, const SqxArgs q)
+{
+    __shared__ double sS[SEQ_TILE];
+    strict_search_part<false>(av, q, (int)blockIdx.x, 0, nullptr, sS);
+}
+
+// ---- the two launches as ONE where every workgroup of the grid is resident at once (the host asks the runtime:
+// workgroups <= CUs x occupancy, smc_filter.hip) -- C2's 1024 tiles are.  A workgroup classifies its tile, takes its
+// ticket and, instead of ending, prepares its draws and then waits for ITS TILE's header from the island's chain (the
+// last workgroup to arrive runs it, as before); then it searches the same tile.  What that removes from the step: the
+// boundary between two dependent kernels (the second one's dispatch, its record and staging loads from a cold start),
+// and the round trip of the roundings' prefixes through memory (8 bytes per particle written and read back: they stay
+// in registers).  What the chain publishes for other workgroups of its own launch are 32-bit payloads under the
+// launch's 32-bit tag (sqx_put): each word is valid on its own, so the chain waits for no store to land and orders
+// nothing, and a waiting workgroup's poll IS the load of its header (sqx_stage_wait).
+template <bool MID>
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_strict_step(const FArgs av, const SqxArgs q)
+{
+    __shared__ double sS[SEQ_TILE];                            // (the chain's tile offsets first, then the tile's staged sums)
+    u64 pin[4];
+    int b;
+    i64 t;
+    if (!strict_classify_part<MID, true>(av, q, pin, b, t, reinterpret_cast<u64*>(sS))) return;
+    // (sS was the chain's scratch if this workgroup ran it: the barrier inside sqx_stage_wait is behind its last read)
+    strict_search_part<true>(av, q, b, t, pin, sS);
 }

@@ -53,12 +53,17 @@ struct SqxArgs {
     u64* hseg;                         // (islands, ntiles) head segment: max lower bound | min upper bound << 16
     u64* Pt;                           // (islands, ntiles + 1) exclusive prefix of Rt, [ntiles] = total
     u64* xraw;                         // (islands, SQX_CAP, 4) exceptions as the tiles append them
-    u64* xs;                           // (islands, SQX_CAP, 4) sorted: index, S bits, Pin, -
+    u64* xs;                           // (islands, SQX_CAP, 8) sorted: index, S bits, Pin | the same as five tagged words (fused launch)
+    u64* hdr;                          // (islands, 3, ntiles) fused launch: the tiles' headers as three arrays of tagged words
     int* xfirst;                       // (islands, ntiles + 1) first sorted exception at or behind each tile's start
     int* hE;                           // (islands, ntiles) header: biased exponent ...
     u64* hI;                           // ... and integer (implicit bit included) of the sum in front of the tile
     u64* ctr;                          // (islands, 4) exceptions appended | overflow | mode of the last run | its exceptions
     unsigned* tick;                    // (islands, SQX_CNT_WORDS) completion tickets
+    u64* done;                         // (2, islands) fused launch: - | workgroups that gave up waiting
+    int poll;                          // fused launch: the pause between two looks of a waiting workgroup, in units of ~0.1 us
+    u64 epoch;                         // fused launch: this launch's number; its low 32 bits (never 0) tag every word the chain
+                                       // publishes for the waiting workgroups, so that a word is either this launch's or ignored
     double* Sfull;                     // (islands, n) the exact path's sums (mode 1)
     u64* trace;                        // SMC_TRACE builds: (2 ntiles + 8, 8) shader-clock stamps (rows: classify per tile,
                                        // 8 rows of the chain, search per tile), else null
@@ -85,16 +90,29 @@ static inline SqxArgs sqx_carve(void* scratch, const i64 n, const int islands, s
     q.Pt = (u64*)p; p += M * (nt + 1) * 8;
     q.hI = (u64*)p; p += M * nt * 8;
     q.xraw = (u64*)p; p += M * SQX_CAP * 32;
-    q.xs = (u64*)p; p += M * SQX_CAP * 32;
+    q.xs = (u64*)p; p += M * SQX_CAP * 64;
     if (counters_at) *counters_at = (size_t)(p - (char*)scratch);
     q.ctr = (u64*)p; p += M * 4 * 8;
     q.tick = (unsigned*)p; p += M * SQX_CNT_WORDS * 4;
-    if (counters_bytes) *counters_bytes = M * (4 * 8 + SQX_CNT_WORDS * 4);
+    q.done = (u64*)p; p += 2 * M * 8;
+    q.epoch = 0ull;
+    q.poll = 4;
+    if (counters_bytes) *counters_bytes = M * (4 * 8 + SQX_CNT_WORDS * 4 + 2 * 8);
+    q.hdr = (u64*)p; p += M * nt * 32;
     q.xfirst = (int*)p; p += M * (nt + 1) * 4;
     q.hE = (int*)p; p += M * nt * 4;
     if (bytes) *bytes = (size_t)(p - (char*)scratch) + 64;
     return q;
 }
+// (a filter restored from another's state: the tags in it count the OTHER filter's launches)
+static inline void sqx_zero_done(hipStream_t st, void* scratch, const i64 n, const int islands)
+{
+    const SqxArgs q = sqx_carve(scratch, n, islands);
+    (void)hipMemsetAsync((void*)q.done, 0, (size_t)islands * 16, st);
+    (void)hipMemsetAsync((void*)q.hdr, 0, (size_t)islands * q.ntiles * 32, st);
+    (void)hipMemsetAsync((void*)q.xs, 0, (size_t)islands * SQX_CAP * 64, st);
+}
+
 // (the counters -- ctr, tick: one contiguous block -- must be zero before the first launch; the passes re-arm them)
 static inline size_t sqx_scratch_bytes(const i64 n, const int islands)
 {
@@ -107,8 +125,8 @@ static inline void sqx_zero_counters(hipStream_t st, void* scratch, const i64 n,
     size_t at = 0, nb = 0;
     (void)sqx_carve(scratch, n, islands, nullptr, &at, &nb);
     (void)hipMemsetAsync((char*)scratch + at, 0, nb, st);
+    sqx_zero_done(st, scratch, n, islands);
 }
-
 // ---- where the weights come from --------------------------------------------------------------------------------
 // an array (the stand-alone operators)
 struct SqxSrcArray {
@@ -165,11 +183,28 @@ __device__ __forceinline__ bool sqx_last_block(unsigned* cnt, const int b, const
     return *s_flag != 0;
 }
 
+// ---- one launch instead of two (k_strict_step, smc_filter_strict.h) ------------------------------------------------
+// XWG: what the chain writes is read by OTHER workgroups of the SAME launch.  A kernel boundary writes every L2 back and
+// invalidates it; inside a launch the eight XCDs' L2s are not coherent with each other for plain accesses, so these words
+// go out with agent-scope (write-through) stores and come in with agent-scope loads, as the tiles' reports to the chain
+// always did.
+#ifdef SMC_EMULATE
+__device__ __forceinline__ void sqx_release_all() {}
+#else
+__device__ __forceinline__ void sqx_release_all() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }   // (the exact path's S: plain stores)
+#endif
+
+// a word of the chain for the waiting workgroups: 32 bits of payload under the launch's tag -- it needs no ordering with
+// any other store, a reader takes it when the tag is this launch's and looks again otherwise
+__device__ __forceinline__ void sqx_put(u64* p, const u64 epoch, const u32 v) { smc_st_agent(p, (epoch << 32) | (u64)v); }
+__device__ __forceinline__ bool sqx_mine(const u64 w, const u64 epoch) { return (u32)(w >> 32) == (u32)epoch; }
+
 // ---- launch 1, per tile ------------------------------------------------------------------------------------------
 // w: this thread's weights 4 tid .. 4 tid + 3 of tile b (0 beyond n); run0: the estimate of the running sum in front of
 // the thread's first element.  Takes the workgroup's completion ticket (the Pin stores -- read by the next launch only --
 // are issued behind it, so that the ticket does not wait for them) and returns whether this workgroup is the island's last.
-__device__ __forceinline__ bool sqx_classify_tile(const double (&w)[4], const double run0, const int isl, const int b, const SqxArgs& q)
+__device__ __forceinline__ bool sqx_classify_tile(const double (&w)[4], const double run0, const int isl, const int b, const SqxArgs& q,
+                                                  u64* pin_keep = nullptr)    // (fused launch: Pin stays in the thread's registers)
 {
     __shared__ int s_flag;
     __shared__ u64 smu[SMC_NWAVE];
@@ -311,8 +346,13 @@ __device__ __forceinline__ bool sqx_classify_tile(const double (&w)[4], const do
     }
     SQX_STAMP(q, b, 4);
     const bool last = sqx_last_block(q.tick + (i64)isl * SQX_CNT_WORDS, b, q.ntiles, &s_flag);
-    smc_st2g(q.Pin + (i64)isl * q.ntiles * SEQ_TILE + i0, Pin[0], Pin[1]);
-    smc_st2g(q.Pin + (i64)isl * q.ntiles * SEQ_TILE + i0 + 2, Pin[2], Pin[3]);
+    if (pin_keep) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pin_keep[k] = Pin[k];
+    } else {
+        smc_st2g(q.Pin + (i64)isl * q.ntiles * SEQ_TILE + i0, Pin[0], Pin[1]);
+        smc_st2g(q.Pin + (i64)isl * q.ntiles * SEQ_TILE + i0 + 2, Pin[2], Pin[3]);
+    }
     SQX_STAMP(q, b, 5);
     return last;
 }
@@ -321,8 +361,9 @@ __device__ __forceinline__ bool sqx_classify_tile(const double (&w)[4], const do
 // One workgroup, on the critical path of the step: every global load it needs that does not depend on another is issued
 // up front (the counters, the first 1024 tiles' totals and head intervals, every slot of the exception list), so that the
 // whole function pays about three memory latencies; the walk reads (dP, W) pairs from LDS, branch-free.
-template <class Src>
-__device__ __forceinline__ void sqx_chain(const Src& src, const int isl, const SqxArgs& q)
+// c_Pt: 8 KB of LDS the caller can spare during the chain (the first 1024 tiles' offsets; larger islands keep the rest in memory)
+template <class Src, bool XWG = false>
+__device__ __forceinline__ void sqx_chain(const Src& src, const int isl, const SqxArgs& q, u64* c_Pt)
 {
     __shared__ u32 c_j[SQX_CAP];
     __shared__ u32 c_acc[SQX_CAP];
@@ -347,7 +388,8 @@ __device__ __forceinline__ void sqx_chain(const Src& src, const int isl, const S
     for (int k = 0; k < 4; ++k) {
         const int b = tid * 4 + k;
         rt0[k] = b < ntiles ? smc_ld_agent(q.Rt + (i64)isl * ntiles + b) : 0ull;
-        hs0[k] = b < ntiles ? smc_ld_agent(q.hseg + (i64)isl * ntiles + b) : (2047ull << 16);
+        const int bh = k * SMC_BLOCK + tid;                    // (the headers' mapping: tile 256 k + tid, see below)
+        hs0[k] = bh < ntiles ? smc_ld_agent(q.hseg + (i64)isl * ntiles + bh) : (2047ull << 16);
     }
     __syncthreads();                                           // (every thread has read the counters)
     SQX_STAMP(q, ntiles, 1);
@@ -370,14 +412,13 @@ __device__ __forceinline__ void sqx_chain(const Src& src, const int isl, const S
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int b = c0 + tid * 4 + k;
-                if (b < ntiles) Pt[b] = run;
-                if (c0 == 0) pt0[k] = run;
+                if (c0 == 0) { pt0[k] = run; c_Pt[tid * 4 + k] = run; }
+                else if (b < ntiles) Pt[b] = run;
                 run += rt[k];
             }
             carry += tot;
             __syncthreads();
         }
-        if (tid == 0) Pt[ntiles] = carry;
         SQX_STAMP(q, ntiles, 2);
         // ---- the exceptions in order of index (rank by counting: a few dozen of them)
         if (tid < cnt) c_j[tid] = (u32)e0;
@@ -385,7 +426,8 @@ __device__ __forceinline__ void sqx_chain(const Src& src, const int isl, const S
         int rank = 0;
         u64 Pg = 0ull;
         if (tid < cnt) {
-            Pg = e1 + Pt[(int)(e0 >> 10)];
+            const int xb = (int)(e0 >> 10);
+            Pg = e1 + (xb < 4 * SMC_BLOCK ? c_Pt[xb] : Pt[xb]);
             const u32 mine = (u32)e0;
             for (int m = 0; m < cnt; ++m) rank += c_j[m] < mine ? 1 : 0;
         }
@@ -395,7 +437,8 @@ __device__ __forceinline__ void sqx_chain(const Src& src, const int isl, const S
             c_P[rank] = Pg;
             c_w[rank] = __longlong_as_double((long long)e2);
             c_acc[rank] = (u32)e3;
-            q.xs[((i64)isl * SQX_CAP + rank) * 4 + 2] = e1;     // (Pin of the exception: launch 2 reads it)
+            // (the sorted list goes to memory behind the verdict: vmcnt counts stores too, and the barriers of this function
+            //  would each wait for the stores in front of them to land)
         }
         __syncthreads();
         SQX_STAMP(q, ntiles, 3);
@@ -410,23 +453,24 @@ __device__ __forceinline__ void sqx_chain(const Src& src, const int isl, const S
                 const u64 Pl = lane < cnt ? c_P[lane] : 0ull;
                 const u64 dPl = Pl - ((lane > 0 && lane < cnt) ? c_P[lane - 1] : 0ull);
                 const double wl = lane < cnt ? c_w[lane] : 0.0;
-                const bool head = cnt > 0 && c_j[0] == 0u;     // (s = W[0] starts the chain: not 0 + W[0])
+                const double dPd = (double)dPl;                // (exact below 2^53; beyond, the check below refuses the step)
                 double s = 0.0, Sl = 0.0;
 #ifndef SMC_EMULATE
                 asm volatile("" : "+v"(s));                    // (a vector value: see the scalar-register note below)
 #endif
-                // (a single wave issues every instruction of the loop back to back -- 28 of them cost 90 ns per exception;
-                //  the checks of the walk's assumptions are therefore NOT made here but afterwards, by every lane for
-                //  its own exception, from the sum its left neighbour recorded)
+                // (a single wave issues every instruction of the loop back to back: the integer form of the step --
+                //  unpack, 64-bit add, repack, 28 instructions -- cost 56 ns per exception.  The same value in floating
+                //  point: the run's integer times the unit in the last place of s, added to s -- EXACT whenever the step is
+                //  legitimate (the integer stays below 2^53 on the grid of a normal s: the product and the sum are then
+                //  representable), and where it is not the result does not matter: the checks of the walk's assumptions
+                //  are made afterwards, by every lane for its own exception from the sum its left neighbour recorded,
+                //  on the integers.  ulp(s) = (s with its fraction cleared) 2^-52, a multiplication the hardware does
+                //  exactly down to the subnormals; s = 0 gives 0 and W[0] starts the chain as 0 + W[0] = W[0].)
                 for (int i = 0; i < cnt; ++i) {
-                    const u64 dP = smc_readlane64(dPl, i);
+                    const double dP = smc_readlane_f64(dPd, i);
                     const double w = smc_readlane_f64(wl, i);
-                    const u64 sb = (u64)__double_as_longlong(s);
-                    const u32 hi = (u32)(sb >> 32), Es = hi >> 20;  // (s >= 0: no sign bit)
-                    const u32 mh = (hi & 0xfffffu) | ((Es < 1u ? Es : 1u) << 20);
-                    const u64 Iv = (((u64)mh << 32) | (u32)sb) + dP;
-                    s = __longlong_as_double((long long)(((u64)((Es << 20) | ((u32)(Iv >> 32) & 0xfffffu)) << 32) | (u32)Iv)) + w;
-                    if (i == 0 && head) s = w;
+                    const double g = __longlong_as_double(__double_as_longlong(s) & 0x7ff0000000000000ll) * 0x1.0p-52;
+                    s = fma(dP, g, s) + w;
                     Sl = lane == i ? s : Sl;
                 }
                 if (lane < cnt) c_S[lane] = Sl;
@@ -492,50 +536,101 @@ __device__ __forceinline__ void sqx_chain(const Src& src, const int isl, const S
                 for (int m = (tid > 2 ? tid - 2 : 0); m < cnt && m < tid + 3; ++m) printf("     x %d j %u S %a w %a acc [%u,%u] P %llu\n", m, c_j[m], c_S[m], c_w[m], c_acc[m] & 0xffffu, c_acc[m] >> 16, (unsigned long long)c_P[m]);
             }
 #endif
-            u64* o = q.xs + ((i64)isl * SQX_CAP + tid) * 4;
-            o[0] = (u64)c_j[tid];
-            o[1] = (u64)__double_as_longlong(c_S[tid]);
         }
         // (measured and dropped, r14: waves 1-3 looking their tiles' first exceptions up WHILE lane 0 walks -- their LDS
         //  traffic sits in front of the walk's reads, and three waves do four waves' work afterwards: 20.8 against 18.5 us)
+        // Thread tid takes tiles c0 + 256 k + tid, k = 0 .. 3: the lanes of a wave then write consecutive words of the header
+        // arrays (whole cache lines).  The fused launch keeps the words in registers until every check has passed.
+        u32 w0[4] = {0u, 0u, 0u, 0u}, w1[4] = {0u, 0u, 0u, 0u}, w2[4] = {0u, 0u, 0u, 0u};
         for (int c0 = 0; c0 < ntiles; c0 += 4 * SMC_BLOCK) {
             u64 hs[4], pt[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int b = c0 + tid * 4 + k;
+                const int b = c0 + k * SMC_BLOCK + tid;
                 hs[k] = c0 == 0 ? hs0[k] : (b < ntiles ? smc_ld_agent(q.hseg + (i64)isl * ntiles + b) : (2047ull << 16));
-                pt[k] = c0 == 0 ? pt0[k] : (b < ntiles ? Pt[b] : 0ull);
+                pt[k] = c0 == 0 ? c_Pt[k * SMC_BLOCK + tid] : (b < ntiles ? Pt[b] : 0ull);
             }
             // first exception with index >= each tile's start: four branch-free lower bounds side by side (the same
             // number of rounds for all, the LDS reads of a round independent)
             int lo[4] = {0, 0, 0, 0};
-            const u32 key0 = (u32)(c0 + tid * 4) << 10;         // (N < 2^32)
+            u32 key[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) key[k] = (u32)(c0 + k * SMC_BLOCK + tid) << 10;      // (N < 2^32)
             for (int n = cnt; n > 1;) {
                 const int half = n >> 1;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) lo[k] = c_j[lo[k] + half - 1] < key0 + ((u32)k << 10) ? lo[k] + half : lo[k];
+                for (int k = 0; k < 4; ++k) lo[k] = c_j[lo[k] + half - 1] < key[k] ? lo[k] + half : lo[k];
                 n -= half;
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int b = c0 + tid * 4 + k;
+                const int b = c0 + k * SMC_BLOCK + tid;
                 if (b >= ntiles) continue;
-                if (cnt > 0) lo[k] += c_j[lo[k]] < key0 + ((u32)k << 10) ? 1 : 0;
-                q.xfirst[(i64)isl * (ntiles + 1) + b] = lo[k];
+                if (cnt > 0) lo[k] += c_j[lo[k]] < key[k] ? 1 : 0;
                 const int qx = lo[k] - 1;
                 const double sb = qx < 0 ? 0.0 : c_S[qx];
                 const u32 e = (u32)seq_bexp(sb);
                 const bool badh = e < (u32)(hs[k] & 0xffffull) || e > (u32)(hs[k] >> 16);
                 if (badh) atomicOr(&c_why, 8u);                // a tile's head segment expected another binade
                 bad = bad || badh;
-                q.hE[(i64)isl * ntiles + b] = (int)e;
-                q.hI[(i64)isl * ntiles + b] = sqx_mant(sb) + (pt[k] - (qx < 0 ? 0ull : c_P[qx]));
+                const u64 hI = sqx_mant(sb) + (pt[k] - (qx < 0 ? 0ull : c_P[qx]));
+                if (c0 == 0) {                                 // (the first 1024 tiles' headers wait in registers for the verdict)
+                    int hi1 = lo[k];                            // first exception at or behind the NEXT tile's start
+                    if (XWG) while (hi1 < cnt && c_j[hi1] < key[k] + 1024u) ++hi1;
+                    w0[k] = (e << 18) | ((u32)lo[k] << 9) | (u32)hi1;
+                    w1[k] = (u32)hI;
+                    w2[k] = (u32)(hI >> 32);
+                } else {                                       // (larger islands, two launches: straight to memory)
+                    q.xfirst[(i64)isl * (ntiles + 1) + b] = lo[k];
+                    q.hE[(i64)isl * ntiles + b] = (int)e;
+                    q.hI[(i64)isl * ntiles + b] = hI;
+                }
             }
         }
-        if (tid == 0) q.xfirst[(i64)isl * (ntiles + 1) + ntiles] = cnt;
         if (bad) c_ok = 0;                                     // (benign race: every writer stores 0)
         __syncthreads();
         slow = c_ok == 0;
+        if (!XWG && !slow) {
+            if (tid == 0) q.xfirst[(i64)isl * (ntiles + 1) + ntiles] = cnt;
+            if (tid < cnt) {                                   // (this thread's exception: slot `rank` of the sorted list)
+                u64* o = q.xs + ((i64)isl * SQX_CAP + rank) * 8;
+                o[0] = e0 & 0xffffffffull;
+                o[1] = (u64)__double_as_longlong(c_S[rank]);
+                o[2] = e1;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int b = k * SMC_BLOCK + tid;
+                if (b >= ntiles) continue;
+                q.xfirst[(i64)isl * (ntiles + 1) + b] = (int)((w0[k] >> 9) & 0x1ffu);
+                q.hE[(i64)isl * ntiles + b] = (int)(w0[k] >> 18);
+                q.hI[(i64)isl * ntiles + b] = (u64)w1[k] | ((u64)w2[k] << 32);
+            }
+        }
+        if (XWG && !slow) {
+            // a header is what a waiting workgroup goes on: nothing was published before this point.  No load from memory
+            // and no barrier between or behind these stores -- vmcnt counts stores too, and a wait for anything then waits
+            // for every write-through store in flight to reach memory (5 us for the lot, measured).
+            if (tid == 0) { ctr[2] = 0ull; ctr[3] = cnt64; }
+            if (tid < cnt) {                                   // (this thread's exception: slot `rank` of the sorted list)
+                u64* o = q.xs + ((i64)isl * SQX_CAP + rank) * 8;
+                const u64 Sb = (u64)__double_as_longlong(c_S[rank]);
+                sqx_put(o + 3, q.epoch, (u32)e0);
+                sqx_put(o + 4, q.epoch, (u32)Sb);
+                sqx_put(o + 5, q.epoch, (u32)(Sb >> 32));
+                sqx_put(o + 6, q.epoch, (u32)e1);
+                sqx_put(o + 7, q.epoch, (u32)(e1 >> 32));
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int b = k * SMC_BLOCK + tid;
+                if (b >= ntiles) continue;
+                u64* h = q.hdr + (i64)isl * ntiles * 3 + b;
+                sqx_put(h, q.epoch, w0[k]);
+                sqx_put(h + ntiles, q.epoch, w1[k]);
+                sqx_put(h + 2 * (i64)ntiles, q.epoch, w2[k]);
+            }
+        }
     }
     if (slow) {
         // ---- the exact path: every tile by the workgroup, scan-until-exception (smc_seqsum.h)
@@ -553,6 +648,19 @@ __device__ __forceinline__ void sqx_chain(const Src& src, const int isl, const S
                 if (tid * 4 + k < m_all) So[lo + tid * 4 + k] = o4[k];
         }
     }
+    if (XWG && slow) {
+        // the waiting workgroups take the sums from memory: written back, then every tile's header says so (bit 31)
+        sqx_release_all();
+        smc_drain_stores();
+        __syncthreads();
+        for (int b = tid; b < ntiles; b += SMC_BLOCK) {
+            u64* h = q.hdr + (i64)isl * ntiles * 3 + b;
+            sqx_put(h, q.epoch, 0x80000000u);
+            sqx_put(h + ntiles, q.epoch, 0u);
+            sqx_put(h + 2 * (i64)ntiles, q.epoch, 0u);
+        }
+    }
+    if (XWG && !slow) { SQX_STAMP(q, ntiles, 5); return; }   // (a barrier here would wait for the published words to land)
     __syncthreads();
     if (tid == 0) { ctr[2] = slow ? (u64)(c_why ? c_why : 16u) : 0ull; ctr[3] = cnt64; }   // (mode word: 0, or why the exact path ran)
     SQX_STAMP(q, ntiles, 5);
@@ -578,8 +686,52 @@ __device__ __forceinline__ SqxStage sqx_stage_load(const SqxArgs& q, const int i
     smc_ld2g(q.Pin + (i64)isl * q.ntiles * SEQ_TILE + i0 + 2, st.Pin[2], st.Pin[3]);
     return st;
 }
+// The fused launch: the same from the tile's tagged header, WAITED for -- one lane polls the three words between
+// s_sleep's until all carry this launch's tag (the chain publishes them when every check has passed), the workgroup
+// takes them from LDS.  Two seconds without them (the exact path of a million weights takes four milliseconds) stop the
+// kernel with a trap rather than hang the device.  Every thread must call; a barrier inside.
+__device__ __forceinline__ SqxStage sqx_stage_wait(const SqxArgs& q, const int isl, const int b, const u64* pin_keep)
+{
+    __shared__ u64 s_h[3];
+    SqxStage st;
+#ifndef SMC_EMULATE
+    if (threadIdx.x == 0) {
+        const u64* h = q.hdr + (i64)isl * q.ntiles * 3 + b;
+        const u64 t0 = wall_clock64();                         // (100 MHz)
+        u64 w0, w1, w2;
+        // (a thousand workgroups wait while ONE works: polled back to back -- three loads every 50 ns each -- they took
+        //  the memory system from the chain, whose last two microseconds became twelve.  One word, a pause of
+        //  q.poll x 0.1 us between two looks; the other two words are there, or a look away, when the first is.)
+        for (;;) {
+            w0 = smc_ld_agent(h);
+            if (sqx_mine(w0, q.epoch)) {
+                w1 = smc_ld_agent(h + q.ntiles);
+                w2 = smc_ld_agent(h + 2 * (i64)q.ntiles);
+                if (sqx_mine(w1, q.epoch) && sqx_mine(w2, q.epoch)) break;
+            }
+            for (int i = 0; i < q.poll; ++i) __builtin_amdgcn_s_sleep(4);
+            if (wall_clock64() - t0 > 200000000ull) {
+                atomicAdd(reinterpret_cast<unsigned long long*>(q.done + gridDim.y + isl), 1ull);
+                __builtin_trap();
+            }
+        }
+        s_h[0] = w0; s_h[1] = w1; s_h[2] = w2;
+    }
+#endif
+    __syncthreads();
+    const u32 w0 = (u32)s_h[0];
+    st.mode = (u64)(w0 >> 31);
+    st.hE = (int)((w0 >> 18) & 0x7ffu);
+    st.xf0 = (int)((w0 >> 9) & 0x1ffu);
+    st.xf1 = (int)(w0 & 0x1ffu);
+    st.hI = (u64)(u32)s_h[1] | ((u64)(u32)s_h[2] << 32);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) st.Pin[k] = pin_keep[k];
+    return st;
+}
 // ... and sS[0 .. 1023] <- S_j of tile b (beyond n: the last sum); returns the sum in front of the tile (-inf for
 // tile 0).  Every thread must call; ends with a barrier.
+template <bool XWG = false>
 __device__ __forceinline__ double sqx_stage_tile(const SqxArgs& q, const int isl, const int b, const SqxStage& ld, double* sS)
 {
     __shared__ u64 s_x[3 * 64];                                // a batch of the tile's exceptions (index, S bits, Pin)
@@ -589,6 +741,9 @@ __device__ __forceinline__ double sqx_stage_tile(const SqxArgs& q, const int isl
     double S_start;
     if (mode != 0ull) {
         const double* Sf = q.Sfull + (i64)isl * (q.n + 8);
+#ifndef SMC_EMULATE
+        if (XWG) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (the chain released its plain stores: sqx_release_all)
+#endif
 #pragma unroll
         for (int k = 0; k < 4; ++k) sS[tid * 4 + k] = Sf[i0 + k < q.n ? i0 + k : q.n - 1];
         S_start = b ? Sf[j0 - 1] : -INFINITY;
@@ -605,7 +760,24 @@ __device__ __forceinline__ double sqx_stage_tile(const SqxArgs& q, const int isl
         for (int e0 = xf0; e0 < xf1; e0 += 64) {               // (uniform trip counts: the tile's exceptions, in order)
             const int ne = xf1 - e0 < 64 ? xf1 - e0 : 64;
             __syncthreads();
-            if (tid < 3 * ne) s_x[tid] = smc_ldg(q.xs + ((i64)isl * SQX_CAP + e0 + tid / 3) * 4 + tid % 3);
+            if (XWG) {
+                if (tid < ne) {                                // (five tagged words per exception: looked at until all are this launch's)
+                    const u64* x = q.xs + ((i64)isl * SQX_CAP + e0 + tid) * 8 + 3;
+                    u64 v[5];
+                    for (;;) {
+                        bool ok = true;
+#pragma unroll
+                        for (int m = 0; m < 5; ++m) { v[m] = smc_ld_agent(x + m); ok = ok && sqx_mine(v[m], q.epoch); }
+                        if (ok) break;
+                        smc_spin_pause();
+                    }
+                    s_x[3 * tid] = (u64)(u32)v[0];
+                    s_x[3 * tid + 1] = (u64)(u32)v[1] | ((u64)(u32)v[2] << 32);
+                    s_x[3 * tid + 2] = (u64)(u32)v[3] | ((u64)(u32)v[4] << 32);
+                }
+            } else if (tid < 3 * ne) {
+                s_x[tid] = smc_ldg(q.xs + ((i64)isl * SQX_CAP + e0 + tid / 3) * 8 + tid % 3);
+            }
             __syncthreads();
             for (int e = 0; e < ne; ++e) {
                 const i64 jx = (i64)s_x[3 * e];
@@ -899,7 +1071,8 @@ k_sqx_classify(const double* W, const double* tsum, const SqxArgs q, const SeqGa
     src.load4((i64)b * SEQ_TILE + (i64)tid * 4, w4);
     const double run0 = before + smc_block_exscan_pos_f64((w4[0] + w4[1]) + (w4[2] + w4[3]), smd, tot);
     __syncthreads();
-    if (sqx_classify_tile(w4, run0, isl, b, q)) sqx_chain(src, isl, q);
+    __shared__ u64 c_Pt[SEQ_TILE];
+    if (sqx_classify_tile(w4, run0, isl, b, q)) sqx_chain(src, isl, q, c_Pt);
 }
 static __global__ void __launch_bounds__(SMC_BLOCK)
 k_sqx_fill(const SqxArgs q, double* S, const SeqGate gate)

@@ -1048,6 +1048,30 @@ def check_strict_never_leaves_the_fast_path(cases, T=300):
         assert np.all(np.isfinite(pf.logLts_islands)) and worst <= 256, (N, scheme, model, worst)
 
 
+def check_strict_one_launch_equals_two(monkeypatch, cases, T=40):
+    """k_strict_step (SMC_PATH_STRICT_ONE_LAUNCH: classify, wait for the island's chain inside the launch, search -- where
+    the whole grid is resident) against the two launches of the default path: the same run, every array."""
+    yr = np.random.RandomState(6)
+    y = [np.array([v]) for v in 0.4 * np.cumsum(yr.standard_normal(T))]
+    for N, nisl, scheme, ESSrmin, expect_one in cases:
+        runs = []
+        for one in (False, True):
+            if one:
+                monkeypatch.setenv("SMC_STRICT_ONE_LAUNCH", "1")
+            pf = pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y), N=N, resampling=scheme, ESSrmin=ESSrmin, seed=31,
+                        strict_ancestors=True, collect="off", n_islands=nisl)
+            if one:
+                monkeypatch.delenv("SMC_STRICT_ONE_LAUNCH")
+            on_gpu = b"EMULATOR" not in _lib.lib().smc_version()       # (the emulator runs one workgroup at a time: two launches)
+            assert ("k_strict_step" in describe(pf)) == (expect_one and one and on_gpu), (N, nisl, describe(pf))
+            pf.step_async(T // 2)
+            pf.run()
+            runs.append((np.array(pf.X), np.array(pf.A), pf.logLts_islands.copy(), pf._summ()[:, :, 4].copy()))
+        assert runs[0][3][:, 1:].sum() >= 2
+        for a, b in zip(runs[0], runs[1]):
+            assert np.array_equal(a, b), (N, nisl, scheme)
+
+
 def check_seq_prefix_sums(sizes=(5000, 1 << 14, 20001), monkeypatch=None):
     """csrc/smc_seqsum.h: the reference's sequential fp64 prefix sums (resampling.py:506-508: s = W[0]; s += W[j])
     computed in parallel must be THE SAME DOUBLES as the loop's, whatever the weights: the element-level pass (mode 0),

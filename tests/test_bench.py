@@ -147,7 +147,7 @@ def test_fractions_are_reproducible_from_profiles():
                 or n_.replace("void ", "").split("<")[0].split("(")[0] == mv]
         assert any(abs(a - d["avg_us"]) < 5e-4 for a in avgs), (f, avgs, d["avg_us"])
         N, isl, dd = wl["N"], wl["islands"], wl["d"]
-        two = any(k in " ".join(rec["kernels"]) for k in ("k_ancestors2", "k_strict_classify"))
+        two = any(k in " ".join(rec["kernels"]) for k in ("k_ancestors2", "k_strict_classify", "k_strict_step"))
         rf = {"kernel": mv, "bound": "hbm", "launch_bytes": (16.0 * dd + 16.0 + (8.0 if two else 0.0)) * N * isl}
         if cfg["workload"] == "c4":
             rf.update(bound="mfma", launch_flop=(44 if cfg.get("collapsed") else 72) * 2048.0 / 16.0 * N * isl)

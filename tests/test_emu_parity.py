@@ -300,6 +300,10 @@ def test_strict_ancestors_heavy_parents():
                                   T=5, ESSrmin=1.0, replays=(False,))
 
 
+def test_strict_one_launch_switch(monkeypatch):
+    pc.check_strict_one_launch_equals_two(monkeypatch, [(3000, 2, "systematic", 0.5, True)], T=12)
+
+
 def test_strict_verifies_every_step():
     pc.check_strict_never_leaves_the_fast_path([(3000, 8, "systematic", "toy", 0.5), (2500, 4, "multinomial", "sv", 1.0)], T=120)
 

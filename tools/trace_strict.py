@@ -54,4 +54,8 @@ print("latest tickets (workgroup: start, reduced, ticket us):",
         round((int(rows[i, 5]) - int(t00)) / 100.0, 2)) for i in late])
 t0 = show("k_strict_classify", st[:nt], ["start", "reduced: K, s, before", "classified", "prefixes", "published", "ticket taken"])
 show("  the island's chain (last workgroup)", st[nt:nt + 1], ["start", "loads back", "tile prefixes", "sorted", "walked", "end"], t0)
-show("k_strict_search", st[nt + 8:], ["start", "record + su", "tile staged", "range known", "end", "last pass: thresholds", "last pass: bisected"])
+desc = ctypes.create_string_buffer(256)
+_lib.check(lib.smc_filter_describe(pf._f, desc, 256))
+one = b"k_strict_step" in desc.value
+print("(%s)" % desc.value.decode())
+show("k_strict_search" + (" (same launch: times from the launch's first stamp)" if one else ""), st[nt + 8:], ["start", "record + su", "tile staged", "range known", "end", "last pass: thresholds", "last pass: bisected"], t0 if one else None)
