@@ -1676,20 +1676,44 @@ __device__ __forceinline__ double f2_log_mean(const FArgs& a, const F2Red& r)
     if (r.bad) return NAN;
     return r.K * 6.93147180369123816490e-01 + (r.K * 1.90821492927058770002e-10 + log(r.s / (double)a.N));
 }
+// What the record of step t takes from memory (earlier launches wrote all of it): requested in ONE go, and early -- the
+// writer is one thread of one workgroup, and written as "load, use, store, load ..." its five loads were five round trips
+// in a row (a store may alias the next load, so the compiler keeps the order; vmcnt counts stores, so every wait for a load
+// also waited for the stores in front of it): 2 us during which that workgroup's other threads stood at the next barrier,
+// in a kernel that takes 6.5 us because its slowest workgroup does.
+struct F2RecIn {
+    double row4, lm_prev, cum_prev, y, aux;
+};
+__device__ __forceinline__ F2RecIn f2_record_loads(const FArgs& a, const int isl, const i64 t, const bool row_only = false)
+{
+    F2RecIn in;
+    const double* row = a.summ + ((i64)isl * (a.T + 1) + (t - 1)) * SUMM_STRIDE;
+    const bool first = t == 1;
+    in.row4 = smc_ldg(row + 4);
+    in.lm_prev = first ? 0.0 : smc_ldg(row + 1 - SUMM_STRIDE);
+    in.cum_prev = first ? 0.0 : smc_ldg(row + 3 - SUMM_STRIDE);
+    in.y = row_only ? 0.0 : smc_ldg(a.y + t * a.dy);          // (row_only: the last row, t = T -- there is no y_T)
+    in.aux = (a.aux && !row_only) ? smc_ldg(a.aux + t) : 0.0;
+    return in;
+}
 // summary row of step ts (the step the partials belong to) -- core.py:355-359
-__device__ __forceinline__ void f2_write_row(const FArgs& a, const int isl, const i64 ts, const F2Red& r)
+__device__ __forceinline__ void f2_write_row(const FArgs& a, const int isl, const i64 ts, const F2Red& r, const F2RecIn& in)
 {
     double* row = a.summ + ((i64)isl * (a.T + 1) + ts) * SUMM_STRIDE;
     const bool first = (ts == 0);
-    const bool resampled = row[4] != 0.0;              // written when step ts was decided
+    const bool resampled = in.row4 != 0.0;             // written when step ts was decided
     const double log_mean = f2_log_mean(a, r);
-    const double loglt = (first || resampled) ? log_mean : log_mean - row[1 - SUMM_STRIDE];
+    const double loglt = (first || resampled) ? log_mean : log_mean - in.lm_prev;
     row[0] = r.ess;
     row[1] = log_mean;
     row[2] = loglt;
-    row[3] = (first ? 0.0 : row[3 - SUMM_STRIDE]) + loglt;
+    row[3] = (first ? 0.0 : in.cum_prev) + loglt;
     row[5] = r.K;                                      // W = p 2^(k - K) / s  (k_f_write_W)
     row[6] = r.rs;
+}
+__device__ __forceinline__ void f2_write_row(const FArgs& a, const int isl, const i64 ts, const F2Red& r)
+{
+    f2_write_row(a, isl, ts, r, f2_record_loads(a, isl, ts + 1, true));
 }
 
 // the sorted uniforms of step t (systematic: the one draw; stratified: read per offspring);
@@ -2091,17 +2115,22 @@ __device__ __forceinline__ void f2_first_offspring(const FArgs& a, const SmcSu& 
 
 // the decision of step t and what k_propagate(t) reads (one thread)
 __device__ __forceinline__ void f2_write_record(const FArgs& a, const int isl, const i64 t, const F2Red& r,
-                                                const bool resample)
+                                                const bool resample, const F2RecIn& in)
 {
     double* info = a.info + (i64)isl * INFO_STRIDE;
-    f2_write_row(a, isl, t - 1, r);
+    f2_write_row(a, isl, t - 1, r, in);
     a.summ[((i64)isl * (a.T + 1) + t) * SUMM_STRIDE + 4] = resample ? 1.0 : 0.0;
     info[0] = (double)t;
     info[1] = resample ? 1.0 : 0.0;
-    info[2] = a.y[t * a.dy];
+    info[2] = in.y;
     info[3] = r.K;
     info[4] = r.rs;
-    info[5] = a.aux ? a.aux[t] : 0.0;
+    info[5] = in.aux;
+}
+__device__ __forceinline__ void f2_write_record(const FArgs& a, const int isl, const i64 t, const F2Red& r,
+                                                const bool resample)
+{
+    f2_write_record(a, isl, t, r, resample, f2_record_loads(a, isl, t));
 }
 // APF: the row of step t-1 comes from the PLAIN weights (evidence, logged ESS, W), the decision
 // and the shares from the auxiliary ones; the constant the weights are reset to,
@@ -2111,14 +2140,15 @@ __device__ __forceinline__ void f2_write_record_apf(const FArgs& a, const int is
                                                     const bool resample)
 {
     double* info = a.info + (i64)isl * INFO_STRIDE;
-    f2_write_row(a, isl, t - 1, r_plain);
+    const F2RecIn in = f2_record_loads(a, isl, t);
+    f2_write_row(a, isl, t - 1, r_plain, in);
     a.summ[((i64)isl * (a.T + 1) + t) * SUMM_STRIDE + 4] = resample ? 1.0 : 0.0;
     info[0] = (double)t;
     info[1] = resample ? 1.0 : 0.0;
-    info[2] = a.y[t * a.dy];
+    info[2] = in.y;
     info[3] = r_aux.K;
     info[4] = r_aux.rs;
-    info[5] = a.aux ? a.aux[t] : 0.0;
+    info[5] = in.aux;
     info[6] = (r_aux.K - r_plain.K) * 6.93147180559945286227e-01 + log(r_aux.s / r_plain.s);
 }
 // The island's reduction by ONE workgroup for any number of tiles, in chunks of 1024 partials
@@ -2234,6 +2264,8 @@ __device__ __forceinline__ int f2_reduce2_island(const FArgs& a, const int isl, 
         return -1;
     }
     if (t == 0) return -1;
+    F2RecIn rin = {0.0, 0.0, 0.0, 0.0, 0.0};                   // (what the record's writer reads: on its way during the reduction)
+    if (tid == 0 && !a.pm2) rin = f2_record_loads(a, isl, t);
     const i64 o = (i64)isl * a.nparts;
     const bool pvec = (a.nparts & 3) == 0;
     const int nchunks = (a.nparts + 4 * SMC_BLOCK - 1) / (4 * SMC_BLOCK);
@@ -2248,7 +2280,7 @@ __device__ __forceinline__ int f2_reduce2_island(const FArgs& a, const int isl, 
             const F2Red r2 = f2_reduce_island(a, isl, sme, true);
             if (tid == 0) f2_write_record_apf(a, isl, t, r, r2, resample);
         } else if (tid == 0) {
-            f2_write_record(a, isl, t, r, resample);
+            f2_write_record(a, isl, t, r, resample, rin);
         }
         if (!resample) return 0;
         // every tile's share and the shares before it.  The chunks' four scans share ONE exchange (wave scans of
@@ -2307,7 +2339,7 @@ __device__ __forceinline__ int f2_reduce2_island(const FArgs& a, const int isl, 
         const F2Red r2 = f2_reduce_island(a, isl, sme, true);
         if (tid == 0) f2_write_record_apf(a, isl, t, r, r2, resample);
     } else if (tid == 0) {
-        f2_write_record(a, isl, t, r, resample);
+        f2_write_record(a, isl, t, r, resample, rin);
     }
     if (!resample) return 0;
     // every tile's share and the shares before it, chunk by chunk (a running carry across chunks)
@@ -2428,6 +2460,8 @@ k_ancestors2(const FArgs av)
         return;
     }
     if (t == 0) return;                                        // the host wrote the record of step 0
+    F2RecIn rin = {0.0, 0.0, 0.0, 0.0, 0.0};                   // (what the record's writer reads: on its way during the reduction)
+    if (!MID && b == 0 && tid == 0) rin = f2_record_loads(a, isl, t);
     if (MID && smc_uniform(r1) == 0.0) return;                 // k_reduce2: step t does not resample
     F_STAMP_A(1);
     SmcSu su;                                                  // (the step's uniform: one Philox call,
@@ -2471,7 +2505,7 @@ k_ancestors2(const FArgs av)
         r.ss = s2;
         f2_finish(a, r);
         const bool resample = r.ess < a.ess_thresh;            // core.py:181-183 (t < T here)
-        if (b == 0 && tid == 0) f2_write_record(a, isl, t, r, resample);
+        if (b == 0 && tid == 0) f2_write_record(a, isl, t, r, resample, rin);
         F_STAMP_A(3);
         if (!resample) return;
         // ---- this tile's share Q_b of the 2^52 scale and the shares before it, G_b

@@ -91,6 +91,8 @@ __device__ __forceinline__ bool strict_classify_part(const FArgs& a, const SqxAr
     }
     if (t == 0) return false;                                  // the host wrote the record of step 0
     if (MID && smc_uniform(r1) == 0.0) return false;           // k_reduce2: step t does not resample
+    F2RecIn rin = {0.0, 0.0, 0.0, 0.0, 0.0};                   // (what the record's writer reads: on its way during the reduction)
+    if (!MID && b == 0 && tid == 0) rin = f2_record_loads(a, isl, t);
     const double Kb = smc_uniform(Kb_v);
     double e4[4], esum = 0.0;
     bool deep = false;                                         // a subnormal e: 2^-1022 and more below the tile's maximum
@@ -105,6 +107,9 @@ __device__ __forceinline__ bool strict_classify_part(const FArgs& a, const SqxAr
     //  weights rise steeply, the head of every array, and then sends the step to the exact path)
     const double eexc = smc_dpp_f64<SMC_DPP_WAVE_SHR1, 0xf, false>(einc);
     double K, rs, before = 0.0;
+    F2Red rec;                                                 // (!MID: the step's record, written by tile 0's workgroup at its end)
+    rec.K = rec.s = rec.ss = rec.ess = rec.rs = rec.log_mean = 0.0;
+    rec.bad = false;
     if (MID) {
         K = smc_uniform(r3);
         rs = smc_uniform(r4);
@@ -154,8 +159,13 @@ __device__ __forceinline__ bool strict_classify_part(const FArgs& a, const SqxAr
         r.ss = s2;
         f2_finish(a, r);
         const bool resample = r.ess < a.ess_thresh;            // core.py:181-183 (t < T here)
-        if (b == 0 && tid == 0) f2_write_record(a, isl, t, r, resample);
-        if (!resample) return false;
+        // (the record is read by the NEXT launch: its stores go out behind the tile's ticket, not in front of the barriers
+        //  on the way to it -- tile 0 carries the head of the array, a dozen exceptions, and is among the last to arrive)
+        if (!resample) {
+            if (b == 0 && tid == 0) f2_write_record(a, isl, t, r, false, rin);
+            return false;
+        }
+        rec = r;
         K = r.K;
         rs = r.rs;
         before = before * rs;
@@ -179,7 +189,9 @@ __device__ __forceinline__ bool strict_classify_part(const FArgs& a, const SqxAr
     for (int w = 0; w < SMC_NWAVE; ++w) ebase += (w < wave) ? s_esc[w] : 0.0;
     const double run0 = before + ldexp(ebase + eexc, (int)dsc) * rs;
     SQX_STAMP(q, b, 1);
-    if (sqx_classify_tile(w4, run0, isl, b, q, FUSED ? pin_keep : nullptr)) sqx_chain<SqxSrcFilter, FUSED>(src, isl, q, lds8k);
+    const bool last = sqx_classify_tile(w4, run0, isl, b, q, FUSED ? pin_keep : nullptr);
+    if (!MID && b == 0 && tid == 0) f2_write_record(a, isl, t, rec, true, rin);
+    if (last) sqx_chain<SqxSrcFilter, FUSED>(src, isl, q, lds8k);
     return true;
 }
 template <bool MID>

@@ -117,6 +117,8 @@ k_ancestors2w(const double* __restrict__ pre_info2, const double* __restrict__ p
         return;
     }
     if (t == 0) return;                                        // the host wrote the record of step 0
+    F2RecIn rin = {0.0, 0.0, 0.0, 0.0, 0.0};                   // (what the record's writer reads: on its way during the reduction)
+    if (blockIdx.x == 0 && tid == 0) rin = f2_record_loads(a, isl, t);
     F_STAMP_A(1);
     SmcSu su;                                                  // (the step's uniform: one Philox call,
     u64 Us;                                                    //  all inputs uniform: scalar unit)
@@ -156,7 +158,7 @@ k_ancestors2w(const double* __restrict__ pre_info2, const double* __restrict__ p
         r.ss = s2;
         f2_finish(a, r);
         const bool resample = r.ess < a.ess_thresh;            // core.py:181-183 (t < T here)
-        if (blockIdx.x == 0 && tid == 0) f2_write_record(a, isl, t, r, resample);
+        if (blockIdx.x == 0 && tid == 0) f2_write_record(a, isl, t, r, resample, rin);
         if (tid == 0) s_dec = resample ? 1 : 0;
         // ---- the shares Q_b of this workgroup's tiles and the shares before each of them: ONE scan of the
         // threads' sums (integers below 2^53: every association gives the same doubles), from which the thread

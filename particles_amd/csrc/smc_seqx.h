@@ -324,15 +324,17 @@ __device__ __forceinline__ bool sqx_classify_tile(const double (&w)[4], const do
             if (cl != 0u || ch != 2047u) { atomicMax(&s_lo[cs], cl); atomicMin(&s_hi[cs], ch); }
         }
     }
+    if (tid == 0) s_base = base_t0;
+    __syncthreads();                                           // (the slots are final, s_base is set)
+    // (every store that must reach memory before the ticket is issued BEHIND this barrier: vmcnt counts stores, and a
+    //  barrier with the tile total's write-through store in front of it waited a microsecond for that store to land --
+    //  in every workgroup, on the path to the island's chain)
+    const u32 base = s_base;
     if (tid == 0) {
-        const u32 base = base_t0;
-        s_base = base;
         if (tile_over || base + xtot > (u32)SQX_CAP) smc_st_agent(q.ctr + (i64)isl * 4 + 1, 1ull);
         smc_st_agent(q.Rt + (i64)isl * q.ntiles + b, rtot);
+        smc_st_agent(q.hseg + (i64)isl * q.ntiles + b, (u64)s_lo[0] | ((u64)s_hi[0] << 16));
     }
-    __syncthreads();                                           // (the slots are final, s_base is set)
-    if (tid == 0) smc_st_agent(q.hseg + (i64)isl * q.ntiles + b, (u64)s_lo[0] | ((u64)s_hi[0] << 16));
-    const u32 base = s_base;
     if (!tile_over && base + xtot <= (u32)SQX_CAP) {
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -345,6 +347,10 @@ __device__ __forceinline__ bool sqx_classify_tile(const double (&w)[4], const do
             }
     }
     SQX_STAMP(q, b, 4);
+    if (xtot) {                                                // (uniform: the exceptions' words are other threads' stores --
+        smc_drain_stores();                                    //  landed before thread 0 takes the ticket)
+        __syncthreads();
+    }
     const bool last = sqx_last_block(q.tick + (i64)isl * SQX_CNT_WORDS, b, q.ntiles, &s_flag);
     if (pin_keep) {
 #pragma unroll
