@@ -32,6 +32,16 @@
 //     su_n <= S_j, the reference's strict `>` advance.  S never exists in HBM.  (k_sqx_fill writes it, for
 //     smc_seq_prefix_sums and the tests.)
 //
+//   (one launch, k_strict_step in smc_filter_strict.h, behind SMC_PATH_STRICT_ONE_LAUNCH: the workgroups of launch 1 stay,
+//    wait for the chain and do launch 2's work on their own tile -- what the chain then publishes are tagged 32-bit words,
+//    sqx_put / sqx_stage_wait below.  Measured equal to the two launches; see smc_filter.hip for why it is off.)
+//
+// Two things about this hardware that shaped the code: (1) vmcnt counts STORES as well as loads, and a barrier's fence
+// waits for vmcnt(0) -- a store that has to reach memory (agent scope: the tiles' reports, the fused launch's words) holds
+// up the next barrier or load wait of its wave for a microsecond, so such stores are issued BEHIND the last barrier that
+// does not need them; (2) one wave alone issues an instruction every few cycles at best -- the walk is as long as its
+// instruction count, which is why it is done in floating point (sqx_chain).
+//
 // Why the result is the reference's, not an approximation: the estimate only PROPOSES a grid per element; everything
 // the fast path assumes -- the binade of the true sum in front of every run of regular elements, the integer staying
 // inside that binade to the end of the run -- is checked against the exactly walked sums before any ancestor is
@@ -405,7 +415,7 @@ __device__ __forceinline__ void sqx_chain(const Src& src, const int isl, const S
     const int cnt = slow ? 0 : (int)cnt64;
     if (!slow) {
         // ---- P offsets of the tiles: thread tid owns tiles 4 tid .. 4 tid + 3 of every chunk of 1024
-        u64 carry = 0ull, pt0[4] = {0ull, 0ull, 0ull, 0ull};
+        u64 carry = 0ull;
         for (int c0 = 0; c0 < ntiles; c0 += 4 * SMC_BLOCK) {
             u64 rt[4];
 #pragma unroll
@@ -418,7 +428,7 @@ __device__ __forceinline__ void sqx_chain(const Src& src, const int isl, const S
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int b = c0 + tid * 4 + k;
-                if (c0 == 0) { pt0[k] = run; c_Pt[tid * 4 + k] = run; }
+                if (c0 == 0) c_Pt[tid * 4 + k] = run;
                 else if (b < ntiles) Pt[b] = run;
                 run += rt[k];
             }
