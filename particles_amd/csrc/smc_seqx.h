@@ -36,10 +36,11 @@
 //    wait for the chain and do launch 2's work on their own tile -- what the chain then publishes are tagged 32-bit words,
 //    sqx_put / sqx_stage_wait below.  Measured equal to the two launches; see smc_filter.hip for why it is off.)
 //
-// Two things about this hardware that shaped the code: (1) vmcnt counts STORES as well as loads, and a barrier's fence
-// waits for vmcnt(0) -- a store that has to reach memory (agent scope: the tiles' reports, the fused launch's words) holds
-// up the next barrier or load wait of its wave for a microsecond, so such stores are issued BEHIND the last barrier that
-// does not need them; (2) one wave alone issues an instruction every few cycles at best -- the walk is as long as its
+// Two things about this hardware that shaped the code: (1) vmcnt counts STORES as well as loads and retires in order --
+// the next wait for ANY load (or an explicit drain) also waits for every store issued before it, and a store that has to
+// reach memory (agent scope: the tiles' reports, the fused launch's words) takes about a microsecond to do so; such
+// stores are therefore issued behind the last load their wave waits for (barriers themselves wait for LDS only);
+// (2) one wave alone issues an instruction every few cycles at best -- the walk is as long as its
 // instruction count, which is why it is done in floating point (sqx_chain).
 //
 // Why the result is the reference's, not an approximation: the estimate only PROPOSES a grid per element; everything
@@ -336,9 +337,8 @@ __device__ __forceinline__ bool sqx_classify_tile(const double (&w)[4], const do
     }
     if (tid == 0) s_base = base_t0;
     __syncthreads();                                           // (the slots are final, s_base is set)
-    // (every store that must reach memory before the ticket is issued BEHIND this barrier: vmcnt counts stores, and a
-    //  barrier with the tile total's write-through store in front of it waited a microsecond for that store to land --
-    //  in every workgroup, on the path to the island's chain)
+    // (every store that must reach memory before the ticket, issued together: the drain in front of the ticket then
+    //  covers one round trip to memory, not two in a row)
     const u32 base = s_base;
     if (tid == 0) {
         if (tile_over || base + xtot > (u32)SQX_CAP) smc_st_agent(q.ctr + (i64)isl * 4 + 1, 1ull);
@@ -453,8 +453,8 @@ __device__ __forceinline__ void sqx_chain(const Src& src, const int isl, const S
             c_P[rank] = Pg;
             c_w[rank] = __longlong_as_double((long long)e2);
             c_acc[rank] = (u32)e3;
-            // (the sorted list goes to memory behind the verdict: vmcnt counts stores too, and the barriers of this function
-            //  would each wait for the stores in front of them to land)
+            // (the sorted list goes to memory behind the verdict: vmcnt counts stores too, and any wait for a load between
+            //  here and there would also wait for these stores to land)
         }
         __syncthreads();
         SQX_STAMP(q, ntiles, 3);
@@ -625,7 +625,7 @@ __device__ __forceinline__ void sqx_chain(const Src& src, const int isl, const S
         }
         if (XWG && !slow) {
             // a header is what a waiting workgroup goes on: nothing was published before this point.  No load from memory
-            // and no barrier between or behind these stores -- vmcnt counts stores too, and a wait for anything then waits
+            // between or behind these stores -- vmcnt counts stores too, and a wait for any load then waits
             // for every write-through store in flight to reach memory (5 us for the lot, measured).
             if (tid == 0) { ctr[2] = 0ull; ctr[3] = cnt64; }
             if (tid < cnt) {                                   // (this thread's exception: slot `rank` of the sorted list)
