@@ -197,6 +197,10 @@ int smc_copy_strided(smc_ctx* ctx, const double* src, int64_t src_stride, double
  *   (randomised QMC; shift = 0 when scramble == 0), then rqmc.safe_generate's map
  *   0.5 + (1 - 1e-10) (u - 0.5) when safe != 0.  d <= 10.  out (N, d) row-major. */
 int smc_argsort(smc_ctx* ctx, const double* x, int64_t N, int64_t* out);
+/* Test access: the radix sort behind smc_argsort / smc_hilbert_sort / smc_wquantiles / the fused SQMC step takes four
+ * passes over the 32 bits below the keys' highest varying bit plus a fix-up (instead of eight passes over all 64) from n
+ * keys on (default 133 120; never below 8 193).  Process-wide; the results are the same permutation either way. */
+int smc_debug_sort_window_min(long long n);
 /* hilbert_sort (hilbert.py:33-58) of N vectors x (N, d), 2 <= d <= 16: standardise each
  * component (np.mean / np.std over the particles), logistic map to (0,1), scale to integers
  * below floor(2^(62/d)), Hilbert index of each point (Witham's codec, hilbert.py:61-292,

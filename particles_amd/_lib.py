@@ -108,6 +108,7 @@ SIGNATURES = {
     "smc_copy_strided": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64]),
     "smc_normal_ppf": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp]),
     "smc_argsort": (c_int, [c_vp, c_vp, c_i64, c_vp]),
+    "smc_debug_sort_window_min": (c_int, [ctypes.c_longlong]),
     "smc_hilbert_array": (c_int, [c_vp, c_vp, c_i64, ctypes.c_int32, c_vp]),
     "smc_hilbert_sort": (c_int, [c_vp, c_vp, c_i64, ctypes.c_int32, c_vp, c_vp]),
     "smc_sobol": (c_int, [c_vp, c_i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_u64, c_vp]),

@@ -33,6 +33,7 @@ struct smc_filter {
     bool strict;           // SMC_FLAG_STRICT_ANCESTORS: sequential fp64 CDF of the filter's weights
     double* strict_ws;     // (n_islands, N) W | (n_islands, N) S | scratch of smc_seqsum.h
     bool strict_literal;   // SMC_PATH_STRICT_LITERAL: S by the one-lane walk, in place
+    bool sq_plan_zero;     // SQMC: the sort workspace's plan words are zero (smc_rs_sort_ws leaves them so)
     bool strict_one_launch; // classify + search as ONE launch (k_strict_step): every workgroup of the grid resident at once
     unsigned long long strict_epoch;   // ... its launches, numbered (SqxArgs::epoch)
     // SMC_FLAG_SQMC (smc_filter_sqmc.h): the point stream, the tape of ndtri(second coordinate), the
@@ -190,7 +191,8 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
             const u64 *perm = f->sq_perm, *skeys = nullptr;
             for (int i = 0; i < a.n_islands; ++i) {        // h_order = argsort(X_{t-1}) (hilbert.py:52-54, d = 1)
                 u64 *k0 = nullptr, *v0 = nullptr;
-                (void)smc_rs_sort_ws(f->ctx, f_X(a, t - 1) + (i64)i * a.N, nullptr, a.N, 0, f->sq_ws, recompute ? &k0 : nullptr, &v0);
+                (void)smc_rs_sort_ws(f->ctx, f_X(a, t - 1) + (i64)i * a.N, nullptr, a.N, 0, f->sq_ws, recompute ? &k0 : nullptr, &v0, f->sq_plan_zero);
+                f->sq_plan_zero = true;               // (every sort leaves its plan words zeroed for the next)
                 if (a.n_islands == 1) { perm = v0; skeys = k0; }
                 else (void)hipMemcpyAsync(f->sq_perm + (i64)i * a.N, v0, (size_t)a.N * 8, hipMemcpyDeviceToDevice, st);
             }
@@ -413,7 +415,8 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
                 i64* perm = (i64*)f->sq_perm + (size_t)i * a.N;
                 if (d == 1) {                      // hilbert.py:52-54: argsort
                     u64* v0 = nullptr;
-                    (void)smc_rs_sort_ws(f->ctx, f_X(a, t - 1) + (size_t)i * a.N, nullptr, a.N, 0, (void*)(lws + a.N), nullptr, &v0);
+                    (void)smc_rs_sort_ws(f->ctx, f_X(a, t - 1) + (size_t)i * a.N, nullptr, a.N, 0, (void*)(lws + a.N), nullptr, &v0, f->sq_plan_zero);
+                    f->sq_plan_zero = true;
                     (void)hipMemcpyAsync(perm, v0, (size_t)a.N * 8, hipMemcpyDeviceToDevice, st);
                 } else {
                     (void)smc_hilbert_sort(f->ctx, f_X(a, t - 1) + (size_t)i * a.N * d, a.N, d, (int64_t*)perm, nullptr);
@@ -764,6 +767,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     // nprocs = 2 on one GPU) each get part of the CUs, and two such kernels would wait for each other's slots.  Off by default.
     // (Not inside replayed graphs either: the epoch is a kernel argument.)
     f->strict_one_launch = false;
+    f->sq_plan_zero = false;
     f->strict_epoch = 0ull;
 #ifndef SMC_EMULATE
     if (f->strict && f->two_level && !f->strict_literal && !o->use_graph && ((uint32_t)o->flags & SMC_PATH_STRICT_ONE_LAUNCH)) {

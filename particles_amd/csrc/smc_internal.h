@@ -66,7 +66,7 @@ int smc_scratch(smc_ctx* ctx, size_t bytes, void** out);
 // keys are fp64 bit patterns, 1: int64.  vals null: payload = index (argsort).  The results stay in `ws`.
 size_t smc_rs_ws_bytes(long long N);
 int smc_rs_sort_ws(smc_ctx* ctx, const void* keys, const void* vals, long long N, int kind, void* ws,
-                   unsigned long long** sorted_keys, unsigned long long** sorted_vals);
+                   unsigned long long** sorted_keys, unsigned long long** sorted_vals, bool plan_is_zero = false);
 
 // the scrambled Sobol' point set `counter` of the stream keyed by `seed` (smc_qmc.hip), (N, d) row-major
 int smc_sobol_points(smc_ctx* ctx, unsigned long long seed, long long N, int d, unsigned long long counter, int sorted,

@@ -19,6 +19,14 @@
 //                 write the consecutive 8-byte slots of a digit's run.
 // HBM traffic per pass: read keys twice, read payload once, write both: 40 B per element (the first pass
 // reads the caller's keys and generates the index payload; an argsort's last pass writes no keys).
+// Beyond RS_WINDOW_MIN keys the eight passes become FOUR plus a fix-up (round 5): the keys' images differ only below
+// their highest varying bit (one pass of maxima: k_rs_minmax); the 32 bits from there down are sorted by four stable
+// passes, after which keys that agree on those 32 bits -- and on everything above -- sit together in input order, and
+// k_rs_fix orders each such group by the remaining low bits (groups are pairs, rarely: N^2 / 2^33 expected collisions
+// over the range of the data; runs of fully equal keys need nothing and may be any length).  A group of more than 32
+// keys with different low bits (a cluster 2^-32 of the data's range wide) raises a flag and ONE workgroup redoes the
+// sort with all eight passes (k_rs_fallback: milliseconds; correct for any input).  Same permutation as before: a stable
+// sort by the full key.
 // The running sum of wquantiles is a three-kernel scan (tile sums, scan of the sums, apply).
 // Everything also runs under the fiber emulator (tests/emu), so the CPU suite exercises it.
 #include "smc_internal.h"
@@ -48,6 +56,61 @@ __host__ __device__ __forceinline__ u64 rs_decode(u64 e, int kind)
 {
     if (kind == RS_KEY_I64) return e ^ 0x8000000000000000ull;
     return (e >> 63) ? (e & 0x7fffffffffffffffull) : ~e;
+}
+
+// plan[0] = max of the key images, plan[1] = max of their complements (= ~min), plan[2] = fix-up overflow flag; all zero
+// between sorts.  The sorted window: 32 bits from the highest bit in which any two keys differ.
+// (Measured and dropped: the maxima spread over 32 slots each, to take the 1024 atomics off two words -- k_rs_minmax 10.6
+//  -> 7.8 us, but the nine kernels that then combine 64 words in their prologue lost 1.3 - 2 us EACH.)
+#define RS_PLAN_WORDS 3
+__device__ __forceinline__ int rs_window_shift(const u64* plan)
+{
+    const u64 x = plan[0] ^ ~plan[1];
+    const int top = x ? 63 - __clzll((long long)x) : 0;
+    return top > 31 ? top - 31 : 0;
+}
+__device__ __forceinline__ int rs_pass_shift(const int shift, const u64* plan) { return plan ? rs_window_shift(plan) + shift : shift; }
+
+// workgroups of 1024 threads, 8192 keys each: a quarter of the atomics on the two words for the same bytes in flight
+#define RS_MM_BLOCK 1024
+#define RS_MM_TILE (8 * RS_MM_BLOCK)
+__global__ void __launch_bounds__(RS_MM_BLOCK)
+k_rs_minmax(const u64* keys, i64 N, int kind, u64* plan)
+{
+    __shared__ u64 s_m[2 * (RS_MM_BLOCK / 64)];
+    const int tid = (int)threadIdx.x, wave = tid >> 6;
+    const i64 base = (i64)blockIdx.x * RS_MM_TILE;
+    u64 mx = 0ull, mn = 0ull;
+#pragma unroll
+    for (int c = 0; c < RS_MM_TILE / RS_MM_BLOCK; ++c) {
+        const i64 i = base + (i64)c * RS_MM_BLOCK + tid;
+        if (i < N) {
+            const u64 e = rs_encode(keys[i], kind);
+            mx = e > mx ? e : mx;
+            mn = ~e > mn ? ~e : mn;
+        }
+    }
+    // (an inclusive max-scan over the wave on the DPP path: lane 63 holds the wave's maximum)
+#define RS_MAX_STEP(CTRL, MASK)                                     \
+    {                                                               \
+        const u64 a = smc_dpp64<CTRL, MASK, true>(mx), b = smc_dpp64<CTRL, MASK, true>(mn); \
+        mx = a > mx ? a : mx;                                       \
+        mn = b > mn ? b : mn;                                       \
+    }
+    RS_MAX_STEP(SMC_DPP_ROW_SHR(1), 0xf)
+    RS_MAX_STEP(SMC_DPP_ROW_SHR(2), 0xf)
+    RS_MAX_STEP(SMC_DPP_ROW_SHR(4), 0xf)
+    RS_MAX_STEP(SMC_DPP_ROW_SHR(8), 0xf)
+    RS_MAX_STEP(SMC_DPP_ROW_BCAST15, 0xa)
+    RS_MAX_STEP(SMC_DPP_ROW_BCAST31, 0xc)
+#undef RS_MAX_STEP
+    if ((tid & 63) == 63) { s_m[wave] = mx; s_m[RS_MM_BLOCK / 64 + wave] = mn; }
+    __syncthreads();
+    if (tid < 2) {
+        u64 m = s_m[tid * (RS_MM_BLOCK / 64)];
+        for (int w = 1; w < RS_MM_BLOCK / 64; ++w) m = s_m[tid * (RS_MM_BLOCK / 64) + w] > m ? s_m[tid * (RS_MM_BLOCK / 64) + w] : m;
+        atomicMax(reinterpret_cast<unsigned long long*>(plan + tid), (unsigned long long)m);
+    }
 }
 
 __global__ void __launch_bounds__(SMC_BLOCK)
@@ -98,10 +161,11 @@ __device__ __forceinline__ void rs_tile_hist(const u64* keys, i64 N, int shift, 
 
 template <bool RAW>
 __global__ void __launch_bounds__(SMC_BLOCK)
-k_rs_hist(const u64* keys, i64 N, int shift, int kind, unsigned* hist, int ntiles)
+k_rs_hist(const u64* keys, i64 N, int shift0, int kind, unsigned* hist, int ntiles, const u64* plan)
 {
     __shared__ unsigned h[256];
     const int tid = (int)threadIdx.x;
+    const int shift = rs_pass_shift(shift0, plan);
     h[tid] = 0u;
     __syncthreads();
     rs_tile_hist<RAW>(keys, N, shift, kind, (int)blockIdx.x, h);
@@ -139,10 +203,12 @@ k_rs_scan(unsigned* hist, unsigned* rowtot, int ntiles)
 //  eight dependent tile reads cost more than the launch they save: 0.207 ms per SQMC step at N = 2^14 against
 //  0.15.)
 #define RS_FEW 64
+// MODE 2 (k_rs_fallback: one workgroup walking the tiles in order): my_first = the first output slot of (digit tid, this
+// tile), handed in; returns the tile's count of digit tid.
 template <bool RAW, int MODE>
-__global__ void __launch_bounds__(SMC_BLOCK)
-k_rs_scatter(const u64* keys, const u64* vals, i64 N, int shift, int kind, const unsigned* offs,
-             const unsigned* rowtot, int ntiles, u64* okeys, u64* ovals)
+__device__ __forceinline__ unsigned rs_scatter_tile(const u64* keys, const u64* vals, i64 N, int shift, int kind, const unsigned* offs,
+                                                    const unsigned* rowtot, int ntiles, u64* okeys, u64* ovals, const int tile,
+                                                    const unsigned my_first = 0u)
 {
     __shared__ unsigned cnt[SMC_NWAVE][256];
     __shared__ unsigned start[256];              // first slot of each digit in the tile's sorted order
@@ -150,23 +216,22 @@ k_rs_scatter(const u64* keys, const u64* vals, i64 N, int shift, int kind, const
     __shared__ u64 sk[RS_TILE], sv[RS_TILE];     // the tile in sorted order
     __shared__ u64 smu[SMC_SM];
     const int tid = (int)threadIdx.x, lane = smc_lane(), wave = smc_wave();
+    if (MODE == 2) __syncthreads();              // (the previous tile's write-out has read sk / sv / goff / start)
 #pragma unroll
     for (int w = 0; w < SMC_NWAVE; ++w) cnt[w][tid] = 0u;
-    unsigned my_off, my_tot;
+    unsigned my_off = 0u, my_tot = 0u;
     if constexpr (MODE == 0) {
-        my_off = offs[(i64)tid * ntiles + blockIdx.x];
+        my_off = offs[(i64)tid * ntiles + tile];
         my_tot = rowtot[tid];
-    } else {
+    } else if constexpr (MODE == 1) {
         const unsigned* row = offs + (i64)tid * ntiles;
-        my_off = 0u;
-        my_tot = 0u;
         for (int w = 0; w < ntiles; ++w) {
             const unsigned c = row[w];
-            my_off += (w < (int)blockIdx.x) ? c : 0u;
+            my_off += (w < tile) ? c : 0u;
             my_tot += c;
         }
     }
-    const i64 tile0 = (i64)blockIdx.x * RS_TILE;
+    const i64 tile0 = (i64)tile * RS_TILE;
     const i64 base = tile0 + (i64)wave * RS_SEG;
     const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));       // lanes below this one
     u64 k[RS_CH], v[RS_CH];
@@ -178,7 +243,9 @@ k_rs_scatter(const u64* keys, const u64* vals, i64 N, int shift, int kind, const
         k[c] = valid ? keys[i] : ~0ull;
         v[c] = (RAW && !vals) ? (u64)i : (valid ? vals[i] : 0ull);
     }
-    {   // keys with a smaller digit anywhere in the input
+    if constexpr (MODE == 2) {
+        goff[tid] = my_first;
+    } else {   // keys with a smaller digit anywhere in the input
         u64 all;
         const u64 lower = smc_block_exscan_u64((u64)my_tot, smu, all);
         goff[tid] = (unsigned)lower + my_off;
@@ -203,11 +270,13 @@ k_rs_scatter(const u64* keys, const u64* vals, i64 N, int shift, int kind, const
         smc_wave_lockstep();
     }
     __syncthreads();
+    unsigned tile_count = 0u;
     {   // digit tid: its slots in the tile's sorted order start after all smaller digits; per
         // wave, after the earlier waves' keys of the same digit
         unsigned c4[SMC_NWAVE], tot = 0u;
 #pragma unroll
         for (int w = 0; w < SMC_NWAVE; ++w) { c4[w] = cnt[w][tid]; tot += c4[w]; }
+        tile_count = tot;
         u64 all;
         unsigned run = (unsigned)smc_block_exscan_u64((u64)tot, smu, all);
         start[tid] = run;
@@ -237,6 +306,113 @@ k_rs_scatter(const u64* keys, const u64* vals, i64 N, int shift, int kind, const
             if (okeys) okeys[pos] = kk;
             ovals[pos] = sv[j];
         }
+    }
+    return tile_count;
+}
+template <bool RAW, int MODE>
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_rs_scatter(const u64* keys, const u64* vals, i64 N, int shift0, int kind, const unsigned* offs,
+             const unsigned* rowtot, int ntiles, u64* okeys, u64* ovals, const u64* plan)
+{
+    (void)rs_scatter_tile<RAW, MODE>(keys, vals, N, rs_pass_shift(shift0, plan), kind, offs, rowtot, ntiles, okeys, ovals, (int)blockIdx.x);
+}
+
+// ---- the fix-up behind the four window passes: keys that agree on the window (and above) sit together in input order;
+// within such a group, order by the low bits (stable).  new position = i - #{j < i in the group: low_j > low_i}
+//                                                                      + #{j > i in the group: low_j < low_i}.
+// A thread looks RS_GCAP keys to either side; a group that reaches further is left where it is if nothing in sight has
+// other low bits (a run of equal keys, any length) -- the keys that DO differ sit in the same group, see the same long
+// group from where they are and raise the flag.
+#define RS_GCAP 32
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_rs_fix(const u64* keys, const u64* vals, i64 N, u64* okeys, u64* ovals, u64* plan)
+{
+    const int tid = (int)threadIdx.x;
+    const i64 tile0 = (i64)blockIdx.x * RS_TILE;
+    const int sh = rs_window_shift(plan);
+    const u64 lowmask = sh ? ((1ull << sh) - 1ull) : 0ull;
+    // (nearly every key is alone in its group: its two neighbours -- the same cache lines as the key itself -- say so)
+    u64 k[RS_TILE / SMC_BLOCK], kl[RS_TILE / SMC_BLOCK], kr[RS_TILE / SMC_BLOCK], v[RS_TILE / SMC_BLOCK];
+#pragma unroll
+    for (int c = 0; c < RS_TILE / SMC_BLOCK; ++c) {
+        const i64 i = tile0 + (i64)c * SMC_BLOCK + tid;
+        const bool in = i < N;
+        k[c] = in ? keys[i] : 0ull;
+        kl[c] = (in && i > 0) ? keys[i - 1] : 0ull;
+        kr[c] = (in && i + 1 < N) ? keys[i + 1] : 0ull;
+        v[c] = in ? vals[i] : 0ull;
+    }
+    bool over = false;
+#pragma unroll
+    for (int c = 0; c < RS_TILE / SMC_BLOCK; ++c) {
+        const i64 i = tile0 + (i64)c * SMC_BLOCK + tid;
+        if (i >= N) continue;
+        const u64 hi = k[c] >> sh, low = k[c] & lowmask;
+        const bool left = i > 0 && (kl[c] >> sh) == hi, right = i + 1 < N && (kr[c] >> sh) == hi;
+        i64 pos = i;
+        if (sh && (left || right)) {
+            int before = 0, after = 0;
+            bool foundL = !left, foundR = !right, other = false;
+            for (int s = 1; left && s <= RS_GCAP; ++s) {
+                if (i - s < 0) { foundL = true; break; }
+                const u64 q = keys[i - s];
+                if ((q >> sh) != hi) { foundL = true; break; }
+                const u64 ql = q & lowmask;
+                before += ql > low ? 1 : 0;
+                other = other || ql != low;
+            }
+            for (int s = 1; right && s <= RS_GCAP; ++s) {
+                if (i + s >= N) { foundR = true; break; }
+                const u64 q = keys[i + s];
+                if ((q >> sh) != hi) { foundR = true; break; }
+                const u64 ql = q & lowmask;
+                after += ql < low ? 1 : 0;
+                other = other || ql != low;
+            }
+            if (foundL && foundR) pos = i - before + after;
+            else over = over || other;
+        }
+        okeys[pos] = k[c];
+        ovals[pos] = v[c];
+    }
+    if (over) plan[2] = 1ull;                   // (benign race: every writer stores 1)
+}
+
+// ---- the whole sort by ONE workgroup, eight passes over the full keys: run only when k_rs_fix raised its flag (the same
+// launch returns at once otherwise).  Pass p reads what pass p - 1 wrote; the result lands where k_rs_fix's would have.
+__global__ void __launch_bounds__(SMC_BLOCK)
+k_rs_fallback(const u64* keys, const u64* vals, i64 N, int kind, u64* kA, u64* vA, u64* kB, u64* vB, u64* plan)
+{
+    __shared__ unsigned h[256];
+    __shared__ u64 smu[SMC_SM];
+    const int tid = (int)threadIdx.x;
+    const bool needed = plan[2] != 0ull;
+    __syncthreads();
+    if (tid < RS_PLAN_WORDS) plan[tid] = 0ull;                             // (the last launch of a sort leaves the plan ready for the next)
+    if (!needed) return;
+    const int ntiles = (int)((N + RS_TILE - 1) / RS_TILE);
+    const u64 *ks = keys, *vs = vals;
+    u64 *kd = kA, *vd = vA;
+    for (int pass = 0; pass < 8; ++pass) {
+        const int shift = 8 * pass;
+        h[tid] = 0u;
+        __syncthreads();
+        for (int t = 0; t < ntiles; ++t) {
+            if (pass == 0) rs_tile_hist<true>(ks, N, shift, kind, t, h);
+            else rs_tile_hist<false>(ks, N, shift, kind, t, h);
+        }
+        __syncthreads();
+        u64 all;
+        unsigned first = (unsigned)smc_block_exscan_u64((u64)h[tid], smu, all);   // keys with a smaller digit
+        for (int t = 0; t < ntiles; ++t) {
+            const unsigned c = pass == 0 ? rs_scatter_tile<true, 2>(ks, vs, N, shift, kind, nullptr, nullptr, ntiles, kd, vd, t, first)
+                                         : rs_scatter_tile<false, 2>(ks, vs, N, shift, kind, nullptr, nullptr, ntiles, kd, vd, t, first);
+            first += c;
+        }
+        __threadfence();
+        __syncthreads();
+        ks = kd; vs = vd;
+        if (kd == kA) { kd = kB; vd = vB; } else { kd = kA; vd = vA; }
     }
 }
 
@@ -333,13 +509,22 @@ k_rs_small(const u64* keys, const u64* vals, i64 N, int kind, u64* okeys, u64* o
 // call in stream order); the sorted payloads (argsort: the permutation, as 64-bit words) and the sorted
 // key IMAGES (rs_encode) are left inside it -- no copy-out.  The fused SQMC step of the filter sorts
 // through this entry once per time step.
+// (tests: the window path from smaller sizes on -- smc_debug_sort_window_min)
+static long long g_rs_window_min = (long long)(RS_FEW + 1) * RS_TILE;
+extern "C" int smc_debug_sort_window_min(long long n)
+{
+    g_rs_window_min = n > RS_ONE_WG ? n : RS_ONE_WG + 1;
+    return SMC_OK;
+}
 size_t smc_rs_ws_bytes(i64 N)
 {
     const size_t ntiles = (size_t)((N + RS_TILE - 1) / RS_TILE);
-    return 4 * (size_t)N * 8 + ntiles * 256 * 4 + 256 * 4 + 256;
+    return 4 * (size_t)N * 8 + ntiles * 256 * 4 + 256 * 4 + 256 + 1024;     // (... + the plan words of the four-pass form)
 }
+// plan_is_zero: the caller has sorted through this workspace before -- every sort leaves the plan words zeroed -- which
+// saves the fill launch per sort.
 int smc_rs_sort_ws(smc_ctx* ctx, const void* keys, const void* vals, i64 N, int kind, void* ws,
-                   u64** sorted_keys, u64** sorted_vals)
+                   u64** sorted_keys, u64** sorted_vals, bool plan_is_zero)
 {
     hipStream_t st = ctx->stream;
     const size_t nb = (size_t)N * 8;
@@ -360,6 +545,37 @@ int smc_rs_sort_ws(smc_ctx* ctx, const void* keys, const void* vals, i64 N, int 
         if (hipGetLastError() != hipSuccess) rc = SMC_ERR_HIP;
         if (sorted_keys) *sorted_keys = k0;
         if (sorted_vals) *sorted_vals = v0;
+    } else if (N >= g_rs_window_min) {
+        // four passes over the 32 bits below the keys' highest varying bit, the low bits by k_rs_fix (see the top of the file)
+        const int ntiles = (int)((N + RS_TILE - 1) / RS_TILE);
+        unsigned* hist = (unsigned*)((char*)ws + 4 * nb);
+        unsigned* rowtot = hist + (size_t)ntiles * 256;
+        u64* plan = (u64*)(rowtot + 256);
+        const int mode = ntiles <= RS_FEW ? 1 : 0;
+        if (!plan_is_zero && hipMemsetAsync(plan, 0, RS_PLAN_WORDS * 8, st) != hipSuccess) rc = SMC_ERR_HIP;
+        SMC_LAUNCH(k_rs_minmax, dim3((unsigned)((N + RS_MM_TILE - 1) / RS_MM_TILE)), dim3(RS_MM_BLOCK), st, (const u64*)keys, N, kind, plan);
+        const u64 *ks = (const u64*)keys, *vs = (const u64*)vals;
+        u64 *kd = k1, *vd = v1;
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 8 * pass;
+            if (pass == 0) SMC_LAUNCH(k_rs_hist<true>, dim3(ntiles), dim3(SMC_BLOCK), st, ks, N, shift, kind, hist, ntiles, (const u64*)plan);
+            else SMC_LAUNCH(k_rs_hist<false>, dim3(ntiles), dim3(SMC_BLOCK), st, ks, N, shift, kind, hist, ntiles, (const u64*)plan);
+            if (mode == 0) SMC_LAUNCH(k_rs_scan, dim3(256), dim3(SMC_BLOCK), st, hist, rowtot, ntiles);
+#define RS_SCATTER(RAWV, MODEV)                                                                                     \
+    SMC_LAUNCH((k_rs_scatter<RAWV, MODEV>), dim3(ntiles), dim3(SMC_BLOCK), st, ks, vs, N, shift, kind,               \
+               (const unsigned*)hist, (const unsigned*)rowtot, ntiles, kd, vd, (const u64*)plan)
+            if (pass == 0) { if (mode == 1) RS_SCATTER(true, 1); else RS_SCATTER(true, 0); }
+            else { if (mode == 1) RS_SCATTER(false, 1); else RS_SCATTER(false, 0); }
+#undef RS_SCATTER
+            ks = kd; vs = vd;
+            if (kd == k1) { kd = k0; vd = v0; } else { kd = k1; vd = v1; }
+        }
+        // (four passes: the window-sorted pairs are in (k0, v0); the fix-up -- and the fallback's eighth pass -- write (k1, v1))
+        SMC_LAUNCH(k_rs_fix, dim3(ntiles), dim3(SMC_BLOCK), st, (const u64*)k0, (const u64*)v0, N, k1, v1, plan);
+        SMC_LAUNCH(k_rs_fallback, dim3(1), dim3(SMC_BLOCK), st, (const u64*)keys, (const u64*)vals, N, kind, k0, v0, k1, v1, plan);
+        if (hipGetLastError() != hipSuccess) rc = SMC_ERR_HIP;
+        if (sorted_keys) *sorted_keys = k1;
+        if (sorted_vals) *sorted_vals = v1;
     } else {
         const int ntiles = (int)((N + RS_TILE - 1) / RS_TILE);
         unsigned* hist = (unsigned*)((char*)ws + 4 * nb);
@@ -372,13 +588,13 @@ int smc_rs_sort_ws(smc_ctx* ctx, const void* keys, const void* vals, i64 N, int 
         const int mode = ntiles <= RS_FEW ? 1 : 0;
         for (int pass = 0; pass < 8; ++pass) {
             const int shift = 8 * pass;
-            if (pass == 0) SMC_LAUNCH(k_rs_hist<true>, dim3(ntiles), dim3(SMC_BLOCK), st, ks, N, shift, kind, hist, ntiles);
-            else SMC_LAUNCH(k_rs_hist<false>, dim3(ntiles), dim3(SMC_BLOCK), st, ks, N, shift, kind, hist, ntiles);
+            if (pass == 0) SMC_LAUNCH(k_rs_hist<true>, dim3(ntiles), dim3(SMC_BLOCK), st, ks, N, shift, kind, hist, ntiles, (const u64*)nullptr);
+            else SMC_LAUNCH(k_rs_hist<false>, dim3(ntiles), dim3(SMC_BLOCK), st, ks, N, shift, kind, hist, ntiles, (const u64*)nullptr);
             if (mode == 0) SMC_LAUNCH(k_rs_scan, dim3(256), dim3(SMC_BLOCK), st, hist, rowtot, ntiles);
             u64* ko = (pass == 7 && !sorted_keys) ? nullptr : kd;
 #define RS_SCATTER(RAWV, MODEV)                                                                                     \
     SMC_LAUNCH((k_rs_scatter<RAWV, MODEV>), dim3(ntiles), dim3(SMC_BLOCK), st, ks, vs, N, shift, kind,               \
-               (const unsigned*)hist, (const unsigned*)rowtot, ntiles, ko, vd)
+               (const unsigned*)hist, (const unsigned*)rowtot, ntiles, ko, vd, (const u64*)nullptr)
             if (pass == 0) { if (mode == 1) RS_SCATTER(true, 1); else RS_SCATTER(true, 0); }
             else { if (mode == 1) RS_SCATTER(false, 1); else RS_SCATTER(false, 0); }
 #undef RS_SCATTER

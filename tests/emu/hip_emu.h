@@ -314,6 +314,8 @@ inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p += v; r
 inline int atomicMin(int* p, int v) { int o = *p; if (v < o) *p = v; return o; }
 inline unsigned atomicMin(unsigned* p, unsigned v) { unsigned o = *p; if (v < o) *p = v; return o; }
 inline unsigned atomicMax(unsigned* p, unsigned v) { unsigned o = *p; if (v > o) *p = v; return o; }
+inline int __clzll(long long x) { return x ? __builtin_clzll((unsigned long long)x) : 64; }
+inline unsigned long long atomicMax(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; if (v > o) *p = v; return o; }
 inline unsigned atomicOr(unsigned* p, unsigned v) { unsigned o = *p; *p |= v; return o; }
 inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) {
     unsigned long long o = *p; *p += v; return o;

@@ -121,6 +121,61 @@ def check_device_sort(sizes=(1, 63, 64, 2047, 2048, 2049, 50001)):
     assert np.array_equal(np.sort(order), np.arange(4097))
 
 
+def check_sort_window(sizes=(8193, 20001, 50001), window_min=8193):
+    """The radix sort's four-pass form (the 32 bits below the keys' highest varying bit, then k_rs_fix on the low bits;
+    csrc/smc_sort.hip) gives np.argsort(kind="stable")'s permutation for: wide and narrow ranges (a state far from 0
+    relative to its spread: the window must start at the highest VARYING bit), heavy duplication (runs of equal keys of
+    any length need no fix-up), values a few ulps apart (groups the fix-up orders), clusters of MORE than 32 distinct keys
+    inside one window value (the one-workgroup eight-pass fallback), all keys equal, two distinct keys, signed zeros and
+    infinities, int64 Hilbert keys -- and the eight-pass form gives the same."""
+    from particles_amd import hilbert
+    rng = np.random.default_rng(11)
+
+    def cases(N):
+        yield "normal", rng.standard_normal(N)
+        yield "wide", rng.standard_normal(N) * 10.0 ** rng.integers(-300, 300, size=N)
+        yield "narrow", 1000.0 + 1e-3 * rng.standard_normal(N)
+        yield "duplicates", rng.integers(0, 37, size=N).astype(np.float64)
+        yield "all equal", np.full(N, 3.25)
+        x = np.full(N, 1.0)
+        x[N // 2] = np.nextafter(1.0, 2.0)
+        yield "two values", x
+        base = rng.standard_normal(N)
+        x = base.copy()                                   # pairs / triples a few ulps apart: groups for the fix-up
+        idx = rng.integers(0, N, size=N // 4)
+        x[idx] = np.nextafter(base[(idx + 1) % N], np.inf)
+        idx = rng.integers(0, N, size=N // 8)
+        x[idx] = np.nextafter(np.nextafter(base[(idx + 2) % N], -np.inf), -np.inf)
+        yield "ulps apart", x
+        x = rng.standard_normal(N)                         # a cluster of 500 distinct values inside one window value
+        c = 0.5 + np.arange(500) * 2.0 ** -52
+        x[rng.choice(N, 500, replace=False)] = rng.permutation(c)
+        yield "tight cluster", x
+        x = rng.standard_normal(N)
+        x[:6] = 0.0, -0.0, np.inf, -np.inf, 5e-324, -5e-324
+        yield "specials", x
+
+    pts = rng.standard_normal((sizes[0], 3))
+    try:
+        for wm in (window_min, 1 << 40):                  # four passes + fix-up from window_min keys on; eight passes
+            _lib.check(_lib.lib().smc_debug_sort_window_min(wm))
+            for N in sizes:
+                for name, x in cases(N):
+                    o = np.asarray(hilbert.argsort(x))
+                    ref = np.argsort(x, kind="stable")
+                    assert np.array_equal(np.sort(o), np.arange(N)), (wm, N, name)
+                    assert np.all(x[o] == x[ref]), (wm, N, name)
+                    nz = x[o] != 0.0                          # (+0 and -0 compare equal: either order is a valid sort)
+                    assert np.array_equal(o[nz], ref[nz]), (wm, N, name, int(np.sum(o != ref)))
+            order = np.asarray(hilbert.hilbert_sort(pts))
+            if wm == window_min:
+                first = order
+            else:
+                assert np.array_equal(first, order)
+    finally:
+        _lib.check(_lib.lib().smc_debug_sort_window_min((64 + 1) * 2048))
+
+
 def check_weights_edges(N):
     w = rs.Weights(lw=np.full(N, -np.inf))                   # SURVEY appendix B
     assert np.isnan(w.W).all() and np.isnan(w.ESS) and np.isnan(w.log_mean)

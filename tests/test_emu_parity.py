@@ -28,6 +28,10 @@ def test_inverse_cdf(N, M):
     pc.check_inverse_cdf(N, M)
 
 
+def test_sort_window_and_fixup():
+    pc.check_sort_window(sizes=(8193, 20001))
+
+
 def test_inverse_cdf_dyadic():
     pc.check_inverse_cdf_dyadic(2048, 3000)
 

@@ -530,6 +530,10 @@ def test_strict_ancestors_heavy_parents():
                                   small=False, T=5, ESSrmin=1.0)
 
 
+def test_sort_window_and_fixup():
+    pc.check_sort_window(sizes=(8193, 50001, (1 << 17) + 5, 1 << 20), window_min=8193)
+
+
 def test_strict_verifies_every_step():
     pc.check_strict_never_leaves_the_fast_path(
         [(5000, 4, "systematic", "toy", 0.5), (3000, 8, "multinomial", "toy", 0.5), (70000, 2, "stratified", "sv", 1.0),
