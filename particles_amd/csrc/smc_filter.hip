@@ -265,7 +265,6 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
             // ... or in one, where the whole grid is resident at once (k_strict_step)
             if (f->strict_one_launch) {
                 do q.epoch = ++f->strict_epoch; while ((uint32_t)q.epoch == 0u);   // (0: the tag of never-written words)
-                if (const char* e = getenv("SMC_STRICT_POLL")) q.poll = atoi(e);   // (perf experiments)
                 if (f->two_level_mid) SMC_LAUNCH(k_strict_step<true>, gt, dim3(SMC_BLOCK), st, f->a, q);
                 else SMC_LAUNCH(k_strict_step<false>, gt, dim3(SMC_BLOCK), st, f->a, q);
             } else {
