@@ -199,7 +199,7 @@ int smc_copy_strided(smc_ctx* ctx, const double* src, int64_t src_stride, double
 int smc_argsort(smc_ctx* ctx, const double* x, int64_t N, int64_t* out);
 /* Test access: the radix sort behind smc_argsort / smc_hilbert_sort / smc_wquantiles / the fused SQMC step takes four
  * passes over the 32 bits below the keys' highest varying bit plus a fix-up (instead of eight passes over all 64) from n
- * keys on (default 133 120; never below 8 193).  Process-wide; the results are the same permutation either way. */
+ * keys on (default and minimum: 8 193, the first size that takes more than one workgroup).  Process-wide; the results are the same permutation either way. */
 int smc_debug_sort_window_min(long long n);
 /* hilbert_sort (hilbert.py:33-58) of N vectors x (N, d), 2 <= d <= 16: standardise each
  * component (np.mean / np.std over the particles), logistic map to (0,1), scale to integers

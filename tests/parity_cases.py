@@ -173,7 +173,7 @@ def check_sort_window(sizes=(8193, 20001, 50001), window_min=8193):
             else:
                 assert np.array_equal(first, order)
     finally:
-        _lib.check(_lib.lib().smc_debug_sort_window_min((64 + 1) * 2048))
+        _lib.check(_lib.lib().smc_debug_sort_window_min(8193))
 
 
 def check_weights_edges(N):

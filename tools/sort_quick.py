@@ -8,7 +8,7 @@ from particles_amd import _lib, hilbert, kalman, resampling as rs, state_space_m
 from particles_amd._lib import DeviceArray
 
 rng = np.random.default_rng(3)
-for log2N in (18, 20, 22):
+for log2N in (14, 15, 16, 17, 18, 20, 22):
     N = 1 << log2N
     x = DeviceArray.from_numpy(rng.standard_normal(N))
     for name, wm in (("eight passes", 1 << 40), ("four + fix-up", 8193)):
@@ -24,7 +24,7 @@ for log2N in (18, 20, 22):
             best = min(best, (time.perf_counter() - t0) / 20)
         print("argsort N=2^%d %-14s %8.1f us" % (log2N, name, best * 1e6), flush=True)
 y = bench.synthetic_data(400)
-for name, wm in (("eight passes", 1 << 40), ("four + fix-up", (64 + 1) * 2048)):
+for name, wm in (("eight passes", 1 << 40), ("four + fix-up", 8193)):
     _lib.check(_lib.lib().smc_debug_sort_window_min(wm))
     rs.set_rng("philox")                                   # (device-generated points: the fused SQMC step)
     pf = pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y), N=1 << 20, seed=5, collect="off", qmc=True)
