@@ -29,7 +29,7 @@ def test_inverse_cdf(N, M):
 
 
 def test_sort_window_and_fixup():
-    pc.check_sort_window(sizes=(8193, 20001))
+    pc.check_sort_window(sizes=(8193, 11003))
 
 
 def test_inverse_cdf_dyadic():
@@ -309,7 +309,7 @@ def test_strict_one_launch_switch(monkeypatch):
 
 
 def test_strict_verifies_every_step():
-    pc.check_strict_never_leaves_the_fast_path([(3000, 8, "systematic", "toy", 0.5), (2500, 4, "multinomial", "sv", 1.0)], T=120)
+    pc.check_strict_never_leaves_the_fast_path([(3000, 4, "systematic", "toy", 0.5), (2500, 2, "multinomial", "sv", 1.0)], T=70)
 
 
 def test_multinomial_spacings_on_the_side_stream(monkeypatch):
