@@ -23,7 +23,7 @@
 // their highest varying bit (one pass of maxima: k_rs_minmax); the 32 bits from there down are sorted by four stable
 // passes, after which keys that agree on those 32 bits -- and on everything above -- sit together in input order, and
 // k_rs_fix orders each such group by the remaining low bits (groups are pairs, rarely: N^2 / 2^33 expected collisions
-// over the range of the data; runs of fully equal keys need nothing and may be any length).  A group of more than 32
+// over the range of the data; runs of fully equal keys need nothing and may be any length).  A group of more than 65
 // keys with different low bits (a cluster 2^-32 of the data's range wide) raises a flag and ONE workgroup redoes the
 // sort with all eight passes (k_rs_fallback: milliseconds; correct for any input).  Same permutation as before: a stable
 // sort by the full key.
@@ -323,7 +323,7 @@ k_rs_scatter(const u64* keys, const u64* vals, i64 N, int shift0, int kind, cons
 // A thread looks RS_GCAP keys to either side; a group that reaches further is left where it is if nothing in sight has
 // other low bits (a run of equal keys, any length) -- the keys that DO differ sit in the same group, see the same long
 // group from where they are and raise the flag.
-#define RS_GCAP 32
+#define RS_GCAP 64
 __global__ void __launch_bounds__(SMC_BLOCK)
 k_rs_fix(const u64* keys, const u64* vals, i64 N, u64* okeys, u64* ovals, u64* plan)
 {

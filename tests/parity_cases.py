@@ -151,6 +151,12 @@ def check_sort_window(sizes=(8193, 20001, 50001), window_min=8193):
         c = 0.5 + np.arange(500) * 2.0 ** -52
         x[rng.choice(N, 500, replace=False)] = rng.permutation(c)
         yield "tight cluster", x
+        par = rng.standard_normal(N // 20 + 1)              # offspring of a parent, jitter far below the window's resolution:
+        cnt = rng.integers(1, 60, size=par.size)            # groups of up to 60 keys the fix-up orders itself
+        x = np.repeat(par, cnt)[:N]
+        x = np.concatenate([x, rng.standard_normal(N - x.size)]) if x.size < N else x
+        x = rng.permutation(x + 1e-13 * rng.standard_normal(N))
+        yield "jittered offspring", x
         x = rng.standard_normal(N)
         x[:6] = 0.0, -0.0, np.inf, -np.inf, 5e-324, -5e-324
         yield "specials", x
