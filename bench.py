@@ -91,7 +91,7 @@ def leg_key(wl):
     if wl["name"] == "c3":
         return "c3_" + wl["scheme"] + sfx
     if wl["name"] == "c4":
-        return "c4_collapsed" if wl["collapsed"] else "c4"
+        return "c4_collapsed" if wl["collapsed"] else ("c4_dense" if wl.get("dense") else "c4")
     return wl["name"] + sfx
 
 
@@ -111,7 +111,7 @@ def committed_profile(wl, kernel, profiles=None):
     if wl["Nlabel"] != "2^%d" % wl["log2N"] or \
             (cfg.get("log2N"), cfg.get("islands"), cfg.get("scheme")) != (wl["log2N"], wl["islands"], wl["scheme"]) or \
             bool(cfg.get("collapsed")) != bool(wl["collapsed"]) or bool(cfg.get("qmc")) != bool(wl.get("qmc")) or \
-            bool(cfg.get("strict")) != bool(wl.get("strict")):
+            bool(cfg.get("strict")) != bool(wl.get("strict")) or bool(cfg.get("dense")) != bool(wl.get("dense")):
         return None
     total, found, us, us_ok = 0.0, 0, 0.0, True
     base = lambda name: name.replace("void ", "").split("<")[0].split("(")[0].strip()
@@ -187,10 +187,11 @@ def reference_available():
     return os.path.isdir(os.path.join(REFERENCE_DIR, "particles"))
 
 
-def _cpu_worker(kind, N, nsteps, nruns, gate, Tdata=0):
+def _cpu_worker(kind, N, nsteps, nruns, gate, Tdata=0, index=0):
     """One worker PROCESS of the CPU baseline (bench.py --cpu-worker ...): `nruns` independent
     bootstrap filters of N particles over the first `nsteps` observations, one after the other,
-    on one core.  gate: a directory -- the worker drops a `ready.<pid>` file when its imports are
+    on one core; run r of worker `index` is seeded 123 + index * nruns + r -- distinct seeds over the whole
+    pool, as multiSMC's workers get them (utils.py:189-213).  gate: a directory -- the worker drops a `ready.<pid>` file when its imports are
     done and starts when the parent creates `go` (so that all workers run at the same time).
     Prints {"t0", "t1", "seconds", "logLt"}; the parent aggregates."""
     for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
@@ -226,7 +227,7 @@ def _cpu_worker(kind, N, nsteps, nruns, gate, Tdata=0):
     t0 = time.time()
     secs, lls = 0.0, []
     for r in range(nruns):
-        s, ll = one(123 + r)
+        s, ll = one(123 + index * nruns + r)
         secs += s
         lls.append(ll)
     print(json.dumps({"t0": t0, "t1": time.time(), "seconds": secs, "logLt": lls}), flush=True)
@@ -238,8 +239,8 @@ def _spawn_workers(kind, N, nsteps, runs_per_worker, nworkers, Tdata=0):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-worker", kind, str(N), str(nsteps),
            str(runs_per_worker), gate, str(int(Tdata))]
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
-    procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env)
-             for _ in range(nworkers)]
+    procs = [subprocess.Popen(cmd + [str(i)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env)
+             for i in range(nworkers)]
     if gate:
         t_wait = time.time()        # all imports done (or a worker died / 120 s passed): go
         while time.time() - t_wait < 120:
@@ -325,10 +326,12 @@ def cpu_baseline(N, nsteps, all_cores=True, kind=None, Tdata=0):
                 "host_nproc": nproc, "kind": kind, "seconds": wall, "runs": len(ws) * per,
                 "sum_of_worker_rates": float(sum(per * Na * Ta / (w["t1"] - w["t0"]) for w in ws)),
                 "start_skew_s": max(w["t0"] for w in ws) - min(w["t0"] for w in ws),
-                "sample": "%d independent runs of (N=2^%d, %d steps) over %d worker processes, one per core, on a "
-                          "host of %d (multiSMC(nruns=%d, nprocs=%d) shape); value = all work / (last end - first start)"
-                          % (len(ws) * per, int(np.log2(Na)), Ta, len(ws), nproc, len(ws) * per, len(ws)),
-                "logLt_sd": float(np.std([l for w in ws for l in w["logLt"]]))}
+                "sample": "%d independent runs (seeds 123 ... %d, one per run) of (N=2^%d, %d steps) over %d worker "
+                          "processes, one per core, on a host of %d (multiSMC(nruns=%d, nprocs=%d) shape); value = all "
+                          "work / (last end - first start)"
+                          % (len(ws) * per, 122 + nw * per, int(np.log2(Na)), Ta, len(ws), nproc, len(ws) * per, len(ws)),
+                "logLt_sd": float(np.std([l for w in ws for l in w["logLt"]])),
+                "distinct_logLt": len(set(l for w in ws for l in w["logLt"]))}
         except Exception as e:          # the leg is a reported baseline: it must not cost the line
             out["all_cores"] = {"error": "%s: %s" % (type(e).__name__, e), "cores": nw, "host_nproc": nproc}
     return out
@@ -345,7 +348,7 @@ def _cpu_name():
 # workloads (BASELINE.json configs)
 # ----------------------------------------------------------------------------------------------
 def make_workload(name, T, scheme="systematic", log2N=None, N=0, islands=1, essrmin=None, collapsed=False, qmc=False,
-                  strict=False):
+                  strict=False, dense=False):
     from particles_amd import kalman
     from particles_amd import state_space_models as ssm
     d = 1
@@ -372,7 +375,8 @@ def make_workload(name, T, scheme="systematic", log2N=None, N=0, islands=1, essr
             x = (model.F @ x if t else np.zeros(d)) + rng.standard_normal(d)
             y.append((x + rng.standard_normal(d)).reshape(1, d))
         fk = ssm.GuidedPF(ssm=model, data=y)
-        label = "C4: MVLinearGauss_Guarniero d=32 guided filter" + (" (collapsed proposal weight)" if collapsed else "")
+        label = "C4: MVLinearGauss_Guarniero d=32 guided filter" + (" (collapsed proposal weight)" if collapsed else "") + \
+                (" [SMC_PATH_MV_DENSE: the model's diagonal factors applied as dense MFMA products all the same]" if dense else "")
     else:
         if name == "c5":      # one GPU's share of 256 islands x 2^18
             log2N = 18 if log2N is None else log2N            # (smaller: functional tests on the emulator)
@@ -386,7 +390,7 @@ def make_workload(name, T, scheme="systematic", log2N=None, N=0, islands=1, essr
     return {"name": name, "fk": fk, "N": N if N > 0 else 1 << log2N, "log2N": log2N, "Nlabel": str(N) if N > 0 else "2^%d" % log2N,
             "islands": islands, "scheme": scheme, "essrmin": 0.5 if essrmin is None else essrmin, "d": d,
             "label": label + (" [strict_ancestors: the reference's sequential fp64 inverse_cdf, bit for bit]" if strict else ""),
-            "collapsed": collapsed, "guided": name == "c4", "qmc": qmc, "strict": strict}
+            "collapsed": collapsed, "guided": name == "c4", "qmc": qmc, "strict": strict, "dense": bool(dense) and name == "c4"}
 
 
 def make_filter(wl, rank=0, graph=False, profile=False):
@@ -396,6 +400,8 @@ def make_filter(wl, rank=0, graph=False, profile=False):
     mode = _lib.RNG_MODE[0]
     if wl.get("qmc"):
         rs.set_rng("philox")              # (device-generated points: the fused SQMC step)
+    if wl.get("dense"):                   # (a verification switch, read when the filter is created: _lib.path_flags)
+        os.environ["SMC_MV_DENSE"] = "1"
     try:
         pf = pa.SMC(fk=wl["fk"], N=wl["N"], resampling=wl["scheme"], ESSrmin=wl["essrmin"], collect="off", seed=123,
                     n_islands=wl["islands"], island_offset=rank * wl["islands"], qmc=bool(wl.get("qmc")),
@@ -403,6 +409,7 @@ def make_filter(wl, rank=0, graph=False, profile=False):
                     strict_ancestors=bool(wl.get("strict")))
     finally:
         rs.set_rng(mode)
+        os.environ.pop("SMC_MV_DENSE", None)
     if wl.get("qmc") and not pf._fused:
         raise RuntimeError("SQMC did not take the fused step (N = 2^k >= 2048 is required)")
     if profile:
@@ -486,12 +493,35 @@ def roofline(wl, step_GBs, mv_ms, rs_ms, nsamples, kernels):
         # GEMM-shaped kernel: priced against the dense fp64 matrix peak (MI355X spec 78.6 TFLOP/s, = its
         # fp64 vector peak).  72 MFMAs (v_mfma_f64_16x16x4: 2048 flop) per 16 particles
         # for the guided d=32 step, 44 with the collapsed weight.
-        flop = (44 if wl["collapsed"] else 72) * 2048.0 / 16.0 * N * isl
+        # "[diagonal factors]" (BASELINE C4's model: G = covX = covY = I): the three triangular factors are applied
+        # element by element and 32 MFMAs per 16 particles remain (F xp, B xp) -- 4 096 flop against 528 B per
+        # particle is BELOW the ridge (78.6 TF / 8 TB/s = 9.8 flop/B), so the bounding roofline of that form is HBM
+        # ("report both bounds for C4"); what limits it in fact is VALU issue (mfma_frac, limiter)
+        diag = "[diagonal factors]" in kernels
+        nm = mfma_per_16(wl["collapsed"], diag)
+        flop = nm * 2048.0 / 16.0 * N * isl
         tf = flop / (mv_ms * 1e-3) / 1e12
-        out.update({"bound": "mfma", "achieved": tf, "peak": FP64_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TF,
-                    "kernel": "k_propagate_mv", "kernel_ms": mv_ms, "launch_bytes": mv_bytes, "launch_flop": flop,
-                    "hbm_achieved_GBs": per[mv_name]["achieved"]})
+        if diag:
+            out.update({"kernel": "k_propagate_mv", "kernel_ms": mv_ms, "launch_bytes": mv_bytes, "launch_flop": flop,
+                        "achieved": per[mv_name]["achieved"], "frac": per[mv_name]["achieved"] / HBM_PEAK_GBS,
+                        "mfma_achieved_TF": tf, "mfma_frac": tf / FP64_PEAK_TF, "mfma_per_16_particles": nm,
+                        "limiter": "valu", "limiter_note": "16 Philox4x32-10 calls + Box-Muller pairs per particle (about 114 vector "
+                        "instructions each) -- and an fp64 MFMA holds the SIMD's vector issue for its 64 cycles "
+                        "(profiles/r15_mfma_shadow.txt), so matrix and vector time add"})
+        else:
+            out.update({"bound": "mfma", "achieved": tf, "peak": FP64_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TF,
+                        "kernel": "k_propagate_mv", "kernel_ms": mv_ms, "launch_bytes": mv_bytes, "launch_flop": flop,
+                        "hbm_achieved_GBs": per[mv_name]["achieved"], "mfma_per_16_particles": nm})
     return out
+
+
+def mfma_per_16(collapsed, diag):
+    """v_mfma_f64_16x16x4_f64 per 16 particles of k_propagate_mv's guided d = 32 step (smc_filter_mv.h): F xp and B xp
+    (16 each), L_P z and L_X^-1 (x - m) (12 each, triangular), -(L_Y^-1 G) x (16); collapsed weight: B xp, -(L_S^-1 G F) xp,
+    L_P z; with diagonal factors the triangular ones and -(L_Y^-1 G) are element-wise."""
+    if diag:
+        return 32
+    return 44 if collapsed else 72
 
 
 ROOFLINE_NOTE = (
@@ -517,6 +547,7 @@ def other_workloads(K=20, W=100, R=15, shrink=0):
             ("c3_stratified", dict(name="c3", scheme="stratified")),
             ("c3_multinomial", dict(name="c3", scheme="multinomial")),
             ("c4", dict(name="c4")),
+            ("c4_dense", dict(name="c4", dense=True)),
             ("c4_collapsed", dict(name="c4", collapsed=True)),
             ("c5", dict(name="c5")),
             ("sqmc", dict(name="c2", qmc=True)),
@@ -554,12 +585,129 @@ def other_workloads(K=20, W=100, R=15, shrink=0):
                         "leg_seconds": time.perf_counter() - t_leg}
             if not shrink:
                 add_profile_fractions(rf, wl)
-            for k in ("traffic", "traffic_source", "frac_rocprof", "frac_physical", "rocprof_kernel_us", "launch_flop"):
+            for k in ("traffic", "traffic_source", "frac_rocprof", "frac_physical", "rocprof_kernel_us", "launch_flop",
+                      "mfma_frac", "mfma_per_16_particles", "limiter"):
                 if k in rf:
                     out[key][k] = rf[k]
         except Exception as e:          # one failing leg must not cost the headline its line
             out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
     return out
+
+
+def small_and_generic_legs(shrink=0):
+    """Driver-visible figures for the three regimes `other_workloads`' big fused legs do not cover:
+      c1            BASELINE config C1 -- ToySSM, N = 1000, T = 200, systematic, ONE filter: the whole T-loop is one launch of
+                    k_filter_small (one workgroup); this is PMMH's inner call (mcmc.py:445-450: one SMC run per MCMC iteration),
+                    so the figure that matters is microseconds per RUN (create + run + read logLt, and run alone);
+      c1_islands    1024 such filters as islands of one launch (SMC^2's N_theta x N_x batch, smc_samplers.py:1110-1113);
+      generic_model a USER-DEFINED StateSpaceModel (PX0 / PX / PY written with the distributions module, core.py:108-197,
+                    state_space_models.py:232-259) at N = 2^20 on the template-method step -- device operators, arrays
+                    resident in HBM, Philox draws: the drop-in's non-fused path.
+    shrink > 0: emulator sizes (functional tests)."""
+    import particles_amd as pa
+    from particles_amd import kalman, distributions as dists, resampling as rs
+    from particles_amd import state_space_models as ssm
+    out = {}
+    N1, T1 = (1000, 200) if not shrink else (300, 6)
+    y = synthetic_data(T1)
+    fk = ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y)
+    for key, isl, reps in (("c1", 1, 30 if not shrink else 2), ("c1_islands", 1024 if not shrink else 3, 8 if not shrink else 2)):
+        t_leg = time.perf_counter()
+        try:
+            mk = lambda seed: pa.SMC(fk=fk, N=N1, resampling="systematic", ESSrmin=0.5, collect="off", seed=seed, n_islands=isl)
+            w = mk(0); w.run(); _ = w.logLts_islands       # (first launch: code object load)
+            desc = _describe(w)
+            tot, run = [], []
+            for r in range(reps):
+                t0 = time.perf_counter()
+                pf = mk(1 + r)
+                t1 = time.perf_counter()
+                pf.run()
+                ll = pf.logLts_islands                     # (the run's result on the host: what PMMH / SMC^2 read)
+                t2 = time.perf_counter()
+                tot.append(t2 - t0); run.append(t2 - t1)
+            dt, dr = float(np.median(tot)), float(np.median(run))
+            units = float(N1) * T1 * isl
+            alg = 56.0 * units                             # SURVEY 8d's accounting (16 d + 40 B per particle-step)
+            out[key] = {"workload": "C1: ToySSM d=1 bootstrap filter, N=%d, T=%d, systematic, ESSrmin=0.5, %d filter(s) in one launch"
+                                    % (N1, T1, isl),
+                        "value": units / dr, "unit": "particle-steps/s", "us_per_run": 1e6 * dr, "us_per_run_with_create": 1e6 * dt,
+                        "us_per_step": 1e6 * dr / T1, "filters": isl, "reps": reps, "step_kernels": desc,
+                        "logLt_first": float(np.atleast_1d(ll)[0]), "kalman_logLt": kalman_loglik_toy(y),
+                        "roofline": {"bound": "hbm", "achieved": alg / dr / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": alg / dr / 1e9 / HBM_PEAK_GBS, "traffic": None, "limiter": "latency+valu",
+                                     "note": "one workgroup per filter runs all T steps in ONE launch with the particles in LDS: "
+                                             "`achieved` prices SURVEY 8d's 56 B per particle-step, bytes that never reach HBM here "
+                                             "(what does: y, the summary ring, the final state); a single filter occupies one CU "
+                                             "of 256 and is bound by the T dependent steps, the batch by VALU issue"},
+                        "leg_seconds": time.perf_counter() - t_leg}
+        except Exception as e:
+            out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+    t_leg = time.perf_counter()
+    try:
+        class UserToySSM(ssm.StateSpaceModel):     # what a user of the reference writes (README.md:66-72)
+            default_params = {"sigma": 0.2}
+
+            def PX0(self):
+                return dists.Normal()
+
+            def PX(self, t, xp):
+                return dists.Normal(loc=xp)
+
+            def PY(self, t, xp, x):
+                return dists.Normal(loc=x, scale=self.sigma)
+        Ng, K, W = (1 << 20, 20, 3) if not shrink else (1 << shrink, 2, 1)
+        yg = synthetic_data(W + K + 1)
+        mode, res = _lib_rng_mode(), _lib_resident()
+        pa.set_resident(True); rs.set_rng("philox")
+        try:
+            pf = pa.SMC(fk=ssm.Bootstrap(ssm=UserToySSM(sigma=0.2), data=yg), N=Ng, resampling="systematic", ESSrmin=0.5,
+                        collect="off")
+            for _ in range(W):
+                next(pf)
+            pf.sync() if hasattr(pf, "sync") else None
+            t0 = time.perf_counter()
+            for _ in range(K):
+                next(pf)
+            ll = float(pf.logLt)                       # (forces the last step's results)
+            dt = (time.perf_counter() - t0) / K
+            fused = bool(getattr(pf, "_fused", False))
+        finally:
+            pa.set_resident(res); rs.set_rng(mode)
+        if fused:
+            raise RuntimeError("the user-defined model took the fused step: the leg would not measure the operator path")
+        out["generic_model"] = {"workload": "user-defined StateSpaceModel (ToySSM written with distributions.Normal), Bootstrap, "
+                                            "N=%d, systematic, ESSrmin=0.5: template-method step on device operators "
+                                            "(set_resident(True), Philox draws)" % Ng,
+                                "value": Ng / dt, "unit": "particle-steps/s", "ms_per_step": 1e3 * dt, "steps": K, "warmup": W,
+                                "logLt": ll, "kalman_logLt": kalman_loglik_toy(yg[:W + K]),
+                                "roofline": {"bound": "hbm", "achieved": 56.0 * Ng / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                             "frac": 56.0 * Ng / dt / 1e9 / HBM_PEAK_GBS, "traffic": None, "limiter": "host+launches",
+                                             "note": "about a dozen operator launches per step, each enqueued from Python through "
+                                                     "ctypes, with one host sync for the ESS decision (core.py:327): bound by the "
+                                                     "host, not by the device; the fused descriptors exist to avoid exactly this"},
+                                "leg_seconds": time.perf_counter() - t_leg}
+    except Exception as e:
+        out["generic_model"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return out
+
+
+def _describe(pf):
+    import ctypes
+    from particles_amd import _lib
+    desc = ctypes.create_string_buffer(256)
+    _lib.check(_lib.lib().smc_filter_describe(pf._f, desc, 256))
+    return desc.value.decode()
+
+
+def _lib_rng_mode():
+    from particles_amd import _lib
+    return _lib.RNG_MODE[0]
+
+
+def _lib_resident():
+    from particles_amd import _lib
+    return bool(_lib.RESIDENT[0])
 
 
 def _spawn_ranks(n):
@@ -583,7 +731,7 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
         kind, N, nsteps, nruns = sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
         return _cpu_worker(kind, N, nsteps, nruns, sys.argv[6] if len(sys.argv) > 6 else "",
-                           int(sys.argv[7]) if len(sys.argv) > 7 else 0)
+                           int(sys.argv[7]) if len(sys.argv) > 7 else 0, int(sys.argv[8]) if len(sys.argv) > 8 else 0)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
@@ -606,6 +754,8 @@ def main():
     ap.add_argument("--other-shrink", type=int, default=0, help=argparse.SUPPRESS)     # tests: other_workloads at 2^k
     ap.add_argument("--collapsed", action="store_true",
                     help="c4: the collapsed form of the optimal proposal's weight (SMC_FLAG_COLLAPSED_PROPOSAL)")
+    ap.add_argument("--dense", action="store_true",
+                    help="c4: SMC_PATH_MV_DENSE -- dense MFMA products although the model's noise factors are diagonal (the `c4_dense` leg)")
     ap.add_argument("--allow-host-gather", action="store_true",
                     help="N > 1: if RCCL cannot be initialised, gather the evidences over the host rendezvous "
                          "(labelled in the line) instead of failing")
@@ -674,7 +824,7 @@ def main():
     R = a.reps if a.reps > 0 else max(3, min(500, -(-(2000 if heavy else 10000) // K)))
     T = W + R * K + (K if world > 1 else 0)      # (N > 1: one more K-step region, timed WITH the evidence gather)
     wl = make_workload(a.workload, T, scheme=a.scheme, log2N=a.log2N, N=a.N, islands=a.islands,
-                       essrmin=a.essrmin, collapsed=a.collapsed, qmc=a.qmc, strict=a.strict)
+                       essrmin=a.essrmin, collapsed=a.collapsed, qmc=a.qmc, strict=a.strict, dense=a.dense)
     a.log2N, a.islands = wl["log2N"], wl["islands"]
     N, d = wl["N"], wl["d"]
     bytes_step = 16.0 * d + 40.0
@@ -829,6 +979,7 @@ def main():
             and (a.log2N == 20 or a.other_shrink):
         out["other_workloads"] = (other_workloads(K=3, W=2, R=2, shrink=a.other_shrink) if a.other_shrink
                                   else other_workloads())
+        out["other_workloads"].update(small_and_generic_legs(shrink=a.other_shrink))
     if rank == 0 and world == 1 and not a.no_cpu_baseline and a.workload == "c2":
         nst = min(a.cpu_steps, T) if a.log2N >= 18 else min(T, 2000)
         try:

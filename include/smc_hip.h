@@ -377,8 +377,8 @@ typedef struct smc_filter_opts {
 #define SMC_PATH_STRICT_LITERAL   (1 << 6)   /* SMC_FLAG_STRICT_ANCESTORS: the sequential CDF by the literal one-lane walk, not its parallel emulation */
 #define SMC_PATH_WIDE4            (1 << 7)   /* k_ancestors2w with 4 tiles per workgroup instead of 2 */
 #define SMC_PATH_SQ_GATHER        (1 << 29)  /* SMC_FLAG_SQMC: gather the sorted log-weights where they could be recomputed */
-#define SMC_PATH_SP_SIDE          (1 << 3)   /* multinomial: the NEXT step's spacings drawn on a side stream beside k_propagate (A/B: measured slower) */
-#define SMC_PATH_NO_SP_SIDE       (1 << 4)   /* ... never (the default) */
+#define SMC_PATH_MV_DENSE         (1 << 3)   /* MVLINGAUSS with diagonal G / covX / covY / cov0: the dense MFMA products all the same (the twin the
+                                               element-wise form is checked against, bit for bit; bench.py's c4_dense leg) */
 #define SMC_PATH_STRICT_ONE_LAUNCH (1u << 31)  /* SMC_FLAG_STRICT_ANCESTORS: k_strict_classify + k_strict_search as ONE launch (k_strict_step) where
                                                 * the whole grid is resident at once; the caller vouches that no other process shares the device */
 #define SMC_PATH_SP_TPW(n)        (((n) & 15) << 25)   /* one-pass spacings: n = 1, 2, 4, 8 tiles of draws per workgroup */

@@ -36,15 +36,31 @@ def is_stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    if not force and not is_stale():
+def build(force=False, verbose=False, extra=(), out=None):
+    """One hipcc -c per source, side by side (the translation units share no device symbols), then one link.
+    extra: more compiler flags (ablation builds: -DSMC_...); out: another library path."""
+    out = out or LIBPATH
+    if not force and not extra and out == LIBPATH and not is_stale():
         return LIBPATH
-    os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [_hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIBPATH]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd + ["-ldl"], check=True)
-    return LIBPATH
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    cflags = [f for f in FLAGS if f != "-shared"] + list(extra)
+    with tempfile.TemporaryDirectory(prefix="smc_build_") as tmp:
+        def one(src):
+            obj = os.path.join(tmp, src.replace(".hip", ".o"))
+            cmd = [_hipcc()] + cflags + ["-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+            return obj
+        with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as ex:
+            objs = list(ex.map(one, SOURCES))
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out, "-ldl"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return out
 
 
 if __name__ == "__main__":

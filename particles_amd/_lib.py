@@ -56,7 +56,7 @@ PATH_FLAGS = {"SMC_FLAT_CDF": 1 << 8, "SMC_TWO_LEVEL_MID": 1 << 9, "SMC_EXACT_CO
               "SMC_NO_NT": 1 << 14, "SMC_NO_HEAVY": 1 << 15, "SMC_NO_TK": 1 << 16,
               "SMC_FLAT_MULTINOMIAL": 1 << 17, "SMC_POW2_ONLY": 1 << 18, "SMC_SPACING_3PASS": 1 << 19,
               "SMC_SPLIT_REDUCE": 1 << 24, "SMC_SQ_GATHER": 1 << 29, "SMC_NO_WIDE": 1 << 30, "SMC_WIDE4": 1 << 7,
-              "SMC_STRICT_LITERAL": 1 << 6, "SMC_NO_XCD_CHUNKS": 1 << 5, "SMC_SP_SIDE": 1 << 3, "SMC_NO_SP_SIDE": 1 << 4,
+              "SMC_STRICT_LITERAL": 1 << 6, "SMC_NO_XCD_CHUNKS": 1 << 5, "SMC_MV_DENSE": 1 << 3,
               "SMC_STRICT_ONE_LAUNCH": 1 << 31}
 
 

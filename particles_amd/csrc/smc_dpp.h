@@ -87,6 +87,66 @@ __device__ __forceinline__ double smc_dpp_f64(double v)
         (long long)smc_dpp64<CTRL, ROW_MASK, OWN>((u64)__double_as_longlong(v)));
 }
 
+// gfx950's lane swaps (v_permlane16_swap_b32 / v_permlane32_swap_b32): ONE VALU instruction trades rows (16 lanes)
+// 1 and 3 of `a` with rows 0 and 2 of `b` (SWAP16), or the upper 32 lanes of `a` with the lower 32 of `b` (SWAP32) --
+// both directions at once, no LDS round trip (ds_bpermute) and no select afterwards:
+//   swap16:  a' = [a.r0, b.r0, a.r2, b.r2]   b' = [a.r1, b.r1, a.r3, b.r3]
+//   swap32:  a' = [a.lo, b.lo]               b' = [a.hi, b.hi]
+#ifdef SMC_EMULATE
+inline void smc_swap16(unsigned& a, unsigned& b)
+{
+    const int l = emu_lane();
+    const unsigned af = hipemu::exchange(a, emu_wbase() + (l ^ 16)), bf = hipemu::exchange(b, emu_wbase() + (l ^ 16));
+    if ((l >> 4) & 1) a = bf; else b = af;
+}
+inline void smc_swap32(unsigned& a, unsigned& b)
+{
+    const int l = emu_lane();
+    const unsigned af = hipemu::exchange(a, emu_wbase() + (l ^ 32)), bf = hipemu::exchange(b, emu_wbase() + (l ^ 32));
+    if (l & 32) a = bf; else b = af;
+}
+#else
+__device__ __forceinline__ void smc_swap16(unsigned& a, unsigned& b)
+{
+    const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    a = r[0]; b = r[1];
+}
+__device__ __forceinline__ void smc_swap32(unsigned& a, unsigned& b)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0]; b = r[1];
+}
+#endif
+__device__ __forceinline__ void smc_swap16_f64(double& a, double& b)
+{
+    const u64 ua = (u64)__double_as_longlong(a), ub = (u64)__double_as_longlong(b);
+    unsigned al = (unsigned)ua, ah = (unsigned)(ua >> 32), bl = (unsigned)ub, bh = (unsigned)(ub >> 32);
+    smc_swap16(al, bl);
+    smc_swap16(ah, bh);
+    a = __longlong_as_double((long long)(((u64)ah << 32) | al));
+    b = __longlong_as_double((long long)(((u64)bh << 32) | bl));
+}
+__device__ __forceinline__ void smc_swap32_f64(double& a, double& b)
+{
+    const u64 ua = (u64)__double_as_longlong(a), ub = (u64)__double_as_longlong(b);
+    unsigned al = (unsigned)ua, ah = (unsigned)(ua >> 32), bl = (unsigned)ub, bh = (unsigned)(ub >> 32);
+    smc_swap32(al, bl);
+    smc_swap32(ah, bh);
+    a = __longlong_as_double((long long)(((u64)ah << 32) | al));
+    b = __longlong_as_double((long long)(((u64)bh << 32) | bl));
+}
+// sum over the 4 lanes l, l ^ 16, l ^ 32, l ^ 48 (one lane of every row), every one of them gets it:
+// (v + v[l ^ 16]) + the same of l ^ 32 -- the tree of two __shfl_xor steps (additions commute: same bits)
+__device__ __forceinline__ double smc_sum_rows(double v)
+{
+    double a = v, b = v;
+    smc_swap16_f64(a, b);        // a = the even row's value of the pair, b = the odd row's
+    a = a + b;
+    b = a;
+    smc_swap32_f64(a, b);        // a = the lower half's pair sum, b = the upper half's
+    return a + b;
+}
+
 // inclusive scans over the 64 lanes of a wave (all lanes must be active)
 __device__ __forceinline__ u64 smc_wave_scan_add_u64(u64 v)
 {

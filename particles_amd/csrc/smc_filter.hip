@@ -40,14 +40,6 @@ struct smc_filter {
     // sort's workspace and -- more than one island -- the islands' permutations
     u64 sp_epoch;          // launches of the merged spacings + reduction kernel so far (see FArgs::sp_epoch)
     bool sp_merge;
-    // multinomial, Philox draws, large N: uniform_spacings of step t + 1 drawn on a SIDE stream while k_propagate(t) runs
-    // (a log-bound kernel beside a byte-bound one); two buffers of (Z, E, look-back words), by the parity of t
-    bool sp_side;
-    hipStream_t side;
-    hipEvent_t ev_sp[2], ev_main;
-    double* su2[2];
-    u64 *E2[2], *sst2[2];
-    i64 sp_ahead_t;        // the step whose spacings the side stream has been given (-1: none)
     bool flush_pending;    // two-level step: the summary row of the last step enqueued is still to be written (k_flush2 on demand)
     bool sqmc, sq_gather;
     bool sq_flat;          // SQMC on the flat step (multivariate filters; univariate ones below two tiles)
@@ -90,7 +82,13 @@ static void launch_propagate(smc_filter* f)
     if (f->kind == SMC_MODEL_MVLINGAUSS) {
 #define MV_CASE(FKV, DPV, COLLV)                                                            \
     if (f->fk == FKV && f->a.dp == DPV && f->mv_collapsed == COLLV) {                       \
-        if (f->a.dx == DPV)                                                                 \
+        if (f->a.dx == DPV && f->a.mv_diag)                                                 \
+            SMC_LAUNCH((k_propagate_mv<FKV, DPV, true, COLLV, true>), grid, dim3(SMC_BLOCK), st,  \
+                       f->a, f->a.mvc);                                                     \
+        else if (f->a.mv_diag)                                                              \
+            SMC_LAUNCH((k_propagate_mv<FKV, DPV, false, COLLV, true>), grid, dim3(SMC_BLOCK), st, \
+                       f->a, f->a.mvc);                                                     \
+        else if (f->a.dx == DPV)                                                            \
             SMC_LAUNCH((k_propagate_mv<FKV, DPV, true, COLLV>), grid, dim3(SMC_BLOCK), st,  \
                        f->a, f->a.mvc);                                                     \
         else                                                                                \
@@ -151,12 +149,6 @@ static void launch_onepass(const FArgs& a, const dim3 gw, hipStream_t st)
     case 4: SMC_LAUNCH(k_f_spacing_onepass<4>, gw, dim3(SMC_BLOCK), st, a); break;
     default: SMC_LAUNCH(k_f_spacing_onepass<8>, gw, dim3(SMC_BLOCK), st, a); break;
     }
-}
-// the side stream's work is made part of the main stream's order (end of every smc_filter_step call, clone, save,
-// destroy): everything outside the step loop then needs to know of one stream only
-static void join_side(smc_filter* f)
-{
-    if (f->sp_side && f->sp_ahead_t >= 0) (void)hipStreamWaitEvent(f->ctx->stream, f->ev_sp[f->sp_ahead_t & 1], 0);
 }
 
 // one time step: [k_prepare, (spacings), k_ancestors] do nothing unless the step
@@ -294,32 +286,7 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
         return;
     }
     if (f->two_level) {
-        if (f->two_level_mid && f->a.scheme == SMC_MULTINOMIAL && f->sp_side && t_known && !f->a.ut) {
-            // large N: the step's spacings were drawn one step ahead on the side stream (or are drawn here, the first
-            // time); the island's reduction is a launch of its own again, and the NEXT step's spacings leave for the side
-            // stream behind this step's k_ancestors2, to run beside k_propagate
-            const int pb = (int)(t & 1);
-            f->a.sp_epoch = 0ull;
-            f->a.sp_ahead = 0;
-            f->a.su = f->su2[pb]; f->a.E = f->E2[pb]; f->a.sst = f->sst2[pb];
-            SMC_LAUNCH(k_reduce2, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
-            if (f->sp_ahead_t == t) (void)hipStreamWaitEvent(st, f->ev_sp[pb], 0);
-            else launch_onepass(f->a, dim3(f->a.sp_nwg, f->a.n_islands), st);
-            SMC_LAUNCH((k_ancestors2<true, true, true, true>), grid, dim3(SMC_BLOCK), st, f->a);
-            if (t + 1 < f->a.T) {
-                const int nb = pb ^ 1;
-                (void)hipEventRecord(f->ev_main, st);
-                (void)hipStreamWaitEvent(f->side, f->ev_main, 0);
-                (void)hipMemsetAsync(f->sst2[nb], 0, (size_t)f->a.n_islands * f->a.sp_nwg * 8, f->side);
-                FArgs b = f->a;
-                b.su = f->su2[nb]; b.E = f->E2[nb]; b.sst = f->sst2[nb];
-                b.sp_ahead = 1;
-                b.sp_t = t + 1;
-                launch_onepass(b, dim3(f->a.sp_nwg, f->a.n_islands), f->side);
-                (void)hipEventRecord(f->ev_sp[nb], f->side);
-                f->sp_ahead_t = t + 1;
-            }
-        } else if (f->two_level_mid && f->a.scheme == SMC_MULTINOMIAL) {
+        if (f->two_level_mid && f->a.scheme == SMC_MULTINOMIAL) {
             // (the island's reduction: a launch of its own, or workgroup 0 of the one-pass spacings kernel)
             const bool merge = f->sp_merge && !f->a.ut && f->a.sp_tpw && t_known;
             f->a.sp_epoch = merge ? ++f->sp_epoch : 0ull;
@@ -506,6 +473,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     SMC_REQUIRE(mv || model->params_host, "params_host is required");
     int dxm = 1, dym = 1, dpm = 1;
     std::vector<double> mvc_host;
+    bool mv_diag = false;
     if (mv) {
         dxm = model->dx; dym = model->dy;
         SMC_REQUIRE(dxm >= 1 && dxm <= 32 && dym >= 1 && dym <= dxm,
@@ -513,7 +481,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
         SMC_REQUIRE(model->F_host && model->G_host && model->covX_host && model->covY_host &&
                         model->mu0_host && model->cov0_host, "MVLINGAUSS matrices are required");
         dpm = dxm <= 16 ? 16 : 32;              // padded to whole 16x16 MFMA blocks
-        if (!mv_build_constants(model, model->fk, dpm, o->T, y_host, mvc_host)) {
+        if (!mv_build_constants(model, model->fk, dpm, o->T, y_host, mvc_host, &mv_diag)) {
             // same failure as MvNormal.__init__ (distributions.py:935-940)
             smc_set_error("MvNormal: argument cov must be a (d, d) pos. definite matrix");
             return SMC_ERR_INVALID;
@@ -623,14 +591,17 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     // MV: a workgroup stages the step's matrices in LDS once and then walks
     // mv_chunks chunks of 256 particles (2 workgroups per CU when N allows)
     a.mv_chunks = 1;
+    a.mv_diag = (mv && mv_diag && !(o->flags & SMC_PATH_MV_DENSE)) ? 1 : 0;
     if (mv) {
-        // 8 by default, halved until the grid has at least 512 workgroups; SMC_PATH_MV_CHUNKS(1|2|4|8)
-        // (tests) is taken as given, so that the multi-chunk prefetch loop is audited at small N too
+        // 8 by default, halved until the grid has at least 512 workgroups (element-wise form: 2 workgroups per CU) or
+        // 1024 (dense form: 3 per CU fit); SMC_PATH_MV_CHUNKS(1|2|4|8) (tests) is taken as given, so that the
+        // multi-chunk prefetch loop is audited at small N too
         const int forced = (o->flags >> 20) & 15;
         if (forced == 1 || forced == 2 || forced == 4 || forced == 8) a.mv_chunks = forced;
         else {
+            const i64 min_grid = a.mv_diag ? 512 : 1024;
             a.mv_chunks = 8;
-            while (a.mv_chunks > 1 && (i64)N / (SMC_BLOCK * a.mv_chunks) < 512) a.mv_chunks >>= 1;
+            while (a.mv_chunks > 1 && (i64)N / (SMC_BLOCK * a.mv_chunks) < min_grid) a.mv_chunks >>= 1;
         }
     }
     const i64 per_wg = mv ? (i64)SMC_BLOCK * a.mv_chunks : (i64)SMC_BLOCK * F_OPT;
@@ -741,17 +712,6 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
             }
         }
     const size_t oSst = carve(a.sp_tpw ? M * a.sp_nwg * 8 : 8);
-    // side-stream spacings (see smc_filter::sp_side): OFF unless SMC_PATH_SP_SIDE asks for them.  Built as VERDICT r4 item 4
-    // proposed and measured at C3 (N = 2^22, profiles/r14d_c3_multinomial_side_stream.txt): 86.6 us per step against 74.2
-    // with the spacings drawn inside the step -- k_propagate is itself 65 % VALU-busy at this size, so the log-bound
-    // kernel beside it finds little idle issue capacity, the island's reduction becomes a launch of its own again
-    // (8 us that the merged launch hid), and two cross-stream event dependencies per step cost more than the overlap
-    // returns.  Kept behind the switch (the test keeps the path alive); eager launches, Philox draws, non-strict step.
-    f->sp_side = a.sp_tpw && !f->strict && !o->use_graph && (o->flags & SMC_PATH_SP_SIDE) &&
-                 !(o->flags & (SMC_PATH_SPLIT_REDUCE | SMC_PATH_NO_SP_SIDE)) && o->rng_mode == SMC_RNG_PHILOX;
-    const size_t oSu2 = carve(f->sp_side ? M * N * 8 + 16 : 8);
-    const size_t oE2 = carve(f->sp_side ? M * (a.ntiles1 + 1) * 8 : 8);
-    const size_t oSst2 = carve(f->sp_side ? M * a.sp_nwg * 8 : 8);
     const size_t oSdec = carve(M * 8);
     f->sp_epoch = 0;
     f->flush_pending = false;
@@ -863,20 +823,6 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     a.su = (double*)(base + oSu);
     a.E = (u64*)(base + oE);
     a.sst = (u64*)(base + oSst);
-    f->su2[0] = a.su; f->E2[0] = a.E; f->sst2[0] = a.sst;
-    f->su2[1] = f->sp_side ? (double*)(base + oSu2) : a.su;
-    f->E2[1] = f->sp_side ? (u64*)(base + oE2) : a.E;
-    f->sst2[1] = f->sp_side ? (u64*)(base + oSst2) : a.sst;
-    f->sp_ahead_t = -1;
-    f->side = nullptr;
-    f->ev_sp[0] = f->ev_sp[1] = f->ev_main = nullptr;
-    if (f->sp_side) {
-        F_CREATE_CHECK(hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking));
-        F_CREATE_CHECK(hipEventCreate(&f->ev_sp[0]));
-        F_CREATE_CHECK(hipEventCreate(&f->ev_sp[1]));
-        F_CREATE_CHECK(hipEventCreate(&f->ev_main));
-        F_CREATE_CHECK(hipMemsetAsync(f->sst2[1], 0, M * a.sp_nwg * 8, ctx->stream));
-    }
     if (a.sp_tpw) F_CREATE_CHECK(hipMemsetAsync(a.sst, 0, M * a.sp_nwg * 8, ctx->stream));
     a.sdec = (u64*)(base + oSdec);
     F_CREATE_CHECK(hipMemsetAsync(a.sdec, 0, M * 8, ctx->stream));
@@ -981,12 +927,6 @@ int smc_filter_destroy(smc_filter* f)
     for (hipGraphExec_t g : f->gexec)
         if (g) (void)hipGraphExecDestroy(g);
     for (hipEvent_t e : f->ev) (void)hipEventDestroy(e);
-    if (f->side) {
-        (void)hipStreamSynchronize(f->side);
-        (void)hipStreamDestroy(f->side);
-        for (hipEvent_t e : {f->ev_sp[0], f->ev_sp[1], f->ev_main})
-            if (e) (void)hipEventDestroy(e);
-    }
     (void)smc_free(f->ctx, f->slab);
     if (f->ll_stage) {
         auto& v = f->ctx->pinned[(size_t)f->a.n_islands * 8];
@@ -1036,14 +976,6 @@ int smc_filter_clone(smc_filter* src, smc_filter** out)
     rebase(a.su); rebase(a.E); rebase(a.sst); rebase(a.mvc); rebase(a.trace); rebase(a.pm2); rebase(a.ps2); rebase(a.pss2);
     rebase(a.eta); rebase(a.lwsv); rebase(a.sdec);
     rebase(f->tmp); rebase(f->strict_ws); rebase(f->sq_z); rebase(f->sq_perm); rebase(f->sq_ws);
-    rebase(f->su2[0]); rebase(f->su2[1]); rebase(f->E2[0]); rebase(f->E2[1]); rebase(f->sst2[0]); rebase(f->sst2[1]);
-    f->side = nullptr;
-    f->ev_sp[0] = f->ev_sp[1] = f->ev_main = nullptr;
-    f->sp_ahead_t = -1;                    // (the copy draws its next spacings itself: it may be re-keyed)
-    if (f->sp_side && (hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking) != hipSuccess ||
-                       hipEventCreate(&f->ev_sp[0]) != hipSuccess || hipEventCreate(&f->ev_sp[1]) != hipSuccess ||
-                       hipEventCreate(&f->ev_main) != hipSuccess))
-        f->sp_side = false;
     hipStream_t st = ctx->stream;
     hipError_t e = hipMemcpyAsync(slab, src->slab, src->slab_bytes, hipMemcpyDeviceToDevice, st);
     if (e == hipSuccess && src->th_buf) {
@@ -1131,10 +1063,8 @@ int smc_filter_load_state(smc_filter* f, const void* in_host, int64_t nbytes)
     f->a.seed = h.seed; f->sp_epoch = h.sp_epoch; f->sq_seed = h.sq_seed; f->sq_ctr0 = h.sq_ctr0;
     f->flush_pending = h.flush_pending != 0;
     f->a.island_offset = h.island_offset;
-    f->sp_ahead_t = -1;                    // (spacings drawn ahead belonged to the filter this one was)
     if (f->strict && !f->strict_literal)   // (k_strict_step's epoch word counted the OTHER filter's launches)
         sqx_zero_done(f->ctx->stream, (void*)(f->strict_ws + 2 * (size_t)f->a.n_islands * f->a.N), f->a.N, f->a.n_islands);
-    if (f->sp_side) SMC_HIP_CHECK(hipMemsetAsync(f->sst2[1], 0, (size_t)f->a.n_islands * f->a.sp_nwg * 8, f->ctx->stream));
     for (hipGraphExec_t& g : f->gexec)          // captured launches carry the old key / counters by value
         if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
     return SMC_OK;
@@ -1145,7 +1075,6 @@ int smc_filter_reseed(smc_filter* f, uint64_t seed)
 {
     SMC_REQUIRE(f, "null filter");
     f->a.seed = seed;
-    f->sp_ahead_t = -1;                    // (spacings drawn ahead carry the old key)
     for (hipGraphExec_t& g : f->gexec)          // captured launches carry the old key by value
         if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
     return SMC_OK;
@@ -1313,7 +1242,6 @@ int smc_filter_step(smc_filter* f, int64_t nsteps)
         enqueue_step(f, kp, f->t_host + done);
     }
     if (f->two_level && todo > 0) f->flush_pending = true;      // summary row of the last step: flush_rows, on demand
-    join_side(f);
     SMC_LAUNCH_CHECK();
     f->t_host += todo;
     return SMC_OK;
@@ -2006,19 +1934,14 @@ int smc_filter_describe(smc_filter* f, char* out, size_t n)
         else s = "k_prepare+k_ancestors";
         if (f->a.scheme == SMC_MULTINOMIAL && !f->a.ut)
             s = (f->a.sp_tpw ? "k_f_spacing_onepass+" : "k_f_spacing_sums+k_f_spacing_scan+k_f_spacing_write+") + s;
-        if (f->sp_side && f->a.scheme == SMC_MULTINOMIAL && !f->a.ut && f->two_level_mid) {
-            // (the spacings of step t + 1 are drawn on the side stream while k_propagate(t) runs)
-            s = "k_reduce2+k_ancestors2";
-        } else if (f->sp_merge && f->a.scheme == SMC_MULTINOMIAL && !f->a.ut && f->two_level_mid) {
+        if (f->sp_merge && f->a.scheme == SMC_MULTINOMIAL && !f->a.ut && f->two_level_mid) {
             const size_t p = s.find("+k_reduce2");
             if (p != std::string::npos) s.replace(0, p + 10, "k_f_spacing_onepass<with k_reduce2>");
         }
         if (mv && f->fk == SMC_FK_APF) s = "k_mv_aux+k_mv_aux_restate+" + s;
         s += mv ? (f->mv_collapsed ? "+k_propagate_mv<collapsed>" : "+k_propagate_mv") : "+k_propagate";
-        if (mv) s += " [mv_chunks=" + std::to_string(f->a.mv_chunks) + "]";
+        if (mv) s += " [mv_chunks=" + std::to_string(f->a.mv_chunks) + "]" + (f->a.mv_diag ? " [diagonal factors]" : "");
         if (f->a.mom) s += "+k_f_moments_partials+k_f_moments_final";
-        if (f->sp_side && f->a.scheme == SMC_MULTINOMIAL && !f->a.ut && f->two_level_mid)
-            s += " [k_f_spacing_onepass of step t+1 on a side stream, beside k_propagate(t)]";
     }
     snprintf(out, n, "%s", s.c_str());
     return SMC_OK;

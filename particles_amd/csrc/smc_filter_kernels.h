@@ -136,8 +136,8 @@ struct FArgs {
     double *eta, *lwsv;    // APF of MVLINGAUSS (smc_filter_mv.h k_mv_aux): (n_islands, N) logeta of the step's
                            // parents and their plain log-weights, set aside while lw + eta drives the resampling
     int xcd_chunks;        // two-level step: workgroup -> tile map that keeps CONSECUTIVE tiles on one XCD (f_tile_xcd)
-    int sp_ahead;          // one-pass uniform_spacings launched AHEAD of its step on the filter's side stream (the draws are a
-    i64 sp_t;              // function of (seed, t) only): the step is sp_t, not the record's, and nobody's decision is awaited
+    int mv_diag;           // MVLINGAUSS: G, covX, covY, cov0 are all diagonal -- the three triangular factors of the step are
+                           // diagonal too and k_propagate_mv<..., DG> applies them element by element (smc_filter_mv.h)
     int strict_e;          // SMC_FLAG_STRICT_ANCESTORS on the two-level step: nobody reads the tile's integer CDF, so `cq` holds
                            // every particle's weight on its TILE's scale instead, e_j = p_j 2^(k_j - K_b) (a double): what
                            // k_strict_classify forms W_j from without evaluating an exponential again
@@ -662,10 +662,9 @@ k_f_spacing_onepass(const FArgs av)
     smc_ntab_stage<SMC_BLOCK>(s_ntab, tid);
     __syncthreads();
     // (merged: the record is being written by workgroup 0 -- the count of steps done is k_propagate's)
-    // (sp_ahead: launched one step ahead on the side stream, while k_propagate(sp_t - 1) runs: the step is the host's)
     const double* info = merged ? a.info2 + (i64)isl * INFO_STRIDE : a.info + (i64)isl * INFO_STRIDE;
-    const i64 t = a.sp_ahead ? a.sp_t : (i64)smc_uniform(info[0]);
-    if (t >= a.T || t == 0 || (!a.sp_ahead && !merged && smc_uniform(info[1]) == 0.0)) return;
+    const i64 t = (i64)smc_uniform(info[0]);
+    if (t >= a.T || t == 0 || (!merged && smc_uniform(info[1]) == 0.0)) return;
     const u32 gisl = (u32)(a.island_offset + isl);
     u64* st = a.sst + (i64)isl * a.sp_nwg;
     u64* E = a.E + (i64)isl * (a.ntiles1 + 1);

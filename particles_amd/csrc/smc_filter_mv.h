@@ -43,6 +43,13 @@
 // reduction, decision and normalisation on them (the resampling kernels then run unchanged), and the
 // propagate kernel resets a resampled particle's weight to log_mean_exp(eta, W) - eta[A] (the constant
 // travels in the step record) or restores the plain weight.
+// DG (FArgs::mv_diag: G, covX, covY and cov0 are all DIAGONAL -- independent noises, e.g. kalman.py:364-394
+// MVLinearGauss_Guarniero_etal, BASELINE config C4): the Cholesky factors L_X, L_Y, L_0, the proposal's L_P = chol(covX
+// - K G covX) and their inverses are diagonal too, so "x = mu + L z", "u = L_X^-1 (x - m)" and "w = L_Y^-1 (y - G x)" are
+// one fma per element instead of 12 + 12 + 16 MFMAs per 16 particles: 32 of the guided step's 72 remain (F xp, B xp).
+// Same bits: in the dense product every other term of an element's sum is (+-0) . v_j, which changes no finite
+// accumulator; `check_mv_diag_equals_dense` compares the two forms particle for particle (SMC_PATH_MV_DENSE keeps the
+// dense kernel selectable: the verification twin, and bench.py's `c4_dense` leg).
 // Philox normals follow the usual contract (pair kp of particle n -> dimensions
 // 2kp, 2kp+1; counter n*ceil(d/2)+kp): the two lanes that own the halves of a
 // pair each generate half of the pairs and swap the other element.
@@ -63,7 +70,9 @@
 #define MV_NMAT 8
 #define MV_VEC(dp) (MV_NMAT * (dp) * (dp))         /* mu0[dp], mup0[dp] */
 #define MV_SCAL(dp) (MV_VEC(dp) + 2 * (dp))        /* cX, cY, cP, c0, cP0, cS, log p(y_0), - */
-#define MV_STEP(dp) (MV_SCAL(dp) + 8)              /* per t: yw_t[dp] = L_Y^-1 y_t, ky_t[dp] = K y_t, ys_t[dp] = L_S^-1 y_t */
+#define MV_DIAGV(dp) (MV_SCAL(dp) + 8)             /* diagonals of LZ, LZ0, XINV, X0INV, NGY (what the DG kernels apply) */
+#define MV_NDIAGV 5
+#define MV_STEP(dp) (MV_DIAGV(dp) + MV_NDIAGV * (dp)) /* per t: yw_t[dp] = L_Y^-1 y_t, ky_t[dp] = K y_t, ys_t[dp] = L_S^-1 y_t */
 #define MV_NSTEPV 3
 #define MV_SIZE(dp, T) (MV_STEP(dp) + MV_NSTEPV * (size_t)(dp) * (T))
 
@@ -93,13 +102,21 @@ __device__ __forceinline__ void mv_product(const double* frag, const double (&v)
 // sum over the 4 lanes (g = 0..3) that share a particle; every one of them gets it
 __device__ __forceinline__ double mv_sum_g(double v)
 {
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
+    return smc_sum_rows(v);       // two lane swaps on the VALU (smc_dpp.h), no LDS round trips
 }
 
-template <int FK, int DP, bool DFULL, bool COLL = false>
-__global__ void __launch_bounds__(SMC_BLOCK)
+// minimum waves per SIMD the register allocation must leave room for (A/B builds: -DSMC_MV_MINW=.. / -DSMC_MV_MINW_DG=..).
+// Dense form: 3 (168 registers, no spill; with 50 KB of LDS three workgroups share a CU, and the host picks 4 chunks
+// per workgroup at N = 2^20: 222 -> 217 us, profiles/r15_c4_ab.txt).  Element-wise form: unconstrained (187 registers,
+// 2 waves per SIMD; 3 or 4 cost spills and 10 - 80 %, same file).
+#ifndef SMC_MV_MINW
+#define SMC_MV_MINW 3
+#endif
+#ifndef SMC_MV_MINW_DG
+#define SMC_MV_MINW_DG 1
+#endif
+template <int FK, int DP, bool DFULL, bool COLL = false, bool DG = false>
+__global__ void __launch_bounds__(SMC_BLOCK, DG ? SMC_MV_MINW_DG : SMC_MV_MINW)
 k_propagate_mv(const FArgs av, const double* __restrict__ C)
 {
     static_assert(!COLL || FK == SMC_FK_GUIDED, "the collapsed form is the guided filter's");
@@ -109,14 +126,16 @@ k_propagate_mv(const FArgs av, const double* __restrict__ C)
     constexpr int NJ = DP / 16;                   // 16-row blocks of a product
     constexpr int MM = DP * DP;
     constexpr bool GUIDED3 = GUIDED && !COLL;                     // the reference's three-term weight
-    constexpr int NSLOT = GUIDED3 ? 5 : 3;
+    // DG: the factors are diagonal and live in sDg; only F, B and (COLL) -(L_S^-1 G F) are staged as fragments
+    constexpr int NSLOT = DG ? (GUIDED ? 2 : 1) : (GUIDED3 ? 5 : 3);
     constexpr int S_F = 0, S_B = COLL ? 0 : 1;
     constexpr int S_LZ = GUIDED3 ? 2 : 1;
     constexpr int S_XINV = 3;
-    constexpr int S_NGY = GUIDED3 ? 4 : 2;        // COLL: holds -(L_S^-1 G F)
+    constexpr int S_NGY = DG ? 1 : (GUIDED3 ? 4 : 2);        // COLL: holds -(L_S^-1 G F)
     const FArgs& a = av;
     __shared__ double sM[NSLOT * MM];
-    __shared__ double sVec[4 * DP];               // mu (t = 0) or K y_t | mu0 | L_Y^-1 y_t | -
+    __shared__ double sVec[4 * DP];               // mu (t = 0) or K y_t | mu0 (t = 0) or 0 | L_Y^-1 y_t | the scalars
+    __shared__ double sDg[DG ? 3 * DP : 1];       // DG: the diagonals of LZ | XINV | NGY of this step
     __shared__ double smd[SMC_SM];
     __shared__ int s_last;
     SMC_NTAB_LDS(s_ntab);
@@ -153,23 +172,33 @@ k_propagate_mv(const FArgs av, const double* __restrict__ C)
                 if (!COLL) sM[S_F * MM + i] = C[MV_F * MM + i];
                 if (GUIDED) sM[S_B * MM + i] = C[MV_B * MM + i];
             }
-            sM[S_LZ * MM + i] = C[m_lz * MM + i];
-            if (GUIDED3) sM[S_XINV * MM + i] = C[m_xinv * MM + i];
-            sM[S_NGY * MM + i] = C[(COLL ? MV_NGF : MV_NGY) * MM + i];
+            if (!DG) sM[S_LZ * MM + i] = C[m_lz * MM + i];
+            if (GUIDED3 && !DG) sM[S_XINV * MM + i] = C[m_xinv * MM + i];
+            if (!DG || COLL) sM[S_NGY * MM + i] = C[(COLL ? MV_NGF : MV_NGY) * MM + i];
+        }
+        if (DG && tid < DP) {
+            const double* dv = C + MV_DIAGV(DP);
+            sDg[tid] = dv[(first ? 1 : 0) * DP + tid];
+            sDg[DP + tid] = dv[(first ? 3 : 2) * DP + tid];
+            sDg[2 * DP + tid] = dv[4 * DP + tid];
         }
         // per-lane reads of these vectors come from LDS: indexed by g from the constant
         // block they turn into scalar loads plus a select chain per element
         if (tid < DP) {
             const double* mu = C + MV_VEC(DP) + (GUIDED ? DP : 0);
             sVec[tid] = first ? mu[tid] : (GUIDED ? ky[tid] : 0.0);
-            sVec[DP + tid] = C[MV_VEC(DP) + tid];
+            sVec[DP + tid] = first ? C[MV_VEC(DP) + tid] : 0.0;
             sVec[2 * DP + tid] = COLL ? ys[tid] : yw[tid];
+            // (the per-particle tail reads its constants from LDS: as scalar loads inside the loop they cost a
+            //  round trip to the scalar cache every fourth iteration, and the SGPR file is full)
+            if (tid < 8) sVec[3 * DP + tid] = scal[tid];
         }
     }
     __syncthreads();
     const double* vMu = sVec + g;                 // element 16 jb + 4 r of the lane's view
     const double* vMu0 = sVec + DP + g;
     const double* vYw = sVec + 2 * DP + g;
+    const double* vDg = sDg + g;                  // (DG) element 16 jb + 4 r of the lane's view of a diagonal
 
     SmcLse lacc = smc_lse_empty();
     const int hp = (d + 1) / 2;
@@ -207,7 +236,7 @@ k_propagate_mv(const FArgs av, const double* __restrict__ C)
         }
     };
     static_assert(MV_G == 1, "the per-particle tail below assumes one group per iteration");
-    double kw = 0.0, kz = 0.0, ku = 0.0;
+    double kw = 0.0, kz = 0.0, ku = 0.0, lwprev = 0.0;
     u32 anext[MV_G];
     double nx[MV_G][NV];
 #pragma unroll
@@ -221,6 +250,12 @@ k_propagate_mv(const FArgs av, const double* __restrict__ C)
         bool valid[MV_G];
         double v[MV_G][NV];                 // current B operand: xp, then z, x, x - m
         smc_v4d am[MV_G][NJ], ax[MV_G][NJ];
+        // the previous log-weight of the particle this lane will own at the end of the quad (not resampled:
+        // resampling.py:241-244), requested three iterations before it is added
+        if ((it & 3) == 0 && !APF && !first && !resample) {
+            const i64 np = particle(it, 0) - pn + lane;
+            lwprev = lwo[np < N ? np : N - 1];
+        }
         // ---- the parents' rows (requested during the previous iteration)
 #pragma unroll
         for (int gi = 0; gi < MV_G; ++gi) {
@@ -239,7 +274,7 @@ k_propagate_mv(const FArgs av, const double* __restrict__ C)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     ax[gi][jb][r] = vMu[16 * jb + 4 * r];                  // mu (t = 0) / K y_t / 0
-                    am[gi][jb][r] = first ? vMu0[16 * jb + 4 * r] : 0.0;
+                    am[gi][jb][r] = vMu0[16 * jb + 4 * r];                 // mu0 (t = 0) / 0
                 }
         if (COLL) {
             // w = L_S^-1 (y - G F xp) accumulates in am (started from L_S^-1 y_t), mu in ax
@@ -271,7 +306,6 @@ k_propagate_mv(const FArgs av, const double* __restrict__ C)
                 // lane (g = 2h + e) needs element e of the pairs kp = 2 j + h, j < NV; the
                 // e = 0 lane generates j < NV/2, its e = 1 neighbour (lane + 16) the rest
                 const int h = g >> 1, e = g & 1;
-                double own[NV / 2], oth[NV / 2];
 #pragma unroll
                 for (int jj = 0; jj < NV / 2; ++jj) {
                     const int j = jj + e * (NV / 2);
@@ -283,15 +317,12 @@ k_propagate_mv(const FArgs av, const double* __restrict__ C)
                         if (2 * kp >= d) z0 = 0.0;
                         if (2 * kp + 1 >= d) z1 = 0.0;
                     }
-                    own[jj] = e ? z1 : z0;
-                    oth[jj] = e ? z0 : z1;
-                }
-#pragma unroll
-                for (int jj = 0; jj < NV / 2; ++jj) oth[jj] = __shfl_xor(oth[jj], 16);
-#pragma unroll
-                for (int jj = 0; jj < NV / 2; ++jj) {       // selects, not v[.. + e * ..]
-                    v[gi][jj] = e ? oth[jj] : own[jj];
-                    v[gi][jj + NV / 2] = e ? own[jj] : oth[jj];
+                    // the e = 0 lane keeps its z0 and takes its neighbour's (pair jj + NV/2); the e = 1 lane keeps
+                    // its z1 and takes its neighbour's (pair jj): rows 1, 3 of z0 trade places with rows 0, 2 of z1
+                    // -- one lane swap per word puts both elements where they belong, no select
+                    smc_swap16_f64(z0, z1);
+                    v[gi][jj] = z0;
+                    v[gi][jj + NV / 2] = z1;
                 }
             }
             double q = 0.0;
@@ -302,7 +333,17 @@ k_propagate_mv(const FArgs av, const double* __restrict__ C)
             zz[gi] = q;
         }
         // ---- x = mu + L z
-        mv_product<DP, true>(sM + S_LZ * MM, v, ax, lane);
+        if (DG) {
+#pragma unroll
+            for (int gi = 0; gi < MV_G; ++gi)
+#pragma unroll
+                for (int jb = 0; jb < NJ; ++jb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        ax[gi][jb][r] = fma(vDg[16 * jb + 4 * r], v[gi][4 * jb + r], ax[gi][jb][r]);
+        } else {
+            mv_product<DP, true>(sM + S_LZ * MM, v, ax, lane);
+        }
         double uu[MV_G];
         if (GUIDED3) {
             // u = L_X^-1 (x - m)
@@ -314,9 +355,9 @@ k_propagate_mv(const FArgs av, const double* __restrict__ C)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         v[gi][4 * jb + r] = ax[gi][jb][r] - am[gi][jb][r];
-                        au[gi][jb][r] = 0.0;
+                        au[gi][jb][r] = DG ? fma(vDg[DP + 16 * jb + 4 * r], v[gi][4 * jb + r], 0.0) : 0.0;
                     }
-            mv_product<DP, true>(sM + S_XINV * MM, v, au, lane);
+            if (!DG) mv_product<DP, true>(sM + S_XINV * MM, v, au, lane);
 #pragma unroll
             for (int gi = 0; gi < MV_G; ++gi) {
                 double q = 0.0;
@@ -350,7 +391,16 @@ k_propagate_mv(const FArgs av, const double* __restrict__ C)
                         if (4 * kb + g < d) px[4 * kb] = v[gi][kb];
                 }
             }
-        if (!COLL) mv_product<DP, false>(sM + S_NGY * MM, v, am, lane);
+        if (!COLL && !DG) mv_product<DP, false>(sM + S_NGY * MM, v, am, lane);
+        if (!COLL && DG) {
+#pragma unroll
+            for (int gi = 0; gi < MV_G; ++gi)
+#pragma unroll
+                for (int jb = 0; jb < NJ; ++jb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        am[gi][jb][r] = fma(vDg[2 * DP + 16 * jb + 4 * r], v[gi][4 * jb + r], am[gi][jb][r]);
+        }
 #pragma unroll
         for (int gi = 0; gi < MV_G; ++gi) {
             double ww = 0.0;
@@ -368,10 +418,11 @@ k_propagate_mv(const FArgs av, const double* __restrict__ C)
             if (q == g) { kw = ww; kz = zs; ku = us; }
             if (q == 3) {
                 const i64 np = particle(it - 3, 0) - pn + lane;
-                double inc = -0.5 * kw - scal[1];                              // kalman.py:345-346
+                const double* sc = sVec + 3 * DP;
+                double inc = -0.5 * kw - sc[1];                                // kalman.py:345-346
                 if (GUIDED3)                                                   // ssm.py:380-392
-                    inc = ((-0.5 * ku - scal[first ? 3 : 0]) + inc) - (-0.5 * kz - scal[first ? 4 : 2]);
-                if (COLL) inc = first ? scal[6] : -0.5 * kw - scal[5];         // log p(y_t | x_{t-1})
+                    inc = ((-0.5 * ku - sc[first ? 3 : 0]) + inc) - (-0.5 * kz - sc[first ? 4 : 2]);
+                if (COLL) inc = first ? sc[6] : -0.5 * kw - sc[5];             // log p(y_t | x_{t-1})
                 if (np < N) {
                     double lw;
                     if (APF && !first) {
@@ -384,7 +435,7 @@ k_propagate_mv(const FArgs av, const double* __restrict__ C)
                         // resampling kernels, which are done: a launch boundary lies in between)
                         if (a.hist) (f_lw(a, t - 1) + (i64)isl * N)[np] = plain;
                     } else
-                    lw = (resample || first) ? inc : lwo[np] + inc;            // resampling.py:241-244
+                    lw = (resample || first) ? inc : lwprev + inc;             // resampling.py:241-244
                     if (lw != lw) lw = -INFINITY;                              // resampling.py:220
                     lwn[np] = lw;
                     smc_lse_push(lacc, lw);
@@ -602,8 +653,20 @@ inline void put_frag(double* dst, int dp, const Mat& M, int r, int c, double sig
 
 // Builds the constants block; returns false if a covariance is not positive definite
 // (the reference raises ValueError in MvNormal.__init__, distributions.py:935-940).
+inline bool mv_is_diag(const mvh::Mat& M, int r, int c)
+{
+    for (int i = 0; i < r; ++i)
+        for (int j = 0; j < c; ++j)
+            if (i != j && M[i * c + j] != 0.0) return false;
+    return true;
+}
+inline void mv_put_diag(double* dst, const mvh::Mat& M, int r, int c, double sign = 1.0)
+{
+    for (int i = 0; i < r && i < c; ++i) dst[i] = sign * M[i * c + i];
+}
+// *diag (optional): every factor the propagate kernel applies after F / B is a diagonal matrix
 inline bool mv_build_constants(const smc_model* m, int fk, int dp, i64 T, const double* y,
-                               std::vector<double>& out)
+                               std::vector<double>& out, bool* diag = nullptr)
 {
     using namespace mvh;
     const int dx = m->dx, dy = m->dy;
@@ -618,6 +681,9 @@ inline bool mv_build_constants(const smc_model* m, int fk, int dp, i64 T, const 
     Mat GY = mul(LYi, dy, dy, G, dx);                                     // (dy,dx)
     put_frag(C + MV_F * dp * dp, dp, F, dx, dx);
     put_frag(C + MV_NGY * dp * dp, dp, GY, dy, dx, -1.0);
+    double* dgv = C + MV_DIAGV(dp);
+    mv_put_diag(dgv + 4 * dp, GY, dy, dx, -1.0);
+    bool dg = mv_is_diag(GY, dy, dx);
     double* scal = C + MV_SCAL(dp);
     scal[0] = logdiag(LX, dx) + dx * SMC_HALFLOG2PI;
     scal[1] = logdiag(LY, dy) + dy * SMC_HALFLOG2PI;
@@ -635,8 +701,14 @@ inline bool mv_build_constants(const smc_model* m, int fk, int dp, i64 T, const 
         put_frag(C + MV_B * dp * dp, dp, mul(IKG, dx, dx, F, dx), dx, dx);
         put_frag(C + MV_LZ * dp * dp, dp, LP, dx, dx);
         put_frag(C + MV_LZ0 * dp * dp, dp, LP0, dx, dx);
-        put_frag(C + MV_XINV * dp * dp, dp, tri_inv(LX, dx), dx, dx);
-        put_frag(C + MV_X0INV * dp * dp, dp, tri_inv(L0, dx), dx, dx);
+        const Mat LXi = tri_inv(LX, dx), L0i = tri_inv(L0, dx);
+        put_frag(C + MV_XINV * dp * dp, dp, LXi, dx, dx);
+        put_frag(C + MV_X0INV * dp * dp, dp, L0i, dx, dx);
+        mv_put_diag(dgv, LP, dx, dx);
+        mv_put_diag(dgv + dp, LP0, dx, dx);
+        mv_put_diag(dgv + 2 * dp, LXi, dx, dx);
+        mv_put_diag(dgv + 3 * dp, L0i, dx, dx);
+        dg = dg && mv_is_diag(LP, dx, dx) && mv_is_diag(LP0, dx, dx) && mv_is_diag(LXi, dx, dx) && mv_is_diag(L0i, dx, dx);
         scal[2] = logdiag(LP, dx) + dx * SMC_HALFLOG2PI;
         scal[4] = logdiag(LP0, dx) + dx * SMC_HALFLOG2PI;
         // collapsed form: S = G covX G' + covY, -(L_S^-1 G F), log p(y_0) = log N(y_0; G mu0, G cov0 G' + covY)
@@ -675,7 +747,11 @@ inline bool mv_build_constants(const smc_model* m, int fk, int dp, i64 T, const 
     } else {
         put_frag(C + MV_LZ * dp * dp, dp, LX, dx, dx);
         put_frag(C + MV_LZ0 * dp * dp, dp, L0, dx, dx);
+        mv_put_diag(dgv, LX, dx, dx);
+        mv_put_diag(dgv + dp, L0, dx, dx);
+        dg = dg && mv_is_diag(LX, dx, dx) && mv_is_diag(L0, dx, dx);
     }
+    if (diag) *diag = dg;
     for (i64 t = 0; t < T; ++t) {
         double* yw = C + MV_STEP(dp) + (size_t)t * MV_NSTEPV * dp;
         const double* yt = y + t * dy;

@@ -495,6 +495,15 @@ def check_mvn_large(N, d):
         assert np.max(np.abs(np.cov(s.T) - cov)) < 0.1 * np.abs(cov).max()
 
 
+def dense_mv_matrices(dx, dy, seed=11):
+    """A MVLinearGauss (kalman.py:296-361) with full covariance matrices and a full observation matrix."""
+    r = np.random.RandomState(seed)
+    spd = lambda n, s: (lambda a: a @ a.T / n + s * np.eye(n))(r.standard_normal((n, n)))
+    F = 0.4 * r.standard_normal((dx, dx)) / np.sqrt(dx) + 0.3 * np.eye(dx)
+    G = r.standard_normal((dy, dx)) / np.sqrt(dx) + np.eye(dy, dx)
+    return dict(F=F, G=G, covX=spd(dx, 0.5), covY=spd(dy, 0.7), mu0=0.1 * r.standard_normal(dx), cov0=spd(dx, 1.0))
+
+
 # ------------------------------------------------------------------ a-1 ----
 MODELS = {
     "toy": (lambda: kalman.ToySSM(0.2), lambda: orc.ToySSM(0.2)),
@@ -507,6 +516,10 @@ MODELS = {
             lambda: orc.Guarniero(alpha=0.4, dx=4)),
     "mv32": (lambda: kalman.MVLinearGauss_Guarniero_etal(alpha=0.4, dx=32),
              lambda: orc.Guarniero(alpha=0.4, dx=32)),
+    # correlated noises, a rectangular G: none of the step's factors is diagonal (the dense MFMA products of k_propagate_mv;
+    # the Guarniero models above have G = covX = covY = I and take its element-wise form, smc_filter_mv.h "DG")
+    "mvd8": (lambda: kalman.MVLinearGauss(**dense_mv_matrices(8, 6)), lambda: orc.MVLinGauss(**dense_mv_matrices(8, 6))),
+    "mvd32": (lambda: kalman.MVLinearGauss(**dense_mv_matrices(32, 32)), lambda: orc.MVLinGauss(**dense_mv_matrices(32, 32))),
     "gordon": (lambda: ssm.Gordon_etal(), lambda: orc.Gordon()),
     "theta": (lambda: ssm.ThetaLogistic(), lambda: orc.ThetaLogistic()),
     "svlev": (lambda: ssm.StochVolLeverage(phi=-0.5), lambda: orc.StochVolLeverage(phi=-0.5)),
@@ -911,7 +924,7 @@ def check_two_level_injected(sizes=(4096, 3000)):
 
 def check_oracle_at_size(model, mk_dev, mk_orc, N, T, scheme="systematic", ESSrmin=0.5, fk="bootstrap",
                          replay=True, n_islands=1, islands=(0,), seed=5, d=1, data_seed=3,
-                         expect_resample=True):
+                         expect_resample=True, dy=None):
     """Oracle parity at BASELINE.json's sizes: a store_history run of T steps audited step by
     step (audit_history: ancestors bit-exact against the contract, near-ties against the
     reference's CDF certified, every particle's X / lw, ESS, evidence), and the production
@@ -922,7 +935,7 @@ def check_oracle_at_size(model, mk_dev, mk_orc, N, T, scheme="systematic", ESSrm
     if d == 1:
         y = [np.array([v]) for v in 0.4 * np.cumsum(rng.standard_normal(T))]
     else:
-        y = [rng.standard_normal((1, d)) for _ in range(T)]
+        y = [rng.standard_normal((1, dy or d)) for _ in range(T)]
     cls = ssm.Bootstrap if fk == "bootstrap" else ssm.GuidedPF
     z = u = None
     if replay:
@@ -1836,6 +1849,44 @@ def check_mv_collapsed(N, d, T=6):
                    seed=31, collapsed_proposal=True)
         e.run()
         assert "collapsed" not in describe(e) and np.isfinite(e.logLt)
+
+
+def check_mv_diag_equals_dense(monkeypatch, cases=((1500, 32), (700, 20), (900, 4), (600, 16)), T=4):
+    """MVLinearGauss with diagonal G / covX / covY / cov0 (every Guarniero model; BASELINE C4): k_propagate_mv applies the
+    step's triangular factors element by element (smc_filter_mv.h "DG") -- the SAME run, bit for bit, as the dense MFMA
+    products (SMC_MV_DENSE=1): guided, bootstrap, collapsed weight, APF; Philox and replayed draws; d = DP and d < DP;
+    and a model whose matrices are NOT diagonal never takes the element-wise form."""
+    rng = np.random.RandomState(8)
+    for N, d in cases:
+        y = [rng.standard_normal((1, d)) for _ in range(T)]
+        mod = lambda: kalman.MVLinearGauss_Guarniero_etal(alpha=0.4, dx=d)
+        z = np.random.RandomState(N).standard_normal((T, 1, N, d))
+        u = np.random.RandomState(N + 1).rand(T, 1, 1)
+        variants = [("guided", dict(fk=ssm.GuidedPF(ssm=mod(), data=y))),
+                    ("bootstrap", dict(fk=ssm.Bootstrap(ssm=mod(), data=y))),
+                    ("collapsed", dict(fk=ssm.GuidedPF(ssm=mod(), data=y), collapsed_proposal=True)),
+                    ("apf", dict(fk=ssm.AuxiliaryPF(ssm=mod(), data=y))),
+                    ("guided-replay", dict(fk=ssm.GuidedPF(ssm=mod(), data=y), replay=(z, u)))]
+        for name, kw in variants:
+            runs = []
+            for dense in (False, True):
+                if dense:
+                    monkeypatch.setenv("SMC_MV_DENSE", "1")
+                pf = pa.SMC(N=N, seed=12, ESSrmin=1.0, store_history=True, collect="off", **kw)
+                assert ("[diagonal factors]" in describe(pf)) == (not dense), describe(pf)
+                pf.run()
+                runs.append(pf)
+                monkeypatch.delenv("SMC_MV_DENSE", raising=False)
+            a, b = runs
+            assert np.any(a._summ()[0, 1:, 4] != 0), name
+            assert np.array_equal(a._summ(), b._summ()), (N, d, name)
+            for t in range(T):
+                assert np.array_equal(a._history(_lib.FIELD_X, t), b._history(_lib.FIELD_X, t)), (N, d, name, t)
+                assert np.array_equal(a._history(_lib.FIELD_LW, t), b._history(_lib.FIELD_LW, t)), (N, d, name, t)
+            assert a.logLt == b.logLt
+    y = [rng.standard_normal((1, 6)) for _ in range(3)]
+    pf = pa.SMC(fk=ssm.GuidedPF(ssm=MODELS["mvd8"][0](), data=y), N=500, seed=1)
+    assert "[diagonal factors]" not in describe(pf) and "k_propagate_mv" in describe(pf)
 
 
 def check_smc2(Ntheta=64, Nx=128, T=30, seed=3, big_Nx=(), big_N=16, big_T=12):
@@ -3010,43 +3061,6 @@ def check_pickle_resume(sizes=(700, 3000)):
     blob = np.empty(nb.value, dtype=np.uint8)
     _lib.check(_lib.lib().smc_filter_save_state(a._f, blob.ctypes.data_as(ctypes.c_void_p), nb.value))
     assert _lib.lib().smc_filter_load_state(b._f, blob.ctypes.data_as(ctypes.c_void_p), nb.value) != 0
-
-
-def check_spacings_side_stream(monkeypatch, sizes=(3000, 8192), T=9):
-    """Multinomial resampling with the NEXT step's uniform_spacings drawn ahead on the filter's side stream
-    (smc_filter::sp_side, SMC_SP_SIDE=1: built as round 4's verdict proposed, measured slower at C3 and therefore off by
-    default) is the same run as with the spacings drawn inside the step, bit for bit: every step resampling or only some (spacings drawn
-    ahead and not used), islands, a deep copy and a pickle taken mid-run, a filter stepped in pieces."""
-    import copy
-    import pickle
-    yr = np.random.RandomState(2)
-    y = [np.array([v]) for v in 0.4 * np.cumsum(yr.standard_normal(T))]
-    for N in sizes:
-        for essr, nisl in ((1.0, 1), (0.5, 2)):
-            runs = {}
-            for name, env in (("side", "SMC_SP_SIDE"), ("inline", "SMC_NO_SP_SIDE")):
-                monkeypatch.setenv(env, "1")
-                pf = pa.SMC(fk=ssm.Bootstrap(ssm=ssm.StochVol(), data=y), N=N, resampling="multinomial", ESSrmin=essr, seed=4,
-                            n_islands=nisl, store_history=True)
-                pf.step_async(3)
-                c = copy.deepcopy(pf)
-                z = pickle.loads(pickle.dumps(pf))
-                outs = []
-                for r in (pf, z):
-                    r.step_async(2)
-                    r.run()
-                    outs.append((np.array(r.X), np.array(r.A), r.logLts_islands.copy(), r._summ().copy(),
-                                 [r._history(_lib.FIELD_A, t, nisl - 1) for t in range(1, T)]))
-                c.run()                                    # (re-keyed by deepcopy: a different run, but a run)
-                assert c.t == T and np.all(np.isfinite(c.logLts_islands))
-                runs[name] = outs
-                monkeypatch.undo()
-            a, b = runs["side"][0], runs["inline"][0]
-            for u, v in zip(a, b):
-                assert all(np.array_equal(p, q) for p, q in zip(u, v)) if isinstance(u, list) else np.array_equal(u, v), (N, essr)
-            for u, v in zip(runs["side"][0], runs["side"][1]):             # the pickled copy: the same run
-                assert all(np.array_equal(p, q) for p, q in zip(u, v)) if isinstance(u, list) else np.array_equal(u, v), (N, essr)
-            assert (a[3][0, :, 4].mean() == 1.0 - 1.0 / T) == (essr == 1.0)
 
 
 def check_models_without_descriptor(golden):

@@ -36,8 +36,16 @@ def test_default_line_carries_other_workloads_and_cpu_legs(tmp_path):
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and "C2" in d["config"]["workload"]
     assert "roofline" in d and d["roofline"]["bound"] == "hbm"
     ow = d["other_workloads"]
-    assert sorted(ow) == ["c2_strict", "c3_multinomial", "c3_stratified", "c3_systematic", "c3_systematic_strict", "c4",
-                          "c4_collapsed", "c5", "sqmc"]
+    assert sorted(ow) == ["c1", "c1_islands", "c2_strict", "c3_multinomial", "c3_stratified", "c3_systematic",
+                          "c3_systematic_strict", "c4", "c4_collapsed", "c4_dense", "c5", "generic_model", "sqmc"]
+    # BASELINE config C1 (one small filter: the PMMH regime), its batched form, and a user-defined model on the operator path
+    small = {k: ow.pop(k) for k in ("c1", "c1_islands", "generic_model")}
+    for key, leg in small.items():
+        assert "error" not in leg, (key, leg)
+        assert leg["value"] > 0 and leg["roofline"]["bound"] == "hbm" and "limiter" in leg["roofline"], (key, leg)
+    assert "k_filter_small" in small["c1"]["step_kernels"] and small["c1"]["filters"] == 1 and small["c1"]["us_per_run"] > 0
+    assert small["c1_islands"]["filters"] > 1 and abs(small["c1"]["logLt_first"] - small["c1"]["kalman_logLt"]) < 3.0
+    assert "user-defined" in small["generic_model"]["workload"]
     # the literal-parity contract (strict_ancestors) is on the driver's line, with its own kernels
     for key in ("c2_strict", "c3_systematic_strict"):
         assert "k_strict_classify+k_strict_search" in ow[key]["step_kernels"] or "k_sqx_classify" in ow[key]["step_kernels"], ow[key]
@@ -54,7 +62,11 @@ def test_default_line_carries_other_workloads_and_cpu_legs(tmp_path):
         for k in ("value", "ms_per_step", "step_frac", "kernel", "frac", "step_kernels"):
             assert k in leg, (key, k)
         assert leg["value"] > 0 and leg["resampled_fraction"] > 0
-    assert ow["c4"]["bound"] == "mfma" and "k_propagate_mv" in ow["c4"]["step_kernels"]
+    # C4's model has diagonal noise factors: the element-wise form (HBM is then the bounding roofline); `c4_dense` keeps
+    # the dense MFMA products measurable
+    assert ow["c4"]["bound"] == "hbm" and "k_propagate_mv" in ow["c4"]["step_kernels"] and "[diagonal factors]" in ow["c4"]["step_kernels"]
+    assert ow["c4"]["mfma_per_16_particles"] == 32 and ow["c4"]["limiter"] == "valu"
+    assert ow["c4_dense"]["bound"] == "mfma" and "[diagonal factors]" not in ow["c4_dense"]["step_kernels"]
     assert "collapsed" in ow["c4_collapsed"]["step_kernels"]
     assert "k_f_spacing" in ow["c3_multinomial"]["step_kernels"] or "spacing" in ow["c3_multinomial"]["step_kernels"]
     cb = d["cpu_baseline"]

@@ -148,6 +148,20 @@ def test_mv_multi_chunk_loop(golden, monkeypatch, chunks, N):
     pc.check_mv_collapsed(N, 32, T=3)
 
 
+def test_mv_diagonal_factors_equal_dense(monkeypatch):
+    pc.check_mv_diag_equals_dense(monkeypatch, cases=((700, 32), (520, 20), (300, 4)), T=3)
+
+
+@pytest.mark.parametrize("model,d,N", [("mvd8", 8, 600), ("mvd32", 32, 520)])
+def test_mv_dense_model_against_the_oracle(model, d, N):
+    """A MVLinearGauss whose covariances and observation matrix are full: the dense MFMA products of k_propagate_mv,
+    every particle of every step against the oracle (guided and bootstrap, replayed and Philox draws)."""
+    mk_dev, mk_orc = pc.MODELS[model]
+    dy = mk_orc().dy
+    pc.check_oracle_at_size(model, mk_dev, mk_orc, N, 3, "systematic", 1.0, fk="guided", d=d, dy=dy)
+    pc.check_oracle_at_size(model, mk_dev, mk_orc, N, 3, "systematic", 1.0, fk="bootstrap", d=d, dy=dy, replay=False)
+
+
 def test_mv_philox_kalman():
     pc.check_mv_kalman(2048, 4, "guided")
     pc.check_mv_kalman(1000, 6, "guided", scheme="stratified")
@@ -310,10 +324,6 @@ def test_strict_one_launch_switch(monkeypatch):
 
 def test_strict_verifies_every_step():
     pc.check_strict_never_leaves_the_fast_path([(3000, 4, "systematic", "toy", 0.5), (2500, 2, "multinomial", "sv", 1.0)], T=70)
-
-
-def test_multinomial_spacings_on_the_side_stream(monkeypatch):
-    pc.check_spacings_side_stream(monkeypatch)
 
 
 def test_models_without_a_fused_descriptor(golden):

@@ -342,6 +342,23 @@ def test_c4_oracle_d32_every_chunk_count(log2N, chunks):
     pc.check_mv_collapsed(N, 32, T=3)
 
 
+def test_mv_diagonal_factors_equal_dense(monkeypatch):
+    """BASELINE C4's model has G = covX = covY = I: the element-wise form of the three triangular factors against the
+    dense MFMA products, bit for bit, up to the benchmarked N = 2^20 (8 chunks per workgroup)."""
+    pc.check_mv_diag_equals_dense(monkeypatch, cases=((1 << 20, 32), (1 << 17, 32), (70001, 20), (1 << 16, 4), (30000, 16)), T=3)
+
+
+@pytest.mark.parametrize("model,d,N", [("mvd8", 8, 1 << 16), ("mvd32", 32, 1 << 18), ("mvd32", 32, 1 << 20)])
+def test_mv_dense_model_against_the_oracle(model, d, N):
+    """A MVLinearGauss whose covariances and observation matrix are full: the dense MFMA products of k_propagate_mv
+    (72 per 16 particles at d = 32), every particle of every step against the oracle."""
+    mk_dev, mk_orc = pc.MODELS[model]
+    dy = mk_orc().dy
+    pc.check_oracle_at_size(model, mk_dev, mk_orc, N, 3, "systematic", 1.0, fk="guided", d=d, dy=dy)
+    if N < 1 << 20:
+        pc.check_oracle_at_size(model, mk_dev, mk_orc, N, 3, "systematic", 1.0, fk="bootstrap", d=d, dy=dy, replay=False)
+
+
 def test_mv_collapsed_proposal():
     pc.check_mv_collapsed(1 << 14, 4)
     pc.check_mv_collapsed(1 << 17, 32)
@@ -548,10 +565,6 @@ def test_strict_one_launch_equals_two(monkeypatch):
     pc.check_strict_one_launch_equals_two(monkeypatch, [
         (1 << 20, 1, "systematic", 0.5, True), ((1 << 18) + 77, 2, "stratified", 1.0, True), (1 << 18, 3, "multinomial", 0.7, True),
         (5000, 4, "systematic", 0.5, True), (1 << 22, 1, "systematic", 1.0, False), (1 << 20, 2, "systematic", 0.5, False)])
-
-
-def test_multinomial_spacings_on_the_side_stream(monkeypatch):
-    pc.check_spacings_side_stream(monkeypatch, sizes=(3000, 1 << 18, 1 << 21))
 
 
 def test_models_without_a_fused_descriptor(golden):

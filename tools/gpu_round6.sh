@@ -1,0 +1,66 @@
+#!/bin/bash
+# Run ON THE GPU BOX (via gpurun).  $1 = stage, TAG = output tag (default r15)
+R=$GRAFT_REPO_ROOT
+TAG=${TAG:-r15}
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd $R
+c4line() {   # $1 = label, rest = env assignments
+  local lab=$1; shift
+  env "$@" timeout 300 python bench.py --workload c4 $C4ARGS --steps 40 --warmup 10 --reps 5 --no-cpu-baseline --no-other-workloads > $O/c4_$lab.json 2>$O/c4_$lab.err
+  python - $O/c4_$lab.json $lab <<'PY'
+import json,sys
+try:
+    d=json.loads([l for l in open(sys.argv[1]) if l.startswith('{')][-1]); r=d.get('roofline',{})
+    print(sys.argv[2], 'us/step %.2f'%(1e3*d['ms_per_step']), 'G/s %.3f'%(d['value']/1e9), 'kernel_ms', r.get('kernel_ms'), 'frac %.3f'%r.get('frac',0), r.get('step_kernels'), 'logLt', d['logLt'][:1])
+except Exception as e:
+    print(sys.argv[2], 'FAILED', e)
+PY
+}
+case $1 in
+micro)  # fp64 MFMA shadow: do fillers between one wave's MFMAs hide?
+    ./tools/micro/shadow.bin > $O/${TAG}_mfma_shadow.txt 2>&1; cat $O/${TAG}_mfma_shadow.txt
+    ;;
+c4ab)   # same-box A/B of k_propagate_mv variants: $2 = space separated "label:ENV=1" items
+    for rep in 1 2; do
+      for item in ${2:-"base:SMC_X=0"}; do
+        spec=${item#*:}; c4line ${item%%:*}_$rep ${spec//,/ }
+      done
+    done
+    ;;
+c4prof) # trace + counters of the C4 leg
+    bash tools/gpu_profile_all.sh $TAG "${2:-c4 c4_collapsed}"
+    ;;
+tests)
+    timeout 1500 python -m pytest tests -m gpu -x -q ${2:+-k "$2"} > $O/${TAG}_pytest_gpu.log 2>&1; echo "pytest rc $?" >> $O/${TAG}_pytest_gpu.log
+    tail -8 $O/${TAG}_pytest_gpu.log
+    ;;
+full)  # the whole GPU suite, the driver's bench line, K = 1000
+    timeout 1500 python -m pytest tests -m gpu -x -q > $O/${TAG}_pytest_gpu.log 2>&1; echo "pytest rc $?" >> $O/${TAG}_pytest_gpu.log
+    tail -6 $O/${TAG}_pytest_gpu.log
+    timeout 900 python bench.py --steps 20 --warmup 5 > $O/${TAG}_bench_driver_line.json 2> $O/${TAG}_bench_driver_line.err; echo "bench rc $?"
+    timeout 300 python bench.py --steps 1000 --warmup 50 --no-other-workloads --no-cpu-baseline > $O/${TAG}_bench_c2_k1000.json 2>/dev/null
+    python - <<PY
+import json
+d = json.load(open("$O/${TAG}_bench_driver_line.json"))
+print("C2", d["value"] / 1e9, d["ms_per_step"], d["roofline"]["frac"], d["roofline"].get("launch_floor_us"), d.get("self_check"))
+for k, v in d["other_workloads"].items():
+    print(k, v.get("value", 0) / 1e9, v.get("ms_per_step"), v.get("frac"), v.get("error"))
+d = json.load(open("$O/${TAG}_bench_c2_k1000.json"))
+print("C2 K=1000", d["value"] / 1e9, d["ms_per_step"])
+PY
+    ;;
+line)  # the driver's bench line only
+    timeout 900 python bench.py --steps 20 --warmup 5 > $O/${TAG}_bench_driver_line.json 2> $O/${TAG}_bench_driver_line.err; echo "bench rc $?"
+    python - <<PY
+import json
+d = json.load(open("$O/${TAG}_bench_driver_line.json"))
+print("C2", d["value"] / 1e9, d["ms_per_step"], d["roofline"]["frac"], d["roofline"].get("launch_floor_us"), d.get("self_check"))
+for k, v in d["other_workloads"].items():
+    print(k, v.get("value", 0) / 1e9, v.get("ms_per_step"), v.get("frac"), v.get("error"))
+PY
+    ;;
+prof)
+    bash tools/gpu_profile_all.sh $TAG "$2"
+    ;;
+esac
