@@ -1206,16 +1206,24 @@ def philox_normals_mv(seed, n, d, t, island=0):
 
 def philox_spacings(seed, M, t, island=0):
     """The device's uniform_spacings(M) in production mode (resampling.py:512-537 on the Philox
-    stream): M + 1 exponential draws in fixed point, q_n = rint(-log(u_n) 2^s), s = 57 - ceil(log2(M + 2)),
+    stream): M + 1 exponential draws in fixed point, q_n = rint(-log(u_n) 2^s), s = min(57 - ceil(log2(M + 2)), 21),
     u_n the open-interval uniform of word n & 1 of Philox call n >> 1 (stream 2); su_n = Z_n / Z_M,
-    Z_n = q_0 + .. + q_n (exact integers: monotone whatever the summation order)."""
+    Z_n = E[n >> 10] + min(q_{1024 (n >> 10)} + .. + q_n, 2^32 - 1) with E[k] the sum of the tiles of 1024 draws in
+    front of tile k and Z_M = q_0 + .. + q_M (exact integers: monotone whatever the summation order; the saturation
+    is what lets the device store 32-bit prefixes -- 32 standard deviations away at s = 21)."""
     lg = 0
     while (1 << lg) < M + 2:
         lg += 1
     u = philox_resample_uniforms(seed, "multinomial", M, t, island)        # M + 1 open-interval uniforms
-    q = np.rint(-np.log(u) * 2.0 ** (57 - lg)).astype(np.uint64)
-    z = np.cumsum(q)
-    return z[:-1].astype(np.float64) / np.float64(z[-1])
+    q = np.rint(-np.log(u) * 2.0 ** min(57 - lg, 21)).astype(np.uint64)
+    tot = np.uint64(q.sum())
+    nt = (M + 1 + 1023) // 1024
+    qp = np.zeros(nt * 1024, dtype=np.uint64)
+    qp[:M + 1] = q
+    qp = qp.reshape(nt, 1024)
+    E = np.concatenate([[0], np.cumsum(qp.sum(axis=1))[:-1]]).astype(np.uint64)
+    z = (E[:, None] + np.minimum(np.cumsum(qp, axis=1), np.uint64(0xFFFFFFFF))).reshape(-1)[:M]
+    return z.astype(np.float64) / np.float64(tot)
 
 
 def philox_resample_uniforms(seed, scheme, M, t, island=0):

@@ -563,7 +563,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     {
         int lg = 0;
         while (((i64)1 << lg) < o->N + 2) ++lg;
-        a.spacing_scale = ldexp(1.0, 57 - lg);
+        a.spacing_scale = ldexp(1.0, 57 - lg < 21 ? 57 - lg : 21);        // (see smc_ops.hip spacing_scale)
     }
     const size_t M = (size_t)o->n_islands, N = (size_t)o->N, T = (size_t)o->T;
     const bool need_su = (scheme == SMC_MULTINOMIAL);

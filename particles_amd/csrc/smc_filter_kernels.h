@@ -176,9 +176,12 @@ __host__ __device__ __forceinline__ u32* f_A(const FArgs& a, i64 t) { return a.A
 #ifdef SMC_TRACE
 #define F_STAMP(k) do { if (threadIdx.x == 0) a.trace[((i64)blockIdx.y * a.nparts + blockIdx.x) * 8 + (k)] = (u64)wall_clock64(); } while (0)
 #define F_STAMP_A(k) do { if (threadIdx.x == 0) a.trace[((i64)a.n_islands * a.nparts + (i64)blockIdx.y * a.ntiles + blockIdx.x) * 8 + (k)] = (u64)wall_clock64(); } while (0)
+// (the one-pass spacings kernel, island 0: the rows the strict step's stamps use in strict filters -- smc_debug_trace_strict)
+#define F_STAMP_S(k) do { if (threadIdx.x == 0 && blockIdx.y == 0) a.trace[((i64)a.n_islands * (a.nparts + a.ntiles) + blockIdx.x) * 8 + (k)] = (u64)wall_clock64(); } while (0)
 #else
 #define F_STAMP(k) do { } while (0)
 #define F_STAMP_A(k) do { } while (0)
+#define F_STAMP_S(k) do { } while (0)
 #endif
 
 // a / b for a model constant b whose correctly rounded reciprocal rb = RN(1/b) sits next to it in
@@ -492,6 +495,10 @@ k_prepare(const FArgs av)
 // The integer spacing of draw n in [0, N] of step t: rint(-log(u_n) 2^s), u_n the open-interval
 // uniform of Philox word n & 1 of call n >> 1 (stream SPACINGS); log by the table-driven routine
 // of the normals (smc_log_u52: <= 3 ulp), the rounding read off the mantissa (q < 2^51).
+// The prefix sum of the draws INSIDE a tile of 1024 saturates at 2^32 - 1 (part of the contract -- oracle
+// philox_spacings -- so that the one-pass kernel can store it as a 32-bit word; with the scale of at most 2^21 a tile's
+// sum is 2^31 +- 2^26: the bound is 32 standard deviations away): Z_n = E[tile] + min(prefix in tile, 2^32 - 1).
+#define SP_OFF_MAX 0xFFFFFFFFull
 __device__ __forceinline__ u64 f_spacing_int(const SmcD2* ntab, const u64 x, const double scale)
 {
     const double m = fma(-smc_log_u52(ntab, x), scale, 4503599627370496.0);      // 2^52 + rint(-log(u) 2^s)
@@ -602,60 +609,66 @@ k_f_spacing_write(const FArgs av)
     f_spacing_q4(a, s_ntab, (u32)t, (u32)(a.island_offset + isl), n0, q);      // the same draws as pass 1
     const u64 tsum = q[0] + q[1] + q[2] + q[3];
     u64 tot;
-    u64 run = smc_block_exscan_u64(tsum, smu, tot) + pre;
+    u64 run = smc_block_exscan_u64(tsum, smu, tot);
     const double dall = (double)all;
     double* su = a.su + (i64)isl * a.N;
 #pragma unroll
     for (int i = 0; i < F_IPT; ++i) {
         run += q[i];
-        if (n0 + i < a.N) su[n0 + i] = (double)run / dall;
+        if (n0 + i < a.N) su[n0 + i] = (double)(pre + (run < SP_OFF_MAX ? run : SP_OFF_MAX)) / dall;
     }
 }
 
-// uniform_spacings in ONE pass (two-level step, production mode): a workgroup makes the draws of TPW
-// consecutive tiles (32 per thread at TPW = 8, kept in registers), scans them, publishes its total,
-// obtains the total of everything before it by a decoupled look-back over the workgroups' status
-// words and writes the integer prefix sums Z_n -- the draws are made once, 8 bytes per draw are
-// written once (k_ancestors2 divides by Z_N when it stages its window), and the tile prefixes E[k] the
-// window search needs come out on the way.  Status word of workgroup w: (its total << 2) | 1, 0 = not
-// there yet (k_ancestors2 zeroes the words again).  The grid is sized by the host so that EVERY
-// workgroup is resident at once (smc_filter_create asks the runtime how many fit): a spinning
-// workgroup can then never keep the one it waits for off the chip, whatever the dispatch order; the
-// spin is bounded all the same.  (3 waves per SIMD at least: 170 VGPRs for the 32 draws of a thread.)
+// uniform_spacings in ONE pass (two-level step, production mode): a workgroup makes the draws of TPW consecutive tiles
+// of 1024, four tiles at a time (16 draws per thread in registers), and writes every draw's prefix sum INSIDE ITS TILE
+// as a 32-bit word right away -- o_n = q_{1024 k} + .. + q_n (saturating at 2^32 - 1: the scale of the draws,
+// spacing_scale = 2^21 at most, puts a tile's sum 32 standard deviations below that) -- so that
+//      Z_n = E[n >> 10] + o_n ,   su_n = fl(Z_n) / fl(Z_N)        (resampling.py:536-537)
+// with E[k] the sum of the tiles in front of tile k.  Only the E[k] need the workgroups in front: the workgroup
+// publishes its total, obtains the total of everything before it by a decoupled look-back over the workgroups' status
+// words and writes its TPW tile prefixes -- 4 bytes per draw go to memory, once, and they leave while the next tiles'
+// logarithms are being computed (round 5 stored the 8-byte Z_n themselves, all of them behind the look-back:
+// generate 9.8 us, wait 3, write 5.3-7.5 at N = 2^22, profiles/r15_trace_spacing_before.txt).  Status word of
+// workgroup w: (its total << 2) | 1, 0 = not there yet (k_ancestors2 zeroes the words again).  The grid is sized by
+// the host so that EVERY workgroup is resident at once (smc_filter_create asks the runtime how many fit): a spinning
+// workgroup can then never keep the one it waits for off the chip, whatever the dispatch order; the spin is bounded
+// all the same.
 #define SP_FLAG_AGG 1ull
 // a.sp_epoch != 0: the launch carries one workgroup more per island -- workgroup 0 is k_reduce2 (the island's
 // reduction, the decision of step t, the tiles' shares), the others draw while it works and look at its
-// decision before they publish anything: the 9 us of a one-workgroup launch on the critical path of
-// every multinomial step (4096 tiles) disappear behind the 4 M logarithms.
-__device__ __forceinline__ int f2_reduce2_island(const FArgs& a, const int isl, double* smd, double* sme);
-template <int TPW>
-__global__ void __launch_bounds__(SMC_BLOCK)
-#ifndef SMC_EMULATE
-__attribute__((amdgpu_waves_per_eu(3, 8)))
+// decision before they publish anything (their offsets are in memory by then: on a step that does not resample
+// nobody reads them): the 9 us of a one-workgroup launch on the critical path of every multinomial step
+// (4096 tiles) disappear behind the 4 M logarithms.
+__device__ __forceinline__ int f2_reduce2_island(const FArgs& a, const int isl, double* smd, double* sme,
+                                                 u64* dec_word = nullptr, const u64 dec_epoch = 0ull);
+#ifndef SMC_SP_MINW
+#define SMC_SP_MINW 5        /* waves per SIMD the register allocation leaves room for (A/B builds) */
 #endif
+template <int TPW>
+__global__ void __launch_bounds__(SMC_BLOCK, SMC_SP_MINW)
 k_f_spacing_onepass(const FArgs av)
 {
     const FArgs& a = av;
-    // 32 draws per thread = 64 registers: with everything else the kernel spilled 100 B per lane at the
-    // 168 registers that keep 3 waves per SIMD (13 MB of scratch traffic per launch at N = 2^22); the
-    // draws of the tiles beyond TREG wait in LDS instead (conflict-free: slot i of a thread at i * 256 + tid)
-    constexpr int TREG = TPW > 4 ? 4 : TPW;
-    __shared__ u64 s_q[TPW > TREG ? TPW - TREG : 1][4 * SMC_BLOCK];
-    __shared__ u64 s_w[TPW][SMC_NWAVE];
+    constexpr int TG = TPW > 4 ? 4 : TPW;          // tiles in flight (registers): 16 draws per thread
+    constexpr int NG = TPW / TG;
+    __shared__ u64 s_w[2][TG][SMC_NWAVE];          // (two areas: ONE barrier per group of tiles)
     __shared__ u64 s_pre;
     SMC_NTAB_LDS(s_ntab);
     const bool merged = a.sp_epoch != 0ull;
     const int isl = (int)blockIdx.y;
     const int tid = (int)threadIdx.x, lane = smc_lane(), wave = smc_wave();
+    F_STAMP_S(0);
     if (merged && blockIdx.x == 0) {
         __shared__ double smd[SMC_SM];
         __shared__ double sme[SMC_SM];
-        const int dec = f2_reduce2_island(a, isl, smd, sme);
-        __syncthreads();
-        if (tid == 0) {
-            smc_drain_stores();
-            smc_st_agent(a.sdec + isl, (a.sp_epoch << 2) | (dec == 1 ? 2ull : 1ull));
-        }
+#ifndef SMC_EMULATE
+        // the launch ends with this workgroup (15 us beside 1024 workgroups drawing, 8.5 alone): its waves go first
+        // wherever they share a SIMD
+        __builtin_amdgcn_s_setprio(3);
+#endif
+        const int dec = f2_reduce2_island(a, isl, smd, sme, a.sdec + isl, a.sp_epoch);
+        if (dec < 0 && tid == 0) smc_st_agent(a.sdec + isl, (a.sp_epoch << 2) | 1ull);     // (no step to run)
+        F_STAMP_S(5);
         return;
     }
     const int w = (int)blockIdx.x - (merged ? 1 : 0);
@@ -665,49 +678,98 @@ k_f_spacing_onepass(const FArgs av)
     const double* info = merged ? a.info2 + (i64)isl * INFO_STRIDE : a.info + (i64)isl * INFO_STRIDE;
     const i64 t = (i64)smc_uniform(info[0]);
     if (t >= a.T || t == 0 || (!merged && smc_uniform(info[1]) == 0.0)) return;
+    F_STAMP_S(1);
     const u32 gisl = (u32)(a.island_offset + isl);
     u64* st = a.sst + (i64)isl * a.sp_nwg;
     u64* E = a.E + (i64)isl * (a.ntiles1 + 1);
-    u64* Z = reinterpret_cast<u64*>(a.su) + (i64)isl * a.N;
-    // ---- the draws of my tiles (tile r: draws 1024 (w TPW + r) + 4 tid ..), wave scans, tile totals
-    u64 q[TPW][4], inc[TPW];
+    u32* O = reinterpret_cast<u32*>(a.su) + (i64)isl * a.N * 2;         // (the island's slot of N doubles: N words used)
+    const bool vec = (a.N & 3) == 0;
+    // ---- the draws of my tiles (tile r: draws 1024 (w TPW + r) + 4 tid ..), tile by tile: wave scans, the
+    // tile's total, every draw's prefix inside its tile -> memory
     // (tiles of the N uniforms: k < ntiles.  The (N+1)-th draw, which only the total needs, sits in the last
     //  of them unless N is a multiple of 1024 -- then the last workgroup makes it by itself, below: the
-    //  grid stays ceil(ntiles / TPW) workgroups, 512 at N = 2^22, which is what the chip holds for certain)
+    //  grid stays ceil(ntiles / TPW) workgroups)
+    u64 tile_tot[TPW];
 #pragma unroll
-    for (int r = 0; r < TPW; ++r) {
-        const i64 k = (i64)w * TPW + r;
-        if (k < a.ntiles) f_spacing_q4(a, s_ntab, (u32)t, gisl, k * F_TILE + (i64)tid * F_IPT, q[r]);
-        else { q[r][0] = q[r][1] = q[r][2] = q[r][3] = 0ull; }
-        inc[r] = smc_wave_scan_add_u64(q[r][0] + q[r][1] + q[r][2] + q[r][3]);
-        if (r >= TREG) {                           // the last two tiles' draws wait in LDS (see s_q)
+    for (int g = 0; g < NG; ++g) {
+        u64 q[TG][4], inc[TG];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) s_q[r - TREG][i * SMC_BLOCK + tid] = q[r][i];
+        for (int r = 0; r < TG; ++r) {
+            const i64 k = (i64)w * TPW + g * TG + r;
+            if (k < a.ntiles) f_spacing_q4(a, s_ntab, (u32)t, gisl, k * F_TILE + (i64)tid * F_IPT, q[r]);
+            else { q[r][0] = q[r][1] = q[r][2] = q[r][3] = 0ull; }
+            inc[r] = smc_wave_scan_add_u64(q[r][0] + q[r][1] + q[r][2] + q[r][3]);
+        }
+        if (lane == 63) {
+#pragma unroll
+            for (int r = 0; r < TG; ++r) s_w[g & 1][r][wave] = inc[r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < TG; ++r) {
+            const i64 k = (i64)w * TPW + g * TG + r;
+            u64 run = 0ull, tot = 0ull;
+#pragma unroll
+            for (int v = 0; v < SMC_NWAVE; ++v) {
+                if (v < wave) run += s_w[g & 1][r][v];
+                tot += s_w[g & 1][r][v];
+            }
+            tile_tot[g * TG + r] = tot;
+            if (k >= a.ntiles) continue;
+            run += inc[r] - (q[r][0] + q[r][1] + q[r][2] + q[r][3]);
+            const i64 n0 = k * F_TILE + (i64)tid * F_IPT;
+            u32 o4[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                run += q[r][i];
+                o4[i] = (u32)(run < SP_OFF_MAX ? run : SP_OFF_MAX);
+            }
+            if (n0 + 3 < a.N && vec) {
+                smc_st4g(O + n0, o4);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (n0 + i < a.N) smc_stg(O + n0 + i, o4[i]);
+            }
         }
     }
+    F_STAMP_S(2);
+    u64 total = 0ull;
+#pragma unroll
+    for (int r = 0; r < TPW; ++r) total += tile_tot[r];
     u64 q_last = 0ull;                             // draw N when it has a tile of its own
     if (w == a.sp_nwg - 1 && a.ntiles1 > a.ntiles && tid == 0) {
         u64 ql[4];
         f_spacing_q4(a, s_ntab, (u32)t, gisl, a.N, ql);       // (N a multiple of 1024 here: draw N is slot 0)
         q_last = ql[0];
     }
-    if (lane == 63) {
-#pragma unroll
-        for (int r = 0; r < TPW; ++r) s_w[r][wave] = inc[r];
-    }
-    __syncthreads();
-    u64 base[TPW], total = 0ull;          // base[r]: everything of my workgroup before this thread's draws of tile r
-#pragma unroll
-    for (int r = 0; r < TPW; ++r) {
-        u64 b = total;
-#pragma unroll
-        for (int v = 0; v < SMC_NWAVE; ++v) {
-            if (v < wave) b += s_w[r][v];
-            total += s_w[r][v];
+    // ---- publish my total; the prefix = the totals of ALL workgroups before me (<= 1024 of them: up to 4
+    // per thread, every load in flight at once -- the workgroups generate side by side and publish within
+    // a microsecond of each other, so a chained look-back would only add its w / 64 dependent rounds).
+    // Status word: (total << 22) | tag.  merged: the tag is the launch's own (from its epoch), so the words are
+    // published -- and the look-back done -- BEFORE the decision is known (a launch that turns out not to resample
+    // leaves words no later launch can mistake for its own); otherwise the decision came with the record, only
+    // resampling launches get here, tag 1, and k_ancestors2 zeroes the words again.
+    const u64 tag = merged ? (a.sp_epoch % 0x3FFFFEull) + 2ull : 1ull;
+    if (tid == 0) smc_st_agent(st + w, (total << 22) | tag);
+    u64 part = 0ull;
+    for (int idx = tid; idx < w; idx += SMC_BLOCK) {
+        u64 word = smc_ld_agent(st + idx);
+        for (int spin = 0; (word & 0x3FFFFFull) != tag && spin < (1 << 22); ++spin) {
+            smc_spin_pause();
+            word = smc_ld_agent(st + idx);
         }
-        base[r] = b + inc[r] - (q[r][0] + q[r][1] + q[r][2] + q[r][3]);
+        part += word >> 22;
     }
-    if (merged) {                                  // the decision of step t (workgroup 0, long done by now)
+    __syncthreads();                                                       // (s_w has been read)
+    part = smc_wave_sum_u64(part);
+    if (lane == 0) s_w[0][0][wave] = part;
+    __syncthreads();
+    u64 excl = 0ull;
+#pragma unroll
+    for (int v = 0; v < SMC_NWAVE; ++v) excl += s_w[0][0][v];
+    F_STAMP_S(3);
+    if (merged) {                                  // the decision of step t (workgroup 0's: published as soon as it has it)
         if (tid == 0) {
             u64 word = smc_ld_agent(a.sdec + isl);
             for (int spin = 0; (word >> 2) != a.sp_epoch && spin < (1 << 24); ++spin) {
@@ -718,61 +780,24 @@ k_f_spacing_onepass(const FArgs av)
         }
         __syncthreads();
         const u64 word = s_pre;
-        __syncthreads();
         if ((word >> 2) != a.sp_epoch || (word & 3ull) != 2ull) return;
     }
-    // ---- publish my total; the prefix = the totals of ALL workgroups before me (<= 1024 of them: up to 4
-    // per thread, every load in flight at once -- the workgroups generate side by side and publish within
-    // a microsecond of each other, so a chained look-back would only add its w / 64 dependent rounds)
-    if (tid == 0) smc_st_agent(st + w, (total << 2) | SP_FLAG_AGG);
-    u64 part = 0ull;
-    for (int idx = tid; idx < w; idx += SMC_BLOCK) {
-        u64 word = smc_ld_agent(st + idx);
-        for (int spin = 0; (word & 3ull) == 0ull && spin < (1 << 22); ++spin) {
-            smc_spin_pause();
-            word = smc_ld_agent(st + idx);
-        }
-        part += word >> 2;
-    }
-    __syncthreads();                                                       // (s_w has been read)
-    part = smc_wave_sum_u64(part);
-    if (lane == 0) s_w[0][wave] = part;
-    __syncthreads();
+    F_STAMP_S(4);
+    // ---- the tiles' exclusive prefixes (the window search of k_ancestors2 probes them; Z_n = E[n >> 10] + o_n)
     if (tid == 0) {
-        u64 excl = 0ull;
+        u64 run = excl;
 #pragma unroll
-        for (int v = 0; v < SMC_NWAVE; ++v) excl += s_w[0][v];
-        s_pre = excl;
+        for (int r = 0; r < TPW; ++r) {
+            const i64 k = (i64)w * TPW + r;
+            if (k < a.ntiles) E[k] = run;
+            run += tile_tot[r];
+        }
         if (w == a.sp_nwg - 1) {
             if (a.ntiles1 > a.ntiles) E[a.ntiles] = excl + total;         // the prefix of draw N's own tile
             E[a.ntiles1] = excl + total + q_last;                         // Z_N
         }
     }
-    __syncthreads();
-    const u64 pre = s_pre;
-    // ---- the prefix sums of my draws; the tiles' exclusive prefixes for the window search
-#pragma unroll
-    for (int r = 0; r < TPW; ++r) {
-        const i64 k = (i64)w * TPW + r;
-        if (k >= a.ntiles) break;
-        const i64 n0 = k * F_TILE + (i64)tid * F_IPT;
-        u64 run = pre + base[r];
-        if (tid == 0) E[k] = run;
-        u64 z4[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            run += (r >= TREG) ? s_q[r - TREG][i * SMC_BLOCK + tid] : q[r][i];
-            z4[i] = run;
-        }
-        if (n0 + 3 < a.N && (a.N & 1) == 0) {
-            smc_st2g(Z + n0, z4[0], z4[1]);
-            smc_st2g(Z + n0 + 2, z4[2], z4[3]);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (n0 + i < a.N) smc_stg(Z + n0 + i, z4[i]);
-        }
-    }
+    F_STAMP_S(5);
 }
 
 // ---------------------------------------------------------------------------
@@ -2253,7 +2278,11 @@ __device__ __forceinline__ F2Red f2_reduce_island_cached(const FArgs& a, const i
 // (a function of the island: k_reduce2 is one launch of it per step; the one-pass spacings kernel of the
 //  multinomial scheme runs it as ITS workgroup 0, side by side with the workgroups that draw.)
 // Returns -1: no step to run (t = 0, or the filter is past T / frozen), 0: step t does not resample, 1: it does.
-__device__ __forceinline__ int f2_reduce2_island(const FArgs& a, const int isl, double* smd, double* sme)
+// dec_word (the one-pass spacings kernel's workgroup 0): the decision is PUBLISHED -- (dec_epoch << 2) | (2 resample, 1 not) -- the
+// moment it is known, before the tiles' shares are formed and written: the launch's other workgroups wait for it
+// (nothing else of this function's results is theirs to read), the shares are the next launch's.
+__device__ __forceinline__ int f2_reduce2_island(const FArgs& a, const int isl, double* smd, double* sme,
+                                                 u64* dec_word, const u64 dec_epoch)
 {
     const int tid = (int)threadIdx.x;
     double* info = a.info + (i64)isl * INFO_STRIDE;
@@ -2275,6 +2304,7 @@ __device__ __forceinline__ int f2_reduce2_island(const FArgs& a, const int isl, 
         double pmc[NC][4], psc[NC][4];
         const F2Red r = f2_reduce_island_cached<NC>(a, isl, smd, pmc, psc);
         const bool resample = r.ess < a.ess_thresh;
+        if (dec_word && tid == 0) smc_st_agent(dec_word, (dec_epoch << 2) | (resample ? 2ull : 1ull));
         if (a.pm2) {
             const F2Red r2 = f2_reduce_island(a, isl, sme, true);
             if (tid == 0) f2_write_record_apf(a, isl, t, r, r2, resample);
@@ -2334,6 +2364,7 @@ __device__ __forceinline__ int f2_reduce2_island(const FArgs& a, const int isl, 
     }
     const F2Red r = f2_reduce_island(a, isl, smd);
     const bool resample = r.ess < a.ess_thresh;
+    if (dec_word && tid == 0) smc_st_agent(dec_word, (dec_epoch << 2) | (resample ? 2ull : 1ull));
     if (a.pm2) {
         const F2Red r2 = f2_reduce_island(a, isl, sme, true);
         if (tid == 0) f2_write_record_apf(a, isl, t, r, r2, resample);
@@ -2394,15 +2425,25 @@ k_reduce2(const FArgs av)
 // function of n, counts are a guess fixed with the definition, nothing is read.
 // SCH (closed-form counts): SMC_STRATIFIED_ / SMC_SYSTEMATIC_ as a compile-time constant -- the kernel of one scheme
 // carries none of the other's code (the stratified draw inlines a dozen Philox calls); 0: a.scheme at run time.
+#ifndef SMC_A2M_MINW
+#define SMC_A2M_MINW 8      /* REGEN form: waves per SIMD the register allocation leaves room for (64 registers, 64 B of
+                               scratch; with 14.6 KB of LDS eight workgroups share a CU: 74.0 -> 72.0 us per step at C3,
+                               profiles/r15_c3_multinomial_ab.txt; A/B builds: -DSMC_A2M_MINW=1) */
+#endif
 template <bool MID, bool MULTI = false, bool POW2 = true, bool REGEN = false, bool SQ = false, int SCH = 0>
-__global__ void __launch_bounds__(SMC_BLOCK)
+__global__ void __launch_bounds__(SMC_BLOCK, REGEN ? SMC_A2M_MINW : 1)
 k_ancestors2(const FArgs av)
 {
     static_assert(!REGEN || (MID && MULTI), "regenerated thresholds: multinomial behind k_reduce2");
     static_assert(!SQ || (MID && MULTI && POW2 && !REGEN), "SQMC: the tape form of the multinomial search");
     const FArgs& a = av;
     constexpr int WIN = 2 * F_PASS;                                        // offspring per pass
-    __shared__ __attribute__((aligned(16))) u32 sP[WIN];
+    // the scatter window sP (8 KB), and -- REGEN -- the staged thresholds sT (12 KB) IN THE SAME MEMORY: sT is dead
+    // when the counts are done, sP is zeroed then (behind the barrier the counts end with) -- 14.6 instead of 22.8 KB of
+    // LDS per workgroup, 8 workgroups per CU instead of 7: N = 2^22's 4096 tiles are two full rounds of the chip
+    constexpr int WMAX = 1536;                                             // staged thresholds
+    __shared__ __attribute__((aligned(16))) double s_raw[REGEN ? WMAX + 4 : WIN / 2];
+    u32* const sP = reinterpret_cast<u32*>(s_raw);
     __shared__ double s_max[SMC_NWAVE];                                    // one area per exchange
     __shared__ double s_sum[2 * SMC_NWAVE];
     __shared__ double s_g[SMC_NWAVE + 1];
@@ -2450,9 +2491,11 @@ k_ancestors2(const FArgs av)
         f_load4<double>(a.ps + o, (i64)tid * 4, a.nparts, pvec, 0.0, ps4);
         f_load4<double>(a.pss + o, (i64)tid * 4, a.nparts, pvec, 0.0, pss4);
     }
-    // the scatter window of the first pass, while the loads are on their way
-    *reinterpret_cast<uint4*>(&sP[tid * 4]) = make_uint4(0u, 0u, 0u, 0u);
-    *reinterpret_cast<uint4*>(&sP[F_PASS + tid * 4]) = make_uint4(0u, 0u, 0u, 0u);
+    // the scatter window of the first pass, while the loads are on their way (REGEN: see s_raw)
+    if (!REGEN) {
+        *reinterpret_cast<uint4*>(&sP[tid * 4]) = make_uint4(0u, 0u, 0u, 0u);
+        *reinterpret_cast<uint4*>(&sP[F_PASS + tid * 4]) = make_uint4(0u, 0u, 0u, 0u);
+    }
     const i64 t = (i64)smc_uniform(r0);
     if (t >= a.T) {
         if (!MID && b == 0 && tid == 0) info[0] = (double)t;   // k_propagate returns on it
@@ -2532,9 +2575,8 @@ k_ancestors2(const FArgs av)
     i64 ns[F_IPT + 1], n_lo, n_hi;
     if (REGEN) {
         // thresholds as integer-valued doubles (<= 2^52: exact, compared in fp64; no 64-bit conversions)
-        constexpr int WMAX = 1536;                                         // staged thresholds (12 KB)
         constexpr int MARGIN = 128;                                        // > 8 sigma of a position inside a tile
-        __shared__ __attribute__((aligned(16))) double sT[WMAX + 4];       // (+ 4 guard slots)
+        double* const sT = s_raw;                                          // (WMAX + 4 guard slots)
         __shared__ i64 s_k[2];
         __shared__ double s_b[4];
         __shared__ i64 s_edge[SMC_BLOCK + 1];
@@ -2571,11 +2613,44 @@ k_ancestors2(const FArgs av)
         s1 = s1 < s0 ? s0 : s1;
         const int nw = (int)(s1 - s0);
         bool staged = nw <= WMAX;
-        const bool zform = a.sp_tpw > 0;           // su holds the integer prefix sums Z_n: su_n = fl(Z_n) / fl(Z_N)
+        const bool zform = a.sp_tpw > 0;           // one-pass spacings: Z_n = E[n >> 10] + o_n (k_f_spacing_onepass), su_n = fl(Z_n) / fl(Z_N)
+        const u32* zo = reinterpret_cast<const u32*>(a.su) + (i64)isl * N * 2;
         if (zform && b < a.sp_nwg && tid == 0) a.sst[(i64)isl * a.sp_nwg + b] = 0ull;     // look-back words: re-armed
-        if (staged) {
-            // (WMAX = 3 x 512: at most three pairs per thread -- all of them requested before the first is used;
-            //  the loop form waited for each pair in turn, 3.0 -> ... us per workgroup in r05t's timeline)
+        const i64 kw0 = smc_uniform_u64((u64)(s0 >> 10));
+        u64 Ew[4] = {0ull, 0ull, 0ull, 0ull};
+        if (zform && staged) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const i64 kk = kw0 + j < (i64)a.ntiles1 ? kw0 + j : (i64)a.ntiles1;
+                Ew[j] = smc_ldg(g.E + kk);          // (requested with the window's words: nothing waits for them here)
+            }
+        }
+        if (staged && zform) {
+            // (WMAX = 3 x 512: at most three pairs per thread -- all of them, and the prefixes of the at most four
+            //  tiles of draws the window touches, requested before anything is used.  Loads on clamped addresses,
+            //  masked when they are written to LDS: no exec-mask region, hence no wait, between two requests.
+            //  s0 is even and a tile of draws starts at a multiple of 1024: a pair lies inside ONE tile)
+            constexpr int NPAIR = WMAX / (2 * SMC_BLOCK);
+            u32 o0[NPAIR], o1[NPAIR];
+            int kt[NPAIR];
+            const i64 last_pair = (N - 1) & ~(i64)1;       // (N odd: the pair (N - 1, N) -- the island's slot has the room)
+#pragma unroll
+            for (int r = 0; r < NPAIR; ++r) {
+                i64 idx = s0 + tid * 2 + r * 2 * SMC_BLOCK;
+                idx = idx < last_pair ? idx : last_pair;
+                smc_ld2g(zo + idx, o0[r], o1[r]);
+                kt[r] = (int)((idx >> 10) - kw0);
+            }
+#pragma unroll
+            for (int r = 0; r < NPAIR; ++r) {
+                const int i = tid * 2 + r * 2 * SMC_BLOCK;
+                const u64 eb = kt[r] <= 0 ? Ew[0] : (kt[r] == 1 ? Ew[1] : (kt[r] == 2 ? Ew[2] : Ew[3]));
+                const double u0 = smc_div_c((double)(eb + (u64)o0[r]), g.dall, g.rdall);
+                const double u1 = smc_div_c((double)(eb + (u64)o1[r]), g.dall, g.rdall);
+                if (i < nw) sT[i] = ceil(u0 * 4503599627370496.0);
+                if (i + 1 < nw) sT[i + 1] = ceil(u1 * 4503599627370496.0);
+            }
+        } else if (staged) {
             constexpr int NPAIR = WMAX / (2 * SMC_BLOCK);
             double w0[NPAIR], w1[NPAIR];
             const bool even = (N & 1) == 0;
@@ -2593,14 +2668,11 @@ k_ancestors2(const FArgs av)
 #pragma unroll
             for (int r = 0; r < NPAIR; ++r) {
                 const int i = tid * 2 + r * 2 * SMC_BLOCK;
-                double u0 = w0[r], u1 = w1[r];
-                if (zform) {
-                    u0 = smc_div_c((double)(u64)__double_as_longlong(u0), g.dall, g.rdall);
-                    u1 = smc_div_c((double)(u64)__double_as_longlong(u1), g.dall, g.rdall);
-                }
-                if (i < nw) sT[i] = ceil(u0 * 4503599627370496.0);
-                if (i + 1 < nw) sT[i + 1] = ceil(u1 * 4503599627370496.0);
+                if (i < nw) sT[i] = ceil(w0[r] * 4503599627370496.0);
+                if (i + 1 < nw) sT[i + 1] = ceil(w1[r] * 4503599627370496.0);
             }
+        }
+        if (staged) {
             __syncthreads();
             // the window must hold every threshold in (G_b, G_b + Q_b]: the one before it at or below
             // G_b (or the window starts with its tile), the one after it above G_b + Q_b (or it ends
@@ -2685,8 +2757,8 @@ k_ancestors2(const FArgs av)
                     i64 lo_ = w_lo, hi_ = w_hi;                            // first threshold in the tiles above C
                     while (lo_ < hi_) {
                         const i64 mid = lo_ + ((hi_ - lo_) >> 1);
-                        double um = smc_ldg(su.u + mid);
-                        if (zform) um = smc_div_c((double)(u64)__double_as_longlong(um), g.dall, g.rdall);
+                        double um = zform ? smc_div_c((double)(smc_ldg(g.E + (mid >> 10)) + (u64)smc_ldg(zo + mid)), g.dall, g.rdall)
+                                          : smc_ldg(su.u + mid);
                         if (f2_t52(um) <= Gb + pos) lo_ = mid + 1; else hi_ = mid;
                     }
                     v = lo_ < N ? lo_ : N;
@@ -2697,6 +2769,9 @@ k_ancestors2(const FArgs av)
         }
         // ---- the next thread's first boundary; the tile's range
         __syncthreads();
+        // (every count is made: the thresholds' memory becomes the scatter window of the first pass)
+        *reinterpret_cast<uint4*>(&sP[tid * 4]) = make_uint4(0u, 0u, 0u, 0u);
+        *reinterpret_cast<uint4*>(&sP[F_PASS + tid * 4]) = make_uint4(0u, 0u, 0u, 0u);
         s_edge[tid] = ns[0];
         if (tid == SMC_BLOCK - 1) s_edge[SMC_BLOCK] = ns[F_IPT];
         __syncthreads();
@@ -3099,11 +3174,11 @@ k_f_spacings_out(const FArgs av, const i64 t, const int isl, double* out)
         u64 q[4];
         f_spacing_q4(a, s_ntab, (u32)t, gisl, n0, q);
         u64 tot;
-        u64 run = carry + smc_block_exscan_u64(q[0] + q[1] + q[2] + q[3], smu, tot);
+        u64 run = smc_block_exscan_u64(q[0] + q[1] + q[2] + q[3], smu, tot);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             run += q[i];
-            if (n0 + i < a.N) Z[n0 + i] = run;
+            if (n0 + i < a.N) Z[n0 + i] = carry + (run < SP_OFF_MAX ? run : SP_OFF_MAX);
         }
         carry += tot;
         __syncthreads();
@@ -3133,11 +3208,11 @@ k_f_spacings_step(const FArgs av, const int isl, double* out)
         u64 q[4];
         f_spacing_q4(a, s_ntab, (u32)t, gisl, n0, q);
         u64 tot;
-        u64 run = carry + smc_block_exscan_u64(q[0] + q[1] + q[2] + q[3], smu, tot);
+        u64 run = smc_block_exscan_u64(q[0] + q[1] + q[2] + q[3], smu, tot);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             run += q[i];
-            if (n0 + i < a.N) Z[n0 + i] = run;
+            if (n0 + i < a.N) Z[n0 + i] = carry + (run < SP_OFF_MAX ? run : SP_OFF_MAX);
         }
         carry += tot;
         __syncthreads();

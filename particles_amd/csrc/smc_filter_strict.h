@@ -225,7 +225,8 @@ __device__ __forceinline__ void strict_search_part(const FArgs& a, const SqxArgs
     if (a.log2N >= 0) su.rM = 1.0 / su.dM;                     // (N = 2^k: the division by N is an exact scaling)
     if (zform) {
         // one-pass uniform_spacings (k_f_spacing_onepass): the integer prefix sums; the look-back words re-armed
-        su.z = reinterpret_cast<const u64*>(a.su) + (i64)isl * a.N;
+        su.zo = reinterpret_cast<const u32*>(a.su) + (i64)isl * a.N * 2;
+        su.zE = a.E + (i64)isl * (a.ntiles1 + 1);
         su.dall = (double)smc_uniform_u64(zall);
         if (b < a.sp_nwg && threadIdx.x == 0) a.sst[(i64)isl * a.sp_nwg + b] = 0ull;
     }

@@ -999,20 +999,24 @@ k_spacing_write(i64 M, double scale, u64 seed, u32 t, u32 island, const u64* E, 
     pre = smc_block_sum_u64(pre, sm);
     all = smc_block_sum_u64(all, sm);
     u64 tot;
-    u64 run = pre + smc_block_exscan_u64(tsum, sm, tot);
+    u64 run = smc_block_exscan_u64(tsum, sm, tot);
     const double dall = (double)all;
 #pragma unroll
     for (int i = 0; i < OPS_IPT; ++i) {
-        run += q[i];
-        if (n0 + i < M) su[n0 + i] = (double)run / dall;
+        run += q[i];          // (the prefix inside a tile of 1024 saturates at 2^32 - 1: the filter kernels' contract, SP_OFF_MAX)
+        if (n0 + i < M) su[n0 + i] = (double)(pre + (run < 0xFFFFFFFFull ? run : 0xFFFFFFFFull)) / dall;
     }
 }
 
+// the fixed-point scale of the exponential draws, q_n = rint(-log(u_n) 2^s): s = min(57 - ceil(log2(M + 2)), 21).
+// 2^21 (any M below 2^36): a spacing is resolved to 2^-21 of the mean spacing -- 2^-43 of the unit interval at M = 2^22 --
+// and the sum of a tile of 1024 draws, 2^31 +- 2^26, fits 32 bits: the one-pass kernel of the fused step stores
+// 4 bytes per draw (smc_filter_kernels.h k_f_spacing_onepass; rounds 3-5 used s = 57 - lg and 8 bytes)
 static double spacing_scale(i64 M)
 {
     int lg = 0;
     while (((i64)1 << lg) < M + 2) ++lg;
-    return ldexp(1.0, 57 - lg);
+    return ldexp(1.0, 57 - lg < 21 ? 57 - lg : 21);
 }
 
 extern "C" int smc_uniform_spacings(smc_ctx* ctx, int64_t M, uint64_t counter, double* su)

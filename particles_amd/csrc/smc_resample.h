@@ -30,14 +30,17 @@ struct SmcSu {
     u32 t, island;
     // stratified, Philox: the last pair of uniforms drawn (consecutive offspring share a call)
     mutable u64 c_pair = ~0ull, c_a = 0ull, c_b = 0ull;
-    // multinomial, one-pass uniform_spacings: the integer prefix sums Z_n of the draws and (double)Z_N -- su_n = Z_n / Z_N,
-    // the quotient resampling.py:537 forms (null: `u` holds the quotients)
-    const u64* z = nullptr;
+    // multinomial, one-pass uniform_spacings (k_f_spacing_onepass): the integer prefix sums of the draws as 32-bit
+    // prefixes inside their tile of 1024, zo, and the tiles' own prefixes, zE -- Z_n = zE[n >> 10] + zo[n] -- and
+    // (double)Z_N: su_n = Z_n / Z_N, the quotient resampling.py:537 forms (null: `u` holds the quotients)
+    const u32* zo = nullptr;
+    const u64* zE = nullptr;
     double dall = 1.0;
     // M a power of two: 1 / M -- the division by M is then an exact scaling and x * rM the same double as x / M
     // (0: divide)
     double rM = 0.0;
 };
+__device__ __forceinline__ u64 smc_su_z(const SmcSu& s, const i64 n) { return s.zE[n >> 10] + (u64)s.zo[n]; }
 __device__ __forceinline__ double smc_su_div(const SmcSu& s, const double y) { return s.rM != 0.0 ? y * s.rM : y / s.dM; }
 
 // the nc-th uniform of the stratified draw
@@ -68,7 +71,7 @@ __device__ __forceinline__ double smc_su_at(const SmcSu& s, i64 n)
         }
         return smc_su_div(s, un + (double)n);
     }
-    return s.z ? (double)s.z[n] / s.dall : s.u[n];
+    return s.zo ? (double)smc_su_z(s, n) / s.dall : s.u[n];
 }
 
 // Both members of the pair (2p, 2p+1) with one Philox call.

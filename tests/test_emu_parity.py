@@ -296,7 +296,7 @@ def test_mv_collapsed_proposal():
 
 
 def test_multinomial_spacings_regenerated():
-    pc.check_device_spacings(sizes=(2048, 3000))
+    pc.check_device_spacings(sizes=(2048, 3000, 3001))
 
 
 def test_strict_ancestors_equal_the_reference_cdf():

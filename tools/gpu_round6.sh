@@ -21,6 +21,22 @@ case $1 in
 micro)  # fp64 MFMA shadow: do fillers between one wave's MFMAs hide?
     ./tools/micro/shadow.bin > $O/${TAG}_mfma_shadow.txt 2>&1; cat $O/${TAG}_mfma_shadow.txt
     ;;
+legab)  # same-box A/B of one bench leg: $2 = bench args, $3 = "label:ENV=1,ENV2=2 ..." items
+    for rep in 1 2; do
+      for item in $3; do
+        lab=${item%%:*}; spec=${item#*:}
+        env ${spec//,/ } timeout 300 python bench.py $2 --no-cpu-baseline --no-other-workloads > $O/ab_${lab}_$rep.json 2>$O/ab_${lab}_$rep.err
+        python - $O/ab_${lab}_$rep.json $lab <<'PY'
+import json,sys
+try:
+    d=json.loads([l for l in open(sys.argv[1]) if l.startswith('{')][-1]); r=d.get('roofline',{})
+    print(sys.argv[2], 'us/step %.2f'%(1e3*d['ms_per_step']), 'G/s %.3f'%(d['value']/1e9), {k[-30:]:round(1e3*v['ms'],2) for k,v in r.get('per_kernel',{}).items()}, r.get('step_kernels'))
+except Exception as e:
+    print(sys.argv[2], 'FAILED', e)
+PY
+      done
+    done
+    ;;
 c4ab)   # same-box A/B of k_propagate_mv variants: $2 = space separated "label:ENV=1" items
     for rep in 1 2; do
       for item in ${2:-"base:SMC_X=0"}; do
@@ -59,6 +75,13 @@ print("C2", d["value"] / 1e9, d["ms_per_step"], d["roofline"]["frac"], d["roofli
 for k, v in d["other_workloads"].items():
     print(k, v.get("value", 0) / 1e9, v.get("ms_per_step"), v.get("frac"), v.get("error"))
 PY
+    ;;
+spacing)
+    python tools/trace_spacing.py 22 > $O/${TAG}_trace_spacing.txt 2>&1; cat $O/${TAG}_trace_spacing.txt
+    python tools/trace_step.py 22 multinomial sv > $O/${TAG}_trace_c3_multinomial.txt 2>&1; head -12 $O/${TAG}_trace_c3_multinomial.txt
+    ;;
+floor)  # in-kernel timelines + the step's floor breakdown (needs particles_amd/lib/abl/libsmc_TRACE.so)
+    (python tools/trace_step.py 20; python tools/trace_step.py 14; python tools/trace_step.py 22 systematic sv) > $O/${TAG}_c2_floor.txt 2>&1; cat $O/${TAG}_c2_floor.txt
     ;;
 prof)
     bash tools/gpu_profile_all.sh $TAG "$2"

@@ -20,7 +20,7 @@ from bench import synthetic_data                                # noqa: E402
 log2N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 scheme = sys.argv[2] if len(sys.argv) > 2 else "systematic"
 N = 1 << log2N
-y = synthetic_data(200)
+y = synthetic_data(1400)
 model = ssm.StochVol() if len(sys.argv) > 3 and sys.argv[3] == "sv" else kalman.ToySSM(0.2)
 pf = pa.SMC(fk=ssm.Bootstrap(ssm=model, data=y), N=N, seed=123, use_graph=False, resampling=scheme,
             ESSrmin=1.0 if len(sys.argv) > 2 else 0.5)
@@ -86,3 +86,26 @@ for name, st, labels in (
         print("  slowest q-ready -> published:", [(int(i), float(d[i]), float((st[i, 0] - t0) / 100.0)) for i in order])
         w = (st[:, 4].astype(np.int64) - st[:, 3].astype(np.int64)) / 100.0
         print("  published -> prefix known by tile index quartile:", [round(float(np.median(w[q * 256:(q + 1) * 256])), 2) for q in range(ntiles // 256)])
+
+# ---- the step's floor: where a step's time goes BETWEEN the kernels.  All stamps are wall_clock64()
+# ticks of one 100 MHz counter, so differences across the two launches of the step are meaningful.
+if two_level:
+    import time
+    A = buf[nparts * 8:].reshape(ntiles, 8)
+    A = A[A[:, 0] > 0]
+    P = buf[:nparts * 8].reshape(nparts, 8)
+    P = P[P[:, 0] > 0]
+    last = lambda M: max(int(M[:, k].max()) for k in range(M.shape[1]))
+    a0, a1, p0, p1 = int(A[:, 0].min()), last(A), int(P[:, 0].min()), last(P)
+    K = 400
+    pf.sync()
+    t0 = time.perf_counter()
+    pf.step_async(K)
+    pf.sync()
+    period = (time.perf_counter() - t0) / K * 1e6
+    ra, gap_ap, rp = (a1 - a0) / 100.0, (p0 - a1) / 100.0, (p1 - p0) / 100.0
+    print("floor breakdown at N = 2^%d (%s), us: step period %.2f (K = %d, this build: the stamps cost a store each) =" % (log2N, scheme, period, K))
+    print("  resampling launch, first workgroup's first stamp -> last workgroup's last stamp   %6.2f" % ra)
+    print("  its last stamp -> k_propagate's first workgroup running (end of kernel: write-back, dispatch of the dependent launch, first wave)   %6.2f" % gap_ap)
+    print("  k_propagate, first stamp -> last stamp                                            %6.2f" % rp)
+    print("  k_propagate's last stamp -> the NEXT step's first workgroup (period - the three above)   %6.2f" % (period - ra - gap_ap - rp))
