@@ -107,6 +107,8 @@ def committed_profile(wl, kernel, profiles=None):
         return None
     with open(path) as fh:
         rec = json.load(fh)
+    if rec.get("source_hash") and rec["source_hash"] != _source_hash():
+        return None          # (a record of kernels whose source has changed since: not this tree's)
     cfg = rec.get("config", {})
     if wl["Nlabel"] != "2^%d" % wl["log2N"] or \
             (cfg.get("log2N"), cfg.get("islands"), cfg.get("scheme")) != (wl["log2N"], wl["islands"], wl["scheme"]) or \
@@ -140,7 +142,19 @@ def committed_profile(wl, kernel, profiles=None):
     if not found:
         return None
     return {"bytes": total, "avg_us": us if us_ok and us > 0 else None,
-            "source": "rocprofv3 PMC, profiles/%s" % rec.get("summary", "")}
+            "source": "rocprofv3 PMC, profiles/%s (tree %s, source %s)" % (rec.get("summary", ""), rec.get("tree", "?"),
+                                                                          rec.get("source_hash", "unstamped"))}
+
+
+_SRC_HASH = []
+
+
+def _source_hash():
+    if not _SRC_HASH:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from source_hash import source_hash
+        _SRC_HASH.append(source_hash())
+    return _SRC_HASH[0]
 
 
 def measured_traffic(wl, kernel, profiles=None):

@@ -362,25 +362,18 @@ typedef struct smc_filter_opts {
 #define SMC_PATH_FLAT_CDF        (1 << 8)   /* flat Q62 CDF (k_ancestors [+ k_prepare]) where the two-level step applies */
 #define SMC_PATH_TWO_LEVEL_MID   (1 << 9)   /* k_reduce2 in front of k_ancestors2 even on resident grids */
 #define SMC_PATH_EXACT_COUNTS    (1 << 10)  /* form every c Q_b / t_b exactly (no fp64 band shortcut) */
-#define SMC_PATH_FORCE_FUSED     (1 << 11)  /* flat step: published tile totals regardless of the grid size */
 #define SMC_PATH_FORCE_UNFUSED   (1 << 12)  /* flat step: k_prepare regardless of the grid size */
 #define SMC_PATH_NO_SMALL        (1 << 13)  /* N <= 1024: the multi-kernel step instead of k_filter_small */
-#define SMC_PATH_NO_NT           (1 << 14)  /* plain instead of streaming stores */
 #define SMC_PATH_NO_HEAVY        (1 << 15)  /* no heavy-parent list */
 #define SMC_PATH_NO_TK           (1 << 16)  /* normals never start on the host's time index */
-#define SMC_PATH_FLAT_MULTINOMIAL (1 << 17) /* multinomial on the flat step */
-#define SMC_PATH_POW2_ONLY       (1 << 18)  /* N not a power of two on the flat step */
 #define SMC_PATH_SPACING_3PASS   (1 << 19)  /* uniform_spacings in three passes instead of one */
 #define SMC_PATH_SPLIT_REDUCE     (1 << 24)  /* multinomial, one-pass spacings: k_reduce2 as a launch of its own */
 #define SMC_PATH_NO_WIDE          (1 << 30)  /* resident two-level step: k_ancestors2 (one tile per workgroup) instead of k_ancestors2w */
 #define SMC_PATH_NO_XCD_CHUNKS    (1 << 5)   /* two-level step: tile = workgroup index instead of contiguous runs of tiles per XCD */
 #define SMC_PATH_STRICT_LITERAL   (1 << 6)   /* SMC_FLAG_STRICT_ANCESTORS: the sequential CDF by the literal one-lane walk, not its parallel emulation */
-#define SMC_PATH_WIDE4            (1 << 7)   /* k_ancestors2w with 4 tiles per workgroup instead of 2 */
 #define SMC_PATH_SQ_GATHER        (1 << 29)  /* SMC_FLAG_SQMC: gather the sorted log-weights where they could be recomputed */
 #define SMC_PATH_MV_DENSE         (1 << 3)   /* MVLINGAUSS with diagonal G / covX / covY / cov0: the dense MFMA products all the same (the twin the
                                                element-wise form is checked against, bit for bit; bench.py's c4_dense leg) */
-#define SMC_PATH_STRICT_ONE_LAUNCH (1u << 31)  /* SMC_FLAG_STRICT_ANCESTORS: k_strict_classify + k_strict_search as ONE launch (k_strict_step) where
-                                                * the whole grid is resident at once; the caller vouches that no other process shares the device */
 #define SMC_PATH_SP_TPW(n)        (((n) & 15) << 25)   /* one-pass spacings: n = 1, 2, 4, 8 tiles of draws per workgroup */
 #define SMC_PATH_MV_CHUNKS(n)    (((n) & 15) << 20)   /* k_propagate_mv: n = 1, 2, 4, 8 chunks per workgroup */
 

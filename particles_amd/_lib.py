@@ -52,12 +52,9 @@ FLAG_SQMC = 4
 # verification switches (include/smc_hip.h SMC_PATH_*): the environment variables the test-suite and
 # tools/ set to force an alternative, equivalent code path; read HERE, not in the library
 PATH_FLAGS = {"SMC_FLAT_CDF": 1 << 8, "SMC_TWO_LEVEL_MID": 1 << 9, "SMC_EXACT_COUNTS": 1 << 10,
-              "SMC_FORCE_FUSED": 1 << 11, "SMC_FORCE_UNFUSED": 1 << 12, "SMC_NO_SMALL": 1 << 13,
-              "SMC_NO_NT": 1 << 14, "SMC_NO_HEAVY": 1 << 15, "SMC_NO_TK": 1 << 16,
-              "SMC_FLAT_MULTINOMIAL": 1 << 17, "SMC_POW2_ONLY": 1 << 18, "SMC_SPACING_3PASS": 1 << 19,
-              "SMC_SPLIT_REDUCE": 1 << 24, "SMC_SQ_GATHER": 1 << 29, "SMC_NO_WIDE": 1 << 30, "SMC_WIDE4": 1 << 7,
-              "SMC_STRICT_LITERAL": 1 << 6, "SMC_NO_XCD_CHUNKS": 1 << 5, "SMC_MV_DENSE": 1 << 3,
-              "SMC_STRICT_ONE_LAUNCH": 1 << 31}
+              "SMC_FORCE_UNFUSED": 1 << 12, "SMC_NO_SMALL": 1 << 13, "SMC_NO_HEAVY": 1 << 15, "SMC_NO_TK": 1 << 16,
+              "SMC_SPACING_3PASS": 1 << 19, "SMC_SPLIT_REDUCE": 1 << 24, "SMC_SQ_GATHER": 1 << 29, "SMC_NO_WIDE": 1 << 30,
+              "SMC_STRICT_LITERAL": 1 << 6, "SMC_NO_XCD_CHUNKS": 1 << 5, "SMC_MV_DENSE": 1 << 3}
 
 
 def path_flags():

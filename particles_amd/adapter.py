@@ -240,17 +240,27 @@ def adapt_smc2(fk):
         return None
     # ... and the inner filters must be batchable as islands with per-island parameters: a univariate model of
     # the fused family (a probe instance at the prior's first draw says which)
-    state = np.random.get_state()                  # (the probe must not cost the caller's seeded stream a draw)
+    # (TWO probes at different prior draws, as islands of one throw-away filter: a per-step term that depends on a
+    #  parameter the prior varies -- Gordon_etal with `d` or `e` in the prior -- and an inner resampling scheme the
+    #  fused step does not run are refused HERE, by the very checks the batch will meet, core.py _create_filter)
+    state = np.random.get_state()                  # (the probes must not cost the caller's seeded stream a draw)
     try:
-        probe = fk.prior.rvs(size=1)
-        theta0 = {k: float(np.ravel(probe[k])[0]) for k in probe.dtype.names}
-        dm = fkc(ssm=ours(**theta0), data=fk.data)._device_model()
+        probe = fk.prior.rvs(size=2)
+        fks = [fkc(ssm=ours(**{k: float(np.ravel(probe[k])[i]) for k in probe.dtype.names}), data=fk.data)
+               for i in range(2)]
+        dm = fks[0]._device_model()
+        if dm is None or dm.get("kind") == _lib.MODEL_MVLINGAUSS:
+            return None
+        opts = {k: v for k, v in (fk.smc_options or {}).items() if k in ("resampling", "ESSrmin")}
+        from .core import SMC as _DevSMC
+        trial = _DevSMC(fk=fks, N=max(2, min(int(fk.init_Nx), 64)), collect="off", seed=0, **opts)
+        if not getattr(trial, "_fused", False):
+            return None
+        del trial
     except Exception:
         return None
     finally:
         np.random.set_state(state)
-    if dm is None or dm.get("kind") == _lib.MODEL_MVLINGAUSS:
-        return None
     return ours, fkc
 
 
@@ -275,9 +285,15 @@ def HipSMC():
                         and kw.get("collect") in (None, "off") and not kw.get("verbose") \
                         and kw.get("resampling", "systematic") == "systematic":     # (the device theta level's scheme)
                     kw2 = {k: v for k, v in kw.items() if k in ("N", "ESSrmin", "resampling", "seed")}
-                    # (adapt_smc2 made every batchability check -- before any draw or device allocation -- so an
-                    #  error from here on is a real one: a bad prior / theta shape, an unknown scheme; it surfaces)
-                    return DeviceSMC2Run(fk, two[0], two[1], **kw2)
+                    # adapt_smc2 ran the batchability checks on two probe islands; should the full batch still be
+                    # refused (a ValueError while the device run is being BUILT: nothing has been stepped), the
+                    # reference's own loop runs it, on the random stream as the caller seeded it
+                    state = np.random.get_state()
+                    try:
+                        return DeviceSMC2Run(fk, two[0], two[1], **kw2)
+                    except ValueError:
+                        np.random.set_state(state)
+                        return super().__new__(cls)
                 mine = adapt(fk) if fk is not None else None
                 if mine is None or kw.get("qmc"):
                     return super().__new__(cls)            # the reference's own path

@@ -254,7 +254,10 @@ class SMC:
                                       or model["kind"] == _lib.MODEL_MVLINGAUSS)
 
     # ------------------------------------------------------------------ fused
-    def _create_filter(self, model, replay, use_graph, island_offset):
+    def _create_filter(self, model, replay, use_graph, island_offset, restore=None):
+        """restore (unpickling): {"path_flags", "sqmc"} of the filter the state was saved from -- the verification
+        switches it was created under (the environment of the RECEIVING process may differ: the slab's layout must not)
+        and its point-set key and counter (the process-wide counter of the receiving process is left alone)."""
         fk = self.fk
         T = fk.T
         y = np.ascontiguousarray(np.asarray(fk.data, dtype=np.float64).reshape(T, -1))
@@ -309,7 +312,8 @@ class SMC:
         o.moments = 1 if self._device_moments else 0
         o.flags = (_lib.FLAG_COLLAPSED_PROPOSAL if self._collapsed else 0) | \
                   (_lib.FLAG_STRICT_ANCESTORS if self._strict else 0) | \
-                  (_lib.FLAG_SQMC if self.qmc else 0) | _lib.path_flags()
+                  (_lib.FLAG_SQMC if self.qmc else 0) | (restore["path_flags"] if restore else _lib.path_flags())
+        self._path_flags = int(o.flags) & ~7
         self._ctx = _lib.ctx()
         h = _lib.c_vp()
         check(lib().smc_filter_create(self._ctx.h, ctypes.byref(m), ctypes.byref(o),
@@ -318,8 +322,13 @@ class SMC:
         if self.qmc:
             # the points of the operator path (rqmc.sobol / sobol_sorted): the context's key, one
             # point-set counter per time step -- the same run whichever path executes it
-            check(lib().smc_filter_sqmc_points(self._f, self._ctx._seed & (2 ** 64 - 1), _lib._counter + 1))
-            _lib._counter += T
+            if restore:              # (the saved state carries the points' key and counter: load_state puts them back)
+                self._sqmc_key = restore["sqmc"]
+                check(lib().smc_filter_sqmc_points(self._f, self._sqmc_key[0], self._sqmc_key[1]))
+            else:
+                self._sqmc_key = (self._ctx._seed & (2 ** 64 - 1), _lib._counter + 1)
+                check(lib().smc_filter_sqmc_points(self._f, self._sqmc_key[0], self._sqmc_key[1]))
+                _lib._counter += T
         if replay is not None:
             z, u = replay
             self._tapes = (_lib.as_device(z)[0], _lib.as_device(u)[0])
@@ -386,9 +395,18 @@ class SMC:
         self._f = None
         self._cache, self._summ_cache = {}, None
         if blob is not None:
-            use_graph, island_offset, _ = self._ctor
+            use_graph, island_offset = self._ctor[0], self._ctor[1]
             model = self.fk._device_model()
-            self._create_filter(model, tapes, use_graph, island_offset)
+            # re-created under the SAVED verification switches and point-set key: the environment and the process-wide
+            # counters of the receiving process are neither read nor moved
+            self._create_filter(model, tapes, use_graph, island_offset,
+                                restore={"path_flags": d.get("_path_flags", _lib.path_flags()),
+                                         "sqmc": d.get("_sqmc_key", (0, 1))})
+            nb = _lib.c_i64()
+            check(lib().smc_filter_state_bytes(self._f, ctypes.byref(nb)))
+            if int(nb.value) != blob.nbytes:
+                raise ValueError("unpickling a device filter: the saved state has %d bytes, a filter of this shape holds %d "
+                                 "(another library build?)" % (blob.nbytes, int(nb.value)))
             check(lib().smc_filter_load_state(self._f, blob.ctypes.data_as(_lib.c_vp), blob.nbytes))
 
     def _invalidate(self):

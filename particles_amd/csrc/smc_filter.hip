@@ -34,8 +34,6 @@ struct smc_filter {
     double* strict_ws;     // (n_islands, N) W | (n_islands, N) S | scratch of smc_seqsum.h
     bool strict_literal;   // SMC_PATH_STRICT_LITERAL: S by the one-lane walk, in place
     bool sq_plan_zero;     // SQMC: the sort workspace's plan words are zero (smc_rs_sort_ws leaves them so)
-    bool strict_one_launch; // classify + search as ONE launch (k_strict_step): every workgroup of the grid resident at once
-    unsigned long long strict_epoch;   // ... its launches, numbered (SqxArgs::epoch)
     // SMC_FLAG_SQMC (smc_filter_sqmc.h): the point stream, the tape of ndtri(second coordinate), the
     // sort's workspace and -- more than one island -- the islands' permutations
     u64 sp_epoch;          // launches of the merged spacings + reduction kernel so far (see FArgs::sp_epoch)
@@ -254,16 +252,9 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
                        f->a, (const double*)f->strict_ws, (const double*)f->a.su);
         } else if (f->two_level) {
             // the same doubles in two launches, S never written (smc_filter_strict.h)
-            // ... or in one, where the whole grid is resident at once (k_strict_step)
-            if (f->strict_one_launch) {
-                do q.epoch = ++f->strict_epoch; while ((uint32_t)q.epoch == 0u);   // (0: the tag of never-written words)
-                if (f->two_level_mid) SMC_LAUNCH(k_strict_step<true>, gt, dim3(SMC_BLOCK), st, f->a, q);
-                else SMC_LAUNCH(k_strict_step<false>, gt, dim3(SMC_BLOCK), st, f->a, q);
-            } else {
-                if (f->two_level_mid) SMC_LAUNCH(k_strict_classify<true>, gt, dim3(SMC_BLOCK), st, f->a, q);
-                else SMC_LAUNCH(k_strict_classify<false>, gt, dim3(SMC_BLOCK), st, f->a, q);
-                SMC_LAUNCH(k_strict_search, gt, dim3(SMC_BLOCK), st, f->a, q);
-            }
+            if (f->two_level_mid) SMC_LAUNCH(k_strict_classify<true>, gt, dim3(SMC_BLOCK), st, f->a, q);
+            else SMC_LAUNCH(k_strict_classify<false>, gt, dim3(SMC_BLOCK), st, f->a, q);
+            SMC_LAUNCH(k_strict_search, gt, dim3(SMC_BLOCK), st, f->a, q);
         } else {
             // one tile (or a flat test path): W materialised, the two launches of smc_seqx.h on the array, S written
             size_t used = 0;
@@ -335,13 +326,8 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
                 const dim3 gridw(f->a.ntiles / f->wide_tpw, f->a.n_islands);
                 // (leading arguments: the fields the kernel's first loads are addressed with, preloaded into SGPRs)
 #define W_LEAD f->a.info2, f->a.pm, f->a.ps, f->a.pss, f->a.cq, f->a.N, f->a.ntiles | (f->a.xcd_chunks ? 1 << 30 : 0)
-                if (f->wide_tpw == 4) {
-                    if (sys) SMC_LAUNCH((k_ancestors2w<4, SMC_SYSTEMATIC_>), gridw, dim3(SMC_BLOCK * 4), st, W_LEAD, f->a);
-                    else SMC_LAUNCH((k_ancestors2w<4, SMC_STRATIFIED_>), gridw, dim3(SMC_BLOCK * 4), st, W_LEAD, f->a);
-                } else {
-                    if (sys) SMC_LAUNCH((k_ancestors2w<2, SMC_SYSTEMATIC_>), gridw, dim3(SMC_BLOCK * 2), st, W_LEAD, f->a);
-                    else SMC_LAUNCH((k_ancestors2w<2, SMC_STRATIFIED_>), gridw, dim3(SMC_BLOCK * 2), st, W_LEAD, f->a);
-                }
+                if (sys) SMC_LAUNCH((k_ancestors2w<2, SMC_SYSTEMATIC_>), gridw, dim3(SMC_BLOCK * 2), st, W_LEAD, f->a);
+                else SMC_LAUNCH((k_ancestors2w<2, SMC_STRATIFIED_>), gridw, dim3(SMC_BLOCK * 2), st, W_LEAD, f->a);
             } else {
                 if (p2) { if (sys) A2_CASE(false, true, SMC_SYSTEMATIC_); else A2_CASE(false, true, SMC_STRATIFIED_); }
                 else { if (sys) A2_CASE(false, false, SMC_SYSTEMATIC_); else A2_CASE(false, false, SMC_STRATIFIED_); }
@@ -532,7 +518,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
         const bool mv_ok = !f->sq_flat || ((!mv || (model->dx >= 2 && model->dx <= 9)) && !o->keep_history && !o->moments &&
                                            !(o->flags & SMC_FLAG_COLLAPSED_PROPOSAL));
         if (!fk_ok || !pow2 || !mv_ok || f->strict || o->rng_mode != SMC_RNG_PHILOX || (f->sq_flat && o->use_graph) ||
-            (o->flags & (SMC_PATH_FLAT_CDF | SMC_PATH_FORCE_FUSED | SMC_PATH_FORCE_UNFUSED | SMC_PATH_FLAT_MULTINOMIAL))) {
+            (o->flags & (SMC_PATH_FLAT_CDF | SMC_PATH_FORCE_UNFUSED))) {
             smc_set_error("SMC_FLAG_SQMC: Bootstrap / Guided filters, N = 2^k with 5 <= k <= 30, Philox mode; MVLINGAUSS "
                           "(2 <= d <= 9) and univariate models with k <= 10: eager launches, no history slots, no moments");
             delete f;
@@ -584,7 +570,6 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     const size_t oA = carve(nA * 4);
     // (published tile totals pay off only while every workgroup of the launch is resident)
     f->fused = (i64)a.ntiles * (i64)M <= F_DIRECT_PREFIX_MAX;
-    if (o->flags & SMC_PATH_FORCE_FUSED) f->fused = a.ntiles <= F_DIRECT_PREFIX_MAX;
     if (o->flags & SMC_PATH_FORCE_UNFUSED) f->fused = false;  // tests: the k_prepare path at any size
     const size_t oQ = carve(M * a.ntiles * 8);
     const size_t oQpre = carve(M * a.ntiles * 8);
@@ -623,9 +608,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     //  spacings drawn between k_reduce2, which decides the step, and k_ancestors2)
     // (any N >= 2 tiles: N = 2^k counts in closed form with integers, other N with the general counts)
     f->two_level = !mv && o->N <= ((int64_t)1 << 30) && a.ntiles >= 2 &&
-                   !(a.log2N < 0 && (o->flags & SMC_PATH_POW2_ONLY)) &&
-                   !(o->flags & (SMC_PATH_FLAT_CDF | SMC_PATH_FORCE_FUSED | SMC_PATH_FORCE_UNFUSED)) &&
-                   !(scheme == SMC_MULTINOMIAL && (o->flags & SMC_PATH_FLAT_MULTINOMIAL));
+                   !(o->flags & (SMC_PATH_FLAT_CDF | SMC_PATH_FORCE_UNFUSED));
     // every workgroup reduces the partials itself while the launch is resident and an island has
     // at most 1024 tiles (4 per thread); otherwise one workgroup per island does it first
     const bool apf2 = !mv && f_is_apf(model->fk) && o->N > F_TILE;      // APF on the two-level step: k_reduce2
@@ -637,16 +620,15 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     f->two_level_mid = f->two_level && (!f->fused || a.ntiles > 1024 || (o->flags & SMC_PATH_TWO_LEVEL_MID) ||
                                         scheme == SMC_MULTINOMIAL || apf2);
     // resident grids of N = 2^k: 2 tiles per workgroup (smc_filter_wide.h; C2, same box: 17.6 us per step, 4 tiles 18.3,
-    // one tile -- k_ancestors2 -- 18.1: profiles/r12d); SMC_PATH_NO_WIDE / _WIDE4 (A/B)
+    // one tile -- k_ancestors2 -- 18.1: profiles/r12d); SMC_PATH_NO_WIDE keeps the one-tile kernel testable at these sizes
     f->wide_tpw = 0;
     if (f->two_level && !f->two_level_mid && a.log2N >= 0 && !(o->flags & SMC_PATH_NO_WIDE) && !f->strict && !f->sqmc) {
-        const int want = (o->flags & SMC_PATH_WIDE4) ? 4 : 2;
-        f->wide_tpw = (a.ntiles % want) == 0 ? want : ((a.ntiles % 2) == 0 ? 2 : 0);
+        f->wide_tpw = (a.ntiles % 2) == 0 ? 2 : 0;
     }
     // ... and of any other N under the systematic scheme (k_ancestors2w<2, .., POW2 = false>: the general counts, any
     // number of tiles -- the last workgroup of a run may hold one tile)
     if (f->two_level && !f->two_level_mid && a.log2N < 0 && scheme == SMC_SYSTEMATIC && a.ntiles >= 2 &&
-        !(o->flags & (SMC_PATH_NO_WIDE | SMC_PATH_POW2_ONLY)) && !f->strict && !f->sqmc)
+        !(o->flags & SMC_PATH_NO_WIDE) && !f->strict && !f->sqmc)
         f->wide_tpw = 2;
     // consecutive tiles on one XCD (f_tile_xcd): any number of tiles with one tile per resampling workgroup; with
     // k_ancestors2w whole multiples of 8 x (its tiles per workgroup) -- else the wide kernel keeps its own XCD-strided map
@@ -717,29 +699,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     f->flush_pending = false;
     // (inside a replayed graph the argument block -- the epoch with it -- is frozen: separate launches there)
     f->sp_merge = a.sp_tpw && merge_fits && !o->use_graph && !(o->flags & SMC_PATH_SPLIT_REDUCE);
-    // strict ancestors, two-level step: classify + search as ONE launch (k_strict_step) -- only when SMC_PATH_STRICT_ONE_LAUNCH
-    // asks for it, and then only where the runtime says the whole grid is resident at once and the island has at most 1024
-    // tiles: the kernel waits inside the launch, and a workgroup that could not start would be waited for for ever.  Built
-    // and measured in round 5 (profiles/r14h_strict_one_launch.txt): 36.8 against 37.1 us per C2 step -- the second launch's
-    // dispatch was already hidden behind the first one's tail, so what is saved is the 8-byte round trip of the roundings'
-    // prefixes.  One per cent does not pay for the condition it needs: two PROCESSES sharing the device (multiSMC with
-    // nprocs = 2 on one GPU) each get part of the CUs, and two such kernels would wait for each other's slots.  Off by default.
-    // (Not inside replayed graphs either: the epoch is a kernel argument.)
-    f->strict_one_launch = false;
     f->sq_plan_zero = false;
-    f->strict_epoch = 0ull;
-#ifndef SMC_EMULATE
-    if (f->strict && f->two_level && !f->strict_literal && !o->use_graph && ((uint32_t)o->flags & SMC_PATH_STRICT_ONE_LAUNCH)) {
-        int per_cu = 0, cus = 0;
-        const hipError_t e1 = f->two_level_mid
-            ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_strict_step<true>, SMC_BLOCK, 0)
-            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_strict_step<false>, SMC_BLOCK, 0);
-        const hipError_t e2 = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
-        const size_t wgs = (size_t)((N + 1023) / 1024) * M;
-        f->strict_one_launch = e1 == hipSuccess && e2 == hipSuccess && wgs <= (size_t)per_cu * (size_t)cus && a.ntiles <= 1024;
-        (void)hipGetLastError();
-    }
-#endif
     const size_t oTmp = carve(N * dxm * 8);
     const size_t oStrict = carve(f->strict ? 2 * M * N * 8 + sqx_scratch_bytes((i64)N, (int)M) + M * a.ntiles * 8 + 64 : 8);
     if (f->sqmc && !f->sq_flat && !f->two_level) {
@@ -810,7 +770,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     a.tk = -1;
     // streaming stores pay while a launch is short (its end-of-kernel write-back shows): C2 +8 %;
     // on the large grids they cost 2 % (C5)
-    a.nt = ((i64)a.ntiles * (i64)M <= F_DIRECT_PREFIX_MAX && !mv && !(o->flags & SMC_PATH_NO_NT)) ? 15 : 0;
+    a.nt = ((i64)a.ntiles * (i64)M <= F_DIRECT_PREFIX_MAX && !mv) ? 15 : 0;
     // (bits: 1 X, 2 lw, 4 the tile CDF, 8 A.  Measured at C2, r12f: any mask that streams lw -- written every step, read
     //  only on the steps that do not resample -- is as fast as streaming everything, 17.63 us; none: 19.31.  With
     //  consecutive tiles per XCD, r12w: 15: 17.4, X plain 17.5, X and the tile CDF plain 18.0, lw only 18.3)
@@ -1925,7 +1885,7 @@ int smc_filter_describe(smc_filter* f, char* out, size_t n)
     } else if (f->strict) {
         if (f->strict_literal) s = std::string(f->two_level ? "k_reduce2+" : "") + "k_strict_W+k_strict_cdf+k_strict_search_S+k_propagate";
         else if (f->two_level) s = std::string(f->two_level_mid ? "k_reduce2+" : "") +
-                                   (f->strict_one_launch ? "k_strict_step[k_strict_classify+k_strict_search]" : "k_strict_classify+k_strict_search") + "+k_propagate";
+                                   std::string("k_strict_classify+k_strict_search") + "+k_propagate";
         else s = "k_strict_W+k_sqx_classify+k_sqx_fill+k_strict_search_S+k_propagate";
     } else {
         if (f->two_level_mid) s = "k_reduce2+k_ancestors2";

@@ -242,25 +242,3 @@ k_strict_search(const FArgs av, const SqxArgs q)
     __shared__ double sS[SEQ_TILE];
     strict_search_part<false>(av, q, (int)blockIdx.x, 0, nullptr, sS);
 }
-
-// ---- the two launches as ONE where every workgroup of the grid is resident at once (the host asks the runtime:
-// workgroups <= CUs x occupancy, smc_filter.hip) -- C2's 1024 tiles are.  A workgroup classifies its tile, takes its
-// ticket and, instead of ending, prepares its draws and then waits for ITS TILE's header from the island's chain (the
-// last workgroup to arrive runs it, as before); then it searches the same tile.  What that removes from the step: the
-// boundary between two dependent kernels (the second one's dispatch, its record and staging loads from a cold start),
-// and the round trip of the roundings' prefixes through memory (8 bytes per particle written and read back: they stay
-// in registers).  What the chain publishes for other workgroups of its own launch are 32-bit payloads under the
-// launch's 32-bit tag (sqx_put): each word is valid on its own, so the chain waits for no store to land and orders
-// nothing, and a waiting workgroup's poll IS the load of its header (sqx_stage_wait).
-template <bool MID>
-__global__ void __launch_bounds__(SMC_BLOCK)
-k_strict_step(const FArgs av, const SqxArgs q)
-{
-    __shared__ double sS[SEQ_TILE];                            // (the chain's tile offsets first, then the tile's staged sums)
-    u64 pin[4];
-    int b;
-    i64 t;
-    if (!strict_classify_part<MID, true>(av, q, pin, b, t, reinterpret_cast<u64*>(sS))) return;
-    // (sS was the chain's scratch if this workgroup ran it: the barrier inside sqx_stage_wait is behind its last read)
-    strict_search_part<true>(av, q, b, t, pin, sS);
-}

@@ -69,12 +69,14 @@ def shard_islands(n_total, rank, world):
     return first, count
 
 
-def _send_msg(sock, payload, key=None):
-    """Length-prefixed message; with `key` (the launch's nonce) an HMAC-SHA256 tag follows the payload."""
+def _send_msg(sock, payload, key=None, ctx=b""):
+    """Length-prefixed message; with `key` (the launch's secret) an HMAC-SHA256 tag over ctx + payload follows the
+    payload -- ctx = direction and the connection's message counter, so a message can be neither replayed nor
+    reflected."""
     if key is not None:
         import hashlib
         import hmac
-        payload = payload + hmac.new(key, payload, hashlib.sha256).digest()
+        payload = payload + hmac.new(key, ctx + payload, hashlib.sha256).digest()
     sock.sendall(struct.pack("<I", len(payload)) + payload)
 
 
@@ -88,18 +90,26 @@ def _recv_exact(sock, n):
     return bytes(buf)
 
 
-def _recv_msg(sock, key=None):
+def _recv_msg(sock, key=None, ctx=b"", maxlen=1 << 31):
     (n,) = struct.unpack("<I", _recv_exact(sock, 4))
+    if n > maxlen:                       # (the handshake's messages are tiny: nobody gets to make rank 0 buffer gigabytes)
+        raise ConnectionError("rendezvous: message of %d bytes where at most %d are expected" % (n, maxlen))
     data = _recv_exact(sock, n)
     if key is None:
         return data
-    # every message behind the handshake is authenticated with the launch's nonce (the 0600 key file): a process that
+    # every message behind the handshake is authenticated with the launch's secret (the 0600 key file): a process that
     # merely reaches the port cannot feed the ranks a pickle (allgather_obj / gather_outputs unpickle what arrives)
     import hashlib
     import hmac
-    if n < 32 or not hmac.compare_digest(hmac.new(key, data[:-32], hashlib.sha256).digest(), data[-32:]):
+    if n < 32 or not hmac.compare_digest(hmac.new(key, ctx + data[:-32], hashlib.sha256).digest(), data[-32:]):
         raise ConnectionError("rendezvous: message authentication failed")
     return data[:-32]
+
+
+def _mac(key, *parts):
+    import hashlib
+    import hmac
+    return hmac.new(key, b"|".join(parts), hashlib.sha256).hexdigest().encode()
 
 
 class _Star:
@@ -120,9 +130,12 @@ class _Star:
         self._keyfile = os.path.join(tempfile.gettempdir(), key)
         self.peers = []
         self.sock = None
-        # rank 0 draws a RANDOM nonce per launch and publishes it with its port; the peers echo what they read.
-        # The key file of a crashed earlier launch (same name: same MASTER_PORT, run id and parent) carries another
-        # nonce and a dead port: a peer that reads it is refused (or rejected by the new rank 0) and reads again
+        # rank 0 draws a RANDOM secret per launch and publishes it with its port in the 0600 key file.  The secret never
+        # crosses the socket: a peer says which rank it is, rank 0 answers with a random challenge, the peer returns
+        # HMAC(secret, rank, challenge) and gets HMAC(secret, "ok", rank, challenge) back -- both ends have then proved
+        # they read the file.  The key file of a crashed earlier launch (same name: same MASTER_PORT, run id and parent)
+        # carries another secret and a dead port: a peer that reads it is refused (or fails the challenge of the new
+        # rank 0) and reads again.  Every later message is authenticated under (direction, per-connection counter).
         nonce = None
         if rank == 0:
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
@@ -157,15 +170,20 @@ class _Star:
                     try:
                         c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                         c.settimeout(timeout)
-                        hello = _recv_msg(c).decode(errors="replace").split(" ", 1)
+                        hello = _recv_msg(c, maxlen=64).decode(errors="replace")
+                        if not hello.isdigit() or not 0 < int(hello) < world or int(hello) in conns:
+                            raise ValueError("not a rank of this launch")
+                        challenge = secrets.token_hex(16).encode()
+                        _send_msg(c, challenge)
+                        import hmac as _hmac
+                        answer = _recv_msg(c, maxlen=128)
+                        if not _hmac.compare_digest(answer, _mac(nonce.encode(), b"hello", hello.encode(), challenge)):
+                            raise ValueError("challenge failed")
+                        hello = [hello]
                     except (OSError, ConnectionError, ValueError, struct.error):
-                        c.close()                      # a half-open or garbled hello: not our business
+                        c.close()                      # a half-open or garbled hello, a stranger: not our business
                         continue
-                    if len(hello) != 2 or hello[1] != nonce or not hello[0].isdigit() \
-                            or not 0 < int(hello[0]) < world or int(hello[0]) in conns:
-                        c.close()                      # not a rank of this launch
-                        continue
-                    _send_msg(c, b"ok")
+                    _send_msg(c, _mac(nonce.encode(), b"ok", hello[0].encode(), challenge))
                     # (the rendezvous timeout ends here: the collectives that follow wait as long as the slowest
                     #  rank's work takes -- uneven shares, a first-use build on one rank)
                     c.settimeout(None)
@@ -194,10 +212,13 @@ class _Star:
                     nonce = f[2]
                     s = socket.create_connection((addr, int(f[0])), timeout=timeout)
                     s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                    _send_msg(s, ("%d %s" % (rank, nonce)).encode())
                     s.settimeout(timeout)
-                    if _recv_msg(s) != b"ok":          # (a live process that is not this launch's rank 0)
-                        raise ValueError("rejected")
+                    _send_msg(s, b"%d" % rank)
+                    challenge = _recv_msg(s, maxlen=128)
+                    _send_msg(s, _mac(nonce.encode(), b"hello", b"%d" % rank, challenge))
+                    import hmac as _hmac
+                    if not _hmac.compare_digest(_recv_msg(s, maxlen=128), _mac(nonce.encode(), b"ok", b"%d" % rank, challenge)):
+                        raise ValueError("rejected")   # (a live process that is not this launch's rank 0)
                     s.settimeout(None)
                 except (OSError, ValueError, IndexError, ConnectionError):
                     if s is not None:
@@ -210,14 +231,17 @@ class _Star:
             self._key = nonce.encode()
 
     def exchange(self, payload=b""):
+        # (one round = one message up and one down on every connection: both ends count rounds)
+        seq = struct.pack("<Q", getattr(self, "_round", 0))
+        self._round = getattr(self, "_round", 0) + 1
         if self.rank == 0:
-            parts = [payload] + [_recv_msg(c, self._key) for c in self.peers]
+            parts = [payload] + [_recv_msg(c, self._key, b"u" + seq) for c in self.peers]
             blob = b"".join(struct.pack("<I", len(p)) + p for p in parts)
             for c in self.peers:
-                _send_msg(c, blob, self._key)
+                _send_msg(c, blob, self._key, b"d" + seq)
             return parts
-        _send_msg(self.sock, payload, self._key)
-        blob = _recv_msg(self.sock, self._key)
+        _send_msg(self.sock, payload, self._key, b"u" + seq)
+        blob = _recv_msg(self.sock, self._key, b"d" + seq)
         parts, off = [], 0
         for _ in range(self.world):
             (n,) = struct.unpack_from("<I", blob, off)

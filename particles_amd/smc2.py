@@ -316,7 +316,8 @@ class SMC2:
         move); every state of every chain stays, together with its filter -- the new population is the
         concatenation [x_0, x_1, .., x_{P-1}] of M theta-particles each, as the reference builds it."""
         M, P, t = self.M, self.P, self.t
-        check(lib().smc_filter_theta_resume(self.pf._f, None))          # time records back to t
+        if getattr(self, "device_theta", True):                         # (ShardedSMC2 over the host star / group=None: the
+            check(lib().smc_filter_theta_resume(self.pf._f, None))      #  theta level is the host's) time records back to t
         ev_all = self._evidences(self.pf)
         cur = self._batch({k: v[A] for k, v in self.theta.items()}, self.Nx, whole=True)
         cur.take_islands_from(self.pf, A)                               # the resampled filters themselves

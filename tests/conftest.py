@@ -6,6 +6,12 @@ import sys
 import numpy as np
 import pytest
 
+# Nothing this suite starts may write into the read-only reference tree: test_adapter.py imports the REAL package from
+# /root/reference and drives its multiSMC through loky worker processes, which do not inherit sys.dont_write_bytecode --
+# they do inherit the environment (round 5 left a __pycache__/ there).
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+sys.dont_write_bytecode = True
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -91,3 +97,16 @@ def pytest_terminal_summary(terminalreporter):
         if ties or draws >= 1 << 20:
             tr.write_line("  %-52s %6d of %13d" % (where, ties, draws))
     tr.write_line("  TOTAL %d near-ties in %d audited ancestors (%.2e per ancestor)" % (tot_t, tot_d, tot_t / max(1, tot_d)))
+    strict = [(w, t, d) for w, t, d in pc.NEAR_TIE_LOG if w.startswith("STRICT")]
+    tr.write_line("  strict_ancestors=True (the reference's sequential fp64 CDF itself): %d differences in %d audited ancestors "
+                  "(must be 0)" % (sum(t for _, t, _ in strict), sum(d for _, _, d in strict)))
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """The reference tree is read-only by contract: no process of this suite may have left bytecode there."""
+    ref = "/root/reference"
+    if os.path.isdir(ref):
+        left = [os.path.join(d, x) for d, sub, _ in os.walk(ref) for x in sub if x == "__pycache__"]
+        if left:
+            session.exitstatus = 1
+            print("\nERROR: the suite wrote into the reference tree: %s" % left[:3])

@@ -339,7 +339,9 @@ struct hipDeviceProp_t {
     size_t totalGlobalMem;
 };
 inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
-inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return 0; }
+// (SMC_EMU_NDEV: how many devices the emulator pretends to see -- the 8-rank launch line of bench.py gives every rank
+//  its own, tests/test_distributed_cpu.py)
+inline hipError_t hipGetDeviceCount(int* n) { const char* e = getenv("SMC_EMU_NDEV"); *n = e && atoi(e) > 0 ? atoi(e) : 1; return 0; }
 inline hipError_t hipSetDevice(int) { return 0; }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     snprintf(p->name, sizeof p->name, "hipemu (CPU fibers)");

@@ -671,6 +671,16 @@ EXACT_MODELS = ("toy", "lg", "gordon")          # IEEE + - * / only: X (and boot
 NEAR_TIE_LOG = []
 
 
+# The integer two-level CDF contract and the reference's sequential fp64 CDF choose a different -- certified near-tie --
+# ancestor about 6e-8 times per ancestor (28 in 4.6e8 audited, GPUTEST r5): a run is held to 20 times that rate
+# (round 5 allowed 1e-5: a regression of two orders of magnitude would have passed), and to at least one.
+NEAR_TIE_RATE = 6e-8
+
+
+def near_tie_allowance(draws):
+    return max(1, int(20 * NEAR_TIE_RATE * draws))
+
+
 def log_near_ties(where, ties, draws):
     """Every audit records how many ancestors differed from the reference's sequential fp64 CDF
     (each one certified a near-tie) out of how many draws: the test log then holds the observed
@@ -721,7 +731,7 @@ def check_filter_replay(golden, case, model, fk, T=None, N=None):
     ties = audit_history(ph, mk_orc, fk, y, scheme, ESSrmin, z=z, u=u,
                          exact=model in EXACT_MODELS, tol=1e-11 if mv else 1e-12)
     log_near_ties("replay %s/%s N=%d T=%d %s" % (case, fk, N, len(y), scheme), ties, sum(o["rs_flag"]) * N)
-    assert ties <= max(1, len(y) * N // 100000)
+    assert ties <= near_tie_allowance(len(y) * N), ties
     if ties == 0 and not mv and len(y) > 1 and np.array_equal(pf.A, o["A"]):
         # nothing flipped anywhere: the free-running oracle IS this run
         exact = model.startswith(EXACT_MODELS)
@@ -779,12 +789,12 @@ def check_two_level_cdf(golden, monkeypatch, N=4096, T=20):
         runs = {}
         for name, env in (("two_level", {}), ("exact_counts", {"SMC_EXACT_COUNTS": "1"}),
                           ("mid", {"SMC_TWO_LEVEL_MID": "1"}), ("flat", {"SMC_FLAT_CDF": "1"}),
-                          ("narrow", {"SMC_NO_WIDE": "1"}), ("wide4", {"SMC_WIDE4": "1"})):
+                          ("narrow", {"SMC_NO_WIDE": "1"})):
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
             pf = pa.SMC(fk=ssm.Bootstrap(ssm=mk_dev(), data=y), N=N, resampling=scheme, ESSrmin=0.5,
                         replay=(z, u), store_history=(name == "two_level"))
-            if name in ("two_level", "wide4", "narrow"):         # (multinomial: k_reduce2 in front, one tile per workgroup)
+            if name in ("two_level", "narrow"):         # (multinomial: k_reduce2 in front, one tile per workgroup)
                 assert ("k_ancestors2w" in describe(pf)) == (name != "narrow" and scheme != "multinomial"), describe(pf)
             pf.run()
             runs[name] = (np.array(pf.A), np.array(pf.X), list(pf.summaries.logLts), list(pf.summaries.rs_flags))
@@ -806,8 +816,8 @@ def check_two_level_cdf(golden, monkeypatch, N=4096, T=20):
         # workgroup of k_ancestors2: the same operations in the same order, the same bits
         assert np.array_equal(A2, runs["mid"][0]) and np.array_equal(X2, runs["mid"][1])
         assert ll2 == runs["mid"][2]
-        # one tile per workgroup (k_ancestors2) / two (the default) / four (k_ancestors2w): the same bits
-        for name in ("narrow", "wide4"):
+        # one tile per workgroup (k_ancestors2) / two (the default, k_ancestors2w): the same bits
+        for name in ("narrow",):
             assert np.array_equal(A2, runs[name][0]) and np.array_equal(X2, runs[name][1]) and ll2 == runs[name][2], name
         assert rf2 == o["rs_flag"] and any(rf2)
         assert rel(ll2, o["logLt"]) < 1e-9 and rel(runs["flat"][2], o["logLt"]) < 1e-9
@@ -962,7 +972,7 @@ def check_oracle_at_size(model, mk_dev, mk_orc, N, T, scheme="systematic", ESSrm
                               island=isl, tol=1e-11 if d > 1 else 1e-12)
     log_near_ties("%s/%s N=%d T=%d %s %s" % (model, fk, N, T, scheme, "replay" if replay else "philox"), ties,
                   int(np.sum(ph._summ()[list(islands), :, 4])) * N)
-    assert ties <= max(1, len(islands) * T * N // 100000), ties
+    assert ties <= near_tie_allowance(len(islands) * T * N), ties
     pf = mk(False)
     pf.run()
     for isl in islands:
@@ -996,7 +1006,7 @@ def check_device_spacings(sizes=(2048, 3000, 1 << 14), seed=91):
                 assert su.shape == (N,) and np.all(np.diff(su) >= 0) and su[0] > 0 and su[-1] < 1
                 assert np.max(np.abs(su - want)) < 1e-13, (N, t, float(np.max(np.abs(su - want))))
             ties = audit_history(pf, lambda: orc.ToySSM(0.2), "bootstrap", y, "multinomial", 1.0, island=isl)
-            assert ties <= max(1, T * N // 100000)
+            assert ties <= near_tie_allowance(T * N), ties
     # order statistics of N uniforms: E su_n = (n + 1) / (N + 1), and a Kolmogorov distance of the size
     # 1 / sqrt(N) from the uniform law
     N = sizes[-1]
@@ -1122,30 +1132,6 @@ def check_strict_never_leaves_the_fast_path(cases, T=300):
                 assert ex.value == 0, (N, nisl, scheme, model, t, isl, ex.value, nx.value)
                 worst = max(worst, nx.value)
         assert np.all(np.isfinite(pf.logLts_islands)) and worst <= 256, (N, scheme, model, worst)
-
-
-def check_strict_one_launch_equals_two(monkeypatch, cases, T=40):
-    """k_strict_step (SMC_PATH_STRICT_ONE_LAUNCH: classify, wait for the island's chain inside the launch, search -- where
-    the whole grid is resident) against the two launches of the default path: the same run, every array."""
-    yr = np.random.RandomState(6)
-    y = [np.array([v]) for v in 0.4 * np.cumsum(yr.standard_normal(T))]
-    for N, nisl, scheme, ESSrmin, expect_one in cases:
-        runs = []
-        for one in (False, True):
-            if one:
-                monkeypatch.setenv("SMC_STRICT_ONE_LAUNCH", "1")
-            pf = pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y), N=N, resampling=scheme, ESSrmin=ESSrmin, seed=31,
-                        strict_ancestors=True, collect="off", n_islands=nisl)
-            if one:
-                monkeypatch.delenv("SMC_STRICT_ONE_LAUNCH")
-            on_gpu = b"EMULATOR" not in _lib.lib().smc_version()       # (the emulator runs one workgroup at a time: two launches)
-            assert ("k_strict_step" in describe(pf)) == (expect_one and one and on_gpu), (N, nisl, describe(pf))
-            pf.step_async(T // 2)
-            pf.run()
-            runs.append((np.array(pf.X), np.array(pf.A), pf.logLts_islands.copy(), pf._summ()[:, :, 4].copy()))
-        assert runs[0][3][:, 1:].sum() >= 2
-        for a, b in zip(runs[0], runs[1]):
-            assert np.array_equal(a, b), (N, nisl, scheme)
 
 
 def check_seq_prefix_sums(sizes=(5000, 1 << 14, 20001), monkeypatch=None):
@@ -3036,7 +3022,17 @@ def check_pickle_resume(sizes=(700, 3000)):
         for _ in range(4):
             next(pf)
         state = np.random.get_state()
-        q = pickle.loads(pickle.dumps(pf))
+        ctr = _lib._counter
+        blob = pickle.dumps(pf)
+        # (unpickling neither moves the receiving process's point-set counter nor reads its environment: the filter is
+        #  re-created under the verification switches it was created with -- ADVICE r5)
+        os.environ["SMC_TWO_LEVEL_MID"] = "1"
+        try:
+            q = pickle.loads(blob)
+        finally:
+            del os.environ["SMC_TWO_LEVEL_MID"]
+        assert _lib._counter == ctr
+        assert not getattr(pf, "_fused", False) or describe(q) == describe(pf)
         assert q is not pf and q.t == pf.t == 4
         outs = []
         for r in (pf, q):

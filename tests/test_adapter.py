@@ -350,6 +350,29 @@ def test_device_smc2_finalises_once_and_declines_what_it_cannot_batch(ref):
     ymv = [np.zeros((1, 2)) for _ in range(4)]
     fk_mv = ssp.SMC2(ssm_cls=rk.MVLinearGauss_Guarniero_etal, prior=prior_mv, data=ymv, init_Nx=16, wastefree=False)
     assert adapter.adapt_smc2(fk_mv) is None
+    # a model whose per-step term depends on a parameter the prior varies (Gordon_etal's d cos(e (t - 1)),
+    # state_space_models.py:531-556, with `e` in the prior) cannot be batched as islands: the adapter says so on two
+    # probe draws and the reference's loop runs it -- it used to pass a one-draw probe and then fail when the batch
+    # was built
+    rssm = ref["ssm"] if "ssm" in ref else __import__("particles.state_space_models", fromlist=["x"])
+    yg = [np.array([v]) for v in np.random.RandomState(1).standard_normal(6)]
+    prior_g = dists.StructDist({"e": dists.Uniform(a=1.0, b=1.4), "sigmaX": dists.Gamma(a=2.0, b=1.0)})
+    fk_g = ssp.SMC2(ssm_cls=rssm.Gordon_etal, prior=prior_g, data=yg, init_Nx=16, len_chain=3, wastefree=False)
+    assert adapter.adapt_smc2(fk_g) is None
+    alg_g = HipSMC(fk=fk_g, N=6)
+    assert isinstance(alg_g, particles.SMC) and not isinstance(alg_g, adapter.DeviceSMC2Run)
+    prior_ok = dists.StructDist({"sigmaX": dists.Gamma(a=2.0, b=1.0)})              # (a parameter of the dynamics' scale only)
+    assert adapter.adapt_smc2(ssp.SMC2(ssm_cls=rssm.Gordon_etal, prior=prior_ok, data=yg, init_Nx=16, len_chain=3,
+                                       wastefree=False)) is not None
+    # should the full batch be refused all the same, the run falls back to the reference's loop on an untouched stream
+    import unittest.mock as um
+    with um.patch.object(adapter, "DeviceSMC2Run", side_effect=ValueError("refused")):
+        np.random.seed(5)
+        fb = HipSMC(fk=mk(), N=8)
+        assert isinstance(fb, particles.SMC)
+        after = np.random.rand()
+        np.random.seed(5)
+        assert np.random.rand() == after
     # (c)
     np.random.seed(77)
     adapter.adapt_smc2(mk())

@@ -99,6 +99,32 @@ def _run_world(world, tmp_path, gloo=False, migrate=False, **env_extra):
     return json.loads(line[7:])
 
 
+def test_rendezvous_messages_are_bound_to_direction_and_counter():
+    """The host star's messages carry HMAC(secret, direction + round counter + payload): a recorded message is refused
+    in another round (replay) and in the other direction (reflection); a length prefix beyond what the handshake
+    expects is refused before anything is buffered; the handshake proves knowledge of the secret on both sides
+    (challenge-response: the secret itself never crosses the socket) -- ADVICE r5."""
+    import socket
+    import struct
+    from particles_amd import distributed as D
+    a, b = socket.socketpair()
+    key = b"secret-of-the-launch"
+    seq0, seq1 = struct.pack("<Q", 0), struct.pack("<Q", 1)
+    D._send_msg(a, b"payload", key, b"u" + seq0)
+    assert D._recv_msg(b, key, b"u" + seq0) == b"payload"
+    for ctx in (b"u" + seq1, b"d" + seq0):            # replayed into the next round; reflected back at the sender
+        D._send_msg(a, b"payload", key, b"u" + seq0)
+        with pytest.raises(ConnectionError, match="authentication"):
+            D._recv_msg(b, key, ctx)
+    a.sendall(struct.pack("<I", 1 << 30))             # "a hello of a gigabyte"
+    with pytest.raises(ConnectionError, match="at most 64"):
+        D._recv_msg(b, maxlen=64)
+    assert D._mac(key, b"hello", b"1", b"c") != D._mac(key, b"ok", b"1", b"c")
+    assert D._mac(key, b"hello", b"1", b"c") != D._mac(b"other", b"hello", b"1", b"c")
+    a.close()
+    b.close()
+
+
 def test_shard_islands_partition():
     from particles_amd.distributed import shard_islands
     for total in (1, 5, 8, 256):
@@ -446,6 +472,33 @@ def test_bench_two_ranks_launch_line(tmp_path):
     m = d5["multiSMC"]
     assert m["nruns"] == 6 and m["distinct_runs"] == 6 and m["value"] > 0 and "multiSMC(nruns=6" in m["call"]
     assert m["evidence_gather"].startswith("host-fallback") and d5["config"]["islands_per_gpu"] == 3
+
+
+def test_bench_eight_rank_c5_line_through_the_rccl_double(tmp_path, has_gpu):
+    """BASELINE config C5 as the driver launches it on an 8-GPU node -- `bench.py --gpus 8 --workload c5`: 8 ranks, one
+    device each, 32 islands per rank, the log-evidences gathered by the library's RCCL all-gather -- on the emulator
+    (8 pretended devices) with tests/emu/fake_rccl.c standing in for RCCL: the line says rccl: true, names 8 distinct
+    devices, and its multiSMC block holds 256 distinct runs (the 8-GPU line is ready, unmeasured)."""
+    import json
+    if has_gpu:
+        pytest.skip("the test double stands in for RCCL on GPU-less boxes")
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    env = dict(os.environ, SMC_TEST_EMULATOR="1", SMC_HIP_LIBRARY=build_emu.build(), SMC_EMU_NDEV="8", **_fake_rccl_env(tmp_path))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "SMC_ALLOW_HOST_GATHER", "SMC_BENCH_NGPU"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--workload", "c5", "--log2N", "10", "--steps", "2",
+           "--warmup", "1", "--reps", "1", "--no-cpu-baseline", "--no-profile"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200, cwd=str(tmp_path))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["rccl"] is True and d["evidence_gather"] == "rccl" and d["scaling"] == "weak"
+    assert len(d["rank_devices"]) == 8 and len(set(d["rank_devices"])) == 8
+    assert d["config"]["islands_per_gpu"] == 32 and d["value"] > 0
+    m = d["multiSMC"]
+    assert m["nruns"] == 256 and m["distinct_runs"] == 256 and m["evidence_gather"] == "rccl" and np.isfinite(m["log_mean_exp_evidence"])
 
 
 def test_bench_spawns_its_own_ranks(tmp_path):

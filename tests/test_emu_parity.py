@@ -318,10 +318,6 @@ def test_strict_ancestors_heavy_parents():
                                   T=5, ESSrmin=1.0, replays=(False,))
 
 
-def test_strict_one_launch_switch(monkeypatch):
-    pc.check_strict_one_launch_equals_two(monkeypatch, [(3000, 2, "systematic", 0.5, True)], T=12)
-
-
 def test_strict_verifies_every_step():
     pc.check_strict_never_leaves_the_fast_path([(3000, 4, "systematic", "toy", 0.5), (2500, 2, "multinomial", "sv", 1.0)], T=70)
 
@@ -352,6 +348,22 @@ def test_device_sort():
 
 def test_smc2_device_theta_level():
     pc.check_smc2(Ntheta=32, Nx=64, big_Nx=(2048,), big_N=4, big_T=6)
+
+
+def test_sharded_smc2_without_a_group_runs_the_wastefree_move():
+    """ShardedSMC2(group=None, wastefree=True): the theta level is the host's (no device collective), and the base class's
+    waste-free move must not ask the device theta level to resume (it did, and failed at the first move)."""
+    from particles_amd import kalman, smc2
+    rng = np.random.RandomState(4)
+    x = np.cumsum(rng.standard_normal(10))
+    y = [np.array([v]) for v in x + 0.3 * rng.standard_normal(10)]
+    kw = dict(ssm_cls=lambda sigmaY: kalman.LinearGauss(rho=1.0, sigmaX=1.0, sigmaY=sigmaY, sigma0=1.0),
+              prior=smc2.IndepPrior(sigmaY=("lognormal", np.log(0.8), 1.2)), data=y, init_Nx=64, N=6, seed=5, ESSrmin=0.9,
+              wastefree=True, len_chain=2)
+    alg = smc2.ShardedSMC2(group=None, **kw)
+    assert not alg.device_theta
+    alg.run()
+    assert len(alg.move_times) >= 1 and np.isfinite(alg.logLt) and len(alg.theta["sigmaY"]) == 12
 
 
 def test_smc2_wastefree_move():

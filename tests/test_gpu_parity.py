@@ -561,12 +561,6 @@ def test_strict_verifies_every_step():
          (1 << 21, 1, "multinomial", "peaky", 1.0)], T=40)
 
 
-def test_strict_one_launch_equals_two(monkeypatch):
-    pc.check_strict_one_launch_equals_two(monkeypatch, [
-        (1 << 20, 1, "systematic", 0.5, True), ((1 << 18) + 77, 2, "stratified", 1.0, True), (1 << 18, 3, "multinomial", 0.7, True),
-        (5000, 4, "systematic", 0.5, True), (1 << 22, 1, "systematic", 1.0, False), (1 << 20, 2, "systematic", 0.5, False)])
-
-
 def test_models_without_a_fused_descriptor(golden):
     pc.check_models_without_descriptor(golden)
 

@@ -21,7 +21,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 
 
 def run(env, mk, y, N, M, scheme, essr, seed):
-    for k in ("SMC_EXACT_COUNTS", "SMC_TWO_LEVEL_MID", "SMC_FLAT_CDF", "SMC_NO_HEAVY", "SMC_SPLIT_REDUCE", "SMC_SPACING_3PASS", "SMC_NO_WIDE", "SMC_WIDE4", "SMC_NO_XCD_CHUNKS"):
+    for k in ("SMC_EXACT_COUNTS", "SMC_TWO_LEVEL_MID", "SMC_FLAT_CDF", "SMC_NO_HEAVY", "SMC_SPLIT_REDUCE", "SMC_SPACING_3PASS", "SMC_NO_WIDE", "SMC_NO_XCD_CHUNKS"):
         os.environ.pop(k, None)
     os.environ.update(env)
     pf = pa.SMC(fk=ssm.Bootstrap(ssm=mk(), data=y), N=N, n_islands=M, resampling=scheme, ESSrmin=essr,
@@ -49,7 +49,7 @@ for c in range(ncases):
     y = [np.array([v]) for v in np.cumsum(rng.standard_normal(T)) * (0.3 if which == 2 else 1.0)]
     seed = int(rng.integers(1, 1 << 30))
     base = run({}, mk, y, N, M, scheme, essr, seed)
-    envs = [{"SMC_EXACT_COUNTS": "1"}, {"SMC_TWO_LEVEL_MID": "1"}, {"SMC_NO_HEAVY": "1"}, {"SMC_NO_WIDE": "1"}, {"SMC_WIDE4": "1"}, {"SMC_NO_XCD_CHUNKS": "1"}]
+    envs = [{"SMC_EXACT_COUNTS": "1"}, {"SMC_TWO_LEVEL_MID": "1"}, {"SMC_NO_HEAVY": "1"}, {"SMC_NO_WIDE": "1"}, {"SMC_NO_XCD_CHUNKS": "1"}]
     if scheme == "multinomial":             # the island's reduction as a launch of its own; uniform_spacings in three passes
         envs += [{"SMC_SPLIT_REDUCE": "1"}, {"SMC_SPACING_3PASS": "1"}]
     for env in envs:
@@ -72,7 +72,7 @@ print("ok: %d cases, %d with a near-tie difference to the flat path, %.1f s" % (
 # ---- SQMC: the fused loop against the operator path on the same points (random sizes, models, islands off)
 from particles_amd import _lib, resampling as rs                      # noqa: E402
 nsq = max(4, ncases // 8)
-for k in ("SMC_EXACT_COUNTS", "SMC_TWO_LEVEL_MID", "SMC_FLAT_CDF", "SMC_NO_HEAVY", "SMC_SPLIT_REDUCE", "SMC_SPACING_3PASS", "SMC_NO_WIDE", "SMC_WIDE4", "SMC_NO_XCD_CHUNKS"):
+for k in ("SMC_EXACT_COUNTS", "SMC_TWO_LEVEL_MID", "SMC_FLAT_CDF", "SMC_NO_HEAVY", "SMC_SPLIT_REDUCE", "SMC_SPACING_3PASS", "SMC_NO_WIDE", "SMC_NO_XCD_CHUNKS"):
     os.environ.pop(k, None)
 rs.set_rng("philox")
 ties = 0

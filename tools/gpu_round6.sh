@@ -80,6 +80,10 @@ spacing)
     python tools/trace_spacing.py 22 > $O/${TAG}_trace_spacing.txt 2>&1; cat $O/${TAG}_trace_spacing.txt
     python tools/trace_step.py 22 multinomial sv > $O/${TAG}_trace_c3_multinomial.txt 2>&1; head -12 $O/${TAG}_trace_c3_multinomial.txt
     ;;
+sort)   # the radix sort: correctness fuzz, timings, the SQMC leg
+    timeout 900 python tools/sort_fuzz.py ${2:-120} > $O/${TAG}_sort_fuzz.txt 2>&1; tail -3 $O/${TAG}_sort_fuzz.txt
+    timeout 600 python tools/sort_perf.py > $O/${TAG}_sort_perf.txt 2>&1; cat $O/${TAG}_sort_perf.txt
+    ;;
 floor)  # in-kernel timelines + the step's floor breakdown (needs particles_amd/lib/abl/libsmc_TRACE.so)
     (python tools/trace_step.py 20; python tools/trace_step.py 14; python tools/trace_step.py 22 systematic sv) > $O/${TAG}_c2_floor.txt 2>&1; cat $O/${TAG}_c2_floor.txt
     ;;

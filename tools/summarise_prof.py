@@ -110,5 +110,11 @@ if traffic:
             rec["summary"] = _a.summary
         if _a.command:
             rec["command"] = _a.command
+        # which tree the record is of: the commit the caller names (SMC_TREE_STAMP: `git rev-parse --short HEAD` plus
+        # "-dirty" -- the GPU box has no .git) and a hash of the device sources, which bench.py / the tests recompute
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from source_hash import source_hash
+        rec["source_hash"] = source_hash()
+        rec["tree"] = os.environ.get("SMC_TREE_STAMP", "unknown")
         json.dump(rec, fh, indent=1)
     print("== traffic.json:", json.dumps(res))

@@ -33,7 +33,7 @@ lib = _lib.lib()
 lib.smc_debug_trace.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 _lib.check(lib.smc_debug_trace(pf._f, buf.ctypes.data_as(ctypes.c_void_p)))
 wide = two_level_wide = log2N <= 20 and scheme != "multinomial" and not os.environ.get("SMC_NO_WIDE")
-two_level = not (os.environ.get("SMC_FLAT_CDF") or os.environ.get("SMC_FORCE_FUSED"))
+two_level = not os.environ.get("SMC_FLAT_CDF")
 for name, st, labels in (
         ("k_ancestors2" if two_level else "k_ancestors<true>", buf[nparts * 8:].reshape(ntiles, 8),
          ["start", "t + loads", "local cdf", "partials reduced", "tile shares", "counts", "end"] if two_level
