@@ -1023,8 +1023,6 @@ int smc_filter_load_state(smc_filter* f, const void* in_host, int64_t nbytes)
     f->a.seed = h.seed; f->sp_epoch = h.sp_epoch; f->sq_seed = h.sq_seed; f->sq_ctr0 = h.sq_ctr0;
     f->flush_pending = h.flush_pending != 0;
     f->a.island_offset = h.island_offset;
-    if (f->strict && !f->strict_literal)   // (k_strict_step's epoch word counted the OTHER filter's launches)
-        sqx_zero_done(f->ctx->stream, (void*)(f->strict_ws + 2 * (size_t)f->a.n_islands * f->a.N), f->a.N, f->a.n_islands);
     for (hipGraphExec_t& g : f->gexec)          // captured launches carry the old key / counters by value
         if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
     return SMC_OK;

@@ -44,10 +44,9 @@ struct SqxSrcFilter {
     }
 };
 
-// FUSED (k_strict_step): the roundings' prefixes stay in pin_keep, the chain's results go out for the other workgroups of
-// the same launch.  Returns whether step t resamples (the same answer in every workgroup of the island); t_out = t.
-template <bool MID, bool FUSED>
-__device__ __forceinline__ bool strict_classify_part(const FArgs& a, const SqxArgs& q, u64* pin_keep, int& b_out, i64& t_out, u64* lds8k)
+// Returns whether step t resamples (the same answer in every workgroup of the island); t_out = t.
+template <bool MID>
+__device__ __forceinline__ bool strict_classify_part(const FArgs& a, const SqxArgs& q, int& b_out, i64& t_out, u64* lds8k)
 {
     __shared__ double s_max[SMC_NWAVE];
     __shared__ double s_esc[SMC_NWAVE];
@@ -189,9 +188,9 @@ __device__ __forceinline__ bool strict_classify_part(const FArgs& a, const SqxAr
     for (int w = 0; w < SMC_NWAVE; ++w) ebase += (w < wave) ? s_esc[w] : 0.0;
     const double run0 = before + ldexp(ebase + eexc, (int)dsc) * rs;
     SQX_STAMP(q, b, 1);
-    const bool last = sqx_classify_tile(w4, run0, isl, b, q, FUSED ? pin_keep : nullptr);
+    const bool last = sqx_classify_tile(w4, run0, isl, b, q);
     if (!MID && b == 0 && tid == 0) f2_write_record(a, isl, t, rec, true, rin);
-    if (last) sqx_chain<SqxSrcFilter, FUSED>(src, isl, q, lds8k);
+    if (last) sqx_chain<SqxSrcFilter>(src, isl, q, lds8k);
     return true;
 }
 template <bool MID>
@@ -201,24 +200,21 @@ k_strict_classify(const FArgs av, const SqxArgs q)
     __shared__ u64 c_Pt[SEQ_TILE];
     int b;
     i64 t;
-    (void)strict_classify_part<MID, false>(av, q, nullptr, b, t, c_Pt);
+    (void)strict_classify_part<MID>(av, q, b, t, c_Pt);
 }
 
-// FUSED: the step resamples and t is known (t_in); the chain's results are another workgroup's stores of this launch.
-template <bool FUSED>
-__device__ __forceinline__ void strict_search_part(const FArgs& a, const SqxArgs& q, const int b, const i64 t_in, const u64* pin_keep, double* sS)
+__device__ __forceinline__ void strict_search_part(const FArgs& a, const SqxArgs& q, const int b, double* sS)
 {
     const int isl = (int)blockIdx.y;
     SQX_STAMP(q, q.ntiles + 8 + b, 0);
     const double* info = a.info + (i64)isl * INFO_STRIDE;
     // every load of the common path in one go: the record, what the tile's sums are staged from, the spacings' total
-    const double r0 = FUSED ? 0.0 : smc_ldg(info), r1 = FUSED ? 1.0 : smc_ldg(info + 1);
-    SqxStage ld;
-    if (!FUSED) ld = sqx_stage_load(q, isl, b);
+    const double r0 = smc_ldg(info), r1 = smc_ldg(info + 1);
+    const SqxStage ld = sqx_stage_load(q, isl, b);
     const bool zform = a.scheme == SMC_MULTINOMIAL_ && !a.ut && a.sp_tpw;
     const u64 zall = zform ? smc_ldg(a.E + (i64)isl * (a.ntiles1 + 1) + a.ntiles1) : 0ull;
-    const i64 t = FUSED ? t_in : (i64)smc_uniform(r0);
-    if (!FUSED && (t >= a.T || t == 0 || smc_uniform(r1) == 0.0)) return;
+    const i64 t = (i64)smc_uniform(r0);
+    if (t >= a.T || t == 0 || smc_uniform(r1) == 0.0) return;
     SmcSu su;
     u64 Us;
     f2_su(a, isl, t, su, Us);
@@ -231,8 +227,7 @@ __device__ __forceinline__ void strict_search_part(const FArgs& a, const SqxArgs
         if (b < a.sp_nwg && threadIdx.x == 0) a.sst[(i64)isl * a.sp_nwg + b] = 0ull;
     }
     SQX_STAMP(q, q.ntiles + 8 + b, 1);
-    if (FUSED) ld = sqx_stage_wait(q, isl, b, pin_keep);      // (everything that does not need the chain is done: now wait for it)
-    const double S_start = sqx_stage_tile<FUSED>(q, isl, b, ld, sS);
+    const double S_start = sqx_stage_tile(q, isl, b, ld, sS);
     SQX_STAMP(q, q.ntiles + 8 + b, 2);
     sqx_search_tile<u32>(q, b, su, sS, S_start, f_A(a, t) + (i64)isl * a.N);
 }
@@ -240,5 +235,5 @@ __global__ void __launch_bounds__(SMC_BLOCK)
 k_strict_search(const FArgs av, const SqxArgs q)
 {
     __shared__ double sS[SEQ_TILE];
-    strict_search_part<false>(av, q, (int)blockIdx.x, 0, nullptr, sS);
+    strict_search_part(av, q, (int)blockIdx.x, sS);
 }

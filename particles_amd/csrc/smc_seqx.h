@@ -32,10 +32,6 @@
 //     su_n <= S_j, the reference's strict `>` advance.  S never exists in HBM.  (k_sqx_fill writes it, for
 //     smc_seq_prefix_sums and the tests.)
 //
-//   (one launch, k_strict_step in smc_filter_strict.h, behind SMC_PATH_STRICT_ONE_LAUNCH: the workgroups of launch 1 stay,
-//    wait for the chain and do launch 2's work on their own tile -- what the chain then publishes are tagged 32-bit words,
-//    sqx_put / sqx_stage_wait below.  Measured equal to the two launches; see smc_filter.hip for why it is off.)
-//
 // Two things about this hardware that shaped the code: (1) vmcnt counts STORES as well as loads and retires in order --
 // the next wait for ANY load (or an explicit drain) also waits for every store issued before it, and a store that has to
 // reach memory (agent scope: the tiles' reports, the fused launch's words) takes about a microsecond to do so; such
@@ -50,7 +46,12 @@
 #pragma once
 #include "smc_seqsum.h"
 
-#define SQX_CAP 256                    /* exceptions per island the walk takes (6 KB of LDS): a few dozen occur */
+#define SQX_CAP 256                    /* exceptions per island the walk takes (8 KB of LDS in the chain's workgroup): a few dozen occur.
+                                          (Round 6 tried 1024 -- four slots per thread of the chain: a likelihood over SORTED states
+                                          rises through hundreds of binades -- and took it back: the classify kernel went from 4 to 3
+                                          waves per SIMD, 37.3 -> 39.8 us per C2 step, and that shape's exceptions grow with N, every
+                                          element of the rising flank being one: at 2^16 they overflow 1024 as well.) */
+#define SQX_XPT (SQX_CAP / SMC_BLOCK)  /* exception slots per thread of the chain */
 #define SQX_TCAP 254                   /* ... per tile */
 #define SQX_CNT_STRIDE 16
 #define SQX_CNT_WORDS (34 * SQX_CNT_STRIDE)
@@ -64,17 +65,12 @@ struct SqxArgs {
     u64* hseg;                         // (islands, ntiles) head segment: max lower bound | min upper bound << 16
     u64* Pt;                           // (islands, ntiles + 1) exclusive prefix of Rt, [ntiles] = total
     u64* xraw;                         // (islands, SQX_CAP, 4) exceptions as the tiles append them
-    u64* xs;                           // (islands, SQX_CAP, 8) sorted: index, S bits, Pin | the same as five tagged words (fused launch)
-    u64* hdr;                          // (islands, 3, ntiles) fused launch: the tiles' headers as three arrays of tagged words
+    u64* xs;                           // (islands, SQX_CAP, 8) sorted: index, S bits, Pin
     int* xfirst;                       // (islands, ntiles + 1) first sorted exception at or behind each tile's start
     int* hE;                           // (islands, ntiles) header: biased exponent ...
     u64* hI;                           // ... and integer (implicit bit included) of the sum in front of the tile
     u64* ctr;                          // (islands, 4) exceptions appended | overflow | mode of the last run | its exceptions
     unsigned* tick;                    // (islands, SQX_CNT_WORDS) completion tickets
-    u64* done;                         // (2, islands) fused launch: - | workgroups that gave up waiting
-    int poll;                          // fused launch: the pause between two looks of a waiting workgroup, in units of ~0.1 us
-    u64 epoch;                         // fused launch: this launch's number; its low 32 bits (never 0) tag every word the chain
-                                       // publishes for the waiting workgroups, so that a word is either this launch's or ignored
     double* Sfull;                     // (islands, n) the exact path's sums (mode 1)
     u64* trace;                        // SMC_TRACE builds: (2 ntiles + 8, 8) shader-clock stamps (rows: classify per tile,
                                        // 8 rows of the chain, search per tile), else null
@@ -105,23 +101,11 @@ static inline SqxArgs sqx_carve(void* scratch, const i64 n, const int islands, s
     if (counters_at) *counters_at = (size_t)(p - (char*)scratch);
     q.ctr = (u64*)p; p += M * 4 * 8;
     q.tick = (unsigned*)p; p += M * SQX_CNT_WORDS * 4;
-    q.done = (u64*)p; p += 2 * M * 8;
-    q.epoch = 0ull;
-    q.poll = 4;
-    if (counters_bytes) *counters_bytes = M * (4 * 8 + SQX_CNT_WORDS * 4 + 2 * 8);
-    q.hdr = (u64*)p; p += M * nt * 32;
+    if (counters_bytes) *counters_bytes = M * (4 * 8 + SQX_CNT_WORDS * 4);
     q.xfirst = (int*)p; p += M * (nt + 1) * 4;
     q.hE = (int*)p; p += M * nt * 4;
     if (bytes) *bytes = (size_t)(p - (char*)scratch) + 64;
     return q;
-}
-// (a filter restored from another's state: the tags in it count the OTHER filter's launches)
-static inline void sqx_zero_done(hipStream_t st, void* scratch, const i64 n, const int islands)
-{
-    const SqxArgs q = sqx_carve(scratch, n, islands);
-    (void)hipMemsetAsync((void*)q.done, 0, (size_t)islands * 16, st);
-    (void)hipMemsetAsync((void*)q.hdr, 0, (size_t)islands * q.ntiles * 32, st);
-    (void)hipMemsetAsync((void*)q.xs, 0, (size_t)islands * SQX_CAP * 64, st);
 }
 
 // (the counters -- ctr, tick: one contiguous block -- must be zero before the first launch; the passes re-arm them)
@@ -136,7 +120,6 @@ static inline void sqx_zero_counters(hipStream_t st, void* scratch, const i64 n,
     size_t at = 0, nb = 0;
     (void)sqx_carve(scratch, n, islands, nullptr, &at, &nb);
     (void)hipMemsetAsync((char*)scratch + at, 0, nb, st);
-    sqx_zero_done(st, scratch, n, islands);
 }
 // ---- where the weights come from --------------------------------------------------------------------------------
 // an array (the stand-alone operators)
@@ -194,28 +177,12 @@ __device__ __forceinline__ bool sqx_last_block(unsigned* cnt, const int b, const
     return *s_flag != 0;
 }
 
-// ---- one launch instead of two (k_strict_step, smc_filter_strict.h) ------------------------------------------------
-// XWG: what the chain writes is read by OTHER workgroups of the SAME launch.  A kernel boundary writes every L2 back and
-// invalidates it; inside a launch the eight XCDs' L2s are not coherent with each other for plain accesses, so these words
-// go out with agent-scope (write-through) stores and come in with agent-scope loads, as the tiles' reports to the chain
-// always did.
-#ifdef SMC_EMULATE
-__device__ __forceinline__ void sqx_release_all() {}
-#else
-__device__ __forceinline__ void sqx_release_all() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }   // (the exact path's S: plain stores)
-#endif
-
-// a word of the chain for the waiting workgroups: 32 bits of payload under the launch's tag -- it needs no ordering with
-// any other store, a reader takes it when the tag is this launch's and looks again otherwise
-__device__ __forceinline__ void sqx_put(u64* p, const u64 epoch, const u32 v) { smc_st_agent(p, (epoch << 32) | (u64)v); }
-__device__ __forceinline__ bool sqx_mine(const u64 w, const u64 epoch) { return (u32)(w >> 32) == (u32)epoch; }
 
 // ---- launch 1, per tile ------------------------------------------------------------------------------------------
 // w: this thread's weights 4 tid .. 4 tid + 3 of tile b (0 beyond n); run0: the estimate of the running sum in front of
 // the thread's first element.  Takes the workgroup's completion ticket (the Pin stores -- read by the next launch only --
 // are issued behind it, so that the ticket does not wait for them) and returns whether this workgroup is the island's last.
-__device__ __forceinline__ bool sqx_classify_tile(const double (&w)[4], const double run0, const int isl, const int b, const SqxArgs& q,
-                                                  u64* pin_keep = nullptr)    // (fused launch: Pin stays in the thread's registers)
+__device__ __forceinline__ bool sqx_classify_tile(const double (&w)[4], const double run0, const int isl, const int b, const SqxArgs& q)
 {
     __shared__ int s_flag;
     __shared__ u64 smu[SMC_NWAVE];
@@ -362,13 +329,8 @@ __device__ __forceinline__ bool sqx_classify_tile(const double (&w)[4], const do
         __syncthreads();
     }
     const bool last = sqx_last_block(q.tick + (i64)isl * SQX_CNT_WORDS, b, q.ntiles, &s_flag);
-    if (pin_keep) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) pin_keep[k] = Pin[k];
-    } else {
-        smc_st2g(q.Pin + (i64)isl * q.ntiles * SEQ_TILE + i0, Pin[0], Pin[1]);
-        smc_st2g(q.Pin + (i64)isl * q.ntiles * SEQ_TILE + i0 + 2, Pin[2], Pin[3]);
-    }
+    smc_st2g(q.Pin + (i64)isl * q.ntiles * SEQ_TILE + i0, Pin[0], Pin[1]);
+    smc_st2g(q.Pin + (i64)isl * q.ntiles * SEQ_TILE + i0 + 2, Pin[2], Pin[3]);
     SQX_STAMP(q, b, 5);
     return last;
 }
@@ -378,7 +340,7 @@ __device__ __forceinline__ bool sqx_classify_tile(const double (&w)[4], const do
 // up front (the counters, the first 1024 tiles' totals and head intervals, every slot of the exception list), so that the
 // whole function pays about three memory latencies; the walk reads (dP, W) pairs from LDS, branch-free.
 // c_Pt: 8 KB of LDS the caller can spare during the chain (the first 1024 tiles' offsets; larger islands keep the rest in memory)
-template <class Src, bool XWG = false>
+template <class Src>
 __device__ __forceinline__ void sqx_chain(const Src& src, const int isl, const SqxArgs& q, u64* c_Pt)
 {
     __shared__ u32 c_j[SQX_CAP];
@@ -390,15 +352,20 @@ __device__ __forceinline__ void sqx_chain(const Src& src, const int isl, const S
     __shared__ int c_ok, s_idx;                                // c_ok: 1, or 0 with c_why saying which assumption failed
     __shared__ unsigned c_why;
     __shared__ double s_tmp;
-    static_assert(SQX_CAP == SMC_BLOCK, "one exception slot per thread");
+    static_assert(SQX_CAP % SMC_BLOCK == 0, "whole exception slots per thread");
     const int tid = (int)threadIdx.x, ntiles = q.ntiles;
     u64* ctr = q.ctr + (i64)isl * 4;
     u64* Pt = q.Pt + (i64)isl * (ntiles + 1);
     SQX_STAMP(q, ntiles, 0);
     // ---- every independent load, at once
     const u64 cnt64 = smc_ld_agent(ctr), ovf = smc_ld_agent(ctr + 1);
-    const u64* ex = q.xraw + ((i64)isl * SQX_CAP + tid) * 4;
-    const u64 e0 = smc_ld_agent(ex), e1 = smc_ld_agent(ex + 1), e2 = smc_ld_agent(ex + 2), e3 = smc_ld_agent(ex + 3);
+    // (slot x of thread tid: exception x 256 + tid of the unsorted list; slot 0 -- all there is, as a rule -- requested
+    //  here with everything else, the others when the count says there are any)
+    u64 e0[SQX_XPT], e1[SQX_XPT], e2[SQX_XPT], e3[SQX_XPT];
+    {
+        const u64* ex = q.xraw + ((i64)isl * SQX_CAP + tid) * 4;
+        e0[0] = smc_ld_agent(ex); e1[0] = smc_ld_agent(ex + 1); e2[0] = smc_ld_agent(ex + 2); e3[0] = smc_ld_agent(ex + 3);
+    }
     u64 rt0[4], hs0[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -413,6 +380,14 @@ __device__ __forceinline__ void sqx_chain(const Src& src, const int isl, const S
     bool slow = ovf != 0ull || cnt64 > (u64)SQX_CAP;
     if (slow && tid == 0) c_why = 1u;                          // more exceptions than the lists hold
     const int cnt = slow ? 0 : (int)cnt64;
+#pragma unroll
+    for (int x = 1; x < SQX_XPT; ++x) {
+        e0[x] = e1[x] = e2[x] = e3[x] = 0ull;
+        if (x * SMC_BLOCK + tid < cnt) {
+            const u64* ex = q.xraw + ((i64)isl * SQX_CAP + x * SMC_BLOCK + tid) * 4;
+            e0[x] = smc_ld_agent(ex); e1[x] = smc_ld_agent(ex + 1); e2[x] = smc_ld_agent(ex + 2); e3[x] = smc_ld_agent(ex + 3);
+        }
+    }
     if (!slow) {
         // ---- P offsets of the tiles: thread tid owns tiles 4 tid .. 4 tid + 3 of every chunk of 1024
         u64 carry = 0ull;
@@ -437,25 +412,34 @@ __device__ __forceinline__ void sqx_chain(const Src& src, const int isl, const S
         }
         SQX_STAMP(q, ntiles, 2);
         // ---- the exceptions in order of index (rank by counting: a few dozen of them)
-        if (tid < cnt) c_j[tid] = (u32)e0;
+#pragma unroll
+        for (int x = 0; x < SQX_XPT; ++x)
+            if (x * SMC_BLOCK + tid < cnt) c_j[x * SMC_BLOCK + tid] = (u32)e0[x];
         __syncthreads();                                       // (c_j complete; Pt visible to the workgroup)
-        int rank = 0;
-        u64 Pg = 0ull;
-        if (tid < cnt) {
-            const int xb = (int)(e0 >> 10);
-            Pg = e1 + (xb < 4 * SMC_BLOCK ? c_Pt[xb] : Pt[xb]);
-            const u32 mine = (u32)e0;
-            for (int m = 0; m < cnt; ++m) rank += c_j[m] < mine ? 1 : 0;
+        int rank[SQX_XPT];
+        u64 Pg[SQX_XPT];
+#pragma unroll
+        for (int x = 0; x < SQX_XPT; ++x) {
+            rank[x] = 0;
+            Pg[x] = 0ull;
+            if (x * SMC_BLOCK + tid < cnt) {
+                const int xb = (int)(e0[x] >> 10);
+                Pg[x] = e1[x] + (xb < 4 * SMC_BLOCK ? c_Pt[xb] : Pt[xb]);
+                const u32 mine = (u32)e0[x];
+                for (int m = 0; m < cnt; ++m) rank[x] += c_j[m] < mine ? 1 : 0;
+            }
         }
         __syncthreads();
-        if (tid < cnt) {
-            c_j[rank] = (u32)e0;
-            c_P[rank] = Pg;
-            c_w[rank] = __longlong_as_double((long long)e2);
-            c_acc[rank] = (u32)e3;
-            // (the sorted list goes to memory behind the verdict: vmcnt counts stores too, and any wait for a load between
-            //  here and there would also wait for these stores to land)
-        }
+#pragma unroll
+        for (int x = 0; x < SQX_XPT; ++x)
+            if (x * SMC_BLOCK + tid < cnt) {
+                c_j[rank[x]] = (u32)e0[x];
+                c_P[rank[x]] = Pg[x];
+                c_w[rank[x]] = __longlong_as_double((long long)e2[x]);
+                c_acc[rank[x]] = (u32)e3[x];
+                // (the sorted list goes to memory behind the verdict: vmcnt counts stores too, and any wait for a load between
+                //  here and there would also wait for these stores to land)
+            }
         __syncthreads();
         SQX_STAMP(q, ntiles, 3);
         // ---- the walk (one thread): a run of regular elements is an integer added on the grid of s, an exception the
@@ -542,16 +526,11 @@ __device__ __forceinline__ void sqx_chain(const Src& src, const int isl, const S
         SQX_STAMP(q, ntiles, 4);
         // ---- verification of every segment against the binade the walk found in front of it; the tiles' headers
         bool bad = false;
-        if (tid < cnt) {
-            const u32 e = (u32)seq_bexp(c_S[tid]);
-            bad = e < (c_acc[tid] & 0xffffu) || e > (c_acc[tid] >> 16);
-            if (bad) atomicOr(&c_why, 4u);                     // the segment behind an exception expected another binade
-#ifdef SQX_DEBUG_PRINT
-            if (bad) {
-                printf("WHY4 isl %d cnt %d x %d j %u S %a (E %u) acc [%u,%u] w %a P %llu\n", isl, cnt, tid, c_j[tid], c_S[tid], e, c_acc[tid] & 0xffffu, c_acc[tid] >> 16, c_w[tid], (unsigned long long)c_P[tid]);
-                for (int m = (tid > 2 ? tid - 2 : 0); m < cnt && m < tid + 3; ++m) printf("     x %d j %u S %a w %a acc [%u,%u] P %llu\n", m, c_j[m], c_S[m], c_w[m], c_acc[m] & 0xffffu, c_acc[m] >> 16, (unsigned long long)c_P[m]);
-            }
-#endif
+        for (int xs_ = tid; xs_ < cnt; xs_ += SMC_BLOCK) {
+            const u32 e = (u32)seq_bexp(c_S[xs_]);
+            const bool b1 = e < (c_acc[xs_] & 0xffffu) || e > (c_acc[xs_] >> 16);
+            bad = bad || b1;
+            if (b1) atomicOr(&c_why, 4u);                      // the segment behind an exception expected another binade
         }
         // (measured and dropped, r14: waves 1-3 looking their tiles' first exceptions up WHILE lane 0 walks -- their LDS
         //  traffic sits in front of the walk's reads, and three waves do four waves' work afterwards: 20.8 against 18.5 us)
@@ -591,9 +570,7 @@ __device__ __forceinline__ void sqx_chain(const Src& src, const int isl, const S
                 bad = bad || badh;
                 const u64 hI = sqx_mant(sb) + (pt[k] - (qx < 0 ? 0ull : c_P[qx]));
                 if (c0 == 0) {                                 // (the first 1024 tiles' headers wait in registers for the verdict)
-                    int hi1 = lo[k];                            // first exception at or behind the NEXT tile's start
-                    if (XWG) while (hi1 < cnt && c_j[hi1] < key[k] + 1024u) ++hi1;
-                    w0[k] = (e << 18) | ((u32)lo[k] << 9) | (u32)hi1;
+                    w0[k] = (e << 16) | (u32)lo[k];
                     w1[k] = (u32)hI;
                     w2[k] = (u32)(hI >> 32);
                 } else {                                       // (larger islands, two launches: straight to memory)
@@ -606,45 +583,23 @@ __device__ __forceinline__ void sqx_chain(const Src& src, const int isl, const S
         if (bad) c_ok = 0;                                     // (benign race: every writer stores 0)
         __syncthreads();
         slow = c_ok == 0;
-        if (!XWG && !slow) {
+        if (!slow) {
             if (tid == 0) q.xfirst[(i64)isl * (ntiles + 1) + ntiles] = cnt;
-            if (tid < cnt) {                                   // (this thread's exception: slot `rank` of the sorted list)
-                u64* o = q.xs + ((i64)isl * SQX_CAP + rank) * 8;
-                o[0] = e0 & 0xffffffffull;
-                o[1] = (u64)__double_as_longlong(c_S[rank]);
-                o[2] = e1;
-            }
+#pragma unroll
+            for (int x = 0; x < SQX_XPT; ++x)
+                if (x * SMC_BLOCK + tid < cnt) {               // (this thread's exceptions: slots `rank` of the sorted list)
+                    u64* o = q.xs + ((i64)isl * SQX_CAP + rank[x]) * 8;
+                    o[0] = e0[x] & 0xffffffffull;
+                    o[1] = (u64)__double_as_longlong(c_S[rank[x]]);
+                    o[2] = e1[x];
+                }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int b = k * SMC_BLOCK + tid;
                 if (b >= ntiles) continue;
-                q.xfirst[(i64)isl * (ntiles + 1) + b] = (int)((w0[k] >> 9) & 0x1ffu);
-                q.hE[(i64)isl * ntiles + b] = (int)(w0[k] >> 18);
+                q.xfirst[(i64)isl * (ntiles + 1) + b] = (int)(w0[k] & 0xffffu);
+                q.hE[(i64)isl * ntiles + b] = (int)(w0[k] >> 16);
                 q.hI[(i64)isl * ntiles + b] = (u64)w1[k] | ((u64)w2[k] << 32);
-            }
-        }
-        if (XWG && !slow) {
-            // a header is what a waiting workgroup goes on: nothing was published before this point.  No load from memory
-            // between or behind these stores -- vmcnt counts stores too, and a wait for any load then waits
-            // for every write-through store in flight to reach memory (5 us for the lot, measured).
-            if (tid == 0) { ctr[2] = 0ull; ctr[3] = cnt64; }
-            if (tid < cnt) {                                   // (this thread's exception: slot `rank` of the sorted list)
-                u64* o = q.xs + ((i64)isl * SQX_CAP + rank) * 8;
-                const u64 Sb = (u64)__double_as_longlong(c_S[rank]);
-                sqx_put(o + 3, q.epoch, (u32)e0);
-                sqx_put(o + 4, q.epoch, (u32)Sb);
-                sqx_put(o + 5, q.epoch, (u32)(Sb >> 32));
-                sqx_put(o + 6, q.epoch, (u32)e1);
-                sqx_put(o + 7, q.epoch, (u32)(e1 >> 32));
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int b = k * SMC_BLOCK + tid;
-                if (b >= ntiles) continue;
-                u64* h = q.hdr + (i64)isl * ntiles * 3 + b;
-                sqx_put(h, q.epoch, w0[k]);
-                sqx_put(h + ntiles, q.epoch, w1[k]);
-                sqx_put(h + 2 * (i64)ntiles, q.epoch, w2[k]);
             }
         }
     }
@@ -664,19 +619,6 @@ __device__ __forceinline__ void sqx_chain(const Src& src, const int isl, const S
                 if (tid * 4 + k < m_all) So[lo + tid * 4 + k] = o4[k];
         }
     }
-    if (XWG && slow) {
-        // the waiting workgroups take the sums from memory: written back, then every tile's header says so (bit 31)
-        sqx_release_all();
-        smc_drain_stores();
-        __syncthreads();
-        for (int b = tid; b < ntiles; b += SMC_BLOCK) {
-            u64* h = q.hdr + (i64)isl * ntiles * 3 + b;
-            sqx_put(h, q.epoch, 0x80000000u);
-            sqx_put(h + ntiles, q.epoch, 0u);
-            sqx_put(h + 2 * (i64)ntiles, q.epoch, 0u);
-        }
-    }
-    if (XWG && !slow) { SQX_STAMP(q, ntiles, 5); return; }   // (a barrier here would wait for the published words to land)
     __syncthreads();
     if (tid == 0) { ctr[2] = slow ? (u64)(c_why ? c_why : 16u) : 0ull; ctr[3] = cnt64; }   // (mode word: 0, or why the exact path ran)
     SQX_STAMP(q, ntiles, 5);
@@ -702,52 +644,8 @@ __device__ __forceinline__ SqxStage sqx_stage_load(const SqxArgs& q, const int i
     smc_ld2g(q.Pin + (i64)isl * q.ntiles * SEQ_TILE + i0 + 2, st.Pin[2], st.Pin[3]);
     return st;
 }
-// The fused launch: the same from the tile's tagged header, WAITED for -- one lane polls the three words between
-// s_sleep's until all carry this launch's tag (the chain publishes them when every check has passed), the workgroup
-// takes them from LDS.  Two seconds without them (the exact path of a million weights takes four milliseconds) stop the
-// kernel with a trap rather than hang the device.  Every thread must call; a barrier inside.
-__device__ __forceinline__ SqxStage sqx_stage_wait(const SqxArgs& q, const int isl, const int b, const u64* pin_keep)
-{
-    __shared__ u64 s_h[3];
-    SqxStage st;
-#ifndef SMC_EMULATE
-    if (threadIdx.x == 0) {
-        const u64* h = q.hdr + (i64)isl * q.ntiles * 3 + b;
-        const u64 t0 = wall_clock64();                         // (100 MHz)
-        u64 w0, w1, w2;
-        // (a thousand workgroups wait while ONE works: polled back to back -- three loads every 50 ns each -- they took
-        //  the memory system from the chain, whose last two microseconds became twelve.  One word, a pause of
-        //  q.poll x 0.1 us between two looks; the other two words are there, or a look away, when the first is.)
-        for (;;) {
-            w0 = smc_ld_agent(h);
-            if (sqx_mine(w0, q.epoch)) {
-                w1 = smc_ld_agent(h + q.ntiles);
-                w2 = smc_ld_agent(h + 2 * (i64)q.ntiles);
-                if (sqx_mine(w1, q.epoch) && sqx_mine(w2, q.epoch)) break;
-            }
-            for (int i = 0; i < q.poll; ++i) __builtin_amdgcn_s_sleep(4);
-            if (wall_clock64() - t0 > 200000000ull) {
-                atomicAdd(reinterpret_cast<unsigned long long*>(q.done + gridDim.y + isl), 1ull);
-                __builtin_trap();
-            }
-        }
-        s_h[0] = w0; s_h[1] = w1; s_h[2] = w2;
-    }
-#endif
-    __syncthreads();
-    const u32 w0 = (u32)s_h[0];
-    st.mode = (u64)(w0 >> 31);
-    st.hE = (int)((w0 >> 18) & 0x7ffu);
-    st.xf0 = (int)((w0 >> 9) & 0x1ffu);
-    st.xf1 = (int)(w0 & 0x1ffu);
-    st.hI = (u64)(u32)s_h[1] | ((u64)(u32)s_h[2] << 32);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) st.Pin[k] = pin_keep[k];
-    return st;
-}
 // ... and sS[0 .. 1023] <- S_j of tile b (beyond n: the last sum); returns the sum in front of the tile (-inf for
 // tile 0).  Every thread must call; ends with a barrier.
-template <bool XWG = false>
 __device__ __forceinline__ double sqx_stage_tile(const SqxArgs& q, const int isl, const int b, const SqxStage& ld, double* sS)
 {
     __shared__ u64 s_x[3 * 64];                                // a batch of the tile's exceptions (index, S bits, Pin)
@@ -757,9 +655,6 @@ __device__ __forceinline__ double sqx_stage_tile(const SqxArgs& q, const int isl
     double S_start;
     if (mode != 0ull) {
         const double* Sf = q.Sfull + (i64)isl * (q.n + 8);
-#ifndef SMC_EMULATE
-        if (XWG) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (the chain released its plain stores: sqx_release_all)
-#endif
 #pragma unroll
         for (int k = 0; k < 4; ++k) sS[tid * 4 + k] = Sf[i0 + k < q.n ? i0 + k : q.n - 1];
         S_start = b ? Sf[j0 - 1] : -INFINITY;
@@ -776,22 +671,7 @@ __device__ __forceinline__ double sqx_stage_tile(const SqxArgs& q, const int isl
         for (int e0 = xf0; e0 < xf1; e0 += 64) {               // (uniform trip counts: the tile's exceptions, in order)
             const int ne = xf1 - e0 < 64 ? xf1 - e0 : 64;
             __syncthreads();
-            if (XWG) {
-                if (tid < ne) {                                // (five tagged words per exception: looked at until all are this launch's)
-                    const u64* x = q.xs + ((i64)isl * SQX_CAP + e0 + tid) * 8 + 3;
-                    u64 v[5];
-                    for (;;) {
-                        bool ok = true;
-#pragma unroll
-                        for (int m = 0; m < 5; ++m) { v[m] = smc_ld_agent(x + m); ok = ok && sqx_mine(v[m], q.epoch); }
-                        if (ok) break;
-                        smc_spin_pause();
-                    }
-                    s_x[3 * tid] = (u64)(u32)v[0];
-                    s_x[3 * tid + 1] = (u64)(u32)v[1] | ((u64)(u32)v[2] << 32);
-                    s_x[3 * tid + 2] = (u64)(u32)v[3] | ((u64)(u32)v[4] << 32);
-                }
-            } else if (tid < 3 * ne) {
+            if (tid < 3 * ne) {
                 s_x[tid] = smc_ldg(q.xs + ((i64)isl * SQX_CAP + e0 + tid / 3) * 8 + tid % 3);
             }
             __syncthreads();

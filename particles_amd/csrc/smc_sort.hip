@@ -23,14 +23,15 @@
 // their highest varying bit (one pass of maxima: k_rs_minmax); the 32 bits from there down are sorted by four stable
 // passes, after which keys that agree on those 32 bits -- and on everything above -- sit together in input order, and
 // k_rs_fix orders each such group by the remaining low bits (groups are pairs, rarely: N^2 / 2^33 expected collisions
-// over the range of the data; runs of fully equal keys need nothing and may be any length).  A group of more than 65
-// keys with different low bits (a cluster 2^-32 of the data's range wide) raises a flag and ONE workgroup redoes the
+// over the range of the data; runs of fully equal keys need nothing and may be any length).  A group reaching more than 64
+// keys to either side of one of its members, with different low bits (a cluster 2^-32 of the data's range wide) raises a flag and ONE workgroup redoes the
 // sort with all eight passes (k_rs_fallback: milliseconds; correct for any input).  Same permutation as before: a stable
 // sort by the full key.
 // The running sum of wquantiles is a three-kernel scan (tile sums, scan of the sums, apply).
 // Everything also runs under the fiber emulator (tests/emu), so the CPU suite exercises it.
 #include "smc_internal.h"
 #include "smc_device.h"
+#include <atomic>
 #include <vector>
 
 #define RS_TILE 2048
@@ -510,7 +511,7 @@ k_rs_small(const u64* keys, const u64* vals, i64 N, int kind, u64* okeys, u64* o
 // key IMAGES (rs_encode) are left inside it -- no copy-out.  The fused SQMC step of the filter sorts
 // through this entry once per time step.
 // (tests: the window path from smaller sizes on -- smc_debug_sort_window_min)
-static long long g_rs_window_min = RS_ONE_WG + 1;      // (every sort that takes more than one workgroup: 86 -> 60 us at 2^14, 171 -> 121 at 2^20)
+static std::atomic<long long> g_rs_window_min{RS_ONE_WG + 1};      // (every sort that takes more than one workgroup: 86 -> 60 us at 2^14, 171 -> 121 at 2^20)
 extern "C" int smc_debug_sort_window_min(long long n)
 {
     g_rs_window_min = n > RS_ONE_WG ? n : RS_ONE_WG + 1;

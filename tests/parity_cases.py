@@ -1177,6 +1177,11 @@ def check_seq_prefix_sums(sizes=(5000, 1 << 14, 20001), monkeypatch=None):
         # below 1.0 for most of the array
         w = np.exp(-60.0 + rng.standard_normal(N)); w[rng.choice(N, 8, replace=False)] = 1.0; cases["degenerate"] = w / w.sum()
         w = np.full(N, 2.0 ** -44); w[:4] = 0.25 - N * 2.0 ** -46; cases["trailing"] = w
+        # a likelihood over SORTED states (what SQMC's Hilbert order hands to inverse_cdf, core.py:339-349): the running sum
+        # rises through several hundred binades, every element of the flank an exception -- more than the lists hold: the
+        # exact path (same doubles, milliseconds)
+        x = np.sort(rng.standard_normal(N)) * 1.3
+        w = np.exp(-0.5 * ((x - 0.3) / 0.2) ** 2); cases["sorted gaussian"] = w / w.sum()
         for name, W in cases.items():
             want = loop(W).view(np.uint64)
             a, fb = seq(W, 0)
@@ -1188,7 +1193,7 @@ def check_seq_prefix_sums(sizes=(5000, 1 << 14, 20001), monkeypatch=None):
             assert fb >= -1 and 0 < nx <= (N + 1023) // 1024
             fast += fb >= 0
             log.append((N, name, fb))
-            if name not in ("ties", "tiny", "some ties"):
+            if name not in ("ties", "tiny", "some ties", "sorted gaussian"):
                 assert 0 <= fb <= 300, (N, name, fb)             # these stay on the fast path (fb: exceptions walked)
             if name == "some ties":
                 assert 64 < fb <= 256, (N, name, fb)             # more exceptions than a wave holds, fewer than the list
