@@ -325,56 +325,86 @@ k_rs_scatter(const u64* keys, const u64* vals, i64 N, int shift0, int kind, cons
 // other low bits (a run of equal keys, any length) -- the keys that DO differ sit in the same group, see the same long
 // group from where they are and raise the flag.
 #define RS_GCAP 64
+// (round 6: the tile's keys go through LDS with one key of halo on either side -- each key is read from memory ONCE, by
+//  16-byte accesses, and nearly every pair leaves by ONE 16-byte store; the version that read every key three times with
+//  8-byte accesses behind exec-mask branches took 22 us of the SQMC step at N = 2^20, profiles/r15_sqmc_step_trace.txt)
 __global__ void __launch_bounds__(SMC_BLOCK)
 k_rs_fix(const u64* keys, const u64* vals, i64 N, u64* okeys, u64* ovals, u64* plan)
 {
+    __shared__ u64 sk[RS_TILE + 2];
+    constexpr int NP = RS_TILE / (2 * SMC_BLOCK);              // pairs per thread
     const int tid = (int)threadIdx.x;
     const i64 tile0 = (i64)blockIdx.x * RS_TILE;
     const int sh = rs_window_shift(plan);
     const u64 lowmask = sh ? ((1ull << sh) - 1ull) : 0ull;
-    // (nearly every key is alone in its group: its two neighbours -- the same cache lines as the key itself -- say so)
-    u64 k[RS_TILE / SMC_BLOCK], kl[RS_TILE / SMC_BLOCK], kr[RS_TILE / SMC_BLOCK], v[RS_TILE / SMC_BLOCK];
+    const bool even = (N & 1) == 0;                            // (pairs are 16-byte aligned in all four arrays)
+    u64 k[2 * NP], v[2 * NP];
 #pragma unroll
-    for (int c = 0; c < RS_TILE / SMC_BLOCK; ++c) {
-        const i64 i = tile0 + (i64)c * SMC_BLOCK + tid;
-        const bool in = i < N;
-        k[c] = in ? keys[i] : 0ull;
-        kl[c] = (in && i > 0) ? keys[i - 1] : 0ull;
-        kr[c] = (in && i + 1 < N) ? keys[i + 1] : 0ull;
-        v[c] = in ? vals[i] : 0ull;
+    for (int c = 0; c < NP; ++c) {
+        const i64 i = tile0 + (i64)c * 2 * SMC_BLOCK + 2 * tid;
+        k[2 * c] = k[2 * c + 1] = v[2 * c] = v[2 * c + 1] = 0ull;
+        if (even && i + 1 < N) {
+            smc_ld2g(keys + i, k[2 * c], k[2 * c + 1]);
+            smc_ld2g(vals + i, v[2 * c], v[2 * c + 1]);
+        } else {
+            if (i < N) { k[2 * c] = keys[i]; v[2 * c] = vals[i]; }
+            if (i + 1 < N) { k[2 * c + 1] = keys[i + 1]; v[2 * c + 1] = vals[i + 1]; }
+        }
     }
+    if (tid == 0) sk[0] = tile0 > 0 ? keys[tile0 - 1] : 0ull;
+    if (tid == 1) sk[RS_TILE + 1] = tile0 + RS_TILE < N ? keys[tile0 + RS_TILE] : 0ull;
+#pragma unroll
+    for (int c = 0; c < NP; ++c) {
+        const int j = c * 2 * SMC_BLOCK + 2 * tid;
+        sk[1 + j] = k[2 * c];
+        sk[2 + j] = k[2 * c + 1];
+    }
+    __syncthreads();
     bool over = false;
 #pragma unroll
-    for (int c = 0; c < RS_TILE / SMC_BLOCK; ++c) {
-        const i64 i = tile0 + (i64)c * SMC_BLOCK + tid;
-        if (i >= N) continue;
-        const u64 hi = k[c] >> sh, low = k[c] & lowmask;
-        const bool left = i > 0 && (kl[c] >> sh) == hi, right = i + 1 < N && (kr[c] >> sh) == hi;
-        i64 pos = i;
-        if (sh && (left || right)) {
-            int before = 0, after = 0;
-            bool foundL = !left, foundR = !right, other = false;
-            for (int s = 1; left && s <= RS_GCAP; ++s) {
-                if (i - s < 0) { foundL = true; break; }
-                const u64 q = keys[i - s];
-                if ((q >> sh) != hi) { foundL = true; break; }
-                const u64 ql = q & lowmask;
-                before += ql > low ? 1 : 0;
-                other = other || ql != low;
+    for (int c = 0; c < NP; ++c) {
+        const int j0 = c * 2 * SMC_BLOCK + 2 * tid;
+        i64 pos[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int j = j0 + e;
+            const i64 i = tile0 + j;
+            pos[e] = i;
+            if (i >= N) continue;
+            const u64 kk = k[2 * c + e];
+            const u64 hi = kk >> sh, low = kk & lowmask;
+            const bool left = i > 0 && (sk[j] >> sh) == hi, right = i + 1 < N && (sk[j + 2] >> sh) == hi;
+            if (sh && (left || right)) {
+                int before = 0, after = 0;
+                bool foundL = !left, foundR = !right, other = false;
+                for (int s_ = 1; left && s_ <= RS_GCAP; ++s_) {
+                    if (i - s_ < 0) { foundL = true; break; }
+                    const u64 q = keys[i - s_];
+                    if ((q >> sh) != hi) { foundL = true; break; }
+                    const u64 ql = q & lowmask;
+                    before += ql > low ? 1 : 0;
+                    other = other || ql != low;
+                }
+                for (int s_ = 1; right && s_ <= RS_GCAP; ++s_) {
+                    if (i + s_ >= N) { foundR = true; break; }
+                    const u64 q = keys[i + s_];
+                    if ((q >> sh) != hi) { foundR = true; break; }
+                    const u64 ql = q & lowmask;
+                    after += ql < low ? 1 : 0;
+                    other = other || ql != low;
+                }
+                if (foundL && foundR) pos[e] = i - before + after;
+                else over = over || other;
             }
-            for (int s = 1; right && s <= RS_GCAP; ++s) {
-                if (i + s >= N) { foundR = true; break; }
-                const u64 q = keys[i + s];
-                if ((q >> sh) != hi) { foundR = true; break; }
-                const u64 ql = q & lowmask;
-                after += ql < low ? 1 : 0;
-                other = other || ql != low;
-            }
-            if (foundL && foundR) pos = i - before + after;
-            else over = over || other;
         }
-        okeys[pos] = k[c];
-        ovals[pos] = v[c];
+        const i64 i0 = tile0 + j0;
+        if (even && i0 + 1 < N && pos[0] == i0 && pos[1] == i0 + 1) {
+            smc_st2g(okeys + i0, k[2 * c], k[2 * c + 1]);
+            smc_st2g(ovals + i0, v[2 * c], v[2 * c + 1]);
+        } else {
+            if (i0 < N) { okeys[pos[0]] = k[2 * c]; ovals[pos[0]] = v[2 * c]; }
+            if (i0 + 1 < N) { okeys[pos[1]] = k[2 * c + 1]; ovals[pos[1]] = v[2 * c + 1]; }
+        }
     }
     if (over) plan[2] = 1ull;                   // (benign race: every writer stores 1)
 }
