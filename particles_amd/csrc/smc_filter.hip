@@ -26,6 +26,7 @@ struct smc_filter {
     bool use_graph;
     bool fused;            // k_ancestors<true> (no k_prepare launch)
     bool two_level;        // k_ancestors2 + tail-free k_propagate (two-level CDF, no intra-launch exchange)
+    bool reduce_narrow;    // SMC_PATH_NO_WIDE: k_reduce2 also where k_reduce2w would run (the A/B the tests compare)
     bool two_level_mid;    // ... with k_reduce2 in front (grids too large for every workgroup to reduce)
     int ragged;            // two-level step with N not a multiple of the tile: 1 (N even), 2 (N odd), else 0
                            // (k_propagate<.., RAGGED>)
@@ -70,6 +71,17 @@ struct smc_filter {
 };
 
 typedef void (*move_fn)(FArgs);
+
+// the island's reduction as a launch of its own: islands of 1025 .. 4096 tiles by a workgroup of 1024 threads (k_reduce2w:
+// the same bits), anything else -- and the APF's two sets of partials -- by k_reduce2
+static void launch_reduce2(smc_filter* f, hipStream_t st)
+{
+    const int nchunks = (f->a.nparts + 4 * SMC_BLOCK - 1) / (4 * SMC_BLOCK);
+    if (nchunks >= 2 && nchunks <= 4 && !f->a.pm2 && !f->reduce_narrow)
+        SMC_LAUNCH(k_reduce2w, dim3(f->a.n_islands), dim3(4 * SMC_BLOCK), st, f->a);
+    else
+        SMC_LAUNCH(k_reduce2, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
+}
 
 #define F_OPT 4     /* new particles per thread of k_propagate */
 
@@ -196,7 +208,7 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
             SQ_CASE(SMC_MODEL_LINGAUSS) SQ_CASE(SMC_MODEL_STOCHVOL) SQ_CASE(SMC_MODEL_GORDON)
             SQ_CASE(SMC_MODEL_THETALOGISTIC) SQ_CASE(SMC_MODEL_SVLEVERAGE) SQ_CASE(SMC_MODEL_DISCRETECOX)
 #undef SQ_CASE
-            SMC_LAUNCH(k_reduce2, dim3(a.n_islands), dim3(SMC_BLOCK), st, f->a);
+            launch_reduce2(f, st);
             SMC_LAUNCH((k_ancestors2<true, true, true, false, true>), grid, dim3(SMC_BLOCK), st, f->a);
             SMC_LAUNCH(k_sq_compose, dim3((unsigned)((a.N / 4 + SMC_BLOCK - 1) / SMC_BLOCK), a.n_islands), dim3(SMC_BLOCK), st,
                        f->a, perm);
@@ -221,7 +233,7 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
         const bool merge = sp1 && f->sp_merge && t_known;
         f->a.sp_epoch = merge ? ++f->sp_epoch : 0ull;
         if (f->two_level && (f->two_level_mid || f->strict_literal) && !merge)
-            SMC_LAUNCH(k_reduce2, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
+            launch_reduce2(f, st);
         if (sp1) {
             const dim3 gw(f->a.sp_nwg + (merge ? 1 : 0), f->a.n_islands);
             switch (f->a.sp_tpw) {
@@ -281,7 +293,7 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
             // (the island's reduction: a launch of its own, or workgroup 0 of the one-pass spacings kernel)
             const bool merge = f->sp_merge && !f->a.ut && f->a.sp_tpw && t_known;
             f->a.sp_epoch = merge ? ++f->sp_epoch : 0ull;
-            if (!merge) SMC_LAUNCH(k_reduce2, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
+            if (!merge) launch_reduce2(f, st);
             if (!f->a.ut) {
                 // production mode: uniform_spacings in two passes over the same draws (tile sums, their
                 // prefixes, the uniforms written once); k_ancestors2 finds its window through the prefixes
@@ -305,7 +317,7 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
             }
         } else {
             // closed-form counts: one instantiation per scheme (see k_ancestors2's SCH)
-            if (f->two_level_mid) SMC_LAUNCH(k_reduce2, dim3(f->a.n_islands), dim3(SMC_BLOCK), st, f->a);
+            if (f->two_level_mid) launch_reduce2(f, st);
 #ifdef SMC_NO_SCHEME_SPLIT                         /* (A/B builds: tools/build_ablations.sh) */
 #define A2_CASE(MIDV, POW2V, SCHV) SMC_LAUNCH((k_ancestors2<MIDV, false, POW2V>), grid, dim3(SMC_BLOCK), st, f->a)
 #else
@@ -622,6 +634,7 @@ int smc_filter_create(smc_ctx* ctx, const smc_model* model, const smc_filter_opt
     // resident grids of N = 2^k: 2 tiles per workgroup (smc_filter_wide.h; C2, same box: 17.6 us per step, 4 tiles 18.3,
     // one tile -- k_ancestors2 -- 18.1: profiles/r12d); SMC_PATH_NO_WIDE keeps the one-tile kernel testable at these sizes
     f->wide_tpw = 0;
+    f->reduce_narrow = (o->flags & SMC_PATH_NO_WIDE) != 0;
     if (f->two_level && !f->two_level_mid && a.log2N >= 0 && !(o->flags & SMC_PATH_NO_WIDE) && !f->strict && !f->sqmc) {
         f->wide_tpw = (a.ntiles % 2) == 0 ? 2 : 0;
     }
@@ -1900,6 +1913,11 @@ int smc_filter_describe(smc_filter* f, char* out, size_t n)
         s += mv ? (f->mv_collapsed ? "+k_propagate_mv<collapsed>" : "+k_propagate_mv") : "+k_propagate";
         if (mv) s += " [mv_chunks=" + std::to_string(f->a.mv_chunks) + "]" + (f->a.mv_diag ? " [diagonal factors]" : "");
         if (f->a.mom) s += "+k_f_moments_partials+k_f_moments_final";
+    }
+    {   // (islands of 1025 .. 4096 tiles: the reduction's launch is the 1024-thread kernel, launch_reduce2)
+        const int nchunks = (f->a.nparts + 4 * SMC_BLOCK - 1) / (4 * SMC_BLOCK);
+        const size_t p = s.find("k_reduce2+");
+        if (p != std::string::npos && nchunks >= 2 && nchunks <= 4 && !f->a.pm2 && !f->reduce_narrow) s.replace(p, 10, "k_reduce2w+");
     }
     snprintf(out, n, "%s", s.c_str());
     return SMC_OK;

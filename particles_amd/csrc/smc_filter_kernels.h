@@ -2396,6 +2396,120 @@ __device__ __forceinline__ int f2_reduce2_island(const FArgs& a, const int isl, 
     }
     return 1;
 }
+// k_reduce2 for islands of 1025 .. 4096 tiles (C3's N = 2^22) as ONE workgroup of 1024 threads: thread (c, i) = chunk c
+// of 1024 tiles, slot i of 256 -- what thread i of k_reduce2 does for its chunk c.  The loads, the power-of-two
+// rescalings and the shares of the 16 tiles a slot owns are done by four threads side by side (sixteen waves hide
+// each other's latencies where four could not: the kernel is one workgroup on the critical path of every step); the
+// slot's two sums are then formed by thread (0, i) from LDS in k_reduce2's order -- chunk by chunk, tile by tile --
+// and reduced over the 256 slots by waves 0 .. 3 exactly as smc_block_sum2 does: the same operations in the same
+// order, hence the same bits (tests: SMC_TWO_LEVEL_MID against the resident step, C3's runs against the oracle).
+__global__ void __launch_bounds__(4 * SMC_BLOCK)
+k_reduce2w(const FArgs av)
+{
+    const FArgs& a = av;
+    constexpr int NC = 4;
+    __shared__ double s_v[NC][4][SMC_BLOCK];                 // [chunk][k][slot]: conflict-free for the slot's owner
+    __shared__ double s_w[NC][4][SMC_BLOCK];
+    __shared__ double s_m[NC * SMC_NWAVE];
+    __shared__ double s_s[2 * SMC_NWAVE];
+    __shared__ double s_x4[NC * SMC_NWAVE];
+    const int isl = (int)blockIdx.x, tid = (int)threadIdx.x;
+    const int c = tid >> 8, i = tid & (SMC_BLOCK - 1), wv = i >> 6, lane = tid & 63;
+    double* info = a.info + (i64)isl * INFO_STRIDE;
+    const i64 t = (i64)smc_uniform(smc_ldg(a.info2 + (i64)isl * INFO_STRIDE));
+    if (t >= a.T) {
+        if (tid == 0) info[0] = (double)t;
+        return;
+    }
+    if (t == 0) return;
+    F2RecIn rin = {0.0, 0.0, 0.0, 0.0, 0.0};
+    if (tid == 0) rin = f2_record_loads(a, isl, t);
+    const i64 o = (i64)isl * a.nparts;
+    const bool pvec = (a.nparts & 3) == 0;
+    const int nchunks = (a.nparts + 4 * SMC_BLOCK - 1) / (4 * SMC_BLOCK);
+    const i64 i0 = (i64)c * 4 * SMC_BLOCK + (i64)i * 4;
+    double pm[4], ps[4], pss[4];
+    if (c < nchunks) {
+        f_load4<double>(a.pm + o, i0, a.nparts, pvec, -INFINITY, pm);
+        f_load4<double>(a.ps + o, i0, a.nparts, pvec, 0.0, ps);
+        f_load4<double>(a.pss + o, i0, a.nparts, pvec, 0.0, pss);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { pm[k] = -INFINITY; ps[k] = 0.0; pss[k] = 0.0; }
+    }
+    F2Red r;
+    {
+        double tm = smc_max2(smc_max2(pm[0], pm[1]), smc_max2(pm[2], pm[3]));
+        tm = smc_wave_max(tm);
+        if (lane == 0) s_m[tid >> 6] = tm;
+        __syncthreads();
+        r.K = s_m[0];
+#pragma unroll
+        for (int w = 1; w < NC * SMC_NWAVE; ++w) r.K = smc_max2(r.K, s_m[w]);
+    }
+    double v4[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        double w;
+        f2_rescale(pm[k], r.K, ps[k], pss[k], v4[k], w);
+        s_v[c][k][i] = v4[k];
+        s_w[c][k][i] = w;
+    }
+    __syncthreads();
+    double s1 = 0.0, s2 = 0.0;
+    if (c == 0) {
+        for (int cc = 0; cc < nchunks; ++cc)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                s1 = s1 + s_v[cc][k][i];
+                s2 = s2 + s_w[cc][k][i];
+            }
+    }
+    s1 = smc_wave_sum(s1);
+    s2 = smc_wave_sum(s2);
+    if (c == 0 && lane == 0) { s_s[wv] = s1; s_s[SMC_NWAVE + wv] = s2; }
+    __syncthreads();
+    {
+        double ra = s_s[0], rb = s_s[SMC_NWAVE];
+#pragma unroll
+        for (int w = 1; w < SMC_NWAVE; ++w) { ra = ra + s_s[w]; rb = rb + s_s[SMC_NWAVE + w]; }
+        r.s = ra;
+        r.ss = rb;
+    }
+    f2_finish(a, r);
+    const bool resample = r.ess < a.ess_thresh;
+    if (tid == 0) f2_write_record(a, isl, t, r, resample, rin);
+    if (!resample) return;
+    // every tile's share and the shares before it (f2_reduce2_island's expressions, one chunk per group of four waves)
+    double* G = reinterpret_cast<double*>(a.Qpre) + (i64)isl * a.ntiles;
+    double* Q = reinterpret_cast<double*>(a.Q) + (i64)isl * a.ntiles;
+    double Q4[4], run = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        Q4[k] = (c < nchunks && i0 + k < a.nparts) ? (a.strict_e ? v4[k] * r.rs : f2_share(v4[k], r.rs)) : 0.0;
+        run += Q4[k];
+    }
+    const double inc = smc_wave_scan_add_f64(run);
+    const double exl = smc_dpp_f64<SMC_DPP_WAVE_SHR1, 0xf, false>(inc);
+    if (lane == 63) s_x4[c * SMC_NWAVE + wv] = inc;
+    __syncthreads();
+    if (c >= nchunks) return;
+    double carry = 0.0;
+    for (int cc = 0; cc < c; ++cc) {
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < SMC_NWAVE; ++w) tot += s_x4[cc * SMC_NWAVE + w];
+        carry += tot;
+    }
+    double base = 0.0;
+#pragma unroll
+    for (int w = 0; w < SMC_NWAVE; ++w)
+        if (w < wv) base += s_x4[c * SMC_NWAVE + w];
+    double g = carry + (base + exl);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (i0 + k < a.nparts) { G[i0 + k] = g; Q[i0 + k] = Q4[k]; g += Q4[k]; }
+}
 __global__ void __launch_bounds__(SMC_BLOCK)
 k_reduce2(const FArgs av)
 {

@@ -1317,6 +1317,24 @@ def check_two_level_stepwise(N=2048):
             pass
 
 
+def check_reduce2_wide(monkeypatch, cases, y):
+    """Islands of 1025 .. 4096 tiles: the reduction's launch is one workgroup of 1024 threads (k_reduce2w) -- against the
+    256-thread kernel (SMC_NO_WIDE keeps it at these sizes) the same run bit for bit: full chunks and a ragged last
+    one; the production scheme, a strict filter (its G_b are fractions, not integers), two islands."""
+    for n, kw in cases:
+        got = {}
+        for name, env in (("wide", {}), ("narrow", {"SMC_NO_WIDE": "1"})):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            pf = pa.SMC(fk=ssm.Bootstrap(ssm=kalman.ToySSM(0.2), data=y), N=n, seed=99, ESSrmin=1.0,
+                        resampling="systematic", **kw)
+            assert ("k_reduce2w+" in describe(pf)) == (name == "wide"), describe(pf)
+            pf.run()
+            got[name] = (np.array(pf.A), np.array(pf.X), np.array(pf.wgts.lw), np.array(pf.logLt))
+            monkeypatch.undo()
+        assert all(np.array_equal(u, v) for u, v in zip(got["wide"], got["narrow"])), (n, kw)
+
+
 def check_two_level_large(golden, monkeypatch, log2N=21, T=6):
     """More than 1024 tiles per island: k_reduce2 walks the partials in chunks.  Production
     (Philox) mode against the flat-Q62 path on the same counters: the same particle system up to
@@ -1336,7 +1354,9 @@ def check_two_level_large(golden, monkeypatch, log2N=21, T=6):
     assert all(runs["two"][3][1:]) and runs["two"][3] == runs["flat"][3]
     assert np.array_equal(runs["two"][0], runs["exact"][0]) and np.array_equal(runs["two"][1], runs["exact"][1])
     assert rel(runs["two"][2], runs["flat"][2]) < 1e-6       # (two particle systems after the first near-tie)
-    # the k_reduce2 route against the oracle, every step, every ancestor
+    check_reduce2_wide(monkeypatch, ((N, {}), (3 * (1 << 20) + 777, {}), (N + 4096 * 3 + 5, {"strict_ancestors": True}),
+                                     (1 << 20 | 12345, {"n_islands": 2})), y[:4])
+    # the k_reduce2w route against the oracle, every step, every ancestor
     check_oracle_at_size("toy", *MODELS["toy"], N, 4, "systematic", 1.0, replay=False, seed=99)
     ll, _ = orc.kalman_loglik(orc.ToySSM(0.2), y)
     assert abs(runs["two"][2][-1] - ll) < 0.05

@@ -118,7 +118,7 @@ def test_committed_traffic_files_are_usable():
         assert os.path.exists(os.path.join(ROOT, "profiles", rec["summary"])), (f, rec["summary"])
         cfg = rec["config"]
         wl = bench.make_workload(cfg["workload"], 4, scheme=cfg["scheme"], collapsed=bool(cfg.get("collapsed")),
-                                 qmc=bool(cfg.get("qmc")), strict=bool(cfg.get("strict")))
+                                 qmc=bool(cfg.get("qmc")), strict=bool(cfg.get("strict")), dense=bool(cfg.get("dense")))
         assert bench.leg_key(wl) == key, (f, bench.leg_key(wl))
         assert (wl["log2N"], wl["islands"]) == (cfg["log2N"], cfg["islands"]), f
         names = [n for n in rec["kernels"] if "k_propagate" in n]
@@ -130,7 +130,8 @@ def test_committed_traffic_files_are_usable():
         assert 0.4 < tr[0] / alg < 2.0, (f, tr[0] / alg)
         # a different size is NOT this record's workload
         wl2 = bench.make_workload(cfg["workload"], 4, scheme=cfg["scheme"], log2N=cfg["log2N"] - 1,
-                                  collapsed=bool(cfg.get("collapsed")), qmc=bool(cfg.get("qmc")), strict=bool(cfg.get("strict")))
+                                  collapsed=bool(cfg.get("collapsed")), qmc=bool(cfg.get("qmc")), strict=bool(cfg.get("strict")),
+                                  dense=bool(cfg.get("dense")))
         if cfg["workload"] != "c5":
             assert bench.measured_traffic(wl2, "k_propagate") is None
 
@@ -143,12 +144,18 @@ def test_fractions_are_reproducible_from_profiles():
     import re
     import bench
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_*.json")))
-    assert len(files) >= 10
+    assert len(files) >= 11
     for f in files:
         rec = json.load(open(f))
         cfg = rec["config"]
         wl = bench.make_workload(cfg["workload"], 4, scheme=cfg["scheme"], collapsed=bool(cfg.get("collapsed")),
-                                 qmc=bool(cfg.get("qmc")), strict=bool(cfg.get("strict")))
+                                 qmc=bool(cfg.get("qmc")), strict=bool(cfg.get("strict")), dense=bool(cfg.get("dense")))
+        # the record is of THIS tree's kernels (tools/source_hash.py: csrc/*, the C header, the compiler flags) -- a leg
+        # whose kernels changed after its record was taken must be profiled again before the tree is committed
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from source_hash import source_hash
+        assert rec.get("source_hash") == source_hash(), (f, rec.get("source_hash"), source_hash(), rec.get("tree"))
+        assert rec.get("tree", "unknown") != "unknown", f
         mv = "k_propagate_mv" if cfg["workload"] == "c4" else "k_propagate"
         name, d = [(n, v) for n, v in rec["kernels"].items() if bench_base(n) == mv][0]
         assert d["avg_us"] and d["avg_us"] > 1.0, f
@@ -161,8 +168,8 @@ def test_fractions_are_reproducible_from_profiles():
         N, isl, dd = wl["N"], wl["islands"], wl["d"]
         two = any(k in " ".join(rec["kernels"]) for k in ("k_ancestors2", "k_strict_classify", "k_strict_step"))
         rf = {"kernel": mv, "bound": "hbm", "launch_bytes": (16.0 * dd + 16.0 + (8.0 if two else 0.0)) * N * isl}
-        if cfg["workload"] == "c4":
-            rf.update(bound="mfma", launch_flop=(44 if cfg.get("collapsed") else 72) * 2048.0 / 16.0 * N * isl)
+        if cfg["workload"] == "c4" and cfg.get("dense"):   # (the dense MFMA products: priced against the fp64 matrix peak)
+            rf.update(bound="mfma", launch_flop=bench.mfma_per_16(bool(cfg.get("collapsed")), False) * 2048.0 / 16.0 * N * isl)
         bench.add_profile_fractions(rf, wl)
         sec = d["avg_us"] * 1e-6
         if rf["bound"] == "mfma":
@@ -173,7 +180,7 @@ def test_fractions_are_reproducible_from_profiles():
             assert abs(rf["frac_physical"] - d["hbm_bytes_per_launch"] / sec / 1e9 / bench.HBM_PEAK_GBS) < 1e-12
             # (the counters see fewer bytes than SURVEY's accounting -- 32-bit ancestors -- except under SQMC, whose
             #  k_propagate also reads the tape of ndtri values)
-            assert 0.3 < rf["frac_physical"] < 1.0 and 0.3 < rf["frac_rocprof"] < 1.0, (f, rf)
+            assert 0.25 < rf["frac_physical"] < 1.0 and 0.3 < rf["frac_rocprof"] < 1.0, (f, rf)
             assert cfg.get("qmc") or rf["frac_physical"] <= rf["frac_rocprof"] * 1.05, (f, rf)
 
 

@@ -28,6 +28,11 @@ def test_inverse_cdf(N, M):
     pc.check_inverse_cdf(N, M)
 
 
+def test_reduce2_wide(monkeypatch):
+    """k_reduce2w (1024 threads) against k_reduce2 at the smallest island it serves (1029 tiles, a ragged second chunk)."""
+    pc.check_reduce2_wide(monkeypatch, (((1 << 20) + 4099, {}),), [np.array([0.3]), np.array([-0.2])])
+
+
 def test_sort_window_and_fixup():
     pc.check_sort_window(sizes=(8193, 11003))
 

@@ -6,7 +6,7 @@
 #   profiles/traffic_<leg>.json        bench.py's roofline.traffic source (config + command inside)
 # are what to copy out of gpurun_out/<tag>/.
 TAG=${1:-r12p}
-LEGS=${2:-"c2 c3_systematic c3_stratified c3_multinomial c4 c4_collapsed c5 sqmc c2_strict c3_systematic_strict"}
+LEGS=${2:-"c2 c3_systematic c3_stratified c3_multinomial c4 c4_dense c4_collapsed c5 sqmc c2_strict c3_systematic_strict"}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -20,6 +20,8 @@ for leg in $LEGS; do
     c3_stratified)  ARGS="--workload c3 --scheme stratified";  CFG='{"workload":"c3","log2N":22,"islands":1,"scheme":"stratified"}' ;;
     c3_multinomial) ARGS="--workload c3 --scheme multinomial"; CFG='{"workload":"c3","log2N":22,"islands":1,"scheme":"multinomial"}' ;;
     c4)             ARGS="--workload c4"; STEPS=40; CFG='{"workload":"c4","log2N":20,"islands":1,"scheme":"systematic","collapsed":false}'
+                    PASSES="FETCH_SIZE;WRITE_SIZE;SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAIT_INST_ANY;SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY SQ_INSTS_SALU GRBM_GUI_ACTIVE" ;;
+    c4_dense)       ARGS="--workload c4 --dense"; STEPS=40; CFG='{"workload":"c4","log2N":20,"islands":1,"scheme":"systematic","collapsed":false,"dense":true}'
                     PASSES="FETCH_SIZE;WRITE_SIZE;SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAIT_INST_ANY;SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY SQ_INSTS_SALU GRBM_GUI_ACTIVE" ;;
     c4_collapsed)   ARGS="--workload c4 --collapsed"; STEPS=40; CFG='{"workload":"c4","log2N":20,"islands":1,"scheme":"systematic","collapsed":true}'
                     PASSES="FETCH_SIZE;WRITE_SIZE;SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAIT_INST_ANY;SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY SQ_INSTS_SALU GRBM_GUI_ACTIVE" ;;
