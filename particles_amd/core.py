@@ -131,9 +131,11 @@ class SMC:
     collapsed_proposal : GuidedPF of an MVLinearGauss only -- weigh with the collapsed form of the
         optimal proposal's weight, log p(y_t | x_{t-1}) (SMC_FLAG_COLLAPSED_PROPOSAL): same
         particles, log-weights equal up to rounding, 40 % fewer matrix instructions
-    strict_ancestors : univariate Bootstrap / Guided filters -- resample with the reference's own
-        sequential fp64 CDF of the filter's weights (SMC_FLAG_STRICT_ANCESTORS): ``A`` equals
-        ``particles.resampling.inverse_cdf(su, W)`` bit for bit, at milliseconds per resampling step
+    strict_ancestors : resample with the reference's own sequential fp64 CDF of the filter's weights: ``A`` equals
+        ``particles.resampling.inverse_cdf(su, W)`` bit for bit.  Fused univariate Bootstrap / Guided filters:
+        SMC_FLAG_STRICT_ANCESTORS (two launches, verified per step); every other filter -- the
+        template-method step, SQMC included (qmc=True then runs on device operators) -- wraps its resampling calls in
+        ``rs.strict_mode`` (``smc_inverse_cdf_strict``)
     use_graph : replay the step sequence from hipGraphs instead of launching the kernels one by
         one (off by default: on MI355X a dependent kernel boundary costs the same either way,
         eager launches measured 2 % faster at C2 and start sooner after an idle stream)
@@ -644,7 +646,9 @@ class SMC:
     def resample_move(self):
         self.rs_flag = self.fk.time_to_resample(self)              # core.py:326-337
         if self.rs_flag:
-            self.A = rs.resampling(self.resampling, self.aux.W, M=self.N)
+            # (strict_ancestors on the template-method step: the reference's sequential CDF, as on the fused one)
+            with rs.strict_mode(self._strict or rs.STRICT[0]):
+                self.A = rs.resampling(self.resampling, self.aux.W, M=self.N)
             self.Xp = self.X[self.A]
             self.reset_weights()
         else:
@@ -666,7 +670,7 @@ class SMC:
             tau = hilbert.argsort(u[:, 0])
             su0 = u[:, 0][tau]
         self.h_order = hilbert.hilbert_sort(self.X)
-        self.A = self.h_order[rs.inverse_cdf(su0, self.aux.W[self.h_order])]
+        self.A = self.h_order[rs.inverse_cdf(su0, self.aux.W[self.h_order], strict=True if self._strict else None)]
         self.Xp = self.X[self.A]
         if self.fk.du == 1:
             v = u[:, 1] if tau is None else u[:, 1][tau]           # u[tau, 1:].squeeze()

@@ -236,6 +236,22 @@ def set_strict(flag=True):
     STRICT[0] = bool(flag)
 
 
+class strict_mode:
+    """``with strict_mode(flag):`` -- ``set_strict(flag)`` for the block (what ``SMC(strict_ancestors=True)`` wraps the
+    resampling calls of its template-method step in, so that the option means the same on every path)."""
+
+    def __init__(self, flag=True):
+        self.flag = bool(flag)
+
+    def __enter__(self):
+        self.saved, STRICT[0] = STRICT[0], self.flag
+        return self
+
+    def __exit__(self, *exc):
+        STRICT[0] = self.saved
+        return False
+
+
 def inverse_cdf(su, W, strict=None):
     """Inverse CDF algorithm for a finite distribution (resampling.py:484-509).
 

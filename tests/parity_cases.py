@@ -1134,6 +1134,42 @@ def check_strict_never_leaves_the_fast_path(cases, T=300):
         assert np.all(np.isfinite(pf.logLts_islands)) and worst <= 256, (N, scheme, model, worst)
 
 
+def check_strict_operator_path(monkeypatch, sizes=(1500, 1 << 13), T=5):
+    """strict_ancestors=True OUTSIDE the fused strict step (strict with qmc): the template-method
+    step of a user-level FeynmanKac and SQMC -- whose inverse_cdf sees the weights of particles in SORTED order, a
+    likelihood over ordered states: the running sum climbs through hundreds of binades, the shape that sends
+    smc_inverse_cdf_strict beyond its exception lists to its exact path.  Every call of inverse_cdf the run makes is
+    recorded: it must have been made in strict mode and return resampling.py:484-509's ancestors literally."""
+    calls = []
+    real = rs.inverse_cdf
+
+    def spy(su, W, strict=None):
+        A = real(su, W, strict=strict)
+        calls.append((np.asarray(su).copy(), np.asarray(W).copy(), np.asarray(A).copy(),
+                      bool(rs.STRICT[0] if strict is None else strict)))
+        return A
+
+    monkeypatch.setattr(rs, "inverse_cdf", spy)
+    rng = np.random.RandomState(3)
+    y = [np.array([v]) for v in 0.5 * np.cumsum(rng.standard_normal(T))]
+    for N in sizes:
+        for kw in (dict(qmc=True), dict(qmc=True, sigY=2e-3), dict(resampling="stratified", ESSrmin=1.0),
+                   dict(resampling="multinomial", ESSrmin=1.0)):
+            kw = dict(kw)
+            model = kalman.ToySSM(kw.pop("sigY", 0.2))
+            fk = ssm.Bootstrap(ssm=model, data=y) if kw.get("qmc") else _PickleCustomFK(ssm=model, data=y)
+            del calls[:]
+            np.random.seed(5)
+            n = 1 << int(np.log2(N)) if kw.get("qmc") else N          # (Sobol' points: N = 2^k)
+            pf = pa.SMC(fk=fk, N=n, strict_ancestors=True, collect="off", **kw)
+            assert not pf._fused                       # (numpy draws / a user subclass: device operators)
+            pf.run()
+            assert len(calls) == T - 1 and not rs.STRICT[0], (N, kw, len(calls))
+            for su, W, A, strict in calls:
+                assert strict and np.array_equal(A, orc.inverse_cdf(su, W)), (N, kw)
+            assert np.isfinite(pf.logLt)
+
+
 def check_seq_prefix_sums(sizes=(5000, 1 << 14, 20001), monkeypatch=None):
     """csrc/smc_seqsum.h: the reference's sequential fp64 prefix sums (resampling.py:506-508: s = W[0]; s += W[j])
     computed in parallel must be THE SAME DOUBLES as the loop's, whatever the weights: the element-level pass (mode 0),

@@ -397,3 +397,7 @@ def test_sequential_prefix_sums_in_parallel(monkeypatch):
 
 def test_auxiliary_bootstrap_fused(golden):
     pc.check_apf_bootstrap(golden, big=((2048, "systematic", 0.7), (3000, "stratified", 0.8)))
+
+
+def test_strict_ancestors_on_the_operator_path(monkeypatch):
+    pc.check_strict_operator_path(monkeypatch, sizes=(1500, 5000))

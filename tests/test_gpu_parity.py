@@ -705,3 +705,9 @@ def test_sequential_prefix_sums_in_parallel(monkeypatch):
 def test_auxiliary_bootstrap_fused(golden):
     import parity_cases as pc
     pc.check_apf_bootstrap(golden)
+
+
+@pytest.mark.gpu
+def test_strict_ancestors_on_the_operator_path(monkeypatch):
+    import parity_cases as pc
+    pc.check_strict_operator_path(monkeypatch, sizes=(1500, 1 << 13, 1 << 17))

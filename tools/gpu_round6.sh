@@ -90,4 +90,18 @@ floor)  # in-kernel timelines + the step's floor breakdown (needs particles_amd/
 prof)
     bash tools/gpu_profile_all.sh $TAG "$2"
     ;;
+final)  # the last tree under load: smoke, in-kernel timelines, fuzzers, soaks, sweeps (each under its own timeout)
+    (timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/${TAG}_smoke.log 2>&1; echo "rc=$?" >> $O/${TAG}_smoke.log); tail -3 $O/${TAG}_smoke.log
+    (python tools/trace_step.py 20; python tools/trace_step.py 14; python tools/trace_step.py 22 systematic sv) > $O/${TAG}_c2_floor_raw.txt 2>&1; grep -A5 "floor breakdown" $O/${TAG}_c2_floor_raw.txt
+    python tools/trace_spacing.py 22 > $O/${TAG}_trace_spacing.txt 2>&1; cat $O/${TAG}_trace_spacing.txt
+    (timeout 900 python tools/sort_fuzz.py 120 > $O/${TAG}_sort_fuzz.txt 2>&1; echo "rc=$?" >> $O/${TAG}_sort_fuzz.txt); tail -3 $O/${TAG}_sort_fuzz.txt
+    (timeout 600 python tools/sort_perf.py > $O/${TAG}_sort_perf.txt 2>&1); cat $O/${TAG}_sort_perf.txt
+    (timeout 900 python tools/strict_soak.py > $O/${TAG}_strict_soak.txt 2>&1; echo "rc=$?" >> $O/${TAG}_strict_soak.txt); tail -12 $O/${TAG}_strict_soak.txt
+    (timeout 600 python tools/strict_perf.py > $O/${TAG}_strict_perf.txt 2>&1); tail -12 $O/${TAG}_strict_perf.txt
+    (timeout 400 python tools/fuzz_paths.py 300 29 > $O/${TAG}_fuzz_paths.txt 2>&1; echo "rc=$?" >> $O/${TAG}_fuzz_paths.txt); tail -3 $O/${TAG}_fuzz_paths.txt
+    (timeout 300 python tools/robustness.py > $O/${TAG}_robustness.txt 2>&1; echo "rc=$?" >> $O/${TAG}_robustness.txt); tail -5 $O/${TAG}_robustness.txt
+    (timeout 300 python tools/size_sweep.py > $O/${TAG}_size_sweep.txt 2>&1); cat $O/${TAG}_size_sweep.txt
+    (timeout 600 python tools/soak.py > $O/${TAG}_soak.txt 2>&1; echo "rc=$?" >> $O/${TAG}_soak.txt); tail -4 $O/${TAG}_soak.txt
+    (timeout 300 python tools/microbench.py > $O/${TAG}_microbench.txt 2>&1); tail -15 $O/${TAG}_microbench.txt
+    ;;
 esac
