@@ -76,6 +76,8 @@ def test_default_line_carries_other_workloads_and_cpu_legs(tmp_path):
         ac = cb["all_cores"]
         assert ac["cores"] == min(64, cb["host"]["nproc"]) and ac["host_nproc"] == cb["host"]["nproc"]
         assert ac["runs"] >= 16 and ac["value"] > 0 and ac["kind"] == cb["kind"]
+        # independent runs, as multiSMC's are (utils.py:189-213): every worker its own seeds (64 copies of one)
+        assert ac["distinct_logLt"] == ac["runs"] and ac["logLt_sd"] > 0
 
 
 @pytest.mark.parametrize("kind", ["port", "reference"])
