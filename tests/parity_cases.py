@@ -160,21 +160,35 @@ def check_sort_window(sizes=(8193, 20001, 50001), window_min=8193):
         x = rng.standard_normal(N)
         x[:6] = 0.0, -0.0, np.inf, -np.inf, 5e-324, -5e-324
         yield "specials", x
+        x = rng.standard_normal(N)                         # outliers: inside / beyond what the logarithmic grid absorbs
+        x[N // 3] = 3000.0
+        yield "outlier 3e3", x
+        x = rng.standard_normal(N)
+        x[N // 3], x[N // 5] = 1e9, -1e12
+        yield "outliers 1e9", x
+        yield "cauchy", rng.standard_cauchy(N)
+        yield "lognormal 20", np.exp(20.0 * rng.standard_normal(N))
+        x = rng.standard_normal(N)
+        x[rng.random(N) < 0.6] = np.nan                    # (more than half the sampled keys non-finite)
+        x[::97] = np.inf
+        yield "mostly nan", x
+        yield "huge range", rng.standard_normal(N) * 1e308
 
     pts = rng.standard_normal((sizes[0], 3))
     try:
-        for wm in (window_min, 1 << 40):                  # four passes + fix-up from window_min keys on; eight passes
+        first = None
+        for wm, lm in ((window_min, 0), (1 << 40, 0)):    # four passes + fix-up from window_min keys on; eight passes
             _lib.check(_lib.lib().smc_debug_sort_window_min(wm))
             for N in sizes:
                 for name, x in cases(N):
                     o = np.asarray(hilbert.argsort(x))
                     ref = np.argsort(x, kind="stable")
-                    assert np.array_equal(np.sort(o), np.arange(N)), (wm, N, name)
-                    assert np.all(x[o] == x[ref]), (wm, N, name)
+                    assert np.array_equal(np.sort(o), np.arange(N)), (wm, lm, N, name)
+                    assert np.array_equal(x[o], x[ref], equal_nan=True), (wm, lm, N, name)
                     nz = x[o] != 0.0                          # (+0 and -0 compare equal: either order is a valid sort)
-                    assert np.array_equal(o[nz], ref[nz]), (wm, N, name, int(np.sum(o != ref)))
+                    assert np.array_equal(o[nz], ref[nz]), (wm, lm, N, name, int(np.sum(o != ref)))
             order = np.asarray(hilbert.hilbert_sort(pts))
-            if wm == window_min:
+            if first is None:
                 first = order
             else:
                 assert np.array_equal(first, order)

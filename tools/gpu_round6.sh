@@ -84,6 +84,9 @@ sort)   # the radix sort: correctness fuzz, timings, the SQMC leg
     timeout 900 python tools/sort_fuzz.py ${2:-120} > $O/${TAG}_sort_fuzz.txt 2>&1; tail -3 $O/${TAG}_sort_fuzz.txt
     timeout 600 python tools/sort_perf.py > $O/${TAG}_sort_perf.txt 2>&1; cat $O/${TAG}_sort_perf.txt
     ;;
+sortab) # the sort's forms on stressing data shapes, the SQMC step on each
+    timeout 900 python tools/sort_quick.py > $O/${TAG}_sort_quick.txt 2>&1; cat $O/${TAG}_sort_quick.txt
+    ;;
 floor)  # in-kernel timelines + the step's floor breakdown (needs particles_amd/lib/abl/libsmc_TRACE.so)
     (python tools/trace_step.py 20; python tools/trace_step.py 14; python tools/trace_step.py 22 systematic sv) > $O/${TAG}_c2_floor.txt 2>&1; cat $O/${TAG}_c2_floor.txt
     ;;
