@@ -82,6 +82,13 @@ k_sq_permute(const FArgs av, const u64* perm, const u64* skeys, double* zbuf, co
     // the XOR of the direction numbers v_k over the set bits of g -- looked up 7 bits at a time in tables the
     // workgroup builds once (5 x 128 words of LDS) instead of walking the 20 bits of every g
     __shared__ u32 s_v2[5 * 128];
+    // the tail arguments of ndtri (27 % of the tile's 1024: smc_qmc.h), packed: slot k * 256 + tid of s_y holds the
+    // argument, then the result; every wave that ran the tail branch for one lane paid for all 64 (25 of this
+    // kernel's 25 us at N = 2^20 were VALU), a packed queue is 1.1 passes per wave instead of 4
+    __shared__ double s_y[4 * SMC_BLOCK];
+    __shared__ unsigned short s_q[4 * SMC_BLOCK];
+    __shared__ unsigned s_nq;
+    if (tid == 0) s_nq = 0u;
     for (int e = tid; e < 5 * 128; e += SMC_BLOCK) {
         const int c = e >> 7, bits = e & 127;
         u32 m = 1u, acc = 0u;
@@ -95,13 +102,32 @@ k_sq_permute(const FArgs av, const u64* perm, const u64* skeys, double* zbuf, co
     const u64 ctr = ctr0 + (u64)t + ((u64)(u32)(a.island_offset + isl) << 32);
     const u32 sh0 = smc_sobol_shift(pseed, ctr, 0u), sh1 = smc_sobol_shift(pseed, ctr, 1u);
     double z[4];
+    bool tl[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const u32 g = smc_sobol_sorted_gray((u32)f_own_idx(own, k), sh0, a.log2N);
         const u32 x1 = sh1 ^ s_v2[g & 127u] ^ s_v2[128 + ((g >> 7) & 127u)] ^ s_v2[256 + ((g >> 14) & 127u)] ^
                        s_v2[384 + ((g >> 21) & 127u)] ^ s_v2[512 + ((g >> 28) & 127u)];
-        z[k] = smc_ndtri(smc_sobol_safe(x1));
+        const double y0 = smc_sobol_safe(x1);
+        z[k] = smc_ndtri_centre(y0, tl[k]);
+        if (tl[k]) {
+            const unsigned q = atomicAdd(&s_nq, 1u);
+            s_q[q] = (unsigned short)(k * SMC_BLOCK + tid);
+            s_y[k * SMC_BLOCK + tid] = y0;
+        }
     }
+    __syncthreads();
+    {
+        const int nq = (int)s_nq;
+        for (int i = tid; i < nq; i += SMC_BLOCK) {
+            const int slot = (int)s_q[i];
+            s_y[slot] = smc_ndtri_tail(s_y[slot]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (tl[k]) z[k] = s_y[k * SMC_BLOCK + tid];
     // (the sorted first coordinates are not written: k_ancestors2<SQ> forms the thresholds from n -- f2_sq_T)
     double* zb = zbuf + (i64)isl * N;
     smc_st2g(zb + own.na, z[0], z[1]);

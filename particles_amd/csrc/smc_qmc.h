@@ -23,7 +23,14 @@ __device__ __forceinline__ double ndtri_p1evl(double x, const double* c, int n)
     for (int i = 1; i < n; ++i) a = a * x + c[i];
     return a;
 }
-__device__ inline double smc_ndtri(double y0)
+// scipy.special.ndtri (Cephes ndtri.c), in two pieces so that a workgroup can evaluate the TAIL branch -- 27 % of
+// uniform arguments, two logarithms, a square root and three divisions: ten times the centre's cost -- on lanes it has
+// packed with tail arguments (k_sq_permute) instead of on every wave that holds one.  smc_ndtri(y0) is the same
+// arithmetic in the same order as before the split.
+//   smc_ndtri_centre(y0, tail): the result for y0 outside (0, 1), at its ends and in the central region
+//                               (exp(-2) < y0 <= 1 - exp(-2)); tail = true and an unspecified value otherwise
+//   smc_ndtri_tail(y0):         the result where smc_ndtri_centre said tail
+__device__ inline double smc_ndtri_centre(const double y0, bool& tail)
 {
     const double P0[5] = {-5.99633501014107895267E1, 9.80010754185999661536E1,
                           -5.66762857469070293439E1, 1.39312609387279679503E1,
@@ -32,6 +39,24 @@ __device__ inline double smc_ndtri(double y0)
                           8.63602421390890590575E1, -2.25462687854119370527E2,
                           2.00260212380060660359E2, -8.20372256168333339912E1,
                           1.59056225126211695515E1, -1.18331621121330003142E0};
+    const double s2pi = 2.50662827463100050242E0, em2 = 0.13533528323661269189;   // sqrt(2 pi), exp(-2)
+    tail = false;
+    if (y0 == 0.0) return -INFINITY;
+    if (y0 == 1.0) return INFINITY;
+    if (!(y0 > 0.0 && y0 < 1.0)) return NAN;
+    double y = y0;
+    if (y > 1.0 - em2) y = 1.0 - y;
+    if (y > em2) {
+        y = y - 0.5;
+        const double y2 = y * y;
+        const double x = y + y * (y2 * ndtri_polevl(y2, P0, 4) / ndtri_p1evl(y2, Q0, 8));
+        return x * s2pi;
+    }
+    tail = true;
+    return 0.0;
+}
+__device__ inline double smc_ndtri_tail(const double y0)
+{
     const double P1[9] = {4.05544892305962419923E0, 3.15251094599893866154E1,
                           5.71628192246421288162E1, 4.40805073893200834700E1,
                           1.46849561928858024014E1, 2.18663306850790267539E0,
@@ -50,19 +75,10 @@ __device__ inline double smc_ndtri(double y0)
                           1.37702099489081330271E0, 2.16236993594496635890E-1,
                           1.34204006088543189037E-2, 3.28014464682127739104E-4,
                           2.89247864745380683936E-6, 6.79019408009981274425E-9};
-    const double s2pi = 2.50662827463100050242E0, em2 = 0.13533528323661269189;   // sqrt(2 pi), exp(-2)
-    if (y0 == 0.0) return -INFINITY;
-    if (y0 == 1.0) return INFINITY;
-    if (!(y0 > 0.0 && y0 < 1.0)) return NAN;
+    const double em2 = 0.13533528323661269189;
     bool neg = true;
     double y = y0;
     if (y > 1.0 - em2) { y = 1.0 - y; neg = false; }
-    if (y > em2) {
-        y = y - 0.5;
-        const double y2 = y * y;
-        const double x = y + y * (y2 * ndtri_polevl(y2, P0, 4) / ndtri_p1evl(y2, Q0, 8));
-        return x * s2pi;
-    }
     double x = sqrt(-2.0 * log(y));
     const double x0 = x - log(x) / x;
     const double z = 1.0 / x;
@@ -70,6 +86,12 @@ __device__ inline double smc_ndtri(double y0)
                                 : z * ndtri_polevl(z, P2, 8) / ndtri_p1evl(z, Q2, 8);
     x = x0 - x1;
     return neg ? -x : x;
+}
+__device__ inline double smc_ndtri(double y0)
+{
+    bool tail;
+    const double c = smc_ndtri_centre(y0, tail);
+    return tail ? smc_ndtri_tail(y0) : c;
 }
 
 
