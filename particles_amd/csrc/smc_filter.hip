@@ -209,9 +209,8 @@ static void enqueue_step(smc_filter* f, int k_prof, i64 t, bool t_known = true)
             SQ_CASE(SMC_MODEL_THETALOGISTIC) SQ_CASE(SMC_MODEL_SVLEVERAGE) SQ_CASE(SMC_MODEL_DISCRETECOX)
 #undef SQ_CASE
             launch_reduce2(f, st);
+            f->a.sq_perm = perm;                     // (A = h_order[sorted position]: composed where the ancestors are stored)
             SMC_LAUNCH((k_ancestors2<true, true, true, false, true>), grid, dim3(SMC_BLOCK), st, f->a);
-            SMC_LAUNCH(k_sq_compose, dim3((unsigned)((a.N / 4 + SMC_BLOCK - 1) / SMC_BLOCK), a.n_islands), dim3(SMC_BLOCK), st,
-                       f->a, perm);
         }
         if (k_prof >= 0 && (k_prof % 3)) (void)hipEventRecord(f->ev[3 * k_prof + 1], st);
         launch_propagate(f);
@@ -1891,7 +1890,7 @@ int smc_filter_describe(smc_filter* f, char* out, size_t n)
         s = std::string(mv ? "smc_hilbert_sort" : "k_rs_sort") + "+k_sobol+k_sqmv_tapes+" + (f->fused ? "k_ancestors<fused>" : "k_prepare+k_ancestors") +
             "+k_sqmv_compose+" + (mv ? "k_propagate_mv [mv_chunks=" + std::to_string(f->a.mv_chunks) + "]" : std::string("k_propagate"));
     } else if (f->sqmc) {
-        s = "k_rs_sort+k_sq_permute+k_reduce2+k_ancestors2+k_sq_compose+k_propagate";
+        s = "k_rs_sort+k_sq_permute+k_reduce2+k_ancestors2+k_propagate";
         if (f->a.mom) s += "+k_f_moments_partials+k_f_moments_final";
     } else if (f->strict) {
         if (f->strict_literal) s = std::string(f->two_level ? "k_reduce2+" : "") + "k_strict_W+k_strict_cdf+k_strict_search_S+k_propagate";

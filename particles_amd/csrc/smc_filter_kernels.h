@@ -133,6 +133,8 @@ struct FArgs {
     u64 sq_seed, sq_ctr;   // SMC_FLAG_SQMC (smc_filter_sqmc.h): the point stream's key and the point set of step t = sq_ctr + t
     u64* sdec;             // one-pass uniform_spacings with the island's reduction as its workgroup 0 (sp_epoch != 0):
     u64 sp_epoch;          // (n_islands) decision words, (epoch << 2) | 2 resample, | 1 not; epoch: unique per launch
+    const u64* sq_perm;    // SMC_FLAG_SQMC: (n_islands, N) h_order of the step being run -- k_ancestors2<SQ> counts in sorted
+                           // positions and stores h_order[position] (core.py:344: A = h_order[inverse_cdf(...)])
     double *eta, *lwsv;    // APF of MVLINGAUSS (smc_filter_mv.h k_mv_aux): (n_islands, N) logeta of the step's
                            // parents and their plain log-weights, set aside while lw + eta drives the resampling
     int xcd_chunks;        // two-level step: workgroup -> tile map that keeps CONSECUTIVE tiles on one XCD (f_tile_xcd)
@@ -2562,6 +2564,10 @@ k_ancestors2(const FArgs av)
     __shared__ double s_sum[2 * SMC_NWAVE];
     __shared__ double s_g[SMC_NWAVE + 1];
     __shared__ u32 s_mx[2 * SMC_NWAVE];
+    // SQ: the tile's parents are SORTED positions; what is stored is the particle at that position, h_order[j0 + j] --
+    // one sequential read of the tile's 1024 entries, an LDS look-up per offspring (round 5: a launch of its own,
+    // k_sq_compose, 5 us + a seam per step: a random 8-byte gather per offspring)
+    __shared__ u32 s_pm[SQ ? F_TILE : 4];
     const int b = f_tile_xcd(av, (int)blockIdx.x), isl = (int)blockIdx.y;
     const int tid = (int)threadIdx.x;
     const int lane = smc_lane(), wave = smc_wave();
@@ -2569,6 +2575,12 @@ k_ancestors2(const FArgs av)
     const i64 j0 = (i64)b * F_TILE;
     const i64 jt = j0 + (i64)tid * F_IPT;
     F_STAMP_A(0);
+    u64 pq[4] = {0ull, 0ull, 0ull, 0ull};
+    if (SQ) {
+        const u64* pp = a.sq_perm + (i64)isl * N + jt;
+        smc_ld2g(pp, pq[0], pq[1]);
+        smc_ld2g(pp + 2, pq[2], pq[3]);
+    }
     double* info = a.info + (i64)isl * INFO_STRIDE;
     const double r0 = smc_ldg(MID ? info : a.info2 + (i64)isl * INFO_STRIDE);
     const double r1 = MID ? smc_ldg(info + 1) : 0.0;
@@ -2627,7 +2639,8 @@ k_ancestors2(const FArgs av)
     if (MID) {
         Gd = smc_uniform(Gmid);
         Qd = smc_uniform(Qmid);
-        __syncthreads();                                       // sP zeroed
+        if (SQ) *reinterpret_cast<uint4*>(&s_pm[tid * 4]) = make_uint4((u32)pq[0], (u32)pq[1], (u32)pq[2], (u32)pq[3]);
+        __syncthreads();                                       // sP zeroed (SQ: s_pm staged)
     } else {
         // ---- all partials -> K, (s, ss), ESS, the decision (f2_reduce_island's operations)
         // (measured, r05p: ONE exchange -- every wave summing on its own maximum, the four wave results put on K
@@ -3130,8 +3143,12 @@ k_ancestors2(const FArgs av)
         const u32 jb = (u32)j0;
         {
             const u32 n0 = pb + (u32)tid * 4u;
-            const u32 a32[4] = {jb + (m0 > ex1 ? m0 : ex1), jb + (m1 > ex1 ? m1 : ex1),
-                                jb + (m2 > ex1 ? m2 : ex1), jb + (m3 > ex1 ? m3 : ex1)};
+            u32 a32[4] = {jb + (m0 > ex1 ? m0 : ex1), jb + (m1 > ex1 ? m1 : ex1),
+                          jb + (m2 > ex1 ? m2 : ex1), jb + (m3 > ex1 ? m3 : ex1)};
+            if (SQ) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a32[i] = s_pm[a32[i] - jb];
+            }
             if (n0 >= lo && n0 + 3u < hi) {                                             // core.py:329
                 if (a.nt & 8) smc_st4g_nt(A + n0, a32);
                 else smc_st4g(A + n0, a32);
@@ -3143,8 +3160,12 @@ k_ancestors2(const FArgs av)
         }
         if (two) {
             const u32 n0 = pb + F_PASS + (u32)tid * 4u;
-            const u32 a32[4] = {jb + (k0 > ex2 ? k0 : ex2), jb + (k1 > ex2 ? k1 : ex2),
-                                jb + (k2 > ex2 ? k2 : ex2), jb + (k3 > ex2 ? k3 : ex2)};
+            u32 a32[4] = {jb + (k0 > ex2 ? k0 : ex2), jb + (k1 > ex2 ? k1 : ex2),
+                          jb + (k2 > ex2 ? k2 : ex2), jb + (k3 > ex2 ? k3 : ex2)};
+            if (SQ) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a32[i] = s_pm[a32[i] - jb];
+            }
             if (n0 + 3u < hi) {                    // (n0 >= lo: the second half starts 1024 past it)
                 if (a.nt & 8) smc_st4g_nt(A + n0, a32);
                 else smc_st4g(A + n0, a32);

@@ -8,7 +8,7 @@
 //                                                                    k_ancestors2<MID, MULTI, .., SQ>: the multinomial
 //                                                                    counts with the thresholds a FUNCTION of n (the
 //                                                                    sorted first coordinates are a regular grid:
-//                                                                    f2_sq_T); k_sq_compose: A <- h_order[A]
+//                                                                    f2_sq_T), storing h_order[A] (FArgs::sq_perm)
 //     X = Gamma(t, X[A], u[tau, 1])  (ppf of the Normal kernel)   -> k_propagate unchanged, its standard normals
 //                                                                    z_n = ndtri(u[tau_n, 1]) read from a tape
 //                                                                    k_sq_permute wrote
@@ -182,24 +182,4 @@ k_sqmv_compose(const FArgs av, const int isl, const i64* perm)
     if (n >= a.N) return;
     u32* A = f_A(a, t) + (i64)isl * a.N;
     A[n] = (u32)perm[A[n]];
-}
-
-// A_t <- h_order[A_t]: k_ancestors2 counted in sorted positions (core.py:344)
-__global__ void __launch_bounds__(SMC_BLOCK)
-k_sq_compose(const FArgs av, const u64* perm)
-{
-    const FArgs& a = av;
-    const int isl = (int)blockIdx.y;
-    const double* info = a.info + (i64)isl * INFO_STRIDE;
-    const i64 t = (i64)smc_uniform(smc_ldg(info));
-    if (t >= a.T || t == 0 || smc_uniform(smc_ldg(info + 1)) == 0.0) return;
-    const i64 n = ((i64)blockIdx.x * SMC_BLOCK + threadIdx.x) * 4;
-    if (n >= a.N) return;
-    u32* A = f_A(a, t) + (i64)isl * a.N;
-    const u64* pi = perm + (i64)isl * a.N;
-    u32 a4[4];
-    smc_ld4g(A + n, a4);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) a4[k] = (u32)smc_ldg(pi + a4[k]);
-    smc_st4g(A + n, a4);
 }
