@@ -299,17 +299,32 @@ def _device_array_from_host(a):
     return DeviceArray.from_numpy(a, dtype=a.dtype)
 
 
+_F64 = np.dtype(np.float64)
+_SCALARS = {}          # DeviceArray.scalar's cache (default context); emptied before the interpreter tears the context down
+import atexit
+atexit.register(_SCALARS.clear)
+
+
 class DeviceArray:
     """A C-contiguous fp64 / int64 array in HBM."""
 
     def __init__(self, shape, dtype=np.float64, context=None):
+        # (plain Python here: the template-method step of a user-defined model creates eight of these per time step,
+        #  and np.prod / np.isscalar / np.dtype cost more than the allocation they describe)
         self.ctx = context or ctx()
-        self.shape = (int(shape),) if np.isscalar(shape) else tuple(int(s) for s in shape)
-        self.dtype = np.dtype(dtype)
+        if type(shape) is int:
+            self.shape = (shape,)
+            size = shape
+        else:
+            self.shape = (int(shape),) if np.isscalar(shape) else tuple(int(s) for s in shape)
+            size = 1
+            for s in self.shape:
+                size *= s
+        self.dtype = _F64 if dtype is np.float64 else np.dtype(dtype)
         assert self.dtype.itemsize == 8
-        self.size = int(np.prod(self.shape)) if self.shape else 1
+        self.size = size
         p = c_vp()
-        check(lib().smc_malloc(self.ctx.h, self.size * 8, ctypes.byref(p)))
+        check(lib().smc_malloc(self.ctx.h, size * 8, ctypes.byref(p)))
         self.ptr = p
 
     @classmethod
@@ -319,6 +334,23 @@ class DeviceArray:
         out = cls(a.shape if a.ndim else (1,), a.dtype, context)
         check(lib().smc_memcpy_h2d(out.ctx.h, out.ptr, a.ctypes.data_as(c_vp), a.nbytes))
         return out
+
+    @classmethod
+    def scalar(cls, v):
+        """A (1,) fp64 array holding the Python / numpy scalar ``v`` -- kept: distributions with scalar parameters
+        (``Normal(loc=xp, scale=self.sigma)``, the observation of the step) ask for the same few values at every time
+        step, and an upload per request was a third of the host's work per step of a user-defined model."""
+        v = float(v)
+        key = v if v == v else "nan"
+        a = _SCALARS.get(key)
+        if a is None:
+            if len(_SCALARS) >= 4096:
+                _SCALARS.clear()
+            a = cls((1,))
+            buf = ctypes.c_double(v)
+            check(lib().smc_memcpy_h2d(a.ctx.h, a.ptr, ctypes.byref(buf), 8))
+            _SCALARS[key] = a
+        return a
 
     def get(self):
         out = np.empty(self.shape, dtype=self.dtype)

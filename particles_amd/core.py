@@ -55,7 +55,7 @@ class FeynmanKac:
 
     @property
     def isAPF(self):
-        return "logeta" in dir(self)
+        return hasattr(self, "logeta")             # (core.py:168-170: "logeta" in dir(self); asked twice per step)
 
     def done(self, smc):
         """Time to stop the algorithm (core.py:177-179)."""

@@ -54,7 +54,11 @@ def _strided(v, N):
     """(DeviceArray, element stride, is_device_input) for a scalar / (1,) / (N,) value."""
     if isinstance(v, DeviceArray):
         return v, (0 if v.size == 1 else 1), True
+    if isinstance(v, (float, int, np.floating)):           # (the common case: a scalar parameter)
+        return DeviceArray.scalar(v), 0, False
     a = np.asarray(v, dtype=np.float64).reshape(-1)
+    if a.size == 1 and N != 1:
+        return DeviceArray.scalar(a[0]), 0, False
     if a.size not in (1, N):
         raise ValueError("operands could not be broadcast together with shape (%d,)" % N)
     return DeviceArray.from_numpy(a), (0 if a.size == 1 else 1), False
