@@ -417,6 +417,12 @@ def check_gather(N, d):
 
 
 # ------------------------------------------------------------ a-2 / a-3 ----
+def stats_norm_logpdf(x, loc, scale):
+    """scipy.stats.norm.logpdf's expression (distributions.py:273-274)."""
+    z = (np.asarray(x) - loc) / scale
+    return -0.5 * z * z - np.log(scale) - 0.5 * np.log(2.0 * np.pi)
+
+
 def check_normal(golden):
     g = golden("dists")
     lp = dists.Normal(loc=g["loc"], scale=0.7).logpdf(g["x"])
@@ -427,6 +433,25 @@ def check_normal(golden):
     z = np.random.standard_normal(64)
     x = dists.Normal(loc=g["loc"], scale=0.7).rvs(size=64, z=z)
     assert np.array_equal(x, g["normal_rvs"])                # loc + scale*z: bit-exact
+    # scalar parameters live in a cache of one-element device arrays (DeviceArray.scalar: uploaded once, through the
+    # kernel arguments of a one-wave launch -- smc_memcpy_h2d's small-copy form): every kind of scalar, the same values
+    # again, a NaN, more distinct values than the cache holds, and a (1,) array beside an (N,) one
+    from particles_amd._lib import DeviceArray as DA, _SCALARS
+    xs = g["x"]
+    for sc in (0.7, np.float64(0.7), 1, np.float32(0.5), np.array([0.7]), np.array(0.7)):
+        for rep in range(2):
+            lp = dists.Normal(loc=0.25, scale=sc).logpdf(xs)
+            ref = stats_norm_logpdf(xs, 0.25, float(np.asarray(sc).reshape(-1)[0]))
+            assert np.max(np.abs(lp - ref)) < 1e-14 * 8, (sc, rep)
+    assert np.all(np.isnan(dists.Normal(loc=0.0, scale=float("nan")).logpdf(xs)))
+    a, b = DA.scalar(0.7), DA.scalar(np.float64(0.7))
+    assert a is b and a.get()[0] == 0.7 and np.isnan(DA.scalar(float("nan")).get()[0])
+    for k in range(4200):                                        # (beyond the cache's 4096 entries: it starts afresh)
+        DA.scalar(1.0 + k * 2.0 ** -20)
+    assert len(_SCALARS) <= 4096 and DA.scalar(1.0 + 4199 * 2.0 ** -20).get()[0] == 1.0 + 4199 * 2.0 ** -20
+    r = np.arange(33, dtype=np.float64)                          # (the kernel-argument copy takes up to 32 words)
+    for n in (1, 2, 31, 32, 33):
+        assert np.array_equal(DA.from_numpy(r[:n]).get(), r[:n]), n
 
 
 def check_poisson(golden):
